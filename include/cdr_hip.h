@@ -1,0 +1,145 @@
+/*
+ * cdr_hip.h -- C ABI of libcdrhip.so: the MI355X (gfx950) cross-domain recommendation hot path.
+ *
+ * Drop-in boundary.  The reference (RUCAIBox/RecBole-CDR, 100 % Python) has no FFI; its hot path is the Python class
+ * contract CrossDomainRecommender.calculate_loss / predict / full_sort_predict (recbole_cdr/model/
+ * crossdomain_recommender.py:14-51) driven by CrossDomainTrainer.fit (recbole_cdr/trainer/trainer.py:43-76).  Every
+ * entry point below replaces the stock torch ops the reference issues at the cited file:line; the Python host
+ * (recbole-cdr_amd/) binds them with ctypes on torch tensors' data_ptr() and presents the reference's class contract.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.  All tensor pointers are DEVICE pointers owned by the
+ *     caller (torch allocations), fp32 row-major contiguous unless a leading dimension is passed; ids are int64
+ *     (torch.LongTensor, the dtype recbole's Interaction hands over).
+ *   - Every function enqueues on `stream` (a hipStream_t passed as void*) and never synchronises the device.
+ *   - Return value: 0 on success, otherwise a negative CDR_E* code or a positive hipError_t; cdr_last_error() returns a
+ *     thread-local message.  No exception crosses the boundary.
+ *   - The library allocates nothing persistent except what a cdr_ctx owns (reduction scratch).
+ *   - Reductions are two-pass with a fixed order (per-block partials -> single finishing block, fp64 accumulate):
+ *     results are run-to-run reproducible; only the dense scatter-add (*_bwd_dense, cdr_scatter_add_rows) uses
+ *     fp32 atomics, as torch's own embedding backward does.
+ */
+#ifndef CDR_HIP_H
+#define CDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDR_OK 0
+#define CDR_EINVAL (-1)   /* bad argument (null pointer, unsupported size)            */
+#define CDR_ENOMEM (-2)   /* scratch allocation failed                                */
+#define CDR_ENODEV (-3)   /* no gfx950 device / kernel image not loadable             */
+
+typedef struct cdr_ctx cdr_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
+int cdr_ctx_destroy(cdr_ctx* ctx);
+const char* cdr_last_error(void);
+int cdr_abi_version(void);                          /* bumped on any signature change                        */
+
+/* ---- K1+K2+K3+K5: negative-sampled pairwise (BPR) loss -------------------------------------------------------
+ * replaces emcdr.py:98-108,119-131,142-154 (source/target_forward x2, BPRLoss, EmbLoss re-gather).
+ *   score_pos[b] = <U[uid[b]], I[pid[b]]>, score_neg[b] = <U[uid[b]], I[nid[b]]>
+ *   out[1] = mean_b -log(gamma + sigmoid(score_pos - score_neg))          (recbole BPRLoss, gamma = 1e-10)
+ *   out[2] = ||U[uid]||_F over the whole batch, repeats included ; out[3] = ||I[pid]||_F   (recbole EmbLoss)
+ *   out[0] = out[1] + reg_weight * (out[2] + out[3]) / B
+ *   gcoef[b] (optional) = d out[1] / d(score_pos[b] - score_neg[b])  -- consumed by the backward / fused step.
+ */
+int cdr_bpr_fwd(cdr_ctx* ctx, void* stream,
+                const float* user_tab, const float* item_tab, int D,
+                const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                float gamma, float reg_weight,
+                float* out4, float* gcoef /* [B] or NULL */);
+
+/* dense backward: grad_user_tab / grad_item_tab are full-size [rows, D] buffers the caller zeroed (what autograd
+ * hands torch.optim for a sparse=False nn.Embedding).  grad_out = upstream d/d out[0] (device scalar). */
+int cdr_bpr_bwd_dense(cdr_ctx* ctx, void* stream,
+                      const float* user_tab, const float* item_tab, int D,
+                      const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                      const float* gcoef, const float* out4, float reg_weight, const float* grad_out,
+                      float* grad_user_tab, float* grad_item_tab);
+
+/* ---- K1+K2+K4+K5: pointwise loss (MSE on the raw dot, or BCE on sigmoid(dot)) ---------------------------------
+ * replaces emcdr.py:111-122,134-145 (MF) ; cmf.py:75-99 ; bitgcf.py:221-247 (tables = propagated embeddings,
+ * reg tables = ego embeddings).  reg_user_tab/reg_item_tab may alias user_tab/item_tab.
+ *   out[1] = loss_kind==MSE ? mean (dot-label)^2 : BCELoss(sigmoid(dot), label) with torch's -100 log clamp
+ *   out[2], out[3] = EmbLoss norms of reg_user_tab[uid], reg_item_tab[iid] ; out[0] = out[1] + reg_weight*(..)/B
+ *   scores[b] (optional) = dot (MSE) or sigmoid(dot) (BCE) ; gcoef[b] (optional) = d out[1] / d dot[b]
+ */
+#define CDR_LOSS_MSE 0
+#define CDR_LOSS_BCE 1
+int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind,
+                  const float* user_tab, const float* item_tab,
+                  const float* reg_user_tab, const float* reg_item_tab, int D,
+                  const int64_t* uid, const int64_t* iid, const float* label, int64_t B,
+                  float reg_weight, float* out4, float* gcoef, float* scores);
+
+int cdr_point_bwd_dense(cdr_ctx* ctx, void* stream,
+                        const float* user_tab, const float* item_tab,
+                        const float* reg_user_tab, const float* reg_item_tab, int D,
+                        const int64_t* uid, const int64_t* iid, int64_t B,
+                        const float* gcoef, const float* out4, float reg_weight, const float* grad_out,
+                        float* grad_user_tab, float* grad_item_tab,
+                        float* grad_reg_user_tab, float* grad_reg_item_tab);
+
+/* ---- K1: row gather / dense scatter-add ---------------------------------------------------------------------
+ * replaces nn.Embedding(idx) (emcdr.py:99-100,159-160 ; conet.py:106-109 ; sscdr.py:138-140 ...) and its dense
+ * backward.  out[r,:] = tab[ids[r],:] ;  grad_tab[ids[r],:] += scale * src[r,:]  (scale: device scalar or NULL=1) */
+int cdr_gather_rows(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out);
+int cdr_scatter_add_rows(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n,
+                         const float* src, const float* scale);
+
+/* K7: mapped-or-target select (emcdr.py:195-197,201-203,222-224 ; sscdr.py:214-216,242-244):
+ *   out[r,:] = ids[r] < n_overlap ? mapped[r,:] : tab[ids[r],:]                                               */
+int cdr_select_mapped(void* stream, const float* mapped, const float* tab, int D,
+                      const int64_t* ids, int64_t n, int64_t n_overlap, float* out);
+
+/* ---- K6/K8/K9: fp32 MFMA contraction with fused epilogue -----------------------------------------------------
+ * C[M,N] = epi( op(A) x op(B) ), exact fp32 (v_mfma_f32_32x32x2_f32).  NT form (transB=1) is the all-items scoring
+ * matmul user_e x all_item_e^T (emcdr.py:232 ; cmf.py:111 ; bitgcf.py:271 ; sscdr.py:256) and nn.Linear
+ * (y = x W^T + b: emcdr.py:86-93 mapping, conet.py:118-137 cross units).
+ *   transA: A is stored [K,M] (lda) ; transB: B is stored [N,K] (ldb), else [K,N].
+ *   epilogue: v = acc (+ bias[n]) ; v = act(v) ; if accumulate: v += C
+ */
+#define CDR_ACT_NONE 0
+#define CDR_ACT_TANH 1
+#define CDR_ACT_RELU 2
+#define CDR_ACT_SIGMOID 3
+int cdr_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, const float* bias, int act, int accumulate);
+
+/* K9 drop-in: scores[u, 0:n0] = <user_e[u], slab0[j]>, scores[u, n0:n0+n1] = <user_e[u], slab1[j]> -- the item
+ * operand given as <= 2 row ranges so the reference's torch.cat copy (emcdr.py:212-214,228-230) never happens. */
+int cdr_fullsort_scores_f32(void* stream, const float* user_e, int64_t U, int D,
+                            const float* slab0, int64_t n0, const float* slab1, int64_t n1,
+                            float* scores /* [U, n0+n1] */);
+
+/* SSCDR scoring (sscdr.py:253-259): scores = -(((-2 <u,i>) + |u|^2) + |i|^2) on already-normalised rows.
+ * norm_scratch: caller-owned [U + N] floats (row norms are recomputed into it).                               */
+int cdr_fullsort_neg_sqdist_f32(void* stream, const float* user_e, int64_t U, int D,
+                                const float* items, int64_t N, float* norm_scratch, float* scores);
+
+/* ---- elementwise helpers used by the model mirrors --------------------------------------------------------- */
+/* d/dx of act given y = act(x): gx = gy * act'(y)  (tanh: 1-y^2, relu: y>0, sigmoid: y(1-y)) ; in place allowed */
+int cdr_act_bwd(void* stream, int act, const float* y, const float* gy, float* gx, int64_t n);
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
+int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate);
+/* mean-squared error over all elements + its gradient: out[0] = mean((a-b)^2) ; ga = 2(a-b)/n * grad_out       */
+int cdr_mse_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* b, int64_t n, float* out1);
+int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const float* grad_out,
+                float* ga /* or NULL */, float* gb /* or NULL */);
+
+/* ---- K13: exact dense Adam (torch.optim.Adam semantics, amsgrad=False, maximize=False) ---------------------- */
+int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDR_HIP_H */

@@ -1,0 +1,148 @@
+"""ctypes binding of libcdrhip.so (include/cdr_hip.h) on torch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every arithmetic kernel is in the
+library.  ``data_ptr()`` of a contiguous fp32 / int64 CUDA tensor is handed over as a raw device pointer together
+with ``torch.cuda.current_stream().cuda_stream`` so that the kernels are ordered with torch's own work.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'lib', 'libcdrhip.so')
+ABI_VERSION = 1
+
+CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into lib/libcdrhip.so (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, 'csrc')
+    cmd = ['make', '-C', csrc, '-j', str(min(8, os.cpu_count() or 1))]
+    if force:
+        subprocess.run(['make', '-C', csrc, 'clean'], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise NativeLibraryError('building libcdrhip.so failed:\n' + r.stdout[-4000:])
+    return _LIB_PATH
+
+
+_c_i64, _c_int, _c_f32, _c_ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes, mirrors include/cdr_hip.h one to one
+_SIGNATURES = {
+    'cdr_ctx_create': [_c_int, ctypes.POINTER(_c_ptr)],
+    'cdr_ctx_destroy': [_c_ptr],
+    'cdr_abi_version': [],
+    'cdr_bpr_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
+    'cdr_bpr_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_f32,
+                          _c_ptr, _c_ptr, _c_ptr],
+    'cdr_point_fwd': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                      _c_f32, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_point_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
+                            _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_gather_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr],
+    'cdr_scatter_add_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_select_mapped': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_ptr],
+    'cdr_gemm_f32': [_c_ptr, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
+                     _c_int, _c_int],
+    'cdr_fullsort_scores_f32': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr],
+    'cdr_fullsort_neg_sqdist_f32': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_act_bwd': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64],
+    'cdr_colsum': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int],
+    'cdr_mse_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_mse_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+_ctx = {}
+
+
+def exported_symbols():
+    return sorted(list(_SIGNATURES) + ['cdr_last_error'])
+
+
+def load():
+    """dlopen the library (no GPU needed for that) and type every entry point.  Raises loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(_LIB_PATH):
+            raise NativeLibraryError(
+                f'{_LIB_PATH} is missing: build it with `make -C recbole-cdr_amd/csrc` (or __graft_entry__.build()). '
+                'There is no CPU / eager fallback for this path.')
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export what the header declares
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        lib.cdr_last_error.argtypes = []
+        lib.cdr_last_error.restype = ctypes.c_char_p
+        if lib.cdr_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(f'libcdrhip ABI {lib.cdr_abi_version()} != binding ABI {ABI_VERSION}; rebuild')
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().cdr_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what} failed (code {rc}): {msg}')
+
+
+def ctx(device):
+    """One cdr_ctx (reduction scratch) per device, created on first use."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _ctx:
+        h = _c_ptr()
+        _check(load().cdr_ctx_create(idx, ctypes.byref(h)), 'cdr_ctx_create')
+        _ctx[idx] = h
+    return _ctx[idx]
+
+
+def stream():
+    return _c_ptr(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Raw device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeLibraryError('libcdrhip works on ROCm device tensors only (got a CPU tensor); there is no CPU path')
+    if not t.is_contiguous():
+        raise ValueError('tensor must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'expected {dtype}, got {t.dtype}')
+    return _c_ptr(t.data_ptr())
+
+
+def f32(t):
+    return ptr(t, torch.float32)
+
+
+def i64(t):
+    return ptr(t, torch.int64)
+
+
+def call(name, *args):
+    _check(getattr(load(), name)(*args), name)

@@ -1,0 +1,90 @@
+// Shared device/host helpers for libcdrhip (gfx950 only: wave = 64 lanes, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/cdr_hip.h"
+
+#define CDR_WAVE 64
+#define CDR_NUM_CU 256
+#define CDR_MAX_PARTIAL_BLOCKS 4096          // grid cap of every two-pass reduction
+#define CDR_PARTIAL_STRIDE 8                 // doubles per block
+
+struct cdr_ctx {
+    int device;
+    double* partials;                        // [CDR_MAX_PARTIAL_BLOCKS][CDR_PARTIAL_STRIDE]
+};
+
+void cdr_set_error(const char* fmt, ...);
+
+#define CDR_CHECK_ARG(cond)                                                         \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            cdr_set_error("%s: invalid argument: %s", __func__, #cond);             \
+            return CDR_EINVAL;                                                      \
+        }                                                                           \
+    } while (0)
+
+#define CDR_HIP(expr)                                                               \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            cdr_set_error("%s: %s -> %s", __func__, #expr, hipGetErrorString(e_));  \
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
+#define CDR_LAUNCH_CHECK()                                                          \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            cdr_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_));\
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
+// ---- wave-level reductions -------------------------------------------------------------------------------------
+// Sum over aligned sub-groups of LPR lanes (LPR a power of two, 1..64); every lane of the group gets the total.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, CDR_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, CDR_WAVE);
+    return v;
+}
+
+// Block-level sum of NV doubles; result valid in thread 0.  smem: NV * (blockDim/64) doubles.
+template <int NV>
+__device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_d(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0.0;
+            for (int w = 0; w < nw; ++w) s += smem[w * NV + i];
+            v[i] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+static inline int cdr_lpr_for(int D) {        // lanes per row when a lane moves one float4
+    int q = (D + 3) / 4, l = 1;
+    while (l < q && l < 64) l <<= 1;
+    return l;
+}

@@ -1,0 +1,459 @@
+// Fused dual-table gather -> dot -> loss kernels (K1+K2+K3/K4+K5 of SURVEY.md 2.2) and their dense backward.
+//
+// Mapping: a row of D fp32 is moved by LPR = D/4 lanes as one float4 (16 B) each, so one wave-instruction fetches
+// 64/LPR whole rows (D=128: 2 rows, 1 KiB; D=64: 4 rows).  A "group" of LPR lanes owns one interaction at a time,
+// walks the batch with a grid stride and keeps UNR interactions' row loads in flight before it touches any of them
+// (HBM-latency hiding by memory-level parallelism: the gather is random 256..512-B reads over tables >> L2/MALL).
+// Dots are reduced inside the group with xor-shuffles; per-interaction losses and the two EmbLoss square sums are
+// accumulated in fp64 per lane, reduced per block, and finished by one block in a fixed order (no float atomics).
+#include "cdr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------ BPR forward
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                         int D, const int64_t* __restrict__ uid,
+                                                         const int64_t* __restrict__ pid,
+                                                         const int64_t* __restrict__ nid, int64_t B, float gamma,
+                                                         float* __restrict__ gcoef, double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float invB = 1.0f / (float)B;
+    double acc[3] = {0.0, 0.0, 0.0};   // loss sum, sum u^2, sum p^2
+
+    for (int64_t base = gg; base < B; base += TG * kUnroll) {
+        if (D4 <= LPR) {
+            // one float4 per lane per row: issue all loads of kUnroll interactions, then reduce
+            float4 u[kUnroll], p[kUnroll], n[kUnroll];
+            const bool live = sub < D4;
+#pragma unroll
+            for (int r = 0; r < kUnroll; ++r) {
+                const int64_t t = base + (int64_t)r * TG;
+                u[r] = p[r] = n[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < B && live) {
+                    const int64_t iu = uid[t], ip = pid[t], in = nid[t];
+                    u[r] = ld4(U + iu * D + 4 * sub);
+                    p[r] = ld4(I + ip * D + 4 * sub);
+                    n[r] = ld4(I + in * D + 4 * sub);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kUnroll; ++r) {
+                const int64_t t = base + (int64_t)r * TG;
+                float dp = group_sum<LPR>(dot4(u[r], p[r]));
+                float dn = group_sum<LPR>(dot4(u[r], n[r]));
+                float su = group_sum<LPR>(dot4(u[r], u[r]));
+                float sp = group_sum<LPR>(dot4(p[r], p[r]));
+                if (t < B && sub == 0) {
+                    const float s = sigmoidf_(dp - dn);
+                    acc[0] += (double)(-logf(gamma + s));
+                    acc[1] += (double)su;
+                    acc[2] += (double)sp;
+                    if (gcoef) gcoef[t] = -invB * (s * (1.0f - s)) / (gamma + s);
+                }
+            }
+        } else {
+            // long rows (D > 256): chunked, one interaction at a time per group
+#pragma unroll 1
+            for (int r = 0; r < kUnroll; ++r) {
+                const int64_t t = base + (int64_t)r * TG;
+                if (t >= B) break;       // uniform across the group
+                const int64_t iu = uid[t], ip = pid[t], in = nid[t];
+                float dp = 0.f, dn = 0.f, su = 0.f, sp = 0.f;
+                for (int c = sub; c < D4; c += LPR) {
+                    const float4 a = ld4(U + iu * D + 4 * c), b = ld4(I + ip * D + 4 * c), q = ld4(I + in * D + 4 * c);
+                    dp += dot4(a, b); dn += dot4(a, q); su += dot4(a, a); sp += dot4(b, b);
+                }
+                dp = group_sum<LPR>(dp); dn = group_sum<LPR>(dn); su = group_sum<LPR>(su); sp = group_sum<LPR>(sp);
+                if (sub == 0) {
+                    const float s = sigmoidf_(dp - dn);
+                    acc[0] += (double)(-logf(gamma + s));
+                    acc[1] += (double)su;
+                    acc[2] += (double)sp;
+                    if (gcoef) gcoef[t] = -invB * (s * (1.0f - s)) / (gamma + s);
+                }
+            }
+        }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+// generic scalar path (D not a multiple of 4): one wave per interaction
+__global__ __launch_bounds__(kBlock) void bpr_fwd_scalar_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                                int D, const int64_t* __restrict__ uid,
+                                                                const int64_t* __restrict__ pid,
+                                                                const int64_t* __restrict__ nid, int64_t B, float gamma,
+                                                                float* __restrict__ gcoef, double* __restrict__ partials) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t TW = (int64_t)gridDim.x * (kBlock / 64);
+    const float invB = 1.0f / (float)B;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t t = gw; t < B; t += TW) {
+        const float* u = U + uid[t] * D; const float* p = I + pid[t] * D; const float* n = I + nid[t] * D;
+        float dp = 0.f, dn = 0.f, su = 0.f, sp = 0.f;
+        for (int c = lane; c < D; c += 64) { const float a = u[c], b = p[c], q = n[c]; dp += a * b; dn += a * q; su += a * a; sp += b * b; }
+        dp = group_sum<64>(dp); dn = group_sum<64>(dn); su = group_sum<64>(su); sp = group_sum<64>(sp);
+        if (lane == 0) {
+            const float s = sigmoidf_(dp - dn);
+            acc[0] += (double)(-logf(gamma + s)); acc[1] += (double)su; acc[2] += (double)sp;
+            if (gcoef) gcoef[t] = -invB * (s * (1.0f - s)) / (gamma + s);
+        }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+// out4 = {total, main, ||U_b||_F, ||I_b||_F}
+__global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                             float reg_weight, float* __restrict__ out4) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float main_loss = (float)(acc[0] / (double)B);
+        const float nu = (float)sqrt(acc[1]), ni = (float)sqrt(acc[2]);
+        out4[1] = main_loss; out4[2] = nu; out4[3] = ni;
+        out4[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BPR dense backward
+// dU[u] += go*g*(p-n) + cu*u ; dI[p] += go*g*u + ci*p ; dI[n] -= go*g*u      (cu = go*reg/(B*||U_b||), ci likewise)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void bpr_bwd_dense_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                               int D, const int64_t* __restrict__ uid,
+                                                               const int64_t* __restrict__ pid,
+                                                               const int64_t* __restrict__ nid, int64_t B,
+                                                               const float* __restrict__ gcoef,
+                                                               const float* __restrict__ out4, float reg_weight,
+                                                               const float* __restrict__ grad_out,
+                                                               float* __restrict__ gU, float* __restrict__ gI) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float nu = out4[2], ni = out4[3];
+    const float cu = (reg_weight != 0.f && nu > 0.f) ? go * reg_weight / ((float)B * nu) : 0.f;
+    const float ci = (reg_weight != 0.f && ni > 0.f) ? go * reg_weight / ((float)B * ni) : 0.f;
+    for (int64_t t = gg; t < B; t += TG) {
+        const int64_t iu = uid[t], ip = pid[t], in = nid[t];
+        const float g = go * gcoef[t];
+        for (int c = sub; c < D4; c += LPR) {
+            const float4 u = ld4(U + iu * D + 4 * c), p = ld4(I + ip * D + 4 * c), n = ld4(I + in * D + 4 * c);
+            float* du = gU + iu * D + 4 * c; float* dp = gI + ip * D + 4 * c; float* dn = gI + in * D + 4 * c;
+            atomicAdd(du + 0, g * (p.x - n.x) + cu * u.x); atomicAdd(du + 1, g * (p.y - n.y) + cu * u.y);
+            atomicAdd(du + 2, g * (p.z - n.z) + cu * u.z); atomicAdd(du + 3, g * (p.w - n.w) + cu * u.w);
+            atomicAdd(dp + 0, g * u.x + ci * p.x); atomicAdd(dp + 1, g * u.y + ci * p.y);
+            atomicAdd(dp + 2, g * u.z + ci * p.z); atomicAdd(dp + 3, g * u.w + ci * p.w);
+            atomicAdd(dn + 0, -g * u.x); atomicAdd(dn + 1, -g * u.y); atomicAdd(dn + 2, -g * u.z); atomicAdd(dn + 3, -g * u.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bpr_bwd_dense_scalar_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                                      int D, const int64_t* __restrict__ uid,
+                                                                      const int64_t* __restrict__ pid,
+                                                                      const int64_t* __restrict__ nid, int64_t B,
+                                                                      const float* __restrict__ gcoef,
+                                                                      const float* __restrict__ out4, float reg_weight,
+                                                                      const float* __restrict__ grad_out,
+                                                                      float* __restrict__ gU, float* __restrict__ gI) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t TW = (int64_t)gridDim.x * (kBlock / 64);
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float nu = out4[2], ni = out4[3];
+    const float cu = (reg_weight != 0.f && nu > 0.f) ? go * reg_weight / ((float)B * nu) : 0.f;
+    const float ci = (reg_weight != 0.f && ni > 0.f) ? go * reg_weight / ((float)B * ni) : 0.f;
+    for (int64_t t = gw; t < B; t += TW) {
+        const int64_t iu = uid[t], ip = pid[t], in = nid[t];
+        const float g = go * gcoef[t];
+        for (int c = lane; c < D; c += 64) {
+            const float u = U[iu * D + c], p = I[ip * D + c], n = I[in * D + c];
+            atomicAdd(gU + iu * D + c, g * (p - n) + cu * u);
+            atomicAdd(gI + ip * D + c, g * u + ci * p);
+            atomicAdd(gI + in * D + c, -g * u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise forward
+// SAME: the EmbLoss tables are the dot tables (EMCDR-MF, CMF); otherwise (BiTGCF) the reg rows come from other tables.
+template <int LPR, bool SAME>
+__global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const float* __restrict__ U,
+                                                           const float* __restrict__ I, const float* __restrict__ RU,
+                                                           const float* __restrict__ RI, int D,
+                                                           const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                           const float* __restrict__ label, int64_t B,
+                                                           float* __restrict__ gcoef, float* __restrict__ scores,
+                                                           double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float invB = 1.0f / (float)B;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t base = gg; base < B; base += TG * kUnroll) {
+#pragma unroll
+        for (int r = 0; r < kUnroll; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            float dx = 0.f, su = 0.f, si = 0.f;
+            if (t < B) {
+                const int64_t iu = uid[t], ii = iid[t];
+                for (int c = sub; c < D4; c += LPR) {
+                    const float4 a = ld4(U + iu * D + 4 * c), b = ld4(I + ii * D + 4 * c);
+                    dx += dot4(a, b);
+                    if (SAME) { su += dot4(a, a); si += dot4(b, b); }
+                    else {
+                        const float4 ra = ld4(RU + iu * D + 4 * c), rb = ld4(RI + ii * D + 4 * c);
+                        su += dot4(ra, ra); si += dot4(rb, rb);
+                    }
+                }
+            }
+            dx = group_sum<LPR>(dx); su = group_sum<LPR>(su); si = group_sum<LPR>(si);
+            if (t < B && sub == 0) {
+                const float y = label[t];
+                float l, g, sc;
+                if (loss_kind == CDR_LOSS_MSE) {
+                    const float d = dx - y;
+                    l = d * d; g = 2.0f * d * invB; sc = dx;
+                } else {
+                    const float p = sigmoidf_(dx);
+                    // torch BCELoss: (y-1)*max(log(1-p),-100) - y*max(log(p),-100); backward (p-y)/max((1-p)p,1e-12)
+                    l = (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+                    const float pq = (1.0f - p) * p;
+                    g = (p - y) / fmaxf(pq, 1e-12f) * invB * pq;
+                    sc = p;
+                }
+                acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si;
+                if (gcoef) gcoef[t] = g;
+                if (scores) scores[t] = sc;
+            }
+        }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void point_fwd_scalar_kernel(int loss_kind, const float* __restrict__ U,
+                                                                  const float* __restrict__ I, const float* __restrict__ RU,
+                                                                  const float* __restrict__ RI, int D,
+                                                                  const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                                  const float* __restrict__ label, int64_t B,
+                                                                  float* __restrict__ gcoef, float* __restrict__ scores,
+                                                                  double* __restrict__ partials) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t TW = (int64_t)gridDim.x * (kBlock / 64);
+    const float invB = 1.0f / (float)B;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t t = gw; t < B; t += TW) {
+        const int64_t iu = uid[t], ii = iid[t];
+        float dx = 0.f, su = 0.f, si = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float a = U[iu * D + c], b = I[ii * D + c], ra = RU[iu * D + c], rb = RI[ii * D + c];
+            dx += a * b; su += ra * ra; si += rb * rb;
+        }
+        dx = group_sum<64>(dx); su = group_sum<64>(su); si = group_sum<64>(si);
+        if (lane == 0) {
+            const float y = label[t];
+            float l, g, sc;
+            if (loss_kind == CDR_LOSS_MSE) { const float d = dx - y; l = d * d; g = 2.0f * d * invB; sc = dx; }
+            else {
+                const float p = sigmoidf_(dx);
+                l = (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+                const float pq = (1.0f - p) * p;
+                g = (p - y) / fmaxf(pq, 1e-12f) * invB * pq; sc = p;
+            }
+            acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si;
+            if (gcoef) gcoef[t] = g;
+            if (scores) scores[t] = sc;
+        }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise dense backward
+// dU[u] += go*g*I[i] ; dI[i] += go*g*U[u] ; dRU[u] += cu*RU[u] ; dRI[i] += ci*RI[i]
+__global__ __launch_bounds__(kBlock) void point_bwd_dense_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                                 const float* __restrict__ RU, const float* __restrict__ RI,
+                                                                 int D, const int64_t* __restrict__ uid,
+                                                                 const int64_t* __restrict__ iid, int64_t B,
+                                                                 const float* __restrict__ gcoef, const float* __restrict__ out4,
+                                                                 float reg_weight, const float* __restrict__ grad_out,
+                                                                 float* __restrict__ gU, float* __restrict__ gI,
+                                                                 float* __restrict__ gRU, float* __restrict__ gRI) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t TW = (int64_t)gridDim.x * (kBlock / 64);
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float nu = out4[2], ni = out4[3];
+    const float cu = (reg_weight != 0.f && nu > 0.f) ? go * reg_weight / ((float)B * nu) : 0.f;
+    const float ci = (reg_weight != 0.f && ni > 0.f) ? go * reg_weight / ((float)B * ni) : 0.f;
+    for (int64_t t = gw; t < B; t += TW) {
+        const int64_t iu = uid[t], ii = iid[t];
+        const float g = go * gcoef[t];
+        for (int c = lane; c < D; c += 64) {
+            const float u = U[iu * D + c], i = I[ii * D + c];
+            float du = g * i, di = g * u;
+            if (gRU == gU) du += cu * RU[iu * D + c]; else if (gRU && cu != 0.f) atomicAdd(gRU + iu * D + c, cu * RU[iu * D + c]);
+            if (gRI == gI) di += ci * RI[ii * D + c]; else if (gRI && ci != 0.f) atomicAdd(gRI + ii * D + c, ci * RI[ii * D + c]);
+            if (gU) atomicAdd(gU + iu * D + c, du);
+            if (gI) atomicAdd(gI + ii * D + c, di);
+        }
+    }
+}
+
+inline int grid_for(int64_t units, int per_block) {
+    int64_t g = (units + per_block - 1) / per_block;
+    const int64_t cap = CDR_NUM_CU * 8;       // 2048 blocks = 8 per CU, grid-stride beyond (guide G11)
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_LPR(lpr, ...)                                  \
+    switch (lpr) {                                              \
+        case 1: { constexpr int L = 1; __VA_ARGS__; } break;    \
+        case 2: { constexpr int L = 2; __VA_ARGS__; } break;    \
+        case 4: { constexpr int L = 4; __VA_ARGS__; } break;    \
+        case 8: { constexpr int L = 8; __VA_ARGS__; } break;    \
+        case 16: { constexpr int L = 16; __VA_ARGS__; } break;  \
+        case 32: { constexpr int L = 32; __VA_ARGS__; } break;  \
+        default: { constexpr int L = 64; __VA_ARGS__; } break;  \
+    }
+
+extern "C" int cdr_bpr_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
+                           const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma,
+                           float reg_weight, float* out4, float* gcoef) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out4);
+    CDR_CHECK_ARG(D > 0 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    int grid;
+    if ((D & 3) == 0) {
+        const int lpr = cdr_lpr_for(D);
+        grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
+        DISPATCH_LPR(lpr, bpr_fwd_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D,
+                                              uid, pid, nid, B, gamma, gcoef, ctx->partials));
+    } else {
+        grid = grid_for(B, kBlock / 64);
+        hipLaunchKernelGGL(bpr_fwd_scalar_kernel, dim3(grid), dim3(kBlock), 0, s, user_tab, item_tab, D, uid, pid, nid, B,
+                           gamma, gcoef, ctx->partials);
+    }
+    CDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_bwd_dense(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
+                                 const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                                 const float* gcoef, const float* out4, float reg_weight, const float* grad_out,
+                                 float* grad_user_tab, float* grad_item_tab) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && gcoef && out4 && grad_user_tab && grad_item_tab);
+    CDR_CHECK_ARG(D > 0 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    if ((D & 3) == 0) {
+        const int lpr = cdr_lpr_for(D);
+        const int grid = grid_for(B, kBlock / lpr);
+        DISPATCH_LPR(lpr, bpr_bwd_dense_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab,
+                                              D, uid, pid, nid, B, gcoef, out4, reg_weight, grad_out, grad_user_tab,
+                                              grad_item_tab));
+    } else {
+        const int grid = grid_for(B, kBlock / 64);
+        hipLaunchKernelGGL(bpr_bwd_dense_scalar_kernel, dim3(grid), dim3(kBlock), 0, s, user_tab, item_tab, D, uid, pid, nid,
+                           B, gcoef, out4, reg_weight, grad_out, grad_user_tab, grad_item_tab);
+    }
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind, const float* user_tab, const float* item_tab,
+                             const float* reg_user_tab, const float* reg_item_tab, int D, const int64_t* uid,
+                             const int64_t* iid, const float* label, int64_t B, float reg_weight, float* out4,
+                             float* gcoef, float* scores) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && out4);
+    CDR_CHECK_ARG(D > 0 && B > 0);
+    CDR_CHECK_ARG(loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE);
+    if (!reg_user_tab) reg_user_tab = user_tab;
+    if (!reg_item_tab) reg_item_tab = item_tab;
+    hipStream_t s = (hipStream_t)stream;
+    const bool same = (reg_user_tab == user_tab) && (reg_item_tab == item_tab);
+    int grid;
+    if ((D & 3) == 0) {
+        const int lpr = cdr_lpr_for(D);
+        grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
+        if (same) {
+            DISPATCH_LPR(lpr, point_fwd_kernel<L, true><<<dim3(grid), dim3(kBlock), 0, s>>>(loss_kind,
+                                                  user_tab, item_tab, reg_user_tab, reg_item_tab, D, uid, iid, label, B,
+                                                  gcoef, scores, ctx->partials));
+        } else {
+            DISPATCH_LPR(lpr, point_fwd_kernel<L, false><<<dim3(grid), dim3(kBlock), 0, s>>>(loss_kind,
+                                                  user_tab, item_tab, reg_user_tab, reg_item_tab, D, uid, iid, label, B,
+                                                  gcoef, scores, ctx->partials));
+        }
+    } else {
+        grid = grid_for(B, kBlock / 64);
+        hipLaunchKernelGGL(point_fwd_scalar_kernel, dim3(grid), dim3(kBlock), 0, s, loss_kind, user_tab, item_tab,
+                           reg_user_tab, reg_item_tab, D, uid, iid, label, B, gcoef, scores, ctx->partials);
+    }
+    CDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_point_bwd_dense(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab,
+                                   const float* reg_user_tab, const float* reg_item_tab, int D, const int64_t* uid,
+                                   const int64_t* iid, int64_t B, const float* gcoef, const float* out4,
+                                   float reg_weight, const float* grad_out, float* grad_user_tab, float* grad_item_tab,
+                                   float* grad_reg_user_tab, float* grad_reg_item_tab) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && gcoef && out4);
+    CDR_CHECK_ARG(D > 0 && B > 0);
+    if (!reg_user_tab || reg_user_tab == user_tab) { reg_user_tab = user_tab; grad_reg_user_tab = grad_user_tab; }
+    if (!reg_item_tab || reg_item_tab == item_tab) { reg_item_tab = item_tab; grad_reg_item_tab = grad_item_tab; }
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(B, kBlock / 64);
+    hipLaunchKernelGGL(point_bwd_dense_kernel, dim3(grid), dim3(kBlock), 0, s, user_tab, item_tab, reg_user_tab,
+                       reg_item_tab, D, uid, iid, B, gcoef, out4, reg_weight, grad_out, grad_user_tab, grad_item_tab,
+                       grad_reg_user_tab, grad_reg_item_tab);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -1,0 +1,240 @@
+// Row movers and small fused elementwise kernels: embedding gather / dense scatter-add (K1), mapped-or-target select
+// (K7), activation backward, column sums, MSE, exact dense Adam (K13).  All HBM-bound: 16 B per lane, whole rows per
+// wave-instruction, grid capped at 8 blocks per CU with a grid stride.
+#include "cdr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_cap(int64_t blocks) {
+    const int64_t cap = CDR_NUM_CU * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---- gather: out[r,:] = tab[ids[r],:]   (optionally ids[r] < n_overlap ? mapped[r,:] : tab[ids[r],:]) -----------
+template <bool SELECT>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ tab, const float* __restrict__ mapped,
+                                                             int D, const int64_t* __restrict__ ids, int64_t n,
+                                                             int64_t n_overlap, float* __restrict__ out) {
+    const int D4 = D >> 2;
+    const int64_t total = n * D4;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D4;
+        const int c = (int)(e - r * D4);
+        const int64_t id = ids[r];
+        const float* src = (SELECT && id < n_overlap) ? mapped + r * D : tab + id * D;
+        st4(out + r * D + 4 * c, ld4(src + 4 * c));
+    }
+}
+
+template <bool SELECT>
+__global__ __launch_bounds__(kBlock) void gather_rows_scalar_kernel(const float* __restrict__ tab, const float* __restrict__ mapped,
+                                                                    int D, const int64_t* __restrict__ ids, int64_t n,
+                                                                    int64_t n_overlap, float* __restrict__ out) {
+    const int64_t total = n * D;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const int c = (int)(e - r * D);
+        const int64_t id = ids[r];
+        out[e] = (SELECT && id < n_overlap) ? mapped[r * D + c] : tab[id * D + c];
+    }
+}
+
+// ---- dense scatter-add: grad_tab[ids[r],:] += scale * src[r,:]  (fp32 atomics, like torch's embedding backward) --
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restrict__ grad_tab, int D,
+                                                                  const int64_t* __restrict__ ids, int64_t n,
+                                                                  const float* __restrict__ src,
+                                                                  const float* __restrict__ scale) {
+    const float sc = scale ? scale[0] : 1.0f;
+    const int64_t total = n * D;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const int c = (int)(e - r * D);
+        atomicAdd(grad_tab + ids[r] * D + c, sc * src[e]);
+    }
+}
+
+// ---- activation backward -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void act_bwd_kernel(int act, const float* __restrict__ y, const float* __restrict__ gy,
+                                                         float* __restrict__ gx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const float yv = y[e], g = gy[e];
+        float d;
+        switch (act) {
+            case CDR_ACT_TANH: d = 1.0f - yv * yv; break;
+            case CDR_ACT_RELU: d = yv > 0.f ? 1.0f : 0.f; break;
+            case CDR_ACT_SIGMOID: d = yv * (1.0f - yv); break;
+            default: d = 1.0f;
+        }
+        gx[e] = g * d;
+    }
+}
+
+// ---- column sums (bias gradients): one block per 64 columns, rows strided over the 4 waves, fixed order ----------
+__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int64_t M, int64_t N,
+                                                        float* __restrict__ out, int accumulate) {
+    __shared__ double sm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (col < N)
+        for (int64_t m = wave; m < M; m += 4) s += (double)X[m * N + col];
+    sm[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < N) {
+        const double t = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+        out[col] = (accumulate ? out[col] : 0.f) + (float)t;
+    }
+}
+
+// ---- MSE ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             int64_t n, double* __restrict__ partials) {
+    __shared__ double smem[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const float d = a[e] - b[e];
+        acc[0] += (double)(d * d);
+    }
+    block_sum_d<1>(acc, smem);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE] = acc[0];
+}
+
+__global__ __launch_bounds__(kBlock) void mse_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t n,
+                                                            float* __restrict__ out1) {
+    __shared__ double smem[4];
+    double acc[1] = {0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) acc[0] += partials[(size_t)b * CDR_PARTIAL_STRIDE];
+    block_sum_d<1>(acc, smem);
+    if (threadIdx.x == 0) out1[0] = (float)(acc[0] / (double)n);
+}
+
+__global__ __launch_bounds__(kBlock) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                         const float* __restrict__ grad_out, float* __restrict__ ga,
+                                                         float* __restrict__ gb) {
+    const float go = (grad_out ? grad_out[0] : 1.0f) * 2.0f / (float)n;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const float g = go * (a[e] - b[e]);
+        if (ga) ga[e] = g;
+        if (gb) gb[e] = -g;
+    }
+}
+
+// ---- exact dense Adam (torch.optim.Adam single-tensor path, amsgrad=False) ------------------------------------------
+//   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(kBlock) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                            float lr, float b1, float b2, float eps, float wd,
+                                                            float step_size, float bc2_sqrt) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        float gv = g[e];
+        const float pv = p[e];
+        if (wd != 0.f) gv += wd * pv;
+        const float mv = m[e] + (gv - m[e]) * (1.0f - b1);        // torch: exp_avg.lerp_(grad, 1-beta1)
+        const float vv = b2 * v[e] + (1.0f - b2) * gv * gv;       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        m[e] = mv; v[e] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[e] = pv - step_size * (mv / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int cdr_gather_rows(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out) {
+    CDR_CHECK_ARG(tab && ids && out && D > 0 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    if ((D & 3) == 0) {
+        const int64_t total = n * (D >> 2);
+        gather_rows_kernel<false><<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(tab, nullptr, D, ids, n, 0, out);
+    } else {
+        const int64_t total = n * D;
+        gather_rows_scalar_kernel<false><<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(tab, nullptr, D, ids, n, 0, out);
+    }
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_select_mapped(void* stream, const float* mapped, const float* tab, int D, const int64_t* ids, int64_t n,
+                                 int64_t n_overlap, float* out) {
+    CDR_CHECK_ARG(mapped && tab && ids && out && D > 0 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    if ((D & 3) == 0) {
+        const int64_t total = n * (D >> 2);
+        gather_rows_kernel<true><<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(tab, mapped, D, ids, n, n_overlap, out);
+    } else {
+        const int64_t total = n * D;
+        gather_rows_scalar_kernel<true><<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(tab, mapped, D, ids, n, n_overlap, out);
+    }
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_scatter_add_rows(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n, const float* src,
+                                    const float* scale) {
+    CDR_CHECK_ARG(grad_tab && ids && src && D > 0 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = n * D;
+    scatter_add_rows_kernel<<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(grad_tab, D, ids, n, src, scale);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_act_bwd(void* stream, int act, const float* y, const float* gy, float* gx, int64_t n) {
+    CDR_CHECK_ARG(y && gy && gx && n > 0);
+    CDR_CHECK_ARG(act >= CDR_ACT_NONE && act <= CDR_ACT_SIGMOID);
+    act_bwd_kernel<<<dim3(grid_cap((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(act, y, gy, gx, n);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate) {
+    (void)ctx;
+    CDR_CHECK_ARG(X && out && M > 0 && N > 0);
+    colsum_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(kBlock), 0, (hipStream_t)stream>>>(X, M, N, out, accumulate);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_mse_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* b, int64_t n, float* out1) {
+    CDR_CHECK_ARG(ctx && a && b && out1 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    int64_t g = (n + kBlock * 4 - 1) / (kBlock * 4);
+    if (g > CDR_MAX_PARTIAL_BLOCKS) g = CDR_MAX_PARTIAL_BLOCKS;
+    if (g > CDR_NUM_CU * 8) g = CDR_NUM_CU * 8;
+    mse_partial_kernel<<<dim3((unsigned)g), dim3(kBlock), 0, s>>>(a, b, n, ctx->partials);
+    CDR_LAUNCH_CHECK();
+    mse_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, (int)g, n, out1);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const float* grad_out, float* ga,
+                           float* gb) {
+    CDR_CHECK_ARG(a && b && n > 0 && (ga || gb));
+    mse_bwd_kernel<<<dim3(grid_cap((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(a, b, n, grad_out, ga, gb);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step) {
+    CDR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    adam_dense_kernel<<<dim3(grid_cap((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
+        param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

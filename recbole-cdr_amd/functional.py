@@ -1,0 +1,233 @@
+"""torch.autograd bridges onto libcdrhip: each Function's forward/backward is one or two native kernel launches.
+
+The reference's caller (recbole ``Trainer._train_epoch``) runs ``loss.backward()`` and a dense ``torch.optim.Adam``
+over ``model.parameters()``, so in drop-in mode the backward kernels write the dense ``[rows, D]`` gradients that a
+``sparse=False`` ``nn.Embedding`` would receive.  The fused row-wise training step that never
+materialises table-sized gradients lives in ``fused.py``.
+"""
+import torch
+from torch.autograd import Function
+
+from . import binding as B_
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise B_.NativeLibraryError('recbole_cdr_amd runs on a ROCm device only: got a CPU tensor '
+                                        '(move the model and the interaction to config["device"])')
+
+
+def _ids(t):
+    return t.reshape(-1).contiguous().to(torch.int64)
+
+
+class BPRGatherLoss(Function):
+    """emcdr.py:123-131 / :146-154 in one launch: gather x3 -> 2 dots -> BPRLoss + reg_weight * EmbLoss."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, uid, pid, nid, gamma, reg_weight):
+        _dev_check(user_w, item_w, uid, pid, nid)
+        uid, pid, nid = _ids(uid), _ids(pid), _ids(nid)
+        n, D = uid.numel(), user_w.shape[1]
+        out4 = torch.empty(4, device=user_w.device, dtype=torch.float32)
+        g = torch.empty(n, device=user_w.device, dtype=torch.float32)
+        B_.call('cdr_bpr_fwd', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), D,
+                B_.i64(uid), B_.i64(pid), B_.i64(nid), n, float(gamma), float(reg_weight), B_.f32(out4), B_.f32(g))
+        ctx.save_for_backward(user_w, item_w, uid, pid, nid, g, out4)
+        ctx.reg_weight = float(reg_weight)
+        return out4[:1].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        user_w, item_w, uid, pid, nid, g, out4 = ctx.saved_tensors
+        gU, gI = torch.zeros_like(user_w), torch.zeros_like(item_w)
+        go = grad_out.reshape(-1).contiguous().to(torch.float32)
+        B_.call('cdr_bpr_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), user_w.shape[1],
+                B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(), B_.f32(g), B_.f32(out4), ctx.reg_weight,
+                B_.f32(go), B_.f32(gU), B_.f32(gI))
+        return gU, gI, None, None, None, None, None
+
+
+class PointGatherLoss(Function):
+    """Pointwise gather -> dot -> (sigmoid) -> MSE/BCE + reg_weight * EmbLoss  (emcdr.py:111-122 ; cmf.py:90-98 ;
+    bitgcf.py:221-247 with separate EmbLoss tables).  Returns (total[1], main[1], scores[B])."""
+
+    @staticmethod
+    def forward(ctx, kind, user_w, item_w, reg_user_w, reg_item_w, uid, iid, label, reg_weight):
+        _dev_check(user_w, item_w, uid, iid, label)
+        uid, iid = _ids(uid), _ids(iid)
+        label = label.reshape(-1).contiguous().to(torch.float32)
+        n, D = uid.numel(), user_w.shape[1]
+        dev = user_w.device
+        out4 = torch.empty(4, device=dev, dtype=torch.float32)
+        g = torch.empty(n, device=dev, dtype=torch.float32)
+        scores = torch.empty(n, device=dev, dtype=torch.float32)
+        B_.call('cdr_point_fwd', B_.ctx(dev), B_.stream(), int(kind), B_.f32(user_w), B_.f32(item_w),
+                B_.f32(reg_user_w), B_.f32(reg_item_w), D, B_.i64(uid), B_.i64(iid), B_.f32(label), n,
+                float(reg_weight), B_.f32(out4), B_.f32(g), B_.f32(scores))
+        ctx.save_for_backward(user_w, item_w, reg_user_w, reg_item_w, uid, iid, g, out4)
+        ctx.reg_weight = float(reg_weight)
+        ctx.mark_non_differentiable(scores)
+        return out4[:1].clone(), scores
+
+    @staticmethod
+    def backward(ctx, grad_out, _gs):
+        user_w, item_w, reg_user_w, reg_item_w, uid, iid, g, out4 = ctx.saved_tensors
+        gU, gI = torch.zeros_like(user_w), torch.zeros_like(item_w)
+        gRU = torch.zeros_like(reg_user_w) if reg_user_w is not None else None
+        gRI = torch.zeros_like(reg_item_w) if reg_item_w is not None else None
+        go = grad_out.reshape(-1).contiguous().to(torch.float32)
+        B_.call('cdr_point_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w),
+                B_.f32(reg_user_w), B_.f32(reg_item_w), user_w.shape[1], B_.i64(uid), B_.i64(iid), uid.numel(),
+                B_.f32(g), B_.f32(out4), ctx.reg_weight, B_.f32(go), B_.f32(gU), B_.f32(gI), B_.f32(gRU), B_.f32(gRI))
+        return None, gU, gI, gRU, gRI, None, None, None, None
+
+
+class GatherRows(Function):
+    """nn.Embedding(idx) with its dense backward."""
+
+    @staticmethod
+    def forward(ctx, weight, ids):
+        _dev_check(weight, ids)
+        shape = tuple(ids.shape)
+        flat = _ids(ids)
+        D = weight.shape[1]
+        out = torch.empty(flat.numel(), D, device=weight.device, dtype=torch.float32)
+        if flat.numel():
+            B_.call('cdr_gather_rows', B_.stream(), B_.f32(weight), D, B_.i64(flat), flat.numel(), B_.f32(out))
+        ctx.save_for_backward(flat)
+        ctx.wshape = tuple(weight.shape)
+        return out.view(*shape, D)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (flat,) = ctx.saved_tensors
+        gW = torch.zeros(ctx.wshape, device=grad_out.device, dtype=torch.float32)
+        if flat.numel():
+            go = grad_out.reshape(-1, ctx.wshape[1]).contiguous()
+            B_.call('cdr_scatter_add_rows', B_.stream(), B_.f32(gW), ctx.wshape[1], B_.i64(flat), flat.numel(),
+                    B_.f32(go), None)
+        return gW, None
+
+
+def gather_rows(weight, ids):
+    return GatherRows.apply(weight, ids)
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=None, accumulate=False):
+    """C = act(op(a) @ op(b) + bias) on the fp32 MFMA kernel; 2-D contiguous operands."""
+    _dev_check(a, b, bias)
+    M = a.shape[1] if trans_a else a.shape[0]
+    K = a.shape[0] if trans_a else a.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    Kb = b.shape[1] if trans_b else b.shape[0]
+    if K != Kb:
+        raise ValueError(f'gemm: inner dimensions differ ({K} vs {Kb})')
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    B_.call('cdr_gemm_f32', B_.stream(), int(trans_a), int(trans_b), M, N, K, B_.f32(a), a.shape[1], B_.f32(b), b.shape[1],
+            B_.f32(out), N, B_.f32(bias), int(act), int(accumulate))
+    return out
+
+
+class LinearAct(Function):
+    """y = act(x W^T + b)  (nn.Linear + Tanh/ReLU/Sigmoid: emcdr.py:86-93, conet.py:74-84, recbole MLPLayers)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        shape = tuple(x.shape)
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        y = gemm(x2, weight.contiguous(), trans_b=True, bias=bias, act=act)
+        ctx.save_for_backward(x2, weight, y)
+        ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, shape
+        return y.view(*shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, y = ctx.saved_tensors
+        gy2 = gy.reshape(-1, weight.shape[0]).contiguous()
+        if ctx.act != B_.ACT_NONE:
+            gz = torch.empty_like(gy2)
+            B_.call('cdr_act_bwd', B_.stream(), ctx.act, B_.f32(y), B_.f32(gy2), B_.f32(gz), gy2.numel())
+        else:
+            gz = gy2
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm(gz, weight.contiguous()).view(ctx.xshape)                     # [rows,out] x [out,in]
+        if ctx.needs_input_grad[1]:
+            gW = gemm(gz, x2, trans_a=True)                                         # [out,rows] x [rows,in]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(weight.shape[0], device=gy.device, dtype=torch.float32)
+            B_.call('cdr_colsum', B_.ctx(gy.device), B_.stream(), B_.f32(gz), gz.shape[0], gz.shape[1], B_.f32(gb), 0)
+        return gx, gW, gb, None
+
+
+def linear(x, weight, bias=None, act=B_.ACT_NONE):
+    return LinearAct.apply(x, weight, bias, act)
+
+
+class MSELoss(Function):
+    """nn.MSELoss(): mean over all elements (emcdr.py:81,162,167)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _dev_check(a, b)
+        a_, b_ = a.contiguous(), b.contiguous()
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        B_.call('cdr_mse_fwd', B_.ctx(a.device), B_.stream(), B_.f32(a_), B_.f32(b_), a_.numel(), B_.f32(out))
+        ctx.save_for_backward(a_, b_)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a_, b_ = ctx.saved_tensors
+        ga = torch.empty_like(a_) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b_) if ctx.needs_input_grad[1] else None
+        go = grad_out.reshape(-1).contiguous()
+        B_.call('cdr_mse_bwd', B_.stream(), B_.f32(a_), B_.f32(b_), a_.numel(), B_.f32(go), B_.f32(ga), B_.f32(gb))
+        return ga, gb
+
+
+def mse_loss(a, b):
+    return MSELoss.apply(a, b)
+
+
+def select_mapped(mapped, weight, ids, n_overlap):
+    """where(id < n_overlap, mapped, weight[id])  -- evaluation only (emcdr.py:195-197,222-224)."""
+    _dev_check(mapped, weight, ids)
+    flat = _ids(ids)
+    D = weight.shape[1]
+    out = torch.empty(flat.numel(), D, device=weight.device, dtype=torch.float32)
+    B_.call('cdr_select_mapped', B_.stream(), B_.f32(mapped.detach().contiguous()), B_.f32(weight.detach()), D, B_.i64(flat),
+            flat.numel(), int(n_overlap), B_.f32(out))
+    return out
+
+
+def fullsort_scores(user_e, slab0, slab1=None):
+    """scores[U, n0+n1] = user_e @ cat(slab0, slab1)^T without the cat copy; slabs are contiguous row ranges."""
+    _dev_check(user_e, slab0, slab1)
+    user_e = user_e.detach().contiguous()
+    U, D = user_e.shape
+    n0 = slab0.shape[0] if slab0 is not None else 0
+    n1 = slab1.shape[0] if slab1 is not None else 0
+    out = torch.empty(U, n0 + n1, device=user_e.device, dtype=torch.float32)
+    B_.call('cdr_fullsort_scores_f32', B_.stream(), B_.f32(user_e), U, D,
+            B_.f32(slab0.detach()) if n0 else None, n0, B_.f32(slab1.detach()) if n1 else None, n1, B_.f32(out))
+    return out
+
+
+def fullsort_neg_sqdist(user_e, items):
+    _dev_check(user_e, items)
+    user_e, items = user_e.detach().contiguous(), items.detach().contiguous()
+    U, D = user_e.shape
+    N = items.shape[0]
+    out = torch.empty(U, N, device=user_e.device, dtype=torch.float32)
+    scratch = torch.empty(U + N, device=user_e.device, dtype=torch.float32)
+    B_.call('cdr_fullsort_neg_sqdist_f32', B_.stream(), B_.f32(user_e), U, D, B_.f32(items), N, B_.f32(scratch), B_.f32(out))
+    return out
+
+
+def adam_dense_(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    B_.call('cdr_adam_dense', B_.stream(), B_.f32(param), B_.f32(grad.contiguous()), B_.f32(exp_avg), B_.f32(exp_avg_sq),
+            param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step))

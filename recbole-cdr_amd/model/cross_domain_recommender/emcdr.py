@@ -1,0 +1,172 @@
+"""EMCDR on libcdrhip -- same class contract as recbole_cdr/model/cross_domain_recommender/emcdr.py.
+
+  calculate_source_loss / calculate_target_loss (emcdr.py:110-154): ONE fused gather-dot-loss launch per step
+      (MF: cdr_point_fwd MSE ; BPR: cdr_bpr_fwd) instead of ~8 ATen kernels, EmbLoss rows shared with the score rows.
+  calculate_map_loss (emcdr.py:156-168): 2 row gathers + fp32-MFMA linear layers + MSE.
+  predict / full_sort_predict (emcdr.py:178-233): mapped-or-target select (K7) + fp32-MFMA scoring over <= 2 row
+      ranges of the item table (no torch.cat copy).
+Parameter names equal the reference's, so its checkpoints' ``state_dict`` load unchanged.
+"""
+import torch
+import torch.nn as nn
+
+from ... import binding as B_
+from ... import functional as F_
+from ...utils import InputType
+from ..crossdomain_recommender import CrossDomainRecommender, xavier_normal_initialization
+
+
+class EMCDR(CrossDomainRecommender):
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
+            "EMCDR model only support user overlapped or item overlapped dataset! "
+        if self.overlapped_num_users > 1:
+            self.mode = 'overlap_users'
+        elif self.overlapped_num_items > 1:
+            self.mode = 'overlap_items'
+        else:
+            self.mode = 'non_overlap'
+        self.phase = 'both'
+
+        self.latent_factor_model = config['latent_factor_model']
+        if self.latent_factor_model == 'MF':
+            self.input_type = InputType.POINTWISE
+            self.SOURCE_LABEL = dataset.source_domain_dataset.label_field
+            self.TARGET_LABEL = dataset.target_domain_dataset.label_field
+        else:
+            self.input_type = InputType.PAIRWISE
+        self.source_latent_dim = config['source_embedding_size']
+        self.target_latent_dim = config['target_embedding_size']
+        self.reg_weight = config['reg_weight']
+        self.map_func = config['mapping_function']
+        if self.map_func == 'linear':
+            self.mapping = nn.Linear(self.source_latent_dim, self.target_latent_dim, bias=False)
+        else:
+            assert config["mlp_hidden_size"] is not None
+            dims = [self.source_latent_dim] + list(config["mlp_hidden_size"]) + [self.target_latent_dim]
+            self.mapping = self.mlp_layers(dims)
+
+        # union-sized tables (emcdr.py:67-71).  The reference's zero-fill of "foreign" rows is overwritten by its own
+        # xavier init, so no rows are zeroed here either.
+        self.source_user_embedding = nn.Embedding(self.total_num_users, self.source_latent_dim)
+        self.source_item_embedding = nn.Embedding(self.total_num_items, self.source_latent_dim)
+        self.target_user_embedding = nn.Embedding(self.total_num_users, self.target_latent_dim)
+        self.target_item_embedding = nn.Embedding(self.total_num_items, self.target_latent_dim)
+        self.bpr_gamma = 1e-10
+        self.apply(xavier_normal_initialization)
+
+    @staticmethod
+    def mlp_layers(layer_dims):
+        mods = []
+        for i, (d_in, d_out) in enumerate(zip(layer_dims[:-1], layer_dims[1:])):
+            mods.append(nn.Linear(d_in, d_out))
+            if i != len(layer_dims[:-1]) - 1:
+                mods.append(nn.Tanh())
+        return nn.Sequential(*mods)
+
+    def set_phase(self, phase):
+        self.phase = phase
+
+    # ---- mapping function on the fp32 MFMA kernel --------------------------------------------------------------
+    def apply_mapping(self, x):
+        if self.map_func == 'linear':
+            return F_.linear(x, self.mapping.weight, None, B_.ACT_NONE)
+        layers = [m for m in self.mapping if isinstance(m, nn.Linear)]
+        for n, lin in enumerate(layers):
+            act = B_.ACT_TANH if n != len(layers) - 1 else B_.ACT_NONE
+            x = F_.linear(x, lin.weight, lin.bias, act)
+        return x
+
+    # ---- losses -------------------------------------------------------------------------------------------------
+    def _domain_loss(self, interaction, domain):
+        U = getattr(self, f'{domain}_user_embedding').weight
+        I = getattr(self, f'{domain}_item_embedding').weight
+        user = interaction[getattr(self, f'{domain.upper()}_USER_ID')]
+        item = interaction[getattr(self, f'{domain.upper()}_ITEM_ID')]
+        if self.latent_factor_model == 'MF':
+            label = interaction[getattr(self, f'{domain.upper()}_LABEL')]
+            loss, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_MSE, U, I, None, None, user, item, label, self.reg_weight)
+            return loss
+        neg = interaction[getattr(self, f'{domain.upper()}_NEG_ITEM_ID')]
+        return F_.BPRGatherLoss.apply(U, I, user, item, neg, self.bpr_gamma, self.reg_weight)
+
+    def calculate_source_loss(self, interaction):
+        return self._domain_loss(interaction, 'source')
+
+    def calculate_target_loss(self, interaction):
+        return self._domain_loss(interaction, 'target')
+
+    def calculate_map_loss(self, interaction):
+        idx = interaction[self.OVERLAP_ID]                      # [OB,1]
+        kind = 'user' if self.mode == 'overlap_users' else 'item'
+        src = F_.gather_rows(getattr(self, f'source_{kind}_embedding').weight, idx)
+        tgt = F_.gather_rows(getattr(self, f'target_{kind}_embedding').weight, idx)
+        return F_.mse_loss(self.apply_mapping(src), tgt)
+
+    def calculate_loss(self, interaction):
+        if self.phase == 'SOURCE':
+            return self.calculate_source_loss(interaction)
+        elif self.phase == 'OVERLAP':
+            return self.calculate_map_loss(interaction)
+        else:
+            return self.calculate_target_loss(interaction)
+
+    # ---- scoring ------------------------------------------------------------------------------------------------
+    def _mapped_rows(self, kind, ids, n_overlap):
+        """where(id < n_overlap, mapping(source[id]), target[id]); the mapping is evaluated for all rows (Q5)."""
+        src = F_.gather_rows(getattr(self, f'source_{kind}_embedding').weight, ids)
+        return F_.select_mapped(self.apply_mapping(src), getattr(self, f'target_{kind}_embedding').weight, ids, n_overlap)
+
+    @staticmethod
+    def _rowdot(a, b):
+        # [B,D].[B,D] -> [B] as the diagonal-free pointwise kernel: reuse the scoring GEMM on row pairs would be
+        # O(B^2); B is the eval batch of explicit (user,item) pairs, so gather-dot it natively.
+        n, D = a.shape
+        ids = torch.arange(n, device=a.device, dtype=torch.int64)
+        zeros = torch.zeros(n, device=a.device, dtype=torch.float32)
+        _, scores = F_.PointGatherLoss.apply(B_.CDR_LOSS_MSE, a.contiguous(), b.contiguous(), None, None, ids, ids, zeros, 0.0)
+        return scores
+
+    def _pair_scores(self, U, I, user, item):
+        zeros = torch.zeros(user.numel(), device=U.device, dtype=torch.float32)
+        _, scores = F_.PointGatherLoss.apply(B_.CDR_LOSS_MSE, U, I, None, None, user, item, zeros, 0.0)
+        return scores
+
+    @torch.no_grad()
+    def predict(self, interaction):
+        if self.phase == 'SOURCE':
+            return self._pair_scores(self.source_user_embedding.weight, self.source_item_embedding.weight,
+                                     interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID])
+        user, item = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
+        if self.phase == 'TARGET':
+            return self._pair_scores(self.target_user_embedding.weight, self.target_item_embedding.weight, user, item)
+        if self.mode == 'overlap_users':
+            user_e = self._mapped_rows('user', user, self.overlapped_num_users)
+            item_e = F_.gather_rows(self.target_item_embedding.weight, item)
+        else:
+            user_e = F_.gather_rows(self.target_user_embedding.weight, user)
+            item_e = self._mapped_rows('item', item, self.overlapped_num_items)
+        return self._rowdot(user_e, item_e)
+
+    @torch.no_grad()
+    def full_sort_predict(self, interaction):
+        OI, TI = self.overlapped_num_items, self.target_num_items
+        if self.phase == 'SOURCE':
+            user_e = F_.gather_rows(self.source_user_embedding.weight, interaction[self.SOURCE_USER_ID])
+            W = self.source_item_embedding.weight
+            score = F_.fullsort_scores(user_e, W[:OI], W[TI:])
+        elif self.phase == 'TARGET':
+            user_e = F_.gather_rows(self.target_user_embedding.weight, interaction[self.TARGET_USER_ID])
+            score = F_.fullsort_scores(user_e, self.target_item_embedding.weight[:TI])
+        else:
+            user = interaction[self.TARGET_USER_ID]
+            if self.mode == 'overlap_users':
+                user_e = self._mapped_rows('user', user, self.overlapped_num_users)
+                score = F_.fullsort_scores(user_e, self.target_item_embedding.weight[:TI])
+            else:
+                user_e = F_.gather_rows(self.target_user_embedding.weight, user)
+                overlap_item_e = self.apply_mapping(self.source_item_embedding.weight[:OI])
+                score = F_.fullsort_scores(user_e, overlap_item_e, self.target_item_embedding.weight[OI:TI])
+        return score.view(-1)

@@ -1,0 +1,76 @@
+"""Abstract cross-domain recommender = the drop-in boundary (recbole_cdr/model/crossdomain_recommender.py:14-51).
+
+Same constructor contract ``(config, dataset)``, same attribute names, same ``set_phase`` hook; the third-party
+``recbole.model.abstract_recommender.AbstractRecommender`` surface the trainer relies on (``calculate_loss`` /
+``predict`` / ``full_sort_predict`` / ``other_parameter`` / ``load_other_parameter``) is restated here because recbole
+is not a dependency of this package.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import xavier_normal_, constant_
+
+from ..utils import ModelType
+
+
+def xavier_normal_initialization(module):
+    """recbole.model.init.xavier_normal_initialization: Embedding / Linear weights ~ xavier normal, biases 0."""
+    if isinstance(module, nn.Embedding):
+        xavier_normal_(module.weight.data)
+    elif isinstance(module, nn.Linear):
+        xavier_normal_(module.weight.data)
+        if module.bias is not None:
+            constant_(module.bias.data, 0)
+
+
+class CrossDomainRecommender(nn.Module):
+    type = ModelType.CROSSDOMAIN
+
+    def __init__(self, config, dataset):
+        super().__init__()
+        # source dataset info
+        self.SOURCE_USER_ID = dataset.source_domain_dataset.uid_field
+        self.SOURCE_ITEM_ID = dataset.source_domain_dataset.iid_field
+        self.SOURCE_NEG_ITEM_ID = config['source_domain']['NEG_PREFIX'] + self.SOURCE_ITEM_ID
+        self.source_num_users = dataset.source_domain_dataset.num(self.SOURCE_USER_ID)
+        self.source_num_items = dataset.source_domain_dataset.num(self.SOURCE_ITEM_ID)
+        # target dataset info
+        self.TARGET_USER_ID = dataset.target_domain_dataset.uid_field
+        self.TARGET_ITEM_ID = dataset.target_domain_dataset.iid_field
+        self.TARGET_NEG_ITEM_ID = config['target_domain']['NEG_PREFIX'] + self.TARGET_ITEM_ID
+        self.target_num_users = dataset.target_domain_dataset.num(self.TARGET_USER_ID)
+        self.target_num_items = dataset.target_domain_dataset.num(self.TARGET_ITEM_ID)
+        # both
+        self.total_num_users = dataset.num_total_user
+        self.total_num_items = dataset.num_total_item
+        self.overlapped_num_users = dataset.num_overlap_user
+        self.overlapped_num_items = dataset.num_overlap_item
+        self.OVERLAP_ID = dataset.overlap_id_field
+        self.device = config['device']
+
+    def set_phase(self, phase):
+        pass
+
+    def calculate_loss(self, interaction):
+        raise NotImplementedError
+
+    def predict(self, interaction):
+        raise NotImplementedError
+
+    def full_sort_predict(self, interaction):
+        raise NotImplementedError
+
+    def other_parameter(self):
+        if hasattr(self, 'other_parameter_name'):
+            return {key: getattr(self, key) for key in self.other_parameter_name}
+        return dict()
+
+    def load_other_parameter(self, para):
+        if para is None:
+            return
+        for key, value in para.items():
+            setattr(self, key, value)
+
+    def __str__(self):
+        params = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
+        return super().__str__() + f'\nTrainable parameters: {params}'

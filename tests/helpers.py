@@ -1,0 +1,70 @@
+"""Shared test helpers: duck-typed dataset/config for the product models, tolerance helpers."""
+import numpy as np
+import torch
+
+
+class _Single:
+    def __init__(self, domain, n_user, n_item, inter_feat=None):
+        self.uid_field = f'{domain}_user_id'
+        self.iid_field = f'{domain}_item_id'
+        self.label_field = f'{domain}_label'
+        self._n = {self.uid_field: n_user, self.iid_field: n_item}
+        self.inter_feat = inter_feat
+
+    def num(self, field):
+        return self._n[field]
+
+
+class FakeDataset:
+    """The attributes CrossDomainRecommender.__init__ reads (crossdomain_recommender.py:21-48)."""
+
+    def __init__(self, ids, s_pairs=None, t_pairs=None):
+        self.ids = ids
+        s_feat = t_feat = None
+        if s_pairs is not None:
+            s_feat = {'source_user_id': torch.as_tensor(s_pairs[:, 0]), 'source_item_id': torch.as_tensor(s_pairs[:, 1])}
+            t_feat = {'target_user_id': torch.as_tensor(t_pairs[:, 0]), 'target_item_id': torch.as_tensor(t_pairs[:, 1])}
+        self.s_pairs, self.t_pairs = s_pairs, t_pairs
+        self.source_domain_dataset = _Single('source', ids.source_num_users, ids.source_num_items, s_feat)
+        self.target_domain_dataset = _Single('target', ids.target_num_users, ids.target_num_items, t_feat)
+        self.num_total_user, self.num_total_item = ids.total_num_users, ids.total_num_items
+        self.num_overlap_user, self.num_overlap_item = ids.OU, ids.OI
+        self.num_target_only_item, self.num_source_only_item = ids.TOI, ids.SOI
+        self.num_target_only_user, self.num_source_only_user = ids.TOU, ids.SOU
+        self.overlap_id_field = 'overlap'
+
+    def inter_matrix(self, form='coo', value_field=None, domain='source'):
+        import scipy.sparse as sp
+        p = self.s_pairs if domain == 'source' else self.t_pairs
+        return sp.coo_matrix((np.ones(len(p), dtype=np.float32), (p[:, 0], p[:, 1])),
+                             shape=(self.num_total_user, self.num_total_item))
+
+
+def base_config(device, **kw):
+    cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': device}
+    cfg.update(kw)
+    return cfg
+
+
+def load_params(model, params):
+    """Copy a {name: tensor} dict (reference naming) into the product model's parameters."""
+    own = dict(model.named_parameters())
+    assert set(own) == set(params), (sorted(own), sorted(params))
+    with torch.no_grad():
+        for k, v in params.items():
+            own[k].copy_(v.to(own[k].device))
+
+
+def to_dev(d, device):
+    return {k: v.to(device) for k, v in d.items()}
+
+
+def assert_close(got, want, rtol=1e-5, atol=None, what=''):
+    """north_star tolerance: 1e-5 relative; `atol` defaults to 1e-5 x the largest magnitude in the expected tensor so
+    that near-cancelled dot products are judged on the scale of the data, not of the cancellation."""
+    got = got.detach().cpu().double().numpy().reshape(-1) if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64).reshape(-1)
+    want = want.detach().cpu().double().numpy().reshape(-1) if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64).reshape(-1)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if atol is None:
+        atol = 1e-5 * (np.abs(want).max() if want.size else 1.0) + 1e-12
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)

@@ -1,0 +1,195 @@
+"""GPU parity (-m gpu): the HIP path through the C ABI vs (1) golden vectors produced by the reference and (2) the
+oracle on larger seeded inputs.  Tolerance: 1e-5 relative (north_star) for fp32 losses / gradients / scores."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, cases
+from helpers import FakeDataset, base_config, load_params, to_dev, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _grads(model):
+    return {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _check_grads(model, g, phase):
+    want = g.group(f'grad/{phase}', as_torch=False)
+    got = _grads(model)
+    for name, ref in want.items():
+        assert name in got, f'{name}: reference has a gradient, product has none'
+        assert_close(got[name], ref, what=f'{g.name}:{phase}:{name}')
+    for name, t in got.items():
+        if name not in want:
+            assert float(t.abs().max()) == 0.0, f'{name}: product has a gradient the reference does not produce'
+
+
+@pytest.mark.parametrize('name', cases('emcdr_'))
+def test_emcdr_golden(name):
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    g = Golden(name)
+    ids = g.idspace()
+    D = int(g.meta('D'))
+    cfg = base_config(DEV, latent_factor_model=str(g.meta('latent_factor_model')), source_embedding_size=D,
+                      target_embedding_size=D, reg_weight=float(g.meta('reg_weight')),
+                      mapping_function=str(g.meta('mapping_function')), mlp_hidden_size=[int(x) for x in g.meta('mlp_hidden_size')])
+    model = EMCDR(cfg, FakeDataset(ids)).to(DEV)
+    load_params(model, g.group('param'))
+    inter = to_dev(g.group('in'), DEV)
+    for phase in ('SOURCE', 'TARGET', 'OVERLAP', 'BOTH'):
+        model.set_phase(phase)
+        model.zero_grad(set_to_none=True)
+        loss = model.calculate_loss(inter)
+        assert_close(loss, g[f'loss/{phase}'], what=f'{name}:{phase}:loss')
+        loss.sum().backward()
+        _check_grads(model, g, phase)
+    ev = to_dev(g.group('evalin'), DEV)
+    for phase in ('SOURCE', 'TARGET', 'OVERLAP', 'BOTH'):
+        model.set_phase(phase)
+        assert_close(model.predict(ev), g[f'predict/{phase}'], what=f'{name}:{phase}:predict')
+        assert_close(model.full_sort_predict(ev), g[f'fullsort/{phase}'], what=f'{name}:{phase}:fullsort')
+
+
+@pytest.mark.parametrize('name', cases('cmf_'))
+def test_cmf_golden(name):
+    from recbole_cdr_amd.model.cross_domain_recommender.cmf import CMF
+    g = Golden(name)
+    ids = g.idspace()
+    cfg = base_config(DEV, embedding_size=int(g.meta('D')), alpha=float(g.meta('alpha')),
+                      **{'lambda': float(g.meta('lam')), 'gamma': float(g.meta('gamma'))})
+    model = CMF(cfg, FakeDataset(ids)).to(DEV)
+    load_params(model, g.group('param'))
+    inter = to_dev(g.group('in'), DEV)
+    loss = model.calculate_loss(inter)
+    assert_close(loss, g['loss/BOTH'], what=f'{name}:loss')
+    loss.sum().backward()
+    _check_grads(model, g, 'BOTH')
+    ev = to_dev(g.group('evalin'), DEV)
+    assert_close(model.predict(ev), g['predict/BOTH'])
+    assert_close(model.full_sort_predict(ev), g['fullsort/BOTH'])
+
+
+# ---------------------------------------------------------------------------------------------- vs the oracle
+@pytest.mark.parametrize('D', [4, 8, 20, 64, 128, 256, 260, 7])
+@pytest.mark.parametrize('k', [1, 4])
+def test_bpr_kernel_vs_oracle(D, k):
+    """cdr_bpr_fwd / cdr_bpr_bwd_dense against the oracle at sizes the oracle finishes in seconds; includes row widths
+    that exercise every lanes-per-row instantiation, the chunked (D > 256) and the scalar (D % 4 != 0) paths."""
+    from oracle import losses
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(D * 10 + k)
+    nu, ni, S = 300, 500, 257
+    U = (torch.randn(nu, D) * 0.3).requires_grad_(True)
+    I = (torch.randn(ni, D) * 0.3).requires_grad_(True)
+    u = torch.randint(0, nu, (S,)).repeat(k)
+    p = torch.randint(0, ni, (S,)).repeat(k)
+    n = torch.randint(0, ni, (S * k,))
+    reg = 0.05
+    ps, ns = (U[u] * I[p]).sum(1), (U[u] * I[n]).sum(1)
+    ref = losses.bpr_loss(ps, ns) + reg * losses.emb_loss(U[u], I[p])
+    ref.sum().backward()
+    Ud, Id = U.detach().to(DEV).requires_grad_(True), I.detach().to(DEV).requires_grad_(True)
+    got = F_.BPRGatherLoss.apply(Ud, Id, u.to(DEV), p.to(DEV), n.to(DEV), 1e-10, reg)
+    assert_close(got, ref, what='loss')
+    (got.sum() * 1.0).backward()
+    assert_close(Ud.grad, U.grad, what='dU')
+    assert_close(Id.grad, I.grad, what='dI')
+
+
+@pytest.mark.parametrize('kind', ['mse', 'bce'])
+@pytest.mark.parametrize('D', [8, 64, 128, 6])
+def test_point_kernel_vs_oracle(kind, D):
+    from oracle import losses
+    from recbole_cdr_amd import functional as F_, binding as B_
+    torch.manual_seed(D)
+    nu, ni, n = 200, 300, 1000
+    U = (torch.randn(nu, D) * 0.5).requires_grad_(True)
+    I = (torch.randn(ni, D) * 0.5).requires_grad_(True)
+    u, i = torch.randint(0, nu, (n,)), torch.randint(0, ni, (n,))
+    y = (torch.rand(n) < 0.3).float()
+    reg = 0.02
+    dot = (U[u] * I[i]).sum(1)
+    main = losses.mse_loss(dot, y) if kind == 'mse' else losses.bce_loss(torch.sigmoid(dot), y)
+    ref = main + reg * losses.emb_loss(U[u], I[i])
+    ref.sum().backward()
+    Ud, Id = U.detach().to(DEV).requires_grad_(True), I.detach().to(DEV).requires_grad_(True)
+    code = B_.CDR_LOSS_MSE if kind == 'mse' else B_.CDR_LOSS_BCE
+    got, sc = F_.PointGatherLoss.apply(code, Ud, Id, None, None, u.to(DEV), i.to(DEV), y.to(DEV), reg)
+    assert_close(got, ref, what='loss')
+    assert_close(sc, dot if kind == 'mse' else torch.sigmoid(dot), what='scores')
+    got.sum().backward()
+    assert_close(Ud.grad, U.grad, what='dU')
+    assert_close(Id.grad, I.grad, what='dI')
+
+
+def test_bce_saturation_matches_torch_clamp():
+    """BCE's log clamp at -100 and its zero gradient in saturation (SURVEY 7 'Transcendentals')."""
+    from oracle import losses
+    from recbole_cdr_amd import functional as F_, binding as B_
+    D = 4
+    U = torch.tensor([[30.0, 0, 0, 0], [-30.0, 0, 0, 0], [0.1, 0, 0, 0]], requires_grad=True)
+    I = torch.tensor([[10.0, 0, 0, 0]], requires_grad=True)
+    u = torch.tensor([0, 1, 2, 0, 1]); i = torch.zeros(5, dtype=torch.int64)
+    y = torch.tensor([0.0, 1.0, 1.0, 1.0, 0.0])
+    ref = losses.bce_loss(torch.sigmoid((U[u] * I[i]).sum(1)), y)
+    ref.backward()
+    Ud, Id = U.detach().to(DEV).requires_grad_(True), I.detach().to(DEV).requires_grad_(True)
+    got, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, Ud, Id, None, None, u.to(DEV), i.to(DEV), y.to(DEV), 0.0)
+    assert_close(got, ref)
+    got.sum().backward()
+    assert_close(Ud.grad, U.grad); assert_close(Id.grad, I.grad)
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 1000, 64), (3, 1350, 64), (5, 777, 128), (33, 130, 20), (100, 64, 12),
+                                   (200, 300, 128), (129, 257, 31), (64, 5, 7)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_vs_torch(M, N, K, ta, tb):
+    """fp32 MFMA contraction vs torch fp32 matmul (floating-point kernel: torch reference per the tier rules), with
+    asymmetric operands so a transposed C would be caught."""
+    from recbole_cdr_amd import functional as F_, binding as B_
+    torch.manual_seed(M + N + K)
+    A = torch.randn(K, M) if ta else torch.randn(M, K)
+    Bm = torch.randn(N, K) if tb else torch.randn(K, N)
+    bias = torch.randn(N)
+    ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double()
+    got = F_.gemm(A.to(DEV), Bm.to(DEV), trans_a=ta, trans_b=tb, bias=bias.to(DEV))
+    assert_close(got, ref.float(), atol=1e-5 * float(ref.abs().max()))
+    got_t = F_.gemm(A.to(DEV), Bm.to(DEV), trans_a=ta, trans_b=tb, bias=bias.to(DEV), act=B_.ACT_TANH)
+    assert_close(got_t, torch.tanh(ref).float(), atol=2e-6)
+
+
+def test_fullsort_two_slabs_and_full_size_property():
+    """Item operand as two row ranges == the reference's torch.cat path; and at a BASELINE-sized slab the scoring is
+    checked through a size-independent property: linearity in the user operand."""
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(0)
+    W = torch.randn(5000, 64)
+    ue = torch.randn(3, 64)
+    ref = ue.double() @ torch.cat([W[:7], W[1200:]]).double().t()
+    got = F_.fullsort_scores(ue.to(DEV), W.to(DEV)[:7], W.to(DEV)[1200:])
+    assert_close(got, ref.float())
+    # full size (10M x 128 would be 5 GB; 2M x 128 = 1 GB is past L2+MALL) -- linearity: s(a+b) = s(a)+s(b)
+    N, D = 2_000_000, 128
+    Wd = torch.randn(N, D, device=DEV) * 0.1
+    a, b = torch.randn(1, D, device=DEV), torch.randn(1, D, device=DEV)
+    sa, sb, sab = F_.fullsort_scores(a, Wd), F_.fullsort_scores(b, Wd), F_.fullsort_scores(a + b, Wd)
+    assert_close(sab, sa + sb, atol=1e-5 * float(sab.abs().max()))
+    idx = torch.randint(0, N, (64,), device=DEV)
+    assert_close(sa[0, idx], (Wd[idx].double() @ a[0].double()).float())
+
+
+def test_adam_dense_matches_torch():
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(1)
+    p0 = torch.randn(1000)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-3, weight_decay=0.01)
+    p = p0.clone().to(DEV); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 6):
+        g = torch.randn(1000)
+        p_ref.grad = g.clone()
+        opt.step()
+        F_.adam_dense_(p, g.to(DEV), m, v, step, lr=1e-3, weight_decay=0.01)
+    assert_close(p, p_ref, rtol=1e-6)
