@@ -139,6 +139,35 @@ int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const f
 int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
+/* ---- fused row-wise training step (tables too large for dense gradients / dense Adam: BASELINE config C5) -----
+ * Replaces, for one BPR step, loss.backward() + optimizer.step() of the reference's loop (trainer.py:59-73 ->
+ * recbole Trainer._train_epoch) without ever materialising a table-sized gradient:
+ *   cdr_bpr_fwd_grad : cdr_bpr_fwd + the compact gradient rows  GU[b] = g_b (I[pid_b]-I[nid_b]),  GP[b] = g_b U[uid_b]
+ *                      out6 = {total, bpr, ||U_b||, ||I_b||, c_u, c_i},  c = reg_weight / (B * norm)
+ *   cdr_sort_ids     : stable radix sort of (row id, occurrence index) over the significant key bits; ids1 (optional)
+ *                      is appended after ids0 (items: ids0 = pid, ids1 = nid -> occurrences [0,B) positive, [B,2B) negative)
+ *   cdr_rowwise_apply: per distinct row r (segment of keys_sorted):
+ *                        grad = sum_{o in seg, o <  neg_start} G[o] - sum_{o in seg, o >= neg_start} G[o - neg_start]
+ *                             + reg_coef[0] * #{o in seg : o < reg_limit} * table[r]
+ *                      then opt 0: SGD  table[r] -= lr * (grad + wd * table[r])
+ *                           opt 1: Adam (torch.optim.Adam arithmetic, per-row lazy) with exp_avg / exp_avg_sq rows.
+ *                      Summation follows occurrence order (the sort is stable): bit-reproducible.
+ */
+int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
+                     const float* user_tab, const float* item_tab, int D,
+                     const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                     float gamma, float reg_weight, float* out6, float* GU /* [B,D] */, float* GP /* [B,D] */);
+int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);
+int cdr_sort_ids(void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1, int64_t num_rows,
+                 uint32_t* keys_sorted /* [n0+n1] */, uint32_t* perm /* [n0+n1] */,
+                 void* workspace, size_t workspace_bytes);
+#define CDR_OPT_SGD 0
+#define CDR_OPT_ADAM 1
+int cdr_rowwise_apply(void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
+                      const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
+                      const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
+
 #ifdef __cplusplus
 }
 #endif

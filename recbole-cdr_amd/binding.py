@@ -64,6 +64,12 @@ _SIGNATURES = {
     'cdr_colsum': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int],
     'cdr_mse_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_mse_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr,
+                         _c_ptr],
+    'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
+    'cdr_sort_ids': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_rowwise_apply': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
+                          _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
     'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
 }
 
@@ -142,6 +148,10 @@ def f32(t):
 
 def i64(t):
     return ptr(t, torch.int64)
+
+
+def raw(t):
+    return ptr(t)
 
 
 def call(name, *args):
