@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""bench.py -- training interactions/sec (+ full-sort items scored/sec) of the MI355X cross-domain hot path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run, one
+rank per GPU over RCCL.  W untimed warm-up steps, then EXACTLY K steps between barrier+synchronize brackets, MAX over
+ranks, rank 0 prints ONE JSON line.
+
+Workload (default `c5`, BASELINE.json configs[4], the configuration north_star quotes its targets on; it fits one
+MI355X): EMCDR-BPR, D=128, union id space of 50,000,001 users x 20,000,001 items (10 M items per domain), fp32
+xavier-normal tables, synthetic uniform interaction streams (seed 2022).  One STEP = one SOURCE-domain batch + one
+TARGET-domain batch of `--batch` (u, i+, i-) triples each: fused gather -> BPR+EmbLoss -> per-row gradients -> row-wise
+Adam update of the touched rows (csrc/cdr_step.hip).  Inputs (tables, id batches) are resident in HBM before the timed
+region.  With N>1 the tables are row-sharded (row r on rank r % N) and every rank contributes its own batch
+(weak scaling in batch; table size fixed); rows/gradients travel by RCCL all-to-all (shard.py).
+
+`--workload c2` runs BASELINE configs[1] (EMCDR ml-1m->ml-100k sized tables, D=64, B=2048) through the drop-in autograd
+path + exact dense Adam instead.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='c5', choices=['c5', 'c2'])
+    ap.add_argument('--batch', type=int, default=1 << 20, help='triples per domain per rank per step (c5)')
+    ap.add_argument('--opt', default='adam', choices=['adam', 'sgd'])
+    ap.add_argument('--users', type=int, default=50_000_001)
+    ap.add_argument('--items-per-domain', type=int, default=10_000_000)
+    ap.add_argument('--dim', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fullsort', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def xavier_table(rows, D, total_rows, gen, dev):
+    # xavier_normal_ on the [total_rows, D] table: std = sqrt(2 / (rows + D))  (recbole xavier_normal_initialization)
+    std = (2.0 / (total_rows + D)) ** 0.5
+    t = torch.empty(rows, D, device=dev, dtype=torch.float32)
+    t.normal_(0.0, std, generator=gen)
+    return t
+
+
+class EventTimer:
+    """HIP-event brackets around individual native calls on torch's current stream (the stream the kernels run on)."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def bracket(self, name):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.setdefault(name, []).append((e0, e1))
+        return e0, e1
+
+    def mean_ms(self, name):
+        ps = self.pairs.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in ps) / max(len(ps), 1)
+
+
+# ------------------------------------------------------------------------------------------------------ C5 workload
+def run_c5(args, world, rank, dev):
+    from recbole_cdr_amd.fused import FusedBPRStep
+    from recbole_cdr_amd import functional as F_
+    D, B = args.dim, args.batch
+    OU, TOI = args.users, args.items_per_domain
+    n_users, n_items = OU, 1 + 2 * TOI                     # union sizes: OI = 1 (PAD), TOI = SOI = 10 M
+    gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
+    if world == 1:
+        tabs = {k: xavier_table(r, D, r, gen, dev) for k, r in
+                (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
+        steps = {'source': FusedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01),
+                 'target': FusedBPRStep(tabs['tu'], tabs['ti'], B, opt=args.opt, reg_weight=0.01)}
+    else:
+        from recbole_cdr_amd.shard import ShardedBPRStep, shard_rows
+        tabs = {k: xavier_table(shard_rows(r, world, rank), D, r, gen, dev) for k, r in
+                (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
+        steps = {'source': ShardedBPRStep(tabs['su'], tabs['si'], n_users, n_items, B, opt=args.opt, reg_weight=0.01),
+                 'target': ShardedBPRStep(tabs['tu'], tabs['ti'], n_users, n_items, B, opt=args.opt, reg_weight=0.01)}
+
+    # synthetic interaction streams: users ~ U{1..OU-1}; target items [1, TOI], source items [TOI+1, 2 TOI]
+    pool = 4
+    batches = []
+    for _ in range(pool):
+        b = {}
+        for dom, lo in (('source', 1 + TOI), ('target', 1)):
+            u = torch.randint(1, OU, (B,), device=dev, generator=gen)
+            p = torch.randint(lo, lo + TOI, (B,), device=dev, generator=gen)
+            n = torch.randint(lo, lo + TOI, (B,), device=dev, generator=gen)
+            b[dom] = (u, p, n)
+        batches.append(b)
+
+    timer = EventTimer()
+
+    def one_step(i, timed):
+        b = batches[i % pool]
+        for dom in ('source', 'target'):
+            steps[dom].step(*b[dom], timer=timer if timed else None)
+
+    for i in range(args.warmup):
+        one_step(i, False)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i, True)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    loss = float(steps['target'].out6[0].item()) if world == 1 else float(steps['target'].loss_value())
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    interactions = 2 * B * args.steps * world
+    result = {
+        'metric': 'training interactions/sec', 'value': interactions / dt, 'unit': 'interactions/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'C5: EMCDR-BPR D=%d, %d users x %d items/domain (union tables %.1f GB fp32), '
+                               'step = source batch + target batch of %d triples each per rank, fwd+bwd+row-wise %s'
+                               % (D, OU - 1, TOI, 4.0 * D * 2 * (n_users + n_items) / 1e9, B, args.opt),
+                   'batch_per_domain_per_rank': B, 'k_neg': 1, 'optimizer': 'rowwise-' + args.opt,
+                   'sharding': 'none' if world == 1 else 'row %% %d' % world},
+        'final_loss': loss,
+    }
+
+    # ---- roofline of the dominant kernel(s): algorithmic bytes / HIP-event time of each native call --------------
+    if rank == 0 and world == 1:
+        uniq = {}
+        for dom in ('source', 'target'):
+            u, p, n = batches[0][dom]
+            uniq[dom] = (int(torch.unique(u).numel()), int(torch.unique(torch.cat([p, n])).numel()))
+        nmom = 6 if args.opt == 'adam' else 2
+        # per launch (one domain's batch of B triples), bytes the algorithm must move:
+        alg = {
+            'bpr_fwd_grad_kernel': B * (3 * 4 * D + 24) + B * 2 * 4 * D,
+            'rowwise_apply_kernel(users)': B * (8 + 4 * D) + uniq['source'][0] * nmom * 4 * D,
+            'rowwise_apply_kernel(items)': 2 * B * (8 + 4 * D) + uniq['source'][1] * nmom * 4 * D,
+        }
+        names = {'bpr_fwd_grad_kernel': 'fwd_grad', 'rowwise_apply_kernel(users)': 'apply_u',
+                 'rowwise_apply_kernel(items)': 'apply_i'}
+        kernels = []
+        for kname, tag in names.items():
+            ms = timer.mean_ms(tag)
+            gbs = alg[kname] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            kernels.append({'kernel': kname, 'avg_ms': ms, 'algorithmic_bytes': alg[kname], 'achieved_GBps': gbs,
+                            'frac': gbs / HBM_PEAK_GBS})
+        for tag in ('sort_u', 'sort_i'):
+            kernels.append({'kernel': 'rocprim radix sort (%s)' % tag, 'avg_ms': timer.mean_ms(tag)})
+        dom_k = max(kernels[:3], key=lambda k: k['avg_ms'])
+        result['roofline'] = {'bound': 'hbm', 'kernel': dom_k['kernel'], 'achieved': dom_k['achieved_GBps'],
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_k['frac'],
+                              'avg_launch_ms': dom_k['avg_ms'], 'traffic': pmc_traffic(dom_k['kernel'])}
+        gk = kernels[0]
+        result['roofline_gather'] = {'bound': 'hbm', 'kernel': gk['kernel'], 'achieved': gk['achieved_GBps'],
+                                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gk['frac'],
+                                     'avg_launch_ms': gk['avg_ms'], 'traffic': pmc_traffic(gk['kernel'])}
+        result['kernels'] = kernels
+
+    # ---- metric 2: full-sort items scored / s (emcdr.py:208-233, TARGET phase) at the reference's U and at U=1024 --
+    if rank == 0 and world == 1 and not args.no_fullsort:
+        fs = {}
+        slab = tabs['ti'][:1 + TOI]
+        # the optimizer state is not needed any more; make room for the [U, N] score matrix (40 GB at U=1024)
+        for st in steps.values():
+            st.ustate = st.istate = None
+            st.GU = st.GP = None
+        torch.cuda.empty_cache()
+        for Uu in (1, 1024):
+            ue = tabs['tu'][1:1 + Uu].contiguous()
+            reps = 5 if Uu == 1 else 3
+            out = torch.empty(Uu, slab.shape[0], device=dev, dtype=torch.float32)
+            F_.fullsort_scores(ue, slab, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                F_.fullsort_scores(ue, slab, out=out)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            N = slab.shape[0]
+            byts = 4.0 * N * D + 4.0 * Uu * D + 4.0 * Uu * N
+            flops = 2.0 * Uu * N * D
+            fs['U=%d' % Uu] = {'items_per_s': Uu * N / (ms * 1e-3), 'ms': ms, 'N': N,
+                               'achieved_GBps': byts / (ms * 1e-3) / 1e9, 'hbm_frac': byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
+                               'mfma_frac': flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            del out
+        result['fullsort'] = fs
+    return result
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------ C2 workload
+def run_c2(args, world, rank, dev):
+    """BASELINE configs[1]: EMCDR (BPR variant) at ml-1m -> ml-100k sizes through the drop-in autograd path with exact
+    dense Adam (the reference's semantics), B = 2048."""
+    from recbole_cdr_amd import functional as F_
+    D, B = 64, 2048
+    n_users, n_items = 6984, 3900
+    gen = torch.Generator(device=dev); gen.manual_seed(2022)
+    U = xavier_table(n_users, D, n_users, gen, dev).requires_grad_(True)
+    I = xavier_table(n_items, D, n_items, gen, dev).requires_grad_(True)
+    mU, vU, mI, vI = (torch.zeros_like(x) for x in (U, U, I, I))
+    u = torch.randint(1, n_users, (B,), device=dev, generator=gen)
+    p = torch.randint(1, n_items, (B,), device=dev, generator=gen)
+    n = torch.randint(1, n_items, (B,), device=dev, generator=gen)
+
+    def one_step(step):
+        U.grad = I.grad = None
+        loss = F_.BPRGatherLoss.apply(U, I, u, p, n, 1e-10, 0.01)
+        loss.sum().backward()
+        with torch.no_grad():
+            F_.adam_dense_(U, U.grad, mU, vU, step)
+            F_.adam_dense_(I, I.grad, mI, vI, step)
+
+    for i in range(args.warmup):
+        one_step(i + 1)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i + 1)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    return {'metric': 'training interactions/sec', 'value': B * args.steps * world / dt, 'unit': 'interactions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: EMCDR-BPR ml-1m->ml-100k sized tables (6984 x 3900), D=64, B=2048, drop-in '
+                                   'autograd + exact dense Adam', 'batch': B}}
+
+
+# ------------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(args):
+    """The oracle's row-wise step (oracle/train_step.py: same loss, same per-row gradients, lazy Adam) timed on this
+    node's host cores on a bounded sample: down-scaled tables (host RAM), same D, batches of 65,536 triples."""
+    from oracle import train_step as ts
+    ncores = os.cpu_count() or 1
+    D = args.dim
+    nu, ni, B = 2_000_000, 1_000_000, 65536
+    g = torch.Generator(); g.manual_seed(2022)
+    U = torch.empty(nu, D).normal_(0, 0.01, generator=g)
+    I = torch.empty(ni, D).normal_(0, 0.01, generator=g)
+    us, is_ = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    mk = lambda hi: torch.randint(1, hi, (B,), generator=g)
+    # pick the intra-op thread count that serves this step best on this host (all cores is not always the fastest
+    # for gather/index_add-bound torch ops); the count used is reported as `cores`
+    best = (None, 0.0)
+    for nt in sorted({min(ncores, t) for t in (8, 16, 32, 64, ncores)}):
+        torch.set_num_threads(nt)
+        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 1, opt=args.opt)
+        t0 = time.perf_counter()
+        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 2, opt=args.opt)
+        rate = B / (time.perf_counter() - t0)
+        if rate > best[1]:
+            best = (nt, rate)
+        if time.perf_counter() - t0 > 5.0:
+            break
+    used = best[0]
+    torch.set_num_threads(used)
+    t0 = time.perf_counter(); steps = 0
+    while time.perf_counter() - t0 < args.cpu_seconds and steps < 200:
+        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), steps + 2, opt=args.opt)
+        steps += 1
+    dt = time.perf_counter() - t0
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            model = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')][0]
+    except Exception:
+        pass
+    return {'value': B * steps / dt, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'kind': 'port',
+            'cpu_model': model,
+            'sample': '%d steps of %d triples, EMCDR-BPR D=%d, oracle row-wise step (fwd+bwd+lazy %s) on down-scaled '
+                      'tables %d users x %d items (host RAM), torch %d threads (best of a sweep)' % (steps, B, D, args.opt, nu, ni, used)}
+
+
+def main():
+    args = parse()
+    world, rank, local = dist_setup(args)
+    dev = torch.device('cuda', local)
+    import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
+    result = run_c5(args, world, rank, dev) if args.workload == 'c5' else run_c2(args, world, rank, dev)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -204,14 +204,16 @@ def select_mapped(mapped, weight, ids, n_overlap):
     return out
 
 
-def fullsort_scores(user_e, slab0, slab1=None):
+def fullsort_scores(user_e, slab0, slab1=None, out=None):
     """scores[U, n0+n1] = user_e @ cat(slab0, slab1)^T without the cat copy; slabs are contiguous row ranges."""
     _dev_check(user_e, slab0, slab1)
     user_e = user_e.detach().contiguous()
     U, D = user_e.shape
     n0 = slab0.shape[0] if slab0 is not None else 0
     n1 = slab1.shape[0] if slab1 is not None else 0
-    out = torch.empty(U, n0 + n1, device=user_e.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(U, n0 + n1, device=user_e.device, dtype=torch.float32)
+    assert out.is_contiguous() and tuple(out.shape) == (U, n0 + n1)
     B_.call('cdr_fullsort_scores_f32', B_.stream(), B_.f32(user_e), U, D,
             B_.f32(slab0.detach()) if n0 else None, n0, B_.f32(slab1.detach()) if n1 else None, n1, B_.f32(out))
     return out
