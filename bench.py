@@ -77,22 +77,6 @@ def xavier_table(rows, D, total_rows, gen, dev):
     return t
 
 
-class EventTimer:
-    """HIP-event brackets around individual native calls on torch's current stream (the stream the kernels run on)."""
-
-    def __init__(self):
-        self.pairs = {}
-
-    def bracket(self, name):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.pairs.setdefault(name, []).append((e0, e1))
-        return e0, e1
-
-    def mean_ms(self, name):
-        ps = self.pairs.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in ps) / max(len(ps), 1)
-
-
 # ------------------------------------------------------------------------------------------------------ C5 workload
 def run_c5(args, world, rank, dev):
     from recbole_cdr_amd.fused import FusedBPRStep
@@ -125,21 +109,28 @@ def run_c5(args, world, rank, dev):
             b[dom] = (u, p, n)
         batches.append(b)
 
-    timer = EventTimer()
+    from recbole_cdr_amd import binding as B_
 
-    def one_step(i, timed):
+    def one_step(i):
         b = batches[i % pool]
         for dom in ('source', 'target'):
-            steps[dom].step(*b[dom], timer=timer if timed else None)
+            steps[dom].step(*b[dom])
 
     for i in range(args.warmup):
-        one_step(i, False)
+        one_step(i)
+    # HIP-event brackets around each hot kernel, recorded by the library on the stream the kernel is launched on
+    B_.timing_enable(dev, args.steps * 2 * 5 + 16)
     barrier(world)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(i, True)
+        one_step(i)
     barrier(world)
     dt = time.perf_counter() - t0
+    timings = {}
+    for name, ms in B_.timing_collect(dev):
+        timings.setdefault(name, []).append(ms)
+    B_.timing_enable(dev, 0)
+    mean_ms = lambda k: (sum(timings[k]) / len(timings[k])) if timings.get(k) else 0.0
     loss = float(steps['target'].out6[0].item()) if world == 1 else float(steps['target'].loss_value())
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -173,16 +164,14 @@ def run_c5(args, world, rank, dev):
             'rowwise_apply_kernel(users)': B * (8 + 4 * D) + uniq['source'][0] * nmom * 4 * D,
             'rowwise_apply_kernel(items)': 2 * B * (8 + 4 * D) + uniq['source'][1] * nmom * 4 * D,
         }
-        names = {'bpr_fwd_grad_kernel': 'fwd_grad', 'rowwise_apply_kernel(users)': 'apply_u',
-                 'rowwise_apply_kernel(items)': 'apply_i'}
         kernels = []
-        for kname, tag in names.items():
-            ms = timer.mean_ms(tag)
+        for kname in ('bpr_fwd_grad_kernel', 'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)'):
+            ms = mean_ms(kname)
             gbs = alg[kname] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             kernels.append({'kernel': kname, 'avg_ms': ms, 'algorithmic_bytes': alg[kname], 'achieved_GBps': gbs,
                             'frac': gbs / HBM_PEAK_GBS})
-        for tag in ('sort_u', 'sort_i'):
-            kernels.append({'kernel': 'rocprim radix sort (%s)' % tag, 'avg_ms': timer.mean_ms(tag)})
+        kernels.append({'kernel': 'sort_ids (make_keys + rocprim radix sort; users and items averaged)',
+                        'avg_ms': mean_ms('sort_ids')})
         dom_k = max(kernels[:3], key=lambda k: k['avg_ms'])
         result['roofline'] = {'bound': 'hbm', 'kernel': dom_k['kernel'], 'achieved': dom_k['achieved_GBps'],
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_k['frac'],

@@ -42,6 +42,19 @@ int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
 int cdr_abi_version(void);                          /* bumped on any signature change                        */
 
+/* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
+ * on.  cdr_timing_enable(ctx, capacity) arms `capacity` slots (0 disarms); every instrumented launch made with this
+ * ctx takes the next free slot; cdr_timing_collect waits for the recorded events, returns (tag, milliseconds) per slot
+ * in launch order and re-arms.  Tags: */
+#define CDR_TAG_BPR_FWD 1
+#define CDR_TAG_POINT_FWD 2
+#define CDR_TAG_BPR_FWD_GRAD 3
+#define CDR_TAG_APPLY_UNSIGNED 4     /* rowwise_apply_kernel<.., SIGNED=false>: user table */
+#define CDR_TAG_APPLY_SIGNED 5       /* rowwise_apply_kernel<.., SIGNED=true >: item table (pos + neg occurrences) */
+#define CDR_TAG_SORT 6
+int cdr_timing_enable(cdr_ctx* ctx, int capacity);
+int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
+
 /* ---- K1+K2+K3+K5: negative-sampled pairwise (BPR) loss -------------------------------------------------------
  * replaces emcdr.py:98-108,119-131,142-154 (source/target_forward x2, BPRLoss, EmbLoss re-gather).
  *   score_pos[b] = <U[uid[b]], I[pid[b]]>, score_neg[b] = <U[uid[b]], I[nid[b]]>
@@ -158,12 +171,12 @@ int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
                      float gamma, float reg_weight, float* out6, float* GU /* [B,D] */, float* GP /* [B,D] */);
 int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);
-int cdr_sort_ids(void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1, int64_t num_rows,
+int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1, int64_t num_rows,
                  uint32_t* keys_sorted /* [n0+n1] */, uint32_t* perm /* [n0+n1] */,
                  void* workspace, size_t workspace_bytes);
 #define CDR_OPT_SGD 0
 #define CDR_OPT_ADAM 1
-int cdr_rowwise_apply(void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
+int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                       const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
                       const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, 'lib', 'libcdrhip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -67,8 +67,10 @@ _SIGNATURES = {
     'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr,
                          _c_ptr],
     'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
-    'cdr_sort_ids': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
-    'cdr_rowwise_apply': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
+    'cdr_timing_enable': [_c_ptr, _c_int],
+    'cdr_timing_collect': [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_f32), _c_int, ctypes.POINTER(_c_int)],
+    'cdr_sort_ids': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_rowwise_apply': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
                           _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
     'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
 }
@@ -156,3 +158,20 @@ def raw(t):
 
 def call(name, *args):
     _check(getattr(load(), name)(*args), name)
+
+
+TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4: 'rowwise_apply_kernel(users)',
+        5: 'rowwise_apply_kernel(items)', 6: 'sort_ids'}
+
+
+def timing_enable(device, capacity):
+    call('cdr_timing_enable', ctx(device), int(capacity))
+
+
+def timing_collect(device, max_n=65536):
+    """-> list of (kernel name, milliseconds) in launch order, measured by HIP events on the launch stream."""
+    tags = (_c_int * max_n)()
+    ms = (_c_f32 * max_n)()
+    n = _c_int(0)
+    call('cdr_timing_collect', ctx(device), tags, ms, max_n, ctypes.byref(n))
+    return [(TAGS.get(tags[i], str(tags[i])), float(ms[i])) for i in range(n.value)]

@@ -13,6 +13,24 @@
 struct cdr_ctx {
     int device;
     double* partials;                        // [CDR_MAX_PARTIAL_BLOCKS][CDR_PARTIAL_STRIDE]
+    // optional HIP-event brackets around the hot kernels, recorded on the launch stream (cdr_timing_*)
+    int timing_cap, timing_n;
+    hipEvent_t* ev0;
+    hipEvent_t* ev1;
+    int* tags;
+};
+
+// RAII bracket: records ev0 now and ev1 at scope exit on `s` when timing is enabled and a slot is free.
+struct cdr_time_scope {
+    cdr_ctx* c; hipStream_t s; int slot;
+    cdr_time_scope(cdr_ctx* ctx, int tag, hipStream_t st) : c(ctx), s(st), slot(-1) {
+        if (c && c->timing_cap > 0 && c->timing_n < c->timing_cap) {
+            slot = c->timing_n++;
+            c->tags[slot] = tag;
+            (void)hipEventRecord(c->ev0[slot], s);
+        }
+    }
+    ~cdr_time_scope() { if (slot >= 0) (void)hipEventRecord(c->ev1[slot], s); }
 };
 
 void cdr_set_error(const char* fmt, ...);

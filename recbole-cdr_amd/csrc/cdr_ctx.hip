@@ -13,7 +13,7 @@ void cdr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cdr_last_error(void) { return g_err; }
-extern "C" int cdr_abi_version(void) { return 1; }
+extern "C" int cdr_abi_version(void) { return 2; }
 
 extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     CDR_CHECK_ARG(out != nullptr);
@@ -28,6 +28,9 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     CDR_HIP(hipSetDevice(device));
     cdr_ctx* c = new cdr_ctx();
     c->device = device;
+    c->timing_cap = c->timing_n = 0;
+    c->ev0 = c->ev1 = nullptr;
+    c->tags = nullptr;
     hipError_t e = hipMalloc(&c->partials, sizeof(double) * CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE);
     hipSetDevice(prev);
     if (e != hipSuccess) {
@@ -39,8 +42,37 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     return CDR_OK;
 }
 
+extern "C" int cdr_timing_enable(cdr_ctx* ctx, int capacity) {
+    CDR_CHECK_ARG(ctx && capacity >= 0);
+    for (int i = 0; i < ctx->timing_cap; ++i) { (void)hipEventDestroy(ctx->ev0[i]); (void)hipEventDestroy(ctx->ev1[i]); }
+    delete[] ctx->ev0; delete[] ctx->ev1; delete[] ctx->tags;
+    ctx->ev0 = ctx->ev1 = nullptr; ctx->tags = nullptr;
+    ctx->timing_cap = ctx->timing_n = 0;
+    if (capacity == 0) return CDR_OK;
+    ctx->ev0 = new hipEvent_t[capacity];
+    ctx->ev1 = new hipEvent_t[capacity];
+    ctx->tags = new int[capacity];
+    for (int i = 0; i < capacity; ++i) { CDR_HIP(hipEventCreate(&ctx->ev0[i])); CDR_HIP(hipEventCreate(&ctx->ev1[i])); }
+    ctx->timing_cap = capacity;
+    return CDR_OK;
+}
+
+extern "C" int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out) {
+    CDR_CHECK_ARG(ctx && tags && ms && n_out && max_n >= 0);
+    int n = ctx->timing_n < max_n ? ctx->timing_n : max_n;
+    for (int i = 0; i < n; ++i) {
+        CDR_HIP(hipEventSynchronize(ctx->ev1[i]));
+        CDR_HIP(hipEventElapsedTime(&ms[i], ctx->ev0[i], ctx->ev1[i]));
+        tags[i] = ctx->tags[i];
+    }
+    *n_out = n;
+    ctx->timing_n = 0;
+    return CDR_OK;
+}
+
 extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
     if (!ctx) return CDR_OK;
+    cdr_timing_enable(ctx, 0);
     if (ctx->partials) hipFree(ctx->partials);
     delete ctx;
     return CDR_OK;

@@ -367,6 +367,7 @@ extern "C" int cdr_bpr_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, co
     CDR_CHECK_ARG(D > 0 && B > 0);
     hipStream_t s = (hipStream_t)stream;
     int grid;
+    cdr_time_scope* ts = new cdr_time_scope(ctx, CDR_TAG_BPR_FWD, s);
     if ((D & 3) == 0) {
         const int lpr = cdr_lpr_for(D);
         grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
@@ -377,6 +378,7 @@ extern "C" int cdr_bpr_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, co
         hipLaunchKernelGGL(bpr_fwd_scalar_kernel, dim3(grid), dim3(kBlock), 0, s, user_tab, item_tab, D, uid, pid, nid, B,
                            gamma, gcoef, ctx->partials);
     }
+    delete ts;
     CDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
     CDR_LAUNCH_CHECK();

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const int64_t* __rest
 
 // ------------------------------------------------------------------------------------------------ segmented apply
 // OPT 0: SGD  w -= lr * grad            OPT 1: Adam on the touched rows (torch.optim.Adam arithmetic per element)
-template <int LPR, int OPT>
+template <int LPR, int OPT, bool SIGNED>
 __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict__ W, float* __restrict__ Mo,
                                                                float* __restrict__ Vo, int D,
                                                                const uint32_t* __restrict__ keys,
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
             int cnt = 0;
             for (int64_t e = q; e < n && keys[e] == row; ++e) {
                 const int64_t o = perm[e];
-                const bool neg = o >= neg_start;
+                const bool neg = SIGNED && o >= neg_start;
                 const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
                 if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
                 else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
@@ -205,8 +205,11 @@ extern "C" int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream, const float* user_ta
     hipStream_t s = (hipStream_t)stream;
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
-    DISPATCH_LPR(lpr, bpr_fwd_grad_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B,
-                                                                                   gamma, GU, GP, ctx->partials));
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_GRAD, s);
+        DISPATCH_LPR(lpr, bpr_fwd_grad_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B,
+                                                                                       gamma, GU, GP, ctx->partials));
+    }
     CDR_LAUNCH_CHECK();
     step_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out6);
     CDR_LAUNCH_CHECK();
@@ -230,7 +233,7 @@ extern "C" int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* byt
     return CDR_OK;
 }
 
-extern "C" int cdr_sort_ids(void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1,
+extern "C" int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1,
                             int64_t num_rows, uint32_t* keys_sorted, uint32_t* perm, void* workspace,
                             size_t workspace_bytes) {
     const int64_t n = n0 + n1;
@@ -245,6 +248,7 @@ extern "C" int cdr_sort_ids(void* stream, const int64_t* ids0, int64_t n0, const
     uint32_t* vals_in = (uint32_t*)((char*)workspace + arr);
     void* tmp = (char*)workspace + 2 * arr;
     size_t tmp_bytes = workspace_bytes - 2 * arr;
+    cdr_time_scope ts(ctx, CDR_TAG_SORT, s);
     make_keys_kernel<<<dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s>>>(ids0, n0, ids1, n1, keys_in, vals_in);
     CDR_LAUNCH_CHECK();
     CDR_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_sorted, (const uint32_t*)vals_in, perm,
@@ -252,7 +256,7 @@ extern "C" int cdr_sort_ids(void* stream, const int64_t* ids0, int64_t n0, const
     return CDR_OK;
 }
 
-extern "C" int cdr_rowwise_apply(void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
+extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                                  const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const float* G,
                                  int64_t neg_start, int64_t reg_limit, const float* reg_coef, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, int64_t step) {
@@ -268,15 +272,14 @@ extern "C" int cdr_rowwise_apply(void* stream, int opt, float* table, float* exp
     }
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_for(n, kBlock / lpr);
-    if (opt == 0) {
-        DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0><<<dim3(grid), dim3(kBlock), 0, s>>>(
-                              table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, lr,
-                              beta1, beta2, eps, weight_decay, step_size, bc2_sqrt));
-    } else {
-        DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(
-                              table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, lr,
-                              beta1, beta2, eps, weight_decay, step_size, bc2_sqrt));
-    }
+    const bool is_signed = neg_start < n;
+    cdr_time_scope ts(ctx, is_signed ? CDR_TAG_APPLY_SIGNED : CDR_TAG_APPLY_UNSIGNED, s);
+#define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt
+    if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
+    else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
+    else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
+    else { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
+#undef APPLY_ARGS
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

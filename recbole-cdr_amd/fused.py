@@ -54,37 +54,26 @@ class FusedBPRStep:
         self.ws_bytes = int(need.value)
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
 
-    def step(self, uid, pid, nid, timer=None):
-        """uid/pid/nid: int64 device tensors [B].  Returns the device tensor out6 (view; [0] = total loss).
-        ``timer`` (bench only): object whose ``bracket(name)`` returns a (start, end) HIP-event pair."""
+    def step(self, uid, pid, nid):
+        """uid/pid/nid: int64 device tensors [B].  Returns the device tensor out6 (view; [0] = total loss)."""
         B = uid.numel()
         assert B <= self.max_batch
         self.step_count += 1
         s = B_.stream()
         ctxh = B_.ctx(self.U.device)
-
-        def timed(name, fn, *a):
-            if timer is None:
-                return B_.call(fn, *a)
-            e0, e1 = timer.bracket(name)
-            e0.record()
-            B_.call(fn, *a)
-            e1.record()
-
-        timed('fwd_grad', 'cdr_bpr_fwd_grad', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid),
-              B_.i64(nid), B, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
-              B_.f32(self.GP))
-        timed('sort_u', 'cdr_sort_ids', s, B_.i64(uid), B, None, 0, self.U.shape[0], B_.raw(self.ukeys),
-              B_.raw(self.uperm), B_.raw(self.ws), self.ws_bytes)
-        timed('apply_u', 'cdr_rowwise_apply', *self._apply_args(self.ustate, self.ukeys, self.uperm, B, self.GU, B, B,
-                                                                self.out6[4:5]))
-        timed('sort_i', 'cdr_sort_ids', s, B_.i64(pid), B, B_.i64(nid), B, self.I.shape[0], B_.raw(self.ikeys),
-              B_.raw(self.iperm), B_.raw(self.ws), self.ws_bytes)
-        timed('apply_i', 'cdr_rowwise_apply', *self._apply_args(self.istate, self.ikeys, self.iperm, 2 * B, self.GP, B, B,
-                                                                self.out6[5:6]))
+        B_.call('cdr_bpr_fwd_grad', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid),
+                B_.i64(nid), B, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
+                B_.f32(self.GP))
+        B_.call('cdr_sort_ids', ctxh, s, B_.i64(uid), B, None, 0, self.U.shape[0], B_.raw(self.ukeys),
+                B_.raw(self.uperm), B_.raw(self.ws), self.ws_bytes)
+        self._apply(ctxh, self.ustate, self.ukeys, self.uperm, B, self.GU, B, B, self.out6[4:5])
+        B_.call('cdr_sort_ids', ctxh, s, B_.i64(pid), B, B_.i64(nid), B, self.I.shape[0], B_.raw(self.ikeys),
+                B_.raw(self.iperm), B_.raw(self.ws), self.ws_bytes)
+        self._apply(ctxh, self.istate, self.ikeys, self.iperm, 2 * B, self.GP, B, B, self.out6[5:6])
         return self.out6
 
-    def _apply_args(self, st, keys, perm, n, G, neg_start, reg_limit, coef):
-        return (B_.stream(), self.opt, B_.f32(st.table), B_.f32(st.exp_avg), B_.f32(st.exp_avg_sq), self.D,
-                B_.raw(keys), B_.raw(perm), n, B_.f32(G), neg_start, reg_limit, B_.f32(coef), float(self.lr),
-                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_count)
+    def _apply(self, ctxh, st, keys, perm, n, G, neg_start, reg_limit, coef):
+        B_.call('cdr_rowwise_apply', ctxh, B_.stream(), self.opt, B_.f32(st.table), B_.f32(st.exp_avg),
+                B_.f32(st.exp_avg_sq), self.D, B_.raw(keys), B_.raw(perm), n, B_.f32(G), neg_start, reg_limit,
+                B_.f32(coef), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                float(self.wd), self.step_count)
