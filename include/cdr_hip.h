@@ -156,7 +156,12 @@ int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg
  * Replaces, for one BPR step, loss.backward() + optimizer.step() of the reference's loop (trainer.py:59-73 ->
  * recbole Trainer._train_epoch) without ever materialising a table-sized gradient:
  *   cdr_bpr_fwd_grad : cdr_bpr_fwd + the compact gradient rows  GU[b] = g_b (I[pid_b]-I[nid_b]),  GP[b] = g_b U[uid_b]
- *                      out6 = {total, bpr, ||U_b||, ||I_b||, c_u, c_i},  c = reg_weight / (B * norm)
+ *                      out9 = {total, bpr, ||U_b||, ||I_b||, c_u, c_i, sum_loss, sum_u2, sum_p2},
+ *                      c = reg_weight / (B_mean * norm).  B_mean (<=0 -> B) is the batch the mean / EmbLoss are
+ *                      taken over: the GLOBAL batch when the step is row-sharded over several GPUs -- the three raw
+ *                      sums are then all-reduced and cdr_loss_finish_sums recomputes out[0..5] from them.
+ *   cdr_build_grad_rows: out[q] = +-G[order[q]] (+ coef * rows[q] for the EmbLoss occurrences) -- the per-occurrence
+ *                      gradient rows, in owner order, that a rank sends back to the rows' owners.
  *   cdr_sort_ids     : stable radix sort of (row id, occurrence index) over the significant key bits; ids1 (optional)
  *                      is appended after ids0 (items: ids0 = pid, ids1 = nid -> occurrences [0,B) positive, [B,2B) negative)
  *   cdr_rowwise_apply: per distinct row r (segment of keys_sorted):
@@ -168,8 +173,11 @@ int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg
  */
 int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      const float* user_tab, const float* item_tab, int D,
-                     const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
-                     float gamma, float reg_weight, float* out6, float* GU /* [B,D] */, float* GP /* [B,D] */);
+                     const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, int64_t B_mean,
+                     float gamma, float reg_weight, float* out9, float* GU /* [B,D] */, float* GP /* [B,D] */);
+int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6);
+int cdr_build_grad_rows(void* stream, const float* G, const int64_t* order, int64_t n, int D,
+                        int64_t neg_start, int64_t reg_limit, const float* rows, const float* coef, float* out);
 int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);
 int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1, int64_t num_rows,
                  uint32_t* keys_sorted /* [n0+n1] */, uint32_t* perm /* [n0+n1] */,

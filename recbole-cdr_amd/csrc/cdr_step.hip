@@ -39,15 +39,14 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
                                                               int D, const int64_t* __restrict__ uid,
                                                               const int64_t* __restrict__ pid,
                                                               const int64_t* __restrict__ nid, int64_t B, float gamma,
-                                                              float* __restrict__ GU, float* __restrict__ GP,
-                                                              double* __restrict__ partials) {
+                                                              float invB, float* __restrict__ GU,
+                                                              float* __restrict__ GP, double* __restrict__ partials) {
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
     const int64_t TG = (int64_t)gridDim.x * GPB;
     const int D4 = D >> 2;
-    const float invB = 1.0f / (float)B;
     double acc[3] = {0.0, 0.0, 0.0};
     const bool live = sub < D4;
 
@@ -94,7 +93,9 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
     }
 }
 
-// out6 = {total, main, ||U_b||, ||I_b||, c_u, c_i} with c = reg_weight / (B * norm)  (0 when the norm is 0)
+// out9 = {total, main, ||U_b||, ||I_b||, c_u, c_i, sum loss, sum u^2, sum p^2} with c = reg_weight / (B * norm)
+// (0 when the norm is 0).  B is the batch size the mean and the EmbLoss are taken over (the GLOBAL batch when the
+// step is sharded: then out9[0..5] are provisional and cdr_loss_finish_sums recomputes them from all-reduced sums).
 __global__ __launch_bounds__(kBlock) void step_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
                                                              float reg_weight, float* __restrict__ out6) {
     __shared__ double smem[3 * (kBlock / 64)];
@@ -111,6 +112,41 @@ __global__ __launch_bounds__(kBlock) void step_finish_kernel(const double* __res
         out6[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
         out6[4] = (reg_weight != 0.f && nu > 0.f) ? reg_weight / ((float)B * nu) : 0.f;
         out6[5] = (reg_weight != 0.f && ni > 0.f) ? reg_weight / ((float)B * ni) : 0.f;
+        out6[6] = (float)acc[0]; out6[7] = (float)acc[1]; out6[8] = (float)acc[2];
+    }
+}
+
+__global__ void finish_sums_kernel(const float* __restrict__ sums3, int64_t B, float reg_weight, float* __restrict__ out6) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float main_loss = sums3[0] / (float)B;
+        const float nu = sqrtf(sums3[1]), ni = sqrtf(sums3[2]);
+        out6[1] = main_loss; out6[2] = nu; out6[3] = ni;
+        out6[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
+        out6[4] = (reg_weight != 0.f && nu > 0.f) ? reg_weight / ((float)B * nu) : 0.f;
+        out6[5] = (reg_weight != 0.f && ni > 0.f) ? reg_weight / ((float)B * ni) : 0.f;
+    }
+}
+
+// out[q,:] = (o >= neg_start ? -G[o - neg_start,:] : G[o,:]) + (o < reg_limit ? c * rows[q,:] : 0),  o = order[q]
+__global__ __launch_bounds__(kBlock) void build_grad_rows_kernel(const float* __restrict__ G, const int64_t* __restrict__ order,
+                                                                 int64_t n, int D, int64_t neg_start, int64_t reg_limit,
+                                                                 const float* __restrict__ rows, const float* __restrict__ coef,
+                                                                 float* __restrict__ out) {
+    const int D4 = D >> 2;
+    const int64_t total = n * D4, stride = (int64_t)gridDim.x * kBlock;
+    const float c = coef ? coef[0] : 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t q = e / D4;
+        const int ch = (int)(e - q * D4);
+        const int64_t o = order[q];
+        const bool neg = o >= neg_start;
+        float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
+        if (neg) { g.x = -g.x; g.y = -g.y; g.z = -g.z; g.w = -g.w; }
+        if (o < reg_limit && c != 0.f) {
+            const float4 r = ld4(rows + q * D + 4 * ch);
+            g.x += c * r.x; g.y += c * r.y; g.z += c * r.z; g.w += c * r.w;
+        }
+        st4(out + q * D + 4 * ch, g);
     }
 }
 
@@ -198,20 +234,40 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
     }
 
 extern "C" int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
-                                const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma,
-                                float reg_weight, float* out6, float* GU, float* GP) {
+                                const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, int64_t B_mean,
+                                float gamma, float reg_weight, float* out6, float* GU, float* GP) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out6 && GU && GP);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0);
     hipStream_t s = (hipStream_t)stream;
+    if (B_mean <= 0) B_mean = B;
+    const float invB = 1.0f / (float)B_mean;
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
     {
         cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_GRAD, s);
         DISPATCH_LPR(lpr, bpr_fwd_grad_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B,
-                                                                                       gamma, GU, GP, ctx->partials));
+                                                                                       gamma, invB, GU, GP, ctx->partials));
     }
     CDR_LAUNCH_CHECK();
-    step_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out6);
+    step_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B_mean, reg_weight, out6);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6) {
+    CDR_CHECK_ARG(sums3 && out6 && B_mean > 0);
+    finish_sums_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(sums3, B_mean, reg_weight, out6);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_build_grad_rows(void* stream, const float* G, const int64_t* order, int64_t n, int D, int64_t neg_start,
+                                   int64_t reg_limit, const float* rows, const float* coef, float* out) {
+    CDR_CHECK_ARG(G && order && out && n > 0 && D > 0 && (D & 3) == 0);
+    CDR_CHECK_ARG(reg_limit <= 0 || rows);
+    const int64_t total = n * (D >> 2);
+    build_grad_rows_kernel<<<dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(G, order, n, D, neg_start,
+                                                                                                   reg_limit, rows, coef, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -43,7 +43,7 @@ class FusedBPRStep:
         self.max_batch = Bm
         self.GU = torch.empty(Bm, self.D, device=dev, dtype=torch.float32)
         self.GP = torch.empty(Bm, self.D, device=dev, dtype=torch.float32)
-        self.out6 = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.out6 = torch.zeros(12, device=dev, dtype=torch.float32)
         self.ukeys = torch.empty(Bm, device=dev, dtype=torch.int32)
         self.uperm = torch.empty(Bm, device=dev, dtype=torch.int32)
         self.ikeys = torch.empty(2 * Bm, device=dev, dtype=torch.int32)
@@ -62,7 +62,7 @@ class FusedBPRStep:
         s = B_.stream()
         ctxh = B_.ctx(self.U.device)
         B_.call('cdr_bpr_fwd_grad', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid),
-                B_.i64(nid), B, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
+                B_.i64(nid), B, 0, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
                 B_.f32(self.GP))
         B_.call('cdr_sort_ids', ctxh, s, B_.i64(uid), B, None, 0, self.U.shape[0], B_.raw(self.ukeys),
                 B_.raw(self.uperm), B_.raw(self.ws), self.ws_bytes)

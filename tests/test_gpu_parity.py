@@ -268,3 +268,32 @@ def test_fused_step_deterministic_and_sorted():
     same = keys[1:] == keys[:-1]
     perm = res[0][3].to(torch.int64)
     assert bool((perm[1:][same] > perm[:-1][same]).all())                # stable: occurrence order inside a segment
+
+
+def test_sharded_step_world1_equals_fused():
+    """shard.ShardedBPRStep with libcdrhip ops over a 1-rank RCCL group == fused.FusedBPRStep (same kernels, plus the
+    route / all-to-all / build-grad-rows path).  World 2 is covered on CPU by tests/test_shard_gloo.py."""
+    import socket
+    import torch.distributed as dist
+    from recbole_cdr_amd.fused import FusedBPRStep
+    from recbole_cdr_amd.shard import ShardedBPRStep
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(3)
+        nu, ni, D, B = 5000, 3000, 128, 40000
+        U0, I0 = torch.randn(nu, D, device=DEV) * 0.1, torch.randn(ni, D, device=DEV) * 0.1
+        Ua, Ia, Ub, Ib = U0.clone(), I0.clone(), U0.clone(), I0.clone()
+        fa = FusedBPRStep(Ua, Ia, B, opt='adam', reg_weight=0.02, lr=0.01)
+        fb = ShardedBPRStep(Ub, Ib, nu, ni, B, opt='adam', reg_weight=0.02, lr=0.01)
+        for step in range(3):
+            u = torch.randint(0, nu, (B,), device=DEV); p = torch.randint(0, ni, (B,), device=DEV)
+            n = torch.randint(0, ni, (B,), device=DEV)
+            la = fa.step(u, p, n)[0].clone()
+            lb = fb.step(u, p, n)[0].clone()
+            assert_close(lb, la, rtol=1e-6, what=f'loss step {step}')
+        assert_close(Ub, Ua, rtol=2e-5, atol=0.01 * 1e-2); assert_close(Ib, Ia, rtol=2e-5, atol=0.01 * 1e-2)
+        assert_close(fb.ustate[0], fa.ustate.exp_avg, rtol=2e-5); assert_close(fb.istate[0], fa.istate.exp_avg, rtol=2e-5)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,133 @@
+"""world_size-2 CPU (gloo) test of the row-sharded training step's exchange logic (shard.ShardedBPRStep): routing by
+owner, the four all-to-alls, the global loss reduction and the owner-side apply.  The arithmetic is injected from the
+oracle (tests may use it); on the GPU the same class runs with libcdrhip (tests/test_gpu_parity.py::test_sharded_*)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class OracleOps:
+    """Stand-in compute for shard.ShardedBPRStep: the oracle's formulas on CPU tensors."""
+
+    def gather_rows(self, table, local_ids):
+        return table[local_ids].clone()
+
+    def fwd_grad(self, urows, irows, upos, ppos, npos, B_mean, gamma, reg_weight, out, GU, GP):
+        u, p, n = urows[upos], irows[ppos], irows[npos]
+        x = (u * p).sum(1) - (u * n).sum(1)
+        s = torch.sigmoid(x)
+        g = -(1.0 / B_mean) * (s * (1 - s)) / (gamma + s)
+        B = upos.numel()
+        GU[:B] = g[:, None] * (p - n)
+        GP[:B] = g[:, None] * u
+        out[6] = (-torch.log(gamma + s)).sum()
+        out[7] = (u * u).sum()
+        out[8] = (p * p).sum()
+
+    def finish_sums(self, sums3, B_mean, reg_weight, out):
+        main = sums3[0] / B_mean
+        nu, ni = sums3[1].sqrt(), sums3[2].sqrt()
+        out[1], out[2], out[3] = main, nu, ni
+        out[0] = main + reg_weight * (nu + ni) / B_mean
+        out[4] = reg_weight / (B_mean * nu) if float(nu) > 0 else 0.0
+        out[5] = reg_weight / (B_mean * ni) if float(ni) > 0 else 0.0
+
+    def build_grad_rows(self, G, order, neg_start, reg_limit, rows, coef):
+        neg = order >= neg_start
+        src = torch.where(neg, order - neg_start, order)
+        out = G[src] * torch.where(neg, -1.0, 1.0)[:, None]
+        reg = (order < reg_limit).float()[:, None] * coef[0] * rows
+        return out + reg
+
+    def sort_apply(self, table, state, local_ids, grads, opt, hp, step):
+        if local_ids.numel() == 0:
+            return
+        rows, inv = torch.unique(local_ids, return_inverse=True)
+        Gs = torch.zeros(rows.numel(), table.shape[1]).index_add_(0, inv, grads)
+        from oracle.train_step import _apply_rows, RowwiseAdamState
+        if opt == 0:
+            _apply_rows(table, None, rows, Gs, 'sgd', hp['lr'], step)
+        else:
+            st = RowwiseAdamState.__new__(RowwiseAdamState)
+            st.m, st.v = state
+            _apply_rows(table, st, rows, Gs, 'adam', hp['lr'], step, hp['b1'], hp['b2'], hp['eps'])
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, opt, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.shard import ShardedBPRStep, shard_of
+        torch.manual_seed(0)                                   # same full tables on every rank
+        nu, ni, D, B, reg, lr = 41, 29, 8, 37, 0.03, 0.05
+        U = torch.randn(nu, D) * 0.3
+        I = torch.randn(ni, D) * 0.3
+        Ul, Il = shard_of(U, world, rank), shard_of(I, world, rank)
+        st = ShardedBPRStep(Ul, Il, nu, ni, B, opt=opt, lr=lr, reg_weight=reg, ops=OracleOps())
+        losses = []
+        batches = []
+        for step in range(3):
+            g = torch.Generator(); g.manual_seed(100 * step + rank)
+            u = torch.randint(0, nu, (B,), generator=g); p = torch.randint(0, ni, (B,), generator=g)
+            n = torch.randint(0, ni, (B,), generator=g)
+            batches.append((u, p, n))
+            out = st.step(u, p, n)
+            losses.append(float(out[0]))
+        # numpy (pickled by value): torch tensors would travel as shared-memory fds that die with the worker
+        q.put((rank, Ul.numpy().copy(), Il.numpy().copy(), losses, [tuple(t.numpy().copy() for t in b) for b in batches]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('opt', ['sgd', 'adam'])
+def test_sharded_step_matches_single_process(opt):
+    from oracle import train_step as ts
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(a), torch.from_numpy(b), l, [tuple(torch.from_numpy(x) for x in bb) for bb in bs])
+           for r, a, b, l, bs in res]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the concatenated global batch
+    torch.manual_seed(0)
+    nu, ni, D, reg, lr = 41, 29, 8, 0.03, 0.05
+    U = torch.randn(nu, D) * 0.3
+    I = torch.randn(ni, D) * 0.3
+    us, is_ = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    for step in range(3):
+        u = torch.cat([res[r][4][step][0] for r in range(world)])
+        p = torch.cat([res[r][4][step][1] for r in range(world)])
+        n = torch.cat([res[r][4][step][2] for r in range(world)])
+        loss = ts.rowwise_step(U, I, us, is_, u, p, n, step + 1, opt=opt, lr=lr, reg_weight=reg)
+        for r in range(world):
+            assert abs(res[r][3][step] - float(loss)) <= 1e-5 * abs(float(loss)), (step, res[r][3][step], float(loss))
+    for r in range(world):
+        atol = lr * 1e-2 if opt == 'adam' else 1e-6
+        torch.testing.assert_close(res[r][1], U[r::world], rtol=2e-5, atol=atol)
+        torch.testing.assert_close(res[r][2], I[r::world], rtol=2e-5, atol=atol)
+
+
+def test_shard_rows_partition():
+    from recbole_cdr_amd.shard import shard_rows
+    for total in (1, 7, 8, 50_000_001):
+        for world in (1, 2, 4, 8):
+            assert sum(shard_rows(total, world, r) for r in range(world)) == total
+            for r in range(world):
+                assert shard_rows(total, world, r) == len(range(r, total, world))
