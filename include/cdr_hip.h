@@ -152,6 +152,18 @@ int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const f
 int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
+/* ---- integer paths (bit-exact) --------------------------------------------------------------------------------
+ * cdr_overlap_remap (HOST function, no GPU): CrossDomainDataset.calculate_user_item_from_both_domain + _remap_fields for
+ * one field (dataset.py:344-445,109-123).  Tokens are UTF-8 bytes: token i = bytes[off[i], off[i+1]); isnan[i] != 0 marks
+ * a NaN token (dropped; its output id is -1).  Output: the remapped id of every occurrence and
+ * counts4 = {num_overlap (PAD included), num_source_only, num_target_only, num_total}.
+ * cdr_revoke_map (device): iid < overlap_item_num ? iid : iid - target_only_item_num  (dataloader.py:244-245). */
+int cdr_overlap_remap(const char* src_bytes, const int64_t* src_off, const uint8_t* src_isnan, int64_t n_src,
+                      const char* tgt_bytes, const int64_t* tgt_off, const uint8_t* tgt_isnan, int64_t n_tgt,
+                      int64_t* src_ids, int64_t* tgt_ids, int64_t* counts4);
+int cdr_revoke_map(void* stream, const int64_t* ids, int64_t n, int64_t overlap_item_num,
+                   int64_t target_only_item_num, int64_t* out);
+
 /* ---- fused row-wise training step (tables too large for dense gradients / dense Adam: BASELINE config C5) -----
  * Replaces, for one BPR step, loss.backward() + optimizer.step() of the reference's loop (trainer.py:59-73 ->
  * recbole Trainer._train_epoch) without ever materialising a table-sized gradient:

@@ -1,0 +1,152 @@
+"""Four-state training loader, mirroring recbole_cdr/data/dataloader.py:25-186 on device-resident interactions.
+
+  DomainTrainLoader     recbole ``TrainDataLoader`` semantics for one domain (third-party): slices of
+                        ``train_batch_size // times`` positives, ``repeat(times)`` + negatives laid out k-major
+                        (pairwise: ``neg_<iid>`` column; pointwise: ``times = 1+k`` rows + ``<domain>_label``).
+  OverlapDataloader     dataloader.py:25-52: slices of the shuffled ``arange(num_overlap)`` as ``[OB,1]``.
+  CrossDomainDataloader dataloader.py:55-186: SOURCE / TARGET / BOTH / OVERLAP; BOTH = target batch updated with the
+                        source batch, source wraps WITHOUT reshuffling, epoch length = target loader (Q11).
+"""
+import torch
+
+from ..utils import CrossDomainDataLoaderState, InputType
+from .interaction import Interaction
+
+
+class DomainTrainLoader:
+    def __init__(self, inter, uid_field, iid_field, label_field, neg_prefix, train_batch_size, neg_k, input_type,
+                 neg_sampler, shuffle=False, generator=None):
+        self.inter = Interaction(inter)
+        self.uid_field, self.iid_field, self.label_field = uid_field, iid_field, label_field
+        self.neg_iid_field = neg_prefix + iid_field
+        self.neg_k, self.input_type, self.neg_sampler = neg_k, input_type, neg_sampler
+        self.times = neg_k if input_type == InputType.PAIRWISE else 1 + neg_k
+        self.step = max(train_batch_size // self.times, 1)
+        self.shuffle, self.generator = shuffle, generator
+        self.pr = 0
+
+    @property
+    def pr_end(self):
+        return len(self.inter)
+
+    def __len__(self):
+        return (self.pr_end + self.step - 1) // self.step
+
+    def __iter__(self):
+        if self.shuffle:
+            n = len(self.inter)
+            perm = torch.randperm(n, generator=self.generator).to(next(iter(self.inter.values())).device)
+            self.inter = self.inter.index_select(perm)
+        return self
+
+    def __next__(self):
+        if self.pr >= self.pr_end:
+            self.pr = 0
+            raise StopIteration()
+        cur = self.inter[self.pr:self.pr + self.step]
+        self.pr += self.step
+        return self._neg_sampling(cur)
+
+    def _neg_sampling(self, cur):
+        S = len(cur)
+        users, items = cur[self.uid_field], cur[self.iid_field]
+        neg = self.neg_sampler(users, items, self.neg_k)             # [S*k], k-major (crossdomain_sampler.py:148-152)
+        if self.input_type == InputType.PAIRWISE:
+            out = cur.repeat(self.neg_k)
+            out[self.neg_iid_field] = neg
+            return out
+        out = cur.repeat(self.times)
+        out[self.iid_field] = torch.cat([items, neg])
+        lab = torch.zeros(S * self.times, device=users.device, dtype=torch.float32)
+        lab[:S] = 1.0
+        out[self.label_field] = lab
+        return out
+
+
+class OverlapDataloader:
+    def __init__(self, num_overlap, overlap_batch_size, field='overlap', shuffle=False, device='cpu', generator=None):
+        self.ids = torch.arange(num_overlap, device=device, dtype=torch.int64)     # PAD 0 included (dataset.py:694)
+        self.step, self.field, self.shuffle, self.generator = overlap_batch_size, field, shuffle, generator
+        self.pr = 0
+
+    @property
+    def pr_end(self):
+        return self.ids.numel()
+
+    def __len__(self):
+        return (self.pr_end + self.step - 1) // self.step
+
+    def __iter__(self):
+        if self.shuffle:
+            self.ids = self.ids[torch.randperm(self.ids.numel(), generator=self.generator).to(self.ids.device)]
+        return self
+
+    def __next__(self):
+        if self.pr >= self.pr_end:
+            self.pr = 0
+            raise StopIteration()
+        cur = self.ids[self.pr:self.pr + self.step]
+        self.pr += self.step
+        return Interaction({self.field: cur.view(-1, 1)})
+
+
+class CrossDomainDataloader:
+    def __init__(self, source_dataloader, target_dataloader, overlap_dataloader):
+        self.source_dataloader, self.target_dataloader = source_dataloader, target_dataloader
+        self.overlap_dataloader = overlap_dataloader
+        self.state = CrossDomainDataLoaderState.BOTH
+
+    def __iter__(self):
+        S = CrossDomainDataLoaderState
+        if self.state == S.SOURCE:
+            return self.source_dataloader.__iter__()
+        if self.state == S.TARGET:
+            return self.target_dataloader.__iter__()
+        if self.state == S.BOTH:
+            self.source_dataloader.__iter__()
+            self.target_dataloader.__iter__()
+            return self
+        return self.overlap_dataloader.__iter__()
+
+    def __next__(self):
+        S = CrossDomainDataLoaderState
+        if self.state == S.SOURCE and self.source_dataloader.pr >= self.source_dataloader.pr_end:
+            self.target_dataloader.pr = 0
+            self.source_dataloader.pr = 0
+            raise StopIteration()
+        if self.state in (S.TARGET, S.BOTH) and self.target_dataloader.pr >= self.target_dataloader.pr_end:
+            self.target_dataloader.pr = 0
+            self.source_dataloader.pr = 0
+            raise StopIteration()
+        if self.state == S.OVERLAP and self.overlap_dataloader.pr >= self.overlap_dataloader.pr_end:
+            self.overlap_dataloader.pr = 0
+            raise StopIteration()
+        return self._next_batch_data()
+
+    def __len__(self):
+        S = CrossDomainDataLoaderState
+        return {S.SOURCE: len(self.source_dataloader), S.TARGET: len(self.target_dataloader),
+                S.BOTH: len(self.target_dataloader), S.OVERLAP: len(self.overlap_dataloader)}[self.state]
+
+    def _next_batch_data(self):
+        S = CrossDomainDataLoaderState
+        if self.state == S.SOURCE:
+            return self.source_dataloader.__next__()
+        if self.state == S.TARGET:
+            return self.target_dataloader.__next__()
+        if self.state == S.OVERLAP:
+            return self.overlap_dataloader.__next__()
+        try:
+            source_data = self.source_dataloader.__next__()
+        except StopIteration:
+            source_data = self.source_dataloader.__next__()          # wraps, no reshuffle (dataloader.py:156-161)
+        target_data = self.target_dataloader.__next__()
+        target_data.update(source_data)
+        return target_data
+
+    def set_mode(self, state):
+        if state not in set(CrossDomainDataLoaderState):
+            raise NotImplementedError(f'Cross Domain data loader has no state named [{state}].')
+        if self.source_dataloader.pr != 0 or self.target_dataloader.pr != 0:
+            raise PermissionError('Cannot change dataloader\'s state within an epoch')
+        self.state = state

@@ -1,0 +1,181 @@
+"""CrossDomainTrainer: the caller of the hot path (recbole_cdr/trainer/trainer.py:18-76).
+
+The reference subclasses third-party ``recbole.trainer.Trainer``; the part of it the phase loop relies on is restated
+here (optimizer built ONCE and kept across phases, ``_train_epoch`` = zero_grad -> calculate_loss ->
+(tuple => sum) -> nan check -> backward -> clip -> step, ``fit`` with eval_step / early stopping, ``evaluate`` =
+full-sort scores -> mask PAD column and history -> top-k).  Metrics are computed on device with torch.topk (plumbing);
+the dense optimizer is the native exact Adam (csrc/cdr_rows.hip ``cdr_adam_dense``).
+"""
+import numpy as np
+import torch
+
+from .. import functional as F_
+from ..utils import train_mode2state
+
+
+class DenseAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (amsgrad=False), each parameter updated by one native kernel launch."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] += 1
+                F_.adam_dense_(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], st['step'], lr=group['lr'],
+                               betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'])
+
+
+def early_stopping(value, best, cur_step, max_step, bigger=True):
+    """recbole.utils.early_stopping."""
+    stop_flag, update_flag = False, False
+    if (bigger and value >= best) or (not bigger and value <= best):
+        cur_step, best, update_flag = 0, value, True
+    else:
+        cur_step += 1
+        if cur_step > max_step:
+            stop_flag = True
+    return best, cur_step, stop_flag, update_flag
+
+
+class Trainer:
+    def __init__(self, config, model):
+        self.config, self.model = config, model
+        self.learning_rate = config['learning_rate'] if 'learning_rate' in config else 1e-3
+        self.epochs = int(config['epochs']) if 'epochs' in config else 1
+        self.eval_step = min(config['eval_step'] if 'eval_step' in config else 1, self.epochs)
+        self.stopping_step = config['stopping_step'] if 'stopping_step' in config else 10
+        self.clip_grad_norm = config['clip_grad_norm'] if 'clip_grad_norm' in config else None
+        self.valid_metric = (config['valid_metric'] if 'valid_metric' in config else 'MRR@10').lower()
+        self.valid_metric_bigger = config['valid_metric_bigger'] if 'valid_metric_bigger' in config else True
+        self.topk = config['topk'] if 'topk' in config else [10]
+        self.device = config['device']
+        self.weight_decay = config['weight_decay'] if 'weight_decay' in config else 0.0
+        self.start_epoch, self.cur_step = 0, 0
+        self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
+        self.best_valid_result = None
+        self.train_loss_dict = dict()
+        self.optimizer = DenseAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+
+    def _train_epoch(self, train_data, epoch_idx):
+        self.model.train()
+        total = None                              # accumulated on device: no per-step host sync
+        for interaction in train_data:
+            interaction = interaction.to(self.device)
+            self.optimizer.zero_grad()
+            losses = self.model.calculate_loss(interaction)
+            loss = sum(losses) if isinstance(losses, tuple) else losses
+            loss = loss.sum()
+            loss.backward()
+            if self.clip_grad_norm:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), **self.clip_grad_norm)
+            self.optimizer.step()
+            total = loss.detach() if total is None else total + loss.detach()
+        value = float(total) if total is not None else 0.0
+        if value != value:
+            raise ValueError('Training loss is nan')
+        return value
+
+    @torch.no_grad()
+    def evaluate(self, eval_data):
+        """eval_data yields (interaction, history_index (rows, cols) or None, positive_u, positive_i) like recbole's
+        FullSortEvalDataLoader; returns {metric@k: value} for recall / mrr / ndcg / hit / precision."""
+        self.model.eval()
+        kmax = max(self.topk)
+        hits, pos_len = [], []
+        for interaction, history_index, positive_u, positive_i in eval_data:
+            interaction = interaction.to(self.device)
+            n_user = len(interaction)
+            scores = self.model.full_sort_predict(interaction).view(n_user, -1)
+            scores[:, 0] = -np.inf
+            if history_index is not None:
+                scores[history_index] = -np.inf
+            _, topk_idx = torch.topk(scores, kmax, dim=-1)
+            pos = torch.zeros_like(scores, dtype=torch.bool)
+            pos[positive_u, positive_i] = True
+            hits.append(torch.gather(pos, 1, topk_idx).float())
+            pos_len.append(pos.sum(1).float())
+        hit = torch.cat(hits)
+        n_pos = torch.cat(pos_len).clamp(min=1)
+        result = {}
+        ranks = torch.arange(1, kmax + 1, device=hit.device, dtype=torch.float32)
+        for k in self.topk:
+            h = hit[:, :k]
+            result[f'recall@{k}'] = float((h.sum(1) / n_pos).mean())
+            result[f'hit@{k}'] = float((h.sum(1) > 0).float().mean())
+            result[f'precision@{k}'] = float((h.sum(1) / k).mean())
+            first = (h * (1.0 / ranks[:k])).max(1).values
+            result[f'mrr@{k}'] = float(first.mean())
+            dcg = (h / torch.log2(ranks[:k] + 1)).sum(1)
+            ideal = torch.cumsum(1.0 / torch.log2(ranks[:k] + 1), 0)
+            idcg = ideal[(n_pos.clamp(max=k).long() - 1)]
+            result[f'ndcg@{k}'] = float((dcg / idcg).mean())
+        return result
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        for epoch_idx in range(self.start_epoch, self.epochs):
+            train_loss = self._train_epoch(train_data, epoch_idx)
+            self.train_loss_dict[epoch_idx] = train_loss
+            if self.eval_step <= 0 or not valid_data:
+                continue
+            if (epoch_idx + 1) % self.eval_step == 0:
+                valid_result = self.evaluate(valid_data)
+                valid_score = valid_result[self.valid_metric]
+                self.best_valid_score, self.cur_step, stop_flag, update_flag = early_stopping(
+                    valid_score, self.best_valid_score, self.cur_step, max_step=self.stopping_step,
+                    bigger=self.valid_metric_bigger)
+                if update_flag:
+                    self.best_valid_result = valid_result
+                if callback_fn:
+                    callback_fn(epoch_idx, valid_score)
+                if stop_flag:
+                    break
+        return self.best_valid_score, self.best_valid_result
+
+
+class CrossDomainTrainer(Trainer):
+    """Phase loop over ``train_modes`` (SOURCE / TARGET / BOTH / OVERLAP) -- trainer.py:43-76."""
+
+    def __init__(self, config, model):
+        super().__init__(config, model)
+        self.train_modes = config['train_modes']
+        self.train_epochs = config['epoch_num']
+        self.split_valid_flag = config['source_split']
+
+    def _reinit(self, phase):
+        """Reset per-phase state; the optimizer (and its Adam moments) is NOT rebuilt (trainer.py:30-41, Q13)."""
+        self.start_epoch = 0
+        self.cur_step = 0
+        self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
+        self.best_valid_result = None
+        self.item_tensor = None
+        self.tot_item_num = None
+        self.train_loss_dict = dict()
+        self.epochs = int(self.train_epochs[phase])
+        self.eval_step = min(self.config['eval_step'] if 'eval_step' in self.config else 1, self.epochs)
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        for phase in range(len(self.train_modes)):
+            self._reinit(phase)
+            scheme = self.train_modes[phase]
+            train_data.set_mode(train_mode2state[scheme])
+            self.model.set_phase(scheme)
+            if self.split_valid_flag and valid_data is not None:
+                source_valid_data, target_valid_data = valid_data
+                if scheme == 'SOURCE':
+                    super().fit(train_data, source_valid_data, verbose, saved, show_progress, callback_fn)
+                else:
+                    super().fit(train_data, target_valid_data, verbose, saved, show_progress, callback_fn)
+            else:
+                super().fit(train_data, valid_data, verbose, saved, show_progress, callback_fn)
+        self.model.set_phase('OVERLAP')
+        return self.best_valid_score, self.best_valid_result

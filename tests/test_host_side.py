@@ -1,0 +1,103 @@
+"""Host-side mirrors of the reference's interface (CPU): native overlap remap bit-exact against the golden vectors, the
+four-state loader against the reference's recorded traces, batch layouts."""
+import numpy as np
+import pytest
+import torch
+
+import recbole_cdr_amd  # noqa: F401
+from recbole_cdr_amd.data import overlap_remap, CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+from recbole_cdr_amd.utils import CrossDomainDataLoaderState, InputType, train_mode2state
+from golden_util import Golden, cases
+
+
+def _tokens(g, key):
+    toks = [str(t) for t in g[f'in/{key}_tokens']]
+    nan = g[f'in/{key}_isnan'] if g.has(f'in/{key}_isnan') else np.zeros(len(toks), bool)
+    return [None if m else t for t, m in zip(toks, nan)]
+
+
+@pytest.mark.parametrize('name', cases('remap_'))
+def test_native_remap_bit_exact(name):
+    g = Golden(name)
+    su, si, tu, ti = (_tokens(g, k) for k in ('source_user', 'source_item', 'target_user', 'target_item'))
+    sfeat = [str(t) for t in g['in/source_user_feat_tokens']] if g.has('in/source_user_feat_tokens') else []
+    tfeat = [str(t) for t in g['in/target_user_feat_tokens']] if g.has('in/target_user_feat_tokens') else []
+    ru = overlap_remap(su + sfeat, tu + tfeat)
+    ri = overlap_remap(si, ti)
+    np.testing.assert_array_equal(ru.source_ids[:len(su)], g['applied/source_user'])
+    np.testing.assert_array_equal(ru.target_ids[:len(tu)], g['applied/target_user'])
+    np.testing.assert_array_equal(ri.source_ids, g['applied/source_item'])
+    np.testing.assert_array_equal(ri.target_ids, g['applied/target_item'])
+    assert (ru.num_overlap, ru.num_source_only, ru.num_target_only, ru.num_total) == tuple(
+        int(g[f'count/{k}']) for k in ('num_overlap_user', 'num_source_only_user', 'num_target_only_user', 'num_total_user'))
+    assert (ri.num_overlap, ri.num_source_only, ri.num_target_only, ri.num_total) == tuple(
+        int(g[f'count/{k}']) for k in ('num_overlap_item', 'num_source_only_item', 'num_target_only_item', 'num_total_item'))
+    # every (token -> id) pair of the reference's dictionaries
+    for prefix, toks, ids in (('source_user', su + sfeat, ru.source_ids), ('target_user', tu + tfeat, ru.target_ids),
+                              ('source_item', si, ri.source_ids), ('target_item', ti, ri.target_ids)):
+        want = dict(zip((str(t) for t in g[f'{prefix}/tokens']), g[f'{prefix}/ids'].tolist()))
+        for t, i in zip(toks, ids):
+            if t is not None:
+                assert want[t] == i, (prefix, t)
+
+
+def test_remap_large_random_matches_oracle():
+    from oracle import remap as oremap
+    rng = np.random.RandomState(1)
+    s = [f'tok{n}' for n in rng.randint(0, 50000, 200000)]
+    t = [f'tok{n}' for n in rng.randint(25000, 90000, 150000)]
+    r = overlap_remap(s, t)
+    ms, _, mt, _, counts = oremap.overlap_remap(s, ['x'], t, ['y'])
+    np.testing.assert_array_equal(r.source_ids, oremap.apply_remap(s, ms))
+    np.testing.assert_array_equal(r.target_ids, oremap.apply_remap(t, mt))
+    assert r.num_total == counts['num_total_user']
+
+
+def _loader(name, n_batches, bs):
+    inter = {f'{name}_user_id': torch.arange(n_batches * bs) // bs, f'{name}_item_id': torch.arange(n_batches * bs)}
+    sampler = lambda u, i, k: torch.zeros(u.numel() * k, dtype=torch.int64)
+    return DomainTrainLoader(inter, f'{name}_user_id', f'{name}_item_id', f'{name}_label', 'neg_', bs, 1,
+                             InputType.PAIRWISE, sampler)
+
+
+def test_four_state_loader_matches_reference_trace():
+    g = Golden('revoke_layout')
+    dl = CrossDomainDataloader(_loader('source', 2, 3), _loader('target', 5, 4), OverlapDataloader(6, 2))
+    for state in ('BOTH', 'SOURCE', 'TARGET', 'OVERLAP'):
+        dl.set_mode(train_mode2state[state])
+        assert len(dl) == int(g[f'layout/{state}/len'])
+        ep = []
+        it = iter(dl)
+        while True:
+            try:
+                b = dl.__next__()
+            except StopIteration:
+                break
+            ep.append([int(b['source_user_id'][0]) if 'source_user_id' in b else -1,
+                       int(b['target_user_id'][0]) if 'target_user_id' in b else -1,
+                       int(b['overlap'][0, 0]) // 2 if 'overlap' in b else -1,
+                       len(b['source_user_id']) if 'source_user_id' in b else 0,
+                       len(b['target_user_id']) if 'target_user_id' in b else 0])
+        assert it is not None
+        np.testing.assert_array_equal(np.array(ep, dtype=np.int64), g[f'layout/{state}/trace'])
+        assert (dl.source_dataloader.pr, dl.target_dataloader.pr, dl.overlap_dataloader.pr) == (0, 0, 0)
+    dl.set_mode(CrossDomainDataLoaderState.BOTH)
+    iter(dl)
+    dl.__next__()
+    with pytest.raises(PermissionError):
+        dl.set_mode(CrossDomainDataLoaderState.SOURCE)
+
+
+def test_train_loader_layouts():
+    """k-major negatives; POINTWISE = repeat(1+k) with labels [1]*S + [0]*(S k)  (SURVEY App. A)."""
+    inter = {'source_user_id': torch.tensor([5, 6, 7]), 'source_item_id': torch.tensor([10, 11, 12])}
+    sampler = lambda u, i, k: torch.arange(100, 100 + u.numel() * k)
+    pw = DomainTrainLoader(inter, 'source_user_id', 'source_item_id', 'source_label', 'neg_', 6, 2, InputType.PAIRWISE, sampler)
+    b = next(iter(pw))
+    assert b['source_user_id'].tolist() == [5, 6, 7, 5, 6, 7] and b['neg_source_item_id'].tolist() == list(range(100, 106))
+    pt = DomainTrainLoader(inter, 'source_user_id', 'source_item_id', 'source_label', 'neg_', 9, 2, InputType.POINTWISE, sampler)
+    b = next(iter(pt))
+    assert b['source_item_id'].tolist() == [10, 11, 12] + list(range(100, 106))
+    assert b['source_label'].tolist() == [1.0] * 3 + [0.0] * 6
+    ov = next(iter(OverlapDataloader(7, 3)))
+    assert tuple(ov['overlap'].shape) == (3, 1) and ov['overlap'][:, 0].tolist() == [0, 1, 2]
