@@ -152,6 +152,69 @@ int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const f
 int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
+/* cdr_gemm_f32 with a per-output-row scale and a pre-activation accumulate -- the CoNet cross unit
+ * (conet.py:127-135):  first  C = s W^T + b           (cdr_gemm_f32, act none)
+ *                      then   C = relu(C + m (.) (t H^T))   (rowscale = m, act relu, accumulate = 2)
+ *   v = rowscale[m] * acc ; accumulate 0: act(v + bias) ; 1: act(v + bias) + C ; 2: act((C + v) + bias)            */
+int cdr_gemm_f32_ex(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, const float* rowscale, int act, int accumulate);
+
+/* ---- CoNet helpers (conet.py:105-242) ------------------------------------------------------------------------- */
+/* out[r*ldo + c] = tab[ids[r]*D + c]  /  grad_tab[ids[r]*D + c] += src[r*lds + c]  (the [u ; i] concatenated input) */
+int cdr_gather_rows_ld(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out, int64_t ldo);
+int cdr_scatter_add_rows_ld(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n, const float* src, int64_t lds);
+int cdr_overlap_mask(void* stream, const int64_t* ids, int64_t n, int64_t n_overlap, float* out);   /* id < n ? 1 : 0 */
+int cdr_rowscale(void* stream, const float* x, const float* scale, int64_t M, int64_t N, float* out);
+int cdr_bcast_add_act(void* stream, const float* P, const float* q, int64_t N, int64_t H, int act, float* out);
+/* nn.BCELoss on probabilities (log clamp -100, mean) and its gradient (p-y)/max(p(1-p),1e-12)/n * grad_out */
+int cdr_bce_prob_fwd(cdr_ctx* ctx, void* stream, const float* p, const float* y, int64_t n, float* out1);
+int cdr_bce_prob_bwd(void* stream, const float* p, const float* y, int64_t n, const float* grad_out, float* gp);
+/* torch.norm(W) (Frobenius, conet.py:198-201) and d/dW = grad_out * W / norm */
+int cdr_frobenius_fwd(cdr_ctx* ctx, void* stream, const float* x, int64_t n, float* out1);
+int cdr_frobenius_bwd(void* stream, const float* x, int64_t n, const float* norm, const float* grad_out, float* gx, int accumulate);
+
+/* ---- SSCDR helpers (sscdr.py:120-187) -------------------------------------------------------------------------- */
+/* embedding_normalize: len = sum x^2, y = x / (len > 1 ? len : 1)  -- the squared-length quirk is kept */
+int cdr_sqnorm_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, float* len_out);
+int cdr_sqnorm_normalize_bwd(void* stream, const float* x, const float* len, const float* gy, int64_t rows, int D, float* gx);
+/* nn.TripletMarginLoss(margin, p=2, eps): mean_r max(||a-p+eps|| - ||a-n+eps|| + margin, 0) */
+int cdr_triplet_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* p, const float* n, int64_t rows, int D,
+                    float margin, float eps, float* out1, float* dap, float* dan);
+int cdr_triplet_bwd(void* stream, const float* a, const float* p, const float* n, int64_t rows, int D, float margin, float eps,
+                    const float* dap, const float* dan, const float* grad_out, float* ga, float* gp, float* gn);
+
+/* ---- BiTGCF (bitgcf.py:130-250) --------------------------------------------------------------------------------
+ * CSR adjacency (int64 indptr [n+1], int64 indices, fp32 values) of the normalised bipartite graph (symmetric).
+ *   cdr_spmm_csr_f32    out = A x E                                  (torch.sparse.mm, bitgcf.py:131)
+ *   cdr_graph_layer_fwd side = A x E ; new = E + (side + E (.) side)   (bitgcf.py:130-135, dropout = identity)
+ *   cdr_graph_layer_bwd gE = gnew (.) (1 + side) + A x (gnew (.) (1 + E))     (tmp: [n, D] scratch)
+ *   cdr_transfer_*      rows < n_overlap: ((lam*s + (1-lam)*t) + (ds*s + dt*t)/(ds+dt+1e-7)) / 2, others pass through
+ *   cdr_l2_normalize_*  F.normalize(p=2, dim=1, eps=1e-12), output written with leading dimension ldo
+ *   cdr_copy_cols / cdr_colblock_mean_*   concat / mean of the layer outputs (bitgcf.py:191-198)
+ *   cdr_embloss_*       recbole EmbLoss of the EGO rows: out3 = {(||U_b|| + ||I_b||)/B, ||U_b||, ||I_b||}            */
+int cdr_spmm_csr_f32(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
+                     const float* E, int D, float* out);
+int cdr_graph_layer_fwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
+                        const float* E, int D, float* side_out, float* new_out);
+int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
+                        const float* E, const float* side, const float* gnew, int D, float* tmp, float* gE);
+int cdr_transfer_fwd(void* stream, const float* S, const float* T, const float* deg_s, const float* deg_t, int64_t rows, int D,
+                     int64_t n_overlap, float lam_s, float lam_t, float* S_out, float* T_out);
+int cdr_transfer_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,
+                     int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* gS, float* gT);
+int cdr_l2_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, int64_t ldo, float* norm_out);
+int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const float* gy, int64_t ldg, int64_t rows, int D,
+                         float* gx, int accumulate);
+int cdr_copy_cols(void* stream, const float* src, int64_t lds, int64_t rows, int D, float* dst, int64_t ldo, int accumulate);
+int cdr_colblock_mean_fwd(void* stream, const float* cat, int64_t rows, int D, int nb, float* out);
+int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, int nb, float* gcat);
+int cdr_embloss_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
+                    const int64_t* uid, const int64_t* iid, int64_t B, float* out3);
+int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const float* item_tab, int D, const int64_t* uid,
+                          const int64_t* iid, int64_t B, const float* out3, const float* grad_out,
+                          float* grad_user_tab, float* grad_item_tab);
+
 /* ---- integer paths (bit-exact) --------------------------------------------------------------------------------
  * cdr_overlap_remap (HOST function, no GPU): CrossDomainDataset.calculate_user_item_from_both_domain + _remap_fields for
  * one field (dataset.py:344-445,109-123).  Tokens are UTF-8 bytes: token i = bytes[off[i], off[i+1]); isnan[i] != 0 marks

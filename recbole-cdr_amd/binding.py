@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, 'lib', 'libcdrhip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -74,6 +74,34 @@ _SIGNATURES = {
     'cdr_sort_ids': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_rowwise_apply': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
                           _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
+    'cdr_gemm_f32_ex': [_c_ptr, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
+                        _c_ptr, _c_int, _c_int],
+    'cdr_gather_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
+    'cdr_scatter_add_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
+    'cdr_overlap_mask': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
+    'cdr_rowscale': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
+    'cdr_bcast_add_act': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr],
+    'cdr_bce_prob_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_bce_prob_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_frobenius_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_frobenius_bwd': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int],
+    'cdr_sqnorm_normalize_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr],
+    'cdr_sqnorm_normalize_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr],
+    'cdr_triplet_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_triplet_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                        _c_ptr],
+    'cdr_spmm_csr_f32': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr],
+    'cdr_graph_layer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr],
+    'cdr_graph_layer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr],
+    'cdr_transfer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
+    'cdr_transfer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
+    'cdr_l2_normalize_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr],
+    'cdr_l2_normalize_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_int],
+    'cdr_copy_cols': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_int],
+    'cdr_colblock_mean_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
+    'cdr_colblock_mean_bwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
+    'cdr_embloss_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_embloss_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_overlap_remap': [ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_revoke_map': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],

@@ -1,0 +1,406 @@
+// Small fused row-wise / elementwise kernels used by the CoNet, SSCDR and BiTGCF mirrors (SURVEY.md 2.2 K4, K8, K10,
+// K11, K12 minus the SpMM).  All HBM-bound streaming kernels: float4 (16 B) per lane where rows are 16-B aligned,
+// one wave per row for row reductions, fixed-order two-pass reductions for scalars.
+#include "cdr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_cap(int64_t blocks) {
+    const int64_t cap = CDR_NUM_CU * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---- strided row gather / scatter-add (concatenated [u ; i] inputs of CoNet: conet.py:106-111) -------------------
+__global__ __launch_bounds__(kBlock) void gather_rows_ld_kernel(const float* __restrict__ tab, int D,
+                                                                const int64_t* __restrict__ ids, int64_t n,
+                                                                float* __restrict__ out, int64_t ldo) {
+    const int64_t total = n * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const int c = (int)(e - r * D);
+        out[r * ldo + c] = tab[ids[r] * D + c];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_ld_kernel(float* __restrict__ grad_tab, int D,
+                                                                     const int64_t* __restrict__ ids, int64_t n,
+                                                                     const float* __restrict__ src, int64_t lds) {
+    const int64_t total = n * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const int c = (int)(e - r * D);
+        atomicAdd(grad_tab + ids[r] * D + c, src[r * lds + c]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void overlap_mask_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t n_overlap,
+                                                              float* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) out[e] = ids[e] < n_overlap ? 1.0f : 0.0f;
+}
+
+// out[m,:] = scale[m] * x[m,:]
+__global__ __launch_bounds__(kBlock) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          int64_t M, int64_t N, float* __restrict__ out) {
+    const int64_t total = M * N, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) out[e] = x[e] * scale[e / N];
+}
+
+// out[i,:] = act(P[i,:] + q[:])   (CoNet full-sort: first layer split into item part P and user part q)
+__global__ __launch_bounds__(kBlock) void bcast_add_act_kernel(const float* __restrict__ P, const float* __restrict__ q,
+                                                               int64_t N, int64_t H, int act, float* __restrict__ out) {
+    const int64_t total = N * H, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        float v = P[e] + q[e % H];
+        if (act == CDR_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == CDR_ACT_TANH) v = tanhf(v);
+        else if (act == CDR_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        out[e] = v;
+    }
+}
+
+// ---- BCE on probabilities (nn.BCELoss: conet.py:63,195-196) --------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                             int64_t n, double* __restrict__ partials) {
+    __shared__ double smem[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const float pv = p[e], yv = y[e];
+        acc[0] += (double)((yv - 1.0f) * fmaxf(logf(1.0f - pv), -100.0f) - yv * fmaxf(logf(pv), -100.0f));
+    }
+    block_sum_d<1>(acc, smem);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE] = acc[0];
+}
+
+// mode 0: out = sum / n (mean) ; mode 1: out = sqrt(sum) (Frobenius norm)
+__global__ __launch_bounds__(kBlock) void scalar_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t n,
+                                                               int mode, float* __restrict__ out1) {
+    __shared__ double smem[4];
+    double acc[1] = {0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) acc[0] += partials[(size_t)b * CDR_PARTIAL_STRIDE];
+    block_sum_d<1>(acc, smem);
+    if (threadIdx.x == 0) out1[0] = mode == 0 ? (float)(acc[0] / (double)n) : (float)sqrt(acc[0]);
+}
+
+__global__ __launch_bounds__(kBlock) void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n,
+                                                         const float* __restrict__ grad_out, float* __restrict__ gp) {
+    const float go = (grad_out ? grad_out[0] : 1.0f) / (float)n;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const float pv = p[e];
+        gp[e] = go * (pv - y[e]) / fmaxf((1.0f - pv) * pv, 1e-12f);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sqsum_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partials) {
+    __shared__ double smem[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) acc[0] += (double)(x[e] * x[e]);
+    block_sum_d<1>(acc, smem);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE] = acc[0];
+}
+
+// gx (+)= go * x / norm   (d||x||_F / dx; 0 where the norm is 0, as torch.norm's backward)
+__global__ __launch_bounds__(kBlock) void frobenius_bwd_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ norm,
+                                                               const float* __restrict__ grad_out, float* __restrict__ gx,
+                                                               int accumulate) {
+    const float nv = norm[0];
+    const float c = nv > 0.f ? (grad_out ? grad_out[0] : 1.0f) / nv : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride)
+        gx[e] = (accumulate ? gx[e] : 0.f) + c * x[e];
+}
+
+// ---- SSCDR: squared-norm "normalize" (sscdr.py:120-124) ------------------------------------------------------------
+//   len = sum x^2 ; y = x / (len > 1 ? len : 1)          one wave per row
+__global__ __launch_bounds__(kBlock) void sqnorm_normalize_fwd_kernel(const float* __restrict__ x, int64_t rows, int D,
+                                                                      float* __restrict__ y, float* __restrict__ len_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    for (int64_t r = w; r < rows; r += TW) {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) { const float v = x[r * D + c]; s += v * v; }
+        s = group_sum<64>(s);
+        const float nrm = s > 1.0f ? s : 1.0f;
+        for (int c = lane; c < D; c += 64) y[r * D + c] = x[r * D + c] / nrm;
+        if (lane == 0 && len_out) len_out[r] = s;
+    }
+}
+
+//   len > 1: gx = gy/len - 2 x (x . gy) / len^2 ; else gx = gy
+__global__ __launch_bounds__(kBlock) void sqnorm_normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ len,
+                                                                      const float* __restrict__ gy, int64_t rows, int D,
+                                                                      float* __restrict__ gx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    for (int64_t r = w; r < rows; r += TW) {
+        const float L = len[r];
+        if (L > 1.0f) {
+            float d = 0.f;
+            for (int c = lane; c < D; c += 64) d += x[r * D + c] * gy[r * D + c];
+            d = group_sum<64>(d);
+            const float k = 2.0f * d / (L * L);
+            for (int c = lane; c < D; c += 64) gx[r * D + c] = gy[r * D + c] / L - k * x[r * D + c];
+        } else {
+            for (int c = lane; c < D; c += 64) gx[r * D + c] = gy[r * D + c];
+        }
+    }
+}
+
+// ---- SSCDR: nn.TripletMarginLoss(margin, p=2, eps=1e-6) (sscdr.py:69,142-144) ------------------------------------
+//   d(a,b) = || a - b + eps ||_2 ; l = max(d_ap - d_an + margin, 0) ; mean over rows
+__global__ __launch_bounds__(kBlock) void triplet_fwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                             const float* __restrict__ n, int64_t rows, int D, float margin,
+                                                             float eps, float* __restrict__ dap, float* __restrict__ dan,
+                                                             double* __restrict__ partials) {
+    __shared__ double smem[4];
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    double acc[1] = {0.0};
+    for (int64_t r = w; r < rows; r += TW) {
+        float sp = 0.f, sn = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float av = a[r * D + c];
+            const float dp = av - p[r * D + c] + eps, dn = av - n[r * D + c] + eps;
+            sp += dp * dp; sn += dn * dn;
+        }
+        sp = group_sum<64>(sp); sn = group_sum<64>(sn);
+        if (lane == 0) {
+            const float d1 = sqrtf(sp), d2 = sqrtf(sn);
+            dap[r] = d1; dan[r] = d2;
+            acc[0] += (double)fmaxf(d1 - d2 + margin, 0.0f);
+        }
+    }
+    block_sum_d<1>(acc, smem);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE] = acc[0];
+}
+
+__global__ __launch_bounds__(kBlock) void triplet_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                             const float* __restrict__ n, int64_t rows, int D, float margin,
+                                                             float eps, const float* __restrict__ dap,
+                                                             const float* __restrict__ dan, const float* __restrict__ grad_out,
+                                                             float* __restrict__ ga, float* __restrict__ gp,
+                                                             float* __restrict__ gn) {
+    const float go = (grad_out ? grad_out[0] : 1.0f) / (float)rows;
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const float d1 = dap[r], d2 = dan[r];
+        float va = 0.f, vp = 0.f, vn = 0.f;
+        if (d1 - d2 + margin > 0.0f) {
+            const float av = a[e];
+            const float u1 = d1 > 0.f ? (av - p[e] + eps) / d1 : 0.f;
+            const float u2 = d2 > 0.f ? (av - n[e] + eps) / d2 : 0.f;
+            va = go * (u1 - u2); vp = -go * u1; vn = go * u2;
+        }
+        if (ga) ga[e] = va;
+        if (gp) gp[e] = vp;
+        if (gn) gn[e] = vn;
+    }
+}
+
+// ---- EmbLoss alone (bitgcf.py:231-233: norms of the EGO rows, different width from the propagated rows) -----------
+__global__ __launch_bounds__(kBlock) void embloss_partial_kernel(const float* __restrict__ U, const float* __restrict__ I, int D,
+                                                                 const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                                 int64_t B, double* __restrict__ partials) {
+    __shared__ double smem[8];
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    double acc[2] = {0.0, 0.0};
+    for (int64_t t = w; t < B; t += TW) {
+        const int64_t iu = uid[t], ii = iid[t];
+        float su = 0.f, si = 0.f;
+        for (int c = lane; c < D; c += 64) { const float a = U[iu * D + c], b = I[ii * D + c]; su += a * a; si += b * b; }
+        su = group_sum<64>(su); si = group_sum<64>(si);
+        if (lane == 0) { acc[0] += (double)su; acc[1] += (double)si; }
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE] = acc[0];
+        partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE + 1] = acc[1];
+    }
+}
+
+// out3 = {(nu + ni)/B, nu, ni}
+__global__ __launch_bounds__(kBlock) void embloss_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                                float* __restrict__ out3) {
+    __shared__ double smem[8];
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        acc[0] += partials[(size_t)b * CDR_PARTIAL_STRIDE];
+        acc[1] += partials[(size_t)b * CDR_PARTIAL_STRIDE + 1];
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float nu = (float)sqrt(acc[0]), ni = (float)sqrt(acc[1]);
+        out3[1] = nu; out3[2] = ni; out3[0] = (nu + ni) / (float)B;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void embloss_bwd_kernel(const float* __restrict__ U, const float* __restrict__ I, int D,
+                                                             const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                             int64_t B, const float* __restrict__ out3,
+                                                             const float* __restrict__ grad_out, float* __restrict__ gU,
+                                                             float* __restrict__ gI) {
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float cu = out3[1] > 0.f ? go / ((float)B * out3[1]) : 0.f;
+    const float ci = out3[2] > 0.f ? go / ((float)B * out3[2]) : 0.f;
+    const int64_t total = B * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t t = e / D;
+        const int c = (int)(e - t * D);
+        const int64_t iu = uid[t], ii = iid[t];
+        atomicAdd(gU + iu * D + c, cu * U[iu * D + c]);
+        atomicAdd(gI + ii * D + c, ci * I[ii * D + c]);
+    }
+}
+
+}  // namespace
+
+#define EL_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
+
+extern "C" int cdr_gather_rows_ld(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out, int64_t ldo) {
+    CDR_CHECK_ARG(tab && ids && out && D > 0 && n > 0 && ldo >= D);
+    gather_rows_ld_kernel<<<EL_GRID(n * D)>>>(tab, D, ids, n, out, ldo);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_scatter_add_rows_ld(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n, const float* src,
+                                       int64_t lds) {
+    CDR_CHECK_ARG(grad_tab && ids && src && D > 0 && n > 0 && lds >= D);
+    scatter_add_rows_ld_kernel<<<EL_GRID(n * D)>>>(grad_tab, D, ids, n, src, lds);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_overlap_mask(void* stream, const int64_t* ids, int64_t n, int64_t n_overlap, float* out) {
+    CDR_CHECK_ARG(ids && out && n > 0);
+    overlap_mask_kernel<<<EL_GRID(n)>>>(ids, n, n_overlap, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_rowscale(void* stream, const float* x, const float* scale, int64_t M, int64_t N, float* out) {
+    CDR_CHECK_ARG(x && scale && out && M > 0 && N > 0);
+    rowscale_kernel<<<EL_GRID(M * N)>>>(x, scale, M, N, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bcast_add_act(void* stream, const float* P, const float* q, int64_t N, int64_t H, int act, float* out) {
+    CDR_CHECK_ARG(P && q && out && N > 0 && H > 0);
+    bcast_add_act_kernel<<<EL_GRID(N * H)>>>(P, q, N, H, act, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+static inline int partial_grid(int64_t n) {
+    int64_t g = (n + kBlock * 4 - 1) / (kBlock * 4);
+    if (g > CDR_NUM_CU * 8) g = CDR_NUM_CU * 8;
+    if (g > CDR_MAX_PARTIAL_BLOCKS) g = CDR_MAX_PARTIAL_BLOCKS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int cdr_bce_prob_fwd(cdr_ctx* ctx, void* stream, const float* p, const float* y, int64_t n, float* out1) {
+    CDR_CHECK_ARG(ctx && p && y && out1 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int g = partial_grid(n);
+    bce_partial_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(p, y, n, ctx->partials);
+    CDR_LAUNCH_CHECK();
+    scalar_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, g, n, 0, out1);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bce_prob_bwd(void* stream, const float* p, const float* y, int64_t n, const float* grad_out, float* gp) {
+    CDR_CHECK_ARG(p && y && gp && n > 0);
+    bce_bwd_kernel<<<EL_GRID(n)>>>(p, y, n, grad_out, gp);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_frobenius_fwd(cdr_ctx* ctx, void* stream, const float* x, int64_t n, float* out1) {
+    CDR_CHECK_ARG(ctx && x && out1 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int g = partial_grid(n);
+    sqsum_partial_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(x, n, ctx->partials);
+    CDR_LAUNCH_CHECK();
+    scalar_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, g, n, 1, out1);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_frobenius_bwd(void* stream, const float* x, int64_t n, const float* norm, const float* grad_out, float* gx,
+                                 int accumulate) {
+    CDR_CHECK_ARG(x && norm && gx && n > 0);
+    frobenius_bwd_kernel<<<EL_GRID(n)>>>(x, n, norm, grad_out, gx, accumulate);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_sqnorm_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, float* len_out) {
+    CDR_CHECK_ARG(x && y && rows > 0 && D > 0);
+    sqnorm_normalize_fwd_kernel<<<dim3(grid_cap((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream>>>(x, rows, D, y, len_out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_sqnorm_normalize_bwd(void* stream, const float* x, const float* len, const float* gy, int64_t rows, int D,
+                                        float* gx) {
+    CDR_CHECK_ARG(x && len && gy && gx && rows > 0 && D > 0);
+    sqnorm_normalize_bwd_kernel<<<dim3(grid_cap((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream>>>(x, len, gy, rows, D, gx);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_triplet_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* p, const float* n, int64_t rows, int D,
+                               float margin, float eps, float* out1, float* dap, float* dan) {
+    CDR_CHECK_ARG(ctx && a && p && n && out1 && dap && dan && rows > 0 && D > 0);
+    hipStream_t s = (hipStream_t)stream;
+    int g = grid_cap((rows + 3) / 4);
+    if (g > CDR_MAX_PARTIAL_BLOCKS) g = CDR_MAX_PARTIAL_BLOCKS;
+    triplet_fwd_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(a, p, n, rows, D, margin, eps, dap, dan, ctx->partials);
+    CDR_LAUNCH_CHECK();
+    scalar_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, g, rows, 0, out1);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_triplet_bwd(void* stream, const float* a, const float* p, const float* n, int64_t rows, int D, float margin,
+                               float eps, const float* dap, const float* dan, const float* grad_out, float* ga, float* gp,
+                               float* gn) {
+    CDR_CHECK_ARG(a && p && n && dap && dan && rows > 0 && D > 0 && (ga || gp || gn));
+    triplet_bwd_kernel<<<EL_GRID(rows * D)>>>(a, p, n, rows, D, margin, eps, dap, dan, grad_out, ga, gp, gn);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_embloss_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
+                               const int64_t* uid, const int64_t* iid, int64_t B, float* out3) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && out3 && B > 0 && D > 0);
+    hipStream_t s = (hipStream_t)stream;
+    int g = grid_cap((B + 3) / 4);
+    if (g > CDR_MAX_PARTIAL_BLOCKS) g = CDR_MAX_PARTIAL_BLOCKS;
+    embloss_partial_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, iid, B, ctx->partials);
+    CDR_LAUNCH_CHECK();
+    embloss_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, g, B, out3);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const float* item_tab, int D, const int64_t* uid,
+                                     const int64_t* iid, int64_t B, const float* out3, const float* grad_out,
+                                     float* grad_user_tab, float* grad_item_tab) {
+    CDR_CHECK_ARG(user_tab && item_tab && uid && iid && out3 && grad_user_tab && grad_item_tab && B > 0 && D > 0);
+    embloss_bwd_kernel<<<EL_GRID(B * D)>>>(user_tab, item_tab, D, uid, iid, B, out3, grad_out, grad_user_tab, grad_item_tab);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
                                                        float* __restrict__ C, int64_t ldc,
                                                        const float* __restrict__ bias, int act, int accumulate,
                                                        const float* __restrict__ rown, const float* __restrict__ coln,
-                                                       int vecA, int vecB) {
+                                                       int vecA, int vecB, const float* __restrict__ rowscale) {
     constexpr int WM = (BM == 128) ? 2 : 1;            // waves along M
     constexpr int WN = 4 / WM;                         // waves along N
     constexpr int TM = BM / (32 * WM);                 // 32x32 tiles per wave along M
@@ -153,8 +153,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
                 if (EPI_SQDIST) {
                     v = -(((-2.0f * v) + rown[m]) + cn);
                 } else {
-                    v = act_apply(act, v + bv);
-                    if (accumulate) v += C[m * ldc + n];
+                    if (rowscale) v *= rowscale[m];
+                    if (accumulate == 2) v = act_apply(act, (C[m * ldc + n] + v) + bv);       // pre-activation add
+                    else {
+                        v = act_apply(act, v + bv);
+                        if (accumulate == 1) v += C[m * ldc + n];                             // post-activation add
+                    }
                 }
                 C[m * ldc + n] = v;
             }
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
 
 template <bool TA, bool TB, bool SQ>
 int launch(hipStream_t s, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-           float* C, int64_t ldc, const float* bias, int act, int accumulate, const float* rown, const float* coln) {
+           float* C, int64_t ldc, const float* bias, int act, int accumulate, const float* rown, const float* coln,
+           const float* rowscale = nullptr) {
     // float4 global loads need 16-B aligned rows along the contiguous dimension
     const int vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
     const int vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
@@ -172,13 +177,13 @@ int launch(hipStream_t s, int64_t M, int64_t N, int64_t K, const float* A, int64
         const int64_t grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
         gemm_f32_kernel<BM, BN, TA, TB, SQ><<<dim3((unsigned)grid), dim3(256), lds, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias,
-                                                                                      act, accumulate, rown, coln, vecA, vecB);
+                                                                                      act, accumulate, rown, coln, vecA, vecB, rowscale);
     } else {
         constexpr int BM = 128, BN = 128;
         const int64_t grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
         gemm_f32_kernel<BM, BN, TA, TB, SQ><<<dim3((unsigned)grid), dim3(256), lds, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias,
-                                                                                      act, accumulate, rown, coln, vecA, vecB);
+                                                                                      act, accumulate, rown, coln, vecA, vecB, rowscale);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdr_set_error("cdr_gemm_f32: launch failed: %s", hipGetErrorString(e)); return (int)e; }
@@ -199,18 +204,25 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int cdr_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
-                            int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
-                            int accumulate) {
+extern "C" int cdr_gemm_f32_ex(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                               int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                               const float* rowscale, int act, int accumulate) {
     CDR_CHECK_ARG(A && B && C);
     CDR_CHECK_ARG(M > 0 && N > 0 && K > 0);
     CDR_CHECK_ARG(act >= CDR_ACT_NONE && act <= CDR_ACT_SIGMOID);
+    CDR_CHECK_ARG(accumulate >= 0 && accumulate <= 2);
     CDR_CHECK_ARG(((M + 127) / 128) * ((N + 127) / 128) < (int64_t)1 << 31);
     hipStream_t s = (hipStream_t)stream;
-    if (!transA && transB) return launch<false, true, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr);
-    if (!transA && !transB) return launch<false, false, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr);
-    if (transA && !transB) return launch<true, false, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr);
-    return launch<true, true, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr);
+    if (!transA && transB) return launch<false, true, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr, rowscale);
+    if (!transA && !transB) return launch<false, false, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr, rowscale);
+    if (transA && !transB) return launch<true, false, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr, rowscale);
+    return launch<true, true, false>(s, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, nullptr, nullptr, rowscale);
+}
+
+extern "C" int cdr_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                            int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                            int accumulate) {
+    return cdr_gemm_f32_ex(stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, act, accumulate);
 }
 
 extern "C" int cdr_fullsort_scores_f32(void* stream, const float* user_e, int64_t U, int D, const float* slab0, int64_t n0,

@@ -1,0 +1,295 @@
+// BiTGCF propagation kernels (recbole_cdr/model/cross_domain_recommender/bitgcf.py:130-205):
+//   spmm_csr_kernel      side = A x E over a CSR adjacency, with the graph-layer math fused into the epilogue
+//                          fwd : new = E + side + E (.) side            (bitgcf.py:130-135, dropout = identity)
+//                          bwd : gE  = gnew (.) (1 + side) + A x tmp     (A is symmetric: A^T = A), tmp = gnew (.) (1 + E)
+//   transfer_*_kernel    bi-directional transfer on the overlapped rows (bitgcf.py:137-172), other rows pass through
+//   l2_normalize_*       F.normalize(x, p=2, dim=1) written straight into a column block of the concat buffer
+//   colblock_mean_*      connect_way == 'mean'
+// One lane group of LPR = D/4 lanes per output row (float4 per lane): 64/LPR rows per wave-instruction; the gather of
+// E[col] rows is the HBM/L2 traffic that bounds the kernel (4D+12 bytes per non-zero).
+#include "cdr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_cap(int64_t blocks) {
+    const int64_t cap = CDR_NUM_CU * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// MODE 0: out = acc ; MODE 1: side_out = acc, out = x + acc + x*acc (x = X[r]) ; MODE 2: out = G[r]*(1 + S[r]) + acc
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+                                                          const float* __restrict__ values, int64_t n_rows,
+                                                          const float* __restrict__ E, int D, const float* __restrict__ X,
+                                                          const float* __restrict__ S, float* __restrict__ side_out,
+                                                          float* __restrict__ out) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    for (int64_t r = gg; r < n_rows; r += TG) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        for (int ch = sub; ch < D4; ch += LPR) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int64_t j = b;
+            for (; j + 1 < e; j += 2) {          // two independent row fetches in flight
+                const int64_t c0 = indices[j], c1 = indices[j + 1];
+                const float v0 = values[j], v1 = values[j + 1];
+                const float4 x0 = ld4(E + c0 * D + 4 * ch), x1 = ld4(E + c1 * D + 4 * ch);
+                acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+                acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
+            }
+            if (j < e) {
+                const int64_t c0 = indices[j];
+                const float v0 = values[j];
+                const float4 x0 = ld4(E + c0 * D + 4 * ch);
+                acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+            }
+            float* o = out + r * D + 4 * ch;
+            if (MODE == 0) {
+                st4(o, acc);
+            } else if (MODE == 1) {
+                const float4 x = ld4(X + r * D + 4 * ch);
+                st4(side_out + r * D + 4 * ch, acc);
+                // reference order: new = side + x*side ; new = x + new
+                st4(o, make_float4(x.x + (acc.x + x.x * acc.x), x.y + (acc.y + x.y * acc.y),
+                                   x.z + (acc.z + x.z * acc.z), x.w + (acc.w + x.w * acc.w)));
+            } else {
+                const float4 g = ld4(X + r * D + 4 * ch), s = ld4(S + r * D + 4 * ch);
+                st4(o, make_float4(g.x * (1.f + s.x) + acc.x, g.y * (1.f + s.y) + acc.y, g.z * (1.f + s.z) + acc.z,
+                                   g.w * (1.f + s.w) + acc.w));
+            }
+        }
+    }
+}
+
+// tmp = g (.) (1 + x)
+__global__ __launch_bounds__(kBlock) void mul_one_plus_kernel(const float* __restrict__ g, const float* __restrict__ x, int64_t n,
+                                                              float* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) out[e] = g[e] * (1.0f + x[e]);
+}
+
+// rows < n_overlap : lam/lap mix (reference operation order) ; other rows: copy
+__global__ __launch_bounds__(kBlock) void transfer_fwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
+                                                              const float* __restrict__ ds, const float* __restrict__ dt,
+                                                              int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t,
+                                                              float* __restrict__ So, float* __restrict__ To) {
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const float s = S[e], t = T[e];
+        if (r < n_overlap) {
+            const float a = ds[r], b = dt[r];
+            const float lap = (a * s + b * t) / ((a + b) + 1e-7f);
+            const float s_lam = lam_s * s + (1.0f - lam_s) * t;
+            const float t_lam = lam_t * t + (1.0f - lam_t) * s;
+            So[e] = (s_lam + lap) / 2.0f;
+            To[e] = (t_lam + lap) / 2.0f;
+        } else {
+            So[e] = s; To[e] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void transfer_bwd_kernel(const float* __restrict__ gSo, const float* __restrict__ gTo,
+                                                              const float* __restrict__ ds, const float* __restrict__ dt,
+                                                              int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t,
+                                                              float* __restrict__ gS, float* __restrict__ gT) {
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const float a = gSo[e], b = gTo[e];
+        if (r < n_overlap) {
+            const float dsv = ds[r], dtv = dt[r];
+            const float dl = (dsv + dtv) + 1e-7f;
+            const float ws = dsv / dl, wt = dtv / dl;
+            gS[e] = 0.5f * (a * (lam_s + ws) + b * ((1.0f - lam_t) + ws));
+            gT[e] = 0.5f * (a * ((1.0f - lam_s) + wt) + b * (lam_t + wt));
+        } else {
+            gS[e] = a; gT[e] = b;
+        }
+    }
+}
+
+// y = x / max(||x||_2, 1e-12), y written with leading dimension ldo (column block of the concat buffer); one wave per row
+__global__ __launch_bounds__(kBlock) void l2_normalize_fwd_kernel(const float* __restrict__ x, int64_t rows, int D,
+                                                                  float* __restrict__ y, int64_t ldo, float* __restrict__ norm_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    for (int64_t r = w; r < rows; r += TW) {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) { const float v = x[r * D + c]; s += v * v; }
+        s = group_sum<64>(s);
+        const float nrm = sqrtf(s);
+        const float den = fmaxf(nrm, 1e-12f);
+        for (int c = lane; c < D; c += 64) y[r * ldo + c] = x[r * D + c] / den;
+        if (lane == 0 && norm_out) norm_out[r] = nrm;
+    }
+}
+
+// gx (+)= (gy - y (y . gy)) / max(norm, eps), y = x / max(norm, eps) ; gy read with leading dimension ldg
+__global__ __launch_bounds__(kBlock) void l2_normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norm,
+                                                                  const float* __restrict__ gy, int64_t ldg, int64_t rows, int D,
+                                                                  float* __restrict__ gx, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    for (int64_t r = w; r < rows; r += TW) {
+        const float den = fmaxf(norm[r], 1e-12f);
+        float d = 0.f;
+        for (int c = lane; c < D; c += 64) d += (x[r * D + c] / den) * gy[r * ldg + c];
+        d = group_sum<64>(d);
+        // below the clamp the forward is x / eps (linear): no projection term
+        const float proj = norm[r] > 1e-12f ? d : 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float v = (gy[r * ldg + c] - (x[r * D + c] / den) * proj) / den;
+            gx[r * D + c] = (accumulate ? gx[r * D + c] : 0.f) + v;
+        }
+    }
+}
+
+// out[r, c] (ldo) = src[r, c] (lds)     /     dst[r,c] (+)= src[r,c]
+__global__ __launch_bounds__(kBlock) void copy_cols_kernel(const float* __restrict__ src, int64_t lds, int64_t rows, int D,
+                                                           float* __restrict__ dst, int64_t ldo, int accumulate) {
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const int c = (int)(e - r * D);
+        const float v = src[r * lds + c];
+        dst[r * ldo + c] = accumulate ? dst[r * ldo + c] + v : v;
+    }
+}
+
+// out[r,c] = (sum_l cat[r, l*D + c]) / nb  (torch.mean over the stacked layer outputs, in layer order)
+__global__ __launch_bounds__(kBlock) void colblock_mean_fwd_kernel(const float* __restrict__ cat, int64_t rows, int D, int nb,
+                                                                   float* __restrict__ out) {
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const int c = (int)(e - r * D);
+        float s = 0.f;
+        for (int l = 0; l < nb; ++l) s += cat[r * (int64_t)nb * D + (int64_t)l * D + c];
+        out[e] = s / (float)nb;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void colblock_mean_bwd_kernel(const float* __restrict__ gout, int64_t rows, int D, int nb,
+                                                                   float* __restrict__ gcat) {
+    const int64_t total = rows * D * nb, stride = (int64_t)gridDim.x * kBlock;
+    const int64_t W = (int64_t)nb * D;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / W;
+        const int c = (int)((e - r * W) % D);
+        gcat[e] = gout[r * D + c] / (float)nb;
+    }
+}
+
+}  // namespace
+
+#define GR_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
+
+#define DISPATCH_LPR(lpr, ...)                                  \
+    switch (lpr) {                                              \
+        case 1: { constexpr int L = 1; __VA_ARGS__; } break;    \
+        case 2: { constexpr int L = 2; __VA_ARGS__; } break;    \
+        case 4: { constexpr int L = 4; __VA_ARGS__; } break;    \
+        case 8: { constexpr int L = 8; __VA_ARGS__; } break;    \
+        case 16: { constexpr int L = 16; __VA_ARGS__; } break;  \
+        case 32: { constexpr int L = 32; __VA_ARGS__; } break;  \
+        default: { constexpr int L = 64; __VA_ARGS__; } break;  \
+    }
+
+extern "C" int cdr_spmm_csr_f32(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
+                                int64_t n_rows, const float* E, int D, float* out) {
+    CDR_CHECK_ARG(indptr && indices && values && E && out && n_rows > 0 && D > 0 && (D & 3) == 0);
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    DISPATCH_LPR(lpr, spmm_csr_kernel<L, 0><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, E,
+                                                                                                 D, nullptr, nullptr, nullptr, out));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_graph_layer_fwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
+                                   int64_t n_rows, const float* E, int D, float* side_out, float* new_out) {
+    CDR_CHECK_ARG(indptr && indices && values && E && side_out && new_out && n_rows > 0 && D > 0 && (D & 3) == 0);
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    DISPATCH_LPR(lpr, spmm_csr_kernel<L, 1><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, E,
+                                                                                                 D, E, nullptr, side_out, new_out));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
+                                   int64_t n_rows, const float* E, const float* side, const float* gnew, int D, float* tmp,
+                                   float* gE) {
+    CDR_CHECK_ARG(indptr && indices && values && E && side && gnew && tmp && gE && n_rows > 0 && D > 0 && (D & 3) == 0);
+    mul_one_plus_kernel<<<GR_GRID(n_rows * D)>>>(gnew, E, n_rows * D, tmp);
+    CDR_LAUNCH_CHECK();
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    DISPATCH_LPR(lpr, spmm_csr_kernel<L, 2><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, tmp,
+                                                                                                 D, gnew, side, nullptr, gE));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_transfer_fwd(void* stream, const float* S, const float* T, const float* deg_s, const float* deg_t,
+                                int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* S_out, float* T_out) {
+    CDR_CHECK_ARG(S && T && deg_s && deg_t && S_out && T_out && rows > 0 && D > 0);
+    transfer_fwd_kernel<<<GR_GRID(rows * D)>>>(S, T, deg_s, deg_t, rows, D, n_overlap, lam_s, lam_t, S_out, T_out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_transfer_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,
+                                int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* gS, float* gT) {
+    CDR_CHECK_ARG(gS_out && gT_out && deg_s && deg_t && gS && gT && rows > 0 && D > 0);
+    transfer_bwd_kernel<<<GR_GRID(rows * D)>>>(gS_out, gT_out, deg_s, deg_t, rows, D, n_overlap, lam_s, lam_t, gS, gT);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_l2_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, int64_t ldo, float* norm_out) {
+    CDR_CHECK_ARG(x && y && rows > 0 && D > 0 && ldo >= D);
+    l2_normalize_fwd_kernel<<<dim3(grid_cap((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream>>>(x, rows, D, y, ldo, norm_out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const float* gy, int64_t ldg, int64_t rows,
+                                    int D, float* gx, int accumulate) {
+    CDR_CHECK_ARG(x && norm && gy && gx && rows > 0 && D > 0 && ldg >= D);
+    l2_normalize_bwd_kernel<<<dim3(grid_cap((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream>>>(x, norm, gy, ldg, rows, D, gx,
+                                                                                                     accumulate);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_copy_cols(void* stream, const float* src, int64_t lds, int64_t rows, int D, float* dst, int64_t ldo,
+                             int accumulate) {
+    CDR_CHECK_ARG(src && dst && rows > 0 && D > 0 && lds >= D && ldo >= D);
+    copy_cols_kernel<<<GR_GRID(rows * D)>>>(src, lds, rows, D, dst, ldo, accumulate);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_colblock_mean_fwd(void* stream, const float* cat, int64_t rows, int D, int nb, float* out) {
+    CDR_CHECK_ARG(cat && out && rows > 0 && D > 0 && nb > 0);
+    colblock_mean_fwd_kernel<<<GR_GRID(rows * D)>>>(cat, rows, D, nb, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, int nb, float* gcat) {
+    CDR_CHECK_ARG(gout && gcat && rows > 0 && D > 0 && nb > 0);
+    colblock_mean_bwd_kernel<<<GR_GRID(rows * D * nb)>>>(gout, rows, D, nb, gcat);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

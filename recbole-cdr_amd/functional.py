@@ -115,9 +115,17 @@ def gather_rows(weight, ids):
     return GatherRows.apply(weight, ids)
 
 
-def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=None, accumulate=False):
-    """C = act(op(a) @ op(b) + bias) on the fp32 MFMA kernel; 2-D contiguous operands."""
-    _dev_check(a, b, bias)
+def _ld(t):
+    """Leading dimension of a 2-D operand whose rows are unit-stride (column slices of a wider matrix are fine)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError('gemm operands must be 2-D with unit column stride')
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=None, accumulate=0, rowscale=None):
+    """C = epi(op(a) @ op(b)) on the fp32 MFMA kernel.  accumulate: 0 act(v+bias) ; 1 act(v+bias)+C ; 2 act((C+v)+bias),
+    v = rowscale[m] * acc."""
+    _dev_check(a, b, bias, rowscale)
     M = a.shape[1] if trans_a else a.shape[0]
     K = a.shape[0] if trans_a else a.shape[1]
     N = b.shape[0] if trans_b else b.shape[1]
@@ -126,8 +134,9 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=Non
         raise ValueError(f'gemm: inner dimensions differ ({K} vs {Kb})')
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    B_.call('cdr_gemm_f32', B_.stream(), int(trans_a), int(trans_b), M, N, K, B_.f32(a), a.shape[1], B_.f32(b), b.shape[1],
-            B_.f32(out), N, B_.f32(bias), int(act), int(accumulate))
+    B_.call('cdr_gemm_f32_ex', B_.stream(), int(trans_a), int(trans_b), M, N, K, B_._c_ptr(a.data_ptr()), _ld(a),
+            B_._c_ptr(b.data_ptr()), _ld(b), B_._c_ptr(out.data_ptr()), _ld(out), B_.f32(bias), B_.f32(rowscale), int(act),
+            int(accumulate))
     return out
 
 
@@ -227,6 +236,137 @@ def fullsort_neg_sqdist(user_e, items):
     out = torch.empty(U, N, device=user_e.device, dtype=torch.float32)
     scratch = torch.empty(U + N, device=user_e.device, dtype=torch.float32)
     B_.call('cdr_fullsort_neg_sqdist_f32', B_.stream(), B_.f32(user_e), U, D, B_.f32(items), N, B_.f32(scratch), B_.f32(out))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- CoNet pieces
+class GatherConcat2(Function):
+    """cat([A[ida], B[idb]], dim=1) in one buffer (conet.py:106-111) with the dense scatter-add backward."""
+
+    @staticmethod
+    def forward(ctx, wa, wb, ida, idb):
+        _dev_check(wa, wb, ida, idb)
+        ida, idb = _ids(ida), _ids(idb)
+        n, D = ida.numel(), wa.shape[1]
+        out = torch.empty(n, 2 * D, device=wa.device, dtype=torch.float32)
+        B_.call('cdr_gather_rows_ld', B_.stream(), B_.f32(wa), D, B_.i64(ida), n, B_.f32(out), 2 * D)
+        B_.call('cdr_gather_rows_ld', B_.stream(), B_.f32(wb), D, B_.i64(idb), n, B_._c_ptr(out.data_ptr() + 4 * D), 2 * D)
+        ctx.save_for_backward(ida, idb)
+        ctx.shapes = (tuple(wa.shape), tuple(wb.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ida, idb = ctx.saved_tensors
+        g = g.contiguous()
+        D = ctx.shapes[0][1]
+        ga = torch.zeros(ctx.shapes[0], device=g.device, dtype=torch.float32)
+        gb = torch.zeros(ctx.shapes[1], device=g.device, dtype=torch.float32)
+        B_.call('cdr_scatter_add_rows_ld', B_.stream(), B_.f32(ga), D, B_.i64(ida), ida.numel(), B_.f32(g), 2 * D)
+        B_.call('cdr_scatter_add_rows_ld', B_.stream(), B_.f32(gb), D, B_.i64(idb), idb.numel(),
+                B_._c_ptr(g.data_ptr() + 4 * D), 2 * D)
+        return ga, gb, None, None
+
+
+def overlap_mask(ids, n_overlap):
+    ids = _ids(ids)
+    out = torch.empty(ids.numel(), device=ids.device, dtype=torch.float32)
+    B_.call('cdr_overlap_mask', B_.stream(), B_.i64(ids), ids.numel(), int(n_overlap), B_.f32(out))
+    return out
+
+
+def _rowscale(x, scale):
+    out = torch.empty_like(x)
+    B_.call('cdr_rowscale', B_.stream(), B_.f32(x), B_.f32(scale), x.shape[0], x.shape[1], B_.f32(out))
+    return out
+
+
+def _act_bwd(act, y, gy):
+    gz = torch.empty_like(gy)
+    B_.call('cdr_act_bwd', B_.stream(), act, B_.f32(y), B_.f32(gy), B_.f32(gz), gy.numel())
+    return gz
+
+
+def _colsum(x):
+    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    B_.call('cdr_colsum', B_.ctx(x.device), B_.stream(), B_.f32(x), x.shape[0], x.shape[1], B_.f32(out), 0)
+    return out
+
+
+class CrossUnit(Function):
+    """One CoNet cross-connection layer for both towers (conet.py:118-137):
+         s' = relu(s Ws^T + bs + m (.) (t H^T)),  t' = relu(t Wt^T + bt + m (.) (s H^T)),  m = 1 on overlapped rows."""
+
+    @staticmethod
+    def forward(ctx, s, t, Ws, bs, Wt, bt, H, m):
+        s, t = s.contiguous(), t.contiguous()
+        so = gemm(s, Ws, trans_b=True, bias=bs)
+        gemm(t, H, trans_b=True, out=so, accumulate=2, rowscale=m, act=B_.ACT_RELU)
+        to = gemm(t, Wt, trans_b=True, bias=bt)
+        gemm(s, H, trans_b=True, out=to, accumulate=2, rowscale=m, act=B_.ACT_RELU)
+        ctx.save_for_backward(s, t, Ws, Wt, H, m, so, to)
+        return so, to
+
+    @staticmethod
+    def backward(ctx, gso, gto):
+        s, t, Ws, Wt, H, m, so, to = ctx.saved_tensors
+        gzs = _act_bwd(B_.ACT_RELU, so, gso.contiguous())
+        gzt = _act_bwd(B_.ACT_RELU, to, gto.contiguous())
+        mgzs, mgzt = _rowscale(gzs, m), _rowscale(gzt, m)
+        gWs = gemm(gzs, s, trans_a=True)
+        gWt = gemm(gzt, t, trans_a=True)
+        gH = gemm(mgzs, t, trans_a=True)
+        gemm(mgzt, s, trans_a=True, out=gH, accumulate=1)
+        gs = gemm(gzs, Ws)
+        gemm(mgzt, H, out=gs, accumulate=1)
+        gt = gemm(gzt, Wt)
+        gemm(mgzs, H, out=gt, accumulate=1)
+        return gs, gt, gWs, _colsum(gzs), gWt, _colsum(gzt), gH, None
+
+
+class BCEProbLoss(Function):
+    """nn.BCELoss() on probabilities (conet.py:63,195-196)."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        p_, y_ = p.reshape(-1).contiguous(), y.reshape(-1).contiguous().to(torch.float32)
+        out = torch.empty(1, device=p.device, dtype=torch.float32)
+        B_.call('cdr_bce_prob_fwd', B_.ctx(p.device), B_.stream(), B_.f32(p_), B_.f32(y_), p_.numel(), B_.f32(out))
+        ctx.save_for_backward(p_, y_)
+        ctx.pshape = tuple(p.shape)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        p_, y_ = ctx.saved_tensors
+        gp = torch.empty_like(p_)
+        B_.call('cdr_bce_prob_bwd', B_.stream(), B_.f32(p_), B_.f32(y_), p_.numel(), B_.f32(go.reshape(-1).contiguous()), B_.f32(gp))
+        return gp.view(ctx.pshape), None
+
+
+class FrobeniusNorm(Function):
+    """torch.norm(W) (conet.py:198-201)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        w_ = w.contiguous()
+        out = torch.empty(1, device=w.device, dtype=torch.float32)
+        B_.call('cdr_frobenius_fwd', B_.ctx(w.device), B_.stream(), B_.f32(w_), w_.numel(), B_.f32(out))
+        ctx.save_for_backward(w_, out)
+        return out.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        w_, norm = ctx.saved_tensors
+        gw = torch.empty_like(w_)
+        B_.call('cdr_frobenius_bwd', B_.stream(), B_.f32(w_), w_.numel(), B_.f32(norm), B_.f32(go.reshape(-1).contiguous()),
+                B_.f32(gw), 0)
+        return gw
+
+
+def bcast_add_act(P, q, act):
+    out = torch.empty_like(P)
+    B_.call('cdr_bcast_add_act', B_.stream(), B_.f32(P), B_.f32(q.contiguous()), P.shape[0], P.shape[1], int(act), B_.f32(out))
     return out
 
 

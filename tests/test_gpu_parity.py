@@ -376,3 +376,58 @@ def test_trainer_phase_loop_matches_oracle_training():
     for k, v in model.named_parameters():
         # a few Adam steps from zero state are ~ lr * sign(g): compare with an absolute bound of 2% of one step
         assert_close(v, params[k], rtol=1e-4, atol=0.01 * 2e-2, what=k)
+
+
+@pytest.mark.parametrize('name', cases('conet_'))
+def test_conet_golden(name):
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    g = Golden(name)
+    ids = g.idspace()
+    cfg = base_config(DEV, embedding_size=int(g.meta('D')), reg_weight=0.01,
+                      mlp_hidden_size=[int(x) for x in g.meta('mlp_hidden_size')])
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    load_params(model, g.group('param'))
+    inter = to_dev(g.group('in'), DEV)
+    with torch.no_grad():
+        assert_close(model.source_forward(inter['source_user_id'], inter['source_item_id']), g['fwd/source'], what='source_forward')
+        assert_close(model.target_forward(inter['target_user_id'], inter['target_item_id']), g['fwd/target'], what='target_forward')
+    loss = model.calculate_loss(inter)
+    assert_close(loss, g['loss/BOTH'], what='loss')
+    loss.backward()
+    _check_grads(model, g, 'BOTH')
+    ev = to_dev(g.group('evalin'), DEV)
+    p = model.predict(ev)
+    assert tuple(p.shape) == tuple(g['predict/BOTH'].shape)
+    assert_close(p, g['predict/BOTH'], what='predict')
+    fs = model.full_sort_predict(ev)
+    assert tuple(fs.shape) == tuple(g['fullsort/BOTH'].shape)
+    assert_close(fs, g['fullsort/BOTH'], what='fullsort')
+
+
+def test_conet_c3_shape_vs_oracle():
+    """CoNet at BASELINE C3's layer shape (D=128, [256,64,32,16,8], k=4 pointwise) on a down-scaled id space, vs the oracle."""
+    from oracle import conet as oconet
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    torch.manual_seed(4)
+    ids = IdSpace(OU=300, TOU=500, SOU=700, OI=1, TOI=900, SOI=1100)
+    cfg = base_config(DEV, embedding_size=128, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    S = 819
+    def batch(users, items):
+        u = torch.from_numpy(np.random.RandomState(1).choice(users, S)).repeat(5)
+        i = torch.from_numpy(np.random.RandomState(2).choice(items, S * 5))
+        y = torch.cat([torch.ones(S), torch.zeros(4 * S)])
+        return u, i, y
+    su, si, sy = batch(np.r_[np.arange(1, ids.OU), np.arange(ids.OU + ids.TOU, ids.total_num_users)], np.arange(ids.OI + ids.TOI, ids.total_num_items))
+    tu, ti, ty = batch(np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI))
+    inter = {'source_user_id': su, 'source_item_id': si, 'source_label': sy, 'target_user_id': tu, 'target_item_id': ti, 'target_label': ty}
+    ref = oconet.calculate_loss(params, ids, inter)
+    ref.backward()
+    loss = model.calculate_loss(to_dev(inter, DEV))
+    assert_close(loss, ref, what='loss')
+    loss.backward()
+    for k, v in model.named_parameters():
+        if params[k].grad is not None:
+            assert_close(v.grad, params[k].grad, rtol=2e-5, atol=2e-5 * float(params[k].grad.abs().max()) + 1e-10, what=k)
