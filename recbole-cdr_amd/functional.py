@@ -364,6 +364,59 @@ class FrobeniusNorm(Function):
         return gw
 
 
+# ---------------------------------------------------------------------------------------------------- SSCDR pieces
+class SqnormNormalize(Function):
+    """SSCDR.embedding_normalize (sscdr.py:120-124): e / max(sum e^2, 1) -- the SQUARED length, quirk kept."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _dev_check(x)
+        x_ = x.contiguous()
+        y = torch.empty_like(x_)
+        ln = torch.empty(x_.shape[0], device=x.device, dtype=torch.float32)
+        B_.call('cdr_sqnorm_normalize_fwd', B_.stream(), B_.f32(x_), x_.shape[0], x_.shape[1], B_.f32(y), B_.f32(ln))
+        ctx.save_for_backward(x_, ln)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_, ln = ctx.saved_tensors
+        gx = torch.empty_like(x_)
+        B_.call('cdr_sqnorm_normalize_bwd', B_.stream(), B_.f32(x_), B_.f32(ln), B_.f32(gy.contiguous()), x_.shape[0],
+                x_.shape[1], B_.f32(gx))
+        return gx
+
+
+def sqnorm_normalize(x):
+    return SqnormNormalize.apply(x)
+
+
+class TripletMarginLoss(Function):
+    """nn.TripletMarginLoss(margin) with torch's defaults p=2, eps=1e-6, mean (sscdr.py:69)."""
+
+    @staticmethod
+    def forward(ctx, a, p, n, margin):
+        _dev_check(a, p, n)
+        a_, p_, n_ = a.contiguous(), p.contiguous(), n.contiguous()
+        rows, D = a_.shape
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        dap = torch.empty(rows, device=a.device, dtype=torch.float32)
+        dan = torch.empty(rows, device=a.device, dtype=torch.float32)
+        B_.call('cdr_triplet_fwd', B_.ctx(a.device), B_.stream(), B_.f32(a_), B_.f32(p_), B_.f32(n_), rows, D, float(margin),
+                1e-6, B_.f32(out), B_.f32(dap), B_.f32(dan))
+        ctx.save_for_backward(a_, p_, n_, dap, dan)
+        ctx.margin = float(margin)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        a_, p_, n_, dap, dan = ctx.saved_tensors
+        ga, gp, gn = torch.empty_like(a_), torch.empty_like(p_), torch.empty_like(n_)
+        B_.call('cdr_triplet_bwd', B_.stream(), B_.f32(a_), B_.f32(p_), B_.f32(n_), a_.shape[0], a_.shape[1], ctx.margin, 1e-6,
+                B_.f32(dap), B_.f32(dan), B_.f32(go.reshape(-1).contiguous()), B_.f32(ga), B_.f32(gp), B_.f32(gn))
+        return ga, gp, gn, None
+
+
 def bcast_add_act(P, q, act):
     out = torch.empty_like(P)
     B_.call('cdr_bcast_add_act', B_.stream(), B_.f32(P), B_.f32(q.contiguous()), P.shape[0], P.shape[1], int(act), B_.f32(out))

@@ -1,0 +1,202 @@
+"""SSCDR on libcdrhip -- same class contract as recbole_cdr/model/cross_domain_recommender/sscdr.py:23-259.
+
+Metric-learning losses = row gather -> squared-norm "normalize" -> triplet margin, all native kernels with native
+backward; the mapping is recbole's ``MLPLayers(..., 'tanh')`` (Linear + Tanh after EVERY layer, the last included --
+SURVEY App. A) on the fp32 MFMA contraction; scoring is the -||u - i||^2 epilogue of the same contraction.
+The semi-supervised (interacted, non-interacted) ids are drawn on the host from numpy's global RNG exactly as the
+reference does inside its loss (sscdr.py:89-118) so that a seeded run samples the same ids.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import binding as B_
+from ... import functional as F_
+from ...utils import InputType
+from ..crossdomain_recommender import CrossDomainRecommender, xavier_normal_initialization
+
+
+class MLPLayers(nn.Module):
+    """recbole.model.layers.MLPLayers restricted to what SSCDR uses (dropout=0, bn=False): parameter names match
+    (``mlp_layers.<3i+1>.weight``) so reference checkpoints load."""
+
+    def __init__(self, layers, activation='tanh'):
+        super().__init__()
+        mods = []
+        for d_in, d_out in zip(layers[:-1], layers[1:]):
+            mods += [nn.Dropout(p=0.0), nn.Linear(d_in, d_out), nn.Tanh()]
+        self.mlp_layers = nn.Sequential(*mods)
+
+    def forward(self, x):
+        for m in self.mlp_layers:
+            if isinstance(m, nn.Linear):
+                x = F_.linear(x, m.weight, m.bias, B_.ACT_TANH)
+        return x
+
+
+class SSCDR(CrossDomainRecommender):
+    input_type = InputType.PAIRWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
+            "SSCDR model only support user overlapped or item overlapped dataset! "
+        if self.overlapped_num_users > 1:
+            self.mode = 'overlap_users'
+        elif self.overlapped_num_items > 1:
+            self.mode = 'overlap_items'
+        else:
+            self.mode = 'non_overlap'
+        self.phase = None
+        self.embedding_size = config['embedding_size']
+        self.lamda = config['lambda']
+        self.margin = config['margin']
+        self.mlp_hidden_size = list(config['mlp_hidden_size'])
+        self.mapping_layer = MLPLayers([self.embedding_size] + self.mlp_hidden_size + [self.embedding_size])
+        if self.mode == 'overlap_users':
+            self.user_interacted_items = self.build_interacted_items(dataset, mode='user')
+        elif self.mode == 'overlap_items':
+            self.item_interacted_users = self.build_interacted_items(dataset, mode='item')
+        self.source_user_embedding = nn.Embedding(self.total_num_users, self.embedding_size)
+        self.source_item_embedding = nn.Embedding(self.total_num_items, self.embedding_size)
+        self.target_user_embedding = nn.Embedding(self.total_num_users, self.embedding_size)
+        self.target_item_embedding = nn.Embedding(self.total_num_items, self.embedding_size)
+        self.apply(xavier_normal_initialization)
+
+    def build_interacted_items(self, dataset, mode='user'):
+        ds = dataset.source_domain_dataset
+        uids = ds.inter_feat[ds.uid_field].cpu().numpy()
+        iids = ds.inter_feat[ds.iid_field].cpu().numpy()
+        if mode == 'user':
+            out = [[] for _ in range(self.total_num_users)]
+            for uid, iid in zip(uids, iids):
+                out[uid].append(iid)
+        else:
+            out = [[] for _ in range(self.total_num_items)]
+            for iid, uid in zip(iids, uids):
+                out[iid].append(uid)
+        return out
+
+    def sample(self, ids, mode='user'):
+        """Host-side, numpy global RNG, same draw order per id as sscdr.py:89-118 (and the same cache mutation)."""
+        ids = ids.cpu().numpy()
+        interacted = np.zeros_like(ids)
+        non_interacted = np.zeros_like(ids)
+        if mode == 'user':
+            cand = list(range(self.overlapped_num_items)) + list(range(self.target_num_items, self.total_num_items))
+            lists = self.user_interacted_items
+        else:
+            cand = list(range(self.overlapped_num_users)) + list(range(self.target_num_users, self.total_num_users))
+            lists = self.item_interacted_users
+        for index, id_ in enumerate(ids):
+            h = lists[id_]
+            if len(h) == 0:
+                h.append(0)
+            c = np.random.choice(cand, size=1)[0]
+            while c in h:
+                c = np.random.choice(cand, size=1)[0]
+            interacted[index] = np.random.choice(h, size=1)[0]
+            non_interacted[index] = c
+        return torch.from_numpy(interacted).to(self.device), torch.from_numpy(non_interacted).to(self.device)
+
+    embedding_normalize = staticmethod(F_.sqnorm_normalize)
+
+    def set_phase(self, phase):
+        self.phase = phase
+
+    def _domain_loss(self, interaction, domain):
+        U = getattr(self, f'{domain}_user_embedding').weight
+        I = getattr(self, f'{domain}_item_embedding').weight
+        pre = domain.upper()
+        ue = F_.gather_rows(U, interaction[getattr(self, f'{pre}_USER_ID')])
+        pe = F_.gather_rows(I, interaction[getattr(self, f'{pre}_ITEM_ID')])
+        ne = F_.gather_rows(I, interaction[getattr(self, f'{pre}_NEG_ITEM_ID')])
+        return F_.TripletMarginLoss.apply(F_.sqnorm_normalize(ue), F_.sqnorm_normalize(pe), F_.sqnorm_normalize(ne),
+                                          self.margin)
+
+    def calculate_source_loss(self, interaction):
+        return self._domain_loss(interaction, 'source')
+
+    def calculate_target_loss(self, interaction):
+        return self._domain_loss(interaction, 'target')
+
+    def calculate_map_loss(self, interaction):
+        idx = interaction[self.OVERLAP_ID].squeeze(1)
+        a, b = ('user', 'item') if self.mode == 'overlap_users' else ('item', 'user')
+        src = F_.gather_rows(getattr(self, f'source_{a}_embedding').weight, idx)
+        tgt = F_.gather_rows(getattr(self, f'target_{a}_embedding').weight, idx)
+        loss_s = F_.mse_loss(self.mapping_layer(src), tgt)
+        pos, neg = self.sample(idx, mode=a)
+        other = getattr(self, f'source_{b}_embedding').weight
+        mp = self.mapping_layer(F_.gather_rows(other, pos))
+        mn = self.mapping_layer(F_.gather_rows(other, neg))
+        loss_u = F_.TripletMarginLoss.apply(F_.sqnorm_normalize(tgt), F_.sqnorm_normalize(mp), F_.sqnorm_normalize(mn),
+                                            self.margin)
+        return loss_s + self.lamda * loss_u
+
+    def calculate_loss(self, interaction):
+        if self.phase == 'SOURCE':
+            return self.calculate_source_loss(interaction)
+        elif self.phase == 'OVERLAP':
+            return self.calculate_map_loss(interaction)
+        else:
+            return self.calculate_target_loss(interaction)
+
+    # ---- scoring --------------------------------------------------------------------------------------------------
+    def _mapped_rows(self, kind, ids, n_overlap):
+        src = F_.gather_rows(getattr(self, f'source_{kind}_embedding').weight, ids)
+        return F_.select_mapped(self.mapping_layer(src), getattr(self, f'target_{kind}_embedding').weight, ids, n_overlap)
+
+    @staticmethod
+    def _neg_rowdist(a, b):
+        """-sum((a-b)^2, 1) for explicit pairs: the triplet kernel's distance with eps=0, squared."""
+        rows, D = a.shape
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        dap = torch.empty(rows, device=a.device, dtype=torch.float32)
+        dan = torch.empty(rows, device=a.device, dtype=torch.float32)
+        a_, b_ = a.contiguous(), b.contiguous()
+        B_.call('cdr_triplet_fwd', B_.ctx(a.device), B_.stream(), B_.f32(a_), B_.f32(b_), B_.f32(b_), rows, D, 0.0, 0.0,
+                B_.f32(out), B_.f32(dap), B_.f32(dan))
+        # d^2 with the sign flipped: one more native elementwise pass (mse-style) would only restate dap*dap
+        return -(dap * dap)
+
+    @torch.no_grad()
+    def predict(self, interaction):
+        if self.phase in ('SOURCE', 'TARGET'):
+            d = self.phase.lower()
+            ue = F_.sqnorm_normalize(F_.gather_rows(getattr(self, f'{d}_user_embedding').weight,
+                                                    interaction[getattr(self, f'{self.phase}_USER_ID')]))
+            ie = F_.sqnorm_normalize(F_.gather_rows(getattr(self, f'{d}_item_embedding').weight,
+                                                    interaction[getattr(self, f'{self.phase}_ITEM_ID')]))
+            return self._neg_rowdist(ue, ie)
+        user, item = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
+        if self.mode == 'overlap_users':
+            ue = self._mapped_rows('user', user, self.overlapped_num_users)
+            ie = F_.gather_rows(self.target_item_embedding.weight, item)
+        else:
+            ue = F_.gather_rows(self.target_user_embedding.weight, user)
+            ie = self._mapped_rows('item', item, self.overlapped_num_items)
+        return self._neg_rowdist(F_.sqnorm_normalize(ue), F_.sqnorm_normalize(ie))
+
+    @torch.no_grad()
+    def full_sort_predict(self, interaction):
+        OI, TI = self.overlapped_num_items, self.target_num_items
+        if self.phase == 'SOURCE':
+            ue = F_.sqnorm_normalize(F_.gather_rows(self.source_user_embedding.weight, interaction[self.SOURCE_USER_ID]))
+            W = self.source_item_embedding.weight
+            all_item = torch.cat([F_.sqnorm_normalize(W[:OI]), F_.sqnorm_normalize(W[TI:])], dim=0)
+        elif self.phase == 'TARGET':
+            ue = F_.sqnorm_normalize(F_.gather_rows(self.target_user_embedding.weight, interaction[self.TARGET_USER_ID]))
+            all_item = F_.sqnorm_normalize(self.target_item_embedding.weight[:TI])
+        else:
+            user = interaction[self.TARGET_USER_ID]
+            if self.mode == 'overlap_users':
+                ue = self._mapped_rows('user', user, self.overlapped_num_users)
+                all_item = self.target_item_embedding.weight[:TI]
+            else:
+                ue = F_.gather_rows(self.target_user_embedding.weight, user)
+                ov = self.mapping_layer(self.source_item_embedding.weight[:OI])
+                all_item = torch.cat([ov, self.target_item_embedding.weight[OI:TI]], dim=0)
+            ue = F_.sqnorm_normalize(ue)
+            all_item = F_.sqnorm_normalize(all_item)
+        return F_.fullsort_neg_sqdist(ue, all_item).view(-1)

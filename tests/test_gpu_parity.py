@@ -431,3 +431,38 @@ def test_conet_c3_shape_vs_oracle():
     for k, v in model.named_parameters():
         if params[k].grad is not None:
             assert_close(v.grad, params[k].grad, rtol=2e-5, atol=2e-5 * float(params[k].grad.abs().max()) + 1e-10, what=k)
+
+
+@pytest.mark.parametrize('name', cases('sscdr_'))
+def test_sscdr_golden(name):
+    from recbole_cdr_amd.model.cross_domain_recommender.sscdr import SSCDR
+    g = Golden(name)
+    ids = g.idspace()
+    indptr, indices = g['aux/hist_indptr'], g['aux/hist_indices']
+    # rebuild the source interactions the reference's model was built from (its cached lists, in order)
+    mode_users = ids.mode == 'overlap_users'
+    own = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    pairs = np.stack([own, indices], 1) if mode_users else np.stack([indices, own], 1)
+    ds = FakeDataset(ids, s_pairs=pairs.astype(np.int64), t_pairs=np.zeros((1, 2), dtype=np.int64))
+    cfg = base_config(DEV, embedding_size=int(g.meta('D')), margin=float(g.meta('margin')),
+                      mlp_hidden_size=[int(x) for x in g.meta('mlp_hidden_size')], **{'lambda': float(g.meta('lam'))})
+    model = SSCDR(cfg, ds).to(DEV)
+    load_params(model, g.group('param'))
+    inter = to_dev(g.group('in'), DEV)
+    for phase in ('SOURCE', 'TARGET', 'BOTH', 'OVERLAP'):
+        model.set_phase(phase)
+        model.zero_grad(set_to_none=True)
+        np.random.seed(99)                      # the reference drew its semi-supervised ids from this seed
+        loss = model.calculate_loss(inter)
+        assert_close(loss, g[f'loss/{phase}'], what=f'{name}:{phase}:loss')
+        loss.backward()
+        _check_grads(model, g, phase)
+    np.random.seed(99)
+    pos, neg = model.sample(inter['overlap'].squeeze(1), mode='user' if mode_users else 'item')
+    np.testing.assert_array_equal(pos.cpu().numpy(), g['aux/sampled_pos'])
+    np.testing.assert_array_equal(neg.cpu().numpy(), g['aux/sampled_neg'])
+    ev = to_dev(g.group('evalin'), DEV)
+    for phase in ('SOURCE', 'TARGET', 'OVERLAP'):
+        model.set_phase(phase)
+        assert_close(model.predict(ev), g[f'predict/{phase}'], what=f'{name}:{phase}:predict')
+        assert_close(model.full_sort_predict(ev), g[f'fullsort/{phase}'], what=f'{name}:{phase}:fullsort')
