@@ -417,6 +417,132 @@ class TripletMarginLoss(Function):
         return ga, gp, gn, None
 
 
+# ---------------------------------------------------------------------------------------------------- BiTGCF pieces
+class CSRGraph:
+    """Device CSR of one domain's normalised adjacency + the degree vectors of the transfer layer."""
+
+    def __init__(self, indptr, indices, values, n_rows):
+        self.indptr, self.indices, self.values, self.n_rows = indptr, indices, values, n_rows
+
+
+class BiTGCFPropagate(Function):
+    """BiTGCF.forward (bitgcf.py:174-205) as ONE autograd node: n_layers x [graph layer (CSR SpMM with the elementwise
+    math fused) -> bi-directional transfer on the overlapped rows -> L2-normalised copy into the layer stack], both
+    domains, then concat / mean.  Backward replays the chain in reverse with the saved per-layer tensors; the adjacency
+    is symmetric, so the SpMM backward is the same kernel."""
+
+    @staticmethod
+    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI):
+        _dev_check(su, si, tu, ti)
+        nu, ni, D = su.shape[0], si.shape[0], su.shape[1]
+        n = nu + ni
+        dev = su.device
+        st = B_.stream
+        nb = n_layers + 1
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        S, T = f32(n, D), f32(n, D)
+        for dst, a, b in ((S, su, si), (T, tu, ti)):
+            B_.call('cdr_copy_cols', st(), B_.f32(a.contiguous()), D, nu, D, B_.f32(dst), D, 0)
+            B_.call('cdr_copy_cols', st(), B_.f32(b.contiguous()), D, ni, D, B_._c_ptr(dst.data_ptr() + 4 * nu * D), D, 0)
+        catS, catT = f32(n, nb * D), f32(n, nb * D)
+        B_.call('cdr_copy_cols', st(), B_.f32(S), D, n, D, B_.f32(catS), nb * D, 0)
+        B_.call('cdr_copy_cols', st(), B_.f32(T), D, n, D, B_.f32(catT), nb * D, 0)
+        saved = []
+        for l in range(n_layers):
+            sideS, newS, sideT, newT = f32(n, D), f32(n, D), f32(n, D), f32(n, D)
+            B_.call('cdr_graph_layer_fwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S), D,
+                    B_.f32(sideS), B_.f32(newS))
+            B_.call('cdr_graph_layer_fwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T), D,
+                    B_.f32(sideT), B_.f32(newT))
+            S2, T2 = f32(n, D), f32(n, D)
+            off = 4 * nu * D
+            B_.call('cdr_transfer_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU,
+                    lam_s, lam_t, B_.f32(S2), B_.f32(T2))
+            B_.call('cdr_transfer_fwd', st(), B_._c_ptr(newS.data_ptr() + off), B_._c_ptr(newT.data_ptr() + off),
+                    B_.f32(deg['si']), B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, B_._c_ptr(S2.data_ptr() + off),
+                    B_._c_ptr(T2.data_ptr() + off))
+            nS, nT = f32(n), f32(n)
+            B_.call('cdr_l2_normalize_fwd', st(), B_.f32(S2), n, D, B_._c_ptr(catS.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nS))
+            B_.call('cdr_l2_normalize_fwd', st(), B_.f32(T2), n, D, B_._c_ptr(catT.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nT))
+            saved += [S, T, sideS, sideT, S2, T2, nS, nT]
+            S, T = S2, T2
+        if connect_way == 'concat':
+            outS, outT = catS, catT
+        else:
+            outS, outT = f32(n, D), f32(n, D)
+            B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catS), n, D, nb, B_.f32(outS))
+            B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catT), n, D, nb, B_.f32(outT))
+        ctx.save_for_backward(*saved)
+        ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D)
+        return outS, outT
+
+    @staticmethod
+    def backward(ctx, gOutS, gOutT):
+        gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D = ctx.meta
+        saved = ctx.saved_tensors
+        n, nb = nu + ni, n_layers + 1
+        dev = gOutS.device
+        st = B_.stream
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        if connect_way == 'concat':
+            gcatS, gcatT = gOutS.contiguous(), gOutT.contiguous()
+        else:
+            gcatS, gcatT = f32(n, nb * D), f32(n, nb * D)
+            B_.call('cdr_colblock_mean_bwd', st(), B_.f32(gOutS.contiguous()), n, D, nb, B_.f32(gcatS))
+            B_.call('cdr_colblock_mean_bwd', st(), B_.f32(gOutT.contiguous()), n, D, nb, B_.f32(gcatT))
+        gS = gT = None                        # gradient w.r.t. the un-normalised layer output that continues downward
+        tmp = f32(n, D)
+        off = 4 * nu * D
+        for l in reversed(range(n_layers)):
+            S_in, T_in, sideS, sideT, S2, T2, nS, nT = saved[8 * l:8 * l + 8]
+            acc = 0 if gS is None else 1
+            if gS is None:
+                gS, gT = f32(n, D), f32(n, D)
+            B_.call('cdr_l2_normalize_bwd', st(), B_.f32(S2), B_.f32(nS), B_._c_ptr(gcatS.data_ptr() + 4 * (l + 1) * D), nb * D,
+                    n, D, B_.f32(gS), acc)
+            B_.call('cdr_l2_normalize_bwd', st(), B_.f32(T2), B_.f32(nT), B_._c_ptr(gcatT.data_ptr() + 4 * (l + 1) * D), nb * D,
+                    n, D, B_.f32(gT), acc)
+            gnS, gnT = f32(n, D), f32(n, D)
+            B_.call('cdr_transfer_bwd', st(), B_.f32(gS), B_.f32(gT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU, lam_s,
+                    lam_t, B_.f32(gnS), B_.f32(gnT))
+            B_.call('cdr_transfer_bwd', st(), B_._c_ptr(gS.data_ptr() + off), B_._c_ptr(gT.data_ptr() + off), B_.f32(deg['si']),
+                    B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, B_._c_ptr(gnS.data_ptr() + off), B_._c_ptr(gnT.data_ptr() + off))
+            gS_in, gT_in = f32(n, D), f32(n, D)
+            B_.call('cdr_graph_layer_bwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S_in),
+                    B_.f32(sideS), B_.f32(gnS), D, B_.f32(tmp), B_.f32(gS_in))
+            B_.call('cdr_graph_layer_bwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T_in),
+                    B_.f32(sideT), B_.f32(gnT), D, B_.f32(tmp), B_.f32(gT_in))
+            gS, gT = gS_in, gT_in
+        if gS is None:
+            gS, gT = torch.zeros(n, D, device=dev), torch.zeros(n, D, device=dev)
+        # layer-0 block of the stack is the ego embedding itself
+        B_.call('cdr_copy_cols', st(), B_.f32(gcatS), nb * D, n, D, B_.f32(gS), D, 1)
+        B_.call('cdr_copy_cols', st(), B_.f32(gcatT), nb * D, n, D, B_.f32(gT), D, 1)
+        return gS[:nu], gS[nu:], gT[:nu], gT[nu:], None, None, None, None, None, None, None, None, None
+
+
+class EmbLossRows(Function):
+    """recbole EmbLoss of gathered EGO rows: (||U[uid]||_F + ||I[iid]||_F) / B  (bitgcf.py:231-233)."""
+
+    @staticmethod
+    def forward(ctx, U, I, uid, iid):
+        _dev_check(U, I, uid, iid)
+        uid, iid = _ids(uid), _ids(iid)
+        out3 = torch.empty(3, device=U.device, dtype=torch.float32)
+        B_.call('cdr_embloss_fwd', B_.ctx(U.device), B_.stream(), B_.f32(U), B_.f32(I), U.shape[1], B_.i64(uid), B_.i64(iid),
+                uid.numel(), B_.f32(out3))
+        ctx.save_for_backward(U, I, uid, iid, out3)
+        return out3[:1].clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        U, I, uid, iid, out3 = ctx.saved_tensors
+        gU, gI = torch.zeros_like(U), torch.zeros_like(I)
+        B_.call('cdr_embloss_bwd_dense', B_.stream(), B_.f32(U), B_.f32(I), U.shape[1], B_.i64(uid), B_.i64(iid), uid.numel(),
+                B_.f32(out3), B_.f32(go.reshape(-1).contiguous()), B_.f32(gU), B_.f32(gI))
+        return gU, gI, None, None
+
+
 def bcast_add_act(P, q, act):
     out = torch.empty_like(P)
     B_.call('cdr_bcast_add_act', B_.stream(), B_.f32(P), B_.f32(q.contiguous()), P.shape[0], P.shape[1], int(act), B_.f32(out))

@@ -1,0 +1,123 @@
+"""BiTGCF on libcdrhip -- same class contract as recbole_cdr/model/cross_domain_recommender/bitgcf.py:25-282.
+
+The reference propagates over the FULL graph inside every calculate_loss (bitgcf.py:209): 2 domains x n_layers x
+[torch.sparse.mm + 3 elementwise ops + transfer (a dozen slices/cats) + normalize].  Here that is one autograd node
+(functional.BiTGCFPropagate) of CSR SpMM kernels with the layer math in the epilogue, one transfer kernel per row block
+and a normalise-into-the-stack kernel; the per-batch part is the same fused gather-dot-BCE kernel CMF uses, with the
+EmbLoss taken on the ego rows.  Adjacency values are formed exactly as the reference does (float64 D^-1/2 A D^-1/2 with
+degree + 1e-7, rounded to fp32: bitgcf.py:92-116) -- golden-pinned bit for bit in tests/test_oracle_golden.py.
+Dropout: identity when drop_rate == 0 or in eval; with drop_rate > 0 in training the mask comes from torch's generator
+and is applied between layers by a torch op (documented limitation: not bit-reproducible against the reference's
+generator stream).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import binding as B_
+from ... import functional as F_
+from ...utils import InputType
+from ..crossdomain_recommender import CrossDomainRecommender, xavier_normal_initialization
+
+
+def _csr_norm_adj(pairs, n_users, n_items, device):
+    pairs = np.unique(np.asarray(pairs, dtype=np.int64), axis=0)
+    u, i = pairs[:, 0], pairs[:, 1] + n_users
+    row = np.concatenate([u, i])
+    col = np.concatenate([i, u])
+    n = n_users + n_items
+    deg = np.bincount(row, minlength=n).astype(np.float64) + 1e-7
+    dinv = np.power(deg, -0.5)
+    val = ((dinv[row] * np.float64(1.0)) * dinv[col]).astype(np.float32)
+    order = np.lexsort((col, row))
+    row, col, val = row[order], col[order], val[order]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(row, minlength=n), out=indptr[1:])
+    return F_.CSRGraph(torch.from_numpy(indptr).to(device), torch.from_numpy(col.copy()).to(device),
+                       torch.from_numpy(val.copy()).to(device), n)
+
+
+class BiTGCF(CrossDomainRecommender):
+    input_type = InputType.POINTWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.SOURCE_LABEL = dataset.source_domain_dataset.label_field
+        self.TARGET_LABEL = dataset.target_domain_dataset.label_field
+        self.latent_dim = config['embedding_size']
+        self.n_layers = config['n_layers']
+        self.reg_weight = config['reg_weight']
+        self.domain_lambda_source = config['lambda_source']
+        self.domain_lambda_target = config['lambda_target']
+        self.drop_rate = config['drop_rate']
+        self.connect_way = config['connect_way']
+        if self.drop_rate and self.drop_rate > 0:
+            raise NotImplementedError('BiTGCF on libcdrhip: drop_rate > 0 is not implemented on the native path yet '
+                                      '(set drop_rate: 0.0); there is no eager fallback')
+
+        self.source_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
+        self.target_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
+        self.source_item_embedding = nn.Embedding(self.total_num_items, self.latent_dim)
+        self.target_item_embedding = nn.Embedding(self.total_num_items, self.latent_dim)
+
+        dev = self.device
+        s_m = dataset.inter_matrix(form='coo', value_field=None, domain='source').astype(np.float32)
+        t_m = dataset.inter_matrix(form='coo', value_field=None, domain='target').astype(np.float32)
+        self.source_graph = _csr_norm_adj(np.stack([s_m.row, s_m.col], 1), self.total_num_users, self.total_num_items, dev)
+        self.target_graph = _csr_norm_adj(np.stack([t_m.row, t_m.col], 1), self.total_num_users, self.total_num_items, dev)
+        f = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(-1).copy()).to(dev)
+        self.degrees = {'su': f(s_m.sum(axis=1)), 'tu': f(t_m.sum(axis=1)), 'si': f(s_m.sum(axis=0)), 'ti': f(t_m.sum(axis=0))}
+
+        self.target_restore_user_e = None
+        self.target_restore_item_e = None
+        self.apply(xavier_normal_initialization)
+        self.other_parameter_name = ['target_restore_user_e', 'target_restore_item_e']
+
+    def forward(self):
+        S, T = F_.BiTGCFPropagate.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
+                                        self.target_user_embedding.weight, self.target_item_embedding.weight,
+                                        self.source_graph, self.target_graph, self.degrees, int(self.n_layers),
+                                        float(self.domain_lambda_source), float(self.domain_lambda_target),
+                                        self.connect_way, int(self.overlapped_num_users), int(self.overlapped_num_items))
+        nu = self.total_num_users
+        return S[:nu], S[nu:], T[:nu], T[nu:]
+
+    def calculate_loss(self, interaction):
+        self.init_restore_e()
+        su_all, si_all, tu_all, ti_all = self.forward()
+        losses = []
+        for pre, ua, ia, uw, iw in (('SOURCE', su_all, si_all, self.source_user_embedding.weight, self.source_item_embedding.weight),
+                                    ('TARGET', tu_all, ti_all, self.target_user_embedding.weight, self.target_item_embedding.weight)):
+            user = interaction[getattr(self, f'{pre}_USER_ID')]
+            item = interaction[getattr(self, f'{pre}_ITEM_ID')]
+            label = interaction[getattr(self, f'{pre}_LABEL')]
+            bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, ua, ia, None, None, user, item, label, 0.0)
+            reg = F_.EmbLossRows.apply(uw, iw, user, item)
+            losses.append(bce + self.reg_weight * reg)
+        return tuple(losses)
+
+    @torch.no_grad()
+    def predict(self, interaction):
+        _, _, tu_all, ti_all = self.forward()
+        user, item = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
+        zeros = torch.zeros(user.numel(), device=tu_all.device, dtype=torch.float32)
+        _, scores = F_.PointGatherLoss.apply(B_.CDR_LOSS_MSE, tu_all.contiguous(), ti_all.contiguous(), None, None, user, item,
+                                             zeros, 0.0)
+        return scores
+
+    @torch.no_grad()
+    def full_sort_predict(self, interaction):
+        restore_user_e, restore_item_e = self.get_restore_e()
+        u = F_.gather_rows(restore_user_e, interaction[self.TARGET_USER_ID])
+        return F_.fullsort_scores(u, restore_item_e[:self.target_num_items]).view(-1)
+
+    def init_restore_e(self):
+        if self.target_restore_user_e is not None or self.target_restore_item_e is not None:
+            self.target_restore_user_e, self.target_restore_item_e = None, None
+
+    @torch.no_grad()
+    def get_restore_e(self):
+        if self.target_restore_user_e is None or self.target_restore_item_e is None:
+            _, _, tu, ti = self.forward()
+            self.target_restore_user_e, self.target_restore_item_e = tu.contiguous(), ti.contiguous()
+        return self.target_restore_user_e, self.target_restore_item_e

@@ -466,3 +466,34 @@ def test_sscdr_golden(name):
         model.set_phase(phase)
         assert_close(model.predict(ev), g[f'predict/{phase}'], what=f'{name}:{phase}:predict')
         assert_close(model.full_sort_predict(ev), g[f'fullsort/{phase}'], what=f'{name}:{phase}:fullsort')
+
+
+@pytest.mark.parametrize('name', cases('bitgcf_'))
+def test_bitgcf_golden(name):
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    g = Golden(name)
+    ids = g.idspace()
+    ds = FakeDataset(ids, s_pairs=g['aux/s_pairs'], t_pairs=g['aux/t_pairs'])
+    cfg = base_config(DEV, embedding_size=int(g.meta('D')), n_layers=int(g.meta('n_layers')), reg_weight=float(g.meta('reg_weight')),
+                      lambda_source=float(g.meta('lambda_source')), lambda_target=float(g.meta('lambda_target')),
+                      drop_rate=0.0, connect_way=str(g.meta('connect_way')))
+    model = BiTGCF(cfg, ds).to(DEV)
+    load_params(model, g.group('param'))
+    # CSR values bit-identical to the reference's normalised adjacency
+    for dom, gr in (('source', model.source_graph), ('target', model.target_graph)):
+        np.testing.assert_array_equal(gr.values.cpu().numpy(), g[f'aux/adj_{dom}_val'])
+        np.testing.assert_array_equal(gr.indices.cpu().numpy(), g[f'aux/adj_{dom}_idx'][1])
+    with torch.no_grad():
+        su, si, tu, ti = model.forward()
+        assert_close(su, g['fwd/source_user'], what='fwd su'); assert_close(si, g['fwd/source_item'], what='fwd si')
+        assert_close(tu, g['fwd/target_user'], what='fwd tu'); assert_close(ti, g['fwd/target_item'], what='fwd ti')
+    inter = to_dev(g.group('in'), DEV)
+    losses = model.calculate_loss(inter)
+    assert isinstance(losses, tuple) and len(losses) == 2
+    assert_close(torch.stack([l.reshape(()) for l in losses]), g['loss/BOTH'], what='losses')
+    sum(losses).sum().backward()
+    _check_grads(model, g, 'BOTH')
+    ev = to_dev(g.group('evalin'), DEV)
+    model.eval()
+    assert_close(model.predict(ev), g['predict/BOTH'], what='predict')
+    assert_close(model.full_sort_predict(ev), g['fullsort/BOTH'], what='fullsort')
