@@ -94,11 +94,18 @@ def run_c5(args, world, rank, dev):
         steps = {'source': FusedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01),
                  'target': FusedBPRStep(tabs['tu'], tabs['ti'], B, opt=args.opt, reg_weight=0.01)}
     else:
-        from recbole_cdr_amd.shard import ShardedBPRStep, shard_rows
+        import torch.distributed as dist
+        from recbole_cdr_amd.shard import ShardedBPRStep, shard_rows, run_pipelined
         tabs = {k: xavier_table(shard_rows(r, world, rank), D, r, gen, dev) for k, r in
                 (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
-        steps = {'source': ShardedBPRStep(tabs['su'], tabs['si'], n_users, n_items, B, opt=args.opt, reg_weight=0.01),
-                 'target': ShardedBPRStep(tabs['tu'], tabs['ti'], n_users, n_items, B, opt=args.opt, reg_weight=0.01)}
+        # one process group (= one RCCL communicator + stream) and one HIP stream per domain: the SOURCE and TARGET
+        # steps touch disjoint tables, so one domain's all-to-alls overlap the other's kernels
+        groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+        streams = {d: torch.cuda.Stream(device=dev) for d in ('source', 'target')}
+        steps = {'source': ShardedBPRStep(tabs['su'], tabs['si'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
+                                          group=groups['source'], stream=streams['source']),
+                 'target': ShardedBPRStep(tabs['tu'], tabs['ti'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
+                                          group=groups['target'], stream=streams['target'])}
 
     # synthetic interaction streams: users ~ U{1..OU-1}; target items [1, TOI], source items [TOI+1, 2 TOI]
     pool = 4
@@ -116,8 +123,11 @@ def run_c5(args, world, rank, dev):
 
     def one_step(i):
         b = batches[i % pool]
-        for dom in ('source', 'target'):
-            steps[dom].step(*b[dom])
+        if sharded:
+            run_pipelined([steps[dom].step_gen(*b[dom]) for dom in ('source', 'target')])
+        else:
+            for dom in ('source', 'target'):
+                steps[dom].step(*b[dom])
 
     for i in range(args.warmup):
         one_step(i)
@@ -150,7 +160,7 @@ def run_c5(args, world, rank, dev):
                                'step = source batch + target batch of %d triples each per rank, fwd+bwd+row-wise %s'
                                % (D, OU - 1, TOI, 4.0 * D * 2 * (n_users + n_items) / 1e9, B, args.opt),
                    'batch_per_domain_per_rank': B, 'k_neg': 1, 'optimizer': 'rowwise-' + args.opt,
-                   'sharding': 'none' if world == 1 else 'row %% %d' % world},
+                   'sharding': 'none' if not sharded else 'row %% %d, user-aligned all-to-all, 2-domain pipelined' % world},
         'final_loss': loss,
     }
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, 'lib', 'libcdrhip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -102,6 +102,10 @@ _SIGNATURES = {
     'cdr_colblock_mean_bwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_embloss_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_embloss_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_route_workspace_bytes': [_c_i64, _c_int, ctypes.POINTER(ctypes.c_size_t)],
+    'cdr_route_by_owner': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_permute_i64': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
+    'cdr_inverse_perm': [_c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_overlap_remap': [ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_revoke_map': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],

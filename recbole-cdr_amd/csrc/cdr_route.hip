@@ -1,0 +1,126 @@
+// Owner routing for row-sharded tables (row r lives on rank r % G): a stable counting sort of ids by owner built on the
+// same rocPRIM radix sort as cdr_sort_ids (over ceil(log2 G) bits: one onesweep pass), the bucket boundaries, and the
+// small index movers the exchange needs (permute-with-divide, inverse permutation).  Index plumbing only.
+#include <cstring>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "cdr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > CDR_NUM_CU * 8) g = CDR_NUM_CU * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__global__ __launch_bounds__(kBlock) void owner_keys_kernel(const int64_t* __restrict__ ids0, int64_t n0,
+                                                            const int64_t* __restrict__ ids1, int64_t n1, int64_t G,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t n = n0 + n1, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const int64_t id = e < n0 ? ids0[e] : ids1[e - n0];
+        keys[e] = (uint32_t)(id % G);
+        vals[e] = (uint32_t)e;
+    }
+}
+
+// starts[k] = first sorted position whose owner is >= k  (k = 0..G) ; counts[k] = starts[k+1] - starts[k]
+__global__ __launch_bounds__(kBlock) void bucket_bounds_kernel(const uint32_t* __restrict__ keys, int64_t n, int G,
+                                                               int64_t* __restrict__ starts) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e <= n; e += stride) {
+        const int lo = (e == 0) ? 0 : (int)keys[e - 1] + 1;
+        const int hi = (e == n) ? G : (int)keys[e];
+        for (int k = lo; k <= hi; ++k) starts[k] = e;
+    }
+}
+
+__global__ void counts_from_starts_kernel(const int64_t* __restrict__ starts, int G, int64_t* __restrict__ counts) {
+    const int k = threadIdx.x;
+    if (k < G) counts[k] = starts[k + 1] - starts[k];
+}
+
+__global__ __launch_bounds__(kBlock) void permute_i64_kernel(const int64_t* __restrict__ src0, int64_t n0,
+                                                             const int64_t* __restrict__ src1, const uint32_t* __restrict__ perm,
+                                                             int64_t n, int64_t divisor, int64_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        const int64_t o = perm[q];
+        const int64_t v = o < n0 ? src0[o] : src1[o - n0];
+        out[q] = divisor > 1 ? v / divisor : v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void inverse_perm_kernel(const uint32_t* __restrict__ perm, int64_t n, int64_t* __restrict__ pos) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) pos[perm[q]] = q;
+}
+
+inline unsigned bits_for(int64_t v) {
+    unsigned b = 1;
+    while (b < 32 && ((int64_t)1 << b) < v) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int cdr_route_by_owner(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1,
+                                  int world, uint32_t* perm, int64_t* counts, void* workspace, size_t workspace_bytes) {
+    (void)ctx;
+    const int64_t n = n0 + n1;
+    CDR_CHECK_ARG(ids0 && n0 > 0 && (n1 == 0 || ids1) && perm && counts && workspace && world >= 1 && world <= 1024);
+    CDR_CHECK_ARG(n <= (int64_t)0x7FFFFFFF);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t arr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t starts_bytes = (((size_t)world + 2) * sizeof(int64_t) + 255) & ~(size_t)255;
+    size_t tmp_need = 0;
+    CDR_HIP(rocprim::radix_sort_pairs(nullptr, tmp_need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                      (uint32_t*)nullptr, (size_t)n, 0u, bits_for(world)));
+    CDR_CHECK_ARG(workspace_bytes >= 3 * arr + starts_bytes + tmp_need);
+    uint32_t* keys_in = (uint32_t*)workspace;
+    uint32_t* vals_in = (uint32_t*)((char*)workspace + arr);
+    uint32_t* keys_out = (uint32_t*)((char*)workspace + 2 * arr);
+    int64_t* starts = (int64_t*)((char*)workspace + 3 * arr);
+    void* tmp = (char*)workspace + 3 * arr + starts_bytes;
+    size_t tmp_bytes = workspace_bytes - 3 * arr - starts_bytes;
+    owner_keys_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(ids0, n0, ids1, n1, (int64_t)world, keys_in, vals_in);
+    CDR_LAUNCH_CHECK();
+    CDR_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)vals_in, perm, (size_t)n,
+                                      0u, bits_for(world), s));
+    bucket_bounds_kernel<<<dim3(grid_for(n + 1)), dim3(kBlock), 0, s>>>(keys_out, n, world, starts);
+    CDR_LAUNCH_CHECK();
+    counts_from_starts_kernel<<<dim3(1), dim3(1024), 0, s>>>(starts, world, counts);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_route_workspace_bytes(int64_t n, int world, size_t* bytes) {
+    CDR_CHECK_ARG(bytes && n > 0 && world >= 1 && world <= 1024);
+    size_t tmp_need = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (size_t)n, 0u, bits_for(world));
+    if (e != hipSuccess) { cdr_set_error("cdr_route_workspace_bytes: %s", hipGetErrorString(e)); return (int)e; }
+    const size_t arr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t starts_bytes = (((size_t)world + 2) * sizeof(int64_t) + 255) & ~(size_t)255;
+    *bytes = 3 * arr + starts_bytes + ((tmp_need + 255) & ~(size_t)255);
+    return CDR_OK;
+}
+
+extern "C" int cdr_permute_i64(void* stream, const int64_t* src0, int64_t n0, const int64_t* src1, const uint32_t* perm,
+                               int64_t n, int64_t divisor, int64_t* out) {
+    CDR_CHECK_ARG(src0 && perm && out && n > 0 && divisor >= 1);
+    permute_i64_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream>>>(src0, n0, src1, perm, n, divisor, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_inverse_perm(void* stream, const uint32_t* perm, int64_t n, int64_t* pos) {
+    CDR_CHECK_ARG(perm && pos && n > 0);
+    inverse_perm_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream>>>(perm, n, pos);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -128,7 +128,7 @@ __global__ void finish_sums_kernel(const float* __restrict__ sums3, int64_t B, f
 }
 
 // out[q,:] = (o >= neg_start ? -G[o - neg_start,:] : G[o,:]) + (o < reg_limit ? c * rows[q,:] : 0),  o = order[q]
-__global__ __launch_bounds__(kBlock) void build_grad_rows_kernel(const float* __restrict__ G, const int64_t* __restrict__ order,
+__global__ __launch_bounds__(kBlock) void build_grad_rows_kernel(const float* __restrict__ G, const uint32_t* __restrict__ order,
                                                                  int64_t n, int D, int64_t neg_start, int64_t reg_limit,
                                                                  const float* __restrict__ rows, const float* __restrict__ coef,
                                                                  float* __restrict__ out) {
@@ -261,7 +261,7 @@ extern "C" int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_
     return CDR_OK;
 }
 
-extern "C" int cdr_build_grad_rows(void* stream, const float* G, const int64_t* order, int64_t n, int D, int64_t neg_start,
+extern "C" int cdr_build_grad_rows(void* stream, const float* G, const uint32_t* order, int64_t n, int D, int64_t neg_start,
                                    int64_t reg_limit, const float* rows, const float* coef, float* out) {
     CDR_CHECK_ARG(G && order && out && n > 0 && D > 0 && (D & 3) == 0);
     CDR_CHECK_ARG(reg_limit <= 0 || rows);

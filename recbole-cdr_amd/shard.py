@@ -1,20 +1,29 @@
-"""Row-sharded tables + the all-to-all exchange of one BPR training step (one process per GPU, RCCL over xGMI).
+"""Row-sharded tables + the exchange of one BPR training step over the GPUs of a node (one process per GPU, RCCL/xGMI).
 
 The reference is single-device (no distributed code at all); this module is the new multi-GPU path of
-north_star.  Parity is defined against the single-device result: with the same GLOBAL batch, the summed per-rank loss
-partials and every touched row after the step equal the 1-GPU fused step (tests/test_shard_gloo.py, world_size 2).
+north_star.  Parity is defined against the single-device result: with the same GLOBAL batch, the loss and every
+touched row after the step equal the 1-GPU fused step (tests/test_shard_gloo.py at world_size 2 on CPU/gloo;
+tests/test_gpu_parity.py::test_sharded_* over a 1-rank RCCL group on the GPU).
 
-Layout    row r of a table lives on rank r % G at local row r // G (balanced for any id distribution that is not
-          adversarially strided; contiguous id blocks of one domain spread over all ranks).
+Layout    row r of a table lives on rank r % G at local row r // G.
 Batch     data-parallel: every rank brings its own B triples (global ids).
-Exchange  per table: ids bucketed by owner -> all_to_all(ids) -> owners gather rows -> all_to_all(rows) ->
-          fused forward/compact-gradient kernel on the received rows -> all_reduce of the three loss sums (the EmbLoss
-          norms are over the GLOBAL batch) -> per-occurrence gradient rows -> all_to_all back -> owners sort + row-wise
-          optimizer.  Only `torch.distributed` collectives move data; bucketing is index plumbing.
+Exchange  USER-ALIGNED: each triple first travels (24 B) to the rank that owns its user row, so user rows and user
+          gradients never cross xGMI.  Only item rows do:
+            0. all_to_all   triples -> owner of u                                  (ids only)
+            1. all_to_all   local item ids -> item owners ; owners gather ; all_to_all rows back   (2 rows / triple)
+            2. fused forward + compact gradients on (local user shard, received item rows); all_reduce of the three
+               loss sums -- the mean and the EmbLoss norms are over the GLOBAL batch
+            3. user rows: local sort + row-wise optimizer.  item rows: per-occurrence gradient rows (EmbLoss term folded
+               in by the requester, which still holds the pre-step rows) -> all_to_all back -> owners sort + apply.
+          Collective sizes are exact (bucket counts are all-gathered; one host sync per routing stage).
+Overlap   ``step_gen`` is a generator that yields exactly where the host has to wait for bucket counts;
+          ``run_pipelined`` round-robins several steps (the SOURCE and TARGET domains touch disjoint tables), each on its
+          own HIP stream and process group, so one domain's all-to-alls overlap the other's kernels.
 
 The arithmetic is behind ``self.ops`` so that the CPU (gloo) tests can drive the same exchange code with stand-in
 compute; the product default (``NativeOps``) is libcdrhip only.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -34,13 +43,54 @@ def shard_of(full_table, world, rank):
 
 
 class NativeOps:
-    """libcdrhip kernels (csrc/cdr_rows.hip, csrc/cdr_step.hip)."""
+    """libcdrhip kernels (csrc/cdr_route.hip, cdr_rows.hip, cdr_step.hip)."""
 
     def __init__(self, device):
         from . import binding as B_
         self.B_ = B_
         self.device = device
-        self._ws = None
+        self._ws = {}
+
+    def _workspace(self, key, nbytes, device):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+            self._ws[key] = ws
+        return ws
+
+    def route(self, ids0, ids1, world):
+        """-> (perm uint32-as-int32 [n], counts int64 [world]) : stable bucketing of ids0 ++ ids1 by id % world."""
+        B_ = self.B_
+        n0 = ids0.numel()
+        n1 = ids1.numel() if ids1 is not None else 0
+        n = n0 + n1
+        dev = ids0.device
+        perm = torch.empty(n, device=dev, dtype=torch.int32)
+        counts = torch.zeros(world, device=dev, dtype=torch.int64)
+        if n == 0:
+            return perm, counts
+        need = ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_route_workspace_bytes(n, world, ctypes.byref(need)), 'cdr_route_workspace_bytes')
+        ws = self._workspace(('route', torch.cuda.current_stream().cuda_stream), need.value, dev)
+        B_.call('cdr_route_by_owner', B_.ctx(self.device), B_.stream(), B_.i64(ids0), n0, B_.i64(ids1) if n1 else None, n1,
+                int(world), B_.raw(perm), B_.i64(counts), B_.raw(ws), ws.numel())
+        return perm, counts
+
+    def permute(self, src0, src1, perm, divisor):
+        B_ = self.B_
+        n = perm.numel()
+        out = torch.empty(n, device=src0.device, dtype=torch.int64)
+        if n:
+            B_.call('cdr_permute_i64', B_.stream(), B_.i64(src0), src0.numel(), B_.i64(src1) if src1 is not None else None,
+                    B_.raw(perm), n, int(divisor), B_.i64(out))
+        return out
+
+    def inverse_perm(self, perm):
+        B_ = self.B_
+        pos = torch.empty(perm.numel(), device=perm.device, dtype=torch.int64)
+        if perm.numel():
+            B_.call('cdr_inverse_perm', B_.stream(), B_.raw(perm), perm.numel(), B_.i64(pos))
+        return pos
 
     def gather_rows(self, table, local_ids):
         B_ = self.B_
@@ -50,60 +100,57 @@ class NativeOps:
                     B_.f32(out))
         return out
 
-    def fwd_grad(self, urows, irows, upos, ppos, npos, B_mean, gamma, reg_weight, out, GU, GP):
+    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GP):
         B_ = self.B_
-        B_.call('cdr_bpr_fwd_grad', B_.ctx(self.device), B_.stream(), B_.f32(urows), B_.f32(irows), urows.shape[1],
-                B_.i64(upos), B_.i64(ppos), B_.i64(npos), upos.numel(), int(B_mean), float(gamma), float(reg_weight),
+        B_.call('cdr_bpr_fwd_grad', B_.ctx(self.device), B_.stream(), B_.f32(utab), B_.f32(itab), utab.shape[1],
+                B_.i64(uidx), B_.i64(pidx), B_.i64(nidx), uidx.numel(), int(B_mean), float(gamma), float(reg_weight),
                 B_.f32(out), B_.f32(GU), B_.f32(GP))
 
     def finish_sums(self, sums3, B_mean, reg_weight, out):
         B_ = self.B_
         B_.call('cdr_loss_finish_sums', B_.stream(), B_.f32(sums3), int(B_mean), float(reg_weight), B_.f32(out))
 
-    def build_grad_rows(self, G, order, neg_start, reg_limit, rows, coef):
+    def build_grad_rows(self, G, perm, neg_start, reg_limit, rows, coef):
         B_ = self.B_
-        out = torch.empty(order.numel(), G.shape[1], device=G.device, dtype=torch.float32)
-        B_.call('cdr_build_grad_rows', B_.stream(), B_.f32(G), B_.i64(order), order.numel(), G.shape[1], int(neg_start),
-                int(reg_limit), B_.f32(rows), B_.f32(coef), B_.f32(out))
+        out = torch.empty(perm.numel(), G.shape[1], device=G.device, dtype=torch.float32)
+        if perm.numel():
+            B_.call('cdr_build_grad_rows', B_.stream(), B_.f32(G), B_.raw(perm), perm.numel(), G.shape[1], int(neg_start),
+                    int(reg_limit), B_.f32(rows), B_.f32(coef), B_.f32(out))
         return out
 
-    def sort_apply(self, table, state, local_ids, grads, opt, hp, step):
-        """Owner side: segment the received (local row, gradient row) pairs and apply the optimizer in place."""
+    def sort_apply(self, table, state, local_ids, grads, opt, hp, step, reg_limit=0, reg_coef=None):
+        """Segment (local row, gradient row) pairs by row and apply the optimizer in place.  With ``reg_limit`` > 0 the
+        EmbLoss term ``reg_coef * count * W[r]`` is added inside the kernel (rows this rank owns)."""
         B_ = self.B_
         n = local_ids.numel()
         if n == 0:
             return
         need = ctypes.c_size_t(0)
         B_._check(B_.load().cdr_sort_workspace_bytes(n, table.shape[0], ctypes.byref(need)), 'cdr_sort_workspace_bytes')
-        if self._ws is None or self._ws.numel() < need.value:
-            self._ws = torch.empty(int(need.value), device=table.device, dtype=torch.uint8)
+        ws = self._workspace(('sort', torch.cuda.current_stream().cuda_stream), need.value, table.device)
         keys = torch.empty(n, device=table.device, dtype=torch.int32)
         perm = torch.empty(n, device=table.device, dtype=torch.int32)
         ctxh = B_.ctx(self.device)
         B_.call('cdr_sort_ids', ctxh, B_.stream(), B_.i64(local_ids), n, None, 0, table.shape[0], B_.raw(keys),
-                B_.raw(perm), B_.raw(self._ws), self._ws.numel())
+                B_.raw(perm), B_.raw(ws), ws.numel())
         m, v = (state if state is not None else (None, None))
         B_.call('cdr_rowwise_apply', ctxh, B_.stream(), opt, B_.f32(table), B_.f32(m), B_.f32(v), table.shape[1],
-                B_.raw(keys), B_.raw(perm), n, B_.f32(grads), n, 0, None, float(hp['lr']), float(hp['b1']),
-                float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step))
+                B_.raw(keys), B_.raw(perm), n, B_.f32(grads), n, int(reg_limit), B_.f32(reg_coef), float(hp['lr']),
+                float(hp['b1']), float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step))
 
 
-class Route:
-    """Bucketing of one id list by owner rank (index plumbing only)."""
-
-    def __init__(self, ids, world):
-        owner = ids % world
-        self.order = torch.argsort(owner, stable=True)           # occurrence index, grouped by owner
-        self.send_counts = torch.bincount(owner, minlength=world)
-        self.local_sorted = (ids // world)[self.order].contiguous()
-        self.pos = torch.empty_like(self.order)
-        self.pos[self.order] = torch.arange(ids.numel(), device=ids.device)
-
-
-def _a2a(out_numel_list, inp, in_splits, out_splits, group, trailing=()):
+def _a2a(inp, in_splits, out_splits, group, trailing=()):
     out = torch.empty((sum(out_splits),) + tuple(trailing), device=inp.device, dtype=inp.dtype)
     dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
     return out
+
+
+def _gather_counts(counts, extra, group, world):
+    """All ranks' bucket counts (+ one extra int per rank) -> list of tensors (no host sync yet)."""
+    payload = torch.cat([counts, torch.tensor([extra], device=counts.device, dtype=torch.int64)])
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload, group=group)
+    return gathered
 
 
 class ShardedBPRStep:
@@ -111,7 +158,8 @@ class ShardedBPRStep:
     (row r % G == rank, local index r // G)."""
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
-                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None):
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
+                 stream=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -127,55 +175,93 @@ class ShardedBPRStep:
         self.ustate = (torch.zeros_like(user_shard), torch.zeros_like(user_shard)) if self.opt == OPT_ADAM else None
         self.istate = (torch.zeros_like(item_shard), torch.zeros_like(item_shard)) if self.opt == OPT_ADAM else None
         self.max_batch = int(max_batch)
-        self.GU = torch.empty(self.max_batch, self.D, device=dev, dtype=torch.float32)
-        self.GP = torch.empty(self.max_batch, self.D, device=dev, dtype=torch.float32)
         self.out = torch.zeros(12, device=dev, dtype=torch.float32)
         self.step_count = 0
+        self.stream = stream                      # optional torch.cuda.Stream for pipelined execution
 
     def loss_value(self):
         return self.out[0]
 
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def step(self, uid, pid, nid):
-        G, grp = self.world, self.group
-        B = uid.numel()
-        assert B <= self.max_batch
-        self.step_count += 1
-        dev = uid.device
-
-        # ---- 1. route ids to the rows' owners ----------------------------------------------------------------
-        ru = Route(uid, G)
-        ri = Route(torch.cat([pid, nid]), G)
-        counts = torch.cat([ru.send_counts, ri.send_counts, torch.tensor([B], device=dev, dtype=torch.int64)])
-        gathered = [torch.empty_like(counts) for _ in range(G)]
-        dist.all_gather(gathered, counts, group=grp)
-        all_counts = torch.stack(gathered).tolist()                      # one host sync per step
-        u_send = [int(c) for c in all_counts[self.rank][:G]]
-        i_send = [int(c) for c in all_counts[self.rank][G:2 * G]]
-        u_recv = [int(all_counts[r][self.rank]) for r in range(G)]
-        i_recv = [int(all_counts[r][G + self.rank]) for r in range(G)]
-        B_global = sum(int(all_counts[r][2 * G]) for r in range(G))
-
-        u_req = _a2a(None, ru.local_sorted, u_send, u_recv, grp)          # local rows other ranks want from me
-        i_req = _a2a(None, ri.local_sorted, i_send, i_recv, grp)
-
-        # ---- 2. owners gather, rows travel back -------------------------------------------------------------
-        urows = _a2a(None, self.ops.gather_rows(self.U, u_req), u_recv, u_send, grp, (self.D,))
-        irows = _a2a(None, self.ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
-
-        # ---- 3. fused forward + compact gradients on the received rows (positions instead of ids) ------------
-        self.ops.fwd_grad(urows, irows, ru.pos, ri.pos[:B].contiguous(), ri.pos[B:].contiguous(), B_global, self.gamma,
-                          self.reg_weight, self.out, self.GU, self.GP)
-        sums = self.out[6:9].clone()
-        dist.all_reduce(sums, group=grp)                                   # loss mean and EmbLoss norms are GLOBAL
-        self.ops.finish_sums(sums, B_global, self.reg_weight, self.out)
-
-        # ---- 4. per-occurrence gradient rows (owner order), EmbLoss term folded in, back to the owners ---------
-        gu = self.ops.build_grad_rows(self.GU, ru.order, B, B, urows, self.out[4:5])
-        gi = self.ops.build_grad_rows(self.GP, ri.order, B, B, irows, self.out[5:6])
-        gu_recv = _a2a(None, gu, u_send, u_recv, grp, (self.D,))
-        gi_recv = _a2a(None, gi, i_send, i_recv, grp, (self.D,))
-
-        # ---- 5. owners: segment by local row, row-wise optimizer ----------------------------------------------
-        self.ops.sort_apply(self.U, self.ustate, u_req, gu_recv, self.opt, self.hp, self.step_count)
-        self.ops.sort_apply(self.I, self.istate, i_req, gi_recv, self.opt, self.hp, self.step_count)
+        for _ in self.step_gen(uid, pid, nid):
+            pass
         return self.out
+
+    def step_gen(self, uid, pid, nid):
+        """Generator form of one step: yields at the two points where the host must wait for bucket counts."""
+        G, grp, ops = self.world, self.group, self.ops
+        B = uid.numel()
+        self.step_count += 1
+
+        # ---- 0. triples travel to the owner of their user row ---------------------------------------------------
+        with self._on_stream():
+            perm0, counts0 = ops.route(uid, None, G)
+            send3 = torch.stack((ops.permute(uid, None, perm0, G), ops.permute(pid, None, perm0, 1),
+                                 ops.permute(nid, None, perm0, 1)), dim=1).contiguous()
+            gathered = _gather_counts(counts0, B, grp, G)
+        yield
+        with self._on_stream():
+            allc = torch.stack(gathered).tolist()                           # host sync #1
+            t_send = [int(c) for c in allc[self.rank][:G]]
+            t_recv = [int(allc[r][self.rank]) for r in range(G)]
+            B_global = sum(int(allc[r][G]) for r in range(G))
+            recv3 = _a2a(send3, t_send, t_recv, grp, (3,))
+            Bl = recv3.shape[0]                                              # triples whose user row is mine
+            u_loc = recv3[:, 0].contiguous()
+            p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
+
+            # ---- 1. item rows: ids to their owners, rows back ---------------------------------------------------
+            if Bl:
+                perm1, counts1 = ops.route(p2, n2, G)
+                i_local_sorted = ops.permute(p2, n2, perm1, G)
+                pos_i = ops.inverse_perm(perm1)
+            else:
+                perm1 = torch.empty(0, device=uid.device, dtype=torch.int32)
+                counts1 = torch.zeros(G, device=uid.device, dtype=torch.int64)
+                i_local_sorted = torch.empty(0, device=uid.device, dtype=torch.int64)
+                pos_i = torch.empty(0, device=uid.device, dtype=torch.int64)
+            gathered = _gather_counts(counts1, 0, grp, G)
+        yield
+        with self._on_stream():
+            allc = torch.stack(gathered).tolist()                           # host sync #2
+            i_send = [int(c) for c in allc[self.rank][:G]]
+            i_recv = [int(allc[r][self.rank]) for r in range(G)]
+            i_req = _a2a(i_local_sorted, i_send, i_recv, grp)                # local item rows other ranks want from me
+            irows = _a2a(ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
+
+            # ---- 2. fused forward + compact gradients; global loss reduction ----------------------------------
+            GU = torch.empty(max(Bl, 1), self.D, device=uid.device, dtype=torch.float32)
+            GP = torch.empty(max(Bl, 1), self.D, device=uid.device, dtype=torch.float32)
+            if Bl:
+                ops.fwd_grad(self.U, irows, u_loc, pos_i[:Bl].contiguous(), pos_i[Bl:].contiguous(), B_global, self.gamma,
+                             self.reg_weight, self.out, GU, GP)
+                sums = self.out[6:9].clone()
+            else:
+                sums = torch.zeros(3, device=uid.device, dtype=torch.float32)
+            dist.all_reduce(sums, group=grp)
+            ops.finish_sums(sums, B_global, self.reg_weight, self.out)
+
+            # ---- 3. user rows are local; item gradients go home ---------------------------------------------------
+            if Bl:
+                ops.sort_apply(self.U, self.ustate, u_loc, GU[:Bl], self.opt, self.hp, self.step_count, reg_limit=Bl,
+                               reg_coef=self.out[4:5])
+                gi = ops.build_grad_rows(GP[:Bl], perm1, Bl, Bl, irows, self.out[5:6])
+            else:
+                gi = torch.empty(0, self.D, device=uid.device, dtype=torch.float32)
+            gi_recv = _a2a(gi, i_send, i_recv, grp, (self.D,))
+            ops.sort_apply(self.I, self.istate, i_req, gi_recv, self.opt, self.hp, self.step_count)
+
+
+def run_pipelined(generators):
+    """Round-robin several ``step_gen`` generators until all finish: while one waits for its bucket counts the others'
+    kernels and collectives are already enqueued on their own streams."""
+    alive = list(generators)
+    while alive:
+        for g in list(alive):
+            try:
+                next(g)
+            except StopIteration:
+                alive.remove(g)

@@ -11,17 +11,32 @@ import torch.multiprocessing as mp
 
 
 class OracleOps:
-    """Stand-in compute for shard.ShardedBPRStep: the oracle's formulas on CPU tensors."""
+    """Stand-in compute for shard.ShardedBPRStep: the oracle's formulas on CPU tensors (same method set as NativeOps)."""
+
+    def route(self, ids0, ids1, world):
+        ids = ids0 if ids1 is None else torch.cat([ids0, ids1])
+        owner = ids % world
+        perm = torch.argsort(owner, stable=True).to(torch.int32)
+        return perm, torch.bincount(owner, minlength=world)
+
+    def permute(self, src0, src1, perm, divisor):
+        src = src0 if src1 is None else torch.cat([src0, src1])
+        return src[perm.long()] // divisor
+
+    def inverse_perm(self, perm):
+        pos = torch.empty(perm.numel(), dtype=torch.int64)
+        pos[perm.long()] = torch.arange(perm.numel())
+        return pos
 
     def gather_rows(self, table, local_ids):
         return table[local_ids].clone()
 
-    def fwd_grad(self, urows, irows, upos, ppos, npos, B_mean, gamma, reg_weight, out, GU, GP):
-        u, p, n = urows[upos], irows[ppos], irows[npos]
+    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GP):
+        u, p, n = utab[uidx], itab[pidx], itab[nidx]
         x = (u * p).sum(1) - (u * n).sum(1)
         s = torch.sigmoid(x)
         g = -(1.0 / B_mean) * (s * (1 - s)) / (gamma + s)
-        B = upos.numel()
+        B = uidx.numel()
         GU[:B] = g[:, None] * (p - n)
         GP[:B] = g[:, None] * u
         out[6] = (-torch.log(gamma + s)).sum()
@@ -36,18 +51,22 @@ class OracleOps:
         out[4] = reg_weight / (B_mean * nu) if float(nu) > 0 else 0.0
         out[5] = reg_weight / (B_mean * ni) if float(ni) > 0 else 0.0
 
-    def build_grad_rows(self, G, order, neg_start, reg_limit, rows, coef):
+    def build_grad_rows(self, G, perm, neg_start, reg_limit, rows, coef):
+        order = perm.long()
         neg = order >= neg_start
         src = torch.where(neg, order - neg_start, order)
         out = G[src] * torch.where(neg, -1.0, 1.0)[:, None]
         reg = (order < reg_limit).float()[:, None] * coef[0] * rows
         return out + reg
 
-    def sort_apply(self, table, state, local_ids, grads, opt, hp, step):
+    def sort_apply(self, table, state, local_ids, grads, opt, hp, step, reg_limit=0, reg_coef=None):
         if local_ids.numel() == 0:
             return
         rows, inv = torch.unique(local_ids, return_inverse=True)
         Gs = torch.zeros(rows.numel(), table.shape[1]).index_add_(0, inv, grads)
+        if reg_limit > 0:
+            cnt = torch.zeros(rows.numel()).index_add_(0, inv, (torch.arange(local_ids.numel()) < reg_limit).float())
+            Gs = Gs + reg_coef[0] * cnt[:, None] * table[rows]
         from oracle.train_step import _apply_rows, RowwiseAdamState
         if opt == 0:
             _apply_rows(table, None, rows, Gs, 'sgd', hp['lr'], step)
@@ -131,3 +150,62 @@ def test_shard_rows_partition():
             assert sum(shard_rows(total, world, r) for r in range(world)) == total
             for r in range(world):
                 assert shard_rows(total, world, r) == len(range(r, total, world))
+
+
+def _worker_pipe(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.shard import ShardedBPRStep, shard_of, run_pipelined
+        groups = [dist.new_group(list(range(world))) for _ in range(2)]
+        torch.manual_seed(0)
+        nu, ni, D, B = 53, 31, 8, 29
+        tabs = [(torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3) for _ in range(2)]
+        steps = [ShardedBPRStep(shard_of(U, world, rank), shard_of(I, world, rank), nu, ni, B, opt='sgd', lr=0.05,
+                                reg_weight=0.02, group=groups[d], ops=OracleOps()) for d, (U, I) in enumerate(tabs)]
+        out = []
+        for it in range(2):
+            bs = []
+            for d in range(2):
+                g = torch.Generator(); g.manual_seed(1000 * it + 10 * d + rank)
+                bs.append((torch.randint(0, nu, (B,), generator=g), torch.randint(0, ni, (B,), generator=g),
+                           torch.randint(0, ni, (B,), generator=g)))
+            run_pipelined([steps[d].step_gen(*bs[d]) for d in range(2)])
+            out.append([tuple(t.numpy().copy() for t in b) for b in bs])
+        q.put((rank, [(st.U.numpy().copy(), st.I.numpy().copy(), float(st.out[0])) for st in steps], out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_two_domains_world3():
+    """run_pipelined over two independent domain steps (own process group each), world_size 3, uneven buckets."""
+    from oracle import train_step as ts
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipe, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    nu, ni, D = 53, 31, 8
+    tabs = [(torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3) for _ in range(2)]
+    for d in range(2):
+        U, I = tabs[d]
+        loss = None
+        for it in range(2):
+            u = torch.cat([torch.from_numpy(res[r][2][it][d][0]) for r in range(world)])
+            p = torch.cat([torch.from_numpy(res[r][2][it][d][1]) for r in range(world)])
+            n = torch.cat([torch.from_numpy(res[r][2][it][d][2]) for r in range(world)])
+            loss = ts.rowwise_step(U, I, None, None, u, p, n, it + 1, opt='sgd', lr=0.05, reg_weight=0.02)
+        for r in range(world):
+            Ur, Ir, lr_ = res[r][1][d]
+            assert abs(lr_ - float(loss)) <= 1e-5 * abs(float(loss))
+            torch.testing.assert_close(torch.from_numpy(Ur), U[r::world], rtol=2e-5, atol=1e-6)
+            torch.testing.assert_close(torch.from_numpy(Ir), I[r::world], rtol=2e-5, atol=1e-6)
