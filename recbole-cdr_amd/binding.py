@@ -12,7 +12,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'lib', 'libcdrhip.so')
+_LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
 ABI_VERSION = 5
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1

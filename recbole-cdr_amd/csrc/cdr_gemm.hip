@@ -12,6 +12,7 @@
 //   <BM=128,BN=128>: 2x2 waves, 2x2 accumulators (64 regs) each -- throughput shape (many users, MLP layers)
 // A-operand rows = M side (users / batch rows), B-operand rows = N side (items / output features), so a lane's
 // accumulator column is an N index and every store instruction writes 32 consecutive floats per half-wave.
+#include <stdlib.h>
 #include "cdr_common.h"
 
 namespace {
@@ -190,6 +191,237 @@ int launch(hipStream_t s, int64_t M, int64_t N, int64_t K, const float* A, int64
     return CDR_OK;
 }
 
+// ---- few-users scoring (U <= 8): HBM-streaming GEMV ----------------------------------------------------------------
+// The reference's full-sort batch is U = max(eval_batch_size // N, 1) users (recbole FullSortEvalDataLoader): 1..8 for
+// every catalogue above 512 items.  There the contraction is a pure stream over the item slab: a lane group of
+// LPR = D/4 lanes owns 32 CONSECUTIVE item rows per chunk (16 KB contiguous at D = 128), keeps 4 of them in flight,
+// holds the U user vectors in registers, reduces each dot product inside the group, and parks the result in LDS so the
+// block writes every score row as whole 1 KiB lines.  Bytes per item = 4D + 4U; no MFMA (padding U to a 32-row tile
+// would make the matrix pipe, not HBM, the limiter).
+template <int LPR, int UMAX>
+__global__ __launch_bounds__(256) void fullsort_gemv_kernel(const float* __restrict__ users, int U, int D,
+                                                            const float* __restrict__ items, int64_t N,
+                                                            float* __restrict__ scores, int64_t ldc) {
+    constexpr int GPB = 256 / LPR;              // groups per block
+    constexpr int RPG = 256 / GPB;              // rows per group per chunk (= LPR)
+    __shared__ float sm[UMAX][256];
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const int D4 = D >> 2;
+    const bool live = sub < D4;
+    float4 uv[UMAX];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u)
+        uv[u] = (u < U && live) ? ld4(users + (int64_t)u * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t n_chunks = (N + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t row0 = chunk * 256 + (int64_t)grp * RPG;
+#pragma unroll 1
+        for (int it = 0; it < RPG; it += 4) {
+            float4 x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + it + r;
+                x[r] = (row < N && live) ? ld4(items + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u) {
+                    const float d = group_sum<LPR>(dot4(uv[u], x[r]));
+                    if (sub == 0) sm[u][grp * RPG + it + r] = d;
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t n = chunk * 256 + threadIdx.x;
+        if (n < N) {
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u)
+                if (u < U) scores[(int64_t)u * ldc + n] = sm[u][threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+
+template <int LPR>
+static int launch_gemv(hipStream_t s, const float* users, int U, int D, const float* items, int64_t N, float* scores, int64_t ldc) {
+    int64_t chunks = (N + 255) / 256;
+    const unsigned grid = (unsigned)(chunks < 4096 ? chunks : 4096);
+    if (U <= 1) fullsort_gemv_kernel<LPR, 1><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, scores, ldc);
+    else if (U <= 2) fullsort_gemv_kernel<LPR, 2><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, scores, ldc);
+    else if (U <= 4) fullsort_gemv_kernel<LPR, 4><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, scores, ldc);
+    else fullsort_gemv_kernel<LPR, 8><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, scores, ldc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdr_set_error("fullsort gemv: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return CDR_OK;
+}
+
+static bool gemv_ok(int64_t U, int D, const float* users, const float* items) {
+    return U <= 4 && (D & 3) == 0 && D >= 16 && D <= 256 && (((uintptr_t)users | (uintptr_t)items) & 15) == 0;
+}
+
+static int gemv_dispatch(hipStream_t s, const float* users, int U, int D, const float* items, int64_t N, float* scores, int64_t ldc) {
+    switch (cdr_lpr_for(D)) {
+        case 4: return launch_gemv<4>(s, users, U, D, items, N, scores, ldc);
+        case 8: return launch_gemv<8>(s, users, U, D, items, N, scores, ldc);
+        case 16: return launch_gemv<16>(s, users, U, D, items, N, scores, ldc);
+        case 32: return launch_gemv<32>(s, users, U, D, items, N, scores, ldc);
+        default: return launch_gemv<64>(s, users, U, D, items, N, scores, ldc);
+    }
+}
+
+// ---- many-users scoring (U >= 64, D <= 128): persistent fp32-MFMA kernel ----------------------------------------------
+// One 256-thread workgroup per CU, resident for the whole call.  Waves are 2 (M) x 2 (N); each wave keeps its users'
+// A fragments for the WHOLE contraction (D <= 128) in registers -- 32*MT rows x D, loaded once -- so the only LDS traffic
+// is the item tile: [64 items, D] double-buffered (2 x 33 KB), filled through registers (global_load issued before the
+// MFMA phase of the previous tile, written to the other buffer after it: one barrier per tile).  Work mapping is
+// XCD-aware: workgroup b runs on XCD b % 8 (observed placement; speed only), and the workgroups of one XCD that share
+// an item stripe walk it together for different user blocks, so an item tile is fetched from HBM once and re-used
+// from that XCD's L2 by the other user blocks instead of being re-read U/BM times.
+template <int MT, int K>
+__global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* __restrict__ A, int M,
+                                                                  const float* __restrict__ B, int NT,
+                                                                  float* __restrict__ C, int64_t ldc) {
+    constexpr int BM = 64 * MT;            // 2 waves along M, MT 32-row tiles each
+    constexpr int BN = 64;                 // 2 waves along N, one 32-col tile each
+    constexpr int KS = K / 8;              // K steps of 8 (one float4 per lane per step feeds 4 MFMAs)
+    constexpr int LDB = K + 4;             // padded LDS row (dwords): 16-B aligned rows, conflict-free ds_read_b128
+    constexpr int BUF = BN * LDB;          // floats per item-tile buffer
+    constexpr int F4R = K / 4;             // float4 per item row
+    constexpr int NQ = BN * F4R / 256;     // float4 each thread stages per tile (K = 128: 8)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- work mapping (block b runs on XCD b % 8: speed only) -----------------------------------------------------
+    const int MB = (M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int MBc = MB < per_xcd ? MB : per_xcd;
+    const int S = per_xcd / MBc;
+    const int mslot = j % MBc, sidx = j / MBc;
+    if (sidx >= S) return;
+    const int stripe = xcd * S + sidx, n_stripes = 8 * S;
+
+    // per-thread staging geometry (compile-time divisors)
+    int st_lds[NQ];
+    int64_t st_gl[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 256 * q;
+        const int r = e / F4R, c = e % F4R;
+        st_lds[q] = r * LDB + 4 * c;
+        st_gl[q] = (int64_t)r * K + 4 * c;
+    }
+    const int frag_off = (wn * 32 + li) * LDB + 4 * lh;
+
+    for (int mb = mslot; mb < MB; mb += MBc) {
+        const int m0 = mb * BM + wm * 32 * MT;
+        // this wave's user rows, whole K, in registers (loaded once per user block)
+        float4 a[MT][KS];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int r = m0 + 32 * t + li;
+            const float* ap = A + (int64_t)(r < M ? r : 0) * K + 4 * lh;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                a[t][s] = ld4(ap + 8 * s);
+                if (r >= M) a[t][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        int tile = stripe;
+        int buf = 0;
+        if (tile < NT) {
+            const float* bp = B + (int64_t)tile * BN * K;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) st4(smem + st_lds[q], ld4(bp + st_gl[q]));
+        }
+        __syncthreads();
+        for (; tile < NT; tile += n_stripes) {
+            const int next = tile + n_stripes;
+            const bool has_next = next < NT;
+            // issue the next tile's global loads now; they land while the MFMAs below run
+            float4 stage[NQ];
+            {
+                const float* bp = B + (int64_t)(has_next ? next : tile) * BN * K;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) stage[q] = ld4(bp + st_gl[q]);
+            }
+            // hipcc otherwise SINKS these loads below the MFMA phase (register pressure heuristic) and serialises
+            // load -> wait -> ds_write after it: 1.7x slower end to end.  Pin the issue point.
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            const float* bs = smem + buf * BUF + frag_off;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float4 b = ld4(bs + 8 * s);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].x, b.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].y, b.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].z, b.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].w, b.w, acc[t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // park the prefetched tile in the other buffer FIRST (last read two iterations ago): the vmcnt wait in front
+            // of these LDS writes covers the loads issued before the MFMA phase, not the epilogue's stores below
+            {
+                float* dst = smem + (buf ^ 1) * BUF;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) st4(dst + st_lds[q], stage[q]);
+            }
+            // epilogue: lane column = item ; register r -> user row (r&3) + 8*(r>>2) + 4*lh
+            float* cp = C + (int64_t)tile * BN + wn * 32 + li;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M) cp[(int64_t)m * ldc] = acc[t][r];
+                }
+            __syncthreads();
+            buf ^= 1;
+        }
+        __syncthreads();
+    }
+}
+
+static bool score_persistent_ok(int64_t U, int D, int64_t N, const float* users, const float* items) {
+    return U > 32 && U < ((int64_t)1 << 30) && (D == 64 || D == 128) && N >= 64 && N < ((int64_t)1 << 36) &&
+           (((uintptr_t)users | (uintptr_t)items) & 15) == 0;
+}
+
+// full 64-item tiles on the persistent kernel; the (< 64)-item tail on the generic tile kernel
+static int launch_score_persistent(hipStream_t s, const float* users, int64_t U, int D, const float* items, int64_t N,
+                                   float* scores, int64_t ldc) {
+    const unsigned grid = CDR_NUM_CU;      // one resident workgroup per CU, 32 per XCD
+    const int NT = (int)(N / 64);
+    const bool small = U <= 64;            // one 32-row tile per wave (BM = 64) instead of two (BM = 128)
+    if (D == 64) {
+        const size_t lds = 2 * (size_t)64 * (64 + 4) * sizeof(float);
+        if (small) score_persistent_kernel<1, 64><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
+        else score_persistent_kernel<2, 64><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
+    } else {
+        const size_t lds = 2 * (size_t)64 * (128 + 4) * sizeof(float);
+        if (small) score_persistent_kernel<1, 128><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
+        else score_persistent_kernel<2, 128><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdr_set_error("score_persistent: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    const int64_t done = (int64_t)NT * 64;
+    if (done < N)
+        return launch<false, true, false>(s, U, N - done, D, users, D, items + done * D, D, scores + done, ldc, nullptr,
+                                          CDR_ACT_NONE, 0, nullptr, nullptr);
+    return CDR_OK;
+}
+
 // row squared norms: out[r] = sum_d X[r,d]^2  (one wave per row)
 __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ X, int64_t rows, int D, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -234,12 +466,16 @@ extern "C" int cdr_fullsort_scores_f32(void* stream, const float* user_e, int64_
     int rc = CDR_OK;
     int64_t off = 0;
     if (slab0 && n0 > 0) {
-        rc = launch<false, true, false>(s, U, n0, D, user_e, D, slab0, D, scores, N, nullptr, CDR_ACT_NONE, 0, nullptr, nullptr);
+        rc = gemv_ok(U, D, user_e, slab0) ? gemv_dispatch(s, user_e, (int)U, D, slab0, n0, scores, N)
+             : score_persistent_ok(U, D, n0, user_e, slab0) ? launch_score_persistent(s, user_e, U, D, slab0, n0, scores, N)
+             : launch<false, true, false>(s, U, n0, D, user_e, D, slab0, D, scores, N, nullptr, CDR_ACT_NONE, 0, nullptr, nullptr);
         if (rc) return rc;
         off = n0;
     }
     if (slab1 && n1 > 0)
-        rc = launch<false, true, false>(s, U, n1, D, user_e, D, slab1, D, scores + off, N, nullptr, CDR_ACT_NONE, 0, nullptr, nullptr);
+        rc = gemv_ok(U, D, user_e, slab1) ? gemv_dispatch(s, user_e, (int)U, D, slab1, n1, scores + off, N)
+             : score_persistent_ok(U, D, n1, user_e, slab1) ? launch_score_persistent(s, user_e, U, D, slab1, n1, scores + off, N)
+             : launch<false, true, false>(s, U, n1, D, user_e, D, slab1, D, scores + off, N, nullptr, CDR_ACT_NONE, 0, nullptr, nullptr);
     return rc;
 }
 

@@ -497,3 +497,22 @@ def test_bitgcf_golden(name):
     model.eval()
     assert_close(model.predict(ev), g['predict/BOTH'], what='predict')
     assert_close(model.full_sort_predict(ev), g['fullsort/BOTH'], what='fullsort')
+
+
+@pytest.mark.parametrize('U,N,D', [(1, 1000, 128), (3, 777, 64), (4, 5000, 128), (33, 4133, 128), (64, 6400, 64), (100, 8229, 128),
+                                   (300, 20011, 64), (130, 63, 128), (40, 2000, 32)])
+def test_fullsort_paths_vs_fp64(U, N, D):
+    """Every scoring path behind cdr_fullsort_scores_f32 -- streaming GEMV (U <= 4), generic MFMA tiles, persistent MFMA
+    kernel (U > 32, D in {64,128}) incl. its (< 64 item) tail and the two-slab form -- against an fp64 product, with
+    asymmetric operands (a transposed result would fail)."""
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(U * 7 + N)
+    W = torch.randn(N + 50, D)
+    ue = torch.randn(U, D)
+    ref = (ue.double() @ W[:N].double().t()).float()
+    got = F_.fullsort_scores(ue.to(DEV), W.to(DEV)[:N])
+    assert_close(got, ref, atol=2e-5 * float(ref.abs().max()))
+    k = N // 3
+    ref2 = (ue.double() @ torch.cat([W[:k], W[k + 17:N + 17]]).double().t()).float()
+    got2 = F_.fullsort_scores(ue.to(DEV), W.to(DEV)[:k], W.to(DEV)[k + 17:N + 17])
+    assert_close(got2, ref2, atol=2e-5 * float(ref2.abs().max()))
