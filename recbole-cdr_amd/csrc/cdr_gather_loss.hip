@@ -36,15 +36,21 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float* __restrict
             // one float4 per lane per row: issue all loads of kUnroll interactions, then reduce
             float4 u[kUnroll], p[kUnroll], n[kUnroll];
             const bool live = sub < D4;
+            int64_t iu[kUnroll], ip[kUnroll], in[kUnroll];      // ids first, then every row load (see cdr_step.hip)
+#pragma unroll
+            for (int r = 0; r < kUnroll; ++r) {
+                const int64_t t = base + (int64_t)r * TG;
+                const int64_t tc = t < B ? t : B - 1;
+                iu[r] = uid[tc]; ip[r] = pid[tc]; in[r] = nid[tc];
+            }
 #pragma unroll
             for (int r = 0; r < kUnroll; ++r) {
                 const int64_t t = base + (int64_t)r * TG;
                 u[r] = p[r] = n[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t < B && live) {
-                    const int64_t iu = uid[t], ip = pid[t], in = nid[t];
-                    u[r] = ld4(U + iu * D + 4 * sub);
-                    p[r] = ld4(I + ip * D + 4 * sub);
-                    n[r] = ld4(I + in * D + 4 * sub);
+                    u[r] = ld4(U + iu[r] * D + 4 * sub);
+                    p[r] = ld4(I + ip[r] * D + 4 * sub);
+                    n[r] = ld4(I + in[r] * D + 4 * sub);
                 }
             }
 #pragma unroll

@@ -52,15 +52,23 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
 
     for (int64_t base = gg; base < B; base += TG * kUnroll) {
         float4 u[kUnroll], p[kUnroll], n[kUnroll];
+        // ids of all kUnroll triples first, THEN all row loads: vmcnt is an in-order counter, so interleaving
+        // "ids(r) -> rows(r)" makes the wait for ids(r+1) also wait for rows(r) and serialises the gathers
+        int64_t iu[kUnroll], ip[kUnroll], in[kUnroll];
+#pragma unroll
+        for (int r = 0; r < kUnroll; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const int64_t tc = t < B ? t : B - 1;
+            iu[r] = uid[tc]; ip[r] = pid[tc]; in[r] = nid[tc];
+        }
 #pragma unroll
         for (int r = 0; r < kUnroll; ++r) {
             const int64_t t = base + (int64_t)r * TG;
             u[r] = p[r] = n[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < B && live) {
-                const int64_t iu = uid[t], ip = pid[t], in = nid[t];
-                u[r] = ld4(U + iu * D + 4 * sub);
-                p[r] = ld4(I + ip * D + 4 * sub);
-                n[r] = ld4(I + in * D + 4 * sub);
+                u[r] = ld4(U + iu[r] * D + 4 * sub);
+                p[r] = ld4(I + ip[r] * D + 4 * sub);
+                n[r] = ld4(I + in[r] * D + 4 * sub);
             }
         }
 #pragma unroll
