@@ -209,6 +209,9 @@ int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const 
 int cdr_copy_cols(void* stream, const float* src, int64_t lds, int64_t rows, int D, float* dst, int64_t ldo, int accumulate);
 int cdr_colblock_mean_fwd(void* stream, const float* cat, int64_t rows, int D, int nb, float* out);
 int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, int nb, float* gcat);
+/* nn.Dropout(p), training mode: out = mask ? x/(1-p) : 0, counter-based mask from `seed` (same call with the same seed on
+ * the upstream gradient is the backward); in place allowed (bitgcf.py:66,134). */
+int cdr_dropout(void* stream, const float* x, int64_t n, float p, uint64_t seed, float* out);
 int cdr_embloss_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
                     const int64_t* uid, const int64_t* iid, int64_t B, float* out3);
 int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const float* item_tab, int D, const int64_t* uid,

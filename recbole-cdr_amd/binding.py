@@ -100,6 +100,7 @@ _SIGNATURES = {
     'cdr_copy_cols': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_int],
     'cdr_colblock_mean_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_colblock_mean_bwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
+    'cdr_dropout': [_c_ptr, _c_ptr, _c_i64, _c_f32, ctypes.c_uint64, _c_ptr],
     'cdr_embloss_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_embloss_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_route_workspace_bytes': [_c_i64, _c_int, ctypes.POINTER(ctypes.c_size_t)],

@@ -189,6 +189,24 @@ __global__ __launch_bounds__(kBlock) void colblock_mean_bwd_kernel(const float* 
     }
 }
 
+// nn.Dropout(p) in training: out = keep ? x / (1-p) : 0 with a counter-based mask -- element e of call `seed` keeps iff
+// splitmix64(seed + e * golden) maps to a uniform >= p.  Stateless, so the backward regenerates the same mask from the
+// same seed (out = dropout(gy)) instead of storing it.  (The reference draws from torch's Philox stream; masks are not
+// bit-comparable across implementations -- SURVEY App. A.1 -- only their distribution is.)
+__global__ __launch_bounds__(kBlock) void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed,
+                                                         float* __restrict__ out) {
+    const float scale = 1.0f / (1.0f - p);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        uint64_t z = seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const float u = (float)(z >> 40) * (1.0f / 16777216.0f);      // 24 uniform bits in [0,1)
+        out[e] = u >= p ? x[e] * scale : 0.0f;
+    }
+}
+
 }  // namespace
 
 #define GR_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
@@ -290,6 +308,13 @@ extern "C" int cdr_colblock_mean_fwd(void* stream, const float* cat, int64_t row
 extern "C" int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, int nb, float* gcat) {
     CDR_CHECK_ARG(gout && gcat && rows > 0 && D > 0 && nb > 0);
     colblock_mean_bwd_kernel<<<GR_GRID(rows * D * nb)>>>(gout, rows, D, nb, gcat);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_dropout(void* stream, const float* x, int64_t n, float p, uint64_t seed, float* out) {
+    CDR_CHECK_ARG(x && out && n > 0 && p >= 0.0f && p < 1.0f);
+    dropout_kernel<<<GR_GRID(n)>>>(x, n, p, seed, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -432,7 +432,7 @@ class BiTGCFPropagate(Function):
     is symmetric, so the SpMM backward is the same kernel."""
 
     @staticmethod
-    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI):
+    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p=0.0, drop_seed=0):
         _dev_check(su, si, tu, ti)
         nu, ni, D = su.shape[0], si.shape[0], su.shape[1]
         n = nu + ni
@@ -454,6 +454,9 @@ class BiTGCFPropagate(Function):
                     B_.f32(sideS), B_.f32(newS))
             B_.call('cdr_graph_layer_fwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T), D,
                     B_.f32(sideT), B_.f32(newT))
+            if drop_p > 0.0:            # nn.Dropout on the layer output (bitgcf.py:134), one mask per (layer, domain)
+                B_.call('cdr_dropout', st(), B_.f32(newS), n * D, float(drop_p), int(drop_seed + 2 * l), B_.f32(newS))
+                B_.call('cdr_dropout', st(), B_.f32(newT), n * D, float(drop_p), int(drop_seed + 2 * l + 1), B_.f32(newT))
             S2, T2 = f32(n, D), f32(n, D)
             off = 4 * nu * D
             B_.call('cdr_transfer_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU,
@@ -473,12 +476,12 @@ class BiTGCFPropagate(Function):
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catS), n, D, nb, B_.f32(outS))
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catT), n, D, nb, B_.f32(outT))
         ctx.save_for_backward(*saved)
-        ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D)
+        ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, float(drop_p), int(drop_seed))
         return outS, outT
 
     @staticmethod
     def backward(ctx, gOutS, gOutT):
-        gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D = ctx.meta
+        gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, drop_p, drop_seed = ctx.meta
         saved = ctx.saved_tensors
         n, nb = nu + ni, n_layers + 1
         dev = gOutS.device
@@ -507,6 +510,9 @@ class BiTGCFPropagate(Function):
                     lam_t, B_.f32(gnS), B_.f32(gnT))
             B_.call('cdr_transfer_bwd', st(), B_._c_ptr(gS.data_ptr() + off), B_._c_ptr(gT.data_ptr() + off), B_.f32(deg['si']),
                     B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, B_._c_ptr(gnS.data_ptr() + off), B_._c_ptr(gnT.data_ptr() + off))
+            if drop_p > 0.0:            # same masks as the forward
+                B_.call('cdr_dropout', st(), B_.f32(gnS), n * D, drop_p, drop_seed + 2 * l, B_.f32(gnS))
+                B_.call('cdr_dropout', st(), B_.f32(gnT), n * D, drop_p, drop_seed + 2 * l + 1, B_.f32(gnT))
             gS_in, gT_in = f32(n, D), f32(n, D)
             B_.call('cdr_graph_layer_bwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S_in),
                     B_.f32(sideS), B_.f32(gnS), D, B_.f32(tmp), B_.f32(gS_in))
@@ -518,7 +524,7 @@ class BiTGCFPropagate(Function):
         # layer-0 block of the stack is the ego embedding itself
         B_.call('cdr_copy_cols', st(), B_.f32(gcatS), nb * D, n, D, B_.f32(gS), D, 1)
         B_.call('cdr_copy_cols', st(), B_.f32(gcatT), nb * D, n, D, B_.f32(gT), D, 1)
-        return gS[:nu], gS[nu:], gT[:nu], gT[nu:], None, None, None, None, None, None, None, None, None
+        return gS[:nu], gS[nu:], gT[:nu], gT[nu:], None, None, None, None, None, None, None, None, None, None, None
 
 
 class EmbLossRows(Function):

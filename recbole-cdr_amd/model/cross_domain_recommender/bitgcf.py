@@ -6,9 +6,9 @@ The reference propagates over the FULL graph inside every calculate_loss (bitgcf
 and a normalise-into-the-stack kernel; the per-batch part is the same fused gather-dot-BCE kernel CMF uses, with the
 EmbLoss taken on the ego rows.  Adjacency values are formed exactly as the reference does (float64 D^-1/2 A D^-1/2 with
 degree + 1e-7, rounded to fp32: bitgcf.py:92-116) -- golden-pinned bit for bit in tests/test_oracle_golden.py.
-Dropout: identity when drop_rate == 0 or in eval; with drop_rate > 0 in training the mask comes from torch's generator
-and is applied between layers by a torch op (documented limitation: not bit-reproducible against the reference's
-generator stream).
+Dropout (bitgcf.py:66,134): identity in eval; in training a native counter-based mask (cdr_dropout) whose per-call seed
+is drawn from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable.  Masks are not bit-comparable with
+the reference's Philox stream: golden parity is pinned at drop_rate = 0, the mask by its statistics.
 """
 import numpy as np
 import torch
@@ -51,9 +51,6 @@ class BiTGCF(CrossDomainRecommender):
         self.domain_lambda_target = config['lambda_target']
         self.drop_rate = config['drop_rate']
         self.connect_way = config['connect_way']
-        if self.drop_rate and self.drop_rate > 0:
-            raise NotImplementedError('BiTGCF on libcdrhip: drop_rate > 0 is not implemented on the native path yet '
-                                      '(set drop_rate: 0.0); there is no eager fallback')
 
         self.source_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
         self.target_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
@@ -78,9 +75,16 @@ class BiTGCF(CrossDomainRecommender):
                                         self.target_user_embedding.weight, self.target_item_embedding.weight,
                                         self.source_graph, self.target_graph, self.degrees, int(self.n_layers),
                                         float(self.domain_lambda_source), float(self.domain_lambda_target),
-                                        self.connect_way, int(self.overlapped_num_users), int(self.overlapped_num_items))
+                                        self.connect_way, int(self.overlapped_num_users), int(self.overlapped_num_items),
+                                        *self._dropout_args())
         nu = self.total_num_users
         return S[:nu], S[nu:], T[:nu], T[nu:]
+
+    def _dropout_args(self):
+        if not self.training or not self.drop_rate:
+            return 0.0, 0
+        seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())
+        return float(self.drop_rate), seed
 
     def calculate_loss(self, interaction):
         self.init_restore_e()

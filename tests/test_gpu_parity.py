@@ -516,3 +516,42 @@ def test_fullsort_paths_vs_fp64(U, N, D):
     ref2 = (ue.double() @ torch.cat([W[:k], W[k + 17:N + 17]]).double().t()).float()
     got2 = F_.fullsort_scores(ue.to(DEV), W.to(DEV)[:k], W.to(DEV)[k + 17:N + 17])
     assert_close(got2, ref2, atol=2e-5 * float(ref2.abs().max()))
+
+
+def test_bitgcf_dropout_statistics_and_backward_mask():
+    """drop_rate > 0 (the reference's default 0.3): keep fraction ~ 1-p, kept values scaled by 1/(1-p), the backward uses
+    the forward's mask, torch.manual_seed makes the step repeatable, eval mode is the identity."""
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    x = torch.randn(200_000, device=DEV) + 3.0
+    out = torch.empty_like(x)
+    B_.call('cdr_dropout', B_.stream(), B_.f32(x), x.numel(), 0.3, 12345, B_.f32(out))
+    keep = out != 0
+    assert abs(float(keep.float().mean()) - 0.7) < 0.01
+    assert_close(out[keep], x[keep] / 0.7, rtol=1e-6)
+    out2 = torch.empty_like(x)
+    B_.call('cdr_dropout', B_.stream(), B_.f32(x), x.numel(), 0.3, 12346, B_.f32(out2))
+    assert float(((out2 != 0) == keep).float().mean()) < 0.65            # a different seed is a different mask
+    g = Golden('bitgcf_users_concat')
+    ids = g.idspace()
+    ds = FakeDataset(ids, s_pairs=g['aux/s_pairs'], t_pairs=g['aux/t_pairs'])
+    cfg = base_config(DEV, embedding_size=int(g.meta('D')), n_layers=2, reg_weight=0.001, lambda_source=0.8, lambda_target=0.7,
+                      drop_rate=0.3, connect_way='concat')
+    model = BiTGCF(cfg, ds).to(DEV)
+    load_params(model, g.group('param'))
+    inter = to_dev(g.group('in'), DEV)
+    def run(seed):
+        torch.manual_seed(seed)
+        model.zero_grad(set_to_none=True)
+        losses = model.calculate_loss(inter)
+        sum(losses).sum().backward()
+        return torch.stack([l.reshape(()) for l in losses]).detach().clone(), model.source_user_embedding.weight.grad.clone()
+    model.train()
+    l1, g1 = run(7); l2, g2 = run(7); l3, _ = run(8)
+    assert torch.equal(l1, l2)
+    assert_close(g1, g2, rtol=1e-5)          # same mask; the dense scatter-add's fp32 atomics reorder sums
+    assert not torch.equal(l1, l3)
+    assert torch.isfinite(g1).all()
+    model.eval()
+    le = torch.stack([l.reshape(()) for l in model.calculate_loss(inter)])
+    assert_close(le, g['loss/BOTH'], what='eval-mode loss == drop_rate 0 golden')
