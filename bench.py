@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='c5', choices=['c5', 'c2'])
+    ap.add_argument('--workload', default='c5', choices=['c5', 'c2', 'c3', 'c4'])
     ap.add_argument('--batch', type=int, default=1 << 20, help='triples per domain per rank per step (c5)')
     ap.add_argument('--opt', default='adam', choices=['adam', 'sgd'])
     ap.add_argument('--users', type=int, default=50_000_001)
@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fullsort', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
     return ap.parse_args()
 
@@ -276,6 +277,122 @@ def run_c2(args, world, rank, dev):
                                    'autograd + exact dense Adam', 'batch': B}}
 
 
+# ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
+def run_model_workload(args, world, rank, dev):
+    """BASELINE configs[2] (CoNet, Amazon-Books -> Movies sizes, D=128, k=4 pointwise) and configs[3] (BiTGCF, Douban sizes,
+    2 layers, D=64) through the drop-in class contract: calculate_loss -> backward -> exact dense Adam (the reference's
+    loop, trainer.py:59-73).  Reports rows/s (a row = one (u, i, label) row of a domain's batch) and the oracle on the
+    host cores beside it."""
+    import numpy as np
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev}
+    if args.workload == 'c3':
+        from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet as Model
+        ds = SyntheticCrossDomainDataset(OU=5983, TOU=20986, SOU=129127, OI=1, TOI=18563, SOI=115172,
+                                         n_source_inter=400000, n_target_inter=200000)
+        cfg.update(embedding_size=128, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+        S, k, name = 819, 4, 'C3: CoNet Amazon-Books->Movies sizes (156,096 users x 133,736 items), D=128, [256,64,32,16,8], k=4'
+    else:
+        from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF as Model
+        ds = SyntheticCrossDomainDataset(OU=15435, TOU=6607, SOU=2651, OI=1, TOI=25802, SOI=33067,
+                                         n_source_inter=809248, n_target_inter=2040000)
+        cfg.update(embedding_size=64, n_layers=2, reg_weight=0.001, lambda_source=0.8, lambda_target=0.8, drop_rate=0.3,
+                   connect_way='concat')
+        S, k, name = 2048, 1, 'C4: BiTGCF Douban-Book->Movie sizes (24,693 users x 58,870 items, nnz 2x%d / 2x%d), D=64, 2 layers, ' \
+                             'full-graph propagation every step' % (len(ds.s_pairs), len(ds.t_pairs))
+    torch.manual_seed(2022)
+    model = Model(cfg, ds).to(dev)
+    opt = DenseAdam(model.parameters(), lr=1e-3)
+    rng = np.random.RandomState(2022)
+    batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
+    rows_per_step = 2 * S * (1 + k)
+
+    from recbole_cdr_amd.graph_step import GraphedTrainStep
+    graphed = GraphedTrainStep(model, opt, batches[0]) if not args.no_graph else None
+
+    def one_step(i):
+        if graphed is not None:
+            return graphed.step(batches[i % 4])       # one hipGraph replay per step (see graph_step.py)
+        opt.zero_grad(set_to_none=True)
+        losses = model.calculate_loss(batches[i % 4])
+        loss = sum(losses) if isinstance(losses, tuple) else losses
+        loss.sum().backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(i)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    result = {'metric': 'training interactions/sec', 'value': rows_per_step * args.steps * world / dt, 'unit': 'interactions/s',
+              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+              'config': {'workload': name + ', drop-in autograd + exact dense Adam' + ('' if args.no_graph else ', step replayed as one hipGraph'),
+                         'rows_per_step': rows_per_step},
+              'final_loss': float(loss.sum())}
+    if rank == 0 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline_model(args, ds, cfg, S, k)
+    return result
+
+
+def cpu_baseline_model(args, ds, cfg, S, k):
+    """The oracle's calculate_loss + autograd + torch.optim.Adam (the reference's literal loop) on the host cores."""
+    import numpy as np
+    from oracle import conet as oconet, bitgcf as obit
+    from oracle.common import IdSpace
+    ids = IdSpace(ds.num_overlap_user, ds.num_target_only_user, ds.num_source_only_user, ds.num_overlap_item,
+                  ds.num_target_only_item, ds.num_source_only_item)
+    torch.manual_seed(0)
+    D = cfg['embedding_size']
+    nu, ni = ids.total_num_users, ids.total_num_items
+    xav = lambda r, c: (torch.randn(r, c) * (2.0 / (r + c)) ** 0.5).requires_grad_(True)
+    params = {f'{d}_{w}_embedding.weight': xav(nu if w == 'user' else ni, D) for d in ('source', 'target') for w in ('user', 'item')}
+    graph = None
+    if args.workload == 'c3':
+        dims = [2 * D] + cfg['mlp_hidden_size']
+        for l, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+            for t in ('source', 'target'):
+                params[f'{t}_crossunit_linear.{l}.weight'] = xav(b, a)
+                params[f'{t}_crossunit_linear.{l}.bias'] = torch.zeros(b, requires_grad=True)
+            params[f'crossparas.{l}.weight'] = xav(b, a)
+        for t in ('source', 'target'):
+            params[f'{t}_outputunit.0.weight'] = xav(1, dims[-1])
+            params[f'{t}_outputunit.0.bias'] = torch.zeros(1, requires_grad=True)
+        loss_fn = lambda b: oconet.calculate_loss(params, ids, b)
+    else:
+        graph = obit.build_graph(ds.s_pairs, ds.t_pairs, nu, ni)
+        loss_fn = lambda b: sum(obit.calculate_loss(params, ids, graph, b, cfg['n_layers'], cfg['lambda_source'],
+                                                    cfg['lambda_target'], cfg['connect_way'], cfg['reg_weight']))
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    rng = np.random.RandomState(1)
+    batch = dict(ds.pointwise_batch('source', S, k, rng, 'cpu'), **ds.pointwise_batch('target', S, k, rng, 'cpu'))
+    ncores = os.cpu_count() or 1
+    best = (None, 0.0)
+    def step():
+        opt.zero_grad()
+        loss_fn(batch).sum().backward()
+        opt.step()
+    for nt in sorted({min(ncores, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        step()
+        t0 = time.perf_counter(); step(); rate = 1.0 / (time.perf_counter() - t0)
+        if rate > best[1]:
+            best = (nt, rate)
+    torch.set_num_threads(best[0])
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < args.cpu_seconds and n < 100:
+        step(); n += 1
+    dt = time.perf_counter() - t0
+    rows = 2 * S * (1 + k)
+    return {'value': rows * n / dt, 'unit': 'interactions/s', 'cores': best[0], 'host_cores': ncores, 'kind': 'port',
+            'sample': '%d steps of %d rows, oracle calculate_loss + autograd + dense torch.optim.Adam, same table sizes, %d threads' % (n, rows, best[0])}
+
+
 # ------------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(args):
     """The oracle's row-wise step (oracle/train_step.py: same loss, same per-row gradients, lazy Adam) timed on this
@@ -326,9 +443,14 @@ def main():
     world, rank, local = dist_setup(args)
     dev = torch.device('cuda', local)
     import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
-    result = run_c5(args, world, rank, dev) if args.workload == 'c5' else run_c2(args, world, rank, dev)
+    if args.workload == 'c5':
+        result = run_c5(args, world, rank, dev)
+    elif args.workload == 'c2':
+        result = run_c2(args, world, rank, dev)
+    else:
+        result = run_model_workload(args, world, rank, dev)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'c5':
             result['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(result), flush=True)
     if world > 1 or args.force_shard:

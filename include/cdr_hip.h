@@ -152,6 +152,11 @@ int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const f
 int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
+/* hipGraph-capturable form: the step count is read from device memory (cdr_inc_i64 bumps it inside the graph) */
+int cdr_adam_dense_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev);
+int cdr_inc_i64(void* stream, int64_t* counter);
+
 /* cdr_gemm_f32 with a per-output-row scale and a pre-activation accumulate -- the CoNet cross unit
  * (conet.py:127-135):  first  C = s W^T + b           (cdr_gemm_f32, act none)
  *                      then   C = relu(C + m (.) (t H^T))   (rowscale = m, act relu, accumulate = 2)

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
                                                        float* __restrict__ C, int64_t ldc,
                                                        const float* __restrict__ bias, int act, int accumulate,
                                                        const float* __restrict__ rown, const float* __restrict__ coln,
-                                                       int vecA, int vecB, const float* __restrict__ rowscale) {
+                                                       int vecA, int vecB, const float* __restrict__ rowscale,
+                                                       int64_t k_chunk) {
     constexpr int WM = (BM == 128) ? 2 : 1;            // waves along M
     constexpr int WN = 4 / WM;                         // waves along N
     constexpr int TM = BM / (32 * WM);                 // 32x32 tiles per wave along M
@@ -113,9 +114,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
-        stage_tile<BM, TA>(As, A, lda, m0, M, k0, K, vecA != 0);
-        stage_tile<BN, !TB>(Bs, B, ldb, n0, N, k0, K, vecB != 0);
+    // split-K (blockIdx.y): weight-gradient shapes (tiny MxN, K = batch rows) would otherwise run on a handful of CUs;
+    // each K slice adds its partial product into a pre-zeroed C with fp32 atomics
+    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
+    const int64_t k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
+    const bool split = gridDim.y > 1;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage_tile<BM, TA>(As, A, lda, m0, M, k0, k_end, vecA != 0);
+        stage_tile<BN, !TB>(Bs, B, ldb, n0, N, k0, k_end, vecB != 0);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
@@ -155,6 +161,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
                     v = -(((-2.0f * v) + rown[m]) + cn);
                 } else {
                     if (rowscale) v *= rowscale[m];
+                    if (split) { atomicAdd(&C[m * ldc + n], v); continue; }
                     if (accumulate == 2) v = act_apply(act, (C[m * ldc + n] + v) + bv);       // pre-activation add
                     else {
                         v = act_apply(act, v + bv);
@@ -173,18 +180,30 @@ int launch(hipStream_t s, int64_t M, int64_t N, int64_t K, const float* A, int64
     // float4 global loads need 16-B aligned rows along the contiguous dimension
     const int vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
     const int vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
+    const int64_t tiles = (M <= 64 ? (M + 31) / 32 : (M + 127) / 128) * ((N + 127) / 128);
+    // split K when the output has too few tiles to fill the chip and the epilogue is a plain (or post-add) product
+    unsigned splits = 1;
+    int64_t k_chunk = K;
+    if (!SQ && tiles < 64 && K >= 1024 && bias == nullptr && act == CDR_ACT_NONE && accumulate != 2) {
+        k_chunk = 256;
+        splits = (unsigned)((K + k_chunk - 1) / k_chunk);
+        if (accumulate == 0) {
+            hipError_t e0 = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+            if (e0 != hipSuccess) { cdr_set_error("cdr_gemm_f32: memset failed: %s", hipGetErrorString(e0)); return (int)e0; }
+        }
+    }
     if (M <= 64) {
         constexpr int BM = 32, BN = 128;
         const int64_t grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-        gemm_f32_kernel<BM, BN, TA, TB, SQ><<<dim3((unsigned)grid), dim3(256), lds, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias,
-                                                                                      act, accumulate, rown, coln, vecA, vecB, rowscale);
+        gemm_f32_kernel<BM, BN, TA, TB, SQ><<<dim3((unsigned)grid, splits), dim3(256), lds, s>>>(
+            M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, rown, coln, vecA, vecB, rowscale, k_chunk);
     } else {
         constexpr int BM = 128, BN = 128;
         const int64_t grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-        gemm_f32_kernel<BM, BN, TA, TB, SQ><<<dim3((unsigned)grid), dim3(256), lds, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias,
-                                                                                      act, accumulate, rown, coln, vecA, vecB, rowscale);
+        gemm_f32_kernel<BM, BN, TA, TB, SQ><<<dim3((unsigned)grid, splits), dim3(256), lds, s>>>(
+            M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, rown, coln, vecA, vecB, rowscale, k_chunk);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdr_set_error("cdr_gemm_f32: launch failed: %s", hipGetErrorString(e)); return (int)e; }

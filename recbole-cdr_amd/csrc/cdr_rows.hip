@@ -77,21 +77,22 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(int act, const float* _
     }
 }
 
-// ---- column sums (bias gradients): one block per 64 columns, rows strided over the 4 waves, fixed order ----------
+// ---- column sums (bias gradients): block = 64 columns x a 256-row slab, rows strided over the 4 waves; slabs combine
+// with one fp32 atomic per column per block into a pre-zeroed (or accumulated-into) output ----------------------------
+constexpr int kColsumRows = 256;
 __global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int64_t M, int64_t N,
-                                                        float* __restrict__ out, int accumulate) {
-    __shared__ double sm[4][64];
+                                                        float* __restrict__ out) {
+    __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + lane;
-    double s = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.y * kColsumRows;
+    const int64_t r1 = r0 + kColsumRows < M ? r0 + kColsumRows : M;
+    float s = 0.f;
     if (col < N)
-        for (int64_t m = wave; m < M; m += 4) s += (double)X[m * N + col];
+        for (int64_t m = r0 + wave; m < r1; m += 4) s += X[m * N + col];
     sm[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && col < N) {
-        const double t = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
-        out[col] = (accumulate ? out[col] : 0.f) + (float)t;
-    }
+    if (wave == 0 && col < N) atomicAdd(out + col, ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane]);
 }
 
 // ---- MSE ------------------------------------------------------------------------------------------------------------
@@ -148,7 +149,45 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(float* __restrict__ 
     }
 }
 
+// capturable variant: the step count lives on the device (hipGraph replays bake host scalars in)
+__global__ __launch_bounds__(kBlock) void adam_dense_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                                float lr, float b1, float b2, float eps, float wd,
+                                                                const int64_t* __restrict__ step_dev) {
+    const double st = (double)step_dev[0];
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, st)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        float gv = g[e];
+        const float pv = p[e];
+        if (wd != 0.f) gv += wd * pv;
+        const float mv = m[e] + (gv - m[e]) * (1.0f - b1);
+        const float vv = b2 * v[e] + (1.0f - b2) * gv * gv;
+        m[e] = mv; v[e] = vv;
+        p[e] = pv - step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void inc_i64_kernel(int64_t* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }
+
 }  // namespace
+
+extern "C" int cdr_adam_dense_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev) {
+    CDR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && n > 0);
+    adam_dense_dev_kernel<<<dim3(grid_cap((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
+        param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_inc_i64(void* stream, int64_t* counter) {
+    CDR_CHECK_ARG(counter);
+    inc_i64_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(counter);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
 
 extern "C" int cdr_gather_rows(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out) {
     CDR_CHECK_ARG(tab && ids && out && D > 0 && n > 0);
@@ -200,7 +239,9 @@ extern "C" int cdr_act_bwd(void* stream, int act, const float* y, const float* g
 extern "C" int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate) {
     (void)ctx;
     CDR_CHECK_ARG(X && out && M > 0 && N > 0);
-    colsum_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(kBlock), 0, (hipStream_t)stream>>>(X, M, N, out, accumulate);
+    if (!accumulate) CDR_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
+    colsum_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)((M + kColsumRows - 1) / kColsumRows)), dim3(kBlock), 0,
+                    (hipStream_t)stream>>>(X, M, N, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -1,0 +1,53 @@
+"""Synthetic cross-domain datasets in the reference's id-space contract (dataset.py:384-399): what bench.py and the
+examples feed the models with when no interaction files are available (the reference's own sample .inter files are
+absent from its repository: SURVEY F3)."""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+
+class _Domain:
+    def __init__(self, name, n_user, n_item, inter_feat):
+        self.uid_field, self.iid_field, self.label_field = f'{name}_user_id', f'{name}_item_id', f'{name}_label'
+        self._n = {self.uid_field: n_user, self.iid_field: n_item}
+        self.inter_feat = inter_feat
+
+    def num(self, field):
+        return self._n[field]
+
+
+class SyntheticCrossDomainDataset:
+    """ids: [0]=PAD, [1,OU) overlap, [OU,OU+TO) target-only, [OU+TO,total) source-only; uniform random interactions."""
+
+    def __init__(self, OU, TOU, SOU, OI, TOI, SOI, n_source_inter, n_target_inter, seed=2022):
+        rng = np.random.RandomState(seed)
+        self.num_overlap_user, self.num_overlap_item = OU, OI
+        self.num_target_only_user, self.num_source_only_user = TOU, SOU
+        self.num_target_only_item, self.num_source_only_item = TOI, SOI
+        self.num_total_user, self.num_total_item = OU + TOU + SOU, OI + TOI + SOI
+        self.overlap_id_field = 'overlap'
+        self.src_users = np.concatenate([np.arange(1, OU), np.arange(OU + TOU, self.num_total_user)])
+        self.src_items = np.concatenate([np.arange(1, OI), np.arange(OI + TOI, self.num_total_item)])
+        self.tgt_users, self.tgt_items = np.arange(1, OU + TOU), np.arange(1, OI + TOI)
+        self.s_pairs = np.unique(np.stack([rng.choice(self.src_users, n_source_inter), rng.choice(self.src_items, n_source_inter)], 1), axis=0)
+        self.t_pairs = np.unique(np.stack([rng.choice(self.tgt_users, n_target_inter), rng.choice(self.tgt_items, n_target_inter)], 1), axis=0)
+        s_feat = {'source_user_id': torch.from_numpy(self.s_pairs[:, 0].copy()), 'source_item_id': torch.from_numpy(self.s_pairs[:, 1].copy())}
+        t_feat = {'target_user_id': torch.from_numpy(self.t_pairs[:, 0].copy()), 'target_item_id': torch.from_numpy(self.t_pairs[:, 1].copy())}
+        self.source_domain_dataset = _Domain('source', OU + SOU, OI + SOI, s_feat)
+        self.target_domain_dataset = _Domain('target', OU + TOU, OI + TOI, t_feat)
+
+    def inter_matrix(self, form='coo', value_field=None, domain='source'):
+        p = self.s_pairs if domain == 'source' else self.t_pairs
+        return sp.coo_matrix((np.ones(len(p), dtype=np.float32), (p[:, 0], p[:, 1])),
+                             shape=(self.num_total_user, self.num_total_item))
+
+    def pointwise_batch(self, domain, S, k, rng, device):
+        """recbole POINTWISE layout: S positives repeated (1+k) times, negatives k-major, labels [1]*S + [0]*(S k)."""
+        pairs = self.s_pairs if domain == 'source' else self.t_pairs
+        items = self.src_items if domain == 'source' else self.tgt_items
+        sel = pairs[rng.randint(0, len(pairs), S)]
+        u = np.tile(sel[:, 0], 1 + k)
+        i = np.concatenate([sel[:, 1], rng.choice(items, S * k)])
+        y = np.concatenate([np.ones(S), np.zeros(S * k)]).astype(np.float32)
+        return {f'{domain}_user_id': torch.from_numpy(u).to(device), f'{domain}_item_id': torch.from_numpy(i).to(device),
+                f'{domain}_label': torch.from_numpy(y).to(device)}

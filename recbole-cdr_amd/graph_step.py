@@ -1,0 +1,49 @@
+"""hipGraph capture of one drop-in training step (calculate_loss -> backward -> dense Adam).
+
+On small, L2-resident configurations (BASELINE C1-C4) the reference's step is hundreds of tiny launches; ours is fewer
+but still launch/host bound from Python.  Every native call enqueues on torch's current stream and allocates through
+torch's caching allocator, so the whole step can be captured once into a hipGraph and replayed: the host then pays one
+graph launch per step instead of one ctypes call + one allocation per kernel.  Batch tensors are static buffers that
+``step`` copies the new ids / labels into (same shapes every step; a ragged last batch runs eagerly).
+"""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, example_interaction, warmup=3):
+        self.model, self.optimizer = model, optimizer
+        self.static = {k: v.clone() for k, v in example_interaction.items()}
+        self.graph = None
+        self.loss = None
+        self._capture(warmup)
+
+    def _eager(self, interaction):
+        self.optimizer.zero_grad(set_to_none=False)
+        losses = self.model.calculate_loss(interaction)
+        loss = sum(losses) if isinstance(losses, tuple) else losses
+        loss = loss.sum()
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _capture(self, warmup):
+        # populate .grad and the optimizer state (and every lazily created native context) before capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._eager(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager(self.static)
+
+    def step(self, interaction):
+        same = all(k in interaction and interaction[k].shape == v.shape for k, v in self.static.items())
+        if not same:
+            return self._eager(interaction)
+        for k, v in self.static.items():
+            v.copy_(interaction[k])
+        self.graph.replay()
+        return self.loss

@@ -14,25 +14,28 @@ from ..utils import train_mode2state
 
 
 class DenseAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (amsgrad=False), each parameter updated by one native kernel launch."""
+    """torch.optim.Adam semantics (amsgrad=False), each parameter updated by one native kernel launch.  The step count is
+    a device scalar bumped by a kernel, so ``step()`` is hipGraph-capturable (graph_step.GraphedTrainStep)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
     def step(self, closure=None):
+        from .. import binding as B_
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is None:
-                    continue
+                    continue                      # like torch: a parameter without a gradient keeps its own step count
                 st = self.state[p]
                 if not st:
-                    st['step'] = 0
+                    st['step'] = torch.zeros(1, device=p.device, dtype=torch.int64)     # per-parameter, on device
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
-                st['step'] += 1
-                F_.adam_dense_(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], st['step'], lr=group['lr'],
-                               betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'])
+                B_.call('cdr_inc_i64', B_.stream(), B_.i64(st['step']))
+                B_.call('cdr_adam_dense_dev', B_.stream(), B_.f32(p.data), B_.f32(p.grad.contiguous()), B_.f32(st['exp_avg']),
+                        B_.f32(st['exp_avg_sq']), p.numel(), float(group['lr']), float(group['betas'][0]),
+                        float(group['betas'][1]), float(group['eps']), float(group['weight_decay']), B_.i64(st['step']))
 
 
 def early_stopping(value, best, cur_step, max_step, bigger=True):
