@@ -590,3 +590,74 @@ def test_graphed_step_equals_eager_step():
         diff = (p2 - p1).abs()
         assert float(diff.max()) <= 0.01 * 2 * 7 + 1e-6, k                 # at most (steps) x 2 lr on any element
         assert float((diff > 1e-4).float().mean()) < 0.02, k                # and only on a small fraction
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def test_edge_single_row_batches_and_int32_ids():
+    """B = 1 for EMCDR, the 2-row minimum for CoNet (conet.py:140), int32 / non-contiguous id tensors."""
+    from oracle import emcdr as oem, conet as oconet
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    ids = IdSpace(OU=6, TOU=5, SOU=4, OI=1, TOI=9, SOI=8)
+    torch.manual_seed(2)
+    cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=8, target_embedding_size=8, reg_weight=0.02,
+                      mapping_function='linear', mlp_hidden_size=[8])
+    m = EMCDR(cfg, FakeDataset(ids)).to(DEV)
+    params = {k: v.detach().cpu() for k, v in m.named_parameters()}
+    inter = {'target_user_id': torch.tensor([3]), 'target_item_id': torch.tensor([4]), 'neg_target_item_id': torch.tensor([7])}
+    m.set_phase('TARGET')
+    assert_close(m.calculate_loss(to_dev(inter, DEV)), oem.calculate_loss(params, ids, inter, 'TARGET', 'BPR', 0.02))
+    wide = torch.arange(20).view(10, 2)                         # non-contiguous column views, int32
+    inter2 = {'target_user_id': (wide[:, 0] % 10 + 1).to(torch.int32), 'target_item_id': (wide[:, 1] % 9 + 1).to(torch.int32),
+              'neg_target_item_id': (wide[:, 0] % 7 + 1)}
+    ref2 = oem.calculate_loss(params, ids, {k: v.long() for k, v in inter2.items()}, 'TARGET', 'BPR', 0.02)
+    assert_close(m.calculate_loss(to_dev(inter2, DEV)), ref2)
+    cfg = base_config(DEV, embedding_size=8, reg_weight=0.01, mlp_hidden_size=[8, 4])
+    c = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    cp = {k: v.detach().cpu() for k, v in c.named_parameters()}
+    # (with B = 1 the reference's squeeze() yields a 0-d prediction that torch's BCELoss rejects against a [1] label, so
+    #  the smallest batch the reference itself can train on is 2 rows -- PAD ids included)
+    two = {'source_user_id': torch.tensor([2, 0]), 'source_item_id': torch.tensor([12, 0]), 'source_label': torch.tensor([1.0, 0.0]),
+           'target_user_id': torch.tensor([0, 7]), 'target_item_id': torch.tensor([0, 3]), 'target_label': torch.tensor([0.0, 1.0])}
+    assert_close(c.calculate_loss(to_dev(two, DEV)), oconet.calculate_loss(cp, ids, two))
+
+
+def test_edge_saturation_and_all_duplicate_ids():
+    """BPR in deep saturation (sigmoid -> 0: loss = -log(1e-10), zero gradient) and a batch that hits ONE user and ONE
+    item 4,096 times (longest possible segments in the row-wise apply, heaviest atomics in the dense backward)."""
+    from oracle import losses
+    from recbole_cdr_amd import functional as F_
+    from recbole_cdr_amd.fused import FusedBPRStep
+    U = torch.tensor([[40.0, 0, 0, 0], [0.5, 0.2, -0.1, 0.3]]); I = torch.tensor([[-1.0, 0, 0, 0], [1.0, 0, 0, 0], [0.3, 0.1, 0.2, -0.4]])
+    u = torch.tensor([0, 0, 1]); p = torch.tensor([0, 1, 2]); n = torch.tensor([1, 0, 0])
+    Ur, Ir = U.clone().requires_grad_(True), I.clone().requires_grad_(True)
+    ref = losses.bpr_loss((Ur[u] * Ir[p]).sum(1), (Ur[u] * Ir[n]).sum(1)) + 0.01 * losses.emb_loss(Ur[u], Ir[p])
+    ref.sum().backward()
+    Ud, Id = U.to(DEV).requires_grad_(True), I.to(DEV).requires_grad_(True)
+    got = F_.BPRGatherLoss.apply(Ud, Id, u.to(DEV), p.to(DEV), n.to(DEV), 1e-10, 0.01)
+    got.sum().backward()
+    assert_close(got, ref); assert_close(Ud.grad, Ur.grad); assert_close(Id.grad, Ir.grad)
+    assert torch.isfinite(Ud.grad).all()
+    torch.manual_seed(9)
+    D, B = 64, 4096
+    U0, I0 = torch.randn(5, D) * 0.2, torch.randn(6, D) * 0.2
+    uu, pp, nn = torch.full((B,), 3), torch.full((B,), 2), torch.full((B,), 5)
+    Ur, Ir = U0.clone().requires_grad_(True), I0.clone().requires_grad_(True)
+    ref = losses.bpr_loss((Ur[uu] * Ir[pp]).sum(1), (Ur[uu] * Ir[nn]).sum(1)) + 0.05 * losses.emb_loss(Ur[uu], Ir[pp])
+    ref.sum().backward()
+    Ud, Id = U0.clone().to(DEV), I0.clone().to(DEV)
+    fs = FusedBPRStep(Ud, Id, B, opt='sgd', lr=0.1, reg_weight=0.05)
+    out = fs.step(uu.to(DEV), pp.to(DEV), nn.to(DEV))
+    assert_close(out[0], ref)
+    assert_close(Ud, U0 - 0.1 * Ur.grad, rtol=1e-4); assert_close(Id, I0 - 0.1 * Ir.grad, rtol=1e-4)
+
+
+def test_edge_wide_rows_and_odd_widths_fused_step_rejects_cleanly():
+    """The fused step supports D % 4 == 0, D <= 256; anything else must fail loudly (error code + message), never fall back."""
+    from recbole_cdr_amd.fused import FusedBPRStep
+    U, I = torch.randn(10, 6, device=DEV), torch.randn(10, 6, device=DEV)
+    fs = FusedBPRStep(U, I, 4, opt='sgd')
+    ids = torch.tensor([1, 2, 3, 4], device=DEV)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        fs.step(ids, ids, ids)
