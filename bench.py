@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--no-fullsort', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-pipeline', action='store_true', help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
     return ap.parse_args()
 
@@ -87,6 +88,14 @@ def run_c5(args, world, rank, dev):
     D, B = args.dim, args.batch
     OU, TOI = args.users, args.items_per_domain
     n_users, n_items = OU, 1 + 2 * TOI                     # union sizes: OI = 1 (PAD), TOI = SOI = 10 M
+    # memory guard: tables (x3 with Adam moments) must fit what this GPU has free; shrink the USER count if they do not
+    # (never silently: the workload string below always states the sizes actually used)
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    state_mult = 3 if args.opt == 'adam' else 1
+    need = lambda nu: 2 * 4.0 * D * (nu + n_items) * state_mult / max(world, 1) + 8e9
+    while need(n_users) > free_b and n_users > 2_000_000:
+        n_users = n_users // 2 + 1
+    OU = n_users
     gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
     sharded = world > 1 or args.force_shard
     if not sharded:
@@ -102,7 +111,7 @@ def run_c5(args, world, rank, dev):
         # one process group (= one RCCL communicator + stream) and one HIP stream per domain: the SOURCE and TARGET
         # steps touch disjoint tables, so one domain's all-to-alls overlap the other's kernels
         groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
-        streams = {d: torch.cuda.Stream(device=dev) for d in ('source', 'target')}
+        streams = {d: (None if args.no_pipeline else torch.cuda.Stream(device=dev)) for d in ('source', 'target')}
         steps = {'source': ShardedBPRStep(tabs['su'], tabs['si'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
                                           group=groups['source'], stream=streams['source']),
                  'target': ShardedBPRStep(tabs['tu'], tabs['ti'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
@@ -124,7 +133,7 @@ def run_c5(args, world, rank, dev):
 
     def one_step(i):
         b = batches[i % pool]
-        if sharded:
+        if sharded and not args.no_pipeline:
             run_pipelined([steps[dom].step_gen(*b[dom]) for dom in ('source', 'target')])
         else:
             for dom in ('source', 'target'):

@@ -272,6 +272,14 @@ int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* 
                       const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
+/* ---- negative sampler on device (recbole_cdr/sampler/crossdomain_sampler.py:139-175,212-221) ----------
+ * out[j + m*S] (k-major) = m-th negative of users[j]: uniform over [lo0,hi0) U [lo1,hi1), redrawn while it is one of the
+ * user's used items (CSR over users, ascending column ids; NULL = no rejection).  *fail_flag is set if 64 redraws did
+ * not find a free item for some element (the reference raises for such users at construction, :241-247).             */
+int cdr_neg_sample_uniform(void* stream, const int64_t* users, int64_t S, int k, int64_t lo0, int64_t hi0,
+                           int64_t lo1, int64_t hi1, const int64_t* used_indptr, const int64_t* used_indices,
+                           uint64_t seed, int64_t* out, int* fail_flag);
+
 /* ---- owner routing for row-sharded tables (row r lives on rank r % world) -- index plumbing of shard.py --------
  * cdr_route_by_owner: stable counting sort of the ids (ids1 appended after ids0) by owner = id % world.
  *     perm[q] = occurrence index at sorted position q ; counts[k] = number of ids owned by rank k (device int64 [world])

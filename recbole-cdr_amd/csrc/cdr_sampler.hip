@@ -1,0 +1,64 @@
+// Negative sampler on device: recbole's `sample_by_user_ids` as used by the cross-domain loaders
+// (recbole_cdr/sampler/crossdomain_sampler.py:139-175,187-221): for every (user j, slot m) draw an item uniformly from the
+// domain's candidate id ranges and redraw while it is one of the user's used (interacted) items; output laid out k-major,
+// neg[j + m*S] = m-th negative of positive j (crossdomain_sampler.py:148-152).
+//   candidates = [lo0, hi0) U [lo1, hi1)   (source domain: [1,OI) U [OI+TOI,total) ; target domain: [1,n_items) U {})
+//   used items = CSR over users, column ids sorted ascending per user (binary search)
+// Counter-based RNG (splitmix64 of seed, element, attempt): reproducible per seed, no state.  The reference draws from
+// numpy's global generator, so individual draws are not comparable -- the distribution and the constraints are.
+#include "cdr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void neg_sample_kernel(const int64_t* __restrict__ users, int64_t S, int k, int64_t lo0,
+                                                            int64_t hi0, int64_t lo1, int64_t hi1,
+                                                            const int64_t* __restrict__ indptr,
+                                                            const int64_t* __restrict__ indices, uint64_t seed,
+                                                            int max_tries, int64_t* __restrict__ out,
+                                                            int* __restrict__ fail_flag) {
+    const int64_t n0 = hi0 > lo0 ? hi0 - lo0 : 0, n1 = hi1 > lo1 ? hi1 - lo1 : 0, ncand = n0 + n1;
+    const int64_t total = S * (int64_t)k, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t u = users[e % S];
+        const int64_t b = indptr ? indptr[u] : 0, en = indptr ? indptr[u + 1] : 0;
+        int64_t pick = -1;
+        for (int t = 0; t < max_tries; ++t) {
+            const uint64_t r = mix64(seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)t * 0xD1B54A32D192ED03ull);
+            // unbiased enough for catalogue sizes << 2^64: multiply-high of a 64-bit uniform by ncand
+            const int64_t c = (int64_t)__umul64hi(r, (uint64_t)ncand);
+            const int64_t id = c < n0 ? lo0 + c : lo1 + (c - n0);
+            int64_t l = b, h = en;                       // binary search in the user's sorted used items
+            while (l < h) {
+                const int64_t mid = (l + h) >> 1;
+                if (indices[mid] < id) l = mid + 1; else h = mid;
+            }
+            if (!(l < en && indices[l] == id)) { pick = id; break; }
+        }
+        if (pick < 0) { pick = n0 ? lo0 : lo1; if (fail_flag) atomicExch(fail_flag, 1); }
+        out[e] = pick;
+    }
+}
+
+}  // namespace
+
+extern "C" int cdr_neg_sample_uniform(void* stream, const int64_t* users, int64_t S, int k, int64_t lo0, int64_t hi0,
+                                      int64_t lo1, int64_t hi1, const int64_t* used_indptr, const int64_t* used_indices,
+                                      uint64_t seed, int64_t* out, int* fail_flag) {
+    CDR_CHECK_ARG(users && out && S > 0 && k > 0);
+    CDR_CHECK_ARG((hi0 > lo0) || (hi1 > lo1));
+    CDR_CHECK_ARG((used_indptr == nullptr) == (used_indices == nullptr));
+    int64_t g = (S * k + kBlock - 1) / kBlock;
+    if (g > CDR_NUM_CU * 8) g = CDR_NUM_CU * 8;
+    neg_sample_kernel<<<dim3((unsigned)g), dim3(kBlock), 0, (hipStream_t)stream>>>(users, S, k, lo0, hi0, lo1, hi1, used_indptr,
+                                                                                 used_indices, seed, 64, out, fail_flag);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

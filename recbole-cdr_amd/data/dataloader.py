@@ -150,3 +150,44 @@ class CrossDomainDataloader:
         if self.source_dataloader.pr != 0 or self.target_dataloader.pr != 0:
             raise PermissionError('Cannot change dataloader\'s state within an epoch')
         self.state = state
+
+
+class FullSortEvalLoader:
+    """Full-sort evaluation batches in recbole's ``FullSortEvalDataLoader`` shape (third-party):
+    yields ``(interaction{uid_field: users}, (history_rows, history_cols), positive_rows, positive_cols)`` with
+    ``eval_batch_size // item_num`` (at least 1) users per batch.
+
+    ``revoke=(overlap_item_num, target_only_item_num)`` turns it into the SOURCE-domain loader of
+    recbole_cdr/data/dataloader.py:189-247: source item ids are non-contiguous, ``full_sort_predict`` concatenates the two
+    ranges, so positives / history ``>= OI`` are shifted down by ``num_target_only_item`` (native ``cdr_revoke_map``)."""
+
+    def __init__(self, uid_field, eval_pairs, history_pairs, item_num, eval_batch_size, device, revoke=None):
+        import numpy as np
+        self.uid_field, self.device = uid_field, device
+        self.step = max(eval_batch_size // item_num, 1)
+        ev = np.unique(np.asarray(eval_pairs, dtype=np.int64), axis=0)
+        hi = np.unique(np.asarray(history_pairs, dtype=np.int64), axis=0) if len(history_pairs) else np.zeros((0, 2), np.int64)
+        self.users = np.unique(ev[:, 0])
+        self._ev = (torch.from_numpy(ev[:, 0].copy()).to(device), torch.from_numpy(ev[:, 1].copy()).to(device))
+        self._hi = (torch.from_numpy(hi[:, 0].copy()).to(device), torch.from_numpy(hi[:, 1].copy()).to(device))
+        if revoke is not None:
+            from .remap import revoke_map
+            self._ev = (self._ev[0], revoke_map(self._ev[1], *revoke))
+            self._hi = (self._hi[0], revoke_map(self._hi[1], *revoke) if self._hi[1].numel() else self._hi[1])
+        self._users_t = torch.from_numpy(self.users.copy()).to(device)
+
+    def __len__(self):
+        return (len(self.users) + self.step - 1) // self.step
+
+    def __iter__(self):
+        n_user_ids = int(self._users_t.max().item()) + 1 if self._users_t.numel() else 1
+        for b in range(len(self)):
+            us = self._users_t[b * self.step:(b + 1) * self.step]
+            row_of = torch.full((n_user_ids,), -1, device=self.device, dtype=torch.int64)
+            row_of[us] = torch.arange(us.numel(), device=self.device)
+            pm = row_of[self._ev[0].clamp(max=n_user_ids - 1)] >= 0
+            pm &= self._ev[0] < n_user_ids
+            hm = (self._hi[0] < n_user_ids)
+            hm &= row_of[self._hi[0].clamp(max=n_user_ids - 1)] >= 0
+            yield (Interaction({self.uid_field: us}), (row_of[self._hi[0][hm]], self._hi[1][hm]),
+                   row_of[self._ev[0][pm]], self._ev[1][pm])

@@ -1,0 +1,46 @@
+"""Device-side negative sampler mirroring recbole_cdr/sampler/crossdomain_sampler.py (CrossDomainSourceSampler) and
+recbole's target-domain sampler: uniform candidates, rejection against the user's used items, k-major output."""
+import numpy as np
+import torch
+
+from . import binding as B_
+
+
+class DeviceNegSampler:
+    """``sample_by_user_ids(user_ids, item_ids, num)`` like the reference's samplers, but the draw runs on the GPU.
+
+    domain='source': candidates [1, OI) U [OI+TOI, total_items)   (crossdomain_sampler.py:212-214)
+    domain='target': candidates [1, OI+TOI)                        (recbole Sampler over the target dataset's items)
+    ``used_pairs``: [n, 2] (user, item) interactions whose items must never be returned for that user."""
+
+    def __init__(self, dataset, domain, used_pairs, device, seed=2022):
+        OI, TOI = dataset.num_overlap_item, dataset.num_target_only_item
+        total_i, total_u = dataset.num_total_item, dataset.num_total_user
+        if domain == 'source':
+            self.ranges = (1, OI, OI + TOI, total_i)
+        else:
+            self.ranges = (1, OI + TOI, 0, 0)
+        pairs = np.unique(np.asarray(used_pairs, dtype=np.int64), axis=0)          # sorted by (user, item)
+        indptr = np.zeros(total_u + 1, dtype=np.int64)
+        np.cumsum(np.bincount(pairs[:, 0], minlength=total_u), out=indptr[1:])
+        n_cand = max(self.ranges[1] - self.ranges[0], 0) + max(self.ranges[3] - self.ranges[2], 0)
+        if (np.diff(indptr) >= n_cand).any():
+            raise ValueError('Some users have interacted with all items, which we can not sample negative items for them. '
+                             'Please set `user_inter_num_interval` to filter those users.')
+        self.indptr = torch.from_numpy(indptr).to(device)
+        self.indices = torch.from_numpy(pairs[:, 1].copy()).to(device)
+        self.fail = torch.zeros(1, device=device, dtype=torch.int32)
+        self.seed, self.calls, self.device = int(seed), 0, device
+
+    def sample_by_user_ids(self, user_ids, item_ids, num):
+        users = user_ids.to(self.device).contiguous().to(torch.int64)
+        S = users.numel()
+        out = torch.empty(S * num, device=self.device, dtype=torch.int64)
+        self.calls += 1
+        lo0, hi0, lo1, hi1 = self.ranges
+        B_.call('cdr_neg_sample_uniform', B_.stream(), B_.i64(users), S, int(num), lo0, hi0, lo1, hi1, B_.i64(self.indptr),
+                B_.i64(self.indices), (self.seed * 0x9E3779B1 + self.calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF, B_.i64(out),
+                B_.raw(self.fail))
+        return out
+
+    __call__ = sample_by_user_ids

@@ -661,3 +661,99 @@ def test_edge_wide_rows_and_odd_widths_fused_step_rejects_cleanly():
     ids = torch.tensor([1, 2, 3, 4], device=DEV)
     with pytest.raises(RuntimeError, match='invalid argument'):
         fs.step(ids, ids, ids)
+
+
+def test_device_negative_sampler_constraints_and_distribution():
+    """recbole sampler contract (crossdomain_sampler.py:139-175,212-221): k-major layout, candidates only from the domain's
+    id ranges, never a used item of that user, uniform over what is left, reproducible per seed.  Checked against the
+    reference's candidate lists restated in the oracle."""
+    from oracle import remap as oremap
+    from recbole_cdr_amd.sampler import DeviceNegSampler
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    ds = SyntheticCrossDomainDataset(OU=30, TOU=20, SOU=25, OI=6, TOI=40, SOI=50, n_source_inter=900, n_target_inter=700, seed=3)
+    _, cand_items = oremap.source_id_lists(30, 20, 25, 6, 40, 50)
+    smp = DeviceNegSampler(ds, 'source', ds.s_pairs, DEV, seed=1)
+    users = torch.from_numpy(ds.s_pairs[:400, 0].copy())
+    k = 5
+    neg = smp.sample_by_user_ids(users, None, k).cpu().numpy()
+    assert neg.shape == (400 * k,)
+    assert np.isin(neg, cand_items).all()
+    used = {}
+    for u, i in ds.s_pairs:
+        used.setdefault(int(u), set()).add(int(i))
+    for m in range(k):
+        for j in range(400):
+            assert int(neg[j + m * 400]) not in used[int(users[j])]            # k-major: neg[j + m*S] belongs to user j
+    assert int(smp.fail.item()) == 0
+    # uniformity for one heavy user: chi-square over its allowed items
+    u0 = int(np.bincount(ds.s_pairs[:, 0]).argmax())
+    allowed = np.array([i for i in cand_items if i not in used[u0]])
+    draws = smp.sample_by_user_ids(torch.full((20000,), u0), None, 4).cpu().numpy()
+    assert np.isin(draws, allowed).all()
+    cnt = np.array([(draws == i).sum() for i in allowed], dtype=np.float64)
+    exp = len(draws) / len(allowed)
+    chi2 = ((cnt - exp) ** 2 / exp).sum()
+    assert chi2 < len(allowed) + 6 * np.sqrt(2 * len(allowed)), (chi2, len(allowed))
+    # reproducible: same seed and call index -> same draws ; target-domain ranges
+    a = DeviceNegSampler(ds, 'source', ds.s_pairs, DEV, seed=7).sample_by_user_ids(users, None, 2)
+    b = DeviceNegSampler(ds, 'source', ds.s_pairs, DEV, seed=7).sample_by_user_ids(users, None, 2)
+    assert torch.equal(a, b)
+    t = DeviceNegSampler(ds, 'target', ds.t_pairs, DEV).sample_by_user_ids(torch.from_numpy(ds.t_pairs[:100, 0].copy()), None, 3).cpu().numpy()
+    assert (t >= 1).all() and (t < 6 + 40).all()
+
+
+def test_end_to_end_emcdr_learns_with_device_sampler():
+    """The whole slice on the GPU: synthetic clustered interactions -> four-state loader with the device negative sampler
+    -> CrossDomainTrainer (SOURCE, TARGET, OVERLAP phases, native dense Adam) -> full-sort evaluation in the target AND in
+    the source domain (revoke map).  The model must beat random ranking by a wide margin."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader, FullSortEvalLoader
+    from recbole_cdr_amd.sampler import DeviceNegSampler
+    from recbole_cdr_amd.utils import InputType
+    rng = np.random.RandomState(0)
+    ids = IdSpace(OU=201, TOU=100, SOU=100, OI=1, TOI=120, SOI=120)
+    C = 6                                                    # latent clusters: user c likes items of cluster c
+    def make(users, items, per_user):
+        pairs = []
+        for u in users:
+            own = items[items % C == u % C]
+            pairs += [(u, i) for i in rng.choice(own, per_user, replace=False)]
+        return np.array(pairs, dtype=np.int64)
+    src_users = np.r_[np.arange(1, ids.OU), np.arange(ids.OU + ids.TOU, ids.total_num_users)]
+    src_items = np.arange(ids.OI + ids.TOI, ids.total_num_items)
+    tgt_users, tgt_items = np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI)
+    s_all, t_all = make(src_users, src_items, 10), make(tgt_users, tgt_items, 10)
+    def split(p):
+        m = rng.rand(len(p)) < 0.8
+        return p[m], p[~m]
+    s_tr, s_te = split(s_all); t_tr, t_te = split(t_all)
+    ds = FakeDataset(ids, s_pairs=s_tr, t_pairs=t_tr)
+    cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=32, target_embedding_size=32, reg_weight=0.0,
+                      mapping_function='linear', mlp_hidden_size=[32], learning_rate=0.02, train_modes=['SOURCE', 'TARGET', 'OVERLAP'],
+                      epoch_num=['25', '25', '5'], source_split=True, eval_step=25, epochs=25, topk=[10], valid_metric='Recall@10')
+    torch.manual_seed(0)
+    model = EMCDR(cfg, ds).to(DEV)
+    dev_t = lambda a: torch.from_numpy(a.copy()).to(DEV)
+    s_smp, t_smp = DeviceNegSampler(ds, 'source', s_tr, DEV), DeviceNegSampler(ds, 'target', t_tr, DEV)
+    train = CrossDomainDataloader(
+        DomainTrainLoader({'source_user_id': dev_t(s_tr[:, 0]), 'source_item_id': dev_t(s_tr[:, 1])}, 'source_user_id', 'source_item_id',
+                          'source_label', 'neg_', 512, 1, InputType.PAIRWISE, s_smp, shuffle=True),
+        DomainTrainLoader({'target_user_id': dev_t(t_tr[:, 0]), 'target_item_id': dev_t(t_tr[:, 1])}, 'target_user_id', 'target_item_id',
+                          'target_label', 'neg_', 512, 1, InputType.PAIRWISE, t_smp, shuffle=True),
+        OverlapDataloader(ids.OU, 64, device=DEV, shuffle=True))
+    n_src_items = ids.OI + ids.SOI
+    valid = (FullSortEvalLoader('source_user_id', s_te, s_tr, n_src_items, 4096, DEV, revoke=(ids.OI, ids.TOI)),
+             FullSortEvalLoader('target_user_id', t_te, t_tr, ids.target_num_items, 4096, DEV))
+    trainer = CrossDomainTrainer(cfg, model)
+    trainer.fit(train, valid)
+    assert model.phase == 'OVERLAP'
+    model.set_phase('TARGET')
+    res_t = trainer.evaluate(valid[1])
+    model.set_phase('SOURCE')
+    res_s = trainer.evaluate(valid[0])
+    random_recall = 10.0 / ids.target_num_items
+    assert res_t['recall@10'] > 5 * random_recall, res_t
+    assert res_s['recall@10'] > 5 * random_recall, res_s
+    assert res_t['ndcg@10'] > 0 and res_t['mrr@10'] > 0
