@@ -257,7 +257,8 @@ int cdr_revoke_map(void* stream, const int64_t* ids, int64_t n, int64_t overlap_
 int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      const float* user_tab, const float* item_tab, int D,
                      const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, int64_t B_mean,
-                     float gamma, float reg_weight, float* out9, float* GU /* [B,D] */, float* GP /* [B,D] */);
+                     float gamma, float reg_weight, float* out9, float* GU /* [B,D] */, float* GP /* [B,D] */,
+                     int scatter /* != 0 (row-sharded step): GP[pid[b]] = g u, GP[nid[b]] = -g u instead of GP[b] = g u */);
 int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6);
 int cdr_build_grad_rows(void* stream, const float* G, const uint32_t* order, int64_t n, int D,
                         int64_t neg_start, int64_t reg_limit, const float* rows, const float* coef, float* out);
@@ -270,7 +271,8 @@ int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, co
 int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                       const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
                       const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef,
-                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                      const int64_t* occ_ids /* NULL, or per-occurrence ids whose bit 62 marks the EmbLoss occurrences */);
 
 /* ---- negative sampler on device (recbole_cdr/sampler/crossdomain_sampler.py:139-175,212-221) ----------
  * out[j + m*S] (k-major) = m-th negative of users[j]: uniform over [lo0,hi0) U [lo1,hi1), redrawn while it is one of the
@@ -283,13 +285,14 @@ int cdr_neg_sample_uniform(void* stream, const int64_t* users, int64_t S, int k,
 /* ---- owner routing for row-sharded tables (row r lives on rank r % world) -- index plumbing of shard.py --------
  * cdr_route_by_owner: stable counting sort of the ids (ids1 appended after ids0) by owner = id % world.
  *     perm[q] = occurrence index at sorted position q ; counts[k] = number of ids owned by rank k (device int64 [world])
- * cdr_permute_i64:    out[q] = src[perm[q]] / divisor   (src = src0 ++ src1 ; divisor = world turns ids into local rows)
+ * cdr_permute_i64:    out[q] = src[perm[q]] / divisor (| 1<<62 for tagged occurrences)  (src = src0 ++ src1 ; divisor = world
+ *                     turns ids into local rows)
  * cdr_inverse_perm:   pos[perm[q]] = q                                                                              */
 int cdr_route_workspace_bytes(int64_t n, int world, size_t* bytes);
 int cdr_route_by_owner(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1,
                        int world, uint32_t* perm, int64_t* counts, void* workspace, size_t workspace_bytes);
 int cdr_permute_i64(void* stream, const int64_t* src0, int64_t n0, const int64_t* src1, const uint32_t* perm,
-                    int64_t n, int64_t divisor, int64_t* out);
+                    int64_t n, int64_t divisor, int64_t flag_below /* occurrences o < flag_below get bit 62 set */, int64_t* out);
 int cdr_inverse_perm(void* stream, const uint32_t* perm, int64_t n, int64_t* pos);
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -65,7 +65,7 @@ _SIGNATURES = {
     'cdr_mse_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_mse_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_f32, _c_ptr,
-                         _c_ptr, _c_ptr],
+                         _c_ptr, _c_ptr, _c_int],
     'cdr_loss_finish_sums': [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr],
     'cdr_build_grad_rows': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
@@ -73,7 +73,7 @@ _SIGNATURES = {
     'cdr_timing_collect': [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_f32), _c_int, ctypes.POINTER(_c_int)],
     'cdr_sort_ids': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_rowwise_apply': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
-                          _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
+                          _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr],
     'cdr_gemm_f32_ex': [_c_ptr, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
                         _c_ptr, _c_int, _c_int],
     'cdr_gather_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
@@ -105,7 +105,7 @@ _SIGNATURES = {
     'cdr_embloss_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_route_workspace_bytes': [_c_i64, _c_int, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_route_by_owner': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
-    'cdr_permute_i64': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
+    'cdr_permute_i64': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_inverse_perm': [_c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_adam_dense_dev': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr],
     'cdr_inc_i64': [_c_ptr, _c_ptr],

@@ -180,7 +180,9 @@ int launch(hipStream_t s, int64_t M, int64_t N, int64_t K, const float* A, int64
     // float4 global loads need 16-B aligned rows along the contiguous dimension
     const int vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
     const int vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
-    const int64_t tiles = (M <= 64 ? (M + 31) / 32 : (M + 127) / 128) * ((N + 127) / 128);
+    // few 128x128 tiles (the MLP layers: M = batch rows, N <= 64) leave most CUs idle: use the 32-row tile there too
+    const bool small_m = M <= 64 || ((M + 127) / 128) * ((N + 127) / 128) < 192;
+    const int64_t tiles = (small_m ? (M + 31) / 32 : (M + 127) / 128) * ((N + 127) / 128);
     // split K when the output has too few tiles to fill the chip and the epilogue is a plain (or post-add) product
     unsigned splits = 1;
     int64_t k_chunk = K;
@@ -192,7 +194,7 @@ int launch(hipStream_t s, int64_t M, int64_t N, int64_t K, const float* A, int64
             if (e0 != hipSuccess) { cdr_set_error("cdr_gemm_f32: memset failed: %s", hipGetErrorString(e0)); return (int)e0; }
         }
     }
-    if (M <= 64) {
+    if (small_m) {
         constexpr int BM = 32, BN = 128;
         const int64_t grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);

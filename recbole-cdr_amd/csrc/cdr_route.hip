@@ -46,12 +46,15 @@ __global__ void counts_from_starts_kernel(const int64_t* __restrict__ starts, in
 
 __global__ __launch_bounds__(kBlock) void permute_i64_kernel(const int64_t* __restrict__ src0, int64_t n0,
                                                              const int64_t* __restrict__ src1, const uint32_t* __restrict__ perm,
-                                                             int64_t n, int64_t divisor, int64_t* __restrict__ out) {
+                                                             int64_t n, int64_t divisor, int64_t flag_below,
+                                                             int64_t* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         const int64_t o = perm[q];
-        const int64_t v = o < n0 ? src0[o] : src1[o - n0];
-        out[q] = divisor > 1 ? v / divisor : v;
+        int64_t v = o < n0 ? src0[o] : src1[o - n0];
+        if (divisor > 1) v /= divisor;
+        if (o < flag_below) v |= (int64_t)1 << 62;           // tags the occurrence (positive item) for the owner
+        out[q] = v;
     }
 }
 
@@ -111,9 +114,9 @@ extern "C" int cdr_route_workspace_bytes(int64_t n, int world, size_t* bytes) {
 }
 
 extern "C" int cdr_permute_i64(void* stream, const int64_t* src0, int64_t n0, const int64_t* src1, const uint32_t* perm,
-                               int64_t n, int64_t divisor, int64_t* out) {
+                               int64_t n, int64_t divisor, int64_t flag_below, int64_t* out) {
     CDR_CHECK_ARG(src0 && perm && out && n > 0 && divisor >= 1);
-    permute_i64_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream>>>(src0, n0, src1, perm, n, divisor, out);
+    permute_i64_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream>>>(src0, n0, src1, perm, n, divisor, flag_below, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -34,7 +34,9 @@ inline int grid_for(int64_t units, int per_block) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward + compact grads
-template <int LPR>
+// SCATTER (row-sharded step): the item operand is the buffer of received rows, one entry per occurrence, and the item
+// gradients are written straight into the send buffer at the same positions: GP[pid[t]] = g u, GP[nid[t]] = -g u.
+template <int LPR, bool SCATTER>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __restrict__ U, const float* __restrict__ I,
                                                               int D, const int64_t* __restrict__ uid,
                                                               const int64_t* __restrict__ pid,
@@ -84,7 +86,12 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
                 if (live) {
                     st4(GU + t * D + 4 * sub, make_float4(g * (p[r].x - n[r].x), g * (p[r].y - n[r].y),
                                                           g * (p[r].z - n[r].z), g * (p[r].w - n[r].w)));
-                    st4(GP + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                    if (SCATTER) {
+                        st4(GP + ip[r] * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                        st4(GP + in[r] * D + 4 * sub, make_float4(-g * u[r].x, -g * u[r].y, -g * u[r].z, -g * u[r].w));
+                    } else {
+                        st4(GP + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                    }
                 }
                 if (sub == 0) {
                     acc[0] += (double)(-logf(gamma + s));
@@ -179,7 +186,8 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
                                                                const float* __restrict__ G, int64_t neg_start,
                                                                int64_t reg_limit, const float* __restrict__ reg_coef,
                                                                float lr, float b1, float b2, float eps, float wd,
-                                                               float step_size, float bc2_sqrt) {
+                                                               float step_size, float bc2_sqrt,
+                                                               const int64_t* __restrict__ occ_ids) {
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
                 const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
                 if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
                 else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
-                cnt += (o < reg_limit) ? 1 : 0;
+                cnt += occ_ids ? (int)((occ_ids[o] >> 62) & 1) : ((o < reg_limit) ? 1 : 0);
             }
             const float rc = c * (float)cnt;
             float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
 
 extern "C" int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
                                 const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, int64_t B_mean,
-                                float gamma, float reg_weight, float* out6, float* GU, float* GP) {
+                                float gamma, float reg_weight, float* out6, float* GU, float* GP, int scatter) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out6 && GU && GP);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0);
     hipStream_t s = (hipStream_t)stream;
@@ -253,8 +261,13 @@ extern "C" int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream, const float* user_ta
     const int grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
     {
         cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_GRAD, s);
-        DISPATCH_LPR(lpr, bpr_fwd_grad_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B,
-                                                                                       gamma, invB, GU, GP, ctx->partials));
+        if (scatter) {
+            DISPATCH_LPR(lpr, bpr_fwd_grad_kernel<L, true><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid,
+                                                                                                 B, gamma, invB, GU, GP, ctx->partials));
+        } else {
+            DISPATCH_LPR(lpr, bpr_fwd_grad_kernel<L, false><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid,
+                                                                                                  B, gamma, invB, GU, GP, ctx->partials));
+        }
     }
     CDR_LAUNCH_CHECK();
     step_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B_mean, reg_weight, out6);
@@ -323,7 +336,7 @@ extern "C" int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int
 extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                                  const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const float* G,
                                  int64_t neg_start, int64_t reg_limit, const float* reg_coef, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, int64_t step) {
+                                 float beta2, float eps, float weight_decay, int64_t step, const int64_t* occ_ids) {
     CDR_CHECK_ARG(table && keys_sorted && perm && G && n > 0);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0);
     CDR_CHECK_ARG(opt == 0 || (opt == 1 && exp_avg && exp_avg_sq && step > 0));
@@ -338,7 +351,7 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
     const int grid = grid_for(n, kBlock / lpr);
     const bool is_signed = neg_start < n;
     cdr_time_scope ts(ctx, is_signed ? CDR_TAG_APPLY_SIGNED : CDR_TAG_APPLY_UNSIGNED, s);
-#define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt
+#define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, occ_ids
     if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }

@@ -63,7 +63,7 @@ class FusedBPRStep:
         ctxh = B_.ctx(self.U.device)
         B_.call('cdr_bpr_fwd_grad', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid),
                 B_.i64(nid), B, 0, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
-                B_.f32(self.GP))
+                B_.f32(self.GP), 0)
         B_.call('cdr_sort_ids', ctxh, s, B_.i64(uid), B, None, 0, self.U.shape[0], B_.raw(self.ukeys),
                 B_.raw(self.uperm), B_.raw(self.ws), self.ws_bytes)
         self._apply(ctxh, self.ustate, self.ukeys, self.uperm, B, self.GU, B, B, self.out6[4:5])
@@ -76,4 +76,4 @@ class FusedBPRStep:
         B_.call('cdr_rowwise_apply', ctxh, B_.stream(), self.opt, B_.f32(st.table), B_.f32(st.exp_avg),
                 B_.f32(st.exp_avg_sq), self.D, B_.raw(keys), B_.raw(perm), n, B_.f32(G), neg_start, reg_limit,
                 B_.f32(coef), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                float(self.wd), self.step_count)
+                float(self.wd), self.step_count, None)

@@ -13,8 +13,9 @@ Exchange  USER-ALIGNED: each triple first travels (24 B) to the rank that owns i
             1. all_to_all   local item ids -> item owners ; owners gather ; all_to_all rows back   (2 rows / triple)
             2. fused forward + compact gradients on (local user shard, received item rows); all_reduce of the three
                loss sums -- the mean and the EmbLoss norms are over the GLOBAL batch
-            3. user rows: local sort + row-wise optimizer.  item rows: per-occurrence gradient rows (EmbLoss term folded
-               in by the requester, which still holds the pre-step rows) -> all_to_all back -> owners sort + apply.
+            3. user rows: local sort + row-wise optimizer.  item rows: the forward kernel has already written the
+               per-occurrence gradient rows into the send buffer in owner order -> all_to_all back -> owners sort +
+               apply, adding the EmbLoss term for the occurrences the requester tagged as positives (bit 62 of the id).
           Collective sizes are exact (bucket counts are all-gathered; one host sync per routing stage).
 Overlap   ``step_gen`` is a generator that yields exactly where the host has to wait for bucket counts;
           ``run_pipelined`` round-robins several steps (the SOURCE and TARGET domains touch disjoint tables), each on its
@@ -30,6 +31,8 @@ import torch
 import torch.distributed as dist
 
 OPT_SGD, OPT_ADAM = 0, 1
+TAG_BIT = 1 << 62                       # marks a positive-item occurrence in the ids a rank sends to an item owner
+TAG_MASK = TAG_BIT - 1
 
 
 def shard_rows(total_rows, world, rank):
@@ -76,13 +79,14 @@ class NativeOps:
                 int(world), B_.raw(perm), B_.i64(counts), B_.raw(ws), ws.numel())
         return perm, counts
 
-    def permute(self, src0, src1, perm, divisor):
+    def permute(self, src0, src1, perm, divisor, flag_below=0):
+        """out[q] = (src0 ++ src1)[perm[q]] // divisor, bit 62 set where perm[q] < flag_below (positive-item tag)."""
         B_ = self.B_
         n = perm.numel()
         out = torch.empty(n, device=src0.device, dtype=torch.int64)
         if n:
             B_.call('cdr_permute_i64', B_.stream(), B_.i64(src0), src0.numel(), B_.i64(src1) if src1 is not None else None,
-                    B_.raw(perm), n, int(divisor), B_.i64(out))
+                    B_.raw(perm), n, int(divisor), int(flag_below), B_.i64(out))
         return out
 
     def inverse_perm(self, perm):
@@ -100,27 +104,21 @@ class NativeOps:
                     B_.f32(out))
         return out
 
-    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GP):
+    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GI):
+        """GI [rows of itab, D]: item gradients written at the item rows' own positions (+ at pidx, - at nidx)."""
         B_ = self.B_
         B_.call('cdr_bpr_fwd_grad', B_.ctx(self.device), B_.stream(), B_.f32(utab), B_.f32(itab), utab.shape[1],
                 B_.i64(uidx), B_.i64(pidx), B_.i64(nidx), uidx.numel(), int(B_mean), float(gamma), float(reg_weight),
-                B_.f32(out), B_.f32(GU), B_.f32(GP))
+                B_.f32(out), B_.f32(GU), B_.f32(GI), 1)
 
     def finish_sums(self, sums3, B_mean, reg_weight, out):
         B_ = self.B_
         B_.call('cdr_loss_finish_sums', B_.stream(), B_.f32(sums3), int(B_mean), float(reg_weight), B_.f32(out))
 
-    def build_grad_rows(self, G, perm, neg_start, reg_limit, rows, coef):
-        B_ = self.B_
-        out = torch.empty(perm.numel(), G.shape[1], device=G.device, dtype=torch.float32)
-        if perm.numel():
-            B_.call('cdr_build_grad_rows', B_.stream(), B_.f32(G), B_.raw(perm), perm.numel(), G.shape[1], int(neg_start),
-                    int(reg_limit), B_.f32(rows), B_.f32(coef), B_.f32(out))
-        return out
-
-    def sort_apply(self, table, state, local_ids, grads, opt, hp, step, reg_limit=0, reg_coef=None):
-        """Segment (local row, gradient row) pairs by row and apply the optimizer in place.  With ``reg_limit`` > 0 the
-        EmbLoss term ``reg_coef * count * W[r]`` is added inside the kernel (rows this rank owns)."""
+    def sort_apply(self, table, state, local_ids, grads, opt, hp, step, reg_limit=0, reg_coef=None, tagged=False):
+        """Segment (local row, gradient row) pairs by row and apply the optimizer in place.  The EmbLoss term
+        ``reg_coef * count * W[r]`` is added inside the kernel: ``count`` = occurrences below ``reg_limit``, or (``tagged``)
+        occurrences whose id carries bit 62 (positive items, tagged by the requesting rank)."""
         B_ = self.B_
         n = local_ids.numel()
         if n == 0:
@@ -136,7 +134,8 @@ class NativeOps:
         m, v = (state if state is not None else (None, None))
         B_.call('cdr_rowwise_apply', ctxh, B_.stream(), opt, B_.f32(table), B_.f32(m), B_.f32(v), table.shape[1],
                 B_.raw(keys), B_.raw(perm), n, B_.f32(grads), n, int(reg_limit), B_.f32(reg_coef), float(hp['lr']),
-                float(hp['b1']), float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step))
+                float(hp['b1']), float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step),
+                B_.i64(local_ids) if tagged else None)
 
 
 def _a2a(inp, in_splits, out_splits, group, trailing=()):
@@ -216,7 +215,7 @@ class ShardedBPRStep:
             # ---- 1. item rows: ids to their owners, rows back ---------------------------------------------------
             if Bl:
                 perm1, counts1 = ops.route(p2, n2, G)
-                i_local_sorted = ops.permute(p2, n2, perm1, G)
+                i_local_sorted = ops.permute(p2, n2, perm1, G, flag_below=Bl)     # bit 62 tags the positive occurrences
                 pos_i = ops.inverse_perm(perm1)
             else:
                 perm1 = torch.empty(0, device=uid.device, dtype=torch.int32)
@@ -229,15 +228,16 @@ class ShardedBPRStep:
             allc = torch.stack(gathered).tolist()                           # host sync #2
             i_send = [int(c) for c in allc[self.rank][:G]]
             i_recv = [int(allc[r][self.rank]) for r in range(G)]
-            i_req = _a2a(i_local_sorted, i_send, i_recv, grp)                # local item rows other ranks want from me
-            irows = _a2a(ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
+            i_req = _a2a(i_local_sorted, i_send, i_recv, grp)                # local item rows other ranks want (tagged)
+            i_req_rows = i_req & TAG_MASK
+            irows = _a2a(ops.gather_rows(self.I, i_req_rows), i_recv, i_send, grp, (self.D,))
 
             # ---- 2. fused forward + compact gradients; global loss reduction ----------------------------------
             GU = torch.empty(max(Bl, 1), self.D, device=uid.device, dtype=torch.float32)
-            GP = torch.empty(max(Bl, 1), self.D, device=uid.device, dtype=torch.float32)
+            gi = torch.empty(2 * Bl, self.D, device=uid.device, dtype=torch.float32)     # send buffer, owner order
             if Bl:
                 ops.fwd_grad(self.U, irows, u_loc, pos_i[:Bl].contiguous(), pos_i[Bl:].contiguous(), B_global, self.gamma,
-                             self.reg_weight, self.out, GU, GP)
+                             self.reg_weight, self.out, GU, gi)
                 sums = self.out[6:9].clone()
             else:
                 sums = torch.zeros(3, device=uid.device, dtype=torch.float32)
@@ -248,11 +248,10 @@ class ShardedBPRStep:
             if Bl:
                 ops.sort_apply(self.U, self.ustate, u_loc, GU[:Bl], self.opt, self.hp, self.step_count, reg_limit=Bl,
                                reg_coef=self.out[4:5])
-                gi = ops.build_grad_rows(GP[:Bl], perm1, Bl, Bl, irows, self.out[5:6])
-            else:
-                gi = torch.empty(0, self.D, device=uid.device, dtype=torch.float32)
             gi_recv = _a2a(gi, i_send, i_recv, grp, (self.D,))
-            ops.sort_apply(self.I, self.istate, i_req, gi_recv, self.opt, self.hp, self.step_count)
+            # the owner adds the EmbLoss term itself (it holds the pre-step row; the tag tells it which occurrences count)
+            ops.sort_apply(self.I, self.istate, i_req, gi_recv, self.opt, self.hp, self.step_count, reg_coef=self.out[5:6],
+                           tagged=True)
 
 
 def run_pipelined(generators):

@@ -19,9 +19,10 @@ class OracleOps:
         perm = torch.argsort(owner, stable=True).to(torch.int32)
         return perm, torch.bincount(owner, minlength=world)
 
-    def permute(self, src0, src1, perm, divisor):
+    def permute(self, src0, src1, perm, divisor, flag_below=0):
         src = src0 if src1 is None else torch.cat([src0, src1])
-        return src[perm.long()] // divisor
+        out = src[perm.long()] // divisor
+        return out | ((perm.long() < flag_below).long() << 62)
 
     def inverse_perm(self, perm):
         pos = torch.empty(perm.numel(), dtype=torch.int64)
@@ -31,14 +32,15 @@ class OracleOps:
     def gather_rows(self, table, local_ids):
         return table[local_ids].clone()
 
-    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GP):
+    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GI):
         u, p, n = utab[uidx], itab[pidx], itab[nidx]
         x = (u * p).sum(1) - (u * n).sum(1)
         s = torch.sigmoid(x)
         g = -(1.0 / B_mean) * (s * (1 - s)) / (gamma + s)
         B = uidx.numel()
         GU[:B] = g[:, None] * (p - n)
-        GP[:B] = g[:, None] * u
+        GI[pidx] = g[:, None] * u
+        GI[nidx] = -g[:, None] * u
         out[6] = (-torch.log(gamma + s)).sum()
         out[7] = (u * u).sum()
         out[8] = (p * p).sum()
@@ -51,21 +53,14 @@ class OracleOps:
         out[4] = reg_weight / (B_mean * nu) if float(nu) > 0 else 0.0
         out[5] = reg_weight / (B_mean * ni) if float(ni) > 0 else 0.0
 
-    def build_grad_rows(self, G, perm, neg_start, reg_limit, rows, coef):
-        order = perm.long()
-        neg = order >= neg_start
-        src = torch.where(neg, order - neg_start, order)
-        out = G[src] * torch.where(neg, -1.0, 1.0)[:, None]
-        reg = (order < reg_limit).float()[:, None] * coef[0] * rows
-        return out + reg
-
-    def sort_apply(self, table, state, local_ids, grads, opt, hp, step, reg_limit=0, reg_coef=None):
+    def sort_apply(self, table, state, local_ids, grads, opt, hp, step, reg_limit=0, reg_coef=None, tagged=False):
         if local_ids.numel() == 0:
             return
-        rows, inv = torch.unique(local_ids, return_inverse=True)
+        flags = ((local_ids >> 62) & 1).float() if tagged else (torch.arange(local_ids.numel()) < reg_limit).float()
+        rows, inv = torch.unique(local_ids & ((1 << 62) - 1), return_inverse=True)
         Gs = torch.zeros(rows.numel(), table.shape[1]).index_add_(0, inv, grads)
-        if reg_limit > 0:
-            cnt = torch.zeros(rows.numel()).index_add_(0, inv, (torch.arange(local_ids.numel()) < reg_limit).float())
+        if reg_coef is not None:
+            cnt = torch.zeros(rows.numel()).index_add_(0, inv, flags)
             Gs = Gs + reg_coef[0] * cnt[:, None] * table[rows]
         from oracle.train_step import _apply_rows, RowwiseAdamState
         if opt == 0:
