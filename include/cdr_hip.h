@@ -243,8 +243,6 @@ int cdr_revoke_map(void* stream, const int64_t* ids, int64_t n, int64_t overlap_
  *                      c = reg_weight / (B_mean * norm).  B_mean (<=0 -> B) is the batch the mean / EmbLoss are
  *                      taken over: the GLOBAL batch when the step is row-sharded over several GPUs -- the three raw
  *                      sums are then all-reduced and cdr_loss_finish_sums recomputes out[0..5] from them.
- *   cdr_build_grad_rows: out[q] = +-G[order[q]] (+ coef * rows[q] for the EmbLoss occurrences) -- the per-occurrence
- *                      gradient rows, in owner order, that a rank sends back to the rows' owners.
  *   cdr_sort_ids     : stable radix sort of (row id, occurrence index) over the significant key bits; ids1 (optional)
  *                      is appended after ids0 (items: ids0 = pid, ids1 = nid -> occurrences [0,B) positive, [B,2B) negative)
  *   cdr_rowwise_apply: per distinct row r (segment of keys_sorted):
@@ -260,8 +258,6 @@ int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      float gamma, float reg_weight, float* out9, float* GU /* [B,D] */, float* GP /* [B,D] */,
                      int scatter /* != 0 (row-sharded step): GP[pid[b]] = g u, GP[nid[b]] = -g u instead of GP[b] = g u */);
 int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6);
-int cdr_build_grad_rows(void* stream, const float* G, const uint32_t* order, int64_t n, int D,
-                        int64_t neg_start, int64_t reg_limit, const float* rows, const float* coef, float* out);
 int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);
 int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1, int64_t num_rows,
                  uint32_t* keys_sorted /* [n0+n1] */, uint32_t* perm /* [n0+n1] */,

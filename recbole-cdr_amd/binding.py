@@ -67,7 +67,6 @@ _SIGNATURES = {
     'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_f32, _c_ptr,
                          _c_ptr, _c_ptr, _c_int],
     'cdr_loss_finish_sums': [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr],
-    'cdr_build_grad_rows': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_timing_enable': [_c_ptr, _c_int],
     'cdr_timing_collect': [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_f32), _c_int, ctypes.POINTER(_c_int)],

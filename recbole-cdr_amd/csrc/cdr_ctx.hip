@@ -32,7 +32,7 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     c->ev0 = c->ev1 = nullptr;
     c->tags = nullptr;
     hipError_t e = hipMalloc(&c->partials, sizeof(double) * CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE);
-    hipSetDevice(prev);
+    (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         delete c;
         cdr_set_error("cdr_ctx_create: scratch allocation failed: %s", hipGetErrorString(e));
@@ -73,7 +73,7 @@ extern "C" int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n,
 extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
     if (!ctx) return CDR_OK;
     cdr_timing_enable(ctx, 0);
-    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->partials) (void)hipFree(ctx->partials);
     delete ctx;
     return CDR_OK;
 }

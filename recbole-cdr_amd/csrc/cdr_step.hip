@@ -142,29 +142,6 @@ __global__ void finish_sums_kernel(const float* __restrict__ sums3, int64_t B, f
     }
 }
 
-// out[q,:] = (o >= neg_start ? -G[o - neg_start,:] : G[o,:]) + (o < reg_limit ? c * rows[q,:] : 0),  o = order[q]
-__global__ __launch_bounds__(kBlock) void build_grad_rows_kernel(const float* __restrict__ G, const uint32_t* __restrict__ order,
-                                                                 int64_t n, int D, int64_t neg_start, int64_t reg_limit,
-                                                                 const float* __restrict__ rows, const float* __restrict__ coef,
-                                                                 float* __restrict__ out) {
-    const int D4 = D >> 2;
-    const int64_t total = n * D4, stride = (int64_t)gridDim.x * kBlock;
-    const float c = coef ? coef[0] : 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
-        const int64_t q = e / D4;
-        const int ch = (int)(e - q * D4);
-        const int64_t o = order[q];
-        const bool neg = o >= neg_start;
-        float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
-        if (neg) { g.x = -g.x; g.y = -g.y; g.z = -g.z; g.w = -g.w; }
-        if (o < reg_limit && c != 0.f) {
-            const float4 r = ld4(rows + q * D + 4 * ch);
-            g.x += c * r.x; g.y += c * r.y; g.z += c * r.z; g.w += c * r.w;
-        }
-        st4(out + q * D + 4 * ch, g);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ keys for the sort
 __global__ __launch_bounds__(kBlock) void make_keys_kernel(const int64_t* __restrict__ ids0, int64_t n0,
                                                            const int64_t* __restrict__ ids1, int64_t n1,
@@ -278,17 +255,6 @@ extern "C" int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream, const float* user_ta
 extern "C" int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6) {
     CDR_CHECK_ARG(sums3 && out6 && B_mean > 0);
     finish_sums_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(sums3, B_mean, reg_weight, out6);
-    CDR_LAUNCH_CHECK();
-    return CDR_OK;
-}
-
-extern "C" int cdr_build_grad_rows(void* stream, const float* G, const uint32_t* order, int64_t n, int D, int64_t neg_start,
-                                   int64_t reg_limit, const float* rows, const float* coef, float* out) {
-    CDR_CHECK_ARG(G && order && out && n > 0 && D > 0 && (D & 3) == 0);
-    CDR_CHECK_ARG(reg_limit <= 0 || rows);
-    const int64_t total = n * (D >> 2);
-    build_grad_rows_kernel<<<dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(G, order, n, D, neg_start,
-                                                                                                   reg_limit, rows, coef, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

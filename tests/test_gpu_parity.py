@@ -757,3 +757,22 @@ def test_end_to_end_emcdr_learns_with_device_sampler():
     assert res_t['recall@10'] > 5 * random_recall, res_t
     assert res_s['recall@10'] > 5 * random_recall, res_s
     assert res_t['ndcg@10'] > 0 and res_t['mrr@10'] > 0
+
+
+def test_spmm_csr_vs_torch_sparse():
+    """cdr_spmm_csr_f32 (torch.sparse.mm, bitgcf.py:131) on a random graph with empty rows, odd/even row lengths."""
+    from recbole_cdr_amd import binding as B_
+    rng = np.random.RandomState(0)
+    n, D, nnz = 500, 64, 6000
+    rows, cols = rng.randint(0, n, nnz), rng.randint(0, n, nnz)
+    rows[rows % 7 == 0] = 1                                   # leave some rows empty, make one heavy
+    pairs = np.unique(np.stack([rows, cols], 1), axis=0)
+    vals = rng.rand(len(pairs)).astype(np.float32)
+    A = torch.sparse_coo_tensor(torch.from_numpy(pairs.T.copy()), torch.from_numpy(vals), (n, n)).coalesce()
+    E = torch.randn(n, D)
+    ref = torch.sparse.mm(A, E)
+    indptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(np.bincount(pairs[:, 0], minlength=n), out=indptr[1:])
+    out = torch.empty(n, D, device=DEV)
+    B_.call('cdr_spmm_csr_f32', B_.stream(), B_.i64(torch.from_numpy(indptr).to(DEV)), B_.i64(torch.from_numpy(pairs[:, 1].copy()).to(DEV)),
+            B_.f32(torch.from_numpy(vals).to(DEV)), n, B_.f32(E.to(DEV)), D, B_.f32(out))
+    assert_close(out, ref)
