@@ -171,8 +171,13 @@ def stream():
     return _c_ptr(torch.cuda.current_stream().cuda_stream)
 
 
+_alive = []      # tensors whose pointers were taken for the call being assembled (see ptr / call)
+
+
 def ptr(t, dtype=None):
-    """Raw device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    """Raw device pointer of a contiguous CUDA tensor (None -> NULL).  The tensor is kept referenced until the native
+    call it is an argument of has been enqueued: a temporary (``x.contiguous()`` of a strided view, ``t.to(dev)``) would
+    otherwise be returned to the caching allocator before the launch and could be handed to the NEXT temporary."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -181,6 +186,7 @@ def ptr(t, dtype=None):
         raise ValueError('tensor must be contiguous')
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f'expected {dtype}, got {t.dtype}')
+    _alive.append(t)
     return _c_ptr(t.data_ptr())
 
 
@@ -197,7 +203,11 @@ def raw(t):
 
 
 def call(name, *args):
-    _check(getattr(load(), name)(*args), name)
+    try:
+        rc = getattr(load(), name)(*args)
+    finally:
+        _alive.clear()           # enqueued: stream order now protects the buffers
+    _check(rc, name)
 
 
 TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4: 'rowwise_apply_kernel(users)',

@@ -773,6 +773,8 @@ def test_spmm_csr_vs_torch_sparse():
     ref = torch.sparse.mm(A, E)
     indptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(np.bincount(pairs[:, 0], minlength=n), out=indptr[1:])
     out = torch.empty(n, D, device=DEV)
-    B_.call('cdr_spmm_csr_f32', B_.stream(), B_.i64(torch.from_numpy(indptr).to(DEV)), B_.i64(torch.from_numpy(pairs[:, 1].copy()).to(DEV)),
-            B_.f32(torch.from_numpy(vals).to(DEV)), n, B_.f32(E.to(DEV)), D, B_.f32(out))
+    # keep every device tensor alive in a name: the C ABI takes raw pointers, a temporary would be freed before the launch
+    d_ptr, d_idx = torch.from_numpy(indptr).to(DEV), torch.from_numpy(pairs[:, 1].copy()).to(DEV)
+    d_val, d_E = torch.from_numpy(vals).to(DEV), E.to(DEV)
+    B_.call('cdr_spmm_csr_f32', B_.stream(), B_.i64(d_ptr), B_.i64(d_idx), B_.f32(d_val), n, B_.f32(d_E), D, B_.f32(out))
     assert_close(out, ref)
