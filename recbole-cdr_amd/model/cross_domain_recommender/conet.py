@@ -72,8 +72,16 @@ class CoNet(CrossDomainRecommender):
         return F_.linear(t, lin.weight, lin.bias, B_.ACT_SIGMOID).squeeze()
 
     def calculate_loss(self, interaction):
-        p_source = self.source_forward(interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID])
-        p_target = self.target_forward(interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID])
+        # source_forward(source batch) and target_forward(target batch) both run BOTH towers (conet.py:186-187); every
+        # op is row-independent, so the two batches go through the cross units as ONE stack of rows (half the launches)
+        # and each output unit reads its own slice -- same numbers per row as two separate passes.
+        su, si = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID]
+        tu, ti = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
+        n_s = su.numel()
+        s, t = self._towers(torch.cat([su.reshape(-1), tu.reshape(-1)]), torch.cat([si.reshape(-1), ti.reshape(-1)]))
+        ls, lt = self.source_outputunit[0], self.target_outputunit[0]
+        p_source = F_.linear(s[:n_s], ls.weight, ls.bias, B_.ACT_SIGMOID).squeeze()
+        p_target = F_.linear(t[n_s:], lt.weight, lt.bias, B_.ACT_SIGMOID).squeeze()
         loss = F_.BCEProbLoss.apply(p_source, interaction[self.SOURCE_LABEL]) + \
             F_.BCEProbLoss.apply(p_target, interaction[self.TARGET_LABEL])
         for para in self.crossparas:
