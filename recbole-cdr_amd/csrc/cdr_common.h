@@ -63,10 +63,28 @@ void cdr_set_error(const char* fmt, ...);
 
 // ---- wave-level reductions -------------------------------------------------------------------------------------
 // Sum over aligned sub-groups of LPR lanes (LPR a power of two, 1..64); every lane of the group gets the total.
+// Butterfly without LDS: quad_perm / row_half_mirror / row_mirror DPP moves inside a 16-lane row, then gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows and wave halves (self-swap: result halves = the two partners).
+// The obvious __shfl_xor chain compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt per step: ~140 LDS round trips per
+// gather iteration, which is what bounded the gather kernels before (per-sample, not per-byte, limited).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, CDR_WAVE);
+    if (LPR >= 2) v = dpp_add_<0xB1>(v);       // quad_perm [1,0,3,2]  : lane ^ 1
+    if (LPR >= 4) v = dpp_add_<0x4E>(v);       // quad_perm [2,3,0,1]  : lane ^ 2
+    if (LPR >= 8) v = dpp_add_<0x141>(v);      // row_half_mirror      : the other quad of the 8-lane half row
+    if (LPR >= 16) v = dpp_add_<0x140>(v);     // row_mirror           : the other half of the 16-lane row
+    if (LPR >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // rows (0,1) and (2,3)
+    }
+    if (LPR >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // wave halves
+    }
     return v;
 }
 

@@ -12,6 +12,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
+constexpr int kUnrollPoint = 8;      // pointwise rows carry 2 row loads each (BPR triples 3): keep as many bytes in flight
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -226,23 +227,57 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
     const int D4 = D >> 2;
     const float invB = 1.0f / (float)B;
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int64_t base = gg; base < B; base += TG * kUnroll) {
+    for (int64_t base = gg; base < B; base += TG * kUnrollPoint) {
+        // ids of the kUnrollPoint rows first, then every row load, then the reductions (vmcnt is in-order: see cdr_step.hip)
+        int64_t iu[kUnrollPoint], ii[kUnrollPoint];
 #pragma unroll
-        for (int r = 0; r < kUnroll; ++r) {
+        for (int r = 0; r < kUnrollPoint; ++r) {
             const int64_t t = base + (int64_t)r * TG;
-            float dx = 0.f, su = 0.f, si = 0.f;
-            if (t < B) {
-                const int64_t iu = uid[t], ii = iid[t];
-                for (int c = sub; c < D4; c += LPR) {
-                    const float4 a = ld4(U + iu * D + 4 * c), b = ld4(I + ii * D + 4 * c);
-                    dx += dot4(a, b);
-                    if (SAME) { su += dot4(a, a); si += dot4(b, b); }
-                    else {
-                        const float4 ra = ld4(RU + iu * D + 4 * c), rb = ld4(RI + ii * D + 4 * c);
-                        su += dot4(ra, ra); si += dot4(rb, rb);
+            const int64_t tc = t < B ? t : B - 1;
+            iu[r] = uid[tc]; ii[r] = iid[tc];
+        }
+        float dxs[kUnrollPoint], sus[kUnrollPoint], sis[kUnrollPoint];
+        if (D4 <= LPR) {
+            float4 a[kUnrollPoint], b[kUnrollPoint], ra[kUnrollPoint], rb[kUnrollPoint];
+            const bool live = sub < D4;
+#pragma unroll
+            for (int r = 0; r < kUnrollPoint; ++r) {
+                const int64_t t = base + (int64_t)r * TG;
+                a[r] = b[r] = ra[r] = rb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < B && live) {
+                    a[r] = ld4(U + iu[r] * D + 4 * sub);
+                    b[r] = ld4(I + ii[r] * D + 4 * sub);
+                    if (!SAME) { ra[r] = ld4(RU + iu[r] * D + 4 * sub); rb[r] = ld4(RI + ii[r] * D + 4 * sub); }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kUnrollPoint; ++r) {
+                dxs[r] = dot4(a[r], b[r]);
+                sus[r] = SAME ? dot4(a[r], a[r]) : dot4(ra[r], ra[r]);
+                sis[r] = SAME ? dot4(b[r], b[r]) : dot4(rb[r], rb[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kUnrollPoint; ++r) {
+                const int64_t t = base + (int64_t)r * TG;
+                dxs[r] = sus[r] = sis[r] = 0.f;
+                if (t < B) {
+                    for (int c = sub; c < D4; c += LPR) {
+                        const float4 a = ld4(U + iu[r] * D + 4 * c), b = ld4(I + ii[r] * D + 4 * c);
+                        dxs[r] += dot4(a, b);
+                        if (SAME) { sus[r] += dot4(a, a); sis[r] += dot4(b, b); }
+                        else {
+                            const float4 ra = ld4(RU + iu[r] * D + 4 * c), rb = ld4(RI + ii[r] * D + 4 * c);
+                            sus[r] += dot4(ra, ra); sis[r] += dot4(rb, rb);
+                        }
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int r = 0; r < kUnrollPoint; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            float dx = dxs[r], su = sus[r], si = sis[r];
             dx = group_sum<LPR>(dx); su = group_sum<LPR>(su); si = group_sum<LPR>(si);
             if (t < B && sub == 0) {
                 const float y = label[t];
@@ -427,7 +462,7 @@ extern "C" int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind, const fl
     int grid;
     if ((D & 3) == 0) {
         const int lpr = cdr_lpr_for(D);
-        grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
+        grid = grid_for((B + kUnrollPoint - 1) / kUnrollPoint, kBlock / lpr);
         if (same) {
             DISPATCH_LPR(lpr, point_fwd_kernel<L, true><<<dim3(grid), dim3(kBlock), 0, s>>>(loss_kind,
                                                   user_tab, item_tab, reg_user_tab, reg_item_tab, D, uid, iid, label, B,

@@ -278,7 +278,7 @@ static int launch_gemv(hipStream_t s, const float* users, int U, int D, const fl
 }
 
 static bool gemv_ok(int64_t U, int D, const float* users, const float* items) {
-    return U <= 4 && (D & 3) == 0 && D >= 16 && D <= 256 && (((uintptr_t)users | (uintptr_t)items) & 15) == 0;
+    return U <= 8 && (D & 3) == 0 && D >= 16 && D <= 256 && (((uintptr_t)users | (uintptr_t)items) & 15) == 0;
 }
 
 static int gemv_dispatch(hipStream_t s, const float* users, int U, int D, const float* items, int64_t N, float* scores, int64_t ldc) {
