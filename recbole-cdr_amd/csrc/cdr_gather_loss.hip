@@ -230,11 +230,12 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
     for (int64_t base = gg; base < B; base += TG * kUnrollPoint) {
         // ids of the kUnrollPoint rows first, then every row load, then the reductions (vmcnt is in-order: see cdr_step.hip)
         int64_t iu[kUnrollPoint], ii[kUnrollPoint];
-#pragma unroll
+        float yl[kUnrollPoint];                  // labels too: a load issued after the reductions would expose a full
+#pragma unroll                                   // memory latency at the tail of every iteration
         for (int r = 0; r < kUnrollPoint; ++r) {
             const int64_t t = base + (int64_t)r * TG;
             const int64_t tc = t < B ? t : B - 1;
-            iu[r] = uid[tc]; ii[r] = iid[tc];
+            iu[r] = uid[tc]; ii[r] = iid[tc]; yl[r] = label[tc];
         }
         float dxs[kUnrollPoint], sus[kUnrollPoint], sis[kUnrollPoint];
         if (D4 <= LPR) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
             float dx = dxs[r], su = sus[r], si = sis[r];
             dx = group_sum<LPR>(dx); su = group_sum<LPR>(su); si = group_sum<LPR>(si);
             if (t < B && sub == 0) {
-                const float y = label[t];
+                const float y = yl[r];
                 float l, g, sc;
                 if (loss_kind == CDR_LOSS_MSE) {
                     const float d = dx - y;
