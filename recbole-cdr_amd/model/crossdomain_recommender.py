@@ -28,23 +28,20 @@ class CrossDomainRecommender(nn.Module):
 
     def __init__(self, config, dataset):
         super().__init__()
-        # source dataset info
-        self.SOURCE_USER_ID = dataset.source_domain_dataset.uid_field
-        self.SOURCE_ITEM_ID = dataset.source_domain_dataset.iid_field
-        self.SOURCE_NEG_ITEM_ID = config['source_domain']['NEG_PREFIX'] + self.SOURCE_ITEM_ID
-        self.source_num_users = dataset.source_domain_dataset.num(self.SOURCE_USER_ID)
-        self.source_num_items = dataset.source_domain_dataset.num(self.SOURCE_ITEM_ID)
-        # target dataset info
-        self.TARGET_USER_ID = dataset.target_domain_dataset.uid_field
-        self.TARGET_ITEM_ID = dataset.target_domain_dataset.iid_field
-        self.TARGET_NEG_ITEM_ID = config['target_domain']['NEG_PREFIX'] + self.TARGET_ITEM_ID
-        self.target_num_users = dataset.target_domain_dataset.num(self.TARGET_USER_ID)
-        self.target_num_items = dataset.target_domain_dataset.num(self.TARGET_ITEM_ID)
-        # both
-        self.total_num_users = dataset.num_total_user
-        self.total_num_items = dataset.num_total_item
-        self.overlapped_num_users = dataset.num_overlap_user
-        self.overlapped_num_items = dataset.num_overlap_item
+        # Per domain d in {source, target}: <D>_USER_ID / <D>_ITEM_ID / <D>_NEG_ITEM_ID field names and
+        # <d>_num_users / <d>_num_items (overlap + that domain's own ids; the tables themselves are union-sized).
+        for dom in ('source', 'target'):
+            single = getattr(dataset, dom + '_domain_dataset')
+            tag = dom.upper()
+            uid, iid = single.uid_field, single.iid_field
+            setattr(self, tag + '_USER_ID', uid)
+            setattr(self, tag + '_ITEM_ID', iid)
+            setattr(self, tag + '_NEG_ITEM_ID', config[dom + '_domain']['NEG_PREFIX'] + iid)
+            setattr(self, dom + '_num_users', single.num(uid))
+            setattr(self, dom + '_num_items', single.num(iid))
+        # Union id space: [0] = PAD, [1, overlapped) shared, then target-only, then source-only ids.
+        self.total_num_users, self.total_num_items = dataset.num_total_user, dataset.num_total_item
+        self.overlapped_num_users, self.overlapped_num_items = dataset.num_overlap_user, dataset.num_overlap_item
         self.OVERLAP_ID = dataset.overlap_id_field
         self.device = config['device']
 
