@@ -46,7 +46,8 @@ def parse():
     ap.add_argument('--no-fullsort', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
-    ap.add_argument('--no-pipeline', action='store_true', help='sharded path: run the two domain steps back to back on one stream')
+    ap.add_argument('--no-pipeline', action='store_true', default=bool(int(os.environ.get('CDR_NO_PIPELINE', '0'))),
+                    help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
     return ap.parse_args()
 
@@ -62,7 +63,9 @@ def dist_setup(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        import datetime
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local),
+                                timeout=datetime.timedelta(minutes=5))     # a wedged collective aborts instead of hanging
     return world, rank, local
 
 
