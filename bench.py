@@ -13,8 +13,8 @@ Adam update of the touched rows (csrc/cdr_step.hip).  Inputs (tables, id batches
 region.  With N>1 the tables are row-sharded (row r on rank r % N) and every rank contributes its own batch
 (weak scaling in batch; table size fixed); rows/gradients travel by RCCL all-to-all (shard.py).
 
-`--workload c2` runs BASELINE configs[1] (EMCDR ml-1m->ml-100k sized tables, D=64, B=2048) through the drop-in autograd
-path + exact dense Adam instead.
+`--workload c2|c3|c4` run BASELINE configs[1..3] (EMCDR ml-1m->ml-100k sizes, CoNet Amazon sizes, BiTGCF Douban sizes)
+through the drop-in class contract (autograd + exact dense Adam), the whole step replayed as one hipGraph.
 """
 import argparse
 import json
@@ -251,44 +251,6 @@ def pmc_traffic(kernel):
         return None
 
 
-# ------------------------------------------------------------------------------------------------------ C2 workload
-def run_c2(args, world, rank, dev):
-    """BASELINE configs[1]: EMCDR (BPR variant) at ml-1m -> ml-100k sizes through the drop-in autograd path with exact
-    dense Adam (the reference's semantics), B = 2048."""
-    from recbole_cdr_amd import functional as F_
-    D, B = 64, 2048
-    n_users, n_items = 6984, 3900
-    gen = torch.Generator(device=dev); gen.manual_seed(2022)
-    U = xavier_table(n_users, D, n_users, gen, dev).requires_grad_(True)
-    I = xavier_table(n_items, D, n_items, gen, dev).requires_grad_(True)
-    mU, vU, mI, vI = (torch.zeros_like(x) for x in (U, U, I, I))
-    u = torch.randint(1, n_users, (B,), device=dev, generator=gen)
-    p = torch.randint(1, n_items, (B,), device=dev, generator=gen)
-    n = torch.randint(1, n_items, (B,), device=dev, generator=gen)
-
-    def one_step(step):
-        U.grad = I.grad = None
-        loss = F_.BPRGatherLoss.apply(U, I, u, p, n, 1e-10, 0.01)
-        loss.sum().backward()
-        with torch.no_grad():
-            F_.adam_dense_(U, U.grad, mU, vU, step)
-            F_.adam_dense_(I, I.grad, mI, vI, step)
-
-    for i in range(args.warmup):
-        one_step(i + 1)
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i + 1)
-    barrier(world)
-    dt = time.perf_counter() - t0
-    return {'metric': 'training interactions/sec', 'value': B * args.steps * world / dt, 'unit': 'interactions/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C2: EMCDR-BPR ml-1m->ml-100k sized tables (6984 x 3900), D=64, B=2048, drop-in '
-                                   'autograd + exact dense Adam', 'batch': B}}
-
-
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
 def run_model_workload(args, world, rank, dev):
     """BASELINE configs[2] (CoNet, Amazon-Books -> Movies sizes, D=128, k=4 pointwise) and configs[3] (BiTGCF, Douban sizes,
@@ -299,7 +261,17 @@ def run_model_workload(args, world, rank, dev):
     from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
     from recbole_cdr_amd.trainer.trainer import DenseAdam
     cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev}
-    if args.workload == 'c3':
+    pairwise = False
+    if args.workload == 'c2':
+        from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR as Model
+        # ml-1m -> ml-100k is an ITEM-overlap pair: 1,603 shared titles, no shared users
+        ds = SyntheticCrossDomainDataset(OU=1, TOU=943, SOU=6040, OI=1604, TOI=61, SOI=2280,
+                                         n_source_inter=575000, n_target_inter=82000)
+        cfg.update(latent_factor_model='BPR', source_embedding_size=64, target_embedding_size=64, reg_weight=0.01,
+                   mapping_function='non_linear', mlp_hidden_size=[128])
+        S, k, pairwise = 2048, 1, True
+        name = 'C2: EMCDR-BPR ml-1m->ml-100k sizes (6,984 users x 3,945 items union), D=64, B=2,048, SOURCE-phase steps'
+    elif args.workload == 'c3':
         from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet as Model
         ds = SyntheticCrossDomainDataset(OU=5983, TOU=20986, SOU=129127, OI=1, TOI=18563, SOI=115172,
                                          n_source_inter=400000, n_target_inter=200000)
@@ -317,8 +289,13 @@ def run_model_workload(args, world, rank, dev):
     model = Model(cfg, ds).to(dev)
     opt = DenseAdam(model.parameters(), lr=1e-3)
     rng = np.random.RandomState(2022)
-    batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
-    rows_per_step = 2 * S * (1 + k)
+    if pairwise:
+        model.set_phase('SOURCE')
+        batches = [ds.pairwise_batch('source', S, k, rng, dev) for _ in range(4)]
+        rows_per_step = S * k
+    else:
+        batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
+        rows_per_step = 2 * S * (1 + k)
 
     from recbole_cdr_amd.graph_step import GraphedTrainStep
     graphed = GraphedTrainStep(model, opt, batches[0]) if not args.no_graph else None
@@ -348,11 +325,11 @@ def run_model_workload(args, world, rank, dev):
                          'rows_per_step': rows_per_step},
               'final_loss': float(loss.sum())}
     if rank == 0 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline_model(args, ds, cfg, S, k)
+        result['cpu_baseline'] = cpu_baseline_model(args, ds, cfg, S, k, batches[0] if pairwise else None)
     return result
 
 
-def cpu_baseline_model(args, ds, cfg, S, k):
+def cpu_baseline_model(args, ds, cfg, S, k, pair_batch=None):
     """The oracle's calculate_loss + autograd + torch.optim.Adam (the reference's literal loop) on the host cores."""
     import numpy as np
     from oracle import conet as oconet, bitgcf as obit
@@ -360,12 +337,18 @@ def cpu_baseline_model(args, ds, cfg, S, k):
     ids = IdSpace(ds.num_overlap_user, ds.num_target_only_user, ds.num_source_only_user, ds.num_overlap_item,
                   ds.num_target_only_item, ds.num_source_only_item)
     torch.manual_seed(0)
-    D = cfg['embedding_size']
+    D = cfg['embedding_size'] if 'embedding_size' in cfg else cfg['source_embedding_size']
     nu, ni = ids.total_num_users, ids.total_num_items
     xav = lambda r, c: (torch.randn(r, c) * (2.0 / (r + c)) ** 0.5).requires_grad_(True)
     params = {f'{d}_{w}_embedding.weight': xav(nu if w == 'user' else ni, D) for d in ('source', 'target') for w in ('user', 'item')}
     graph = None
-    if args.workload == 'c3':
+    if args.workload == 'c2':
+        from oracle import emcdr as oem
+        for l, (a, b) in enumerate(((D, 128), (128, D))):
+            params[f'mapping.{2 * l}.weight'] = xav(b, a)
+            params[f'mapping.{2 * l}.bias'] = torch.zeros(b, requires_grad=True)
+        loss_fn = lambda b: oem.calculate_loss(params, ids, b, 'SOURCE', 'BPR', cfg['reg_weight'])
+    elif args.workload == 'c3':
         dims = [2 * D] + cfg['mlp_hidden_size']
         for l, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
             for t in ('source', 'target'):
@@ -382,7 +365,10 @@ def cpu_baseline_model(args, ds, cfg, S, k):
                                                     cfg['lambda_target'], cfg['connect_way'], cfg['reg_weight']))
     opt = torch.optim.Adam(list(params.values()), lr=1e-3)
     rng = np.random.RandomState(1)
-    batch = dict(ds.pointwise_batch('source', S, k, rng, 'cpu'), **ds.pointwise_batch('target', S, k, rng, 'cpu'))
+    if pair_batch is not None:
+        batch = ds.pairwise_batch('source', S, k, rng, 'cpu')
+    else:
+        batch = dict(ds.pointwise_batch('source', S, k, rng, 'cpu'), **ds.pointwise_batch('target', S, k, rng, 'cpu'))
     ncores = os.cpu_count() or 1
     best = (None, 0.0)
     def step():
@@ -400,7 +386,7 @@ def cpu_baseline_model(args, ds, cfg, S, k):
     while time.perf_counter() - t0 < args.cpu_seconds and n < 100:
         step(); n += 1
     dt = time.perf_counter() - t0
-    rows = 2 * S * (1 + k)
+    rows = S * k if pair_batch is not None else 2 * S * (1 + k)
     return {'value': rows * n / dt, 'unit': 'interactions/s', 'cores': best[0], 'host_cores': ncores, 'kind': 'port',
             'sample': '%d steps of %d rows, oracle calculate_loss + autograd + dense torch.optim.Adam, same table sizes, %d threads' % (n, rows, best[0])}
 
@@ -457,8 +443,6 @@ def main():
     import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
     if args.workload == 'c5':
         result = run_c5(args, world, rank, dev)
-    elif args.workload == 'c2':
-        result = run_c2(args, world, rank, dev)
     else:
         result = run_model_workload(args, world, rank, dev)
     if rank == 0:

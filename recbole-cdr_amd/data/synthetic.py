@@ -51,3 +51,12 @@ class SyntheticCrossDomainDataset:
         y = np.concatenate([np.ones(S), np.zeros(S * k)]).astype(np.float32)
         return {f'{domain}_user_id': torch.from_numpy(u).to(device), f'{domain}_item_id': torch.from_numpy(i).to(device),
                 f'{domain}_label': torch.from_numpy(y).to(device)}
+
+    def pairwise_batch(self, domain, S, k, rng, device):
+        """recbole PAIRWISE layout: S positives repeated k times, ``neg_<iid>`` k-major."""
+        pairs = self.s_pairs if domain == 'source' else self.t_pairs
+        items = self.src_items if domain == 'source' else self.tgt_items
+        sel = pairs[rng.randint(0, len(pairs), S)]
+        return {f'{domain}_user_id': torch.from_numpy(np.tile(sel[:, 0], k)).to(device),
+                f'{domain}_item_id': torch.from_numpy(np.tile(sel[:, 1], k)).to(device),
+                f'neg_{domain}_item_id': torch.from_numpy(rng.choice(items, S * k)).to(device)}
