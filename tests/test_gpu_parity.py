@@ -778,3 +778,88 @@ def test_spmm_csr_vs_torch_sparse():
     d_val, d_E = torch.from_numpy(vals).to(DEV), E.to(DEV)
     B_.call('cdr_spmm_csr_f32', B_.stream(), B_.i64(d_ptr), B_.i64(d_idx), B_.f32(d_val), n, B_.f32(d_E), D, B_.f32(out))
     assert_close(out, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world_size > 1 with the NATIVE kernels: several ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+# device; the driver's 8-GPU run is the only place real xGMI traffic happens).  Same exchange code, same libcdrhip ops,
+# real owner arithmetic (id % G, id // G, bit-62 tags) -- only the transport differs.
+def _shared_gpu_worker(rank, world, port, pipelined, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.shard import ShardedBPRStep, shard_of, run_pipelined
+        torch.cuda.set_device(0)
+        torch.manual_seed(11)
+        nu, ni, D, B = 7001, 3003, 64, 6000 + 17 * rank                  # ragged: every rank brings a different B
+        tabs = [(torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1) for _ in range(2 if pipelined else 1)]
+        steps, shards = [], []
+        for d, (U, I) in enumerate(tabs):
+            Ul, Il = shard_of(U, world, rank).to(DEV), shard_of(I, world, rank).to(DEV)
+            grp = dist.new_group(backend='gloo') if pipelined else None
+            stream = torch.cuda.Stream() if pipelined else None
+            steps.append(ShardedBPRStep(Ul, Il, nu, ni, B, opt='adam', lr=0.01, reg_weight=0.02, group=grp, stream=stream))
+            shards.append((Ul, Il))
+        losses, batches = [], []
+        for it in range(3):
+            per_dom = []
+            for d in range(len(tabs)):
+                g = torch.Generator(); g.manual_seed(1000 * it + 10 * d + rank)
+                u = torch.randint(0, nu, (B,), generator=g); p = torch.randint(0, ni, (B,), generator=g)
+                n = torch.randint(0, ni, (B,), generator=g)
+                if it == 1:
+                    u[: B // 2] = u[0]                                   # heavy duplication -> long segments at one owner
+                per_dom.append((u, p, n))
+            batches.append(per_dom)
+            if pipelined:
+                torch.cuda.synchronize()
+                run_pipelined([steps[d].step_gen(*(t.to(DEV) for t in per_dom[d])) for d in range(len(tabs))])
+                torch.cuda.synchronize()
+            else:
+                steps[0].step(*(t.to(DEV) for t in per_dom[0]))
+            losses.append([float(s.out[0]) for s in steps])
+        q.put((rank, [(a.cpu().numpy(), b.cpu().numpy()) for a, b in shards], losses,
+               [[tuple(t.numpy() for t in dom) for dom in it] for it in batches]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,pipelined', [(2, False), (3, True)])
+def test_sharded_native_ranks_share_one_gpu(world, pipelined):
+    import socket
+    import torch.multiprocessing as mp
+    from recbole_cdr_amd.fused import FusedBPRStep
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, pipelined, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    torch.manual_seed(11)
+    nu, ni, D = 7001, 3003, 64
+    ndom = 2 if pipelined else 1
+    tabs = [(torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1) for _ in range(ndom)]
+    Bg = sum(6000 + 17 * r for r in range(world))
+    for d in range(ndom):
+        U, I = tabs[d][0].to(DEV), tabs[d][1].to(DEV)
+        ref = FusedBPRStep(U, I, Bg, opt='adam', lr=0.01, reg_weight=0.02)
+        for it in range(3):
+            u, p, n = (torch.from_numpy(np.concatenate([res[r][3][it][d][k] for r in range(world)])).to(DEV) for k in range(3))
+            loss = float(ref.step(u, p, n)[0])
+            for r in range(world):
+                assert abs(res[r][2][it][d] - loss) <= 2e-6 * abs(loss), (d, it, r, res[r][2][it][d], loss)
+        for r in range(world):
+            assert_close(torch.from_numpy(res[r][1][d][0]).to(DEV), U[r::world], rtol=2e-5, atol=0.01 * 1e-2, what=f'U dom{d} rank{r}')
+            assert_close(torch.from_numpy(res[r][1][d][1]).to(DEV), I[r::world], rtol=2e-5, atol=0.01 * 1e-2, what=f'I dom{d} rank{r}')
