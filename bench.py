@@ -58,14 +58,22 @@ def dist_setup(args):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
         raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    # CDR_BENCH_SHARED_GPU=1: every rank on cuda:0 over gloo -- a functional check of the N>1 code path on a 1-GPU box
+    # (RCCL refuses two ranks on one device); never a performance number, and the JSON line says so.
+    shared = bool(int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')))
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1 or args.force_shard:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         import datetime
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local),
-                                timeout=datetime.timedelta(minutes=5))     # a wedged collective aborts instead of hanging
+        if shared:
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local),
+                                    timeout=datetime.timedelta(minutes=5))  # a wedged collective aborts instead of hanging
     return world, rank, local
 
 
@@ -207,6 +215,21 @@ def run_c5(args, world, rank, dev):
                                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gk['frac'],
                                      'avg_launch_ms': gk['avg_ms'], 'traffic': pmc_traffic(gk['kernel'])}
         result['kernels'] = kernels
+
+    if rank == 0 and sharded:
+        # N > 1: the exchange adds all-to-alls between the kernels; the kernels themselves are the 1-GPU ones.  Buckets
+        # are balanced in expectation (uniform ids), so one fwd_grad launch sees ~B triples: 3 rows read, GU + 2 GI rows
+        # written (scatter mode).  Rank 0's own HIP-event durations.
+        ms = mean_ms('bpr_fwd_grad_kernel')
+        byts = B * (3 * 4 * D + 24) + B * 3 * 4 * D
+        gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        result['roofline'] = {'bound': 'hbm', 'kernel': 'bpr_fwd_grad_kernel (rank 0, scatter mode, ~B triples per launch)',
+                              'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                              'avg_launch_ms': ms, 'traffic': None}
+        result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
+                             ('bpr_fwd_grad_kernel', 'rowwise_apply_kernel(users)', 'sort_ids')]
+        if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
+            result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
 
     # ---- metric 2: full-sort items scored / s (emcdr.py:208-233, TARGET phase) at the reference's U and at U=1024 --
     if rank == 0 and not sharded and not args.no_fullsort:
