@@ -185,6 +185,31 @@ def run_c5(args, world, rank, dev):
         'final_loss': loss,
     }
 
+    # ---- OVERLAP phase (emcdr.py:133-137): mapping(source_user_e[idx]) -> target_user_e[idx], OB = 65,536 shuffled
+    # overlapped ids per rank, linear mapping D x D; the user tables' row-wise Adam state is the one the BPR steps use
+    if not getattr(args, 'no_map', False):
+        from recbole_cdr_amd.fused import FusedMapStep
+        Wm = torch.nn.Parameter(xavier_table(D, D, D, gen, dev))
+        if sharded:
+            dist.broadcast(Wm.data, 0)                    # the mapping is replicated: same initial weights on every rank
+        fmap = FusedMapStep(tabs['su'], tabs['tu'], lambda x: F_.linear(x, Wm, None, B_.ACT_NONE), [Wm], 65536, opt=args.opt,
+                            group=(dist.group.WORLD if sharded else None),
+                            source_state=steps['source'].ustate, target_state=steps['target'].ustate)
+        OB = 65536
+        idxs = [torch.randint(1, OU, (OB, 1), device=dev, generator=gen) for _ in range(4)]
+        for i in range(3):
+            fmap.step(idxs[i % 4])
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(20):
+            fmap.step(idxs[i % 4])
+        barrier(world)
+        tm = torch.tensor([(time.perf_counter() - t0) / 20], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        result['overlap_phase'] = {'ms_per_step': float(tm) * 1e3, 'overlap_ids_per_s': OB * world / float(tm),
+                                   'batch_per_rank': OB, 'mapping': 'linear %dx%d' % (D, D), 'loss': float(fmap.loss)}
+
     # ---- roofline of the dominant kernel(s): algorithmic bytes / HIP-event time of each native call --------------
     if rank == 0 and not sharded:
         uniq = {}
@@ -260,6 +285,40 @@ def run_c5(args, world, rank, dev):
                                'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
                                'mfma_frac': flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
             del out
+        result['fullsort'] = fs
+    # ---- metric 2 at N > 1: the target item table is row-sharded; every rank scores its rows, the [U, N/G] partials are
+    # all-gathered and re-ordered into the reference's [U, N] layout on every rank (shard.ShardedFullSort) ------------
+    if sharded and not args.no_fullsort:
+        from recbole_cdr_amd.shard import ShardedFullSort
+        for st in steps.values():
+            st.ustate = st.istate = None
+        torch.cuda.empty_cache()
+        fsr = ShardedFullSort(tabs['ti'], 1 + TOI)
+        fs = {}
+        for Uu in (1, 1024):
+            ids = torch.arange(1, 1 + Uu, device=dev, dtype=torch.int64)
+            ue = fsr.user_rows(tabs['tu'], ids)
+            out = fsr.scores(ue); del out
+            reps = 3
+            barrier(world)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = fsr.scores(ue); del out
+            barrier(world)
+            t_all = torch.tensor([(time.perf_counter() - t0) / reps], device=dev, dtype=torch.float64)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                part = fsr.local_scores(ue); del part
+            e1.record(); torch.cuda.synchronize()
+            t_loc = torch.tensor([e0.elapsed_time(e1) / reps * 1e-3], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t_all, op=dist.ReduceOp.MAX); dist.all_reduce(t_loc, op=dist.ReduceOp.MAX)
+            N = 1 + TOI
+            fs['U=%d' % Uu] = {'items_per_s': Uu * N / float(t_all), 'ms': float(t_all) * 1e3, 'N': N,
+                               'local_scoring_ms': float(t_loc) * 1e3,
+                               'local_scoring_items_per_s_all_ranks': Uu * N / float(t_loc),
+                               'allgather_bytes_per_rank': 4.0 * Uu * fsr.Nl * (world - 1)}
         result['fullsort'] = fs
     return result
 

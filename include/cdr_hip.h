@@ -291,6 +291,15 @@ int cdr_permute_i64(void* stream, const int64_t* src0, int64_t n0, const int64_t
                     int64_t n, int64_t divisor, int64_t flag_below /* occurrences o < flag_below get bit 62 set */, int64_t* out);
 int cdr_inverse_perm(void* stream, const uint32_t* perm, int64_t n, int64_t* pos);
 
+/* ---- full-sort over row-sharded tables (SURVEY 8e "Full-sort": each rank scores its item shard, all-gather) -----------
+ * cdr_interleave_shards: the all-gathered scores are shard-major [world][U][Nl]; the reference's full_sort_predict
+ *     layout (emcdr.py:208-233 -> score.view(-1)) is [U][N] in item-id order: out[u][c] = gathered[c % world][u][c / world].
+ * cdr_gather_owned_rows: out[r,:] = ids[r] % world == rank ? shard[ids[r] / world,:] : 0 -- all-reduce(sum) of this over the
+ *     ranks replicates the eval users' rows exactly.                                                                  */
+int cdr_interleave_shards(void* stream, const float* gathered, int world, int64_t U, int64_t Nl, int64_t N, float* out);
+int cdr_gather_owned_rows(void* stream, const float* shard, int D, const int64_t* ids, int64_t n, int world, int rank,
+                          float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,3 +57,23 @@ def rowwise_step(U, I, ustate, istate, uid, pid, nid, step, opt='adam', lr=1e-3,
         _apply_rows(U, ustate, ru, GU, opt, lr, step)
         _apply_rows(I, istate, ri, GI, opt, lr, step)
     return loss.detach()
+
+
+def rowwise_map_step(map_params, S, T, sstate, tstate, idx, step_s, step_t, map_optimizer, opt='adam', lr=1e-3):
+    """EMCDR OVERLAP-phase step (emcdr.py:133-137 map loss) with the two embedding tables updated on the touched rows
+    only; the mapping parameters (``map_params``: the 'mapping.*' leaf tensors, requires_grad) take ``map_optimizer``'s
+    dense step, exactly as in the reference."""
+    idx = idx.reshape(-1)
+    src = S[idx].requires_grad_(True)
+    tgt = T[idx].requires_grad_(True)
+    map_optimizer.zero_grad()
+    loss = torch.nn.functional.mse_loss(emcdr.mapping(map_params, src), tgt)
+    loss.backward()
+    with torch.no_grad():
+        rows, inv = torch.unique(idx, return_inverse=True)
+        GS = torch.zeros(rows.numel(), S.shape[1]).index_add_(0, inv, src.grad)
+        GT = torch.zeros(rows.numel(), T.shape[1]).index_add_(0, inv, tgt.grad)
+        _apply_rows(S, sstate, rows, GS, opt, lr, step_s)
+        _apply_rows(T, tstate, rows, GT, opt, lr, step_t)
+    map_optimizer.step()
+    return loss.detach()

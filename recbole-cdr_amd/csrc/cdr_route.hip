@@ -127,3 +127,57 @@ extern "C" int cdr_inverse_perm(void* stream, const uint32_t* perm, int64_t n, i
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
+
+// ---- full-sort over row-sharded item tables: after the all-gather the scores sit shard-major, [G][U][Nl] with shard g
+// holding the items g, g+G, g+2G, ... ; the reference's layout is [U][N] in item-id order.  One streaming pass:
+// out[u][c] = gathered[c % G][u][c / G].  A thread produces 4 consecutive outputs (one 16-byte store); within a wave the
+// reads fall into G streams of consecutive floats, so both sides stay full-line.
+__global__ __launch_bounds__(kBlock) void interleave_shards_kernel(const float* __restrict__ g, int G, int64_t U, int64_t Nl,
+                                                                   int64_t N, float* __restrict__ out) {
+    const int64_t quads = (N + 3) / 4;
+    const int64_t total = U * quads;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t u = t / quads, c0 = (t - u * quads) * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + j;
+            v[j] = c < N ? g[((int64_t)(c % G) * U + u) * Nl + c / G] : 0.f;
+        }
+        float* o = out + u * N + c0;
+        if (c0 + 3 < N && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (c0 + j < N) o[j] = v[j];
+        }
+    }
+}
+
+extern "C" int cdr_interleave_shards(void* stream, const float* gathered, int world, int64_t U, int64_t Nl, int64_t N, float* out) {
+    CDR_CHECK_ARG(gathered && out && world >= 1 && U > 0 && Nl > 0 && N > 0 && N <= Nl * (int64_t)world);
+    const int64_t total = U * ((N + 3) / 4);
+    interleave_shards_kernel<<<dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream>>>(gathered, world, U, Nl, N, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+// rows of a sharded table for a REPLICATED id list: out[r] = table[ids[r] / G] if ids[r] % G == rank else 0 -- summing
+// this over the ranks (all-reduce) gives every rank the gathered rows exactly (x + 0 == x).
+__global__ __launch_bounds__(kBlock) void gather_owned_rows_kernel(const float* __restrict__ tab, int D, const int64_t* __restrict__ ids,
+                                                                   int64_t n, int64_t G, int64_t rank, float* __restrict__ out) {
+    const int64_t total = n * D;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = t / D; const int d = (int)(t - r * D);
+        const int64_t id = ids[r];
+        out[t] = (id % G == rank) ? tab[(id / G) * D + d] : 0.f;
+    }
+}
+
+extern "C" int cdr_gather_owned_rows(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, int world, int rank,
+                                     float* out) {
+    CDR_CHECK_ARG(tab && ids && out && D > 0 && n > 0 && world >= 1 && rank >= 0 && rank < world);
+    gather_owned_rows_kernel<<<dim3(grid_for(n * D)), dim3(kBlock), 0, (hipStream_t)stream>>>(tab, D, ids, n, world, rank, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -15,10 +15,13 @@ OPT_SGD, OPT_ADAM = 0, 1
 
 
 class RowwiseState:
-    """Per-table optimizer state for the row-wise Adam (allocated lazily; SGD needs none)."""
+    """Per-table optimizer state for the row-wise Adam (SGD needs no moments).  ``step`` counts the updates this TABLE
+    has received -- like torch.optim.Adam's per-parameter ``state['step']`` -- so one state object can be shared by the
+    step objects of several phases (SOURCE / TARGET BPR steps and the OVERLAP map step touch the same user tables)."""
 
     def __init__(self, table, opt):
         self.table = table
+        self.step = 0
         self.exp_avg = torch.zeros_like(table) if opt == OPT_ADAM else None
         self.exp_avg_sq = torch.zeros_like(table) if opt == OPT_ADAM else None
 
@@ -27,7 +30,7 @@ class FusedBPRStep:
     """One object per (user table, item table) pair; buffers are sized for ``max_batch`` triples and reused."""
 
     def __init__(self, user_table, item_table, max_batch, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0):
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None):
         assert user_table.is_cuda and item_table.is_cuda, 'FusedBPRStep needs ROCm device tensors'
         assert user_table.shape[1] == item_table.shape[1]
         self.U, self.I = user_table, item_table
@@ -35,9 +38,8 @@ class FusedBPRStep:
         self.opt = OPT_ADAM if opt == 'adam' else OPT_SGD
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.gamma, self.reg_weight = gamma, reg_weight
-        self.ustate = RowwiseState(user_table, self.opt)
-        self.istate = RowwiseState(item_table, self.opt)
-        self.step_count = 0
+        self.ustate = user_state if user_state is not None else RowwiseState(user_table, self.opt)
+        self.istate = item_state if item_state is not None else RowwiseState(item_table, self.opt)
         dev = user_table.device
         Bm = int(max_batch)
         self.max_batch = Bm
@@ -58,7 +60,6 @@ class FusedBPRStep:
         """uid/pid/nid: int64 device tensors [B].  Returns the device tensor out6 (view; [0] = total loss)."""
         B = uid.numel()
         assert B <= self.max_batch
-        self.step_count += 1
         s = B_.stream()
         ctxh = B_.ctx(self.U.device)
         B_.call('cdr_bpr_fwd_grad', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid),
@@ -73,7 +74,119 @@ class FusedBPRStep:
         return self.out6
 
     def _apply(self, ctxh, st, keys, perm, n, G, neg_start, reg_limit, coef):
+        st.step += 1
         B_.call('cdr_rowwise_apply', ctxh, B_.stream(), self.opt, B_.f32(st.table), B_.f32(st.exp_avg),
                 B_.f32(st.exp_avg_sq), self.D, B_.raw(keys), B_.raw(perm), n, B_.f32(G), neg_start, reg_limit,
                 B_.f32(coef), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                float(self.wd), self.step_count, None)
+                float(self.wd), st.step, None)
+
+
+class FusedMapStep:
+    """EMCDR's OVERLAP phase (emcdr.py:133-137 ``calculate_map_loss``: MSE(mapping(source_e[idx]), target_e[idx])) as an
+    O(batch) step: the two embedding tables are updated row-wise on the overlapped ids only; the mapping function's own
+    parameters (a few hundred KB) keep the exact dense Adam.
+
+    ``mapping_fn``  x [n, Ds] -> [n, Dt] built from functional.linear (autograd through the native GEMM kernels), e.g. a
+                    model's ``apply_mapping``;  ``mapping_params`` its parameters.
+    ``group``       optional process group: the tables are then this rank's row shards (row r % G == rank at r // G) and
+                    ``step`` takes GLOBAL ids.  Both tables use the same sharding rule and an overlapped id names the same
+                    entity in both, so after ONE all-to-all of ids everything is local: the "overlapped-user transfer
+                    step" moves 8 B per id, never a row.  The MSE mean is over the global batch; the mapping gradients
+                    are all-reduced (every rank then takes the same dense Adam step on its replica).
+    """
+
+    def __init__(self, source_table, target_table, mapping_fn, mapping_params, max_batch, opt='adam', lr=1e-3,
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, group=None, source_state=None, target_state=None):
+        from .trainer.trainer import DenseAdam
+        assert source_table.is_cuda and target_table.is_cuda, 'FusedMapStep needs ROCm device tensors'
+        self.S, self.T = source_table, target_table
+        self.mapping_fn = mapping_fn
+        self.mapping_params = list(mapping_params)
+        self.opt = OPT_ADAM if opt == 'adam' else OPT_SGD
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # the row-wise moments may be shared with the FusedBPRStep objects of the SOURCE / TARGET phases (one optimizer
+        # state per table across phases, like the reference's single Adam instance: trainer.py:30-41)
+        self.sstate = source_state if source_state is not None else RowwiseState(source_table, self.opt)
+        self.tstate = target_state if target_state is not None else RowwiseState(target_table, self.opt)
+        self.map_opt = DenseAdam(self.mapping_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) \
+            if self.opt == OPT_ADAM else None
+        self.group = group
+        self.loss = torch.zeros((), device=source_table.device, dtype=torch.float32)
+        self._ws = None
+
+    def _route(self, idx):
+        """Global ids -> the local row indices this rank owns (one all-to-all of ids), plus the global batch size."""
+        import torch.distributed as dist
+        from .shard import NativeOps, _a2a, _gather_counts
+        G, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        ops = NativeOps(idx.device) if not hasattr(self, '_ops') else self._ops
+        self._ops = ops
+        perm, counts = ops.route(idx, None, G)
+        send = ops.permute(idx, None, perm, G)
+        allc = torch.stack(_gather_counts(counts, idx.numel(), self.group, G)).tolist()          # one host sync
+        t_send = [int(c) for c in allc[rank][:G]]
+        t_recv = [int(allc[r][rank]) for r in range(G)]
+        n_global = sum(int(allc[r][G]) for r in range(G))
+        return _a2a(send, t_send, t_recv, self.group), n_global
+
+    def step(self, idx):
+        """idx: int64 device tensor of overlapped ids, any shape ([OB,1] from the OverlapDataloader).  Returns the loss
+        (device scalar; the global-batch MSE when sharded)."""
+        idx = idx.reshape(-1).contiguous()
+        n_global = idx.numel()
+        if self.group is not None:
+            idx, n_global = self._route(idx)
+        n = idx.numel()
+        D_s, D_t = self.S.shape[1], self.T.shape[1]
+        dev = self.S.device
+        s = B_.stream()
+        for p in self.mapping_params:
+            p.grad = None
+        if n:
+            src = torch.empty(n, D_s, device=dev, dtype=torch.float32)
+            tgt = torch.empty(n, D_t, device=dev, dtype=torch.float32)
+            B_.call('cdr_gather_rows', s, B_.f32(self.S), D_s, B_.i64(idx), n, B_.f32(src))
+            B_.call('cdr_gather_rows', s, B_.f32(self.T), D_t, B_.i64(idx), n, B_.f32(tgt))
+            src.requires_grad_(True); tgt.requires_grad_(True)
+            from . import functional as F_
+            local = F_.mse_loss(self.mapping_fn(src), tgt)              # mean over n * Dt
+            loss = local * (float(n) / float(n_global))                  # this rank's share of the global mean
+            loss.backward()
+            loss = loss.detach()
+        else:
+            loss = torch.zeros((), device=dev, dtype=torch.float32)
+        if self.group is not None:
+            import torch.distributed as dist
+            flat = torch.cat([loss.reshape(1)] + [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                                  for p in self.mapping_params])
+            dist.all_reduce(flat, group=self.group)
+            loss, off = flat[0], 1
+            for p in self.mapping_params:
+                p.grad = flat[off:off + p.numel()].view_as(p).clone()
+                off += p.numel()
+        self.loss = loss
+        self.sstate.step += 1                  # per TABLE, also on a rank that received no ids (the shards stay in step)
+        self.tstate.step += 1
+        if n:
+            ctxh = B_.ctx(dev)
+            need = ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_sort_workspace_bytes(n, self.S.shape[0], ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+            if self._ws is None or self._ws.numel() < need.value:
+                self._ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+            keys = torch.empty(n, device=dev, dtype=torch.int32)
+            perm = torch.empty(n, device=dev, dtype=torch.int32)
+            # the same ids index both tables: one sort serves both applies
+            B_.call('cdr_sort_ids', ctxh, s, B_.i64(idx), n, None, 0, self.S.shape[0], B_.raw(keys), B_.raw(perm),
+                    B_.raw(self._ws), self._ws.numel())
+            for st, g in ((self.sstate, src.grad), (self.tstate, tgt.grad)):
+                B_.call('cdr_rowwise_apply', ctxh, s, self.opt, B_.f32(st.table), B_.f32(st.exp_avg), B_.f32(st.exp_avg_sq),
+                        st.table.shape[1], B_.raw(keys), B_.raw(perm), n, B_.f32(g), n, 0, None, float(self.lr),
+                        float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), st.step, None)
+        if self.map_opt is not None:
+            self.map_opt.step()
+        else:
+            with torch.no_grad():
+                for p in self.mapping_params:
+                    if p.grad is not None:
+                        p.add_(p.grad + self.wd * p if self.wd else p.grad, alpha=-self.lr)
+        return self.loss

@@ -158,7 +158,8 @@ class ShardedBPRStep:
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
-                 stream=None):
+                 stream=None, user_state=None, item_state=None):
+        from .fused import RowwiseState
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -171,15 +172,19 @@ class ShardedBPRStep:
         self.gamma, self.reg_weight = gamma, reg_weight
         dev = user_shard.device
         self.ops = ops if ops is not None else NativeOps(dev)
-        self.ustate = (torch.zeros_like(user_shard), torch.zeros_like(user_shard)) if self.opt == OPT_ADAM else None
-        self.istate = (torch.zeros_like(item_shard), torch.zeros_like(item_shard)) if self.opt == OPT_ADAM else None
+        # per-table optimizer state (moments + update count); may be shared with the OVERLAP phase's FusedMapStep
+        self.ustate = user_state if user_state is not None else RowwiseState(user_shard, self.opt)
+        self.istate = item_state if item_state is not None else RowwiseState(item_shard, self.opt)
         self.max_batch = int(max_batch)
         self.out = torch.zeros(12, device=dev, dtype=torch.float32)
-        self.step_count = 0
         self.stream = stream                      # optional torch.cuda.Stream for pipelined execution
 
     def loss_value(self):
         return self.out[0]
+
+    @staticmethod
+    def _moments(st):
+        return (st.exp_avg, st.exp_avg_sq) if st.exp_avg is not None else None
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
@@ -193,7 +198,8 @@ class ShardedBPRStep:
         """Generator form of one step: yields at the two points where the host must wait for bucket counts."""
         G, grp, ops = self.world, self.group, self.ops
         B = uid.numel()
-        self.step_count += 1
+        self.ustate.step += 1                      # per table, on every rank (also one whose buckets came up empty)
+        self.istate.step += 1
 
         # ---- 0. triples travel to the owner of their user row ---------------------------------------------------
         with self._on_stream():
@@ -246,12 +252,12 @@ class ShardedBPRStep:
 
             # ---- 3. user rows are local; item gradients go home ---------------------------------------------------
             if Bl:
-                ops.sort_apply(self.U, self.ustate, u_loc, GU[:Bl], self.opt, self.hp, self.step_count, reg_limit=Bl,
-                               reg_coef=self.out[4:5])
+                ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,
+                               reg_limit=Bl, reg_coef=self.out[4:5])
             gi_recv = _a2a(gi, i_send, i_recv, grp, (self.D,))
             # the owner adds the EmbLoss term itself (it holds the pre-step row; the tag tells it which occurrences count)
-            ops.sort_apply(self.I, self.istate, i_req, gi_recv, self.opt, self.hp, self.step_count, reg_coef=self.out[5:6],
-                           tagged=True)
+            ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step,
+                           reg_coef=self.out[5:6], tagged=True)
 
 
 def run_pipelined(generators):
@@ -264,3 +270,54 @@ def run_pipelined(generators):
                 next(g)
             except StopIteration:
                 alive.remove(g)
+
+
+class ShardedFullSort:
+    """``full_sort_predict`` (emcdr.py:208-233, TARGET / OVERLAP phase) over row-sharded tables: every rank scores the
+    eval users against ITS rows of the target item table (the 1-GPU scoring kernels on N/G rows), the partial score
+    matrices are all-gathered, and one streaming kernel puts them into the reference's ``[U, N]`` item-id order.
+
+    ``n_scored`` = the number of leading global item rows that are scored (``target_num_items`` = OI + TOI: the target
+    phase scores a prefix of the union-sized table).  The eval users' rows are replicated first (``user_rows``): U*D*4
+    bytes, nothing next to the U*N*4*(G-1)/G bytes of the score all-gather, which is what bounds this path on xGMI --
+    callers that only need top-k should rank per shard and exchange k candidates instead."""
+
+    def __init__(self, item_shard, n_scored, group=None):
+        from . import binding as B_
+        self.B_ = B_
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.I = item_shard
+        self.N = int(n_scored)
+        self.Nl = (self.N + self.world - 1) // self.world            # rows per shard in the gathered layout (last one padded)
+        self._pad = torch.zeros(1, item_shard.shape[1], device=item_shard.device, dtype=torch.float32)
+
+    def user_rows(self, table_shard, ids):
+        """Rows ``ids`` (replicated list of GLOBAL ids) of a sharded table, replicated on every rank."""
+        B_ = self.B_
+        ids = ids.reshape(-1).contiguous()
+        out = torch.empty(ids.numel(), table_shard.shape[1], device=table_shard.device, dtype=torch.float32)
+        B_.call('cdr_gather_owned_rows', B_.stream(), B_.f32(table_shard), table_shard.shape[1], B_.i64(ids), ids.numel(),
+                self.world, self.rank, B_.f32(out))
+        dist.all_reduce(out, group=self.group)
+        return out
+
+    def local_scores(self, user_e):
+        """[U, Nl] scores of this rank's item rows r = rank, rank + G, ... < n_scored (column Nl-1 may be padding)."""
+        from . import functional as F_
+        mine = shard_rows(self.N, self.world, self.rank)
+        if mine == self.Nl:
+            return F_.fullsort_scores(user_e, self.I[:mine])
+        return F_.fullsort_scores(user_e, self.I[:mine], self._pad)                  # mine == Nl - 1: one padded column
+
+    def scores(self, user_e):
+        """user_e [U, D] (replicated) -> [U, n_scored] on every rank, identical to the single-device result."""
+        B_ = self.B_
+        U = user_e.shape[0]
+        part = self.local_scores(user_e)
+        gathered = torch.empty(self.world * U, self.Nl, device=part.device, dtype=torch.float32)   # [G][U][Nl], dim-0 concat
+        dist.all_gather_into_tensor(gathered, part, group=self.group)
+        out = torch.empty(U, self.N, device=part.device, dtype=torch.float32)
+        B_.call('cdr_interleave_shards', B_.stream(), B_.f32(gathered), self.world, U, self.Nl, self.N, B_.f32(out))
+        return out

@@ -247,6 +247,90 @@ def test_fused_step_vs_oracle(opt, D, k):
             assert_close(Id, I, rtol=2e-5, what=f'I after step {step}')
 
 
+def _make_mapping(dims, seed):
+    """(params dict in the oracle's naming, device parameter list, device mapping_fn) for a linear (2 dims) or tanh-MLP
+    mapping function (emcdr.py:74-93)."""
+    from recbole_cdr_amd import functional as F_, binding as B_
+    g = torch.Generator(); g.manual_seed(seed)
+    cpu, dev = {}, []
+    if len(dims) == 2:
+        w = torch.randn(dims[1], dims[0], generator=g) * 0.2
+        cpu['mapping.weight'] = w.clone().requires_grad_(True)
+        dev.append(torch.nn.Parameter(w.clone().to(DEV)))
+        return cpu, dev, lambda x: F_.linear(x, dev[0], None, B_.ACT_NONE)
+    for n, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        w, bias = torch.randn(b, a, generator=g) * 0.2, torch.randn(b, generator=g) * 0.1
+        cpu[f'mapping.{2 * n}.weight'] = w.clone().requires_grad_(True)
+        cpu[f'mapping.{2 * n}.bias'] = bias.clone().requires_grad_(True)
+        dev += [torch.nn.Parameter(w.clone().to(DEV)), torch.nn.Parameter(bias.clone().to(DEV))]
+    L = len(dims) - 1
+
+    def fn(x):
+        for n in range(L):
+            x = F_.linear(x, dev[2 * n], dev[2 * n + 1], B_.ACT_TANH if n != L - 1 else B_.ACT_NONE)
+        return x
+    return cpu, dev, fn
+
+
+@pytest.mark.parametrize('dims', [(64, 64), (32, 48, 16), (128, 64, 128)])
+def test_fused_map_step_vs_oracle(dims):
+    """OVERLAP phase as an O(batch) step: loss, both tables' touched rows, their moments and the mapping parameters after
+    three steps == oracle (autograd + lazy row-wise Adam on the tables + torch.optim.Adam on the mapping)."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import FusedMapStep
+    torch.manual_seed(sum(dims))
+    rows, lr, OB = 300, 0.01, 100
+    S, T = torch.randn(rows, dims[0]) * 0.3, torch.randn(rows, dims[-1]) * 0.3
+    Sd, Td = S.clone().to(DEV), T.clone().to(DEV)
+    cpu, dev, fn = _make_mapping(dims, 5)
+    fm = FusedMapStep(Sd, Td, fn, dev, OB, lr=lr)
+    ss, tst = ts.RowwiseAdamState(S), ts.RowwiseAdamState(T)
+    mopt = torch.optim.Adam(list(cpu.values()), lr=lr)
+    for step in range(1, 4):
+        idx = torch.randperm(rows - 1)[:OB].add(1).reshape(-1, 1)          # [OB,1] unique ids like the OverlapDataloader
+        if step == 2:
+            idx[: OB // 4] = idx[0]                                       # duplicates must be summed, not raced
+        want = ts.rowwise_map_step(cpu, S, T, ss, tst, idx, step, step, mopt, lr=lr)
+        got = fm.step(idx.to(DEV))
+        assert_close(got, want, what=f'map loss step {step}')
+        assert_close(fm.sstate.exp_avg, ss.m, rtol=5e-5, what=f'source exp_avg step {step}')
+        assert_close(fm.tstate.exp_avg, tst.m, rtol=5e-5, what=f'target exp_avg step {step}')
+        assert_close(Sd, S, rtol=2e-5, atol=lr * 1e-2, what=f'source rows step {step}')
+        assert_close(Td, T, rtol=2e-5, atol=lr * 1e-2, what=f'target rows step {step}')
+        for (k, c), d in zip(cpu.items(), dev):
+            assert_close(d, c.detach(), rtol=2e-5, atol=lr * 2e-2, what=f'{k} step {step}')
+        # continue from identical states (Adam's m / (sqrt(v) + eps) amplifies rounding where |g| ~ eps)
+        S.copy_(Sd.cpu()); T.copy_(Td.cpu())
+        ss.m.copy_(fm.sstate.exp_avg.cpu()); ss.v.copy_(fm.sstate.exp_avg_sq.cpu())
+        tst.m.copy_(fm.tstate.exp_avg.cpu()); tst.v.copy_(fm.tstate.exp_avg_sq.cpu())
+        with torch.no_grad():
+            for c, d in zip(cpu.values(), dev):
+                c.copy_(d.detach().cpu())
+            for c, d in zip(cpu.values(), dev):
+                st_c, st_d = mopt.state[c], fm.map_opt.state[d]
+                st_c['exp_avg'].copy_(st_d['exp_avg'].cpu()); st_c['exp_avg_sq'].copy_(st_d['exp_avg_sq'].cpu())
+
+
+def test_rowwise_state_is_shared_across_phases():
+    """One optimizer state per TABLE (the reference keeps a single Adam across SOURCE / TARGET / OVERLAP: trainer.py:30-41):
+    a BPR step followed by a map step on the same user table continues that table's update count and moments."""
+    from recbole_cdr_amd.fused import FusedBPRStep, FusedMapStep
+    torch.manual_seed(0)
+    D = 32
+    SU, SI, TU = (torch.randn(200, D, device=DEV) * 0.1 for _ in range(3))
+    cpu, dev, fn = _make_mapping((D, D), 1)
+    bpr = FusedBPRStep(SU, SI, 64, lr=0.01)
+    fm = FusedMapStep(SU, TU, fn, dev, 64, lr=0.01, source_state=bpr.ustate)
+    ids = torch.randint(1, 200, (64,), device=DEV)
+    bpr.step(ids, ids, ids.flip(0))
+    assert bpr.ustate.step == 1 and fm.sstate is bpr.ustate
+    m_before = bpr.ustate.exp_avg.clone()
+    fm.step(ids[:50])
+    assert bpr.ustate.step == 2 and fm.tstate.step == 1
+    touched = torch.unique(ids[:50])
+    assert not torch.equal(bpr.ustate.exp_avg[touched], m_before[touched])
+
+
 def test_fused_step_deterministic_and_sorted():
     """Bit-reproducibility of the row-wise step (fixed-order segment sums) and sortedness of the id sort."""
     from recbole_cdr_amd.fused import FusedBPRStep
@@ -294,7 +378,7 @@ def test_sharded_step_world1_equals_fused():
             lb = fb.step(u, p, n)[0].clone()
             assert_close(lb, la, rtol=1e-6, what=f'loss step {step}')
         assert_close(Ub, Ua, rtol=2e-5, atol=0.01 * 1e-2); assert_close(Ib, Ia, rtol=2e-5, atol=0.01 * 1e-2)
-        assert_close(fb.ustate[0], fa.ustate.exp_avg, rtol=2e-5); assert_close(fb.istate[0], fa.istate.exp_avg, rtol=2e-5)
+        assert_close(fb.ustate.exp_avg, fa.ustate.exp_avg, rtol=2e-5); assert_close(fb.istate.exp_avg, fa.istate.exp_avg, rtol=2e-5)
     finally:
         dist.destroy_process_group()
 
@@ -780,6 +864,28 @@ def test_spmm_csr_vs_torch_sparse():
     assert_close(out, ref)
 
 
+def _collect_ranks(q, procs, limit=300):
+    """One result per worker, sorted by rank; gives up as soon as a worker has died instead of waiting out the limit."""
+    import queue
+    import time
+    res, t0 = [], time.time()
+    try:
+        while len(res) < len(procs):
+            try:
+                res.append(q.get(timeout=2))
+            except queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f'worker exit codes {dead}'
+                assert time.time() - t0 < limit, 'workers timed out'
+    finally:
+        for p in procs:
+            p.join(timeout=30 if len(res) == len(procs) else 1)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return sorted(res, key=lambda t: t[0])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # world_size > 1 with the NATIVE kernels: several ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
 # device; the driver's 8-GPU run is the only place real xGMI traffic happens).  Same exchange code, same libcdrhip ops,
@@ -839,14 +945,7 @@ def test_sharded_native_ranks_share_one_gpu(world, pipelined):
     procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, pipelined, q)) for r in range(world)]
     for p in procs:
         p.start()
-    try:
-        res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
-    finally:
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()
-    assert all(p.exitcode == 0 for p in procs)
+    res = _collect_ranks(q, procs)
     torch.manual_seed(11)
     nu, ni, D = 7001, 3003, 64
     ndom = 2 if pipelined else 1
@@ -863,3 +962,83 @@ def test_sharded_native_ranks_share_one_gpu(world, pipelined):
         for r in range(world):
             assert_close(torch.from_numpy(res[r][1][d][0]).to(DEV), U[r::world], rtol=2e-5, atol=0.01 * 1e-2, what=f'U dom{d} rank{r}')
             assert_close(torch.from_numpy(res[r][1][d][1]).to(DEV), I[r::world], rtol=2e-5, atol=0.01 * 1e-2, what=f'I dom{d} rank{r}')
+
+
+def _shared_gpu_map_eval_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.fused import FusedMapStep
+        from recbole_cdr_amd.shard import ShardedFullSort, shard_of
+        torch.cuda.set_device(0)
+        torch.manual_seed(21)
+        nu, ni, D = 1501, 2003, 64
+        SU, TU, TI = (torch.randn(n, D) * 0.2 for n in (nu, nu, ni))
+        SUl, TUl, TIl = (shard_of(t, world, rank).to(DEV) for t in (SU, TU, TI))
+        _cpu, dev, fn = _make_mapping((D, 32, D), 9)
+        fm = FusedMapStep(SUl, TUl, fn, dev, 400, lr=0.01, group=dist.group.WORLD)
+        losses, batches = [], []
+        for it in range(3):
+            g = torch.Generator(); g.manual_seed(50 * it + rank)
+            idx = torch.randperm(nu - 1, generator=g)[: 100 + 7 * rank].add(1).reshape(-1, 1)
+            if it == 2 and rank == world - 1:
+                idx = idx[:0]                                            # a rank with an empty overlap batch
+            batches.append(idx.numpy())
+            losses.append(float(fm.step(idx.to(DEV))))
+        # full-sort over the sharded target item table, two prefix lengths (one not divisible by the world size)
+        evals = {}
+        for n_scored in (ni, 1000):
+            fs = ShardedFullSort(TIl, n_scored)
+            for Uu in (3, 40):
+                ids = torch.arange(5, 5 + Uu) * 7 % nu
+                ue = fs.user_rows(TUl, ids.to(DEV))
+                evals[(n_scored, Uu)] = (ue.cpu().numpy(), fs.scores(ue).cpu().numpy())
+        q.put((rank, SUl.cpu().numpy(), TUl.cpu().numpy(), [p.detach().cpu().numpy() for p in dev], losses, batches, evals))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_map_step_and_fullsort_ranks_share_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    from recbole_cdr_amd import functional as F_
+    from recbole_cdr_amd.fused import FusedMapStep
+    world = 3
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shared_gpu_map_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    torch.manual_seed(21)
+    nu, ni, D = 1501, 2003, 64
+    SU, TU, TI = (torch.randn(n, D) * 0.2 for n in (nu, nu, ni))
+    TU0, TI0 = TU.clone().to(DEV), TI.to(DEV)
+    # full-sort first (it ran on the post-training user table in the workers, so compare against the gathered rows)
+    for (n_scored, Uu), (ue, sc) in res[0][6].items():
+        want = F_.fullsort_scores(torch.from_numpy(ue).to(DEV), TI0[:n_scored])
+        for r in range(world):
+            np.testing.assert_array_equal(res[r][6][(n_scored, Uu)][0], ue)           # every rank holds the same user rows
+            assert_close(torch.from_numpy(res[r][6][(n_scored, Uu)][1]).to(DEV), want, rtol=1e-6, what=f'scores {n_scored} U={Uu} rank {r}')
+    # the map step against the single-device step on the concatenated batches
+    SUd, TUd = SU.to(DEV), TU0
+    _cpu, dev, fn = _make_mapping((D, 32, D), 9)
+    ref = FusedMapStep(SUd, TUd, fn, dev, 400, lr=0.01)
+    for it in range(3):
+        idx = torch.from_numpy(np.concatenate([res[r][5][it] for r in range(world)])).to(DEV)
+        loss = float(ref.step(idx))
+        for r in range(world):
+            assert abs(res[r][4][it] - loss) <= 1e-5 * abs(loss), (it, r, res[r][4][it], loss)
+    for r in range(world):
+        assert_close(torch.from_numpy(res[r][1]).to(DEV), SUd[r::world], rtol=2e-5, atol=0.01 * 2e-2, what=f'source shard {r}')
+        assert_close(torch.from_numpy(res[r][2]).to(DEV), TUd[r::world], rtol=2e-5, atol=0.01 * 2e-2, what=f'target shard {r}')
+        for a, b in zip(res[r][3], dev):
+            assert_close(torch.from_numpy(a).to(DEV), b.detach(), rtol=2e-5, atol=0.01 * 2e-2, what=f'mapping replica {r}')
+    # the user rows each rank gathered are rows of the trained target table
+    ids = torch.arange(5, 8) * 7 % nu
+    assert_close(torch.from_numpy(res[0][6][(ni, 3)][0]).to(DEV), TUd[ids.to(DEV)], rtol=2e-5, atol=0.01 * 2e-2)
