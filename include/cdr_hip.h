@@ -250,7 +250,10 @@ int cdr_revoke_map(void* stream, const int64_t* ids, int64_t n, int64_t overlap_
  *                             + reg_coef[0] * #{o in seg : o < reg_limit} * table[r]
  *                      then opt 0: SGD  table[r] -= lr * (grad + wd * table[r])
  *                           opt 1: Adam (torch.optim.Adam arithmetic, per-row lazy) with exp_avg / exp_avg_sq rows.
- *                      Summation follows occurrence order (the sort is stable): bit-reproducible.
+ *                      Summation follows occurrence order (the sort is stable): bit-reproducible.  Segments longer than
+ *                      32 occurrences (skewed id streams) are cut into pieces of 256 that are summed in parallel and
+ *                      combined in piece order -- still a fixed order; the partial sums live in ctx-owned scratch, so a
+ *                      ctx must not be used from two streams at once (the host binding keeps one per stream).
  */
 int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      const float* user_tab, const float* item_tab, int D,

@@ -157,16 +157,23 @@ def _check(rc, what):
         raise RuntimeError(f'{what} failed (code {rc}): {msg}')
 
 
-def ctx(device):
-    """One cdr_ctx (reduction scratch) per device, created on first use."""
+def _dev_index(device):
     idx = torch.device(device).index
-    if idx is None:
-        idx = torch.cuda.current_device()
-    if idx not in _ctx:
+    return torch.cuda.current_device() if idx is None else idx
+
+
+def ctx(device):
+    """The cdr_ctx (reduction partials, long-segment scratch, timing ring) of (device, CURRENT stream), created on first
+    use.  One per stream: two steps pipelined on two HIP streams (shard.run_pipelined) must not share reduction scratch."""
+    idx = _dev_index(device)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    if key not in _ctx:
         h = _c_ptr()
         _check(load().cdr_ctx_create(idx, ctypes.byref(h)), 'cdr_ctx_create')
-        _ctx[idx] = h
-    return _ctx[idx]
+        _ctx[key] = h
+        if _timing_cap.get(idx, 0):
+            _check(load().cdr_timing_enable(h, _timing_cap[idx]), 'cdr_timing_enable')
+    return _ctx[key]
 
 
 def stream():
@@ -216,14 +223,29 @@ TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4:
         5: 'rowwise_apply_kernel(items)', 6: 'sort_ids'}
 
 
+_timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device
+
+
 def timing_enable(device, capacity):
-    call('cdr_timing_enable', ctx(device), int(capacity))
+    """HIP-event brackets around the hot kernels on every stream of ``device`` (capacity 0 switches them off)."""
+    idx = _dev_index(device)
+    _timing_cap[idx] = int(capacity)
+    ctx(device)                                    # make sure the current stream has a context
+    for (d, _s), h in _ctx.items():
+        if d == idx:
+            call('cdr_timing_enable', h, int(capacity))
 
 
 def timing_collect(device, max_n=65536):
-    """-> list of (kernel name, milliseconds) in launch order, measured by HIP events on the launch stream."""
-    tags = (_c_int * max_n)()
-    ms = (_c_f32 * max_n)()
-    n = _c_int(0)
-    call('cdr_timing_collect', ctx(device), tags, ms, max_n, ctypes.byref(n))
-    return [(TAGS.get(tags[i], str(tags[i])), float(ms[i])) for i in range(n.value)]
+    """-> list of (kernel name, milliseconds), per stream in launch order, measured by HIP events on the launch stream."""
+    idx = _dev_index(device)
+    res = []
+    for (d, _s), h in _ctx.items():
+        if d != idx:
+            continue
+        tags = (_c_int * max_n)()
+        ms = (_c_f32 * max_n)()
+        n = _c_int(0)
+        call('cdr_timing_collect', h, tags, ms, max_n, ctypes.byref(n))
+        res += [(TAGS.get(tags[i], str(tags[i])), float(ms[i])) for i in range(n.value)]
+    return res

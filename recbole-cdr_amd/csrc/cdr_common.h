@@ -13,6 +13,8 @@
 struct cdr_ctx {
     int device;
     double* partials;                        // [CDR_MAX_PARTIAL_BLOCKS][CDR_PARTIAL_STRIDE]
+    void* scratch;                           // grow-on-demand device scratch (long-segment partial sums of cdr_rowwise_apply)
+    size_t scratch_bytes;
     // optional HIP-event brackets around the hot kernels, recorded on the launch stream (cdr_timing_*)
     int timing_cap, timing_n;
     hipEvent_t* ev0;
@@ -34,6 +36,7 @@ struct cdr_time_scope {
 };
 
 void cdr_set_error(const char* fmt, ...);
+int cdr_ctx_scratch(cdr_ctx* ctx, size_t bytes, void** out);
 
 #define CDR_CHECK_ARG(cond)                                                         \
     do {                                                                            \

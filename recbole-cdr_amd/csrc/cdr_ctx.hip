@@ -31,6 +31,8 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     c->timing_cap = c->timing_n = 0;
     c->ev0 = c->ev1 = nullptr;
     c->tags = nullptr;
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
     hipError_t e = hipMalloc(&c->partials, sizeof(double) * CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
@@ -39,6 +41,26 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
         return CDR_ENOMEM;
     }
     *out = c;
+    return CDR_OK;
+}
+
+// Device scratch owned by the context, grown (never shrunk) on demand.  hipFree synchronises the device, so work still
+// reading the old block has finished before it is released.  A context serves ONE stream at a time (the host binding
+// keeps one per (device, stream)): its scratch and reduction partials are not shared between concurrent launches.
+int cdr_ctx_scratch(cdr_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->scratch_bytes < bytes) {
+        int prev = 0;
+        CDR_HIP(hipGetDevice(&prev));
+        CDR_HIP(hipSetDevice(ctx->device));
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&ctx->scratch, want);
+        (void)hipSetDevice(prev);
+        if (e != hipSuccess) { cdr_set_error("cdr_ctx_scratch: %zu bytes: %s", want, hipGetErrorString(e)); return CDR_ENOMEM; }
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
     return CDR_OK;
 }
 
@@ -74,6 +96,7 @@ extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
     if (!ctx) return CDR_OK;
     cdr_timing_enable(ctx, 0);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
     return CDR_OK;
 }

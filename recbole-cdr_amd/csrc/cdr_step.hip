@@ -155,6 +155,45 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const int64_t* __rest
 
 // ------------------------------------------------------------------------------------------------ segmented apply
 // OPT 0: SGD  w -= lr * grad            OPT 1: Adam on the touched rows (torch.optim.Adam arithmetic per element)
+//
+// Segments up to kLongSeg occurrences are summed by their head's lane group (the common case: a batch of 1-2 M ids over
+// 10-50 M rows has segments of 1-5).  Skewed id streams (Zipf item popularity, SURVEY 8d synthetic inputs (ii)) put tens
+// of thousands of occurrences into one segment; walking those with one lane group took 52 ms per step.  A head that
+// sees a long segment therefore only registers it: the segment is cut into pieces of kPiece occurrences, every piece is
+// summed by its own lane group (seg_piece_sum_kernel), and a finishing kernel adds the piece sums in piece order and
+// applies the optimizer.  All three levels add in a fixed order: results stay bit-reproducible.
+constexpr int kLongSeg = 32;
+constexpr int kPiece = 256;
+
+struct seg_long { int64_t head, len, base; };           // sorted position of the head, occurrences, first piece index
+struct seg_piece { int64_t start; int64_t len; };
+
+struct apply_hp { float lr, b1, b2, eps, wd, step_size, bc2_sqrt; };
+
+template <int OPT>
+__device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __restrict__ mp, float* __restrict__ vp, float4 w,
+                                             float4 acc, float rc, const apply_hp& h) {
+    float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
+    float4 wn;
+    if (OPT == 0) {
+        if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
+        wn = make_float4(w.x - h.lr * gr.x, w.y - h.lr * gr.y, w.z - h.lr * gr.z, w.w - h.lr * gr.w);
+    } else {
+        float4 m = ld4(mp), v = ld4(vp);
+        if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
+        m.x += (gr.x - m.x) * (1.0f - h.b1); m.y += (gr.y - m.y) * (1.0f - h.b1);
+        m.z += (gr.z - m.z) * (1.0f - h.b1); m.w += (gr.w - m.w) * (1.0f - h.b1);
+        v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
+        v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
+        st4(mp, m); st4(vp, v);
+        wn = make_float4(w.x - h.step_size * (m.x / (sqrtf(v.x) / h.bc2_sqrt + h.eps)),
+                         w.y - h.step_size * (m.y / (sqrtf(v.y) / h.bc2_sqrt + h.eps)),
+                         w.z - h.step_size * (m.z / (sqrtf(v.z) / h.bc2_sqrt + h.eps)),
+                         w.w - h.step_size * (m.w / (sqrtf(v.w) / h.bc2_sqrt + h.eps)));
+    }
+    st4(wp, wn);
+}
+
 template <int LPR, int OPT, bool SIGNED>
 __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict__ W, float* __restrict__ Mo,
                                                                float* __restrict__ Vo, int D,
@@ -162,9 +201,9 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
                                                                const uint32_t* __restrict__ perm, int64_t n,
                                                                const float* __restrict__ G, int64_t neg_start,
                                                                int64_t reg_limit, const float* __restrict__ reg_coef,
-                                                               float lr, float b1, float b2, float eps, float wd,
-                                                               float step_size, float bc2_sqrt,
-                                                               const int64_t* __restrict__ occ_ids) {
+                                                               apply_hp hp, const int64_t* __restrict__ occ_ids,
+                                                               unsigned* __restrict__ counters, seg_long* __restrict__ longs,
+                                                               seg_piece* __restrict__ pieces) {
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
@@ -172,43 +211,133 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
     const int D4 = D >> 2;
     const float c = reg_coef ? reg_coef[0] : 0.f;
     for (int64_t q = gg; q < n; q += TG) {
+        // three independent probes, issued together (prefetching them one iteration ahead was measured slower: the copies
+        // of the prefetched registers at the loop's back edge wait for this iteration's row stores)
         const uint32_t row = keys[q];
-        if (q > 0 && keys[q - 1] == row) continue;          // not a segment head (uniform inside the group)
+        const uint32_t before = keys[q > 0 ? q - 1 : 0];
+        const uint32_t far = keys[q + kLongSeg < n ? q + kLongSeg : n - 1];
+        const bool head = !(q > 0 && before == row);         // uniform inside the lane group
+        const bool is_long = q + kLongSeg < n && far == row;  // registered below, summed by the piece kernels
+        if (head && !is_long) {
+            for (int ch = sub; ch < D4; ch += LPR) {
+                float* wp = W + (int64_t)row * D + 4 * ch;
+                const float4 w = ld4(wp);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int cnt = 0;
+                for (int64_t e = q; e < n && keys[e] == row; ++e) {
+                    const int64_t o = perm[e];
+                    const bool neg = SIGNED && o >= neg_start;
+                    const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
+                    if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
+                    else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
+                    cnt += occ_ids ? (int)((occ_ids[o] >> 62) & 1) : ((o < reg_limit) ? 1 : 0);
+                }
+                apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
+                                  w, acc, c * (float)cnt, hp);
+            }
+        }
+    }
+    // ---- registration of the long segments, one THREAD per sorted position.  Kept out of the loop above on purpose: with
+    // the atomics inside it hipcc put an s_waitcnt vmcnt(0) on the loop's back edge (every iteration then waited for its
+    // own row stores before issuing the next key loads: +25 % on the whole kernel).
+    if (counters == nullptr) return;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q + kLongSeg < n; q += (int64_t)gridDim.x * kBlock) {
+        const uint32_t row = keys[q];
+        const uint32_t before = keys[q > 0 ? q - 1 : 0];
+        const uint32_t far = keys[q + kLongSeg];
+        if ((q > 0 && before == row) || far != row) continue;
+        int64_t lo = q + kLongSeg, hi = n;                   // keys[lo] == row, keys[hi] != row (or hi == n): keys are sorted
+        while (lo + 1 < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] == row) lo = mid; else hi = mid;
+        }
+        const int64_t len = hi - q;
+        const unsigned np = (unsigned)((len + kPiece - 1) / kPiece);
+        const unsigned base = atomicAdd(&counters[0], np);
+        const unsigned li = atomicAdd(&counters[1], 1u);
+        longs[li] = seg_long{q, len, (int64_t)base};
+        for (unsigned k = 0; k < np; ++k) {
+            const int64_t st = q + (int64_t)k * kPiece;
+            pieces[base + k] = seg_piece{st, (hi - st) < kPiece ? (hi - st) : (int64_t)kPiece};
+        }
+    }
+}
+
+// One lane group per piece of a long segment: partial[pi] = signed sum of the piece's gradient rows in occurrence order,
+// pcnt[pi] = its EmbLoss occurrences.  Four row loads in flight per lane; the adds stay in order.
+template <int LPR, bool SIGNED>
+__global__ __launch_bounds__(kBlock) void seg_piece_sum_kernel(int D, const uint32_t* __restrict__ perm,
+                                                               const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
+                                                               const int64_t* __restrict__ occ_ids,
+                                                               const unsigned* __restrict__ counters,
+                                                               const seg_piece* __restrict__ pieces, float* __restrict__ partial,
+                                                               int* __restrict__ pcnt) {
+    constexpr int GPB = kBlock / LPR;
+    constexpr int UN = 4;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const int64_t np = counters[0];
+    for (int64_t pi = gg; pi < np; pi += TG) {
+        const seg_piece pc = pieces[pi];
+        for (int ch = sub; ch < D4; ch += LPR) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cnt = 0;
+            for (int64_t e0 = 0; e0 < pc.len; e0 += UN) {
+                int64_t o[UN]; float4 g[UN]; bool neg[UN];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) o[j] = (e0 + j < pc.len) ? (int64_t)perm[pc.start + e0 + j] : -1;
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    neg[j] = SIGNED && o[j] >= neg_start;
+                    g[j] = o[j] >= 0 ? ld4(G + (neg[j] ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    if (o[j] < 0) continue;
+                    if (neg[j]) { acc.x -= g[j].x; acc.y -= g[j].y; acc.z -= g[j].z; acc.w -= g[j].w; }
+                    else { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; }
+                    cnt += occ_ids ? (int)((occ_ids[o[j]] >> 62) & 1) : ((o[j] < reg_limit) ? 1 : 0);
+                }
+            }
+            st4(partial + pi * D + 4 * ch, acc);
+            if (ch == 0) pcnt[pi] = cnt;
+        }
+    }
+}
+
+// One lane group per long segment: piece sums added in piece order, then the same update as the head-only path.
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                                 int D, const uint32_t* __restrict__ keys,
+                                                                 const float* __restrict__ reg_coef, apply_hp hp,
+                                                                 const unsigned* __restrict__ counters,
+                                                                 const seg_long* __restrict__ longs,
+                                                                 const float* __restrict__ partial, const int* __restrict__ pcnt) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float c = reg_coef ? reg_coef[0] : 0.f;
+    const int64_t nl = counters[1];
+    for (int64_t li = gg; li < nl; li += TG) {
+        const seg_long sg = longs[li];
+        const uint32_t row = keys[sg.head];
+        const int64_t np = (sg.len + kPiece - 1) / kPiece;
         for (int ch = sub; ch < D4; ch += LPR) {
             float* wp = W + (int64_t)row * D + 4 * ch;
             const float4 w = ld4(wp);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int cnt = 0;
-            for (int64_t e = q; e < n && keys[e] == row; ++e) {
-                const int64_t o = perm[e];
-                const bool neg = SIGNED && o >= neg_start;
-                const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
-                if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
-                else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
-                cnt += occ_ids ? (int)((occ_ids[o] >> 62) & 1) : ((o < reg_limit) ? 1 : 0);
+            for (int64_t k = 0; k < np; ++k) {
+                const float4 g = ld4(partial + (sg.base + k) * D + 4 * ch);
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+                cnt += pcnt[sg.base + k];
             }
-            const float rc = c * (float)cnt;
-            float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
-            float4 wn;
-            if (OPT == 0) {
-                if (wd != 0.f) { gr.x += wd * w.x; gr.y += wd * w.y; gr.z += wd * w.z; gr.w += wd * w.w; }
-                wn = make_float4(w.x - lr * gr.x, w.y - lr * gr.y, w.z - lr * gr.z, w.w - lr * gr.w);
-            } else {
-                float* mp = Mo + (int64_t)row * D + 4 * ch;
-                float* vp = Vo + (int64_t)row * D + 4 * ch;
-                float4 m = ld4(mp), v = ld4(vp);
-                if (wd != 0.f) { gr.x += wd * w.x; gr.y += wd * w.y; gr.z += wd * w.z; gr.w += wd * w.w; }
-                m.x += (gr.x - m.x) * (1.0f - b1); m.y += (gr.y - m.y) * (1.0f - b1);
-                m.z += (gr.z - m.z) * (1.0f - b1); m.w += (gr.w - m.w) * (1.0f - b1);
-                v.x = b2 * v.x + (1.0f - b2) * gr.x * gr.x; v.y = b2 * v.y + (1.0f - b2) * gr.y * gr.y;
-                v.z = b2 * v.z + (1.0f - b2) * gr.z * gr.z; v.w = b2 * v.w + (1.0f - b2) * gr.w * gr.w;
-                st4(mp, m); st4(vp, v);
-                wn = make_float4(w.x - step_size * (m.x / (sqrtf(v.x) / bc2_sqrt + eps)),
-                                 w.y - step_size * (m.y / (sqrtf(v.y) / bc2_sqrt + eps)),
-                                 w.z - step_size * (m.z / (sqrtf(v.z) / bc2_sqrt + eps)),
-                                 w.w - step_size * (m.w / (sqrtf(v.w) / bc2_sqrt + eps)));
-            }
-            st4(wp, wn);
+            apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
+                              w, acc, c * (float)cnt, hp);
         }
     }
 }
@@ -316,13 +445,43 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_for(n, kBlock / lpr);
     const bool is_signed = neg_start < n;
+    const apply_hp hp{lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt};
+    // long-segment scratch: counters | seg_long[long_cap] | seg_piece[piece_cap] | int pcnt[piece_cap] | float partial[piece_cap][D]
+    const bool may_have_long = n > kLongSeg;
+    unsigned* counters = nullptr; seg_long* longs = nullptr; seg_piece* pieces = nullptr; int* pcnt = nullptr; float* partial = nullptr;
+    int64_t long_cap = 0, piece_cap = 0;
+    if (may_have_long) {
+        CDR_CHECK_ARG(ctx != nullptr);
+        long_cap = n / (kLongSeg + 1) + 1;
+        piece_cap = n / kPiece + long_cap + 1;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_long = 256, o_piece = o_long + up(sizeof(seg_long) * long_cap), o_cnt = o_piece + up(sizeof(seg_piece) * piece_cap),
+                     o_part = o_cnt + up(sizeof(int) * piece_cap), total = o_part + sizeof(float) * (size_t)piece_cap * D;
+        void* base = nullptr;
+        int rc = cdr_ctx_scratch(ctx, total, &base);
+        if (rc != CDR_OK) return rc;
+        counters = (unsigned*)base; longs = (seg_long*)((char*)base + o_long); pieces = (seg_piece*)((char*)base + o_piece);
+        pcnt = (int*)((char*)base + o_cnt); partial = (float*)((char*)base + o_part);
+        CDR_HIP(hipMemsetAsync(counters, 0, 16, s));
+    }
     cdr_time_scope ts(ctx, is_signed ? CDR_TAG_APPLY_SIGNED : CDR_TAG_APPLY_UNSIGNED, s);
-#define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, occ_ids
+#define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, hp, occ_ids, counters, longs, pieces
     if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
 #undef APPLY_ARGS
     CDR_LAUNCH_CHECK();
+    if (may_have_long) {
+        // sized for the worst case, but a launch whose counters read 0 retires in a few microseconds
+        const int gp = grid_for(piece_cap < 16384 ? piece_cap : 16384, kBlock / lpr);
+        if (is_signed) { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, true><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, occ_ids, counters, pieces, partial, pcnt)); }
+        else { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, false><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, occ_ids, counters, pieces, partial, pcnt)); }
+        CDR_LAUNCH_CHECK();
+        const int gl = grid_for(long_cap < 4096 ? long_cap : 4096, kBlock / lpr);
+        if (opt == 0) { DISPATCH_LPR(lpr, seg_long_finish_kernel<L, 0><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, D, keys_sorted, reg_coef, hp, counters, longs, partial, pcnt)); }
+        else { DISPATCH_LPR(lpr, seg_long_finish_kernel<L, 1><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, D, keys_sorted, reg_coef, hp, counters, longs, partial, pcnt)); }
+        CDR_LAUNCH_CHECK();
+    }
     return CDR_OK;
 }

@@ -36,7 +36,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the stream that ran the warm-up: the native contexts are per (device, stream) and creating one
+        # allocates, which is not allowed while a stream is capturing
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._eager(self.static)
 
     def step(self, interaction):

@@ -1042,3 +1042,34 @@ def test_sharded_map_step_and_fullsort_ranks_share_one_gpu():
     # the user rows each rank gathered are rows of the trained target table
     ids = torch.arange(5, 8) * 7 % nu
     assert_close(torch.from_numpy(res[0][6][(ni, 3)][0]).to(DEV), TUd[ids.to(DEV)], rtol=2e-5, atol=0.01 * 2e-2)
+
+
+@pytest.mark.parametrize('opt', ['sgd', 'adam'])
+def test_fused_step_long_segments(opt):
+    """Skewed ids (SURVEY 8d synthetic inputs (ii)): one item takes 40 % of the positives, a few more take hundreds, one
+    user takes thousands -> segments far beyond the head-only limit go through the piece-sum / finish kernels.  Same
+    loss and rows as the oracle's row-wise step; bit-equal on a rerun."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import FusedBPRStep
+    torch.manual_seed(5)
+    nu, ni, D, B, lr, reg = 3000, 2000, 64, 20000, 0.01, 0.02
+    U, I = torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1
+    u = torch.randint(0, nu, (B,)); p = torch.randint(0, ni, (B,)); n = torch.randint(0, ni, (B,))
+    p[: int(0.4 * B)] = 7                                  # 8,000 occurrences of one positive
+    p[int(0.4 * B): int(0.4 * B) + 300] = 11               # 300 (two pieces)
+    p[int(0.5 * B): int(0.5 * B) + 33] = 13                # 33 (just over the head-only limit)
+    n[100:1500] = 7                                        # the hot item also as a negative: signed sums inside pieces
+    u[5000:9000] = 42
+    perm = torch.randperm(B); u, p, n = u[perm], p[perm], n[perm]
+    outs = []
+    for rep in range(2):
+        Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+        fs = FusedBPRStep(Ud, Id, B, opt=opt, lr=lr, reg_weight=reg)
+        loss = fs.step(u.to(DEV), p.to(DEV), n.to(DEV))[0].clone()
+        outs.append((loss, Ud, Id))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
+    Uo, Io = U.clone(), I.clone()
+    want = ts.rowwise_step(Uo, Io, ts.RowwiseAdamState(Uo), ts.RowwiseAdamState(Io), u, p, n, 1, opt=opt, lr=lr, reg_weight=reg)
+    assert_close(outs[0][0], want, what='loss')
+    atol = lr * 1e-2 if opt == 'adam' else 1e-6
+    assert_close(outs[0][1], Uo, rtol=2e-5, atol=atol, what='users'); assert_close(outs[0][2], Io, rtol=2e-5, atol=atol, what='items')
