@@ -19,7 +19,7 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
     res[counter] = {k: {'mean': v[0] / max(v[1], 1), 'dispatches': v[1]} for k, v in acc.items()}
 summary = {}
 for k in set(res['FETCH_SIZE']) | set(res['WRITE_SIZE']):
-    short = k.split('(')[0][-80:]
+    short = k.replace('(anonymous namespace)::', '').replace('void ', '', 1).split('(')[0][-80:]
     f = res['FETCH_SIZE'].get(k, {}).get('mean', 0.0)
     w = res['WRITE_SIZE'].get(k, {}).get('mean', 0.0)
     summary[short] = {'FETCH_SIZE_mean': f, 'WRITE_SIZE_mean': w, 'fetch_bytes': f * 1024, 'fetch_bytes_x2': 2 * f * 1024,
