@@ -113,6 +113,49 @@ class EMCDR(CrossDomainRecommender):
         else:
             return self.calculate_target_loss(interaction)
 
+    # ---- O(batch) training step (large tables) ------------------------------------------------------------------
+    def fused_train_step(self, interaction, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """``calculate_loss -> backward -> optimizer.step`` of the current phase without table-sized gradients or a dense
+        optimizer sweep (fused.FusedBPRStep / fused.FusedMapStep on this model's own tables): what
+        ``CrossDomainTrainer`` runs when ``config['optimizer_mode'] == 'rowwise'``.  Same loss and per-row gradients as
+        ``calculate_loss``; the embedding tables take the row-wise (lazy) Adam, the mapping function the exact dense one.
+        One optimizer state per table, shared by the phases.  BPR latent factor model only."""
+        from ...fused import FusedBPRStep, FusedMapStep, RowwiseState, OPT_ADAM, OPT_SGD
+        if self.latent_factor_model != 'BPR':
+            raise NotImplementedError('fused_train_step covers the pairwise (BPR) EMCDR; use the dense step for MF')
+        code = OPT_ADAM if opt == 'adam' else OPT_SGD
+        cache = self.__dict__.setdefault('_fused', {'states': {}, 'steps': {}})
+
+        def state(name):
+            if name not in cache['states']:
+                cache['states'][name] = RowwiseState(getattr(self, name).weight.data, code)
+            return cache['states'][name]
+
+        hp = dict(opt=opt, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        if self.phase == 'OVERLAP':
+            kind = 'user' if self.mode == 'overlap_users' else 'item'
+            idx = interaction[self.OVERLAP_ID]
+            key = ('map', kind)
+            if key not in cache['steps']:
+                cache['steps'][key] = FusedMapStep(
+                    getattr(self, f'source_{kind}_embedding').weight.data, getattr(self, f'target_{kind}_embedding').weight.data,
+                    self.apply_mapping, list(self.mapping.parameters()), idx.numel(),
+                    source_state=state(f'source_{kind}_embedding'), target_state=state(f'target_{kind}_embedding'), **hp)
+            return cache['steps'][key].step(idx)
+        domain = 'source' if self.phase == 'SOURCE' else 'target'
+        user = interaction[getattr(self, f'{domain.upper()}_USER_ID')].reshape(-1)
+        item = interaction[getattr(self, f'{domain.upper()}_ITEM_ID')].reshape(-1)
+        neg = interaction[getattr(self, f'{domain.upper()}_NEG_ITEM_ID')].reshape(-1)
+        key = ('bpr', domain)
+        step = cache['steps'].get(key)
+        if step is None or step.max_batch < user.numel():
+            step = FusedBPRStep(getattr(self, f'{domain}_user_embedding').weight.data,
+                                getattr(self, f'{domain}_item_embedding').weight.data, user.numel(), gamma=self.bpr_gamma,
+                                reg_weight=self.reg_weight, user_state=state(f'{domain}_user_embedding'),
+                                item_state=state(f'{domain}_item_embedding'), **hp)
+            cache['steps'][key] = step
+        return step.step(user, item, neg)[0]
+
     # ---- scoring ------------------------------------------------------------------------------------------------
     def _mapped_rows(self, kind, ids, n_overlap):
         """where(id < n_overlap, mapping(source[id]), target[id]); the mapping is evaluated for all rows (Q5)."""

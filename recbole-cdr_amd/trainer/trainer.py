@@ -68,12 +68,23 @@ class Trainer:
         self.best_valid_result = None
         self.train_loss_dict = dict()
         self.optimizer = DenseAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        # 'dense'   : the reference's literal loop -- autograd into table-sized gradients + Adam over every parameter
+        # 'rowwise' : the model's O(batch) fused step (tables too large for dense gradients, e.g. BASELINE config C5)
+        self.optimizer_mode = config['optimizer_mode'] if 'optimizer_mode' in config else 'dense'
+        if self.optimizer_mode not in ('dense', 'rowwise'):
+            raise ValueError(f"optimizer_mode must be 'dense' or 'rowwise', got {self.optimizer_mode!r}")
+        if self.optimizer_mode == 'rowwise' and not hasattr(self.model, 'fused_train_step'):
+            raise NotImplementedError(f'{type(self.model).__name__} has no fused_train_step; use optimizer_mode=dense')
 
     def _train_epoch(self, train_data, epoch_idx):
         self.model.train()
         total = None                              # accumulated on device: no per-step host sync
         for interaction in train_data:
             interaction = interaction.to(self.device)
+            if self.optimizer_mode == 'rowwise':
+                loss = self.model.fused_train_step(interaction, lr=self.learning_rate, weight_decay=self.weight_decay)
+                total = loss.detach().clone() if total is None else total + loss.detach()
+                continue
             self.optimizer.zero_grad()
             losses = self.model.calculate_loss(interaction)
             loss = sum(losses) if isinstance(losses, tuple) else losses

@@ -454,12 +454,86 @@ def test_trainer_phase_loop_matches_oracle_training():
                 loss = oem.calculate_loss(params, ids, b, phase, 'BPR', 0.01)
                 loss.sum().backward()
                 opt.step()
-                tot += float(loss.sum())
+                tot += float(loss.detach().sum())
             ref_log.append(tot)
     assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=2e-5, what='epoch losses')
     for k, v in model.named_parameters():
         # a few Adam steps from zero state are ~ lr * sign(g): compare with an absolute bound of 2% of one step
         assert_close(v, params[k], rtol=1e-4, atol=0.01 * 2e-2, what=k)
+
+
+def test_trainer_rowwise_mode_matches_oracle_rowwise_training():
+    """CrossDomainTrainer with optimizer_mode='rowwise' (EMCDR.fused_train_step: FusedBPRStep / FusedMapStep on the model's
+    own tables, one optimizer state per table across phases) over SOURCE -> TARGET -> OVERLAP against the oracle's
+    row-wise steps on the same batches: per-epoch loss sums and every parameter."""
+    from oracle import train_step as ts
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+    from recbole_cdr_amd.utils import InputType, train_mode2state
+    torch.manual_seed(12)
+    ids = IdSpace(OU=20, TOU=15, SOU=18, OI=1, TOI=30, SOI=34)
+    D, lr, reg = 16, 0.01, 0.01
+    cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=D, target_embedding_size=D, reg_weight=reg,
+                      mapping_function='non_linear', mlp_hidden_size=[24], learning_rate=lr, optimizer_mode='rowwise',
+                      train_modes=['SOURCE', 'TARGET', 'OVERLAP'], epoch_num=['2', '1', '2'], source_split=False,
+                      eval_step=1, epochs=2)
+    model = EMCDR(cfg, FakeDataset(ids)).to(DEV)
+    params = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+    rng = np.random.RandomState(0)
+    src_u = np.array(list(range(1, ids.OU)) + list(range(ids.OU + ids.TOU, ids.total_num_users)))
+    src_i = np.arange(ids.OI + ids.TOI, ids.total_num_items)
+    tgt_u, tgt_i = np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI)
+    s_inter = {'source_user_id': torch.from_numpy(rng.choice(src_u, 96)), 'source_item_id': torch.from_numpy(rng.choice(src_i, 96))}
+    t_inter = {'target_user_id': torch.from_numpy(rng.choice(tgt_u, 80)), 'target_item_id': torch.from_numpy(rng.choice(tgt_i, 80))}
+    neg_rng = {'s': np.random.RandomState(1), 't': np.random.RandomState(2)}
+    s_sampler = lambda u, i, k: torch.from_numpy(neg_rng['s'].choice(src_i, u.numel() * k)).to(u.device)
+    t_sampler = lambda u, i, k: torch.from_numpy(neg_rng['t'].choice(tgt_i, u.numel() * k)).to(u.device)
+    mk = lambda: CrossDomainDataloader(
+        DomainTrainLoader(s_inter, 'source_user_id', 'source_item_id', 'source_label', 'neg_', 32, 1, InputType.PAIRWISE, s_sampler),
+        DomainTrainLoader(t_inter, 'target_user_id', 'target_item_id', 'target_label', 'neg_', 32, 1, InputType.PAIRWISE, t_sampler),
+        OverlapDataloader(ids.OU, 8))
+    trainer = CrossDomainTrainer(cfg, model)
+    log = []
+    orig = trainer._train_epoch
+    trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
+    trainer.fit(mk())
+    assert model.phase == 'OVERLAP' and len(log) == 5
+    assert all(p.grad is None for n, p in model.named_parameters() if 'embedding' in n)       # nothing table-sized was built
+    # oracle: same batches, row-wise steps, one state + update count per table across phases
+    neg_rng['s'], neg_rng['t'] = np.random.RandomState(1), np.random.RandomState(2)
+    tabs = {k: params[f'{k}.weight'] for k in ('source_user_embedding', 'source_item_embedding', 'target_user_embedding',
+                                               'target_item_embedding')}
+    st = {k: ts.RowwiseAdamState(v) for k, v in tabs.items()}
+    cnt = {k: 0 for k in tabs}
+    mp = {k: v.requires_grad_(True) for k, v in params.items() if k.startswith('mapping.')}
+    mopt = torch.optim.Adam(list(mp.values()), lr=lr)
+    dl = mk()
+    ref_log = []
+    for phase, epochs in (('SOURCE', 2), ('TARGET', 1), ('OVERLAP', 2)):
+        dl.set_mode(train_mode2state[phase])
+        for _ in range(epochs):
+            tot = 0.0
+            for b in dl:
+                if phase == 'OVERLAP':
+                    cnt['source_user_embedding'] += 1; cnt['target_user_embedding'] += 1
+                    loss = ts.rowwise_map_step(mp, tabs['source_user_embedding'], tabs['target_user_embedding'],
+                                               st['source_user_embedding'], st['target_user_embedding'], b['overlap'],
+                                               cnt['source_user_embedding'], cnt['target_user_embedding'], mopt, lr=lr)
+                else:
+                    d = phase.lower()
+                    # rowwise_step takes one count for both tables: they advance together inside a domain phase
+                    cnt[f'{d}_user_embedding'] += 1; cnt[f'{d}_item_embedding'] += 1
+                    assert cnt[f'{d}_user_embedding'] == cnt[f'{d}_item_embedding']
+                    loss = ts.rowwise_step(tabs[f'{d}_user_embedding'], tabs[f'{d}_item_embedding'], st[f'{d}_user_embedding'],
+                                           st[f'{d}_item_embedding'], b[f'{d}_user_id'], b[f'{d}_item_id'],
+                                           b[f'neg_{d}_item_id'], cnt[f'{d}_user_embedding'], lr=lr, reg_weight=reg)
+                tot += float(loss.sum())
+            ref_log.append(tot)
+    assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=5e-5, what='epoch losses')
+    for k, v in model.named_parameters():
+        assert_close(v, params[k].detach(), rtol=1e-4, atol=lr * 5e-2, what=k)
 
 
 @pytest.mark.parametrize('name', cases('conet_'))
