@@ -133,6 +133,18 @@ int cdr_fullsort_scores_f32(void* stream, const float* user_e, int64_t U, int D,
                             const float* slab0, int64_t n0, const float* slab1, int64_t n1,
                             float* scores /* [U, n0+n1] */);
 
+/* Mask + top-k fused after the scoring contraction (recbole Trainer._full_sort_batch_eval: scores[:,0] =
+ * -inf, scores[history_index] = -inf, then Collector's torch.topk): for every user the k largest scores over the columns
+ * [0, n0+n1) of cdr_fullsort_scores_f32's matrix, WITHOUT materialising it when U > 32 and D is 64 or 128 (the score tile
+ * stays in LDS; only k entries per user and item stripe reach HBM).  hist_indptr [U+1] / hist_cols: the columns to skip
+ * per user (ascending inside each user's range), or both NULL.  out_vals descending; out_idx = column index, -1 (with
+ * -inf) when fewer than k columns are left.  Ties between equal scores resolve to the one met first.  k <= 64.          */
+int cdr_fullsort_topk_workspace_bytes(int64_t U, int D, int64_t n0, int64_t n1, int k, size_t* bytes);
+int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t U, int D,
+                          const float* slab0, int64_t n0, const float* slab1, int64_t n1, int k,
+                          const int64_t* hist_indptr, const int64_t* hist_cols, int exclude_first_col,
+                          float* out_vals /* [U,k] */, int64_t* out_idx /* [U,k] */, void* workspace, size_t workspace_bytes);
+
 /* SSCDR scoring (sscdr.py:253-259): scores = -(((-2 <u,i>) + |u|^2) + |i|^2) on already-normalised rows.
  * norm_scratch: caller-owned [U + N] floats (row norms are recomputed into it).                               */
 int cdr_fullsort_neg_sqdist_f32(void* stream, const float* user_e, int64_t U, int D,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -106,6 +106,9 @@ _SIGNATURES = {
     'cdr_route_by_owner': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_permute_i64': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_inverse_perm': [_c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_fullsort_topk_workspace_bytes': [_c_i64, _c_int, _c_i64, _c_i64, _c_int, _c_ptr],
+    'cdr_fullsort_topk_f32': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr,
+                              _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_interleave_shards': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_gather_owned_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_adam_dense_dev': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr],

@@ -291,6 +291,53 @@ static int gemv_dispatch(hipStream_t s, const float* users, int U, int D, const 
     }
 }
 
+// ---- running top-k of one user, kept by a whole wave (mask + top-k fused after scoring) -------------------
+// Lane j holds entry j of the list (values descending; k <= 64).  A wave "offers" 64 candidate scores at once: a ballot
+// against the current k-th value rejects almost all of them after the first few tiles (expected survivors per user over
+// N items: k ln(N/k)), the survivors are inserted one at a time with a shuffle (no LDS, no sort).  Masked columns -- the
+// PAD item and the user's history, given as a CSR with ascending columns (the reference sets those scores to -inf before
+// torch.topk: recbole Trainer._full_sort_batch_eval) -- are tested only for survivors.
+struct topk_mask {
+    const int64_t* indptr;      // [U + 1] or nullptr
+    const int64_t* cols;        // ascending inside each user's range
+    int exclude_col0;
+};
+
+__device__ __forceinline__ bool topk_masked(const topk_mask& mk, int64_t u, int col) {
+    if (mk.exclude_col0 && col == 0) return true;
+    if (!mk.indptr) return false;
+    int64_t lo = mk.indptr[u], hi = mk.indptr[u + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t c = mk.cols[mid];
+        if (c == col) return true;
+        if (c < col) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// e / ec: this lane's list entry (lanes >= k carry -inf / -1 and never change).  Returns the new k-th value.
+__device__ __forceinline__ float topk_offer(float v, int col, float thr, float& e, int& ec, int k, const topk_mask& mk, int64_t u) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long m = __ballot(v > thr);
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float cv = __shfl(v, l);
+        const int cc = __shfl(col, l);
+        if (!(cv > thr) || topk_masked(mk, u, cc)) continue;                  // wave-uniform
+        const int pos = __popcll(__ballot(lane < k && e >= cv));                // entries that stay in front (ties: first seen)
+        const float up = __shfl_up(e, 1);
+        const int upc = __shfl_up(ec, 1);
+        if (lane < k) {
+            if (lane == pos) { e = cv; ec = cc; }
+            else if (lane > pos) { e = up; ec = upc; }
+        }
+        thr = __shfl(e, k - 1);
+    }
+    return thr;
+}
+
 // ---- many-users scoring (U >= 64, D <= 128): persistent fp32-MFMA kernel ----------------------------------------------
 // One 256-thread workgroup per CU, resident for the whole call.  Waves are 2 (M) x 2 (N); each wave keeps its users'
 // A fragments for the WHOLE contraction (D <= 128) in registers -- 32*MT rows x D, loaded once -- so the only LDS traffic
@@ -299,10 +346,51 @@ static int gemv_dispatch(hipStream_t s, const float* users, int U, int D, const 
 // XCD-aware: workgroup b runs on XCD b % 8 (observed placement; speed only), and the workgroups of one XCD that share
 // an item stripe walk it together for different user blocks, so an item tile is fetched from HBM once and re-used
 // from that XCD's L2 by the other user blocks instead of being re-read U/BM times.
-template <int MT, int K>
+constexpr int kTopkQueue = 256;
+
+struct topk_out {
+    int k;
+    int col_off;                // column index of this slab's first item
+    float* pv;                  // partial lists [producer][M][k]
+    int* pc;
+    topk_mask mk;
+};
+
+// Mask test for the queued candidates, one per lane (64 binary searches in flight), then the survivors enter their
+// user's list one at a time (LDS only).  Thresholds may have risen since a candidate was queued: re-tested on insert.
+__device__ __forceinline__ void topk_flush(volatile float* qv, volatile int* qc, volatile int* qu, int qn, volatile float* thr_l,
+                                           volatile float* lv, volatile int* lc, const topk_out& tk, int64_t u0) {
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < qn; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < qn;
+        const float v = valid ? qv[i] : -INFINITY;
+        const int c = valid ? qc[i] : 0;
+        const int ul = valid ? qu[i] : 0;
+        const bool ok = valid && v > thr_l[ul] && !topk_masked(tk.mk, u0 + ul, c);
+        unsigned long long m = __ballot(ok);
+        const topk_mask none{nullptr, nullptr, 0};
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float cv = __shfl(v, l);
+            const int cc = __shfl(c, l);
+            const int cu = __shfl(ul, l);
+            const float thr = thr_l[cu];
+            if (!(cv > thr)) continue;
+            float e = lane < tk.k ? lv[cu * tk.k + lane] : -INFINITY;
+            int ec = lane < tk.k ? lc[cu * tk.k + lane] : -1;
+            const float nthr = topk_offer(lane == 0 ? cv : -INFINITY, cc, thr, e, ec, tk.k, none, 0);
+            if (lane < tk.k) { lv[cu * tk.k + lane] = e; lc[cu * tk.k + lane] = ec; }
+            if (lane == 0) thr_l[cu] = nthr;
+        }
+    }
+}
+
+template <int MT, int K, bool TOPK>
 __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* __restrict__ A, int M,
                                                                   const float* __restrict__ B, int NT,
-                                                                  float* __restrict__ C, int64_t ldc) {
+                                                                  float* __restrict__ C, int64_t ldc, topk_out tk) {
     constexpr int BM = 64 * MT;            // 2 waves along M, MT 32-row tiles each
     constexpr int BN = 64;                 // 2 waves along N, one 32-col tile each
     constexpr int KS = K / 8;              // K steps of 8 (one float4 per lane per step feeds 4 MFMAs)
@@ -337,9 +425,25 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         st_gl[q] = (int64_t)r * K + 4 * c;
     }
     const int frag_off = (wn * 32 + li) * LDB + 4 * lh;
+    // TOPK: LDS behind the two item buffers = score tile [BM][65] | k-th values [BM] | list values [BM][k] | list columns
+    constexpr int SCS = 65;
+    float* sc = smem + 2 * BUF;
+    volatile float* thr_l = sc + BM * SCS;
+    volatile float* lv = thr_l + BM;
+    volatile int* lc = reinterpret_cast<volatile int*>(lv + BM * (TOPK ? tk.k : 0));
+    constexpr int RPW = BM / 4;            // user rows each wave scans
+    constexpr int QC = kTopkQueue;         // per-wave queue of candidates waiting for the mask test
+    volatile float* qv = reinterpret_cast<volatile float*>(lc + BM * (TOPK ? tk.k : 0)) + wave * QC * 3;
+    volatile int* qc = reinterpret_cast<volatile int*>(qv + QC);
+    volatile int* qu = qc + QC;
+    int qn = 0;                            // wave-uniform
 
     for (int mb = mslot; mb < MB; mb += MBc) {
         const int m0 = mb * BM + wm * 32 * MT;
+        if (TOPK) {
+            for (int i = tid; i < BM; i += 256) thr_l[i] = -INFINITY;
+            for (int i = tid; i < BM * tk.k; i += 256) { lv[i] = -INFINITY; lc[i] = -1; }
+        }
         // this wave's user rows, whole K, in registers (loaded once per user block)
         float4 a[MT][KS];
 #pragma unroll
@@ -399,18 +503,127 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                 for (int q = 0; q < NQ; ++q) st4(dst + st_lds[q], stage[q]);
             }
             // epilogue: lane column = item ; register r -> user row (r&3) + 8*(r>>2) + 4*lh
-            float* cp = C + (int64_t)tile * BN + wn * 32 + li;
+            if (!TOPK) {
+                float* cp = C + (int64_t)tile * BN + wn * 32 + li;
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
+                for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < M) cp[(int64_t)m * ldc] = acc[t][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (m < M) cp[(int64_t)m * ldc] = acc[t][r];
+                    }
+                __syncthreads();
+            } else {
+                // the [BM, 64] score tile goes to LDS instead of HBM; every wave then offers its rows' 64 scores to the
+                // rows' running top-k lists (nothing but the final k per user and stripe ever leaves the CU)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sc[(wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * SCS + wn * 32 + li] = acc[t][r];
+                __syncthreads();
+                // Survivors of the k-th-value test are only QUEUED (wave-private, LDS): the history test is a chain of
+                // dependent global loads (~5 us), so it runs for up to 64 queued candidates at once, one per lane, when
+                // the queue is half full -- not once per survivor on the tile's critical path (measured: 2x the kernel).
+                const int col = tk.col_off + tile * BN + lane;
+                // all of this wave's rows first (independent LDS reads), then the tests: a read -> test -> branch chain per
+                // row is latency-bound and cost as much as the MFMA phase itself
+                float vr[RPW];
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) vr[rr] = sc[(wave * RPW + rr) * SCS + lane];
+                const float tl = thr_l[wave * RPW + (lane % RPW)];          // k-th values of the wave's rows, one per lane
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int ul = wave * RPW + rr;
+                    const float thr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tl), rr));
+                    const bool pass = vr[rr] > thr && (int64_t)mb * BM + ul < M;
+                    const unsigned long long m = __ballot(pass);
+                    if (m == 0) continue;
+                    if (pass) {
+                        const int at = qn + __popcll(m & ((1ull << lane) - 1));
+                        qv[at] = vr[rr]; qc[at] = col; qu[at] = ul;
+                    }
+                    qn += __popcll(m);
+                    if (qn > QC - 64) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
                 }
-            __syncthreads();
+                if (qn >= QC / 2) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+                __syncthreads();                   // the next tile's scores overwrite sc
+            }
             buf ^= 1;
         }
+        if (TOPK && qn) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
         __syncthreads();
+        if (TOPK) {
+            // this stripe's candidates for its user block: partial list [stripe][user][k]
+            for (int i = tid; i < BM * tk.k; i += 256) {
+                const int64_t ug = (int64_t)mb * BM + i / tk.k;
+                if (ug < M) {
+                    const int64_t o = ((int64_t)stripe * M + ug) * tk.k + i % tk.k;
+                    tk.pv[o] = lv[i];
+                    tk.pc[o] = lc[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Scores already in memory ([U, n] with leading dimension ld): one wave per (user, chunk of columns), list in registers.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, int64_t ld, int64_t U, int64_t n,
+                                                        int64_t chunk, int col_off, int k, topk_mask mk,
+                                                        float* __restrict__ pv, int* __restrict__ pc, int64_t prod0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= U * n_chunks) return;
+    const int64_t u = w / n_chunks, ch = w % n_chunks;
+    const int64_t c0 = ch * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+    float e = -INFINITY, thr = -INFINITY;
+    int ec = -1;
+    const float* row = scores + u * ld;
+    for (int64_t c = c0; c < c1; c += 64 * 8) {                     // 8 independent loads in flight, offered in column order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t cc = c + 64 * j + lane;
+            v[j] = cc < c1 ? row[cc] : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) thr = topk_offer(v[j], col_off + (int)(c + 64 * j + lane), thr, e, ec, k, mk, u);
+    }
+    if (lane < k) {
+        const int64_t o = ((prod0 + ch) * U + u) * k + lane;
+        pv[o] = e;
+        pc[o] = ec;
+    }
+}
+
+// Final lists: one wave per user merges the P partial lists (already masked).
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pc, int64_t P,
+                                                         int64_t U, int k, float* __restrict__ out_v, int64_t* __restrict__ out_c) {
+    const int lane = threadIdx.x & 63;
+    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= U) return;
+    float e = -INFINITY, thr = -INFINITY;
+    int ec = -1;
+    const topk_mask none{nullptr, nullptr, 0};
+    const int64_t total = P * k;                                     // candidate i = entry i % k of producer i / k
+    for (int64_t i0 = 0; i0 < total; i0 += 64 * 8) {
+        float v[8];
+        int c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = i0 + 64 * j + lane;
+            const int64_t o = ((i / k) * U + u) * k + i % k;
+            v[j] = i < total ? pv[o] : -INFINITY;
+            c[j] = i < total ? pc[o] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) thr = topk_offer(v[j], c[j], thr, e, ec, k, none, u);
+    }
+    if (lane < k) {
+        out_v[u * k + lane] = e;
+        out_c[u * k + lane] = ec;
     }
 }
 
@@ -427,12 +640,12 @@ static int launch_score_persistent(hipStream_t s, const float* users, int64_t U,
     const bool small = U <= 64;            // one 32-row tile per wave (BM = 64) instead of two (BM = 128)
     if (D == 64) {
         const size_t lds = 2 * (size_t)64 * (64 + 4) * sizeof(float);
-        if (small) score_persistent_kernel<1, 64><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
-        else score_persistent_kernel<2, 64><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
+        if (small) score_persistent_kernel<1, 64, false><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc, topk_out{});
+        else score_persistent_kernel<2, 64, false><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc, topk_out{});
     } else {
         const size_t lds = 2 * (size_t)64 * (128 + 4) * sizeof(float);
-        if (small) score_persistent_kernel<1, 128><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
-        else score_persistent_kernel<2, 128><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc);
+        if (small) score_persistent_kernel<1, 128, false><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc, topk_out{});
+        else score_persistent_kernel<2, 128, false><<<dim3(grid), dim3(256), lds, s>>>(users, (int)U, items, NT, scores, ldc, topk_out{});
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdr_set_error("score_persistent: launch failed: %s", hipGetErrorString(e)); return (int)e; }
@@ -498,6 +711,152 @@ extern "C" int cdr_fullsort_scores_f32(void* stream, const float* user_e, int64_
              : score_persistent_ok(U, D, n1, user_e, slab1) ? launch_score_persistent(s, user_e, U, D, slab1, n1, scores + off, N)
              : launch<false, true, false>(s, U, n1, D, user_e, D, slab1, D, scores + off, N, nullptr, CDR_ACT_NONE, 0, nullptr, nullptr);
     return rc;
+}
+
+// ---- mask + top-k fused after scoring ---------------------------------------------------------------------
+namespace {
+
+constexpr int64_t kTopkSub = 16384;                 // columns per wave in topk_rows_kernel
+constexpr size_t kTopkScoreBytes = (size_t)256 << 20;   // score staging for the unfused passes
+
+struct topk_plan {
+    bool fused[2];
+    int64_t stripes[2], fused_cols[2];              // fused: producers and the columns they cover (multiple of 64)
+    int64_t pass_cols;                              // unfused: columns scored per pass
+    int64_t producers, score_floats;
+};
+
+static size_t fused_lds_bytes(int D, int MT, int k) {
+    const int BM = 64 * MT;
+    return sizeof(float) * ((size_t)2 * 64 * (D + 4) + (size_t)BM * 65 + BM + (size_t)BM * k * 2 + (size_t)4 * kTopkQueue * 3);
+}
+
+static topk_plan make_topk_plan(int64_t U, int D, const int64_t n[2], int k, const float* users, const float* const slab[2]) {
+    topk_plan p{};
+    int64_t pass = (int64_t)(kTopkScoreBytes / sizeof(float)) / U;
+    pass = pass / kTopkSub * kTopkSub;
+    if (pass < kTopkSub) pass = kTopkSub;
+    p.pass_cols = pass;
+    int64_t max_unfused = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (n[i] <= 0) continue;
+        const int MT = U <= 64 ? 1 : 2;
+        p.fused[i] = U > 32 && (D == 64 || D == 128) && n[i] >= 64 && U < ((int64_t)1 << 30) &&
+                     (slab[i] == nullptr || ((((uintptr_t)users | (uintptr_t)slab[i]) & 15) == 0)) &&
+                     fused_lds_bytes(D, MT, k) <= (size_t)160 * 1024;
+        if (p.fused[i]) {
+            const int BM = 64 * MT;
+            const int64_t MB = (U + BM - 1) / BM, per_xcd = CDR_NUM_CU / 8;
+            const int64_t MBc = MB < per_xcd ? MB : per_xcd;
+            p.stripes[i] = 8 * (per_xcd / MBc);
+            p.fused_cols[i] = n[i] / 64 * 64;
+            p.producers += p.stripes[i];
+            const int64_t tail = n[i] - p.fused_cols[i];
+            if (tail > 0) { p.producers += 1; if (tail > max_unfused) max_unfused = tail; }
+        } else {
+            for (int64_t c = 0; c < n[i]; c += pass) {
+                const int64_t cn = n[i] - c < pass ? n[i] - c : pass;
+                p.producers += (cn + kTopkSub - 1) / kTopkSub;
+                if (cn > max_unfused) max_unfused = cn;
+            }
+        }
+    }
+    p.score_floats = U * max_unfused;
+    return p;
+}
+
+static size_t topk_ws_bytes(const topk_plan& p, int64_t U, int k) {
+    const size_t part = ((size_t)p.producers * U * k * 4 + 255) & ~(size_t)255;
+    return 2 * part + (((size_t)p.score_floats * 4 + 255) & ~(size_t)255);
+}
+
+static int score_block(hipStream_t s, const float* user_e, int64_t U, int D, const float* items, int64_t n, float* scores, int64_t ld) {
+    return gemv_ok(U, D, user_e, items) ? gemv_dispatch(s, user_e, (int)U, D, items, n, scores, ld)
+           : score_persistent_ok(U, D, n, user_e, items) ? launch_score_persistent(s, user_e, U, D, items, n, scores, ld)
+           : launch<false, true, false>(s, U, n, D, user_e, D, items, D, scores, ld, nullptr, CDR_ACT_NONE, 0, nullptr, nullptr);
+}
+
+}  // namespace
+
+extern "C" int cdr_fullsort_topk_workspace_bytes(int64_t U, int D, int64_t n0, int64_t n1, int k, size_t* bytes) {
+    CDR_CHECK_ARG(bytes && U > 0 && D > 0 && k >= 1 && k <= 64 && n0 >= 0 && n1 >= 0 && n0 + n1 > 0);
+    const int64_t n[2] = {n0, n1};
+    const float* const slab[2] = {nullptr, nullptr};
+    *bytes = topk_ws_bytes(make_topk_plan(U, D, n, k, nullptr, slab), U, k);
+    return CDR_OK;
+}
+
+extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t U, int D, const float* slab0, int64_t n0,
+                                     const float* slab1, int64_t n1, int k, const int64_t* hist_indptr,
+                                     const int64_t* hist_cols, int exclude_first_col, float* out_vals, int64_t* out_idx,
+                                     void* workspace, size_t workspace_bytes) {
+    CDR_CHECK_ARG(user_e && out_vals && out_idx && workspace && U > 0 && D > 0 && k >= 1 && k <= 64);
+    CDR_CHECK_ARG((slab0 && n0 > 0) || (slab1 && n1 > 0));
+    CDR_CHECK_ARG((hist_indptr == nullptr) == (hist_cols == nullptr));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n[2] = {slab0 ? n0 : 0, slab1 ? n1 : 0};
+    const float* const slab[2] = {slab0, slab1};
+    CDR_CHECK_ARG(n[0] + n[1] < ((int64_t)1 << 31) && n[0] + n[1] >= k);
+    // the workspace was sized without the pointers (alignment unknown): plan the same way, then demote unaligned slabs
+    const float* const none[2] = {nullptr, nullptr};
+    topk_plan p = make_topk_plan(U, D, n, k, nullptr, none);
+    for (int i = 0; i < 2; ++i)
+        if (p.fused[i] && ((((uintptr_t)user_e | (uintptr_t)slab[i]) & 15) != 0)) {
+            cdr_set_error("cdr_fullsort_topk_f32: operands must be 16-byte aligned");
+            return CDR_EINVAL;
+        }
+    const size_t need = topk_ws_bytes(p, U, k);
+    if (workspace_bytes < need) { cdr_set_error("cdr_fullsort_topk_f32: workspace %zu < %zu bytes", workspace_bytes, need); return CDR_EINVAL; }
+    const size_t part = ((size_t)p.producers * U * k * 4 + 255) & ~(size_t)255;
+    float* pv = (float*)workspace;
+    int* pc = (int*)((char*)workspace + part);
+    float* sbuf = (float*)((char*)workspace + 2 * part);
+    const topk_mask mk{hist_indptr, hist_cols, exclude_first_col};
+    int64_t prod = 0, col_off = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (n[i] <= 0) continue;
+        if (p.fused[i]) {
+            const topk_out tk{k, (int)col_off, pv + prod * U * k, pc + prod * U * k, mk};
+            const int NT = (int)(n[i] / 64);
+            const unsigned grid = CDR_NUM_CU;
+            const bool small = U <= 64;
+            const size_t lds = fused_lds_bytes(D, small ? 1 : 2, k);
+            if (D == 64) {
+                if (small) score_persistent_kernel<1, 64, true><<<dim3(grid), dim3(256), lds, s>>>(user_e, (int)U, slab[i], NT, nullptr, 0, tk);
+                else score_persistent_kernel<2, 64, true><<<dim3(grid), dim3(256), lds, s>>>(user_e, (int)U, slab[i], NT, nullptr, 0, tk);
+            } else {
+                if (small) score_persistent_kernel<1, 128, true><<<dim3(grid), dim3(256), lds, s>>>(user_e, (int)U, slab[i], NT, nullptr, 0, tk);
+                else score_persistent_kernel<2, 128, true><<<dim3(grid), dim3(256), lds, s>>>(user_e, (int)U, slab[i], NT, nullptr, 0, tk);
+            }
+            CDR_LAUNCH_CHECK();
+            prod += p.stripes[i];
+            const int64_t tail = n[i] - p.fused_cols[i];
+            if (tail > 0) {
+                int rc = launch<false, true, false>(s, U, tail, D, user_e, D, slab[i] + p.fused_cols[i] * D, D, sbuf, tail, nullptr,
+                                                    CDR_ACT_NONE, 0, nullptr, nullptr);
+                if (rc) return rc;
+                topk_rows_kernel<<<dim3((unsigned)((U + 3) / 4)), dim3(256), 0, s>>>(sbuf, tail, U, tail, tail, (int)(col_off + p.fused_cols[i]),
+                                                                                    k, mk, pv, pc, prod);
+                CDR_LAUNCH_CHECK();
+                prod += 1;
+            }
+        } else {
+            for (int64_t c = 0; c < n[i]; c += p.pass_cols) {
+                const int64_t cn = n[i] - c < p.pass_cols ? n[i] - c : p.pass_cols;
+                int rc = score_block(s, user_e, U, D, slab[i] + c * D, cn, sbuf, cn);
+                if (rc) return rc;
+                const int64_t chunks = (cn + kTopkSub - 1) / kTopkSub;
+                topk_rows_kernel<<<dim3((unsigned)((U * chunks + 3) / 4)), dim3(256), 0, s>>>(sbuf, cn, U, cn, kTopkSub, (int)(col_off + c), k,
+                                                                                             mk, pv, pc, prod);
+                CDR_LAUNCH_CHECK();
+                prod += chunks;
+            }
+        }
+        col_off += n[i];
+    }
+    topk_merge_kernel<<<dim3((unsigned)((U + 3) / 4)), dim3(256), 0, s>>>(pv, pc, prod, U, k, out_vals, out_idx);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
 }
 
 extern "C" int cdr_fullsort_neg_sqdist_f32(void* stream, const float* user_e, int64_t U, int D, const float* items,

@@ -5,6 +5,8 @@ over ``model.parameters()``, so in drop-in mode the backward kernels write the d
 ``sparse=False`` ``nn.Embedding`` would receive.  The fused row-wise training step that never
 materialises table-sized gradients lives in ``fused.py``.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -226,6 +228,35 @@ def fullsort_scores(user_e, slab0, slab1=None, out=None):
     B_.call('cdr_fullsort_scores_f32', B_.stream(), B_.f32(user_e), U, D,
             B_.f32(slab0.detach()) if n0 else None, n0, B_.f32(slab1.detach()) if n1 else None, n1, B_.f32(out))
     return out
+
+
+_topk_ws = {}
+
+
+def fullsort_topk(user_e, slab0, slab1=None, k=10, hist_indptr=None, hist_cols=None, exclude_first_col=True):
+    """(values [U,k] descending, columns [U,k] int64) of ``fullsort_scores(user_e, slab0, slab1)`` after the evaluation
+    mask -- column 0 (PAD) and, per user, the ascending columns ``hist_cols[hist_indptr[u]:hist_indptr[u+1]]`` -- without
+    materialising the [U, N] matrix when U > 32 and D is 64 or 128 (cdr_fullsort_topk_f32)."""
+    _dev_check(user_e, slab0, slab1, hist_indptr, hist_cols)
+    user_e = user_e.detach().contiguous()
+    U, D = user_e.shape
+    n0 = slab0.shape[0] if slab0 is not None else 0
+    n1 = slab1.shape[0] if slab1 is not None else 0
+    dev = user_e.device
+    need = ctypes.c_size_t(0)
+    B_._check(B_.load().cdr_fullsort_topk_workspace_bytes(U, D, n0, n1, int(k), ctypes.byref(need)),
+              'cdr_fullsort_topk_workspace_bytes')
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _topk_ws.get(key)
+    if ws is None or ws.numel() < need.value:
+        ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+        _topk_ws[key] = ws
+    vals = torch.empty(U, k, device=dev, dtype=torch.float32)
+    idx = torch.empty(U, k, device=dev, dtype=torch.int64)
+    B_.call('cdr_fullsort_topk_f32', B_.stream(), B_.f32(user_e), U, D, B_.f32(slab0.detach()) if n0 else None, n0,
+            B_.f32(slab1.detach()) if n1 else None, n1, int(k), B_.i64(hist_indptr), B_.i64(hist_cols),
+            1 if exclude_first_col else 0, B_.f32(vals), B_.i64(idx), B_.raw(ws), ws.numel())
+    return vals, idx
 
 
 def fullsort_neg_sqdist(user_e, items):

@@ -1147,3 +1147,41 @@ def test_fused_step_long_segments(opt):
     assert_close(outs[0][0], want, what='loss')
     atol = lr * 1e-2 if opt == 'adam' else 1e-6
     assert_close(outs[0][1], Uo, rtol=2e-5, atol=atol, what='users'); assert_close(outs[0][2], Io, rtol=2e-5, atol=atol, what='items')
+
+
+@pytest.mark.parametrize('U,D,N,k', [(1, 128, 20011, 10), (5, 64, 70001, 20), (40, 128, 9000, 10), (70, 64, 33333, 50),
+                                      (200, 128, 40000, 10), (130, 32, 20000, 5), (33, 128, 64, 64)])
+def test_fullsort_topk_matches_topk_of_masked_scores(U, D, N, k):
+    """Fused mask + top-k == torch.topk over the evaluation-masked output of the scoring kernel (the same contraction
+    kernels produce both, so values are bit-equal; columns may differ only between exactly tied scores).  History rows
+    deliberately contain each user's best columns so that the mask decides the result."""
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(U + N)
+    ue = torch.randn(U, D, device=DEV)
+    n0 = N // 3
+    tab = torch.randn(N, D, device=DEV)
+    slab0, slab1 = tab[:n0].contiguous(), tab[n0:].contiguous()
+    full = F_.fullsort_scores(ue, slab0, slab1)
+    best = torch.topk(full, min(7, N - k), dim=1).indices                        # mask away the top 7 of every user ...
+    rnd = torch.randint(0, N, (U, 30), device=DEV)                               # ... and 30 random columns
+    cols = [torch.unique(torch.cat([best[u], rnd[u]])) for u in range(U)]        # ascending, deduplicated
+    if N - k < 40:
+        cols = [c[:0] for c in cols]
+    indptr = torch.zeros(U + 1, dtype=torch.int64, device=DEV)
+    indptr[1:] = torch.cumsum(torch.tensor([c.numel() for c in cols], device=DEV), 0)
+    hist = torch.cat(cols) if cols else torch.empty(0, dtype=torch.int64, device=DEV)
+    masked = full.clone()
+    masked[:, 0] = -float('inf')
+    for u in range(U):
+        masked[u, cols[u]] = -float('inf')
+    kk = min(k, N - 1 - max(c.numel() for c in cols)) if k == 64 else k
+    want_v, want_i = torch.topk(masked, kk, dim=1)
+    got_v, got_i = F_.fullsort_topk(ue, slab0, slab1, k=kk, hist_indptr=indptr, hist_cols=hist if hist.numel() else torch.zeros(1, dtype=torch.int64, device=DEV))
+    assert torch.equal(got_v, want_v), (got_v - want_v).abs().max()
+    same = got_i == want_i
+    if not bool(same.all()):                       # only exact ties may swap
+        assert torch.equal(torch.gather(masked, 1, got_i), want_v)
+    # no history, PAD column kept: plain top-k of the matrix
+    got_v2, got_i2 = F_.fullsort_topk(ue, slab0, slab1, k=kk, exclude_first_col=False)
+    w2 = torch.topk(full, kk, dim=1)
+    assert torch.equal(got_v2, w2.values) and torch.equal(torch.gather(full, 1, got_i2), w2.values)
