@@ -51,3 +51,10 @@ class CMF(CrossDomainRecommender):
         user_e = F_.gather_rows(self.user_embedding.weight, interaction[self.TARGET_USER_ID])
         score = F_.fullsort_scores(user_e, self.item_embedding.weight[:self.target_num_items])
         return score.view(-1)
+
+    @torch.no_grad()
+    def full_sort_topk(self, interaction, k, hist_indptr=None, hist_cols=None):
+        """(values, columns) [U,k] of ``full_sort_predict`` after recbole's evaluation mask, without the [U, N] matrix."""
+        user_e = F_.gather_rows(self.user_embedding.weight, interaction[self.TARGET_USER_ID])
+        return F_.fullsort_topk(user_e, self.item_embedding.weight[:self.target_num_items], None, k=k,
+                                hist_indptr=hist_indptr, hist_cols=hist_cols, exclude_first_col=True)

@@ -194,22 +194,32 @@ class EMCDR(CrossDomainRecommender):
         return self._rowdot(user_e, item_e)
 
     @torch.no_grad()
-    def full_sort_predict(self, interaction):
+    def _full_sort_operands(self, interaction):
+        """(user_e [U,D], slab0, slab1): the operands of the all-items contraction of the current phase; the item operand is
+        <= 2 contiguous row ranges, so the reference's torch.cat copies (emcdr.py:212-214,228-230) never happen."""
         OI, TI = self.overlapped_num_items, self.target_num_items
         if self.phase == 'SOURCE':
             user_e = F_.gather_rows(self.source_user_embedding.weight, interaction[self.SOURCE_USER_ID])
             W = self.source_item_embedding.weight
-            score = F_.fullsort_scores(user_e, W[:OI], W[TI:])
-        elif self.phase == 'TARGET':
+            return user_e, W[:OI], W[TI:]
+        if self.phase == 'TARGET':
             user_e = F_.gather_rows(self.target_user_embedding.weight, interaction[self.TARGET_USER_ID])
-            score = F_.fullsort_scores(user_e, self.target_item_embedding.weight[:TI])
-        else:
-            user = interaction[self.TARGET_USER_ID]
-            if self.mode == 'overlap_users':
-                user_e = self._mapped_rows('user', user, self.overlapped_num_users)
-                score = F_.fullsort_scores(user_e, self.target_item_embedding.weight[:TI])
-            else:
-                user_e = F_.gather_rows(self.target_user_embedding.weight, user)
-                overlap_item_e = self.apply_mapping(self.source_item_embedding.weight[:OI])
-                score = F_.fullsort_scores(user_e, overlap_item_e, self.target_item_embedding.weight[OI:TI])
-        return score.view(-1)
+            return user_e, self.target_item_embedding.weight[:TI], None
+        user = interaction[self.TARGET_USER_ID]
+        if self.mode == 'overlap_users':
+            return self._mapped_rows('user', user, self.overlapped_num_users), self.target_item_embedding.weight[:TI], None
+        user_e = F_.gather_rows(self.target_user_embedding.weight, user)
+        return user_e, self.apply_mapping(self.source_item_embedding.weight[:OI]), self.target_item_embedding.weight[OI:TI]
+
+    @torch.no_grad()
+    def full_sort_predict(self, interaction):
+        user_e, slab0, slab1 = self._full_sort_operands(interaction)
+        return F_.fullsort_scores(user_e, slab0 if slab0.shape[0] else None, slab1).view(-1)
+
+    @torch.no_grad()
+    def full_sort_topk(self, interaction, k, hist_indptr=None, hist_cols=None):
+        """Evaluation without the [U, N] matrix: (values [U,k], columns [U,k]) of ``full_sort_predict`` after recbole's
+        mask (column 0 and the per-user history columns, CSR with ascending columns) -- what ``Trainer.evaluate`` needs."""
+        user_e, slab0, slab1 = self._full_sort_operands(interaction)
+        return F_.fullsort_topk(user_e, slab0 if slab0.shape[0] else None, slab1, k=k, hist_indptr=hist_indptr,
+                                hist_cols=hist_cols, exclude_first_col=True)

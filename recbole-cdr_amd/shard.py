@@ -321,3 +321,37 @@ class ShardedFullSort:
         out = torch.empty(U, self.N, device=part.device, dtype=torch.float32)
         B_.call('cdr_interleave_shards', B_.stream(), B_.f32(gathered), self.world, U, self.Nl, self.N, B_.f32(out))
         return out
+
+    def topk(self, user_e, k, hist_indptr=None, hist_cols=None, exclude_first_col=True):
+        """(values, global columns) [U, k] of ``scores(user_e)`` after the evaluation mask, identical on every rank, WITHOUT
+        the all-gather of the score matrix: each rank runs the fused mask + top-k kernel over its own item rows and only
+        its k candidates per user (12 B each) are exchanged -- the form that scales.
+        ``hist_indptr`` / ``hist_cols``: per-user ascending GLOBAL columns to skip (replicated)."""
+        from . import functional as F_
+        G, rank = self.world, self.rank
+        U = user_e.shape[0]
+        mine = shard_rows(self.N, G, rank)
+        lp = lc = None
+        if hist_indptr is not None:
+            own = (hist_cols % G) == rank                                    # my share of every user's history, local columns
+            lc = (hist_cols[own] // G).contiguous()
+            owner_user = torch.repeat_interleave(torch.arange(U, device=hist_cols.device), hist_indptr[1:] - hist_indptr[:-1])
+            lp = torch.zeros(U + 1, device=hist_cols.device, dtype=torch.int64)
+            lp[1:] = torch.cumsum(torch.bincount(owner_user[own], minlength=U), 0)
+            if lc.numel() == 0:
+                lp = lc = None
+        kk = min(k, mine)
+        vals, lidx = F_.fullsort_topk(user_e, self.I[:mine], None, k=kk, hist_indptr=lp, hist_cols=lc,
+                                      exclude_first_col=bool(exclude_first_col and rank == 0))
+        if kk < k:
+            vals = torch.cat([vals, vals.new_full((U, k - kk), float('-inf'))], 1)
+            lidx = torch.cat([lidx, lidx.new_full((U, k - kk), -1)], 1)
+        gidx = torch.where(lidx >= 0, lidx * G + rank, lidx)
+        allv = torch.empty(G * U, k, device=vals.device, dtype=torch.float32)
+        alli = torch.empty(G * U, k, device=vals.device, dtype=torch.int64)
+        dist.all_gather_into_tensor(allv, vals.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(alli, gidx.contiguous(), group=self.group)
+        cand_v = allv.view(G, U, k).permute(1, 0, 2).reshape(U, G * k)       # G*k candidates per user: index plumbing
+        cand_i = alli.view(G, U, k).permute(1, 0, 2).reshape(U, G * k)
+        top = torch.topk(cand_v, k, dim=1)
+        return top.values, torch.gather(cand_i, 1, top.indices)

@@ -71,6 +71,8 @@ class Trainer:
         # 'dense'   : the reference's literal loop -- autograd into table-sized gradients + Adam over every parameter
         # 'rowwise' : the model's O(batch) fused step (tables too large for dense gradients, e.g. BASELINE config C5)
         self.optimizer_mode = config['optimizer_mode'] if 'optimizer_mode' in config else 'dense'
+        # evaluation through the model's fused mask + top-k kernel when it has one (False: full score matrix + torch.topk)
+        self.fused_topk = config['fused_topk'] if 'fused_topk' in config else True
         if self.optimizer_mode not in ('dense', 'rowwise'):
             raise ValueError(f"optimizer_mode must be 'dense' or 'rowwise', got {self.optimizer_mode!r}")
         if self.optimizer_mode == 'rowwise' and not hasattr(self.model, 'fused_train_step'):
@@ -99,6 +101,31 @@ class Trainer:
             raise ValueError('Training loss is nan')
         return value
 
+    def _topk_hits(self, interaction, n_user, history_index, positive_u, positive_i, kmax):
+        """Hit matrix [U, kmax] and positives per user from the model's fused mask + top-k (no [U, N] score matrix): the
+        history (rows, cols) pairs become a CSR with ascending columns, positives are matched by sorted (user, item) keys."""
+        dev = self.device
+        N = int(self.model.target_num_items) if hasattr(self.model, 'target_num_items') else None
+        indptr = cols = None
+        if history_index is not None:
+            rows, hc = (torch.as_tensor(t, device=dev, dtype=torch.int64) for t in history_index)
+            span = int(hc.max()) + 1 if hc.numel() else 1
+            key = torch.sort(rows * span + hc).values
+            cols = (key % span).contiguous()
+            indptr = torch.zeros(n_user + 1, device=dev, dtype=torch.int64)
+            indptr[1:] = torch.cumsum(torch.bincount(key // span, minlength=n_user), 0)
+            if cols.numel() == 0:
+                indptr = cols = None
+        _vals, idx = self.model.full_sort_topk(interaction, kmax, hist_indptr=indptr, hist_cols=cols)
+        pu = torch.as_tensor(positive_u, device=dev, dtype=torch.int64)
+        pi = torch.as_tensor(positive_i, device=dev, dtype=torch.int64)
+        span = max(int(idx.max()) + 1, int(pi.max()) + 1 if pi.numel() else 1, N or 1)
+        pkey = torch.sort(pu * span + pi).values
+        qkey = (torch.arange(n_user, device=dev).unsqueeze(1) * span + idx.clamp(min=0)).reshape(-1)
+        at = torch.searchsorted(pkey, qkey).clamp(max=max(pkey.numel() - 1, 0))
+        hit = (pkey[at] == qkey).view(n_user, kmax) & (idx >= 0) if pkey.numel() else torch.zeros_like(idx, dtype=torch.bool)
+        return hit.float(), torch.bincount(pu, minlength=n_user).float()
+
     @torch.no_grad()
     def evaluate(self, eval_data):
         """eval_data yields (interaction, history_index (rows, cols) or None, positive_u, positive_i) like recbole's
@@ -109,6 +136,10 @@ class Trainer:
         for interaction, history_index, positive_u, positive_i in eval_data:
             interaction = interaction.to(self.device)
             n_user = len(interaction)
+            if self.fused_topk and hasattr(self.model, 'full_sort_topk'):
+                h, npos = self._topk_hits(interaction, n_user, history_index, positive_u, positive_i, kmax)
+                hits.append(h); pos_len.append(npos)
+                continue
             scores = self.model.full_sort_predict(interaction).view(n_user, -1)
             scores[:, 0] = -np.inf
             if history_index is not None:

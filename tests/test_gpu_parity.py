@@ -915,6 +915,14 @@ def test_end_to_end_emcdr_learns_with_device_sampler():
     assert res_t['recall@10'] > 5 * random_recall, res_t
     assert res_s['recall@10'] > 5 * random_recall, res_s
     assert res_t['ndcg@10'] > 0 and res_t['mrr@10'] > 0
+    # the two evaluation paths -- fused mask + top-k kernel vs full score matrix + torch.topk -- give the same metrics
+    assert trainer.fused_topk
+    trainer.fused_topk = False
+    ref_s = trainer.evaluate(valid[0])
+    model.set_phase('TARGET')
+    ref_t = trainer.evaluate(valid[1])
+    for k in res_t:
+        assert abs(res_t[k] - ref_t[k]) < 1e-6 and abs(res_s[k] - ref_s[k]) < 1e-6, (k, res_t[k], ref_t[k], res_s[k], ref_s[k])
 
 
 def test_spmm_csr_vs_torch_sparse():
@@ -1071,6 +1079,11 @@ def _shared_gpu_map_eval_worker(rank, world, port, q):
                 ids = torch.arange(5, 5 + Uu) * 7 % nu
                 ue = fs.user_rows(TUl, ids.to(DEV))
                 evals[(n_scored, Uu)] = (ue.cpu().numpy(), fs.scores(ue).cpu().numpy())
+                g = torch.Generator(); g.manual_seed(Uu)
+                hc = torch.sort(torch.randint(1, n_scored, (Uu, 12), generator=g), dim=1).values       # duplicates allowed
+                hp = torch.arange(Uu + 1) * hc.shape[1]
+                tv, ti = fs.topk(ue, 10, hist_indptr=hp.to(DEV), hist_cols=hc.reshape(-1).contiguous().to(DEV))
+                evals[('topk', n_scored, Uu)] = (tv.cpu().numpy(), ti.cpu().numpy(), hc.numpy())
         q.put((rank, SUl.cpu().numpy(), TUl.cpu().numpy(), [p.detach().cpu().numpy() for p in dev], losses, batches, evals))
     finally:
         dist.destroy_process_group()
@@ -1094,7 +1107,21 @@ def test_sharded_map_step_and_fullsort_ranks_share_one_gpu():
     SU, TU, TI = (torch.randn(n, D) * 0.2 for n in (nu, nu, ni))
     TU0, TI0 = TU.clone().to(DEV), TI.to(DEV)
     # full-sort first (it ran on the post-training user table in the workers, so compare against the gathered rows)
-    for (n_scored, Uu), (ue, sc) in res[0][6].items():
+    for key, val in res[0][6].items():
+        if key[0] == 'topk':                      # sharded mask + top-k == top-k of the masked single-device matrix
+            _t, n_scored, Uu = key
+            tv, ti, hc = val
+            full = F_.fullsort_scores(torch.from_numpy(res[0][6][(n_scored, Uu)][0]).to(DEV), TI0[:n_scored])
+            full[:, 0] = -float('inf')
+            full.scatter_(1, torch.from_numpy(hc).to(DEV), -float('inf'))
+            want = torch.topk(full, 10, dim=1)
+            for r in range(world):
+                rv, ri = res[r][6][key][0], res[r][6][key][1]
+                np.testing.assert_array_equal(rv, tv); np.testing.assert_array_equal(ri, ti)      # identical on every rank
+            assert_close(torch.from_numpy(tv).to(DEV), want.values, rtol=1e-6, what=f'sharded topk values {key}')
+            assert torch.equal(torch.gather(full, 1, torch.from_numpy(ti).to(DEV)), torch.from_numpy(tv).to(DEV))
+            continue
+        (n_scored, Uu), (ue, sc) = key, val
         want = F_.fullsort_scores(torch.from_numpy(ue).to(DEV), TI0[:n_scored])
         for r in range(world):
             np.testing.assert_array_equal(res[r][6][(n_scored, Uu)][0], ue)           # every rank holds the same user rows
