@@ -209,6 +209,7 @@ def run_c5(args, world, rank, dev):
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         result['overlap_phase'] = {'ms_per_step': float(tm) * 1e3, 'overlap_ids_per_s': OB * world / float(tm),
                                    'batch_per_rank': OB, 'mapping': 'linear %dx%d' % (D, D), 'loss': float(fmap.loss)}
+        del fmap                                   # it shares (and would keep alive) the user tables' Adam moments
 
     # ---- roofline of the dominant kernel(s): algorithmic bytes / HIP-event time of each native call --------------
     if rank == 0 and not sharded:
