@@ -168,6 +168,11 @@ int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg
 int cdr_adam_dense_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev);
 int cdr_inc_i64(void* stream, int64_t* counter);
+/* the same update for `count` parameter tensors in one launch (+ one launch that bumps their device step counters first):
+ * host arrays of device pointers, one entry per tensor */
+int cdr_adam_multi_dev(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev,
+                       float lr, float beta1, float beta2, float eps, float weight_decay);
 
 /* cdr_gemm_f32 with a per-output-row scale and a pre-activation accumulate -- the CoNet cross unit
  * (conet.py:127-135):  first  C = s W^T + b           (cdr_gemm_f32, act none)

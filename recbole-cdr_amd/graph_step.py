@@ -18,7 +18,10 @@ class GraphedTrainStep:
         self._capture(warmup)
 
     def _eager(self, interaction):
-        self.optimizer.zero_grad(set_to_none=False)
+        # set_to_none: autograd then hands each parameter its gradient buffer instead of "zero-fill, then add into it" (two
+        # extra kernels per parameter per step); inside the capture those buffers come from the graph's private pool, so
+        # their addresses are the same on every replay
+        self.optimizer.zero_grad(set_to_none=True)
         losses = self.model.calculate_loss(interaction)
         loss = sum(losses) if isinstance(losses, tuple) else losses
         loss = loss.sum()

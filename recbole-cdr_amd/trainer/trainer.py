@@ -22,8 +22,10 @@ class DenseAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        import ctypes
         from .. import binding as B_
         for group in self.param_groups:
+            ps, gs, ms, vs, ns, ss, keep = [], [], [], [], [], [], []
             for p in group['params']:
                 if p.grad is None:
                     continue                      # like torch: a parameter without a gradient keeps its own step count
@@ -32,10 +34,17 @@ class DenseAdam(torch.optim.Optimizer):
                     st['step'] = torch.zeros(1, device=p.device, dtype=torch.int64)     # per-parameter, on device
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
-                B_.call('cdr_inc_i64', B_.stream(), B_.i64(st['step']))
-                B_.call('cdr_adam_dense_dev', B_.stream(), B_.f32(p.data), B_.f32(p.grad.contiguous()), B_.f32(st['exp_avg']),
-                        B_.f32(st['exp_avg_sq']), p.numel(), float(group['lr']), float(group['betas'][0]),
-                        float(group['betas'][1]), float(group['eps']), float(group['weight_decay']), B_.i64(st['step']))
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(g)
+                ps.append(B_.f32(p.data)); gs.append(B_.f32(g)); ms.append(B_.f32(st['exp_avg'])); vs.append(B_.f32(st['exp_avg_sq']))
+                ns.append(p.numel()); ss.append(B_.i64(st['step']))
+            if not ps:
+                continue
+            n = len(ps)
+            arr = lambda xs: (ctypes.c_void_p * n)(*[x.value if hasattr(x, 'value') else x for x in xs])
+            B_.call('cdr_adam_multi_dev', B_.stream(), n, arr(ps), arr(gs), arr(ms), arr(vs), (ctypes.c_int64 * n)(*ns), arr(ss),
+                    float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
+                    float(group['weight_decay']))
 
 
 def early_stopping(value, best, cur_step, max_step, bigger=True):
