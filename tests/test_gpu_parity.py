@@ -1212,3 +1212,61 @@ def test_fullsort_topk_matches_topk_of_masked_scores(U, D, N, k):
     got_v2, got_i2 = F_.fullsort_topk(ue, slab0, slab1, k=kk, exclude_first_col=False)
     w2 = torch.topk(full, kk, dim=1)
     assert torch.equal(got_v2, w2.values) and torch.equal(torch.gather(full, 1, got_i2), w2.values)
+
+
+def test_full_c5_size_properties():
+    """BASELINE C5 table sizes (one domain: 50,000,001 x 128 users, 20,000,001 x 128 items, B = 1,048,576 triples), through
+    properties that do not need an oracle run at that size:
+      * lr = 0 leaves both tables bit-identical; rows outside the batch are never written (bit-exact);
+      * with reg = 0 the item gradients cancel exactly in the sum (dI[p] = +g u, dI[n] = -g u): the column sums of the item
+        table's change vanish relative to the total movement -- a checksum over 2 M updated rows;
+      * the step is bit-reproducible on a second copy of the tables;
+      * scoring: a user's scores over all 10,000,001 target items agree between the streaming (U = 1), the tile (U = 16) and
+        the persistent MFMA (U = 64) kernels, and the fused top-k returns exactly the k largest of them."""
+    from recbole_cdr_amd import functional as F_
+    from recbole_cdr_amd.fused import FusedBPRStep
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 120e9:
+        pytest.skip('needs ~110 GB of free HBM')
+    nu, ni, D, B, TOI = 50_000_001, 20_000_001, 128, 1 << 20, 10_000_000
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    U = torch.empty(nu, D, device=DEV).normal_(0, 0.05, generator=g)
+    I = torch.empty(ni, D, device=DEV).normal_(0, 0.05, generator=g)
+    u = torch.randint(1, nu, (B,), device=DEV, generator=g)
+    p = torch.randint(1, 1 + TOI, (B,), device=DEV, generator=g)
+    n = torch.randint(1, 1 + TOI, (B,), device=DEV, generator=g)
+    csum = lambda t: (t.view(-1)[::4097].double().sum(), t[-1].clone(), t[0].clone())      # cheap fingerprint + exact rows
+    # lr = 0: nothing moves
+    touched_i = torch.unique(torch.cat([p, n]))
+    before_i = I[touched_i].clone(); before_u_rows = U[u[:1000]].clone()
+    FusedBPRStep(U, I, B, opt='sgd', lr=0.0, reg_weight=0.0).step(u, p, n)
+    assert torch.equal(I[touched_i], before_i) and torch.equal(U[u[:1000]], before_u_rows)
+    # one real step on two copies of the touched state: reproducible, untouched rows untouched, item gradients cancel
+    mask = torch.ones(ni, dtype=torch.bool, device=DEV); mask[touched_i] = False
+    outside = torch.nonzero(mask)[:: max(1, int(mask.sum()) // 2000)].flatten()[:2000]
+    keep_out = I[outside].clone()
+    I2 = I.clone()
+    U2_rows_idx = torch.unique(u)
+    U2 = U[U2_rows_idx].clone()                                        # the user table is 25.6 GB: second run replays on the saved rows
+    lr = 0.1 * B                                                       # the loss is a mean over B: per-row updates ~ 0.1 * g * u, far above the tables' ulp
+    l1 = FusedBPRStep(U, I, B, opt='sgd', lr=lr, reg_weight=0.0).step(u, p, n)[0].clone()
+    after_u = U[U2_rows_idx].clone()
+    U[U2_rows_idx] = U2                                                # restore the touched user rows, run again on the copy of I
+    l2 = FusedBPRStep(U, I2, B, opt='sgd', lr=lr, reg_weight=0.0).step(u, p, n)[0].clone()
+    assert torch.equal(l1, l2) and torch.equal(U[U2_rows_idx], after_u) and torch.equal(I[touched_i], I2[touched_i])
+    assert torch.equal(I[outside], keep_out)
+    delta = (I[touched_i] - before_i).double()
+    assert float(delta.abs().sum()) > 0
+    assert float(delta.sum(0).abs().max()) <= 1e-5 * float(delta.abs().sum(0).max()), 'item gradients must cancel in the sum'
+    del I2, delta, before_i, mask
+    # scoring over the full 10,000,001-item slab
+    slab = I[:1 + TOI]
+    ue = U[1:65].contiguous()
+    s64 = F_.fullsort_scores(ue, slab)
+    s16 = F_.fullsort_scores(ue[:16].contiguous(), slab)
+    s1 = F_.fullsort_scores(ue[:1].contiguous(), slab)
+    scale = float(s64[0].abs().max())
+    assert float((s1[0] - s64[0]).abs().max()) <= 1e-5 * scale and float((s16 - s64[:16]).abs().max()) <= 1e-5 * scale
+    tv, ti = F_.fullsort_topk(ue, slab, None, k=10, exclude_first_col=False)
+    want = torch.topk(s64, 10, dim=1)
+    assert torch.equal(tv, want.values) and torch.equal(torch.gather(s64, 1, ti), want.values)
