@@ -52,6 +52,7 @@ int cdr_abi_version(void);                          /* bumped on any signature c
 #define CDR_TAG_APPLY_UNSIGNED 4     /* rowwise_apply_kernel<.., SIGNED=false>: user table */
 #define CDR_TAG_APPLY_SIGNED 5       /* rowwise_apply_kernel<.., SIGNED=true >: item table (pos + neg occurrences) */
 #define CDR_TAG_SORT 6
+#define CDR_TAG_POINT_FWD_GRAD 7
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
 
@@ -278,6 +279,12 @@ int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      float gamma, float reg_weight, float* out9, float* GU /* [B,D] */, float* GP /* [B,D] */,
                      int scatter /* != 0 (row-sharded step): GP[pid[b]] = g u, GP[nid[b]] = -g u instead of GP[b] = g u */);
 int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6);
+/* pointwise form of the same step (EMCDR's default MF latent factor model, emcdr.py:111-122: MSE(dot, label) +
+ * reg_weight * EmbLoss(u_rows, i_rows); CDR_LOSS_BCE = BCE on sigmoid(dot) as in cmf.py:75-99): GU[b] = g_b i_b, GI[b] = g_b u_b,
+ * out9 as above; apply both tables with cdr_sort_ids + cdr_rowwise_apply (neg_start = n, reg_limit = n).                 */
+int cdr_point_fwd_grad(cdr_ctx* ctx, void* stream, int loss_kind, const float* user_tab, const float* item_tab, int D,
+                       const int64_t* uid, const int64_t* iid, const float* label, int64_t B, float reg_weight,
+                       float* out9, float* GU /* [B,D] */, float* GI /* [B,D] */);
 int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);
 int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int64_t n0, const int64_t* ids1, int64_t n1, int64_t num_rows,
                  uint32_t* keys_sorted /* [n0+n1] */, uint32_t* perm /* [n0+n1] */,

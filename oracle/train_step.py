@@ -77,3 +77,21 @@ def rowwise_map_step(map_params, S, T, sstate, tstate, idx, step_s, step_t, map_
         _apply_rows(T, tstate, rows, GT, opt, lr, step_t)
     map_optimizer.step()
     return loss.detach()
+
+
+def rowwise_point_step(U, I, ustate, istate, uid, iid, label, step_u, step_i, opt='adam', lr=1e-3, reg_weight=0.01, loss='mse'):
+    """Pointwise step on the touched rows only; loss as emcdr.domain_loss for MF (emcdr.py:111-122) or BCE on sigmoid(dot)
+    (cmf.py:75-99)."""
+    from .losses import mse_loss
+    ue = U[uid].requires_grad_(True)
+    ie = I[iid].requires_grad_(True)
+    dot = (ue * ie).sum(1)
+    main = mse_loss(dot, label) if loss == 'mse' else torch.nn.functional.binary_cross_entropy(torch.sigmoid(dot), label)
+    total = main + reg_weight * emb_loss(ue, ie)
+    gu, gi = torch.autograd.grad(total.sum(), [ue, ie])
+    with torch.no_grad():
+        ru, inv_u = torch.unique(uid, return_inverse=True)
+        ri, inv_i = torch.unique(iid, return_inverse=True)
+        _apply_rows(U, ustate, ru, torch.zeros(ru.numel(), U.shape[1]).index_add_(0, inv_u, gu), opt, lr, step_u)
+        _apply_rows(I, istate, ri, torch.zeros(ri.numel(), I.shape[1]).index_add_(0, inv_i, gi), opt, lr, step_i)
+    return total.detach()

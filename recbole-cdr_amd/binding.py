@@ -113,6 +113,7 @@ _SIGNATURES = {
     'cdr_gather_owned_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_adam_dense_dev': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr],
     'cdr_inc_i64': [_c_ptr, _c_ptr],
+    'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32],
     'cdr_neg_sample_uniform': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64,
                                _c_ptr, _c_ptr],
@@ -224,7 +225,7 @@ def call(name, *args):
 
 
 TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4: 'rowwise_apply_kernel(users)',
-        5: 'rowwise_apply_kernel(items)', 6: 'sort_ids'}
+        5: 'rowwise_apply_kernel(items)', 6: 'sort_ids', 7: 'point_fwd_grad_kernel'}
 
 
 _timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device

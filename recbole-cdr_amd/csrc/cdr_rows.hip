@@ -22,12 +22,26 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     const int D4 = D >> 2;
     const int64_t total = n * D4;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
-        const int64_t r = e / D4;
-        const int c = (int)(e - r * D4);
-        const int64_t id = ids[r];
-        const float* src = (SELECT && id < n_overlap) ? mapped + r * D : tab + id * D;
-        st4(out + r * D + 4 * c, ld4(src + 4 * c));
+    constexpr int UN = 4;           // ids of UN elements first, then UN independent row loads in flight, then the stores
+    for (int64_t e0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; e0 < total; e0 += stride * UN) {
+        int64_t r[UN], id[UN];
+        int c[UN];
+        float4 v[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int64_t e = e0 + j * stride;
+            r[j] = e < total ? e / D4 : 0;
+            c[j] = e < total ? (int)(e - r[j] * D4) : 0;
+            id[j] = ids[r[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const float* src = (SELECT && id[j] < n_overlap) ? mapped + r[j] * D : tab + id[j] * D;
+            v[j] = ld4(src + 4 * c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j)
+            if (e0 + j * stride < total) st4(out + r[j] * D + 4 * c[j], v[j]);
     }
 }
 

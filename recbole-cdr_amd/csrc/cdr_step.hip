@@ -108,6 +108,74 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
     }
 }
 
+// Pointwise counterpart (EMCDR's default MF latent factor model: emcdr.py:111-122, MSE on the raw dot; BCE on sigmoid(dot) as in
+// cmf.py:75-99): one pass over the batch's (user, item, label) rows; compact gradient rows GU[b] = g_b i_b, GI[b] = g_b u_b.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void point_fwd_grad_kernel(int loss_kind, const float* __restrict__ U, const float* __restrict__ I,
+                                                                int D, const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                                const float* __restrict__ label, int64_t B, float invB,
+                                                                float* __restrict__ GU, float* __restrict__ GI,
+                                                                double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    double acc[3] = {0.0, 0.0, 0.0};
+    const bool live = sub < D4;
+    for (int64_t base = gg; base < B; base += TG * kUnroll) {
+        float4 u[kUnroll], v[kUnroll];
+        int64_t iu[kUnroll], ii[kUnroll];
+        float yl[kUnroll];
+#pragma unroll
+        for (int r = 0; r < kUnroll; ++r) {                  // ids and labels first, then every row load (vmcnt is in-order)
+            const int64_t t = base + (int64_t)r * TG;
+            const int64_t tc = t < B ? t : B - 1;
+            iu[r] = uid[tc]; ii[r] = iid[tc]; yl[r] = label[tc];
+        }
+#pragma unroll
+        for (int r = 0; r < kUnroll; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            u[r] = v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < B && live) {
+                u[r] = ld4(U + iu[r] * D + 4 * sub);
+                v[r] = ld4(I + ii[r] * D + 4 * sub);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kUnroll; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const float dx = group_sum<LPR>(dot4(u[r], v[r]));
+            const float su = group_sum<LPR>(dot4(u[r], u[r]));
+            const float si = group_sum<LPR>(dot4(v[r], v[r]));
+            if (t < B) {
+                const float y = yl[r];
+                float l, g;
+                if (loss_kind == CDR_LOSS_MSE) {
+                    const float d = dx - y;
+                    l = d * d; g = 2.0f * d * invB;
+                } else {                                       // torch BCELoss on sigmoid(dot): -100 log clamp, 1e-12 backward clamp
+                    const float p = sigmoidf_(dx);
+                    l = (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+                    const float pq = (1.0f - p) * p;
+                    g = (p - y) / fmaxf(pq, 1e-12f) * invB * pq;
+                }
+                if (live) {
+                    st4(GU + t * D + 4 * sub, make_float4(g * v[r].x, g * v[r].y, g * v[r].z, g * v[r].w));
+                    st4(GI + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                }
+                if (sub == 0) { acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si; }
+            }
+        }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
 // out9 = {total, main, ||U_b||, ||I_b||, c_u, c_i, sum loss, sum u^2, sum p^2} with c = reg_weight / (B * norm)
 // (0 when the norm is 0).  B is the batch size the mean and the EmbLoss are taken over (the GLOBAL batch when the
 // step is sharded: then out9[0..5] are provisional and cdr_loss_finish_sums recomputes them from all-reduced sums).
@@ -377,6 +445,25 @@ extern "C" int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream, const float* user_ta
     }
     CDR_LAUNCH_CHECK();
     step_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B_mean, reg_weight, out6);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_point_fwd_grad(cdr_ctx* ctx, void* stream, int loss_kind, const float* user_tab, const float* item_tab, int D,
+                                 const int64_t* uid, const int64_t* iid, const float* label, int64_t B, float reg_weight,
+                                 float* out9, float* GU, float* GI) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && out9 && GU && GI);
+    CDR_CHECK_ARG((loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE) && D > 0 && (D & 3) == 0 && D <= 256 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_POINT_FWD_GRAD, s);
+        DISPATCH_LPR(lpr, point_fwd_grad_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(loss_kind, user_tab, item_tab, D, uid, iid, label, B,
+                                                                                        1.0f / (float)B, GU, GI, ctx->partials));
+    }
+    CDR_LAUNCH_CHECK();
+    step_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -81,6 +81,54 @@ class FusedBPRStep:
                 float(self.wd), st.step, None)
 
 
+class FusedPointStep:
+    """Pointwise counterpart of FusedBPRStep: rows (user, item, label) -- recbole's pointwise layout, sampled negatives stacked
+    behind the positives with label 0 -- MSE on the raw dot (EMCDR's default MF latent factor model, emcdr.py:111-122) or BCE
+    on sigmoid(dot), plus ``reg_weight * EmbLoss(u_rows, i_rows)``; both tables updated row-wise on the batch's rows."""
+
+    def __init__(self, user_table, item_table, max_batch, loss='mse', opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, reg_weight=0.0, user_state=None, item_state=None):
+        assert user_table.is_cuda and item_table.is_cuda, 'FusedPointStep needs ROCm device tensors'
+        assert user_table.shape[1] == item_table.shape[1]
+        self.U, self.I = user_table, item_table
+        self.D = user_table.shape[1]
+        self.kind = B_.CDR_LOSS_MSE if loss == 'mse' else B_.CDR_LOSS_BCE
+        self.opt = OPT_ADAM if opt == 'adam' else OPT_SGD
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.reg_weight = reg_weight
+        self.ustate = user_state if user_state is not None else RowwiseState(user_table, self.opt)
+        self.istate = item_state if item_state is not None else RowwiseState(item_table, self.opt)
+        dev = user_table.device
+        Bm = int(max_batch)
+        self.max_batch = Bm
+        self.GU = torch.empty(Bm, self.D, device=dev, dtype=torch.float32)
+        self.GI = torch.empty(Bm, self.D, device=dev, dtype=torch.float32)
+        self.out6 = torch.zeros(12, device=dev, dtype=torch.float32)
+        self.keys = torch.empty(Bm, device=dev, dtype=torch.int32)
+        self.perm = torch.empty(Bm, device=dev, dtype=torch.int32)
+        need = ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_sort_workspace_bytes(Bm, max(user_table.shape[0], item_table.shape[0]), ctypes.byref(need)),
+                  'cdr_sort_workspace_bytes')
+        self.ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+
+    def step(self, uid, iid, label):
+        """uid / iid int64 [B], label fp32 [B].  Returns out6 (view; [0] = total loss)."""
+        B = uid.numel()
+        assert B <= self.max_batch
+        s = B_.stream()
+        ctxh = B_.ctx(self.U.device)
+        B_.call('cdr_point_fwd_grad', ctxh, s, self.kind, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(iid),
+                B_.f32(label), B, float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI))
+        for st, ids, G, coef in ((self.ustate, uid, self.GU, self.out6[4:5]), (self.istate, iid, self.GI, self.out6[5:6])):
+            B_.call('cdr_sort_ids', ctxh, s, B_.i64(ids), B, None, 0, st.table.shape[0], B_.raw(self.keys), B_.raw(self.perm),
+                    B_.raw(self.ws), self.ws.numel())
+            st.step += 1
+            B_.call('cdr_rowwise_apply', ctxh, s, self.opt, B_.f32(st.table), B_.f32(st.exp_avg), B_.f32(st.exp_avg_sq), self.D,
+                    B_.raw(self.keys), B_.raw(self.perm), B, B_.f32(G), B, B, B_.f32(coef), float(self.lr), float(self.betas[0]),
+                    float(self.betas[1]), float(self.eps), float(self.wd), st.step, None)
+        return self.out6
+
+
 class FusedMapStep:
     """EMCDR's OVERLAP phase (emcdr.py:133-137 ``calculate_map_loss``: MSE(mapping(source_e[idx]), target_e[idx])) as an
     O(batch) step: the two embedding tables are updated row-wise on the overlapped ids only; the mapping function's own

@@ -119,10 +119,8 @@ class EMCDR(CrossDomainRecommender):
         optimizer sweep (fused.FusedBPRStep / fused.FusedMapStep on this model's own tables): what
         ``CrossDomainTrainer`` runs when ``config['optimizer_mode'] == 'rowwise'``.  Same loss and per-row gradients as
         ``calculate_loss``; the embedding tables take the row-wise (lazy) Adam, the mapping function the exact dense one.
-        One optimizer state per table, shared by the phases.  BPR latent factor model only."""
-        from ...fused import FusedBPRStep, FusedMapStep, RowwiseState, OPT_ADAM, OPT_SGD
-        if self.latent_factor_model != 'BPR':
-            raise NotImplementedError('fused_train_step covers the pairwise (BPR) EMCDR; use the dense step for MF')
+        One optimizer state per table, shared by the phases.  Both latent factor models (MF: pointwise MSE; BPR)."""
+        from ...fused import FusedBPRStep, FusedPointStep, FusedMapStep, RowwiseState, OPT_ADAM, OPT_SGD
         code = OPT_ADAM if opt == 'adam' else OPT_SGD
         cache = self.__dict__.setdefault('_fused', {'states': {}, 'steps': {}})
 
@@ -145,6 +143,17 @@ class EMCDR(CrossDomainRecommender):
         domain = 'source' if self.phase == 'SOURCE' else 'target'
         user = interaction[getattr(self, f'{domain.upper()}_USER_ID')].reshape(-1)
         item = interaction[getattr(self, f'{domain.upper()}_ITEM_ID')].reshape(-1)
+        if self.latent_factor_model == 'MF':
+            label = interaction[getattr(self, f'{domain.upper()}_LABEL')].reshape(-1).float()
+            key = ('mf', domain)
+            step = cache['steps'].get(key)
+            if step is None or step.max_batch < user.numel():
+                step = FusedPointStep(getattr(self, f'{domain}_user_embedding').weight.data,
+                                      getattr(self, f'{domain}_item_embedding').weight.data, user.numel(), loss='mse',
+                                      reg_weight=self.reg_weight, user_state=state(f'{domain}_user_embedding'),
+                                      item_state=state(f'{domain}_item_embedding'), **hp)
+                cache['steps'][key] = step
+            return step.step(user, item, label)[0]
         neg = interaction[getattr(self, f'{domain.upper()}_NEG_ITEM_ID')].reshape(-1)
         key = ('bpr', domain)
         step = cache['steps'].get(key)

@@ -1270,3 +1270,96 @@ def test_full_c5_size_properties():
     tv, ti = F_.fullsort_topk(ue, slab, None, k=10, exclude_first_col=False)
     want = torch.topk(s64, 10, dim=1)
     assert torch.equal(tv, want.values) and torch.equal(torch.gather(s64, 1, ti), want.values)
+
+
+@pytest.mark.parametrize('loss', ['mse', 'bce'])
+@pytest.mark.parametrize('opt,D', [('sgd', 64), ('adam', 128), ('adam', 16)])
+def test_fused_point_step_vs_oracle(loss, opt, D):
+    """Pointwise O(batch) step (EMCDR's default MF model / BCE on sigmoid(dot)): loss and touched rows after three steps ==
+    oracle autograd + (SGD | lazy Adam); duplicate ids and one long user segment included."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import FusedPointStep
+    torch.manual_seed(D)
+    nu, ni, B, lr, reg = 60, 45, 300, 0.05, 0.02
+    U, I = torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3
+    Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+    fs = FusedPointStep(Ud, Id, B, loss=loss, opt=opt, lr=lr, reg_weight=reg)
+    su, si = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    for step in range(1, 4):
+        u = torch.randint(0, nu, (B,)); i = torch.randint(0, ni, (B,))
+        y = (torch.rand(B) < 0.4).float()
+        if step == 2:
+            u[:80] = 7                                           # > 32 occurrences of one row: the piece path of the apply
+        want = ts.rowwise_point_step(U, I, su, si, u, i, y, step, step, opt=opt, lr=lr, reg_weight=reg, loss=loss)
+        got = fs.step(u.to(DEV), i.to(DEV), y.to(DEV))[0]
+        assert_close(got, want, what=f'loss step {step}')
+        atol = lr * 1e-2 if opt == 'adam' else 1e-6
+        assert_close(Ud, U, rtol=2e-5, atol=atol, what=f'U step {step}'); assert_close(Id, I, rtol=2e-5, atol=atol, what=f'I step {step}')
+        if opt == 'adam':
+            assert_close(fs.ustate.exp_avg, su.m, rtol=5e-5, what='exp_avg U')
+            U.copy_(Ud.cpu()); I.copy_(Id.cpu())
+            su.m.copy_(fs.ustate.exp_avg.cpu()); su.v.copy_(fs.ustate.exp_avg_sq.cpu())
+            si.m.copy_(fs.istate.exp_avg.cpu()); si.v.copy_(fs.istate.exp_avg_sq.cpu())
+
+
+def test_trainer_rowwise_mode_mf():
+    """optimizer_mode='rowwise' with EMCDR's DEFAULT latent factor model (MF, pointwise labels): two SOURCE epochs and one
+    OVERLAP epoch against the oracle's row-wise steps."""
+    from oracle import train_step as ts
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+    from recbole_cdr_amd.utils import InputType, train_mode2state
+    torch.manual_seed(13)
+    ids = IdSpace(OU=20, TOU=15, SOU=18, OI=1, TOI=30, SOI=34)
+    D, lr, reg = 16, 0.01, 0.01
+    cfg = base_config(DEV, latent_factor_model='MF', source_embedding_size=D, target_embedding_size=D, reg_weight=reg,
+                      mapping_function='linear', mlp_hidden_size=[24], learning_rate=lr, optimizer_mode='rowwise',
+                      train_modes=['SOURCE', 'OVERLAP'], epoch_num=['2', '1'], source_split=False, eval_step=1, epochs=2)
+    model = EMCDR(cfg, FakeDataset(ids)).to(DEV)
+    params = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+    rng = np.random.RandomState(0)
+    src_u = np.array(list(range(1, ids.OU)) + list(range(ids.OU + ids.TOU, ids.total_num_users)))
+    src_i = np.arange(ids.OI + ids.TOI, ids.total_num_items)
+    tgt_u, tgt_i = np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI)
+    s_inter = {'source_user_id': torch.from_numpy(rng.choice(src_u, 96)), 'source_item_id': torch.from_numpy(rng.choice(src_i, 96))}
+    t_inter = {'target_user_id': torch.from_numpy(rng.choice(tgt_u, 80)), 'target_item_id': torch.from_numpy(rng.choice(tgt_i, 80))}
+    neg_rng = {'s': np.random.RandomState(1), 't': np.random.RandomState(2)}
+    s_sampler = lambda u, i, k: torch.from_numpy(neg_rng['s'].choice(src_i, u.numel() * k)).to(u.device)
+    t_sampler = lambda u, i, k: torch.from_numpy(neg_rng['t'].choice(tgt_i, u.numel() * k)).to(u.device)
+    mk = lambda: CrossDomainDataloader(
+        DomainTrainLoader(s_inter, 'source_user_id', 'source_item_id', 'source_label', 'neg_', 32, 1, InputType.POINTWISE, s_sampler),
+        DomainTrainLoader(t_inter, 'target_user_id', 'target_item_id', 'target_label', 'neg_', 32, 1, InputType.POINTWISE, t_sampler),
+        OverlapDataloader(ids.OU, 8))
+    trainer = CrossDomainTrainer(cfg, model)
+    log = []
+    orig = trainer._train_epoch
+    trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
+    trainer.fit(mk())
+    assert len(log) == 3
+    neg_rng['s'], neg_rng['t'] = np.random.RandomState(1), np.random.RandomState(2)
+    SU, SI, TU = params['source_user_embedding.weight'], params['source_item_embedding.weight'], params['target_user_embedding.weight']
+    st = {'su': ts.RowwiseAdamState(SU), 'si': ts.RowwiseAdamState(SI), 'tu': ts.RowwiseAdamState(TU)}
+    cnt = {'su': 0, 'si': 0, 'tu': 0}
+    mp = {k: v.requires_grad_(True) for k, v in params.items() if k.startswith('mapping.')}
+    mopt = torch.optim.Adam(list(mp.values()), lr=lr)
+    dl = mk()
+    ref_log = []
+    for phase, epochs in (('SOURCE', 2), ('OVERLAP', 1)):
+        dl.set_mode(train_mode2state[phase])
+        for _ in range(epochs):
+            tot = 0.0
+            for b in dl:
+                if phase == 'OVERLAP':
+                    cnt['su'] += 1; cnt['tu'] += 1
+                    loss = ts.rowwise_map_step(mp, SU, TU, st['su'], st['tu'], b['overlap'], cnt['su'], cnt['tu'], mopt, lr=lr)
+                else:
+                    cnt['su'] += 1; cnt['si'] += 1
+                    loss = ts.rowwise_point_step(SU, SI, st['su'], st['si'], b['source_user_id'], b['source_item_id'],
+                                                 b['source_label'].float(), cnt['su'], cnt['si'], lr=lr, reg_weight=reg)
+                tot += float(loss.sum())
+            ref_log.append(tot)
+    assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=5e-5, what='epoch losses')
+    for k, v in model.named_parameters():
+        assert_close(v, params[k].detach(), rtol=1e-4, atol=lr * 5e-2, what=k)
