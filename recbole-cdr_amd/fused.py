@@ -1,4 +1,5 @@
-"""Fused row-wise training step: forward + backward + optimizer for one BPR batch without table-sized gradients.
+"""Fused row-wise training steps: forward + backward + optimizer for one batch without table-sized gradients
+(FusedBPRStep: pairwise BPR; FusedPointStep: pointwise MSE / BCE; FusedMapStep: EMCDR's OVERLAP-phase mapping loss).
 
 This is the large-table counterpart of ``loss.backward(); optimizer.step()`` in the reference's loop
 (recbole_cdr/trainer/trainer.py:59-73 -> recbole ``Trainer._train_epoch``): dense ``[rows, D]`` gradients and a dense

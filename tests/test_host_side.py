@@ -101,3 +101,59 @@ def test_train_loader_layouts():
     assert b['source_label'].tolist() == [1.0] * 3 + [0.0] * 6
     ov = next(iter(OverlapDataloader(7, 3)))
     assert tuple(ov['overlap'].shape) == (3, 1) and ov['overlap'][:, 0].tolist() == [0, 1, 2]
+
+
+def test_evaluate_topk_path_equals_full_matrix_path():
+    """Trainer.evaluate's two routes -- the model's ``full_sort_topk`` (CSR history mask + sorted-key hit matching on the
+    host side) and the reference's full score matrix + in-place -inf + torch.topk -- give identical metrics.  The model
+    here is a CPU stand-in with both methods written in plain torch, so only the host logic is under test."""
+    from recbole_cdr_amd.trainer.trainer import Trainer
+
+    class Stub(torch.nn.Module):
+        target_num_items = 57
+
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator(); g.manual_seed(0)
+            self.w = torch.nn.Parameter(torch.randn(40, 8, generator=g))
+            self.items = torch.randn(57, 8, generator=g)
+
+        def full_sort_predict(self, inter):
+            return (self.w[inter['uid']] @ self.items.t()).reshape(-1)
+
+        def full_sort_topk(self, inter, k, hist_indptr=None, hist_cols=None):
+            s = (self.w[inter['uid']] @ self.items.t()).detach().clone()
+            s[:, 0] = -float('inf')
+            if hist_indptr is not None:
+                for u in range(s.shape[0]):
+                    s[u, hist_cols[hist_indptr[u]:hist_indptr[u + 1]]] = -float('inf')
+            return torch.topk(s, k, dim=1)
+
+    class Inter(dict):
+        def to(self, dev):
+            return self
+
+        def __len__(self):
+            return self['uid'].numel()
+
+    rng = np.random.RandomState(3)
+    batches = []
+    for lo in (0, 16, 32):
+        uid = torch.arange(lo, min(lo + 16, 40))
+        n = uid.numel()
+        hr = np.repeat(np.arange(n), 5); hc = rng.randint(1, 57, hr.size)
+        pu = np.repeat(np.arange(n), 3); pi = rng.randint(1, 57, pu.size)
+        pairs = np.unique(np.stack([pu, pi], 1), axis=0)                      # (user, item) positives, deduplicated
+        hist = (torch.from_numpy(hr), torch.from_numpy(hc)) if lo != 16 else None     # one batch without history
+        batches.append((Inter(uid=uid), hist, torch.from_numpy(pairs[:, 0]), torch.from_numpy(pairs[:, 1])))
+    cfg = {'device': 'cpu', 'topk': [5, 10], 'valid_metric': 'Recall@10'}
+    model = Stub()
+    tr = Trainer.__new__(Trainer)
+    tr.config, tr.model, tr.device, tr.topk = cfg, model, 'cpu', [5, 10]
+    tr.fused_topk = True
+    a = tr.evaluate(batches)
+    tr.fused_topk = False
+    b = tr.evaluate(batches)
+    assert set(a) == set(b) and a['recall@10'] > 0
+    for k in a:
+        assert abs(a[k] - b[k]) < 1e-7, (k, a[k], b[k])
