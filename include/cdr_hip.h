@@ -295,7 +295,15 @@ int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* 
                       const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
                       const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                      const int64_t* occ_ids /* NULL, or per-occurrence ids whose bit 62 marks the EmbLoss occurrences */);
+                      const int64_t* occ_ids /* NULL, or per-occurrence ids whose bit 62 marks the EmbLoss occurrences */,
+                      uint32_t key_base /* 0, or the table bit cdr_sort_ids_two_tables put on this table's keys */);
+/* Both tables of a step in one sort (the radix sort's cost is a fixed ~0.16 ms at these sizes): table a's n_a keys come out
+ * first (keys_sorted[0, n_a), perm = occurrence index), table b's n_b0 + n_b1 behind them with *key_base_out added to the
+ * key and perm = occurrence index inside b's own list (ids_b0 ++ ids_b1).  Size the workspace with
+ * cdr_sort_workspace_bytes(n_a + n_b0 + n_b1, 2^(1 + ceil(log2(max(rows_a, rows_b))))).                               */
+int cdr_sort_ids_two_tables(cdr_ctx* ctx, void* stream, const int64_t* ids_a, int64_t n_a, int64_t rows_a,
+                            const int64_t* ids_b0, int64_t n_b0, const int64_t* ids_b1, int64_t n_b1, int64_t rows_b,
+                            uint32_t* keys_sorted, uint32_t* perm, uint32_t* key_base_out, void* workspace, size_t workspace_bytes);
 
 /* ---- negative sampler on device (recbole_cdr/sampler/crossdomain_sampler.py:139-175,212-221) ----------
  * out[j + m*S] (k-major) = m-th negative of users[j]: uniform over [lo0,hi0) U [lo1,hi1), redrawn while it is one of the

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -72,7 +72,9 @@ _SIGNATURES = {
     'cdr_timing_collect': [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_f32), _c_int, ctypes.POINTER(_c_int)],
     'cdr_sort_ids': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_rowwise_apply': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
-                          _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr],
+                          _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr, ctypes.c_uint32],
+    'cdr_sort_ids_two_tables': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+                                _c_ptr, ctypes.c_size_t],
     'cdr_gemm_f32_ex': [_c_ptr, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
                         _c_ptr, _c_int, _c_int],
     'cdr_gather_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],

@@ -135,7 +135,7 @@ class NativeOps:
         B_.call('cdr_rowwise_apply', ctxh, B_.stream(), opt, B_.f32(table), B_.f32(m), B_.f32(v), table.shape[1],
                 B_.raw(keys), B_.raw(perm), n, B_.f32(grads), n, int(reg_limit), B_.f32(reg_coef), float(hp['lr']),
                 float(hp['b1']), float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step),
-                B_.i64(local_ids) if tagged else None)
+                B_.i64(local_ids) if tagged else None, 0)
 
 
 def _a2a(inp, in_splits, out_splits, group, trailing=()):

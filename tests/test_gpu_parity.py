@@ -343,14 +343,18 @@ def test_fused_step_deterministic_and_sorted():
         Ud, Id = U0.clone(), I0.clone()
         fs = FusedBPRStep(Ud, Id, max_batch=B, opt='adam', reg_weight=0.01)
         fs.step(u, p, n)
-        res.append((Ud.clone(), Id.clone(), fs.ikeys.clone(), fs.iperm.clone()))
+        res.append((Ud.clone(), Id.clone(), fs.keys[:3 * B].clone(), fs.perm[:3 * B].clone(), fs._key_base.value))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # one sort for both tables: [0, B) the user keys, [B, 3B) the item keys carrying the table bit
     keys = res[0][2].to(torch.int64) & 0xFFFFFFFF
-    assert bool((keys[1:] >= keys[:-1]).all())
-    both = torch.cat([p, n])
-    assert torch.equal(both[res[0][3].to(torch.int64)], keys)            # perm is a permutation consistent with keys
-    same = keys[1:] == keys[:-1]
     perm = res[0][3].to(torch.int64)
+    base = res[0][4]
+    assert base >= max(nu, ni) and bool((keys[1:] >= keys[:-1]).all())
+    assert bool((keys[:B] < base).all()) and bool((keys[B:] >= base).all())
+    assert torch.equal(u[perm[:B]], keys[:B])                              # perm is a permutation consistent with keys
+    both = torch.cat([p, n])
+    assert torch.equal(both[perm[B:]], keys[B:] - base)
+    same = keys[1:] == keys[:-1]
     assert bool((perm[1:][same] > perm[:-1][same]).all())                # stable: occurrence order inside a segment
 
 

@@ -23,8 +23,9 @@ def timeit(fn, reps=30):
     for _ in range(reps):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     ts.sort(); return ts[len(ts) // 2], ts[0]
-B_.call('cdr_sort_ids', ctxh, B_.stream(), B_.i64(u), B, None, 0, nu, B_.raw(st.ukeys), B_.raw(st.uperm), B_.raw(st.ws), st.ws_bytes)
-mu = timeit(lambda: st._apply(ctxh, st.ustate, st.ukeys, st.uperm, B, st.GU, B, B, st.out6[4:5]))
-B_.call('cdr_sort_ids', ctxh, B_.stream(), B_.i64(p), B, B_.i64(n), B, ni, B_.raw(st.ikeys), B_.raw(st.iperm), B_.raw(st.ws), st.ws_bytes)
-mi = timeit(lambda: st._apply(ctxh, st.istate, st.ikeys, st.iperm, 2 * B, st.GP, B, B, st.out6[5:6]))
+import ctypes
+B_.call('cdr_sort_ids_two_tables', ctxh, B_.stream(), B_.i64(u), B, nu, B_.i64(p), B, B_.i64(n), B, ni, B_.raw(st.keys), B_.raw(st.perm),
+        ctypes.byref(st._key_base), B_.raw(st.ws), st.ws_bytes)
+mu = timeit(lambda: st._apply(ctxh, st.ustate, st.keys[:B], st.perm[:B], B, st.GU, B, B, st.out6[4:5], 0))
+mi = timeit(lambda: st._apply(ctxh, st.istate, st.keys[B:3 * B], st.perm[B:3 * B], 2 * B, st.GP, B, B, st.out6[5:6], st._key_base.value))
 print(f'{os.environ.get("CDR_LIB_PATH", "default"):24s} apply users median {mu[0]:.4f} min {mu[1]:.4f} ms | items median {mi[0]:.4f} min {mi[1]:.4f} ms', flush=True)
