@@ -1367,3 +1367,28 @@ def test_trainer_rowwise_mode_mf():
     assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=5e-5, what='epoch losses')
     for k, v in model.named_parameters():
         assert_close(v, params[k].detach(), rtol=1e-4, atol=lr * 5e-2, what=k)
+
+
+def test_fullsort_topk_fewer_columns_than_k_left():
+    """A user whose mask leaves fewer than k columns gets the survivors first, then (-inf, -1) padding -- the rows of
+    torch.topk over the masked matrix would carry arbitrary masked columns there."""
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(0)
+    U, D, N, k = 40, 64, 200, 5
+    ue, tab = torch.randn(U, D, device=DEV), torch.randn(N, D, device=DEV)
+    keep = {0: [17, 150], 1: [], 2: [3]}                                # users 0..2 keep 2 / 0 / 1 columns; the rest keep all
+    cols, ptr = [], [0]
+    for u in range(U):
+        if u in keep:
+            c = [j for j in range(1, N) if j not in keep[u]]
+        else:
+            c = [5, 9]
+        cols += c; ptr.append(len(cols))
+    v, i = F_.fullsort_topk(ue, tab, None, k=k, hist_indptr=torch.tensor(ptr, device=DEV), hist_cols=torch.tensor(cols, device=DEV))
+    full = F_.fullsort_scores(ue, tab)
+    for u, kept in keep.items():
+        want = sorted(kept, key=lambda c: -float(full[u, c]))
+        assert i[u].tolist() == want + [-1] * (k - len(want))
+        assert torch.equal(v[u, :len(want)], full[u, want]) and bool(torch.isinf(v[u, len(want):]).all())
+    ref = full.clone(); ref[:, 0] = -float('inf'); ref[:, [5, 9]] = -float('inf')
+    assert torch.equal(v[3:], torch.topk(ref[3:], k, dim=1).values)
