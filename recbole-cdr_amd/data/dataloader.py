@@ -13,6 +13,14 @@ from ..utils import CrossDomainDataLoaderState, InputType
 from .interaction import Interaction
 
 
+def _randperm(n, device, generator):
+    """Epoch shuffle where the data lives: a host permutation of 12 M interactions costs 0.3 s -- ten times the epoch's
+    kernels -- so without an explicit (host) generator it is drawn on the data's own device."""
+    if generator is not None:
+        return torch.randperm(n, generator=generator, device=generator.device).to(device)
+    return torch.randperm(n, device=device)
+
+
 class DomainTrainLoader:
     def __init__(self, inter, uid_field, iid_field, label_field, neg_prefix, train_batch_size, neg_k, input_type,
                  neg_sampler, shuffle=False, generator=None):
@@ -35,7 +43,7 @@ class DomainTrainLoader:
     def __iter__(self):
         if self.shuffle:
             n = len(self.inter)
-            perm = torch.randperm(n, generator=self.generator).to(next(iter(self.inter.values())).device)
+            perm = _randperm(n, next(iter(self.inter.values())).device, self.generator)
             self.inter = self.inter.index_select(perm)
         return self
 
@@ -78,7 +86,7 @@ class OverlapDataloader:
 
     def __iter__(self):
         if self.shuffle:
-            self.ids = self.ids[torch.randperm(self.ids.numel(), generator=self.generator).to(self.ids.device)]
+            self.ids = self.ids[_randperm(self.ids.numel(), self.ids.device, self.generator)]
         return self
 
     def __next__(self):

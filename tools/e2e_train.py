@@ -1,0 +1,63 @@
+"""The whole path at scale, through the reference's own loop: synthetic cross-domain dataset (resident on the device) ->
+four-state loader with the DEVICE negative sampler -> CrossDomainTrainer(optimizer_mode='rowwise') over SOURCE, TARGET and
+OVERLAP epochs (EMCDR-BPR, D=128: FusedBPRStep / FusedMapStep on the model's own tables) -> full-sort evaluation with the
+fused mask + top-k kernel.  Reports wall-clock interactions/s per phase INCLUDING sampling, batching and Python."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import recbole_cdr_amd  # noqa: F401
+from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader, FullSortEvalLoader
+from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+from recbole_cdr_amd.sampler import DeviceNegSampler
+from recbole_cdr_amd.trainer import CrossDomainTrainer
+from recbole_cdr_amd.utils import InputType
+
+dev = 'cuda:0'
+OU, TOI, NI, BATCH = int(os.environ.get('E2E_USERS', 4_000_001)), int(os.environ.get('E2E_ITEMS', 1_000_000)), \
+    int(os.environ.get('E2E_INTER', 12_000_000)), 1 << 20
+t0 = time.time()
+ds = SyntheticCrossDomainDataset(OU=OU, TOU=0, SOU=0, OI=1, TOI=TOI, SOI=TOI, n_source_inter=NI, n_target_inter=NI)
+cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev,
+       'latent_factor_model': 'BPR', 'source_embedding_size': 128, 'target_embedding_size': 128, 'reg_weight': 0.01,
+       'mapping_function': 'linear', 'mlp_hidden_size': [128], 'learning_rate': 1e-3, 'optimizer_mode': 'rowwise',
+       'train_modes': ['SOURCE', 'TARGET', 'OVERLAP'], 'epoch_num': ['2', '2', '2'], 'source_split': False, 'eval_step': 0,
+       'epochs': 2, 'topk': [10], 'valid_metric': 'Recall@10'}
+torch.manual_seed(2022)
+model = EMCDR(cfg, ds).to(dev)
+dt = lambda a: torch.from_numpy(a.copy()).to(dev)
+held = 20_000                                           # target interactions held out for the evaluation
+t_tr, t_te = ds.t_pairs[held:], ds.t_pairs[:held]
+s_smp, t_smp = DeviceNegSampler(ds, 'source', ds.s_pairs, dev), DeviceNegSampler(ds, 'target', ds.t_pairs, dev)
+train = CrossDomainDataloader(
+    DomainTrainLoader({'source_user_id': dt(ds.s_pairs[:, 0]), 'source_item_id': dt(ds.s_pairs[:, 1])}, 'source_user_id', 'source_item_id',
+                      'source_label', 'neg_', BATCH, 1, InputType.PAIRWISE, s_smp, shuffle=True),
+    DomainTrainLoader({'target_user_id': dt(t_tr[:, 0]), 'target_item_id': dt(t_tr[:, 1])}, 'target_user_id', 'target_item_id',
+                      'target_label', 'neg_', BATCH, 1, InputType.PAIRWISE, t_smp, shuffle=True),
+    OverlapDataloader(OU, 65536, device=dev, shuffle=True))
+print(f'setup (host-side synthetic data, CSR for the sampler, tables): {time.time() - t0:.1f} s; '
+      f'{len(ds.s_pairs)} source / {len(t_tr)} target interactions, {OU - 1} overlapped users, {TOI} items per domain', flush=True)
+trainer = CrossDomainTrainer(cfg, model)
+orig, log = trainer._train_epoch, []
+def timed(data, e):
+    torch.cuda.synchronize(); t = time.time()
+    v = orig(data, e)
+    torch.cuda.synchronize(); log.append((time.time() - t, v))
+    return v
+trainer._train_epoch = timed
+trainer.fit(train)
+rows = [('SOURCE', len(ds.s_pairs))] * 2 + [('TARGET', len(t_tr))] * 2 + [('OVERLAP', OU)] * 2   # first epoch of a phase
+for (phase, n), (sec, loss) in zip(rows, log):                                                  # also builds its step objects
+    print(f'{phase:8s} epoch: {sec * 1e3:9.1f} ms wall for {n} rows = {n / sec / 1e6:8.1f} M rows/s (epoch loss sum {loss:.4f})', flush=True)
+# evaluation in the target domain after the OVERLAP phase (users mapped through the learned mapping): fused mask + top-10
+te_users = np.unique(t_te[:, 0])[:4096]
+t_te = t_te[np.isin(t_te[:, 0], te_users)]
+hist = t_tr[np.isin(t_tr[:, 0], te_users)]
+loader = FullSortEvalLoader('target_user_id', t_te, hist, ds.num_overlap_item + ds.num_target_only_item, 1024 * (1 + TOI), dev)
+for attempt in ('first call (allocates the workspaces)', 'second call'):
+    torch.cuda.synchronize(); t = time.time()
+    res = trainer.evaluate(loader)
+    torch.cuda.synchronize(); sec = time.time() - t
+    print(f'evaluate, {attempt}: {len(te_users)} users x {1 + TOI} items in {sec * 1e3:.1f} ms = '
+          f'{len(te_users) * (1 + TOI) / sec / 1e9:.1f} G items/s wall; recall@10 {res["recall@10"]:.5f}', flush=True)
