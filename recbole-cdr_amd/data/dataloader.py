@@ -173,11 +173,19 @@ class FullSortEvalLoader:
         import numpy as np
         self.uid_field, self.device = uid_field, device
         self.step = max(eval_batch_size // item_num, 1)
-        ev = np.unique(np.asarray(eval_pairs, dtype=np.int64), axis=0)
+        ev = np.unique(np.asarray(eval_pairs, dtype=np.int64), axis=0)                 # sorted by (user, item)
         hi = np.unique(np.asarray(history_pairs, dtype=np.int64), axis=0) if len(history_pairs) else np.zeros((0, 2), np.int64)
         self.users = np.unique(ev[:, 0])
-        self._ev = (torch.from_numpy(ev[:, 0].copy()).to(device), torch.from_numpy(ev[:, 1].copy()).to(device))
-        self._hi = (torch.from_numpy(hi[:, 0].copy()).to(device), torch.from_numpy(hi[:, 1].copy()).to(device))
+        # both pair lists are sorted by user, the batches are runs of consecutive evaluated users: every batch owns ONE
+        # contiguous slice of each list (O(batch) per batch; masking all pairs per batch was quadratic in the eval set)
+        hi = hi[np.isin(hi[:, 0], self.users)] if len(hi) else hi
+        starts = self.users[::self.step]
+        self._ev_ptr = np.append(np.searchsorted(ev[:, 0], starts, side='left'), len(ev))
+        self._hi_ptr = np.append(np.searchsorted(hi[:, 0], starts, side='left'), len(hi))
+        rank = np.searchsorted(self.users, ev[:, 0])                                   # position of each pair's user among the evaluated users
+        hrank = np.searchsorted(self.users, hi[:, 0]) if len(hi) else np.zeros(0, np.int64)
+        self._ev = (torch.from_numpy(rank % self.step).to(device), torch.from_numpy(ev[:, 1].copy()).to(device))
+        self._hi = (torch.from_numpy(hrank % self.step).to(device), torch.from_numpy(hi[:, 1].copy()).to(device))
         if revoke is not None:
             from .remap import revoke_map
             self._ev = (self._ev[0], revoke_map(self._ev[1], *revoke))
@@ -188,14 +196,8 @@ class FullSortEvalLoader:
         return (len(self.users) + self.step - 1) // self.step
 
     def __iter__(self):
-        n_user_ids = int(self._users_t.max().item()) + 1 if self._users_t.numel() else 1
         for b in range(len(self)):
             us = self._users_t[b * self.step:(b + 1) * self.step]
-            row_of = torch.full((n_user_ids,), -1, device=self.device, dtype=torch.int64)
-            row_of[us] = torch.arange(us.numel(), device=self.device)
-            pm = row_of[self._ev[0].clamp(max=n_user_ids - 1)] >= 0
-            pm &= self._ev[0] < n_user_ids
-            hm = (self._hi[0] < n_user_ids)
-            hm &= row_of[self._hi[0].clamp(max=n_user_ids - 1)] >= 0
-            yield (Interaction({self.uid_field: us}), (row_of[self._hi[0][hm]], self._hi[1][hm]),
-                   row_of[self._ev[0][pm]], self._ev[1][pm])
+            e0, e1, h0, h1 = self._ev_ptr[b], self._ev_ptr[b + 1], self._hi_ptr[b], self._hi_ptr[b + 1]
+            yield (Interaction({self.uid_field: us}), (self._hi[0][h0:h1], self._hi[1][h0:h1]),
+                   self._ev[0][e0:e1], self._ev[1][e0:e1])

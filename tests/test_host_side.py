@@ -157,3 +157,25 @@ def test_evaluate_topk_path_equals_full_matrix_path():
     assert set(a) == set(b) and a['recall@10'] > 0
     for k in a:
         assert abs(a[k] - b[k]) < 1e-7, (k, a[k], b[k])
+
+
+def test_full_sort_eval_loader_batches():
+    """Every batch of FullSortEvalLoader carries exactly the positives / history pairs of its own users, as rows relative
+    to the batch (recbole FullSortEvalDataLoader's (interaction, history_index, positive_u, positive_i) contract)."""
+    from recbole_cdr_amd.data import FullSortEvalLoader
+    rng = np.random.RandomState(1)
+    ev = np.stack([rng.randint(1, 60, 300), rng.randint(1, 40, 300)], 1)
+    hi = np.stack([rng.randint(1, 80, 900), rng.randint(1, 40, 900)], 1)          # includes users that are not evaluated
+    loader = FullSortEvalLoader('uid', ev, hi, item_num=40, eval_batch_size=40 * 7, device='cpu')
+    assert loader.step == 7
+    ev_set, hi_set = {tuple(p) for p in ev.tolist()}, {tuple(p) for p in hi.tolist()}
+    users_seen = []
+    for inter, (hr, hc), pu, pi in loader:
+        us = inter['uid'].tolist()
+        users_seen += us
+        got_pos = {(us[r], c) for r, c in zip(pu.tolist(), pi.tolist())}
+        got_hist = {(us[r], c) for r, c in zip(hr.tolist(), hc.tolist())}
+        assert got_pos == {p for p in ev_set if p[0] in us}
+        assert got_hist == {p for p in hi_set if p[0] in us}
+    assert users_seen == sorted({p[0] for p in ev_set})
+    assert len(loader) == (len(users_seen) + 6) // 7
