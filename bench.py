@@ -408,9 +408,22 @@ def run_model_workload(args, world, rank, dev):
         rows_per_step = 2 * S * (1 + k)
 
     from recbole_cdr_amd.graph_step import GraphedTrainStep
-    graphed = GraphedTrainStep(model, opt, batches[0]) if not args.no_graph else None
+    sdp = None
+    if world > 1:
+        # N > 1: data parallel, every rank its own batches, ONE reduce-scatter + ONE all-gather of the flat parameter buffer
+        # per step and the dense Adam sweep (the largest cost of these steps) split over the ranks (dp.ShardedDataParallel)
+        from recbole_cdr_amd.dp import ShardedDataParallel
+        rng = np.random.RandomState(2022 + rank)
+        if pairwise:
+            batches = [ds.pairwise_batch('source', S, k, rng, dev) for _ in range(4)]
+        else:
+            batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
+        sdp = ShardedDataParallel(model, lr=1e-3)
+    graphed = GraphedTrainStep(model, opt, batches[0]) if (not args.no_graph and sdp is None) else None
 
     def one_step(i):
+        if sdp is not None:
+            return sdp.step(batches[i % 4])
         if graphed is not None:
             return graphed.step(batches[i % 4])       # one hipGraph replay per step (see graph_step.py)
         opt.zero_grad(set_to_none=True)
@@ -431,7 +444,7 @@ def run_model_workload(args, world, rank, dev):
     result = {'metric': 'training interactions/sec', 'value': rows_per_step * args.steps * world / dt, 'unit': 'interactions/s',
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-              'config': {'workload': name + ', drop-in autograd + exact dense Adam' + ('' if args.no_graph else ', step replayed as one hipGraph'),
+              'config': {'workload': name + ', drop-in autograd + exact dense Adam' + (', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
                          'rows_per_step': rows_per_step},
               'final_loss': float(loss.sum())}
     if rank == 0 and not args.no_cpu_baseline:

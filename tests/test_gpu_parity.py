@@ -1392,3 +1392,125 @@ def test_fullsort_topk_fewer_columns_than_k_left():
         assert torch.equal(v[u, :len(want)], full[u, want]) and bool(torch.isinf(v[u, len(want):]).all())
     ref = full.clone(); ref[:, 0] = -float('inf'); ref[:, [5, 9]] = -float('inf')
     assert torch.equal(v[3:], torch.topk(ref[3:], k, dim=1).values)
+
+
+def _sdp_models(kind, dev):
+    """Small model + per-step batch maker for the sharded-data-parallel tests (same seeds on every rank)."""
+    from oracle.common import IdSpace
+    ids = IdSpace(OU=12, TOU=9, SOU=11, OI=1, TOI=25, SOI=21)
+    torch.manual_seed(4)
+    if kind == 'conet':
+        from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+        cfg = base_config(dev, embedding_size=16, reg_weight=0.01, mlp_hidden_size=[16, 8])
+        model = CoNet(cfg, FakeDataset(ids)).to(dev)
+    else:
+        from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+        cfg = base_config(dev, latent_factor_model='BPR', source_embedding_size=16, target_embedding_size=16, reg_weight=0.01,
+                          mapping_function='non_linear', mlp_hidden_size=[12])
+        model = EMCDR(cfg, FakeDataset(ids)).to(dev)
+
+    def batch(step, rank):
+        g = torch.Generator(); g.manual_seed(1000 * step + rank)
+        r = lambda lo, hi, n: torch.randint(lo, hi, (n,), generator=g)
+        src_i = lambda n: torch.where(torch.rand(n, generator=g) < 0.5, r(1, ids.OI, n) if ids.OI > 1 else r(ids.OI + ids.TOI, ids.total_num_items, n),
+                                      r(ids.OI + ids.TOI, ids.total_num_items, n))
+        n = 24 + rank                                        # ragged: every rank its own batch size
+        if kind == 'conet':
+            return {'source_user_id': r(1, ids.OU, n), 'source_item_id': src_i(n), 'source_label': (torch.rand(n, generator=g) < 0.5).float(),
+                    'target_user_id': r(1, ids.OU + ids.TOU, n), 'target_item_id': r(1, ids.OI + ids.TOI, n),
+                    'target_label': (torch.rand(n, generator=g) < 0.5).float()}
+        if step < 2:
+            return {'source_user_id': r(1, ids.OU, n), 'source_item_id': src_i(n), 'neg_source_item_id': src_i(n)}
+        return {'overlap': r(1, ids.OU, n).reshape(-1, 1)}
+    phase = (lambda step: None) if kind == 'conet' else (lambda step: 'SOURCE' if step < 2 else 'OVERLAP')
+    return model, batch, phase
+
+
+def _sdp_worker(rank, world, port, kind, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dp import ShardedDataParallel
+        torch.cuda.set_device(0)
+        model, batch, phase = _sdp_models(kind, DEV)
+        sdp = ShardedDataParallel(model, lr=0.01)
+        losses = []
+        for step in range(4):
+            if phase(step):
+                model.set_phase(phase(step))
+            losses.append(float(sdp.step({k: v.to(DEV) for k, v in batch(step, rank).items()})))
+        q.put((rank, {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}, losses))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['conet', 'emcdr'])
+def test_sharded_data_parallel_matches_mean_gradient_adam(kind):
+    """dp.ShardedDataParallel over 3 ranks (sharing cuda:0, gloo transport): parameters after 4 steps == one process that
+    averages the three per-rank gradients and takes torch.optim.Adam steps (params without a gradient in a phase are skipped:
+    EMCDR's SOURCE -> OVERLAP switch); every rank ends with the same replica; per-rank losses match."""
+    import socket
+    import torch.multiprocessing as mp
+    world = 3
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sdp_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    model, batch, phase = _sdp_models(kind, DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    for step in range(4):
+        if phase(step):
+            model.set_phase(phase(step))
+        grads = {}
+        for r in range(world):
+            model.zero_grad(set_to_none=True)
+            losses = model.calculate_loss({k: v.to(DEV) for k, v in batch(step, r).items()})
+            loss = (sum(losses) if isinstance(losses, tuple) else losses).sum()
+            loss.backward()
+            lv = float(loss.detach())
+            assert abs(res[r][2][step] - lv) <= 2e-5 * abs(lv), (step, r, res[r][2][step], lv)
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    grads[k] = grads.get(k, 0) + p.grad.detach().clone() / world
+        model.zero_grad(set_to_none=True)
+        for k, p in model.named_parameters():
+            if k in grads:
+                p.grad = grads[k]
+        opt.step()
+    for r in range(world):
+        for k, p in model.named_parameters():
+            assert_close(torch.from_numpy(res[r][1][k]).to(DEV), p.detach(), rtol=1e-4, atol=0.01 * 5e-2, what=f'{k} rank {r}')
+            np.testing.assert_array_equal(res[r][1][k], res[0][1][k])
+
+
+def test_sharded_data_parallel_world1_rccl_equals_dense_adam():
+    """The RCCL code path of dp.ShardedDataParallel (reduce_scatter_tensor + in-place all_gather_into_tensor) on a 1-rank
+    group: identical to the plain drop-in loop with the native dense Adam."""
+    import socket
+    import torch.distributed as dist
+    from recbole_cdr_amd.dp import ShardedDataParallel
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        model_a, batch, _ = _sdp_models('conet', DEV)
+        model_b, _, _ = _sdp_models('conet', DEV)
+        sdp = ShardedDataParallel(model_a, lr=0.01)
+        opt = DenseAdam(model_b.parameters(), lr=0.01)
+        for step in range(3):
+            b = {k: v.to(DEV) for k, v in batch(step, 0).items()}
+            la = sdp.step(b)
+            opt.zero_grad()
+            lb = sum(model_b.calculate_loss(b)).sum() if isinstance(model_b.calculate_loss(b), tuple) else model_b.calculate_loss(b).sum()
+            lb.backward(); opt.step()
+            assert_close(la, lb.detach(), rtol=1e-6, what=f'loss step {step}')
+        for (k, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+            assert_close(pa.detach(), pb.detach(), rtol=1e-5, atol=0.01 * 1e-2, what=k)
+    finally:
+        dist.destroy_process_group()
