@@ -23,8 +23,9 @@ from . import binding as B_
 
 
 class ShardedDataParallel:
-    def __init__(self, model, group=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, group=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adam_impl=None):
         self.model, self.group = model, group
+        self.adam_impl = adam_impl       # CPU (gloo) tests inject stand-in arithmetic; the product default is libcdrhip only
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -74,7 +75,9 @@ class ShardedDataParallel:
             a, b = max(self.offsets[i], self.lo), min(self.offsets[i] + self.params[i].numel(), self.hi)
             if a < b:
                 segs.append((a - self.lo, b - a, i))
-        if segs:
+        if segs and self.adam_impl is not None:
+            self.adam_impl(self, segs)
+        elif segs:
             n = len(segs)
             arr = lambda xs: (ctypes.c_void_p * n)(*[x.value for x in xs])
             sl = lambda t: [B_.f32(t[a:a + m]) for a, m, _ in segs]

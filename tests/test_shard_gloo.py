@@ -204,3 +204,91 @@ def test_pipelined_two_domains_world3():
             assert abs(lr_ - float(loss)) <= 1e-5 * abs(float(loss))
             torch.testing.assert_close(torch.from_numpy(Ur), U[r::world], rtol=2e-5, atol=1e-6)
             torch.testing.assert_close(torch.from_numpy(Ir), I[r::world], rtol=2e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dp.ShardedDataParallel (flat parameter buffer, reduce-scatter + all-gather, sharded Adam) on CPU: a pure-torch stand-in
+# model and injected Adam arithmetic, so the flattening / slicing / per-parameter step logic runs under gloo here; the
+# native kernels run the same class in tests/test_gpu_parity.py::test_sharded_data_parallel_*.
+class _TinyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator(); g.manual_seed(0)
+        self.a = torch.nn.Parameter(torch.randn(37, 5, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(11, generator=g))
+        self.c = torch.nn.Parameter(torch.randn(23, 3, generator=g))       # gets no gradient in phase 0
+        self.phase = 0
+
+    def calculate_loss(self, x):
+        loss = ((self.a[x['i']] * x['v']).sum(1) - self.b[x['j']]).pow(2).mean()
+        if self.phase:
+            loss = loss + self.c[x['k']].pow(2).sum()
+        return loss
+
+
+def _torch_adam_segments(sdp, segs):
+    b1, b2 = sdp.betas
+    for off, n, i in segs:
+        sdp.steps[i] += 1
+        t = int(sdp.steps[i])
+        g = sdp.gshard[off:off + n]
+        m, v, p = sdp.exp_avg[off:off + n], sdp.exp_avg_sq[off:off + n], sdp.pshard[off:off + n]
+        m.mul_(b1).add_(g, alpha=1 - b1); v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.sub_((sdp.lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + sdp.eps))
+
+
+def _tiny_batch(step, rank):
+    g = torch.Generator(); g.manual_seed(77 * step + rank)
+    n = 9 + rank
+    return {'i': torch.randint(0, 37, (n,), generator=g), 'j': torch.randint(0, 11, (n,), generator=g),
+            'k': torch.randint(0, 23, (n,), generator=g), 'v': torch.randn(n, 5, generator=g)}
+
+
+def _worker_dp(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dp import ShardedDataParallel
+        model = _TinyModel()
+        sdp = ShardedDataParallel(model, lr=0.05, adam_impl=_torch_adam_segments)
+        for step in range(5):
+            model.phase = int(step >= 2)
+            sdp.step(_tiny_batch(step, rank))
+        q.put((rank, {k: v.detach().numpy().copy() for k, v in model.named_parameters()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_data_parallel_gloo(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dp, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _TinyModel()
+    opt = torch.optim.Adam(ref.parameters(), lr=0.05)
+    for step in range(5):
+        ref.phase = int(step >= 2)
+        acc = {}
+        for r in range(world):
+            ref.zero_grad(set_to_none=True)
+            ref.calculate_loss(_tiny_batch(step, r)).backward()
+            for k, p in ref.named_parameters():
+                if p.grad is not None:
+                    acc[k] = acc.get(k, 0) + p.grad.clone() / world
+        ref.zero_grad(set_to_none=True)
+        for k, p in ref.named_parameters():
+            if k in acc:
+                p.grad = acc[k]
+        opt.step()
+    for r in range(world):
+        for k, p in ref.named_parameters():
+            torch.testing.assert_close(torch.from_numpy(res[r][1][k]), p.detach(), rtol=1e-5, atol=1e-6)
