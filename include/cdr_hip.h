@@ -312,6 +312,12 @@ int cdr_sort_ids_two_tables(cdr_ctx* ctx, void* stream, const int64_t* ids_a, in
 int cdr_neg_sample_uniform(void* stream, const int64_t* users, int64_t S, int k, int64_t lo0, int64_t hi0,
                            int64_t lo1, int64_t hi1, const int64_t* used_indptr, const int64_t* used_indices,
                            uint64_t seed, int64_t* out, int* fail_flag);
+/* popularity-biased variant (crossdomain_sampler.py:66-114, distribution == 'popularity'): candidates drawn through a Walker
+ * alias table over the n_keys distinct items of the sampler's interactions (keys / prob / alias as the reference builds
+ * them; alias holds item ids), then the same rejection and layout. */
+int cdr_neg_sample_alias(void* stream, const int64_t* users, int64_t S, int k, const int64_t* keys, const float* prob,
+                         const int64_t* alias, int64_t n_keys, const int64_t* used_indptr, const int64_t* used_indices,
+                         uint64_t seed, int64_t* out, int* fail_flag);
 
 /* ---- owner routing for row-sharded tables (row r lives on rank r % world) -- index plumbing of shard.py --------
  * cdr_route_by_owner: stable counting sort of the ids (ids1 appended after ids0) by owner = id % world.

@@ -117,6 +117,7 @@ _SIGNATURES = {
     'cdr_inc_i64': [_c_ptr, _c_ptr],
     'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32],
+    'cdr_neg_sample_alias': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64, _c_ptr, _c_ptr],
     'cdr_neg_sample_uniform': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64,
                                _c_ptr, _c_ptr],
     'cdr_overlap_remap': [ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],

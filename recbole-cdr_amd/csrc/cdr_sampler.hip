@@ -47,7 +47,52 @@ __global__ __launch_bounds__(kBlock) void neg_sample_kernel(const int64_t* __res
     }
 }
 
+// Popularity-biased candidates (crossdomain_sampler.py:66-114): Walker alias table over the distinct items of the sampler's
+// interactions, built on the host exactly as the reference does; a draw is "uniform column c, uniform p: p < prob[c] ? keys[c] :
+// alias[c]".  Same rejection against the user's used items, same k-major layout.
+__global__ __launch_bounds__(kBlock) void neg_sample_alias_kernel(const int64_t* __restrict__ users, int64_t S, int k,
+                                                                  const int64_t* __restrict__ keys, const float* __restrict__ prob,
+                                                                  const int64_t* __restrict__ alias, int64_t n_keys,
+                                                                  const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+                                                                  uint64_t seed, int max_tries, int64_t* __restrict__ out,
+                                                                  int* __restrict__ fail_flag) {
+    const int64_t total = S * (int64_t)k, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t u = users[e % S];
+        const int64_t b = indptr ? indptr[u] : 0, en = indptr ? indptr[u + 1] : 0;
+        int64_t pick = -1;
+        for (int t = 0; t < max_tries; ++t) {
+            const uint64_t r = mix64(seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)t * 0xD1B54A32D192ED03ull);
+            const int64_t c = (int64_t)__umul64hi(r, (uint64_t)n_keys);
+            const float p = (float)(mix64(r ^ 0xA5A5A5A5A5A5A5A5ull) >> 40) * (1.0f / 16777216.0f);       // 24-bit uniform in [0,1)
+            const int64_t al = alias[c];
+            const int64_t id = (prob[c] > p || al < 0) ? keys[c] : al;      // al < 0: a column the construction left whole
+            int64_t l = b, h = en;
+            while (l < h) {
+                const int64_t mid = (l + h) >> 1;
+                if (indices[mid] < id) l = mid + 1; else h = mid;
+            }
+            if (!(l < en && indices[l] == id)) { pick = id; break; }
+        }
+        if (pick < 0) { pick = keys[0]; if (fail_flag) atomicExch(fail_flag, 1); }
+        out[e] = pick;
+    }
+}
+
 }  // namespace
+
+extern "C" int cdr_neg_sample_alias(void* stream, const int64_t* users, int64_t S, int k, const int64_t* keys, const float* prob,
+                                    const int64_t* alias, int64_t n_keys, const int64_t* used_indptr, const int64_t* used_indices,
+                                    uint64_t seed, int64_t* out, int* fail_flag) {
+    CDR_CHECK_ARG(users && out && keys && prob && alias && S > 0 && k > 0 && n_keys > 0);
+    CDR_CHECK_ARG((used_indptr == nullptr) == (used_indices == nullptr));
+    int64_t g = (S * k + kBlock - 1) / kBlock;
+    if (g > CDR_NUM_CU * 8) g = CDR_NUM_CU * 8;
+    neg_sample_alias_kernel<<<dim3((unsigned)g), dim3(kBlock), 0, (hipStream_t)stream>>>(users, S, k, keys, prob, alias, n_keys, used_indptr,
+                                                                                       used_indices, seed, 64, out, fail_flag);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
 
 extern "C" int cdr_neg_sample_uniform(void* stream, const int64_t* users, int64_t S, int k, int64_t lo0, int64_t hi0,
                                       int64_t lo1, int64_t hi1, const int64_t* used_indptr, const int64_t* used_indices,

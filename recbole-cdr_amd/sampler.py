@@ -13,7 +13,7 @@ class DeviceNegSampler:
     domain='target': candidates [1, OI+TOI)                        (recbole Sampler over the target dataset's items)
     ``used_pairs``: [n, 2] (user, item) interactions whose items must never be returned for that user."""
 
-    def __init__(self, dataset, domain, used_pairs, device, seed=2022):
+    def __init__(self, dataset, domain, used_pairs, device, seed=2022, distribution='uniform'):
         OI, TOI = dataset.num_overlap_item, dataset.num_target_only_item
         total_i, total_u = dataset.num_total_item, dataset.num_total_user
         if domain == 'source':
@@ -31,12 +31,26 @@ class DeviceNegSampler:
         self.indices = torch.from_numpy(pairs[:, 1].copy()).to(device)
         self.fail = torch.zeros(1, device=device, dtype=torch.int32)
         self.seed, self.calls, self.device = int(seed), 0, device
+        if distribution not in ('uniform', 'popularity'):
+            raise NotImplementedError(f'The sampling distribution [{distribution}] is not implemented.')
+        self.distribution = distribution
+        if distribution == 'popularity':
+            keys, prob, alias = build_alias_table(np.asarray(used_pairs, dtype=np.int64)[:, 1])
+            self.keys = torch.from_numpy(keys).to(device)
+            self.prob = torch.from_numpy(prob.astype(np.float32)).to(device)
+            self.alias = torch.from_numpy(alias).to(device)
 
     def sample_by_user_ids(self, user_ids, item_ids, num):
         users = user_ids.to(self.device).contiguous().to(torch.int64)
         S = users.numel()
         out = torch.empty(S * num, device=self.device, dtype=torch.int64)
         self.calls += 1
+        seed = (self.seed * 0x9E3779B1 + self.calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        if self.distribution == 'popularity':
+            B_.call('cdr_neg_sample_alias', B_.stream(), B_.i64(users), S, int(num), B_.i64(self.keys), B_.f32(self.prob),
+                    B_.i64(self.alias), self.keys.numel(), B_.i64(self.indptr), B_.i64(self.indices), seed, B_.i64(out),
+                    B_.raw(self.fail))
+            return out
         lo0, hi0, lo1, hi1 = self.ranges
         B_.call('cdr_neg_sample_uniform', B_.stream(), B_.i64(users), S, int(num), lo0, hi0, lo1, hi1, B_.i64(self.indptr),
                 B_.i64(self.indices), (self.seed * 0x9E3779B1 + self.calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF, B_.i64(out),
@@ -44,3 +58,26 @@ class DeviceNegSampler:
         return out
 
     __call__ = sample_by_user_ids
+
+
+def build_alias_table(candidates):
+    """Walker alias table over the item ids of the sampler's interactions, as crossdomain_sampler.py:66-94 builds it
+    (probabilities scaled to mean 1, large / small queues served first-in first-out).  -> (keys [n] int64 in first-occurrence
+    order like ``Counter``, prob [n] float64, alias [n] int64 item ids; an unassigned alias stays -1 and is never drawn
+    because its prob is 1)."""
+    from collections import Counter, deque
+    cnt = Counter(np.asarray(candidates).tolist())
+    keys = np.fromiter(cnt.keys(), dtype=np.int64, count=len(cnt))
+    prob = np.fromiter(cnt.values(), dtype=np.float64, count=len(cnt)) / len(candidates) * len(cnt)
+    alias = np.full(len(cnt), -1, dtype=np.int64)
+    large = deque(np.nonzero(prob > 1)[0].tolist())
+    small = deque(np.nonzero(prob < 1)[0].tolist())
+    while large and small:
+        l, s = large.popleft(), small.popleft()
+        alias[s] = keys[l]
+        prob[l] -= 1 - prob[s]
+        if prob[l] < 1:
+            small.append(l)
+        elif prob[l] > 1:
+            large.append(l)
+    return keys, prob, alias

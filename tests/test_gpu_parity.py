@@ -1514,3 +1514,40 @@ def test_sharded_data_parallel_world1_rccl_equals_dense_adam():
             assert_close(pa.detach(), pb.detach(), rtol=1e-5, atol=0.01 * 1e-2, what=k)
     finally:
         dist.destroy_process_group()
+
+
+def test_device_sampler_popularity_distribution():
+    """distribution='popularity' (crossdomain_sampler.py:66-114): negatives follow the item frequencies of the sampler's
+    interactions (alias table), never hit the user's own items, come out k-major, and are reproducible per seed."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.sampler import DeviceNegSampler
+    ids = IdSpace(OU=50, TOU=30, SOU=0, OI=1, TOI=120, SOI=5)
+    rng = np.random.RandomState(2)
+    items = rng.zipf(1.4, 6000) % 100 + 1                                     # skewed popularity over items 1..100
+    users = rng.randint(1, 80, 6000)
+    pairs = np.unique(np.stack([users, items], 1), axis=0)
+    ds = FakeDataset(ids)
+    smp = DeviceNegSampler(ds, 'target', pairs, DEV, seed=11, distribution='popularity')
+    S, k = 40000, 3
+    u = torch.from_numpy(rng.randint(1, 80, S)).to(DEV)
+    neg = smp(u, None, k)
+    assert neg.shape == (S * k,) and int(smp.fail.item()) == 0
+    # k-major + rejection: slot m of positive j is neg[j + m*S] and is never one of user j's items
+    used = {(int(a), int(b)) for a, b in pairs}
+    un, nn_ = u.cpu().numpy(), neg.cpu().numpy()
+    assert not any((int(un[j % S]), int(nn_[j])) in used for j in range(0, S * k, 97))
+    # frequencies: compare with the popularity restricted to what each user may receive, aggregated over users
+    cnt = np.bincount(pairs[:, 1], minlength=ids.total_num_items).astype(np.float64)
+    pop = cnt / cnt.sum()
+    expect = np.zeros_like(pop)
+    for usr in range(1, 80):
+        mask = np.ones_like(pop); mask[pairs[pairs[:, 0] == usr, 1]] = 0
+        q = pop * mask
+        expect += (un == usr).sum() * k * q / q.sum()
+    got = np.bincount(nn_, minlength=ids.total_num_items).astype(np.float64)
+    big = expect > 200
+    assert big.sum() >= 10
+    assert np.abs(got[big] - expect[big]).max() / expect[big].max() < 0.05 and np.all(np.abs(got[big] / expect[big] - 1) < 0.15)
+    assert got[cnt == 0].sum() == 0                                          # items nobody interacted with are never drawn
+    smp2 = DeviceNegSampler(ds, 'target', pairs, DEV, seed=11, distribution='popularity')
+    assert torch.equal(smp2(u, None, k), neg)

@@ -179,3 +179,41 @@ def test_full_sort_eval_loader_batches():
         assert got_hist == {p for p in hi_set if p[0] in us}
     assert users_seen == sorted({p[0] for p in ev_set})
     assert len(loader) == (len(users_seen) + 6) // 7
+
+
+def test_alias_table_matches_reference_construction():
+    """build_alias_table == the reference's _build_alias_table (crossdomain_sampler.py:66-94) restated with its dicts and lists:
+    same keys, same probabilities, same aliases; and the table reproduces the item frequencies exactly."""
+    from collections import Counter
+    from recbole_cdr_amd.sampler import build_alias_table
+    rng = np.random.RandomState(0)
+    cand = (rng.zipf(1.3, 5000) % 97 + 3).tolist()
+    prob = dict(Counter(cand)); alias = prob.copy()
+    large_q, small_q = [], []
+    for i in prob:
+        alias[i] = -1
+        prob[i] = prob[i] / len(cand) * len(prob)
+        if prob[i] > 1:
+            large_q.append(i)
+        elif prob[i] < 1:
+            small_q.append(i)
+    while len(large_q) != 0 and len(small_q) != 0:
+        l = large_q.pop(0); s = small_q.pop(0)
+        alias[s] = l
+        prob[l] = prob[l] - (1 - prob[s])
+        if prob[l] < 1:
+            small_q.append(l)
+        elif prob[l] > 1:
+            large_q.append(l)
+    keys, p, a = build_alias_table(np.array(cand))
+    assert keys.tolist() == list(prob.keys())
+    np.testing.assert_allclose(p, np.array(list(prob.values())), rtol=1e-12)
+    assert a.tolist() == [alias[k] for k in prob]
+    # mass of item x = (prob[x] + sum over columns c with alias[c] == x of (1 - prob[c])) / n  must be its frequency
+    mass = {int(k): min(pv, 1.0) for k, pv in zip(keys, p)}
+    for k, pv, al in zip(keys, p, a):
+        if al >= 0:
+            mass[int(al)] += 1.0 - min(pv, 1.0)
+    cnt = Counter(cand)
+    for k in cnt:
+        assert abs(mass[k] / len(keys) - cnt[k] / len(cand)) < 1e-9
