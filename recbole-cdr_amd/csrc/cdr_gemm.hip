@@ -319,13 +319,18 @@ __device__ __forceinline__ bool topk_masked(const topk_mask& mk, int64_t u, int 
 // e / ec: this lane's list entry (lanes >= k carry -inf / -1 and never change).  Returns the new k-th value.
 __device__ __forceinline__ float topk_offer(float v, int col, float thr, float& e, int& ec, int k, const topk_mask& mk, int64_t u) {
     const int lane = threadIdx.x & 63;
-    unsigned long long m = __ballot(v > thr);
+    bool pass = v > thr;
+    if (__ballot(pass) == 0) return thr;
+    // every surviving lane tests ITS column against the mask at the same time (64 binary searches in flight): testing them one
+    // after the other inside the insertion loop put ~2.5 us of dependent loads on each of the k ln(n/k) survivors of a wave
+    if (pass && (mk.indptr || mk.exclude_col0)) pass = !topk_masked(mk, u, col);
+    unsigned long long m = __ballot(pass);
     while (m) {
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
         const float cv = __shfl(v, l);
         const int cc = __shfl(col, l);
-        if (!(cv > thr) || topk_masked(mk, u, cc)) continue;                  // wave-uniform
+        if (!(cv > thr)) continue;                                             // wave-uniform: the k-th value rose meanwhile
         const int pos = __popcll(__ballot(lane < k && e >= cv));                // entries that stay in front (ties: first seen)
         const float up = __shfl_up(e, 1);
         const int upc = __shfl_up(ec, 1);
@@ -598,23 +603,29 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     }
 }
 
-// Final lists: one wave per user merges the P partial lists (already masked).
+// Merge of partial lists (already masked): one wave per (user, group of `gsz` producers).  With `out_pv` set the group's list
+// goes to partial list `group` of the next level; the last level (one group) writes the final [U, k] output.
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pc, int64_t P,
-                                                         int64_t U, int k, float* __restrict__ out_v, int64_t* __restrict__ out_c) {
+                                                         int64_t U, int k, int64_t gsz, float* __restrict__ out_pv,
+                                                         int* __restrict__ out_pc, float* __restrict__ out_v,
+                                                         int64_t* __restrict__ out_c) {
     const int lane = threadIdx.x & 63;
-    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= U) return;
+    const int64_t groups = (P + gsz - 1) / gsz;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= U * groups) return;
+    const int64_t u = w % U, grp = w / U;
+    const int64_t p0 = grp * gsz, p1 = p0 + gsz < P ? p0 + gsz : P;
     float e = -INFINITY, thr = -INFINITY;
     int ec = -1;
     const topk_mask none{nullptr, nullptr, 0};
-    const int64_t total = P * k;                                     // candidate i = entry i % k of producer i / k
+    const int64_t total = (p1 - p0) * k;                             // candidate i = entry i % k of producer p0 + i / k
     for (int64_t i0 = 0; i0 < total; i0 += 64 * 8) {
         float v[8];
         int c[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t i = i0 + 64 * j + lane;
-            const int64_t o = ((i / k) * U + u) * k + i % k;
+            const int64_t o = ((p0 + i / k) * U + u) * k + i % k;
             v[j] = i < total ? pv[o] : -INFINITY;
             c[j] = i < total ? pc[o] : -1;
         }
@@ -622,8 +633,13 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         for (int j = 0; j < 8; ++j) thr = topk_offer(v[j], c[j], thr, e, ec, k, none, u);
     }
     if (lane < k) {
-        out_v[u * k + lane] = e;
-        out_c[u * k + lane] = ec;
+        if (out_pv) {
+            out_pv[(grp * U + u) * k + lane] = e;
+            out_pc[(grp * U + u) * k + lane] = ec;
+        } else {
+            out_v[u * k + lane] = e;
+            out_c[u * k + lane] = ec;
+        }
     }
 }
 
@@ -716,10 +732,12 @@ extern "C" int cdr_fullsort_scores_f32(void* stream, const float* user_e, int64_
 // ---- mask + top-k fused after scoring ---------------------------------------------------------------------
 namespace {
 
-constexpr int64_t kTopkSub = 16384;                 // columns per wave in topk_rows_kernel
+constexpr int64_t kTopkSubMax = 16384;              // columns per wave in topk_rows_kernel (fewer when U is small)
+constexpr int64_t kTopkMergeGroup = 64;             // partial lists merged per wave and level
 constexpr size_t kTopkScoreBytes = (size_t)256 << 20;   // score staging for the unfused passes
 
 struct topk_plan {
+    int64_t sub;                                    // columns per wave of topk_rows_kernel
     bool fused[2];
     int64_t stripes[2], fused_cols[2];              // fused: producers and the columns they cover (multiple of 64)
     int64_t pass_cols;                              // unfused: columns scored per pass
@@ -733,6 +751,10 @@ static size_t fused_lds_bytes(int D, int MT, int k) {
 
 static topk_plan make_topk_plan(int64_t U, int D, const int64_t n[2], int k, const float* users, const float* const slab[2]) {
     topk_plan p{};
+    // a wave walks its columns with 8 loads in flight: few users = few waves, so give each a shorter walk (U = 1, N = 10 M:
+    // 2,442 waves of 8 iterations instead of 611 of 32)
+    p.sub = U >= 16 ? kTopkSubMax : U >= 4 ? 8192 : 4096;
+    const int64_t kTopkSub = p.sub;
     int64_t pass = (int64_t)(kTopkScoreBytes / sizeof(float)) / U;
     pass = pass / kTopkSub * kTopkSub;
     if (pass < kTopkSub) pass = kTopkSub;
@@ -765,9 +787,14 @@ static topk_plan make_topk_plan(int64_t U, int D, const int64_t n[2], int k, con
     return p;
 }
 
+static size_t topk_part_bytes(int64_t producers, int64_t U, int k) {
+    return ((size_t)producers * U * k * 4 + 255) & ~(size_t)255;
+}
+
+// level-0 lists (values + columns) | level-1 lists (one per kTopkMergeGroup level-0 lists) | score staging
 static size_t topk_ws_bytes(const topk_plan& p, int64_t U, int k) {
-    const size_t part = ((size_t)p.producers * U * k * 4 + 255) & ~(size_t)255;
-    return 2 * part + (((size_t)p.score_floats * 4 + 255) & ~(size_t)255);
+    const int64_t l1 = (p.producers + kTopkMergeGroup - 1) / kTopkMergeGroup;
+    return 2 * topk_part_bytes(p.producers, U, k) + 2 * topk_part_bytes(l1, U, k) + (((size_t)p.score_floats * 4 + 255) & ~(size_t)255);
 }
 
 static int score_block(hipStream_t s, const float* user_e, int64_t U, int D, const float* items, int64_t n, float* scores, int64_t ld) {
@@ -807,10 +834,15 @@ extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t 
         }
     const size_t need = topk_ws_bytes(p, U, k);
     if (workspace_bytes < need) { cdr_set_error("cdr_fullsort_topk_f32: workspace %zu < %zu bytes", workspace_bytes, need); return CDR_EINVAL; }
-    const size_t part = ((size_t)p.producers * U * k * 4 + 255) & ~(size_t)255;
+    const size_t part = topk_part_bytes(p.producers, U, k);
+    const int64_t l1 = (p.producers + kTopkMergeGroup - 1) / kTopkMergeGroup;
+    const size_t part1 = topk_part_bytes(l1, U, k);
     float* pv = (float*)workspace;
     int* pc = (int*)((char*)workspace + part);
-    float* sbuf = (float*)((char*)workspace + 2 * part);
+    float* pv1 = (float*)((char*)workspace + 2 * part);
+    int* pc1 = (int*)((char*)workspace + 2 * part + part1);
+    float* sbuf = (float*)((char*)workspace + 2 * part + 2 * part1);
+    const int64_t kTopkSub = p.sub;
     const topk_mask mk{hist_indptr, hist_cols, exclude_first_col};
     int64_t prod = 0, col_off = 0;
     for (int i = 0; i < 2; ++i) {
@@ -854,7 +886,13 @@ extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t 
         }
         col_off += n[i];
     }
-    topk_merge_kernel<<<dim3((unsigned)((U + 3) / 4)), dim3(256), 0, s>>>(pv, pc, prod, U, k, out_vals, out_idx);
+    if (prod > 2 * kTopkMergeGroup) {                                // two levels: groups of 64 lists, then the l1 group lists
+        topk_merge_kernel<<<dim3((unsigned)((U * l1 + 3) / 4)), dim3(256), 0, s>>>(pv, pc, prod, U, k, kTopkMergeGroup, pv1, pc1, nullptr, nullptr);
+        CDR_LAUNCH_CHECK();
+        topk_merge_kernel<<<dim3((unsigned)((U + 3) / 4)), dim3(256), 0, s>>>(pv1, pc1, l1, U, k, l1, nullptr, nullptr, out_vals, out_idx);
+    } else {
+        topk_merge_kernel<<<dim3((unsigned)((U + 3) / 4)), dim3(256), 0, s>>>(pv, pc, prod, U, k, prod, nullptr, nullptr, out_vals, out_idx);
+    }
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
