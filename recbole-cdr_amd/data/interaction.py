@@ -1,6 +1,5 @@
 """Minimal stand-in for recbole's ``Interaction`` (third-party): a dict of equal-length tensors with
 ``[str]`` / ``[slice]`` access, ``to``, ``update`` and ``__len__`` -- the input contract of ``calculate_loss``."""
-import torch
 
 
 class Interaction(dict):

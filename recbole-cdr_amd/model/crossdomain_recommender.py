@@ -6,7 +6,6 @@ Same constructor contract ``(config, dataset)``, same attribute names, same ``se
 is not a dependency of this package.
 """
 import numpy as np
-import torch
 import torch.nn as nn
 from torch.nn.init import xavier_normal_, constant_
 

@@ -9,7 +9,6 @@ the dense optimizer is the native exact Adam (csrc/cdr_rows.hip ``cdr_adam_dense
 import numpy as np
 import torch
 
-from .. import functional as F_
 from ..utils import train_mode2state
 
 
