@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true', default=bool(int(os.environ.get('CDR_NO_PIPELINE', '0'))),
                     help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
+    ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
 
 
@@ -124,9 +125,9 @@ def run_c5(args, world, rank, dev):
         groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
         streams = {d: (None if args.no_pipeline else torch.cuda.Stream(device=dev)) for d in ('source', 'target')}
         steps = {'source': ShardedBPRStep(tabs['su'], tabs['si'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
-                                          group=groups['source'], stream=streams['source']),
+                                          group=groups['source'], stream=streams['source'], dedup=not args.no_dedup),
                  'target': ShardedBPRStep(tabs['tu'], tabs['ti'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
-                                          group=groups['target'], stream=streams['target'])}
+                                          group=groups['target'], stream=streams['target'], dedup=not args.no_dedup)}
 
     # synthetic interaction streams: users ~ U{1..OU-1}; target items [1, TOI], source items [TOI+1, 2 TOI]
     pool = 4
@@ -181,7 +182,7 @@ def run_c5(args, world, rank, dev):
                                'step = source batch + target batch of %d triples each per rank, fwd+bwd+row-wise %s'
                                % (D, OU - 1, TOI, 4.0 * D * 2 * (n_users + n_items) / 1e9, B, args.opt),
                    'batch_per_domain_per_rank': B, 'k_neg': 1, 'optimizer': 'rowwise-' + args.opt,
-                   'sharding': 'none' if not sharded else 'row %% %d, user-aligned all-to-all, 2-domain pipelined' % world},
+                   'sharding': 'none' if not sharded else 'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
         'final_loss': loss,
     }
 

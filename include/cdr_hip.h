@@ -332,6 +332,22 @@ int cdr_permute_i64(void* stream, const int64_t* src0, int64_t n0, const int64_t
                     int64_t n, int64_t divisor, int64_t flag_below /* occurrences o < flag_below get bit 62 set */, int64_t* out);
 int cdr_inverse_perm(void* stream, const uint32_t* perm, int64_t n, int64_t* pos);
 
+/* ---- id de-duplication for the row-sharded step (a rank requests each distinct row once and returns one summed
+ * gradient row per distinct id).  Input: the step's item occurrences sorted by key = (owner << local_bits) | local_row with
+ * cdr_sort_ids (keys_sorted, perm).
+ *   cdr_dedup_sorted: uniq_index[q] = dense index of sorted position q's segment ; uniq_local[j] = local row of unique j (grouped
+ *                     by owner, ascending) ; occ_to_uniq[o] = unique index of occurrence o ; counts[k] = uniques owned by rank k ;
+ *                     n_uniq[0] = number of uniques (all on the device).
+ *   cdr_segsum_rows : out[j,:] = sum_{o in unique j, o < neg_start} G[o] - sum_{o >= neg_start} G[o - neg_start]
+ *                               + reg_coef[0] * #{o < neg_start} * rows[j,:]      (occurrence order: bit-reproducible)       */
+int cdr_dedup_workspace_bytes(int64_t n, size_t* bytes);
+int cdr_dedup_sorted(void* stream, const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, int world, int local_bits,
+                     uint32_t* uniq_index /* [n] */, int64_t* uniq_local /* [n] */, int64_t* occ_to_uniq /* [n] */,
+                     int64_t* counts /* [world + 1]: one scratch slot */, int64_t* n_uniq /* [1] */, void* workspace, size_t workspace_bytes);
+int cdr_segsum_rows(cdr_ctx* ctx, void* stream, const uint32_t* keys_sorted, const uint32_t* perm, const uint32_t* uniq_index,
+                    int64_t n, const float* G, int64_t neg_start, int D, const float* rows /* [n_uniq, D] or NULL */,
+                    const float* reg_coef /* device scalar or NULL */, float* out /* [n_uniq, D] */);
+
 /* ---- full-sort over row-sharded tables (SURVEY 8e "Full-sort": each rank scores its item shard, all-gather) -----------
  * cdr_interleave_shards: the all-gathered scores are shard-major [world][U][Nl]; the reference's full_sort_predict
  *     layout (emcdr.py:208-233 -> score.view(-1)) is [U][N] in item-id order: out[u][c] = gathered[c % world][u][c / world].

@@ -111,6 +111,9 @@ _SIGNATURES = {
     'cdr_fullsort_topk_workspace_bytes': [_c_i64, _c_int, _c_i64, _c_i64, _c_int, _c_ptr],
     'cdr_fullsort_topk_f32': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr,
                               _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_dedup_workspace_bytes': [_c_i64, _c_ptr],
+    'cdr_dedup_sorted': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_segsum_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr],
     'cdr_interleave_shards': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_gather_owned_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_adam_dense_dev': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr],

@@ -104,12 +104,52 @@ class NativeOps:
                     B_.f32(out))
         return out
 
-    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GI):
-        """GI [rows of itab, D]: item gradients written at the item rows' own positions (+ at pidx, - at nidx)."""
+    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GI, scatter=True):
+        """scatter: GI [rows of itab, D], item gradients written at the item rows' own positions (+ at pidx, - at nidx);
+        else GI [B, D] = g u per triple (compact)."""
         B_ = self.B_
         B_.call('cdr_bpr_fwd_grad', B_.ctx(self.device), B_.stream(), B_.f32(utab), B_.f32(itab), utab.shape[1],
                 B_.i64(uidx), B_.i64(pidx), B_.i64(nidx), uidx.numel(), int(B_mean), float(gamma), float(reg_weight),
-                B_.f32(out), B_.f32(GU), B_.f32(GI), 1)
+                B_.f32(out), B_.f32(GU), B_.f32(GI), 1 if scatter else 0)
+
+    def dedup(self, ids0, ids1, world, local_rows):
+        """The distinct item rows behind the occurrences ids0 ++ ids1 (global ids): plan with ``uniq_local`` (local rows,
+        grouped by owner, ascending), ``umap`` (occurrence -> unique index), ``counts`` (uniques per owner, device) and the
+        sorted occurrence order that ``segsum`` sums over."""
+        B_ = self.B_
+        dev = ids0.device
+        n = ids0.numel() + ids1.numel()
+        lb = max(int(local_rows - 1).bit_length(), 1)
+        key0 = ((ids0 % world) << lb) | (ids0 // world)                      # index plumbing: owner-major sort key
+        key1 = ((ids1 % world) << lb) | (ids1 // world)
+        need = ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_sort_workspace_bytes(n, world << lb, ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+        need2 = ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_dedup_workspace_bytes(n, ctypes.byref(need2)), 'cdr_dedup_workspace_bytes')
+        ws = self._workspace(('dedup', torch.cuda.current_stream().cuda_stream), max(need.value, need2.value), dev)
+        keys = torch.empty(n, device=dev, dtype=torch.int32)
+        perm = torch.empty(n, device=dev, dtype=torch.int32)
+        ctxh = B_.ctx(self.device)
+        B_.call('cdr_sort_ids', ctxh, B_.stream(), B_.i64(key0), ids0.numel(), B_.i64(key1), ids1.numel(), world << lb,
+                B_.raw(keys), B_.raw(perm), B_.raw(ws), ws.numel())
+        uidx = torch.empty(n, device=dev, dtype=torch.int32)
+        uniq_local = torch.empty(n, device=dev, dtype=torch.int64)
+        umap = torch.empty(n, device=dev, dtype=torch.int64)
+        counts = torch.empty(world + 1, device=dev, dtype=torch.int64)           # [world] counts + one scratch slot
+        n_uniq = torch.empty(1, device=dev, dtype=torch.int64)
+        B_.call('cdr_dedup_sorted', B_.stream(), B_.raw(keys), B_.raw(perm), n, int(world), lb, B_.raw(uidx), B_.i64(uniq_local),
+                B_.i64(umap), B_.i64(counts), B_.i64(n_uniq), B_.raw(ws), ws.numel())
+        return {'keys': keys, 'perm': perm, 'uidx': uidx, 'uniq_local': uniq_local, 'umap': umap, 'counts': counts[:world], 'n': n}
+
+    def segsum(self, plan, G_rows, neg_start, rows, reg_coef, n_uniq):
+        """One summed gradient row per distinct item (+ the EmbLoss term coef * #positives * row) -> [n_uniq, D]."""
+        B_ = self.B_
+        D = G_rows.shape[1]
+        out = torch.empty(n_uniq, D, device=G_rows.device, dtype=torch.float32)
+        if plan['n']:
+            B_.call('cdr_segsum_rows', B_.ctx(self.device), B_.stream(), B_.raw(plan['keys']), B_.raw(plan['perm']),
+                    B_.raw(plan['uidx']), plan['n'], B_.f32(G_rows), int(neg_start), D, B_.f32(rows), B_.f32(reg_coef), B_.f32(out))
+        return out
 
     def finish_sums(self, sums3, B_mean, reg_weight, out):
         B_ = self.B_
@@ -158,7 +198,7 @@ class ShardedBPRStep:
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
-                 stream=None, user_state=None, item_state=None):
+                 stream=None, user_state=None, item_state=None, dedup=True):
         from .fused import RowwiseState
         self.group = group
         self.world = dist.get_world_size(group)
@@ -178,6 +218,8 @@ class ShardedBPRStep:
         self.max_batch = int(max_batch)
         self.out = torch.zeros(12, device=dev, dtype=torch.float32)
         self.stream = stream                      # optional torch.cuda.Stream for pipelined execution
+        self.dedup = bool(dedup)                  # request each distinct item row once, return one summed gradient row per item
+        self.n_items_total = int(n_items_total)
 
     def loss_value(self):
         return self.out[0]
@@ -218,6 +260,10 @@ class ShardedBPRStep:
             u_loc = recv3[:, 0].contiguous()
             p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
 
+        if self.dedup:                              # (outside the stream context: the generator yields in there)
+            yield from self._items_dedup(uid.device, Bl, B_global, u_loc, p2, n2)
+            return
+        with self._on_stream():
             # ---- 1. item rows: ids to their owners, rows back ---------------------------------------------------
             if Bl:
                 perm1, counts1 = ops.route(p2, n2, G)
@@ -258,6 +304,48 @@ class ShardedBPRStep:
             # the owner adds the EmbLoss term itself (it holds the pre-step row; the tag tells it which occurrences count)
             ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step,
                            reg_coef=self.out[5:6], tagged=True)
+
+
+    def _items_dedup(self, dev, Bl, B_global, u_loc, p2, n2):
+        """Steps 1-3 with id de-duplication: every distinct item row crosses xGMI once per step in each direction (the rows
+        out, ONE gradient row -- summed over the item's occurrences here, EmbLoss term included -- back)."""
+        G, grp, ops = self.world, self.group, self.ops
+        with self._on_stream():
+            if Bl:
+                plan = ops.dedup(p2, n2, G, shard_rows(self.n_items_total, G, 0))
+                counts1 = plan['counts']
+            else:
+                plan, counts1 = None, torch.zeros(G, device=dev, dtype=torch.int64)
+            gathered = _gather_counts(counts1, 0, grp, G)
+        yield
+        with self._on_stream():
+            allc = torch.stack(gathered).tolist()                           # host sync #2
+            i_send = [int(c) for c in allc[self.rank][:G]]
+            i_recv = [int(allc[r][self.rank]) for r in range(G)]
+            n_uniq = sum(i_send)
+            uniq = plan['uniq_local'][:n_uniq] if Bl else torch.empty(0, device=dev, dtype=torch.int64)
+            i_req = _a2a(uniq, i_send, i_recv, grp)                          # my item rows other ranks want, each once per rank
+            irows = _a2a(ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
+            GU = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
+            GP = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
+            if Bl:
+                umap = plan['umap']
+                ops.fwd_grad(self.U, irows, u_loc, umap[:Bl].contiguous(), umap[Bl:].contiguous(), B_global, self.gamma,
+                             self.reg_weight, self.out, GU, GP, scatter=False)
+                sums = self.out[6:9].clone()
+            else:
+                sums = torch.zeros(3, device=dev, dtype=torch.float32)
+            dist.all_reduce(sums, group=grp)
+            ops.finish_sums(sums, B_global, self.reg_weight, self.out)
+            if Bl:
+                ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,
+                               reg_limit=Bl, reg_coef=self.out[4:5])
+                gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq)
+            else:
+                gi = torch.empty(0, self.D, device=dev, dtype=torch.float32)
+            gi_recv = _a2a(gi, i_send, i_recv, grp, (self.D,))
+            # the EmbLoss term is already inside the rows: the owner just sums what it received per row and applies
+            ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step)
 
 
 def run_pipelined(generators):

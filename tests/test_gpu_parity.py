@@ -976,7 +976,7 @@ def _collect_ranks(q, procs, limit=300):
 # world_size > 1 with the NATIVE kernels: several ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
 # device; the driver's 8-GPU run is the only place real xGMI traffic happens).  Same exchange code, same libcdrhip ops,
 # real owner arithmetic (id % G, id // G, bit-62 tags) -- only the transport differs.
-def _shared_gpu_worker(rank, world, port, pipelined, q):
+def _shared_gpu_worker(rank, world, port, pipelined, dedup, q):
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -994,7 +994,7 @@ def _shared_gpu_worker(rank, world, port, pipelined, q):
             Ul, Il = shard_of(U, world, rank).to(DEV), shard_of(I, world, rank).to(DEV)
             grp = dist.new_group(backend='gloo') if pipelined else None
             stream = torch.cuda.Stream() if pipelined else None
-            steps.append(ShardedBPRStep(Ul, Il, nu, ni, B, opt='adam', lr=0.01, reg_weight=0.02, group=grp, stream=stream))
+            steps.append(ShardedBPRStep(Ul, Il, nu, ni, B, opt='adam', lr=0.01, reg_weight=0.02, group=grp, stream=stream, dedup=dedup))
             shards.append((Ul, Il))
         losses, batches = [], []
         for it in range(3):
@@ -1005,6 +1005,7 @@ def _shared_gpu_worker(rank, world, port, pipelined, q):
                 n = torch.randint(0, ni, (B,), generator=g)
                 if it == 1:
                     u[: B // 2] = u[0]                                   # heavy duplication -> long segments at one owner
+                    p[: B // 3] = p[0]; n[100:700] = p[0]                # one hot item, also as a negative: long item segments
                 per_dom.append((u, p, n))
             batches.append(per_dom)
             if pipelined:
@@ -1020,15 +1021,15 @@ def _shared_gpu_worker(rank, world, port, pipelined, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,pipelined', [(2, False), (3, True)])
-def test_sharded_native_ranks_share_one_gpu(world, pipelined):
+@pytest.mark.parametrize('world,pipelined,dedup', [(2, False, False), (3, True, False), (2, False, True), (3, True, True)])
+def test_sharded_native_ranks_share_one_gpu(world, pipelined, dedup):
     import socket
     import torch.multiprocessing as mp
     from recbole_cdr_amd.fused import FusedBPRStep
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, pipelined, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, pipelined, dedup, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = _collect_ranks(q, procs)

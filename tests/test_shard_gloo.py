@@ -32,15 +32,33 @@ class OracleOps:
     def gather_rows(self, table, local_ids):
         return table[local_ids].clone()
 
-    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GI):
+    def dedup(self, ids0, ids1, world, local_rows):
+        ids = torch.cat([ids0, ids1])
+        lb = max(int(local_rows - 1).bit_length(), 1)
+        key = ((ids % world) << lb) | (ids // world)
+        uniq, umap = torch.unique(key, return_inverse=True)                 # ascending key = grouped by owner, ascending local row
+        return {'uniq_local': uniq & ((1 << lb) - 1), 'umap': umap, 'counts': torch.bincount(uniq >> lb, minlength=world), 'n': ids.numel()}
+
+    def segsum(self, plan, G_rows, neg_start, rows, reg_coef, n_uniq):
+        n = plan['n']
+        sign = torch.cat([torch.ones(neg_start), -torch.ones(n - neg_start)])
+        src = torch.cat([G_rows, G_rows[: n - neg_start]]) * sign[:, None]
+        out = torch.zeros(n_uniq, G_rows.shape[1]).index_add_(0, plan['umap'], src)
+        cnt = torch.zeros(n_uniq).index_add_(0, plan['umap'][:neg_start], torch.ones(neg_start))
+        return out + float(reg_coef[0]) * cnt[:, None] * rows
+
+    def fwd_grad(self, utab, itab, uidx, pidx, nidx, B_mean, gamma, reg_weight, out, GU, GI, scatter=True):
         u, p, n = utab[uidx], itab[pidx], itab[nidx]
         x = (u * p).sum(1) - (u * n).sum(1)
         s = torch.sigmoid(x)
         g = -(1.0 / B_mean) * (s * (1 - s)) / (gamma + s)
         B = uidx.numel()
         GU[:B] = g[:, None] * (p - n)
-        GI[pidx] = g[:, None] * u
-        GI[nidx] = -g[:, None] * u
+        if scatter:
+            GI[pidx] = g[:, None] * u
+            GI[nidx] = -g[:, None] * u
+        else:
+            GI[:B] = g[:, None] * u
         out[6] = (-torch.log(gamma + s)).sum()
         out[7] = (u * u).sum()
         out[8] = (p * p).sum()
@@ -75,7 +93,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, opt, q):
+def _worker(rank, world, port, opt, dedup, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -87,7 +105,7 @@ def _worker(rank, world, port, opt, q):
         U = torch.randn(nu, D) * 0.3
         I = torch.randn(ni, D) * 0.3
         Ul, Il = shard_of(U, world, rank), shard_of(I, world, rank)
-        st = ShardedBPRStep(Ul, Il, nu, ni, B, opt=opt, lr=lr, reg_weight=reg, ops=OracleOps())
+        st = ShardedBPRStep(Ul, Il, nu, ni, B, opt=opt, lr=lr, reg_weight=reg, ops=OracleOps(), dedup=dedup)
         losses = []
         batches = []
         for step in range(3):
@@ -103,14 +121,15 @@ def _worker(rank, world, port, opt, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('dedup', [False, True])
 @pytest.mark.parametrize('opt', ['sgd', 'adam'])
-def test_sharded_step_matches_single_process(opt):
+def test_sharded_step_matches_single_process(opt, dedup):
     from oracle import train_step as ts
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, dedup, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
