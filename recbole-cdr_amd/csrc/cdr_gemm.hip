@@ -438,16 +438,19 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
     volatile int* lc = reinterpret_cast<volatile int*>(lv + BM * (TOPK ? tk.k : 0));
     constexpr int RPW = BM / 4;            // user rows each wave scans
     constexpr int QC = kTopkQueue;         // per-wave queue of candidates waiting for the mask test
-    volatile float* qv = reinterpret_cast<volatile float*>(lc + BM * (TOPK ? tk.k : 0)) + wave * QC * 3;
+    volatile float* q0 = reinterpret_cast<volatile float*>(lc + BM * (TOPK ? tk.k : 0));     // four queues: values | columns | rows
+    volatile float* qv = q0 + wave * QC * 3;
     volatile int* qc = reinterpret_cast<volatile int*>(qv + QC);
     volatile int* qu = qc + QC;
-    int qn = 0;                            // wave-uniform
+    int* qcnt = reinterpret_cast<int*>(const_cast<float*>(q0) + 4 * QC * 3);                  // [4] queue fills, [4] = overflow flag
 
     for (int mb = mslot; mb < MB; mb += MBc) {
         const int m0 = mb * BM + wm * 32 * MT;
+        int tiles_done = 0;
         if (TOPK) {
             for (int i = tid; i < BM; i += 256) thr_l[i] = -INFINITY;
             for (int i = tid; i < BM * tk.k; i += 256) { lv[i] = -INFINITY; lc[i] = -1; }
+            if (tid < 5) qcnt[tid] = 0;
         }
         // this wave's user rows, whole K, in registers (loaded once per user block)
         float4 a[MT][KS];
@@ -519,44 +522,109 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                     }
                 __syncthreads();
             } else {
-                // the [BM, 64] score tile goes to LDS instead of HBM; every wave then offers its rows' 64 scores to the
-                // rows' running top-k lists (nothing but the final k per user and stripe ever leaves the CU)
+                // Fast path: every accumulator is compared IN REGISTERS with the k-th value of its user row; the rare survivor
+                // (expected k ln(n/k) per user over the whole stream) reserves a slot in the queue of the wave that owns the
+                // row's list (LDS atomic) -- no LDS round trip of the score tile, no extra barrier.  Queues are drained between
+                // two barriers when one is half full.  The first tiles of a user block (thresholds still -inf) and any tile
+                // whose survivors do not fit take the slow path: the whole tile goes through LDS and the owner waves scan it.
+                bool slow = tiles_done < 2;
+                const int qstart = qcnt[wave];
+                // the k-th values of four consecutive user rows come as one 16-byte LDS read (they only change in the drain
+                // phases, which sit between barriers)
+                float4 th4[MT][4];
+                bool any = false;
+                if (!slow) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        sc[(wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * SCS + wn * 32 + li] = acc[t][r];
-                __syncthreads();
-                // Survivors of the k-th-value test are only QUEUED (wave-private, LDS): the history test is a chain of
-                // dependent global loads (~5 us), so it runs for up to 64 queued candidates at once, one per lane, when
-                // the queue is half full -- not once per survivor on the tile's critical path (measured: 2x the kernel).
-                const int col = tk.col_off + tile * BN + lane;
-                // all of this wave's rows first (independent LDS reads), then the tests: a read -> test -> branch chain per
-                // row is latency-bound and cost as much as the MFMA phase itself
-                float vr[RPW];
-#pragma unroll
-                for (int rr = 0; rr < RPW; ++rr) vr[rr] = sc[(wave * RPW + rr) * SCS + lane];
-                const float tl = thr_l[wave * RPW + (lane % RPW)];          // k-th values of the wave's rows, one per lane
-#pragma unroll
-                for (int rr = 0; rr < RPW; ++rr) {
-                    const int ul = wave * RPW + rr;
-                    const float thr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tl), rr));
-                    const bool pass = vr[rr] > thr && (int64_t)mb * BM + ul < M;
-                    const unsigned long long m = __ballot(pass);
-                    if (m == 0) continue;
-                    if (pass) {
-                        const int at = qn + __popcll(m & ((1ull << lane) - 1));
-                        qv[at] = vr[rr]; qc[at] = col; qu[at] = ul;
-                    }
-                    qn += __popcll(m);
-                    if (qn > QC - 64) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            th4[t][r4] = *reinterpret_cast<const float4*>(const_cast<const float*>(thr_l) + wm * 32 * MT + 32 * t + 8 * r4 + 4 * lh);
+                            any |= acc[t][4 * r4] > th4[t][r4].x || acc[t][4 * r4 + 1] > th4[t][r4].y ||
+                                   acc[t][4 * r4 + 2] > th4[t][r4].z || acc[t][4 * r4 + 3] > th4[t][r4].w;
+                        }
                 }
-                if (qn >= QC / 2) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
-                __syncthreads();                   // the next tile's scores overwrite sc
+                if (!slow && __ballot(any)) {       // about half of the tiles end here: no survivor in the whole wave
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                          const float th[4] = {th4[t][r4].x, th4[t][r4].y, th4[t][r4].z, th4[t][r4].w};
+#pragma unroll
+                          for (int rl = 0; rl < 4; ++rl) {
+                            const int r = 4 * r4 + rl;
+                            const int ul = wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const bool pass = acc[t][r] > th[rl] && (int64_t)mb * BM + ul < M;
+                            if (__ballot(pass) == 0) continue;
+                            if (pass) {
+                                const int owner = ul / RPW;
+                                const int slot = atomicAdd(&qcnt[owner], 1);
+                                if (slot < QC) {
+                                    volatile float* ov = q0 + owner * QC * 3;
+                                    ov[slot] = acc[t][r];
+                                    reinterpret_cast<volatile int*>(ov + QC)[slot] = tk.col_off + tile * BN + wn * 32 + li;
+                                    reinterpret_cast<volatile int*>(ov + 2 * QC)[slot] = ul;
+                                } else {
+                                    qcnt[4] = 1;
+                                }
+                            }
+                          }
+                        }
+                }
+                __syncthreads();                   // parked tile + queue appends visible
+                if (!slow && qcnt[4]) {            // some queue overflowed: forget this tile's appends, redo it the slow way
+                    slow = true;
+                    if (lane == 0) qcnt[wave] = qstart;
+                }
+                bool refresh = false;
+                if (slow) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            sc[(wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * SCS + wn * 32 + li] = acc[t][r];
+                    __syncthreads();
+                    if (tid == 0) qcnt[4] = 0;
+                    int qn = qcnt[wave];           // the owner wave scans its rows: private appends, flushes as it goes
+                    const int col = tk.col_off + tile * BN + lane;
+                    const float tl = thr_l[wave * RPW + (lane % RPW)];
+#pragma unroll 1
+                    for (int r0 = 0; r0 < RPW; r0 += 8) {                         // eight rows' scores at a time (independent reads)
+                        float vr[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) vr[j] = sc[(wave * RPW + r0 + j) * SCS + lane];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int ul = wave * RPW + r0 + j;
+                            const float thr = __shfl(tl, r0 + j);
+                            const bool pass = vr[j] > thr && (int64_t)mb * BM + ul < M;
+                            const unsigned long long m = __ballot(pass);
+                            if (m == 0) continue;
+                            if (pass) {
+                                const int at = qn + __popcll(m & ((1ull << lane) - 1));
+                                qv[at] = vr[j]; qc[at] = col; qu[at] = ul;
+                            }
+                            qn += __popcll(m);
+                            if (qn > QC - 64) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+                        }
+                    }
+                    if (qn) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+                    if (lane == 0) qcnt[wave] = 0;
+                    refresh = true;
+                } else if (qcnt[0] >= QC / 2 || qcnt[1] >= QC / 2 || qcnt[2] >= QC / 2 || qcnt[3] >= QC / 2) {   // uniform
+                    const int qn = qcnt[wave];
+                    if (qn) topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM);
+                    if (lane == 0) qcnt[wave] = 0;
+                    refresh = true;
+                }
+                if (refresh) __syncthreads();      // lists, k-th values and empty queues visible before anyone appends again
+                ++tiles_done;
             }
             buf ^= 1;
         }
-        if (TOPK && qn) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+        if (TOPK) {                            // drain what the fast path left in the queues
+            const int qn = qcnt[wave];
+            if (qn) topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM);
+        }
         __syncthreads();
         if (TOPK) {
             // this stripe's candidates for its user block: partial list [stripe][user][k]
@@ -746,7 +814,7 @@ struct topk_plan {
 
 static size_t fused_lds_bytes(int D, int MT, int k) {
     const int BM = 64 * MT;
-    return sizeof(float) * ((size_t)2 * 64 * (D + 4) + (size_t)BM * 65 + BM + (size_t)BM * k * 2 + (size_t)4 * kTopkQueue * 3);
+    return sizeof(float) * ((size_t)2 * 64 * (D + 4) + (size_t)BM * 65 + BM + (size_t)BM * k * 2 + (size_t)4 * kTopkQueue * 3 + 8);
 }
 
 static topk_plan make_topk_plan(int64_t U, int D, const int64_t n[2], int k, const float* users, const float* const slab[2]) {
