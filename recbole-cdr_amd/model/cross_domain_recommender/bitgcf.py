@@ -115,6 +115,14 @@ class BiTGCF(CrossDomainRecommender):
         u = F_.gather_rows(restore_user_e, interaction[self.TARGET_USER_ID])
         return F_.fullsort_scores(u, restore_item_e[:self.target_num_items]).view(-1)
 
+    @torch.no_grad()
+    def full_sort_topk(self, interaction, k, hist_indptr=None, hist_cols=None):
+        """(values, columns) [U,k] of ``full_sort_predict`` after recbole's evaluation mask, without the [U, N] matrix."""
+        restore_user_e, restore_item_e = self.get_restore_e()
+        u = F_.gather_rows(restore_user_e, interaction[self.TARGET_USER_ID])
+        return F_.fullsort_topk(u, restore_item_e[:self.target_num_items], None, k=k, hist_indptr=hist_indptr,
+                                hist_cols=hist_cols, exclude_first_col=True)
+
     def init_restore_e(self):
         if self.target_restore_user_e is not None or self.target_restore_item_e is not None:
             self.target_restore_user_e, self.target_restore_item_e = None, None

@@ -659,6 +659,11 @@ def test_bitgcf_golden(name):
     model.eval()
     assert_close(model.predict(ev), g['predict/BOTH'], what='predict')
     assert_close(model.full_sort_predict(ev), g['fullsort/BOTH'], what='fullsort')
+    n_u = ev[model.TARGET_USER_ID].numel()
+    full = model.full_sort_predict(ev).view(n_u, -1).clone()
+    full[:, 0] = -float('inf')
+    tv, ti = model.full_sort_topk(ev, 3)
+    assert torch.equal(tv, torch.topk(full, 3, dim=1).values) and torch.equal(torch.gather(full, 1, ti), tv)
 
 
 @pytest.mark.parametrize('U,N,D', [(1, 1000, 128), (3, 777, 64), (4, 5000, 128), (33, 4133, 128), (64, 6400, 64), (100, 8229, 128),
