@@ -40,7 +40,8 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-int cdr_abi_version(void);                          /* bumped on any signature change                        */
+#define CDR_ABI_VERSION 9
+int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
  * on.  cdr_timing_enable(ctx, capacity) arms `capacity` slots (0 disarms); every instrumented launch made with this

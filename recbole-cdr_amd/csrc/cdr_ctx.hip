@@ -13,7 +13,7 @@ void cdr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cdr_last_error(void) { return g_err; }
-extern "C" int cdr_abi_version(void) { return 9; }
+extern "C" int cdr_abi_version(void) { return CDR_ABI_VERSION; }
 
 extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     CDR_CHECK_ARG(out != nullptr);

@@ -1,0 +1,112 @@
+/* A plain C consumer of libcdrhip.so: no Python, no torch -- device buffers from the HIP runtime, entry points from
+ * include/cdr_hip.h.  Runs the pairwise loss (cdr_bpr_fwd), the all-items scoring (cdr_fullsort_scores_f32) and one fused
+ * row-wise SGD step (cdr_bpr_fwd_grad -> cdr_sort_ids_two_tables -> cdr_rowwise_apply x2) on small tables and checks every
+ * result against the same arithmetic done here in double precision.  Exit code 0 = all within 1e-5 relative.
+ * Build: hipcc -x c tests/abi_c/abi_smoke.c -Iinclude -Lrecbole-cdr_amd/lib -lcdrhip -o tests/abi_c/abi_smoke           */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <hip/hip_runtime_api.h>
+#include "cdr_hip.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define CHECK_CDR(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, cdr_last_error()); return 3; } } while (0)
+
+static uint64_t rng_state = 88172645463325252ull;
+static double urand(void) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (double)(rng_state >> 11) / 9007199254740992.0; }
+static int close_enough(double got, double want, double scale, const char* what) {
+    const double tol = 1e-5 * (fabs(want) > scale ? fabs(want) : scale);
+    if (fabs(got - want) > tol) { fprintf(stderr, "MISMATCH %s: got %.9g want %.9g\n", what, got, want); return 0; }
+    return 1;
+}
+
+int main(void) {
+    enum { NU = 500, NI = 300, D = 64, B = 2000 };
+    const float gamma = 1e-10f, reg = 0.01f, lr = 0.05f;
+    float* U = (float*)malloc(sizeof(float) * NU * D); float* I = (float*)malloc(sizeof(float) * NI * D);
+    int64_t *u = (int64_t*)malloc(8 * B), *p = (int64_t*)malloc(8 * B), *n = (int64_t*)malloc(8 * B);
+    for (int i = 0; i < NU * D; ++i) U[i] = (float)(urand() - 0.5) * 0.4f;
+    for (int i = 0; i < NI * D; ++i) I[i] = (float)(urand() - 0.5) * 0.4f;
+    for (int b = 0; b < B; ++b) { u[b] = (int64_t)(urand() * NU); p[b] = (int64_t)(urand() * NI); n[b] = (int64_t)(urand() * NI); }
+    if (cdr_abi_version() != CDR_ABI_VERSION) { fprintf(stderr, "library ABI %d, header ABI %d\n", cdr_abi_version(), CDR_ABI_VERSION); return 4; }
+
+    /* ---- host reference in double ---------------------------------------------------------------------------- */
+    double loss = 0, su = 0, sp = 0;
+    double* g = (double*)malloc(sizeof(double) * B);
+    for (int b = 0; b < B; ++b) {
+        double dp = 0, dn = 0;
+        for (int d = 0; d < D; ++d) {
+            const double uu = U[u[b] * D + d], pp = I[p[b] * D + d], nn = I[n[b] * D + d];
+            dp += uu * pp; dn += uu * nn; su += uu * uu; sp += pp * pp;
+        }
+        const double s = 1.0 / (1.0 + exp(-(dp - dn)));
+        loss += -log((double)gamma + s);
+        g[b] = -(1.0 / B) * (s * (1.0 - s)) / ((double)gamma + s);
+    }
+    const double main_loss = loss / B, nu_ = sqrt(su), ni_ = sqrt(sp), total = main_loss + reg * (nu_ + ni_) / B;
+    const double cu = reg / (B * nu_), ci = reg / (B * ni_);
+    double* Uref = (double*)malloc(sizeof(double) * NU * D); double* Iref = (double*)malloc(sizeof(double) * NI * D);
+    for (int i = 0; i < NU * D; ++i) Uref[i] = U[i];
+    for (int i = 0; i < NI * D; ++i) Iref[i] = I[i];
+    for (int b = 0; b < B; ++b)                                   /* SGD on the summed gradients at the pre-step weights */
+        for (int d = 0; d < D; ++d) {
+            const double uu = U[u[b] * D + d], pp = I[p[b] * D + d], nn = I[n[b] * D + d];
+            Uref[u[b] * D + d] -= lr * (g[b] * (pp - nn) + cu * uu);
+            Iref[p[b] * D + d] -= lr * (g[b] * uu + ci * pp);
+            Iref[n[b] * D + d] -= lr * (-g[b] * uu);
+        }
+
+    /* ---- device side through the C ABI ------------------------------------------------------------------------ */
+    float *dU, *dI, *dOut, *dGU, *dGP, *dScores; int64_t *du, *dp_, *dn_; uint32_t *dKeys, *dPerm; void* dWs;
+    CHECK_HIP(hipSetDevice(0));
+    CHECK_HIP(hipMalloc((void**)&dU, sizeof(float) * NU * D)); CHECK_HIP(hipMalloc((void**)&dI, sizeof(float) * NI * D));
+    CHECK_HIP(hipMalloc((void**)&dOut, sizeof(float) * 16)); CHECK_HIP(hipMalloc((void**)&dGU, sizeof(float) * B * D));
+    CHECK_HIP(hipMalloc((void**)&dGP, sizeof(float) * B * D)); CHECK_HIP(hipMalloc((void**)&dScores, sizeof(float) * 3 * NI));
+    CHECK_HIP(hipMalloc((void**)&du, 8 * B)); CHECK_HIP(hipMalloc((void**)&dp_, 8 * B)); CHECK_HIP(hipMalloc((void**)&dn_, 8 * B));
+    CHECK_HIP(hipMalloc((void**)&dKeys, 4 * 3 * B)); CHECK_HIP(hipMalloc((void**)&dPerm, 4 * 3 * B));
+    CHECK_HIP(hipMemcpy(dU, U, sizeof(float) * NU * D, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dI, I, sizeof(float) * NI * D, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(du, u, 8 * B, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dp_, p, 8 * B, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(dn_, n, 8 * B, hipMemcpyHostToDevice)); CHECK_HIP(hipMemset(dOut, 0, sizeof(float) * 16));
+    cdr_ctx* ctx = NULL;
+    CHECK_CDR(cdr_ctx_create(0, &ctx));
+    float out[16];
+    int ok = 1;
+
+    CHECK_CDR(cdr_bpr_fwd(ctx, NULL, dU, dI, D, du, dp_, dn_, B, gamma, reg, dOut, NULL));
+    CHECK_HIP(hipDeviceSynchronize()); CHECK_HIP(hipMemcpy(out, dOut, sizeof(float) * 4, hipMemcpyDeviceToHost));
+    ok &= close_enough(out[0], total, 0, "bpr_fwd total loss") & close_enough(out[1], main_loss, 0, "bpr_fwd main loss") &
+          close_enough(out[2], nu_, 0, "EmbLoss user norm") & close_enough(out[3], ni_, 0, "EmbLoss item norm");
+
+    CHECK_CDR(cdr_fullsort_scores_f32(NULL, dU, 3, D, dI, NI, NULL, 0, dScores));
+    float* sc = (float*)malloc(sizeof(float) * 3 * NI);
+    CHECK_HIP(hipDeviceSynchronize()); CHECK_HIP(hipMemcpy(sc, dScores, sizeof(float) * 3 * NI, hipMemcpyDeviceToHost));
+    for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < NI; j += 37) {
+            double want = 0;
+            for (int d = 0; d < D; ++d) want += (double)U[q * D + d] * I[j * D + d];
+            ok &= close_enough(sc[q * NI + j], want, 0.05, "full-sort score");
+        }
+
+    size_t ws_bytes = 0;
+    CHECK_CDR(cdr_sort_workspace_bytes(3 * B, 2048, &ws_bytes));            /* keys < 2 * 2^ceil(log2(max rows)) = 1024 */
+    CHECK_HIP(hipMalloc(&dWs, ws_bytes));
+    uint32_t key_base = 0;
+    CHECK_CDR(cdr_bpr_fwd_grad(ctx, NULL, dU, dI, D, du, dp_, dn_, B, 0, gamma, reg, dOut, dGU, dGP, 0));
+    CHECK_CDR(cdr_sort_ids_two_tables(ctx, NULL, du, B, NU, dp_, B, dn_, B, NI, dKeys, dPerm, &key_base, dWs, ws_bytes));
+    CHECK_CDR(cdr_rowwise_apply(ctx, NULL, CDR_OPT_SGD, dU, NULL, NULL, D, dKeys, dPerm, B, dGU, B, B, dOut + 4, lr, 0.9f, 0.999f, 1e-8f,
+                                0.f, 1, NULL, 0));
+    CHECK_CDR(cdr_rowwise_apply(ctx, NULL, CDR_OPT_SGD, dI, NULL, NULL, D, dKeys + B, dPerm + B, 2 * B, dGP, B, B, dOut + 5, lr, 0.9f,
+                                0.999f, 1e-8f, 0.f, 1, NULL, key_base));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(out, dOut, sizeof(float) * 6, hipMemcpyDeviceToHost));
+    ok &= close_enough(out[0], total, 0, "fused step loss");
+    float* U2 = (float*)malloc(sizeof(float) * NU * D); float* I2 = (float*)malloc(sizeof(float) * NI * D);
+    CHECK_HIP(hipMemcpy(U2, dU, sizeof(float) * NU * D, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(I2, dI, sizeof(float) * NI * D, hipMemcpyDeviceToHost));
+    for (int i = 0; i < NU * D; ++i) ok &= close_enough(U2[i], Uref[i], 0.2, "user table after the step");
+    for (int i = 0; i < NI * D; ++i) ok &= close_enough(I2[i], Iref[i], 0.2, "item table after the step");
+    CHECK_CDR(cdr_ctx_destroy(ctx));
+    printf(ok ? "abi_smoke: OK (loss %.7f)\n" : "abi_smoke: FAILED (loss %.7f)\n", out[0]);
+    return ok ? 0 : 1;
+}

@@ -55,3 +55,18 @@ def test_get_model_lookup():
     assert recbole_cdr_amd.get_model('CMF').__name__ == 'CMF'
     with pytest.raises(ValueError):
         recbole_cdr_amd.get_model('NoSuchModel')
+
+
+def test_header_is_valid_c_and_c_consumer_links():
+    """include/cdr_hip.h compiles as C11 (gcc -fsyntax-only) and the plain-C consumer tests/abi_c/abi_smoke.c builds against the
+    library -- the boundary does not depend on C++ or torch.  (The program itself runs in the -m gpu suite.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = '#include "cdr_hip.h"\nint main(void) { return cdr_abi_version() == CDR_ABI_VERSION ? 0 : 1; }\n'
+    r = subprocess.run(['gcc', '-std=c11', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', '-', '-I', os.path.join(root, 'include')],
+                       input=probe.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run(['make', '-B', '-C', os.path.join(root, 'tests', 'abi_c')], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert os.path.isfile(os.path.join(root, 'tests', 'abi_c', 'abi_smoke'))

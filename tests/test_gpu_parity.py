@@ -1557,3 +1557,17 @@ def test_device_sampler_popularity_distribution():
     assert got[cnt == 0].sum() == 0                                          # items nobody interacted with are never drawn
     smp2 = DeviceNegSampler(ds, 'target', pairs, DEV, seed=11, distribution='popularity')
     assert torch.equal(smp2(u, None, k), neg)
+
+
+def test_plain_c_consumer_of_the_abi():
+    """tests/abi_c/abi_smoke: a C program (gcc + the HIP runtime, no torch) drives cdr_bpr_fwd, cdr_fullsort_scores_f32 and one
+    fused row-wise SGD step through libcdrhip.so and checks them against its own double-precision arithmetic."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, 'tests', 'abi_c', 'abi_smoke')
+    if not os.path.isfile(exe):
+        subprocess.run(['make', '-C', os.path.dirname(exe)], check=True)
+    r = subprocess.run([exe], capture_output=True, timeout=120)
+    assert r.returncode == 0, (r.stdout.decode(), r.stderr.decode())
+    assert b'abi_smoke: OK' in r.stdout
