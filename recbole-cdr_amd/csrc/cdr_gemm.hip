@@ -351,6 +351,131 @@ __device__ __forceinline__ float topk_offer(float v, int col, float thr, float& 
 // XCD-aware: workgroup b runs on XCD b % 8 (observed placement; speed only), and the workgroups of one XCD that share
 // an item stripe walk it together for different user blocks, so an item tile is fetched from HBM once and re-used
 // from that XCD's L2 by the other user blocks instead of being re-read U/BM times.
+// ---- few users (U <= 8): the streaming GEMV with the mask + top-k behind it ------------------------------------------------
+// Same stream over the item slab as fullsort_gemv_kernel (a lane group owns 32 consecutive item rows per chunk, users in
+// registers, the chunk's 256 scores per user parked in LDS) -- but instead of writing them out, wave w offers the scores of users
+// w and w + 4 to their running lists (registers: lane j = entry j).  Survivors of the k-th-value test wait in a per-user LDS queue
+// and are mask-tested 64 at a time (one history search per lane), so the dependent global loads of the search are paid once per
+// 64 survivors, not once each.  A block ends with one partial list per user; the reference's U = 1 evaluation never writes the
+// 40 MB score vector.
+constexpr int kGemvQueue = 128;
+
+template <int LPR, int UMAX>
+__global__ __launch_bounds__(256) void fullsort_gemv_topk_kernel(const float* __restrict__ users, int U, int D,
+                                                                 const float* __restrict__ items, int64_t N, int col_off, int k,
+                                                                 topk_mask mk, float* __restrict__ pv, int* __restrict__ pc,
+                                                                 int64_t prod0) {
+    constexpr int GPB = 256 / LPR;
+    constexpr int RPG = 256 / GPB;
+    constexpr int SLOTS = (UMAX + 3) / 4;                     // users per wave
+    __shared__ float sm[UMAX][256];
+    __shared__ float qv[UMAX][kGemvQueue];
+    __shared__ int qc[UMAX][kGemvQueue];
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D4 = D >> 2;
+    const bool live = sub < D4;
+    float4 uv[UMAX];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u)
+        uv[u] = (u < U && live) ? ld4(users + (int64_t)u * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float e[SLOTS], thr[SLOTS];
+    int ec[SLOTS], qn[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) { e[sl] = thr[sl] = -INFINITY; ec[sl] = -1; qn[sl] = 0; }
+    const int64_t n_chunks = (N + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t row0 = chunk * 256 + (int64_t)grp * RPG;
+#pragma unroll 1
+        for (int it = 0; it < RPG; it += 4) {
+            float4 x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + it + r;
+                x[r] = (row < N && live) ? ld4(items + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u) {
+                    const float d = group_sum<LPR>(dot4(uv[u], x[r]));
+                    if (sub == 0) sm[u][grp * RPG + it + r] = d;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int u = wave + 4 * sl;
+            if (u >= U || u >= UMAX) continue;                 // wave-uniform
+            volatile float* myv = qv[u];
+            volatile int* myc = qc[u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t nrow = chunk * 256 + 64 * j + lane;
+                const float v = sm[u][64 * j + lane];
+                const bool pass = nrow < N && v > thr[sl];
+                const unsigned long long m = __ballot(pass);
+                if (m == 0) continue;
+                if (pass) {
+                    const int at = qn[sl] + __popcll(m & ((1ull << lane) - 1));
+                    myv[at] = v; myc[at] = col_off + (int)nrow;
+                }
+                qn[sl] += __popcll(m);
+                if (qn[sl] > kGemvQueue - 64) {
+                    for (int b = 0; b < qn[sl]; b += 64) {
+                        const int i = b + lane;
+                        thr[sl] = topk_offer(i < qn[sl] ? myv[i] : -INFINITY, i < qn[sl] ? myc[i] : 0, thr[sl], e[sl], ec[sl], k, mk, u);
+                    }
+                    qn[sl] = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int u = wave + 4 * sl;
+        if (u >= U || u >= UMAX) continue;
+        volatile float* myv = qv[u];
+        volatile int* myc = qc[u];
+        for (int b = 0; b < qn[sl]; b += 64) {
+            const int i = b + lane;
+            thr[sl] = topk_offer(i < qn[sl] ? myv[i] : -INFINITY, i < qn[sl] ? myc[i] : 0, thr[sl], e[sl], ec[sl], k, mk, u);
+        }
+        if (lane < k) {
+            const int64_t o = ((prod0 + blockIdx.x) * U + u) * k + lane;
+            pv[o] = e[sl];
+            pc[o] = ec[sl];
+        }
+    }
+}
+
+constexpr int kGemvTopkBlocks = 1024;
+
+template <int LPR>
+static int launch_gemv_topk(hipStream_t s, const float* users, int U, int D, const float* items, int64_t N, int col_off, int k,
+                            const topk_mask& mk, float* pv, int* pc, int64_t prod0, unsigned grid) {
+    if (U <= 1) fullsort_gemv_topk_kernel<LPR, 1><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, col_off, k, mk, pv, pc, prod0);
+    else if (U <= 2) fullsort_gemv_topk_kernel<LPR, 2><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, col_off, k, mk, pv, pc, prod0);
+    else if (U <= 4) fullsort_gemv_topk_kernel<LPR, 4><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, col_off, k, mk, pv, pc, prod0);
+    else fullsort_gemv_topk_kernel<LPR, 8><<<dim3(grid), dim3(256), 0, s>>>(users, U, D, items, N, col_off, k, mk, pv, pc, prod0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdr_set_error("fullsort gemv top-k: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return CDR_OK;
+}
+
+static int gemv_topk_dispatch(hipStream_t s, const float* users, int U, int D, const float* items, int64_t N, int col_off, int k,
+                              const topk_mask& mk, float* pv, int* pc, int64_t prod0, unsigned grid) {
+    switch (cdr_lpr_for(D)) {
+        case 4: return launch_gemv_topk<4>(s, users, U, D, items, N, col_off, k, mk, pv, pc, prod0, grid);
+        case 8: return launch_gemv_topk<8>(s, users, U, D, items, N, col_off, k, mk, pv, pc, prod0, grid);
+        case 16: return launch_gemv_topk<16>(s, users, U, D, items, N, col_off, k, mk, pv, pc, prod0, grid);
+        case 32: return launch_gemv_topk<32>(s, users, U, D, items, N, col_off, k, mk, pv, pc, prod0, grid);
+        default: return launch_gemv_topk<64>(s, users, U, D, items, N, col_off, k, mk, pv, pc, prod0, grid);
+    }
+}
+
 constexpr int kTopkQueue = 256;
 
 struct topk_out {
@@ -806,6 +931,8 @@ constexpr size_t kTopkScoreBytes = (size_t)256 << 20;   // score staging for the
 
 struct topk_plan {
     int64_t sub;                                    // columns per wave of topk_rows_kernel
+    bool gemv[2];                                   // U <= 8: streaming GEMV with the top-k behind it (no score staging)
+    int64_t gemv_blocks[2];
     bool fused[2];
     int64_t stripes[2], fused_cols[2];              // fused: producers and the columns they cover (multiple of 64)
     int64_t pass_cols;                              // unfused: columns scored per pass
@@ -834,7 +961,12 @@ static topk_plan make_topk_plan(int64_t U, int D, const int64_t n[2], int k, con
         p.fused[i] = U > 32 && (D == 64 || D == 128) && n[i] >= 64 && U < ((int64_t)1 << 30) &&
                      (slab[i] == nullptr || ((((uintptr_t)users | (uintptr_t)slab[i]) & 15) == 0)) &&
                      fused_lds_bytes(D, MT, k) <= (size_t)160 * 1024;
-        if (p.fused[i]) {
+        p.gemv[i] = !p.fused[i] && U <= 8 && (D & 3) == 0 && D >= 16 && D <= 256;
+        if (p.gemv[i]) {
+            const int64_t chunks = (n[i] + 255) / 256;
+            p.gemv_blocks[i] = chunks < kGemvTopkBlocks ? chunks : kGemvTopkBlocks;
+            p.producers += p.gemv_blocks[i];
+        } else if (p.fused[i]) {
             const int BM = 64 * MT;
             const int64_t MB = (U + BM - 1) / BM, per_xcd = CDR_NUM_CU / 8;
             const int64_t MBc = MB < per_xcd ? MB : per_xcd;
@@ -915,7 +1047,14 @@ extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t 
     int64_t prod = 0, col_off = 0;
     for (int i = 0; i < 2; ++i) {
         if (n[i] <= 0) continue;
-        if (p.fused[i]) {
+        if (p.gemv[i] && ((((uintptr_t)user_e | (uintptr_t)slab[i]) & 15) == 0)) {
+            int rc = gemv_topk_dispatch(s, user_e, (int)U, D, slab[i], n[i], (int)col_off, k, mk, pv, pc, prod, (unsigned)p.gemv_blocks[i]);
+            if (rc) return rc;
+            prod += p.gemv_blocks[i];
+        } else if (p.gemv[i]) {
+            cdr_set_error("cdr_fullsort_topk_f32: operands must be 16-byte aligned");
+            return CDR_EINVAL;
+        } else if (p.fused[i]) {
             const topk_out tk{k, (int)col_off, pv + prod * U * k, pc + prod * U * k, mk};
             const int NT = (int)(n[i] / 64);
             const unsigned grid = CDR_NUM_CU;
