@@ -19,11 +19,22 @@ OU, TOI, NI, BATCH = int(os.environ.get('E2E_USERS', 4_000_001)), int(os.environ
     int(os.environ.get('E2E_INTER', 12_000_000)), 1 << 20
 t0 = time.time()
 ds = SyntheticCrossDomainDataset(OU=OU, TOU=0, SOU=0, OI=1, TOI=TOI, SOI=TOI, n_source_inter=NI, n_target_inter=NI)
+C = int(os.environ.get('E2E_CLUSTERS', 0))
+EPOCHS = os.environ.get('E2E_EPOCHS', '2')
+if C:
+    # learnable structure: user u and item i interact only when u % C == (item's index in its domain) % C
+    rng = np.random.RandomState(7)
+    def clustered(n, item_lo):
+        u = rng.randint(1, OU, n)
+        j = rng.randint(0, TOI // C, n) * C + u % C                       # index inside the domain, same residue as the user
+        return np.unique(np.stack([u, item_lo + np.minimum(j, TOI - 1)], 1), axis=0)
+    ds.t_pairs, ds.s_pairs = clustered(NI, 1), clustered(NI, 1 + TOI)
+    rng.shuffle(ds.t_pairs)
 cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev,
        'latent_factor_model': 'BPR', 'source_embedding_size': 128, 'target_embedding_size': 128, 'reg_weight': 0.01,
-       'mapping_function': 'linear', 'mlp_hidden_size': [128], 'learning_rate': 1e-3, 'optimizer_mode': 'rowwise',
-       'train_modes': ['SOURCE', 'TARGET', 'OVERLAP'], 'epoch_num': ['2', '2', '2'], 'source_split': False, 'eval_step': 0,
-       'epochs': 2, 'topk': [10], 'valid_metric': 'Recall@10'}
+       'mapping_function': 'linear', 'mlp_hidden_size': [128], 'learning_rate': float(os.environ.get('E2E_LR', 1e-3)), 'optimizer_mode': 'rowwise',
+       'train_modes': ['SOURCE', 'TARGET', 'OVERLAP'], 'epoch_num': [EPOCHS, EPOCHS, '2'], 'source_split': False, 'eval_step': 0,
+       'epochs': int(EPOCHS), 'learning_rate_note': 'lr below', 'topk': [10], 'valid_metric': 'Recall@10'}
 torch.manual_seed(2022)
 model = EMCDR(cfg, ds).to(dev)
 dt = lambda a: torch.from_numpy(a.copy()).to(dev)
@@ -47,7 +58,7 @@ def timed(data, e):
     return v
 trainer._train_epoch = timed
 trainer.fit(train)
-rows = [('SOURCE', len(ds.s_pairs))] * 2 + [('TARGET', len(t_tr))] * 2 + [('OVERLAP', OU)] * 2   # first epoch of a phase
+rows = [('SOURCE', len(ds.s_pairs))] * int(EPOCHS) + [('TARGET', len(t_tr))] * int(EPOCHS) + [('OVERLAP', OU)] * 2   # first epoch of a phase
 for (phase, n), (sec, loss) in zip(rows, log):                                                  # also builds its step objects
     print(f'{phase:8s} epoch: {sec * 1e3:9.1f} ms wall for {n} rows = {n / sec / 1e6:8.1f} M rows/s (epoch loss sum {loss:.4f})', flush=True)
 # evaluation in the target domain after the OVERLAP phase (users mapped through the learned mapping): fused mask + top-10
@@ -55,6 +66,12 @@ te_users = np.unique(t_te[:, 0])[:4096]
 t_te = t_te[np.isin(t_te[:, 0], te_users)]
 hist = t_tr[np.isin(t_tr[:, 0], te_users)]
 loader = FullSortEvalLoader('target_user_id', t_te, hist, ds.num_overlap_item + ds.num_target_only_item, 1024 * (1 + TOI), dev)
+if C:
+    model.set_phase('TARGET')
+    r = trainer.evaluate(loader)
+    print(f'clustered data ({C} clusters): recall@10 in the TARGET phase {r["recall@10"]:.5f}, hit@10 {r["hit@10"]:.5f} '
+          f'(random ranking: {10.0 / TOI:.6f}; a perfect cluster model: ~{min(1.0, 10.0 * C / TOI):.4f})', flush=True)
+    model.set_phase('OVERLAP')
 for attempt in ('first call (allocates the workspaces)', 'second call'):
     torch.cuda.synchronize(); t = time.time()
     res = trainer.evaluate(loader)
