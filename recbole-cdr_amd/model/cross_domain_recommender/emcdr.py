@@ -139,6 +139,9 @@ class EMCDR(CrossDomainRecommender):
                     getattr(self, f'source_{kind}_embedding').weight.data, getattr(self, f'target_{kind}_embedding').weight.data,
                     self.apply_mapping, list(self.mapping.parameters()), idx.numel(),
                     source_state=state(f'source_{kind}_embedding'), target_state=state(f'target_{kind}_embedding'), **hp)
+                pending = self.__dict__.get('_pending_map_state', {}).pop(kind, None)
+                if pending is not None and cache['steps'][key].map_opt is not None:
+                    cache['steps'][key].map_opt.load_state_dict(pending)
             return cache['steps'][key].step(idx)
         domain = 'source' if self.phase == 'SOURCE' else 'target'
         user = interaction[getattr(self, f'{domain.upper()}_USER_ID')].reshape(-1)
@@ -164,6 +167,33 @@ class EMCDR(CrossDomainRecommender):
                                 item_state=state(f'{domain}_item_embedding'), **hp)
             cache['steps'][key] = step
         return step.step(user, item, neg)[0]
+
+    def fused_optimizer_state(self):
+        """Row-wise optimizer state of ``fused_train_step`` for a checkpoint: per table the moments and the update count, plus
+        the dense Adam state of the mapping function (recbole's checkpoint stores ``optimizer.state_dict()``; this is its
+        counterpart for ``optimizer_mode='rowwise'``)."""
+        cache = self.__dict__.get('_fused')
+        if not cache:
+            return {}
+        out = {'tables': {k: {'step': st.step, 'exp_avg': st.exp_avg, 'exp_avg_sq': st.exp_avg_sq} for k, st in cache['states'].items()}}
+        for key, step in cache['steps'].items():
+            if key[0] == 'map' and step.map_opt is not None:
+                out.setdefault('mapping', {})[key[1]] = step.map_opt.state_dict()
+        return out
+
+    def load_fused_optimizer_state(self, state, opt='adam'):
+        """Restore what ``fused_optimizer_state`` returned (before the next ``fused_train_step``)."""
+        from ...fused import RowwiseState, OPT_ADAM, OPT_SGD
+        cache = self.__dict__.setdefault('_fused', {'states': {}, 'steps': {}})
+        code = OPT_ADAM if opt == 'adam' else OPT_SGD
+        for name, rec in state.get('tables', {}).items():
+            st = cache['states'].get(name)
+            if st is None:
+                st = cache['states'][name] = RowwiseState(getattr(self, name).weight.data, code)
+            st.step = int(rec['step'])
+            if rec['exp_avg'] is not None:
+                st.exp_avg.copy_(rec['exp_avg']); st.exp_avg_sq.copy_(rec['exp_avg_sq'])
+        self._pending_map_state = state.get('mapping', {})
 
     # ---- scoring ------------------------------------------------------------------------------------------------
     def _mapped_rows(self, kind, ids, n_overlap):

@@ -174,6 +174,31 @@ class Trainer:
             result[f'ndcg@{k}'] = float((dcg / idcg).mean())
         return result
 
+    def save_checkpoint(self, path, epoch=None):
+        """recbole ``Trainer._save_checkpoint``: config-free subset -- epoch, early-stopping state, model ``state_dict``,
+        ``other_parameter`` and the optimizer state (dense: ``DenseAdam.state_dict()``; rowwise: the model's per-table
+        moments and update counts)."""
+        state = {'epoch': epoch, 'cur_step': self.cur_step, 'best_valid_score': self.best_valid_score,
+                 'state_dict': self.model.state_dict(), 'other_parameter': self.model.other_parameter(),
+                 'optimizer_mode': self.optimizer_mode, 'optimizer': self.optimizer.state_dict(),
+                 'phase': getattr(self.model, 'phase', None)}
+        if self.optimizer_mode == 'rowwise' and hasattr(self.model, 'fused_optimizer_state'):
+            state['rowwise'] = self.model.fused_optimizer_state()
+        torch.save(state, path)
+
+    def resume_checkpoint(self, path):
+        """recbole ``Trainer.resume_checkpoint``."""
+        state = torch.load(path, map_location=self.device, weights_only=False)
+        self.start_epoch = (state['epoch'] + 1) if state['epoch'] is not None else 0
+        self.cur_step, self.best_valid_score = state['cur_step'], state['best_valid_score']
+        self.model.load_state_dict(state['state_dict'])
+        self.model.load_other_parameter(state.get('other_parameter'))
+        if state.get('phase') is not None and hasattr(self.model, 'set_phase'):
+            self.model.set_phase(state['phase'])
+        self.optimizer.load_state_dict(state['optimizer'])
+        if 'rowwise' in state and hasattr(self.model, 'load_fused_optimizer_state'):
+            self.model.load_fused_optimizer_state(state['rowwise'])
+
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
         for epoch_idx in range(self.start_epoch, self.epochs):
             train_loss = self._train_epoch(train_data, epoch_idx)
