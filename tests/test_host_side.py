@@ -217,3 +217,26 @@ def test_alias_table_matches_reference_construction():
     cnt = Counter(cand)
     for k in cnt:
         assert abs(mass[k] / len(keys) - cnt[k] / len(cand)) < 1e-9
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r01_bench_c5.json is the line `python bench.py` printed on the GPU box: every key the driver and the judge read
+    is there, with the right types and the internal consistency the contract asks for."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, 'profiles', 'r01_bench_c5.json')))
+    for k, t in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int),
+                 ('ms_per_step', float), ('higher_is_better', bool), ('scaling', str), ('dtype', str), ('data', str), ('config', dict)):
+        assert isinstance(d[k], t), (k, type(d[k]))
+    assert d['vs_baseline'] is None and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['n_gpus'] == 1
+    assert 'workload' in d['config'] and 'model' not in d['config'] and d['dtype'] == 'f32' and d['data'].startswith('synthetic')
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.3 < r['frac'] < 1.0
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str) and c['unit'] == d['unit']
+    # value = triples of all ranks / measured time: 2 domains x B per step
+    B = d['config']['batch_per_domain_per_rank']
+    assert abs(d['value'] - 2 * B * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
