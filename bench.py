@@ -153,6 +153,9 @@ def run_c5(args, world, rank, dev):
 
     for i in range(args.warmup):
         one_step(i)
+    if sharded:
+        for st in steps.values():
+            st.profile(True)
     # HIP-event brackets around each hot kernel, recorded by the library on the stream the kernel is launched on
     B_.timing_enable(dev, args.steps * 2 * 5 + 16)
     barrier(world)
@@ -243,6 +246,20 @@ def run_c5(args, world, rank, dev):
                                      'avg_launch_ms': gk['avg_ms'], 'traffic': pmc_traffic(gk['kernel'])}
         result['kernels'] = kernels
 
+    if sharded:
+        # what the links carried and how long this rank's two domain streams spent inside all-to-alls (they overlap each other
+        # and the other domain's kernels, so this is NOT additive with the kernel times: it says which side bounds the step)
+        xb, xms = 0, 0.0
+        for st in steps.values():
+            b_, m_ = st.exchange_stats()
+            xb += b_; xms += m_
+        xt = torch.tensor([xb / args.steps, xms / args.steps], device=dev, dtype=torch.float64)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(xt, op=dist.ReduceOp.MAX)
+        result['exchange'] = {'bytes_to_other_ranks_per_step_per_rank': float(xt[0]), 'all_to_all_ms_per_step_max_rank': float(xt[1]),
+                              'note': 'event time inside the 4+4 all-to-alls of a step, both domain streams summed; overlaps the other '
+                                      "domain's kernels"}
     if rank == 0 and sharded:
         # N > 1: the exchange adds all-to-alls between the kernels; the kernels themselves are the 1-GPU ones.  Buckets
         # are balanced in expectation (uniform ids), so one fwd_grad launch sees ~B triples: 3 rows read, GU + 2 GI rows

@@ -224,6 +224,31 @@ class ShardedBPRStep:
     def loss_value(self):
         return self.out[0]
 
+    def profile(self, on=True):
+        """Count the bytes this rank sends to OTHER ranks and bracket every all-to-all with HIP events on the step's stream
+        (bench.py reports both for N > 1: what the links carried and how long the step waited on them)."""
+        self._prof = {'bytes': 0, 'events': []} if on else None
+
+    def exchange_stats(self):
+        """-> (bytes sent to other ranks, milliseconds inside all-to-alls) since ``profile()``; synchronises."""
+        if not self.__dict__.get('_prof'):
+            return 0, 0.0
+        torch.cuda.synchronize()
+        return self._prof['bytes'], sum(a.elapsed_time(b) for a, b in self._prof['events'])
+
+    def _x(self, inp, in_splits, out_splits, group, trailing=()):
+        prof = self.__dict__.get('_prof')
+        if not prof or not inp.is_cuda:
+            return _a2a(inp, in_splits, out_splits, group, trailing)
+        row = inp.element_size() * (inp.numel() // max(inp.shape[0], 1))
+        prof['bytes'] += row * (sum(in_splits) - in_splits[self.rank])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = _a2a(inp, in_splits, out_splits, group, trailing)
+        b.record()
+        prof['events'].append((a, b))
+        return out
+
     @staticmethod
     def _moments(st):
         return (st.exp_avg, st.exp_avg_sq) if st.exp_avg is not None else None
@@ -255,7 +280,7 @@ class ShardedBPRStep:
             t_send = [int(c) for c in allc[self.rank][:G]]
             t_recv = [int(allc[r][self.rank]) for r in range(G)]
             B_global = sum(int(allc[r][G]) for r in range(G))
-            recv3 = _a2a(send3, t_send, t_recv, grp, (3,))
+            recv3 = self._x(send3, t_send, t_recv, grp, (3,))
             Bl = recv3.shape[0]                                              # triples whose user row is mine
             u_loc = recv3[:, 0].contiguous()
             p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
@@ -280,9 +305,9 @@ class ShardedBPRStep:
             allc = torch.stack(gathered).tolist()                           # host sync #2
             i_send = [int(c) for c in allc[self.rank][:G]]
             i_recv = [int(allc[r][self.rank]) for r in range(G)]
-            i_req = _a2a(i_local_sorted, i_send, i_recv, grp)                # local item rows other ranks want (tagged)
+            i_req = self._x(i_local_sorted, i_send, i_recv, grp)                # local item rows other ranks want (tagged)
             i_req_rows = i_req & TAG_MASK
-            irows = _a2a(ops.gather_rows(self.I, i_req_rows), i_recv, i_send, grp, (self.D,))
+            irows = self._x(ops.gather_rows(self.I, i_req_rows), i_recv, i_send, grp, (self.D,))
 
             # ---- 2. fused forward + compact gradients; global loss reduction ----------------------------------
             GU = torch.empty(max(Bl, 1), self.D, device=uid.device, dtype=torch.float32)
@@ -300,7 +325,7 @@ class ShardedBPRStep:
             if Bl:
                 ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,
                                reg_limit=Bl, reg_coef=self.out[4:5])
-            gi_recv = _a2a(gi, i_send, i_recv, grp, (self.D,))
+            gi_recv = self._x(gi, i_send, i_recv, grp, (self.D,))
             # the owner adds the EmbLoss term itself (it holds the pre-step row; the tag tells it which occurrences count)
             ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step,
                            reg_coef=self.out[5:6], tagged=True)
@@ -324,8 +349,8 @@ class ShardedBPRStep:
             i_recv = [int(allc[r][self.rank]) for r in range(G)]
             n_uniq = sum(i_send)
             uniq = plan['uniq_local'][:n_uniq] if Bl else torch.empty(0, device=dev, dtype=torch.int64)
-            i_req = _a2a(uniq, i_send, i_recv, grp)                          # my item rows other ranks want, each once per rank
-            irows = _a2a(ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
+            i_req = self._x(uniq, i_send, i_recv, grp)                          # my item rows other ranks want, each once per rank
+            irows = self._x(ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
             GU = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
             GP = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
             if Bl:
@@ -343,7 +368,7 @@ class ShardedBPRStep:
                 gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq)
             else:
                 gi = torch.empty(0, self.D, device=dev, dtype=torch.float32)
-            gi_recv = _a2a(gi, i_send, i_recv, grp, (self.D,))
+            gi_recv = self._x(gi, i_send, i_recv, grp, (self.D,))
             # the EmbLoss term is already inside the rows: the owner just sums what it received per row and applies
             ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step)
 
