@@ -597,6 +597,11 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
             for (int q = 0; q < NQ; ++q) st4(smem + st_lds[q], ld4(bp + st_gl[q]));
         }
         __syncthreads();
+        // PIPE (score output, two accumulator tiles per wave): the scores of tile i are written while tile i+1's MFMAs run
+        // (they wait in `prev`), not between two MFMA phases: +2..13 % at U >= 256; with one tile per wave (U <= 64) it lost
+        constexpr bool PIPE = !TOPK && MT == 2;
+        f32x16 prev[MT];
+        int prev_tile = -1;
         for (; tile < NT; tile += n_stripes) {
             const int next = tile + n_stripes;
             const bool has_next = next < NT;
@@ -626,6 +631,21 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].z, b.z, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].w, b.w, acc[t], 0, 0, 0);
                 }
+                if (PIPE && s < KS / 2) {       // the previous tile's stores ride in the first half of this MFMA phase
+                    constexpr int PER = (MT * 16 + KS / 2 - 1) / (KS / 2);
+                    if (prev_tile >= 0) {
+                        float* cpp = C + (int64_t)prev_tile * BN + wn * 32 + li;
+#pragma unroll
+                        for (int j = 0; j < PER; ++j) {
+                            const int i = s * PER + j;
+                            if (i < MT * 16) {
+                                const int t = i / 16, r = i % 16;
+                                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                if (m < M) cpp[(int64_t)m * ldc] = prev[t][r];
+                            }
+                        }
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // park the prefetched tile in the other buffer FIRST (last read two iterations ago): the vmcnt wait in front
@@ -637,14 +657,20 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
             }
             // epilogue: lane column = item ; register r -> user row (r&3) + 8*(r>>2) + 4*lh
             if (!TOPK) {
-                float* cp = C + (int64_t)tile * BN + wn * 32 + li;
+                if (PIPE) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t) prev[t] = acc[t];
+                    prev_tile = tile;
+                } else {
+                    float* cp = C + (int64_t)tile * BN + wn * 32 + li;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (m < M) cp[(int64_t)m * ldc] = acc[t][r];
-                    }
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (m < M) cp[(int64_t)m * ldc] = acc[t][r];
+                        }
+                }
                 __syncthreads();
             } else {
                 // Fast path: every accumulator is compared IN REGISTERS with the k-th value of its user row; the rare survivor
@@ -745,6 +771,16 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                 ++tiles_done;
             }
             buf ^= 1;
+        }
+        if (PIPE && prev_tile >= 0) {          // the last tile of this user block
+            float* cpp = C + (int64_t)prev_tile * BN + wn * 32 + li;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M) cpp[(int64_t)m * ldc] = prev[t][r];
+                }
         }
         if (TOPK) {                            // drain what the fast path left in the queues
             const int qn = qcnt[wave];
