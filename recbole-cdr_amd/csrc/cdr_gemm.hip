@@ -598,8 +598,9 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         }
         __syncthreads();
         // PIPE (score output, two accumulator tiles per wave): the scores of tile i are written while tile i+1's MFMAs run
-        // (they wait in `prev`), not between two MFMA phases: +2..13 % at U >= 256; with one tile per wave (U <= 64) it lost
-        constexpr bool PIPE = !TOPK && MT == 2;
+        // (they wait in `prev`), not between two MFMA phases.  Same-box A/B: +4 % (D = 128) / +17 % (D = 64) at U = 1,024; with
+        // one tile per wave (U <= 64) +14 % at D = 64 and -3 % at D = 128, hence the condition
+        constexpr bool PIPE = !TOPK && (MT == 2 || K == 64);
         f32x16 prev[MT];
         int prev_tile = -1;
         for (; tile < NT; tile += n_stripes) {
