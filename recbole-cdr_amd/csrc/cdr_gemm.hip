@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         // (they wait in `prev`), not between two MFMA phases.  Same-box A/B: +4 % (D = 128) / +17 % (D = 64) at U = 1,024; with
         // one tile per wave (U <= 64) +14 % at D = 64 and -3 % at D = 128, hence the condition
         constexpr bool PIPE = !TOPK && (MT == 2 || K == 64);
+        // D = 128, two tiles per wave: also the LDS park of the prefetched tile moves into the phase (+8 % at U = 1,024; it lost
+        // 5..20 % at D = 64, where the phase is half as long)
+        constexpr bool PARK_IN = PIPE && MT == 2 && K == 128;
         f32x16 prev[MT];
         int prev_tile = -1;
         for (; tile < NT; tile += n_stripes) {
@@ -632,13 +635,19 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].z, b.z, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].w, b.w, acc[t], 0, 0, 0);
                 }
-                if (PIPE && s < KS / 2) {       // the previous tile's stores ride in the first half of this MFMA phase
+                if (PARK_IN && s == KS / 4) {   // the prefetched tile is parked inside the phase too (its loads landed a while ago)
+                    float* dst = smem + (buf ^ 1) * BUF;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) st4(dst + st_lds[q], stage[q]);
+                }
+                // the previous tile's stores ride in one half of this MFMA phase: the second half when the park sits in the first
+                if (PIPE && (PARK_IN ? s >= KS / 2 : s < KS / 2)) {
                     constexpr int PER = (MT * 16 + KS / 2 - 1) / (KS / 2);
                     if (prev_tile >= 0) {
                         float* cpp = C + (int64_t)prev_tile * BN + wn * 32 + li;
 #pragma unroll
                         for (int j = 0; j < PER; ++j) {
-                            const int i = s * PER + j;
+                            const int i = (PARK_IN ? s - KS / 2 : s) * PER + j;
                             if (i < MT * 16) {
                                 const int t = i / 16, r = i % 16;
                                 const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
             __builtin_amdgcn_sched_barrier(0);
             // park the prefetched tile in the other buffer FIRST (last read two iterations ago): the vmcnt wait in front
             // of these LDS writes covers the loads issued before the MFMA phase, not the epilogue's stores below
-            {
+            if (!PARK_IN) {
                 float* dst = smem + (buf ^ 1) * BUF;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) st4(dst + st_lds[q], stage[q]);
