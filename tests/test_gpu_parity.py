@@ -1627,3 +1627,30 @@ def test_checkpoint_resume_continues_bit_exactly(mode, tmp_path):
             assert torch.equal(pa, pc), k                      # fixed-order reductions: the resumed run is bit-identical
         else:
             assert_close(pc.detach(), pa.detach(), rtol=1e-6, atol=1e-7, what=k)   # dense backward accumulates with fp32 atomics
+
+
+def test_integration_md_stub_runs_as_documented():
+    """The ctypes stub INTEGRATION.md tells a maintainer to paste into the reference's emcdr.py is executed verbatim (only the
+    library path is resolved) and its autograd Function is held to the oracle: the document stays true to the ABI."""
+    import os
+    import re
+    from oracle import losses
+    from recbole_cdr_amd import binding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = re.search(r"```python\n# --- add near the imports.*?```", text, re.S).group(0)
+    code = block[len('```python\n'):-3].split('# --- inside class EMCDR')[0]
+    code = code.replace('ctypes.CDLL("libcdrhip.so")', f'ctypes.CDLL({binding.lib_path()!r})')
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    torch.manual_seed(0)
+    U = (torch.randn(300, 64) * 0.2); I = (torch.randn(200, 64) * 0.2)
+    u, p, n = torch.randint(0, 300, (500,)), torch.randint(0, 200, (500,)), torch.randint(0, 200, (500,))
+    Ur, Ir = U.clone().requires_grad_(True), I.clone().requires_grad_(True)
+    ref = losses.bpr_loss((Ur[u] * Ir[p]).sum(1), (Ur[u] * Ir[n]).sum(1)) + 0.01 * losses.emb_loss(Ur[u], Ir[p])
+    ref.sum().backward()
+    Ud, Id = U.to(DEV).requires_grad_(True), I.to(DEV).requires_grad_(True)
+    got = ns['_BPR'].apply(Ud, Id, u.to(DEV), p.to(DEV), n.to(DEV), 0.01)
+    got.sum().backward()
+    assert_close(got.reshape(()), ref.detach(), what='stub loss')
+    assert_close(Ud.grad, Ur.grad, what='stub dU'); assert_close(Id.grad, Ir.grad, what='stub dI')
