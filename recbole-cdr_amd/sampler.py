@@ -20,15 +20,19 @@ class DeviceNegSampler:
             self.ranges = (1, OI, OI + TOI, total_i)
         else:
             self.ranges = (1, OI + TOI, 0, 0)
-        pairs = np.unique(np.asarray(used_pairs, dtype=np.int64), axis=0)          # sorted by (user, item)
-        indptr = np.zeros(total_u + 1, dtype=np.int64)
-        np.cumsum(np.bincount(pairs[:, 0], minlength=total_u), out=indptr[1:])
+        # the per-user CSR of used items, built where it will live: one sort of (user, item) keys on the device (numpy's
+        # np.unique(axis=0) over 12 M pairs took ~5 s per sampler)
+        pairs_t = torch.as_tensor(np.asarray(used_pairs, dtype=np.int64) if not torch.is_tensor(used_pairs) else used_pairs).to(device)
+        key = torch.unique(pairs_t[:, 0] * total_i + pairs_t[:, 1])               # sorted by (user, item), duplicates dropped
+        users_sorted = key // total_i
+        indptr = torch.zeros(total_u + 1, device=device, dtype=torch.int64)
+        indptr[1:] = torch.cumsum(torch.bincount(users_sorted, minlength=total_u), 0)
         n_cand = max(self.ranges[1] - self.ranges[0], 0) + max(self.ranges[3] - self.ranges[2], 0)
-        if (np.diff(indptr) >= n_cand).any():
+        if bool(((indptr[1:] - indptr[:-1]) >= n_cand).any()):
             raise ValueError('Some users have interacted with all items, which we can not sample negative items for them. '
                              'Please set `user_inter_num_interval` to filter those users.')
-        self.indptr = torch.from_numpy(indptr).to(device)
-        self.indices = torch.from_numpy(pairs[:, 1].copy()).to(device)
+        self.indptr = indptr
+        self.indices = (key % total_i).contiguous()
         self.fail = torch.zeros(1, device=device, dtype=torch.int32)
         self.seed, self.calls, self.device = int(seed), 0, device
         if distribution not in ('uniform', 'popularity'):
