@@ -13,7 +13,7 @@ Adam update of the touched rows (csrc/cdr_step.hip).  Inputs (tables, id batches
 region.  With N>1 the tables are row-sharded (row r on rank r % N) and every rank contributes its own batch
 (weak scaling in batch; table size fixed); rows/gradients travel by RCCL all-to-all (shard.py).
 
-`--workload c2|c3|c4` run BASELINE configs[1..3] (EMCDR ml-1m->ml-100k sizes, CoNet Amazon sizes, BiTGCF Douban sizes)
+`--workload c1|c2|c3|c4` run BASELINE configs[0..3] (CMF and EMCDR at ml-1m->ml-100k sizes, CoNet Amazon sizes, BiTGCF Douban sizes)
 through the drop-in class contract (autograd + exact dense Adam), the whole step replayed as one hipGraph.
 """
 import argparse
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='c5', choices=['c5', 'c2', 'c3', 'c4'])
+    ap.add_argument('--workload', default='c5', choices=['c5', 'c1', 'c2', 'c3', 'c4'])
     ap.add_argument('--batch', type=int, default=1 << 20, help='triples per domain per rank per step (c5)')
     ap.add_argument('--opt', default='adam', choices=['adam', 'sgd'])
     ap.add_argument('--users', type=int, default=50_000_001)
@@ -390,7 +390,15 @@ def run_model_workload(args, world, rank, dev):
     from recbole_cdr_amd.trainer.trainer import DenseAdam
     cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev}
     pairwise = False
-    if args.workload == 'c2':
+    if args.workload == 'c1':
+        from recbole_cdr_amd.model.cross_domain_recommender.cmf import CMF as Model
+        # BASELINE configs[0]: the reference's default run (CMF, ml-1m -> ml-100k, embedding_size 64); same id space as C2
+        ds = SyntheticCrossDomainDataset(OU=1, TOU=943, SOU=6040, OI=1604, TOI=61, SOI=2280,
+                                         n_source_inter=575000, n_target_inter=82000)
+        cfg.update(embedding_size=64, alpha=0.5, **{'lambda': 0.0, 'gamma': 0.0})
+        S, k = 1024, 1
+        name = 'C1: CMF ml-1m->ml-100k sizes (6,984 users x 3,945 items union, shared tables), D=64, 2 x 2,048 rows per step'
+    elif args.workload == 'c2':
         from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR as Model
         # ml-1m -> ml-100k is an ITEM-overlap pair: 1,603 shared titles, no shared users
         ds = SyntheticCrossDomainDataset(OU=1, TOU=943, SOU=6040, OI=1604, TOI=61, SOI=2280,
@@ -483,7 +491,11 @@ def cpu_baseline_model(args, ds, cfg, S, k, pair_batch=None):
     xav = lambda r, c: (torch.randn(r, c) * (2.0 / (r + c)) ** 0.5).requires_grad_(True)
     params = {f'{d}_{w}_embedding.weight': xav(nu if w == 'user' else ni, D) for d in ('source', 'target') for w in ('user', 'item')}
     graph = None
-    if args.workload == 'c2':
+    if args.workload == 'c1':
+        from oracle import cmf as ocmf
+        params = {'user_embedding.weight': xav(nu, D), 'item_embedding.weight': xav(ni, D)}
+        loss_fn = lambda b: ocmf.calculate_loss(params, ids, b, cfg['alpha'], cfg['lambda'], cfg['gamma'])
+    elif args.workload == 'c2':
         from oracle import emcdr as oem
         for l, (a, b) in enumerate(((D, 128), (128, D))):
             params[f'mapping.{2 * l}.weight'] = xav(b, a)
