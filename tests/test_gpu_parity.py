@@ -1409,6 +1409,16 @@ def _sdp_models(kind, dev):
         from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
         cfg = base_config(dev, embedding_size=16, reg_weight=0.01, mlp_hidden_size=[16, 8])
         model = CoNet(cfg, FakeDataset(ids)).to(dev)
+    elif kind == 'bitgcf':
+        # BASELINE configs[3] ("BiTGCF ..., item table row-sharded across 4 x MI355X"): every rank propagates the full graph on
+        # the replicated tables for its own batch, the tables' Adam state and sweep are sharded
+        from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+        rng = np.random.RandomState(3)
+        s_pairs = np.unique(np.stack([rng.randint(1, ids.OU, 150), rng.randint(ids.OI + ids.TOI, ids.total_num_items, 150)], 1), axis=0)
+        t_pairs = np.unique(np.stack([rng.randint(1, ids.OU + ids.TOU, 150), rng.randint(1, ids.OI + ids.TOI, 150)], 1), axis=0)
+        cfg = base_config(dev, embedding_size=16, n_layers=2, reg_weight=0.001, lambda_source=0.8, lambda_target=0.8, drop_rate=0.0,
+                          connect_way='concat')
+        model = BiTGCF(cfg, FakeDataset(ids, s_pairs=s_pairs, t_pairs=t_pairs)).to(dev)
     else:
         from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
         cfg = base_config(dev, latent_factor_model='BPR', source_embedding_size=16, target_embedding_size=16, reg_weight=0.01,
@@ -1421,14 +1431,14 @@ def _sdp_models(kind, dev):
         src_i = lambda n: torch.where(torch.rand(n, generator=g) < 0.5, r(1, ids.OI, n) if ids.OI > 1 else r(ids.OI + ids.TOI, ids.total_num_items, n),
                                       r(ids.OI + ids.TOI, ids.total_num_items, n))
         n = 24 + rank                                        # ragged: every rank its own batch size
-        if kind == 'conet':
+        if kind in ('conet', 'bitgcf'):
             return {'source_user_id': r(1, ids.OU, n), 'source_item_id': src_i(n), 'source_label': (torch.rand(n, generator=g) < 0.5).float(),
                     'target_user_id': r(1, ids.OU + ids.TOU, n), 'target_item_id': r(1, ids.OI + ids.TOI, n),
                     'target_label': (torch.rand(n, generator=g) < 0.5).float()}
         if step < 2:
             return {'source_user_id': r(1, ids.OU, n), 'source_item_id': src_i(n), 'neg_source_item_id': src_i(n)}
         return {'overlap': r(1, ids.OU, n).reshape(-1, 1)}
-    phase = (lambda step: None) if kind == 'conet' else (lambda step: 'SOURCE' if step < 2 else 'OVERLAP')
+    phase = (lambda step: None) if kind in ('conet', 'bitgcf') else (lambda step: 'SOURCE' if step < 2 else 'OVERLAP')
     return model, batch, phase
 
 
@@ -1453,7 +1463,7 @@ def _sdp_worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['conet', 'emcdr'])
+@pytest.mark.parametrize('kind', ['conet', 'emcdr', 'bitgcf'])
 def test_sharded_data_parallel_matches_mean_gradient_adam(kind):
     """dp.ShardedDataParallel over 3 ranks (sharing cuda:0, gloo transport): parameters after 4 steps == one process that
     averages the three per-rank gradients and takes torch.optim.Adam steps (params without a gradient in a phase are skipped:
