@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 9
+#define CDR_ABI_VERSION 10
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -353,10 +353,15 @@ int cdr_segsum_rows(cdr_ctx* ctx, void* stream, const uint32_t* keys_sorted, con
  * cdr_interleave_shards: the all-gathered scores are shard-major [world][U][Nl]; the reference's full_sort_predict
  *     layout (emcdr.py:208-233 -> score.view(-1)) is [U][N] in item-id order: out[u][c] = gathered[c % world][u][c / world].
  * cdr_gather_owned_rows: out[r,:] = ids[r] % world == rank ? shard[ids[r] / world,:] : 0 -- all-reduce(sum) of this over the
- *     ranks replicates the eval users' rows exactly.                                                                  */
+ *     ranks replicates the eval users' rows exactly.
+ * cdr_topk_merge_shards: vals / local_idx are the all-gathered per-shard top-k lists [world][U][k] (local row l of shard p is
+ *     item l * world + p; short lists padded with (-inf, -1)); out = the k best per user, value descending, ties to the
+ *     smaller item id -- the sharded form of cdr_fullsort_topk_f32's output.  world * k <= 4096.                       */
 int cdr_interleave_shards(void* stream, const float* gathered, int world, int64_t U, int64_t Nl, int64_t N, float* out);
 int cdr_gather_owned_rows(void* stream, const float* shard, int D, const int64_t* ids, int64_t n, int world, int rank,
                           float* out);
+int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_idx, int world, int64_t U, int k,
+                          float* out_vals, int64_t* out_idx);
 
 #ifdef __cplusplus
 }

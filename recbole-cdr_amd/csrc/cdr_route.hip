@@ -181,3 +181,56 @@ extern "C" int cdr_gather_owned_rows(void* stream, const float* tab, int D, cons
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
+
+// Per-shard top-k lists -> the global top-k (sharded full-sort evaluation): every rank all-gathers its k best
+// (value, LOCAL row) per user; one wave per user then selects k times over the world*k candidates, translating
+// local row l of producer p to the global item id l * world + p.  Order: value descending, ties to the smaller item id --
+// independent of the rank count.  Producers pad short lists with (-inf, -1); those never win.
+__global__ __launch_bounds__(kBlock) void topk_merge_shards_kernel(const float* __restrict__ vals, const int64_t* __restrict__ lidx,
+                                                                   int G, int64_t U, int k, float* __restrict__ out_v,
+                                                                   int64_t* __restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int64_t u = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (u >= U) return;
+    const int C = G * k;
+    constexpr int64_t kNone = INT64_MAX;
+    uint64_t used = 0;                                   // bit s: my candidate lane + 64 s is already in the output
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int64_t bi = kNone;
+        int bslot = -1;
+        for (int s = 0, c = lane; c < C; ++s, c += 64) {
+            if ((used >> s) & 1) continue;
+            const int p = c / k, j = c - p * k;
+            const int64_t o = ((int64_t)p * U + u) * k + j;
+            const int64_t li = lidx[o];
+            if (li < 0) continue;
+            const float v = vals[o];
+            const int64_t gi = li * G + p;
+            if (v > bv || (v == bv && gi < bi)) { bv = v; bi = gi; bslot = s; }
+        }
+        float wv = bv;
+        int64_t wi = bi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(wv, off, 64);
+            const int64_t oi = __shfl_xor(wi, off, 64);
+            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+        }
+        if (bslot >= 0 && bi == wi) used |= 1ull << bslot;          // item ids are unique over the candidates
+        if (lane == 0) {
+            out_v[u * k + r] = wi == kNone ? -INFINITY : wv;
+            out_i[u * k + r] = wi == kNone ? -1 : wi;
+        }
+    }
+}
+
+extern "C" int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_idx, int world, int64_t U, int k,
+                                     float* out_vals, int64_t* out_idx) {
+    CDR_CHECK_ARG(vals && local_idx && out_vals && out_idx && world >= 1 && U > 0 && k > 0);
+    CDR_CHECK_ARG((int64_t)world * k <= 64 * 64);
+    topk_merge_shards_kernel<<<dim3((unsigned)((U + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, (hipStream_t)stream>>>(
+        vals, local_idx, world, U, k, out_vals, out_idx);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

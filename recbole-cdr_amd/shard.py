@@ -459,12 +459,12 @@ class ShardedFullSort:
         if kk < k:
             vals = torch.cat([vals, vals.new_full((U, k - kk), float('-inf'))], 1)
             lidx = torch.cat([lidx, lidx.new_full((U, k - kk), -1)], 1)
-        gidx = torch.where(lidx >= 0, lidx * G + rank, lidx)
-        allv = torch.empty(G * U, k, device=vals.device, dtype=torch.float32)
+        allv = torch.empty(G * U, k, device=vals.device, dtype=torch.float32)             # [G][U][k], dim-0 concat
         alli = torch.empty(G * U, k, device=vals.device, dtype=torch.int64)
         dist.all_gather_into_tensor(allv, vals.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(alli, gidx.contiguous(), group=self.group)
-        cand_v = allv.view(G, U, k).permute(1, 0, 2).reshape(U, G * k)       # G*k candidates per user: index plumbing
-        cand_i = alli.view(G, U, k).permute(1, 0, 2).reshape(U, G * k)
-        top = torch.topk(cand_v, k, dim=1)
-        return top.values, torch.gather(cand_i, 1, top.indices)
+        dist.all_gather_into_tensor(alli, lidx.contiguous(), group=self.group)
+        B_ = self.B_
+        out_v = torch.empty(U, k, device=vals.device, dtype=torch.float32)
+        out_i = torch.empty(U, k, device=vals.device, dtype=torch.int64)
+        B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(allv), B_.i64(alli), G, U, k, B_.f32(out_v), B_.i64(out_i))
+        return out_v, out_i

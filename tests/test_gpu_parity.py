@@ -1664,3 +1664,29 @@ def test_integration_md_stub_runs_as_documented():
     got.sum().backward()
     assert_close(got.reshape(()), ref.detach(), what='stub loss')
     assert_close(Ud.grad, Ur.grad, what='stub dU'); assert_close(Id.grad, Ir.grad, what='stub dI')
+
+
+@pytest.mark.parametrize('G,U,k', [(1, 5, 10), (3, 70, 10), (8, 33, 64), (5, 9, 1)])
+def test_topk_merge_shards_orders_by_value_then_item_id(G, U, k):
+    """cdr_topk_merge_shards against a lexsort of the candidates: value descending, ties to the smaller GLOBAL item id
+    (l * world + p), (-inf, -1) padding never selected before a real candidate and reproduced when a user has fewer than k."""
+    from recbole_cdr_amd import binding as B_
+    g = torch.Generator().manual_seed(G * 100 + k)
+    vals = torch.randint(0, 6, (G, U, k), generator=g).float()                     # few distinct values: many ties
+    lidx = torch.stack([torch.stack([torch.randperm(4 * k, generator=g)[:k] for _ in range(U)]) for _ in range(G)])
+    pad = torch.rand(G, U, k, generator=g) < 0.3
+    pad[:, 0] = True                                                                # user 0: no candidate at all
+    if U > 1:
+        pad[:, 1] = False
+    vals[pad] = -float('inf'); lidx[pad] = -1
+    ov = torch.empty(U, k, device=DEV); oi = torch.empty(U, k, device=DEV, dtype=torch.int64)
+    dv, di = vals.to(DEV).contiguous(), lidx.to(DEV).contiguous()
+    B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(dv), B_.i64(di), G, U, k, B_.f32(ov), B_.i64(oi))
+    ov, oi = ov.cpu(), oi.cpu()
+    for u in range(U):
+        cand = [(-float(vals[p, u, j]), int(lidx[p, u, j]) * G + p) for p in range(G) for j in range(k) if lidx[p, u, j] >= 0]
+        cand.sort()
+        want_i = [c[1] for c in cand[:k]] + [-1] * max(0, k - len(cand))
+        want_v = [-c[0] for c in cand[:k]] + [-float('inf')] * max(0, k - len(cand))
+        assert oi[u].tolist() == want_i, u
+        assert ov[u].tolist() == want_v, u
