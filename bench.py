@@ -49,6 +49,9 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true', default=bool(int(os.environ.get('CDR_NO_PIPELINE', '0'))),
                     help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
+    ap.add_argument('--shard', default='dim', choices=['dim', 'row'],
+                    help='N>1 layout of the C5 tables: dim = every rank holds D/N columns of every row (ids all-gathered, one partial '
+                         'score per triple all-reduced); row = rows r %% N with the row / gradient-row all-to-all exchange')
     ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
 
@@ -110,7 +113,25 @@ def run_c5(args, world, rank, dev):
     OU = n_users
     gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
     sharded = world > 1 or args.force_shard
-    if not sharded:
+    dim_mode = sharded and args.shard == 'dim'
+    if dim_mode:
+        import torch.distributed as dist
+        from recbole_cdr_amd.dimshard import DimShardedBPRStep
+        if D % (4 * world):
+            raise SystemExit('--shard dim needs --dim to be a multiple of 4 x N')
+        Ds = D // world
+        tabs = {}
+        for k, r in (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items)):
+            tabs[k] = torch.empty(r, Ds, device=dev, dtype=torch.float32).normal_(0.0, (2.0 / (r + D)) ** 0.5, generator=gen)
+        # one process group (= one RCCL communicator) and one HIP stream per domain: the two domain steps touch disjoint
+        # tables and have no host sync inside, so they simply queue up side by side and one's collectives overlap the other's kernels
+        groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+        streams = {d: (None if args.no_pipeline else torch.cuda.Stream(device=dev)) for d in ('source', 'target')}
+        steps = {'source': DimShardedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01, group=groups['source'],
+                                             stream=streams['source']),
+                 'target': DimShardedBPRStep(tabs['tu'], tabs['ti'], B, opt=args.opt, reg_weight=0.01, group=groups['target'],
+                                             stream=streams['target'])}
+    elif not sharded:
         tabs = {k: xavier_table(r, D, r, gen, dev) for k, r in
                 (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
         steps = {'source': FusedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01),
@@ -145,7 +166,7 @@ def run_c5(args, world, rank, dev):
 
     def one_step(i):
         b = batches[i % pool]
-        if sharded and not args.no_pipeline:
+        if sharded and not dim_mode and not args.no_pipeline:
             run_pipelined([steps[dom].step_gen(*b[dom]) for dom in ('source', 'target')])
         else:
             for dom in ('source', 'target'):
@@ -165,7 +186,16 @@ def run_c5(args, world, rank, dev):
     barrier(world)
     dt = time.perf_counter() - t0
     timings = {}
-    for name, ms in B_.timing_collect(dev):
+    collected = B_.timing_collect(dev)
+    if dim_mode and not args.no_pipeline:
+        # the two domain streams ran side by side in the timed region, so its per-kernel event times include sharing the
+        # GPU with the other domain's kernels; the roofline figures come from two extra steps with the domains serialised
+        for i in range(2):
+            for dom in ('source', 'target'):
+                steps[dom].step(*batches[i % pool][dom])
+                torch.cuda.synchronize()
+        collected = B_.timing_collect(dev)
+    for name, ms in collected:
         timings.setdefault(name, []).append(ms)
     B_.timing_enable(dev, 0)
     mean_ms = lambda k: (sum(timings[k]) / len(timings[k])) if timings.get(k) else 0.0
@@ -185,9 +215,74 @@ def run_c5(args, world, rank, dev):
                                'step = source batch + target batch of %d triples each per rank, fwd+bwd+row-wise %s'
                                % (D, OU - 1, TOI, 4.0 * D * 2 * (n_users + n_items) / 1e9, B, args.opt),
                    'batch_per_domain_per_rank': B, 'k_neg': 1, 'optimizer': 'rowwise-' + args.opt,
-                   'sharding': 'none' if not sharded else 'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
+                   'sharding': 'none' if not sharded else
+                   ('dimension: %d of %d columns of every row per rank; ids all-gathered, one partial score per triple all-reduced, '
+                    '2 domains on their own streams' % (D // world, D)) if dim_mode else
+                   'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
         'final_loss': loss,
     }
+
+    if sharded:
+        # what the links carried and how long this rank's two domain streams spent inside all-to-alls (they overlap each other
+        # and the other domain's kernels, so this is NOT additive with the kernel times: it says which side bounds the step)
+        xb, xms = 0, 0.0
+        for st in steps.values():
+            b_, m_ = st.exchange_stats()
+            xb += b_; xms += m_
+        xt = torch.tensor([xb / args.steps, xms / args.steps], device=dev, dtype=torch.float64)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(xt, op=dist.ReduceOp.MAX)
+        result['exchange'] = {'bytes_to_other_ranks_per_step_per_rank': float(xt[0]), 'collective_ms_per_step_max_rank': float(xt[1]),
+                              'note': 'HIP-event time inside the data-path collectives of a step (dim: 3 id all-gathers + 1 all-reduce per '
+                                      "domain; row: 4 all-to-alls per domain), both domain streams summed; overlaps the other domain's kernels"}
+    if rank == 0 and dim_mode:
+        # every rank walks the GLOBAL batch on [rows, D/N] tables: the kernels are the single-GPU ones at width Ds
+        Bg = B * world
+        ids = steps['source'].ids if world > 1 else None
+        pn = torch.cat([ids[1, :Bg], ids[2, :Bg]]) if ids is not None else torch.cat(batches[(args.steps - 1) % pool]['source'][1:])
+        uniq_i = int(torch.unique(pn).numel())
+        nmom = 6 if args.opt == 'adam' else 2
+        ms = mean_ms('rowwise_apply_kernel(items)')
+        byts = 2 * Bg * (8 + 4 * Ds) + uniq_i * nmom * 4 * Ds
+        gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        result['roofline'] = {'bound': 'hbm', 'kernel': 'rowwise_apply_kernel(items) (rank 0: %d occurrences of the global batch on %d-column rows)' % (2 * Bg, Ds),
+                              'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                              'avg_launch_ms': ms, 'traffic': None}
+        result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
+                             ('bpr_partial_diff_kernel', 'bpr_grad_from_diff_kernel', 'sort_ids', 'rowwise_apply_kernel(users)',
+                              'rowwise_apply_kernel(items)')]
+        if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
+            result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
+    if rank == 0 and sharded and not dim_mode:
+        # N > 1: the exchange adds all-to-alls between the kernels; the kernels themselves are the 1-GPU ones.  Buckets
+        # are balanced in expectation (uniform ids), so one fwd_grad launch sees ~B triples: 3 rows read, GU + 2 GI rows
+        # written (scatter mode).  Rank 0's own HIP-event durations.
+        ms = mean_ms('bpr_fwd_grad_kernel')
+        byts = B * (3 * 4 * D + 24) + B * 3 * 4 * D
+        gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        result['roofline'] = {'bound': 'hbm', 'kernel': 'bpr_fwd_grad_kernel (rank 0, scatter mode, ~B triples per launch)',
+                              'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                              'avg_launch_ms': ms, 'traffic': None}
+        result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
+                             ('bpr_fwd_grad_kernel', 'rowwise_apply_kernel(users)', 'sort_ids')]
+        if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
+            result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
+
+    if dim_mode:
+        # phase switch: the OVERLAP step and the full-sort run on ROW shards (ids / k candidates are all they exchange there),
+        # so the user tables with their Adam moments and the target item table are transposed once (one all-to-all each)
+        from types import SimpleNamespace
+        from recbole_cdr_amd.dimshard import dim_to_row_shards, state_to_row_shards
+        barrier(world)
+        t0 = time.perf_counter()
+        ust = {d: state_to_row_shards(steps[d].ustate) for d in ('source', 'target')}
+        ti_rows = dim_to_row_shards(tabs['ti'])
+        barrier(world)
+        result['relayout_dim_to_row_s'] = time.perf_counter() - t0
+        steps = {d: SimpleNamespace(ustate=ust[d], istate=None) for d in ('source', 'target')}
+        tabs = {'su': ust['source'].table, 'tu': ust['target'].table, 'ti': ti_rows}
+        torch.cuda.empty_cache()
 
     # ---- OVERLAP phase (emcdr.py:133-137): mapping(source_user_e[idx]) -> target_user_e[idx], OB = 65,536 shuffled
     # overlapped ids per rank, linear mapping D x D; the user tables' row-wise Adam state is the one the BPR steps use
@@ -245,35 +340,6 @@ def run_c5(args, world, rank, dev):
                                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gk['frac'],
                                      'avg_launch_ms': gk['avg_ms'], 'traffic': pmc_traffic(gk['kernel'])}
         result['kernels'] = kernels
-
-    if sharded:
-        # what the links carried and how long this rank's two domain streams spent inside all-to-alls (they overlap each other
-        # and the other domain's kernels, so this is NOT additive with the kernel times: it says which side bounds the step)
-        xb, xms = 0, 0.0
-        for st in steps.values():
-            b_, m_ = st.exchange_stats()
-            xb += b_; xms += m_
-        xt = torch.tensor([xb / args.steps, xms / args.steps], device=dev, dtype=torch.float64)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(xt, op=dist.ReduceOp.MAX)
-        result['exchange'] = {'bytes_to_other_ranks_per_step_per_rank': float(xt[0]), 'all_to_all_ms_per_step_max_rank': float(xt[1]),
-                              'note': 'event time inside the 4+4 all-to-alls of a step, both domain streams summed; overlaps the other '
-                                      "domain's kernels"}
-    if rank == 0 and sharded:
-        # N > 1: the exchange adds all-to-alls between the kernels; the kernels themselves are the 1-GPU ones.  Buckets
-        # are balanced in expectation (uniform ids), so one fwd_grad launch sees ~B triples: 3 rows read, GU + 2 GI rows
-        # written (scatter mode).  Rank 0's own HIP-event durations.
-        ms = mean_ms('bpr_fwd_grad_kernel')
-        byts = B * (3 * 4 * D + 24) + B * 3 * 4 * D
-        gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        result['roofline'] = {'bound': 'hbm', 'kernel': 'bpr_fwd_grad_kernel (rank 0, scatter mode, ~B triples per launch)',
-                              'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                              'avg_launch_ms': ms, 'traffic': None}
-        result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
-                             ('bpr_fwd_grad_kernel', 'rowwise_apply_kernel(users)', 'sort_ids')]
-        if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
-            result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
 
     # ---- metric 2: full-sort items scored / s (emcdr.py:208-233, TARGET phase) at the reference's U and at U=1024 --
     if rank == 0 and not sharded and not args.no_fullsort:

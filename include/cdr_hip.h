@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 10
+#define CDR_ABI_VERSION 11
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -54,6 +54,8 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_APPLY_SIGNED 5       /* rowwise_apply_kernel<.., SIGNED=true >: item table (pos + neg occurrences) */
 #define CDR_TAG_SORT 6
 #define CDR_TAG_POINT_FWD_GRAD 7
+#define CDR_TAG_BPR_PARTIAL_DIFF 8
+#define CDR_TAG_BPR_GRAD_FROM_DIFF 9
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
 
@@ -362,6 +364,21 @@ int cdr_gather_owned_rows(void* stream, const float* shard, int D, const int64_t
                           float* out);
 int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_idx, int world, int64_t U, int k,
                           float* out_vals, int64_t* out_idx);
+
+/* ---- BPR step over DIMENSION-sharded tables (the alternative to the row exchange above) ---------------------
+ * Rank r holds columns [r*Ds, (r+1)*Ds) of every row (Ds = D / world) and walks the GLOBAL batch (ids all-gathered, 24 B per
+ * triple); the only data-path collective is ONE all-reduce(sum) of diff[0 .. B+2):
+ *   cdr_bpr_partial_diff   : diff[t] = <u,p> - <u,n> over this rank's columns (emcdr.py:98-108 split over columns);
+ *                            diff[B] = sum_t |u_t|^2, diff[B+1] = sum_t |p_t|^2 over them (EmbLoss norms)
+ *   cdr_bpr_grad_from_diff : from the all-reduced diff: s = sigmoid(diff[t]), g = -(1/B) s (1-s) / (gamma + s);
+ *                            GU[t,:] = g (p - n), GP[t,:] = g u on this rank's columns; out9 laid out as cdr_bpr_fwd_grad's
+ *                            (the same on every rank).  cdr_sort_ids_two_tables + cdr_rowwise_apply then run on the
+ *                            [rows, Ds] tables exactly as in the single-GPU step.                                      */
+int cdr_bpr_partial_diff(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds,
+                         const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float* diff /* [B + 2] */);
+int cdr_bpr_grad_from_diff(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds,
+                           const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight,
+                           const float* diff /* [B + 2], all-reduced */, float* out9, float* GU, float* GP);
 
 #ifdef __cplusplus
 }

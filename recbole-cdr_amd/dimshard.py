@@ -1,0 +1,184 @@
+"""BPR training step over DIMENSION-sharded embedding tables.
+
+Rank r holds columns ``[r*Ds, (r+1)*Ds)`` of every row of the user and the item table (``Ds = D / world``) with the
+matching slice of the row-wise optimizer state.  Every rank brings its own batch (weak scaling, as shard.ShardedBPRStep);
+the step is
+
+    all-gather  the triples' ids                          24 B per triple
+    cdr_bpr_partial_diff   <u,p> - <u,n> over my columns   (csrc/cdr_dimshard.hip)
+    all-reduce  one float per triple + the two EmbLoss norms
+    cdr_bpr_grad_from_diff + cdr_sort_ids_two_tables + 2 x cdr_rowwise_apply     (the single-GPU fused step on [rows, Ds])
+
+-- 28 B per triple on xGMI against the ~2.1 KB of the row exchange (emcdr.py:98-108,119-131 need only the dot products to
+cross the column cut; every gradient element stays with the rank that holds its column).  No bucket counts, no host
+sync: all sizes are static.  The price is that every rank walks the GLOBAL batch on rows 1/world as wide, so the ids are
+sorted ``world`` times over and gathers shrink to ``4*Ds`` bytes.
+
+The batch size must be the same on every rank (a sharded loader pads or drops the ragged tail)."""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+OPT_SGD, OPT_ADAM = 0, 1
+
+
+def dim_shard_of(full_table, world, rank):
+    """Columns of ``full_table`` [rows, D] that rank ``rank`` of ``world`` holds -> contiguous [rows, D / world]."""
+    D = full_table.shape[1]
+    assert D % (4 * world) == 0, 'D / world must be a multiple of 4 (one float4 per lane)'
+    Ds = D // world
+    return full_table[:, rank * Ds:(rank + 1) * Ds].contiguous()
+
+
+def dim_to_row_shards(cols, group=None):
+    """[rows, Ds] column slice -> this rank's ROW shard [ceil-ish(rows / G), D] (row r % G == rank at r // G): the layout
+    shard.ShardedFullSort evaluates on.  One all-to-all of the whole slice (rows * Ds * 4 B per rank), once per evaluation."""
+    G, rank = dist.get_world_size(group), dist.get_rank(group)
+    if G == 1:
+        return cols
+    rows, Ds = cols.shape
+    from .shard import shard_rows
+    n_q = [shard_rows(rows, G, q) for q in range(G)]
+    send = torch.cat([cols[q::G] for q in range(G)])                       # [rows, Ds], grouped by destination
+    recv = torch.empty(G * n_q[rank], Ds, device=cols.device, dtype=cols.dtype)
+    dist.all_to_all_single(recv, send, output_split_sizes=[n_q[rank]] * G, input_split_sizes=n_q, group=group)
+    return recv.view(G, n_q[rank], Ds).permute(1, 0, 2).reshape(n_q[rank], G * Ds).contiguous()
+
+
+def row_to_dim_shards(row_shard, total_rows, group=None):
+    """Inverse of ``dim_to_row_shards``: this rank's row shard [rows_r, D] -> its column slice [total_rows, D / G]."""
+    G, rank = dist.get_world_size(group), dist.get_rank(group)
+    if G == 1:
+        return row_shard
+    from .shard import shard_rows
+    n_q = [shard_rows(total_rows, G, q) for q in range(G)]
+    D = row_shard.shape[1]
+    Ds = D // G
+    send = row_shard.view(n_q[rank], G, Ds).permute(1, 0, 2).contiguous().view(G * n_q[rank], Ds)
+    recv = torch.empty(total_rows, Ds, device=row_shard.device, dtype=row_shard.dtype)
+    dist.all_to_all_single(recv, send, output_split_sizes=n_q, input_split_sizes=[n_q[rank]] * G, group=group)
+    out = torch.empty(total_rows, Ds, device=row_shard.device, dtype=row_shard.dtype)
+    o = 0
+    for q in range(G):
+        out[q::G] = recv[o:o + n_q[q]]
+        o += n_q[q]
+    return out
+
+
+def state_to_row_shards(state, group=None):
+    """fused.RowwiseState of a column slice -> RowwiseState of this rank's row shard (table and both moments re-laid out, the
+    update count kept): the phase switch from dimension-sharded BPR epochs to the row-sharded OVERLAP step / full-sort."""
+    from .fused import RowwiseState
+    out = RowwiseState.__new__(RowwiseState)
+    out.table = dim_to_row_shards(state.table, group)
+    out.step = state.step
+    out.exp_avg = dim_to_row_shards(state.exp_avg, group) if state.exp_avg is not None else None
+    out.exp_avg_sq = dim_to_row_shards(state.exp_avg_sq, group) if state.exp_avg_sq is not None else None
+    return out
+
+
+class NativeDimOps:
+    """libcdrhip arithmetic for DimShardedBPRStep: the two kernels of csrc/cdr_dimshard.hip around fused.FusedBPRStep's
+    buffers, sort and row-wise applies (run on [rows, Ds] tables)."""
+
+    def __init__(self, user_cols, item_cols, max_global_batch, **kw):
+        from . import binding as B_
+        from .fused import FusedBPRStep
+        self.B_ = B_
+        self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, **kw)
+        self.out = self.fs.out6
+
+    def partial_diff(self, uid, pid, nid, diff):
+        B_, fs = self.B_, self.fs
+        B_.call('cdr_bpr_partial_diff', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
+                B_.i64(pid), B_.i64(nid), uid.numel(), B_.f32(diff))
+
+    def grad_apply(self, uid, pid, nid, diff):
+        B_, fs = self.B_, self.fs
+        B_.call('cdr_bpr_grad_from_diff', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
+                B_.i64(pid), B_.i64(nid), uid.numel(), float(fs.gamma), float(fs.reg_weight), B_.f32(diff), B_.f32(fs.out6),
+                B_.f32(fs.GU), B_.f32(fs.GP))
+        return fs.sort_apply(uid, pid, nid)
+
+
+class DimShardedBPRStep:
+    """``user_cols`` / ``item_cols``: this rank's column slices [rows, D / world] (``dim_shard_of``).  ``step`` takes the rank's
+    own batch (global row ids, the same length on every rank) and returns out (view; [0] = total loss of the GLOBAL batch,
+    identical on every rank).  ``ops``: compute stand-in for the CPU (gloo) tests; default = the native kernels."""
+
+    def __init__(self, user_cols, item_cols, batch_per_rank, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None, stream=None, user_state=None,
+                 item_state=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.U, self.I = user_cols, item_cols
+        self.Ds = user_cols.shape[1]
+        Bg = int(batch_per_rank) * self.world
+        self.max_batch = Bg
+        dev = user_cols.device
+        self.ops = ops if ops is not None else NativeDimOps(
+            user_cols, item_cols, Bg, opt=opt, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, gamma=gamma,
+            reg_weight=reg_weight, user_state=user_state, item_state=item_state)
+        self.ids = torch.empty(3, Bg, device=dev, dtype=torch.int64)
+        self.diff = torch.empty(Bg + 2, device=dev, dtype=torch.float32)
+        self.out = self.ops.out
+        self.stream = stream
+        self._prof = None
+
+    @property
+    def ustate(self):
+        return self.ops.fs.ustate
+
+    @property
+    def istate(self):
+        return self.ops.fs.istate
+
+    def loss_value(self):
+        return self.out[0]
+
+    def profile(self, on=True):
+        self._prof = {'bytes': 0, 'events': []} if on else None
+
+    def exchange_stats(self):
+        """-> (bytes this rank sent to other ranks, milliseconds inside collectives) since ``profile()``; synchronises."""
+        if not self._prof:
+            return 0, 0.0
+        torch.cuda.synchronize()
+        return self._prof['bytes'], sum(a.elapsed_time(b) for a, b in self._prof['events'])
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    @contextlib.contextmanager
+    def _timed(self, nbytes):
+        if not self._prof or not self.U.is_cuda:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self._prof['bytes'] += int(nbytes)
+        self._prof['events'].append((a, b))
+
+    def step(self, uid, pid, nid):
+        G, grp, ops = self.world, self.group, self.ops
+        Bl = uid.numel()
+        Bg = G * Bl
+        assert Bg <= self.max_batch
+        with self._on_stream():
+            if G > 1:
+                with self._timed(3 * 8 * Bl * (G - 1)):
+                    for j, t in enumerate((uid, pid, nid)):
+                        dist.all_gather_into_tensor(self.ids[j, :Bg], t.contiguous(), group=grp)
+                u, p, n = self.ids[0, :Bg], self.ids[1, :Bg], self.ids[2, :Bg]
+            else:
+                u, p, n = uid, pid, nid
+            diff = self.diff[:Bg + 2]
+            ops.partial_diff(u, p, n, diff)
+            if G > 1:
+                with self._timed(2 * 4 * (Bg + 2) * (G - 1) // G):            # ring all-reduce: reduce-scatter + all-gather
+                    dist.all_reduce(diff, group=grp)
+            return ops.grad_apply(u, p, n, diff)

@@ -63,11 +63,17 @@ class FusedBPRStep:
         """uid/pid/nid: int64 device tensors [B].  Returns the device tensor out6 (view; [0] = total loss)."""
         B = uid.numel()
         assert B <= self.max_batch
+        B_.call('cdr_bpr_fwd_grad', B_.ctx(self.U.device), B_.stream(), B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid),
+                B_.i64(pid), B_.i64(nid), B, 0, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
+                B_.f32(self.GP), 0)
+        return self.sort_apply(uid, pid, nid)
+
+    def sort_apply(self, uid, pid, nid):
+        """Second half of the step: GU / GP / out6[4:6] are in place (written by the forward kernel -- or, for dimension-sharded
+        tables, by cdr_bpr_grad_from_diff after the all-reduce: dimshard.py); one sort for both tables, two row-wise applies."""
+        B = uid.numel()
         s = B_.stream()
         ctxh = B_.ctx(self.U.device)
-        B_.call('cdr_bpr_fwd_grad', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid),
-                B_.i64(nid), B, 0, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU),
-                B_.f32(self.GP), 0)
         B_.call('cdr_sort_ids_two_tables', ctxh, s, B_.i64(uid), B, self.U.shape[0], B_.i64(pid), B, B_.i64(nid), B,
                 self.I.shape[0], B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws_bytes)
         self._apply(ctxh, self.ustate, self.keys[:B], self.perm[:B], B, self.GU, B, B, self.out6[4:5], 0)

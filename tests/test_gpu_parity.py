@@ -1690,3 +1690,105 @@ def test_topk_merge_shards_orders_by_value_then_item_id(G, U, k):
         want_v = [-c[0] for c in cand[:k]] + [-float('inf')] * max(0, k - len(cand))
         assert oi[u].tolist() == want_i, u
         assert ov[u].tolist() == want_v, u
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dimension-sharded BPR step (dimshard.py, csrc/cdr_dimshard.hip)
+@pytest.mark.parametrize('D,B', [(128, 5000), (64, 333), (32, 1), (16, 4097), (8, 77)])
+def test_partial_diff_and_grad_from_diff_equal_the_fused_forward(D, B):
+    """One rank holding ALL columns: cdr_bpr_partial_diff + cdr_bpr_grad_from_diff reproduce cdr_bpr_fwd_grad (loss,
+    norms, coefficients, compact gradient rows) -- the arithmetic that the all-reduce is cut into."""
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(D + B)
+    nu, ni = 900, 700
+    U, I = torch.randn(nu, D, device=DEV) * 0.3, torch.randn(ni, D, device=DEV) * 0.3
+    u, p, n = torch.randint(0, nu, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV)
+    out_a, GU_a, GP_a = torch.zeros(12, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    out_b, GU_b, GP_b = torch.zeros(12, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    ctx, s = B_.ctx(U.device), B_.stream()
+    B_.call('cdr_bpr_fwd_grad', ctx, s, B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(p), B_.i64(n), B, 0, 1e-10, 0.05, B_.f32(out_a),
+            B_.f32(GU_a), B_.f32(GP_a), 0)
+    diff = torch.empty(B + 2, device=DEV)
+    B_.call('cdr_bpr_partial_diff', ctx, s, B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(p), B_.i64(n), B, B_.f32(diff))
+    want = (U[u] * I[p]).sum(1) - (U[u] * I[n]).sum(1)
+    assert_close(diff[:B], want, rtol=1e-5, atol=1e-6, what='diff')
+    B_.call('cdr_bpr_grad_from_diff', ctx, s, B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(p), B_.i64(n), B, 1e-10, 0.05, B_.f32(diff),
+            B_.f32(out_b), B_.f32(GU_b), B_.f32(GP_b))
+    assert_close(GU_b, GU_a, rtol=1e-5, atol=1e-9, what='GU')                  # dot products may contract to FMAs differently
+    assert_close(GP_b, GP_a, rtol=1e-5, atol=1e-9, what='GP')
+    assert_close(out_b[:9], out_a[:9], rtol=1e-6, atol=0, what='out9')
+
+
+def _dim_shared_gpu_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import DimShardedBPRStep, dim_shard_of, dim_to_row_shards
+        torch.cuda.set_device(0)
+        torch.manual_seed(11)
+        nu, ni, D, B = 7001, 3003, 64, 3000
+        tabs = [(torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1) for _ in range(2)]
+        steps, cols = [], []
+        for d, (U, I) in enumerate(tabs):
+            Uc, Ic = dim_shard_of(U, world, rank).to(DEV), dim_shard_of(I, world, rank).to(DEV)
+            steps.append(DimShardedBPRStep(Uc, Ic, B, opt='adam', lr=0.01, reg_weight=0.02, group=dist.new_group(backend='gloo'),
+                                           stream=torch.cuda.Stream()))
+            cols.append((Uc, Ic))
+        losses, batches = [], []
+        for it in range(3):
+            per_dom = []
+            for d in range(2):
+                g = torch.Generator(); g.manual_seed(1000 * it + 10 * d + rank)
+                u = torch.randint(0, nu, (B,), generator=g); p = torch.randint(0, ni, (B,), generator=g)
+                n = torch.randint(0, ni, (B,), generator=g)
+                if it == 1:
+                    u[: B // 2] = u[0]; p[: B // 3] = p[0]; n[100:700] = p[0]        # long segments in both tables
+                per_dom.append((u, p, n))
+            batches.append(per_dom)
+            torch.cuda.synchronize()
+            for d in range(2):                                                  # no host sync inside: the two domains just queue up
+                steps[d].step(*(t.to(DEV) for t in per_dom[d]))
+            torch.cuda.synchronize()
+            losses.append([float(s.out[0]) for s in steps])
+        rows = dim_to_row_shards(cols[0][1])
+        q.put((rank, [(a.cpu().numpy(), b.cpu().numpy()) for a, b in cols], losses,
+               [[tuple(t.numpy() for t in dom) for dom in it] for it in batches], rows.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_dim_sharded_native_ranks_share_one_gpu(world):
+    """DimShardedBPRStep with the native kernels, `world` ranks on cuda:0 over gloo, two domains on their own streams:
+    every rank's columns equal the single-GPU fused step's on the concatenated batch; the loss is the global one."""
+    import socket
+    import torch.multiprocessing as mp
+    from recbole_cdr_amd.fused import FusedBPRStep
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dim_shared_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    torch.manual_seed(11)
+    nu, ni, D, B = 7001, 3003, 64, 3000
+    Ds = D // world
+    tabs = [(torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1) for _ in range(2)]
+    for d in range(2):
+        U, I = tabs[d][0].to(DEV), tabs[d][1].to(DEV)
+        ref = FusedBPRStep(U, I, world * B, opt='adam', lr=0.01, reg_weight=0.02)
+        for it in range(3):
+            u, p, n = (torch.from_numpy(np.concatenate([res[r][3][it][d][k] for r in range(world)])).to(DEV) for k in range(3))
+            loss = float(ref.step(u, p, n)[0])
+            for r in range(world):
+                assert abs(res[r][2][it][d] - loss) <= 2e-6 * abs(loss), (d, it, r, res[r][2][it][d], loss)
+        for r in range(world):
+            assert_close(torch.from_numpy(res[r][1][d][0]).to(DEV), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'U dom{d} rank{r}')
+            assert_close(torch.from_numpy(res[r][1][d][1]).to(DEV), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'I dom{d} rank{r}')
+            if d == 0:
+                assert_close(torch.from_numpy(res[r][4]).to(DEV), I[r::world], rtol=2e-5, atol=1e-4, what=f'row shard rank{r}')

@@ -311,3 +311,97 @@ def test_sharded_data_parallel_gloo(world):
     for r in range(world):
         for k, p in ref.named_parameters():
             torch.testing.assert_close(torch.from_numpy(res[r][1][k]), p.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dimshard.DimShardedBPRStep (columns of every row on every rank; ids all-gathered, one partial score all-reduced) on CPU
+class OracleDimOps:
+    """Stand-in compute for dimshard.DimShardedBPRStep on CPU tensors: the formulas of csrc/cdr_dimshard.hip's two
+    kernels, then the same per-table segment + apply as OracleOps.sort_apply on this rank's columns."""
+
+    def __init__(self, user_cols, item_cols, opt, hp, gamma, reg_weight):
+        self.U, self.I, self.opt, self.hp, self.gamma, self.reg_weight = user_cols, item_cols, opt, hp, gamma, reg_weight
+        self.out = torch.zeros(12)
+        self.state = [(torch.zeros_like(user_cols), torch.zeros_like(user_cols)), (torch.zeros_like(item_cols), torch.zeros_like(item_cols))]
+        self.t = 0
+
+    def partial_diff(self, uid, pid, nid, diff):
+        u, p, n = self.U[uid], self.I[pid], self.I[nid]
+        B = uid.numel()
+        diff[:B] = (u * p).sum(1) - (u * n).sum(1)
+        diff[B] = (u * u).sum()
+        diff[B + 1] = (p * p).sum()
+
+    def grad_apply(self, uid, pid, nid, diff):
+        B = uid.numel()
+        u, p, n = self.U[uid], self.I[pid], self.I[nid]
+        s = torch.sigmoid(diff[:B])
+        g = -(1.0 / B) * (s * (1 - s)) / (self.gamma + s)
+        GU, GP = g[:, None] * (p - n), g[:, None] * u
+        OracleOps().finish_sums(torch.stack([(-torch.log(self.gamma + s)).sum(), diff[B], diff[B + 1]]), B, self.reg_weight, self.out)
+        self.t += 1
+        o = OracleOps()
+        o.sort_apply(self.U, self.state[0], uid, GU, self.opt, self.hp, self.t, reg_limit=B, reg_coef=self.out[4:5])
+        o.sort_apply(self.I, self.state[1], torch.cat([pid, nid]), torch.cat([GP, -GP]), self.opt, self.hp, self.t, reg_limit=B,
+                     reg_coef=self.out[5:6])
+        return self.out
+
+
+def _worker_dim(rank, world, port, opt, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import DimShardedBPRStep, dim_shard_of, dim_to_row_shards, row_to_dim_shards
+        torch.manual_seed(0)
+        nu, ni, D, B, reg, lr = 41, 29, 8 * world, 23, 0.03, 0.05
+        U, I = torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3
+        Uc, Ic = dim_shard_of(U, world, rank), dim_shard_of(I, world, rank)
+        hp = {'lr': lr, 'b1': 0.9, 'b2': 0.999, 'eps': 1e-8, 'wd': 0.0}
+        st = DimShardedBPRStep(Uc, Ic, B, ops=OracleDimOps(Uc, Ic, 1 if opt == 'adam' else 0, hp, 1e-10, reg))
+        losses, batches = [], []
+        for step in range(3):
+            g = torch.Generator(); g.manual_seed(100 * step + rank)
+            u = torch.randint(0, nu, (B,), generator=g); p = torch.randint(0, ni, (B,), generator=g)
+            n = torch.randint(0, ni, (B,), generator=g)
+            batches.append((u, p, n))
+            losses.append(float(st.step(u, p, n)[0]))
+        rows = dim_to_row_shards(Uc)                                           # the layout the sharded full-sort evaluates on
+        back = row_to_dim_shards(rows, nu)
+        assert torch.equal(back, Uc)
+        q.put((rank, Uc.numpy().copy(), Ic.numpy().copy(), losses, [tuple(t.numpy().copy() for t in b) for b in batches],
+               rows.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,opt', [(2, 'sgd'), (3, 'adam')])
+def test_dim_sharded_step_matches_single_process(world, opt):
+    """Column slices of the single-process result, the global loss on every rank, and the column -> row-shard transpose."""
+    from oracle import train_step as ts
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dim, args=(r, world, port, opt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    nu, ni, D, reg, lr = 41, 29, 8 * world, 0.03, 0.05
+    U, I = torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3
+    us, is_ = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    for step in range(3):
+        u, p, n = (torch.cat([torch.from_numpy(res[r][4][step][k]) for r in range(world)]) for k in range(3))
+        loss = ts.rowwise_step(U, I, us, is_, u, p, n, step + 1, opt=opt, lr=lr, reg_weight=reg)
+        for r in range(world):
+            assert abs(res[r][3][step] - float(loss)) <= 1e-5 * abs(float(loss)), (step, res[r][3][step], float(loss))
+    Ds = D // world
+    atol = lr * 1e-2 if opt == 'adam' else 1e-6
+    for r in range(world):
+        torch.testing.assert_close(torch.from_numpy(res[r][1]), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=atol)
+        torch.testing.assert_close(torch.from_numpy(res[r][2]), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=atol)
+        torch.testing.assert_close(torch.from_numpy(res[r][5]), U[r::world], rtol=2e-5, atol=atol)
