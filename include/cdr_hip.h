@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 11
+#define CDR_ABI_VERSION 12
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -374,6 +374,12 @@ int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_
  *                            GU[t,:] = g (p - n), GP[t,:] = g u on this rank's columns; out9 laid out as cdr_bpr_fwd_grad's
  *                            (the same on every rank).  cdr_sort_ids_two_tables + cdr_rowwise_apply then run on the
  *                            [rows, Ds] tables exactly as in the single-GPU step.                                      */
+/* The ids cross the links as int32 (12 B per triple; every table here has < 2^31 rows): cdr_ids_pack32 narrows the rank's three
+ * id arrays into out32[3][Bl] (bad_flag[0] = 1 if an id does not fit); after ONE all-gather the buffer is rank-major
+ * [world][3][Bl] and cdr_ids_unpack32 widens it to the field-major int64 [3][world * Bl] the kernels read.               */
+int cdr_ids_pack32(void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t Bl, int32_t* out32,
+                   int* bad_flag);
+int cdr_ids_unpack32(void* stream, const int32_t* gathered, int world, int64_t Bl, int64_t* out64);
 int cdr_bpr_partial_diff(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds,
                          const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float* diff /* [B + 2] */);
 int cdr_bpr_grad_from_diff(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds,

@@ -172,6 +172,31 @@ __global__ __launch_bounds__(kBlock) void dimshard_finish_kernel(const double* _
     }
 }
 
+// ids travel as int32 (table rows < 2^31 everywhere in this library: the sort keys are 32-bit): 12 B per triple on the links.
+//   pack   : out32[j * Bl + t] = (int32) src_j[t]                      j = 0 (user), 1 (positive), 2 (negative)
+//   unpack : the all-gathered buffer is rank-major [G][3][Bl]; the kernels want field-major int64 [3][G * Bl]
+__global__ __launch_bounds__(kBlock) void ids_pack32_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ p,
+                                                            const int64_t* __restrict__ n, int64_t Bl, int32_t* __restrict__ out,
+                                                            int* __restrict__ bad) {
+    const int64_t total = 3 * Bl, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t j = e / Bl, t = e - j * Bl;
+        const int64_t v = j == 0 ? u[t] : j == 1 ? p[t] : n[t];
+        if (v < 0 || v > 0x7FFFFFFFll) atomicExch(bad, 1);
+        out[e] = (int32_t)v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ids_unpack32_kernel(const int32_t* __restrict__ in, int G, int64_t Bl,
+                                                              int64_t* __restrict__ out) {
+    const int64_t Bg = (int64_t)G * Bl, total = 3 * Bg, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t j = e / Bg, r = e - j * Bg;            // out[j][g * Bl + t]
+        const int64_t g = r / Bl, t = r - g * Bl;
+        out[e] = (int64_t)in[(g * 3 + j) * Bl + t];
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_LPR(lpr, ...)                                  \
@@ -218,6 +243,21 @@ extern "C" int cdr_bpr_grad_from_diff(cdr_ctx* ctx, void* stream, const float* u
     }
     CDR_LAUNCH_CHECK();
     dimshard_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, diff + B, out9);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_ids_pack32(void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t Bl, int32_t* out32,
+                              int* bad_flag) {
+    CDR_CHECK_ARG(uid && pid && nid && out32 && bad_flag && Bl > 0);
+    ids_pack32_kernel<<<dim3(grid_for(3 * Bl, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(uid, pid, nid, Bl, out32, bad_flag);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_ids_unpack32(void* stream, const int32_t* gathered, int world, int64_t Bl, int64_t* out64) {
+    CDR_CHECK_ARG(gathered && out64 && world >= 1 && Bl > 0);
+    ids_unpack32_kernel<<<dim3(grid_for(3 * Bl * world, kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(gathered, world, Bl, out64);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -4,12 +4,12 @@ Rank r holds columns ``[r*Ds, (r+1)*Ds)`` of every row of the user and the item 
 matching slice of the row-wise optimizer state.  Every rank brings its own batch (weak scaling, as shard.ShardedBPRStep);
 the step is
 
-    all-gather  the triples' ids                          24 B per triple
+    all-gather  the triples' ids, narrowed to int32       12 B per triple (cdr_ids_pack32 / cdr_ids_unpack32)
     cdr_bpr_partial_diff   <u,p> - <u,n> over my columns   (csrc/cdr_dimshard.hip)
     all-reduce  one float per triple + the two EmbLoss norms
     cdr_bpr_grad_from_diff + cdr_sort_ids_two_tables + 2 x cdr_rowwise_apply     (the single-GPU fused step on [rows, Ds])
 
--- 28 B per triple on xGMI against the ~2.1 KB of the row exchange (emcdr.py:98-108,119-131 need only the dot products to
+-- 16 B per triple on xGMI against the ~2.1 KB of the row exchange (emcdr.py:98-108,119-131 need only the dot products to
 cross the column cut; every gradient element stays with the rank that holds its column).  No bucket counts, no host
 sync: all sizes are static.  The price is that every rank walks the GLOBAL batch on rows 1/world as wide, so the ids are
 sorted ``world`` times over and gathers shrink to ``4*Ds`` bytes.
@@ -89,6 +89,20 @@ class NativeDimOps:
         self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, **kw)
         self.out = self.fs.out6
 
+    def pack_ids(self, uid, pid, nid, out32):
+        B_ = self.B_
+        if not hasattr(self, '_bad'):
+            self._bad = torch.zeros(1, device=uid.device, dtype=torch.int32)
+        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(), B_.raw(out32), B_.raw(self._bad))
+
+    def unpack_ids(self, gathered32, world, Bl, out64):
+        B_ = self.B_
+        B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered32), int(world), int(Bl), B_.i64(out64))
+
+    def ids_fit(self):
+        """False if any id handed to ``pack_ids`` so far did not fit int32 (synchronises; the tables here never have 2^31 rows)."""
+        return not hasattr(self, '_bad') or int(self._bad.item()) == 0
+
     def partial_diff(self, uid, pid, nid, diff):
         B_, fs = self.B_, self.fs
         B_.call('cdr_bpr_partial_diff', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
@@ -121,7 +135,9 @@ class DimShardedBPRStep:
         self.ops = ops if ops is not None else NativeDimOps(
             user_cols, item_cols, Bg, opt=opt, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, gamma=gamma,
             reg_weight=reg_weight, user_state=user_state, item_state=item_state)
-        self.ids = torch.empty(3, Bg, device=dev, dtype=torch.int64)
+        self.ids = torch.empty(3 * Bg, device=dev, dtype=torch.int64)
+        self.ids32 = torch.empty(3 * int(batch_per_rank), device=dev, dtype=torch.int32)
+        self.gath32 = torch.empty(3 * Bg, device=dev, dtype=torch.int32)
         self.diff = torch.empty(Bg + 2, device=dev, dtype=torch.float32)
         self.out = self.ops.out
         self.stream = stream
@@ -168,12 +184,16 @@ class DimShardedBPRStep:
         Bl = uid.numel()
         Bg = G * Bl
         assert Bg <= self.max_batch
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())           # the ids were produced on the caller's stream
         with self._on_stream():
             if G > 1:
-                with self._timed(3 * 8 * Bl * (G - 1)):
-                    for j, t in enumerate((uid, pid, nid)):
-                        dist.all_gather_into_tensor(self.ids[j, :Bg], t.contiguous(), group=grp)
-                u, p, n = self.ids[0, :Bg], self.ids[1, :Bg], self.ids[2, :Bg]
+                ops.pack_ids(uid, pid, nid, self.ids32[:3 * Bl])
+                with self._timed(3 * 4 * Bl * (G - 1)):
+                    dist.all_gather_into_tensor(self.gath32[:3 * Bg], self.ids32[:3 * Bl], group=grp)
+                idv = self.ids[:3 * Bg].view(3, Bg)                               # field-major global ids of this step
+                ops.unpack_ids(self.gath32[:3 * Bg], G, Bl, idv)
+                u, p, n = idv[0], idv[1], idv[2]
             else:
                 u, p, n = uid, pid, nid
             diff = self.diff[:Bg + 2]

@@ -1792,3 +1792,23 @@ def test_dim_sharded_native_ranks_share_one_gpu(world):
             assert_close(torch.from_numpy(res[r][1][d][1]).to(DEV), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'I dom{d} rank{r}')
             if d == 0:
                 assert_close(torch.from_numpy(res[r][4]).to(DEV), I[r::world], rtol=2e-5, atol=1e-4, what=f'row shard rank{r}')
+
+
+def test_ids_pack32_unpack32_round_trip_and_overflow_flag():
+    from recbole_cdr_amd import binding as B_
+    G, Bl = 3, 1001
+    g = torch.Generator().manual_seed(5)
+    per_rank = [[torch.randint(0, 2 ** 31 - 1, (Bl,), generator=g) for _ in range(3)] for _ in range(G)]
+    bad = torch.zeros(1, device=DEV, dtype=torch.int32)
+    gathered = torch.empty(G, 3 * Bl, device=DEV, dtype=torch.int32)
+    for r in range(G):
+        u, p, n = (t.to(DEV) for t in per_rank[r])
+        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(u), B_.i64(p), B_.i64(n), Bl, B_.raw(gathered[r]), B_.raw(bad))
+    out = torch.empty(3, G * Bl, device=DEV, dtype=torch.int64)
+    B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered), G, Bl, B_.i64(out))
+    for j in range(3):
+        assert torch.equal(out[j].cpu(), torch.cat([per_rank[r][j] for r in range(G)]))
+    assert int(bad.item()) == 0
+    big = torch.full((Bl,), 2 ** 31, device=DEV, dtype=torch.int64)
+    B_.call('cdr_ids_pack32', B_.stream(), B_.i64(big), B_.i64(big), B_.i64(big), Bl, B_.raw(gathered[0]), B_.raw(bad))
+    assert int(bad.item()) == 1

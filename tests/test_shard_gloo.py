@@ -325,6 +325,12 @@ class OracleDimOps:
         self.state = [(torch.zeros_like(user_cols), torch.zeros_like(user_cols)), (torch.zeros_like(item_cols), torch.zeros_like(item_cols))]
         self.t = 0
 
+    def pack_ids(self, uid, pid, nid, out32):
+        out32.copy_(torch.cat([uid, pid, nid]).to(torch.int32))
+
+    def unpack_ids(self, gathered32, world, Bl, out64):
+        out64.copy_(gathered32.view(world, 3, Bl).permute(1, 0, 2).reshape(3, world * Bl).to(torch.int64))
+
     def partial_diff(self, uid, pid, nid, diff):
         u, p, n = self.U[uid], self.I[pid], self.I[nid]
         B = uid.numel()
