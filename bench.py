@@ -280,8 +280,16 @@ def run_c5(args, world, rank, dev):
         from recbole_cdr_amd.dimshard import dim_to_row_shards, state_to_row_shards
         barrier(world)
         t0 = time.perf_counter()
-        ust = {d: state_to_row_shards(steps[d].ustate) for d in ('source', 'target')}
-        ti_rows = dim_to_row_shards(tabs['ti'])
+        ust, ti_cols = {}, tabs['ti']
+        tabs.clear()
+        for d in ('source', 'target'):
+            st = steps.pop(d)
+            ustate = st.ustate
+            del st                                  # gradient / sort buffers and the item moments go first
+            torch.cuda.empty_cache()
+            ust[d] = state_to_row_shards(ustate, consume=True)
+        ti_rows = dim_to_row_shards(ti_cols)
+        del ti_cols
         barrier(world)
         result['relayout_dim_to_row_s'] = time.perf_counter() - t0
         steps = {d: SimpleNamespace(ustate=ust[d], istate=None) for d in ('source', 'target')}

@@ -66,15 +66,19 @@ def row_to_dim_shards(row_shard, total_rows, group=None):
     return out
 
 
-def state_to_row_shards(state, group=None):
+def state_to_row_shards(state, group=None, consume=False):
     """fused.RowwiseState of a column slice -> RowwiseState of this rank's row shard (table and both moments re-laid out, the
-    update count kept): the phase switch from dimension-sharded BPR epochs to the row-sharded OVERLAP step / full-sort."""
+    update count kept): the phase switch from dimension-sharded BPR epochs to the row-sharded OVERLAP step / full-sort.
+    ``consume``: drop each column-slice tensor from ``state`` as soon as it is converted (peak memory = one tensor extra)."""
     from .fused import RowwiseState
     out = RowwiseState.__new__(RowwiseState)
-    out.table = dim_to_row_shards(state.table, group)
     out.step = state.step
-    out.exp_avg = dim_to_row_shards(state.exp_avg, group) if state.exp_avg is not None else None
-    out.exp_avg_sq = dim_to_row_shards(state.exp_avg_sq, group) if state.exp_avg_sq is not None else None
+    for name in ('table', 'exp_avg', 'exp_avg_sq'):
+        t = getattr(state, name)
+        setattr(out, name, dim_to_row_shards(t, group) if t is not None else None)
+        if consume:
+            setattr(state, name, None)
+        del t
     return out
 
 
