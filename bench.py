@@ -294,6 +294,7 @@ def run_c5(args, world, rank, dev):
         result['relayout_dim_to_row_s'] = time.perf_counter() - t0
         steps = {d: SimpleNamespace(ustate=ust[d], istate=None) for d in ('source', 'target')}
         tabs = {'su': ust['source'].table, 'tu': ust['target'].table, 'ti': ti_rows}
+        del ust, ti_rows                            # `steps` owns the moments now (the full-sort leg below drops them)
         torch.cuda.empty_cache()
 
     # ---- OVERLAP phase (emcdr.py:133-137): mapping(source_user_e[idx]) -> target_user_e[idx], OB = 65,536 shuffled
