@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 12
+#define CDR_ABI_VERSION 13
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -56,6 +56,8 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_POINT_FWD_GRAD 7
 #define CDR_TAG_BPR_PARTIAL_DIFF 8
 #define CDR_TAG_BPR_GRAD_FROM_DIFF 9
+#define CDR_TAG_POINT_PARTIAL_DOT 10
+#define CDR_TAG_POINT_GRAD_FROM_DOT 11
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
 
@@ -377,14 +379,24 @@ int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_
 /* The ids cross the links as int32 (12 B per triple; every table here has < 2^31 rows): cdr_ids_pack32 narrows the rank's three
  * id arrays into out32[3][Bl] (bad_flag[0] = 1 if an id does not fit); after ONE all-gather the buffer is rank-major
  * [world][3][Bl] and cdr_ids_unpack32 widens it to the field-major int64 [3][world * Bl] the kernels read.               */
-int cdr_ids_pack32(void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t Bl, int32_t* out32,
-                   int* bad_flag);
-int cdr_ids_unpack32(void* stream, const int32_t* gathered, int world, int64_t Bl, int64_t* out64);
+int cdr_ids_pack32(void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid /* or NULL */,
+                   const float* label /* pointwise rows: fp32 bit pattern in the third slot; NULL iff nid is given */, int64_t Bl,
+                   int32_t* out32, int* bad_flag);
+int cdr_ids_unpack32(void* stream, const int32_t* gathered, int world, int64_t Bl, int64_t* out64 /* [3][world*Bl]; [2][..] used if label_out */,
+                     float* label_out /* [world*Bl] or NULL */);
 int cdr_bpr_partial_diff(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds,
                          const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float* diff /* [B + 2] */);
 int cdr_bpr_grad_from_diff(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds,
                            const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight,
                            const float* diff /* [B + 2], all-reduced */, float* out9, float* GU, float* GP);
+/* Pointwise rows (user, item, label) in the same layout -- EMCDR's MF latent factor model (emcdr.py:111-122, MSE on the dot) and
+ * BCE on sigmoid(dot) (cmf.py:75-99): dot[t] = <u,i> over this rank's columns, dot[B], dot[B+1] = its share of the EmbLoss norms
+ * -> all-reduce -> GU[t,:] = g i, GI[t,:] = g u with cdr_point_fwd_grad's loss arithmetic and out9 layout.                        */
+int cdr_point_partial_dot(cdr_ctx* ctx, void* stream, const float* user_cols, const float* item_cols, int Ds, const int64_t* uid,
+                          const int64_t* iid, int64_t B, float* dot /* [B + 2] */);
+int cdr_point_grad_from_dot(cdr_ctx* ctx, void* stream, int loss_kind, const float* user_cols, const float* item_cols, int Ds,
+                            const int64_t* uid, const int64_t* iid, const float* label, int64_t B, float reg_weight,
+                            const float* dot /* [B + 2], all-reduced */, float* out9, float* GU, float* GI);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -116,8 +116,11 @@ _SIGNATURES = {
     'cdr_segsum_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr],
     'cdr_interleave_shards': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_gather_owned_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
-    'cdr_ids_pack32': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr],
-    'cdr_ids_unpack32': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_ptr],
+    'cdr_ids_pack32': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_ids_unpack32': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_ptr, _c_ptr],
+    'cdr_point_partial_dot': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_point_grad_from_dot': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr,
+                                _c_ptr, _c_ptr],
     'cdr_bpr_partial_diff': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_bpr_grad_from_diff': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr,
                                _c_ptr, _c_ptr, _c_ptr],
@@ -238,7 +241,8 @@ def call(name, *args):
 
 TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4: 'rowwise_apply_kernel(users)',
         5: 'rowwise_apply_kernel(items)', 6: 'sort_ids', 7: 'point_fwd_grad_kernel',
-        8: 'bpr_partial_diff_kernel', 9: 'bpr_grad_from_diff_kernel'}
+        8: 'bpr_partial_diff_kernel', 9: 'bpr_grad_from_diff_kernel',
+        10: 'point_partial_dot_kernel', 11: 'point_grad_from_dot_kernel'}
 
 
 _timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device

@@ -93,21 +93,25 @@ class NativeDimOps:
         self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, **kw)
         self.out = self.fs.out6
 
-    def pack_ids(self, uid, pid, nid, out32):
+    def pack_ids(self, a, b, c, out32):
+        """c: int64 ids (pairwise: negatives) or fp32 labels (pointwise rows)."""
         B_ = self.B_
         if not hasattr(self, '_bad'):
-            self._bad = torch.zeros(1, device=uid.device, dtype=torch.int32)
-        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(), B_.raw(out32), B_.raw(self._bad))
+            self._bad = torch.zeros(1, device=a.device, dtype=torch.int32)
+        is_label = c.dtype == torch.float32
+        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(a), B_.i64(b), None if is_label else B_.i64(c), B_.f32(c) if is_label else None,
+                a.numel(), B_.raw(out32), B_.raw(self._bad))
 
-    def unpack_ids(self, gathered32, world, Bl, out64):
+    def unpack_ids(self, gathered32, world, Bl, out64, label_out=None):
         B_ = self.B_
-        B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered32), int(world), int(Bl), B_.i64(out64))
+        B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered32), int(world), int(Bl), B_.i64(out64),
+                B_.f32(label_out) if label_out is not None else None)
 
     def ids_fit(self):
         """False if any id handed to ``pack_ids`` so far did not fit int32 (synchronises; the tables here never have 2^31 rows)."""
         return not hasattr(self, '_bad') or int(self._bad.item()) == 0
 
-    def partial_diff(self, uid, pid, nid, diff):
+    def partial(self, uid, pid, nid, diff):
         B_, fs = self.B_, self.fs
         B_.call('cdr_bpr_partial_diff', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
                 B_.i64(pid), B_.i64(nid), uid.numel(), B_.f32(diff))
@@ -120,14 +124,34 @@ class NativeDimOps:
         return fs.sort_apply(uid, pid, nid)
 
 
-class DimShardedBPRStep:
-    """``user_cols`` / ``item_cols``: this rank's column slices [rows, D / world] (``dim_shard_of``).  ``step`` takes the rank's
-    own batch (global row ids, the same length on every rank) and returns out (view; [0] = total loss of the GLOBAL batch,
-    identical on every rank).  ``ops``: compute stand-in for the CPU (gloo) tests; default = the native kernels."""
+class NativePointDimOps(NativeDimOps):
+    """Pointwise rows (user, item, label): fused.FusedPointStep's buffers around cdr_point_partial_dot / cdr_point_grad_from_dot."""
 
-    def __init__(self, user_cols, item_cols, batch_per_rank, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None, stream=None, user_state=None,
-                 item_state=None):
+    def __init__(self, user_cols, item_cols, max_global_batch, **kw):
+        from . import binding as B_
+        from .fused import FusedPointStep
+        self.B_ = B_
+        self.fs = FusedPointStep(user_cols, item_cols, max_global_batch, **kw)
+        self.out = self.fs.out6
+
+    def partial(self, uid, iid, label, dot):
+        B_, fs = self.B_, self.fs
+        B_.call('cdr_point_partial_dot', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid), B_.i64(iid),
+                uid.numel(), B_.f32(dot))
+
+    def grad_apply(self, uid, iid, label, dot):
+        B_, fs = self.B_, self.fs
+        B_.call('cdr_point_grad_from_dot', B_.ctx(fs.U.device), B_.stream(), fs.kind, B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
+                B_.i64(iid), B_.f32(label), uid.numel(), float(fs.reg_weight), B_.f32(dot), B_.f32(fs.out6), B_.f32(fs.GU), B_.f32(fs.GI))
+        return fs.sort_apply(uid, iid)
+
+
+class _DimShardedStep:
+    """Skeleton shared by the pairwise and the pointwise step: pack -> all-gather -> unpack -> partial scores -> all-reduce ->
+    gradients + sort + row-wise applies.  ``third_is_label``: the third per-row array is an fp32 label, not an id."""
+    third_is_label = False
+
+    def _setup(self, user_cols, item_cols, batch_per_rank, group, ops, stream):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -136,10 +160,9 @@ class DimShardedBPRStep:
         Bg = int(batch_per_rank) * self.world
         self.max_batch = Bg
         dev = user_cols.device
-        self.ops = ops if ops is not None else NativeDimOps(
-            user_cols, item_cols, Bg, opt=opt, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, gamma=gamma,
-            reg_weight=reg_weight, user_state=user_state, item_state=item_state)
+        self.ops = ops
         self.ids = torch.empty(3 * Bg, device=dev, dtype=torch.int64)
+        self.labels = torch.empty(Bg, device=dev, dtype=torch.float32) if self.third_is_label else None
         self.ids32 = torch.empty(3 * int(batch_per_rank), device=dev, dtype=torch.int32)
         self.gath32 = torch.empty(3 * Bg, device=dev, dtype=torch.int32)
         self.diff = torch.empty(Bg + 2, device=dev, dtype=torch.float32)
@@ -183,26 +206,60 @@ class DimShardedBPRStep:
         self._prof['bytes'] += int(nbytes)
         self._prof['events'].append((a, b))
 
-    def step(self, uid, pid, nid):
+    def step(self, a, b, c):
+        """Pairwise: (uid, pid, nid); pointwise: (uid, iid, label).  The rank's own rows, the same count on every rank."""
         G, grp, ops = self.world, self.group, self.ops
-        Bl = uid.numel()
+        Bl = a.numel()
         Bg = G * Bl
         assert Bg <= self.max_batch
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())           # the ids were produced on the caller's stream
         with self._on_stream():
             if G > 1:
-                ops.pack_ids(uid, pid, nid, self.ids32[:3 * Bl])
+                ops.pack_ids(a, b, c, self.ids32[:3 * Bl])
                 with self._timed(3 * 4 * Bl * (G - 1)):
                     dist.all_gather_into_tensor(self.gath32[:3 * Bg], self.ids32[:3 * Bl], group=grp)
-                idv = self.ids[:3 * Bg].view(3, Bg)                               # field-major global ids of this step
-                ops.unpack_ids(self.gath32[:3 * Bg], G, Bl, idv)
-                u, p, n = idv[0], idv[1], idv[2]
-            else:
-                u, p, n = uid, pid, nid
+                idv = self.ids[:3 * Bg].view(3, Bg)                               # field-major global rows of this step
+                if self.third_is_label:
+                    ops.unpack_ids(self.gath32[:3 * Bg], G, Bl, idv, self.labels[:Bg])
+                    a, b, c = idv[0], idv[1], self.labels[:Bg]
+                else:
+                    ops.unpack_ids(self.gath32[:3 * Bg], G, Bl, idv)
+                    a, b, c = idv[0], idv[1], idv[2]
             diff = self.diff[:Bg + 2]
-            ops.partial_diff(u, p, n, diff)
+            ops.partial(a, b, c, diff)
             if G > 1:
                 with self._timed(2 * 4 * (Bg + 2) * (G - 1) // G):            # ring all-reduce: reduce-scatter + all-gather
                     dist.all_reduce(diff, group=grp)
-            return ops.grad_apply(u, p, n, diff)
+            return ops.grad_apply(a, b, c, diff)
+
+
+class DimShardedBPRStep(_DimShardedStep):
+    """``user_cols`` / ``item_cols``: this rank's column slices [rows, D / world] (``dim_shard_of``).  ``step(uid, pid, nid)`` takes
+    the rank's own batch (global row ids, the same length on every rank) and returns out (view; [0] = total loss of the GLOBAL
+    batch, identical on every rank).  ``ops``: compute stand-in for the CPU (gloo) tests; default = the native kernels."""
+
+    def __init__(self, user_cols, item_cols, batch_per_rank, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None, stream=None, user_state=None,
+                 item_state=None):
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if ops is None:
+            ops = NativeDimOps(user_cols, item_cols, int(batch_per_rank) * world, opt=opt, lr=lr, betas=betas, eps=eps,
+                               weight_decay=weight_decay, gamma=gamma, reg_weight=reg_weight, user_state=user_state,
+                               item_state=item_state)
+        self._setup(user_cols, item_cols, batch_per_rank, group, ops, stream)
+
+
+class DimShardedPointStep(_DimShardedStep):
+    """Pointwise counterpart (fused.FusedPointStep in the dimension layout): ``step(uid, iid, label)`` with recbole's pointwise
+    rows -- MSE on the raw dot (EMCDR's MF latent factor model) or BCE on sigmoid(dot)."""
+    third_is_label = True
+
+    def __init__(self, user_cols, item_cols, batch_per_rank, loss='mse', opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, reg_weight=0.0, group=None, ops=None, stream=None, user_state=None, item_state=None):
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if ops is None:
+            ops = NativePointDimOps(user_cols, item_cols, int(batch_per_rank) * world, loss=loss, opt=opt, lr=lr, betas=betas,
+                                    eps=eps, weight_decay=weight_decay, reg_weight=reg_weight, user_state=user_state,
+                                    item_state=item_state)
+        self._setup(user_cols, item_cols, batch_per_rank, group, ops, stream)

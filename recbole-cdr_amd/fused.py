@@ -125,10 +125,15 @@ class FusedPointStep:
         """uid / iid int64 [B], label fp32 [B].  Returns out6 (view; [0] = total loss)."""
         B = uid.numel()
         assert B <= self.max_batch
+        B_.call('cdr_point_fwd_grad', B_.ctx(self.U.device), B_.stream(), self.kind, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid),
+                B_.i64(iid), B_.f32(label), B, float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI))
+        return self.sort_apply(uid, iid)
+
+    def sort_apply(self, uid, iid):
+        """Second half of the step (GU / GI / out6[4:6] in place -- also what dimshard.DimShardedPointStep runs after its all-reduce)."""
+        B = uid.numel()
         s = B_.stream()
         ctxh = B_.ctx(self.U.device)
-        B_.call('cdr_point_fwd_grad', ctxh, s, self.kind, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(iid),
-                B_.f32(label), B, float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI))
         B_.call('cdr_sort_ids_two_tables', ctxh, s, B_.i64(uid), B, self.U.shape[0], B_.i64(iid), B, None, 0, self.I.shape[0],
                 B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws.numel())
         for st, lo, G, coef, base in ((self.ustate, 0, self.GU, self.out6[4:5], 0),

@@ -1803,12 +1803,107 @@ def test_ids_pack32_unpack32_round_trip_and_overflow_flag():
     gathered = torch.empty(G, 3 * Bl, device=DEV, dtype=torch.int32)
     for r in range(G):
         u, p, n = (t.to(DEV) for t in per_rank[r])
-        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(u), B_.i64(p), B_.i64(n), Bl, B_.raw(gathered[r]), B_.raw(bad))
+        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(u), B_.i64(p), B_.i64(n), None, Bl, B_.raw(gathered[r]), B_.raw(bad))
     out = torch.empty(3, G * Bl, device=DEV, dtype=torch.int64)
-    B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered), G, Bl, B_.i64(out))
+    B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered), G, Bl, B_.i64(out), None)
     for j in range(3):
         assert torch.equal(out[j].cpu(), torch.cat([per_rank[r][j] for r in range(G)]))
     assert int(bad.item()) == 0
     big = torch.full((Bl,), 2 ** 31, device=DEV, dtype=torch.int64)
-    B_.call('cdr_ids_pack32', B_.stream(), B_.i64(big), B_.i64(big), B_.i64(big), Bl, B_.raw(gathered[0]), B_.raw(bad))
+    B_.call('cdr_ids_pack32', B_.stream(), B_.i64(big), B_.i64(big), B_.i64(big), None, Bl, B_.raw(gathered[0]), B_.raw(bad))
     assert int(bad.item()) == 1
+    # pointwise rows: the label's bit pattern rides in the third slot and comes back as fp32
+    lab = [torch.rand(Bl, generator=g) for _ in range(G)]
+    for r in range(G):
+        B_.call('cdr_ids_pack32', B_.stream(), B_.i64(per_rank[r][0].to(DEV)), B_.i64(per_rank[r][1].to(DEV)), None, B_.f32(lab[r].to(DEV)),
+                Bl, B_.raw(gathered[r]), B_.raw(bad))
+    out.fill_(-7)
+    lab_out = torch.empty(G * Bl, device=DEV)
+    B_.call('cdr_ids_unpack32', B_.stream(), B_.raw(gathered), G, Bl, B_.i64(out), B_.f32(lab_out))
+    assert torch.equal(lab_out.cpu(), torch.cat(lab)) and torch.equal(out[1].cpu(), torch.cat([per_rank[r][1] for r in range(G)]))
+    assert bool((out[2] == -7).all())
+
+
+@pytest.mark.parametrize('kind', ['mse', 'bce'])
+@pytest.mark.parametrize('D,B', [(128, 3000), (16, 1025), (8, 3)])
+def test_point_partial_dot_and_grad_from_dot_equal_the_fused_forward(kind, D, B):
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(D + B)
+    nu, ni = 900, 700
+    code = B_.CDR_LOSS_MSE if kind == 'mse' else B_.CDR_LOSS_BCE
+    U, I = torch.randn(nu, D, device=DEV) * 0.3, torch.randn(ni, D, device=DEV) * 0.3
+    u, i = torch.randint(0, nu, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV)
+    y = (torch.rand(B, device=DEV) < 0.4).float()
+    out_a, GU_a, GI_a = torch.zeros(12, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    out_b, GU_b, GI_b = torch.zeros(12, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    ctx, s = B_.ctx(U.device), B_.stream()
+    B_.call('cdr_point_fwd_grad', ctx, s, code, B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(i), B_.f32(y), B, 0.05, B_.f32(out_a),
+            B_.f32(GU_a), B_.f32(GI_a))
+    dot = torch.empty(B + 2, device=DEV)
+    B_.call('cdr_point_partial_dot', ctx, s, B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(i), B, B_.f32(dot))
+    assert_close(dot[:B], (U[u] * I[i]).sum(1), rtol=1e-5, atol=1e-6, what='dot')
+    B_.call('cdr_point_grad_from_dot', ctx, s, code, B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(i), B_.f32(y), B, 0.05, B_.f32(dot),
+            B_.f32(out_b), B_.f32(GU_b), B_.f32(GI_b))
+    assert_close(GU_b, GU_a, rtol=1e-5, atol=1e-9, what='GU')
+    assert_close(GI_b, GI_a, rtol=1e-5, atol=1e-9, what='GI')
+    assert_close(out_b[:9], out_a[:9], rtol=1e-6, atol=0, what='out9')
+
+
+def _dim_point_shared_gpu_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import DimShardedPointStep, dim_shard_of
+        torch.cuda.set_device(0)
+        torch.manual_seed(13)
+        nu, ni, D, B = 5003, 2001, 96, 2500
+        U, I = torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1
+        Uc, Ic = dim_shard_of(U, world, rank).to(DEV), dim_shard_of(I, world, rank).to(DEV)
+        st = DimShardedPointStep(Uc, Ic, B, loss='mse', opt='adam', lr=0.01, reg_weight=0.02)
+        losses, batches = [], []
+        for it in range(3):
+            g = torch.Generator(); g.manual_seed(1000 * it + rank)
+            u = torch.randint(0, nu, (B,), generator=g); i = torch.randint(0, ni, (B,), generator=g)
+            y = (torch.rand(B, generator=g) < 0.3).float()
+            if it == 1:
+                u[: B // 2] = u[0]; i[: B // 3] = i[0]
+            batches.append((u, i, y))
+            st.step(u.to(DEV), i.to(DEV), y.to(DEV))
+            losses.append(float(st.out[0]))
+        assert st.ops.ids_fit()
+        q.put((rank, Uc.cpu().numpy(), Ic.cpu().numpy(), losses, [tuple(t.numpy() for t in b) for b in batches]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dim_sharded_point_step_ranks_share_one_gpu():
+    """DimShardedPointStep (MF latent factor model: MSE on the dot), 3 ranks x 32 columns on cuda:0 over gloo, against
+    FusedPointStep on the full tables and the concatenated rows."""
+    import socket
+    import torch.multiprocessing as mp
+    from recbole_cdr_amd.fused import FusedPointStep
+    world = 3
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dim_point_shared_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    torch.manual_seed(13)
+    nu, ni, D, B = 5003, 2001, 96, 2500
+    Ds = D // world
+    U, I = (torch.randn(nu, D) * 0.1).to(DEV), (torch.randn(ni, D) * 0.1).to(DEV)
+    ref = FusedPointStep(U, I, world * B, loss='mse', opt='adam', lr=0.01, reg_weight=0.02)
+    for it in range(3):
+        u, i, y = (torch.from_numpy(np.concatenate([res[r][4][it][k] for r in range(world)])).to(DEV) for k in range(3))
+        loss = float(ref.step(u, i, y)[0])
+        for r in range(world):
+            assert abs(res[r][3][it] - loss) <= 2e-6 * abs(loss), (it, r, res[r][3][it], loss)
+    for r in range(world):
+        assert_close(torch.from_numpy(res[r][1]).to(DEV), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'U rank{r}')
+        assert_close(torch.from_numpy(res[r][2]).to(DEV), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'I rank{r}')

@@ -328,10 +328,10 @@ class OracleDimOps:
     def pack_ids(self, uid, pid, nid, out32):
         out32.copy_(torch.cat([uid, pid, nid]).to(torch.int32))
 
-    def unpack_ids(self, gathered32, world, Bl, out64):
+    def unpack_ids(self, gathered32, world, Bl, out64, label_out=None):
         out64.copy_(gathered32.view(world, 3, Bl).permute(1, 0, 2).reshape(3, world * Bl).to(torch.int64))
 
-    def partial_diff(self, uid, pid, nid, diff):
+    def partial(self, uid, pid, nid, diff):
         u, p, n = self.U[uid], self.I[pid], self.I[nid]
         B = uid.numel()
         diff[:B] = (u * p).sum(1) - (u * n).sum(1)
@@ -411,3 +411,87 @@ def test_dim_sharded_step_matches_single_process(world, opt):
         torch.testing.assert_close(torch.from_numpy(res[r][1]), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=atol)
         torch.testing.assert_close(torch.from_numpy(res[r][2]), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=atol)
         torch.testing.assert_close(torch.from_numpy(res[r][5]), U[r::world], rtol=2e-5, atol=atol)
+
+
+class OraclePointDimOps(OracleDimOps):
+    """Pointwise rows (user, item, label), MSE on the dot: the label travels as its fp32 bit pattern in the third int32 slot."""
+
+    def pack_ids(self, uid, iid, label, out32):
+        out32.copy_(torch.cat([uid.to(torch.int32), iid.to(torch.int32), label.view(torch.int32)]))
+
+    def unpack_ids(self, gathered32, world, Bl, out64, label_out=None):
+        g = gathered32.view(world, 3, Bl).permute(1, 0, 2).reshape(3, world * Bl)
+        out64[:2].copy_(g[:2].to(torch.int64))
+        label_out.copy_(g[2].contiguous().view(torch.float32))
+
+    def partial(self, uid, iid, label, dot):
+        u, v = self.U[uid], self.I[iid]
+        B = uid.numel()
+        dot[:B] = (u * v).sum(1)
+        dot[B] = (u * u).sum()
+        dot[B + 1] = (v * v).sum()
+
+    def grad_apply(self, uid, iid, label, dot):
+        B = uid.numel()
+        u, v = self.U[uid], self.I[iid]
+        d = dot[:B] - label
+        g = 2.0 * d / B
+        OracleOps().finish_sums(torch.stack([(d * d).sum(), dot[B], dot[B + 1]]), B, self.reg_weight, self.out)
+        self.t += 1
+        o = OracleOps()
+        o.sort_apply(self.U, self.state[0], uid, g[:, None] * v, self.opt, self.hp, self.t, reg_limit=B, reg_coef=self.out[4:5])
+        o.sort_apply(self.I, self.state[1], iid, g[:, None] * u, self.opt, self.hp, self.t, reg_limit=B, reg_coef=self.out[5:6])
+        return self.out
+
+
+def _worker_dim_point(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import DimShardedPointStep, dim_shard_of
+        torch.manual_seed(0)
+        nu, ni, D, B, reg, lr = 41, 29, 8 * world, 23, 0.03, 0.05
+        U, I = torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3
+        Uc, Ic = dim_shard_of(U, world, rank), dim_shard_of(I, world, rank)
+        hp = {'lr': lr, 'b1': 0.9, 'b2': 0.999, 'eps': 1e-8, 'wd': 0.0}
+        st = DimShardedPointStep(Uc, Ic, B, ops=OraclePointDimOps(Uc, Ic, 1, hp, 0.0, reg))
+        losses, batches = [], []
+        for step in range(3):
+            g = torch.Generator(); g.manual_seed(100 * step + rank)
+            u = torch.randint(0, nu, (B,), generator=g); i = torch.randint(0, ni, (B,), generator=g)
+            y = (torch.rand(B, generator=g) < 0.4).float()
+            batches.append((u, i, y))
+            losses.append(float(st.step(u, i, y)[0]))
+        q.put((rank, Uc.numpy().copy(), Ic.numpy().copy(), losses, [tuple(t.numpy().copy() for t in b) for b in batches]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dim_sharded_point_step_matches_single_process():
+    from oracle import train_step as ts
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dim_point, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    nu, ni, D, reg, lr = 41, 29, 8 * world, 0.03, 0.05
+    U, I = torch.randn(nu, D) * 0.3, torch.randn(ni, D) * 0.3
+    us, is_ = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    for step in range(3):
+        u, i, y = (torch.cat([torch.from_numpy(res[r][4][step][k]) for r in range(world)]) for k in range(3))
+        loss = ts.rowwise_point_step(U, I, us, is_, u, i, y, step + 1, step + 1, loss='mse', opt='adam', lr=lr, reg_weight=reg)
+        for r in range(world):
+            assert abs(res[r][3][step] - float(loss)) <= 1e-5 * abs(float(loss)), (step, res[r][3][step], float(loss))
+    Ds = D // world
+    for r in range(world):
+        torch.testing.assert_close(torch.from_numpy(res[r][1]), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=lr * 1e-2)
+        torch.testing.assert_close(torch.from_numpy(res[r][2]), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=lr * 1e-2)
