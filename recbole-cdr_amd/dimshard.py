@@ -31,11 +31,11 @@ def dim_shard_of(full_table, world, rank):
     return full_table[:, rank * Ds:(rank + 1) * Ds].contiguous()
 
 
-def dim_to_row_shards(cols, group=None):
+def dim_to_row_shards(cols, group=None, force=False):
     """[rows, Ds] column slice -> this rank's ROW shard [ceil-ish(rows / G), D] (row r % G == rank at r // G): the layout
     shard.ShardedFullSort evaluates on.  One all-to-all of the whole slice (rows * Ds * 4 B per rank), once per evaluation."""
     G, rank = dist.get_world_size(group), dist.get_rank(group)
-    if G == 1:
+    if G == 1 and not force:                  # force: issue the (identity) all-to-all anyway -- the one-GPU RCCL test
         return cols
     rows, Ds = cols.shape
     from .shard import shard_rows
@@ -46,10 +46,10 @@ def dim_to_row_shards(cols, group=None):
     return recv.view(G, n_q[rank], Ds).permute(1, 0, 2).reshape(n_q[rank], G * Ds).contiguous()
 
 
-def row_to_dim_shards(row_shard, total_rows, group=None):
+def row_to_dim_shards(row_shard, total_rows, group=None, force=False):
     """Inverse of ``dim_to_row_shards``: this rank's row shard [rows_r, D] -> its column slice [total_rows, D / G]."""
     G, rank = dist.get_world_size(group), dist.get_rank(group)
-    if G == 1:
+    if G == 1 and not force:
         return row_shard
     from .shard import shard_rows
     n_q = [shard_rows(total_rows, G, q) for q in range(G)]
@@ -169,6 +169,7 @@ class _DimShardedStep:
         self.out = self.ops.out
         self.stream = stream
         self._prof = None
+        self.force_collectives = False           # run the (identity) collectives at world 1 too: exercises the RCCL calls on one GPU
 
     @property
     def ustate(self):
@@ -214,8 +215,9 @@ class _DimShardedStep:
         assert Bg <= self.max_batch
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())           # the ids were produced on the caller's stream
+        comm = G > 1 or (self.force_collectives and dist.is_initialized())
         with self._on_stream():
-            if G > 1:
+            if comm:
                 ops.pack_ids(a, b, c, self.ids32[:3 * Bl])
                 with self._timed(3 * 4 * Bl * (G - 1)):
                     dist.all_gather_into_tensor(self.gath32[:3 * Bg], self.ids32[:3 * Bl], group=grp)
@@ -228,7 +230,7 @@ class _DimShardedStep:
                     a, b, c = idv[0], idv[1], idv[2]
             diff = self.diff[:Bg + 2]
             ops.partial(a, b, c, diff)
-            if G > 1:
+            if comm:
                 with self._timed(2 * 4 * (Bg + 2) * (G - 1) // G):            # ring all-reduce: reduce-scatter + all-gather
                     dist.all_reduce(diff, group=grp)
             return ops.grad_apply(a, b, c, diff)

@@ -1907,3 +1907,41 @@ def test_dim_sharded_point_step_ranks_share_one_gpu():
     for r in range(world):
         assert_close(torch.from_numpy(res[r][1]).to(DEV), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'U rank{r}')
         assert_close(torch.from_numpy(res[r][2]).to(DEV), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=1e-4, what=f'I rank{r}')
+
+
+def test_dim_sharded_step_on_rccl_world1_equals_fused():
+    """The dimension-sharded step's collectives (int32 all-gather into a buffer slice, fp32 all-reduce of a slice, the column ->
+    row all-to-all) issued on a real RCCL communicator -- one rank, so they are identities and the result must equal the plain
+    fused step bit for bit; what this pins is that RCCL accepts the buffers, dtypes and views the step hands it."""
+    import torch.distributed as dist
+    from recbole_cdr_amd.dimshard import DimShardedBPRStep, DimShardedPointStep, dim_to_row_shards, row_to_dim_shards
+    from recbole_cdr_amd.fused import FusedBPRStep, FusedPointStep
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(3)
+        nu, ni, D, B = 4001, 3001, 64, 5000
+        U, I = torch.randn(nu, D, device=DEV) * 0.1, torch.randn(ni, D, device=DEV) * 0.1
+        Ua, Ia, Ub, Ib = U.clone(), I.clone(), U.clone(), I.clone()
+        a = DimShardedBPRStep(Ua, Ia, B, opt='adam', lr=0.01, reg_weight=0.02, stream=torch.cuda.Stream())
+        a.force_collectives = True
+        b = FusedBPRStep(Ub, Ib, B, opt='adam', lr=0.01, reg_weight=0.02)
+        pa = DimShardedPointStep(Ua, Ia, B, opt='adam', lr=0.01, reg_weight=0.02, user_state=a.ustate, item_state=a.istate)
+        pa.force_collectives = True
+        pb = FusedPointStep(Ub, Ib, B, opt='adam', lr=0.01, reg_weight=0.02, user_state=b.ustate, item_state=b.istate)
+        for it in range(3):
+            u, p, n = torch.randint(0, nu, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV)
+            y = (torch.rand(B, device=DEV) < 0.5).float()
+            la = a.step(u, p, n); torch.cuda.synchronize()
+            lb = b.step(u, p, n)
+            assert_close(la[:6], lb[:6], rtol=1e-6, atol=0, what='bpr out')
+            la = pa.step(u, p, y); torch.cuda.synchronize()
+            lb = pb.step(u, p, y)
+            assert_close(la[:6], lb[:6], rtol=1e-6, atol=0, what='point out')
+        assert a.ops.ids_fit() and pa.ops.ids_fit()
+        assert_close(Ua, Ub, rtol=2e-5, atol=1e-4, what='U')              # Adam, lr 0.01: FMA contraction differs between the kernels
+        assert_close(Ia, Ib, rtol=2e-5, atol=1e-4, what='I')
+        assert torch.equal(row_to_dim_shards(dim_to_row_shards(Ua, force=True), nu, force=True), Ua)
+    finally:
+        dist.destroy_process_group()
