@@ -1945,3 +1945,95 @@ def test_dim_sharded_step_on_rccl_world1_equals_fused():
         assert torch.equal(row_to_dim_shards(dim_to_row_shards(Ua, force=True), nu, force=True), Ua)
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole EMCDR schedule over several ranks: SOURCE and TARGET BPR steps in the dimension layout, the phase switch
+# (tables AND Adam moments transposed to row shards, update counts kept), OVERLAP steps in the row layout, sharded top-k.
+def _schedule_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import DimShardedBPRStep, dim_shard_of, dim_to_row_shards, state_to_row_shards
+        from recbole_cdr_amd.fused import FusedMapStep
+        from recbole_cdr_amd.shard import ShardedFullSort
+        torch.cuda.set_device(0)
+        nu, ni, D, B, OB = 1201, 901, 64, 700, 90
+        torch.manual_seed(31)
+        SU, SI, TU, TI = (torch.randn(n, D) * 0.2 for n in (nu, ni, nu, ni))
+        cols = {k: dim_shard_of(t, world, rank).to(DEV) for k, t in (('su', SU), ('si', SI), ('tu', TU), ('ti', TI))}
+        hp = dict(opt='adam', lr=0.01, reg_weight=0.02)
+        steps = {'source': DimShardedBPRStep(cols['su'], cols['si'], B, **hp), 'target': DimShardedBPRStep(cols['tu'], cols['ti'], B, **hp)}
+        losses = []
+        for dom, n_steps in (('source', 3), ('target', 2)):                  # unequal counts: the two user tables' Adam step counts differ
+            for it in range(n_steps):
+                g = torch.Generator(); g.manual_seed({'source': 100, 'target': 200}[dom] + 10 * it + rank)
+                u, p, n = (torch.randint(1, hi, (B,), generator=g).to(DEV) for hi in (nu, ni, ni))
+                losses.append(float(steps[dom].step(u, p, n)[0]))
+        sst, tst = state_to_row_shards(steps['source'].ustate), state_to_row_shards(steps['target'].ustate)
+        ti_rows = dim_to_row_shards(cols['ti'])
+        _cpu, dev, fn = _make_mapping((D, D), 9)
+        fm = FusedMapStep(sst.table, tst.table, fn, dev, OB, lr=0.01, group=dist.group.WORLD, source_state=sst, target_state=tst)
+        for it in range(3):
+            g = torch.Generator(); g.manual_seed(300 + 10 * it + rank)
+            idx = torch.randperm(nu - 1, generator=g)[:OB].add(1).reshape(-1, 1)
+            losses.append(float(fm.step(idx.to(DEV))))
+        fs = ShardedFullSort(ti_rows, ni)
+        ids = torch.arange(1, 41)
+        tv, tix = fs.topk(fs.user_rows(tst.table, ids.to(DEV)), 10)
+        q.put((rank, losses, tst.table.cpu().numpy(), sst.table.cpu().numpy(), tv.cpu().numpy(), tix.cpu().numpy(),
+               dev[0].detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_schedule_dim_then_row_layout_matches_single_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    from recbole_cdr_amd import functional as F_
+    from recbole_cdr_amd.fused import FusedBPRStep, FusedMapStep
+    world = 2
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    nu, ni, D, B, OB = 1201, 901, 64, 700, 90
+    torch.manual_seed(31)
+    SU, SI, TU, TI = ((torch.randn(n, D) * 0.2).to(DEV) for n in (nu, ni, nu, ni))
+    hp = dict(opt='adam', lr=0.01, reg_weight=0.02)
+    steps = {'source': FusedBPRStep(SU, SI, world * B, **hp), 'target': FusedBPRStep(TU, TI, world * B, **hp)}
+    want = []
+    for dom, n_steps in (('source', 3), ('target', 2)):
+        for it in range(n_steps):
+            parts = []
+            for r in range(world):
+                g = torch.Generator(); g.manual_seed({'source': 100, 'target': 200}[dom] + 10 * it + r)
+                parts.append([torch.randint(1, hi, (B,), generator=g) for hi in (nu, ni, ni)])
+            u, p, n = (torch.cat([parts[r][k] for r in range(world)]).to(DEV) for k in range(3))
+            want.append(float(steps[dom].step(u, p, n)[0]))
+    _cpu, dev, fn = _make_mapping((D, D), 9)
+    fm = FusedMapStep(SU, TU, fn, dev, world * OB, lr=0.01, source_state=steps['source'].ustate, target_state=steps['target'].ustate)
+    for it in range(3):
+        idx = []
+        for r in range(world):
+            g = torch.Generator(); g.manual_seed(300 + 10 * it + r)
+            idx.append(torch.randperm(nu - 1, generator=g)[:OB].add(1))
+        want.append(float(fm.step(torch.cat(idx).reshape(-1, 1).to(DEV))))
+    for r in range(world):
+        for k, (a, b) in enumerate(zip(res[r][1], want)):
+            assert abs(a - b) <= 1e-5 * abs(b), (r, k, a, b)
+        assert_close(torch.from_numpy(res[r][2]).to(DEV), TU[r::world], rtol=2e-5, atol=1e-4, what=f'target users rank{r}')
+        assert_close(torch.from_numpy(res[r][3]).to(DEV), SU[r::world], rtol=2e-5, atol=1e-4, what=f'source users rank{r}')
+        assert_close(torch.from_numpy(res[r][6]).to(DEV), dev[0].detach(), rtol=2e-5, atol=1e-4, what='mapping weight')
+    tv, tix = F_.fullsort_topk(TU[1:41].contiguous(), TI, None, k=10)
+    for r in range(world):
+        assert_close(torch.from_numpy(res[r][4]).to(DEV), tv, rtol=1e-4, atol=1e-5, what='top-k values')
+        same = (torch.from_numpy(res[r][5]).to(DEV) == tix).float().mean()
+        assert float(same) > 0.97, float(same)                      # tables agree to ~1e-5: a near-tie may swap two neighbours
