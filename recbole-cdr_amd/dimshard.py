@@ -82,6 +82,85 @@ def state_to_row_shards(state, group=None, consume=False):
     return out
 
 
+def state_to_dim_shards(state, total_rows, group=None):
+    """Inverse of ``state_to_row_shards`` (OVERLAP epochs done, back to dimension-sharded BPR epochs)."""
+    from .fused import RowwiseState
+    out = RowwiseState.__new__(RowwiseState)
+    out.step = state.step
+    for name in ('table', 'exp_avg', 'exp_avg_sq'):
+        t = getattr(state, name)
+        setattr(out, name, row_to_dim_shards(t, total_rows, group) if t is not None else None)
+    return out
+
+
+class ShardedTables:
+    """The embedding tables of one model over the ranks of ``group``, each with its row-wise optimizer state, in whichever of
+    the two layouts the current phase wants: 'dim' (column slice of every row: BPR / MF steps) or 'row' (rows r % G == rank:
+    the OVERLAP step, full-sort evaluation).  ``state(name, layout)`` transposes table and moments when the layout changes
+    (update count kept); ``rows(name)`` is a row-shard view for evaluation that leaves a 'dim' state where it is (the table
+    alone is transposed into a temporary that ``touched(name)`` -- called by every training step -- invalidates)."""
+
+    def __init__(self, group, opt_code):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.opt = opt_code
+        self.entries = {}
+
+    def adopt(self, name, full_table, layout='dim'):
+        """``full_table``: the replicated [rows, D] tensor (identical on every rank) -> this rank's shard + a fresh state."""
+        from .fused import RowwiseState
+        from .shard import shard_of
+        shard = dim_shard_of(full_table, self.world, self.rank) if layout == 'dim' else shard_of(full_table, self.world, self.rank).contiguous()
+        self.entries[name] = {'layout': layout, 'state': RowwiseState(shard, self.opt), 'rows': full_table.shape[0],
+                              'D': full_table.shape[1], 'version': 0, 'eval_rows': None}
+        return shard
+
+    def layout(self, name):
+        return self.entries[name]['layout']
+
+    def version(self, name):
+        return self.entries[name]['version']
+
+    def state(self, name, layout):
+        e = self.entries[name]
+        if e['layout'] != layout:
+            e['state'] = (state_to_row_shards(e['state'], self.group, consume=True) if layout == 'row'
+                          else state_to_dim_shards(e['state'], e['rows'], self.group))
+            e['layout'], e['eval_rows'] = layout, None
+            e['version'] += 1
+        return e['state']
+
+    def touched(self, name):
+        self.entries[name]['eval_rows'] = None
+
+    def rows(self, name):
+        e = self.entries[name]
+        if e['layout'] == 'row':
+            return e['state'].table
+        if e['eval_rows'] is None:
+            e['eval_rows'] = dim_to_row_shards(e['state'].table, self.group)
+        return e['eval_rows']
+
+    def full(self, name):
+        """The replicated [rows, D] table again (checkpointing / hand-over to a single-process run): all-gather of the shards."""
+        e = self.entries[name]
+        t = e['state'].table
+        if e['layout'] == 'dim':
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t.contiguous(), group=self.group)
+            return torch.cat(parts, dim=1)
+        from .shard import shard_rows
+        out = torch.empty(e['rows'], e['D'], device=t.device, dtype=t.dtype)
+        for q in range(self.world):
+            part = torch.empty(shard_rows(e['rows'], self.world, q), e['D'], device=t.device, dtype=t.dtype)
+            if q == self.rank:
+                part.copy_(t)
+            dist.broadcast(part, dist.get_global_rank(self.group, q) if self.group is not None else q, group=self.group)
+            out[q::self.world] = part
+        return out
+
+
 class NativeDimOps:
     """libcdrhip arithmetic for DimShardedBPRStep: the two kernels of csrc/cdr_dimshard.hip around fused.FusedBPRStep's
     buffers, sort and row-wise applies (run on [rows, Ds] tables)."""

@@ -200,6 +200,9 @@ class FusedMapStep:
         n_global = idx.numel()
         if self.group is not None:
             idx, n_global = self._route(idx)
+        if n_global == 0:                          # an empty batch (on every rank) is a no-op: no state advances
+            self.loss = torch.zeros((), device=self.S.device, dtype=torch.float32)
+            return self.loss
         n = idx.numel()
         D_s, D_t = self.S.shape[1], self.T.shape[1]
         dev = self.S.device

@@ -56,6 +56,8 @@ class EMCDR(CrossDomainRecommender):
         self.target_item_embedding = nn.Embedding(self.total_num_items, self.target_latent_dim)
         self.bpr_gamma = 1e-10
         self.apply(xavier_normal_initialization)
+        # optional: the tables sharded over the GPUs of a node (optimizer_mode='rowwise' only; see _dist_train_step)
+        self.__dict__['_dist_cfg'] = config['dist_group'] if 'dist_group' in config else None
 
     @staticmethod
     def mlp_layers(layer_dims):
@@ -123,6 +125,8 @@ class EMCDR(CrossDomainRecommender):
         from ...fused import FusedBPRStep, FusedPointStep, FusedMapStep, RowwiseState, OPT_ADAM, OPT_SGD
         code = OPT_ADAM if opt == 'adam' else OPT_SGD
         cache = self.__dict__.setdefault('_fused', {'states': {}, 'steps': {}})
+        if self._dist_group() is not None:
+            return self._dist_train_step(interaction, code, dict(opt=opt, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
         def state(name):
             if name not in cache['states']:
@@ -167,6 +171,119 @@ class EMCDR(CrossDomainRecommender):
                                 item_state=state(f'{domain}_item_embedding'), **hp)
             cache['steps'][key] = step
         return step.step(user, item, neg)[0]
+
+    # ---- the same step over the GPUs of a node (config['dist_group']: a torch.distributed group, or True for WORLD) ----------
+    _TABLES = ('source_user_embedding', 'source_item_embedding', 'target_user_embedding', 'target_item_embedding')
+
+    def _dist_group(self):
+        g = self.__dict__.get('_dist_cfg')
+        if g is None or g is False:
+            return None
+        import torch.distributed as dist
+        return dist.group.WORLD if g is True else g
+
+    def _dist_tables(self, code):
+        """First use: make every rank's parameters rank 0's, then keep only this rank's shard of each embedding table (the
+        nn.Embedding weights become views of the shards: column slices [rows, D/G] while the BPR / MF phases train, row shards in
+        the OVERLAP phase -- dimshard.ShardedTables)."""
+        T = self.__dict__.get('_dist')
+        if T is None:
+            import torch.distributed as dist
+            from ...dimshard import ShardedTables
+            grp = self._dist_group()
+            T = ShardedTables(grp, code)
+            src = dist.get_global_rank(grp, 0)
+            for p in self.parameters():
+                dist.broadcast(p.data, src, group=grp)
+            for name in self._TABLES:
+                emb = getattr(self, name)
+                emb.weight.data = T.adopt(name, emb.weight.data, 'dim')
+            self.__dict__['_dist'] = T
+        return T
+
+    def _dist_state(self, T, name, layout):
+        st = T.state(name, layout)
+        getattr(self, name).weight.data = st.table             # the module's parameter IS the shard the kernels update
+        return st
+
+    def _dist_train_step(self, interaction, code, hp):
+        """SOURCE / TARGET: dimshard.DimShardedBPRStep / DimShardedPointStep on this rank's column slices, fed with this rank's
+        rows of the batch (the same count on every rank).  OVERLAP: both tables (and their moments) are transposed to row shards
+        once, then fused.FusedMapStep(group=...) exchanges nothing but ids.  Returns the GLOBAL batch's loss on every rank."""
+        from ...dimshard import DimShardedBPRStep, DimShardedPointStep
+        from ...fused import FusedMapStep
+        T = self._dist_tables(code)
+        cache = self.__dict__['_fused']
+        if self.phase == 'OVERLAP':
+            kind = 'user' if self.mode == 'overlap_users' else 'item'
+            names = (f'source_{kind}_embedding', f'target_{kind}_embedding')
+            sst, tst = (self._dist_state(T, n, 'row') for n in names)
+            key = ('map', kind, T.version(names[0]), T.version(names[1]))
+            step = cache['steps'].get(key)
+            if step is None:
+                step = FusedMapStep(sst.table, tst.table, self.apply_mapping, list(self.mapping.parameters()), 1, group=T.group,
+                                    source_state=sst, target_state=tst, **hp)
+                if cache.get('map_opt') is not None:
+                    step.map_opt = cache['map_opt']               # the mapping's Adam state outlives a layout change
+                cache['map_opt'] = step.map_opt
+                cache['steps'][key] = step
+            for n in names:
+                T.touched(n)
+            return step.step(interaction[self.OVERLAP_ID])
+        domain = 'source' if self.phase == 'SOURCE' else 'target'
+        names = (f'{domain}_user_embedding', f'{domain}_item_embedding')
+        ust, ist = (self._dist_state(T, n, 'dim') for n in names)
+        user = interaction[getattr(self, f'{domain.upper()}_USER_ID')].reshape(-1)
+        item = interaction[getattr(self, f'{domain.upper()}_ITEM_ID')].reshape(-1)
+        if user.numel() == 0:                      # the trainer's ragged-tail rule left nothing (on every rank alike)
+            return torch.zeros((), device=user.device, dtype=torch.float32)
+        mf = self.latent_factor_model == 'MF'
+        key = ('mf' if mf else 'bpr', domain, T.version(names[0]), T.version(names[1]))
+        step = cache['steps'].get(key)
+        if step is None or step.max_batch < user.numel() * T.world:
+            if mf:
+                step = DimShardedPointStep(ust.table, ist.table, user.numel(), loss='mse', reg_weight=self.reg_weight, group=T.group,
+                                           user_state=ust, item_state=ist, **hp)
+            else:
+                step = DimShardedBPRStep(ust.table, ist.table, user.numel(), gamma=self.bpr_gamma, reg_weight=self.reg_weight,
+                                         group=T.group, user_state=ust, item_state=ist, **hp)
+            cache['steps'][key] = step
+        for n in names:
+            T.touched(n)
+        third = (interaction[getattr(self, f'{domain.upper()}_LABEL')].reshape(-1).float() if mf
+                 else interaction[getattr(self, f'{domain.upper()}_NEG_ITEM_ID')].reshape(-1))
+        return step.step(user, item, third)[0]
+
+    @torch.no_grad()
+    def _dist_full_sort_topk(self, interaction, k, hist_indptr, hist_cols):
+        """``full_sort_topk`` over row shards: every rank evaluates the same users against ITS item rows (fused mask + top-k
+        kernel), k candidates per user are all-gathered and merged -- identical result on every rank (shard.ShardedFullSort)."""
+        from ...shard import ShardedFullSort
+        from ...fused import OPT_ADAM
+        T = self._dist_tables(OPT_ADAM)
+        OI, TI = self.overlapped_num_items, self.target_num_items
+        if self.phase == 'SOURCE':
+            raise NotImplementedError('distributed evaluation of the SOURCE phase (two item ranges) is not implemented')
+        user = interaction[self.TARGET_USER_ID]
+        items = T.rows('target_item_embedding')
+        if self.phase != 'TARGET' and self.mode != 'overlap_users':
+            # item-overlap: rows [0, OI) of the scored slab are mapping(source rows); both tables follow the same r % G rule, so a
+            # rank maps exactly the local rows it owns
+            n_l = len(range(T.rank, OI, T.world))
+            items = items.clone()
+            if n_l:
+                items[:n_l] = self.apply_mapping(T.rows('source_item_embedding')[:n_l].contiguous())
+        fs = ShardedFullSort(items, TI, group=T.group)
+        user_e = fs.user_rows(T.rows('target_user_embedding'), user)
+        if self.phase != 'TARGET' and self.mode == 'overlap_users':
+            mapped = self.apply_mapping(fs.user_rows(T.rows('source_user_embedding'), user))
+            user_e = torch.where((user < self.overlapped_num_users).unsqueeze(1), mapped, user_e)      # emcdr.py:219-226 (Q5)
+        return fs.topk(user_e, k, hist_indptr=hist_indptr, hist_cols=hist_cols, exclude_first_col=True)
+
+    def gather_full_tables(self):
+        """{name: replicated [rows, D] table} from the shards (checkpoint / hand-over to a single-process model)."""
+        T = self.__dict__.get('_dist')
+        return {n: T.full(n) for n in self._TABLES} if T is not None else {n: getattr(self, n).weight.data for n in self._TABLES}
 
     def fused_optimizer_state(self):
         """Row-wise optimizer state of ``fused_train_step`` for a checkpoint: per table the moments and the update count, plus
@@ -259,6 +376,8 @@ class EMCDR(CrossDomainRecommender):
     def full_sort_topk(self, interaction, k, hist_indptr=None, hist_cols=None):
         """Evaluation without the [U, N] matrix: (values [U,k], columns [U,k]) of ``full_sort_predict`` after recbole's
         mask (column 0 and the per-user history columns, CSR with ascending columns) -- what ``Trainer.evaluate`` needs."""
+        if self._dist_group() is not None:
+            return self._dist_full_sort_topk(interaction, k, hist_indptr, hist_cols)
         user_e, slab0, slab1 = self._full_sort_operands(interaction)
         return F_.fullsort_topk(user_e, slab0 if slab0.shape[0] else None, slab1, k=k, hist_indptr=hist_indptr,
                                 hist_cols=hist_cols, exclude_first_col=True)

@@ -81,6 +81,15 @@ class Trainer:
         self.optimizer_mode = config['optimizer_mode'] if 'optimizer_mode' in config else 'dense'
         # evaluation through the model's fused mask + top-k kernel when it has one (False: full score matrix + torch.topk)
         self.fused_topk = config['fused_topk'] if 'fused_topk' in config else True
+        # config['dist_group'] (a torch.distributed group, or True for WORLD) with optimizer_mode='rowwise': the model's tables are
+        # sharded over the group's GPUs; every rank runs the SAME loaders and trains on rows rank::world of every batch (a ragged
+        # tail of < world rows is skipped, as a DistributedSampler(drop_last=True) would); evaluation is replicated.
+        self.dist_group = None
+        if 'dist_group' in config and config['dist_group'] not in (None, False):
+            import torch.distributed as dist
+            self.dist_group = dist.group.WORLD if config['dist_group'] is True else config['dist_group']
+            if self.optimizer_mode != 'rowwise':
+                raise ValueError("dist_group needs optimizer_mode='rowwise' (small-table models: dp.ShardedDataParallel)")
         if self.optimizer_mode not in ('dense', 'rowwise'):
             raise ValueError(f"optimizer_mode must be 'dense' or 'rowwise', got {self.optimizer_mode!r}")
         if self.optimizer_mode == 'rowwise' and not hasattr(self.model, 'fused_train_step'):
@@ -91,6 +100,8 @@ class Trainer:
         total = None                              # accumulated on device: no per-step host sync
         for interaction in train_data:
             interaction = interaction.to(self.device)
+            if self.dist_group is not None:
+                interaction = self._my_rows(interaction)
             if self.optimizer_mode == 'rowwise':
                 loss = self.model.fused_train_step(interaction, lr=self.learning_rate, weight_decay=self.weight_decay)
                 total = loss.detach().clone() if total is None else total + loss.detach()
@@ -108,6 +119,12 @@ class Trainer:
         if value != value:
             raise ValueError('Training loss is nan')
         return value
+
+    def _my_rows(self, interaction):
+        import torch.distributed as dist
+        from ..data.interaction import Interaction
+        world, rank = dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
+        return Interaction({k: v[:v.shape[0] - v.shape[0] % world][rank::world].contiguous() for k, v in interaction.items()})
 
     def _topk_hits(self, interaction, n_user, history_index, positive_u, positive_i, kmax):
         """Hit matrix [U, kmax] and positives per user from the model's fused mask + top-k (no [U, N] score matrix): the
