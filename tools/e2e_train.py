@@ -1,7 +1,11 @@
 """The whole path at scale, through the reference's own loop: synthetic cross-domain dataset (resident on the device) ->
 four-state loader with the DEVICE negative sampler -> CrossDomainTrainer(optimizer_mode='rowwise') over SOURCE, TARGET and
 OVERLAP epochs (EMCDR-BPR, D=128: FusedBPRStep / FusedMapStep on the model's own tables) -> full-sort evaluation with the
-fused mask + top-k kernel.  Reports wall-clock interactions/s per phase INCLUDING sampling, batching and Python."""
+fused mask + top-k kernel.  Reports wall-clock interactions/s per phase INCLUDING sampling, batching and Python.
+
+Over several GPUs: ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/e2e_train.py`` (one rank per
+GPU; config['dist_group'] = True: tables sharded, every rank trains rows rank::N of each batch, evaluation replicated).
+CDR_BENCH_SHARED_GPU=1 puts every rank on cuda:0 over gloo -- a functional check on a one-GPU box, not a measurement."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,7 +18,17 @@ from recbole_cdr_amd.sampler import DeviceNegSampler
 from recbole_cdr_amd.trainer import CrossDomainTrainer
 from recbole_cdr_amd.utils import InputType
 
-dev = 'cuda:0'
+WORLD, RANK = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+SHARED = bool(int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')))
+dev = 'cuda:%d' % (0 if SHARED else int(os.environ.get('LOCAL_RANK', '0')))
+torch.cuda.set_device(dev)
+if WORLD > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29544')
+    dist.init_process_group('gloo' if SHARED else 'nccl', rank=RANK, world_size=WORLD,
+                            **({} if SHARED else {'device_id': torch.device(dev)}))
+    if RANK:
+        sys.stdout = open(os.devnull, 'w')                # rank 0 reports; every rank computes the same numbers
 OU, TOI, NI, BATCH = int(os.environ.get('E2E_USERS', 4_000_001)), int(os.environ.get('E2E_ITEMS', 1_000_000)), \
     int(os.environ.get('E2E_INTER', 12_000_000)), 1 << 20
 t0 = time.time()
@@ -35,7 +49,9 @@ cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 
        'mapping_function': 'linear', 'mlp_hidden_size': [128], 'learning_rate': float(os.environ.get('E2E_LR', 1e-3)), 'optimizer_mode': 'rowwise',
        'train_modes': ['SOURCE', 'TARGET', 'OVERLAP'], 'epoch_num': [EPOCHS, EPOCHS, '2'], 'source_split': False, 'eval_step': 0,
        'epochs': int(EPOCHS), 'learning_rate_note': 'lr below', 'topk': [10], 'valid_metric': 'Recall@10'}
-torch.manual_seed(2022)
+if WORLD > 1:
+    cfg['dist_group'] = True
+torch.manual_seed(2022)                                   # the same seed on every rank: replicated loaders and samplers draw alike
 model = EMCDR(cfg, ds).to(dev)
 dt = lambda a: torch.from_numpy(a.copy()).to(dev)
 held = 20_000                                           # target interactions held out for the evaluation
