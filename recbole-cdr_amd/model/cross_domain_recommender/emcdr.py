@@ -108,6 +108,7 @@ class EMCDR(CrossDomainRecommender):
         return F_.mse_loss(self.apply_mapping(src), tgt)
 
     def calculate_loss(self, interaction):
+        self._whole_tables_only('calculate_loss')
         if self.phase == 'SOURCE':
             return self.calculate_source_loss(interaction)
         elif self.phase == 'OVERLAP':
@@ -174,6 +175,11 @@ class EMCDR(CrossDomainRecommender):
 
     # ---- the same step over the GPUs of a node (config['dist_group']: a torch.distributed group, or True for WORLD) ----------
     _TABLES = ('source_user_embedding', 'source_item_embedding', 'target_user_embedding', 'target_item_embedding')
+
+    def _whole_tables_only(self, what):
+        if self.__dict__.get('_dist') is not None:
+            raise RuntimeError(f'EMCDR.{what} needs whole tables, but this model holds one shard of each (config["dist_group"]): '
+                               'use fused_train_step / full_sort_topk, or gather_full_tables() into a single-process model')
 
     def _dist_group(self):
         g = self.__dict__.get('_dist_cfg')
@@ -335,6 +341,7 @@ class EMCDR(CrossDomainRecommender):
 
     @torch.no_grad()
     def predict(self, interaction):
+        self._whole_tables_only('predict')
         if self.phase == 'SOURCE':
             return self._pair_scores(self.source_user_embedding.weight, self.source_item_embedding.weight,
                                      interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID])
@@ -369,6 +376,7 @@ class EMCDR(CrossDomainRecommender):
 
     @torch.no_grad()
     def full_sort_predict(self, interaction):
+        self._whole_tables_only('full_sort_predict')
         user_e, slab0, slab1 = self._full_sort_operands(interaction)
         return F_.fullsort_scores(user_e, slab0 if slab0.shape[0] else None, slab1).view(-1)
 

@@ -195,6 +195,8 @@ class Trainer:
         """recbole ``Trainer._save_checkpoint``: config-free subset -- epoch, early-stopping state, model ``state_dict``,
         ``other_parameter`` and the optimizer state (dense: ``DenseAdam.state_dict()``; rowwise: the model's per-table
         moments and update counts)."""
+        if self.dist_group is not None:
+            raise NotImplementedError('checkpointing a sharded model: gather_full_tables() on the model, save from one rank')
         state = {'epoch': epoch, 'cur_step': self.cur_step, 'best_valid_score': self.best_valid_score,
                  'state_dict': self.model.state_dict(), 'other_parameter': self.model.other_parameter(),
                  'optimizer_mode': self.optimizer_mode, 'optimizer': self.optimizer.state_dict(),

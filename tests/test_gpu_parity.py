@@ -2096,6 +2096,8 @@ def _dist_trainer_worker(rank, world, port, lfm, q):
         model.set_phase('TARGET')
         score = trainer.evaluate(valid)['recall@5']
         full = {k: v.cpu().numpy() for k, v in model.gather_full_tables().items()}
+        with pytest.raises(RuntimeError, match='whole tables'):            # a shard is not a table: no silent use of one
+            model.full_sort_predict(next(iter(valid))[0])
         faulthandler.cancel_dump_traceback_later()
         q.put((rank, log, score, final, full, {k: v.detach().cpu().numpy() for k, v in model.mapping.named_parameters()},
                [tuple(model.source_user_embedding.weight.shape), model._dist.layout('target_user_embedding')]))
