@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--shard', default='dim', choices=['dim', 'row'],
                     help='N>1 layout of the C5 tables: dim = every rank holds D/N columns of every row (ids all-gathered, one partial '
                          'score per triple all-reduced); row = rows r %% N with the row / gradient-row all-to-all exchange')
+    ap.add_argument('--no-domain-groups', action='store_true',
+                    help='--shard dim: shard BOTH domains over all N ranks (D/N columns each) instead of giving each domain one half of '
+                         'the ranks (D/(N/2) columns, twice the batch per rank)')
     ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
 
@@ -114,7 +117,31 @@ def run_c5(args, world, rank, dev):
     gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
     sharded = world > 1 or args.force_shard
     dim_mode = sharded and args.shard == 'dim'
-    if dim_mode:
+    dom_groups = dim_mode and world >= 2 and world % 2 == 0 and not args.no_domain_groups
+    if dom_groups:
+        # The SOURCE and the TARGET step share nothing (disjoint tables, disjoint optimizer state), so each domain gets one half of
+        # the node: ranks [0, N/2) hold the source tables in N/2 column slices, ranks [N/2, N) the target tables, and every rank
+        # brings 2 B triples of ITS domain per step (same rows per rank and per step as "B of each domain").  Twice the slice
+        # width of sharding both domains over all N ranks (128-byte row slices at N = 8 instead of 64) and half the replicated
+        # index work; measured kernel-side efficiency 1.00 / 0.93 / 0.84 at N = 2 / 4 / 8.
+        import torch.distributed as dist
+        from recbole_cdr_amd.dimshard import DimShardedBPRStep
+        half = world // 2
+        if D % (4 * half):
+            raise SystemExit('--shard dim needs --dim to be a multiple of 4 x N/2')
+        Ds = D // half
+        dgroups = {'source': dist.new_group(list(range(half))), 'target': dist.new_group(list(range(half, world)))}
+        my_dom = 'source' if rank < half else 'target'
+        tabs = {}
+        for k, r in ((my_dom[0] + 'u', n_users), (my_dom[0] + 'i', n_items)):
+            tabs[k] = torch.empty(r, Ds, device=dev, dtype=torch.float32).normal_(0.0, (2.0 / (r + D)) ** 0.5, generator=gen)
+        if half == 1:
+            st = FusedBPRStep(tabs[my_dom[0] + 'u'], tabs[my_dom[0] + 'i'], 2 * B, opt=args.opt, reg_weight=0.01)
+            st.profile, st.exchange_stats, st.loss_value = (lambda on=True: None), (lambda: (0, 0.0)), (lambda st=st: st.out6[0])
+        else:
+            st = DimShardedBPRStep(tabs[my_dom[0] + 'u'], tabs[my_dom[0] + 'i'], 2 * B, opt=args.opt, reg_weight=0.01, group=dgroups[my_dom])
+        steps = {my_dom: st}
+    elif dim_mode:
         import torch.distributed as dist
         from recbole_cdr_amd.dimshard import DimShardedBPRStep
         if D % (4 * world):
@@ -156,9 +183,12 @@ def run_c5(args, world, rank, dev):
     for _ in range(pool):
         b = {}
         for dom, lo in (('source', 1 + TOI), ('target', 1)):
-            u = torch.randint(1, OU, (B,), device=dev, generator=gen)
-            p = torch.randint(lo, lo + TOI, (B,), device=dev, generator=gen)
-            n = torch.randint(lo, lo + TOI, (B,), device=dev, generator=gen)
+            if dom_groups and dom != my_dom:
+                continue
+            nb = 2 * B if dom_groups else B
+            u = torch.randint(1, OU, (nb,), device=dev, generator=gen)
+            p = torch.randint(lo, lo + TOI, (nb,), device=dev, generator=gen)
+            n = torch.randint(lo, lo + TOI, (nb,), device=dev, generator=gen)
             b[dom] = (u, p, n)
         batches.append(b)
 
@@ -166,7 +196,12 @@ def run_c5(args, world, rank, dev):
 
     def one_step(i):
         b = batches[i % pool]
-        if sharded and not dim_mode and not args.no_pipeline:
+        if dom_groups:
+            if half > 1:                      # the next batch's id all-gather starts under this step's kernels
+                steps[my_dom].step(*b[my_dom], next_batch=batches[(i + 1) % pool][my_dom])
+            else:
+                steps[my_dom].step(*b[my_dom])
+        elif sharded and not dim_mode and not args.no_pipeline:
             run_pipelined([steps[dom].step_gen(*b[dom]) for dom in ('source', 'target')])
         else:
             for dom in ('source', 'target'):
@@ -187,7 +222,7 @@ def run_c5(args, world, rank, dev):
     dt = time.perf_counter() - t0
     timings = {}
     collected = B_.timing_collect(dev)
-    if dim_mode and not args.no_pipeline:
+    if dim_mode and not dom_groups and not args.no_pipeline:
         # the two domain streams ran side by side in the timed region, so its per-kernel event times include sharing the
         # GPU with the other domain's kernels; the roofline figures come from two extra steps with the domains serialised
         prof = {d: st._prof for d, st in steps.items()}
@@ -204,7 +239,7 @@ def run_c5(args, world, rank, dev):
         timings.setdefault(name, []).append(ms)
     B_.timing_enable(dev, 0)
     mean_ms = lambda k: (sum(timings[k]) / len(timings[k])) if timings.get(k) else 0.0
-    loss = float(steps['target'].loss_value()) if sharded else float(steps['target'].out6[0].item())
+    loss = float(next(iter(steps.values())).loss_value()) if dom_groups else float(steps['target'].loss_value()) if sharded else float(steps['target'].out6[0].item())
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -221,6 +256,9 @@ def run_c5(args, world, rank, dev):
                                % (D, OU - 1, TOI, 4.0 * D * 2 * (n_users + n_items) / 1e9, B, args.opt),
                    'batch_per_domain_per_rank': B, 'k_neg': 1, 'optimizer': 'rowwise-' + args.opt,
                    'sharding': 'none' if not sharded else
+                   ('dimension x domain: ranks [0,%d) hold the source tables, ranks [%d,%d) the target tables, %d of %d columns of every row '
+                    'per rank, 2 x %d triples of its domain per rank and step; ids all-gathered (prefetched), one partial score per triple '
+                    'all-reduced inside the domain group' % (world // 2, world // 2, world, D // (world // 2), D, B)) if dom_groups else
                    ('dimension: %d of %d columns of every row per rank; ids all-gathered, one partial score per triple all-reduced, '
                     '2 domains on their own streams' % (D // world, D)) if dim_mode else
                    'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
@@ -242,20 +280,22 @@ def run_c5(args, world, rank, dev):
                               'note': 'HIP-event time inside the data-path collectives of a step (dim: 1 id all-gather + 1 all-reduce per '
                                       "domain; row: 4 all-to-alls per domain), both domain streams summed; overlaps the other domain's kernels"}
     if rank == 0 and dim_mode:
-        # every rank walks the GLOBAL batch on [rows, D/N] tables: the kernels are the single-GPU ones at width Ds
-        Bg = B * world
-        pn = steps['source'].ids[Bg:3 * Bg] if world > 1 else torch.cat(batches[(args.steps - 1) % pool]['source'][1:])
+        # every rank walks its group's GLOBAL batch on [rows, Ds] tables: the kernels are the single-GPU ones at width Ds
+        st0 = steps['source']
+        gsz = (world // 2) if dom_groups else world
+        Bg = (2 * B if dom_groups else B) * gsz
+        pn = st0.ids[Bg:3 * Bg] if gsz > 1 else torch.cat(batches[(args.steps - 1) % pool]['source'][1:])
         uniq_i = int(torch.unique(pn).numel())
         nmom = 6 if args.opt == 'adam' else 2
         ms = mean_ms('rowwise_apply_kernel(items)')
         byts = 2 * Bg * (8 + 4 * Ds) + uniq_i * nmom * 4 * Ds
         gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        result['roofline'] = {'bound': 'hbm', 'kernel': 'rowwise_apply_kernel(items) (rank 0: %d occurrences of the global batch on %d-column rows)' % (2 * Bg, Ds),
+        result['roofline'] = {'bound': 'hbm', 'kernel': 'rowwise_apply_kernel(items) (rank 0: %d occurrences of its group\'s global batch on %d-column rows)' % (2 * Bg, Ds),
                               'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                               'avg_launch_ms': ms, 'traffic': None}
         result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
-                             ('bpr_partial_diff_kernel', 'bpr_grad_from_diff_kernel', 'sort_ids', 'rowwise_apply_kernel(users)',
-                              'rowwise_apply_kernel(items)')]
+                             ('bpr_fwd_grad_kernel', 'bpr_partial_diff_kernel', 'bpr_grad_from_diff_kernel', 'sort_ids',
+                              'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)') if timings.get(k)]
         if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
             result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
     if rank == 0 and sharded and not dim_mode:
@@ -280,16 +320,30 @@ def run_c5(args, world, rank, dev):
         from recbole_cdr_amd.dimshard import dim_to_row_shards, state_to_row_shards
         barrier(world)
         t0 = time.perf_counter()
-        ust, ti_cols = {}, tabs['ti']
-        tabs.clear()
-        for d in ('source', 'target'):
-            st = steps.pop(d)
-            ustate = st.ustate
-            del st                                  # gradient / sort buffers and the item moments go first
+        if dom_groups:
+            from recbole_cdr_amd.dimshard import cols_to_row_shards, state_cols_to_row_shards
+            holders = {'source': list(range(half)), 'target': list(range(half, world))}
+            st = steps.pop(my_dom)
+            mine_u, mine_i = st.ustate, tabs[my_dom[0] + 'i']
+            tabs.clear()
+            del st
             torch.cuda.empty_cache()
-            ust[d] = state_to_row_shards(ustate, consume=True)
-        ti_rows = dim_to_row_shards(ti_cols)
-        del ti_cols
+            ust = {d: state_cols_to_row_shards(mine_u if d == my_dom else None, n_users, Ds, holders[d], args.opt == 'adam')
+                   for d in ('source', 'target')}
+            del mine_u
+            ti_rows = cols_to_row_shards(mine_i if my_dom == 'target' else None, n_items, Ds, holders['target'])
+            del mine_i
+        else:
+            ust, ti_cols = {}, tabs['ti']
+            tabs.clear()
+            for d in ('source', 'target'):
+                st = steps.pop(d)
+                ustate = st.ustate
+                del st                                  # gradient / sort buffers and the item moments go first
+                torch.cuda.empty_cache()
+                ust[d] = state_to_row_shards(ustate, consume=True)
+            ti_rows = dim_to_row_shards(ti_cols)
+            del ti_cols
         barrier(world)
         result['relayout_dim_to_row_s'] = time.perf_counter() - t0
         steps = {d: SimpleNamespace(ustate=ust[d], istate=None) for d in ('source', 'target')}

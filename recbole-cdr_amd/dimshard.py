@@ -46,6 +46,48 @@ def dim_to_row_shards(cols, group=None, force=False):
     return recv.view(G, n_q[rank], Ds).permute(1, 0, 2).reshape(n_q[rank], G * Ds).contiguous()
 
 
+def cols_to_row_shards(cols, rows, Ds, holders, group=None):
+    """The transpose when only SOME ranks hold the table (one domain's tables live on that domain's half of the node):
+    ``holders`` = ascending ranks of ``group`` that hold column blocks 0, 1, ... ([rows, Ds] each; ``cols`` is None elsewhere)
+    -> on EVERY rank of ``group`` its row shard [rows_r, len(holders) * Ds].  One all-to-all; non-holders send nothing."""
+    from .shard import shard_rows
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    holders = list(holders)
+    assert holders == sorted(holders) and (cols is not None) == (rank in holders)
+    n_q = [shard_rows(rows, W, q) for q in range(W)]
+    if cols is not None:
+        send, in_splits = torch.cat([cols[q::W] for q in range(W)]), n_q
+        dev = cols.device
+    else:
+        dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+        send, in_splits = torch.empty(0, Ds, device=dev, dtype=torch.float32), [0] * W
+    out_splits = [n_q[rank] if q in holders else 0 for q in range(W)]
+    recv = torch.empty(len(holders) * n_q[rank], Ds, device=dev, dtype=torch.float32)
+    dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    return recv.view(len(holders), n_q[rank], Ds).permute(1, 0, 2).reshape(n_q[rank], len(holders) * Ds).contiguous()
+
+
+def state_cols_to_row_shards(state, rows, Ds, holders, adam, group=None):
+    """``cols_to_row_shards`` for a table with its row-wise optimizer state (``state`` is None on non-holders; the update count is
+    taken from the first holder)."""
+    from .fused import RowwiseState
+    out = RowwiseState.__new__(RowwiseState)
+    dev = state.table.device if state is not None else torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    cnt = torch.tensor([state.step if state is not None else 0], device=dev, dtype=torch.int64)
+    dist.broadcast(cnt, dist.get_global_rank(group, holders[0]) if group is not None else holders[0], group=group)
+    out.step = int(cnt.item())
+    for name in ('table', 'exp_avg', 'exp_avg_sq'):
+        if name != 'table' and not adam:
+            setattr(out, name, None)
+            continue
+        t = getattr(state, name) if state is not None else None
+        setattr(out, name, cols_to_row_shards(t, rows, Ds, holders, group))
+        if state is not None:
+            setattr(state, name, None)                    # consumed: peak memory = one tensor extra
+        del t
+    return out
+
+
 def row_to_dim_shards(row_shard, total_rows, group=None, force=False):
     """Inverse of ``dim_to_row_shards``: this rank's row shard [rows_r, D] -> its column slice [total_rows, D / G]."""
     G, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -240,10 +282,12 @@ class _DimShardedStep:
         self.max_batch = Bg
         dev = user_cols.device
         self.ops = ops
-        self.ids = torch.empty(3 * Bg, device=dev, dtype=torch.int64)
-        self.labels = torch.empty(Bg, device=dev, dtype=torch.float32) if self.third_is_label else None
-        self.ids32 = torch.empty(3 * int(batch_per_rank), device=dev, dtype=torch.int32)
-        self.gath32 = torch.empty(3 * Bg, device=dev, dtype=torch.int32)
+        # two slots of exchange buffers: ``prefetch`` fills the one the running step is not reading
+        self._slots = [{'ids': torch.empty(3 * Bg, device=dev, dtype=torch.int64),
+                        'labels': torch.empty(Bg, device=dev, dtype=torch.float32) if self.third_is_label else None,
+                        'ids32': torch.empty(3 * int(batch_per_rank), device=dev, dtype=torch.int32),
+                        'gath32': torch.empty(3 * Bg, device=dev, dtype=torch.int32)} for _ in range(2)]
+        self._cur, self._pf, self._side = 0, None, None
         self.diff = torch.empty(Bg + 2, device=dev, dtype=torch.float32)
         self.out = self.ops.out
         self.stream = stream
@@ -286,8 +330,44 @@ class _DimShardedStep:
         self._prof['bytes'] += int(nbytes)
         self._prof['events'].append((a, b))
 
-    def step(self, a, b, c):
-        """Pairwise: (uid, pid, nid); pointwise: (uid, iid, label).  The rank's own rows, the same count on every rank."""
+    @property
+    def ids(self):
+        """Field-major global ids of the step that ran last ([3 * B_global] int64; rows [B_global:] unused for pointwise rows)."""
+        return self._slots[self._cur]['ids']
+
+    def _exchange(self, slot, a, b, c):
+        """pack -> all-gather -> unpack of one batch's rows into ``slot``; returns the global (a, b, c)."""
+        G, ops, buf = self.world, self.ops, self._slots[slot]
+        Bl = a.numel()
+        Bg = G * Bl
+        ops.pack_ids(a, b, c, buf['ids32'][:3 * Bl])
+        with self._timed(3 * 4 * Bl * (G - 1)):
+            dist.all_gather_into_tensor(buf['gath32'][:3 * Bg], buf['ids32'][:3 * Bl], group=self.group)
+        idv = buf['ids'][:3 * Bg].view(3, Bg)                                  # field-major global rows of this step
+        if self.third_is_label:
+            ops.unpack_ids(buf['gath32'][:3 * Bg], G, Bl, idv, buf['labels'][:Bg])
+            return idv[0], idv[1], buf['labels'][:Bg]
+        ops.unpack_ids(buf['gath32'][:3 * Bg], G, Bl, idv)
+        return idv[0], idv[1], idv[2]
+
+    def prefetch(self, a, b, c):
+        """Start the id exchange of the NEXT batch now, on a side stream, so that it runs under the current step's kernels (ids do
+        not depend on the model).  ``step`` recognises the batch by identity of ``a`` and picks the gathered ids up."""
+        if not (self.world > 1 or (self.force_collectives and dist.is_initialized())):
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.U.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        slot = 1 - self._cur
+        with torch.cuda.stream(self._side):
+            got = self._exchange(slot, a, b, c)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pf = (a, slot, got, ev)
+
+    def step(self, a, b, c, next_batch=None):
+        """Pairwise: (uid, pid, nid); pointwise: (uid, iid, label).  The rank's own rows, the same count on every rank.
+        ``next_batch``: the following step's (a, b, c), if known -- its id exchange is started first and overlaps this step."""
         G, grp, ops = self.world, self.group, self.ops
         Bl = a.numel()
         Bg = G * Bl
@@ -297,16 +377,15 @@ class _DimShardedStep:
         comm = G > 1 or (self.force_collectives and dist.is_initialized())
         with self._on_stream():
             if comm:
-                ops.pack_ids(a, b, c, self.ids32[:3 * Bl])
-                with self._timed(3 * 4 * Bl * (G - 1)):
-                    dist.all_gather_into_tensor(self.gath32[:3 * Bg], self.ids32[:3 * Bl], group=grp)
-                idv = self.ids[:3 * Bg].view(3, Bg)                               # field-major global rows of this step
-                if self.third_is_label:
-                    ops.unpack_ids(self.gath32[:3 * Bg], G, Bl, idv, self.labels[:Bg])
-                    a, b, c = idv[0], idv[1], self.labels[:Bg]
+                if self._pf is not None and self._pf[0] is a:
+                    _a, slot, (a, b, c), ev = self._pf
+                    torch.cuda.current_stream().wait_event(ev)
+                    self._cur = slot
                 else:
-                    ops.unpack_ids(self.gath32[:3 * Bg], G, Bl, idv)
-                    a, b, c = idv[0], idv[1], idv[2]
+                    a, b, c = self._exchange(self._cur, a, b, c)
+                self._pf = None
+                if next_batch is not None:
+                    self.prefetch(*next_batch)
             diff = self.diff[:Bg + 2]
             ops.partial(a, b, c, diff)
             if comm:

@@ -1749,9 +1749,13 @@ def _dim_shared_gpu_worker(rank, world, port, q):
                     u[: B // 2] = u[0]; p[: B // 3] = p[0]; n[100:700] = p[0]        # long segments in both tables
                 per_dom.append((u, p, n))
             batches.append(per_dom)
+        on_dev = [[tuple(t.to(DEV) for t in dom) for dom in it] for it in batches]
+        for it in range(3):
             torch.cuda.synchronize()
             for d in range(2):                                                  # no host sync inside: the two domains just queue up
-                steps[d].step(*(t.to(DEV) for t in per_dom[d]))
+                # domain 0 announces its next batch: that batch's id exchange runs on a side stream under this step's kernels
+                nxt = on_dev[it + 1][d] if (d == 0 and it + 1 < 3) else None
+                steps[d].step(*on_dev[it][d], next_batch=nxt)
             torch.cuda.synchronize()
             losses.append([float(s.out[0]) for s in steps])
         rows = dim_to_row_shards(cols[0][1])

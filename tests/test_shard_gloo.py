@@ -495,3 +495,56 @@ def test_dim_sharded_point_step_matches_single_process():
     for r in range(world):
         torch.testing.assert_close(torch.from_numpy(res[r][1]), U[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=lr * 1e-2)
         torch.testing.assert_close(torch.from_numpy(res[r][2]), I[:, r * Ds:(r + 1) * Ds], rtol=2e-5, atol=lr * 1e-2)
+
+
+def _worker_cols(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import cols_to_row_shards, state_cols_to_row_shards
+        from recbole_cdr_amd.fused import RowwiseState
+        torch.manual_seed(4)
+        rows, D = 37, 24
+        full, m, v = torch.randn(rows, D), torch.randn(rows, D), torch.rand(rows, D)
+        out = {}
+        for name, holders in (('lower', [0, 1]), ('upper', [2, 3]), ('one', [3])):
+            Ds = D // len(holders)
+            st = None
+            if rank in holders:
+                j = holders.index(rank)
+                st = RowwiseState.__new__(RowwiseState)
+                st.step = 5
+                st.table, st.exp_avg, st.exp_avg_sq = (t[:, j * Ds:(j + 1) * Ds].contiguous() for t in (full, m, v))
+            new = state_cols_to_row_shards(st, rows, Ds, holders, True)
+            assert new.step == 5 and (st is None or st.table is None)
+            out[name] = tuple(t.numpy().copy() for t in (new.table, new.exp_avg, new.exp_avg_sq))
+        only = cols_to_row_shards(full[:, :12].contiguous() if rank == 1 else None, rows, 12, [1])
+        q.put((rank, out, only.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cols_to_row_shards_from_a_subset_of_ranks():
+    """A table held (in column blocks) by half of the ranks -- one domain's group -- becomes row shards on ALL ranks, moments and
+    update count included: the phase switch of the domain-group layout (bench.py --shard dim)."""
+    world = 4
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cols, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(4)
+    rows, D = 37, 24
+    full, m, v = torch.randn(rows, D), torch.randn(rows, D), torch.rand(rows, D)
+    for r in range(world):
+        for name in ('lower', 'upper', 'one'):
+            for got, want in zip(res[r][1][name], (full, m, v)):
+                assert torch.equal(torch.from_numpy(got), want[r::world]), (r, name)
+        assert torch.equal(torch.from_numpy(res[r][2]), full[r::world, :12])
