@@ -277,8 +277,9 @@ def run_c5(args, world, rank, dev):
             import torch.distributed as dist
             dist.all_reduce(xt, op=dist.ReduceOp.MAX)
         result['exchange'] = {'bytes_to_other_ranks_per_step_per_rank': float(xt[0]), 'collective_ms_per_step_max_rank': float(xt[1]),
-                              'note': 'HIP-event time inside the data-path collectives of a step (dim: 1 id all-gather + 1 all-reduce per '
-                                      "domain; row: 4 all-to-alls per domain), both domain streams summed; overlaps the other domain's kernels"}
+                              'note': 'bytes: everything the data path sends; ms: HIP-event time of the collectives that are bracketed (dim: the id '
+                                      'all-gather, which runs prefetched on a side stream -- the score all-reduce is asynchronous under the id sort and '
+                                      'not bracketed; row: the 4 all-to-alls per domain, both domain streams summed)'}
     if rank == 0 and dim_mode:
         # every rank walks its group's GLOBAL batch on [rows, Ds] tables: the kernels are the single-GPU ones at width Ds
         st0 = steps['source']

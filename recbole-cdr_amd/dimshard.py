@@ -6,8 +6,8 @@ the step is
 
     all-gather  the triples' ids, narrowed to int32       12 B per triple (cdr_ids_pack32 / cdr_ids_unpack32)
     cdr_bpr_partial_diff   <u,p> - <u,n> over my columns   (csrc/cdr_dimshard.hip)
-    all-reduce  one float per triple + the two EmbLoss norms
-    cdr_bpr_grad_from_diff + cdr_sort_ids_two_tables + 2 x cdr_rowwise_apply     (the single-GPU fused step on [rows, Ds])
+    all-reduce  one float per triple + the two EmbLoss norms        || cdr_sort_ids_two_tables (needs only the ids)
+    cdr_bpr_grad_from_diff + 2 x cdr_rowwise_apply                  (the single-GPU fused step on [rows, Ds])
 
 -- 16 B per triple on xGMI against the ~2.1 KB of the row exchange (emcdr.py:98-108,119-131 need only the dot products to
 cross the column cut; every gradient element stays with the rank that holds its column).  No bucket counts, no host
@@ -242,7 +242,11 @@ class NativeDimOps:
         B_.call('cdr_bpr_grad_from_diff', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
                 B_.i64(pid), B_.i64(nid), uid.numel(), float(fs.gamma), float(fs.reg_weight), B_.f32(diff), B_.f32(fs.out6),
                 B_.f32(fs.GU), B_.f32(fs.GP))
-        return fs.sort_apply(uid, pid, nid)
+        return fs.apply_sorted(uid.numel())
+
+    def presort(self, uid, pid, nid):
+        """The id sort of the step; needs only the ids, so the step issues it while the partial scores are being all-reduced."""
+        self.fs.sort_ids(uid, pid, nid)
 
 
 class NativePointDimOps(NativeDimOps):
@@ -264,7 +268,10 @@ class NativePointDimOps(NativeDimOps):
         B_, fs = self.B_, self.fs
         B_.call('cdr_point_grad_from_dot', B_.ctx(fs.U.device), B_.stream(), fs.kind, B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
                 B_.i64(iid), B_.f32(label), uid.numel(), float(fs.reg_weight), B_.f32(dot), B_.f32(fs.out6), B_.f32(fs.GU), B_.f32(fs.GI))
-        return fs.sort_apply(uid, iid)
+        return fs.apply_sorted(uid.numel())
+
+    def presort(self, uid, iid, label):
+        self.fs.sort_ids(uid, iid)
 
 
 class _DimShardedStep:
@@ -388,9 +395,14 @@ class _DimShardedStep:
                     self.prefetch(*next_batch)
             diff = self.diff[:Bg + 2]
             ops.partial(a, b, c, diff)
+            work = None
             if comm:
-                with self._timed(2 * 4 * (Bg + 2) * (G - 1) // G):            # ring all-reduce: reduce-scatter + all-gather
-                    dist.all_reduce(diff, group=grp)
+                if self._prof:
+                    self._prof['bytes'] += 2 * 4 * (Bg + 2) * (G - 1) // G          # ring all-reduce: reduce-scatter + all-gather
+                work = dist.all_reduce(diff, group=grp, async_op=True)
+            ops.presort(a, b, c)                      # the id sort needs no scores: it runs while the links carry them
+            if work is not None:
+                work.wait()                           # stream-level wait: the host does not block
             return ops.grad_apply(a, b, c, diff)
 
 

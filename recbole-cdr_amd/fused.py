@@ -69,13 +69,20 @@ class FusedBPRStep:
         return self.sort_apply(uid, pid, nid)
 
     def sort_apply(self, uid, pid, nid):
-        """Second half of the step: GU / GP / out6[4:6] are in place (written by the forward kernel -- or, for dimension-sharded
-        tables, by cdr_bpr_grad_from_diff after the all-reduce: dimshard.py); one sort for both tables, two row-wise applies."""
+        """Second half of the step: GU / GP / out6[4:6] are in place (written by the forward kernel); one sort for both tables,
+        two row-wise applies."""
+        self.sort_ids(uid, pid, nid)
+        return self.apply_sorted(uid.numel())
+
+    def sort_ids(self, uid, pid, nid):
+        """The id sort alone -- it needs nothing but the ids, so dimshard.py runs it under the all-reduce of the partial scores."""
         B = uid.numel()
-        s = B_.stream()
+        B_.call('cdr_sort_ids_two_tables', B_.ctx(self.U.device), B_.stream(), B_.i64(uid), B, self.U.shape[0], B_.i64(pid), B,
+                B_.i64(nid), B, self.I.shape[0], B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws),
+                self.ws_bytes)
+
+    def apply_sorted(self, B):
         ctxh = B_.ctx(self.U.device)
-        B_.call('cdr_sort_ids_two_tables', ctxh, s, B_.i64(uid), B, self.U.shape[0], B_.i64(pid), B, B_.i64(nid), B,
-                self.I.shape[0], B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws_bytes)
         self._apply(ctxh, self.ustate, self.keys[:B], self.perm[:B], B, self.GU, B, B, self.out6[4:5], 0)
         self._apply(ctxh, self.istate, self.keys[B:3 * B], self.perm[B:3 * B], 2 * B, self.GP, B, B, self.out6[5:6],
                     self._key_base.value)
@@ -130,12 +137,18 @@ class FusedPointStep:
         return self.sort_apply(uid, iid)
 
     def sort_apply(self, uid, iid):
-        """Second half of the step (GU / GI / out6[4:6] in place -- also what dimshard.DimShardedPointStep runs after its all-reduce)."""
+        """Second half of the step (GU / GI / out6[4:6] in place): one sort for both tables, two row-wise applies."""
+        self.sort_ids(uid, iid)
+        return self.apply_sorted(uid.numel())
+
+    def sort_ids(self, uid, iid):
         B = uid.numel()
+        B_.call('cdr_sort_ids_two_tables', B_.ctx(self.U.device), B_.stream(), B_.i64(uid), B, self.U.shape[0], B_.i64(iid), B, None, 0,
+                self.I.shape[0], B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws.numel())
+
+    def apply_sorted(self, B):
         s = B_.stream()
         ctxh = B_.ctx(self.U.device)
-        B_.call('cdr_sort_ids_two_tables', ctxh, s, B_.i64(uid), B, self.U.shape[0], B_.i64(iid), B, None, 0, self.I.shape[0],
-                B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws.numel())
         for st, lo, G, coef, base in ((self.ustate, 0, self.GU, self.out6[4:5], 0),
                                       (self.istate, B, self.GI, self.out6[5:6], self._key_base.value)):
             st.step += 1
