@@ -14,7 +14,12 @@ cross the column cut; every gradient element stays with the rank that holds its 
 sync: all sizes are static.  The price is that every rank walks the GLOBAL batch on rows 1/world as wide, so the ids are
 sorted ``world`` times over and gathers shrink to ``4*Ds`` bytes.
 
-The batch size must be the same on every rank (a sharded loader pads or drops the ragged tail)."""
+The batch size must be the same on every rank (a sharded loader pads or drops the ragged tail).
+
+Contents: the layout transposes (``dim_shard_of``, ``dim_to_row_shards`` / ``row_to_dim_shards`` between all ranks,
+``cols_to_row_shards`` when one domain's tables live on half of the ranks -- bench.py's domain groups), their RowwiseState forms,
+``ShardedTables`` (a model's tables in whichever layout the phase wants), and the steps ``DimShardedBPRStep`` /
+``DimShardedPointStep`` with ``step(..., next_batch=)`` prefetching the next id exchange."""
 import contextlib
 
 import torch

@@ -2144,3 +2144,46 @@ def test_distributed_trainer_fit_matches_single_process(lfm):
             assert_close(torch.from_numpy(res[r][5][k]).to(DEV), v.detach(), rtol=1e-4, atol=0.01 * 5e-2, what=k)
         # the source user table stayed a row shard after OVERLAP (nothing trained it since); the target one went back to columns
         assert res[r][6] == [(len(range(r, model.total_num_users, world)), 16), 'dim']
+
+
+def test_dim_layout_full_size_properties():
+    """The dimension layout at the shape one rank sees at N = 8 (domain groups: 32 of 128 columns of the 50,000,001-user and
+    20,000,001-item tables, its group's global batch of 8 x 1,048,576 triples), through properties that need no oracle run:
+      * the partial scores are additive over a column cut: diff(32 columns) = diff(first 16) + diff(last 16), norms included --
+        which is exactly what the all-reduce relies on;
+      * partial_diff -> grad_from_diff -> sort -> applies moves the tables as the fused single-GPU step does on the same slice
+        (same loss to 1e-6, same rows to fp32 rounding), i.e. cutting the step around the all-reduce changes nothing."""
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.dimshard import DimShardedBPRStep
+    from recbole_cdr_amd.fused import FusedBPRStep
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 90e9:
+        pytest.skip('needs ~80 GB of free HBM')
+    nu, ni, Ds, Bg, TOI = 50_000_001, 20_000_001, 32, 8 << 20, 10_000_000
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    U = torch.empty(nu, Ds, device=DEV).normal_(0, 0.1, generator=g)
+    I = torch.empty(ni, Ds, device=DEV).normal_(0, 0.1, generator=g)
+    u = torch.randint(1, nu, (Bg,), device=DEV, generator=g)
+    p = torch.randint(1, 1 + TOI, (Bg,), device=DEV, generator=g)
+    n = torch.randint(1, 1 + TOI, (Bg,), device=DEV, generator=g)
+    ctx, s = B_.ctx(U.device), B_.stream()
+    diffs = []
+    for lo, hi in ((0, 32), (0, 16), (16, 32)):
+        Uc, Ic = (U if hi - lo == 32 else U[:, lo:hi].contiguous()), (I if hi - lo == 32 else I[:, lo:hi].contiguous())
+        d = torch.empty(Bg + 2, device=DEV)
+        B_.call('cdr_bpr_partial_diff', ctx, s, B_.f32(Uc), B_.f32(Ic), hi - lo, B_.i64(u), B_.i64(p), B_.i64(n), Bg, B_.f32(d))
+        diffs.append(d)
+        del Uc, Ic
+    assert_close(diffs[1][:Bg] + diffs[2][:Bg], diffs[0][:Bg], rtol=1e-5, atol=1e-6, what='diff over a column cut')
+    assert_close(diffs[1][Bg:] + diffs[2][Bg:], diffs[0][Bg:], rtol=1e-5, what='EmbLoss norms over a column cut')
+    del diffs
+    U2, I2 = U.clone(), I.clone()
+    a = DimShardedBPRStep(U, I, Bg, opt='adam', lr=1e-3, reg_weight=0.01)            # no process group: the one-rank form of the step
+    b = FusedBPRStep(U2, I2, Bg, opt='adam', lr=1e-3, reg_weight=0.01)
+    la, lb = a.step(u, p, n).clone(), b.step(u, p, n).clone()
+    assert_close(la[:6], lb[:6], rtol=1e-6, atol=0, what='loss, norms, coefficients')
+    rows_u, rows_i = u[:4096], torch.cat([p[:2048], n[:2048]])
+    assert_close(U[rows_u], U2[rows_u], rtol=1e-5, atol=1e-6, what='user rows')
+    assert_close(I[rows_i], I2[rows_i], rtol=1e-5, atol=1e-6, what='item rows')
+    fp = lambda t: t.view(-1)[::4099].double().sum()
+    assert abs(float(fp(U) - fp(U2))) <= 1e-6 * abs(float(fp(U2))) + 1e-3 and abs(float(fp(I) - fp(I2))) <= 1e-6 * abs(float(fp(I2))) + 1e-3
