@@ -299,7 +299,7 @@ class _DimShardedStep:
                         'labels': torch.empty(Bg, device=dev, dtype=torch.float32) if self.third_is_label else None,
                         'ids32': torch.empty(3 * int(batch_per_rank), device=dev, dtype=torch.int32),
                         'gath32': torch.empty(3 * Bg, device=dev, dtype=torch.int32)} for _ in range(2)]
-        self._cur, self._pf, self._side = 0, None, None
+        self._cur, self._pf, self._side, self._checked_size = 0, None, None, -1
         self.diff = torch.empty(Bg + 2, device=dev, dtype=torch.float32)
         self.out = self.ops.out
         self.stream = stream
@@ -387,6 +387,15 @@ class _DimShardedStep:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())           # the ids were produced on the caller's stream
         comm = G > 1 or (self.force_collectives and dist.is_initialized())
+        if comm and Bl != self._checked_size:
+            # a rank with a different row count would make the fixed-size all-gather undefined: compare once per batch size
+            sizes = torch.tensor([Bl], device=a.device, dtype=torch.int64)
+            allsz = [torch.empty_like(sizes) for _ in range(G)]
+            dist.all_gather(allsz, sizes, group=grp)
+            got = [int(t.item()) for t in allsz]
+            if any(x != Bl for x in got):
+                raise ValueError(f'dimension-sharded step needs the same number of rows on every rank, got {got}')
+            self._checked_size = Bl
         with self._on_stream():
             if comm:
                 if self._pf is not None and self._pf[0] is a:

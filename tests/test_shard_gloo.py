@@ -551,3 +551,36 @@ def test_cols_to_row_shards_from_a_subset_of_ranks():
             for got, want in zip(res[r][1][name], (full, m, v)):
                 assert torch.equal(torch.from_numpy(got), want[r::world]), (r, name)
         assert torch.equal(torch.from_numpy(res[r][2]), full[r::world, :12])
+
+
+def _worker_ragged(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.dimshard import DimShardedBPRStep
+        U, I = torch.randn(30, 8), torch.randn(20, 8)
+        hp = {'lr': 0.1, 'b1': 0.9, 'b2': 0.999, 'eps': 1e-8, 'wd': 0.0}
+        st = DimShardedBPRStep(U, I, 32, ops=OracleDimOps(U, I, 0, hp, 1e-10, 0.0))
+        B = 23 + rank                                                        # one row more on rank 1
+        try:
+            st.step(torch.randint(0, 30, (B,)), torch.randint(0, 20, (B,)), torch.randint(0, 20, (B,)))
+            q.put((rank, 'no error'))
+        except ValueError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dim_sharded_step_rejects_ragged_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all('same number of rows on every rank, got [23, 24]' in r[1] for r in res), res
