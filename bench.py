@@ -725,6 +725,13 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # the contract is ONE JSON line on stdout; RCCL and gloo print banners through C stdio (some only when the process exits),
+    # so with a process group everything else written to fd 1 is sent to stderr and the line goes to the saved descriptor
+    real_stdout = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.force_shard:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
     world, rank, local = dist_setup(args)
     dev = torch.device('cuda', local)
     import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
@@ -735,7 +742,10 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == 'c5':
             result['cpu_baseline'] = cpu_baseline(args)
-        print(json.dumps(result), flush=True)
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(result) + '\n').encode())
+        else:
+            print(json.dumps(result), flush=True)
     if world > 1 or args.force_shard:
         import torch.distributed as dist
         dist.destroy_process_group()
