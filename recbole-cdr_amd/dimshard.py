@@ -93,6 +93,47 @@ def state_cols_to_row_shards(state, rows, Ds, holders, adam, group=None):
     return out
 
 
+def row_shards_to_cols(row_shard, rows, D, holders, group=None):
+    """Inverse of ``cols_to_row_shards``: every rank's row shard [rows_r, D] -> column block j [rows, D / len(holders)] on
+    ``holders[j]``, None on the other ranks (they send, and receive nothing)."""
+    from .shard import shard_rows
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    holders = list(holders)
+    h = len(holders)
+    Ds = D // h
+    n_q = [shard_rows(rows, W, q) for q in range(W)]
+    blocks = row_shard.view(n_q[rank], h, Ds).permute(1, 0, 2).contiguous()                 # [h, rows_r, Ds], ascending holder rank
+    in_splits = [n_q[rank] if q in holders else 0 for q in range(W)]
+    mine = rank in holders
+    out_splits = n_q if mine else [0] * W
+    recv = torch.empty(rows if mine else 0, Ds, device=row_shard.device, dtype=row_shard.dtype)
+    dist.all_to_all_single(recv, blocks.view(h * n_q[rank], Ds), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    if not mine:
+        return None
+    out = torch.empty(rows, Ds, device=row_shard.device, dtype=row_shard.dtype)
+    o = 0
+    for q in range(W):
+        out[q::W] = recv[o:o + n_q[q]]
+        o += n_q[q]
+    return out
+
+
+def state_row_shards_to_cols(state, rows, D, holders, group=None):
+    """``row_shards_to_cols`` for a table with its moments: a RowwiseState on the holders, None elsewhere."""
+    from .fused import RowwiseState
+    parts = {}
+    for name in ('table', 'exp_avg', 'exp_avg_sq'):
+        t = getattr(state, name)
+        parts[name] = row_shards_to_cols(t, rows, D, holders, group) if t is not None else None
+        setattr(state, name, None)
+    if dist.get_rank(group) not in list(holders):
+        return None
+    out = RowwiseState.__new__(RowwiseState)
+    out.step = state.step
+    out.table, out.exp_avg, out.exp_avg_sq = parts['table'], parts['exp_avg'], parts['exp_avg_sq']
+    return out
+
+
 def row_to_dim_shards(row_shard, total_rows, group=None, force=False):
     """Inverse of ``dim_to_row_shards``: this rank's row shard [rows_r, D] -> its column slice [total_rows, D / G]."""
     G, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -142,10 +183,12 @@ def state_to_dim_shards(state, total_rows, group=None):
 
 class ShardedTables:
     """The embedding tables of one model over the ranks of ``group``, each with its row-wise optimizer state, in whichever of
-    the two layouts the current phase wants: 'dim' (column slice of every row: BPR / MF steps) or 'row' (rows r % G == rank:
-    the OVERLAP step, full-sort evaluation).  ``state(name, layout)`` transposes table and moments when the layout changes
-    (update count kept); ``rows(name)`` is a row-shard view for evaluation that leaves a 'dim' state where it is (the table
-    alone is transposed into a temporary that ``touched(name)`` -- called by every training step -- invalidates)."""
+    the two layouts the current phase wants: 'dim' (column blocks of every row on the table's ``holders`` -- all ranks, or one
+    half of them when each domain trains on its own half: BPR / MF steps) or 'row' (rows r % G == rank on ALL ranks: the OVERLAP
+    step, full-sort evaluation).  ``state(name, layout)`` transposes table and moments when the layout changes (update count
+    kept; None on a rank that holds nothing of the table); ``rows(name)`` is a row-shard view for evaluation that leaves a
+    'dim' state where it is (the table alone is transposed into a temporary that ``touched(name)`` -- called by every training
+    step -- invalidates)."""
 
     def __init__(self, group, opt_code):
         self.group = group
@@ -154,13 +197,21 @@ class ShardedTables:
         self.opt = opt_code
         self.entries = {}
 
-    def adopt(self, name, full_table, layout='dim'):
-        """``full_table``: the replicated [rows, D] tensor (identical on every rank) -> this rank's shard + a fresh state."""
+    def adopt(self, name, full_table, layout='dim', holders=None, hgroup=None):
+        """``full_table``: the replicated [rows, D] tensor (identical on every rank) -> this rank's shard (None if it holds
+        nothing) + a fresh state.  ``holders`` / ``hgroup``: the ranks of ``group`` (ascending) that hold the 'dim' layout's
+        column blocks and their process group; default all ranks."""
         from .fused import RowwiseState
         from .shard import shard_of
-        shard = dim_shard_of(full_table, self.world, self.rank) if layout == 'dim' else shard_of(full_table, self.world, self.rank).contiguous()
-        self.entries[name] = {'layout': layout, 'state': RowwiseState(shard, self.opt), 'rows': full_table.shape[0],
-                              'D': full_table.shape[1], 'version': 0, 'eval_rows': None}
+        holders = list(range(self.world)) if holders is None else list(holders)
+        if layout == 'dim':
+            shard = dim_shard_of(full_table, len(holders), holders.index(self.rank)) if self.rank in holders else None
+        else:
+            shard = shard_of(full_table, self.world, self.rank).contiguous()
+        self.entries[name] = {'layout': layout, 'state': RowwiseState(shard, self.opt) if shard is not None else None,
+                              'rows': full_table.shape[0], 'D': full_table.shape[1], 'version': 0, 'eval_rows': None,
+                              'holders': holders, 'hgroup': hgroup if hgroup is not None else self.group,
+                              'device': full_table.device}
         return shard
 
     def layout(self, name):
@@ -169,11 +220,17 @@ class ShardedTables:
     def version(self, name):
         return self.entries[name]['version']
 
+    def holder_group(self, name):
+        return self.entries[name]['hgroup']
+
     def state(self, name, layout):
         e = self.entries[name]
         if e['layout'] != layout:
-            e['state'] = (state_to_row_shards(e['state'], self.group, consume=True) if layout == 'row'
-                          else state_to_dim_shards(e['state'], e['rows'], self.group))
+            h = len(e['holders'])
+            if layout == 'row':
+                e['state'] = state_cols_to_row_shards(e['state'], e['rows'], e['D'] // h, e['holders'], self.opt == OPT_ADAM, self.group)
+            else:
+                e['state'] = state_row_shards_to_cols(e['state'], e['rows'], e['D'], e['holders'], self.group)
             e['layout'], e['eval_rows'] = layout, None
             e['version'] += 1
         return e['state']
@@ -186,24 +243,30 @@ class ShardedTables:
         if e['layout'] == 'row':
             return e['state'].table
         if e['eval_rows'] is None:
-            e['eval_rows'] = dim_to_row_shards(e['state'].table, self.group)
+            t = e['state'].table if e['state'] is not None else None
+            e['eval_rows'] = cols_to_row_shards(t, e['rows'], e['D'] // len(e['holders']), e['holders'], self.group)
         return e['eval_rows']
 
     def full(self, name):
-        """The replicated [rows, D] table again (checkpointing / hand-over to a single-process run): all-gather of the shards."""
-        e = self.entries[name]
-        t = e['state'].table
-        if e['layout'] == 'dim':
-            parts = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(parts, t.contiguous(), group=self.group)
-            return torch.cat(parts, dim=1)
+        """The replicated [rows, D] table again (checkpointing / hand-over to a single-process run)."""
         from .shard import shard_rows
+        e = self.entries[name]
+        t = e['state'].table if e['state'] is not None else None
+        src = lambda q: dist.get_global_rank(self.group, q) if self.group is not None else q
+        if e['layout'] == 'dim':
+            Ds = e['D'] // len(e['holders'])
+            parts = []
+            for q in e['holders']:
+                part = t.clone() if q == self.rank else torch.empty(e['rows'], Ds, device=e['device'], dtype=torch.float32)
+                dist.broadcast(part, src(q), group=self.group)
+                parts.append(part)
+            return torch.cat(parts, dim=1)
         out = torch.empty(e['rows'], e['D'], device=t.device, dtype=t.dtype)
         for q in range(self.world):
             part = torch.empty(shard_rows(e['rows'], self.world, q), e['D'], device=t.device, dtype=t.dtype)
             if q == self.rank:
                 part.copy_(t)
-            dist.broadcast(part, dist.get_global_rank(self.group, q) if self.group is not None else q, group=self.group)
+            dist.broadcast(part, src(q), group=self.group)
             out[q::self.world] = part
         return out
 

@@ -58,6 +58,7 @@ class EMCDR(CrossDomainRecommender):
         self.apply(xavier_normal_initialization)
         # optional: the tables sharded over the GPUs of a node (optimizer_mode='rowwise' only; see _dist_train_step)
         self.__dict__['_dist_cfg'] = config['dist_group'] if 'dist_group' in config else None
+        self.__dict__['_dist_parallel'] = bool(config['parallel_domains']) if 'parallel_domains' in config else False
 
     @staticmethod
     def mlp_layers(layer_dims):
@@ -201,16 +202,41 @@ class EMCDR(CrossDomainRecommender):
             src = dist.get_global_rank(grp, 0)
             for p in self.parameters():
                 dist.broadcast(p.data, src, group=grp)
+            # parallel_domains: the SOURCE and the TARGET phase touch disjoint tables, so each domain's tables live (in the
+            # dimension layout) on one half of the ranks and the trainer runs the two phases at the same time
+            halves = None
+            if self.__dict__.get('_dist_parallel') and T.world >= 2 and T.world % 2 == 0:
+                half = T.world // 2
+                to_global = lambda rs: [dist.get_global_rank(grp, r) for r in rs]
+                halves = {'source': (list(range(half)), dist.new_group(to_global(range(half)))),
+                          'target': (list(range(half, T.world)), dist.new_group(to_global(range(half, T.world))))}
             for name in self._TABLES:
                 emb = getattr(self, name)
-                emb.weight.data = T.adopt(name, emb.weight.data, 'dim')
+                holders, hgroup = halves[name.split('_')[0]] if halves else (None, None)
+                shard = T.adopt(name, emb.weight.data, 'dim', holders=holders, hgroup=hgroup)
+                emb.weight.data = shard if shard is not None else emb.weight.data.new_empty(0, emb.weight.shape[1])
             self.__dict__['_dist'] = T
         return T
 
     def _dist_state(self, T, name, layout):
         st = T.state(name, layout)
+        if st is None:
+            raise RuntimeError(f'this rank holds no part of {name} in the {layout!r} layout: with parallel_domains the SOURCE and '
+                               'TARGET phases run on their own halves of the ranks (CrossDomainTrainer schedules them so)')
         getattr(self, name).weight.data = st.table             # the module's parameter IS the shard the kernels update
         return st
+
+    def dist_prepare(self, domains):
+        """Collective over the whole group: bring the tables of ``domains`` ('source' / 'target') into the dimension layout before
+        a phase that only part of the ranks will train (the transposes involve every rank, also those that end up holding
+        nothing of a table)."""
+        from ...fused import OPT_ADAM
+        T = self._dist_tables(OPT_ADAM)
+        for name in self._TABLES:
+            if name.split('_')[0] in domains:
+                st = T.state(name, 'dim')
+                emb = getattr(self, name)
+                emb.weight.data = st.table if st is not None else emb.weight.data.new_empty(0, emb.weight.shape[1])
 
     def _dist_train_step(self, interaction, code, hp):
         """SOURCE / TARGET: dimshard.DimShardedBPRStep / DimShardedPointStep on this rank's column slices, fed with this rank's
@@ -246,13 +272,13 @@ class EMCDR(CrossDomainRecommender):
         mf = self.latent_factor_model == 'MF'
         key = ('mf' if mf else 'bpr', domain, T.version(names[0]), T.version(names[1]))
         step = cache['steps'].get(key)
-        if step is None or step.max_batch < user.numel() * T.world:
+        if step is None or step.max_batch < user.numel() * step.world:
             if mf:
-                step = DimShardedPointStep(ust.table, ist.table, user.numel(), loss='mse', reg_weight=self.reg_weight, group=T.group,
-                                           user_state=ust, item_state=ist, **hp)
+                step = DimShardedPointStep(ust.table, ist.table, user.numel(), loss='mse', reg_weight=self.reg_weight,
+                                           group=T.holder_group(names[0]), user_state=ust, item_state=ist, **hp)
             else:
                 step = DimShardedBPRStep(ust.table, ist.table, user.numel(), gamma=self.bpr_gamma, reg_weight=self.reg_weight,
-                                         group=T.group, user_state=ust, item_state=ist, **hp)
+                                         group=T.holder_group(names[0]), user_state=ust, item_state=ist, **hp)
             cache['steps'][key] = step
         for n in names:
             T.touched(n)

@@ -123,7 +123,10 @@ class Trainer:
     def _my_rows(self, interaction):
         import torch.distributed as dist
         from ..data.interaction import Interaction
-        world, rank = dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
+        if self.__dict__.get('_row_group') is not None:        # a domain's half of the ranks (parallel_domains): rows grank::half
+            rank, world = self._row_group
+        else:
+            world, rank = dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
         return Interaction({k: v[:v.shape[0] - v.shape[0] % world][rank::world].contiguous() for k, v in interaction.items()})
 
     def _topk_hits(self, interaction, n_user, history_index, positive_u, positive_i, kmax):
@@ -260,8 +263,47 @@ class CrossDomainTrainer(Trainer):
         self.epochs = int(self.train_epochs[phase])
         self.eval_step = min(self.config['eval_step'] if 'eval_step' in self.config else 1, self.epochs)
 
+    def _fit_domains_in_parallel(self, train_data, phase, both, verbose, saved, show_progress, callback_fn):
+        """config['parallel_domains'] with a dist_group: a SOURCE phase followed by a TARGET phase (or the reverse) touches
+        disjoint tables and disjoint optimizer state, so the lower half of the ranks runs the SOURCE epochs while the upper half
+        runs the TARGET epochs -- each domain's tables cut into world/2 column slices instead of world (twice the slice width,
+        half the replicated index work: DESIGN.md 6.1).  Same result as running the two phases one after the other; no
+        evaluation inside (it needs every rank); the halves meet again at a barrier.  ``both`` False: a SOURCE or TARGET phase
+        on its own -- only that domain's half trains, the other half waits."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
+        half = world // 2
+        mine = 'SOURCE' if rank < half else 'TARGET'
+        schemes = [self.train_modes[phase]] + ([self.train_modes[phase + 1]] if both else [])
+        if hasattr(self.model, 'dist_prepare'):
+            self.model.dist_prepare([s_.lower() for s_ in schemes])          # collective: every rank, also the idle half
+        if mine in schemes:
+            self._reinit(phase + schemes.index(mine))
+            train_data.set_mode(train_mode2state[mine])
+            self.model.set_phase(mine)
+            self._row_group = (rank % half, half)
+            try:
+                Trainer.fit(self, train_data, None, verbose, saved, show_progress, callback_fn)
+            finally:
+                self._row_group = None
+        dist.barrier(group=self.dist_group)
+
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        parallel = False
+        if self.dist_group is not None and 'parallel_domains' in self.config and self.config['parallel_domains']:
+            import torch.distributed as dist
+            parallel = dist.get_world_size(self.dist_group) % 2 == 0
+        skip = False
         for phase in range(len(self.train_modes)):
+            if skip:                                 # ran together with the previous phase
+                skip = False
+                continue
+            nxt = self.train_modes[phase + 1] if phase + 1 < len(self.train_modes) else None
+            if parallel and self.train_modes[phase] in ('SOURCE', 'TARGET'):
+                both = {self.train_modes[phase], nxt} == {'SOURCE', 'TARGET'}
+                self._fit_domains_in_parallel(train_data, phase, both, verbose, saved, show_progress, callback_fn)
+                skip = both
+                continue
             self._reinit(phase)
             scheme = self.train_modes[phase]
             train_data.set_mode(train_mode2state[scheme])

@@ -2045,7 +2045,7 @@ def test_whole_schedule_dim_then_row_layout_matches_single_gpu():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CrossDomainTrainer over several ranks: config['dist_group'] + optimizer_mode='rowwise'
-def _dist_trainer_setup(dev, lfm, dist_group=None):
+def _dist_trainer_setup(dev, lfm, dist_group=None, parallel=False):
     from oracle.common import IdSpace
     from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
     from recbole_cdr_amd.trainer import CrossDomainTrainer
@@ -2054,7 +2054,7 @@ def _dist_trainer_setup(dev, lfm, dist_group=None):
     torch.manual_seed(12)
     ids = IdSpace(OU=21, TOU=15, SOU=18, OI=1, TOI=30, SOI=34)
     D, lr, reg = 16, 0.01, 0.01
-    extra = {'dist_group': dist_group} if dist_group is not None else {}
+    extra = {'dist_group': dist_group, 'parallel_domains': parallel} if dist_group is not None else {}
     cfg = base_config(dev, latent_factor_model=lfm, source_embedding_size=D, target_embedding_size=D, reg_weight=reg,
                       mapping_function='non_linear', mlp_hidden_size=[24], learning_rate=lr, optimizer_mode='rowwise',
                       train_modes=['SOURCE', 'TARGET', 'OVERLAP', 'TARGET'], epoch_num=['2', '1', '2', '1'], source_split=False,
@@ -2080,7 +2080,7 @@ def _dist_trainer_setup(dev, lfm, dist_group=None):
     return CrossDomainTrainer(cfg, model), model, train, valid
 
 
-def _dist_trainer_worker(rank, world, port, lfm, q):
+def _dist_trainer_worker(rank, world, port, lfm, q, parallel=False):
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -2091,7 +2091,7 @@ def _dist_trainer_worker(rank, world, port, lfm, q):
     try:
         import recbole_cdr_amd  # noqa: F401
         torch.cuda.set_device(0)
-        trainer, model, train, valid = _dist_trainer_setup(DEV, lfm, dist_group=True)
+        trainer, model, train, valid = _dist_trainer_setup(DEV, lfm, dist_group=True, parallel=parallel)
         log = []
         orig = trainer._train_epoch
         trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
@@ -2109,25 +2109,26 @@ def _dist_trainer_worker(rank, world, port, lfm, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('lfm', ['BPR', 'MF'])
-def test_distributed_trainer_fit_matches_single_process(lfm):
+@pytest.mark.parametrize('lfm,world,parallel', [('BPR', 2, False), ('MF', 2, False), ('BPR', 4, True), ('MF', 2, True)])
+def test_distributed_trainer_fit_matches_single_process(lfm, world, parallel):
     """CrossDomainTrainer.fit with config['dist_group'] over 2 ranks (SOURCE x2, TARGET, OVERLAP x2, TARGET again -- so the
     tables go dimension -> row -> dimension layout) and the sharded evaluation in the OVERLAP and TARGET phases, against the same
     trainer in one process: per-epoch losses, metrics, every table gathered back, the mapping."""
     import socket
     import torch.multiprocessing as mp
-    world = 2
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_trainer_worker, args=(r, world, port, lfm, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dist_trainer_worker, args=(r, world, port, lfm, q, parallel)) for r in range(world)]
     for p in procs:
         p.start()
     res = _collect_ranks(q, procs)
     trainer, model, train, valid = _dist_trainer_setup(DEV, lfm)
     # the single-process run must see what the ranks saw: the ragged tails (< world rows) that the distributed run skips
     orig_step = model.fused_train_step
-    model.fused_train_step = lambda inter, **kw: orig_step(type(inter)({k: v[:v.shape[0] - v.shape[0] % world] for k, v in inter.items()}), **kw)
+    # (a domain phase under parallel_domains splits its batches over HALF of the ranks)
+    mod = lambda: world if (model.phase == 'OVERLAP' or not parallel) else world // 2
+    model.fused_train_step = lambda inter, **kw: orig_step(type(inter)({k: v[:v.shape[0] - v.shape[0] % mod()] for k, v in inter.items()}), **kw)
     log = []
     orig = trainer._train_epoch
     trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
@@ -2136,7 +2137,9 @@ def test_distributed_trainer_fit_matches_single_process(lfm):
     model.set_phase('TARGET')
     score = trainer.evaluate(valid)['recall@5']
     for r in range(world):
-        assert_close(torch.tensor(res[r][1]), torch.tensor(log), rtol=5e-5, what=f'epoch losses rank{r}')
+        # epochs: SOURCE, SOURCE, TARGET, OVERLAP, OVERLAP, TARGET; under parallel_domains a rank only sees its own domain's
+        mine = log if not parallel else [log[i] for i in ((0, 1, 3, 4) if r < world // 2 else (2, 3, 4, 5))]
+        assert_close(torch.tensor(res[r][1]), torch.tensor(mine), rtol=5e-5, what=f'epoch losses rank{r}')
         assert abs(res[r][2] - score) < 1e-6 and res[r][3] == pytest.approx(final, abs=1e-6), (res[r][2], score, res[r][3], final)
         for k, v in res[r][4].items():
             assert_close(torch.from_numpy(v).to(DEV), getattr(model, k).weight.data, rtol=1e-4, atol=0.01 * 5e-2, what=k)
