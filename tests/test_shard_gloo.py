@@ -524,6 +524,13 @@ def _worker_cols(rank, world, port, q):
             assert new.step == 5 and (st is None or st.table is None)
             out[name] = tuple(t.numpy().copy() for t in (new.table, new.exp_avg, new.exp_avg_sq))
         only = cols_to_row_shards(full[:, :12].contiguous() if rank == 1 else None, rows, 12, [1])
+        # and back: row shards on every rank -> column blocks on a (different) holder set, nothing elsewhere
+        from recbole_cdr_amd.dimshard import row_shards_to_cols
+        back = row_shards_to_cols(full[rank::world].contiguous(), rows, D, [0, 2, 3])
+        assert (back is None) == (rank == 1)
+        if back is not None:
+            j = [0, 2, 3].index(rank)
+            assert torch.equal(back, full[:, j * 8:(j + 1) * 8])
         q.put((rank, out, only.numpy().copy()))
     finally:
         dist.destroy_process_group()
