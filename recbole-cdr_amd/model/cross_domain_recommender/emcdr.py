@@ -253,6 +253,8 @@ class EMCDR(CrossDomainRecommender):
             key = ('map', kind, T.version(names[0]), T.version(names[1]))
             step = cache['steps'].get(key)
             if step is None:
+                for k in [k for k in cache['steps'] if k[:2] == key[:2]]:
+                    del cache['steps'][k]                         # a step object of an earlier layout: its buffers can go
                 step = FusedMapStep(sst.table, tst.table, self.apply_mapping, list(self.mapping.parameters()), 1, group=T.group,
                                     source_state=sst, target_state=tst, **hp)
                 if cache.get('map_opt') is not None:
@@ -273,6 +275,8 @@ class EMCDR(CrossDomainRecommender):
         key = ('mf' if mf else 'bpr', domain, T.version(names[0]), T.version(names[1]))
         step = cache['steps'].get(key)
         if step is None or step.max_batch < user.numel() * step.world:
+            for k in [k for k in cache['steps'] if k[:2] == key[:2]]:
+                del cache['steps'][k]
             if mf:
                 step = DimShardedPointStep(ust.table, ist.table, user.numel(), loss='mse', reg_weight=self.reg_weight,
                                            group=T.holder_group(names[0]), user_state=ust, item_state=ist, **hp)

@@ -51,6 +51,7 @@ cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 
        'epochs': int(EPOCHS), 'learning_rate_note': 'lr below', 'topk': [10], 'valid_metric': 'Recall@10'}
 if WORLD > 1:
     cfg['dist_group'] = True
+    cfg['parallel_domains'] = bool(int(os.environ.get('E2E_PARALLEL', '1')))      # SOURCE and TARGET epochs on their own halves of the ranks
 torch.manual_seed(2022)                                   # the same seed on every rank: replicated loaders and samplers draw alike
 model = EMCDR(cfg, ds).to(dev)
 dt = lambda a: torch.from_numpy(a.copy()).to(dev)
@@ -75,6 +76,8 @@ def timed(data, e):
 trainer._train_epoch = timed
 trainer.fit(train)
 rows = [('SOURCE', len(ds.s_pairs))] * int(EPOCHS) + [('TARGET', len(t_tr))] * int(EPOCHS) + [('OVERLAP', OU)] * 2   # first epoch of a phase
+if WORLD > 1 and cfg['parallel_domains'] and WORLD % 2 == 0:
+    rows = [r for r in rows if r[0] != 'TARGET']                # rank 0 reports: it trained the SOURCE domain while the upper half trained TARGET
 for (phase, n), (sec, loss) in zip(rows, log):                                                  # also builds its step objects
     print(f'{phase:8s} epoch: {sec * 1e3:9.1f} ms wall for {n} rows = {n / sec / 1e6:8.1f} M rows/s (epoch loss sum {loss:.4f})', flush=True)
 # evaluation in the target domain after the OVERLAP phase (users mapped through the learned mapping): fused mask + top-10
