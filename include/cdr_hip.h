@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 13
+#define CDR_ABI_VERSION 14
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -365,6 +365,7 @@ int cdr_interleave_shards(void* stream, const float* gathered, int world, int64_
 int cdr_gather_owned_rows(void* stream, const float* shard, int D, const int64_t* ids, int64_t n, int world, int rank,
                           float* out);
 int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_idx, int world, int64_t U, int k,
+                          int local_to_global /* 1: entry l of shard p is item l * world + p; 0: entries are output columns already */,
                           float* out_vals, int64_t* out_idx);
 
 /* ---- BPR step over DIMENSION-sharded tables (the alternative to the row exchange above) ---------------------

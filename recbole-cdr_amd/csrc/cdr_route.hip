@@ -187,7 +187,7 @@ extern "C" int cdr_gather_owned_rows(void* stream, const float* tab, int D, cons
 // local row l of producer p to the global item id l * world + p.  Order: value descending, ties to the smaller item id --
 // independent of the rank count.  Producers pad short lists with (-inf, -1); those never win.
 __global__ __launch_bounds__(kBlock) void topk_merge_shards_kernel(const float* __restrict__ vals, const int64_t* __restrict__ lidx,
-                                                                   int G, int64_t U, int k, float* __restrict__ out_v,
+                                                                   int G, int64_t U, int k, int to_global, float* __restrict__ out_v,
                                                                    int64_t* __restrict__ out_i) {
     const int lane = threadIdx.x & 63;
     const int64_t u = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void topk_merge_shards_kernel(const float* 
             const int64_t li = lidx[o];
             if (li < 0) continue;
             const float v = vals[o];
-            const int64_t gi = li * G + p;
+            const int64_t gi = to_global ? li * G + p : li;        // to_global 0: the producers already sent output columns
             if (v > bv || (v == bv && gi < bi)) { bv = v; bi = gi; bslot = s; }
         }
         float wv = bv;
@@ -226,11 +226,11 @@ __global__ __launch_bounds__(kBlock) void topk_merge_shards_kernel(const float* 
 }
 
 extern "C" int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_idx, int world, int64_t U, int k,
-                                     float* out_vals, int64_t* out_idx) {
+                                     int local_to_global, float* out_vals, int64_t* out_idx) {
     CDR_CHECK_ARG(vals && local_idx && out_vals && out_idx && world >= 1 && U > 0 && k > 0);
     CDR_CHECK_ARG((int64_t)world * k <= 64 * 64);
     topk_merge_shards_kernel<<<dim3((unsigned)((U + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, (hipStream_t)stream>>>(
-        vals, local_idx, world, U, k, out_vals, out_idx);
+        vals, local_idx, world, U, k, local_to_global, out_vals, out_idx);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -298,8 +298,11 @@ class EMCDR(CrossDomainRecommender):
         from ...fused import OPT_ADAM
         T = self._dist_tables(OPT_ADAM)
         OI, TI = self.overlapped_num_items, self.target_num_items
-        if self.phase == 'SOURCE':
-            raise NotImplementedError('distributed evaluation of the SOURCE phase (two item ranges) is not implemented')
+        if self.phase == 'SOURCE':                  # emcdr.py:208-214: cat(W_s[:OI], W_s[TI:]) -- two row ranges of the sharded table
+            fs = ShardedFullSort(T.rows('source_item_embedding'), self.total_num_items, group=T.group)
+            user_e = fs.user_rows(T.rows('source_user_embedding'), interaction[self.SOURCE_USER_ID])
+            return fs.topk_ranges(user_e, k, [(0, OI), (TI, self.total_num_items)], hist_indptr=hist_indptr, hist_cols=hist_cols,
+                                  exclude_first_col=True)
         user = interaction[self.TARGET_USER_ID]
         items = T.rows('target_item_embedding')
         if self.phase != 'TARGET' and self.mode != 'overlap_users':

@@ -466,5 +466,70 @@ class ShardedFullSort:
         B_ = self.B_
         out_v = torch.empty(U, k, device=vals.device, dtype=torch.float32)
         out_i = torch.empty(U, k, device=vals.device, dtype=torch.int64)
-        B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(allv), B_.i64(alli), G, U, k, B_.f32(out_v), B_.i64(out_i))
+        B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(allv), B_.i64(alli), G, U, k, 1, B_.f32(out_v), B_.i64(out_i))
+        return out_v, out_i
+
+
+    def topk_ranges(self, user_e, k, ranges, hist_indptr=None, hist_cols=None, exclude_first_col=True):
+        """``topk`` when the scored slab is the concatenation of up to two row RANGES of the sharded table -- the SOURCE phase
+        of emcdr.py:208-214 scores ``cat(W_s[:OI], W_s[TI:])``.  ``ranges`` = [(lo, hi), ...] in concatenation order; output
+        columns (and ``hist_cols``) count along the concatenation, as ``full_sort_predict``'s do.  Each rank scores its rows of
+        every range (a contiguous local slice each), converts its candidates to output columns, and the lists are merged."""
+        from . import functional as F_
+        B_ = self.B_
+        G, rank = self.world, self.rank
+        U = user_e.shape[0]
+        assert 1 <= len(ranges) <= 2
+        # local slice of range j: global row r = l * G + rank in [lo, hi)  <=>  l in [ceil((lo - rank) / G), ceil((hi - rank) / G))
+        loc = [((lo - rank + G - 1) // G if lo > rank else 0, (hi - rank + G - 1) // G if hi > rank else 0) for lo, hi in ranges]
+        base = [0]
+        for lo, hi in ranges:
+            base.append(base[-1] + (hi - lo))                                   # output column of each range's first row
+        lbase = [0]
+        for a, b in loc:
+            lbase.append(lbase[-1] + (b - a))                                   # local column of each range's first local row
+        slabs = [self.I[a:b] for a, b in loc]
+        lp = lc = None
+        if hist_indptr is not None and hist_cols.numel():
+            c = hist_cols
+            j = torch.zeros_like(c) if len(ranges) == 1 else (c >= base[1]).long()
+            lo_t = torch.tensor([r[0] for r in ranges], device=c.device)[j]
+            r = lo_t + (c - torch.tensor(base[:-1], device=c.device)[j])        # global row of each history column
+            own = (r % G) == rank
+            lcol = (r // G) - torch.tensor([a for a, _ in loc], device=c.device)[j] + torch.tensor(lbase[:-1], device=c.device)[j]
+            owner_user = torch.repeat_interleave(torch.arange(U, device=c.device), hist_indptr[1:] - hist_indptr[:-1])
+            key = torch.sort(owner_user[own] * (lbase[-1] + 1) + lcol[own]).values      # ascending local columns per user
+            lc = (key % (lbase[-1] + 1)).contiguous()
+            lp = torch.zeros(U + 1, device=c.device, dtype=torch.int64)
+            lp[1:] = torch.cumsum(torch.bincount(key // (lbase[-1] + 1), minlength=U), 0)
+            if lc.numel() == 0:
+                lp = lc = None
+        n_local = lbase[-1]
+        kk = min(k, n_local)
+        first_mine = exclude_first_col and ranges[0][0] % G == rank and loc[0][1] > loc[0][0]
+        if kk > 0:
+            s0 = slabs[0] if slabs[0].shape[0] else None
+            s1 = slabs[1] if len(slabs) > 1 and slabs[1].shape[0] else None
+            if s0 is None:
+                s0, s1 = s1, None
+            vals, lidx = F_.fullsort_topk(user_e, s0, s1, k=kk, hist_indptr=lp, hist_cols=lc, exclude_first_col=bool(first_mine))
+        else:
+            vals = user_e.new_empty(U, 0)
+            lidx = torch.empty(U, 0, device=user_e.device, dtype=torch.int64)
+        if kk < k:
+            vals = torch.cat([vals, vals.new_full((U, k - kk), float('-inf'))], 1)
+            lidx = torch.cat([lidx, lidx.new_full((U, k - kk), -1)], 1)
+        # local column -> output column (index plumbing): range j, local row l = loc[j][0] + (col - lbase[j]), row r = l*G + rank
+        col = lidx.clamp(min=0)
+        j = torch.zeros_like(col) if len(ranges) == 1 else (col >= lbase[1]).long()
+        t = lambda xs: torch.tensor(xs, device=col.device)[j]
+        r = (t([a for a, _ in loc]) + (col - t(lbase[:-1]))) * G + rank
+        out_col = torch.where(lidx >= 0, t(base[:-1]) + (r - t([lo for lo, _ in ranges])), lidx)
+        allv = torch.empty(G * U, k, device=vals.device, dtype=torch.float32)
+        alli = torch.empty(G * U, k, device=vals.device, dtype=torch.int64)
+        dist.all_gather_into_tensor(allv, vals.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(alli, out_col.contiguous(), group=self.group)
+        out_v = torch.empty(U, k, device=vals.device, dtype=torch.float32)
+        out_i = torch.empty(U, k, device=vals.device, dtype=torch.int64)
+        B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(allv), B_.i64(alli), G, U, k, 0, B_.f32(out_v), B_.i64(out_i))
         return out_v, out_i

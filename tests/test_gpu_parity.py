@@ -1681,7 +1681,7 @@ def test_topk_merge_shards_orders_by_value_then_item_id(G, U, k):
     vals[pad] = -float('inf'); lidx[pad] = -1
     ov = torch.empty(U, k, device=DEV); oi = torch.empty(U, k, device=DEV, dtype=torch.int64)
     dv, di = vals.to(DEV).contiguous(), lidx.to(DEV).contiguous()
-    B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(dv), B_.i64(di), G, U, k, B_.f32(ov), B_.i64(oi))
+    B_.call('cdr_topk_merge_shards', B_.stream(), B_.f32(dv), B_.i64(di), G, U, k, 1, B_.f32(ov), B_.i64(oi))
     ov, oi = ov.cpu(), oi.cpu()
     for u in range(U):
         cand = [(-float(vals[p, u, j]), int(lidx[p, u, j]) * G + p) for p in range(G) for j in range(k) if lidx[p, u, j] >= 0]
@@ -1989,8 +1989,16 @@ def _schedule_worker(rank, world, port, q):
         fs = ShardedFullSort(ti_rows, ni)
         ids = torch.arange(1, 41)
         tv, tix = fs.topk(fs.user_rows(tst.table, ids.to(DEV)), 10)
+        # the SOURCE phase's slab: two row ranges of the source item table, history in concatenated columns
+        si_rows = dim_to_row_shards(cols['si'])
+        fs2 = ShardedFullSort(si_rows, ni)
+        g = torch.Generator(); g.manual_seed(77)
+        hc = torch.sort(torch.randint(1, 7 + (ni - 300), (40, 9), generator=g), dim=1).values
+        hp = torch.arange(41) * 9
+        rv, rix = fs2.topk_ranges(fs2.user_rows(sst.table, ids.to(DEV)), 10, [(0, 7), (300, ni)], hist_indptr=hp.to(DEV),
+                                  hist_cols=hc.reshape(-1).contiguous().to(DEV))
         q.put((rank, losses, tst.table.cpu().numpy(), sst.table.cpu().numpy(), tv.cpu().numpy(), tix.cpu().numpy(),
-               dev[0].detach().cpu().numpy()))
+               dev[0].detach().cpu().numpy(), rv.cpu().numpy(), rix.cpu().numpy(), hc.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -2041,6 +2049,15 @@ def test_whole_schedule_dim_then_row_layout_matches_single_gpu():
         assert_close(torch.from_numpy(res[r][4]).to(DEV), tv, rtol=1e-4, atol=1e-5, what='top-k values')
         same = (torch.from_numpy(res[r][5]).to(DEV) == tix).float().mean()
         assert float(same) > 0.97, float(same)                      # tables agree to ~1e-5: a near-tie may swap two neighbours
+    # two-range slab (SOURCE phase): against the masked single-GPU matrix over cat(SI[:7], SI[300:])
+    full = F_.fullsort_scores(SU[1:41].contiguous(), SI[:7], SI[300:])
+    full[:, 0] = -float('inf')
+    full.scatter_(1, torch.from_numpy(res[0][9]).to(DEV), -float('inf'))
+    want = torch.topk(full, 10, dim=1)
+    for r in range(world):
+        assert_close(torch.from_numpy(res[r][7]).to(DEV), want.values, rtol=1e-4, atol=1e-5, what='two-range top-k values')
+        got_scores = torch.gather(full, 1, torch.from_numpy(res[r][8]).to(DEV))
+        assert_close(got_scores, want.values, rtol=1e-4, atol=1e-5, what='two-range top-k columns point at the top scores')
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -2077,7 +2094,15 @@ def _dist_trainer_setup(dev, lfm, dist_group=None, parallel=False):
     ev = rng.choice(tgt_u, 40), rng.choice(tgt_i, 40)
     valid = FullSortEvalLoader('target_user_id', np.stack(ev, 1), np.stack([t_inter['target_user_id'].numpy(), t_inter['target_item_id'].numpy()], 1),
                                ids.OI + ids.TOI, 4 * (ids.OI + ids.TOI), dev)
-    return CrossDomainTrainer(cfg, model), model, train, valid
+    # SOURCE-phase evaluation (source_split runs): source item ids are not contiguous -- the loader revokes them to the
+    # concatenated columns of cat(W_s[:OI], W_s[TI:]) (dataloader.py:240-247)
+    sev = rng.choice(src_u, 30), rng.choice(src_i, 30)
+    n_src_cols = ids.OI + ids.SOI
+    valid_src = FullSortEvalLoader('source_user_id', np.stack(sev, 1), np.stack([s_inter['source_user_id'].numpy(), s_inter['source_item_id'].numpy()], 1),
+                                   n_src_cols, 4 * n_src_cols, dev, revoke=(ids.OI, ids.TOI))
+    trainer = CrossDomainTrainer(cfg, model)
+    trainer.valid_src = valid_src
+    return trainer, model, train, valid
 
 
 def _dist_trainer_worker(rank, world, port, lfm, q, parallel=False):
@@ -2099,6 +2124,8 @@ def _dist_trainer_worker(rank, world, port, lfm, q, parallel=False):
         final = trainer.evaluate(valid)                                      # fit leaves the model in the OVERLAP phase: mapped users
         model.set_phase('TARGET')
         score = trainer.evaluate(valid)['recall@5']
+        model.set_phase('SOURCE')
+        final = dict(final, source_recall=trainer.evaluate(trainer.valid_src)['recall@5'])
         full = {k: v.cpu().numpy() for k, v in model.gather_full_tables().items()}
         with pytest.raises(RuntimeError, match='whole tables'):            # a shard is not a table: no silent use of one
             model.full_sort_predict(next(iter(valid))[0])
@@ -2136,6 +2163,8 @@ def test_distributed_trainer_fit_matches_single_process(lfm, world, parallel):
     final = trainer.evaluate(valid)
     model.set_phase('TARGET')
     score = trainer.evaluate(valid)['recall@5']
+    model.set_phase('SOURCE')
+    final = dict(final, source_recall=trainer.evaluate(trainer.valid_src)['recall@5'])
     for r in range(world):
         # epochs: SOURCE, SOURCE, TARGET, OVERLAP, OVERLAP, TARGET; under parallel_domains a rank only sees its own domain's
         mine = log if not parallel else [log[i] for i in ((0, 1, 3, 4) if r < world // 2 else (2, 3, 4, 5))]
