@@ -117,6 +117,9 @@ def run_c5(args, world, rank, dev):
     gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
     sharded = world > 1 or args.force_shard
     dim_mode = sharded and args.shard == 'dim'
+    if dim_mode and D % (4 * (world // 2 if world % 2 == 0 and not args.no_domain_groups else world)):
+        dim_mode = False                            # the column cut needs float4-wide slices: fall back to the row exchange
+        print('bench: --dim %d does not cut into float4 slices over %d ranks; using --shard row' % (D, world), file=sys.stderr)
     dom_groups = dim_mode and world >= 2 and world % 2 == 0 and not args.no_domain_groups
     if dom_groups:
         # The SOURCE and the TARGET step share nothing (disjoint tables, disjoint optimizer state), so each domain gets one half of
