@@ -79,7 +79,9 @@ def dist_setup(args):
         if shared:
             dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local),
+            # no device_id: communicators are then created lazily with ncclCommInitRank, per group, by its members only --
+            # the long-standing path; binding a device would create every sub-group with ncclCommSplit instead
+            dist.init_process_group('nccl', rank=rank, world_size=world,
                                     timeout=datetime.timedelta(minutes=5))  # a wedged collective aborts instead of hanging
     return world, rank, local
 

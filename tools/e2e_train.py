@@ -25,8 +25,7 @@ torch.cuda.set_device(dev)
 if WORLD > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29544')
-    dist.init_process_group('gloo' if SHARED else 'nccl', rank=RANK, world_size=WORLD,
-                            **({} if SHARED else {'device_id': torch.device(dev)}))
+    dist.init_process_group('gloo' if SHARED else 'nccl', rank=RANK, world_size=WORLD)
     if RANK:
         sys.stdout = open(os.devnull, 'w')                # rank 0 reports; every rank computes the same numbers
 OU, TOI, NI, BATCH = int(os.environ.get('E2E_USERS', 4_000_001)), int(os.environ.get('E2E_ITEMS', 1_000_000)), \
