@@ -2219,3 +2219,36 @@ def test_dim_layout_full_size_properties():
     assert_close(I[rows_i], I2[rows_i], rtol=1e-5, atol=1e-6, what='item rows')
     fp = lambda t: t.view(-1)[::4099].double().sum()
     assert abs(float(fp(U) - fp(U2))) <= 1e-6 * abs(float(fp(U2))) + 1e-3 and abs(float(fp(I) - fp(I2))) <= 1e-6 * abs(float(fp(I2))) + 1e-3
+
+
+@pytest.mark.parametrize('world,extra', [(2, []), (4, []), (2, ['--shard', 'row'])])
+def test_bench_multi_rank_line_contract(world, extra):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one rank per process) -- here with every rank on
+    cuda:0 over gloo (CDR_BENCH_SHARED_GPU=1, small tables): stdout is exactly ONE JSON line from rank 0 with the contract's
+    keys, the whole-job value, a roofline and an exchange object; the other legs (OVERLAP step, sharded full-sort) ran."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CDR_BENCH_SHARED_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '2',
+           '--users', '400001', '--items-per-domain', '100000', '--batch', '8192'] + extra
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == world and d['steps'] == 3 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['metric'] == 'training interactions/sec' and d['higher_is_better'] is True and d['dtype'] == 'f32'
+    assert 'FUNCTIONAL CHECK ONLY' in d['data'] and 'sharding' in d['config'] and 'cpu_baseline' not in d
+    B = d['config']['batch_per_domain_per_rank']
+    assert abs(d['value'] - 2 * B * world / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert d['exchange']['bytes_to_other_ranks_per_step_per_rank'] >= 0
+    assert 0 < d['final_loss'] < 1 and d['overlap_phase']['loss'] >= 0
+    assert d['fullsort']['U=1']['masked_top10']['ms'] > 0 and d['fullsort']['U=1024']['items_per_s'] > 0
