@@ -259,6 +259,9 @@ class EMCDR(CrossDomainRecommender):
                                     source_state=sst, target_state=tst, **hp)
                 if cache.get('map_opt') is not None:
                     step.map_opt = cache['map_opt']               # the mapping's Adam state outlives a layout change
+                pending = self.__dict__.pop('_pending_dist_map_state', None)
+                if pending is not None and step.map_opt is not None:
+                    step.map_opt.load_state_dict(pending)         # ... and a checkpoint
                 cache['map_opt'] = step.map_opt
                 cache['steps'][key] = step
             for n in names:
@@ -318,6 +321,49 @@ class EMCDR(CrossDomainRecommender):
             mapped = self.apply_mapping(fs.user_rows(T.rows('source_user_embedding'), user))
             user_e = torch.where((user < self.overlapped_num_users).unsqueeze(1), mapped, user_e)      # emcdr.py:219-226 (Q5)
         return fs.topk(user_e, k, hist_indptr=hist_indptr, hist_cols=hist_cols, exclude_first_col=True)
+
+    def dist_checkpoint(self):
+        """This rank's part of the sharded model for a checkpoint: per table its layout, holder ranks, update count and the
+        local table / moments (None where the rank holds nothing); the replicated mapping and its dense Adam state."""
+        T = self.__dict__.get('_dist')
+        if T is None:
+            raise RuntimeError('no sharded state yet: nothing was trained or evaluated in distributed mode')
+        tabs = {}
+        for name, e in T.entries.items():
+            st = e['state']
+            tabs[name] = {'layout': e['layout'], 'holders': list(e['holders']), 'step': st.step if st is not None else None,
+                          'table': st.table if st is not None else None,
+                          'exp_avg': st.exp_avg if st is not None else None, 'exp_avg_sq': st.exp_avg_sq if st is not None else None}
+        mo = self.__dict__.get('_fused', {}).get('map_opt')
+        return {'world': T.world, 'rank': T.rank, 'tables': tabs, 'mapping': self.mapping.state_dict(),
+                'map_opt': mo.state_dict() if mo is not None else None}
+
+    def load_dist_checkpoint(self, state):
+        """Restore what ``dist_checkpoint`` returned on the same rank of a group of the same size (collective: a table saved in the
+        row layout is first brought there on every rank)."""
+        from ...fused import OPT_ADAM
+        T = self._dist_tables(OPT_ADAM)
+        if (state['world'], state['rank']) != (T.world, T.rank):
+            raise ValueError(f"checkpoint of rank {state['rank']}/{state['world']} loaded on rank {T.rank}/{T.world}")
+        for name, rec in state['tables'].items():
+            e = T.entries[name]
+            if list(rec['holders']) != list(e['holders']):
+                raise ValueError(f'{name}: saved with holder ranks {rec["holders"]}, this run uses {e["holders"]} (parallel_domains differs)')
+            st = T.state(name, rec['layout'])
+            if st is not None:
+                st.step = int(rec['step'])
+                st.table.copy_(rec['table'])
+                if st.exp_avg is not None and rec['exp_avg'] is not None:
+                    st.exp_avg.copy_(rec['exp_avg']); st.exp_avg_sq.copy_(rec['exp_avg_sq'])
+            emb = getattr(self, name)
+            emb.weight.data = st.table if st is not None else emb.weight.data.new_empty(0, emb.weight.shape[1])
+            e['version'] += 1                                     # step objects built on the old tensors are stale
+            e['eval_rows'] = None
+        self.mapping.load_state_dict(state['mapping'])
+        cache = self.__dict__.setdefault('_fused', {'states': {}, 'steps': {}})
+        cache['steps'].clear()
+        cache['map_opt'] = None
+        self.__dict__['_pending_dist_map_state'] = state.get('map_opt')
 
     def gather_full_tables(self):
         """{name: replicated [rows, D] table} from the shards (checkpoint / hand-over to a single-process model)."""

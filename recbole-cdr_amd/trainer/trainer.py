@@ -197,9 +197,14 @@ class Trainer:
     def save_checkpoint(self, path, epoch=None):
         """recbole ``Trainer._save_checkpoint``: config-free subset -- epoch, early-stopping state, model ``state_dict``,
         ``other_parameter`` and the optimizer state (dense: ``DenseAdam.state_dict()``; rowwise: the model's per-table
-        moments and update counts)."""
+        moments and update counts).  With a ``dist_group``: one file per rank, ``<path>.rank<r>``."""
         if self.dist_group is not None:
-            raise NotImplementedError('checkpointing a sharded model: gather_full_tables() on the model, save from one rank')
+            # a sharded model: every rank writes ITS shards (tables + moments in their current layout) next to the replicated parts
+            import torch.distributed as dist
+            state = {'epoch': epoch, 'cur_step': self.cur_step, 'best_valid_score': self.best_valid_score,
+                     'phase': getattr(self.model, 'phase', None), 'dist': self.model.dist_checkpoint()}
+            torch.save(state, f'{path}.rank{dist.get_rank(self.dist_group)}')
+            return
         state = {'epoch': epoch, 'cur_step': self.cur_step, 'best_valid_score': self.best_valid_score,
                  'state_dict': self.model.state_dict(), 'other_parameter': self.model.other_parameter(),
                  'optimizer_mode': self.optimizer_mode, 'optimizer': self.optimizer.state_dict(),
@@ -210,6 +215,15 @@ class Trainer:
 
     def resume_checkpoint(self, path):
         """recbole ``Trainer.resume_checkpoint``."""
+        if self.dist_group is not None:
+            import torch.distributed as dist
+            state = torch.load(f'{path}.rank{dist.get_rank(self.dist_group)}', map_location=self.device, weights_only=False)
+            self.start_epoch = (state['epoch'] + 1) if state['epoch'] is not None else 0
+            self.cur_step, self.best_valid_score = state['cur_step'], state['best_valid_score']
+            self.model.load_dist_checkpoint(state['dist'])
+            if state.get('phase') is not None:
+                self.model.set_phase(state['phase'])
+            return
         state = torch.load(path, map_location=self.device, weights_only=False)
         self.start_epoch = (state['epoch'] + 1) if state['epoch'] is not None else 0
         self.cur_step, self.best_valid_score = state['cur_step'], state['best_valid_score']

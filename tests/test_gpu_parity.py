@@ -2062,7 +2062,7 @@ def test_whole_schedule_dim_then_row_layout_matches_single_gpu():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CrossDomainTrainer over several ranks: config['dist_group'] + optimizer_mode='rowwise'
-def _dist_trainer_setup(dev, lfm, dist_group=None, parallel=False):
+def _dist_trainer_setup(dev, lfm, dist_group=None, parallel=False, modes=None, epochs=None):
     from oracle.common import IdSpace
     from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
     from recbole_cdr_amd.trainer import CrossDomainTrainer
@@ -2074,7 +2074,7 @@ def _dist_trainer_setup(dev, lfm, dist_group=None, parallel=False):
     extra = {'dist_group': dist_group, 'parallel_domains': parallel} if dist_group is not None else {}
     cfg = base_config(dev, latent_factor_model=lfm, source_embedding_size=D, target_embedding_size=D, reg_weight=reg,
                       mapping_function='non_linear', mlp_hidden_size=[24], learning_rate=lr, optimizer_mode='rowwise',
-                      train_modes=['SOURCE', 'TARGET', 'OVERLAP', 'TARGET'], epoch_num=['2', '1', '2', '1'], source_split=False,
+                      train_modes=modes or ['SOURCE', 'TARGET', 'OVERLAP', 'TARGET'], epoch_num=epochs or ['2', '1', '2', '1'], source_split=False,
                       eval_step=1, epochs=2, topk=[5], valid_metric='recall@5', **extra)
     model = EMCDR(cfg, FakeDataset(ids)).to(dev)
     rng = np.random.RandomState(0)
@@ -2252,3 +2252,53 @@ def test_bench_multi_rank_line_contract(world, extra):
     assert d['exchange']['bytes_to_other_ranks_per_step_per_rank'] >= 0
     assert 0 < d['final_loss'] < 1 and d['overlap_phase']['loss'] >= 0
     assert d['fullsort']['U=1']['masked_top10']['ms'] > 0 and d['fullsort']['U=1024']['items_per_s'] > 0
+
+
+def _dist_ckpt_worker(rank, world, port, path, q):
+    import os
+    import faulthandler
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    faulthandler.dump_traceback_later(270, exit=True)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        torch.cuda.set_device(0)
+        S, T, O = 'SOURCE', 'TARGET', 'OVERLAP'
+        tr_a, m_a, data_a, _ = _dist_trainer_setup(DEV, 'BPR', True, modes=[S, O, T, O], epochs=['1', '1', '1', '1'])
+        tr_a.fit(data_a, None, verbose=False, saved=False)                       # uninterrupted
+        tr_b, _m_b, data_b, _ = _dist_trainer_setup(DEV, 'BPR', True, modes=[S, O], epochs=['1', '1'])
+        tr_b.fit(data_b, None, verbose=False, saved=False)
+        tr_b.save_checkpoint(path, epoch=0)                                      # tables are row shards at this point (OVERLAP ran last)
+        tr_c, m_c, data_c, _ = _dist_trainer_setup(DEV, 'BPR', True, modes=[T, O], epochs=['1', '1'])
+        with torch.no_grad():
+            for p in m_c.parameters():
+                p.add_(1.0)                                                      # whatever the fresh model held must not matter
+        tr_c.resume_checkpoint(path)
+        tr_c.fit(data_c, None, verbose=False, saved=False)
+        fa, fc = m_a.gather_full_tables(), m_c.gather_full_tables()
+        same = {k: bool(torch.equal(fa[k], fc[k])) for k in fa}
+        same.update({'mapping.' + k: bool(torch.equal(v, dict(m_c.mapping.named_parameters())[k])) for k, v in m_a.mapping.named_parameters()})
+        faulthandler.cancel_dump_traceback_later()
+        q.put((rank, same, os.path.exists(f'{path}.rank{rank}')))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_checkpoint_resume_continues_bit_exactly(tmp_path):
+    """Sharded checkpoint (one file per rank: tables and moments in whatever layout they are in -- row shards after an OVERLAP
+    phase --, update counts, the mapping and its Adam state): SOURCE, OVERLAP | save | fresh model, resume | TARGET, OVERLAP
+    equals the uninterrupted four phases bit for bit on every table and on the mapping."""
+    import socket
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_ckpt_worker, args=(r, world, port, str(tmp_path / 'ckpt.pth'), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    for r in range(world):
+        assert res[r][2] and all(res[r][1].values()), res[r][1]
