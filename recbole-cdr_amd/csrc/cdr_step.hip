@@ -732,11 +732,11 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
     cdr_time_scope ts(ctx, is_signed ? CDR_TAG_APPLY_SIGNED : CDR_TAG_APPLY_UNSIGNED, s);
 #define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, hp, occ_ids, counters, longs, pieces
 #define COOP(L_, O_, S_) rowwise_apply_coop_kernel<L_, O_, S_><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)
-#define COOP_LPR(O_, S_) switch (lpr) { case 1: COOP(1, O_, S_); break; case 2: COOP(2, O_, S_); break; case 4: COOP(4, O_, S_); break; \
-                                         case 8: COOP(8, O_, S_); break; default: COOP(16, O_, S_); break; }
-    // narrow rows with signed occurrences (an item table of a dimension-sharded step: ~2 hits per row): the cooperative form.
-    // Same-box A/B (tools/mb_dimshard.py): -16 % at 64 columns, -3 % at 16-32; 128-column rows keep the serial kernel.
-    if (lpr <= 16 && is_signed) {
+#define COOP_LPR(O_, S_) if (lpr == 8) { COOP(8, O_, S_); } else { COOP(16, O_, S_); }
+    // 32- and 64-column rows with signed occurrences (an item table of a dimension-sharded step: ~2 hits per row): the
+    // cooperative form.  Same-box A/B (tools/mb_dimshard.py): -16 % at 64 columns, -3 % at 32; at 16 columns (16 positions per
+    // window, 4 reduction steps) it LOSES 15 %, and 128-column rows (2 positions per wave) have nothing to share.
+    if ((lpr == 8 || lpr == 16) && is_signed) {
         if (opt == 0) { COOP_LPR(0, true) } else { COOP_LPR(1, true) }
     }
     else if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
