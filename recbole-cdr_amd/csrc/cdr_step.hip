@@ -410,131 +410,6 @@ __global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(float* __restri
     }
 }
 
-template <int OPT>
-__device__ __forceinline__ void apply_update_pre(float* __restrict__ wp, float* __restrict__ mp, float* __restrict__ vp, float4 w,
-                                                 float4 m, float4 v, float4 acc, float rc, const apply_hp& h) {
-    float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
-    float4 wn;
-    if (OPT == 0) {
-        if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
-        wn = make_float4(w.x - h.lr * gr.x, w.y - h.lr * gr.y, w.z - h.lr * gr.z, w.w - h.lr * gr.w);
-    } else {
-        if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
-        m.x += (gr.x - m.x) * (1.0f - h.b1); m.y += (gr.y - m.y) * (1.0f - h.b1);
-        m.z += (gr.z - m.z) * (1.0f - h.b1); m.w += (gr.w - m.w) * (1.0f - h.b1);
-        v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
-        v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
-        st4(mp, m); st4(vp, v);
-        wn = make_float4(w.x - h.step_size * (m.x / (sqrtf(v.x) / h.bc2_sqrt + h.eps)),
-                         w.y - h.step_size * (m.y / (sqrtf(v.y) / h.bc2_sqrt + h.eps)),
-                         w.z - h.step_size * (m.z / (sqrtf(v.z) / h.bc2_sqrt + h.eps)),
-                         w.w - h.step_size * (m.w / (sqrtf(v.w) / h.bc2_sqrt + h.eps)));
-    }
-    st4(wp, wn);
-}
-
-// ---- narrow rows (dimension-sharded tables: 16-64 columns) -----------------------------------------------------------
-// In rowwise_apply_kernel a segment's head walks its occurrences one after the other while the lane groups sitting on the
-// segment's other positions idle; with 8-16 lane groups per wave the wave advances at the pace of its longest segment, and an
-// item table whose rows are hit 2.1 times on average ran at 3.5 TB/s where the user table (1.1 hits) ran at 5.0.  Here EVERY
-// position of the wave's window (64 / LPR consecutive sorted positions) loads its own gradient row at once, a segmented
-// reduction over the lane groups (log2 steps of ds_bpermute: position g takes g + d when both hold the same row) brings the
-// window's part of each segment to its head, and only what spills past the window is walked serially.  Fixed association
-// order => bit-reproducible; it differs from the serial order in the last bit.
-template <int LPR, int OPT, bool SIGNED>
-__global__ __launch_bounds__(kBlock) void rowwise_apply_coop_kernel(float* __restrict__ W, float* __restrict__ Mo,
-                                                                    float* __restrict__ Vo, int D,
-                                                                    const uint32_t* __restrict__ keys,
-                                                                    const uint32_t* __restrict__ perm, int64_t n,
-                                                                    const float* __restrict__ G, int64_t neg_start,
-                                                                    int64_t reg_limit, const float* __restrict__ reg_coef,
-                                                                    apply_hp hp, const int64_t* __restrict__ occ_ids,
-                                                                    unsigned* __restrict__ counters, seg_long* __restrict__ longs,
-                                                                    seg_piece* __restrict__ pieces) {
-    static_assert(LPR <= 16, "one wave must hold at least four positions");
-    constexpr int GPB = kBlock / LPR;          // positions per block and iteration
-    constexpr int WIN = 64 / LPR;              // positions per wave: the window of the segmented reduction
-    const int sub = threadIdx.x % LPR;
-    const int gw = (threadIdx.x & 63) / LPR;   // this lane group's position inside its wave's window
-    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-    const int64_t TG = (int64_t)gridDim.x * GPB;
-    const bool live = sub < (D >> 2);
-    const float c = reg_coef ? reg_coef[0] : 0.f;
-    const int64_t rounds = (n + TG - 1) / TG;                  // every lane takes part in every round's shuffles
-    for (int64_t it = 0; it < rounds; ++it) {
-        const int64_t q = gg + it * TG;
-        const bool in = q < n;
-        const int64_t qc = in ? q : n - 1;
-        const uint32_t row = keys[qc];
-        const uint32_t before = keys[qc > 0 ? qc - 1 : 0];
-        const uint32_t far = keys[qc + kLongSeg < n ? qc + kLongSeg : n - 1];
-        const int64_t o = perm[qc];
-        const bool head = in && !(qc > 0 && before == row);
-        const bool is_long = in && qc + kLongSeg < n && far == row;     // same for every position of a long segment's first 32
-        const bool neg = SIGNED && o >= neg_start;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in && live) v = ld4(G + (neg ? o - neg_start : o) * D + 4 * sub);
-        if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-        int cnt = in ? (occ_ids ? (int)((occ_ids[o] >> 62) & 1) : ((o < reg_limit) ? 1 : 0)) : 0;
-        // the head's own row and moments travel while the reduction runs
-        float* wp = W + (int64_t)row * D + 4 * sub;
-        float* mp = OPT ? Mo + (int64_t)row * D + 4 * sub : nullptr;
-        float* vp = OPT ? Vo + (int64_t)row * D + 4 * sub : nullptr;
-        const bool mine = head && !is_long && live;
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f), m = w, vv = w;
-        if (mine) { w = ld4(wp); if (OPT) { m = ld4(mp); vv = ld4(vp); } }
-        // segmented reduction towards the lower positions: after the step with distance d, position g holds the sum over
-        // g .. g + 2d - 1 of the positions that carry its row (sorted keys: equal at distance d => equal in between)
-        const uint32_t rk = in ? row : 0xFFFFFFFFu;
-#pragma unroll
-        for (int d = 1; d < WIN; d <<= 1) {
-            const uint32_t r2 = (uint32_t)__shfl_down((int)rk, d * LPR, 64);
-            const float ax = __shfl_down(v.x, d * LPR, 64), ay = __shfl_down(v.y, d * LPR, 64);
-            const float az = __shfl_down(v.z, d * LPR, 64), aw = __shfl_down(v.w, d * LPR, 64);
-            const int ac = __shfl_down(cnt, d * LPR, 64);
-            if (gw + d < WIN && r2 == rk) { v.x += ax; v.y += ay; v.z += az; v.w += aw; cnt += ac; }
-        }
-        if (head && !is_long) {
-            // what spills past this wave's window: walked serially, as in rowwise_apply_kernel
-            const int64_t wend = q + (WIN - gw);
-            if (wend < n && keys[wend] == row) {
-                for (int64_t e = wend; e < n && keys[e] == row; ++e) {
-                    const int64_t o2 = perm[e];
-                    const bool ng = SIGNED && o2 >= neg_start;
-                    if (live) {
-                        const float4 g2 = ld4(G + (ng ? o2 - neg_start : o2) * D + 4 * sub);
-                        if (ng) { v.x -= g2.x; v.y -= g2.y; v.z -= g2.z; v.w -= g2.w; }
-                        else { v.x += g2.x; v.y += g2.y; v.z += g2.z; v.w += g2.w; }
-                    }
-                    cnt += occ_ids ? (int)((occ_ids[o2] >> 62) & 1) : ((o2 < reg_limit) ? 1 : 0);
-                }
-            }
-            if (live) apply_update_pre<OPT>(wp, mp, vp, w, m, vv, v, c * (float)cnt, hp);
-        }
-    }
-    if (counters == nullptr) return;                          // registration of the long segments: as in rowwise_apply_kernel
-    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q + kLongSeg < n; q += (int64_t)gridDim.x * kBlock) {
-        const uint32_t row = keys[q];
-        const uint32_t before = keys[q > 0 ? q - 1 : 0];
-        const uint32_t far = keys[q + kLongSeg];
-        if ((q > 0 && before == row) || far != row) continue;
-        int64_t lo = q + kLongSeg, hi = n;
-        while (lo + 1 < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] == row) lo = mid; else hi = mid;
-        }
-        const int64_t len = hi - q;
-        const unsigned np = (unsigned)((len + kPiece - 1) / kPiece);
-        const unsigned base = atomicAdd(&counters[0], np);
-        const unsigned li = atomicAdd(&counters[1], 1u);
-        longs[li] = seg_long{q, len, (int64_t)base};
-        for (unsigned k = 0; k < np; ++k) {
-            const int64_t st = q + (int64_t)k * kPiece;
-            pieces[base + k] = seg_piece{st, (hi - st) < kPiece ? (hi - st) : (int64_t)kPiece};
-        }
-    }
-}
-
 // Two tables in ONE sort: rocPRIM's radix sort costs ~0.16 ms whether it sorts 1 M or 3 M pairs (a chain of small launches),
 // so the user ids and the item ids of a step are sorted together; the item keys carry one extra high bit (key_base), which
 // puts them behind every user key and is subtracted again by the apply kernel.
@@ -731,20 +606,10 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
     }
     cdr_time_scope ts(ctx, is_signed ? CDR_TAG_APPLY_SIGNED : CDR_TAG_APPLY_UNSIGNED, s);
 #define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, hp, occ_ids, counters, longs, pieces
-#define COOP(L_, O_, S_) rowwise_apply_coop_kernel<L_, O_, S_><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)
-#define COOP_LPR(O_, S_) if (lpr == 8) { COOP(8, O_, S_); } else { COOP(16, O_, S_); }
-    // 32- and 64-column rows with signed occurrences (an item table of a dimension-sharded step: ~2 hits per row): the
-    // cooperative form.  Same-box A/B (tools/mb_dimshard.py): -16 % at 64 columns, -3 % at 32; at 16 columns (16 positions per
-    // window, 4 reduction steps) it LOSES 15 %, and 128-column rows (2 positions per wave) have nothing to share.
-    if ((lpr == 8 || lpr == 16) && is_signed) {
-        if (opt == 0) { COOP_LPR(0, true) } else { COOP_LPR(1, true) }
-    }
-    else if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
+    if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
     else { DISPATCH_LPR(lpr, rowwise_apply_kernel<L, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(APPLY_ARGS)); }
-#undef COOP_LPR
-#undef COOP
 #undef APPLY_ARGS
     CDR_LAUNCH_CHECK();
     if (may_have_long) {
