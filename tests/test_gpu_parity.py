@@ -955,7 +955,7 @@ def test_spmm_csr_vs_torch_sparse():
     assert_close(out, ref)
 
 
-def _collect_ranks(q, procs, limit=300):
+def _collect_ranks(q, procs, limit=600):
     """One result per worker, sorted by rank; gives up as soon as a worker has died instead of waiting out the limit."""
     import queue
     import time
@@ -2111,7 +2111,7 @@ def _dist_trainer_worker(rank, world, port, lfm, q, parallel=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import faulthandler
-    faulthandler.dump_traceback_later(270, exit=True)                  # a wedged collective shows where, instead of hanging the suite
+    faulthandler.dump_traceback_later(570, exit=True)                  # a wedged collective shows where, instead of hanging the suite
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import recbole_cdr_amd  # noqa: F401
@@ -2260,7 +2260,7 @@ def _dist_ckpt_worker(rank, world, port, path, q):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    faulthandler.dump_traceback_later(270, exit=True)
+    faulthandler.dump_traceback_later(570, exit=True)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import recbole_cdr_amd  # noqa: F401
