@@ -68,3 +68,53 @@ def assert_close(got, want, rtol=1e-5, atol=None, what=''):
     if atol is None:
         atol = 1e-5 * (np.abs(want).max() if want.size else 1.0) + 1e-12
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)
+
+
+DEV = 'cuda:0'
+
+
+def make_mapping(dims, seed):
+    """(params dict in the oracle's naming, device parameter list, device mapping_fn) for a linear (2 dims) or tanh-MLP
+    mapping function (emcdr.py:74-93)."""
+    from recbole_cdr_amd import functional as F_, binding as B_
+    g = torch.Generator(); g.manual_seed(seed)
+    cpu, dev = {}, []
+    if len(dims) == 2:
+        w = torch.randn(dims[1], dims[0], generator=g) * 0.2
+        cpu['mapping.weight'] = w.clone().requires_grad_(True)
+        dev.append(torch.nn.Parameter(w.clone().to(DEV)))
+        return cpu, dev, lambda x: F_.linear(x, dev[0], None, B_.ACT_NONE)
+    for n, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        w, bias = torch.randn(b, a, generator=g) * 0.2, torch.randn(b, generator=g) * 0.1
+        cpu[f'mapping.{2 * n}.weight'] = w.clone().requires_grad_(True)
+        cpu[f'mapping.{2 * n}.bias'] = bias.clone().requires_grad_(True)
+        dev += [torch.nn.Parameter(w.clone().to(DEV)), torch.nn.Parameter(bias.clone().to(DEV))]
+    L = len(dims) - 1
+
+    def fn(x):
+        for n in range(L):
+            x = F_.linear(x, dev[2 * n], dev[2 * n + 1], B_.ACT_TANH if n != L - 1 else B_.ACT_NONE)
+        return x
+    return cpu, dev, fn
+
+
+def collect_ranks(q, procs, limit=600):
+    """One result per worker, sorted by rank; gives up as soon as a worker has died instead of waiting out the limit."""
+    import queue
+    import time
+    res, t0 = [], time.time()
+    try:
+        while len(res) < len(procs):
+            try:
+                res.append(q.get(timeout=2))
+            except queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f'worker exit codes {dead}'
+                assert time.time() - t0 < limit, 'workers timed out'
+    finally:
+        for p in procs:
+            p.join(timeout=30 if len(res) == len(procs) else 1)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return sorted(res, key=lambda t: t[0])
