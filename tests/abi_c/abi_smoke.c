@@ -1,6 +1,7 @@
 /* A plain C consumer of libcdrhip.so: no Python, no torch -- device buffers from the HIP runtime, entry points from
  * include/cdr_hip.h.  Runs the pairwise loss (cdr_bpr_fwd), the all-items scoring (cdr_fullsort_scores_f32) and one fused
- * row-wise SGD step (cdr_bpr_fwd_grad -> cdr_sort_ids_two_tables -> cdr_rowwise_apply x2) on small tables and checks every
+ * row-wise SGD step (cdr_bpr_fwd_grad -> cdr_sort_ids_two_tables -> cdr_rowwise_apply x2; then the same step in the dimension
+ * layout's call sequence, cdr_ids_pack32 ... cdr_bpr_grad_from_diff) on small tables and checks every
  * result against the same arithmetic done here in double precision.  Exit code 0 = all within 1e-5 relative.
  * Build: hipcc -x c tests/abi_c/abi_smoke.c -Iinclude -Lrecbole-cdr_amd/lib -lcdrhip -o tests/abi_c/abi_smoke           */
 #include <math.h>
@@ -106,6 +107,34 @@ int main(void) {
     CHECK_HIP(hipMemcpy(U2, dU, sizeof(float) * NU * D, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(I2, dI, sizeof(float) * NI * D, hipMemcpyDeviceToHost));
     for (int i = 0; i < NU * D; ++i) ok &= close_enough(U2[i], Uref[i], 0.2, "user table after the step");
     for (int i = 0; i < NI * D; ++i) ok &= close_enough(I2[i], Iref[i], 0.2, "item table after the step");
+    /* ---- the same step in the dimension layout's call sequence, one rank holding every column: ids narrowed
+     * and widened again around where the all-gather would be, partial scores, where the all-reduce would be, sort, gradients
+     * from the scores, the two applies -- on fresh copies of the tables, against the same host reference ------------------- */
+    float *dU2, *dI2, *dDiff; int32_t *dIds32; int64_t* dIds64; int* dBad;
+    CHECK_HIP(hipMalloc((void**)&dU2, sizeof(float) * NU * D)); CHECK_HIP(hipMalloc((void**)&dI2, sizeof(float) * NI * D));
+    CHECK_HIP(hipMemcpy(dU2, U, sizeof(float) * NU * D, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dI2, I, sizeof(float) * NI * D, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMalloc((void**)&dDiff, sizeof(float) * (B + 2))); CHECK_HIP(hipMalloc((void**)&dIds32, 4 * 3 * B));
+    CHECK_HIP(hipMalloc((void**)&dIds64, 8 * 3 * B)); CHECK_HIP(hipMalloc((void**)&dBad, 4)); CHECK_HIP(hipMemset(dBad, 0, 4));
+    CHECK_CDR(cdr_ids_pack32(NULL, du, dp_, dn_, NULL, B, dIds32, dBad));
+    /* ncclAllGather(dIds32 -> [G][3][B]) would go here; G = 1 */
+    CHECK_CDR(cdr_ids_unpack32(NULL, dIds32, 1, B, dIds64, NULL));
+    const int64_t *gu = dIds64, *gp = dIds64 + B, *gn = dIds64 + 2 * B;
+    CHECK_CDR(cdr_bpr_partial_diff(ctx, NULL, dU2, dI2, D, gu, gp, gn, B, dDiff));
+    /* ncclAllReduce(dDiff, B + 2, sum) would go here */
+    CHECK_CDR(cdr_sort_ids_two_tables(ctx, NULL, gu, B, NU, gp, B, gn, B, NI, dKeys, dPerm, &key_base, dWs, ws_bytes));
+    CHECK_CDR(cdr_bpr_grad_from_diff(ctx, NULL, dU2, dI2, D, gu, gp, gn, B, gamma, reg, dDiff, dOut, dGU, dGP));
+    CHECK_CDR(cdr_rowwise_apply(ctx, NULL, CDR_OPT_SGD, dU2, NULL, NULL, D, dKeys, dPerm, B, dGU, B, B, dOut + 4, lr, 0.9f, 0.999f, 1e-8f,
+                                0.f, 1, NULL, 0));
+    CHECK_CDR(cdr_rowwise_apply(ctx, NULL, CDR_OPT_SGD, dI2, NULL, NULL, D, dKeys + B, dPerm + B, 2 * B, dGP, B, B, dOut + 5, lr, 0.9f,
+                                0.999f, 1e-8f, 0.f, 1, NULL, key_base));
+    CHECK_HIP(hipDeviceSynchronize());
+    int bad = 1;
+    CHECK_HIP(hipMemcpy(&bad, dBad, 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(out, dOut, sizeof(float) * 6, hipMemcpyDeviceToHost));
+    ok &= (bad == 0) & close_enough(out[0], total, 0, "dimension-layout step loss");
+    CHECK_HIP(hipMemcpy(U2, dU2, sizeof(float) * NU * D, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(I2, dI2, sizeof(float) * NI * D, hipMemcpyDeviceToHost));
+    for (int i = 0; i < NU * D; ++i) ok &= close_enough(U2[i], Uref[i], 0.2, "user table after the dimension-layout step");
+    for (int i = 0; i < NI * D; ++i) ok &= close_enough(I2[i], Iref[i], 0.2, "item table after the dimension-layout step");
     CHECK_CDR(cdr_ctx_destroy(ctx));
     printf(ok ? "abi_smoke: OK (loss %.7f)\n" : "abi_smoke: FAILED (loss %.7f)\n", out[0]);
     return ok ? 0 : 1;
