@@ -159,15 +159,17 @@ def test_evaluate_topk_path_equals_full_matrix_path():
         assert abs(a[k] - b[k]) < 1e-7, (k, a[k], b[k])
 
 
-def test_full_sort_eval_loader_batches():
+@pytest.mark.parametrize('users_per_batch', [None, 16])
+def test_full_sort_eval_loader_batches(users_per_batch):
     """Every batch of FullSortEvalLoader carries exactly the positives / history pairs of its own users, as rows relative
-    to the batch (recbole FullSortEvalDataLoader's (interaction, history_index, positive_u, positive_i) contract)."""
+    to the batch (recbole FullSortEvalDataLoader's (interaction, history_index, positive_u, positive_i) contract); the batch is
+    eval_batch_size // item_num users, or the throughput-sized override for the fused top-k evaluation."""
     from recbole_cdr_amd.data import FullSortEvalLoader
     rng = np.random.RandomState(1)
     ev = np.stack([rng.randint(1, 60, 300), rng.randint(1, 40, 300)], 1)
     hi = np.stack([rng.randint(1, 80, 900), rng.randint(1, 40, 900)], 1)          # includes users that are not evaluated
-    loader = FullSortEvalLoader('uid', ev, hi, item_num=40, eval_batch_size=40 * 7, device='cpu')
-    assert loader.step == 7
+    loader = FullSortEvalLoader('uid', ev, hi, item_num=40, eval_batch_size=40 * 7, device='cpu', users_per_batch=users_per_batch)
+    assert loader.step == (users_per_batch or 7)
     ev_set, hi_set = {tuple(p) for p in ev.tolist()}, {tuple(p) for p in hi.tolist()}
     users_seen = []
     for inter, (hr, hc), pu, pi in loader:
@@ -178,7 +180,7 @@ def test_full_sort_eval_loader_batches():
         assert got_pos == {p for p in ev_set if p[0] in us}
         assert got_hist == {p for p in hi_set if p[0] in us}
     assert users_seen == sorted({p[0] for p in ev_set})
-    assert len(loader) == (len(users_seen) + 6) // 7
+    assert len(loader) == (len(users_seen) + loader.step - 1) // loader.step
 
 
 def test_alias_table_matches_reference_construction():
