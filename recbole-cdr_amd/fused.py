@@ -204,6 +204,8 @@ class FusedMapStep:
         t_send = [int(c) for c in allc[rank][:G]]
         t_recv = [int(allc[r][rank]) for r in range(G)]
         n_global = sum(int(allc[r][G]) for r in range(G))
+        if n_global == 0:                          # nothing anywhere: no zero-byte all-to-all either
+            return send, 0
         return _a2a(send, t_send, t_recv, self.group), n_global
 
     def step(self, idx):
