@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 14
+#define CDR_ABI_VERSION 15
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -58,6 +58,9 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_BPR_GRAD_FROM_DIFF 9
 #define CDR_TAG_POINT_PARTIAL_DOT 10
 #define CDR_TAG_POINT_GRAD_FROM_DOT 11
+#define CDR_TAG_CONET_FWD 12           /* conet_fwd_kernel: gather + every cross unit + output unit + BCE */
+#define CDR_TAG_CONET_BWD 13           /* conet_bwd_kernel: data gradients of the towers */
+#define CDR_TAG_CONET_WGRAD 14         /* conet_wgrad_kernel: weight gradients, one wave per (tile, row chunk) */
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
 
@@ -201,6 +204,32 @@ int cdr_bce_prob_bwd(void* stream, const float* p, const float* y, int64_t n, co
 /* torch.norm(W) (Frobenius, conet.py:198-201) and d/dW = grad_out * W / norm */
 int cdr_frobenius_fwd(cdr_ctx* ctx, void* stream, const float* x, int64_t n, float* out1);
 int cdr_frobenius_bwd(void* stream, const float* x, int64_t n, const float* norm, const float* grad_out, float* gx, int accumulate);
+
+/* ---- CoNet towers fused (conet.py:105-203: source_forward + target_forward + BCELoss x2 + reg) -------------------------
+ * One stack of R rows -- rows [0, n_source) are the source batch, the rest the target batch -- runs BOTH towers through the
+ * L cross units  s' = relu(s Ws^T + bs + m (.) (t H^T)),  t' = relu(t Wt^T + bt + m (.) (s H^T))  (conet.py:118-137;
+ * m = 1 where the user -- or item, overlap_users = 0 -- id is < n_overlap, PAD id 0 included), the output unit of the tower
+ * a row belongs to (sigmoid(Linear(d_L, 1)), conet.py:140,179) and nn.BCELoss against label[r]:
+ *   out[1] = BCE(source rows), out[2] = BCE(target rows), out[4 + l] = ||H_l||_F, out[3] = sum_l out[4 + l],
+ *   out[0] = (out[1] + out[2]) + out[3]                                                         (conet.py:195-201)
+ * dims[0..L] = {2 D, mlp_hidden_size...}, every entry a multiple of 4 and <= CDR_CONET_MAX_LAYERS layers; params = host array
+ * of 5 L + 4 device pointers {Ws_l [d_{l+1}, d_l], bs_l, Wt_l, bt_l, H_l} for l < L, then {wo_s [1, d_L], bo_s, wo_t, bo_t}.
+ * The forward keeps what the backward needs: x0 [R, 4 D] (the gathered [s | t] inputs), acts [R, act_width] (post-ReLU
+ * outputs of every layer, act_width = 2 sum_l d_{l+1}), prob [R], maskf [R].
+ * cdr_conet_bwd: gx0 [R, 4 D] = d loss / d x0 (columns [0,D) -> source user table row user[r], [D,2D) -> source item table,
+ * [2D,3D) -> target user table, [3D,4D) -> target item table: scatter with cdr_scatter_add_rows_ld); grads = host array of
+ * 5 L + 4 device pointers laid out as params, every entry overwritten (d||H_l||_F included); gz [R, act_width] is scratch.
+ * No float atomics: partial sums are added in a fixed order.  cdr_conet_plan gives act_width and the workspace size.         */
+#define CDR_CONET_MAX_LAYERS 8
+int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width, size_t* workspace_bytes);
+int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab, const float* ti_tab,
+                  int D, const int64_t* user, const int64_t* item, int64_t R, int64_t n_source, int64_t n_overlap,
+                  int overlap_users, int L, const int* dims, const float* const* params, const float* label,
+                  float* x0, float* acts, float* prob, float* maskf, float* out /* [4 + L] */);
+int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L, const int* dims, const float* const* params,
+                  const float* label, const float* x0, const float* acts, const float* prob, const float* maskf,
+                  const float* out, const float* grad_out /* device scalar or NULL = 1 */, float* gz, float* gx0,
+                  float* const* grads, void* workspace, size_t workspace_bytes);
 
 /* ---- SSCDR helpers (sscdr.py:120-187) -------------------------------------------------------------------------- */
 /* embedding_normalize: len = sum x^2, y = x / (len > 1 ? len : 1)  -- the squared-length quirk is kept */

@@ -1,0 +1,816 @@
+// CoNet towers fused (conet.py:105-203): the whole `source_forward` + `target_forward` + BCE + reg of one step in ONE
+// forward launch, and its backward in three (data gradients, weight gradients by rows, fixed-order reduction).
+//
+// Per step the reference runs, for a stack of R = B_source + B_target rows, both towers through L cross units
+//     s' = relu(s Ws^T + bs + m (.) (t H^T)),   t' = relu(t Wt^T + bt + m (.) (s H^T)),   m = 1 on overlapped rows
+// (four products per layer: 152.6 kFLOP per row at dims [256,64,32,16,8]) -- round 1 served that with 54 generic GEMM
+// launches per step and ran at 1.5 % of the fp32 MFMA roofline.  Here:
+//
+//   conet_fwd_kernel     a workgroup owns 32 rows: gathers the four embedding rows of each (coalesced 512-B segments)
+//                        into LDS as [s | t], then walks the layers with v_mfma_f32_32x32x2_f32 -- activations never
+//                        leave LDS between layers; the first layer's weight fragments stream from L2 (four K steps per
+//                        request so that every 128-B line is consumed while it is hot in L1, next group prefetched under
+//                        the MFMAs), the small later layers' weights are staged in LDS once per workgroup -- output unit,
+//                        sigmoid and the BCE terms in the same pass.  It also stores what the backward needs: x0 [R, 2*d0],
+//                        the post-ReLU activations [R, actw], prob, mask.
+//   conet_bwd_kernel     same 32-row ownership, layers in reverse: gz = g (.) (act > 0) kept in LDS as the MFMA A operand,
+//                        g_in = gz_own W_own + m (.) gz_other H, a wave accumulating up to four 32-column tiles at once
+//                        (one A fragment read feeds 32 MFMAs); gz goes to HBM once (for the weight gradients), the input
+//                        gradient [R, 2*d0] once (for the embedding update).
+//   conet_wgrad_kernel   every weight gradient is gz^T x in, a contraction over the R rows: one WAVE per (pair of 32-row
+//                        m tiles, 32-column n tile, row chunk) accumulating its Ws, Wt and H tiles together, both operands
+//                        read coalesced straight from HBM/L2 (lane = output column, 4 rows per lane per step), bias
+//                        gradients as the A operand's running row sum; partials go to a workspace and
+//                        conet_wgrad_finish_kernel adds them in chunk order (plus d||H||_F) -- no float atomics anywhere:
+//                        the tower backward is bit-reproducible.
+#include <string.h>
+#include "cdr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMaxL = CDR_CONET_MAX_LAYERS;
+constexpr int kRows = 32;                       // rows per workgroup pass = one MFMA M tile
+constexpr int kJobFloats = 6 * 1024 + 128;      // a wgrad job's partial: six 32x32 tiles + four bias rows
+constexpr size_t kLdsBudget = 150 * 1024;
+
+struct conet_net {
+    int L, vec, wlds;                           // wlds: the weights of layers >= 1 are staged in LDS
+    int dims[kMaxL + 1];
+    int act_off[kMaxL + 1];                     // column of layer l's outputs in acts / gz; act_off[L] = row width
+    int wl_off[kMaxL + 1];                      // float offset of layer l's {Ws, Wt, H} block in the LDS weight area (l >= 1)
+    const float* Ws[kMaxL]; const float* bs[kMaxL]; const float* Wt[kMaxL]; const float* bt[kMaxL]; const float* H[kMaxL];
+    const float* wo[2]; const float* bo[2];
+};
+struct conet_grads {
+    float* Ws[kMaxL]; float* bs[kMaxL]; float* Wt[kMaxL]; float* bt[kMaxL]; float* H[kMaxL];
+    float* wo[2]; float* bo[2];
+};
+struct conet_tiles { int ntiles; int off[kMaxL + 1]; };
+
+__device__ __forceinline__ float4 ldw4(const float* p, bool vec) {
+    return vec ? ld4(p) : make_float4(p[0], p[1], p[2], p[3]);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+#ifdef CDR_CONET_PROF
+__device__ long long* g_conet_prof = nullptr;
+#define STAMP(i) do { if (g_conet_prof && blockIdx.x == 0 && threadIdx.x == 0) g_conet_prof[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#define MFMA4(acc, a, b)                                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).y, (b).y, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).z, (b).z, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).w, (b).w, acc, 0, 0, 0)
+#define MF1(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global STORE of
+// the phase (the saved activations / gz / gx0 rows, which nothing in the kernel reads back): ~1.5 us per layer, more than
+// the small layers' MFMA time.  Register results of global LOADS are still waited for by their consumers.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The {Ws, Wt, H} of every layer >= 1 into LDS, rows padded to din + 4 floats (conflict-free 16-B fragment reads).
+__device__ __forceinline__ void stage_weights(const conet_net& net, float* wl) {
+    const bool vec = net.vec != 0;
+    for (int l = 1; l < net.L; ++l) {
+        const int din = net.dims[l], dout = net.dims[l + 1], WS = din + 4, q = din >> 2;
+        for (int mat = 0; mat < 3; ++mat) {
+            const float* src = mat == 0 ? net.Ws[l] : mat == 1 ? net.Wt[l] : net.H[l];
+            float* dst = wl + net.wl_off[l] + mat * dout * WS;
+            for (int e = threadIdx.x; e < dout * q; e += 256) {
+                const int row = e / q, c = e - row * q;
+                st4(dst + row * WS + 4 * c, ldw4(src + (int64_t)row * din + 4 * c, vec));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ forward
+// One cross unit for the workgroup's 32 rows.  Xin [32][2 din + 4] = [s | t] in LDS, Xout likewise; a wave takes
+// (tower, 32-column tile) jobs and keeps two accumulators, the tower's own product and the cross product.
+template <bool WL>
+__device__ __forceinline__ void fwd_layer(const conet_net& net, int l, const float* __restrict__ Xin, float* __restrict__ Xout,
+                                          const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ acts,
+                                          int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int XS = 2 * din + 4, XO = 2 * dout + 4;
+    const int NT = (dout + 31) >> 5, KS = (din + 7) >> 3;
+    const int off = net.act_off[l], actw = net.act_off[net.L];
+    const bool vec = net.vec != 0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int job = wave; job < 2 * NT; job += 4) {
+        const int tower = job / NT, n0 = (job - tower * NT) * 32;
+        const int n = n0 + li;
+        const bool nv = n < dout;
+        const float* xo = Xin + li * XS + (tower ? din : 0);
+        const float* xc = Xin + li * XS + (tower ? 0 : din);
+        f32x16 am = zero16(), ac = zero16();
+        if (WL) {
+            const int WS = din + 4;
+            const float* wm = wl + net.wl_off[l] + (tower ? dout * WS : 0) + (nv ? n : 0) * WS;
+            const float* hc = wl + net.wl_off[l] + 2 * dout * WS + (nv ? n : 0) * WS;
+            for (int s = 0; s < KS; ++s) {
+                const int k = 8 * s + 4 * lh;
+                const bool kv = k < din;
+                const float4 b0 = (kv && nv) ? ld4(wm + k) : z4, b1 = (kv && nv) ? ld4(hc + k) : z4;
+                const float4 a0 = kv ? ld4(xo + k) : z4, a1 = kv ? ld4(xc + k) : z4;
+                MFMA4(am, a0, b0);
+                MFMA4(ac, a1, b1);
+            }
+        } else {
+            // fragments straight from L2: a lane reads 16 B of row n per K step, i.e. a wave touches 32 lines for 32 B each;
+            // asking for four K steps at once consumes every 128-B line while it is hot (one K step per request re-fetched
+            // each line four times through a thrashing L1); the next group is in flight under this group's 32 MFMAs
+            const float* wm = (tower ? net.Wt[l] : net.Ws[l]) + (int64_t)(nv ? n : 0) * din;
+            const float* hc = net.H[l] + (int64_t)(nv ? n : 0) * din;
+            const int KG = (KS + 3) >> 2;
+            float4 nm[4], nc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 8 * j + 4 * lh;
+                const bool ok = nv && k < din;
+                nm[j] = ok ? ldw4(wm + k, vec) : z4;
+                nc[j] = ok ? ldw4(hc + k, vec) : z4;
+            }
+            for (int g = 0; g < KG; ++g) {
+                float4 cm[4], cc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cm[j] = nm[j]; cc[j] = nc[j]; }
+                if (g + 1 < KG) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 8 * (4 * (g + 1) + j) + 4 * lh;
+                        const bool ok = nv && k < din;
+                        nm[j] = ok ? ldw4(wm + k, vec) : z4;
+                        nc[j] = ok ? ldw4(hc + k, vec) : z4;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 8 * (4 * g + j) + 4 * lh;
+                    const bool kv = k < din;
+                    const float4 a0 = kv ? ld4(xo + k) : z4, a1 = kv ? ld4(xc + k) : z4;
+                    MFMA4(am, a0, cm[j]);
+                    MFMA4(ac, a1, cc[j]);
+                }
+            }
+        }
+        if (nv) {
+            const float bv = (tower ? net.bt[l] : net.bs[l])[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = am[r] + bv;
+                if (mrow[row] != 0.f) v += ac[r];                      // conet.py:127-129 / :132-134
+                v = v > 0.f ? v : 0.f;
+                Xout[row * XO + tower * dout + n] = v;
+                if (row0 + row < R) acts[(row0 + row) * actw + off + tower * dout + n] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const float* __restrict__ su, const float* __restrict__ si,
+                                                        const float* __restrict__ tu, const float* __restrict__ ti, int D,
+                                                        const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+                                                        int64_t R, int64_t n_source, int64_t n_overlap, int overlap_users,
+                                                        const float* __restrict__ label, int strideA, int strideB,
+                                                        float* __restrict__ x0, float* __restrict__ acts, float* __restrict__ prob,
+                                                        float* __restrict__ maskf, double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float mrow[kRows];
+    __shared__ double red[2 * 4];
+    float* bufA = smem;                                  // inputs of the even layers
+    float* bufB = smem + kRows * strideA;                // inputs of the odd layers
+    float* wl = bufB + kRows * strideB;                  // weights of layers >= 1 (when net.wlds)
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int D4 = D >> 2;
+    double lacc0 = 0.0, lacc1 = 0.0;
+    if (net.wlds) stage_weights(net, wl);                // visible after the first gather's barrier
+    const int64_t nrb = (R + kRows - 1) / kRows;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        STAMP(0);
+        {   // ---- gather [su | si | tu | ti] of 32 rows: 8 threads per row, 16 B each, 128 B contiguous per octet
+            const int row = t >> 3, c0 = t & 7;
+            const int64_t g = rb * kRows + row;
+            const bool valid = g < R;
+            const int64_t gc = valid ? g : R - 1;
+            const int64_t uid = user[gc], iid = item[gc];
+            float* xr = bufA + row * (4 * D + 4);
+            for (int c = c0; c < D4; c += 8) {
+                const float4 a = ld4(su + uid * D + 4 * c), b = ld4(si + iid * D + 4 * c);
+                const float4 e = ld4(tu + uid * D + 4 * c), f = ld4(ti + iid * D + 4 * c);
+                st4(xr + 4 * c, a); st4(xr + D + 4 * c, b); st4(xr + 2 * D + 4 * c, e); st4(xr + 3 * D + 4 * c, f);
+                if (valid) {
+                    float* xg = x0 + g * (4 * (int64_t)D);
+                    st4(xg + 4 * c, a); st4(xg + D + 4 * c, b); st4(xg + 2 * D + 4 * c, e); st4(xg + 3 * D + 4 * c, f);
+                }
+            }
+            if (c0 == 0) {
+                const float m = ((overlap_users ? uid : iid) < n_overlap) ? 1.f : 0.f;     // PAD id 0 counts
+                mrow[row] = m;
+                if (valid) maskf[g] = m;
+            }
+        }
+        lds_barrier();
+        STAMP(1);
+        for (int l = 0; l < net.L; ++l) {
+            const float* Xin = (l & 1) ? bufB : bufA;
+            float* Xout = (l & 1) ? bufA : bufB;
+            if (l > 0 && net.wlds) fwd_layer<true>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            else fwd_layer<false>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            lds_barrier();
+            STAMP(2 + l);
+        }
+        if (t < kRows) {   // ---- output unit + sigmoid + BCE term of the tower this row belongs to (conet.py:140,179,195-196)
+            const int64_t g = rb * kRows + t;
+            if (g < R) {
+                const int tower = g >= n_source ? 1 : 0;
+                const int dL = net.dims[net.L];
+                const float* h = ((net.L & 1) ? bufB : bufA) + t * (2 * dL + 4) + tower * dL;
+                const float* w = net.wo[tower];
+                float z = 0.f;
+                for (int j = 0; j < dL; ++j) z += h[j] * w[j];
+                z += net.bo[tower][0];
+                const float p = 1.0f / (1.0f + expf(-z));
+                prob[g] = p;
+                const float y = label[g];
+                const double term = (double)((y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f));
+                if (tower) lacc1 += term; else lacc0 += term;
+            }
+        }
+        lds_barrier();
+        STAMP(2 + net.L);
+    }
+    double lacc[2] = {lacc0, lacc1};
+    block_sum_d<2>(lacc, red);
+    if (t == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = lacc[0]; o[1] = lacc[1];
+    }
+}
+
+// out = {total, bce_source, bce_target, reg, ||H_0||_F .. ||H_{L-1}||_F}
+__global__ __launch_bounds__(256) void conet_fwd_finish_kernel(conet_net net, const double* __restrict__ partials, int nblocks,
+                                                               int64_t n_source, int64_t R, float* __restrict__ out) {
+    __shared__ double red[(2 + kMaxL) * 4];
+    double acc[2 + kMaxL];
+#pragma unroll
+    for (int i = 0; i < 2 + kMaxL; ++i) acc[i] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1];
+    }
+#pragma unroll
+    for (int l = 0; l < kMaxL; ++l) {                         // sum H_l^2: fp64, thread-strided then one fixed-order block sum
+        if (l < net.L) {
+            const int n = net.dims[l] * net.dims[l + 1];
+            const float* h = net.H[l];
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            int e = threadIdx.x;
+            for (; e + 768 < n; e += 1024) {
+                const float a = h[e], b = h[e + 256], c = h[e + 512], d = h[e + 768];
+                q0 += (double)a * a; q1 += (double)b * b; q2 += (double)c * c; q3 += (double)d * d;
+            }
+            for (; e < n; e += 256) q0 += (double)h[e] * (double)h[e];
+            acc[2 + l] = (q0 + q1) + (q2 + q3);
+        }
+    }
+    block_sum_d<2 + kMaxL>(acc, red);
+    if (threadIdx.x == 0) {
+        float reg = 0.f;
+        for (int l = 0; l < net.L; ++l) {                     // conet.py:198-201: un-weighted sum of ||H_l||_F
+            const float nv = (float)sqrt(acc[2 + l]);
+            out[4 + l] = nv;
+            reg += nv;
+        }
+        const float ls = (float)(acc[0] / (double)n_source), lt = (float)(acc[1] / (double)(R - n_source));
+        out[1] = ls; out[2] = lt; out[3] = reg;
+        out[0] = (ls + lt) + reg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward (data)
+// g_in of one cross unit: Gl [32][2 dout + 4] = gz of both towers in LDS.  A wave takes (tower, group of <= 4 column tiles)
+// units: the two A fragments of a K step feed 8 accumulators; the B values (W[k][n], lane = n: coalesced rows) of the
+// next K step are in flight under the current step's MFMAs.
+template <bool WL>
+__device__ __forceinline__ void bwd_layer(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ Gn,
+                                          const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ gx0,
+                                          int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4;
+    const int NT = (din + 31) >> 5, NG = (NT + 3) >> 2, KS = (dout + 7) >> 3;
+    const int ldw = WL ? din + 4 : din;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = wave; u < 2 * NG; u += 4) {
+        const int tower = u / NG, t0 = (u - tower * NG) * 4;
+        const float* Wm = WL ? wl + net.wl_off[l] + (tower ? dout * ldw : 0) : (tower ? net.Wt[l] : net.Ws[l]);
+        const float* Hm = WL ? wl + net.wl_off[l] + 2 * dout * ldw : net.H[l];
+        const float* ao = Gl + li * GS + (tower ? dout : 0);
+        const float* ax = Gl + li * GS + (tower ? 0 : dout);
+        int ncol[4]; bool nv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ncol[j] = (t0 + j) * 32 + li; nv[j] = ncol[j] < din; }
+        f32x16 am[4], ac[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { am[j] = zero16(); ac[j] = zero16(); }
+        float4 nm[4], nc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            nm[j] = nc[j] = z4;
+            const int k = 4 * lh;
+            if (nv[j] && k < dout) {                          // dout % 4 == 0: a chunk of 4 k is all in or all out
+                const float* w0 = Wm + k * ldw + ncol[j];
+                const float* h0 = Hm + k * ldw + ncol[j];
+                nm[j] = make_float4(w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]);
+                nc[j] = make_float4(h0[0], h0[ldw], h0[2 * ldw], h0[3 * ldw]);
+            }
+        }
+        for (int s = 0; s < KS; ++s) {
+            const int k = 8 * s + 4 * lh;
+            const bool kv = k < dout;
+            float4 cm[4], cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cm[j] = nm[j]; cc[j] = nc[j]; }
+            const int kn = k + 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nm[j] = nc[j] = z4;
+                if (nv[j] && kn < dout) {
+                    const float* w0 = Wm + kn * ldw + ncol[j];
+                    const float* h0 = Hm + kn * ldw + ncol[j];
+                    nm[j] = make_float4(w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]);
+                    nc[j] = make_float4(h0[0], h0[ldw], h0[2 * ldw], h0[3 * ldw]);
+                }
+            }
+            const float4 a0 = kv ? ld4(ao + k) : z4, a1 = kv ? ld4(ax + k) : z4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (t0 + j < NT) {                            // wave-uniform
+                    MFMA4(am[j], a0, cm[j]);
+                    MFMA4(ac[j], a1, cc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!nv[j]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = am[j][r];
+                if (mrow[row] != 0.f) v += ac[j][r];
+                if (l > 0) Gn[row * GN + tower * din + ncol[j]] = v;
+                else if (row0 + row < R) gx0[(row0 + row) * (2 * (int64_t)din) + tower * din + ncol[j]] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R, int64_t n_source, const float* __restrict__ label,
+                                                        const float* __restrict__ prob, const float* __restrict__ maskf,
+                                                        const float* __restrict__ acts, const float* __restrict__ grad_out,
+                                                        int strideG0, int strideG1, float* __restrict__ gz, float* __restrict__ gx0,
+                                                        float* __restrict__ ou_part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float mrow[kRows], dzrow[kRows];
+    __shared__ int trow[kRows];
+    float* G0 = smem;                                    // output gradients of the even layers
+    float* G1 = smem + kRows * strideG0;                 // ... of the odd layers
+    float* hl = G1 + kRows * strideG1;                   // last layer's activations of the 32 rows [32][2 dL]
+    float* wl = hl + kRows * 2 * net.dims[net.L];        // weights of layers >= 1 (when net.wlds)
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int L = net.L, actw = net.act_off[L], dL = net.dims[L];
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    float ou_acc = 0.f;
+    if (net.wlds) stage_weights(net, wl);
+    const int64_t nrb = (R + kRows - 1) / kRows;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        STAMP(16);
+        if (t < kRows) {
+            const int64_t g = rb * kRows + t;
+            float dz = 0.f, m = 0.f;
+            int tower = 0;
+            if (g < R) {
+                tower = g >= n_source ? 1 : 0;
+                const float p = prob[g], y = label[g];
+                const float nd = (float)(tower ? R - n_source : n_source);
+                const float gp = (go / nd) * (p - y) / fmaxf((1.0f - p) * p, 1e-12f);     // BCELoss backward (mean)
+                dz = (gp * (1.0f - p)) * p;                                                // sigmoid backward
+                m = maskf[g];
+            }
+            dzrow[t] = dz; mrow[t] = m; trow[t] = tower;
+        }
+        for (int e = t; e < kRows * 2 * dL; e += 256) {      // the output units' inputs, for their weight gradients
+            const int row = e / (2 * dL), c = e - row * 2 * dL;
+            const int64_t g = rb * kRows + row;
+            hl[e] = g < R ? acts[g * actw + net.act_off[L - 1] + c] : 0.f;
+        }
+        lds_barrier();
+        STAMP(17);
+        {
+            float* Gl = ((L - 1) & 1) ? G1 : G0;
+            const int GS = 2 * dL + 4;
+            for (int e = t; e < kRows * 2 * dL; e += 256) {
+                const int row = e / (2 * dL), c = e - row * 2 * dL;
+                const int tower = c >= dL ? 1 : 0, j = c - tower * dL;
+                Gl[row * GS + c] = (trow[row] == tower) ? dzrow[row] * net.wo[tower][j] : 0.f;
+            }
+            if (t < 2 * (dL + 1)) {                          // output-unit gradients of this block's rows, in row order
+                const int tower = t / (dL + 1), jj = t - tower * (dL + 1);
+                for (int row = 0; row < kRows; ++row)
+                    if (trow[row] == tower) ou_acc += dzrow[row] * (jj < dL ? hl[row * 2 * dL + tower * dL + jj] : 1.0f);
+            }
+        }
+        lds_barrier();
+        STAMP(18);
+        for (int l = L - 1; l >= 0; --l) {
+            const int dout = net.dims[l + 1];
+            const int GS = 2 * dout + 4;
+            float* Gl = (l & 1) ? G1 : G0;
+            float* Gn = (l & 1) ? G0 : G1;
+            const int off = net.act_off[l];
+            const int q = (2 * dout) >> 2;                   // float4 per row: widths are multiples of 4, rows 16-B aligned
+            for (int e = t; e < kRows * q; e += 256) {       // ReLU backward; gz kept for the weight gradients
+                const int row = e / q, c = 4 * (e - row * q);
+                const int64_t g = rb * kRows + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < R) {
+                    const float4 a = ld4(acts + g * actw + off + c), gg = ld4(Gl + row * GS + c);
+                    v = make_float4(a.x > 0.f ? gg.x : 0.f, a.y > 0.f ? gg.y : 0.f, a.z > 0.f ? gg.z : 0.f, a.w > 0.f ? gg.w : 0.f);
+                    st4(gz + g * actw + off + c, v);
+                }
+                st4(Gl + row * GS + c, v);
+            }
+            lds_barrier();
+            STAMP(19 + 2 * (L - 1 - l));
+            if (l > 0 && net.wlds) bwd_layer<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            else bwd_layer<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            lds_barrier();
+            STAMP(20 + 2 * (L - 1 - l));
+        }
+    }
+    if (t < 2 * (dL + 1)) ou_part[(size_t)blockIdx.x * 2 * (dL + 1) + t] = ou_acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------ weight gradients
+// One WAVE per (layer, pair of 32-row m tiles, 32-column n tile, chunk of batch rows): it accumulates the Ws, Wt and H tiles
+// of its m tiles at once, so a K step of 8 batch rows costs 16 + 8 operand loads for 32 MFMAs (the first version, one
+// tile per wave, loaded 8 per 4 and re-read every operand panel for every tile: 105 us + a 146 us serial reduction).
+struct job_id { int l, mp, nt; };
+__device__ __forceinline__ job_id decode_job(const conet_net& net, const conet_tiles& jl, int jb) {
+    job_id d;
+    d.l = 0;
+    for (int l = 1; l < net.L; ++l) if (jb >= jl.off[l]) d.l = l;
+    const int local = jb - jl.off[d.l];
+    const int NT = (net.dims[d.l] + 31) >> 5;
+    d.mp = local / NT;
+    d.nt = local - d.mp * NT;
+    return d;
+}
+
+struct wg_ops { float s0[4], t0[4], s1[4], t1[4], xs[4], xt[4], mk[4]; };
+
+__global__ __launch_bounds__(256) void conet_wgrad_kernel(conet_net net, conet_tiles jl, int64_t R, int64_t kc, int nsplit,
+                                                          const float* __restrict__ x0, const float* __restrict__ acts,
+                                                          const float* __restrict__ gz, const float* __restrict__ maskf,
+                                                          float* __restrict__ wpart) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int64_t job = (int64_t)blockIdx.x * 4 + wave;
+    if (job >= (int64_t)jl.ntiles * nsplit) return;
+    const int jb = (int)(job % jl.ntiles), sp = (int)(job / jl.ntiles);
+    const job_id d = decode_job(net, jl, jb);
+    const int din = net.dims[d.l], dout = net.dims[d.l + 1];
+    const int actw = net.act_off[net.L];
+    const float* in = d.l == 0 ? x0 : acts + net.act_off[d.l - 1];
+    const int64_t ldin = d.l == 0 ? 2 * din : actw;
+    const int m0 = d.mp * 64 + li, m1 = m0 + 32, n = d.nt * 32 + li;
+    const bool two = d.mp * 64 + 32 < dout;                  // wave-uniform: the job has a second m tile
+    const bool mv0 = m0 < dout, mv1 = two && m1 < dout, nv = n < din;
+    const float* gs0 = gz + net.act_off[d.l] + (mv0 ? m0 : 0);          // tower s columns; tower t at + dout
+    const float* gs1 = gz + net.act_off[d.l] + (mv1 ? m1 : 0);
+    const float* bsp = in + (nv ? n : 0);                               // s_in column n; t_in at + din
+    const int64_t r_begin = (int64_t)sp * kc, r_end = (r_begin + kc < R) ? r_begin + kc : R;
+    f32x16 aWs0 = zero16(), aWt0 = zero16(), aH0 = zero16(), aWs1 = zero16(), aWt1 = zero16(), aH1 = zero16();
+    float bs0 = 0.f, bt0 = 0.f, bs1 = 0.f, bt1 = 0.f;
+    auto load = [&](int64_t r0, wg_ops& o) {
+        const int64_t rr = r0 + 4 * lh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t row = rr + c;
+            const bool rv = row < r_end;
+            const int64_t rc = rv ? row : r_begin;
+            o.mk[c] = rv ? maskf[rc] : 0.f;
+            o.s0[c] = (rv && mv0) ? gs0[rc * actw] : 0.f;
+            o.t0[c] = (rv && mv0) ? gs0[rc * actw + dout] : 0.f;
+            o.xs[c] = (rv && nv) ? bsp[rc * ldin] : 0.f;
+            o.xt[c] = (rv && nv) ? bsp[rc * ldin + din] : 0.f;
+            o.s1[c] = (rv && mv1) ? gs1[rc * actw] : 0.f;
+            o.t1[c] = (rv && mv1) ? gs1[rc * actw + dout] : 0.f;
+        }
+    };
+    wg_ops nx;
+    load(r_begin, nx);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 8) {
+        const wg_ops cu = nx;
+        if (r0 + 8 < r_end) load(r0 + 8, nx);                // next 8 rows in flight under this step's MFMAs
+        // Ws += gz_s^T s_in ; Wt += gz_t^T t_in ; H += (m gz_s)^T t_in + (m gz_t)^T s_in      (conet.py:127-134 transposed)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ms = cu.mk[c] != 0.f ? cu.s0[c] : 0.f, mt = cu.mk[c] != 0.f ? cu.t0[c] : 0.f;
+            MF1(aWs0, cu.s0[c], cu.xs[c]);
+            MF1(aWt0, cu.t0[c], cu.xt[c]);
+            MF1(aH0, ms, cu.xt[c]);
+            MF1(aH0, mt, cu.xs[c]);
+        }
+        bs0 += (cu.s0[0] + cu.s0[1]) + (cu.s0[2] + cu.s0[3]);
+        bt0 += (cu.t0[0] + cu.t0[1]) + (cu.t0[2] + cu.t0[3]);
+        if (two) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ms = cu.mk[c] != 0.f ? cu.s1[c] : 0.f, mt = cu.mk[c] != 0.f ? cu.t1[c] : 0.f;
+                MF1(aWs1, cu.s1[c], cu.xs[c]);
+                MF1(aWt1, cu.t1[c], cu.xt[c]);
+                MF1(aH1, ms, cu.xt[c]);
+                MF1(aH1, mt, cu.xs[c]);
+            }
+            bs1 += (cu.s1[0] + cu.s1[1]) + (cu.s1[2] + cu.s1[3]);
+            bt1 += (cu.t1[0] + cu.t1[1]) + (cu.t1[2] + cu.t1[3]);
+        }
+    }
+    // partial of this (job, chunk): six 32x32 tiles in accumulator order {m tile, {Ws, Wt, H}}, then four bias rows
+    float* o = wpart + ((size_t)sp * jl.ntiles + jb) * kJobFloats;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o[0 * 1024 + r * 64 + lane] = aWs0[r];
+        o[1 * 1024 + r * 64 + lane] = aWt0[r];
+        o[2 * 1024 + r * 64 + lane] = aH0[r];
+    }
+    if (two) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[3 * 1024 + r * 64 + lane] = aWs1[r];
+            o[4 * 1024 + r * 64 + lane] = aWt1[r];
+            o[5 * 1024 + r * 64 + lane] = aH1[r];
+        }
+    }
+    if (d.nt == 0) {                                           // bias gradients = column sums of gz: the A operand's running sum
+        const float a = bs0 + __shfl_xor(bs0, 32, 64), b = bt0 + __shfl_xor(bt0, 32, 64);
+        const float c = bs1 + __shfl_xor(bs1, 32, 64), e = bt1 + __shfl_xor(bt1, 32, 64);
+        if (lh == 0) { o[6144 + li] = a; o[6144 + 32 + li] = b; o[6144 + 64 + li] = c; o[6144 + 96 + li] = e; }
+    }
+}
+
+// One THREAD per output element: the chunk partials added in chunk order (fixed order, independent loads), plus d||H||_F.
+__global__ __launch_bounds__(256) void conet_wgrad_finish_kernel(conet_net net, conet_grads gr, conet_tiles jl, int nsplit,
+                                                                 const float* __restrict__ wpart, const float* __restrict__ ou_part,
+                                                                 int n_ou_blocks, const float* __restrict__ out,
+                                                                 const float* __restrict__ grad_out) {
+    constexpr int kBlocksPerJob = (kJobFloats + 255) / 256;
+    __shared__ float ou_sh[256];
+    const int jb = blockIdx.x / kBlocksPerJob;
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    if (jb >= jl.ntiles) {                                    // output units: block partials added in a fixed two-level order
+        const int dL = net.dims[net.L], w = 2 * (dL + 1), nch = 256 / w;
+        const int j = threadIdx.x % w, ch = threadIdx.x / w;
+        float s = 0.f;
+        if (ch < nch) for (int b = ch; b < n_ou_blocks; b += nch) s += ou_part[(size_t)b * w + j];
+        ou_sh[threadIdx.x] = s;
+        __syncthreads();
+        if ((int)threadIdx.x < w) {
+            float tot = 0.f;
+            for (int c = 0; c < nch; ++c) tot += ou_sh[c * w + j];
+            const int tower = j / (dL + 1), jj = j - tower * (dL + 1);
+            if (jj < dL) gr.wo[tower][jj] = tot; else gr.bo[tower][0] = tot;
+        }
+        return;
+    }
+    const int e = (blockIdx.x - jb * kBlocksPerJob) * 256 + threadIdx.x;
+    if (e >= kJobFloats) return;
+    const job_id d = decode_job(net, jl, jb);
+    const int din = net.dims[d.l], dout = net.dims[d.l + 1];
+    int m, n = 0, mat;
+    if (e < 6144) {
+        const int t6 = e >> 10, idx = e & 1023, r = idx >> 6, lane = idx & 63;
+        mat = t6 % 3;
+        m = d.mp * 64 + (t6 / 3) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        n = d.nt * 32 + (lane & 31);
+        if (m >= dout || n >= din) return;
+    } else {
+        const int bi = e - 6144;
+        if (d.nt != 0 || bi >= 128) return;
+        mat = 3 + ((bi >> 5) & 1);                            // 3: bs, 4: bt
+        m = d.mp * 64 + (bi >> 6) * 32 + (bi & 31);
+        if (m >= dout) return;
+    }
+    const float* base = wpart + (size_t)jb * kJobFloats + e;
+    const size_t stride = (size_t)jl.ntiles * kJobFloats;
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = base[(size_t)(sp + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; sp < nsplit; ++sp) s += base[(size_t)sp * stride];
+    if (mat == 2) {
+        const float nv = out[4 + d.l];                        // d||H||_F / dH = H / ||H||_F (0 at 0, as torch.norm's backward)
+        if (nv > 0.f) s += (go / nv) * net.H[d.l][(int64_t)m * din + n];
+        gr.H[d.l][(int64_t)m * din + n] = s;
+    } else if (mat == 0) gr.Ws[d.l][(int64_t)m * din + n] = s;
+    else if (mat == 1) gr.Wt[d.l][(int64_t)m * din + n] = s;
+    else if (mat == 3) gr.bs[d.l][m] = s;
+    else gr.bt[d.l][m] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------ host side
+struct lds_plan { int strideA, strideB, strideG0, strideG1; size_t wl_floats, fwd_bytes, bwd_bytes; };
+
+int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* const* params) {
+    if (L < 1 || L > kMaxL || !dims || !params) return 0;
+    net.L = L;
+    net.vec = 1;
+    int off = 0;
+    for (int l = 0; l <= L; ++l) {
+        if (dims[l] <= 0 || (dims[l] & 3)) return 0;                 // float4 chunks along every contraction index
+        net.dims[l] = dims[l];
+    }
+    for (int l = 0; l < L; ++l) { net.act_off[l] = off; off += 2 * dims[l + 1]; }
+    net.act_off[L] = off;
+    for (int l = L + 1; l <= kMaxL; ++l) { net.dims[l] = 0; net.act_off[l] = off; }
+    for (int l = 0; l < kMaxL; ++l) { net.Ws[l] = net.bs[l] = net.Wt[l] = net.bt[l] = net.H[l] = nullptr; }
+    for (int l = 0; l < L; ++l) {
+        net.Ws[l] = params[5 * l]; net.bs[l] = params[5 * l + 1]; net.Wt[l] = params[5 * l + 2]; net.bt[l] = params[5 * l + 3];
+        net.H[l] = params[5 * l + 4];
+        if (!net.Ws[l] || !net.bs[l] || !net.Wt[l] || !net.bt[l] || !net.H[l]) return 0;
+        if (((uintptr_t)net.Ws[l] | (uintptr_t)net.Wt[l] | (uintptr_t)net.H[l]) & 15) net.vec = 0;
+    }
+    net.wo[0] = params[5 * L]; net.bo[0] = params[5 * L + 1]; net.wo[1] = params[5 * L + 2]; net.bo[1] = params[5 * L + 3];
+    if (!net.wo[0] || !net.bo[0] || !net.wo[1] || !net.bo[1]) return 0;
+    if (2 * (dims[L] + 1) > 256) return 0;
+    // LDS: forward = two ping-pong activation buffers (layer l reads buffer l & 1); backward = two gradient buffers (layer l's
+    // output gradient in buffer l & 1) + the last activations; both + the staged weights of layers >= 1 when they fit
+    int ea = 0, oa = 0, ge = 0, go = 0;
+    for (int l = 0; l <= L; ++l) { int& m = (l & 1) ? oa : ea; if (dims[l] > m) m = dims[l]; }
+    for (int l = 0; l < L; ++l) { int& m = (l & 1) ? go : ge; if (dims[l + 1] > m) m = dims[l + 1]; }
+    lp.strideA = 2 * ea + 4; lp.strideB = 2 * oa + 4; lp.strideG0 = 2 * ge + 4; lp.strideG1 = 2 * go + 4;
+    size_t wl = 0;
+    for (int l = 0; l <= kMaxL; ++l) net.wl_off[l] = 0;
+    for (int l = 1; l < L; ++l) { net.wl_off[l] = (int)wl; wl += (size_t)3 * dims[l + 1] * (dims[l] + 4); }
+    net.wl_off[L] = (int)wl;
+    const size_t fwd = (size_t)kRows * (lp.strideA + lp.strideB) * sizeof(float);
+    const size_t bwd = (size_t)kRows * (lp.strideG0 + lp.strideG1 + 2 * dims[L]) * sizeof(float);
+    if (fwd > kLdsBudget || bwd > kLdsBudget) return 0;
+    net.wlds = (L > 1 && fwd + wl * sizeof(float) <= kLdsBudget && bwd + wl * sizeof(float) <= kLdsBudget) ? 1 : 0;
+    lp.wl_floats = net.wlds ? wl : 0;
+    lp.fwd_bytes = fwd + lp.wl_floats * sizeof(float);
+    lp.bwd_bytes = bwd + lp.wl_floats * sizeof(float);
+    return 1;
+}
+
+void fill_tiles(const conet_net& net, conet_tiles& tl) {        // wgrad jobs: (layer, pair of m tiles, n tile)
+    int n = 0;
+    for (int l = 0; l < net.L; ++l) {
+        tl.off[l] = n;
+        n += ((net.dims[l + 1] + 63) / 64) * ((net.dims[l] + 31) / 32);
+    }
+    for (int l = net.L; l <= kMaxL; ++l) tl.off[l] = n;
+    tl.ntiles = n;
+}
+
+inline int64_t rows_grid(int64_t R) {
+    int64_t g = (R + kRows - 1) / kRows;
+    if (g > 2048) g = 2048;                      // <= CDR_MAX_PARTIAL_BLOCKS; 8 resident blocks per CU at most
+    return g < 1 ? 1 : g;
+}
+
+inline void split_plan(int ntiles, int64_t R, int* nsplit, int64_t* kc) {
+    int64_t ns = (1024 + ntiles - 1) / ntiles;                 // one wave per SIMD of the chip
+    const int64_t max_ns = (R + 63) / 64;
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    int64_t c = (R + ns - 1) / ns;
+    c = (c + 7) & ~(int64_t)7;
+    *kc = c;
+    *nsplit = (int)((R + c - 1) / c);
+}
+
+int lds_opt_in(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return CDR_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { cdr_set_error("cdr_conet: %zu B of LDS refused: %s", bytes, hipGetErrorString(e)); return (int)e; }
+    return CDR_OK;
+}
+
+}  // namespace
+
+#ifdef CDR_CONET_PROF
+extern "C" int cdr_conet_debug_prof(long long* dev_buf) {
+    CDR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conet_prof), &dev_buf, sizeof(dev_buf)));
+    return CDR_OK;
+}
+#endif
+
+extern "C" int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width, size_t* workspace_bytes) {
+    CDR_CHECK_ARG(dims && act_width && workspace_bytes && R > 0);
+    conet_net net;
+    lds_plan lp;
+    const float* dummy[5 * kMaxL + 4];
+    for (auto& p : dummy) p = (const float*)16;
+    if (!fill_net(net, lp, L, dims, dummy)) { cdr_set_error("cdr_conet_plan: unsupported layer sizes"); return CDR_EINVAL; }
+    conet_tiles tl;
+    fill_tiles(net, tl);
+    int nsplit; int64_t kc;
+    split_plan(tl.ntiles, R, &nsplit, &kc);
+    *act_width = net.act_off[L];
+    const size_t wpart = (size_t)tl.ntiles * nsplit * kJobFloats * sizeof(float);
+    const size_t ou = (size_t)rows_grid(R) * 2 * (dims[L] + 1) * sizeof(float);
+    *workspace_bytes = ((wpart + 255) & ~(size_t)255) + ou;
+    return CDR_OK;
+}
+
+extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab,
+                             const float* ti_tab, int D, const int64_t* user, const int64_t* item, int64_t R, int64_t n_source,
+                             int64_t n_overlap, int overlap_users, int L, const int* dims, const float* const* params,
+                             const float* label, float* x0, float* acts, float* prob, float* maskf, float* out) {
+    CDR_CHECK_ARG(ctx && su_tab && si_tab && tu_tab && ti_tab && user && item && label && x0 && acts && prob && maskf && out);
+    CDR_CHECK_ARG(R > 0 && n_source >= 0 && n_source <= R && D > 0 && (D & 3) == 0);
+    conet_net net;
+    lds_plan lp;
+    if (!fill_net(net, lp, L, dims, params) || dims[0] != 2 * D) { cdr_set_error("cdr_conet_fwd: unsupported layer sizes"); return CDR_EINVAL; }
+    int rc = lds_opt_in((const void*)conet_fwd_kernel, lp.fwd_bytes);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)rows_grid(R);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_CONET_FWD, s);
+        conet_fwd_kernel<<<dim3(grid), dim3(256), lp.fwd_bytes, s>>>(net, su_tab, si_tab, tu_tab, ti_tab, D, user, item, R, n_source,
+                                                                     n_overlap, overlap_users, label, lp.strideA, lp.strideB, x0, acts,
+                                                                     prob, maskf, ctx->partials);
+    }
+    CDR_LAUNCH_CHECK();
+    conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(net, ctx->partials, grid, n_source, R, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L, const int* dims,
+                             const float* const* params, const float* label, const float* x0, const float* acts, const float* prob,
+                             const float* maskf, const float* out, const float* grad_out, float* gz, float* gx0,
+                             float* const* grads, void* workspace, size_t workspace_bytes) {
+    CDR_CHECK_ARG(ctx && label && x0 && acts && prob && maskf && out && gz && gx0 && grads && workspace);
+    CDR_CHECK_ARG(R > 0 && n_source >= 0 && n_source <= R);
+    conet_net net;
+    lds_plan lp;
+    if (!fill_net(net, lp, L, dims, params)) { cdr_set_error("cdr_conet_bwd: unsupported layer sizes"); return CDR_EINVAL; }
+    int aw = 0; size_t need = 0;
+    int rc = cdr_conet_plan(L, dims, R, &aw, &need);
+    if (rc) return rc;
+    CDR_CHECK_ARG(workspace_bytes >= need);
+    conet_grads gr;
+    memset(&gr, 0, sizeof(gr));
+    for (int l = 0; l < L; ++l) {
+        gr.Ws[l] = grads[5 * l]; gr.bs[l] = grads[5 * l + 1]; gr.Wt[l] = grads[5 * l + 2]; gr.bt[l] = grads[5 * l + 3]; gr.H[l] = grads[5 * l + 4];
+        CDR_CHECK_ARG(gr.Ws[l] && gr.bs[l] && gr.Wt[l] && gr.bt[l] && gr.H[l]);
+    }
+    gr.wo[0] = grads[5 * L]; gr.bo[0] = grads[5 * L + 1]; gr.wo[1] = grads[5 * L + 2]; gr.bo[1] = grads[5 * L + 3];
+    CDR_CHECK_ARG(gr.wo[0] && gr.bo[0] && gr.wo[1] && gr.bo[1]);
+    conet_tiles tl;
+    fill_tiles(net, tl);
+    int nsplit; int64_t kc;
+    split_plan(tl.ntiles, R, &nsplit, &kc);
+    float* wpart = (float*)workspace;
+    const size_t wpart_bytes = ((size_t)tl.ntiles * nsplit * kJobFloats * sizeof(float) + 255) & ~(size_t)255;
+    float* ou_part = (float*)((char*)workspace + wpart_bytes);
+    rc = lds_opt_in((const void*)conet_bwd_kernel, lp.bwd_bytes);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)rows_grid(R);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_CONET_BWD, s);
+        conet_bwd_kernel<<<dim3(grid), dim3(256), lp.bwd_bytes, s>>>(net, R, n_source, label, prob, maskf, acts, grad_out, lp.strideG0,
+                                                                     lp.strideG1, gz, gx0, ou_part);
+    }
+    CDR_LAUNCH_CHECK();
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_CONET_WGRAD, s);
+        const int64_t jobs = (int64_t)tl.ntiles * nsplit;
+        conet_wgrad_kernel<<<dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, s>>>(net, tl, R, kc, nsplit, x0, acts, gz, maskf, wpart);
+    }
+    CDR_LAUNCH_CHECK();
+    conet_wgrad_finish_kernel<<<dim3((unsigned)(tl.ntiles * ((kJobFloats + 255) / 256) + 1)), dim3(256), 0, s>>>(
+        net, gr, tl, nsplit, wpart, ou_part, grid, out, grad_out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -395,6 +395,74 @@ class FrobeniusNorm(Function):
         return gw
 
 
+_conet_ws = {}
+
+
+def conet_supported(dims):
+    """True when the fused tower kernels (csrc/cdr_conet.hip) take these layer widths ({2D, mlp_hidden_size...})."""
+    aw, need = ctypes.c_int(0), ctypes.c_size_t(0)
+    arr = (ctypes.c_int * len(dims))(*[int(d) for d in dims])
+    return B_.load().cdr_conet_plan(len(dims) - 1, arr, 1024, ctypes.byref(aw), ctypes.byref(need)) == 0
+
+
+class ConetFusedLoss(Function):
+    """CoNet.calculate_loss (conet.py:183-203) as ONE autograd node on the fused tower kernels: forward = gather + every
+    cross unit of both towers + output units + BCE x2 + sum ||H_l||_F in one launch (+ a finishing block); backward = data
+    gradients, weight gradients (fixed-order reduction, no float atomics), then the dense embedding gradients the
+    reference's caller expects for ``sparse=False`` tables.  ``params`` = for every layer (Ws, bs, Wt, bt, H), then
+    (wo_s, bo_s, wo_t, bo_t)."""
+
+    @staticmethod
+    def forward(ctx, su, si, tu, ti, user, item, label, n_source, n_overlap, overlap_users, dims, *params):
+        _dev_check(su, si, tu, ti, user, item, label, *params)
+        user, item = _ids(user), _ids(item)
+        label = label.reshape(-1).contiguous().to(torch.float32)
+        R, D, L = user.numel(), su.shape[1], len(dims) - 1
+        dev = su.device
+        params = tuple(p.contiguous() for p in params)
+        dims_c = (ctypes.c_int * (L + 1))(*[int(d) for d in dims])
+        aw, need = ctypes.c_int(0), ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_conet_plan(L, dims_c, R, ctypes.byref(aw), ctypes.byref(need)), 'cdr_conet_plan')
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        x0, acts, prob, maskf, out = f32(R, 4 * D), f32(R, aw.value), f32(R), f32(R), f32(4 + L)
+        pp = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        B_.call('cdr_conet_fwd', B_.ctx(dev), B_.stream(), B_.f32(su), B_.f32(si), B_.f32(tu), B_.f32(ti), D, B_.i64(user),
+                B_.i64(item), R, int(n_source), int(n_overlap), 1 if overlap_users else 0, L, dims_c, pp, B_.f32(label),
+                B_.f32(x0), B_.f32(acts), B_.f32(prob), B_.f32(maskf), B_.f32(out))
+        ctx.save_for_backward(user, item, label, x0, acts, prob, maskf, out, *params)
+        ctx.meta = (int(n_source), tuple(int(d) for d in dims), aw.value, int(need.value), tuple(su.shape), tuple(si.shape))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, grad_loss, _g_out):
+        user, item, label, x0, acts, prob, maskf, out = ctx.saved_tensors[:8]
+        params = ctx.saved_tensors[8:]
+        n_source, dims, aw, need, ushape, ishape = ctx.meta
+        R, L, D = user.numel(), len(dims) - 1, ushape[1]
+        dev = x0.device
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _conet_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            _conet_ws[key] = ws
+        gz = torch.empty(R, aw, device=dev, dtype=torch.float32)
+        gx0 = torch.empty(R, 4 * D, device=dev, dtype=torch.float32)
+        grads = tuple(torch.empty_like(p) for p in params)
+        dims_c = (ctypes.c_int * (L + 1))(*dims)
+        pp = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        go = grad_loss.reshape(-1).contiguous().to(torch.float32)
+        B_.call('cdr_conet_bwd', B_.ctx(dev), B_.stream(), R, n_source, L, dims_c, pp, B_.f32(label), B_.f32(x0), B_.f32(acts),
+                B_.f32(prob), B_.f32(maskf), B_.f32(out), B_.f32(go), B_.f32(gz), B_.f32(gx0), gp, B_.raw(ws), ws.numel())
+        gsu, gtu = torch.zeros(ushape, device=dev), torch.zeros(ushape, device=dev)
+        gsi, gti = torch.zeros(ishape, device=dev), torch.zeros(ishape, device=dev)
+        for k, (g, ids) in enumerate(((gsu, user), (gsi, item), (gtu, user), (gti, item))):
+            B_.call('cdr_scatter_add_rows_ld', B_.stream(), B_.f32(g), D, B_.i64(ids), R, B_._c_ptr(gx0.data_ptr() + 4 * k * D), 4 * D)
+        del params, pp, gp
+        return (gsu, gsi, gtu, gti, None, None, None, None, None, None, None) + grads
+
+
 # ---------------------------------------------------------------------------------------------------- SSCDR pieces
 class SqnormNormalize(Function):
     """SSCDR.embedding_normalize (sscdr.py:120-124): e / max(sum e^2, 1) -- the SQUARED length, quirk kept."""

@@ -47,6 +47,11 @@ class CoNet(CrossDomainRecommender):
         self.target_outputunit = nn.Sequential(nn.Linear(self.cross_layers[-1], 1), nn.Sigmoid())
         self.crossparas = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
         self.apply(xavier_normal_initialization)
+        # layer widths the fused tower kernels take (multiples of 4, <= 8 layers, fits LDS); otherwise -- or with
+        # config['conet_fused'] = False -- every cross unit is four launches of the generic MFMA GEMM (_towers)
+        self._dims = tuple(dims)
+        fused = config['conet_fused'] if 'conet_fused' in config else True
+        self.fused_towers = bool(fused) and self.latent_dim % 4 == 0 and F_.conet_supported(self._dims)
 
     # ---- both towers through every cross unit ----------------------------------------------------------------------
     def _towers(self, user, item):
@@ -71,14 +76,33 @@ class CoNet(CrossDomainRecommender):
         lin = self.target_outputunit[0]
         return F_.linear(t, lin.weight, lin.bias, B_.ACT_SIGMOID).squeeze()
 
+    def _fused_params(self):
+        ps = []
+        for l in range(len(self.crossparas)):
+            ls, lt = self.source_crossunit_linear[l], self.target_crossunit_linear[l]
+            ps += [ls.weight, ls.bias, lt.weight, lt.bias, self.crossparas[l].weight]
+        so, to = self.source_outputunit[0], self.target_outputunit[0]
+        return ps + [so.weight, so.bias, to.weight, to.bias]
+
     def calculate_loss(self, interaction):
         # source_forward(source batch) and target_forward(target batch) both run BOTH towers (conet.py:186-187); every
-        # op is row-independent, so the two batches go through the cross units as ONE stack of rows (half the launches)
-        # and each output unit reads its own slice -- same numbers per row as two separate passes.
+        # op is row-independent, so the two batches go through the cross units as ONE stack of rows and each output unit
+        # reads its own slice -- same numbers per row as two separate passes.
         su, si = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID]
         tu, ti = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
         n_s = su.numel()
-        s, t = self._towers(torch.cat([su.reshape(-1), tu.reshape(-1)]), torch.cat([si.reshape(-1), ti.reshape(-1)]))
+        user, item = torch.cat([su.reshape(-1), tu.reshape(-1)]), torch.cat([si.reshape(-1), ti.reshape(-1)])
+        if self.fused_towers:
+            # the whole loss as one autograd node on csrc/cdr_conet.hip (one forward launch, three backward launches)
+            label = torch.cat([interaction[self.SOURCE_LABEL].reshape(-1), interaction[self.TARGET_LABEL].reshape(-1)])
+            over_users = self.mode == 'overlap_users'
+            loss, self.last_loss_parts = F_.ConetFusedLoss.apply(
+                self.source_user_embedding.weight, self.source_item_embedding.weight, self.target_user_embedding.weight,
+                self.target_item_embedding.weight, user, item, label, n_s,
+                self.overlapped_num_users if over_users else self.overlapped_num_items, over_users, self._dims,
+                *self._fused_params())
+            return loss
+        s, t = self._towers(user, item)
         ls, lt = self.source_outputunit[0], self.target_outputunit[0]
         p_source = F_.linear(s[:n_s], ls.weight, ls.bias, B_.ACT_SIGMOID).squeeze()
         p_target = F_.linear(t[n_s:], lt.weight, lt.bias, B_.ACT_SIGMOID).squeeze()

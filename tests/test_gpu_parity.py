@@ -516,14 +516,18 @@ def test_trainer_rowwise_mode_matches_oracle_rowwise_training():
         assert_close(v, params[k].detach(), rtol=1e-4, atol=lr * 5e-2, what=k)
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'gemm'])
 @pytest.mark.parametrize('name', cases('conet_'))
-def test_conet_golden(name):
+def test_conet_golden(name, fused):
+    """Both routes of calculate_loss -- the fused tower kernels (csrc/cdr_conet.hip) and the per-layer MFMA GEMMs -- against
+    the reference's own loss and gradients."""
     from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
     g = Golden(name)
     ids = g.idspace()
-    cfg = base_config(DEV, embedding_size=int(g.meta('D')), reg_weight=0.01,
+    cfg = base_config(DEV, embedding_size=int(g.meta('D')), reg_weight=0.01, conet_fused=fused,
                       mlp_hidden_size=[int(x) for x in g.meta('mlp_hidden_size')])
     model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    assert model.fused_towers == fused
     load_params(model, g.group('param'))
     inter = to_dev(g.group('in'), DEV)
     with torch.no_grad():
@@ -542,15 +546,18 @@ def test_conet_golden(name):
     assert_close(fs, g['fullsort/BOTH'], what='fullsort')
 
 
-def test_conet_c3_shape_vs_oracle():
-    """CoNet at BASELINE C3's layer shape (D=128, [256,64,32,16,8], k=4 pointwise) on a down-scaled id space, vs the oracle."""
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'gemm'])
+def test_conet_c3_shape_vs_oracle(fused):
+    """CoNet at BASELINE C3's layer shape (D=128, [256,64,32,16,8], k=4 pointwise) on a down-scaled id space, vs the oracle:
+    loss and every gradient at north_star's 1e-5."""
     from oracle import conet as oconet
     from oracle.common import IdSpace
     from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
     torch.manual_seed(4)
     ids = IdSpace(OU=300, TOU=500, SOU=700, OI=1, TOI=900, SOI=1100)
-    cfg = base_config(DEV, embedding_size=128, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+    cfg = base_config(DEV, embedding_size=128, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8], conet_fused=fused)
     model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    assert model.fused_towers == fused
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
     S = 819
     def batch(users, items):
@@ -568,7 +575,54 @@ def test_conet_c3_shape_vs_oracle():
     loss.backward()
     for k, v in model.named_parameters():
         if params[k].grad is not None:
-            assert_close(v.grad, params[k].grad, rtol=2e-5, atol=2e-5 * float(params[k].grad.abs().max()) + 1e-10, what=k)
+            assert_close(v.grad, params[k].grad, what=k)
+
+
+@pytest.mark.parametrize('R,n_s,hidden,D', [(77, 33, [12, 8, 4], 8), (64, 2, [64, 32], 16), (1000, 998, [40], 20), (4, 2, [8, 4], 8),
+                                          (4097, 2048, [32, 32, 16, 8], 128)])
+def test_conet_fused_ragged_shapes_and_determinism(R, n_s, hidden, D):
+    """The fused tower kernels on row counts that are not multiples of the 32-row tile, one-row domains, widths that are not
+    multiples of 8 / 32, a widening layer, the tuned [32,32,16,8] stack -- loss and every gradient vs the oracle at 1e-5 --
+    and twice in a row: bit-identical (no float atomics in the tower backward; the dense embedding scatter is compared
+    through the deterministic input gradient)."""
+    from oracle import conet as oconet
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    torch.manual_seed(R)
+    ids = IdSpace(OU=30, TOU=50, SOU=70, OI=1, TOI=90, SOI=110)
+    cfg = base_config(DEV, embedding_size=D, reg_weight=0.01, mlp_hidden_size=hidden)
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    assert model.fused_towers
+    with torch.no_grad():                                   # biases are zero after xavier init: make them matter
+        for n, p in model.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    rs = np.random.RandomState(R)
+    n_t = R - n_s
+    inter = {'source_user_id': torch.from_numpy(rs.randint(0, ids.total_num_users, n_s)),
+             'source_item_id': torch.from_numpy(rs.randint(0, ids.total_num_items, n_s)),
+             'source_label': torch.from_numpy((rs.rand(n_s) < 0.4).astype(np.float32)),
+             'target_user_id': torch.from_numpy(rs.randint(0, ids.OU + ids.TOU, n_t)),
+             'target_item_id': torch.from_numpy(rs.randint(0, ids.OI + ids.TOI, n_t)),
+             'target_label': torch.from_numpy((rs.rand(n_t) < 0.4).astype(np.float32))}
+    ref = oconet.calculate_loss(params, ids, inter)
+    ref.backward()
+    dev_inter = to_dev(inter, DEV)
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        loss = model.calculate_loss(dev_inter)
+        loss.backward()
+        runs.append((loss.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters() if 'embedding' not in k}))
+    assert_close(runs[0][0], ref, what='loss')
+    parts = model.last_loss_parts.cpu()
+    assert_close(parts[1] + parts[2] + parts[3], ref, what='loss parts')
+    for k, v in model.named_parameters():
+        assert_close(v.grad, params[k].grad, what=k)
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
 @pytest.mark.parametrize('name', cases('sscdr_'))

@@ -1,0 +1,54 @@
+"""Micro-benchmark of the fused CoNet tower kernels at BASELINE C3's shape: HIP-event time per kernel (recorded in the
+library on the launch stream) and FLOP rates.  `CDR_CONET_PROF=1` with a -DCDR_CONET_PROF build also prints block 0's
+phase stamps (wall_clock64, 10 ns ticks)."""
+import ctypes
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import recbole_cdr_amd  # noqa: E402
+from recbole_cdr_amd import binding as B_  # noqa: E402
+from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset  # noqa: E402
+from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet  # noqa: E402
+
+dev = 'cuda:0'
+ds = SyntheticCrossDomainDataset(OU=5983, TOU=20986, SOU=129127, OI=1, TOI=18563, SOI=115172, n_source_inter=400000, n_target_inter=200000)
+cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev, 'embedding_size': 128,
+       'reg_weight': 0.01, 'mlp_hidden_size': [64, 32, 16, 8]}
+torch.manual_seed(0)
+model = CoNet(cfg, ds).to(dev)
+rng = np.random.RandomState(0)
+S, k = 819, 4
+batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
+prof = None
+if os.environ.get('CDR_CONET_PROF'):
+    prof = torch.zeros(64, dtype=torch.int64, device=dev)
+    lib = B_.load()
+    lib.cdr_conet_debug_prof.argtypes = [ctypes.c_void_p]
+    assert lib.cdr_conet_debug_prof(ctypes.c_void_p(prof.data_ptr())) == 0
+for i in range(5):
+    model.zero_grad(set_to_none=True)
+    model.calculate_loss(batches[i % 4]).backward()
+torch.cuda.synchronize()
+B_.timing_enable(dev, 4096)
+for i in range(50):
+    model.zero_grad(set_to_none=True)
+    model.calculate_loss(batches[i % 4]).backward()
+torch.cuda.synchronize()
+acc = {}
+for name, ms in B_.timing_collect(dev):
+    acc.setdefault(name, []).append(ms)
+R = 2 * S * (1 + k)
+fl = 152.6e3 * R
+for name, v in acc.items():
+    v = np.array(v[5:])
+    mult = {'conet_fwd_kernel': 1, 'conet_bwd_kernel': 1, 'conet_wgrad_kernel': 1}.get(name, 0)
+    print('%-22s avg %.1f us  min %.1f us  %s' % (name, v.mean() * 1e3, v.min() * 1e3,
+                                                  ('%.1f TFLOP/s' % (fl * mult / (v.mean() * 1e-3) / 1e12)) if mult else ''))
+if prof is not None:
+    p = prof.cpu().numpy()
+    f = p[:2 + 4 + 1]
+    print('fwd stamps (us from start):', [round((x - f[0]) / 100.0, 2) for x in f])
+    b = p[16:16 + 3 + 8]
+    print('bwd stamps (us from start):', [round((x - b[0]) / 100.0, 2) for x in b])
