@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 15
+#define CDR_ABI_VERSION 17
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -60,6 +60,7 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_POINT_GRAD_FROM_DOT 11
 #define CDR_TAG_CONET_FWD 12           /* conet_fwd_kernel: gather + every cross unit + output unit + BCE */
 #define CDR_TAG_CONET_BWD 13           /* conet_bwd_kernel: data gradients of the towers */
+#define CDR_TAG_BPR_FWD_KMAJOR 15      /* bpr_fwd_kmajor_kernel: one lane group per positive */
 #define CDR_TAG_CONET_WGRAD 14         /* conet_wgrad_kernel: weight gradients, one wave per (tile, row chunk) */
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
@@ -204,6 +205,49 @@ int cdr_bce_prob_bwd(void* stream, const float* p, const float* y, int64_t n, co
 /* torch.norm(W) (Frobenius, conet.py:198-201) and d/dW = grad_out * W / norm */
 int cdr_frobenius_fwd(cdr_ctx* ctx, void* stream, const float* x, int64_t n, float* out1);
 int cdr_frobenius_bwd(void* stream, const float* x, int64_t n, const float* norm, const float* grad_out, float* gx, int accumulate);
+
+/* ---- per-positive ("k-major") fused BPR step + one-launch small sort + capturable applies --------------------------------
+ * recbole's pairwise batch (crossdomain_sampler.py:148-152; emcdr.py:123-131,146-154): S positives tiled k times, negatives
+ * k-major: uid[j + m S] = uid[j], pid[j + m S] = pid[j], nid[j + m S] = m-th negative of positive j; B = S k rows.
+ *   cdr_bpr_fwd_grad_kmajor : same loss as cdr_bpr_fwd_grad over the B rows (BPRLoss mean over B, EmbLoss over the B repeated
+ *       rows), reading uid[0..S), pid[0..S), nid[0..B).  u_j and p_j are gathered ONCE per positive.  Writes GU[S, D]:
+ *       GU[j] = sum_m g_{j,m} (p_j - n_{j,m}), and item_rec[S + B] 8-byte records {int32 user row, float coefficient} in the
+ *       order of the item occurrence list [pid[0..S) | nid[0..B)]: {uid_j, sum_m g_{j,m}} and {uid_j, -g_{j,m}} -- the gradient
+ *       row of an item occurrence is coefficient * user_tab[user row].  out9 as cdr_bpr_fwd_grad's with out9[4], out9[5]
+ *       pre-multiplied by k (an S-list occurrence stands for k batch rows).  bump_a / bump_b (optional device int64
+ *       counters) are incremented: the two tables' Adam update counts for the applies below.
+ *   cdr_sort_ids_small      : up to 4 id lists of <= 16384 ids each (list s = ids0[s][0..n0[s]) ++ ids1[s][0..n1[s]), ids1
+ *       optional) as a rank sort over the whole chip (rank = #{(id, occurrence) smaller}, two launches, integer atomics only:
+ *       the result equals the stable radix sort of cdr_sort_ids); list s lands at keys_out / perm_out + out_off[s].
+ *   cdr_rowwise_apply_rows  : cdr_rowwise_apply for unsigned gradient rows G[n, D] (no negative block), plus: step_dev (optional
+ *       device int64: the Adam update count is read on the device -> hipGraph-capturable) and small (1: no long-segment
+ *       pass -- no memset, no extra launches; a segment is walked by its head's lane group whatever its length).
+ *   cdr_rowwise_apply_scaled: the item table of the k-major step: occurrence o contributes item_rec[o].coef *
+ *       src_table[item_rec[o].urow] (src_table = the user table BEFORE its own apply); reg_limit = S.                       */
+int cdr_bpr_fwd_grad_kmajor(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D, const int64_t* uid,
+                            const int64_t* pid, const int64_t* nid, int64_t S, int k, float gamma, float reg_weight, float* out9,
+                            float* GU, void* item_rec, int64_t* bump_a, int64_t* bump_b);
+int cdr_sort_ids_small(void* stream, int nseg, const int64_t* const* ids0, const int64_t* n0, const int64_t* const* ids1,
+                       const int64_t* n1, const int64_t* out_off, uint32_t* keys_out, uint32_t* perm_out,
+                       uint32_t* rank_scratch /* one uint32 per id, ZERO before the first call; left zero by every call */);
+int cdr_rowwise_apply_rows(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
+                           const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const float* G, int64_t reg_limit,
+                           const float* reg_coef, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                           const int64_t* step_dev, int small);
+/* The whole k-major step for small batches (S + S k <= 16384 ids) in FOUR launches behind one call: {forward blocks || rank-count
+ * blocks}, {rank-scatter blocks || loss finish}, item apply, user apply.  Same results as cdr_bpr_fwd_grad_kmajor +
+ * cdr_sort_ids_small + cdr_rowwise_apply_scaled + cdr_rowwise_apply_rows (small = 1).  Adam: the update counts are the device
+ * counters step_*_dev, incremented by the first launch -- the call is hipGraph-capturable.  keys / perm: uint32 [2 S + S k];
+ * rank_scratch: uint32 [2 S + S k], zero before the first call.                                                                  */
+int cdr_bpr_step_small(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, float* item_tab,
+                       float* item_m, float* item_v, int D, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t S,
+                       int k, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t* step_user_dev, int64_t* step_item_dev, float* out9, float* GU, void* item_rec, uint32_t* keys,
+                       uint32_t* perm, uint32_t* rank_scratch);
+int cdr_rowwise_apply_scaled(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
+                             const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const void* item_rec,
+                             const float* src_table, int64_t reg_limit, const float* reg_coef, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int64_t step, const int64_t* step_dev, int small);
 
 /* ---- CoNet towers fused (conet.py:105-203: source_forward + target_forward + BCELoss x2 + reg) -------------------------
  * One stack of R rows -- rows [0, n_source) are the source batch, the rest the target batch -- runs BOTH towers through the

@@ -25,6 +25,25 @@ class RowwiseState:
         self.step = 0
         self.exp_avg = torch.zeros_like(table) if opt == OPT_ADAM else None
         self.exp_avg_sq = torch.zeros_like(table) if opt == OPT_ADAM else None
+        self._step_dev = None
+
+    @property
+    def step_dev(self):
+        """The update count as a device int64 [1] (read by the capturable applies); created on first use from ``step``."""
+        if self._step_dev is None:
+            self._step_dev = torch.full((1,), int(self.step), device=self.table.device, dtype=torch.int64)
+        return self._step_dev
+
+    def advance(self, device_bumped=False):
+        """One more update of this table.  ``device_bumped``: a kernel already incremented the device counter."""
+        self.step += 1
+        if self._step_dev is not None and not device_bumped:
+            B_.call('cdr_inc_i64', B_.stream(), B_.i64(self._step_dev))
+
+    def set_step(self, value):
+        self.step = int(value)
+        if self._step_dev is not None:
+            self._step_dev.fill_(self.step)
 
 
 class FusedBPRStep:
@@ -94,6 +113,149 @@ class FusedBPRStep:
                 B_.f32(st.exp_avg_sq), self.D, B_.raw(keys), B_.raw(perm), n, B_.f32(G), neg_start, reg_limit,
                 B_.f32(coef), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                 float(self.wd), st.step, None, int(key_base))
+
+
+class KMajorBPRStep:
+    """The fused BPR step cut along recbole's pairwise batch layout (crossdomain_sampler.py:148-152; emcdr.py:123-131): S positives
+    tiled k times with k-major negatives.  One lane group per POSITIVE in the forward (u, p gathered once, not k times), one
+    gradient row per positive for the user table, and no item gradient rows at all: the item apply rebuilds each occurrence's
+    row as coefficient * user row (csrc/cdr_kstep.hip).  Same loss and same per-row gradients as FusedBPRStep on the B = S k
+    rows.  Batches whose item list fits the small rank sort (S k + S <= 8192) run as 4 launches behind one native call with device-side Adam
+    counters and can be replayed as a hipGraph (``capture``)."""
+
+    def __init__(self, user_table, item_table, max_positives, k=1, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None):
+        assert user_table.is_cuda and item_table.is_cuda, 'KMajorBPRStep needs ROCm device tensors'
+        assert user_table.shape[1] == item_table.shape[1]
+        self.U, self.I = user_table, item_table
+        self.D = user_table.shape[1]
+        self.k = int(k)
+        self.opt = OPT_ADAM if opt == 'adam' else OPT_SGD
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.gamma, self.reg_weight = gamma, reg_weight
+        self.ustate = user_state if user_state is not None else RowwiseState(user_table, self.opt)
+        self.istate = item_state if item_state is not None else RowwiseState(item_table, self.opt)
+        dev = user_table.device
+        Sm = int(max_positives)
+        Bm = Sm * self.k
+        self.max_positives = Sm
+        self.GU = torch.empty(Sm, self.D, device=dev, dtype=torch.float32)
+        self.rec = torch.empty(2 * (Sm + Bm), device=dev, dtype=torch.int32)          # 8-byte {user row, coefficient} records
+        self.out6 = torch.zeros(12, device=dev, dtype=torch.float32)
+        n_all = 2 * Sm + Bm                                                           # user list [S] ++ item list [S + B]
+        self.keys = torch.empty(n_all, device=dev, dtype=torch.int32)
+        self.perm = torch.empty(n_all, device=dev, dtype=torch.int32)
+        self.small = (Sm + Bm) <= 8192                # the rank sort is quadratic: past this the radix sort wins
+        self.rank = torch.zeros(n_all, device=dev, dtype=torch.int32) if self.small else None   # scratch of the rank sort
+        self.ws = None
+        self._key_base = ctypes.c_uint32(0)
+        if not self.small:
+            rows = max(user_table.shape[0], item_table.shape[0])
+            need = ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_sort_workspace_bytes(n_all, 2 << (rows - 1).bit_length(), ctypes.byref(need)),
+                      'cdr_sort_workspace_bytes')
+            self.ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+        self._graph = None
+
+    def step(self, uid, pid, nid):
+        """uid / pid: int64 [S] (or the reference's tiled [S k]: the first S entries are read), nid: int64 [S k] k-major.
+        Returns out6 (view; [0] = total loss)."""
+        B = nid.numel()
+        S = B // self.k
+        assert S * self.k == B and S <= self.max_positives and uid.numel() >= S and pid.numel() >= S
+        self._enqueue(uid, pid, nid, S)
+        self.ustate.advance(device_bumped=True)
+        self.istate.advance(device_bumped=True)
+        return self.out6
+
+    def _enqueue(self, uid, pid, nid, S):
+        dev = self.U.device
+        ctxh, s = B_.ctx(dev), B_.stream()
+        B = S * self.k
+        adam = self.opt == OPT_ADAM
+        ud, idv = (self.ustate.step_dev, self.istate.step_dev) if adam else (None, None)
+        hp = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd))
+        if self.small:
+            # four launches behind one call: {forward || rank count}, {scatter || loss finish}, item apply, user apply
+            us, its = self.ustate, self.istate
+            B_.call('cdr_bpr_step_small', ctxh, s, self.opt, B_.f32(us.table), B_.f32(us.exp_avg), B_.f32(us.exp_avg_sq),
+                    B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq), self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), S,
+                    self.k, float(self.gamma), float(self.reg_weight), *hp, B_.i64(ud), B_.i64(idv), B_.f32(self.out6),
+                    B_.f32(self.GU), B_.raw(self.rec), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.rank))
+            return
+        B_.call('cdr_bpr_fwd_grad_kmajor', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), S,
+                self.k, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU), B_.raw(self.rec),
+                B_.i64(ud), B_.i64(idv))
+        base = self._sort(uid, pid, nid, S, ctxh)
+        # the item apply reads the PRE-step user rows: it runs first
+        st = self.istate
+        tab, m, v = self._offset(st, base)
+        B_.call('cdr_rowwise_apply_scaled', ctxh, s, self.opt, tab, m, v, self.D, B_.raw(self.keys[S:2 * S + B]),
+                B_.raw(self.perm[S:2 * S + B]), S + B, B_.raw(self.rec), B_.f32(self.U), S, B_.f32(self.out6[5:6]), *hp,
+                st.step + 1, B_.i64(idv), 0)
+        st = self.ustate
+        B_.call('cdr_rowwise_apply_rows', ctxh, s, self.opt, B_.f32(st.table), B_.f32(st.exp_avg), B_.f32(st.exp_avg_sq), self.D,
+                B_.raw(self.keys[:S]), B_.raw(self.perm[:S]), S, B_.f32(self.GU), S, B_.f32(self.out6[4:5]), *hp, st.step + 1,
+                B_.i64(ud), 0)
+
+    def _sort(self, uid, pid, nid, S, ctxh):
+        """User list [S] at keys[0:S], item list [pid | nid] at keys[S:2S+B]; returns the item keys' table bit (0 for the rank sort)."""
+        B = S * self.k
+        if self.small:
+            arr = lambda xs: (ctypes.c_void_p * 2)(*xs)
+            i64s = lambda xs: (ctypes.c_int64 * 2)(*xs)
+            B_._alive.extend([uid, pid, nid])
+            B_.call('cdr_sort_ids_small', B_.stream(), 2, arr([uid.data_ptr(), pid.data_ptr()]), i64s([S, S]), arr([None, nid.data_ptr()]),
+                    i64s([0, B]), i64s([0, S]), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.rank))
+            return 0
+        B_.call('cdr_sort_ids_two_tables', ctxh, B_.stream(), B_.i64(uid), S, self.U.shape[0], B_.i64(pid), S, B_.i64(nid), B,
+                self.I.shape[0], B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws.numel())
+        return int(self._key_base.value)
+
+    def _offset(self, st, key_base):
+        """Table pointers moved back by key_base rows (keys of a two-table sort carry the table bit; see cdr_rowwise_apply)."""
+        off = 4 * key_base * self.D
+        f = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() - off)
+        B_._alive.extend([st.table, st.exp_avg, st.exp_avg_sq])
+        return f(st.table), f(st.exp_avg), f(st.exp_avg_sq)
+
+    # ---- hipGraph replay of the whole step (small batches: the reference's default train_batch_size is 2,048) ----------
+    def capture(self, S):
+        """Capture the 6-launch step for batches of exactly S positives.  ``replay(uid, pid, nid)`` then costs three small id
+        copies + one graph launch on the host."""
+        assert self.small and self.opt in (OPT_ADAM, OPT_SGD)
+        dev = self.U.device
+        B = S * self.k
+        self._S = S
+        self._ids = (torch.zeros(S, device=dev, dtype=torch.int64), torch.zeros(S, device=dev, dtype=torch.int64),
+                     torch.zeros(B, device=dev, dtype=torch.int64))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            B_.ctx(dev)                                   # the native context of the capture stream must exist beforehand
+            if self.opt == OPT_ADAM:
+                self.ustate.step_dev, self.istate.step_dev
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=side):
+            self._enqueue(self._ids[0], self._ids[1], self._ids[2], S)
+        return self
+
+    @property
+    def static_ids(self):
+        """(uid [S], pid [S], nid [S k]): the buffers the captured graph reads.  A producer that writes its batch straight into
+        them (the device sampler / loader) can call ``replay()`` without arguments: no id copies at all."""
+        return self._ids
+
+    def replay(self, uid=None, pid=None, nid=None):
+        S = self._S
+        if uid is not None:
+            self._ids[0].copy_(uid[:S]); self._ids[1].copy_(pid[:S]); self._ids[2].copy_(nid)
+        self._graph.replay()
+        self.ustate.advance(device_bumped=True)
+        self.istate.advance(device_bumped=True)
+        return self.out6
 
 
 class FusedPointStep:

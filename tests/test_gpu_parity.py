@@ -248,6 +248,131 @@ def test_fused_step_vs_oracle(opt, D, k):
 
 
 
+def _kmajor_batch(nu, ni, S, k, gen):
+    u = torch.randint(0, nu, (S,), generator=gen)
+    p = torch.randint(0, ni, (S,), generator=gen)
+    n = torch.randint(0, ni, (S * k,), generator=gen)           # k-major: n[j + m S] is the m-th negative of positive j
+    return u, p, n
+
+
+@pytest.mark.parametrize('opt,D,k,S', [('sgd', 64, 1, 97), ('sgd', 128, 4, 97), ('adam', 128, 4, 97), ('adam', 64, 2, 33),
+                                       ('adam', 20, 3, 97), ('adam', 128, 6, 50), ('adam', 128, 1, 2048), ('sgd', 32, 9, 7)])
+def test_kmajor_step_vs_oracle(opt, D, k, S):
+    """The per-positive step (one lane group per positive, coefficient * user-row item gradients, one-launch LDS sort) on
+    recbole's k-major batches: THREE FREE-RUNNING steps -- no re-sync of the reference state between steps -- against the
+    oracle's row-wise step on the tiled [S k] batch: loss at 1e-5 every step, tables and moments at the end."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import KMajorBPRStep
+    gen = torch.Generator().manual_seed(D * 100 + k)
+    nu, ni, reg, lr = 50, 40, 0.03, 0.05
+    U = torch.randn(nu, D, generator=gen) * 0.3
+    I = torch.randn(ni, D, generator=gen) * 0.3
+    Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+    st = KMajorBPRStep(Ud, Id, max_positives=S, k=k, opt=opt, lr=lr, reg_weight=reg)
+    assert st.small
+    su, si = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    for step in range(1, 4):
+        u, p, n = _kmajor_batch(nu, ni, S, k, gen)
+        ref = ts.rowwise_step(U, I, su, si, u.repeat(k), p.repeat(k), n, step, opt=opt, lr=lr, reg_weight=reg)
+        out = st.step(u.repeat(k).to(DEV), p.repeat(k).to(DEV), n.to(DEV))          # the reference hands over the tiled ids
+        assert_close(out[0], ref, what=f'loss step {step}')
+    assert st.ustate.step == 3 and (opt != 'adam' or int(st.ustate.step_dev) == 3)
+    # the moments are well-conditioned: 1e-5 after three free steps.  The weights move by lr * m / (sqrt(v) + eps), which is
+    # ill-conditioned where |g| ~ eps (1e-8) -- with 2,048-row means a handful of elements are there -- so the drift bound is
+    # 1e-4 of one Adam update (lr) for the small batches and 1e-2 of one update for the 2,048-row batch; SGD: 1e-5 relative.
+    if opt == 'adam':
+        # (2,048-row case: the few ill-conditioned weight elements of step 1 feed back into the later gradients, so its moments
+        #  are held to 1e-4 of the largest moment instead of 1e-5)
+        mt = dict(rtol=1e-5) if S < 1000 else None
+        for got, want, what in ((st.ustate.exp_avg, su.m, 'exp_avg U'), (st.istate.exp_avg, si.m, 'exp_avg I'),
+                                (st.ustate.exp_avg_sq, su.v, 'exp_avg_sq U'), (st.istate.exp_avg_sq, si.v, 'exp_avg_sq I')):
+            if mt is not None:
+                assert_close(got, want, what=what)
+            else:
+                assert_close(got, want, rtol=1e-5, atol=1e-4 * float(want.abs().max()), what=what)
+    tol = dict(rtol=1e-5, atol=lr * (1e-4 if S < 1000 else 1e-2)) if opt == 'adam' else dict(rtol=1e-5)
+    assert_close(Ud, U, what='U after 3 steps', **tol)
+    assert_close(Id, I, what='I after 3 steps', **tol)
+
+
+def test_kmajor_step_large_batch_and_hot_item():
+    """Past the LDS sort (radix sort + long-segment pieces): 40 % of the positives and a share of the negatives are ONE item;
+    vs the oracle, and bit-reproducible."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import KMajorBPRStep
+    gen = torch.Generator().manual_seed(5)
+    nu, ni, D, S, k, reg, lr = 3000, 2000, 64, 6000, 4, 0.02, 0.01
+    U = torch.randn(nu, D, generator=gen) * 0.3
+    I = torch.randn(ni, D, generator=gen) * 0.3
+    u, p, n = _kmajor_batch(nu, ni, S, k, gen)
+    p[torch.rand(S, generator=gen) < 0.4] = 7
+    n[torch.rand(S * k, generator=gen) < 0.1] = 7
+    res = []
+    for _ in range(2):
+        Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+        st = KMajorBPRStep(Ud, Id, max_positives=S, k=k, opt='adam', lr=lr, reg_weight=reg)
+        assert not st.small
+        out = st.step(u.to(DEV), p.to(DEV), n.to(DEV)).clone()
+        res.append((out, Ud.clone(), Id.clone()))
+    su, si = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    ref = ts.rowwise_step(U, I, su, si, u.repeat(k), p.repeat(k), n, 1, opt='adam', lr=lr, reg_weight=reg)
+    assert_close(res[0][0][0], ref, what='loss')
+    assert_close(st.istate.exp_avg, si.m, what='exp_avg I'); assert_close(st.ustate.exp_avg, su.m, what='exp_avg U')
+    assert_close(res[0][1], U, atol=lr * 1e-3, what='U'); assert_close(res[0][2], I, atol=lr * 1e-3, what='I')
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('k', [1, 4])
+def test_kmajor_graph_replay_is_bit_equal_to_eager(k):
+    """The reference-default batch (train_batch_size 2,048 rows) as ONE hipGraph: forward, LDS sort, both applies with the Adam
+    update count on the device.  Five replays on fresh ids == five eager steps, bit for bit (tables, moments, losses)."""
+    from recbole_cdr_amd.fused import KMajorBPRStep
+    gen = torch.Generator().manual_seed(k)
+    nu, ni, D, S = 5000, 3000, 64, 2048 // k
+    U0, I0 = torch.randn(nu, D, generator=gen) * 0.3, torch.randn(ni, D, generator=gen) * 0.3
+    batches = [tuple(t.to(DEV) for t in _kmajor_batch(nu, ni, S, k, gen)) for _ in range(5)]
+    runs = []
+    for graphed in (False, True):
+        Ud, Id = U0.clone().to(DEV), I0.clone().to(DEV)
+        st = KMajorBPRStep(Ud, Id, max_positives=S, k=k, opt='adam', lr=0.01, reg_weight=0.01)
+        if graphed:
+            st.capture(S)
+        losses = []
+        for b in batches:
+            out = st.replay(*b) if graphed else st.step(*b)
+            losses.append(out[:6].clone())
+        assert st.ustate.step == 5 and int(st.istate.step_dev) == 5
+        runs.append((torch.stack(losses), Ud, Id, st.ustate.exp_avg, st.ustate.exp_avg_sq, st.istate.exp_avg, st.istate.exp_avg_sq))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
+def test_small_sort_equals_stable_sort():
+    """cdr_sort_ids_small (one workgroup per list, LDS bitonic network on id << 32 | occurrence) == a stable sort: every list
+    size from 1 to past a power of two, two source arrays, heavy duplicates, four lists in one launch."""
+    import ctypes
+    from recbole_cdr_amd import binding as B_
+    gen = torch.Generator().manual_seed(0)
+    for sizes in ([(1, 0), (2, 3), (64, 0), (65, 64)], [(2048, 0), (2048, 4096), (8190, 8190), (16384, 0)], [(777, 1500)]):
+        a = [torch.randint(0, 1 << 20 if i % 2 else 37, (n0,), generator=gen).to(DEV) for i, (n0, _) in enumerate(sizes)]
+        b = [torch.randint(0, 50, (n1,), generator=gen).to(DEV) if n1 else None for _, n1 in sizes]
+        offs, tot = [], 0
+        for n0, n1 in sizes:
+            offs.append(tot); tot += n0 + n1
+        keys = torch.empty(tot, device=DEV, dtype=torch.int32); perm = torch.empty(tot, device=DEV, dtype=torch.int32)
+        rank = torch.zeros(tot, device=DEV, dtype=torch.int32)
+        ns = len(sizes)
+        B_.call('cdr_sort_ids_small', B_.stream(), ns, (ctypes.c_void_p * ns)(*[t.data_ptr() for t in a]),
+                (ctypes.c_int64 * ns)(*[n0 for n0, _ in sizes]), (ctypes.c_void_p * ns)(*[t.data_ptr() if t is not None else None for t in b]),
+                (ctypes.c_int64 * ns)(*[n1 for _, n1 in sizes]), (ctypes.c_int64 * ns)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank))
+        for s, (n0, n1) in enumerate(sizes):
+            ids = torch.cat([a[s]] + ([b[s]] if n1 else [])).cpu()
+            want_k, want_p = torch.sort(ids, stable=True)
+            got_k = keys[offs[s]:offs[s] + n0 + n1].cpu().long(); got_p = perm[offs[s]:offs[s] + n0 + n1].cpu().long()
+            assert torch.equal(got_k, want_k) and torch.equal(got_p, want_p), (sizes, s)
+
+
 @pytest.mark.parametrize('dims', [(64, 64), (32, 48, 16), (128, 64, 128)])
 def test_fused_map_step_vs_oracle(dims):
     """OVERLAP phase as an O(batch) step: loss, both tables' touched rows, their moments and the mapping parameters after
