@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 17
+#define CDR_ABI_VERSION 18
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -61,6 +61,7 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_CONET_FWD 12           /* conet_fwd_kernel: gather + every cross unit + output unit + BCE */
 #define CDR_TAG_CONET_BWD 13           /* conet_bwd_kernel: data gradients of the towers */
 #define CDR_TAG_BPR_FWD_KMAJOR 15      /* bpr_fwd_kmajor_kernel: one lane group per positive */
+#define CDR_TAG_MAP_STEP 16             /* map_step_kernel: the OVERLAP step of distinct ids in one pass */
 #define CDR_TAG_CONET_WGRAD 14         /* conet_wgrad_kernel: weight gradients, one wave per (tile, row chunk) */
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
@@ -248,6 +249,24 @@ int cdr_rowwise_apply_scaled(cdr_ctx* ctx, void* stream, int opt, float* table, 
                              const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const void* item_rec,
                              const float* src_table, int64_t reg_limit, const float* reg_coef, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int64_t step, const int64_t* step_dev, int small);
+
+/* ---- EMCDR OVERLAP phase for batches of DISTINCT ids (emcdr.py:156-168 + mapping :59-64,86-93) in two launches ------------------
+ * The reference's OverlapDataloader yields slices of a shuffled arange(num_overlap) (data/dataloader.py:37-52): ids are distinct
+ * within a batch, so each row is updated by exactly one occurrence and nothing is sorted.  Launch 1: gather S[idx], T[idx] ->
+ * mapping (L layers W_l [d_{l+1}, d_l], optional bias, act[l] in {CDR_ACT_NONE, CDR_ACT_TANH}; the last layer has no activation)
+ * -> loss = mean((mapping(S[idx]) - T[idx])^2) -> backward -> SGD / Adam on the two rows of every id in place (lazy row-wise
+ * Adam, as cdr_rowwise_apply) + per-workgroup partial sums of the mapping's gradients.  Launch 2: partials added in workgroup
+ * order, loss_out[0], exact dense Adam on the mapping parameters.  Device update counters: step_src_dev / step_tgt_dev hold the
+ * tables' counts BEFORE the step and are advanced by it; step_W / step_b (one int64 per parameter tensor) likewise.
+ * PRECONDITION: idx[0..n) pairwise distinct (repeated ids: use the general path).                      */
+#define CDR_MAP_MAX_LAYERS 4
+int cdr_map_step_plan(int L, const int* dims, const int* has_bias, int64_t n, size_t* workspace_bytes);
+int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* src_tab, float* src_m, float* src_v, float* tgt_tab,
+                        float* tgt_m, float* tgt_v, const int64_t* idx, int64_t n, int L, const int* dims, const int* acts,
+                        float* const* W, float* const* bias, float* const* mW, float* const* vW, float* const* mb,
+                        float* const* vb, int64_t* const* step_W, int64_t* const* step_b, int64_t* step_src_dev,
+                        int64_t* step_tgt_dev, float lr, float beta1, float beta2, float eps, float weight_decay, float* loss_out,
+                        void* workspace, size_t workspace_bytes);
 
 /* ---- CoNet towers fused (conet.py:105-203: source_forward + target_forward + BCELoss x2 + reg) -------------------------
  * One stack of R rows -- rows [0, n_source) are the source batch, the rest the target batch -- runs BOTH towers through the

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -141,6 +141,10 @@ _SIGNATURES = {
                                  _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr, _c_int],
     'cdr_bpr_step_small': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int,
                            _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_map_step_plan': [_c_int, _c_ptr, _c_ptr, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
+    'cdr_map_step_unique': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
+                            _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32,
+                            _c_f32, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_conet_plan': [_c_int, _c_ptr, _c_i64, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_size_t)],
     'cdr_conet_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_ptr,
                       _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
@@ -257,7 +261,7 @@ TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4:
         5: 'rowwise_apply_kernel(items)', 6: 'sort_ids', 7: 'point_fwd_grad_kernel',
         8: 'bpr_partial_diff_kernel', 9: 'bpr_grad_from_diff_kernel',
         10: 'point_partial_dot_kernel', 11: 'point_grad_from_dot_kernel',
-        12: 'conet_fwd_kernel', 13: 'conet_bwd_kernel', 14: 'conet_wgrad_kernel', 15: 'bpr_fwd_kmajor_kernel'}
+        12: 'conet_fwd_kernel', 13: 'conet_bwd_kernel', 14: 'conet_wgrad_kernel', 15: 'bpr_fwd_kmajor_kernel', 16: 'map_step_kernel'}
 
 
 _timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device

@@ -1,0 +1,454 @@
+// EMCDR's OVERLAP phase ("overlapped-user transfer step": emcdr.py:156-168 calculate_map_loss, mapping :59-64,86-93) as TWO
+// launches for the batches the reference's own loader produces.
+//
+// OverlapDataloader hands out slices of a shuffled arange(num_overlap) (data/dataloader.py:37-52, dataset.py:694-696): the ids
+// of one batch are DISTINCT.  Every row is then touched by exactly one occurrence, so nothing has to be sorted or
+// de-duplicated and the optimizer can run where the gradient is produced:
+//
+//   map_step_kernel     a workgroup owns 32 ids at a time: gathers S[id] and T[id] into LDS, runs the mapping function
+//                       (Linear, or Linear+Tanh ... Linear) on v_mfma_f32_32x32x2_f32 with the activations in LDS,
+//                       d = mapped - T[id] (MSE partial), walks the mapping backwards to dL/dS[id], accumulates the mapping's
+//                       weight gradients of ALL its ids in registers (gz^T x input, one accumulator per 32x32 tile), and
+//                       applies SGD / Adam to the two table rows in place: 2 row reads, 4 moment reads, 6 writes per id --
+//                       the 6,144 B/id of SURVEY 8d and not a byte more (round 1: ~20 launches through autograd, compact
+//                       gradient rows written and re-read, a radix sort: 0.93 TB/s).
+//   map_finish_kernel   adds the per-workgroup partials in workgroup order (loss, weight and bias gradients) and takes the
+//                       exact dense Adam step on the mapping's parameters, one thread per element.
+//
+// Update counts live on the device (tables: read as count + 1 by launch 1, advanced by launch 2; mapping parameters: advanced
+// by launch 1, read by launch 2), so the pair is hipGraph-capturable.  Batches with repeated ids take the general path
+// (fused.FusedMapStep: gather -> mapping -> MSE -> sort -> row-wise applies).
+#include <string.h>
+#include "cdr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMapMaxL = CDR_MAP_MAX_LAYERS;
+constexpr int kRows = 32;
+constexpr int kSlots = 8;                      // weight-gradient tiles a wave may own (128 accumulator registers)
+
+struct map_net {
+    int L, vec, ntiles, nbias;
+    int dims[kMapMaxL + 1];
+    int act[kMapMaxL];                         // CDR_ACT_* after layer l
+    int tile_off[kMapMaxL + 1];                // first weight-gradient tile of layer l
+    int bias_off[kMapMaxL + 1];
+    int buf_off[kMapMaxL + 1];                 // LDS float offset of layer l's INPUT buffer (buf_off[0] = X); [L] = mapped / gz
+    const float* W[kMapMaxL];
+    const float* b[kMapMaxL];
+};
+struct map_opt { float lr, b1, b2, eps, wd; int opt; };
+struct map_params { float* W[kMapMaxL]; float* b[kMapMaxL]; float* mW[kMapMaxL]; float* vW[kMapMaxL]; float* mb[kMapMaxL]; float* vb[kMapMaxL];
+                    int64_t* sW[kMapMaxL]; int64_t* sb[kMapMaxL]; };
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+__device__ __forceinline__ float4 ldw4(const float* p, bool vec) {
+    return vec ? ld4(p) : make_float4(p[0], p[1], p[2], p[3]);
+}
+#define MFMA4(acc, a, b)                                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).y, (b).y, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).z, (b).z, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).w, (b).w, acc, 0, 0, 0)
+#define MF1(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void adam_hp(const map_opt& o, const int64_t* step_dev, int64_t plus, float& step_size, float& bc2_sqrt) {
+    step_size = o.lr; bc2_sqrt = 1.f;
+    if (o.opt == 1) {
+        const double st = (double)(step_dev[0] + plus);
+        step_size = (float)((double)o.lr / (1.0 - pow((double)o.b1, st)));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)o.b2, st));
+    }
+}
+
+// one element of torch.optim.Adam / SGD (same arithmetic as cdr_step.hip's apply_update)
+__device__ __forceinline__ float upd1(float w, float g, float& m, float& v, const map_opt& o, float step_size, float bc2_sqrt) {
+    if (o.wd != 0.f) g += o.wd * w;
+    if (o.opt == 0) return w - o.lr * g;
+    m += (g - m) * (1.0f - o.b1);
+    v = o.b2 * v + (1.0f - o.b2) * g * g;
+    return w - step_size * (m / (sqrtf(v) / bc2_sqrt + o.eps));
+}
+
+__global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt opt, float* __restrict__ S, float* __restrict__ mS,
+                                                       float* __restrict__ vS, float* __restrict__ T, float* __restrict__ mT,
+                                                       float* __restrict__ vT, const int64_t* __restrict__ idx, int64_t n,
+                                                       const int64_t* __restrict__ step_s, const int64_t* __restrict__ step_t,
+                                                       int gx_off, int t_off, float* __restrict__ wpart, double* __restrict__ lpart,
+                                                       map_params bump) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float rowok[kRows];
+    __shared__ double red[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int L = net.L, Ds = net.dims[0], Dt = net.dims[L];
+    const bool vec = net.vec != 0;
+    float* X = smem + net.buf_off[0];
+    float* GX = smem + gx_off;
+    float* Tb = smem + t_off;
+    const int XS = Ds + 4, TS = Dt + 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && t == 0) {                          // the mapping parameters' update counts: read by launch 2 only
+        for (int l = 0; l < L; ++l) { if (bump.sW[l]) bump.sW[l][0] += 1; if (bump.sb[l]) bump.sb[l][0] += 1; }
+    }
+    float ss_s, bc_s, ss_t, bc_t;
+    adam_hp(opt, step_s, 1, ss_s, bc_s);
+    adam_hp(opt, step_t, 1, ss_t, bc_t);
+    const float gscale = 2.0f / ((float)n * (float)Dt);        // d mean((a-b)^2) / da
+    f32x16 wacc[kSlots];
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) wacc[q] = zero16();
+    float bacc[2] = {0.f, 0.f};
+    double lsum = 0.0;
+    const int64_t nrb = (n + kRows - 1) / kRows;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        {   // ---- gather S[id] and T[id]: 8 threads per row
+            const int row = t >> 3, c0 = t & 7;
+            const int64_t g = rb * kRows + row;
+            const bool valid = g < n;
+            const int64_t id = idx[valid ? g : n - 1];
+            for (int c = c0; c < (Ds >> 2); c += 8) st4(X + row * XS + 4 * c, ld4(S + id * Ds + 4 * c));
+            for (int c = c0; c < (Dt >> 2); c += 8) st4(Tb + row * TS + 4 * c, ld4(T + id * Dt + 4 * c));
+            if (c0 == 0) rowok[row] = valid ? 1.f : 0.f;
+        }
+        lds_barrier();
+        // ---- forward through the mapping (emcdr.py:86-93); the last layer's epilogue leaves gz = dL/d mapped in its buffer
+        for (int l = 0; l < L; ++l) {
+            const int din = net.dims[l], dout = net.dims[l + 1];
+            const float* Xin = smem + net.buf_off[l];
+            float* Xout = smem + net.buf_off[l + 1];
+            const int IS = din + 4, OS = dout + 4;
+            const int NT = (dout + 31) >> 5, KS = (din + 7) >> 3, KG = (KS + 3) >> 2;
+            const bool last = l == L - 1;
+            for (int job = wave; job < NT; job += 4) {
+                const int ncol = job * 32 + li;
+                const bool nv = ncol < dout;
+                const float* wm = net.W[l] + (int64_t)(nv ? ncol : 0) * din;
+                const float* xo = Xin + li * IS;
+                f32x16 am = zero16();
+                float4 nm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int k = 8 * j + 4 * lh; nm[j] = (nv && k < din) ? ldw4(wm + k, vec) : z4; }
+                for (int g = 0; g < KG; ++g) {                       // four K steps per request, next group in flight (cdr_conet.hip)
+                    float4 cm[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cm[j] = nm[j];
+                    if (g + 1 < KG) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int k = 8 * (4 * (g + 1) + j) + 4 * lh; nm[j] = (nv && k < din) ? ldw4(wm + k, vec) : z4; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 8 * (4 * g + j) + 4 * lh;
+                        const float4 a0 = k < din ? ld4(xo + k) : z4;
+                        MFMA4(am, a0, cm[j]);
+                    }
+                }
+                if (nv) {
+                    const float bv = net.b[l] ? net.b[l][ncol] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float v = am[r] + bv;
+                        if (net.act[l] == CDR_ACT_TANH) v = tanhf(v);
+                        if (last) {
+                            const float d = rowok[row] != 0.f ? v - Tb[row * TS + ncol] : 0.f;      // nn.MSELoss (emcdr.py:81,162)
+                            lsum += (double)d * (double)d;
+                            v = gscale * d;
+                        }
+                        Xout[row * OS + ncol] = v;
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        // ---- backward: weight gradients of every layer into the wave's register tiles, data gradient down to the source rows
+        for (int l = L - 1; l >= 0; --l) {
+            const int din = net.dims[l], dout = net.dims[l + 1];
+            float* Ain = smem + net.buf_off[l];                      // layer input (post-activation of layer l-1)
+            const float* Gz = smem + net.buf_off[l + 1];             // dL/d(pre-activation output of layer l)
+            const int IS = din + 4, OS = dout + 4;
+            const int MT = (dout + 31) >> 5, NTW = (din + 31) >> 5;
+            // (1) dW_l += gz^T x input: this wave's tiles of layer l
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) {
+                const int tile = wave + 4 * q;
+                if (tile >= net.tile_off[l] && tile < net.tile_off[l + 1]) {             // wave-uniform
+                    const int loc = tile - net.tile_off[l], mt = loc / NTW, nt = loc - mt * NTW;
+                    const int m = mt * 32 + li, nn = nt * 32 + li;
+                    const bool mv = m < dout, nv = nn < din;
+#pragma unroll
+                    for (int s = 0; s < kRows / 8; ++s) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int row = 8 * s + 4 * lh + c;
+                            const float a = mv ? Gz[row * OS + m] : 0.f;
+                            const float b = nv ? Ain[row * IS + nn] : 0.f;
+                            MF1(wacc[q], a, b);
+                        }
+                    }
+                }
+            }
+            // bias gradients: column sums of gz over the 32 rows, one thread per column (fixed row order)
+            if (net.b[l]) {                                          // thread t owns bias elements t and t + 256 of the flat list
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int c = t + 256 * sl - net.bias_off[l];
+                    if (c >= 0 && c < dout) {
+                        float sum = 0.f;
+                        for (int row = 0; row < kRows; ++row) sum += Gz[row * OS + c];
+                        bacc[sl] += sum;
+                    }
+                }
+            }
+            // (2) g_in = gz W_l ; for l > 0 folded with the previous layer's activation derivative, IN PLACE over its output
+            float* Gout = l > 0 ? Ain : GX;
+            const int GS = l > 0 ? IS : XS;
+            const int NT = (din + 31) >> 5, KS = (dout + 7) >> 3;
+            lds_barrier();                                            // every wave is done reading Ain as the dW operand
+            for (int job = wave; job < NT; job += 4) {
+                const int ncol = job * 32 + li;
+                const bool nv = ncol < din;
+                const float* w0 = net.W[l] + (nv ? ncol : 0);
+                const float* ao = Gz + li * OS;
+                f32x16 am = zero16();
+                float4 nb = z4;
+                if (nv && 4 * lh < dout) { const float* p = w0 + (int64_t)(4 * lh) * din; nb = make_float4(p[0], p[din], p[2 * din], p[3 * din]); }
+                for (int s = 0; s < KS; ++s) {
+                    const int k = 8 * s + 4 * lh;
+                    const float4 cb = nb;
+                    const int kn = k + 8;
+                    nb = z4;
+                    if (nv && kn < dout) { const float* p = w0 + (int64_t)kn * din; nb = make_float4(p[0], p[din], p[2 * din], p[3 * din]); }
+                    const float4 a0 = k < dout ? ld4(ao + k) : z4;
+                    MFMA4(am, a0, cb);
+                }
+                if (nv) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float v = am[r];
+                        if (l > 0 && net.act[l - 1] == CDR_ACT_TANH) { const float a = Ain[row * IS + ncol]; v *= (1.0f - a * a); }
+                        Gout[row * GS + ncol] = v;
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        {   // ---- the two table rows of every id: SGD / Adam in place (w from LDS: the pre-step row gathered above)
+            const int row = t >> 3, c0 = t & 7;
+            const int64_t g = rb * kRows + row;
+            if (g < n) {
+                const int64_t id = idx[g];
+                const float* gm = smem + net.buf_off[L];
+                for (int c = c0; c < (Ds >> 2); c += 8) {
+                    const int64_t o = id * Ds + 4 * c;
+                    const float4 w = ld4(X + row * XS + 4 * c), gg = ld4(GX + row * XS + 4 * c);
+                    float4 m = z4, v = z4;
+                    if (opt.opt) { m = ld4(mS + o); v = ld4(vS + o); }
+                    float4 wn;
+                    wn.x = upd1(w.x, gg.x, m.x, v.x, opt, ss_s, bc_s); wn.y = upd1(w.y, gg.y, m.y, v.y, opt, ss_s, bc_s);
+                    wn.z = upd1(w.z, gg.z, m.z, v.z, opt, ss_s, bc_s); wn.w = upd1(w.w, gg.w, m.w, v.w, opt, ss_s, bc_s);
+                    st4(S + o, wn);
+                    if (opt.opt) { st4(mS + o, m); st4(vS + o, v); }
+                }
+                for (int c = c0; c < (Dt >> 2); c += 8) {
+                    const int64_t o = id * Dt + 4 * c;
+                    const float4 w = ld4(Tb + row * TS + 4 * c), gn = ld4(gm + row * TS + 4 * c);      // dL/dT[id] = -dL/d mapped
+                    float4 m = z4, v = z4;
+                    if (opt.opt) { m = ld4(mT + o); v = ld4(vT + o); }
+                    float4 wn;
+                    wn.x = upd1(w.x, -gn.x, m.x, v.x, opt, ss_t, bc_t); wn.y = upd1(w.y, -gn.y, m.y, v.y, opt, ss_t, bc_t);
+                    wn.z = upd1(w.z, -gn.z, m.z, v.z, opt, ss_t, bc_t); wn.w = upd1(w.w, -gn.w, m.w, v.w, opt, ss_t, bc_t);
+                    st4(T + o, wn);
+                    if (opt.opt) { st4(mT + o, m); st4(vT + o, v); }
+                }
+            }
+        }
+        lds_barrier();
+    }
+    // ---- this workgroup's partials: weight-gradient tiles (accumulator order), bias sums, loss
+    const size_t pstride = (size_t)net.ntiles * 1024 + net.nbias;
+    float* o = wpart + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+        const int tile = wave + 4 * q;
+        if (tile < net.ntiles) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)tile * 1024 + r * 64 + lane] = wacc[q][r];
+        }
+    }
+    if (t < net.nbias) o[(size_t)net.ntiles * 1024 + t] = bacc[0];
+    if (t + 256 < net.nbias) o[(size_t)net.ntiles * 1024 + 256 + t] = bacc[1];
+    lsum = wave_sum_d(lsum);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void map_finish_kernel(map_net net, map_opt opt, map_params P, const float* __restrict__ wpart,
+                                                         const double* __restrict__ lpart, int nwg, int64_t n, float* __restrict__ loss_out,
+                                                         int64_t* step_s, int64_t* step_t) {
+    const size_t pstride = (size_t)net.ntiles * 1024 + net.nbias;
+    if (blockIdx.x == gridDim.x - 1) {                          // last block: the loss (workgroup order) and the tables' counters
+        __shared__ double red[4];
+        double s[1] = {0.0};
+        for (int b = threadIdx.x; b < nwg; b += 256) s[0] += lpart[b];
+        block_sum_d<1>(s, red);
+        if (threadIdx.x == 0) {
+            loss_out[0] = (float)(s[0] / ((double)n * (double)net.dims[net.L]));
+            if (step_s) step_s[0] += 1;
+            if (step_t) step_t[0] += 1;
+        }
+        return;
+    }
+    // one thread per mapping parameter element: gradient = sum of the workgroup partials in workgroup order, then dense Adam
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int l = 0, isb = 0;
+    int64_t base = 0;
+    bool found = false;
+    for (int q = 0; q < net.L && !found; ++q) {
+        const int64_t nw = (int64_t)net.dims[q] * net.dims[q + 1];
+        if (e < base + nw) { l = q; isb = 0; e -= base; found = true; break; }
+        base += nw;
+        const int64_t nb = net.b[q] ? net.dims[q + 1] : 0;
+        if (e < base + nb) { l = q; isb = 1; e -= base; found = true; break; }
+        base += nb;
+    }
+    if (!found) return;
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    size_t off;
+    if (!isb) {
+        const int m = (int)(e / din), nn = (int)(e - (int64_t)m * din);
+        const int NTW = (din + 31) >> 5;
+        const int tile = net.tile_off[l] + (m >> 5) * NTW + (nn >> 5);
+        const int mm = m & 31, h = (mm >> 2) & 1, r = (mm & 3) + 4 * (mm >> 3);
+        off = (size_t)tile * 1024 + r * 64 + (nn & 31) + 32 * h;
+    } else {
+        off = (size_t)net.ntiles * 1024 + net.bias_off[l] + e;
+    }
+    float g = 0.f;
+    int b = 0;
+    for (; b + 8 <= nwg; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = wpart[(size_t)(b + j) * pstride + off];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g += v[j];
+    }
+    for (; b < nwg; ++b) g += wpart[(size_t)b * pstride + off];
+    float* p = isb ? P.b[l] : P.W[l];
+    float* mp = isb ? P.mb[l] : P.mW[l];
+    float* vp = isb ? P.vb[l] : P.vW[l];
+    const int64_t* sp = isb ? P.sb[l] : P.sW[l];
+    float ss, bc;
+    adam_hp(opt, sp, 0, ss, bc);                               // launch 1 already advanced the parameters' counters
+    float m = 0.f, v = 0.f;
+    if (opt.opt) { m = mp[e]; v = vp[e]; }
+    p[e] = upd1(p[e], g, m, v, opt, ss, bc);
+    if (opt.opt) { mp[e] = m; vp[e] = v; }
+}
+
+int fill(map_net& net, int L, const int* dims, const int* acts, const float* const* W, const float* const* b, size_t* lds_bytes,
+         int* gx_off, int* t_off) {
+    if (L < 1 || L > kMapMaxL || !dims || !W) return 0;
+    memset(&net, 0, sizeof(net));
+    net.L = L; net.vec = 1;
+    int tiles = 0, nb = 0, off = 0;
+    for (int l = 0; l <= L; ++l) { if (dims[l] <= 0 || (dims[l] & 3) || dims[l] > 1024) return 0; net.dims[l] = dims[l]; }
+    for (int l = 0; l < L; ++l) {
+        net.act[l] = acts ? acts[l] : CDR_ACT_NONE;
+        if (net.act[l] != CDR_ACT_NONE && net.act[l] != CDR_ACT_TANH) return 0;
+        net.W[l] = W[l]; net.b[l] = b ? b[l] : nullptr;
+        if (!net.W[l]) return 0;
+        if ((uintptr_t)net.W[l] & 15) net.vec = 0;
+        net.tile_off[l] = tiles; tiles += ((dims[l + 1] + 31) / 32) * ((dims[l] + 31) / 32);
+        net.bias_off[l] = nb; if (net.b[l]) nb += dims[l + 1];
+    }
+    if (net.act[L - 1] != CDR_ACT_NONE) return 0;               // the reference's mapping ends in a plain Linear (emcdr.py:86-93)
+    net.tile_off[L] = tiles; net.bias_off[L] = nb;
+    net.ntiles = tiles; net.nbias = nb;
+    if (tiles > 4 * kSlots || nb > 512) return 0;
+    for (int l = 0; l <= L; ++l) { net.buf_off[l] = off; off += kRows * (dims[l] + 4); }     // X, hidden activations, mapped / gz
+    *gx_off = off; off += kRows * (dims[0] + 4);
+    *t_off = off; off += kRows * (dims[L] + 4);
+    *lds_bytes = (size_t)off * sizeof(float);
+    return *lds_bytes <= 150 * 1024;
+}
+
+inline int wg_count(int64_t n) {
+    int64_t g = (n + kRows - 1) / kRows;
+    if (g > 2 * CDR_NUM_CU) g = 2 * CDR_NUM_CU;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int cdr_map_step_plan(int L, const int* dims, const int* has_bias, int64_t n, size_t* workspace_bytes) {
+    CDR_CHECK_ARG(dims && workspace_bytes && n > 0);
+    map_net net;
+    const float* W[kMapMaxL]; const float* b[kMapMaxL];
+    for (int l = 0; l < kMapMaxL; ++l) { W[l] = (const float*)16; b[l] = (has_bias && l < L && has_bias[l]) ? (const float*)16 : nullptr; }
+    size_t lds; int gx, to;
+    if (!fill(net, L, dims, nullptr, W, b, &lds, &gx, &to)) { cdr_set_error("cdr_map_step_plan: unsupported mapping shape"); return CDR_EINVAL; }
+    const int nwg = wg_count(n);
+    *workspace_bytes = (size_t)nwg * ((size_t)net.ntiles * 1024 + net.nbias) * sizeof(float) + 256 + (size_t)nwg * sizeof(double);
+    return CDR_OK;
+}
+
+extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* src_tab, float* src_m, float* src_v, float* tgt_tab,
+                                   float* tgt_m, float* tgt_v, const int64_t* idx, int64_t n, int L, const int* dims, const int* acts,
+                                   float* const* W, float* const* bias, float* const* mW, float* const* vW, float* const* mb,
+                                   float* const* vb, int64_t* const* step_W, int64_t* const* step_b, int64_t* step_src_dev,
+                                   int64_t* step_tgt_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   float* loss_out, void* workspace, size_t workspace_bytes) {
+    CDR_CHECK_ARG(ctx && src_tab && tgt_tab && idx && n > 0 && W && loss_out && workspace);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && src_m && src_v && tgt_m && tgt_v && mW && vW && step_W && step_src_dev && step_tgt_dev));
+    map_net net;
+    size_t lds; int gx, to;
+    const float* Wc[kMapMaxL]; const float* bc[kMapMaxL];
+    for (int l = 0; l < kMapMaxL; ++l) { Wc[l] = l < L ? W[l] : nullptr; bc[l] = (bias && l < L) ? bias[l] : nullptr; }
+    if (!fill(net, L, dims, acts, Wc, bc, &lds, &gx, &to)) { cdr_set_error("cdr_map_step_unique: unsupported mapping shape"); return CDR_EINVAL; }
+    map_params P;
+    memset(&P, 0, sizeof(P));
+    for (int l = 0; l < L; ++l) {
+        P.W[l] = W[l]; P.b[l] = bias ? bias[l] : nullptr;
+        if (opt == 1) {
+            P.mW[l] = mW[l]; P.vW[l] = vW[l]; P.sW[l] = step_W[l];
+            CDR_CHECK_ARG(P.mW[l] && P.vW[l] && P.sW[l]);
+            if (P.b[l]) { CDR_CHECK_ARG(mb && vb && step_b && mb[l] && vb[l] && step_b[l]); P.mb[l] = mb[l]; P.vb[l] = vb[l]; P.sb[l] = step_b[l]; }
+        }
+    }
+    const int nwg = wg_count(n);
+    const size_t wbytes = (size_t)nwg * ((size_t)net.ntiles * 1024 + net.nbias) * sizeof(float);
+    const size_t woff = (wbytes + 255) & ~(size_t)255;
+    CDR_CHECK_ARG(workspace_bytes >= woff + (size_t)nwg * sizeof(double));
+    float* wpart = (float*)workspace;
+    double* lpart = (double*)((char*)workspace + woff);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)map_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cdr_set_error("cdr_map_step_unique: %zu B of LDS refused: %s", lds, hipGetErrorString(e)); return (int)e; }
+    }
+    const map_opt mo{lr, beta1, beta2, eps, weight_decay, opt};
+    hipStream_t s = (hipStream_t)stream;
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_MAP_STEP, s);
+        map_step_kernel<<<dim3(nwg), dim3(256), lds, s>>>(net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev,
+                                                          step_tgt_dev, gx, to, wpart, lpart, P);
+    }
+    CDR_LAUNCH_CHECK();
+    int64_t elems = 0;
+    for (int l = 0; l < L; ++l) elems += (int64_t)dims[l] * dims[l + 1] + (net.b[l] ? dims[l + 1] : 0);
+    map_finish_kernel<<<dim3((unsigned)((elems + 255) / 256 + 1)), dim3(256), 0, s>>>(net, mo, P, wpart, lpart, nwg, n, loss_out,
+                                                                                      opt == 1 ? step_src_dev : nullptr,
+                                                                                      opt == 1 ? step_tgt_dev : nullptr);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -22,28 +22,33 @@ class RowwiseState:
 
     def __init__(self, table, opt):
         self.table = table
-        self.step = 0
+        self._step = 0
         self.exp_avg = torch.zeros_like(table) if opt == OPT_ADAM else None
         self.exp_avg_sq = torch.zeros_like(table) if opt == OPT_ADAM else None
         self._step_dev = None
 
     @property
+    def step(self):
+        return self._step
+
+    @step.setter
+    def step(self, value):                       # (checkpoint restore, layout changes) keeps the device mirror in step
+        self._step = int(value)
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._step)
+
+    @property
     def step_dev(self):
         """The update count as a device int64 [1] (read by the capturable applies); created on first use from ``step``."""
         if self._step_dev is None:
-            self._step_dev = torch.full((1,), int(self.step), device=self.table.device, dtype=torch.int64)
+            self._step_dev = torch.full((1,), int(self._step), device=self.table.device, dtype=torch.int64)
         return self._step_dev
 
     def advance(self, device_bumped=False):
         """One more update of this table.  ``device_bumped``: a kernel already incremented the device counter."""
-        self.step += 1
+        self._step += 1
         if self._step_dev is not None and not device_bumped:
             B_.call('cdr_inc_i64', B_.stream(), B_.i64(self._step_dev))
-
-    def set_step(self, value):
-        self.step = int(value)
-        if self._step_dev is not None:
-            self._step_dev.fill_(self.step)
 
 
 class FusedBPRStep:
@@ -108,7 +113,7 @@ class FusedBPRStep:
         return self.out6
 
     def _apply(self, ctxh, st, keys, perm, n, G, neg_start, reg_limit, coef, key_base):
-        st.step += 1
+        st.advance()
         B_.call('cdr_rowwise_apply', ctxh, B_.stream(), self.opt, B_.f32(st.table), B_.f32(st.exp_avg),
                 B_.f32(st.exp_avg_sq), self.D, B_.raw(keys), B_.raw(perm), n, B_.f32(G), neg_start, reg_limit,
                 B_.f32(coef), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
@@ -313,7 +318,7 @@ class FusedPointStep:
         ctxh = B_.ctx(self.U.device)
         for st, lo, G, coef, base in ((self.ustate, 0, self.GU, self.out6[4:5], 0),
                                       (self.istate, B, self.GI, self.out6[5:6], self._key_base.value)):
-            st.step += 1
+            st.advance()
             B_.call('cdr_rowwise_apply', ctxh, s, self.opt, B_.f32(st.table), B_.f32(st.exp_avg), B_.f32(st.exp_avg_sq), self.D,
                     B_.raw(self.keys[lo:lo + B]), B_.raw(self.perm[lo:lo + B]), B, B_.f32(G), B, B, B_.f32(coef), float(self.lr),
                     float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), st.step, None, int(base))
@@ -335,7 +340,7 @@ class FusedMapStep:
     """
 
     def __init__(self, source_table, target_table, mapping_fn, mapping_params, max_batch, opt='adam', lr=1e-3,
-                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, group=None, source_state=None, target_state=None):
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, group=None, source_state=None, target_state=None, layers=None):
         from .trainer.trainer import DenseAdam
         assert source_table.is_cuda and target_table.is_cuda, 'FusedMapStep needs ROCm device tensors'
         self.S, self.T = source_table, target_table
@@ -352,6 +357,61 @@ class FusedMapStep:
         self.group = group
         self.loss = torch.zeros((), device=source_table.device, dtype=torch.float32)
         self._ws = None
+        # ``layers``: the mapping function's structure [(weight [out, in], bias or None, ACT_NONE | ACT_TANH), ...] (emcdr.py:59-64,
+        # 86-93).  With it, batches of DISTINCT ids -- what the reference's OverlapDataloader yields -- run as two native launches
+        # (csrc/cdr_mapstep.hip): ``step(idx, unique=True)``.
+        self.layers = None
+        self._uws = None
+        if layers is not None and group is None:
+            dims = [layers[0][0].shape[1]] + [w.shape[0] for w, _, _ in layers]
+            need = ctypes.c_size_t(0)
+            L = len(layers)
+            if L <= 4 and B_.load().cdr_map_step_plan(L, (ctypes.c_int * (L + 1))(*dims), (ctypes.c_int * L)(*[int(b is not None) for _, b, _ in layers]),
+                                                       max(int(max_batch), 1), ctypes.byref(need)) == 0:
+                self.layers, self._dims = list(layers), dims
+                self._loss1 = torch.zeros(1, device=source_table.device, dtype=torch.float32)
+
+    def _step_unique(self, idx):
+        """Two launches: gather + mapping + MSE + backward + in-place row updates + gradient partials, then reduction + dense Adam on
+        the mapping.  Update counts are device counters (capturable)."""
+        n = idx.numel()
+        dev = self.S.device
+        L = len(self.layers)
+        need = ctypes.c_size_t(0)
+        dims_c = (ctypes.c_int * (L + 1))(*self._dims)
+        B_._check(B_.load().cdr_map_step_plan(L, dims_c, (ctypes.c_int * L)(*[int(b is not None) for _, b, _ in self.layers]), n,
+                                              ctypes.byref(need)), 'cdr_map_step_plan')
+        if self._uws is None or self._uws.numel() < need.value:
+            self._uws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+        adam = self.opt == OPT_ADAM
+        ptrs = lambda xs: (ctypes.c_void_p * L)(*[None if x is None else x.data_ptr() for x in xs])
+        Ws = [w.data for w, _, _ in self.layers]
+        bs = [None if b is None else b.data for _, b, _ in self.layers]
+        mW = vW = mb = vb = sW = sb = [None] * L
+        if adam:
+            def st(p):
+                d = self.map_opt.state[p]
+                if not d:
+                    d['step'] = torch.zeros(1, device=dev, dtype=torch.int64)
+                    d['exp_avg'] = torch.zeros_like(p); d['exp_avg_sq'] = torch.zeros_like(p)
+                return d
+            sts = [st(w) for w, _, _ in self.layers]
+            stb = [None if b is None else st(b) for _, b, _ in self.layers]
+            mW, vW, sW = [d['exp_avg'] for d in sts], [d['exp_avg_sq'] for d in sts], [d['step'] for d in sts]
+            mb = [None if d is None else d['exp_avg'] for d in stb]; vb = [None if d is None else d['exp_avg_sq'] for d in stb]
+            sb = [None if d is None else d['step'] for d in stb]
+        keep = [Ws, bs, mW, vW, mb, vb, sW, sb]                         # alive until the call is enqueued
+        ss, ts_ = (self.sstate.step_dev, self.tstate.step_dev) if adam else (None, None)
+        B_.call('cdr_map_step_unique', B_.ctx(dev), B_.stream(), self.opt, B_.f32(self.S), B_.f32(self.sstate.exp_avg),
+                B_.f32(self.sstate.exp_avg_sq), B_.f32(self.T), B_.f32(self.tstate.exp_avg), B_.f32(self.tstate.exp_avg_sq), B_.i64(idx), n,
+                L, dims_c, (ctypes.c_int * L)(*[int(a) for _, _, a in self.layers]), ptrs(Ws), ptrs(bs), ptrs(mW), ptrs(vW), ptrs(mb),
+                ptrs(vb), ptrs(sW), ptrs(sb), B_.i64(ss), B_.i64(ts_), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                float(self.eps), float(self.wd), B_.f32(self._loss1), B_.raw(self._uws), self._uws.numel())
+        del keep
+        self.sstate.advance(device_bumped=True)
+        self.tstate.advance(device_bumped=True)
+        self.loss = self._loss1[0]
+        return self.loss
 
     def _route(self, idx):
         """Global ids -> the local row indices this rank owns (one all-to-all of ids), plus the global batch size."""
@@ -370,11 +430,14 @@ class FusedMapStep:
             return send, 0
         return _a2a(send, t_send, t_recv, self.group), n_global
 
-    def step(self, idx):
+    def step(self, idx, unique=False):
         """idx: int64 device tensor of overlapped ids, any shape ([OB,1] from the OverlapDataloader).  Returns the loss
-        (device scalar; the global-batch MSE when sharded)."""
+        (device scalar; the global-batch MSE when sharded).  ``unique=True`` asserts that the ids are pairwise distinct (slices of
+        a permutation, as the reference's loader yields them): the two-launch path of csrc/cdr_mapstep.hip."""
         idx = idx.reshape(-1).contiguous()
         n_global = idx.numel()
+        if unique and self.layers is not None and n_global > 0:
+            return self._step_unique(idx)
         if self.group is not None:
             idx, n_global = self._route(idx)
         if n_global == 0:                          # an empty batch (on every rank) is a no-op: no state advances
@@ -409,8 +472,8 @@ class FusedMapStep:
                 p.grad = flat[off:off + p.numel()].view_as(p).clone()
                 off += p.numel()
         self.loss = loss
-        self.sstate.step += 1                  # per TABLE, also on a rank that received no ids (the shards stay in step)
-        self.tstate.step += 1
+        self.sstate.advance()                  # per TABLE, also on a rank that received no ids (the shards stay in step)
+        self.tstate.advance()
         if n:
             ctxh = B_.ctx(dev)
             need = ctypes.c_size_t(0)

@@ -265,8 +265,8 @@ class ShardedBPRStep:
         """Generator form of one step: yields at the two points where the host must wait for bucket counts."""
         G, grp, ops = self.world, self.group, self.ops
         B = uid.numel()
-        self.ustate.step += 1                      # per table, on every rank (also one whose buckets came up empty)
-        self.istate.step += 1
+        self.ustate.advance()                      # per table, on every rank (also one whose buckets came up empty)
+        self.istate.advance()
 
         # ---- 0. triples travel to the owner of their user row ---------------------------------------------------
         with self._on_stream():

@@ -248,6 +248,57 @@ def test_fused_step_vs_oracle(opt, D, k):
 
 
 
+@pytest.mark.parametrize('dims,opt,OB', [((64, 64), 'adam', 100), ((128, 128), 'adam', 1000), ((32, 48, 16), 'adam', 100),
+                                         ((128, 64, 128), 'adam', 257), ((64, 128, 64), 'sgd', 100), ((20, 12), 'adam', 33)])
+def test_map_step_unique_ids_vs_oracle(dims, opt, OB):
+    """The two-launch OVERLAP step for batches of DISTINCT ids (what the reference's OverlapDataloader yields: slices of a
+    shuffled arange, dataloader.py:37-52): three free-running steps == the oracle's step (autograd + lazy row-wise Adam on the
+    two tables + torch.optim.Adam / SGD on the mapping): loss every step, both tables, their moments and the mapping at the
+    end; untouched rows bit-identical; and the general (sorting) path on the same ids agrees."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.fused import FusedMapStep
+    gen = torch.Generator().manual_seed(sum(dims) + OB)
+    rows, lr = 1500, 0.01
+    S, T = torch.randn(rows, dims[0], generator=gen) * 0.3, torch.randn(rows, dims[-1], generator=gen) * 0.3
+    cpu, dev_params, fn = _make_mapping(list(dims), 3)
+    if len(dims) == 2:
+        layers = [(dev_params[0], None, B_.ACT_NONE)]
+    else:
+        L = len(dims) - 1
+        layers = [(dev_params[2 * n], dev_params[2 * n + 1], B_.ACT_TANH if n != L - 1 else B_.ACT_NONE) for n in range(L)]
+    Sd, Td = S.clone().to(DEV), T.clone().to(DEV)
+    fm = FusedMapStep(Sd, Td, fn, dev_params, OB, opt=opt, lr=lr, layers=layers)
+    assert fm.layers is not None
+    # the general path on a copy, for cross-checking
+    Sg, Tg = S.clone().to(DEV), T.clone().to(DEV)
+    _, gparams, gfn = _make_mapping(list(dims), 3)
+    fg = FusedMapStep(Sg, Tg, gfn, gparams, OB, opt=opt, lr=lr)
+    sst, tst = ts.RowwiseAdamState(S), ts.RowwiseAdamState(T)
+    mopt = torch.optim.Adam(list(cpu.values()), lr=lr) if opt == 'adam' else torch.optim.SGD(list(cpu.values()), lr=lr)
+    S0 = S.clone()
+    touched = torch.zeros(rows, dtype=torch.bool)
+    for step in range(1, 4):
+        idx = torch.randperm(rows, generator=gen)[:OB].view(-1, 1)                     # [OB, 1] as the loader hands it over (Q7)
+        touched[idx.view(-1)] = True
+        ref = ts.rowwise_map_step(cpu, S, T, sst, tst, idx, step, step, mopt, opt=opt, lr=lr)
+        got = fm.step(idx.to(DEV), unique=True)
+        assert_close(got, ref, what=f'loss step {step}')
+        assert_close(fg.step(idx.to(DEV)), ref, what=f'general path loss step {step}')
+    # Adam weights: lr * m / (sqrt(v) + eps) is ill-conditioned where |g| ~ eps, so a handful of elements may differ by up to
+    # 1e-2 of one update; the moments (checked below at 1e-5) are the well-conditioned comparison
+    tol = dict(rtol=1e-5, atol=lr * 1e-2) if opt == 'adam' else dict(rtol=1e-5)
+    assert_close(Sd, S, what='S', **tol); assert_close(Td, T, what='T', **tol)
+    assert torch.equal(Sd.cpu()[~touched], S0[~touched])
+    if opt == 'adam':
+        assert_close(fm.sstate.exp_avg, sst.m, what='exp_avg S'); assert_close(fm.tstate.exp_avg, tst.m, what='exp_avg T')
+        assert_close(fm.sstate.exp_avg_sq, sst.v, what='exp_avg_sq S')
+        assert int(fm.sstate.step_dev) == 3 and fm.tstate.step == 3
+    for (k, v), p in zip(cpu.items(), dev_params):
+        assert_close(p, v.detach(), what=k, **tol)
+    assert_close(Sd, Sg, what='two paths, S', **tol); assert_close(Td, Tg, what='two paths, T', **tol)
+
+
 def _kmajor_batch(nu, ni, S, k, gen):
     u = torch.randint(0, nu, (S,), generator=gen)
     p = torch.randint(0, ni, (S,), generator=gen)
