@@ -78,6 +78,8 @@ __device__ __forceinline__ float upd1(float w, float g, float& m, float& v, cons
     return w - step_size * (m / (sqrtf(v) / bc2_sqrt + o.eps));
 }
 
+// SLOTS: weight-gradient tiles per wave (4 -> 64 accumulator registers, 8 -> 128)
+template <int SLOTS>
 __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt opt, float* __restrict__ S, float* __restrict__ mS,
                                                        float* __restrict__ vS, float* __restrict__ T, float* __restrict__ mT,
                                                        float* __restrict__ vT, const int64_t* __restrict__ idx, int64_t n,
@@ -102,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
     adam_hp(opt, step_s, 1, ss_s, bc_s);
     adam_hp(opt, step_t, 1, ss_t, bc_t);
     const float gscale = 2.0f / ((float)n * (float)Dt);        // d mean((a-b)^2) / da
-    f32x16 wacc[kSlots];
+    f32x16 wacc[SLOTS];
 #pragma unroll
-    for (int q = 0; q < kSlots; ++q) wacc[q] = zero16();
+    for (int q = 0; q < SLOTS; ++q) wacc[q] = zero16();
     float bacc[2] = {0.f, 0.f};
     double lsum = 0.0;
     const int64_t nrb = (n + kRows - 1) / kRows;
@@ -119,6 +121,25 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
             if (c0 == 0) rowok[row] = valid ? 1.f : 0.f;
         }
         lds_barrier();
+        // ---- touch the NEXT block's rows and moments (one 4-byte load per 128-B line, value unused): a gather of 32 random rows
+        // x 6 arrays over 25-GB tables costs up to ~20 us of TLB walks + HBM latency from one workgroup (measured with
+        // wall_clock64 stamps); started here it runs under this block's MFMA phases.  Tried and dropped: holding the moments in
+        // registers from gather to apply (37 spills, slower), and issuing all 16 moment loads of the apply at once (the TLB
+        // walks of 192 pages then serialise: 17-23 us against 12 us for the chunk-by-chunk loop).
+        float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
+        {
+            const int64_t gn = (rb + gridDim.x) * kRows + (t >> 3);
+            if (gn < n) {
+                const int64_t idn = idx[gn];
+                const int c0 = t & 7, side = c0 >> 2, line = c0 & 3;
+                const int Dd = side ? Dt : Ds;
+                const float* w = side ? T : S; const float* m = side ? mT : mS; const float* v = side ? vT : vS;
+                for (int ln = line; ln * 32 < Dd; ln += 4) {
+                    pf0 += w[idn * Dd + ln * 32];
+                    if (opt.opt) { pf1 += m[idn * Dd + ln * 32]; pf2 += v[idn * Dd + ln * 32]; }
+                }
+            }
+        }
         // ---- forward through the mapping (emcdr.py:86-93); the last layer's epilogue leaves gz = dL/d mapped in its buffer
         for (int l = 0; l < L; ++l) {
             const int din = net.dims[l], dout = net.dims[l + 1];
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
             const int MT = (dout + 31) >> 5, NTW = (din + 31) >> 5;
             // (1) dW_l += gz^T x input: this wave's tiles of layer l
 #pragma unroll
-            for (int q = 0; q < kSlots; ++q) {
+            for (int q = 0; q < SLOTS; ++q) {
                 const int tile = wave + 4 * q;
                 if (tile >= net.tile_off[l] && tile < net.tile_off[l + 1]) {             // wave-uniform
                     const int loc = tile - net.tile_off[l], mt = loc / NTW, nt = loc - mt * NTW;
@@ -272,13 +293,14 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                 }
             }
         }
+        asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2));          // keeps the touch loads alive; they have long landed
         lds_barrier();
     }
     // ---- this workgroup's partials: weight-gradient tiles (accumulator order), bias sums, loss
     const size_t pstride = (size_t)net.ntiles * 1024 + net.nbias;
     float* o = wpart + (size_t)blockIdx.x * pstride;
 #pragma unroll
-    for (int q = 0; q < kSlots; ++q) {
+    for (int q = 0; q < SLOTS; ++q) {
         const int tile = wave + 4 * q;
         if (tile < net.ntiles) {
 #pragma unroll
@@ -432,16 +454,20 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
     CDR_CHECK_ARG(workspace_bytes >= woff + (size_t)nwg * sizeof(double));
     float* wpart = (float*)workspace;
     double* lpart = (double*)((char*)workspace + woff);
+    const bool few = net.ntiles <= 16;
+    const void* fn = few ? (const void*)map_step_kernel<4> : (const void*)map_step_kernel<8>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)map_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cdr_set_error("cdr_map_step_unique: %zu B of LDS refused: %s", lds, hipGetErrorString(e)); return (int)e; }
     }
     const map_opt mo{lr, beta1, beta2, eps, weight_decay, opt};
     hipStream_t s = (hipStream_t)stream;
     {
         cdr_time_scope ts(ctx, CDR_TAG_MAP_STEP, s);
-        map_step_kernel<<<dim3(nwg), dim3(256), lds, s>>>(net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev,
-                                                          step_tgt_dev, gx, to, wpart, lpart, P);
+#define MS_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, gx, to, wpart, lpart, P
+        if (few) map_step_kernel<4><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);
+        else map_step_kernel<8><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);
+#undef MS_ARGS
     }
     CDR_LAUNCH_CHECK();
     int64_t elems = 0;

@@ -73,6 +73,13 @@ class EMCDR(CrossDomainRecommender):
         self.phase = phase
 
     # ---- mapping function on the fp32 MFMA kernel --------------------------------------------------------------
+    def mapping_layers(self):
+        """[(weight, bias or None, activation after the layer)] of the mapping function (emcdr.py:59-64,86-93)."""
+        if self.map_func == 'linear':
+            return [(self.mapping.weight, None, B_.ACT_NONE)]
+        lins = [m for m in self.mapping if isinstance(m, nn.Linear)]
+        return [(l.weight, l.bias, B_.ACT_TANH if n != len(lins) - 1 else B_.ACT_NONE) for n, l in enumerate(lins)]
+
     def apply_mapping(self, x):
         if self.map_func == 'linear':
             return F_.linear(x, self.mapping.weight, None, B_.ACT_NONE)
@@ -143,12 +150,14 @@ class EMCDR(CrossDomainRecommender):
             if key not in cache['steps']:
                 cache['steps'][key] = FusedMapStep(
                     getattr(self, f'source_{kind}_embedding').weight.data, getattr(self, f'target_{kind}_embedding').weight.data,
-                    self.apply_mapping, list(self.mapping.parameters()), idx.numel(),
+                    self.apply_mapping, list(self.mapping.parameters()), idx.numel(), layers=self.mapping_layers(),
                     source_state=state(f'source_{kind}_embedding'), target_state=state(f'target_{kind}_embedding'), **hp)
                 pending = self.__dict__.get('_pending_map_state', {}).pop(kind, None)
                 if pending is not None and cache['steps'][key].map_opt is not None:
                     cache['steps'][key].map_opt.load_state_dict(pending)
-            return cache['steps'][key].step(idx)
+            # the reference's OverlapDataloader yields slices of a shuffled arange (data/dataloader.py:37-52): distinct ids, which
+            # the two-launch step relies on.  A caller feeding its own, possibly repeated ids sets model.overlap_ids_unique = False.
+            return cache['steps'][key].step(idx, unique=getattr(self, 'overlap_ids_unique', True))
         domain = 'source' if self.phase == 'SOURCE' else 'target'
         user = interaction[getattr(self, f'{domain.upper()}_USER_ID')].reshape(-1)
         item = interaction[getattr(self, f'{domain.upper()}_ITEM_ID')].reshape(-1)
