@@ -62,6 +62,7 @@ class DomainTrainLoader:
         if self.input_type == InputType.PAIRWISE:
             out = cur.repeat(self.neg_k)
             out[self.neg_iid_field] = neg
+            out.k_major = self.neg_k             # layout hint for the per-positive fused step: S positives tiled k times
             return out
         out = cur.repeat(self.times)
         out[self.iid_field] = torch.cat([items, neg])

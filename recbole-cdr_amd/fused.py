@@ -16,6 +16,8 @@ OPT_SGD, OPT_ADAM = 0, 1
 
 
 class RowwiseState:
+    _step = 0                 # class-level defaults: objects built with __new__ (layout transposes in dimshard.py) start consistent
+    _step_dev = None
     """Per-table optimizer state for the row-wise Adam (SGD needs no moments).  ``step`` counts the updates this TABLE
     has received -- like torch.optim.Adam's per-parameter ``state['step']`` -- so one state object can be shared by the
     step objects of several phases (SOURCE / TARGET BPR steps and the OVERLAP map step touch the same user tables)."""

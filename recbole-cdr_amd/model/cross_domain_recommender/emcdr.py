@@ -173,6 +173,23 @@ class EMCDR(CrossDomainRecommender):
                 cache['steps'][key] = step
             return step.step(user, item, label)[0]
         neg = interaction[getattr(self, f'{domain.upper()}_NEG_ITEM_ID')].reshape(-1)
+        # recbole's pairwise batches tile S positives k times with k-major negatives (crossdomain_sampler.py:148-152); the loader
+        # says so (Interaction.k_major).  Then the per-positive step serves k >= 2 (u, p gathered once per positive) and every
+        # batch small enough for its four-launch form (the reference default of 2,048 rows); k = 1 at large batches stays on the
+        # per-triple step, which is faster there.
+        k = getattr(interaction, 'k_major', None)
+        rows = user.numel()
+        if k is not None and rows % k == 0 and (k >= 2 or rows + rows // k <= 8192):
+            from ...fused import KMajorBPRStep
+            key = ('bprk', domain, k)
+            step = cache['steps'].get(key)
+            if step is None or step.max_positives < rows // k:
+                step = KMajorBPRStep(getattr(self, f'{domain}_user_embedding').weight.data,
+                                     getattr(self, f'{domain}_item_embedding').weight.data, rows // k, k=k, gamma=self.bpr_gamma,
+                                     reg_weight=self.reg_weight, user_state=state(f'{domain}_user_embedding'),
+                                     item_state=state(f'{domain}_item_embedding'), **hp)
+                cache['steps'][key] = step
+            return step.step(user, item, neg)[0]
         key = ('bpr', domain)
         step = cache['steps'].get(key)
         if step is None or step.max_batch < user.numel():
