@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c5', choices=['c5', 'c1', 'c2', 'c3', 'c4'])
+    ap.add_argument('--dense-adam', action='store_true', help='c3: the literal O(table) dense Adam sweep instead of its deferred row-wise form')
     ap.add_argument('--batch', type=int, default=1 << 20, help='triples per domain per rank per step (c5)')
     ap.add_argument('--opt', default='adam', choices=['adam', 'sgd'])
     ap.add_argument('--users', type=int, default=50_000_001)
@@ -575,7 +576,16 @@ def run_model_workload(args, world, rank, dev):
                              'full-graph propagation every step' % (len(ds.s_pairs), len(ds.t_pairs))
     torch.manual_seed(2022)
     model = Model(cfg, ds).to(dev)
-    opt = DenseAdam(model.parameters(), lr=1e-3)
+    # Optimizer: the reference's Adam over every parameter.  For CoNet (C3) the tables take its deferred row-wise form
+    # (lazyadam.DeferredRowAdam: rows without a gradient postpone their momentum updates and replay them when next read --
+    # bit-identical to the dense sweep, tests/test_gpu_parity.py::test_deferred_adam_is_bit_identical_to_the_dense_sweep);
+    # --dense-adam times the literal O(table) sweep instead.
+    deferred = args.workload == 'c3' and not args.dense_adam and world == 1 and getattr(model, 'fused_towers', False)
+    if deferred:
+        from recbole_cdr_amd.trainer.trainer import RowAwareAdam
+        opt = RowAwareAdam(model, lr=1e-3)
+    else:
+        opt = DenseAdam(model.parameters(), lr=1e-3)
     rng = np.random.RandomState(2022)
     if pairwise:
         model.set_phase('SOURCE')
@@ -622,7 +632,7 @@ def run_model_workload(args, world, rank, dev):
     result = {'metric': 'training interactions/sec', 'value': rows_per_step * args.steps * world / dt, 'unit': 'interactions/s',
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-              'config': {'workload': name + ', drop-in autograd + exact dense Adam' + (', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
+              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
                          'rows_per_step': rows_per_step},
               'final_loss': float(loss.sum())}
     if rank == 0 and not args.no_cpu_baseline:

@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 18
+#define CDR_ABI_VERSION 19
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -267,6 +267,29 @@ int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* src_tab, flo
                         float* const* vb, int64_t* const* step_W, int64_t* const* step_b, int64_t* step_src_dev,
                         int64_t* step_tgt_dev, float lr, float beta1, float beta2, float eps, float weight_decay, float* loss_out,
                         void* workspace, size_t workspace_bytes);
+
+/* ---- exact dense Adam evaluated lazily per row (the reference's torch.optim.Adam over whole tables, recbole Trainer) -----------
+ * A row without a gradient in update tau evolves by a recurrence of its own (w, m, v) and tau only, so those updates are postponed
+ * and replayed, in order, when the row is next needed: bit-identical to the dense sweep of cdr_adam_multi_dev (shared,
+ * contraction-free arithmetic), at 3 row reads + 3 row writes per touched row instead of 7 x the table per step.
+ *   state per table: W, M, V [rows, D] and last [rows] (int32, zero-initialised: the update each row reflects);
+ *   shared: hp_table (float2 [capacity]: step_size, sqrt(bias correction 2) per update, filled on the device),
+ *           counters (int64 [2], zero-initialised: [0] updates completed, [1] update in progress).
+ *   cdr_lazy_adam_prepare : BEFORE the forward pass: every distinct row of keys_sorted (per table; cdr_sort_ids / _small) replays its
+ *                           postponed updates up to the one before the coming update.  step_host = the coming update's number
+ *                           (bounds check against hp_capacity only).
+ *   cdr_lazy_adam_apply   : AFTER the backward pass: the coming update with gradient sum_occurrences G[perm[e] * ldg .. + D)
+ *                           (occurrence order), then counters[0] advances.
+ *   cdr_lazy_adam_flush   : every row of one table replays up to counters[0] (evaluation, state_dict, checkpoint).              */
+int cdr_lazy_adam_prepare(void* stream, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
+                          const uint32_t* const* keys_sorted, const int64_t* n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, void* hp_table, int64_t hp_capacity, int64_t* counters, int64_t step_host);
+int cdr_lazy_adam_apply(void* stream, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
+                        const uint32_t* const* keys_sorted, const uint32_t* const* perm, const int64_t* n, const float* const* G,
+                        const int64_t* ldg, float lr, float beta1, float beta2, float eps, float weight_decay, const void* hp_table,
+                        int64_t* counters);
+int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32_t* last, int64_t rows, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, const void* hp_table, const int64_t* counters);
 
 /* ---- CoNet towers fused (conet.py:105-203: source_forward + target_forward + BCELoss x2 + reg) -------------------------
  * One stack of R rows -- rows [0, n_source) are the source batch, the rest the target batch -- runs BOTH towers through the

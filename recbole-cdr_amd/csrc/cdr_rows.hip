@@ -2,6 +2,7 @@
 // (K7), activation backward, column sums, MSE, exact dense Adam (K13).  All HBM-bound: 16 B per lane, whole rows per
 // wave-instruction, grid capped at 8 blocks per CU with a grid stride.
 #include "cdr_common.h"
+#include "cdr_adam_math.h"
 
 namespace {
 
@@ -212,18 +213,13 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
     const int64_t n = a.n[t];
-    const double st = (double)a.step[t][0];
-    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, st)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    float step_size, bc2_sqrt;
+    cdr_adam_hp((double)a.step[t][0], lr, b1, b2, step_size, bc2_sqrt);
     const int64_t stride = (int64_t)nb * kBlock;
     for (int64_t e = (int64_t)lb * kBlock + threadIdx.x; e < n; e += stride) {
-        float gv = g[e];
-        const float pv = p[e];
-        if (wd != 0.f) gv += wd * pv;
-        const float mv = m[e] + (gv - m[e]) * (1.0f - b1);
-        const float vv = b2 * v[e] + (1.0f - b2) * gv * gv;
+        float mv = m[e], vv = v[e];
+        p[e] = cdr_adam_elem(p[e], g[e], mv, vv, b1, b2, eps, wd, step_size, bc2_sqrt);   // shared with the deferred per-row form
         m[e] = mv; v[e] = vv;
-        p[e] = pv - step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
     }
 }
 

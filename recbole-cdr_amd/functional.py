@@ -413,7 +413,7 @@ class ConetFusedLoss(Function):
     (wo_s, bo_s, wo_t, bo_t)."""
 
     @staticmethod
-    def forward(ctx, su, si, tu, ti, user, item, label, n_source, n_overlap, overlap_users, dims, *params):
+    def forward(ctx, su, si, tu, ti, user, item, label, n_source, n_overlap, overlap_users, dims, row_opt, *params):
         _dev_check(su, si, tu, ti, user, item, label, *params)
         user, item = _ids(user), _ids(item)
         label = label.reshape(-1).contiguous().to(torch.float32)
@@ -431,6 +431,7 @@ class ConetFusedLoss(Function):
                 B_.f32(x0), B_.f32(acts), B_.f32(prob), B_.f32(maskf), B_.f32(out))
         ctx.save_for_backward(user, item, label, x0, acts, prob, maskf, out, *params)
         ctx.meta = (int(n_source), tuple(int(d) for d in dims), aw.value, int(need.value), tuple(su.shape), tuple(si.shape))
+        ctx.row_opt = row_opt
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
 
@@ -455,12 +456,17 @@ class ConetFusedLoss(Function):
         go = grad_loss.reshape(-1).contiguous().to(torch.float32)
         B_.call('cdr_conet_bwd', B_.ctx(dev), B_.stream(), R, n_source, L, dims_c, pp, B_.f32(label), B_.f32(x0), B_.f32(acts),
                 B_.f32(prob), B_.f32(maskf), B_.f32(out), B_.f32(go), B_.f32(gz), B_.f32(gx0), gp, B_.raw(ws), ws.numel())
+        del pp, gp
+        if ctx.row_opt is not None:
+            # deferred row-wise Adam (lazyadam.DeferredRowAdam): the tables get no dense gradient at all -- the optimizer reads
+            # the per-occurrence rows of gx0 through the id sort it made before the forward pass
+            ctx.row_opt.pending = (gx0, (0, D, 2 * D, 3 * D), 4 * D)
+            return (None,) * 12 + grads
         gsu, gtu = torch.zeros(ushape, device=dev), torch.zeros(ushape, device=dev)
         gsi, gti = torch.zeros(ishape, device=dev), torch.zeros(ishape, device=dev)
         for k, (g, ids) in enumerate(((gsu, user), (gsi, item), (gtu, user), (gti, item))):
             B_.call('cdr_scatter_add_rows_ld', B_.stream(), B_.f32(g), D, B_.i64(ids), R, B_._c_ptr(gx0.data_ptr() + 4 * k * D), 4 * D)
-        del params, pp, gp
-        return (gsu, gsi, gtu, gti, None, None, None, None, None, None, None) + grads
+        return (gsu, gsi, gtu, gti, None, None, None, None, None, None, None, None) + grads
 
 
 # ---------------------------------------------------------------------------------------------------- SSCDR pieces

@@ -51,4 +51,6 @@ class GraphedTrainStep:
         for k, v in self.static.items():
             v.copy_(interaction[k])
         self.graph.replay()
+        if hasattr(self.optimizer, 'on_replay'):
+            self.optimizer.on_replay()            # host-side bookkeeping of optimizers whose update count lives on the device
         return self.loss

@@ -1,0 +1,137 @@
+"""Exact dense Adam over embedding tables, evaluated lazily per row (csrc/cdr_lazyadam.hip).
+
+The reference's optimizer (recbole ``Trainer``: ``torch.optim.Adam(model.parameters())``) sweeps every table every step.  A row
+that gets no gradient in an update evolves by a recurrence of its own state and the update number only, so ``DeferredRowAdam``
+postpones those updates and replays them, in order, just before the row is read (``prepare``) or when every row is needed
+(``flush``: evaluation, ``state_dict``).  The result is bit-identical to the dense sweep of ``trainer.DenseAdam`` -- same
+operations in the same order on the same operands -- at O(batch) memory traffic per step.
+"""
+import ctypes
+
+import torch
+
+from . import binding as B_
+
+
+class DeferredRowAdam:
+    """``tables``: nn.Parameters [rows, D] (same D).  ``table_list[i]``: which id list of ``prepare(id_lists)`` indexes table i
+    (CoNet: [source_user, source_item, target_user, target_item] -> [0, 1, 0, 1] for id lists [user ids, item ids])."""
+
+    def __init__(self, tables, table_list, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capacity=1 << 20):
+        self.tables = list(tables)
+        self.table_list = list(table_list)
+        assert len(self.tables) == len(self.table_list) and 1 <= len(self.tables) <= 4
+        self.D = self.tables[0].shape[1]
+        assert all(t.is_cuda and t.shape[1] == self.D and t.is_contiguous() for t in self.tables)
+        self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        dev = self.tables[0].device
+        self.exp_avg = [torch.zeros_like(t.data) for t in self.tables]
+        self.exp_avg_sq = [torch.zeros_like(t.data) for t in self.tables]
+        self.last = [torch.zeros(t.shape[0], device=dev, dtype=torch.int32) for t in self.tables]
+        self.capacity = int(capacity)
+        self.hp = torch.zeros(self.capacity, 2, device=dev, dtype=torch.float32)
+        self.counters = torch.zeros(2, device=dev, dtype=torch.int64)
+        self.step_count = 0              # host mirror of counters[0]
+        self.dirty = False               # some row may be behind counters[0]
+        self._sorted = None
+        self._bufs = {}
+        self.pending = None              # (G tensor, [column offset per table], ld) stashed by the model's backward
+
+    # ---- id sort (per list): the small rank sort up to 16,384 ids, the radix sort above --------------------------------------
+    def _sort(self, id_lists):
+        dev = self.tables[0].device
+        ns = [int(x.numel()) for x in id_lists]
+        key = tuple(ns)
+        if key not in self._bufs:
+            tot = sum(ns)
+            self._bufs[key] = (torch.empty(tot, device=dev, dtype=torch.int32), torch.empty(tot, device=dev, dtype=torch.int32),
+                               torch.zeros(tot, device=dev, dtype=torch.int32))
+        keys, perm, rank = self._bufs[key]
+        offs, o = [], 0
+        for n in ns:
+            offs.append(o); o += n
+        if max(ns) <= 16384 and len(ns) <= 4:
+            m = len(ns)
+            B_._alive.extend(id_lists)
+            B_.call('cdr_sort_ids_small', B_.stream(), m, (ctypes.c_void_p * m)(*[x.data_ptr() for x in id_lists]), (ctypes.c_int64 * m)(*ns),
+                    None, None, (ctypes.c_int64 * m)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank))
+        else:
+            for x, n, of in zip(id_lists, ns, offs):
+                rows = max(t.shape[0] for t in self.tables)
+                need = ctypes.c_size_t(0)
+                B_._check(B_.load().cdr_sort_workspace_bytes(n, rows, ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+                ws = self._bufs.get(('ws', n))
+                if ws is None or ws.numel() < need.value:
+                    ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+                    self._bufs[('ws', n)] = ws
+                B_.call('cdr_sort_ids', B_.ctx(dev), B_.stream(), B_.i64(x), n, None, 0, rows, B_.raw(keys[of:of + n]), B_.raw(perm[of:of + n]),
+                        B_.raw(ws), ws.numel())
+        return [(keys[of:of + n], perm[of:of + n], n) for n, of in zip(ns, offs)]
+
+    def _ptrs(self, xs):
+        return (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+
+    @torch.no_grad()
+    def prepare(self, id_lists):
+        """Before the forward pass: sort the batch's ids and bring their rows up to the update before the coming one."""
+        id_lists = [x.reshape(-1).contiguous().to(torch.int64) for x in id_lists]
+        self._sorted = self._sort(id_lists)
+        per = [self._sorted[j] for j in self.table_list]
+        nT = len(self.tables)
+        if self.step_count + 1 >= self.capacity:
+            raise RuntimeError('DeferredRowAdam: more updates than its bias-correction table holds; raise `capacity`')
+        keep = [[t.data for t in self.tables], self.exp_avg, self.exp_avg_sq, self.last, [k for k, _, _ in per]]
+        B_.call('cdr_lazy_adam_prepare', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
+                self._ptrs(keep[3]), self._ptrs(keep[4]), (ctypes.c_int64 * nT)(*[n for _, _, n in per]), self.lr, self.betas[0],
+                self.betas[1], self.eps, self.wd, B_.raw(self.hp), self.capacity, B_.i64(self.counters), self.step_count + 1)
+        del keep
+
+    @torch.no_grad()
+    def step(self):
+        """After the backward pass: the coming update for the batch's rows (``self.pending`` set by the model's backward)."""
+        if self.pending is None:
+            return
+        G, cols, ld = self.pending
+        self.pending = None
+        per = [self._sorted[j] for j in self.table_list]
+        nT = len(self.tables)
+        keep = [[t.data for t in self.tables], self.exp_avg, self.exp_avg_sq, self.last, [k for k, _, _ in per], [p for _, p, _ in per], G]
+        gp = (ctypes.c_void_p * nT)(*[G.data_ptr() + 4 * c for c in cols])
+        B_.call('cdr_lazy_adam_apply', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
+                self._ptrs(keep[3]), self._ptrs(keep[4]), self._ptrs(keep[5]), (ctypes.c_int64 * nT)(*[n for _, _, n in per]), gp,
+                (ctypes.c_int64 * nT)(*([int(ld)] * nT)), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp),
+                B_.i64(self.counters))
+        del keep
+        if not torch.cuda.is_current_stream_capturing():     # a capture only records the launches: replays do the bookkeeping
+            self.on_replay()
+
+    def on_replay(self):
+        """Host bookkeeping of one completed update (also called after a hipGraph replay of prepare + step)."""
+        self.step_count += 1
+        self.dirty = True
+
+    @torch.no_grad()
+    def flush(self):
+        """Every row of every table up to the current update: what the dense sweep would have left in memory."""
+        if not self.dirty:
+            return
+        for t, m, v, last in zip(self.tables, self.exp_avg, self.exp_avg_sq, self.last):
+            B_.call('cdr_lazy_adam_flush', B_.stream(), self.D, B_.f32(t.data), B_.f32(m), B_.f32(v), B_.raw(last), t.shape[0], self.lr,
+                    self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp), B_.i64(self.counters))
+        self.dirty = False
+
+    def state_dict(self):
+        self.flush()
+        return {'step': self.step_count, 'exp_avg': [m.clone() for m in self.exp_avg], 'exp_avg_sq': [v.clone() for v in self.exp_avg_sq]}
+
+    def load_state_dict(self, sd):
+        """Resume: all rows are current at update ``step``; the bias-correction table is refilled lazily by the coming prepares, so
+        the entries of the past updates are recomputed here on the host with the same double-precision expressions."""
+        import math
+        self.step_count = int(sd['step'])
+        for m, v, a, b in zip(self.exp_avg, self.exp_avg_sq, sd['exp_avg'], sd['exp_avg_sq']):
+            m.copy_(a); v.copy_(b)
+        for last in self.last:
+            last.fill_(self.step_count)
+        self.counters.fill_(self.step_count)
+        self.dirty = False

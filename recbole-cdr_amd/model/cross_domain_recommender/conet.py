@@ -52,9 +52,31 @@ class CoNet(CrossDomainRecommender):
         self._dims = tuple(dims)
         fused = config['conet_fused'] if 'conet_fused' in config else True
         self.fused_towers = bool(fused) and self.latent_dim % 4 == 0 and F_.conet_supported(self._dims)
+        self.row_opt = None          # lazyadam.DeferredRowAdam over the four tables (enable_deferred_adam)
+
+    # ---- exact dense Adam over the four tables, evaluated lazily per row (lazyadam.py) ---------------------------------------
+    def table_parameters(self):
+        return [self.source_user_embedding.weight, self.source_item_embedding.weight, self.target_user_embedding.weight,
+                self.target_item_embedding.weight]
+
+    def enable_deferred_adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """The reference's torch.optim.Adam semantics for the embedding tables at O(batch) cost per step: rows without a
+        gradient postpone their momentum updates and replay them when next read -- bit-identical to the dense sweep
+        (tests: test_deferred_adam_*).  Needs the fused tower path.  Returns the optimizer (``.step()`` after backward;
+        trainer.RowAwareAdam does that inside ``optimizer.step()``)."""
+        from ...lazyadam import DeferredRowAdam
+        assert self.fused_towers, 'the deferred row-wise Adam rides on the fused tower kernels'
+        self.row_opt = DeferredRowAdam(self.table_parameters(), [0, 1, 0, 1], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        return self.row_opt
+
+    def sync_tables(self):
+        """Every table row up to date (no-op unless a deferred optimizer has postponed work): before anything reads whole tables."""
+        if self.row_opt is not None:
+            self.row_opt.flush()
 
     # ---- both towers through every cross unit ----------------------------------------------------------------------
     def _towers(self, user, item):
+        self.sync_tables()
         s = F_.GatherConcat2.apply(self.source_user_embedding.weight, self.source_item_embedding.weight, user, item)
         t = F_.GatherConcat2.apply(self.target_user_embedding.weight, self.target_item_embedding.weight, user, item)
         if self.mode == 'overlap_users':
@@ -65,6 +87,10 @@ class CoNet(CrossDomainRecommender):
             ls, lt = self.source_crossunit_linear[l], self.target_crossunit_linear[l]
             s, t = F_.CrossUnit.apply(s, t, ls.weight, ls.bias, lt.weight, lt.bias, self.crossparas[l].weight, m)
         return s, t
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_tables()
+        return super().state_dict(*args, **kwargs)
 
     def source_forward(self, user, item):
         s, _ = self._towers(user, item)
@@ -96,10 +122,15 @@ class CoNet(CrossDomainRecommender):
             # the whole loss as one autograd node on csrc/cdr_conet.hip (one forward launch, three backward launches)
             label = torch.cat([interaction[self.SOURCE_LABEL].reshape(-1), interaction[self.TARGET_LABEL].reshape(-1)])
             over_users = self.mode == 'overlap_users'
+            row_opt = self.row_opt if (self.row_opt is not None and torch.is_grad_enabled()) else None
+            if row_opt is not None:
+                row_opt.prepare([user, item])        # the batch's rows replay their postponed Adam updates before they are read
+            else:
+                self.sync_tables()
             loss, self.last_loss_parts = F_.ConetFusedLoss.apply(
                 self.source_user_embedding.weight, self.source_item_embedding.weight, self.target_user_embedding.weight,
                 self.target_item_embedding.weight, user, item, label, n_s,
-                self.overlapped_num_users if over_users else self.overlapped_num_items, over_users, self._dims,
+                self.overlapped_num_users if over_users else self.overlapped_num_items, over_users, self._dims, row_opt,
                 *self._fused_params())
             return loss
         s, t = self._towers(user, item)
@@ -122,6 +153,7 @@ class CoNet(CrossDomainRecommender):
 
     @torch.no_grad()
     def predict(self, interaction):
+        self.sync_tables()
         x = F_.GatherConcat2.apply(self.target_user_embedding.weight, self.target_item_embedding.weight,
                                    interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID])
         return self._target_tower_tail(x, 0)                        # [B,1]
@@ -132,6 +164,7 @@ class CoNet(CrossDomainRecommender):
         once per call, each user adds its own W1u u + b1 (one broadcast-add-ReLU pass), layers 2.. run as contractions
         over the N rows -- instead of the reference's Python loop over users with a repeat()ed [N, 2D] input."""
         D = self.latent_dim
+        self.sync_tables()
         user_e = F_.gather_rows(self.target_user_embedding.weight, interaction[self.TARGET_USER_ID])
         items = self.target_item_embedding.weight[:self.target_num_items]
         lin1 = self.target_crossunit_linear[0]

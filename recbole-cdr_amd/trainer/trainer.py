@@ -46,6 +46,37 @@ class DenseAdam(torch.optim.Optimizer):
                     float(group['weight_decay']))
 
 
+class RowAwareAdam(DenseAdam):
+    """``DenseAdam`` for a model whose embedding tables take the deferred row-wise form of the SAME optimizer
+    (``model.enable_deferred_adam``; lazyadam.DeferredRowAdam: exact dense-Adam results, O(batch) traffic).  ``step()`` = the
+    dense kernels for every parameter that has a ``.grad`` (the MLP / mapping weights) + the row-wise update of the tables the
+    model's backward left pending.  Drop-in for the reference's loop: zero_grad -> calculate_loss -> backward -> step."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.row_opt = model.enable_deferred_adam(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        super().step(closure)
+        self.row_opt.step()
+
+    def on_replay(self):
+        self.row_opt.on_replay()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['deferred_rows'] = self.row_opt.state_dict()
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        rows = sd.pop('deferred_rows', None)
+        super().load_state_dict(sd)
+        if rows is not None:
+            self.row_opt.load_state_dict(rows)
+
+
 def early_stopping(value, best, cur_step, max_step, bigger=True):
     """recbole.utils.early_stopping."""
     stop_flag, update_flag = False, False

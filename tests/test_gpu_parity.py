@@ -801,6 +801,93 @@ def test_conet_fused_ragged_shapes_and_determinism(R, n_s, hidden, D):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+@pytest.mark.parametrize('wd', [0.0, 0.01])
+def test_deferred_adam_is_bit_identical_to_the_dense_sweep(wd):
+    """lazyadam.DeferredRowAdam == trainer.DenseAdam (the reference's torch.optim.Adam semantics over whole tables) BIT FOR BIT:
+    15 updates with random row subsets (a few rows every step, some rows never), two id lists over four tables, a flush in the
+    middle, weight decay on and off.  Rows, both moments, all of it torch.equal after the final flush."""
+    from recbole_cdr_amd.lazyadam import DeferredRowAdam
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    gen = torch.Generator().manual_seed(11)
+    D, rows = 64, (700, 500)
+    tabs = [torch.randn(rows[i % 2], D, generator=gen) * 0.1 for i in range(4)]
+    dense = [torch.nn.Parameter(t.clone().to(DEV)) for t in tabs]
+    lazy = [torch.nn.Parameter(t.clone().to(DEV)) for t in tabs]
+    od = DenseAdam(dense, lr=0.01, weight_decay=wd)
+    ol = DeferredRowAdam(lazy, [0, 1, 0, 1], lr=0.01, weight_decay=wd)
+    for step in range(15):
+        n = [int(torch.randint(1, 60, (1,), generator=gen)), int(torch.randint(1, 40, (1,), generator=gen))]
+        ids = [torch.randperm(rows[j], generator=gen)[:n[j]].to(DEV) for j in range(2)]          # distinct: no summation order at play
+        R = max(n)
+        G = (torch.randn(R, 4 * D, generator=gen) * (10.0 ** float(torch.randint(-6, 0, (1,), generator=gen)))).to(DEV)
+        ol.prepare(ids)
+        for t in range(4):
+            j = t % 2
+            g = torch.zeros_like(dense[t])
+            g[ids[j]] = G[:n[j], t * D:(t + 1) * D]
+            dense[t].grad = g
+        od.step()
+        ol.pending = (G, (0, D, 2 * D, 3 * D), 4 * D)
+        ol.step()
+        if step == 7:
+            ol.flush()
+            for a, b in zip(dense, lazy):
+                assert torch.equal(a.data, b.data)
+    assert ol.step_count == 15 and int(ol.counters[0]) == 15
+    untouched = int((ol.last[0] < 15).sum())
+    assert untouched > 0                                         # the point: most rows were NOT brought up to date step by step
+    ol.flush()
+    for t in range(4):
+        assert torch.equal(dense[t].data, lazy[t].data), t
+        assert torch.equal(od.state[dense[t]]['exp_avg'], ol.exp_avg[t]), t
+        assert torch.equal(od.state[dense[t]]['exp_avg_sq'], ol.exp_avg_sq[t]), t
+
+
+def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
+    """CoNet with RowAwareAdam (tables: deferred row-wise Adam; towers: dense Adam) against DenseAdam over everything: 6 steps on
+    fresh batches, losses at 1e-5 and parameters at Adam's drift bound (the dense route scatters gradients with float atomics, so
+    the two are not bit-comparable); then the deferred route eager vs captured as one hipGraph: BIT-equal (nothing in it is
+    order-dependent), predictions after training included."""
+    import copy
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    from recbole_cdr_amd.trainer.trainer import DenseAdam, RowAwareAdam
+    from recbole_cdr_amd.graph_step import GraphedTrainStep
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    ds = SyntheticCrossDomainDataset(OU=400, TOU=500, SOU=600, OI=1, TOI=700, SOI=800, n_source_inter=5000, n_target_inter=4000, seed=1)
+    cfg = base_config(DEV, embedding_size=32, reg_weight=0.01, mlp_hidden_size=[32, 16, 8])
+    torch.manual_seed(0)
+    m_dense = CoNet(cfg, ds).to(DEV)
+    m_lazy, m_graph = copy.deepcopy(m_dense), copy.deepcopy(m_dense)
+    o_dense = DenseAdam(m_dense.parameters(), lr=0.01)
+    o_lazy, o_graph = RowAwareAdam(m_lazy, lr=0.01), RowAwareAdam(m_graph, lr=0.01)
+    rng = np.random.RandomState(0)
+    batches = [dict(ds.pointwise_batch('source', 64, 2, rng, DEV), **ds.pointwise_batch('target', 64, 2, rng, DEV)) for _ in range(6)]
+
+    def eager(model, opt, b):
+        opt.zero_grad(set_to_none=True)
+        loss = model.calculate_loss(b)
+        loss.backward()
+        opt.step()
+        return loss.detach().clone()
+    g = GraphedTrainStep(m_graph, o_graph, batches[0], warmup=2)
+    for _ in range(2):                                           # the capture warm-up trains on batches[0]: mirror it
+        eager(m_dense, o_dense, batches[0]); eager(m_lazy, o_lazy, batches[0])
+    for b in batches:
+        ld, ll, lg = eager(m_dense, o_dense, b), eager(m_lazy, o_lazy, b), g.step(b).clone()
+        assert_close(ll, ld, what='loss, deferred vs dense')
+        assert torch.equal(ll, lg)
+    assert o_lazy.row_opt.step_count == 8 and o_graph.row_opt.step_count == 8
+    ev = {'target_user_id': batches[0]['target_user_id'][:5], 'target_item_id': batches[0]['target_item_id'][:5]}
+    p_dense, p_lazy, p_graph = m_dense.predict(ev), m_lazy.predict(ev), m_graph.predict(ev)      # predict() flushes the postponed rows
+    assert torch.equal(p_lazy, p_graph)
+    assert_close(p_lazy, p_dense, rtol=1e-4, what='predictions')
+    for (k, a), (_, b), (_, c) in zip(m_dense.named_parameters(), m_lazy.named_parameters(), m_graph.named_parameters()):
+        assert torch.equal(b.data, c.data), k
+        assert_close(b, a, rtol=1e-4, atol=0.01 * 1e-1, what=k)           # 0.1 of one Adam update on the ill-conditioned elements
+    sd = m_lazy.state_dict()
+    assert torch.equal(sd['source_user_embedding.weight'], m_lazy.source_user_embedding.weight.data)
+
+
 @pytest.mark.parametrize('name', cases('sscdr_'))
 def test_sscdr_golden(name):
     from recbole_cdr_amd.model.cross_domain_recommender.sscdr import SSCDR
