@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 19
+#define CDR_ABI_VERSION 21
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -230,7 +230,9 @@ int cdr_bpr_fwd_grad_kmajor(cdr_ctx* ctx, void* stream, const float* user_tab, c
                             float* GU, void* item_rec, int64_t* bump_a, int64_t* bump_b);
 int cdr_sort_ids_small(void* stream, int nseg, const int64_t* const* ids0, const int64_t* n0, const int64_t* const* ids1,
                        const int64_t* n1, const int64_t* out_off, uint32_t* keys_out, uint32_t* perm_out,
-                       uint32_t* rank_scratch /* one uint32 per id, ZERO before the first call; left zero by every call */);
+                       uint32_t* rank_scratch /* one uint32 per id, ZERO before the first call; left zero by every call */,
+                       int64_t max_id /* an upper bound of the ids, or 0: when id and occurrence index fit 32 bits together the
+                                         comparison loop works on one composite word (3x fewer instructions) */);
 int cdr_rowwise_apply_rows(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                            const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const float* G, int64_t reg_limit,
                            const float* reg_coef, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
@@ -244,7 +246,7 @@ int cdr_bpr_step_small(cdr_ctx* ctx, void* stream, int opt, float* user_tab, flo
                        float* item_m, float* item_v, int D, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t S,
                        int k, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t* step_user_dev, int64_t* step_item_dev, float* out9, float* GU, void* item_rec, uint32_t* keys,
-                       uint32_t* perm, uint32_t* rank_scratch);
+                       uint32_t* perm, uint32_t* rank_scratch, int64_t max_rows /* >= rows of both tables, or 0 */);
 int cdr_rowwise_apply_scaled(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                              const uint32_t* keys_sorted, const uint32_t* perm, int64_t n, const void* item_rec,
                              const float* src_table, int64_t reg_limit, const float* reg_coef, float lr, float beta1, float beta2,
@@ -292,7 +294,8 @@ int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32
                         float beta2, float eps, float weight_decay, const void* hp_table, const int64_t* counters);
 
 /* ---- CoNet towers fused (conet.py:105-203: source_forward + target_forward + BCELoss x2 + reg) -------------------------
- * One stack of R rows -- rows [0, n_source) are the source batch, the rest the target batch -- runs BOTH towers through the
+ * One stack of R rows -- rows [0, n_source) are the source batch (user_s, item_s, label_s), the rest the target batch (the two
+ * batches stay separate tensors, as calculate_loss receives them; the kernel stacks them) -- runs BOTH towers through the
  * L cross units  s' = relu(s Ws^T + bs + m (.) (t H^T)),  t' = relu(t Wt^T + bt + m (.) (s H^T))  (conet.py:118-137;
  * m = 1 where the user -- or item, overlap_users = 0 -- id is < n_overlap, PAD id 0 included), the output unit of the tower
  * a row belongs to (sigmoid(Linear(d_L, 1)), conet.py:140,179) and nn.BCELoss against label[r]:
@@ -309,9 +312,11 @@ int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32
 #define CDR_CONET_MAX_LAYERS 8
 int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width, size_t* workspace_bytes);
 int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab, const float* ti_tab,
-                  int D, const int64_t* user, const int64_t* item, int64_t R, int64_t n_source, int64_t n_overlap,
-                  int overlap_users, int L, const int* dims, const float* const* params, const float* label,
-                  float* x0, float* acts, float* prob, float* maskf, float* out /* [4 + L] */);
+                  int D, const int64_t* user_s /* [n_source] */, const int64_t* user_t /* [R - n_source] */, const int64_t* item_s,
+                  const int64_t* item_t, int64_t R, int64_t n_source, int64_t n_overlap, int overlap_users, int L, const int* dims,
+                  const float* const* params, const float* label_s, const float* label_t, float* x0, float* acts, float* prob,
+                  float* maskf, float* label_cat /* [R]: the stacked labels, for cdr_conet_bwd */,
+                  int64_t* ids_cat /* [2 R]: the stacked user ids, then the stacked item ids */, float* out /* [4 + L] */);
 int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L, const int* dims, const float* const* params,
                   const float* label, const float* x0, const float* acts, const float* prob, const float* maskf,
                   const float* out, const float* grad_out /* device scalar or NULL = 1 */, float* gz, float* gx0,

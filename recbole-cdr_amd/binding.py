@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 19
+ABI_VERSION = 21
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -134,13 +134,13 @@ _SIGNATURES = {
                                _c_ptr, _c_ptr],
     'cdr_bpr_fwd_grad_kmajor': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr,
                                 _c_ptr, _c_ptr, _c_ptr],
-    'cdr_sort_ids_small': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_sort_ids_small': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_rowwise_apply_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_f32,
                                _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr, _c_int],
     'cdr_rowwise_apply_scaled': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_ptr,
                                  _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr, _c_int],
     'cdr_bpr_step_small': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int,
-                           _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+                           _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_map_step_plan': [_c_int, _c_ptr, _c_ptr, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_map_step_unique': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
                             _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32,
@@ -151,8 +151,8 @@ _SIGNATURES = {
                             _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_lazy_adam_flush': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_conet_plan': [_c_int, _c_ptr, _c_i64, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_size_t)],
-    'cdr_conet_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_ptr,
-                      _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_conet_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
+                      _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_conet_bwd': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                       _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_overlap_remap': [ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],

@@ -180,9 +180,12 @@ __device__ __forceinline__ void fwd_layer(const conet_net& net, int l, const flo
 
 __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const float* __restrict__ su, const float* __restrict__ si,
                                                         const float* __restrict__ tu, const float* __restrict__ ti, int D,
-                                                        const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+                                                        const int64_t* __restrict__ user_s, const int64_t* __restrict__ user_t,
+                                                        const int64_t* __restrict__ item_s, const int64_t* __restrict__ item_t,
                                                         int64_t R, int64_t n_source, int64_t n_overlap, int overlap_users,
-                                                        const float* __restrict__ label, int strideA, int strideB,
+                                                        const float* __restrict__ label_s, const float* __restrict__ label_t,
+                                                        float* __restrict__ label_cat, int64_t* __restrict__ ids_cat,
+                                                        int strideA, int strideB,
                                                         float* __restrict__ x0, float* __restrict__ acts, float* __restrict__ prob,
                                                         float* __restrict__ maskf, double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -203,7 +206,9 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
             const int64_t g = rb * kRows + row;
             const bool valid = g < R;
             const int64_t gc = valid ? g : R - 1;
-            const int64_t uid = user[gc], iid = item[gc];
+            // the source batch and the target batch arrive as separate tensors (conet.py:184-191): stacked here, not by a cat
+            const bool src = gc < n_source;
+            const int64_t uid = src ? user_s[gc] : user_t[gc - n_source], iid = src ? item_s[gc] : item_t[gc - n_source];
             float* xr = bufA + row * (4 * D + 4);
             for (int c = c0; c < D4; c += 8) {
                 const float4 a = ld4(su + uid * D + 4 * c), b = ld4(si + iid * D + 4 * c);
@@ -217,7 +222,10 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
             if (c0 == 0) {
                 const float m = ((overlap_users ? uid : iid) < n_overlap) ? 1.f : 0.f;     // PAD id 0 counts
                 mrow[row] = m;
-                if (valid) maskf[g] = m;
+                if (valid) {
+                    maskf[g] = m;
+                    ids_cat[g] = uid; ids_cat[R + g] = iid;               // for the embedding update (scatter / row-wise sort)
+                }
             }
         }
         lds_barrier();
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
                 z += net.bo[tower][0];
                 const float p = 1.0f / (1.0f + expf(-z));
                 prob[g] = p;
-                const float y = label[g];
+                const float y = tower ? label_t[g - n_source] : label_s[g];
+                label_cat[g] = y;
                 const double term = (double)((y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f));
                 if (tower) lacc1 += term; else lacc0 += term;
             }
@@ -741,11 +750,14 @@ extern "C" int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width,
 }
 
 extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab,
-                             const float* ti_tab, int D, const int64_t* user, const int64_t* item, int64_t R, int64_t n_source,
+                             const float* ti_tab, int D, const int64_t* user_s, const int64_t* user_t, const int64_t* item_s,
+                             const int64_t* item_t, int64_t R, int64_t n_source,
                              int64_t n_overlap, int overlap_users, int L, const int* dims, const float* const* params,
-                             const float* label, float* x0, float* acts, float* prob, float* maskf, float* out) {
-    CDR_CHECK_ARG(ctx && su_tab && si_tab && tu_tab && ti_tab && user && item && label && x0 && acts && prob && maskf && out);
+                             const float* label_s, const float* label_t, float* x0, float* acts, float* prob, float* maskf,
+                             float* label_cat, int64_t* ids_cat, float* out) {
+    CDR_CHECK_ARG(ctx && su_tab && si_tab && tu_tab && ti_tab && x0 && acts && prob && maskf && label_cat && ids_cat && out);
     CDR_CHECK_ARG(R > 0 && n_source >= 0 && n_source <= R && D > 0 && (D & 3) == 0);
+    CDR_CHECK_ARG((n_source == 0 || (user_s && item_s && label_s)) && (n_source == R || (user_t && item_t && label_t)));
     conet_net net;
     lds_plan lp;
     if (!fill_net(net, lp, L, dims, params) || dims[0] != 2 * D) { cdr_set_error("cdr_conet_fwd: unsupported layer sizes"); return CDR_EINVAL; }
@@ -755,9 +767,9 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
     const int grid = (int)rows_grid(R);
     {
         cdr_time_scope ts(ctx, CDR_TAG_CONET_FWD, s);
-        conet_fwd_kernel<<<dim3(grid), dim3(256), lp.fwd_bytes, s>>>(net, su_tab, si_tab, tu_tab, ti_tab, D, user, item, R, n_source,
-                                                                     n_overlap, overlap_users, label, lp.strideA, lp.strideB, x0, acts,
-                                                                     prob, maskf, ctx->partials);
+        conet_fwd_kernel<<<dim3(grid), dim3(256), lp.fwd_bytes, s>>>(net, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s, item_t,
+                                                                     R, n_source, n_overlap, overlap_users, label_s, label_t, label_cat,
+                                                                     ids_cat, lp.strideA, lp.strideB, x0, acts, prob, maskf, ctx->partials);
     }
     CDR_LAUNCH_CHECK();
     conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(net, ctx->partials, grid, n_source, R, out);

@@ -504,7 +504,7 @@ extern "C" int cdr_bpr_step_small(cdr_ctx* ctx, void* stream, int opt, float* us
                                   float* item_m, float* item_v, int D, const int64_t* uid, const int64_t* pid, const int64_t* nid,
                                   int64_t S, int k, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps,
                                   float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev, float* out9, float* GU,
-                                  void* item_rec_buf, uint32_t* keys, uint32_t* perm, uint32_t* rank_scratch) {
+                                  void* item_rec_buf, uint32_t* keys, uint32_t* perm, uint32_t* rank_scratch, int64_t max_rows) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && item_rec_buf && keys && perm && rank_scratch);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && S > 0 && k >= 1 && k <= 64);
     CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user_dev && step_item_dev));
@@ -515,7 +515,7 @@ extern "C" int cdr_bpr_step_small(cdr_ctx* ctx, void* stream, int opt, float* us
     const int64_t* ids0[2] = {uid, pid};
     const int64_t* ids1[2] = {nullptr, nid};
     const int64_t n0[2] = {S, S}, n1[2] = {0, B}, off[2] = {0, S};
-    if (!ranksort::plan(sa, 2, ids0, n0, ids1, n1, off)) { cdr_set_error("cdr_bpr_step_small: bad id lists"); return CDR_EINVAL; }
+    if (!ranksort::plan(sa, 2, ids0, n0, ids1, n1, off, max_rows)) { cdr_set_error("cdr_bpr_step_small: bad id lists"); return CDR_EINVAL; }
     const float invB = 1.0f / (float)B;
     const int lpr = cdr_lpr_for(D);
     item_rec* rec = (item_rec*)item_rec_buf;

@@ -31,10 +31,10 @@ __global__ __launch_bounds__(ranksort::kTile) void rank_scatter_kernel(ranksort:
 
 extern "C" int cdr_sort_ids_small(void* stream, int nseg, const int64_t* const* ids0, const int64_t* n0, const int64_t* const* ids1,
                                   const int64_t* n1, const int64_t* out_off, uint32_t* keys_out, uint32_t* perm_out,
-                                  uint32_t* rank_scratch) {
+                                  uint32_t* rank_scratch, int64_t max_id) {
     CDR_CHECK_ARG(keys_out && perm_out && rank_scratch);
     ranksort::small_sort_args a;
-    if (!ranksort::plan(a, nseg, ids0, n0, ids1, n1, out_off)) { cdr_set_error("cdr_sort_ids_small: bad list description"); return CDR_EINVAL; }
+    if (!ranksort::plan(a, nseg, ids0, n0, ids1, n1, out_off, max_id)) { cdr_set_error("cdr_sort_ids_small: bad list description"); return CDR_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     rank_count_kernel<<<dim3(a.count_blocks), dim3(ranksort::kTile), 0, st>>>(a, rank_scratch);
     CDR_LAUNCH_CHECK();

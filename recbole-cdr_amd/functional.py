@@ -413,34 +413,39 @@ class ConetFusedLoss(Function):
     (wo_s, bo_s, wo_t, bo_t)."""
 
     @staticmethod
-    def forward(ctx, su, si, tu, ti, user, item, label, n_source, n_overlap, overlap_users, dims, row_opt, *params):
-        _dev_check(su, si, tu, ti, user, item, label, *params)
-        user, item = _ids(user), _ids(item)
-        label = label.reshape(-1).contiguous().to(torch.float32)
-        R, D, L = user.numel(), su.shape[1], len(dims) - 1
+    def forward(ctx, su, si, tu, ti, user_s, item_s, label_s, user_t, item_t, label_t, n_overlap, overlap_users, dims, row_opt, *params):
+        _dev_check(su, si, tu, ti, user_s, item_s, label_s, user_t, item_t, label_t, *params)
+        user_s, item_s, user_t, item_t = _ids(user_s), _ids(item_s), _ids(user_t), _ids(item_t)
+        label_s = label_s.reshape(-1).contiguous().to(torch.float32)
+        label_t = label_t.reshape(-1).contiguous().to(torch.float32)
+        n_source = user_s.numel()
+        R, D, L = n_source + user_t.numel(), su.shape[1], len(dims) - 1
         dev = su.device
         params = tuple(p.contiguous() for p in params)
         dims_c = (ctypes.c_int * (L + 1))(*[int(d) for d in dims])
         aw, need = ctypes.c_int(0), ctypes.c_size_t(0)
         B_._check(B_.load().cdr_conet_plan(L, dims_c, R, ctypes.byref(aw), ctypes.byref(need)), 'cdr_conet_plan')
         f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        x0, acts, prob, maskf, out = f32(R, 4 * D), f32(R, aw.value), f32(R), f32(R), f32(4 + L)
+        x0, acts, prob, maskf, label, out = f32(R, 4 * D), f32(R, aw.value), f32(R), f32(R), f32(R), f32(4 + L)
+        ids = torch.empty(2 * R, device=dev, dtype=torch.int64)          # the stacked user ids, then the stacked item ids
         pp = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
-        B_.call('cdr_conet_fwd', B_.ctx(dev), B_.stream(), B_.f32(su), B_.f32(si), B_.f32(tu), B_.f32(ti), D, B_.i64(user),
-                B_.i64(item), R, int(n_source), int(n_overlap), 1 if overlap_users else 0, L, dims_c, pp, B_.f32(label),
-                B_.f32(x0), B_.f32(acts), B_.f32(prob), B_.f32(maskf), B_.f32(out))
-        ctx.save_for_backward(user, item, label, x0, acts, prob, maskf, out, *params)
+        B_.call('cdr_conet_fwd', B_.ctx(dev), B_.stream(), B_.f32(su), B_.f32(si), B_.f32(tu), B_.f32(ti), D, B_.i64(user_s),
+                B_.i64(user_t), B_.i64(item_s), B_.i64(item_t), R, int(n_source), int(n_overlap), 1 if overlap_users else 0, L, dims_c,
+                pp, B_.f32(label_s), B_.f32(label_t), B_.f32(x0), B_.f32(acts), B_.f32(prob), B_.f32(maskf), B_.f32(label),
+                B_.i64(ids), B_.f32(out))
+        ctx.save_for_backward(ids, label, x0, acts, prob, maskf, out, *params)
         ctx.meta = (int(n_source), tuple(int(d) for d in dims), aw.value, int(need.value), tuple(su.shape), tuple(si.shape))
         ctx.row_opt = row_opt
         ctx.mark_non_differentiable(out)
-        return out[0].clone(), out
+        return out[0], out
 
     @staticmethod
     def backward(ctx, grad_loss, _g_out):
-        user, item, label, x0, acts, prob, maskf, out = ctx.saved_tensors[:8]
-        params = ctx.saved_tensors[8:]
+        ids, label, x0, acts, prob, maskf, out = ctx.saved_tensors[:7]
+        params = ctx.saved_tensors[7:]
         n_source, dims, aw, need, ushape, ishape = ctx.meta
-        R, L, D = user.numel(), len(dims) - 1, ushape[1]
+        R, L, D = label.numel(), len(dims) - 1, ushape[1]
+        user, item = ids[:R], ids[R:]
         dev = x0.device
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
         ws = _conet_ws.get(key)
@@ -461,12 +466,12 @@ class ConetFusedLoss(Function):
             # deferred row-wise Adam (lazyadam.DeferredRowAdam): the tables get no dense gradient at all -- the optimizer reads
             # the per-occurrence rows of gx0 through the id sort it made before the forward pass
             ctx.row_opt.pending = (gx0, (0, D, 2 * D, 3 * D), 4 * D)
-            return (None,) * 12 + grads
+            return (None,) * 14 + grads
         gsu, gtu = torch.zeros(ushape, device=dev), torch.zeros(ushape, device=dev)
         gsi, gti = torch.zeros(ishape, device=dev), torch.zeros(ishape, device=dev)
         for k, (g, ids) in enumerate(((gsu, user), (gsi, item), (gtu, user), (gti, item))):
             B_.call('cdr_scatter_add_rows_ld', B_.stream(), B_.f32(g), D, B_.i64(ids), R, B_._c_ptr(gx0.data_ptr() + 4 * k * D), 4 * D)
-        return (gsu, gsi, gtu, gti, None, None, None, None, None, None, None, None) + grads
+        return (gsu, gsi, gtu, gti) + (None,) * 10 + grads
 
 
 # ---------------------------------------------------------------------------------------------------- SSCDR pieces

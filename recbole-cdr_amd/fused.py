@@ -188,7 +188,8 @@ class KMajorBPRStep:
             B_.call('cdr_bpr_step_small', ctxh, s, self.opt, B_.f32(us.table), B_.f32(us.exp_avg), B_.f32(us.exp_avg_sq),
                     B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq), self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), S,
                     self.k, float(self.gamma), float(self.reg_weight), *hp, B_.i64(ud), B_.i64(idv), B_.f32(self.out6),
-                    B_.f32(self.GU), B_.raw(self.rec), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.rank))
+                    B_.f32(self.GU), B_.raw(self.rec), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.rank),
+                    max(self.U.shape[0], self.I.shape[0]))
             return
         B_.call('cdr_bpr_fwd_grad_kmajor', ctxh, s, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), S,
                 self.k, float(self.gamma), float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU), B_.raw(self.rec),
@@ -213,7 +214,7 @@ class KMajorBPRStep:
             i64s = lambda xs: (ctypes.c_int64 * 2)(*xs)
             B_._alive.extend([uid, pid, nid])
             B_.call('cdr_sort_ids_small', B_.stream(), 2, arr([uid.data_ptr(), pid.data_ptr()]), i64s([S, S]), arr([None, nid.data_ptr()]),
-                    i64s([0, B]), i64s([0, S]), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.rank))
+                    i64s([0, B]), i64s([0, S]), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.rank), max(self.U.shape[0], self.I.shape[0]))
             return 0
         B_.call('cdr_sort_ids_two_tables', ctxh, B_.stream(), B_.i64(uid), S, self.U.shape[0], B_.i64(pid), S, B_.i64(nid), B,
                 self.I.shape[0], B_.raw(self.keys), B_.raw(self.perm), ctypes.byref(self._key_base), B_.raw(self.ws), self.ws.numel())

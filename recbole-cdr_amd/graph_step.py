@@ -24,7 +24,8 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         losses = self.model.calculate_loss(interaction)
         loss = sum(losses) if isinstance(losses, tuple) else losses
-        loss = loss.sum()
+        if loss.dim():
+            loss = loss.sum()
         loss.backward()
         self.optimizer.step()
         return loss.detach()
@@ -48,8 +49,8 @@ class GraphedTrainStep:
         same = all(k in interaction and interaction[k].shape == v.shape for k, v in self.static.items())
         if not same:
             return self._eager(interaction)
-        for k, v in self.static.items():
-            v.copy_(interaction[k])
+        keys = list(self.static)
+        torch._foreach_copy_([self.static[k] for k in keys], [interaction[k] for k in keys])      # one launch per dtype, not one per field
         self.graph.replay()
         if hasattr(self.optimizer, 'on_replay'):
             self.optimizer.on_replay()            # host-side bookkeeping of optimizers whose update count lives on the device

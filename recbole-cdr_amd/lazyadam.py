@@ -39,8 +39,12 @@ class DeferredRowAdam:
 
     # ---- id sort (per list): the small rank sort up to 16,384 ids, the radix sort above --------------------------------------
     def _sort(self, id_lists):
+        """``id_lists``: per list one id tensor or a pair of tensors (the list is their concatenation, never materialised)."""
         dev = self.tables[0].device
-        ns = [int(x.numel()) for x in id_lists]
+        pairs = [x if isinstance(x, (tuple, list)) else (x, None) for x in id_lists]
+        pairs = [(a.reshape(-1).contiguous().to(torch.int64), None if b is None or b.numel() == 0 else b.reshape(-1).contiguous().to(torch.int64))
+                 for a, b in pairs]
+        ns = [int(a.numel()) + (0 if b is None else int(b.numel())) for a, b in pairs]
         key = tuple(ns)
         if key not in self._bufs:
             tot = sum(ns)
@@ -50,22 +54,24 @@ class DeferredRowAdam:
         offs, o = [], 0
         for n in ns:
             offs.append(o); o += n
+        rows = max(t.shape[0] for t in self.tables)
         if max(ns) <= 16384 and len(ns) <= 4:
             m = len(ns)
-            B_._alive.extend(id_lists)
-            B_.call('cdr_sort_ids_small', B_.stream(), m, (ctypes.c_void_p * m)(*[x.data_ptr() for x in id_lists]), (ctypes.c_int64 * m)(*ns),
-                    None, None, (ctypes.c_int64 * m)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank))
+            B_._alive.extend([t for p in pairs for t in p if t is not None])
+            B_.call('cdr_sort_ids_small', B_.stream(), m, (ctypes.c_void_p * m)(*[a.data_ptr() for a, _ in pairs]),
+                    (ctypes.c_int64 * m)(*[a.numel() for a, _ in pairs]), (ctypes.c_void_p * m)(*[None if b is None else b.data_ptr() for _, b in pairs]),
+                    (ctypes.c_int64 * m)(*[0 if b is None else b.numel() for _, b in pairs]), (ctypes.c_int64 * m)(*offs), B_.raw(keys),
+                    B_.raw(perm), B_.raw(rank), rows)
         else:
-            for x, n, of in zip(id_lists, ns, offs):
-                rows = max(t.shape[0] for t in self.tables)
+            for (a, b), n, of in zip(pairs, ns, offs):
                 need = ctypes.c_size_t(0)
                 B_._check(B_.load().cdr_sort_workspace_bytes(n, rows, ctypes.byref(need)), 'cdr_sort_workspace_bytes')
                 ws = self._bufs.get(('ws', n))
                 if ws is None or ws.numel() < need.value:
                     ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
                     self._bufs[('ws', n)] = ws
-                B_.call('cdr_sort_ids', B_.ctx(dev), B_.stream(), B_.i64(x), n, None, 0, rows, B_.raw(keys[of:of + n]), B_.raw(perm[of:of + n]),
-                        B_.raw(ws), ws.numel())
+                B_.call('cdr_sort_ids', B_.ctx(dev), B_.stream(), B_.i64(a), a.numel(), B_.i64(b), 0 if b is None else b.numel(), rows,
+                        B_.raw(keys[of:of + n]), B_.raw(perm[of:of + n]), B_.raw(ws), ws.numel())
         return [(keys[of:of + n], perm[of:of + n], n) for n, of in zip(ns, offs)]
 
     def _ptrs(self, xs):
@@ -74,7 +80,6 @@ class DeferredRowAdam:
     @torch.no_grad()
     def prepare(self, id_lists):
         """Before the forward pass: sort the batch's ids and bring their rows up to the update before the coming one."""
-        id_lists = [x.reshape(-1).contiguous().to(torch.int64) for x in id_lists]
         self._sorted = self._sort(id_lists)
         per = [self._sorted[j] for j in self.table_list]
         nT = len(self.tables)

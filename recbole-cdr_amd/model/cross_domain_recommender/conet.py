@@ -117,22 +117,23 @@ class CoNet(CrossDomainRecommender):
         su, si = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID]
         tu, ti = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
         n_s = su.numel()
-        user, item = torch.cat([su.reshape(-1), tu.reshape(-1)]), torch.cat([si.reshape(-1), ti.reshape(-1)])
         if self.fused_towers:
-            # the whole loss as one autograd node on csrc/cdr_conet.hip (one forward launch, three backward launches)
-            label = torch.cat([interaction[self.SOURCE_LABEL].reshape(-1), interaction[self.TARGET_LABEL].reshape(-1)])
+            # the whole loss as one autograd node on csrc/cdr_conet.hip (one forward launch, three backward launches); the
+            # kernel stacks the source and the target batch itself
             over_users = self.mode == 'overlap_users'
             row_opt = self.row_opt if (self.row_opt is not None and torch.is_grad_enabled()) else None
             if row_opt is not None:
-                row_opt.prepare([user, item])        # the batch's rows replay their postponed Adam updates before they are read
+                # the batch's rows replay their postponed Adam updates before they are read
+                row_opt.prepare([(su, tu), (si, ti)])
             else:
                 self.sync_tables()
             loss, self.last_loss_parts = F_.ConetFusedLoss.apply(
                 self.source_user_embedding.weight, self.source_item_embedding.weight, self.target_user_embedding.weight,
-                self.target_item_embedding.weight, user, item, label, n_s,
+                self.target_item_embedding.weight, su, si, interaction[self.SOURCE_LABEL], tu, ti, interaction[self.TARGET_LABEL],
                 self.overlapped_num_users if over_users else self.overlapped_num_items, over_users, self._dims, row_opt,
                 *self._fused_params())
             return loss
+        user, item = torch.cat([su.reshape(-1), tu.reshape(-1)]), torch.cat([si.reshape(-1), ti.reshape(-1)])
         s, t = self._towers(user, item)
         ls, lt = self.source_outputunit[0], self.target_outputunit[0]
         p_source = F_.linear(s[:n_s], ls.weight, ls.bias, B_.ACT_SIGMOID).squeeze()

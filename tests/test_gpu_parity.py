@@ -405,8 +405,11 @@ def test_small_sort_equals_stable_sort():
     import ctypes
     from recbole_cdr_amd import binding as B_
     gen = torch.Generator().manual_seed(0)
-    for sizes in ([(1, 0), (2, 3), (64, 0), (65, 64)], [(2048, 0), (2048, 4096), (8190, 8190), (16384, 0)], [(777, 1500)]):
-        a = [torch.randint(0, 1 << 20 if i % 2 else 37, (n0,), generator=gen).to(DEV) for i, (n0, _) in enumerate(sizes)]
+    for sizes, max_id in (([(1, 0), (2, 3), (64, 0), (65, 64)], 0), ([(2048, 0), (2048, 4096), (8190, 8190), (16384, 0)], 0),
+                          ([(777, 1500)], 0), ([(2048, 0), (2048, 4096)], 1 << 20), ([(8190, 0), (100, 8090)], (1 << 18) - 1),
+                          ([(16384, 0)], 1 << 20)):                       # max_id known: the composite-word comparison when it fits
+        hi = max_id if max_id else 1 << 20
+        a = [torch.randint(0, hi if i % 2 else 37, (n0,), generator=gen).to(DEV) for i, (n0, _) in enumerate(sizes)]
         b = [torch.randint(0, 50, (n1,), generator=gen).to(DEV) if n1 else None for _, n1 in sizes]
         offs, tot = [], 0
         for n0, n1 in sizes:
@@ -416,7 +419,7 @@ def test_small_sort_equals_stable_sort():
         ns = len(sizes)
         B_.call('cdr_sort_ids_small', B_.stream(), ns, (ctypes.c_void_p * ns)(*[t.data_ptr() for t in a]),
                 (ctypes.c_int64 * ns)(*[n0 for n0, _ in sizes]), (ctypes.c_void_p * ns)(*[t.data_ptr() if t is not None else None for t in b]),
-                (ctypes.c_int64 * ns)(*[n1 for _, n1 in sizes]), (ctypes.c_int64 * ns)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank))
+                (ctypes.c_int64 * ns)(*[n1 for _, n1 in sizes]), (ctypes.c_int64 * ns)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank), max_id)
         for s, (n0, n1) in enumerate(sizes):
             ids = torch.cat([a[s]] + ([b[s]] if n1 else [])).cpu()
             want_k, want_p = torch.sort(ids, stable=True)

@@ -17,7 +17,7 @@ for sizes in ([(100, 0)], [(2048, 0), (2048, 2048)], [(512, 0), (512, 2048)], [(
     ns = len(sizes)
     args = (B_.stream(), ns, (ctypes.c_void_p * ns)(*[t.data_ptr() for t in a]), (ctypes.c_int64 * ns)(*[n0 for n0, _ in sizes]),
             (ctypes.c_void_p * ns)(*[t.data_ptr() if t is not None else None for t in b]), (ctypes.c_int64 * ns)(*[n1 for _, n1 in sizes]),
-            (ctypes.c_int64 * ns)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank))
+            (ctypes.c_int64 * ns)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank), int(os.environ.get('MAXID', 0)))
     for _ in range(5):
         B_.call('cdr_sort_ids_small', *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
