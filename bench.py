@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--no-domain-groups', action='store_true',
                     help='--shard dim: shard BOTH domains over all N ranks (D/N columns each) instead of giving each domain one half of '
                          'the ranks (D/(N/2) columns, twice the batch per rank)')
+    ap.add_argument('--single-layout', action='store_true', help='N>1: time only the --shard layout (default: both, in one record)')
     ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
 
@@ -372,22 +373,39 @@ def run_c5(args, world, rank, dev):
             if sharded:
                 dist.broadcast(Wm.data, 0)                    # the mapping is replicated: same initial weights on every rank
             fmap = FusedMapStep(tabs['su'], tabs['tu'], lambda x: F_.linear(x, Wm, None, B_.ACT_NONE), [Wm], 65536, opt=args.opt,
-                                group=(dist.group.WORLD if sharded else None),
+                                group=(dist.group.WORLD if sharded else None), layers=[(Wm, None, B_.ACT_NONE)],
                                 source_state=steps['source'].ustate, target_state=steps['target'].ustate)
             OB = 65536
-            idxs = [torch.randint(1, OU, (OB, 1), device=dev, generator=gen) for _ in range(4)]
+            # the reference's OverlapDataloader yields slices of a shuffled arange (data/dataloader.py:37-52): distinct ids
+            perm_ids = torch.randperm(OU - 1, device=dev, generator=gen)[:4 * OB] + 1
+            idxs = [perm_ids[i * OB:(i + 1) * OB].view(-1, 1).contiguous() for i in range(4)]
+            uniq = not sharded
             for i in range(3):
-                fmap.step(idxs[i % 4])
+                fmap.step(idxs[i % 4], unique=uniq)
             barrier(world)
             t0 = time.perf_counter()
             for i in range(20):
-                fmap.step(idxs[i % 4])
+                fmap.step(idxs[i % 4], unique=uniq)
             barrier(world)
             tm = torch.tensor([(time.perf_counter() - t0) / 20], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ob_bytes = OB * 2 * 6 * 4 * D                      # two rows per id, 6 x 4D bytes per row
             result['overlap_phase'] = {'ms_per_step': float(tm) * 1e3, 'overlap_ids_per_s': OB * world / float(tm),
-                                       'batch_per_rank': OB, 'mapping': 'linear %dx%d' % (D, D), 'loss': float(fmap.loss)}
+                                       'batch_per_rank': OB, 'mapping': 'linear %dx%d' % (D, D), 'loss': float(fmap.loss),
+                                       'launches': 2 if uniq else None,
+                                       'roofline': {'bound': 'hbm', 'achieved': ob_bytes / float(tm) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                                    'frac': ob_bytes / float(tm) / 1e9 / HBM_PEAK_GBS,
+                                                    'algorithmic_bytes': ob_bytes, 'what': '6,144 B per id (SURVEY 8d), wall time of the whole step'}}
+            if uniq:
+                small = [perm_ids[i * 100:(i + 1) * 100].view(-1, 1).contiguous() for i in range(4)]
+                for i in range(3):
+                    fmap.step(small[i % 4], unique=True)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for i in range(200):
+                    fmap.step(small[i % 4], unique=True)
+                torch.cuda.synchronize()
+                result['overlap_phase']['ob100_ms_per_step'] = (time.perf_counter() - t0) / 200 * 1e3
             del fmap                                   # it shares (and would keep alive) the user tables' Adam moments
 
     except Exception as e:  # noqa: BLE001
@@ -423,6 +441,75 @@ def run_c5(args, world, rank, dev):
                                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gk['frac'],
                                      'avg_launch_ms': gk['avg_ms'], 'traffic': pmc_traffic(gk['kernel'])}
         result['kernels'] = kernels
+        # the STEP against SURVEY 8d's floor for a fused row-wise-Adam step: 6 x 4D bytes per touched row, three rows per triple
+        dom_ms = dt / args.steps * 1e3 / 2.0
+        step_bytes = B * 3 * 6 * 4 * D
+        result['roofline_step'] = {'bound': 'hbm', 'what': 'one domain step (forward + sort + two applies) of %d triples against SURVEY 8d\'s '
+                                   '9,216 B/triple at D=128 (6 x 4D per touched row, 3 rows per triple, no reuse counted)' % B,
+                                   'achieved': step_bytes / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': step_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'ms_per_domain_step': dom_ms,
+                                   'algorithmic_bytes': step_bytes,
+                                   'traffic': pmc_traffic('domain_step')}
+        # the gather under both byte models of SURVEY 8d: one triple = 3 rows + 3 ids; with per-positive reuse (2 + k) rows per k triples
+        result['roofline_gather']['byte_models'] = {
+            'per_triple_B': 3 * 4 * D + 24, 'per_positive_reuse_floor_B_at_k1': (2 + 1) * 4 * D // 1,
+            'note': 'the headline batch is k = 1 (every triple has its own positive): both models coincide up to the 24 B of ids; the k = 4 '
+                    'leg below (`per_positive_k4`) is measured against (2 + k) 4D / k = 768 B per triple'}
+
+    try:
+        # ---- the per-positive (k-major) step at k = 4, and the reference-default 2,048-row batch as one hipGraph -------------
+        if rank == 0 and not sharded and not getattr(args, 'no_extra_legs', False):
+            from recbole_cdr_amd.fused import KMajorBPRStep
+            k = 4
+            S = B // k
+            st0 = steps['source']
+            km = KMajorBPRStep(tabs['su'], tabs['si'], S, k=k, opt=args.opt, reg_weight=0.01, user_state=st0.ustate, item_state=st0.istate)
+            kb = [(torch.randint(1, OU, (S,), device=dev, generator=gen), torch.randint(1 + TOI, 1 + 2 * TOI, (S,), device=dev, generator=gen),
+                   torch.randint(1 + TOI, 1 + 2 * TOI, (B,), device=dev, generator=gen)) for _ in range(4)]
+            tiled = [(b[0].repeat(k), b[1].repeat(k), b[2]) for b in kb]
+            def timed(fn, data, n=20):
+                for i in range(3):
+                    fn(*data[i % 4])
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for i in range(n):
+                    fn(*data[i % 4])
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            B_.timing_enable(dev, 256)
+            ms_k = timed(km.step, kb)
+            kt = {}
+            for nm, ms in B_.timing_collect(dev):
+                kt.setdefault(nm, []).append(ms)
+            B_.timing_enable(dev, 0)
+            ms_t = timed(st0.step, tiled)
+            fwd_ms = sum(kt.get('bpr_fwd_kmajor_kernel', [0.0])) / max(len(kt.get('bpr_fwd_kmajor_kernel', [0.0])), 1)
+            fwd_bytes = S * ((2 + k) * 4 * D + 8 * (2 + k)) + S * 4 * D + (S + B) * 8       # rows + ids read, GU rows + item records written
+            result['per_positive_k4'] = {
+                'rows_per_domain_step': B, 'k': k, 'ms_per_domain_step': ms_k, 'rows_per_s': B / (ms_k * 1e-3),
+                'per_triple_step_same_batch_ms': ms_t, 'speedup_vs_per_triple_step': ms_t / ms_k,
+                'gather_kernel': {'kernel': 'bpr_fwd_kmajor_kernel', 'avg_ms': fwd_ms, 'algorithmic_bytes': fwd_bytes,
+                                  'achieved_GBps': fwd_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0,
+                                  'frac': fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_ms > 0 else 0.0,
+                                  'byte_model': '(2 + k) rows + (2 + k) ids read, 1 gradient row + (1 + k) 8-B records written per positive = '
+                                                '%d B per triple at k = 4' % (fwd_bytes // B)}}
+            del km
+            # the reference's default train_batch_size (2,048 rows, properties/overall.yaml:19): 4 launches, replayed as a hipGraph
+            S2 = 2048
+            sm = KMajorBPRStep(tabs['su'], tabs['si'], S2, k=1, opt=args.opt, reg_weight=0.01, user_state=st0.ustate, item_state=st0.istate)
+            sb = [(torch.randint(1, OU, (S2,), device=dev, generator=gen), torch.randint(1 + TOI, 1 + 2 * TOI, (S2,), device=dev, generator=gen),
+                   torch.randint(1 + TOI, 1 + 2 * TOI, (S2,), device=dev, generator=gen)) for _ in range(4)]
+            ms_e = timed(sm.step, sb, n=200)
+            sm.capture(S2)
+            ms_g = timed(sm.replay, sb, n=200)
+            ms_i = timed(lambda *a: sm.replay(), sb, n=200)
+            result['small_batch_2048'] = {'rows_per_domain_step': S2, 'eager_ms': ms_e, 'hipgraph_ms_with_3_id_copies': ms_g,
+                                          'hipgraph_ms_ids_written_in_place': ms_i, 'rows_per_s': S2 / (ms_i * 1e-3),
+                                          'launches': 4, 'note': 'C5 table sizes; {forward || rank-count}, {rank-scatter || loss finish}, '
+                                                                 'item apply, user apply; Adam update counts on the device'}
+            del sm
+    except Exception as e:  # noqa: BLE001
+        result.setdefault('leg_errors', {})['per_positive_small_batch'] = repr(e)[:500]
+        print('bench: per-positive / small-batch leg failed: %r' % (e,), file=sys.stderr)
 
     try:                                          # a failure in this extra leg must not cost the headline measurement
         # ---- metric 2: full-sort items scored / s (emcdr.py:208-233, TARGET phase) at the reference's U and at U=1024 --
@@ -523,13 +610,18 @@ def run_c5(args, world, rank, dev):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), with their provenance: the
+    counters are collected in separate profiler runs of this same command (tools/profile_bench.sh), NOT in this invocation."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f).get(kernel)
+            v = json.load(f).get(kernel)
     except Exception:
+        v = None
+    if v is None:
         return None
+    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                  'passes over this command; not measured in this invocation)'}
 
 
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
@@ -635,6 +727,60 @@ def run_model_workload(args, world, rank, dev):
               'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
                          'rows_per_step': rows_per_step},
               'final_loss': float(loss.sum())}
+    # ---- roofline of the step (SURVEY 8d figures; C1-C4 tables sit in L2 / Infinity Cache, so the HBM fractions are nominal) ----
+    step_s = dt / args.steps
+    D = cfg['embedding_size'] if 'embedding_size' in cfg else cfg['source_embedding_size']
+    nu, ni = ds.num_total_user, ds.num_total_item
+    if args.workload == 'c3':
+        dims = [2 * D] + list(cfg['mlp_hidden_size'])
+        fwd_flop_row = 8 * sum(a * b for a, b in zip(dims[:-1], dims[1:]))          # 4 products per cross unit, 2 flop per MAC
+        flops = 3.0 * fwd_flop_row * rows_per_step                                   # forward + data gradient + weight gradient
+        tf = flops / step_s / 1e12
+        roof = {'bound': 'fp32', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP32_MFMA_PEAK_TFLOPS,
+                'what': 'whole step (gather + towers fwd/bwd + optimizer) against the fp32 MFMA peak: %.1f kFLOP per row forward x 3 x %d rows'
+                        % (fwd_flop_row / 1e3, rows_per_step), 'algorithmic_flops': flops, 'traffic': None}
+        if world == 1 and getattr(model, 'fused_towers', False):
+            # the three tower kernels alone: HIP events recorded in the library on the launch stream, a few eager steps after the timed region
+            from recbole_cdr_amd import binding as B_
+            B_.timing_enable(dev, 256)
+            for i in range(8):
+                opt.zero_grad(set_to_none=True)
+                model.calculate_loss(batches[i % 4]).backward()
+                opt.step()
+            torch.cuda.synchronize()
+            kt = {}
+            for nm, ms in B_.timing_collect(dev):
+                kt.setdefault(nm, []).append(ms)
+            B_.timing_enable(dev, 0)
+            ks, tot = [], 0.0
+            for nm, share in (('conet_fwd_kernel', 1.0), ('conet_bwd_kernel', 1.0), ('conet_wgrad_kernel', 1.0)):
+                v = kt.get(nm, [])[2:]
+                if v:
+                    ms = sum(v) / len(v)
+                    tot += ms
+                    ks.append({'kernel': nm, 'avg_ms': ms, 'algorithmic_flops': fwd_flop_row * rows_per_step * share,
+                               'achieved_TFLOPs': fwd_flop_row * rows_per_step * share / (ms * 1e-3) / 1e12})
+            if tot > 0:
+                roof['tower_kernels'] = {'sum_avg_ms': tot, 'achieved': flops / (tot * 1e-3) / 1e12, 'unit': 'TFLOP/s',
+                                         'frac': flops / (tot * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            result['kernels'] = ks
+    elif args.workload == 'c4':
+        L = cfg['n_layers']
+        nnz = 2 * (len(ds.s_pairs) + len(ds.t_pairs))                               # symmetric adjacency of both domains
+        byts = 2.0 * L * (nnz * (4 * D + 12) + 2 * (nu + ni) * 4 * D) + 7.0 * 4 * 2 * (nu + ni) * D     # SpMM fwd+bwd per layer + dense Adam
+        gbs = byts / step_s / 1e9
+        roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
+                'what': 'SpMM (4D + 12 B per nnz + 4D per output row, fwd + bwd, %d layers, both domains) + dense Adam (7 x 4 B per table element); '
+                        'the 43 MB of tables and the adjacency live in L2 / Infinity Cache: nominal fraction' % L, 'traffic': None}
+    else:
+        per_row = (3 * 4 * D + 24) if pairwise else (2 * 4 * D + 20)
+        tabs_el = (2 if args.workload == 'c2' else 1) * 0 + sum(p.numel() for p in model.parameters() if p.grad is not None)
+        byts = float(rows_per_step * per_row + 7 * 4 * tabs_el)
+        gbs = byts / step_s / 1e9
+        roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
+                'what': 'gather (%d B per row) + exact dense Adam over the parameters that received a gradient (7 x 4 B per element); the '
+                        'tables (a few MB) are L2-resident and the step is launch / latency bound: nominal fraction' % per_row, 'traffic': None}
+    result['roofline'] = roof
     if rank == 0 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_model(args, ds, cfg, S, k, batches[0] if pairwise else None)
     return result
@@ -696,14 +842,22 @@ def cpu_baseline_model(args, ds, cfg, S, k, pair_batch=None):
         t0 = time.perf_counter(); step(); rate = 1.0 / (time.perf_counter() - t0)
         if rate > best[1]:
             best = (nt, rate)
-    torch.set_num_threads(best[0])
-    t0 = time.perf_counter(); n = 0
-    while time.perf_counter() - t0 < args.cpu_seconds and n < 100:
-        step(); n += 1
-    dt = time.perf_counter() - t0
     rows = S * k if pair_batch is not None else 2 * S * (1 + k)
-    return {'value': rows * n / dt, 'unit': 'interactions/s', 'cores': best[0], 'host_cores': ncores, 'kind': 'port',
-            'sample': '%d steps of %d rows, oracle calculate_loss + autograd + dense torch.optim.Adam, same table sizes, %d threads' % (n, rows, best[0])}
+    def measure(nt, seconds):
+        torch.set_num_threads(nt)
+        step()
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds and n < 100:
+            step(); n += 1
+        return rows * n / (time.perf_counter() - t0), n
+    rate, n = measure(best[0], args.cpu_seconds)
+    rate_all, n_all = measure(ncores, min(args.cpu_seconds, 5.0))
+    rate_one, n_one = measure(1, min(args.cpu_seconds, 5.0))
+    return {'value': rate, 'unit': 'interactions/s', 'cores': best[0], 'host_cores': ncores, 'kind': 'port',
+            'sample': '%d steps of %d rows, oracle calculate_loss + autograd + dense torch.optim.Adam, same table sizes and batch shape as the '
+                      'GPU line, %d threads (best of a sweep)' % (n, rows, best[0]),
+            'all_cores': {'value': rate_all, 'unit': 'interactions/s', 'cores': ncores, 'sample': '%d steps, same shape' % n_all},
+            'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one}}
 
 
 # ------------------------------------------------------------------------------------------------------ CPU baseline
@@ -733,22 +887,30 @@ def cpu_baseline(args):
         if time.perf_counter() - t0 > 5.0:
             break
     used = best[0]
+    def measure(nt, seconds):
+        torch.set_num_threads(nt)
+        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 3, opt=args.opt)
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds and n < 200:
+            ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), n + 4, opt=args.opt)
+            n += 1
+        return B * n / (time.perf_counter() - t0), n
+    rate, steps = measure(used, args.cpu_seconds)
+    rate_all, n_all = measure(ncores, min(args.cpu_seconds, 6.0))          # torch.set_num_threads(os.cpu_count()) ...
+    rate_one, n_one = measure(1, min(args.cpu_seconds, 6.0))               # ... and a 1-thread figure
     torch.set_num_threads(used)
-    t0 = time.perf_counter(); steps = 0
-    while time.perf_counter() - t0 < args.cpu_seconds and steps < 200:
-        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), steps + 2, opt=args.opt)
-        steps += 1
-    dt = time.perf_counter() - t0
     model = ''
     try:
         with open('/proc/cpuinfo') as f:
             model = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')][0]
     except Exception:
         pass
-    return {'value': B * steps / dt, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'kind': 'port',
-            'cpu_model': model,
-            'sample': '%d steps of %d triples, EMCDR-BPR D=%d, oracle row-wise step (fwd+bwd+lazy %s) on down-scaled '
-                      'tables %d users x %d items (host RAM), torch %d threads (best of a sweep)' % (steps, B, D, args.opt, nu, ni, used)}
+    sample = ('EMCDR-BPR D=%d, oracle row-wise step (fwd+bwd+lazy %s), batches of %d triples on down-scaled tables %d users x %d items '
+              '(host RAM)' % (D, args.opt, B, nu, ni))
+    return {'value': rate, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'kind': 'port', 'cpu_model': model,
+            'sample': '%d steps, %s, torch %d threads (best of a sweep)' % (steps, sample, used),
+            'all_cores': {'value': rate_all, 'unit': 'interactions/s', 'cores': ncores, 'sample': '%d steps, same shape' % n_all},
+            'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one}}
 
 
 def main():
@@ -763,7 +925,26 @@ def main():
     world, rank, local = dist_setup(args)
     dev = torch.device('cuda', local)
     import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
-    if args.workload == 'c5':
+    if args.workload == 'c5' and (world > 1 or args.force_shard) and not args.single_layout:
+        # N > 1: BOTH layouts of the C5 tables in one record -- north_star's row shard (rows r % N, row / gradient-row all-to-all)
+        # and the dimension shard (D/N columns of every row, ids all-gathered, one partial score per triple all-reduced) -- so
+        # that one hardware run shows them side by side.  The headline fields are those of --shard (default dim).
+        import copy
+        import gc
+        first, second = args.shard, ('row' if args.shard == 'dim' else 'dim')
+        result = run_c5(args, world, rank, dev)
+        gc.collect(); torch.cuda.empty_cache()
+        a2 = copy.copy(args)
+        a2.shard, a2.no_fullsort, a2.no_map, a2.no_extra_legs = second, True, True, True
+        other = None
+        try:
+            other = run_c5(a2, world, rank, dev)
+        except Exception as e:  # noqa: BLE001
+            result.setdefault('leg_errors', {})['layout_' + second] = repr(e)[:500]
+        pick = lambda r: None if r is None else {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'n_gpus', 'exchange', 'kernels',
+                                                                      'roofline')} | {'sharding': r['config']['sharding']}
+        result['layouts'] = {first: pick(result), second: pick(other)}
+    elif args.workload == 'c5':
         result = run_c5(args, world, rank, dev)
     else:
         result = run_model_workload(args, world, rank, dev)
