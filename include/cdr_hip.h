@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 21
+#define CDR_ABI_VERSION 22
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -347,6 +347,16 @@ int cdr_graph_layer_fwd(void* stream, const int64_t* indptr, const int64_t* indi
                         const float* E, int D, float* side_out, float* new_out);
 int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
                         const float* E, const float* side, const float* gnew, int D, float* tmp, float* gE);
+/* Row-sharded BiTGCF (BASELINE configs[3]; SURVEY 8e: E and the CSR sharded by destination row, per-layer all-gather of E): the rank
+ * holds n_rows rows of the CSR whose column indices address the ALL-GATHERED embedding buffer; the row's own value comes from the
+ * local slice.  Forward: side = A_rows E_gathered, new = E_rows + side + E_rows (.) side (bitgcf.py:130-135).  Backward (the
+ * adjacency is symmetric): tmp_rows = gnew_rows (.) (1 + E_rows) [cdr_mul_one_plus] is all-gathered by the host, then
+ * gE_rows = gnew_rows (.) (1 + side_rows) + A_rows tmp_gathered.                                                                 */
+int cdr_graph_layer_fwd_rows(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
+                             const float* E_gathered, const float* E_rows, int D, float* side_out, float* new_out);
+int cdr_mul_one_plus(void* stream, const float* g, const float* x, int64_t n, float* out);
+int cdr_graph_layer_bwd_rows(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
+                             const float* tmp_gathered, const float* gnew_rows, const float* side_rows, int D, float* gE_rows);
 int cdr_transfer_fwd(void* stream, const float* S, const float* T, const float* deg_s, const float* deg_t, int64_t rows, int D,
                      int64_t n_overlap, float lam_s, float lam_t, float* S_out, float* T_out);
 int cdr_transfer_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -94,6 +94,9 @@ _SIGNATURES = {
     'cdr_spmm_csr_f32': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr],
     'cdr_graph_layer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr],
     'cdr_graph_layer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr],
+    'cdr_graph_layer_fwd_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr],
+    'cdr_mul_one_plus': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_graph_layer_bwd_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr],
     'cdr_transfer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_transfer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_l2_normalize_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr],

@@ -1,0 +1,294 @@
+"""BiTGCF with the embedding tables AND the graph row-sharded over the GPUs of a node (BASELINE configs[3]: "BiTGCF Douban-Book ->
+Music 2-layer GCN, item table row-sharded across 4 x MI355X"; SURVEY 8e: E and the CSR sharded by destination row, per-layer
+all-gather of E).  Reference math: recbole_cdr/model/cross_domain_recommender/bitgcf.py:130-135 (graph layer), :137-172 (transfer
+layer), :174-205 (forward), :207-250 (loss).
+
+Partition.  Users and items are cut into G contiguous blocks each (padded to equal size); rank r owns user block r and item block
+r of all four tables, their Adam state, the rows of both normalised adjacencies that belong to those nodes, and the degree
+vectors of the transfer layer.  An entity has the same id in both domains, so a rank owns BOTH domains' rows of every node it
+owns: the transfer layer (which mixes source row r with target row r) is local.  Everything in the propagation is row-wise
+EXCEPT the SpMM, whose gather side needs every row:
+
+    forward, per layer and domain     all-gather E_l (n x D)              -> local SpMM rows + fused layer math
+    backward, per layer and domain    all-gather g (.) (1 + E_l)          -> local SpMM rows   (A is symmetric: A^T g = A g)
+    after the propagation             all-gather the stacked outputs      -> every rank evaluates the (small) batch itself
+
+The batch loss is replicated -- 8 k rows against a propagation over 80 k nodes x 2 domains x L layers -- so its gradient with
+respect to the gathered tables is identical on every rank and each rank simply keeps its own segment: the data path contains
+all-gathers only, no reduction, and the result does not depend on the rank count beyond fp32 summation order inside a row.
+
+``ops`` supplies the local arithmetic: ``NativeGraphOps`` (libcdrhip) here, the oracle's torch formulas in the gloo CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class BlockPartition:
+    def __init__(self, n_users, n_items, world):
+        self.nu, self.ni, self.G = int(n_users), int(n_items), int(world)
+        self.bu = -(-self.nu // self.G)
+        self.bi = -(-self.ni // self.G)
+        self.nl = self.bu + self.bi                      # rows per rank: [user block ; item block]
+
+    def user_pos(self, u):
+        """Position of user id u in the all-gathered buffer [G * nl, .]."""
+        return (u // self.bu) * self.nl + (u % self.bu)
+
+    def item_pos(self, i):
+        return (i // self.bi) * self.nl + self.bu + (i % self.bi)
+
+    def overlap_local(self, n_overlap, rank, block):
+        return int(min(max(n_overlap - rank * block, 0), block))
+
+    def shard(self, full, rank, users):
+        """Rank's block of a full [rows, ...] table, zero-padded to the block size."""
+        b = self.bu if users else self.bi
+        lo = rank * b
+        part = full[lo:lo + b]
+        if part.shape[0] < b:
+            pad = torch.zeros((b - part.shape[0],) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+            part = torch.cat([part, pad], dim=0)
+        return part.contiguous()
+
+    def unshard(self, gathered, users):
+        """[G * nl, W] all-gathered buffer -> the full [nu or ni, W] table in id order."""
+        W = gathered.shape[1]
+        g = gathered.view(self.G, self.nl, W)
+        blk = g[:, :self.bu] if users else g[:, self.bu:]
+        return blk.reshape(-1, W)[:self.nu if users else self.ni]
+
+
+def local_norm_adj(pairs, part, rank):
+    """This rank's rows of D^-1/2 A D^-1/2 (values formed exactly as bitgcf.py:103-115: float64 product with degree + 1e-7, rounded to
+    fp32), as CSR over the rank's local row order with column indices into the all-gathered buffer."""
+    nu, ni = part.nu, part.ni
+    pairs = np.unique(np.asarray(pairs, dtype=np.int64), axis=0)
+    u, i = pairs[:, 0], pairs[:, 1]
+    deg_u = np.bincount(u, minlength=nu).astype(np.float64) + 1e-7
+    deg_i = np.bincount(i, minlength=ni).astype(np.float64) + 1e-7
+    du, di = np.power(deg_u, -0.5), np.power(deg_i, -0.5)
+    upos = (u // part.bu) * part.nl + (u % part.bu)
+    ipos = (i // part.bi) * part.nl + part.bu + (i % part.bi)
+    mine_u = (u // part.bu) == rank                       # rows of my users: neighbours are items
+    mine_i = (i // part.bi) == rank
+    rows = np.concatenate([u[mine_u] % part.bu, part.bu + (i[mine_i] % part.bi)])
+    cols = np.concatenate([ipos[mine_u], upos[mine_i]])
+    vals = np.concatenate([(du[u[mine_u]] * np.float64(1.0)) * di[i[mine_u]], (di[i[mine_i]] * np.float64(1.0)) * du[u[mine_i]]]).astype(np.float32)
+    # the single-process CSR orders a row's entries by global column (users first, then items); keep that order so that the fp32
+    # row sums add in the same sequence: sort by (row, global column)
+    gcol = np.concatenate([nu + i[mine_u], u[mine_i]])
+    order = np.lexsort((gcol, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    indptr = np.zeros(part.nl + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=part.nl), out=indptr[1:])
+    return indptr, cols.astype(np.int64), vals
+
+
+class NativeGraphOps:
+    """libcdrhip kernels on device tensors (csrc/cdr_graph.hip, cdr_gather_loss.hip)."""
+
+    def __init__(self, device):
+        from . import binding as B_, functional as F_
+        self.B_, self.F_, self.device = B_, F_, device
+
+    def tensor(self, a):
+        return torch.as_tensor(a).to(self.device)
+
+    def graph_layer_fwd(self, csr, Eg, E):
+        B_ = self.B_
+        side, new = torch.empty_like(E), torch.empty_like(E)
+        B_.call('cdr_graph_layer_fwd_rows', B_.stream(), B_.i64(csr[0]), B_.i64(csr[1]), B_.f32(csr[2]), E.shape[0], B_.f32(Eg), B_.f32(E),
+                E.shape[1], B_.f32(side), B_.f32(new))
+        return side, new
+
+    def mul_one_plus(self, g, x):
+        B_ = self.B_
+        out = torch.empty_like(g)
+        B_.call('cdr_mul_one_plus', B_.stream(), B_.f32(g), B_.f32(x), g.numel(), B_.f32(out))
+        return out
+
+    def graph_layer_bwd(self, csr, tmp_g, gnew, side):
+        B_ = self.B_
+        gE = torch.empty_like(gnew)
+        B_.call('cdr_graph_layer_bwd_rows', B_.stream(), B_.i64(csr[0]), B_.i64(csr[1]), B_.f32(csr[2]), gnew.shape[0], B_.f32(tmp_g),
+                B_.f32(gnew), B_.f32(side), gnew.shape[1], B_.f32(gE))
+        return gE
+
+    def transfer_fwd(self, S, T, ds, dt, n_overlap, lam_s, lam_t):
+        B_ = self.B_
+        So, To = torch.empty_like(S), torch.empty_like(T)
+        B_.call('cdr_transfer_fwd', B_.stream(), B_.f32(S), B_.f32(T), B_.f32(ds), B_.f32(dt), S.shape[0], S.shape[1], int(n_overlap),
+                float(lam_s), float(lam_t), B_.f32(So), B_.f32(To))
+        return So, To
+
+    def transfer_bwd(self, gSo, gTo, ds, dt, n_overlap, lam_s, lam_t):
+        B_ = self.B_
+        gS, gT = torch.empty_like(gSo), torch.empty_like(gTo)
+        B_.call('cdr_transfer_bwd', B_.stream(), B_.f32(gSo), B_.f32(gTo), B_.f32(ds), B_.f32(dt), gSo.shape[0], gSo.shape[1], int(n_overlap),
+                float(lam_s), float(lam_t), B_.f32(gS), B_.f32(gT))
+        return gS, gT
+
+    def l2norm_fwd(self, x):
+        B_ = self.B_
+        y, nrm = torch.empty_like(x), torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        B_.call('cdr_l2_normalize_fwd', B_.stream(), B_.f32(x), x.shape[0], x.shape[1], B_.f32(y), x.shape[1], B_.f32(nrm))
+        return y, nrm
+
+    def l2norm_bwd(self, x, nrm, gy):
+        B_ = self.B_
+        gx = torch.empty_like(x)
+        B_.call('cdr_l2_normalize_bwd', B_.stream(), B_.f32(x), B_.f32(nrm), B_.f32(gy.contiguous()), x.shape[1], x.shape[0], x.shape[1],
+                B_.f32(gx), 0)
+        return gx
+
+    def batch_loss(self, out_g, E0_g, pu, pi, label, reg_weight):
+        """bitgcf.py:221-247 on the all-gathered tables (ids already mapped to gathered positions): BCE(sigmoid(<u, i>)) +
+        reg_weight * EmbLoss(ego rows).  Returns (loss, d loss / d out_g, d loss / d E0_g), dense."""
+        F_, B_ = self.F_, self.B_
+        a = out_g.detach().requires_grad_(True)
+        e = E0_g.detach().requires_grad_(True)
+        bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, a, a, None, None, pu, pi, label, 0.0)
+        reg = F_.EmbLossRows.apply(e, e, pu, pi)
+        loss = bce + reg_weight * reg
+        loss.sum().backward()
+        return loss.detach().reshape(()), a.grad, e.grad
+
+
+class ShardedBiTGCF:
+    """One rank's share of BiTGCF.  ``init``: dict of the four FULL tables (reference naming) every rank slices its blocks from
+    (tests / small graphs), or None for a rank-local xavier draw."""
+
+    TABLES = ('source_user_embedding.weight', 'source_item_embedding.weight', 'target_user_embedding.weight',
+              'target_item_embedding.weight')
+
+    def __init__(self, n_users, n_items, n_overlap_users, n_overlap_items, s_pairs, t_pairs, embedding_size, n_layers, lambda_source,
+                 lambda_target, connect_way, reg_weight, ops, group=None, init=None, seed=2022):
+        self.group = group
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.part = BlockPartition(n_users, n_items, self.G)
+        self.ops, self.D, self.L = ops, int(embedding_size), int(n_layers)
+        self.lam_s, self.lam_t, self.connect_way, self.reg_weight = float(lambda_source), float(lambda_target), connect_way, float(reg_weight)
+        p, r = self.part, self.rank
+        self.OU_l, self.OI_l = p.overlap_local(n_overlap_users, r, p.bu), p.overlap_local(n_overlap_items, r, p.bi)
+        T = ops.tensor
+        self.csr = {}
+        for dom, pairs in (('s', s_pairs), ('t', t_pairs)):
+            ip, ix, vv = local_norm_adj(pairs, p, r)
+            self.csr[dom] = (T(ip), T(ix), T(vv))
+        deg = lambda pairs, axis, n: np.bincount(np.asarray(pairs)[:, axis], minlength=n).astype(np.float32)
+        full_deg = {'su': deg(s_pairs, 0, p.nu), 'tu': deg(t_pairs, 0, p.nu), 'si': deg(s_pairs, 1, p.ni), 'ti': deg(t_pairs, 1, p.ni)}
+        self.deg = {k: T(p.shard(torch.from_numpy(v), r, users=k.endswith('u'))) for k, v in full_deg.items()}
+        self.params = {}
+        gen = torch.Generator().manual_seed(seed + 7919 * r)
+        for name in self.TABLES:
+            users = '_user_' in name
+            if init is not None:
+                blk = p.shard(init[name].detach().to('cpu', torch.float32), r, users)
+            else:
+                rows = p.nu if users else p.ni
+                blk = torch.randn(p.bu if users else p.bi, self.D, generator=gen) * (2.0 / (rows + self.D)) ** 0.5
+                lo = r * (p.bu if users else p.bi)
+                blk[max(rows - lo, 0):] = 0.0                 # padding rows beyond the table stay zero
+            self.params[name] = torch.nn.Parameter(T(blk))
+
+    # ---- collectives -------------------------------------------------------------------------------------------------
+    def gather(self, x):
+        if self.G == 1:
+            return x
+        x = x.contiguous()
+        out = torch.empty((self.G * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
+    # ---- propagation ---------------------------------------------------------------------------------------------------
+    def _propagate(self):
+        p, ops, D = self.part, self.ops, self.D
+        P = self.params
+        E = {'s': torch.cat([P[self.TABLES[0]].data, P[self.TABLES[1]].data], 0), 't': torch.cat([P[self.TABLES[2]].data, P[self.TABLES[3]].data], 0)}
+        stack = {'s': [E['s']], 't': [E['t']]}
+        saved = []
+        E0_g = None
+        for _ in range(self.L):
+            Eg = {d: self.gather(E[d]) for d in 'st'}
+            if E0_g is None:
+                E0_g = Eg
+            side, new = {}, {}
+            for d in 'st':
+                side[d], new[d] = ops.graph_layer_fwd(self.csr[d], Eg[d], E[d])
+            Su, Tu = ops.transfer_fwd(new['s'][:p.bu], new['t'][:p.bu], self.deg['su'], self.deg['tu'], self.OU_l, self.lam_s, self.lam_t)
+            Si, Ti = ops.transfer_fwd(new['s'][p.bu:], new['t'][p.bu:], self.deg['si'], self.deg['ti'], self.OI_l, self.lam_s, self.lam_t)
+            S2 = {'s': torch.cat([Su, Si], 0), 't': torch.cat([Tu, Ti], 0)}
+            nrm = {}
+            for d in 'st':
+                y, nrm[d] = ops.l2norm_fwd(S2[d])
+                stack[d].append(y)
+            saved.append((E, side, S2, nrm))
+            E = S2
+        if E0_g is None:
+            E0_g = {d: self.gather(stack[d][0]) for d in 'st'}
+        nb = self.L + 1
+        if self.connect_way == 'concat':
+            out = {d: torch.cat(stack[d], 1) for d in 'st'}
+        else:
+            out = {d: torch.stack(stack[d], 1).mean(1) for d in 'st'}
+        return out, E0_g, saved, nb
+
+    def loss_and_grads(self, inter):
+        """(loss_source, loss_target) of the FULL batch ``inter`` (every rank passes the same batch) and this rank's gradient blocks in
+        ``self.params[...].grad``."""
+        p, ops, D = self.part, self.ops, self.D
+        out, E0_g, saved, nb = self._propagate()
+        losses, g_out, g_E0 = [], {}, {}
+        seg = slice(self.rank * p.nl, (self.rank + 1) * p.nl)
+        for d, pre in (('s', 'source'), ('t', 'target')):
+            out_g = self.gather(out[d])
+            pu, pi = p.user_pos(inter[f'{pre}_user_id'].reshape(-1)), p.item_pos(inter[f'{pre}_item_id'].reshape(-1))
+            loss, go, ge = ops.batch_loss(out_g, E0_g[d], pu, pi, inter[f'{pre}_label'].reshape(-1).float(), self.reg_weight)
+            losses.append(loss)
+            g_out[d], g_E0[d] = go[seg], ge[seg]                # identical on every rank: keep the own segment
+        # ---- backward through the stack, last layer first
+        if self.connect_way == 'concat':
+            g_blk = {d: [g_out[d][:, b * D:(b + 1) * D] for b in range(nb)] for d in 'st'}
+        else:
+            g_blk = {d: [g_out[d] / nb for _ in range(nb)] for d in 'st'}
+        g_next = {d: None for d in 'st'}
+        for l in reversed(range(self.L)):
+            E, side, S2, nrm = saved[l]
+            gS2 = {}
+            for d in 'st':
+                g = ops.l2norm_bwd(S2[d], nrm[d], g_blk[d][l + 1])
+                gS2[d] = g if g_next[d] is None else g + g_next[d]
+            gSu, gTu = ops.transfer_bwd(gS2['s'][:p.bu], gS2['t'][:p.bu], self.deg['su'], self.deg['tu'], self.OU_l, self.lam_s, self.lam_t)
+            gSi, gTi = ops.transfer_bwd(gS2['s'][p.bu:], gS2['t'][p.bu:], self.deg['si'], self.deg['ti'], self.OI_l, self.lam_s, self.lam_t)
+            gnew = {'s': torch.cat([gSu, gSi], 0), 't': torch.cat([gTu, gTi], 0)}
+            for d in 'st':
+                tmp_g = self.gather(ops.mul_one_plus(gnew[d], E[d]))          # A is symmetric: A^T g = A g on the gathered g (1 + E)
+                g_next[d] = ops.graph_layer_bwd(self.csr[d], tmp_g, gnew[d], side[d])
+        for d, names in (('s', self.TABLES[:2]), ('t', self.TABLES[2:])):
+            g = g_blk[d][0] + g_E0[d]
+            if g_next[d] is not None:
+                g = g + g_next[d]
+            self.params[names[0]].grad = g[:p.bu].contiguous()
+            self.params[names[1]].grad = g[p.bu:].contiguous()
+        return tuple(losses)
+
+    @torch.no_grad()
+    def propagated_tables(self):
+        """The four FULL propagated tables (evaluation: bitgcf.py:264-282), assembled from every rank's rows."""
+        out, _, _, _ = self._propagate()
+        res = []
+        for d in 'st':
+            g = self.gather(out[d])
+            res += [self.part.unshard(g, True), self.part.unshard(g, False)]
+        return res
+
+    @torch.no_grad()
+    def full_tables(self):
+        """The four FULL embedding tables in id order (tests, checkpoints)."""
+        res = {}
+        for d, names in (('s', self.TABLES[:2]), ('t', self.TABLES[2:])):
+            g = self.gather(torch.cat([self.params[names[0]].data, self.params[names[1]].data], 0))
+            res[names[0]], res[names[1]] = self.part.unshard(g, True), self.part.unshard(g, False)
+        return res

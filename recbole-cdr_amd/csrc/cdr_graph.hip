@@ -258,6 +258,41 @@ extern "C" int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const in
     return CDR_OK;
 }
 
+// Row-sharded forms (BASELINE configs[3]: tables and CSR sharded by destination row): the rank holds n_rows rows of the CSR with
+// column indices into the ALL-GATHERED embedding buffer; the row's own value comes from the local slice.
+extern "C" int cdr_graph_layer_fwd_rows(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
+                                        int64_t n_rows, const float* E_gathered, const float* E_rows, int D, float* side_out,
+                                        float* new_out) {
+    CDR_CHECK_ARG(indptr && indices && values && E_gathered && E_rows && side_out && new_out && n_rows > 0 && D > 0 && (D & 3) == 0);
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    DISPATCH_LPR(lpr, spmm_csr_kernel<L, 1><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows,
+                                                                                                 E_gathered, D, E_rows, nullptr, side_out,
+                                                                                                 new_out));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_mul_one_plus(void* stream, const float* g, const float* x, int64_t n, float* out) {
+    CDR_CHECK_ARG(g && x && out && n > 0);
+    mul_one_plus_kernel<<<GR_GRID(n)>>>(g, x, n, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_graph_layer_bwd_rows(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
+                                        int64_t n_rows, const float* tmp_gathered, const float* gnew_rows, const float* side_rows, int D,
+                                        float* gE_rows) {
+    CDR_CHECK_ARG(indptr && indices && values && tmp_gathered && gnew_rows && side_rows && gE_rows && n_rows > 0 && D > 0 && (D & 3) == 0);
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    DISPATCH_LPR(lpr, spmm_csr_kernel<L, 2><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows,
+                                                                                                 tmp_gathered, D, gnew_rows, side_rows,
+                                                                                                 nullptr, gE_rows));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
 extern "C" int cdr_transfer_fwd(void* stream, const float* S, const float* T, const float* deg_s, const float* deg_t,
                                 int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* S_out, float* T_out) {
     CDR_CHECK_ARG(S && T && deg_s && deg_t && S_out && T_out && rows > 0 && D > 0);

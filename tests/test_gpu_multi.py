@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import DEV, FakeDataset, base_config, assert_close, make_mapping as _make_mapping, collect_ranks as _collect_ranks
+from helpers import DEV, FakeDataset, base_config, assert_close, load_params, make_mapping as _make_mapping, collect_ranks as _collect_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -621,3 +621,84 @@ def test_distributed_checkpoint_resume_continues_bit_exactly(tmp_path):
     res = _collect_ranks(q, procs)
     for r in range(world):
         assert res[r][2] and all(res[r][1].values()), res[r][1]
+
+
+# ---------------------------------------------------------------------------------------------- row-sharded BiTGCF (configs[3])
+def _bitgcf_shared_gpu_worker(rank, world, port, connect_way, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF, NativeGraphOps
+        from recbole_cdr_amd.trainer.trainer import DenseAdam
+        from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+        torch.cuda.set_device(0)
+        ds, params, batches = _bitgcf_gpu_case()
+        m = ShardedBiTGCF(ds.num_total_user, ds.num_total_item, ds.num_overlap_user, ds.num_overlap_item, ds.s_pairs, ds.t_pairs, 64, 2,
+                          0.8, 0.7, connect_way, 0.001, NativeGraphOps(DEV), init=params)
+        opt = DenseAdam(list(m.params.values()), lr=0.01)
+        losses = []
+        for b in batches:
+            opt.zero_grad(set_to_none=True)
+            ls, lt = m.loss_and_grads(b)
+            losses.append((float(ls), float(lt)))
+            opt.step()
+        full = m.full_tables()
+        q.put((rank, losses, {k: v.cpu().numpy() for k, v in full.items()}, [t.cpu().numpy() for t in m.propagated_tables()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _bitgcf_gpu_case():
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    ds = SyntheticCrossDomainDataset(OU=301, TOU=200, SOU=150, OI=1, TOI=400, SOI=350, n_source_inter=4000, n_target_inter=5000, seed=5)
+    g = torch.Generator().manual_seed(9)
+    params = {k: torch.randn(ds.num_total_user if '_user_' in k else ds.num_total_item, 64, generator=g) * 0.1
+              for k in ('source_user_embedding.weight', 'source_item_embedding.weight', 'target_user_embedding.weight',
+                        'target_item_embedding.weight')}
+    rng = np.random.RandomState(2)
+    batches = [dict(ds.pointwise_batch('source', 128, 1, rng, DEV), **ds.pointwise_batch('target', 128, 1, rng, DEV)) for _ in range(3)]
+    return ds, params, batches
+
+
+@pytest.mark.parametrize('world,connect_way', [(2, 'concat'), (3, 'mean')])
+def test_row_sharded_bitgcf_native_ranks_share_one_gpu(world, connect_way):
+    """bitgcf_shard.ShardedBiTGCF on the NATIVE kernels (cdr_graph_layer_fwd_rows / _bwd_rows, transfer, normalise, gather-dot-BCE),
+    `world` ranks on cuda:0 over gloo: three Adam steps -- both losses every step, the four tables gathered back and the propagated
+    tables -- equal the single-GPU BiTGCF model (dense autograd + DenseAdam) on the same batches."""
+    import socket
+    import torch.multiprocessing as mp
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bitgcf_shared_gpu_worker, args=(r, world, port, connect_way, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect_ranks(q, procs)
+    ds, params, batches = _bitgcf_gpu_case()
+    cfg = base_config(DEV, embedding_size=64, n_layers=2, reg_weight=0.001, lambda_source=0.8, lambda_target=0.7, drop_rate=0.0,
+                      connect_way=connect_way)
+    ref = BiTGCF(cfg, ds).to(DEV)
+    load_params(ref, params)
+    opt = DenseAdam(ref.parameters(), lr=0.01)
+    want = []
+    for b in batches:
+        opt.zero_grad(set_to_none=True)
+        ls, lt = ref.calculate_loss(b)
+        (ls + lt).sum().backward()
+        want.append((float(ls), float(lt)))
+        opt.step()
+    with torch.no_grad():
+        prop = ref.forward()
+    for r, losses, full, got_prop in res:
+        for (a, b), (c, d) in zip(losses, want):
+            assert abs(a - c) <= 1e-5 * abs(c) and abs(b - d) <= 1e-5 * abs(d), (r, losses, want)
+        for k, v in ref.named_parameters():
+            assert_close(torch.from_numpy(full[k]), v.detach(), rtol=1e-5, atol=0.01 * 1e-2, what=k)
+        for a, b in zip(got_prop, prop):
+            assert_close(torch.from_numpy(a), b, what='propagated table')
