@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--no-domain-groups', action='store_true',
                     help='--shard dim: shard BOTH domains over all N ranks (D/N columns each) instead of giving each domain one half of '
                          'the ranks (D/(N/2) columns, twice the batch per rank)')
+    ap.add_argument('--replica-dp', action='store_true', help='c4 with N>1: replica data parallelism with sharded Adam (dp.py) instead of the row-sharded graph')
     ap.add_argument('--single-layout', action='store_true', help='N>1: time only the --shard layout (default: both, in one record)')
     ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
@@ -689,7 +690,21 @@ def run_model_workload(args, world, rank, dev):
 
     from recbole_cdr_amd.graph_step import GraphedTrainStep
     sdp = None
-    if world > 1:
+    rowshard = None
+    if args.workload == 'c4' and (world > 1 or args.force_shard) and not args.replica_dp:
+        # BASELINE configs[3] as named: the tables (with their Adam state), the adjacency rows and the transfer-layer degrees
+        # row-sharded over the ranks, per-layer all-gather of E forward and of g (1 + E) backward (bitgcf_shard.py).  The batch is
+        # replicated -- every rank evaluates the same 8,192 rows against the all-gathered propagated tables -- so the total work
+        # is fixed as N grows: STRONG scaling of the per-step propagation.
+        from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF, NativeGraphOps
+        rowshard = ShardedBiTGCF(ds.num_total_user, ds.num_total_item, ds.num_overlap_user, ds.num_overlap_item, ds.s_pairs, ds.t_pairs,
+                                 cfg['embedding_size'], cfg['n_layers'], cfg['lambda_source'], cfg['lambda_target'], cfg['connect_way'],
+                                 cfg['reg_weight'], NativeGraphOps(dev), drop_rate=cfg['drop_rate'])
+        del model, opt
+        torch.cuda.empty_cache()
+        opt = DenseAdam(list(rowshard.params.values()), lr=1e-3)
+        model = None
+    elif world > 1:
         # N > 1: data parallel, every rank its own batches, ONE reduce-scatter + ONE all-gather of the flat parameter buffer
         # per step and the dense Adam sweep (the largest cost of these steps) split over the ranks (dp.ShardedDataParallel)
         from recbole_cdr_amd.dp import ShardedDataParallel
@@ -699,9 +714,14 @@ def run_model_workload(args, world, rank, dev):
         else:
             batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
         sdp = ShardedDataParallel(model, lr=1e-3)
-    graphed = GraphedTrainStep(model, opt, batches[0]) if (not args.no_graph and sdp is None) else None
+    graphed = GraphedTrainStep(model, opt, batches[0]) if (not args.no_graph and sdp is None and rowshard is None) else None
 
     def one_step(i):
+        if rowshard is not None:
+            opt.zero_grad(set_to_none=True)
+            ls, lt = rowshard.loss_and_grads(batches[i % 4])
+            opt.step()
+            return ls + lt
         if sdp is not None:
             return sdp.step(batches[i % 4])
         if graphed is not None:
@@ -721,10 +741,17 @@ def run_model_workload(args, world, rank, dev):
         loss = one_step(i)
     barrier(world)
     dt = time.perf_counter() - t0
-    result = {'metric': 'training interactions/sec', 'value': rows_per_step * args.steps * world / dt, 'unit': 'interactions/s',
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    job_rows = rows_per_step * (1 if rowshard is not None else world)
+    result = {'metric': 'training interactions/sec', 'value': job_rows * args.steps / dt, 'unit': 'interactions/s',
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
+              'higher_is_better': True, 'scaling': 'strong' if rowshard is not None else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+              'data': 'synthetic' + ('; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo' if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')) else ''),
+              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
                          'rows_per_step': rows_per_step},
               'final_loss': float(loss.sum())}
     # ---- roofline of the step (SURVEY 8d figures; C1-C4 tables sit in L2 / Infinity Cache, so the HBM fractions are nominal) ----
@@ -774,13 +801,17 @@ def run_model_workload(args, world, rank, dev):
                         'the 43 MB of tables and the adjacency live in L2 / Infinity Cache: nominal fraction' % L, 'traffic': None}
     else:
         per_row = (3 * 4 * D + 24) if pairwise else (2 * 4 * D + 20)
-        tabs_el = (2 if args.workload == 'c2' else 1) * 0 + sum(p.numel() for p in model.parameters() if p.grad is not None)
+        tabs_el = sum(p.numel() for p in model.parameters() if p.grad is not None)
         byts = float(rows_per_step * per_row + 7 * 4 * tabs_el)
         gbs = byts / step_s / 1e9
         roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
                 'what': 'gather (%d B per row) + exact dense Adam over the parameters that received a gradient (7 x 4 B per element); the '
                         'tables (a few MB) are L2-resident and the step is launch / latency bound: nominal fraction' % per_row, 'traffic': None}
     result['roofline'] = roof
+    if rowshard is not None:
+        p_ = rowshard.part
+        result['exchange'] = {'all_gather_bytes_received_per_rank_per_step': float((world - 1) * p_.nl * 4 * cfg['embedding_size'] * (4 * cfg['n_layers'] + 2 * (cfg['n_layers'] + 1))),
+                              'collectives_per_step': 2 * (2 * cfg['n_layers'] + 1), 'note': 'per domain: L all-gathers of E forward, L of g(1+E) backward, one of the stacked outputs'}
     if rank == 0 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_model(args, ds, cfg, S, k, batches[0] if pairwise else None)
     return result

@@ -129,6 +129,12 @@ class NativeGraphOps:
                 float(lam_s), float(lam_t), B_.f32(gS), B_.f32(gT))
         return gS, gT
 
+    def dropout(self, x, p, seed):
+        B_ = self.B_
+        out = torch.empty_like(x)
+        B_.call('cdr_dropout', B_.stream(), B_.f32(x), x.numel(), float(p), int(seed), B_.f32(out))
+        return out
+
     def l2norm_fwd(self, x):
         B_ = self.B_
         y, nrm = torch.empty_like(x), torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
@@ -163,13 +169,14 @@ class ShardedBiTGCF:
               'target_item_embedding.weight')
 
     def __init__(self, n_users, n_items, n_overlap_users, n_overlap_items, s_pairs, t_pairs, embedding_size, n_layers, lambda_source,
-                 lambda_target, connect_way, reg_weight, ops, group=None, init=None, seed=2022):
+                 lambda_target, connect_way, reg_weight, ops, group=None, init=None, seed=2022, drop_rate=0.0):
         self.group = group
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.part = BlockPartition(n_users, n_items, self.G)
         self.ops, self.D, self.L = ops, int(embedding_size), int(n_layers)
         self.lam_s, self.lam_t, self.connect_way, self.reg_weight = float(lambda_source), float(lambda_target), connect_way, float(reg_weight)
+        self.drop_rate, self.training = float(drop_rate), True     # nn.Dropout on every graph layer's output (bitgcf.py:66,134)
         p, r = self.part, self.rank
         self.OU_l, self.OI_l = p.overlap_local(n_overlap_users, r, p.bu), p.overlap_local(n_overlap_items, r, p.bi)
         T = ops.tensor
@@ -210,13 +217,19 @@ class ShardedBiTGCF:
         stack = {'s': [E['s']], 't': [E['t']]}
         saved = []
         E0_g = None
+        seeds = None
+        if self.training and self.drop_rate > 0.0:
+            seeds = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 40).item()) + (self.rank << 44)
+        self._seeds = seeds
         for _ in range(self.L):
             Eg = {d: self.gather(E[d]) for d in 'st'}
             if E0_g is None:
                 E0_g = Eg
             side, new = {}, {}
-            for d in 'st':
+            for k, d in enumerate('st'):
                 side[d], new[d] = ops.graph_layer_fwd(self.csr[d], Eg[d], E[d])
+                if seeds is not None:                       # one counter-based mask per (layer, domain, rank); re-made in the backward
+                    new[d] = ops.dropout(new[d], self.drop_rate, seeds + 2 * len(saved) + k)
             Su, Tu = ops.transfer_fwd(new['s'][:p.bu], new['t'][:p.bu], self.deg['su'], self.deg['tu'], self.OU_l, self.lam_s, self.lam_t)
             Si, Ti = ops.transfer_fwd(new['s'][p.bu:], new['t'][p.bu:], self.deg['si'], self.deg['ti'], self.OI_l, self.lam_s, self.lam_t)
             S2 = {'s': torch.cat([Su, Si], 0), 't': torch.cat([Tu, Ti], 0)}
@@ -263,6 +276,8 @@ class ShardedBiTGCF:
             gSu, gTu = ops.transfer_bwd(gS2['s'][:p.bu], gS2['t'][:p.bu], self.deg['su'], self.deg['tu'], self.OU_l, self.lam_s, self.lam_t)
             gSi, gTi = ops.transfer_bwd(gS2['s'][p.bu:], gS2['t'][p.bu:], self.deg['si'], self.deg['ti'], self.OI_l, self.lam_s, self.lam_t)
             gnew = {'s': torch.cat([gSu, gSi], 0), 't': torch.cat([gTu, gTi], 0)}
+            if self._seeds is not None:
+                gnew = {d: ops.dropout(gnew[d], self.drop_rate, self._seeds + 2 * l + k) for k, d in enumerate('st')}
             for d in 'st':
                 tmp_g = self.gather(ops.mul_one_plus(gnew[d], E[d]))          # A is symmetric: A^T g = A g on the gathered g (1 + E)
                 g_next[d] = ops.graph_layer_bwd(self.csr[d], tmp_g, gnew[d], side[d])
@@ -276,8 +291,12 @@ class ShardedBiTGCF:
 
     @torch.no_grad()
     def propagated_tables(self):
-        """The four FULL propagated tables (evaluation: bitgcf.py:264-282), assembled from every rank's rows."""
-        out, _, _, _ = self._propagate()
+        """The four FULL propagated tables (evaluation: bitgcf.py:264-282; dropout off), assembled from every rank's rows."""
+        was, self.training = self.training, False
+        try:
+            out, _, _, _ = self._propagate()
+        finally:
+            self.training = was
         res = []
         for d in 'st':
             g = self.gather(out[d])
