@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 22
+#define CDR_ABI_VERSION 23
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -370,6 +370,9 @@ int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, 
 /* nn.Dropout(p), training mode: out = mask ? x/(1-p) : 0, counter-based mask from `seed` (same call with the same seed on
  * the upstream gradient is the backward); in place allowed (bitgcf.py:66,134). */
 int cdr_dropout(void* stream, const float* x, int64_t n, float p, uint64_t seed, float* out);
+/* hipGraph-capturable form: the seed is a device counter (bump it with cdr_inc_i64 once per step, inside the captured step), `salt`
+ * separates the masks drawn within one step (layer, domain).  A host seed would be baked into the graph and repeat one mask forever. */
+int cdr_dropout_dev(void* stream, const float* x, int64_t n, float p, const int64_t* seed_dev, uint64_t salt, float* out);
 int cdr_embloss_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_tab, int D,
                     const int64_t* uid, const int64_t* iid, int64_t B, float* out3);
 int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const float* item_tab, int D, const int64_t* uid,

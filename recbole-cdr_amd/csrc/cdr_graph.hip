@@ -207,6 +207,28 @@ __global__ __launch_bounds__(kBlock) void dropout_kernel(const float* __restrict
     }
 }
 
+// The same mask family with the seed held in DEVICE memory: a hipGraph replay bakes host scalars into its launches, so a
+// host-drawn seed would repeat one mask on every replayed step; here the counter is bumped by a captured cdr_inc_i64 and each
+// replay draws a fresh mask.  `salt` separates the masks of one step (layer, domain).
+__global__ __launch_bounds__(kBlock) void dropout_dev_kernel(const float* __restrict__ x, int64_t n, float p,
+                                                             const int64_t* __restrict__ seed_dev, uint64_t salt,
+                                                             float* __restrict__ out) {
+    uint64_t s0 = (uint64_t)seed_dev[0] * 0xD1342543DE82EF95ull + 0x9E3779B97F4A7C15ull;      // consecutive counters -> unrelated seeds
+    s0 = (s0 ^ (s0 >> 30)) * 0xBF58476D1CE4E5B9ull;
+    s0 = (s0 ^ (s0 >> 27)) * 0x94D049BB133111EBull;
+    const uint64_t seed = (s0 ^ (s0 >> 31)) + salt * 0xA24BAED4963EE407ull;
+    const float scale = 1.0f / (1.0f - p);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        uint64_t z = seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+        out[e] = u >= p ? x[e] * scale : 0.0f;
+    }
+}
+
 }  // namespace
 
 #define GR_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
@@ -343,6 +365,13 @@ extern "C" int cdr_colblock_mean_fwd(void* stream, const float* cat, int64_t row
 extern "C" int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, int nb, float* gcat) {
     CDR_CHECK_ARG(gout && gcat && rows > 0 && D > 0 && nb > 0);
     colblock_mean_bwd_kernel<<<GR_GRID(rows * D * nb)>>>(gout, rows, D, nb, gcat);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_dropout_dev(void* stream, const float* x, int64_t n, float p, const int64_t* seed_dev, uint64_t salt, float* out) {
+    CDR_CHECK_ARG(x && out && seed_dev && n > 0 && p >= 0.0f && p < 1.0f);
+    dropout_dev_kernel<<<GR_GRID(n)>>>(x, n, p, seed_dev, salt, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

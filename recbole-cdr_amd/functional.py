@@ -535,6 +535,14 @@ class CSRGraph:
         self.indptr, self.indices, self.values, self.n_rows = indptr, indices, values, n_rows
 
 
+def _dropout(x, n, p, seed, salt):
+    """In-place counter-based dropout; ``seed`` a host int or a device int64 [1] counter."""
+    if torch.is_tensor(seed):
+        B_.call('cdr_dropout_dev', B_.stream(), B_.f32(x), n, float(p), B_.i64(seed), int(salt), B_.f32(x))
+    else:
+        B_.call('cdr_dropout', B_.stream(), B_.f32(x), n, float(p), int(seed + salt), B_.f32(x))
+
+
 class BiTGCFPropagate(Function):
     """BiTGCF.forward (bitgcf.py:174-205) as ONE autograd node: n_layers x [graph layer (CSR SpMM with the elementwise
     math fused) -> bi-directional transfer on the overlapped rows -> L2-normalised copy into the layer stack], both
@@ -543,6 +551,8 @@ class BiTGCFPropagate(Function):
 
     @staticmethod
     def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p=0.0, drop_seed=0):
+        # drop_seed: a host int, or a device int64 [1] counter (the capturable form: a hipGraph replay would bake a host seed
+        # into its launches and repeat one mask on every step)
         _dev_check(su, si, tu, ti)
         nu, ni, D = su.shape[0], si.shape[0], su.shape[1]
         n = nu + ni
@@ -565,8 +575,8 @@ class BiTGCFPropagate(Function):
             B_.call('cdr_graph_layer_fwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T), D,
                     B_.f32(sideT), B_.f32(newT))
             if drop_p > 0.0:            # nn.Dropout on the layer output (bitgcf.py:134), one mask per (layer, domain)
-                B_.call('cdr_dropout', st(), B_.f32(newS), n * D, float(drop_p), int(drop_seed + 2 * l), B_.f32(newS))
-                B_.call('cdr_dropout', st(), B_.f32(newT), n * D, float(drop_p), int(drop_seed + 2 * l + 1), B_.f32(newT))
+                _dropout(newS, n * D, drop_p, drop_seed, 2 * l)
+                _dropout(newT, n * D, drop_p, drop_seed, 2 * l + 1)
             S2, T2 = f32(n, D), f32(n, D)
             off = 4 * nu * D
             B_.call('cdr_transfer_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU,
@@ -586,7 +596,7 @@ class BiTGCFPropagate(Function):
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catS), n, D, nb, B_.f32(outS))
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catT), n, D, nb, B_.f32(outT))
         ctx.save_for_backward(*saved)
-        ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, float(drop_p), int(drop_seed))
+        ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, float(drop_p), drop_seed)
         return outS, outT
 
     @staticmethod
@@ -621,8 +631,8 @@ class BiTGCFPropagate(Function):
             B_.call('cdr_transfer_bwd', st(), B_._c_ptr(gS.data_ptr() + off), B_._c_ptr(gT.data_ptr() + off), B_.f32(deg['si']),
                     B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, B_._c_ptr(gnS.data_ptr() + off), B_._c_ptr(gnT.data_ptr() + off))
             if drop_p > 0.0:            # same masks as the forward
-                B_.call('cdr_dropout', st(), B_.f32(gnS), n * D, drop_p, drop_seed + 2 * l, B_.f32(gnS))
-                B_.call('cdr_dropout', st(), B_.f32(gnT), n * D, drop_p, drop_seed + 2 * l + 1, B_.f32(gnT))
+                _dropout(gnS, n * D, drop_p, drop_seed, 2 * l)
+                _dropout(gnT, n * D, drop_p, drop_seed, 2 * l + 1)
             gS_in, gT_in = f32(n, D), f32(n, D)
             B_.call('cdr_graph_layer_bwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S_in),
                     B_.f32(sideS), B_.f32(gnS), D, B_.f32(tmp), B_.f32(gS_in))

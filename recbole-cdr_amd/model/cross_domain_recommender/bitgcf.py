@@ -6,8 +6,9 @@ The reference propagates over the FULL graph inside every calculate_loss (bitgcf
 and a normalise-into-the-stack kernel; the per-batch part is the same fused gather-dot-BCE kernel CMF uses, with the
 EmbLoss taken on the ego rows.  Adjacency values are formed exactly as the reference does (float64 D^-1/2 A D^-1/2 with
 degree + 1e-7, rounded to fp32: bitgcf.py:92-116) -- golden-pinned bit for bit in tests/test_oracle_golden.py.
-Dropout (bitgcf.py:66,134): identity in eval; in training a native counter-based mask (cdr_dropout) whose per-call seed
-is drawn from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable.  Masks are not bit-comparable with
+Dropout (bitgcf.py:66,134): identity in eval; in training a native counter-based mask (cdr_dropout_dev) whose seed sits in device
+memory: drawn from torch's CPU generator per step when run eagerly (``torch.manual_seed`` makes runs repeatable), advanced by a
+captured kernel when the step is replayed as a hipGraph (a fresh mask per replay).  Masks are not bit-comparable with
 the reference's Philox stream: golden parity is pinned at drop_rate = 0, the mask by its statistics.
 """
 import numpy as np
@@ -81,10 +82,22 @@ class BiTGCF(CrossDomainRecommender):
         return S[:nu], S[nu:], T[:nu], T[nu:]
 
     def _dropout_args(self):
+        """(p, seed).  The seed lives in a DEVICE int64: eagerly it is re-drawn from torch's CPU generator on every training forward
+        (``torch.manual_seed`` makes a step repeatable); inside a hipGraph capture (graph_step.GraphedTrainStep) a host draw would be
+        baked into the graph and every replay would repeat ONE mask, so there the captured step advances the device value itself
+        with one tiny kernel and each replay draws a fresh mask, as nn.Dropout does."""
         if not self.training or not self.drop_rate:
             return 0.0, 0
-        seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())
-        return float(self.drop_rate), seed
+        dev = self.source_user_embedding.weight.device
+        st = self.__dict__.get('_drop_state')
+        if st is None or st.device != dev:
+            st = torch.zeros(1, device=dev, dtype=torch.int64)
+            self.__dict__['_drop_state'] = st
+        if torch.cuda.is_current_stream_capturing():
+            B_.call('cdr_inc_i64', B_.stream(), B_.i64(st))
+        else:
+            st.fill_(int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item()))
+        return float(self.drop_rate), st
 
     def calculate_loss(self, interaction):
         self.init_restore_e()

@@ -1020,6 +1020,37 @@ def test_bitgcf_dropout_statistics_and_backward_mask():
     assert_close(le, g['loss/BOTH'], what='eval-mode loss == drop_rate 0 golden')
 
 
+def test_bitgcf_dropout_under_graph_replay_draws_a_fresh_mask_every_step():
+    """a host-drawn dropout seed is baked into a captured hipGraph and every replay would repeat ONE mask.
+    The seed is a device counter bumped inside the captured step: two replays on the SAME batch give different losses (different
+    masks), an eval-mode loss is mask-free, and the keep rate of the device-seeded kernel is 1 - p."""
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    from recbole_cdr_amd.graph_step import GraphedTrainStep
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    ds = SyntheticCrossDomainDataset(OU=101, TOU=80, SOU=70, OI=1, TOI=120, SOI=110, n_source_inter=1500, n_target_inter=1800, seed=2)
+    cfg = base_config(DEV, embedding_size=16, n_layers=2, reg_weight=0.001, lambda_source=0.8, lambda_target=0.8, drop_rate=0.5,
+                      connect_way='concat')
+    torch.manual_seed(3)
+    m = BiTGCF(cfg, ds).to(DEV)
+    opt = DenseAdam(m.parameters(), lr=0.0)                       # lr 0: the weights never move, so only the mask changes the loss
+    rng = np.random.RandomState(0)
+    b = dict(ds.pointwise_batch('source', 64, 1, rng, DEV), **ds.pointwise_batch('target', 64, 1, rng, DEV))
+    g = GraphedTrainStep(m, opt, b, warmup=1)
+    losses = [float(g.step(b)) for _ in range(4)]
+    assert len({round(l, 7) for l in losses}) == 4, losses       # four replays, four masks
+    x = torch.ones(1 << 20, device=DEV); out = torch.empty_like(x)
+    seed = torch.tensor([41], device=DEV, dtype=torch.int64)
+    B_.call('cdr_dropout_dev', B_.stream(), B_.f32(x), x.numel(), 0.3, B_.i64(seed), 0, B_.f32(out))
+    keep = float((out > 0).float().mean())
+    assert abs(keep - 0.7) < 3e-3 and abs(float(out.max()) - 1 / 0.7) < 1e-6
+    out2 = torch.empty_like(x)
+    B_.call('cdr_dropout_dev', B_.stream(), B_.f32(x), x.numel(), 0.3, B_.i64(seed + 1), 0, B_.f32(out2))
+    agree = float(((out > 0) == (out2 > 0)).float().mean())
+    assert abs(agree - (0.49 + 0.09)) < 5e-3                     # consecutive counters: independent masks
+
+
 def test_graphed_step_equals_eager_step():
     """hipGraph replay of calculate_loss -> backward -> native dense Adam == the same steps run eagerly (CoNet, 4 steps,
     fresh ids every step): parameters and losses."""
