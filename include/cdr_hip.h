@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 23
+#define CDR_ABI_VERSION 24
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -197,6 +197,10 @@ int cdr_gemm_f32_ex(void* stream, int transA, int transB, int64_t M, int64_t N, 
 /* out[r*ldo + c] = tab[ids[r]*D + c]  /  grad_tab[ids[r]*D + c] += src[r*lds + c]  (the [u ; i] concatenated input) */
 int cdr_gather_rows_ld(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out, int64_t ldo);
 int cdr_scatter_add_rows_ld(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n, const float* src, int64_t lds);
+/* the deterministic form: ids sorted by cdr_sort_ids / cdr_sort_ids_small (keys_sorted, perm); every distinct row of the ZEROED
+ * grad_tab receives the sum of its occurrences' rows src[perm[e] * lds ..] in occurrence order -- no float atomics */
+int cdr_scatter_rows_sorted(void* stream, float* grad_tab, int D, const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
+                            const float* src, int64_t lds);
 int cdr_overlap_mask(void* stream, const int64_t* ids, int64_t n, int64_t n_overlap, float* out);   /* id < n ? 1 : 0 */
 int cdr_rowscale(void* stream, const float* x, const float* scale, int64_t M, int64_t N, float* out);
 int cdr_bcast_add_act(void* stream, const float* P, const float* q, int64_t N, int64_t H, int act, float* out);

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -79,6 +79,7 @@ _SIGNATURES = {
                         _c_ptr, _c_int, _c_int],
     'cdr_gather_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
     'cdr_scatter_add_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
+    'cdr_scatter_rows_sorted': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64],
     'cdr_overlap_mask': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
     'cdr_rowscale': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
     'cdr_bcast_add_act': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr],

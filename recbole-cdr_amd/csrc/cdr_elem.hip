@@ -272,6 +272,38 @@ extern "C" int cdr_gather_rows_ld(void* stream, const float* tab, int D, const i
     return CDR_OK;
 }
 
+// Deterministic counterpart of cdr_scatter_add_rows_ld: the ids come SORTED (cdr_sort_ids / cdr_sort_ids_small), every distinct row
+// is written once with the sum of its occurrences' rows in occurrence order -- no float atomics, run-to-run reproducible.
+// grad_tab must be zero (rows the batch does not touch stay zero).
+namespace {
+__global__ __launch_bounds__(kBlock) void scatter_rows_sorted_kernel(float* __restrict__ grad_tab, int D, const uint32_t* __restrict__ keys,
+                                                                     const uint32_t* __restrict__ perm, int64_t n,
+                                                                     const float* __restrict__ src, int64_t lds) {
+    const int D4 = D >> 2;
+    const int64_t total = n * D4, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < total; w += stride) {
+        const int64_t q = w / D4;
+        const int ch = (int)(w - q * D4);
+        const uint32_t row = keys[q];
+        if (q > 0 && keys[q - 1] == row) continue;                     // segment heads only
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e = q; e < n && keys[e] == row; ++e) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (int64_t)perm[e] * lds + 4 * ch);
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        *reinterpret_cast<float4*>(grad_tab + (int64_t)row * D + 4 * ch) = acc;
+    }
+}
+}  // namespace
+
+extern "C" int cdr_scatter_rows_sorted(void* stream, float* grad_tab, int D, const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
+                                       const float* src, int64_t lds) {
+    CDR_CHECK_ARG(grad_tab && keys_sorted && perm && src && D > 0 && (D & 3) == 0 && n > 0 && lds >= D && (lds & 3) == 0);
+    scatter_rows_sorted_kernel<<<EL_GRID(n * (D >> 2))>>>(grad_tab, D, keys_sorted, perm, n, src, lds);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
 extern "C" int cdr_scatter_add_rows_ld(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n, const float* src,
                                        int64_t lds) {
     CDR_CHECK_ARG(grad_tab && ids && src && D > 0 && n > 0 && lds >= D);

@@ -50,6 +50,8 @@ class DomainTrainLoader:
     def __next__(self):
         if self.pr >= self.pr_end:
             self.pr = 0
+            if hasattr(self.neg_sampler, 'check_failures'):
+                self.neg_sampler.check_failures()        # one host sync per epoch: did any draw fall back to a fixed candidate?
             raise StopIteration()
         cur = self.inter[self.pr:self.pr + self.step]
         self.pr += self.step

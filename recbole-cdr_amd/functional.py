@@ -396,6 +396,39 @@ class FrobeniusNorm(Function):
 
 
 _conet_ws = {}
+_sort_bufs = {}
+
+
+def sort_id_lists(lists, max_id):
+    """[(keys_sorted, perm, n)] per id list (uint32 views of shared buffers): the chip-wide rank sort for lists <= 16384 ids,
+    the radix sort above.  Buffers are cached per (device, stream, sizes)."""
+    lists = [x.reshape(-1).contiguous().to(torch.int64) for x in lists]
+    dev = lists[0].device
+    ns = [int(x.numel()) for x in lists]
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tuple(ns))
+    if key not in _sort_bufs:
+        tot = sum(ns)
+        _sort_bufs[key] = [torch.empty(tot, device=dev, dtype=torch.int32), torch.empty(tot, device=dev, dtype=torch.int32),
+                           torch.zeros(tot, device=dev, dtype=torch.int32), None]
+    keys, perm, rank, ws = _sort_bufs[key]
+    offs, o = [], 0
+    for n in ns:
+        offs.append(o); o += n
+    m = len(ns)
+    if max(ns) <= 16384 and m <= 4:
+        B_._alive.extend(lists)
+        B_.call('cdr_sort_ids_small', B_.stream(), m, (ctypes.c_void_p * m)(*[x.data_ptr() for x in lists]), (ctypes.c_int64 * m)(*ns),
+                None, None, (ctypes.c_int64 * m)(*offs), B_.raw(keys), B_.raw(perm), B_.raw(rank), int(max_id))
+    else:
+        for x, n, of in zip(lists, ns, offs):
+            need = ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_sort_workspace_bytes(n, int(max_id), ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+            if ws is None or ws.numel() < need.value:
+                ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+                _sort_bufs[key][3] = ws
+            B_.call('cdr_sort_ids', B_.ctx(dev), B_.stream(), B_.i64(x), n, None, 0, int(max_id), B_.raw(keys[of:of + n]),
+                    B_.raw(perm[of:of + n]), B_.raw(ws), ws.numel())
+    return [(keys[of:of + n], perm[of:of + n], n) for n, of in zip(ns, offs)]
 
 
 def conet_supported(dims):
@@ -467,10 +500,14 @@ class ConetFusedLoss(Function):
             # the per-occurrence rows of gx0 through the id sort it made before the forward pass
             ctx.row_opt.pending = (gx0, (0, D, 2 * D, 3 * D), 4 * D)
             return (None,) * 14 + grads
+        # dense gradients for the reference's dense optimizer, WITHOUT float atomics: one id sort per list, then every distinct row
+        # is written once with its occurrences summed in occurrence order (run-to-run reproducible)
         gsu, gtu = torch.zeros(ushape, device=dev), torch.zeros(ushape, device=dev)
         gsi, gti = torch.zeros(ishape, device=dev), torch.zeros(ishape, device=dev)
-        for k, (g, ids) in enumerate(((gsu, user), (gsi, item), (gtu, user), (gti, item))):
-            B_.call('cdr_scatter_add_rows_ld', B_.stream(), B_.f32(g), D, B_.i64(ids), R, B_._c_ptr(gx0.data_ptr() + 4 * k * D), 4 * D)
+        (ku, pu, _), (ki, pi, _) = sort_id_lists([user, item], max(ushape[0], ishape[0]))
+        for k, (g, kk, pp_) in enumerate(((gsu, ku, pu), (gsi, ki, pi), (gtu, ku, pu), (gti, ki, pi))):
+            B_.call('cdr_scatter_rows_sorted', B_.stream(), B_.f32(g), D, B_.raw(kk), B_.raw(pp_), R, B_._c_ptr(gx0.data_ptr() + 4 * k * D),
+                    4 * D)
         return (gsu, gsi, gtu, gti) + (None,) * 10 + grads
 
 

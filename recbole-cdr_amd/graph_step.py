@@ -10,8 +10,12 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, example_interaction, warmup=3):
+    def __init__(self, model, optimizer, example_interaction, warmup=3, restore_after_warmup=True):
+        """``restore_after_warmup``: the warm-up runs REAL steps on ``example_interaction`` (every lazily created buffer, native context
+        and optimizer state must exist before the capture); with True the parameters and the optimizer state are put back afterwards,
+        so swapping the eager loop for the graphed one does not add ``warmup`` extra updates on batch 0."""
         self.model, self.optimizer = model, optimizer
+        self.restore_after_warmup = restore_after_warmup
         self.static = {k: v.clone() for k, v in example_interaction.items()}
         self.graph = None
         self.loss = None
@@ -34,16 +38,51 @@ class GraphedTrainStep:
         # populate .grad and the optimizer state (and every lazily created native context) before capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        snap = self._snapshot() if self.restore_after_warmup else None
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
+            for i in range(max(warmup, 1)):
                 self._eager(self.static)
+                if i == 0 and snap is not None:
+                    snap = self._snapshot(snap)           # optimizer state created by the first step: remembered as zeros
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            self._restore(snap)
         self.graph = torch.cuda.CUDAGraph()
         # capture on the stream that ran the warm-up: the native contexts are per (device, stream) and creating one
         # allocates, which is not allowed while a stream is capturing
         with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._eager(self.static)
+
+    # ---- warm-up without side effects: in-place snapshot / restore (addresses must not change: the capture follows) -------------
+    def _state_tensors(self):
+        ts = [p.data for p in self.model.parameters()]
+        for st in self.optimizer.state.values():
+            ts += [v for v in st.values() if torch.is_tensor(v)]
+        ro = getattr(self.optimizer, 'row_opt', None)
+        if ro is not None:
+            ts += ro.exp_avg + ro.exp_avg_sq + ro.last + [ro.counters]
+        ds = getattr(self.model, '_drop_state', None)
+        if ds is not None:
+            ts.append(ds)
+        return ts
+
+    def _snapshot(self, prev=None):
+        ts = self._state_tensors()
+        if prev is None:
+            ro = getattr(self.optimizer, 'row_opt', None)
+            return {'tensors': [(t, t.clone()) for t in ts], 'row': None if ro is None else (ro.step_count, ro.dirty)}
+        known = {t.data_ptr() for t, _ in prev['tensors']}
+        prev['tensors'] += [(t, torch.zeros_like(t)) for t in ts if t.data_ptr() not in known]   # state born in step 1 started at zero
+        return prev
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for t, c in snap['tensors']:
+                t.copy_(c)
+        ro = getattr(self.optimizer, 'row_opt', None)
+        if ro is not None and snap['row'] is not None:
+            ro.step_count, ro.dirty = snap['row']
 
     def step(self, interaction):
         same = all(k in interaction and interaction[k].shape == v.shape for k, v in self.static.items())

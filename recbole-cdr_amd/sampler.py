@@ -63,6 +63,16 @@ class DeviceNegSampler:
 
     __call__ = sample_by_user_ids
 
+    def check_failures(self):
+        """The kernels give up after 64 rejected draws and fall back to the first candidate, raising a device flag (a user whose
+        history covers almost the whole candidate range): the reference's sampler would loop until every draw is valid.  One host
+        sync: call it where that is cheap (the loaders do, once per epoch).  Raises if any fallback happened since the last check."""
+        if int(self.fail.item()):
+            self.fail.zero_()
+            raise RuntimeError('DeviceNegSampler: a draw was rejected 64 times and fell back to a fixed candidate (a user interacted with '
+                               'nearly every item of the range): the returned negatives may contain an interacted item. Filter such users '
+                               '(`user_inter_num_interval`) as the reference requires.')
+
 
 def build_alias_table(candidates):
     """Walker alias table over the item ids of the sampler's interactions, as crossdomain_sampler.py:66-94 builds it

@@ -46,6 +46,18 @@ class DenseAdam(torch.optim.Optimizer):
                     float(group['weight_decay']))
 
 
+def _dense_adam_load(self, state_dict):
+    """torch.optim.Adam checkpoints keep ``step`` as a Python float or a 0-d tensor: convert to this optimizer's device int64 [1]."""
+    torch.optim.Optimizer.load_state_dict(self, state_dict)
+    for p, st in self.state.items():
+        if 'step' in st and not (torch.is_tensor(st['step']) and st['step'].dtype == torch.int64 and st['step'].numel() == 1
+                                 and st['step'].dim() == 1):
+            st['step'] = torch.full((1,), int(float(st['step'])), device=p.device, dtype=torch.int64)
+
+
+DenseAdam.load_state_dict = _dense_adam_load
+
+
 class RowAwareAdam(DenseAdam):
     """``DenseAdam`` for a model whose embedding tables take the deferred row-wise form of the SAME optimizer
     (``model.enable_deferred_adam``; lazyadam.DeferredRowAdam: exact dense-Adam results, O(batch) traffic).  ``step()`` = the
@@ -125,6 +137,15 @@ class Trainer:
             raise ValueError(f"optimizer_mode must be 'dense' or 'rowwise', got {self.optimizer_mode!r}")
         if self.optimizer_mode == 'rowwise' and not hasattr(self.model, 'fused_train_step'):
             raise NotImplementedError(f'{type(self.model).__name__} has no fused_train_step; use optimizer_mode=dense')
+        if self.optimizer_mode == 'rowwise' and self.clip_grad_norm:
+            # the fused step never materialises the gradient, so there is no norm to clip: refuse rather than ignore silently
+            raise ValueError("clip_grad_norm is not supported with optimizer_mode='rowwise' (the fused step applies per-row updates "
+                             "without forming the full gradient); use optimizer_mode='dense' or unset clip_grad_norm")
+        if 'parallel_domains' in config and config['parallel_domains']:
+            import warnings
+            warnings.warn('parallel_domains: the SOURCE and TARGET phases of a parallel stage run WITHOUT validation, early stopping, '
+                          'best_valid_score updates and callback_fn (evaluation needs every rank); later phases evaluate as usual',
+                          stacklevel=2)
 
     def _train_epoch(self, train_data, epoch_idx):
         self.model.train()

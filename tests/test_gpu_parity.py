@@ -872,14 +872,12 @@ def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
         loss.backward()
         opt.step()
         return loss.detach().clone()
-    g = GraphedTrainStep(m_graph, o_graph, batches[0], warmup=2)
-    for _ in range(2):                                           # the capture warm-up trains on batches[0]: mirror it
-        eager(m_dense, o_dense, batches[0]); eager(m_lazy, o_lazy, batches[0])
+    g = GraphedTrainStep(m_graph, o_graph, batches[0], warmup=2)     # the warm-up's two real steps are undone before the capture
     for b in batches:
         ld, ll, lg = eager(m_dense, o_dense, b), eager(m_lazy, o_lazy, b), g.step(b).clone()
         assert_close(ll, ld, what='loss, deferred vs dense')
         assert torch.equal(ll, lg)
-    assert o_lazy.row_opt.step_count == 8 and o_graph.row_opt.step_count == 8
+    assert o_lazy.row_opt.step_count == 6 and o_graph.row_opt.step_count == 6
     ev = {'target_user_id': batches[0]['target_user_id'][:5], 'target_item_id': batches[0]['target_item_id'][:5]}
     p_dense, p_lazy, p_graph = m_dense.predict(ev), m_lazy.predict(ev), m_graph.predict(ev)      # predict() flushes the postponed rows
     assert torch.equal(p_lazy, p_graph)
@@ -1053,7 +1051,7 @@ def test_bitgcf_dropout_under_graph_replay_draws_a_fresh_mask_every_step():
 
 def test_graphed_step_equals_eager_step():
     """hipGraph replay of calculate_loss -> backward -> native dense Adam == the same steps run eagerly (CoNet, 4 steps,
-    fresh ids every step): parameters and losses."""
+    fresh ids every step): parameters and losses BIT for bit, and the capture's warm-up leaves no trace."""
     import copy
     from oracle.common import IdSpace
     from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
@@ -1068,22 +1066,15 @@ def test_graphed_step_equals_eager_step():
     o1, o2 = DenseAdam(m1.parameters(), lr=0.01), DenseAdam(m2.parameters(), lr=0.01)
     rng = np.random.RandomState(0)
     batches = [dict(ds.pointwise_batch('source', 32, 2, rng, DEV), **ds.pointwise_batch('target', 32, 2, rng, DEV)) for _ in range(4)]
-    # the capture warm-up itself trains (3 eager steps on batches[0]); mirror it on the eager model
-    g = GraphedTrainStep(m2, o2, batches[0], warmup=3)
+    g = GraphedTrainStep(m2, o2, batches[0], warmup=3)            # the warm-up's three real steps are undone before the capture
     def eager(b):
         o1.zero_grad(set_to_none=False)
-        l = m1.calculate_loss(b).sum(); l.backward(); o1.step(); return l.detach()
-    for _ in range(3):
-        eager(batches[0])
+        l = m1.calculate_loss(b).sum(); l.backward(); o1.step(); return l.detach().clone()
     for b in batches:
         le, lg = eager(b), g.step(b).clone()
-        # fp32 atomics in the dense scatter-add reorder sums; Adam from zero state turns ~0 gradients into +-lr steps, so
-        # the two runs may differ by a few lr on a handful of elements: bound the loss at 1e-3 relative
-        assert_close(lg, le, rtol=1e-3, what='loss')
-    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-        diff = (p2 - p1).abs()
-        assert float(diff.max()) <= 0.01 * 2 * 7 + 1e-6, k                 # at most (steps) x 2 lr on any element
-        assert float((diff > 1e-4).float().mean()) < 0.02, k                # and only on a small fraction
+        assert torch.equal(lg, le)               # nothing order-dependent is left in the CoNet step: the towers' backward adds in a
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):     # fixed order, the embedding scatter is sorted
+        assert torch.equal(p1.data, p2.data), k
 
 
 # ---------------------------------------------------------------------------------------------- edge cases
