@@ -701,4 +701,5 @@ def test_row_sharded_bitgcf_native_ranks_share_one_gpu(world, connect_way):
         for k, v in ref.named_parameters():
             assert_close(torch.from_numpy(full[k]), v.detach(), rtol=1e-5, atol=0.01 * 1e-2, what=k)
         for a, b in zip(got_prop, prop):
-            assert_close(torch.from_numpy(a), b, what='propagated table')
+            # three Adam steps in: the tables agree within Adam's drift bound (1e-2 of one update), and so do the propagated rows
+            assert_close(torch.from_numpy(a), b, rtol=1e-5, atol=0.01 * 1e-2, what='propagated table')

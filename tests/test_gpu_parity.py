@@ -19,7 +19,9 @@ def _check_grads(model, g, phase):
     got = _grads(model)
     for name, ref in want.items():
         assert name in got, f'{name}: reference has a gradient, product has none'
-        assert_close(got[name], ref, what=f'{g.name}:{phase}:{name}')
+        # (embedding gradients are SIGNED sums over occurrences -- a negative's row cancels against a positive's -- so a row can sit
+        #  far below the magnitude of its terms: rows within 10^2 of the largest are held to 1e-5 of their own scale)
+        assert_close(got[name], ref, what=f'{g.name}:{phase}:{name}', row_floor=1e-2)
     for name, t in got.items():
         if name not in want:
             assert float(t.abs().max()) == 0.0, f'{name}: product has a gradient the reference does not produce'
@@ -207,8 +209,11 @@ def _lazy_adam_ref(W, G, touched, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-
 @pytest.mark.parametrize('opt', ['sgd', 'adam'])
 @pytest.mark.parametrize('D,k', [(64, 1), (128, 4), (16, 2)])
 def test_fused_step_vs_oracle(opt, D, k):
-    """Three consecutive fused steps == oracle autograd gradients + (SGD | lazy Adam), heavy id duplication included."""
-    from oracle import losses
+    """Three consecutive fused steps, FREE-RUNNING (the reference state is never re-synchronised to the device result), == the oracle's
+    row-wise step (autograd gradients + SGD | lazy Adam), heavy id duplication included: the loss of every step at 1e-5, the moments
+    at 1e-5 after the FIRST step, then within the drift bound (SGD: 1e-5 relative; Adam: 1e-2 of ONE update, lr -- the
+    quotient m / (sqrt(v) + eps) is ill-conditioned for the few elements whose gradient is within a few eps of zero)."""
+    from oracle import train_step as ts
     from recbole_cdr_amd.fused import FusedBPRStep
     torch.manual_seed(D + k)
     nu, ni, S, reg, lr = 50, 40, 97, 0.03, 0.05
@@ -216,36 +221,25 @@ def test_fused_step_vs_oracle(opt, D, k):
     I = torch.randn(ni, D) * 0.3
     Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
     fs = FusedBPRStep(Ud, Id, max_batch=S * k, opt=opt, lr=lr, reg_weight=reg)
-    mU, vU, mI, vI = (torch.zeros_like(x) for x in (U, U, I, I))
+    su, si = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
     for step in range(1, 4):
         u = torch.randint(0, nu, (S,)).repeat(k); p = torch.randint(0, ni, (S,)).repeat(k); n = torch.randint(0, ni, (S * k,))
-        Ur, Ir = U.clone().requires_grad_(True), I.clone().requires_grad_(True)
-        ref = losses.bpr_loss((Ur[u] * Ir[p]).sum(1), (Ur[u] * Ir[n]).sum(1)) + reg * losses.emb_loss(Ur[u], Ir[p])
-        ref.sum().backward()
+        ref = ts.rowwise_step(U, I, su, si, u, p, n, step, opt=opt, lr=lr, reg_weight=reg)
         out = fs.step(u.to(DEV), p.to(DEV), n.to(DEV))
         assert_close(out[0], ref, what=f'loss step {step}')
-        tu, ti = torch.unique(u), torch.unique(torch.cat([p, n]))
-        if opt == 'sgd':
-            U[tu] -= lr * Ur.grad[tu]; I[ti] -= lr * Ir.grad[ti]
-        else:
-            _lazy_adam_ref(U, Ur.grad, tu, mU, vU, step, lr=lr); _lazy_adam_ref(I, Ir.grad, ti, mI, vI, step, lr=lr)
-        if opt == 'adam':
-            # m / (sqrt(v) + eps) is ill-conditioned where |g| ~ eps (the first step is ~ lr * sign(g)), so the weights
-            # get an absolute bound of 1% of one update; the moments, which are well-conditioned, carry the 1e-5 check.
-            assert_close(fs.ustate.exp_avg, mU, rtol=2e-5, what=f'exp_avg U step {step}')
-            assert_close(fs.istate.exp_avg, mI, rtol=2e-5, what=f'exp_avg I step {step}')
-            assert_close(fs.ustate.exp_avg_sq, vU, rtol=4e-5, what=f'exp_avg_sq U step {step}')
-            assert_close(Ud, U, rtol=2e-5, atol=lr * 1e-2, what=f'U after step {step}')
-            assert_close(Id, I, rtol=2e-5, atol=lr * 1e-2, what=f'I after step {step}')
-            # continue from identical states so that conditioning noise does not compound across steps
-            U.copy_(Ud.cpu()); I.copy_(Id.cpu())
-            mU.copy_(fs.ustate.exp_avg.cpu()); vU.copy_(fs.ustate.exp_avg_sq.cpu())
-            mI.copy_(fs.istate.exp_avg.cpu()); vI.copy_(fs.istate.exp_avg_sq.cpu())
-        else:
-            assert_close(Ud, U, rtol=2e-5, what=f'U after step {step}')
-            assert_close(Id, I, rtol=2e-5, what=f'I after step {step}')
-
-
+        if opt == 'adam' and step == 1:
+            # from identical states the moments (= the summed gradients) agree at 1e-5; item rows add signed occurrences (row_floor)
+            assert_close(fs.ustate.exp_avg, su.m, what='exp_avg U, step 1'); assert_close(fs.istate.exp_avg, si.m, what='exp_avg I, step 1', row_floor=1e-2)
+            assert_close(fs.ustate.exp_avg_sq, su.v, what='exp_avg_sq U, step 1'); assert_close(fs.istate.exp_avg_sq, si.v, what='exp_avg_sq I, step 1')
+    if opt == 'adam':
+        # after three free steps the few ill-conditioned weight elements (|g| within a few eps of 0: their first update is ~ +-lr
+        # whatever the rounding) have fed back into the later gradients: the drift is bounded, not 1e-5
+        for got, want, what in ((fs.ustate.exp_avg, su.m, 'exp_avg U'), (fs.istate.exp_avg, si.m, 'exp_avg I'),
+                                (fs.ustate.exp_avg_sq, su.v, 'exp_avg_sq U'), (fs.istate.exp_avg_sq, si.v, 'exp_avg_sq I')):
+            assert_close(got, want, rtol=1e-5, atol=2e-4 * float(want.abs().max()), what=what + ' after 3 free steps')
+        assert_close(Ud, U, rtol=1e-5, atol=lr * 1e-2, what='U after 3 steps'); assert_close(Id, I, rtol=1e-5, atol=lr * 1e-2, what='I after 3 steps')
+    else:
+        assert_close(Ud, U, what='U after 3 steps'); assert_close(Id, I, what='I after 3 steps')
 
 
 @pytest.mark.parametrize('dims,opt,OB', [((64, 64), 'adam', 100), ((128, 128), 'adam', 1000), ((32, 48, 16), 'adam', 100),

@@ -10,14 +10,20 @@ from recbole_cdr_amd.utils import CrossDomainDataLoaderState, InputType, train_m
 from golden_util import Golden, cases
 
 
+# The integer paths (a11 overlap remap, a13 batch layout) are host code, but the driver's round-end record is the `-m gpu` session on
+# the GPU box: these tests run in BOTH sessions (one unmarked instance, one gpu-marked instance) so that the record covers them.
+both_sessions = pytest.mark.parametrize('session', ['host', pytest.param('gpu_box', marks=pytest.mark.gpu)])
+
+
 def _tokens(g, key):
     toks = [str(t) for t in g[f'in/{key}_tokens']]
     nan = g[f'in/{key}_isnan'] if g.has(f'in/{key}_isnan') else np.zeros(len(toks), bool)
     return [None if m else t for t, m in zip(toks, nan)]
 
 
+@both_sessions
 @pytest.mark.parametrize('name', cases('remap_'))
-def test_native_remap_bit_exact(name):
+def test_native_remap_bit_exact(name, session):
     g = Golden(name)
     su, si, tu, ti = (_tokens(g, k) for k in ('source_user', 'source_item', 'target_user', 'target_item'))
     sfeat = [str(t) for t in g['in/source_user_feat_tokens']] if g.has('in/source_user_feat_tokens') else []
@@ -41,7 +47,8 @@ def test_native_remap_bit_exact(name):
                 assert want[t] == i, (prefix, t)
 
 
-def test_remap_large_random_matches_oracle():
+@both_sessions
+def test_remap_large_random_matches_oracle(session):
     from oracle import remap as oremap
     rng = np.random.RandomState(1)
     s = [f'tok{n}' for n in rng.randint(0, 50000, 200000)]
@@ -60,7 +67,8 @@ def _loader(name, n_batches, bs):
                              InputType.PAIRWISE, sampler)
 
 
-def test_four_state_loader_matches_reference_trace():
+@both_sessions
+def test_four_state_loader_matches_reference_trace(session):
     g = Golden('revoke_layout')
     dl = CrossDomainDataloader(_loader('source', 2, 3), _loader('target', 5, 4), OverlapDataloader(6, 2))
     for state in ('BOTH', 'SOURCE', 'TARGET', 'OVERLAP'):
@@ -88,7 +96,8 @@ def test_four_state_loader_matches_reference_trace():
         dl.set_mode(CrossDomainDataLoaderState.SOURCE)
 
 
-def test_train_loader_layouts():
+@both_sessions
+def test_train_loader_layouts(session):
     """k-major negatives; POINTWISE = repeat(1+k) with labels [1]*S + [0]*(S k)  (SURVEY App. A)."""
     inter = {'source_user_id': torch.tensor([5, 6, 7]), 'source_item_id': torch.tensor([10, 11, 12])}
     sampler = lambda u, i, k: torch.arange(100, 100 + u.numel() * k)
