@@ -180,24 +180,36 @@ class FullSortEvalLoader:
         # uses it (Trainer.evaluate does) may ask for a throughput-sized batch instead: 1,024 users per call score 36 times
         # more users per second than one at a time.
         self.step = int(users_per_batch) if users_per_batch else max(eval_batch_size // item_num, 1)
-        ev = np.unique(np.asarray(eval_pairs, dtype=np.int64), axis=0)                 # sorted by (user, item)
-        hi = np.unique(np.asarray(history_pairs, dtype=np.int64), axis=0) if len(history_pairs) else np.zeros((0, 2), np.int64)
-        self.users = np.unique(ev[:, 0])
+        # Built where it will live (recbole's history / positive matrices are host numpy; np.unique(axis=0) over 12 M
+        # pairs took seconds): de-duplication and the (user, item) order are ONE device sort of integer keys per list.
+        as_dev = lambda pairs: (torch.as_tensor(np.asarray(pairs, dtype=np.int64) if not torch.is_tensor(pairs) else pairs).to(device)
+                                .reshape(-1, 2))
+        ev_t, hi_t = as_dev(eval_pairs), as_dev(history_pairs) if len(history_pairs) else torch.zeros(0, 2, dtype=torch.int64, device=device)
+        mul = int(max(int(ev_t[:, 1].max()) if ev_t.numel() else 0, int(hi_t[:, 1].max()) if hi_t.numel() else 0)) + 1
+        ev_key = torch.unique(ev_t[:, 0] * mul + ev_t[:, 1])                              # sorted by (user, item), duplicates dropped
+        ev_u, ev_i = ev_key // mul, ev_key % mul
+        users_t = torch.unique(ev_u)
+        hi_key = torch.unique(hi_t[:, 0] * mul + hi_t[:, 1]) if hi_t.numel() else hi_t.new_zeros(0)
+        hi_u, hi_i = hi_key // mul, hi_key % mul
         # both pair lists are sorted by user, the batches are runs of consecutive evaluated users: every batch owns ONE
         # contiguous slice of each list (O(batch) per batch; masking all pairs per batch was quadratic in the eval set)
-        hi = hi[np.isin(hi[:, 0], self.users)] if len(hi) else hi
-        starts = self.users[::self.step]
-        self._ev_ptr = np.append(np.searchsorted(ev[:, 0], starts, side='left'), len(ev))
-        self._hi_ptr = np.append(np.searchsorted(hi[:, 0], starts, side='left'), len(hi))
-        rank = np.searchsorted(self.users, ev[:, 0])                                   # position of each pair's user among the evaluated users
-        hrank = np.searchsorted(self.users, hi[:, 0]) if len(hi) else np.zeros(0, np.int64)
-        self._ev = (torch.from_numpy(rank % self.step).to(device), torch.from_numpy(ev[:, 1].copy()).to(device))
-        self._hi = (torch.from_numpy(hrank % self.step).to(device), torch.from_numpy(hi[:, 1].copy()).to(device))
+        if hi_u.numel():
+            pos = torch.searchsorted(users_t, hi_u).clamp_(max=users_t.numel() - 1)
+            keep = users_t[pos] == hi_u                                                    # history of evaluated users only
+            hi_u, hi_i = hi_u[keep], hi_i[keep]
+        starts = users_t[::self.step]
+        self.users = users_t.cpu().numpy()
+        self._ev_ptr = np.append(torch.searchsorted(ev_u, starts, right=False).cpu().numpy(), ev_u.numel())
+        self._hi_ptr = np.append(torch.searchsorted(hi_u, starts, right=False).cpu().numpy(), hi_u.numel())
+        rank = torch.searchsorted(users_t, ev_u)                                           # position of each pair's user among the evaluated users
+        hrank = torch.searchsorted(users_t, hi_u) if hi_u.numel() else hi_u
+        self._ev = (rank % self.step, ev_i.contiguous())
+        self._hi = (hrank % self.step, hi_i.contiguous())
         if revoke is not None:
             from .remap import revoke_map
             self._ev = (self._ev[0], revoke_map(self._ev[1], *revoke))
             self._hi = (self._hi[0], revoke_map(self._hi[1], *revoke) if self._hi[1].numel() else self._hi[1])
-        self._users_t = torch.from_numpy(self.users.copy()).to(device)
+        self._users_t = users_t
 
     def __len__(self):
         return (len(self.users) + self.step - 1) // self.step

@@ -22,20 +22,23 @@ from ..crossdomain_recommender import CrossDomainRecommender, xavier_normal_init
 
 
 def _csr_norm_adj(pairs, n_users, n_items, device):
-    pairs = np.unique(np.asarray(pairs, dtype=np.int64), axis=0)
-    u, i = pairs[:, 0], pairs[:, 1] + n_users
-    row = np.concatenate([u, i])
-    col = np.concatenate([i, u])
+    """D^-1/2 A D^-1/2 of the bipartite graph as a device CSR, BUILT ON THE DEVICE (bitgcf.py:92-116 goes through a scipy DOK
+    matrix on the host): de-duplication and the (row, column) ordering are device sorts of integer keys, degrees a
+    device bincount.  The values stay bit-identical to the reference's: the n degree^-1/2 factors are formed in float64 with the
+    host's libm (np.power, as the reference does; n numbers), the per-edge product ((d_i^-1/2 * 1.0) * d_j^-1/2) is an IEEE
+    float64 multiply on the device, rounded to fp32 once -- golden-pinned in tests/test_oracle_golden.py / test_gpu_parity.py."""
+    p = torch.as_tensor(np.asarray(pairs, dtype=np.int64) if not torch.is_tensor(pairs) else pairs).to(device)
     n = n_users + n_items
-    deg = np.bincount(row, minlength=n).astype(np.float64) + 1e-7
-    dinv = np.power(deg, -0.5)
-    val = ((dinv[row] * np.float64(1.0)) * dinv[col]).astype(np.float32)
-    order = np.lexsort((col, row))
-    row, col, val = row[order], col[order], val[order]
-    indptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(np.bincount(row, minlength=n), out=indptr[1:])
-    return F_.CSRGraph(torch.from_numpy(indptr).to(device), torch.from_numpy(col.copy()).to(device),
-                       torch.from_numpy(val.copy()).to(device), n)
+    key = torch.unique(p[:, 0] * n_items + p[:, 1])                       # distinct (user, item) edges, sorted
+    u, i = key // n_items, key % n_items + n_users
+    row, col = torch.cat([u, i]), torch.cat([i, u])
+    deg = torch.bincount(row, minlength=n)
+    dinv = torch.from_numpy(np.power(deg.cpu().numpy().astype(np.float64) + 1e-7, -0.5)).to(device)
+    val = ((dinv[row] * 1.0) * dinv[col]).to(torch.float32)
+    order = torch.argsort(row * n + col)                                  # CSR order: by row, columns ascending
+    indptr = torch.zeros(n + 1, device=device, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(deg, 0)
+    return F_.CSRGraph(indptr, col[order].contiguous(), val[order].contiguous(), n)
 
 
 class BiTGCF(CrossDomainRecommender):
