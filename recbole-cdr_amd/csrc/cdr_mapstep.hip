@@ -88,14 +88,15 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                                                        map_params bump) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float rowok[kRows];
+    __shared__ int64_t rowid[kRows];
     __shared__ double red[4];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
     const int L = net.L, Ds = net.dims[0], Dt = net.dims[L];
     const bool vec = net.vec != 0;
     float* X = smem + net.buf_off[0];
     float* GX = smem + gx_off;
-    float* Tb = smem + t_off;
     const int XS = Ds + 4, TS = Dt + 4;
+    (void)t_off;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (blockIdx.x == 0 && t == 0) {                          // the mapping parameters' update counts: read by launch 2 only
         for (int l = 0; l < L; ++l) { if (bump.sW[l]) bump.sW[l][0] += 1; if (bump.sb[l]) bump.sb[l][0] += 1; }
@@ -117,8 +118,10 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
             const bool valid = g < n;
             const int64_t id = idx[valid ? g : n - 1];
             for (int c = c0; c < (Ds >> 2); c += 8) st4(X + row * XS + 4 * c, ld4(S + id * Ds + 4 * c));
-            for (int c = c0; c < (Dt >> 2); c += 8) st4(Tb + row * TS + 4 * c, ld4(T + id * Dt + 4 * c));
-            if (c0 == 0) rowok[row] = valid ? 1.f : 0.f;
+            // (the target rows are NOT staged: the last layer's epilogue and the apply read them straight from the table -- three
+            //  16.9-KB buffers instead of four let THREE workgroups share a CU, and resident workgroups are what hides the ~20-us
+            //  latency of a block's random-row traffic)
+            if (c0 == 0) { rowok[row] = valid ? 1.f : 0.f; rowid[row] = id; }
         }
         lds_barrier();
         // ---- touch the NEXT block's rows and moments (one 4-byte load per 128-B line, value unused): a gather of 32 random rows
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                         float v = am[r] + bv;
                         if (net.act[l] == CDR_ACT_TANH) v = tanhf(v);
                         if (last) {
-                            const float d = rowok[row] != 0.f ? v - Tb[row * TS + ncol] : 0.f;      // nn.MSELoss (emcdr.py:81,162)
+                            const float d = rowok[row] != 0.f ? v - T[rowid[row] * Dt + ncol] : 0.f;   // nn.MSELoss (emcdr.py:81,162)
                             lsum += (double)d * (double)d;
                             v = gscale * d;
                         }
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                 }
                 for (int c = c0; c < (Dt >> 2); c += 8) {
                     const int64_t o = id * Dt + 4 * c;
-                    const float4 w = ld4(Tb + row * TS + 4 * c), gn = ld4(gm + row * TS + 4 * c);      // dL/dT[id] = -dL/d mapped
+                    const float4 w = ld4(T + o), gn = ld4(gm + row * TS + 4 * c);                      // dL/dT[id] = -dL/d mapped
                     float4 m = z4, v = z4;
                     if (opt.opt) { m = ld4(mT + o); v = ld4(vT + o); }
                     float4 wn;
@@ -315,15 +318,18 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
     if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void map_finish_kernel(map_net net, map_opt opt, map_params P, const float* __restrict__ wpart,
+__global__ __launch_bounds__(1024) void map_finish_kernel(map_net net, map_opt opt, map_params P, const float* __restrict__ wpart,
                                                          const double* __restrict__ lpart, int nwg, int64_t n, float* __restrict__ loss_out,
                                                          int64_t* step_s, int64_t* step_t) {
     const size_t pstride = (size_t)net.ntiles * 1024 + net.nbias;
     if (blockIdx.x == gridDim.x - 1) {                          // last block: the loss (workgroup order) and the tables' counters
         __shared__ double red[4];
         double s[1] = {0.0};
-        for (int b = threadIdx.x; b < nwg; b += 256) s[0] += lpart[b];
-        block_sum_d<1>(s, red);
+        if (threadIdx.x < 256) for (int b = threadIdx.x; b < nwg; b += 256) s[0] += lpart[b];
+        s[0] = wave_sum_d(s[0]);
+        if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s[0];
+        __syncthreads();
+        if (threadIdx.x == 0) s[0] = (red[0] + red[1]) + (red[2] + red[3]);
         if (threadIdx.x == 0) {
             loss_out[0] = (float)(s[0] / ((double)n * (double)net.dims[net.L]));
             if (step_s) step_s[0] += 1;
@@ -331,8 +337,12 @@ __global__ __launch_bounds__(256) void map_finish_kernel(map_net net, map_opt op
         }
         return;
     }
-    // one thread per mapping parameter element: gradient = sum of the workgroup partials in workgroup order, then dense Adam
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // 64 parameter elements per block x SIXTEEN partial sums each: thread (sub, el) adds the partials of workgroups sub, sub + 16,
+    // ... (coalesced across el, independent across sub), then the sixteen sums are added in order through LDS -- deterministic, and
+    // 16x shorter than one thread walking every workgroup's partial
+    __shared__ float part[16][64];
+    const int sub = threadIdx.x >> 6, el = threadIdx.x & 63;
+    int64_t e = (int64_t)blockIdx.x * 64 + el;
     int l = 0, isb = 0;
     int64_t base = 0;
     bool found = false;
@@ -344,28 +354,29 @@ __global__ __launch_bounds__(256) void map_finish_kernel(map_net net, map_opt op
         if (e < base + nb) { l = q; isb = 1; e -= base; found = true; break; }
         base += nb;
     }
-    if (!found) return;
     const int din = net.dims[l], dout = net.dims[l + 1];
-    size_t off;
-    if (!isb) {
-        const int m = (int)(e / din), nn = (int)(e - (int64_t)m * din);
-        const int NTW = (din + 31) >> 5;
-        const int tile = net.tile_off[l] + (m >> 5) * NTW + (nn >> 5);
-        const int mm = m & 31, h = (mm >> 2) & 1, r = (mm & 3) + 4 * (mm >> 3);
-        off = (size_t)tile * 1024 + r * 64 + (nn & 31) + 32 * h;
-    } else {
-        off = (size_t)net.ntiles * 1024 + net.bias_off[l] + e;
+    size_t off = 0;
+    if (found) {
+        if (!isb) {
+            const int m = (int)(e / din), nn = (int)(e - (int64_t)m * din);
+            const int NTW = (din + 31) >> 5;
+            const int tile = net.tile_off[l] + (m >> 5) * NTW + (nn >> 5);
+            const int mm = m & 31, h = (mm >> 2) & 1, r = (mm & 3) + 4 * (mm >> 3);
+            off = (size_t)tile * 1024 + r * 64 + (nn & 31) + 32 * h;
+        } else {
+            off = (size_t)net.ntiles * 1024 + net.bias_off[l] + e;
+        }
     }
     float g = 0.f;
-    int b = 0;
-    for (; b + 8 <= nwg; b += 8) {
-        float v[8];
+    if (found)
+        for (int b = sub; b < nwg; b += 16) g += wpart[(size_t)b * pstride + off];
+    part[sub][el] = g;
+    __syncthreads();
+    if (!found || sub != 0) return;
+    g = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = wpart[(size_t)(b + j) * pstride + off];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g += v[j];
-    }
-    for (; b < nwg; ++b) g += wpart[(size_t)b * pstride + off];
+    for (int j = 0; j < 16; ++j) g += part[j][el];
+    (void)dout;
     float* p = isb ? P.b[l] : P.W[l];
     float* mp = isb ? P.mb[l] : P.mW[l];
     float* vp = isb ? P.vb[l] : P.vW[l];
@@ -400,14 +411,14 @@ int fill(map_net& net, int L, const int* dims, const int* acts, const float* con
     if (tiles > 4 * kSlots || nb > 512) return 0;
     for (int l = 0; l <= L; ++l) { net.buf_off[l] = off; off += kRows * (dims[l] + 4); }     // X, hidden activations, mapped / gz
     *gx_off = off; off += kRows * (dims[0] + 4);
-    *t_off = off; off += kRows * (dims[L] + 4);
+    *t_off = off;                                             // (no staging buffer for the target rows)
     *lds_bytes = (size_t)off * sizeof(float);
     return *lds_bytes <= 150 * 1024;
 }
 
-inline int wg_count(int64_t n) {
+inline int wg_count(int64_t n, int per_cu = 2) {
     int64_t g = (n + kRows - 1) / kRows;
-    if (g > 2 * CDR_NUM_CU) g = 2 * CDR_NUM_CU;
+    if (g > (int64_t)per_cu * CDR_NUM_CU) g = (int64_t)per_cu * CDR_NUM_CU;     // resident workgroups: each one walks several 32-id blocks
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -448,7 +459,7 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
             if (P.b[l]) { CDR_CHECK_ARG(mb && vb && step_b && mb[l] && vb[l] && step_b[l]); P.mb[l] = mb[l]; P.vb[l] = vb[l]; P.sb[l] = step_b[l]; }
         }
     }
-    const int nwg = wg_count(n);
+    const int nwg = wg_count(n, 2);        // (three resident workgroups per CU measured no faster and add a third more partials)
     const size_t wbytes = (size_t)nwg * ((size_t)net.ntiles * 1024 + net.nbias) * sizeof(float);
     const size_t woff = (wbytes + 255) & ~(size_t)255;
     CDR_CHECK_ARG(workspace_bytes >= woff + (size_t)nwg * sizeof(double));
@@ -472,7 +483,7 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
     CDR_LAUNCH_CHECK();
     int64_t elems = 0;
     for (int l = 0; l < L; ++l) elems += (int64_t)dims[l] * dims[l + 1] + (net.b[l] ? dims[l + 1] : 0);
-    map_finish_kernel<<<dim3((unsigned)((elems + 255) / 256 + 1)), dim3(256), 0, s>>>(net, mo, P, wpart, lpart, nwg, n, loss_out,
+    map_finish_kernel<<<dim3((unsigned)((elems + 63) / 64 + 1)), dim3(1024), 0, s>>>(net, mo, P, wpart, lpart, nwg, n, loss_out,
                                                                                       opt == 1 ? step_src_dev : nullptr,
                                                                                       opt == 1 ? step_tgt_dev : nullptr);
     CDR_LAUNCH_CHECK();
