@@ -124,25 +124,11 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
             if (c0 == 0) { rowok[row] = valid ? 1.f : 0.f; rowid[row] = id; }
         }
         lds_barrier();
-        // ---- touch the NEXT block's rows and moments (one 4-byte load per 128-B line, value unused): a gather of 32 random rows
-        // x 6 arrays over 25-GB tables costs up to ~20 us of TLB walks + HBM latency from one workgroup (measured with
-        // wall_clock64 stamps); started here it runs under this block's MFMA phases.  Tried and dropped: holding the moments in
-        // registers from gather to apply (37 spills, slower), and issuing all 16 moment loads of the apply at once (the TLB
-        // walks of 192 pages then serialise: 17-23 us against 12 us for the chunk-by-chunk loop).
-        float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
-        {
-            const int64_t gn = (rb + gridDim.x) * kRows + (t >> 3);
-            if (gn < n) {
-                const int64_t idn = idx[gn];
-                const int c0 = t & 7, side = c0 >> 2, line = c0 & 3;
-                const int Dd = side ? Dt : Ds;
-                const float* w = side ? T : S; const float* m = side ? mT : mS; const float* v = side ? vT : vS;
-                for (int ln = line; ln * 32 < Dd; ln += 4) {
-                    pf0 += w[idn * Dd + ln * 32];
-                    if (opt.opt) { pf1 += m[idn * Dd + ln * 32]; pf2 += v[idn * Dd + ln * 32]; }
-                }
-            }
-        }
+        // (Tried and dropped, each measured with wall_clock64 stamps and at OB = 65,536: touching the next block's rows and moments
+        //  one 4-byte load per line ahead of time -- the unloaded gather falls from 20 to 4 us but under load the touched lines are
+        //  evicted again and HBM traffic grows 1.5x for no gain; holding the moments in registers from gather to apply -- 37 spills,
+        //  slower; issuing all 16 moment loads of the apply at once -- 17-23 us against 12 for the chunk-by-chunk loop; three
+        //  resident workgroups per CU -- no faster, a third more partials.)
         // ---- forward through the mapping (emcdr.py:86-93); the last layer's epilogue leaves gz = dL/d mapped in its buffer
         for (int l = 0; l < L; ++l) {
             const int din = net.dims[l], dout = net.dims[l + 1];
@@ -296,7 +282,6 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                 }
             }
         }
-        asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2));          // keeps the touch loads alive; they have long landed
         lds_barrier();
     }
     // ---- this workgroup's partials: weight-gradient tiles (accumulator order), bias sums, loss
