@@ -21,7 +21,8 @@ header for which symbols carry arithmetic and the resulting parity caveat).
 Reference entry points exercised (file:line under /root/reference/recbole_cdr):
   model/cross_domain_recommender/emcdr.py:110-233, cmf.py:75-112,
   conet.py:105-242, sscdr.py:89-259, bitgcf.py:92-282,
-  data/dataset.py:344-445, data/dataloader.py:114-162,240-247.
+  clfm.py:74-145, dtcdr.py:112-211, deepapf.py:69-175, natr.py:75-191, dcdcsr.py:90-280,
+  data/dataset.py:151-249 (get_history_matrix, called unbound), :344-445, data/dataloader.py:114-162,240-247.
 """
 import os
 import sys
@@ -44,7 +45,12 @@ from recbole_cdr.model.cross_domain_recommender.cmf import CMF  # noqa: E402
 from recbole_cdr.model.cross_domain_recommender.conet import CoNet  # noqa: E402
 from recbole_cdr.model.cross_domain_recommender.sscdr import SSCDR  # noqa: E402
 from recbole_cdr.model.cross_domain_recommender.bitgcf import BiTGCF  # noqa: E402
-from recbole_cdr.data.dataset import CrossDomainDataset  # noqa: E402
+from recbole_cdr.model.cross_domain_recommender.clfm import CLFM  # noqa: E402
+from recbole_cdr.model.cross_domain_recommender.dtcdr import DTCDR  # noqa: E402
+from recbole_cdr.model.cross_domain_recommender.deepapf import DeepAPF  # noqa: E402
+from recbole_cdr.model.cross_domain_recommender.natr import NATR  # noqa: E402
+from recbole_cdr.model.cross_domain_recommender.dcdcsr import DCDCSR  # noqa: E402
+from recbole_cdr.data.dataset import CrossDomainDataset, CrossDomainSingleDataset  # noqa: E402
 from recbole_cdr.data.dataloader import CrossDomainDataloader, CrossDomainFullSortEvalDataLoader  # noqa: E402
 from recbole_cdr.utils import CrossDomainDataLoaderState  # noqa: E402
 
@@ -100,6 +106,29 @@ class _Dataset:
 
     def meta(self):
         return dict(OU=self.OU, TOU=self.TOU, SOU=self.SOU, OI=self.OI, TOI=self.TOI, SOI=self.SOI)
+
+    # -- history matrices: the REFERENCE's get_history_matrix (dataset.py:200-249) run unbound on a duck-typed single dataset,
+    #    sized by the union id space as CrossDomainDataset.history_{user,item}_matrix do (dataset.py:596-654)
+    def _history(self, domain, row):
+        class _Feat(dict):
+            def __len__(self):
+                return len(next(iter(self.values())))
+
+        class _S:
+            pass
+        d = self.source_domain_dataset if domain == 'source' else self.target_domain_dataset
+        s = _S()
+        s.uid_field, s.iid_field = d.uid_field, d.iid_field
+        s.inter_feat = _Feat(d.inter_feat)
+        s._check_field = lambda *a: None
+        s.logger = type('L', (), {'warning': staticmethod(lambda *a, **k: None)})()
+        return CrossDomainSingleDataset.get_history_matrix(s, self.num_total_user, self.num_total_item, row=row)
+
+    def history_item_matrix(self, value_field=None, domain='source'):
+        return self._history(domain, 'user')
+
+    def history_user_matrix(self, value_field=None, domain='source'):
+        return self._history(domain, 'item')
 
 
 def users_overlap_ds(seed=1):
@@ -414,6 +443,207 @@ def gen_bitgcf():
             dump(f'bitgcf_{mode}_{connect}', out)
 
 
+def _eval_inputs(ds, rng, out, n=4, source=False):
+    eu = np.array([0, 1, 3, ds.OU + ds.TOU - 1], dtype=np.int64)[:n]
+    ei = rng.choice(np.arange(0, ds.OI + ds.TOI), len(eu)).astype(np.int64)
+    ev = {'target_user_id': torch.from_numpy(eu), 'target_item_id': torch.from_numpy(ei)}
+    if source:
+        ev['source_user_id'] = torch.from_numpy(rng.choice(ds.src_users, len(eu)).astype(np.int64))
+        ev['source_item_id'] = torch.from_numpy(rng.choice(ds.src_items, len(eu)).astype(np.int64))
+    for kk, v in ev.items():
+        out[f'evalin/{kk}'] = _np(v)
+    return ev
+
+
+def _randomise_biases(model):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias'):
+                p.normal_(0, 0.1)
+
+
+def gen_clfm():
+    """clfm.py:74-145.  ``target_item_embedding_size`` is read from ``source_item_embedding_size`` (clfm.py:39)."""
+    for tag, mk, share in (('users', users_overlap_ds, 6), ('items', items_overlap_ds, 6), ('users_allshared', users_overlap_ds, 16)):
+        torch.manual_seed(41 + share + len(tag))
+        ds = mk()
+        cfg = base_config(user_embedding_size=12, source_item_embedding_size=16, target_item_embedding_size=16,
+                          share_embedding_size=share, alpha=0.3, reg_weight=0.01)
+        model = CLFM(cfg, ds)
+        rng = np.random.RandomState(17 + share)
+        inter = {}
+        inter.update(pointwise_batch(ds, rng, 10, 1, 'source'))
+        inter.update(pointwise_batch(ds, rng, 9, 2, 'target'))
+        out = {}
+        put_meta(out, ds, model='CLFM', mode=tag.split('_')[0], user_embedding_size=12, item_embedding_size=16,
+                 share_embedding_size=share, alpha=0.3, reg_weight=0.01)
+        put_params(out, model)
+        put_inputs(out, inter)
+        loss_and_grads(model, inter, out, 'BOTH')
+        ev = _eval_inputs(ds, rng, out)
+        with torch.no_grad():
+            out['predict/BOTH'] = _np(model.predict(ev))
+            out['fullsort/BOTH'] = _np(model.full_sort_predict(ev))
+        dump(f'clfm_{tag}', out)
+
+
+def gen_dtcdr():
+    """dtcdr.py:112-126 (neumf_forward), :182-199 (calculate_loss), :201-207 (predict); base_model = NeuMF, dropout_prob = 0
+    (the dropout mask is a torch-RNG stream, not comparable across implementations)."""
+    if not hasattr(np, 'NINF'):          # numpy >= 2 dropped the alias the reference uses (dtcdr.py:55-59). Harness-side shim.
+        np.NINF = -np.inf
+    for mode, mk in (('users', users_overlap_ds), ('items', items_overlap_ds)):
+        torch.manual_seed(61 + len(mode))
+        ds = mk()
+        cfg = base_config(embedding_size=8, mlp_hidden_size=[12, 6], dropout_prob=0.0, base_model='NeuMF', alpha=0.4)
+        model = DTCDR(cfg, ds)
+        _randomise_biases(model)
+        with torch.no_grad():                          # exact ties of torch.maximum (gradient split 1/2 : 1/2)
+            model.target_user_embedding.weight[1, :3] = model.source_user_embedding.weight[1, :3]
+            model.target_item_embedding.weight[1, 2:5] = model.source_item_embedding.weight[1, 2:5]
+        rng = np.random.RandomState(29)
+        inter = {}
+        inter.update(pointwise_batch(ds, rng, 10, 1, 'source'))
+        inter.update(pointwise_batch(ds, rng, 9, 2, 'target'))
+        inter['source_user_id'][4] = 1; inter['source_item_id'][5] = 1 if ds.OI > 1 else inter['source_item_id'][5]
+        inter['target_user_id'][4] = 1; inter['target_item_id'][5] = 1
+        out = {}
+        put_meta(out, ds, model='DTCDR', mode=mode, D=8, mlp_hidden_size=np.array([12, 6]), alpha=0.4, base_model='NeuMF')
+        put_params(out, model)
+        put_inputs(out, inter)
+        model.train()
+        loss_and_grads(model, inter, out, 'BOTH')
+        ev = _eval_inputs(ds, rng, out)
+        model.eval()
+        with torch.no_grad():
+            out['predict/BOTH'] = _np(model.predict(ev))
+        dump(f'dtcdr_{mode}_neumf', out)
+
+
+def gen_deepapf():
+    """deepapf.py:69-152 (source/target_forward, both modes), :160-175 (calculate_loss), :154-158 (predict)."""
+    for mode, mk in (('users', users_overlap_ds), ('items', items_overlap_ds)):
+        torch.manual_seed(83 + len(mode))
+        ds = mk()
+        cfg = base_config(embedding_size=8, beta=0.5)
+        model = DeepAPF(cfg, ds)
+        _randomise_biases(model)
+        rng = np.random.RandomState(31)
+        inter = {}
+        inter.update(pointwise_batch(ds, rng, 10, 1, 'source'))
+        inter.update(pointwise_batch(ds, rng, 9, 2, 'target'))
+        n_ov = ds.OU if mode == 'users' else ds.OI
+        key = 'user_id' if mode == 'users' else 'item_id'
+        inter[f'source_{key}'][5] = n_ov if mode == 'items' else inter[f'source_{key}'][5]   # id == overlapped_num: NOT masked (">" in deepapf.py:75)
+        inter[f'target_{key}'][5] = n_ov
+        inter[f'target_{key}'][6] = n_ov - 1
+        out = {}
+        put_meta(out, ds, model='DeepAPF', mode=mode, D=8)
+        put_params(out, model)
+        put_inputs(out, inter)
+        loss_and_grads(model, inter, out, 'BOTH')
+        with torch.no_grad():
+            out['fwd/source'] = _np(model.source_forward(inter['source_user_id'], inter['source_item_id']))
+            out['fwd/target'] = _np(model.target_forward(inter['target_user_id'], inter['target_item_id']))
+        ev = _eval_inputs(ds, rng, out)
+        with torch.no_grad():
+            out['predict/BOTH'] = _np(model.predict(ev))
+        dump(f'deepapf_{mode}', out)
+
+
+def gen_natr():
+    """natr.py:75-96 (history info), :98-110 (phase 1), :112-156 (phase 2, both modes), :158-175, :177-191 (predict)."""
+    for mode, mk in (('users', users_overlap_ds), ('items', items_overlap_ds)):
+        torch.manual_seed(97 + len(mode))
+        ds = mk()
+        cfg = base_config(source_embedding_size=8, target_embedding_size=12, reg_weight=1e-3, max_inter_length=5)
+        model = NATR(cfg, ds)
+        _randomise_biases(model)
+        rng = np.random.RandomState(37)
+        inter = {}
+        inter.update(pointwise_batch(ds, rng, 10, 1, 'source'))
+        inter.update(pointwise_batch(ds, rng, 9, 2, 'target'))
+        out = {}
+        put_meta(out, ds, model='NATR', mode=mode, Ds=8, Dt=12, reg_weight=1e-3, max_inter_length=5)
+        put_params(out, model)
+        put_inputs(out, inter)
+        out['aux/s_pairs'] = ds.s_pairs.astype(np.int64)
+        out['aux/t_pairs'] = ds.t_pairs.astype(np.int64)
+        hist = model.history_user_matrix if mode == 'users' else model.history_item_matrix
+        out['aux/history_matrix'] = _np(hist)
+        out['aux/history_lens'] = _np(model.history_lens)
+        out['aux/mask_mat'] = _np(model.mask_mat)
+        ev = _eval_inputs(ds, rng, out, source=True)
+        for phase in ('SOURCE', 'TARGET'):            # TARGET freezes the source tables (natr.py:69-73): keep this order
+            model.set_phase(phase)
+            loss_and_grads(model, inter, out, phase)
+            with torch.no_grad():
+                out[f'predict/{phase}'] = _np(model.predict(ev))
+        dump(f'natr_{mode}', out)
+
+
+class _DenseDataset(_Dataset):
+    """Every id of either domain interacts at least once (DCDCSR divides by popularity sums: dcdcsr.py:117-133)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        rng = np.random.RandomState(1234)
+        s_extra = [np.stack([self.src_users, rng.choice(self.src_items, len(self.src_users))], 1),
+                   np.stack([rng.choice(self.src_users, len(self.src_items)), self.src_items], 1)]
+        t_extra = [np.stack([self.tgt_users, rng.choice(self.tgt_items, len(self.tgt_users))], 1),
+                   np.stack([rng.choice(self.tgt_users, len(self.tgt_items)), self.tgt_items], 1)]
+        self.s_pairs = np.unique(np.concatenate([self.s_pairs] + s_extra), axis=0)
+        self.t_pairs = np.unique(np.concatenate([self.t_pairs] + t_extra), axis=0)
+        rng.shuffle(self.s_pairs); rng.shuffle(self.t_pairs)          # history order = order of appearance
+        self.source_domain_dataset.inter_feat = {'source_user_id': torch.from_numpy(self.s_pairs[:, 0].copy()),
+                                                 'source_item_id': torch.from_numpy(self.s_pairs[:, 1].copy())}
+        self.target_domain_dataset.inter_feat = {'target_user_id': torch.from_numpy(self.t_pairs[:, 0].copy()),
+                                                 'target_item_id': torch.from_numpy(self.t_pairs[:, 1].copy())}
+
+
+def gen_dcdcsr():
+    """dcdcsr.py:90-110 (set_phase), :112-127 (BPR), :129-165 (benchmark), :168-192 (map loss), :194-280."""
+    for mode, args in (('users', dict(OU=12, TOU=10, SOU=14, OI=1, TOI=20, SOI=24, seed=1)),
+                       ('items', dict(OU=1, TOU=15, SOU=18, OI=10, TOI=12, SOI=13, seed=2))):
+        torch.manual_seed(113 + len(mode))
+        ds = _DenseDataset(**args)
+        cfg = base_config(latent_factor_model='BPR', embedding_size=8, mlp_hidden_size=[12], k=3, map_batch_size=9)
+        model = DCDCSR(cfg, ds)
+        _randomise_biases(model)
+        rng = np.random.RandomState(41)
+        inter = {}
+        inter.update(pairwise_batch(ds, rng, 10, 2, 'source'))
+        inter.update(pairwise_batch(ds, rng, 11, 2, 'target'))
+        out = {}
+        put_meta(out, ds, model='DCDCSR', mode=mode, D=8, mlp_hidden_size=np.array([12]), k=3, map_batch_size=9)
+        put_params(out, model)
+        put_inputs(out, inter)
+        out['aux/s_pairs'] = ds.s_pairs.astype(np.int64)
+        out['aux/t_pairs'] = ds.t_pairs.astype(np.int64)
+        unit = 'user' if mode == 'users' else 'item'
+        out['aux/source_pop'] = _np(getattr(model, f'source_{unit}2pop'))
+        out['aux/target_pop'] = _np(getattr(model, f'target_{unit}2pop'))
+        ev = _eval_inputs(ds, rng, out, source=True)
+
+        def evals(tag):
+            with torch.no_grad():
+                out[f'predict/{tag}'] = _np(model.predict(ev))
+                out[f'fullsort/{tag}'] = _np(model.full_sort_predict(ev))
+        model.set_phase('SOURCE'); loss_and_grads(model, inter, out, 'SOURCE'); evals('SOURCE')
+        model.set_phase('TARGET'); loss_and_grads(model, inter, out, 'TARGET'); evals('TARGET')
+        model.set_phase('BOTH')
+        out['fwd/benchmark_embedding'] = _np(model.benchmark_embedding)
+        n_units = ds.OU + ds.TOU if mode == 'users' else ds.OI + ds.TOI
+        np.random.seed(77)
+        out['aux/sampled_index'] = np.random.randint(0, n_units, 9).astype(np.int64)
+        np.random.seed(77)
+        loss_and_grads(model, inter, out, 'BOTH')
+        model.set_phase('TARGET')
+        out['fwd/affine_embedding'] = _np(model.affine_embedding)
+        loss_and_grads(model, inter, out, 'TARGET2'); evals('TARGET2')
+        dump(f'dcdcsr_{mode}', out)
+
+
 # ----------------------------------------------------------------------------------------------
 def gen_remap():
     """dataset.py:344-445 on raw string tokens, called unbound on a duck-typed object."""
@@ -572,5 +802,10 @@ if __name__ == '__main__':
     gen_conet()
     gen_sscdr()
     gen_bitgcf()
+    gen_clfm()
+    gen_dtcdr()
+    gen_deepapf()
+    gen_natr()
+    gen_dcdcsr()
     gen_remap()
     gen_revoke_and_layout()

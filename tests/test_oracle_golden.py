@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from oracle import emcdr, cmf, conet, sscdr, bitgcf, remap
+from oracle import emcdr, cmf, conet, sscdr, bitgcf, remap, clfm, dtcdr, deepapf, natr, dcdcsr, history
 from golden_util import Golden, cases
 
 RTOL, ATOL = 1e-6, 1e-7
@@ -192,3 +192,117 @@ def test_revoke_map_and_layout():
     users, items = remap.source_id_lists(12, 10, 14, 1, 20, 24)
     assert users[0] == 1 and users[10] == 11 and users[11] == 22 and len(users) == 11 + 14
     assert items[0] == 21 and len(items) == 24
+
+
+# ---------------------------------------------------------------------------------------------- the five remaining models
+@pytest.mark.parametrize('name', cases('clfm_'))
+def test_clfm(name):
+    g = Golden(name)
+    ids = g.idspace()
+    params = g.group('param', requires_grad=True)
+    inter = g.group('in')
+    loss = clfm.calculate_loss(params, ids, inter, float(g.meta('alpha')), float(g.meta('reg_weight')))
+    close(loss, g['loss/BOTH'])
+    loss.sum().backward()
+    check_grads(params, g, 'BOTH')
+    ev = g.group('evalin')
+    with torch.no_grad():
+        close(clfm.predict(params, ids, ev), g['predict/BOTH'])
+        close(clfm.full_sort_predict(params, ids, ev), g['fullsort/BOTH'])
+
+
+@pytest.mark.parametrize('name', cases('dtcdr_'))
+def test_dtcdr(name):
+    g = Golden(name)
+    ids = g.idspace()
+    params = g.group('param', requires_grad=True)
+    loss = dtcdr.calculate_loss(params, ids, g.group('in'), float(g.meta('alpha')))
+    close(loss, g['loss/BOTH'])
+    loss.backward()
+    check_grads(params, g, 'BOTH')
+    with torch.no_grad():
+        close(dtcdr.predict(params, ids, g.group('evalin')), g['predict/BOTH'])
+
+
+@pytest.mark.parametrize('name', cases('deepapf_'))
+def test_deepapf(name):
+    g = Golden(name)
+    ids = g.idspace()
+    params = g.group('param', requires_grad=True)
+    inter = g.group('in')
+    loss = deepapf.calculate_loss(params, ids, inter)
+    close(loss, g['loss/BOTH'])
+    loss.backward()
+    check_grads(params, g, 'BOTH')
+    with torch.no_grad():
+        close(deepapf.forward(params, ids, inter['source_user_id'], inter['source_item_id'], 'source'), g['fwd/source'])
+        close(deepapf.forward(params, ids, inter['target_user_id'], inter['target_item_id'], 'target'), g['fwd/target'])
+        close(deepapf.predict(params, ids, g.group('evalin')), g['predict/BOTH'])
+
+
+@pytest.mark.parametrize('name', cases('natr_'))
+def test_natr(name):
+    g = Golden(name)
+    ids = g.idspace()
+    params = g.group('param', requires_grad=True)
+    inter = g.group('in')
+    hist = natr.history_info(ids, g['aux/t_pairs'], int(g.meta('max_inter_length')))
+    np.testing.assert_array_equal(hist[0].numpy(), g['aux/history_matrix'])            # dataset.py:181-249, bit-exact
+    np.testing.assert_array_equal(hist[1].numpy(), g['aux/history_lens'])
+    np.testing.assert_array_equal(hist[2].numpy(), g['aux/mask_mat'])
+    ev = g.group('evalin')
+    for phase in ('SOURCE', 'TARGET'):
+        zero_grads(params)
+        if phase == 'TARGET':                          # natr.py:69-73
+            params['source_user_embedding.weight'].requires_grad_(False)
+            params['source_item_embedding.weight'].requires_grad_(False)
+        loss = natr.calculate_loss(params, ids, hist, inter, phase, float(g.meta('reg_weight')))
+        close(loss, g[f'loss/{phase}'])
+        loss.backward()
+        check_grads(params, g, phase)
+        with torch.no_grad():
+            close(natr.predict(params, ids, hist, ev, phase), g[f'predict/{phase}'])
+    assert natr.calculate_loss(params, ids, hist, inter, 'BOTH', 0.0) is None          # natr.py:175-176
+
+
+@pytest.mark.parametrize('name', cases('dcdcsr_'))
+def test_dcdcsr(name):
+    g = Golden(name)
+    ids = g.idspace()
+    params = g.group('param', requires_grad=True)
+    inter = g.group('in')
+    ev = g.group('evalin')
+    pops = dcdcsr.unit_pops(ids, g['aux/s_pairs'], g['aux/t_pairs'])
+    np.testing.assert_array_equal(pops[0].numpy(), g['aux/source_pop'])
+    np.testing.assert_array_equal(pops[1].numpy(), g['aux/target_pop'])
+
+    def evals(stage, affine=None):
+        with torch.no_grad():
+            close(dcdcsr.predict(params, ids, ev, stage, affine), g[f'predict/{stage}'])
+            close(dcdcsr.full_sort_predict(params, ids, ev, stage, affine), g[f'fullsort/{stage}'])
+    for stage in ('SOURCE', 'TARGET'):
+        zero_grads(params)
+        loss = dcdcsr.rec_loss(params, ids, inter, stage)
+        close(loss, g[f'loss/{stage}'])
+        loss.backward()
+        check_grads(params, g, stage)
+        evals(stage)
+    bench = dcdcsr.build_benchmark_embedding(params, ids, pops, int(g.meta('k')))
+    close(bench, g['fwd/benchmark_embedding'])
+    np.random.seed(77)
+    unit_n = ids.target_num_users if ids.mode == 'overlap_users' else ids.target_num_items
+    sampled = np.random.randint(0, unit_n, int(g.meta('map_batch_size')))                # dcdcsr.py:175
+    np.testing.assert_array_equal(sampled, g['aux/sampled_index'])
+    zero_grads(params)
+    loss = dcdcsr.map_loss(params, ids, bench, sampled)
+    close(loss, g['loss/BOTH'])
+    loss.backward()
+    check_grads(params, g, 'BOTH')
+    affine = dcdcsr.build_affine_embedding(params, ids)
+    close(affine, g['fwd/affine_embedding'])
+    zero_grads(params)
+    loss = dcdcsr.rec_loss(params, ids, inter, 'TARGET2', affine)
+    close(loss, g['loss/TARGET2'])
+    loss.backward()
+    check_grads(params, g, 'TARGET2')
+    evals('TARGET2', affine)
