@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 24
+#define CDR_ABI_VERSION 25
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -535,6 +535,47 @@ int cdr_point_partial_dot(cdr_ctx* ctx, void* stream, const float* user_cols, co
 int cdr_point_grad_from_dot(cdr_ctx* ctx, void* stream, int loss_kind, const float* user_cols, const float* item_cols, int Ds,
                             const int64_t* uid, const int64_t* iid, const float* label, int64_t B, float reg_weight,
                             const float* dot /* [B + 2], all-reduced */, float* out9, float* GU, float* GI);
+
+/* ---- row-wise fusions of the five remaining models (their dense layers run on cdr_gemm_f32_ex) ------------------
+ * DTCDR (dtcdr.py:112-126): out[r, 0..D) = maximum(A[ids[r]], B[ids[r]]) written with row stride ldo (the [user ; item] operand of
+ * the NeuMF tower is two such calls into one [n, 2D] buffer); the backward routes g to the larger operand, half to each on a tie
+ * (torch.maximum), scatter-added into dense [rows, D] gradients (either may be NULL).                                          */
+int cdr_gather_max2(void* stream, const float* A, const float* B, int D, const int64_t* ids, int64_t n, float* out, int64_t ldo);
+int cdr_gather_max2_bwd(void* stream, const float* A, const float* B, int D, const int64_t* ids, int64_t n, const float* g,
+                        int64_t ldg, float* gA /* or NULL */, float* gB /* or NULL */);
+/* DeepAPF (deepapf.py:69-152).  s / o / t = gathered share / domain-only / other-side rows [B, D].
+ *   cdr_apf_prod    : X[b] = s[b] (.) t[b], X[B + b] = o[b] (.) t[b]     -- the attention MLP's [2B, D] operand (:77-78)
+ *   cdr_apf_combine : a[2B] = the MLP's scores; the share score is replaced by -1e31 where ids[b] > n_overlap (STRICTLY greater,
+ *                     :75,80), alpha = softmax over the pair, e = alpha_s s + alpha_o o, p = sigmoid(wp . (e (.) t))  (:82-88)
+ *   the backwards return per-row gradients; gwp_rows [B, D] is reduced over the batch with cdr_colsum (fixed order).            */
+int cdr_apf_prod(void* stream, const float* s, const float* o, const float* t, int64_t B, int D, float* X);
+int cdr_apf_prod_bwd(void* stream, const float* s, const float* o, const float* t, const float* gX, int64_t B, int D,
+                     float* gs, float* go, float* gt);
+int cdr_apf_combine(void* stream, const float* a, const float* s, const float* o, const float* t, const float* wp,
+                    const int64_t* ids, int64_t n_overlap, int64_t B, int D, float* p, float* alpha_s);
+int cdr_apf_combine_bwd(void* stream, const float* s, const float* o, const float* t, const float* wp, const float* p,
+                        const float* alpha_s, const float* gp, int64_t B, int D, float* ga /* [2B] */, float* gs, float* go,
+                        float* gt, float* gwp_rows);
+/* DCDCSR (dcdcsr.py:167-172): y = (x - mean) / (max - mean) per row, mean = (max + min) / 2; stats [n, 2] = (mean, max) or NULL.
+ * The backward spreads the amax / amin gradients evenly over tied elements, as torch does.                                      */
+int cdr_maxmin_norm(void* stream, const float* x, int64_t n, int D, float* y, float* stats /* or NULL */);
+int cdr_maxmin_norm_bwd(void* stream, const float* x, const float* gy, int64_t n, int D, float* gx);
+/* NATR phase 2 (natr.py:112-156) after the transfer layer: per batch row
+ *   score[l] = bu + wu . relu(pu (.) He[l]) + (mask[l] ? 0 : -10000) ; att = softmax_l(score) ; su = sum_l att[l] He[l]
+ *   b_s = bd + wd . relu(su (.) qi), b_p = bd + wd . relu(pu (.) qi) ; beta = e^b_s / (e^b_s + e^b_p)
+ *   p = sigmoid((beta su + (1 - beta) pu) . qi)
+ * He [B, L, D] = transfer_layer(source rows of the history), pu [B, D] the side the history belongs to, qi [B, D] the other side.
+ * Saved for the backward: att [B, L], su [B, D], beta [B], p [B].  The backward returns gHe, gpu, gqi and per-row partials of the
+ * four parameter gradients (gwu_rows, gwd_rows [B, D]; gb_rows [B, 2] = d bu, d bd) for cdr_colsum.                               */
+#define CDR_ROWMODEL_MAX_DIM 256
+#define CDR_NATR_MAX_HIST 256
+int cdr_natr_att_fwd(void* stream, const float* He, const float* pu, const float* qi, const float* mask, const float* wu,
+                     const float* bu, const float* wd, const float* bd, int64_t B, int L, int D, float* att, float* su,
+                     float* beta, float* p);
+int cdr_natr_att_bwd(void* stream, const float* He, const float* pu, const float* qi, const float* mask, const float* wu,
+                     const float* bu, const float* wd, const float* bd, int64_t B, int L, int D, const float* att,
+                     const float* su, const float* beta, const float* p, const float* gp, float* gHe, float* gpu, float* gqi,
+                     float* gwu_rows, float* gwd_rows, float* gb_rows);
 
 #ifdef __cplusplus
 }

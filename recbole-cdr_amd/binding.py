@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -106,6 +106,17 @@ _SIGNATURES = {
     'cdr_colblock_mean_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_colblock_mean_bwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_dropout_dev': [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, ctypes.c_uint64, _c_ptr],
+    'cdr_gather_max2': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
+    'cdr_gather_max2_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_apf_prod': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr],
+    'cdr_apf_prod_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_apf_combine': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr],
+    'cdr_apf_combine_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr,
+                            _c_ptr, _c_ptr],
+    'cdr_maxmin_norm': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr],
+    'cdr_maxmin_norm_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr],
+    'cdr_natr_att_fwd': [_c_ptr] * 9 + [_c_i64, _c_int, _c_int] + [_c_ptr] * 4,
+    'cdr_natr_att_bwd': [_c_ptr] * 9 + [_c_i64, _c_int, _c_int] + [_c_ptr] * 11,
     'cdr_dropout': [_c_ptr, _c_ptr, _c_i64, _c_f32, ctypes.c_uint64, _c_ptr],
     'cdr_embloss_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_embloss_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],

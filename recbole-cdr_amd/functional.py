@@ -715,3 +715,140 @@ def bcast_add_act(P, q, act):
 def adam_dense_(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     B_.call('cdr_adam_dense', B_.stream(), B_.f32(param), B_.f32(grad.contiguous()), B_.f32(exp_avg), B_.f32(exp_avg_sq),
             param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step))
+
+
+# ---------------------------------------------------------------------------------------------- the five remaining models
+class GatherMaxConcat(Function):
+    """cat([maximum(Us[u], Ut[u]), maximum(Is[i], It[i])], -1) in one [n, 2D] buffer (dtcdr.py:113-123) with torch.maximum's
+    backward (ties split evenly) scatter-added into the four dense table gradients."""
+
+    @staticmethod
+    def forward(ctx, us, ut, i_s, it, uid, iid):
+        _dev_check(us, ut, i_s, it, uid, iid)
+        uid, iid = _ids(uid), _ids(iid)
+        n, D = uid.numel(), us.shape[1]
+        out = torch.empty(n, 2 * D, device=us.device, dtype=torch.float32)
+        B_.call('cdr_gather_max2', B_.stream(), B_.f32(us), B_.f32(ut), D, B_.i64(uid), n, B_.f32(out), 2 * D)
+        B_.call('cdr_gather_max2', B_.stream(), B_.f32(i_s), B_.f32(it), D, B_.i64(iid), n, B_._c_ptr(out.data_ptr() + 4 * D), 2 * D)
+        ctx.save_for_backward(us, ut, i_s, it, uid, iid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        us, ut, i_s, it, uid, iid = ctx.saved_tensors
+        g = g.contiguous()
+        D, n = us.shape[1], uid.numel()
+        need = ctx.needs_input_grad
+        grads = [torch.zeros_like(w) if need[k] else None for k, w in enumerate((us, ut, i_s, it))]
+        if need[0] or need[1]:
+            B_.call('cdr_gather_max2_bwd', B_.stream(), B_.f32(us), B_.f32(ut), D, B_.i64(uid), n, B_.f32(g), 2 * D,
+                    B_.f32(grads[0]), B_.f32(grads[1]))
+        if need[2] or need[3]:
+            B_.call('cdr_gather_max2_bwd', B_.stream(), B_.f32(i_s), B_.f32(it), D, B_.i64(iid), n,
+                    B_._c_ptr(g.data_ptr() + 4 * D), 2 * D, B_.f32(grads[2]), B_.f32(grads[3]))
+        return grads[0], grads[1], grads[2], grads[3], None, None
+
+
+class ApfProduct(Function):
+    """[s (.) t ; o (.) t] -> [2B, D]: both candidates of DeepAPF's attention MLP in one operand (deepapf.py:77-78)."""
+
+    @staticmethod
+    def forward(ctx, s, o, t):
+        s, o, t = s.contiguous(), o.contiguous(), t.contiguous()
+        B, D = s.shape
+        X = torch.empty(2 * B, D, device=s.device, dtype=torch.float32)
+        B_.call('cdr_apf_prod', B_.stream(), B_.f32(s), B_.f32(o), B_.f32(t), B, D, B_.f32(X))
+        ctx.save_for_backward(s, o, t)
+        return X
+
+    @staticmethod
+    def backward(ctx, gX):
+        s, o, t = ctx.saved_tensors
+        B, D = s.shape
+        gs, go, gt = torch.empty_like(s), torch.empty_like(o), torch.empty_like(t)
+        B_.call('cdr_apf_prod_bwd', B_.stream(), B_.f32(s), B_.f32(o), B_.f32(t), B_.f32(gX.contiguous()), B, D,
+                B_.f32(gs), B_.f32(go), B_.f32(gt))
+        return gs, go, gt
+
+
+class ApfCombine(Function):
+    """masked 2-way softmax over (share, only) scores, attention-merged embedding, predict layer, sigmoid (deepapf.py:80-88)."""
+
+    @staticmethod
+    def forward(ctx, a, s, o, t, wp, ids, n_overlap):
+        a, s, o, t, wp = a.reshape(-1).contiguous(), s.contiguous(), o.contiguous(), t.contiguous(), wp.reshape(-1).contiguous()
+        ids = _ids(ids)
+        B, D = s.shape
+        p = torch.empty(B, device=s.device, dtype=torch.float32)
+        al = torch.empty(B, device=s.device, dtype=torch.float32)
+        B_.call('cdr_apf_combine', B_.stream(), B_.f32(a), B_.f32(s), B_.f32(o), B_.f32(t), B_.f32(wp), B_.i64(ids),
+                int(n_overlap), B, D, B_.f32(p), B_.f32(al))
+        ctx.save_for_backward(s, o, t, wp, p, al)
+        ctx.ashape, ctx.wshape = None, None
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        s, o, t, wp, p, al = ctx.saved_tensors
+        B, D = s.shape
+        dev = s.device
+        ga = torch.empty(2 * B, 1, device=dev, dtype=torch.float32)
+        gs, go, gt, rows = (torch.empty(B, D, device=dev, dtype=torch.float32) for _ in range(4))
+        B_.call('cdr_apf_combine_bwd', B_.stream(), B_.f32(s), B_.f32(o), B_.f32(t), B_.f32(wp), B_.f32(p), B_.f32(al),
+                B_.f32(gp.contiguous()), B, D, B_.f32(ga), B_.f32(gs), B_.f32(go), B_.f32(gt), B_.f32(rows))
+        return ga, gs, go, gt, _colsum(rows).view(1, D), None, None
+
+
+class MaxMinNormalize(Function):
+    """(x - mean) / (max - mean) per row, mean = (max + min) / 2 (dcdcsr.py:167-172).  Returns (y, stats [n, 2] = mean, max)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, D = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(n, 2, device=x.device, dtype=torch.float32)
+        B_.call('cdr_maxmin_norm', B_.stream(), B_.f32(x), n, D, B_.f32(y), B_.f32(stats))
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, gy, _gs):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        B_.call('cdr_maxmin_norm_bwd', B_.stream(), B_.f32(x), B_.f32(gy.contiguous()), x.shape[0], x.shape[1], B_.f32(gx))
+        return gx
+
+
+class NatrAttention(Function):
+    """NATR's unit-level attention over transferred history rows + domain-level gate + score (natr.py:117-136 / :139-156)."""
+
+    @staticmethod
+    def forward(ctx, He, pu, qi, mask, wu, bu, wd, bd):
+        He, pu, qi, mask = He.contiguous(), pu.contiguous(), qi.contiguous(), mask.contiguous()
+        wu_, wd_ = wu.reshape(-1).contiguous(), wd.reshape(-1).contiguous()
+        Bn, L, D = He.shape
+        dev = He.device
+        att = torch.empty(Bn, L, device=dev, dtype=torch.float32)
+        su = torch.empty(Bn, D, device=dev, dtype=torch.float32)
+        beta = torch.empty(Bn, device=dev, dtype=torch.float32)
+        p = torch.empty(Bn, device=dev, dtype=torch.float32)
+        B_.call('cdr_natr_att_fwd', B_.stream(), B_.f32(He), B_.f32(pu), B_.f32(qi), B_.f32(mask), B_.f32(wu_), B_.f32(bu),
+                B_.f32(wd_), B_.f32(bd), Bn, L, D, B_.f32(att), B_.f32(su), B_.f32(beta), B_.f32(p))
+        ctx.save_for_backward(He, pu, qi, mask, wu_, bu, wd_, bd, att, su, beta, p)
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        He, pu, qi, mask, wu_, bu, wd_, bd, att, su, beta, p = ctx.saved_tensors
+        Bn, L, D = He.shape
+        dev = He.device
+        gHe = torch.empty_like(He)
+        gpu, gqi, rwu, rwd = (torch.empty(Bn, D, device=dev, dtype=torch.float32) for _ in range(4))
+        rb = torch.empty(Bn, 2, device=dev, dtype=torch.float32)
+        B_.call('cdr_natr_att_bwd', B_.stream(), B_.f32(He), B_.f32(pu), B_.f32(qi), B_.f32(mask), B_.f32(wu_), B_.f32(bu),
+                B_.f32(wd_), B_.f32(bd), Bn, L, D, B_.f32(att), B_.f32(su), B_.f32(beta), B_.f32(p), B_.f32(gp.contiguous()),
+                B_.f32(gHe), B_.f32(gpu), B_.f32(gqi), B_.f32(rwu), B_.f32(rwd), B_.f32(rb))
+        gb = _colsum(rb)
+        return gHe, gpu, gqi, None, _colsum(rwu).view(1, D), gb[:1], _colsum(rwd).view(1, D), gb[1:]

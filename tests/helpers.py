@@ -40,6 +40,19 @@ class FakeDataset:
                              shape=(self.num_total_user, self.num_total_item))
 
 
+    # dataset.py:596-654 on the product's device builder (data/history.py)
+    def _history(self, domain, row, device=None):
+        from recbole_cdr_amd.data.history import history_matrix
+        p = self.s_pairs if domain == 'source' else self.t_pairs
+        return history_matrix(p[:, 0], p[:, 1], self.num_total_user, self.num_total_item, row, device or getattr(self, 'device', 'cpu'))
+
+    def history_item_matrix(self, value_field=None, domain='source'):
+        return self._history(domain, 'user')
+
+    def history_user_matrix(self, value_field=None, domain='source'):
+        return self._history(domain, 'item')
+
+
 def base_config(device, **kw):
     cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': device}
     cfg.update(kw)

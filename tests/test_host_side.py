@@ -251,3 +251,27 @@ def test_committed_bench_line_keeps_the_driver_contract():
     # value = triples of all ranks / measured time: 2 domains x B per step
     B = d['config']['batch_per_domain_per_rank']
     assert abs(d['value'] - 2 * B * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+
+
+@both_sessions
+def test_history_matrix_builder_bit_exact(session):
+    """data/history.py (torch sort / scatter; runs on whatever device it is given) against the reference's get_history_matrix
+    output recorded in NATR's fixtures (dataset.py:181-249) and against the oracle's loop restatement on a larger random case."""
+    from golden_util import Golden
+    from oracle.history import history_matrix as oracle_hist
+    from recbole_cdr_amd.data.history import history_matrix
+    for name, row in (('natr_users', 'item'), ('natr_items', 'user')):
+        g = Golden(name)
+        ids = g.idspace()
+        t = g['aux/t_pairs']
+        mat, val, lens = history_matrix(t[:, 0], t[:, 1], ids.total_num_users, ids.total_num_items, row, 'cpu')
+        L = int(g.meta('max_inter_length'))
+        np.testing.assert_array_equal(mat[:, :L].numpy(), g['aux/history_matrix'])
+        np.testing.assert_array_equal(lens.numpy(), g['aux/history_lens'])
+    rng = np.random.RandomState(0)
+    u, i = rng.randint(0, 300, 5000), rng.randint(0, 200, 5000)
+    for row in ('user', 'item'):
+        want = oracle_hist(u, i, 300, 200, row)
+        got = history_matrix(u, i, 300, 200, row, 'cpu')
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a.numpy(), b.numpy())
