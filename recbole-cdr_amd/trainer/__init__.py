@@ -1,1 +1,1 @@
-from .trainer import CrossDomainTrainer  # noqa: F401
+from .trainer import CrossDomainTrainer, DCDCSRTrainer  # noqa: F401

@@ -384,3 +384,27 @@ class CrossDomainTrainer(Trainer):
                 super().fit(train_data, valid_data, verbose, saved, show_progress, callback_fn)
         self.model.set_phase('OVERLAP')
         return self.best_valid_score, self.best_valid_result
+
+
+class DCDCSRTrainer(CrossDomainTrainer):
+    """trainer.py:79-139: the same phase loop, except that the BOTH phase (DCDCSR's mapping phase: the loss ignores the batch and
+    nothing can be ranked before the second TARGET visit builds the affine table) runs WITHOUT validation data.
+    ``train_modes`` typically ['SOURCE', 'TARGET', 'BOTH', 'TARGET'] (properties/model/DCDCSR.yaml): ``epoch_num`` is indexed by the
+    phase's POSITION, and the model counts its visits of each phase (dcdcsr.py:90-92)."""
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        for phase in range(len(self.train_modes)):
+            self._reinit(phase)
+            scheme = self.train_modes[phase]
+            train_data.set_mode(train_mode2state[scheme])
+            self.model.set_phase(scheme)
+            if scheme == 'BOTH':
+                Trainer.fit(self, train_data, None, verbose, saved, show_progress, callback_fn)
+            elif self.split_valid_flag and valid_data is not None:
+                source_valid_data, target_valid_data = valid_data
+                Trainer.fit(self, train_data, source_valid_data if scheme == 'SOURCE' else target_valid_data, verbose, saved,
+                            show_progress, callback_fn)
+            else:
+                Trainer.fit(self, train_data, valid_data, verbose, saved, show_progress, callback_fn)
+        self.model.set_phase('OVERLAP')
+        return self.best_valid_score, self.best_valid_result

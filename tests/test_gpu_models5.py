@@ -269,3 +269,153 @@ def test_deepapf_default_size_vs_oracle():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
         else:
             assert_close(p.grad, P[n].grad, what=n, row_floor=1e-2)
+
+
+# ---------------------------------------------------------------------------------------------- through the trainers
+def _loaders(ids, input_type, k, seed, n_s=96, n_t=80, bs=32, OB=8):
+    from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+    rng = np.random.RandomState(seed)
+    src_u = np.array(list(range(1, ids.OU)) + list(range(ids.OU + ids.TOU, ids.total_num_users)))
+    src_i = np.array(list(range(1, ids.OI)) + list(range(ids.OI + ids.TOI, ids.total_num_items)))
+    tgt_u, tgt_i = np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI)
+    s_pairs = np.stack([np.concatenate([src_u, rng.choice(src_u, n_s)]), np.concatenate([rng.choice(src_i, len(src_u)), rng.choice(src_i, n_s)])], 1)
+    t_pairs = np.stack([np.concatenate([tgt_u, rng.choice(tgt_u, n_t)]), np.concatenate([rng.choice(tgt_i, len(tgt_u)), rng.choice(tgt_i, n_t)])], 1)
+    # every item appears as well (popularities > 0: dcdcsr.py:147-149 divides by them)
+    s_pairs = np.concatenate([s_pairs, np.stack([rng.choice(src_u, len(src_i)), src_i], 1)])
+    t_pairs = np.concatenate([t_pairs, np.stack([rng.choice(tgt_u, len(tgt_i)), tgt_i], 1)])
+    s_inter = {'source_user_id': torch.from_numpy(s_pairs[:, 0].copy()), 'source_item_id': torch.from_numpy(s_pairs[:, 1].copy())}
+    t_inter = {'target_user_id': torch.from_numpy(t_pairs[:, 0].copy()), 'target_item_id': torch.from_numpy(t_pairs[:, 1].copy())}
+    neg_rng = {}
+
+    def reset():
+        neg_rng['s'], neg_rng['t'] = np.random.RandomState(seed + 1), np.random.RandomState(seed + 2)
+    reset()
+    s_sampler = lambda u, i, kk: torch.from_numpy(neg_rng['s'].choice(src_i, u.numel() * kk)).to(u.device)
+    t_sampler = lambda u, i, kk: torch.from_numpy(neg_rng['t'].choice(tgt_i, u.numel() * kk)).to(u.device)
+    mk = lambda: CrossDomainDataloader(
+        DomainTrainLoader(s_inter, 'source_user_id', 'source_item_id', 'source_label', 'neg_', bs, k, input_type, s_sampler),
+        DomainTrainLoader(t_inter, 'target_user_id', 'target_item_id', 'target_label', 'neg_', bs, k, input_type, t_sampler),
+        OverlapDataloader(max(ids.OU, ids.OI), OB))
+    return mk, reset, s_pairs, t_pairs
+
+
+def _epoch_batches(dl, phase):
+    from recbole_cdr_amd.utils import train_mode2state
+    dl.set_mode(train_mode2state[phase])
+    it = iter(dl)
+    while True:
+        try:
+            yield next(it)
+        except StopIteration:
+            return
+
+
+def test_dcdcsr_trainer_phase_loop_matches_oracle_training():
+    """DCDCSRTrainer.fit over SOURCE -> TARGET -> BOTH -> TARGET (trainer.py:79-139; dense native Adam, one optimizer across the
+    phases) against the oracle trained with torch.optim.Adam on the same batches and the same numpy draws: per-epoch loss sums,
+    the benchmark / affine tables built at the phase switches, and the final parameters."""
+    from oracle import dcdcsr as o
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.dcdcsr import DCDCSR
+    from recbole_cdr_amd.trainer import DCDCSRTrainer
+    from recbole_cdr_amd.utils import InputType, get_trainer, ModelType
+    assert get_trainer(ModelType.CROSSDOMAIN, 'DCDCSR') is DCDCSRTrainer
+    torch.manual_seed(13)
+    ids = IdSpace(OU=20, TOU=15, SOU=18, OI=1, TOI=30, SOI=34)
+    mk, reset, s_pairs, t_pairs = _loaders(ids, InputType.PAIRWISE, 1, seed=4)
+    modes, epochs = ['SOURCE', 'TARGET', 'BOTH', 'TARGET'], [2, 1, 2, 1]
+    cfg = base_config(DEV, latent_factor_model='BPR', embedding_size=16, mlp_hidden_size=[24], k=4, map_batch_size=32,
+                      learning_rate=0.01, train_modes=modes, epoch_num=[str(e) for e in epochs], source_split=False,
+                      eval_step=1, epochs=2)
+    ds = FakeDataset(ids, s_pairs, t_pairs)
+    ds.device = DEV
+    model = DCDCSR(cfg, ds).to(DEV)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    trainer = DCDCSRTrainer(cfg, model)
+    log, orig = [], trainer._train_epoch
+    trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
+    np.random.seed(5)
+    trainer.fit(mk())
+    assert model.phase == 'OVERLAP' and len(log) == sum(epochs)
+    # ---- oracle
+    reset()
+    np.random.seed(5)
+    pops = o.unit_pops(ids, s_pairs, t_pairs)
+    opt = torch.optim.Adam(list(params.values()), lr=0.01)
+    dl = mk()
+    ref_log, seen, bench, affine = [], {}, None, None
+    for phase, n_ep in zip(modes, epochs):
+        seen[phase] = seen.get(phase, 0) + 1
+        stage = 'TARGET2' if (phase == 'TARGET' and seen[phase] == 2) else phase
+        if phase == 'BOTH':
+            bench = o.build_benchmark_embedding(params, ids, pops, 4)
+        if stage == 'TARGET2':
+            affine = o.build_affine_embedding(params, ids)
+        for _ in range(n_ep):
+            tot = 0.0
+            for b in _epoch_batches(dl, phase):
+                opt.zero_grad()
+                if phase == 'BOTH':
+                    loss = o.map_loss(params, ids, bench, np.random.randint(0, ids.target_num_users, 32))
+                else:
+                    loss = o.rec_loss(params, ids, b, stage, affine)
+                loss.backward()
+                opt.step()
+                tot += float(loss.detach())
+            ref_log.append(tot)
+    assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=2e-5, what='epoch losses')
+    assert_close(model.benchmark_embedding, bench, rtol=1e-4, atol=1e-5, what='benchmark table after training')
+    assert_close(model.affine_embedding, affine, rtol=1e-4, atol=1e-4, what='affine table after training')
+    for k, v in model.named_parameters():
+        assert_close(v, params[k], rtol=1e-4, atol=0.01 * 2e-2, what=k)     # a few Adam steps ~ lr * sign(g): 2 % of one step
+
+
+def test_natr_trainer_phase_loop_matches_oracle_training():
+    """CrossDomainTrainer.fit over SOURCE -> TARGET with NATR (POINTWISE batches with labelled negatives; the TARGET phase freezes the
+    source tables, natr.py:69-73) against the oracle trained with torch.optim.Adam on the same batches."""
+    from oracle import natr as o
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.natr import NATR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.utils import InputType
+    torch.manual_seed(17)
+    ids = IdSpace(OU=1, TOU=25, SOU=22, OI=18, TOI=20, SOI=16)
+    mk, reset, s_pairs, t_pairs = _loaders(ids, InputType.POINTWISE, 1, seed=6)
+    cfg = base_config(DEV, source_embedding_size=16, target_embedding_size=24, reg_weight=1e-3, max_inter_length=6,
+                      learning_rate=0.01, train_modes=['SOURCE', 'TARGET'], epoch_num=['2', '2'], source_split=False,
+                      eval_step=1, epochs=2)
+    ds = FakeDataset(ids, s_pairs, t_pairs)
+    ds.device = DEV
+    model = NATR(cfg, ds).to(DEV)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    trainer = CrossDomainTrainer(cfg, model)
+    log, orig = [], trainer._train_epoch
+    trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
+    trainer.fit(mk())
+    assert len(log) == 4
+    reset()
+    hist = o.history_info(ids, t_pairs, 6)
+    opt = torch.optim.Adam(list(params.values()), lr=0.01)
+    dl = mk()
+    ref_log = []
+    for phase in ('SOURCE', 'TARGET'):
+        if phase == 'TARGET':
+            params['source_user_embedding.weight'].requires_grad_(False)
+            params['source_item_embedding.weight'].requires_grad_(False)
+        for _ in range(2):
+            tot = 0.0
+            for b in _epoch_batches(dl, phase):
+                opt.zero_grad()
+                loss = o.calculate_loss(params, ids, hist, b, phase, 1e-3)
+                loss.backward()
+                opt.step()
+                tot += float(loss.detach())
+            ref_log.append(tot)
+    assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=2e-5, what='epoch losses')
+    for k, v in model.named_parameters():
+        if k.endswith('attention_layer.bias'):
+            # the loss does not depend on either attention bias (softmax / gate shift invariance): their gradients are rounding residue
+            # (~1e-9) that Adam normalises into steps of arbitrary sign -- both implementations drift, by less than lr per step
+            assert abs(float(v.detach()) - float(params[k].detach())) <= 0.01 * 40
+            continue
+        assert_close(v, params[k], rtol=1e-4, atol=0.01 * 2e-2, what=k)
