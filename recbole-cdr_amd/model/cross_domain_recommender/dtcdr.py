@@ -31,34 +31,34 @@ class MLPLayers(nn.Module):
         self.mlp_layers = nn.Sequential(*mods)
         self.logger = None
 
-    def forward(self, x):
+    def forward(self, x, seed=None, salt=0):
+        """``seed``: device int64 [1] counter of the step's dropout masks (None: no dropout); layer n uses stream ``salt + n``."""
         n = 0
         for m in self.mlp_layers:
             if isinstance(m, nn.Linear):
-                if self.training and self.dropout > 0:
-                    x = x.clone() if n == 0 else x
-                    seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())
-                    x = _Dropout.apply(x, self.dropout, seed)
+                if seed is not None and self.training and self.dropout > 0:
+                    x = _Dropout.apply(x, self.dropout, seed, salt + n)
                 x = F_.linear(x, m.weight, m.bias, B_.ACT_RELU)
                 n += 1
         return x
 
 
 class _Dropout(torch.autograd.Function):
-    """x * mask / (1 - p) with the native counter-based mask; the backward re-applies the same mask."""
+    """x * mask / (1 - p) with the native counter-based mask (cdr_dropout_dev: the seed is read from device memory, so a captured
+    step draws a fresh mask on every replay); the backward re-applies the same mask."""
 
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, salt):
         y = x.contiguous().clone()
-        F_._dropout(y, y.numel(), p, seed, 0)
-        ctx.p, ctx.seed = p, seed
+        F_._dropout(y, y.numel(), p, seed, salt)
+        ctx.p, ctx.seed, ctx.salt = p, seed, salt
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous().clone()
-        F_._dropout(g, g.numel(), ctx.p, ctx.seed, 0)
-        return g, None, None
+        F_._dropout(g, g.numel(), ctx.p, ctx.seed, ctx.salt)
+        return g, None, None, None
 
 
 class DTCDR(CrossDomainRecommender):
@@ -89,16 +89,35 @@ class DTCDR(CrossDomainRecommender):
         self.target_predict_layer = nn.Linear(self.mlp_hidden_size[-1], 1)
         self.apply(xavier_normal_initialization)
 
-    def neumf_forward(self, user, item, domain='source'):
+    def _drop_seed(self):
+        """Device-resident seed of this step's dropout masks: re-drawn from torch's CPU generator when run eagerly, advanced by a
+        captured kernel inside a hipGraph capture (a host draw would be baked into the graph: one mask for every replay)."""
+        if not self.training or not self.dropout_prob:
+            return None
+        dev = self.source_user_embedding.weight.device
+        st = self.__dict__.get('_drop_state')
+        if st is None or st.device != dev:
+            st = torch.zeros(1, device=dev, dtype=torch.int64)
+            self.__dict__['_drop_state'] = st
+        if torch.cuda.is_current_stream_capturing():
+            B_.call('cdr_inc_i64', B_.stream(), B_.i64(st))
+        else:
+            st.fill_(int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item()))
+        return st
+
+    def neumf_forward(self, user, item, domain='source', seed=None):
         x = F_.GatherMaxConcat.apply(self.source_user_embedding.weight, self.target_user_embedding.weight,
                                      self.source_item_embedding.weight, self.target_item_embedding.weight, user, item)
         mlp = self.source_mlp_layers if domain == 'source' else self.target_mlp_layers
         head = self.source_predict_layer if domain == 'source' else self.target_predict_layer
-        return F_.linear(mlp(x), head.weight, head.bias, B_.ACT_SIGMOID).squeeze(-1)
+        if seed is None:
+            seed = self._drop_seed()
+        return F_.linear(mlp(x, seed, 0 if domain == 'source' else 64), head.weight, head.bias, B_.ACT_SIGMOID).squeeze(-1)
 
     def calculate_loss(self, interaction):
-        ps = self.neumf_forward(interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], 'source')
-        pt = self.neumf_forward(interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], 'target')
+        seed = self._drop_seed()
+        ps = self.neumf_forward(interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], 'source', seed)
+        pt = self.neumf_forward(interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], 'target', seed)
         loss_s = F_.BCEProbLoss.apply(ps, interaction[self.SOURCE_LABEL])
         loss_t = F_.BCEProbLoss.apply(pt, interaction[self.TARGET_LABEL])
         return loss_s * self.alpha + loss_t * (1 - self.alpha)

@@ -419,3 +419,72 @@ def test_natr_trainer_phase_loop_matches_oracle_training():
             assert abs(float(v.detach()) - float(params[k].detach())) <= 0.01 * 40
             continue
         assert_close(v, params[k], rtol=1e-4, atol=0.01 * 2e-2, what=k)
+
+
+def test_five_models_replay_as_one_hipgraph_equal_to_eager():
+    """graph_step.GraphedTrainStep on CLFM / DTCDR / DeepAPF / NATR phase 2 / DCDCSR's BPR phase: 3 replays on changing batches leave
+    the same loss values as the eager loop from the same start (1e-5: the dense scatter-add's fp32 atomics reorder sums), and DTCDR
+    with dropout draws a fresh mask on every replay (the seed is a device counter advanced inside the captured step)."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.graph_step import GraphedTrainStep
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    from recbole_cdr_amd.model.cross_domain_recommender.clfm import CLFM
+    from recbole_cdr_amd.model.cross_domain_recommender.dtcdr import DTCDR
+    from recbole_cdr_amd.model.cross_domain_recommender.deepapf import DeepAPF
+    from recbole_cdr_amd.model.cross_domain_recommender.natr import NATR
+    from recbole_cdr_amd.model.cross_domain_recommender.dcdcsr import DCDCSR
+    ids = IdSpace(OU=1, TOU=60, SOU=70, OI=40, TOI=50, SOI=45)
+    rng = np.random.RandomState(1)
+    src_u = np.arange(ids.OU + ids.TOU, ids.total_num_users)
+    src_i = np.r_[1:ids.OI, ids.OI + ids.TOI:ids.total_num_items]
+    s_pairs = np.stack([rng.choice(src_u, 900), rng.choice(src_i, 900)], 1)
+    t_pairs = np.stack([rng.randint(1, ids.OU + ids.TOU, 900), rng.randint(1, ids.OI + ids.TOI, 900)], 1)
+    ds = FakeDataset(ids, s_pairs, t_pairs)
+    ds.device = DEV
+
+    def batch(pairwise, B=128):
+        t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int64)).to(DEV)
+        out = {}
+        for d, us, its in (('source', src_u, src_i), ('target', np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI))):
+            out[f'{d}_user_id'], out[f'{d}_item_id'] = t(rng.choice(us, B)), t(rng.choice(its, B))
+            if pairwise:
+                out[f'neg_{d}_item_id'] = t(rng.choice(its, B))
+            else:
+                out[f'{d}_label'] = torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32)).to(DEV)
+        return out
+    cases = [(CLFM, dict(user_embedding_size=16, source_item_embedding_size=16, target_item_embedding_size=16, share_embedding_size=8,
+                         alpha=0.5, reg_weight=1e-3), False, None),
+             (DTCDR, dict(embedding_size=16, mlp_hidden_size=[16, 8], dropout_prob=0.0, base_model='NeuMF', alpha=0.5), False, None),
+             (DeepAPF, dict(embedding_size=16, beta=0.5), False, None),
+             (NATR, dict(source_embedding_size=16, target_embedding_size=16, reg_weight=1e-3, max_inter_length=8), False, 'TARGET'),
+             (DCDCSR, dict(latent_factor_model='BPR', embedding_size=16, mlp_hidden_size=[16], k=3, map_batch_size=32), True, 'TARGET')]
+    for cls, kw, pairwise, phase in cases:
+        batches = [batch(pairwise) for _ in range(4)]
+        runs = []
+        for graphed in (False, True):
+            torch.manual_seed(9)
+            m = cls(base_config(DEV, **kw), ds).to(DEV)
+            if phase:
+                m.set_phase(phase)
+            m.train()
+            opt = DenseAdam(m.parameters(), lr=0.01)
+            if graphed:
+                g = GraphedTrainStep(m, opt, batches[0])
+                runs.append([float(g.step(b)) for b in batches])
+            else:
+                out = []
+                for b in batches:
+                    opt.zero_grad(set_to_none=True)
+                    loss = m.calculate_loss(b).sum()
+                    loss.backward()
+                    opt.step()
+                    out.append(float(loss.detach()))
+                runs.append(out)
+        assert_close(torch.tensor(runs[1]), torch.tensor(runs[0]), rtol=1e-5, atol=1e-7, what=cls.__name__)
+    torch.manual_seed(3)
+    m = DTCDR(base_config(DEV, embedding_size=16, mlp_hidden_size=[16, 8], dropout_prob=0.5, base_model='NeuMF', alpha=0.5), ds).to(DEV)
+    m.train()
+    b = batch(False)
+    g = GraphedTrainStep(m, DenseAdam(m.parameters(), lr=0.0), b, warmup=1)
+    losses = [float(g.step(b)) for _ in range(4)]
+    assert len({round(l, 7) for l in losses}) == 4, losses
