@@ -78,6 +78,18 @@ __device__ __forceinline__ float upd1(float w, float g, float& m, float& v, cons
     return w - step_size * (m / (sqrtf(v) / bc2_sqrt + o.eps));
 }
 
+// the same update with the two divisions and the square root on the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 instead of their
+// IEEE expansions (map_pipe_kernel only -- its row waves are VALU-issue bound and the expansions are two thirds of their work):
+// exp_avg and exp_avg_sq are bit-identical, the step differs from upd1's by <= ~3 ulp of the QUOTIENT, i.e. <= 4e-7 x lr on the
+// weight -- below half an ulp of the weight in all but tie cases
+__device__ __forceinline__ float updq(float w, float g, float& m, float& v, const map_opt& o, float step_size, float rbc) {
+    if (o.wd != 0.f) g += o.wd * w;
+    if (o.opt == 0) return w - o.lr * g;
+    m += (g - m) * (1.0f - o.b1);
+    v = o.b2 * v + (1.0f - o.b2) * g * g;
+    return w - step_size * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * rbc + o.eps));
+}
+
 // SLOTS: weight-gradient tiles per wave (4 -> 64 accumulator registers, 8 -> 128)
 template <int SLOTS>
 __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt opt, float* __restrict__ S, float* __restrict__ mS,
@@ -303,6 +315,327 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
     if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- the linear mapping (emcdr.py:59-64: Linear(Ds, Dt, bias=False)) with Ds == Dt in {64, 128}: two wave groups ------------------
+// map_step_kernel is bound by LATENCY, not bandwidth: per 32-id block a workgroup waits three times for random rows out of
+// 25-GB tables (source rows; target rows in the epilogue; four moment rows in the apply) and its MFMA loops wait behind the apply's
+// stores (vmcnt retires in order): ~50 us per block, two workgroups per CU to hide it, 1.8 TB/s.  Here ONE 512-thread workgroup
+// per CU splits into
+//   * four MFMA waves (one per SIMD): forward, loss + gz, weight-gradient tiles, dL/dS -- LDS in, LDS out, no table traffic, no
+//     stores; their only global loads are the mapping's weights (L2);
+//   * four row waves that keep the NEXT block's six rows per id in flight with global_load_lds (LDS DMA: no registers; counted by
+//     THEIR vmcnt only) and run the optimizer: Adam on the target rows of block b while the MFMA waves do its backward, Adam on
+//     the source rows of block b while they do the forward of block b + 1.  Each lane updates exactly the 16-byte chunks it
+//     prefetched itself (same lane -> (row, chunk) map for the DMA and for the update), so the staging arrays need no
+//     synchronisation between row waves and are refilled the moment the lane is done with them.
+// The staged rows are XOR-swizzled through the DMA's SOURCE address (LDS DMA writes lane-linear, so padding is not available:
+// physical chunk p of row r holds logical chunk p ^ (r mod chunks)): the MFMA operand reads (lane = row, same logical chunk) and
+// the row waves' own reads are both conflict-free and no copy into a padded operand buffer is needed.
+// LDS at D = 128: gz 16.9 KB + dL/dS 16.9 KB + source rows 2 x 16 KB (double-buffered: block b's are the update's `w` while
+// b + 1's arrive) + T, mT, vT, mS, vS 5 x 16 KB = 145 KB.
+#ifdef CDR_MAP_PROF
+__device__ long long g_map_prof[64];
+#define MP_STAMP(slot) do { if (blockIdx.x == 7 && k == 2 && (t == 0 || t == 256)) g_map_prof[(t ? 32 : 0) + (slot)] = wall_clock64(); } while (0)
+#else
+#define MP_STAMP(slot) do { } while (0)
+#endif
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS DMA as an asm statement: through __builtin_amdgcn_global_load_lds hipcc treats every later ds_read of the wave as a possible
+// reader of the in-flight DMA and drains it with vmcnt(0) first -- exactly the wait this kernel exists to avoid.  M0 (the
+// wave-uniform LDS destination) is written and restored inside the statement.
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+
+template <int NI>
+__global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt opt, float* __restrict__ S, float* __restrict__ mS,
+                                                         float* __restrict__ vS, float* __restrict__ T, float* __restrict__ mT,
+                                                         float* __restrict__ vT, const int64_t* __restrict__ idx, int64_t n,
+                                                         const int64_t* __restrict__ step_s, const int64_t* __restrict__ step_t,
+                                                         float* __restrict__ wpart, double* __restrict__ lpart, map_params bump) {
+    constexpr int D = 32 * NI;                 // Ds == Dt
+    constexpr int LR = D / 4;                  // 16-byte chunks (= DMA lanes) per row
+    constexpr int RPI = 64 / LR;               // rows per DMA instruction (1 KiB of LDS)
+    constexpr int GS = D + 4;                  // padded row stride of the two MFMA-written buffers
+    constexpr int SLOTS = NI * NI / 4 > 0 ? NI * NI / 4 : 1;       // weight-gradient tiles per MFMA wave
+    constexpr int NJ = (NI + 3) / 4;           // 32-column jobs per MFMA wave
+    constexpr int NQ = NI;                     // DMA instructions per row wave and array (4 row waves)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float rok[3][kRows];
+    __shared__ int64_t rid[3][kRows];
+    __shared__ double red[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li0 = lane & 31, lh0 = lane >> 5;
+    const bool rowwave = wave >= 4;
+    float* GZ = smem;                          // [32][GS]  mapped -> gz = dL/d mapped
+    float* GX = GZ + kRows * GS;               // [32][GS]  dL/dS
+    float* SS = GX + kRows * GS;               // [2][32][D] source rows (swizzled)
+    float* ST = SS + 2 * kRows * D;            // [32][D] each, swizzled alike
+    float* SMT = ST + kRows * D;
+    float* SVT = SMT + kRows * D;
+    float* SMS = SVT + kRows * D;
+    float* SVS = SMS + kRows * D;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool adam = opt.opt != 0;
+    float ss_s, bc_s, ss_t, bc_t;
+    adam_hp(opt, step_s, 1, ss_s, bc_s);
+    adam_hp(opt, step_t, 1, ss_t, bc_t);
+    const float gscale = 2.0f / ((float)n * (float)D);
+    const float* __restrict__ W = net.W[0];
+    if (blockIdx.x == 0 && t == 0 && bump.sW[0]) bump.sW[0][0] += 1;
+    const int64_t nrb = (n + kRows - 1) / kRows;
+    f32x16 wacc[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) wacc[q] = zero16();
+    double lsum = 0.0;
+
+    // (address arithmetic below is re-derived per phase from a laundered lane id: left alone, LICM hoists ~200 loop-invariant LDS /
+    //  global offsets out of the block loop and spills them -- and a spill reload inside a row wave is a vector memory load whose
+    //  wait drains the DMA queue)
+    auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    // ---- row waves: lane <-> (row, physical chunk) of DMA instruction i = pw + 4 q, q < NQ
+    const int pw = wave - 4;
+    auto stage = [&](const float* __restrict__ tab, float* dst, const int64_t* ids) {
+        const int ln = fresh(lane);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = pw + 4 * q, row = i * RPI + ln / LR, p = ln % LR;
+            glds16(tab + ids[row] * D + 4 * (p ^ (row & (LR - 1))), dst + i * 256);
+        }
+    };
+    // Adam / SGD on this lane's chunks of DMA instructions [q0, q1): g = sign * G[row][logical chunk]
+    auto apply = [&](int q0, int q1, float* __restrict__ tab, float* __restrict__ mtab, float* __restrict__ vtab, const float* stW,
+                     const float* stM, const float* stV, const float* G, float sign, const int64_t* ids, const float* ok,
+                     float ssz, float bcs) {
+        const int ln = fresh(lane);
+        const float rbc = 1.0f / bcs;
+        for (int q = q0; q < q1; ++q) {
+            const int i = pw + 4 * q, row = i * RPI + ln / LR, p = ln % LR, c = p ^ (row & (LR - 1));
+            if (ok[row] == 0.f) continue;
+            const int so = (row * LR + p) * 4;
+            const float4 w = ld4(stW + so), g = ld4(G + row * GS + 4 * c);
+            float4 m = z4, v = z4;
+            if (adam) { m = ld4(stM + so); v = ld4(stV + so); }
+            float4 wn;
+            wn.x = updq(w.x, sign * g.x, m.x, v.x, opt, ssz, rbc); wn.y = updq(w.y, sign * g.y, m.y, v.y, opt, ssz, rbc);
+            wn.z = updq(w.z, sign * g.z, m.z, v.z, opt, ssz, rbc); wn.w = updq(w.w, sign * g.w, m.w, v.w, opt, ssz, rbc);
+            const int64_t o = ids[row] * D + 4 * c;
+            st4(tab + o, wn);
+            if (adam) { st4(mtab + o, m); st4(vtab + o, v); }
+        }
+    };
+    if (t < kRows) {                                                     // ids of this workgroup's first block
+        const int64_t g = (int64_t)blockIdx.x * kRows + t;
+        rid[0][t] = idx[g < n ? g : n - 1];
+        rok[0][t] = g < n ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (rowwave) {
+        __builtin_amdgcn_s_setprio(3);
+        stage(S, SS, rid[0]);
+        stage(T, ST, rid[0]);
+        if (adam) { stage(mT, SMT, rid[0]); stage(vT, SVT, rid[0]); }
+        vm_wait<0>();
+    }
+    lds_barrier();
+    // group-0 weights of the forward and of the dL/dS contraction: loaded once, resident across blocks (their L2 latency would
+    // otherwise open every MFMA phase)
+    float4 wf0[NJ][4], wb0[NJ][4];
+    if (!rowwave) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int job = wave + 4 * jj;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wf0[jj][j] = z4; wb0[jj][j] = z4;
+                if (job < NI) {
+                    wf0[jj][j] = ld4(W + (int64_t)(job * 32 + li0) * D + 8 * j + 4 * lh0);
+                    const float* p = W + (int64_t)(8 * j + 4 * lh0) * D + job * 32 + li0;
+                    wb0[jj][j] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
+                }
+            }
+        }
+    }
+    int k = 0;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x, ++k) {
+        const int par = k & 1, r3 = k % 3, r3n = (k + 1) % 3, r3p = (k + 2) % 3;
+        const bool has_next = rb + gridDim.x < nrb;
+        float* Xs = SS + par * kRows * D;                               // this block's source rows
+        MP_STAMP(0);
+        if (!rowwave) {
+            // ---- forward: mapped = X W^T, one 32-column tile per job
+            int64_t idn = 0; float okn = 0.f;
+            if (t < kRows && has_next) { const int64_t g = (rb + gridDim.x) * kRows + t; idn = idx[g < n ? g : n - 1]; okn = g < n ? 1.f : 0.f; }
+            f32x16 am[NJ];
+            int li = fresh(li0), lh = fresh(lh0);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int job = wave + 4 * jj;
+                am[jj] = zero16();
+                if (job < NI) {
+                    // K in groups of four steps: the weights of group g + 1 (L2) and the operand chunks of group g + 1 (LDS) are
+                    // requested before group g's sixteen MFMAs; group 0's weights stay in registers across blocks (wf0)
+                    const float* wm = W + (int64_t)(job * 32 + li) * D;
+                    const float* xr = Xs + li * D;
+                    const int sw = li & (LR - 1);
+                    float4 nm[4], an[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { nm[j] = wf0[jj][j]; an[j] = ld4(xr + ((2 * j + lh) ^ sw) * 4); }
+#pragma unroll
+                    for (int g = 0; g < D / 32; ++g) {
+                        float4 cm[4], ca[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { cm[j] = nm[j]; ca[j] = an[j]; }
+                        if (g + 1 < D / 32) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                nm[j] = ld4(wm + 8 * (4 * (g + 1) + j) + 4 * lh);
+                                an[j] = ld4(xr + ((2 * (4 * (g + 1) + j) + lh) ^ sw) * 4);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { MFMA4(am[jj], ca[j], cm[j]); }
+                    }
+                }
+            }
+            if (t < kRows && has_next) { rid[r3n][t] = idn; rok[r3n][t] = okn; }
+            MP_STAMP(1);
+            lds_barrier();                                               // ---- X: the target rows of this block are in LDS
+            MP_STAMP(2);
+            li = fresh(li0); lh = fresh(lh0);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int job = wave + 4 * jj;
+                if (job < NI) {
+                    const int ncol = job * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float tv = ST[(row * LR + ((ncol >> 2) ^ (row & (LR - 1)))) * 4 + (ncol & 3)];
+                        const float d = rok[r3][row] != 0.f ? am[jj][r] - tv : 0.f;              // nn.MSELoss (emcdr.py:81,162)
+                        lsum += (double)d * (double)d;
+                        GZ[row * GS + ncol] = gscale * d;
+                    }
+                }
+            }
+            MP_STAMP(3);
+            lds_barrier();                                               // ---- F: gz is complete
+            MP_STAMP(4);
+            // ---- dW += gz^T x : this wave's tiles; the 32 operand words of tile q + 1 are requested before tile q's 16 MFMAs
+            {
+                float av[2][16], bv[2][16];
+                auto fetch = [&](int q, float* a_, float* b_) {
+                    const int tile = wave + 4 * q, mt = tile / NI, nt = tile - mt * NI;
+                    const int l_i = fresh(li0), l_h = fresh(lh0);
+                    const int m = mt * 32 + l_i, nn = nt * 32 + l_i;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = 8 * (e >> 2) + 4 * l_h + (e & 3);
+                        a_[e] = GZ[row * GS + m];
+                        b_[e] = Xs[(row * LR + ((nn >> 2) ^ (row & (LR - 1)))) * 4 + (nn & 3)];
+                    }
+                };
+                if (wave < NI * NI) fetch(0, av[0], bv[0]);
+#pragma unroll
+                for (int q = 0; q < SLOTS; ++q) {
+                    if (wave + 4 * q < NI * NI) {
+                        if (q + 1 < SLOTS && wave + 4 * (q + 1) < NI * NI) fetch(q + 1, av[(q + 1) & 1], bv[(q + 1) & 1]);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) MF1(wacc[q], av[q & 1][e], bv[q & 1][e]);
+                    }
+                }
+            }
+            MP_STAMP(5);
+            lds_barrier();                                               // ---- M: the previous block's dL/dS has been consumed
+            MP_STAMP(6);
+            // ---- dL/dS = gz W  (K = the mapping's output dimension, in groups of four steps like the forward; W is read down a
+            //      column here: four strided words per step)
+            li = fresh(li0); lh = fresh(lh0);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int job = wave + 4 * jj;
+                if (job < NI) {
+                    const int ncol = job * 32 + li;
+                    const float* w0 = W + ncol;
+                    const float* ao = GZ + li * GS;
+                    f32x16 ag = zero16();
+                    float4 nb[4], an[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { nb[j] = wb0[jj][j]; an[j] = ld4(ao + 8 * j + 4 * lh); }
+#pragma unroll
+                    for (int g = 0; g < D / 32; ++g) {
+                        float4 cb[4], ca[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { cb[j] = nb[j]; ca[j] = an[j]; }
+                        if (g + 1 < D / 32) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int kk = 8 * (4 * (g + 1) + j) + 4 * lh;
+                                const float* p = w0 + (int64_t)kk * D;
+                                nb[j] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
+                                an[j] = ld4(ao + kk);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { MFMA4(ag, ca[j], cb[j]); }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        GX[row * GS + ncol] = ag[r];
+                    }
+                }
+            }
+            MP_STAMP(7);
+            lds_barrier();                                               // ---- E
+            MP_STAMP(8);
+        } else {
+            vm_wait<0>();                                                // T, mT, vT of this block and mS, vS of the previous one
+            MP_STAMP(1);
+            if (k > 0) apply(0, NQ / 2, S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            MP_STAMP(2);
+            lds_barrier();                                               // ---- X
+            if (k > 0) apply(NQ / 2, NQ, S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            if (has_next) stage(S, SS + (par ^ 1) * kRows * D, rid[r3n]);
+            if (adam) { stage(mS, SMS, rid[r3]); stage(vS, SVS, rid[r3]); }
+            MP_STAMP(3);
+            lds_barrier();                                               // ---- F
+            MP_STAMP(4);
+            apply(0, NQ / 2, T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
+            MP_STAMP(5);
+            lds_barrier();                                               // ---- M
+            apply(NQ / 2, NQ, T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
+            if (has_next) {
+                stage(T, ST, rid[r3n]);
+                if (adam) { stage(mT, SMT, rid[r3n]); stage(vT, SVT, rid[r3n]); vm_wait<5 * NQ>(); } else vm_wait<NQ>();
+            }                                                            // (the next block's source rows have landed)
+            MP_STAMP(7);
+            lds_barrier();                                               // ---- E
+            MP_STAMP(8);
+        }
+    }
+    if (rowwave) {                                                       // the last block's source rows
+        const int par = (k - 1) & 1, r3 = (k - 1) % 3;
+        vm_wait<0>();
+        apply(0, NQ, S, mS, vS, SS + par * kRows * D, SMS, SVS, GX, 1.f, rid[r3], rok[r3], ss_s, bc_s);
+    } else {
+        float* o = wpart + (size_t)blockIdx.x * ((size_t)net.ntiles * 1024 + net.nbias);
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int tile = wave + 4 * q;
+            if (tile < NI * NI) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)tile * 1024 + r * 64 + lane] = wacc[q][r];
+            }
+        }
+        lsum = wave_sum_d(lsum);
+        if (lane == 0) red[wave] = lsum;
+    }
+    __syncthreads();
+    if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(1024) void map_finish_kernel(map_net net, map_opt opt, map_params P, const float* __restrict__ wpart,
                                                          const double* __restrict__ lpart, int nwg, int64_t n, float* __restrict__ loss_out,
                                                          int64_t* step_s, int64_t* step_t) {
@@ -409,6 +742,10 @@ inline int wg_count(int64_t n, int per_cu = 2) {
 
 }  // namespace
 
+#ifdef CDR_MAP_PROF
+extern "C" int cdr_map_prof_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_map_prof), sizeof(long long) * 64); }
+#endif
+
 extern "C" int cdr_map_step_plan(int L, const int* dims, const int* has_bias, int64_t n, size_t* workspace_bytes) {
     CDR_CHECK_ARG(dims && workspace_bytes && n > 0);
     map_net net;
@@ -444,7 +781,11 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
             if (P.b[l]) { CDR_CHECK_ARG(mb && vb && step_b && mb[l] && vb[l] && step_b[l]); P.mb[l] = mb[l]; P.vb[l] = vb[l]; P.sb[l] = step_b[l]; }
         }
     }
-    const int nwg = wg_count(n, 2);        // (three resident workgroups per CU measured no faster and add a third more partials)
+    // the two-wave-group kernel for the shape it is written for (linear mapping without bias, Ds == Dt in {64, 128}, 16-B aligned
+    // weights); everything else takes the two-workgroups-per-CU kernel
+    const int Dp = dims[0];
+    const bool pipe = L == 1 && !net.b[0] && net.vec && dims[1] == Dp && (Dp == 64 || Dp == 128);
+    const int nwg = pipe ? wg_count(n, 1) : wg_count(n, 2);        // (three resident workgroups per CU measured no faster)
     const size_t wbytes = (size_t)nwg * ((size_t)net.ntiles * 1024 + net.nbias) * sizeof(float);
     const size_t woff = (wbytes + 255) & ~(size_t)255;
     CDR_CHECK_ARG(workspace_bytes >= woff + (size_t)nwg * sizeof(double));
@@ -452,6 +793,10 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
     double* lpart = (double*)((char*)workspace + woff);
     const bool few = net.ntiles <= 16;
     const void* fn = few ? (const void*)map_step_kernel<4> : (const void*)map_step_kernel<8>;
+    if (pipe) {
+        lds = ((size_t)2 * kRows * (Dp + 4) + 7 * (size_t)kRows * Dp) * sizeof(float);
+        fn = Dp == 128 ? (const void*)map_pipe_kernel<4> : (const void*)map_pipe_kernel<2>;
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cdr_set_error("cdr_map_step_unique: %zu B of LDS refused: %s", lds, hipGetErrorString(e)); return (int)e; }
@@ -461,8 +806,12 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
     {
         cdr_time_scope ts(ctx, CDR_TAG_MAP_STEP, s);
 #define MS_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, gx, to, wpart, lpart, P
-        if (few) map_step_kernel<4><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);
+#define MP_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, wpart, lpart, P
+        if (pipe && Dp == 128) map_pipe_kernel<4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe) map_pipe_kernel<2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (few) map_step_kernel<4><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);
         else map_step_kernel<8><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);
+#undef MP_ARGS
 #undef MS_ARGS
     }
     CDR_LAUNCH_CHECK();

@@ -243,7 +243,10 @@ def test_fused_step_vs_oracle(opt, D, k):
 
 
 @pytest.mark.parametrize('dims,opt,OB', [((64, 64), 'adam', 100), ((128, 128), 'adam', 1000), ((32, 48, 16), 'adam', 100),
-                                         ((128, 64, 128), 'adam', 257), ((64, 128, 64), 'sgd', 100), ((20, 12), 'adam', 33)])
+                                         ((128, 64, 128), 'adam', 257), ((64, 128, 64), 'sgd', 100), ((20, 12), 'adam', 33),
+                                         # the two-wave-group kernel (linear, D in {64, 128}) past one block per workgroup: 256
+                                         # workgroups x 32 ids = 8,192 ids per round -> 4 and 3 rounds, ragged last round and block
+                                         ((128, 128), 'adam', 30001), ((64, 64), 'adam', 20011), ((128, 128), 'sgd', 9000)])
 def test_map_step_unique_ids_vs_oracle(dims, opt, OB):
     """The two-launch OVERLAP step for batches of DISTINCT ids (what the reference's OverlapDataloader yields: slices of a
     shuffled arange, dataloader.py:37-52): three free-running steps == the oracle's step (autograd + lazy row-wise Adam on the
@@ -253,7 +256,7 @@ def test_map_step_unique_ids_vs_oracle(dims, opt, OB):
     from recbole_cdr_amd import binding as B_
     from recbole_cdr_amd.fused import FusedMapStep
     gen = torch.Generator().manual_seed(sum(dims) + OB)
-    rows, lr = 1500, 0.01
+    rows, lr = max(1500, OB + OB // 3), 0.01
     S, T = torch.randn(rows, dims[0], generator=gen) * 0.3, torch.randn(rows, dims[-1], generator=gen) * 0.3
     cpu, dev_params, fn = _make_mapping(list(dims), 3)
     if len(dims) == 2:
