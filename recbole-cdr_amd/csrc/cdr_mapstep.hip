@@ -19,6 +19,7 @@
 // by launch 1, read by launch 2), so the pair is hipGraph-capturable.  Batches with repeated ids take the general path
 // (fused.FusedMapStep: gather -> mapping -> MSE -> sort -> row-wise applies).
 #include <string.h>
+#include <type_traits>
 #include "cdr_common.h"
 
 namespace {
@@ -404,27 +405,41 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             glds16(tab + ids[row] * D + 4 * (p ^ (row & (LR - 1))), dst + i * 256);
         }
     };
-    // Adam / SGD on this lane's chunks of DMA instructions [q0, q1): g = sign * G[row][logical chunk]
-    auto apply = [&](int q0, int q1, float* __restrict__ tab, float* __restrict__ mtab, float* __restrict__ vtab, const float* stW,
+    // Adam / SGD on this lane's chunks of DMA instructions [Q0, Q1): g = sign * G[row][logical chunk].  Every operand of the
+    // whole range is requested before the arithmetic starts (one wave per role and SIMD: nothing else hides the LDS latency)
+    auto apply = [&](auto Q0c, auto Q1c, float* __restrict__ tab, float* __restrict__ mtab, float* __restrict__ vtab, const float* stW,
                      const float* stM, const float* stV, const float* G, float sign, const int64_t* ids, const float* ok,
                      float ssz, float bcs) {
+        constexpr int Q0 = decltype(Q0c)::value, Q1 = decltype(Q1c)::value, NQQ = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
+        if (Q1 <= Q0) return;
         const int ln = fresh(lane);
         const float rbc = 1.0f / bcs;
-        for (int q = q0; q < q1; ++q) {
-            const int i = pw + 4 * q, row = i * RPI + ln / LR, p = ln % LR, c = p ^ (row & (LR - 1));
-            if (ok[row] == 0.f) continue;
-            const int so = (row * LR + p) * 4;
-            const float4 w = ld4(stW + so), g = ld4(G + row * GS + 4 * c);
-            float4 m = z4, v = z4;
-            if (adam) { m = ld4(stM + so); v = ld4(stV + so); }
+        const int r0 = ln / LR, p = ln % LR;
+        float4 w[NQQ], g[NQQ], m[NQQ], v[NQQ];
+        int64_t o[NQQ];
+        float okf[NQQ];
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) {
+            const int row = (pw + 4 * (Q0 + q)) * RPI + r0, c = p ^ (row & (LR - 1)), so = (row * LR + p) * 4;
+            w[q] = ld4(stW + so); g[q] = ld4(G + row * GS + 4 * c);
+            m[q] = z4; v[q] = z4;
+            if (adam) { m[q] = ld4(stM + so); v[q] = ld4(stV + so); }
+            o[q] = ids[row] * D + 4 * c;
+            okf[q] = ok[row];
+        }
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) {
             float4 wn;
-            wn.x = updq(w.x, sign * g.x, m.x, v.x, opt, ssz, rbc); wn.y = updq(w.y, sign * g.y, m.y, v.y, opt, ssz, rbc);
-            wn.z = updq(w.z, sign * g.z, m.z, v.z, opt, ssz, rbc); wn.w = updq(w.w, sign * g.w, m.w, v.w, opt, ssz, rbc);
-            const int64_t o = ids[row] * D + 4 * c;
-            st4(tab + o, wn);
-            if (adam) { st4(mtab + o, m); st4(vtab + o, v); }
+            wn.x = updq(w[q].x, sign * g[q].x, m[q].x, v[q].x, opt, ssz, rbc); wn.y = updq(w[q].y, sign * g[q].y, m[q].y, v[q].y, opt, ssz, rbc);
+            wn.z = updq(w[q].z, sign * g[q].z, m[q].z, v[q].z, opt, ssz, rbc); wn.w = updq(w[q].w, sign * g[q].w, m[q].w, v[q].w, opt, ssz, rbc);
+            if (okf[q] != 0.f) {
+                st4(tab + o[q], wn);
+                if (adam) { st4(mtab + o[q], m[q]); st4(vtab + o[q], v[q]); }
+            }
         }
     };
+    using std::integral_constant;
+#define IC(v) integral_constant<int, (v)>{}
     if (t < kRows) {                                                     // ids of this workgroup's first block
         const int64_t g = (int64_t)blockIdx.x * kRows + t;
         rid[0][t] = idx[g < n ? g : n - 1];
@@ -529,11 +544,16 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
                     const int tile = wave + 4 * q, mt = tile / NI, nt = tile - mt * NI;
                     const int l_i = fresh(li0), l_h = fresh(lh0);
                     const int m = mt * 32 + l_i, nn = nt * 32 + l_i;
+                    // row = rc | (lh << 2) with rc = 8 (e >> 2) + (e & 3) a compile-time constant (bit 2 clear): the lane part of both
+                    // addresses is formed once, each word costs one XOR (the swizzle) and a read with an immediate offset
+                    const float* ga = GZ + (4 * l_h) * GS + m;
+                    const float* xb = Xs + (4 * l_h) * D + (nn & 3);
+                    const int cb = (nn >> 2) ^ (l_h << 2);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int row = 8 * (e >> 2) + 4 * l_h + (e & 3);
-                        a_[e] = GZ[row * GS + m];
-                        b_[e] = Xs[(row * LR + ((nn >> 2) ^ (row & (LR - 1)))) * 4 + (nn & 3)];
+                        const int rc = 8 * (e >> 2) + (e & 3);
+                        a_[e] = ga[rc * GS];
+                        b_[e] = xb[rc * D + ((cb ^ (rc & (LR - 1))) << 2)];
                     }
                 };
                 if (wave < NI * NI) fetch(0, av[0], bv[0]);
@@ -593,19 +613,19 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
         } else {
             vm_wait<0>();                                                // T, mT, vT of this block and mS, vS of the previous one
             MP_STAMP(1);
-            if (k > 0) apply(0, NQ / 2, S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            if (k > 0) apply(IC(0), IC(NQ / 2), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
             MP_STAMP(2);
             lds_barrier();                                               // ---- X
-            if (k > 0) apply(NQ / 2, NQ, S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            if (k > 0) apply(IC(NQ / 2), IC(NQ), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
             if (has_next) stage(S, SS + (par ^ 1) * kRows * D, rid[r3n]);
             if (adam) { stage(mS, SMS, rid[r3]); stage(vS, SVS, rid[r3]); }
             MP_STAMP(3);
             lds_barrier();                                               // ---- F
             MP_STAMP(4);
-            apply(0, NQ / 2, T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
+            apply(IC(0), IC(NQ / 2), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
             MP_STAMP(5);
             lds_barrier();                                               // ---- M
-            apply(NQ / 2, NQ, T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
+            apply(IC(NQ / 2), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
             if (has_next) {
                 stage(T, ST, rid[r3n]);
                 if (adam) { stage(mT, SMT, rid[r3n]); stage(vT, SVT, rid[r3n]); vm_wait<5 * NQ>(); } else vm_wait<NQ>();
@@ -618,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
     if (rowwave) {                                                       // the last block's source rows
         const int par = (k - 1) & 1, r3 = (k - 1) % 3;
         vm_wait<0>();
-        apply(0, NQ, S, mS, vS, SS + par * kRows * D, SMS, SVS, GX, 1.f, rid[r3], rok[r3], ss_s, bc_s);
+        apply(IC(0), IC(NQ), S, mS, vS, SS + par * kRows * D, SMS, SVS, GX, 1.f, rid[r3], rok[r3], ss_s, bc_s);
     } else {
         float* o = wpart + (size_t)blockIdx.x * ((size_t)net.ntiles * 1024 + net.nbias);
 #pragma unroll
