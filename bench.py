@@ -381,14 +381,21 @@ def run_c5(args, world, rank, dev):
             perm_ids = torch.randperm(OU - 1, device=dev, generator=gen)[:4 * OB] + 1
             idxs = [perm_ids[i * OB:(i + 1) * OB].view(-1, 1).contiguous() for i in range(4)]
             uniq = not sharded
-            for i in range(3):
+            for i in range(10):
                 fmap.step(idxs[i % 4], unique=uniq)
             barrier(world)
+            if uniq:
+                B_.timing_enable(dev, 128)                    # HIP events around the step's first launch, on the launch stream
             t0 = time.perf_counter()
-            for i in range(20):
+            for i in range(60):
                 fmap.step(idxs[i % 4], unique=uniq)
             barrier(world)
-            tm = torch.tensor([(time.perf_counter() - t0) / 20], device=dev, dtype=torch.float64)
+            tm = torch.tensor([(time.perf_counter() - t0) / 60], device=dev, dtype=torch.float64)
+            kms = None
+            if uniq:
+                ks = [ms for nm, ms in B_.timing_collect(dev) if nm == 'map_step_kernel']
+                B_.timing_enable(dev, 0)
+                kms = sum(ks) / len(ks) if ks else None
             if world > 1:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             ob_bytes = OB * 2 * 6 * 4 * D                      # two rows per id, 6 x 4D bytes per row
@@ -398,6 +405,13 @@ def run_c5(args, world, rank, dev):
                                        'roofline': {'bound': 'hbm', 'achieved': ob_bytes / float(tm) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                     'frac': ob_bytes / float(tm) / 1e9 / HBM_PEAK_GBS,
                                                     'algorithmic_bytes': ob_bytes, 'what': '6,144 B per id (SURVEY 8d), wall time of the whole step'}}
+            if kms:
+                # the step's first launch does all of the table traffic (the second reduces the mapping's gradient partials)
+                result['overlap_phase']['roofline_kernel'] = {
+                    'bound': 'hbm', 'kernel': 'map_pipe_kernel (cdr_map_step_unique, launch 1 of 2)', 'avg_launch_ms': kms,
+                    'achieved': ob_bytes / (kms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': ob_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes': ob_bytes,
+                    'traffic': pmc_traffic('map_step_kernel')}
             if uniq:
                 small = [perm_ids[i * 100:(i + 1) * 100].view(-1, 1).contiguous() for i in range(4)]
                 for i in range(3):
@@ -407,6 +421,27 @@ def run_c5(args, world, rank, dev):
                     fmap.step(small[i % 4], unique=True)
                 torch.cuda.synchronize()
                 result['overlap_phase']['ob100_ms_per_step'] = (time.perf_counter() - t0) / 200 * 1e3
+                # the reference's DEFAULT mapping is the tanh MLP (properties/model/EMCDR.yaml: non_linear, hidden 128): the same two-launch
+                # step on its general-shape kernel (the wave-group kernel above is written for the linear mapping)
+                W1, b1 = torch.nn.Parameter(xavier_table(128, D, D, gen, dev)), torch.nn.Parameter(torch.zeros(128, device=dev))
+                W2, b2 = torch.nn.Parameter(xavier_table(D, 128, 128, gen, dev)), torch.nn.Parameter(torch.zeros(D, device=dev))
+                fmlp = FusedMapStep(tabs['su'], tabs['tu'],
+                                    lambda x: F_.linear(F_.linear(x, W1, b1, B_.ACT_TANH), W2, b2, B_.ACT_NONE), [W1, b1, W2, b2], 65536,
+                                    opt=args.opt, layers=[(W1, b1, B_.ACT_TANH), (W2, b2, B_.ACT_NONE)],
+                                    source_state=steps['source'].ustate, target_state=steps['target'].ustate)
+                nl = {}
+                for name, id_lists, reps in (('OB=65536', idxs, 20), ('OB=100', small, 200)):
+                    for i in range(3):
+                        fmlp.step(id_lists[i % 4], unique=True)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for i in range(reps):
+                        fmlp.step(id_lists[i % 4], unique=True)
+                    torch.cuda.synchronize()
+                    nl[name + '_ms_per_step'] = (time.perf_counter() - t0) / reps * 1e3
+                nl['mapping'] = 'tanh MLP %d-128-%d' % (D, D)
+                nl['frac_of_hbm_peak_at_OB=65536'] = ob_bytes / (nl['OB=65536_ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                result['overlap_phase']['non_linear'] = nl
+                del fmlp
             del fmap                                   # it shares (and would keep alive) the user tables' Adam moments
 
     except Exception as e:  # noqa: BLE001

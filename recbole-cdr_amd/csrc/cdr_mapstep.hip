@@ -5,7 +5,12 @@
 // of one batch are DISTINCT.  Every row is then touched by exactly one occurrence, so nothing has to be sorted or
 // de-duplicated and the optimizer can run where the gradient is produced:
 //
-//   map_step_kernel     a workgroup owns 32 ids at a time: gathers S[id] and T[id] into LDS, runs the mapping function
+//   map_pipe_kernel     (the linear mapping, Ds == Dt in {64, 128}: EMCDR's default and BASELINE C5) one 512-thread workgroup per
+//                       CU: four MFMA waves do forward / loss / weight-gradient tiles / dL/dS on 32 ids at a time out of LDS, four
+//                       row waves keep the next block's six rows per id in flight with LDS DMA and apply SGD / Adam to the
+//                       two table rows in place -- see the comment above the kernel.  3.3 TB/s at OB = 65,536.
+//   map_step_kernel     (every other mapping shape: tanh MLPs, biases, Ds != Dt) a workgroup owns 32 ids at a time: gathers S[id]
+//                       and T[id] into LDS, runs the mapping function
 //                       (Linear, or Linear+Tanh ... Linear) on v_mfma_f32_32x32x2_f32 with the activations in LDS,
 //                       d = mapped - T[id] (MSE partial), walks the mapping backwards to dL/dS[id], accumulates the mapping's
 //                       weight gradients of ALL its ids in registers (gz^T x input, one accumulator per 32x32 tile), and
@@ -397,14 +402,43 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
     auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
     // ---- row waves: lane <-> (row, physical chunk) of DMA instruction i = pw + 4 q, q < NQ
     const int pw = wave - 4;
-    auto stage = [&](const float* __restrict__ tab, float* dst, const int64_t* ids) {
+    // byte offsets of this lane's NQ chunks inside a table, for the rows of one block: all ids are read from LDS first (one wait),
+    // and the result serves every table staged for that block
+    auto row_offsets = [&](const int64_t* ids, int64_t (&off)[NQ]) {
         const int ln = fresh(lane);
+        int64_t idv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) idv[q] = ids[(pw + 4 * q) * RPI + ln / LR];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int i = pw + 4 * q, row = i * RPI + ln / LR, p = ln % LR;
-            glds16(tab + ids[row] * D + 4 * (p ^ (row & (LR - 1))), dst + i * 256);
+            const int row = (pw + 4 * q) * RPI + ln / LR, p = ln % LR;
+            off[q] = (idv[q] * D + 4 * (p ^ (row & (LR - 1)))) * (int64_t)sizeof(float);
         }
     };
+    // NQ DMA instructions of one table in ONE asm statement: M0 saved once, set per instruction, restored once
+    auto stage = [&](const float* __restrict__ tab, unsigned dst_bytes, const int64_t (&off)[NQ]) {
+        const char* base = reinterpret_cast<const char*>(tab);
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(dst_bytes + (unsigned)pw * 1024u);   // instruction i = pw + 4 q writes 1 KiB at i * 1 KiB
+        unsigned keep;
+        if constexpr (NQ == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]),
+                           "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u), "s"(d0 + 12288u)
+                         : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(base + off[0]), "v"(base + off[1]), "s"(d0), "s"(d0 + 4096u) : "memory");
+    };
+    auto lds_off = [](const float* p) {
+        return (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+    };
+    const unsigned bSS = lds_off(SS), bST = lds_off(ST), bSMT = lds_off(SMT), bSVT = lds_off(SVT), bSMS = lds_off(SMS), bSVS = lds_off(SVS);
+    int64_t roff[NQ];
     // Adam / SGD on this lane's chunks of DMA instructions [Q0, Q1): g = sign * G[row][logical chunk].  Every operand of the
     // whole range is requested before the arithmetic starts (one wave per role and SIMD: nothing else hides the LDS latency)
     auto apply = [&](auto Q0c, auto Q1c, float* __restrict__ tab, float* __restrict__ mtab, float* __restrict__ vtab, const float* stW,
@@ -448,26 +482,28 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
     __syncthreads();
     if (rowwave) {
         __builtin_amdgcn_s_setprio(3);
-        stage(S, SS, rid[0]);
-        stage(T, ST, rid[0]);
-        if (adam) { stage(mT, SMT, rid[0]); stage(vT, SVT, rid[0]); }
+        row_offsets(rid[0], roff);
+        stage(S, bSS, roff);
+        stage(T, bST, roff);
+        if (adam) { stage(mT, bSMT, roff); stage(vT, bSVT, roff); }
         vm_wait<0>();
     }
     lds_barrier();
-    // group-0 weights of the forward and of the dL/dS contraction: loaded once, resident across blocks (their L2 latency would
-    // otherwise open every MFMA phase)
-    float4 wf0[NJ][4], wb0[NJ][4];
+    // weights that stay in registers across blocks: ALL of the dL/dS contraction's (it reads W down a column -- 4-byte strided
+    // loads whose L2 latency under the step's HBM load no one-group look-ahead covers) and the first K group of the forward's
+    float4 wf0[NJ][4], wb[NJ][D / 8];
     if (!rowwave) {
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             const int job = wave + 4 * jj;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wf0[jj][j] = z4; wb0[jj][j] = z4;
+            for (int j = 0; j < 4; ++j) wf0[jj][j] = job < NI ? ld4(W + (int64_t)(job * 32 + li0) * D + 8 * j + 4 * lh0) : z4;
+#pragma unroll
+            for (int s8 = 0; s8 < D / 8; ++s8) {
+                wb[jj][s8] = z4;
                 if (job < NI) {
-                    wf0[jj][j] = ld4(W + (int64_t)(job * 32 + li0) * D + 8 * j + 4 * lh0);
-                    const float* p = W + (int64_t)(8 * j + 4 * lh0) * D + job * 32 + li0;
-                    wb0[jj][j] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
+                    const float* p = W + (int64_t)(8 * s8 + 4 * lh0) * D + job * 32 + li0;
+                    wb[jj][s8] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
                 }
             }
         }
@@ -577,28 +613,22 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
                 const int job = wave + 4 * jj;
                 if (job < NI) {
                     const int ncol = job * 32 + li;
-                    const float* w0 = W + ncol;
-                    const float* ao = GZ + li * GS;
+                    const float* ao = GZ + li * GS + 4 * lh;
                     f32x16 ag = zero16();
-                    float4 nb[4], an[4];
+                    float4 an[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { nb[j] = wb0[jj][j]; an[j] = ld4(ao + 8 * j + 4 * lh); }
+                    for (int j = 0; j < 4; ++j) an[j] = ld4(ao + 8 * j);
 #pragma unroll
                     for (int g = 0; g < D / 32; ++g) {
-                        float4 cb[4], ca[4];
+                        float4 ca[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { cb[j] = nb[j]; ca[j] = an[j]; }
+                        for (int j = 0; j < 4; ++j) ca[j] = an[j];
                         if (g + 1 < D / 32) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int kk = 8 * (4 * (g + 1) + j) + 4 * lh;
-                                const float* p = w0 + (int64_t)kk * D;
-                                nb[j] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
-                                an[j] = ld4(ao + kk);
-                            }
+                            for (int j = 0; j < 4; ++j) an[j] = ld4(ao + 8 * (4 * (g + 1) + j));
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { MFMA4(ag, ca[j], cb[j]); }
+                        for (int j = 0; j < 4; ++j) { MFMA4(ag, ca[j], wb[jj][4 * g + j]); }
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -617,8 +647,8 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             MP_STAMP(2);
             lds_barrier();                                               // ---- X
             if (k > 0) apply(IC(NQ / 2), IC(NQ), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
-            if (has_next) stage(S, SS + (par ^ 1) * kRows * D, rid[r3n]);
-            if (adam) { stage(mS, SMS, rid[r3]); stage(vS, SVS, rid[r3]); }
+            if (has_next) { row_offsets(rid[r3n], roff); stage(S, bSS + (unsigned)((par ^ 1) * kRows * D * 4), roff); }
+            if (adam) { row_offsets(rid[r3], roff); stage(mS, bSMS, roff); stage(vS, bSVS, roff); }
             MP_STAMP(3);
             lds_barrier();                                               // ---- F
             MP_STAMP(4);
@@ -627,8 +657,9 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             lds_barrier();                                               // ---- M
             apply(IC(NQ / 2), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
             if (has_next) {
-                stage(T, ST, rid[r3n]);
-                if (adam) { stage(mT, SMT, rid[r3n]); stage(vT, SVT, rid[r3n]); vm_wait<5 * NQ>(); } else vm_wait<NQ>();
+                row_offsets(rid[r3n], roff);
+                stage(T, bST, roff);
+                if (adam) { stage(mT, bSMT, roff); stage(vT, bSVT, roff); vm_wait<5 * NQ>(); } else vm_wait<NQ>();
             }                                                            // (the next block's source rows have landed)
             MP_STAMP(7);
             lds_barrier();                                               // ---- E

@@ -571,6 +571,17 @@ def test_bench_multi_rank_line_contract(world, extra):
     assert d['exchange']['bytes_to_other_ranks_per_step_per_rank'] >= 0
     assert 0 < d['final_loss'] < 1 and d['overlap_phase']['loss'] >= 0
     assert d['fullsort']['U=1']['masked_top10']['ms'] > 0 and d['fullsort']['U=1024']['items_per_s'] > 0
+    # BOTH layouts of the C5 tables in the one record: north_star's row shard and the dimension shard, each with its
+    # own whole-job value, exchange bytes and sharding label; the headline fields are the first one's
+    lay = d['layouts']
+    assert set(lay) == {'dim', 'row'} and 'leg_errors' not in d, d.get('leg_errors')
+    first = 'row' if extra else 'dim'
+    assert lay[first]['value'] == d['value'] and lay[first]['ms_per_step'] == d['ms_per_step']
+    for name, rec in lay.items():
+        assert rec['n_gpus'] == world and rec['value'] > 0 and rec['scaling'] == 'weak' and name in rec['sharding'].lower(), (name, rec)
+        assert rec['exchange']['bytes_to_other_ranks_per_step_per_rank'] >= 0
+    if world > 1:
+        assert lay['row']['exchange']['bytes_to_other_ranks_per_step_per_rank'] > lay['dim']['exchange']['bytes_to_other_ranks_per_step_per_rank']
 
 
 def _dist_ckpt_worker(rank, world, port, path, q):

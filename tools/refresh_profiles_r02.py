@@ -37,7 +37,7 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
         raw[k]['dispatches_' + C] = len(big)
         raw[k]['all_dispatches'] = len(vals)
         raw[k]['sum_' + C + '_KiB'] = round(sum(vals), 2)
-    keep = [r for r in rows if any(s in r['Kernel_Name'] for s in ('rowwise_apply', 'bpr_fwd', 'apply2', 'map_step', 'seg_piece', 'seg_long', 'radix_sort', 'make_keys', 'rank_'))]
+    keep = [r for r in rows if any(s in r['Kernel_Name'] for s in ('rowwise_apply', 'bpr_fwd', 'apply2', 'map_step', 'map_pipe', 'seg_piece', 'seg_long', 'radix_sort', 'make_keys', 'rank_'))]
     with open(os.path.join(prof, f'{tag}_pmc_{C}_dispatches.csv'), 'w', newline='') as fh:
         w = csv.DictWriter(fh, fieldnames=['Dispatch_Id', 'Grid_Size', 'Kernel_Name', 'Counter_Name', 'Counter_Value'])
         w.writeheader()
@@ -50,7 +50,7 @@ find = lambda pat: next((k for k in raw if pat in k), None)
 names = {'bpr_fwd_grad_kernel': find('bpr_fwd_grad_kernel<32, false>'), 'rowwise_apply_kernel(users)': find('rowwise_apply_kernel<32, 1, false>'),
          'rowwise_apply_kernel(items)': find('rowwise_apply_kernel<32, 1, true>'), 'bpr_fwd_kmajor_kernel(k=4)': find('bpr_fwd_kmajor_kernel<32, 4, 2>'),
          'apply2_kernel(items, coefficient x user row)': find('apply2_kernel<32, 1, 1>'), 'apply2_kernel(users, S rows)': find('apply2_kernel<32, 1, 0>'),
-         'map_step_kernel': find('map_step_kernel')}
+         'map_step_kernel': find('map_pipe_kernel') or find('map_step_kernel')}   # the OVERLAP step's first launch, whichever form ran
 o = {'_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of `python bench.py --no-cpu-baseline --no-fullsort '
               '--steps 3 --warmup 1`, tools/profile_r02.sh; B = 1,048,576 triples per domain, D = 128, row-wise Adam). FETCH_SIZE x 1024 x 2 (gfx950 '
               'wide-stream correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024. Mean over each kernel\'s large dispatches (the small-batch '
