@@ -1577,6 +1577,58 @@ def test_full_c5_size_properties():
     assert torch.equal(tv, want.values) and torch.equal(torch.gather(s64, 1, ti), want.values)
 
 
+def test_full_c5_size_overlap_step_properties():
+    """The OVERLAP step at BASELINE C5 sizes (two user tables of 50,000,001 x 128 with Adam moments: 154 GB; 65,536 distinct ids
+    per step = 8 rounds of 32-id blocks per workgroup of map_pipe_kernel), through size-independent properties:
+      * lr = 0 leaves every touched row of both tables bit-identical;
+      * three Adam steps through the two-launch path == the same three steps through the general (sorting) path from the same start:
+        losses at 1e-5, touched rows / moments / mapping within the Adam-step conditioning bound, rows outside the batches never
+        written (bit-exact);
+      * the three steps are bit-reproducible from the same start."""
+    from recbole_cdr_amd import functional as F_, binding as B_
+    from recbole_cdr_amd.fused import FusedMapStep
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 170e9:
+        pytest.skip('needs ~160 GB of free HBM')
+    nu, D, OB, lr = 50_000_001, 128, 65536, 1e-3
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    S = torch.empty(nu, D, device=DEV).normal_(0, 0.05, generator=g)
+    T = torch.empty(nu, D, device=DEV).normal_(0, 0.05, generator=g)
+    W0 = torch.randn(D, D, device=DEV, generator=g) * 0.05
+    ids = (torch.randperm(nu - 1, device=DEV, generator=g)[:3 * OB] + 1)
+    batches = [ids[i * OB:(i + 1) * OB].view(-1, 1).contiguous() for i in range(3)]
+    touched = ids
+    outside = torch.randint(1, nu, (4096,), device=DEV, generator=g)
+    outside = outside[~torch.isin(outside, touched)]
+    S0, T0, So, To = S[touched].clone(), T[touched].clone(), S[outside].clone(), T[outside].clone()
+
+    def make(opt, lr_):
+        W = torch.nn.Parameter(W0.clone())
+        return W, FusedMapStep(S, T, lambda x: F_.linear(x, W, None, B_.ACT_NONE), [W], OB, opt=opt, lr=lr_, layers=[(W, None, B_.ACT_NONE)])
+    W, fm = make('sgd', 0.0)
+    fm.step(batches[0], unique=True)
+    assert torch.equal(S[touched], S0) and torch.equal(T[touched], T0)
+    del fm
+    runs = []
+    for unique in (True, False, True):
+        S[touched] = S0; T[touched] = T0
+        W, fm = make('adam', lr)
+        losses = [float(fm.step(b, **({'unique': True} if unique else {}))) for b in batches]
+        runs.append((losses, S[touched].clone(), T[touched].clone(), fm.sstate.exp_avg[touched].clone(), fm.tstate.exp_avg_sq[touched].clone(),
+                     W.detach().clone()))
+        assert torch.equal(S[outside], So) and torch.equal(T[outside], To)
+        del fm
+        torch.cuda.empty_cache()
+    a, b, c = runs
+    assert_close(torch.tensor(a[0]), torch.tensor(b[0]), what='losses, two paths')
+    tol = dict(rtol=1e-5, atol=lr * 1e-2)          # Adam's lr * m / (sqrt(v) + eps) is ill-conditioned where |g| ~ eps (see the small-size test)
+    assert_close(a[1], b[1], what='S rows', **tol); assert_close(a[2], b[2], what='T rows', **tol)
+    assert_close(a[3], b[3], what='exp_avg S'); assert_close(a[4], b[4], what='exp_avg_sq T')
+    assert_close(a[5], b[5], what='mapping', **tol)
+    assert a[0] == c[0] and all(torch.equal(x, y) for x, y in zip(a[1:], c[1:])), 'the two-launch path must be bit-reproducible'
+    assert float((a[1] - S0).abs().max()) > 0 and float((a[2] - T0).abs().max()) > 0
+
+
 @pytest.mark.parametrize('loss', ['mse', 'bce'])
 @pytest.mark.parametrize('opt,D', [('sgd', 64), ('adam', 128), ('adam', 16)])
 def test_fused_point_step_vs_oracle(loss, opt, D):
