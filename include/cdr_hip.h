@@ -164,7 +164,8 @@ int cdr_fullsort_neg_sqdist_f32(void* stream, const float* user_e, int64_t U, in
 /* ---- elementwise helpers used by the model mirrors --------------------------------------------------------- */
 /* d/dx of act given y = act(x): gx = gy * act'(y)  (tanh: 1-y^2, relu: y>0, sigmoid: y(1-y)) ; in place allowed */
 int cdr_act_bwd(void* stream, int act, const float* y, const float* gy, float* gx, int64_t n);
-/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients, batch reductions of per-row parameter-gradient partials): two launches,
+ * fixed summation order (slab partials in the context's scratch, added in slab order): bit-reproducible */
 int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate);
 /* mean-squared error over all elements + its gradient: out[0] = mean((a-b)^2) ; ga = 2(a-b)/n * grad_out       */
 int cdr_mse_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* b, int64_t n, float* out1);

@@ -92,22 +92,38 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(int act, const float* _
     }
 }
 
-// ---- column sums (bias gradients): block = 64 columns x a 256-row slab, rows strided over the 4 waves; slabs combine
-// with one fp32 atomic per column per block into a pre-zeroed (or accumulated-into) output ----------------------------
-constexpr int kColsumRows = 256;
-__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int64_t M, int64_t N,
-                                                        float* __restrict__ out) {
+// ---- column sums (bias gradients; batch reductions of per-row parameter-gradient partials): two passes, FIXED summation order.
+// Pass 1: block = 64 columns x one slab of rows, the slab's rows strided over the 4 waves with four independent accumulators per
+// lane (a wave's loads are 256-B row pieces: the chain of dependent adds, not bandwidth, bounded the old one-accumulator loop at
+// 12 us for 4,096 x 64); the four waves' sums are added in wave order.  Pass 2: one thread per column adds the slabs in slab order.
+constexpr int kColsumMaxSlabs = 128;
+__global__ __launch_bounds__(kBlock) void colsum_slab_kernel(const float* __restrict__ X, int64_t M, int64_t N, int64_t rows_per_slab,
+                                                             float* __restrict__ part) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t r0 = (int64_t)blockIdx.y * kColsumRows;
-    const int64_t r1 = r0 + kColsumRows < M ? r0 + kColsumRows : M;
-    float s = 0.f;
-    if (col < N)
-        for (int64_t m = r0 + wave; m < r1; m += 4) s += X[m * N + col];
-    sm[wave][lane] = s;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    const int64_t r1 = r0 + rows_per_slab < M ? r0 + rows_per_slab : M;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < N) {
+        int64_t m = r0 + wave;
+        for (; m + 12 < r1; m += 16) {
+            s0 += X[m * N + col]; s1 += X[(m + 4) * N + col]; s2 += X[(m + 8) * N + col]; s3 += X[(m + 12) * N + col];
+        }
+        for (; m < r1; m += 4) s0 += X[m * N + col];
+    }
+    sm[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && col < N) atomicAdd(out + col, ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane]);
+    if (wave == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+}
+
+__global__ __launch_bounds__(kBlock) void colsum_finish_kernel(const float* __restrict__ part, int slabs, int64_t N, int accumulate,
+                                                               float* __restrict__ out) {
+    const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < slabs; ++b) s += part[(int64_t)b * N + col];
+    out[col] = accumulate ? out[col] + s : s;
 }
 
 // ---- MSE ------------------------------------------------------------------------------------------------------------
@@ -314,11 +330,17 @@ extern "C" int cdr_act_bwd(void* stream, int act, const float* y, const float* g
 }
 
 extern "C" int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate) {
-    (void)ctx;
-    CDR_CHECK_ARG(X && out && M > 0 && N > 0);
-    if (!accumulate) CDR_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
-    colsum_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)((M + kColsumRows - 1) / kColsumRows)), dim3(kBlock), 0,
-                    (hipStream_t)stream>>>(X, M, N, out);
+    CDR_CHECK_ARG(ctx && X && out && M > 0 && N > 0);
+    int64_t rows_per_slab = 64;
+    int64_t slabs = (M + rows_per_slab - 1) / rows_per_slab;
+    if (slabs > kColsumMaxSlabs) { rows_per_slab = (M + kColsumMaxSlabs - 1) / kColsumMaxSlabs; slabs = (M + rows_per_slab - 1) / rows_per_slab; }
+    void* part = nullptr;
+    int rc = cdr_ctx_scratch(ctx, (size_t)slabs * (size_t)N * sizeof(float), &part);
+    if (rc != CDR_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    colsum_slab_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)slabs), dim3(kBlock), 0, s>>>(X, M, N, rows_per_slab, (float*)part);
+    CDR_LAUNCH_CHECK();
+    colsum_finish_kernel<<<dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>((const float*)part, (int)slabs, N, accumulate, out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

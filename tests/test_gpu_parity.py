@@ -2037,3 +2037,23 @@ def test_topk_merge_shards_orders_by_value_then_item_id(G, U, k):
         want_v = [-c[0] for c in cand[:k]] + [-float('inf')] * max(0, k - len(cand))
         assert oi[u].tolist() == want_i, u
         assert ov[u].tolist() == want_v, u
+
+
+@pytest.mark.parametrize('M,N', [(1, 1), (63, 64), (4096, 64), (100_000, 12), (70_001, 130), (3, 1000)])
+def test_colsum_fixed_order(M, N):
+    """cdr_colsum: two-pass column sums against an fp64 reference, bit-reproducible across calls (no atomics), accumulate mode."""
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(M + N)
+    x = torch.randn(M, N, device=DEV)
+    want = x.double().sum(0)
+    outs = []
+    for _ in range(3):
+        out = torch.empty(N, device=DEV)
+        B_.call('cdr_colsum', B_.ctx(x.device), B_.stream(), B_.f32(x), M, N, B_.f32(out), 0)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    scale = float(x.abs().sum(0).max())
+    assert float((outs[0].double() - want).abs().max()) <= 1e-6 * scale
+    acc = outs[0].clone()
+    B_.call('cdr_colsum', B_.ctx(x.device), B_.stream(), B_.f32(x), M, N, B_.f32(acc), 1)
+    assert float((acc.double() - 2 * want).abs().max()) <= 2e-6 * scale
