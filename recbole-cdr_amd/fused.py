@@ -416,6 +416,51 @@ class FusedMapStep:
         self.loss = self._loss1[0]
         return self.loss
 
+    # ---- hipGraph replay of the two-launch step (the reference's default overlap_batch_size is 100: launch-bound) ----------------
+    def capture(self, OB):
+        """Capture the distinct-id step for batches of exactly OB ids.  ``replay(idx)`` then costs one id copy + one graph launch;
+        every update count the kernels read lives on the device."""
+        assert self.layers is not None and self.group is None
+        dev = self.S.device
+        self._OB = OB
+        self._idx = torch.arange(1, OB + 1, device=dev, dtype=torch.int64)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            B_.ctx(dev)                                   # the native context of the capture stream must exist beforehand
+            if self.opt == OPT_ADAM:
+                self.sstate.step_dev, self.tstate.step_dev
+                for w, b, _ in self.layers:                # the mapping's Adam state and the workspace: created outside the capture
+                    for prm in (w, b):
+                        if prm is not None and not self.map_opt.state[prm]:
+                            d = self.map_opt.state[prm]
+                            d['step'] = torch.zeros(1, device=dev, dtype=torch.int64)
+                            d['exp_avg'] = torch.zeros_like(prm); d['exp_avg_sq'] = torch.zeros_like(prm)
+            need = ctypes.c_size_t(0)
+            L = len(self.layers)
+            B_._check(B_.load().cdr_map_step_plan(L, (ctypes.c_int * (L + 1))(*self._dims),
+                                                  (ctypes.c_int * L)(*[int(b is not None) for _, b, _ in self.layers]), OB,
+                                                  ctypes.byref(need)), 'cdr_map_step_plan')
+            if self._uws is None or self._uws.numel() < need.value:
+                self._uws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        host = (self.sstate._step, self.tstate._step)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=side):
+            self._step_unique(self._idx)
+        self.sstate._step, self.tstate._step = host       # the capture enqueued nothing: host counts advance per replay
+        return self
+
+    def replay(self, idx=None):
+        if idx is not None:
+            self._idx.copy_(idx.reshape(-1)[:self._OB])
+        self._graph.replay()
+        self.sstate.advance(device_bumped=True)
+        self.tstate.advance(device_bumped=True)
+        self.loss = self._loss1[0]
+        return self.loss
+
     def _route(self, idx):
         """Global ids -> the local row indices this rank owns (one all-to-all of ids), plus the global batch size."""
         import torch.distributed as dist

@@ -2057,3 +2057,35 @@ def test_colsum_fixed_order(M, N):
     acc = outs[0].clone()
     B_.call('cdr_colsum', B_.ctx(x.device), B_.stream(), B_.f32(x), M, N, B_.f32(acc), 1)
     assert float((acc.double() - 2 * want).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize('dims,OB', [((128, 128), 100), ((64, 64), 9000), ((32, 48, 16), 100)])
+def test_map_step_unique_replays_as_hipgraph_bit_equal(dims, OB):
+    """FusedMapStep.capture / replay: the two-launch OVERLAP step as one hipGraph (Adam update counts on the device) leaves tables,
+    moments, mapping and losses BIT-identical to the same steps launched eagerly, on changing id batches."""
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.fused import FusedMapStep
+    gen = torch.Generator().manual_seed(sum(dims) + OB)
+    rows = 2 * OB + 500
+    S, T = torch.randn(rows, dims[0], generator=gen) * 0.3, torch.randn(rows, dims[-1], generator=gen) * 0.3
+    batches = [torch.randperm(rows, generator=gen)[:OB].view(-1, 1).to(DEV) for _ in range(4)]
+    runs = []
+    for graphed in (False, True):
+        _, params, fn = _make_mapping(list(dims), 3)
+        if len(dims) == 2:
+            layers = [(params[0], None, B_.ACT_NONE)]
+        else:
+            L = len(dims) - 1
+            layers = [(params[2 * n], params[2 * n + 1], B_.ACT_TANH if n != L - 1 else B_.ACT_NONE) for n in range(L)]
+        Sd, Td = S.clone().to(DEV), T.clone().to(DEV)
+        fm = FusedMapStep(Sd, Td, fn, params, OB, opt='adam', lr=0.01, layers=layers)
+        if graphed:
+            fm.capture(OB)
+            losses = [fm.replay(b).clone() for b in batches]
+        else:
+            losses = [fm.step(b, unique=True).clone() for b in batches]
+        assert fm.sstate.step == 4 and int(fm.sstate.step_dev) == 4
+        runs.append((torch.stack(losses), Sd, Td, fm.sstate.exp_avg, fm.tstate.exp_avg_sq, [p.detach().clone() for p in params]))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert all(torch.equal(x, y) for x, y in zip(a[5], b[5]))

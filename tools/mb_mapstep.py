@@ -30,6 +30,14 @@ for kind in ('linear', 'mlp'):
         perm = torch.randperm(NU - 1, device=dev, generator=g)[:OB * 8] + 1
         idxs = [perm[i * OB:(i + 1) * OB].view(-1, 1).contiguous() for i in range(8)]
         fm = FusedMapStep(S, T, fn, params, OB, opt='adam', lr=1e-3, layers=layers, source_state=ss, target_state=ts_)
+        fm.capture(OB)
+        for i in range(5):
+            fm.replay(idxs[i % 8])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(200):
+            fm.replay(idxs[i % 8])
+        torch.cuda.synchronize()
+        print('%-6s OB %6d %-12s: %.4f ms per step (wall), one id copy + one graph launch' % (kind, OB, 'hipGraph', (time.perf_counter() - t0) / 200 * 1e3))
         for name, kw in (('general', {}), ('distinct-ids', {'unique': True})):
             for i in range(5):
                 fm.step(idxs[i % 8], **kw)
