@@ -9,7 +9,9 @@
 //                       CU: four MFMA waves do forward / loss / weight-gradient tiles / dL/dS on 32 ids at a time out of LDS, four
 //                       row waves keep the next block's six rows per id in flight with LDS DMA and apply SGD / Adam to the
 //                       two table rows in place -- see the comment above the kernel.  3.3 TB/s at OB = 65,536.
-//   map_step_kernel     (every other mapping shape: tanh MLPs, biases, Ds != Dt) a workgroup owns 32 ids at a time: gathers S[id]
+//   map_pipe2_kernel    the same two wave groups for the reference's default mapping, Linear + Tanh + Linear with D and H in {64, 128}
+//                       (gz and dL/dS share an LDS buffer; seven barriers per block): 1.6-1.8 TB/s.
+//   map_step_kernel     (every other mapping shape: deeper MLPs, odd widths, Ds != Dt) a workgroup owns 32 ids at a time: gathers S[id]
 //                       and T[id] into LDS, runs the mapping function
 //                       (Linear, or Linear+Tanh ... Linear) on v_mfma_f32_32x32x2_f32 with the activations in LDS,
 //                       d = mapped - T[id] (MSE partial), walks the mapping backwards to dL/dS[id], accumulates the mapping's
@@ -687,6 +689,394 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
     if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- the same two wave groups for the reference's DEFAULT mapping: Linear(D, H) + Tanh + Linear(H, D) (emcdr.py:86-93;
+// properties/model/EMCDR.yaml: non_linear, hidden 128), D and H in {64, 128} ----------------------------------------------------
+// Twice the MFMA phases per block (two forwards, two weight-gradient phases, two data-gradient phases: seven barriers) around the same
+// row-wave schedule.  LDS: one more operand buffer (the hidden activations) does not fit beside everything else, so gz = dL/d mapped and
+// dL/dS SHARE a buffer -- gz is dead once the target rows are updated and the first layer's backward has run, dL/dS is dead once the
+// source rows are updated, which the row waves finish before the next block's forward reaches its epilogue.  Weights come from L2
+// (32 weight-gradient tiles take half of the register file).
+template <int NI, int NHI>
+__global__ __launch_bounds__(512, 1) void map_pipe2_kernel(map_net net, map_opt opt, float* __restrict__ S, float* __restrict__ mS,
+                                                         float* __restrict__ vS, float* __restrict__ T, float* __restrict__ mT,
+                                                         float* __restrict__ vT, const int64_t* __restrict__ idx, int64_t n,
+                                                         const int64_t* __restrict__ step_s, const int64_t* __restrict__ step_t,
+                                                         float* __restrict__ wpart, double* __restrict__ lpart, map_params bump) {
+    constexpr int D = 32 * NI;                 // Ds == Dt
+    constexpr int H = 32 * NHI;                // hidden width
+    constexpr int HS = H + 4;
+    constexpr int LR = D / 4;                  // 16-byte chunks (= DMA lanes) per row
+    constexpr int RPI = 64 / LR;               // rows per DMA instruction (1 KiB of LDS)
+    constexpr int GS = D + 4;                  // padded row stride of the two MFMA-written buffers
+    constexpr int TL = NI * NHI;               // weight-gradient tiles per layer (layer 0: [H][D], layer 1: [D][H])
+    constexpr int SL = TL / 4;                 // ... per MFMA wave and layer (TL is a multiple of 4)
+    constexpr int NJD = (NI + 3) / 4, NJH = (NHI + 3) / 4;      // 32-column jobs per MFMA wave over D / over H
+    constexpr int NQ = NI;                     // DMA instructions per row wave and array (4 row waves)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float rok[3][kRows];
+    __shared__ int64_t rid[3][kRows];
+    __shared__ double red[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li0 = lane & 31, lh0 = lane >> 5;
+    const bool rowwave = wave >= 4;
+    float* GZ = smem;                          // [32][GS]  mapped -> gz = dL/d mapped, later dL/dS (shared: see above)
+    float* GX = GZ;
+    float* HB = GZ + kRows * GS;               // [32][HS]  hidden activations -> dL/d(hidden pre-activation)
+    float* SS = HB + kRows * HS;               // [2][32][D] source rows (swizzled)
+    float* ST = SS + 2 * kRows * D;            // [32][D] each, swizzled alike
+    float* SMT = ST + kRows * D;
+    float* SVT = SMT + kRows * D;
+    float* SMS = SVT + kRows * D;
+    float* SVS = SMS + kRows * D;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool adam = opt.opt != 0;
+    float ss_s, bc_s, ss_t, bc_t;
+    adam_hp(opt, step_s, 1, ss_s, bc_s);
+    adam_hp(opt, step_t, 1, ss_t, bc_t);
+    const float gscale = 2.0f / ((float)n * (float)D);
+    const float* __restrict__ W1 = net.W[0];   // [H][D]
+    const float* __restrict__ W2 = net.W[1];   // [D][H]
+    const float* __restrict__ B1 = net.b[0];
+    const float* __restrict__ B2 = net.b[1];
+    if (blockIdx.x == 0 && t == 0) {
+        for (int l = 0; l < 2; ++l) { if (bump.sW[l]) bump.sW[l][0] += 1; if (bump.sb[l]) bump.sb[l][0] += 1; }
+    }
+    const int64_t nrb = (n + kRows - 1) / kRows;
+    f32x16 wacc[2 * SL];                       // [0, SL): layer 0's tiles wave + 4 q ; [SL, 2 SL): layer 1's
+#pragma unroll
+    for (int q = 0; q < 2 * SL; ++q) wacc[q] = zero16();
+    float bacc = 0.f;                          // MFMA-wave thread t owns flat bias element t (b1 then b2)
+    double lsum = 0.0;
+
+    // (address arithmetic below is re-derived per phase from a laundered lane id: left alone, LICM hoists ~200 loop-invariant LDS /
+    //  global offsets out of the block loop and spills them -- and a spill reload inside a row wave is a vector memory load whose
+    //  wait drains the DMA queue)
+    auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    // ---- row waves: lane <-> (row, physical chunk) of DMA instruction i = pw + 4 q, q < NQ
+    const int pw = wave - 4;
+    // byte offsets of this lane's NQ chunks inside a table, for the rows of one block: all ids are read from LDS first (one wait),
+    // and the result serves every table staged for that block
+    auto row_offsets = [&](const int64_t* ids, int64_t (&off)[NQ]) {
+        const int ln = fresh(lane);
+        int64_t idv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) idv[q] = ids[(pw + 4 * q) * RPI + ln / LR];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int row = (pw + 4 * q) * RPI + ln / LR, p = ln % LR;
+            off[q] = (idv[q] * D + 4 * (p ^ (row & (LR - 1)))) * (int64_t)sizeof(float);
+        }
+    };
+    // NQ DMA instructions of one table in ONE asm statement: M0 saved once, set per instruction, restored once
+    auto stage = [&](const float* __restrict__ tab, unsigned dst_bytes, const int64_t (&off)[NQ]) {
+        const char* base = reinterpret_cast<const char*>(tab);
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(dst_bytes + (unsigned)pw * 1024u);   // instruction i = pw + 4 q writes 1 KiB at i * 1 KiB
+        unsigned keep;
+        if constexpr (NQ == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]),
+                           "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u), "s"(d0 + 12288u)
+                         : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(base + off[0]), "v"(base + off[1]), "s"(d0), "s"(d0 + 4096u) : "memory");
+    };
+    auto lds_off = [](const float* p) {
+        return (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+    };
+    const unsigned bSS = lds_off(SS), bST = lds_off(ST), bSMT = lds_off(SMT), bSVT = lds_off(SVT), bSMS = lds_off(SMS), bSVS = lds_off(SVS);
+    int64_t roff[NQ];
+    // Adam / SGD on this lane's chunks of DMA instructions [Q0, Q1): g = sign * G[row][logical chunk].  Every operand of the
+    // whole range is requested before the arithmetic starts (one wave per role and SIMD: nothing else hides the LDS latency)
+    auto apply = [&](auto Q0c, auto Q1c, float* __restrict__ tab, float* __restrict__ mtab, float* __restrict__ vtab, const float* stW,
+                     const float* stM, const float* stV, const float* G, float sign, const int64_t* ids, const float* ok,
+                     float ssz, float bcs) {
+        constexpr int Q0 = decltype(Q0c)::value, Q1 = decltype(Q1c)::value, NQQ = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
+        if (Q1 <= Q0) return;
+        const int ln = fresh(lane);
+        const float rbc = 1.0f / bcs;
+        const int r0 = ln / LR, p = ln % LR;
+        float4 w[NQQ], g[NQQ], m[NQQ], v[NQQ];
+        int64_t o[NQQ];
+        float okf[NQQ];
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) {
+            const int row = (pw + 4 * (Q0 + q)) * RPI + r0, c = p ^ (row & (LR - 1)), so = (row * LR + p) * 4;
+            w[q] = ld4(stW + so); g[q] = ld4(G + row * GS + 4 * c);
+            m[q] = z4; v[q] = z4;
+            if (adam) { m[q] = ld4(stM + so); v[q] = ld4(stV + so); }
+            o[q] = ids[row] * D + 4 * c;
+            okf[q] = ok[row];
+        }
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) {
+            float4 wn;
+            wn.x = updq(w[q].x, sign * g[q].x, m[q].x, v[q].x, opt, ssz, rbc); wn.y = updq(w[q].y, sign * g[q].y, m[q].y, v[q].y, opt, ssz, rbc);
+            wn.z = updq(w[q].z, sign * g[q].z, m[q].z, v[q].z, opt, ssz, rbc); wn.w = updq(w[q].w, sign * g[q].w, m[q].w, v[q].w, opt, ssz, rbc);
+            if (okf[q] != 0.f) {
+                st4(tab + o[q], wn);
+                if (adam) { st4(mtab + o[q], m[q]); st4(vtab + o[q], v[q]); }
+            }
+        }
+    };
+    using std::integral_constant;
+#define IC(v) integral_constant<int, (v)>{}
+    if (t < kRows) {                                                     // ids of this workgroup's first block
+        const int64_t g = (int64_t)blockIdx.x * kRows + t;
+        rid[0][t] = idx[g < n ? g : n - 1];
+        rok[0][t] = g < n ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (rowwave) {
+        __builtin_amdgcn_s_setprio(3);
+        row_offsets(rid[0], roff);
+        stage(S, bSS, roff);
+        stage(T, bST, roff);
+        if (adam) { stage(mT, bSMT, roff); stage(vT, bSVT, roff); }
+        vm_wait<0>();
+    }
+    lds_barrier();
+    int k = 0;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x, ++k) {
+        const int par = k & 1, r3 = k % 3, r3n = (k + 1) % 3, r3p = (k + 2) % 3;
+        const bool has_next = rb + gridDim.x < nrb;
+        float* Xs = SS + par * kRows * D;                               // this block's source rows
+        MP_STAMP(0);
+        if (!rowwave) {
+            int64_t idn = 0; float okn = 0.f;
+            if (t < kRows && has_next) { const int64_t g = (rb + gridDim.x) * kRows + t; idn = idx[g < n ? g : n - 1]; okn = g < n ? 1.f : 0.f; }
+            int li = fresh(li0), lh = fresh(lh0);
+            // C[32 x 32-col tile] = A (LDS, one row per lane) x Wg[ncol][0..K) -- weight ROWS, K in groups of four steps, the next
+            // group's weights (L2) and operand chunks (LDS) requested before the current group's sixteen MFMAs
+            auto contract_rows = [&](auto Kc, const float* __restrict__ Wg, int ncol, auto a_chunk) {
+                constexpr int K = decltype(Kc)::value;
+                f32x16 acc = zero16();
+                const float* wm = Wg + (int64_t)ncol * K + 4 * lh;
+                float4 nm[4], an[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { nm[j] = ld4(wm + 8 * j); an[j] = a_chunk(2 * j + lh); }
+#pragma unroll
+                for (int g = 0; g < K / 32; ++g) {
+                    float4 cm[4], ca[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cm[j] = nm[j]; ca[j] = an[j]; }
+                    if (g + 1 < K / 32) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { nm[j] = ld4(wm + 8 * (4 * (g + 1) + j)); an[j] = a_chunk(2 * (4 * (g + 1) + j) + lh); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { MFMA4(acc, ca[j], cm[j]); }
+                }
+                return acc;
+            };
+            // C = A (LDS) x Wg[0..K)[ncol] -- weight COLUMNS (the data-gradient products): four strided words per K step
+            auto contract_cols = [&](auto Kc, auto LDc, const float* __restrict__ Wg, int ncol, const float* ao) {
+                constexpr int K = decltype(Kc)::value, LDW = decltype(LDc)::value;
+                f32x16 acc = zero16();
+                const float* w0 = Wg + (int64_t)(4 * lh) * LDW + ncol;
+                float4 nb[4], an[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float* p = w0 + (int64_t)(8 * j) * LDW; nb[j] = make_float4(p[0], p[LDW], p[2 * LDW], p[3 * LDW]); an[j] = ld4(ao + 8 * j); }
+#pragma unroll
+                for (int g = 0; g < K / 32; ++g) {
+                    float4 cb[4], ca[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cb[j] = nb[j]; ca[j] = an[j]; }
+                    if (g + 1 < K / 32) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int kk = 8 * (4 * (g + 1) + j);
+                            const float* p = w0 + (int64_t)kk * LDW;
+                            nb[j] = make_float4(p[0], p[LDW], p[2 * LDW], p[3 * LDW]); an[j] = ld4(ao + kk);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { MFMA4(acc, ca[j], cb[j]); }
+                }
+                return acc;
+            };
+            // ---- forward 0: HB = tanh(X W1^T + b1)
+#pragma unroll
+            for (int jj = 0; jj < NJH; ++jj) {
+                const int job = wave + 4 * jj;
+                if (job < NHI) {
+                    const int ncol = job * 32 + li;
+                    const float* xr = Xs + li * D;
+                    const int sw = li & (LR - 1);
+                    const f32x16 acc = contract_rows(IC(D), W1, ncol, [&](int ch) { return ld4(xr + ((ch ^ sw) << 2)); });
+                    MP_STAMP(1);
+                    const float bv = B1 ? B1[ncol] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) HB[((r & 3) + 8 * (r >> 2) + 4 * lh) * HS + ncol] = tanhf(acc[r] + bv);
+                }
+            }
+            if (t < kRows && has_next) { rid[r3n][t] = idn; rok[r3n][t] = okn; }
+            MP_STAMP(2);
+            lds_barrier();                                               // ---- 1: hidden activations complete
+            // ---- forward 1: mapped = HB W2^T + b2 (kept in registers across the barrier)
+            li = fresh(li0); lh = fresh(lh0);
+            f32x16 am[NJD];
+#pragma unroll
+            for (int jj = 0; jj < NJD; ++jj) {
+                const int job = wave + 4 * jj;
+                am[jj] = zero16();
+                if (job < NI) {
+                    const float* hr = HB + li * HS;
+                    am[jj] = contract_rows(IC(H), W2, job * 32 + li, [&](int ch) { return ld4(hr + 4 * ch); });
+                }
+            }
+            MP_STAMP(3);
+            lds_barrier();                                               // ---- X: target rows landed; the previous dL/dS is consumed
+            li = fresh(li0); lh = fresh(lh0);
+#pragma unroll
+            for (int jj = 0; jj < NJD; ++jj) {
+                const int job = wave + 4 * jj;
+                if (job < NI) {
+                    const int ncol = job * 32 + li;
+                    const float bv = B2 ? B2[ncol] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float tv = ST[(row * LR + ((ncol >> 2) ^ (row & (LR - 1)))) * 4 + (ncol & 3)];
+                        const float d = rok[r3][row] != 0.f ? (am[jj][r] + bv) - tv : 0.f;       // nn.MSELoss (emcdr.py:81,162)
+                        lsum += (double)d * (double)d;
+                        GZ[row * GS + ncol] = gscale * d;
+                    }
+                }
+            }
+            MP_STAMP(4);
+            lds_barrier();                                               // ---- F: gz complete
+            // weight-gradient tiles of one layer: dW[m][nn] += sum_rows gz[row][m] in[row][nn]; the 32 operand words of a tile are
+            // requested before its 16 MFMAs, the next tile's before them
+            auto dw_layer = [&](auto QBc, auto NTWc, const float* gzb, int gzs, auto in_word) {
+                constexpr int QB = decltype(QBc)::value, NTW = decltype(NTWc)::value;
+                float av[2][16], bv[2][16];
+                auto fetch = [&](int q, float* a_, float* b_) {
+                    const int loc = wave + 4 * q, mt = loc / NTW, nt = loc - mt * NTW;
+                    const int l_i = fresh(li0), l_h = fresh(lh0);
+                    const float* ga = gzb + (4 * l_h) * gzs + mt * 32 + l_i;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rc = 8 * (e >> 2) + (e & 3);
+                        a_[e] = ga[rc * gzs];
+                        b_[e] = in_word(rc, l_h, nt * 32 + l_i);
+                    }
+                };
+                fetch(0, av[0], bv[0]);
+#pragma unroll
+                for (int q = 0; q < SL; ++q) {
+                    if (q + 1 < SL) fetch(q + 1, av[(q + 1) & 1], bv[(q + 1) & 1]);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) MF1(wacc[QB + q], av[q & 1][e], bv[q & 1][e]);
+                }
+            };
+            // ---- layer 1: dW2 += gz^T HB ; db2 += column sums of gz
+            dw_layer(IC(SL), IC(NHI), GZ, GS, [&](int rc, int l_h, int nn) { return HB[(rc + 4 * l_h) * HS + nn]; });
+            if (B2 && t >= H && t < H + D) {
+                float sum = 0.f;
+                for (int row = 0; row < kRows; ++row) sum += GZ[row * GS + (t - H)];
+                bacc += sum;
+            }
+            MP_STAMP(5);
+            lds_barrier();                                               // ---- 4: HB may be overwritten
+            // ---- dL/d hidden = gz W2, folded with tanh' = 1 - a^2, in place over HB
+            li = fresh(li0); lh = fresh(lh0);
+#pragma unroll
+            for (int jj = 0; jj < NJH; ++jj) {
+                const int job = wave + 4 * jj;
+                if (job < NHI) {
+                    const int ncol = job * 32 + li;
+                    const f32x16 acc = contract_cols(IC(D), IC(H), W2, ncol, GZ + li * GS + 4 * lh);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ((r & 3) + 8 * (r >> 2) + 4 * lh) * HS + ncol;
+                        const float a_ = HB[o];
+                        HB[o] = acc[r] * (1.0f - a_ * a_);
+                    }
+                }
+            }
+            MP_STAMP(6);
+            lds_barrier();                                               // ---- 5: gz0 complete
+            // ---- layer 0: dW1 += gz0^T X ; db1 += column sums of gz0
+            dw_layer(IC(0), IC(NI), HB, HS, [&](int rc, int l_h, int nn) {
+                return Xs[(rc + 4 * l_h) * D + ((((nn >> 2) ^ (l_h << 2)) ^ (rc & (LR - 1))) << 2) + (nn & 3)];
+            });
+            if (B1 && t < H) {
+                float sum = 0.f;
+                for (int row = 0; row < kRows; ++row) sum += HB[row * HS + t];
+                bacc += sum;
+            }
+            MP_STAMP(7);
+            lds_barrier();                                               // ---- M: the target update has read gz for the last time
+            // ---- dL/dS = gz0 W1 into the shared buffer
+            li = fresh(li0); lh = fresh(lh0);
+#pragma unroll
+            for (int jj = 0; jj < NJD; ++jj) {
+                const int job = wave + 4 * jj;
+                if (job < NI) {
+                    const int ncol = job * 32 + li;
+                    const f32x16 acc = contract_cols(IC(H), IC(D), W1, ncol, HB + li * HS + 4 * lh);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) GX[((r & 3) + 8 * (r >> 2) + 4 * lh) * GS + ncol] = acc[r];
+                }
+            }
+            MP_STAMP(8);
+            lds_barrier();                                               // ---- E
+            MP_STAMP(9);
+        } else {
+            vm_wait<0>();                                                // T, mT, vT of this block and mS, vS of the previous one
+            MP_STAMP(1);
+            if (k > 0) apply(IC(0), IC(NQ / 2), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            lds_barrier();                                               // ---- 1
+            if (k > 0) apply(IC(NQ / 2), IC(NQ), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            if (has_next) { row_offsets(rid[r3n], roff); stage(S, bSS + (unsigned)((par ^ 1) * kRows * D * 4), roff); }
+            if (adam) { row_offsets(rid[r3], roff); stage(mS, bSMS, roff); stage(vS, bSVS, roff); }
+            MP_STAMP(2);
+            lds_barrier();                                               // ---- X: dL/dS of the previous block is consumed
+            MP_STAMP(3);
+            lds_barrier();                                               // ---- F
+            MP_STAMP(4);
+            apply(IC(0), IC(NQ / 2), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
+            lds_barrier();                                               // ---- 4
+            apply(IC(NQ / 2), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
+            if (has_next) {
+                row_offsets(rid[r3n], roff);
+                stage(T, bST, roff);
+                if (adam) { stage(mT, bSMT, roff); stage(vT, bSVT, roff); }
+            }
+            lds_barrier();                                               // ---- 5
+            MP_STAMP(5);
+            lds_barrier();                                               // ---- M: gz has been read for the last time
+            if (has_next) { if (adam) vm_wait<5 * NQ>(); else vm_wait<NQ>(); }   // the next block's source rows have landed
+            MP_STAMP(7);
+            lds_barrier();                                               // ---- E
+            MP_STAMP(8);
+        }
+    }
+    if (rowwave) {                                                       // the last block's source rows
+        const int par = (k - 1) & 1, r3 = (k - 1) % 3;
+        vm_wait<0>();
+        apply(IC(0), IC(NQ), S, mS, vS, SS + par * kRows * D, SMS, SVS, GX, 1.f, rid[r3], rok[r3], ss_s, bc_s);
+    } else {
+        float* o = wpart + (size_t)blockIdx.x * ((size_t)net.ntiles * 1024 + net.nbias);
+#pragma unroll
+        for (int q = 0; q < 2 * SL; ++q) {
+            const int tile = (q < SL ? 0 : TL) + wave + 4 * (q < SL ? q : q - SL);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)tile * 1024 + r * 64 + lane] = wacc[q][r];
+        }
+        if (t < net.nbias) o[(size_t)net.ntiles * 1024 + t] = bacc;
+        lsum = wave_sum_d(lsum);
+        if (lane == 0) red[wave] = lsum;
+    }
+    __syncthreads();
+    if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(1024) void map_finish_kernel(map_net net, map_opt opt, map_params P, const float* __restrict__ wpart,
                                                          const double* __restrict__ lpart, int nwg, int64_t n, float* __restrict__ loss_out,
                                                          int64_t* step_s, int64_t* step_t) {
@@ -836,7 +1226,11 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
     // weights); everything else takes the two-workgroups-per-CU kernel
     const int Dp = dims[0];
     const bool pipe = L == 1 && !net.b[0] && net.vec && dims[1] == Dp && (Dp == 64 || Dp == 128);
-    const int nwg = pipe ? wg_count(n, 1) : wg_count(n, 2);        // (three resident workgroups per CU measured no faster)
+    // ... and its two-layer form for the default tanh MLP: D -> H -> D, D and H in {64, 128}, biases on both layers or on neither
+    const int Hp = L == 2 ? dims[1] : 0;
+    const bool pipe2 = L == 2 && net.vec && net.act[0] == CDR_ACT_TANH && dims[2] == Dp && (Dp == 64 || Dp == 128) &&
+                       (Hp == 64 || Hp == 128) && ((net.b[0] != nullptr) == (net.b[1] != nullptr));
+    const int nwg = (pipe || pipe2) ? wg_count(n, 1) : wg_count(n, 2);        // (three resident workgroups per CU measured no faster)
     const size_t wbytes = (size_t)nwg * ((size_t)net.ntiles * 1024 + net.nbias) * sizeof(float);
     const size_t woff = (wbytes + 255) & ~(size_t)255;
     CDR_CHECK_ARG(workspace_bytes >= woff + (size_t)nwg * sizeof(double));
@@ -848,6 +1242,11 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
         lds = ((size_t)2 * kRows * (Dp + 4) + 7 * (size_t)kRows * Dp) * sizeof(float);
         fn = Dp == 128 ? (const void*)map_pipe_kernel<4> : (const void*)map_pipe_kernel<2>;
     }
+    if (pipe2) {
+        lds = ((size_t)kRows * (Dp + 4) + (size_t)kRows * (Hp + 4) + 7 * (size_t)kRows * Dp) * sizeof(float);
+        fn = Dp == 128 ? (Hp == 128 ? (const void*)map_pipe2_kernel<4, 4> : (const void*)map_pipe2_kernel<4, 2>)
+                       : (Hp == 128 ? (const void*)map_pipe2_kernel<2, 4> : (const void*)map_pipe2_kernel<2, 2>);
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cdr_set_error("cdr_map_step_unique: %zu B of LDS refused: %s", lds, hipGetErrorString(e)); return (int)e; }
@@ -858,7 +1257,11 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
         cdr_time_scope ts(ctx, CDR_TAG_MAP_STEP, s);
 #define MS_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, gx, to, wpart, lpart, P
 #define MP_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, wpart, lpart, P
-        if (pipe && Dp == 128) map_pipe_kernel<4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        if (pipe2 && Dp == 128 && Hp == 128) map_pipe2_kernel<4, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2 && Dp == 128) map_pipe2_kernel<4, 2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2 && Hp == 128) map_pipe2_kernel<2, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2) map_pipe2_kernel<2, 2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe && Dp == 128) map_pipe_kernel<4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
         else if (pipe) map_pipe_kernel<2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
         else if (few) map_step_kernel<4><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);
         else map_step_kernel<8><<<dim3(nwg), dim3(256), lds, s>>>(MS_ARGS);

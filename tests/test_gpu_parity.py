@@ -246,7 +246,9 @@ def test_fused_step_vs_oracle(opt, D, k):
                                          ((128, 64, 128), 'adam', 257), ((64, 128, 64), 'sgd', 100), ((20, 12), 'adam', 33),
                                          # the two-wave-group kernel (linear, D in {64, 128}) past one block per workgroup: 256
                                          # workgroups x 32 ids = 8,192 ids per round -> 4 and 3 rounds, ragged last round and block
-                                         ((128, 128), 'adam', 30001), ((64, 64), 'adam', 20011), ((128, 128), 'sgd', 9000)])
+                                         ((128, 128), 'adam', 30001), ((64, 64), 'adam', 20011), ((128, 128), 'sgd', 9000),
+                                         # ... and its two-layer form (tanh MLP, D and H in {64, 128})
+                                         ((128, 128, 128), 'adam', 20003), ((64, 128, 64), 'adam', 9000), ((64, 64, 64), 'sgd', 300)])
 def test_map_step_unique_ids_vs_oracle(dims, opt, OB):
     """The two-launch OVERLAP step for batches of DISTINCT ids (what the reference's OverlapDataloader yields: slices of a
     shuffled arange, dataloader.py:37-52): three free-running steps == the oracle's step (autograd + lazy row-wise Adam on the
@@ -2059,7 +2061,7 @@ def test_colsum_fixed_order(M, N):
     assert float((acc.double() - 2 * want).abs().max()) <= 2e-6 * scale
 
 
-@pytest.mark.parametrize('dims,OB', [((128, 128), 100), ((64, 64), 9000), ((32, 48, 16), 100)])
+@pytest.mark.parametrize('dims,OB', [((128, 128), 100), ((64, 64), 9000), ((32, 48, 16), 100), ((64, 128, 64), 100), ((128, 128, 128), 9000)])
 def test_map_step_unique_replays_as_hipgraph_bit_equal(dims, OB):
     """FusedMapStep.capture / replay: the two-launch OVERLAP step as one hipGraph (Adam update counts on the device) leaves tables,
     moments, mapping and losses BIT-identical to the same steps launched eagerly, on changing id batches."""

@@ -11,8 +11,14 @@ from recbole_cdr_amd.fused import FusedMapStep, RowwiseState, OPT_ADAM
 dev='cuda:0'; NU=50_000_001; D=128
 S=torch.empty(NU,D,device=dev).normal_(0,1e-3); T=torch.empty(NU,D,device=dev).normal_(0,1e-3)
 ss,ts_=RowwiseState(S,OPT_ADAM),RowwiseState(T,OPT_ADAM)
-W=torch.nn.Parameter(torch.randn(D,D,device=dev)*0.05)
-fm=FusedMapStep(S,T,lambda x:F_.linear(x,W,None,B_.ACT_NONE),[W],65536,opt='adam',lr=1e-3,layers=[(W,None,B_.ACT_NONE)],source_state=ss,target_state=ts_)
+if os.environ.get('MAP', 'linear') == 'linear':
+    W=torch.nn.Parameter(torch.randn(D,D,device=dev)*0.05)
+    fm=FusedMapStep(S,T,lambda x:F_.linear(x,W,None,B_.ACT_NONE),[W],65536,opt='adam',lr=1e-3,layers=[(W,None,B_.ACT_NONE)],source_state=ss,target_state=ts_)
+else:
+    W1,b1=torch.nn.Parameter(torch.randn(128,D,device=dev)*0.05),torch.nn.Parameter(torch.zeros(128,device=dev))
+    W2,b2=torch.nn.Parameter(torch.randn(D,128,device=dev)*0.05),torch.nn.Parameter(torch.zeros(D,device=dev))
+    fm=FusedMapStep(S,T,lambda x:F_.linear(F_.linear(x,W1,b1,B_.ACT_TANH),W2,b2,B_.ACT_NONE),[W1,b1,W2,b2],65536,opt='adam',lr=1e-3,
+                    layers=[(W1,b1,B_.ACT_TANH),(W2,b2,B_.ACT_NONE)],source_state=ss,target_state=ts_)
 g=torch.Generator(device=dev).manual_seed(0)
 perm=torch.randperm(NU-1,device=dev,generator=g)[:65536*4]+1
 for i in range(4):
