@@ -649,6 +649,7 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             MP_STAMP(2);
             lds_barrier();                                               // ---- X
             if (k > 0) apply(IC(NQ / 2), IC(NQ), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            MP_STAMP(9);
             if (has_next) { row_offsets(rid[r3n], roff); stage(S, bSS + (unsigned)((par ^ 1) * kRows * D * 4), roff); }
             if (adam) { row_offsets(rid[r3], roff); stage(mS, bSMS, roff); stage(vS, bSVS, roff); }
             MP_STAMP(3);
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             MP_STAMP(5);
             lds_barrier();                                               // ---- M
             apply(IC(NQ / 2), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
+            MP_STAMP(10);
             if (has_next) {
                 row_offsets(rid[r3n], roff);
                 stage(T, bST, roff);
