@@ -265,7 +265,11 @@ int cdr_rowwise_apply_scaled(cdr_ctx* ctx, void* stream, int opt, float* table, 
  * Adam, as cdr_rowwise_apply) + per-workgroup partial sums of the mapping's gradients.  Launch 2: partials added in workgroup
  * order, loss_out[0], exact dense Adam on the mapping parameters.  Device update counters: step_src_dev / step_tgt_dev hold the
  * tables' counts BEFORE the step and are advanced by it; step_W / step_b (one int64 per parameter tensor) likewise.
- * PRECONDITION: idx[0..n) pairwise distinct (repeated ids: use the general path).                      */
+ * PRECONDITION: idx[0..n) pairwise distinct (repeated ids: use the general path).
+ * Launch 1 is one of three kernels by shape (same arguments, same results): the linear mapping and the Linear-Tanh-Linear MLP with
+ * widths in {64, 128} run as MFMA waves + row waves with LDS-DMA prefetch (csrc/cdr_mapstep.hip); those two take the Adam STEP's two
+ * divisions and square root on v_rcp_f32 / v_sqrt_f32 (1 ulp each: the weight differs from the IEEE form by <= 4e-7 x lr; exp_avg and
+ * exp_avg_sq are bit-identical); every other shape runs the single-group kernel with IEEE arithmetic throughout.                 */
 #define CDR_MAP_MAX_LAYERS 4
 int cdr_map_step_plan(int L, const int* dims, const int* has_bias, int64_t n, size_t* workspace_bytes);
 int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* src_tab, float* src_m, float* src_v, float* tgt_tab,
