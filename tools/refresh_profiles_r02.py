@@ -11,7 +11,7 @@ for w in ('c5', 'c3'):
     ks = glob.glob(os.path.join(out, f'trace_{w}', '**', '*kernel_stats.csv'), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(prof, f'{tag}_bench_{w}_kernel_stats.csv'))
-for t in ('sweep_small', 'mb_kmajor', 'mb_mapstep', 'mb_conet', 'mb_smallsort'):
+for t in ('sweep_small', 'mb_kmajor', 'mb_mapstep', 'mb_conet', 'mb_smallsort', 'mb_models5'):
     f = os.path.join(out, t + '.txt')
     if os.path.exists(f):
         txt = [l for l in open(f).read().splitlines() if 'amdgpu.ids' not in l and 'radix sort) 0.0000' not in l]
