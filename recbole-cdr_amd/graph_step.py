@@ -16,7 +16,19 @@ class GraphedTrainStep:
         so swapping the eager loop for the graphed one does not add ``warmup`` extra updates on batch 0."""
         self.model, self.optimizer = model, optimizer
         self.restore_after_warmup = restore_after_warmup
-        self.static = {k: v.clone() for k, v in example_interaction.items()}
+        # the batch fields live side by side in ONE byte buffer (16-B aligned views): a producer that hands over a batch already
+        # packed this way (``pack``) costs one device copy per step instead of one per field (6-7 for a two-domain pointwise batch:
+        # 30-40 us, a sixth of the C3 step)
+        self._layout, off = {}, 0
+        for k, v in example_interaction.items():
+            nb = v.numel() * v.element_size()
+            self._layout[k] = (off, nb, v.dtype, tuple(v.shape))
+            off += (nb + 15) // 16 * 16
+        dev = next(iter(example_interaction.values())).device
+        self.flat = torch.empty(max(off, 16), device=dev, dtype=torch.uint8)
+        self.static = {k: self.flat[o:o + nb].view(dt).view(shape) for k, (o, nb, dt, shape) in self._layout.items()}
+        for k, v in example_interaction.items():
+            self.static[k].copy_(v)
         self.graph = None
         self.loss = None
         self._capture(warmup)
@@ -84,7 +96,21 @@ class GraphedTrainStep:
         if ro is not None and snap['row'] is not None:
             ro.step_count, ro.dirty = snap['row']
 
+    def pack(self, interaction):
+        """The batch in the captured step's own byte layout (a new uint8 tensor): ``step(packed)`` then needs ONE device copy."""
+        out = torch.empty_like(self.flat)
+        for k, (o, nb, dt, shape) in self._layout.items():
+            out[o:o + nb].view(dt).view(shape).copy_(interaction[k])
+        return out
+
     def step(self, interaction):
+        if torch.is_tensor(interaction):                      # a batch packed by ``pack``
+            assert interaction.dtype == torch.uint8 and interaction.numel() == self.flat.numel(), 'not a batch packed for this step'
+            self.flat.copy_(interaction)
+            self.graph.replay()
+            if hasattr(self.optimizer, 'on_replay'):
+                self.optimizer.on_replay()
+            return self.loss
         same = all(k in interaction and interaction[k].shape == v.shape for k, v in self.static.items())
         if not same:
             return self._eager(interaction)

@@ -2091,3 +2091,33 @@ def test_map_step_unique_replays_as_hipgraph_bit_equal(dims, OB):
     a, b = runs
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     assert all(torch.equal(x, y) for x, y in zip(a[5], b[5]))
+
+
+def test_graphed_step_packed_batch_equals_field_copies():
+    """GraphedTrainStep.pack / step(packed): the batch handed over as one byte buffer gives bit-identical steps to the per-field hand-over
+    (CMF, pointwise two-domain batch: int64 ids and fp32 labels in one buffer)."""
+    from recbole_cdr_amd.model.cross_domain_recommender.cmf import CMF
+    from recbole_cdr_amd.graph_step import GraphedTrainStep
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    from oracle.common import IdSpace
+    ids = IdSpace(30, 20, 25, 1, 40, 35)
+    gen = torch.Generator().manual_seed(4)
+
+    def batch():
+        out = {}
+        for d, nu, ni in (('source', ids.total_num_users, ids.total_num_items), ('target', ids.target_num_users, ids.target_num_items)):
+            out[f'{d}_user_id'] = torch.randint(1, nu, (37,), generator=gen).to(DEV)
+            out[f'{d}_item_id'] = torch.randint(1, ni, (37,), generator=gen).to(DEV)
+            out[f'{d}_label'] = (torch.rand(37, generator=gen) < 0.5).float().to(DEV)
+        return out
+    batches = [batch() for _ in range(4)]
+    outs = []
+    for packed in (False, True):
+        torch.manual_seed(1)
+        m = CMF(base_config(DEV, embedding_size=16, alpha=0.4, **{'lambda': 0.01, 'gamma': 0.02}), FakeDataset(ids)).to(DEV)
+        g = GraphedTrainStep(m, DenseAdam(m.parameters(), lr=0.01), batches[0])
+        losses = [g.step(g.pack(b) if packed else b).clone() for b in batches]
+        outs.append((torch.stack(losses), m.user_embedding.weight.detach().clone(), m.item_embedding.weight.detach().clone()))
+    # (dense scatter-add backward: fp32 atomics reorder sums between runs -> 1e-5, not bit equality)
+    assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-7, what='losses')
+    assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6, what='user table'); assert_close(outs[1][2], outs[0][2], rtol=1e-5, atol=1e-6, what='item table')
