@@ -492,6 +492,21 @@ extern "C" int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_
     return CDR_OK;
 }
 
+// rocPRIM's Onesweep with a configuration measured for this step's shape (tools/sort_tune.hip: 3,145,728 (key, index) pairs,
+// 27 significant bits): 1,024-thread blocks x 8 items, 9-bit digits (27 bits = 3 passes instead of 4), wave-match ranking --
+// 117 us against 161 us for the library's gfx950 default.  Used from 2^18 pairs up; smaller sorts keep the default.
+using big_sort_config = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
+                                        rocprim::block_radix_rank_algorithm::match>>;
+constexpr int64_t kBigSort = 1 << 18;
+
+static inline hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                                    size_t n, unsigned bits, hipStream_t s) {
+    if ((int64_t)n >= kBigSort) return rocprim::radix_sort_pairs<big_sort_config>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, bits, s);
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, bits, s);
+}
+
 static inline unsigned bits_for(int64_t num_rows) {
     unsigned b = 1;
     while (b < 32 && ((int64_t)1 << b) < num_rows) ++b;
@@ -501,8 +516,7 @@ static inline unsigned bits_for(int64_t num_rows) {
 extern "C" int cdr_sort_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes) {
     CDR_CHECK_ARG(bytes && n > 0 && num_rows > 0 && num_rows <= (int64_t)0xFFFFFFFFu && n <= (int64_t)0x7FFFFFFF);
     size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, bits_for(num_rows));
+    hipError_t e = sort_pairs(nullptr, tmp, nullptr, nullptr, nullptr, nullptr, (size_t)n, bits_for(num_rows), (hipStream_t)0);
     if (e != hipSuccess) { cdr_set_error("cdr_sort_workspace_bytes: %s", hipGetErrorString(e)); return (int)e; }
     tmp = (tmp + 255) & ~(size_t)255;
     *bytes = tmp + 2 * (((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255);
@@ -527,8 +541,7 @@ extern "C" int cdr_sort_ids(cdr_ctx* ctx, void* stream, const int64_t* ids0, int
     cdr_time_scope ts(ctx, CDR_TAG_SORT, s);
     make_keys_kernel<<<dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s>>>(ids0, n0, ids1, n1, keys_in, vals_in);
     CDR_LAUNCH_CHECK();
-    CDR_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_sorted, (const uint32_t*)vals_in, perm,
-                                      (size_t)n, 0u, bits_for(num_rows), s));
+    CDR_HIP(sort_pairs(tmp, tmp_bytes, keys_in, keys_sorted, vals_in, perm, (size_t)n, bits_for(num_rows), s));
     return CDR_OK;
 }
 
@@ -555,8 +568,7 @@ extern "C" int cdr_sort_ids_two_tables(cdr_ctx* ctx, void* stream, const int64_t
     cdr_time_scope ts(ctx, CDR_TAG_SORT, s);
     make_keys2_kernel<<<dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s>>>(ids_a, n_a, ids_b0, n_b0, ids_b1, n_b1, key_base, keys_in, vals_in);
     CDR_LAUNCH_CHECK();
-    CDR_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_sorted, (const uint32_t*)vals_in, perm,
-                                      (size_t)n, 0u, hb + 1, s));
+    CDR_HIP(sort_pairs(tmp, tmp_bytes, keys_in, keys_sorted, vals_in, perm, (size_t)n, hb + 1, s));
     *key_base_out = key_base;
     return CDR_OK;
 }
