@@ -2121,3 +2121,36 @@ def test_graphed_step_packed_batch_equals_field_copies():
     # (dense scatter-add backward: fp32 atomics reorder sums between runs -> 1e-5, not bit equality)
     assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-7, what='losses')
     assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6, what='user table'); assert_close(outs[1][2], outs[0][2], rtol=1e-5, atol=1e-6, what='item table')
+
+
+@pytest.mark.parametrize('n,rows', [(1000, 50_000_001), ((1 << 17) - 1, 20_000_001), (1 << 17, 20_000_001), ((1 << 18) + 5, 1 << 16),
+                                    (1 << 20, 50_000_001), ((3 << 20) + 7, 50_000_001)])
+def test_sort_ids_stable_across_config_thresholds(n, rows):
+    """cdr_sort_ids / cdr_sort_ids_two_tables: sorted keys and a STABLE permutation (equal to torch's stable sort of the same
+    composite keys) on both sides of the sizes where the radix-sort configuration changes (library default below 2^17 pairs, the
+    measured Onesweep configuration from there: csrc/cdr_step.hip)."""
+    import ctypes
+    from recbole_cdr_amd import binding as B_
+    g = torch.Generator(device=DEV); g.manual_seed(n % 1000)
+    ids = torch.randint(0, rows, (n,), device=DEV, generator=g)
+    ids[: n // 8] = ids[0]                                            # a long run of one key: stability is visible
+    keys = torch.empty(n, device=DEV, dtype=torch.int32); perm = torch.empty(n, device=DEV, dtype=torch.int32)
+    need = ctypes.c_size_t(0)
+    B_._check(B_.load().cdr_sort_workspace_bytes(n, rows, ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+    ws = torch.empty(need.value, device=DEV, dtype=torch.uint8)
+    B_.call('cdr_sort_ids', B_.ctx(torch.device(DEV)), B_.stream(), B_.i64(ids), n, None, 0, rows, B_.raw(keys), B_.raw(perm), B_.raw(ws), ws.numel())
+    want = torch.sort(ids, stable=True)
+    assert torch.equal(keys.long(), want.values) and torch.equal(perm.long(), want.indices)
+    # two tables in one call: table b's keys sort behind every key of table a
+    nb = n // 2 + 1
+    ids_b = torch.randint(0, rows // 3 + 1, (nb,), device=DEV, generator=g)
+    nt = n + nb
+    keys2 = torch.empty(nt, device=DEV, dtype=torch.int32); perm2 = torch.empty(nt, device=DEV, dtype=torch.int32)
+    B_._check(B_.load().cdr_sort_workspace_bytes(nt, 1 << 28, ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+    ws = torch.empty(need.value, device=DEV, dtype=torch.uint8)
+    base = ctypes.c_uint32(0)
+    B_.call('cdr_sort_ids_two_tables', B_.ctx(torch.device(DEV)), B_.stream(), B_.i64(ids), n, rows, B_.i64(ids_b), nb, None, 0, rows // 3 + 1,
+            B_.raw(keys2), B_.raw(perm2), ctypes.byref(base), B_.raw(ws), ws.numel())
+    comp = torch.cat([ids, ids_b + int(base.value)])
+    want = torch.sort(comp, stable=True)
+    assert torch.equal(keys2.long() & 0xFFFFFFFF, want.values) and torch.equal(perm2.long(), want.indices)
