@@ -248,7 +248,9 @@ def test_fused_step_vs_oracle(opt, D, k):
                                          # workgroups x 32 ids = 8,192 ids per round -> 4 and 3 rounds, ragged last round and block
                                          ((128, 128), 'adam', 30001), ((64, 64), 'adam', 20011), ((128, 128), 'sgd', 9000),
                                          # ... and its two-layer form (tanh MLP, D and H in {64, 128})
-                                         ((128, 128, 128), 'adam', 20003), ((64, 128, 64), 'adam', 9000), ((64, 64, 64), 'sgd', 300)])
+                                         ((128, 128, 128), 'adam', 20003), ((64, 128, 64), 'adam', 9000), ((64, 64, 64), 'sgd', 300),
+                                         # degenerate batches: a single id, one row short of / past a 32-id block
+                                         ((128, 128), 'adam', 1), ((128, 128), 'adam', 33), ((64, 128, 64), 'adam', 31), ((128, 128, 128), 'adam', 2)])
 def test_map_step_unique_ids_vs_oracle(dims, opt, OB):
     """The two-launch OVERLAP step for batches of DISTINCT ids (what the reference's OverlapDataloader yields: slices of a
     shuffled arange, dataloader.py:37-52): three free-running steps == the oracle's step (autograd + lazy row-wise Adam on the
