@@ -76,14 +76,18 @@ class PointGatherLoss(Function):
     @staticmethod
     def backward(ctx, grad_out, _gs):
         user_w, item_w, reg_user_w, reg_item_w, uid, iid, g, out4 = ctx.saved_tensors
-        gU, gI = torch.zeros_like(user_w), torch.zeros_like(item_w)
+        # the same tensor as user AND item operand (BiTGCF scores rows of one stacked [users ; items] table): one gradient buffer,
+        # both scatters add into it, and autograd gets it once -- instead of two table-sized buffers plus the add that merges them
+        shared = user_w.data_ptr() == item_w.data_ptr() and user_w.shape == item_w.shape and user_w.stride() == item_w.stride()
+        gU = torch.zeros_like(user_w)
+        gI = gU if shared else torch.zeros_like(item_w)
         gRU = torch.zeros_like(reg_user_w) if reg_user_w is not None else None
         gRI = torch.zeros_like(reg_item_w) if reg_item_w is not None else None
         go = grad_out.reshape(-1).contiguous().to(torch.float32)
         B_.call('cdr_point_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w),
                 B_.f32(reg_user_w), B_.f32(reg_item_w), user_w.shape[1], B_.i64(uid), B_.i64(iid), uid.numel(),
                 B_.f32(g), B_.f32(out4), ctx.reg_weight, B_.f32(go), B_.f32(gU), B_.f32(gI), B_.f32(gRU), B_.f32(gRI))
-        return None, gU, gI, gRU, gRI, None, None, None, None
+        return None, gU, (None if shared else gI), gRU, gRI, None, None, None, None
 
 
 class GatherRows(Function):

@@ -74,13 +74,17 @@ class BiTGCF(CrossDomainRecommender):
         self.apply(xavier_normal_initialization)
         self.other_parameter_name = ['target_restore_user_e', 'target_restore_item_e']
 
-    def forward(self):
-        S, T = F_.BiTGCFPropagate.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
+    def _propagate(self):
+        """(S, T): the propagated [users ; items] stacks of the two domains, one tensor each."""
+        return F_.BiTGCFPropagate.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
                                         self.target_user_embedding.weight, self.target_item_embedding.weight,
                                         self.source_graph, self.target_graph, self.degrees, int(self.n_layers),
                                         float(self.domain_lambda_source), float(self.domain_lambda_target),
                                         self.connect_way, int(self.overlapped_num_users), int(self.overlapped_num_items),
                                         *self._dropout_args())
+
+    def forward(self):
+        S, T = self._propagate()
         nu = self.total_num_users
         return S[:nu], S[nu:], T[:nu], T[nu:]
 
@@ -104,14 +108,18 @@ class BiTGCF(CrossDomainRecommender):
 
     def calculate_loss(self, interaction):
         self.init_restore_e()
-        su_all, si_all, tu_all, ti_all = self.forward()
+        S, T = self._propagate()
+        nu = self.total_num_users
         losses = []
-        for pre, ua, ia, uw, iw in (('SOURCE', su_all, si_all, self.source_user_embedding.weight, self.source_item_embedding.weight),
-                                    ('TARGET', tu_all, ti_all, self.target_user_embedding.weight, self.target_item_embedding.weight)):
+        for pre, stack, uw, iw in (('SOURCE', S, self.source_user_embedding.weight, self.source_item_embedding.weight),
+                                   ('TARGET', T, self.target_user_embedding.weight, self.target_item_embedding.weight)):
             user = interaction[getattr(self, f'{pre}_USER_ID')]
             item = interaction[getattr(self, f'{pre}_ITEM_ID')]
             label = interaction[getattr(self, f'{pre}_LABEL')]
-            bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, ua, ia, None, None, user, item, label, 0.0)
+            # rows of the stacked [users ; items] table (items at row nu + id): no slices, so the loss's gradient is ONE buffer of
+            # the stack's shape handed straight to the propagation's backward (slicing cost two zero-fills, two copies and an add
+            # per domain and step)
+            bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, stack, stack, None, None, user, item + nu, label, 0.0)
             reg = F_.EmbLossRows.apply(uw, iw, user, item)
             losses.append(bce + self.reg_weight * reg)
         return tuple(losses)
