@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 25
+#define CDR_ABI_VERSION 26
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -370,6 +370,16 @@ int cdr_transfer_fwd(void* stream, const float* S, const float* T, const float* 
                      int64_t n_overlap, float lam_s, float lam_t, float* S_out, float* T_out);
 int cdr_transfer_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,
                      int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* gS, float* gT);
+/* the same with nn.Dropout of the layer output (bitgcf.py:134) folded in: the forward reads S / T through the mask, the backward writes
+ * gS / gT through it.  Mask = cdr_dropout's (host `seed`) or cdr_dropout_dev's (`seed_dev` != NULL) with salt_s / salt_t for the two
+ * domains; elem0 = element offset of this row block inside the [n, D] layer output (so that the user and the item block, launched
+ * separately, draw the masks one call over the whole output would).                                                              */
+int cdr_transfer_drop_fwd(void* stream, const float* S, const float* T, const float* deg_s, const float* deg_t, int64_t rows, int D,
+                          int64_t n_overlap, float lam_s, float lam_t, float p, uint64_t seed, const int64_t* seed_dev,
+                          uint64_t salt_s, uint64_t salt_t, int64_t elem0, float* S_out, float* T_out);
+int cdr_transfer_drop_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,
+                          int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float p, uint64_t seed,
+                          const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, int64_t elem0, float* gS, float* gT);
 int cdr_l2_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, int64_t ldo, float* norm_out);
 int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const float* gy, int64_t ldg, int64_t rows, int D,
                          float* gx, int accumulate);

@@ -229,6 +229,75 @@ __global__ __launch_bounds__(kBlock) void dropout_dev_kernel(const float* __rest
     }
 }
 
+// ---- the same two transfer kernels with nn.Dropout of the layer output folded in (bitgcf.py:134 precedes the transfer layer):
+// forward: the inputs are read THROUGH the mask (s = drop(S[e]), t = drop(T[e])); backward: the outputs are written through it.
+// Same mask family and the same (seed, salt, element) -> keep mapping as dropout_kernel / dropout_dev_kernel; `elem0` is the
+// element offset of this row block inside the [n, D] layer output (the item block starts at nu * D).
+struct drop_arg { float p; uint64_t seed; const int64_t* seed_dev; uint64_t salt_s, salt_t; int64_t elem0; };
+__device__ __forceinline__ uint64_t drop_seed_of(const drop_arg& d, uint64_t salt) {
+    if (!d.seed_dev) return d.seed + salt;
+    uint64_t s0 = (uint64_t)d.seed_dev[0] * 0xD1342543DE82EF95ull + 0x9E3779B97F4A7C15ull;
+    s0 = (s0 ^ (s0 >> 30)) * 0xBF58476D1CE4E5B9ull;
+    s0 = (s0 ^ (s0 >> 27)) * 0x94D049BB133111EBull;
+    return (s0 ^ (s0 >> 31)) + salt * 0xA24BAED4963EE407ull;
+}
+__device__ __forceinline__ float drop_factor(uint64_t seed, int64_t e, float p, float scale) {
+    uint64_t z = seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f) >= p ? scale : 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void transfer_drop_fwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
+                                                                   const float* __restrict__ ds, const float* __restrict__ dt,
+                                                                   int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t,
+                                                                   drop_arg dr, float* __restrict__ So, float* __restrict__ To) {
+    const uint64_t seed_s = drop_seed_of(dr, dr.salt_s), seed_t = drop_seed_of(dr, dr.salt_t);
+    const float scale = 1.0f / (1.0f - dr.p);
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const float fs = drop_factor(seed_s, dr.elem0 + e, dr.p, scale), ft = drop_factor(seed_t, dr.elem0 + e, dr.p, scale);
+        const float s = fs != 0.f ? S[e] * scale : 0.0f, t = ft != 0.f ? T[e] * scale : 0.0f;
+        if (r < n_overlap) {
+            const float a = ds[r], b = dt[r];
+            const float lap = (a * s + b * t) / ((a + b) + 1e-7f);
+            const float s_lam = lam_s * s + (1.0f - lam_s) * t;
+            const float t_lam = lam_t * t + (1.0f - lam_t) * s;
+            So[e] = (s_lam + lap) / 2.0f;
+            To[e] = (t_lam + lap) / 2.0f;
+        } else {
+            So[e] = s; To[e] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void transfer_drop_bwd_kernel(const float* __restrict__ gSo, const float* __restrict__ gTo,
+                                                                   const float* __restrict__ ds, const float* __restrict__ dt,
+                                                                   int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t,
+                                                                   drop_arg dr, float* __restrict__ gS, float* __restrict__ gT) {
+    const uint64_t seed_s = drop_seed_of(dr, dr.salt_s), seed_t = drop_seed_of(dr, dr.salt_t);
+    const float scale = 1.0f / (1.0f - dr.p);
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        const float a = gSo[e], b = gTo[e];
+        float gs_, gt_;
+        if (r < n_overlap) {
+            const float dsv = ds[r], dtv = dt[r];
+            const float dl = (dsv + dtv) + 1e-7f;
+            const float ws = dsv / dl, wt = dtv / dl;
+            gs_ = 0.5f * (a * (lam_s + ws) + b * ((1.0f - lam_t) + ws));
+            gt_ = 0.5f * (a * ((1.0f - lam_s) + wt) + b * (lam_t + wt));
+        } else {
+            gs_ = a; gt_ = b;
+        }
+        gS[e] = drop_factor(seed_s, dr.elem0 + e, dr.p, scale) != 0.f ? gs_ * scale : 0.0f;
+        gT[e] = drop_factor(seed_t, dr.elem0 + e, dr.p, scale) != 0.f ? gt_ * scale : 0.0f;
+    }
+}
+
 }  // namespace
 
 #define GR_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
@@ -327,6 +396,26 @@ extern "C" int cdr_transfer_bwd(void* stream, const float* gS_out, const float* 
                                 int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* gS, float* gT) {
     CDR_CHECK_ARG(gS_out && gT_out && deg_s && deg_t && gS && gT && rows > 0 && D > 0);
     transfer_bwd_kernel<<<GR_GRID(rows * D)>>>(gS_out, gT_out, deg_s, deg_t, rows, D, n_overlap, lam_s, lam_t, gS, gT);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_transfer_drop_fwd(void* stream, const float* S, const float* T, const float* deg_s, const float* deg_t, int64_t rows,
+                                     int D, int64_t n_overlap, float lam_s, float lam_t, float p, uint64_t seed, const int64_t* seed_dev,
+                                     uint64_t salt_s, uint64_t salt_t, int64_t elem0, float* S_out, float* T_out) {
+    CDR_CHECK_ARG(S && T && deg_s && deg_t && S_out && T_out && rows > 0 && D > 0 && p > 0.f && p < 1.f && elem0 >= 0);
+    const drop_arg dr{p, seed, seed_dev, salt_s, salt_t, elem0};
+    transfer_drop_fwd_kernel<<<GR_GRID(rows * D)>>>(S, T, deg_s, deg_t, rows, D, n_overlap, lam_s, lam_t, dr, S_out, T_out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_transfer_drop_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,
+                                     int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float p, uint64_t seed,
+                                     const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, int64_t elem0, float* gS, float* gT) {
+    CDR_CHECK_ARG(gS_out && gT_out && deg_s && deg_t && gS && gT && rows > 0 && D > 0 && p > 0.f && p < 1.f && elem0 >= 0);
+    const drop_arg dr{p, seed, seed_dev, salt_s, salt_t, elem0};
+    transfer_drop_bwd_kernel<<<GR_GRID(rows * D)>>>(gS_out, gT_out, deg_s, deg_t, rows, D, n_overlap, lam_s, lam_t, dr, gS, gT);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -2158,3 +2158,42 @@ def test_sort_ids_stable_across_config_thresholds(n, rows):
     # (the permutation of table b's entries counts inside b's own list: make_keys2_kernel)
     want_perm = torch.where(want.indices >= n, want.indices - n, want.indices)
     assert torch.equal(keys2.long() & 0xFFFFFFFF, want.values) and torch.equal(perm2.long(), want_perm)
+
+
+@pytest.mark.parametrize('dev_seed', [False, True])
+def test_transfer_with_folded_dropout_equals_dropout_then_transfer(dev_seed):
+    """cdr_transfer_drop_fwd / _bwd == cdr_dropout(_dev) followed by (preceded by) cdr_transfer_fwd / _bwd, bit for bit: same masks per
+    (seed, salt, element), user block and item block launched separately with their element offsets (bitgcf.py:134,137-172)."""
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(3)
+    nu, ni, D, OU, OI, p = 700, 500, 64, 120, 1, 0.3
+    n = nu + ni
+    S, T = torch.randn(n, D, device=DEV), torch.randn(n, D, device=DEV)
+    deg = {k: torch.rand(m, device=DEV) * 5 for k, m in (('su', nu), ('tu', nu), ('si', ni), ('ti', ni))}
+    seed_t = torch.tensor([12345], device=DEV, dtype=torch.int64)
+    st = B_.stream
+    off = 4 * nu * D
+
+    def drop(x, salt):
+        y = torch.empty_like(x)
+        if dev_seed:
+            B_.call('cdr_dropout_dev', st(), B_.f32(x), x.numel(), p, B_.i64(seed_t), salt, B_.f32(y))
+        else:
+            B_.call('cdr_dropout', st(), B_.f32(x), x.numel(), p, 777 + salt, B_.f32(y))
+        return y
+    dargs = (p, 0 if dev_seed else 777, B_.i64(seed_t) if dev_seed else None, 4, 5)
+    for name in ('fwd', 'bwd'):
+        A, Bm = (drop(S, 4), drop(T, 5)) if name == 'fwd' else (S, T)
+        r1, r2, f1, f2 = (torch.empty(n, D, device=DEV) for _ in range(4))
+        for (xs, xt, o1, o2, fused) in ((A, Bm, r1, r2, False), (S, T, f1, f2, True)):
+            for blk, (rows, ds, dt, nov, e0) in enumerate(((nu, deg['su'], deg['tu'], OU, 0), (ni, deg['si'], deg['ti'], OI, nu * D))):
+                o = off * blk
+                ptr = lambda t_: B_._c_ptr(t_.data_ptr() + o)
+                if fused:
+                    B_.call(f'cdr_transfer_drop_{name}', st(), ptr(xs), ptr(xt), B_.f32(ds), B_.f32(dt), rows, D, nov, 0.8, 0.7, *dargs, e0,
+                            ptr(o1), ptr(o2))
+                else:
+                    B_.call(f'cdr_transfer_{name}', st(), ptr(xs), ptr(xt), B_.f32(ds), B_.f32(dt), rows, D, nov, 0.8, 0.7, ptr(o1), ptr(o2))
+        if name == 'bwd':
+            r1, r2 = drop(r1, 4), drop(r2, 5)
+        assert torch.equal(r1, f1) and torch.equal(r2, f2), name
