@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 26
+#define CDR_ABI_VERSION 27
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -380,6 +380,20 @@ int cdr_transfer_drop_fwd(void* stream, const float* S, const float* T, const fl
 int cdr_transfer_drop_bwd(void* stream, const float* gS_out, const float* gT_out, const float* deg_s, const float* deg_t,
                           int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float p, uint64_t seed,
                           const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, int64_t elem0, float* gS, float* gT);
+/* One launch per layer and direction for everything between the graph layer and the layer stack (bitgcf.py:134,137-172,190-199), users
+ * and items, both domains: [dropout of the layer output, p = 0: none] -> transfer on the overlapped rows -> L2-normalised copy into
+ * the stack's column block (leading dimension ldc / ldg); one wave per row of the stacked [users ; items] table.  Same arithmetic in
+ * the same order as cdr_dropout(_dev) / cdr_transfer_* / cdr_l2_normalize_* run one after the other.  The backward adds the gradient
+ * arriving from the layer above (gS_prev / gT_prev, both NULL for the top layer) before the transfer's backward.                  */
+int cdr_bitgcf_mix_fwd(void* stream, const float* newS, const float* newT, const float* deg_su, const float* deg_tu,
+                       const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI, float lam_s,
+                       float lam_t, float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, float* S2,
+                       float* T2, float* catS_block, float* catT_block, int64_t ldc, float* nS, float* nT);
+int cdr_bitgcf_mix_bwd(void* stream, const float* S2, const float* T2, const float* nS, const float* nT, const float* gcatS_block,
+                       const float* gcatT_block, int64_t ldg, const float* gS_prev, const float* gT_prev, const float* deg_su,
+                       const float* deg_tu, const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU,
+                       int64_t OI, float lam_s, float lam_t, float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s,
+                       uint64_t salt_t, float* gnS, float* gnT);
 int cdr_l2_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, int64_t ldo, float* norm_out);
 int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const float* gy, int64_t ldg, int64_t rows, int D,
                          float* gx, int accumulate);

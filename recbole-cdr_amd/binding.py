@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -100,6 +100,10 @@ _SIGNATURES = {
     'cdr_graph_layer_bwd_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr],
     'cdr_transfer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_transfer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
+    'cdr_bitgcf_mix_fwd': [_c_ptr] * 7 + [_c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_f32, ctypes.c_uint64, _c_ptr, ctypes.c_uint64,
+                           ctypes.c_uint64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_bitgcf_mix_bwd': [_c_ptr] * 7 + [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_f32, _c_f32,
+                           _c_f32, ctypes.c_uint64, _c_ptr, ctypes.c_uint64, ctypes.c_uint64, _c_ptr, _c_ptr],
     'cdr_transfer_drop_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_f32, ctypes.c_uint64, _c_ptr,
                               ctypes.c_uint64, ctypes.c_uint64, _c_i64, _c_ptr, _c_ptr],
     'cdr_transfer_drop_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_f32, ctypes.c_uint64, _c_ptr,

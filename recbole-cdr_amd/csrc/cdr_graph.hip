@@ -298,6 +298,127 @@ __global__ __launch_bounds__(kBlock) void transfer_drop_bwd_kernel(const float* 
     }
 }
 
+// ---- one pass per layer and direction for everything between the graph layer and the layer stack (bitgcf.py:134,137-172,190-199):
+// [dropout of the layer output] -> transfer on the overlapped rows -> L2-normalised copy into the stack, users and items, both
+// domains; one wave per row of the stacked [users ; items] table (row < nu: user block, else item block).  Same arithmetic, in the
+// same order, as dropout_kernel / transfer_*_kernel / l2_normalize_*_kernel run one after the other -- four launches and two extra
+// passes over the [n, D] buffers less per layer and direction.
+struct mix_arg {
+    const float* deg_su; const float* deg_tu; const float* deg_si; const float* deg_ti;
+    int64_t nu, ni, OU, OI; int D; float lam_s, lam_t;
+    drop_arg dr;                                   // dr.p == 0: no dropout
+};
+constexpr int kMixMaxJ = 8;                       // D <= 512
+
+template <int J>
+__global__ __launch_bounds__(kBlock) void mix_fwd_kernel(mix_arg a, const float* __restrict__ newS, const float* __restrict__ newT,
+                                                         float* __restrict__ S2, float* __restrict__ T2, float* __restrict__ catS,
+                                                         float* __restrict__ catT, int64_t ldc, float* __restrict__ nS, float* __restrict__ nT) {
+    const int lane = threadIdx.x & 63, D = a.D;
+    const int64_t n = a.nu + a.ni;
+    const bool drop = a.dr.p > 0.f;
+    const uint64_t seed_s = drop ? drop_seed_of(a.dr, a.dr.salt_s) : 0, seed_t = drop ? drop_seed_of(a.dr, a.dr.salt_t) : 0;
+    const float scale = drop ? 1.0f / (1.0f - a.dr.p) : 1.0f;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    for (int64_t r = w; r < n; r += TW) {
+        const bool user = r < a.nu;
+        const int64_t rl = user ? r : r - a.nu;
+        const bool mixrow = rl < (user ? a.OU : a.OI);
+        float da = 0.f, db = 0.f;
+        if (mixrow) { da = (user ? a.deg_su : a.deg_si)[rl]; db = (user ? a.deg_tu : a.deg_ti)[rl]; }
+        float so[J], to[J], ss = 0.f, st = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = lane + 64 * j;
+            so[j] = to[j] = 0.f;
+            if (c < D) {
+                const int64_t e = r * D + c;
+                float s_ = newS[e], t_ = newT[e];
+                if (drop) {
+                    s_ = drop_factor(seed_s, e, a.dr.p, scale) != 0.f ? s_ * scale : 0.0f;
+                    t_ = drop_factor(seed_t, e, a.dr.p, scale) != 0.f ? t_ * scale : 0.0f;
+                }
+                if (mixrow) {
+                    const float lap = (da * s_ + db * t_) / ((da + db) + 1e-7f);
+                    const float s_lam = a.lam_s * s_ + (1.0f - a.lam_s) * t_;
+                    const float t_lam = a.lam_t * t_ + (1.0f - a.lam_t) * s_;
+                    so[j] = (s_lam + lap) / 2.0f; to[j] = (t_lam + lap) / 2.0f;
+                } else { so[j] = s_; to[j] = t_; }
+                S2[e] = so[j]; T2[e] = to[j];
+                ss += so[j] * so[j]; st += to[j] * to[j];
+            }
+        }
+        ss = group_sum<64>(ss); st = group_sum<64>(st);
+        const float ns_ = sqrtf(ss), nt_ = sqrtf(st);
+        const float ds_ = fmaxf(ns_, 1e-12f), dt_ = fmaxf(nt_, 1e-12f);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) { catS[r * ldc + c] = so[j] / ds_; catT[r * ldc + c] = to[j] / dt_; }
+        }
+        if (lane == 0) { nS[r] = ns_; nT[r] = nt_; }
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(kBlock) void mix_bwd_kernel(mix_arg a, const float* __restrict__ S2, const float* __restrict__ T2,
+                                                         const float* __restrict__ nS, const float* __restrict__ nT,
+                                                         const float* __restrict__ gcatS, const float* __restrict__ gcatT, int64_t ldg,
+                                                         const float* __restrict__ gS_prev, const float* __restrict__ gT_prev,
+                                                         float* __restrict__ gnS, float* __restrict__ gnT) {
+    const int lane = threadIdx.x & 63, D = a.D;
+    const int64_t n = a.nu + a.ni;
+    const bool drop = a.dr.p > 0.f;
+    const uint64_t seed_s = drop ? drop_seed_of(a.dr, a.dr.salt_s) : 0, seed_t = drop ? drop_seed_of(a.dr, a.dr.salt_t) : 0;
+    const float scale = drop ? 1.0f / (1.0f - a.dr.p) : 1.0f;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    for (int64_t r = w; r < n; r += TW) {
+        const bool user = r < a.nu;
+        const int64_t rl = user ? r : r - a.nu;
+        const bool mixrow = rl < (user ? a.OU : a.OI);
+        const float ns_ = nS[r], nt_ = nT[r];
+        const float ds_ = fmaxf(ns_, 1e-12f), dt_ = fmaxf(nt_, 1e-12f);
+        float xs[J], xt[J], gys[J], gyt[J], dS = 0.f, dT = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = lane + 64 * j;
+            xs[j] = xt[j] = gys[j] = gyt[j] = 0.f;
+            if (c < D) {
+                xs[j] = S2[r * D + c]; xt[j] = T2[r * D + c];
+                gys[j] = gcatS[r * ldg + c]; gyt[j] = gcatT[r * ldg + c];
+                dS += (xs[j] / ds_) * gys[j]; dT += (xt[j] / dt_) * gyt[j];
+            }
+        }
+        dS = group_sum<64>(dS); dT = group_sum<64>(dT);
+        const float pS = ns_ > 1e-12f ? dS : 0.f, pT = nt_ > 1e-12f ? dT : 0.f;
+        float wsv = 0.f, wtv = 0.f;
+        if (mixrow) {
+            const float dsv = (user ? a.deg_su : a.deg_si)[rl], dtv = (user ? a.deg_tu : a.deg_ti)[rl];
+            const float dl = (dsv + dtv) + 1e-7f;
+            wsv = dsv / dl; wtv = dtv / dl;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                const int64_t e = r * D + c;
+                const float ga = (gS_prev ? gS_prev[e] : 0.f) + (gys[j] - (xs[j] / ds_) * pS) / ds_;
+                const float gb = (gT_prev ? gT_prev[e] : 0.f) + (gyt[j] - (xt[j] / dt_) * pT) / dt_;
+                float os, ot;
+                if (mixrow) {
+                    os = 0.5f * (ga * (a.lam_s + wsv) + gb * ((1.0f - a.lam_t) + wsv));
+                    ot = 0.5f * (ga * ((1.0f - a.lam_s) + wtv) + gb * (a.lam_t + wtv));
+                } else { os = ga; ot = gb; }
+                if (drop) {
+                    os = drop_factor(seed_s, e, a.dr.p, scale) != 0.f ? os * scale : 0.0f;
+                    ot = drop_factor(seed_t, e, a.dr.p, scale) != 0.f ? ot * scale : 0.0f;
+                }
+                gnS[e] = os; gnT[e] = ot;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #define GR_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
@@ -396,6 +517,46 @@ extern "C" int cdr_transfer_bwd(void* stream, const float* gS_out, const float* 
                                 int64_t rows, int D, int64_t n_overlap, float lam_s, float lam_t, float* gS, float* gT) {
     CDR_CHECK_ARG(gS_out && gT_out && deg_s && deg_t && gS && gT && rows > 0 && D > 0);
     transfer_bwd_kernel<<<GR_GRID(rows * D)>>>(gS_out, gT_out, deg_s, deg_t, rows, D, n_overlap, lam_s, lam_t, gS, gT);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+#define MIX_DISPATCH(KERNEL, ...)                                                                                                   \
+    switch ((D + 63) / 64) {                                                                                                      \
+        case 1: KERNEL<1><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(__VA_ARGS__); break;                    \
+        case 2: KERNEL<2><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(__VA_ARGS__); break;                    \
+        case 3: KERNEL<3><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(__VA_ARGS__); break;                    \
+        case 4: KERNEL<4><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(__VA_ARGS__); break;                    \
+        default: KERNEL<8><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(__VA_ARGS__); break;                   \
+    }
+
+extern "C" int cdr_bitgcf_mix_fwd(void* stream, const float* newS, const float* newT, const float* deg_su, const float* deg_tu,
+                                  const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI,
+                                  float lam_s, float lam_t, float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s,
+                                  uint64_t salt_t, float* S2, float* T2, float* catS_block, float* catT_block, int64_t ldc, float* nS,
+                                  float* nT) {
+    CDR_CHECK_ARG(newS && newT && deg_su && deg_tu && deg_si && deg_ti && S2 && T2 && catS_block && catT_block && nS && nT);
+    CDR_CHECK_ARG(nu > 0 && ni > 0 && D > 0 && D <= 64 * kMixMaxJ && ldc >= D && p >= 0.f && p < 1.f);
+    const mix_arg a{deg_su, deg_tu, deg_si, deg_ti, nu, ni, OU, OI, D, lam_s, lam_t, drop_arg{p, seed, seed_dev, salt_s, salt_t, 0}};
+    int64_t grid = (nu + ni + 3) / 4;
+    if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
+    MIX_DISPATCH(mix_fwd_kernel, a, newS, newT, S2, T2, catS_block, catT_block, ldc, nS, nT);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bitgcf_mix_bwd(void* stream, const float* S2, const float* T2, const float* nS, const float* nT,
+                                  const float* gcatS_block, const float* gcatT_block, int64_t ldg, const float* gS_prev,
+                                  const float* gT_prev, const float* deg_su, const float* deg_tu, const float* deg_si,
+                                  const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI, float lam_s, float lam_t,
+                                  float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, float* gnS,
+                                  float* gnT) {
+    CDR_CHECK_ARG(S2 && T2 && nS && nT && gcatS_block && gcatT_block && deg_su && deg_tu && deg_si && deg_ti && gnS && gnT);
+    CDR_CHECK_ARG(nu > 0 && ni > 0 && D > 0 && D <= 64 * kMixMaxJ && ldg >= D && p >= 0.f && p < 1.f && ((gS_prev == nullptr) == (gT_prev == nullptr)));
+    const mix_arg a{deg_su, deg_tu, deg_si, deg_ti, nu, ni, OU, OI, D, lam_s, lam_t, drop_arg{p, seed, seed_dev, salt_s, salt_t, 0}};
+    int64_t grid = (nu + ni + 3) / 4;
+    if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
+    MIX_DISPATCH(mix_bwd_kernel, a, S2, T2, nS, nT, gcatS_block, gcatT_block, ldg, gS_prev, gT_prev, gnS, gnT);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -615,25 +615,13 @@ class BiTGCFPropagate(Function):
                     B_.f32(sideS), B_.f32(newS))
             B_.call('cdr_graph_layer_fwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T), D,
                     B_.f32(sideT), B_.f32(newT))
-            S2, T2 = f32(n, D), f32(n, D)
-            off = 4 * nu * D
-            if drop_p > 0.0:            # nn.Dropout on the layer output (bitgcf.py:134), one mask per (layer, domain), applied as the
-                dev_seed = torch.is_tensor(drop_seed)                    # transfer layer reads its inputs (no pass of its own)
-                dargs = (float(drop_p), 0 if dev_seed else int(drop_seed), B_.i64(drop_seed) if dev_seed else None, 2 * l, 2 * l + 1)
-                B_.call('cdr_transfer_drop_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU,
-                        lam_s, lam_t, *dargs, 0, B_.f32(S2), B_.f32(T2))
-                B_.call('cdr_transfer_drop_fwd', st(), B_._c_ptr(newS.data_ptr() + off), B_._c_ptr(newT.data_ptr() + off),
-                        B_.f32(deg['si']), B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, *dargs, nu * D, B_._c_ptr(S2.data_ptr() + off),
-                        B_._c_ptr(T2.data_ptr() + off))
-            else:
-                B_.call('cdr_transfer_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU,
-                        lam_s, lam_t, B_.f32(S2), B_.f32(T2))
-                B_.call('cdr_transfer_fwd', st(), B_._c_ptr(newS.data_ptr() + off), B_._c_ptr(newT.data_ptr() + off),
-                        B_.f32(deg['si']), B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, B_._c_ptr(S2.data_ptr() + off),
-                        B_._c_ptr(T2.data_ptr() + off))
-            nS, nT = f32(n), f32(n)
-            B_.call('cdr_l2_normalize_fwd', st(), B_.f32(S2), n, D, B_._c_ptr(catS.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nS))
-            B_.call('cdr_l2_normalize_fwd', st(), B_.f32(T2), n, D, B_._c_ptr(catT.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nT))
+            # [dropout ->] transfer -> L2-normalised copy into the layer stack: one launch for users and items of both domains
+            S2, T2, nS, nT = f32(n, D), f32(n, D), f32(n), f32(n)
+            dev_seed = torch.is_tensor(drop_seed)
+            B_.call('cdr_bitgcf_mix_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']),
+                    B_.f32(deg['ti']), nu, ni, D, OU, OI, lam_s, lam_t, float(drop_p), 0 if dev_seed else int(drop_seed),
+                    B_.i64(drop_seed) if dev_seed else None, 2 * l, 2 * l + 1, B_.f32(S2), B_.f32(T2),
+                    B_._c_ptr(catS.data_ptr() + 4 * (l + 1) * D), B_._c_ptr(catT.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nS), B_.f32(nT))
             saved += [S, T, sideS, sideT, S2, T2, nS, nT]
             S, T = S2, T2
         if connect_way == 'concat':
@@ -662,30 +650,16 @@ class BiTGCFPropagate(Function):
             B_.call('cdr_colblock_mean_bwd', st(), B_.f32(gOutT.contiguous()), n, D, nb, B_.f32(gcatT))
         gS = gT = None                        # gradient w.r.t. the un-normalised layer output that continues downward
         tmp = f32(n, D)
-        off = 4 * nu * D
         for l in reversed(range(n_layers)):
             S_in, T_in, sideS, sideT, S2, T2, nS, nT = saved[8 * l:8 * l + 8]
-            acc = 0 if gS is None else 1
-            if gS is None:
-                gS, gT = f32(n, D), f32(n, D)
-            B_.call('cdr_l2_normalize_bwd', st(), B_.f32(S2), B_.f32(nS), B_._c_ptr(gcatS.data_ptr() + 4 * (l + 1) * D), nb * D,
-                    n, D, B_.f32(gS), acc)
-            B_.call('cdr_l2_normalize_bwd', st(), B_.f32(T2), B_.f32(nT), B_._c_ptr(gcatT.data_ptr() + 4 * (l + 1) * D), nb * D,
-                    n, D, B_.f32(gT), acc)
+            # backward of the same chain in one launch: normalise -> (+ gradient from the layer above) -> transfer [-> dropout mask]
             gnS, gnT = f32(n, D), f32(n, D)
-            if drop_p > 0.0:            # same masks as the forward, applied as the transfer layer's backward writes its outputs
-                dev_seed = torch.is_tensor(drop_seed)
-                dargs = (float(drop_p), 0 if dev_seed else int(drop_seed), B_.i64(drop_seed) if dev_seed else None, 2 * l, 2 * l + 1)
-                B_.call('cdr_transfer_drop_bwd', st(), B_.f32(gS), B_.f32(gT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU, lam_s,
-                        lam_t, *dargs, 0, B_.f32(gnS), B_.f32(gnT))
-                B_.call('cdr_transfer_drop_bwd', st(), B_._c_ptr(gS.data_ptr() + off), B_._c_ptr(gT.data_ptr() + off), B_.f32(deg['si']),
-                        B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, *dargs, nu * D, B_._c_ptr(gnS.data_ptr() + off),
-                        B_._c_ptr(gnT.data_ptr() + off))
-            else:
-                B_.call('cdr_transfer_bwd', st(), B_.f32(gS), B_.f32(gT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU, lam_s,
-                        lam_t, B_.f32(gnS), B_.f32(gnT))
-                B_.call('cdr_transfer_bwd', st(), B_._c_ptr(gS.data_ptr() + off), B_._c_ptr(gT.data_ptr() + off), B_.f32(deg['si']),
-                        B_.f32(deg['ti']), ni, D, OI, lam_s, lam_t, B_._c_ptr(gnS.data_ptr() + off), B_._c_ptr(gnT.data_ptr() + off))
+            dev_seed = torch.is_tensor(drop_seed)
+            B_.call('cdr_bitgcf_mix_bwd', st(), B_.f32(S2), B_.f32(T2), B_.f32(nS), B_.f32(nT),
+                    B_._c_ptr(gcatS.data_ptr() + 4 * (l + 1) * D), B_._c_ptr(gcatT.data_ptr() + 4 * (l + 1) * D), nb * D,
+                    B_.f32(gS), B_.f32(gT), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']), B_.f32(deg['ti']), nu, ni, D, OU, OI,
+                    lam_s, lam_t, float(drop_p), 0 if dev_seed else int(drop_seed), B_.i64(drop_seed) if dev_seed else None,
+                    2 * l, 2 * l + 1, B_.f32(gnS), B_.f32(gnT))
             gS_in, gT_in = f32(n, D), f32(n, D)
             B_.call('cdr_graph_layer_bwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S_in),
                     B_.f32(sideS), B_.f32(gnS), D, B_.f32(tmp), B_.f32(gS_in))

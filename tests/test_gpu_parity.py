@@ -2197,3 +2197,63 @@ def test_transfer_with_folded_dropout_equals_dropout_then_transfer(dev_seed):
         if name == 'bwd':
             r1, r2 = drop(r1, 4), drop(r2, 5)
         assert torch.equal(r1, f1) and torch.equal(r2, f2), name
+
+
+@pytest.mark.parametrize('D,p', [(8, 0.0), (64, 0.3), (100, 0.5), (300, 0.2)])
+def test_bitgcf_mix_kernels_equal_the_unfused_chain(D, p):
+    """cdr_bitgcf_mix_fwd / _bwd (one launch per layer and direction) == dropout -> transfer (users, items) -> L2 normalise and its
+    backward run as separate kernels: forward bit for bit, backward to the last bit or two (FMA contraction); row widths on 1, 2 and 5+
+    lane passes per row."""
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(D)
+    nu, ni, OU, OI, nb = 301, 222, 57, 1, 3
+    n = nu + ni
+    st = B_.stream
+    newS, newT = torch.randn(n, D, device=DEV), torch.randn(n, D, device=DEV)
+    newS[5] = 0.0                                                # an all-zero row: the clamp branch of the normalisation
+    deg = {k: torch.rand(m, device=DEV) * 5 for k, m in (('su', nu), ('tu', nu), ('si', ni), ('ti', ni))}
+    seed = torch.tensor([99], device=DEV, dtype=torch.int64)
+    f32 = lambda *sh: torch.empty(*sh, device=DEV)
+    off = 4 * nu * D
+    # ---- unfused forward
+    a, b = newS.clone(), newT.clone()
+    if p > 0:
+        B_.call('cdr_dropout_dev', st(), B_.f32(a), n * D, p, B_.i64(seed), 2, B_.f32(a))
+        B_.call('cdr_dropout_dev', st(), B_.f32(b), n * D, p, B_.i64(seed), 3, B_.f32(b))
+    S2, T2 = f32(n, D), f32(n, D)
+    B_.call('cdr_transfer_fwd', st(), B_.f32(a), B_.f32(b), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU, 0.8, 0.7, B_.f32(S2), B_.f32(T2))
+    B_.call('cdr_transfer_fwd', st(), B_._c_ptr(a.data_ptr() + off), B_._c_ptr(b.data_ptr() + off), B_.f32(deg['si']), B_.f32(deg['ti']), ni, D, OI,
+            0.8, 0.7, B_._c_ptr(S2.data_ptr() + off), B_._c_ptr(T2.data_ptr() + off))
+    catS, catT, nS, nT = torch.zeros(n, nb * D, device=DEV), torch.zeros(n, nb * D, device=DEV), f32(n), f32(n)
+    B_.call('cdr_l2_normalize_fwd', st(), B_.f32(S2), n, D, B_._c_ptr(catS.data_ptr() + 4 * D), nb * D, B_.f32(nS))
+    B_.call('cdr_l2_normalize_fwd', st(), B_.f32(T2), n, D, B_._c_ptr(catT.data_ptr() + 4 * D), nb * D, B_.f32(nT))
+    # ---- fused forward
+    S2f, T2f, catSf, catTf, nSf, nTf = f32(n, D), f32(n, D), torch.zeros(n, nb * D, device=DEV), torch.zeros(n, nb * D, device=DEV), f32(n), f32(n)
+    B_.call('cdr_bitgcf_mix_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']), B_.f32(deg['ti']),
+            nu, ni, D, OU, OI, 0.8, 0.7, p, 0, B_.i64(seed), 2, 3, B_.f32(S2f), B_.f32(T2f), B_._c_ptr(catSf.data_ptr() + 4 * D),
+            B_._c_ptr(catTf.data_ptr() + 4 * D), nb * D, B_.f32(nSf), B_.f32(nTf))
+    for x, y, what in ((S2, S2f, 'S2'), (T2, T2f, 'T2'), (catS, catSf, 'catS'), (catT, catTf, 'catT'), (nS, nSf, 'nS'), (nT, nTf, 'nT')):
+        assert_close(y, x, rtol=1e-6, atol=1e-6, what=what)        # (FMA contraction may differ between the kernels: last bit)
+    assert torch.equal(S2 == 0, S2f == 0) and torch.equal(T2 == 0, T2f == 0)          # identical dropout masks
+    # ---- backward, with and without a gradient from the layer above
+    gcatS, gcatT = torch.randn(n, nb * D, device=DEV), torch.randn(n, nb * D, device=DEV)
+    for prev in (False, True):
+        gS = torch.randn(n, D, device=DEV) if prev else f32(n, D)
+        gT = torch.randn(n, D, device=DEV) if prev else f32(n, D)
+        gS0, gT0 = (gS.clone(), gT.clone()) if prev else (None, None)
+        B_.call('cdr_l2_normalize_bwd', st(), B_.f32(S2), B_.f32(nS), B_._c_ptr(gcatS.data_ptr() + 4 * D), nb * D, n, D, B_.f32(gS), int(prev))
+        B_.call('cdr_l2_normalize_bwd', st(), B_.f32(T2), B_.f32(nT), B_._c_ptr(gcatT.data_ptr() + 4 * D), nb * D, n, D, B_.f32(gT), int(prev))
+        gnS, gnT = f32(n, D), f32(n, D)
+        B_.call('cdr_transfer_bwd', st(), B_.f32(gS), B_.f32(gT), B_.f32(deg['su']), B_.f32(deg['tu']), nu, D, OU, 0.8, 0.7, B_.f32(gnS), B_.f32(gnT))
+        B_.call('cdr_transfer_bwd', st(), B_._c_ptr(gS.data_ptr() + off), B_._c_ptr(gT.data_ptr() + off), B_.f32(deg['si']), B_.f32(deg['ti']), ni, D,
+                OI, 0.8, 0.7, B_._c_ptr(gnS.data_ptr() + off), B_._c_ptr(gnT.data_ptr() + off))
+        if p > 0:
+            B_.call('cdr_dropout_dev', st(), B_.f32(gnS), n * D, p, B_.i64(seed), 2, B_.f32(gnS))
+            B_.call('cdr_dropout_dev', st(), B_.f32(gnT), n * D, p, B_.i64(seed), 3, B_.f32(gnT))
+        gnSf, gnTf = f32(n, D), f32(n, D)
+        B_.call('cdr_bitgcf_mix_bwd', st(), B_.f32(S2), B_.f32(T2), B_.f32(nS), B_.f32(nT), B_._c_ptr(gcatS.data_ptr() + 4 * D),
+                B_._c_ptr(gcatT.data_ptr() + 4 * D), nb * D, B_.f32(gS0), B_.f32(gT0), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']),
+                B_.f32(deg['ti']), nu, ni, D, OU, OI, 0.8, 0.7, p, 0, B_.i64(seed), 2, 3, B_.f32(gnSf), B_.f32(gnTf))
+        # (the backward's fused multiply-adds may contract differently in the two kernels: last-bit differences)
+        assert_close(gnSf, gnS, rtol=1e-6, atol=1e-6, what=f'gnS prev={prev}'); assert_close(gnTf, gnT, rtol=1e-6, atol=1e-6, what=f'gnT prev={prev}')
+        assert torch.equal(gnS == 0, gnSf == 0)                  # the dropout mask itself is identical
