@@ -383,7 +383,8 @@ int cdr_transfer_drop_bwd(void* stream, const float* gS_out, const float* gT_out
 /* One launch per layer and direction for everything between the graph layer and the layer stack (bitgcf.py:134,137-172,190-199), users
  * and items, both domains: [dropout of the layer output, p = 0: none] -> transfer on the overlapped rows -> L2-normalised copy into
  * the stack's column block (leading dimension ldc / ldg); one wave per row of the stacked [users ; items] table.  Same arithmetic in
- * the same order as cdr_dropout(_dev) / cdr_transfer_* / cdr_l2_normalize_* run one after the other.  The backward adds the gradient
+ * the same order as cdr_dropout(_dev) / cdr_transfer_* / cdr_l2_normalize_* run one after the other (equal to the last bit or two: FMA
+ * contraction; identical dropout masks).  The backward adds the gradient
  * arriving from the layer above (gS_prev / gT_prev, both NULL for the top layer) before the transfer's backward.                  */
 int cdr_bitgcf_mix_fwd(void* stream, const float* newS, const float* newT, const float* deg_su, const float* deg_tu,
                        const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI, float lam_s,
