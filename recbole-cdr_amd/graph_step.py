@@ -41,7 +41,7 @@ class GraphedTrainStep:
         losses = self.model.calculate_loss(interaction)
         loss = sum(losses) if isinstance(losses, tuple) else losses
         if loss.dim():
-            loss = loss.sum()
+            loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()   # (a [1]-shaped loss: a view, not a reduction launch)
         loss.backward()
         self.optimizer.step()
         return loss.detach()

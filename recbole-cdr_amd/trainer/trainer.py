@@ -161,7 +161,7 @@ class Trainer:
             self.optimizer.zero_grad()
             losses = self.model.calculate_loss(interaction)
             loss = sum(losses) if isinstance(losses, tuple) else losses
-            loss = loss.sum()
+            loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()   # (a [1]-shaped loss: a view, not a reduction launch)
             loss.backward()
             if self.clip_grad_norm:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), **self.clip_grad_norm)
