@@ -101,6 +101,59 @@ class PointGatherLoss(Function):
         return None, gU, (None if shared else gI), gRU, gRI, None, None, None, None
 
 
+_pair_w = {}
+
+
+def _pair_weights(dev, alpha):
+    """[alpha, 1 - alpha] on the device, created once per (device, alpha): a host-to-device copy is not allowed inside a hipGraph capture
+    (the eager warm-up steps that precede a capture create it)."""
+    key = (str(dev), alpha)
+    if key not in _pair_w:
+        _pair_w[key] = torch.tensor([alpha, 1.0 - alpha], device=dev, dtype=torch.float32)
+    return _pair_w[key]
+
+
+class TwoDomainPointLoss(Function):
+    """alpha * L(source batch) + (1 - alpha) * L(target batch) for two pointwise batches on the SAME pair of tables (cmf.py:81-99: both
+    domains share user_embedding / item_embedding): two fused gather-dot-loss launches, and in the backward two scatter launches
+    into ONE pair of gradient buffers -- instead of two autograd nodes with their own table-sized gradients, the adds that merge
+    them and the scalar arithmetic in between.  Returns (total [1], per-domain losses [2])."""
+
+    @staticmethod
+    def forward(ctx, kind, user_w, item_w, su, si, sl, reg_s, tu, ti, tl, reg_t, alpha):
+        _dev_check(user_w, item_w, su, si, tu, ti)
+        dev = user_w.device
+        D = user_w.shape[1]
+        ids = [_ids(su), _ids(si), _ids(tu), _ids(ti)]
+        labels = [sl.reshape(-1).contiguous().to(torch.float32), tl.reshape(-1).contiguous().to(torch.float32)]
+        out8 = torch.empty(2, 4, device=dev, dtype=torch.float32)
+        gs = []
+        for d, (u, i, y, reg) in enumerate(((ids[0], ids[1], labels[0], reg_s), (ids[2], ids[3], labels[1], reg_t))):
+            n = u.numel()
+            g = torch.empty(n, device=dev, dtype=torch.float32)
+            scores = torch.empty(n, device=dev, dtype=torch.float32)
+            B_.call('cdr_point_fwd', B_.ctx(dev), B_.stream(), int(kind), B_.f32(user_w), B_.f32(item_w), None, None, D, B_.i64(u), B_.i64(i),
+                    B_.f32(y), n, float(reg), B_._c_ptr(out8.data_ptr() + 16 * d), B_.f32(g), B_.f32(scores))
+            gs.append(g)
+        w = _pair_weights(dev, float(alpha))
+        ctx.save_for_backward(user_w, item_w, *ids, *gs, out8, w)
+        ctx.regs = (float(reg_s), float(reg_t))
+        losses = out8[:, 0]
+        ctx.mark_non_differentiable(losses)
+        return (losses * w).sum().reshape(1), losses
+
+    @staticmethod
+    def backward(ctx, grad_out, _gl):
+        user_w, item_w, su, si, tu, ti, g_s, g_t, out8, w = ctx.saved_tensors
+        gU, gI = _zeros_like2(user_w, item_w)
+        go2 = (grad_out.reshape(-1)[:1].to(torch.float32) * w).contiguous()               # d total / d L_domain, on the device
+        for d, (u, i, g, reg) in enumerate(((su, si, g_s, ctx.regs[0]), (tu, ti, g_t, ctx.regs[1]))):
+            B_.call('cdr_point_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), None, None, user_w.shape[1],
+                    B_.i64(u), B_.i64(i), u.numel(), B_.f32(g), B_._c_ptr(out8.data_ptr() + 16 * d), reg, B_._c_ptr(go2.data_ptr() + 4 * d),
+                    B_.f32(gU), B_.f32(gI), None, None)
+        return None, gU, gI, None, None, None, None, None, None, None, None, None
+
+
 class GatherRows(Function):
     """nn.Embedding(idx) with its dense backward."""
 

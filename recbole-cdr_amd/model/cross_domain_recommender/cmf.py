@@ -36,11 +36,13 @@ class CMF(CrossDomainRecommender):
         return p
 
     def calculate_loss(self, interaction):
-        loss_s, _ = self._loss_and_prob(interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID],
-                                        interaction[self.SOURCE_LABEL], self.lamda)
-        loss_t, _ = self._loss_and_prob(interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID],
-                                        interaction[self.TARGET_LABEL], self.gamma)
-        return loss_s * self.alpha + loss_t * (1 - self.alpha)
+        # both domains' batches on the shared tables as ONE autograd node (two loss launches forward, two scatter launches into one pair
+        # of gradient buffers backward)
+        total, _ = F_.TwoDomainPointLoss.apply(
+            B_.CDR_LOSS_BCE, self.user_embedding.weight, self.item_embedding.weight,
+            interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.SOURCE_LABEL], self.lamda,
+            interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], interaction[self.TARGET_LABEL], self.gamma, self.alpha)
+        return total
 
     @torch.no_grad()
     def predict(self, interaction):
