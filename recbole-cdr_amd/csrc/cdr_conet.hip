@@ -178,6 +178,65 @@ __device__ __forceinline__ void fwd_layer(const conet_net& net, int l, const flo
     }
 }
 
+// The L2-streamed layer without a predicate in its loop, for din % 128 == 0, dout % 32 == 0 and 16-B aligned weights (C3's first
+// layer, 256 -> 64).  fwd_layer<false> keeps one group of fragments (4 K steps = 32 MFMAs = 0.9 us) in flight, which is less
+// than the latency of these loads (a wave's request touches 32 lines of 32 B each), behind `if (k < din)` exec masks; here
+// four register sets rotate through a loop unrolled by four groups, so every group is requested two groups (1.8 us) before
+// its MFMAs, and the A fragments of a group are read from LDS in one batch.  Same K order as fwd_layer: bit-identical sums.
+__device__ __forceinline__ void fwd_layer_stream(const conet_net& net, int l, const float* __restrict__ Xin, float* __restrict__ Xout,
+                                                 const float* __restrict__ mrow, float* __restrict__ acts,
+                                                 int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int XS = 2 * din + 4, XO = 2 * dout + 4;
+    const int NT = dout >> 5, KQ = din >> 7;
+    const int off = net.act_off[l], actw = net.act_off[net.L];
+    for (int job = wave; job < 2 * NT; job += 4) {
+        const int tower = job / NT, n = (job - tower * NT) * 32 + li;
+        const float* xo = Xin + li * XS + (tower ? din : 0) + 4 * lh;
+        const float* xc = Xin + li * XS + (tower ? 0 : din) + 4 * lh;
+        const float* wm = tower ? net.Wt[l] : net.Ws[l];                  // wave-uniform bases + one 32-bit lane offset: the
+        const float* hc = net.H[l];                                       // 32 requests of a round share a single address VGPR
+        const unsigned vo = (unsigned)(n * din + 4 * lh);
+        const float bv = (tower ? net.bt[l] : net.bs[l])[n];
+        f32x16 am = zero16(), ac = zero16();
+        float4 m0[4], c0[4], m1[4], c1[4], m2[4], c2[4], m3[4], c3[4];
+#define CDR_LOADG(M, C, KB)                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { M[j] = ld4(wm + (KB) + (vo + 8 * j)); C[j] = ld4(hc + (KB) + (vo + 8 * j)); }
+#define CDR_MFG(M, C, KB) {                                                                         \
+            float4 a0[4], a1[4];                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { a0[j] = ld4(xo + (KB) + 8 * j); a1[j] = ld4(xc + (KB) + 8 * j); } \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { MFMA4(am, a0[j], M[j]); MFMA4(ac, a1[j], C[j]); } }
+        CDR_LOADG(m0, c0, 0);
+        CDR_LOADG(m1, c1, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < KQ; ++q) {
+            const int kb = q << 7;
+            const int kw = q + 1 < KQ ? kb + 128 : 0;         // the last round re-requests the first groups (unused) instead of branching
+            // sched_barrier: hipcc's scheduler otherwise sinks every request down to just before its MFMAs (lower register pressure,
+            // no latency hidden)
+            CDR_LOADG(m2, c2, kb + 64); __builtin_amdgcn_sched_barrier(0);
+            CDR_MFG(m0, c0, kb);        __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADG(m3, c3, kb + 96); __builtin_amdgcn_sched_barrier(0);
+            CDR_MFG(m1, c1, kb + 32);   __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADG(m0, c0, kw);      __builtin_amdgcn_sched_barrier(0);
+            CDR_MFG(m2, c2, kb + 64);   __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADG(m1, c1, kw + 32); __builtin_amdgcn_sched_barrier(0);
+            CDR_MFG(m3, c3, kb + 96);   __builtin_amdgcn_sched_barrier(0);
+        }
+#undef CDR_LOADG
+#undef CDR_MFG
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = am[r] + bv;
+            if (mrow[row] != 0.f) v += ac[r];                          // conet.py:127-129 / :132-134
+            v = v > 0.f ? v : 0.f;
+            Xout[row * XO + tower * dout + n] = v;
+            if (row0 + row < R) acts[(row0 + row) * actw + off + tower * dout + n] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const float* __restrict__ su, const float* __restrict__ si,
                                                         const float* __restrict__ tu, const float* __restrict__ ti, int D,
                                                         const int64_t* __restrict__ user_s, const int64_t* __restrict__ user_t,
@@ -234,6 +293,8 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
             const float* Xin = (l & 1) ? bufB : bufA;
             float* Xout = (l & 1) ? bufA : bufB;
             if (l > 0 && net.wlds) fwd_layer<true>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            else if (net.vec && !(net.dims[l] & 127) && !(net.dims[l + 1] & 31))
+                fwd_layer_stream(net, l, Xin, Xout, mrow, acts, rb * kRows, R, wave, li, lh);
             else fwd_layer<false>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
             lds_barrier();
             STAMP(2 + l);
@@ -385,6 +446,137 @@ __device__ __forceinline__ void bwd_layer(const conet_net& net, int l, const flo
     }
 }
 
+// bwd_layer without a predicate in its loop, for dout % 32 == 0 and din % (32 NJ) == 0: a wave owns NJ whole column tiles, the
+// B values rotate through four register sets in a loop unrolled by four K steps (each set is requested two steps before its
+// MFMAs; bwd_layer's exec-masked loads and wave-uniform branches made hipcc wait for every step's loads right before their use
+// and shuttle the accumulators between VGPRs and AGPRs around every 8 MFMAs: 22 us for C3's first layer, 6.5 us for its
+// second).  Used with NJ = 1 for din % 32 == 0; din % 128 == 0 takes bwd_layer_quad.  Same K order as bwd_layer:
+// bit-identical sums.
+template <bool WL, int NJ>
+__device__ __forceinline__ void bwd_layer_tiles(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ Gn,
+                                                const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ gx0,
+                                                int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4;
+    const int NG = (din >> 5) / NJ, KQ = dout >> 5;
+    const int ldw = WL ? din + 4 : din;
+    for (int u = wave; u < 2 * NG; u += 4) {
+        const int tower = u / NG, c0 = (u - tower * NG) * NJ * 32 + li;
+        const float* Wm = WL ? wl + net.wl_off[l] + (tower ? dout * ldw : 0) : (tower ? net.Wt[l] : net.Ws[l]);   // wave-uniform
+        const float* Hm = WL ? wl + net.wl_off[l] + 2 * dout * ldw : net.H[l];
+        const unsigned vo = (unsigned)(4 * lh * ldw + c0);                // the one lane-dependent part of every B address
+        const float* ao = Gl + li * GS + (tower ? dout : 0) + 4 * lh;
+        const float* ax = Gl + li * GS + (tower ? 0 : dout) + 4 * lh;
+        f32x16 am[NJ], ac[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { am[j] = zero16(); ac[j] = zero16(); }
+        float4 m0[NJ], h0[NJ], m1[NJ], h1[NJ], m2[NJ], h2[NJ], m3[NJ], h3[NJ];
+#define CDR_LOADS(M, Hh, K)                                                                         \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                            \
+            const float* w_ = Wm + (K) * ldw;                                                       \
+            const float* h_ = Hm + (K) * ldw;                                                       \
+            const unsigned o_ = vo + 32 * j;                                                        \
+            M[j] = make_float4(w_[o_], (w_ + ldw)[o_], (w_ + 2 * ldw)[o_], (w_ + 3 * ldw)[o_]);     \
+            Hh[j] = make_float4(h_[o_], (h_ + ldw)[o_], (h_ + 2 * ldw)[o_], (h_ + 3 * ldw)[o_]); }
+#define CDR_MFS(M, Hh, K) {                                                                         \
+            const float4 a0 = ld4(ao + (K)), a1 = ld4(ax + (K));                                    \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) { MFMA4(am[j], a0, M[j]); MFMA4(ac[j], a1, Hh[j]); } }
+        CDR_LOADS(m0, h0, 0);
+        CDR_LOADS(m1, h1, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < KQ; ++q) {
+            const int kb = q << 5;
+            const int kw = q + 1 < KQ ? kb + 32 : 0;
+            CDR_LOADS(m2, h2, kb + 16); __builtin_amdgcn_sched_barrier(0);       // see fwd_layer_stream
+            CDR_MFS(m0, h0, kb);        __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADS(m3, h3, kb + 24); __builtin_amdgcn_sched_barrier(0);
+            CDR_MFS(m1, h1, kb + 8);    __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADS(m0, h0, kw);      __builtin_amdgcn_sched_barrier(0);
+            CDR_MFS(m2, h2, kb + 16);   __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADS(m1, h1, kw + 8);  __builtin_amdgcn_sched_barrier(0);
+            CDR_MFS(m3, h3, kb + 24);   __builtin_amdgcn_sched_barrier(0);
+        }
+#undef CDR_LOADS
+#undef CDR_MFS
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = am[j][r];
+                if (mrow[row] != 0.f) v += ac[j][r];
+                if (l > 0) Gn[row * GN + tower * din + c0 + 32 * j] = v;
+                else if (row0 + row < R) gx0[(row0 + row) * (2 * (int64_t)din) + tower * din + c0 + 32 * j] = v;
+            }
+        }
+    }
+}
+
+// The 128-column form of bwd_layer_tiles: the wave's four accumulator tiles take columns cb + 4 li + j (j = tile) instead of
+// cb + 32 j + li, so the four B values a lane needs from one row of W are 16 contiguous bytes -- 8 dwordx4 requests per K
+// step instead of 32 dword ones (a returning request costs the CU's vector-memory path about as much either way, and with
+// dwords that path, not the MFMAs, set the pace) -- and its outputs go out as one 16-B store per row.  Which columns share
+// a tile does not enter any sum: bit-identical to bwd_layer.
+__device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+template <bool WL>
+__device__ __forceinline__ void bwd_layer_quad(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ Gn,
+                                               const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ gx0,
+                                               int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4;
+    const int NG = din >> 7, KQ = dout >> 5;
+    const int ldw = WL ? din + 4 : din;
+    for (int u = wave; u < 2 * NG; u += 4) {
+        const int tower = u / NG, c0 = (u - tower * NG) * 128 + 4 * li;
+        const float* Wm = WL ? wl + net.wl_off[l] + (tower ? dout * ldw : 0) : (tower ? net.Wt[l] : net.Ws[l]);   // wave-uniform
+        const float* Hm = WL ? wl + net.wl_off[l] + 2 * dout * ldw : net.H[l];
+        const unsigned vo = (unsigned)(4 * lh * ldw + c0);
+        const float* ao = Gl + li * GS + (tower ? dout : 0) + 4 * lh;
+        const float* ax = Gl + li * GS + (tower ? 0 : dout) + 4 * lh;
+        f32x16 am[4], ac[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { am[j] = zero16(); ac[j] = zero16(); }
+        float4 m0[4], h0[4], m1[4], h1[4], m2[4], h2[4], m3[4], h3[4];       // [r] = W[k + r][c0 .. c0 + 3]
+#define CDR_LOADS(M, Hh, K)                                                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                             \
+            M[r] = ld4(Wm + ((K) + r) * ldw + vo);                                                  \
+            Hh[r] = ld4(Hm + ((K) + r) * ldw + vo); }
+#define CDR_MFS(M, Hh, K) {                                                                         \
+            const float4 a0 = ld4(ao + (K)), a1 = ld4(ax + (K));                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+                MF1(am[j], a0.x, comp4(M[0], j)); MF1(am[j], a0.y, comp4(M[1], j));                 \
+                MF1(am[j], a0.z, comp4(M[2], j)); MF1(am[j], a0.w, comp4(M[3], j));                 \
+                MF1(ac[j], a1.x, comp4(Hh[0], j)); MF1(ac[j], a1.y, comp4(Hh[1], j));               \
+                MF1(ac[j], a1.z, comp4(Hh[2], j)); MF1(ac[j], a1.w, comp4(Hh[3], j)); } }
+        CDR_LOADS(m0, h0, 0);
+        CDR_LOADS(m1, h1, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < KQ; ++q) {
+            const int kb = q << 5;
+            const int kw = q + 1 < KQ ? kb + 32 : 0;
+            CDR_LOADS(m2, h2, kb + 16); __builtin_amdgcn_sched_barrier(0);       // see fwd_layer_stream
+            CDR_MFS(m0, h0, kb);        __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADS(m3, h3, kb + 24); __builtin_amdgcn_sched_barrier(0);
+            CDR_MFS(m1, h1, kb + 8);    __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADS(m0, h0, kw);      __builtin_amdgcn_sched_barrier(0);
+            CDR_MFS(m2, h2, kb + 16);   __builtin_amdgcn_sched_barrier(0);
+            CDR_LOADS(m1, h1, kw + 8);  __builtin_amdgcn_sched_barrier(0);
+            CDR_MFS(m3, h3, kb + 24);   __builtin_amdgcn_sched_barrier(0);
+        }
+#undef CDR_LOADS
+#undef CDR_MFS
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool cross = mrow[row] != 0.f;
+            const float4 v = make_float4(cross ? am[0][r] + ac[0][r] : am[0][r], cross ? am[1][r] + ac[1][r] : am[1][r],
+                                         cross ? am[2][r] + ac[2][r] : am[2][r], cross ? am[3][r] + ac[3][r] : am[3][r]);
+            if (l > 0) st4(Gn + row * GN + tower * din + c0, v);
+            else if (row0 + row < R) st4(gx0 + (row0 + row) * (2 * (int64_t)din) + tower * din + c0, v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R, int64_t n_source, const float* __restrict__ label,
                                                         const float* __restrict__ prob, const float* __restrict__ maskf,
                                                         const float* __restrict__ acts, const float* __restrict__ grad_out,
@@ -462,7 +654,15 @@ __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R
             }
             lds_barrier();
             STAMP(19 + 2 * (L - 1 - l));
-            if (l > 0 && net.wlds) bwd_layer<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            const int din = net.dims[l];
+            const bool lds_w = l > 0 && net.wlds;
+            if (!(dout & 31) && !(din & 127)) {              // whole tiles: the predicate-free loops
+                if (lds_w) bwd_layer_quad<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+                else bwd_layer_quad<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            } else if (!(dout & 31) && !(din & 31)) {
+                if (lds_w) bwd_layer_tiles<true, 1>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+                else bwd_layer_tiles<false, 1>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            } else if (lds_w) bwd_layer<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
             else bwd_layer<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
             lds_barrier();
             STAMP(20 + 2 * (L - 1 - l));

@@ -759,10 +759,11 @@ def test_conet_c3_shape_vs_oracle(fused):
 
 
 @pytest.mark.parametrize('R,n_s,hidden,D', [(77, 33, [12, 8, 4], 8), (64, 2, [64, 32], 16), (1000, 998, [40], 20), (4, 2, [8, 4], 8),
-                                          (4097, 2048, [32, 32, 16, 8], 128)])
+                                          (4097, 2048, [32, 32, 16, 8], 128), (100, 50, [128, 32], 64)])
 def test_conet_fused_ragged_shapes_and_determinism(R, n_s, hidden, D):
     """The fused tower kernels on row counts that are not multiples of the 32-row tile, one-row domains, widths that are not
-    multiples of 8 / 32, a widening layer, the tuned [32,32,16,8] stack -- loss and every gradient vs the oracle at 1e-5 --
+    multiples of 8 / 32, a widening layer, the tuned [32,32,16,8] stack, a 128-wide second layer (the 128-column backward loop on
+    LDS-staged weights) -- loss and every gradient vs the oracle at 1e-5 --
     and twice in a row: bit-identical (no float atomics in the tower backward; the dense embedding scatter is compared
     through the deterministic input gradient)."""
     from oracle import conet as oconet
