@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R
 // One WAVE per (layer, pair of 32-row m tiles, 32-column n tile, chunk of batch rows): it accumulates the Ws, Wt and H tiles
 // of its m tiles at once, so a K step of 8 batch rows costs 16 + 8 operand loads for 32 MFMAs (the first version, one
 // tile per wave, loaded 8 per 4 and re-read every operand panel for every tile: 105 us + a 146 us serial reduction).
+// The four waves of a workgroup share the job and add their tiles through LDS before the partial is written (wgrad_job).
 struct job_id { int l, mp, nt; };
 __device__ __forceinline__ job_id decode_job(const conet_net& net, const conet_tiles& jl, int jb) {
     job_id d;
@@ -688,95 +689,144 @@ __device__ __forceinline__ job_id decode_job(const conet_net& net, const conet_t
 }
 
 struct wg_ops { float s0[4], t0[4], s1[4], t1[4], xs[4], xt[4], mk[4]; };
+struct wg_src { const float* gs0; const float* gs1; const float* bsp; const float* maskf; int64_t actw, ldin, r_safe, r_end; int dout, din; };
 
-__global__ __launch_bounds__(256) void conet_wgrad_kernel(conet_net net, conet_tiles jl, int64_t R, int64_t kc, int nsplit,
+// 8 batch rows of operands (lane half lh takes rows first + 0..3): no predicate -- rows past the chunk are re-read from a
+// valid row and zeroed (A side) where they are used, columns past the layer are clamped and never read back.
+template <bool TWO>
+__device__ __forceinline__ void wg_load(wg_ops& o, const wg_src& q, int64_t first) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t row = first + c, rc = row < q.r_end ? row : q.r_safe;
+        o.mk[c] = q.maskf[rc];
+        o.s0[c] = q.gs0[rc * q.actw]; o.t0[c] = q.gs0[rc * q.actw + q.dout];
+        o.xs[c] = q.bsp[rc * q.ldin]; o.xt[c] = q.bsp[rc * q.ldin + q.din];
+        if (TWO) { o.s1[c] = q.gs1[rc * q.actw]; o.t1[c] = q.gs1[rc * q.actw + q.dout]; }
+    }
+}
+
+// Ws += gz_s^T s_in ; Wt += gz_t^T t_in ; H += (m gz_s)^T t_in + (m gz_t)^T s_in      (conet.py:127-134 transposed)
+template <bool TWO, bool TAIL>
+__device__ __forceinline__ void wg_use(const wg_ops& cu, int64_t first, int64_t r_end, f32x16 (&acc)[6], float (&bias)[4]) {
+    float s0[4], t0[4], s1[4], t1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool rv = !TAIL || first + c < r_end;
+        s0[c] = rv ? cu.s0[c] : 0.f; t0[c] = rv ? cu.t0[c] : 0.f;
+        if (TWO) { s1[c] = rv ? cu.s1[c] : 0.f; t1[c] = rv ? cu.t1[c] : 0.f; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float ms = cu.mk[c] != 0.f ? s0[c] : 0.f, mt = cu.mk[c] != 0.f ? t0[c] : 0.f;
+        MF1(acc[0], s0[c], cu.xs[c]);
+        MF1(acc[1], t0[c], cu.xt[c]);
+        MF1(acc[2], ms, cu.xt[c]);
+        MF1(acc[2], mt, cu.xs[c]);
+    }
+    bias[0] += (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    bias[1] += (t0[0] + t0[1]) + (t0[2] + t0[3]);
+    if (TWO) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ms = cu.mk[c] != 0.f ? s1[c] : 0.f, mt = cu.mk[c] != 0.f ? t1[c] : 0.f;
+            MF1(acc[3], s1[c], cu.xs[c]);
+            MF1(acc[4], t1[c], cu.xt[c]);
+            MF1(acc[5], ms, cu.xt[c]);
+            MF1(acc[5], mt, cu.xs[c]);
+        }
+        bias[2] += (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        bias[3] += (t1[0] + t1[1]) + (t1[2] + t1[3]);
+    }
+}
+
+// The row loop of one wave and the workgroup's reduction.  Three operand sets rotate through a loop unrolled by three steps, so a
+// step's 20-28 requests are issued two steps (64 MFMAs with a second m tile) before they are used -- gz and x0 were written by
+// the previous kernel and come from the Infinity Cache, further away than one step; sched_barrier keeps hipcc from sinking
+// them back (see fwd_layer_stream).  The four waves of a workgroup take four consecutive row chunks of the SAME job and add
+// their tiles through LDS in wave order before anything goes to HBM: a quarter of the partials to write here and to re-read in
+// conet_wgrad_finish_kernel (26 MB -> 6.5 MB per step at C3).
+template <bool TWO>
+__device__ __forceinline__ void wgrad_job(const wg_src& q, int64_t r_begin, bool bias_job, float* __restrict__ red, float* __restrict__ o,
+                                          int wave, int lane, int lh) {
+    f32x16 acc[6];
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = zero16();
+    const int64_t nrows = q.r_end > r_begin ? q.r_end - r_begin : 0;
+    const int64_t nfull = nrows >> 3;
+    const int64_t rf = r_begin + 4 * lh;
+    wg_ops A, B, C;
+    wg_load<TWO>(A, q, rf);
+    wg_load<TWO>(B, q, rf + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    int64_t st = 0;
+    for (; st + 3 <= nfull; st += 3) {
+        const int64_t r = rf + 8 * st;
+        wg_load<TWO>(C, q, r + 16);              __builtin_amdgcn_sched_barrier(0);
+        wg_use<TWO, false>(A, r, q.r_end, acc, bias);      __builtin_amdgcn_sched_barrier(0);
+        wg_load<TWO>(A, q, r + 24);              __builtin_amdgcn_sched_barrier(0);
+        wg_use<TWO, false>(B, r + 8, q.r_end, acc, bias);  __builtin_amdgcn_sched_barrier(0);
+        wg_load<TWO>(B, q, r + 32);              __builtin_amdgcn_sched_barrier(0);
+        wg_use<TWO, false>(C, r + 16, q.r_end, acc, bias); __builtin_amdgcn_sched_barrier(0);
+    }
+    if (st < nfull) {
+        wg_use<TWO, false>(A, rf + 8 * st, q.r_end, acc, bias);
+        ++st;
+        if (st < nfull) { wg_use<TWO, false>(B, rf + 8 * st, q.r_end, acc, bias); ++st; }
+    }
+    if (nrows & 7) {                                          // the chunk that ends at R: rows past it contribute zeros
+        wg_load<TWO>(C, q, rf + 8 * nfull);
+        wg_use<TWO, true>(C, rf + 8 * nfull, q.r_end, acc, bias);
+    }
+    // this wave's partial in the layout of the job's partial: tiles in accumulator order {m tile, {Ws, Wt, H}}, then four bias rows
+    float* my = red + (size_t)wave * kJobFloats;
+    constexpr int NTILE = TWO ? 6 : 3;
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[i * 1024 + r * 64 + lane] = acc[i][r];
+    }
+    if (bias_job) {                                           // bias gradients = column sums of gz: the A operand's running sum
+        const float a = bias[0] + __shfl_xor(bias[0], 32, 64), b = bias[1] + __shfl_xor(bias[1], 32, 64);
+        const float c = bias[2] + __shfl_xor(bias[2], 32, 64), e = bias[3] + __shfl_xor(bias[3], 32, 64);
+        if (lh == 0) { const int li = lane & 31; my[6144 + li] = a; my[6144 + 32 + li] = b; my[6144 + 64 + li] = c; my[6144 + 96 + li] = e; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NTILE * 1024; e += 256)
+        o[e] = ((red[e] + red[kJobFloats + e]) + red[2 * kJobFloats + e]) + red[3 * kJobFloats + e];
+    if (bias_job && threadIdx.x < 128) {
+        const int e = 6144 + threadIdx.x;
+        o[e] = ((red[e] + red[kJobFloats + e]) + red[2 * kJobFloats + e]) + red[3 * kJobFloats + e];
+    }
+}
+
+// One WORKGROUP per (job, group of four row chunks); wave w takes chunk 4 g + w.
+__global__ __launch_bounds__(256) void conet_wgrad_kernel(conet_net net, conet_tiles jl, int64_t R, int64_t kc,
                                                           const float* __restrict__ x0, const float* __restrict__ acts,
                                                           const float* __restrict__ gz, const float* __restrict__ maskf,
                                                           float* __restrict__ wpart) {
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [4][kJobFloats]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    const int64_t job = (int64_t)blockIdx.x * 4 + wave;
-    if (job >= (int64_t)jl.ntiles * nsplit) return;
-    const int jb = (int)(job % jl.ntiles), sp = (int)(job / jl.ntiles);
+    const int jb = (int)(blockIdx.x % (unsigned)jl.ntiles), g = (int)(blockIdx.x / (unsigned)jl.ntiles);
     const job_id d = decode_job(net, jl, jb);
     const int din = net.dims[d.l], dout = net.dims[d.l + 1];
     const int actw = net.act_off[net.L];
     const float* in = d.l == 0 ? x0 : acts + net.act_off[d.l - 1];
-    const int64_t ldin = d.l == 0 ? 2 * din : actw;
     const int m0 = d.mp * 64 + li, m1 = m0 + 32, n = d.nt * 32 + li;
-    const bool two = d.mp * 64 + 32 < dout;                  // wave-uniform: the job has a second m tile
-    const bool mv0 = m0 < dout, mv1 = two && m1 < dout, nv = n < din;
-    const float* gs0 = gz + net.act_off[d.l] + (mv0 ? m0 : 0);          // tower s columns; tower t at + dout
-    const float* gs1 = gz + net.act_off[d.l] + (mv1 ? m1 : 0);
-    const float* bsp = in + (nv ? n : 0);                               // s_in column n; t_in at + din
-    const int64_t r_begin = (int64_t)sp * kc, r_end = (r_begin + kc < R) ? r_begin + kc : R;
-    f32x16 aWs0 = zero16(), aWt0 = zero16(), aH0 = zero16(), aWs1 = zero16(), aWt1 = zero16(), aH1 = zero16();
-    float bs0 = 0.f, bt0 = 0.f, bs1 = 0.f, bt1 = 0.f;
-    auto load = [&](int64_t r0, wg_ops& o) {
-        const int64_t rr = r0 + 4 * lh;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int64_t row = rr + c;
-            const bool rv = row < r_end;
-            const int64_t rc = rv ? row : r_begin;
-            o.mk[c] = rv ? maskf[rc] : 0.f;
-            o.s0[c] = (rv && mv0) ? gs0[rc * actw] : 0.f;
-            o.t0[c] = (rv && mv0) ? gs0[rc * actw + dout] : 0.f;
-            o.xs[c] = (rv && nv) ? bsp[rc * ldin] : 0.f;
-            o.xt[c] = (rv && nv) ? bsp[rc * ldin + din] : 0.f;
-            o.s1[c] = (rv && mv1) ? gs1[rc * actw] : 0.f;
-            o.t1[c] = (rv && mv1) ? gs1[rc * actw + dout] : 0.f;
-        }
-    };
-    wg_ops nx;
-    load(r_begin, nx);
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += 8) {
-        const wg_ops cu = nx;
-        if (r0 + 8 < r_end) load(r0 + 8, nx);                // next 8 rows in flight under this step's MFMAs
-        // Ws += gz_s^T s_in ; Wt += gz_t^T t_in ; H += (m gz_s)^T t_in + (m gz_t)^T s_in      (conet.py:127-134 transposed)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ms = cu.mk[c] != 0.f ? cu.s0[c] : 0.f, mt = cu.mk[c] != 0.f ? cu.t0[c] : 0.f;
-            MF1(aWs0, cu.s0[c], cu.xs[c]);
-            MF1(aWt0, cu.t0[c], cu.xt[c]);
-            MF1(aH0, ms, cu.xt[c]);
-            MF1(aH0, mt, cu.xs[c]);
-        }
-        bs0 += (cu.s0[0] + cu.s0[1]) + (cu.s0[2] + cu.s0[3]);
-        bt0 += (cu.t0[0] + cu.t0[1]) + (cu.t0[2] + cu.t0[3]);
-        if (two) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float ms = cu.mk[c] != 0.f ? cu.s1[c] : 0.f, mt = cu.mk[c] != 0.f ? cu.t1[c] : 0.f;
-                MF1(aWs1, cu.s1[c], cu.xs[c]);
-                MF1(aWt1, cu.t1[c], cu.xt[c]);
-                MF1(aH1, ms, cu.xt[c]);
-                MF1(aH1, mt, cu.xs[c]);
-            }
-            bs1 += (cu.s1[0] + cu.s1[1]) + (cu.s1[2] + cu.s1[3]);
-            bt1 += (cu.t1[0] + cu.t1[1]) + (cu.t1[2] + cu.t1[3]);
-        }
-    }
-    // partial of this (job, chunk): six 32x32 tiles in accumulator order {m tile, {Ws, Wt, H}}, then four bias rows
-    float* o = wpart + ((size_t)sp * jl.ntiles + jb) * kJobFloats;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        o[0 * 1024 + r * 64 + lane] = aWs0[r];
-        o[1 * 1024 + r * 64 + lane] = aWt0[r];
-        o[2 * 1024 + r * 64 + lane] = aH0[r];
-    }
-    if (two) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o[3 * 1024 + r * 64 + lane] = aWs1[r];
-            o[4 * 1024 + r * 64 + lane] = aWt1[r];
-            o[5 * 1024 + r * 64 + lane] = aH1[r];
-        }
-    }
-    if (d.nt == 0) {                                           // bias gradients = column sums of gz: the A operand's running sum
-        const float a = bs0 + __shfl_xor(bs0, 32, 64), b = bt0 + __shfl_xor(bt0, 32, 64);
-        const float c = bs1 + __shfl_xor(bs1, 32, 64), e = bt1 + __shfl_xor(bt1, 32, 64);
-        if (lh == 0) { o[6144 + li] = a; o[6144 + 32 + li] = b; o[6144 + 64 + li] = c; o[6144 + 96 + li] = e; }
-    }
+    const bool two = d.mp * 64 + 32 < dout;                  // workgroup-uniform: the job has a second m tile
+    wg_src q;
+    q.gs0 = gz + net.act_off[d.l] + (m0 < dout ? m0 : 0);               // tower s columns; tower t at + dout
+    q.gs1 = gz + net.act_off[d.l] + (m1 < dout ? m1 : 0);
+    q.bsp = in + (n < din ? n : 0);                                     // s_in column n; t_in at + din
+    q.maskf = maskf;
+    q.actw = actw; q.ldin = d.l == 0 ? 2 * din : actw;
+    q.dout = dout; q.din = din;
+    const int64_t r_begin = (int64_t)(4 * g + wave) * kc;
+    q.r_end = (r_begin + kc < R) ? r_begin + kc : R;
+    q.r_safe = r_begin < R ? r_begin : R - 1;
+    float* o = wpart + ((size_t)g * jl.ntiles + jb) * kJobFloats;
+    if (two) wgrad_job<true>(q, r_begin, d.nt == 0, red, o, wave, lane, lh);
+    else wgrad_job<false>(q, r_begin, d.nt == 0, red, o, wave, lane, lh);
 }
 
 // One THREAD per output element: the chunk partials added in chunk order (fixed order, independent loads), plus d||H||_F.
@@ -905,7 +955,7 @@ inline int64_t rows_grid(int64_t R) {
 }
 
 inline void split_plan(int ntiles, int64_t R, int* nsplit, int64_t* kc) {
-    int64_t ns = (1024 + ntiles - 1) / ntiles;                 // one wave per SIMD of the chip
+    int64_t ns = 4 * (int64_t)(CDR_NUM_CU / ntiles > 0 ? CDR_NUM_CU / ntiles : 1);   // one workgroup (four chunks, 100 KB of LDS) per CU
     const int64_t max_ns = (R + 63) / 64;
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
@@ -1005,7 +1055,10 @@ extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_so
     float* wpart = (float*)workspace;
     const size_t wpart_bytes = ((size_t)tl.ntiles * nsplit * kJobFloats * sizeof(float) + 255) & ~(size_t)255;
     float* ou_part = (float*)((char*)workspace + wpart_bytes);
+    const int ngroup = (nsplit + 3) / 4;                      // a workgroup adds four chunks before writing: partials per job
     rc = lds_opt_in((const void*)conet_bwd_kernel, lp.bwd_bytes);
+    if (rc) return rc;
+    rc = lds_opt_in((const void*)conet_wgrad_kernel, 4 * kJobFloats * sizeof(float));
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)rows_grid(R);
@@ -1017,12 +1070,12 @@ extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_so
     CDR_LAUNCH_CHECK();
     {
         cdr_time_scope ts(ctx, CDR_TAG_CONET_WGRAD, s);
-        const int64_t jobs = (int64_t)tl.ntiles * nsplit;
-        conet_wgrad_kernel<<<dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, s>>>(net, tl, R, kc, nsplit, x0, acts, gz, maskf, wpart);
+        conet_wgrad_kernel<<<dim3((unsigned)(tl.ntiles * ngroup)), dim3(256), 4 * kJobFloats * sizeof(float), s>>>(net, tl, R, kc, x0, acts, gz,
+                                                                                                                    maskf, wpart);
     }
     CDR_LAUNCH_CHECK();
     conet_wgrad_finish_kernel<<<dim3((unsigned)(tl.ntiles * ((kJobFloats + 255) / 256) + 1)), dim3(256), 0, s>>>(
-        net, gr, tl, nsplit, wpart, ou_part, grid, out, grad_out);
+        net, gr, tl, ngroup, wpart, ou_part, grid, out, grad_out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
