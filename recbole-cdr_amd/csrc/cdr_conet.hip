@@ -33,6 +33,8 @@ constexpr int kMaxL = CDR_CONET_MAX_LAYERS;
 constexpr int kRows = 32;                       // rows per workgroup pass = one MFMA M tile
 constexpr int kJobFloats = 6 * 1024 + 128;      // a wgrad job's partial: six 32x32 tiles + four bias rows
 constexpr size_t kLdsBudget = 150 * 1024;
+constexpr int kConetPartial = 16;               // doubles per forward block in ctx->partials (2 BCE sums + kMaxL norms); grid <= 2048
+static_assert(2 + CDR_CONET_MAX_LAYERS <= kConetPartial && 2048 * kConetPartial <= CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE, "partials");
 
 struct conet_net {
     int L, vec, wlds;                           // wlds: the weights of layers >= 1 are staged in LDS
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
                                                         float* __restrict__ maskf, double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float mrow[kRows];
-    __shared__ double red[2 * 4];
+    __shared__ double red[(2 + kMaxL) * 4];
     float* bufA = smem;                                  // inputs of the even layers
     float* bufB = smem + kRows * strideA;                // inputs of the odd layers
     float* wl = bufB + kRows * strideB;                  // weights of layers >= 1 (when net.wlds)
@@ -320,11 +322,27 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
         lds_barrier();
         STAMP(2 + net.L);
     }
-    double lacc[2] = {lacc0, lacc1};
-    block_sum_d<2>(lacc, red);
+    // this block's slice of sum H_l^2 (conet.py:198-201), so that the finishing block adds gridDim.x numbers per layer instead of
+    // walking every H with 256 threads (a chain of dependent cache misses: 9 us of a 185 us step)
+    double lacc[2 + kMaxL];
+    lacc[0] = lacc0; lacc[1] = lacc1;
+#pragma unroll
+    for (int l = 0; l < kMaxL; ++l) {
+        double q = 0.0;
+        if (l < net.L) {
+            const int n = net.dims[l] * net.dims[l + 1];
+            const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int lo = (int)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            const float* h = net.H[l];
+            for (int e = lo + t; e < hi; e += 256) q += (double)h[e] * (double)h[e];
+        }
+        lacc[2 + l] = q;
+    }
+    block_sum_d<2 + kMaxL>(lacc, red);
     if (t == 0) {
-        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
-        o[0] = lacc[0]; o[1] = lacc[1];
+        double* o = partials + (size_t)blockIdx.x * kConetPartial;
+#pragma unroll
+        for (int i = 0; i < 2 + kMaxL; ++i) o[i] = lacc[i];
     }
 }
 
@@ -335,24 +353,10 @@ __global__ __launch_bounds__(256) void conet_fwd_finish_kernel(conet_net net, co
     double acc[2 + kMaxL];
 #pragma unroll
     for (int i = 0; i < 2 + kMaxL; ++i) acc[i] = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
-        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
-        acc[0] += o[0]; acc[1] += o[1];
-    }
+    for (int b = threadIdx.x; b < nblocks; b += 256) {        // per block: the two BCE sums and its slice of every sum H_l^2, all fp64
+        const double* o = partials + (size_t)b * kConetPartial;
 #pragma unroll
-    for (int l = 0; l < kMaxL; ++l) {                         // sum H_l^2: fp64, thread-strided then one fixed-order block sum
-        if (l < net.L) {
-            const int n = net.dims[l] * net.dims[l + 1];
-            const float* h = net.H[l];
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-            int e = threadIdx.x;
-            for (; e + 768 < n; e += 1024) {
-                const float a = h[e], b = h[e + 256], c = h[e + 512], d = h[e + 768];
-                q0 += (double)a * a; q1 += (double)b * b; q2 += (double)c * c; q3 += (double)d * d;
-            }
-            for (; e < n; e += 256) q0 += (double)h[e] * (double)h[e];
-            acc[2 + l] = (q0 + q1) + (q2 + q3);
-        }
+        for (int i = 0; i < 2 + kMaxL; ++i) acc[i] += o[i];
     }
     block_sum_d<2 + kMaxL>(acc, red);
     if (threadIdx.x == 0) {

@@ -79,6 +79,7 @@ class PointGatherLoss(Function):
         ctx.save_for_backward(user_w, item_w, reg_user_w, reg_item_w, uid, iid, g, out4)
         ctx.reg_weight = float(reg_weight)
         ctx.mark_non_differentiable(scores)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
         return out4[:1], scores
 
     @staticmethod
@@ -140,6 +141,7 @@ class TwoDomainPointLoss(Function):
         ctx.regs = (float(reg_s), float(reg_t))
         losses = out8[:, 0]
         ctx.mark_non_differentiable(losses)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
         return (losses * w).sum().reshape(1), losses
 
     @staticmethod
@@ -538,6 +540,7 @@ class ConetFusedLoss(Function):
         ctx.meta = (int(n_source), tuple(int(d) for d in dims), aw.value, int(need.value), tuple(su.shape), tuple(si.shape))
         ctx.row_opt = row_opt
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
         return out[0], out
 
     @staticmethod
@@ -865,6 +868,7 @@ class MaxMinNormalize(Function):
         B_.call('cdr_maxmin_norm', B_.stream(), B_.f32(x), n, D, B_.f32(y), B_.f32(stats))
         ctx.save_for_backward(x)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
         return y, stats
 
     @staticmethod

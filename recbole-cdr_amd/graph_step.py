@@ -31,6 +31,7 @@ class GraphedTrainStep:
             self.static[k].copy_(v)
         self.graph = None
         self.loss = None
+        self._one = torch.ones((), device=dev, dtype=torch.float32)       # d loss / d loss, made once: backward() would fill one per step
         self._capture(warmup)
 
     def _eager(self, interaction):
@@ -42,7 +43,7 @@ class GraphedTrainStep:
         loss = sum(losses) if isinstance(losses, tuple) else losses
         if loss.dim():
             loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()   # (a [1]-shaped loss: a view, not a reduction launch)
-        loss.backward()
+        loss.backward(self._one if loss.dtype == torch.float32 else None)
         self.optimizer.step()
         return loss.detach()
 
