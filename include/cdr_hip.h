@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 27
+#define CDR_ABI_VERSION 28
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -352,10 +352,20 @@ int cdr_triplet_bwd(void* stream, const float* a, const float* p, const float* n
  *   cdr_embloss_*       recbole EmbLoss of the EGO rows: out3 = {(||U_b|| + ||I_b||)/B, ||U_b||, ||I_b||}            */
 int cdr_spmm_csr_f32(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
                      const float* E, int D, float* out);
+/* row_flags (uint8 [n_rows], NULL = every row): the rows of the LAST propagation layer that the loss gathers -- nothing else reads
+ * that layer's output (bitgcf.py:200-205,222-240 index it with the batch's user / item ids only).  Forward: only flagged rows of
+ * side / new are computed (the others stay unwritten).  Backward: the caller guarantees gnew == 0 outside the flagged rows; the
+ * non-zeros whose column is not flagged are skipped (exact zeros of the sum: gE is bit-identical to the unflagged call), tmp is not
+ * used (may be NULL).  cdr_row_flags builds the set from id lists (rows offsets[i] + ids[i][k]) into one work buffer that starts with
+ * the byte flags and also holds the set as a bit map (the backward's column probes, copied into LDS) and as a compacted row list
+ * (the forward walks it); row_flags arguments take that buffer.                                                                  */
 int cdr_graph_layer_fwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
-                        const float* E, int D, float* side_out, float* new_out);
+                        const float* E, int D, float* side_out, float* new_out, const uint8_t* row_flags);
 int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values, int64_t n_rows,
-                        const float* E, const float* side, const float* gnew, int D, float* tmp, float* gE);
+                        const float* E, const float* side, const float* gnew, int D, float* tmp, float* gE, const uint8_t* row_flags);
+int cdr_row_flags_layout(int64_t rows, size_t* bytes);      /* size of the work buffer below (16-B aligned device memory) */
+int cdr_row_flags(void* stream, int n_lists, const int64_t* const* ids, const int64_t* counts, const int64_t* offsets, int64_t rows,
+                  uint8_t* work, size_t work_bytes);
 /* Row-sharded BiTGCF (BASELINE configs[3]; SURVEY 8e: E and the CSR sharded by destination row, per-layer all-gather of E): the rank
  * holds n_rows rows of the CSR whose column indices address the ALL-GATHERED embedding buffer; the row's own value comes from the
  * local slice.  Forward: side = A_rows E_gathered, new = E_rows + side + E_rows (.) side (bitgcf.py:130-135).  Backward (the
@@ -385,16 +395,18 @@ int cdr_transfer_drop_bwd(void* stream, const float* gS_out, const float* gT_out
  * the stack's column block (leading dimension ldc / ldg); one wave per row of the stacked [users ; items] table.  Same arithmetic in
  * the same order as cdr_dropout(_dev) / cdr_transfer_* / cdr_l2_normalize_* run one after the other (equal to the last bit or two: FMA
  * contraction; identical dropout masks).  The backward adds the gradient
- * arriving from the layer above (gS_prev / gT_prev, both NULL for the top layer) before the transfer's backward.                  */
+ * arriving from the layer above (gS_prev / gT_prev, both NULL for the top layer) before the transfer's backward.
+ * row_flags (NULL = all rows; see cdr_graph_layer_fwd): forward writes zeros into the stack block of unflagged rows and nothing else
+ * for them; backward (top layer only: gS_prev == NULL) writes zero gradient rows for them without reading their saved tensors.   */
 int cdr_bitgcf_mix_fwd(void* stream, const float* newS, const float* newT, const float* deg_su, const float* deg_tu,
                        const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI, float lam_s,
                        float lam_t, float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, float* S2,
-                       float* T2, float* catS_block, float* catT_block, int64_t ldc, float* nS, float* nT);
+                       float* T2, float* catS_block, float* catT_block, int64_t ldc, float* nS, float* nT, const uint8_t* row_flags);
 int cdr_bitgcf_mix_bwd(void* stream, const float* S2, const float* T2, const float* nS, const float* nT, const float* gcatS_block,
                        const float* gcatT_block, int64_t ldg, const float* gS_prev, const float* gT_prev, const float* deg_su,
                        const float* deg_tu, const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU,
                        int64_t OI, float lam_s, float lam_t, float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s,
-                       uint64_t salt_t, float* gnS, float* gnT);
+                       uint64_t salt_t, float* gnS, float* gnT, const uint8_t* row_flags);
 int cdr_l2_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, int64_t ldo, float* norm_out);
 int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const float* gy, int64_t ldg, int64_t rows, int D,
                          float* gx, int accumulate);

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -93,17 +93,19 @@ _SIGNATURES = {
     'cdr_triplet_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                         _c_ptr],
     'cdr_spmm_csr_f32': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr],
-    'cdr_graph_layer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr],
-    'cdr_graph_layer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr],
+    'cdr_graph_layer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_graph_layer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_row_flags': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, ctypes.c_size_t],
+    'cdr_row_flags_layout': [_c_i64, _c_ptr],
     'cdr_graph_layer_fwd_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr],
     'cdr_mul_one_plus': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_graph_layer_bwd_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr],
     'cdr_transfer_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_transfer_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_bitgcf_mix_fwd': [_c_ptr] * 7 + [_c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_f32, ctypes.c_uint64, _c_ptr, ctypes.c_uint64,
-                           ctypes.c_uint64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+                           ctypes.c_uint64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_bitgcf_mix_bwd': [_c_ptr] * 7 + [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_f32, _c_f32,
-                           _c_f32, ctypes.c_uint64, _c_ptr, ctypes.c_uint64, ctypes.c_uint64, _c_ptr, _c_ptr],
+                           _c_f32, ctypes.c_uint64, _c_ptr, ctypes.c_uint64, ctypes.c_uint64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_transfer_drop_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_f32, ctypes.c_uint64, _c_ptr,
                               ctypes.c_uint64, ctypes.c_uint64, _c_i64, _c_ptr, _c_ptr],
     'cdr_transfer_drop_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_f32, _c_f32, _c_f32, ctypes.c_uint64, _c_ptr,

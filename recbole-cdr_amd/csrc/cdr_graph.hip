@@ -20,13 +20,117 @@ inline int grid_cap(int64_t blocks) {
     return (int)blocks;
 }
 
+// acc = sum_j values[j] * E[indices[j]] over one CSR row, for one 16-B chunk `ch` of the row, in index order.  The lane group reads
+// LPR indices and values with ONE coalesced request each (the next batch's before this batch's gathers) and hands them round inside the
+// group, so no gather waits for "its" index load.  At D = 64 a row is 16 lanes and a wave serves four rows: the kernel is bound by the
+// instructions it issues per non-zero, not by bytes (the two-at-a-time loop this replaces spent ~19 per non-zero and ran at a fifth of
+// the gather bandwidth: 88 us per SpMM at C4).  With 16-lane groups the hand-round is a DPP row broadcast (one VALU move, no LDS
+// round trip), full batches run without a predicate and the row offset is a 32-bit multiply-add on a wave-uniform base: ~8 per
+// non-zero.  Same additions in the same order in every variant.
+template <int Q>
+__device__ __forceinline__ int row16_bcast(int v) {              // lane Q of the caller's 16-lane row (DPP row_newbcast / row_share)
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + Q, 0xF, 0xF, false);
+}
+template <int Q>
+__device__ __forceinline__ float row16_bcastf(float v) { return __int_as_float(row16_bcast<Q>(__float_as_int(v))); }
+
+#define CDR_NZ8(Q0)                                                                                                        \
+    {                                                                                                                      \
+        float4 x0 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 0>(ci) * D + c4)), x1 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 1>(ci) * D + c4)); \
+        float4 x2 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 2>(ci) * D + c4)), x3 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 3>(ci) * D + c4)); \
+        float4 x4 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 4>(ci) * D + c4)), x5 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 5>(ci) * D + c4)); \
+        float4 x6 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 6>(ci) * D + c4)), x7 = ld4(E + (size_t)(unsigned)(row16_bcast<Q0 + 7>(ci) * D + c4)); \
+        CDR_NZ_FMA(x0, Q0 + 0) CDR_NZ_FMA(x1, Q0 + 1) CDR_NZ_FMA(x2, Q0 + 2) CDR_NZ_FMA(x3, Q0 + 3)                          \
+        CDR_NZ_FMA(x4, Q0 + 4) CDR_NZ_FMA(x5, Q0 + 5) CDR_NZ_FMA(x6, Q0 + 6) CDR_NZ_FMA(x7, Q0 + 7)                          \
+    }
+#define CDR_NZ_FMA(X, Q) { const float v_ = row16_bcastf<Q>(vi); acc.x += v_ * X.x; acc.y += v_ * X.y; acc.z += v_ * X.z; acc.w += v_ * X.w; }
+
+template <int LPR>
+__device__ __forceinline__ float4 csr_row_dot(const int64_t* __restrict__ indices, const float* __restrict__ values, int64_t b, int64_t e,
+                                              const float* __restrict__ E, int D, int ch, int sub, bool small) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cn = 0; float vn = 0.f;
+    if (b + sub < e) { cn = (int)indices[b + sub]; vn = values[b + sub]; }
+    int64_t j = b;
+    if (LPR == 16 && small) {                                    // small: every element offset of E fits 32 bits
+        const int c4 = 4 * ch;
+        for (; j + 16 <= e; j += 16) {
+            const int ci = cn; const float vi = vn;
+            const int64_t jn = j + 16 + sub;
+            cn = 0; vn = 0.f;
+            if (jn < e) { cn = (int)indices[jn]; vn = values[jn]; }
+            CDR_NZ8(0)
+            CDR_NZ8(8)
+        }
+    }
+    for (; j < e; j += LPR) {                                    // any group width; with 16 lanes: the row's last, partial batch
+        const int ci = cn; const float vi = vn;
+        const int64_t jn = j + LPR + sub;
+        cn = 0; vn = 0.f;
+        if (jn < e) { cn = (int)indices[jn]; vn = values[jn]; }
+        const int cnt = (int)((e - j) < (int64_t)LPR ? (e - j) : (int64_t)LPR);
+        for (int q0 = 0; q0 < cnt; q0 += 8) {
+            float4 x[8]; float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = __shfl(ci, q0 + q, LPR);
+                v[q] = __shfl(vi, q0 + q, LPR);
+                x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q0 + q < cnt) x[q] = ld4(E + (int64_t)c * D + 4 * ch);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q0 + q < cnt) { acc.x += v[q] * x[q].x; acc.y += v[q] * x[q].y; acc.z += v[q] * x[q].z; acc.w += v[q] * x[q].w; }
+            }
+        }
+    }
+    return acc;
+}
+#undef CDR_NZ8
+#undef CDR_NZ_FMA
+
+// the same for the flagged backward: the term of column c is values[j] * (G[c] (.) (1 + E[c])) where flags[c] != 0 and an exact zero
+// elsewhere (skipped).  Every lane probes the flag of its own index (LPR probes in flight per group, one batch ahead of the gathers,
+// the indices two batches ahead); the group then walks the set bits of its flag mask in ascending order -- the non-zeros that
+// matter, a fifth of them at C4 -- instead of testing every position.
+template <int LPR>
+__device__ __forceinline__ float4 csr_row_dot_flagged(const int64_t* __restrict__ indices, const float* __restrict__ values, int64_t b,
+                                                      int64_t e, const float* __restrict__ G, const float* __restrict__ E,
+                                                      const uint32_t* flags, int D, int ch, int sub) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c1 = 0, c2 = 0, f1 = 0; float v1 = 0.f, v2 = 0.f;
+    if (b + sub < e) { c1 = (int)indices[b + sub]; v1 = values[b + sub]; }
+    if (b + LPR + sub < e) { c2 = (int)indices[b + LPR + sub]; v2 = values[b + LPR + sub]; }
+    if (b + sub < e) f1 = (int)((flags[c1 >> 5] >> (c1 & 31)) & 1u);
+    const int gbase = (int)(threadIdx.x & 63) - sub;             // first lane of this group inside the wave
+    for (int64_t j = b; j < e; j += LPR) {
+        const int ci = c1, fi = f1; const float vi = v1;
+        c1 = c2; v1 = v2;
+        f1 = (j + LPR + sub < e) ? (int)((flags[c1 >> 5] >> (c1 & 31)) & 1u) : 0;
+        const int64_t j2 = j + 2 * LPR + sub;
+        c2 = 0; v2 = 0.f;
+        if (j2 < e) { c2 = (int)indices[j2]; v2 = values[j2]; }
+        unsigned long long m = (__ballot(fi != 0) >> gbase) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull));
+        while (m) {                                               // group-uniform: every lane of the group holds the same mask
+            const int q = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int c = __shfl(ci, q, LPR);
+            const float v = __shfl(vi, q, LPR);
+            const float4 g = ld4(G + (int64_t)c * D + 4 * ch), x = ld4(E + (int64_t)c * D + 4 * ch);
+            const float4 t = make_float4(g.x * (1.0f + x.x), g.y * (1.0f + x.y), g.z * (1.0f + x.z), g.w * (1.0f + x.w));
+            acc.x += v * t.x; acc.y += v * t.y; acc.z += v * t.z; acc.w += v * t.w;
+        }
+    }
+    return acc;
+}
+
 // MODE 0: out = acc ; MODE 1: side_out = acc, out = x + acc + x*acc (x = X[r]) ; MODE 2: out = G[r]*(1 + S[r]) + acc
 template <int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
                                                           const float* __restrict__ values, int64_t n_rows,
                                                           const float* __restrict__ E, int D, const float* __restrict__ X,
                                                           const float* __restrict__ S, float* __restrict__ side_out,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, bool small) {
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
@@ -35,21 +139,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int64_t* __restr
     for (int64_t r = gg; r < n_rows; r += TG) {
         const int64_t b = indptr[r], e = indptr[r + 1];
         for (int ch = sub; ch < D4; ch += LPR) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int64_t j = b;
-            for (; j + 1 < e; j += 2) {          // two independent row fetches in flight
-                const int64_t c0 = indices[j], c1 = indices[j + 1];
-                const float v0 = values[j], v1 = values[j + 1];
-                const float4 x0 = ld4(E + c0 * D + 4 * ch), x1 = ld4(E + c1 * D + 4 * ch);
-                acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
-                acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
-            }
-            if (j < e) {
-                const int64_t c0 = indices[j];
-                const float v0 = values[j];
-                const float4 x0 = ld4(E + c0 * D + 4 * ch);
-                acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
-            }
+            const float4 acc = csr_row_dot<LPR>(indices, values, b, e, E, D, ch, sub, small);
             float* o = out + r * D + 4 * ch;
             if (MODE == 0) {
                 st4(o, acc);
@@ -64,6 +154,91 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int64_t* __restr
                 st4(o, make_float4(g.x * (1.f + s.x) + acc.x, g.y * (1.f + s.y) + acc.y, g.z * (1.f + s.z) + acc.z,
                                    g.w * (1.f + s.w) + acc.w));
             }
+        }
+    }
+}
+
+// The LAST propagation layer only feeds the rows the loss gathers (a few thousand of n): `flags[r] != 0` marks them.
+//   forward  (graph layer): only flagged rows are computed; the others' side / new rows are left unwritten and never read
+//   backward (graph layer): gnew is zero outside the flagged rows, so a non-zero's gather (gnew[c], E[c]: tmp is formed on the fly)
+//                           happens only where flags[c] != 0 -- every skipped term is an exact zero of the unmasked sum, the
+//                           remaining ones are added in the same order: bit-identical gE, 4D + 12 -> ~13 B per non-zero
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_rows_fwd_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+                                                               const float* __restrict__ values, int64_t n_rows,
+                                                               const float* __restrict__ E, int D, const int32_t* __restrict__ rowlist,
+                                                               const int32_t* __restrict__ rowcount,
+                                                               float* __restrict__ side_out, float* __restrict__ out, bool small) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const int64_t nsel = rowcount[0];                            // the flagged rows, compacted (any order: a row's result is its own)
+    for (int64_t i = gg; i < nsel; i += TG) {
+        const int64_t r = rowlist[i];
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        for (int ch = sub; ch < D4; ch += LPR) {
+            const float4 acc = csr_row_dot<LPR>(indices, values, b, e, E, D, ch, sub, small);       // same order as spmm_csr_kernel
+            const float4 x = ld4(E + r * D + 4 * ch);
+            st4(side_out + r * D + 4 * ch, acc);
+            st4(out + r * D + 4 * ch, make_float4(x.x + (acc.x + x.x * acc.x), x.y + (acc.y + x.y * acc.y),
+                                                  x.z + (acc.z + x.z * acc.z), x.w + (acc.w + x.w * acc.w)));
+        }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_flagged_bwd_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+                                                                  const float* __restrict__ values, int64_t n_rows,
+                                                                  const float* __restrict__ E, int D, const float* __restrict__ G,
+                                                                  const float* __restrict__ S, const uint32_t* __restrict__ bitmap,
+                                                                  int lds_words, float* __restrict__ out) {
+    extern __shared__ uint32_t bm_lds[];
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    // one probe per non-zero: from a copy of the bitmap in LDS (n / 8 bytes: 10 KB at C4) instead of one L2 request each -- as many
+    // requests as the gathers they were meant to save
+    for (int w = threadIdx.x; w < lds_words; w += kBlock) bm_lds[w] = bitmap[w];
+    if (lds_words) __syncthreads();
+    const uint32_t* flags = lds_words ? bm_lds : bitmap;
+    for (int64_t r = gg; r < n_rows; r += TG) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        const bool own = (flags[r >> 5] >> (r & 31)) & 1u;
+        for (int ch = sub; ch < D4; ch += LPR) {
+            const float4 acc = csr_row_dot_flagged<LPR>(indices, values, b, e, G, E, flags, D, ch, sub);
+            float4 o = acc;
+            if (own) {
+                const float4 g = ld4(G + r * D + 4 * ch), s_ = ld4(S + r * D + 4 * ch);
+                o = make_float4(g.x * (1.f + s_.x) + acc.x, g.y * (1.f + s_.y) + acc.y, g.z * (1.f + s_.z) + acc.z,
+                                g.w * (1.f + s_.w) + acc.w);
+            }
+            st4(out + r * D + 4 * ch, o);
+        }
+    }
+}
+
+// Marks the rows off[i] + ids[i][k]: flags[r] = 1 (bytes, for the row-wise kernels), bit r of the bitmap (for the SpMM's column probes)
+// and, for the thread that set the bit first, an entry of the compacted row list.  work = [flags | bitmap | count | list], see
+// cdr_row_flags_layout; the first three are zero on entry.
+struct flag_lists { const int64_t* ids[8]; int64_t n[8]; int64_t off[8]; int count; };
+__global__ __launch_bounds__(kBlock) void row_flags_kernel(flag_lists fl, int64_t rows, uint8_t* __restrict__ flags,
+                                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ count,
+                                                           int32_t* __restrict__ list) {
+    const int li = blockIdx.y;
+    const int64_t n = fl.n[li];
+    const int64_t* ids = fl.ids[li];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = fl.off[li] + ids[i];
+        if (r < 0 || r >= rows) continue;
+        const uint32_t bit = 1u << (r & 31);
+        const uint32_t old = atomicOr(&bitmap[r >> 5], bit);
+        if (!(old & bit)) {
+            flags[r] = 1;
+            list[atomicAdd(count, 1)] = (int32_t)r;
         }
     }
 }
@@ -313,7 +488,8 @@ constexpr int kMixMaxJ = 8;                       // D <= 512
 template <int J>
 __global__ __launch_bounds__(kBlock) void mix_fwd_kernel(mix_arg a, const float* __restrict__ newS, const float* __restrict__ newT,
                                                          float* __restrict__ S2, float* __restrict__ T2, float* __restrict__ catS,
-                                                         float* __restrict__ catT, int64_t ldc, float* __restrict__ nS, float* __restrict__ nT) {
+                                                         float* __restrict__ catT, int64_t ldc, float* __restrict__ nS, float* __restrict__ nT,
+                                                         const uint8_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63, D = a.D;
     const int64_t n = a.nu + a.ni;
     const bool drop = a.dr.p > 0.f;
@@ -321,6 +497,14 @@ __global__ __launch_bounds__(kBlock) void mix_fwd_kernel(mix_arg a, const float*
     const float scale = drop ? 1.0f / (1.0f - a.dr.p) : 1.0f;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
     for (int64_t r = w; r < n; r += TW) {
+        if (flags && !flags[r]) {                  // a row the loss never reads (last layer): its block of the stack is zero, nothing else exists
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = lane + 64 * j;
+                if (c < D) { catS[r * ldc + c] = 0.f; catT[r * ldc + c] = 0.f; }
+            }
+            continue;
+        }
         const bool user = r < a.nu;
         const int64_t rl = user ? r : r - a.nu;
         const bool mixrow = rl < (user ? a.OU : a.OI);
@@ -365,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(mix_arg a, const float*
                                                          const float* __restrict__ nS, const float* __restrict__ nT,
                                                          const float* __restrict__ gcatS, const float* __restrict__ gcatT, int64_t ldg,
                                                          const float* __restrict__ gS_prev, const float* __restrict__ gT_prev,
-                                                         float* __restrict__ gnS, float* __restrict__ gnT) {
+                                                         float* __restrict__ gnS, float* __restrict__ gnT, const uint8_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63, D = a.D;
     const int64_t n = a.nu + a.ni;
     const bool drop = a.dr.p > 0.f;
@@ -373,6 +557,14 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(mix_arg a, const float*
     const float scale = drop ? 1.0f / (1.0f - a.dr.p) : 1.0f;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
     for (int64_t r = w; r < n; r += TW) {
+        if (flags && !flags[r]) {                  // (only with gS_prev == nullptr) no gradient reaches this row: exact zeros
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = lane + 64 * j;
+                if (c < D) { gnS[r * D + c] = 0.f; gnT[r * D + c] = 0.f; }
+            }
+            continue;
+        }
         const bool user = r < a.nu;
         const int64_t rl = user ? r : r - a.nu;
         const bool mixrow = rl < (user ? a.OU : a.OI);
@@ -419,6 +611,16 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(mix_arg a, const float*
     }
 }
 
+// the row-flag work buffer (cdr_row_flags): byte flags [rows], bit map [ceil(rows / 32)] words, the list's length, the list [rows]
+struct row_flag_views { uint8_t* flags; uint32_t* bitmap; int32_t* count; int32_t* list; size_t zero_bytes, bytes; };
+inline row_flag_views flag_views(const uint8_t* work, int64_t rows) {
+    const size_t o_bm = ((size_t)rows + 15) & ~(size_t)15;
+    const size_t o_cnt = o_bm + (((size_t)(rows + 31) / 32 * 4 + 15) & ~(size_t)15);
+    const size_t o_list = o_cnt + 16;
+    uint8_t* w = const_cast<uint8_t*>(work);
+    return row_flag_views{w, (uint32_t*)(w + o_bm), (int32_t*)(w + o_cnt), (int32_t*)(w + o_list), o_list, o_list + (size_t)rows * 4};
+}
+
 }  // namespace
 
 #define GR_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
@@ -440,32 +642,51 @@ extern "C" int cdr_spmm_csr_f32(void* stream, const int64_t* indptr, const int64
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
     DISPATCH_LPR(lpr, spmm_csr_kernel<L, 0><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, E,
-                                                                                                 D, nullptr, nullptr, nullptr, out));
+                                                                                                 D, nullptr, nullptr, nullptr, out, false));
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
 
 extern "C" int cdr_graph_layer_fwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
-                                   int64_t n_rows, const float* E, int D, float* side_out, float* new_out) {
+                                   int64_t n_rows, const float* E, int D, float* side_out, float* new_out, const uint8_t* row_flags) {
     CDR_CHECK_ARG(indptr && indices && values && E && side_out && new_out && n_rows > 0 && D > 0 && (D & 3) == 0);
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    const bool small = n_rows * (int64_t)D < ((int64_t)1 << 30);        // square adjacency: every column index < n_rows
+    if (row_flags) {
+        row_flag_views v = flag_views(row_flags, n_rows);
+        DISPATCH_LPR(lpr, spmm_rows_fwd_kernel<L><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, E, D,
+                                                                                                       v.list, v.count, side_out, new_out,
+                                                                                                       small));
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
+    }
     DISPATCH_LPR(lpr, spmm_csr_kernel<L, 1><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, E,
-                                                                                                 D, E, nullptr, side_out, new_out));
+                                                                                                 D, E, nullptr, side_out, new_out, small));
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
 
 extern "C" int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
                                    int64_t n_rows, const float* E, const float* side, const float* gnew, int D, float* tmp,
-                                   float* gE) {
-    CDR_CHECK_ARG(indptr && indices && values && E && side && gnew && tmp && gE && n_rows > 0 && D > 0 && (D & 3) == 0);
-    mul_one_plus_kernel<<<GR_GRID(n_rows * D)>>>(gnew, E, n_rows * D, tmp);
-    CDR_LAUNCH_CHECK();
+                                   float* gE, const uint8_t* row_flags) {
+    CDR_CHECK_ARG(indptr && indices && values && E && side && gnew && (tmp || row_flags) && gE && n_rows > 0 && D > 0 && (D & 3) == 0);
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
+    const bool small = n_rows * (int64_t)D < ((int64_t)1 << 30);
+    if (row_flags) {                                           // gnew is zero outside the flagged rows (caller's contract)
+        row_flag_views v = flag_views(row_flags, n_rows);
+        const int64_t words = (n_rows + 31) / 32;
+        const int lds_words = words * 4 <= 20 * 1024 ? (int)words : 0;          // <= 20 KB per block: 8 blocks per CU keep their LDS
+        DISPATCH_LPR(lpr, spmm_flagged_bwd_kernel<L><<<dim3(grid), dim3(kBlock), (size_t)lds_words * 4, (hipStream_t)stream>>>(
+            indptr, indices, values, n_rows, E, D, gnew, side, v.bitmap, lds_words, gE));
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
+    }
+    mul_one_plus_kernel<<<GR_GRID(n_rows * D)>>>(gnew, E, n_rows * D, tmp);
+    CDR_LAUNCH_CHECK();
     DISPATCH_LPR(lpr, spmm_csr_kernel<L, 2><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows, tmp,
-                                                                                                 D, gnew, side, nullptr, gE));
+                                                                                                 D, gnew, side, nullptr, gE, small));
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
@@ -480,8 +701,36 @@ extern "C" int cdr_graph_layer_fwd_rows(void* stream, const int64_t* indptr, con
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
     DISPATCH_LPR(lpr, spmm_csr_kernel<L, 1><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows,
                                                                                                  E_gathered, D, E_rows, nullptr, side_out,
-                                                                                                 new_out));
+                                                                                                 new_out, false));
     CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_row_flags_layout(int64_t rows, size_t* bytes) {
+    CDR_CHECK_ARG(rows > 0 && bytes);
+    *bytes = flag_views(nullptr, rows).bytes;
+    return CDR_OK;
+}
+
+extern "C" int cdr_row_flags(void* stream, int n_lists, const int64_t* const* ids, const int64_t* counts, const int64_t* offsets,
+                             int64_t rows, uint8_t* work, size_t work_bytes) {
+    CDR_CHECK_ARG(n_lists >= 0 && n_lists <= 8 && rows > 0 && rows < ((int64_t)1 << 31) && work && (n_lists == 0 || (ids && counts && offsets)));
+    row_flag_views v = flag_views(work, rows);
+    CDR_CHECK_ARG(work_bytes >= v.bytes && ((uintptr_t)work & 15) == 0);
+    CDR_HIP(hipMemsetAsync(work, 0, v.zero_bytes, (hipStream_t)stream));
+    flag_lists fl{};
+    int64_t nmax = 0;
+    for (int i = 0; i < n_lists; ++i) {
+        CDR_CHECK_ARG(counts[i] <= 0 || ids[i]);
+        fl.ids[i] = ids[i]; fl.n[i] = counts[i] > 0 ? counts[i] : 0; fl.off[i] = offsets[i];
+        if (fl.n[i] > nmax) nmax = fl.n[i];
+    }
+    fl.count = n_lists;
+    if (nmax > 0) {
+        row_flags_kernel<<<dim3(grid_cap((nmax + kBlock - 1) / kBlock), n_lists), dim3(kBlock), 0, (hipStream_t)stream>>>(
+            fl, rows, v.flags, v.bitmap, v.count, v.list);
+        CDR_LAUNCH_CHECK();
+    }
     return CDR_OK;
 }
 
@@ -500,7 +749,7 @@ extern "C" int cdr_graph_layer_bwd_rows(void* stream, const int64_t* indptr, con
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
     DISPATCH_LPR(lpr, spmm_csr_kernel<L, 2><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(indptr, indices, values, n_rows,
                                                                                                  tmp_gathered, D, gnew_rows, side_rows,
-                                                                                                 nullptr, gE_rows));
+                                                                                                 nullptr, gE_rows, false));
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
@@ -534,13 +783,13 @@ extern "C" int cdr_bitgcf_mix_fwd(void* stream, const float* newS, const float* 
                                   const float* deg_si, const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI,
                                   float lam_s, float lam_t, float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s,
                                   uint64_t salt_t, float* S2, float* T2, float* catS_block, float* catT_block, int64_t ldc, float* nS,
-                                  float* nT) {
+                                  float* nT, const uint8_t* row_flags) {
     CDR_CHECK_ARG(newS && newT && deg_su && deg_tu && deg_si && deg_ti && S2 && T2 && catS_block && catT_block && nS && nT);
     CDR_CHECK_ARG(nu > 0 && ni > 0 && D > 0 && D <= 64 * kMixMaxJ && ldc >= D && p >= 0.f && p < 1.f);
     const mix_arg a{deg_su, deg_tu, deg_si, deg_ti, nu, ni, OU, OI, D, lam_s, lam_t, drop_arg{p, seed, seed_dev, salt_s, salt_t, 0}};
     int64_t grid = (nu + ni + 3) / 4;
     if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
-    MIX_DISPATCH(mix_fwd_kernel, a, newS, newT, S2, T2, catS_block, catT_block, ldc, nS, nT);
+    MIX_DISPATCH(mix_fwd_kernel, a, newS, newT, S2, T2, catS_block, catT_block, ldc, nS, nT, row_flags);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
@@ -550,13 +799,14 @@ extern "C" int cdr_bitgcf_mix_bwd(void* stream, const float* S2, const float* T2
                                   const float* gT_prev, const float* deg_su, const float* deg_tu, const float* deg_si,
                                   const float* deg_ti, int64_t nu, int64_t ni, int D, int64_t OU, int64_t OI, float lam_s, float lam_t,
                                   float p, uint64_t seed, const int64_t* seed_dev, uint64_t salt_s, uint64_t salt_t, float* gnS,
-                                  float* gnT) {
+                                  float* gnT, const uint8_t* row_flags) {
     CDR_CHECK_ARG(S2 && T2 && nS && nT && gcatS_block && gcatT_block && deg_su && deg_tu && deg_si && deg_ti && gnS && gnT);
     CDR_CHECK_ARG(nu > 0 && ni > 0 && D > 0 && D <= 64 * kMixMaxJ && ldg >= D && p >= 0.f && p < 1.f && ((gS_prev == nullptr) == (gT_prev == nullptr)));
     const mix_arg a{deg_su, deg_tu, deg_si, deg_ti, nu, ni, OU, OI, D, lam_s, lam_t, drop_arg{p, seed, seed_dev, salt_s, salt_t, 0}};
     int64_t grid = (nu + ni + 3) / 4;
     if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
-    MIX_DISPATCH(mix_bwd_kernel, a, S2, T2, nS, nT, gcatS_block, gcatT_block, ldg, gS_prev, gT_prev, gnS, gnT);
+    CDR_CHECK_ARG(!row_flags || !gS_prev);                    // flags mean "no gradient reaches the other rows": last layer only
+    MIX_DISPATCH(mix_bwd_kernel, a, S2, T2, nS, nT, gcatS_block, gcatT_block, ldg, gS_prev, gT_prev, gnS, gnT, row_flags);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

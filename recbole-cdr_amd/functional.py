@@ -658,9 +658,14 @@ class BiTGCFPropagate(Function):
     is symmetric, so the SpMM backward is the same kernel."""
 
     @staticmethod
-    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p=0.0, drop_seed=0):
+    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p=0.0, drop_seed=0, rows_hint=None):
         # drop_seed: a host int, or a device int64 [1] counter (the capturable form: a hipGraph replay would bake a host seed
         # into its launches and repeat one mask on every step)
+        # rows_hint = (user ids, item ids, user ids, item ids, ...): the ONLY rows of the returned stacks the caller will read
+        # (calculate_loss gathers the batch's users and items, nothing else: bitgcf.py:222-240).  The last layer's output feeds
+        # nothing but those rows, so its graph layer, its transfer / normalise and their backward run on the flagged rows only
+        # (a tenth of the table at BASELINE C4): same numbers in the flagged rows, same gradients bit for bit (the skipped terms
+        # are exact zeros); every other row of the last layer's block reads 0.  Without the hint every row is computed.
         _dev_check(su, si, tu, ti)
         nu, ni, D = su.shape[0], si.shape[0], su.shape[1]
         n = nu + ni
@@ -668,6 +673,17 @@ class BiTGCFPropagate(Function):
         st = B_.stream
         nb = n_layers + 1
         f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        flags = None
+        if rows_hint is not None and n_layers >= 1:
+            lists = [_ids(x) for x in rows_hint]
+            m = len(lists)
+            assert m % 2 == 0, 'rows_hint = (users, items) pairs'
+            need = ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_row_flags_layout(n, ctypes.byref(need)), 'cdr_row_flags_layout')
+            flags = torch.empty(int(need.value), device=dev, dtype=torch.uint8)      # byte flags, then the bit map and the row list
+            B_._alive.extend(lists)
+            B_.call('cdr_row_flags', st(), m, (ctypes.c_void_p * m)(*[x.data_ptr() for x in lists]), (ctypes.c_int64 * m)(*[x.numel() for x in lists]),
+                    (ctypes.c_int64 * m)(*[0 if k % 2 == 0 else nu for k in range(m)]), n, B_.raw(flags), flags.numel())
         S, T = f32(n, D), f32(n, D)
         for dst, a, b in ((S, su, si), (T, tu, ti)):
             B_.call('cdr_copy_cols', st(), B_.f32(a.contiguous()), D, nu, D, B_.f32(dst), D, 0)
@@ -678,17 +694,18 @@ class BiTGCFPropagate(Function):
         saved = []
         for l in range(n_layers):
             sideS, newS, sideT, newT = f32(n, D), f32(n, D), f32(n, D), f32(n, D)
+            fl = B_.raw(flags) if (flags is not None and l == n_layers - 1) else None
             B_.call('cdr_graph_layer_fwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S), D,
-                    B_.f32(sideS), B_.f32(newS))
+                    B_.f32(sideS), B_.f32(newS), fl)
             B_.call('cdr_graph_layer_fwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T), D,
-                    B_.f32(sideT), B_.f32(newT))
+                    B_.f32(sideT), B_.f32(newT), fl)
             # [dropout ->] transfer -> L2-normalised copy into the layer stack: one launch for users and items of both domains
             S2, T2, nS, nT = f32(n, D), f32(n, D), f32(n), f32(n)
             dev_seed = torch.is_tensor(drop_seed)
             B_.call('cdr_bitgcf_mix_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']),
                     B_.f32(deg['ti']), nu, ni, D, OU, OI, lam_s, lam_t, float(drop_p), 0 if dev_seed else int(drop_seed),
                     B_.i64(drop_seed) if dev_seed else None, 2 * l, 2 * l + 1, B_.f32(S2), B_.f32(T2),
-                    B_._c_ptr(catS.data_ptr() + 4 * (l + 1) * D), B_._c_ptr(catT.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nS), B_.f32(nT))
+                    B_._c_ptr(catS.data_ptr() + 4 * (l + 1) * D), B_._c_ptr(catT.data_ptr() + 4 * (l + 1) * D), nb * D, B_.f32(nS), B_.f32(nT), fl)
             saved += [S, T, sideS, sideT, S2, T2, nS, nT]
             S, T = S2, T2
         if connect_way == 'concat':
@@ -699,6 +716,7 @@ class BiTGCFPropagate(Function):
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catT), n, D, nb, B_.f32(outT))
         ctx.save_for_backward(*saved)
         ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, float(drop_p), drop_seed)
+        ctx.flags = flags
         return outS, outT
 
     @staticmethod
@@ -719,6 +737,7 @@ class BiTGCFPropagate(Function):
         tmp = f32(n, D)
         for l in reversed(range(n_layers)):
             S_in, T_in, sideS, sideT, S2, T2, nS, nT = saved[8 * l:8 * l + 8]
+            fl = B_.raw(ctx.flags) if (ctx.flags is not None and l == n_layers - 1) else None
             # backward of the same chain in one launch: normalise -> (+ gradient from the layer above) -> transfer [-> dropout mask]
             gnS, gnT = f32(n, D), f32(n, D)
             dev_seed = torch.is_tensor(drop_seed)
@@ -726,19 +745,19 @@ class BiTGCFPropagate(Function):
                     B_._c_ptr(gcatS.data_ptr() + 4 * (l + 1) * D), B_._c_ptr(gcatT.data_ptr() + 4 * (l + 1) * D), nb * D,
                     B_.f32(gS), B_.f32(gT), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']), B_.f32(deg['ti']), nu, ni, D, OU, OI,
                     lam_s, lam_t, float(drop_p), 0 if dev_seed else int(drop_seed), B_.i64(drop_seed) if dev_seed else None,
-                    2 * l, 2 * l + 1, B_.f32(gnS), B_.f32(gnT))
+                    2 * l, 2 * l + 1, B_.f32(gnS), B_.f32(gnT), fl)
             gS_in, gT_in = f32(n, D), f32(n, D)
             B_.call('cdr_graph_layer_bwd', st(), B_.i64(gs.indptr), B_.i64(gs.indices), B_.f32(gs.values), n, B_.f32(S_in),
-                    B_.f32(sideS), B_.f32(gnS), D, B_.f32(tmp), B_.f32(gS_in))
+                    B_.f32(sideS), B_.f32(gnS), D, B_.f32(tmp), B_.f32(gS_in), fl)
             B_.call('cdr_graph_layer_bwd', st(), B_.i64(gt.indptr), B_.i64(gt.indices), B_.f32(gt.values), n, B_.f32(T_in),
-                    B_.f32(sideT), B_.f32(gnT), D, B_.f32(tmp), B_.f32(gT_in))
+                    B_.f32(sideT), B_.f32(gnT), D, B_.f32(tmp), B_.f32(gT_in), fl)
             gS, gT = gS_in, gT_in
         if gS is None:
             gS, gT = torch.zeros(n, D, device=dev), torch.zeros(n, D, device=dev)
         # layer-0 block of the stack is the ego embedding itself
         B_.call('cdr_copy_cols', st(), B_.f32(gcatS), nb * D, n, D, B_.f32(gS), D, 1)
         B_.call('cdr_copy_cols', st(), B_.f32(gcatT), nb * D, n, D, B_.f32(gT), D, 1)
-        return gS[:nu], gS[nu:], gT[:nu], gT[nu:], None, None, None, None, None, None, None, None, None, None, None
+        return gS[:nu], gS[nu:], gT[:nu], gT[nu:], None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class EmbLossRows(Function):

@@ -55,6 +55,8 @@ class BiTGCF(CrossDomainRecommender):
         self.domain_lambda_target = config['lambda_target']
         self.drop_rate = config['drop_rate']
         self.connect_way = config['connect_way']
+        # config['bitgcf_sparse_last_layer'] = False: every row of the last layer is computed in calculate_loss, as the reference does
+        self.sparse_last_layer = bool(config['bitgcf_sparse_last_layer']) if 'bitgcf_sparse_last_layer' in config else True
 
         self.source_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
         self.target_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
@@ -74,14 +76,15 @@ class BiTGCF(CrossDomainRecommender):
         self.apply(xavier_normal_initialization)
         self.other_parameter_name = ['target_restore_user_e', 'target_restore_item_e']
 
-    def _propagate(self):
-        """(S, T): the propagated [users ; items] stacks of the two domains, one tensor each."""
+    def _propagate(self, rows_hint=None):
+        """(S, T): the propagated [users ; items] stacks of the two domains, one tensor each.  ``rows_hint`` = (user ids, item ids,
+        ...): the only rows the caller will read -- the last layer is then evaluated on those rows alone (see BiTGCFPropagate)."""
         return F_.BiTGCFPropagate.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
                                         self.target_user_embedding.weight, self.target_item_embedding.weight,
                                         self.source_graph, self.target_graph, self.degrees, int(self.n_layers),
                                         float(self.domain_lambda_source), float(self.domain_lambda_target),
                                         self.connect_way, int(self.overlapped_num_users), int(self.overlapped_num_items),
-                                        *self._dropout_args())
+                                        *self._dropout_args(), rows_hint)
 
     def forward(self):
         S, T = self._propagate()
@@ -108,7 +111,11 @@ class BiTGCF(CrossDomainRecommender):
 
     def calculate_loss(self, interaction):
         self.init_restore_e()
-        S, T = self._propagate()
+        # the loss reads the batch's user and item rows of the two stacks and nothing else (the transfer couples a row of one domain
+        # with the SAME row of the other, so both batches flag both stacks)
+        hint = (interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.TARGET_USER_ID],
+                interaction[self.TARGET_ITEM_ID]) if self.sparse_last_layer else None
+        S, T = self._propagate(hint)
         nu = self.total_num_users
         losses = []
         for pre, stack, uw, iw in (('SOURCE', S, self.source_user_embedding.weight, self.source_item_embedding.weight),

@@ -1020,6 +1020,61 @@ def test_bitgcf_dropout_statistics_and_backward_mask():
     assert_close(le, g['loss/BOTH'], what='eval-mode loss == drop_rate 0 golden')
 
 
+@pytest.mark.parametrize('n_layers,connect,p,D', [(2, 'concat', 0.0, 16), (2, 'concat', 0.3, 16), (1, 'concat', 0.0, 16), (3, 'mean', 0.3, 16),
+                                                  (2, 'concat', 0.3, 8), (2, 'concat', 0.0, 64), (2, 'mean', 0.0, 24)])
+def test_bitgcf_last_layer_on_the_batch_rows_only_is_bit_identical(n_layers, connect, p, D):
+    """BiTGCFPropagate(rows_hint=...) evaluates the LAST layer on the rows the loss reads only (flag-skipping SpMM forward and
+    backward, flag-skipping transfer / normalise): on those rows the stacks are torch.equal to the full evaluation, the last layer's
+    block of every other row reads 0, and for a gradient that lives on those rows (what the loss sends back) all four table gradients
+    are torch.equal -- the skipped terms are exact zeros of the same sums.  Then the model: calculate_loss with and without the
+    switch gives equal losses (gradients agree to the dense scatter's atomic reordering)."""
+    from recbole_cdr_amd import functional as F_
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    ds = SyntheticCrossDomainDataset(OU=101, TOU=80, SOU=70, OI=1, TOI=120, SOI=110, n_source_inter=1500, n_target_inter=1800, seed=2)
+    cfg = base_config(DEV, embedding_size=D, n_layers=n_layers, reg_weight=0.001, lambda_source=0.8, lambda_target=0.7, drop_rate=p,
+                      connect_way=connect)
+    torch.manual_seed(5)
+    m = BiTGCF(cfg, ds).to(DEV)
+    m.train()
+    nu, n = m.total_num_users, m.total_num_users + m.total_num_items
+    rs = np.random.RandomState(1)
+    us, it_s = torch.from_numpy(rs.randint(0, nu, 40)).to(DEV), torch.from_numpy(rs.randint(0, m.total_num_items, 40)).to(DEV)
+    ut, it_t = torch.from_numpy(rs.randint(0, nu, 33)).to(DEV), torch.from_numpy(rs.randint(0, m.total_num_items, 33)).to(DEV)
+    rows = torch.unique(torch.cat([us, ut, it_s + nu, it_t + nu]))
+    tabs = [m.source_user_embedding.weight, m.source_item_embedding.weight, m.target_user_embedding.weight, m.target_item_embedding.weight]
+
+    def run(hint):
+        return F_.BiTGCFPropagate.apply(*tabs, m.source_graph, m.target_graph, m.degrees, n_layers, 0.8, 0.7, connect, int(m.overlapped_num_users),
+                                        int(m.overlapped_num_items), p, 1234, hint)
+    S0, T0 = run(None)
+    S1, T1 = run((us, it_s, ut, it_t))
+    assert torch.equal(S0[rows], S1[rows]) and torch.equal(T0[rows], T1[rows])
+    if connect == 'concat':
+        rest = torch.ones(n, dtype=torch.bool, device=DEV); rest[rows] = False
+        assert float(S1[rest][:, n_layers * D:].abs().max()) == 0.0 and float(T1[rest][:, n_layers * D:].abs().max()) == 0.0
+        assert torch.equal(S0[:, :n_layers * D], S1[:, :n_layers * D])          # the lower layers are computed everywhere
+    gS, gT = torch.zeros_like(S0), torch.zeros_like(T0)
+    gS[rows] = torch.randn(rows.numel(), S0.shape[1], device=DEV); gT[rows] = torch.randn(rows.numel(), T0.shape[1], device=DEV)
+    g0 = torch.autograd.grad([S0, T0], tabs, [gS, gT])
+    g1 = torch.autograd.grad([S1, T1], tabs, [gS, gT])
+    for a, b, what in zip(g0, g1, ('su', 'si', 'tu', 'ti')):
+        assert torch.equal(a, b), what
+    inter = {'source_user_id': us, 'source_item_id': it_s, 'source_label': (torch.rand(40, device=DEV) < 0.5).float(),
+             'target_user_id': ut, 'target_item_id': it_t, 'target_label': (torch.rand(33, device=DEV) < 0.5).float()}
+    out = []
+    for sparse in (True, False):
+        m.sparse_last_layer = sparse
+        torch.manual_seed(9)
+        m.zero_grad(set_to_none=True)
+        losses = m.calculate_loss(inter)
+        sum(losses).sum().backward()
+        out.append((torch.stack([l.reshape(()) for l in losses]).detach().clone(), [t.grad.clone() for t in tabs]))
+    assert torch.equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
 def test_bitgcf_dropout_under_graph_replay_draws_a_fresh_mask_every_step():
     """a host-drawn dropout seed is baked into a captured hipGraph and every replay would repeat ONE mask.
     The seed is a device counter bumped inside the captured step: two replays on the SAME batch give different losses (different
@@ -2232,7 +2287,7 @@ def test_bitgcf_mix_kernels_equal_the_unfused_chain(D, p):
     S2f, T2f, catSf, catTf, nSf, nTf = f32(n, D), f32(n, D), torch.zeros(n, nb * D, device=DEV), torch.zeros(n, nb * D, device=DEV), f32(n), f32(n)
     B_.call('cdr_bitgcf_mix_fwd', st(), B_.f32(newS), B_.f32(newT), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']), B_.f32(deg['ti']),
             nu, ni, D, OU, OI, 0.8, 0.7, p, 0, B_.i64(seed), 2, 3, B_.f32(S2f), B_.f32(T2f), B_._c_ptr(catSf.data_ptr() + 4 * D),
-            B_._c_ptr(catTf.data_ptr() + 4 * D), nb * D, B_.f32(nSf), B_.f32(nTf))
+            B_._c_ptr(catTf.data_ptr() + 4 * D), nb * D, B_.f32(nSf), B_.f32(nTf), None)
     for x, y, what in ((S2, S2f, 'S2'), (T2, T2f, 'T2'), (catS, catSf, 'catS'), (catT, catTf, 'catT'), (nS, nSf, 'nS'), (nT, nTf, 'nT')):
         assert_close(y, x, rtol=1e-6, atol=1e-6, what=what)        # (FMA contraction may differ between the kernels: last bit)
     assert torch.equal(S2 == 0, S2f == 0) and torch.equal(T2 == 0, T2f == 0)          # identical dropout masks
@@ -2254,7 +2309,7 @@ def test_bitgcf_mix_kernels_equal_the_unfused_chain(D, p):
         gnSf, gnTf = f32(n, D), f32(n, D)
         B_.call('cdr_bitgcf_mix_bwd', st(), B_.f32(S2), B_.f32(T2), B_.f32(nS), B_.f32(nT), B_._c_ptr(gcatS.data_ptr() + 4 * D),
                 B_._c_ptr(gcatT.data_ptr() + 4 * D), nb * D, B_.f32(gS0), B_.f32(gT0), B_.f32(deg['su']), B_.f32(deg['tu']), B_.f32(deg['si']),
-                B_.f32(deg['ti']), nu, ni, D, OU, OI, 0.8, 0.7, p, 0, B_.i64(seed), 2, 3, B_.f32(gnSf), B_.f32(gnTf))
+                B_.f32(deg['ti']), nu, ni, D, OU, OI, 0.8, 0.7, p, 0, B_.i64(seed), 2, 3, B_.f32(gnSf), B_.f32(gnTf), None)
         # (the backward's fused multiply-adds may contract differently in the two kernels: last-bit differences)
         assert_close(gnSf, gnS, rtol=1e-6, atol=1e-6, what=f'gnS prev={prev}'); assert_close(gnTf, gnT, rtol=1e-6, atol=1e-6, what=f'gnT prev={prev}')
         assert torch.equal(gnS == 0, gnSf == 0)                  # the dropout mask itself is identical
