@@ -411,6 +411,11 @@ int cdr_l2_normalize_fwd(void* stream, const float* x, int64_t rows, int D, floa
 int cdr_l2_normalize_bwd(void* stream, const float* x, const float* norm, const float* gy, int64_t ldg, int64_t rows, int D,
                          float* gx, int accumulate);
 int cdr_copy_cols(void* stream, const float* src, int64_t lds, int64_t rows, int D, float* dst, int64_t ldo, int accumulate);
+/* BiTGCF's ego layer in one launch (bitgcf.py:175-178,190): S = [su ; si], T = [tu ; ti] (contiguous [nu + ni, D]) and the same rows into
+ * column block 0 of the two layer stacks (leading dimension ldc); and its backward's last step: gS += block 0 of gcatS, likewise gT. */
+int cdr_bitgcf_stack(void* stream, const float* su, const float* si, const float* tu, const float* ti, int64_t nu, int64_t ni, int D,
+                     float* S, float* T, float* catS, float* catT, int64_t ldc);
+int cdr_bitgcf_unstack_bwd(void* stream, const float* gcatS, const float* gcatT, int64_t ldg, int64_t n, int D, float* gS, float* gT);
 int cdr_colblock_mean_fwd(void* stream, const float* cat, int64_t rows, int D, int nb, float* out);
 int cdr_colblock_mean_bwd(void* stream, const float* gout, int64_t rows, int D, int nb, float* gcat);
 /* nn.Dropout(p), training mode: out = mask ? x/(1-p) : 0, counter-based mask from `seed` (same call with the same seed on

@@ -113,6 +113,8 @@ _SIGNATURES = {
     'cdr_l2_normalize_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr],
     'cdr_l2_normalize_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_int],
     'cdr_copy_cols': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_int],
+    'cdr_bitgcf_stack': [_c_ptr] * 5 + [_c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64],
+    'cdr_bitgcf_unstack_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr],
     'cdr_colblock_mean_fwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_colblock_mean_bwd': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
     'cdr_dropout_dev': [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, ctypes.c_uint64, _c_ptr],

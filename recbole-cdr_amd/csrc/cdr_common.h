@@ -118,6 +118,20 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem) {
     }
 }
 
+// Clears a few words on a stream with a KERNEL.  hipMemsetAsync is not used for this: captured into a hipGraph, the memset node was
+// not reliably ordered before the kernel nodes that followed it (cdr_row_flags: the list length it should have reset kept growing
+// from replay to replay until the list overran; eager launches were always fine).
+static __global__ void cdr_zero_u32_kernel(uint32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t cdr_zero_u32(void* p, int64_t n_words, hipStream_t s) {
+    int64_t g = (n_words + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    cdr_zero_u32_kernel<<<dim3((unsigned)g), dim3(256), 0, s>>>((uint32_t*)p, n_words);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }

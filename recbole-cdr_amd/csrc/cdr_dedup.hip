@@ -272,7 +272,7 @@ extern "C" int cdr_segsum_rows(cdr_ctx* ctx, void* stream, const uint32_t* keys_
     seg_piece* pieces = (seg_piece*)((char*)base + o_piece);
     int* pcnt = (int*)((char*)base + o_cnt);
     float* partial = (float*)((char*)base + o_part);
-    CDR_HIP(hipMemsetAsync(counters, 0, 16, s));
+    CDR_HIP(cdr_zero_u32(counters, 4, s));
     const int64_t groups = (n + (kBlock / lpr) - 1) / (kBlock / lpr);
     DISPATCH_LPR(lpr, segsum_head_kernel<L><<<dim3(grid_cap(groups)), dim3(kBlock), 0, s>>>(keys_sorted, perm, uniq_index, n, G, neg_start, D, rows,
                                                                                           reg_coef, out, counters, longs, pieces));

@@ -138,8 +138,13 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int64_t* __restr
     const int D4 = D >> 2;
     for (int64_t r = gg; r < n_rows; r += TG) {
         const int64_t b = indptr[r], e = indptr[r + 1];
-        for (int ch = sub; ch < D4; ch += LPR) {
+        for (int ch0 = 0; ch0 < D4; ch0 += LPR) {
+            // every lane of the group takes part in handing the indices round, also the ones past the row's last chunk (D / 4 not a
+            // power of two): they redo chunk 0 and store nothing
+            const bool live = ch0 + sub < D4;
+            const int ch = live ? ch0 + sub : 0;
             const float4 acc = csr_row_dot<LPR>(indices, values, b, e, E, D, ch, sub, small);
+            if (!live) continue;
             float* o = out + r * D + 4 * ch;
             if (MODE == 0) {
                 st4(o, acc);
@@ -178,8 +183,11 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_fwd_kernel(const int64_t* __
     for (int64_t i = gg; i < nsel; i += TG) {
         const int64_t r = rowlist[i];
         const int64_t b = indptr[r], e = indptr[r + 1];
-        for (int ch = sub; ch < D4; ch += LPR) {
+        for (int ch0 = 0; ch0 < D4; ch0 += LPR) {
+            const bool live = ch0 + sub < D4;                    // (see spmm_csr_kernel)
+            const int ch = live ? ch0 + sub : 0;
             const float4 acc = csr_row_dot<LPR>(indices, values, b, e, E, D, ch, sub, small);       // same order as spmm_csr_kernel
+            if (!live) continue;
             const float4 x = ld4(E + r * D + 4 * ch);
             st4(side_out + r * D + 4 * ch, acc);
             st4(out + r * D + 4 * ch, make_float4(x.x + (acc.x + x.x * acc.x), x.y + (acc.y + x.y * acc.y),
@@ -208,8 +216,11 @@ __global__ __launch_bounds__(kBlock) void spmm_flagged_bwd_kernel(const int64_t*
     for (int64_t r = gg; r < n_rows; r += TG) {
         const int64_t b = indptr[r], e = indptr[r + 1];
         const bool own = (flags[r >> 5] >> (r & 31)) & 1u;
-        for (int ch = sub; ch < D4; ch += LPR) {
+        for (int ch0 = 0; ch0 < D4; ch0 += LPR) {
+            const bool live = ch0 + sub < D4;                    // (see spmm_csr_kernel)
+            const int ch = live ? ch0 + sub : 0;
             const float4 acc = csr_row_dot_flagged<LPR>(indices, values, b, e, G, E, flags, D, ch, sub);
+            if (!live) continue;
             float4 o = acc;
             if (own) {
                 const float4 g = ld4(G + r * D + 4 * ch), s_ = ld4(S + r * D + 4 * ch);
@@ -225,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void spmm_flagged_bwd_kernel(const int64_t*
 // and, for the thread that set the bit first, an entry of the compacted row list.  work = [flags | bitmap | count | list], see
 // cdr_row_flags_layout; the first three are zero on entry.
 struct flag_lists { const int64_t* ids[8]; int64_t n[8]; int64_t off[8]; int count; };
+
 __global__ __launch_bounds__(kBlock) void row_flags_kernel(flag_lists fl, int64_t rows, uint8_t* __restrict__ flags,
                                                            uint32_t* __restrict__ bitmap, int32_t* __restrict__ count,
                                                            int32_t* __restrict__ list) {
@@ -337,6 +349,42 @@ __global__ __launch_bounds__(kBlock) void copy_cols_kernel(const float* __restri
         const int c = (int)(e - r * D);
         const float v = src[r * lds + c];
         dst[r * ldo + c] = accumulate ? dst[r * ldo + c] + v : v;
+    }
+}
+
+// The ego layer of both domains in ONE launch: S = [su ; si], T = [tu ; ti] (the first graph layer's input) and the same rows as
+// block 0 of the two layer stacks (six copy_cols launches before).  float4 per thread; D % 4 == 0.
+__global__ __launch_bounds__(kBlock) void bitgcf_stack_kernel(const float* __restrict__ su, const float* __restrict__ si,
+                                                              const float* __restrict__ tu, const float* __restrict__ ti, int64_t nu,
+                                                              int64_t ni, int D, float* __restrict__ S, float* __restrict__ T,
+                                                              float* __restrict__ catS, float* __restrict__ catT, int64_t ldc) {
+    const int D4 = D >> 2;
+    const int64_t total = (nu + ni) * D4, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D4;
+        const int c = 4 * (int)(e - r * D4);
+        const bool user = r < nu;
+        const int64_t o = (user ? r : r - nu) * D + c;
+        const float4 a = ld4((user ? su : si) + o), b = ld4((user ? tu : ti) + o);
+        st4(S + r * D + c, a); st4(T + r * D + c, b);
+        st4(catS + r * ldc + c, a); st4(catT + r * ldc + c, b);
+    }
+}
+
+// gS += block 0 of gcatS, gT += block 0 of gcatT (the ego rows' share of the stack's gradient), one launch
+__global__ __launch_bounds__(kBlock) void bitgcf_unstack_bwd_kernel(const float* __restrict__ gcatS, const float* __restrict__ gcatT,
+                                                                    int64_t ldg, int64_t n, int D, float* __restrict__ gS,
+                                                                    float* __restrict__ gT) {
+    const int D4 = D >> 2;
+    const int64_t total = n * D4, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D4;
+        const int c = 4 * (int)(e - r * D4);
+        const float4 a = ld4(gcatS + r * ldg + c), b = ld4(gcatT + r * ldg + c);
+        float4 x = ld4(gS + r * D + c), y = ld4(gT + r * D + c);
+        x.x += a.x; x.y += a.y; x.z += a.z; x.w += a.w;
+        y.x += b.x; y.y += b.y; y.z += b.z; y.w += b.w;
+        st4(gS + r * D + c, x); st4(gT + r * D + c, y);
     }
 }
 
@@ -717,7 +765,8 @@ extern "C" int cdr_row_flags(void* stream, int n_lists, const int64_t* const* id
     CDR_CHECK_ARG(n_lists >= 0 && n_lists <= 8 && rows > 0 && rows < ((int64_t)1 << 31) && work && (n_lists == 0 || (ids && counts && offsets)));
     row_flag_views v = flag_views(work, rows);
     CDR_CHECK_ARG(work_bytes >= v.bytes && ((uintptr_t)work & 15) == 0);
-    CDR_HIP(hipMemsetAsync(work, 0, v.zero_bytes, (hipStream_t)stream));
+    // (a kernel, not hipMemsetAsync: see cdr_zero_u32)
+    CDR_HIP(cdr_zero_u32(work, (int64_t)(v.zero_bytes / 4), (hipStream_t)stream));
     flag_lists fl{};
     int64_t nmax = 0;
     for (int i = 0; i < n_lists; ++i) {
@@ -851,6 +900,22 @@ extern "C" int cdr_copy_cols(void* stream, const float* src, int64_t lds, int64_
                              int accumulate) {
     CDR_CHECK_ARG(src && dst && rows > 0 && D > 0 && lds >= D && ldo >= D);
     copy_cols_kernel<<<GR_GRID(rows * D)>>>(src, lds, rows, D, dst, ldo, accumulate);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bitgcf_stack(void* stream, const float* su, const float* si, const float* tu, const float* ti, int64_t nu, int64_t ni,
+                                int D, float* S, float* T, float* catS, float* catT, int64_t ldc) {
+    CDR_CHECK_ARG(su && si && tu && ti && S && T && catS && catT && nu > 0 && ni > 0 && D > 0 && (D & 3) == 0 && ldc >= D && (ldc & 3) == 0);
+    bitgcf_stack_kernel<<<GR_GRID((nu + ni) * (D / 4))>>>(su, si, tu, ti, nu, ni, D, S, T, catS, catT, ldc);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bitgcf_unstack_bwd(void* stream, const float* gcatS, const float* gcatT, int64_t ldg, int64_t n, int D, float* gS,
+                                      float* gT) {
+    CDR_CHECK_ARG(gcatS && gcatT && gS && gT && n > 0 && D > 0 && (D & 3) == 0 && ldg >= D && (ldg & 3) == 0);
+    bitgcf_unstack_bwd_kernel<<<GR_GRID(n * (D / 4))>>>(gcatS, gcatT, ldg, n, D, gS, gT);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -423,7 +423,7 @@ int apply2(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float* exp_avg, f
         if (rc != CDR_OK) return rc;
         counters = (unsigned*)base; longs = (seg_long*)((char*)base + o_long); pieces = (seg_piece*)((char*)base + o_piece);
         pcnt = (int*)((char*)base + o_cnt); partial = (float*)((char*)base + o_part);
-        CDR_HIP(hipMemsetAsync(counters, 0, 16, s));
+        CDR_HIP(cdr_zero_u32(counters, 4, s));
     }
     cdr_time_scope ts(ctx, tag, s);
 #define A2 table, exp_avg, exp_avg_sq, D, keys, perm, n, G, rec, Usrc, reg_limit, reg_coef, hp, sd, counters, longs, pieces

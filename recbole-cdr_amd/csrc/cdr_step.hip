@@ -615,7 +615,7 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
         if (rc != CDR_OK) return rc;
         counters = (unsigned*)base; longs = (seg_long*)((char*)base + o_long); pieces = (seg_piece*)((char*)base + o_piece);
         pcnt = (int*)((char*)base + o_cnt); partial = (float*)((char*)base + o_part);
-        CDR_HIP(hipMemsetAsync(counters, 0, 16, s));
+        CDR_HIP(cdr_zero_u32(counters, 4, s));
     }
     cdr_time_scope ts(ctx, is_signed ? CDR_TAG_APPLY_SIGNED : CDR_TAG_APPLY_UNSIGNED, s);
 #define APPLY_ARGS table, exp_avg, exp_avg_sq, D, keys_sorted, perm, n, G, neg_start, reg_limit, reg_coef, hp, occ_ids, counters, longs, pieces

@@ -658,7 +658,8 @@ class BiTGCFPropagate(Function):
     is symmetric, so the SpMM backward is the same kernel."""
 
     @staticmethod
-    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p=0.0, drop_seed=0, rows_hint=None):
+    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p=0.0, drop_seed=0, rows_hint=None,
+                emb_loss=False):
         # drop_seed: a host int, or a device int64 [1] counter (the capturable form: a hipGraph replay would bake a host seed
         # into its launches and repeat one mask on every step)
         # rows_hint = (user ids, item ids, user ids, item ids, ...): the ONLY rows of the returned stacks the caller will read
@@ -666,6 +667,9 @@ class BiTGCFPropagate(Function):
         # nothing but those rows, so its graph layer, its transfer / normalise and their backward run on the flagged rows only
         # (a tenth of the table at BASELINE C4): same numbers in the flagged rows, same gradients bit for bit (the skipped terms
         # are exact zeros); every other row of the last layer's block reads 0.  Without the hint every row is computed.
+        # emb_loss (with rows_hint = (source users, source items, target users, target items)): two more outputs, recbole's EmbLoss of
+        # the two batches' EGO rows (bitgcf.py:231-233, as functional.EmbLossRows); their gradient rows are added straight into the
+        # table gradients this node returns -- as separate nodes they cost two zero-filled tables and four table-sized adds per step.
         _dev_check(su, si, tu, ti)
         nu, ni, D = su.shape[0], si.shape[0], su.shape[1]
         n = nu + ni
@@ -684,13 +688,9 @@ class BiTGCFPropagate(Function):
             B_._alive.extend(lists)
             B_.call('cdr_row_flags', st(), m, (ctypes.c_void_p * m)(*[x.data_ptr() for x in lists]), (ctypes.c_int64 * m)(*[x.numel() for x in lists]),
                     (ctypes.c_int64 * m)(*[0 if k % 2 == 0 else nu for k in range(m)]), n, B_.raw(flags), flags.numel())
-        S, T = f32(n, D), f32(n, D)
-        for dst, a, b in ((S, su, si), (T, tu, ti)):
-            B_.call('cdr_copy_cols', st(), B_.f32(a.contiguous()), D, nu, D, B_.f32(dst), D, 0)
-            B_.call('cdr_copy_cols', st(), B_.f32(b.contiguous()), D, ni, D, B_._c_ptr(dst.data_ptr() + 4 * nu * D), D, 0)
-        catS, catT = f32(n, nb * D), f32(n, nb * D)
-        B_.call('cdr_copy_cols', st(), B_.f32(S), D, n, D, B_.f32(catS), nb * D, 0)
-        B_.call('cdr_copy_cols', st(), B_.f32(T), D, n, D, B_.f32(catT), nb * D, 0)
+        S, T, catS, catT = f32(n, D), f32(n, D), f32(n, nb * D), f32(n, nb * D)
+        B_.call('cdr_bitgcf_stack', st(), B_.f32(su.contiguous()), B_.f32(si.contiguous()), B_.f32(tu.contiguous()), B_.f32(ti.contiguous()),
+                nu, ni, D, B_.f32(S), B_.f32(T), B_.f32(catS), B_.f32(catT), nb * D)
         saved = []
         for l in range(n_layers):
             sideS, newS, sideT, newT = f32(n, D), f32(n, D), f32(n, D), f32(n, D)
@@ -714,17 +714,33 @@ class BiTGCFPropagate(Function):
             outS, outT = f32(n, D), f32(n, D)
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catS), n, D, nb, B_.f32(outS))
             B_.call('cdr_colblock_mean_fwd', st(), B_.f32(catT), n, D, nb, B_.f32(outT))
+        embS = embT = None
+        ctx.emb = None
+        if emb_loss:
+            assert rows_hint is not None and len(rows_hint) == 4, 'emb_loss needs rows_hint = (source users, source items, target users, target items)'
+            ids4 = [_ids(x) for x in rows_hint]
+            su_, si_, tu_, ti_ = su.contiguous(), si.contiguous(), tu.contiguous(), ti.contiguous()
+            o3s, o3t = f32(3), f32(3)
+            B_.call('cdr_embloss_fwd', B_.ctx(dev), st(), B_.f32(su_), B_.f32(si_), D, B_.i64(ids4[0]), B_.i64(ids4[1]), ids4[0].numel(), B_.f32(o3s))
+            B_.call('cdr_embloss_fwd', B_.ctx(dev), st(), B_.f32(tu_), B_.f32(ti_), D, B_.i64(ids4[2]), B_.i64(ids4[3]), ids4[2].numel(), B_.f32(o3t))
+            ctx.emb = (su_, si_, tu_, ti_, ids4, o3s, o3t)
+            embS, embT = o3s[:1], o3t[:1]
         ctx.save_for_backward(*saved)
         ctx.meta = (gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, float(drop_p), drop_seed)
         ctx.flags = flags
-        return outS, outT
+        ctx.set_materialize_grads(False)
+        return outS, outT, embS, embT
 
     @staticmethod
-    def backward(ctx, gOutS, gOutT):
+    def backward(ctx, gOutS, gOutT, gEmbS=None, gEmbT=None):
         gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, nu, ni, D, drop_p, drop_seed = ctx.meta
         saved = ctx.saved_tensors
         n, nb = nu + ni, n_layers + 1
-        dev = gOutS.device
+        dev = saved[0].device if len(saved) else (gOutS if gOutS is not None else gOutT).device
+        if gOutS is None or gOutT is None:       # (an unused stack: its gradient is zero)
+            z = lambda: torch.zeros(n, nb * D if connect_way == 'concat' else D, device=dev, dtype=torch.float32)
+            gOutS = z() if gOutS is None else gOutS
+            gOutT = z() if gOutT is None else gOutT
         st = B_.stream
         f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         if connect_way == 'concat':
@@ -755,9 +771,14 @@ class BiTGCFPropagate(Function):
         if gS is None:
             gS, gT = torch.zeros(n, D, device=dev), torch.zeros(n, D, device=dev)
         # layer-0 block of the stack is the ego embedding itself
-        B_.call('cdr_copy_cols', st(), B_.f32(gcatS), nb * D, n, D, B_.f32(gS), D, 1)
-        B_.call('cdr_copy_cols', st(), B_.f32(gcatT), nb * D, n, D, B_.f32(gT), D, 1)
-        return gS[:nu], gS[nu:], gT[:nu], gT[nu:], None, None, None, None, None, None, None, None, None, None, None, None
+        B_.call('cdr_bitgcf_unstack_bwd', st(), B_.f32(gcatS), B_.f32(gcatT), nb * D, n, D, B_.f32(gS), B_.f32(gT))
+        if ctx.emb is not None:
+            su_, si_, tu_, ti_, ids4, o3s, o3t = ctx.emb
+            for g, (U, I, u, i, o3, go) in ((gS, (su_, si_, ids4[0], ids4[1], o3s, gEmbS)), (gT, (tu_, ti_, ids4[2], ids4[3], o3t, gEmbT))):
+                if go is not None:
+                    B_.call('cdr_embloss_bwd_dense', st(), B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(i), u.numel(), B_.f32(o3),
+                            B_.f32(go.reshape(-1).contiguous()), B_.f32(g), B_._c_ptr(g.data_ptr() + 4 * nu * D))
+        return (gS[:nu], gS[nu:], gT[:nu], gT[nu:]) + (None,) * 13
 
 
 class EmbLossRows(Function):

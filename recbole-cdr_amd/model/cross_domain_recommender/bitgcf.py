@@ -76,18 +76,19 @@ class BiTGCF(CrossDomainRecommender):
         self.apply(xavier_normal_initialization)
         self.other_parameter_name = ['target_restore_user_e', 'target_restore_item_e']
 
-    def _propagate(self, rows_hint=None):
-        """(S, T): the propagated [users ; items] stacks of the two domains, one tensor each.  ``rows_hint`` = (user ids, item ids,
-        ...): the only rows the caller will read -- the last layer is then evaluated on those rows alone (see BiTGCFPropagate)."""
+    def _propagate(self, rows_hint=None, emb_loss=False):
+        """(S, T, reg_s, reg_t): the propagated [users ; items] stacks of the two domains, one tensor each, and (``emb_loss``) the
+        EmbLoss of the two batches' ego rows.  ``rows_hint`` = (user ids, item ids, ...): the only rows the caller will read --
+        the last layer is then evaluated on those rows alone (see BiTGCFPropagate)."""
         return F_.BiTGCFPropagate.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
                                         self.target_user_embedding.weight, self.target_item_embedding.weight,
                                         self.source_graph, self.target_graph, self.degrees, int(self.n_layers),
                                         float(self.domain_lambda_source), float(self.domain_lambda_target),
                                         self.connect_way, int(self.overlapped_num_users), int(self.overlapped_num_items),
-                                        *self._dropout_args(), rows_hint)
+                                        *self._dropout_args(), rows_hint, emb_loss)
 
     def forward(self):
-        S, T = self._propagate()
+        S, T, _, _ = self._propagate()
         nu = self.total_num_users
         return S[:nu], S[nu:], T[:nu], T[nu:]
 
@@ -115,11 +116,11 @@ class BiTGCF(CrossDomainRecommender):
         # with the SAME row of the other, so both batches flag both stacks)
         hint = (interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.TARGET_USER_ID],
                 interaction[self.TARGET_ITEM_ID]) if self.sparse_last_layer else None
-        S, T = self._propagate(hint)
+        S, T, reg_s, reg_t = self._propagate(hint, emb_loss=hint is not None)
         nu = self.total_num_users
         losses = []
-        for pre, stack, uw, iw in (('SOURCE', S, self.source_user_embedding.weight, self.source_item_embedding.weight),
-                                   ('TARGET', T, self.target_user_embedding.weight, self.target_item_embedding.weight)):
+        for pre, stack, uw, iw, reg in (('SOURCE', S, self.source_user_embedding.weight, self.source_item_embedding.weight, reg_s),
+                                        ('TARGET', T, self.target_user_embedding.weight, self.target_item_embedding.weight, reg_t)):
             user = interaction[getattr(self, f'{pre}_USER_ID')]
             item = interaction[getattr(self, f'{pre}_ITEM_ID')]
             label = interaction[getattr(self, f'{pre}_LABEL')]
@@ -127,7 +128,8 @@ class BiTGCF(CrossDomainRecommender):
             # the stack's shape handed straight to the propagation's backward (slicing cost two zero-fills, two copies and an add
             # per domain and step)
             bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, stack, stack, None, None, user, item + nu, label, 0.0)
-            reg = F_.EmbLossRows.apply(uw, iw, user, item)
+            if reg is None:
+                reg = F_.EmbLossRows.apply(uw, iw, user, item)
             losses.append(bce + self.reg_weight * reg)
         return tuple(losses)
 

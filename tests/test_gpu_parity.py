@@ -1,5 +1,6 @@
 """GPU parity (-m gpu): the HIP path through the C ABI vs (1) golden vectors produced by the reference and (2) the
 oracle on larger seeded inputs.  Tolerance: 1e-5 relative (north_star) for fp32 losses / gradients / scores."""
+import ctypes
 import numpy as np
 import pytest
 import torch
@@ -1047,8 +1048,8 @@ def test_bitgcf_last_layer_on_the_batch_rows_only_is_bit_identical(n_layers, con
     def run(hint):
         return F_.BiTGCFPropagate.apply(*tabs, m.source_graph, m.target_graph, m.degrees, n_layers, 0.8, 0.7, connect, int(m.overlapped_num_users),
                                         int(m.overlapped_num_items), p, 1234, hint)
-    S0, T0 = run(None)
-    S1, T1 = run((us, it_s, ut, it_t))
+    S0, T0, _, _ = run(None)
+    S1, T1, _, _ = run((us, it_s, ut, it_t))
     assert torch.equal(S0[rows], S1[rows]) and torch.equal(T0[rows], T1[rows])
     if connect == 'concat':
         rest = torch.ones(n, dtype=torch.bool, device=DEV); rest[rows] = False
@@ -1309,11 +1310,15 @@ def test_end_to_end_emcdr_learns_with_device_sampler():
         assert abs(res_t[k] - ref_t[k]) < 1e-6 and abs(res_s[k] - ref_s[k]) < 1e-6, (k, res_t[k], ref_t[k], res_s[k], ref_s[k])
 
 
-def test_spmm_csr_vs_torch_sparse():
-    """cdr_spmm_csr_f32 (torch.sparse.mm, bitgcf.py:131) on a random graph with empty rows, odd/even row lengths."""
+@pytest.mark.parametrize('D', [64, 8, 24, 48, 96, 128, 260])
+def test_spmm_csr_vs_torch_sparse(D):
+    """cdr_spmm_csr_f32 (torch.sparse.mm, bitgcf.py:131) on a random graph with empty rows, odd/even row lengths, rows longer than one
+    index batch of the lane group; widths whose D / 4 is and is not a power of two (the lanes of a group hand the indices round: the
+    ones past the last chunk must still take part), one wider than a wave (several chunks per lane).  Then the graph layer's forward
+    and backward (cdr_graph_layer_fwd / _bwd, with and without row flags) against the same math in torch."""
     from recbole_cdr_amd import binding as B_
     rng = np.random.RandomState(0)
-    n, D, nnz = 500, 64, 6000
+    n, nnz = 500, 6000
     rows, cols = rng.randint(0, n, nnz), rng.randint(0, n, nnz)
     rows[rows % 7 == 0] = 1                                   # leave some rows empty, make one heavy
     pairs = np.unique(np.stack([rows, cols], 1), axis=0)
@@ -1328,6 +1333,41 @@ def test_spmm_csr_vs_torch_sparse():
     d_val, d_E = torch.from_numpy(vals).to(DEV), E.to(DEV)
     B_.call('cdr_spmm_csr_f32', B_.stream(), B_.i64(d_ptr), B_.i64(d_idx), B_.f32(d_val), n, B_.f32(d_E), D, B_.f32(out))
     assert_close(out, ref)
+    # graph layer: side = A E, new = E + side + E (.) side ; backward gE = g (.) (1 + side) + A^T (g (.) (1 + E)) -- with a symmetric A
+    ps = np.unique(np.concatenate([pairs, pairs[:, ::-1]]), axis=0)
+    vs = rng.rand(len(ps)).astype(np.float32)
+    key = {(int(a), int(b)): i for i, (a, b) in enumerate(ps)}
+    vs = np.array([vs[min(key[(int(a), int(b))], key[(int(b), int(a))])] for a, b in ps], dtype=np.float32)      # symmetric values
+    As = torch.sparse_coo_tensor(torch.from_numpy(ps.T.copy()), torch.from_numpy(vs), (n, n)).coalesce()
+    ip = np.zeros(n + 1, dtype=np.int64); np.cumsum(np.bincount(ps[:, 0], minlength=n), out=ip[1:])
+    s_ptr, s_idx, s_val = torch.from_numpy(ip).to(DEV), torch.from_numpy(ps[:, 1].copy()).to(DEV), torch.from_numpy(vs).to(DEV)
+    side_ref = torch.sparse.mm(As, E)
+    new_ref = E + (side_ref + E * side_ref)
+    side, new = torch.empty(n, D, device=DEV), torch.empty(n, D, device=DEV)
+    B_.call('cdr_graph_layer_fwd', B_.stream(), B_.i64(s_ptr), B_.i64(s_idx), B_.f32(s_val), n, B_.f32(d_E), D, B_.f32(side), B_.f32(new), None)
+    assert_close(side, side_ref); assert_close(new, new_ref)
+    sel = torch.from_numpy(rng.choice(n, 60, replace=False)).to(DEV)
+    g = torch.zeros(n, D, device=DEV); g[sel] = torch.randn(60, D, device=DEV)
+    gE_ref = g.cpu() * (1 + side_ref) + torch.sparse.mm(As, g.cpu() * (1 + E))
+    tmp, gE = torch.empty(n, D, device=DEV), torch.empty(n, D, device=DEV)
+    B_.call('cdr_graph_layer_bwd', B_.stream(), B_.i64(s_ptr), B_.i64(s_idx), B_.f32(s_val), n, B_.f32(d_E), B_.f32(side), B_.f32(g), D, B_.f32(tmp),
+            B_.f32(gE), None)
+    assert_close(gE, gE_ref, atol=1e-6)
+    need = ctypes.c_size_t(0)
+    B_._check(B_.load().cdr_row_flags_layout(n, ctypes.byref(need)), 'layout')
+    work = torch.empty(int(need.value), device=DEV, dtype=torch.uint8)
+    B_.call('cdr_row_flags', B_.stream(), 1, (ctypes.c_void_p * 1)(sel.data_ptr()), (ctypes.c_int64 * 1)(60), (ctypes.c_int64 * 1)(0), n, B_.raw(work),
+            work.numel())
+    assert int(work[:n].sum()) == 60 and bool((work[:n][sel] == 1).all())
+    side2, new2 = torch.full((n, D), 7.0, device=DEV), torch.full((n, D), 7.0, device=DEV)
+    B_.call('cdr_graph_layer_fwd', B_.stream(), B_.i64(s_ptr), B_.i64(s_idx), B_.f32(s_val), n, B_.f32(d_E), D, B_.f32(side2), B_.f32(new2), B_.raw(work))
+    assert torch.equal(side2[sel], side[sel]) and torch.equal(new2[sel], new[sel])
+    rest = torch.ones(n, dtype=torch.bool, device=DEV); rest[sel] = False
+    assert bool((side2[rest] == 7.0).all())                    # unflagged rows are not touched
+    gE2 = torch.empty(n, D, device=DEV)
+    B_.call('cdr_graph_layer_bwd', B_.stream(), B_.i64(s_ptr), B_.i64(s_idx), B_.f32(s_val), n, B_.f32(d_E), B_.f32(side2), B_.f32(g), D, None,
+            B_.f32(gE2), B_.raw(work))
+    assert torch.equal(gE2, gE)                                 # the skipped terms are exact zeros
 
 
 
