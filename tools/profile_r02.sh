@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-2 evidence run (on the GPU box through gpurun): bench lines of every BASELINE config, rocprofv3 kernel stats of the c5 and
 # c3 commands, PMC passes (FETCH_SIZE / WRITE_SIZE in their own runs, --kernel-trace only), the sweeps and micro-benchmarks.
+# (rocprofv3 runs sit under `timeout`: a traced hipGraph replay of the C4 step once hung the profiler for the whole call.)
 # Everything lands under gpurun_out/r02/; tools/refresh_profiles_r02.py copies the summaries into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -17,10 +18,10 @@ python tools/mb_conet.py > $O/mb_conet.txt 2>&1; echo "mb_conet rc=$?"
 python tools/mb_smallsort.py > $O/mb_smallsort.txt 2>&1; echo "mb_smallsort rc=$?"
 python tools/mb_models5.py > $O/mb_models5.txt 2>&1; echo "mb_models5 rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5 -o trace -- python $R/bench.py --no-cpu-baseline > $O/bench_c5_under_rocprof.json 2> $O/trace_c5.err; echo "trace c5 rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 100 --warmup 10 > $O/bench_c3_under_rocprof.json 2> $O/trace_c3.err; echo "trace c3 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5 -o trace -- python $R/bench.py --no-cpu-baseline > $O/bench_c5_under_rocprof.json 2> $O/trace_c5.err; echo "trace c5 rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 100 --warmup 10 > $O/bench_c3_under_rocprof.json 2> $O/trace_c3.err; echo "trace c3 rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o pmc -- python $R/bench.py --no-cpu-baseline --no-fullsort --steps 3 --warmup 1 > $O/bench_pmc_$C.json 2> $O/pmc_$C.err; echo "pmc $C rc=$?"
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o pmc -- python $R/bench.py --no-cpu-baseline --no-fullsort --steps 3 --warmup 1 > $O/bench_pmc_$C.json 2> $O/pmc_$C.err; echo "pmc $C rc=$?"
 done
 find $O -name "*kernel_trace.csv" -size +6M -delete
 find $O -name "*counter_collection.csv" -size +24M -delete
