@@ -239,6 +239,46 @@ __device__ __forceinline__ void fwd_layer_stream(const conet_net& net, int l, co
     }
 }
 
+// The small layers on LDS-staged weights without a predicate in the K loop, for din % 8 == 0: a column past dout works on weight
+// row 0 and is dropped at the store (the predicated fwd_layer<true> compiled to an exec-masked block per operand: 4.6 / 3.4 /
+// 2.8 us for C3's 64->32->16->8 where the MFMAs take 1.7 / 0.9 / 0.4).  Same K order: bit-identical.
+__device__ __forceinline__ void fwd_layer_lds(const conet_net& net, int l, const float* __restrict__ Xin, float* __restrict__ Xout,
+                                              const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ acts,
+                                              int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int XS = 2 * din + 4, XO = 2 * dout + 4, WS = din + 4;
+    const int NT = (dout + 31) >> 5, KS = din >> 3;
+    const int off = net.act_off[l], actw = net.act_off[net.L];
+    for (int job = wave; job < 2 * NT; job += 4) {
+        const int tower = job / NT, n = (job - tower * NT) * 32 + li;
+        const bool nv = n < dout;
+        const int nc = nv ? n : 0;
+        const float* xo = Xin + li * XS + (tower ? din : 0) + 4 * lh;
+        const float* xc = Xin + li * XS + (tower ? 0 : din) + 4 * lh;
+        const float* wm = wl + net.wl_off[l] + (tower ? dout * WS : 0) + nc * WS + 4 * lh;
+        const float* hc = wl + net.wl_off[l] + 2 * dout * WS + nc * WS + 4 * lh;
+        const float bv = (tower ? net.bt[l] : net.bs[l])[nc];      // requested before the MFMAs, used after them
+        f32x16 am = zero16(), ac = zero16();
+#pragma unroll 2
+        for (int s = 0; s < KS; ++s) {
+            const float4 b0 = ld4(wm + 8 * s), b1 = ld4(hc + 8 * s), a0 = ld4(xo + 8 * s), a1 = ld4(xc + 8 * s);
+            MFMA4(am, a0, b0);
+            MFMA4(ac, a1, b1);
+        }
+        if (nv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = am[r] + bv;
+                if (mrow[row] != 0.f) v += ac[r];                      // conet.py:127-129 / :132-134
+                v = v > 0.f ? v : 0.f;
+                Xout[row * XO + tower * dout + n] = v;
+                if (row0 + row < R) acts[(row0 + row) * actw + off + tower * dout + n] = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const float* __restrict__ su, const float* __restrict__ si,
                                                         const float* __restrict__ tu, const float* __restrict__ ti, int D,
                                                         const int64_t* __restrict__ user_s, const int64_t* __restrict__ user_t,
@@ -294,7 +334,8 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
         for (int l = 0; l < net.L; ++l) {
             const float* Xin = (l & 1) ? bufB : bufA;
             float* Xout = (l & 1) ? bufA : bufB;
-            if (l > 0 && net.wlds) fwd_layer<true>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            if (l > 0 && net.wlds && !(net.dims[l] & 7)) fwd_layer_lds(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            else if (l > 0 && net.wlds) fwd_layer<true>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
             else if (net.vec && !(net.dims[l] & 127) && !(net.dims[l + 1] & 31))
                 fwd_layer_stream(net, l, Xin, Xout, mrow, acts, rb * kRows, R, wave, li, lh);
             else fwd_layer<false>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
@@ -581,6 +622,46 @@ __device__ __forceinline__ void bwd_layer_quad(const conet_net& net, int l, cons
     }
 }
 
+// bwd_layer<true> for the small layers (dout % 8 == 0, any din): one column tile per unit, no predicate in the K loop (a column past
+// din reads weight column 0 and is dropped at the store).  Same K order: bit-identical.
+__device__ __forceinline__ void bwd_layer_lds(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ Gn,
+                                              const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ gx0,
+                                              int64_t row0, int64_t R, int wave, int li, int lh) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4, ldw = din + 4;
+    const int NT = (din + 31) >> 5, KS = dout >> 3;
+    for (int u = wave; u < 2 * NT; u += 4) {
+        const int tower = u / NT, c0 = (u - tower * NT) * 32 + li;
+        const bool cv = c0 < din;
+        const int cc = cv ? c0 : 0;
+        const float* Wm = wl + net.wl_off[l] + (tower ? dout * ldw : 0) + 4 * lh * ldw + cc;
+        const float* Hm = wl + net.wl_off[l] + 2 * dout * ldw + 4 * lh * ldw + cc;
+        const float* ao = Gl + li * GS + (tower ? dout : 0) + 4 * lh;
+        const float* ax = Gl + li * GS + (tower ? 0 : dout) + 4 * lh;
+        f32x16 am = zero16(), ac = zero16();
+#pragma unroll 2
+        for (int s = 0; s < KS; ++s) {
+            const float* w_ = Wm + 8 * s * ldw;
+            const float* h_ = Hm + 8 * s * ldw;
+            const float4 m = make_float4(w_[0], w_[ldw], w_[2 * ldw], w_[3 * ldw]);
+            const float4 h = make_float4(h_[0], h_[ldw], h_[2 * ldw], h_[3 * ldw]);
+            const float4 a0 = ld4(ao + 8 * s), a1 = ld4(ax + 8 * s);
+            MFMA4(am, a0, m);
+            MFMA4(ac, a1, h);
+        }
+        if (cv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = am[r];
+                if (mrow[row] != 0.f) v += ac[r];
+                if (l > 0) Gn[row * GN + tower * din + c0] = v;
+                else if (row0 + row < R) gx0[(row0 + row) * (2 * (int64_t)din) + tower * din + c0] = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R, int64_t n_source, const float* __restrict__ label,
                                                         const float* __restrict__ prob, const float* __restrict__ maskf,
                                                         const float* __restrict__ acts, const float* __restrict__ grad_out,
@@ -666,7 +747,8 @@ __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R
             } else if (!(dout & 31) && !(din & 31)) {
                 if (lds_w) bwd_layer_tiles<true, 1>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
                 else bwd_layer_tiles<false, 1>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
-            } else if (lds_w) bwd_layer<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            } else if (lds_w && !(dout & 7)) bwd_layer_lds(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            else if (lds_w) bwd_layer<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
             else bwd_layer<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
             lds_barrier();
             STAMP(20 + 2 * (L - 1 - l));
