@@ -229,9 +229,30 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
     const int64_t n = a.n[t];
-    float step_size, bc2_sqrt;
-    cdr_adam_hp((double)a.step[t][0], lr, b1, b2, step_size, bc2_sqrt);
+    // the two bias corrections (two fp64 pow each) once per block, not once per thread: they were a third of this kernel's time on
+    // the 43 MB of C4's tables and most of it on the few KB of C3's tower weights.  Same expression, same value.
+    __shared__ float hp[2];
+    if (threadIdx.x == 0) {
+        float ss, bc;
+        cdr_adam_hp((double)a.step[t][0], lr, b1, b2, ss, bc);
+        hp[0] = ss; hp[1] = bc;
+    }
+    __syncthreads();
+    const float step_size = hp[0], bc2_sqrt = hp[1];
     const int64_t stride = (int64_t)nb * kBlock;
+    if (!(n & 3) && !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) {           // 16-B requests
+        const int64_t n4 = n >> 2;
+        for (int64_t e = (int64_t)lb * kBlock + threadIdx.x; e < n4; e += stride) {
+            float4 pv = ld4(p + 4 * e), mv = ld4(m + 4 * e), vv = ld4(v + 4 * e);
+            const float4 gv = ld4(g + 4 * e);
+            pv.x = cdr_adam_elem(pv.x, gv.x, mv.x, vv.x, b1, b2, eps, wd, step_size, bc2_sqrt);
+            pv.y = cdr_adam_elem(pv.y, gv.y, mv.y, vv.y, b1, b2, eps, wd, step_size, bc2_sqrt);
+            pv.z = cdr_adam_elem(pv.z, gv.z, mv.z, vv.z, b1, b2, eps, wd, step_size, bc2_sqrt);
+            pv.w = cdr_adam_elem(pv.w, gv.w, mv.w, vv.w, b1, b2, eps, wd, step_size, bc2_sqrt);
+            st4(p + 4 * e, pv); st4(m + 4 * e, mv); st4(v + 4 * e, vv);
+        }
+        return;
+    }
     for (int64_t e = (int64_t)lb * kBlock + threadIdx.x; e < n; e += stride) {
         float mv = m[e], vv = v[e];
         p[e] = cdr_adam_elem(p[e], g[e], mv, vv, b1, b2, eps, wd, step_size, bc2_sqrt);   // shared with the deferred per-row form
