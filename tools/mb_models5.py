@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Step time of the five models of SURVEY 8f-4 at their default sizes (properties/model/*.yaml: D = 64, train_batch_size 2,048,
+"""Step time of the five models of SURVEY 8f-4 (and of SSCDR, SURVEY 8a row a8, which no BASELINE config names) at their default sizes (properties/model/*.yaml: D = 64, train_batch_size 2,048,
 ml-1m -> ml-100k sized id space as BASELINE C1/C2): calculate_loss + backward + dense native Adam, eager and as one hipGraph
 (graph_step.GraphedTrainStep), beside the oracle's torch-CPU restatement of the same step on the host (all cores / 1 thread).
 Usage on an MI355X: python tools/mb_models5.py [--steps 200]"""
@@ -70,6 +70,8 @@ def main():
     from recbole_cdr_amd.model.cross_domain_recommender.natr import NATR
     from recbole_cdr_amd.model.cross_domain_recommender.dcdcsr import DCDCSR
     from oracle import clfm as o_clfm, dtcdr as o_dtcdr, deepapf as o_apf, natr as o_natr, dcdcsr as o_dc
+    from recbole_cdr_amd.model.cross_domain_recommender.sscdr import SSCDR
+    from oracle import sscdr as o_ss
     # item-overlap pair shaped like ml-1m -> ml-100k (OU = 1, 943 + 6,040 users, ~1,600 shared / 3,883 / 1,664 items)
     ids = IdSpace(OU=1, TOU=943, SOU=6040, OI=1603, TOI=61, SOI=2280)
     rng = np.random.RandomState(0)
@@ -92,6 +94,11 @@ def main():
          False, 'TARGET', None),
         ('DCDCSR-BPR', DCDCSR, dict(latent_factor_model='BPR', embedding_size=64, mlp_hidden_size=[128], k=10, map_batch_size=1024),
          True, 'TARGET', lambda P, b, m: o_dc.rec_loss(P, ids, b, 'TARGET')),
+        # SSCDR (sscdr.py:89-195): the triplet-margin phase on squared-norm-normalised rows, and the map phase (MSE + lambda x triplet on
+        # items drawn by the in-loss numpy sampler: host work inside the loss, so that phase is timed eagerly only)
+        ('SSCDR-triplet', SSCDR, {'embedding_size': 64, 'margin': 0.2, 'mlp_hidden_size': [128], 'lambda': 0.1}, True, 'TARGET',
+         lambda P, b, m: o_ss.calculate_loss(P, ids, b, 'TARGET', 0.2, 0.1)),
+        ('SSCDR-map', SSCDR, {'embedding_size': 64, 'margin': 0.2, 'mlp_hidden_size': [128], 'lambda': 0.1}, True, 'OVERLAP', None),
     ]
     for name, cls, kw, pairwise, phase, oracle_loss in cases:
         torch.manual_seed(0)
@@ -101,6 +108,8 @@ def main():
         model.train()
         opt = DenseAdam(model.parameters(), lr=1e-3)
         b = {k: v.to(DEV) for k, v in batch(ids, B, pairwise, rng).items()}
+        if name == 'SSCDR-map':
+            b['overlap'] = torch.from_numpy(rng.choice(np.arange(1, ids.OI), 100, replace=False)).view(-1, 1).to(DEV)    # OB = 100 (default)
 
         def eager():
             opt.zero_grad(set_to_none=True)
@@ -111,13 +120,15 @@ def main():
         t_eager = timed(eager, a.steps)
         t_graph = None
         try:
+            if name == 'SSCDR-map':
+                raise RuntimeError('the numpy sampler runs on the host inside the loss (sscdr.py:94-111)')
             g = GraphedTrainStep(model, opt, b)
             t_graph = timed(lambda: g.graph.replay(), a.steps)
         except Exception as e:                                     # noqa: BLE001 -- report, do not hide
             t_graph = f'not capturable: {type(e).__name__}: {e}'
-        row = {'model': name, 'rows_per_step': 2 * B if name != 'NATR-phase2' and name != 'DCDCSR-BPR' else B,
+        row = {'model': name, 'rows_per_step': 100 if name == 'SSCDR-map' else B if name in ('NATR-phase2', 'DCDCSR-BPR', 'SSCDR-triplet') else 2 * B,
                'eager_ms': round(t_eager, 4), 'graph_ms': t_graph if isinstance(t_graph, str) else round(t_graph, 4)}
-        if not a.no_cpu:
+        if not a.no_cpu and (oracle_loss is not None or name == 'NATR-phase2'):
             P = {k: v.detach().cpu().clone().requires_grad_(v.requires_grad) for k, v in model.named_parameters()}
             bc = {k: v.cpu() for k, v in b.items()}
             if name == 'NATR-phase2':
