@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 28
+#define CDR_ABI_VERSION 29
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -180,6 +180,9 @@ int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg
 int cdr_adam_dense_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev);
 int cdr_inc_i64(void* stream, int64_t* counter);
+/* A few loss scalars combined on the device in ONE launch (cmf.py:97-99: alpha * L_s + (1 - alpha) * L_t): mode 0: out[0] = sum_i
+ * x[i * x_stride] * w[i], i < n <= 64, added in index order; mode 1 (its backward): out[i] = scale[0] * w[i].                    */
+int cdr_scalar_mix(void* stream, int mode, int n, const float* x, int64_t x_stride, const float* w, const float* scale, float* out);
 /* the same update for `count` parameter tensors in one launch (+ one launch that bumps their device step counters first):
  * host arrays of device pointers, one entry per tensor */
 int cdr_adam_multi_dev(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,

@@ -260,6 +260,22 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     }
 }
 
+// mode 0: out[0] = sum_i x[i * stride] * w[i] in index order (the weighted total of a few loss scalars); mode 1: out[i] = scale[0] * w[i]
+// (its backward): one launch each where torch needs a multiply and a reduction
+__global__ void scalar_mix_kernel(int mode, int n, const float* __restrict__ x, int64_t stride, const float* __restrict__ w,
+                                  const float* __restrict__ scale, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    if (mode == 0) {
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int i = 0; i < n; ++i) s = s + x[i * stride] * w[i];
+            out[0] = s;
+        }
+    } else if ((int)threadIdx.x < n) {
+        out[threadIdx.x] = scale[0] * w[threadIdx.x];
+    }
+}
+
 }  // namespace
 
 extern "C" int cdr_adam_dense_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
@@ -293,6 +309,13 @@ extern "C" int cdr_adam_multi_dev(void* stream, int count, float* const* params,
         adam_multi_dev_kernel<<<dim3(blocks), dim3(kBlock), 0, s>>>(a, lr, beta1, beta2, eps, weight_decay);
         CDR_LAUNCH_CHECK();
     }
+    return CDR_OK;
+}
+
+extern "C" int cdr_scalar_mix(void* stream, int mode, int n, const float* x, int64_t x_stride, const float* w, const float* scale, float* out) {
+    CDR_CHECK_ARG(n > 0 && n <= 64 && w && out && (mode == 0 ? x != nullptr : scale != nullptr));
+    scalar_mix_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(mode, n, x, x_stride, w, scale, out);
+    CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
 

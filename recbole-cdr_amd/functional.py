@@ -142,13 +142,16 @@ class TwoDomainPointLoss(Function):
         losses = out8[:, 0]
         ctx.mark_non_differentiable(losses)
         ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
-        return (losses * w).sum().reshape(1), losses
+        total = torch.empty(1, device=dev, dtype=torch.float32)
+        B_.call('cdr_scalar_mix', B_.stream(), 0, 2, B_.f32(out8), 4, B_.f32(w), None, B_.f32(total))      # (losses * w).sum(): one launch
+        return total, losses
 
     @staticmethod
     def backward(ctx, grad_out, _gl):
         user_w, item_w, su, si, tu, ti, g_s, g_t, out8, w = ctx.saved_tensors
         gU, gI = _zeros_like2(user_w, item_w)
-        go2 = (grad_out.reshape(-1)[:1].to(torch.float32) * w).contiguous()               # d total / d L_domain, on the device
+        go2 = torch.empty(2, device=user_w.device, dtype=torch.float32)                   # d total / d L_domain, on the device
+        B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(grad_out.reshape(-1)[:1].contiguous().to(torch.float32)), B_.f32(go2))
         for d, (u, i, g, reg) in enumerate(((su, si, g_s, ctx.regs[0]), (tu, ti, g_t, ctx.regs[1]))):
             B_.call('cdr_point_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), None, None, user_w.shape[1],
                     B_.i64(u), B_.i64(i), u.numel(), B_.f32(g), B_._c_ptr(out8.data_ptr() + 16 * d), reg, B_._c_ptr(go2.data_ptr() + 4 * d),
