@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 29
+#define CDR_ABI_VERSION 30
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -110,6 +110,18 @@ int cdr_point_bwd_dense(cdr_ctx* ctx, void* stream,
                         const float* gcoef, const float* out4, float reg_weight, const float* grad_out,
                         float* grad_user_tab, float* grad_item_tab,
                         float* grad_reg_user_tab, float* grad_reg_item_tab);
+/* Two pointwise batches in ONE launch each way (CMF's two domains on shared tables, cmf.py:81-99; BiTGCF's two stacks): every pointer
+ * argument is a host array of two (batch 0, batch 1) with cdr_point_fwd / cdr_point_bwd_dense's meaning, same arithmetic per batch.
+ * D % 4 == 0.  total (may be NULL): total[0] = w[0] * out4[0][0] + w[1] * out4[1][0], written by the same finishing block.      */
+int cdr_point_fwd_pair(cdr_ctx* ctx, void* stream, int loss_kind, const float* const* user_tab, const float* const* item_tab,
+                       const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
+                       const int64_t* const* iid, const float* const* label, const int64_t* B, const float* reg_weight,
+                       float* const* out4, float* const* gcoef, float* const* scores, const float* w, float* total);
+int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float* const* user_tab, const float* const* item_tab,
+                             const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
+                             const int64_t* const* iid, const int64_t* B, const float* const* gcoef, const float* const* out4,
+                             const float* reg_weight, const float* const* grad_out, float* const* grad_user_tab,
+                             float* const* grad_item_tab, float* const* grad_reg_user_tab, float* const* grad_reg_item_tab);
 
 /* ---- K1: row gather / dense scatter-add ---------------------------------------------------------------------
  * replaces nn.Embedding(idx) (emcdr.py:99-100,159-160 ; conet.py:106-109 ; sscdr.py:138-140 ...) and its dense

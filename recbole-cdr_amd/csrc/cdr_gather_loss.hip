@@ -130,8 +130,8 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_scalar_kernel(const float* __r
 }
 
 // out4 = {total, main, ||U_b||_F, ||I_b||_F}
-__global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
-                                                             float reg_weight, float* __restrict__ out4) {
+__device__ __forceinline__ void loss_finish_body(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                 float reg_weight, float* __restrict__ out4) {
     __shared__ double smem[3 * (kBlock / 64)];
     double acc[3] = {0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
@@ -145,6 +145,10 @@ __global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* __res
         out4[1] = main_loss; out4[2] = nu; out4[3] = ni;
         out4[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
     }
+}
+__global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                             float reg_weight, float* __restrict__ out4) {
+    loss_finish_body(partials, nblocks, B, reg_weight, out4);
 }
 
 // ------------------------------------------------------------------------------------------------ BPR dense backward
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_dense_scalar_kernel(const floa
 // ------------------------------------------------------------------------------------------------ pointwise forward
 // SAME: the EmbLoss tables are the dot tables (EMCDR-MF, CMF); otherwise (BiTGCF) the reg rows come from other tables.
 template <int LPR, bool SAME>
-__global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const float* __restrict__ U,
+__device__ __forceinline__ void point_fwd_body(int loss_kind, const float* __restrict__ U,
                                                            const float* __restrict__ I, const float* __restrict__ RU,
                                                            const float* __restrict__ RI, int D,
                                                            const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
@@ -307,6 +311,32 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
     }
 }
 
+template <int LPR, bool SAME>
+__global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const float* __restrict__ U, const float* __restrict__ I,
+                                                           const float* __restrict__ RU, const float* __restrict__ RI, int D,
+                                                           const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                           const float* __restrict__ label, int64_t B, float* __restrict__ gcoef,
+                                                           float* __restrict__ scores, double* __restrict__ partials) {
+    point_fwd_body<LPR, SAME>(loss_kind, U, I, RU, RI, D, uid, iid, label, B, gcoef, scores, partials);
+}
+
+// Two batches in one launch (blockIdx.y = batch; CMF's two domains on shared tables, BiTGCF's two stacks): same arithmetic per batch,
+// half the launches of a launch-bound step.  Batch d's partials live at partials + d * kPairPartials.
+struct point_pair {
+    const float* U[2]; const float* I[2]; const float* RU[2]; const float* RI[2];
+    const int64_t* uid[2]; const int64_t* iid[2]; const float* label[2]; int64_t B[2];
+    float* gcoef[2]; float* scores[2]; float* out4[2]; float reg[2];
+    const float* go[2]; float* gU[2]; float* gI[2]; float* gRU[2]; float* gRI[2];
+};
+constexpr size_t kPairPartials = (size_t)(CDR_MAX_PARTIAL_BLOCKS / 2) * CDR_PARTIAL_STRIDE;
+
+template <int LPR, bool SAME>
+__global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, point_pair a, int D, double* __restrict__ partials) {
+    const int d = blockIdx.y;
+    point_fwd_body<LPR, SAME>(loss_kind, a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.uid[d], a.iid[d], a.label[d], a.B[d], a.gcoef[d],
+                              a.scores[d], partials + d * kPairPartials);
+}
+
 __global__ __launch_bounds__(kBlock) void point_fwd_scalar_kernel(int loss_kind, const float* __restrict__ U,
                                                                   const float* __restrict__ I, const float* __restrict__ RU,
                                                                   const float* __restrict__ RI, int D,
@@ -352,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_scalar_kernel(int loss_kind,
 
 // ------------------------------------------------------------------------------------------------ pointwise dense backward
 // dU[u] += go*g*I[i] ; dI[i] += go*g*U[u] ; dRU[u] += cu*RU[u] ; dRI[i] += ci*RI[i]
-__global__ __launch_bounds__(kBlock) void point_bwd_dense_kernel(const float* __restrict__ U, const float* __restrict__ I,
+__device__ __forceinline__ void point_bwd_dense_body(const float* __restrict__ U, const float* __restrict__ I,
                                                                  const float* __restrict__ RU, const float* __restrict__ RI,
                                                                  int D, const int64_t* __restrict__ uid,
                                                                  const int64_t* __restrict__ iid, int64_t B,
@@ -378,6 +408,33 @@ __global__ __launch_bounds__(kBlock) void point_bwd_dense_kernel(const float* __
             if (gU) atomicAdd(gU + iu * D + c, du);
             if (gI) atomicAdd(gI + ii * D + c, di);
         }
+    }
+}
+__global__ __launch_bounds__(kBlock) void point_bwd_dense_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                                 const float* __restrict__ RU, const float* __restrict__ RI,
+                                                                 int D, const int64_t* __restrict__ uid,
+                                                                 const int64_t* __restrict__ iid, int64_t B,
+                                                                 const float* __restrict__ gcoef, const float* __restrict__ out4,
+                                                                 float reg_weight, const float* __restrict__ grad_out,
+                                                                 float* __restrict__ gU, float* __restrict__ gI,
+                                                                 float* __restrict__ gRU, float* __restrict__ gRI) {
+    point_bwd_dense_body(U, I, RU, RI, D, uid, iid, B, gcoef, out4, reg_weight, grad_out, gU, gI, gRU, gRI);
+}
+__global__ __launch_bounds__(kBlock) void point_bwd_dense_pair_kernel(point_pair a, int D) {
+    const int d = blockIdx.y;
+    point_bwd_dense_body(a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.uid[d], a.iid[d], a.B[d], a.gcoef[d], a.out4[d], a.reg[d], a.go[d],
+                         a.gU[d], a.gI[d], a.gRU[d], a.gRI[d]);
+}
+// both batches' losses, then (optionally) total[0] = w[0] * L_0 + w[1] * L_1: one block, the second batch after the first
+__global__ __launch_bounds__(kBlock) void loss_finish_pair_kernel(const double* __restrict__ partials, int nblocks, point_pair a,
+                                                                  const float* __restrict__ w, float* __restrict__ total) {
+    loss_finish_body(partials, nblocks, a.B[0], a.reg[0], a.out4[0]);
+    __syncthreads();
+    loss_finish_body(partials + kPairPartials, nblocks, a.B[1], a.reg[1], a.out4[1]);
+    __syncthreads();
+    if (total && threadIdx.x == 0) {
+#pragma clang fp contract(off)
+        total[0] = (0.f + a.out4[0][0] * w[0]) + a.out4[1][0] * w[1];
     }
 }
 
@@ -480,6 +537,65 @@ extern "C" int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind, const fl
     }
     CDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+// Two pointwise batches at once (see point_pair): arrays of two per argument; reg tables NULL = the dot tables.  D % 4 == 0.
+extern "C" int cdr_point_fwd_pair(cdr_ctx* ctx, void* stream, int loss_kind, const float* const* user_tab, const float* const* item_tab,
+                                  const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
+                                  const int64_t* const* iid, const float* const* label, const int64_t* B, const float* reg_weight,
+                                  float* const* out4, float* const* gcoef, float* const* scores, const float* w, float* total) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && B && reg_weight && out4 && D > 0 && (D & 3) == 0);
+    CDR_CHECK_ARG(loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE);
+    CDR_CHECK_ARG((total == nullptr) || w);
+    point_pair a{};
+    bool same = true;
+    int64_t bmax = 0;
+    for (int d = 0; d < 2; ++d) {
+        CDR_CHECK_ARG(user_tab[d] && item_tab[d] && uid[d] && iid[d] && label[d] && out4[d] && B[d] > 0);
+        a.U[d] = user_tab[d]; a.I[d] = item_tab[d];
+        a.RU[d] = (reg_user_tab && reg_user_tab[d]) ? reg_user_tab[d] : user_tab[d];
+        a.RI[d] = (reg_item_tab && reg_item_tab[d]) ? reg_item_tab[d] : item_tab[d];
+        same = same && a.RU[d] == a.U[d] && a.RI[d] == a.I[d];
+        a.uid[d] = uid[d]; a.iid[d] = iid[d]; a.label[d] = label[d]; a.B[d] = B[d];
+        a.gcoef[d] = gcoef ? gcoef[d] : nullptr; a.scores[d] = scores ? scores[d] : nullptr; a.out4[d] = out4[d]; a.reg[d] = reg_weight[d];
+        if (B[d] > bmax) bmax = B[d];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    int grid = grid_for((bmax + kUnrollPoint - 1) / kUnrollPoint, kBlock / lpr);
+    if (grid > CDR_MAX_PARTIAL_BLOCKS / 2) grid = CDR_MAX_PARTIAL_BLOCKS / 2;
+    if (same) { DISPATCH_LPR(lpr, point_fwd_pair_kernel<L, true><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(loss_kind, a, D, ctx->partials)); }
+    else { DISPATCH_LPR(lpr, point_fwd_pair_kernel<L, false><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(loss_kind, a, D, ctx->partials)); }
+    CDR_LAUNCH_CHECK();
+    loss_finish_pair_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, a, w, total);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float* const* user_tab, const float* const* item_tab,
+                                        const float* const* reg_user_tab, const float* const* reg_item_tab, int D,
+                                        const int64_t* const* uid, const int64_t* const* iid, const int64_t* B,
+                                        const float* const* gcoef, const float* const* out4, const float* reg_weight,
+                                        const float* const* grad_out, float* const* grad_user_tab, float* const* grad_item_tab,
+                                        float* const* grad_reg_user_tab, float* const* grad_reg_item_tab) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && B && gcoef && out4 && reg_weight && grad_out && grad_user_tab && grad_item_tab && D > 0);
+    point_pair a{};
+    int64_t bmax = 0;
+    for (int d = 0; d < 2; ++d) {
+        CDR_CHECK_ARG(user_tab[d] && item_tab[d] && uid[d] && iid[d] && gcoef[d] && out4[d] && B[d] > 0);
+        a.U[d] = user_tab[d]; a.I[d] = item_tab[d];
+        a.gU[d] = grad_user_tab[d]; a.gI[d] = grad_item_tab[d];
+        const float* ru = reg_user_tab ? reg_user_tab[d] : nullptr; const float* ri = reg_item_tab ? reg_item_tab[d] : nullptr;
+        if (!ru || ru == user_tab[d]) { a.RU[d] = user_tab[d]; a.gRU[d] = a.gU[d]; } else { a.RU[d] = ru; a.gRU[d] = grad_reg_user_tab ? grad_reg_user_tab[d] : nullptr; }
+        if (!ri || ri == item_tab[d]) { a.RI[d] = item_tab[d]; a.gRI[d] = a.gI[d]; } else { a.RI[d] = ri; a.gRI[d] = grad_reg_item_tab ? grad_reg_item_tab[d] : nullptr; }
+        a.uid[d] = uid[d]; a.iid[d] = iid[d]; a.B[d] = B[d]; a.gcoef[d] = const_cast<float*>(gcoef[d]); a.out4[d] = const_cast<float*>(out4[d]);
+        a.reg[d] = reg_weight[d]; a.go[d] = grad_out[d];
+        if (B[d] > bmax) bmax = B[d];
+    }
+    const int grid = grid_for(bmax, kBlock / 64);
+    point_bwd_dense_pair_kernel<<<dim3(grid, 2), dim3(kBlock), 0, (hipStream_t)stream>>>(a, D);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -128,35 +128,96 @@ class TwoDomainPointLoss(Function):
         ids = [_ids(su), _ids(si), _ids(tu), _ids(ti)]
         labels = [sl.reshape(-1).contiguous().to(torch.float32), tl.reshape(-1).contiguous().to(torch.float32)]
         out8 = torch.empty(2, 4, device=dev, dtype=torch.float32)
-        gs = []
-        for d, (u, i, y, reg) in enumerate(((ids[0], ids[1], labels[0], reg_s), (ids[2], ids[3], labels[1], reg_t))):
-            n = u.numel()
-            g = torch.empty(n, device=dev, dtype=torch.float32)
-            scores = torch.empty(n, device=dev, dtype=torch.float32)
-            B_.call('cdr_point_fwd', B_.ctx(dev), B_.stream(), int(kind), B_.f32(user_w), B_.f32(item_w), None, None, D, B_.i64(u), B_.i64(i),
-                    B_.f32(y), n, float(reg), B_._c_ptr(out8.data_ptr() + 16 * d), B_.f32(g), B_.f32(scores))
-            gs.append(g)
         w = _pair_weights(dev, float(alpha))
+        total = torch.empty(1, device=dev, dtype=torch.float32)
+        gs = [torch.empty(ids[0].numel(), device=dev, dtype=torch.float32), torch.empty(ids[2].numel(), device=dev, dtype=torch.float32)]
+        if D % 4 == 0:
+            # both batches in one gather-dot-loss launch and one finishing block that also forms alpha * L_s + (1 - alpha) * L_t
+            P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+            keep = [user_w, item_w, out8, w, total] + ids + labels + gs
+            B_.call('cdr_point_fwd_pair', B_.ctx(dev), B_.stream(), int(kind), P2(user_w.data_ptr(), user_w.data_ptr()),
+                    P2(item_w.data_ptr(), item_w.data_ptr()), None, None, D, P2(ids[0].data_ptr(), ids[2].data_ptr()),
+                    P2(ids[1].data_ptr(), ids[3].data_ptr()), P2(labels[0].data_ptr(), labels[1].data_ptr()), I2(ids[0].numel(), ids[2].numel()),
+                    F2(float(reg_s), float(reg_t)), P2(out8.data_ptr(), out8.data_ptr() + 16), P2(gs[0].data_ptr(), gs[1].data_ptr()), None,
+                    B_.f32(w), B_.f32(total))
+            del keep
+        else:
+            for d, (u, i, y, reg) in enumerate(((ids[0], ids[1], labels[0], reg_s), (ids[2], ids[3], labels[1], reg_t))):
+                B_.call('cdr_point_fwd', B_.ctx(dev), B_.stream(), int(kind), B_.f32(user_w), B_.f32(item_w), None, None, D, B_.i64(u), B_.i64(i),
+                        B_.f32(y), u.numel(), float(reg), B_._c_ptr(out8.data_ptr() + 16 * d), B_.f32(gs[d]), None)
+            B_.call('cdr_scalar_mix', B_.stream(), 0, 2, B_.f32(out8), 4, B_.f32(w), None, B_.f32(total))      # (losses * w).sum(): one launch
         ctx.save_for_backward(user_w, item_w, *ids, *gs, out8, w)
         ctx.regs = (float(reg_s), float(reg_t))
         losses = out8[:, 0]
         ctx.mark_non_differentiable(losses)
         ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
-        total = torch.empty(1, device=dev, dtype=torch.float32)
-        B_.call('cdr_scalar_mix', B_.stream(), 0, 2, B_.f32(out8), 4, B_.f32(w), None, B_.f32(total))      # (losses * w).sum(): one launch
         return total, losses
 
     @staticmethod
     def backward(ctx, grad_out, _gl):
         user_w, item_w, su, si, tu, ti, g_s, g_t, out8, w = ctx.saved_tensors
         gU, gI = _zeros_like2(user_w, item_w)
-        go2 = torch.empty(2, device=user_w.device, dtype=torch.float32)                   # d total / d L_domain, on the device
-        B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(grad_out.reshape(-1)[:1].contiguous().to(torch.float32)), B_.f32(go2))
-        for d, (u, i, g, reg) in enumerate(((su, si, g_s, ctx.regs[0]), (tu, ti, g_t, ctx.regs[1]))):
-            B_.call('cdr_point_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), None, None, user_w.shape[1],
-                    B_.i64(u), B_.i64(i), u.numel(), B_.f32(g), B_._c_ptr(out8.data_ptr() + 16 * d), reg, B_._c_ptr(go2.data_ptr() + 4 * d),
-                    B_.f32(gU), B_.f32(gI), None, None)
+        dev, D = user_w.device, user_w.shape[1]
+        go2 = torch.empty(2, device=dev, dtype=torch.float32)                   # d total / d L_domain, on the device
+        go = grad_out.reshape(-1)[:1].contiguous().to(torch.float32)
+        B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(go), B_.f32(go2))
+        if D % 4 == 0:
+            P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+            B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(user_w.data_ptr(), user_w.data_ptr()), P2(item_w.data_ptr(), item_w.data_ptr()),
+                    None, None, D, P2(su.data_ptr(), tu.data_ptr()), P2(si.data_ptr(), ti.data_ptr()), I2(su.numel(), tu.numel()),
+                    P2(g_s.data_ptr(), g_t.data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(*ctx.regs),
+                    P2(go2.data_ptr(), go2.data_ptr() + 4), P2(gU.data_ptr(), gU.data_ptr()), P2(gI.data_ptr(), gI.data_ptr()), None, None)
+        else:
+            for d, (u, i, g, reg) in enumerate(((su, si, g_s, ctx.regs[0]), (tu, ti, g_t, ctx.regs[1]))):
+                B_.call('cdr_point_bwd_dense', B_.ctx(dev), B_.stream(), B_.f32(user_w), B_.f32(item_w), None, None, D,
+                        B_.i64(u), B_.i64(i), u.numel(), B_.f32(g), B_._c_ptr(out8.data_ptr() + 16 * d), reg, B_._c_ptr(go2.data_ptr() + 4 * d),
+                        B_.f32(gU), B_.f32(gI), None, None)
         return None, gU, gI, None, None, None, None, None, None, None, None, None
+
+
+class TwoStackPointLoss(Function):
+    """Two pointwise losses, each on its own stacked [users ; items] table (BiTGCF scores the batch rows of the two propagated stacks:
+    bitgcf.py:222-240; ``item ids`` are already offset by the number of users): one gather-dot-loss launch and one finishing block
+    for both, one scatter launch into two gradient buffers out of ONE zero-fill -- half the launches of two PointGatherLoss nodes.
+    Returns (loss_s [1], loss_t [1])."""
+
+    @staticmethod
+    def forward(ctx, kind, S, T, us, is_, ls, ut, it, lt):
+        _dev_check(S, T, us, is_, ut, it)
+        dev, D = S.device, S.shape[1]
+        assert D % 4 == 0 and S.is_contiguous() and T.is_contiguous()
+        ids = [_ids(us), _ids(is_), _ids(ut), _ids(it)]
+        labels = [ls.reshape(-1).contiguous().to(torch.float32), lt.reshape(-1).contiguous().to(torch.float32)]
+        out8 = torch.empty(2, 4, device=dev, dtype=torch.float32)
+        gs = [torch.empty(ids[0].numel(), device=dev, dtype=torch.float32), torch.empty(ids[2].numel(), device=dev, dtype=torch.float32)]
+        P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+        B_.call('cdr_point_fwd_pair', B_.ctx(dev), B_.stream(), int(kind), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr(), T.data_ptr()), None, None,
+                D, P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), P2(labels[0].data_ptr(), labels[1].data_ptr()),
+                I2(ids[0].numel(), ids[2].numel()), F2(0.0, 0.0), P2(out8.data_ptr(), out8.data_ptr() + 16), P2(gs[0].data_ptr(), gs[1].data_ptr()),
+                None, None, None)
+        ctx.save_for_backward(S, T, *ids, *gs, out8)
+        ctx.set_materialize_grads(False)
+        return out8[0, :1], out8[1, :1]
+
+    @staticmethod
+    def backward(ctx, g_s, g_t):
+        S, T, us, is_, ut, it, gc_s, gc_t, out8 = ctx.saved_tensors
+        dev, D = S.device, S.shape[1]
+        gS, gT = _zeros_like2(S, T)
+        zero = None
+        gos = []
+        for g in (g_s, g_t):
+            if g is None:
+                zero = torch.zeros(1, device=dev, dtype=torch.float32) if zero is None else zero
+                g = zero
+            gos.append(g.reshape(-1)[:1].contiguous().to(torch.float32))
+        P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+        B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr(), T.data_ptr()), None, None, D,
+                P2(us.data_ptr(), ut.data_ptr()), P2(is_.data_ptr(), it.data_ptr()), I2(us.numel(), ut.numel()),
+                P2(gc_s.data_ptr(), gc_t.data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(0.0, 0.0),
+                P2(gos[0].data_ptr(), gos[1].data_ptr()), P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr(), gT.data_ptr()), None, None)
+        del gos
+        return None, gS, gT, None, None, None, None, None, None
 
 
 class GatherRows(Function):

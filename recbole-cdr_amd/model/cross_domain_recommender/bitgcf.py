@@ -118,16 +118,18 @@ class BiTGCF(CrossDomainRecommender):
                 interaction[self.TARGET_ITEM_ID]) if self.sparse_last_layer else None
         S, T, reg_s, reg_t = self._propagate(hint, emb_loss=hint is not None)
         nu = self.total_num_users
+        su, si, sl = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.SOURCE_LABEL]
+        tu, ti, tl = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], interaction[self.TARGET_LABEL]
+        # rows of the stacked [users ; items] tables (items at row nu + id): no slices, so each loss's gradient is ONE buffer of the
+        # stack's shape handed straight to the propagation's backward; both domains' losses in one launch each way when the width allows
+        if S.shape[1] % 4 == 0 and S.is_contiguous() and T.is_contiguous():
+            bce_s, bce_t = F_.TwoStackPointLoss.apply(B_.CDR_LOSS_BCE, S, T, su, si + nu, sl, tu, ti + nu, tl)
+        else:
+            bce_s, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, S, S, None, None, su, si + nu, sl, 0.0)
+            bce_t, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, T, T, None, None, tu, ti + nu, tl, 0.0)
         losses = []
-        for pre, stack, uw, iw, reg in (('SOURCE', S, self.source_user_embedding.weight, self.source_item_embedding.weight, reg_s),
-                                        ('TARGET', T, self.target_user_embedding.weight, self.target_item_embedding.weight, reg_t)):
-            user = interaction[getattr(self, f'{pre}_USER_ID')]
-            item = interaction[getattr(self, f'{pre}_ITEM_ID')]
-            label = interaction[getattr(self, f'{pre}_LABEL')]
-            # rows of the stacked [users ; items] table (items at row nu + id): no slices, so the loss's gradient is ONE buffer of
-            # the stack's shape handed straight to the propagation's backward (slicing cost two zero-fills, two copies and an add
-            # per domain and step)
-            bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, stack, stack, None, None, user, item + nu, label, 0.0)
+        for bce, uw, iw, user, item, reg in ((bce_s, self.source_user_embedding.weight, self.source_item_embedding.weight, su, si, reg_s),
+                                             (bce_t, self.target_user_embedding.weight, self.target_item_embedding.weight, tu, ti, reg_t)):
             if reg is None:
                 reg = F_.EmbLossRows.apply(uw, iw, user, item)
             losses.append(bce + self.reg_weight * reg)
