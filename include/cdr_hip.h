@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 30
+#define CDR_ABI_VERSION 31
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -120,8 +120,9 @@ int cdr_point_fwd_pair(cdr_ctx* ctx, void* stream, int loss_kind, const float* c
 int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float* const* user_tab, const float* const* item_tab,
                              const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
                              const int64_t* const* iid, const int64_t* B, const float* const* gcoef, const float* const* out4,
-                             const float* reg_weight, const float* const* grad_out, float* const* grad_user_tab,
-                             float* const* grad_item_tab, float* const* grad_reg_user_tab, float* const* grad_reg_item_tab);
+                             const float* reg_weight, const float* const* grad_out, const float* grad_scale,
+                             float* const* grad_user_tab, float* const* grad_item_tab, float* const* grad_reg_user_tab,
+                             float* const* grad_reg_item_tab);    /* grad_scale (host [2], NULL = 1): batch d's d loss = grad_out[d][0] * grad_scale[d] */
 
 /* ---- K1: row gather / dense scatter-add ---------------------------------------------------------------------
  * replaces nn.Embedding(idx) (emcdr.py:99-100,159-160 ; conet.py:106-109 ; sscdr.py:138-140 ...) and its dense

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -156,7 +156,7 @@ _SIGNATURES = {
     'cdr_adam_dense_dev': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr],
     'cdr_inc_i64': [_c_ptr, _c_ptr],
     'cdr_point_fwd_pair': [_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 10,
-    'cdr_point_bwd_dense_pair': [_c_ptr, _c_ptr] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 11,
+    'cdr_point_bwd_dense_pair': [_c_ptr, _c_ptr] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 12,
     'cdr_scalar_mix': [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32],

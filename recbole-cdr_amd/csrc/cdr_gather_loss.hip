@@ -326,7 +326,7 @@ struct point_pair {
     const float* U[2]; const float* I[2]; const float* RU[2]; const float* RI[2];
     const int64_t* uid[2]; const int64_t* iid[2]; const float* label[2]; int64_t B[2];
     float* gcoef[2]; float* scores[2]; float* out4[2]; float reg[2];
-    const float* go[2]; float* gU[2]; float* gI[2]; float* gRU[2]; float* gRI[2];
+    const float* go[2]; float* gU[2]; float* gI[2]; float* gRU[2]; float* gRI[2]; float gscale[2];
 };
 constexpr size_t kPairPartials = (size_t)(CDR_MAX_PARTIAL_BLOCKS / 2) * CDR_PARTIAL_STRIDE;
 
@@ -389,11 +389,11 @@ __device__ __forceinline__ void point_bwd_dense_body(const float* __restrict__ U
                                                                  const float* __restrict__ gcoef, const float* __restrict__ out4,
                                                                  float reg_weight, const float* __restrict__ grad_out,
                                                                  float* __restrict__ gU, float* __restrict__ gI,
-                                                                 float* __restrict__ gRU, float* __restrict__ gRI) {
+                                                                 float* __restrict__ gRU, float* __restrict__ gRI, float gscale) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int64_t TW = (int64_t)gridDim.x * (kBlock / 64);
-    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float go = (grad_out ? grad_out[0] : 1.0f) * gscale;     // gscale: the batch's weight in the caller's total (1 = none)
     const float nu = out4[2], ni = out4[3];
     const float cu = (reg_weight != 0.f && nu > 0.f) ? go * reg_weight / ((float)B * nu) : 0.f;
     const float ci = (reg_weight != 0.f && ni > 0.f) ? go * reg_weight / ((float)B * ni) : 0.f;
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(kBlock) void point_bwd_dense_kernel(const float* __
                                                                  float reg_weight, const float* __restrict__ grad_out,
                                                                  float* __restrict__ gU, float* __restrict__ gI,
                                                                  float* __restrict__ gRU, float* __restrict__ gRI) {
-    point_bwd_dense_body(U, I, RU, RI, D, uid, iid, B, gcoef, out4, reg_weight, grad_out, gU, gI, gRU, gRI);
+    point_bwd_dense_body(U, I, RU, RI, D, uid, iid, B, gcoef, out4, reg_weight, grad_out, gU, gI, gRU, gRI, 1.0f);
 }
 __global__ __launch_bounds__(kBlock) void point_bwd_dense_pair_kernel(point_pair a, int D) {
     const int d = blockIdx.y;
     point_bwd_dense_body(a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.uid[d], a.iid[d], a.B[d], a.gcoef[d], a.out4[d], a.reg[d], a.go[d],
-                         a.gU[d], a.gI[d], a.gRU[d], a.gRI[d]);
+                         a.gU[d], a.gI[d], a.gRU[d], a.gRI[d], a.gscale[d]);
 }
 // both batches' losses, then (optionally) total[0] = w[0] * L_0 + w[1] * L_1: one block, the second batch after the first
 __global__ __launch_bounds__(kBlock) void loss_finish_pair_kernel(const double* __restrict__ partials, int nblocks, point_pair a,
@@ -578,8 +578,8 @@ extern "C" int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float*
                                         const float* const* reg_user_tab, const float* const* reg_item_tab, int D,
                                         const int64_t* const* uid, const int64_t* const* iid, const int64_t* B,
                                         const float* const* gcoef, const float* const* out4, const float* reg_weight,
-                                        const float* const* grad_out, float* const* grad_user_tab, float* const* grad_item_tab,
-                                        float* const* grad_reg_user_tab, float* const* grad_reg_item_tab) {
+                                        const float* const* grad_out, const float* grad_scale, float* const* grad_user_tab,
+                                        float* const* grad_item_tab, float* const* grad_reg_user_tab, float* const* grad_reg_item_tab) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && B && gcoef && out4 && reg_weight && grad_out && grad_user_tab && grad_item_tab && D > 0);
     point_pair a{};
     int64_t bmax = 0;
@@ -591,7 +591,7 @@ extern "C" int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float*
         if (!ru || ru == user_tab[d]) { a.RU[d] = user_tab[d]; a.gRU[d] = a.gU[d]; } else { a.RU[d] = ru; a.gRU[d] = grad_reg_user_tab ? grad_reg_user_tab[d] : nullptr; }
         if (!ri || ri == item_tab[d]) { a.RI[d] = item_tab[d]; a.gRI[d] = a.gI[d]; } else { a.RI[d] = ri; a.gRI[d] = grad_reg_item_tab ? grad_reg_item_tab[d] : nullptr; }
         a.uid[d] = uid[d]; a.iid[d] = iid[d]; a.B[d] = B[d]; a.gcoef[d] = const_cast<float*>(gcoef[d]); a.out4[d] = const_cast<float*>(out4[d]);
-        a.reg[d] = reg_weight[d]; a.go[d] = grad_out[d];
+        a.reg[d] = reg_weight[d]; a.go[d] = grad_out[d]; a.gscale[d] = grad_scale ? grad_scale[d] : 1.0f;
         if (B[d] > bmax) bmax = B[d];
     }
     const int grid = grid_for(bmax, kBlock / 64);

@@ -148,6 +148,7 @@ class TwoDomainPointLoss(Function):
             B_.call('cdr_scalar_mix', B_.stream(), 0, 2, B_.f32(out8), 4, B_.f32(w), None, B_.f32(total))      # (losses * w).sum(): one launch
         ctx.save_for_backward(user_w, item_w, *ids, *gs, out8, w)
         ctx.regs = (float(reg_s), float(reg_t))
+        ctx.alpha = float(alpha)
         losses = out8[:, 0]
         ctx.mark_non_differentiable(losses)
         ctx.set_materialize_grads(False)      # no zero-filled gradient for the non-differentiable output (a launch per step)
@@ -158,16 +159,18 @@ class TwoDomainPointLoss(Function):
         user_w, item_w, su, si, tu, ti, g_s, g_t, out8, w = ctx.saved_tensors
         gU, gI = _zeros_like2(user_w, item_w)
         dev, D = user_w.device, user_w.shape[1]
-        go2 = torch.empty(2, device=dev, dtype=torch.float32)                   # d total / d L_domain, on the device
         go = grad_out.reshape(-1)[:1].contiguous().to(torch.float32)
-        B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(go), B_.f32(go2))
         if D % 4 == 0:
+            # d total / d L_domain = grad_out * weight: the scatter kernel multiplies (the weights are host floats, as in _pair_weights)
             P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
             B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(user_w.data_ptr(), user_w.data_ptr()), P2(item_w.data_ptr(), item_w.data_ptr()),
                     None, None, D, P2(su.data_ptr(), tu.data_ptr()), P2(si.data_ptr(), ti.data_ptr()), I2(su.numel(), tu.numel()),
                     P2(g_s.data_ptr(), g_t.data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(*ctx.regs),
-                    P2(go2.data_ptr(), go2.data_ptr() + 4), P2(gU.data_ptr(), gU.data_ptr()), P2(gI.data_ptr(), gI.data_ptr()), None, None)
+                    P2(go.data_ptr(), go.data_ptr()), F2(ctx.alpha, 1.0 - ctx.alpha), P2(gU.data_ptr(), gU.data_ptr()),
+                    P2(gI.data_ptr(), gI.data_ptr()), None, None)
         else:
+            go2 = torch.empty(2, device=dev, dtype=torch.float32)
+            B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(go), B_.f32(go2))
             for d, (u, i, g, reg) in enumerate(((su, si, g_s, ctx.regs[0]), (tu, ti, g_t, ctx.regs[1]))):
                 B_.call('cdr_point_bwd_dense', B_.ctx(dev), B_.stream(), B_.f32(user_w), B_.f32(item_w), None, None, D,
                         B_.i64(u), B_.i64(i), u.numel(), B_.f32(g), B_._c_ptr(out8.data_ptr() + 16 * d), reg, B_._c_ptr(go2.data_ptr() + 4 * d),
@@ -215,7 +218,7 @@ class TwoStackPointLoss(Function):
         B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr(), T.data_ptr()), None, None, D,
                 P2(us.data_ptr(), ut.data_ptr()), P2(is_.data_ptr(), it.data_ptr()), I2(us.numel(), ut.numel()),
                 P2(gc_s.data_ptr(), gc_t.data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(0.0, 0.0),
-                P2(gos[0].data_ptr(), gos[1].data_ptr()), P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr(), gT.data_ptr()), None, None)
+                P2(gos[0].data_ptr(), gos[1].data_ptr()), None, P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr(), gT.data_ptr()), None, None)
         del gos
         return None, gS, gT, None, None, None, None, None, None
 
