@@ -1076,6 +1076,56 @@ def test_bitgcf_last_layer_on_the_batch_rows_only_is_bit_identical(n_layers, con
         assert_close(a, b, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('kind', ['mse', 'bce'])
+def test_point_pair_kernels_equal_two_single_calls(kind):
+    """cdr_point_fwd_pair / cdr_point_bwd_dense_pair (two batches per launch, blockIdx.y = batch) against two cdr_point_fwd /
+    cdr_point_bwd_dense calls: losses, norms and per-row coefficients bit-equal, the weighted total = w0 L0 + w1 L1, the scattered
+    gradients equal (distinct ids per batch, so the fp32 atomics have nothing to reorder) -- different tables per batch, different
+    batch lengths, a reg weight on one of them; cdr_scalar_mix's two modes."""
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(3)
+    D, k = 24, (B_.CDR_LOSS_MSE if kind == 'mse' else B_.CDR_LOSS_BCE)
+    U = [torch.randn(300, D, device=DEV) * 0.3, torch.randn(200, D, device=DEV) * 0.3]
+    I = [torch.randn(250, D, device=DEV) * 0.3, torch.randn(220, D, device=DEV) * 0.3]
+    Bn = [190, 77]
+    uid = [torch.randperm(300, device=DEV)[:Bn[0]], torch.randperm(200, device=DEV)[:Bn[1]]]
+    iid = [torch.randperm(250, device=DEV)[:Bn[0]], torch.randperm(220, device=DEV)[:Bn[1]]]
+    y = [(torch.rand(n, device=DEV) < 0.5).float() for n in Bn]
+    reg = [0.01, 0.0]
+    f32 = lambda *sh: torch.empty(*sh, device=DEV, dtype=torch.float32)
+    out_s, g_s = [f32(4), f32(4)], [f32(Bn[0]), f32(Bn[1])]
+    for d in range(2):
+        B_.call('cdr_point_fwd', B_.ctx(DEV), B_.stream(), k, B_.f32(U[d]), B_.f32(I[d]), None, None, D, B_.i64(uid[d]), B_.i64(iid[d]), B_.f32(y[d]),
+                Bn[d], reg[d], B_.f32(out_s[d]), B_.f32(g_s[d]), None)
+    out8, g_p, total = f32(2, 4), [f32(Bn[0]), f32(Bn[1])], f32(1)
+    w = torch.tensor([0.3, 0.7], device=DEV)
+    P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+    B_.call('cdr_point_fwd_pair', B_.ctx(DEV), B_.stream(), k, P2(U[0].data_ptr(), U[1].data_ptr()), P2(I[0].data_ptr(), I[1].data_ptr()), None, None, D,
+            P2(uid[0].data_ptr(), uid[1].data_ptr()), P2(iid[0].data_ptr(), iid[1].data_ptr()), P2(y[0].data_ptr(), y[1].data_ptr()), I2(*Bn), F2(*reg),
+            P2(out8.data_ptr(), out8.data_ptr() + 16), P2(g_p[0].data_ptr(), g_p[1].data_ptr()), None, B_.f32(w), B_.f32(total))
+    for d in range(2):
+        assert torch.equal(out8[d], out_s[d]) and torch.equal(g_p[d], g_s[d]), d
+    assert float(total) == float(out8[0, 0] * w[0] + out8[1, 0] * w[1])
+    mix = f32(1)
+    B_.call('cdr_scalar_mix', B_.stream(), 0, 2, B_.f32(out8), 4, B_.f32(w), None, B_.f32(mix))
+    assert torch.equal(mix, total)
+    go = torch.tensor([1.7], device=DEV)
+    go2 = f32(2)
+    B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(go), B_.f32(go2))
+    assert torch.equal(go2, go * w)
+    gU_s, gI_s = [torch.zeros_like(t) for t in U], [torch.zeros_like(t) for t in I]
+    for d in range(2):
+        B_.call('cdr_point_bwd_dense', B_.ctx(DEV), B_.stream(), B_.f32(U[d]), B_.f32(I[d]), None, None, D, B_.i64(uid[d]), B_.i64(iid[d]), Bn[d],
+                B_.f32(g_s[d]), B_.f32(out_s[d]), reg[d], B_._c_ptr(go2.data_ptr() + 4 * d), B_.f32(gU_s[d]), B_.f32(gI_s[d]), None, None)
+    gU_p, gI_p = [torch.zeros_like(t) for t in U], [torch.zeros_like(t) for t in I]
+    B_.call('cdr_point_bwd_dense_pair', B_.ctx(DEV), B_.stream(), P2(U[0].data_ptr(), U[1].data_ptr()), P2(I[0].data_ptr(), I[1].data_ptr()), None, None, D,
+            P2(uid[0].data_ptr(), uid[1].data_ptr()), P2(iid[0].data_ptr(), iid[1].data_ptr()), I2(*Bn), P2(g_p[0].data_ptr(), g_p[1].data_ptr()),
+            P2(out8.data_ptr(), out8.data_ptr() + 16), F2(*reg), P2(go.data_ptr(), go.data_ptr()), F2(0.3, 0.7), P2(gU_p[0].data_ptr(), gU_p[1].data_ptr()),
+            P2(gI_p[0].data_ptr(), gI_p[1].data_ptr()), None, None)
+    for d in range(2):
+        assert torch.equal(gU_p[d], gU_s[d]) and torch.equal(gI_p[d], gI_s[d]), d
+
+
 def test_bitgcf_dropout_under_graph_replay_draws_a_fresh_mask_every_step():
     """a host-drawn dropout seed is baked into a captured hipGraph and every replay would repeat ONE mask.
     The seed is a device counter bumped inside the captured step: two replays on the SAME batch give different losses (different
