@@ -259,6 +259,14 @@ __global__ __launch_bounds__(kBlock) void row_flags_kernel(flag_lists fl, int64_
 __global__ __launch_bounds__(kBlock) void mul_one_plus_kernel(const float* __restrict__ g, const float* __restrict__ x, int64_t n,
                                                               float* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if (!(n & 3) && !(((uintptr_t)g | (uintptr_t)x | (uintptr_t)out) & 15)) {                        // 16-B requests
+        const int64_t n4 = n >> 2;
+        for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n4; e += stride) {
+            const float4 a = ld4(g + 4 * e), b = ld4(x + 4 * e);
+            st4(out + 4 * e, make_float4(a.x * (1.0f + b.x), a.y * (1.0f + b.y), a.z * (1.0f + b.z), a.w * (1.0f + b.w)));
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) out[e] = g[e] * (1.0f + x[e]);
 }
 
