@@ -358,7 +358,7 @@ int cdr_triplet_bwd(void* stream, const float* a, const float* p, const float* n
                     const float* dap, const float* dan, const float* grad_out, float* ga, float* gp, float* gn);
 
 /* ---- BiTGCF (bitgcf.py:130-250) --------------------------------------------------------------------------------
- * CSR adjacency (int64 indptr [n+1], int64 indices, fp32 values) of the normalised bipartite graph (symmetric).
+ * CSR adjacency (int64 indptr [n+1], int64 indices < 2^31, fp32 values) of the normalised bipartite graph (symmetric).
  *   cdr_spmm_csr_f32    out = A x E                                  (torch.sparse.mm, bitgcf.py:131)
  *   cdr_graph_layer_fwd side = A x E ; new = E + (side + E (.) side)   (bitgcf.py:130-135, dropout = identity)
  *   cdr_graph_layer_bwd gE = gnew (.) (1 + side) + A x (gnew (.) (1 + E))     (tmp: [n, D] scratch)

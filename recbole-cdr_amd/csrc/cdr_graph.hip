@@ -706,6 +706,7 @@ extern "C" int cdr_spmm_csr_f32(void* stream, const int64_t* indptr, const int64
 extern "C" int cdr_graph_layer_fwd(void* stream, const int64_t* indptr, const int64_t* indices, const float* values,
                                    int64_t n_rows, const float* E, int D, float* side_out, float* new_out, const uint8_t* row_flags) {
     CDR_CHECK_ARG(indptr && indices && values && E && side_out && new_out && n_rows > 0 && D > 0 && (D & 3) == 0);
+    CDR_CHECK_ARG(n_rows < ((int64_t)1 << 31));                 // column indices travel between lanes as 32-bit values
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
     const bool small = n_rows * (int64_t)D < ((int64_t)1 << 30);        // square adjacency: every column index < n_rows
@@ -727,6 +728,7 @@ extern "C" int cdr_graph_layer_bwd(void* stream, const int64_t* indptr, const in
                                    int64_t n_rows, const float* E, const float* side, const float* gnew, int D, float* tmp,
                                    float* gE, const uint8_t* row_flags) {
     CDR_CHECK_ARG(indptr && indices && values && E && side && gnew && (tmp || row_flags) && gE && n_rows > 0 && D > 0 && (D & 3) == 0);
+    CDR_CHECK_ARG(n_rows < ((int64_t)1 << 31));
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_cap((n_rows + kBlock / lpr - 1) / (kBlock / lpr));
     const bool small = n_rows * (int64_t)D < ((int64_t)1 << 30);
