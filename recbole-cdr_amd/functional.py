@@ -180,12 +180,13 @@ class TwoDomainPointLoss(Function):
 
 class TwoStackPointLoss(Function):
     """Two pointwise losses, each on its own stacked [users ; items] table (BiTGCF scores the batch rows of the two propagated stacks:
-    bitgcf.py:222-240; ``item ids`` are already offset by the number of users): one gather-dot-loss launch and one finishing block
+    bitgcf.py:222-240; item i is row ``nu + i`` of its stack -- the item operand is simply the stack from row ``nu`` on, so the ids go in
+    unshifted): one gather-dot-loss launch and one finishing block
     for both, one scatter launch into two gradient buffers out of ONE zero-fill -- half the launches of two PointGatherLoss nodes.
     Returns (loss_s [1], loss_t [1])."""
 
     @staticmethod
-    def forward(ctx, kind, S, T, us, is_, ls, ut, it, lt):
+    def forward(ctx, kind, S, T, nu, us, is_, ls, ut, it, lt):
         _dev_check(S, T, us, is_, ut, it)
         dev, D = S.device, S.shape[1]
         assert D % 4 == 0 and S.is_contiguous() and T.is_contiguous()
@@ -194,11 +195,13 @@ class TwoStackPointLoss(Function):
         out8 = torch.empty(2, 4, device=dev, dtype=torch.float32)
         gs = [torch.empty(ids[0].numel(), device=dev, dtype=torch.float32), torch.empty(ids[2].numel(), device=dev, dtype=torch.float32)]
         P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
-        B_.call('cdr_point_fwd_pair', B_.ctx(dev), B_.stream(), int(kind), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr(), T.data_ptr()), None, None,
+        io = 4 * int(nu) * D                                          # byte offset of the item rows inside a stack
+        B_.call('cdr_point_fwd_pair', B_.ctx(dev), B_.stream(), int(kind), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io), None, None,
                 D, P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), P2(labels[0].data_ptr(), labels[1].data_ptr()),
                 I2(ids[0].numel(), ids[2].numel()), F2(0.0, 0.0), P2(out8.data_ptr(), out8.data_ptr() + 16), P2(gs[0].data_ptr(), gs[1].data_ptr()),
                 None, None, None)
         ctx.save_for_backward(S, T, *ids, *gs, out8)
+        ctx.nu = int(nu)
         ctx.set_materialize_grads(False)
         return out8[0, :1], out8[1, :1]
 
@@ -215,12 +218,13 @@ class TwoStackPointLoss(Function):
                 g = zero
             gos.append(g.reshape(-1)[:1].contiguous().to(torch.float32))
         P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
-        B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr(), T.data_ptr()), None, None, D,
+        io = 4 * ctx.nu * D
+        B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io), None, None, D,
                 P2(us.data_ptr(), ut.data_ptr()), P2(is_.data_ptr(), it.data_ptr()), I2(us.numel(), ut.numel()),
                 P2(gc_s.data_ptr(), gc_t.data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(0.0, 0.0),
-                P2(gos[0].data_ptr(), gos[1].data_ptr()), None, P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr(), gT.data_ptr()), None, None)
+                P2(gos[0].data_ptr(), gos[1].data_ptr()), None, P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr() + io, gT.data_ptr() + io), None, None)
         del gos
-        return None, gS, gT, None, None, None, None, None, None
+        return None, gS, gT, None, None, None, None, None, None, None
 
 
 class GatherRows(Function):

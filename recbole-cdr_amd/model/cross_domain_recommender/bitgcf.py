@@ -123,7 +123,7 @@ class BiTGCF(CrossDomainRecommender):
         # rows of the stacked [users ; items] tables (items at row nu + id): no slices, so each loss's gradient is ONE buffer of the
         # stack's shape handed straight to the propagation's backward; both domains' losses in one launch each way when the width allows
         if S.shape[1] % 4 == 0 and S.is_contiguous() and T.is_contiguous():
-            bce_s, bce_t = F_.TwoStackPointLoss.apply(B_.CDR_LOSS_BCE, S, T, su, si + nu, sl, tu, ti + nu, tl)
+            bce_s, bce_t = F_.TwoStackPointLoss.apply(B_.CDR_LOSS_BCE, S, T, nu, su, si, sl, tu, ti, tl)
         else:
             bce_s, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, S, S, None, None, su, si + nu, sl, 0.0)
             bce_t, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, T, T, None, None, tu, ti + nu, tl, 0.0)
