@@ -227,6 +227,57 @@ class TwoStackPointLoss(Function):
         return None, gS, gT, None, None, None, None, None, None, None
 
 
+class TwoPointLoss(Function):
+    """Two pointwise losses on two different (user, item) table pairs in one launch each way (CLFM: each domain's factor rows against its
+    item table, clfm.py:87-113) -- PointGatherLoss twice, with half the launches.  Returns (loss_0 [1], loss_1 [1], scores_0, scores_1)."""
+
+    @staticmethod
+    def forward(ctx, kind, U0, I0, U1, I1, u0, i0, l0, u1, i1, l1):
+        _dev_check(U0, I0, U1, I1, u0, i0, u1, i1)
+        dev, D = U0.device, U0.shape[1]
+        assert D % 4 == 0 and I0.shape[1] == D and U1.shape[1] == D and I1.shape[1] == D
+        tabs = [t.contiguous() for t in (U0, I0, U1, I1)]
+        ids = [_ids(u0), _ids(i0), _ids(u1), _ids(i1)]
+        labels = [l0.reshape(-1).contiguous().to(torch.float32), l1.reshape(-1).contiguous().to(torch.float32)]
+        n0, n1 = ids[0].numel(), ids[2].numel()
+        out8 = torch.empty(2, 4, device=dev, dtype=torch.float32)
+        gs = [torch.empty(n0, device=dev, dtype=torch.float32), torch.empty(n1, device=dev, dtype=torch.float32)]
+        sc = [torch.empty(n0, device=dev, dtype=torch.float32), torch.empty(n1, device=dev, dtype=torch.float32)]
+        P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+        B_.call('cdr_point_fwd_pair', B_.ctx(dev), B_.stream(), int(kind), P2(tabs[0].data_ptr(), tabs[2].data_ptr()), P2(tabs[1].data_ptr(), tabs[3].data_ptr()),
+                None, None, D, P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()),
+                P2(labels[0].data_ptr(), labels[1].data_ptr()), I2(n0, n1), F2(0.0, 0.0), P2(out8.data_ptr(), out8.data_ptr() + 16),
+                P2(gs[0].data_ptr(), gs[1].data_ptr()), P2(sc[0].data_ptr(), sc[1].data_ptr()), None, None)
+        ctx.save_for_backward(*tabs, *ids, *gs, out8)
+        ctx.mark_non_differentiable(sc[0], sc[1])
+        ctx.set_materialize_grads(False)
+        return out8[0, :1], out8[1, :1], sc[0], sc[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1, _s0, _s1):
+        U0, I0, U1, I1, u0, i0, u1, i1, gc0, gc1, out8 = ctx.saved_tensors
+        dev, D = U0.device, U0.shape[1]
+        sizes = [t.numel() for t in (U0, I0, U1, I1)]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)            # four gradient tables, one fill
+        gt, o = [], 0
+        for t, n in zip((U0, I0, U1, I1), sizes):
+            gt.append(flat[o:o + n].view(t.shape)); o += n
+        zero = None
+        gos = []
+        for g in (g0, g1):
+            if g is None:
+                zero = torch.zeros(1, device=dev, dtype=torch.float32) if zero is None else zero
+                g = zero
+            gos.append(g.reshape(-1)[:1].contiguous().to(torch.float32))
+        P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+        B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(U0.data_ptr(), U1.data_ptr()), P2(I0.data_ptr(), I1.data_ptr()), None, None, D,
+                P2(u0.data_ptr(), u1.data_ptr()), P2(i0.data_ptr(), i1.data_ptr()), I2(u0.numel(), u1.numel()), P2(gc0.data_ptr(), gc1.data_ptr()),
+                P2(out8.data_ptr(), out8.data_ptr() + 16), F2(0.0, 0.0), P2(gos[0].data_ptr(), gos[1].data_ptr()), None,
+                P2(gt[0].data_ptr(), gt[2].data_ptr()), P2(gt[1].data_ptr(), gt[3].data_ptr()), None, None)
+        del gos
+        return None, gt[0], gt[1], gt[2], gt[3], None, None, None, None, None, None
+
+
 class GatherRows(Function):
     """nn.Embedding(idx) with its dense backward."""
 

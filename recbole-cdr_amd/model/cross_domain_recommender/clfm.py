@@ -78,14 +78,27 @@ class CLFM(CrossDomainRecommender):
         with torch.no_grad():
             return self._loss_and_prob(user, item, torch.zeros(user.numel(), device=user.device), 'target')[1]
 
+    def _rows(self, n, dev):
+        """arange(n) on the device, made once per batch length (the factor rows of a batch are addressed 0..n-1)."""
+        cache = self.__dict__.setdefault('_row_ids', {})
+        key = (n, str(dev))
+        if key not in cache:
+            cache[key] = torch.arange(n, device=dev, dtype=torch.int64)
+        return cache[key]
+
     def calculate_loss(self, interaction):
-        out = []
-        for dom, tag in (('source', 'SOURCE'), ('target', 'TARGET')):
-            user = interaction[getattr(self, f'{tag}_USER_ID')]
-            item = interaction[getattr(self, f'{tag}_ITEM_ID')]
-            label = interaction[getattr(self, f'{tag}_LABEL')]
-            bce, _ = self._loss_and_prob(user, item, label, dom)
-            out.append(bce + self.reg_weight * self._emb_loss(user, item, dom))
+        su, si, sl = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.SOURCE_LABEL]
+        tu, ti, tl = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], interaction[self.TARGET_LABEL]
+        (Us, Is), (Ut, It) = self._tables('source'), self._tables('target')
+        fs, ft = self._factors(F_.gather_rows(Us, su), 'source'), self._factors(F_.gather_rows(Ut, tu), 'target')
+        if fs.shape[1] == ft.shape[1] and fs.shape[1] % 4 == 0:
+            # both domains' gather-dot-BCE in one launch each way (functional.TwoPointLoss)
+            bce_s, bce_t, _, _ = F_.TwoPointLoss.apply(B_.CDR_LOSS_BCE, fs, Is, ft, It, self._rows(fs.shape[0], fs.device), si, sl,
+                                                       self._rows(ft.shape[0], ft.device), ti, tl)
+        else:
+            bce_s, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, fs, Is, None, None, self._rows(fs.shape[0], fs.device), si, sl, 0.0)
+            bce_t, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, ft, It, None, None, self._rows(ft.shape[0], ft.device), ti, tl, 0.0)
+        out = [bce_s + self.reg_weight * self._emb_loss(su, si, 'source'), bce_t + self.reg_weight * self._emb_loss(tu, ti, 'target')]
         return out[0] * self.alpha + out[1] * (1 - self.alpha)
 
     @torch.no_grad()
