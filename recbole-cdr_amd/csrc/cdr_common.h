@@ -118,9 +118,9 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem) {
     }
 }
 
-// Clears a few words on a stream with a KERNEL.  hipMemsetAsync is not used for this: captured into a hipGraph, the memset node was
-// not reliably ordered before the kernel nodes that followed it (cdr_row_flags: the list length it should have reset kept growing
-// from replay to replay until the list overran; eager launches were always fine).
+// Clears a few words on a stream with a KERNEL.  hipMemsetAsync is not used for this: issued inside a captured step it did not take
+// effect on replay (cdr_row_flags: the list length it should have reset kept growing from replay to replay until the list overran;
+// dropped from the capture or run out of order -- not determined; eager launches were always fine).
 static __global__ void cdr_zero_u32_kernel(uint32_t* __restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
