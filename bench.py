@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--no-fullsort', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
+    ap.add_argument('--full-last-layer', action='store_true', help='c4: evaluate every row of the last propagation layer (the reference\'s order) instead of the rows the loss gathers')
     ap.add_argument('--no-pipeline', action='store_true', default=bool(int(os.environ.get('CDR_NO_PIPELINE', '0'))),
                     help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
@@ -699,7 +700,7 @@ def run_model_workload(args, world, rank, dev):
         ds = SyntheticCrossDomainDataset(OU=15435, TOU=6607, SOU=2651, OI=1, TOI=25802, SOI=33067,
                                          n_source_inter=809248, n_target_inter=2040000)
         cfg.update(embedding_size=64, n_layers=2, reg_weight=0.001, lambda_source=0.8, lambda_target=0.8, drop_rate=0.3,
-                   connect_way='concat')
+                   connect_way='concat', bitgcf_sparse_last_layer=not args.full_last_layer)
         S, k, name = 2048, 1, 'C4: BiTGCF Douban-Book->Movie sizes (24,693 users x 58,870 items, nnz 2x%d / 2x%d), D=64, 2 layers, ' \
                              'full-graph propagation every step' % (len(ds.s_pairs), len(ds.t_pairs))
     torch.manual_seed(2022)

@@ -11,6 +11,7 @@ python bench.py > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"
 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fullsort > $O/bench_c5_200steps.json 2> /dev/null; echo "c5-200 rc=$?"
 for w in c1 c2 c3 c4; do python bench.py --workload $w --steps 200 --warmup 20 > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$?"; done
 python bench.py --workload c3 --dense-adam --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_c3_dense_adam.json 2> /dev/null; echo "c3-dense rc=$?"
+python bench.py --workload c4 --full-last-layer --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c4_full_last_layer.json 2> /dev/null; echo "c4-full rc=$?"
 python tools/sweep_small.py > $O/sweep_small.txt 2>&1; echo "sweep_small rc=$?"
 python tools/mb_kmajor.py > $O/mb_kmajor.txt 2>&1; echo "mb_kmajor rc=$?"
 python tools/mb_mapstep.py > $O/mb_mapstep.txt 2>&1; echo "mb_mapstep rc=$?"

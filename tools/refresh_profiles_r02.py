@@ -3,7 +3,7 @@ import csv, glob, json, os, shutil
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out, prof, tag = os.path.join(root, 'gpurun_out', 'r02'), os.path.join(root, 'profiles'), 'r02'
 last = lambda f: open(f).read().strip().splitlines()[-1] + '\n'
-for w in ('c1', 'c2', 'c3', 'c4', 'c5', 'c5_200steps', 'c3_dense_adam', 'c5_under_rocprof', 'c3_under_rocprof'):
+for w in ('c1', 'c2', 'c3', 'c4', 'c5', 'c5_200steps', 'c3_dense_adam', 'c4_full_last_layer', 'c5_under_rocprof', 'c3_under_rocprof'):
     f = os.path.join(out, f'bench_{w}.json')
     if os.path.exists(f):
         open(os.path.join(prof, f'{tag}_bench_{w}.json'), 'w').write(last(f))
