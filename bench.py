@@ -31,6 +31,31 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 FP32_MFMA_PEAK_TFLOPS = 157.3
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (a container that sees 256
+    CPUs but owns 8 of them oversubscribes 32x with torch.set_num_threads(os.cpu_count()))."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f2:
+                        n = min(n, max(1, -(-q // int(f2.read().split()[0]))))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -45,6 +70,7 @@ def parse():
     ap.add_argument('--dim', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fullsort', action='store_true')
+    ap.add_argument('--no-config-legs', action='store_true', help='c5, N=1: skip the compact C1-C4 legs (BASELINE configs[0..3]) behind the headline')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
     ap.add_argument('--full-last-layer', action='store_true', help='c4: evaluate every row of the last propagation layer (the reference\'s order) instead of the rows the loss gathers')
@@ -450,48 +476,96 @@ def run_c5(args, world, rank, dev):
         print('bench: relayout_overlap leg failed: %r' % (e,), file=sys.stderr)
     # ---- roofline of the dominant kernel(s): algorithmic bytes / HIP-event time of each native call --------------
     if rank == 0 and not sharded:
-        uniq = {}
-        for dom in ('source', 'target'):
-            u, p, n = batches[0][dom]
-            uniq[dom] = (int(torch.unique(u).numel()), int(torch.unique(torch.cat([p, n])).numel()))
+        med_ms = lambda k: (sorted(timings[k])[len(timings[k]) // 2]) if timings.get(k) else 0.0
+        fused = bool(getattr(steps['source'], 'fuse_singles', False))
         nmom = 6 if args.opt == 'adam' else 2
-        # per launch (one domain's batch of B triples), bytes the algorithm must move:
-        alg = {
-            'bpr_fwd_grad_kernel': B * (3 * 4 * D + 24) + B * 2 * 4 * D,
-            'rowwise_apply_kernel(users)': B * (8 + 4 * D) + uniq['source'][0] * nmom * 4 * D,
-            'rowwise_apply_kernel(items)': 2 * B * (8 + 4 * D) + uniq['source'][1] * nmom * 4 * D,
-        }
+        row_b = 4 * D
+        # occupancy statistics of one batch (outside the timed region): distinct rows, rows that occur once, their occurrences
+        u, p, n = batches[0]['source']
+        cu_ = torch.unique(u, return_counts=True)[1]
+        ci_ = torch.unique(torch.cat([p, n]), return_counts=True)[1]
+        du, di = int(cu_.numel()), int(ci_.numel())                       # distinct touched rows
+        su_, si_ = int((cu_ == 1).sum()), int((ci_ == 1).sum())            # rows with exactly one occurrence (= single occurrences)
+        both_single = int(((torch.bincount(p, minlength=n_items)[p] + torch.bincount(n, minlength=n_items)[p] == 1) &
+                           (torch.bincount(p, minlength=n_items)[n] + torch.bincount(n, minlength=n_items)[n] == 1)).sum()) if fused else 0
         kernels = []
-        for kname in ('bpr_fwd_grad_kernel', 'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)'):
-            ms = mean_ms(kname)
-            gbs = alg[kname] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            kernels.append({'kernel': kname, 'avg_ms': ms, 'algorithmic_bytes': alg[kname], 'achieved_GBps': gbs,
-                            'frac': gbs / HBM_PEAK_GBS})
-        kernels.append({'kernel': 'sort_ids (make_keys + rocprim radix sort; users and items averaged)',
-                        'avg_ms': mean_ms('sort_ids')})
-        dom_k = max(kernels[:3], key=lambda k: k['avg_ms'])
+        if fused:
+            # SURVEY 8d bytes (the figure roofline.frac is computed from): 6 x 4D per row the kernel UPDATES (its single-occurrence
+            # rows: w, m, v read and written) + 4D per row it only gathers (occurrences of duplicate rows).  design_bytes adds what
+            # this implementation moves on top: ids, flags, squared norms, and the compact gradient rows of the duplicate occurrences.
+            dup_occ = (B - su_) + (2 * B - si_)
+            alg_fa = (su_ + si_) * nmom * row_b + dup_occ * row_b
+            des_fa = alg_fa + B * (24 + 3) + (su_ + si_) * 4 + (B - su_) * row_b + (B - both_single) * row_b
+            alg_du = (B - su_) * row_b + (du - su_) * nmom * row_b          # duplicate users: one gradient row per occurrence + RMW per row
+            alg_di = (2 * B - si_) * row_b + (di - si_) * nmom * row_b
+            des_du = alg_du + (B - su_) * 8 + (du - su_) * 8
+            des_di = alg_di + (2 * B - si_) * 8 + (di - si_) * 8
+            des_fl = 3 * B * (4 + 4 + 1) + (B + B) * 4                      # keys + perm read, flag bytes written, squared norms gathered
+            for kname, alg_b, des_b in (('bpr_fwd_apply_kernel', alg_fa, des_fa), ('occ_flags_kernel', 0, des_fl),
+                                        ('rowwise_apply_kernel(users)', alg_du, des_du), ('rowwise_apply_kernel(items)', alg_di, des_di)):
+                ms = med_ms(kname)
+                kernels.append({'kernel': kname + (' [duplicate rows only]' if kname.startswith('rowwise') else ''), 'avg_ms': mean_ms(kname), 'median_ms': ms,
+                                'algorithmic_bytes': alg_b, 'design_bytes': des_b,
+                                'achieved_GBps': alg_b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, 'frac': alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                                'design_GBps': des_b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
+        else:
+            alg = {'bpr_fwd_grad_kernel': (B * 3 * row_b, B * (3 * row_b + 24) + B * 2 * row_b),
+                   'rowwise_apply_kernel(users)': (du * nmom * row_b, B * (8 + row_b) + du * nmom * row_b),
+                   'rowwise_apply_kernel(items)': (di * nmom * row_b, 2 * B * (8 + row_b) + di * nmom * row_b)}
+            for kname, (alg_b, des_b) in alg.items():
+                ms = med_ms(kname)
+                kernels.append({'kernel': kname, 'avg_ms': mean_ms(kname), 'median_ms': ms, 'algorithmic_bytes': alg_b, 'design_bytes': des_b,
+                                'achieved_GBps': alg_b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, 'frac': alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                                'design_GBps': des_b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
+        kernels.append({'kernel': 'sort_ids (make_keys + rocprim radix sort of the 3 B (id, occurrence) pairs of a domain step)',
+                        'avg_ms': mean_ms('sort_ids'), 'median_ms': med_ms('sort_ids')})
+        dom_k = max(kernels[:-1], key=lambda k: k['median_ms'])
         result['roofline'] = {'bound': 'hbm', 'kernel': dom_k['kernel'], 'achieved': dom_k['achieved_GBps'],
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_k['frac'],
-                              'avg_launch_ms': dom_k['avg_ms'], 'traffic': pmc_traffic(dom_k['kernel'])}
-        gk = kernels[0]
-        result['roofline_gather'] = {'bound': 'hbm', 'kernel': gk['kernel'], 'achieved': gk['achieved_GBps'],
-                                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gk['frac'],
-                                     'avg_launch_ms': gk['avg_ms'], 'traffic': pmc_traffic(gk['kernel'])}
+                              'avg_launch_ms': dom_k['median_ms'], 'algorithmic_bytes': dom_k['algorithmic_bytes'],
+                              'bytes_model': 'SURVEY 8d: 6 x 4D bytes per row the launch updates (w, m, v read + written) + 4D per row it only gathers; '
+                                             'avg_launch_ms = median of the HIP-event brackets of the timed region\'s launches',
+                              'design_bytes': dom_k['design_bytes'], 'design_GBps': dom_k['design_GBps'],
+                              'design_frac': dom_k['design_GBps'] / HBM_PEAK_GBS,
+                              'traffic': pmc_traffic(dom_k['kernel'].split(' ')[0])}
         result['kernels'] = kernels
-        # the STEP against SURVEY 8d's floor for a fused row-wise-Adam step: 6 x 4D bytes per touched row, three rows per triple
+        result['batch_occupancy'] = {'triples': B, 'distinct_user_rows': du, 'distinct_item_rows': di, 'single_user_rows': su_, 'single_item_rows': si_}
+        # the STEP against SURVEY 8d's floor for a fused row-wise-Adam step: 6 x 4D bytes per touched row
         dom_ms = dt / args.steps * 1e3 / 2.0
-        step_bytes = B * 3 * 6 * 4 * D
-        result['roofline_step'] = {'bound': 'hbm', 'what': 'one domain step (forward + sort + two applies) of %d triples against SURVEY 8d\'s '
+        step_bytes = B * 3 * nmom * row_b
+        distinct_bytes = (du + di) * nmom * row_b
+        result['roofline_step'] = {'bound': 'hbm', 'what': 'one domain step (sort + flags + forward/optimizer + duplicate-row applies) of %d triples against SURVEY 8d\'s '
                                    '9,216 B/triple at D=128 (6 x 4D per touched row, 3 rows per triple, no reuse counted)' % B,
                                    'achieved': step_bytes / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': step_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'ms_per_domain_step': dom_ms,
                                    'algorithmic_bytes': step_bytes,
+                                   'distinct_rows': {'algorithmic_bytes': distinct_bytes, 'achieved': distinct_bytes / (dom_ms * 1e-3) / 1e9,
+                                                     'frac': distinct_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     'what': '6 x 4D per DISTINCT touched row (%d user + %d item rows)' % (du, di)},
                                    'traffic': pmc_traffic('domain_step')}
-        # the gather under both byte models of SURVEY 8d: one triple = 3 rows + 3 ids; with per-positive reuse (2 + k) rows per k triples
-        result['roofline_gather']['byte_models'] = {
-            'per_triple_B': 3 * 4 * D + 24, 'per_positive_reuse_floor_B_at_k1': (2 + 1) * 4 * D // 1,
-            'note': 'the headline batch is k = 1 (every triple has its own positive): both models coincide up to the 24 B of ids; the k = 4 '
-                    'leg below (`per_positive_k4`) is measured against (2 + k) 4D / k = 768 B per triple'}
+        # north_star's "dual-domain embedding gather": the forward-only gather kernel on the same tables and batches (3 rows + 3 ids per
+        # triple, SURVEY 8d: 1,560 B per triple at D = 128), timed on its own after the timed region
+        try:
+            out4 = torch.zeros(4, device=dev, dtype=torch.float32)
+            B_.timing_enable(dev, 64)
+            for rep in range(6):
+                for dom, (tu, ti) in (('source', ('su', 'si')), ('target', ('tu', 'ti'))):
+                    uu, pp, nn = batches[rep % pool][dom]
+                    B_.call('cdr_bpr_fwd', B_.ctx(dev), B_.stream(), B_.f32(tabs[tu]), B_.f32(tabs[ti]), D, B_.i64(uu), B_.i64(pp), B_.i64(nn), B,
+                            1e-10, 0.01, B_.f32(out4), None)
+            torch.cuda.synchronize()
+            gat = [ms for nm, ms in B_.timing_collect(dev) if nm == 'bpr_fwd_kernel'][4:]     # in-library HIP events; first launches dropped
+            B_.timing_enable(dev, 0)
+            gms = sorted(gat)[len(gat) // 2]
+            gb = B * (3 * row_b + 24)
+            result['roofline_gather'] = {'bound': 'hbm', 'kernel': 'bpr_fwd_kernel (forward-only gather + BPR/EmbLoss sums, one domain batch)', 'achieved': gb / (gms * 1e-3) / 1e9,
+                                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_launch_ms': gms,
+                                         'algorithmic_bytes': gb, 'traffic': pmc_traffic('bpr_fwd_kernel'),
+                                         'byte_models': {'per_triple_B': 3 * row_b + 24, 'per_positive_reuse_floor_B_at_k1': 3 * row_b,
+                                                         'note': 'k = 1: both SURVEY 8d models coincide up to the 24 B of ids; the k = 4 leg (`per_positive_k4`) is '
+                                                                 'measured against (2 + k) 4D / k = 768 B per triple'}}
+        except Exception as e:  # noqa: BLE001
+            result.setdefault('leg_errors', {})['gather'] = repr(e)[:300]
 
     try:
         # ---- the per-positive (k-major) step at k = 4, and the reference-default 2,048-row batch as one hipGraph -------------
@@ -519,7 +593,10 @@ def run_c5(args, world, rank, dev):
                 kt.setdefault(nm, []).append(ms)
             B_.timing_enable(dev, 0)
             ms_t = timed(st0.step, tiled)
-            fwd_ms = sum(kt.get('bpr_fwd_kmajor_kernel', [0.0])) / max(len(kt.get('bpr_fwd_kmajor_kernel', [0.0])), 1)
+            # median of the launches after the three warm-up calls: a bracket whose first event is recorded on an idle stream also spans the
+            # host's launch latency (round 2's figure averaged those in and read 1.8x the rocprofv3 duration of the same launches)
+            fk = sorted(kt.get('bpr_fwd_kmajor_kernel', [0.0])[3:]) or [0.0]
+            fwd_ms = fk[len(fk) // 2]
             fwd_bytes = S * ((2 + k) * 4 * D + 8 * (2 + k)) + S * 4 * D + (S + B) * 8       # rows + ids read, GU rows + item records written
             result['per_positive_k4'] = {
                 'rows_per_domain_step': B, 'k': k, 'ms_per_domain_step': ms_k, 'rows_per_s': B / (ms_k * 1e-3),
@@ -530,6 +607,26 @@ def run_c5(args, world, rank, dev):
                                   'byte_model': '(2 + k) rows + (2 + k) ids read, 1 gradient row + (1 + k) 8-B records written per positive = '
                                                 '%d B per triple at k = 4' % (fwd_bytes // B)}}
             del km
+            # ---- SURVEY 8d's synthetic grid on the per-triple step: B = 65,536 uniform; B = 1,048,576 and 65,536 with Zipf(1.05) positives
+            def zipf_items(nn, lo):
+                r = torch.rand(nn, device=dev, generator=gen, dtype=torch.float64)
+                a = 1.05
+                x = ((float(TOI) ** (1 - a) - 1) * r + 1) ** (1 / (1 - a))            # inverse CDF of the continuous Zipf(1.05) over TOI ranks
+                return lo + (x.long().clamp_(1, TOI) - 1)
+            grid = {}
+            for name, nb, zipf in (('B=65536 uniform', 65536, False), ('B=1048576 zipf(1.05) positives', B, True), ('B=65536 zipf(1.05) positives', 65536, True)):
+                gs = FusedBPRStep(tabs['su'], tabs['si'], nb, opt=args.opt, reg_weight=0.01, user_state=st0.ustate, item_state=st0.istate)
+                gb_ = [(torch.randint(1, OU, (nb,), device=dev, generator=gen),
+                        zipf_items(nb, 1 + TOI) if zipf else torch.randint(1 + TOI, 1 + 2 * TOI, (nb,), device=dev, generator=gen),
+                        torch.randint(1 + TOI, 1 + 2 * TOI, (nb,), device=dev, generator=gen)) for _ in range(4)]
+                ms_g = timed(gs.step, gb_, n=40 if nb < B else 20)
+                top = int(torch.bincount(gb_[0][1] - (1 + TOI)).max()) if zipf else None
+                grid[name] = {'rows_per_domain_step': nb, 'ms_per_domain_step': ms_g, 'rows_per_s': nb / (ms_g * 1e-3),
+                              'frac_of_hbm_peak_at_9216_B_per_triple': nb * 3 * 6 * 4 * D / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if top is not None:
+                    grid[name]['occurrences_of_hottest_item'] = top
+                del gs, gb_
+            result['synthetic_grid'] = grid
             # the reference's default train_batch_size (2,048 rows, properties/overall.yaml:19): 4 launches, replayed as a hipGraph
             S2 = 2048
             sm = KMajorBPRStep(tabs['su'], tabs['si'], S2, k=1, opt=args.opt, reg_weight=0.01, user_state=st0.ustate, item_state=st0.istate)
@@ -907,13 +1004,13 @@ def cpu_baseline_model(args, ds, cfg, S, k, pair_batch=None):
         batch = ds.pairwise_batch('source', S, k, rng, 'cpu')
     else:
         batch = dict(ds.pointwise_batch('source', S, k, rng, 'cpu'), **ds.pointwise_batch('target', S, k, rng, 'cpu'))
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     best = (None, 0.0)
     def step():
         opt.zero_grad()
         loss_fn(batch).sum().backward()
         opt.step()
-    for nt in sorted({min(ncores, t) for t in (8, 16, 32, 64)}):
+    for nt in sorted({min(ncores, t) for t in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         step()
         t0 = time.perf_counter(); step(); rate = 1.0 / (time.perf_counter() - t0)
@@ -924,13 +1021,13 @@ def cpu_baseline_model(args, ds, cfg, S, k, pair_batch=None):
         torch.set_num_threads(nt)
         step()
         t0 = time.perf_counter(); n = 0
-        while time.perf_counter() - t0 < seconds and n < 100:
+        while (time.perf_counter() - t0 < seconds or n < 5) and n < 100:          # at least 5 steps whatever the time box
             step(); n += 1
         return rows * n / (time.perf_counter() - t0), n
     rate, n = measure(best[0], args.cpu_seconds)
     rate_all, n_all = measure(ncores, min(args.cpu_seconds, 5.0))
     rate_one, n_one = measure(1, min(args.cpu_seconds, 5.0))
-    return {'value': rate, 'unit': 'interactions/s', 'cores': best[0], 'host_cores': ncores, 'kind': 'port',
+    return {'value': rate, 'unit': 'interactions/s', 'cores': best[0], 'host_cores': ncores, 'os_cpu_count': os.cpu_count(), 'kind': 'port',
             'sample': '%d steps of %d rows, oracle calculate_loss + autograd + dense torch.optim.Adam, same table sizes and batch shape as the '
                       'GPU line, %d threads (best of a sweep)' % (n, rows, best[0]),
             'all_cores': {'value': rate_all, 'unit': 'interactions/s', 'cores': ncores, 'sample': '%d steps, same shape' % n_all},
@@ -942,7 +1039,7 @@ def cpu_baseline(args):
     """The oracle's row-wise step (oracle/train_step.py: same loss, same per-row gradients, lazy Adam) timed on this
     node's host cores on a bounded sample: down-scaled tables (host RAM), same D, batches of 65,536 triples."""
     from oracle import train_step as ts
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     D = args.dim
     nu, ni, B = 2_000_000, 1_000_000, 65536
     g = torch.Generator(); g.manual_seed(2022)
@@ -953,7 +1050,7 @@ def cpu_baseline(args):
     # pick the intra-op thread count that serves this step best on this host (all cores is not always the fastest
     # for gather/index_add-bound torch ops); the count used is reported as `cores`
     best = (None, 0.0)
-    for nt in sorted({min(ncores, t) for t in (8, 16, 32, 64, ncores)}):
+    for nt in sorted({min(ncores, t) for t in (4, 8, 16, 32, 64, ncores)}):
         torch.set_num_threads(nt)
         ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 1, opt=args.opt)
         t0 = time.perf_counter()
@@ -968,7 +1065,7 @@ def cpu_baseline(args):
         torch.set_num_threads(nt)
         ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 3, opt=args.opt)
         t0 = time.perf_counter(); n = 0
-        while time.perf_counter() - t0 < seconds and n < 200:
+        while (time.perf_counter() - t0 < seconds or n < 5) and n < 200:          # at least 5 steps whatever the time box
             ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), n + 4, opt=args.opt)
             n += 1
         return B * n / (time.perf_counter() - t0), n
@@ -984,7 +1081,7 @@ def cpu_baseline(args):
         pass
     sample = ('EMCDR-BPR D=%d, oracle row-wise step (fwd+bwd+lazy %s), batches of %d triples on down-scaled tables %d users x %d items '
               '(host RAM)' % (D, args.opt, B, nu, ni))
-    return {'value': rate, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'kind': 'port', 'cpu_model': model,
+    return {'value': rate, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'os_cpu_count': os.cpu_count(), 'kind': 'port', 'cpu_model': model,
             'sample': '%d steps, %s, torch %d threads (best of a sweep)' % (steps, sample, used),
             'all_cores': {'value': rate_all, 'unit': 'interactions/s', 'cores': ncores, 'sample': '%d steps, same shape' % n_all},
             'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one}}
@@ -1023,6 +1120,35 @@ def main():
         result['layouts'] = {first: pick(result), second: pick(other)}
     elif args.workload == 'c5':
         result = run_c5(args, world, rank, dev)
+        if world == 1 and not args.no_config_legs:
+            # BASELINE configs[0..3] behind the headline, compact: so that ONE default invocation covers all five configurations.
+            # Each leg is the full `--workload cN` measurement at 200 steps (they take 0.03-1 ms each) with a 3-second CPU sample.
+            import copy
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            legs = {}
+            for wl, extra in (('c1', {}), ('c2', {}), ('c3', {}), ('c4', {'full_last_layer': True}), ('c4', {})):
+                a = copy.copy(args)
+                a.workload, a.steps, a.warmup, a.cpu_seconds = wl, 200, 20, 3.0
+                for k_, v_ in extra.items():
+                    setattr(a, k_, v_)
+                if wl == 'c4' and not extra:
+                    a.no_cpu_baseline = True                 # same CPU formulation as the full-last-layer leg: measured once
+                name = wl if not (wl == 'c4' and extra) else 'c4_full_last_layer'
+                try:
+                    r = run_model_workload(a, world, rank, dev)
+                    legs[name] = {k_: r.get(k_) for k_ in ('value', 'unit', 'ms_per_step', 'steps', 'roofline', 'kernels', 'cpu_baseline', 'final_loss')
+                                  if r.get(k_) is not None}
+                    legs[name]['workload'] = r['config']['workload']
+                    legs[name]['rows_per_step'] = r['config']['rows_per_step']
+                    cb = legs[name].get('cpu_baseline')
+                    if cb:
+                        legs[name]['vs_cpu'] = r['value'] / cb['value'] if cb.get('value') else None
+                except Exception as e:  # noqa: BLE001
+                    result.setdefault('leg_errors', {})['config_' + name] = repr(e)[:500]
+                    print('bench: config leg %s failed: %r' % (name, e), file=sys.stderr)
+                gc.collect(); torch.cuda.empty_cache()
+            result['configs'] = legs
     else:
         result = run_model_workload(args, world, rank, dev)
     if rank == 0:

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -67,6 +67,11 @@ _SIGNATURES = {
     'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_f32, _c_ptr,
                          _c_ptr, _c_ptr, _c_int],
     'cdr_loss_finish_sums': [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr],
+    'cdr_row_sqnorms': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr],
+    'cdr_bpr_step_fused_heads_words': [_c_i64, ctypes.POINTER(_c_i64)],
+    'cdr_bpr_step_fused': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int,
+                           _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_i64,
+                           _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_timing_enable': [_c_ptr, _c_int],
     'cdr_timing_collect': [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_f32), _c_int, ctypes.POINTER(_c_int)],
@@ -297,7 +302,8 @@ TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4:
         5: 'rowwise_apply_kernel(items)', 6: 'sort_ids', 7: 'point_fwd_grad_kernel',
         8: 'bpr_partial_diff_kernel', 9: 'bpr_grad_from_diff_kernel',
         10: 'point_partial_dot_kernel', 11: 'point_grad_from_dot_kernel',
-        12: 'conet_fwd_kernel', 13: 'conet_bwd_kernel', 14: 'conet_wgrad_kernel', 15: 'bpr_fwd_kmajor_kernel', 16: 'map_step_kernel'}
+        12: 'conet_fwd_kernel', 13: 'conet_bwd_kernel', 14: 'conet_wgrad_kernel', 15: 'bpr_fwd_kmajor_kernel', 16: 'map_step_kernel',
+        17: 'occ_flags_kernel', 18: 'bpr_fwd_apply_kernel'}
 
 
 _timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device

@@ -13,6 +13,7 @@
 // would compute for the touched rows.  Rows not in the batch are not touched (for Adam this is the usual lazy/sparse
 // variant: untouched rows keep their moments and do not move) -- documented in DESIGN.md as the one deliberate
 // difference from the reference's dense torch.optim.Adam, which is O(table) per step.
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -427,6 +428,411 @@ __global__ __launch_bounds__(kBlock) void make_keys2_kernel(const int64_t* __res
     }
 }
 
+
+// ================================================================================================ single-occurrence rows in the forward
+// Round 3.  At C5 a batch of 1 M triples names ~0.98 M users that occur ONCE and ~1.6 M of its 2 M item occurrences are the only
+// occurrence of their row.  For such a row the "segment sum" is one gradient row that the forward kernel has in registers, so the
+// forward kernel applies the optimizer itself: it reads the row's two moments next to the row, writes all three back, and the
+// compact gradient row (GU[b] / GP[b]) is neither written nor read again, nor is the row re-read by an apply kernel:
+//
+//   cdr_sort_ids_two_tables   as before, but FIRST (it needs only the ids)
+//   occ_flags_kernel          one pass over the sorted keys: flags[occurrence] = "only occurrence of its row", the heads of the
+//                             remaining (duplicate) segments compacted into two lists, and the EmbLoss norms of the batch
+//                             summed from the per-row squared norms that every writer of a table keeps up to date (N2)
+//   bpr_fwd_apply_kernel      gather 3 rows (+ 2 moments per single row) -> loss -> single rows: optimizer in place;
+//                             duplicate rows: GU[b] / GP[b] as before
+//   rowwise_apply_dups_kernel the segmented apply over the duplicate segments only (same sums, same order as rowwise_apply_kernel)
+//
+// Same arithmetic per row as cdr_bpr_fwd_grad + cdr_rowwise_apply (one occurrence: 0 + g, then the same update), fixed order
+// everywhere: bit-reproducible.  Bytes per triple at D = 128, uniform ids: ~9.5 KB against 12.9 KB before (SURVEY 8d floor 9.2 KB).
+struct tab_ptrs { float* W; float* M; float* V; float* N2; };
+
+template <int OPT>
+__device__ __forceinline__ float4 upd_math(float4 w, float4& m, float4& v, float4 acc, float rc, const apply_hp& h) {
+    float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
+    if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
+    if (OPT == 0) return make_float4(w.x - h.lr * gr.x, w.y - h.lr * gr.y, w.z - h.lr * gr.z, w.w - h.lr * gr.w);
+    m.x += (gr.x - m.x) * (1.0f - h.b1); m.y += (gr.y - m.y) * (1.0f - h.b1);
+    m.z += (gr.z - m.z) * (1.0f - h.b1); m.w += (gr.w - m.w) * (1.0f - h.b1);
+    v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
+    v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
+#ifdef CDR_FAST_ADAM   /* experiment switch (tools/): hardware 1-ulp rcp / sqrt instead of the IEEE sequences */
+    const float ib = __builtin_amdgcn_rcpf(h.bc2_sqrt);
+#define CDR_UPDQ(W, M, V) (W - h.step_size * (M * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(V) * ib + h.eps)))
+    return make_float4(CDR_UPDQ(w.x, m.x, v.x), CDR_UPDQ(w.y, m.y, v.y), CDR_UPDQ(w.z, m.z, v.z), CDR_UPDQ(w.w, m.w, v.w));
+#undef CDR_UPDQ
+#else
+    return make_float4(w.x - h.step_size * (m.x / (sqrtf(v.x) / h.bc2_sqrt + h.eps)),
+                       w.y - h.step_size * (m.y / (sqrtf(v.y) / h.bc2_sqrt + h.eps)),
+                       w.z - h.step_size * (m.z / (sqrtf(v.z) / h.bc2_sqrt + h.eps)),
+                       w.w - h.step_size * (m.w / (sqrtf(v.w) / h.bc2_sqrt + h.eps)));
+#endif
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void row_sqnorm_kernel(const float* __restrict__ W, int64_t rows, int D, float* __restrict__ out) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int D4 = D >> 2;
+    for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += (int64_t)gridDim.x * GPB) {
+        float acc = 0.f;
+        for (int ch = sub; ch < D4; ch += LPR) { const float4 w = ld4(W + r * D + 4 * ch); acc += dot4(w, w); }
+        acc = group_sum<LPR>(acc);
+        if (sub == 0) out[r] = acc;
+    }
+}
+
+// keys / perm: the two-table sort's output (section A = positions [0, nA): user keys; section B = [nA, n): item keys + key_base).
+// flags[o] for A occurrences o in [0, nA), flags[nA + o] for B occurrences.  cnt[0] / cnt[1]: lengths of headsA / headsB (sorted
+// positions, relative to their section, of the first occurrence of every row that occurs more than once; list order is
+// irrelevant -- every segment is summed in occurrence order by whoever takes it).  partials: block sums of the batch rows'
+// squared norms (A: every occurrence; B: occurrences o < reg_limit_b, the positives).
+// A thread takes kFlagIT consecutive positions and a block reserves its share of each list with ONE atomic: with an atomic per
+// 256 positions the 24 k same-address atomics of a 3 M-position launch were most of its 0.157 ms.
+constexpr int kFlagIT = 8;
+__global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                                           int64_t nA, int64_t n, int64_t reg_limit_b, uint32_t key_base,
+                                                           const float* __restrict__ An2, const float* __restrict__ Bn2,
+                                                           uint8_t* __restrict__ flags, uint32_t* __restrict__ headsA,
+                                                           uint32_t* __restrict__ headsB, unsigned* __restrict__ cnt,
+                                                           double* __restrict__ partials) {
+    constexpr int NW = kBlock / 64;
+    __shared__ double smem[2 * NW];
+    __shared__ unsigned wcnt[2][NW], wbase[2][NW];
+    double acc[2] = {0.0, 0.0};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * kFlagIT; base < n; base += (int64_t)gridDim.x * kBlock * kFlagIT) {
+        const int64_t q0 = base + (int64_t)threadIdx.x * kFlagIT;
+        uint32_t k[kFlagIT + 2], o[kFlagIT];
+#pragma unroll
+        for (int j = 0; j < kFlagIT + 2; ++j) {
+            const int64_t q = q0 - 1 + j;
+            k[j] = (q >= 0 && q < n) ? keys[q] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kFlagIT; ++j) o[j] = q0 + j < n ? perm[q0 + j] : 0u;
+        float nv[kFlagIT];
+        unsigned hA = 0, hB = 0;                           // bit j: position q0 + j heads a duplicate segment
+#pragma unroll
+        for (int j = 0; j < kFlagIT; ++j) {
+            const int64_t q = q0 + j;
+            nv[j] = 0.f;
+            if (q < n) {
+                const uint32_t row = k[j + 1];
+                const bool first = q == 0 || k[j] != row, last = q + 1 >= n || k[j + 2] != row;
+                if (q < nA) {
+                    flags[o[j]] = (uint8_t)(first && last);
+                    if (An2) nv[j] = An2[row];
+                    hA |= (unsigned)(first && !last) << j;
+                } else {
+                    flags[nA + o[j]] = (uint8_t)(first && last);
+                    if (Bn2 && (int64_t)o[j] < reg_limit_b) nv[j] = Bn2[row - key_base];
+                    hB |= (unsigned)(first && !last) << j;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kFlagIT; ++j) { if (q0 + j < nA) acc[0] += (double)nv[j]; else acc[1] += (double)nv[j]; }
+        // exclusive prefix of the per-thread head counts: inside the wave by shuffles, across waves through LDS, one atomic per list
+        unsigned cA = (unsigned)__popc(hA), cB = (unsigned)__popc(hB), pA = cA, pB = cB;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned a = __shfl_up(pA, d, 64), b = __shfl_up(pB, d, 64);
+            if (lane >= d) { pA += a; pB += b; }
+        }
+        if (lane == 63) { wcnt[0][wave] = pA; wcnt[1][wave] = pB; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int t = threadIdx.x;
+            unsigned tot = 0;
+            for (int w = 0; w < NW; ++w) { wbase[t][w] = tot; tot += wcnt[t][w]; }
+            const unsigned b = tot ? atomicAdd(&cnt[t], tot) : 0u;
+            for (int w = 0; w < NW; ++w) wbase[t][w] += b;
+        }
+        __syncthreads();
+        unsigned sA = wbase[0][wave] + pA - cA, sB = wbase[1][wave] + pB - cB;
+#pragma unroll
+        for (int j = 0; j < kFlagIT; ++j) {
+            if ((hA >> j) & 1u) headsA[sA++] = (uint32_t)(q0 + j);
+            if ((hB >> j) & 1u) headsB[sB++] = (uint32_t)(q0 + j - nA);
+        }
+        __syncthreads();
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+// out9[4], out9[5] = reg_weight / (B * ||rows||) from the cached squared norms (0 when there is no EmbLoss or the norm is 0)
+__global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                             float reg_weight, float* __restrict__ out9) {
+    __shared__ double smem[2 * (kBlock / 64)];
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1];
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float nu = (float)sqrt(acc[0]), ni = (float)sqrt(acc[1]);
+        out9[4] = (reg_weight != 0.f && nu > 0.f) ? reg_weight / ((float)B * nu) : 0.f;
+        out9[5] = (reg_weight != 0.f && ni > 0.f) ? reg_weight / ((float)B * ni) : 0.f;
+    }
+}
+
+// loss scalars of the fused step: as step_finish_kernel, but out9[4..5] (the EmbLoss coefficients the kernels used) stay
+__global__ __launch_bounds__(kBlock) void step_finish_keep_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                                  float reg_weight, float* __restrict__ out9) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float main_loss = (float)(acc[0] / (double)B);
+        const float nu = (float)sqrt(acc[1]), ni = (float)sqrt(acc[2]);
+        out9[1] = main_loss; out9[2] = nu; out9[3] = ni;
+        out9[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
+        out9[6] = (float)acc[0]; out9[7] = (float)acc[1]; out9[8] = (float)acc[2];
+    }
+}
+
+template <int LPR, int OPT, int UN>
+__global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
+                                                               const int64_t* __restrict__ pid, const int64_t* __restrict__ nid,
+                                                               const uint8_t* __restrict__ flags, int64_t B, float gamma, float invB,
+                                                               const float* __restrict__ coef, apply_hp hu, apply_hp hi,
+                                                               float* __restrict__ GU, float* __restrict__ GP,
+                                                               double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const bool live = sub < D4;
+    const float cu = coef[0], ci = coef[1];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    double acc[3] = {0.0, 0.0, 0.0};
+
+    // ids + flags of the NEXT iteration are requested right behind this iteration's row loads, i.e. BEFORE its stores: vmcnt
+    // retires in order, so a wait for ids that were issued after the stores would also wait for every store's acknowledgement
+    int64_t iu[UN], ip[UN], in[UN];
+    uint8_t fu8[UN], fp8[UN], fn8[UN];
+#pragma unroll
+    for (int r = 0; r < UN; ++r) {
+        const int64_t t = gg + (int64_t)r * TG;
+        const int64_t tc = t < B ? t : B - 1;
+        iu[r] = uid[tc]; ip[r] = pid[tc]; in[r] = nid[tc];
+        fu8[r] = flags[tc]; fp8[r] = flags[B + tc]; fn8[r] = flags[2 * B + tc];
+    }
+    for (int64_t base = gg; base < B; base += TG * UN) {
+        float4 u[UN], p[UN], n[UN], um[UN], uv[UN], pm[UN], pv[UN], nm[UN], nv[UN];
+        int64_t ou[UN], op[UN], on[UN];
+        bool fu[UN], fp[UN], fn[UN];
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const bool ok = t < B && live;
+            fu[r] = fu8[r] != 0 && t < B; fp[r] = fp8[r] != 0 && t < B; fn[r] = fn8[r] != 0 && t < B;
+            ou[r] = iu[r] * D + 4 * sub; op[r] = ip[r] * D + 4 * sub; on[r] = in[r] * D + 4 * sub;
+            u[r] = ok ? ld4(TU.W + ou[r]) : z4;
+            p[r] = ok ? ld4(TI.W + op[r]) : z4;
+            n[r] = ok ? ld4(TI.W + on[r]) : z4;
+            um[r] = uv[r] = pm[r] = pv[r] = nm[r] = nv[r] = z4;
+            if (OPT == 1) {
+                if (ok && fu[r]) { um[r] = ld4(TU.M + ou[r]); uv[r] = ld4(TU.V + ou[r]); }
+                if (ok && fp[r]) { pm[r] = ld4(TI.M + op[r]); pv[r] = ld4(TI.V + op[r]); }
+                if (ok && fn[r]) { nm[r] = ld4(TI.M + on[r]); nv[r] = ld4(TI.V + on[r]); }
+            }
+        }
+        int64_t ju[UN], jp[UN], jn[UN];
+        uint8_t gu8[UN], gp8[UN], gn8[UN];
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int64_t t = base + (int64_t)(UN + r) * TG;
+            const int64_t tc = t < B ? t : B - 1;
+            ju[r] = uid[tc]; jp[r] = pid[tc]; jn[r] = nid[tc];
+            gu8[r] = flags[tc]; gp8[r] = flags[B + tc]; gn8[r] = flags[2 * B + tc];
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // keep the requests above the arithmetic (the scheduler sinks them otherwise)
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const float dp = group_sum<LPR>(dot4(u[r], p[r]));
+            const float dn = group_sum<LPR>(dot4(u[r], n[r]));
+            const float su = group_sum<LPR>(dot4(u[r], u[r]));
+            const float sp = group_sum<LPR>(dot4(p[r], p[r]));
+            const float s = sigmoidf_(dp - dn);
+            const float g = -invB * (s * (1.0f - s)) / (gamma + s);
+            const float4 gu = make_float4(g * (p[r].x - n[r].x), g * (p[r].y - n[r].y), g * (p[r].z - n[r].z), g * (p[r].w - n[r].w));
+            const float4 gi = make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w);
+            const bool ok = t < B && live;
+            // ---- user row
+            float4 wu = z4, wp = z4, wn = z4;
+            if (fu[r]) {
+                wu = upd_math<OPT>(u[r], um[r], uv[r], gu, cu, hu);
+                if (live) { if (OPT == 1) { st4(TU.M + ou[r], um[r]); st4(TU.V + ou[r], uv[r]); } st4(TU.W + ou[r], wu); }
+            } else if (ok) st4(GU + t * D + 4 * sub, gu);
+            // ---- positive item row (EmbLoss occurrence), negative item row (gradient -g u, no EmbLoss)
+            if (fp[r]) {
+                wp = upd_math<OPT>(p[r], pm[r], pv[r], gi, ci, hi);
+                if (live) { if (OPT == 1) { st4(TI.M + op[r], pm[r]); st4(TI.V + op[r], pv[r]); } st4(TI.W + op[r], wp); }
+            }
+            if (fn[r]) {
+                wn = upd_math<OPT>(n[r], nm[r], nv[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w), 0.f, hi);
+                if (live) { if (OPT == 1) { st4(TI.M + on[r], nm[r]); st4(TI.V + on[r], nv[r]); } st4(TI.W + on[r], wn); }
+            }
+            if (ok && !(fp[r] && fn[r])) st4(GP + t * D + 4 * sub, gi);
+            // ---- the updated rows' squared norms (every lane takes part in the reductions; only single rows are stored)
+            if (TU.N2) {
+                const float q0 = group_sum<LPR>(dot4(wu, wu)), q1 = group_sum<LPR>(dot4(wp, wp)), q2 = group_sum<LPR>(dot4(wn, wn));
+                if (sub == 0) {
+                    if (fu[r]) TU.N2[iu[r]] = q0;
+                    if (fp[r]) TI.N2[ip[r]] = q1;
+                    if (fn[r]) TI.N2[in[r]] = q2;
+                }
+            }
+            if (t < B && sub == 0) {
+                acc[0] += (double)(-logf(gamma + s));
+                acc[1] += (double)su;
+                acc[2] += (double)sp;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            iu[r] = ju[r]; ip[r] = jp[r]; in[r] = jn[r];
+            fu8[r] = gu8[r]; fp8[r] = gp8[r]; fn8[r] = gn8[r];
+        }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+// The segmented apply over the DUPLICATE segments only: heads[0 .. *nheads) are the sorted positions of their first occurrences
+// (any order: every segment is summed by one lane group in occurrence order, whoever takes it).  Long segments as in
+// rowwise_apply_kernel; every updated row's squared norm goes to N2 (optional).
+template <int LPR, int OPT, bool SIGNED>
+__global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                                    float* __restrict__ N2, int D, const uint32_t* __restrict__ keys,
+                                                                    const uint32_t* __restrict__ perm, int64_t n,
+                                                                    const uint32_t* __restrict__ heads, const unsigned* __restrict__ nheads,
+                                                                    const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
+                                                                    const float* __restrict__ reg_coef, apply_hp hp,
+                                                                    unsigned* __restrict__ counters, seg_long* __restrict__ longs,
+                                                                    seg_piece* __restrict__ pieces) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float c = reg_coef ? reg_coef[0] : 0.f;
+    const int64_t nh = (int64_t)nheads[0];
+    for (int64_t h = gg; h < nh; h += TG) {
+        const int64_t q = heads[h];
+        const uint32_t row = keys[q];
+        const bool is_long = q + kLongSeg < n && keys[q + kLongSeg] == row;
+        if (is_long) continue;
+        float nn = 0.f;
+        for (int ch = sub; ch < D4; ch += LPR) {
+            const int64_t off = (int64_t)row * D + 4 * ch;
+            const float4 w = ld4(W + off);
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
+            if (OPT == 1) { m = ld4(Mo + off); v = ld4(Vo + off); }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cnt = 0;
+            for (int64_t e = q; e < n && keys[e] == row; ++e) {
+                const int64_t o = perm[e];
+                const bool neg = SIGNED && o >= neg_start;
+                const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
+                if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
+                else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
+                cnt += (o < reg_limit) ? 1 : 0;
+            }
+            const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
+            if (OPT == 1) { st4(Mo + off, m); st4(Vo + off, v); }
+            st4(W + off, wn);
+            nn += dot4(wn, wn);
+        }
+        if (N2) {
+            nn = group_sum<LPR>(nn);
+            if (sub == 0) N2[row] = nn;
+        }
+    }
+    if (counters == nullptr) return;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q + kLongSeg < n; q += (int64_t)gridDim.x * kBlock) {
+        const uint32_t row = keys[q];
+        const uint32_t before = keys[q > 0 ? q - 1 : 0];
+        const uint32_t far = keys[q + kLongSeg];
+        if ((q > 0 && before == row) || far != row) continue;
+        int64_t lo = q + kLongSeg, hi = n;
+        while (lo + 1 < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] == row) lo = mid; else hi = mid;
+        }
+        const int64_t len = hi - q;
+        const unsigned np = (unsigned)((len + kPiece - 1) / kPiece);
+        const unsigned base = atomicAdd(&counters[0], np);
+        const unsigned li = atomicAdd(&counters[1], 1u);
+        longs[li] = seg_long{q, len, (int64_t)base};
+        for (unsigned k = 0; k < np; ++k) {
+            const int64_t st = q + (int64_t)k * kPiece;
+            pieces[base + k] = seg_piece{st, (hi - st) < kPiece ? (hi - st) : (int64_t)kPiece};
+        }
+    }
+}
+
+// seg_long_finish_kernel + the updated row's squared norm
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void seg_long_finish_n2_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                                    float* __restrict__ N2, int D, const uint32_t* __restrict__ keys,
+                                                                    const float* __restrict__ reg_coef, apply_hp hp,
+                                                                    const unsigned* __restrict__ counters,
+                                                                    const seg_long* __restrict__ longs,
+                                                                    const float* __restrict__ partial, const int* __restrict__ pcnt) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float c = reg_coef ? reg_coef[0] : 0.f;
+    const int64_t nl = counters[1];
+    for (int64_t li = gg; li < nl; li += TG) {
+        const seg_long sg = longs[li];
+        const uint32_t row = keys[sg.head];
+        const int64_t np = (sg.len + kPiece - 1) / kPiece;
+        float nn = 0.f;
+        for (int ch = sub; ch < D4; ch += LPR) {
+            const int64_t off = (int64_t)row * D + 4 * ch;
+            const float4 w = ld4(W + off);
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
+            if (OPT == 1) { m = ld4(Mo + off); v = ld4(Vo + off); }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cnt = 0;
+            for (int64_t k = 0; k < np; ++k) {
+                const float4 g = ld4(partial + (sg.base + k) * D + 4 * ch);
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+                cnt += pcnt[sg.base + k];
+            }
+            const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
+            if (OPT == 1) { st4(Mo + off, m); st4(Vo + off, v); }
+            st4(W + off, wn);
+            nn += dot4(wn, wn);
+        }
+        if (N2) {
+            nn = group_sum<LPR>(nn);
+            if (sub == 0) N2[row] = nn;
+        }
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_LPR(lpr, ...)                                  \
@@ -637,4 +1043,139 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
         CDR_LAUNCH_CHECK();
     }
     return CDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the fused step (round 3)
+extern "C" int cdr_row_sqnorms(void* stream, const float* table, int64_t rows, int D, float* out) {
+    CDR_CHECK_ARG(table && out && rows > 0 && D > 0 && (D & 3) == 0);
+    const int lpr = cdr_lpr_for(D);
+    const int grid = grid_for(rows, kBlock / lpr);
+    DISPATCH_LPR(lpr, row_sqnorm_kernel<L><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(table, rows, D, out));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+namespace {
+
+static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float* exp_avg, float* exp_avg_sq, float* n2, int D,
+                      const uint32_t* keys, const uint32_t* perm, int64_t n, const uint32_t* heads, const unsigned* nheads,
+                      const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef, const apply_hp& hp,
+                      uint32_t key_base, int tag) {
+    if (key_base) {
+        table -= (int64_t)key_base * D;
+        if (exp_avg) exp_avg -= (int64_t)key_base * D;
+        if (exp_avg_sq) exp_avg_sq -= (int64_t)key_base * D;
+        if (n2) n2 -= (int64_t)key_base;
+    }
+    const int lpr = cdr_lpr_for(D);
+    const bool is_signed = neg_start < n;
+    const bool may_have_long = n > kLongSeg;
+    unsigned* counters = nullptr; seg_long* longs = nullptr; seg_piece* pieces = nullptr; int* pcnt = nullptr; float* partial = nullptr;
+    int64_t long_cap = 0, piece_cap = 0;
+    if (may_have_long) {
+        long_cap = n / (kLongSeg + 1) + 1;
+        piece_cap = n / kPiece + long_cap + 1;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_long = 256, o_piece = o_long + up(sizeof(seg_long) * long_cap), o_cnt = o_piece + up(sizeof(seg_piece) * piece_cap),
+                     o_part = o_cnt + up(sizeof(int) * piece_cap), total = o_part + sizeof(float) * (size_t)piece_cap * D;
+        void* base = nullptr;
+        int rc = cdr_ctx_scratch(ctx, total, &base);
+        if (rc != CDR_OK) return rc;
+        counters = (unsigned*)base; longs = (seg_long*)((char*)base + o_long); pieces = (seg_piece*)((char*)base + o_piece);
+        pcnt = (int*)((char*)base + o_cnt); partial = (float*)((char*)base + o_part);
+        CDR_HIP(cdr_zero_u32(counters, 4, s));
+    }
+    // the duplicate segments are a fraction of the list (uniform ids: ~1 % of the users, ~10 % of the item rows): a grid for half of
+    // the worst case, the loop covers the rest
+    const int grid = grid_for(n / 4 + 1, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, tag, s);
+#define DUP_ARGS table, exp_avg, exp_avg_sq, n2, D, keys, perm, n, heads, nheads, G, neg_start, reg_limit, reg_coef, hp, counters, longs, pieces
+        if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
+        else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
+        else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
+        else { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
+#undef DUP_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    if (may_have_long) {
+        const int gp = grid_for(piece_cap < 16384 ? piece_cap : 16384, kBlock / lpr);
+        if (is_signed) { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, true><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, nullptr, counters, pieces, partial, pcnt)); }
+        else { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, false><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, nullptr, counters, pieces, partial, pcnt)); }
+        CDR_LAUNCH_CHECK();
+        const int gl = grid_for(long_cap < 4096 ? long_cap : 4096, kBlock / lpr);
+        if (opt == 0) { DISPATCH_LPR(lpr, seg_long_finish_n2_kernel<L, 0><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, n2, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
+        else { DISPATCH_LPR(lpr, seg_long_finish_n2_kernel<L, 1><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, n2, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
+        CDR_LAUNCH_CHECK();
+    }
+    return CDR_OK;
+}
+
+static apply_hp make_hp(int opt, float lr, float beta1, float beta2, float eps, float wd, int64_t step) {
+    float step_size = lr, bc2_sqrt = 1.f;
+    if (opt == 1) {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
+    return apply_hp{lr, beta1, beta2, eps, wd, step_size, bc2_sqrt};
+}
+
+}  // namespace
+
+extern "C" int cdr_bpr_step_fused_heads_words(int64_t B, int64_t* words) {
+    CDR_CHECK_ARG(words && B > 0);
+    *words = 4 + (B / 2 + 1) + (B + 1);          // {counters[4] | heads of the user list | heads of the item list}
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, float* user_n2,
+                                  int64_t user_rows, float* item_tab, float* item_m, float* item_v, float* item_n2, int64_t item_rows,
+                                  int D, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma,
+                                  float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  int64_t step_user, int64_t step_item, float* out9, float* GU, float* GP, uint32_t* keys,
+                                  uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    CDR_CHECK_ARG(reg_weight == 0.f || (user_n2 && item_n2));
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t key_base = 0;
+    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, pid, B, nid, B, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    unsigned* cnt = (unsigned*)heads;
+    uint32_t* headsA = heads + 4;
+    uint32_t* headsB = headsA + (B / 2 + 1);
+    CDR_HIP(cdr_zero_u32(cnt, 4, s));
+    const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, B, key_base, reg_weight != 0.f ? user_n2 : nullptr,
+                                                               reg_weight != 0.f ? item_n2 : nullptr, flags, headsA, headsB, cnt, ctx->partials);
+    }
+    CDR_LAUNCH_CHECK();
+    coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, fgrid, B, reg_weight, out9);
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    const tab_ptrs TU{user_tab, user_m, user_v, user_n2}, TI{item_tab, item_m, item_v, item_n2};
+    const int lpr = cdr_lpr_for(D);
+    static const int un = [] { const char* e = getenv("CDR_FWD_APPLY_UN"); return (e && e[0] == '1') ? 1 : 2; }();   // A/B switch (tools/)
+    const int grid = grid_for((B + un - 1) / un, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_APPLY, s);
+#define FA_ARGS TU, TI, D, uid, pid, nid, flags, B, gamma, 1.0f / (float)B, out9 + 4, hu, hi, GU, GP, ctx->partials
+        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 0, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+        else if (un == 1) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+        else { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+#undef FA_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9);
+    CDR_LAUNCH_CHECK();
+    rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, user_n2, D, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0,
+                    CDR_TAG_APPLY_UNSIGNED);
+    if (rc) return rc;
+    return apply_dups(ctx, s, opt, item_tab, item_m, item_v, item_n2, D, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi,
+                      key_base, CDR_TAG_APPLY_SIGNED);
 }

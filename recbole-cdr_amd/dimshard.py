@@ -279,7 +279,7 @@ class NativeDimOps:
         from . import binding as B_
         from .fused import FusedBPRStep
         self.B_ = B_
-        self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, **kw)
+        self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, fuse_singles=False, **kw)   # the forward is cut in two around the all-reduce
         self.out = self.fs.out6
 
     def pack_ids(self, a, b, c, out32):

@@ -500,7 +500,8 @@ def test_fused_step_deterministic_and_sorted():
         Ud, Id = U0.clone(), I0.clone()
         fs = FusedBPRStep(Ud, Id, max_batch=B, opt='adam', reg_weight=0.01)
         fs.step(u, p, n)
-        res.append((Ud.clone(), Id.clone(), fs.keys[:3 * B].clone(), fs.perm[:3 * B].clone(), fs._key_base.value))
+        res.append((Ud.clone(), Id.clone(), fs.keys[:3 * B].clone(), fs.perm[:3 * B].clone(), 1 << (max(nu, ni) - 1).bit_length(),
+                    fs.flags[:3 * B].clone(), fs.heads.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     # one sort for both tables: [0, B) the user keys, [B, 3B) the item keys carrying the table bit
     keys = res[0][2].to(torch.int64) & 0xFFFFFFFF
@@ -513,6 +514,18 @@ def test_fused_step_deterministic_and_sorted():
     assert torch.equal(both[perm[B:]], keys[B:] - base)
     same = keys[1:] == keys[:-1]
     assert bool((perm[1:][same] > perm[:-1][same]).all())                # stable: occurrence order inside a segment
+    # the single-occurrence flags and the duplicate-segment heads the fused step derives from the sorted keys
+    first = torch.ones(3 * B, dtype=torch.bool, device=DEV); first[1:] = ~same
+    last = torch.ones(3 * B, dtype=torch.bool, device=DEV); last[:-1] = ~same
+    occ = torch.cat([perm[:B], B + perm[B:]])
+    want_flags = torch.zeros(3 * B, dtype=torch.uint8, device=DEV); want_flags[occ] = (first & last).to(torch.uint8)
+    assert torch.equal(res[0][5], want_flags)
+    heads = res[0][6].to(torch.int64)
+    nA, nB = int(heads[0]), int(heads[1])
+    hd = first & ~last
+    assert nA == int(hd[:B].sum()) and nB == int(hd[B:].sum())
+    assert torch.equal(torch.sort(heads[4:4 + nA]).values, torch.nonzero(hd[:B]).flatten())
+    assert torch.equal(torch.sort(heads[4 + B // 2 + 1:4 + B // 2 + 1 + nB]).values, torch.nonzero(hd[B:]).flatten())
 
 
 def test_sharded_step_world1_equals_fused():
@@ -1598,6 +1611,91 @@ def test_sharded_map_step_and_fullsort_ranks_share_one_gpu():
     # the user rows each rank gathered are rows of the trained target table
     ids = torch.arange(5, 8) * 7 % nu
     assert_close(torch.from_numpy(res[0][6][(ni, 3)][0]).to(DEV), TUd[ids.to(DEV)], rtol=2e-5, atol=0.01 * 2e-2)
+
+
+@pytest.mark.parametrize('opt,reg', [('adam', 0.03), ('sgd', 0.03), ('adam', 0.0)])
+@pytest.mark.parametrize('D', [8, 24, 64, 128, 256])
+def test_fused_step_single_rows_in_the_forward(opt, reg, D):
+    """cdr_bpr_step_fused: rows that occur once in the batch are updated by the forward kernel, duplicate rows by the segmented
+    apply.  A batch that mixes both (users mostly single, items ~half duplicated, p == n in some triples, one long segment):
+    three free-running steps against the oracle's row-wise step, against the two-pass path (fuse_singles=False: same sums, same
+    order -- only the EmbLoss coefficient comes from cached squared norms, so results agree to rounding), the squared-norm cache
+    against the rows, rows outside the batch bit-identical, reruns bit-equal."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import FusedBPRStep
+    torch.manual_seed(D)
+    nu, ni, B, lr = 4000, 900, 700, 0.05
+    U = torch.randn(nu, D) * 0.3
+    I = torch.randn(ni, D) * 0.3
+    runs = []
+    for fuse in (True, False, True):
+        Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+        fs = FusedBPRStep(Ud, Id, max_batch=B, opt=opt, lr=lr, reg_weight=reg, fuse_singles=fuse)
+        assert fs.fuse_singles == fuse
+        Uo, Io = U.clone(), I.clone()
+        su, si = ts.RowwiseAdamState(Uo), ts.RowwiseAdamState(Io)
+        g = torch.Generator().manual_seed(7)
+        losses = []
+        for step in range(1, 4):
+            u = torch.randint(1, nu, (B,), generator=g); p = torch.randint(1, ni, (B,), generator=g); n = torch.randint(1, ni, (B,), generator=g)
+            n[:5] = p[:5]                                   # the same item as positive and negative of one triple
+            p[100:160] = 3                                  # a segment past the head-only limit (60 occurrences)
+            if step == 2:
+                u[200:210] = u[0]                           # a user with 11 occurrences
+            ref = ts.rowwise_step(Uo, Io, su, si, u, p, n, step, opt=opt, lr=lr, reg_weight=reg)
+            out = fs.step(u.to(DEV), p.to(DEV), n.to(DEV))
+            losses.append(out[0].clone())
+            if fuse:
+                assert_close(out[0], ref, what=f'loss step {step}')
+                if step == 1:
+                    untouched_u = torch.ones(nu, dtype=torch.bool); untouched_u[u] = False
+                    untouched_i = torch.ones(ni, dtype=torch.bool); untouched_i[p] = False; untouched_i[n] = False
+                    assert torch.equal(Ud.cpu()[untouched_u], U[untouched_u]) and torch.equal(Id.cpu()[untouched_i], I[untouched_i])
+                    if opt == 'adam':
+                        assert_close(fs.ustate.exp_avg, su.m, what='exp_avg U, step 1'); assert_close(fs.istate.exp_avg, si.m, what='exp_avg I, step 1', row_floor=1e-2)
+                        assert_close(fs.ustate.exp_avg_sq, su.v, what='exp_avg_sq U, step 1'); assert_close(fs.istate.exp_avg_sq, si.v, what='exp_avg_sq I, step 1')
+        if fuse:
+            atol = lr * 1e-2 if opt == 'adam' else 1e-6
+            assert_close(Ud, Uo, rtol=1e-5, atol=atol, what='U after 3 steps'); assert_close(Id, Io, rtol=1e-5, atol=atol, what='I after 3 steps')
+            if reg:
+                assert fs.ustate.nrm2_ok and fs.istate.nrm2_ok
+                assert_close(fs.ustate.nrm2, (Ud * Ud).sum(1), rtol=1e-5, atol=1e-9, what='squared-norm cache, users')
+                assert_close(fs.istate.nrm2, (Id * Id).sum(1), rtol=1e-5, atol=1e-9, what='squared-norm cache, items')
+        runs.append((torch.stack(losses), Ud.clone(), Id.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[2])), 'rerun differs'
+    # the two-pass path: same per-row sums in the same order; the EmbLoss coefficient may differ in its last bit
+    # (SGD: to rounding; Adam: hipcc contracts g (p - n) + c w into one fma where the two-pass path rounds the stored gradient row
+    #  first, and m / (sqrt(v) + eps) turns that last bit into up to 1e-2 of one update for elements whose gradient is ~eps)
+    tol = dict(rtol=1e-6, atol=1e-7) if opt == 'sgd' else dict(rtol=1e-5, atol=lr * 1e-2)
+    for a, b, what in zip(runs[0], runs[1], ('losses', 'U', 'I')):
+        assert_close(a, b, what='fused vs two-pass ' + what, **tol)
+
+
+def test_fused_step_norm_cache_follows_other_writers():
+    """The squared-norm cache is dropped when anything else updates the table (the OVERLAP map step shares the user tables'
+    state) and rebuilt by the next fused step: the result equals a fresh step object's."""
+    from recbole_cdr_amd.fused import FusedBPRStep, KMajorBPRStep
+    torch.manual_seed(3)
+    nu, ni, D, B = 3000, 800, 64, 400
+    U, I = (torch.randn(nu, D) * 0.3).to(DEV), (torch.randn(ni, D) * 0.3).to(DEV)
+    u = torch.randint(1, nu, (B,), device=DEV); p = torch.randint(1, ni, (B,), device=DEV); n = torch.randint(1, ni, (B,), device=DEV)
+    fs = FusedBPRStep(U, I, B, opt='adam', lr=0.05, reg_weight=0.05)
+    fs.step(u, p, n)
+    assert fs.ustate.nrm2_ok
+    km = KMajorBPRStep(U, I, B, k=1, opt='adam', lr=0.05, reg_weight=0.05, user_state=fs.ustate, item_state=fs.istate)
+    km.step(u, p, n)                                        # another writer of both tables
+    assert not fs.ustate.nrm2_ok and not fs.istate.nrm2_ok
+    U2, I2 = U.clone(), I.clone()
+    fresh = FusedBPRStep(U2, I2, B, opt='adam', lr=0.05, reg_weight=0.05)
+    for st_new, st_old in ((fresh.ustate, fs.ustate), (fresh.istate, fs.istate)):
+        st_new.exp_avg.copy_(st_old.exp_avg); st_new.exp_avg_sq.copy_(st_old.exp_avg_sq); st_new.step = st_old.step
+    a = fs.step(u, p, n).clone()
+    b = fresh.step(u, p, n).clone()
+    assert torch.equal(a, b) and torch.equal(U, U2) and torch.equal(I, I2)
+    U[5] += 1.0                                             # written behind the step objects' back: the caller says so
+    fs.ustate.invalidate_norms()
+    fs.step(u, p, n)
+    assert_close(fs.ustate.nrm2, (U * U).sum(1), rtol=1e-5, atol=1e-9, what='cache after invalidate_norms')
 
 
 @pytest.mark.parametrize('opt', ['sgd', 'adam'])
