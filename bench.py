@@ -495,13 +495,14 @@ def run_c5(args, world, rank, dev):
             # this implementation moves on top: ids, flags, squared norms, and the compact gradient rows of the duplicate occurrences.
             dup_occ = (B - su_) + (2 * B - si_)
             alg_fa = (su_ + si_) * nmom * row_b + dup_occ * row_b
-            des_fa = alg_fa + B * (24 + 3) + (su_ + si_) * 4 + (B - su_) * row_b + (B - both_single) * row_b
+            des_fa = alg_fa + B * (24 + 4) + (B - su_) * row_b + (B - both_single) * row_b
             alg_du = (B - su_) * row_b + (du - su_) * nmom * row_b          # duplicate users: one gradient row per occurrence + RMW per row
             alg_di = (2 * B - si_) * row_b + (di - si_) * nmom * row_b
             des_du = alg_du + (B - su_) * 8 + (du - su_) * 8
             des_di = alg_di + (2 * B - si_) * 8 + (di - si_) * 8
-            des_fl = 3 * B * (4 + 4 + 1) + (B + B) * 4                      # keys + perm read, flag bytes written, squared norms gathered
-            for kname, alg_b, des_b in (('bpr_fwd_apply_kernel', alg_fa, des_fa), ('occ_flags_kernel', 0, des_fl),
+            des_fl = 3 * B * (4 + 4 + 1)                                    # keys + perm read, flag bytes written
+            des_bn = B * (2 * row_b + 16)                                   # the EmbLoss norms: user + positive row of every triple gathered once more
+            for kname, alg_b, des_b in (('bpr_fwd_apply_kernel', alg_fa, des_fa), ('batch_norms_kernel', 0, des_bn), ('occ_flags_kernel', 0, des_fl),
                                         ('rowwise_apply_kernel(users)', alg_du, des_du), ('rowwise_apply_kernel(items)', alg_di, des_di)):
                 ms = med_ms(kname)
                 kernels.append({'kernel': kname + (' [duplicate rows only]' if kname.startswith('rowwise') else ''), 'avg_ms': mean_ms(kname), 'median_ms': ms,
@@ -534,7 +535,7 @@ def run_c5(args, world, rank, dev):
         dom_ms = dt / args.steps * 1e3 / 2.0
         step_bytes = B * 3 * nmom * row_b
         distinct_bytes = (du + di) * nmom * row_b
-        result['roofline_step'] = {'bound': 'hbm', 'what': 'one domain step (sort + flags + forward/optimizer + duplicate-row applies) of %d triples against SURVEY 8d\'s '
+        result['roofline_step'] = {'bound': 'hbm', 'what': 'one domain step (batch norms + sort + flags + forward/optimizer + duplicate-row applies) of %d triples against SURVEY 8d\'s '
                                    '9,216 B/triple at D=128 (6 x 4D per touched row, 3 rows per triple, no reuse counted)' % B,
                                    'achieved': step_bytes / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': step_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'ms_per_domain_step': dom_ms,

@@ -63,8 +63,9 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_BPR_FWD_KMAJOR 15      /* bpr_fwd_kmajor_kernel: one lane group per positive */
 #define CDR_TAG_MAP_STEP 16             /* map_step_kernel: the OVERLAP step of distinct ids in one pass */
 #define CDR_TAG_CONET_WGRAD 14         /* conet_wgrad_kernel: weight gradients, one wave per (tile, row chunk) */
-#define CDR_TAG_OCC_FLAGS 17            /* occ_flags_kernel: single-occurrence flags + duplicate-segment heads + batch norms */
+#define CDR_TAG_OCC_FLAGS 17            /* occ_flags_kernel: single-occurrence flags + duplicate-segment heads */
 #define CDR_TAG_BPR_FWD_APPLY 18        /* bpr_fwd_apply_kernel: forward + optimizer on the single-occurrence rows */
+#define CDR_TAG_BATCH_NORMS 19          /* batch_norms_kernel: EmbLoss norms of the batch's user and positive rows */
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
 
@@ -487,23 +488,21 @@ int cdr_bpr_fwd_grad(cdr_ctx* ctx, void* stream,
                      int scatter /* != 0 (row-sharded step): GP[pid[b]] = g u, GP[nid[b]] = -g u instead of GP[b] = g u */);
 int cdr_loss_finish_sums(void* stream, const float* sums3, int64_t B_mean, float reg_weight, float* out6);
 /* The same step with the optimizer of every row that occurs ONCE in the batch applied by the forward kernel itself (round 3;
- * replaces cdr_bpr_fwd_grad + cdr_sort_ids_two_tables + 2 x cdr_rowwise_apply for emcdr.py:123-131,146-154 + Adam): the ids are
- * sorted first; one pass over the sorted keys marks the single occurrences, compacts the heads of the duplicate segments and
- * sums the batch's EmbLoss norms from per-row squared norms (user_n2 / item_n2: float [rows], ||row||^2 of every row, kept up to
- * date by every kernel of this call -- fill them with cdr_row_sqnorms before the first call and after any other writer touched the
- * table; may be NULL when reg_weight == 0); the forward kernel reads the two moments of a single row next to the row and writes
- * row + moments back (its GU[b] / GP[b] is never written); duplicate rows go through the segmented apply as before.  Per row the
- * arithmetic is that of cdr_rowwise_apply.  keys / perm: uint32 [3B]; flags: uint8 [3B]; heads: uint32
- * [cdr_bpr_step_fused_heads_words(B)]; sort_ws as for cdr_sort_ids_two_tables(3B).  step_user / step_item: the tables' update
- * counts INCLUDING this update (Adam bias correction).  out9 as cdr_bpr_fwd_grad's.                                              */
-int cdr_row_sqnorms(void* stream, const float* table, int64_t rows, int D, float* out /* [rows] */);
+ * replaces cdr_bpr_fwd_grad + cdr_sort_ids_two_tables + 2 x cdr_rowwise_apply for emcdr.py:123-131,146-154 + Adam): the EmbLoss
+ * norms of the batch are gathered first (the gradient coefficient reg_weight / (B ||rows||) is needed before the first row is
+ * updated), the ids are sorted, one pass over the sorted keys marks the single occurrences and compacts the heads of the
+ * duplicate segments; the forward kernel reads the two moments of a single row next to the row and writes row + moments back
+ * (its GU[b] / GP[b] is never written); duplicate rows go through the segmented apply as before.  Per row the arithmetic is
+ * that of cdr_rowwise_apply.  keys / perm: uint32 [3B]; flags: uint8 [4B], 4-byte aligned ({user, positive, negative, -} per
+ * triple); heads: uint32 [cdr_bpr_step_fused_heads_words(B)]; sort_ws as for cdr_sort_ids_two_tables(3B).  step_user /
+ * step_item: the tables' update counts INCLUDING this update (Adam bias correction).  out9 as cdr_bpr_fwd_grad's.             */
 int cdr_bpr_step_fused_heads_words(int64_t B, int64_t* words);
-int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, float* user_n2,
-                       int64_t user_rows, float* item_tab, float* item_m, float* item_v, float* item_n2, int64_t item_rows, int D,
-                       const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight,
-                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
-                       float* out9, float* GU /* [B,D] */, float* GP /* [B,D] */, uint32_t* keys, uint32_t* perm, uint8_t* flags,
-                       uint32_t* heads, void* sort_ws, size_t sort_ws_bytes);
+int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                       float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                       const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item, float* out9,
+                       float* GU /* [B,D] */, float* GP /* [B,D] */, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                       void* sort_ws, size_t sort_ws_bytes);
 /* pointwise form of the same step (EMCDR's default MF latent factor model, emcdr.py:111-122: MSE(dot, label) +
  * reg_weight * EmbLoss(u_rows, i_rows); CDR_LOSS_BCE = BCE on sigmoid(dot) as in cmf.py:75-99): GU[b] = g_b i_b, GI[b] = g_b u_b,
  * out9 as above; apply both tables with cdr_sort_ids + cdr_rowwise_apply (neg_start = n, reg_limit = n).                 */

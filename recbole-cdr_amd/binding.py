@@ -67,9 +67,8 @@ _SIGNATURES = {
     'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_f32, _c_ptr,
                          _c_ptr, _c_ptr, _c_int],
     'cdr_loss_finish_sums': [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr],
-    'cdr_row_sqnorms': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr],
     'cdr_bpr_step_fused_heads_words': [_c_i64, ctypes.POINTER(_c_i64)],
-    'cdr_bpr_step_fused': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int,
+    'cdr_bpr_step_fused': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int,
                            _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_i64,
                            _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
@@ -303,7 +302,7 @@ TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4:
         8: 'bpr_partial_diff_kernel', 9: 'bpr_grad_from_diff_kernel',
         10: 'point_partial_dot_kernel', 11: 'point_grad_from_dot_kernel',
         12: 'conet_fwd_kernel', 13: 'conet_bwd_kernel', 14: 'conet_wgrad_kernel', 15: 'bpr_fwd_kmajor_kernel', 16: 'map_step_kernel',
-        17: 'occ_flags_kernel', 18: 'bpr_fwd_apply_kernel'}
+        17: 'occ_flags_kernel', 18: 'bpr_fwd_apply_kernel', 19: 'batch_norms_kernel'}
 
 
 _timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device

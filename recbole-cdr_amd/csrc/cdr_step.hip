@@ -436,16 +436,20 @@ __global__ __launch_bounds__(kBlock) void make_keys2_kernel(const int64_t* __res
 // compact gradient row (GU[b] / GP[b]) is neither written nor read again, nor is the row re-read by an apply kernel:
 //
 //   cdr_sort_ids_two_tables   as before, but FIRST (it needs only the ids)
-//   occ_flags_kernel          one pass over the sorted keys: flags[occurrence] = "only occurrence of its row", the heads of the
-//                             remaining (duplicate) segments compacted into two lists, and the EmbLoss norms of the batch
-//                             summed from the per-row squared norms that every writer of a table keeps up to date (N2)
+//   occ_flags_kernel          one pass over the sorted keys: flags[occurrence] = "only occurrence of its row" and the heads of the
+//                             remaining (duplicate) segments compacted into two lists
+//   batch_norms_kernel        the EmbLoss norms ||U[uid]||, ||I[pid]|| of the batch (its gradient coefficient is a global scalar the
+//                             optimizer needs BEFORE the first row is updated): a gather of 2 rows per triple.  (First version: a
+//                             per-row squared-norm cache kept current by every writer -- its 2.6 M scattered 4-byte stores per
+//                             step, partial-line read-modify-writes at the HBM, cost 0.35 ms per domain step against 0.18 ms for
+//                             this gather, measured A/B.)
 //   bpr_fwd_apply_kernel      gather 3 rows (+ 2 moments per single row) -> loss -> single rows: optimizer in place;
 //                             duplicate rows: GU[b] / GP[b] as before
 //   rowwise_apply_dups_kernel the segmented apply over the duplicate segments only (same sums, same order as rowwise_apply_kernel)
 //
 // Same arithmetic per row as cdr_bpr_fwd_grad + cdr_rowwise_apply (one occurrence: 0 + g, then the same update), fixed order
 // everywhere: bit-reproducible.  Bytes per triple at D = 128, uniform ids: ~9.5 KB against 12.9 KB before (SURVEY 8d floor 9.2 KB).
-struct tab_ptrs { float* W; float* M; float* V; float* N2; };
+struct tab_ptrs { float* W; float* M; float* V; };
 
 template <int OPT>
 __device__ __forceinline__ float4 upd_math(float4 w, float4& m, float4& v, float4 acc, float rc, const apply_hp& h) {
@@ -469,37 +473,61 @@ __device__ __forceinline__ float4 upd_math(float4 w, float4& m, float4& v, float
 #endif
 }
 
+// partials[block] = {sum_b ||U[uid[b]]||^2, sum_b ||I[pid[b]]||^2}: the EmbLoss norms of the batch (emcdr.py:129-131: reg_loss(user_e, pos_e))
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void row_sqnorm_kernel(const float* __restrict__ W, int64_t rows, int D, float* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void batch_norms_kernel(const float* __restrict__ U, const float* __restrict__ I, int D,
+                                                             const int64_t* __restrict__ uid, const int64_t* __restrict__ pid, int64_t B,
+                                                             double* __restrict__ partials) {
     constexpr int GPB = kBlock / LPR;
+    constexpr int UNR = 8;
+    __shared__ double smem[2 * (kBlock / 64)];
     const int sub = threadIdx.x % LPR;
-    const int D4 = D >> 2;
-    for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += (int64_t)gridDim.x * GPB) {
-        float acc = 0.f;
-        for (int ch = sub; ch < D4; ch += LPR) { const float4 w = ld4(W + r * D + 4 * ch); acc += dot4(w, w); }
-        acc = group_sum<LPR>(acc);
-        if (sub == 0) out[r] = acc;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const bool live = sub < (D >> 2);
+    double acc[2] = {0.0, 0.0};
+    for (int64_t base = gg; base < B; base += TG * UNR) {
+        int64_t iu[UNR], ip[UNR];
+        float4 u[UNR], p[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const int64_t tc = t < B ? t : B - 1;
+            iu[r] = uid[tc]; ip[r] = pid[tc];
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            u[r] = p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < B && live) { u[r] = ld4(U + iu[r] * D + 4 * sub); p[r] = ld4(I + ip[r] * D + 4 * sub); }
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const float su = group_sum<LPR>(dot4(u[r], u[r])), sp = group_sum<LPR>(dot4(p[r], p[r]));
+            if (sub == 0) { acc[0] += (double)su; acc[1] += (double)sp; }
+        }
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1];
     }
 }
 
 // keys / perm: the two-table sort's output (section A = positions [0, nA): user keys; section B = [nA, n): item keys + key_base).
-// flags[o] for A occurrences o in [0, nA), flags[nA + o] for B occurrences.  cnt[0] / cnt[1]: lengths of headsA / headsB (sorted
+// flags: 4 bytes per triple b = {its user occurrence, its positive (B occurrence b), its negative (B occurrence nA + b), unused}
+// (section B holds 2 nA occurrences: the step's item list [pid | nid]); one 32-bit load per triple in the forward kernel.  cnt[0] / cnt[1]: lengths of headsA / headsB (sorted
 // positions, relative to their section, of the first occurrence of every row that occurs more than once; list order is
-// irrelevant -- every segment is summed in occurrence order by whoever takes it).  partials: block sums of the batch rows'
-// squared norms (A: every occurrence; B: occurrences o < reg_limit_b, the positives).
+// irrelevant -- every segment is summed in occurrence order by whoever takes it).
 // A thread takes kFlagIT consecutive positions and a block reserves its share of each list with ONE atomic: with an atomic per
 // 256 positions the 24 k same-address atomics of a 3 M-position launch were most of its 0.157 ms.
 constexpr int kFlagIT = 8;
 __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
-                                                           int64_t nA, int64_t n, int64_t reg_limit_b, uint32_t key_base,
-                                                           const float* __restrict__ An2, const float* __restrict__ Bn2,
-                                                           uint8_t* __restrict__ flags, uint32_t* __restrict__ headsA,
-                                                           uint32_t* __restrict__ headsB, unsigned* __restrict__ cnt,
-                                                           double* __restrict__ partials) {
+                                                           int64_t nA, int64_t n, uint8_t* __restrict__ flags,
+                                                           uint32_t* __restrict__ headsA, uint32_t* __restrict__ headsB,
+                                                           unsigned* __restrict__ cnt) {
     constexpr int NW = kBlock / 64;
-    __shared__ double smem[2 * NW];
     __shared__ unsigned wcnt[2][NW], wbase[2][NW];
-    double acc[2] = {0.0, 0.0};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t base = (int64_t)blockIdx.x * kBlock * kFlagIT; base < n; base += (int64_t)gridDim.x * kBlock * kFlagIT) {
         const int64_t q0 = base + (int64_t)threadIdx.x * kFlagIT;
@@ -511,28 +539,22 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
         }
 #pragma unroll
         for (int j = 0; j < kFlagIT; ++j) o[j] = q0 + j < n ? perm[q0 + j] : 0u;
-        float nv[kFlagIT];
         unsigned hA = 0, hB = 0;                           // bit j: position q0 + j heads a duplicate segment
 #pragma unroll
         for (int j = 0; j < kFlagIT; ++j) {
             const int64_t q = q0 + j;
-            nv[j] = 0.f;
             if (q < n) {
                 const uint32_t row = k[j + 1];
                 const bool first = q == 0 || k[j] != row, last = q + 1 >= n || k[j + 2] != row;
                 if (q < nA) {
-                    flags[o[j]] = (uint8_t)(first && last);
-                    if (An2) nv[j] = An2[row];
+                    flags[4 * (int64_t)o[j]] = (uint8_t)(first && last);
                     hA |= (unsigned)(first && !last) << j;
                 } else {
-                    flags[nA + o[j]] = (uint8_t)(first && last);
-                    if (Bn2 && (int64_t)o[j] < reg_limit_b) nv[j] = Bn2[row - key_base];
+                    flags[(int64_t)o[j] < nA ? 4 * (int64_t)o[j] + 1 : 4 * ((int64_t)o[j] - nA) + 2] = (uint8_t)(first && last);
                     hB |= (unsigned)(first && !last) << j;
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < kFlagIT; ++j) { if (q0 + j < nA) acc[0] += (double)nv[j]; else acc[1] += (double)nv[j]; }
         // exclusive prefix of the per-thread head counts: inside the wave by shuffles, across waves through LDS, one atomic per list
         unsigned cA = (unsigned)__popc(hA), cB = (unsigned)__popc(hB), pA = cA, pB = cB;
 #pragma unroll
@@ -558,14 +580,9 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
         }
         __syncthreads();
     }
-    block_sum_d<2>(acc, smem);
-    if (threadIdx.x == 0) {
-        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
-        o[0] = acc[0]; o[1] = acc[1];
-    }
 }
 
-// out9[4], out9[5] = reg_weight / (B * ||rows||) from the cached squared norms (0 when there is no EmbLoss or the norm is 0)
+// out9[4], out9[5] = reg_weight / (B * ||rows||) from batch_norms_kernel's partial sums (0 when there is no EmbLoss or the norm is 0)
 __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
                                                              float reg_weight, float* __restrict__ out9) {
     __shared__ double smem[2 * (kBlock / 64)];
@@ -604,7 +621,7 @@ __global__ __launch_bounds__(kBlock) void step_finish_keep_kernel(const double* 
 template <int LPR, int OPT, int UN>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
                                                                const int64_t* __restrict__ pid, const int64_t* __restrict__ nid,
-                                                               const uint8_t* __restrict__ flags, int64_t B, float gamma, float invB,
+                                                               const uint32_t* __restrict__ flags4, int64_t B, float gamma, float invB,
                                                                const float* __restrict__ coef, apply_hp hu, apply_hp hi,
                                                                float* __restrict__ GU, float* __restrict__ GP,
                                                                double* __restrict__ partials) {
@@ -619,17 +636,20 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     double acc[3] = {0.0, 0.0, 0.0};
 
-    // ids + flags of the NEXT iteration are requested right behind this iteration's row loads, i.e. BEFORE its stores: vmcnt
-    // retires in order, so a wait for ids that were issued after the stores would also wait for every store's acknowledgement
-    int64_t iu[UN], ip[UN], in[UN];
-    uint8_t fu8[UN], fp8[UN], fn8[UN];
+    // The ids + flags of the NEXT iteration are requested right behind this iteration's row loads and are waited for together
+    // with them, BEFORE this iteration's stores are issued: vmcnt retires in order, so a wait for anything requested after the
+    // stores also waits for every store's acknowledgement (the first version of this loop had s_waitcnt vmcnt(0) at its head).
+    uint32_t iu[UN], ip[UN], in[UN], fl[UN];
 #pragma unroll
     for (int r = 0; r < UN; ++r) {
         const int64_t t = gg + (int64_t)r * TG;
         const int64_t tc = t < B ? t : B - 1;
-        iu[r] = uid[tc]; ip[r] = pid[tc]; in[r] = nid[tc];
-        fu8[r] = flags[tc]; fp8[r] = flags[B + tc]; fn8[r] = flags[2 * B + tc];
+        iu[r] = (uint32_t)uid[tc]; ip[r] = (uint32_t)pid[tc]; in[r] = (uint32_t)nid[tc];
+        fl[r] = flags4[tc];
     }
+    // (waited for HERE: a wait that the loop header inherits from this prologue is a static s_waitcnt vmcnt(0) on every iteration)
+#pragma unroll
+    for (int r = 0; r < UN; ++r) asm volatile("" : "+v"(iu[r]), "+v"(ip[r]), "+v"(in[r]), "+v"(fl[r]));
     for (int64_t base = gg; base < B; base += TG * UN) {
         float4 u[UN], p[UN], n[UN], um[UN], uv[UN], pm[UN], pv[UN], nm[UN], nv[UN];
         int64_t ou[UN], op[UN], on[UN];
@@ -638,8 +658,8 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
         for (int r = 0; r < UN; ++r) {
             const int64_t t = base + (int64_t)r * TG;
             const bool ok = t < B && live;
-            fu[r] = fu8[r] != 0 && t < B; fp[r] = fp8[r] != 0 && t < B; fn[r] = fn8[r] != 0 && t < B;
-            ou[r] = iu[r] * D + 4 * sub; op[r] = ip[r] * D + 4 * sub; on[r] = in[r] * D + 4 * sub;
+            fu[r] = (fl[r] & 0xFFu) != 0 && t < B; fp[r] = (fl[r] & 0xFF00u) != 0 && t < B; fn[r] = (fl[r] & 0xFF0000u) != 0 && t < B;
+            ou[r] = (int64_t)iu[r] * D + 4 * sub; op[r] = (int64_t)ip[r] * D + 4 * sub; on[r] = (int64_t)in[r] * D + 4 * sub;
             u[r] = ok ? ld4(TU.W + ou[r]) : z4;
             p[r] = ok ? ld4(TI.W + op[r]) : z4;
             n[r] = ok ? ld4(TI.W + on[r]) : z4;
@@ -650,64 +670,60 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
                 if (ok && fn[r]) { nm[r] = ld4(TI.M + on[r]); nv[r] = ld4(TI.V + on[r]); }
             }
         }
-        int64_t ju[UN], jp[UN], jn[UN];
-        uint8_t gu8[UN], gp8[UN], gn8[UN];
+        uint32_t ju[UN], jp[UN], jn[UN], gl[UN];
 #pragma unroll
         for (int r = 0; r < UN; ++r) {
             const int64_t t = base + (int64_t)(UN + r) * TG;
             const int64_t tc = t < B ? t : B - 1;
-            ju[r] = uid[tc]; jp[r] = pid[tc]; jn[r] = nid[tc];
-            gu8[r] = flags[tc]; gp8[r] = flags[B + tc]; gn8[r] = flags[2 * B + tc];
+            ju[r] = (uint32_t)uid[tc]; jp[r] = (uint32_t)pid[tc]; jn[r] = (uint32_t)nid[tc];
+            gl[r] = flags4[tc];
         }
         __builtin_amdgcn_sched_barrier(0);                  // keep the requests above the arithmetic (the scheduler sinks them otherwise)
+        float gco[UN], sus[UN], sps[UN], lss[UN];
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const float dp = group_sum<LPR>(dot4(u[r], p[r]));
+            const float dn = group_sum<LPR>(dot4(u[r], n[r]));
+            sus[r] = group_sum<LPR>(dot4(u[r], u[r]));
+            sps[r] = group_sum<LPR>(dot4(p[r], p[r]));
+            const float s = sigmoidf_(dp - dn);
+            gco[r] = -invB * (s * (1.0f - s)) / (gamma + s);
+            lss[r] = -logf(gamma + s);
+        }
+        // every request of this iteration -- rows AND the next ids -- has returned here; nothing below waits on vmcnt again
+#pragma unroll
+        for (int r = 0; r < UN; ++r) asm volatile("" : "+v"(ju[r]), "+v"(jp[r]), "+v"(jn[r]), "+v"(gl[r]));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < UN; ++r) {
             const int64_t t = base + (int64_t)r * TG;
-            const float dp = group_sum<LPR>(dot4(u[r], p[r]));
-            const float dn = group_sum<LPR>(dot4(u[r], n[r]));
-            const float su = group_sum<LPR>(dot4(u[r], u[r]));
-            const float sp = group_sum<LPR>(dot4(p[r], p[r]));
-            const float s = sigmoidf_(dp - dn);
-            const float g = -invB * (s * (1.0f - s)) / (gamma + s);
+            const float g = gco[r];
             const float4 gu = make_float4(g * (p[r].x - n[r].x), g * (p[r].y - n[r].y), g * (p[r].z - n[r].z), g * (p[r].w - n[r].w));
             const float4 gi = make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w);
             const bool ok = t < B && live;
             // ---- user row
-            float4 wu = z4, wp = z4, wn = z4;
             if (fu[r]) {
-                wu = upd_math<OPT>(u[r], um[r], uv[r], gu, cu, hu);
+                const float4 wu = upd_math<OPT>(u[r], um[r], uv[r], gu, cu, hu);
                 if (live) { if (OPT == 1) { st4(TU.M + ou[r], um[r]); st4(TU.V + ou[r], uv[r]); } st4(TU.W + ou[r], wu); }
             } else if (ok) st4(GU + t * D + 4 * sub, gu);
             // ---- positive item row (EmbLoss occurrence), negative item row (gradient -g u, no EmbLoss)
             if (fp[r]) {
-                wp = upd_math<OPT>(p[r], pm[r], pv[r], gi, ci, hi);
+                const float4 wp = upd_math<OPT>(p[r], pm[r], pv[r], gi, ci, hi);
                 if (live) { if (OPT == 1) { st4(TI.M + op[r], pm[r]); st4(TI.V + op[r], pv[r]); } st4(TI.W + op[r], wp); }
             }
             if (fn[r]) {
-                wn = upd_math<OPT>(n[r], nm[r], nv[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w), 0.f, hi);
+                const float4 wn = upd_math<OPT>(n[r], nm[r], nv[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w), 0.f, hi);
                 if (live) { if (OPT == 1) { st4(TI.M + on[r], nm[r]); st4(TI.V + on[r], nv[r]); } st4(TI.W + on[r], wn); }
             }
             if (ok && !(fp[r] && fn[r])) st4(GP + t * D + 4 * sub, gi);
-            // ---- the updated rows' squared norms (every lane takes part in the reductions; only single rows are stored)
-            if (TU.N2) {
-                const float q0 = group_sum<LPR>(dot4(wu, wu)), q1 = group_sum<LPR>(dot4(wp, wp)), q2 = group_sum<LPR>(dot4(wn, wn));
-                if (sub == 0) {
-                    if (fu[r]) TU.N2[iu[r]] = q0;
-                    if (fp[r]) TI.N2[ip[r]] = q1;
-                    if (fn[r]) TI.N2[in[r]] = q2;
-                }
-            }
             if (t < B && sub == 0) {
-                acc[0] += (double)(-logf(gamma + s));
-                acc[1] += (double)su;
-                acc[2] += (double)sp;
+                acc[0] += (double)lss[r];
+                acc[1] += (double)sus[r];
+                acc[2] += (double)sps[r];
             }
         }
 #pragma unroll
-        for (int r = 0; r < UN; ++r) {
-            iu[r] = ju[r]; ip[r] = jp[r]; in[r] = jn[r];
-            fu8[r] = gu8[r]; fp8[r] = gp8[r]; fn8[r] = gn8[r];
-        }
+        for (int r = 0; r < UN; ++r) { iu[r] = ju[r]; ip[r] = jp[r]; in[r] = jn[r]; fl[r] = gl[r]; }
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -718,10 +734,10 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
 
 // The segmented apply over the DUPLICATE segments only: heads[0 .. *nheads) are the sorted positions of their first occurrences
 // (any order: every segment is summed by one lane group in occurrence order, whoever takes it).  Long segments as in
-// rowwise_apply_kernel; every updated row's squared norm goes to N2 (optional).
+// rowwise_apply_kernel.
 template <int LPR, int OPT, bool SIGNED>
 __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
-                                                                    float* __restrict__ N2, int D, const uint32_t* __restrict__ keys,
+                                                                    int D, const uint32_t* __restrict__ keys,
                                                                     const uint32_t* __restrict__ perm, int64_t n,
                                                                     const uint32_t* __restrict__ heads, const unsigned* __restrict__ nheads,
                                                                     const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
@@ -740,7 +756,6 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __res
         const uint32_t row = keys[q];
         const bool is_long = q + kLongSeg < n && keys[q + kLongSeg] == row;
         if (is_long) continue;
-        float nn = 0.f;
         for (int ch = sub; ch < D4; ch += LPR) {
             const int64_t off = (int64_t)row * D + 4 * ch;
             const float4 w = ld4(W + off);
@@ -759,11 +774,6 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __res
             const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
             if (OPT == 1) { st4(Mo + off, m); st4(Vo + off, v); }
             st4(W + off, wn);
-            nn += dot4(wn, wn);
-        }
-        if (N2) {
-            nn = group_sum<LPR>(nn);
-            if (sub == 0) N2[row] = nn;
         }
     }
     if (counters == nullptr) return;
@@ -785,50 +795,6 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __res
         for (unsigned k = 0; k < np; ++k) {
             const int64_t st = q + (int64_t)k * kPiece;
             pieces[base + k] = seg_piece{st, (hi - st) < kPiece ? (hi - st) : (int64_t)kPiece};
-        }
-    }
-}
-
-// seg_long_finish_kernel + the updated row's squared norm
-template <int LPR, int OPT>
-__global__ __launch_bounds__(kBlock) void seg_long_finish_n2_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
-                                                                    float* __restrict__ N2, int D, const uint32_t* __restrict__ keys,
-                                                                    const float* __restrict__ reg_coef, apply_hp hp,
-                                                                    const unsigned* __restrict__ counters,
-                                                                    const seg_long* __restrict__ longs,
-                                                                    const float* __restrict__ partial, const int* __restrict__ pcnt) {
-    constexpr int GPB = kBlock / LPR;
-    const int sub = threadIdx.x % LPR;
-    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-    const int64_t TG = (int64_t)gridDim.x * GPB;
-    const int D4 = D >> 2;
-    const float c = reg_coef ? reg_coef[0] : 0.f;
-    const int64_t nl = counters[1];
-    for (int64_t li = gg; li < nl; li += TG) {
-        const seg_long sg = longs[li];
-        const uint32_t row = keys[sg.head];
-        const int64_t np = (sg.len + kPiece - 1) / kPiece;
-        float nn = 0.f;
-        for (int ch = sub; ch < D4; ch += LPR) {
-            const int64_t off = (int64_t)row * D + 4 * ch;
-            const float4 w = ld4(W + off);
-            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
-            if (OPT == 1) { m = ld4(Mo + off); v = ld4(Vo + off); }
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int cnt = 0;
-            for (int64_t k = 0; k < np; ++k) {
-                const float4 g = ld4(partial + (sg.base + k) * D + 4 * ch);
-                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-                cnt += pcnt[sg.base + k];
-            }
-            const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
-            if (OPT == 1) { st4(Mo + off, m); st4(Vo + off, v); }
-            st4(W + off, wn);
-            nn += dot4(wn, wn);
-        }
-        if (N2) {
-            nn = group_sum<LPR>(nn);
-            if (sub == 0) N2[row] = nn;
         }
     }
 }
@@ -1046,18 +1012,9 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
 }
 
 // ------------------------------------------------------------------------------------------------ the fused step (round 3)
-extern "C" int cdr_row_sqnorms(void* stream, const float* table, int64_t rows, int D, float* out) {
-    CDR_CHECK_ARG(table && out && rows > 0 && D > 0 && (D & 3) == 0);
-    const int lpr = cdr_lpr_for(D);
-    const int grid = grid_for(rows, kBlock / lpr);
-    DISPATCH_LPR(lpr, row_sqnorm_kernel<L><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(table, rows, D, out));
-    CDR_LAUNCH_CHECK();
-    return CDR_OK;
-}
-
 namespace {
 
-static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float* exp_avg, float* exp_avg_sq, float* n2, int D,
+static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
                       const uint32_t* keys, const uint32_t* perm, int64_t n, const uint32_t* heads, const unsigned* nheads,
                       const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef, const apply_hp& hp,
                       uint32_t key_base, int tag) {
@@ -1065,7 +1022,6 @@ static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float*
         table -= (int64_t)key_base * D;
         if (exp_avg) exp_avg -= (int64_t)key_base * D;
         if (exp_avg_sq) exp_avg_sq -= (int64_t)key_base * D;
-        if (n2) n2 -= (int64_t)key_base;
     }
     const int lpr = cdr_lpr_for(D);
     const bool is_signed = neg_start < n;
@@ -1085,12 +1041,12 @@ static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float*
         pcnt = (int*)((char*)base + o_cnt); partial = (float*)((char*)base + o_part);
         CDR_HIP(cdr_zero_u32(counters, 4, s));
     }
-    // the duplicate segments are a fraction of the list (uniform ids: ~1 % of the users, ~10 % of the item rows): a grid for half of
-    // the worst case, the loop covers the rest
+    // the duplicate segments are a fraction of the list (uniform ids at C5: ~1 % of the users, ~10 % of the item rows): a grid for a
+    // quarter of the positions, the loop covers the rest
     const int grid = grid_for(n / 4 + 1, kBlock / lpr);
     {
         cdr_time_scope ts(ctx, tag, s);
-#define DUP_ARGS table, exp_avg, exp_avg_sq, n2, D, keys, perm, n, heads, nheads, G, neg_start, reg_limit, reg_coef, hp, counters, longs, pieces
+#define DUP_ARGS table, exp_avg, exp_avg_sq, D, keys, perm, n, heads, nheads, G, neg_start, reg_limit, reg_coef, hp, counters, longs, pieces
         if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
         else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
         else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
@@ -1104,8 +1060,8 @@ static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float*
         else { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, false><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, nullptr, counters, pieces, partial, pcnt)); }
         CDR_LAUNCH_CHECK();
         const int gl = grid_for(long_cap < 4096 ? long_cap : 4096, kBlock / lpr);
-        if (opt == 0) { DISPATCH_LPR(lpr, seg_long_finish_n2_kernel<L, 0><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, n2, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
-        else { DISPATCH_LPR(lpr, seg_long_finish_n2_kernel<L, 1><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, n2, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
+        if (opt == 0) { DISPATCH_LPR(lpr, seg_long_finish_kernel<L, 0><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
+        else { DISPATCH_LPR(lpr, seg_long_finish_kernel<L, 1><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
         CDR_LAUNCH_CHECK();
     }
     return CDR_OK;
@@ -1129,17 +1085,31 @@ extern "C" int cdr_bpr_step_fused_heads_words(int64_t B, int64_t* words) {
     return CDR_OK;
 }
 
-extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, float* user_n2,
-                                  int64_t user_rows, float* item_tab, float* item_m, float* item_v, float* item_n2, int64_t item_rows,
-                                  int D, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B, float gamma,
-                                  float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                  int64_t step_user, int64_t step_item, float* out9, float* GU, float* GP, uint32_t* keys,
-                                  uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
+extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                                  float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                                  const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
+                                  float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                                  void* sort_ws, size_t sort_ws_bytes) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
     CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
-    CDR_CHECK_ARG(reg_weight == 0.f || (user_n2 && item_n2));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    // ---- EmbLoss coefficients first (they do not need the sort): out9[4], out9[5]
+    if (reg_weight != 0.f) {
+        const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
+        {
+            cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+            DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, B, ctx->partials));
+        }
+        CDR_LAUNCH_CHECK();
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9);
+    } else {
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9);
+    }
+    CDR_LAUNCH_CHECK();
     uint32_t key_base = 0;
     int rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, pid, B, nid, B, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
     if (rc) return rc;
@@ -1150,22 +1120,18 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
     const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
     {
         cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
-        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, B, key_base, reg_weight != 0.f ? user_n2 : nullptr,
-                                                               reg_weight != 0.f ? item_n2 : nullptr, flags, headsA, headsB, cnt, ctx->partials);
+        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, flags, headsA, headsB, cnt);
     }
-    CDR_LAUNCH_CHECK();
-    coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, fgrid, B, reg_weight, out9);
     CDR_LAUNCH_CHECK();
     const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
     const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
-    const tab_ptrs TU{user_tab, user_m, user_v, user_n2}, TI{item_tab, item_m, item_v, item_n2};
-    const int lpr = cdr_lpr_for(D);
-    static const int un = [] { const char* e = getenv("CDR_FWD_APPLY_UN"); return (e && e[0] == '1') ? 1 : 2; }();   // A/B switch (tools/)
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
+    static const int un = [] { const char* e = getenv("CDR_FWD_APPLY_UN"); return (e && e[0] == '2') ? 2 : 1; }();   // A/B switch (tools/)
     const int grid = grid_for((B + un - 1) / un, kBlock / lpr);
     {
         cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_APPLY, s);
-#define FA_ARGS TU, TI, D, uid, pid, nid, flags, B, gamma, 1.0f / (float)B, out9 + 4, hu, hi, GU, GP, ctx->partials
-        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 0, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+#define FA_ARGS TU, TI, D, uid, pid, nid, (const uint32_t*)flags, B, gamma, 1.0f / (float)B, out9 + 4, hu, hi, GU, GP, ctx->partials
+        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 0, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
         else if (un == 1) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
         else { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
 #undef FA_ARGS
@@ -1173,9 +1139,8 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
     CDR_LAUNCH_CHECK();
     step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9);
     CDR_LAUNCH_CHECK();
-    rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, user_n2, D, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0,
-                    CDR_TAG_APPLY_UNSIGNED);
+    rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, D, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0, CDR_TAG_APPLY_UNSIGNED);
     if (rc) return rc;
-    return apply_dups(ctx, s, opt, item_tab, item_m, item_v, item_n2, D, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi,
-                      key_base, CDR_TAG_APPLY_SIGNED);
+    return apply_dups(ctx, s, opt, item_tab, item_m, item_v, D, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base,
+                      CDR_TAG_APPLY_SIGNED);
 }

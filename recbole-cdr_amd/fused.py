@@ -19,16 +19,9 @@ OPT_SGD, OPT_ADAM = 0, 1
 class RowwiseState:
     """Per-table optimizer state for the row-wise Adam (SGD needs no moments).  ``step`` counts the updates this TABLE
     has received -- like torch.optim.Adam's per-parameter ``state['step']`` -- so one state object can be shared by the
-    step objects of several phases (SOURCE / TARGET BPR steps and the OVERLAP map step touch the same user tables).
-
-    ``nrm2`` (float [rows], ||row||^2) is the cache ``FusedBPRStep``'s single-occurrence path sums the batch's EmbLoss norms
-    from (csrc/cdr_step.hip, cdr_bpr_step_fused): its kernels keep it current for the rows they write; any other update of
-    the table (``advance()`` without ``keeps_norms``, a restored checkpoint, a layout change) drops it and the next fused step
-    recomputes it with one pass over the table."""
+    step objects of several phases (SOURCE / TARGET BPR steps and the OVERLAP map step touch the same user tables)."""
     _step = 0                 # class-level defaults: objects built with __new__ (layout transposes in dimshard.py) start consistent
     _step_dev = None
-    nrm2 = None
-    nrm2_ok = False
 
     def __init__(self, table, opt):
         self.table = table
@@ -36,8 +29,6 @@ class RowwiseState:
         self.exp_avg = torch.zeros_like(table) if opt == OPT_ADAM else None
         self.exp_avg_sq = torch.zeros_like(table) if opt == OPT_ADAM else None
         self._step_dev = None
-        self.nrm2 = None
-        self.nrm2_ok = False
 
     @property
     def step(self):
@@ -46,7 +37,6 @@ class RowwiseState:
     @step.setter
     def step(self, value):                       # (checkpoint restore, layout changes) keeps the device mirror in step
         self._step = int(value)
-        self.nrm2_ok = False
         if self._step_dev is not None:
             self._step_dev.fill_(self._step)
 
@@ -57,28 +47,11 @@ class RowwiseState:
             self._step_dev = torch.full((1,), int(self._step), device=self.table.device, dtype=torch.int64)
         return self._step_dev
 
-    def advance(self, device_bumped=False, keeps_norms=False):
-        """One more update of this table.  ``device_bumped``: a kernel already incremented the device counter.
-        ``keeps_norms``: the updating kernels wrote the new squared norms of the rows they changed."""
+    def advance(self, device_bumped=False):
+        """One more update of this table.  ``device_bumped``: a kernel already incremented the device counter."""
         self._step += 1
-        if not keeps_norms:
-            self.nrm2_ok = False
         if self._step_dev is not None and not device_bumped:
             B_.call('cdr_inc_i64', B_.stream(), B_.i64(self._step_dev))
-
-    def invalidate_norms(self):
-        """Call after writing the table by any other means than the step objects."""
-        self.nrm2_ok = False
-
-    def norms(self):
-        """The up-to-date squared-norm cache (recomputed here when some other writer touched the table)."""
-        if self.nrm2 is None or self.nrm2.shape[0] != self.table.shape[0]:
-            self.nrm2 = torch.empty(self.table.shape[0], device=self.table.device, dtype=torch.float32)
-            self.nrm2_ok = False
-        if not self.nrm2_ok:
-            B_.call('cdr_row_sqnorms', B_.stream(), B_.f32(self.table), self.table.shape[0], self.table.shape[1], B_.f32(self.nrm2))
-            self.nrm2_ok = True
-        return self.nrm2
 
 
 class FusedBPRStep:
@@ -117,7 +90,7 @@ class FusedBPRStep:
         if self.fuse_singles:
             words = ctypes.c_int64(0)
             B_._check(B_.load().cdr_bpr_step_fused_heads_words(Bm, ctypes.byref(words)), 'cdr_bpr_step_fused_heads_words')
-            self.flags = torch.empty(3 * Bm, device=dev, dtype=torch.uint8)
+            self.flags = torch.zeros(4 * Bm, device=dev, dtype=torch.uint8)      # {user, positive, negative, -} per triple
             self.heads = torch.empty(int(words.value), device=dev, dtype=torch.int32)
 
     def step(self, uid, pid, nid):
@@ -132,17 +105,14 @@ class FusedBPRStep:
         return self.sort_apply(uid, pid, nid)
 
     def _step_fused(self, uid, pid, nid, B):
-        """Sort first, then ONE pass that also applies the optimizer to every row occurring once in the batch; the segmented
-        applies see the duplicate rows only (csrc/cdr_step.hip, "single-occurrence rows in the forward")."""
+        """Batch norms and sort first, then ONE pass that also applies the optimizer to every row occurring once in the batch; the
+        segmented applies see the duplicate rows only (csrc/cdr_step.hip, "single-occurrence rows in the forward")."""
         us, its = self.ustate, self.istate
-        reg = self.reg_weight != 0.0
-        un2 = us.norms() if reg else None
-        in2 = its.norms() if reg else None
-        us.advance(keeps_norms=reg)
-        its.advance(keeps_norms=reg)
+        us.advance()
+        its.advance()
         B_.call('cdr_bpr_step_fused', B_.ctx(self.U.device), B_.stream(), self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
-                B_.f32(us.exp_avg_sq), B_.f32(un2), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq),
-                B_.f32(in2), its.table.shape[0], self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), B, float(self.gamma),
+                B_.f32(us.exp_avg_sq), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq),
+                its.table.shape[0], self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), B, float(self.gamma),
                 float(self.reg_weight), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
                 us.step, its.step, B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GP), B_.raw(self.keys), B_.raw(self.perm),
                 B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes)

@@ -501,7 +501,7 @@ def test_fused_step_deterministic_and_sorted():
         fs = FusedBPRStep(Ud, Id, max_batch=B, opt='adam', reg_weight=0.01)
         fs.step(u, p, n)
         res.append((Ud.clone(), Id.clone(), fs.keys[:3 * B].clone(), fs.perm[:3 * B].clone(), 1 << (max(nu, ni) - 1).bit_length(),
-                    fs.flags[:3 * B].clone(), fs.heads.clone()))
+                    fs.flags[:4 * B].clone(), fs.heads.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     # one sort for both tables: [0, B) the user keys, [B, 3B) the item keys carrying the table bit
     keys = res[0][2].to(torch.int64) & 0xFFFFFFFF
@@ -517,8 +517,8 @@ def test_fused_step_deterministic_and_sorted():
     # the single-occurrence flags and the duplicate-segment heads the fused step derives from the sorted keys
     first = torch.ones(3 * B, dtype=torch.bool, device=DEV); first[1:] = ~same
     last = torch.ones(3 * B, dtype=torch.bool, device=DEV); last[:-1] = ~same
-    occ = torch.cat([perm[:B], B + perm[B:]])
-    want_flags = torch.zeros(3 * B, dtype=torch.uint8, device=DEV); want_flags[occ] = (first & last).to(torch.uint8)
+    occ = torch.cat([4 * perm[:B], torch.where(perm[B:] < B, 4 * perm[B:] + 1, 4 * (perm[B:] - B) + 2)])   # 4 bytes per triple: u, p, n, -
+    want_flags = torch.zeros(4 * B, dtype=torch.uint8, device=DEV); want_flags[occ] = (first & last).to(torch.uint8)
     assert torch.equal(res[0][5], want_flags)
     heads = res[0][6].to(torch.int64)
     nA, nB = int(heads[0]), int(heads[1])
@@ -1619,8 +1619,8 @@ def test_fused_step_single_rows_in_the_forward(opt, reg, D):
     """cdr_bpr_step_fused: rows that occur once in the batch are updated by the forward kernel, duplicate rows by the segmented
     apply.  A batch that mixes both (users mostly single, items ~half duplicated, p == n in some triples, one long segment):
     three free-running steps against the oracle's row-wise step, against the two-pass path (fuse_singles=False: same sums, same
-    order -- only the EmbLoss coefficient comes from cached squared norms, so results agree to rounding), the squared-norm cache
-    against the rows, rows outside the batch bit-identical, reruns bit-equal."""
+    order; the EmbLoss norms are summed by another kernel, so results agree to rounding), rows outside the batch bit-identical,
+    reruns bit-equal."""
     from oracle import train_step as ts
     from recbole_cdr_amd.fused import FusedBPRStep
     torch.manual_seed(D)
@@ -1657,10 +1657,6 @@ def test_fused_step_single_rows_in_the_forward(opt, reg, D):
         if fuse:
             atol = lr * 1e-2 if opt == 'adam' else 1e-6
             assert_close(Ud, Uo, rtol=1e-5, atol=atol, what='U after 3 steps'); assert_close(Id, Io, rtol=1e-5, atol=atol, what='I after 3 steps')
-            if reg:
-                assert fs.ustate.nrm2_ok and fs.istate.nrm2_ok
-                assert_close(fs.ustate.nrm2, (Ud * Ud).sum(1), rtol=1e-5, atol=1e-9, what='squared-norm cache, users')
-                assert_close(fs.istate.nrm2, (Id * Id).sum(1), rtol=1e-5, atol=1e-9, what='squared-norm cache, items')
         runs.append((torch.stack(losses), Ud.clone(), Id.clone()))
     assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[2])), 'rerun differs'
     # the two-pass path: same per-row sums in the same order; the EmbLoss coefficient may differ in its last bit
@@ -1669,33 +1665,6 @@ def test_fused_step_single_rows_in_the_forward(opt, reg, D):
     tol = dict(rtol=1e-6, atol=1e-7) if opt == 'sgd' else dict(rtol=1e-5, atol=lr * 1e-2)
     for a, b, what in zip(runs[0], runs[1], ('losses', 'U', 'I')):
         assert_close(a, b, what='fused vs two-pass ' + what, **tol)
-
-
-def test_fused_step_norm_cache_follows_other_writers():
-    """The squared-norm cache is dropped when anything else updates the table (the OVERLAP map step shares the user tables'
-    state) and rebuilt by the next fused step: the result equals a fresh step object's."""
-    from recbole_cdr_amd.fused import FusedBPRStep, KMajorBPRStep
-    torch.manual_seed(3)
-    nu, ni, D, B = 3000, 800, 64, 400
-    U, I = (torch.randn(nu, D) * 0.3).to(DEV), (torch.randn(ni, D) * 0.3).to(DEV)
-    u = torch.randint(1, nu, (B,), device=DEV); p = torch.randint(1, ni, (B,), device=DEV); n = torch.randint(1, ni, (B,), device=DEV)
-    fs = FusedBPRStep(U, I, B, opt='adam', lr=0.05, reg_weight=0.05)
-    fs.step(u, p, n)
-    assert fs.ustate.nrm2_ok
-    km = KMajorBPRStep(U, I, B, k=1, opt='adam', lr=0.05, reg_weight=0.05, user_state=fs.ustate, item_state=fs.istate)
-    km.step(u, p, n)                                        # another writer of both tables
-    assert not fs.ustate.nrm2_ok and not fs.istate.nrm2_ok
-    U2, I2 = U.clone(), I.clone()
-    fresh = FusedBPRStep(U2, I2, B, opt='adam', lr=0.05, reg_weight=0.05)
-    for st_new, st_old in ((fresh.ustate, fs.ustate), (fresh.istate, fs.istate)):
-        st_new.exp_avg.copy_(st_old.exp_avg); st_new.exp_avg_sq.copy_(st_old.exp_avg_sq); st_new.step = st_old.step
-    a = fs.step(u, p, n).clone()
-    b = fresh.step(u, p, n).clone()
-    assert torch.equal(a, b) and torch.equal(U, U2) and torch.equal(I, I2)
-    U[5] += 1.0                                             # written behind the step objects' back: the caller says so
-    fs.ustate.invalidate_norms()
-    fs.step(u, p, n)
-    assert_close(fs.ustate.nrm2, (U * U).sum(1), rtol=1e-5, atol=1e-9, what='cache after invalidate_norms')
 
 
 @pytest.mark.parametrize('opt', ['sgd', 'adam'])

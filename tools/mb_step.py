@@ -15,7 +15,7 @@ dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev); g.manual_seed(2022)
 U = torch.empty(nu, D, device=dev).normal_(0, 0.01, generator=g)
 I = torch.empty(ni, D, device=dev).normal_(0, 0.01, generator=g)
-st = FusedBPRStep(U, I, B, opt='adam', reg_weight=0.01)
+st = FusedBPRStep(U, I, B, opt='adam', reg_weight=float(os.environ.get('CDR_MB_REG', '0.01')))
 half = ni // 2
 def items():
     if not zipf:
@@ -47,6 +47,6 @@ for k, v in kt.items():
 if st.fuse_singles:
     torch.cuda.synchronize()
     c = st.heads[:2].tolist()
-    f = st.flags[:3 * B].view(3, B).float().mean(1).tolist()
+    f = st.flags[:4 * B].view(B, 4).float().mean(0).tolist()
     print('  single fractions u/p/n: %.4f %.4f %.4f; duplicate segments users %d items %d' % (f[0], f[1], f[2], c[0], c[1]))
 print('  loss %.6f' % float(st.out6[0]))
