@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 32
+#define CDR_ABI_VERSION 33
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -306,8 +306,9 @@ int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* src_tab, flo
  *   shared: hp_table (float2 [capacity]: step_size, sqrt(bias correction 2) per update, filled on the device),
  *           counters (int64 [2], zero-initialised: [0] updates completed, [1] update in progress).
  *   cdr_lazy_adam_prepare : BEFORE the forward pass: every distinct row of keys_sorted (per table; cdr_sort_ids / _small) replays its
- *                           postponed updates up to the one before the coming update.  step_host = the coming update's number
- *                           (bounds check against hp_capacity only).
+ *                           postponed updates up to the one before the coming update.  step_host = the coming update's number.
+ *                           hp_table: float2 [hp_capacity], a RING indexed by update number & (hp_capacity - 1) (hp_capacity a
+ *                           power of two): no row may fall hp_capacity updates behind -- the caller flushes at least that often.
  *   cdr_lazy_adam_apply   : AFTER the backward pass: the coming update with gradient sum_occurrences G[perm[e] * ldg .. + D)
  *                           (occurrence order), then counters[0] advances.
  *   cdr_lazy_adam_flush   : every row of one table replays up to counters[0] (evaluation, state_dict, checkpoint).              */
@@ -317,9 +318,9 @@ int cdr_lazy_adam_prepare(void* stream, int count, int D, float* const* W, float
 int cdr_lazy_adam_apply(void* stream, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
                         const uint32_t* const* keys_sorted, const uint32_t* const* perm, const int64_t* n, const float* const* G,
                         const int64_t* ldg, float lr, float beta1, float beta2, float eps, float weight_decay, const void* hp_table,
-                        int64_t* counters);
+                        int64_t hp_capacity, int64_t* counters);
 int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32_t* last, int64_t rows, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, const void* hp_table, const int64_t* counters);
+                        float beta2, float eps, float weight_decay, const void* hp_table, int64_t hp_capacity, const int64_t* counters);
 
 /* ---- CoNet towers fused (conet.py:105-203: source_forward + target_forward + BCELoss x2 + reg) -------------------------
  * One stack of R rows -- rows [0, n_source) are the source batch (user_s, item_s, label_s), the rest the target batch (the two

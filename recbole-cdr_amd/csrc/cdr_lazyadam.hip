@@ -15,6 +15,9 @@
 //   lz_apply_kernel     after the backward pass: update t with the row's summed gradient (occurrence order: deterministic)
 //   lz_flush_kernel     brings EVERY row to the current update (evaluation, state_dict, checkpoint): the postponed sweeps,
 //                       paid once per use instead of once per step
+// The per-update scalars (step size, sqrt of the second bias correction) live in a RING of hp_capacity entries indexed by
+// update number & (hp_capacity - 1): a row may be at most hp_capacity - 1 updates behind, which the host guarantees by flushing
+// every table at least that often (lazyadam.DeferredRowAdam) -- no bound on the number of updates of a run.
 // Memory per step: 3 row reads + 3 row writes per touched row (twice: prepare + apply) instead of 7 x the table.
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
@@ -29,7 +32,7 @@ struct lz_table {
     const uint32_t* keys; const uint32_t* perm; int64_t n;          // sorted ids of the batch's occurrences for this table
     const float* G; int64_t ldg;                                    // gradient of occurrence o: G[o * ldg .. + D)
 };
-struct lz_args { lz_table t[kMaxTab]; int count, D; float lr, b1, b2, eps, wd; };
+struct lz_args { lz_table t[kMaxTab]; int count, D; float lr, b1, b2, eps, wd; int64_t hp_mask; };   // hp is a ring of hp_mask + 1 entries
 
 inline int grid_for(int64_t units, int per_block) {
     int64_t g = (units + per_block - 1) / per_block;
@@ -42,7 +45,7 @@ inline int grid_for(int64_t units, int per_block) {
 __device__ __forceinline__ void replay(float4& w, float4& m, float4& v, int64_t from, int64_t to, const float2* __restrict__ hp,
                                        const lz_args& a) {
     for (int64_t tau = from + 1; tau <= to; ++tau) {
-        const float2 h = hp[tau];
+        const float2 h = hp[tau & a.hp_mask];
         w.x = cdr_adam_elem(w.x, 0.f, m.x, v.x, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
         w.y = cdr_adam_elem(w.y, 0.f, m.y, v.y, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
         w.z = cdr_adam_elem(w.z, 0.f, m.z, v.z, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void lz_prepare_kernel(lz_args a, float2* _
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         float ss, bc;
         cdr_adam_hp((double)t, a.lr, a.b1, a.b2, ss, bc);           // read by lz_apply_kernel (next launch) and by later replays
-        hp[t] = make_float2(ss, bc);
+        hp[t & a.hp_mask] = make_float2(ss, bc);
         counters[1] = t;
     }
     for (int64_t q = gg; q < tb.n; q += TG) {
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void lz_apply_kernel(lz_args a, const float
     const int64_t TG = (int64_t)gridDim.x * GPB;
     const int D = a.D, D4 = D >> 2;
     const int64_t t = counters[1];
-    const float2 h = hp[t];
+    const float2 h = hp[t & a.hp_mask];
     for (int64_t q = gg; q < tb.n; q += TG) {
         const uint32_t row = tb.keys[q];
         if (q > 0 && tb.keys[q - 1] == row) continue;
@@ -150,10 +153,11 @@ __global__ __launch_bounds__(kBlock) void lz_flush_kernel(lz_args a, int64_t row
 
 int fill(lz_args& a, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
          const uint32_t* const* keys, const uint32_t* const* perm, const int64_t* n, const float* const* G, const int64_t* ldg,
-         float lr, float b1, float b2, float eps, float wd, bool need_grads, int64_t* nmax) {
+         float lr, float b1, float b2, float eps, float wd, bool need_grads, int64_t* nmax, int64_t hp_capacity) {
     if (count < 1 || count > kMaxTab || D <= 0 || (D & 3) || !W || !M || !V || !last) return 0;
+    if (hp_capacity < 2 || (hp_capacity & (hp_capacity - 1))) return 0;               // a power of two: the ring index is tau & mask
     a = lz_args{};
-    a.count = count; a.D = D; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
+    a.count = count; a.D = D; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd; a.hp_mask = hp_capacity - 1;
     *nmax = 0;
     for (int i = 0; i < count; ++i) {
         if (!W[i] || !M[i] || !V[i] || !last[i]) return 0;
@@ -177,9 +181,9 @@ extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* cons
                                      int32_t* const* last, const uint32_t* const* keys_sorted, const int64_t* n, float lr, float beta1,
                                      float beta2, float eps, float weight_decay, void* hp_table, int64_t hp_capacity,
                                      int64_t* counters, int64_t step_host) {
-    CDR_CHECK_ARG(hp_table && counters && step_host >= 1 && step_host < hp_capacity);
+    CDR_CHECK_ARG(hp_table && counters && step_host >= 1);
     lz_args a; int64_t nmax;
-    if (!fill(a, count, D, W, M, V, last, keys_sorted, nullptr, n, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax)) {
+    if (!fill(a, count, D, W, M, V, last, keys_sorted, nullptr, n, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax, hp_capacity)) {
         cdr_set_error("cdr_lazy_adam_prepare: bad table description"); return CDR_EINVAL;
     }
     const int lpr = cdr_lpr_for(D);
@@ -192,10 +196,10 @@ extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* cons
 extern "C" int cdr_lazy_adam_apply(void* stream, int count, int D, float* const* W, float* const* M, float* const* V,
                                    int32_t* const* last, const uint32_t* const* keys_sorted, const uint32_t* const* perm,
                                    const int64_t* n, const float* const* G, const int64_t* ldg, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, const void* hp_table, int64_t* counters) {
+                                   float eps, float weight_decay, const void* hp_table, int64_t hp_capacity, int64_t* counters) {
     CDR_CHECK_ARG(hp_table && counters);
     lz_args a; int64_t nmax;
-    if (!fill(a, count, D, W, M, V, last, keys_sorted, perm, n, G, ldg, lr, beta1, beta2, eps, weight_decay, true, &nmax)) {
+    if (!fill(a, count, D, W, M, V, last, keys_sorted, perm, n, G, ldg, lr, beta1, beta2, eps, weight_decay, true, &nmax, hp_capacity)) {
         cdr_set_error("cdr_lazy_adam_apply: bad table description"); return CDR_EINVAL;
     }
     const int lpr = cdr_lpr_for(D);
@@ -208,11 +212,11 @@ extern "C" int cdr_lazy_adam_apply(void* stream, int count, int D, float* const*
 
 extern "C" int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32_t* last, int64_t rows, float lr,
                                    float beta1, float beta2, float eps, float weight_decay, const void* hp_table,
-                                   const int64_t* counters) {
+                                   int64_t hp_capacity, const int64_t* counters) {
     CDR_CHECK_ARG(hp_table && counters && rows > 0);
     lz_args a; int64_t nmax;
     float* Wp[1] = {W}; float* Mp[1] = {M}; float* Vp[1] = {V}; int32_t* lp[1] = {last};
-    if (!fill(a, 1, D, Wp, Mp, Vp, lp, nullptr, nullptr, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax)) {
+    if (!fill(a, 1, D, Wp, Mp, Vp, lp, nullptr, nullptr, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax, hp_capacity)) {
         cdr_set_error("cdr_lazy_adam_flush: bad table description"); return CDR_EINVAL;
     }
     const int lpr = cdr_lpr_for(D);

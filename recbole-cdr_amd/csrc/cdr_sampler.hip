@@ -42,7 +42,25 @@ __global__ __launch_bounds__(kBlock) void neg_sample_kernel(const int64_t* __res
             }
             if (!(l < en && indices[l] == id)) { pick = id; break; }
         }
-        if (pick < 0) { pick = n0 ? lo0 : lo1; if (fail_flag) atomicExch(fail_flag, 1); }
+        if (pick < 0) {
+            // max_tries rejections (a user whose history covers most of the range): the reference's loop would go on until a
+            // draw is free, i.e. it returns a uniform draw over the FREE candidates -- pick the r-th free id directly by walking
+            // the user's sorted history inside the range.  O(history) for this one element; never taken at ordinary densities.
+            auto lower = [&](int64_t x) { int64_t l = b, h = en; while (l < h) { const int64_t m = (l + h) >> 1; if (indices[m] < x) l = m + 1; else h = m; } return l; };
+            const int64_t a0 = n0 ? lower(lo0) : b, z0 = n0 ? lower(hi0) : b, a1 = n1 ? lower(lo1) : b, z1 = n1 ? lower(hi1) : b;
+            const int64_t free0 = n0 - (z0 - a0), free1 = n1 - (z1 - a1);
+            if (free0 + free1 > 0) {
+                const uint64_t r = mix64(seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)max_tries * 0xD1B54A32D192ED03ull);
+                int64_t k_ = (int64_t)__umul64hi(r, (uint64_t)(free0 + free1));
+                int64_t id, p0, p1;
+                if (k_ < free0) { id = lo0 + k_; p0 = a0; p1 = z0; } else { id = lo1 + (k_ - free0); p0 = a1; p1 = z1; }
+                for (int64_t q = p0; q < p1 && indices[q] <= id; ++q) ++id;     // skip the used ids at or below the running candidate
+                pick = id;
+            } else {
+                pick = n0 ? lo0 : lo1;                       // every candidate is used: there is no valid answer (the loaders refuse such users)
+                if (fail_flag) atomicExch(fail_flag, 1);
+            }
+        }
         out[e] = pick;
     }
 }
@@ -74,7 +92,19 @@ __global__ __launch_bounds__(kBlock) void neg_sample_alias_kernel(const int64_t*
             }
             if (!(l < en && indices[l] == id)) { pick = id; break; }
         }
-        if (pick < 0) { pick = keys[0]; if (fail_flag) atomicExch(fail_flag, 1); }
+        if (pick < 0) {
+            // max_tries rejections: scan the alias table's keys cyclically from a random column for one the user has not used
+            // (valid; for this rare element the popularity weighting is given up -- the reference would keep drawing)
+            const uint64_t r = mix64(seed + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)max_tries * 0xD1B54A32D192ED03ull);
+            const int64_t c0 = (int64_t)__umul64hi(r, (uint64_t)n_keys);
+            for (int64_t j = 0; j < n_keys && pick < 0; ++j) {
+                const int64_t id = keys[(c0 + j) % n_keys];
+                int64_t l = b, h = en;
+                while (l < h) { const int64_t mid = (l + h) >> 1; if (indices[mid] < id) l = mid + 1; else h = mid; }
+                if (!(l < en && indices[l] == id)) pick = id;
+            }
+            if (pick < 0) { pick = keys[0]; if (fail_flag) atomicExch(fail_flag, 1); }
+        }
         out[e] = pick;
     }
 }

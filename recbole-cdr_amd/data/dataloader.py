@@ -50,8 +50,6 @@ class DomainTrainLoader:
     def __next__(self):
         if self.pr >= self.pr_end:
             self.pr = 0
-            if hasattr(self.neg_sampler, 'check_failures'):
-                self.neg_sampler.check_failures()        # one host sync per epoch: did any draw fall back to a fixed candidate?
             raise StopIteration()
         cur = self.inter[self.pr:self.pr + self.step]
         self.pr += self.step
@@ -107,8 +105,17 @@ class CrossDomainDataloader:
         self.overlap_dataloader = overlap_dataloader
         self.state = CrossDomainDataLoaderState.BOTH
 
+    def check_samplers(self):
+        """One host sync per epoch, in every mode, at the START of the next epoch (never in the middle of one): did the device
+        sampler meet a user without any free candidate (sampler.DeviceNegSampler.check_failures)?"""
+        for dl in (self.source_dataloader, self.target_dataloader):
+            smp = getattr(dl, 'neg_sampler', None)
+            if smp is not None and hasattr(smp, 'check_failures'):
+                smp.check_failures()
+
     def __iter__(self):
         S = CrossDomainDataLoaderState
+        self.check_samplers()
         if self.state == S.SOURCE:
             return self.source_dataloader.__iter__()
         if self.state == S.TARGET:

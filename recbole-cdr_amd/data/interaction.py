@@ -1,18 +1,31 @@
 """Minimal stand-in for recbole's ``Interaction`` (third-party): a dict of equal-length tensors with
-``[str]`` / ``[slice]`` access, ``to``, ``update`` and ``__len__`` -- the input contract of ``calculate_loss``."""
+``[str]`` / ``[slice]`` access, ``to``, ``update`` and ``__len__`` -- the input contract of ``calculate_loss``.
+
+``k_major`` (None or k) is a layout hint the pairwise loader sets (data/dataloader.py): the rows are S positives tiled k times with
+k-major negatives (crossdomain_sampler.py:148-152).  It survives the operations that keep that layout (``to``, ``update``) and is
+dropped by those that do not (row slicing, ``index_select``, ``repeat``)."""
 
 
 class Interaction(dict):
+    k_major = None
+
     def __getitem__(self, key):
         if isinstance(key, str):
             return dict.__getitem__(self, key)
         return Interaction({k: v[key] for k, v in self.items()})
 
     def to(self, device):
-        return Interaction({k: v.to(device) for k, v in self.items()})
+        out = Interaction({k: v.to(device) for k, v in self.items()})
+        out.k_major = self.k_major
+        return out
 
     def update(self, other):
         dict.update(self, other)
+        ok = getattr(other, 'k_major', None)
+        if ok is not None and (len(self) == 0 or self.k_major in (None, ok)):
+            self.k_major = ok            # BOTH-mode merge (dataloader.py:156-161): both domains' loaders use the same k, or none is kept
+        elif ok != self.k_major:
+            self.k_major = None
         return self
 
     def __len__(self):

@@ -17,7 +17,7 @@ class DeferredRowAdam:
     """``tables``: nn.Parameters [rows, D] (same D).  ``table_list[i]``: which id list of ``prepare(id_lists)`` indexes table i
     (CoNet: [source_user, source_item, target_user, target_item] -> [0, 1, 0, 1] for id lists [user ids, item ids])."""
 
-    def __init__(self, tables, table_list, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capacity=1 << 20):
+    def __init__(self, tables, table_list, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capacity=1 << 16):
         self.tables = list(tables)
         self.table_list = list(table_list)
         assert len(self.tables) == len(self.table_list) and 1 <= len(self.tables) <= 4
@@ -28,8 +28,12 @@ class DeferredRowAdam:
         self.exp_avg = [torch.zeros_like(t.data) for t in self.tables]
         self.exp_avg_sq = [torch.zeros_like(t.data) for t in self.tables]
         self.last = [torch.zeros(t.shape[0], device=dev, dtype=torch.int32) for t in self.tables]
-        self.capacity = int(capacity)
+        # per-update scalars (step size, sqrt(bias correction 2)) in a RING of ``capacity`` entries indexed by update number: a row
+        # may lag at most capacity - 1 updates, which ``_bound_lag`` guarantees by flushing every table before the ring wraps onto
+        # an entry some row still needs -- one O(table) sweep per ``capacity`` / 2 updates, no limit on the length of a run
+        self.capacity = 1 << max(int(capacity) - 1, 1).bit_length()
         self.hp = torch.zeros(self.capacity, 2, device=dev, dtype=torch.float32)
+        self._flushed_at = 0             # update number every row is known to have reached
         self.counters = torch.zeros(2, device=dev, dtype=torch.int64)
         self.step_count = 0              # host mirror of counters[0]
         self.dirty = False               # some row may be behind counters[0]
@@ -83,8 +87,8 @@ class DeferredRowAdam:
         self._sorted = self._sort(id_lists)
         per = [self._sorted[j] for j in self.table_list]
         nT = len(self.tables)
-        if self.step_count + 1 >= self.capacity:
-            raise RuntimeError('DeferredRowAdam: more updates than its bias-correction table holds; raise `capacity`')
+        if not torch.cuda.is_current_stream_capturing():
+            self._bound_lag()
         keep = [[t.data for t in self.tables], self.exp_avg, self.exp_avg_sq, self.last, [k for k, _, _ in per]]
         B_.call('cdr_lazy_adam_prepare', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
                 self._ptrs(keep[3]), self._ptrs(keep[4]), (ctypes.c_int64 * nT)(*[n for _, _, n in per]), self.lr, self.betas[0],
@@ -105,7 +109,7 @@ class DeferredRowAdam:
         B_.call('cdr_lazy_adam_apply', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
                 self._ptrs(keep[3]), self._ptrs(keep[4]), self._ptrs(keep[5]), (ctypes.c_int64 * nT)(*[n for _, _, n in per]), gp,
                 (ctypes.c_int64 * nT)(*([int(ld)] * nT)), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp),
-                B_.i64(self.counters))
+                self.capacity, B_.i64(self.counters))
         del keep
         if not torch.cuda.is_current_stream_capturing():     # a capture only records the launches: replays do the bookkeeping
             self.on_replay()
@@ -114,6 +118,13 @@ class DeferredRowAdam:
         """Host bookkeeping of one completed update (also called after a hipGraph replay of prepare + step)."""
         self.step_count += 1
         self.dirty = True
+        self._bound_lag()
+
+    def _bound_lag(self):
+        """Keep every row less than ``capacity`` updates behind (the ring of per-update scalars): flush when half of it is used.
+        Runs between steps -- also between hipGraph replays, whose launches only ever index the ring modulo its size."""
+        if self.step_count - self._flushed_at >= self.capacity // 2:
+            self.flush()
 
     @torch.no_grad()
     def flush(self):
@@ -122,17 +133,17 @@ class DeferredRowAdam:
             return
         for t, m, v, last in zip(self.tables, self.exp_avg, self.exp_avg_sq, self.last):
             B_.call('cdr_lazy_adam_flush', B_.stream(), self.D, B_.f32(t.data), B_.f32(m), B_.f32(v), B_.raw(last), t.shape[0], self.lr,
-                    self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp), B_.i64(self.counters))
+                    self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp), self.capacity, B_.i64(self.counters))
         self.dirty = False
+        self._flushed_at = self.step_count
 
     def state_dict(self):
         self.flush()
         return {'step': self.step_count, 'exp_avg': [m.clone() for m in self.exp_avg], 'exp_avg_sq': [v.clone() for v in self.exp_avg_sq]}
 
     def load_state_dict(self, sd):
-        """Resume: all rows are current at update ``step``; the bias-correction table is refilled lazily by the coming prepares, so
-        the entries of the past updates are recomputed here on the host with the same double-precision expressions."""
-        import math
+        """Resume: every row is current at update ``step`` (``last`` = ``step`` everywhere), so no entry of the per-update ring from
+        before ``step`` is ever read again; the coming prepares fill it from there."""
         self.step_count = int(sd['step'])
         for m, v, a, b in zip(self.exp_avg, self.exp_avg_sq, sd['exp_avg'], sd['exp_avg_sq']):
             m.copy_(a); v.copy_(b)
@@ -140,3 +151,4 @@ class DeferredRowAdam:
             last.fill_(self.step_count)
         self.counters.fill_(self.step_count)
         self.dirty = False
+        self._flushed_at = self.step_count

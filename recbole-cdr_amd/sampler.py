@@ -64,14 +64,16 @@ class DeviceNegSampler:
     __call__ = sample_by_user_ids
 
     def check_failures(self):
-        """The kernels give up after 64 rejected draws and fall back to the first candidate, raising a device flag (a user whose
-        history covers almost the whole candidate range): the reference's sampler would loop until every draw is valid.  One host
-        sync: call it where that is cheap (the loaders do, once per epoch).  Raises if any fallback happened since the last check."""
+        """After 64 rejected draws the kernels stop drawing and pick a free candidate directly (uniform sampler: a uniform draw over
+        the user's FREE candidates, which is what the reference's redraw loop converges to; popularity sampler: the first unused key
+        from a random column on), so a returned negative is never an interacted item.  The device flag is raised only when a user
+        has NO free candidate at all -- which the constructor refuses for the uniform ranges, and which can still happen for the
+        popularity table (a user who interacted with every item that has any interaction).  One host sync: the loaders call it
+        once per epoch, in every mode."""
         if int(self.fail.item()):
             self.fail.zero_()
-            raise RuntimeError('DeviceNegSampler: a draw was rejected 64 times and fell back to a fixed candidate (a user interacted with '
-                               'nearly every item of the range): the returned negatives may contain an interacted item. Filter such users '
-                               '(`user_inter_num_interval`) as the reference requires.')
+            raise RuntimeError('DeviceNegSampler: a user has interacted with every candidate item; no negative exists for them. '
+                               'Filter such users (`user_inter_num_interval`) as the reference requires.')
 
 
 def build_alias_table(candidates):

@@ -87,6 +87,21 @@ class RowAwareAdam(DenseAdam):
         super().load_state_dict(sd)
         if rows is not None:
             self.row_opt.load_state_dict(rows)
+            return
+        # a checkpoint written by DenseAdam / torch.optim.Adam: the tables' moments sit in the per-parameter state -- take them over
+        # (a dense optimizer leaves every row at the same update count, which is what the row-wise form resumes from)
+        ro = self.row_opt
+        got = [self.state.get(t) for t in ro.tables]
+        if all(st and 'exp_avg' in st for st in got):
+            steps = {int(float(st['step'])) for st in got}
+            if len(steps) != 1:
+                raise ValueError('RowAwareAdam.load_state_dict: the tables carry different update counts (%s); the deferred row-wise '
+                                 'form keeps ONE count for its tables' % sorted(steps))
+            ro.load_state_dict({'step': steps.pop(), 'exp_avg': [st['exp_avg'] for st in got], 'exp_avg_sq': [st['exp_avg_sq'] for st in got]})
+            for t in ro.tables:
+                self.state.pop(t, None)
+        elif any(st and 'exp_avg' in st for st in got):
+            raise ValueError('RowAwareAdam.load_state_dict: optimizer state for only some of the embedding tables')
 
 
 def early_stopping(value, best, cur_step, max_step, bigger=True):
@@ -179,7 +194,12 @@ class Trainer:
             rank, world = self._row_group
         else:
             world, rank = dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
-        return Interaction({k: v[:v.shape[0] - v.shape[0] % world][rank::world].contiguous() for k, v in interaction.items()})
+        out = Interaction({k: v[:v.shape[0] - v.shape[0] % world][rank::world].contiguous() for k, v in interaction.items()})
+        # rows j + m S of a k-major batch: every world-th row is again k-major (S / world positives) when world divides S
+        km, n = getattr(interaction, 'k_major', None), len(interaction)
+        if km and n % km == 0 and (n // km) % world == 0:
+            out.k_major = km
+        return out
 
     def _topk_hits(self, interaction, n_user, history_index, positive_u, positive_i, kmax):
         """Hit matrix [U, kmax] and positives per user from the model's fused mask + top-k (no [U, N] score matrix): the

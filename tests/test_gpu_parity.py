@@ -675,6 +675,9 @@ def test_trainer_rowwise_mode_matches_oracle_rowwise_training():
     trainer.fit(mk())
     assert model.phase == 'OVERLAP' and len(log) == 5
     assert all(p.grad is None for n, p in model.named_parameters() if 'embedding' in n)       # nothing table-sized was built
+    # the loader's k-major layout hint survives Trainer._train_epoch (interaction.to(device)): the per-positive step was used
+    assert ('bprk', 'source', 1) in model._fused['steps'] and ('bprk', 'target', 1) in model._fused['steps'], list(model._fused['steps'])
+    assert ('bpr', 'source') not in model._fused['steps']
     # oracle: same batches, row-wise steps, one state + update count per table across phases
     neg_rng['s'], neg_rng['t'] = np.random.RandomState(1), np.random.RandomState(2)
     tabs = {k: params[f'{k}.weight'] for k in ('source_user_embedding', 'source_item_embedding', 'target_user_embedding',
@@ -820,6 +823,41 @@ def test_conet_fused_ragged_shapes_and_determinism(R, n_s, hidden, D):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+def test_deferred_adam_ring_of_update_scalars_wraps():
+    """The per-update scalars live in a ring (capacity 8 here): 45 updates -- five times round -- stay bit-identical to the dense
+    sweep because the optimizer flushes every table before an entry some row still needs is overwritten; also through
+    state_dict / load_state_dict in the middle, and RowAwareAdam takes over a DENSE optimizer's checkpoint."""
+    from recbole_cdr_amd.lazyadam import DeferredRowAdam
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    gen = torch.Generator().manual_seed(5)
+    D, rows = 32, 300
+    tab = torch.randn(rows, D, generator=gen) * 0.1
+    dense, lazy = torch.nn.Parameter(tab.clone().to(DEV)), torch.nn.Parameter(tab.clone().to(DEV))
+    od = DenseAdam([dense], lr=0.01)
+    ol = DeferredRowAdam([lazy], [0], lr=0.01, capacity=8)
+    assert ol.capacity == 8
+    for step in range(45):
+        n = int(torch.randint(1, 20, (1,), generator=gen))
+        ids = torch.randperm(rows, generator=gen)[:n].to(DEV)
+        G = (torch.randn(n, D, generator=gen) * 1e-2).to(DEV)
+        ol.prepare([ids])
+        g = torch.zeros_like(dense); g[ids] = G
+        dense.grad = g
+        od.step()
+        ol.pending = (G, (0,), D)
+        ol.step()
+        assert ol.step_count - ol._flushed_at < ol.capacity
+        if step == 20:                                           # resume from a checkpoint into a fresh optimizer
+            sd = ol.state_dict()
+            ol2 = DeferredRowAdam([lazy], [0], lr=0.01, capacity=8)
+            ol2.load_state_dict(sd)
+            ol = ol2
+    ol.flush()
+    assert ol.step_count == 45
+    assert torch.equal(dense.data, lazy.data)
+    assert torch.equal(od.state[dense]['exp_avg'], ol.exp_avg[0]) and torch.equal(od.state[dense]['exp_avg_sq'], ol.exp_avg_sq[0])
+
+
 @pytest.mark.parametrize('wd', [0.0, 0.01])
 def test_deferred_adam_is_bit_identical_to_the_dense_sweep(wd):
     """lazyadam.DeferredRowAdam == trainer.DenseAdam (the reference's torch.optim.Adam semantics over whole tables) BIT FOR BIT:
@@ -903,6 +941,16 @@ def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
         assert_close(b, a, rtol=1e-4, atol=0.01 * 1e-1, what=k)           # 0.1 of one Adam update on the ill-conditioned elements
     sd = m_lazy.state_dict()
     assert torch.equal(sd['source_user_embedding.weight'], m_lazy.source_user_embedding.weight.data)
+    # a checkpoint written by the DENSE optimizer resumes in the row-wise form: the tables' moments and update count are taken over
+    m_new = copy.deepcopy(m_dense)
+    o_new = RowAwareAdam(m_new, lr=0.01)
+    o_new.load_state_dict(o_dense.state_dict())
+    assert o_new.row_opt.step_count == 6
+    for t_new, t_old, m_, v_ in zip(o_new.row_opt.tables, m_dense.table_parameters(), o_new.row_opt.exp_avg, o_new.row_opt.exp_avg_sq):
+        assert torch.equal(m_, o_dense.state[t_old]['exp_avg']) and torch.equal(v_, o_dense.state[t_old]['exp_avg_sq'])
+        assert t_new not in o_new.state or not o_new.state[t_new]
+    l_new, l_old = eager(m_new, o_new, batches[0]), eager(m_dense, o_dense, batches[0])
+    assert_close(l_new, l_old, what='loss after resuming a dense checkpoint row-wise')
 
 
 @pytest.mark.parametrize('name', cases('sscdr_'))
@@ -1306,6 +1354,37 @@ def test_device_negative_sampler_constraints_and_distribution():
     assert torch.equal(a, b)
     t = DeviceNegSampler(ds, 'target', ds.t_pairs, DEV).sample_by_user_ids(torch.from_numpy(ds.t_pairs[:100, 0].copy()), None, 3).cpu().numpy()
     assert (t >= 1).all() and (t < 6 + 40).all()
+
+
+def test_device_negative_sampler_dense_history_never_returns_a_used_item():
+    """A user who interacted with all but 3 of 400 candidates: 64 uniform draws all hit used items with probability 0.6, the
+    reference's sampler would simply keep drawing.  The kernel's direct pick of a free candidate keeps every negative valid and
+    uniform over the 3 free items; no failure flag.  Popularity sampler: same user, every draw valid."""
+    from recbole_cdr_amd.sampler import DeviceNegSampler
+    from types import SimpleNamespace
+    ds = SimpleNamespace(num_overlap_item=1, num_target_only_item=400, num_total_item=401 + 50, num_total_user=10)
+    free = {17, 230, 399}
+    pairs = np.array([(3, i) for i in range(1, 401) if i not in free] + [(4, 5), (4, 9)], dtype=np.int64)
+    smp = DeviceNegSampler(ds, 'target', pairs, DEV, seed=3)
+    draws = smp.sample_by_user_ids(torch.full((6000,), 3), None, 2).cpu().numpy()
+    assert set(np.unique(draws).tolist()) == free
+    cnt = np.array([(draws == i).sum() for i in sorted(free)], dtype=np.float64)
+    assert (np.abs(cnt - len(draws) / 3) < 6 * np.sqrt(len(draws) * (1 / 3) * (2 / 3))).all(), cnt
+    smp.check_failures()                                         # nothing to report
+    # source ranges [1, OI) U [OI + TOI, total): a user dense in BOTH ranges
+    ds2 = SimpleNamespace(num_overlap_item=20, num_target_only_item=30, num_total_item=50 + 100, num_total_user=10)
+    cand = list(range(1, 20)) + list(range(50, 150))
+    free2 = {4, 77, 149}
+    pairs2 = np.array([(2, i) for i in cand if i not in free2], dtype=np.int64)
+    smp2 = DeviceNegSampler(ds2, 'source', pairs2, DEV, seed=5)
+    d2 = smp2.sample_by_user_ids(torch.full((3000,), 2), None, 1).cpu().numpy()
+    assert set(np.unique(d2).tolist()) == free2
+    smp2.check_failures()
+    pop = DeviceNegSampler(ds, 'target', np.concatenate([pairs, np.array([(5, i) for i in free], dtype=np.int64)]), DEV, seed=3,
+                           distribution='popularity')
+    dp = pop.sample_by_user_ids(torch.full((2000,), 3), None, 1).cpu().numpy()
+    assert set(np.unique(dp).tolist()) <= free
+    pop.check_failures()
 
 
 def test_end_to_end_emcdr_learns_with_device_sampler():
