@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 33
+#define CDR_ABI_VERSION 34
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -537,6 +537,14 @@ int cdr_sort_ids_two_tables(cdr_ctx* ctx, void* stream, const int64_t* ids_a, in
 int cdr_neg_sample_uniform(void* stream, const int64_t* users, int64_t S, int k, int64_t lo0, int64_t hi0,
                            int64_t lo1, int64_t hi1, const int64_t* used_indptr, const int64_t* used_indices,
                            uint64_t seed, int64_t* out, int* fail_flag);
+/* SSCDR's in-loss sampler (sscdr.py:89-118) on the device: per overlapped id one interacted source-domain entity (uniform over the
+ * id's interaction list, repeats included; an empty list counts as [0]) and one non-interacted candidate of [lo0, hi0) U [lo1, hi1)
+ * (redrawn while it is in the list; after 64 rejections the r-th free candidate is taken directly).  hist = CSR over ids, entries
+ * ascending per id.  calls_dev (optional device int64): the call number mixed into the RNG key, so that a captured launch draws
+ * fresh ids on every replay when the caller bumps it (cdr_inc_i64) behind the launch.                                           */
+int cdr_sscdr_pair_sample(void* stream, const int64_t* ids, int64_t n, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1,
+                          const int64_t* hist_indptr, const int64_t* hist_indices, uint64_t seed, const int64_t* calls_dev,
+                          int64_t* pos_out, int64_t* neg_out, int* fail_flag);
 /* popularity-biased variant (crossdomain_sampler.py:66-114, distribution == 'popularity'): candidates drawn through a Walker
  * alias table over the n_keys distinct items of the sampler's interactions (keys / prob / alias as the reference builds
  * them; alias holds item ids), then the same rejection and layout. */

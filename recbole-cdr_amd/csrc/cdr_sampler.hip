@@ -109,7 +109,85 @@ __global__ __launch_bounds__(kBlock) void neg_sample_alias_kernel(const int64_t*
     }
 }
 
+// SSCDR's in-loss sampler (sscdr.py:89-118) on the device: for every overlapped id one INTERACTED source-domain entity, uniform over
+// the id's interaction list (repeats count, as np.random.choice over the Python list does; an empty list is [0], :98-99,110-111),
+// and one NON-interacted one, uniform over the candidate ids [lo0, hi0) U [lo1, hi1) (= range(overlapped) + range(target_num,
+// total), 0 included) and redrawn while it is in the list.  hist = CSR over ids, entries sorted ascending per id (repeats kept).
+// Counter-based RNG keyed by (seed, call number, element, attempt); the call number may live on the device (calls_dev: read here,
+// bumped by cdr_inc_i64 behind the launch) so that a hipGraph replay of the loss draws fresh ids every time.
+__global__ __launch_bounds__(kBlock) void sscdr_pair_sample_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t lo0, int64_t hi0,
+                                                                   int64_t lo1, int64_t hi1, const int64_t* __restrict__ indptr,
+                                                                   const int64_t* __restrict__ indices, uint64_t seed,
+                                                                   const int64_t* __restrict__ calls_dev, int max_tries,
+                                                                   int64_t* __restrict__ pos_out, int64_t* __restrict__ neg_out,
+                                                                   int* __restrict__ fail_flag) {
+    const int64_t n0 = hi0 > lo0 ? hi0 - lo0 : 0, n1 = hi1 > lo1 ? hi1 - lo1 : 0, ncand = n0 + n1;
+    const uint64_t sd = seed + (calls_dev ? (uint64_t)calls_dev[0] * 0x85EBCA77C2B2AE63ull : 0ull);
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+        const int64_t id = ids[e];
+        const int64_t b = indptr[id], en = indptr[id + 1];
+        const bool empty = en == b;                          // the reference appends 0 to an empty list: interacted = 0, and 0 is "used"
+        const uint64_t r0 = mix64(sd + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
+        pos_out[e] = empty ? 0 : indices[b + (int64_t)__umul64hi(r0, (uint64_t)(en - b))];
+        auto used = [&](int64_t x) {
+            if (empty) return x == 0;
+            int64_t l = b, h = en;
+            while (l < h) { const int64_t m = (l + h) >> 1; if (indices[m] < x) l = m + 1; else h = m; }
+            return l < en && indices[l] == x;
+        };
+        int64_t pick = -1;
+        for (int t = 0; t < max_tries; ++t) {
+            const uint64_t r = mix64(sd + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)t * 0xD1B54A32D192ED03ull);
+            const int64_t c = (int64_t)__umul64hi(r, (uint64_t)ncand);
+            const int64_t x = c < n0 ? lo0 + c : lo1 + (c - n0);
+            if (!used(x)) { pick = x; break; }
+        }
+        if (pick < 0) {
+            // max_tries rejections: the r-th FREE candidate directly (what the redraw loop converges to), walking the DISTINCT used ids
+            auto lower = [&](int64_t x) { int64_t l = b, h = en; while (l < h) { const int64_t m = (l + h) >> 1; if (indices[m] < x) l = m + 1; else h = m; } return l; };
+            auto distinct_in = [&](int64_t lo, int64_t hi) {     // distinct used ids inside [lo, hi)
+                if (hi <= lo) return (int64_t)0;
+                if (empty) return (int64_t)((lo <= 0 && 0 < hi) ? 1 : 0);
+                int64_t c = 0, last = -1;
+                for (int64_t q = lower(lo); q < en && indices[q] < hi; ++q) { if (indices[q] != last) { ++c; last = indices[q]; } }
+                return c;
+            };
+            const int64_t free0 = n0 - distinct_in(lo0, hi0), free1 = n1 - distinct_in(lo1, hi1);
+            if (free0 + free1 > 0) {
+                const uint64_t r = mix64(sd + (uint64_t)(e + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)max_tries * 0xD1B54A32D192ED03ull);
+                int64_t k_ = (int64_t)__umul64hi(r, (uint64_t)(free0 + free1));
+                const bool first = k_ < free0;
+                int64_t x = first ? lo0 + k_ : lo1 + (k_ - free0);
+                const int64_t lo = first ? lo0 : lo1, hi = first ? hi0 : hi1;
+                if (empty) { if (lo <= 0 && 0 <= x) ++x; }
+                else {
+                    int64_t last = -1;
+                    for (int64_t q = lower(lo); q < en && indices[q] < hi && indices[q] <= x; ++q) { if (indices[q] != last) { ++x; last = indices[q]; } }
+                }
+                pick = x;
+            } else {
+                pick = n0 ? lo0 : lo1;
+                if (fail_flag) atomicExch(fail_flag, 1);
+            }
+        }
+        neg_out[e] = pick;
+    }
+}
+
 }  // namespace
+
+extern "C" int cdr_sscdr_pair_sample(void* stream, const int64_t* ids, int64_t n, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1,
+                                     const int64_t* hist_indptr, const int64_t* hist_indices, uint64_t seed, const int64_t* calls_dev,
+                                     int64_t* pos_out, int64_t* neg_out, int* fail_flag) {
+    CDR_CHECK_ARG(ids && n > 0 && hist_indptr && hist_indices && pos_out && neg_out);
+    CDR_CHECK_ARG((hi0 > lo0) || (hi1 > lo1));
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > CDR_NUM_CU * 8) g = CDR_NUM_CU * 8;
+    sscdr_pair_sample_kernel<<<dim3((unsigned)g), dim3(kBlock), 0, (hipStream_t)stream>>>(ids, n, lo0, hi0, lo1, hi1, hist_indptr, hist_indices,
+                                                                                        seed, calls_dev, 64, pos_out, neg_out, fail_flag);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
 
 extern "C" int cdr_neg_sample_alias(void* stream, const int64_t* users, int64_t S, int k, const int64_t* keys, const float* prob,
                                     const int64_t* alias, int64_t n_keys, const int64_t* used_indptr, const int64_t* used_indices,

@@ -4,7 +4,9 @@ Metric-learning losses = row gather -> squared-norm "normalize" -> triplet margi
 backward; the mapping is recbole's ``MLPLayers(..., 'tanh')`` (Linear + Tanh after EVERY layer, the last included --
 SURVEY App. A) on the fp32 MFMA contraction; scoring is the -||u - i||^2 epilogue of the same contraction.
 The semi-supervised (interacted, non-interacted) ids are drawn on the host from numpy's global RNG exactly as the
-reference does inside its loss (sscdr.py:89-118) so that a seeded run samples the same ids.
+reference does inside its loss (sscdr.py:89-118) so that a seeded run samples the same ids -- or, with
+``config['sscdr_device_sampler'] = True``, by a kernel over the device-resident interaction lists (``sample_device``: same
+distribution and constraints, counter-based RNG, no host work inside the loss, so the OVERLAP step replays as a hipGraph).
 """
 import numpy as np
 import torch
@@ -52,6 +54,8 @@ class SSCDR(CrossDomainRecommender):
         self.lamda = config['lambda']
         self.margin = config['margin']
         self.mlp_hidden_size = list(config['mlp_hidden_size'])
+        self.device_sampler = bool(config['sscdr_device_sampler']) if 'sscdr_device_sampler' in config else False
+        self.sampler_seed = int(config['seed']) if 'seed' in config else 2022
         self.mapping_layer = MLPLayers([self.embedding_size] + self.mlp_hidden_size + [self.embedding_size])
         if self.mode == 'overlap_users':
             self.user_interacted_items = self.build_interacted_items(dataset, mode='user')
@@ -106,6 +110,39 @@ class SSCDR(CrossDomainRecommender):
             non_interacted[index] = c
         return torch.from_numpy(interacted).to(self.device), torch.from_numpy(non_interacted).to(self.device)
 
+    def _device_lists(self, mode):
+        """The interaction lists of ``build_interacted_items`` as a device CSR (entries ascending per id, repeats kept), the candidate
+        ranges of sscdr.py:94-95,106-107 and the sampler's device state; built once, from the lists the constructor made."""
+        cache = self.__dict__.setdefault('_dev_lists', {})
+        if mode not in cache:
+            lists = self.user_interacted_items if mode == 'user' else self.item_interacted_users
+            lens = np.fromiter((len(h) for h in lists), dtype=np.int64, count=len(lists))
+            flat = np.fromiter((x for h in lists for x in sorted(h)), dtype=np.int64, count=int(lens.sum()))
+            indptr = np.zeros(len(lists) + 1, dtype=np.int64)
+            np.cumsum(lens, out=indptr[1:])
+            dev = self.source_user_embedding.weight.device
+            if mode == 'user':
+                rng = (0, self.overlapped_num_items, self.target_num_items, self.total_num_items)
+            else:
+                rng = (0, self.overlapped_num_users, self.target_num_users, self.total_num_users)
+            cache[mode] = (torch.from_numpy(indptr).to(dev), torch.from_numpy(flat if flat.size else np.zeros(1, dtype=np.int64)).to(dev), rng,
+                           torch.zeros(1, device=dev, dtype=torch.int64), torch.zeros(1, device=dev, dtype=torch.int32))
+        return cache[mode]
+
+    def sample_device(self, ids, mode='user'):
+        """``sample`` on the device (csrc/cdr_sampler.hip: sscdr_pair_sample_kernel): same distribution -- interacted uniform over the
+        id's interaction list (an empty list counts as [0]), non-interacted uniform over the candidates not in it -- but its own
+        counter-based RNG stream (``config['seed']``, a device call counter), and the cached lists are not mutated."""
+        indptr, indices, (lo0, hi0, lo1, hi1), calls, fail = self._device_lists(mode)
+        ids = ids.reshape(-1).contiguous().to(torch.int64)
+        n = ids.numel()
+        pos = torch.empty(n, device=ids.device, dtype=torch.int64)
+        neg = torch.empty(n, device=ids.device, dtype=torch.int64)
+        B_.call('cdr_sscdr_pair_sample', B_.stream(), B_.i64(ids), n, lo0, hi0, lo1, hi1, B_.i64(indptr), B_.i64(indices),
+                (self.sampler_seed * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF, B_.i64(calls), B_.i64(pos), B_.i64(neg), B_.raw(fail))
+        B_.call('cdr_inc_i64', B_.stream(), B_.i64(calls))
+        return pos, neg
+
     embedding_normalize = staticmethod(F_.sqnorm_normalize)
 
     def set_phase(self, phase):
@@ -133,7 +170,7 @@ class SSCDR(CrossDomainRecommender):
         src = F_.gather_rows(getattr(self, f'source_{a}_embedding').weight, idx)
         tgt = F_.gather_rows(getattr(self, f'target_{a}_embedding').weight, idx)
         loss_s = F_.mse_loss(self.mapping_layer(src), tgt)
-        pos, neg = self.sample(idx, mode=a)
+        pos, neg = self.sample_device(idx, mode=a) if self.device_sampler else self.sample(idx, mode=a)
         other = getattr(self, f'source_{b}_embedding').weight
         mp = self.mapping_layer(F_.gather_rows(other, pos))
         mn = self.mapping_layer(F_.gather_rows(other, neg))

@@ -953,6 +953,83 @@ def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
     assert_close(l_new, l_old, what='loss after resuming a dense checkpoint row-wise')
 
 
+@pytest.mark.parametrize('users_overlap', [True, False])
+def test_sscdr_device_sampler(users_overlap):
+    """config['sscdr_device_sampler']: the in-loss sampler of sscdr.py:89-118 as a kernel over the device-resident interaction
+    lists.  Constraints (interacted id from the id's list -- 0 for an empty list --, non-interacted id a candidate outside it, an id
+    whose list covers almost every candidate included), distribution (chi-square: interacted ~ multiplicity in the list, non-
+    interacted uniform over the free candidates), fresh draws per call, the map loss against the oracle on the ids the kernel drew,
+    and the whole OVERLAP step replayed as a hipGraph (the draws change from replay to replay)."""
+    from oracle import sscdr as o_ss
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.sscdr import SSCDR
+    from recbole_cdr_amd.graph_step import GraphedTrainStep
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    ids = IdSpace(OU=40, TOU=30, SOU=35, OI=1, TOI=60, SOI=70) if users_overlap else IdSpace(OU=1, TOU=30, SOU=35, OI=40, TOI=60, SOI=70)
+    rng = np.random.RandomState(4)
+    nov = ids.OU if users_overlap else ids.OI
+    other_cand = (list(range(ids.OI)) + list(range(ids.OI + ids.TOI, ids.total_num_items))) if users_overlap else \
+        (list(range(ids.OU)) + list(range(ids.OU + ids.TOU, ids.total_num_users)))
+    real = [c for c in other_cand if c != 0]
+    own = rng.randint(1, nov, 600)
+    oth = rng.choice(real, 600)
+    dense_id, empty_id = 7, 9
+    keep = (own != dense_id) & (own != empty_id)
+    own, oth = own[keep], oth[keep]
+    free = set(real[3::17])                                                     # the dense id interacts with everything but these (and 0)
+    dn = np.array([c for c in real if c not in free])
+    own = np.concatenate([own, np.full(len(dn), dense_id), np.full(3, 5)]); oth = np.concatenate([oth, dn, np.full(3, real[0])])   # id 5: a repeated entry
+    pairs = np.stack([own, oth], 1) if users_overlap else np.stack([oth, own], 1)
+    ds = FakeDataset(ids, s_pairs=pairs.astype(np.int64), t_pairs=np.zeros((1, 2), dtype=np.int64))
+    cfg = base_config(DEV, embedding_size=16, margin=0.3, mlp_hidden_size=[24], sscdr_device_sampler=True, seed=11, **{'lambda': 0.5})
+    torch.manual_seed(0)
+    model = SSCDR(cfg, ds).to(DEV)
+    mode = 'user' if users_overlap else 'item'
+    lists = model.user_interacted_items if users_overlap else model.item_interacted_users
+    q = torch.arange(1, nov, device=DEV)
+    pos, neg = model.sample_device(q, mode)
+    pos2, neg2 = model.sample_device(q, mode)
+    assert not (torch.equal(pos, pos2) and torch.equal(neg, neg2))              # the device call counter moved on
+    for i, p_, n_ in zip(q.tolist(), pos.tolist(), neg.tolist()):
+        h = lists[i] if len(lists[i]) else [0]
+        assert p_ in h and n_ in other_cand and n_ not in h, (i, p_, n_)
+    # the dense id: every draw valid, uniform over its free candidates (0 is a candidate too and free for it)
+    d = model.sample_device(torch.full((6000,), dense_id, device=DEV), mode)[1].cpu().numpy()
+    want_free = sorted(free | {0})
+    assert sorted(set(d.tolist())) == want_free
+    cnt = np.array([(d == c).sum() for c in want_free], dtype=np.float64)
+    assert ((cnt - len(d) / len(want_free)) ** 2 / (len(d) / len(want_free))).sum() < len(want_free) + 6 * np.sqrt(2 * len(want_free))
+    # id 5: interacted draws follow the multiplicities of its list
+    p5 = model.sample_device(torch.full((8000,), 5, device=DEV), mode)[0].cpu().numpy()
+    vals, mult = np.unique(np.asarray(lists[5]), return_counts=True)
+    assert sorted(set(p5.tolist())) == sorted(vals.tolist())
+    exp = mult / mult.sum() * len(p5)
+    assert (((np.array([(p5 == v).sum() for v in vals]) - exp) ** 2) / exp).sum() < len(vals) + 6 * np.sqrt(2 * len(vals))
+    assert int(model._device_lists(mode)[4].item()) == 0
+    # the empty id: interacted = 0, and 0 is never its non-interacted draw
+    pe, ne = model.sample_device(torch.full((500,), empty_id, device=DEV), mode)
+    assert bool((pe == 0).all()) and bool((ne != 0).all())
+    # the OVERLAP step as ONE hipGraph: replays draw different ids (the loss moves although the batch does not).  (Captured BEFORE any
+    # eager forward of this test: a forward whose autograd graph -- or its output -- was still alive when a capture ended took the
+    # process down in torch's capture_end on this stack.)
+    model.set_phase('OVERLAP')
+    inter = {'overlap': torch.randperm(nov - 1, device=DEV)[:20].view(-1, 1) + 1}
+    opt = DenseAdam(model.parameters(), lr=0.0)                                 # lr 0: only the sampled ids change between replays
+    g = GraphedTrainStep(model, opt, inter)
+    ls = [float(g.step(inter)) for _ in range(6)]
+    assert len(set(ls)) > 1, ls
+    del g
+    # the loss on the ids the kernel drew == the oracle's map loss on those ids
+    drawn = {}
+    orig = model.sample_device
+    model.sample_device = lambda i_, mode='user': drawn.setdefault('pn', orig(i_, mode))
+    loss = model.calculate_loss(inter).detach()
+    model.sample_device = orig
+    P = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    want = o_ss.calculate_loss(P, ids, {'overlap': inter['overlap'].cpu()}, 'OVERLAP', 0.3, 0.5, drawn['pn'][0].cpu(), drawn['pn'][1].cpu())
+    assert_close(loss, want, what='map loss with device-sampled ids')
+
+
 @pytest.mark.parametrize('name', cases('sscdr_'))
 def test_sscdr_golden(name):
     from recbole_cdr_amd.model.cross_domain_recommender.sscdr import SSCDR

@@ -99,6 +99,9 @@ def main():
         ('SSCDR-triplet', SSCDR, {'embedding_size': 64, 'margin': 0.2, 'mlp_hidden_size': [128], 'lambda': 0.1}, True, 'TARGET',
          lambda P, b, m: o_ss.calculate_loss(P, ids, b, 'TARGET', 0.2, 0.1)),
         ('SSCDR-map', SSCDR, {'embedding_size': 64, 'margin': 0.2, 'mlp_hidden_size': [128], 'lambda': 0.1}, True, 'OVERLAP', None),
+        # ... and with the in-loss sampler on the device (config['sscdr_device_sampler']): no host work inside the loss, capturable
+        ('SSCDR-map-device-sampler', SSCDR, {'embedding_size': 64, 'margin': 0.2, 'mlp_hidden_size': [128], 'lambda': 0.1, 'sscdr_device_sampler': True},
+         True, 'OVERLAP', None),
     ]
     for name, cls, kw, pairwise, phase, oracle_loss in cases:
         torch.manual_seed(0)
@@ -108,7 +111,7 @@ def main():
         model.train()
         opt = DenseAdam(model.parameters(), lr=1e-3)
         b = {k: v.to(DEV) for k, v in batch(ids, B, pairwise, rng).items()}
-        if name == 'SSCDR-map':
+        if name.startswith('SSCDR-map'):
             b['overlap'] = torch.from_numpy(rng.choice(np.arange(1, ids.OI), 100, replace=False)).view(-1, 1).to(DEV)    # OB = 100 (default)
 
         def eager():
@@ -126,7 +129,7 @@ def main():
             t_graph = timed(lambda: g.graph.replay(), a.steps)
         except Exception as e:                                     # noqa: BLE001 -- report, do not hide
             t_graph = f'not capturable: {type(e).__name__}: {e}'
-        row = {'model': name, 'rows_per_step': 100 if name == 'SSCDR-map' else B if name in ('NATR-phase2', 'DCDCSR-BPR', 'SSCDR-triplet') else 2 * B,
+        row = {'model': name, 'rows_per_step': 100 if name.startswith('SSCDR-map') else B if name in ('NATR-phase2', 'DCDCSR-BPR', 'SSCDR-triplet') else 2 * B,
                'eager_ms': round(t_eager, 4), 'graph_ms': t_graph if isinstance(t_graph, str) else round(t_graph, 4)}
         if not a.no_cpu and (oracle_loss is not None or name == 'NATR-phase2'):
             P = {k: v.detach().cpu().clone().requires_grad_(v.requires_grad) for k, v in model.named_parameters()}
