@@ -148,69 +148,32 @@ def run_c5(args, world, rank, dev):
     OU = n_users
     gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
     sharded = world > 1 or args.force_shard
-    dim_mode = sharded and args.shard == 'dim'
-    if dim_mode and D % (4 * (world // 2 if world % 2 == 0 and not args.no_domain_groups else world)):
-        dim_mode = False                            # the column cut needs float4-wide slices: fall back to the row exchange
-        print('bench: --dim %d does not cut into float4 slices over %d ranks; using --shard row' % (D, world), file=sys.stderr)
-    dom_groups = dim_mode and world >= 2 and world % 2 == 0 and not args.no_domain_groups
+    lay = None
+    if sharded:
+        # which groups / step objects / streams every rank builds, and how a step drives them, lives in the package
+        # (recbole_cdr_amd/c5_layouts.py) so that the CPU gloo tests run this exact sequence with stand-in arithmetic
+        from recbole_cdr_amd import c5_layouts
+        mode, _ = c5_layouts.resolve(world, args.shard, D, not args.no_domain_groups)
+        if args.shard == 'dim' and mode == 'row':
+            print('bench: --dim %d does not cut into float4 slices over %d ranks; using --shard row' % (D, world), file=sys.stderr)
+
+        def make_table(name, rows, cols, total_cols):
+            total_rows = n_users if name[1] == 'u' else n_items
+            return torch.empty(rows, cols, device=dev, dtype=torch.float32).normal_(0.0, (2.0 / (total_rows + total_cols)) ** 0.5, generator=gen)
+        lay = c5_layouts.build(world, rank, args.shard, D, B, n_users, n_items, make_table, dict(opt=args.opt, reg_weight=0.01),
+                               domain_groups=not args.no_domain_groups, pipeline=not args.no_pipeline, dedup=not args.no_dedup, device=dev)
+        steps, tabs = lay.steps, lay.tabs
+    dim_mode = sharded and lay.mode in ('dim', 'dim-groups')
+    dom_groups = sharded and lay.mode == 'dim-groups'
     if dom_groups:
-        # The SOURCE and the TARGET step share nothing (disjoint tables, disjoint optimizer state), so each domain gets one half of
-        # the node: ranks [0, N/2) hold the source tables in N/2 column slices, ranks [N/2, N) the target tables, and every rank
-        # brings 2 B triples of ITS domain per step (same rows per rank and per step as "B of each domain").  Twice the slice
-        # width of sharding both domains over all N ranks (128-byte row slices at N = 8 instead of 64) and half the replicated
-        # index work; measured kernel-side efficiency 1.00 / 0.93 / 0.84 at N = 2 / 4 / 8.
-        import torch.distributed as dist
-        from recbole_cdr_amd.dimshard import DimShardedBPRStep
-        half = world // 2
-        if D % (4 * half):
-            raise SystemExit('--shard dim needs --dim to be a multiple of 4 x N/2')
-        Ds = D // half
-        dgroups = {'source': dist.new_group(list(range(half))), 'target': dist.new_group(list(range(half, world)))}
-        my_dom = 'source' if rank < half else 'target'
-        tabs = {}
-        for k, r in ((my_dom[0] + 'u', n_users), (my_dom[0] + 'i', n_items)):
-            tabs[k] = torch.empty(r, Ds, device=dev, dtype=torch.float32).normal_(0.0, (2.0 / (r + D)) ** 0.5, generator=gen)
-        if half == 1:
-            st = FusedBPRStep(tabs[my_dom[0] + 'u'], tabs[my_dom[0] + 'i'], 2 * B, opt=args.opt, reg_weight=0.01)
-            st.profile, st.exchange_stats, st.loss_value = (lambda on=True: None), (lambda: (0, 0.0)), (lambda st=st: st.out6[0])
-        else:
-            st = DimShardedBPRStep(tabs[my_dom[0] + 'u'], tabs[my_dom[0] + 'i'], 2 * B, opt=args.opt, reg_weight=0.01, group=dgroups[my_dom])
-        steps = {my_dom: st}
+        half, my_dom, Ds = lay.half, lay.my_dom, lay.Ds
     elif dim_mode:
-        import torch.distributed as dist
-        from recbole_cdr_amd.dimshard import DimShardedBPRStep
-        if D % (4 * world):
-            raise SystemExit('--shard dim needs --dim to be a multiple of 4 x N')
-        Ds = D // world
-        tabs = {}
-        for k, r in (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items)):
-            tabs[k] = torch.empty(r, Ds, device=dev, dtype=torch.float32).normal_(0.0, (2.0 / (r + D)) ** 0.5, generator=gen)
-        # one process group (= one RCCL communicator) and one HIP stream per domain: the two domain steps touch disjoint
-        # tables and have no host sync inside, so they simply queue up side by side and one's collectives overlap the other's kernels
-        groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
-        streams = {d: (None if args.no_pipeline else torch.cuda.Stream(device=dev)) for d in ('source', 'target')}
-        steps = {'source': DimShardedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01, group=groups['source'],
-                                             stream=streams['source']),
-                 'target': DimShardedBPRStep(tabs['tu'], tabs['ti'], B, opt=args.opt, reg_weight=0.01, group=groups['target'],
-                                             stream=streams['target'])}
-    elif not sharded:
+        Ds = lay.Ds
+    if not sharded:
         tabs = {k: xavier_table(r, D, r, gen, dev) for k, r in
                 (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
         steps = {'source': FusedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01),
                  'target': FusedBPRStep(tabs['tu'], tabs['ti'], B, opt=args.opt, reg_weight=0.01)}
-    else:
-        import torch.distributed as dist
-        from recbole_cdr_amd.shard import ShardedBPRStep, shard_rows, run_pipelined
-        tabs = {k: xavier_table(shard_rows(r, world, rank), D, r, gen, dev) for k, r in
-                (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
-        # one process group (= one RCCL communicator + stream) and one HIP stream per domain: the SOURCE and TARGET
-        # steps touch disjoint tables, so one domain's all-to-alls overlap the other's kernels
-        groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
-        streams = {d: (None if args.no_pipeline else torch.cuda.Stream(device=dev)) for d in ('source', 'target')}
-        steps = {'source': ShardedBPRStep(tabs['su'], tabs['si'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
-                                          group=groups['source'], stream=streams['source'], dedup=not args.no_dedup),
-                 'target': ShardedBPRStep(tabs['tu'], tabs['ti'], n_users, n_items, B, opt=args.opt, reg_weight=0.01,
-                                          group=groups['target'], stream=streams['target'], dedup=not args.no_dedup)}
 
     # synthetic interaction streams: users ~ U{1..OU-1}; target items [1, TOI], source items [TOI+1, 2 TOI]
     pool = 4
@@ -230,17 +193,12 @@ def run_c5(args, world, rank, dev):
     from recbole_cdr_amd import binding as B_
 
     def one_step(i):
+        if lay is not None:
+            lay.run(batches, i)
+            return
         b = batches[i % pool]
-        if dom_groups:
-            if half > 1:                      # the next batch's id all-gather starts under this step's kernels
-                steps[my_dom].step(*b[my_dom], next_batch=batches[(i + 1) % pool][my_dom])
-            else:
-                steps[my_dom].step(*b[my_dom])
-        elif sharded and not dim_mode and not args.no_pipeline:
-            run_pipelined([steps[dom].step_gen(*b[dom]) for dom in ('source', 'target')])
-        else:
-            for dom in ('source', 'target'):
-                steps[dom].step(*b[dom])
+        for dom in ('source', 'target'):
+            steps[dom].step(*b[dom])
 
     if sharded:
         # communicators are created lazily by their first collective (seconds, once): two set-up steps take that out of the way

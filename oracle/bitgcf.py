@@ -3,7 +3,7 @@ bitgcf.py: get_norm_adj_mat :92-116, graph_layer :130-135, transfer_layer :137-1
 calculate_loss :207-250, predict :252-262, full_sort_predict :264-272.
 
 params: {source,target}_{user,item}_embedding.weight.  ``graph`` (see build_graph) carries the two normalised
-adjacencies and the four degree vectors.  Dropout is taken as identity (drop_rate=0 / eval): with p>0 the reference
+adjacencies and the four degree vectors.  Dropout is identity unless explicit masks are passed (``forward(masks=...)``): with p>0 the reference
 draws from torch's global generator, which is not reproducible outside its own process.
 """
 import numpy as np
@@ -64,13 +64,18 @@ def transfer_layer(ids, graph, S, T, lam_s, lam_t):
     return torch.cat([s_u, s_i], dim=0), torch.cat([t_u, t_i], dim=0)
 
 
-def forward(params, ids, graph, n_layers, lam_s, lam_t, connect_way):
+def forward(params, ids, graph, n_layers, lam_s, lam_t, connect_way, masks=None):
+    """``masks`` (optional): {(layer, 's' | 't'): [n_users + n_items, D] tensor of 0 or 1 / (1 - p)} -- nn.Dropout(p) of the graph
+    layer's output in training mode (bitgcf.py:66,134) with the mask given explicitly (the reference draws it from torch's global
+    generator; a test hands over the mask the product drew so that values, not only statistics, can be compared)."""
     S = torch.cat([params['source_user_embedding.weight'], params['source_item_embedding.weight']], dim=0)
     T = torch.cat([params['target_user_embedding.weight'], params['target_item_embedding.weight']], dim=0)
     s_list, t_list = [S], [T]
-    for _ in range(n_layers):
+    for l in range(n_layers):
         S = graph_layer(graph['source_adj'], S)
         T = graph_layer(graph['target_adj'], T)
+        if masks is not None:
+            S, T = S * masks[(l, 's')], T * masks[(l, 't')]
         S, T = transfer_layer(ids, graph, S, T, lam_s, lam_t)
         s_list.append(F.normalize(S, p=2, dim=1))      # normalised copies are stacked, raw ones continue (Q10)
         t_list.append(F.normalize(T, p=2, dim=1))
@@ -84,8 +89,8 @@ def forward(params, ids, graph, n_layers, lam_s, lam_t, connect_way):
     return su, si, tu, ti
 
 
-def calculate_loss(params, ids, graph, inter, n_layers, lam_s, lam_t, connect_way, reg_weight):
-    su_all, si_all, tu_all, ti_all = forward(params, ids, graph, n_layers, lam_s, lam_t, connect_way)
+def calculate_loss(params, ids, graph, inter, n_layers, lam_s, lam_t, connect_way, reg_weight, masks=None):
+    su_all, si_all, tu_all, ti_all = forward(params, ids, graph, n_layers, lam_s, lam_t, connect_way, masks)
     out = []
     for d, ua, ia in (('source', su_all, si_all), ('target', tu_all, ti_all)):
         u, i, y = inter[f'{d}_user_id'], inter[f'{d}_item_id'], inter[f'{d}_label']

@@ -202,11 +202,21 @@ class ShardedBiTGCF:
 
     # ---- collectives -------------------------------------------------------------------------------------------------
     def gather(self, x):
+        return self.gather_finish(self.gather_start(x))
+
+    def gather_start(self, x):
+        """Issue the all-gather of this rank's rows and return a handle: the two domains of a layer are independent until the
+        transfer, so both gathers are issued before the first SpMM and the second one travels under it (``gather_finish``)."""
         if self.G == 1:
-            return x
+            return x, None
         x = x.contiguous()
         out = torch.empty((self.G * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
-        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out, (dist.all_gather_into_tensor(out, x, group=self.group, async_op=True), x)     # x kept alive until the wait
+
+    def gather_finish(self, handle):
+        out, work = handle
+        if work is not None:
+            work[0].wait()                      # stream-level wait on the GPU: the host does not block
         return out
 
     # ---- propagation ---------------------------------------------------------------------------------------------------
@@ -222,14 +232,15 @@ class ShardedBiTGCF:
             seeds = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 40).item()) + (self.rank << 44)
         self._seeds = seeds
         for _ in range(self.L):
-            Eg = {d: self.gather(E[d]) for d in 'st'}
-            if E0_g is None:
-                E0_g = Eg
-            side, new = {}, {}
+            pend = {d: self.gather_start(E[d]) for d in 'st'}       # both in flight; 't' arrives under the SpMM of 's'
+            Eg, side, new = {}, {}, {}
             for k, d in enumerate('st'):
+                Eg[d] = self.gather_finish(pend[d])
                 side[d], new[d] = ops.graph_layer_fwd(self.csr[d], Eg[d], E[d])
                 if seeds is not None:                       # one counter-based mask per (layer, domain, rank); re-made in the backward
                     new[d] = ops.dropout(new[d], self.drop_rate, seeds + 2 * len(saved) + k)
+            if E0_g is None:
+                E0_g = Eg
             Su, Tu = ops.transfer_fwd(new['s'][:p.bu], new['t'][:p.bu], self.deg['su'], self.deg['tu'], self.OU_l, self.lam_s, self.lam_t)
             Si, Ti = ops.transfer_fwd(new['s'][p.bu:], new['t'][p.bu:], self.deg['si'], self.deg['ti'], self.OI_l, self.lam_s, self.lam_t)
             S2 = {'s': torch.cat([Su, Si], 0), 't': torch.cat([Tu, Ti], 0)}
@@ -255,8 +266,9 @@ class ShardedBiTGCF:
         out, E0_g, saved, nb = self._propagate()
         losses, g_out, g_E0 = [], {}, {}
         seg = slice(self.rank * p.nl, (self.rank + 1) * p.nl)
+        pend = {d: self.gather_start(out[d]) for d in 'st'}         # the target stack arrives under the source batch loss
         for d, pre in (('s', 'source'), ('t', 'target')):
-            out_g = self.gather(out[d])
+            out_g = self.gather_finish(pend[d])
             pu, pi = p.user_pos(inter[f'{pre}_user_id'].reshape(-1)), p.item_pos(inter[f'{pre}_item_id'].reshape(-1))
             loss, go, ge = ops.batch_loss(out_g, E0_g[d], pu, pi, inter[f'{pre}_label'].reshape(-1).float(), self.reg_weight)
             losses.append(loss)
@@ -278,9 +290,9 @@ class ShardedBiTGCF:
             gnew = {'s': torch.cat([gSu, gSi], 0), 't': torch.cat([gTu, gTi], 0)}
             if self._seeds is not None:
                 gnew = {d: ops.dropout(gnew[d], self.drop_rate, self._seeds + 2 * l + k) for k, d in enumerate('st')}
+            pend = {d: self.gather_start(ops.mul_one_plus(gnew[d], E[d])) for d in 'st'}   # A is symmetric: A^T g = A g on the gathered g (1 + E)
             for d in 'st':
-                tmp_g = self.gather(ops.mul_one_plus(gnew[d], E[d]))          # A is symmetric: A^T g = A g on the gathered g (1 + E)
-                g_next[d] = ops.graph_layer_bwd(self.csr[d], tmp_g, gnew[d], side[d])
+                g_next[d] = ops.graph_layer_bwd(self.csr[d], self.gather_finish(pend[d]), gnew[d], side[d])
         for d, names in (('s', self.TABLES[:2]), ('t', self.TABLES[2:])):
             g = g_blk[d][0] + g_E0[d]
             if g_next[d] is not None:

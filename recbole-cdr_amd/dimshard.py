@@ -430,10 +430,13 @@ class _DimShardedStep:
         not depend on the model).  ``step`` recognises the batch by identity of ``a`` and picks the gathered ids up."""
         if not (self.world > 1 or (self.force_collectives and dist.is_initialized())):
             return
+        slot = 1 - self._cur
+        if not self.U.is_cuda:                       # CPU (gloo tests): the same double-buffered hand-over, exchanged in place
+            self._pf = (a, slot, self._exchange(slot, a, b, c), None)
+            return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.U.device)
         self._side.wait_stream(torch.cuda.current_stream())
-        slot = 1 - self._cur
         with torch.cuda.stream(self._side):
             got = self._exchange(slot, a, b, c)
             ev = torch.cuda.Event()
@@ -463,7 +466,8 @@ class _DimShardedStep:
             if comm:
                 if self._pf is not None and self._pf[0] is a:
                     _a, slot, (a, b, c), ev = self._pf
-                    torch.cuda.current_stream().wait_event(ev)
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
                     self._cur = slot
                 else:
                     a, b, c = self._exchange(self._cur, a, b, c)

@@ -23,14 +23,7 @@ class CoNet(CrossDomainRecommender):
         super().__init__(config, dataset)
         self.SOURCE_LABEL = dataset.source_domain_dataset.label_field
         self.TARGET_LABEL = dataset.target_domain_dataset.label_field
-        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
-            "CoNet model only support user overlapped or item overlapped dataset! "
-        if self.overlapped_num_users > 1:
-            self.mode = 'overlap_users'
-        elif self.overlapped_num_items > 1:
-            self.mode = 'overlap_items'
-        else:
-            self.mode = 'non_overlap'
+        self.mode = self.one_sided_overlap_mode()
         self.latent_dim = config['embedding_size']
         self.reg_weight = config['reg_weight']
         self.cross_layers = list(config["mlp_hidden_size"])

@@ -26,18 +26,11 @@ class DCDCSR(CrossDomainRecommender):
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
-        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
-            "DCDCSR model only support user overlapped or item overlapped dataset! "
-        if self.overlapped_num_users > 1:
-            self.mode = 'overlap_users'
-        elif self.overlapped_num_items > 1:
-            self.mode = 'overlap_items'
-        else:
-            self.mode = 'non_overlap'
+        self.mode = self.one_sided_overlap_mode()
         self.phase = None
         self.phase2count = {'SOURCE': 0, 'TARGET': 0, 'BOTH': 0, 'OVERLAP': 0}
         self.latent_factor_model = config['latent_factor_model']
-        assert self.latent_factor_model in ['BPR'], "latent_factor model must be in [BPR]"
+        assert self.latent_factor_model in ['BPR'], f'DCDCSR trains its latent factors with BPR only (latent_factor_model={self.latent_factor_model!r})'
         self.embedding_size = config['embedding_size']
         self.mlp_hidden_size = list(config['mlp_hidden_size'])
         self.k = config['k']

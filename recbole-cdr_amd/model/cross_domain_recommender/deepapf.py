@@ -22,14 +22,7 @@ class DeepAPF(CrossDomainRecommender):
         super().__init__(config, dataset)
         self.SOURCE_LABEL = dataset.source_domain_dataset.label_field
         self.TARGET_LABEL = dataset.target_domain_dataset.label_field
-        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
-            "DeepAPF model only support user overlapped or item overlapped dataset! "
-        if self.overlapped_num_users > 1:
-            self.mode = 'overlap_users'
-        elif self.overlapped_num_items > 1:
-            self.mode = 'overlap_items'
-        else:
-            self.mode = 'non_overlap'
+        self.mode = self.one_sided_overlap_mode()
         self.embedding_size = config['embedding_size']
         self.beta = config['beta']
 

@@ -73,7 +73,7 @@ class DTCDR(CrossDomainRecommender):
         self.dropout_prob = config['dropout_prob']
         self.base_model = config['base_model']
         self.alpha = config['alpha']
-        assert self.base_model in ['NeuMF', 'DMF'], "based model {} is not supported! ".format(self.base_model)
+        assert self.base_model in ['NeuMF', 'DMF'], f'DTCDR base_model must be NeuMF or DMF, got {self.base_model!r}'
         if self.base_model != 'NeuMF':
             raise NotImplementedError("DTCDR base_model 'DMF' is not provided by this build (see the module docstring)")
 

@@ -20,14 +20,7 @@ class EMCDR(CrossDomainRecommender):
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
-        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
-            "EMCDR model only support user overlapped or item overlapped dataset! "
-        if self.overlapped_num_users > 1:
-            self.mode = 'overlap_users'
-        elif self.overlapped_num_items > 1:
-            self.mode = 'overlap_items'
-        else:
-            self.mode = 'non_overlap'
+        self.mode = self.one_sided_overlap_mode()
         self.phase = 'both'
 
         self.latent_factor_model = config['latent_factor_model']

@@ -41,14 +41,7 @@ class SSCDR(CrossDomainRecommender):
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
-        assert self.overlapped_num_items == 1 or self.overlapped_num_users == 1, \
-            "SSCDR model only support user overlapped or item overlapped dataset! "
-        if self.overlapped_num_users > 1:
-            self.mode = 'overlap_users'
-        elif self.overlapped_num_items > 1:
-            self.mode = 'overlap_items'
-        else:
-            self.mode = 'non_overlap'
+        self.mode = self.one_sided_overlap_mode()
         self.phase = None
         self.embedding_size = config['embedding_size']
         self.lamda = config['lambda']

@@ -44,6 +44,15 @@ class CrossDomainRecommender(nn.Module):
         self.OVERLAP_ID = dataset.overlap_id_field
         self.device = config['device']
 
+    def one_sided_overlap_mode(self):
+        """'overlap_users' | 'overlap_items' | 'non_overlap' for the models that need the domains to share EITHER users OR items
+        (emcdr.py:33-40 and the same guard in conet / sscdr / natr / deepapf / dcdcsr).  An overlap count of 1 is the PAD id alone."""
+        nu, ni = self.overlapped_num_users, self.overlapped_num_items
+        if nu > 1 and ni > 1:
+            raise AssertionError(f'{type(self).__name__} handles a user-overlapped or an item-overlapped pair of domains, not both '
+                                 f'({nu - 1} shared users and {ni - 1} shared items in this dataset)')
+        return 'overlap_users' if nu > 1 else 'overlap_items' if ni > 1 else 'non_overlap'
+
     def set_phase(self, phase):
         pass
 

@@ -1101,6 +1101,61 @@ def test_bitgcf_golden(name):
     assert torch.equal(tv, torch.topk(full, 3, dim=1).values) and torch.equal(torch.gather(full, 1, ti), tv)
 
 
+@pytest.mark.parametrize('sparse_last,connect_way', [(True, 'concat'), (False, 'concat'), (True, 'mean')])
+def test_bitgcf_training_dropout_value_parity_with_the_same_mask(sparse_last, connect_way):
+    """BiTGCF at the setting the C4 bench runs (drop_rate = 0.3, training mode): VALUES, not only statistics.  The product's
+    counter-based mask of every (layer, domain) is exported with cdr_dropout_dev on a tensor of ones -- same seed state, same salt,
+    same element index as the fused mix kernels use -- and handed to the oracle's forward (bitgcf.py:66,134 with an explicit mask):
+    both losses and all four table gradients at 1e-5, with the last layer restricted to the batch's rows and without."""
+    from oracle import bitgcf as obit
+    from oracle.common import IdSpace
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    ids = IdSpace(OU=30, TOU=25, SOU=20, OI=1, TOI=40, SOI=35)
+    rng = np.random.RandomState(2)
+    D, L, p = 16, 2, 0.3
+    su_ = np.r_[1:ids.OU, ids.OU + ids.TOU:ids.total_num_users]; si_ = np.r_[ids.OI + ids.TOI:ids.total_num_items]
+    tu_ = np.r_[1:ids.OU + ids.TOU]; ti_ = np.r_[1:ids.OI + ids.TOI]
+    s_pairs = np.unique(np.stack([rng.choice(su_, 400), rng.choice(si_, 400)], 1), axis=0)
+    t_pairs = np.unique(np.stack([rng.choice(tu_, 500), rng.choice(ti_, 500)], 1), axis=0)
+    ds = FakeDataset(ids, s_pairs=s_pairs.astype(np.int64), t_pairs=t_pairs.astype(np.int64))
+    cfg = base_config(DEV, embedding_size=D, n_layers=L, reg_weight=1e-3, lambda_source=0.8, lambda_target=0.7, drop_rate=p,
+                      connect_way=connect_way, bitgcf_sparse_last_layer=sparse_last)
+    torch.manual_seed(1)
+    model = BiTGCF(cfg, ds).to(DEV)
+    model.train()
+    B = 64
+    inter = {'source_user_id': torch.from_numpy(rng.choice(su_, B)), 'source_item_id': torch.from_numpy(rng.choice(si_, B)),
+             'source_label': torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32)),
+             'target_user_id': torch.from_numpy(rng.choice(tu_, B)), 'target_item_id': torch.from_numpy(rng.choice(ti_, B)),
+             'target_label': torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32))}
+    # the seed the model will draw for this forward (bitgcf._dropout_args: one draw from torch's CPU generator per training forward)
+    torch.manual_seed(77)
+    seed_val = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())
+    seed = torch.full((1,), seed_val, device=DEV, dtype=torch.int64)
+    n = ids.total_num_users + ids.total_num_items
+    ones = torch.ones(n, D, device=DEV)
+    masks = {}
+    for l in range(L):
+        for k, d in enumerate('st'):
+            m = torch.empty_like(ones)
+            B_.call('cdr_dropout_dev', B_.stream(), B_.f32(ones), ones.numel(), p, B_.i64(seed), 2 * l + k, B_.f32(m))
+            masks[(l, d)] = m.cpu()
+            kept = float((m != 0).float().mean())
+            assert abs(kept - (1 - p)) < 0.05 and bool(((m == 0) | ((m - 1 / (1 - p)).abs() < 1e-6)).all())
+    torch.manual_seed(77)
+    losses = model.calculate_loss(to_dev(inter, DEV))
+    assert int(model._drop_state.item()) == seed_val
+    sum(losses).sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    graph = obit.build_graph(s_pairs, t_pairs, ids.total_num_users, ids.total_num_items)
+    want = obit.calculate_loss(P, ids, graph, inter, L, 0.8, 0.7, connect_way, 1e-3, masks=masks)
+    assert_close(torch.stack([x.reshape(()) for x in losses]), torch.stack([x.detach().reshape(()) for x in want]), what='losses under dropout')
+    sum(want).sum().backward()
+    for k, v in model.named_parameters():
+        assert_close(v.grad, P[k].grad, what=f'grad {k} under dropout')
+
+
 @pytest.mark.parametrize('U,N,D', [(1, 1000, 128), (3, 777, 64), (4, 5000, 128), (33, 4133, 128), (64, 6400, 64), (100, 8229, 128),
                                    (300, 20011, 64), (130, 63, 128), (40, 2000, 32)])
 def test_fullsort_paths_vs_fp64(U, N, D):

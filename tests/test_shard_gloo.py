@@ -736,3 +736,93 @@ def test_row_sharded_bitgcf_matches_single_process(world, connect_way):
             torch.testing.assert_close(torch.from_numpy(full[k]), v.detach(), rtol=1e-5, atol=0.01 * 1e-2)
         for a, b in zip(got_prop, prop):
             torch.testing.assert_close(torch.from_numpy(a), b, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N for C5, as the package lays it out (recbole_cdr_amd/c5_layouts.py: the SAME group creation, step objects,
+# prefetched id exchange and two-domain pipelining bench.py runs), under gloo on CPU with stand-in arithmetic.
+def _worker_layout(rank, world, port, layout, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd import c5_layouts
+        from recbole_cdr_amd.dimshard import dim_shard_of
+        from recbole_cdr_amd.shard import shard_of
+        nu, ni, D, B, reg, lr = 47, 31, 16, 11, 0.03, 0.05
+        torch.manual_seed(0)
+        full = {k: torch.randn(r, D) * 0.3 for k, r in (('su', nu), ('si', ni), ('tu', nu), ('ti', ni))}
+        mode, Ds = c5_layouts.resolve(world, layout, D)
+
+        def make_table(name, rows, cols, total_cols):
+            if mode == 'row':
+                t = shard_of(full[name], world, rank)
+            else:
+                G = world // 2 if mode == 'dim-groups' else world
+                t = dim_shard_of(full[name], G, rank % G)
+            assert tuple(t.shape) == (rows, cols), (name, t.shape, rows, cols)
+            return t.clone()
+        hp = {'lr': lr, 'b1': 0.9, 'b2': 0.999, 'eps': 1e-8, 'wd': 0.0}
+        lay = c5_layouts.build(world, rank, layout, D, B, nu, ni, make_table, dict(opt='adam', lr=lr, reg_weight=reg), device='cpu',
+                               dim_ops=lambda U, I, mb: OracleDimOps(U, I, 1, hp, 1e-10, reg), row_ops=OracleOps)
+        assert lay.mode == mode
+        doms = lay.rank_domains()
+        nb = 2 * B if mode == 'dim-groups' else B
+        pool = []
+        for it in range(3):
+            b = {}
+            for d in doms:
+                g = torch.Generator(); g.manual_seed(1000 * it + 10 * (d == 'target') + rank)
+                b[d] = (torch.randint(0, nu, (nb,), generator=g), torch.randint(0, ni, (nb,), generator=g), torch.randint(0, ni, (nb,), generator=g))
+            pool.append(b)
+        losses = []
+        for i in range(4):                                       # step 3 re-uses batch 0: the prefetch slot wraps round the pool
+            lay.run(pool, i)
+            losses.append({d: float(lay.steps[d].loss_value()) for d in doms})
+        q.put((rank, mode, {k: v.numpy().copy() for k, v in lay.tabs.items()}, losses,
+               [{d: tuple(t.numpy().copy() for t in b[d]) for d in b} for b in pool]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,layout', [(2, 'dim'), (4, 'dim'), (2, 'row'), (4, 'row')])
+def test_bench_layouts_under_gloo(world, layout):
+    """N = 2: the dimension layout cuts BOTH domains over both ranks (collectives at the first multi-GPU point); N = 4: one domain
+    per half of the ranks with the prefetched id all-gather; 'row': the pipelined all-to-all exchange.  Losses of every step and
+    every rank's slice of all four tables equal the single-process oracle on the concatenated batches."""
+    from oracle import train_step as ts
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_layout, args=(r, world, port, layout, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mode = res[0][1]
+    assert mode == {(2, 'dim'): 'dim', (4, 'dim'): 'dim-groups', (2, 'row'): 'row', (4, 'row'): 'row'}[(world, layout)]
+    nu, ni, D, reg, lr = 47, 31, 16, 0.03, 0.05
+    torch.manual_seed(0)
+    full = {k: torch.randn(r, D) * 0.3 for k, r in (('su', nu), ('si', ni), ('tu', nu), ('ti', ni))}
+    half = world // 2
+    for d in ('source', 'target'):
+        members = [r for r in range(world) if mode != 'dim-groups' or (r < half) == (d == 'source')]
+        U, I = full[d[0] + 'u'], full[d[0] + 'i']
+        us, is_ = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+        for i in range(4):
+            u, p, n = (torch.cat([torch.from_numpy(res[r][4][i % 3][d][k]) for r in members]) for k in range(3))
+            loss = ts.rowwise_step(U, I, us, is_, u, p, n, i + 1, opt='adam', lr=lr, reg_weight=reg)
+            for r in members:
+                assert abs(res[r][3][i][d] - float(loss)) <= 1e-5 * abs(float(loss)), (d, i, r, res[r][3][i][d], float(loss))
+        for gi, r in enumerate(members):
+            for name, T in ((d[0] + 'u', U), (d[0] + 'i', I)):
+                got = torch.from_numpy(res[r][2][name])
+                if mode == 'row':
+                    want = T[r::world]
+                else:
+                    G = len(members)
+                    want = T[:, gi * (D // G):(gi + 1) * (D // G)]
+                torch.testing.assert_close(got, want, rtol=2e-5, atol=lr * 1e-2)
