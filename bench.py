@@ -70,6 +70,7 @@ def parse():
     ap.add_argument('--dim', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fullsort', action='store_true')
+    ap.add_argument('--headline-only', action='store_true', help='c5, N=1: the headline step alone (no OVERLAP / per-positive / grid / full-sort / C1-C4 legs, no CPU baseline): the command whose rocprofv3 --stats averages are the headline kernels\' own (profiles/*_headline_kernel_stats.csv)')
     ap.add_argument('--no-config-legs', action='store_true', help='c5, N=1: skip the compact C1-C4 legs (BASELINE configs[0..3]) behind the headline')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
@@ -486,7 +487,10 @@ def run_c5(args, world, rank, dev):
                                              'avg_launch_ms = median of the HIP-event brackets of the timed region\'s launches',
                               'design_bytes': dom_k['design_bytes'], 'design_GBps': dom_k['design_GBps'],
                               'design_frac': dom_k['design_GBps'] / HBM_PEAK_GBS,
-                              'traffic': pmc_traffic(dom_k['kernel'].split(' ')[0])}
+                              'traffic': pmc_traffic(dom_k['kernel'].split(' ')[0]),
+                              'rocprof': 'profiles/r03_bench_c5_headline_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `python bench.py --headline-only` '
+                                         '(this kernel on the headline batch only; the default command also launches it on the k = 4 and synthetic-grid '
+                                         'batches, so ITS stats file averages over several batch sizes)'}
         result['kernels'] = kernels
         result['batch_occupancy'] = {'triples': B, 'distinct_user_rows': du, 'distinct_item_rows': di, 'single_user_rows': su_, 'single_item_rows': si_}
         # the STEP against SURVEY 8d's floor for a fused row-wise-Adam step: 6 x 4D bytes per touched row
@@ -713,8 +717,8 @@ def pmc_traffic(kernel):
         v = None
     if v is None:
         return None
-    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                                  'passes over this command; not measured in this invocation)'}
+    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_r03.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                  'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --steps 3 --warmup 1`; not measured in this invocation)'}
 
 
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
@@ -1048,6 +1052,8 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.headline_only:
+        args.no_map = args.no_extra_legs = args.no_fullsort = args.no_config_legs = args.no_cpu_baseline = True
     # the contract is ONE JSON line on stdout; RCCL and gloo print banners through C stdio (some only when the process exits),
     # so with a process group everything else written to fd 1 is sent to stderr and the line goes to the saved descriptor
     real_stdout = None

@@ -745,35 +745,107 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __res
                                                                     unsigned* __restrict__ counters, seg_long* __restrict__ longs,
                                                                     seg_piece* __restrict__ pieces) {
     constexpr int GPB = kBlock / LPR;
+    constexpr int SU = 4;                                 // segments in flight per lane group
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
     const int64_t TG = (int64_t)gridDim.x * GPB;
     const int D4 = D >> 2;
     const float c = reg_coef ? reg_coef[0] : 0.f;
     const int64_t nh = (int64_t)nheads[0];
-    for (int64_t h = gg; h < nh; h += TG) {
-        const int64_t q = heads[h];
-        const uint32_t row = keys[q];
-        const bool is_long = q + kLongSeg < n && keys[q + kLongSeg] == row;
-        if (is_long) continue;
-        for (int ch = sub; ch < D4; ch += LPR) {
-            const int64_t off = (int64_t)row * D + 4 * ch;
-            const float4 w = ld4(W + off);
-            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
-            if (OPT == 1) { m = ld4(Mo + off); v = ld4(Vo + off); }
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int cnt = 0;
-            for (int64_t e = q; e < n && keys[e] == row; ++e) {
-                const int64_t o = perm[e];
-                const bool neg = SIGNED && o >= neg_start;
-                const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
-                if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
-                else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
-                cnt += (o < reg_limit) ? 1 : 0;
+    if (D4 <= LPR) {
+        // Whole rows per lane (D <= 256).  A segment is a chain of dependent random accesses (head -> keys -> perm -> gradient rows,
+        // next to w, m, v): one segment at a time per lane group left the kernel latency-bound (0.197 ms for 0.8 GB at C5).  SU
+        // segments go through the chain together: SU heads, then SU x 3 keys, then their rows, moments and the first two
+        // occurrences' gradient rows (most duplicate rows have two or three occurrences) are all requested before anything is used.
+        const bool live = sub < D4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t h0 = gg * SU; h0 < nh; h0 += TG * SU) {
+            int64_t q[SU]; uint32_t row[SU], k1[SU], k2[SU]; bool ok[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) { ok[j] = h0 + j < nh; q[j] = ok[j] ? (int64_t)heads[h0 + j] : 0; }
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                row[j] = keys[q[j]];
+                k1[j] = q[j] + 1 < n ? keys[q[j] + 1] : ~0u;               // (a head of a duplicate segment: keys[q + 1] == row)
+                k2[j] = q[j] + 2 < n ? keys[q[j] + 2] : ~0u;
             }
-            const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
-            if (OPT == 1) { st4(Mo + off, m); st4(Vo + off, v); }
-            st4(W + off, wn);
+            uint32_t far[SU], o0[SU], o1[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                far[j] = q[j] + kLongSeg < n ? keys[q[j] + kLongSeg] : ~0u;
+                o0[j] = perm[q[j]]; o1[j] = q[j] + 1 < n ? perm[q[j] + 1] : 0u;
+            }
+            float4 w[SU], m[SU], v[SU], g0[SU], g1[SU];
+            int64_t off[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                ok[j] = ok[j] && !(far[j] == row[j] && row[j] != ~0u && q[j] + kLongSeg < n);      // long segments: registered below
+                off[j] = (int64_t)row[j] * D + 4 * sub;
+                w[j] = m[j] = v[j] = g0[j] = g1[j] = z4;
+                if (ok[j] && live) {
+                    w[j] = ld4(W + off[j]);
+                    if (OPT == 1) { m[j] = ld4(Mo + off[j]); v[j] = ld4(Vo + off[j]); }
+                    const bool n0 = SIGNED && (int64_t)o0[j] >= neg_start, n1 = SIGNED && (int64_t)o1[j] >= neg_start;
+                    g0[j] = ld4(G + (n0 ? (int64_t)o0[j] - neg_start : (int64_t)o0[j]) * D + 4 * sub);
+                    g1[j] = ld4(G + (n1 ? (int64_t)o1[j] - neg_start : (int64_t)o1[j]) * D + 4 * sub);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                if (!ok[j]) continue;
+                float4 acc = z4;
+                int cnt = 0;
+                {   // occurrences 0 and 1 (always present), in occurrence order, exactly as the one-at-a-time loop adds them
+                    const bool n0 = SIGNED && (int64_t)o0[j] >= neg_start, n1 = SIGNED && (int64_t)o1[j] >= neg_start;
+                    if (n0) { acc.x -= g0[j].x; acc.y -= g0[j].y; acc.z -= g0[j].z; acc.w -= g0[j].w; }
+                    else { acc.x += g0[j].x; acc.y += g0[j].y; acc.z += g0[j].z; acc.w += g0[j].w; }
+                    cnt += ((int64_t)o0[j] < reg_limit) ? 1 : 0;
+                    if (n1) { acc.x -= g1[j].x; acc.y -= g1[j].y; acc.z -= g1[j].z; acc.w -= g1[j].w; }
+                    else { acc.x += g1[j].x; acc.y += g1[j].y; acc.z += g1[j].z; acc.w += g1[j].w; }
+                    cnt += ((int64_t)o1[j] < reg_limit) ? 1 : 0;
+                }
+                if (k2[j] == row[j]) {                                     // third and later occurrences: the general walk
+                    for (int64_t e = q[j] + 2; e < n && keys[e] == row[j]; ++e) {
+                        const int64_t o = perm[e];
+                        const bool neg = SIGNED && o >= neg_start;
+                        const float4 g = live ? ld4(G + (neg ? o - neg_start : o) * D + 4 * sub) : z4;
+                        if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
+                        else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
+                        cnt += (o < reg_limit) ? 1 : 0;
+                    }
+                }
+                const float4 wn = upd_math<OPT>(w[j], m[j], v[j], acc, c * (float)cnt, hp);
+                if (live) {
+                    if (OPT == 1) { st4(Mo + off[j], m[j]); st4(Vo + off[j], v[j]); }
+                    st4(W + off[j], wn);
+                }
+            }
+        }
+    } else {
+        for (int64_t h = gg; h < nh; h += TG) {
+            const int64_t q = heads[h];
+            const uint32_t row = keys[q];
+            const bool is_long = q + kLongSeg < n && keys[q + kLongSeg] == row;
+            if (is_long) continue;
+            for (int ch = sub; ch < D4; ch += LPR) {
+                const int64_t off = (int64_t)row * D + 4 * ch;
+                const float4 w = ld4(W + off);
+                float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
+                if (OPT == 1) { m = ld4(Mo + off); v = ld4(Vo + off); }
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int cnt = 0;
+                for (int64_t e = q; e < n && keys[e] == row; ++e) {
+                    const int64_t o = perm[e];
+                    const bool neg = SIGNED && o >= neg_start;
+                    const float4 g = ld4(G + (neg ? o - neg_start : o) * D + 4 * ch);
+                    if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
+                    else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
+                    cnt += (o < reg_limit) ? 1 : 0;
+                }
+                const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
+                if (OPT == 1) { st4(Mo + off, m); st4(Vo + off, v); }
+                st4(W + off, wn);
+            }
         }
     }
     if (counters == nullptr) return;
@@ -1043,7 +1115,7 @@ static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float*
     }
     // the duplicate segments are a fraction of the list (uniform ids at C5: ~1 % of the users, ~10 % of the item rows): a grid for a
     // quarter of the positions, the loop covers the rest
-    const int grid = grid_for(n / 4 + 1, kBlock / lpr);
+    const int grid = grid_for(n / 16 + 1, kBlock / lpr);          // four segments per lane group and round
     {
         cdr_time_scope ts(ctx, tag, s);
 #define DUP_ARGS table, exp_avg, exp_avg_sq, D, keys, perm, n, heads, nheads, G, neg_start, reg_limit, reg_coef, hp, counters, longs, pieces

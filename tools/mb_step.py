@@ -40,7 +40,7 @@ kt = {}
 for nm, ms in B_.timing_collect(dev):
     kt.setdefault(nm, []).append(ms)
 print('fuse_singles=%s UN=%s zipf=%s: %.3f ms per domain step of %d triples (%.3e triples/s; 9216 B/triple -> %.2f TB/s)' % (
-    st.fuse_singles, os.environ.get('CDR_FWD_APPLY_UN', '2'), zipf, dt, B, B / dt * 1e3, 9216.0 * B / dt / 1e9))
+    st.fuse_singles, os.environ.get('CDR_FWD_APPLY_UN', '1'), zipf, dt, B, B / dt * 1e3, 9216.0 * B / dt / 1e9))
 for k, v in kt.items():
     v = sorted(v)
     print('  %-32s n=%3d median %.4f ms  min %.4f  max %.4f' % (k, len(v), v[len(v) // 2], v[0], v[-1]))
