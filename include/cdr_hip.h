@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 34
+#define CDR_ABI_VERSION 35
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -504,6 +504,18 @@ int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, flo
                        float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item, float* out9,
                        float* GU /* [B,D] */, float* GP /* [B,D] */, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
                        void* sort_ws, size_t sort_ws_bytes);
+/* ... and on recbole's pairwise batch layout (S positives tiled k times, k-major negatives: crossdomain_sampler.py:148-152): one
+ * lane group per positive, u and p gathered once; uid / pid [S], nid [S k]; the loss, the per-row gradients and the update are
+ * those of cdr_bpr_step_fused on the B = S k tiled rows.  GU [S, D]; GI [S + S k, D] (gradient rows of the duplicate item
+ * occurrences, indexed like the item list [pid | nid]); keys / perm uint32 [2 S + S k]; flags / heads sized by
+ * cdr_bpr_step_fused_kmajor_sizes; sort_ws as for cdr_sort_ids_two_tables(2 S + S k).                                        */
+int cdr_bpr_step_fused_kmajor_sizes(int64_t S, int k, int64_t* flag_bytes, int64_t* heads_words);
+int cdr_bpr_step_fused_kmajor(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                              float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                              const int64_t* pid, const int64_t* nid, int64_t S, int k, float gamma, float reg_weight, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
+                              float* out9, float* GU, float* GI, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                              void* sort_ws, size_t sort_ws_bytes);
 /* pointwise form of the same step (EMCDR's default MF latent factor model, emcdr.py:111-122: MSE(dot, label) +
  * reg_weight * EmbLoss(u_rows, i_rows); CDR_LOSS_BCE = BCE on sigmoid(dot) as in cmf.py:75-99): GU[b] = g_b i_b, GI[b] = g_b u_b,
  * out9 as above; apply both tables with cdr_sort_ids + cdr_rowwise_apply (neg_start = n, reg_limit = n).                 */

@@ -515,15 +515,16 @@ __global__ __launch_bounds__(kBlock) void batch_norms_kernel(const float* __rest
 }
 
 // keys / perm: the two-table sort's output (section A = positions [0, nA): user keys; section B = [nA, n): item keys + key_base).
-// flags: 4 bytes per triple b = {its user occurrence, its positive (B occurrence b), its negative (B occurrence nA + b), unused}
-// (section B holds 2 nA occurrences: the step's item list [pid | nid]); one 32-bit load per triple in the forward kernel.  cnt[0] / cnt[1]: lengths of headsA / headsB (sorted
+// flags: fstride bytes per positive j = {its user occurrence (A occurrence j), its positive (B occurrence j), its negatives (B
+// occurrence nA + j + m nA for m = 0 .. k - 1: recbole's k-major layout), padding}; the per-triple step is the case k = 1 of it
+// (fstride = 4: one 32-bit load per triple in the forward kernel).  cnt[0] / cnt[1]: lengths of headsA / headsB (sorted
 // positions, relative to their section, of the first occurrence of every row that occurs more than once; list order is
 // irrelevant -- every segment is summed in occurrence order by whoever takes it).
 // A thread takes kFlagIT consecutive positions and a block reserves its share of each list with ONE atomic: with an atomic per
 // 256 positions the 24 k same-address atomics of a 3 M-position launch were most of its 0.157 ms.
 constexpr int kFlagIT = 8;
 __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
-                                                           int64_t nA, int64_t n, uint8_t* __restrict__ flags,
+                                                           int64_t nA, int64_t n, int fstride, uint8_t* __restrict__ flags,
                                                            uint32_t* __restrict__ headsA, uint32_t* __restrict__ headsB,
                                                            unsigned* __restrict__ cnt) {
     constexpr int NW = kBlock / 64;
@@ -547,10 +548,14 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
                 const uint32_t row = k[j + 1];
                 const bool first = q == 0 || k[j] != row, last = q + 1 >= n || k[j + 2] != row;
                 if (q < nA) {
-                    flags[4 * (int64_t)o[j]] = (uint8_t)(first && last);
+                    flags[(int64_t)fstride * o[j]] = (uint8_t)(first && last);
                     hA |= (unsigned)(first && !last) << j;
                 } else {
-                    flags[(int64_t)o[j] < nA ? 4 * (int64_t)o[j] + 1 : 4 * ((int64_t)o[j] - nA) + 2] = (uint8_t)(first && last);
+                    const int64_t ob = o[j];
+                    int64_t fi;
+                    if (ob < nA) fi = fstride * ob + 1;
+                    else { const int64_t r_ = ob - nA, m_ = r_ / nA; fi = fstride * (r_ - m_ * nA) + 2 + m_; }
+                    flags[fi] = (uint8_t)(first && last);
                     hB |= (unsigned)(first && !last) << j;
                 }
             }
@@ -583,8 +588,10 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
 }
 
 // out9[4], out9[5] = reg_weight / (B * ||rows||) from batch_norms_kernel's partial sums (0 when there is no EmbLoss or the norm is 0)
+// (k-major batches: the partials are sums over the S positives, every one of which stands for k rows of the batch -- the norm is taken
+// over B = S k rows and the coefficient is handed out pre-multiplied by k, per S-list occurrence)
 __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
-                                                             float reg_weight, float* __restrict__ out9) {
+                                                             float reg_weight, float* __restrict__ out9, int kmul = 1) {
     __shared__ double smem[2 * (kBlock / 64)];
     double acc[2] = {0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
@@ -593,9 +600,9 @@ __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __res
     }
     block_sum_d<2>(acc, smem);
     if (threadIdx.x == 0) {
-        const float nu = (float)sqrt(acc[0]), ni = (float)sqrt(acc[1]);
-        out9[4] = (reg_weight != 0.f && nu > 0.f) ? reg_weight / ((float)B * nu) : 0.f;
-        out9[5] = (reg_weight != 0.f && ni > 0.f) ? reg_weight / ((float)B * ni) : 0.f;
+        const float nu = (float)sqrt((double)kmul * acc[0]), ni = (float)sqrt((double)kmul * acc[1]);
+        out9[4] = (reg_weight != 0.f && nu > 0.f) ? (float)kmul * (reg_weight / ((float)B * nu)) : 0.f;
+        out9[5] = (reg_weight != 0.f && ni > 0.f) ? (float)kmul * (reg_weight / ((float)B * ni)) : 0.f;
     }
 }
 
@@ -724,6 +731,102 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
         }
 #pragma unroll
         for (int r = 0; r < UN; ++r) { iu[r] = ju[r]; ip[r] = jp[r]; in[r] = jn[r]; fl[r] = gl[r]; }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+// The same idea on recbole's pairwise batch layout (S positives tiled k times, negatives k-major: crossdomain_sampler.py:148-152;
+// csrc/cdr_kstep.hip): one lane group per POSITIVE gathers u and p once and its k negatives; every row among them that occurs once
+// in the step's lists (users [S]; items [pid | nid]) is updated in place from registers -- user: sum_m g_m (p - n_m) + k c_u u,
+// positive: (sum_m g_m) u + k c_i p, negative m: -g_m u -- and a duplicate row's gradient row goes to GU[j] / GI[occurrence] for
+// the segmented apply (no {user row, coefficient} records here: the user row an item gradient is made of is updated by this very
+// kernel).  flags: fstride bytes per positive {user, positive, negative 0 .. k - 1} from occ_flags_kernel.
+template <int LPR, int OPT, int KC>
+__global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
+                                                                      const int64_t* __restrict__ pid, const int64_t* __restrict__ nid,
+                                                                      const uint8_t* __restrict__ flags, int fstride, int64_t S, int k,
+                                                                      float gamma, float invB, const float* __restrict__ coef,
+                                                                      apply_hp hu, apply_hp hi, float* __restrict__ GU,
+                                                                      float* __restrict__ GI, double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const bool live = sub < D4;
+    const float cu = coef[0], ci = coef[1];                 // pre-multiplied by k (coef_finish_kernel)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t j = gg; j < S; j += TG) {
+        const uint8_t* fl = flags + j * fstride;
+        const int64_t iu = uid[j], ip = pid[j];
+        const bool fu = fl[0] != 0, fp = fl[1] != 0;
+        int64_t in0[KC]; bool fn0[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) { const int m = c < k ? c : k - 1; in0[c] = nid[j + (int64_t)m * S]; fn0[c] = fl[2 + m] != 0; }
+        const int64_t ou = iu * D + 4 * sub, op = ip * D + 4 * sub;
+        float4 u = z4, p = z4, um = z4, uv = z4, pm = z4, pv = z4;
+        if (live) {
+            u = ld4(TU.W + ou); p = ld4(TI.W + op);
+            if (OPT == 1) {
+                if (fu) { um = ld4(TU.M + ou); uv = ld4(TU.V + ou); }
+                if (fp) { pm = ld4(TI.M + op); pv = ld4(TI.V + op); }
+            }
+        }
+        float4 gu = z4;
+        float gs = 0.f, dp = 0.f;
+        for (int m0 = 0; m0 < k; m0 += KC) {
+            int64_t in[KC], on[KC]; bool fn[KC];
+            float4 n[KC], nm[KC], nv[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (m0 == 0) { in[c] = in0[c]; fn[c] = fn0[c]; }
+                else { const int m = m0 + c < k ? m0 + c : k - 1; in[c] = nid[j + (int64_t)m * S]; fn[c] = fl[2 + m] != 0; }
+                fn[c] = fn[c] && m0 + c < k;
+                on[c] = in[c] * D + 4 * sub;
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                n[c] = live ? ld4(TI.W + on[c]) : z4;
+                nm[c] = nv[c] = z4;
+                if (OPT == 1 && live && fn[c]) { nm[c] = ld4(TI.M + on[c]); nv[c] = ld4(TI.V + on[c]); }
+            }
+            if (m0 == 0) {
+                dp = group_sum<LPR>(dot4(u, p));
+                const float su = group_sum<LPR>(dot4(u, u)), sp = group_sum<LPR>(dot4(p, p));
+                if (sub == 0) { acc[1] += (double)k * (double)su; acc[2] += (double)k * (double)sp; }      // EmbLoss sees k copies
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const float dn = group_sum<LPR>(dot4(u, n[c]));
+                if (m0 + c < k) {
+                    const float sg = sigmoidf_(dp - dn);
+                    const float g = -invB * (sg * (1.0f - sg)) / (gamma + sg);
+                    gu.x += g * (p.x - n[c].x); gu.y += g * (p.y - n[c].y); gu.z += g * (p.z - n[c].z); gu.w += g * (p.w - n[c].w);
+                    gs += g;
+                    if (sub == 0) acc[0] += (double)(-logf(gamma + sg));
+                    const float4 gn = make_float4(0.f - g * u.x, 0.f - g * u.y, 0.f - g * u.z, 0.f - g * u.w);
+                    if (fn[c]) {
+                        const float4 wn = upd_math<OPT>(n[c], nm[c], nv[c], gn, 0.f, hi);
+                        if (live) { if (OPT == 1) { st4(TI.M + on[c], nm[c]); st4(TI.V + on[c], nv[c]); } st4(TI.W + on[c], wn); }
+                    } else if (live) st4(GI + (S + j + (int64_t)(m0 + c) * S) * D + 4 * sub, gn);
+                }
+            }
+        }
+        if (fu) {
+            const float4 wu = upd_math<OPT>(u, um, uv, gu, cu, hu);
+            if (live) { if (OPT == 1) { st4(TU.M + ou, um); st4(TU.V + ou, uv); } st4(TU.W + ou, wu); }
+        } else if (live) st4(GU + j * D + 4 * sub, gu);
+        const float4 gp = make_float4(gs * u.x, gs * u.y, gs * u.z, gs * u.w);
+        if (fp) {
+            const float4 wp = upd_math<OPT>(p, pm, pv, gp, ci, hi);
+            if (live) { if (OPT == 1) { st4(TI.M + op, pm); st4(TI.V + op, pv); } st4(TI.W + op, wp); }
+        } else if (live) st4(GI + j * D + 4 * sub, gp);
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -1192,7 +1295,7 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
     const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
     {
         cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
-        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, flags, headsA, headsB, cnt);
+        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, 4, flags, headsA, headsB, cnt);
     }
     CDR_LAUNCH_CHECK();
     const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
@@ -1214,5 +1317,76 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
     rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, D, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0, CDR_TAG_APPLY_UNSIGNED);
     if (rc) return rc;
     return apply_dups(ctx, s, opt, item_tab, item_m, item_v, D, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base,
+                      CDR_TAG_APPLY_SIGNED);
+}
+
+
+// ---- the per-positive (k-major) form: uid / pid [S] (the first S entries of recbole's tiled [S k] columns), nid [S k] k-major
+extern "C" int cdr_bpr_step_fused_kmajor_sizes(int64_t S, int k, int64_t* flag_bytes, int64_t* heads_words) {
+    CDR_CHECK_ARG(flag_bytes && heads_words && S > 0 && k >= 1 && k <= 64);
+    const int fstride = (2 + k + 3) & ~3;
+    *flag_bytes = S * (int64_t)fstride;
+    *heads_words = 4 + (S / 2 + 1) + ((S + S * (int64_t)k) / 2 + 1);
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_step_fused_kmajor(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v,
+                                         int64_t user_rows, float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D,
+                                         const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t S, int k, float gamma,
+                                         float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                         int64_t step_user, int64_t step_item, float* out9, float* GU, float* GI, uint32_t* keys,
+                                         uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GI && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && S > 0 && k >= 1 && k <= 64);
+    const int64_t B = S * (int64_t)k, nI = S + B;
+    CDR_CHECK_ARG(S + nI <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const int fstride = (2 + k + 3) & ~3;
+    if (reg_weight != 0.f) {
+        const int ngrid = grid_for((S + 7) / 8, kBlock / lpr);
+        {
+            cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+            DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, S, ctx->partials));
+        }
+        CDR_LAUNCH_CHECK();
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, k);
+    } else {
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, k);
+    }
+    CDR_LAUNCH_CHECK();
+    uint32_t key_base = 0;
+    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, S, user_rows, pid, S, nid, B, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    unsigned* cnt = (unsigned*)heads;
+    uint32_t* headsA = heads + 4;
+    uint32_t* headsB = headsA + (S / 2 + 1);
+    CDR_HIP(cdr_zero_u32(cnt, 4, s));
+    const int fgrid = grid_for(S + nI, kBlock * kFlagIT);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, S, S + nI, fstride, flags, headsA, headsB, cnt);
+    }
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
+    const int grid = grid_for(S, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_APPLY, s);
+#define FK_ARGS TU, TI, D, uid, pid, nid, flags, fstride, S, k, gamma, 1.0f / (float)B, out9 + 4, hu, hi, GU, GI, ctx->partials
+        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kmajor_kernel<L, 0, 4><<<dim3(grid), dim3(kBlock), 0, s>>>(FK_ARGS)); }
+        else if (k <= 2) { DISPATCH_LPR(lpr, bpr_fwd_apply_kmajor_kernel<L, 1, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(FK_ARGS)); }
+        else { DISPATCH_LPR(lpr, bpr_fwd_apply_kmajor_kernel<L, 1, 4><<<dim3(grid), dim3(kBlock), 0, s>>>(FK_ARGS)); }
+#undef FK_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9);
+    CDR_LAUNCH_CHECK();
+    // duplicate rows: users over GU [S, D]; items over GI [S + B, D] (one row per occurrence of [pid | nid], signs folded in)
+    rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, D, keys, perm, S, headsA, cnt, GU, S, S, out9 + 4, hu, 0, CDR_TAG_APPLY_UNSIGNED);
+    if (rc) return rc;
+    return apply_dups(ctx, s, opt, item_tab, item_m, item_v, D, keys + S, perm + S, nI, headsB, cnt + 1, GI, nI, S, out9 + 5, hi, key_base,
                       CDR_TAG_APPLY_SIGNED);
 }

@@ -155,7 +155,7 @@ class KMajorBPRStep:
     counters and can be replayed as a hipGraph (``capture``)."""
 
     def __init__(self, user_table, item_table, max_positives, k=1, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None):
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True):
         assert user_table.is_cuda and item_table.is_cuda, 'KMajorBPRStep needs ROCm device tensors'
         assert user_table.shape[1] == item_table.shape[1]
         self.U, self.I = user_table, item_table
@@ -171,7 +171,19 @@ class KMajorBPRStep:
         Bm = Sm * self.k
         self.max_positives = Sm
         self.GU = torch.empty(Sm, self.D, device=dev, dtype=torch.float32)
-        self.rec = torch.empty(2 * (Sm + Bm), device=dev, dtype=torch.int32)          # 8-byte {user row, coefficient} records
+        # large batches: rows that occur once are updated by the forward kernel (cdr_bpr_step_fused_kmajor); the duplicate item
+        # occurrences get their gradient row written (the user row it is made of is updated by that same kernel) instead of a record
+        self.fuse_singles = (bool(fuse_singles) and (Sm + Bm) > 8192 and self.D % 4 == 0 and self.D <= 256 and self.k <= 64
+                             and os.environ.get('CDR_FUSE_SINGLES', '1') != '0')
+        if self.fuse_singles:
+            fb, hw = ctypes.c_int64(0), ctypes.c_int64(0)
+            B_._check(B_.load().cdr_bpr_step_fused_kmajor_sizes(Sm, self.k, ctypes.byref(fb), ctypes.byref(hw)), 'cdr_bpr_step_fused_kmajor_sizes')
+            self.GI = torch.empty(Sm + Bm, self.D, device=dev, dtype=torch.float32)
+            self.flags = torch.zeros(int(fb.value), device=dev, dtype=torch.uint8)
+            self.heads = torch.empty(int(hw.value), device=dev, dtype=torch.int32)
+            self.rec = None
+        else:
+            self.rec = torch.empty(2 * (Sm + Bm), device=dev, dtype=torch.int32)      # 8-byte {user row, coefficient} records
         self.out6 = torch.zeros(12, device=dev, dtype=torch.float32)
         n_all = 2 * Sm + Bm                                                           # user list [S] ++ item list [S + B]
         self.keys = torch.empty(n_all, device=dev, dtype=torch.int32)
@@ -194,6 +206,16 @@ class KMajorBPRStep:
         B = nid.numel()
         S = B // self.k
         assert S * self.k == B and S <= self.max_positives and uid.numel() >= S and pid.numel() >= S
+        if self.fuse_singles:
+            us, its = self.ustate, self.istate
+            us.advance(); its.advance()
+            B_.call('cdr_bpr_step_fused_kmajor', B_.ctx(self.U.device), B_.stream(), self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
+                    B_.f32(us.exp_avg_sq), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq),
+                    its.table.shape[0], self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), S, self.k, float(self.gamma), float(self.reg_weight),
+                    float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), us.step, its.step,
+                    B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI), B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.flags),
+                    B_.raw(self.heads), B_.raw(self.ws), self.ws.numel())
+            return self.out6
         self._enqueue(uid, pid, nid, S)
         self.ustate.advance(device_bumped=True)
         self.istate.advance(device_bumped=True)

@@ -135,6 +135,22 @@ int main(void) {
     CHECK_HIP(hipMemcpy(U2, dU2, sizeof(float) * NU * D, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(I2, dI2, sizeof(float) * NI * D, hipMemcpyDeviceToHost));
     for (int i = 0; i < NU * D; ++i) ok &= close_enough(U2[i], Uref[i], 0.2, "user table after the dimension-layout step");
     for (int i = 0; i < NI * D; ++i) ok &= close_enough(I2[i], Iref[i], 0.2, "item table after the dimension-layout step");
+    /* ---- the same step as ONE call (cdr_bpr_step_fused: rows that occur once are updated by the forward kernel), on fresh copies -- */
+    {
+        float *dU3, *dI3; uint8_t* dFlags; uint32_t* dHeads; int64_t words = 0;
+        CHECK_HIP(hipMalloc((void**)&dU3, sizeof(float) * NU * D)); CHECK_HIP(hipMalloc((void**)&dI3, sizeof(float) * NI * D));
+        CHECK_HIP(hipMemcpy(dU3, U, sizeof(float) * NU * D, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dI3, I, sizeof(float) * NI * D, hipMemcpyHostToDevice));
+        CHECK_CDR(cdr_bpr_step_fused_heads_words(B, &words));
+        CHECK_HIP(hipMalloc((void**)&dFlags, 4 * B)); CHECK_HIP(hipMalloc((void**)&dHeads, 4 * (size_t)words));
+        CHECK_CDR(cdr_bpr_step_fused(ctx, NULL, CDR_OPT_SGD, dU3, NULL, NULL, NU, dI3, NULL, NULL, NI, D, du, dp_, dn_, B, gamma, reg, lr, 0.9f,
+                                     0.999f, 1e-8f, 0.f, 1, 1, dOut, dGU, dGP, dKeys, dPerm, dFlags, dHeads, dWs, ws_bytes));
+        CHECK_HIP(hipDeviceSynchronize());
+        CHECK_HIP(hipMemcpy(out, dOut, sizeof(float) * 6, hipMemcpyDeviceToHost));
+        ok &= close_enough(out[0], total, 0, "one-call fused step loss");
+        CHECK_HIP(hipMemcpy(U2, dU3, sizeof(float) * NU * D, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(I2, dI3, sizeof(float) * NI * D, hipMemcpyDeviceToHost));
+        for (int i = 0; i < NU * D; ++i) ok &= close_enough(U2[i], Uref[i], 0.2, "user table after the one-call fused step");
+        for (int i = 0; i < NI * D; ++i) ok &= close_enough(I2[i], Iref[i], 0.2, "item table after the one-call fused step");
+    }
     CHECK_CDR(cdr_ctx_destroy(ctx));
     printf(ok ? "abi_smoke: OK (loss %.7f)\n" : "abi_smoke: FAILED (loss %.7f)\n", out[0]);
     return ok ? 0 : 1;

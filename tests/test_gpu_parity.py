@@ -376,6 +376,54 @@ def test_kmajor_step_large_batch_and_hot_item():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('opt', ['adam', 'sgd'])
+@pytest.mark.parametrize('D,k,S', [(128, 4, 2500), (64, 2, 3000), (8, 5, 2000), (256, 9, 1200), (24, 1, 5000)])
+def test_kmajor_fused_step_single_rows_in_the_forward(opt, D, k, S):
+    """cdr_bpr_step_fused_kmajor (past the small-batch form): rows that occur once in the step's lists are updated by the per-positive
+    forward kernel, duplicate rows by the segmented apply over GU / GI.  Mostly-single users, items half duplicated, a positive that
+    is also one of its own negatives, a long segment; k = 1, 2, 4 (one chunk), 5 and 9 (several chunks).  Three free-running steps
+    against the oracle's row-wise step on the tiled [S k] batch and against the record-based two-pass path; reruns bit-equal."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import KMajorBPRStep
+    gen = torch.Generator().manual_seed(D + k)
+    nu, ni, reg, lr = 40000, 2 * S * (1 + k) // 3, 0.03, 0.05
+    U = torch.randn(nu, D, generator=gen) * 0.3
+    I = torch.randn(ni, D, generator=gen) * 0.3
+    runs = []
+    for fuse in (True, False, True):
+        Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+        st = KMajorBPRStep(Ud, Id, max_positives=S, k=k, opt=opt, lr=lr, reg_weight=reg, fuse_singles=fuse)
+        assert not st.small and st.fuse_singles == fuse
+        Uo, Io = U.clone(), I.clone()
+        su, si = ts.RowwiseAdamState(Uo), ts.RowwiseAdamState(Io)
+        g2 = torch.Generator().manual_seed(3)
+        losses = []
+        for step in range(1, 4):
+            u = torch.randint(1, nu, (S,), generator=g2); p = torch.randint(1, ni, (S,), generator=g2); n = torch.randint(1, ni, (S * k,), generator=g2)
+            n[:4] = p[:4]                                   # a positive that is its own first negative
+            p[50:120] = 5                                   # a long segment
+            if step == 2:
+                u[300:309] = u[0]
+            ref = ts.rowwise_step(Uo, Io, su, si, u.repeat(k), p.repeat(k), n, step, opt=opt, lr=lr, reg_weight=reg)
+            out = st.step(u.to(DEV), p.to(DEV), n.to(DEV))
+            losses.append(out[0].clone())
+            if fuse:
+                assert_close(out[0], ref, what=f'loss step {step}')
+                if step == 1 and opt == 'adam':
+                    assert_close(st.ustate.exp_avg, su.m, what='exp_avg U, step 1'); assert_close(st.istate.exp_avg, si.m, what='exp_avg I, step 1', row_floor=1e-2)
+                    assert_close(st.ustate.exp_avg_sq, su.v, what='exp_avg_sq U, step 1'); assert_close(st.istate.exp_avg_sq, si.v, what='exp_avg_sq I, step 1')
+        if fuse:
+            atol = lr * 1e-2 if opt == 'adam' else 1e-6
+            assert_close(Ud, Uo, rtol=1e-5, atol=atol, what='U after 3 steps'); assert_close(Id, Io, rtol=1e-5, atol=atol, what='I after 3 steps')
+            fl = st.flags[:S * ((2 + k + 3) // 4 * 4)].view(S, -1)[:, :2 + k].float().mean(0)
+            assert float(fl[0]) > 0.8 and 0.05 < float(fl[2]) < 0.95         # the batch exercises both paths
+        runs.append((torch.stack(losses), Ud.clone(), Id.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[2])), 'rerun differs'
+    tol = dict(rtol=1e-5, atol=1e-6) if opt == 'sgd' else dict(rtol=1e-5, atol=lr * 1e-2)
+    for a, b, what in zip(runs[0], runs[1], ('losses', 'U', 'I')):
+        assert_close(a, b, what='fused vs record-based ' + what, **tol)
+
+
 @pytest.mark.parametrize('k', [1, 4])
 def test_kmajor_graph_replay_is_bit_equal_to_eager(k):
     """The reference-default batch (train_batch_size 2,048 rows) as ONE hipGraph: forward, LDS sort, both applies with the Adam

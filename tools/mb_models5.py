@@ -143,10 +143,17 @@ def main():
                 copt.zero_grad()
                 oracle_loss(P, bc, None).sum().backward()
                 copt.step()
-            for threads, key in ((os.cpu_count(), 'cpu_all_cores_ms'), (1, 'cpu_one_thread_ms')):
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+            try:                                         # the cgroup quota, not the 256 CPUs the container can see
+                q_, p_ = open('/sys/fs/cgroup/cpu.max').read().split()
+                if q_ != 'max':
+                    ncores = min(ncores, max(1, -(-int(q_) // int(p_))))
+            except Exception:
+                pass
+            for threads, key in ((ncores, 'cpu_all_cores_ms'), (1, 'cpu_one_thread_ms')):
                 torch.set_num_threads(threads)
                 row[key] = round(cpu_timed(cpu_step), 3)
-            row['cpu_cores'] = os.cpu_count()
+            row['cpu_cores'] = ncores
         rows.append(row)
         print(json.dumps(row), flush=True)
 
