@@ -27,6 +27,7 @@
 // (fused.FusedMapStep: gather -> mapping -> MSE -> sort -> row-wise applies).
 #include <string.h>
 #include <type_traits>
+#include <cstdlib>
 #include "cdr_common.h"
 
 namespace {
@@ -1079,6 +1080,387 @@ __global__ __launch_bounds__(512, 1) void map_pipe2_kernel(map_net net, map_opt 
     if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- map_pipe2_kernel with (i) the weight-gradient accumulation in the ROW waves and (ii) every contraction's weight tile resident
+// in registers one contraction ahead (round 3; the comment inside says what the stamps showed) -----------------------------------
+template <int NI, int NHI>
+__global__ __launch_bounds__(512, 1) void map_pipe3_kernel(map_net net, map_opt opt, float* __restrict__ S, float* __restrict__ mS,
+                                                         float* __restrict__ vS, float* __restrict__ T, float* __restrict__ mT,
+                                                         float* __restrict__ vT, const int64_t* __restrict__ idx, int64_t n,
+                                                         const int64_t* __restrict__ step_s, const int64_t* __restrict__ step_t,
+                                                         float* __restrict__ wpart, double* __restrict__ lpart, map_params bump) {
+    constexpr int D = 32 * NI;                 // Ds == Dt
+    constexpr int H = 32 * NHI;                // hidden width
+    constexpr int HS = H + 4;
+    constexpr int LR = D / 4;                  // 16-byte chunks (= DMA lanes) per row
+    constexpr int RPI = 64 / LR;               // rows per DMA instruction (1 KiB of LDS)
+    constexpr int GS = D + 4;                  // padded row stride of the two MFMA-written buffers
+    constexpr int TL = NI * NHI;               // weight-gradient tiles per layer (layer 0: [H][D], layer 1: [D][H])
+    constexpr int SL = TL / 4;                 // ... per MFMA wave and layer (TL is a multiple of 4)
+    constexpr int NJD = (NI + 3) / 4, NJH = (NHI + 3) / 4;      // 32-column jobs per MFMA wave over D / over H
+    constexpr int NQ = NI;                     // DMA instructions per row wave and array (4 row waves)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float rok[3][kRows];
+    __shared__ int64_t rid[3][kRows];
+    __shared__ double red[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li0 = lane & 31, lh0 = lane >> 5;
+    const bool rowwave = wave >= 4;
+    float* GZ = smem;                          // [32][GS]  mapped -> gz = dL/d mapped, later dL/dS (shared: see above)
+    float* GX = GZ;
+    float* HB = GZ + kRows * GS;               // [32][HS]  hidden activations -> dL/d(hidden pre-activation)
+    float* SS = HB + kRows * HS;               // [2][32][D] source rows (swizzled)
+    float* ST = SS + 2 * kRows * D;            // [32][D] each, swizzled alike
+    float* SMT = ST + kRows * D;
+    float* SVT = SMT + kRows * D;
+    float* SMS = SVT + kRows * D;
+    float* SVS = SMS + kRows * D;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool adam = opt.opt != 0;
+    float ss_s, bc_s, ss_t, bc_t;
+    adam_hp(opt, step_s, 1, ss_s, bc_s);
+    adam_hp(opt, step_t, 1, ss_t, bc_t);
+    const float gscale = 2.0f / ((float)n * (float)D);
+    const float* __restrict__ W1 = net.W[0];   // [H][D]
+    const float* __restrict__ W2 = net.W[1];   // [D][H]
+    const float* __restrict__ B1 = net.b[0];
+    const float* __restrict__ B2 = net.b[1];
+    if (blockIdx.x == 0 && t == 0) {
+        for (int l = 0; l < 2; ++l) { if (bump.sW[l]) bump.sW[l][0] += 1; if (bump.sb[l]) bump.sb[l][0] += 1; }
+    }
+    const int64_t nrb = (n + kRows - 1) / kRows;
+    float bacc = 0.f;                          // MFMA-wave thread t owns flat bias element t (b1 then b2)
+    double lsum = 0.0;
+
+    // (address arithmetic below is re-derived per phase from a laundered lane id: left alone, LICM hoists ~200 loop-invariant LDS /
+    //  global offsets out of the block loop and spills them -- and a spill reload inside a row wave is a vector memory load whose
+    //  wait drains the DMA queue)
+    auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    // ---- row waves: lane <-> (row, physical chunk) of DMA instruction i = pw + 4 q, q < NQ
+    const int pw = wave - 4;
+    // byte offsets of this lane's NQ chunks inside a table, for the rows of one block: all ids are read from LDS first (one wait),
+    // and the result serves every table staged for that block
+    auto row_offsets = [&](const int64_t* ids, int64_t (&off)[NQ]) {
+        const int ln = fresh(lane);
+        int64_t idv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) idv[q] = ids[(pw + 4 * q) * RPI + ln / LR];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int row = (pw + 4 * q) * RPI + ln / LR, p = ln % LR;
+            off[q] = (idv[q] * D + 4 * (p ^ (row & (LR - 1)))) * (int64_t)sizeof(float);
+        }
+    };
+    // NQ DMA instructions of one table in ONE asm statement: M0 saved once, set per instruction, restored once
+    auto stage = [&](const float* __restrict__ tab, unsigned dst_bytes, const int64_t (&off)[NQ]) {
+        const char* base = reinterpret_cast<const char*>(tab);
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(dst_bytes + (unsigned)pw * 1024u);   // instruction i = pw + 4 q writes 1 KiB at i * 1 KiB
+        unsigned keep;
+        if constexpr (NQ == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]),
+                           "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u), "s"(d0 + 12288u)
+                         : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(base + off[0]), "v"(base + off[1]), "s"(d0), "s"(d0 + 4096u) : "memory");
+    };
+    auto lds_off = [](const float* p) {
+        return (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+    };
+    const unsigned bSS = lds_off(SS), bST = lds_off(ST), bSMT = lds_off(SMT), bSVT = lds_off(SVT), bSMS = lds_off(SMS), bSVS = lds_off(SVS);
+    int64_t roff[NQ];
+    // Adam / SGD on this lane's chunks of DMA instructions [Q0, Q1): g = sign * G[row][logical chunk].  Every operand of the
+    // whole range is requested before the arithmetic starts (one wave per role and SIMD: nothing else hides the LDS latency)
+    auto apply = [&](auto Q0c, auto Q1c, float* __restrict__ tab, float* __restrict__ mtab, float* __restrict__ vtab, const float* stW,
+                     const float* stM, const float* stV, const float* G, float sign, const int64_t* ids, const float* ok,
+                     float ssz, float bcs) {
+        constexpr int Q0 = decltype(Q0c)::value, Q1 = decltype(Q1c)::value, NQQ = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
+        if (Q1 <= Q0) return;
+        const int ln = fresh(lane);
+        const float rbc = 1.0f / bcs;
+        const int r0 = ln / LR, p = ln % LR;
+        float4 w[NQQ], g[NQQ], m[NQQ], v[NQQ];
+        int64_t o[NQQ];
+        float okf[NQQ];
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) {
+            const int row = (pw + 4 * (Q0 + q)) * RPI + r0, c = p ^ (row & (LR - 1)), so = (row * LR + p) * 4;
+            w[q] = ld4(stW + so); g[q] = ld4(G + row * GS + 4 * c);
+            m[q] = z4; v[q] = z4;
+            if (adam) { m[q] = ld4(stM + so); v[q] = ld4(stV + so); }
+            o[q] = ids[row] * D + 4 * c;
+            okf[q] = ok[row];
+        }
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) {
+            float4 wn;
+            wn.x = updq(w[q].x, sign * g[q].x, m[q].x, v[q].x, opt, ssz, rbc); wn.y = updq(w[q].y, sign * g[q].y, m[q].y, v[q].y, opt, ssz, rbc);
+            wn.z = updq(w[q].z, sign * g[q].z, m[q].z, v[q].z, opt, ssz, rbc); wn.w = updq(w[q].w, sign * g[q].w, m[q].w, v[q].w, opt, ssz, rbc);
+            if (okf[q] != 0.f) {
+                st4(tab + o[q], wn);
+                if (adam) { st4(mtab + o[q], m[q]); st4(vtab + o[q], v[q]); }
+            }
+        }
+    };
+    using std::integral_constant;
+#define IC(v) integral_constant<int, (v)>{}
+    if (t < kRows) {                                                     // ids of this workgroup's first block
+        const int64_t g = (int64_t)blockIdx.x * kRows + t;
+        rid[0][t] = idx[g < n ? g : n - 1];
+        rok[0][t] = g < n ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (rowwave) {
+        __builtin_amdgcn_s_setprio(3);
+        row_offsets(rid[0], roff);
+        stage(S, bSS, roff);
+        stage(T, bST, roff);
+        if (adam) { stage(mT, bSMT, roff); stage(vT, bSVT, roff); }
+        vm_wait<0>();
+    }
+    lds_barrier();
+    // ---- MFMA waves: weight tiles of their 32-column job, one contraction AHEAD.  In map_pipe2_kernel the weights stream from L2
+    // one K group (0.45 us of MFMAs) ahead of their use, behind the row waves' DMA traffic in the CU's vector-memory path: stamps of
+    // one block show the four 64-MFMA contractions at 4.5 / 6.2 / 6.5 / 12 us where the matrix pipe needs 1.8-2 us each.  With the
+    // weight-gradient accumulators (128 registers) moved to the row waves, two 64-register tile buffers fit: the tile of the NEXT
+    // contraction is requested before the current one starts and has a whole phase (and a barrier) to arrive.
+    const int job = wave;                                                 // one 32-column tile per MFMA wave and contraction
+    auto load_rows = [&](auto Kc, const float* __restrict__ Wg, int ncol, float4 (&T)[16]) {      // T[i] = Wg[ncol][8 i + 4 lh ..]
+        constexpr int K = decltype(Kc)::value;
+        const float* wm = Wg + (int64_t)ncol * K + 4 * fresh(lh0);
+#pragma unroll
+        for (int i = 0; i < K / 8; ++i) T[i] = ld4(wm + 8 * i);
+    };
+    auto load_cols = [&](auto Kc, auto LDc, const float* __restrict__ Wg, int ncol, float4 (&T)[16]) {   // T[i] = Wg[8 i + 4 lh + 0..3][ncol]
+        constexpr int K = decltype(Kc)::value, LDW = decltype(LDc)::value;
+        const float* w0 = Wg + (int64_t)(4 * fresh(lh0)) * LDW + ncol;
+#pragma unroll
+        for (int i = 0; i < K / 8; ++i) { const float* q_ = w0 + (int64_t)(8 * i) * LDW; T[i] = make_float4(q_[0], q_[LDW], q_[2 * LDW], q_[3 * LDW]); }
+    };
+    // 64 (K = 128) MFMAs on a resident tile; the A chunks of the next group of four K steps are read from LDS under the current group
+    auto contract = [&](auto Kc, const float4 (&T)[16], auto a_chunk) {
+        constexpr int K = decltype(Kc)::value;
+        f32x16 acc = zero16();
+        float4 an[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) an[j] = a_chunk(j);
+#pragma unroll
+        for (int g = 0; g < K / 32; ++g) {
+            float4 ca[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ca[j] = an[j];
+            if (g + 1 < K / 32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) an[j] = a_chunk(4 * (g + 1) + j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { MFMA4(acc, ca[j], T[4 * g + j]); }
+        }
+        return acc;
+    };
+    // weight-gradient tiles of one layer (ROW waves): dW[m][nn] += sum_rows gz[row][m] in[row][nn]
+    auto dw_layer = [&](f32x16 (&wacc)[2 * SL], auto QBc, auto NTWc, const float* gzb, int gzs, auto in_word) {
+        constexpr int QB = decltype(QBc)::value, NTW = decltype(NTWc)::value;
+        float av[2][16], bv[2][16];
+        auto fetch = [&](int q, float* a_, float* b_) {
+            const int loc = pw + 4 * q, mt = loc / NTW, nt = loc - mt * NTW;
+            const int l_i = fresh(li0), l_h = fresh(lh0);
+            const float* ga = gzb + (4 * l_h) * gzs + mt * 32 + l_i;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rc = 8 * (e >> 2) + (e & 3);
+                a_[e] = ga[rc * gzs];
+                b_[e] = in_word(rc, l_h, nt * 32 + l_i);
+            }
+        };
+        fetch(0, av[0], bv[0]);
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            if (q + 1 < SL) fetch(q + 1, av[(q + 1) & 1], bv[(q + 1) & 1]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) MF1(wacc[QB + q], av[q & 1][e], bv[q & 1][e]);
+        }
+    };
+    // Each role runs its OWN block loop (same barriers per block in both): the row waves' 128 accumulator registers and the MFMA
+    // waves' two 64-register weight tiles are then never live in the same code, which one loop with a branch inside made them
+    // (239 registers spilled to scratch in that form).
+    float* o = wpart + (size_t)blockIdx.x * ((size_t)net.ntiles * 1024 + net.nbias);
+    if (!rowwave) {
+        float4 TA[16], TB[16];
+        if (job < NHI) load_rows(IC(D), W1, job * 32 + li0, TA);         // the first block's forward-0 tile
+        int k = 0;
+        for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x, ++k) {
+            const int par = k & 1, r3 = k % 3, r3n = (k + 1) % 3, r3p = (k + 2) % 3;
+            const bool has_next = rb + gridDim.x < nrb;
+            float* Xs = SS + par * kRows * D;                               // this block's source rows
+            MP_STAMP(0);
+            int64_t idn = 0; float okn = 0.f;
+            if (t < kRows && has_next) { const int64_t g = (rb + gridDim.x) * kRows + t; idn = idx[g < n ? g : n - 1]; okn = g < n ? 1.f : 0.f; }
+            int li = fresh(li0), lh = fresh(lh0);
+            // ---- forward 0: HB = tanh(X W1^T + b1)          [TA = W1 rows ; request TB = W2 rows]
+            if (job < NI) load_rows(IC(H), W2, job * 32 + li, TB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (job < NHI) {
+                const int ncol = job * 32 + li;
+                const float* xr = Xs + li * D;
+                const int sw = li & (LR - 1);
+                const f32x16 acc = contract(IC(D), TA, [&](int i) { return ld4(xr + (((2 * i + lh) ^ sw) << 2)); });
+                MP_STAMP(1);
+                const float bv = B1 ? B1[ncol] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) HB[((r & 3) + 8 * (r >> 2) + 4 * lh) * HS + ncol] = tanhf(acc[r] + bv);
+            }
+            if (t < kRows && has_next) { rid[r3n][t] = idn; rok[r3n][t] = okn; }
+            MP_STAMP(2);
+            lds_barrier();                                               // ---- 1: hidden activations complete
+            // ---- forward 1: mapped = HB W2^T + b2            [TB = W2 rows ; request TA = W2 columns]
+            li = fresh(li0); lh = fresh(lh0);
+            if (job < NHI) load_cols(IC(D), IC(H), W2, job * 32 + li, TA);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 am = zero16();
+            if (job < NI) {
+                const float* hr = HB + li * HS;
+                am = contract(IC(H), TB, [&](int i) { return ld4(hr + 4 * (2 * i + lh)); });
+            }
+            MP_STAMP(3);
+            lds_barrier();                                               // ---- X: target rows landed; the previous dL/dS is consumed
+            li = fresh(li0); lh = fresh(lh0);
+            if (job < NI) {
+                const int ncol = job * 32 + li;
+                const float bv = B2 ? B2[ncol] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float tv = ST[(row * LR + ((ncol >> 2) ^ (row & (LR - 1)))) * 4 + (ncol & 3)];
+                    const float d = rok[r3][row] != 0.f ? (am[r] + bv) - tv : 0.f;              // nn.MSELoss (emcdr.py:81,162)
+                    lsum += (double)d * (double)d;
+                    GZ[row * GS + ncol] = gscale * d;
+                }
+            }
+            MP_STAMP(4);
+            lds_barrier();                                               // ---- F: gz complete
+            // ---- dL/d hidden = gz W2: the contraction now (the row waves are still reading HB for dW2), its in-place epilogue after 4
+            //      [TA = W2 columns ; request TB = W1 columns]
+            li = fresh(li0); lh = fresh(lh0);
+            if (job < NI) load_cols(IC(H), IC(D), W1, job * 32 + li, TB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (B2 && t >= H && t < H + D) {
+                float sum = 0.f;
+                for (int row = 0; row < kRows; ++row) sum += GZ[row * GS + (t - H)];
+                bacc += sum;
+            }
+            f32x16 ah = zero16();
+            if (job < NHI) {
+                const float* ao = GZ + li * GS + 4 * lh;
+                ah = contract(IC(D), TA, [&](int i) { return ld4(ao + 8 * i); });
+            }
+            MP_STAMP(5);
+            lds_barrier();                                               // ---- 4: HB may be overwritten
+            li = fresh(li0); lh = fresh(lh0);
+            if (job < NHI) {
+                const int ncol = job * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ((r & 3) + 8 * (r >> 2) + 4 * lh) * HS + ncol;
+                    const float a_ = HB[o];
+                    HB[o] = ah[r] * (1.0f - a_ * a_);                      // tanh' = 1 - a^2
+                }
+            }
+            MP_STAMP(6);
+            lds_barrier();                                               // ---- 5: gz0 complete
+            // ---- dL/dS = gz0 W1: contraction now, written to the shared buffer after M  [TB = W1 columns ; request TA = W1 rows]
+            li = fresh(li0); lh = fresh(lh0);
+            if (job < NHI) load_rows(IC(D), W1, job * 32 + li, TA);     // the next block's forward 0 (or nobody's)
+            __builtin_amdgcn_sched_barrier(0);
+            if (B1 && t < H) {
+                float sum = 0.f;
+                for (int row = 0; row < kRows; ++row) sum += HB[row * HS + t];
+                bacc += sum;
+            }
+            f32x16 ax = zero16();
+            if (job < NI) {
+                const float* ao = HB + li * HS + 4 * lh;
+                ax = contract(IC(H), TB, [&](int i) { return ld4(ao + 8 * i); });
+            }
+            MP_STAMP(7);
+            lds_barrier();                                               // ---- M: the target update has read gz for the last time
+            li = fresh(li0); lh = fresh(lh0);
+            if (job < NI) {
+                const int ncol = job * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) GX[((r & 3) + 8 * (r >> 2) + 4 * lh) * GS + ncol] = ax[r];
+            }
+            MP_STAMP(8);
+            lds_barrier();                                               // ---- E
+            MP_STAMP(9);
+        }
+        if (t < net.nbias) o[(size_t)net.ntiles * 1024 + t] = bacc;
+        lsum = wave_sum_d(lsum);
+        if (lane == 0) red[wave] = lsum;
+    } else {
+        f32x16 wacc[2 * SL];                       // [0, SL): layer 0's tiles pw + 4 q ; [SL, 2 SL): layer 1's
+#pragma unroll
+        for (int q = 0; q < 2 * SL; ++q) wacc[q] = zero16();
+        int k = 0;
+        for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x, ++k) {
+            const int par = k & 1, r3 = k % 3, r3n = (k + 1) % 3, r3p = (k + 2) % 3;
+            const bool has_next = rb + gridDim.x < nrb;
+            float* Xs = SS + par * kRows * D;                               // this block's source rows
+            MP_STAMP(0);
+            vm_wait<0>();                                                // T, mT, vT of this block and mS, vS of the previous one
+            MP_STAMP(1);
+            if (k > 0) apply(IC(0), IC(NQ / 2), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            lds_barrier();                                               // ---- 1
+            if (k > 0) apply(IC(NQ / 2), IC(NQ), S, mS, vS, SS + (par ^ 1) * kRows * D, SMS, SVS, GX, 1.f, rid[r3p], rok[r3p], ss_s, bc_s);
+            if (has_next) { row_offsets(rid[r3n], roff); stage(S, bSS + (unsigned)((par ^ 1) * kRows * D * 4), roff); }
+            if (adam) { row_offsets(rid[r3], roff); stage(mS, bSMS, roff); stage(vS, bSVS, roff); }
+            MP_STAMP(2);
+            lds_barrier();                                               // ---- X: dL/dS of the previous block is consumed
+            MP_STAMP(3);
+            lds_barrier();                                               // ---- F
+            MP_STAMP(4);
+            apply(IC(0), IC(NQ / 2), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
+            // ---- layer 1: dW2 += gz^T HB (HB is overwritten after barrier 4)
+            dw_layer(wacc, IC(SL), IC(NHI), GZ, GS, [&](int rc, int l_h, int nn) { return HB[(rc + 4 * l_h) * HS + nn]; });
+            lds_barrier();                                               // ---- 4
+            apply(IC(NQ / 2), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
+            if (has_next) {
+                row_offsets(rid[r3n], roff);
+                stage(T, bST, roff);
+                if (adam) { stage(mT, bSMT, roff); stage(vT, bSVT, roff); }
+            }
+            lds_barrier();                                               // ---- 5
+            MP_STAMP(5);
+            // ---- layer 0: dW1 += gz0^T X
+            dw_layer(wacc, IC(0), IC(NI), HB, HS, [&](int rc, int l_h, int nn) {
+                return Xs[(rc + 4 * l_h) * D + ((((nn >> 2) ^ (l_h << 2)) ^ (rc & (LR - 1))) << 2) + (nn & 3)];
+            });
+            lds_barrier();                                               // ---- M: gz has been read for the last time
+            if (has_next) { if (adam) vm_wait<5 * NQ>(); else vm_wait<NQ>(); }   // the next block's source rows have landed
+            MP_STAMP(7);
+            lds_barrier();                                               // ---- E
+            MP_STAMP(8);
+        }
+        {                                                                // the last block's source rows, then this wave's weight-gradient tiles
+            const int par = (k - 1) & 1, r3 = (k - 1) % 3;
+            vm_wait<0>();
+            apply(IC(0), IC(NQ), S, mS, vS, SS + par * kRows * D, SMS, SVS, GX, 1.f, rid[r3], rok[r3], ss_s, bc_s);
+#pragma unroll
+            for (int q = 0; q < 2 * SL; ++q) {
+                const int tile = (q < SL ? 0 : TL) + pw + 4 * (q < SL ? q : q - SL);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)tile * 1024 + r * 64 + lane] = wacc[q][r];
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) lpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(1024) void map_finish_kernel(map_net net, map_opt opt, map_params P, const float* __restrict__ wpart,
                                                          const double* __restrict__ lpart, int nwg, int64_t n, float* __restrict__ loss_out,
                                                          int64_t* step_s, int64_t* step_t) {
@@ -1248,6 +1630,12 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
         lds = ((size_t)kRows * (Dp + 4) + (size_t)kRows * (Hp + 4) + 7 * (size_t)kRows * Dp) * sizeof(float);
         fn = Dp == 128 ? (Hp == 128 ? (const void*)map_pipe2_kernel<4, 4> : (const void*)map_pipe2_kernel<4, 2>)
                        : (Hp == 128 ? (const void*)map_pipe2_kernel<2, 4> : (const void*)map_pipe2_kernel<2, 2>);
+        const void* fn3 = Dp == 128 ? (Hp == 128 ? (const void*)map_pipe3_kernel<4, 4> : (const void*)map_pipe3_kernel<4, 2>)
+                                    : (Hp == 128 ? (const void*)map_pipe3_kernel<2, 4> : (const void*)map_pipe3_kernel<2, 2>);
+        if (lds > 64 * 1024) {
+            hipError_t e3 = hipFuncSetAttribute(fn3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e3 != hipSuccess) { cdr_set_error("cdr_map_step_unique: %zu B of LDS refused: %s", lds, hipGetErrorString(e3)); return (int)e3; }
+        }
     }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1259,7 +1647,12 @@ extern "C" int cdr_map_step_unique(cdr_ctx* ctx, void* stream, int opt, float* s
         cdr_time_scope ts(ctx, CDR_TAG_MAP_STEP, s);
 #define MS_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, gx, to, wpart, lpart, P
 #define MP_ARGS net, mo, src_tab, src_m, src_v, tgt_tab, tgt_m, tgt_v, idx, n, step_src_dev, step_tgt_dev, wpart, lpart, P
-        if (pipe2 && Dp == 128 && Hp == 128) map_pipe2_kernel<4, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        static const bool old_pipe2 = [] { const char* e = getenv("CDR_MAP_PIPE2"); return e && e[0] == '1'; }();     // A/B switch (tools/)
+        if (pipe2 && !old_pipe2 && Dp == 128 && Hp == 128) map_pipe3_kernel<4, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2 && !old_pipe2 && Dp == 128) map_pipe3_kernel<4, 2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2 && !old_pipe2 && Hp == 128) map_pipe3_kernel<2, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2 && !old_pipe2) map_pipe3_kernel<2, 2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
+        else if (pipe2 && Dp == 128 && Hp == 128) map_pipe2_kernel<4, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
         else if (pipe2 && Dp == 128) map_pipe2_kernel<4, 2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
         else if (pipe2 && Hp == 128) map_pipe2_kernel<2, 4><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);
         else if (pipe2) map_pipe2_kernel<2, 2><<<dim3(nwg), dim3(512), lds, s>>>(MP_ARGS);

@@ -24,7 +24,9 @@ for k in (1, 4):
     tiled = [(b[0].repeat(k), b[1].repeat(k), b[2]) for b in batches]
     old = FusedBPRStep(U, I, ROWS, opt='adam', lr=1e-3, reg_weight=0.01, user_state=us, item_state=its)
     new = KMajorBPRStep(U, I, S, k=k, opt='adam', lr=1e-3, reg_weight=0.01, user_state=us, item_state=its)
-    for name, fn, data in (('per-triple', lambda b: old.step(*b), tiled), ('per-positive', lambda b: new.step(*b), batches)):
+    rec = KMajorBPRStep(U, I, S, k=k, opt='adam', lr=1e-3, reg_weight=0.01, user_state=us, item_state=its, fuse_singles=False)   # round 2's form
+    for name, fn, data in (('per-triple', lambda b: old.step(*b), tiled), ('per-positive', lambda b: new.step(*b), batches),
+                           ('per-positive (records, r02)', lambda b: rec.step(*b), batches)):
         for i in range(5):
             fn(data[i % 4])
         torch.cuda.synchronize()
@@ -40,5 +42,5 @@ for k in (1, 4):
             acc.setdefault(nm, []).append(ms)
         B_.timing_enable(dev, 0)
         ks = ', '.join('%s %.3f' % (nm.replace('_kernel', ''), float(np.mean(v))) for nm, v in acc.items())
-        print('k=%d rows=%d %-12s: %.3f ms per domain step = %.0f M rows/s | %s' % (k, ROWS, name, dt, ROWS / dt / 1e3, ks))
-    del old, new
+        print('k=%d rows=%d %-27s: %.3f ms per domain step = %.0f M rows/s | %s' % (k, ROWS, name, dt, ROWS / dt / 1e3, ks))
+    del old, new, rec

@@ -17,6 +17,7 @@ python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fullsort --no-con
 python tools/mb_step.py > $O/mb_step.txt 2>&1; python tools/mb_step.py 50000001 20000001 1048576 128 zipf >> $O/mb_step.txt 2>&1; echo "mb_step rc=$?"
 CDR_FUSE_SINGLES=0 python tools/mb_step.py >> $O/mb_step.txt 2>&1
 python tools/mb_step2.py > $O/mb_step2.txt 2>&1; echo "mb_step2 rc=$?"
+python tools/mb_kmajor.py > $O/mb_kmajor.txt 2>&1; echo "mb_kmajor rc=$?"
 python tools/mb_mapstep.py > $O/mb_mapstep.txt 2>&1; echo "mb_mapstep rc=$?"
 python tools/mb_models5.py > $O/mb_models5.txt 2>&1; echo "mb_models5 rc=$?"
 cd /tmp && export TMPDIR=/tmp

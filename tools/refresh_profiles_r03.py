@@ -11,7 +11,7 @@ for w in ('c5', 'c5_headline', 'c3', 'c4'):
     ks = glob.glob(os.path.join(out, f'trace_{w}', '**', '*kernel_stats.csv'), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(prof, f'{tag}_bench_{w}_kernel_stats.csv'))
-for t in ('mb_step', 'mb_step2', 'mb_mapstep', 'mb_models5', 'mb_fullsort_under_pmc'):
+for t in ('mb_step', 'mb_step2', 'mb_kmajor', 'mb_mapstep', 'mb_models5', 'mb_fullsort_under_pmc'):
     f = os.path.join(out, t + '.txt')
     if os.path.exists(f):
         txt = [l for l in open(f).read().splitlines() if 'amdgpu.ids' not in l]
@@ -27,7 +27,7 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
     by = {}
     for r in rows:
         by.setdefault(short(r['Kernel_Name']), []).append(float(r['Counter_Value']))
-    HEAD = ('bpr_fwd_apply_kernel<32', 'batch_norms_kernel<32', 'occ_flags_kernel', 'rowwise_apply_dups_kernel<32, 1, false>', 'rowwise_apply_dups_kernel<32, 1, true>')
+    HEAD = ('bpr_fwd_apply_kernel<32', 'batch_norms_kernel<32', 'occ_flags_kernel', 'make_keys2_kernel', 'rowwise_apply_dups_kernel<32, 1, false>', 'rowwise_apply_dups_kernel<32, 1, true>')
     for k, vals in by.items():
         big = [v for v in vals if v > 0.5 * max(vals)] if max(vals) > 0 else vals
         if any(h in k for h in HEAD):
