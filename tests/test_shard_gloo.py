@@ -786,7 +786,7 @@ def _worker_layout(rank, world, port, layout, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,layout', [(2, 'dim'), (4, 'dim'), (2, 'row'), (4, 'row')])
+@pytest.mark.parametrize('world,layout', [(2, 'dim'), (4, 'dim'), (8, 'dim'), (2, 'row'), (4, 'row'), (8, 'row')])
 def test_bench_layouts_under_gloo(world, layout):
     """N = 2: the dimension layout cuts BOTH domains over both ranks (collectives at the first multi-GPU point); N = 4: one domain
     per half of the ranks with the prefetched id all-gather; 'row': the pipelined all-to-all exchange.  Losses of every step and
@@ -803,7 +803,7 @@ def test_bench_layouts_under_gloo(world, layout):
         p.join(timeout=60)
         assert p.exitcode == 0
     mode = res[0][1]
-    assert mode == {(2, 'dim'): 'dim', (4, 'dim'): 'dim-groups', (2, 'row'): 'row', (4, 'row'): 'row'}[(world, layout)]
+    assert mode == {(2, 'dim'): 'dim', (4, 'dim'): 'dim-groups', (8, 'dim'): 'dim-groups', (2, 'row'): 'row', (4, 'row'): 'row', (8, 'row'): 'row'}[(world, layout)]
     nu, ni, D, reg, lr = 47, 31, 16, 0.03, 0.05
     torch.manual_seed(0)
     full = {k: torch.randn(r, D) * 0.3 for k, r in (('su', nu), ('si', ni), ('tu', nu), ('ti', ni))}
