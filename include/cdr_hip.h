@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 35
+#define CDR_ABI_VERSION 36
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -337,7 +337,10 @@ int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32
  * cdr_conet_bwd: gx0 [R, 4 D] = d loss / d x0 (columns [0,D) -> source user table row user[r], [D,2D) -> source item table,
  * [2D,3D) -> target user table, [3D,4D) -> target item table: scatter with cdr_scatter_add_rows_ld); grads = host array of
  * 5 L + 4 device pointers laid out as params, every entry overwritten (d||H_l||_F included); gz [R, act_width] is scratch.
- * No float atomics: partial sums are added in a fixed order.  cdr_conet_plan gives act_width and the workspace size.         */
+ * No float atomics: partial sums are added in a fixed order.  cdr_conet_plan gives act_width and the workspace size.
+ * Training steps: cdr_conet_fwd with gz, gx0 and the workspace given (all three or none) also runs the DATA backward of every row
+ * block in the same launch, for a unit upstream gradient, and reports it in *data_gradients_done (0: this shape keeps the two-launch
+ * route); cdr_conet_bwd is then called with that flag, skips its data pass and applies grad_out (any value) to the results.       */
 #define CDR_CONET_MAX_LAYERS 8
 int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width, size_t* workspace_bytes);
 int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab, const float* ti_tab,
@@ -345,11 +348,12 @@ int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* 
                   const int64_t* item_t, int64_t R, int64_t n_source, int64_t n_overlap, int overlap_users, int L, const int* dims,
                   const float* const* params, const float* label_s, const float* label_t, float* x0, float* acts, float* prob,
                   float* maskf, float* label_cat /* [R]: the stacked labels, for cdr_conet_bwd */,
-                  int64_t* ids_cat /* [2 R]: the stacked user ids, then the stacked item ids */, float* out /* [4 + L] */);
+                  int64_t* ids_cat /* [2 R]: the stacked user ids, then the stacked item ids */, float* out /* [4 + L] */,
+                  float* gz, float* gx0, void* workspace, size_t workspace_bytes, int* data_gradients_done);
 int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L, const int* dims, const float* const* params,
                   const float* label, const float* x0, const float* acts, const float* prob, const float* maskf,
                   const float* out, const float* grad_out /* device scalar or NULL = 1 */, float* gz, float* gx0,
-                  float* const* grads, void* workspace, size_t workspace_bytes);
+                  float* const* grads, void* workspace, size_t workspace_bytes, int data_gradients_done);
 
 /* ---- SSCDR helpers (sscdr.py:120-187) -------------------------------------------------------------------------- */
 /* embedding_normalize: len = sum x^2, y = x / (len > 1 ? len : 1)  -- the squared-length quirk is kept */

@@ -24,6 +24,7 @@
 //                        conet_wgrad_finish_kernel adds them in chunk order (plus d||H||_F) -- no float atomics anywhere:
 //                        the tower backward is bit-reproducible.
 #include <string.h>
+#include <type_traits>
 #include "cdr_common.h"
 
 namespace {
@@ -38,6 +39,7 @@ static_assert(2 + CDR_CONET_MAX_LAYERS <= kConetPartial && 2048 * kConetPartial 
 
 struct conet_net {
     int L, vec, wlds;                           // wlds: the weights of layers >= 1 are staged in LDS
+    int wl_chunks;                              // 16-byte chunks of those weights (unpadded)
     int dims[kMaxL + 1];
     int act_off[kMaxL + 1];                     // column of layer l's outputs in acts / gz; act_off[L] = row width
     int wl_off[kMaxL + 1];                      // float offset of layer l's {Ws, Wt, H} block in the LDS weight area (l >= 1)
@@ -387,10 +389,9 @@ __global__ __launch_bounds__(256) void conet_fwd_kernel(conet_net net, const flo
     }
 }
 
-// out = {total, bce_source, bce_target, reg, ||H_0||_F .. ||H_{L-1}||_F}
-__global__ __launch_bounds__(256) void conet_fwd_finish_kernel(conet_net net, const double* __restrict__ partials, int nblocks,
-                                                               int64_t n_source, int64_t R, float* __restrict__ out) {
-    __shared__ double red[(2 + kMaxL) * 4];
+// out = {total, bce_source, bce_target, reg, ||H_0||_F .. ||H_{L-1}||_F}: one workgroup adds the forward blocks' partials
+__device__ __forceinline__ void conet_finish_block(const conet_net& net, const double* __restrict__ partials, int nblocks,
+                                                   int64_t n_source, int64_t R, float* __restrict__ out, double* red) {
     double acc[2 + kMaxL];
 #pragma unroll
     for (int i = 0; i < 2 + kMaxL; ++i) acc[i] = 0.0;
@@ -411,6 +412,12 @@ __global__ __launch_bounds__(256) void conet_fwd_finish_kernel(conet_net net, co
         out[1] = ls; out[2] = lt; out[3] = reg;
         out[0] = (ls + lt) + reg;
     }
+}
+
+__global__ __launch_bounds__(256) void conet_fwd_finish_kernel(conet_net net, const double* __restrict__ partials, int nblocks,
+                                                               int64_t n_source, int64_t R, float* __restrict__ out) {
+    __shared__ double red[(2 + kMaxL) * 4];
+    conet_finish_block(net, partials, nblocks, n_source, R, out, red);
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward (data)
@@ -757,6 +764,300 @@ __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R
     if (t < 2 * (dL + 1)) ou_part[(size_t)blockIdx.x * 2 * (dL + 1) + t] = ou_acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------ forward + data backward
+// Training steps: conet_fwd_kernel's pass and conet_bwd_kernel's pass over the same 32 rows in ONE launch, for a unit upstream
+// gradient (the loss is what `.backward()` is called on; any other factor is applied afterwards, conet_wgrad_finish_kernel).  Nothing
+// about a row block's data gradient depends on another block -- BCELoss's mean divides by the batch size, known up front -- so the
+// backward can start the moment the block's output unit is done: every layer's activations are still in LDS (each keeps its own
+// region instead of two ping-pong buffers), the backward's prologue (probabilities, labels, masks and the last activations back from
+// HBM: 4.5 us) and its copy of the staged weights disappear with the second launch.  The two gradient buffers take over the region
+// of the layer-0 input, which is dead after the first cross unit.  Same device functions, same order of operations as the two
+// kernels: bit-identical activations, gz, input gradients and loss.
+struct conet_fb_lds { int a_off[kMaxL + 1]; int g0_off, g1_off, wl_off; };
+
+// The kernel's prologue with every global request in flight at once: stage_weights() walks its 35 KB one load -> one LDS store at a
+// time (nine dependent L2 round trips per thread: 7.1 us, measured with wall_clock64 stamps), and the gather then starts its own two
+// dependent rounds (ids, then rows: 5.9 us).  Here the small layers' weights travel by LDS DMA (global_load_lds_dwordx4: no
+// registers, nothing to wait for until the first barrier) out of a loop of a few dozen instructions -- the prologue runs once per
+// workgroup, so every instruction of it is an instruction-cache miss, and a register-staged version unrolled over eight chunks per
+// thread was no faster than the dependent loop -- followed by the output units' weights, the thread's element of every sum H_l^2,
+// and the gather's ids and rows; LDS stores come last.
+struct fb_prologue {
+    float wo;
+    float he[kMaxL];
+};
+
+// One DMA instruction fills 64 consecutive 16-byte chunks of the row-PADDED weight area ([rows][din + 4] per matrix): the lane's
+// source is found from its destination chunk (a pad chunk re-reads its row's first chunk; nobody reads it back).
+__device__ __forceinline__ void stage_weights_dma(const conet_net& net, float* wl) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)wl;
+    const int total = net.wl_off[net.L] >> 2;                       // padded chunks
+    for (int i0 = 64 * wave; i0 < total; i0 += 256) {
+        int c = i0 + lane;
+        if (c >= total) c = total - 1;                              // (the last instruction's tail lanes: a valid source, dropped below)
+        const float* src = net.Ws[1];
+        // (l is a compile-time constant in every copy: indexed by a loop variable, each field of `net` is a dependent scalar load from
+        //  the kernel-argument segment -- 6 us for this loop)
+#pragma unroll
+        for (int l = 1; l < kMaxL; ++l) {
+            const int din = net.dims[l], dout = net.dims[l + 1], q1 = (din >> 2) + 1, n1 = dout * q1;
+            const int r3 = c - (net.wl_off[l] >> 2);
+            if (l < net.L && r3 >= 0 && r3 < 3 * n1) {
+                const int mat = (r3 >= n1 ? 1 : 0) + (r3 >= 2 * n1 ? 1 : 0);
+                const int r = r3 - mat * n1;
+                const int row = (int)(((float)r + 0.5f) * (1.0f / (float)q1));         // exact: r < 2^20, q1 small
+                const int col = r - row * q1;
+                src = (mat == 0 ? net.Ws[l] : mat == 1 ? net.Wt[l] : net.H[l]) + (int64_t)row * din + 4 * (col < q1 - 1 ? col : 0);
+            }
+        }
+        // the instruction writes lane-linear from M0: lanes past `total` would land in the next region -- the host sizes the weight
+        // area to whole instructions (fill_net: 256 floats of slack)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)i0 * 16u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+
+// this block's slice [lo, hi) of H_l (the sum of squares is split over the grid: conet_fwd_kernel)
+__device__ __forceinline__ void hsq_slice(const conet_net& net, int l, int& lo, int& hi) {
+    const int n = net.dims[l] * net.dims[l + 1];
+    const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    lo = (int)blockIdx.x * chunk;
+    hi = lo + chunk < n ? lo + chunk : n;
+}
+
+__device__ __forceinline__ void prologue_issue(const conet_net& net, float* wl, fb_prologue& pr) {
+    const int t = threadIdx.x, dL = net.dims[net.L];
+    STAMP(43);
+    if (net.wlds) stage_weights_dma(net, wl);
+    STAMP(44);
+    pr.wo = 0.f;
+    if (t < 2 * (dL + 1)) {
+        const int tower = t / (dL + 1), jj = t - tower * (dL + 1);
+        pr.wo = jj < dL ? net.wo[tower][jj] : net.bo[tower][0];
+    }
+#pragma unroll
+    for (int l = 0; l < kMaxL; ++l) {
+        pr.he[l] = 0.f;
+        if (l < net.L) {
+            int lo, hi;
+            hsq_slice(net, l, lo, hi);
+            if (lo + t < hi) pr.he[l] = net.H[l][lo + t];
+        }
+    }
+    STAMP(45);
+}
+
+// hq [kMaxL][4]: per wave, this block's slice of every sum H_l^2 (added over the waves in wave order by the tail, as block_sum_d does)
+__device__ __forceinline__ void prologue_commit(const conet_net& net, float* wo_sh, double* hq, fb_prologue& pr) {
+    const int t = threadIdx.x;
+    if (t < 2 * (net.dims[net.L] + 1)) wo_sh[t] = pr.wo;
+#pragma unroll
+    for (int l = 0; l < kMaxL; ++l) {
+        if (l < net.L) {
+            double q = (double)pr.he[l] * (double)pr.he[l];
+            int lo, hi;
+            hsq_slice(net, l, lo, hi);
+            const float* h = net.H[l];
+            for (int e = lo + t + 256; e < hi; e += 256) q += (double)h[e] * (double)h[e];
+            q = wave_sum_d(q);
+            if ((t & 63) == 0) hq[l * 4 + (t >> 6)] = q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_lds lo, const float* __restrict__ su,
+                                                       const float* __restrict__ si, const float* __restrict__ tu,
+                                                       const float* __restrict__ ti, int D, const int64_t* __restrict__ user_s,
+                                                       const int64_t* __restrict__ user_t, const int64_t* __restrict__ item_s,
+                                                       const int64_t* __restrict__ item_t, int64_t R, int64_t n_source,
+                                                       int64_t n_overlap, int overlap_users, const float* __restrict__ label_s,
+                                                       const float* __restrict__ label_t, float* __restrict__ label_cat,
+                                                       int64_t* __restrict__ ids_cat, float* __restrict__ x0, float* __restrict__ acts,
+                                                       float* __restrict__ prob, float* __restrict__ maskf, double* __restrict__ partials,
+                                                       float* __restrict__ gz, float* __restrict__ gx0, float* __restrict__ ou_part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float mrow[kRows], dzrow[kRows];
+    __shared__ int trow[kRows];
+    __shared__ float yrow[kRows], wo_sh[256];
+    __shared__ double red[2 * 4], hq[kMaxL * 4];
+    float* wl = smem + lo.wl_off;
+    float* G0 = smem + lo.g0_off;
+    float* G1 = smem + lo.g1_off;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int D4 = D >> 2, L = net.L, actw = net.act_off[L], dL = net.dims[L];
+    double lacc0 = 0.0, lacc1 = 0.0;
+    float ou_acc = 0.f;
+    STAMP(40);
+    fb_prologue pr;
+    prologue_issue(net, wl, pr);
+    const int64_t nrb = (R + kRows - 1) / kRows;
+    auto gather = [&](int64_t rb, auto first) {   // ---- gather [su | si | tu | ti] of 32 rows (8 threads per row, 16 B each): every row request of a 128-column pass is in
+            //      flight before anything is parked
+            float* bufA = smem + lo.a_off[0];
+            const int row = t >> 3, c0 = t & 7;
+            const int64_t g = rb * kRows + row;
+            const bool valid = g < R;
+            const int64_t gc = valid ? g : R - 1;
+            const bool src = gc < n_source;
+            const int64_t uid = src ? user_s[gc] : user_t[gc - n_source], iid = src ? item_s[gc] : item_t[gc - n_source];
+            const float y = c0 == 0 ? (src ? label_s[gc] : label_t[gc - n_source]) : 0.f;
+            float* xr = bufA + row * (4 * D + 4);
+            for (int cb = 0; cb < D4; cb += 32) {
+                float4 a[4], b[4], e[4], f[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = cb + c0 + 8 * i;
+                    if (c < D4) {
+                        a[i] = ld4(su + uid * D + 4 * c); b[i] = ld4(si + iid * D + 4 * c);
+                        e[i] = ld4(tu + uid * D + 4 * c); f[i] = ld4(ti + iid * D + 4 * c);
+                    }
+                }
+                if (decltype(first)::value && cb == 0) prologue_commit(net, wo_sh, hq, pr);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = cb + c0 + 8 * i;
+                    if (c < D4) {
+                        st4(xr + 4 * c, a[i]); st4(xr + D + 4 * c, b[i]); st4(xr + 2 * D + 4 * c, e[i]); st4(xr + 3 * D + 4 * c, f[i]);
+                        if (valid) {
+                            float* xg = x0 + g * (4 * (int64_t)D);
+                            st4(xg + 4 * c, a[i]); st4(xg + D + 4 * c, b[i]); st4(xg + 2 * D + 4 * c, e[i]); st4(xg + 3 * D + 4 * c, f[i]);
+                        }
+                    }
+                }
+            }
+            if (decltype(first)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights' DMA has landed (nothing tracks it)
+            if (c0 == 0) {
+                const float m = ((overlap_users ? uid : iid) < n_overlap) ? 1.f : 0.f;     // PAD id 0 counts
+                mrow[row] = m;
+                yrow[row] = y;
+                if (valid) {
+                    maskf[g] = m;
+                    label_cat[g] = y;
+                    ids_cat[g] = uid; ids_cat[R + g] = iid;               // for the embedding update (scatter / row-wise sort)
+                }
+            }
+        };
+    // the loop is rotated: a block's gather sits at the END of the previous block's pass, the first one in front of the loop with the
+    // prologue's LDS stores inside it (inside the loop, the prologue's registers would stay live through every MFMA phase)
+    STAMP(0);
+    if ((int64_t)blockIdx.x < nrb) gather((int64_t)blockIdx.x, std::true_type{});
+    else { prologue_commit(net, wo_sh, hq, pr); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        lds_barrier();
+        STAMP(1);
+        for (int l = 0; l < L; ++l) {
+            const float* Xin = smem + lo.a_off[l];
+            float* Xout = smem + lo.a_off[l + 1];
+            if (l > 0 && net.wlds && !(net.dims[l] & 7)) fwd_layer_lds(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            else if (l > 0 && net.wlds) fwd_layer<true>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            else if (net.vec && !(net.dims[l] & 127) && !(net.dims[l + 1] & 31))
+                fwd_layer_stream(net, l, Xin, Xout, mrow, acts, rb * kRows, R, wave, li, lh);
+            else fwd_layer<false>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
+            lds_barrier();
+            STAMP(2 + l);
+        }
+        const float* hl = smem + lo.a_off[L];                       // [32][2 dL + 4]
+        const int HS = 2 * dL + 4;
+        if (t < kRows) {   // ---- output unit + sigmoid + BCE term (conet.py:140,179,195-196), and d loss / d logit for a unit upstream gradient
+            const int64_t g = rb * kRows + t;
+            float dz = 0.f;
+            int tower = 0;
+            if (g < R) {
+                tower = g >= n_source ? 1 : 0;
+                const float* h = hl + t * HS + tower * dL;
+                const float* w = wo_sh + tower * (dL + 1);
+                float z = 0.f;
+                for (int j = 0; j < dL; ++j) z += h[j] * w[j];
+                z += w[dL];
+                const float p = 1.0f / (1.0f + expf(-z));
+                prob[g] = p;
+                const float y = yrow[t];
+                const double term = (double)((y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f));
+                if (tower) lacc1 += term; else lacc0 += term;
+                const float nd = (float)(tower ? R - n_source : n_source);
+                const float gp = (1.0f / nd) * (p - y) / fmaxf((1.0f - p) * p, 1e-12f);      // BCELoss backward (mean)
+                dz = (gp * (1.0f - p)) * p;                                                  // sigmoid backward
+            }
+            dzrow[t] = dz; trow[t] = tower;
+        }
+        lds_barrier();
+        STAMP(2 + L);
+        {   // ---- the output units' input gradient and their own weight gradients (this block's rows, in row order)
+            float* Gl = ((L - 1) & 1) ? G1 : G0;
+            for (int e = t; e < kRows * 2 * dL; e += 256) {
+                const int row = e / (2 * dL), c = e - row * 2 * dL;
+                const int tower = c >= dL ? 1 : 0, j = c - tower * dL;
+                Gl[row * HS + c] = (trow[row] == tower) ? dzrow[row] * wo_sh[tower * (dL + 1) + j] : 0.f;
+            }
+            if (t < 2 * (dL + 1)) {
+                const int tower = t / (dL + 1), jj = t - tower * (dL + 1);
+                float dzv[kRows], hv[kRows];                          // all 64 LDS reads first, then the row-ordered sum
+#pragma unroll
+                for (int row = 0; row < kRows; ++row) {
+                    dzv[row] = trow[row] == tower ? dzrow[row] : 0.f;
+                    hv[row] = jj < dL ? hl[row * HS + tower * dL + jj] : 1.0f;
+                }
+#pragma unroll
+                for (int row = 0; row < kRows; ++row) ou_acc = fmaf(dzv[row], hv[row], ou_acc);
+            }
+        }
+        lds_barrier();
+        for (int l = L - 1; l >= 0; --l) {
+            const int dout = net.dims[l + 1];
+            const int GS = 2 * dout + 4;
+            float* Gl = (l & 1) ? G1 : G0;
+            float* Gn = (l & 1) ? G0 : G1;
+            const float* Al = smem + lo.a_off[l + 1];                // this layer's post-ReLU outputs, same row stride as Gl
+            const int off = net.act_off[l];
+            const int q = (2 * dout) >> 2;
+            for (int e = t; e < kRows * q; e += 256) {              // ReLU backward; gz kept for the weight gradients
+                const int row = e / q, c = 4 * (e - row * q);
+                const int64_t g = rb * kRows + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < R) {
+                    const float4 a = ld4(Al + row * GS + c), gg = ld4(Gl + row * GS + c);
+                    v = make_float4(a.x > 0.f ? gg.x : 0.f, a.y > 0.f ? gg.y : 0.f, a.z > 0.f ? gg.z : 0.f, a.w > 0.f ? gg.w : 0.f);
+                    st4(gz + g * actw + off + c, v);
+                }
+                st4(Gl + row * GS + c, v);
+            }
+            lds_barrier();
+            const int din = net.dims[l];
+            const bool lds_w = l > 0 && net.wlds;
+            if (!(dout & 31) && !(din & 127)) {
+                if (lds_w) bwd_layer_quad<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+                else bwd_layer_quad<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            } else if (!(dout & 31) && !(din & 31)) {
+                if (lds_w) bwd_layer_tiles<true, 1>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+                else bwd_layer_tiles<false, 1>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            } else if (lds_w && !(dout & 7)) bwd_layer_lds(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            else if (lds_w) bwd_layer<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            else bwd_layer<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
+            lds_barrier();
+            STAMP(3 + L + (L - 1 - l));
+        }
+        if (rb + gridDim.x < nrb) gather(rb + gridDim.x, std::false_type{});
+    }
+    STAMP(41);
+    if (t < 2 * (dL + 1)) ou_part[(size_t)blockIdx.x * 2 * (dL + 1) + t] = ou_acc;
+    double lacc[2];
+    lacc[0] = lacc0; lacc[1] = lacc1;
+    block_sum_d<2>(lacc, red);
+    if (t == 0) {
+        double* o = partials + (size_t)blockIdx.x * kConetPartial;
+        o[0] = lacc[0]; o[1] = lacc[1];
+#pragma unroll
+        for (int l = 0; l < kMaxL; ++l) o[2 + l] = l < net.L ? ((hq[4 * l] + hq[4 * l + 1]) + hq[4 * l + 2]) + hq[4 * l + 3] : 0.0;
+    }
+    // (Tried: the block that finishes last -- a sign-in counter behind __threadfence() -- adds the partials instead of
+    //  conet_fwd_finish_kernel's launch.  The release fence is an L2 write-back at agent scope, i.e. of EVERY dirty line of the XCD:
+    //  this kernel's 40 MB of saved activations and gradients.  72 -> 82 us; the 5 us launch stays.)
+    STAMP(42);
+}
+
 // ------------------------------------------------------------------------------------------------------------ weight gradients
 // One WAVE per (layer, pair of 32-row m tiles, 32-column n tile, chunk of batch rows): it accumulates the Ws, Wt and H tiles
 // of its m tiles at once, so a K step of 8 batch rows costs 16 + 8 operand loads for 32 MFMAs (the first version, one
@@ -919,11 +1220,21 @@ __global__ __launch_bounds__(256) void conet_wgrad_kernel(conet_net net, conet_t
 __global__ __launch_bounds__(256) void conet_wgrad_finish_kernel(conet_net net, conet_grads gr, conet_tiles jl, int nsplit,
                                                                  const float* __restrict__ wpart, const float* __restrict__ ou_part,
                                                                  int n_ou_blocks, const float* __restrict__ out,
-                                                                 const float* __restrict__ grad_out) {
+                                                                 const float* __restrict__ grad_out, float* __restrict__ gx0_unit,
+                                                                 int64_t n_gx0) {
     constexpr int kBlocksPerJob = (kJobFloats + 255) / 256;
     __shared__ float ou_sh[256];
     const int jb = blockIdx.x / kBlocksPerJob;
     const float go = grad_out ? grad_out[0] : 1.0f;
+    // gx0_unit != null: the data gradients (gz, hence the partials here, and the input gradient) were made by conet_fb_kernel for a
+    // unit upstream gradient; everything is linear in it, so any other value is applied now -- a no-op for `loss.backward()`
+    const float unit_scale = gx0_unit ? go : 1.0f;
+    if (gx0_unit && go != 1.0f)
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (n_gx0 >> 2); e += (int64_t)gridDim.x * 256) {
+            float4 v = ld4(gx0_unit + 4 * e);
+            v.x *= go; v.y *= go; v.z *= go; v.w *= go;
+            st4(gx0_unit + 4 * e, v);
+        }
     if (jb >= jl.ntiles) {                                    // output units: block partials added in a fixed two-level order
         const int dL = net.dims[net.L], w = 2 * (dL + 1), nch = 256 / w;
         const int j = threadIdx.x % w, ch = threadIdx.x / w;
@@ -934,6 +1245,7 @@ __global__ __launch_bounds__(256) void conet_wgrad_finish_kernel(conet_net net, 
         if ((int)threadIdx.x < w) {
             float tot = 0.f;
             for (int c = 0; c < nch; ++c) tot += ou_sh[c * w + j];
+            if (unit_scale != 1.0f) tot *= unit_scale;
             const int tower = j / (dL + 1), jj = j - tower * (dL + 1);
             if (jj < dL) gr.wo[tower][jj] = tot; else gr.bo[tower][0] = tot;
         }
@@ -969,6 +1281,7 @@ __global__ __launch_bounds__(256) void conet_wgrad_finish_kernel(conet_net net, 
         for (int j = 0; j < 8; ++j) s += v[j];
     }
     for (; sp < nsplit; ++sp) s += base[(size_t)sp * stride];
+    if (unit_scale != 1.0f) s *= unit_scale;
     if (mat == 2) {
         const float nv = out[4 + d.l];                        // d||H||_F / dH = H / ||H||_F (0 at 0, as torch.norm's backward)
         if (nv > 0.f) s += (go / nv) * net.H[d.l][(int64_t)m * din + n];
@@ -980,7 +1293,7 @@ __global__ __launch_bounds__(256) void conet_wgrad_finish_kernel(conet_net net, 
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
-struct lds_plan { int strideA, strideB, strideG0, strideG1; size_t wl_floats, fwd_bytes, bwd_bytes; };
+struct lds_plan { int strideA, strideB, strideG0, strideG1; size_t wl_floats, fwd_bytes, bwd_bytes; conet_fb_lds fb; size_t fb_bytes; };
 
 int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* const* params) {
     if (L < 1 || L > kMaxL || !dims || !params) return 0;
@@ -1014,6 +1327,8 @@ int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* 
     for (int l = 0; l <= kMaxL; ++l) net.wl_off[l] = 0;
     for (int l = 1; l < L; ++l) { net.wl_off[l] = (int)wl; wl += (size_t)3 * dims[l + 1] * (dims[l] + 4); }
     net.wl_off[L] = (int)wl;
+    net.wl_chunks = 0;
+    for (int l = 1; l < L; ++l) net.wl_chunks += 3 * dims[l + 1] * (dims[l] >> 2);
     const size_t fwd = (size_t)kRows * (lp.strideA + lp.strideB) * sizeof(float);
     const size_t bwd = (size_t)kRows * (lp.strideG0 + lp.strideG1 + 2 * dims[L]) * sizeof(float);
     if (fwd > kLdsBudget || bwd > kLdsBudget) return 0;
@@ -1021,6 +1336,16 @@ int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* 
     lp.wl_floats = net.wlds ? wl : 0;
     lp.fwd_bytes = fwd + lp.wl_floats * sizeof(float);
     lp.bwd_bytes = bwd + lp.wl_floats * sizeof(float);
+    // conet_fb_kernel: the layer-0 input, one region per layer's activations, the staged weights; the two gradient buffers inside the
+    // layer-0 input's region when they fit there (fb_bytes = 0: the shape takes the two-launch route)
+    size_t o = 0;
+    for (int l = 0; l <= L; ++l) { lp.fb.a_off[l] = (int)o; o += (size_t)kRows * (2 * dims[l] + 4); }
+    for (int l = L + 1; l <= kMaxL; ++l) lp.fb.a_off[l] = (int)o;
+    if ((size_t)kRows * (lp.strideG0 + lp.strideG1) <= (size_t)lp.fb.a_off[1]) { lp.fb.g0_off = 0; lp.fb.g1_off = kRows * lp.strideG0; }
+    else { lp.fb.g0_off = (int)o; lp.fb.g1_off = (int)o + kRows * lp.strideG0; o += (size_t)kRows * (lp.strideG0 + lp.strideG1); }
+    lp.fb.wl_off = (int)o;
+    o += lp.wl_floats + (lp.wl_floats ? 256 : 0);          // whole DMA instructions (stage_weights_dma)
+    lp.fb_bytes = (o * sizeof(float) <= kLdsBudget && (net.wlds || L == 1)) ? o * sizeof(float) : 0;
     return 1;
 }
 
@@ -1090,8 +1415,11 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
                              const int64_t* item_t, int64_t R, int64_t n_source,
                              int64_t n_overlap, int overlap_users, int L, const int* dims, const float* const* params,
                              const float* label_s, const float* label_t, float* x0, float* acts, float* prob, float* maskf,
-                             float* label_cat, int64_t* ids_cat, float* out) {
+                             float* label_cat, int64_t* ids_cat, float* out, float* gz, float* gx0, void* workspace,
+                             size_t workspace_bytes, int* data_gradients_done) {
     CDR_CHECK_ARG(ctx && su_tab && si_tab && tu_tab && ti_tab && x0 && acts && prob && maskf && label_cat && ids_cat && out);
+    CDR_CHECK_ARG((gz == nullptr) == (gx0 == nullptr) && (gz == nullptr || (workspace && data_gradients_done)));
+    if (data_gradients_done) *data_gradients_done = 0;
     CDR_CHECK_ARG(R > 0 && n_source >= 0 && n_source <= R && D > 0 && (D & 3) == 0);
     CDR_CHECK_ARG((n_source == 0 || (user_s && item_s && label_s)) && (n_source == R || (user_t && item_t && label_t)));
     conet_net net;
@@ -1101,6 +1429,32 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)rows_grid(R);
+    if (gz && lp.fb_bytes) {                     // training step: forward and data backward of every 32-row block in one launch
+        int aw = 0; size_t need = 0;
+        rc = cdr_conet_plan(L, dims, R, &aw, &need);
+        if (rc) return rc;
+        CDR_CHECK_ARG(workspace_bytes >= need);
+        conet_tiles tl;
+        fill_tiles(net, tl);
+        int nsplit; int64_t kc;
+        split_plan(tl.ntiles, R, &nsplit, &kc);
+        const size_t wpart_bytes = ((size_t)tl.ntiles * nsplit * kJobFloats * sizeof(float) + 255) & ~(size_t)255;
+        float* ou_part = (float*)((char*)workspace + wpart_bytes);
+        rc = lds_opt_in((const void*)conet_fb_kernel, lp.fb_bytes);
+        if (rc) return rc;
+        {
+            cdr_time_scope ts(ctx, CDR_TAG_CONET_FWD, s);
+            conet_fb_kernel<<<dim3(grid), dim3(256), lp.fb_bytes, s>>>(net, lp.fb, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s,
+                                                                       item_t, R, n_source, n_overlap, overlap_users, label_s, label_t,
+                                                                       label_cat, ids_cat, x0, acts, prob, maskf, ctx->partials, gz, gx0,
+                                                                       ou_part);
+        }
+        CDR_LAUNCH_CHECK();
+        conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(net, ctx->partials, grid, n_source, R, out);
+        CDR_LAUNCH_CHECK();
+        *data_gradients_done = 1;
+        return CDR_OK;
+    }
     {
         cdr_time_scope ts(ctx, CDR_TAG_CONET_FWD, s);
         conet_fwd_kernel<<<dim3(grid), dim3(256), lp.fwd_bytes, s>>>(net, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s, item_t,
@@ -1116,7 +1470,7 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
 extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L, const int* dims,
                              const float* const* params, const float* label, const float* x0, const float* acts, const float* prob,
                              const float* maskf, const float* out, const float* grad_out, float* gz, float* gx0,
-                             float* const* grads, void* workspace, size_t workspace_bytes) {
+                             float* const* grads, void* workspace, size_t workspace_bytes, int data_gradients_done) {
     CDR_CHECK_ARG(ctx && label && x0 && acts && prob && maskf && out && gz && gx0 && grads && workspace);
     CDR_CHECK_ARG(R > 0 && n_source >= 0 && n_source <= R);
     conet_net net;
@@ -1148,7 +1502,7 @@ extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_so
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)rows_grid(R);
-    {
+    if (!data_gradients_done) {
         cdr_time_scope ts(ctx, CDR_TAG_CONET_BWD, s);
         conet_bwd_kernel<<<dim3(grid), dim3(256), lp.bwd_bytes, s>>>(net, R, n_source, label, prob, maskf, acts, grad_out, lp.strideG0,
                                                                      lp.strideG1, gz, gx0, ou_part);
@@ -1161,7 +1515,8 @@ extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_so
     }
     CDR_LAUNCH_CHECK();
     conet_wgrad_finish_kernel<<<dim3((unsigned)(tl.ntiles * ((kJobFloats + 255) / 256) + 1)), dim3(256), 0, s>>>(
-        net, gr, tl, ngroup, wpart, ou_part, grid, out, grad_out);
+        net, gr, tl, ngroup, wpart, ou_part, grid, out, grad_out, data_gradients_done ? gx0 : nullptr,
+        data_gradients_done ? R * 2 * (int64_t)dims[0] : 0);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

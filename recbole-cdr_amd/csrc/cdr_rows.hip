@@ -216,6 +216,9 @@ struct adam_multi_args {
     int count;
 };
 
+// (Tried in round 3: no separate launch for the bump -- every block signs in on the upper half of tensor 0's counter word with one
+//  atomicAdd and the last one writes the counters.  Same-address atomics serialise: +6 us on C1's 650 blocks, +55 us on C4's 10 k,
+//  against the 4.7 us launch it removed; numbers in profiles/r03_ab_adam_signin.txt.)
 __global__ void inc_multi_kernel(adam_multi_args a) {
     if (blockIdx.x == 0 && (int)threadIdx.x < a.count) a.step[threadIdx.x][0] += 1;
 }

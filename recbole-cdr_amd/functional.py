@@ -6,6 +6,7 @@ over ``model.parameters()``, so in drop-in mode the backward kernels write the d
 materialises table-sized gradients lives in ``fused.py``.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -588,6 +589,18 @@ class FrobeniusNorm(Function):
 
 
 _conet_ws = {}
+
+
+def _conet_workspace(dev, need):
+    """The tower kernels' scratch (weight-gradient partials, output-unit partials), one per device and stream."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _conet_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        _conet_ws[key] = ws
+    return ws
+
+
 _sort_bufs = {}
 
 
@@ -654,11 +667,21 @@ class ConetFusedLoss(Function):
         x0, acts, prob, maskf, label, out = f32(R, 4 * D), f32(R, aw.value), f32(R), f32(R), f32(R), f32(4 + L)
         ids = torch.empty(2 * R, device=dev, dtype=torch.int64)          # the stacked user ids, then the stacked item ids
         pp = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        # a forward that will be differentiated also runs the data backward of every row block, in the same launch (for a unit upstream
+        # gradient; ``backward`` applies any other): the activations never leave LDS in between
+        train = any(ctx.needs_input_grad) and os.environ.get('CDR_CONET_TWO_LAUNCH', '0') != '1'     # (the switch is for A/B runs and tests)
+        gz = gx0 = ws = None
+        if train:
+            # (a workspace of its own: its output-unit partials must survive until THIS node's backward, whatever runs in between)
+            gz, gx0, ws = f32(R, aw.value), f32(R, 4 * D), torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+        done = ctypes.c_int(0)
         B_.call('cdr_conet_fwd', B_.ctx(dev), B_.stream(), B_.f32(su), B_.f32(si), B_.f32(tu), B_.f32(ti), D, B_.i64(user_s),
                 B_.i64(user_t), B_.i64(item_s), B_.i64(item_t), R, int(n_source), int(n_overlap), 1 if overlap_users else 0, L, dims_c,
                 pp, B_.f32(label_s), B_.f32(label_t), B_.f32(x0), B_.f32(acts), B_.f32(prob), B_.f32(maskf), B_.f32(label),
-                B_.i64(ids), B_.f32(out))
+                B_.i64(ids), B_.f32(out), B_.f32(gz) if train else None, B_.f32(gx0) if train else None, B_.raw(ws) if train else None,
+                ws.numel() if train else 0, ctypes.byref(done))
         ctx.save_for_backward(ids, label, x0, acts, prob, maskf, out, *params)
+        ctx.data_done = (gz, gx0, ws) if done.value else None
         ctx.meta = (int(n_source), tuple(int(d) for d in dims), aw.value, int(need.value), tuple(su.shape), tuple(si.shape))
         ctx.row_opt = row_opt
         ctx.mark_non_differentiable(out)
@@ -673,20 +696,21 @@ class ConetFusedLoss(Function):
         R, L, D = label.numel(), len(dims) - 1, ushape[1]
         user, item = ids[:R], ids[R:]
         dev = x0.device
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        ws = _conet_ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, device=dev, dtype=torch.uint8)
-            _conet_ws[key] = ws
-        gz = torch.empty(R, aw, device=dev, dtype=torch.float32)
-        gx0 = torch.empty(R, 4 * D, device=dev, dtype=torch.float32)
+        done = ctx.data_done is not None
+        if done:
+            gz, gx0, ws = ctx.data_done      # made by the forward's launch; the workspace holds its output-unit partials
+            ctx.data_done = None
+        else:
+            ws = _conet_workspace(dev, need)
+            gz = torch.empty(R, aw, device=dev, dtype=torch.float32)
+            gx0 = torch.empty(R, 4 * D, device=dev, dtype=torch.float32)
         grads = tuple(torch.empty_like(p) for p in params)
         dims_c = (ctypes.c_int * (L + 1))(*dims)
         pp = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
         gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         go = grad_loss.reshape(-1).contiguous().to(torch.float32)
         B_.call('cdr_conet_bwd', B_.ctx(dev), B_.stream(), R, n_source, L, dims_c, pp, B_.f32(label), B_.f32(x0), B_.f32(acts),
-                B_.f32(prob), B_.f32(maskf), B_.f32(out), B_.f32(go), B_.f32(gz), B_.f32(gx0), gp, B_.raw(ws), ws.numel())
+                B_.f32(prob), B_.f32(maskf), B_.f32(out), B_.f32(go), B_.f32(gz), B_.f32(gx0), gp, B_.raw(ws), ws.numel(), 1 if done else 0)
         del pp, gp
         if ctx.row_opt is not None:
             # deferred row-wise Adam (lazyadam.DeferredRowAdam): the tables get no dense gradient at all -- the optimizer reads

@@ -871,6 +871,62 @@ def test_conet_fused_ragged_shapes_and_determinism(R, n_s, hidden, D):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+def test_conet_forward_and_data_backward_in_one_launch(monkeypatch):
+    """A differentiated CoNet forward also runs the data backward of every row block in the same launch (conet_fb_kernel), for a
+    unit upstream gradient: (a) same loss bits and same gradients as the two-launch route (table and layer gradients bit for bit: same
+    device functions in the same order; the output units' few numbers within 1e-6), (b) an upstream gradient other than 1 is applied
+    afterwards: ``(2.5 * loss).backward()`` against the oracle's autograd at 1e-5."""
+    from oracle import conet as oconet
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    torch.manual_seed(11)
+    ids = IdSpace(OU=300, TOU=500, SOU=700, OI=1, TOI=900, SOI=1100)
+    cfg = base_config(DEV, embedding_size=128, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    rs = np.random.RandomState(3)
+    n_s, n_t = 1001, 777
+    inter = {'source_user_id': torch.from_numpy(rs.randint(0, ids.total_num_users, n_s)),
+             'source_item_id': torch.from_numpy(rs.randint(0, ids.total_num_items, n_s)),
+             'source_label': torch.from_numpy((rs.rand(n_s) < 0.3).astype(np.float32)),
+             'target_user_id': torch.from_numpy(rs.randint(0, ids.OU + ids.TOU, n_t)),
+             'target_item_id': torch.from_numpy(rs.randint(0, ids.OI + ids.TOI, n_t)),
+             'target_label': torch.from_numpy((rs.rand(n_t) < 0.3).astype(np.float32))}
+    dev_inter = to_dev(inter, DEV)
+
+    def run(scale):
+        model.zero_grad(set_to_none=True)
+        loss = model.calculate_loss(dev_inter)
+        (loss * scale if scale != 1.0 else loss).backward()
+        return loss.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
+
+    from recbole_cdr_amd import binding as B_
+    B_.timing_enable(DEV, 64)
+    one = run(1.0)
+    tags = [n for n, _ in B_.timing_collect(DEV)]
+    assert 'conet_bwd_kernel' not in tags and 'conet_fwd_kernel' in tags, tags          # one launch did both
+    monkeypatch.setenv('CDR_CONET_TWO_LAUNCH', '1')
+    B_.timing_enable(DEV, 64)
+    two = run(1.0)
+    assert 'conet_bwd_kernel' in [n for n, _ in B_.timing_collect(DEV)]
+    monkeypatch.delenv('CDR_CONET_TWO_LAUNCH')
+    B_.timing_enable(DEV, 0)
+    assert torch.equal(one[0], two[0])
+    for k in one[1]:
+        if 'output' in k or k.split('.')[0] in ('source_output', 'target_output') or one[1][k].numel() <= 16:
+            torch.testing.assert_close(one[1][k], two[1][k], rtol=1e-6, atol=1e-9, msg=k)
+        else:
+            assert torch.equal(one[1][k], two[1][k]), k
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    (oconet.calculate_loss(params, ids, inter) * 2.5).backward()
+    scaled = run(2.5)
+    for k, v in scaled[1].items():
+        assert_close(v, params[k].grad, what=k)
+
+
 def test_deferred_adam_ring_of_update_scalars_wraps():
     """The per-update scalars live in a ring (capacity 8 here): 45 updates -- five times round -- stay bit-identical to the dense
     sweep because the optimizer flushes every table before an entry some row still needs is overwritten; also through

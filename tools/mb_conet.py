@@ -48,7 +48,11 @@ for name, v in acc.items():
                                                   ('%.1f TFLOP/s' % (fl * mult / (v.mean() * 1e-3) / 1e12)) if mult else ''))
 if prof is not None:
     p = prof.cpu().numpy()
-    f = p[:2 + 4 + 1]
-    print('fwd stamps (us from start):', [round((x - f[0]) / 100.0, 2) for x in f])
-    b = p[16:16 + 3 + 8]
-    print('bwd stamps (us from start):', [round((x - b[0]) / 100.0, 2) for x in b])
+    if p[40]:        # conet_fb_kernel: entry, [gather, layers 0..3, output unit], [backward layers 3..0], tail start, end
+        f = [p[40], p[43], p[44], p[45]] + list(p[:2 + 4 + 1 + 4]) + [p[41], p[42]]
+        print('fwd+bwd stamps (us from kernel entry):', [round(float(x - f[0]) / 100.0, 2) for x in f])
+    else:
+        f = p[:2 + 4 + 1]
+        print('fwd stamps (us from start):', [round(float(x - f[0]) / 100.0, 2) for x in f])
+        b = p[16:16 + 3 + 8]
+        print('bwd stamps (us from start):', [round(float(x - b[0]) / 100.0, 2) for x in b])
