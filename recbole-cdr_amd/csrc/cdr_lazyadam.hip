@@ -74,6 +74,8 @@ __global__ __launch_bounds__(kBlock) void lz_prepare_kernel(lz_args a, float2* _
         if (q > 0 && tb.keys[q - 1] == row) continue;                // one lane group per DISTINCT row
         const int64_t from = tb.last[row];
         if (from >= t - 1) continue;
+        // (Tried: one or two elements per lane instead of a float4 and four updates' scalars per request, to shorten the dependent chain
+        //  of the most-postponed row: 17.5 -> 18.7 us.  The launch moves ~60 MB of 512-byte row segments: it is at the HBM rate.)
         for (int ch = sub; ch < D4; ch += LPR) {
             const int64_t o = (int64_t)row * D + 4 * ch;
             float4 w = ld4(tb.W + o), m = ld4(tb.M + o), v = ld4(tb.V + o);
@@ -94,22 +96,46 @@ __global__ __launch_bounds__(kBlock) void lz_apply_kernel(lz_args a, const float
     const int D = a.D, D4 = D >> 2;
     const int64_t t = counters[1];
     const float2 h = hp[t & a.hp_mask];
+    // lanes of this group inside its wave, for the group-wide ballot / shuffles below
+    const int gbase = (threadIdx.x & 63) / LPR * LPR;
+    const unsigned long long gmask = LPR >= 64 ? ~0ull : ((1ull << LPR) - 1ull);
     for (int64_t q = gg; q < tb.n; q += TG) {
         const uint32_t row = tb.keys[q];
         if (q > 0 && tb.keys[q - 1] == row) continue;
-        for (int ch = sub; ch < D4; ch += LPR) {
+        for (int c0 = 0; c0 < D4; c0 += LPR) {                 // every lane of the group runs every pass (the ballot and shuffles below)
+            const int ch = c0 + sub < D4 ? c0 + sub : 0;
+            const bool act = c0 + sub < D4;
             const int64_t o = (int64_t)row * D + 4 * ch;
             float4 w = ld4(tb.W + o), m = ld4(tb.M + o), v = ld4(tb.V + o);
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int64_t e = q; e < tb.n && tb.keys[e] == row; ++e) {              // the row's occurrences, in occurrence order
-                const float4 x = ld4(tb.G + (int64_t)tb.perm[e] * tb.ldg + 4 * ch);
-                g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+            // the row's occurrences, summed in occurrence order.  Walking them one by one is a chain of two dependent global loads per
+            // occurrence (key, then permutation entry, then the gradient row: five occurrences of a user = ten round trips, most of this
+            // kernel's 18 us); here the group reads LPR keys at once, then its permutation entries at once, then up to eight gradient
+            // rows at once -- three round trips for a row with up to eight occurrences.
+            for (int64_t e = q;;) {
+                const uint32_t kk = e + sub < tb.n ? tb.keys[e + sub] : ~row;
+                const unsigned long long hit = (__ballot(kk == row) >> gbase) & gmask;
+                const int run = hit == gmask ? LPR : __builtin_ctzll(~hit);          // leading lanes of the group that still see this row
+                const uint32_t pe = sub < run ? tb.perm[e + sub] : 0u;
+                for (int i0 = 0; i0 < run; i0 += 8) {
+                    float4 x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t pi = (uint32_t)__shfl((int)pe, gbase + (i0 + i < run ? i0 + i : 0));
+                        x[i] = i0 + i < run ? ld4(tb.G + (int64_t)pi * tb.ldg + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i0 + i < run) { g.x += x[i].x; g.y += x[i].y; g.z += x[i].z; g.w += x[i].w; }
+                }
+                if (run < LPR) break;
+                e += run;
             }
             w.x = cdr_adam_elem(w.x, g.x, m.x, v.x, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
             w.y = cdr_adam_elem(w.y, g.y, m.y, v.y, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
             w.z = cdr_adam_elem(w.z, g.z, m.z, v.z, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
             w.w = cdr_adam_elem(w.w, g.w, m.w, v.w, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
-            st4(tb.W + o, w); st4(tb.M + o, m); st4(tb.V + o, v);
+            if (act) { st4(tb.W + o, w); st4(tb.M + o, m); st4(tb.V + o, v); }
         }
         if (sub == 0) tb.last[row] = (int32_t)t;
     }
