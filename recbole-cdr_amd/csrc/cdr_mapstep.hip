@@ -371,6 +371,11 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
     constexpr int SLOTS = NI * NI / 4 > 0 ? NI * NI / 4 : 1;       // weight-gradient tiles per MFMA wave
     constexpr int NJ = (NI + 3) / 4;           // 32-column jobs per MFMA wave
     constexpr int NQ = NI;                     // DMA instructions per row wave and array (4 row waves)
+    // target rows updated before barrier M (the rest after it).  Stamps of one block (tools/prof_mapstep.py): whatever update arithmetic
+    // a row wave has left after M runs against the dL/dS contraction of its SIMD (resident weights: back-to-back MFMAs) and takes 2.5-3 us
+    // per quarter of the rows where a quarter takes 0.9 us before M, and barrier E then waits for it.  Halves: 0.1251 ms per launch at
+    // OB = 65,536; three quarters before M: 0.1238; everything: 0.1223 (alternating processes on one box, profiles/r03_ab_map_qt.txt).
+    constexpr int QT = NQ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float rok[3][kRows];
     __shared__ int64_t rid[3][kRows];
@@ -656,10 +661,10 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             MP_STAMP(3);
             lds_barrier();                                               // ---- F
             MP_STAMP(4);
-            apply(IC(0), IC(NQ / 2), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
+            apply(IC(0), IC(QT), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);   // dL/dT[id] = -dL/d mapped
             MP_STAMP(5);
             lds_barrier();                                               // ---- M
-            apply(IC(NQ / 2), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
+            apply(IC(QT), IC(NQ), T, mT, vT, ST, SMT, SVT, GZ, -1.f, rid[r3], rok[r3], ss_t, bc_t);
             MP_STAMP(10);
             if (has_next) {
                 row_offsets(rid[r3n], roff);
