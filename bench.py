@@ -925,7 +925,8 @@ def run_model_workload(args, world, rank, dev):
                 kt.setdefault(nm, []).append(ms)
             B_.timing_enable(dev, 0)
             ks, tot = [], 0.0
-            for nm, share in (('conet_fwd_kernel', 1.0), ('conet_bwd_kernel', 1.0), ('conet_wgrad_kernel', 1.0)):
+            # (a training step's forward also runs the data backward: conet_fb_kernel carries two of the three passes)
+            for nm, share in (('conet_fb_kernel', 2.0), ('conet_fwd_kernel', 1.0), ('conet_bwd_kernel', 1.0), ('conet_wgrad_kernel', 1.0)):
                 v = kt.get(nm, [])[2:]
                 if v:
                     ms = sum(v) / len(v)

@@ -66,6 +66,7 @@ int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the
 #define CDR_TAG_OCC_FLAGS 17            /* occ_flags_kernel: single-occurrence flags + duplicate-segment heads */
 #define CDR_TAG_BPR_FWD_APPLY 18        /* bpr_fwd_apply_kernel: forward + optimizer on the single-occurrence rows */
 #define CDR_TAG_BATCH_NORMS 19          /* batch_norms_kernel: EmbLoss norms of the batch's user and positive rows */
+#define CDR_TAG_CONET_FB 20             /* conet_fb_kernel: conet_fwd_kernel's and conet_bwd_kernel's passes over a row block in one launch */
 int cdr_timing_enable(cdr_ctx* ctx, int capacity);
 int cdr_timing_collect(cdr_ctx* ctx, int* tags, float* ms, int max_n, int* n_out);
 

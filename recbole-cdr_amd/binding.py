@@ -308,7 +308,7 @@ TAGS = {1: 'bpr_fwd_kernel', 2: 'point_fwd_kernel', 3: 'bpr_fwd_grad_kernel', 4:
         8: 'bpr_partial_diff_kernel', 9: 'bpr_grad_from_diff_kernel',
         10: 'point_partial_dot_kernel', 11: 'point_grad_from_dot_kernel',
         12: 'conet_fwd_kernel', 13: 'conet_bwd_kernel', 14: 'conet_wgrad_kernel', 15: 'bpr_fwd_kmajor_kernel', 16: 'map_step_kernel',
-        17: 'occ_flags_kernel', 18: 'bpr_fwd_apply_kernel', 19: 'batch_norms_kernel'}
+        17: 'occ_flags_kernel', 18: 'bpr_fwd_apply_kernel', 19: 'batch_norms_kernel', 20: 'conet_fb_kernel'}
 
 
 _timing_cap = {}     # device index -> ring capacity requested for every context (= stream) of that device

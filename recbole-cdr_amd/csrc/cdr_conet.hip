@@ -1443,7 +1443,7 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
         rc = lds_opt_in((const void*)conet_fb_kernel, lp.fb_bytes);
         if (rc) return rc;
         {
-            cdr_time_scope ts(ctx, CDR_TAG_CONET_FWD, s);
+            cdr_time_scope ts(ctx, CDR_TAG_CONET_FB, s);
             conet_fb_kernel<<<dim3(grid), dim3(256), lp.fb_bytes, s>>>(net, lp.fb, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s,
                                                                        item_t, R, n_source, n_overlap, overlap_users, label_s, label_t,
                                                                        label_cat, ids_cat, x0, acts, prob, maskf, ctx->partials, gz, gx0,

@@ -907,7 +907,7 @@ def test_conet_forward_and_data_backward_in_one_launch(monkeypatch):
     B_.timing_enable(DEV, 64)
     one = run(1.0)
     tags = [n for n, _ in B_.timing_collect(DEV)]
-    assert 'conet_bwd_kernel' not in tags and 'conet_fwd_kernel' in tags, tags          # one launch did both
+    assert 'conet_bwd_kernel' not in tags and 'conet_fwd_kernel' not in tags and 'conet_fb_kernel' in tags, tags          # one launch did both
     monkeypatch.setenv('CDR_CONET_TWO_LAUNCH', '1')
     B_.timing_enable(DEV, 64)
     two = run(1.0)

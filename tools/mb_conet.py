@@ -43,7 +43,7 @@ R = 2 * S * (1 + k)
 fl = 152.6e3 * R
 for name, v in acc.items():
     v = np.array(v[5:])
-    mult = {'conet_fwd_kernel': 1, 'conet_bwd_kernel': 1, 'conet_wgrad_kernel': 1}.get(name, 0)
+    mult = {'conet_fb_kernel': 2, 'conet_fwd_kernel': 1, 'conet_bwd_kernel': 1, 'conet_wgrad_kernel': 1}.get(name, 0)
     print('%-22s avg %.1f us  min %.1f us  %s' % (name, v.mean() * 1e3, v.min() * 1e3,
                                                   ('%.1f TFLOP/s' % (fl * mult / (v.mean() * 1e-3) / 1e12)) if mult else ''))
 if prof is not None:
