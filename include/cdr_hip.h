@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 36
+#define CDR_ABI_VERSION 37
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -134,6 +134,12 @@ int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float* const* use
 int cdr_gather_rows(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out);
 int cdr_scatter_add_rows(void* stream, float* grad_tab, int D, const int64_t* ids, int64_t n,
                          const float* src, const float* scale);
+/* the two above for up to four (table, id list) pairs in ONE launch (host arrays of device pointers); bump_counter: optional device
+ * int64 advanced by one in the gather's launch (a call counter the launch in front of it read: sscdr.py:166's sampler) */
+int cdr_gather_rows_multi(void* stream, int count, const float* const* tabs, int D, const int64_t* const* ids, const int64_t* n,
+                          float* const* outs, int64_t* bump_counter);
+int cdr_scatter_add_rows_multi(void* stream, int count, float* const* grad_tabs, int D, const int64_t* const* ids, const int64_t* n,
+                               const float* const* srcs);
 
 /* K7: mapped-or-target select (emcdr.py:195-197,201-203,222-224 ; sscdr.py:214-216,242-244):
  *   out[r,:] = ids[r] < n_overlap ? mapped[r,:] : tab[ids[r],:]                                               */
@@ -184,6 +190,17 @@ int cdr_act_bwd(void* stream, int act, const float* y, const float* gy, float* g
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients, batch reductions of per-row parameter-gradient partials): two launches,
  * fixed summation order (slab partials in the context's scratch, added in slab order): bit-reproducible */
 int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate);
+/* dW [out, in] = gz^T x and db [out] = column sums of gz (db may be NULL) in ONE launch, for the backward of nn.Linear on small
+ * batches (gz [rows, out], x [rows, in] row-major; emcdr.py:86-93, sscdr.py:60-66): fixed-order sums, no float atomics */
+int cdr_linear_wgrad_small(void* stream, const float* gz, const float* y_out /* or NULL */, int act, const float* x, int64_t rows, int dout,
+                           int din, float* dW, float* db);
+/* (y_out given: gz is the OUTPUT gradient and the kernel forms gz (.) act'(y_out) itself -- no cdr_act_bwd launch in front) */
+/* the forward and the input gradient of the same small layers, one wave per 32 x 32 output tile, operands from global memory:
+ *   w_is_k_major = 0: C [M, N] = act(A [M, K] W^T + bias), W [N, K] row-major (y = act(x W^T + b));
+ *   w_is_k_major = 1: C [M, N] = A [M, K] W, W [K, N] row-major (dx = gz W); bias NULL / act CDR_ACT_NONE there.  K % 4 == 0. */
+int cdr_linear_small(void* stream, int w_is_k_major, const float* A, int64_t lda, const float* W, int64_t ldw, int64_t M, int N, int K,
+                     const float* bias, int act, float* C, int64_t ldc, const float* a_out /* or NULL: A := A (.) a_act'(a_out), same shape */,
+                     int a_act);
 /* mean-squared error over all elements + its gradient: out[0] = mean((a-b)^2) ; ga = 2(a-b)/n * grad_out       */
 int cdr_mse_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* b, int64_t n, float* out1);
 int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t n, const float* grad_out,
@@ -360,6 +377,14 @@ int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L
 /* embedding_normalize: len = sum x^2, y = x / (len > 1 ? len : 1)  -- the squared-length quirk is kept */
 int cdr_sqnorm_normalize_fwd(void* stream, const float* x, int64_t rows, int D, float* y, float* len_out);
 int cdr_sqnorm_normalize_bwd(void* stream, const float* x, const float* len, const float* gy, int64_t rows, int D, float* gx);
+/* SSCDR's whole map-phase loss in one pass (sscdr.py:161-172): mapped3 [3 n, D] = the mapping applied to [source rows of the overlapped
+ * ids ; rows of the sampled interacted ids ; rows of the sampled non-interacted ids], target_rows [n, D] the ids' target rows.
+ *   out3 = {MSE(mapped3[:n], target_rows) + lambda * triplet(normalize(target_rows), normalize(mapped3[n:2n]), normalize(mapped3[2n:])),
+ *           the MSE, the triplet term};  g_mapped3 / g_target_rows = d out3[0] / d inputs for a unit upstream gradient
+ * (cdr_scale2_unless_one applies any other: x *= s, y *= s unless the device scalar s is exactly 1).                                  */
+int cdr_sscdr_map_loss(cdr_ctx* ctx, void* stream, const float* mapped3, const float* target_rows, int64_t n, int D, float margin,
+                       float eps, float lambda, float* out3, float* g_mapped3, float* g_target_rows);
+int cdr_scale2_unless_one(void* stream, const float* scale_dev, float* x, int64_t nx, float* y, int64_t ny);
 /* nn.TripletMarginLoss(margin, p=2, eps): mean_r max(||a-p+eps|| - ||a-n+eps|| + margin, 0) */
 int cdr_triplet_fwd(cdr_ctx* ctx, void* stream, const float* a, const float* p, const float* n, int64_t rows, int D,
                     float margin, float eps, float* out1, float* dap, float* dan);

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -54,6 +54,10 @@ _SIGNATURES = {
     'cdr_point_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
                             _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_gather_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr],
+    'cdr_gather_rows_multi': [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_scatter_add_rows_multi': [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_sscdr_map_loss': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_scale2_unless_one': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64],
     'cdr_scatter_add_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr],
     'cdr_select_mapped': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_ptr],
     'cdr_gemm_f32': [_c_ptr, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
@@ -62,6 +66,8 @@ _SIGNATURES = {
     'cdr_fullsort_neg_sqdist_f32': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr],
     'cdr_act_bwd': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_colsum': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int],
+    'cdr_linear_wgrad_small': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr],
+    'cdr_linear_small': [_c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_int],
     'cdr_mse_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_mse_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_bpr_fwd_grad': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_f32, _c_ptr,

@@ -205,6 +205,101 @@ __global__ __launch_bounds__(kBlock) void triplet_bwd_kernel(const float* __rest
     }
 }
 
+// ---- SSCDR map phase in one pass (sscdr.py:161-172): loss_s = MSE(mapped source rows, target rows); loss_u = triplet(normalize(target
+// rows), normalize(mapped interacted rows), normalize(mapped non-interacted rows)); total = loss_s + lambda loss_u -- and, in the same pass,
+// d total / d inputs for a unit upstream gradient (the arithmetic of mse_bwd_kernel, triplet_bwd_kernel and sqnorm_normalize_bwd_kernel
+// chained per row).  M3 [3 n, D] = the mapping of [source rows ; interacted ; non-interacted], T [n, D]; one wave per row.
+//   partials: [0] sum (ms - t)^2, [1] sum of the hinge terms
+__device__ __forceinline__ float sq_norm_bwd(float x, float g, float L, float dot) {       // sqnorm_normalize_bwd_kernel, one element
+    return L > 1.0f ? g / L - (2.0f * dot / (L * L)) * x : g;
+}
+
+__global__ __launch_bounds__(kBlock) void sscdr_map_loss_kernel(const float* __restrict__ M3, const float* __restrict__ T, int64_t n, int D,
+                                                                float margin, float eps, float lambda, float* __restrict__ G3,
+                                                                float* __restrict__ GT, double* __restrict__ partials) {
+    __shared__ double smem[8];
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), TW = (int64_t)gridDim.x * 4;
+    const float cs = 2.0f / (float)(n * D);                  // mse_bwd_kernel: go * 2 / numel
+    const float cu = lambda / (float)n;                      // triplet_bwd_kernel: (lambda go) / rows
+    double acc[2] = {0.0, 0.0};
+    for (int64_t r = w; r < n; r += TW) {
+        const float* ms = M3 + r * D;
+        const float* mp = M3 + (n + r) * D;
+        const float* mn = M3 + (2 * n + r) * D;
+        const float* t = T + r * D;
+        float se = 0.f, lt = 0.f, lp = 0.f, lq = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float d = ms[c] - t[c];
+            se += d * d; lt += t[c] * t[c]; lp += mp[c] * mp[c]; lq += mn[c] * mn[c];
+        }
+        se = group_sum<64>(se); lt = group_sum<64>(lt); lp = group_sum<64>(lp); lq = group_sum<64>(lq);
+        const float nt = lt > 1.0f ? lt : 1.0f, np_ = lp > 1.0f ? lp : 1.0f, nq = lq > 1.0f ? lq : 1.0f;
+        float sp = 0.f, sn = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float av = t[c] / nt;
+            const float dp = av - mp[c] / np_ + eps, dn = av - mn[c] / nq + eps;
+            sp += dp * dp; sn += dn * dn;
+        }
+        sp = group_sum<64>(sp); sn = group_sum<64>(sn);
+        const float d1 = sqrtf(sp), d2 = sqrtf(sn);
+        const bool active = d1 - d2 + margin > 0.0f;
+        if (lane == 0) { acc[0] += (double)se; acc[1] += (double)fmaxf(d1 - d2 + margin, 0.0f); }
+        // gradients of the triplet term w.r.t. the three normalised rows, then through the normalisation (needs x . g per row)
+        float da = 0.f, dpp = 0.f, dq = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float av = t[c] / nt;
+            const float u1 = (active && d1 > 0.f) ? (av - mp[c] / np_ + eps) / d1 : 0.f;
+            const float u2 = (active && d2 > 0.f) ? (av - mn[c] / nq + eps) / d2 : 0.f;
+            da += t[c] * (cu * (u1 - u2)); dpp += mp[c] * (-cu * u1); dq += mn[c] * (cu * u2);
+        }
+        da = group_sum<64>(da); dpp = group_sum<64>(dpp); dq = group_sum<64>(dq);
+        for (int c = lane; c < D; c += 64) {
+            const float av = t[c] / nt;
+            const float u1 = (active && d1 > 0.f) ? (av - mp[c] / np_ + eps) / d1 : 0.f;
+            const float u2 = (active && d2 > 0.f) ? (av - mn[c] / nq + eps) / d2 : 0.f;
+            const float gs = cs * (ms[c] - t[c]);
+            G3[r * D + c] = gs;
+            G3[(n + r) * D + c] = sq_norm_bwd(mp[c], -cu * u1, lp, dpp);
+            G3[(2 * n + r) * D + c] = sq_norm_bwd(mn[c], cu * u2, lq, dq);
+            GT[r * D + c] = -gs + sq_norm_bwd(t[c], cu * (u1 - u2), lt, da);
+        }
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE] = acc[0];
+        partials[(size_t)blockIdx.x * CDR_PARTIAL_STRIDE + 1] = acc[1];
+    }
+}
+
+// out3 = {loss_s + lambda loss_u, loss_s, loss_u}
+__global__ __launch_bounds__(kBlock) void sscdr_map_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t n, int D,
+                                                                  float lambda, float* __restrict__ out3) {
+    __shared__ double smem[8];
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        acc[0] += partials[(size_t)b * CDR_PARTIAL_STRIDE];
+        acc[1] += partials[(size_t)b * CDR_PARTIAL_STRIDE + 1];
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float ls = (float)(acc[0] / (double)(n * D)), lu = (float)(acc[1] / (double)n);
+        out3[1] = ls; out3[2] = lu;
+        out3[0] = ls + lambda * lu;
+    }
+}
+
+// x *= s[0], y *= s[0] unless s[0] is exactly 1 (gradients made for a unit upstream gradient: `loss.backward()` passes 1)
+__global__ __launch_bounds__(kBlock) void scale2_unless_one_kernel(const float* __restrict__ s, float* __restrict__ x, int64_t nx,
+                                                                   float* __restrict__ y, int64_t ny) {
+    const float sc = s[0];
+    if (sc == 1.0f) return;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nx + ny; e += stride) {
+        if (e < nx) x[e] *= sc; else y[e - nx] *= sc;
+    }
+}
+
 // ---- EmbLoss alone (bitgcf.py:231-233: norms of the EGO rows, different width from the propagated rows) -----------
 __global__ __launch_bounds__(kBlock) void embloss_partial_kernel(const float* __restrict__ U, const float* __restrict__ I, int D,
                                                                  const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
@@ -402,6 +497,27 @@ extern "C" int cdr_triplet_fwd(cdr_ctx* ctx, void* stream, const float* a, const
     triplet_fwd_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(a, p, n, rows, D, margin, eps, dap, dan, ctx->partials);
     CDR_LAUNCH_CHECK();
     scalar_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, g, rows, 0, out1);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_sscdr_map_loss(cdr_ctx* ctx, void* stream, const float* mapped3, const float* target_rows, int64_t n, int D,
+                                  float margin, float eps, float lambda, float* out3, float* g_mapped3, float* g_target_rows) {
+    CDR_CHECK_ARG(ctx && mapped3 && target_rows && out3 && g_mapped3 && g_target_rows && n > 0 && D > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_cap((n + 3) / 4);
+    sscdr_map_loss_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(mapped3, target_rows, n, D, margin, eps, lambda, g_mapped3, g_target_rows,
+                                                           ctx->partials);
+    CDR_LAUNCH_CHECK();
+    sscdr_map_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, g, n, D, lambda, out3);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_scale2_unless_one(void* stream, const float* scale_dev, float* x, int64_t nx, float* y, int64_t ny) {
+    CDR_CHECK_ARG(scale_dev && nx >= 0 && ny >= 0 && (nx == 0 || x) && (ny == 0 || y));
+    if (nx + ny == 0) return CDR_OK;
+    scale2_unless_one_kernel<<<EL_GRID(nx + ny)>>>(scale_dev, x, nx, y, ny);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -75,6 +75,44 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
     }
 }
 
+// ---- several (table, id list) pairs in ONE launch (blockIdx.y = list): the small steps are launch-bound, and SSCDR's map phase reads
+// four row sets per step (sscdr.py:161-172) ---------------------------------------------------------------------------------------
+constexpr int kMultiLists = 4;
+struct rows_multi {
+    const float* tab[kMultiLists]; float* gtab[kMultiLists];
+    const int64_t* ids[kMultiLists]; int64_t n[kMultiLists];
+    float* out[kMultiLists]; const float* src[kMultiLists];
+    int count, D;
+};
+
+__global__ __launch_bounds__(kBlock) void gather_rows_multi_kernel(rows_multi a, int64_t* __restrict__ bump) {
+    const int l = blockIdx.y;
+    const float* __restrict__ tab = a.tab[l];
+    const int64_t* __restrict__ ids = a.ids[l];
+    float* __restrict__ out = a.out[l];
+    const int D = a.D;
+    const int64_t total = a.n[l] * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        out[e] = tab[ids[r] * D + (e - r * D)];
+    }
+    // an optional device counter of the caller's, advanced here: the launch in front of this one read it (SSCDR's sampler call number)
+    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bump[0] += 1;
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_multi_kernel(rows_multi a) {
+    const int l = blockIdx.y;
+    float* __restrict__ g = a.gtab[l];
+    const int64_t* __restrict__ ids = a.ids[l];
+    const float* __restrict__ src = a.src[l];
+    const int D = a.D;
+    const int64_t total = a.n[l] * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / D;
+        atomicAdd(g + ids[r] * D + (e - r * D), src[e]);
+    }
+}
+
 // ---- activation backward -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void act_bwd_kernel(int act, const float* __restrict__ y, const float* __restrict__ gy,
                                                          float* __restrict__ gx, int64_t n) {
@@ -364,6 +402,39 @@ extern "C" int cdr_scatter_add_rows(void* stream, float* grad_tab, int D, const 
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = n * D;
     scatter_add_rows_kernel<<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(grad_tab, D, ids, n, src, scale);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_gather_rows_multi(void* stream, int count, const float* const* tabs, int D, const int64_t* const* ids,
+                                     const int64_t* n, float* const* outs, int64_t* bump_counter) {
+    CDR_CHECK_ARG(count >= 1 && count <= kMultiLists && tabs && ids && n && outs && D > 0);
+    rows_multi a{};
+    a.count = count; a.D = D;
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        CDR_CHECK_ARG(n[i] >= 0 && (n[i] == 0 || (tabs[i] && ids[i] && outs[i])));
+        a.tab[i] = tabs[i]; a.ids[i] = ids[i]; a.n[i] = n[i]; a.out[i] = outs[i];
+        if (n[i] > nmax) nmax = n[i];
+    }
+    gather_rows_multi_kernel<<<dim3(grid_cap((nmax * D + kBlock - 1) / kBlock), count), dim3(kBlock), 0, (hipStream_t)stream>>>(a, bump_counter);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_scatter_add_rows_multi(void* stream, int count, float* const* grad_tabs, int D, const int64_t* const* ids,
+                                          const int64_t* n, const float* const* srcs) {
+    CDR_CHECK_ARG(count >= 1 && count <= kMultiLists && grad_tabs && ids && n && srcs && D > 0);
+    rows_multi a{};
+    a.count = count; a.D = D;
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        CDR_CHECK_ARG(n[i] >= 0 && (n[i] == 0 || (grad_tabs[i] && ids[i] && srcs[i])));
+        a.gtab[i] = grad_tabs[i]; a.ids[i] = ids[i]; a.n[i] = n[i]; a.src[i] = srcs[i];
+        if (n[i] > nmax) nmax = n[i];
+    }
+    if (nmax == 0) return CDR_OK;
+    scatter_add_rows_multi_kernel<<<dim3(grid_cap((nmax * D + kBlock - 1) / kBlock), count), dim3(kBlock), 0, (hipStream_t)stream>>>(a);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -335,6 +335,15 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=Non
     return out
 
 
+_SMALL_WGRAD_ROWS = 512      # up to here one workgroup per dW tile walks the batch faster than the general contraction gets going (at 4,096 rows it is 2x slower)
+
+
+def _small_linear(x2, weight):
+    """Small batches go to the one-wave-per-tile kernels of csrc/cdr_linear.hip (the general contraction's start-up dominates them)."""
+    return (x2.shape[0] <= _SMALL_WGRAD_ROWS and x2.shape[1] % 4 == 0 and x2.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
+            and weight.is_contiguous())
+
+
 class LinearAct(Function):
     """y = act(x W^T + b)  (nn.Linear + Tanh/ReLU/Sigmoid: emcdr.py:86-93, conet.py:74-84, recbole MLPLayers)."""
 
@@ -342,7 +351,13 @@ class LinearAct(Function):
     def forward(ctx, x, weight, bias, act):
         shape = tuple(x.shape)
         x2 = x.reshape(-1, shape[-1]).contiguous()
-        y = gemm(x2, weight.contiguous(), trans_b=True, bias=bias, act=act)
+        if _small_linear(x2, weight):
+            w_ = weight.contiguous()
+            y = torch.empty(x2.shape[0], w_.shape[0], device=x2.device, dtype=torch.float32)
+            B_.call('cdr_linear_small', B_.stream(), 0, B_.f32(x2), x2.shape[1], B_.f32(w_), w_.shape[1], x2.shape[0], w_.shape[0], w_.shape[1],
+                    None if bias is None else B_.f32(bias.contiguous()), int(act), B_.f32(y), y.shape[1], None, 0)
+        else:
+            y = gemm(x2, weight.contiguous(), trans_b=True, bias=bias, act=act)
         ctx.save_for_backward(x2, weight, y)
         ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, shape
         return y.view(*shape[:-1], weight.shape[0])
@@ -351,6 +366,27 @@ class LinearAct(Function):
     def backward(ctx, gy):
         x2, weight, y = ctx.saved_tensors
         gy2 = gy.reshape(-1, weight.shape[0]).contiguous()
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        w_ = weight.contiguous()
+        rows, dout, din = gy2.shape[0], w_.shape[0], w_.shape[1]
+        if rows <= _SMALL_WGRAD_ROWS and dout % 4 == 0 and gy2.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and y.is_contiguous():
+            # small batches (csrc/cdr_linear.hip): dx in one launch, dW + db in one launch, the activation's backward inside both --
+            # instead of an activation pass, two contractions and a two-launch column sum
+            gx = gW = gb = None
+            yp = B_.f32(y) if ctx.act != B_.ACT_NONE else None
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty(rows, din, device=gy2.device, dtype=torch.float32)
+                B_.call('cdr_linear_small', B_.stream(), 1, B_.f32(gy2), dout, B_.f32(w_), din, rows, din, dout, None, B_.ACT_NONE,
+                        B_.f32(gx), din, yp, int(ctx.act))
+                gx = gx.view(ctx.xshape)
+            if ctx.needs_input_grad[1] or want_b:
+                gW = torch.empty_like(w_)
+                gb = torch.empty(dout, device=gy2.device, dtype=torch.float32) if want_b else None
+                B_.call('cdr_linear_wgrad_small', B_.stream(), B_.f32(gy2), yp, int(ctx.act), B_.f32(x2), rows, dout, din, B_.f32(gW),
+                        None if gb is None else B_.f32(gb))
+                if not ctx.needs_input_grad[1]:
+                    gW = None
+            return gx, gW, gb, None
         if ctx.act != B_.ACT_NONE:
             gz = torch.empty_like(gy2)
             B_.call('cdr_act_bwd', B_.stream(), ctx.act, B_.f32(y), B_.f32(gy2), B_.f32(gz), gy2.numel())
@@ -358,10 +394,10 @@ class LinearAct(Function):
             gz = gy2
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gemm(gz, weight.contiguous()).view(ctx.xshape)                     # [rows,out] x [out,in]
+            gx = gemm(gz, w_).view(ctx.xshape)                                      # [rows,out] x [out,in]
         if ctx.needs_input_grad[1]:
             gW = gemm(gz, x2, trans_a=True)                                         # [out,rows] x [rows,in]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_b:
             gb = torch.empty(weight.shape[0], device=gy.device, dtype=torch.float32)
             B_.call('cdr_colsum', B_.ctx(gy.device), B_.stream(), B_.f32(gz), gz.shape[0], gz.shape[1], B_.f32(gb), 0)
         return gx, gW, gb, None
@@ -729,6 +765,79 @@ class ConetFusedLoss(Function):
 
 
 # ---------------------------------------------------------------------------------------------------- SSCDR pieces
+class GatherMapRows(Function):
+    """The four row sets of SSCDR's map phase (sscdr.py:161-168) in ONE launch, and their dense backward in one zero-fill + one scatter
+    launch: ``X3`` [3 n, D] = [source_tab[idx] ; other_tab[pos] ; other_tab[neg]] (what the mapping is applied to), ``Tt`` [n, D] =
+    target_tab[idx].  ``bump``: optional device int64 advanced in the gather's launch (the sampler's call counter)."""
+
+    @staticmethod
+    def forward(ctx, source_tab, target_tab, other_tab, idx, pos, neg, bump):
+        _dev_check(source_tab, target_tab, other_tab, idx, pos, neg)
+        idx, pos, neg = _ids(idx), _ids(pos), _ids(neg)
+        n, D = idx.numel(), source_tab.shape[1]
+        dev = source_tab.device
+        X3 = torch.empty(3 * n, D, device=dev, dtype=torch.float32)
+        Tt = torch.empty(n, D, device=dev, dtype=torch.float32)
+        P4, I4 = ctypes.c_void_p * 4, ctypes.c_int64 * 4
+        keep = [source_tab, target_tab, other_tab, idx, pos, neg, X3, Tt]
+        B_.call('cdr_gather_rows_multi', B_.stream(), 4, P4(source_tab.data_ptr(), other_tab.data_ptr(), other_tab.data_ptr(), target_tab.data_ptr()),
+                D, P4(idx.data_ptr(), pos.data_ptr(), neg.data_ptr(), idx.data_ptr()), I4(n, n, n, n),
+                P4(X3.data_ptr(), X3.data_ptr() + 4 * n * D, X3.data_ptr() + 8 * n * D, Tt.data_ptr()), None if bump is None else B_.i64(bump))
+        del keep
+        ctx.save_for_backward(idx, pos, neg)
+        ctx.shapes = (tuple(source_tab.shape), tuple(target_tab.shape), tuple(other_tab.shape))
+        return X3, Tt
+
+    @staticmethod
+    def backward(ctx, gX3, gT):
+        idx, pos, neg = ctx.saved_tensors
+        ss, ts, os_ = ctx.shapes
+        n, D = idx.numel(), ss[1]
+        dev = idx.device
+        ns, nt, no = ss[0] * D, ts[0] * D, os_[0] * D
+        flat = torch.zeros(ns + nt + no, device=dev, dtype=torch.float32)              # the three dense gradients out of ONE fill
+        gs, gt, go_ = flat[:ns].view(ss), flat[ns:ns + nt].view(ts), flat[ns + nt:].view(os_)
+        P4, I4 = ctypes.c_void_p * 4, ctypes.c_int64 * 4
+        gX3 = None if gX3 is None else gX3.contiguous()
+        gT = None if gT is None else gT.contiguous()
+        x0 = 0 if gX3 is None else gX3.data_ptr()
+        nx = n if gX3 is not None else 0
+        keep = [flat, gX3, gT, idx, pos, neg]
+        B_.call('cdr_scatter_add_rows_multi', B_.stream(), 4, P4(gs.data_ptr(), go_.data_ptr(), go_.data_ptr(), gt.data_ptr()), D,
+                P4(idx.data_ptr(), pos.data_ptr(), neg.data_ptr(), idx.data_ptr()), I4(nx, nx, nx, n if gT is not None else 0),
+                P4(x0, x0 + 4 * n * D, x0 + 8 * n * D, 0 if gT is None else gT.data_ptr()))
+        del keep
+        return gs, gt, go_, None, None, None, None
+
+
+class SSCDRMapLoss(Function):
+    """SSCDR.calculate_map_loss's arithmetic after the mapping (sscdr.py:165-172) as ONE node: MSE + lambda x triplet on squared-norm
+    normalised rows, its gradients made in the same pass for a unit upstream gradient and rescaled in ``backward`` only if another one
+    arrives.  Returns (total [], parts [3] = total, MSE, triplet term)."""
+
+    @staticmethod
+    def forward(ctx, mapped3, target_rows, margin, lamda):
+        _dev_check(mapped3, target_rows)
+        m3, tt = mapped3.contiguous(), target_rows.contiguous()
+        n, D = tt.shape
+        assert tuple(m3.shape) == (3 * n, D)
+        out3 = torch.empty(3, device=m3.device, dtype=torch.float32)
+        g3, gt = torch.empty_like(m3), torch.empty_like(tt)
+        B_.call('cdr_sscdr_map_loss', B_.ctx(m3.device), B_.stream(), B_.f32(m3), B_.f32(tt), n, D, float(margin), 1e-6, float(lamda),
+                B_.f32(out3), B_.f32(g3), B_.f32(gt))
+        ctx.save_for_backward(g3, gt)
+        ctx.mark_non_differentiable(out3)
+        ctx.set_materialize_grads(False)
+        return out3[0], out3
+
+    @staticmethod
+    def backward(ctx, go, _parts):
+        g3, gt = ctx.saved_tensors
+        go = go.reshape(-1)[:1].contiguous().to(torch.float32)
+        B_.call('cdr_scale2_unless_one', B_.stream(), B_.f32(go), B_.f32(g3), g3.numel(), B_.f32(gt), gt.numel())
+        return g3, gt, None, None
+
+
 class SqnormNormalize(Function):
     """SSCDR.embedding_normalize (sscdr.py:120-124): e / max(sum e^2, 1) -- the SQUARED length, quirk kept."""
 

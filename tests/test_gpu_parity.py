@@ -1057,6 +1057,90 @@ def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
     assert_close(l_new, l_old, what='loss after resuming a dense checkpoint row-wise')
 
 
+
+@pytest.mark.parametrize('rows,dout,din,bias', [(300, 128, 64, True), (300, 64, 128, True), (7, 5, 3, True), (512, 33, 65, False), (4096, 33, 65, False),
+                                                (1, 32, 32, True), (130, 96, 40, True), (100, 64, 12, True), (33, 8, 200, True)])
+def test_linear_backward_small_batches_one_launch(rows, dout, din, bias):
+    """nn.Linear's weight and bias gradients for small batches come from ONE launch (cdr_linear_wgrad_small: a workgroup per 32 x 32 tile
+    of dW, four waves over the batch rows, fixed-order sums): against fp64 on the host, ragged tiles and row counts included, and twice
+    in a row bit-identical."""
+    from recbole_cdr_amd import functional as F_, binding as B_
+    gen = torch.Generator().manual_seed(rows + dout)
+    x = torch.randn(rows, din, generator=gen)
+    W = torch.randn(dout, din, generator=gen) * 0.2
+    b = torch.randn(dout, generator=gen) * 0.1 if bias else None
+    gy = torch.randn(rows, dout, generator=gen)
+    y_ref = torch.tanh(x.double() @ W.double().t() + (b.double() if bias else 0.0))
+    gz = gy.double() * (1.0 - y_ref * y_ref)
+    want_W, want_b, want_x = gz.t() @ x.double(), gz.sum(0), gz @ W.double()
+    outs = []
+    for _ in range(2):
+        xd, Wd = x.to(DEV).requires_grad_(True), W.to(DEV).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True) if bias else None
+        y = F_.linear(xd, Wd, bd, B_.ACT_TANH)
+        y.backward(gy.to(DEV))
+        outs.append((Wd.grad.clone(), None if bd is None else bd.grad.clone(), xd.grad.clone()))
+    gW, gb, gx = outs[0]
+    assert_close(gW, want_W.float(), what='dW')
+    assert_close(gx, want_x.float(), what='dx')
+    if bias:
+        assert_close(gb, want_b.float(), what='db')
+        assert rows > 512 or torch.equal(outs[0][1], outs[1][1])
+    assert rows > 512 or torch.equal(outs[0][0], outs[1][0])          # (past 512 rows: the general contraction, split over K with atomics)
+    # the forward of the same layer
+    with torch.no_grad():
+        y = F_.linear(x.to(DEV), W.to(DEV), None if b is None else b.to(DEV), B_.ACT_TANH)
+    assert_close(y, y_ref.float(), what='y')
+
+
+@pytest.mark.parametrize('users_overlap,D,hidden', [(True, 16, [24]), (False, 64, [128]), (True, 20, [12, 8])])
+def test_sscdr_fused_map_loss_equals_the_chain_of_nodes(users_overlap, D, hidden):
+    """SSCDR's map phase with the device sampler runs as sampler + ONE gather of its four row sets + the mapping on the stacked rows +
+    ONE loss kernel that also leaves the gradients (functional.GatherMapRows / SSCDRMapLoss); with ``sscdr_fused_map = False`` it is the
+    chain of gather / MLP x3 / MSE / normalize x3 / triplet nodes.  Same draws (the device call counter is reset): loss and every
+    gradient agree at 1e-5, also for an upstream gradient other than 1, and the counter advances once per loss either way."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.sscdr import SSCDR
+    ids = IdSpace(OU=40, TOU=30, SOU=35, OI=1, TOI=60, SOI=70) if users_overlap else IdSpace(OU=1, TOU=30, SOU=35, OI=40, TOI=60, SOI=70)
+    rng = np.random.RandomState(8)
+    nov = ids.OU if users_overlap else ids.OI
+    other = (list(range(1, ids.OI)) + list(range(ids.OI + ids.TOI, ids.total_num_items))) if users_overlap else \
+        (list(range(1, ids.OU)) + list(range(ids.OU + ids.TOU, ids.total_num_users)))
+    own, oth = rng.randint(1, nov, 500), rng.choice(other, 500)
+    pairs = np.stack([own, oth], 1) if users_overlap else np.stack([oth, own], 1)
+    ds = FakeDataset(ids, s_pairs=pairs.astype(np.int64), t_pairs=np.zeros((1, 2), dtype=np.int64))
+    cfg = base_config(DEV, embedding_size=D, margin=0.3, mlp_hidden_size=hidden, sscdr_device_sampler=True, seed=5, **{'lambda': 0.7})
+    torch.manual_seed(1)
+    model = SSCDR(cfg, ds).to(DEV)
+    with torch.no_grad():                                   # rows longer than 1 in squared norm, so that the normalisation's Jacobian matters
+        for n_, p_ in model.named_parameters():
+            if 'embedding' in n_:
+                p_.mul_(40.0)
+    assert model.fused_map
+    model.set_phase('OVERLAP')
+    mode = 'user' if users_overlap else 'item'
+    counter = model._device_lists(mode)[3]
+    inter = {'overlap': (torch.randperm(nov - 1, device=DEV)[:33] + 1).view(-1, 1)}
+
+    def run(fused, scale):
+        model.fused_map = fused
+        counter.fill_(77)
+        model.zero_grad(set_to_none=True)
+        loss = model.calculate_loss(inter)
+        (loss * scale if scale != 1.0 else loss).backward()
+        assert int(counter.item()) == 78
+        return loss.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+
+    for scale in (1.0, 2.5):
+        lf, gf = run(True, scale)
+        lu, gu = run(False, scale)
+        assert_close(lf, lu, what='loss')
+        assert set(gf) == set(gu)
+        for k in gu:
+            assert_close(gf[k], gu[k], what=k)
+    model.fused_map = True
+
+
 @pytest.mark.parametrize('users_overlap', [True, False])
 def test_sscdr_device_sampler(users_overlap):
     """config['sscdr_device_sampler']: the in-loss sampler of sscdr.py:89-118 as a kernel over the device-resident interaction

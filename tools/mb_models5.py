@@ -61,6 +61,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--only', default=None, help='run one case by name (for kernel traces)')
     a = ap.parse_args()
     from recbole_cdr_amd.graph_step import GraphedTrainStep
     from recbole_cdr_amd.trainer.trainer import DenseAdam
@@ -104,6 +105,8 @@ def main():
          True, 'OVERLAP', None),
     ]
     for name, cls, kw, pairwise, phase, oracle_loss in cases:
+        if a.only and name != a.only:
+            continue
         torch.manual_seed(0)
         model = cls(base_config(DEV, **kw), ds).to(DEV)
         if phase:
