@@ -833,6 +833,9 @@ class SSCDRMapLoss(Function):
     @staticmethod
     def backward(ctx, go, _parts):
         g3, gt = ctx.saved_tensors
+        if getattr(ctx, 'consumed', False):          # the stored gradients are rescaled in place: a second pass would scale them twice
+            raise RuntimeError('SSCDRMapLoss: backward through this node a second time (retain_graph) is not supported')
+        ctx.consumed = True
         go = go.reshape(-1)[:1].contiguous().to(torch.float32)
         B_.call('cdr_scale2_unless_one', B_.stream(), B_.f32(go), B_.f32(g3), g3.numel(), B_.f32(gt), gt.numel())
         return g3, gt, None, None
