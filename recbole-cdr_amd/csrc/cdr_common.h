@@ -9,10 +9,12 @@
 #define CDR_NUM_CU 256
 #define CDR_MAX_PARTIAL_BLOCKS 4096          // grid cap of every two-pass reduction
 #define CDR_PARTIAL_STRIDE 8                 // doubles per block
+#define CDR_TICKETS 1024
 
 struct cdr_ctx {
     int device;
     double* partials;                        // [CDR_MAX_PARTIAL_BLOCKS][CDR_PARTIAL_STRIDE]
+    unsigned* tickets;                       // [CDR_TICKETS] zero-initialised sign-in counters ('the block that signs in last finishes'); atomicInc wraps them back to 0
     void* scratch;                           // grow-on-demand device scratch (long-segment partial sums of cdr_rowwise_apply)
     size_t scratch_bytes;
     // optional HIP-event brackets around the hot kernels, recorded on the launch stream (cdr_timing_*)

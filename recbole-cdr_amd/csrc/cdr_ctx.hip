@@ -33,9 +33,15 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     c->tags = nullptr;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->partials = nullptr;
+    c->tickets = nullptr;
     hipError_t e = hipMalloc(&c->partials, sizeof(double) * CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE);
+    if (e == hipSuccess) e = hipMalloc(&c->tickets, sizeof(unsigned) * CDR_TICKETS);
+    if (e == hipSuccess) e = hipMemset(c->tickets, 0, sizeof(unsigned) * CDR_TICKETS);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
+        if (c->partials) (void)hipFree(c->partials);
+        if (c->tickets) (void)hipFree(c->tickets);
         delete c;
         cdr_set_error("cdr_ctx_create: scratch allocation failed: %s", hipGetErrorString(e));
         return CDR_ENOMEM;
@@ -96,6 +102,7 @@ extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
     if (!ctx) return CDR_OK;
     cdr_timing_enable(ctx, 0);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->tickets) (void)hipFree(ctx->tickets);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
     return CDR_OK;

@@ -12,6 +12,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBlock = 256;
+constexpr int kWgPart = 32 * 32 + 32;                          // floats of one partial: a dW tile + its bias row
 constexpr int kWgWaves = 8, kWgBlock = 64 * kWgWaves;     // linear_wgrad_small_kernel: waves (= batch-row slices) per 32 x 32 tile
 
 // gz = gy * act'(y) on the way into the contractions (act_bwd_kernel's expressions): the activation backward as a launch of its own
@@ -29,15 +30,18 @@ __device__ __forceinline__ float dact(int act, float y, float g) {
 
 __global__ __launch_bounds__(kWgBlock) void linear_wgrad_small_kernel(const float* __restrict__ gz, const float* __restrict__ yact, int act,
                                                                      const float* __restrict__ x, int64_t rows, int dout, int din,
-                                                                     float* __restrict__ dW, float* __restrict__ db) {
+                                                                     float* __restrict__ dW, float* __restrict__ db, int64_t chunk,
+                                                                     float* __restrict__ part, unsigned* __restrict__ tickets) {
     __shared__ float red[kWgWaves][32 * 33];
     __shared__ float bred[kWgWaves][32];
+    __shared__ int last_block;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
     const int oc = o0 + li < dout ? o0 + li : dout - 1, ic = i0 + li < din ? i0 + li : din - 1;     // clamped: dropped at the store
-    // rows [r0, r1) of this wave, r0 even
-    const int64_t per = ((rows + kWgWaves - 1) / kWgWaves + 1) & ~(int64_t)1;
-    const int64_t r0 = wave * per, r1 = r0 + per < rows ? r0 + per : rows;
+    // batch rows [c0, c1) of this workgroup (blockIdx.z: larger batches are cut into chunks), [r0, r1) of this wave, both even-aligned
+    const int64_t c0 = (int64_t)blockIdx.z * chunk, c1 = c0 + chunk < rows ? c0 + chunk : rows;
+    const int64_t per = ((c1 - c0 + kWgWaves - 1) / kWgWaves + 1) & ~(int64_t)1;
+    const int64_t r0 = c0 + wave * per < c1 ? c0 + wave * per : c1, r1 = r0 + per < c1 ? r0 + per : c1;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -85,22 +89,60 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_small_kernel(const floa
     bsum += __shfl_xor(bsum, 32);                                   // the two row parities of out column li
     if (lh == 0) bred[wave][li] = bsum;
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 32; e += kWgBlock) {
-        const int ro = e >> 5, ci = e & 31;
-        if (o0 + ro < dout && i0 + ci < din) {
-            const int q = ro * 33 + ci;
-            float v = red[0][q];
+    const int nz = gridDim.z;
+    if (nz == 1) {
+        for (int e = threadIdx.x; e < 32 * 32; e += kWgBlock) {
+            const int ro = e >> 5, ci = e & 31;
+            if (o0 + ro < dout && i0 + ci < din) {
+                const int q = ro * 33 + ci;
+                float v = red[0][q];
 #pragma unroll
-            for (int w = 1; w < kWgWaves; ++w) v += red[w][q];     // wave order: run-to-run identical
-            dW[(int64_t)(o0 + ro) * din + i0 + ci] = v;
+                for (int w = 1; w < kWgWaves; ++w) v += red[w][q]; // wave order: run-to-run identical
+                dW[(int64_t)(o0 + ro) * din + i0 + ci] = v;
+            }
         }
-    }
-    if (db && blockIdx.y == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < dout) {
-        const int q = threadIdx.x;
-        float v = bred[0][q];
+        if (db && blockIdx.y == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < dout) {
+            const int q = threadIdx.x;
+            float v = bred[0][q];
 #pragma unroll
-        for (int w = 1; w < kWgWaves; ++w) v += bred[w][q];
-        db[o0 + q] = v;
+            for (int w = 1; w < kWgWaves; ++w) v += bred[w][q];
+            db[o0 + q] = v;
+        }
+        return;
+    }
+    // several chunks per tile: every workgroup leaves its partial tile (+ bias row) in the workspace, and the one that signs in LAST on
+    // the tile's counter adds them in chunk order -- fixed order again.  The partials travel with system-scope stores and loads (written
+    // through / read past the per-XCD L2s): no release fence, which on this part is a write-back of the whole L2 per workgroup; one
+    // counter per tile, so no more than gridDim.z atomics meet on an address.
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* mine = part + ((size_t)tile * nz + blockIdx.z) * kWgPart;
+    for (int e = threadIdx.x; e < 32 * 32 + 32; e += kWgBlock) {
+        float v;
+        if (e < 1024) {
+            const int q = (e >> 5) * 33 + (e & 31);
+            v = red[0][q];
+#pragma unroll
+            for (int w = 1; w < kWgWaves; ++w) v += red[w][q];
+        } else {
+            v = bred[0][e - 1024];
+#pragma unroll
+            for (int w = 1; w < kWgWaves; ++w) v += bred[w][e - 1024];
+        }
+        __hip_atomic_store(mine + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partials have been written through ...
+    __syncthreads();                                   // ... every thread's have
+    if (threadIdx.x == 0) last_block = atomicInc(tickets + tile, (unsigned)nz - 1) == (unsigned)nz - 1 ? 1 : 0;   // wraps to 0 for the next launch
+    __syncthreads();
+    if (!last_block) return;
+    const float* all = part + (size_t)tile * nz * kWgPart;
+    for (int e = threadIdx.x; e < 32 * 32 + 32; e += kWgBlock) {
+        float v = __hip_atomic_load(all + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int z = 1; z < nz; ++z) v += __hip_atomic_load(all + (size_t)z * kWgPart + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (e < 1024) {
+            const int ro = e >> 5, ci = e & 31;
+            if (o0 + ro < dout && i0 + ci < din) dW[(int64_t)(o0 + ro) * din + i0 + ci] = v;
+        } else if (db && blockIdx.y == 0 && o0 + (e - 1024) < dout) db[o0 + e - 1024] = v;
     }
 }
 
@@ -180,12 +222,27 @@ __global__ __launch_bounds__(64) void linear_small_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int cdr_linear_wgrad_small(void* stream, const float* gz, const float* y_out, int act, const float* x, int64_t rows, int dout,
-                                      int din, float* dW, float* db) {
-    CDR_CHECK_ARG(gz && x && dW && rows > 0 && dout > 0 && din > 0);
-    CDR_CHECK_ARG((dout + 31) / 32 <= 65535 && (din + 31) / 32 <= 65535);
-    linear_wgrad_small_kernel<<<dim3((dout + 31) / 32, (din + 31) / 32), dim3(kWgBlock), 0, (hipStream_t)stream>>>(gz, y_out, act, x, rows, dout,
-                                                                                                              din, dW, db);
+extern "C" int cdr_linear_wgrad_small(cdr_ctx* ctx, void* stream, const float* gz, const float* y_out, int act, const float* x, int64_t rows,
+                                      int dout, int din, float* dW, float* db) {
+    CDR_CHECK_ARG(ctx && gz && x && dW && rows > 0 && dout > 0 && din > 0);
+    const int tx = (dout + 31) / 32, ty = (din + 31) / 32;
+    CDR_CHECK_ARG(tx <= 65535 && ty <= 65535);
+    // up to 512 rows per workgroup (64 per wave); more rows -> more chunks per tile, added by the last workgroup to finish (256-row chunks
+    // were slower: 15.3 -> 18.0 us at 4,096 rows)
+    int64_t nz = (rows + 511) / 512;
+    if (nz > 64) nz = 64;
+    if ((int64_t)tx * ty > CDR_TICKETS) { cdr_set_error("cdr_linear_wgrad_small: %d x %d tiles exceed the %d sign-in counters", tx, ty, CDR_TICKETS); return CDR_EINVAL; }
+    const int64_t chunk = (((rows + nz - 1) / nz) + 1) & ~(int64_t)1;
+    nz = (rows + chunk - 1) / chunk;
+    float* part = nullptr;
+    if (nz > 1) {
+        void* p = nullptr;
+        int rc = cdr_ctx_scratch(ctx, (size_t)tx * ty * nz * kWgPart * sizeof(float), &p);
+        if (rc) return rc;
+        part = (float*)p;
+    }
+    linear_wgrad_small_kernel<<<dim3(tx, ty, (unsigned)nz), dim3(kWgBlock), 0, (hipStream_t)stream>>>(gz, y_out, act, x, rows, dout, din, dW, db,
+                                                                                                     chunk, part, ctx->tickets);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -335,7 +335,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=Non
     return out
 
 
-_SMALL_WGRAD_ROWS = 512      # up to here one workgroup per dW tile walks the batch faster than the general contraction gets going (at 4,096 rows it is 2x slower)
+_SMALL_WGRAD_ROWS = 16384    # batches up to here take the one-wave-per-tile kernels of csrc/cdr_linear.hip (dW: 512-row chunks per workgroup)
 
 
 def _small_linear(x2, weight):
@@ -369,21 +369,29 @@ class LinearAct(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         w_ = weight.contiguous()
         rows, dout, din = gy2.shape[0], w_.shape[0], w_.shape[1]
-        if rows <= _SMALL_WGRAD_ROWS and dout % 4 == 0 and gy2.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and y.is_contiguous():
+        if rows <= _SMALL_WGRAD_ROWS and y.is_contiguous():
             # small batches (csrc/cdr_linear.hip): dx in one launch, dW + db in one launch, the activation's backward inside both --
             # instead of an activation pass, two contractions and a two-launch column sum
             gx = gW = gb = None
-            yp = B_.f32(y) if ctx.act != B_.ACT_NONE else None
+            dx_small = dout % 4 == 0 and gy2.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+            gz, yp = gy2, (B_.f32(y) if ctx.act != B_.ACT_NONE else None)
             if ctx.needs_input_grad[0]:
-                gx = torch.empty(rows, din, device=gy2.device, dtype=torch.float32)
-                B_.call('cdr_linear_small', B_.stream(), 1, B_.f32(gy2), dout, B_.f32(w_), din, rows, din, dout, None, B_.ACT_NONE,
-                        B_.f32(gx), din, yp, int(ctx.act))
+                if dx_small:
+                    gx = torch.empty(rows, din, device=gy2.device, dtype=torch.float32)
+                    B_.call('cdr_linear_small', B_.stream(), 1, B_.f32(gy2), dout, B_.f32(w_), din, rows, din, dout, None, B_.ACT_NONE,
+                            B_.f32(gx), din, yp, int(ctx.act))
+                else:                                # widths that are not multiples of 4: gz by its own launch, dx on the general contraction
+                    if ctx.act != B_.ACT_NONE:
+                        gz = torch.empty_like(gy2)
+                        B_.call('cdr_act_bwd', B_.stream(), ctx.act, B_.f32(y), B_.f32(gy2), B_.f32(gz), gy2.numel())
+                        yp = None
+                    gx = gemm(gz, w_)
                 gx = gx.view(ctx.xshape)
             if ctx.needs_input_grad[1] or want_b:
                 gW = torch.empty_like(w_)
                 gb = torch.empty(dout, device=gy2.device, dtype=torch.float32) if want_b else None
-                B_.call('cdr_linear_wgrad_small', B_.stream(), B_.f32(gy2), yp, int(ctx.act), B_.f32(x2), rows, dout, din, B_.f32(gW),
-                        None if gb is None else B_.f32(gb))
+                B_.call('cdr_linear_wgrad_small', B_.ctx(gy2.device), B_.stream(), B_.f32(gz), yp, int(ctx.act), B_.f32(x2), rows, dout, din,
+                        B_.f32(gW), None if gb is None else B_.f32(gb))
                 if not ctx.needs_input_grad[1]:
                     gW = None
             return gx, gW, gb, None
