@@ -6,7 +6,7 @@
 #      ... and of `python bench.py --headline-only` (the headline kernels on the headline batch alone)       -> trace_c5_headline/
 #   3. --pmc FETCH_SIZE / WRITE_SIZE, each in its own pass (--kernel-trace only), over the headline + OVERLAP legs (--steps 3)
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over the U = 1,024 scoring kernel (tools/mb_fullsort.py)
-#   5. rocprofv3 --kernel-trace --stats of `--workload c3` and `--workload c4` (eager: a traced hipGraph replay once hung the profiler)
+#   5. rocprofv3 --kernel-trace --stats of `--workload c1|c2|c3` (graph replays) and `--workload c4` (eager: a traced hipGraph replay of it once hung the profiler)
 #   6. micro-benchmarks: the fused step per kernel (uniform / Zipf), both domains on one vs two streams, OVERLAP step, models5
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -24,6 +24,9 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5 -o trace -- python $R/bench.py --no-cpu-baseline > $O/bench_c5_under_rocprof.json 2> $O/trace_c5.err; echo "trace c5 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5_headline -o trace -- python $R/bench.py --headline-only > $O/bench_c5_headline_under_rocprof.json 2> $O/trace_c5_headline.err; echo "trace c5 headline rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 100 --warmup 10 > $O/bench_c3_under_rocprof.json 2> $O/trace_c3.err; echo "trace c3 rc=$?"
+for W in c1 c2; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -o trace -- python $R/bench.py --workload $W --no-cpu-baseline --steps 200 --warmup 20 > $O/bench_${W}_under_rocprof.json 2> $O/trace_$W.err; echo "trace $W rc=$?"
+done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -o trace -- python $R/bench.py --workload c4 --no-cpu-baseline --no-graph --steps 50 --warmup 5 > $O/bench_c4_under_rocprof.json 2> $O/trace_c4.err; echo "trace c4 rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o pmc -- python $R/bench.py --no-cpu-baseline --no-fullsort --no-config-legs --steps 3 --warmup 1 > $O/bench_pmc_$C.json 2> $O/pmc_$C.err; echo "pmc $C rc=$?"
