@@ -540,7 +540,7 @@ def test_dim_layout_full_size_properties():
     assert abs(float(fp(U) - fp(U2))) <= 1e-6 * abs(float(fp(U2))) + 1e-3 and abs(float(fp(I) - fp(I2))) <= 1e-6 * abs(float(fp(I2))) + 1e-3
 
 
-@pytest.mark.parametrize('world,extra', [(2, []), (4, []), (2, ['--shard', 'row'])])
+@pytest.mark.parametrize('world,extra', [(2, []), (4, []), (8, []), (2, ['--shard', 'row'])])
 def test_bench_multi_rank_line_contract(world, extra):
     """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one rank per process) -- here with every rank on
     cuda:0 over gloo (CDR_BENCH_SHARED_GPU=1, small tables): stdout is exactly ONE JSON line from rank 0 with the contract's
