@@ -84,6 +84,51 @@ def test_dtcdr_dropout_trains_and_is_identity_in_eval():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+def test_dtcdr_training_dropout_value_parity_with_the_same_mask():
+    """DTCDR with dropout_prob > 0 in training mode: VALUES, not only statistics.  The product's counter-based mask of every (domain,
+    layer) is exported with cdr_dropout_dev on a tensor of ones -- same device seed, same salt (source: layer index, target: 64 + layer
+    index), same element order -- and handed to the oracle's MLP: loss and every gradient at 1e-5."""
+    from oracle import dtcdr as o_dt
+    from oracle.common import IdSpace
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.model.cross_domain_recommender.dtcdr import DTCDR
+    ids = IdSpace(12, 10, 14, 1, 20, 24)
+    D, hidden, p, B = 16, [32, 16], 0.4, 96
+    cfg = base_config(DEV, embedding_size=D, mlp_hidden_size=hidden, dropout_prob=p, base_model='NeuMF', alpha=0.3)
+    torch.manual_seed(3)
+    model = DTCDR(cfg, FakeDataset(ids)).to(DEV)
+    model.train()
+    rng = np.random.RandomState(5)
+    inter = {'source_user_id': torch.from_numpy(rng.randint(1, ids.total_num_users, B)), 'source_item_id': torch.from_numpy(rng.randint(1, ids.total_num_items, B)),
+             'source_label': torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32)),
+             'target_user_id': torch.from_numpy(rng.randint(1, ids.OU + ids.TOU, B)), 'target_item_id': torch.from_numpy(rng.randint(1, ids.OI + ids.TOI, B)),
+             'target_label': torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32))}
+    # the seed the model will draw for this forward (DTCDR._drop_seed: one draw from torch's CPU generator per eager training forward)
+    torch.manual_seed(91)
+    seed_val = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())
+    seed = torch.full((1,), seed_val, device=DEV, dtype=torch.int64)
+    masks = {}
+    widths = [2 * D] + hidden[:-1]
+    for dom, salt0 in (('source', 0), ('target', 64)):
+        for n, w in enumerate(widths):
+            ones = torch.ones(B, w, device=DEV)
+            m = torch.empty_like(ones)
+            B_.call('cdr_dropout_dev', B_.stream(), B_.f32(ones), ones.numel(), p, B_.i64(seed), salt0 + n, B_.f32(m))
+            kept = float((m != 0).float().mean())
+            assert abs(kept - (1 - p)) < 0.08 and bool(((m == 0) | ((m - 1 / (1 - p)).abs() < 1e-6)).all())
+            masks[(dom, n)] = m.cpu()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    want = o_dt.calculate_loss(params, ids, inter, 0.3, masks)
+    want.backward()
+    torch.manual_seed(91)
+    loss = model.calculate_loss(to_dev(inter, DEV))
+    assert_close(loss, want, what='loss')
+    loss.backward()
+    for k, v in model.named_parameters():
+        if params[k].grad is not None:
+            assert_close(v.grad, params[k].grad, what=k)
+
+
 @pytest.mark.parametrize('name', cases('deepapf_'))
 def test_deepapf_golden(name):
     from recbole_cdr_amd.model.cross_domain_recommender.deepapf import DeepAPF
