@@ -22,6 +22,73 @@ def _zeros_like2(a, b):
     return flat[:a.numel()].view(a.shape), flat[a.numel():].view(b.shape)
 
 
+# ---- run-to-run reproducible dense gradients (opt-in) -------------------------------------------------------------------------------
+# The drop-in losses hand autograd DENSE [rows, D] gradients built with fp32 atomics, like torch's embedding backward: the order of the
+# adds into a row that occurs several times in a batch is not fixed, so two runs can differ in the last bit.  With
+# ``set_deterministic(True)`` (or CDR_DETERMINISTIC=1) the same kernels run on the batch's GATHERED rows with the occurrence index as
+# the id -- every address receives exactly one add -- and the per-occurrence rows are then summed per distinct id in occurrence order
+# (id sort + cdr_scatter_rows_sorted, as the CoNet node always does).  Covers EMCDR (BPR and MF), CMF and SSCDR; a few launches more
+# per step, so it is off by default.
+_DETERMINISTIC = [False]
+
+
+def set_deterministic(flag):
+    _DETERMINISTIC[0] = bool(flag)
+
+
+def deterministic():
+    return _DETERMINISTIC[0] or os.environ.get('CDR_DETERMINISTIC', '0') == '1'
+
+
+_arange_cache = {}
+
+
+def _arange(dev, n):
+    key = str(dev)
+    a = _arange_cache.get(key)
+    if a is None or a.numel() < n:
+        a = torch.arange(max(n, 4096), device=dev, dtype=torch.int64)
+        _arange_cache[key] = a
+    return a[:n]
+
+
+def _gather_plain(weight, ids):
+    out = torch.empty(ids.numel(), weight.shape[1], device=weight.device, dtype=torch.float32)
+    if ids.numel():
+        B_.call('cdr_gather_rows', B_.stream(), B_.f32(weight), weight.shape[1], B_.i64(ids), ids.numel(), B_.f32(out))
+    return out
+
+
+def _scatter_rows_deterministic(shape, ids, rows):
+    """zeros(shape) with rows[o] added to row ids[o], the occurrences of a row summed in occurrence order (no float atomics)."""
+    g = torch.zeros(shape, device=rows.device, dtype=torch.float32)
+    if ids.numel():
+        (k, p, n), = sort_id_lists([ids], shape[0])
+        rows = rows.contiguous()
+        B_.call('cdr_scatter_rows_sorted', B_.stream(), B_.f32(g), shape[1], B_.raw(k), B_.raw(p), n, B_.f32(rows), rows.shape[1])
+    return g
+
+
+def _det_point_rows(U, I, RU, RI, uid, iid, gcoef, out4_ptr, reg, go):
+    """Per-occurrence gradient rows of one pointwise batch from cdr_point_bwd_dense on the gathered rows: (dU, dI, dRU, dRI), the last two
+    None when the EmbLoss tables are the dot tables (their term is then inside dU / dI)."""
+    dev, D, n = U.device, U.shape[1], uid.numel()
+    ar = _arange(dev, n)
+    sep_u = RU is not None and RU.data_ptr() != U.data_ptr()
+    sep_i = RI is not None and RI.data_ptr() != I.data_ptr()
+    Ur, Ir = _gather_plain(U, uid), _gather_plain(I, iid)
+    RUr = _gather_plain(RU, uid) if sep_u else None
+    RIr = _gather_plain(RI, iid) if sep_i else None
+    flat = torch.zeros((2 + int(sep_u) + int(sep_i)) * n * D, device=dev, dtype=torch.float32)
+    parts = [flat[k * n * D:(k + 1) * n * D].view(n, D) for k in range(2 + int(sep_u) + int(sep_i))]
+    dU, dI = parts[0], parts[1]
+    dRU = parts[2] if sep_u else None
+    dRI = parts[2 + int(sep_u)] if sep_i else None
+    B_.call('cdr_point_bwd_dense', B_.ctx(dev), B_.stream(), B_.f32(Ur), B_.f32(Ir), B_.f32(RUr), B_.f32(RIr), D, B_.i64(ar), B_.i64(ar), n,
+            B_.f32(gcoef), out4_ptr, float(reg), B_.f32(go), B_.f32(dU), B_.f32(dI), B_.f32(dRU), B_.f32(dRI))
+    return dU, dI, dRU, dRI
+
+
 def _dev_check(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -52,8 +119,19 @@ class BPRGatherLoss(Function):
     @staticmethod
     def backward(ctx, grad_out):
         user_w, item_w, uid, pid, nid, g, out4 = ctx.saved_tensors
-        gU, gI = _zeros_like2(user_w, item_w)
         go = grad_out.reshape(-1).contiguous().to(torch.float32)
+        if deterministic():
+            dev, D, n = user_w.device, user_w.shape[1], uid.numel()
+            ar = _arange(dev, 2 * n)
+            items = torch.cat([pid, nid])
+            Ur, Ir = _gather_plain(user_w, uid), _gather_plain(item_w, items)
+            flat = torch.zeros(3 * n * D, device=dev, dtype=torch.float32)
+            dU, dI = flat[:n * D].view(n, D), flat[n * D:].view(2 * n, D)
+            B_.call('cdr_bpr_bwd_dense', B_.ctx(dev), B_.stream(), B_.f32(Ur), B_.f32(Ir), D, B_.i64(ar[:n]), B_.i64(ar[:n]), B_.i64(ar[n:]), n,
+                    B_.f32(g), B_.f32(out4), ctx.reg_weight, B_.f32(go), B_.f32(dU), B_.f32(dI))
+            return (_scatter_rows_deterministic(user_w.shape, uid, dU), _scatter_rows_deterministic(item_w.shape, items, dI),
+                    None, None, None, None, None)
+        gU, gI = _zeros_like2(user_w, item_w)
         B_.call('cdr_bpr_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), user_w.shape[1],
                 B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(), B_.f32(g), B_.f32(out4), ctx.reg_weight,
                 B_.f32(go), B_.f32(gU), B_.f32(gI))
@@ -89,6 +167,20 @@ class PointGatherLoss(Function):
         # the same tensor as user AND item operand (BiTGCF scores rows of one stacked [users ; items] table): one gradient buffer,
         # both scatters add into it, and autograd gets it once -- instead of two table-sized buffers plus the add that merges them
         shared = user_w.data_ptr() == item_w.data_ptr() and user_w.shape == item_w.shape and user_w.stride() == item_w.stride()
+        if deterministic():
+            go = grad_out.reshape(-1).contiguous().to(torch.float32)
+            dU, dI, dRU, dRI = _det_point_rows(user_w, item_w, reg_user_w, reg_item_w, uid, iid, g, B_.f32(out4), ctx.reg_weight, go)
+            if shared:
+                gU = _scatter_rows_deterministic(user_w.shape, torch.cat([uid, iid]), torch.cat([dU, dI]))
+                gI = None
+            else:
+                gU, gI = _scatter_rows_deterministic(user_w.shape, uid, dU), _scatter_rows_deterministic(item_w.shape, iid, dI)
+            gRU = gRI = None
+            if reg_user_w is not None:
+                gRU = _scatter_rows_deterministic(reg_user_w.shape, uid, dRU) if dRU is not None else torch.zeros_like(reg_user_w)
+            if reg_item_w is not None:
+                gRI = _scatter_rows_deterministic(reg_item_w.shape, iid, dRI) if dRI is not None else torch.zeros_like(reg_item_w)
+            return None, gU, gI, gRU, gRI, None, None, None, None
         if shared:
             gU = torch.zeros_like(user_w)
             gI = gU
@@ -158,9 +250,17 @@ class TwoDomainPointLoss(Function):
     @staticmethod
     def backward(ctx, grad_out, _gl):
         user_w, item_w, su, si, tu, ti, g_s, g_t, out8, w = ctx.saved_tensors
-        gU, gI = _zeros_like2(user_w, item_w)
         dev, D = user_w.device, user_w.shape[1]
         go = grad_out.reshape(-1)[:1].contiguous().to(torch.float32)
+        if deterministic():
+            go2 = torch.empty(2, device=dev, dtype=torch.float32)
+            B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(go), B_.f32(go2))
+            rows = [_det_point_rows(user_w, item_w, None, None, u, i, g, B_._c_ptr(out8.data_ptr() + 16 * d), reg, go2[d:d + 1])
+                    for d, (u, i, g, reg) in enumerate(((su, si, g_s, ctx.regs[0]), (tu, ti, g_t, ctx.regs[1])))]
+            gU = _scatter_rows_deterministic(user_w.shape, torch.cat([su, tu]), torch.cat([rows[0][0], rows[1][0]]))
+            gI = _scatter_rows_deterministic(item_w.shape, torch.cat([si, ti]), torch.cat([rows[0][1], rows[1][1]]))
+            return None, gU, gI, None, None, None, None, None, None, None, None, None
+        gU, gI = _zeros_like2(user_w, item_w)
         if D % 4 == 0:
             # d total / d L_domain = grad_out * weight: the scatter kernel multiplies (the weights are host floats, as in _pair_weights)
             P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
@@ -298,6 +398,8 @@ class GatherRows(Function):
     @staticmethod
     def backward(ctx, grad_out):
         (flat,) = ctx.saved_tensors
+        if deterministic():
+            return _scatter_rows_deterministic(ctx.wshape, flat, grad_out.reshape(-1, ctx.wshape[1])), None
         gW = torch.zeros(ctx.wshape, device=grad_out.device, dtype=torch.float32)
         if flat.numel():
             go = grad_out.reshape(-1, ctx.wshape[1]).contiguous()
@@ -802,6 +904,12 @@ class GatherMapRows(Function):
         ss, ts, os_ = ctx.shapes
         n, D = idx.numel(), ss[1]
         dev = idx.device
+        if deterministic():
+            zx, zt = (lambda: torch.zeros(3 * n, D, device=dev)), (lambda: torch.zeros(n, D, device=dev))
+            gX3 = zx() if gX3 is None else gX3.contiguous()
+            gT = zt() if gT is None else gT.contiguous()
+            return (_scatter_rows_deterministic(ss, idx, gX3[:n]), _scatter_rows_deterministic(ts, idx, gT),
+                    _scatter_rows_deterministic(os_, torch.cat([pos, neg]), gX3[n:]), None, None, None, None)
         ns, nt, no = ss[0] * D, ts[0] * D, os_[0] * D
         flat = torch.zeros(ns + nt + no, device=dev, dtype=torch.float32)              # the three dense gradients out of ONE fill
         gs, gt, go_ = flat[:ns].view(ss), flat[ns:ns + nt].view(ts), flat[ns + nt:].view(os_)

@@ -1058,6 +1058,63 @@ def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
 
 
 
+def test_deterministic_dense_backward():
+    """``functional.set_deterministic(True)``: the drop-in losses' dense gradients without float atomics (the same backward kernels on
+    the batch's gathered rows with the occurrence index as the id, then the per-occurrence rows summed per distinct id in occurrence
+    order).  Batches full of repeated ids: equal to the atomic route at 1e-6, and bit-equal from run to run."""
+    from recbole_cdr_amd import functional as F_, binding as B_
+    gen = torch.Generator().manual_seed(12)
+    nu, ni, D, n = 37, 29, 16, 600
+    U0, I0 = torch.randn(nu, D, generator=gen) * 0.3, torch.randn(ni, D, generator=gen) * 0.3
+    RU0, RI0 = torch.randn(nu, 8, generator=gen), torch.randn(ni, 8, generator=gen)
+    u = torch.randint(0, nu, (n,), generator=gen).to(DEV)
+    p_ = torch.randint(0, ni, (n,), generator=gen).to(DEV)
+    q_ = torch.randint(0, ni, (n,), generator=gen).to(DEV)
+    y = (torch.rand(n, generator=gen) < 0.5).float().to(DEV)
+
+    def leaves(*ts):
+        return [t.clone().to(DEV).requires_grad_(True) for t in ts]
+
+    def bpr():
+        U, I = leaves(U0, I0)
+        (F_.BPRGatherLoss.apply(U, I, u, p_, q_, 1e-10, 0.01) * 1.7).sum().backward()
+        return [U.grad, I.grad]
+
+    def point(kind):
+        U, I = leaves(U0, I0)
+        F_.PointGatherLoss.apply(kind, U, I, None, None, u, p_, y, 0.02)[0].sum().backward()
+        return [U.grad, I.grad]
+
+    def point_shared():
+        S, = leaves(torch.cat([U0, I0]))
+        F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, S, S, None, None, u, p_ + nu, y, 0.0)[0].sum().backward()
+        return [S.grad]
+
+    def pair():
+        U, I = leaves(U0, I0)
+        F_.TwoDomainPointLoss.apply(B_.CDR_LOSS_BCE, U, I, u, p_, y, 0.01, u.flip(0), q_, 1 - y, 0.03, 0.3)[0].sum().backward()
+        return [U.grad, I.grad]
+
+    def gather():
+        W, = leaves(U0)
+        (F_.gather_rows(W, u) * torch.arange(n, device=DEV).view(-1, 1).float().sin()).sum().backward()
+        return [W.grad]
+
+    cases = {'bpr': bpr, 'mse': lambda: point(B_.CDR_LOSS_MSE), 'bce': lambda: point(B_.CDR_LOSS_BCE), 'shared': point_shared,
+             'pair': pair, 'gather': gather}
+    try:
+        for name, fn in cases.items():
+            F_.set_deterministic(False)
+            want = fn()
+            F_.set_deterministic(True)
+            a, b = fn(), fn()
+            for x, y_, w in zip(a, b, want):
+                assert torch.equal(x, y_), name
+                torch.testing.assert_close(x, w, rtol=1e-5, atol=1e-7, msg=name)
+    finally:
+        F_.set_deterministic(False)
+
+
 @pytest.mark.parametrize('rows,dout,din,bias', [(300, 128, 64, True), (300, 64, 128, True), (7, 5, 3, True), (512, 33, 65, False), (4096, 33, 65, False), (5000, 40, 72, True), (16384, 16, 8, True),
                                                 (1, 32, 32, True), (130, 96, 40, True), (100, 64, 12, True), (33, 8, 200, True)])
 def test_linear_backward_small_batches_one_launch(rows, dout, din, bias):
