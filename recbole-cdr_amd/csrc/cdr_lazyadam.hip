@@ -44,6 +44,10 @@ inline int grid_for(int64_t units, int per_block) {
 // replay updates (from, to] of one row chunk without gradient
 __device__ __forceinline__ void replay(float4& w, float4& m, float4& v, int64_t from, int64_t to, const float2* __restrict__ hp,
                                        const lz_args& a) {
+    // a chunk whose moments are all zero (a row that never received a gradient) is a fixed point of the gradient-free update when there
+    // is no weight decay: m and v stay 0 and w moves by step_size * 0 / eps = 0 -- nothing to replay, bit for bit.  (Without this the
+    // periodic flush replays tens of thousands of updates for every untouched row: 2.9 s per 32,768 steps at C3's table sizes.)
+    if (a.wd == 0.f && m.x == 0.f && m.y == 0.f && m.z == 0.f && m.w == 0.f && v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f) return;
     for (int64_t tau = from + 1; tau <= to; ++tau) {
         const float2 h = hp[tau & a.hp_mask];
         w.x = cdr_adam_elem(w.x, 0.f, m.x, v.x, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
