@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 38
+#define CDR_ABI_VERSION 39
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -192,8 +192,9 @@ int cdr_act_bwd(void* stream, int act, const float* y, const float* gy, float* g
 int cdr_colsum(cdr_ctx* ctx, void* stream, const float* X, int64_t M, int64_t N, float* out, int accumulate);
 /* dW [out, in] = gz^T x and db [out] = column sums of gz (db may be NULL) in ONE launch, for the backward of nn.Linear on small
  * batches (gz [rows, out], x [rows, in] row-major; emcdr.py:86-93, sscdr.py:60-66): fixed-order sums, no float atomics */
+int cdr_linear_wgrad_small_workspace(int64_t rows, int dout, int din, size_t* bytes);   /* 0 up to 512 rows */
 int cdr_linear_wgrad_small(cdr_ctx* ctx, void* stream, const float* gz, const float* y_out /* or NULL */, int act, const float* x,
-                           int64_t rows, int dout, int din, float* dW, float* db);
+                           int64_t rows, int dout, int din, float* dW, float* db, void* workspace, size_t workspace_bytes);
 /* (y_out given: gz is the OUTPUT gradient and the kernel forms gz (.) act'(y_out) itself -- no cdr_act_bwd launch in front) */
 /* the forward and the input gradient of the same small layers, one wave per 32 x 32 output tile, operands from global memory:
  *   w_is_k_major = 0: C [M, N] = act(A [M, K] W^T + bias), W [N, K] row-major (y = act(x W^T + b));

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -66,7 +66,8 @@ _SIGNATURES = {
     'cdr_fullsort_neg_sqdist_f32': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr],
     'cdr_act_bwd': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_colsum': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int],
-    'cdr_linear_wgrad_small': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr],
+    'cdr_linear_wgrad_small': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_linear_wgrad_small_workspace': [_c_i64, _c_int, _c_int, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_linear_small': [_c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_int],
     'cdr_mse_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_mse_bwd': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],

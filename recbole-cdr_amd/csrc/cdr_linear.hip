@@ -222,27 +222,41 @@ __global__ __launch_bounds__(64) void linear_small_kernel(const float* __restric
 
 }  // namespace
 
+namespace {
+// up to 512 rows per workgroup (64 per wave); more rows -> more chunks per tile, added by the last workgroup to finish (256-row chunks
+// were slower: 15.3 -> 18.0 us at 4,096 rows)
+inline void wgrad_split(int64_t rows, int64_t* chunk, int64_t* nz) {
+    int64_t n = (rows + 511) / 512;
+    if (n > 64) n = 64;
+    *chunk = (((rows + n - 1) / n) + 1) & ~(int64_t)1;
+    *nz = (rows + *chunk - 1) / *chunk;
+}
+}  // namespace
+
+extern "C" int cdr_linear_wgrad_small_workspace(int64_t rows, int dout, int din, size_t* bytes) {
+    CDR_CHECK_ARG(bytes && rows > 0 && dout > 0 && din > 0);
+    int64_t chunk, nz;
+    wgrad_split(rows, &chunk, &nz);
+    *bytes = nz > 1 ? (size_t)((dout + 31) / 32) * ((din + 31) / 32) * nz * kWgPart * sizeof(float) : 0;
+    return CDR_OK;
+}
+
 extern "C" int cdr_linear_wgrad_small(cdr_ctx* ctx, void* stream, const float* gz, const float* y_out, int act, const float* x, int64_t rows,
-                                      int dout, int din, float* dW, float* db) {
+                                      int dout, int din, float* dW, float* db, void* workspace, size_t workspace_bytes) {
     CDR_CHECK_ARG(ctx && gz && x && dW && rows > 0 && dout > 0 && din > 0);
     const int tx = (dout + 31) / 32, ty = (din + 31) / 32;
     CDR_CHECK_ARG(tx <= 65535 && ty <= 65535);
-    // up to 512 rows per workgroup (64 per wave); more rows -> more chunks per tile, added by the last workgroup to finish (256-row chunks
-    // were slower: 15.3 -> 18.0 us at 4,096 rows)
-    int64_t nz = (rows + 511) / 512;
-    if (nz > 64) nz = 64;
     if ((int64_t)tx * ty > CDR_TICKETS) { cdr_set_error("cdr_linear_wgrad_small: %d x %d tiles exceed the %d sign-in counters", tx, ty, CDR_TICKETS); return CDR_EINVAL; }
-    const int64_t chunk = (((rows + nz - 1) / nz) + 1) & ~(int64_t)1;
-    nz = (rows + chunk - 1) / chunk;
-    float* part = nullptr;
-    if (nz > 1) {
-        void* p = nullptr;
-        int rc = cdr_ctx_scratch(ctx, (size_t)tx * ty * nz * kWgPart * sizeof(float), &p);
-        if (rc) return rc;
-        part = (float*)p;
-    }
+    int64_t chunk, nz;
+    wgrad_split(rows, &chunk, &nz);
+    size_t need = 0;
+    int rc = cdr_linear_wgrad_small_workspace(rows, dout, din, &need);
+    if (rc) return rc;
+    // the partial tiles live in the CALLER's workspace (not in the context's grow-on-demand scratch: a captured hipGraph keeps the
+    // pointer it was recorded with)
+    CDR_CHECK_ARG(need == 0 || (workspace && workspace_bytes >= need));
     linear_wgrad_small_kernel<<<dim3(tx, ty, (unsigned)nz), dim3(kWgBlock), 0, (hipStream_t)stream>>>(gz, y_out, act, x, rows, dout, din, dW, db,
-                                                                                                     chunk, part, ctx->tickets);
+                                                                                                     chunk, (float*)workspace, ctx->tickets);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

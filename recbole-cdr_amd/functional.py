@@ -492,8 +492,12 @@ class LinearAct(Function):
             if ctx.needs_input_grad[1] or want_b:
                 gW = torch.empty_like(w_)
                 gb = torch.empty(dout, device=gy2.device, dtype=torch.float32) if want_b else None
+                need = ctypes.c_size_t(0)
+                B_._check(B_.load().cdr_linear_wgrad_small_workspace(rows, dout, din, ctypes.byref(need)), 'cdr_linear_wgrad_small_workspace')
+                # (a tensor of this call's own: under a hipGraph capture it comes from the graph's pool and stays where the graph expects it)
+                ws = torch.empty(int(need.value), device=gy2.device, dtype=torch.uint8) if need.value else None
                 B_.call('cdr_linear_wgrad_small', B_.ctx(gy2.device), B_.stream(), B_.f32(gz), yp, int(ctx.act), B_.f32(x2), rows, dout, din,
-                        B_.f32(gW), None if gb is None else B_.f32(gb))
+                        B_.f32(gW), None if gb is None else B_.f32(gb), None if ws is None else B_.raw(ws), int(need.value))
                 if not ctx.needs_input_grad[1]:
                     gW = None
             return gx, gW, gb, None
