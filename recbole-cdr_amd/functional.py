@@ -437,6 +437,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=B_.ACT_NONE, out=Non
     return out
 
 
+_WGRAD_CHUNKED_ROWS = 1 << 18  # ... and up to here the weight gradients alone (64 chunks of <= 4,096 rows per tile)
 _SMALL_WGRAD_ROWS = 16384    # batches up to here take the one-wave-per-tile kernels of csrc/cdr_linear.hip (dW: 512-row chunks per workgroup)
 
 
@@ -509,6 +510,17 @@ class LinearAct(Function):
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = gemm(gz, w_).view(ctx.xshape)                                      # [rows,out] x [out,in]
+        if (ctx.needs_input_grad[1] or want_b) and rows <= _WGRAD_CHUNKED_ROWS and (dout + 31) // 32 * ((din + 31) // 32) <= 1024:
+            # larger batches: dx stays on the general contraction, dW + db still come from ONE fixed-order launch (up to 64 row chunks per
+            # tile) instead of a transposed GEMM with split-K atomics + a two-launch column sum
+            gW = torch.empty_like(w_)
+            gb = torch.empty(dout, device=gy2.device, dtype=torch.float32) if want_b else None
+            need = ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_linear_wgrad_small_workspace(rows, dout, din, ctypes.byref(need)), 'cdr_linear_wgrad_small_workspace')
+            ws = torch.empty(int(need.value), device=gy2.device, dtype=torch.uint8) if need.value else None
+            B_.call('cdr_linear_wgrad_small', B_.ctx(gy2.device), B_.stream(), B_.f32(gz), None, 0, B_.f32(x2), rows, dout, din,
+                    B_.f32(gW), None if gb is None else B_.f32(gb), None if ws is None else B_.raw(ws), int(need.value))
+            return gx, (gW if ctx.needs_input_grad[1] else None), gb, None
         if ctx.needs_input_grad[1]:
             gW = gemm(gz, x2, trans_a=True)                                         # [out,rows] x [rows,in]
         if want_b:

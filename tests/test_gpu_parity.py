@@ -1115,7 +1115,7 @@ def test_deterministic_dense_backward():
         F_.set_deterministic(False)
 
 
-@pytest.mark.parametrize('rows,dout,din,bias', [(300, 128, 64, True), (300, 64, 128, True), (7, 5, 3, True), (512, 33, 65, False), (4096, 33, 65, False), (5000, 40, 72, True), (16384, 16, 8, True),
+@pytest.mark.parametrize('rows,dout,din,bias', [(300, 128, 64, True), (300, 64, 128, True), (7, 5, 3, True), (512, 33, 65, False), (4096, 33, 65, False), (5000, 40, 72, True), (16384, 16, 8, True), (40000, 24, 40, True), (102400, 64, 64, True),
                                                 (1, 32, 32, True), (130, 96, 40, True), (100, 64, 12, True), (33, 8, 200, True)])
 def test_linear_backward_small_batches_one_launch(rows, dout, din, bias):
     """nn.Linear's weight and bias gradients for small batches come from ONE launch (cdr_linear_wgrad_small: a workgroup per 32 x 32 tile
