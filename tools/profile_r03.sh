@@ -34,7 +34,7 @@ done
 MB_U=1024 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o pmc -- python $R/tools/mb_fullsort.py 128 > $O/mb_fullsort_under_pmc.txt 2> $O/pmc_mfma.err; echo "pmc mfma rc=$?"
 for T in conet mapstep; do
   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$T -o pmc -- python $R/tools/mb_$T.py > $O/mb_${T}_under_pmc.txt 2> $O/pmc_mfma_$T.err; echo "pmc mfma $T rc=$?"
-done   # (summarised by hand into profiles/r03_pmc_mfma_conet_map.json: busy / ((active / 8 XCDs) x 1,024 SIMDs) per kernel)
+done   # (tools/refresh_profiles_r03.py -> profiles/r03_pmc_mfma_conet_map.json: busy / ((active / 8 XCDs) x 1,024 SIMDs) per kernel)
 find $O -name "*kernel_trace.csv" -size +6M -delete
 find $O -name "*counter_collection.csv" -size +24M -delete
 ls -la $O | head -60
