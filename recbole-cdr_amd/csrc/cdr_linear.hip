@@ -114,6 +114,11 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_small_kernel(const floa
     // the tile's counter adds them in chunk order -- fixed order again.  The partials travel with system-scope stores and loads (written
     // through / read past the per-XCD L2s): no release fence, which on this part is a write-back of the whole L2 per workgroup; one
     // counter per tile, so no more than gridDim.z atomics meet on an address.
+    // (this hand-over is relaxed in the language's memory model; it is ordered by the hardware's behaviour -- sc0 sc1 stores are
+    // acknowledged by memory before s_waitcnt vmcnt(0) retires, sc0 sc1 loads never hit a cache -- so it is tied to the one target below.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "cdr_linear.hip: the fence-free partial-tile hand-over is only valid on gfx950 (write-through system-scope stores); add __threadfence() pairs for another target"
+#endif
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     float* mine = part + ((size_t)tile * nz + blockIdx.z) * kWgPart;
     for (int e = threadIdx.x; e < 32 * 32 + 32; e += kWgBlock) {

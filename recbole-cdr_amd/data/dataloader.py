@@ -50,6 +50,10 @@ class DomainTrainLoader:
     def __next__(self):
         if self.pr >= self.pr_end:
             self.pr = 0
+            # end of this loader's own epoch (standalone use, or the source side wrapping in BOTH mode): one host sync, so a user
+            # without any free negative is reported even when no CrossDomainDataloader epoch follows
+            if hasattr(self.neg_sampler, 'check_failures'):
+                self.neg_sampler.check_failures()
             raise StopIteration()
         cur = self.inter[self.pr:self.pr + self.step]
         self.pr += self.step
@@ -106,8 +110,8 @@ class CrossDomainDataloader:
         self.state = CrossDomainDataLoaderState.BOTH
 
     def check_samplers(self):
-        """One host sync per epoch, in every mode, at the START of the next epoch (never in the middle of one): did the device
-        sampler meet a user without any free candidate (sampler.DeviceNegSampler.check_failures)?"""
+        """One host sync per sampler at the START and at the END of an epoch, in every mode (never in the middle of one): did the
+        device sampler meet a user without any free candidate (sampler.DeviceNegSampler.check_failures)?"""
         for dl in (self.source_dataloader, self.target_dataloader):
             smp = getattr(dl, 'neg_sampler', None)
             if smp is not None and hasattr(smp, 'check_failures'):
@@ -131,10 +135,12 @@ class CrossDomainDataloader:
         if self.state == S.SOURCE and self.source_dataloader.pr >= self.source_dataloader.pr_end:
             self.target_dataloader.pr = 0
             self.source_dataloader.pr = 0
+            self.check_samplers()                    # end of the epoch (the LAST epoch has no following __iter__ to do it)
             raise StopIteration()
         if self.state in (S.TARGET, S.BOTH) and self.target_dataloader.pr >= self.target_dataloader.pr_end:
             self.target_dataloader.pr = 0
             self.source_dataloader.pr = 0
+            self.check_samplers()
             raise StopIteration()
         if self.state == S.OVERLAP and self.overlap_dataloader.pr >= self.overlap_dataloader.pr_end:
             self.overlap_dataloader.pr = 0

@@ -20,10 +20,13 @@ class Interaction(dict):
         return out
 
     def update(self, other):
+        was_empty = dict.__len__(self) == 0
         dict.update(self, other)
         ok = getattr(other, 'k_major', None)
-        if ok is not None and (len(self) == 0 or self.k_major in (None, ok)):
-            self.k_major = ok            # BOTH-mode merge (dataloader.py:156-161): both domains' loaders use the same k, or none is kept
+        # BOTH-mode merge (dataloader.py:156-161): the hint survives only when both sides carry the SAME k (or self had no rows yet);
+        # a hinted batch merged into rows without a hint -- or the reverse -- leaves a mixture that is not k-major
+        if was_empty:
+            self.k_major = ok
         elif ok != self.k_major:
             self.k_major = None
         return self

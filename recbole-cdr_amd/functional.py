@@ -441,6 +441,11 @@ _WGRAD_CHUNKED_ROWS = 1 << 18  # ... and up to here the weight gradients alone (
 _SMALL_WGRAD_ROWS = 16384    # batches up to here take the one-wave-per-tile kernels of csrc/cdr_linear.hip (dW: 512-row chunks per workgroup)
 
 
+def _wgrad_tiles_fit(dout, din):
+    """cdr_linear_wgrad_small hands one ticket to every 32 x 32 tile of dW and has CDR_TICKETS = 1024 of them (csrc/cdr_linear.hip)."""
+    return (dout + 31) // 32 * ((din + 31) // 32) <= 1024
+
+
 def _small_linear(x2, weight):
     """Small batches go to the one-wave-per-tile kernels of csrc/cdr_linear.hip (the general contraction's start-up dominates them)."""
     return (x2.shape[0] <= _SMALL_WGRAD_ROWS and x2.shape[1] % 4 == 0 and x2.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
@@ -490,7 +495,17 @@ class LinearAct(Function):
                         yp = None
                     gx = gemm(gz, w_)
                 gx = gx.view(ctx.xshape)
-            if ctx.needs_input_grad[1] or want_b:
+            if (ctx.needs_input_grad[1] or want_b) and not _wgrad_tiles_fit(dout, din):
+                # more 32 x 32 tiles than the one-launch kernel has tickets for (e.g. a 2048 x 1024 layer): the general route
+                if yp is not None:
+                    gz = torch.empty_like(gy2)
+                    B_.call('cdr_act_bwd', B_.stream(), ctx.act, B_.f32(y), B_.f32(gy2), B_.f32(gz), gy2.numel())
+                if ctx.needs_input_grad[1]:
+                    gW = gemm(gz, x2, trans_a=True)
+                if want_b:
+                    gb = torch.empty(dout, device=gy2.device, dtype=torch.float32)
+                    B_.call('cdr_colsum', B_.ctx(gy2.device), B_.stream(), B_.f32(gz), rows, dout, B_.f32(gb), 0)
+            elif ctx.needs_input_grad[1] or want_b:
                 gW = torch.empty_like(w_)
                 gb = torch.empty(dout, device=gy2.device, dtype=torch.float32) if want_b else None
                 need = ctypes.c_size_t(0)
@@ -510,7 +525,7 @@ class LinearAct(Function):
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = gemm(gz, w_).view(ctx.xshape)                                      # [rows,out] x [out,in]
-        if (ctx.needs_input_grad[1] or want_b) and rows <= _WGRAD_CHUNKED_ROWS and (dout + 31) // 32 * ((din + 31) // 32) <= 1024:
+        if (ctx.needs_input_grad[1] or want_b) and rows <= _WGRAD_CHUNKED_ROWS and _wgrad_tiles_fit(dout, din):
             # larger batches: dx stays on the general contraction, dW + db still come from ONE fixed-order launch (up to 64 row chunks per
             # tile) instead of a transposed GEMM with split-K atomics + a two-launch column sum
             gW = torch.empty_like(w_)

@@ -196,8 +196,9 @@ class Trainer:
             world, rank = dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
         out = Interaction({k: v[:v.shape[0] - v.shape[0] % world][rank::world].contiguous() for k, v in interaction.items()})
         # rows j + m S of a k-major batch: every world-th row is again k-major (S / world positives) when world divides S
-        km, n = getattr(interaction, 'k_major', None), len(interaction)
-        if km and n % km == 0 and (n // km) % world == 0:
+        # (EVERY field: in BOTH mode the source and target columns of one batch may differ in length)
+        km = getattr(interaction, 'k_major', None)
+        if km and all(v.shape[0] % km == 0 and (v.shape[0] // km) % world == 0 for v in interaction.values()):
             out.k_major = km
         return out
 
