@@ -811,16 +811,9 @@ def run_model_workload(args, world, rank, dev):
                              'full-graph propagation every step' % (len(ds.s_pairs), len(ds.t_pairs))
     torch.manual_seed(2022)
     model = Model(cfg, ds).to(dev)
-    # Optimizer: the reference's Adam over every parameter.  For CoNet (C3) the tables take its deferred row-wise form
-    # (lazyadam.DeferredRowAdam: rows without a gradient postpone their momentum updates and replay them when next read --
-    # bit-identical to the dense sweep, tests/test_gpu_parity.py::test_deferred_adam_is_bit_identical_to_the_dense_sweep);
-    # --dense-adam times the literal O(table) sweep instead.
-    deferred = args.workload == 'c3' and not args.dense_adam and world == 1 and getattr(model, 'fused_towers', False)
-    if deferred:
-        from recbole_cdr_amd.trainer.trainer import RowAwareAdam
-        opt = RowAwareAdam(model, lr=1e-3)
-    else:
-        opt = DenseAdam(model.parameters(), lr=1e-3)
+    # Optimizer: the reference's Adam over every parameter -- built by the product's trainer at N = 1 (for CoNet its deferred row-wise
+    # form, lazyadam.DeferredRowAdam: bit-identical to the dense sweep; --dense-adam keeps the literal O(table) sweep)
+    deferred, opt = False, None
     rng = np.random.RandomState(2022)
     if pairwise:
         model.set_phase('SOURCE')
@@ -830,9 +823,10 @@ def run_model_workload(args, world, rank, dev):
         batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
         rows_per_step = 2 * S * (1 + k)
 
-    from recbole_cdr_amd.graph_step import GraphedTrainStep
     sdp = None
     rowshard = None
+    trainer = None
+    via = None
     if args.workload == 'c4' and (world > 1 or args.force_shard) and not args.replica_dp:
         # BASELINE configs[3] as named: the tables (with their Adam state), the adjacency rows and the transfer-layer degrees
         # row-sharded over the ranks, per-layer all-gather of E forward and of g (1 + E) backward (bitgcf_shard.py).  The batch is
@@ -842,7 +836,7 @@ def run_model_workload(args, world, rank, dev):
         rowshard = ShardedBiTGCF(ds.num_total_user, ds.num_total_item, ds.num_overlap_user, ds.num_overlap_item, ds.s_pairs, ds.t_pairs,
                                  cfg['embedding_size'], cfg['n_layers'], cfg['lambda_source'], cfg['lambda_target'], cfg['connect_way'],
                                  cfg['reg_weight'], NativeGraphOps(dev), drop_rate=cfg['drop_rate'])
-        del model, opt
+        del model
         torch.cuda.empty_cache()
         opt = DenseAdam(list(rowshard.params.values()), lr=1e-3)
         model = None
@@ -856,10 +850,39 @@ def run_model_workload(args, world, rank, dev):
         else:
             batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
         sdp = ShardedDataParallel(model, lr=1e-3)
-    graphed = GraphedTrainStep(model, opt, batches[0]) if (not args.no_graph and sdp is None and rowshard is None) else None
-    # the synthetic batches in the captured step's packed layout (what a device-side loader would fill directly): batch hand-over =
-    # ONE device copy inside the timed step instead of one per field; data generation stays outside the timed region as before
-    packed = [graphed.pack(b) for b in batches] if graphed is not None else None
+    else:
+        # N = 1: THE PRODUCT'S LOOP.  CrossDomainTrainer.fit over device-resident loaders of this synthetic dataset (the interaction
+        # lists tiled to args.steps full batches per epoch, shuffled every epoch, negatives drawn by the device sampler): the trainer
+        # captures producer + calculate_loss + backward + Adam once per phase and an epoch is a run of hipGraph replays
+        # (trainer/trainer.py::_train_epoch_graphed).  One fit() = one epoch = exactly args.steps steps; the first fit() is the
+        # warm-up (it also pays the capture), the second is timed.  Nothing of the step lives in this file any more.
+        from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+        from recbole_cdr_amd.sampler import DeviceNegSampler
+        from recbole_cdr_amd.trainer import CrossDomainTrainer
+        from recbole_cdr_amd.utils import InputType
+        it_ = InputType.PAIRWISE if pairwise else InputType.POINTWISE
+        times = k if pairwise else 1 + k
+
+        def stream_of(pairs, n):
+            reps = (n + len(pairs) - 1) // len(pairs)
+            sel = np.tile(pairs, (reps, 1))[:n]
+            return torch.from_numpy(np.ascontiguousarray(sel[:, 0])).to(dev), torch.from_numpy(np.ascontiguousarray(sel[:, 1])).to(dev)
+        su, si = stream_of(ds.s_pairs, args.steps * S)
+        tu, ti = stream_of(ds.t_pairs, args.steps * S)
+        gen = torch.Generator(device=dev); gen.manual_seed(2022)
+        loaders = CrossDomainDataloader(
+            DomainTrainLoader({'source_user_id': su, 'source_item_id': si}, 'source_user_id', 'source_item_id', 'source_label', 'neg_',
+                              S * times, k, it_, DeviceNegSampler(ds, 'source', ds.s_pairs, dev), shuffle=True, generator=gen),
+            DomainTrainLoader({'target_user_id': tu, 'target_item_id': ti}, 'target_user_id', 'target_item_id', 'target_label', 'neg_',
+                              S * times, k, it_, DeviceNegSampler(ds, 'target', ds.t_pairs, dev), shuffle=True, generator=gen),
+            OverlapDataloader(max(ds.num_overlap_user, ds.num_overlap_item), 100, device=dev, shuffle=True, generator=gen))
+        phase = 'SOURCE' if pairwise else 'BOTH'
+        tcfg = dict(cfg, learning_rate=1e-3, train_modes=[phase], epoch_num=['1'], epochs=1, eval_step=0, source_split=False,
+                    graph_step=not args.no_graph, deferred_adam=not args.dense_adam)
+        trainer = CrossDomainTrainer(tcfg, model)
+        opt = trainer.optimizer
+        deferred = type(opt).__name__ == 'RowAwareAdam'
+        via = 'CrossDomainTrainer.fit'
 
     def one_step(i):
         if rowshard is not None:
@@ -867,25 +890,28 @@ def run_model_workload(args, world, rank, dev):
             ls, lt = rowshard.loss_and_grads(batches[i % 4])
             opt.step()
             return ls + lt
-        if sdp is not None:
-            return sdp.step(batches[i % 4])
-        if graphed is not None:
-            return graphed.step(packed[i % 4])        # one device copy + one hipGraph replay per step (see graph_step.py)
-        opt.zero_grad(set_to_none=True)
-        losses = model.calculate_loss(batches[i % 4])
-        loss = sum(losses) if isinstance(losses, tuple) else losses
-        loss.sum().backward()
-        opt.step()
-        return loss
+        return sdp.step(batches[i % 4])
 
-    for i in range(args.warmup):
-        one_step(i)
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = one_step(i)
-    barrier(world)
-    dt = time.perf_counter() - t0
+    if trainer is not None:
+        trainer.fit(loaders)                                   # warm-up epoch: args.steps steps (>= --warmup), captures the step
+        warm = dict(trainer.graph_stats)
+        barrier(world)
+        t0 = time.perf_counter()
+        trainer.fit(loaders)                                   # the timed epoch: exactly args.steps steps + the epoch's shuffle and loss read-back
+        barrier(world)
+        dt = time.perf_counter() - t0
+        loss = torch.tensor(trainer.train_loss_dict[0] / args.steps)
+        stats = {k_: trainer.graph_stats[k_] - warm[k_] for k_ in warm}
+        assert stats['replayed'] + stats['eager'] == args.steps, stats
+    else:
+        for i in range(args.warmup):
+            one_step(i)
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = one_step(i)
+        barrier(world)
+        dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -896,8 +922,10 @@ def run_model_workload(args, world, rank, dev):
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
               'higher_is_better': True, 'scaling': 'strong' if rowshard is not None else 'weak', 'vs_baseline': None, 'dtype': 'f32',
               'data': 'synthetic' + ('; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo' if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')) else ''),
-              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else '' if args.no_graph else ', step replayed as one hipGraph'),
-                         'rows_per_step': rows_per_step},
+              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else ', eager trainer loop' if args.no_graph else ', batch production + step replayed as one hipGraph per batch'),
+                         'rows_per_step': rows_per_step, 'via': via,
+                         'trainer_steps': None if trainer is None else dict(stats, warmup_steps_run=args.steps, optimizer=type(opt).__name__,
+                                                                            timed='one fit() = one shuffled epoch of exactly --steps full batches, sampler + loader + step + loss read-back')},
               'final_loss': float(loss.sum())}
     # ---- roofline of the step (SURVEY 8d figures; C1-C4 tables sit in L2 / Infinity Cache, so the HBM fractions are nominal) ----
     step_s = dt / args.steps
@@ -916,8 +944,9 @@ def run_model_workload(args, world, rank, dev):
             from recbole_cdr_amd import binding as B_
             B_.timing_enable(dev, 256)
             for i in range(8):
+                b_ = batches[i % 4]
                 opt.zero_grad(set_to_none=True)
-                model.calculate_loss(batches[i % 4]).backward()
+                model.calculate_loss(b_).backward()
                 opt.step()
             torch.cuda.synchronize()
             kt = {}

@@ -40,7 +40,7 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
-#define CDR_ABI_VERSION 39
+#define CDR_ABI_VERSION 40
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -219,10 +219,12 @@ int cdr_inc_i64(void* stream, int64_t* counter);
  * x[i * x_stride] * w[i], i < n <= 64, added in index order; mode 1 (its backward): out[i] = scale[0] * w[i].                    */
 int cdr_scalar_mix(void* stream, int mode, int n, const float* x, int64_t x_stride, const float* w, const float* scale, float* out);
 /* the same update for `count` parameter tensors in one launch (+ one launch that bumps their device step counters first):
- * host arrays of device pointers, one entry per tensor */
+ * host arrays of device pointers, one entry per tensor.  loss / loss_sum (both or neither): the counter launch also does
+ * loss_sum[0] += loss[0] -- recbole Trainer._train_epoch's `total_loss += loss.item()` (recbole_cdr/trainer/trainer.py:59-73 runs
+ * that loop) kept on the device, no launch and no host sync of its own. */
 int cdr_adam_multi_dev(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev,
-                       float lr, float beta1, float beta2, float eps, float weight_decay);
+                       float lr, float beta1, float beta2, float eps, float weight_decay, const float* loss, float* loss_sum);
 
 /* cdr_gemm_f32 with a per-output-row scale and a pre-activation accumulate -- the CoNet cross unit
  * (conet.py:127-135):  first  C = s W^T + b           (cdr_gemm_f32, act none)
@@ -373,6 +375,19 @@ int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_source, int L
                   const float* label, const float* x0, const float* acts, const float* prob, const float* maskf,
                   const float* out, const float* grad_out /* device scalar or NULL = 1 */, float* gz, float* gx0,
                   float* const* grads, void* workspace, size_t workspace_bytes, int data_gradients_done);
+
+/* ---- CoNet full-sort scoring, all users x all items in one launch (conet.py:222-242: the reference's per-user Python loop over the
+ * target tower without cross terms) --------------------------------------------------------------------------------------
+ * The first layer is separable, W1 [u ; i] + b1 = Q[u] + P[i] with Q = user_e W1[:, :D]^T + b1 [U, h1] and P = items W1[:, D:]^T
+ * [N, h1] (two cdr_gemm_f32_ex calls); this entry does the rest for every (u, i):
+ *      out[u, i] = sigmoid(wo . relu(W_T ... relu(W_1 relu(P[i] + Q[u]) + b_1) ... + b_T) + bo)
+ * W[t]: [tail_dims[t], d_in] row-major (d_in = h1 for t = 0, tail_dims[t - 1] after), b[t]: [tail_dims[t]]; wo: [tail_dims[last]].
+ * Range: h1 <= 64, 1 <= n_tail <= 3, every tail width <= 32 (cdr_conet_fullsort_supported returns 1 / 0; outside it the call
+ * returns CDR_EINVAL and the host keeps its contraction-per-layer path).  No intermediate touches memory.                       */
+int cdr_conet_fullsort_supported(int h1, int n_tail, const int* tail_dims);
+int cdr_conet_fullsort(void* stream, const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t U, int64_t N, int h1,
+                       int n_tail, const int* tail_dims, const float* const* W, const float* const* b, const float* wo,
+                       const float* bo, float* out, int64_t ldo);
 
 /* ---- SSCDR helpers (sscdr.py:120-187) -------------------------------------------------------------------------- */
 /* embedding_normalize: len = sum x^2, y = x / (len > 1 ? len : 1)  -- the squared-length quirk is kept */
@@ -594,6 +609,36 @@ int cdr_sscdr_pair_sample(void* stream, const int64_t* ids, int64_t n, int64_t l
 int cdr_neg_sample_alias(void* stream, const int64_t* users, int64_t S, int k, const int64_t* keys, const float* prob,
                          const int64_t* alias, int64_t n_keys, const int64_t* used_indptr, const int64_t* used_indices,
                          uint64_t seed, int64_t* out, int* fail_flag);
+
+/* ---- the loader's batch on the device, in one launch -----------------------------------------------------
+ * replaces recbole's TrainDataLoader._next_batch_data + _neg_sampling as the cross-domain loaders drive them
+ * (recbole_cdr/data/dataloader.py:114-162: slice of the epoch's shuffled interactions -> repeat -> sample_by_user_ids ->
+ * join, crossdomain_sampler.py:139-175) and OverlapDataloader's slice (dataloader.py:37-52).  Rows [start, start + S) of the
+ * two int64 columns users_all / items_all [n_rows]:
+ *   pairwise  (pointwise = 0, k >= 1): out_users[j + m S] = u_j, out_items[j + m S] = i_j, out_neg[j + m S] = m-th negative (m < k)
+ *   pointwise (pointwise = 1, k >= 1): out_users[j + t S] = u_j (t <= k); out_items[j] = i_j, out_items[S + j + m S] = m-th negative
+ *   k == 0                           : out_users[j] = users_all[start + j]  (items_all / out_items / out_neg may be NULL)
+ * cursor: DEVICE int64 [4] = {start, draws, sign-in word (0 between launches), spare}.  The launch reads start and draws, and
+ * its last workgroup to finish stores start + S and draws + 1, so the call can be captured in a hipGraph: every replay yields the
+ * next batch with fresh negatives.  dist = 0: uniform candidates [lo0,hi0) U [lo1,hi1) (cdr_neg_sample_uniform's draw with
+ * seed + draws * 0x85EBCA77C2B2AE63); dist = 1: the alias table (cdr_neg_sample_alias's draw).  Rows past n_rows yield PAD 0.   */
+/* The same arguments as a struct, and several loaders in ONE launch (the BOTH state produces the target and the source batch
+ * together, recbole_cdr/data/dataloader.py:156-161): job i is served by grid row i.                                          */
+typedef struct cdr_batch_job {
+    const int64_t* users_all; const int64_t* items_all; int64_t n_rows; int64_t* cursor; int64_t S;
+    int32_t k, pointwise, dist, reserved;
+    int64_t lo0, hi0, lo1, hi1;
+    const int64_t* keys; const float* prob; const int64_t* alias; int64_t n_keys;
+    const int64_t* used_indptr; const int64_t* used_indices; uint64_t seed;
+    int64_t* out_users; int64_t* out_items; int64_t* out_neg; int* fail_flag;
+} cdr_batch_job;
+#define CDR_BATCH_MAX_JOBS 4
+int cdr_batch_produce_jobs(void* stream, const cdr_batch_job* jobs, int n_jobs);
+int cdr_batch_produce(void* stream, const int64_t* users_all, const int64_t* items_all, int64_t n_rows, int64_t* cursor,
+                      int64_t S, int k, int pointwise, int dist, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1,
+                      const int64_t* keys, const float* prob, const int64_t* alias, int64_t n_keys,
+                      const int64_t* used_indptr, const int64_t* used_indices, uint64_t seed, int64_t* out_users,
+                      int64_t* out_items, int64_t* out_neg, int* fail_flag);
 
 /* ---- owner routing for row-sharded tables (row r lives on rank r % world) -- index plumbing of shard.py --------
  * cdr_route_by_owner: stable counting sort of the ids (ids1 appended after ids0) by owner = id % world.

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -174,10 +174,13 @@ _SIGNATURES = {
     'cdr_point_bwd_dense_pair': [_c_ptr, _c_ptr] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 12,
     'cdr_scalar_mix': [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
-    'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32],
+    'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_neg_sample_alias': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64, _c_ptr, _c_ptr],
     'cdr_neg_sample_uniform': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64,
                                _c_ptr, _c_ptr],
+    'cdr_batch_produce': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr,
+                          _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_batch_produce_jobs': [_c_ptr, _c_ptr, _c_int],
     'cdr_sscdr_pair_sample': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_bpr_fwd_grad_kmajor': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr,
                                 _c_ptr, _c_ptr, _c_ptr],
@@ -203,10 +206,22 @@ _SIGNATURES = {
                       _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t, ctypes.POINTER(_c_int)],
     'cdr_conet_bwd': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                       _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t, _c_int],
+    'cdr_conet_fullsort_supported': [_c_int, _c_int, _c_ptr],
+    'cdr_conet_fullsort': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_overlap_remap': [ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_revoke_map': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],
 }
+
+class BatchJob(ctypes.Structure):
+    """``cdr_batch_job`` of include/cdr_hip.h."""
+    _fields_ = [('users_all', _c_ptr), ('items_all', _c_ptr), ('n_rows', _c_i64), ('cursor', _c_ptr), ('S', _c_i64),
+                ('k', ctypes.c_int32), ('pointwise', ctypes.c_int32), ('dist', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('lo0', _c_i64), ('hi0', _c_i64), ('lo1', _c_i64), ('hi1', _c_i64),
+                ('keys', _c_ptr), ('prob', _c_ptr), ('alias', _c_ptr), ('n_keys', _c_i64),
+                ('used_indptr', _c_ptr), ('used_indices', _c_ptr), ('seed', ctypes.c_uint64),
+                ('out_users', _c_ptr), ('out_items', _c_ptr), ('out_neg', _c_ptr), ('fail_flag', _c_ptr)]
+
 
 _lib = None
 _lib_lock = threading.Lock()

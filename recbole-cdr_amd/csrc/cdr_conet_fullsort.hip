@@ -1,0 +1,217 @@
+// CoNet full-sort scoring in ONE launch (conet.py:222-242): every evaluated user against every target item through the target
+// tower WITHOUT cross terms -- the reference loops over users in Python and pushes a repeat()ed [N, 2D] input through the tower
+// per user; the product's previous path hoisted the separable first layer but still ran a Python loop of generic contractions with
+// [N, h] intermediates in HBM per user.
+//
+// The first layer is separable: W1 [u ; i] + b1 = (W1u u + b1) + W1i i =: Q[u] + P[i].  P [N, h1] and Q [U, h1] come from two plain
+// contractions (cdr_gemm_f32_ex); this kernel does everything behind them for all U x N pairs:
+//      h1 = relu(P[i] + Q[u]) -> h2 = relu(W2 h1 + b2) -> ... -> sigmoid(wo . hL + bo)            ~2 (h1 d2 + d2 d3 + ...) FLOP per pair
+//
+// Layout.  A wave owns a tile of 32 items and keeps their P rows in registers for all the users it serves; the layers run
+// TRANSPOSED on v_mfma_f32_32x32x2_f32 -- A = the layer's weights (rows = output features), B = the activations (columns = the 32
+// items) -- so a layer's accumulator (C[feature][item]: lane = item + 32 * ((feature / 4) % 2), register = 4 * (feature / 8) +
+// feature % 4) IS the next layer's B operand, register for register: lane half h holds features 8 g + 4 h + (0..3) in registers
+// 4 g + (0..3), and K step r of the next layer contracts "register r of both halves" -- only the order of the K sum changes, and the
+// weights are loaded once per lane in exactly that order.  No activation ever leaves the registers; nothing but P, Q and the
+// scores touches memory.  Q rows of the workgroup's user chunk sit in LDS (read as wave-half broadcasts).
+//
+// Work: MFMA steps per (32 items x 1 user) = h1/2 + 4 ceil(d2/8) + 4 ceil(d3/8) (...): 56 x 64 cycles for [64,32,16,8] (75 % of the
+// executed MFMA flops are algorithmic: the 16- and 8-row layers use half / a quarter of a 32-row tile).  The VALU side (P + q, ReLU,
+// bias: ~135 instructions per tile-user) runs under the MFMAs of the SIMD's other wave.
+#include "cdr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kFsBlock = 256;                    // 4 waves: 4 item tiles per workgroup pass, one user chunk
+constexpr int kFsUsers = 32;                     // users per LDS chunk (32 x 64 floats = 8 KB)
+
+struct fs_args {
+    const float* P; int64_t ldp;                 // [N, >= h1]  item part of the first layer (no bias)
+    const float* Q; int64_t ldq;                 // [U, >= h1]  user part + bias
+    int64_t U, N;
+    int h1, n_tail;                              // n_tail in 1..3 layers behind the first
+    int d[3];                                    // their widths
+    const float* W[3]; const float* b[3];        // W[t]: [d[t], d_in] row-major (d_in = h1 or d[t-1])
+    const float* wo; const float* bo;            // output unit [d_last], [1]
+    float* out; int64_t ldo;                     // [U, N]
+    int users_per_block;                         // a multiple of kFsUsers
+};
+
+#define FS_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+
+__device__ __forceinline__ f32x16 fs_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// feature held by (register r, lane half h) of a 32x32 accumulator
+__device__ __forceinline__ int fs_feat(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+
+// S1: K steps of the first tail layer (h1 <= 2 S1; half h contracts features h S1 + s).  G2/G3/G4: 8-feature register groups of the
+// tail layers' outputs (G = 0: layer absent); the next layer contracts 4 G steps.
+template <int S1, int G2, int G3, int G4>
+__global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
+    __shared__ __attribute__((aligned(16))) float Ql[kFsUsers * 2 * S1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const int d2 = a.d[0], d3 = G3 ? a.d[1] : 0, d4 = G4 ? a.d[2] : 0;
+    constexpr int R2 = 4 * G2, R3 = 4 * G3, R4 = 4 * G4;
+
+    // ---- static per-lane weight fragments, in the K order of the register chain ------------------------------------------------
+    float w2[S1], b2[R2];
+#pragma unroll
+    for (int s = 0; s < S1; ++s) { const int f = h * S1 + s; w2[s] = (c < d2 && f < a.h1) ? a.W[0][(int64_t)c * a.h1 + f] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < R2; ++r) { const int j = fs_feat(r, h); b2[r] = j < d2 ? a.b[0][j] : 0.f; }
+    float w3[R2 ? R2 : 1], b3[R3 ? R3 : 1], w4[R3 ? R3 : 1], b4[R4 ? R4 : 1];
+    if (G3) {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) { const int f = fs_feat(r, h); w3[r] = (c < d3 && f < d2) ? a.W[1][(int64_t)c * d2 + f] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < R3; ++r) { const int j = fs_feat(r, h); b3[r] = j < d3 ? a.b[1][j] : 0.f; }
+    }
+    if (G4) {
+#pragma unroll
+        for (int r = 0; r < R3; ++r) { const int f = fs_feat(r, h); w4[r] = (c < d4 && f < d3) ? a.W[2][(int64_t)c * d3 + f] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < R4; ++r) { const int j = fs_feat(r, h); b4[r] = j < d4 ? a.b[2][j] : 0.f; }
+    }
+    constexpr int RL = G4 ? R4 : (G3 ? R3 : R2);                      // registers of the last layer's output
+    const int dl = G4 ? d4 : (G3 ? d3 : d2);
+    float wo[RL];
+#pragma unroll
+    for (int r = 0; r < RL; ++r) { const int j = fs_feat(r, h); wo[r] = j < dl ? a.wo[j] : 0.f; }
+    const float bo = a.bo[0];
+
+    const int64_t u_lo = (int64_t)blockIdx.y * a.users_per_block;
+    const int64_t u_hi = u_lo + a.users_per_block < a.U ? u_lo + a.users_per_block : a.U;
+    const int64_t n_tiles = (a.N + 31) >> 5;
+    const int64_t tile_stride = (int64_t)gridDim.x * 4;
+    // every wave of the workgroup runs the same number of tile rounds (the Q chunk is staged behind workgroup barriers)
+    const int64_t rounds = (n_tiles + tile_stride - 1) / tile_stride;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t tile = ((int64_t)rd * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool live = tile < n_tiles;
+        const int64_t item = tile * 32 + c;
+        const bool iv = live && item < a.N;
+        // the tile's P rows: lane (item c, half h) keeps features h S1 .. h S1 + S1 - 1
+        float p[S1];
+        {
+            const float* pr = a.P + (iv ? item : 0) * a.ldp + h * S1;
+#pragma unroll
+            for (int s = 0; s < S1; s += 4) {
+                const int f = h * S1 + s;
+                if (iv && f + 3 < a.h1 && !(a.ldp & 3)) {
+                    const float4 v = ld4(pr + s);
+                    p[s] = v.x; p[s + 1] = v.y; p[s + 2] = v.z; p[s + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p[s + q] = (iv && f + q < a.h1) ? pr[s + q] : 0.f;
+                }
+            }
+        }
+        for (int64_t u0 = u_lo; u0 < u_hi; u0 += kFsUsers) {
+            const int nu = (int)(u_hi - u0 < kFsUsers ? u_hi - u0 : kFsUsers);
+            __syncthreads();                                       // the previous chunk has been consumed by every wave
+            for (int e = threadIdx.x; e < nu * 2 * S1; e += kFsBlock) {
+                const int uu = e / (2 * S1), f = e - uu * 2 * S1;
+                Ql[e] = f < a.h1 ? a.Q[(u0 + uu) * a.ldq + f] : 0.f;
+            }
+            __syncthreads();
+            if (!live) continue;
+            for (int uu = 0; uu < nu; ++uu) {
+                const float* q = Ql + uu * 2 * S1 + h * S1;
+                f32x16 acc = fs_zero();
+#pragma unroll
+                for (int s = 0; s < S1; s += 4) {
+                    const float4 qv = *reinterpret_cast<const float4*>(q + s);
+                    FS_MFMA(acc, w2[s], fmaxf(p[s] + qv.x, 0.f));
+                    FS_MFMA(acc, w2[s + 1], fmaxf(p[s + 1] + qv.y, 0.f));
+                    FS_MFMA(acc, w2[s + 2], fmaxf(p[s + 2] + qv.z, 0.f));
+                    FS_MFMA(acc, w2[s + 3], fmaxf(p[s + 3] + qv.w, 0.f));
+                }
+                if (G3) {
+                    f32x16 a3 = fs_zero();
+#pragma unroll
+                    for (int r = 0; r < R2; ++r) FS_MFMA(a3, w3[r], fmaxf(acc[r] + b2[r], 0.f));
+                    if (G4) {
+                        f32x16 a4 = fs_zero();
+#pragma unroll
+                        for (int r = 0; r < R3; ++r) FS_MFMA(a4, w4[r], fmaxf(a3[r] + b3[r], 0.f));
+#pragma unroll
+                        for (int r = 0; r < R4; ++r) acc[r] = fmaxf(a4[r] + b4[r], 0.f);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R3; ++r) acc[r] = fmaxf(a3[r] + b3[r], 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R2; ++r) acc[r] = fmaxf(acc[r] + b2[r], 0.f);
+                }
+                // output unit: this half's features in register order, then the other half's partial (lane ^ 32)
+                float z = 0.f;
+#pragma unroll
+                for (int r = 0; r < RL; ++r) z += wo[r] * acc[r];
+                z += __shfl_xor(z, 32, 64);
+                if (h == 0 && iv) a.out[(u0 + uu) * a.ldo + item] = 1.0f / (1.0f + expf(-(z + bo)));
+            }
+        }
+    }
+}
+
+template <int S1, int G2, int G3, int G4>
+int fs_launch(const fs_args& a, hipStream_t s) {
+    const int64_t n_tiles = (a.N + 31) >> 5;
+    // user chunks per block: enough workgroups to cover the chip's 1,024 SIMDs about twice when the problem allows it
+    fs_args b = a;
+    int64_t gx = (n_tiles + 3) / 4;
+    int64_t chunks = (a.U + kFsUsers - 1) / kFsUsers;
+    int64_t gy = 1;
+    while (gx * gy < 2 * CDR_NUM_CU && gy < chunks) gy *= 2;
+    if (gy > chunks) gy = chunks;
+    int64_t per = (chunks + gy - 1) / gy;
+    gy = (chunks + per - 1) / per;
+    b.users_per_block = (int)(per * kFsUsers);
+    if (gx > 8 * CDR_NUM_CU) gx = 8 * CDR_NUM_CU;            // waves walk the remaining tiles (their weights stay loaded)
+    conet_fullsort_kernel<S1, G2, G3, G4><<<dim3((unsigned)gx, (unsigned)gy), dim3(kFsBlock), 0, s>>>(b);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cdr_conet_fullsort_supported(int h1, int n_tail, const int* tail_dims) {
+    if (h1 < 1 || h1 > 64 || n_tail < 1 || n_tail > 3 || !tail_dims) return 0;
+    for (int t = 0; t < n_tail; ++t)
+        if (tail_dims[t] < 1 || tail_dims[t] > 32) return 0;
+    return 1;
+}
+
+extern "C" int cdr_conet_fullsort(void* stream, const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t U, int64_t N, int h1,
+                                  int n_tail, const int* tail_dims, const float* const* W, const float* const* b, const float* wo,
+                                  const float* bo, float* out, int64_t ldo) {
+    CDR_CHECK_ARG(P && Q && out && W && b && wo && bo && tail_dims && U > 0 && N > 0 && ldp >= h1 && ldq >= h1 && ldo >= N);
+    if (!cdr_conet_fullsort_supported(h1, n_tail, tail_dims)) {
+        cdr_set_error("cdr_conet_fullsort: tower [%d -> %d layers] outside the kernel's range (first width <= 64, 1..3 further layers of width <= 32)",
+                      h1, n_tail);
+        return CDR_EINVAL;
+    }
+    fs_args a{};
+    a.P = P; a.ldp = ldp; a.Q = Q; a.ldq = ldq; a.U = U; a.N = N; a.h1 = h1; a.n_tail = n_tail; a.wo = wo; a.bo = bo; a.out = out; a.ldo = ldo;
+    for (int t = 0; t < n_tail; ++t) {
+        CDR_CHECK_ARG(W[t] && b[t]);
+        a.d[t] = tail_dims[t]; a.W[t] = W[t]; a.b[t] = b[t];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int g2 = (a.d[0] + 7) / 8, g3 = n_tail > 1 ? (a.d[1] + 7) / 8 : 0, g4 = n_tail > 2 ? (a.d[2] + 7) / 8 : 0;
+    const bool small1 = h1 <= 32;
+    // the reference's default tower [.., 64, 32, 16, 8] (properties/model/CoNet.yaml) gets its exact instantiation; anything else within
+    // range runs zero-padded on the next larger one
+    if (!small1 && n_tail == 3 && g2 <= 4 && g3 <= 2 && g4 <= 1) fs_launch<32, 4, 2, 1>(a, s);
+    else if (n_tail == 3) small1 ? fs_launch<16, 4, 4, 4>(a, s) : fs_launch<32, 4, 4, 4>(a, s);
+    else if (n_tail == 2) small1 ? fs_launch<16, 4, 4, 0>(a, s) : fs_launch<32, 4, 4, 0>(a, s);
+    else small1 ? fs_launch<16, 4, 0, 0>(a, s) : fs_launch<32, 4, 0, 0>(a, s);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}

@@ -257,8 +257,11 @@ struct adam_multi_args {
 // (Tried in round 3: no separate launch for the bump -- every block signs in on the upper half of tensor 0's counter word with one
 //  atomicAdd and the last one writes the counters.  Same-address atomics serialise: +6 us on C1's 650 blocks, +55 us on C4's 10 k,
 //  against the 4.7 us launch it removed; numbers in profiles/r03_ab_adam_signin.txt.)
-__global__ void inc_multi_kernel(adam_multi_args a) {
+// The same one-workgroup launch keeps the epoch's loss total when asked to (loss_sum[0] += loss[0]: the trainer's per-step
+// `total_loss += loss.item()` of recbole Trainer._train_epoch, without the host sync and without a launch of its own).
+__global__ void inc_multi_kernel(adam_multi_args a, const float* __restrict__ loss, float* __restrict__ loss_sum) {
     if (blockIdx.x == 0 && (int)threadIdx.x < a.count) a.step[threadIdx.x][0] += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 63 && loss_sum) loss_sum[0] += loss[0];
 }
 
 __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args a, float lr, float b1, float b2, float eps, float wd) {
@@ -330,8 +333,9 @@ extern "C" int cdr_adam_dense_dev(void* stream, float* param, const float* grad,
 
 extern "C" int cdr_adam_multi_dev(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev, float lr, float beta1,
-                                  float beta2, float eps, float weight_decay) {
+                                  float beta2, float eps, float weight_decay, const float* loss, float* loss_sum) {
     CDR_CHECK_ARG(count > 0 && params && grads && exp_avg && exp_avg_sq && numel && step_dev);
+    CDR_CHECK_ARG((loss == nullptr) == (loss_sum == nullptr));
     hipStream_t s = (hipStream_t)stream;
     for (int base = 0; base < count; base += kAdamMulti) {
         adam_multi_args a{};
@@ -345,7 +349,7 @@ extern "C" int cdr_adam_multi_dev(void* stream, int count, float* const* params,
             blocks += grid_cap((numel[j] + kBlock * 4 - 1) / (kBlock * 4));      // ~4 elements per thread, capped per tensor
         }
         a.blk_start[a.count] = blocks;
-        inc_multi_kernel<<<dim3(1), dim3(64), 0, s>>>(a);
+        inc_multi_kernel<<<dim3(1), dim3(64), 0, s>>>(a, base == 0 ? loss : nullptr, base == 0 ? loss_sum : nullptr);
         CDR_LAUNCH_CHECK();
         adam_multi_dev_kernel<<<dim3(blocks), dim3(kBlock), 0, s>>>(a, lr, beta1, beta2, eps, weight_decay);
         CDR_LAUNCH_CHECK();

@@ -32,6 +32,7 @@ class DomainTrainLoader:
         self.step = max(train_batch_size // self.times, 1)
         self.shuffle, self.generator = shuffle, generator
         self.pr = 0
+        self._pinned = False
 
     @property
     def pr_end(self):
@@ -40,11 +41,22 @@ class DomainTrainLoader:
     def __len__(self):
         return (self.pr_end + self.step - 1) // self.step
 
+    def pin(self):
+        """Keep the interaction columns at fixed addresses from now on (an epoch shuffle then permutes them IN PLACE): what a
+        captured batch producer (data/producer.py) reads must not move between hipGraph replays."""
+        if not self._pinned:
+            self.inter = Interaction({k: v.contiguous().clone() for k, v in self.inter.items()})     # (own copies: the caller's tensors stay as they are)
+            self._pinned = True
+
     def __iter__(self):
         if self.shuffle:
             n = len(self.inter)
             perm = _randperm(n, next(iter(self.inter.values())).device, self.generator)
-            self.inter = self.inter.index_select(perm)
+            if self._pinned:
+                for v in self.inter.values():
+                    v.copy_(v[perm])                 # the same permutation of the same order as index_select below, landed in place
+            else:
+                self.inter = self.inter.index_select(perm)
         return self
 
     def __next__(self):
@@ -81,6 +93,13 @@ class OverlapDataloader:
         self.ids = torch.arange(num_overlap, device=device, dtype=torch.int64)     # PAD 0 included (dataset.py:694)
         self.step, self.field, self.shuffle, self.generator = overlap_batch_size, field, shuffle, generator
         self.pr = 0
+        self._pinned = False
+
+    def pin(self):
+        """Fixed address for the id list (shuffled in place from now on): see DomainTrainLoader.pin."""
+        if not self._pinned:
+            self.ids = self.ids.contiguous().clone()
+            self._pinned = True
 
     @property
     def pr_end(self):
@@ -91,7 +110,11 @@ class OverlapDataloader:
 
     def __iter__(self):
         if self.shuffle:
-            self.ids = self.ids[_randperm(self.ids.numel(), self.ids.device, self.generator)]
+            perm = _randperm(self.ids.numel(), self.ids.device, self.generator)
+            if self._pinned:
+                self.ids.copy_(self.ids[perm])
+            else:
+                self.ids = self.ids[perm]
         return self
 
     def __next__(self):
@@ -108,6 +131,26 @@ class CrossDomainDataloader:
         self.source_dataloader, self.target_dataloader = source_dataloader, target_dataloader
         self.overlap_dataloader = overlap_dataloader
         self.state = CrossDomainDataLoaderState.BOTH
+
+    def device_producer(self):
+        """The current state's batches as ONE capturable launch per loader into fixed buffers (data/producer.py), or None when a
+        loader of this state keeps its data on the host or samples with something other than ``sampler.DeviceNegSampler``."""
+        from .producer import DeviceBatchProducer, CompositeProducer
+        S = CrossDomainDataLoaderState
+        loaders = {S.SOURCE: [self.source_dataloader], S.TARGET: [self.target_dataloader],
+                   S.BOTH: [self.target_dataloader, self.source_dataloader], S.OVERLAP: [self.overlap_dataloader]}[self.state]
+        cache = self.__dict__.setdefault('_producers', {})
+        parts = []
+        for dl in loaders:
+            if id(dl) not in cache:
+                cache[id(dl)] = DeviceBatchProducer(dl) if DeviceBatchProducer.supports(dl) else None
+            if cache[id(dl)] is None:
+                return None
+            parts.append(cache[id(dl)])
+        key = ('state', self.state)
+        if key not in cache:
+            cache[key] = CompositeProducer(parts)
+        return cache[key]
 
     def check_samplers(self):
         """One host sync per sampler at the START and at the END of an epoch, in every mode (never in the middle of one): did the

@@ -820,6 +820,34 @@ def conet_supported(dims):
     return B_.load().cdr_conet_plan(len(dims) - 1, arr, 1024, ctypes.byref(aw), ctypes.byref(need)) == 0
 
 
+def conet_fullsort_supported(h1, tail_dims):
+    """True when csrc/cdr_conet_fullsort.hip takes a target tower of these widths behind the separable first layer."""
+    arr = (ctypes.c_int * max(len(tail_dims), 1))(*[int(d) for d in tail_dims])
+    return len(tail_dims) >= 1 and B_.load().cdr_conet_fullsort_supported(int(h1), len(tail_dims), arr) == 1
+
+
+@torch.no_grad()
+def conet_fullsort(P, Q, weights, biases, wo, bo, out=None):
+    """[U, N] scores of CoNet.full_sort_predict (conet.py:222-242) from the two halves of the separable first layer -- P [N, h1]
+    (items), Q [U, h1] (users + bias) -- the remaining layers ``weights[t]`` [d_t, d_in] / ``biases[t]`` and the output unit
+    ``wo`` [d_last] / ``bo`` [1]: one launch, no intermediate in memory (csrc/cdr_conet_fullsort.hip)."""
+    _dev_check(P, Q, wo, bo, *weights, *biases)
+    U, N, h1 = Q.shape[0], P.shape[0], P.shape[1]
+    assert Q.shape[1] == h1 and P.stride(1) == 1 and Q.stride(1) == 1
+    T = len(weights)
+    ws = [w.contiguous() for w in weights]
+    bs = [b.contiguous() for b in biases]
+    wo_, bo_ = wo.reshape(-1).contiguous(), bo.reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty(U, N, device=P.device, dtype=torch.float32)
+    dims = (ctypes.c_int * T)(*[int(w.shape[0]) for w in ws])
+    B_._alive.extend(ws + bs + [P, Q])
+    B_.call('cdr_conet_fullsort', B_.stream(), B_._c_ptr(P.data_ptr()), P.stride(0), B_._c_ptr(Q.data_ptr()), Q.stride(0), U, N, h1, T, dims,
+            (ctypes.c_void_p * T)(*[w.data_ptr() for w in ws]), (ctypes.c_void_p * T)(*[b.data_ptr() for b in bs]), B_.f32(wo_), B_.f32(bo_),
+            B_.f32(out), out.stride(0))
+    return out
+
+
 class ConetFusedLoss(Function):
     """CoNet.calculate_loss (conet.py:183-203) as ONE autograd node on the fused tower kernels: forward = gather + every
     cross unit of both towers + output units + BCE x2 + sum ||H_l||_F in one launch (+ a finishing block); backward = data

@@ -3,32 +3,63 @@
 On small, L2-resident configurations (BASELINE C1-C4) the reference's step is hundreds of tiny launches; ours is fewer
 but still launch/host bound from Python.  Every native call enqueues on torch's current stream and allocates through
 torch's caching allocator, so the whole step can be captured once into a hipGraph and replayed: the host then pays one
-graph launch per step instead of one ctypes call + one allocation per kernel.  Batch tensors are static buffers that
-``step`` copies the new ids / labels into (same shapes every step; a ragged last batch runs eagerly).
+graph launch per step instead of one ctypes call + one allocation per kernel.
+
+Where the batch comes from:
+  * ``producer`` (data/producer.py): the batch is produced by a launch INSIDE the captured step into the producer's own fixed
+    tensors (device cursor, device-side negative sampling) -- ``replay()`` is the whole step, nothing is copied;
+  * otherwise the batch tensors are static buffers that ``step`` copies the new ids / labels into (same shapes every step; a ragged
+    last batch runs eagerly).
+``loss_sum`` (a device scalar): every step -- replayed or eager -- adds its loss to it, inside the graph for replays, so an epoch's
+loss total costs no extra launch and no host sync per step (``CrossDomainTrainer`` reads it once per epoch).
 """
 import torch
 
+from .data.interaction import Interaction
+
+
+def step_and_sum(optimizer, loss, loss_sum):
+    """``optimizer.step()`` + ``loss_sum += loss``.  trainer.DenseAdam does the addition inside its own counter launch (``loss_pair``);
+    with any other optimizer -- or when no parameter had a gradient -- it is one elementwise launch here."""
+    fold = loss_sum is not None and hasattr(optimizer, 'loss_pair') and loss.dtype == torch.float32 and loss.dim() == 0 and loss.is_contiguous()
+    if fold:
+        optimizer.loss_pair = (loss, loss_sum)
+    optimizer.step()
+    if loss_sum is not None and (not fold or optimizer.loss_pair is not None):
+        if fold:
+            optimizer.loss_pair = None
+        loss_sum.add_(loss)
+
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, example_interaction, warmup=3, restore_after_warmup=True):
+    def __init__(self, model, optimizer, example_interaction=None, warmup=3, restore_after_warmup=True, producer=None, loss_sum=None):
         """``restore_after_warmup``: the warm-up runs REAL steps on ``example_interaction`` (every lazily created buffer, native context
         and optimizer state must exist before the capture); with True the parameters and the optimizer state are put back afterwards,
         so swapping the eager loop for the graphed one does not add ``warmup`` extra updates on batch 0."""
         self.model, self.optimizer = model, optimizer
         self.restore_after_warmup = restore_after_warmup
-        # the batch fields live side by side in ONE byte buffer (16-B aligned views): a producer that hands over a batch already
-        # packed this way (``pack``) costs one device copy per step instead of one per field (6-7 for a two-domain pointwise batch:
-        # 30-40 us, a sixth of the C3 step)
-        self._layout, off = {}, 0
-        for k, v in example_interaction.items():
-            nb = v.numel() * v.element_size()
-            self._layout[k] = (off, nb, v.dtype, tuple(v.shape))
-            off += (nb + 15) // 16 * 16
-        dev = next(iter(example_interaction.values())).device
-        self.flat = torch.empty(max(off, 16), device=dev, dtype=torch.uint8)
-        self.static = {k: self.flat[o:o + nb].view(dt).view(shape) for k, (o, nb, dt, shape) in self._layout.items()}
-        for k, v in example_interaction.items():
-            self.static[k].copy_(v)
+        self.producer, self.loss_sum = producer, loss_sum
+        if producer is not None:
+            self.static = producer.fields
+            self.flat, self._layout = None, None
+            dev = next(iter(self.static.values())).device
+        else:
+            # the batch fields live side by side in ONE byte buffer (16-B aligned views): a caller that hands over a batch already
+            # packed this way (``pack``) costs one device copy per step instead of one per field
+            self._layout, off = {}, 0
+            for k, v in example_interaction.items():
+                nb = v.numel() * v.element_size()
+                self._layout[k] = (off, nb, v.dtype, tuple(v.shape))
+                off += (nb + 15) // 16 * 16
+            dev = next(iter(example_interaction.values())).device
+            self.flat = torch.empty(max(off, 16), device=dev, dtype=torch.uint8)
+            self.static = Interaction()
+            for k, (o, nb, dt, shape) in self._layout.items():
+                self.static[k] = self.flat[o:o + nb].view(dt).view(shape)
+            if getattr(example_interaction, 'k_major', None) is not None:
+                self.static.k_major = example_interaction.k_major          # the layout hint is part of what the capture was made for
+            for k, v in example_interaction.items():
+                self.static[k].copy_(v)
         self.graph = None
         self.loss = None
         self._one = torch.ones((), device=dev, dtype=torch.float32)       # d loss / d loss, made once: backward() would fill one per step
@@ -44,8 +75,15 @@ class GraphedTrainStep:
         if loss.dim():
             loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()   # (a [1]-shaped loss: a view, not a reduction launch)
         loss.backward(self._one if loss.dtype == torch.float32 else None)
-        self.optimizer.step()
-        return loss.detach()
+        loss = loss.detach()
+        step_and_sum(self.optimizer, loss, self.loss_sum)
+        return loss
+
+    def _whole(self):
+        """What the graph holds: (produce the batch) -> step -> (add the loss to the epoch's total)."""
+        if self.producer is not None:
+            self.producer.launch()
+        return self._eager(self.static)
 
     def _capture(self, warmup):
         # populate .grad and the optimizer state (and every lazily created native context) before capture
@@ -54,7 +92,7 @@ class GraphedTrainStep:
         snap = self._snapshot() if self.restore_after_warmup else None
         with torch.cuda.stream(side):
             for i in range(max(warmup, 1)):
-                self._eager(self.static)
+                self._whole()
                 if i == 0 and snap is not None:
                     snap = self._snapshot(snap)           # optimizer state created by the first step: remembered as zeros
         torch.cuda.current_stream().wait_stream(side)
@@ -65,7 +103,7 @@ class GraphedTrainStep:
         # capture on the stream that ran the warm-up: the native contexts are per (device, stream) and creating one
         # allocates, which is not allowed while a stream is capturing
         with torch.cuda.graph(self.graph, stream=side):
-            self.loss = self._eager(self.static)
+            self.loss = self._whole()
 
     # ---- warm-up without side effects: in-place snapshot / restore (addresses must not change: the capture follows) -------------
     def _state_tensors(self):
@@ -78,6 +116,12 @@ class GraphedTrainStep:
         ds = getattr(self.model, '_drop_state', None)
         if ds is not None:
             ts.append(ds)
+        if hasattr(self.model, 'graph_state_tensors'):
+            ts += list(self.model.graph_state_tensors())     # device-side counters a model's loss advances (e.g. an in-loss sampler's)
+        if self.producer is not None:
+            ts += self.producer.state_tensors()
+        if self.loss_sum is not None:
+            ts.append(self.loss_sum)
         return ts
 
     def _snapshot(self, prev=None):
@@ -104,20 +148,25 @@ class GraphedTrainStep:
             out[o:o + nb].view(dt).view(shape).copy_(interaction[k])
         return out
 
-    def step(self, interaction):
-        if torch.is_tensor(interaction):                      # a batch packed by ``pack``
-            assert interaction.dtype == torch.uint8 and interaction.numel() == self.flat.numel(), 'not a batch packed for this step'
-            self.flat.copy_(interaction)
-            self.graph.replay()
-            if hasattr(self.optimizer, 'on_replay'):
-                self.optimizer.on_replay()
-            return self.loss
-        same = all(k in interaction and interaction[k].shape == v.shape for k, v in self.static.items())
-        if not same:
-            return self._eager(interaction)
-        keys = list(self.static)
-        torch._foreach_copy_([self.static[k] for k in keys], [interaction[k] for k in keys])      # one launch per dtype, not one per field
+    def replay(self):
+        """One captured step (with a producer: on the NEXT batch of the loader).  The caller keeps the loader's position in step
+        (``producer.advance()``)."""
         self.graph.replay()
         if hasattr(self.optimizer, 'on_replay'):
             self.optimizer.on_replay()            # host-side bookkeeping of optimizers whose update count lives on the device
         return self.loss
+
+    def matches(self, interaction):
+        return all(k in interaction and interaction[k].shape == v.shape and interaction[k].dtype == v.dtype for k, v in self.static.items()) \
+            and getattr(interaction, 'k_major', None) == getattr(self.static, 'k_major', None)
+
+    def step(self, interaction):
+        if torch.is_tensor(interaction):                      # a batch packed by ``pack``
+            assert interaction.dtype == torch.uint8 and interaction.numel() == self.flat.numel(), 'not a batch packed for this step'
+            self.flat.copy_(interaction)
+            return self.replay()
+        if self.producer is not None or not self.matches(interaction):
+            return self._eager(interaction)                   # a batch of another shape (ragged tail), or one the loader itself served
+        keys = list(self.static)
+        torch._foreach_copy_([self.static[k] for k in keys], [interaction[k] for k in keys])      # one launch per dtype, not one per field
+        return self.replay()

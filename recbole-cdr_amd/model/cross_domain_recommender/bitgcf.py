@@ -110,6 +110,9 @@ class BiTGCF(CrossDomainRecommender):
             st.fill_(int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item()))
         return float(self.drop_rate), st
 
+    def graph_key(self):
+        return ('BiTGCF',)          # (the dropout seed is a device value the captured step advances itself: _dropout_args)
+
     def calculate_loss(self, interaction):
         self.init_restore_e()
         # the loss reads the batch's user and item rows of the two stacks and nothing else (the transfer couples a row of one domain

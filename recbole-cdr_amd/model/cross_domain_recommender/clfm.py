@@ -86,6 +86,9 @@ class CLFM(CrossDomainRecommender):
             cache[key] = torch.arange(n, device=dev, dtype=torch.int64)
         return cache[key]
 
+    def graph_key(self):
+        return ('CLFM',)
+
     def calculate_loss(self, interaction):
         su, si, sl = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.SOURCE_LABEL]
         tu, ti, tl = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], interaction[self.TARGET_LABEL]

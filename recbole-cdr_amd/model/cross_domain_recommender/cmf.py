@@ -35,6 +35,9 @@ class CMF(CrossDomainRecommender):
             _, p = self._loss_and_prob(user, item, zeros, 0.0)
         return p
 
+    def graph_key(self):
+        return ('CMF',)
+
     def calculate_loss(self, interaction):
         # both domains' batches on the shared tables as ONE autograd node (two loss launches forward, two scatter launches into one pair
         # of gradient buffers backward)

@@ -103,6 +103,9 @@ class CoNet(CrossDomainRecommender):
         so, to = self.source_outputunit[0], self.target_outputunit[0]
         return ps + [so.weight, so.bias, to.weight, to.bias]
 
+    def graph_key(self):
+        return ('CoNet', self.fused_towers, self.row_opt is not None)
+
     def calculate_loss(self, interaction):
         # source_forward(source batch) and target_forward(target batch) both run BOTH towers (conet.py:186-187); every
         # op is row-independent, so the two batches go through the cross units as ONE stack of rows and each output unit
@@ -165,6 +168,13 @@ class CoNet(CrossDomainRecommender):
         W1 = lin1.weight                                              # [h1, 2D]
         P = F_.gemm(items, W1[:, D:], trans_b=True)                    # [N, h1]
         Q = F_.gemm(user_e, W1[:, :D], trans_b=True, bias=lin1.bias)    # [U, h1]
+        tail = list(self.target_crossunit_linear)[1:]
+        if (self.__dict__.get('fullsort_fused', True) and tail
+                and F_.conet_fullsort_supported(W1.shape[0], [l.weight.shape[0] for l in tail])):
+            # every (user, item) pair through layers 2.. and the output unit in ONE launch, activations in registers
+            # (csrc/cdr_conet_fullsort.hip) -- no per-user loop, no [N, h] intermediates
+            lo = self.target_outputunit[0]
+            return F_.conet_fullsort(P, Q, [l.weight for l in tail], [l.bias for l in tail], lo.weight, lo.bias)
         rows = []
         for u in range(user_e.shape[0]):
             h = F_.bcast_add_act(P, Q[u], B_.ACT_RELU)

@@ -148,6 +148,11 @@ class DCDCSR(CrossDomainRecommender):
             return self.affine_embedding, self.target_item_embedding.weight, 'TARGET'
         return self.target_user_embedding.weight, self.affine_embedding, 'TARGET'
 
+    def graph_key(self):
+        # BOTH: the map loss draws its rows with numpy on the host (:175 of the reference) -- not capturable.  The other phases read
+        # tables that depend on how often the phase has been visited (affine_embedding is rebuilt on the second TARGET visit).
+        return None if self.phase == 'BOTH' else ('DCDCSR', self.phase, self.phase2count.get(self.phase, 0))
+
     def calculate_loss(self, interaction):
         count = self.phase2count.get(self.phase, 0)
         if self.phase == 'BOTH':

@@ -67,6 +67,9 @@ class DeepAPF(CrossDomainRecommender):
     def predict(self, interaction):
         return self.target_forward(interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID])
 
+    def graph_key(self):
+        return ('DeepAPF',)
+
     def calculate_loss(self, interaction):
         p_source = self.source_forward(interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID])
         p_target = self.target_forward(interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID])

@@ -114,6 +114,9 @@ class DTCDR(CrossDomainRecommender):
             seed = self._drop_seed()
         return F_.linear(mlp(x, seed, 0 if domain == 'source' else 64), head.weight, head.bias, B_.ACT_SIGMOID).squeeze(-1)
 
+    def graph_key(self):
+        return ('DTCDR',)           # (dropout: a device-side seed the captured step advances itself, _dropout_args)
+
     def calculate_loss(self, interaction):
         seed = self._drop_seed()
         ps = self.neumf_forward(interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], 'source', seed)

@@ -65,6 +65,9 @@ class EMCDR(CrossDomainRecommender):
     def set_phase(self, phase):
         self.phase = phase
 
+    def graph_key(self):
+        return None if self._dist_group() is not None else ('EMCDR', self.phase)
+
     # ---- mapping function on the fp32 MFMA kernel --------------------------------------------------------------
     def mapping_layers(self):
         """[(weight, bias or None, activation after the layer)] of the mapping function (emcdr.py:59-64,86-93)."""

@@ -98,6 +98,9 @@ class NATR(CrossDomainRecommender):
             reg_loss = n if reg_loss is None else reg_loss + n
         return rec_loss + self.reg_weight * reg_loss
 
+    def graph_key(self):
+        return ('NATR', self.phase)
+
     def calculate_loss(self, interaction):
         if self.phase == 'SOURCE':
             return self.calculate_phase1_loss(interaction)

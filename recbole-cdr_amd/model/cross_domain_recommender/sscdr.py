@@ -185,6 +185,16 @@ class SSCDR(CrossDomainRecommender):
                                             self.margin)
         return loss_s + self.lamda * loss_u
 
+    def graph_key(self):
+        # OVERLAP with the reference's numpy sampler: host draws inside the loss -- not capturable; the device sampler is
+        if self.phase == 'OVERLAP' and not self.device_sampler:
+            return None
+        return ('SSCDR', self.phase, self.device_sampler and self.fused_map)
+
+    def graph_state_tensors(self):
+        """Device-side call counters of the in-loss sampler (a captured step's warm-up must put them back)."""
+        return [v[3] for v in self.__dict__.get('_dev_lists', {}).values()]
+
     def calculate_loss(self, interaction):
         if self.phase == 'SOURCE':
             return self.calculate_source_loss(interaction)

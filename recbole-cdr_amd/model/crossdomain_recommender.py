@@ -56,6 +56,13 @@ class CrossDomainRecommender(nn.Module):
     def set_phase(self, phase):
         pass
 
+    def graph_key(self):
+        """Hashable tag of what ``calculate_loss`` would enqueue right now, or None when the step must not be captured in a hipGraph
+        (``Trainer`` replays one captured step per batch shape and key: graph_step.GraphedTrainStep).  A model answers with a key
+        only when its loss does ALL per-step work on the device -- a host draw, a host counter or a tensor rebuilt per phase visit
+        would be frozen into the capture.  Default: not capturable (the eager loop)."""
+        return None
+
     def calculate_loss(self, interaction):
         raise NotImplementedError
 

@@ -63,6 +63,11 @@ class DeviceNegSampler:
 
     __call__ = sample_by_user_ids
 
+    def graph_seed(self):
+        """Base seed of the draws made inside a captured batch producer (data/producer.py): the kernel adds its own device-side draw
+        count, so hipGraph replays never repeat a draw; a different stream of numbers from ``sample_by_user_ids``' host-counted one."""
+        return (self.seed * 0x9E3779B1 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+
     def check_failures(self):
         """After 64 rejected draws the kernels stop drawing and pick a free candidate directly (uniform sampler: a uniform draw over
         the user's FREE candidates, which is what the reference's redraw loop converges to; popularity sampler: the first unused key

@@ -18,6 +18,9 @@ class DenseAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # (loss, loss_sum) device scalars handed over by the training loop before ``step()``: the launch that bumps the step counters
+        # also adds this step's loss to the epoch's total (no launch of its own).  ``step`` sets it back to None once it has done so.
+        self.loss_pair = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -41,9 +44,10 @@ class DenseAdam(torch.optim.Optimizer):
                 continue
             n = len(ps)
             arr = lambda xs: (ctypes.c_void_p * n)(*[x.value if hasattr(x, 'value') else x for x in xs])
+            lp, self.loss_pair = self.loss_pair, None
             B_.call('cdr_adam_multi_dev', B_.stream(), n, arr(ps), arr(gs), arr(ms), arr(vs), (ctypes.c_int64 * n)(*ns), arr(ss),
                     float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
-                    float(group['weight_decay']))
+                    float(group['weight_decay']), None if lp is None else B_.f32(lp[0]), None if lp is None else B_.f32(lp[1]))
 
 
 def _dense_adam_load(self, state_dict):
@@ -133,10 +137,30 @@ class Trainer:
         self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
         self.best_valid_result = None
         self.train_loss_dict = dict()
-        self.optimizer = DenseAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
         # 'dense'   : the reference's literal loop -- autograd into table-sized gradients + Adam over every parameter
         # 'rowwise' : the model's O(batch) fused step (tables too large for dense gradients, e.g. BASELINE config C5)
         self.optimizer_mode = config['optimizer_mode'] if 'optimizer_mode' in config else 'dense'
+        on_gpu = torch.device(self.device).type == 'cuda'
+        # The reference's Adam over every parameter.  A model that offers ``enable_deferred_adam`` (CoNet on its fused tower kernels)
+        # gets the SAME optimizer with its embedding tables evaluated lazily per row -- bit-identical to the dense sweep
+        # (lazyadam.py), O(batch) instead of O(table) traffic per step.  config['deferred_adam'] = False keeps the literal sweep;
+        # gradient clipping needs the whole gradient, so it does too.
+        deferred = (config['deferred_adam'] if 'deferred_adam' in config else True) and self.optimizer_mode == 'dense' and on_gpu \
+            and not self.clip_grad_norm and hasattr(self.model, 'enable_deferred_adam') and getattr(self.model, 'fused_towers', True) \
+            and all(p.is_cuda for p in self.model.parameters())
+        if deferred:
+            self.optimizer = RowAwareAdam(self.model, lr=self.learning_rate, weight_decay=self.weight_decay)
+        else:
+            self.optimizer = DenseAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        # Dense mode on a GPU: each (phase, batch shape) is captured ONCE as a hipGraph -- batch production by the device loader,
+        # calculate_loss, backward, optimizer -- and an epoch is a run of replays (graph_step.GraphedTrainStep); ragged tails and
+        # models whose loss needs the host (``model.graph_key()`` is None) take the eager loop below.  config['graph_step'] = False
+        # switches it off.
+        self.graph_step = bool(config['graph_step'] if 'graph_step' in config else True) and on_gpu and self.optimizer_mode == 'dense' \
+            and not self.clip_grad_norm
+        self._graphs = {}
+        self._loss_sum = None
+        self.graph_stats = {'replayed': 0, 'eager': 0, 'captures': 0}
         # evaluation through the model's fused mask + top-k kernel when it has one (False: full score matrix + torch.topk)
         self.fused_topk = config['fused_topk'] if 'fused_topk' in config else True
         # config['dist_group'] (a torch.distributed group, or True for WORLD) with optimizer_mode='rowwise': the model's tables are
@@ -162,8 +186,88 @@ class Trainer:
                           'best_valid_score updates and callback_fn (evaluation needs every rank); later phases evaluate as usual',
                           stacklevel=2)
 
+    # ---- dense mode, one hipGraph replay per step --------------------------------------------------------------------------------
+    def _graph_for(self, key, example=None, producer=None):
+        """The captured step for ``key`` (built on first use; False once a capture has failed: that key stays eager)."""
+        gs = self._graphs.get(key)
+        if gs is None:
+            from ..graph_step import GraphedTrainStep
+            try:
+                gs = GraphedTrainStep(self.model, self.optimizer, example, producer=producer, loss_sum=self._loss_sum)
+                self.graph_stats['captures'] += 1
+            except Exception as e:                                      # noqa: BLE001 -- reported, and the eager loop still trains
+                import warnings
+                warnings.warn(f'hipGraph capture of the training step failed for {key!r} ({type(e).__name__}: {e}); running it eagerly')
+                gs = False
+            self._graphs[key] = gs
+        return gs
+
+    def _eager_step(self, interaction):
+        self.optimizer.zero_grad(set_to_none=True)
+        losses = self.model.calculate_loss(interaction)
+        loss = sum(losses) if isinstance(losses, tuple) else losses
+        loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
+        loss.backward()
+        from ..graph_step import step_and_sum
+        step_and_sum(self.optimizer, loss.detach(), self._loss_sum)
+        self.graph_stats['eager'] += 1
+
+    def _train_epoch_graphed(self, train_data, mkey):
+        """recbole ``Trainer._train_epoch`` (zero_grad -> calculate_loss -> backward -> step per batch) with every full-shape batch
+        served by ONE hipGraph replay.  With a device loader (``train_data.device_producer()``) the replay also produces the batch
+        -- slice of the shuffled interactions, tiling, negative sampling -- so the host's part of a step is the replay call; the
+        loader's own ``__next__`` serves what a capture cannot (ragged tails, the BOTH-mode source wrap) and ends the epoch."""
+        if self._loss_sum is None:
+            self._loss_sum = torch.zeros((), device=self.device, dtype=torch.float32)
+        self._loss_sum.zero_()
+        state = getattr(train_data, 'state', None)
+        it = iter(train_data)                                  # (epoch shuffle; in place once a producer has pinned the columns)
+        prod = train_data.device_producer() if hasattr(train_data, 'device_producer') else None
+        if prod is not None:
+            prod.resync()
+            key = (mkey, state, 'device-loader')
+            while True:
+                gs = self._graphs.get(key)
+                if prod.full_ahead() and gs is not False:
+                    if gs is None:
+                        gs = self._graph_for(key, producer=prod)
+                        if gs is False:
+                            prod.resync()
+                            continue
+                    gs.replay()
+                    prod.advance()
+                    self.graph_stats['replayed'] += 1
+                    continue
+                try:
+                    interaction = next(it)
+                except StopIteration:
+                    break
+                self._eager_step(interaction)
+                prod.resync()
+        else:
+            for interaction in it:
+                interaction = interaction.to(self.device)
+                sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in interaction.items())
+                key = (mkey, state, sig, getattr(interaction, 'k_major', None))
+                gs = self._graphs.get(key)
+                if gs is None and not any(k[:2] == key[:2] for k in self._graphs):
+                    gs = self._graph_for(key, example=interaction)         # the first batch shape of this (model key, loader state)
+                if gs and gs.matches(interaction):
+                    gs.step(interaction)
+                    self.graph_stats['replayed'] += 1
+                else:
+                    self._eager_step(interaction)                          # ragged tail (another shape), or a failed capture
+        value = float(self._loss_sum)
+        if value != value:
+            raise ValueError('Training loss is nan')
+        return value
+
     def _train_epoch(self, train_data, epoch_idx):
         self.model.train()
+        if self.graph_step and self.optimizer_mode == 'dense' and self.dist_group is None:
+            mkey = self.model.graph_key() if hasattr(self.model, 'graph_key') else None
+            if mkey is not None:
+                return self._train_epoch_graphed(train_data, mkey)
         total = None                              # accumulated on device: no per-step host sync (SURVEY section 5)
         for interaction in train_data:
             interaction = interaction.to(self.device)
@@ -300,6 +404,7 @@ class Trainer:
         state = torch.load(path, map_location=self.device, weights_only=False)
         self.start_epoch = (state['epoch'] + 1) if state['epoch'] is not None else 0
         self.cur_step, self.best_valid_score = state['cur_step'], state['best_valid_score']
+        self._graphs.clear()                       # captured steps point at the optimizer state tensors about to be replaced
         self.model.load_state_dict(state['state_dict'])
         self.model.load_other_parameter(state.get('other_parameter'))
         if state.get('phase') is not None and hasattr(self.model, 'set_phase'):

@@ -1,0 +1,349 @@
+"""The product's trainer loop on the captured step: the device batch producer (csrc/cdr_sampler.hip
+batch_produce_kernel) against the loader it replaces, and ``CrossDomainTrainer.fit`` with one hipGraph replay per batch against the
+same steps run eagerly.  Reference: recbole_cdr/trainer/trainer.py:43-76, data/dataloader.py:25-186, crossdomain_sampler.py:139-175."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import DEV, FakeDataset, base_config, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(seed=0, n_s=700, n_t=500):
+    from oracle.common import IdSpace
+    ids = IdSpace(OU=40, TOU=30, SOU=35, OI=1, TOI=60, SOI=70)
+    rng = np.random.RandomState(seed)
+    src_u = np.array(list(range(1, ids.OU)) + list(range(ids.OU + ids.TOU, ids.total_num_users)))
+    src_i = np.arange(ids.OI + ids.TOI, ids.total_num_items)
+    tgt_u, tgt_i = np.arange(1, ids.OU + ids.TOU), np.arange(1, ids.OI + ids.TOI)
+    s_pairs = np.unique(np.stack([rng.choice(src_u, n_s), rng.choice(src_i, n_s)], 1), axis=0)
+    t_pairs = np.unique(np.stack([rng.choice(tgt_u, n_t), rng.choice(tgt_i, n_t)], 1), axis=0)
+    rng.shuffle(s_pairs); rng.shuffle(t_pairs)
+    ds = FakeDataset(ids, s_pairs, t_pairs)
+    return ids, ds, s_pairs, t_pairs
+
+
+def _loaders(ids, ds, s_pairs, t_pairs, input_type, batch, k, shuffle=False, ob=16, seed=5):
+    from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+    from recbole_cdr_amd.sampler import DeviceNegSampler
+    dt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    s_smp, t_smp = DeviceNegSampler(ds, 'source', s_pairs, DEV, seed=seed), DeviceNegSampler(ds, 'target', t_pairs, DEV, seed=seed + 1)
+    gen = lambda j: torch.Generator(device=DEV).manual_seed(1000 * seed + j) if shuffle else None
+    return CrossDomainDataloader(
+        DomainTrainLoader({'source_user_id': dt(s_pairs[:, 0]), 'source_item_id': dt(s_pairs[:, 1])}, 'source_user_id', 'source_item_id',
+                          'source_label', 'neg_', batch, k, input_type, s_smp, shuffle=shuffle, generator=gen(1)),
+        DomainTrainLoader({'target_user_id': dt(t_pairs[:, 0]), 'target_item_id': dt(t_pairs[:, 1])}, 'target_user_id', 'target_item_id',
+                          'target_label', 'neg_', batch, k, input_type, t_smp, shuffle=shuffle, generator=gen(2)),
+        OverlapDataloader(ids.OU, ob, device=DEV, shuffle=shuffle, generator=gen(3)))
+
+
+@pytest.mark.parametrize('pointwise,k', [(False, 1), (False, 3), (True, 1), (True, 4)])
+def test_batch_producer_layout_draws_and_cursor(pointwise, k):
+    """One launch = the loader's batch: rows [start, start + S) tiled in recbole's layout, negatives bit-equal to
+    cdr_neg_sample_uniform with the producer's seed rule, never an interacted item; the device cursor moves on by S per launch."""
+    from recbole_cdr_amd import binding as B_
+    from recbole_cdr_amd.data.producer import DeviceBatchProducer
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset()
+    it = InputType.POINTWISE if pointwise else InputType.PAIRWISE
+    batch = 64 * (1 + k if pointwise else k)
+    dl = _loaders(ids, ds, s_pairs, t_pairs, it, batch, k).source_dataloader
+    assert DeviceBatchProducer.supports(dl)
+    prod = DeviceBatchProducer(dl)
+    S = dl.step
+    assert S == 64
+    smp = dl.neg_sampler
+    used = set(map(tuple, s_pairs.tolist()))
+    for call in range(3):
+        prod.launch()
+        torch.cuda.synchronize()
+        start = call * S
+        u, i = s_pairs[start:start + S, 0], s_pairs[start:start + S, 1]
+        T = 1 + k if pointwise else k
+        got_u = prod.fields['source_user_id'].cpu().numpy()
+        assert (got_u == np.tile(u, T)).all()
+        users_d = torch.from_numpy(u.copy()).to(DEV)
+        want_neg = torch.empty(S * k, device=DEV, dtype=torch.int64)
+        seed = (smp.graph_seed() + call * 0x85EBCA77C2B2AE63) & 0xFFFFFFFFFFFFFFFF
+        lo0, hi0, lo1, hi1 = smp.ranges
+        B_.call('cdr_neg_sample_uniform', B_.stream(), B_.i64(users_d), S, k, lo0, hi0, lo1, hi1, B_.i64(smp.indptr), B_.i64(smp.indices),
+                seed, B_.i64(want_neg), B_.raw(smp.fail))
+        want_neg = want_neg.cpu().numpy()
+        items = prod.fields['source_item_id'].cpu().numpy()
+        if pointwise:
+            assert (items[:S] == i).all() and (items[S:] == want_neg).all()
+            lab = prod.fields['source_label'].cpu().numpy()
+            assert (lab[:S] == 1).all() and (lab[S:] == 0).all()
+            neg = items[S:]
+        else:
+            assert (items == np.tile(i, k)).all()
+            neg = prod.fields['neg_source_item_id'].cpu().numpy()
+            assert (neg == want_neg).all()
+            assert prod.fields.k_major == k
+        assert all((int(a), int(b)) not in used for a, b in zip(np.tile(u, k), neg))
+        assert ((neg >= ids.OI + ids.TOI) & (neg < ids.total_num_items)).all()          # source candidates (OI = 1: no overlapped items)
+        cur = prod.cursor.cpu().numpy()
+        assert cur[0] == (call + 1) * S and cur[1] == call + 1 and cur[2] == 0
+    assert int(smp.fail.item()) == 0
+
+
+def test_batch_producer_overlap_slices_and_graph_replay():
+    """k = 0: OverlapDataloader's [OB, 1] slices; captured once, every replay yields the next slice."""
+    from recbole_cdr_amd.data.producer import DeviceBatchProducer
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset()
+    ov = _loaders(ids, ds, s_pairs, t_pairs, InputType.PAIRWISE, 32, 1, ob=8).overlap_dataloader
+    prod = DeviceBatchProducer(ov)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        prod.launch()
+    torch.cuda.synchronize()
+    prod.resync()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        prod.launch()
+    prod.resync()
+    for b in range(ids.OU // 8):
+        g.replay()
+        torch.cuda.synchronize()
+        assert prod.fields['overlap'].shape == (8, 1)
+        assert prod.fields['overlap'].view(-1).tolist() == list(range(8 * b, 8 * b + 8))
+        prod.advance()
+    assert ov.pr == ids.OU // 8 * 8 and not prod.full_ahead() or ids.OU % 8 == 0
+
+
+def _params(model):
+    return {k: v.detach().clone() for k, v in model.named_parameters()}
+
+
+@pytest.mark.parametrize('mapping', ['linear', 'non_linear'])
+def test_trainer_fit_on_replays_equals_the_same_steps_run_eagerly(mapping):
+    """CrossDomainTrainer.fit(SOURCE, TARGET, OVERLAP) on device loaders: every full batch is one hipGraph replay that produces the
+    batch itself.  Reference run: the SAME launches issued eagerly (producer launch -> zero_grad -> calculate_loss -> backward ->
+    DenseAdam.step; ragged tails through the loader): the same kernels in the same order on the same data."""
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    from recbole_cdr_amd.utils import InputType, train_mode2state
+    ids, ds, s_pairs, t_pairs = _dataset(1)
+    cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=16, target_embedding_size=16, reg_weight=0.01,
+                      mapping_function=mapping, mlp_hidden_size=[24], learning_rate=0.01, train_modes=['SOURCE', 'TARGET', 'OVERLAP'],
+                      epoch_num=['2', '2', '2'], source_split=False, eval_step=0, epochs=2)
+    torch.manual_seed(3)
+    model = EMCDR(cfg, ds).to(DEV)
+    init = _params(model)
+    torch.manual_seed(77)
+    dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.PAIRWISE, 64, 1, shuffle=True)
+    trainer = CrossDomainTrainer(cfg, model)
+    log = []
+    orig = trainer._train_epoch
+    trainer._train_epoch = lambda data, e: (log.append(orig(data, e)) or log[-1])
+    trainer.fit(dl)
+    assert trainer.graph_stats['captures'] == 3 and trainer.graph_stats['replayed'] > 0
+    n_full = 2 * (len(s_pairs) // 64 + len(t_pairs) // 64 + ids.OU // 16)
+    n_tail = 2 * ((len(s_pairs) % 64 > 0) + (len(t_pairs) % 64 > 0) + (ids.OU % 16 > 0))
+    assert trainer.graph_stats['replayed'] == n_full and trainer.graph_stats['eager'] == n_tail
+
+    # the same sequence without any graph
+    torch.manual_seed(3)
+    ref = EMCDR(cfg, ds).to(DEV)
+    with torch.no_grad():
+        for k, v in ref.named_parameters():
+            v.copy_(init[k])
+    torch.manual_seed(77)
+    dl2 = _loaders(ids, ds, s_pairs, t_pairs, InputType.PAIRWISE, 64, 1, shuffle=True)
+    opt = DenseAdam(ref.parameters(), lr=0.01)
+    ref_log = []
+
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        loss = ref.calculate_loss(b)
+        loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    for phase in ('SOURCE', 'TARGET', 'OVERLAP'):
+        dl2.set_mode(train_mode2state[phase])
+        ref.set_phase(phase)
+        ref.train()
+        for _ in range(2):
+            it = iter(dl2)
+            prod = dl2.device_producer()
+            prod.resync()
+            tot = torch.zeros((), device=DEV)
+            while True:
+                if prod.full_ahead():
+                    prod.launch()
+                    tot += step(prod.fields)
+                    prod.advance()
+                    continue
+                try:
+                    b = next(it)
+                except StopIteration:
+                    break
+                tot += step(b)
+                prod.resync()
+            ref_log.append(float(tot))
+    assert len(log) == len(ref_log) == 6
+    # (the dense backward adds duplicate rows with fp32 atomics, whose order is not fixed: rounding-level differences are allowed)
+    assert_close(torch.tensor(log), torch.tensor(ref_log), rtol=1e-5, what='epoch losses')
+    for k, v in model.named_parameters():
+        assert_close(v, dict(ref.named_parameters())[k], rtol=1e-4, atol=0.02 * 0.01, what=k)
+
+
+def test_trainer_epochs_cover_every_interaction_once():
+    """An epoch of replays + the loader's ragged tail visits every interaction exactly once (shuffled in place), in the loader's
+    k-major layout, and two epochs differ in order and in negatives."""
+    from recbole_cdr_amd.utils import InputType, train_mode2state
+    ids, ds, s_pairs, t_pairs = _dataset(2)
+    torch.manual_seed(5)
+    dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.PAIRWISE, 96, 2, shuffle=True)
+    dl.set_mode(train_mode2state['TARGET'])
+    want = sorted(map(tuple, t_pairs.tolist()))
+    seen_epochs = []
+    for _ in range(2):
+        it = iter(dl)
+        prod = dl.device_producer()
+        prod.resync()
+        rows, negs = [], []
+        while True:
+            if prod.full_ahead():
+                prod.launch(); prod.advance()
+                b = prod.fields
+            else:
+                try:
+                    b = next(it)
+                except StopIteration:
+                    break
+                prod.resync()
+            n = b['target_user_id'].numel() // 2
+            u, i = b['target_user_id'][:n].tolist(), b['target_item_id'][:n].tolist()
+            assert b['target_user_id'][n:].tolist() == u and b['target_item_id'][n:].tolist() == i and b.k_major == 2
+            rows += list(zip(u, i)); negs += b['neg_target_item_id'].tolist()
+        assert sorted(rows) == want
+        seen_epochs.append((rows, negs))
+    assert seen_epochs[0][0] != seen_epochs[1][0] and seen_epochs[0][1] != seen_epochs[1][1]
+
+
+def test_trainer_both_mode_source_wraps_under_replays():
+    """BOTH state (CMF's only phase): the source loader is shorter than the target loader, wraps without reshuffling
+    (dataloader.py:156-161) and the epoch ends with the target loader -- with the wrap batches served by the loader and everything else
+    by replays, the run equals the eager trainer on the same loaders."""
+    from recbole_cdr_amd.model.cross_domain_recommender.cmf import CMF
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset(3, n_s=300, n_t=900)
+    cfg = base_config(DEV, embedding_size=16, alpha=0.4, learning_rate=0.01, train_modes=['BOTH'], epoch_num=['3'], source_split=False,
+                      eval_step=0, epochs=3, **{'lambda': 0.01, 'gamma': 0.02})
+    outs = []
+    for graph in (True, False):
+        torch.manual_seed(4)
+        model = CMF(cfg, ds).to(DEV)
+        torch.manual_seed(9)
+        dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.POINTWISE, 128, 1, shuffle=False)
+        trainer = CrossDomainTrainer(dict(cfg, graph_step=graph), model)
+        log = []
+        orig = trainer._train_epoch
+        trainer._train_epoch = lambda data, e, o=orig, l=log: (l.append(o(data, e)) or l[-1])
+        trainer.fit(dl)
+        outs.append((log, _params(model), dict(trainer.graph_stats)))
+    (lg, pg, sg), (le, pe, se) = outs
+    assert sg['replayed'] > 0 and sg['eager'] > 0 and se['replayed'] == 0
+    # shuffle=False: both runs see the same positives; the negatives come from different counter streams (in-graph vs host-counted),
+    # so the comparison is statistical on the loss and exact on the schedule
+    assert len(lg) == len(le) == 3
+    assert sg['replayed'] + sg['eager'] == 3 * ((len(t_pairs) + 63) // 64)
+    for a, b in zip(lg, le):
+        assert abs(a - b) < 0.1 * abs(b), (lg, le)
+
+
+def test_conet_trainer_uses_deferred_adam_and_matches_dense():
+    """Trainer picks RowAwareAdam for CoNet (exact dense Adam evaluated lazily per row) and replays the step; against the same
+    trainer with the literal dense sweep, eagerly: same losses, same parameters after two epochs (bit-identical update rule)."""
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.trainer.trainer import RowAwareAdam, DenseAdam
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset(4)
+    cfg = base_config(DEV, embedding_size=16, reg_weight=0.01, mlp_hidden_size=[32, 16, 8], learning_rate=0.01, train_modes=['BOTH'],
+                      epoch_num=['2'], source_split=False, eval_step=0, epochs=2)
+    outs = []
+    for fast in (True, False):
+        torch.manual_seed(6)
+        model = CoNet(cfg, ds).to(DEV)
+        rng = {'s': np.random.RandomState(1), 't': np.random.RandomState(2)}
+        src_i = np.arange(ids.OI + ids.TOI, ids.total_num_items); tgt_i = np.arange(1, ids.OI + ids.TOI)
+        s_smp = lambda u, i, k: torch.from_numpy(rng['s'].choice(src_i, u.numel() * k)).to(u.device)
+        t_smp = lambda u, i, k: torch.from_numpy(rng['t'].choice(tgt_i, u.numel() * k)).to(u.device)
+        from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader
+        dt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        dl = CrossDomainDataloader(
+            DomainTrainLoader({'source_user_id': dt(s_pairs[:, 0]), 'source_item_id': dt(s_pairs[:, 1])}, 'source_user_id', 'source_item_id',
+                              'source_label', 'neg_', 128, 1, InputType.POINTWISE, s_smp),
+            DomainTrainLoader({'target_user_id': dt(t_pairs[:, 0]), 'target_item_id': dt(t_pairs[:, 1])}, 'target_user_id', 'target_item_id',
+                              'target_label', 'neg_', 128, 1, InputType.POINTWISE, t_smp),
+            OverlapDataloader(ids.OU, 8, device=DEV))
+        trainer = CrossDomainTrainer(dict(cfg, graph_step=fast, deferred_adam=fast), model)
+        assert isinstance(trainer.optimizer, RowAwareAdam if fast else DenseAdam)
+        log = []
+        orig = trainer._train_epoch
+        trainer._train_epoch = lambda data, e, o=orig, l=log: (l.append(o(data, e)) or l[-1])
+        trainer.fit(dl)
+        outs.append((log, {k: v.detach().clone() for k, v in model.state_dict().items()}, dict(trainer.graph_stats)))
+    (lf, pf, sf), (ld, pd, sd) = outs
+    assert sf['replayed'] > 0 and sd['replayed'] == 0
+    assert_close(torch.tensor(lf), torch.tensor(ld), rtol=1e-5, what='epoch losses')
+    for k in pf:
+        assert_close(pf[k], pd[k], rtol=1e-4, atol=0.01 * 1e-2, what=k)
+
+
+# ---- cdr_conet_fullsort (conet.py:222-242) ---------------------------------------------------------------------
+@pytest.mark.parametrize('D,layers,U,N', [(16, [64, 32, 16, 8], 5, 77), (128, [64, 32, 16, 8], 64, 2000), (8, [12, 8, 4], 3, 41),
+                                          (32, [48, 24], 7, 100), (16, [20, 32, 32, 32], 9, 65), (64, [64, 8], 33, 1)])
+def test_conet_fullsort_kernel_vs_fp64_tower(D, layers, U, N):
+    """All users x all items through the target tower in one launch against an fp64 evaluation of the reference's formula
+    (cat([u, i]) -> Linear + ReLU per layer -> Linear + Sigmoid), 1e-5 relative; shapes: the default tower, C3's D = 128, the golden
+    'a' tower, two- and four-layer towers, widths that are not multiples of 8, a one-item catalogue."""
+    from recbole_cdr_amd import functional as F_
+    g = torch.Generator().manual_seed(D + N)
+    dims = [2 * D] + layers
+    Ws = [torch.randn(b, a, generator=g) * (2.0 / (a + b)) ** 0.5 for a, b in zip(dims[:-1], dims[1:])]
+    bs = [torch.randn(b, generator=g) * 0.1 for b in dims[1:]]
+    wo, bo = torch.randn(1, dims[-1], generator=g) * 0.5, torch.randn(1, generator=g) * 0.1
+    users, items = torch.randn(U, D, generator=g) * 0.3, torch.randn(N, D, generator=g) * 0.3
+    x = torch.cat([users.double().unsqueeze(1).expand(U, N, D), items.double().unsqueeze(0).expand(U, N, D)], dim=2)
+    for W, b in zip(Ws, bs):
+        x = torch.relu(x @ W.double().t() + b.double())
+    want = torch.sigmoid(x @ wo.double().t() + bo.double()).squeeze(-1)
+    dv = lambda t: t.to(DEV)
+    P = F_.gemm(dv(items), dv(Ws[0])[:, D:], trans_b=True)
+    Q = F_.gemm(dv(users), dv(Ws[0])[:, :D], trans_b=True, bias=dv(bs[0]))
+    assert F_.conet_fullsort_supported(layers[0], layers[1:])
+    got = F_.conet_fullsort(P, Q, [dv(w) for w in Ws[1:]], [dv(b) for b in bs[1:]], dv(wo), dv(bo))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (U, N)
+    assert_close(got, want.float(), rtol=1e-5, what='conet fullsort')
+
+
+def test_conet_full_sort_predict_fused_equals_layerwise_path():
+    """CoNet.full_sort_predict on the one-launch kernel against the same model's per-user contraction path (the round-3 product
+    path, still what towers outside the kernel's range take): C3-shaped tower, 40 users x 3,000 items."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    ids = IdSpace(OU=50, TOU=30, SOU=20, OI=1, TOI=2999, SOI=500)
+    cfg = base_config(DEV, embedding_size=32, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+    torch.manual_seed(1)
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias'):
+                p.normal_(0, 0.1)
+    ev = {'target_user_id': torch.arange(1, 41, device=DEV)}
+    fused = model.full_sort_predict(ev)
+    model.__dict__['fullsort_fused'] = False
+    loop = model.full_sort_predict(ev)
+    assert fused.shape == loop.shape == (40, ids.OI + ids.TOI)
+    assert_close(fused, loop, rtol=1e-5, what='fused vs layerwise')
