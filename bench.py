@@ -72,6 +72,8 @@ def parse():
     ap.add_argument('--no-fullsort', action='store_true')
     ap.add_argument('--headline-only', action='store_true', help='c5, N=1: the headline step alone (no OVERLAP / per-positive / grid / full-sort / C1-C4 legs, no CPU baseline): the command whose rocprofv3 --stats averages are the headline kernels\' own (profiles/*_headline_kernel_stats.csv)')
     ap.add_argument('--no-config-legs', action='store_true', help='c5, N=1: skip the compact C1-C4 legs (BASELINE configs[0..3]) behind the headline')
+    ap.add_argument('--no-e2e', action='store_true', help='c5, N=1: skip the end-to-end leg (CrossDomainTrainer.fit over SOURCE / TARGET / OVERLAP epochs + evaluate at the headline table sizes)')
+    ap.add_argument('--only-e2e', action='store_true', help='c5, N=1: the end-to-end leg alone')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
     ap.add_argument('--full-last-layer', action='store_true', help='c4: evaluate every row of the last propagation layer (the reference\'s order) instead of the rows the loss gathers')
@@ -1073,6 +1075,183 @@ def cpu_baseline_model(args, ds, cfg, S, k, pair_batch=None):
             'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one}}
 
 
+# ------------------------------------------------------------------------------------------------------ end-to-end leg
+def e2e_leg(args, dev):
+    """The whole path through the product's own loop at the headline's table sizes: EMCDR-BPR (D = args.dim) on args.users x
+    2 x args.items_per_domain, synthetic interactions generated and kept on the device -> four-state loader with the device negative
+    sampler -> CrossDomainTrainer(optimizer_mode='rowwise').fit over SOURCE, TARGET and OVERLAP (two epochs each: the first allocates
+    the row-wise Adam state, the second is reported) -> Trainer.evaluate (fused mask + top-10) on 4,096 users.  Wall-clock rows/s per
+    epoch INCLUDING shuffle, sampling, batching, Python and the loss read-back, next to the step-only rate of the same step objects on
+    one resident batch of the same size (recbole_cdr/trainer/trainer.py:43-76, data/dataloader.py:114-162,
+    sampler/crossdomain_sampler.py:139-175)."""
+    import numpy as np
+    from recbole_cdr_amd.data import CrossDomainDataloader, OverlapDataloader, DomainTrainLoader, FullSortEvalLoader
+    from recbole_cdr_amd.data.synthetic import DeviceSyntheticDataset
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.sampler import DeviceNegSampler
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.utils import InputType
+    OU, NI, B = int(args.users), int(args.items_per_domain), int(args.batch)
+    steps_per_epoch = 8
+    t_setup = time.perf_counter()
+    ds = DeviceSyntheticDataset(OU=OU, TOU=0, SOU=0, OI=1, TOI=NI, SOI=NI, n_source_inter=steps_per_epoch * B + B // 2,
+                                n_target_inter=steps_per_epoch * B + B // 2 + 20000, device=dev)
+    cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev, 'latent_factor_model': 'BPR',
+           'source_embedding_size': args.dim, 'target_embedding_size': args.dim, 'reg_weight': 0.01, 'mapping_function': 'linear',
+           'mlp_hidden_size': [128], 'learning_rate': 1e-3, 'optimizer_mode': 'rowwise', 'train_modes': ['SOURCE', 'TARGET', 'OVERLAP'],
+           'epoch_num': ['2', '2', '2'], 'source_split': False, 'eval_step': 0, 'epochs': 2, 'topk': [10], 'valid_metric': 'Recall@10'}
+    torch.manual_seed(2022)
+    with torch.device(dev):
+        model = EMCDR(cfg, ds)                                   # 4 tables created (and xavier-initialised) on the device
+    held = 20000
+    t_tr, t_te = ds.t_pairs[held:], ds.t_pairs[:held]
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    OB = B
+    train = CrossDomainDataloader(
+        DomainTrainLoader({'source_user_id': ds.s_pairs[:, 0].contiguous(), 'source_item_id': ds.s_pairs[:, 1].contiguous()}, 'source_user_id',
+                          'source_item_id', 'source_label', 'neg_', B, 1, InputType.PAIRWISE, DeviceNegSampler(ds, 'source', ds.s_pairs, dev),
+                          shuffle=True, generator=gen),
+        DomainTrainLoader({'target_user_id': t_tr[:, 0].contiguous(), 'target_item_id': t_tr[:, 1].contiguous()}, 'target_user_id',
+                          'target_item_id', 'target_label', 'neg_', B, 1, InputType.PAIRWISE, DeviceNegSampler(ds, 'target', ds.t_pairs, dev),
+                          shuffle=True, generator=gen),
+        OverlapDataloader(OU, OB, device=dev, shuffle=True, generator=gen))
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    trainer = CrossDomainTrainer(cfg, model)
+    orig, log = trainer._train_epoch, []
+
+    def timed(data, e):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        v = orig(data, e)
+        torch.cuda.synchronize(); log.append((time.perf_counter() - t, v))
+        return v
+    trainer._train_epoch = timed
+    trainer.fit(train)
+    rows = {'SOURCE': len(ds.s_pairs), 'TARGET': len(t_tr), 'OVERLAP': OU}
+    out = {'what': 'EMCDR-BPR D=%d, %d users x 2 x %d items, B=%d, OB=%d, CrossDomainTrainer.fit(optimizer_mode=rowwise) on device loaders; '
+                   'second epoch of each phase (the first allocates the row-wise Adam state)' % (args.dim, OU, NI, B, OB),
+           'via': 'CrossDomainTrainer.fit', 'setup_s': t_setup, 'phases': {}}
+    for j, ph in enumerate(('SOURCE', 'TARGET', 'OVERLAP')):
+        sec, loss = log[2 * j + 1]
+        out['phases'][ph] = {'epoch_ms': sec * 1e3, 'rows': rows[ph], 'rows_per_s': rows[ph] / sec, 'first_epoch_ms': log[2 * j][0] * 1e3,
+                             'epoch_loss_sum': loss}
+    # ---- step-only rate of the same step objects on one resident full batch -----------------------------------------------------
+    from recbole_cdr_amd.utils import train_mode2state
+    for ph in ('SOURCE', 'TARGET', 'OVERLAP'):
+        train.set_mode(train_mode2state[ph])
+        model.set_phase(ph)
+        prod = train.device_producer()
+        it = iter(train)
+        prod.resync()
+        prod.launch()
+        n = OB if ph == 'OVERLAP' else B
+        for _ in range(2):
+            model.fused_train_step(prod.fields, lr=1e-3)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(8):
+            model.fused_train_step(prod.fields, lr=1e-3)
+        torch.cuda.synchronize()
+        step_rate = 8 * n / (time.perf_counter() - t0)
+        out['phases'][ph]['step_only_rows_per_s'] = step_rate
+        out['phases'][ph]['epoch_over_step_only'] = out['phases'][ph]['rows_per_s'] / step_rate
+        for dl in (train.source_dataloader, train.target_dataloader, train.overlap_dataloader):
+            dl.pr = 0
+    # ---- evaluation: fused mask + top-10 over the whole catalogue ----------------------------------------------------------------
+    model.set_phase('OVERLAP')
+    te_users = torch.unique(t_te[:, 0])[:4096]
+    keep = torch.isin(t_te[:, 0], te_users)
+    hist = t_tr[torch.isin(t_tr[:, 0], te_users)]
+    loader = FullSortEvalLoader('target_user_id', t_te[keep], hist, ds.num_overlap_item + ds.num_target_only_item, 0, dev, users_per_batch=1024)
+    res = trainer.evaluate(loader)                                # first call sizes the workspaces
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = trainer.evaluate(loader)
+    torch.cuda.synchronize(); sec = time.perf_counter() - t0
+    nU, N = int(te_users.numel()), ds.num_overlap_item + ds.num_target_only_item
+    out['evaluate'] = {'users': nU, 'items': N, 'ms': sec * 1e3, 'items_per_s': nU * N / sec, 'recall@10': res['recall@10'],
+                       'what': 'Trainer.evaluate: mapped-user rows x the target item table, history + PAD masked, top-10, metrics'}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------ CoNet full-sort leg
+def conet_fullsort_leg(args, dev):
+    """Metric 2 for BASELINE configs[2]: CoNet.full_sort_predict (conet.py:222-242: the target tower, no cross terms, over every
+    item) through the product model -- gather of the user rows, the two halves of the separable first layer (P = items W1i^T once,
+    Q = users W1u^T + b1), then cdr_conet_fullsort for all U x N pairs in one launch.  C3's catalogue (18,564 target items) and a
+    1,000,001-item synthetic one, U = 1 (recbole's default eval batch of 4,096 // N users) and U = 64; the oracle's per-user loop on
+    the host cores beside it (bounded sample)."""
+    from recbole_cdr_amd.data.synthetic import SyntheticCrossDomainDataset
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    from recbole_cdr_amd import binding as B_
+    D, layers = 128, [64, 32, 16, 8]
+    pair_flop = 2.0 * sum(a * b for a, b in zip(layers[:-1], layers[1:])) + 2.0 * layers[-1]      # behind the hoisted first layer
+    out = {'what': 'CoNet.full_sort_predict, D=%d, tower [%d,%s]; %.0f FLOP per (user, item) pair behind the separable first layer '
+                   '(2 N D h1 more, once per call, for P)' % (D, 2 * D, ','.join(map(str, layers)), pair_flop), 'cases': {}}
+    for N in (18564, 1_000_001):
+        ds = SyntheticCrossDomainDataset(OU=5983, TOU=2000, SOU=2000, OI=1, TOI=N - 1, SOI=1000, n_source_inter=2000, n_target_inter=2000)
+        cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev, 'embedding_size': D,
+               'reg_weight': 0.01, 'mlp_hidden_size': layers}
+        torch.manual_seed(2022)
+        model = CoNet(cfg, ds).to(dev)
+        model.eval()
+        for Uu in (1, 64):
+            inter = {model.TARGET_USER_ID: torch.arange(1, 1 + Uu, device=dev, dtype=torch.int64)}
+            for _ in range(3):
+                sc = model.full_sort_predict(inter)
+            reps = 20 if N < 100000 else 5
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                sc = model.full_sort_predict(inter)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            # the one-launch kernel alone (HIP events around it on the launch stream)
+            from recbole_cdr_amd import functional as F_
+            ue = F_.gather_rows(model.target_user_embedding.weight, inter[model.TARGET_USER_ID])
+            W1 = model.target_crossunit_linear[0].weight
+            P = F_.gemm(model.target_item_embedding.weight[:model.target_num_items], W1[:, D:], trans_b=True)
+            Q = F_.gemm(ue, W1[:, :D], trans_b=True, bias=model.target_crossunit_linear[0].bias)
+            tail = list(model.target_crossunit_linear)[1:]
+            lo = model.target_outputunit[0]
+            res = torch.empty(Uu, P.shape[0], device=dev)
+            call = lambda: F_.conet_fullsort(P, Q, [l.weight for l in tail], [l.bias for l in tail], lo.weight, lo.bias, out=res)
+            call(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record(); torch.cuda.synchronize()
+            kms = e0.elapsed_time(e1) / reps
+            Nn = int(sc.shape[1])
+            flops = pair_flop * Uu * Nn
+            byts = 4.0 * (Nn * layers[0] + Uu * layers[0] + Uu * Nn)                       # P read once, Q, scores written
+            case = {'items_per_s': Uu * Nn / (ms * 1e-3), 'ms': ms, 'U': Uu, 'N': Nn,
+                    'kernel': {'name': 'conet_fullsort_kernel', 'avg_ms': kms, 'algorithmic_flops': flops, 'achieved_TFLOPs': flops / (kms * 1e-3) / 1e12,
+                               'frac_fp32_mfma_peak': flops / (kms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                               'algorithmic_bytes': byts, 'achieved_GBs': byts / (kms * 1e-3) / 1e9, 'frac_hbm_peak': byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    'bound': 'mfma' if flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) > byts / (HBM_PEAK_GBS * 1e9) else 'hbm'}
+            out['cases']['N=%d U=%d' % (Nn, Uu)] = case
+        if N == 18564 and not args.no_cpu_baseline:
+            from oracle import conet as oconet
+            from oracle.common import IdSpace
+            ids = IdSpace(ds.num_overlap_user, ds.num_target_only_user, ds.num_source_only_user, ds.num_overlap_item,
+                          ds.num_target_only_item, ds.num_source_only_item)
+            params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            ncores = host_cores()
+            torch.set_num_threads(ncores)
+            inter_c = {'target_user_id': torch.arange(1, 9)}
+            with torch.no_grad():
+                oconet.full_sort_predict(params, ids, {'target_user_id': torch.arange(1, 3)})
+                t0 = time.perf_counter(); n = 0
+                while time.perf_counter() - t0 < min(args.cpu_seconds, 5.0) or n < 2:
+                    oconet.full_sort_predict(params, ids, inter_c); n += 1
+                dt = (time.perf_counter() - t0) / n
+            out['cpu_baseline'] = {'value': 8 * N / dt, 'unit': 'items/s', 'cores': ncores, 'kind': 'port',
+                                   'sample': '%d calls of the oracle\'s full_sort_predict (the reference\'s per-user loop), 8 users x %d items, torch CPU' % (n, N)}
+        del model
+        torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(args):
     """The oracle's row-wise step (oracle/train_step.py: same loss, same per-row gradients, lazy Adam) timed on this
@@ -1129,7 +1308,7 @@ def cpu_baseline(args):
 def main():
     args = parse()
     if args.headline_only:
-        args.no_map = args.no_extra_legs = args.no_fullsort = args.no_config_legs = args.no_cpu_baseline = True
+        args.no_map = args.no_extra_legs = args.no_fullsort = args.no_config_legs = args.no_cpu_baseline = args.no_e2e = True
     # the contract is ONE JSON line on stdout; RCCL and gloo print banners through C stdio (some only when the process exits),
     # so with a process group everything else written to fd 1 is sent to stderr and the line goes to the saved descriptor
     real_stdout = None
@@ -1140,6 +1319,9 @@ def main():
     world, rank, local = dist_setup(args)
     dev = torch.device('cuda', local)
     import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
+    if args.only_e2e:
+        print(json.dumps({'e2e': e2e_leg(args, dev)}), flush=True)
+        return
     if args.workload == 'c5' and (world > 1 or args.force_shard) and not args.single_layout:
         # N > 1: BOTH layouts of the C5 tables in one record -- north_star's row shard (rows r % N, row / gradient-row all-to-all)
         # and the dimension shard (D/N columns of every row, ids all-gathered, one partial score per triple all-reduced) -- so
@@ -1192,6 +1374,21 @@ def main():
             result['configs'] = legs
     else:
         result = run_model_workload(args, world, rank, dev)
+    if world == 1 and rank == 0 and args.workload == 'c5' and not args.no_e2e:
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        try:
+            result['e2e'] = e2e_leg(args, dev)
+        except Exception as e:  # noqa: BLE001
+            result.setdefault('leg_errors', {})['e2e'] = repr(e)[:500]
+            print('bench: e2e leg failed: %r' % (e,), file=sys.stderr)
+        gc.collect(); torch.cuda.empty_cache()
+    if world == 1 and rank == 0 and not args.no_fullsort and args.workload in ('c5', 'c3'):
+        try:
+            result.setdefault('fullsort', {})['conet'] = conet_fullsort_leg(args, dev)
+        except Exception as e:  # noqa: BLE001
+            result.setdefault('leg_errors', {})['fullsort_conet'] = repr(e)[:500]
+            print('bench: conet fullsort leg failed: %r' % (e,), file=sys.stderr)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == 'c5':
             result['cpu_baseline'] = cpu_baseline(args)

@@ -35,7 +35,7 @@ struct fs_args {
     const float* W[3]; const float* b[3];        // W[t]: [d[t], d_in] row-major (d_in = h1 or d[t-1])
     const float* wo; const float* bo;            // output unit [d_last], [1]
     float* out; int64_t ldo;                     // [U, N]
-    int users_per_block;                         // a multiple of kFsUsers
+    int users_per_block;                         // a multiple of 8
 };
 
 #define FS_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
@@ -60,30 +60,44 @@ __global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
     constexpr int R2 = 4 * G2, R3 = 4 * G3, R4 = 4 * G4;
 
     // ---- static per-lane weight fragments, in the K order of the register chain ------------------------------------------------
+    // (every address is clamped into its array and the value masked afterwards: straight-line loads -- a bounds BRANCH per element made
+    //  this prologue ~200 divergent branches, most of the launch for one-user calls)
+    const auto ldz = [](const float* __restrict__ base, int64_t idx, bool ok) { const float v = base[ok ? idx : 0]; return ok ? v : 0.f; };
     float w2[S1], b2[R2];
+    if (!(a.h1 & 3) && !((uintptr_t)a.W[0] & 15)) {                  // 16-byte requests: a group of four features is wholly inside or outside
 #pragma unroll
-    for (int s = 0; s < S1; ++s) { const int f = h * S1 + s; w2[s] = (c < d2 && f < a.h1) ? a.W[0][(int64_t)c * a.h1 + f] : 0.f; }
+        for (int s = 0; s < S1; s += 4) {
+            const int f = h * S1 + s;
+            const bool ok = c < d2 && f < a.h1;
+            const float4 v = ld4(a.W[0] + (ok ? (int64_t)c * a.h1 + f : 0));
+            w2[s] = ok ? v.x : 0.f; w2[s + 1] = ok ? v.y : 0.f; w2[s + 2] = ok ? v.z : 0.f; w2[s + 3] = ok ? v.w : 0.f;
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < R2; ++r) { const int j = fs_feat(r, h); b2[r] = j < d2 ? a.b[0][j] : 0.f; }
+        for (int s = 0; s < S1; ++s) { const int f = h * S1 + s; w2[s] = ldz(a.W[0], (int64_t)c * a.h1 + f, c < d2 && f < a.h1); }
+    }
+#pragma unroll
+    for (int r = 0; r < R2; ++r) { const int j = fs_feat(r, h); b2[r] = ldz(a.b[0], j, j < d2); }
     float w3[R2 ? R2 : 1], b3[R3 ? R3 : 1], w4[R3 ? R3 : 1], b4[R4 ? R4 : 1];
     if (G3) {
 #pragma unroll
-        for (int r = 0; r < R2; ++r) { const int f = fs_feat(r, h); w3[r] = (c < d3 && f < d2) ? a.W[1][(int64_t)c * d2 + f] : 0.f; }
+        for (int r = 0; r < R2; ++r) { const int f = fs_feat(r, h); w3[r] = ldz(a.W[1], (int64_t)c * d2 + f, c < d3 && f < d2); }
 #pragma unroll
-        for (int r = 0; r < R3; ++r) { const int j = fs_feat(r, h); b3[r] = j < d3 ? a.b[1][j] : 0.f; }
+        for (int r = 0; r < R3; ++r) { const int j = fs_feat(r, h); b3[r] = ldz(a.b[1], j, j < d3); }
     }
     if (G4) {
 #pragma unroll
-        for (int r = 0; r < R3; ++r) { const int f = fs_feat(r, h); w4[r] = (c < d4 && f < d3) ? a.W[2][(int64_t)c * d3 + f] : 0.f; }
+        for (int r = 0; r < R3; ++r) { const int f = fs_feat(r, h); w4[r] = ldz(a.W[2], (int64_t)c * d3 + f, c < d4 && f < d3); }
 #pragma unroll
-        for (int r = 0; r < R4; ++r) { const int j = fs_feat(r, h); b4[r] = j < d4 ? a.b[2][j] : 0.f; }
+        for (int r = 0; r < R4; ++r) { const int j = fs_feat(r, h); b4[r] = ldz(a.b[2], j, j < d4); }
     }
     constexpr int RL = G4 ? R4 : (G3 ? R3 : R2);                      // registers of the last layer's output
     const int dl = G4 ? d4 : (G3 ? d3 : d2);
     float wo[RL];
 #pragma unroll
-    for (int r = 0; r < RL; ++r) { const int j = fs_feat(r, h); wo[r] = j < dl ? a.wo[j] : 0.f; }
+    for (int r = 0; r < RL; ++r) { const int j = fs_feat(r, h); wo[r] = ldz(a.wo, j, j < dl); }
     const float bo = a.bo[0];
+    const bool p_vec = !(a.ldp & 3) && !(a.h1 & 3) && !((uintptr_t)a.P & 15);
 
     const int64_t u_lo = (int64_t)blockIdx.y * a.users_per_block;
     const int64_t u_hi = u_lo + a.users_per_block < a.U ? u_lo + a.users_per_block : a.U;
@@ -99,16 +113,17 @@ __global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
         // the tile's P rows: lane (item c, half h) keeps features h S1 .. h S1 + S1 - 1
         float p[S1];
         {
-            const float* pr = a.P + (iv ? item : 0) * a.ldp + h * S1;
+            const float* pr = a.P + (iv ? item : 0) * a.ldp;
 #pragma unroll
             for (int s = 0; s < S1; s += 4) {
                 const int f = h * S1 + s;
-                if (iv && f + 3 < a.h1 && !(a.ldp & 3)) {
-                    const float4 v = ld4(pr + s);
-                    p[s] = v.x; p[s + 1] = v.y; p[s + 2] = v.z; p[s + 3] = v.w;
+                if (p_vec) {                                        // h1 % 4 == 0: a 16-byte group is wholly inside or wholly outside the row
+                    const bool ok = iv && f < a.h1;
+                    const float4 v = ld4(pr + (ok ? f : 0));
+                    p[s] = ok ? v.x : 0.f; p[s + 1] = ok ? v.y : 0.f; p[s + 2] = ok ? v.z : 0.f; p[s + 3] = ok ? v.w : 0.f;
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) p[s + q] = (iv && f + q < a.h1) ? pr[s + q] : 0.f;
+                    for (int q = 0; q < 4; ++q) { const bool ok = iv && f + q < a.h1; const float v = pr[ok ? f + q : 0]; p[s + q] = ok ? v : 0.f; }
                 }
             }
         }
@@ -167,13 +182,15 @@ int fs_launch(const fs_args& a, hipStream_t s) {
     // user chunks per block: enough workgroups to cover the chip's 1,024 SIMDs about twice when the problem allows it
     fs_args b = a;
     int64_t gx = (n_tiles + 3) / 4;
-    int64_t chunks = (a.U + kFsUsers - 1) / kFsUsers;
+    // users per workgroup: a multiple of 8, as few as it takes to give every SIMD ~4 waves (two are resident at this register count;
+    // the rest evens out the tail) -- a wave's prologue (its weight fragments: ~100 loads) is paid once per (tile, user group)
+    const int64_t groups = (a.U + 7) / 8;
     int64_t gy = 1;
-    while (gx * gy < 2 * CDR_NUM_CU && gy < chunks) gy *= 2;
-    if (gy > chunks) gy = chunks;
-    int64_t per = (chunks + gy - 1) / gy;
-    gy = (chunks + per - 1) / per;
-    b.users_per_block = (int)(per * kFsUsers);
+    while (gx * 4 * gy < 4 * 4 * CDR_NUM_CU && gy < groups) gy *= 2;
+    if (gy > groups) gy = groups;
+    const int64_t per = (groups + gy - 1) / gy;
+    gy = (groups + per - 1) / per;
+    b.users_per_block = (int)(per * 8);
     if (gx > 8 * CDR_NUM_CU) gx = 8 * CDR_NUM_CU;            // waves walk the remaining tiles (their weights stay loaded)
     conet_fullsort_kernel<S1, G2, G3, G4><<<dim3((unsigned)gx, (unsigned)gy), dim3(kFsBlock), 0, s>>>(b);
     return 0;

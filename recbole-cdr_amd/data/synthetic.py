@@ -60,3 +60,33 @@ class SyntheticCrossDomainDataset:
         return {f'{domain}_user_id': torch.from_numpy(np.tile(sel[:, 0], k)).to(device),
                 f'{domain}_item_id': torch.from_numpy(np.tile(sel[:, 1], k)).to(device),
                 f'neg_{domain}_item_id': torch.from_numpy(rng.choice(items, S * k)).to(device)}
+
+
+class DeviceSyntheticDataset:
+    """The same id-space contract with the interactions generated ON the device (torch): what the C5-sized end-to-end leg of bench.py
+    trains on -- 50 M users x 10 M items per domain leave no room for host-side np.unique over tens of millions of pairs.
+    ``s_pairs`` / ``t_pairs``: int64 [n, 2] device tensors of distinct (user, item) pairs in random order."""
+
+    def __init__(self, OU, TOU, SOU, OI, TOI, SOI, n_source_inter, n_target_inter, device, seed=2022):
+        g = torch.Generator(device=device); g.manual_seed(seed)
+        self.num_overlap_user, self.num_overlap_item = OU, OI
+        self.num_target_only_user, self.num_source_only_user = TOU, SOU
+        self.num_target_only_item, self.num_source_only_item = TOI, SOI
+        self.num_total_user, self.num_total_item = OU + TOU + SOU, OI + TOI + SOI
+        self.overlap_id_field = 'overlap'
+
+        def draw(n, lo_a, hi_a, lo_b, hi_b):
+            """n ids uniform over [lo_a, hi_a) U [lo_b, hi_b)"""
+            na, nb = max(hi_a - lo_a, 0), max(hi_b - lo_b, 0)
+            c = torch.randint(0, na + nb, (n,), device=device, generator=g)
+            return torch.where(c < na, c + lo_a, c - na + lo_b)
+
+        def pairs(n, urange, irange):
+            u, i = draw(n, *urange), draw(n, *irange)
+            key = torch.unique(u * self.num_total_item + i)
+            key = key[torch.randperm(key.numel(), device=device, generator=g)]
+            return torch.stack([key // self.num_total_item, key % self.num_total_item], 1).contiguous()
+        self.s_pairs = pairs(n_source_inter, (1, OU, OU + TOU, self.num_total_user), (1, OI, OI + TOI, self.num_total_item))
+        self.t_pairs = pairs(n_target_inter, (1, OU + TOU, 0, 0), (1, OI + TOI, 0, 0))
+        self.source_domain_dataset = _Domain('source', OU + SOU, OI + SOI, {'source_user_id': self.s_pairs[:, 0], 'source_item_id': self.s_pairs[:, 1]})
+        self.target_domain_dataset = _Domain('target', OU + TOU, OI + TOI, {'target_user_id': self.t_pairs[:, 0], 'target_item_id': self.t_pairs[:, 1]})

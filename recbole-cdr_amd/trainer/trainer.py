@@ -269,6 +269,10 @@ class Trainer:
             if mkey is not None:
                 return self._train_epoch_graphed(train_data, mkey)
         total = None                              # accumulated on device: no per-step host sync
+        if self.optimizer_mode == 'rowwise' and self.dist_group is None and hasattr(train_data, 'device_producer'):
+            prod = train_data.device_producer()
+            if prod is not None:
+                return self._train_epoch_rowwise_produced(train_data, prod)
         for interaction in train_data:
             interaction = interaction.to(self.device)
             if self.dist_group is not None:
@@ -287,6 +291,34 @@ class Trainer:
             self.optimizer.step()
             total = loss.detach() if total is None else total + loss.detach()
         value = float(total) if total is not None else 0.0
+        if value != value:
+            raise ValueError('Training loss is nan')
+        return value
+
+    def _train_epoch_rowwise_produced(self, train_data, prod):
+        """The rowwise loop on a device loader: every full batch is ONE producer launch (slice of the shuffled interactions + tiling +
+        negative sampling into fixed buffers, data/producer.py) followed by the model's fused O(batch) step; the loader's own
+        ``__next__`` serves ragged tails and ends the epoch.  (The fused steps of large batches read host-side update counts, so
+        they are launched, not replayed; at >= 1 M rows per step the host's part is < 2 % of the step.)"""
+        if self._loss_sum is None:
+            self._loss_sum = torch.zeros((), device=self.device, dtype=torch.float32)
+        self._loss_sum.zero_()
+        it = iter(train_data)
+        prod.resync()
+        while True:
+            if prod.full_ahead():
+                prod.launch()
+                prod.advance()
+                interaction = prod.fields
+            else:
+                try:
+                    interaction = next(it)
+                except StopIteration:
+                    break
+                prod.resync()
+            loss = self.model.fused_train_step(interaction, lr=self.learning_rate, weight_decay=self.weight_decay)
+            self._loss_sum.add_(loss.detach().reshape(()))
+        value = float(self._loss_sum)
         if value != value:
             raise ValueError('Training loss is nan')
         return value
