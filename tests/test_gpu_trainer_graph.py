@@ -347,3 +347,95 @@ def test_conet_full_sort_predict_fused_equals_layerwise_path():
     loop = model.full_sort_predict(ev)
     assert fused.shape == loop.shape == (40, ids.OI + ids.TOI)
     assert_close(fused, loop, rtol=1e-5, what='fused vs layerwise')
+
+
+# ---- full-size parity of the instantiations the bench times (emcdr.py:110-154) ---------------------------------
+def _rows_close(got, want, what, rtol=1e-5, abs_floor=0.0):
+    """assert_close's matrix rule on the device (the operands here are up to 1 M x 128): |got - want| <= rtol |want| + 1e-5 x
+    max(row max, 1e-3 x tensor max)."""
+    big = float(want.abs().max())
+    floor = 1e-5 * torch.maximum(want.abs().amax(1, keepdim=True), torch.tensor(1e-3 * big, device=want.device)) + 1e-12
+    bad = (got - want).abs() > rtol * want.abs() + floor + abs_floor
+    n_bad = int(bad.sum())
+    assert n_bad == 0, f'{what}: {n_bad} / {bad.numel()} elements beyond {rtol:g} (row-scaled floor)'
+
+
+@pytest.mark.parametrize('kind', ['adam', 'kmajor4', 'zipf'])
+def test_full_c5_size_adam_instantiations(kind):
+    """BASELINE C5 table sizes (50,000,001 x 128 users, 20,000,001 x 128 items, 1,048,576 triples) with the ADAM instantiations the
+    bench times -- cdr_bpr_step_fused (bpr_fwd_apply_kernel<32,1,1>), cdr_bpr_step_fused_kmajor at k = 4, and the Zipf(1.05) batch
+    with its long duplicate segments -- through properties that need no oracle run at that size:
+      * lr = 0: every weight bit-identical; the moments become non-zero on exactly the batch's rows and nowhere else;
+      * first-step moments against an INDEPENDENT run: m = (1 - b1) g and v = (1 - b2) g^2 where g is recovered from the weight
+        change of the plain SGD step (FusedBPRStep(opt='sgd'), the instantiation round 3 already covers) on the same triples;
+      * a real first Adam step equals -lr g / (|g| + eps) element by element (g from that SGD run), and twice from the same start is
+        bit-identical in weights, both moments and the loss."""
+    from recbole_cdr_amd.fused import FusedBPRStep, KMajorBPRStep, RowwiseState, OPT_ADAM
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 170e9:
+        pytest.skip('needs ~150 GB of free HBM')
+    nu, ni, D, B, TOI = 50_000_001, 20_000_001, 128, 1 << 20, 10_000_000
+    b1, b2 = 0.9, 0.999
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+    U = torch.empty(nu, D, device=DEV).normal_(0, 0.05, generator=g)
+    I = torch.empty(ni, D, device=DEV).normal_(0, 0.05, generator=g)
+    k = 4 if kind == 'kmajor4' else 1
+    S = B // k
+    u = torch.randint(1, nu, (S,), device=DEV, generator=g)
+    if kind == 'zipf':
+        r = torch.rand(S, device=DEV, generator=g, dtype=torch.float64)
+        p = 1 + ((float(TOI) ** (1 - 1.05) - 1) * r + 1).pow(1 / (1 - 1.05)).long().clamp_(1, TOI) - 1
+        assert int(torch.bincount(p).max()) > 10000                     # the hottest item occurs tens of thousands of times
+    else:
+        p = torch.randint(1, 1 + TOI, (S,), device=DEV, generator=g)
+    n = torch.randint(1, 1 + TOI, (B,), device=DEV, generator=g)
+    uf, pf = u.repeat(k), p.repeat(k)                                    # the triples, one per row (k-major)
+    ust, ist = RowwiseState(U, OPT_ADAM), RowwiseState(I, OPT_ADAM)
+
+    def make(lr):
+        if kind == 'kmajor4':
+            st = KMajorBPRStep(U, I, S, k=4, opt='adam', lr=lr, reg_weight=0.0, user_state=ust, item_state=ist)
+            assert st.fuse_singles
+            return lambda: st.step(u, p, n)[0].clone()
+        st = FusedBPRStep(U, I, B, opt='adam', lr=lr, reg_weight=0.0, user_state=ust, item_state=ist)
+        assert st.fuse_singles
+        return lambda: st.step(uf, pf, n)[0].clone()
+    tu, ti = torch.unique(uf), torch.unique(torch.cat([pf, n]))
+    Wu0, Wi0 = U[tu].clone(), I[ti].clone()
+    # ---- lr = 0 -----------------------------------------------------------------------------------------------------------------
+    loss0 = make(0.0)()
+    assert torch.equal(U[tu], Wu0) and torch.equal(I[ti], Wi0)
+    for st, touched, name in ((ust, tu, 'user'), (ist, ti, 'item')):
+        for mom in (st.exp_avg, st.exp_avg_sq):
+            nz = torch.nonzero(mom.abs().amax(1) > 0).flatten()
+            assert bool(torch.isin(nz, touched).all()), f'{name} moments written outside the batch'
+            assert touched.numel() - 3 <= nz.numel() <= touched.numel(), (name, nz.numel(), touched.numel())   # (p == n cancels a row: ~0.1 expected)
+            del nz
+    mu, vu, mi, vi = ust.exp_avg[tu].clone(), ust.exp_avg_sq[tu].clone(), ist.exp_avg[ti].clone(), ist.exp_avg_sq[ti].clone()
+    # ---- the gradient from an independent instantiation: plain SGD step on the same triples --------------------------------------
+    lr_s = float(B)
+    FusedBPRStep(U, I, B, opt='sgd', lr=lr_s, reg_weight=0.0).step(uf, pf, n)
+    gu, gi = (Wu0 - U[tu]) / lr_s, (Wi0 - I[ti]) / lr_s
+    U[tu] = Wu0; I[ti] = Wi0
+    _rows_close(mu, (1 - b1) * gu, 'user exp_avg vs (1 - b1) g')
+    _rows_close(mi, (1 - b1) * gi, 'item exp_avg vs (1 - b1) g')
+    _rows_close(vu, (1 - b2) * gu * gu, 'user exp_avg_sq vs (1 - b2) g^2', rtol=3e-5)
+    _rows_close(vi, (1 - b2) * gi * gi, 'item exp_avg_sq vs (1 - b2) g^2', rtol=3e-5)
+    del mu, vu, mi, vi
+    # ---- a real first Adam step, twice from the same start ------------------------------------------------------------------------
+    lr = 1e-3
+    runs = []
+    for _ in range(2):
+        for st, touched in ((ust, tu), (ist, ti)):
+            st.exp_avg[touched] = 0; st.exp_avg_sq[touched] = 0
+            st.step = 0
+        U[tu] = Wu0; I[ti] = Wi0
+        loss = make(lr)()
+        runs.append((loss, U[tu].clone(), I[ti].clone(), ust.exp_avg[tu].clone(), ist.exp_avg_sq[ti].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1])), 'the Adam step is not reproducible'
+    assert torch.equal(runs[0][0], loss0)                                  # same forward
+    # first Adam step from zero moments: m_hat = g, v_hat = g^2, so dw = -lr g / (|g| + eps) -- with g from the independent SGD run
+    # (|g| ~ 2e-8 here, the same order as eps = 1e-8: the eps term is exercised, |dw| ~ 0.7 lr)
+    # (both sides are differences of fp32 weights ~0.05: one ulp of those, 3.7e-9, is the absolute resolution -- 2e-8 = 2e-5 of the step)
+    _rows_close(runs[0][1] - Wu0, -lr * gu / (gu.abs() + 1e-8), 'user first Adam step', rtol=1e-4, abs_floor=2e-8)
+    _rows_close(runs[0][2] - Wi0, -lr * gi / (gi.abs() + 1e-8), 'item first Adam step', rtol=1e-4, abs_floor=2e-8)
