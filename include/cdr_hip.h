@@ -40,6 +40,11 @@ typedef struct cdr_ctx cdr_ctx;
 int cdr_ctx_create(int device, cdr_ctx** out);      /* allocates the reduction scratch on `device`           */
 int cdr_ctx_destroy(cdr_ctx* ctx);
 const char* cdr_last_error(void);
+/* The NEXT forward launch made with this context (cdr_bpr_fwd / cdr_point_fwd / cdr_point_fwd_pair) also zero-fills [ptr, ptr + bytes)
+ * (16-byte aligned, a multiple of 16 bytes): the dense [rows, D] gradient buffers the step's backward scatters into -- what
+ * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
+ * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
+int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
 #define CDR_ABI_VERSION 40
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
@@ -224,7 +229,10 @@ int cdr_scalar_mix(void* stream, int mode, int n, const float* x, int64_t x_stri
  * that loop) kept on the device, no launch and no host sync of its own. */
 int cdr_adam_multi_dev(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev,
-                       float lr, float beta1, float beta2, float eps, float weight_decay, const float* loss, float* loss_sum);
+                       float lr, float beta1, float beta2, float eps, float weight_decay, const float* loss, float* loss_sum,
+                       unsigned* ticket);
+/* ticket (optional): a zero-initialised device word owned by the caller.  With it, updates of up to 512 fat workgroups run as ONE
+ * launch: the kernel evaluates update number step + 1 itself and its last workgroup to finish stores the counters (and the loss total). */
 
 /* cdr_gemm_f32 with a per-output-row scale and a pre-activation accumulate -- the CoNet cross unit
  * (conet.py:127-135):  first  C = s W^T + b           (cdr_gemm_f32, act none)

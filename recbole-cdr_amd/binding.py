@@ -46,6 +46,7 @@ _SIGNATURES = {
     'cdr_ctx_create': [_c_int, ctypes.POINTER(_c_ptr)],
     'cdr_ctx_destroy': [_c_ptr],
     'cdr_abi_version': [],
+    'cdr_ctx_scrub_next': [_c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_bpr_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_bpr_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_f32,
                           _c_ptr, _c_ptr, _c_ptr],
@@ -174,7 +175,7 @@ _SIGNATURES = {
     'cdr_point_bwd_dense_pair': [_c_ptr, _c_ptr] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 12,
     'cdr_scalar_mix': [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
-    'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
+    'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     'cdr_neg_sample_alias': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64, _c_ptr, _c_ptr],
     'cdr_neg_sample_uniform': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64,
                                _c_ptr, _c_ptr],

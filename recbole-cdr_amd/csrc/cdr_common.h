@@ -17,6 +17,8 @@ struct cdr_ctx {
     unsigned* tickets;                       // [CDR_TICKETS] zero-initialised sign-in counters ('the block that signs in last finishes'); atomicInc wraps them back to 0
     void* scratch;                           // grow-on-demand device scratch (long-segment partial sums of cdr_rowwise_apply)
     size_t scratch_bytes;
+    void* scrub_ptr;                         // cdr_ctx_scrub_next: a region the NEXT forward launch on this context zero-fills on the side
+    size_t scrub_bytes;
     // optional HIP-event brackets around the hot kernels, recorded on the launch stream (cdr_timing_*)
     int timing_cap, timing_n;
     hipEvent_t* ev0;
@@ -133,6 +135,41 @@ static inline hipError_t cdr_zero_u32(void* p, int64_t n_words, hipStream_t s) {
     cdr_zero_u32_kernel<<<dim3((unsigned)g), dim3(256), 0, s>>>((uint32_t*)p, n_words);
     return hipGetLastError();
 }
+
+// ---- "the workgroup that signs in last finishes": a two-pass reduction without the second launch, for grids of a few hundred blocks
+// (the finishing launch is ~4.7 us of a 40 us captured step at the reference's default batch of 2,048 rows).  Partials travel with
+// system-scope stores and loads (written through / read past the per-XCD L2s, as in cdr_linear.hip): no release fence, which on this
+// part is a write-back of the whole L2 per workgroup.  Tied to gfx950 for that reason.  ticket: a zero-initialised word (cdr_ctx::tickets);
+// atomicInc wraps it back to 0, so the next launch on the stream finds it clean.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "cdr_common.h: the fence-free partial hand-over (cdr_sign_in_last) is only valid on gfx950; add __threadfence() pairs for another target"
+#endif
+__device__ __forceinline__ void cdr_store_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double cdr_load_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// call with the block's partials already stored by cdr_store_sys (any thread); true in EVERY thread of the block that signed in last
+__device__ __forceinline__ bool cdr_sign_in_last(unsigned* ticket, unsigned nblocks) {
+    __shared__ int cdr_last_flag_;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's partial stores have been acknowledged by memory ...
+    __syncthreads();                                          // ... every thread's have
+    if (threadIdx.x == 0) cdr_last_flag_ = atomicInc(ticket, nblocks - 1) == nblocks - 1 ? 1 : 0;
+    __syncthreads();
+    return cdr_last_flag_ != 0;
+}
+// Side job of a forward kernel: zero-fill n16 16-byte words (the dense gradient buffers its backward will scatter into -- a separate fill
+// launch is ~5 us of a 40 us step; spread over a kernel that is waiting on its gathers anyway it is free).
+__device__ __forceinline__ void cdr_scrub(uint4* __restrict__ z, int64_t n16) {
+    if (!z) return;
+    const int64_t nth = (int64_t)gridDim.x * gridDim.y * blockDim.x;
+    const int64_t me = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = me; i < n16; i += nth) z[i] = zero;
+}
+// host side: hand the pending region to the launch being assembled (and clear it); `done` = false if this path cannot scrub in-kernel
+static inline void cdr_take_scrub(cdr_ctx* ctx, uint4** z, int64_t* n16) {
+    *z = (uint4*)ctx->scrub_ptr; *n16 = (int64_t)(ctx->scrub_bytes / 16);
+    ctx->scrub_ptr = nullptr; ctx->scrub_bytes = 0;
+}
+constexpr int kSignInMaxBlocks = 512;        // beyond this the same-address atomics cost more than the launch they replace (profiles/r03_ab_adam_signin.txt)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

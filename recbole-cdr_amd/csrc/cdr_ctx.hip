@@ -33,6 +33,7 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     c->tags = nullptr;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->scrub_ptr = nullptr; c->scrub_bytes = 0;
     c->partials = nullptr;
     c->tickets = nullptr;
     hipError_t e = hipMalloc(&c->partials, sizeof(double) * CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE);
@@ -105,5 +106,13 @@ extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
     if (ctx->tickets) (void)hipFree(ctx->tickets);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
+    return CDR_OK;
+}
+
+// The next forward launch made with this context (cdr_bpr_fwd / cdr_point_fwd / cdr_point_fwd_pair) also zero-fills [ptr, ptr + bytes):
+// the dense gradient buffers of the step's backward, cleared under the forward's gathers instead of by a launch of their own.
+extern "C" int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes) {
+    CDR_CHECK_ARG(ctx && ptr && bytes > 0 && (bytes & 15) == 0 && ((uintptr_t)ptr & 15) == 0);
+    ctx->scrub_ptr = ptr; ctx->scrub_bytes = bytes;
     return CDR_OK;
 }

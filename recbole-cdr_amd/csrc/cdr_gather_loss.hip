@@ -17,14 +17,37 @@ constexpr int kUnrollPoint = 8;      // pointwise rows carry 2 row loads each (B
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------ BPR forward
+// out4 = {total, main, ||U_b||_F, ||I_b||_F}
+template <bool SYS = false>
+__device__ __forceinline__ void loss_finish_body(const double* __restrict__ partials, int nblocks, int64_t B,
+                                                 float reg_weight, float* __restrict__ out4) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        if (SYS) { acc[0] += cdr_load_sys(o); acc[1] += cdr_load_sys(o + 1); acc[2] += cdr_load_sys(o + 2); }      // (past the L2s: cdr_sign_in_last)
+        else { acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; }
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float main_loss = (float)(acc[0] / (double)B);
+        const float nu = (float)sqrt(acc[1]), ni = (float)sqrt(acc[2]);
+        out4[1] = main_loss; out4[2] = nu; out4[3] = ni;
+        out4[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
+    }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float* __restrict__ U, const float* __restrict__ I,
                                                          int D, const int64_t* __restrict__ uid,
                                                          const int64_t* __restrict__ pid,
                                                          const int64_t* __restrict__ nid, int64_t B, float gamma,
-                                                         float* __restrict__ gcoef, double* __restrict__ partials) {
+                                                         float* __restrict__ gcoef, double* __restrict__ partials,
+                                                         unsigned* __restrict__ ticket, float reg_weight, float* __restrict__ out4,
+                                                         uint4* __restrict__ scrub, int64_t scrub_n16) {
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
+    cdr_scrub(scrub, scrub_n16);
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
     const int64_t TG = (int64_t)gridDim.x * GPB;
@@ -95,8 +118,10 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float* __restrict
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
         double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
-        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+        cdr_store_sys(o, acc[0]); cdr_store_sys(o + 1, acc[1]); cdr_store_sys(o + 2, acc[2]);
     }
+    // small grids: the block that signs in last is the finishing pass (no second launch)
+    if (ticket && cdr_sign_in_last(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
 }
 
 // generic scalar path (D not a multiple of 4): one wave per interaction
@@ -129,23 +154,6 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_scalar_kernel(const float* __r
     }
 }
 
-// out4 = {total, main, ||U_b||_F, ||I_b||_F}
-__device__ __forceinline__ void loss_finish_body(const double* __restrict__ partials, int nblocks, int64_t B,
-                                                 float reg_weight, float* __restrict__ out4) {
-    __shared__ double smem[3 * (kBlock / 64)];
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
-        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
-    }
-    block_sum_d<3>(acc, smem);
-    if (threadIdx.x == 0) {
-        const float main_loss = (float)(acc[0] / (double)B);
-        const float nu = (float)sqrt(acc[1]), ni = (float)sqrt(acc[2]);
-        out4[1] = main_loss; out4[2] = nu; out4[3] = ni;
-        out4[0] = main_loss + reg_weight * ((nu + ni) / (float)B);
-    }
-}
 __global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
                                                              float reg_weight, float* __restrict__ out4) {
     loss_finish_body(partials, nblocks, B, reg_weight, out4);
@@ -307,7 +315,7 @@ __device__ __forceinline__ void point_fwd_body(int loss_kind, const float* __res
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
         double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
-        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+        cdr_store_sys(o, acc[0]); cdr_store_sys(o + 1, acc[1]); cdr_store_sys(o + 2, acc[2]);       // (see cdr_sign_in_last)
     }
 }
 
@@ -316,8 +324,12 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
                                                            const float* __restrict__ RU, const float* __restrict__ RI, int D,
                                                            const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
                                                            const float* __restrict__ label, int64_t B, float* __restrict__ gcoef,
-                                                           float* __restrict__ scores, double* __restrict__ partials) {
+                                                           float* __restrict__ scores, double* __restrict__ partials,
+                                                           unsigned* __restrict__ ticket, float reg_weight, float* __restrict__ out4,
+                                                           uint4* __restrict__ scrub, int64_t scrub_n16) {
+    cdr_scrub(scrub, scrub_n16);
     point_fwd_body<LPR, SAME>(loss_kind, U, I, RU, RI, D, uid, iid, label, B, gcoef, scores, partials);
+    if (ticket && cdr_sign_in_last(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
 }
 
 // Two batches in one launch (blockIdx.y = batch; CMF's two domains on shared tables, BiTGCF's two stacks): same arithmetic per batch,
@@ -331,10 +343,24 @@ struct point_pair {
 constexpr size_t kPairPartials = (size_t)(CDR_MAX_PARTIAL_BLOCKS / 2) * CDR_PARTIAL_STRIDE;
 
 template <int LPR, bool SAME>
-__global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, point_pair a, int D, double* __restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, point_pair a, int D, double* __restrict__ partials,
+                                                                unsigned* __restrict__ ticket, const float* __restrict__ w,
+                                                                float* __restrict__ total, uint4* __restrict__ scrub, int64_t scrub_n16) {
     const int d = blockIdx.y;
+    cdr_scrub(scrub, scrub_n16);
     point_fwd_body<LPR, SAME>(loss_kind, a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.uid[d], a.iid[d], a.label[d], a.B[d], a.gcoef[d],
                               a.scores[d], partials + d * kPairPartials);
+    // small grids: the block (of either batch) that signs in last finishes both losses and their weighted total
+    if (ticket && cdr_sign_in_last(ticket, gridDim.x * gridDim.y)) {
+        loss_finish_body<true>(partials, gridDim.x, a.B[0], a.reg[0], a.out4[0]);
+        __syncthreads();
+        loss_finish_body<true>(partials + kPairPartials, gridDim.x, a.B[1], a.reg[1], a.out4[1]);
+        __syncthreads();
+        if (total && threadIdx.x == 0) {
+#pragma clang fp contract(off)
+            total[0] = (0.f + a.out4[0][0] * w[0]) + a.out4[1][0] * w[1];
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void point_fwd_scalar_kernel(int loss_kind, const float* __restrict__ U,
@@ -466,12 +492,18 @@ extern "C" int cdr_bpr_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, co
     CDR_CHECK_ARG(D > 0 && B > 0);
     hipStream_t s = (hipStream_t)stream;
     int grid;
+    bool fused_finish = false;
+    uint4* zs; int64_t zn;
+    cdr_take_scrub(ctx, &zs, &zn);
+    if (zs && (D & 3) != 0) { CDR_HIP(cdr_zero_u32(zs, zn * 4, s)); }        // the scalar path has no side job: a plain fill
     cdr_time_scope* ts = new cdr_time_scope(ctx, CDR_TAG_BPR_FWD, s);
     if ((D & 3) == 0) {
         const int lpr = cdr_lpr_for(D);
         grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
+        fused_finish = grid <= kSignInMaxBlocks;
         DISPATCH_LPR(lpr, bpr_fwd_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D,
-                                              uid, pid, nid, B, gamma, gcoef, ctx->partials));
+                                              uid, pid, nid, B, gamma, gcoef, ctx->partials, fused_finish ? ctx->tickets : nullptr,
+                                              reg_weight, out4, zs, zn));
     } else {
         grid = grid_for(B, kBlock / 64);
         hipLaunchKernelGGL(bpr_fwd_scalar_kernel, dim3(grid), dim3(kBlock), 0, s, user_tab, item_tab, D, uid, pid, nid, B,
@@ -479,7 +511,7 @@ extern "C" int cdr_bpr_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, co
     }
     delete ts;
     CDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
+    if (!fused_finish) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
@@ -518,17 +550,23 @@ extern "C" int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind, const fl
     hipStream_t s = (hipStream_t)stream;
     const bool same = (reg_user_tab == user_tab) && (reg_item_tab == item_tab);
     int grid;
+    bool fused_finish = false;
+    uint4* zs; int64_t zn;
+    cdr_take_scrub(ctx, &zs, &zn);
+    if (zs && (D & 3) != 0) { CDR_HIP(cdr_zero_u32(zs, zn * 4, s)); }
     if ((D & 3) == 0) {
         const int lpr = cdr_lpr_for(D);
         grid = grid_for((B + kUnrollPoint - 1) / kUnrollPoint, kBlock / lpr);
+        fused_finish = grid <= kSignInMaxBlocks;
+        unsigned* tk = fused_finish ? ctx->tickets : nullptr;
         if (same) {
             DISPATCH_LPR(lpr, point_fwd_kernel<L, true><<<dim3(grid), dim3(kBlock), 0, s>>>(loss_kind,
                                                   user_tab, item_tab, reg_user_tab, reg_item_tab, D, uid, iid, label, B,
-                                                  gcoef, scores, ctx->partials));
+                                                  gcoef, scores, ctx->partials, tk, reg_weight, out4, zs, zn));
         } else {
             DISPATCH_LPR(lpr, point_fwd_kernel<L, false><<<dim3(grid), dim3(kBlock), 0, s>>>(loss_kind,
                                                   user_tab, item_tab, reg_user_tab, reg_item_tab, D, uid, iid, label, B,
-                                                  gcoef, scores, ctx->partials));
+                                                  gcoef, scores, ctx->partials, tk, reg_weight, out4, zs, zn));
         }
     } else {
         grid = grid_for(B, kBlock / 64);
@@ -536,7 +574,7 @@ extern "C" int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind, const fl
                            reg_user_tab, reg_item_tab, D, uid, iid, label, B, gcoef, scores, ctx->partials);
     }
     CDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
+    if (!fused_finish) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, B, reg_weight, out4);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
@@ -566,10 +604,14 @@ extern "C" int cdr_point_fwd_pair(cdr_ctx* ctx, void* stream, int loss_kind, con
     const int lpr = cdr_lpr_for(D);
     int grid = grid_for((bmax + kUnrollPoint - 1) / kUnrollPoint, kBlock / lpr);
     if (grid > CDR_MAX_PARTIAL_BLOCKS / 2) grid = CDR_MAX_PARTIAL_BLOCKS / 2;
-    if (same) { DISPATCH_LPR(lpr, point_fwd_pair_kernel<L, true><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(loss_kind, a, D, ctx->partials)); }
-    else { DISPATCH_LPR(lpr, point_fwd_pair_kernel<L, false><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(loss_kind, a, D, ctx->partials)); }
+    const bool fused_finish = 2 * grid <= kSignInMaxBlocks;
+    unsigned* tk = fused_finish ? ctx->tickets : nullptr;
+    uint4* zs; int64_t zn;
+    cdr_take_scrub(ctx, &zs, &zn);
+    if (same) { DISPATCH_LPR(lpr, point_fwd_pair_kernel<L, true><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(loss_kind, a, D, ctx->partials, tk, w, total, zs, zn)); }
+    else { DISPATCH_LPR(lpr, point_fwd_pair_kernel<L, false><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(loss_kind, a, D, ctx->partials, tk, w, total, zs, zn)); }
     CDR_LAUNCH_CHECK();
-    loss_finish_pair_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, a, w, total);
+    if (!fused_finish) loss_finish_pair_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, a, w, total);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

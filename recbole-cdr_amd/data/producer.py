@@ -99,9 +99,13 @@ class DeviceBatchProducer:
         """Does the loader's next batch have all ``step`` rows (what the captured launch produces)?"""
         return self.loader.pr + self.S <= self.loader.pr_end
 
-    def advance(self):
-        """Host mirror of the cursor move a launch (replay) makes."""
-        self.loader.pr += self.S
+    def full_count(self):
+        """How many full batches lie ahead of the loader's position."""
+        return max(self.loader.pr_end - self.loader.pr, 0) // self.S
+
+    def advance(self, n=1):
+        """Host mirror of the cursor move ``n`` launches (replays) make."""
+        self.loader.pr += n * self.S
 
     def resync(self):
         """Device cursor := the loader's ``pr`` (after the loader itself served a batch, wrapped or started an epoch)."""
@@ -127,9 +131,12 @@ class CompositeProducer:
     def full_ahead(self):
         return all(p.full_ahead() for p in self.parts)
 
-    def advance(self):
+    def full_count(self):
+        return min(p.full_count() for p in self.parts)
+
+    def advance(self, n=1):
         for p in self.parts:
-            p.advance()
+            p.advance(n)
 
     def resync(self):
         for p in self.parts:

@@ -84,7 +84,7 @@ class ShardedDataParallel:
             B_.call('cdr_adam_multi_dev', B_.stream(), n, arr(sl(self.pshard)), arr(sl(self.gshard)), arr(sl(self.exp_avg)),
                     arr(sl(self.exp_avg_sq)), (ctypes.c_int64 * n)(*[m for _, m, _ in segs]),
                     arr([B_.i64(self.steps[i:i + 1]) for _, _, i in segs]), float(self.lr), float(self.betas[0]),
-                    float(self.betas[1]), float(self.eps), float(self.wd), None, None)
+                    float(self.betas[1]), float(self.eps), float(self.wd), None, None, None)
         if self._gloo:
             dist.all_gather_into_tensor(self.flat, self.pshard.clone(), group=self.group)
         else:

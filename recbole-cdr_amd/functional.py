@@ -22,6 +22,33 @@ def _zeros_like2(a, b):
     return flat[:a.numel()].view(a.shape), flat[a.numel():].view(b.shape)
 
 
+def _prezero_for_backward(ctx, *tables):
+    """Called in a loss's forward, BEFORE its forward launch: when a backward will follow, allocate the dense gradient buffers of
+    ``tables`` now (one flat buffer) and let the forward launch zero-fill them on the side (cdr_ctx_scrub_next) -- the separate fill
+    launch was ~5 us of a 40 us step at the reference's default batch.  ``_grads_for`` hands them out in the backward."""
+    ctx.pre = None
+    tabs = [t for t in tables if t is not None]
+    if deterministic() or not tabs or not any(ctx.needs_input_grad) or not all(t.is_contiguous() for t in tabs):
+        return
+    offs, n = [], 0
+    for t in tabs:
+        offs.append(n)
+        n += (t.numel() + 3) // 4 * 4                       # every view starts on a 16-byte boundary
+    flat = torch.empty(n, device=tabs[0].device, dtype=torch.float32)
+    B_.call('cdr_ctx_scrub_next', B_.ctx(flat.device), B_.raw(flat), 4 * n)
+    ctx.pre = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tabs)]
+
+
+def _grads_for(ctx, a, b):
+    """Zeroed gradient buffers shaped like a and b: the ones the forward launch cleared (first backward through this node), else a
+    fresh fill."""
+    pre = getattr(ctx, 'pre', None)
+    if pre is not None and len(pre) == (1 if b is None else 2):
+        ctx.pre = None
+        return pre[0], (pre[1] if b is not None else None)
+    return _zeros_like2(a, b)
+
+
 # ---- run-to-run reproducible dense gradients (opt-in) -------------------------------------------------------------------------------
 # The drop-in losses hand autograd DENSE [rows, D] gradients built with fp32 atomics, like torch's embedding backward: the order of the
 # adds into a row that occurs several times in a batch is not fixed, so two runs can differ in the last bit.  With
@@ -110,6 +137,7 @@ class BPRGatherLoss(Function):
         n, D = uid.numel(), user_w.shape[1]
         out4 = torch.empty(4, device=user_w.device, dtype=torch.float32)
         g = torch.empty(n, device=user_w.device, dtype=torch.float32)
+        _prezero_for_backward(ctx, user_w, item_w)
         B_.call('cdr_bpr_fwd', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), D,
                 B_.i64(uid), B_.i64(pid), B_.i64(nid), n, float(gamma), float(reg_weight), B_.f32(out4), B_.f32(g))
         ctx.save_for_backward(user_w, item_w, uid, pid, nid, g, out4)
@@ -131,7 +159,7 @@ class BPRGatherLoss(Function):
                     B_.f32(g), B_.f32(out4), ctx.reg_weight, B_.f32(go), B_.f32(dU), B_.f32(dI))
             return (_scatter_rows_deterministic(user_w.shape, uid, dU), _scatter_rows_deterministic(item_w.shape, items, dI),
                     None, None, None, None, None)
-        gU, gI = _zeros_like2(user_w, item_w)
+        gU, gI = _grads_for(ctx, user_w, item_w)
         B_.call('cdr_bpr_bwd_dense', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), user_w.shape[1],
                 B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(), B_.f32(g), B_.f32(out4), ctx.reg_weight,
                 B_.f32(go), B_.f32(gU), B_.f32(gI))
@@ -224,8 +252,10 @@ class TwoDomainPointLoss(Function):
         w = _pair_weights(dev, float(alpha))
         total = torch.empty(1, device=dev, dtype=torch.float32)
         gs = [torch.empty(ids[0].numel(), device=dev, dtype=torch.float32), torch.empty(ids[2].numel(), device=dev, dtype=torch.float32)]
+        ctx.pre = None
         if D % 4 == 0:
             # both batches in one gather-dot-loss launch and one finishing block that also forms alpha * L_s + (1 - alpha) * L_t
+            _prezero_for_backward(ctx, user_w, item_w)
             P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
             keep = [user_w, item_w, out8, w, total] + ids + labels + gs
             B_.call('cdr_point_fwd_pair', B_.ctx(dev), B_.stream(), int(kind), P2(user_w.data_ptr(), user_w.data_ptr()),
@@ -260,7 +290,7 @@ class TwoDomainPointLoss(Function):
             gU = _scatter_rows_deterministic(user_w.shape, torch.cat([su, tu]), torch.cat([rows[0][0], rows[1][0]]))
             gI = _scatter_rows_deterministic(item_w.shape, torch.cat([si, ti]), torch.cat([rows[0][1], rows[1][1]]))
             return None, gU, gI, None, None, None, None, None, None, None, None, None
-        gU, gI = _zeros_like2(user_w, item_w)
+        gU, gI = _grads_for(ctx, user_w, item_w)
         if D % 4 == 0:
             # d total / d L_domain = grad_out * weight: the scatter kernel multiplies (the weights are host floats, as in _pair_weights)
             P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2

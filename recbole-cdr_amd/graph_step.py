@@ -32,7 +32,7 @@ def step_and_sum(optimizer, loss, loss_sum):
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, example_interaction=None, warmup=3, restore_after_warmup=True, producer=None, loss_sum=None):
+    def __init__(self, model, optimizer, example_interaction=None, warmup=3, restore_after_warmup=True, producer=None, loss_sum=None, unroll=1):
         """``restore_after_warmup``: the warm-up runs REAL steps on ``example_interaction`` (every lazily created buffer, native context
         and optimizer state must exist before the capture); with True the parameters and the optimizer state are put back afterwards,
         so swapping the eager loop for the graphed one does not add ``warmup`` extra updates on batch 0."""
@@ -60,7 +60,12 @@ class GraphedTrainStep:
                 self.static.k_major = example_interaction.k_major          # the layout hint is part of what the capture was made for
             for k, v in example_interaction.items():
                 self.static[k].copy_(v)
+        # ``unroll`` (with a producer only): a second graph holding ``unroll`` consecutive steps.  Between two graph launches the GPU idles
+        # for ~5-9 us (measured: profiles/r04_graph_gap.txt) -- a fifth of a 40 us step at the reference's default batch; ``replay_many``
+        # pays it once per ``unroll`` steps.
+        self.unroll = int(unroll) if producer is not None else 1
         self.graph = None
+        self.graph_k = None
         self.loss = None
         self._one = torch.ones((), device=dev, dtype=torch.float32)       # d loss / d loss, made once: backward() would fill one per step
         self._capture(warmup)
@@ -104,6 +109,11 @@ class GraphedTrainStep:
         # allocates, which is not allowed while a stream is capturing
         with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._whole()
+        if self.unroll > 1:
+            self.graph_k = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_k, stream=side):
+                for _ in range(self.unroll):
+                    self._whole()
 
     # ---- warm-up without side effects: in-place snapshot / restore (addresses must not change: the capture follows) -------------
     def _state_tensors(self):
@@ -155,6 +165,13 @@ class GraphedTrainStep:
         if hasattr(self.optimizer, 'on_replay'):
             self.optimizer.on_replay()            # host-side bookkeeping of optimizers whose update count lives on the device
         return self.loss
+
+    def replay_many(self):
+        """``unroll`` captured steps in one graph launch (producer only: each of them produces its own batch)."""
+        self.graph_k.replay()
+        if hasattr(self.optimizer, 'on_replay'):
+            for _ in range(self.unroll):
+                self.optimizer.on_replay()
 
     def matches(self, interaction):
         return all(k in interaction and interaction[k].shape == v.shape and interaction[k].dtype == v.dtype for k, v in self.static.items()) \

@@ -40,14 +40,18 @@ class DenseAdam(torch.optim.Optimizer):
                 keep.append(g)
                 ps.append(B_.f32(p.data)); gs.append(B_.f32(g)); ms.append(B_.f32(st['exp_avg'])); vs.append(B_.f32(st['exp_avg_sq']))
                 ns.append(p.numel()); ss.append(B_.i64(st['step']))
+                ps_dev = p.device
             if not ps:
                 continue
             n = len(ps)
             arr = lambda xs: (ctypes.c_void_p * n)(*[x.value if hasattr(x, 'value') else x for x in xs])
             lp, self.loss_pair = self.loss_pair, None
+            tk = self.__dict__.get('_ticket')
+            if tk is None or tk.device != ps_dev:
+                tk = self._ticket = torch.zeros(1, device=ps_dev, dtype=torch.int32)        # sign-in word of the one-launch form
             B_.call('cdr_adam_multi_dev', B_.stream(), n, arr(ps), arr(gs), arr(ms), arr(vs), (ctypes.c_int64 * n)(*ns), arr(ss),
                     float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
-                    float(group['weight_decay']), None if lp is None else B_.f32(lp[0]), None if lp is None else B_.f32(lp[1]))
+                    float(group['weight_decay']), None if lp is None else B_.f32(lp[0]), None if lp is None else B_.f32(lp[1]), B_.raw(tk))
 
 
 def _dense_adam_load(self, state_dict):
@@ -158,6 +162,8 @@ class Trainer:
         # switches it off.
         self.graph_step = bool(config['graph_step'] if 'graph_step' in config else True) and on_gpu and self.optimizer_mode == 'dense' \
             and not self.clip_grad_norm
+        # steps per graph launch on a device loader (the idle time between two graph launches is ~5-9 us: amortised over this many steps)
+        self.graph_unroll = int(config['graph_unroll']) if 'graph_unroll' in config else 8
         self._graphs = {}
         self._loss_sum = None
         self.graph_stats = {'replayed': 0, 'eager': 0, 'captures': 0}
@@ -193,7 +199,8 @@ class Trainer:
         if gs is None:
             from ..graph_step import GraphedTrainStep
             try:
-                gs = GraphedTrainStep(self.model, self.optimizer, example, producer=producer, loss_sum=self._loss_sum)
+                gs = GraphedTrainStep(self.model, self.optimizer, example, producer=producer, loss_sum=self._loss_sum,
+                                      unroll=self.graph_unroll)
                 self.graph_stats['captures'] += 1
             except Exception as e:                                      # noqa: BLE001 -- reported, and the eager loop still trains
                 import warnings
@@ -234,6 +241,12 @@ class Trainer:
                         if gs is False:
                             prod.resync()
                             continue
+                    k = gs.unroll
+                    if k > 1 and prod.full_count() >= k:
+                        gs.replay_many()                          # k steps, one graph launch
+                        prod.advance(k)
+                        self.graph_stats['replayed'] += k
+                        continue
                     gs.replay()
                     prod.advance()
                     self.graph_stats['replayed'] += 1
