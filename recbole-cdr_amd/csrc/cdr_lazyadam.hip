@@ -48,12 +48,30 @@ __device__ __forceinline__ void replay(float4& w, float4& m, float4& v, int64_t 
     // is no weight decay: m and v stay 0 and w moves by step_size * 0 / eps = 0 -- nothing to replay, bit for bit.  (Without this the
     // periodic flush replays tens of thousands of updates for every untouched row: 2.9 s per 32,768 steps at C3's table sizes.)
     if (a.wd == 0.f && m.x == 0.f && m.y == 0.f && m.z == 0.f && m.w == 0.f && v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f) return;
-    for (int64_t tau = from + 1; tau <= to; ++tau) {
-        const float2 h = hp[tau & a.hp_mask];
-        w.x = cdr_adam_elem(w.x, 0.f, m.x, v.x, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
-        w.y = cdr_adam_elem(w.y, 0.f, m.y, v.y, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
-        w.z = cdr_adam_elem(w.z, 0.f, m.z, v.z, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
-        w.w = cdr_adam_elem(w.w, 0.f, m.w, v.w, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
+    // The per-update scalars are read EIGHT updates at a time, the next eight requested before this eight are applied: with real
+    // (non-repeating) batches a row is tens to hundreds of updates behind, and one dependent L2 round trip per update (~0.3 us) was
+    // most of the replay (round 4: lz_prepare_kernel 58 us at C3 with the arithmetic already on v_sqrt / v_rcp).  Entries past `to`
+    // are read (any ring slot is readable) and not used.
+    constexpr int CH = 8;
+    float2 hn[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) hn[j] = hp[(from + 1 + j) & a.hp_mask];
+    for (int64_t tau = from + 1; tau <= to; tau += CH) {
+        float2 h[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = hn[j];
+        if (tau + CH <= to) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) hn[j] = hp[(tau + CH + j) & a.hp_mask];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (tau + j > to) break;
+            w.x = cdr_adam_elem(w.x, 0.f, m.x, v.x, a.b1, a.b2, a.eps, a.wd, h[j].x, h[j].y);
+            w.y = cdr_adam_elem(w.y, 0.f, m.y, v.y, a.b1, a.b2, a.eps, a.wd, h[j].x, h[j].y);
+            w.z = cdr_adam_elem(w.z, 0.f, m.z, v.z, a.b1, a.b2, a.eps, a.wd, h[j].x, h[j].y);
+            w.w = cdr_adam_elem(w.w, 0.f, m.w, v.w, a.b1, a.b2, a.eps, a.wd, h[j].x, h[j].y);
+        }
     }
 }
 
@@ -87,6 +105,74 @@ __global__ __launch_bounds__(kBlock) void lz_prepare_kernel(lz_args a, float2* _
             st4(tb.W + o, w); st4(tb.M + o, m); st4(tb.V + o, v);
         }
         if (sub == 0) tb.last[row] = (int32_t)(t - 1);
+    }
+}
+
+// ---- the same, ONE element per lane (round 4) ------------------------------------------------------------------------------------
+// With real batches the kernel's time is the serial replay of its most-postponed row: a C3 user row comes up every ~60 steps on
+// average and the worst of a batch's ~1,600 is ~400 updates behind.  A lane that owns a float4 issues 4 x 16 instruction slots per
+// update (256 cycles per update on its SIMD): 400 updates = 100 k cycles = 45 us, whatever the rest of the chip does.  One element
+// per lane makes that 64 cycles per update -- the chip-wide VALU work is unchanged, the critical path a quarter.  Updates are applied
+// eight at a time in straight-line code (only m' = m - m (1 - b1) and v' = b2 v are carried from update to update; the eight
+// sqrt / rcp chains behind them overlap), with the gradient-free arithmetic written out (the terms that multiply g = 0 add +0).
+__device__ __forceinline__ float lz_elem_nograd(float pv, float& m, float& v, float b1, float b2, float eps, float step_size, float bc2) {
+#pragma clang fp contract(off)
+    // cdr_adam_elem with gv = 0, wd = 0:  (0 - m) = -m exactly;  ((1 - b2) * 0) * 0 = +0 and b2 v + 0 = b2 v exactly (v >= 0)
+    const float mv = m + (0.f - m) * (1.0f - b1);
+    const float vv = b2 * v;
+    m = mv; v = vv;
+#ifdef CDR_ADAM_IEEE
+    const float denom = sqrtf(vv) / bc2 + eps;
+    return pv - step_size * (mv / denom);
+#else
+    const float denom = __builtin_amdgcn_sqrtf(vv) * bc2 + eps;
+    return pv - step_size * (mv * __builtin_amdgcn_rcpf(denom));
+#endif
+}
+
+__global__ __launch_bounds__(kBlock) void lz_prepare1_kernel(lz_args a, float2* __restrict__ hp, int64_t* __restrict__ counters, int lanes_per_row) {
+    const lz_table tb = a.t[blockIdx.y];
+    const int rows_per_block = kBlock / lanes_per_row;
+    const int sub = threadIdx.x % lanes_per_row;
+    const int64_t gg = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
+    const int64_t TG = (int64_t)gridDim.x * rows_per_block;
+    const int D = a.D;
+    const int64_t t = counters[0] + 1;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        float ss, bc;
+        cdr_adam_hp((double)t, a.lr, a.b1, a.b2, ss, bc);
+        hp[t & a.hp_mask] = make_float2(ss, bc);
+        counters[1] = t;
+    }
+    // (Tried on the C3 stream, 41.7 us as written: scalar loop control via readfirstlane 46.5 us; eight rows in flight per lane group
+    //  46.9 us; the four tables interleaved over a 1-D grid 58.3 us.  ~20 us of it is the replay's VALU time at full chip occupancy.)
+    for (int64_t q = gg; q < tb.n; q += TG) {
+        const uint32_t row = tb.keys[q];
+        if (q > 0 && tb.keys[q - 1] == row) continue;                // one lane group per DISTINCT row
+        const int64_t from = tb.last[row], to = t - 1;
+        if (from >= to) continue;
+        if (sub < D) {
+            const int64_t o = (int64_t)row * D + sub;
+            float w = tb.W[o], m = tb.M[o], v = tb.V[o];
+            if (a.wd != 0.f || m != 0.f || v != 0.f) {               // (zero moments without weight decay: a fixed point, as in replay())
+                constexpr int CH = 8;
+                int64_t tau = from + 1;
+                if (a.wd == 0.f) {
+                    for (; tau + CH - 1 <= to; tau += CH) {          // eight updates, straight line
+                        float2 h[CH];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) h[j] = hp[(tau + j) & a.hp_mask];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) w = lz_elem_nograd(w, m, v, a.b1, a.b2, a.eps, h[j].x, h[j].y);
+                    }
+                    for (; tau <= to; ++tau) { const float2 h = hp[tau & a.hp_mask]; w = lz_elem_nograd(w, m, v, a.b1, a.b2, a.eps, h.x, h.y); }
+                } else {
+                    for (; tau <= to; ++tau) { const float2 h = hp[tau & a.hp_mask]; w = cdr_adam_elem(w, 0.f, m, v, a.b1, a.b2, a.eps, a.wd, h.x, h.y); }
+                }
+                tb.W[o] = w; tb.M[o] = m; tb.V[o] = v;
+            }
+        }
+        if (sub == 0) tb.last[row] = (int32_t)to;
     }
 }
 
@@ -215,6 +301,15 @@ extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* cons
     lz_args a; int64_t nmax;
     if (!fill(a, count, D, W, M, V, last, keys_sorted, nullptr, n, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax, hp_capacity)) {
         cdr_set_error("cdr_lazy_adam_prepare: bad table description"); return CDR_EINVAL;
+    }
+    if (D <= kBlock) {
+        // one element per lane: a row takes D lanes rounded up to whole waves (see lz_prepare1_kernel)
+        const int lanes = (D + 63) / 64 * 64;
+        int64_t g = (nmax + kBlock / lanes - 1) / (kBlock / lanes);
+        if (g > CDR_NUM_CU * 32) g = CDR_NUM_CU * 32;
+        lz_prepare1_kernel<<<dim3((unsigned)g, count), dim3(kBlock), 0, (hipStream_t)stream>>>(a, (float2*)hp_table, counters, lanes);
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
     }
     const int lpr = cdr_lpr_for(D);
     const dim3 grid(grid_for(nmax, kBlock / lpr), count);
