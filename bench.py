@@ -1135,6 +1135,19 @@ def e2e_leg(args, dev):
         sec, loss = log[2 * j + 1]
         out['phases'][ph] = {'epoch_ms': sec * 1e3, 'rows': rows[ph], 'rows_per_s': rows[ph] / sec, 'first_epoch_ms': log[2 * j][0] * 1e3,
                              'epoch_loss_sum': loss}
+    # ---- the SOURCE and the TARGET epoch side by side on two HIP streams (config['parallel_domains'] on one GPU) ----------------------
+    cfg2 = dict(cfg, parallel_domains=True, train_modes=['SOURCE', 'TARGET'], epoch_num=['1', '1'])
+    tr2 = CrossDomainTrainer(cfg2, model)
+    tr2.fit(train)                                                # (creates the streams and their native contexts)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tr2.fit(train)
+    torch.cuda.synchronize(); sec2 = time.perf_counter() - t0
+    seq = out['phases']['SOURCE']['epoch_ms'] + out['phases']['TARGET']['epoch_ms']
+    out['source_and_target_on_two_streams'] = {'ms': sec2 * 1e3, 'rows': rows['SOURCE'] + rows['TARGET'],
+                                               'rows_per_s': (rows['SOURCE'] + rows['TARGET']) / sec2, 'sequential_ms': seq,
+                                               'speedup_over_sequential_phases': seq / (sec2 * 1e3),
+                                               'what': 'one SOURCE epoch and one TARGET epoch enqueued side by side (CrossDomainTrainer with parallel_domains: '
+                                                       'disjoint tables and optimizer state, bit-identical to the sequential phases)'}
     # ---- step-only rate of the same step objects on one resident full batch -----------------------------------------------------
     from recbole_cdr_amd.utils import train_mode2state
     for ph in ('SOURCE', 'TARGET', 'OVERLAP'):

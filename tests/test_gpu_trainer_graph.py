@@ -439,3 +439,38 @@ def test_full_c5_size_adam_instantiations(kind):
     # (both sides are differences of fp32 weights ~0.05: one ulp of those, 3.7e-9, is the absolute resolution -- 2e-8 = 2e-5 of the step)
     _rows_close(runs[0][1] - Wu0, -lr * gu / (gu.abs() + 1e-8), 'user first Adam step', rtol=1e-4, abs_floor=2e-8)
     _rows_close(runs[0][2] - Wi0, -lr * gi / (gi.abs() + 1e-8), 'item first Adam step', rtol=1e-4, abs_floor=2e-8)
+
+
+def test_parallel_domains_on_two_streams_equals_sequential_phases():
+    """config['parallel_domains'] on one GPU (rowwise mode): the SOURCE and TARGET epochs enqueued side by side on two HIP streams leave
+    exactly the tables, moments and epoch losses of the two phases run one after the other (disjoint state; same batches: the device
+    loaders draw from per-loader generators and per-sampler counters)."""
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset(7, n_s=900, n_t=700)
+    base = base_config(DEV, latent_factor_model='BPR', source_embedding_size=16, target_embedding_size=16, reg_weight=0.01,
+                       mapping_function='linear', mlp_hidden_size=[24], learning_rate=0.01, train_modes=['SOURCE', 'TARGET', 'OVERLAP'],
+                       epoch_num=['3', '2', '1'], source_split=False, eval_step=0, epochs=3, optimizer_mode='rowwise')
+    outs = []
+    for par in (True, False):
+        torch.manual_seed(3)
+        model = EMCDR(base, ds).to(DEV)
+        dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.PAIRWISE, 128, 1, shuffle=True)
+        trainer = CrossDomainTrainer(dict(base, parallel_domains=par), model)
+        log = []
+        orig = trainer._train_epoch
+        trainer._train_epoch = lambda data, e, o=orig, l=log: (l.append(o(data, e)) or l[-1])
+        if par:
+            orig2 = trainer._fit_domains_on_two_streams
+            trainer._fit_domains_on_two_streams = lambda d, p, o=orig2, l=log: l.append(o(d, p))
+        trainer.fit(dl)
+        torch.cuda.synchronize()
+        outs.append((log, {k: v.detach().clone() for k, v in model.named_parameters()}, model.fused_optimizer_state()))
+    (lp, pp, sp), (ls, ps, ss) = outs
+    assert isinstance(lp[0], dict) and lp[0]['SOURCE'] == ls[:3] and lp[0]['TARGET'] == ls[3:5] and lp[1:] == ls[5:]
+    for k in pp:
+        assert torch.equal(pp[k], ps[k]), k
+    for name in sp['tables']:
+        assert sp['tables'][name]['step'] == ss['tables'][name]['step']
+        assert torch.equal(sp['tables'][name]['exp_avg'], ss['tables'][name]['exp_avg']), name
