@@ -88,6 +88,8 @@ def parse():
                          'the ranks (D/(N/2) columns, twice the batch per rank)')
     ap.add_argument('--replica-dp', action='store_true', help='c4 with N>1: replica data parallelism with sharded Adam (dp.py) instead of the row-sharded graph')
     ap.add_argument('--single-layout', action='store_true', help='N>1: time only the --shard layout (default: both, in one record)')
+    ap.add_argument('--preflight-seconds', type=float, default=30.0, help='N>1: deadline for a candidate layout to create its groups and run its first two steps on every rank')
+    ap.add_argument('--no-layout-fallback', action='store_true', help='N>1: fail instead of trying the next layout / independent replicas')
     ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
 
@@ -116,14 +118,37 @@ def dist_setup(args):
             # the long-standing path; binding a device would create every sub-group with ncclCommSplit instead
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     timeout=datetime.timedelta(minutes=5))  # a wedged collective aborts instead of hanging
+        global CTRL
+        from recbole_cdr_amd import preflight
+        CTRL = preflight.control_group()
     return world, rank, local
 
 
+CTRL = None            # gloo control group (preflight.control_group): barriers, verdicts and timing scalars never depend on RCCL
+
+
 def barrier(world):
+    torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        dist.barrier(group=CTRL)
     torch.cuda.synchronize()
+
+
+def ctrl_max(t):
+    """MAX over ranks of a small tensor of timing scalars, over the control group (host copies); returned on t's device."""
+    import torch.distributed as dist
+    c = t.detach().to('cpu', copy=True)
+    dist.all_reduce(c, op=dist.ReduceOp.MAX, group=CTRL)
+    return c.to(t.device)
+
+
+class LayoutUnavailable(RuntimeError):
+    """No candidate layout came up on every rank within the preflight deadline; ``attempts`` says what failed where."""
+
+    def __init__(self, attempts):
+        super().__init__('no multi-GPU layout came up: %s' % [(a['layout'], a['errors']) for a in attempts])
+        self.attempts = attempts
 
 
 def xavier_table(rows, D, total_rows, gen, dev):
@@ -136,6 +161,7 @@ def xavier_table(rows, D, total_rows, gen, dev):
 
 # ------------------------------------------------------------------------------------------------------ C5 workload
 def run_c5(args, world, rank, dev):
+    import torch.distributed as dist
     from recbole_cdr_amd.fused import FusedBPRStep
     from recbole_cdr_amd import functional as F_
     D, B = args.dim, args.batch
@@ -152,20 +178,70 @@ def run_c5(args, world, rank, dev):
     gen = torch.Generator(device=dev); gen.manual_seed(2022 + rank)
     sharded = world > 1 or args.force_shard
     lay = None
+    attempts = None
+    pool = 4
+
+    def make_batches(dom_groups_, my_dom_):
+        # synthetic interaction streams: users ~ U{1..OU-1}; target items [1, TOI], source items [TOI+1, 2 TOI]
+        out = []
+        for _ in range(pool):
+            b = {}
+            for dom, lo in (('source', 1 + TOI), ('target', 1)):
+                if dom_groups_ and dom != my_dom_:
+                    continue
+                nb = 2 * B if dom_groups_ else B
+                u = torch.randint(1, OU, (nb,), device=dev, generator=gen)
+                p = torch.randint(lo, lo + TOI, (nb,), device=dev, generator=gen)
+                n = torch.randint(lo, lo + TOI, (nb,), device=dev, generator=gen)
+                b[dom] = (u, p, n)
+            out.append(b)
+        return out
     if sharded:
         # which groups / step objects / streams every rank builds, and how a step drives them, lives in the package
-        # (recbole_cdr_amd/c5_layouts.py) so that the CPU gloo tests run this exact sequence with stand-in arithmetic
-        from recbole_cdr_amd import c5_layouts
-        mode, _ = c5_layouts.resolve(world, args.shard, D, not args.no_domain_groups)
-        if args.shard == 'dim' and mode == 'row':
+        # (recbole_cdr_amd/c5_layouts.py) so that the CPU gloo tests run this exact sequence with stand-in arithmetic.  The layout
+        # is brought up under a watchdog (recbole_cdr_amd/preflight.py): group creation + the first two steps of a candidate within
+        # --preflight-seconds on EVERY rank, else the next candidate: dim-groups -> dim -> row; none: LayoutUnavailable (main() then
+        # runs N independent replicas and still prints the line).
+        from recbole_cdr_amd import c5_layouts, preflight
+        first, _ = c5_layouts.resolve(world, args.shard, D, not args.no_domain_groups)
+        if args.shard == 'dim' and first == 'row':
             print('bench: --dim %d does not cut into float4 slices over %d ranks; using --shard row' % (D, world), file=sys.stderr)
+        order = ['dim-groups', 'dim', 'row']
+        chain = [first] + [m for m in order[order.index(first) + 1:]
+                           if m == 'row' or c5_layouts.resolve(world, 'dim', D, m == 'dim-groups')[0] == m]
+        if args.single_layout or args.no_layout_fallback:
+            chain = chain[:1]
 
         def make_table(name, rows, cols, total_cols):
             total_rows = n_users if name[1] == 'u' else n_items
             return torch.empty(rows, cols, device=dev, dtype=torch.float32).normal_(0.0, (2.0 / (total_rows + total_cols)) ** 0.5, generator=gen)
-        lay = c5_layouts.build(world, rank, args.shard, D, B, n_users, n_items, make_table, dict(opt=args.opt, reg_weight=0.01),
-                               domain_groups=not args.no_domain_groups, pipeline=not args.no_pipeline, dedup=not args.no_dedup, device=dev)
-        steps, tabs = lay.steps, lay.tabs
+
+        # every candidate's process groups, created up front by every rank in the same order (c5_layouts.make_groups says why)
+        all_groups = {name: c5_layouts.make_groups(world, name) for name in chain}
+
+        def build(name):
+            cand = c5_layouts.build(world, rank, 'row' if name == 'row' else 'dim', D, B, n_users, n_items, make_table, dict(opt=args.opt, reg_weight=0.01),
+                                    domain_groups=name == 'dim-groups', pipeline=not args.no_pipeline, dedup=not args.no_dedup, device=dev,
+                                    groups=all_groups[name])
+            cand.batches = make_batches(cand.mode == 'dim-groups', cand.my_dom)
+            return cand
+
+        def first_steps(cand):
+            # communicators are created lazily by their first collective (seconds, once): two set-up steps take that out of the way
+            for i in range(2):
+                cand.run(cand.batches, i)
+            torch.cuda.synchronize()
+
+        def cleanup(cand):
+            cand.steps.clear(); cand.tabs.clear(); cand.batches = None
+        if world > 1:
+            name, lay, attempts = preflight.try_layouts(chain, build, first_steps, CTRL, seconds=args.preflight_seconds, device=dev, cleanup=cleanup)
+            if name is None:
+                raise LayoutUnavailable(attempts)
+        else:
+            lay = build(chain[0]); first_steps(lay)
+        steps, tabs, batches = lay.steps, lay.tabs, lay.batches
+        args.shard = 'row' if lay.mode == 'row' else 'dim'
     dim_mode = sharded and lay.mode in ('dim', 'dim-groups')
     dom_groups = sharded and lay.mode == 'dim-groups'
     if dom_groups:
@@ -177,21 +253,7 @@ def run_c5(args, world, rank, dev):
                 (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
         steps = {'source': FusedBPRStep(tabs['su'], tabs['si'], B, opt=args.opt, reg_weight=0.01),
                  'target': FusedBPRStep(tabs['tu'], tabs['ti'], B, opt=args.opt, reg_weight=0.01)}
-
-    # synthetic interaction streams: users ~ U{1..OU-1}; target items [1, TOI], source items [TOI+1, 2 TOI]
-    pool = 4
-    batches = []
-    for _ in range(pool):
-        b = {}
-        for dom, lo in (('source', 1 + TOI), ('target', 1)):
-            if dom_groups and dom != my_dom:
-                continue
-            nb = 2 * B if dom_groups else B
-            u = torch.randint(1, OU, (nb,), device=dev, generator=gen)
-            p = torch.randint(lo, lo + TOI, (nb,), device=dev, generator=gen)
-            n = torch.randint(lo, lo + TOI, (nb,), device=dev, generator=gen)
-            b[dom] = (u, p, n)
-        batches.append(b)
+        batches = make_batches(False, None)
 
     from recbole_cdr_amd import binding as B_
 
@@ -203,11 +265,6 @@ def run_c5(args, world, rank, dev):
         for dom in ('source', 'target'):
             steps[dom].step(*b[dom])
 
-    if sharded:
-        # communicators are created lazily by their first collective (seconds, once): two set-up steps take that out of the way
-        # even when the caller asks for --warmup 0; they are not counted as warm-up and never timed
-        for i in range(2):
-            one_step(i)
     for i in range(args.warmup):
         one_step(i)
     if sharded:
@@ -244,8 +301,7 @@ def run_c5(args, world, rank, dev):
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = ctrl_max(tmax)
     dt = float(tmax.item())
     interactions = 2 * B * args.steps * world
     result = {
@@ -265,6 +321,16 @@ def run_c5(args, world, rank, dev):
                    'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
         'final_loss': loss,
     }
+    if attempts is not None:
+        # what the preflight saw: which candidate layouts were tried, how long each took to come up (group creation + two steps) and
+        # every rank's error string for those that did not; ranks_seen = the size of each data group as RCCL itself counts it
+        result['layout_fallback'] = {'used': lay.mode, 'attempts': attempts, 'fell_back': len(attempts) > 1}
+        try:
+            from recbole_cdr_amd import preflight
+            result['layout_fallback']['ranks_seen'] = {d: preflight.ranks_seen(g, dev) for d, g in getattr(lay, 'groups', {}).items()
+                                                       if d in lay.rank_domains()}
+        except Exception as e:  # noqa: BLE001
+            result['layout_fallback']['ranks_seen_error'] = repr(e)[:200]
 
     if sharded:
         # what the links carried and how long this rank's two domain streams spent inside all-to-alls (they overlap each other
@@ -275,8 +341,7 @@ def run_c5(args, world, rank, dev):
             xb += b_; xms += m_
         xt = torch.tensor([xb / args.steps, xms / args.steps], device=dev, dtype=torch.float64)
         if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(xt, op=dist.ReduceOp.MAX)
+            xt = ctrl_max(xt)
         result['exchange'] = {'bytes_to_other_ranks_per_step_per_rank': float(xt[0]), 'collective_ms_per_step_max_rank': float(xt[1]),
                               'note': 'bytes: everything the data path sends; ms: HIP-event time of the collectives that are bracketed (dim: the id '
                                       'all-gather, which runs prefetched on a side stream -- the score all-reduce is asynchronous under the id sort and '
@@ -385,7 +450,7 @@ def run_c5(args, world, rank, dev):
                 B_.timing_enable(dev, 0)
                 kms = sum(ks) / len(ks) if ks else None
             if world > 1:
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                tm = ctrl_max(tm)
             ob_bytes = OB * 2 * 6 * 4 * D                      # two rows per id, 6 x 4D bytes per row
             result['overlap_phase'] = {'ms_per_step': float(tm) * 1e3, 'overlap_ids_per_s': OB * world / float(tm),
                                        'batch_per_rank': OB, 'mapping': 'linear %dx%d' % (D, D), 'loss': float(fmap.loss),
@@ -727,7 +792,7 @@ def run_c5(args, world, rank, dev):
                 e1.record(); torch.cuda.synchronize()
                 t_loc = torch.tensor([e0.elapsed_time(e1) / reps * 1e-3], device=dev, dtype=torch.float64)
                 if world > 1:
-                    dist.all_reduce(t_all, op=dist.ReduceOp.MAX); dist.all_reduce(t_loc, op=dist.ReduceOp.MAX)
+                    t_all, t_loc = ctrl_max(t_all), ctrl_max(t_loc)
                 N = 1 + TOI
                 hist = torch.sort(torch.randint(1, 1 + TOI, (Uu, 50), device='cpu', generator=torch.Generator().manual_seed(7)),
                                   dim=1).values.reshape(-1).contiguous().to(dev)                 # replicated: same on every rank
@@ -740,7 +805,7 @@ def run_c5(args, world, rank, dev):
                 barrier(world)
                 t_top = torch.tensor([(time.perf_counter() - t0) / reps], device=dev, dtype=torch.float64)
                 if world > 1:
-                    dist.all_reduce(t_top, op=dist.ReduceOp.MAX)
+                    t_top = ctrl_max(t_top)
                 fs['U=%d' % Uu] = {'items_per_s': Uu * N / float(t_all), 'ms': float(t_all) * 1e3, 'N': N,
                                    'masked_top10': {'ms': float(t_top) * 1e3, 'items_per_s': Uu * N / float(t_top),
                                                     'exchange_bytes_per_rank': 12.0 * Uu * 10 * (world - 1)},
@@ -752,6 +817,36 @@ def run_c5(args, world, rank, dev):
         result.setdefault('leg_errors', {})['fullsort'] = repr(e)[:500]
         print('bench: fullsort leg failed: %r' % (e,), file=sys.stderr)
     return result
+
+
+_gather_bw_cache = {}
+
+
+def measured_gather_bandwidth(dev, footprint_bytes, D, B=1 << 20, reps=30):
+    """GB/s of a pure random-row gather (cdr_embloss_fwd: squared norms of B + B rows of two tables, 3 floats written) over a working set of
+    ``footprint_bytes``: the roof of the cache-resident configurations (C1 / C2 / C4 tables live in L2 / Infinity Cache, where the 8 TB/s
+    HBM peak bounds nothing).  Same measurement as tools/mb_cache_gather.py, run here on the config's own footprint."""
+    key = (int(footprint_bytes) >> 20, D)
+    if key in _gather_bw_cache:
+        return _gather_bw_cache[key]
+    from recbole_cdr_amd import binding as B_
+    rows = max(int(footprint_bytes) // (2 * 4 * D), 16)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    U = torch.randn(rows, D, device=dev, generator=g); I = torch.randn(rows, D, device=dev, generator=g)
+    u = torch.randint(0, rows, (B,), device=dev, generator=g); i = torch.randint(0, rows, (B,), device=dev, generator=g)
+    out3 = torch.empty(3, device=dev)
+    call = lambda: B_.call('cdr_embloss_fwd', B_.ctx(dev), B_.stream(), B_.f32(U), B_.f32(I), D, B_.i64(u), B_.i64(i), B, B_.f32(out3))
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    gbs = 2.0 * B * D * 4 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+    _gather_bw_cache[key] = gbs
+    return gbs
 
 
 def pmc_traffic(kernel):
@@ -916,9 +1011,7 @@ def run_model_workload(args, world, rank, dev):
         dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        dt = float(ctrl_max(torch.tensor([dt], device=dev, dtype=torch.float64)))
     job_rows = rows_per_step * (1 if rowshard is not None else world)
     result = {'metric': 'training interactions/sec', 'value': job_rows * args.steps / dt, 'unit': 'interactions/s',
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -976,7 +1069,12 @@ def run_model_workload(args, world, rank, dev):
         spmm = nnz * (4 * D + 12) + 2 * (nu + ni) * 4 * D                           # one graph layer, one direction, both domains
         byts = 2.0 * full_layers * spmm + 7.0 * 4 * 2 * (nu + ni) * D              # full SpMMs fwd + bwd, + dense Adam
         gbs = byts / step_s / 1e9
-        roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
+        foot = 4.0 * 2 * (nu + ni) * D * 4 + nnz * 12.0                           # 4 tables + their Adam moments' share the SpMM touches + the adjacency
+        cache_bw = measured_gather_bandwidth(dev, foot, D)
+        roof = {'bound': 'cache', 'achieved': gbs, 'peak': cache_bw, 'unit': 'GB/s', 'frac': gbs / cache_bw, 'algorithmic_bytes': byts,
+                'peak_what': 'MEASURED in this run: random-row gather bandwidth (cdr_embloss_fwd, 2 x 1,048,576 rows of %d B) over a %.0f MB working set '
+                             '-- the tables, gradients and adjacency of this configuration sit in L2 / Infinity Cache, where the HBM peak bounds nothing' % (4 * D, foot / 1e6),
+                'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
                 'what': 'SpMM (4D + 12 B per nnz + 4D per output row, fwd + bwd, both domains) of the %d of %d layers that are evaluated on every row '
                         '+ dense Adam (7 x 4 B per table element)%s; the 43 MB of tables and the adjacency live in L2 / Infinity Cache, where the '
                         'SpMM gathers run at ~10 TB/s: NOMINAL fraction of the HBM peak, DESIGN 4.10'
@@ -988,9 +1086,15 @@ def run_model_workload(args, world, rank, dev):
         tabs_el = sum(p.numel() for p in model.parameters() if p.grad is not None)
         byts = float(rows_per_step * per_row + 7 * 4 * tabs_el)
         gbs = byts / step_s / 1e9
-        roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
-                'what': 'gather (%d B per row) + exact dense Adam over the parameters that received a gradient (7 x 4 B per element); the '
-                        'tables (a few MB) are L2-resident and the step is launch / latency bound: nominal fraction' % per_row, 'traffic': None}
+        foot = 7.0 * 4 * tabs_el
+        cache_bw = measured_gather_bandwidth(dev, foot, D)
+        n_launch = 5
+        roof = {'bound': 'launch', 'achieved': gbs, 'peak': cache_bw, 'unit': 'GB/s', 'frac': gbs / cache_bw, 'algorithmic_bytes': byts,
+                'peak_what': 'MEASURED in this run: random-row gather bandwidth over a %.0f MB working set (L2-resident): what the bytes of this step could '
+                             'move at.  The step is not bound by it: it is %d dependent launches of ~5-9 us each (producer, forward, backward, Adam) -- '
+                             'ms_per_step and launches are the figures that matter here' % (foot / 1e6, n_launch),
+                'launches_per_step': n_launch, 'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
+                'what': 'gather (%d B per row) + exact dense Adam over the parameters that received a gradient (7 x 4 B per element)' % per_row, 'traffic': None}
     result['roofline'] = roof
     if rowshard is not None:
         p_ = rowshard.part
@@ -1318,6 +1422,26 @@ def cpu_baseline(args):
             'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one}}
 
 
+def run_replicas(args, world, rank, dev, attempts):
+    """Last resort of ``--gpus N`` when no sharded layout came up (LayoutUnavailable): every rank runs the one-GPU headline step on its
+    own GPU with its own full tables -- no data-path communication at all -- and the line reports N x the slowest rank's rate, with
+    what failed (``layout_fallback``).  Weak scaling of independent replicas: says nothing about the collectives, and says so."""
+    import copy
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.no_map = a.no_extra_legs = a.no_fullsort = a.no_config_legs = a.no_cpu_baseline = a.no_e2e = True
+    a.force_shard = False
+    r = run_c5(a, 1, 0, dev)
+    ms = float(ctrl_max(torch.tensor([r['ms_per_step']], dtype=torch.float64)))
+    r.update(value=world * 2 * args.batch / (ms * 1e-3), n_gpus=world, ms_per_step=ms, scaling='weak')
+    r['config']['sharding'] = ('none: %d INDEPENDENT REPLICAS (fallback: no sharded layout came up within %.0f s on every rank) -- each rank '
+                               'its own full tables and batches, no data-path communication' % (world, args.preflight_seconds))
+    r['config']['sharding_mode'] = 'replicas'
+    r['layout_fallback'] = {'used': 'replicas', 'attempts': attempts, 'fell_back': True}
+    return r
+
+
 def main():
     args = parse()
     if args.headline_only:
@@ -1341,21 +1465,28 @@ def main():
         # that one hardware run shows them side by side.  The headline fields are those of --shard (default dim).
         import copy
         import gc
-        first, second = args.shard, ('row' if args.shard == 'dim' else 'dim')
-        result = run_c5(args, world, rank, dev)
-        gc.collect(); torch.cuda.empty_cache()
-        a2 = copy.copy(args)
-        a2.shard, a2.no_fullsort, a2.no_map, a2.no_extra_legs = second, True, True, True
-        other = None
         try:
-            other = run_c5(a2, world, rank, dev)
-        except Exception as e:  # noqa: BLE001
-            result.setdefault('leg_errors', {})['layout_' + second] = repr(e)[:500]
-        pick = lambda r: None if r is None else {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'n_gpus', 'exchange', 'kernels',
-                                                                      'roofline')} | {'sharding': r['config']['sharding']}
-        result['layouts'] = {first: pick(result), second: pick(other)}
+            result = run_c5(args, world, rank, dev)            # (brings its layout up under the preflight watchdog; args.shard = what came up)
+        except LayoutUnavailable as e:
+            result = run_replicas(args, world, rank, dev, e.attempts)
+        if result['config'].get('sharding_mode') != 'replicas':
+            first, second = args.shard, ('row' if args.shard == 'dim' else 'dim')
+            gc.collect(); torch.cuda.empty_cache()
+            a2 = copy.copy(args)
+            a2.shard, a2.no_fullsort, a2.no_map, a2.no_extra_legs, a2.no_layout_fallback = second, True, True, True, True
+            other = None
+            try:
+                other = run_c5(a2, world, rank, dev)
+            except Exception as e:  # noqa: BLE001
+                result.setdefault('leg_errors', {})['layout_' + second] = repr(e)[:500]
+            pick = lambda r: None if r is None else {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'n_gpus', 'exchange', 'kernels',
+                                                                          'roofline', 'layout_fallback')} | {'sharding': r['config']['sharding']}
+            result['layouts'] = {first: pick(result), second: pick(other)}
     elif args.workload == 'c5':
-        result = run_c5(args, world, rank, dev)
+        try:
+            result = run_c5(args, world, rank, dev)
+        except LayoutUnavailable as e:
+            result = run_replicas(args, world, rank, dev, e.attempts)
         if world == 1 and not args.no_config_legs:
             # BASELINE configs[0..3] behind the headline, compact: so that ONE default invocation covers all five configurations.
             # Each leg is the full `--workload cN` measurement at 200 steps (they take 0.03-1 ms each) with a 3-second CPU sample.
@@ -1411,6 +1542,11 @@ def main():
             print(json.dumps(result), flush=True)
     if world > 1 or args.force_shard:
         import torch.distributed as dist
+        stuck = any('still blocked' in str(e) for a in (result.get('layout_fallback') or {}).get('attempts', []) for e in a['errors'].values()) \
+            if isinstance(result, dict) else False
+        if stuck:
+            sys.stderr.flush()
+            os._exit(0)                           # a watchdog thread is still inside a communicator that never formed: do not wait for it
         dist.destroy_process_group()
 
 

@@ -54,8 +54,19 @@ def resolve(world, layout, D, domain_groups=True):
     return ('dim-groups' if groups else 'dim'), D // G
 
 
+def make_groups(world, mode):
+    """The process groups of layout ``mode`` ('dim-groups' | 'dim' | 'row').  ``dist.new_group`` must be called by EVERY rank in the same
+    order, so a caller that may abandon a layout half-way (preflight.try_layouts) creates the groups of all its candidates up front,
+    on every rank, and hands them to ``build`` -- a rank that failed early would otherwise leave the others' later ``new_group`` calls
+    paired with the wrong partners.  (With RCCL a group costs nothing until its first collective.)"""
+    if mode == 'dim-groups':
+        half = world // 2
+        return {'source': dist.new_group(list(range(half))), 'target': dist.new_group(list(range(half, world)))}
+    return {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+
+
 def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, domain_groups=True, pipeline=True, dedup=True, device=None,
-          dim_ops=None, row_ops=None, plain_step=None):
+          dim_ops=None, row_ops=None, plain_step=None, groups=None):
     """``make_table(name, rows, cols, total_cols)`` -> this rank's fp32 table [rows, cols] (name in su, si, tu, ti).
     ``step_kw``: optimizer / loss keywords of the step classes (opt, reg_weight, lr ...).
     ``dim_ops(user_cols, item_cols, max_global_batch)`` / ``row_ops()``: compute stand-ins for the CPU tests (None: native kernels).
@@ -69,7 +80,7 @@ def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, doma
     mk_stream = (lambda: torch.cuda.Stream(device=device)) if (cuda and pipeline) else (lambda: None)
     if lay.mode == 'dim-groups':
         half = lay.half = world // 2
-        groups = {'source': dist.new_group(list(range(half))), 'target': dist.new_group(list(range(half, world)))}
+        groups = groups if groups is not None else make_groups(world, 'dim-groups')
         lay.my_dom = 'source' if rank < half else 'target'
         k = lay.my_dom[0]
         lay.tabs = {k + 'u': make_table(k + 'u', n_users, lay.Ds, D), k + 'i': make_table(k + 'i', n_items, lay.Ds, D)}
@@ -81,14 +92,14 @@ def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, doma
         lay.tabs = {n: make_table(n, r, lay.Ds, D) for n, r in (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
         # one process group (= one communicator) and one stream per domain: the two domain steps touch disjoint tables and have no
         # host sync inside, so they queue up side by side and one's collectives overlap the other's kernels
-        lay.groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+        lay.groups = groups if groups is not None else make_groups(world, 'dim')
         for d in ('source', 'target'):
             U, I = lay.tabs[d[0] + 'u'], lay.tabs[d[0] + 'i']
             ops = dim_ops(U, I, B * world) if dim_ops is not None else None
             lay.steps[d] = DimShardedBPRStep(U, I, B, group=lay.groups[d], ops=ops, stream=mk_stream(), **step_kw)
     else:
         lay.tabs = {n: make_table(n, shard_rows(r, world, rank), D, D) for n, r in (('su', n_users), ('si', n_items), ('tu', n_users), ('ti', n_items))}
-        lay.groups = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+        lay.groups = groups if groups is not None else make_groups(world, 'row')
         for d in ('source', 'target'):
             lay.steps[d] = ShardedBPRStep(lay.tabs[d[0] + 'u'], lay.tabs[d[0] + 'i'], n_users, n_items, B, group=lay.groups[d],
                                           ops=row_ops() if row_ops is not None else None, stream=mk_stream(), dedup=dedup, **step_kw)

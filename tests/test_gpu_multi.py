@@ -584,6 +584,39 @@ def test_bench_multi_rank_line_contract(world, extra):
         assert lay['row']['exchange']['bytes_to_other_ranks_per_step_per_rank'] > lay['dim']['exchange']['bytes_to_other_ranks_per_step_per_rank']
 
 
+@pytest.mark.parametrize('inject,used', [('dim:raise@1', 'row'), ('dim,row:raise@0', 'replicas')])
+def test_bench_multi_rank_layout_fallback(inject, used):
+    """The first hardware run of `bench.py --gpus N` must not be losable: a layout that fails to come up on some
+    rank is abandoned by every rank and the next one is tried (dim -> row), and when none comes up the ranks run independent replicas
+    -- ONE JSON line with the contract's keys either way, `layout_fallback` saying what failed where and how many ranks each data group
+    really has.  World 2 on cuda:0 over gloo with injected failures."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CDR_BENCH_SHARED_GPU='1', CDR_PREFLIGHT_FAIL=inject)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--users', '400001',
+           '--items-per-domain', '100000', '--batch', '8192', '--preflight-seconds', '20', '--no-fullsort']
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]
+    d = json.loads(lines[0])
+    fb = d['layout_fallback']
+    assert fb['used'] == used and fb['fell_back'] is True and fb['attempts'][0]['layout'] == 'dim' and fb['attempts'][0]['ok'] is False
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['metric'] == 'training interactions/sec'
+    B = d['config']['batch_per_domain_per_rank']
+    assert abs(d['value'] - 2 * B * 2 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    if used == 'row':
+        assert fb['ranks_seen'] == {'source': 2, 'target': 2} and 'row' in d['config']['sharding']
+    else:
+        assert 'INDEPENDENT REPLICAS' in d['config']['sharding'] and [a['ok'] for a in fb['attempts']] == [False, False]
+
+
 def _dist_ckpt_worker(rank, world, port, path, q):
     import os
     import faulthandler

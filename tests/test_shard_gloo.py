@@ -826,3 +826,91 @@ def test_bench_layouts_under_gloo(world, layout):
                     G = len(members)
                     want = T[:, gi * (D // G):(gi + 1) * (D // G)]
                 torch.testing.assert_close(got, want, rtol=2e-5, atol=lr * 1e-2)
+
+
+# ---- preflight: guarded bring-up of a layout and the fallback chain ------------------------------------------------
+def _worker_preflight(rank, world, port, inject, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['CDR_PREFLIGHT_FAIL'] = inject
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recbole_cdr_amd  # noqa: F401
+        from recbole_cdr_amd import c5_layouts, preflight
+        from recbole_cdr_amd.dimshard import dim_shard_of
+        from recbole_cdr_amd.shard import shard_of
+        ctrl = preflight.control_group(timeout_s=60)
+        nu, ni, D, B, reg, lr = 47, 31, 16, 11, 0.03, 0.05
+        torch.manual_seed(0)
+        full = {k: torch.randn(r, D) * 0.3 for k, r in (('su', nu), ('si', ni), ('tu', nu), ('ti', ni))}
+        hp = {'lr': lr, 'b1': 0.9, 'b2': 0.999, 'eps': 1e-8, 'wd': 0.0}
+
+        all_groups = {name: c5_layouts.make_groups(world, name) for name in ('dim-groups', 'dim', 'row')}
+
+        def build(name):
+            mode = name
+
+            def make_table(nm, rows, cols, total_cols):
+                if mode == 'row':
+                    return shard_of(full[nm], world, rank).clone()
+                G = world // 2 if mode == 'dim-groups' else world
+                return dim_shard_of(full[nm], G, rank % G).clone()
+            lay = c5_layouts.build(world, rank, 'row' if name == 'row' else 'dim', D, B, nu, ni, make_table, dict(opt='adam', lr=lr, reg_weight=reg),
+                                   domain_groups=name == 'dim-groups', device='cpu', groups=all_groups[name],
+                                   dim_ops=lambda U, I, mb: OracleDimOps(U, I, 1, hp, 1e-10, reg), row_ops=OracleOps)
+            assert lay.mode == name
+            nb = 2 * B if name == 'dim-groups' else B
+            lay.batches = []
+            for it in range(2):
+                b = {}
+                for d in lay.rank_domains():
+                    g = torch.Generator(); g.manual_seed(1000 * it + 10 * (d == 'target') + rank)
+                    b[d] = (torch.randint(0, nu, (nb,), generator=g), torch.randint(0, ni, (nb,), generator=g), torch.randint(0, ni, (nb,), generator=g))
+                lay.batches.append(b)
+            return lay
+
+        def first_steps(lay):
+            for i in range(2):
+                lay.run(lay.batches, i)
+        name, lay, attempts = preflight.try_layouts(['dim-groups', 'dim', 'row'], build, first_steps, ctrl, seconds=8.0, device='cpu')
+        seen = None
+        if lay is not None:
+            seen = {d: preflight.ranks_seen(g, 'cpu') for d, g in lay.groups.items() if d in lay.rank_domains()}
+            lay.run(lay.batches, 0)                                   # the layout that came up keeps working
+        q.put((rank, name, [(a['layout'], a['ok'], sorted(a['errors'])) for a in attempts], seen))
+    finally:
+        if inject:
+            q.close(); q.join_thread()                               # (the result has left this process before it is cut short)
+            os._exit(0)                                              # (watchdog threads are still blocked in abandoned collectives: as bench.py does)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('inject,used,tried', [
+    ('', 'dim-groups', [('dim-groups', True, [])]),
+    # (rank 1 raises before its first collective: its group partner, rank 0, waits for it until the deadline and is abandoned too)
+    ('dim-groups:raise@1', 'dim', [('dim-groups', False, [0, 1]), ('dim', True, [])]),
+    ('dim-groups:hang@2,dim:raise', 'row', [('dim-groups', False, [2, 3]), ('dim', False, [0, 1, 2, 3]), ('row', True, [])]),
+    ('dim-groups,dim,row:raise@3', None, [('dim-groups', False, [0, 1, 2, 3]), ('dim', False, [0, 1, 2, 3]), ('row', False, [0, 1, 2, 3])]),
+])
+def test_preflight_fallback_chain_under_gloo(inject, used, tried):
+    """bench.py --gpus N brings its layout up under recbole_cdr_amd/preflight.py: a candidate that raises on one rank, or blocks past
+    the deadline on one rank, is abandoned by EVERY rank (verdicts agreed over the gloo control group) and the next one is tried --
+    dim-groups -> dim -> row -> none (the caller then runs independent replicas).  World 4 on CPU with the oracle arithmetic."""
+    world = 4
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_preflight, args=(r, world, port, inject, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, name, attempts, seen in res:
+        assert name == used, (r, name, attempts)
+        assert attempts == tried, (r, attempts)
+        if used == 'dim-groups':
+            assert list(seen.values()) == [2]
+        elif used is not None:
+            assert seen == {'source': 4, 'target': 4}
