@@ -924,30 +924,62 @@ def run_model_workload(args, world, rank, dev):
     rowshard = None
     trainer = None
     via = None
-    if args.workload == 'c4' and (world > 1 or args.force_shard) and not args.replica_dp:
-        # BASELINE configs[3] as named: the tables (with their Adam state), the adjacency rows and the transfer-layer degrees
-        # row-sharded over the ranks, per-layer all-gather of E forward and of g (1 + E) backward (bitgcf_shard.py).  The batch is
-        # replicated -- every rank evaluates the same 8,192 rows against the all-gathered propagated tables -- so the total work
-        # is fixed as N grows: STRONG scaling of the per-step propagation.
-        from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF, NativeGraphOps
-        rowshard = ShardedBiTGCF(ds.num_total_user, ds.num_total_item, ds.num_overlap_user, ds.num_overlap_item, ds.s_pairs, ds.t_pairs,
-                                 cfg['embedding_size'], cfg['n_layers'], cfg['lambda_source'], cfg['lambda_target'], cfg['connect_way'],
-                                 cfg['reg_weight'], NativeGraphOps(dev), drop_rate=cfg['drop_rate'])
-        del model
-        torch.cuda.empty_cache()
-        opt = DenseAdam(list(rowshard.params.values()), lr=1e-3)
-        model = None
-    elif world > 1:
-        # N > 1: data parallel, every rank its own batches, ONE reduce-scatter + ONE all-gather of the flat parameter buffer
-        # per step and the dense Adam sweep (the largest cost of these steps) split over the ranks (dp.ShardedDataParallel)
-        from recbole_cdr_amd.dp import ShardedDataParallel
+    attempts = None
+    replicas = False
+    if world > 1 or (args.workload == 'c4' and args.force_shard):
+        # N > 1 (recbole_cdr_amd/preflight.py: each candidate is built and driven through its first step under a watchdog, verdicts agreed over
+        # the gloo control group; none comes up -> every rank runs the one-GPU trainer path on its own GPU, independent replicas):
+        #   'rowshard' (c4, BASELINE configs[3] as named): the tables (with their Adam state), the adjacency rows and the transfer-layer degrees
+        #       row-sharded over the ranks, per-layer all-gather of E forward and of g (1 + E) backward (bitgcf_shard.py).  The batch is
+        #       replicated, so the total work is fixed as N grows: STRONG scaling of the per-step propagation.
+        #   'replica-dp': data parallel, every rank its own batches, ONE reduce-scatter + ONE all-gather of the flat parameter buffer per
+        #       step and the dense Adam sweep split over the ranks (dp.ShardedDataParallel)
+        from recbole_cdr_amd import preflight
         rng = np.random.RandomState(2022 + rank)
         if pairwise:
-            batches = [ds.pairwise_batch('source', S, k, rng, dev) for _ in range(4)]
+            dp_batches = [ds.pairwise_batch('source', S, k, rng, dev) for _ in range(4)]
         else:
-            batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
-        sdp = ShardedDataParallel(model, lr=1e-3)
-    else:
+            dp_batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
+
+        # a communicator of its own per candidate, created up front by every rank (a candidate abandoned half-way leaves collectives pending
+        # in ITS group only: the next candidate is not paired with them)
+        import torch.distributed as dist
+        cand_groups = {nm: (dist.new_group(list(range(world))) if world > 1 else None) for nm in ('rowshard', 'replica-dp')}
+
+        def build(name):
+            if name == 'rowshard':
+                from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF, NativeGraphOps
+                rs = ShardedBiTGCF(ds.num_total_user, ds.num_total_item, ds.num_overlap_user, ds.num_overlap_item, ds.s_pairs, ds.t_pairs,
+                                   cfg['embedding_size'], cfg['n_layers'], cfg['lambda_source'], cfg['lambda_target'], cfg['connect_way'],
+                                   cfg['reg_weight'], NativeGraphOps(dev), group=cand_groups['rowshard'], drop_rate=cfg['drop_rate'])
+                return ('rowshard', rs, DenseAdam(list(rs.params.values()), lr=1e-3))
+            from recbole_cdr_amd.dp import ShardedDataParallel
+            return ('replica-dp', ShardedDataParallel(model, group=cand_groups['replica-dp'], lr=1e-3), None)
+
+        def first_step(c):
+            if c[0] == 'rowshard':
+                c[2].zero_grad(set_to_none=True); c[1].loss_and_grads(batches[0]); c[2].step()
+            else:
+                c[1].step(dp_batches[0])
+            torch.cuda.synchronize()
+        cands = (['rowshard'] if args.workload == 'c4' and not args.replica_dp else []) + ['replica-dp']
+        if world > 1:
+            lname, c, attempts = preflight.try_layouts(cands[:1] if args.no_layout_fallback else cands, build, first_step, CTRL,
+                                                      seconds=args.preflight_seconds, device=dev)
+        else:
+            lname, c = cands[0], build(cands[0])
+        if lname == 'rowshard':
+            rowshard, opt = c[1], c[2]
+            del model
+            torch.cuda.empty_cache()
+            model = None
+        elif lname == 'replica-dp':
+            sdp, batches = c[1], dp_batches
+        else:
+            if args.no_layout_fallback:
+                raise LayoutUnavailable(attempts)
+            replicas = True
+    if rowshard is None and sdp is None:
         # N = 1: THE PRODUCT'S LOOP.  CrossDomainTrainer.fit over device-resident loaders of this synthetic dataset (the interaction
         # lists tiled to args.steps full batches per epoch, shuffled every epoch, negatives drawn by the device sampler): the trainer
         # captures producer + calculate_loss + backward + Adam once per phase and an epoch is a run of hipGraph replays
@@ -1013,15 +1045,20 @@ def run_model_workload(args, world, rank, dev):
         import torch.distributed as dist
         dt = float(ctrl_max(torch.tensor([dt], device=dev, dtype=torch.float64)))
     job_rows = rows_per_step * (1 if rowshard is not None else world)
+    if replicas:
+        name = name + '; N = %d INDEPENDENT REPLICAS (fallback: no sharded / data-parallel layout came up on every rank)' % world
     result = {'metric': 'training interactions/sec', 'value': job_rows * args.steps / dt, 'unit': 'interactions/s',
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
               'higher_is_better': True, 'scaling': 'strong' if rowshard is not None else 'weak', 'vs_baseline': None, 'dtype': 'f32',
               'data': 'synthetic' + ('; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo' if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')) else ''),
-              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if world > 1 else ', eager trainer loop' if args.no_graph else ', batch production + step replayed as one hipGraph per batch'),
+              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if sdp is not None else ', eager trainer loop' if args.no_graph else ', batch production + step replayed as one hipGraph per batch'),
                          'rows_per_step': rows_per_step, 'via': via,
                          'trainer_steps': None if trainer is None else dict(stats, warmup_steps_run=args.steps, optimizer=type(opt).__name__,
                                                                             timed='one fit() = one shuffled epoch of exactly --steps full batches, sampler + loader + step + loss read-back')},
               'final_loss': float(loss.sum())}
+    if attempts is not None:
+        result['layout_fallback'] = {'used': 'rowshard' if rowshard is not None else 'replica-dp' if sdp is not None else 'replicas', 'attempts': attempts,
+                                     'fell_back': len(attempts) > 1 or replicas}
     # ---- roofline of the step (SURVEY 8d figures; C1-C4 tables sit in L2 / Infinity Cache, so the HBM fractions are nominal) ----
     step_s = dt / args.steps
     D = cfg['embedding_size'] if 'embedding_size' in cfg else cfg['source_embedding_size']

@@ -617,6 +617,35 @@ def test_bench_multi_rank_layout_fallback(inject, used):
         assert 'INDEPENDENT REPLICAS' in d['config']['sharding'] and [a['ok'] for a in fb['attempts']] == [False, False]
 
 
+@pytest.mark.parametrize('inject,used', [('', 'rowshard'), ('rowshard:raise@1', 'replica-dp'), ('rowshard,replica-dp:raise@0', 'replicas')])
+def test_bench_c4_multi_rank_layout_fallback(inject, used):
+    """`bench.py --workload c4 --gpus 2` (BASELINE configs[3]: the row-sharded graph) under the same watchdog: rowshard -> replica data
+    parallel -> independent replicas of the product's trainer loop; one JSON line either way.  cuda:0 shared over gloo."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CDR_BENCH_SHARED_GPU='1', CDR_PREFLIGHT_FAIL=inject)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--workload', 'c4', '--gpus', '2', '--steps', '4', '--warmup', '1',
+           '--preflight-seconds', '60', '--no-cpu-baseline']
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]
+    d = json.loads(lines[0])
+    fb = d['layout_fallback']
+    assert fb['used'] == used and fb['fell_back'] == (used != 'rowshard') and d['n_gpus'] == 2 and d['value'] > 0 and 0 < d['final_loss'] < 10
+    rows = d['config']['rows_per_step']
+    want = rows * (1 if used == 'rowshard' else 2) / (d['ms_per_step'] * 1e-3)
+    assert abs(d['value'] - want) / want < 1e-6
+    if used == 'replicas':
+        assert 'INDEPENDENT REPLICAS' in d['config']['workload'] and d['config']['via'] == 'CrossDomainTrainer.fit'
+
+
 def _dist_ckpt_worker(rank, world, port, path, q):
     import os
     import faulthandler
