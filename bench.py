@@ -87,6 +87,7 @@ def parse():
                     help='--shard dim: shard BOTH domains over all N ranks (D/N columns each) instead of giving each domain one half of '
                          'the ranks (D/(N/2) columns, twice the batch per rank)')
     ap.add_argument('--replica-dp', action='store_true', help='c4 with N>1: replica data parallelism with sharded Adam (dp.py) instead of the row-sharded graph')
+    ap.add_argument('--single-stream', action='store_true', help='c5, N=1: enqueue the TARGET domain step behind the SOURCE domain step on one stream (default: two streams)')
     ap.add_argument('--single-layout', action='store_true', help='N>1: time only the --shard layout (default: both, in one record)')
     ap.add_argument('--preflight-seconds', type=float, default=30.0, help='N>1: deadline for a candidate layout to create its groups and run its first two steps on every rank')
     ap.add_argument('--no-layout-fallback', action='store_true', help='N>1: fail instead of trying the next layout / independent replicas')
@@ -257,11 +258,32 @@ def run_c5(args, world, rank, dev):
 
     from recbole_cdr_amd import binding as B_
 
-    def one_step(i):
+    # N = 1: the SOURCE and the TARGET domain step of a benchmark step are enqueued on two HIP streams -- what the product's trainer does
+    # with config['parallel_domains'] (trainer.py::_fit_domains_on_two_streams): disjoint tables and optimizer state, bit-identical to
+    # one after the other; tails and small launches of one domain run under the other's kernels.  The roofline needs kernels timed ALONE:
+    # their HIP-event brackets come from the same number of single-stream steps right behind the timed region (`single_stream`), and
+    # `--headline-only` (the command the rocprofv3 summary is taken from) runs single-stream throughout, so the two agree.
+    two_streams = not sharded and not args.single_stream and not args.headline_only
+    if two_streams:
+        dstreams = {d: torch.cuda.Stream(device=dev) for d in ('source', 'target')}
+        for d in dstreams:
+            with torch.cuda.stream(dstreams[d]):
+                B_.ctx(dev)                                # the native context of each stream, created outside the timed region
+
+    def one_step(i, serial=False):
         if lay is not None:
             lay.run(batches, i)
             return
         b = batches[i % pool]
+        if two_streams and not serial:
+            cur = torch.cuda.current_stream()
+            for d in ('source', 'target'):
+                dstreams[d].wait_stream(cur)
+                with torch.cuda.stream(dstreams[d]):
+                    steps[d].step(*b[d])
+            for d in ('source', 'target'):
+                cur.wait_stream(dstreams[d])
+            return
         for dom in ('source', 'target'):
             steps[dom].step(*b[dom])
 
@@ -271,13 +293,24 @@ def run_c5(args, world, rank, dev):
         for st in steps.values():
             st.profile(True)
     # HIP-event brackets around each hot kernel, recorded by the library on the stream the kernel is launched on
-    B_.timing_enable(dev, args.steps * 2 * 5 + 16)
+    if not two_streams:
+        B_.timing_enable(dev, args.steps * 2 * 5 + 16)
     barrier(world)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
     barrier(world)
     dt = time.perf_counter() - t0
+    single = None
+    if two_streams:
+        for i in range(2):
+            one_step(i, serial=True)
+        B_.timing_enable(dev, args.steps * 2 * 5 + 16)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i, serial=True)
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t1) / args.steps
     timings = {}
     collected = B_.timing_collect(dev)
     if dim_mode and not dom_groups and not args.no_pipeline:
@@ -321,6 +354,11 @@ def run_c5(args, world, rank, dev):
                    'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
         'final_loss': loss,
     }
+    if single is not None:
+        result['config']['streams'] = 'the two domain steps of a step on two HIP streams (CrossDomainTrainer parallel_domains); kernel brackets / roofline from single-stream steps'
+        result['single_stream'] = {'ms_per_step': single * 1e3, 'value': 2 * B / single, 'unit': 'interactions/s', 'steps': args.steps,
+                                   'what': 'the same steps with the TARGET domain step enqueued behind the SOURCE domain step on one stream, right after the '
+                                           'timed region: the per-kernel HIP-event brackets (kernels, roofline) are taken here, with every kernel running alone'}
     if attempts is not None:
         # what the preflight saw: which candidate layouts were tried, how long each took to come up (group creation + two steps) and
         # every rank's error string for those that did not; ranks_seen = the size of each data group as RCCL itself counts it
@@ -551,21 +589,24 @@ def run_c5(args, world, rank, dev):
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_k['frac'],
                               'avg_launch_ms': dom_k['median_ms'], 'algorithmic_bytes': dom_k['algorithmic_bytes'],
                               'bytes_model': 'SURVEY 8d: 6 x 4D bytes per row the launch updates (w, m, v read + written) + 4D per row it only gathers; '
-                                             'avg_launch_ms = median of the HIP-event brackets of the timed region\'s launches',
+                                             'avg_launch_ms = median of the HIP-event brackets of ' + ('the single-stream steps right behind the timed region '
+                                             '(in the timed region the two domains\' kernels overlap on two streams: brackets taken there would time a kernel '
+                                             'sharing the chip)' if two_streams else 'the timed region\'s launches'),
                               'design_bytes': dom_k['design_bytes'], 'design_GBps': dom_k['design_GBps'],
                               'design_frac': dom_k['design_GBps'] / HBM_PEAK_GBS,
                               'traffic': pmc_traffic(dom_k['kernel'].split(' ')[0]),
-                              'rocprof': 'profiles/r03_bench_c5_headline_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `python bench.py --headline-only` '
-                                         '(this kernel on the headline batch only; the default command also launches it on the k = 4 and synthetic-grid '
-                                         'batches, so ITS stats file averages over several batch sizes)'}
+                              'rocprof': 'profiles/r04_bench_c5_headline_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `python bench.py --headline-only` '
+                                         '(single stream, this kernel on the headline batch only; the default command also launches it on the k = 4 and synthetic-grid '
+                                         'batches and beside the other domain\'s kernels, so ITS stats file averages over several situations)'}
         result['kernels'] = kernels
         result['batch_occupancy'] = {'triples': B, 'distinct_user_rows': du, 'distinct_item_rows': di, 'single_user_rows': su_, 'single_item_rows': si_}
         # the STEP against SURVEY 8d's floor for a fused row-wise-Adam step: 6 x 4D bytes per touched row
         dom_ms = dt / args.steps * 1e3 / 2.0
         step_bytes = B * 3 * nmom * row_b
         distinct_bytes = (du + di) * nmom * row_b
-        result['roofline_step'] = {'bound': 'hbm', 'what': 'one domain step (batch norms + sort + flags + forward/optimizer + duplicate-row applies) of %d triples against SURVEY 8d\'s '
-                                   '9,216 B/triple at D=128 (6 x 4D per touched row, 3 rows per triple, no reuse counted)' % B,
+        result['roofline_step'] = {'bound': 'hbm', 'what': ('one domain step (batch norms + sort + flags + forward/optimizer + duplicate-row applies) of %d triples against SURVEY 8d\'s '
+                                   '9,216 B/triple at D=128 (6 x 4D per touched row, 3 rows per triple, no reuse counted)' % B) +
+                                   ('; ms_per_domain_step = half of the two-stream step (the two domain steps overlap)' if two_streams else ''),
                                    'achieved': step_bytes / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': step_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'ms_per_domain_step': dom_ms,
                                    'algorithmic_bytes': step_bytes,
@@ -601,7 +642,7 @@ def run_c5(args, world, rank, dev):
         # ---- the same step with the two domains on their own HIP streams (they share nothing: disjoint tables and optimizer state):
         # tails and small launches of one domain run under the other's kernels.  Reported beside the headline, which stays the
         # single-stream measurement so that its per-kernel brackets and the rocprofv3 averages are those of kernels running alone.
-        if rank == 0 and not sharded and not getattr(args, 'no_extra_legs', False):
+        if rank == 0 and not sharded and not two_streams and not getattr(args, 'no_extra_legs', False):
             dstreams = {d: torch.cuda.Stream(device=dev) for d in ('source', 'target')}
             for d in dstreams:
                 with torch.cuda.stream(dstreams[d]):
@@ -845,8 +886,20 @@ def measured_gather_bandwidth(dev, footprint_bytes, D, B=1 << 20, reps=30):
         call()
     e1.record(); torch.cuda.synchronize()
     gbs = 2.0 * B * D * 4 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
-    _gather_bw_cache[key] = gbs
-    return gbs
+    # ... and the rate at which the same working set STREAMS through the cache level it sits in (a sum over it, repeated): an upper
+    # bound for any access pattern at that footprint -- random 256-B rows are per-request bound well below it, sorted adjacency lists
+    # (C4's SpMM) sit in between
+    flat = torch.cat([U.reshape(-1), I.reshape(-1)])
+    for _ in range(3):
+        flat.sum()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        flat.sum()
+    e1.record(); torch.cuda.synchronize()
+    stream = flat.numel() * 4.0 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+    _gather_bw_cache[key] = (gbs, stream)
+    return gbs, stream
 
 
 def pmc_traffic(kernel):
@@ -860,8 +913,8 @@ def pmc_traffic(kernel):
         v = None
     if v is None:
         return None
-    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_r03.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                                  'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --steps 3 --warmup 1`; not measured in this invocation)'}
+    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_r04.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                  'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --single-stream --steps 3 --warmup 1`; not measured in this invocation)'}
 
 
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
@@ -1107,11 +1160,13 @@ def run_model_workload(args, world, rank, dev):
         byts = 2.0 * full_layers * spmm + 7.0 * 4 * 2 * (nu + ni) * D              # full SpMMs fwd + bwd, + dense Adam
         gbs = byts / step_s / 1e9
         foot = 4.0 * 2 * (nu + ni) * D * 4 + nnz * 12.0                           # 4 tables + their Adam moments' share the SpMM touches + the adjacency
-        cache_bw = measured_gather_bandwidth(dev, foot, D)
-        roof = {'bound': 'cache', 'achieved': gbs, 'peak': cache_bw, 'unit': 'GB/s', 'frac': gbs / cache_bw, 'algorithmic_bytes': byts,
-                'peak_what': 'MEASURED in this run: random-row gather bandwidth (cdr_embloss_fwd, 2 x 1,048,576 rows of %d B) over a %.0f MB working set '
-                             '-- the tables, gradients and adjacency of this configuration sit in L2 / Infinity Cache, where the HBM peak bounds nothing' % (4 * D, foot / 1e6),
-                'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
+        gather_bw, stream_bw = measured_gather_bandwidth(dev, foot, D)
+        roof = {'bound': 'cache', 'achieved': gbs, 'peak': max(stream_bw, gather_bw), 'unit': 'GB/s', 'frac': gbs / max(stream_bw, gather_bw), 'algorithmic_bytes': byts,
+                'peak_what': 'MEASURED in this run on a %.0f MB working set (the tables, gradients and adjacency of this configuration sit in L2 / Infinity '
+                             'Cache, where the HBM peak bounds nothing): the rate at which it streams through that cache level (a sum over it) -- an upper '
+                             'bound for any access pattern; uniformly random %d-B rows gather at %.0f GB/s there (per-request bound), the SpMM\'s sorted '
+                             'adjacency lists in between' % (foot / 1e6, 4 * D, gather_bw),
+                'random_row_gather_GBs_measured': gather_bw, 'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
                 'what': 'SpMM (4D + 12 B per nnz + 4D per output row, fwd + bwd, both domains) of the %d of %d layers that are evaluated on every row '
                         '+ dense Adam (7 x 4 B per table element)%s; the 43 MB of tables and the adjacency live in L2 / Infinity Cache, where the '
                         'SpMM gathers run at ~10 TB/s: NOMINAL fraction of the HBM peak, DESIGN 4.10'
@@ -1124,13 +1179,13 @@ def run_model_workload(args, world, rank, dev):
         byts = float(rows_per_step * per_row + 7 * 4 * tabs_el)
         gbs = byts / step_s / 1e9
         foot = 7.0 * 4 * tabs_el
-        cache_bw = measured_gather_bandwidth(dev, foot, D)
-        n_launch = 5
-        roof = {'bound': 'launch', 'achieved': gbs, 'peak': cache_bw, 'unit': 'GB/s', 'frac': gbs / cache_bw, 'algorithmic_bytes': byts,
-                'peak_what': 'MEASURED in this run: random-row gather bandwidth over a %.0f MB working set (L2-resident): what the bytes of this step could '
-                             'move at.  The step is not bound by it: it is %d dependent launches of ~5-9 us each (producer, forward, backward, Adam) -- '
-                             'ms_per_step and launches are the figures that matter here' % (foot / 1e6, n_launch),
-                'launches_per_step': n_launch, 'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
+        gather_bw, stream_bw = measured_gather_bandwidth(dev, foot, D)
+        n_launch = 4
+        roof = {'bound': 'launch', 'achieved': gbs, 'peak': max(stream_bw, gather_bw), 'unit': 'GB/s', 'frac': gbs / max(stream_bw, gather_bw), 'algorithmic_bytes': byts,
+                'peak_what': 'MEASURED in this run on a %.0f MB working set (L2-resident): the rate at which it streams through L2 (random %d-B rows gather at '
+                             '%.0f GB/s there).  The step is not bound by either: it is %d dependent launches of ~5-10 us each (producer, forward, backward, '
+                             'Adam) -- ms_per_step and launches_per_step are the figures that matter here' % (foot / 1e6, 4 * D, gather_bw, n_launch),
+                'random_row_gather_GBs_measured': gather_bw, 'launches_per_step': n_launch, 'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
                 'what': 'gather (%d B per row) + exact dense Adam over the parameters that received a gradient (7 x 4 B per element)' % per_row, 'traffic': None}
     result['roofline'] = roof
     if rowshard is not None:

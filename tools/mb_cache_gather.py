@@ -37,8 +37,18 @@ def measure(D, footprint_bytes, B=1 << 20, reps=50):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     byts = 2.0 * B * D * 4
-    return {'D': D, 'footprint_MB': 2 * rows * D * 4 / 1e6, 'rows_per_table': rows, 'gathered_rows_per_launch': 2 * B, 'ms': ms,
-            'GBps': byts / (ms * 1e-3) / 1e9}
+    # the same working set streamed through the cache level it sits in (a sum over it): upper bound for any access pattern at that footprint
+    flat = torch.cat([U.reshape(-1), I.reshape(-1)])
+    for _ in range(3):
+        flat.sum()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        flat.sum()
+    e1.record(); torch.cuda.synchronize()
+    sms = e0.elapsed_time(e1) / reps
+    return {'D': D, 'footprint_MB': 2 * rows * D * 4 / 1e6, 'rows_per_table': rows, 'gathered_rows_per_launch': 2 * B, 'gather_ms': ms,
+            'random_row_gather_GBps': byts / (ms * 1e-3) / 1e9, 'stream_sum_ms': sms, 'stream_GBps': flat.numel() * 4.0 / (sms * 1e-3) / 1e9}
 
 
 if __name__ == '__main__':

@@ -1,11 +1,18 @@
 #!/bin/bash
 # Round-4 evidence run (on the GPU box through gpurun).  Everything lands under gpurun_out/r04/; tools/refresh_profiles_r04.py copies the
-# summaries into profiles/ (tag r04).  Pass a list of section names to run only those: legs e2e c5 trace_c5 trace_cfg pmc mb
+# summaries into profiles/ (tag r04) and rebuilds profiles/pmc_traffic.json.  Sections (pass names to run a subset):
+#   legs       `bench.py --workload c1..c4` (through CrossDomainTrainer.fit) + c3 with the literal dense Adam + c4 with the full last layer
+#   e2e        `bench.py --only-e2e`: fit() over SOURCE / TARGET / OVERLAP epochs + evaluate at the headline table sizes
+#   c5         the default command `python bench.py` (headline + every leg)
+#   trace_c5   rocprofv3 --kernel-trace --stats of `bench.py --headline-only`
+#   trace_cfg  rocprofv3 --kernel-trace --stats of `--workload c1|c2|c3` (graph replays) and of the CoNet full-sort leg
+#   pmc        --pmc FETCH_SIZE / WRITE_SIZE (own passes, --kernel-trace only) over the headline; MFMA-busy over the CoNet full-sort kernel
+#   mb         micro-benchmarks: cache-resident gather bandwidth, graph-launch gap
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04; mkdir -p $O
 cd $R
-W="${*:-legs e2e c5 trace_c5 trace_cfg}"
+W="${*:-legs e2e c5 trace_c5 trace_cfg pmc mb}"
 has() { [[ " $W " == *" $1 "* ]]; }
 if has legs; then
   for w in c1 c2 c3 c4; do python bench.py --workload $w --steps 200 --warmup 20 > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$?"; done
@@ -14,14 +21,25 @@ if has legs; then
 fi
 if has e2e; then python bench.py --only-e2e > $O/bench_e2e.json 2> $O/bench_e2e.err; echo "e2e rc=$?"; fi
 if has c5; then python bench.py > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"; fi
+if has mb; then
+  python tools/mb_cache_gather.py > $O/mb_cache_gather.txt 2>&1; echo "mb_cache_gather rc=$?"
+  python tools/mb_graph_gap.py > $O/graph_gap.txt 2>&1; echo "graph_gap rc=$?"
+fi
 cd /tmp && export TMPDIR=/tmp
 if has trace_c5; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5_headline -o trace -- python $R/bench.py --headline-only > $O/bench_c5_headline_under_rocprof.json 2> $O/trace_c5_headline.err; echo "trace c5 headline rc=$?"
 fi
 if has trace_cfg; then
   for Wl in c1 c2 c3; do
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$Wl -o trace -- python $R/bench.py --workload $Wl --no-cpu-baseline --steps 200 --warmup 20 > $O/bench_${Wl}_under_rocprof.json 2> $O/trace_$Wl.err; echo "trace $Wl rc=$?"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$Wl -o trace -- python $R/bench.py --workload $Wl --no-cpu-baseline --no-fullsort --steps 200 --warmup 20 > $O/bench_${Wl}_under_rocprof.json 2> $O/trace_$Wl.err; echo "trace $Wl rc=$?"
   done
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fullsort_conet -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 20 --warmup 2 > $O/bench_fullsort_conet_under_rocprof.json 2> $O/trace_fullsort_conet.err; echo "trace fullsort conet rc=$?"
+fi
+if has pmc; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o pmc -- python $R/bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --single-stream --steps 3 --warmup 1 > $O/bench_pmc_$C.json 2> $O/pmc_$C.err; echo "pmc $C rc=$?"
+  done
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_conet_fullsort -o pmc -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 20 --warmup 2 > $O/bench_c3_under_pmc.json 2> $O/pmc_mfma_conet_fullsort.err; echo "pmc mfma conet fullsort rc=$?"
 fi
 find $O -name "*kernel_trace.csv" -size +6M -delete
 find $O -name "*counter_collection.csv" -size +24M -delete

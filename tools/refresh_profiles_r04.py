@@ -53,7 +53,7 @@ names = {'bpr_fwd_apply_kernel': find('bpr_fwd_apply_kernel<32'), 'batch_norms_k
          'bpr_fwd_kernel': find('bpr_fwd_kernel<32'), 'bpr_fwd_kmajor_kernel(k=4)': find('bpr_fwd_kmajor_kernel<32, 4, 2>'),
          'map_step_kernel': find('map_pipe_kernel') or find('map_step_kernel')}
 o = {'_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of `python bench.py --no-cpu-baseline --no-fullsort '
-              '--no-config-legs --steps 3 --warmup 1`, tools/profile_r04.sh; B = 1,048,576 triples per domain, D = 128, row-wise Adam). FETCH_SIZE x 1024 x 2 '
+              '--no-config-legs --no-e2e --single-stream --steps 3 --warmup 1`, tools/profile_r04.sh; B = 1,048,576 triples per domain, D = 128, row-wise Adam). FETCH_SIZE x 1024 x 2 '
               '(gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024. Mean over each kernel\'s first 8 dispatches = the '
               'headline batch (1 warm-up + 3 timed steps x 2 domains). `domain_step` = batch norms + sort + flags + forward/optimizer + both duplicate-row '
               'applies (the sort\'s share: all make_keys / rocPRIM dispatches of the run divided by its number of sorts).',
