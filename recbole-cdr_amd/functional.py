@@ -917,6 +917,10 @@ class ConetFusedLoss(Function):
                 ws.numel() if train else 0, ctypes.byref(done))
         ctx.save_for_backward(ids, label, x0, acts, prob, maskf, out, *params)
         ctx.data_done = (gz, gx0, ws) if done.value else None
+        if row_opt is not None:
+            # the per-occurrence gradient rows of a unit upstream gradient exist already (the forward launch ran the data backward): a
+            # pipelined captured step may launch the row update now (lazyadam.DeferredRowAdam.apply_early)
+            row_opt.early = (gx0, (0, D, 2 * D, 3 * D), 4 * D) if done.value else None
         ctx.meta = (int(n_source), tuple(int(d) for d in dims), aw.value, int(need.value), tuple(su.shape), tuple(si.shape))
         ctx.row_opt = row_opt
         ctx.mark_non_differentiable(out)

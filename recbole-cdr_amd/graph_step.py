@@ -18,6 +18,10 @@ import torch
 from .data.interaction import Interaction
 
 
+def dev_of(interaction):
+    return next(iter(interaction.values())).device
+
+
 def step_and_sum(optimizer, loss, loss_sum):
     """``optimizer.step()`` + ``loss_sum += loss``.  trainer.DenseAdam does the addition inside its own counter launch (``loss_pair``);
     with any other optimizer -- or when no parameter had a gradient -- it is one elementwise launch here."""
@@ -32,7 +36,8 @@ def step_and_sum(optimizer, loss, loss_sum):
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, example_interaction=None, warmup=3, restore_after_warmup=True, producer=None, loss_sum=None, unroll=1):
+    def __init__(self, model, optimizer, example_interaction=None, warmup=3, restore_after_warmup=True, producer=None, loss_sum=None, unroll=1,
+                 pipeline=True):
         """``restore_after_warmup``: the warm-up runs REAL steps on ``example_interaction`` (every lazily created buffer, native context
         and optimizer state must exist before the capture); with True the parameters and the optimizer state are put back afterwards,
         so swapping the eager loop for the graphed one does not add ``warmup`` extra updates on batch 0."""
@@ -64,6 +69,8 @@ class GraphedTrainStep:
         # for ~5-9 us (measured: profiles/r04_graph_gap.txt) -- a fifth of a 40 us step at the reference's default batch; ``replay_many``
         # pays it once per ``unroll`` steps.
         self.unroll = int(unroll) if producer is not None else 1
+        self.pipeline = bool(pipeline)       # (False: the unrolled graph keeps the plain launch order -- A/B runs and tests)
+        self._side2 = torch.cuda.Stream(device=dev) if producer is not None else None
         self.graph = None
         self.graph_k = None
         self.loss = None
@@ -90,6 +97,49 @@ class GraphedTrainStep:
             self.producer.launch()
         return self._eager(self.static)
 
+    def _can_pipeline(self):
+        return (self.producer is not None and self.unroll > 1 and hasattr(self.model, 'prepare_batch')
+                and hasattr(self.model, 'apply_rows_early') and getattr(self.optimizer, 'row_opt', None) is not None
+                and self.pipeline)
+
+    def _whole_many(self, k):
+        """``k`` consecutive steps.  With a model that offers ``prepare_batch`` / ``apply_rows_early`` (CoNet on the deferred Adam) the
+        steps are SOFTWARE-PIPELINED over two streams: behind step i's forward launch the side stream runs {row update of step i ->
+        produce batch i+1 -> its id sort -> the replay of its rows' postponed updates} while the main stream runs {weight gradients ->
+        their reduction -> dense Adam of the tower weights}; they join before step i+1's forward.  The same launches on the same operands
+        as the plain order (only independent launches overlap): bit-identical results.  Dependencies: the producer overwrites the batch
+        buffers after the forward that read them (the backward works on the forward's own copies); the next batch's replay comes
+        after this batch's row update on the same stream; the next forward needs both branches."""
+        if not self._can_pipeline():
+            loss = None
+            for _ in range(k):
+                loss = self._whole()
+            return loss
+        main, side = torch.cuda.current_stream(), self._side2
+        self.producer.launch()
+        self.model.prepare_batch(self.static)
+        loss = None
+        for i in range(k):
+            self.optimizer.zero_grad(set_to_none=True)
+            losses = self.model.calculate_loss(self.static)
+            loss = sum(losses) if isinstance(losses, tuple) else losses
+            if loss.dim():
+                loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ahead = bool(self.model.apply_rows_early())
+                if ahead and i + 1 < k:
+                    self.producer.launch()
+                    self.model.prepare_batch(self.static)
+            loss.backward(self._one)
+            loss = loss.detach()
+            step_and_sum(self.optimizer, loss, self.loss_sum)
+            main.wait_stream(side)
+            if not ahead and i + 1 < k:                      # the row update could not run early: the next batch waits for it
+                self.producer.launch()
+                self.model.prepare_batch(self.static)
+        return loss
+
     def _capture(self, warmup):
         # populate .grad and the optimizer state (and every lazily created native context) before capture
         side = torch.cuda.Stream()
@@ -110,10 +160,21 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._whole()
         if self.unroll > 1:
+            if self._can_pipeline():
+                # the pipelined order once eagerly (on the capture stream): the side stream's native context must exist before a capture
+                # uses it, and the state it moves is put back like the warm-up's
+                snap2 = self._snapshot() if self.restore_after_warmup else None
+                with torch.cuda.stream(side):
+                    with torch.cuda.stream(self._side2):
+                        from . import binding as B_
+                        B_.ctx(dev_of(self.static))
+                    self._whole_many(2)
+                torch.cuda.synchronize()
+                if snap2 is not None:
+                    self._restore(snap2)
             self.graph_k = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_k, stream=side):
-                for _ in range(self.unroll):
-                    self._whole()
+                self._whole_many(self.unroll)
 
     # ---- warm-up without side effects: in-place snapshot / restore (addresses must not change: the capture follows) -------------
     def _state_tensors(self):

@@ -40,6 +40,12 @@ class DeferredRowAdam:
         self._sorted = None
         self._bufs = {}
         self.pending = None              # (G tensor, [column offset per table], ld) stashed by the model's backward
+        # software pipelining of an unrolled captured step (graph_step.GraphedTrainStep): ``early`` = the same triple, available as soon as
+        # the model's FORWARD launch has produced the per-occurrence gradient rows (CoNet: conet_fb_kernel, for a unit upstream gradient);
+        # ``apply_early()`` launches the update then, and the ``step()`` that follows the backward only does the bookkeeping
+        self.early = None
+        self._applied_early = False
+        self._prepared = None            # id of the batch ``prepare`` last ran for (``prepare_once``)
 
     # ---- id sort (per list): the small rank sort up to 16,384 ids, the radix sort above --------------------------------------
     def _sort(self, id_lists):
@@ -96,10 +102,33 @@ class DeferredRowAdam:
         del keep
 
     @torch.no_grad()
+    def apply_early(self):
+        """The update of ``step()`` launched right behind the forward pass (``self.early`` set by the model's forward): valid only when
+        the upstream gradient of the loss is exactly 1, which ``GraphedTrainStep`` guarantees (``loss.backward(ones)``)."""
+        if self.early is None:
+            return False
+        self.pending, self.early = self.early, None
+        self._launch_apply()
+        self._applied_early = True
+        return True
+
+    @torch.no_grad()
     def step(self):
         """After the backward pass: the coming update for the batch's rows (``self.pending`` set by the model's backward)."""
+        self.early = None
+        if self._applied_early:                      # launched by apply_early(): the backward's stash is the same rows again
+            self._applied_early = False
+            self.pending = None
+            if not torch.cuda.is_current_stream_capturing():
+                self.on_replay()
+            return
         if self.pending is None:
             return
+        self._launch_apply()
+        if not torch.cuda.is_current_stream_capturing():     # a capture only records the launches: replays do the bookkeeping
+            self.on_replay()
+
+    def _launch_apply(self):
         G, cols, ld = self.pending
         self.pending = None
         per = [self._sorted[j] for j in self.table_list]
@@ -111,8 +140,6 @@ class DeferredRowAdam:
                 (ctypes.c_int64 * nT)(*([int(ld)] * nT)), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp),
                 self.capacity, B_.i64(self.counters))
         del keep
-        if not torch.cuda.is_current_stream_capturing():     # a capture only records the launches: replays do the bookkeeping
-            self.on_replay()
 
     def on_replay(self):
         """Host bookkeeping of one completed update (also called after a hipGraph replay of prepare + step)."""

@@ -106,6 +106,24 @@ class CoNet(CrossDomainRecommender):
     def graph_key(self):
         return ('CoNet', self.fused_towers, self.row_opt is not None)
 
+    # ---- hooks for a software-pipelined captured step (graph_step.GraphedTrainStep) ---------------------------------------------------
+    def prepare_batch(self, interaction):
+        """The part of ``calculate_loss`` that needs only the batch's ids and the row update of the PREVIOUS step: the id sort and the
+        replay of the rows' postponed Adam updates.  ``calculate_loss`` on the same interaction object then skips it.  Returns False when
+        there is nothing to run ahead (no deferred optimizer)."""
+        if self.row_opt is None or not self.fused_towers:
+            return False
+        su, si = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID]
+        tu, ti = interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID]
+        self.row_opt.prepare([(su, tu), (si, ti)])
+        self.row_opt._prepared = id(interaction)
+        return True
+
+    def apply_rows_early(self):
+        """Right behind ``calculate_loss`` of a step whose loss will be differentiated with a unit upstream gradient: launch the
+        tables' row update now (the forward launch already produced its gradient rows)."""
+        return self.row_opt is not None and self.row_opt.apply_early()
+
     def calculate_loss(self, interaction):
         # source_forward(source batch) and target_forward(target batch) both run BOTH towers (conet.py:186-187); every
         # op is row-independent, so the two batches go through the cross units as ONE stack of rows and each output unit
@@ -119,8 +137,10 @@ class CoNet(CrossDomainRecommender):
             over_users = self.mode == 'overlap_users'
             row_opt = self.row_opt if (self.row_opt is not None and torch.is_grad_enabled()) else None
             if row_opt is not None:
-                # the batch's rows replay their postponed Adam updates before they are read
-                row_opt.prepare([(su, tu), (si, ti)])
+                # the batch's rows replay their postponed Adam updates before they are read (unless prepare_batch ran ahead for this batch)
+                if row_opt._prepared != id(interaction):
+                    row_opt.prepare([(su, tu), (si, ti)])
+                row_opt._prepared = None
             else:
                 self.sync_tables()
             loss, self.last_loss_parts = F_.ConetFusedLoss.apply(

@@ -164,6 +164,8 @@ class Trainer:
             and not self.clip_grad_norm
         # steps per graph launch on a device loader (the idle time between two graph launches is ~5-9 us: amortised over this many steps)
         self.graph_unroll = int(config['graph_unroll']) if 'graph_unroll' in config else 8
+        # ... and, for models that can run part of the next step ahead (CoNet on the deferred Adam), those steps software-pipelined over two streams
+        self.graph_pipeline = bool(config['graph_pipeline']) if 'graph_pipeline' in config else True
         self._graphs = {}
         self._loss_sum = None
         self.graph_stats = {'replayed': 0, 'eager': 0, 'captures': 0}
@@ -200,7 +202,7 @@ class Trainer:
             from ..graph_step import GraphedTrainStep
             try:
                 gs = GraphedTrainStep(self.model, self.optimizer, example, producer=producer, loss_sum=self._loss_sum,
-                                      unroll=self.graph_unroll)
+                                      unroll=self.graph_unroll, pipeline=self.graph_pipeline)
                 self.graph_stats['captures'] += 1
             except Exception as e:                                      # noqa: BLE001 -- reported, and the eager loop still trains
                 import warnings

@@ -24,6 +24,7 @@ if has c5; then python bench.py > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 
 if has mb; then
   python tools/mb_cache_gather.py > $O/mb_cache_gather.txt 2>&1; echo "mb_cache_gather rc=$?"
   python tools/mb_graph_gap.py > $O/graph_gap.txt 2>&1; echo "graph_gap rc=$?"
+  hipcc --offload-arch=gfx950 -O3 tools/mb_cache_bw.hip -o /tmp/mb_cache_bw && /tmp/mb_cache_bw > $O/mb_cache_bw.txt 2>&1; echo "mb_cache_bw rc=$?"
 fi
 cd /tmp && export TMPDIR=/tmp
 if has trace_c5; then

@@ -11,7 +11,7 @@ for w in ('c5_headline', 'c1', 'c2', 'c3', 'fullsort_conet'):
     ks = glob.glob(os.path.join(out, f'trace_{w}', '**', '*kernel_stats.csv'), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(prof, f'{tag}_bench_{w}_kernel_stats.csv'))
-for t in ('mb_cache_gather', 'graph_gap', 'mb_models5', 'mb_mapstep', 'gputests'):
+for t in ('mb_cache_gather', 'mb_cache_bw', 'graph_gap', 'mb_models5', 'mb_mapstep', 'gputests'):
     f = os.path.join(out, t + '.txt')
     if os.path.exists(f):
         txt = [l for l in open(f).read().splitlines() if 'amdgpu.ids' not in l]
