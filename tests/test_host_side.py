@@ -275,3 +275,52 @@ def test_history_matrix_builder_bit_exact(session):
         got = history_matrix(u, i, 300, 200, row, 'cpu')
         for a, b in zip(got, want):
             np.testing.assert_array_equal(a.numpy(), b.numpy())
+
+
+# ---- round 4 host logic ---------------------------------------------------------------------------------------------------------------
+def test_interaction_update_keeps_the_k_major_hint_only_when_both_sides_agree():
+    """merging a k-major batch into rows WITHOUT the hint (or with another k) must not mark the mixture k-major; an empty
+    Interaction adopts the other side's hint; equal hints survive (the BOTH-mode merge of two pairwise loaders with the same k)."""
+    from recbole_cdr_amd.data.interaction import Interaction
+    a = Interaction({'x': torch.arange(4)}); a.k_major = 2
+    b = Interaction({'y': torch.arange(4)}); b.k_major = 2
+    assert a.update(b).k_major == 2
+    c = Interaction({'x': torch.arange(4)})                           # rows without a hint
+    assert c.update(b).k_major is None
+    d = Interaction({'x': torch.arange(4)}); d.k_major = 3
+    assert d.update(b).k_major is None
+    assert Interaction().update(b).k_major == 2                       # nothing there yet: adopt
+    e = Interaction({'x': torch.arange(4)}); e.k_major = 2
+    assert e.update(Interaction({'z': torch.arange(4)})).k_major is None
+
+
+def test_domain_loader_pin_shuffles_in_place_with_the_same_permutation():
+    """DomainTrainLoader.pin() (what a captured batch producer needs: fixed addresses): an epoch shuffle permutes the columns IN PLACE
+    with the permutation the un-pinned loader would have applied, and the caller's tensors are left alone."""
+    from recbole_cdr_amd.data import DomainTrainLoader
+    from recbole_cdr_amd.utils import InputType
+    u, i = torch.arange(100), torch.arange(100) * 7
+    smp = lambda uu, ii, k: torch.zeros(uu.numel() * k, dtype=torch.int64)
+    mk = lambda: DomainTrainLoader({'u': u.clone(), 'i': i.clone()}, 'u', 'i', 'l', 'neg_', 16, 1, InputType.PAIRWISE, smp, shuffle=True,
+                                   generator=torch.Generator().manual_seed(5))
+    a, b = mk(), mk()
+    src = a.inter['u']
+    b.pin()
+    addr = b.inter['u'].data_ptr()
+    for _ in range(3):
+        iter(a); iter(b)
+        assert torch.equal(a.inter['u'], b.inter['u']) and torch.equal(a.inter['i'], b.inter['i'])
+        assert torch.equal(b.inter['i'], b.inter['u'] * 7) and b.inter['u'].data_ptr() == addr
+    assert torch.equal(src, torch.arange(100)) or a.inter['u'] is not src
+
+
+def test_trainer_row_shard_keeps_the_k_major_hint_only_when_every_field_divides():
+    """Trainer._my_rows checks EVERY field's length (BOTH-mode batches carry columns of two lengths)."""
+    from recbole_cdr_amd.data.interaction import Interaction
+    from recbole_cdr_amd.trainer.trainer import Trainer
+    t = Trainer.__new__(Trainer)
+    t.__dict__['_row_group'] = (1, 2)                                  # rank 1 of 2, no process group needed
+    ok = Interaction({'a': torch.arange(8), 'b': torch.arange(8)}); ok.k_major = 2
+    assert t._my_rows(ok).k_major == 2
+    bad = Interaction({'a': torch.arange(8), 'b': torch.arange(10)}); bad.k_major = 2   # 10 / 2 = 5 positives: not divisible by 2 ranks
+    assert t._my_rows(bad).k_major is None
