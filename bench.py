@@ -740,6 +740,23 @@ def run_c5(args, world, rank, dev):
                 top = int(torch.bincount(gb_[0][1] - (1 + TOI)).max()) if zipf else None
                 grid[name] = {'rows_per_domain_step': nb, 'ms_per_domain_step': ms_g, 'rows_per_s': nb / (ms_g * 1e-3),
                               'frac_of_hbm_peak_at_9216_B_per_triple': nb * 3 * 6 * 4 * D / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if getattr(gs, 'device_counts', False):
+                    # the same step replayed as a hipGraph (update counts on the device: cdr_bpr_step_fused_dev) -- what CrossDomainTrainer's
+                    # rowwise loop does on a device loader: the ~20 launches of a step without their launch gaps
+                    side_ = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(side_):
+                        gs.step(*gb_[0])
+                    torch.cuda.synchronize()
+                    cg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cg, stream=side_):
+                        gs.step(*gb_[0])
+
+                    def rep(*_a):
+                        cg.replay(); gs.replayed()
+                    ms_r = timed(rep, gb_, n=40 if nb < B else 20)
+                    grid[name]['hipgraph_ms_per_domain_step'] = ms_r
+                    grid[name]['hipgraph_frac_of_hbm_peak_at_9216_B_per_triple'] = nb * 3 * 6 * 4 * D / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    del cg
                 if top is not None:
                     grid[name]['occurrences_of_hottest_item'] = top
                 del gs, gb_

@@ -558,6 +558,16 @@ int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, flo
                        float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item, float* out9,
                        float* GU /* [B,D] */, float* GP /* [B,D] */, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
                        void* sort_ws, size_t sort_ws_bytes);
+/* The same step (Adam) with the tables' update counts in DEVICE memory: *step_user_dev / *step_item_dev hold the counts BEFORE the call
+ * and are advanced by it; hp_dev: 4 floats of caller-owned device scratch for the Adam scalars derived from them.  Nothing about the update
+ * number is baked into the launches: the call can be captured in a hipGraph and replayed (emcdr.py:110-154 under recbole's step loop,
+ * one graph launch per batch). */
+int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                           float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                           const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
+                           float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                           void* sort_ws, size_t sort_ws_bytes);
 /* ... and on recbole's pairwise batch layout (S positives tiled k times, k-major negatives: crossdomain_sampler.py:148-152): one
  * lane group per positive, u and p gathered once; uid / pid [S], nid [S k]; the loss, the per-row gradients and the update are
  * those of cdr_bpr_step_fused on the B = S k tiled rows.  GU [S, D]; GI [S + S k, D] (gradient rows of the duplicate item

@@ -237,7 +237,10 @@ constexpr int kPiece = 256;
 struct seg_long { int64_t head, len, base; };           // sorted position of the head, occurrences, first piece index
 struct seg_piece { int64_t start; int64_t len; };
 
-struct apply_hp { float lr, b1, b2, eps, wd, step_size, bc2_sqrt; };
+// dev (optional): {step_size, bc2_sqrt} in DEVICE memory, written earlier on the stream from device-resident update counts
+// (coef_finish_kernel) -- the capturable form of the step: a hipGraph replay must not bake the update number into its launches.
+struct apply_hp { float lr, b1, b2, eps, wd, step_size, bc2_sqrt; const float* dev; };
+#define HP_FROM_DEV(h) do { if ((h).dev) { (h).step_size = (h).dev[0]; (h).bc2_sqrt = (h).dev[1]; } } while (0)
 
 template <int OPT>
 __device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __restrict__ mp, float* __restrict__ vp, float4 w,
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
                                                                apply_hp hp, const int64_t* __restrict__ occ_ids,
                                                                unsigned* __restrict__ counters, seg_long* __restrict__ longs,
                                                                seg_piece* __restrict__ pieces) {
+    HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(float* __restri
                                                                  const unsigned* __restrict__ counters,
                                                                  const seg_long* __restrict__ longs,
                                                                  const float* __restrict__ partial, const int* __restrict__ pcnt) {
+    HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
@@ -590,9 +595,20 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
 // out9[4], out9[5] = reg_weight / (B * ||rows||) from batch_norms_kernel's partial sums (0 when there is no EmbLoss or the norm is 0)
 // (k-major batches: the partials are sums over the S positives, every one of which stands for k rows of the batch -- the norm is taken
 // over B = S k rows and the coefficient is handed out pre-multiplied by k, per S-list occurrence)
+// step_dev (optional; the capturable step): {user table's, item table's} update counts in device memory -- advanced here, and the Adam
+// scalars of the new counts left in hp_dev[0..3] = {step_size_u, bc2_sqrt_u, step_size_i, bc2_sqrt_i} for the kernels behind (apply_hp::dev)
 __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
-                                                             float reg_weight, float* __restrict__ out9, int kmul = 1) {
+                                                             float reg_weight, float* __restrict__ out9, int kmul = 1,
+                                                             int64_t* __restrict__ step_u_dev = nullptr, int64_t* __restrict__ step_i_dev = nullptr,
+                                                             float* __restrict__ hp_dev = nullptr, float lr = 0.f, float b1 = 0.f, float b2 = 0.f) {
     __shared__ double smem[2 * (kBlock / 64)];
+    if (hp_dev && threadIdx.x < 2) {
+        int64_t* c = threadIdx.x == 0 ? step_u_dev : step_i_dev;
+        const int64_t st = c[0] + 1;
+        c[0] = st;
+        hp_dev[2 * threadIdx.x] = (float)((double)lr / (1.0 - pow((double)b1, (double)st)));
+        hp_dev[2 * threadIdx.x + 1] = (float)sqrt(1.0 - pow((double)b2, (double)st));
+    }
     double acc[2] = {0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
         const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
@@ -632,6 +648,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
                                                                const float* __restrict__ coef, apply_hp hu, apply_hp hi,
                                                                float* __restrict__ GU, float* __restrict__ GP,
                                                                double* __restrict__ partials) {
+    HP_FROM_DEV(hu); HP_FROM_DEV(hi);
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
     const int sub = threadIdx.x % LPR;
@@ -752,6 +769,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs T
                                                                       float gamma, float invB, const float* __restrict__ coef,
                                                                       apply_hp hu, apply_hp hi, float* __restrict__ GU,
                                                                       float* __restrict__ GI, double* __restrict__ partials) {
+    HP_FROM_DEV(hu); HP_FROM_DEV(hi);
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
     const int sub = threadIdx.x % LPR;
@@ -847,6 +865,7 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __res
                                                                     const float* __restrict__ reg_coef, apply_hp hp,
                                                                     unsigned* __restrict__ counters, seg_long* __restrict__ longs,
                                                                     seg_piece* __restrict__ pieces) {
+    HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     constexpr int SU = 4;                                 // segments in flight per lane group
     const int sub = threadIdx.x % LPR;
@@ -1260,19 +1279,16 @@ extern "C" int cdr_bpr_step_fused_heads_words(int64_t B, int64_t* words) {
     return CDR_OK;
 }
 
-extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
-                                  float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
-                                  const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
-                                  float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
-                                  float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                                  void* sort_ws, size_t sort_ws_bytes) {
-    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
-    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
-    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
-    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                               float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                               const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
+                               int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
+                               float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                               void* sort_ws, size_t sort_ws_bytes) {
     hipStream_t s = (hipStream_t)stream;
     const int lpr = cdr_lpr_for(D);
-    // ---- EmbLoss coefficients first (they do not need the sort): out9[4], out9[5]
+    // ---- EmbLoss coefficients first (they do not need the sort): out9[4], out9[5]  (+ the device-resident update counts, when given)
     if (reg_weight != 0.f) {
         const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
         {
@@ -1280,9 +1296,9 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
             DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, B, ctx->partials));
         }
         CDR_LAUNCH_CHECK();
-        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9);
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2);
     } else {
-        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9);
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2);
     }
     CDR_LAUNCH_CHECK();
     uint32_t key_base = 0;
@@ -1298,8 +1314,9 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
         occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, 4, flags, headsA, headsB, cnt);
     }
     CDR_LAUNCH_CHECK();
-    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
-    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    if (hp_dev && opt == 1) { hu.dev = hp_dev; hi.dev = hp_dev + 2; }          // the scalars coef_finish_kernel left on the device
     const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
     static const int un = [] { const char* e = getenv("CDR_FWD_APPLY_UN"); return (e && e[0] == '2') ? 2 : 1; }();   // A/B switch (tools/)
     const int grid = grid_for((B + un - 1) / un, kBlock / lpr);
@@ -1318,6 +1335,39 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
     if (rc) return rc;
     return apply_dups(ctx, s, opt, item_tab, item_m, item_v, D, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base,
                       CDR_TAG_APPLY_SIGNED);
+}
+
+extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                                  float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                                  const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
+                                  float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                                  void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    return bpr_step_fused_impl(ctx, stream, opt, user_tab, user_m, user_v, user_rows, item_tab, item_m, item_v, item_rows, D, uid, pid, nid, B, gamma,
+                               reg_weight, lr, beta1, beta2, eps, weight_decay, step_user, step_item, nullptr, nullptr, nullptr, out9, GU, GP,
+                               keys, perm, flags, heads, sort_ws, sort_ws_bytes);
+}
+
+// The same step with the tables' update counts in DEVICE memory (int64 each, advanced by the call's first finishing block) and the Adam
+// scalars derived from them on the device (hp_dev: 4 floats of scratch owned by the caller): nothing about the update number is baked
+// into the launches, so the call can be captured in a hipGraph and replayed.
+extern "C" int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                                      float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid,
+                                      const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
+                                      float beta1, float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev,
+                                      float* hp_dev, float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags,
+                                      uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 1 && user_m && user_v && item_m && item_v && step_user_dev && step_item_dev && hp_dev);
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    return bpr_step_fused_impl(ctx, stream, opt, user_tab, user_m, user_v, user_rows, item_tab, item_m, item_v, item_rows, D, uid, pid, nid, B, gamma,
+                               reg_weight, lr, beta1, beta2, eps, weight_decay, 1, 1, step_user_dev, step_item_dev, hp_dev, out9, GU, GP,
+                               keys, perm, flags, heads, sort_ws, sort_ws_bytes);
 }
 
 

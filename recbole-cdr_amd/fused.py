@@ -58,7 +58,7 @@ class FusedBPRStep:
     """One object per (user table, item table) pair; buffers are sized for ``max_batch`` triples and reused."""
 
     def __init__(self, user_table, item_table, max_batch, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True):
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True, device_counts=True):
         assert user_table.is_cuda and item_table.is_cuda, 'FusedBPRStep needs ROCm device tensors'
         assert user_table.shape[1] == item_table.shape[1]
         self.U, self.I = user_table, item_table
@@ -87,6 +87,10 @@ class FusedBPRStep:
         self._key_base = ctypes.c_uint32(0)
         # single-occurrence rows updated by the forward kernel (cdr_bpr_step_fused): D <= 256 like cdr_bpr_fwd_grad
         self.fuse_singles = bool(fuse_singles) and self.D % 4 == 0 and self.D <= 256 and os.environ.get('CDR_FUSE_SINGLES', '1') != '0'   # env: A/B runs
+        # Adam update counts on the device (cdr_bpr_step_fused_dev): the step can then be captured in a hipGraph (``replayed`` keeps the
+        # host mirrors in step); the host-count form stays available (device_counts=False: the sharded layouts drive it)
+        self.device_counts = bool(device_counts) and self.fuse_singles
+        self._hp_dev = None
         if self.fuse_singles:
             words = ctypes.c_int64(0)
             B_._check(B_.load().cdr_bpr_step_fused_heads_words(Bm, ctypes.byref(words)), 'cdr_bpr_step_fused_heads_words')
@@ -108,6 +112,21 @@ class FusedBPRStep:
         """Batch norms and sort first, then ONE pass that also applies the optimizer to every row occurring once in the batch; the
         segmented applies see the duplicate rows only (csrc/cdr_step.hip, "single-occurrence rows in the forward")."""
         us, its = self.ustate, self.istate
+        if self.opt == OPT_ADAM and self.device_counts:
+            # the capturable form: the update counts live on the device and the call advances them itself (the host mirrors follow)
+            if self._hp_dev is None:
+                self._hp_dev = torch.zeros(4, device=self.U.device, dtype=torch.float32)
+            su, si = us.step_dev, its.step_dev
+            B_.call('cdr_bpr_step_fused_dev', B_.ctx(self.U.device), B_.stream(), self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
+                    B_.f32(us.exp_avg_sq), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq),
+                    its.table.shape[0], self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), B, float(self.gamma),
+                    float(self.reg_weight), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+                    B_.i64(su), B_.i64(si), B_.f32(self._hp_dev), B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GP), B_.raw(self.keys),
+                    B_.raw(self.perm), B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes)
+            if not torch.cuda.is_current_stream_capturing():
+                us.advance(device_bumped=True)
+                its.advance(device_bumped=True)
+            return self.out6
         us.advance()
         its.advance()
         B_.call('cdr_bpr_step_fused', B_.ctx(self.U.device), B_.stream(), self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
@@ -117,6 +136,12 @@ class FusedBPRStep:
                 us.step, its.step, B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GP), B_.raw(self.keys), B_.raw(self.perm),
                 B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes)
         return self.out6
+
+    def replayed(self, n=1):
+        """Host bookkeeping of ``n`` hipGraph replays of ``step`` (device_counts form): the update counts' host mirrors."""
+        for _ in range(n):
+            self.ustate.advance(device_bumped=True)
+            self.istate.advance(device_bumped=True)
 
     def sort_apply(self, uid, pid, nid):
         """Second half of the step: GU / GP / out6[4:6] are in place (written by the forward kernel); one sort for both tables,
@@ -457,8 +482,9 @@ class FusedMapStep:
                 ptrs(vb), ptrs(sW), ptrs(sb), B_.i64(ss), B_.i64(ts_), float(self.lr), float(self.betas[0]), float(self.betas[1]),
                 float(self.eps), float(self.wd), B_.f32(self._loss1), B_.raw(self._uws), self._uws.numel())
         del keep
-        self.sstate.advance(device_bumped=True)
-        self.tstate.advance(device_bumped=True)
+        if not torch.cuda.is_current_stream_capturing():       # (a capture enqueues nothing: the host counts advance per replay)
+            self.sstate.advance(device_bumped=True)
+            self.tstate.advance(device_bumped=True)
         self.loss = self._loss1[0]
         return self.loss
 

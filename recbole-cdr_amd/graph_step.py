@@ -248,3 +248,46 @@ class GraphedTrainStep:
         keys = list(self.static)
         torch._foreach_copy_([self.static[k] for k in keys], [interaction[k] for k in keys])      # one launch per dtype, not one per field
         return self.replay()
+
+
+class GraphedRowwiseStep:
+    """The rowwise counterpart (optimizer_mode='rowwise': tables too large for dense gradients): {device batch producer ->
+    ``model.fused_train_step`` -> loss total} x ``unroll`` captured as one hipGraph.  There is no warm-up to undo -- at 72 GB of tables
+    nothing can be snapshotted -- so the caller runs its first real steps of the phase through ``eager()`` (on this object's stream: the
+    native contexts and every lazily created buffer then exist where the capture needs them) and only then calls ``capture()``, which
+    executes nothing.  The model keeps its host-side update counts in step through ``model.fused_replayed(n)``."""
+
+    def __init__(self, model, producer, loss_sum, step_kwargs, unroll=4):
+        self.model, self.producer, self.loss_sum, self.kw, self.unroll = model, producer, loss_sum, dict(step_kwargs), int(unroll)
+        self.side = torch.cuda.Stream(device=dev_of(producer.fields))
+        self.graph = self.graph_k = None
+        self.eager_steps = 0
+
+    def _one(self):
+        self.producer.launch()
+        loss = self.model.fused_train_step(self.producer.fields, **self.kw)
+        self.loss_sum.add_(loss.detach().reshape(()))
+
+    def eager(self):
+        """One real step on the capture stream (ordered with the caller's stream on both sides)."""
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self._one()
+        cur.wait_stream(self.side)
+        self.eager_steps += 1
+
+    def capture(self):
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.side):
+            self._one()
+        if self.unroll > 1:
+            self.graph_k = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_k, stream=self.side):
+                for _ in range(self.unroll):
+                    self._one()
+
+    def replay(self, many=False):
+        (self.graph_k if many else self.graph).replay()
+        self.model.fused_replayed(self.unroll if many else 1)

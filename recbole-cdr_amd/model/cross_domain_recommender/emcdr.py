@@ -196,6 +196,36 @@ class EMCDR(CrossDomainRecommender):
             cache['steps'][key] = step
         return step.step(user, item, neg)[0]
 
+    def fused_graph_key(self, interaction):
+        """Hashable tag of the launches ``fused_train_step(interaction)`` would make, or None when they must not be captured in a
+        hipGraph: capturable are the per-triple BPR step (update counts on the device: cdr_bpr_step_fused_dev) and the distinct-id
+        OVERLAP step; the MF steps and the per-positive forms read host-side update counts."""
+        if self._dist_group() is not None:
+            return None
+        if self.phase == 'OVERLAP':
+            return ('map', self.mode) if getattr(self, 'overlap_ids_unique', True) and self.map_func in ('linear', 'non_linear') else None
+        if self.latent_factor_model == 'MF':
+            return None
+        domain = 'source' if self.phase == 'SOURCE' else 'target'
+        k = getattr(interaction, 'k_major', None)
+        rows = interaction[getattr(self, f'{domain.upper()}_USER_ID')].numel()
+        if k is not None and rows % k == 0 and (k >= 2 or rows + rows // k <= 8192):
+            return None                                        # per-positive forms (fused.KMajorBPRStep)
+        return ('bpr', domain, rows)
+
+    def fused_replayed(self, n=1):
+        """Host bookkeeping of ``n`` hipGraph replays of the current phase's ``fused_train_step`` (the update counts' host mirrors)."""
+        cache = self.__dict__.get('_fused', {'steps': {}})
+        if self.phase == 'OVERLAP':
+            kind = 'user' if self.mode == 'overlap_users' else 'item'
+            st = cache['steps'].get(('map', kind))
+            for _ in range(n):
+                st.sstate.advance(device_bumped=True)
+                st.tstate.advance(device_bumped=True)
+            return
+        domain = 'source' if self.phase == 'SOURCE' else 'target'
+        cache['steps'][('bpr', domain)].replayed(n)
+
     # ---- the same step over the GPUs of a node (config['dist_group']: a torch.distributed group, or True for WORLD) ----------
     _TABLES = ('source_user_embedding', 'source_item_embedding', 'target_user_embedding', 'target_item_embedding')
 

@@ -162,6 +162,9 @@ class Trainer:
         # switches it off.
         self.graph_step = bool(config['graph_step'] if 'graph_step' in config else True) and on_gpu and self.optimizer_mode == 'dense' \
             and not self.clip_grad_norm
+        # ... and rowwise mode on a device loader: {producer -> model.fused_train_step -> loss total} replayed where the model says its fused
+        # step is capturable (model.fused_graph_key)
+        self.graph_step_rowwise = bool(config['graph_step'] if 'graph_step' in config else True) and on_gpu and self.optimizer_mode == 'rowwise'
         # steps per graph launch on a device loader (the idle time between two graph launches is ~5-9 us: amortised over this many steps)
         self.graph_unroll = int(config['graph_unroll']) if 'graph_unroll' in config else 8
         # ... and, for models that can run part of the next step ahead (CoNet on the deferred Adam), those steps software-pipelined over two streams
@@ -320,7 +323,37 @@ class Trainer:
         self._loss_sum.zero_()
         it = iter(train_data)
         prod.resync()
+        # full batches of a capturable phase (model.fused_graph_key): the first two run eagerly on the capture stream -- real steps, they
+        # create every buffer and context the capture needs -- then {producer -> fused step -> loss total} is replayed, 4 steps per launch
+        gkey = self.model.fused_graph_key(prod.fields) if (self.graph_step_rowwise and hasattr(self.model, 'fused_graph_key')) else None
+        gs = None
+        if gkey is not None:
+            gkey = (gkey, getattr(train_data, 'state', None), id(prod))
+            gs = self._graphs.get(gkey)
+            if gs is None:
+                from ..graph_step import GraphedRowwiseStep
+                gs = self._graphs[gkey] = GraphedRowwiseStep(self.model, prod, self._loss_sum,
+                                                             dict(lr=self.learning_rate, weight_decay=self.weight_decay), unroll=4)
         while True:
+            if gs is not None and gs is not False and prod.full_ahead():
+                if gs.graph is None:
+                    if gs.eager_steps < 2:
+                        gs.eager(); prod.advance()
+                        continue
+                    try:
+                        gs.capture()
+                        self.graph_stats['captures'] += 1
+                    except Exception as e:                              # noqa: BLE001 -- reported, and the eager loop still trains
+                        import warnings
+                        warnings.warn(f'hipGraph capture of the rowwise step failed for {gkey!r} ({type(e).__name__}: {e}); running it eagerly')
+                        gs = self._graphs[gkey] = False
+                        prod.resync()
+                        continue
+                many = gs.graph_k is not None and prod.full_count() >= gs.unroll
+                gs.replay(many)
+                prod.advance(gs.unroll if many else 1)
+                self.graph_stats['replayed'] += gs.unroll if many else 1
+                continue
             if prod.full_ahead():
                 prod.launch()
                 prod.advance()

@@ -505,3 +505,44 @@ def test_conet_pipelined_unrolled_graph_is_bit_identical_to_the_plain_order():
         assert torch.equal(pp[k], ps[k]), k
     for a, b in zip(op['deferred_rows']['exp_avg'], os_['deferred_rows']['exp_avg']):
         assert torch.equal(a, b)
+
+
+def test_rowwise_trainer_on_replays_equals_the_eager_rowwise_loop():
+    """optimizer_mode='rowwise' on device loaders: the per-triple BPR step (update counts on the device: cdr_bpr_step_fused_dev) and the
+    distinct-id OVERLAP step replayed as hipGraphs -- {producer -> fused step -> loss total}, four steps per launch after two eager steps
+    -- against the same trainer with graph_step=False: same producer launches, same kernels: tables, moments, mapping, update counts and
+    epoch losses bit-equal."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.utils import InputType
+    ids = IdSpace(OU=3000, TOU=500, SOU=400, OI=1, TOI=2500, SOI=2200)
+    rng = np.random.RandomState(3)
+    src_u = np.r_[1:ids.OU, ids.OU + ids.TOU:ids.total_num_users]
+    s_pairs = np.unique(np.stack([rng.choice(src_u, 120000), rng.randint(ids.OI + ids.TOI, ids.total_num_items, 120000)], 1), axis=0)
+    t_pairs = np.unique(np.stack([rng.randint(1, ids.OU + ids.TOU, 120000), rng.randint(1, ids.OI + ids.TOI, 120000)], 1), axis=0)
+    rng.shuffle(s_pairs); rng.shuffle(t_pairs)
+    ds = FakeDataset(ids, s_pairs, t_pairs)
+    cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=32, target_embedding_size=32, reg_weight=0.01,
+                      mapping_function='linear', mlp_hidden_size=[24], learning_rate=0.01, train_modes=['SOURCE', 'TARGET', 'OVERLAP'],
+                      epoch_num=['2', '1', '2'], source_split=False, eval_step=0, epochs=2, optimizer_mode='rowwise')
+    outs = []
+    for graph in (True, False):
+        torch.manual_seed(3)
+        model = EMCDR(cfg, ds).to(DEV)
+        dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.PAIRWISE, 8192, 1, shuffle=True, ob=256)
+        trainer = CrossDomainTrainer(dict(cfg, graph_step=graph), model)
+        log = []
+        orig = trainer._train_epoch
+        trainer._train_epoch = lambda data, e, o=orig, l=log: (l.append(o(data, e)) or l[-1])
+        trainer.fit(dl)
+        torch.cuda.synchronize()
+        outs.append((log, {k: v.detach().clone() for k, v in model.named_parameters()}, model.fused_optimizer_state(), dict(trainer.graph_stats)))
+    (lg, pg, sg, stg), (le, pe, se, ste) = outs
+    assert stg['captures'] == 3 and stg['replayed'] > 20 and ste['replayed'] == 0
+    assert lg == le, (lg, le)
+    for k in pg:
+        assert torch.equal(pg[k], pe[k]), k
+    for name in sg['tables']:
+        assert sg['tables'][name]['step'] == se['tables'][name]['step'], name
+        assert torch.equal(sg['tables'][name]['exp_avg'], se['tables'][name]['exp_avg']), name
