@@ -18,6 +18,8 @@
 // Work: MFMA steps per (32 items x 1 user) = h1/2 + 4 ceil(d2/8) + 4 ceil(d3/8) (...): 56 x 64 cycles for [64,32,16,8] (75 % of the
 // executed MFMA flops are algorithmic: the 16- and 8-row layers use half / a quarter of a 32-row tile).  The VALU side (P + q, ReLU,
 // bias: ~135 instructions per tile-user) runs under the MFMAs of the SIMD's other wave.
+// (Tried: two users per pass, i.e. two independent accumulator chains per wave: 260 VGPRs -> one wave per SIMD instead of two, 0.57 ->
+//  0.47 of the fp32 MFMA peak at 64 users x 1 M items.  Two resident waves hide more than two chains in one.)
 #include "cdr_common.h"
 
 namespace {
