@@ -740,7 +740,7 @@ def run_c5(args, world, rank, dev):
                 top = int(torch.bincount(gb_[0][1] - (1 + TOI)).max()) if zipf else None
                 grid[name] = {'rows_per_domain_step': nb, 'ms_per_domain_step': ms_g, 'rows_per_s': nb / (ms_g * 1e-3),
                               'frac_of_hbm_peak_at_9216_B_per_triple': nb * 3 * 6 * 4 * D / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                if getattr(gs, 'device_counts', False):
+                if getattr(gs, 'device_counts', False) and nb <= 65536:         # (larger sorts are not replay-safe: EMCDR.fused_graph_key)
                     # the same step replayed as a hipGraph (update counts on the device: cdr_bpr_step_fused_dev) -- what CrossDomainTrainer's
                     # rowwise loop does on a device loader: the ~20 launches of a step without their launch gaps
                     side_ = torch.cuda.Stream(device=dev)
@@ -1334,7 +1334,8 @@ def e2e_leg(args, dev):
     cfg = {'source_domain': {'NEG_PREFIX': 'neg_'}, 'target_domain': {'NEG_PREFIX': 'neg_'}, 'device': dev, 'latent_factor_model': 'BPR',
            'source_embedding_size': args.dim, 'target_embedding_size': args.dim, 'reg_weight': 0.01, 'mapping_function': 'linear',
            'mlp_hidden_size': [128], 'learning_rate': 1e-3, 'optimizer_mode': 'rowwise', 'train_modes': ['SOURCE', 'TARGET', 'OVERLAP'],
-           'epoch_num': ['2', '2', '2'], 'source_split': False, 'eval_step': 0, 'epochs': 2, 'topk': [10], 'valid_metric': 'Recall@10'}
+           'epoch_num': ['2', '2', '2'], 'source_split': False, 'eval_step': 0, 'epochs': 2, 'topk': [10], 'valid_metric': 'Recall@10',
+           'graph_step': os.environ.get('CDR_E2E_GRAPH', '1') != '0'}
     torch.manual_seed(2022)
     with torch.device(dev):
         model = EMCDR(cfg, ds)                                   # 4 tables created (and xavier-initialised) on the device

@@ -211,6 +211,12 @@ class EMCDR(CrossDomainRecommender):
         rows = interaction[getattr(self, f'{domain.upper()}_USER_ID')].numel()
         if k is not None and rows % k == 0 and (k >= 2 or rows + rows // k <= 8192):
             return None                                        # per-positive forms (fused.KMajorBPRStep)
+        if rows > 65536:
+            # Above ~200 k keys rocPRIM sorts with its Onesweep configuration, whose temporary-storage resets do not survive a hipGraph
+            # replay on this ROCm (the same defect cdr_common.h records for hipMemsetAsync inside a captured step): the replayed sort
+            # hands the applies garbage positions -- an illegal access at B = 1,048,576, found by bench.py --only-e2e.  Nothing is lost:
+            # at these sizes the step is the sum of its kernels, a replay saves no time.
+            return None
         return ('bpr', domain, rows)
 
     def fused_replayed(self, n=1):
