@@ -73,6 +73,10 @@ class DeferredRowAdam:
                     (ctypes.c_int64 * m)(*[0 if b is None else b.numel() for _, b in pairs]), (ctypes.c_int64 * m)(*offs), B_.raw(keys),
                     B_.raw(perm), B_.raw(rank), rows)
         else:
+            if torch.cuda.is_current_stream_capturing() and max(ns) > 65536:
+                # rocPRIM's Onesweep configuration (above ~200 k keys) is not hipGraph-replay-safe on this ROCm (EMCDR.fused_graph_key has
+                # the story); refusing here makes the trainer's capture fail cleanly and the phase run eagerly
+                raise RuntimeError('DeferredRowAdam: id lists of %d entries need the radix sort, which must not be captured in a hipGraph' % max(ns))
             for (a, b), n, of in zip(pairs, ns, offs):
                 need = ctypes.c_size_t(0)
                 B_._check(B_.load().cdr_sort_workspace_bytes(n, rows, ctypes.byref(need)), 'cdr_sort_workspace_bytes')

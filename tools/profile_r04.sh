@@ -9,6 +9,7 @@
 #   pmc        --pmc FETCH_SIZE / WRITE_SIZE (own passes, --kernel-trace only) over the headline; MFMA-busy over the CoNet full-sort kernel
 #   mb         micro-benchmarks: cache-resident gather bandwidth, graph-launch gap
 set -u
+ulimit -c 0          # (a faulting kernel must not fill the box's disk with a GPU core dump: everything behind it would fail)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04; mkdir -p $O
 cd $R
