@@ -21,6 +21,7 @@ import json
 import os
 import sys
 import time
+T_START = time.perf_counter()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -1668,6 +1669,9 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == 'c5':
             result['cpu_baseline'] = cpu_baseline(args)
+        from recbole_cdr_amd import functional as F_
+        result['deterministic_backward'] = bool(F_.deterministic())      # CDR_DETERMINISTIC=1: the drop-in losses' dense gradients without float atomics
+        result['bench_wall_s'] = round(time.perf_counter() - T_START, 1)  # the whole invocation, imports and every leg included
         if real_stdout is not None:
             os.write(real_stdout, (json.dumps(result) + '\n').encode())
         else:
