@@ -1095,6 +1095,11 @@ def run_model_workload(args, world, rank, dev):
         phase = 'SOURCE' if pairwise else 'BOTH'
         tcfg = dict(cfg, learning_rate=1e-3, train_modes=[phase], epoch_num=['1'], epochs=1, eval_step=0, source_split=False,
                     graph_step=not args.no_graph, deferred_adam=not args.dense_adam)
+        if os.environ.get('CDR_GRAPH_PIPELINE'):               # A/B runs (tools/, tests): '0' plain order, 'two_ahead', '1' the default
+            gp = os.environ['CDR_GRAPH_PIPELINE']
+            tcfg['graph_pipeline'] = {'0': False, '1': True}.get(gp, gp)
+        if os.environ.get('CDR_GRAPH_UNROLL'):
+            tcfg['graph_unroll'] = int(os.environ['CDR_GRAPH_UNROLL'])
         trainer = CrossDomainTrainer(tcfg, model)
         opt = trainer.optimizer
         deferred = type(opt).__name__ == 'RowAwareAdam'
@@ -1118,7 +1123,7 @@ def run_model_workload(args, world, rank, dev):
         dt = time.perf_counter() - t0
         loss = torch.tensor(trainer.train_loss_dict[0] / args.steps)
         stats = {k_: trainer.graph_stats[k_] - warm[k_] for k_ in warm}
-        assert stats['replayed'] + stats['eager'] == args.steps, stats
+        assert args.no_graph or stats['replayed'] + stats['eager'] == args.steps, stats
     else:
         for i in range(args.warmup):
             one_step(i)
@@ -1143,6 +1148,13 @@ def run_model_workload(args, world, rank, dev):
                          'trainer_steps': None if trainer is None else dict(stats, warmup_steps_run=args.steps, optimizer=type(opt).__name__,
                                                                             timed='one fit() = one shuffled epoch of exactly --steps full batches, sampler + loader + step + loss read-back')},
               'final_loss': float(loss.sum())}
+    if world == 1 and trainer is not None:
+        # the trained state as exact fp64 sums (after the timed region): two invocations with the same flags must print the same digits
+        if hasattr(model, 'sync_tables'):
+            model.sync_tables()
+        with torch.no_grad():
+            result['state_checksum'] = {n_: repr(float(p_.detach().double().sum())) for n_, p_ in model.named_parameters()}
+            result['state_checksum']['abs_total'] = repr(float(sum(p_.detach().double().abs().sum() for p_ in model.parameters())))
     if attempts is not None:
         result['layout_fallback'] = {'used': 'rowshard' if rowshard is not None else 'replica-dp' if sdp is not None else 'replicas', 'attempts': attempts,
                                      'fell_back': len(attempts) > 1 or replicas}

@@ -134,7 +134,6 @@ __global__ __launch_bounds__(kBlock) void lz_prepare1_kernel(lz_args a, float2* 
     const lz_table tb = a.t[blockIdx.y];
     const int rows_per_block = kBlock / lanes_per_row;
     const int sub = threadIdx.x % lanes_per_row;
-    const int64_t gg = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
     const int64_t TG = (int64_t)gridDim.x * rows_per_block;
     const int D = a.D;
     const int64_t t = counters[0] + 1;
@@ -146,10 +145,22 @@ __global__ __launch_bounds__(kBlock) void lz_prepare1_kernel(lz_args a, float2* 
     }
     // (Tried on the C3 stream, 41.7 us as written: scalar loop control via readfirstlane 46.5 us; eight rows in flight per lane group
     //  46.9 us; the four tables interleaved over a 1-D grid 58.3 us.  ~20 us of it is the replay's VALU time at full chip occupancy.)
-    for (int64_t q = gg; q < tb.n; q += TG) {
-        const uint32_t row = tb.keys[q];
-        if (q > 0 && tb.keys[q - 1] == row) continue;                // one lane group per DISTINCT row
-        const int64_t from = tb.last[row], to = t - 1;
+    // A row wider than 64 elements is spread over several WAVES, which all read last[row] and of which one moves it: every iteration
+    // of the (block-uniform) loop therefore has a barrier between the reads and that write.  (Without it a wave that starts its
+    // iteration after its sibling has finished finds last[row] already advanced and leaves its part of the row unreplayed -- which is
+    // what the first version of this kernel did: rare, timing-dependent, found by comparing the trained state of two invocations.)
+    const bool wide = lanes_per_row > 64;
+    const int64_t to = t - 1;
+    for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < tb.n; base += TG) {
+        const int grp = threadIdx.x / lanes_per_row;                     // (192 lanes per row leave 64 threads of the block without a row)
+        const int64_t q = base + grp;
+        uint32_t row = 0;
+        int64_t from = to;
+        if (grp < rows_per_block && q < tb.n) {
+            row = tb.keys[q];
+            if (!(q > 0 && tb.keys[q - 1] == row)) from = tb.last[row];   // one lane group per DISTINCT row
+        }
+        if (wide) __syncthreads();
         if (from >= to) continue;
         if (sub < D) {
             const int64_t o = (int64_t)row * D + sub;

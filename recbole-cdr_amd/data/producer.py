@@ -60,7 +60,26 @@ class DeviceBatchProducer:
                 self.fields.k_major = self.k
         self.device = dev
         self.cursor = torch.zeros(4, device=dev, dtype=torch.int64)      # {next row, draws so far, sign-in word, spare}
+        self._slots = [(self.out_users, self.out_items, self.out_neg, self.fields)]
         self.resync()
+
+    def add_slot(self):
+        """A further set of output buffers (-> its index): ``launch(slot)`` then produces the next batch THERE, so a batch can be produced
+        while an earlier one is still being read (graph_step's pipelined unrolled step).  The cursor is shared: batches come in loader order
+        whichever slot they land in."""
+        u, i, n, f = self._slots[0]
+        nf = Interaction({k: (v if (k == getattr(self.loader, 'label_field', None) and self.pointwise) else torch.zeros_like(v)) for k, v in f.items()})
+        if getattr(f, 'k_major', None) is not None:
+            nf.k_major = f.k_major
+        if self.kind == 'overlap':
+            self._slots.append((nf[self.loader.field], None, None, nf))
+        else:
+            ld = self.loader
+            self._slots.append((nf[ld.uid_field], nf[ld.iid_field], None if n is None else nf[ld.neg_iid_field], nf))
+        return len(self._slots) - 1
+
+    def fields_slot(self, slot):
+        return self._slots[slot][3]
 
     @staticmethod
     def supports(loader):
@@ -74,26 +93,27 @@ class DeviceBatchProducer:
         cols = [inter[loader.uid_field], inter[loader.iid_field]]
         return all(c.is_cuda and c.dtype == torch.int64 and c.dim() == 1 for c in cols) and dict.__len__(inter) == 2 and loader.neg_k >= 1      # (Interaction.__len__ counts rows)
 
-    def job(self):
+    def job(self, slot=0):
         """This producer's arguments as a ``cdr_batch_job`` (binding.BatchJob); the tensors behind the pointers are owned by the
         producer, the loader and the sampler, so they outlive every launch."""
         smp = self.sampler
+        out_users, out_items, out_neg, _ = self._slots[slot]
         J = B_.BatchJob()
         J.users_all, J.n_rows, J.cursor, J.S = self.users_all.data_ptr(), self.users_all.numel(), self.cursor.data_ptr(), self.S
-        J.k, J.pointwise, J.out_users = self.k, self.pointwise, self.out_users.data_ptr()
+        J.k, J.pointwise, J.out_users = self.k, self.pointwise, out_users.data_ptr()
         if smp is None:
             return J
-        J.items_all, J.out_items = self.items_all.data_ptr(), self.out_items.data_ptr()
-        J.out_neg = None if self.out_neg is None else self.out_neg.data_ptr()
+        J.items_all, J.out_items = self.items_all.data_ptr(), out_items.data_ptr()
+        J.out_neg = None if out_neg is None else out_neg.data_ptr()
         J.lo0, J.hi0, J.lo1, J.hi1 = smp.ranges
         if smp.distribution == 'popularity':
             J.dist, J.keys, J.prob, J.alias, J.n_keys = 1, smp.keys.data_ptr(), smp.prob.data_ptr(), smp.alias.data_ptr(), smp.keys.numel()
         J.used_indptr, J.used_indices, J.seed, J.fail_flag = smp.indptr.data_ptr(), smp.indices.data_ptr(), smp.graph_seed(), smp.fail.data_ptr()
         return J
 
-    def launch(self):
+    def launch(self, slot=0):
         """Enqueue the production of the NEXT batch on the current stream (capturable)."""
-        launch_jobs([self.job()])
+        launch_jobs([self.job(slot)])
 
     def full_ahead(self):
         """Does the loader's next batch have all ``step`` rows (what the captured launch produces)?"""
@@ -124,9 +144,20 @@ class CompositeProducer:
         self.fields = Interaction()
         for p in self.parts:
             self.fields.update(p.fields)
+        self._slots = [self.fields]
 
-    def launch(self):
-        launch_jobs([p.job() for p in self.parts])             # ONE launch: grid row i produces loader i's batch
+    def add_slot(self):
+        f = Interaction()
+        for p in self.parts:
+            f.update(p.fields_slot(p.add_slot()))
+        self._slots.append(f)
+        return len(self._slots) - 1
+
+    def fields_slot(self, slot):
+        return self._slots[slot]
+
+    def launch(self, slot=0):
+        launch_jobs([p.job(slot) for p in self.parts])         # ONE launch: grid row i produces loader i's batch
 
     def full_ahead(self):
         return all(p.full_ahead() for p in self.parts)

@@ -69,7 +69,8 @@ class GraphedTrainStep:
         # for ~5-9 us (measured: profiles/r04_graph_gap.txt) -- a fifth of a 40 us step at the reference's default batch; ``replay_many``
         # pays it once per ``unroll`` steps.
         self.unroll = int(unroll) if producer is not None else 1
-        self.pipeline = bool(pipeline)       # (False: the unrolled graph keeps the plain launch order -- A/B runs and tests)
+        self.pipeline = pipeline             # True: pipelined one batch ahead | 'two_ahead' | False: the unrolled graph keeps the plain launch order
+        self._statics = None
         self._side2 = torch.cuda.Stream(device=dev) if producer is not None else None
         self.graph = None
         self.graph_k = None
@@ -116,6 +117,48 @@ class GraphedTrainStep:
                 loss = self._whole()
             return loss
         main, side = torch.cuda.current_stream(), self._side2
+        if self.pipeline != 'two_ahead' or not (hasattr(self.model, 'sort_batch') and hasattr(self.producer, 'add_slot')):
+            return self._whole_many_one_ahead(k, main, side)
+        # pipeline='two_ahead' (measured equal to the default on C3 -- the two branches do not overlap enough for the shorter critical
+        # path to show, DESIGN 4.R4 -- and kept selectable).  The production and the id sort of a batch depend on nothing a step writes, so they are issued TWO steps
+        # ahead at the tail of the main stream (behind the dense Adam, where the main branch has slack), and the side stream keeps only
+        # what depends on the row update: {row update of step i -> replay of batch i+1's rows}.  Critical path of a step: forward +
+        # max(weight gradients + reduction + dense Adam + producer + sort, row update + replay) instead of forward + row update +
+        # producer + sort + replay.  Two batch slots (batch i+2 overwrites batch i, whose forward is behind it on the main stream) and
+        # three sets of sort buffers (the row update of step i still reads set i while set i+2 is written).
+        P, M = self.producer, self.model
+        if self._statics is None:
+            self._statics = [P.fields_slot(0), P.fields_slot(P.add_slot())]
+        st = self._statics
+        P.launch(0); M.sort_batch(st[0], 0); M.replay_batch(st[0], 0)
+        if k > 1:
+            P.launch(1); M.sort_batch(st[1], 1)
+        loss = None
+        for i in range(k):
+            cur = st[i & 1]
+            self.optimizer.zero_grad(set_to_none=True)
+            losses = M.calculate_loss(cur)
+            loss = sum(losses) if isinstance(losses, tuple) else losses
+            if loss.dim():
+                loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ahead = bool(M.apply_rows_early())
+                if ahead and i + 1 < k:
+                    M.replay_batch(st[(i + 1) & 1], (i + 1) % 3)
+            loss.backward(self._one)
+            loss = loss.detach()
+            step_and_sum(self.optimizer, loss, self.loss_sum)
+            if i + 2 < k:
+                P.launch(i & 1); M.sort_batch(cur, (i + 2) % 3)
+            main.wait_stream(side)
+            if not ahead and i + 1 < k:                      # the row update could not run early: the next batch's replay waits for it
+                M.replay_batch(st[(i + 1) & 1], (i + 1) % 3)
+        return loss
+
+    def _whole_many_one_ahead(self, k, main, side):
+        """The default pipelined order: the side stream runs {row update of step i -> produce batch i+1 -> its id sort -> the replay of its
+        rows} beside the main stream's weight gradients and dense Adam."""
         self.producer.launch()
         self.model.prepare_batch(self.static)
         loss = None

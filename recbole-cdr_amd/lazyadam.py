@@ -38,6 +38,7 @@ class DeferredRowAdam:
         self.step_count = 0              # host mirror of counters[0]
         self.dirty = False               # some row may be behind counters[0]
         self._sorted = None
+        self._sorted_slots = {}
         self._bufs = {}
         self.pending = None              # (G tensor, [column offset per table], ld) stashed by the model's backward
         # software pipelining of an unrolled captured step (graph_step.GraphedTrainStep): ``early`` = the same triple, available as soon as
@@ -48,14 +49,15 @@ class DeferredRowAdam:
         self._prepared = None            # id of the batch ``prepare`` last ran for (``prepare_once``)
 
     # ---- id sort (per list): the small rank sort up to 16,384 ids, the radix sort above --------------------------------------
-    def _sort(self, id_lists):
-        """``id_lists``: per list one id tensor or a pair of tensors (the list is their concatenation, never materialised)."""
+    def _sort(self, id_lists, slot=0):
+        """``id_lists``: per list one id tensor or a pair of tensors (the list is their concatenation, never materialised).  ``slot``: which
+        set of key / position buffers receives the result (a sort can run ahead of the batches still using the other sets)."""
         dev = self.tables[0].device
         pairs = [x if isinstance(x, (tuple, list)) else (x, None) for x in id_lists]
         pairs = [(a.reshape(-1).contiguous().to(torch.int64), None if b is None or b.numel() == 0 else b.reshape(-1).contiguous().to(torch.int64))
                  for a, b in pairs]
         ns = [int(a.numel()) + (0 if b is None else int(b.numel())) for a, b in pairs]
-        key = tuple(ns)
+        key = tuple(ns) + (('slot', slot),)
         if key not in self._bufs:
             tot = sum(ns)
             self._bufs[key] = (torch.empty(tot, device=dev, dtype=torch.int32), torch.empty(tot, device=dev, dtype=torch.int32),
@@ -95,6 +97,20 @@ class DeferredRowAdam:
     def prepare(self, id_lists):
         """Before the forward pass: sort the batch's ids and bring their rows up to the update before the coming one."""
         self._sorted = self._sort(id_lists)
+        self._launch_prepare()
+
+    @torch.no_grad()
+    def sort_ahead(self, id_lists, slot):
+        """The id sort of ``prepare`` alone, for a batch that is not the next one to be read, into buffer set ``slot``;
+        ``prepare_sorted(slot)`` later does the rest.  (The sort reads nothing the updates in between write.)"""
+        self._sorted_slots[slot] = self._sort(id_lists, slot)
+
+    @torch.no_grad()
+    def prepare_sorted(self, slot):
+        self._sorted = self._sorted_slots[slot]
+        self._launch_prepare()
+
+    def _launch_prepare(self):
         per = [self._sorted[j] for j in self.table_list]
         nT = len(self.tables)
         if not torch.cuda.is_current_stream_capturing():

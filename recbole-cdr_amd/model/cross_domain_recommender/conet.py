@@ -119,6 +119,21 @@ class CoNet(CrossDomainRecommender):
         self.row_opt._prepared = id(interaction)
         return True
 
+    def _id_lists(self, interaction):
+        return [(interaction[self.SOURCE_USER_ID], interaction[self.TARGET_USER_ID]), (interaction[self.SOURCE_ITEM_ID], interaction[self.TARGET_ITEM_ID])]
+
+    def sort_batch(self, interaction, slot):
+        """``prepare_batch`` in two halves for a step pipelined two batches deep: the id sort of a batch (depends on its ids only) ..."""
+        if self.row_opt is None or not self.fused_towers:
+            return False
+        self.row_opt.sort_ahead(self._id_lists(interaction), slot)
+        return True
+
+    def replay_batch(self, interaction, slot):
+        """... and the replay of its rows' postponed updates (depends on the row update of the step before it)."""
+        self.row_opt.prepare_sorted(slot)
+        self.row_opt._prepared = id(interaction)
+
     def apply_rows_early(self):
         """Right behind ``calculate_loss`` of a step whose loss will be differentiated with a unit upstream gradient: launch the
         tables' row update now (the forward launch already produced its gradient rows)."""

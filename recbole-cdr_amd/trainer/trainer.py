@@ -168,7 +168,8 @@ class Trainer:
         # steps per graph launch on a device loader (the idle time between two graph launches is ~5-9 us: amortised over this many steps)
         self.graph_unroll = int(config['graph_unroll']) if 'graph_unroll' in config else 8
         # ... and, for models that can run part of the next step ahead (CoNet on the deferred Adam), those steps software-pipelined over two streams
-        self.graph_pipeline = bool(config['graph_pipeline']) if 'graph_pipeline' in config else True
+        gp = config['graph_pipeline'] if 'graph_pipeline' in config else True
+        self.graph_pipeline = gp if isinstance(gp, str) else bool(gp)          # True (one batch ahead) | 'two_ahead' | False
         self._graphs = {}
         self._loss_sum = None
         self.graph_stats = {'replayed': 0, 'eager': 0, 'captures': 0}

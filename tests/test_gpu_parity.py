@@ -1004,6 +1004,47 @@ def test_deferred_adam_is_bit_identical_to_the_dense_sweep(wd):
         assert torch.equal(od.state[dense[t]]['exp_avg_sq'], ol.exp_avg_sq[t]), t
 
 
+@pytest.mark.parametrize('D', [128, 192, 256])
+def test_deferred_adam_rows_wider_than_a_wave_at_c3_scale(D):
+    """Rows of more than 64 elements are replayed by several waves (``lz_prepare1_kernel``), which must all see the row's ``last`` before
+    one of them moves it: 30 updates of 16,000 distinct ids out of 150,000 rows (BASELINE C3's table and batch sizes; thousands of blocks,
+    every row a different lag), against the dense sweep, bit for bit -- and the same run twice.  (The first version of that kernel lost
+    part of a row's replay about once per few thousand rows, depending on wave timing; the 64-wide test above cannot see it.)"""
+    from recbole_cdr_amd.lazyadam import DeferredRowAdam
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    rows = (150_000, 130_000)
+
+    def run(lazy_opt):
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        tabs = [torch.nn.Parameter(torch.randn(rows[i % 2], D, generator=gen, device=DEV) * 0.1) for i in range(4)]
+        opt = DeferredRowAdam(tabs, [0, 1, 0, 1], lr=0.01) if lazy_opt else DenseAdam(tabs, lr=0.01)
+        for step in range(30):
+            n = 16_000 - 37 * step
+            ids = [torch.randperm(rows[j], generator=gen, device=DEV)[:n] for j in range(2)]      # distinct: no summation order at play
+            G = torch.randn(n, 4 * D, generator=gen, device=DEV) * 1e-2
+            if lazy_opt:
+                opt.prepare(ids)
+                opt.pending = (G, (0, D, 2 * D, 3 * D), 4 * D)
+                opt.step()
+            else:
+                for t in range(4):
+                    g = torch.zeros_like(tabs[t])
+                    g[ids[t % 2]] = G[:, t * D:(t + 1) * D]
+                    tabs[t].grad = g
+                opt.step()
+        if lazy_opt:
+            opt.flush()
+            return [t.data for t in tabs], opt.exp_avg, opt.exp_avg_sq
+        return [t.data for t in tabs], [opt.state[t]['exp_avg'] for t in tabs], [opt.state[t]['exp_avg_sq'] for t in tabs]
+
+    dense, lazy, again = run(False), run(True), run(True)
+    for t in range(4):
+        for k, what in enumerate(('rows', 'exp_avg', 'exp_avg_sq')):
+            bad = int((dense[k][t] != lazy[k][t]).sum())
+            assert bad == 0, (what, t, bad)
+            assert torch.equal(lazy[k][t], again[k][t]), (what, t)
+
+
 def test_conet_deferred_adam_trains_like_dense_adam_and_replays_as_a_graph():
     """CoNet with RowAwareAdam (tables: deferred row-wise Adam; towers: dense Adam) against DenseAdam over everything: 6 steps on
     fresh batches, losses at 1e-5 and parameters at Adam's drift bound (the dense route scatters gradients with float atomics, so

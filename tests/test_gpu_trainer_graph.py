@@ -487,7 +487,7 @@ def test_conet_pipelined_unrolled_graph_is_bit_identical_to_the_plain_order():
     cfg = base_config(DEV, embedding_size=16, reg_weight=0.01, mlp_hidden_size=[32, 16, 8], learning_rate=0.01, train_modes=['BOTH'],
                       epoch_num=['3'], source_split=False, eval_step=0, epochs=3)
     outs = []
-    for pipe in (True, False):
+    for pipe in (True, False, 'two_ahead'):
         torch.manual_seed(6)
         model = CoNet(cfg, ds).to(DEV)
         dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.POINTWISE, 128, 1, shuffle=True)
@@ -497,14 +497,16 @@ def test_conet_pipelined_unrolled_graph_is_bit_identical_to_the_plain_order():
         trainer._train_epoch = lambda data, e, o=orig, l=log: (l.append(o(data, e)) or l[-1])
         trainer.fit(dl)
         gs = [g for g in trainer._graphs.values() if g][0]
-        assert gs._can_pipeline() == pipe and gs.unroll == 8 and trainer.graph_stats['replayed'] >= 3 * 16
+        assert bool(gs._can_pipeline()) == bool(pipe) and gs.unroll == 8 and trainer.graph_stats['replayed'] >= 3 * 16
+        assert (gs._statics is not None) == (pipe == 'two_ahead')          # (the two-batches-deep order really ran on its second batch slot)
         outs.append((log, {k: v.detach().clone() for k, v in model.state_dict().items()}, trainer.optimizer.state_dict()))
-    (lp, pp, op), (ls, ps, os_) = outs
-    assert lp == ls, (lp, ls)
-    for k in pp:
-        assert torch.equal(pp[k], ps[k]), k
-    for a, b in zip(op['deferred_rows']['exp_avg'], os_['deferred_rows']['exp_avg']):
-        assert torch.equal(a, b)
+    (ls, ps, os_) = outs[1]                                                  # the plain order
+    for (lp, pp, op) in (outs[0], outs[2]):
+        assert lp == ls, (lp, ls)
+        for k in pp:
+            assert torch.equal(pp[k], ps[k]), k
+        for a, b in zip(op['deferred_rows']['exp_avg'], os_['deferred_rows']['exp_avg']):
+            assert torch.equal(a, b)
 
 
 def test_rowwise_trainer_on_replays_equals_the_eager_rowwise_loop():
@@ -546,3 +548,34 @@ def test_rowwise_trainer_on_replays_equals_the_eager_rowwise_loop():
     for name in sg['tables']:
         assert sg['tables'][name]['step'] == se['tables'][name]['step'], name
         assert torch.equal(sg['tables'][name]['exp_avg'], se['tables'][name]['exp_avg']), name
+
+
+def _bench_c3_state(extra=(), env=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--workload', 'c3', '--no-cpu-baseline', '--no-fullsort', '--steps', '40', '--warmup', '4'] + list(extra)
+    p = subprocess.run(cmd, cwd=root, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    return d['state_checksum'], d['final_loss'], d['config']['trainer_steps']
+
+
+@pytest.mark.gpu
+def test_c3_trained_state_is_the_dense_sweeps_in_every_launch_order_and_process():
+    """BASELINE C3 (CoNet, 156 k users x 134 k items, D = 128, 8,190 rows per step) through ``CrossDomainTrainer.fit``, 40 + 40 steps, each
+    variant in a process of its own: the literal dense Adam sweep; the deferred Adam in the plain launch order; pipelined one batch ahead
+    (the default) and two batches ahead.  The exact fp64 sums of every trained parameter agree across all of them, and a repeat of the
+    default run prints the same digits.  (This is the check that found the wave race in ``lz_prepare1_kernel``: the deferred runs differed
+    from the dense sweep -- and from each other -- in the seventh digit.)"""
+    dense, loss_d, _ = _bench_c3_state(['--dense-adam'])
+    runs = {'plain': _bench_c3_state(env={'CDR_GRAPH_PIPELINE': '0'}),
+            'one_ahead': _bench_c3_state(),
+            'one_ahead again': _bench_c3_state(),
+            'two_ahead': _bench_c3_state(env={'CDR_GRAPH_PIPELINE': 'two_ahead'})}
+    for name, (state, loss, steps) in runs.items():
+        assert steps['optimizer'] == 'RowAwareAdam' and steps['replayed'] == 40, (name, steps)
+        assert state == dense, (name, {k: (state[k], dense[k]) for k in dense if state[k] != dense[k]})
+        assert loss == loss_d, (name, loss, loss_d)
