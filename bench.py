@@ -355,6 +355,10 @@ def run_c5(args, world, rank, dev):
                    'row %% %d, user-aligned all-to-all%s, 2-domain pipelined' % (world, '' if args.no_dedup else ' of de-duplicated item rows')},
         'final_loss': loss,
     }
+    if world == 1 and not sharded:
+        # the trained tables as exact fp64 sums (after the timed region and its single-stream repeat, before any other leg trains on them):
+        # two invocations with the same flags must print the same digits
+        result['state_checksum'] = {k_: repr(float(torch.sum(v_, dtype=torch.float64))) for k_, v_ in tabs.items()}
     if single is not None:
         result['config']['streams'] = 'the two domain steps of a step on two HIP streams (CrossDomainTrainer parallel_domains); kernel brackets / roofline from single-stream steps'
         result['single_stream'] = {'ms_per_step': single * 1e3, 'value': 2 * B / single, 'unit': 'interactions/s', 'steps': args.steps,

@@ -579,3 +579,24 @@ def test_c3_trained_state_is_the_dense_sweeps_in_every_launch_order_and_process(
         assert steps['optimizer'] == 'RowAwareAdam' and steps['replayed'] == 40, (name, steps)
         assert state == dense, (name, {k: (state[k], dense[k]) for k in dense if state[k] != dense[k]})
         assert loss == loss_d, (name, loss, loss_d)
+
+
+@pytest.mark.gpu
+def test_headline_step_trains_the_same_tables_in_every_process_and_stream_layout():
+    """``bench.py --headline-only`` (EMCDR-BPR fused row-wise step, Zipf-free uniform batches with duplicate rows) three times in processes of
+    their own -- two domain streams, again, and one stream: the exact fp64 sums of the four trained tables and the last loss agree."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], [], ['--single-stream']):
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--headline-only', '--steps', '6', '--warmup', '2', '--users', '2000001',
+               '--items-per-domain', '300000', '--batch', '262144'] + extra
+        p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+        outs.append((d['state_checksum'], d['final_loss']))
+    assert outs[0] == outs[1] == outs[2], outs
+    assert len(outs[0][0]) == 4 and all(float(v) == float(v) for v in outs[0][0].values())
