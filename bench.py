@@ -1388,6 +1388,8 @@ def e2e_leg(args, dev):
         sec, loss = log[2 * j + 1]
         out['phases'][ph] = {'epoch_ms': sec * 1e3, 'rows': rows[ph], 'rows_per_s': rows[ph] / sec, 'first_epoch_ms': log[2 * j][0] * 1e3,
                              'epoch_loss_sum': loss}
+    with torch.no_grad():                                         # (exact fp64 sums of the state fit() trained: same digits in every invocation)
+        out['state_checksum_after_fit'] = {n_: repr(float(torch.sum(p_.detach(), dtype=torch.float64))) for n_, p_ in model.named_parameters()}
     # ---- the SOURCE and the TARGET epoch side by side on two HIP streams (config['parallel_domains'] on one GPU) ----------------------
     cfg2 = dict(cfg, parallel_domains=True, train_modes=['SOURCE', 'TARGET'], epoch_num=['1', '1'])
     tr2 = CrossDomainTrainer(cfg2, model)
@@ -1396,6 +1398,8 @@ def e2e_leg(args, dev):
     tr2.fit(train)
     torch.cuda.synchronize(); sec2 = time.perf_counter() - t0
     seq = out['phases']['SOURCE']['epoch_ms'] + out['phases']['TARGET']['epoch_ms']
+    with torch.no_grad():
+        out['state_checksum_after_two_stream_epochs'] = {n_: repr(float(torch.sum(p_.detach(), dtype=torch.float64))) for n_, p_ in model.named_parameters()}
     out['source_and_target_on_two_streams'] = {'ms': sec2 * 1e3, 'rows': rows['SOURCE'] + rows['TARGET'],
                                                'rows_per_s': (rows['SOURCE'] + rows['TARGET']) / sec2, 'sequential_ms': seq,
                                                'speedup_over_sequential_phases': seq / (sec2 * 1e3),

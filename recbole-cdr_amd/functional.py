@@ -54,7 +54,7 @@ def _grads_for(ctx, a, b):
 # adds into a row that occurs several times in a batch is not fixed, so two runs can differ in the last bit.  With
 # ``set_deterministic(True)`` (or CDR_DETERMINISTIC=1) the same kernels run on the batch's GATHERED rows with the occurrence index as
 # the id -- every address receives exactly one add -- and the per-occurrence rows are then summed per distinct id in occurrence order
-# (id sort + cdr_scatter_rows_sorted, as the CoNet node always does).  Covers EMCDR (BPR and MF), CMF and SSCDR; a few launches more
+# (id sort + cdr_scatter_rows_sorted, as the CoNet node always does).  Covers EMCDR (BPR and MF), CMF, SSCDR and BiTGCF; a few launches more
 # per step, so it is off by default.
 _DETERMINISTIC = [False]
 
@@ -340,7 +340,6 @@ class TwoStackPointLoss(Function):
     def backward(ctx, g_s, g_t):
         S, T, us, is_, ut, it, gc_s, gc_t, out8 = ctx.saved_tensors
         dev, D = S.device, S.shape[1]
-        gS, gT = _zeros_like2(S, T)
         zero = None
         gos = []
         for g in (g_s, g_t):
@@ -348,6 +347,15 @@ class TwoStackPointLoss(Function):
                 zero = torch.zeros(1, device=dev, dtype=torch.float32) if zero is None else zero
                 g = zero
             gos.append(g.reshape(-1)[:1].contiguous().to(torch.float32))
+        if deterministic():
+            # per-occurrence rows of each stack (users, then items at row nu + i), then one in-order segment sum per stack
+            outs = []
+            for d, (W, u, i, gc) in enumerate(((S, us, is_, gc_s), (T, ut, it, gc_t))):
+                Wi = W[ctx.nu:]
+                dU, dI, _, _ = _det_point_rows(W, Wi, None, None, u, i, gc, B_._c_ptr(out8.data_ptr() + 16 * d), 0.0, gos[d])
+                outs.append(_scatter_rows_deterministic(W.shape, torch.cat([u, i + ctx.nu]), torch.cat([dU, dI])))
+            return None, outs[0], outs[1], None, None, None, None, None, None, None
+        gS, gT = _zeros_like2(S, T)
         P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
         io = 4 * ctx.nu * D
         B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io), None, None, D,
@@ -1264,6 +1272,16 @@ class EmbLossRows(Function):
     @staticmethod
     def backward(ctx, go):
         U, I, uid, iid, out3 = ctx.saved_tensors
+        if deterministic():
+            # the same kernel on the gathered rows with the occurrence index as the id (one add per address), then in-order segment sums
+            n, D = uid.numel(), U.shape[1]
+            ar = _arange(U.device, n)
+            Ur, Ir = _gather_plain(U, uid), _gather_plain(I, iid)
+            flat = torch.zeros(2 * n * D, device=U.device, dtype=torch.float32)
+            dU, dI = flat[:n * D].view(n, D), flat[n * D:].view(n, D)
+            B_.call('cdr_embloss_bwd_dense', B_.stream(), B_.f32(Ur), B_.f32(Ir), D, B_.i64(ar), B_.i64(ar), n,
+                    B_.f32(out3), B_.f32(go.reshape(-1).contiguous()), B_.f32(dU), B_.f32(dI))
+            return _scatter_rows_deterministic(U.shape, uid, dU), _scatter_rows_deterministic(I.shape, iid, dI), None, None
         gU, gI = _zeros_like2(U, I)
         B_.call('cdr_embloss_bwd_dense', B_.stream(), B_.f32(U), B_.f32(I), U.shape[1], B_.i64(uid), B_.i64(iid), uid.numel(),
                 B_.f32(out3), B_.f32(go.reshape(-1).contiguous()), B_.f32(gU), B_.f32(gI))

@@ -1141,8 +1141,19 @@ def test_deterministic_dense_backward():
         (F_.gather_rows(W, u) * torch.arange(n, device=DEV).view(-1, 1).float().sin()).sum().backward()
         return [W.grad]
 
+    def two_stack():                                             # BiTGCF's batch loss: rows of two stacked [users ; items] tables
+        S, T = leaves(torch.cat([U0, I0]), torch.cat([U0.flip(0), I0.flip(0)]))
+        ls, lt = F_.TwoStackPointLoss.apply(B_.CDR_LOSS_BCE, S, T, nu, u, p_, y, u.flip(0), q_, 1 - y)
+        (0.7 * ls + 1.3 * lt).sum().backward()
+        return [S.grad, T.grad]
+
+    def embloss_rows():
+        U, I = leaves(U0, I0)
+        (F_.EmbLossRows.apply(U, I, u, p_) * 0.9).sum().backward()
+        return [U.grad, I.grad]
+
     cases = {'bpr': bpr, 'mse': lambda: point(B_.CDR_LOSS_MSE), 'bce': lambda: point(B_.CDR_LOSS_BCE), 'shared': point_shared,
-             'pair': pair, 'gather': gather}
+             'pair': pair, 'gather': gather, 'two_stack': two_stack, 'embloss_rows': embloss_rows}
     try:
         for name, fn in cases.items():
             F_.set_deterministic(False)

@@ -2,7 +2,7 @@
 # `bench.py --workload c1|c2` through CrossDomainTrainer.fit with and without it.  Output: gpurun_out/det/summary.txt
 ulimit -c 0
 O=gpurun_out/det; mkdir -p $O
-for wl in c1 c2; do
+for wl in c1 c2 c4; do
   for d in 0 1; do
     CDR_DETERMINISTIC=$d python bench.py --workload $wl --no-cpu-baseline --steps 200 --warmup 20 > $O/${wl}_det$d.json 2> $O/${wl}_det$d.err || echo "$wl det=$d rc=$?"
   done
@@ -10,7 +10,7 @@ done
 python - <<'PY' | tee gpurun_out/det/summary.txt
 import json
 print('atomic-free dense backward (CDR_DETERMINISTIC=1) vs the default float-atomic scatter; bench.py --workload cN through CrossDomainTrainer.fit, 200 steps')
-for wl in ('c1', 'c2'):
+for wl in ("c1", "c2", "c4"):
     r = {}
     for d in (0, 1):
         try:
