@@ -879,6 +879,10 @@ def run_c5(args, world, rank, dev):
     except Exception as e:  # noqa: BLE001
         result.setdefault('leg_errors', {})['fullsort'] = repr(e)[:500]
         print('bench: fullsort leg failed: %r' % (e,), file=sys.stderr)
+    if world == 1 and not sharded:
+        # ... and once more after every other leg has trained on the same tables (OVERLAP steps, k-major, Zipf and small batches, graphs):
+        # all of them run a fixed number of steps, so this too is the same in every invocation with the same flags
+        result['state_checksum_after_all_legs'] = {k_: repr(float(torch.sum(v_, dtype=torch.float64))) for k_, v_ in tabs.items()}
     return result
 
 
