@@ -1004,12 +1004,13 @@ def test_deferred_adam_is_bit_identical_to_the_dense_sweep(wd):
         assert torch.equal(od.state[dense[t]]['exp_avg_sq'], ol.exp_avg_sq[t]), t
 
 
-@pytest.mark.parametrize('D', [128, 192, 256])
-def test_deferred_adam_rows_wider_than_a_wave_at_c3_scale(D):
+@pytest.mark.parametrize('D,n0', [(128, 16_000), (192, 16_000), (256, 16_000), (128, 40_000)])
+def test_deferred_adam_rows_wider_than_a_wave_at_c3_scale(D, n0):
     """Rows of more than 64 elements are replayed by several waves (``lz_prepare1_kernel``), which must all see the row's ``last`` before
     one of them moves it: 30 updates of 16,000 distinct ids out of 150,000 rows (BASELINE C3's table and batch sizes; thousands of blocks,
     every row a different lag), against the dense sweep, bit for bit -- and the same run twice.  (The first version of that kernel lost
-    part of a row's replay about once per few thousand rows, depending on wave timing; the 64-wide test above cannot see it.)"""
+    part of a row's replay about once per few thousand rows, depending on wave timing; the 64-wide test above cannot see it.)  40,000 ids:
+    the radix id sort instead of the rank sort, and several passes of the replay kernel's block-uniform loop."""
     from recbole_cdr_amd.lazyadam import DeferredRowAdam
     from recbole_cdr_amd.trainer.trainer import DenseAdam
     rows = (150_000, 130_000)
@@ -1019,7 +1020,7 @@ def test_deferred_adam_rows_wider_than_a_wave_at_c3_scale(D):
         tabs = [torch.nn.Parameter(torch.randn(rows[i % 2], D, generator=gen, device=DEV) * 0.1) for i in range(4)]
         opt = DeferredRowAdam(tabs, [0, 1, 0, 1], lr=0.01) if lazy_opt else DenseAdam(tabs, lr=0.01)
         for step in range(30):
-            n = 16_000 - 37 * step
+            n = n0 - 37 * step
             ids = [torch.randperm(rows[j], generator=gen, device=DEV)[:n] for j in range(2)]      # distinct: no summation order at play
             G = torch.randn(n, 4 * D, generator=gen, device=DEV) * 1e-2
             if lazy_opt:
