@@ -753,7 +753,7 @@ def run_c5(args, world, rank, dev):
                         gs.step(*gb_[0])
                     torch.cuda.synchronize()
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg, stream=side_):
+                    with B_.capturing(cg, side_):
                         gs.step(*gb_[0])
 
                     def rep(*_a):

@@ -4,12 +4,33 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream; ever
 library.  ``data_ptr()`` of a contiguous fp32 / int64 CUDA tensor is handed over as a raw device pointer together
 with ``torch.cuda.current_stream().cuda_stream`` so that the kernels are ordered with torch's own work.
 """
+import contextlib
 import ctypes
+import gc
 import os
 import subprocess
 import threading
 
 import torch
+
+
+@contextlib.contextmanager
+def capturing(graph, stream):
+    """``torch.cuda.graph(graph, stream=stream)`` with Python's cyclic collector held off.  Since torch 2.9 ``torch.cuda.graph`` no longer
+    runs ``gc.collect()`` on entry, so a dead cycle that owns an older ``CUDAGraph`` (a previous phase's captured step) can be collected
+    in the middle of a capture: its ``hipGraphExecDestroy`` is refused under the global capture mode, the C++ destructor throws and the
+    process aborts ('Fatal Python error: Aborted ... Garbage-collecting', seen in the GPU suite).  Collect first, keep the collector off
+    until the capture has ended."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only

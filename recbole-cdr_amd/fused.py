@@ -317,7 +317,7 @@ class KMajorBPRStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, stream=side):
+        with B_.capturing(self._graph, side):
             self._enqueue(self._ids[0], self._ids[1], self._ids[2], S)
         return self
 
@@ -519,7 +519,7 @@ class FusedMapStep:
         torch.cuda.synchronize()
         host = (self.sstate._step, self.tstate._step)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, stream=side):
+        with B_.capturing(self._graph, side):
             self._step_unique(self._idx)
         self.sstate._step, self.tstate._step = host       # the capture enqueued nothing: host counts advance per replay
         return self

@@ -15,6 +15,7 @@ loss total costs no extra launch and no host sync per step (``CrossDomainTrainer
 """
 import torch
 
+from .binding import capturing
 from .data.interaction import Interaction
 
 
@@ -200,7 +201,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         # capture on the stream that ran the warm-up: the native contexts are per (device, stream) and creating one
         # allocates, which is not allowed while a stream is capturing
-        with torch.cuda.graph(self.graph, stream=side):
+        with capturing(self.graph, side):
             self.loss = self._whole()
         if self.unroll > 1:
             if self._can_pipeline():
@@ -216,7 +217,7 @@ class GraphedTrainStep:
                 if snap2 is not None:
                     self._restore(snap2)
             self.graph_k = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_k, stream=side):
+            with capturing(self.graph_k, side):
                 self._whole_many(self.unroll)
 
     # ---- warm-up without side effects: in-place snapshot / restore (addresses must not change: the capture follows) -------------
@@ -323,11 +324,11 @@ class GraphedRowwiseStep:
     def capture(self):
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.side):
+        with capturing(self.graph, self.side):
             self._one()
         if self.unroll > 1:
             self.graph_k = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_k, stream=self.side):
+            with capturing(self.graph_k, self.side):
                 for _ in range(self.unroll):
                     self._one()
 

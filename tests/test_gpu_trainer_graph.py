@@ -92,6 +92,7 @@ def test_batch_producer_layout_draws_and_cursor(pointwise, k):
 
 def test_batch_producer_overlap_slices_and_graph_replay():
     """k = 0: OverlapDataloader's [OB, 1] slices; captured once, every replay yields the next slice."""
+    from recbole_cdr_amd import binding as B_
     from recbole_cdr_amd.data.producer import DeviceBatchProducer
     from recbole_cdr_amd.utils import InputType
     ids, ds, s_pairs, t_pairs = _dataset()
@@ -103,7 +104,7 @@ def test_batch_producer_overlap_slices_and_graph_replay():
     torch.cuda.synchronize()
     prod.resync()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with B_.capturing(g, side):
         prod.launch()
     prod.resync()
     for b in range(ids.OU // 8):

@@ -23,7 +23,7 @@ for K in (1, 5, 40):
         B_.call('cdr_inc_i64', B_.stream(), B_.i64(cnt))
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with B_.capturing(g, side):
         for _ in range(K):
             B_.call('cdr_inc_i64', B_.stream(), B_.i64(cnt))
     for _ in range(20):
