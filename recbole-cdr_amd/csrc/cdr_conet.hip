@@ -23,6 +23,7 @@
 //                        gradients as the A operand's running row sum; partials go to a workspace and
 //                        conet_wgrad_finish_kernel adds them in chunk order (plus d||H||_F) -- no float atomics anywhere:
 //                        the tower backward is bit-reproducible.
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include "cdr_common.h"
@@ -64,8 +65,11 @@ __device__ __forceinline__ f32x16 zero16() {
 #ifdef CDR_CONET_PROF
 __device__ long long* g_conet_prof = nullptr;
 #define STAMP(i) do { if (g_conet_prof && blockIdx.x == 0 && threadIdx.x == 0) g_conet_prof[i] = wall_clock64(); } while (0)
+// every block's entry / exit time (conet_fb_kernel): is a launch its slowest block, or its start-up and drain?  (buffer: 64 + 2 * grid words)
+#define STAMPB(i) do { if (g_conet_prof && threadIdx.x == 0) g_conet_prof[64 + 2 * blockIdx.x + (i)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPB(i) do { } while (0)
 #endif
 #define MFMA4(acc, a, b)                                                          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0);       \
@@ -764,6 +768,301 @@ __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R
     if (t < 2 * (dL + 1)) ou_part[(size_t)blockIdx.x * 2 * (dL + 1) + t] = ou_acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------ eight-wave cross units
+// conet_fb_kernel<8>: the same 32-row block on EIGHT waves (two per SIMD).  A cross unit is two independent products per (tower,
+// column tile) -- the tower's own weights and the shared H -- which the four-wave functions above accumulate side by side in one
+// wave (am, ac).  Here each product is a job of its own: "own" waves (which = 0) and "cross" waves (which = 1) run them concurrently,
+// the cross wave parks its raw accumulator where the result belongs (the layer's output region in LDS; a scratch region for the
+// layer-0 input gradient, which leaves for HBM), and behind one LDS barrier the own wave finishes exactly as before:
+// v = am + b; if (mask) v += ac.  Each accumulator sees the same operands in the same K order, the sum am + ac is formed by the same
+// instruction: bit-identical to the four-wave kernel.  What it buys: C3's 8,190 rows are one block per CU, so a launch is one block's
+// chain of LDS / L2 round trips in front of its MFMAs; with a second wave on every SIMD one wave's waits sit behind the other's
+// MFMAs, the small layers (two jobs for four waves before) occupy four SIMDs, and a block without an overlapped row (`anym` false)
+// skips the cross product altogether.
+#ifndef CDR_FB8_GJ
+#define CDR_FB8_GJ 4
+#endif
+struct split_job { bool active; int which, u; };
+__device__ __forceinline__ split_job split_pick(int wave, int u0, int NU) {
+    const int rem = NU - u0;
+    const bool wide = rem > 2;                   // >= 3 units left: own on waves 0-3, cross on waves 4-7 (one of each per SIMD)
+    split_job j;
+    j.which = wide ? wave >> 2 : (wave >> 1) & 1;   // <= 2 units: own on waves 0-1, cross on waves 2-3 (a SIMD each)
+    const int uu = wide ? wave & 3 : wave & 1;
+    j.active = (wide || wave < 4) && uu < rem;
+    j.u = j.active ? u0 + uu : 0;
+    return j;
+}
+
+// layer 0 of the forward (din % 128 == 0, dout % 32 == 0, weights streamed from L2): fwd_layer_stream, one product per wave
+__device__ __forceinline__ void fwd_layer_stream8(const conet_net& net, int l, const float* __restrict__ Xin, float* __restrict__ Xout,
+                                                  const float* __restrict__ mrow, float* __restrict__ acts,
+                                                  int64_t row0, int64_t R, int wave, int li, int lh, bool anym) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int XS = 2 * din + 4, XO = 2 * dout + 4;
+    constexpr int GJ = CDR_FB8_GJ;                    // K steps (of 8) per register set
+    const int NT = dout >> 5, KQ = din / (32 * GJ), NU = 2 * NT;
+    const int off = net.act_off[l], actw = net.act_off[net.L];
+    for (int u0 = 0; u0 < NU; u0 += 4) {
+        const split_job sj = split_pick(wave, u0, NU);
+        const int tower = sj.u / NT, n = (sj.u - tower * NT) * 32 + li;
+        const bool work = sj.active && (!sj.which || anym);
+        f32x16 acc = zero16();
+        if (work) {
+            const float* xa = Xin + li * XS + ((tower ^ sj.which) ? din : 0) + 4 * lh;
+            const float* wb = sj.which ? net.H[l] : (tower ? net.Wt[l] : net.Ws[l]);
+            const unsigned vo = (unsigned)(n * din + 4 * lh);
+            float4 m0[GJ], m1[GJ], m2[GJ], m3[GJ];
+#define CDR_LOADG(M, KB) _Pragma("unroll") for (int j = 0; j < GJ; ++j) { M[j] = ld4(wb + (KB) + (vo + 8 * j)); }
+#define CDR_MFG(M, KB) {                                                                            \
+            float4 a0[GJ];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < GJ; ++j) { a0[j] = ld4(xa + (KB) + 8 * j); }      \
+            _Pragma("unroll") for (int j = 0; j < GJ; ++j) { MFMA4(acc, a0[j], M[j]); } }
+            CDR_LOADG(m0, 0);
+            CDR_LOADG(m1, 8 * GJ);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < KQ; ++q) {
+                const int kb = q * 32 * GJ;
+                const int kw = q + 1 < KQ ? kb + 32 * GJ : 0;
+                CDR_LOADG(m2, kb + 16 * GJ); __builtin_amdgcn_sched_barrier(0);       // see fwd_layer_stream
+                CDR_MFG(m0, kb);             __builtin_amdgcn_sched_barrier(0);
+                CDR_LOADG(m3, kb + 24 * GJ); __builtin_amdgcn_sched_barrier(0);
+                CDR_MFG(m1, kb + 8 * GJ);    __builtin_amdgcn_sched_barrier(0);
+                CDR_LOADG(m0, kw);           __builtin_amdgcn_sched_barrier(0);
+                CDR_MFG(m2, kb + 16 * GJ);   __builtin_amdgcn_sched_barrier(0);
+                CDR_LOADG(m1, kw + 8 * GJ);  __builtin_amdgcn_sched_barrier(0);
+                CDR_MFG(m3, kb + 24 * GJ);   __builtin_amdgcn_sched_barrier(0);
+            }
+#undef CDR_LOADG
+#undef CDR_MFG
+            if (sj.which) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xout[((r & 3) + 8 * (r >> 2) + 4 * lh) * XO + tower * dout + n] = acc[r];
+            }
+        }
+        lds_barrier();
+        if (sj.active && !sj.which) {
+            const float bv = (tower ? net.bt[l] : net.bs[l])[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[r] + bv;
+                if (mrow[row] != 0.f) v += Xout[row * XO + tower * dout + n];      // conet.py:127-129 / :132-134
+                v = v > 0.f ? v : 0.f;
+                Xout[row * XO + tower * dout + n] = v;
+                if (row0 + row < R) acts[(row0 + row) * actw + off + tower * dout + n] = v;
+            }
+        }
+    }
+}
+
+// the small layers of the forward on LDS-staged weights (din % 8 == 0): fwd_layer_lds, one product per wave
+__device__ __forceinline__ void fwd_layer_lds8(const conet_net& net, int l, const float* __restrict__ Xin, float* __restrict__ Xout,
+                                               const float* __restrict__ wl, const float* __restrict__ mrow, float* __restrict__ acts,
+                                               int64_t row0, int64_t R, int wave, int li, int lh, bool anym) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int XS = 2 * din + 4, XO = 2 * dout + 4, WS = din + 4;
+    const int NT = (dout + 31) >> 5, KS = din >> 3, NU = 2 * NT;
+    const int off = net.act_off[l], actw = net.act_off[net.L];
+    for (int u0 = 0; u0 < NU; u0 += 4) {
+        const split_job sj = split_pick(wave, u0, NU);
+        const int tower = sj.u / NT, n = (sj.u - tower * NT) * 32 + li;
+        const bool nv = n < dout;
+        const int nc = nv ? n : 0;
+        const bool work = sj.active && (!sj.which || anym);
+        f32x16 acc = zero16();
+        float bv = 0.f;
+        if (work) {
+            const float* xa = Xin + li * XS + ((tower ^ sj.which) ? din : 0) + 4 * lh;
+            const float* wb = wl + net.wl_off[l] + (sj.which ? 2 * dout * WS : (tower ? dout * WS : 0)) + nc * WS + 4 * lh;
+            if (!sj.which) bv = (tower ? net.bt[l] : net.bs[l])[nc];            // requested before the MFMAs, used after them
+#pragma unroll 2
+            for (int s = 0; s < KS; ++s) {
+                const float4 b0 = ld4(wb + 8 * s), a0 = ld4(xa + 8 * s);
+                MFMA4(acc, a0, b0);
+            }
+            if (sj.which && nv) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xout[((r & 3) + 8 * (r >> 2) + 4 * lh) * XO + tower * dout + n] = acc[r];
+            }
+        }
+        lds_barrier();
+        if (sj.active && !sj.which && nv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[r] + bv;
+                if (mrow[row] != 0.f) v += Xout[row * XO + tower * dout + n];
+                v = v > 0.f ? v : 0.f;
+                Xout[row * XO + tower * dout + n] = v;
+                if (row0 + row < R) acts[(row0 + row) * actw + off + tower * dout + n] = v;
+            }
+        }
+    }
+}
+
+// bwd_layer_lds (l >= 1, dout % 8 == 0), one product per wave; the cross accumulator waits in Gn
+__device__ __forceinline__ void bwd_layer_lds8(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ Gn,
+                                               const float* __restrict__ wl, const float* __restrict__ mrow, int wave, int li, int lh,
+                                               bool anym) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4, ldw = din + 4;
+    const int NT = (din + 31) >> 5, KS = dout >> 3, NU = 2 * NT;
+    for (int u0 = 0; u0 < NU; u0 += 4) {
+        const split_job sj = split_pick(wave, u0, NU);
+        const int tower = sj.u / NT, c0 = (sj.u - tower * NT) * 32 + li;
+        const bool cv = c0 < din;
+        const int cc = cv ? c0 : 0;
+        const bool work = sj.active && (!sj.which || anym);
+        f32x16 acc = zero16();
+        if (work) {
+            const float* Wb = wl + net.wl_off[l] + (sj.which ? 2 * dout * ldw : (tower ? dout * ldw : 0)) + 4 * lh * ldw + cc;
+            const float* aa = Gl + li * GS + ((tower ^ sj.which) ? dout : 0) + 4 * lh;
+#pragma unroll 2
+            for (int s = 0; s < KS; ++s) {
+                const float* w_ = Wb + 8 * s * ldw;
+                const float4 m = make_float4(w_[0], w_[ldw], w_[2 * ldw], w_[3 * ldw]);
+                const float4 a0 = ld4(aa + 8 * s);
+                MFMA4(acc, a0, m);
+            }
+            if (sj.which && cv) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Gn[((r & 3) + 8 * (r >> 2) + 4 * lh) * GN + tower * din + c0] = acc[r];
+            }
+        }
+        lds_barrier();
+        if (sj.active && !sj.which && cv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[r];
+                if (mrow[row] != 0.f) v += Gn[row * GN + tower * din + c0];
+                Gn[row * GN + tower * din + c0] = v;
+            }
+        }
+    }
+}
+
+// bwd_layer_tiles<true, 1> (l >= 1, dout % 32 == 0, din % 32 == 0 -- the 128-column shapes too), one product per wave
+__device__ __forceinline__ void bwd_layer_tiles8(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ Gn,
+                                                 const float* __restrict__ wl, const float* __restrict__ mrow, int wave, int li, int lh,
+                                                 bool anym) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4;
+    const int NG = din >> 5, KQ = dout >> 5, NU = 2 * NG;
+    const int ldw = din + 4;
+    for (int u0 = 0; u0 < NU; u0 += 4) {
+        const split_job sj = split_pick(wave, u0, NU);
+        const int tower = sj.u / NG, c0 = (sj.u - tower * NG) * 32 + li;
+        const bool work = sj.active && (!sj.which || anym);
+        f32x16 acc = zero16();
+        if (work) {
+            const float* Wb = wl + net.wl_off[l] + (sj.which ? 2 * dout * ldw : (tower ? dout * ldw : 0));
+            const unsigned vo = (unsigned)(4 * lh * ldw + c0);
+            const float* aa = Gl + li * GS + ((tower ^ sj.which) ? dout : 0) + 4 * lh;
+            float4 m0, m1, m2, m3;
+#define CDR_LOADS(M, K) { const float* w_ = Wb + (K) * ldw; M = make_float4(w_[vo], (w_ + ldw)[vo], (w_ + 2 * ldw)[vo], (w_ + 3 * ldw)[vo]); }
+#define CDR_MFS(M, K) { const float4 a0 = ld4(aa + (K)); MFMA4(acc, a0, M); }
+            CDR_LOADS(m0, 0);
+            CDR_LOADS(m1, 8);
+            for (int q = 0; q < KQ; ++q) {
+                const int kb = q << 5;
+                const int kw = q + 1 < KQ ? kb + 32 : 0;
+                CDR_LOADS(m2, kb + 16);
+                CDR_MFS(m0, kb);
+                CDR_LOADS(m3, kb + 24);
+                CDR_MFS(m1, kb + 8);
+                CDR_LOADS(m0, kw);
+                CDR_MFS(m2, kb + 16);
+                CDR_LOADS(m1, kw + 8);
+                CDR_MFS(m3, kb + 24);
+            }
+#undef CDR_LOADS
+#undef CDR_MFS
+            if (sj.which) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Gn[((r & 3) + 8 * (r >> 2) + 4 * lh) * GN + tower * din + c0] = acc[r];
+            }
+        }
+        lds_barrier();
+        if (sj.active && !sj.which) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[r];
+                if (mrow[row] != 0.f) v += Gn[row * GN + tower * din + c0];
+                Gn[row * GN + tower * din + c0] = v;
+            }
+        }
+    }
+}
+
+// bwd_layer_quad for layer 0 (dout % 32 == 0, din % 128 == 0, weights streamed from L2), one product per wave.  The result leaves
+// for gx0 in HBM, so the cross accumulator waits in a scratch region X [32][2 din + 4] of LDS (conet_fb_lds::x_off).
+__device__ __forceinline__ void bwd_layer_quad8(const conet_net& net, int l, const float* __restrict__ Gl, float* __restrict__ X,
+                                                const float* __restrict__ mrow, float* __restrict__ gx0, int64_t row0, int64_t R,
+                                                int wave, int li, int lh, bool anym) {
+    const int din = net.dims[l], dout = net.dims[l + 1];
+    const int GS = 2 * dout + 4, GN = 2 * din + 4;
+    const int NG = din >> 7, KQ = dout >> 5, NU = 2 * NG;
+    const int ldw = din;
+    for (int u0 = 0; u0 < NU; u0 += 4) {
+        const split_job sj = split_pick(wave, u0, NU);
+        const int tower = sj.u / NG, c0 = (sj.u - tower * NG) * 128 + 4 * li;
+        const bool work = sj.active && (!sj.which || anym);
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = zero16();
+        if (work) {
+            const float* Wb = sj.which ? net.H[l] : (tower ? net.Wt[l] : net.Ws[l]);
+            const unsigned vo = (unsigned)(4 * lh * ldw + c0);
+            const float* aa = Gl + li * GS + ((tower ^ sj.which) ? dout : 0) + 4 * lh;
+            float4 m0[4], m1[4], m2[4], m3[4];                                    // [r] = W[k + r][c0 .. c0 + 3]
+#define CDR_LOADS(M, K) _Pragma("unroll") for (int r = 0; r < 4; ++r) { M[r] = ld4(Wb + ((K) + r) * ldw + vo); }
+#define CDR_MFS(M, K) {                                                                             \
+            const float4 a0 = ld4(aa + (K));                                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+                MF1(acc[j], a0.x, comp4(M[0], j)); MF1(acc[j], a0.y, comp4(M[1], j));               \
+                MF1(acc[j], a0.z, comp4(M[2], j)); MF1(acc[j], a0.w, comp4(M[3], j)); } }
+            CDR_LOADS(m0, 0);
+            CDR_LOADS(m1, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < KQ; ++q) {
+                const int kb = q << 5;
+                const int kw = q + 1 < KQ ? kb + 32 : 0;
+                CDR_LOADS(m2, kb + 16); __builtin_amdgcn_sched_barrier(0);       // see fwd_layer_stream
+                CDR_MFS(m0, kb);        __builtin_amdgcn_sched_barrier(0);
+                CDR_LOADS(m3, kb + 24); __builtin_amdgcn_sched_barrier(0);
+                CDR_MFS(m1, kb + 8);    __builtin_amdgcn_sched_barrier(0);
+                CDR_LOADS(m0, kw);      __builtin_amdgcn_sched_barrier(0);
+                CDR_MFS(m2, kb + 16);   __builtin_amdgcn_sched_barrier(0);
+                CDR_LOADS(m1, kw + 8);  __builtin_amdgcn_sched_barrier(0);
+                CDR_MFS(m3, kb + 24);   __builtin_amdgcn_sched_barrier(0);
+            }
+#undef CDR_LOADS
+#undef CDR_MFS
+            if (sj.which) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st4(X + ((r & 3) + 8 * (r >> 2) + 4 * lh) * GN + tower * din + c0, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
+            }
+        }
+        lds_barrier();
+        if (sj.active && !sj.which) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                if (mrow[row] != 0.f) {
+                    const float4 c = ld4(X + row * GN + tower * din + c0);
+                    v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+                }
+                if (row0 + row < R) st4(gx0 + (row0 + row) * (2 * (int64_t)din) + tower * din + c0, v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ forward + data backward
 // Training steps: conet_fwd_kernel's pass and conet_bwd_kernel's pass over the same 32 rows in ONE launch, for a unit upstream
 // gradient (the loss is what `.backward()` is called on; any other factor is applied afterwards, conet_wgrad_finish_kernel).  Nothing
@@ -773,7 +1072,7 @@ __global__ __launch_bounds__(256) void conet_bwd_kernel(conet_net net, int64_t R
 // HBM: 4.5 us) and its copy of the staged weights disappear with the second launch.  The two gradient buffers take over the region
 // of the layer-0 input, which is dead after the first cross unit.  Same device functions, same order of operations as the two
 // kernels: bit-identical activations, gz, input gradients and loss.
-struct conet_fb_lds { int a_off[kMaxL + 1]; int g0_off, g1_off, wl_off; };
+struct conet_fb_lds { int a_off[kMaxL + 1]; int g0_off, g1_off, wl_off, x_off; };   // x_off: conet_fb_kernel<8>'s scratch (bwd_layer_quad8)
 
 // The kernel's prologue with every global request in flight at once: stage_weights() walks its 35 KB one load -> one LDS store at a
 // time (nine dependent L2 round trips per thread: 7.1 us, measured with wall_clock64 stamps), and the gather then starts its own two
@@ -793,7 +1092,7 @@ __device__ __forceinline__ void stage_weights_dma(const conet_net& net, float* w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)wl;
     const int total = net.wl_off[net.L] >> 2;                       // padded chunks
-    for (int i0 = 64 * wave; i0 < total; i0 += 256) {
+    for (int i0 = 64 * wave; i0 < total; i0 += (int)blockDim.x) {
         int c = i0 + lane;
         if (c >= total) c = total - 1;                              // (the last instruction's tail lanes: a valid source, dropped below)
         const float* src = net.Ws[1];
@@ -844,7 +1143,7 @@ __device__ __forceinline__ void prologue_issue(const conet_net& net, float* wl, 
         if (l < net.L) {
             int lo, hi;
             hsq_slice(net, l, lo, hi);
-            if (lo + t < hi) pr.he[l] = net.H[l][lo + t];
+            if (t < 256 && lo + t < hi) pr.he[l] = net.H[l][lo + t];
         }
     }
     STAMP(45);
@@ -854,6 +1153,7 @@ __device__ __forceinline__ void prologue_issue(const conet_net& net, float* wl, 
 __device__ __forceinline__ void prologue_commit(const conet_net& net, float* wo_sh, double* hq, fb_prologue& pr) {
     const int t = threadIdx.x;
     if (t < 2 * (net.dims[net.L] + 1)) wo_sh[t] = pr.wo;
+    if (t >= 256) return;                      // (conet_fb_kernel<8>: the H^2 slices stay on the first four waves -- same sums in the same order)
 #pragma unroll
     for (int l = 0; l < kMaxL; ++l) {
         if (l < net.L) {
@@ -868,7 +1168,8 @@ __device__ __forceinline__ void prologue_commit(const conet_net& net, float* wo_
     }
 }
 
-__global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_lds lo, const float* __restrict__ su,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void conet_fb_kernel(conet_net net, conet_fb_lds lo, const float* __restrict__ su,
                                                        const float* __restrict__ si, const float* __restrict__ tu,
                                                        const float* __restrict__ ti, int D, const int64_t* __restrict__ user_s,
                                                        const int64_t* __restrict__ user_t, const int64_t* __restrict__ item_s,
@@ -882,7 +1183,8 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
     __shared__ float mrow[kRows], dzrow[kRows];
     __shared__ int trow[kRows];
     __shared__ float yrow[kRows], wo_sh[256];
-    __shared__ double red[2 * 4], hq[kMaxL * 4];
+    __shared__ double red[2 * NW], hq[kMaxL * 4];
+    constexpr int NTH = 64 * NW, TPR = 2 * NW, NI = 32 / TPR;        // threads, threads per gathered row, 16-B chunks per thread and table
     float* wl = smem + lo.wl_off;
     float* G0 = smem + lo.g0_off;
     float* G1 = smem + lo.g1_off;
@@ -891,13 +1193,14 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
     double lacc0 = 0.0, lacc1 = 0.0;
     float ou_acc = 0.f;
     STAMP(40);
+    STAMPB(0);
     fb_prologue pr;
     prologue_issue(net, wl, pr);
     const int64_t nrb = (R + kRows - 1) / kRows;
     auto gather = [&](int64_t rb, auto first) {   // ---- gather [su | si | tu | ti] of 32 rows (8 threads per row, 16 B each): every row request of a 128-column pass is in
             //      flight before anything is parked
             float* bufA = smem + lo.a_off[0];
-            const int row = t >> 3, c0 = t & 7;
+            const int row = t / TPR, c0 = t % TPR;
             const int64_t g = rb * kRows + row;
             const bool valid = g < R;
             const int64_t gc = valid ? g : R - 1;
@@ -906,10 +1209,10 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
             const float y = c0 == 0 ? (src ? label_s[gc] : label_t[gc - n_source]) : 0.f;
             float* xr = bufA + row * (4 * D + 4);
             for (int cb = 0; cb < D4; cb += 32) {
-                float4 a[4], b[4], e[4], f[4];
+                float4 a[NI], b[NI], e[NI], f[NI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = cb + c0 + 8 * i;
+                for (int i = 0; i < NI; ++i) {
+                    const int c = cb + c0 + TPR * i;
                     if (c < D4) {
                         a[i] = ld4(su + uid * D + 4 * c); b[i] = ld4(si + iid * D + 4 * c);
                         e[i] = ld4(tu + uid * D + 4 * c); f[i] = ld4(ti + iid * D + 4 * c);
@@ -917,8 +1220,8 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
                 }
                 if (decltype(first)::value && cb == 0) prologue_commit(net, wo_sh, hq, pr);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = cb + c0 + 8 * i;
+                for (int i = 0; i < NI; ++i) {
+                    const int c = cb + c0 + TPR * i;
                     if (c < D4) {
                         st4(xr + 4 * c, a[i]); st4(xr + D + 4 * c, b[i]); st4(xr + 2 * D + 4 * c, e[i]); st4(xr + 3 * D + 4 * c, f[i]);
                         if (valid) {
@@ -948,9 +1251,14 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         lds_barrier();
         STAMP(1);
+        const bool anym = NW == 8 && __ballot(mrow[li] != 0.f) != 0ull;     // any overlapped row in this block (8 waves: else no cross product)
         for (int l = 0; l < L; ++l) {
             const float* Xin = smem + lo.a_off[l];
             float* Xout = smem + lo.a_off[l + 1];
+            if (NW == 8) {                                        // (the host offers this kernel for the shape class of these two only)
+                if (l == 0) fwd_layer_stream8(net, l, Xin, Xout, mrow, acts, rb * kRows, R, wave, li, lh, anym);
+                else fwd_layer_lds8(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh, anym);
+            } else
             if (l > 0 && net.wlds && !(net.dims[l] & 7)) fwd_layer_lds(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
             else if (l > 0 && net.wlds) fwd_layer<true>(net, l, Xin, Xout, wl, mrow, acts, rb * kRows, R, wave, li, lh);
             else if (net.vec && !(net.dims[l] & 127) && !(net.dims[l + 1] & 31))
@@ -987,7 +1295,7 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
         STAMP(2 + L);
         {   // ---- the output units' input gradient and their own weight gradients (this block's rows, in row order)
             float* Gl = ((L - 1) & 1) ? G1 : G0;
-            for (int e = t; e < kRows * 2 * dL; e += 256) {
+            for (int e = t; e < kRows * 2 * dL; e += NTH) {
                 const int row = e / (2 * dL), c = e - row * 2 * dL;
                 const int tower = c >= dL ? 1 : 0, j = c - tower * dL;
                 Gl[row * HS + c] = (trow[row] == tower) ? dzrow[row] * wo_sh[tower * (dL + 1) + j] : 0.f;
@@ -1013,7 +1321,7 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
             const float* Al = smem + lo.a_off[l + 1];                // this layer's post-ReLU outputs, same row stride as Gl
             const int off = net.act_off[l];
             const int q = (2 * dout) >> 2;
-            for (int e = t; e < kRows * q; e += 256) {              // ReLU backward; gz kept for the weight gradients
+            for (int e = t; e < kRows * q; e += NTH) {              // ReLU backward; gz kept for the weight gradients
                 const int row = e / q, c = 4 * (e - row * q);
                 const int64_t g = rb * kRows + row;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1027,6 +1335,11 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
             lds_barrier();
             const int din = net.dims[l];
             const bool lds_w = l > 0 && net.wlds;
+            if (NW == 8) {
+                if (l == 0) bwd_layer_quad8(net, l, Gl, smem + lo.x_off, mrow, gx0, rb * kRows, R, wave, li, lh, anym);
+                else if (!(dout & 31) && !(din & 31)) bwd_layer_tiles8(net, l, Gl, Gn, wl, mrow, wave, li, lh, anym);
+                else bwd_layer_lds8(net, l, Gl, Gn, wl, mrow, wave, li, lh, anym);
+            } else
             if (!(dout & 31) && !(din & 127)) {
                 if (lds_w) bwd_layer_quad<true>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
                 else bwd_layer_quad<false>(net, l, Gl, Gn, wl, mrow, gx0, rb * kRows, R, wave, li, lh);
@@ -1056,6 +1369,7 @@ __global__ __launch_bounds__(256) void conet_fb_kernel(conet_net net, conet_fb_l
     //  conet_fwd_finish_kernel's launch.  The release fence is an L2 write-back at agent scope, i.e. of EVERY dirty line of the XCD:
     //  this kernel's 40 MB of saved activations and gradients.  72 -> 82 us; the 5 us launch stays.)
     STAMP(42);
+    STAMPB(1);
 }
 
 // ------------------------------------------------------------------------------------------------------------ weight gradients
@@ -1293,7 +1607,7 @@ __global__ __launch_bounds__(256) void conet_wgrad_finish_kernel(conet_net net, 
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
-struct lds_plan { int strideA, strideB, strideG0, strideG1; size_t wl_floats, fwd_bytes, bwd_bytes; conet_fb_lds fb; size_t fb_bytes; };
+struct lds_plan { int strideA, strideB, strideG0, strideG1; size_t wl_floats, fwd_bytes, bwd_bytes; conet_fb_lds fb; size_t fb_bytes; int fb8; };
 
 int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* const* params) {
     if (L < 1 || L > kMaxL || !dims || !params) return 0;
@@ -1346,6 +1660,16 @@ int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* 
     lp.fb.wl_off = (int)o;
     o += lp.wl_floats + (lp.wl_floats ? 256 : 0);          // whole DMA instructions (stage_weights_dma)
     lp.fb_bytes = (o * sizeof(float) <= kLdsBudget && (net.wlds || L == 1)) ? o * sizeof(float) : 0;
+    // conet_fb_kernel<8> (one product per wave): layer 0 streamed in whole tiles, every later layer on LDS-staged weights in 8-wide K
+    // steps, and room behind G0 -- over the dead G1, layer-0 input and activation regions -- for the layer-0 cross accumulator
+    // [32][2 d0 + 4] (bwd_layer_quad8).  Other shapes keep the four-wave kernel.
+    lp.fb8 = 0;
+    lp.fb.x_off = lp.fb.g1_off;
+    if (lp.fb_bytes && L > 1 && net.wlds && net.vec && !(dims[0] & 127) && !(dims[1] & 31) && lp.fb.g0_off == 0 &&
+        (size_t)lp.fb.g1_off + (size_t)kRows * (2 * dims[0] + 4) <= (size_t)lp.fb.wl_off) {
+        lp.fb8 = 1;
+        for (int l = 1; l <= L; ++l) if (dims[l] & 7) lp.fb8 = 0;
+    }
     return 1;
 }
 
@@ -1440,14 +1764,23 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
         split_plan(tl.ntiles, R, &nsplit, &kc);
         const size_t wpart_bytes = ((size_t)tl.ntiles * nsplit * kJobFloats * sizeof(float) + 255) & ~(size_t)255;
         float* ou_part = (float*)((char*)workspace + wpart_bytes);
-        rc = lds_opt_in((const void*)conet_fb_kernel, lp.fb_bytes);
+        const char* fbw = getenv("CDR_CONET_FB_WAVES");               // "4": the four-wave kernel (A/B runs and the bit-equality test only)
+        const bool waves4 = fbw && atoi(fbw) == 4;
+        const bool eight = lp.fb8 && !waves4;
+        rc = lds_opt_in(eight ? (const void*)conet_fb_kernel<8> : (const void*)conet_fb_kernel<4>, lp.fb_bytes);
         if (rc) return rc;
         {
             cdr_time_scope ts(ctx, CDR_TAG_CONET_FB, s);
-            conet_fb_kernel<<<dim3(grid), dim3(256), lp.fb_bytes, s>>>(net, lp.fb, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s,
-                                                                       item_t, R, n_source, n_overlap, overlap_users, label_s, label_t,
-                                                                       label_cat, ids_cat, x0, acts, prob, maskf, ctx->partials, gz, gx0,
-                                                                       ou_part);
+            if (eight)
+                conet_fb_kernel<8><<<dim3(grid), dim3(512), lp.fb_bytes, s>>>(net, lp.fb, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s,
+                                                                              item_t, R, n_source, n_overlap, overlap_users, label_s, label_t,
+                                                                              label_cat, ids_cat, x0, acts, prob, maskf, ctx->partials, gz, gx0,
+                                                                              ou_part);
+            else
+                conet_fb_kernel<4><<<dim3(grid), dim3(256), lp.fb_bytes, s>>>(net, lp.fb, su_tab, si_tab, tu_tab, ti_tab, D, user_s, user_t, item_s,
+                                                                              item_t, R, n_source, n_overlap, overlap_users, label_s, label_t,
+                                                                              label_cat, ids_cat, x0, acts, prob, maskf, ctx->partials, gz, gx0,
+                                                                              ou_part);
         }
         CDR_LAUNCH_CHECK();
         conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(net, ctx->partials, grid, n_source, R, out);

@@ -927,6 +927,57 @@ def test_conet_forward_and_data_backward_in_one_launch(monkeypatch):
         assert_close(v, params[k].grad, what=k)
 
 
+@pytest.mark.parametrize('R,n_s,hidden,D,clustered', [(8190, 4095, [64, 32, 16, 8], 128, False), (8190, 4095, [64, 32, 16, 8], 128, True),
+                                                    (1000, 3, [64, 32, 16, 8], 128, False), (4097, 2048, [64, 16, 8], 128, True),
+                                                    (500, 250, [32, 32, 16, 8], 128, False)])
+def test_conet_eight_wave_kernel_is_bit_identical_to_the_four_wave_kernel(monkeypatch, R, n_s, hidden, D, clustered):
+    """conet_fb_kernel<8> (one product of a cross unit per wave, two waves per SIMD, the cross accumulator handed over through LDS; a
+    block without an overlapped row skips the cross product) against conet_fb_kernel<4> (CDR_CONET_FB_WAVES=4): loss, every layer
+    gradient and every table gradient bit for bit -- C3's shape and row count, overlapped rows scattered over all blocks or clustered
+    in the first ones (so that both kinds of block exist), a nearly one-domain batch, a three-layer stack, the tuned [32, 32, 16, 8] stack
+    (one column tile in layer 0: two units per pass)."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    from recbole_cdr_amd import binding as B_
+    torch.manual_seed(R + D)
+    ids = IdSpace(OU=300, TOU=500, SOU=700, OI=1, TOI=900, SOI=1100)
+    cfg = base_config(DEV, embedding_size=D, reg_weight=0.01, mlp_hidden_size=hidden)
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    assert model.fused_towers
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    rs = np.random.RandomState(R)
+    n_t = R - n_s
+    su, tu = rs.randint(0, ids.total_num_users, n_s), rs.randint(0, ids.OU + ids.TOU, n_t)
+    if clustered:                                             # overlapped users (id < OU) first: later blocks have none
+        su, tu = np.sort(su), np.sort(tu)
+    inter = {'source_user_id': torch.from_numpy(su), 'source_item_id': torch.from_numpy(rs.randint(0, ids.total_num_items, n_s)),
+             'source_label': torch.from_numpy((rs.rand(n_s) < 0.3).astype(np.float32)),
+             'target_user_id': torch.from_numpy(tu), 'target_item_id': torch.from_numpy(rs.randint(0, ids.OI + ids.TOI, n_t)),
+             'target_label': torch.from_numpy((rs.rand(n_t) < 0.3).astype(np.float32))}
+    dev_inter = to_dev(inter, DEV)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        B_.timing_enable(DEV, 64)
+        loss = model.calculate_loss(dev_inter)
+        loss.backward()
+        tags = [n for n, _ in B_.timing_collect(DEV)]
+        B_.timing_enable(DEV, 0)
+        assert 'conet_fb_kernel' in tags, tags
+        return loss.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
+
+    eight = run()
+    monkeypatch.setenv('CDR_CONET_FB_WAVES', '4')
+    four = run()
+    monkeypatch.delenv('CDR_CONET_FB_WAVES')
+    assert torch.equal(eight[0], four[0])
+    for k in eight[1]:
+        assert torch.equal(eight[1][k], four[1][k]), k
+
+
 def test_deferred_adam_ring_of_update_scalars_wraps():
     """The per-update scalars live in a ring (capacity 8 here): 45 updates -- five times round -- stay bit-identical to the dense
     sweep because the optimizer flushes every table before an entry some row still needs is overwritten; also through

@@ -23,7 +23,7 @@ S, k = 819, 4
 batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
 prof = None
 if os.environ.get('CDR_CONET_PROF'):
-    prof = torch.zeros(64, dtype=torch.int64, device=dev)
+    prof = torch.zeros(64 + 2 * 2048, dtype=torch.int64, device=dev)
     lib = B_.load()
     lib.cdr_conet_debug_prof.argtypes = [ctypes.c_void_p]
     assert lib.cdr_conet_debug_prof(ctypes.c_void_p(prof.data_ptr())) == 0
@@ -51,6 +51,12 @@ if prof is not None:
     if p[40]:        # conet_fb_kernel: entry, [gather, layers 0..3, output unit], [backward layers 3..0], tail start, end
         f = [p[40], p[43], p[44], p[45]] + list(p[:2 + 4 + 1 + 4]) + [p[41], p[42]]
         print('fwd+bwd stamps (us from kernel entry):', [round(float(x - f[0]) / 100.0, 2) for x in f])
+        nb = (R + 31) // 32
+        be = p[64:64 + 2 * nb].reshape(nb, 2).astype(np.float64) / 100.0        # per block: entry, exit (us)
+        t0 = be[:, 0].min()
+        print('blocks: entry %.2f .. %.2f us after the first one; exit %.2f .. %.2f us; block duration min %.2f median %.2f max %.2f us' % (
+            be[:, 0].min() - t0, be[:, 0].max() - t0, be[:, 1].min() - t0, be[:, 1].max() - t0,
+            (be[:, 1] - be[:, 0]).min(), np.median(be[:, 1] - be[:, 0]), (be[:, 1] - be[:, 0]).max()))
     else:
         f = p[:2 + 4 + 1]
         print('fwd stamps (us from start):', [round(float(x - f[0]) / 100.0, 2) for x in f])
