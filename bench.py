@@ -81,6 +81,9 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true', default=bool(int(os.environ.get('CDR_NO_PIPELINE', '0'))),
                     help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
+    ap.add_argument('--routed-batch-loss', action='store_true', help='c4 row shard: the routed batch loss even with one rank (--force-shard A/B)')
+    ap.add_argument('--replicated-batch-loss', action='store_true', help='c4 row shard: every rank scores the whole batch on the all-gathered stacked tables '
+                                                                         '(round-3 form) instead of its B/N slice on routed rows')
     ap.add_argument('--shard', default='dim', choices=['dim', 'row'],
                     help='N>1 layout of the C5 tables: dim = every rank holds D/N columns of every row (ids all-gathered, one partial '
                          'score per triple all-reduced); row = rows r %% N with the row / gradient-row all-to-all exchange')
@@ -1046,7 +1049,8 @@ def run_model_workload(args, world, rank, dev):
                 from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF, NativeGraphOps
                 rs = ShardedBiTGCF(ds.num_total_user, ds.num_total_item, ds.num_overlap_user, ds.num_overlap_item, ds.s_pairs, ds.t_pairs,
                                    cfg['embedding_size'], cfg['n_layers'], cfg['lambda_source'], cfg['lambda_target'], cfg['connect_way'],
-                                   cfg['reg_weight'], NativeGraphOps(dev), group=cand_groups['rowshard'], drop_rate=cfg['drop_rate'])
+                                   cfg['reg_weight'], NativeGraphOps(dev), group=cand_groups['rowshard'], drop_rate=cfg['drop_rate'],
+                                   batch_loss='replicated' if args.replicated_batch_loss else ('routed' if args.routed_batch_loss else 'auto'))
                 return ('rowshard', rs, DenseAdam(list(rs.params.values()), lr=1e-3))
             from recbole_cdr_amd.dp import ShardedDataParallel
             return ('replica-dp', ShardedDataParallel(model, group=cand_groups['replica-dp'], lr=1e-3), None)
@@ -1250,8 +1254,22 @@ def run_model_workload(args, world, rank, dev):
     result['roofline'] = roof
     if rowshard is not None:
         p_ = rowshard.part
-        result['exchange'] = {'all_gather_bytes_received_per_rank_per_step': float((world - 1) * p_.nl * 4 * cfg['embedding_size'] * (4 * cfg['n_layers'] + 2 * (cfg['n_layers'] + 1))),
-                              'collectives_per_step': 2 * (2 * cfg['n_layers'] + 1), 'note': 'per domain: L all-gathers of E forward, L of g(1+E) backward, one of the stacked outputs'}
+        D_, L_ = cfg['embedding_size'], cfg['n_layers']
+        layer_bytes = float((world - 1) * p_.nl * 4 * D_ * 4 * L_)                  # 2 domains x (L forward + L backward) all-gathers of [nl, D]
+        if rowshard.batch_loss == 'replicated':
+            result['exchange'] = {'all_gather_bytes_received_per_rank_per_step': layer_bytes + float((world - 1) * p_.nl * 4 * D_ * 2 * (L_ + 1)),
+                                  'collectives_per_step': 2 * (2 * L_ + 1), 'batch_loss': 'replicated',
+                                  'note': 'per domain: L all-gathers of E forward, L of g(1+E) backward, one of the stacked outputs'}
+        else:
+            Wx = (L_ + 1) * D_ if cfg['connect_way'] == 'concat' else 2 * D_
+            Bs = -(-(rows_per_step // 2) // world)
+            row_bytes = float(2 * 2 * (world - 1) * 2 * Bs * Wx * 4)                  # 2 domains x (reduce-scatter + all-gather) of [2 Bs, Wx] per rank
+            result['exchange'] = {'all_gather_bytes_received_per_rank_per_step': layer_bytes, 'batch_row_bytes_received_per_rank_per_step': row_bytes,
+                                  'collectives_per_step': 2 * (2 * L_) + 2 * 2 + 1, 'batch_loss': 'routed',
+                                  'note': 'per domain: L all-gathers of E forward, L of g(1+E) backward; the batch: one reduce-scatter of the owned rows of every '
+                                          'batch row [N, 2 B/N, W] -> each rank scores its B/N slice, one all-reduce of six sums, one all-gather of the gradient rows '
+                                          '(instead of the all-gather of the stacked [n, (L+1) D] tables: %.1f MB per rank and step at N = %d)'
+                                          % ((world - 1) * p_.nl * 4 * D_ * 2 * (L_ + 1) / 1e6, world)}
     if rank == 0 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_model(args, ds, cfg, S, k, batches[0] if pairwise else None)
     return result

@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 40
+#define CDR_ABI_VERSION 41
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -698,6 +698,14 @@ int cdr_segsum_rows(cdr_ctx* ctx, void* stream, const uint32_t* keys_sorted, con
 int cdr_interleave_shards(void* stream, const float* gathered, int world, int64_t U, int64_t Nl, int64_t N, float* out);
 int cdr_gather_owned_rows(void* stream, const float* shard, int D, const int64_t* ids, int64_t n, int world, int rank,
                           float* out);
+/* Block-partitioned tables (BiTGCF's row shard, BASELINE configs[3]; reference math bitgcf.py:221-247: the batch loss gathers
+ * user / item rows of the propagated tables): the rank owns positions [lo, lo + rows) of the all-gathered layout.
+ * cdr_gather_block_rows: out[r,:] = owned(pos[r]) ? shard[pos[r] - lo,:] : 0 (pos < 0 = padding slot) -- a reduce-scatter(sum) over the
+ *     ranks of this, taken over the REPLICATED batch's positions, hands every rank the rows of its slice of the batch exactly.
+ * cdr_scatter_add_block_rows: grad_shard[pos[r] - lo,:] += src[r,:] for the owned positions (fp32 atomics, as cdr_scatter_add_rows). */
+int cdr_gather_block_rows(void* stream, const float* shard, int D, const int64_t* pos, int64_t n, int64_t lo, int64_t rows, float* out);
+int cdr_scatter_add_block_rows(void* stream, float* grad_shard, int D, const int64_t* pos, int64_t n, int64_t lo, int64_t rows,
+                               const float* src);
 int cdr_topk_merge_shards(void* stream, const float* vals, const int64_t* local_idx, int world, int64_t U, int k,
                           int local_to_global /* 1: entry l of shard p is item l * world + p; 0: entries are output columns already */,
                           float* out_vals, int64_t* out_idx);

@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -184,6 +184,8 @@ _SIGNATURES = {
     'cdr_segsum_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr],
     'cdr_interleave_shards': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_gather_owned_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_int, _c_int, _c_ptr],
+    'cdr_gather_block_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
+    'cdr_scatter_add_block_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_ids_pack32': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr],
     'cdr_ids_unpack32': [_c_ptr, _c_ptr, _c_int, _c_i64, _c_ptr, _c_ptr],
     'cdr_point_partial_dot': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr],

@@ -11,11 +11,18 @@ EXCEPT the SpMM, whose gather side needs every row:
 
     forward, per layer and domain     all-gather E_l (n x D)              -> local SpMM rows + fused layer math
     backward, per layer and domain    all-gather g (.) (1 + E_l)          -> local SpMM rows   (A is symmetric: A^T g = A g)
-    after the propagation             all-gather the stacked outputs      -> every rank evaluates the (small) batch itself
+    after the propagation             the batch's rows to the rank that scores them (below)
 
-The batch loss is replicated -- 8 k rows against a propagation over 80 k nodes x 2 domains x L layers -- so its gradient with
-respect to the gathered tables is identical on every rank and each rank simply keeps its own segment: the data path contains
-all-gathers only, no reduction, and the result does not depend on the rank count beyond fp32 summation order inside a row.
+The batch loss (``batch_loss='routed'``, what 'auto' picks for more than one rank).  Every rank holds the whole batch's ids (the loader is replicated), so no id
+exchange is needed: rank r scores rows [r B/G, (r+1) B/G) of the batch.  Each rank gathers, for EVERY batch row, the user / item row
+of the stacked output it owns (zeros otherwise: ``cdr_gather_block_rows``); one reduce-scatter (sum; exactly one addend per row is
+non-zero, so the sum is exact) hands every rank the rows of its slice -- 2 B (L+1) D floats on the wire instead of the all-gather of
+the whole stacked table (n (L+1) D: 61 MB per domain at Douban sizes against 12.6 MB).  The slice's BCE sum and the two EmbLoss
+sums of squares are all-reduced (six floats for both domains), each rank forms the gradient rows of its slice with the GLOBAL
+batch size and norms, an all-gather returns them and every rank scatter-adds the rows it owns (``cdr_scatter_add_block_rows``).
+Per rank the batch costs 1/G of the scoring and no dense [n, W] gradient of the gathered table.  ``batch_loss='replicated'`` keeps the
+round-3 form: all-gather of the stacked outputs, every rank evaluates the whole batch on the gathered tables and keeps its own
+segment of the (identical) gradient -- all-gathers only, no reduction.
 
 ``ops`` supplies the local arithmetic: ``NativeGraphOps`` (libcdrhip) here, the oracle's torch formulas in the gloo CPU tests.
 """
@@ -148,6 +155,58 @@ class NativeGraphOps:
                 B_.f32(gx), 0)
         return gx
 
+    # ---- routed batch loss: rows of this rank's slice of the batch -------------------------------------------------------------------
+    def gather_owned(self, X, pos, lo):
+        """out[r] = X[pos[r] - lo] where this rank owns position pos[r] of the gathered layout, else 0 (pos < 0: padding)."""
+        B_ = self.B_
+        out = torch.empty(pos.numel(), X.shape[1], device=X.device, dtype=torch.float32)
+        B_.call('cdr_gather_block_rows', B_.stream(), B_.f32(X), X.shape[1], B_.i64(pos), pos.numel(), int(lo), X.shape[0], B_.f32(out))
+        return out
+
+    def scatter_owned(self, rows, W, pos, lo, src):
+        B_ = self.B_
+        g = torch.zeros(rows, W, device=src.device, dtype=torch.float32)
+        B_.call('cdr_scatter_add_block_rows', B_.stream(), B_.f32(g), W, B_.i64(pos), pos.numel(), int(lo), rows, B_.f32(src.contiguous()))
+        return g
+
+    def slice_partials(self, rows, Bs, n, W, D, concat, label):
+        """This rank's slice of the batch as delivered by the reduce-scatter: rows [2 Bs, Wx] = [user rows ; item rows] (the first n of each
+        half are real), Wx = W (concat: the ego rows are the first D columns) or W + D (mean: ego rows behind the W output columns).
+        -> (state, [sum of BCE terms, sum ||ego user rows||^2, sum ||ego item rows||^2]): the three numbers that are all-reduced."""
+        F_, B_ = self.F_, self.B_
+        dev = rows.device
+        if n == 0:
+            return None, torch.zeros(3, device=dev, dtype=torch.float32)
+        key = (n, Bs, str(dev))
+        if getattr(self, '_ar_key', None) != key:
+            ar = torch.arange(n, device=dev, dtype=torch.int64)
+            self._ar_key, self._ar = key, (ar, ar + Bs)
+        au, ai = self._ar
+        a = (rows.detach() if rows.shape[1] == W else rows[:, :W].contiguous()).requires_grad_(True)      # the compact [2 Bs, W] "table"
+        bce, _ = F_.PointGatherLoss.apply(B_.CDR_LOSS_BCE, a, a, None, None, au, ai, label, 0.0)         # mean over the n rows
+        e = (rows[:, :D] if concat else rows[:, W:]).contiguous()
+        out3 = torch.empty(3, device=dev, dtype=torch.float32)
+        B_.call('cdr_embloss_fwd', B_.ctx(dev), B_.stream(), B_.f32(e), B_.f32(e), D, B_.i64(au), B_.i64(ai), n, B_.f32(out3))
+        part = torch.cat([bce.detach().reshape(1) * float(n), out3[1:3] * out3[1:3]])
+        return (a, bce, e, n, concat, D, au, ai), part
+
+    def slice_grads(self, state, totals, B, reg_weight):
+        """Gradient rows [2 Bs, Wx] of the slice for the GLOBAL batch: d/d rows of [BCE-sum / B + reg_weight (||Eu|| + ||Ei||) / B] with the
+        all-reduced sums (recbole's EmbLoss: un-squared norms of the whole batch's rows)."""
+        B_ = self.B_
+        a, bce, e, n, concat, D, au, ai = state
+        (bce.sum() * (float(n) / float(B))).backward()
+        out3 = torch.cat([totals[:1], torch.sqrt(totals[1:3])]).contiguous()          # [., ||Eu||, ||Ei||] of the whole batch
+        go = torch.full((1,), float(reg_weight) * float(n) / float(B), device=e.device, dtype=torch.float32)
+        ge = torch.zeros_like(e)
+        B_.call('cdr_embloss_bwd_dense', B_.stream(), B_.f32(e), B_.f32(e), D, B_.i64(au), B_.i64(ai), n, B_.f32(out3), B_.f32(go),
+                B_.f32(ge), B_.f32(ge))
+        if concat:
+            g = a.grad
+            g[:, :D] += ge
+            return g
+        return torch.cat([a.grad, ge], 1)
+
     def batch_loss(self, out_g, E0_g, pu, pi, label, reg_weight):
         """bitgcf.py:221-247 on the all-gathered tables (ids already mapped to gathered positions): BCE(sigmoid(<u, i>)) +
         reg_weight * EmbLoss(ego rows).  Returns (loss, d loss / d out_g, d loss / d E0_g), dense."""
@@ -169,9 +228,13 @@ class ShardedBiTGCF:
               'target_item_embedding.weight')
 
     def __init__(self, n_users, n_items, n_overlap_users, n_overlap_items, s_pairs, t_pairs, embedding_size, n_layers, lambda_source,
-                 lambda_target, connect_way, reg_weight, ops, group=None, init=None, seed=2022, drop_rate=0.0):
+                 lambda_target, connect_way, reg_weight, ops, group=None, init=None, seed=2022, drop_rate=0.0, batch_loss='auto'):
+        assert batch_loss in ('auto', 'routed', 'replicated'), batch_loss
         self.group = group
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        # 'auto': routed rows wherever there is a wire to save; one rank alone has none, and the routed form's ~27 extra small launches
+        # cost it 0.25 ms per step there (profiles/r04_c4_batch_loss.txt)
+        self.batch_loss = ('routed' if self.G > 1 else 'replicated') if batch_loss == 'auto' else batch_loss
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.part = BlockPartition(n_users, n_items, self.G)
         self.ops, self.D, self.L = ops, int(embedding_size), int(n_layers)
@@ -219,8 +282,31 @@ class ShardedBiTGCF:
             work[0].wait()                      # stream-level wait on the GPU: the host does not block
         return out
 
+    def _is_gloo(self):
+        return self.G > 1 and dist.get_backend(self.group) == 'gloo'          # the functional-test transport has no reduce_scatter
+
+    def reduce_scatter_rows(self, S):
+        """S [G, m, W]: chunk r summed over the ranks -> [m, W] on rank r."""
+        if self.G == 1:
+            return S[0]
+        if self._is_gloo():
+            dist.all_reduce(S, group=self.group)
+            return S[self.rank].clone()
+        out = torch.empty(tuple(S.shape[1:]), device=S.device, dtype=S.dtype)
+        dist.reduce_scatter_tensor(out, S, group=self.group)
+        return out
+
+    def all_gather_rows(self, x):
+        """[m, W] of every rank -> [G * m, W] in rank order."""
+        if self.G == 1:
+            return x
+        x = x.contiguous()
+        out = torch.empty((self.G * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
     # ---- propagation ---------------------------------------------------------------------------------------------------
-    def _propagate(self):
+    def _propagate(self, want_ego_gathered=True):
         p, ops, D = self.part, self.ops, self.D
         P = self.params
         E = {'s': torch.cat([P[self.TABLES[0]].data, P[self.TABLES[1]].data], 0), 't': torch.cat([P[self.TABLES[2]].data, P[self.TABLES[3]].data], 0)}
@@ -250,29 +336,76 @@ class ShardedBiTGCF:
                 stack[d].append(y)
             saved.append((E, side, S2, nrm))
             E = S2
-        if E0_g is None:
+        if E0_g is None and want_ego_gathered:
             E0_g = {d: self.gather(stack[d][0]) for d in 'st'}
         nb = self.L + 1
         if self.connect_way == 'concat':
             out = {d: torch.cat(stack[d], 1) for d in 'st'}
         else:
             out = {d: torch.stack(stack[d], 1).mean(1) for d in 'st'}
-        return out, E0_g, saved, nb
+        return out, E0_g, saved, nb, {d: stack[d][0] for d in 'st'}
+
+    def _routed_batch_loss(self, inter, out, ego):
+        """The batch loss with rank r scoring rows [r Bs, (r+1) Bs) of the (replicated) batch: rows by reduce-scatter, three sums per domain by
+        all-reduce, gradient rows by all-gather (module docstring).  -> (losses, g_out, g_E0) with g_* = this rank's [nl, .] segments."""
+        p, ops, D, G, r = self.part, self.ops, self.D, self.G, self.rank
+        lo = r * p.nl
+        concat = self.connect_way == 'concat'                    # then the ego rows are the first D columns of the stacked output
+        st, parts = {}, []
+        for d, pre in (('s', 'source'), ('t', 'target')):
+            uid, iid = inter[f'{pre}_user_id'].reshape(-1), inter[f'{pre}_item_id'].reshape(-1)
+            B = uid.numel()
+            Bs = -(-B // G)
+            pad = G * Bs - B
+            pu, pi = p.user_pos(uid), p.item_pos(iid)
+            if pad:
+                fill = torch.full((pad,), -1, device=pu.device, dtype=pu.dtype)
+                pu, pi = torch.cat([pu, fill]), torch.cat([pi, fill])
+            posS = torch.stack([pu.view(G, Bs), pi.view(G, Bs)], 1).reshape(-1).contiguous()      # [G][user rows of slice g ; item rows of slice g]
+            X = out[d] if concat else torch.cat([out[d], ego[d]], 1)
+            W = out[d].shape[1]
+            rows = self.reduce_scatter_rows(ops.gather_owned(X.contiguous(), posS, lo).view(G, 2 * Bs, X.shape[1]))
+            n = max(0, min(Bs, B - r * Bs))                                                       # real rows of my slice
+            label = inter[f'{pre}_label'].reshape(-1).float()[r * Bs:r * Bs + n].contiguous()
+            state, part = ops.slice_partials(rows, Bs, n, W, D, concat, label)
+            st[d] = (state, posS, B, Bs, n, X.shape[1], W)
+            parts.append(part)
+        totals = torch.cat(parts)
+        if G > 1:
+            dist.all_reduce(totals, group=self.group)                                             # six floats: both domains at once
+        t2 = totals.view(2, 3)
+        bkey = (st['s'][2], st['t'][2])
+        if getattr(self, '_bd_key', None) != bkey:               # (a host-to-device copy per step would drain the stream: cached)
+            self._bd_key, self._bd = bkey, torch.tensor([float(bkey[0]), float(bkey[1])], device=totals.device)
+        Bd = self._bd
+        lvec = t2[:, 0] / Bd + self.reg_weight * (torch.sqrt(t2[:, 1]) + torch.sqrt(t2[:, 2])) / Bd
+        losses, g_out, g_E0 = [lvec[0], lvec[1]], {}, {}
+        for k, d in enumerate('st'):
+            state, posS, B, Bs, n, Wx, W = st[d]
+            grow = ops.slice_grads(state, totals[3 * k:3 * k + 3], B, self.reg_weight) if n else \
+                torch.zeros(2 * Bs, Wx, device=totals.device, dtype=torch.float32)
+            g = ops.scatter_owned(p.nl, Wx, posS, lo, self.all_gather_rows(grow))
+            g_out[d] = g[:, :W]
+            g_E0[d] = None if concat else g[:, W:]
+        return losses, g_out, g_E0
 
     def loss_and_grads(self, inter):
         """(loss_source, loss_target) of the FULL batch ``inter`` (every rank passes the same batch) and this rank's gradient blocks in
         ``self.params[...].grad``."""
         p, ops, D = self.part, self.ops, self.D
-        out, E0_g, saved, nb = self._propagate()
+        out, E0_g, saved, nb, ego = self._propagate(want_ego_gathered=self.batch_loss == 'replicated')
         losses, g_out, g_E0 = [], {}, {}
-        seg = slice(self.rank * p.nl, (self.rank + 1) * p.nl)
-        pend = {d: self.gather_start(out[d]) for d in 'st'}         # the target stack arrives under the source batch loss
-        for d, pre in (('s', 'source'), ('t', 'target')):
-            out_g = self.gather_finish(pend[d])
-            pu, pi = p.user_pos(inter[f'{pre}_user_id'].reshape(-1)), p.item_pos(inter[f'{pre}_item_id'].reshape(-1))
-            loss, go, ge = ops.batch_loss(out_g, E0_g[d], pu, pi, inter[f'{pre}_label'].reshape(-1).float(), self.reg_weight)
-            losses.append(loss)
-            g_out[d], g_E0[d] = go[seg], ge[seg]                # identical on every rank: keep the own segment
+        if self.batch_loss == 'routed':
+            losses, g_out, g_E0 = self._routed_batch_loss(inter, out, ego)
+        else:
+            seg = slice(self.rank * p.nl, (self.rank + 1) * p.nl)
+            pend = {d: self.gather_start(out[d]) for d in 'st'}         # the target stack arrives under the source batch loss
+            for d, pre in (('s', 'source'), ('t', 'target')):
+                out_g = self.gather_finish(pend[d])
+                pu, pi = p.user_pos(inter[f'{pre}_user_id'].reshape(-1)), p.item_pos(inter[f'{pre}_item_id'].reshape(-1))
+                loss, go, ge = ops.batch_loss(out_g, E0_g[d], pu, pi, inter[f'{pre}_label'].reshape(-1).float(), self.reg_weight)
+                losses.append(loss)
+                g_out[d], g_E0[d] = go[seg], ge[seg]                # identical on every rank: keep the own segment
         # ---- backward through the stack, last layer first
         if self.connect_way == 'concat':
             g_blk = {d: [g_out[d][:, b * D:(b + 1) * D] for b in range(nb)] for d in 'st'}
@@ -294,7 +427,7 @@ class ShardedBiTGCF:
             for d in 'st':
                 g_next[d] = ops.graph_layer_bwd(self.csr[d], self.gather_finish(pend[d]), gnew[d], side[d])
         for d, names in (('s', self.TABLES[:2]), ('t', self.TABLES[2:])):
-            g = g_blk[d][0] + g_E0[d]
+            g = g_blk[d][0] if g_E0[d] is None else g_blk[d][0] + g_E0[d]
             if g_next[d] is not None:
                 g = g + g_next[d]
             self.params[names[0]].grad = g[:p.bu].contiguous()
@@ -306,7 +439,7 @@ class ShardedBiTGCF:
         """The four FULL propagated tables (evaluation: bitgcf.py:264-282; dropout off), assembled from every rank's rows."""
         was, self.training = self.training, False
         try:
-            out, _, _, _ = self._propagate()
+            out, _, _, _, _ = self._propagate()
         finally:
             self.training = was
         res = []

@@ -182,6 +182,47 @@ extern "C" int cdr_gather_owned_rows(void* stream, const float* tab, int D, cons
     return CDR_OK;
 }
 
+// Block-partitioned tables (bitgcf_shard.BlockPartition): a rank owns the rows whose position in the all-gathered layout lies in
+// [lo, lo + rows).  For a REPLICATED list of positions (every rank holds the whole batch's ids) the rows travel by reduction instead of
+// by an id exchange: out[r] = shard[pos[r] - lo] if this rank owns pos[r], else 0 (pos < 0: nobody's, a padding slot) -- a reduce-scatter
+// (sum) of this over the ranks hands every rank the rows of ITS slice of the batch exactly (x + 0 + ... + 0 == x); and the way back,
+// grad_shard[pos[r] - lo] += src[r] for the owned positions of the all-gathered gradient rows (bitgcf.py:221-247 over row-sharded tables).
+__global__ __launch_bounds__(kBlock) void gather_block_rows_kernel(const float* __restrict__ tab, int D, const int64_t* __restrict__ pos,
+                                                                   int64_t n, int64_t lo, int64_t rows, float* __restrict__ out) {
+    const int64_t total = n * D;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = t / D; const int d = (int)(t - r * D);
+        const int64_t q = pos[r] - lo;
+        out[t] = (pos[r] >= 0 && q >= 0 && q < rows) ? tab[q * D + d] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_add_block_rows_kernel(float* __restrict__ grad, int D, const int64_t* __restrict__ pos,
+                                                                        int64_t n, int64_t lo, int64_t rows, const float* __restrict__ src) {
+    const int64_t total = n * D;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = t / D; const int d = (int)(t - r * D);
+        const int64_t q = pos[r] - lo;
+        if (pos[r] >= 0 && q >= 0 && q < rows) atomicAdd(grad + q * D + d, src[t]);
+    }
+}
+
+extern "C" int cdr_gather_block_rows(void* stream, const float* shard, int D, const int64_t* pos, int64_t n, int64_t lo, int64_t rows,
+                                     float* out) {
+    CDR_CHECK_ARG(shard && pos && out && D > 0 && n > 0 && rows > 0);
+    gather_block_rows_kernel<<<dim3(grid_for(n * D)), dim3(kBlock), 0, (hipStream_t)stream>>>(shard, D, pos, n, lo, rows, out);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_scatter_add_block_rows(void* stream, float* grad_shard, int D, const int64_t* pos, int64_t n, int64_t lo, int64_t rows,
+                                          const float* src) {
+    CDR_CHECK_ARG(grad_shard && pos && src && D > 0 && n > 0 && rows > 0);
+    scatter_add_block_rows_kernel<<<dim3(grid_for(n * D)), dim3(kBlock), 0, (hipStream_t)stream>>>(grad_shard, D, pos, n, lo, rows, src);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
 // Per-shard top-k lists -> the global top-k (sharded full-sort evaluation): every rank all-gathers its k best
 // (value, LOCAL row) per user; one wave per user then selects k times over the world*k candidates, translating
 // local row l of producer p to the global item id l * world + p.  Order: value descending, ties to the smaller item id --

@@ -642,6 +642,36 @@ class OracleGraphOps:
         xr = x.clone().requires_grad_(True)
         return torch.autograd.grad(torch.nn.functional.normalize(xr, p=2, dim=1), xr, gy)[0]
 
+    def gather_owned(self, X, pos, lo):
+        q = pos - lo
+        own = (pos >= 0) & (q >= 0) & (q < X.shape[0])
+        out = torch.zeros(pos.numel(), X.shape[1], dtype=X.dtype)
+        out[own] = X[q[own]]
+        return out
+
+    def scatter_owned(self, rows, W, pos, lo, src):
+        q = pos - lo
+        own = (pos >= 0) & (q >= 0) & (q < rows)
+        return torch.zeros(rows, W, dtype=src.dtype).index_add_(0, q[own], src[own])
+
+    def slice_partials(self, rows, Bs, n, W, D, concat, label):
+        if n == 0:
+            return None, torch.zeros(3)
+        x = rows.detach().clone().requires_grad_(True)
+        xu, xi = x[:n, :W], x[Bs:Bs + n, :W]
+        eu, ei = (x[:n, :D], x[Bs:Bs + n, :D]) if concat else (x[:n, W:], x[Bs:Bs + n, W:])
+        p = torch.sigmoid((xu * xi).sum(1))
+        bce_sum = torch.nn.functional.binary_cross_entropy(p, label, reduction='sum')        # recbole's BCELoss, un-averaged
+        return (x, eu, ei, bce_sum), torch.stack([bce_sum.detach(), (eu.detach() ** 2).sum(), (ei.detach() ** 2).sum()])
+
+    def slice_grads(self, state, totals, B, reg_weight):
+        x, eu, ei, bce_sum = state
+        # d/d rows of [BCE-sum / B + reg_weight (||Eu||_F + ||Ei||_F) / B] with the norms of the WHOLE batch (EmbLoss: un-squared norms):
+        # d||E||_F / d e = e / ||E||_F, written as a surrogate whose autograd gradient is exactly that
+        nu, ni = torch.sqrt(totals[1]), torch.sqrt(totals[2])
+        surrogate = bce_sum / B + reg_weight * ((eu * eu.detach()).sum() / nu + (ei * ei.detach()).sum() / ni) / B
+        return torch.autograd.grad(surrogate, x)[0]
+
     def batch_loss(self, out_g, E0_g, pu, pi, label, reg_weight):
         from oracle.losses import bce_loss, emb_loss
         a = out_g.detach().requires_grad_(True); e = E0_g.detach().requires_grad_(True)
@@ -675,7 +705,7 @@ def _bitgcf_case(connect_way, seed=3):
     return ids, s_pairs, t_pairs, params, inter, D
 
 
-def _worker_bitgcf(rank, world, port, connect_way, q):
+def _worker_bitgcf(rank, world, port, connect_way, q, batch_loss='routed'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -684,7 +714,7 @@ def _worker_bitgcf(rank, world, port, connect_way, q):
         from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF
         ids, s_pairs, t_pairs, params, inter, D = _bitgcf_case(connect_way)
         m = ShardedBiTGCF(ids.total_num_users, ids.total_num_items, ids.OU, ids.OI, s_pairs, t_pairs, D, 2, 0.8, 0.7, connect_way, 0.01,
-                          OracleGraphOps(), init=params)
+                          OracleGraphOps(), init=params, batch_loss=batch_loss)
         opt = torch.optim.Adam(list(m.params.values()), lr=0.01)
         losses = []
         for _ in range(2):                                        # two steps: the second one runs on updated shards
@@ -699,17 +729,21 @@ def _worker_bitgcf(rank, world, port, connect_way, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,connect_way', [(2, 'concat'), (3, 'mean'), (4, 'concat')])
-def test_row_sharded_bitgcf_matches_single_process(world, connect_way):
+@pytest.mark.parametrize('world,connect_way,batch_loss', [(2, 'concat', 'routed'), (3, 'mean', 'routed'), (4, 'concat', 'routed'),
+                                                          (3, 'concat', 'routed'), (2, 'mean', 'replicated'), (4, 'concat', 'replicated')])
+def test_row_sharded_bitgcf_matches_single_process(world, connect_way, batch_loss):
     """BASELINE configs[3]: tables, Adam state, adjacency rows and transfer-layer degrees cut into ``world`` row blocks, per-layer
     all-gather of E (forward) and of g (1 + E) (backward); uneven blocks (padding rows), overlap rows that straddle the block
     boundary, user-overlap and item-overlap id spaces.  Two Adam steps: both losses, all four full tables and the propagated
-    tables equal the single-process oracle (torch autograd over the reference's formulas)."""
+    tables equal the single-process oracle (torch autograd over the reference's formulas).  ``routed``: rank r scores its B / world
+    slice of the batch (40 rows over 3 ranks: 14 + 14 + 12, padding slots) on rows delivered by a reduce-scatter, the BCE sum and the
+    EmbLoss sums of squares are all-reduced, gradient rows return by all-gather; ``replicated``: every rank scores the whole batch on the
+    all-gathered stacked tables."""
     from oracle import bitgcf as obit
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_bitgcf, args=(r, world, port, connect_way, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_bitgcf, args=(r, world, port, connect_way, q, batch_loss)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
