@@ -339,12 +339,12 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
 // One lane group per piece of a long segment: partial[pi] = signed sum of the piece's gradient rows in occurrence order,
 // pcnt[pi] = its EmbLoss occurrences.  Four row loads in flight per lane; the adds stay in order.
 template <int LPR, bool SIGNED>
-__global__ __launch_bounds__(kBlock) void seg_piece_sum_kernel(int D, const uint32_t* __restrict__ perm,
-                                                               const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
-                                                               const int64_t* __restrict__ occ_ids,
-                                                               const unsigned* __restrict__ counters,
-                                                               const seg_piece* __restrict__ pieces, float* __restrict__ partial,
-                                                               int* __restrict__ pcnt) {
+__device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __restrict__ perm,
+                                                   const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
+                                                   const int64_t* __restrict__ occ_ids,
+                                                   const unsigned* __restrict__ counters,
+                                                   const seg_piece* __restrict__ pieces, float* __restrict__ partial,
+                                                   int* __restrict__ pcnt) {
     constexpr int GPB = kBlock / LPR;
     constexpr int UN = 4;
     const int sub = threadIdx.x % LPR;
@@ -379,15 +379,24 @@ __global__ __launch_bounds__(kBlock) void seg_piece_sum_kernel(int D, const uint
         }
     }
 }
+template <int LPR, bool SIGNED>
+__global__ __launch_bounds__(kBlock) void seg_piece_sum_kernel(int D, const uint32_t* __restrict__ perm,
+                                                               const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
+                                                               const int64_t* __restrict__ occ_ids,
+                                                               const unsigned* __restrict__ counters,
+                                                               const seg_piece* __restrict__ pieces, float* __restrict__ partial,
+                                                               int* __restrict__ pcnt) {
+    seg_piece_sum_body<LPR, SIGNED>(D, perm, G, neg_start, reg_limit, occ_ids, counters, pieces, partial, pcnt);
+}
 
 // One lane group per long segment: piece sums added in piece order, then the same update as the head-only path.
 template <int LPR, int OPT>
-__global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
-                                                                 int D, const uint32_t* __restrict__ keys,
-                                                                 const float* __restrict__ reg_coef, apply_hp hp,
-                                                                 const unsigned* __restrict__ counters,
-                                                                 const seg_long* __restrict__ longs,
-                                                                 const float* __restrict__ partial, const int* __restrict__ pcnt) {
+__device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                     int D, const uint32_t* __restrict__ keys,
+                                                     const float* __restrict__ reg_coef, apply_hp hp,
+                                                     const unsigned* __restrict__ counters,
+                                                     const seg_long* __restrict__ longs,
+                                                     const float* __restrict__ partial, const int* __restrict__ pcnt) {
     HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
@@ -414,6 +423,15 @@ __global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(float* __restri
                               w, acc, c * (float)cnt, hp);
         }
     }
+}
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                                 int D, const uint32_t* __restrict__ keys,
+                                                                 const float* __restrict__ reg_coef, apply_hp hp,
+                                                                 const unsigned* __restrict__ counters,
+                                                                 const seg_long* __restrict__ longs,
+                                                                 const float* __restrict__ partial, const int* __restrict__ pcnt) {
+    seg_long_finish_body<LPR, OPT>(W, Mo, Vo, D, keys, reg_coef, hp, counters, longs, partial, pcnt);
 }
 
 // Two tables in ONE sort: rocPRIM's radix sort costs ~0.16 ms whether it sorts 1 M or 3 M pairs (a chain of small launches),
@@ -600,8 +618,10 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
 __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
                                                              float reg_weight, float* __restrict__ out9, int kmul = 1,
                                                              int64_t* __restrict__ step_u_dev = nullptr, int64_t* __restrict__ step_i_dev = nullptr,
-                                                             float* __restrict__ hp_dev = nullptr, float lr = 0.f, float b1 = 0.f, float b2 = 0.f) {
+                                                             float* __restrict__ hp_dev = nullptr, float lr = 0.f, float b1 = 0.f, float b2 = 0.f,
+                                                             unsigned* __restrict__ zero4 = nullptr) {
     __shared__ double smem[2 * (kBlock / 64)];
+    if (zero4 && threadIdx.x >= 64 && threadIdx.x < 68) zero4[threadIdx.x - 64] = 0u;       // the head lists' counters (occ_flags_kernel): no launch of their own
     if (hp_dev && threadIdx.x < 2) {
         int64_t* c = threadIdx.x == 0 ? step_u_dev : step_i_dev;
         const int64_t st = c[0] + 1;
@@ -624,8 +644,12 @@ __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __res
 
 // loss scalars of the fused step: as step_finish_kernel, but out9[4..5] (the EmbLoss coefficients the kernels used) stay
 __global__ __launch_bounds__(kBlock) void step_finish_keep_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
-                                                                  float reg_weight, float* __restrict__ out9) {
+                                                                  float reg_weight, float* __restrict__ out9,
+                                                                  unsigned* __restrict__ zero_a = nullptr, unsigned* __restrict__ zero_b = nullptr) {
     __shared__ double smem[3 * (kBlock / 64)];
+    // the long-segment counters of the two duplicate-row applies behind this launch (apply_dups_pair): no launches of their own
+    if (zero_a && threadIdx.x >= 64 && threadIdx.x < 68) zero_a[threadIdx.x - 64] = 0u;
+    if (zero_b && threadIdx.x >= 128 && threadIdx.x < 132) zero_b[threadIdx.x - 128] = 0u;
     double acc[3] = {0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
         const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
@@ -857,14 +881,14 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs T
 // (any order: every segment is summed by one lane group in occurrence order, whoever takes it).  Long segments as in
 // rowwise_apply_kernel.
 template <int LPR, int OPT, bool SIGNED>
-__global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
-                                                                    int D, const uint32_t* __restrict__ keys,
-                                                                    const uint32_t* __restrict__ perm, int64_t n,
-                                                                    const uint32_t* __restrict__ heads, const unsigned* __restrict__ nheads,
-                                                                    const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
-                                                                    const float* __restrict__ reg_coef, apply_hp hp,
-                                                                    unsigned* __restrict__ counters, seg_long* __restrict__ longs,
-                                                                    seg_piece* __restrict__ pieces) {
+__device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                        int D, const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ perm, int64_t n,
+                                                        const uint32_t* __restrict__ heads, const unsigned* __restrict__ nheads,
+                                                        const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
+                                                        const float* __restrict__ reg_coef, apply_hp hp,
+                                                        unsigned* __restrict__ counters, seg_long* __restrict__ longs,
+                                                        seg_piece* __restrict__ pieces) {
     HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     constexpr int SU = 4;                                 // segments in flight per lane group
@@ -991,6 +1015,35 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_dups_kernel(float* __res
             pieces[base + k] = seg_piece{st, (hi - st) < kPiece ? (hi - st) : (int64_t)kPiece};
         }
     }
+}
+// The two tables of a fused step in ONE launch each (round 4): blockIdx.y = 0 the user table's duplicate segments, 1 the item table's.
+// The device functions are the ones above with SIGNED = true for both sides -- the user side passes neg_start = n, so no occurrence is
+// ever negated: the same sums in the same order as the two launches of round 3.  (Not the same BITS as the round-3 build on rows whose
+// moments are non-zero: hipcc fuses the Adam update's multiply-adds differently in this instantiation -- 1 ulp on such rows, found by
+// running both builds on one batch, tools/ab_step_builds.py; reruns of one build are bit-equal as before.)  At 65,536 triples the step's six
+// small apply launches and three counter clears were ~45 us of its 230; the two sides also share the chip instead of queueing.
+struct dup_side {
+    float* W; float* M; float* V; const uint32_t* keys; const uint32_t* perm; int64_t n; const uint32_t* heads; const unsigned* nheads;
+    const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp;
+    unsigned* counters; seg_long* longs; seg_piece* pieces; int* pcnt; float* partial;
+};
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void rowwise_apply_dups2_kernel(int D, dup_side a, dup_side b) {
+    const dup_side& t = blockIdx.y ? b : a;
+    rowwise_apply_dups_body<LPR, OPT, true>(t.W, t.M, t.V, D, t.keys, t.perm, t.n, t.heads, t.nheads, t.G, t.neg_start, t.reg_limit, t.reg_coef, t.hp,
+                                            t.counters, t.longs, t.pieces);
+}
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void seg_piece_sum2_kernel(int D, dup_side a, dup_side b) {
+    const dup_side& t = blockIdx.y ? b : a;
+    if (t.counters == nullptr) return;
+    seg_piece_sum_body<LPR, true>(D, t.perm, t.G, t.neg_start, t.reg_limit, nullptr, t.counters, t.pieces, t.partial, t.pcnt);
+}
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void seg_long_finish2_kernel(int D, dup_side a, dup_side b) {
+    const dup_side& t = blockIdx.y ? b : a;
+    if (t.counters == nullptr) return;
+    seg_long_finish_body<LPR, OPT>(t.W, t.M, t.V, D, t.keys, t.reg_coef, t.hp, t.counters, t.longs, t.partial, t.pcnt);
 }
 
 }  // namespace
@@ -1208,54 +1261,68 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
 // ------------------------------------------------------------------------------------------------ the fused step (round 3)
 namespace {
 
-static int apply_dups(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float* exp_avg, float* exp_avg_sq, int D,
-                      const uint32_t* keys, const uint32_t* perm, int64_t n, const uint32_t* heads, const unsigned* nheads,
-                      const float* G, int64_t neg_start, int64_t reg_limit, const float* reg_coef, const apply_hp& hp,
-                      uint32_t key_base, int tag) {
-    if (key_base) {
-        table -= (int64_t)key_base * D;
-        if (exp_avg) exp_avg -= (int64_t)key_base * D;
-        if (exp_avg_sq) exp_avg_sq -= (int64_t)key_base * D;
+// Both tables' duplicate-row applies of a fused step: one scratch request carved for the two sides, three launches with blockIdx.y =
+// side instead of six (+ two counter clears, which the caller folds into step_finish_keep_kernel: dups_plan first, then that launch).
+struct dup_host { float* table; float* m; float* v; const uint32_t* keys; const uint32_t* perm; int64_t n; const uint32_t* heads; const unsigned* nheads;
+                  const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp; uint32_t key_base; };
+struct dups_plan { dup_side side[2]; int64_t long_cap[2], piece_cap[2]; };
+
+static int dups_plan_make(cdr_ctx* ctx, int D, const dup_host (&h)[2], dups_plan& pl) {
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off[2][5], total = 0;
+    for (int i = 0; i < 2; ++i) {
+        pl.long_cap[i] = pl.piece_cap[i] = 0;
+        if (h[i].n > kLongSeg) {
+            pl.long_cap[i] = h[i].n / (kLongSeg + 1) + 1;
+            pl.piece_cap[i] = h[i].n / kPiece + pl.long_cap[i] + 1;
+            off[i][0] = total; total += 256;
+            off[i][1] = total; total += up(sizeof(seg_long) * pl.long_cap[i]);
+            off[i][2] = total; total += up(sizeof(seg_piece) * pl.piece_cap[i]);
+            off[i][3] = total; total += up(sizeof(int) * pl.piece_cap[i]);
+            off[i][4] = total; total += up(sizeof(float) * (size_t)pl.piece_cap[i] * D);
+        }
     }
-    const int lpr = cdr_lpr_for(D);
-    const bool is_signed = neg_start < n;
-    const bool may_have_long = n > kLongSeg;
-    unsigned* counters = nullptr; seg_long* longs = nullptr; seg_piece* pieces = nullptr; int* pcnt = nullptr; float* partial = nullptr;
-    int64_t long_cap = 0, piece_cap = 0;
-    if (may_have_long) {
-        long_cap = n / (kLongSeg + 1) + 1;
-        piece_cap = n / kPiece + long_cap + 1;
-        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t o_long = 256, o_piece = o_long + up(sizeof(seg_long) * long_cap), o_cnt = o_piece + up(sizeof(seg_piece) * piece_cap),
-                     o_part = o_cnt + up(sizeof(int) * piece_cap), total = o_part + sizeof(float) * (size_t)piece_cap * D;
-        void* base = nullptr;
-        int rc = cdr_ctx_scratch(ctx, total, &base);
+    char* base = nullptr;
+    if (total) {
+        void* b = nullptr;
+        int rc = cdr_ctx_scratch(ctx, total, &b);
         if (rc != CDR_OK) return rc;
-        counters = (unsigned*)base; longs = (seg_long*)((char*)base + o_long); pieces = (seg_piece*)((char*)base + o_piece);
-        pcnt = (int*)((char*)base + o_cnt); partial = (float*)((char*)base + o_part);
-        CDR_HIP(cdr_zero_u32(counters, 4, s));
+        base = (char*)b;
     }
-    // the duplicate segments are a fraction of the list (uniform ids at C5: ~1 % of the users, ~10 % of the item rows): a grid for a
-    // quarter of the positions, the loop covers the rest
-    const int grid = grid_for(n / 16 + 1, kBlock / lpr);          // four segments per lane group and round
+    for (int i = 0; i < 2; ++i) {
+        dup_side& t = pl.side[i];
+        const int64_t kb = (int64_t)h[i].key_base * D;
+        t.W = h[i].table - kb; t.M = h[i].m ? h[i].m - kb : nullptr; t.V = h[i].v ? h[i].v - kb : nullptr;
+        t.keys = h[i].keys; t.perm = h[i].perm; t.n = h[i].n; t.heads = h[i].heads; t.nheads = h[i].nheads; t.G = h[i].G;
+        t.neg_start = h[i].neg_start; t.reg_limit = h[i].reg_limit; t.reg_coef = h[i].reg_coef; t.hp = h[i].hp;
+        t.counters = nullptr; t.longs = nullptr; t.pieces = nullptr; t.pcnt = nullptr; t.partial = nullptr;
+        if (pl.long_cap[i]) {
+            t.counters = (unsigned*)(base + off[i][0]); t.longs = (seg_long*)(base + off[i][1]); t.pieces = (seg_piece*)(base + off[i][2]);
+            t.pcnt = (int*)(base + off[i][3]); t.partial = (float*)(base + off[i][4]);
+        }
+    }
+    return CDR_OK;
+}
+
+static int apply_dups_pair(cdr_ctx* ctx, hipStream_t s, int opt, int D, const dups_plan& pl) {
+    const int lpr = cdr_lpr_for(D);
+    const int64_t nmax = pl.side[0].n > pl.side[1].n ? pl.side[0].n : pl.side[1].n;
+    const int grid = grid_for(nmax / 16 + 1, kBlock / lpr);          // four segments per lane group and round (apply_dups)
     {
-        cdr_time_scope ts(ctx, tag, s);
-#define DUP_ARGS table, exp_avg, exp_avg_sq, D, keys, perm, n, heads, nheads, G, neg_start, reg_limit, reg_coef, hp, counters, longs, pieces
-        if (opt == 0 && !is_signed) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 0, false><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
-        else if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
-        else if (!is_signed) { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 1, false><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
-        else { DISPATCH_LPR(lpr, rowwise_apply_dups_kernel<L, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(DUP_ARGS)); }
-#undef DUP_ARGS
+        cdr_time_scope ts(ctx, CDR_TAG_APPLY_SIGNED, s);
+        if (opt == 0) { DISPATCH_LPR(lpr, rowwise_apply_dups2_kernel<L, 0><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
+        else { DISPATCH_LPR(lpr, rowwise_apply_dups2_kernel<L, 1><<<dim3(grid, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
     }
     CDR_LAUNCH_CHECK();
-    if (may_have_long) {
-        const int gp = grid_for(piece_cap < 16384 ? piece_cap : 16384, kBlock / lpr);
-        if (is_signed) { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, true><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, nullptr, counters, pieces, partial, pcnt)); }
-        else { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, false><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, nullptr, counters, pieces, partial, pcnt)); }
+    if (pl.long_cap[0] || pl.long_cap[1]) {
+        const int64_t pc = pl.piece_cap[0] > pl.piece_cap[1] ? pl.piece_cap[0] : pl.piece_cap[1];
+        const int64_t lc = pl.long_cap[0] > pl.long_cap[1] ? pl.long_cap[0] : pl.long_cap[1];
+        const int gp = grid_for(pc < 16384 ? pc : 16384, kBlock / lpr);
+        DISPATCH_LPR(lpr, seg_piece_sum2_kernel<L><<<dim3(gp, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1]));
         CDR_LAUNCH_CHECK();
-        const int gl = grid_for(long_cap < 4096 ? long_cap : 4096, kBlock / lpr);
-        if (opt == 0) { DISPATCH_LPR(lpr, seg_long_finish_kernel<L, 0><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
-        else { DISPATCH_LPR(lpr, seg_long_finish_kernel<L, 1><<<dim3(gl), dim3(kBlock), 0, s>>>(table, exp_avg, exp_avg_sq, D, keys, reg_coef, hp, counters, longs, partial, pcnt)); }
+        const int gl = grid_for(lc < 4096 ? lc : 4096, kBlock / lpr);
+        if (opt == 0) { DISPATCH_LPR(lpr, seg_long_finish2_kernel<L, 0><<<dim3(gl, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
+        else { DISPATCH_LPR(lpr, seg_long_finish2_kernel<L, 1><<<dim3(gl, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
         CDR_LAUNCH_CHECK();
     }
     return CDR_OK;
@@ -1296,9 +1363,11 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
             DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, B, ctx->partials));
         }
         CDR_LAUNCH_CHECK();
-        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2);
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2,
+                                                            (unsigned*)heads);
     } else {
-        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2);
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2,
+                                                            (unsigned*)heads);
     }
     CDR_LAUNCH_CHECK();
     uint32_t key_base = 0;
@@ -1306,8 +1375,7 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
     if (rc) return rc;
     unsigned* cnt = (unsigned*)heads;
     uint32_t* headsA = heads + 4;
-    uint32_t* headsB = headsA + (B / 2 + 1);
-    CDR_HIP(cdr_zero_u32(cnt, 4, s));
+    uint32_t* headsB = headsA + (B / 2 + 1);           // (cnt[0..3] were cleared by coef_finish_kernel)
     const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
     {
         cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
@@ -1329,12 +1397,14 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
 #undef FA_ARGS
     }
     CDR_LAUNCH_CHECK();
-    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9);
-    CDR_LAUNCH_CHECK();
-    rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, D, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0, CDR_TAG_APPLY_UNSIGNED);
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0},
+                               {item_tab, item_m, item_v, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base}};
+    dups_plan pl;
+    rc = dups_plan_make(ctx, D, sides, pl);
     if (rc) return rc;
-    return apply_dups(ctx, s, opt, item_tab, item_m, item_v, D, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base,
-                      CDR_TAG_APPLY_SIGNED);
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, D, pl);
 }
 
 extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
@@ -1401,9 +1471,9 @@ extern "C" int cdr_bpr_step_fused_kmajor(cdr_ctx* ctx, void* stream, int opt, fl
             DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, S, ctx->partials));
         }
         CDR_LAUNCH_CHECK();
-        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, k);
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, k, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, (unsigned*)heads);
     } else {
-        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, k);
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, k, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, (unsigned*)heads);
     }
     CDR_LAUNCH_CHECK();
     uint32_t key_base = 0;
@@ -1411,8 +1481,7 @@ extern "C" int cdr_bpr_step_fused_kmajor(cdr_ctx* ctx, void* stream, int opt, fl
     if (rc) return rc;
     unsigned* cnt = (unsigned*)heads;
     uint32_t* headsA = heads + 4;
-    uint32_t* headsB = headsA + (S / 2 + 1);
-    CDR_HIP(cdr_zero_u32(cnt, 4, s));
+    uint32_t* headsB = headsA + (S / 2 + 1);           // (cnt[0..3] were cleared by coef_finish_kernel)
     const int fgrid = grid_for(S + nI, kBlock * kFlagIT);
     {
         cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
@@ -1432,11 +1501,13 @@ extern "C" int cdr_bpr_step_fused_kmajor(cdr_ctx* ctx, void* stream, int opt, fl
 #undef FK_ARGS
     }
     CDR_LAUNCH_CHECK();
-    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9);
-    CDR_LAUNCH_CHECK();
     // duplicate rows: users over GU [S, D]; items over GI [S + B, D] (one row per occurrence of [pid | nid], signs folded in)
-    rc = apply_dups(ctx, s, opt, user_tab, user_m, user_v, D, keys, perm, S, headsA, cnt, GU, S, S, out9 + 4, hu, 0, CDR_TAG_APPLY_UNSIGNED);
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, S, headsA, cnt, GU, S, S, out9 + 4, hu, 0},
+                               {item_tab, item_m, item_v, keys + S, perm + S, nI, headsB, cnt + 1, GI, nI, S, out9 + 5, hi, key_base}};
+    dups_plan pl;
+    rc = dups_plan_make(ctx, D, sides, pl);
     if (rc) return rc;
-    return apply_dups(ctx, s, opt, item_tab, item_m, item_v, D, keys + S, perm + S, nI, headsB, cnt + 1, GI, nI, S, out9 + 5, hi, key_base,
-                      CDR_TAG_APPLY_SIGNED);
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, D, pl);
 }
