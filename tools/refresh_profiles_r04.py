@@ -27,7 +27,7 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
     by = {}
     for r in rows:
         by.setdefault(short(r['Kernel_Name']), []).append(float(r['Counter_Value']))
-    HEAD = ('bpr_fwd_apply_kernel<32', 'batch_norms_kernel<32', 'occ_flags_kernel', 'make_keys2_kernel', 'rowwise_apply_dups_kernel<32, 1, false>', 'rowwise_apply_dups_kernel<32, 1, true>')
+    HEAD = ('bpr_fwd_apply_kernel<32', 'batch_norms_kernel<32', 'occ_flags_kernel', 'make_keys2_kernel', 'rowwise_apply_dups2_kernel<32, 1>')
     for k, vals in by.items():
         big = [v for v in vals if v > 0.5 * max(vals)] if max(vals) > 0 else vals
         if any(h in k for h in HEAD):
@@ -49,21 +49,21 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
 byt = lambda k: int(raw[k].get('FETCH_SIZE_KiB', 0) * 1024 * 2 + raw[k].get('WRITE_SIZE_KiB', 0) * 1024) if k in raw else None
 find = lambda pat: next((k for k in raw if pat in k), None)
 names = {'bpr_fwd_apply_kernel': find('bpr_fwd_apply_kernel<32'), 'batch_norms_kernel': find('batch_norms_kernel<32'), 'occ_flags_kernel': find('occ_flags_kernel'),
-         'rowwise_apply_kernel(users)': find('rowwise_apply_dups_kernel<32, 1, false>'), 'rowwise_apply_kernel(items)': find('rowwise_apply_dups_kernel<32, 1, true>'),
+         'rowwise_apply_dups2_kernel': find('rowwise_apply_dups2_kernel<32, 1>'),        # both tables' duplicate rows in one launch (round 4)
          'bpr_fwd_kernel': find('bpr_fwd_kernel<32'), 'bpr_fwd_kmajor_kernel(k=4)': find('bpr_fwd_kmajor_kernel<32, 4, 2>'),
          'map_step_kernel': find('map_pipe_kernel') or find('map_step_kernel')}
 o = {'_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of `python bench.py --no-cpu-baseline --no-fullsort '
               '--no-config-legs --no-e2e --single-stream --steps 3 --warmup 1`, tools/profile_r04.sh; B = 1,048,576 triples per domain, D = 128, row-wise Adam). FETCH_SIZE x 1024 x 2 '
               '(gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024. Mean over each kernel\'s first 8 dispatches = the '
-              'headline batch (1 warm-up + 3 timed steps x 2 domains). `domain_step` = batch norms + sort + flags + forward/optimizer + both duplicate-row '
-              'applies (the sort\'s share: all make_keys / rocPRIM dispatches of the run divided by its number of sorts).',
+              'headline batch (1 warm-up + 3 timed steps x 2 domains). `domain_step` = batch norms + sort + flags + forward/optimizer + the duplicate-row '
+              'apply of both tables (the sort\'s share: all make_keys / rocPRIM dispatches of the run divided by its number of sorts).',
      '_raw': {v: raw[v] for v in names.values() if v}}
 for k, v in names.items():
     if v:
         o[k] = byt(v)
 sort_k = [k for k in raw if 'radix_sort' in k or 'make_keys2' in k or 'onesweep' in k or 'merge_sort' in k]
 n_sorts = raw.get(find('make_keys2_kernel') or '', {}).get('all_dispatches', 0)
-need = ('bpr_fwd_apply_kernel', 'batch_norms_kernel', 'occ_flags_kernel', 'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)')
+need = ('bpr_fwd_apply_kernel', 'batch_norms_kernel', 'occ_flags_kernel', 'rowwise_apply_dups2_kernel')
 if n_sorts and all(names[k] for k in need):
     sort_bytes = sum(raw[k].get('sum_FETCH_SIZE_KiB', 0) * 2048 + raw[k].get('sum_WRITE_SIZE_KiB', 0) * 1024 for k in sort_k) / n_sorts
     o['sort_ids(per call)'] = int(sort_bytes)
