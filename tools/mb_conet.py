@@ -21,6 +21,13 @@ model = CoNet(cfg, ds).to(dev)
 rng = np.random.RandomState(0)
 S, k = 819, 4
 batches = [dict(ds.pointwise_batch('source', S, k, rng, dev), **ds.pointwise_batch('target', S, k, rng, dev)) for _ in range(4)]
+if os.environ.get('MB_CLUSTER'):        # what-if: each domain's rows ordered by user id, i.e. the overlapped users' rows (id < n_overlap) in the first blocks
+    for b in batches:
+        for dom in ('source', 'target'):
+            o = torch.argsort(b[f'{dom}_user_id'], stable=True)
+            for f in ('user_id', 'item_id', 'label'):
+                b[f'{dom}_{f}'] = b[f'{dom}_{f}'][o].contiguous()
+    print('rows ordered by user id inside each domain (MB_CLUSTER)')
 prof = None
 if os.environ.get('CDR_CONET_PROF'):
     prof = torch.zeros(64 + 2 * 2048, dtype=torch.int64, device=dev)
