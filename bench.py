@@ -122,6 +122,15 @@ def dist_setup(args):
     shared = bool(int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')))
     if shared:
         local = 0
+        if world > 1 and args.workload == 'c5':
+            # every rank allocates its own tables on the ONE device: refuse sizes that cannot fit `world` times (a run that drives the box out of
+            # VRAM takes the box down with it) -- the functional checks pass small --users / --items-per-domain / --batch
+            per_rank = (args.users + 2 * args.items_per_domain) * args.dim * 4 * 3 / max(world // 2, 1)       # tables + two Adam moments, upper bound
+            total = torch.cuda.get_device_properties(0).total_memory
+            if per_rank * world > 0.6 * total:
+                raise SystemExit('CDR_BENCH_SHARED_GPU=1 with %d ranks needs ~%.0f GB on one %.0f GB device at these table sizes: pass smaller '
+                                 '--users / --items-per-domain (this mode is a functional check, never a measurement)'
+                                 % (world, per_rank * world / 1e9, total / 1e9))
     torch.cuda.set_device(local)
     if world > 1 or args.force_shard:
         import torch.distributed as dist
