@@ -2790,6 +2790,41 @@ def test_integration_md_stub_runs_as_documented():
     assert_close(Ud.grad, Ur.grad, what='stub dU'); assert_close(Id.grad, Ir.grad, what='stub dI')
 
 
+@pytest.mark.parametrize('rows,W,n,lo', [(37, 8, 200, 100), (1000, 192, 4099, 0), (5, 4, 3, 7)])
+def test_block_owned_row_gather_and_scatter(rows, W, n, lo):
+    """cdr_gather_block_rows / cdr_scatter_add_block_rows (BiTGCF's routed batch rows, bitgcf_shard.py): positions inside [lo, lo + rows)
+    are this rank's, everything else -- other ranks' positions on either side, padding slots (-1) -- gathers zeros and scatters nothing;
+    repeated positions accumulate.  Bit-exact against torch indexing (the gather), allclose against index_add_ (fp32 atomics)."""
+    from recbole_cdr_amd import binding as B_
+    g = torch.Generator().manual_seed(rows + n)
+    X = torch.randn(rows, W, generator=g).to(DEV)
+    pos = torch.randint(-1, lo + rows + 50, (n,), generator=g)
+    pos[::7] = -1
+    pos = pos.to(DEV)
+    out = torch.empty(n, W, device=DEV)
+    B_.call('cdr_gather_block_rows', B_.stream(), B_.f32(X), W, B_.i64(pos), n, lo, rows, B_.f32(out))
+    q = pos - lo
+    own = (pos >= 0) & (q >= 0) & (q < rows)
+    want = torch.zeros(n, W, device=DEV)
+    want[own] = X[q[own]]
+    assert torch.equal(out, want)
+    assert int(own.sum()) > 0 or n < 10
+    src = torch.randn(n, W, generator=g).to(DEV)
+    grad = torch.zeros(rows, W, device=DEV)
+    B_.call('cdr_scatter_add_block_rows', B_.stream(), B_.f32(grad), W, B_.i64(pos), n, lo, rows, B_.f32(src))
+    ref = torch.zeros(rows, W, device=DEV).index_add_(0, q[own], src[own])
+    torch.testing.assert_close(grad, ref, rtol=1e-5, atol=1e-6)
+    # the pair is what a reduce-scatter needs: the owners' gathers of one position list sum to the rows of the concatenated table
+    full = torch.randn(3 * rows, W, generator=g).to(DEV)
+    allpos = torch.randint(0, 3 * rows, (n,), generator=g).to(DEV)
+    acc = torch.zeros(n, W, device=DEV)
+    for r in range(3):
+        part = torch.empty(n, W, device=DEV)
+        B_.call('cdr_gather_block_rows', B_.stream(), B_.f32(full[r * rows:(r + 1) * rows].contiguous()), W, B_.i64(allpos), n, r * rows, rows, B_.f32(part))
+        acc += part
+    assert torch.equal(acc, full[allpos])
+
+
 @pytest.mark.parametrize('G,U,k', [(1, 5, 10), (3, 70, 10), (8, 33, 64), (5, 9, 1)])
 def test_topk_merge_shards_orders_by_value_then_item_id(G, U, k):
     """cdr_topk_merge_shards against a lexsort of the candidates: value descending, ties to the smaller GLOBAL item id
