@@ -681,7 +681,7 @@ class OracleGraphOps:
         return loss.detach().reshape(()), ga, ge
 
 
-def _bitgcf_case(connect_way, seed=3):
+def _bitgcf_case(connect_way, seed=3, B=40):
     import numpy as np
     from oracle.common import IdSpace
     ids = IdSpace(OU=9, TOU=7, SOU=5, OI=1, TOI=11, SOI=8) if connect_way == 'concat' else IdSpace(OU=1, TOU=8, SOU=6, OI=10, TOI=7, SOI=9)
@@ -697,7 +697,6 @@ def _bitgcf_case(connect_way, seed=3):
     D = 8
     params = {k: torch.randn(nu if '_user_' in k else ni, D, generator=g) * 0.3
               for k in ('source_user_embedding.weight', 'source_item_embedding.weight', 'target_user_embedding.weight', 'target_item_embedding.weight')}
-    B = 40
     inter = {'source_user_id': torch.from_numpy(s_pairs[:B, 0].copy()), 'source_item_id': torch.from_numpy(s_pairs[:B, 1].copy()),
              'source_label': (torch.rand(B, generator=g) < 0.5).float(),
              'target_user_id': torch.from_numpy(t_pairs[:B, 0].copy()), 'target_item_id': torch.from_numpy(t_pairs[:B, 1].copy()),
@@ -705,14 +704,14 @@ def _bitgcf_case(connect_way, seed=3):
     return ids, s_pairs, t_pairs, params, inter, D
 
 
-def _worker_bitgcf(rank, world, port, connect_way, q, batch_loss='routed'):
+def _worker_bitgcf(rank, world, port, connect_way, q, batch_loss='routed', B=40):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import recbole_cdr_amd  # noqa: F401
         from recbole_cdr_amd.bitgcf_shard import ShardedBiTGCF
-        ids, s_pairs, t_pairs, params, inter, D = _bitgcf_case(connect_way)
+        ids, s_pairs, t_pairs, params, inter, D = _bitgcf_case(connect_way, B=B)
         m = ShardedBiTGCF(ids.total_num_users, ids.total_num_items, ids.OU, ids.OI, s_pairs, t_pairs, D, 2, 0.8, 0.7, connect_way, 0.01,
                           OracleGraphOps(), init=params, batch_loss=batch_loss)
         opt = torch.optim.Adam(list(m.params.values()), lr=0.01)
@@ -729,28 +728,29 @@ def _worker_bitgcf(rank, world, port, connect_way, q, batch_loss='routed'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,connect_way,batch_loss', [(2, 'concat', 'routed'), (3, 'mean', 'routed'), (4, 'concat', 'routed'),
-                                                          (3, 'concat', 'routed'), (2, 'mean', 'replicated'), (4, 'concat', 'replicated')])
-def test_row_sharded_bitgcf_matches_single_process(world, connect_way, batch_loss):
+@pytest.mark.parametrize('world,connect_way,batch_loss,B', [(2, 'concat', 'routed', 40), (3, 'mean', 'routed', 40), (4, 'concat', 'routed', 40),
+                                                            (3, 'concat', 'routed', 40), (4, 'mean', 'routed', 5), (2, 'mean', 'replicated', 40),
+                                                            (4, 'concat', 'replicated', 40)])
+def test_row_sharded_bitgcf_matches_single_process(world, connect_way, batch_loss, B):
     """BASELINE configs[3]: tables, Adam state, adjacency rows and transfer-layer degrees cut into ``world`` row blocks, per-layer
     all-gather of E (forward) and of g (1 + E) (backward); uneven blocks (padding rows), overlap rows that straddle the block
     boundary, user-overlap and item-overlap id spaces.  Two Adam steps: both losses, all four full tables and the propagated
     tables equal the single-process oracle (torch autograd over the reference's formulas).  ``routed``: rank r scores its B / world
     slice of the batch (40 rows over 3 ranks: 14 + 14 + 12, padding slots) on rows delivered by a reduce-scatter, the BCE sum and the
     EmbLoss sums of squares are all-reduced, gradient rows return by all-gather; ``replicated``: every rank scores the whole batch on the
-    all-gathered stacked tables."""
+    all-gathered stacked tables.  B = 5 over 4 ranks: slices of 2, 2, 1 and 0 rows (a rank with nothing to score still takes part in every collective)."""
     from oracle import bitgcf as obit
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_bitgcf, args=(r, world, port, connect_way, q, batch_loss)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_bitgcf, args=(r, world, port, connect_way, q, batch_loss, B)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ids, s_pairs, t_pairs, params, inter, D = _bitgcf_case(connect_way)
+    ids, s_pairs, t_pairs, params, inter, D = _bitgcf_case(connect_way, B=B)
     ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     graph = obit.build_graph(s_pairs, t_pairs, ids.total_num_users, ids.total_num_items)
     opt = torch.optim.Adam(list(ref.values()), lr=0.01)
