@@ -120,8 +120,8 @@ def _params(model):
     return {k: v.detach().clone() for k, v in model.named_parameters()}
 
 
-@pytest.mark.parametrize('mapping', ['linear', 'non_linear'])
-def test_trainer_fit_on_replays_equals_the_same_steps_run_eagerly(mapping):
+@pytest.mark.parametrize('mapping,graph_pipeline', [('linear', True), ('non_linear', True), ('linear', 'producer_ahead')])
+def test_trainer_fit_on_replays_equals_the_same_steps_run_eagerly(mapping, graph_pipeline):
     """CrossDomainTrainer.fit(SOURCE, TARGET, OVERLAP) on device loaders: every full batch is one hipGraph replay that produces the
     batch itself.  Reference run: the SAME launches issued eagerly (producer launch -> zero_grad -> calculate_loss -> backward ->
     DenseAdam.step; ragged tails through the loader): the same kernels in the same order on the same data."""
@@ -132,7 +132,8 @@ def test_trainer_fit_on_replays_equals_the_same_steps_run_eagerly(mapping):
     ids, ds, s_pairs, t_pairs = _dataset(1)
     cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=16, target_embedding_size=16, reg_weight=0.01,
                       mapping_function=mapping, mlp_hidden_size=[24], learning_rate=0.01, train_modes=['SOURCE', 'TARGET', 'OVERLAP'],
-                      epoch_num=['2', '2', '2'], source_split=False, eval_step=0, epochs=2)
+                      epoch_num=['2', '2', '2'], source_split=False, eval_step=0, epochs=2, graph_pipeline=graph_pipeline)
+    # ('producer_ahead': the opt-in order that produces batch i + 1 on a side stream beside step i, two batch slots -- same launches, same data)
     torch.manual_seed(3)
     model = EMCDR(cfg, ds).to(DEV)
     init = _params(model)
