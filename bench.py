@@ -1606,6 +1606,31 @@ def cpu_baseline(args):
     rate, steps = measure(used, args.cpu_seconds)
     rate_all, n_all = measure(ncores, min(args.cpu_seconds, 6.0))          # torch.set_num_threads(os.cpu_count()) ...
     rate_one, n_one = measure(1, min(args.cpu_seconds, 6.0))               # ... and a 1-thread figure
+    # the reference's OWN formulation beside the port's: dense autograd (index_select backward = a dense [rows, D] gradient) and
+    # torch.optim.Adam over every row of both tables each step (recbole Trainer + emcdr.py:110-131), same tables, same batch shape; bounded to a
+    # few steps -- each one sweeps the 1.5 GB of tables several times
+    ref_form = None
+    try:
+        from oracle import losses as ol
+        torch.set_num_threads(ncores)
+        Ud, Id = U.clone().requires_grad_(True), I.clone().requires_grad_(True)
+        dopt = torch.optim.Adam([Ud, Id], lr=1e-3)
+        def dense_step():
+            u_, p_, n_ = mk(nu), mk(ni), mk(ni)
+            dopt.zero_grad()
+            ue, pe, ne = Ud[u_], Id[p_], Id[n_]
+            (ol.bpr_loss((ue * pe).sum(1), (ue * ne).sum(1)) + 0.01 * ol.emb_loss(ue, pe)).sum().backward()
+            dopt.step()
+        dense_step()
+        t0 = time.perf_counter(); nd = 0
+        while (time.perf_counter() - t0 < min(args.cpu_seconds, 6.0) or nd < 2) and nd < 20:
+            dense_step(); nd += 1
+        ref_form = {'value': B * nd / (time.perf_counter() - t0), 'unit': 'interactions/s', 'cores': ncores,
+                    'sample': '%d steps, the reference\'s formulation of the same step (autograd with dense table gradients + torch.optim.Adam over every '
+                              'row), same tables and batches' % nd}
+        del Ud, Id, dopt
+    except Exception as e:                       # (a host without the RAM for the dense gradients and moments: the port's figure stands alone)
+        ref_form = {'error': repr(e)[:200]}
     torch.set_num_threads(used)
     model = ''
     try:
@@ -1618,7 +1643,8 @@ def cpu_baseline(args):
     return {'value': rate, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'os_cpu_count': os.cpu_count(), 'kind': 'port', 'cpu_model': model,
             'sample': '%d steps, %s, torch %d threads (best of a sweep)' % (steps, sample, used),
             'all_cores': {'value': rate_all, 'unit': 'interactions/s', 'cores': ncores, 'sample': '%d steps, same shape' % n_all},
-            'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one}}
+            'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one},
+            'reference_formulation': ref_form}
 
 
 def run_replicas(args, world, rank, dev, attempts):
