@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 41
+#define CDR_ABI_VERSION 42
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -781,6 +781,31 @@ int cdr_natr_att_bwd(void* stream, const float* He, const float* pu, const float
                      const float* bu, const float* wd, const float* bd, int64_t B, int L, int D, const float* att,
                      const float* su, const float* beta, const float* p, const float* gp, float* gHe, float* gpu, float* gqi,
                      float* gwu_rows, float* gwd_rows, float* gb_rows);
+
+/* ---- (10) the exchanges of the multi-GPU path (SURVEY 8b family (10), 8e) ---------------------------------------------------
+ * For a host that is not Python: what shard.ShardedBPRStep / ShardedFullSort do through torch.distributed, over one RCCL communicator
+ * per process (one process per GPU; RCCL is bound at run time, so a torch process shares the RCCL torch has loaded).  Reference math
+ * these exchanges serve: emcdr.py:110-154 on row-sharded tables (ids travel to the owner of their row, rows come back, gradient rows
+ * go home), the OVERLAP transfer step emcdr.py:156-168, the sharded full-sort emcdr.py:208-233.  Counts are HOST arrays [world]; the
+ * send buffer is ordered by destination rank, the receive buffer by source rank.  Everything is enqueued on `stream`.
+ *   cdr_comm_unique_id    rank 0 makes the 128-byte id and hands it to the other ranks by the host's own means
+ *   cdr_comm_init         collective over the `world` processes, on the calling thread's current HIP device
+ *   cdr_a2a_ids           int64 ids, send_counts[p] of them to rank p     cdr_a2a_rows   fp32 rows of width D, send_rows[p] to rank p
+ *   cdr_allgather_scores  n floats of every rank -> [world * n] in rank order (the per-shard scores / top-k candidates of full-sort)
+ *   cdr_allreduce_sum_f32 in place (loss sums, the dimension shard's partial scores)
+ * Errors: CDR_ENODEV when librccl cannot be loaded, 1000 + ncclResult_t when RCCL reports one (cdr_last_error has its text). */
+typedef struct cdr_comm cdr_comm;
+#define CDR_COMM_ID_BYTES 128
+int cdr_comm_unique_id(void* id_out /* CDR_COMM_ID_BYTES */);
+int cdr_comm_init(cdr_comm** comm, int rank, int world, const void* unique_id);
+int cdr_comm_destroy(cdr_comm* comm);
+int cdr_comm_info(const cdr_comm* comm, int* rank, int* world);
+int cdr_a2a_ids(cdr_comm* comm, void* stream, const int64_t* send, const int64_t* send_counts, int64_t* recv,
+                const int64_t* recv_counts);
+int cdr_a2a_rows(cdr_comm* comm, void* stream, const float* send, const int64_t* send_rows, float* recv, const int64_t* recv_rows,
+                 int D);
+int cdr_allgather_scores(cdr_comm* comm, void* stream, const float* send, int64_t n, float* recv);
+int cdr_allreduce_sum_f32(cdr_comm* comm, void* stream, float* buf, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,27 @@ int main(void) {
         for (int i = 0; i < NU * D; ++i) ok &= close_enough(U2[i], Uref[i], 0.2, "user table after the one-call fused step");
         for (int i = 0; i < NI * D; ++i) ok &= close_enough(I2[i], Iref[i], 0.2, "item table after the one-call fused step");
     }
+    /* ---- family (10): the exchanges of the multi-GPU path from a host without torch -- a one-rank communicator (RCCL from the loader path) ---- */
+    {
+        unsigned char id[CDR_COMM_ID_BYTES];
+        int rc = cdr_comm_unique_id(id);
+        if (rc == CDR_ENODEV) printf("abi_smoke: librccl not loadable here, comm family skipped (%s)\n", cdr_last_error());
+        else {
+            cdr_comm* comm = NULL; int rank = -1, world = -1;
+            ok &= rc == 0;
+            CHECK_CDR(cdr_comm_init(&comm, 0, 1, id));
+            CHECK_CDR(cdr_comm_info(comm, &rank, &world));
+            ok &= rank == 0 && world == 1;
+            const int64_t nrows[1] = {B};
+            CHECK_CDR(cdr_a2a_rows(comm, NULL, dGU, nrows, dGP, nrows, D));           /* rows to "their owner" and back: the identity on one rank */
+            CHECK_CDR(cdr_allreduce_sum_f32(comm, NULL, dOut, 6));
+            CHECK_HIP(hipDeviceSynchronize());
+            float after[6];
+            CHECK_HIP(hipMemcpy(after, dOut, sizeof(after), hipMemcpyDeviceToHost));
+            ok &= close_enough(after[0], out[0], 0, "loss through a one-rank all-reduce");
+            CHECK_CDR(cdr_comm_destroy(comm));
+        }
+    }
     CHECK_CDR(cdr_ctx_destroy(ctx));
     printf(ok ? "abi_smoke: OK (loss %.7f)\n" : "abi_smoke: FAILED (loss %.7f)\n", out[0]);
     return ok ? 0 : 1;

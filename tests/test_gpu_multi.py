@@ -776,3 +776,45 @@ def test_row_sharded_bitgcf_native_ranks_share_one_gpu(world, connect_way):
         for a, b in zip(got_prop, prop):
             # three Adam steps in: the tables agree within Adam's drift bound (1e-2 of one update), and so do the propagated rows
             assert_close(torch.from_numpy(a), b, rtol=1e-5, atol=0.01 * 1e-2, what='propagated table')
+
+
+# ---------------------------------------------------------------------------------------------- C-ABI exchanges (SURVEY 8b family (10))
+def test_comm_family_one_rank_communicator():
+    """cdr_comm_* / cdr_a2a_* / cdr_allgather_scores / cdr_allreduce_sum_f32 through the C ABI inside a torch process (RCCL bound at run time to
+    the librccl torch loaded): a ONE-rank communicator is all a one-GPU box allows (RCCL refuses two ranks on one device), so this checks the
+    binding, the unique-id hand-over, the stream ordering and the count / offset arithmetic -- every exchange is then the identity."""
+    import ctypes
+    from recbole_cdr_amd import binding as B_
+    lib = B_.load()
+    idb = ctypes.create_string_buffer(128)
+    B_.call('cdr_comm_unique_id', ctypes.cast(idb, ctypes.c_void_p))
+    assert any(idb.raw)
+    comm = ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    B_.call('cdr_comm_init', ctypes.cast(ctypes.pointer(comm), ctypes.c_void_p), 0, 1, ctypes.cast(idb, ctypes.c_void_p))
+    assert comm.value
+    try:
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        B_.call('cdr_comm_info', comm, ctypes.cast(ctypes.pointer(r), ctypes.c_void_p), ctypes.cast(ctypes.pointer(w), ctypes.c_void_p))
+        assert (r.value, w.value) == (0, 1)
+        g = torch.Generator().manual_seed(0)
+        ids = torch.randint(0, 1 << 40, (1000,), generator=g).to(DEV)
+        got = torch.empty_like(ids)
+        cnt = (ctypes.c_int64 * 1)(1000)
+        B_.call('cdr_a2a_ids', comm, B_.stream(), B_.i64(ids), ctypes.cast(cnt, ctypes.c_void_p), B_.i64(got), ctypes.cast(cnt, ctypes.c_void_p))
+        rows = torch.randn(333, 64, generator=g).to(DEV)
+        back = torch.empty_like(rows)
+        rc = (ctypes.c_int64 * 1)(333)
+        B_.call('cdr_a2a_rows', comm, B_.stream(), B_.f32(rows), ctypes.cast(rc, ctypes.c_void_p), B_.f32(back), ctypes.cast(rc, ctypes.c_void_p), 64)
+        sc = torch.randn(5000, generator=g).to(DEV)
+        allsc = torch.empty_like(sc)
+        B_.call('cdr_allgather_scores', comm, B_.stream(), B_.f32(sc), sc.numel(), B_.f32(allsc))
+        red = sc.clone()
+        B_.call('cdr_allreduce_sum_f32', comm, B_.stream(), B_.f32(red), red.numel())
+        torch.cuda.synchronize()
+        assert torch.equal(got, ids) and torch.equal(back, rows) and torch.equal(allsc, sc) and torch.equal(red, sc)
+        # a negative count is refused before anything is enqueued
+        bad = (ctypes.c_int64 * 1)(-1)
+        assert lib.cdr_a2a_ids(comm, B_.stream(), B_.i64(ids), ctypes.cast(bad, ctypes.c_void_p), B_.i64(got), ctypes.cast(cnt, ctypes.c_void_p)) != 0
+    finally:
+        B_.call('cdr_comm_destroy', comm)
