@@ -929,13 +929,14 @@ def test_conet_forward_and_data_backward_in_one_launch(monkeypatch):
 
 @pytest.mark.parametrize('R,n_s,hidden,D,clustered', [(8190, 4095, [64, 32, 16, 8], 128, False), (8190, 4095, [64, 32, 16, 8], 128, True),
                                                     (1000, 3, [64, 32, 16, 8], 128, False), (4097, 2048, [64, 16, 8], 128, True),
-                                                    (500, 250, [32, 32, 16, 8], 128, False)])
+                                                    (500, 250, [32, 32, 16, 8], 128, False), (70001, 35000, [64, 32, 16, 8], 128, False)])
 def test_conet_eight_wave_kernel_is_bit_identical_to_the_four_wave_kernel(monkeypatch, R, n_s, hidden, D, clustered):
     """conet_fb_kernel<8> (one product of a cross unit per wave, two waves per SIMD, the cross accumulator handed over through LDS; a
     block without an overlapped row skips the cross product) against conet_fb_kernel<4> (CDR_CONET_FB_WAVES=4): loss, every layer
     gradient and every table gradient bit for bit -- C3's shape and row count, overlapped rows scattered over all blocks or clustered
     in the first ones (so that both kinds of block exist), a nearly one-domain batch, a three-layer stack, the tuned [32, 32, 16, 8] stack
-    (one column tile in layer 0: two units per pass)."""
+    (one column tile in layer 0: two units per pass), and 70,001 rows -- more 32-row blocks than the 2,048-workgroup grid, so every workgroup walks
+    several blocks (the rotated gather inside the loop, the scratch region re-used)."""
     from oracle.common import IdSpace
     from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
     from recbole_cdr_amd import binding as B_
