@@ -93,7 +93,7 @@ if src:
 
 # ---- matrix-pipe utilisation of the mapping and CoNet kernels (own --pmc passes over tools/mb_conet.py / mb_mapstep.py)
 mf = {}
-for T in ('conet', 'mapstep', 'map'):
+for T in ('conet', 'conet_fullsort', 'mapstep', 'map'):
     src = glob.glob(os.path.join(out, 'pmc_mfma_' + T, '**', '*counter_collection.csv'), recursive=True)
     if not src:
         continue
@@ -101,7 +101,7 @@ for T in ('conet', 'mapstep', 'map'):
     for r in csv.DictReader(open(src[0])):
         by.setdefault(short(r['Kernel_Name']), {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
     for k, v in by.items():
-        if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and 'GRBM_GUI_ACTIVE' in v and any(x in k for x in ('conet_fb', 'conet_wgrad_kernel', 'map_pipe')) and 'finish' not in k:
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and 'GRBM_GUI_ACTIVE' in v and any(x in k for x in ('conet_fb', 'conet_wgrad_kernel', 'conet_fullsort_kernel', 'map_pipe')) and 'finish' not in k:
             b, a = v['SQ_VALU_MFMA_BUSY_CYCLES'], v['GRBM_GUI_ACTIVE']
             n = min(len(a), len(b))
             b, a = b[n // 4:n], a[n // 4:n]
@@ -109,7 +109,7 @@ for T in ('conet', 'mapstep', 'map'):
             mf[k] = {'dispatches': len(b), 'SQ_VALU_MFMA_BUSY_CYCLES': mb, 'GRBM_GUI_ACTIVE': ma, 'mfma_busy_over_active_cycles_x_simds': mb / ((ma / 8) * 1024)}
 if mf:
     note = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace over tools/mb_conet.py (C3 shape, 8,190 rows) and tools/mb_mapstep.py "
-            "(OVERLAP step, linear and tanh-MLP mappings, OB = 100 and 65,536: the averages are dominated by the OB = 65,536 launches), own pass, one MI355X, "
-            "round 4.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1,024 SIMDs; mfma_busy_over_active_cycles_x_simds = share of the kernel's cycles in which a "
+            "(OVERLAP step, linear and tanh-MLP mappings, OB = 100 and 65,536: the averages are dominated by the OB = 65,536 launches) and over `bench.py --workload c3` "
+            "(the CoNet full-sort leg: conet_fullsort_kernel at its four shapes, averaged), own passes, one MI355X, round 4.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1,024 SIMDs; mfma_busy_over_active_cycles_x_simds = share of the kernel's cycles in which a "
             "SIMD's matrix pipe is busy. First quarter of each kernel's dispatches (warm-up) dropped.")
     json.dump(dict({'_note': note}, **mf), open(os.path.join(prof, f'{tag}_pmc_mfma_conet_map.json'), 'w'), indent=1)
