@@ -7,13 +7,16 @@
 #   trace_c5   rocprofv3 --kernel-trace --stats of `bench.py --headline-only`
 #   trace_cfg  rocprofv3 --kernel-trace --stats of `--workload c1|c2|c3` (graph replays) and of the CoNet full-sort leg
 #   pmc        --pmc FETCH_SIZE / WRITE_SIZE (own passes, --kernel-trace only) over the headline; MFMA-busy over the CoNet full-sort kernel
+#   mfma       --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over tools/mb_conet.py and tools/mb_mapstep.py
 #   mb         micro-benchmarks: cache-resident gather bandwidth, graph-launch gap
+# (The per-block stamps of conet_fb_kernel need a -DCDR_CONET_PROF build of cdr_conet.hip linked as another .so and CDR_LIB_PATH / CDR_CONET_PROF=1:
+#  profiles/r04_mb_conet_waves.txt names the commands.)
 set -u
 ulimit -c 0          # (a faulting kernel must not fill the box's disk with a GPU core dump: everything behind it would fail)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04; mkdir -p $O
 cd $R
-W="${*:-legs e2e c5 trace_c5 trace_cfg pmc mb}"
+W="${*:-legs e2e c5 trace_c5 trace_cfg pmc mfma mb}"
 has() { [[ " $W " == *" $1 "* ]]; }
 if has legs; then
   for w in c1 c2 c3 c4; do python bench.py --workload $w --steps 200 --warmup 20 > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$?"; done
@@ -42,6 +45,10 @@ if has pmc; then
     timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o pmc -- python $R/bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --single-stream --steps 3 --warmup 1 > $O/bench_pmc_$C.json 2> $O/pmc_$C.err; echo "pmc $C rc=$?"
   done
   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_conet_fullsort -o pmc -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 20 --warmup 2 > $O/bench_c3_under_pmc.json 2> $O/pmc_mfma_conet_fullsort.err; echo "pmc mfma conet fullsort rc=$?"
+fi
+if has mfma; then          # matrix-pipe counters of the CoNet training kernels and the mapping kernels (own passes; refresh files r04_pmc_mfma_conet_map.json)
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_conet -o pmc -- python $R/tools/mb_conet.py > $O/mb_conet_under_pmc.txt 2> $O/pmc_mfma_conet.err; echo "pmc conet rc=$?"
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_mapstep -o pmc -- python $R/tools/mb_mapstep.py > $O/mb_mapstep_under_pmc.txt 2> $O/pmc_mfma_mapstep.err; echo "pmc mapstep rc=$?"
 fi
 find $O -name "*kernel_trace.csv" -size +6M -delete
 find $O -name "*counter_collection.csv" -size +24M -delete
