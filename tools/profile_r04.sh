@@ -35,7 +35,7 @@ if has trace_c5; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5_headline -o trace -- python $R/bench.py --headline-only > $O/bench_c5_headline_under_rocprof.json 2> $O/trace_c5_headline.err; echo "trace c5 headline rc=$?"
 fi
 if has trace_cfg; then
-  for Wl in c1 c2 c3; do
+  for Wl in c1 c2 c3 c4; do
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$Wl -o trace -- python $R/bench.py --workload $Wl --no-cpu-baseline --no-fullsort --steps 200 --warmup 20 > $O/bench_${Wl}_under_rocprof.json 2> $O/trace_$Wl.err; echo "trace $Wl rc=$?"
   done
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fullsort_conet -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --steps 20 --warmup 2 > $O/bench_fullsort_conet_under_rocprof.json 2> $O/trace_fullsort_conet.err; echo "trace fullsort conet rc=$?"

@@ -3,11 +3,11 @@ import csv, glob, json, os, shutil
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out, prof, tag = os.path.join(root, 'gpurun_out', 'r04'), os.path.join(root, 'profiles'), 'r04'
 last = lambda f: open(f).read().strip().splitlines()[-1] + '\n'
-for w in ('c5', 'c1', 'c2', 'c3', 'c4', 'c3_dense_adam', 'c4_full_last_layer', 'e2e', 'c5_headline_under_rocprof', 'c1_under_rocprof', 'c2_under_rocprof', 'c3_under_rocprof', 'fullsort_conet_under_rocprof'):
+for w in ('c5', 'c1', 'c2', 'c3', 'c4', 'c3_dense_adam', 'c4_full_last_layer', 'e2e', 'c5_headline_under_rocprof', 'c1_under_rocprof', 'c2_under_rocprof', 'c3_under_rocprof', 'c4_under_rocprof', 'fullsort_conet_under_rocprof'):
     f = os.path.join(out, f'bench_{w}.json')
     if os.path.exists(f) and os.path.getsize(f):
         open(os.path.join(prof, f'{tag}_bench_{w}.json'), 'w').write(last(f))
-for w in ('c5_headline', 'c1', 'c2', 'c3', 'fullsort_conet'):
+for w in ('c5_headline', 'c1', 'c2', 'c3', 'c4', 'fullsort_conet'):
     ks = glob.glob(os.path.join(out, f'trace_{w}', '**', '*kernel_stats.csv'), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(prof, f'{tag}_bench_{w}_kernel_stats.csv'))
