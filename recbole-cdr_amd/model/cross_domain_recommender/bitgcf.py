@@ -135,7 +135,7 @@ class BiTGCF(CrossDomainRecommender):
                                              (bce_t, self.target_user_embedding.weight, self.target_item_embedding.weight, tu, ti, reg_t)):
             if reg is None:
                 reg = F_.EmbLossRows.apply(uw, iw, user, item)
-            losses.append(bce + self.reg_weight * reg)
+            losses.append(torch.add(bce, reg, alpha=self.reg_weight))        # bce + reg_weight * reg in ONE elementwise launch (a 4.7 us launch each at C4)
         return tuple(losses)
 
     @torch.no_grad()
