@@ -33,6 +33,107 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 
 
 
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                 'dtype', 'data')
+DETAIL_FILE = 'bench_detail.json'
+LINE_LIMIT = 4096
+
+
+def _clip(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + '...'
+
+
+def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
+    """The ONE line the driver parses: the contract keys, `config`, `roofline` (with `traffic` as a number of bytes or null),
+    `cpu_baseline`, the wall time of the invocation and the name of the file every leg went to.  Everything else bench.py
+    measures (per-kernel brackets, the OVERLAP / k=4 / grid / full-sort legs, the C1-C4 legs, the end-to-end leg, both N>1
+    layouts) is in `detail_file`.  Round 4's line carried all of that inline (24.7 KB) and the driver could not parse it
+    (BENCH_r04.json `parsed: null`); this one is bounded by `limit` bytes and a test holds it there."""
+    line = {k: result.get(k) for k in CONTRACT_KEYS}
+    cfg = result.get('config') or {}
+    line['config'] = {k: (_clip(v, 320) if isinstance(v, str) else v) for k, v in cfg.items()
+                      if isinstance(v, (str, int, float, bool)) or v is None}
+    rf = result.get('roofline')
+    if isinstance(rf, dict):
+        tr = rf.get('traffic')
+        out = {k: rf.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'algorithmic_bytes') if k in rf}
+        out['traffic'] = tr.get('bytes') if isinstance(tr, dict) else tr
+        if isinstance(tr, dict) and tr.get('source'):
+            out['traffic_source'] = _clip(tr['source'], 200)
+        if out.get('traffic') and rf.get('algorithmic_bytes'):
+            out['traffic_over_algorithmic'] = round(out['traffic'] / rf['algorithmic_bytes'], 4)
+        line['roofline'] = out
+    cb = result.get('cpu_baseline')
+    if isinstance(cb, dict):
+        line['cpu_baseline'] = {k: (_clip(v, 260) if isinstance(v, str) else v) for k, v in cb.items()
+                                if k in ('value', 'unit', 'cores', 'kind', 'sample', 'host_cores', 'cpu_model')}
+        if cb.get('value') and result.get('value'):
+            line['vs_cpu'] = round(result['value'] / cb['value'], 1)
+    # a handful of scalars a reader wants beside the headline without opening the detail file
+    extra = {}
+    rs = result.get('roofline_step')
+    if isinstance(rs, dict) and rs.get('frac') is not None:
+        extra['step_frac_of_hbm_peak'] = rs['frac']
+    fs = result.get('fullsort')
+    if isinstance(fs, dict):
+        for name, leg in fs.items():
+            if isinstance(leg, dict) and isinstance(leg.get('items_per_s'), (int, float)):
+                extra['fullsort_items_per_s_' + name.replace('=', '')] = leg['items_per_s']
+    lay = result.get('layouts')
+    if isinstance(lay, dict):
+        extra['layouts'] = {k: (None if v is None else {'value': v.get('value'), 'ms_per_step': v.get('ms_per_step')}) for k, v in lay.items()}
+    lf = result.get('layout_fallback')
+    if isinstance(lf, dict):
+        extra['layout'] = {k: lf.get(k) for k in ('chosen', 'ranks_seen') if k in lf}
+    legs = result.get('configs')
+    if isinstance(legs, dict):
+        extra['config_legs_ms_per_step'] = {k: round(v['ms_per_step'], 5) for k, v in legs.items() if isinstance(v, dict) and v.get('ms_per_step')}
+    if result.get('leg_errors'):
+        extra['leg_errors'] = sorted(result['leg_errors'])
+    line.update(extra)
+    for k in ('deterministic_backward', 'bench_wall_s'):
+        if k in result:
+            line[k] = result[k]
+    line['detail_file'] = detail_file
+    # bounded whatever the legs put in: drop the optional scalars first, then clip the two prose fields harder
+    for drop in (tuple(extra), ('traffic_source',), ()):
+        txt = json.dumps(line, separators=(',', ':'))
+        if len(txt) <= limit:
+            return txt
+        for k in drop:
+            line.pop(k, None)
+            (line.get('roofline') or {}).pop(k, None)
+    line['config'] = {k: (_clip(v, 120) if isinstance(v, str) else v) for k, v in line['config'].items()}
+    if 'cpu_baseline' in line:
+        line['cpu_baseline']['sample'] = _clip(line['cpu_baseline'].get('sample', ''), 120)
+    txt = json.dumps(line, separators=(',', ':'))
+    assert len(txt) <= limit, len(txt)
+    return txt
+
+
+def emit(result, real_stdout=None, detail_dir=None):
+    """Write every leg to bench_detail.json (repo root; also gpurun_out/ when that directory exists, so a gpurun call brings it
+    back) and print the compact line as the LAST line of stdout."""
+    paths = [os.path.join(detail_dir or ROOT, DETAIL_FILE)]
+    go = os.path.join(ROOT, 'gpurun_out')
+    if detail_dir is None and os.path.isdir(go):
+        paths.append(os.path.join(go, DETAIL_FILE))
+    for p in paths:
+        try:
+            with open(p, 'w') as f:
+                json.dump(result, f, indent=1)
+                f.write('\n')
+        except OSError as e:
+            print('bench: could not write %s: %r' % (p, e), file=sys.stderr)
+    txt = compact_line(result) + '\n'
+    if real_stdout is not None:
+        os.write(real_stdout, txt.encode())
+    else:
+        sys.stdout.write(txt)
+        sys.stdout.flush()
+
+
 def exact_sum(t, step=1 << 28):
     """fp64 sum of a (large) fp32 tensor in slices: ``torch.sum(t, dtype=float64)`` materialises an fp64 copy of the whole operand on this
     build (48 GiB for a 25.6 GB table), which does not fit beside the C5 tables once a few legs have run.  Slice order is fixed: the digits
@@ -1764,10 +1865,7 @@ def main():
         from recbole_cdr_amd import functional as F_
         result['deterministic_backward'] = bool(F_.deterministic())      # CDR_DETERMINISTIC=1: the drop-in losses' dense gradients without float atomics
         result['bench_wall_s'] = round(time.perf_counter() - T_START, 1)  # the whole invocation, imports and every leg included
-        if real_stdout is not None:
-            os.write(real_stdout, (json.dumps(result) + '\n').encode())
-        else:
-            print(json.dumps(result), flush=True)
+        emit(result, real_stdout)
     if world > 1 or args.force_shard:
         import torch.distributed as dist
         stuck = any('still blocked' in str(e) for a in (result.get('layout_fallback') or {}).get('attempts', []) for e in a['errors'].values()) \

@@ -253,7 +253,7 @@ class FullSortEvalLoader:
             pos = torch.searchsorted(users_t, hi_u).clamp_(max=users_t.numel() - 1)
             keep = users_t[pos] == hi_u                                                    # history of evaluated users only
             hi_u, hi_i = hi_u[keep], hi_i[keep]
-        starts = users_t[::self.step]
+        starts = users_t[::self.step].contiguous()                                          # (a strided boundary tensor makes searchsorted warn on stderr)
         self.users = users_t.cpu().numpy()
         self._ev_ptr = np.append(torch.searchsorted(ev_u, starts, right=False).cpu().numpy(), ev_u.numel())
         self._hi_ptr = np.append(torch.searchsorted(hi_u, starts, right=False).cpu().numpy(), hi_u.numel())
