@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 42
+#define CDR_ABI_VERSION 43
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -804,6 +804,12 @@ int cdr_a2a_ids(cdr_comm* comm, void* stream, const int64_t* send, const int64_t
                 const int64_t* recv_counts);
 int cdr_a2a_rows(cdr_comm* comm, void* stream, const float* send, const int64_t* send_rows, float* recv, const int64_t* recv_rows,
                  int D);
+/* The offset / element-count arithmetic of one all-to-all(v), host only (needs neither RCCL nor a device): what cdr_a2a_ids / _rows
+ * hand to ncclSend / ncclRecv for each peer.  counts[p] rows of `unit` elements of `elem` bytes; any output pointer may be NULL.
+ * CDR_EINVAL on a negative count.  (Serves the same reference lines as the exchanges above; lets a host size its buffers.) */
+int cdr_a2a_plan(int world, const int64_t* send_counts, const int64_t* recv_counts, int64_t unit, int64_t elem,
+                 int64_t* send_off_bytes, int64_t* recv_off_bytes, int64_t* send_elems, int64_t* recv_elems,
+                 int64_t* send_total_rows, int64_t* recv_total_rows);
 int cdr_allgather_scores(cdr_comm* comm, void* stream, const float* send, int64_t n, float* recv);
 int cdr_allreduce_sum_f32(cdr_comm* comm, void* stream, float* buf, int64_t n);
 

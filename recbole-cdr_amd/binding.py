@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -191,6 +191,7 @@ _SIGNATURES = {
     'cdr_comm_info': [_c_ptr, _c_ptr, _c_ptr],
     'cdr_a2a_ids': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_a2a_rows': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int],
+    'cdr_a2a_plan': [_c_int, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_allgather_scores': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     'cdr_allreduce_sum_f32': [_c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_scatter_add_block_rows': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],

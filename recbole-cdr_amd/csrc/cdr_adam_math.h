@@ -14,8 +14,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-//   g += wd*p ; m = m + (g - m)(1 - b1) ; v = b2 v + (1 - b2) g g ; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
-// bc2 = the hp value of cdr_adam_hp below: 1 / sqrt(1 - b2^t) (default) or sqrt(1 - b2^t) (-DCDR_ADAM_IEEE)
+// THE update term of every Adam kernel of this library (dense sweep, deferred per-row form, the row-wise fused steps of cdr_step.hip /
+// cdr_kstep.hip, the OVERLAP step of cdr_mapstep.hip):   step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// `bc2` is the value cdr_adam_hp returns for update t.  Default: v_sqrt_f32 / v_rcp_f32 (1 ulp each) and bc2 = 1 / sqrt(1 - b2^t) rounded
+// once from fp64; -DCDR_ADAM_IEEE: sqrtf and two IEEE divisions with bc2 = sqrt(1 - b2^t) (torch's own sequence).  One function, one
+// rounding: two optimizers of this product never round the same expression differently.
+// Drift against torch.optim.Adam over 2,000 free-running updates: tests/test_gpu_parity.py::test_adam_long_horizon_vs_torch.
+__device__ __forceinline__ float cdr_adam_term(float mv, float vv, float step_size, float bc2, float eps) {
+#pragma clang fp contract(off)
+#ifdef CDR_ADAM_IEEE
+    const float denom = sqrtf(vv) / bc2 + eps;
+    return step_size * (mv / denom);
+#else
+    const float denom = __builtin_amdgcn_sqrtf(vv) * bc2 + eps;      // v_sqrt_f32 (1 ulp; a denormal v counts as 0: its update is < 1e-19 lr)
+    return step_size * (mv * __builtin_amdgcn_rcpf(denom));          // v_rcp_f32 (1 ulp); denom >= eps
+#endif
+}
+
+//   g += wd*p ; m = m + (g - m)(1 - b1) ; v = b2 v + (1 - b2) g g ; p -= cdr_adam_term(m, v)
 __device__ __forceinline__ float cdr_adam_elem(float pv, float gv, float& m, float& v, float b1, float b2, float eps, float wd,
                                                float step_size, float bc2) {
 #pragma clang fp contract(off)
@@ -23,17 +39,11 @@ __device__ __forceinline__ float cdr_adam_elem(float pv, float gv, float& m, flo
     const float mv = m + (gv - m) * (1.0f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
     const float vv = b2 * v + ((1.0f - b2) * gv) * gv;    // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
     m = mv; v = vv;
-#ifdef CDR_ADAM_IEEE
-    const float denom = sqrtf(vv) / bc2 + eps;
-    return pv - step_size * (mv / denom);
-#else
-    const float denom = __builtin_amdgcn_sqrtf(vv) * bc2 + eps;      // v_sqrt_f32 (1 ulp; a denormal v counts as 0: its update is < 1e-19 lr)
-    return pv - step_size * (mv * __builtin_amdgcn_rcpf(denom));     // v_rcp_f32 (1 ulp); denom >= eps
-#endif
+    return pv - cdr_adam_term(mv, vv, step_size, bc2, eps);
 }
 
-// bias corrections of update number `st` (>= 1), as the capturable dense kernel computes them
-__device__ __forceinline__ void cdr_adam_hp(double st, float lr, float b1, float b2, float& step_size, float& bc2) {
+// bias corrections of update number `st` (>= 1): on the host (launch arguments) and on the device (capturable kernels) alike
+__host__ __device__ __forceinline__ void cdr_adam_hp(double st, float lr, float b1, float b2, float& step_size, float& bc2) {
     step_size = (float)((double)lr / (1.0 - pow((double)b1, st)));
 #ifdef CDR_ADAM_IEEE
     bc2 = (float)sqrt(1.0 - pow((double)b2, st));

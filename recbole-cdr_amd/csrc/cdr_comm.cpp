@@ -46,7 +46,11 @@ rccl_api* rccl() {
                 api.AllGather && api.AllReduce && api.GetErrorString) state = 1;
         }
     }
-    if (state != 1) { cdr_set_error("cdr_comm: librccl.so could not be loaded / bound (%s)", dlerror() ? dlerror() : "missing symbol"); return nullptr; }
+    if (state != 1) {
+        const char* why = dlerror();             // (ONE call: dlerror() clears the message it returns)
+        cdr_set_error("cdr_comm: librccl.so could not be loaded / bound (%s)", why ? why : "missing symbol");
+        return nullptr;
+    }
     return &api;
 }
 
@@ -101,21 +105,50 @@ extern "C" int cdr_comm_info(const cdr_comm* comm, int* rank, int* world) {
     return CDR_OK;
 }
 
+// The arithmetic of one all-to-all(v), host only (no RCCL, no device): peer p's slice of the send buffer starts where the slices of
+// peers 0..p-1 end, likewise on the receive side; counts are in rows of `unit` elements of `elem` bytes.  Exported so that the
+// offsets for peers != self are testable on a machine without a GPU (tests/test_abi.py) and a non-Python host can size its buffers.
+extern "C" int cdr_a2a_plan(int world, const int64_t* send_counts, const int64_t* recv_counts, int64_t unit, int64_t elem,
+                            int64_t* send_off_bytes, int64_t* recv_off_bytes, int64_t* send_elems, int64_t* recv_elems,
+                            int64_t* send_total_rows, int64_t* recv_total_rows) {
+    CDR_CHECK_ARG(world >= 1 && send_counts && recv_counts && unit > 0 && elem > 0);
+    int64_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+        if (send_counts[p] < 0 || recv_counts[p] < 0) { cdr_set_error("cdr_a2a: negative count for peer %d", p); return CDR_EINVAL; }
+        if (send_off_bytes) send_off_bytes[p] = so * unit * elem;
+        if (recv_off_bytes) recv_off_bytes[p] = ro * unit * elem;
+        if (send_elems) send_elems[p] = send_counts[p] * unit;
+        if (recv_elems) recv_elems[p] = recv_counts[p] * unit;
+        so += send_counts[p]; ro += recv_counts[p];
+    }
+    if (send_total_rows) *send_total_rows = so;
+    if (recv_total_rows) *recv_total_rows = ro;
+    return CDR_OK;
+}
+
 // send: this rank's buffer, ordered by destination (rows for rank 0 first); counts are HOST arrays [world] in units of `unit` elements
 static int a2a(cdr_comm* comm, void* stream, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
                int64_t unit, ncclDataType_t dt, size_t elem) {
     rccl_api* a = rccl();
     if (!a) return CDR_ENODEV;
     hipStream_t s = (hipStream_t)stream;
-    CDR_NCCL(a, a->GroupStart());
-    int64_t so = 0, ro = 0;
-    for (int p = 0; p < comm->world; ++p) {
-        if (send_counts[p] < 0 || recv_counts[p] < 0) { a->GroupEnd(); cdr_set_error("cdr_a2a: negative count for peer %d", p); return CDR_EINVAL; }
-        if (send_counts[p]) CDR_NCCL(a, a->Send((const char*)send + so * unit * elem, (size_t)(send_counts[p] * unit), dt, p, comm->comm, s));
-        if (recv_counts[p]) CDR_NCCL(a, a->Recv((char*)recv + ro * unit * elem, (size_t)(recv_counts[p] * unit), dt, p, comm->comm, s));
-        so += send_counts[p]; ro += recv_counts[p];
+    const int W = comm->world;
+    int64_t* plan = (int64_t*)malloc(sizeof(int64_t) * 4 * (size_t)W);
+    if (!plan) return CDR_ENOMEM;
+    int64_t *soff = plan, *roff = plan + W, *sel = plan + 2 * W, *rel = plan + 3 * W;
+    int rc = cdr_a2a_plan(W, send_counts, recv_counts, unit, (int64_t)elem, soff, roff, sel, rel, nullptr, nullptr);
+    if (rc != CDR_OK) { free(plan); return rc; }
+    ncclResult_t r = a->GroupStart();
+    if (r != ncclSuccess) { free(plan); cdr_set_error("cdr_a2a: ncclGroupStart -> %s", a->GetErrorString(r)); return 1000 + (int)r; }
+    const char* what = nullptr;
+    for (int p = 0; p < W && r == ncclSuccess; ++p) {
+        if (sel[p]) { r = a->Send((const char*)send + soff[p], (size_t)sel[p], dt, p, comm->comm, s); what = "ncclSend"; }
+        if (r == ncclSuccess && rel[p]) { r = a->Recv((char*)recv + roff[p], (size_t)rel[p], dt, p, comm->comm, s); what = "ncclRecv"; }
     }
-    CDR_NCCL(a, a->GroupEnd());
+    free(plan);
+    ncclResult_t e = a->GroupEnd();              // ALWAYS closed: an error inside the group must not leave the communicator in an open group
+    if (r != ncclSuccess) { cdr_set_error("cdr_a2a: %s -> %s", what, a->GetErrorString(r)); return 1000 + (int)r; }
+    if (e != ncclSuccess) { cdr_set_error("cdr_a2a: ncclGroupEnd -> %s", a->GetErrorString(e)); return 1000 + (int)e; }
     return CDR_OK;
 }
 

@@ -18,6 +18,7 @@
 // sort (cdr_smallsort.hip), two applies -- is hipGraph-capturable; `small` drops the long-segment machinery (its memset and
 // two extra launches) for batches whose worst-case segment a single lane group can walk.
 #include "cdr_common.h"
+#include "cdr_adam_math.h"
 #include "cdr_ranksort.h"
 
 namespace {
@@ -223,10 +224,8 @@ __device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __re
         v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
         v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
         st4(mp, m); st4(vp, v);
-        wn = make_float4(w.x - h.step_size * (m.x / (sqrtf(v.x) / h.bc2_sqrt + h.eps)),
-                         w.y - h.step_size * (m.y / (sqrtf(v.y) / h.bc2_sqrt + h.eps)),
-                         w.z - h.step_size * (m.z / (sqrtf(v.z) / h.bc2_sqrt + h.eps)),
-                         w.w - h.step_size * (m.w / (sqrtf(v.w) / h.bc2_sqrt + h.eps)));
+        wn = make_float4(w.x - cdr_adam_term(m.x, v.x, h.step_size, h.bc2_sqrt, h.eps), w.y - cdr_adam_term(m.y, v.y, h.step_size, h.bc2_sqrt, h.eps),
+                         w.z - cdr_adam_term(m.z, v.z, h.step_size, h.bc2_sqrt, h.eps), w.w - cdr_adam_term(m.w, v.w, h.step_size, h.bc2_sqrt, h.eps));
     }
     st4(wp, wn);
 }
@@ -234,8 +233,7 @@ __device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __re
 __device__ __forceinline__ void hp_from_device(apply_hp& hp, const int64_t* step_dev) {
     if (step_dev) {                                           // capturable: the update count lives on the device
         const double st = (double)step_dev[0];
-        hp.step_size = (float)((double)hp.lr / (1.0 - pow((double)hp.b1, st)));
-        hp.bc2_sqrt = (float)sqrt(1.0 - pow((double)hp.b2, st));
+        cdr_adam_hp(st, hp.lr, hp.b1, hp.b2, hp.step_size, hp.bc2_sqrt);
     }
 }
 
@@ -401,9 +399,7 @@ int apply2(cdr_ctx* ctx, hipStream_t s, int opt, float* table, float* exp_avg, f
            int small, int tag) {
     float step_size = lr, bc2_sqrt = 1.f;
     if (opt == 1 && !step_dev) {
-        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-        step_size = (float)((double)lr / bc1);
-        bc2_sqrt = (float)sqrt(bc2);
+        cdr_adam_hp((double)step, lr, beta1, beta2, step_size, bc2_sqrt);       // (bc2_sqrt carries cdr_adam_hp's bc2: cdr_adam_math.h)
     }
     const apply_hp hp{lr, beta1, beta2, eps, wd, step_size, bc2_sqrt};
     const int64_t* sd = opt == 1 ? step_dev : nullptr;

@@ -121,13 +121,7 @@ __device__ __forceinline__ float lz_elem_nograd(float pv, float& m, float& v, fl
     const float mv = m + (0.f - m) * (1.0f - b1);
     const float vv = b2 * v;
     m = mv; v = vv;
-#ifdef CDR_ADAM_IEEE
-    const float denom = sqrtf(vv) / bc2 + eps;
-    return pv - step_size * (mv / denom);
-#else
-    const float denom = __builtin_amdgcn_sqrtf(vv) * bc2 + eps;
-    return pv - step_size * (mv * __builtin_amdgcn_rcpf(denom));
-#endif
+    return pv - cdr_adam_term(mv, vv, step_size, bc2, eps);
 }
 
 __global__ __launch_bounds__(kBlock) void lz_prepare1_kernel(lz_args a, float2* __restrict__ hp, int64_t* __restrict__ counters, int lanes_per_row) {

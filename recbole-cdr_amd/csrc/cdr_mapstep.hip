@@ -29,6 +29,7 @@
 #include <type_traits>
 #include <cstdlib>
 #include "cdr_common.h"
+#include "cdr_adam_math.h"
 
 namespace {
 
@@ -72,9 +73,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void adam_hp(const map_opt& o, const int64_t* step_dev, int64_t plus, float& step_size, float& bc2_sqrt) {
     step_size = o.lr; bc2_sqrt = 1.f;
     if (o.opt == 1) {
-        const double st = (double)(step_dev[0] + plus);
-        step_size = (float)((double)o.lr / (1.0 - pow((double)o.b1, st)));
-        bc2_sqrt = (float)sqrt(1.0 - pow((double)o.b2, st));
+        cdr_adam_hp((double)(step_dev[0] + plus), o.lr, o.b1, o.b2, step_size, bc2_sqrt);      // (bc2_sqrt carries cdr_adam_hp's bc2: cdr_adam_math.h)
     }
 }
 
@@ -84,19 +83,13 @@ __device__ __forceinline__ float upd1(float w, float g, float& m, float& v, cons
     if (o.opt == 0) return w - o.lr * g;
     m += (g - m) * (1.0f - o.b1);
     v = o.b2 * v + (1.0f - o.b2) * g * g;
-    return w - step_size * (m / (sqrtf(v) / bc2_sqrt + o.eps));
+    return w - cdr_adam_term(m, v, step_size, bc2_sqrt, o.eps);
 }
 
-// the same update with the two divisions and the square root on the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 instead of their
-// IEEE expansions (map_pipe_kernel only -- its row waves are VALU-issue bound and the expansions are two thirds of their work):
-// exp_avg and exp_avg_sq are bit-identical, the step differs from upd1's by <= ~3 ulp of the QUOTIENT, i.e. <= 4e-7 x lr on the
-// weight -- below half an ulp of the weight in all but tie cases
-__device__ __forceinline__ float updq(float w, float g, float& m, float& v, const map_opt& o, float step_size, float rbc) {
-    if (o.wd != 0.f) g += o.wd * w;
-    if (o.opt == 0) return w - o.lr * g;
-    m += (g - m) * (1.0f - o.b1);
-    v = o.b2 * v + (1.0f - o.b2) * g * g;
-    return w - step_size * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * rbc + o.eps));
+// (round 4 had a second form of this update on v_rcp_f32 / v_sqrt_f32 for map_pipe_kernel alone; since round 5 EVERY Adam kernel of the
+// library takes its update term from cdr_adam_term, so the pipe kernels call the same function as everything else)
+__device__ __forceinline__ float updq(float w, float g, float& m, float& v, const map_opt& o, float step_size, float bc2) {
+    return upd1(w, g, m, v, o, step_size, bc2);
 }
 
 // SLOTS: weight-gradient tiles per wave (4 -> 64 accumulator registers, 8 -> 128)
@@ -455,7 +448,7 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
         constexpr int Q0 = decltype(Q0c)::value, Q1 = decltype(Q1c)::value, NQQ = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
         if (Q1 <= Q0) return;
         const int ln = fresh(lane);
-        const float rbc = 1.0f / bcs;
+        const float rbc = bcs;                       // cdr_adam_hp's bc2 as it is
         const int r0 = ln / LR, p = ln % LR;
         float4 w[NQQ], g[NQQ], m[NQQ], v[NQQ];
         int64_t o[NQQ];
@@ -806,7 +799,7 @@ __global__ __launch_bounds__(512, 1) void map_pipe2_kernel(map_net net, map_opt 
         constexpr int Q0 = decltype(Q0c)::value, Q1 = decltype(Q1c)::value, NQQ = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
         if (Q1 <= Q0) return;
         const int ln = fresh(lane);
-        const float rbc = 1.0f / bcs;
+        const float rbc = bcs;                       // cdr_adam_hp's bc2 as it is
         const int r0 = ln / LR, p = ln % LR;
         float4 w[NQQ], g[NQQ], m[NQQ], v[NQQ];
         int64_t o[NQQ];
@@ -1186,7 +1179,7 @@ __global__ __launch_bounds__(512, 1) void map_pipe3_kernel(map_net net, map_opt 
         constexpr int Q0 = decltype(Q0c)::value, Q1 = decltype(Q1c)::value, NQQ = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
         if (Q1 <= Q0) return;
         const int ln = fresh(lane);
-        const float rbc = 1.0f / bcs;
+        const float rbc = bcs;                       // cdr_adam_hp's bc2 as it is
         const int r0 = ln / LR, p = ln % LR;
         float4 w[NQQ], g[NQQ], m[NQQ], v[NQQ];
         int64_t o[NQQ];

@@ -207,14 +207,9 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(float* __restrict__ 
                                                             float step_size, float bc2_sqrt) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
-        float gv = g[e];
-        const float pv = p[e];
-        if (wd != 0.f) gv += wd * pv;
-        const float mv = m[e] + (gv - m[e]) * (1.0f - b1);        // torch: exp_avg.lerp_(grad, 1-beta1)
-        const float vv = b2 * v[e] + (1.0f - b2) * gv * gv;       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        float mv = m[e], vv = v[e];
+        p[e] = cdr_adam_elem(p[e], g[e], mv, vv, b1, b2, eps, wd, step_size, bc2_sqrt);   // (bc2_sqrt: cdr_adam_hp's bc2) the ONE element update
         m[e] = mv; v[e] = vv;
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        p[e] = pv - step_size * (mv / denom);
     }
 }
 
@@ -223,18 +218,13 @@ __global__ __launch_bounds__(kBlock) void adam_dense_dev_kernel(float* __restric
                                                                 float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                                 float lr, float b1, float b2, float eps, float wd,
                                                                 const int64_t* __restrict__ step_dev) {
-    const double st = (double)step_dev[0];
-    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, st)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    float step_size, bc2_sqrt;
+    cdr_adam_hp((double)step_dev[0], lr, b1, b2, step_size, bc2_sqrt);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
-        float gv = g[e];
-        const float pv = p[e];
-        if (wd != 0.f) gv += wd * pv;
-        const float mv = m[e] + (gv - m[e]) * (1.0f - b1);
-        const float vv = b2 * v[e] + (1.0f - b2) * gv * gv;
+        float mv = m[e], vv = v[e];
+        p[e] = cdr_adam_elem(p[e], g[e], mv, vv, b1, b2, eps, wd, step_size, bc2_sqrt);   // (bc2_sqrt: cdr_adam_hp's bc2) the ONE element update
         m[e] = mv; v[e] = vv;
-        p[e] = pv - step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
     }
 }
 
@@ -519,10 +509,8 @@ extern "C" int cdr_mse_bwd(void* stream, const float* a, const float* b, int64_t
 extern "C" int cdr_adam_dense(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                               float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step) {
     CDR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0);
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    float step_size, bc2_sqrt;
+    cdr_adam_hp((double)step, lr, beta1, beta2, step_size, bc2_sqrt);
     adam_dense_kernel<<<dim3(grid_cap((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
         param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt);
     CDR_LAUNCH_CHECK();

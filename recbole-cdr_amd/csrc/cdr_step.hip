@@ -18,6 +18,7 @@
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "cdr_common.h"
+#include "cdr_adam_math.h"
 
 namespace {
 
@@ -258,10 +259,8 @@ __device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __re
         v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
         v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
         st4(mp, m); st4(vp, v);
-        wn = make_float4(w.x - h.step_size * (m.x / (sqrtf(v.x) / h.bc2_sqrt + h.eps)),
-                         w.y - h.step_size * (m.y / (sqrtf(v.y) / h.bc2_sqrt + h.eps)),
-                         w.z - h.step_size * (m.z / (sqrtf(v.z) / h.bc2_sqrt + h.eps)),
-                         w.w - h.step_size * (m.w / (sqrtf(v.w) / h.bc2_sqrt + h.eps)));
+        wn = make_float4(w.x - cdr_adam_term(m.x, v.x, h.step_size, h.bc2_sqrt, h.eps), w.y - cdr_adam_term(m.y, v.y, h.step_size, h.bc2_sqrt, h.eps),
+                         w.z - cdr_adam_term(m.z, v.z, h.step_size, h.bc2_sqrt, h.eps), w.w - cdr_adam_term(m.w, v.w, h.step_size, h.bc2_sqrt, h.eps));
     }
     st4(wp, wn);
 }
@@ -483,17 +482,8 @@ __device__ __forceinline__ float4 upd_math(float4 w, float4& m, float4& v, float
     m.z += (gr.z - m.z) * (1.0f - h.b1); m.w += (gr.w - m.w) * (1.0f - h.b1);
     v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
     v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
-#ifdef CDR_FAST_ADAM   /* experiment switch (tools/): hardware 1-ulp rcp / sqrt instead of the IEEE sequences */
-    const float ib = __builtin_amdgcn_rcpf(h.bc2_sqrt);
-#define CDR_UPDQ(W, M, V) (W - h.step_size * (M * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(V) * ib + h.eps)))
-    return make_float4(CDR_UPDQ(w.x, m.x, v.x), CDR_UPDQ(w.y, m.y, v.y), CDR_UPDQ(w.z, m.z, v.z), CDR_UPDQ(w.w, m.w, v.w));
-#undef CDR_UPDQ
-#else
-    return make_float4(w.x - h.step_size * (m.x / (sqrtf(v.x) / h.bc2_sqrt + h.eps)),
-                       w.y - h.step_size * (m.y / (sqrtf(v.y) / h.bc2_sqrt + h.eps)),
-                       w.z - h.step_size * (m.z / (sqrtf(v.z) / h.bc2_sqrt + h.eps)),
-                       w.w - h.step_size * (m.w / (sqrtf(v.w) / h.bc2_sqrt + h.eps)));
-#endif
+    return make_float4(w.x - cdr_adam_term(m.x, v.x, h.step_size, h.bc2_sqrt, h.eps), w.y - cdr_adam_term(m.y, v.y, h.step_size, h.bc2_sqrt, h.eps),
+                       w.z - cdr_adam_term(m.z, v.z, h.step_size, h.bc2_sqrt, h.eps), w.w - cdr_adam_term(m.w, v.w, h.step_size, h.bc2_sqrt, h.eps));
 }
 
 // partials[block] = {sum_b ||U[uid[b]]||^2, sum_b ||I[pid[b]]||^2}: the EmbLoss norms of the batch (emcdr.py:129-131: reg_loss(user_e, pos_e))
@@ -626,8 +616,7 @@ __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __res
         int64_t* c = threadIdx.x == 0 ? step_u_dev : step_i_dev;
         const int64_t st = c[0] + 1;
         c[0] = st;
-        hp_dev[2 * threadIdx.x] = (float)((double)lr / (1.0 - pow((double)b1, (double)st)));
-        hp_dev[2 * threadIdx.x + 1] = (float)sqrt(1.0 - pow((double)b2, (double)st));
+        cdr_adam_hp((double)st, lr, b1, b2, hp_dev[2 * threadIdx.x], hp_dev[2 * threadIdx.x + 1]);
     }
     double acc[2] = {0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
@@ -1210,9 +1199,7 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
     }
     float step_size = lr, bc2_sqrt = 1.f;
     if (opt == 1) {
-        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-        step_size = (float)((double)lr / bc1);
-        bc2_sqrt = (float)sqrt(bc2);
+        cdr_adam_hp((double)step, lr, beta1, beta2, step_size, bc2_sqrt);       // (bc2_sqrt carries cdr_adam_hp's bc2: cdr_adam_math.h)
     }
     const int lpr = cdr_lpr_for(D);
     const int grid = grid_for(n, kBlock / lpr);
@@ -1331,9 +1318,7 @@ static int apply_dups_pair(cdr_ctx* ctx, hipStream_t s, int opt, int D, const du
 static apply_hp make_hp(int opt, float lr, float beta1, float beta2, float eps, float wd, int64_t step) {
     float step_size = lr, bc2_sqrt = 1.f;
     if (opt == 1) {
-        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-        step_size = (float)((double)lr / bc1);
-        bc2_sqrt = (float)sqrt(bc2);
+        cdr_adam_hp((double)step, lr, beta1, beta2, step_size, bc2_sqrt);       // (bc2_sqrt carries cdr_adam_hp's bc2: cdr_adam_math.h)
     }
     return apply_hp{lr, beta1, beta2, eps, wd, step_size, bc2_sqrt};
 }

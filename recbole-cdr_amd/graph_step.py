@@ -102,39 +102,7 @@ class GraphedTrainStep:
     def _can_pipeline(self):
         return (self.producer is not None and self.unroll > 1 and hasattr(self.model, 'prepare_batch')
                 and hasattr(self.model, 'apply_rows_early') and getattr(self.optimizer, 'row_opt', None) is not None
-                and self.pipeline and self.pipeline != 'producer_ahead')
-
-    def _can_produce_ahead(self):
-        """``pipeline='producer_ahead'`` (opt-in): any model on a device producer with output slots, batch i + 1 produced beside step i
-        (`_whole_many_producer_ahead`).  Measured SLOWER than the plain order on C1 / C2 / C4 and therefore not a default."""
-        return (self.producer is not None and self.unroll > 1 and self.pipeline == 'producer_ahead' and hasattr(self.producer, 'add_slot'))
-
-    def _whole_many_producer_ahead(self, k, main, side):
-        """``k`` consecutive steps of ANY model with the production of batch i + 1 on a side stream beside step i.  A small configuration's
-        step is four dependent launches of 8-10 us each (producer, forward, backward, Adam: DESIGN 4.R4) and the producer -- slice + tile +
-        negative sampling, a chain of dependent L2 round trips over a few thousand rows on a handful of workgroups -- depends on nothing a step
-        writes, so on paper it comes off the chain for free (the chip is nearly empty beside it).  MEASURED (profiles/r04_ab_producer_ahead.txt,
-        alternating processes, 400 steps): C1 0.0377 -> 0.0405 ms, C2 0.0361 -> 0.0395 ms, C4 0.747 -> 0.782 ms per step, final losses
-        identical -- inside a captured graph the fork and the join of the second stream cost more (~3 us per step) than the producer's 7.5 us
-        return, the same finding as for CoNet's third stream.  Kept selectable, not a default.  Two output slots: the backward of step i still reads
-        the ids of batch i (the drop-in losses keep references, not copies) while batch i + 1 is written.  Order: producers run in loader order
-        (the device cursor is theirs alone: each waits for its predecessor through the stream joins); slot (i + 1) & 1 was last read by step
-        i - 1, which lies behind the fork on the main stream.  The same launches on the same operands as the plain order."""
-        P = self.producer
-        if self._statics is None:
-            self._statics = [P.fields_slot(0), P.fields_slot(P.add_slot())]
-        st = self._statics
-        P.launch(0)
-        loss = None
-        for i in range(k):
-            if i + 1 < k:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    P.launch((i + 1) & 1)
-            loss = self._eager(st[i & 1])
-            if i + 1 < k:
-                main.wait_stream(side)
-        return loss
+                and bool(self.pipeline))
 
     def _whole_many(self, k):
         """``k`` consecutive steps.  With a model that offers ``prepare_batch`` / ``apply_rows_early`` (CoNet on the deferred Adam) the
@@ -144,8 +112,6 @@ class GraphedTrainStep:
         as the plain order (only independent launches overlap): bit-identical results.  Dependencies: the producer overwrites the batch
         buffers after the forward that read them (the backward works on the forward's own copies); the next batch's replay comes
         after this batch's row update on the same stream; the next forward needs both branches."""
-        if self._can_produce_ahead():
-            return self._whole_many_producer_ahead(k, torch.cuda.current_stream(), self._side2)
         if not self._can_pipeline():
             loss = None
             for _ in range(k):
@@ -219,40 +185,56 @@ class GraphedTrainStep:
         return loss
 
     def _capture(self, warmup):
-        # populate .grad and the optimizer state (and every lazily created native context) before capture
+        """Warm-up (real steps, state put back afterwards), then the captures.  Whatever fails on the way -- a warm-up step, the pipelined
+        pre-run, a capture -- the parameters, optimizer state and loader / sampler counters are restored to what they were on entry
+        before the exception leaves (a failed capture used to leave the warm-up's updates applied), and the exception
+        carries ``state_restored`` so that the trainer's warning can say so."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         snap = self._snapshot() if self.restore_after_warmup else None
-        with torch.cuda.stream(side):
-            for i in range(max(warmup, 1)):
-                self._whole()
-                if i == 0 and snap is not None:
-                    snap = self._snapshot(snap)           # optimizer state created by the first step: remembered as zeros
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if snap is not None:
-            self._restore(snap)
-        self.graph = torch.cuda.CUDAGraph()
-        # capture on the stream that ran the warm-up: the native contexts are per (device, stream) and creating one
-        # allocates, which is not allowed while a stream is capturing
-        with capturing(self.graph, side):
-            self.loss = self._whole()
-        if self.unroll > 1:
-            if self._can_pipeline() or self._can_produce_ahead():
-                # the pipelined order once eagerly (on the capture stream): the side stream's native context must exist before a capture
-                # uses it, and the state it moves is put back like the warm-up's
-                snap2 = self._snapshot() if self.restore_after_warmup else None
-                with torch.cuda.stream(side):
-                    with torch.cuda.stream(self._side2):
-                        from . import binding as B_
-                        B_.ctx(dev_of(self.static))
-                    self._whole_many(2)
+        try:
+            # populate .grad and the optimizer state (and every lazily created native context) before capture
+            with torch.cuda.stream(side):
+                for i in range(max(warmup, 1)):
+                    self._whole()
+                    if i == 0 and snap is not None:
+                        snap = self._snapshot(snap)           # optimizer state created by the first step: remembered as zeros
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if snap is not None:
+                self._restore(snap)
+            self.graph = torch.cuda.CUDAGraph()
+            # capture on the stream that ran the warm-up: the native contexts are per (device, stream) and creating one
+            # allocates, which is not allowed while a stream is capturing
+            with capturing(self.graph, side):
+                self.loss = self._whole()
+            if self.unroll > 1:
+                if self._can_pipeline():
+                    # the pipelined order once eagerly (on the capture stream): the side stream's native context must exist before a
+                    # capture uses it, and the state it moves is put back like the warm-up's
+                    with torch.cuda.stream(side):
+                        with torch.cuda.stream(self._side2):
+                            from . import binding as B_
+                            B_.ctx(dev_of(self.static))
+                        self._whole_many(2)
+                    torch.cuda.synchronize()
+                    if snap is not None:
+                        self._restore(snap)
+                self.graph_k = torch.cuda.CUDAGraph()
+                with capturing(self.graph_k, side):
+                    self._whole_many(self.unroll)
+        except BaseException as e:
+            restored = False
+            try:
                 torch.cuda.synchronize()
-                if snap2 is not None:
-                    self._restore(snap2)
-            self.graph_k = torch.cuda.CUDAGraph()
-            with capturing(self.graph_k, side):
-                self._whole_many(self.unroll)
+                if snap is not None:
+                    self._restore(snap)
+                    restored = True
+            except Exception:                                 # noqa: BLE001 -- a stream left in an invalidated capture: nothing more to do here
+                pass
+            self.graph = self.graph_k = None
+            e.state_restored = restored
+            raise
 
     # ---- warm-up without side effects: in-place snapshot / restore (addresses must not change: the capture follows) -------------
     def _state_tensors(self):

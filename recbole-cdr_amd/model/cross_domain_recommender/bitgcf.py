@@ -161,6 +161,15 @@ class BiTGCF(CrossDomainRecommender):
         return F_.fullsort_topk(u, restore_item_e[:self.target_num_items], None, k=k, hist_indptr=hist_indptr,
                                 hist_cols=hist_cols, exclude_first_col=True)
 
+    def on_train_steps(self):
+        # a replayed step runs no Python: the trainer calls this after replays so that the next evaluation propagates the TRAINED tables
+        self.init_restore_e()
+
+    def train(self, mode=True):
+        if mode:
+            self.init_restore_e()                 # (whoever trains without this package's Trainer still gets a fresh cache per training visit)
+        return super().train(mode)
+
     def init_restore_e(self):
         if self.target_restore_user_e is not None or self.target_restore_item_e is not None:
             self.target_restore_user_e, self.target_restore_item_e = None, None

@@ -63,6 +63,11 @@ class CrossDomainRecommender(nn.Module):
         would be frozen into the capture.  Default: not capturable (the eager loop)."""
         return None
 
+    def on_train_steps(self):
+        """Called by ``Trainer`` after training steps that ran WITHOUT the model's Python (hipGraph replays): the place to drop
+        anything ``calculate_loss`` would have invalidated on the host -- e.g. BiTGCF's cached propagated embeddings
+        (bitgcf.py:146-148 of the reference clears them at the top of every ``calculate_loss``).  Default: nothing cached."""
+
     def calculate_loss(self, interaction):
         raise NotImplementedError
 

@@ -85,15 +85,26 @@ class RowAwareAdam(DenseAdam):
         self.row_opt.on_replay()
 
     def state_dict(self):
+        """The layout ``torch.optim.Adam.state_dict()`` writes -- the tables' flushed moments and update count under the standard
+        per-parameter 'state' entries -- so that a checkpoint resumes under DenseAdam, torch.optim.Adam or this class alike
+        (the moments used to sit under an extra key that the dense loaders silently ignored)."""
         sd = super().state_dict()
-        sd['deferred_rows'] = self.row_opt.state_dict()
+        rows = self.row_opt.state_dict()                                  # (flushes: every row at the current update)
+        index, i = {}, 0
+        for g in self.param_groups:
+            for p_ in g['params']:
+                index[id(p_)] = i
+                i += 1
+        for t, m, v in zip(self.row_opt.tables, rows['exp_avg'], rows['exp_avg_sq']):
+            sd['state'][index[id(t)]] = {'step': torch.full((1,), int(rows['step']), device=t.device, dtype=torch.int64),
+                                         'exp_avg': m, 'exp_avg_sq': v}
         return sd
 
     def load_state_dict(self, sd):
         sd = dict(sd)
         rows = sd.pop('deferred_rows', None)
         super().load_state_dict(sd)
-        if rows is not None:
+        if rows is not None:                          # (checkpoints written before round 5 kept the tables' moments under this key)
             self.row_opt.load_state_dict(rows)
             return
         # a checkpoint written by DenseAdam / torch.optim.Adam: the tables' moments sit in the per-parameter state -- take them over
@@ -210,7 +221,9 @@ class Trainer:
                 self.graph_stats['captures'] += 1
             except Exception as e:                                      # noqa: BLE001 -- reported, and the eager loop still trains
                 import warnings
-                warnings.warn(f'hipGraph capture of the training step failed for {key!r} ({type(e).__name__}: {e}); running it eagerly')
+                back = 'parameters / optimizer state / loader counters restored to their values before the warm-up' \
+                    if getattr(e, 'state_restored', False) else 'the warm-up steps that ran before the failure stay applied'
+                warnings.warn(f'hipGraph capture of the training step failed for {key!r} ({type(e).__name__}: {e}); running it eagerly ({back})')
                 gs = False
             self._graphs[key] = gs
         return gs
@@ -276,6 +289,8 @@ class Trainer:
                     self.graph_stats['replayed'] += 1
                 else:
                     self._eager_step(interaction)                          # ragged tail (another shape), or a failed capture
+        if self.graph_stats['replayed'] and hasattr(self.model, 'on_train_steps'):
+            self.model.on_train_steps()                                    # replays ran no model Python: host-side caches are stale now
         value = float(self._loss_sum)
         if value != value:
             raise ValueError('Training loss is nan')

@@ -197,6 +197,85 @@ def test_adam_dense_matches_torch():
     assert_close(p, p_ref, rtol=1e-6)
 
 
+def test_adam_long_horizon_vs_torch(capsys):
+    """2,000 FREE-RUNNING updates of the product's Adam (cdr_adam_term: v_sqrt_f32 / v_rcp_f32, 1 ulp each, bias
+    correction rounded once from fp64) against torch.optim.Adam (fp32, CPU) on a C2-shaped table (6,984 x 64, xavier) with sparse
+    gradients (2,048 random rows per step, magnitudes 1e-4 .. 1e-1, all other rows g = 0 -- dense Adam still moves them).  Three entry
+    points: trainer.DenseAdam (cdr_adam_multi_dev), cdr_adam_dense (host step count), lazyadam.DeferredRowAdam (lazy per row).
+    Bound: the weight error, relative to the row's largest weight, stays <= 1e-5 -- and it is compared with the reference's OWN fp32 noise
+    (torch fp32 Adam against torch fp64 Adam on the same gradients): the product's deviation from torch is of that size, not above."""
+    from recbole_cdr_amd import functional as F_
+    from recbole_cdr_amd.lazyadam import DeferredRowAdam
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    rows, D, B, steps, lr = 6984, 64, 2048, 2000, 1e-3
+    gen = torch.Generator().manual_seed(2022)
+    w0 = torch.randn(rows, D, generator=gen) * (2.0 / (rows + D)) ** 0.5
+    ref32 = w0.clone().requires_grad_(True); o32 = torch.optim.Adam([ref32], lr=lr)
+    ref64 = w0.double().requires_grad_(True); o64 = torch.optim.Adam([ref64], lr=lr)
+    pd = torch.nn.Parameter(w0.clone().to(DEV)); od = DenseAdam([pd], lr=lr)
+    ph = w0.clone().to(DEV); mh, vh = torch.zeros_like(ph), torch.zeros_like(ph)
+    pl = torch.nn.Parameter(w0.clone().to(DEV)); ol = DeferredRowAdam([pl], [0], lr=lr)
+    for step in range(1, steps + 1):
+        ids = torch.randperm(rows, generator=gen)[:B]
+        G = torch.randn(B, D, generator=gen) * (10.0 ** float(torch.empty(1).uniform_(-4, -1, generator=gen)))
+        g = torch.zeros(rows, D); g[ids] = G
+        ref32.grad = g; o32.step()
+        ref64.grad = g.double(); o64.step()
+        gd, Gd, idd = g.to(DEV), G.to(DEV), ids.to(DEV)
+        pd.grad = gd; od.step()
+        F_.adam_dense_(ph, gd, mh, vh, step, lr=lr)
+        ol.prepare([idd]); ol.pending = (Gd, (0,), D); ol.step()
+    ol.flush()
+    torch.cuda.synchronize()
+    want = ref32.detach()
+    row_scale = want.abs().amax(1, keepdim=True)
+
+    def err(x):
+        d = (x.double() - want.double()).abs()
+        return float(d.max()), float((d / row_scale.double()).max())
+
+    noise_abs, noise_rel = err(ref64.detach().float())                  # the reference's own fp32 rounding noise after 2,000 updates
+    report = {'torch_fp32_vs_torch_fp64': (noise_abs, noise_rel)}
+    assert torch.equal(pd.data, pl.data) and torch.equal(pd.data, ph), 'the three entry points share one arithmetic: bit-identical'
+    for name, x in (('DenseAdam', pd.data.cpu()), ('cdr_adam_dense', ph.cpu()), ('DeferredRowAdam', pl.data.cpu())):
+        a, r = err(x)
+        report[name] = (a, r)
+        assert r <= 1e-5, (name, a, r)
+        assert a <= 4 * noise_abs + 1e-9, (name, a, noise_abs)             # within a small multiple of what fp32 itself loses
+    moved = float((want - w0).abs().max())
+    assert moved > 50 * lr                                                  # the run is long enough to matter: weights moved by >> one update
+    with capsys.disabled():
+        print('\nadam_long_horizon: 2000 updates, max |w - w0| = %.3e; (max abs err, max err / row max): %s'
+              % (moved, {k: ('%.2e' % v[0], '%.2e' % v[1]) for k, v in report.items()}))
+
+
+def test_rowwise_adam_step_long_horizon_vs_oracle(capsys):
+    """The O(batch) fused BPR step (cdr_step.hip; row-wise Adam: only touched rows move) over 300 FREE-RUNNING steps against the oracle's
+    row-wise step on the CPU (autograd + the same lazy Adam in torch arithmetic): gradients depend on the weights here, so rounding
+    differences feed back.  Loss of every 50th step at 1e-5; tables at the end within 1e-4 of the row scale (observed value printed)."""
+    from oracle import train_step as ts
+    from recbole_cdr_amd.fused import FusedBPRStep
+    torch.manual_seed(7)
+    nu, ni, D, B, lr, reg, steps = 3000, 2000, 64, 1024, 1e-3, 0.01, 300
+    U = torch.randn(nu, D) * 0.05; I = torch.randn(ni, D) * 0.05
+    Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+    fs = FusedBPRStep(Ud, Id, max_batch=B, opt='adam', lr=lr, reg_weight=reg)
+    su, si = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
+    for step in range(1, steps + 1):
+        u = torch.randint(0, nu, (B,)); p = torch.randint(0, ni, (B,)); n = torch.randint(0, ni, (B,))
+        ref = ts.rowwise_step(U, I, su, si, u, p, n, step, opt='adam', lr=lr, reg_weight=reg)
+        out = fs.step(u.to(DEV), p.to(DEV), n.to(DEV))
+        if step % 50 == 0:
+            assert_close(out[0], ref, what=f'loss step {step}')
+    worst = {}
+    for name, got, want in (('U', Ud.cpu(), U), ('I', Id.cpu(), I)):
+        d = (got.double() - want.double()).abs() / want.abs().amax(1, keepdim=True).double()
+        worst[name] = float(d.max())
+        assert worst[name] <= 1e-4, (name, worst[name])
+    with capsys.disabled():
+        print('\nrowwise_adam_long_horizon: 300 free-running steps, max err / row max: %s' % {k: '%.2e' % v for k, v in worst.items()})
+
+
 # ---------------------------------------------------------------------------------------------- fused row-wise step
 def _lazy_adam_ref(W, G, touched, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam's arithmetic restricted to the touched rows (the documented lazy variant)."""

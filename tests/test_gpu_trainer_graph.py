@@ -120,7 +120,7 @@ def _params(model):
     return {k: v.detach().clone() for k, v in model.named_parameters()}
 
 
-@pytest.mark.parametrize('mapping,graph_pipeline', [('linear', True), ('non_linear', True), ('linear', 'producer_ahead')])
+@pytest.mark.parametrize('mapping,graph_pipeline', [('linear', True), ('non_linear', True)])
 def test_trainer_fit_on_replays_equals_the_same_steps_run_eagerly(mapping, graph_pipeline):
     """CrossDomainTrainer.fit(SOURCE, TARGET, OVERLAP) on device loaders: every full batch is one hipGraph replay that produces the
     batch itself.  Reference run: the SAME launches issued eagerly (producer launch -> zero_grad -> calculate_loss -> backward ->
@@ -133,7 +133,6 @@ def test_trainer_fit_on_replays_equals_the_same_steps_run_eagerly(mapping, graph
     cfg = base_config(DEV, latent_factor_model='BPR', source_embedding_size=16, target_embedding_size=16, reg_weight=0.01,
                       mapping_function=mapping, mlp_hidden_size=[24], learning_rate=0.01, train_modes=['SOURCE', 'TARGET', 'OVERLAP'],
                       epoch_num=['2', '2', '2'], source_split=False, eval_step=0, epochs=2, graph_pipeline=graph_pipeline)
-    # ('producer_ahead': the opt-in order that produces batch i + 1 on a side stream beside step i, two batch slots -- same launches, same data)
     torch.manual_seed(3)
     model = EMCDR(cfg, ds).to(DEV)
     init = _params(model)
@@ -507,8 +506,10 @@ def test_conet_pipelined_unrolled_graph_is_bit_identical_to_the_plain_order():
         assert lp == ls, (lp, ls)
         for k in pp:
             assert torch.equal(pp[k], ps[k]), k
-        for a, b in zip(op['deferred_rows']['exp_avg'], os_['deferred_rows']['exp_avg']):
-            assert torch.equal(a, b)
+        assert 'deferred_rows' not in op and op['state'].keys() == os_['state'].keys()
+        for i_ in op['state']:
+            for f_ in ('exp_avg', 'exp_avg_sq', 'step'):
+                assert torch.equal(op['state'][i_][f_], os_['state'][i_][f_]), (i_, f_)
 
 
 def test_rowwise_trainer_on_replays_equals_the_eager_rowwise_loop():
@@ -602,3 +603,83 @@ def test_headline_step_trains_the_same_tables_in_every_process_and_stream_layout
         outs.append((d['state_checksum'], d['final_loss']))
     assert outs[0] == outs[1] == outs[2], outs
     assert len(outs[0][0]) == 4 and all(float(v) == float(v) for v in outs[0][0].values())
+
+
+def test_bitgcf_evaluation_after_replayed_epochs_sees_the_trained_tables():
+    """BiTGCF caches its propagated target embeddings for evaluation and the reference clears that cache at the top of
+    every calculate_loss (bitgcf.py:146-148) -- Python a hipGraph replay never runs.  With every batch of an epoch a full-shape replay,
+    the evaluation after the NEXT epoch must still see the trained tables (Trainer calls model.on_train_steps() after replays)."""
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset(7, n_s=900, n_t=900)
+    s_pairs, t_pairs = s_pairs[:384], t_pairs[:384]                      # 6 full batches of 64 positives (+64 negatives) per epoch: no ragged tail
+    ds = FakeDataset(ids, s_pairs, t_pairs)
+    cfg = base_config(DEV, embedding_size=16, n_layers=2, reg_weight=1e-3, lambda_source=0.8, lambda_target=0.7, drop_rate=0.0,
+                      connect_way='concat', learning_rate=0.05, train_modes=['BOTH'], epoch_num=['1'], source_split=False, eval_step=0, epochs=1)
+    ev = {'target_user_id': torch.arange(1, 9, device=DEV)}
+    scores = {}
+    for graph in (True, False):
+        torch.manual_seed(4)
+        model = BiTGCF(cfg, ds).to(DEV)
+        dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.POINTWISE, 128, 1, shuffle=False)
+        trainer = CrossDomainTrainer(dict(cfg, graph_step=graph), model)
+        trainer.fit(dl)                                                   # epoch 0 (graph: warm-up + capture + replays)
+        model.eval()
+        first = model.full_sort_predict(ev).clone()                       # fills the cache
+        before = dict(trainer.graph_stats)
+        trainer.fit(dl)                                                   # epoch 1: with graph_step every batch is a replay
+        after = dict(trainer.graph_stats)
+        model.eval()
+        got = model.full_sort_predict(ev).clone()
+        model.init_restore_e()
+        fresh = model.full_sort_predict(ev).clone()
+        assert torch.equal(got, fresh), 'evaluation reused embeddings propagated before the last epoch'
+        assert not torch.allclose(got, first), 'an epoch at lr 0.05 must move the scores'
+        if graph:
+            assert after['replayed'] - before['replayed'] == 6 and after['eager'] == before['eager'], (before, after)
+        scores[graph] = got
+
+
+def test_row_aware_adam_checkpoint_is_the_torch_adam_layout_both_ways():
+    """RowAwareAdam.state_dict() keeps the embedding tables' moments under the standard per-parameter 'state'
+    entries.  A CoNet run checkpointed under the deferred form resumes under DenseAdam (and the reverse) and a further epoch lands on
+    the parameters of the uninterrupted run; torch.optim.Adam loads the same dict too."""
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    from recbole_cdr_amd.trainer import CrossDomainTrainer
+    from recbole_cdr_amd.trainer.trainer import RowAwareAdam, DenseAdam
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset(11)
+    cfg = base_config(DEV, embedding_size=16, reg_weight=0.01, mlp_hidden_size=[32, 16, 8], learning_rate=0.01, train_modes=['BOTH'],
+                      epoch_num=['1'], source_split=False, eval_step=0, epochs=1, graph_step=False)
+
+    def run(first_deferred, second_deferred, resume):
+        torch.manual_seed(6)
+        model = CoNet(cfg, ds).to(DEV)
+        dl = _loaders(ids, ds, s_pairs, t_pairs, InputType.POINTWISE, 128, 1, shuffle=False, seed=3)
+        tr = CrossDomainTrainer(dict(cfg, deferred_adam=first_deferred), model)
+        assert isinstance(tr.optimizer, RowAwareAdam if first_deferred else DenseAdam)
+        tr.fit(dl)
+        if resume:
+            sd_opt, sd_model = tr.optimizer.state_dict(), {k: v.clone() for k, v in model.state_dict().items()}
+            assert 'deferred_rows' not in sd_opt
+            n_params = sum(len(g['params']) for g in sd_opt['param_groups'])
+            assert len(sd_opt['state']) == n_params, 'every parameter (tables included) carries its moments'
+            torch.optim.Adam(CoNet(cfg, ds).to(DEV).parameters()).load_state_dict(sd_opt)       # the reference's optimizer accepts it
+            torch.manual_seed(6)
+            model = CoNet(cfg, ds).to(DEV)
+            model.load_state_dict(sd_model)
+            tr2 = CrossDomainTrainer(dict(cfg, deferred_adam=second_deferred), model)
+            assert isinstance(tr2.optimizer, RowAwareAdam if second_deferred else DenseAdam)
+            tr2.optimizer.load_state_dict(sd_opt)
+            tr = tr2
+        tr.fit(dl)                                              # (shuffle=False + the sampler's counter stream continue: same batches either way)
+        if hasattr(tr.optimizer, 'row_opt'):
+            tr.optimizer.row_opt.flush()
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    want = run(True, True, resume=False)
+    for a, b in ((True, False), (False, True), (True, True)):
+        got = run(a, b, resume=True)
+        for k in want:
+            assert_close(got[k], want[k], rtol=1e-5, atol=1e-7, what=f'{a}->{b}:{k}')
