@@ -82,10 +82,14 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
                 extra['fullsort_items_per_s_' + name.replace('=', '')] = leg['items_per_s']
     lay = result.get('layouts')
     if isinstance(lay, dict):
-        extra['layouts'] = {k: (None if v is None else {'value': v.get('value'), 'ms_per_step': v.get('ms_per_step')}) for k, v in lay.items()}
+        extra['layouts'] = {k: (None if v is None else {'value': v.get('value'), 'ms_per_step': v.get('ms_per_step'),
+                                                        'sharding': _clip(v.get('sharding', ''), 60)}) for k, v in lay.items()}
     lf = result.get('layout_fallback')
     if isinstance(lf, dict):
-        extra['layout'] = {k: lf.get(k) for k in ('chosen', 'ranks_seen') if k in lf}
+        extra['layout_fallback'] = {k: lf.get(k) for k in ('used', 'fell_back', 'ranks_seen') if k in lf}
+    ex = result.get('exchange')
+    if isinstance(ex, dict):
+        extra['exchange'] = {k: v for k, v in ex.items() if isinstance(v, (int, float))}
     legs = result.get('configs')
     if isinstance(legs, dict):
         extra['config_legs_ms_per_step'] = {k: round(v['ms_per_step'], 5) for k, v in legs.items() if isinstance(v, dict) and v.get('ms_per_step')}
@@ -112,13 +116,16 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
     return txt
 
 
-def emit(result, real_stdout=None, detail_dir=None):
+def emit(result, real_stdout=None, detail_dir=None, detail_file=None):
     """Write every leg to bench_detail.json (repo root; also gpurun_out/ when that directory exists, so a gpurun call brings it
-    back) and print the compact line as the LAST line of stdout."""
-    paths = [os.path.join(detail_dir or ROOT, DETAIL_FILE)]
-    go = os.path.join(ROOT, 'gpurun_out')
-    if detail_dir is None and os.path.isdir(go):
-        paths.append(os.path.join(go, DETAIL_FILE))
+    back; `--detail-file PATH` names another place) and print the compact line as the LAST line of stdout."""
+    if detail_file:
+        paths = [os.path.abspath(detail_file)]
+    else:
+        paths = [os.path.join(detail_dir or ROOT, DETAIL_FILE)]
+        go = os.path.join(ROOT, 'gpurun_out')
+        if detail_dir is None and os.path.isdir(go):
+            paths.append(os.path.join(go, DETAIL_FILE))
     for p in paths:
         try:
             with open(p, 'w') as f:
@@ -126,7 +133,7 @@ def emit(result, real_stdout=None, detail_dir=None):
                 f.write('\n')
         except OSError as e:
             print('bench: could not write %s: %r' % (p, e), file=sys.stderr)
-    txt = compact_line(result) + '\n'
+    txt = compact_line(result, detail_file=detail_file or DETAIL_FILE) + '\n'
     if real_stdout is not None:
         os.write(real_stdout, txt.encode())
     else:
@@ -183,6 +190,7 @@ def parse():
     ap.add_argument('--items-per-domain', type=int, default=10_000_000)
     ap.add_argument('--dim', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--detail-file', default=None, help='where every leg of the run is written as JSON (default: bench_detail.json at the repo root)')
     ap.add_argument('--no-fullsort', action='store_true')
     ap.add_argument('--headline-only', action='store_true', help='c5, N=1: the headline step alone (no OVERLAP / per-positive / grid / full-sort / C1-C4 legs, no CPU baseline): the command whose rocprofv3 --stats averages are the headline kernels\' own (profiles/*_headline_kernel_stats.csv)')
     ap.add_argument('--no-config-legs', action='store_true', help='c5, N=1: skip the compact C1-C4 legs (BASELINE configs[0..3]) behind the headline')
@@ -1865,7 +1873,7 @@ def main():
         from recbole_cdr_amd import functional as F_
         result['deterministic_backward'] = bool(F_.deterministic())      # CDR_DETERMINISTIC=1: the drop-in losses' dense gradients without float atomics
         result['bench_wall_s'] = round(time.perf_counter() - T_START, 1)  # the whole invocation, imports and every leg included
-        emit(result, real_stdout)
+        emit(result, real_stdout, detail_file=args.detail_file)
     if world > 1 or args.force_shard:
         import torch.distributed as dist
         stuck = any('still blocked' in str(e) for a in (result.get('layout_fallback') or {}).get('attempts', []) for e in a['errors'].values()) \

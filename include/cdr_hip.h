@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 43
+#define CDR_ABI_VERSION 44
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -568,6 +568,38 @@ int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float* user_tab,
                            float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
                            float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
                            void* sort_ws, size_t sort_ws_bytes);
+
+/* ---- the fused single-occurrence update inside the two multi-GPU layouts (reference math emcdr.py:110-154 on sharded tables:
+ * the reference itself is single-device, parity = the one-GPU result).
+ * DIMENSION shard -- the step cut in two around the all-reduce of the partial scores (cdr_bpr_partial_diff):
+ *   cdr_bpr_step_presort    ids only (runs under the all-reduce): two-table sort + occurrence flags + duplicate-segment heads;
+ *                           *key_base_out = the table bit of the item keys (host value; hand it to cdr_bpr_step_from_diff)
+ *   cdr_bpr_step_from_diff  diff [B + 2] = all-reduced {x_t ..., sum u^2, sum p^2}; every row occurring once in the GLOBAL batch is updated
+ *                           by the pass that re-gathers this rank's column slices, duplicate rows through GU / GP + the segmented apply
+ * buffers (keys, perm [3 B]; flags [4 B] 4-byte aligned; heads cdr_bpr_step_fused_heads_words(B) words) as cdr_bpr_step_fused's. */
+int cdr_bpr_step_presort(cdr_ctx* ctx, void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                         int64_t user_rows, int64_t item_rows, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                         void* sort_ws, size_t sort_ws_bytes, uint32_t* key_base_out);
+int cdr_bpr_step_from_diff(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, float* item_tab,
+                           float* item_m, float* item_v, int Ds, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                           float gamma, float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           int64_t step_user, int64_t step_item, const float* diff, uint32_t key_base, float* out9, float* GU, float* GP,
+                           const uint32_t* keys, const uint32_t* perm, const uint8_t* flags, uint32_t* heads);
+/* ROW shard -- a rank's triples after user-aligned routing: local user rows u_loc, the item rows it asked for in `irows` (one row per
+ * distinct item, indexed by ip / in).
+ *   cdr_batch_norm_sums       sums3 = {0, sum ||U[u]||^2, sum ||irows[ip]||^2}: all-reduce over the ranks, then cdr_loss_finish_sums puts the
+ *                             EmbLoss coefficients of the GLOBAL batch into out9[4..5] BEFORE any row moves
+ *   cdr_bpr_shard_local_step  sort + flags of the local user rows, one forward-and-update pass (user rows occurring once updated in place;
+ *                             GU for duplicate user rows; GP[t] = g_t u_t for every triple, never an item update), segmented apply of
+ *                             the duplicate user rows.  out9[4..5] in; out9[6..8] = this rank's {loss sum, sum u^2, sum p^2} out.
+ *                             B_global: the divisor of the mean (triples of all ranks).  flags [4 Bl] must be zero-initialised once. */
+int cdr_batch_norm_sums(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_rows, int D, const int64_t* uid,
+                        const int64_t* pid, int64_t B, float* sums3);
+int cdr_bpr_shard_local_step(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                             const float* irows, int D, const int64_t* u_loc, const int64_t* ip, const int64_t* in, int64_t Bl,
+                             int64_t B_global, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step_user, float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm,
+                             uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes);
 /* ... and on recbole's pairwise batch layout (S positives tiled k times, k-major negatives: crossdomain_sampler.py:148-152): one
  * lane group per positive, u and p gathered once; uid / pid [S], nid [S k]; the loss, the per-row gradients and the update are
  * those of cdr_bpr_step_fused on the B = S k tiled rows.  GU [S, D]; GI [S + S k, D] (gradient rows of the duplicate item

@@ -605,11 +605,12 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
 // over B = S k rows and the coefficient is handed out pre-multiplied by k, per S-list occurrence)
 // step_dev (optional; the capturable step): {user table's, item table's} update counts in device memory -- advanced here, and the Adam
 // scalars of the new counts left in hp_dev[0..3] = {step_size_u, bc2_sqrt_u, step_size_i, bc2_sqrt_i} for the kernels behind (apply_hp::dev)
+// norms2 (optional): {sum ||u||^2, sum ||p||^2} GIVEN (all-reduced over ranks) instead of summed from `partials`
 __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
                                                              float reg_weight, float* __restrict__ out9, int kmul = 1,
                                                              int64_t* __restrict__ step_u_dev = nullptr, int64_t* __restrict__ step_i_dev = nullptr,
                                                              float* __restrict__ hp_dev = nullptr, float lr = 0.f, float b1 = 0.f, float b2 = 0.f,
-                                                             unsigned* __restrict__ zero4 = nullptr) {
+                                                             unsigned* __restrict__ zero4 = nullptr, const float* __restrict__ norms2 = nullptr) {
     __shared__ double smem[2 * (kBlock / 64)];
     if (zero4 && threadIdx.x >= 64 && threadIdx.x < 68) zero4[threadIdx.x - 64] = 0u;       // the head lists' counters (occ_flags_kernel): no launch of their own
     if (hp_dev && threadIdx.x < 2) {
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __res
     }
     block_sum_d<2>(acc, smem);
     if (threadIdx.x == 0) {
+        if (norms2) { acc[0] = (double)norms2[0]; acc[1] = (double)norms2[1]; }
         const float nu = (float)sqrt((double)kmul * acc[0]), ni = (float)sqrt((double)kmul * acc[1]);
         out9[4] = (reg_weight != 0.f && nu > 0.f) ? (float)kmul * (reg_weight / ((float)B * nu)) : 0.f;
         out9[5] = (reg_weight != 0.f && ni > 0.f) ? (float)kmul * (reg_weight / ((float)B * ni)) : 0.f;
@@ -634,7 +636,8 @@ __global__ __launch_bounds__(kBlock) void coef_finish_kernel(const double* __res
 // loss scalars of the fused step: as step_finish_kernel, but out9[4..5] (the EmbLoss coefficients the kernels used) stay
 __global__ __launch_bounds__(kBlock) void step_finish_keep_kernel(const double* __restrict__ partials, int nblocks, int64_t B,
                                                                   float reg_weight, float* __restrict__ out9,
-                                                                  unsigned* __restrict__ zero_a = nullptr, unsigned* __restrict__ zero_b = nullptr) {
+                                                                  unsigned* __restrict__ zero_a = nullptr, unsigned* __restrict__ zero_b = nullptr,
+                                                                  const float* __restrict__ norms2 = nullptr) {
     __shared__ double smem[3 * (kBlock / 64)];
     // the long-segment counters of the two duplicate-row applies behind this launch (apply_dups_pair): no launches of their own
     if (zero_a && threadIdx.x >= 64 && threadIdx.x < 68) zero_a[threadIdx.x - 64] = 0u;
@@ -646,6 +649,7 @@ __global__ __launch_bounds__(kBlock) void step_finish_keep_kernel(const double* 
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
+        if (norms2) { acc[1] = (double)norms2[0]; acc[2] = (double)norms2[1]; }
         const float main_loss = (float)(acc[0] / (double)B);
         const float nu = (float)sqrt(acc[1]), ni = (float)sqrt(acc[2]);
         out9[1] = main_loss; out9[2] = nu; out9[3] = ni;
@@ -654,13 +658,42 @@ __global__ __launch_bounds__(kBlock) void step_finish_keep_kernel(const double* 
     }
 }
 
-template <int LPR, int OPT, int UN>
+// {0, sum u^2, sum p^2} of batch_norms_kernel's partials as three floats (the row shard all-reduces them before the update)
+__global__ __launch_bounds__(kBlock) void norm_sums_kernel(const double* __restrict__ partials, int nblocks, float* __restrict__ sums3) {
+    __shared__ double smem[2 * (kBlock / 64)];
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1];
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) { sums3[0] = 0.f; sums3[1] = (float)acc[0]; sums3[2] = (float)acc[1]; }
+}
+
+// out9[6..8] = this rank's {loss sum, sum u^2, sum p^2} from the forward's partials; nothing else of out9 moves (row shard: the caller
+// all-reduces the three and finishes the loss with cdr_loss_finish_sums)
+__global__ __launch_bounds__(kBlock) void shard_sums_kernel(const double* __restrict__ partials, int nblocks, float* __restrict__ out9,
+                                                            unsigned* __restrict__ zero_a) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    if (zero_a && threadIdx.x >= 64 && threadIdx.x < 68) zero_a[threadIdx.x - 64] = 0u;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) { out9[6] = (float)acc[0]; out9[7] = (float)acc[1]; out9[8] = (float)acc[2]; }
+}
+
+// XD (round 5, the dimension-sharded step): the triple's score x_t = <u,p> - <u,n> is GIVEN (xdiff[t]: the all-reduced sum of every
+// rank's column-slice partials, cdr_dimshard.hip) instead of being formed from the rows held here; the norm partials are not produced.
+template <int LPR, int OPT, int UN, bool XD = false>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
                                                                const int64_t* __restrict__ pid, const int64_t* __restrict__ nid,
                                                                const uint32_t* __restrict__ flags4, int64_t B, float gamma, float invB,
                                                                const float* __restrict__ coef, apply_hp hu, apply_hp hi,
                                                                float* __restrict__ GU, float* __restrict__ GP,
-                                                               double* __restrict__ partials) {
+                                                               double* __restrict__ partials, const float* __restrict__ xdiff = nullptr) {
     HP_FROM_DEV(hu); HP_FROM_DEV(hi);
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
@@ -677,16 +710,18 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
     // with them, BEFORE this iteration's stores are issued: vmcnt retires in order, so a wait for anything requested after the
     // stores also waits for every store's acknowledgement (the first version of this loop had s_waitcnt vmcnt(0) at its head).
     uint32_t iu[UN], ip[UN], in[UN], fl[UN];
+    float xd[UN];
 #pragma unroll
     for (int r = 0; r < UN; ++r) {
         const int64_t t = gg + (int64_t)r * TG;
         const int64_t tc = t < B ? t : B - 1;
         iu[r] = (uint32_t)uid[tc]; ip[r] = (uint32_t)pid[tc]; in[r] = (uint32_t)nid[tc];
         fl[r] = flags4[tc];
+        xd[r] = XD ? xdiff[tc] : 0.f;
     }
     // (waited for HERE: a wait that the loop header inherits from this prologue is a static s_waitcnt vmcnt(0) on every iteration)
 #pragma unroll
-    for (int r = 0; r < UN; ++r) asm volatile("" : "+v"(iu[r]), "+v"(ip[r]), "+v"(in[r]), "+v"(fl[r]));
+    for (int r = 0; r < UN; ++r) asm volatile("" : "+v"(iu[r]), "+v"(ip[r]), "+v"(in[r]), "+v"(fl[r]), "+v"(xd[r]));
     for (int64_t base = gg; base < B; base += TG * UN) {
         float4 u[UN], p[UN], n[UN], um[UN], uv[UN], pm[UN], pv[UN], nm[UN], nv[UN];
         int64_t ou[UN], op[UN], on[UN];
@@ -708,28 +743,35 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             }
         }
         uint32_t ju[UN], jp[UN], jn[UN], gl[UN];
+        float yd[UN];
 #pragma unroll
         for (int r = 0; r < UN; ++r) {
             const int64_t t = base + (int64_t)(UN + r) * TG;
             const int64_t tc = t < B ? t : B - 1;
             ju[r] = (uint32_t)uid[tc]; jp[r] = (uint32_t)pid[tc]; jn[r] = (uint32_t)nid[tc];
             gl[r] = flags4[tc];
+            yd[r] = XD ? xdiff[tc] : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);                  // keep the requests above the arithmetic (the scheduler sinks them otherwise)
         float gco[UN], sus[UN], sps[UN], lss[UN];
 #pragma unroll
         for (int r = 0; r < UN; ++r) {
-            const float dp = group_sum<LPR>(dot4(u[r], p[r]));
-            const float dn = group_sum<LPR>(dot4(u[r], n[r]));
-            sus[r] = group_sum<LPR>(dot4(u[r], u[r]));
-            sps[r] = group_sum<LPR>(dot4(p[r], p[r]));
-            const float s = sigmoidf_(dp - dn);
+            float x;
+            if (XD) { x = xd[r]; sus[r] = sps[r] = 0.f; }
+            else {
+                const float dp = group_sum<LPR>(dot4(u[r], p[r]));
+                const float dn = group_sum<LPR>(dot4(u[r], n[r]));
+                sus[r] = group_sum<LPR>(dot4(u[r], u[r]));
+                sps[r] = group_sum<LPR>(dot4(p[r], p[r]));
+                x = dp - dn;
+            }
+            const float s = sigmoidf_(x);
             gco[r] = -invB * (s * (1.0f - s)) / (gamma + s);
             lss[r] = -logf(gamma + s);
         }
         // every request of this iteration -- rows AND the next ids -- has returned here; nothing below waits on vmcnt again
 #pragma unroll
-        for (int r = 0; r < UN; ++r) asm volatile("" : "+v"(ju[r]), "+v"(jp[r]), "+v"(jn[r]), "+v"(gl[r]));
+        for (int r = 0; r < UN; ++r) asm volatile("" : "+v"(ju[r]), "+v"(jp[r]), "+v"(jn[r]), "+v"(gl[r]), "+v"(yd[r]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < UN; ++r) {
@@ -760,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             }
         }
 #pragma unroll
-        for (int r = 0; r < UN; ++r) { iu[r] = ju[r]; ip[r] = jp[r]; in[r] = jn[r]; fl[r] = gl[r]; }
+        for (int r = 0; r < UN; ++r) { iu[r] = ju[r]; ip[r] = jp[r]; in[r] = jn[r]; fl[r] = gl[r]; xd[r] = yd[r]; }
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -1425,6 +1467,134 @@ extern "C" int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float
                                keys, perm, flags, heads, sort_ws, sort_ws_bytes);
 }
 
+
+// ---- round 5: the fused single-occurrence update inside the two multi-GPU layouts -----------------------------------
+// DIMENSION shard (cdr_dimshard.hip): the step is cut in two around the all-reduce of the partial scores.
+//   cdr_bpr_step_presort    needs only the ids -> runs under the all-reduce: two-table sort + occurrence flags + duplicate-segment heads
+//   cdr_bpr_step_from_diff  behind the all-reduce: EmbLoss coefficients from the all-reduced norms (diff[B], diff[B+1]), then ONE pass that
+//                           re-gathers the column slices, forms g_t from the GIVEN score diff[t], updates every row that occurs once in
+//                           place and writes gradient rows only for duplicate rows; the duplicate segments are applied as in the one-GPU step.
+extern "C" int cdr_bpr_step_presort(cdr_ctx* ctx, void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t B,
+                                    int64_t user_rows, int64_t item_rows, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                                    void* sort_ws, size_t sort_ws_bytes, uint32_t* key_base_out) {
+    CDR_CHECK_ARG(ctx && uid && pid && nid && keys && perm && flags && heads && sort_ws && key_base_out && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, pid, B, nid, B, item_rows, keys, perm, key_base_out, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    CDR_HIP(cdr_zero_u32(heads, 4, s));                     // the two head lists' counters
+    const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, 4, flags, heads + 4, heads + 4 + (B / 2 + 1), (unsigned*)heads);
+    }
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_step_from_diff(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, float* item_tab,
+                                      float* item_m, float* item_v, int Ds, const int64_t* uid, const int64_t* pid, const int64_t* nid,
+                                      int64_t B, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, int64_t step_user, int64_t step_item, const float* diff, uint32_t key_base,
+                                      float* out9, float* GU, float* GP, const uint32_t* keys, const uint32_t* perm, const uint8_t* flags,
+                                      uint32_t* heads) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && diff && out9 && GU && GP && keys && perm && flags && heads);
+    CDR_CHECK_ARG(Ds > 0 && (Ds & 3) == 0 && Ds <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(Ds);
+    coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, reg_weight, out9, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, diff + B);
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
+    const int grid = grid_for(B, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_APPLY, s);
+#define FA_ARGS TU, TI, Ds, uid, pid, nid, (const uint32_t*)flags, B, gamma, 1.0f / (float)B, out9 + 4, hu, hi, GU, GP, ctx->partials, diff
+        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 0, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+        else { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+#undef FA_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    unsigned* cnt = (unsigned*)heads;
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, B, heads + 4, cnt, GU, B, B, out9 + 4, hu, 0},
+                               {item_tab, item_m, item_v, keys + B, perm + B, 2 * B, heads + 4 + (B / 2 + 1), cnt + 1, GP, B, B, out9 + 5, hi, key_base}};
+    dups_plan pl;
+    int rc = dups_plan_make(ctx, Ds, sides, pl);
+    if (rc) return rc;
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters, diff + B);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, Ds, pl);
+}
+
+// ROW shard (shard.ShardedBPRStep): after user-aligned routing the user rows of a rank's triples are its own, the item rows arrive in a
+// compact buffer (`irows`, one row per distinct item, indexed by ip / in).
+//   cdr_batch_norm_sums       sums3 = {0, sum ||U[u]||^2, sum ||irows[ip]||^2} of the rank's triples -> all-reduced by the caller (the EmbLoss
+//                             coefficients need the GLOBAL norms before any row is updated) -> cdr_loss_finish_sums leaves them in out9[4..5]
+//   cdr_bpr_shard_local_step  sort of the local user rows + flags, then the one-GPU forward-and-update kernel with the item "table" = irows
+//                             and no item row ever flagged: user rows that occur once are updated in place, duplicate user rows go through
+//                             GU and the segmented apply, GP[t] = g_t u_t for EVERY triple (summed per distinct item and sent home by the
+//                             caller: cdr_segsum_rows).  out9[6..8] = this rank's {loss sum, sum u^2, sum p^2}; out9[4..5] untouched.
+extern "C" int cdr_batch_norm_sums(cdr_ctx* ctx, void* stream, const float* user_tab, const float* item_rows, int D, const int64_t* uid,
+                                   const int64_t* pid, int64_t B, float* sums3) {
+    CDR_CHECK_ARG(ctx && user_tab && item_rows && uid && pid && sums3 && D > 0 && (D & 3) == 0 && D <= 256 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+        DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_rows, D, uid, pid, B, ctx->partials));
+    }
+    CDR_LAUNCH_CHECK();
+    norm_sums_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, sums3);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_shard_local_step(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                                        const float* irows, int D, const int64_t* u_loc, const int64_t* ip, const int64_t* in, int64_t Bl,
+                                        int64_t B_global, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps,
+                                        float weight_decay, int64_t step_user, float* out9, float* GU, float* GP, uint32_t* keys,
+                                        uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && irows && u_loc && ip && in && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && Bl > 0 && Bl <= (int64_t)0x7FFFFFFF && B_global >= Bl);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && step_user > 0));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    int rc = cdr_sort_ids(ctx, stream, u_loc, Bl, nullptr, 0, user_rows, keys, perm, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    CDR_HIP(cdr_zero_u32(heads, 4, s));
+    unsigned* cnt = (unsigned*)heads;
+    uint32_t* headsA = heads + 4;
+    uint32_t* headsB = headsA + (Bl / 2 + 1);                       // stays empty: no item row is ever updated here
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(grid_for(Bl, kBlock * kFlagIT)), dim3(kBlock), 0, s>>>(keys, perm, Bl, Bl, 4, flags, headsA, headsB, cnt);
+    }
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(0, lr, beta1, beta2, eps, weight_decay, 1);                // (never used: the p / n flag bytes stay 0)
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{const_cast<float*>(irows), nullptr, nullptr};
+    const int grid = grid_for(Bl, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_APPLY, s);
+#define FA_ARGS TU, TI, D, u_loc, ip, in, (const uint32_t*)flags, Bl, gamma, 1.0f / (float)B_global, out9 + 4, hu, hi, GU, GP, ctx->partials
+        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 0, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+        else { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+#undef FA_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, Bl, headsA, cnt, GU, Bl, Bl, out9 + 4, hu, 0},
+                               {const_cast<float*>(irows), nullptr, nullptr, keys, perm, 0, headsB, cnt + 1, GP, 0, 0, out9 + 5, hi, 0}};
+    dups_plan pl;
+    rc = dups_plan_make(ctx, D, sides, pl);
+    if (rc) return rc;
+    shard_sums_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, out9, pl.side[0].counters);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, D, pl);
+}
 
 // ---- the per-positive (k-major) form: uid / pid [S] (the first S entries of recbole's tiled [S k] columns), nid [S k] k-major
 extern "C" int cdr_bpr_step_fused_kmajor_sizes(int64_t S, int k, int64_t* flag_bytes, int64_t* heads_words) {

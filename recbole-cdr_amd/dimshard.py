@@ -279,7 +279,11 @@ class NativeDimOps:
         from . import binding as B_
         from .fused import FusedBPRStep
         self.B_ = B_
-        self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, fuse_singles=False, **kw)   # the forward is cut in two around the all-reduce
+        # the forward is cut in two around the all-reduce; since round 5 its second half is the one-GPU step's forward-and-update pass
+        # (rows that occur once in the GLOBAL batch are updated by the pass that re-gathers them: cdr_bpr_step_from_diff).
+        # fuse_singles=False (or CDR_FUSE_SINGLES=0) keeps the round-1 form: compact gradient rows for every triple + segmented applies.
+        self.fs = FusedBPRStep(user_cols, item_cols, max_global_batch, fuse_singles=kw.pop('fuse_singles', True), device_counts=False, **kw)
+        self.fused = self.fs.fuse_singles
         self.out = self.fs.out6
 
     def pack_ids(self, a, b, c, out32):
@@ -307,13 +311,30 @@ class NativeDimOps:
 
     def grad_apply(self, uid, pid, nid, diff):
         B_, fs = self.B_, self.fs
+        if self.fused:
+            us, its = fs.ustate, fs.istate
+            us.advance(); its.advance()
+            B_.call('cdr_bpr_step_from_diff', B_.ctx(fs.U.device), B_.stream(), fs.opt, B_.f32(us.table), B_.f32(us.exp_avg), B_.f32(us.exp_avg_sq),
+                    B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq), fs.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(),
+                    float(fs.gamma), float(fs.reg_weight), float(fs.lr), float(fs.betas[0]), float(fs.betas[1]), float(fs.eps), float(fs.wd),
+                    us.step, its.step, B_.f32(diff), int(fs._key_base.value), B_.f32(fs.out6), B_.f32(fs.GU), B_.f32(fs.GP), B_.raw(fs.keys),
+                    B_.raw(fs.perm), B_.raw(fs.flags), B_.raw(fs.heads))
+            return fs.out6
         B_.call('cdr_bpr_grad_from_diff', B_.ctx(fs.U.device), B_.stream(), B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
                 B_.i64(pid), B_.i64(nid), uid.numel(), float(fs.gamma), float(fs.reg_weight), B_.f32(diff), B_.f32(fs.out6),
                 B_.f32(fs.GU), B_.f32(fs.GP))
         return fs.apply_sorted(uid.numel())
 
     def presort(self, uid, pid, nid):
-        """The id sort of the step; needs only the ids, so the step issues it while the partial scores are being all-reduced."""
+        """The id sort of the step (fused form: + the occurrence flags and duplicate-segment heads); needs only the ids, so the step issues
+        it while the partial scores are being all-reduced."""
+        if self.fused:
+            import ctypes
+            B_, fs = self.B_, self.fs
+            B_.call('cdr_bpr_step_presort', B_.ctx(fs.U.device), B_.stream(), B_.i64(uid), B_.i64(pid), B_.i64(nid), uid.numel(), fs.U.shape[0],
+                    fs.I.shape[0], B_.raw(fs.keys), B_.raw(fs.perm), B_.raw(fs.flags), B_.raw(fs.heads), B_.raw(fs.ws), fs.ws_bytes,
+                    ctypes.byref(fs._key_base))
+            return
         self.fs.sort_ids(uid, pid, nid)
 
 

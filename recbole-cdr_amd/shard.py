@@ -151,6 +151,42 @@ class NativeOps:
                     B_.raw(plan['uidx']), plan['n'], B_.f32(G_rows), int(neg_start), D, B_.f32(rows), B_.f32(reg_coef), B_.f32(out))
         return out
 
+    def batch_norms(self, utab, irows, u_loc, ip):
+        """{0, sum ||U[u]||^2, sum ||irows[ip]||^2} of this rank's triples (device [3]): all-reduced, they give the EmbLoss coefficients of
+        the GLOBAL batch before any row is updated."""
+        B_ = self.B_
+        sums = torch.empty(3, device=utab.device, dtype=torch.float32)
+        B_.call('cdr_batch_norm_sums', B_.ctx(self.device), B_.stream(), B_.f32(utab), B_.f32(irows), utab.shape[1], B_.i64(u_loc),
+                B_.i64(ip), u_loc.numel(), B_.f32(sums))
+        return sums
+
+    def local_step(self, utab, ustate, irows, u_loc, ip, in_, B_mean, gamma, reg_weight, opt, hp, step, out):
+        """The requester's half of the row-sharded step on the one-GPU kernels (cdr_bpr_shard_local_step): user rows that occur once are
+        updated by the forward pass itself, duplicate user rows by the segmented apply; returns GP [Bl, D] (g_t u_t per triple) for
+        ``segsum``.  ``out[4:6]`` = the coefficients (in); ``out[6:9]`` = this rank's loss / norm sums (out)."""
+        B_ = self.B_
+        Bl, D, dev = u_loc.numel(), utab.shape[1], utab.device
+        key = ('local', torch.cuda.current_stream().cuda_stream, utab.data_ptr())
+        buf = self._ws.get(key)
+        if buf is None or buf['cap'] < Bl:
+            cap = max(int(Bl * 1.25), 1024)
+            words, need = ctypes.c_int64(0), ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_bpr_step_fused_heads_words(cap, ctypes.byref(words)), 'cdr_bpr_step_fused_heads_words')
+            B_._check(B_.load().cdr_sort_workspace_bytes(cap, utab.shape[0], ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+            buf = self._ws[key] = {
+                'cap': cap, 'GU': torch.empty(cap, D, device=dev, dtype=torch.float32), 'GP': torch.empty(cap, D, device=dev, dtype=torch.float32),
+                'keys': torch.empty(cap, device=dev, dtype=torch.int32), 'perm': torch.empty(cap, device=dev, dtype=torch.int32),
+                'flags': torch.zeros(4 * cap, device=dev, dtype=torch.uint8),        # the item bytes of every group stay 0: no item row is updated here
+                'heads': torch.empty(int(words.value), device=dev, dtype=torch.int32),
+                'ws': torch.empty(int(need.value), device=dev, dtype=torch.uint8)}
+        m, v = ustate if ustate is not None else (None, None)
+        B_.call('cdr_bpr_shard_local_step', B_.ctx(self.device), B_.stream(), opt, B_.f32(utab), B_.f32(m), B_.f32(v), utab.shape[0],
+                B_.f32(irows), D, B_.i64(u_loc), B_.i64(ip), B_.i64(in_), Bl, int(B_mean), float(gamma), float(reg_weight), float(hp['lr']),
+                float(hp['b1']), float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step), B_.f32(out), B_.f32(buf['GU']),
+                B_.f32(buf['GP']), B_.raw(buf['keys']), B_.raw(buf['perm']), B_.raw(buf['flags']), B_.raw(buf['heads']), B_.raw(buf['ws']),
+                buf['ws'].numel())
+        return buf['GP']
+
     def finish_sums(self, sums3, B_mean, reg_weight, out):
         B_ = self.B_
         B_.call('cdr_loss_finish_sums', B_.stream(), B_.f32(sums3), int(B_mean), float(reg_weight), B_.f32(out))
@@ -198,7 +234,7 @@ class ShardedBPRStep:
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
-                 stream=None, user_state=None, item_state=None, dedup=True):
+                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True):
         from .fused import RowwiseState
         self.group = group
         self.world = dist.get_world_size(group)
@@ -219,6 +255,8 @@ class ShardedBPRStep:
         self.out = torch.zeros(12, device=dev, dtype=torch.float32)
         self.stream = stream                      # optional torch.cuda.Stream for pipelined execution
         self.dedup = bool(dedup)                  # request each distinct item row once, return one summed gradient row per item
+        # (with dedup) the requester's half on the one-GPU step's kernels: user rows occurring once updated by the forward pass itself
+        self.fuse_singles = bool(fuse_singles) and self.D % 4 == 0 and self.D <= 256
         self.n_items_total = int(n_items_total)
 
     def loss_value(self):
@@ -351,23 +389,45 @@ class ShardedBPRStep:
             uniq = plan['uniq_local'][:n_uniq] if Bl else torch.empty(0, device=dev, dtype=torch.int64)
             i_req = self._x(uniq, i_send, i_recv, grp)                          # my item rows other ranks want, each once per rank
             irows = self._x(ops.gather_rows(self.I, i_req), i_recv, i_send, grp, (self.D,))
-            GU = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
-            GP = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
-            if Bl:
-                umap = plan['umap']
-                ops.fwd_grad(self.U, irows, u_loc, umap[:Bl].contiguous(), umap[Bl:].contiguous(), B_global, self.gamma,
-                             self.reg_weight, self.out, GU, GP, scatter=False)
-                sums = self.out[6:9].clone()
+            if self.fuse_singles and hasattr(ops, 'local_step'):
+                # round 5: the one-GPU step's forward-and-update pass on the requester's side.  The EmbLoss coefficients need the norms of
+                # the GLOBAL batch before the first row moves: a norms pass over the rows held here + a 12-byte all-reduce come first.
+                if Bl:
+                    umap = plan['umap']
+                    ip, in_ = umap[:Bl].contiguous(), umap[Bl:].contiguous()
+                    norms = ops.batch_norms(self.U, irows, u_loc, ip)
+                else:
+                    norms = torch.zeros(3, device=dev, dtype=torch.float32)
+                dist.all_reduce(norms, group=grp)
+                ops.finish_sums(norms, B_global, self.reg_weight, self.out)          # out[4:6] = the coefficients every rank uses
+                if Bl:
+                    GP = ops.local_step(self.U, self._moments(self.ustate), irows, u_loc, ip, in_, B_global, self.gamma, self.reg_weight,
+                                        self.opt, self.hp, self.ustate.step, self.out)
+                    loss = self.out[6:7].clone()
+                else:
+                    loss = torch.zeros(1, device=dev, dtype=torch.float32)
+                dist.all_reduce(loss, group=grp)
+                norms[0:1] = loss                                                    # {global loss sum, global sum u^2, global sum p^2}
+                ops.finish_sums(norms, B_global, self.reg_weight, self.out)
+                gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq) if Bl else torch.empty(0, self.D, device=dev, dtype=torch.float32)
             else:
-                sums = torch.zeros(3, device=dev, dtype=torch.float32)
-            dist.all_reduce(sums, group=grp)
-            ops.finish_sums(sums, B_global, self.reg_weight, self.out)
-            if Bl:
-                ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,
-                               reg_limit=Bl, reg_coef=self.out[4:5])
-                gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq)
-            else:
-                gi = torch.empty(0, self.D, device=dev, dtype=torch.float32)
+                GU = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
+                GP = torch.empty(max(Bl, 1), self.D, device=dev, dtype=torch.float32)
+                if Bl:
+                    umap = plan['umap']
+                    ops.fwd_grad(self.U, irows, u_loc, umap[:Bl].contiguous(), umap[Bl:].contiguous(), B_global, self.gamma,
+                                 self.reg_weight, self.out, GU, GP, scatter=False)
+                    sums = self.out[6:9].clone()
+                else:
+                    sums = torch.zeros(3, device=dev, dtype=torch.float32)
+                dist.all_reduce(sums, group=grp)
+                ops.finish_sums(sums, B_global, self.reg_weight, self.out)
+                if Bl:
+                    ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,
+                                   reg_limit=Bl, reg_coef=self.out[4:5])
+                    gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq)
+                else:
+                    gi = torch.empty(0, self.D, device=dev, dtype=torch.float32)
             gi_recv = self._x(gi, i_send, i_recv, grp, (self.D,))
             # the EmbLoss term is already inside the rows: the owner just sums what it received per row and applies
             ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step)

@@ -540,8 +540,21 @@ def test_dim_layout_full_size_properties():
     assert abs(float(fp(U) - fp(U2))) <= 1e-6 * abs(float(fp(U2))) + 1e-3 and abs(float(fp(I) - fp(I2))) <= 1e-6 * abs(float(fp(I2))) + 1e-3
 
 
+def _bench_line_and_detail(p, tmp_path):
+    """The LAST stdout line of a bench.py run (the bounded contract line) and the detail record it names (every leg)."""
+    import json
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]
+    assert len(lines[0]) <= 4096
+    line = json.loads(lines[0])
+    full = json.load(open(line['detail_file']))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        assert line[k] == full[k], k
+    return line, full
+
+
 @pytest.mark.parametrize('world,extra', [(2, []), (4, []), (8, []), (2, ['--shard', 'row'])])
-def test_bench_multi_rank_line_contract(world, extra):
+def test_bench_multi_rank_line_contract(world, extra, tmp_path):
     """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one rank per process) -- here with every rank on
     cuda:0 over gloo (CDR_BENCH_SHARED_GPU=1, small tables): stdout is exactly ONE JSON line from rank 0 with the contract's
     keys, the whole-job value, a roofline and an exchange object; the other legs (OVERLAP step, sharded full-sort) ran."""
@@ -555,12 +568,10 @@ def test_bench_multi_rank_line_contract(world, extra):
     env = dict(os.environ, CDR_BENCH_SHARED_GPU='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '2',
-           '--users', '400001', '--items-per-domain', '100000', '--batch', '8192'] + extra
+           '--users', '400001', '--items-per-domain', '100000', '--batch', '8192', '--detail-file', str(tmp_path / 'detail.json')] + extra
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, lines[:5]
-    d = json.loads(lines[0])
+    line, d = _bench_line_and_detail(p, tmp_path)
     assert d['n_gpus'] == world and d['steps'] == 3 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['metric'] == 'training interactions/sec' and d['higher_is_better'] is True and d['dtype'] == 'f32'
     assert 'FUNCTIONAL CHECK ONLY' in d['data'] and 'sharding' in d['config'] and 'cpu_baseline' not in d
@@ -569,6 +580,8 @@ def test_bench_multi_rank_line_contract(world, extra):
     r = d['roofline']
     assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert d['exchange']['bytes_to_other_ranks_per_step_per_rank'] >= 0
+    assert line['exchange']['bytes_to_other_ranks_per_step_per_rank'] == d['exchange']['bytes_to_other_ranks_per_step_per_rank']
+    assert set(line['layouts']) == {'dim', 'row'} and line['roofline']['frac'] == d['roofline']['frac'] and 'cpu_baseline' not in line
     assert 0 < d['final_loss'] < 1 and d['overlap_phase']['loss'] >= 0
     assert d['fullsort']['U=1']['masked_top10']['ms'] > 0 and d['fullsort']['U=1024']['items_per_s'] > 0
     # BOTH layouts of the C5 tables in the one record: north_star's row shard and the dimension shard, each with its
@@ -585,7 +598,7 @@ def test_bench_multi_rank_line_contract(world, extra):
 
 
 @pytest.mark.parametrize('inject,used', [('dim:raise@1', 'row'), ('dim,row:raise@0', 'replicas')])
-def test_bench_multi_rank_layout_fallback(inject, used):
+def test_bench_multi_rank_layout_fallback(inject, used, tmp_path):
     """The first hardware run of `bench.py --gpus N` must not be losable: a layout that fails to come up on some
     rank is abandoned by every rank and the next one is tried (dim -> row), and when none comes up the ranks run independent replicas
     -- ONE JSON line with the contract's keys either way, `layout_fallback` saying what failed where and how many ranks each data group
@@ -600,14 +613,13 @@ def test_bench_multi_rank_layout_fallback(inject, used):
     env = dict(os.environ, CDR_BENCH_SHARED_GPU='1', CDR_PREFLIGHT_FAIL=inject)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--users', '400001',
-           '--items-per-domain', '100000', '--batch', '8192', '--preflight-seconds', '20', '--no-fullsort']
+           '--items-per-domain', '100000', '--batch', '8192', '--preflight-seconds', '20', '--no-fullsort', '--detail-file', str(tmp_path / 'detail.json')]
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, lines[:5]
-    d = json.loads(lines[0])
+    line, d = _bench_line_and_detail(p, tmp_path)
     fb = d['layout_fallback']
     assert fb['used'] == used and fb['fell_back'] is True and fb['attempts'][0]['layout'] == 'dim' and fb['attempts'][0]['ok'] is False
+    assert line['layout_fallback']['used'] == used and line['layout_fallback']['fell_back'] is True      # the line itself says what ran
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['metric'] == 'training interactions/sec'
     B = d['config']['batch_per_domain_per_rank']
     assert abs(d['value'] - 2 * B * 2 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
@@ -618,7 +630,7 @@ def test_bench_multi_rank_layout_fallback(inject, used):
 
 
 @pytest.mark.parametrize('inject,used', [('', 'rowshard'), ('rowshard:raise@1', 'replica-dp'), ('rowshard,replica-dp:raise@0', 'replicas')])
-def test_bench_c4_multi_rank_layout_fallback(inject, used):
+def test_bench_c4_multi_rank_layout_fallback(inject, used, tmp_path):
     """`bench.py --workload c4 --gpus 2` (BASELINE configs[3]: the row-sharded graph) under the same watchdog: rowshard -> replica data
     parallel -> independent replicas of the product's trainer loop; one JSON line either way.  cuda:0 shared over gloo."""
     import json
@@ -631,12 +643,10 @@ def test_bench_c4_multi_rank_layout_fallback(inject, used):
     env = dict(os.environ, CDR_BENCH_SHARED_GPU='1', CDR_PREFLIGHT_FAIL=inject)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--workload', 'c4', '--gpus', '2', '--steps', '4', '--warmup', '1',
-           '--preflight-seconds', '60', '--no-cpu-baseline']
+           '--preflight-seconds', '60', '--no-cpu-baseline', '--detail-file', str(tmp_path / 'detail.json')]
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, lines[:5]
-    d = json.loads(lines[0])
+    line, d = _bench_line_and_detail(p, tmp_path)
     fb = d['layout_fallback']
     assert fb['used'] == used and fb['fell_back'] == (used != 'rowshard') and d['n_gpus'] == 2 and d['value'] > 0 and 0 < d['final_loss'] < 10
     rows = d['config']['rows_per_step']

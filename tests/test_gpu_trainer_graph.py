@@ -559,10 +559,16 @@ def _bench_c3_state(extra=(), env=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--workload', 'c3', '--no-cpu-baseline', '--no-fullsort', '--steps', '40', '--warmup', '4'] + list(extra)
-    p = subprocess.run(cmd, cwd=root, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, 'detail.json')
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--workload', 'c3', '--no-cpu-baseline', '--no-fullsort', '--steps', '40', '--warmup', '4',
+               '--detail-file', detail] + list(extra)
+        p = subprocess.run(cmd, cwd=root, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])          # the bounded contract line ...
+        d = json.load(open(detail))                                                       # ... and every leg, in the file it names
+        assert line['detail_file'] == detail and line['value'] == d['value']
     return d['state_checksum'], d['final_loss'], d['config']['trainer_steps']
 
 
@@ -594,12 +600,15 @@ def test_headline_step_trains_the_same_tables_in_every_process_and_stream_layout
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
+    import tempfile
     for extra in ([], [], ['--single-stream']):
-        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--headline-only', '--steps', '6', '--warmup', '2', '--users', '2000001',
-               '--items-per-domain', '300000', '--batch', '262144'] + extra
-        p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-3000:]
-        d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+        with tempfile.TemporaryDirectory() as tmp:
+            detail = os.path.join(tmp, 'detail.json')
+            cmd = [sys.executable, os.path.join(root, 'bench.py'), '--headline-only', '--steps', '6', '--warmup', '2', '--users', '2000001',
+                   '--items-per-domain', '300000', '--batch', '262144', '--detail-file', detail] + extra
+            p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-3000:]
+            d = json.load(open(detail))
         outs.append((d['state_checksum'], d['final_loss']))
     assert outs[0] == outs[1] == outs[2], outs
     assert len(outs[0][0]) == 4 and all(float(v) == float(v) for v in outs[0][0].values())

@@ -63,6 +63,21 @@ class OracleOps:
         out[7] = (u * u).sum()
         out[8] = (p * p).sum()
 
+    def batch_norms(self, utab, irows, u_loc, ip):
+        u, p = utab[u_loc], irows[ip]
+        return torch.stack([torch.zeros(()), (u * u).sum(), (p * p).sum()])
+
+    def local_step(self, utab, ustate, irows, u_loc, ip, in_, B_mean, gamma, reg_weight, opt, hp, step, out):
+        """shard.NativeOps.local_step in the oracle's arithmetic: forward + compact gradients, the user rows updated here (out[4] = the
+        EmbLoss coefficient of the GLOBAL batch, set by the caller), GP returned for segsum; out[6:9] = this rank's sums."""
+        Bl = u_loc.numel()
+        GU, GP = torch.zeros(Bl, utab.shape[1]), torch.zeros(Bl, utab.shape[1])
+        keep = out[4:6].clone()
+        self.fwd_grad(utab, irows, u_loc, ip, in_, B_mean, gamma, reg_weight, out, GU, GP, scatter=False)
+        out[4:6] = keep
+        self.sort_apply(utab, ustate, u_loc, GU, opt, hp, step, reg_limit=Bl, reg_coef=out[4:5])
+        return GP
+
     def finish_sums(self, sums3, B_mean, reg_weight, out):
         main = sums3[0] / B_mean
         nu, ni = sums3[1].sqrt(), sums3[2].sqrt()
