@@ -80,6 +80,9 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
         for name, leg in fs.items():
             if isinstance(leg, dict) and isinstance(leg.get('items_per_s'), (int, float)):
                 extra['fullsort_items_per_s_' + name.replace('=', '')] = leg['items_per_s']
+    ing = result.get('ingest')
+    if isinstance(ing, dict) and ing.get('value'):
+        extra['ingest_tokens_per_s'] = ing['value']
     lay = result.get('layouts')
     if isinstance(lay, dict):
         extra['layouts'] = {k: (None if v is None else {'value': v.get('value'), 'ms_per_step': v.get('ms_per_step'),
@@ -196,6 +199,8 @@ def parse():
     ap.add_argument('--no-config-legs', action='store_true', help='c5, N=1: skip the compact C1-C4 legs (BASELINE configs[0..3]) behind the headline')
     ap.add_argument('--no-e2e', action='store_true', help='c5, N=1: skip the end-to-end leg (CrossDomainTrainer.fit over SOURCE / TARGET / OVERLAP epochs + evaluate at the headline table sizes)')
     ap.add_argument('--only-e2e', action='store_true', help='c5, N=1: the end-to-end leg alone')
+    ap.add_argument('--no-ingest', action='store_true', help='c5, N=1: skip the ingest leg (overlap id remap of the C5 id space on the device)')
+    ap.add_argument('--only-ingest', action='store_true', help='c5, N=1: the ingest leg alone')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-graph', action='store_true', help='c3/c4: run the step eagerly instead of replaying a hipGraph')
     ap.add_argument('--full-last-layer', action='store_true', help='c4: evaluate every row of the last propagation layer (the reference\'s order) instead of the rows the loss gathers')
@@ -1597,6 +1602,112 @@ def e2e_leg(args, dev):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------ ingest leg
+def synthetic_tokens(n_ids, lo, dev, gen, prefix=b'u'):
+    """Packed tokens (bytes uint8, offsets int64 [n + 1]) of ``prefix`` + the decimal digits of a random permutation of [lo, lo + n_ids),
+    built with torch ops on the device (setup, not timed): mixed lengths, so byte order differs from numeric order ('u10' < 'u2')."""
+    ids = torch.randperm(n_ids, device=dev, generator=gen) + lo
+    p10 = torch.tensor([10 ** k for k in range(9, -1, -1)], device=dev, dtype=torch.int64)         # up to 10 digits
+    nd = torch.ones_like(ids)
+    for k in range(1, 10):
+        nd += (ids >= 10 ** k).to(torch.int64)
+    L = len(prefix)
+    lens = nd + L
+    off = torch.zeros(n_ids + 1, device=dev, dtype=torch.int64)
+    torch.cumsum(lens, 0, out=off[1:])
+    out = torch.empty(int(off[-1]), device=dev, dtype=torch.uint8)
+    step = 1 << 24                                                          # (a [n, 10] digit matrix of 50 M ids in slices)
+    for a in range(0, n_ids, step):
+        b = min(a + step, n_ids)
+        d = ((ids[a:b, None] // p10[None, :]) % 10 + 48).to(torch.uint8)                            # right-aligned digits
+        keep = torch.arange(10, device=dev)[None, :] >= (10 - nd[a:b, None])
+        body = d[keep]                                                                              # row-major: each id's digits in order
+        pos = off[a:b, None] + L + (torch.arange(10, device=dev)[None, :] - (10 - nd[a:b, None]))
+        out[pos[keep]] = body
+        for j, ch in enumerate(prefix):
+            out[off[a:b] + j] = ch
+    return out, off
+
+
+def ingest_leg(args, dev):
+    """The overlap id remap of the C5 id space on the device (csrc/cdr_remap_dev.hip; dataset.py:344-445 + :109-123): the USER field =
+    `--users` tokens per domain, every user in both domains (all overlapped, each domain in its own shuffled order); the ITEM field =
+    `--items-per-domain` tokens per domain, disjoint.  Token bytes and offsets are resident in HBM when the timed region starts, ids
+    come back in HBM.  Beside it on the host cores: the oracle (Python sets + sorted) and the library's single-threaded host form
+    (cdr_overlap_remap) on bounded samples of the same token shape."""
+    from recbole_cdr_amd.data import overlap_remap_packed, overlap_remap
+    from recbole_cdr_amd.data.remap import _pack
+    from recbole_cdr_amd import binding as B_
+    import ctypes
+    import numpy as np
+    gen = torch.Generator(device=dev).manual_seed(2022)
+    nU, nI = int(args.users) - 1, int(args.items_per_domain)
+    out = {'what': 'CrossDomainDataset overlap remap (dataset.py:344-445, :109-123) of one field of both domains: all occurrences radix-sorted '
+                   'together in byte order, runs = distinct tokens, ids from class-wise scans; bit-exact with the host form '
+                   '(tests/test_gpu_remap.py)', 'fields': {}}
+    for name, (ns, nt, lo_s, lo_t) in {'users': (nU, nU, 1, 1), 'items': (nI, nI, 1, 1 + nI)}.items():
+        sb, so = synthetic_tokens(ns, lo_s, dev, gen, b'u' if name == 'users' else b'i')
+        tb, to = synthetic_tokens(nt, lo_t, dev, gen, b'u' if name == 'users' else b'i')
+        torch.cuda.synchronize()
+        overlap_remap_packed((sb[:1000], so[:101], None), (tb[:1000], to[:101], None), dev)         # warm-up: module load
+        torch.cuda.synchronize()
+        best, passes, counts = None, 0, None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sid, tid, counts, passes = overlap_remap_packed((sb, so, None), (tb, to, None), dev)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        c = counts.tolist()
+        ok = (c == [nU + 1, 0, 0, nU + 1]) if name == 'users' else (c == [1, nI, nI, 2 * nI + 1])
+        # property at full size: ids are a bijection onto their range, and byte order of tokens == id order inside a class
+        chk = bool(torch.equal(torch.sort(sid).values, torch.arange(1, ns + 1, device=dev) + (0 if name == 'users' else nI))) if ok else False
+        out['fields'][name] = {'source_tokens': ns, 'target_tokens': nt, 'token_bytes': int(sb.numel() + tb.numel()), 'seconds': best,
+                               'tokens_per_s': (ns + nt) / best, 'radix_passes': passes, 'counts4': c, 'counts_ok': bool(ok), 'ids_are_a_permutation': chk}
+        del sb, so, tb, to, sid, tid
+        torch.cuda.empty_cache()
+    tot = sum(f['source_tokens'] + f['target_tokens'] for f in out['fields'].values())
+    sec = sum(f['seconds'] for f in out['fields'].values())
+    out['value'], out['unit'], out['seconds'] = tot / sec, 'tokens/s', sec
+    if not args.no_cpu_baseline:
+        # host baselines on bounded samples of the same token shape (users: all overlapped, shuffled)
+        rng = np.random.RandomState(2022)
+        def sample(n):
+            a, b = rng.permutation(n) + 1, rng.permutation(n) + 1
+            return np.char.add('u', a.astype(str)).tolist(), np.char.add('u', b.astype(str)).tolist()
+        from oracle import remap as oremap
+        n_or = 1_000_000
+        s, t = sample(n_or)
+        t0 = time.perf_counter()
+        ms, _, mt, _, _ = oremap.overlap_remap(s, ['x'], t, ['y'])
+        a_s, a_t = oremap.apply_remap(s, ms), oremap.apply_remap(t, mt)
+        t_or = time.perf_counter() - t0
+        n_h = 4_000_000
+        s2, t2 = sample(n_h)
+        sbb, soo, snn = _pack(s2); tbb, too, tnn = _pack(t2)
+        sid = np.empty(n_h, np.int64); tid = np.empty(n_h, np.int64); c4 = np.zeros(4, np.int64)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        t0 = time.perf_counter()
+        B_.call('cdr_overlap_remap', sbb, vp(soo), vp(snn), n_h, tbb, vp(too), vp(tnn), n_h, vp(sid), vp(tid), vp(c4))
+        t_h = time.perf_counter() - t0
+        # the same sample through the device form INCLUDING the host-to-device copy of bytes + offsets and the copy of the ids back
+        u8 = lambda b: np.frombuffer(b, np.uint8)
+        t0 = time.perf_counter()
+        ds, dt_, _c, _p = overlap_remap_packed((u8(sbb), soo, None), (u8(tbb), too, None), dev)
+        hs, ht = ds.cpu().numpy(), dt_.cpu().numpy()
+        t_pcie = time.perf_counter() - t0
+        same = bool(np.array_equal(hs, sid) and np.array_equal(ht, tid))
+        out['cpu_baseline'] = {'value': 2 * n_or / t_or, 'unit': 'tokens/s', 'cores': 1, 'kind': 'port',
+                               'sample': '%d + %d user tokens, oracle/remap.py (Python sets, sorted, dict lookups), one thread' % (n_or, n_or)}
+        out['host_form'] = {'value': 2 * n_h / t_h, 'unit': 'tokens/s', 'cores': 1,
+                            'sample': '%d + %d user tokens, cdr_overlap_remap (csrc/cdr_remap.cpp: hash sets + std::sort), one thread' % (n_h, n_h)}
+        out['device_form_from_host_buffers'] = {'value': 2 * n_h / t_pcie, 'unit': 'tokens/s', 'bit_equal_to_host_form': same,
+                                                'sample': '%d + %d tokens, H2D of bytes + offsets and D2H of the ids inside the timed region' % (n_h, n_h)}
+        out['vs_cpu'] = out['value'] / out['cpu_baseline']['value']
+        out['vs_host_form'] = out['value'] / out['host_form']['value']
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------ CoNet full-sort leg
 def conet_fullsort_leg(args, dev):
     """Metric 2 for BASELINE configs[2]: CoNet.full_sort_predict (conet.py:222-242: the target tower, no cross terms, over every
@@ -1764,7 +1875,7 @@ def run_replicas(args, world, rank, dev, attempts):
     import gc
     gc.collect(); torch.cuda.empty_cache()
     a = copy.copy(args)
-    a.no_map = a.no_extra_legs = a.no_fullsort = a.no_config_legs = a.no_cpu_baseline = a.no_e2e = True
+    a.no_map = a.no_extra_legs = a.no_fullsort = a.no_config_legs = a.no_cpu_baseline = a.no_e2e = a.no_ingest = True
     a.force_shard = False
     r = run_c5(a, 1, 0, dev)
     ms = float(ctrl_max(torch.tensor([r['ms_per_step']], dtype=torch.float64)))
@@ -1779,7 +1890,7 @@ def run_replicas(args, world, rank, dev, attempts):
 def main():
     args = parse()
     if args.headline_only:
-        args.no_map = args.no_extra_legs = args.no_fullsort = args.no_config_legs = args.no_cpu_baseline = args.no_e2e = True
+        args.no_map = args.no_extra_legs = args.no_fullsort = args.no_config_legs = args.no_cpu_baseline = args.no_e2e = args.no_ingest = True
     # the contract is ONE JSON line on stdout; RCCL and gloo print banners through C stdio (some only when the process exits),
     # so with a process group everything else written to fd 1 is sent to stderr and the line goes to the saved descriptor
     real_stdout = None
@@ -1792,6 +1903,9 @@ def main():
     import recbole_cdr_amd  # noqa: F401  (raises loudly if libcdrhip.so is missing)
     if args.only_e2e:
         print(json.dumps({'e2e': e2e_leg(args, dev)}), flush=True)
+        return
+    if args.only_ingest:
+        print(json.dumps({'ingest': ingest_leg(args, dev)}), flush=True)
         return
     if args.workload == 'c5' and (world > 1 or args.force_shard) and not args.single_layout:
         # N > 1: BOTH layouts of the C5 tables in one record -- north_star's row shard (rows r % N, row / gradient-row all-to-all)
@@ -1860,6 +1974,15 @@ def main():
         except Exception as e:  # noqa: BLE001
             result.setdefault('leg_errors', {})['e2e'] = repr(e)[:500]
             print('bench: e2e leg failed: %r' % (e,), file=sys.stderr)
+        gc.collect(); torch.cuda.empty_cache()
+    if world == 1 and rank == 0 and args.workload == 'c5' and not args.no_ingest:
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        try:
+            result['ingest'] = ingest_leg(args, dev)
+        except Exception as e:  # noqa: BLE001
+            result.setdefault('leg_errors', {})['ingest'] = repr(e)[:500]
+            print('bench: ingest leg failed: %r' % (e,), file=sys.stderr)
         gc.collect(); torch.cuda.empty_cache()
     if world == 1 and rank == 0 and not args.no_fullsort and args.workload in ('c5', 'c3'):
         try:

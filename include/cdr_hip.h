@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 44
+#define CDR_ABI_VERSION 46
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -513,6 +513,17 @@ int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const float* item
 int cdr_overlap_remap(const char* src_bytes, const int64_t* src_off, const uint8_t* src_isnan, int64_t n_src,
                       const char* tgt_bytes, const int64_t* tgt_off, const uint8_t* tgt_isnan, int64_t n_tgt,
                       int64_t* src_ids, int64_t* tgt_ids, int64_t* counts4);
+/* The same remap ON THE DEVICE, for fields of 10^7..10^9 token occurrences (dataset.py:344-445 + :109-123 as above, bit-exact
+ * with cdr_overlap_remap): all occurrences of both domains are sorted together in byte order by K + 1 stable radix sorts (K = ceil(longest
+ * token / 8)), a run of equal tokens is one distinct token, its class the OR of its occurrences' domains, its id the class base + the number
+ * of runs of the same class before it.  Every pointer is DEVICE memory (bytes uint8, offsets int64 [n + 1], isnan uint8 [n] or NULL);
+ * ids come back as int64 per occurrence (-1 for NaN), counts4 = {OV (PAD counted), source-only, target-only, total} on the device.
+ * workspace: cdr_overlap_remap_dev_workspace_bytes(n_src, n_tgt), 256-byte aligned.  n_src + n_tgt < 2^32 - 1.  One host wait inside
+ * (token count and longest token decide the number of passes; *passes_out, optional, reports it): not capturable, ingest runs once. */
+int cdr_overlap_remap_dev_workspace_bytes(int64_t n_src, int64_t n_tgt, size_t* bytes);
+int cdr_overlap_remap_dev(void* stream, const uint8_t* src_bytes, const int64_t* src_off, const uint8_t* src_isnan, int64_t n_src,
+                          const uint8_t* tgt_bytes, const int64_t* tgt_off, const uint8_t* tgt_isnan, int64_t n_tgt, int64_t* src_ids,
+                          int64_t* tgt_ids, int64_t* counts4, void* workspace, size_t workspace_bytes, int64_t* passes_out);
 int cdr_revoke_map(void* stream, const int64_t* ids, int64_t n, int64_t overlap_item_num,
                    int64_t target_only_item_num, int64_t* out);
 
@@ -557,7 +568,12 @@ int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, flo
                        const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item, float* out9,
                        float* GU /* [B,D] */, float* GP /* [B,D] */, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                       void* sort_ws, size_t sort_ws_bytes);
+                       void* sort_ws, size_t sort_ws_bytes, float* user_n2 /* [user_rows] or NULL */, float* item_n2 /* [item_rows] or NULL */);
+/* user_n2 / item_n2 (both or neither): the tables' squared-row-norm caches, n2[r] = sum of squares of row r as cdr_row_norms2 fills them.
+ * With them the EmbLoss norms of the batch (emcdr.py:129-131, recbole EmbLoss) are summed from 8 bytes per triple instead of a second
+ * gather of two rows, and every row the step stores gets its new entry -- the caller must refill (cdr_row_norms2) after anything ELSE
+ * has written the tables. */
+int cdr_row_norms2(void* stream, const float* table, int64_t rows, int D, float* n2);
 /* The same step (Adam) with the tables' update counts in DEVICE memory: *step_user_dev / *step_item_dev hold the counts BEFORE the call
  * and are advanced by it; hp_dev: 4 floats of caller-owned device scratch for the Adam scalars derived from them.  Nothing about the update
  * number is baked into the launches: the call can be captured in a hipGraph and replayed (emcdr.py:110-154 under recbole's step loop,
@@ -567,7 +583,7 @@ int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float* user_tab,
                            const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
                            float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                           void* sort_ws, size_t sort_ws_bytes);
+                           void* sort_ws, size_t sort_ws_bytes, float* user_n2, float* item_n2);
 
 /* ---- the fused single-occurrence update inside the two multi-GPU layouts (reference math emcdr.py:110-154 on sharded tables:
  * the reference itself is single-device, parity = the one-GPU result).

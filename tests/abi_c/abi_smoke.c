@@ -71,6 +71,7 @@ int main(void) {
     CHECK_HIP(hipMemcpy(du, u, 8 * B, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dp_, p, 8 * B, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dn_, n, 8 * B, hipMemcpyHostToDevice)); CHECK_HIP(hipMemset(dOut, 0, sizeof(float) * 16));
     cdr_ctx* ctx = NULL;
+    fprintf(stderr, "abi_smoke: stage ctx\n"); fflush(stderr);
     CHECK_CDR(cdr_ctx_create(0, &ctx));
     float out[16];
     int ok = 1;
@@ -91,6 +92,7 @@ int main(void) {
         }
 
     size_t ws_bytes = 0;
+    fprintf(stderr, "abi_smoke: stage two-pass step\n"); fflush(stderr);
     CHECK_CDR(cdr_sort_workspace_bytes(3 * B, 2048, &ws_bytes));            /* keys < 2 * 2^ceil(log2(max rows)) = 1024 */
     CHECK_HIP(hipMalloc(&dWs, ws_bytes));
     uint32_t key_base = 0;
@@ -115,6 +117,7 @@ int main(void) {
     CHECK_HIP(hipMemcpy(dU2, U, sizeof(float) * NU * D, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dI2, I, sizeof(float) * NI * D, hipMemcpyHostToDevice));
     CHECK_HIP(hipMalloc((void**)&dDiff, sizeof(float) * (B + 2))); CHECK_HIP(hipMalloc((void**)&dIds32, 4 * 3 * B));
     CHECK_HIP(hipMalloc((void**)&dIds64, 8 * 3 * B)); CHECK_HIP(hipMalloc((void**)&dBad, 4)); CHECK_HIP(hipMemset(dBad, 0, 4));
+    fprintf(stderr, "abi_smoke: stage dimension layout\n"); fflush(stderr);
     CHECK_CDR(cdr_ids_pack32(NULL, du, dp_, dn_, NULL, B, dIds32, dBad));
     /* ncclAllGather(dIds32 -> [G][3][B]) would go here; G = 1 */
     CHECK_CDR(cdr_ids_unpack32(NULL, dIds32, 1, B, dIds64, NULL));
@@ -140,10 +143,11 @@ int main(void) {
         float *dU3, *dI3; uint8_t* dFlags; uint32_t* dHeads; int64_t words = 0;
         CHECK_HIP(hipMalloc((void**)&dU3, sizeof(float) * NU * D)); CHECK_HIP(hipMalloc((void**)&dI3, sizeof(float) * NI * D));
         CHECK_HIP(hipMemcpy(dU3, U, sizeof(float) * NU * D, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dI3, I, sizeof(float) * NI * D, hipMemcpyHostToDevice));
+        fprintf(stderr, "abi_smoke: stage one-call fused step\n"); fflush(stderr);
         CHECK_CDR(cdr_bpr_step_fused_heads_words(B, &words));
         CHECK_HIP(hipMalloc((void**)&dFlags, 4 * B)); CHECK_HIP(hipMalloc((void**)&dHeads, 4 * (size_t)words));
         CHECK_CDR(cdr_bpr_step_fused(ctx, NULL, CDR_OPT_SGD, dU3, NULL, NULL, NU, dI3, NULL, NULL, NI, D, du, dp_, dn_, B, gamma, reg, lr, 0.9f,
-                                     0.999f, 1e-8f, 0.f, 1, 1, dOut, dGU, dGP, dKeys, dPerm, dFlags, dHeads, dWs, ws_bytes));
+                                     0.999f, 1e-8f, 0.f, 1, 1, dOut, dGU, dGP, dKeys, dPerm, dFlags, dHeads, dWs, ws_bytes, NULL, NULL));
         CHECK_HIP(hipDeviceSynchronize());
         CHECK_HIP(hipMemcpy(out, dOut, sizeof(float) * 6, hipMemcpyDeviceToHost));
         ok &= close_enough(out[0], total, 0, "one-call fused step loss");
@@ -154,12 +158,15 @@ int main(void) {
     /* ---- family (10): the exchanges of the multi-GPU path from a host without torch -- a one-rank communicator (RCCL from the loader path) ---- */
     {
         unsigned char id[CDR_COMM_ID_BYTES];
+        fprintf(stderr, "abi_smoke: stage comm family (RCCL)\n"); fflush(stderr);
         int rc = cdr_comm_unique_id(id);
         if (rc == CDR_ENODEV) printf("abi_smoke: librccl not loadable here, comm family skipped (%s)\n", cdr_last_error());
         else {
             cdr_comm* comm = NULL; int rank = -1, world = -1;
             ok &= rc == 0;
+            fprintf(stderr, "abi_smoke: stage comm init\n"); fflush(stderr);
             CHECK_CDR(cdr_comm_init(&comm, 0, 1, id));
+            fprintf(stderr, "abi_smoke: stage comm exchanges\n"); fflush(stderr);
             CHECK_CDR(cdr_comm_info(comm, &rank, &world));
             ok &= rank == 0 && world == 1;
             const int64_t nrows[1] = {B};

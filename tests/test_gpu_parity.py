@@ -2782,7 +2782,12 @@ def test_plain_c_consumer_of_the_abi():
     exe = os.path.join(root, 'tests', 'abi_c', 'abi_smoke')
     if not os.path.isfile(exe):
         subprocess.run(['make', '-C', os.path.dirname(exe)], check=True)
-    r = subprocess.run([exe], capture_output=True, timeout=120)
+    # (RCCL's bootstrap of the one-rank communicator picks a network interface: pin it to loopback -- a fresh box's hostname may not resolve)
+    env = dict(os.environ, NCCL_SOCKET_IFNAME='lo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    try:
+        r = subprocess.run([exe], capture_output=True, timeout=180, env=env)
+    except subprocess.TimeoutExpired as e:                         # say WHERE it stood still: the program prints a line per stage
+        raise AssertionError('abi_smoke timed out; stderr so far: %r' % ((e.stderr or b'').decode()[-600:],))
     assert r.returncode == 0, (r.stdout.decode(), r.stderr.decode())
     assert b'abi_smoke: OK' in r.stdout
 
