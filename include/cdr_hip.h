@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 46
+#define CDR_ABI_VERSION 47
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -568,12 +568,7 @@ int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, flo
                        const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item, float* out9,
                        float* GU /* [B,D] */, float* GP /* [B,D] */, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                       void* sort_ws, size_t sort_ws_bytes, float* user_n2 /* [user_rows] or NULL */, float* item_n2 /* [item_rows] or NULL */);
-/* user_n2 / item_n2 (both or neither): the tables' squared-row-norm caches, n2[r] = sum of squares of row r as cdr_row_norms2 fills them.
- * With them the EmbLoss norms of the batch (emcdr.py:129-131, recbole EmbLoss) are summed from 8 bytes per triple instead of a second
- * gather of two rows, and every row the step stores gets its new entry -- the caller must refill (cdr_row_norms2) after anything ELSE
- * has written the tables. */
-int cdr_row_norms2(void* stream, const float* table, int64_t rows, int D, float* n2);
+                       void* sort_ws, size_t sort_ws_bytes);
 /* The same step (Adam) with the tables' update counts in DEVICE memory: *step_user_dev / *step_item_dev hold the counts BEFORE the call
  * and are advanced by it; hp_dev: 4 floats of caller-owned device scratch for the Adam scalars derived from them.  Nothing about the update
  * number is baked into the launches: the call can be captured in a hipGraph and replayed (emcdr.py:110-154 under recbole's step loop,
@@ -583,7 +578,7 @@ int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float* user_tab,
                            const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
                            float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                           void* sort_ws, size_t sort_ws_bytes, float* user_n2, float* item_n2);
+                           void* sort_ws, size_t sort_ws_bytes);
 
 /* ---- the fused single-occurrence update inside the two multi-GPU layouts (reference math emcdr.py:110-154 on sharded tables:
  * the reference itself is single-device, parity = the one-GPU result).

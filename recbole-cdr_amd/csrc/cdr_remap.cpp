@@ -7,6 +7,7 @@
 //                      iid < OI ? iid : iid - num_target_only_item   (device kernel, int64)
 // cdr_overlap_remap is host code (strings); nothing here touches the GPU except cdr_revoke_map.
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -48,15 +49,17 @@ extern "C" int cdr_overlap_remap(const char* src_bytes, const int64_t* src_off, 
     const Side S = make_side(src_bytes, src_off, src_isnan, n_src);
     const Side T = make_side(tgt_bytes, tgt_off, tgt_isnan, n_tgt);
     std::unordered_set<std::string_view> sset, tset;
+    sset.reserve((size_t)n_src); tset.reserve((size_t)n_tgt);
     for (auto& t : S.tok) if (t.data()) sset.insert(t);
     for (auto& t : T.tok) if (t.data()) tset.insert(t);
     std::vector<std::string_view> overlap, s_only, t_only;
     for (auto& t : sset) (tset.count(t) ? overlap : s_only).push_back(t);
     for (auto& t : tset) if (!sset.count(t)) t_only.push_back(t);
     // Python's str ordering is code-point order; for valid UTF-8 that equals unsigned byte order
-    auto lt = [](std::string_view a, std::string_view b) {
-        return std::lexicographical_compare(a.begin(), a.end(), b.begin(), b.end(),
-                                            [](char x, char y) { return (unsigned char)x < (unsigned char)y; });
+    auto lt = [](std::string_view a, std::string_view b) {                 // memcmp compares as unsigned char
+        const size_t m = a.size() < b.size() ? a.size() : b.size();
+        const int c = m ? memcmp(a.data(), b.data(), m) : 0;
+        return c != 0 ? c < 0 : a.size() < b.size();
     };
     std::sort(overlap.begin(), overlap.end(), lt);
     std::sort(s_only.begin(), s_only.end(), lt);

@@ -244,8 +244,8 @@ struct apply_hp { float lr, b1, b2, eps, wd, step_size, bc2_sqrt; const float* d
 #define HP_FROM_DEV(h) do { if ((h).dev) { (h).step_size = (h).dev[0]; (h).bc2_sqrt = (h).dev[1]; } } while (0)
 
 template <int OPT>
-__device__ __forceinline__ float4 apply_update(float* __restrict__ wp, float* __restrict__ mp, float* __restrict__ vp, float4 w,
-                                               float4 acc, float rc, const apply_hp& h) {
+__device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __restrict__ mp, float* __restrict__ vp, float4 w,
+                                             float4 acc, float rc, const apply_hp& h) {
     float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
     float4 wn;
     if (OPT == 0) {
@@ -263,7 +263,6 @@ __device__ __forceinline__ float4 apply_update(float* __restrict__ wp, float* __
                          w.z - cdr_adam_term(m.z, v.z, h.step_size, h.bc2_sqrt, h.eps), w.w - cdr_adam_term(m.w, v.w, h.step_size, h.bc2_sqrt, h.eps));
     }
     st4(wp, wn);
-    return wn;
 }
 
 template <int LPR, int OPT, bool SIGNED>
@@ -396,8 +395,7 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
                                                      const float* __restrict__ reg_coef, apply_hp hp,
                                                      const unsigned* __restrict__ counters,
                                                      const seg_long* __restrict__ longs,
-                                                     const float* __restrict__ partial, const int* __restrict__ pcnt,
-                                                     float* __restrict__ N2 = nullptr) {
+                                                     const float* __restrict__ partial, const int* __restrict__ pcnt) {
     HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     const int sub = threadIdx.x % LPR;
@@ -410,7 +408,6 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
         const seg_long sg = longs[li];
         const uint32_t row = keys[sg.head];
         const int64_t np = (sg.len + kPiece - 1) / kPiece;
-        float sq = 0.f;
         for (int ch = sub; ch < D4; ch += LPR) {
             float* wp = W + (int64_t)row * D + 4 * ch;
             const float4 w = ld4(wp);
@@ -421,13 +418,8 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
                 acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                 cnt += pcnt[sg.base + k];
             }
-            const float4 wn = apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
-                                                w, acc, c * (float)cnt, hp);
-            sq += dot4(wn, wn);
-        }
-        if (N2) {                                                  // (one chunk per lane, D <= 4 LPR: the same sum batch_norms_kernel forms)
-            const float s2 = group_sum<LPR>(sq);
-            if (sub == 0) N2[row] = s2;
+            apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
+                              w, acc, c * (float)cnt, hp);
         }
     }
 }
@@ -479,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void make_keys2_kernel(const int64_t* __res
 //
 // Same arithmetic per row as cdr_bpr_fwd_grad + cdr_rowwise_apply (one occurrence: 0 + g, then the same update), fixed order
 // everywhere: bit-reproducible.  Bytes per triple at D = 128, uniform ids: ~9.5 KB against 12.9 KB before (SURVEY 8d floor 9.2 KB).
-struct tab_ptrs { float* W; float* M; float* V; float* N2; };      // N2 (optional): the table's squared-row-norm cache, kept current by every store of a row
+struct tab_ptrs { float* W; float* M; float* V; };
 
 template <int OPT>
 __device__ __forceinline__ float4 upd_math(float4 w, float4& m, float4& v, float4 acc, float rc, const apply_hp& h) {
@@ -532,37 +524,6 @@ __global__ __launch_bounds__(kBlock) void batch_norms_kernel(const float* __rest
     if (threadIdx.x == 0) {
         double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
         o[0] = acc[0]; o[1] = acc[1];
-    }
-}
-
-// The same two sums from the tables' squared-row-norm caches (n2[r] = group_sum(dot4(row, row)), the float batch_norms_kernel forms per
-// row, kept current by every kernel of the fused step that stores a row): 8 bytes per triple instead of two rows (1,024 B at D = 128).
-__global__ __launch_bounds__(kBlock) void batch_norms_cached_kernel(const float* __restrict__ n2u, const float* __restrict__ n2i,
-                                                                    const int64_t* __restrict__ uid, const int64_t* __restrict__ pid, int64_t B,
-                                                                    double* __restrict__ partials) {
-    __shared__ double smem[2 * (kBlock / 64)];
-    double acc[2] = {0.0, 0.0};
-    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < B; t += (int64_t)gridDim.x * kBlock) {
-        acc[0] += (double)n2u[uid[t]];
-        acc[1] += (double)n2i[pid[t]];
-    }
-    block_sum_d<2>(acc, smem);
-    if (threadIdx.x == 0) {
-        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
-        o[0] = acc[0]; o[1] = acc[1];
-    }
-}
-
-// n2[r] = squared norm of row r, for every row of a table (the cache's first fill: one streaming pass)
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void row_norms2_kernel(const float* __restrict__ W, int64_t rows, int D, float* __restrict__ n2) {
-    constexpr int GPB = kBlock / LPR;
-    const int sub = threadIdx.x % LPR;
-    const bool live = sub < (D >> 2);
-    for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += (int64_t)gridDim.x * GPB) {
-        const float4 w = live ? ld4(W + r * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float s2 = group_sum<LPR>(dot4(w, w));
-        if (sub == 0) n2[r] = s2;
     }
 }
 
@@ -823,18 +784,15 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             if (fu[r]) {
                 const float4 wu = upd_math<OPT>(u[r], um[r], uv[r], gu, cu, hu);
                 if (live) { if (OPT == 1) { st4(TU.M + ou[r], um[r]); st4(TU.V + ou[r], uv[r]); } st4(TU.W + ou[r], wu); }
-                if (TU.N2) { const float s2 = group_sum<LPR>(dot4(wu, wu)); if (sub == 0) TU.N2[iu[r]] = s2; }
             } else if (ok) st4(GU + t * D + 4 * sub, gu);
             // ---- positive item row (EmbLoss occurrence), negative item row (gradient -g u, no EmbLoss)
             if (fp[r]) {
                 const float4 wp = upd_math<OPT>(p[r], pm[r], pv[r], gi, ci, hi);
                 if (live) { if (OPT == 1) { st4(TI.M + op[r], pm[r]); st4(TI.V + op[r], pv[r]); } st4(TI.W + op[r], wp); }
-                if (TI.N2) { const float s2 = group_sum<LPR>(dot4(wp, wp)); if (sub == 0) TI.N2[ip[r]] = s2; }
             }
             if (fn[r]) {
                 const float4 wn = upd_math<OPT>(n[r], nm[r], nv[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w), 0.f, hi);
                 if (live) { if (OPT == 1) { st4(TI.M + on[r], nm[r]); st4(TI.V + on[r], nv[r]); } st4(TI.W + on[r], wn); }
-                if (TI.N2) { const float s2 = group_sum<LPR>(dot4(wn, wn)); if (sub == 0) TI.N2[in[r]] = s2; }
             }
             if (ok && !(fp[r] && fn[r])) st4(GP + t * D + 4 * sub, gi);
             if (t < B && sub == 0) {
@@ -961,7 +919,7 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
                                                         const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
                                                         const float* __restrict__ reg_coef, apply_hp hp,
                                                         unsigned* __restrict__ counters, seg_long* __restrict__ longs,
-                                                        seg_piece* __restrict__ pieces, float* __restrict__ N2 = nullptr) {
+                                                        seg_piece* __restrict__ pieces) {
     HP_FROM_DEV(hp);
     constexpr int GPB = kBlock / LPR;
     constexpr int SU = 4;                                 // segments in flight per lane group
@@ -1038,7 +996,6 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
                     if (OPT == 1) { st4(Mo + off[j], m[j]); st4(Vo + off[j], v[j]); }
                     st4(W + off[j], wn);
                 }
-                if (N2) { const float s2 = group_sum<LPR>(dot4(wn, wn)); if (sub == 0) N2[row[j]] = s2; }       // (non-live lanes hold zeros)
             }
         }
     } else {
@@ -1100,13 +1057,12 @@ struct dup_side {
     float* W; float* M; float* V; const uint32_t* keys; const uint32_t* perm; int64_t n; const uint32_t* heads; const unsigned* nheads;
     const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp;
     unsigned* counters; seg_long* longs; seg_piece* pieces; int* pcnt; float* partial;
-    float* N2;                                  // optional squared-row-norm cache of the table (moved back by key_base rows like W)
 };
 template <int LPR, int OPT>
 __global__ __launch_bounds__(kBlock) void rowwise_apply_dups2_kernel(int D, dup_side a, dup_side b) {
     const dup_side& t = blockIdx.y ? b : a;
     rowwise_apply_dups_body<LPR, OPT, true>(t.W, t.M, t.V, D, t.keys, t.perm, t.n, t.heads, t.nheads, t.G, t.neg_start, t.reg_limit, t.reg_coef, t.hp,
-                                            t.counters, t.longs, t.pieces, t.N2);
+                                            t.counters, t.longs, t.pieces);
 }
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void seg_piece_sum2_kernel(int D, dup_side a, dup_side b) {
@@ -1118,7 +1074,7 @@ template <int LPR, int OPT>
 __global__ __launch_bounds__(kBlock) void seg_long_finish2_kernel(int D, dup_side a, dup_side b) {
     const dup_side& t = blockIdx.y ? b : a;
     if (t.counters == nullptr) return;
-    seg_long_finish_body<LPR, OPT>(t.W, t.M, t.V, D, t.keys, t.reg_coef, t.hp, t.counters, t.longs, t.partial, t.pcnt, t.N2);
+    seg_long_finish_body<LPR, OPT>(t.W, t.M, t.V, D, t.keys, t.reg_coef, t.hp, t.counters, t.longs, t.partial, t.pcnt);
 }
 
 }  // namespace
@@ -1337,7 +1293,7 @@ namespace {
 // Both tables' duplicate-row applies of a fused step: one scratch request carved for the two sides, three launches with blockIdx.y =
 // side instead of six (+ two counter clears, which the caller folds into step_finish_keep_kernel: dups_plan first, then that launch).
 struct dup_host { float* table; float* m; float* v; const uint32_t* keys; const uint32_t* perm; int64_t n; const uint32_t* heads; const unsigned* nheads;
-                  const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp; uint32_t key_base; float* n2; };
+                  const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp; uint32_t key_base; };
 struct dups_plan { dup_side side[2]; int64_t long_cap[2], piece_cap[2]; };
 
 static int dups_plan_make(cdr_ctx* ctx, int D, const dup_host (&h)[2], dups_plan& pl) {
@@ -1369,7 +1325,6 @@ static int dups_plan_make(cdr_ctx* ctx, int D, const dup_host (&h)[2], dups_plan
         t.keys = h[i].keys; t.perm = h[i].perm; t.n = h[i].n; t.heads = h[i].heads; t.nheads = h[i].nheads; t.G = h[i].G;
         t.neg_start = h[i].neg_start; t.reg_limit = h[i].reg_limit; t.reg_coef = h[i].reg_coef; t.hp = h[i].hp;
         t.counters = nullptr; t.longs = nullptr; t.pieces = nullptr; t.pcnt = nullptr; t.partial = nullptr;
-        t.N2 = h[i].n2 ? h[i].n2 - (int64_t)h[i].key_base : nullptr;
         if (pl.long_cap[i]) {
             t.counters = (unsigned*)(base + off[i][0]); t.longs = (seg_long*)(base + off[i][1]); t.pieces = (seg_piece*)(base + off[i][2]);
             t.pcnt = (int*)(base + off[i][3]); t.partial = (float*)(base + off[i][4]);
@@ -1424,19 +1379,15 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
                                float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
                                int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
                                float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                               void* sort_ws, size_t sort_ws_bytes, float* user_n2 = nullptr, float* item_n2 = nullptr) {
+                               void* sort_ws, size_t sort_ws_bytes) {
     hipStream_t s = (hipStream_t)stream;
     const int lpr = cdr_lpr_for(D);
     // ---- EmbLoss coefficients first (they do not need the sort): out9[4], out9[5]  (+ the device-resident update counts, when given)
-    // user_n2 / item_n2 (round 5): the tables' squared-row-norm caches -- the norms pass then reads 8 B per triple instead of two rows
-    // (1.07 GB of the 11.2 GB a C5 domain step moved), and every kernel below that stores a row stores its new squared norm too
     if (reg_weight != 0.f) {
-        const bool cached = user_n2 && item_n2;
-        const int ngrid = cached ? grid_for(B, kBlock * 4) : grid_for((B + 7) / 8, kBlock / lpr);
+        const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
         {
             cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
-            if (cached) batch_norms_cached_kernel<<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_n2, item_n2, uid, pid, B, ctx->partials);
-            else { DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, B, ctx->partials)); }
+            DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, B, ctx->partials));
         }
         CDR_LAUNCH_CHECK();
         coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, 1, step_user_dev, step_item_dev, hp_dev, lr, beta1, beta2,
@@ -1461,7 +1412,7 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
     apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
     apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
     if (hp_dev && opt == 1) { hu.dev = hp_dev; hi.dev = hp_dev + 2; }          // the scalars coef_finish_kernel left on the device
-    const tab_ptrs TU{user_tab, user_m, user_v, user_n2}, TI{item_tab, item_m, item_v, item_n2};
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
     static const int un = [] { const char* e = getenv("CDR_FWD_APPLY_UN"); return (e && e[0] == '2') ? 2 : 1; }();   // A/B switch (tools/)
     const int grid = grid_for((B + un - 1) / un, kBlock / lpr);
     {
@@ -1473,8 +1424,8 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
 #undef FA_ARGS
     }
     CDR_LAUNCH_CHECK();
-    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0, user_n2},
-                               {item_tab, item_m, item_v, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base, item_n2}};
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0},
+                               {item_tab, item_m, item_v, keys + B, perm + B, 2 * B, headsB, cnt + 1, GP, B, B, out9 + 5, hi, key_base}};
     dups_plan pl;
     rc = dups_plan_make(ctx, D, sides, pl);
     if (rc) return rc;
@@ -1488,14 +1439,14 @@ extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* us
                                   const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
                                   float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
                                   float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
-                                  void* sort_ws, size_t sort_ws_bytes, float* user_n2, float* item_n2) {
+                                  void* sort_ws, size_t sort_ws_bytes) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
     CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
-    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0 && (user_n2 != nullptr) == (item_n2 != nullptr));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
     return bpr_step_fused_impl(ctx, stream, opt, user_tab, user_m, user_v, user_rows, item_tab, item_m, item_v, item_rows, D, uid, pid, nid, B, gamma,
                                reg_weight, lr, beta1, beta2, eps, weight_decay, step_user, step_item, nullptr, nullptr, nullptr, out9, GU, GP,
-                               keys, perm, flags, heads, sort_ws, sort_ws_bytes, user_n2, item_n2);
+                               keys, perm, flags, heads, sort_ws, sort_ws_bytes);
 }
 
 // The same step with the tables' update counts in DEVICE memory (int64 each, advanced by the call's first finishing block) and the Adam
@@ -1506,26 +1457,16 @@ extern "C" int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float
                                       const int64_t* pid, const int64_t* nid, int64_t B, float gamma, float reg_weight, float lr,
                                       float beta1, float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev,
                                       float* hp_dev, float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags,
-                                      uint32_t* heads, void* sort_ws, size_t sort_ws_bytes, float* user_n2, float* item_n2) {
+                                      uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && out9 && GU && GP && keys && perm && flags && heads && sort_ws);
     CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
     CDR_CHECK_ARG(opt == 1 && user_m && user_v && item_m && item_v && step_user_dev && step_item_dev && hp_dev);
-    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0 && (user_n2 != nullptr) == (item_n2 != nullptr));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
     return bpr_step_fused_impl(ctx, stream, opt, user_tab, user_m, user_v, user_rows, item_tab, item_m, item_v, item_rows, D, uid, pid, nid, B, gamma,
                                reg_weight, lr, beta1, beta2, eps, weight_decay, 1, 1, step_user_dev, step_item_dev, hp_dev, out9, GU, GP,
-                               keys, perm, flags, heads, sort_ws, sort_ws_bytes, user_n2, item_n2);
+                               keys, perm, flags, heads, sort_ws, sort_ws_bytes);
 }
 
-
-// n2[r] = squared norm of row r of a [rows, D] table (D % 4 == 0, D <= 256): the first fill of the cache cdr_bpr_step_fused(_dev) keeps current
-extern "C" int cdr_row_norms2(void* stream, const float* table, int64_t rows, int D, float* n2) {
-    CDR_CHECK_ARG(table && n2 && rows > 0 && D > 0 && (D & 3) == 0 && D <= 256);
-    const int lpr = cdr_lpr_for(D);
-    const int grid = grid_for(rows, kBlock / lpr);
-    DISPATCH_LPR(lpr, row_norms2_kernel<L><<<dim3(grid), dim3(kBlock), 0, (hipStream_t)stream>>>(table, rows, D, n2));
-    CDR_LAUNCH_CHECK();
-    return CDR_OK;
-}
 
 // ---- round 5: the fused single-occurrence update inside the two multi-GPU layouts -----------------------------------
 // DIMENSION shard (cdr_dimshard.hip): the step is cut in two around the all-reduce of the partial scores.

@@ -39,7 +39,10 @@ def overlap_remap_packed(source, target, device):
     def put(x, dt):
         if x is None:
             return None
-        t = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
+        if not torch.is_tensor(x):
+            x = np.ascontiguousarray(x)
+            x = torch.from_numpy(x if x.flags.writeable else x.copy())      # (np.frombuffer views of bytes objects are read-only: torch warns)
+        t = x
         return t.to(device=dev, dtype=dt).contiguous()
 
     (sb, so, sn), (tb, to, tn) = [(put(b, torch.uint8), put(o, torch.int64), put(m, torch.uint8)) for b, o, m in (source, target)]

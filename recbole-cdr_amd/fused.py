@@ -29,21 +29,6 @@ class RowwiseState:
         self.exp_avg = torch.zeros_like(table) if opt == OPT_ADAM else None
         self.exp_avg_sq = torch.zeros_like(table) if opt == OPT_ADAM else None
         self._step_dev = None
-        self._n2, self._n2_ok, self._n2_version = None, False, None
-
-    def norms2(self):
-        """The table's squared-row-norm cache [rows] (fp32, n2[r] = sum of squares of row r) for ``cdr_bpr_step_fused``: the EmbLoss
-        norms of a batch are then summed from 8 bytes per triple instead of a second gather of two rows, and the step keeps the entries
-        of the rows it stores current.  Valid as long as nothing else has written the table: every other update path goes through
-        ``advance()`` (which drops it) and torch-side in-place writes move ``table._version``; an invalid cache is refilled here with one
-        streaming pass (cdr_row_norms2)."""
-        t = self.table
-        if self._n2 is None or self._n2.numel() != t.shape[0] or self._n2.device != t.device:
-            self._n2, self._n2_ok = torch.empty(t.shape[0], device=t.device, dtype=torch.float32), False
-        if not self._n2_ok or self._n2_version != t._version:
-            B_.call('cdr_row_norms2', B_.stream(), B_.f32(t), t.shape[0], t.shape[1], B_.f32(self._n2))
-            self._n2_ok, self._n2_version = True, t._version
-        return self._n2
 
     @property
     def step(self):
@@ -52,7 +37,6 @@ class RowwiseState:
     @step.setter
     def step(self, value):                       # (checkpoint restore, layout changes) keeps the device mirror in step
         self._step = int(value)
-        self._n2_ok = False
         if self._step_dev is not None:
             self._step_dev.fill_(self._step)
 
@@ -63,12 +47,9 @@ class RowwiseState:
             self._step_dev = torch.full((1,), int(self._step), device=self.table.device, dtype=torch.int64)
         return self._step_dev
 
-    def advance(self, device_bumped=False, keeps_norms=False):
-        """One more update of this table.  ``device_bumped``: a kernel already incremented the device counter.  ``keeps_norms``: the
-        update maintained the squared-row-norm cache (``norms2``); every other update path leaves it stale, so it is dropped."""
+    def advance(self, device_bumped=False):
+        """One more update of this table.  ``device_bumped``: a kernel already incremented the device counter."""
         self._step += 1
-        if not keeps_norms:
-            self._n2_ok = False
         if self._step_dev is not None and not device_bumped:
             B_.call('cdr_inc_i64', B_.stream(), B_.i64(self._step_dev))
 
@@ -77,8 +58,7 @@ class FusedBPRStep:
     """One object per (user table, item table) pair; buffers are sized for ``max_batch`` triples and reused."""
 
     def __init__(self, user_table, item_table, max_batch, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True, device_counts=True,
-                 norm_cache=True):
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True, device_counts=True):
         assert user_table.is_cuda and item_table.is_cuda, 'FusedBPRStep needs ROCm device tensors'
         assert user_table.shape[1] == item_table.shape[1]
         self.U, self.I = user_table, item_table
@@ -111,10 +91,6 @@ class FusedBPRStep:
         # host mirrors in step); the host-count form stays available (device_counts=False: the sharded layouts drive it)
         self.device_counts = bool(device_counts) and self.fuse_singles
         self._hp_dev = None
-        # round 5: the EmbLoss norms of the batch from per-row caches (RowwiseState.norms2) instead of a second gather of 2 rows per triple
-        # (1.07 of the 11.2 GB a C5 domain step moved).  Eager steps only: a captured step must not depend on host-side validity, so it
-        # runs the gather form and leaves the cache stale (``replayed`` -> ``advance()`` drops it).  CDR_NORM_CACHE=0: A/B runs.
-        self.norm_cache = bool(norm_cache) and self.fuse_singles and float(reg_weight) != 0.0 and os.environ.get('CDR_NORM_CACHE', '1') != '0'
         if self.fuse_singles:
             words = ctypes.c_int64(0)
             B_._check(B_.load().cdr_bpr_step_fused_heads_words(Bm, ctypes.byref(words)), 'cdr_bpr_step_fused_heads_words')
@@ -136,8 +112,6 @@ class FusedBPRStep:
         """Batch norms and sort first, then ONE pass that also applies the optimizer to every row occurring once in the batch; the
         segmented applies see the duplicate rows only (csrc/cdr_step.hip, "single-occurrence rows in the forward")."""
         us, its = self.ustate, self.istate
-        cached = self.norm_cache and not torch.cuda.is_current_stream_capturing()
-        n2u, n2i = (us.norms2(), its.norms2()) if cached else (None, None)
         if self.opt == OPT_ADAM and self.device_counts:
             # the capturable form: the update counts live on the device and the call advances them itself (the host mirrors follow)
             if self._hp_dev is None:
@@ -148,19 +122,19 @@ class FusedBPRStep:
                     its.table.shape[0], self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), B, float(self.gamma),
                     float(self.reg_weight), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
                     B_.i64(su), B_.i64(si), B_.f32(self._hp_dev), B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GP), B_.raw(self.keys),
-                    B_.raw(self.perm), B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes, B_.f32(n2u), B_.f32(n2i))
+                    B_.raw(self.perm), B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes)
             if not torch.cuda.is_current_stream_capturing():
-                us.advance(device_bumped=True, keeps_norms=cached)
-                its.advance(device_bumped=True, keeps_norms=cached)
+                us.advance(device_bumped=True)
+                its.advance(device_bumped=True)
             return self.out6
-        us.advance(keeps_norms=cached)
-        its.advance(keeps_norms=cached)
+        us.advance()
+        its.advance()
         B_.call('cdr_bpr_step_fused', B_.ctx(self.U.device), B_.stream(), self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
                 B_.f32(us.exp_avg_sq), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq),
                 its.table.shape[0], self.D, B_.i64(uid), B_.i64(pid), B_.i64(nid), B, float(self.gamma),
                 float(self.reg_weight), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
                 us.step, its.step, B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GP), B_.raw(self.keys), B_.raw(self.perm),
-                B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes, B_.f32(n2u), B_.f32(n2i))
+                B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws_bytes)
         return self.out6
 
     def replayed(self, n=1):

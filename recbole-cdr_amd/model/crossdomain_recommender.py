@@ -63,14 +63,6 @@ class CrossDomainRecommender(nn.Module):
         would be frozen into the capture.  Default: not capturable (the eager loop)."""
         return None
 
-    def load_state_dict(self, *args, **kwargs):
-        """torch's ``load_state_dict`` + dropping what the fused row-wise steps cache ABOUT the tables' contents (fused.RowwiseState.norms2:
-        the squared-row-norm caches; they alias ``weight.data``, whose writes through the Parameter they cannot see)."""
-        out = super().load_state_dict(*args, **kwargs)
-        for st in ((self.__dict__.get('_fused') or {}).get('states') or {}).values():
-            st._n2_ok = False
-        return out
-
     def on_train_steps(self):
         """Called by ``Trainer`` after training steps that ran WITHOUT the model's Python (hipGraph replays): the place to drop
         anything ``calculate_loss`` would have invalidated on the host -- e.g. BiTGCF's cached propagated embeddings

@@ -214,7 +214,17 @@ class NativeOps:
                 B_.i64(local_ids) if tagged else None, 0)
 
 
+SELF_VIA_COLLECTIVE = bool(int(__import__('os').environ.get('CDR_A2A_SELF_VIA_RCCL', '0')))   # 1: the round-1..4 behaviour (A/B runs, RCCL bring-up on one GPU)
+
+
 def _a2a(inp, in_splits, out_splits, group, trailing=()):
+    """all-to-all(v) of rows.  With ONE rank nothing has to move: the buffer is handed on as it is (measured on one MI355X with
+    --force-shard: 5.3 of the 10.3 ms of a step were RCCL's eight self-copies inside all_to_all_single, which say nothing about the
+    algorithm's local cost -- with more ranks those bytes travel over xGMI).  CDR_A2A_SELF_VIA_RCCL=1 keeps the collective in the
+    one-rank case (RCCL bring-up on a single GPU, A/B runs)."""
+    if dist.get_world_size(group) == 1 and not SELF_VIA_COLLECTIVE:
+        assert in_splits[0] == out_splits[0] == inp.shape[0]
+        return inp
     out = torch.empty((sum(out_splits),) + tuple(trailing), device=inp.device, dtype=inp.dtype)
     dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
     return out

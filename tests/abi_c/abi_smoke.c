@@ -147,7 +147,7 @@ int main(void) {
         CHECK_CDR(cdr_bpr_step_fused_heads_words(B, &words));
         CHECK_HIP(hipMalloc((void**)&dFlags, 4 * B)); CHECK_HIP(hipMalloc((void**)&dHeads, 4 * (size_t)words));
         CHECK_CDR(cdr_bpr_step_fused(ctx, NULL, CDR_OPT_SGD, dU3, NULL, NULL, NU, dI3, NULL, NULL, NI, D, du, dp_, dn_, B, gamma, reg, lr, 0.9f,
-                                     0.999f, 1e-8f, 0.f, 1, 1, dOut, dGU, dGP, dKeys, dPerm, dFlags, dHeads, dWs, ws_bytes, NULL, NULL));
+                                     0.999f, 1e-8f, 0.f, 1, 1, dOut, dGU, dGP, dKeys, dPerm, dFlags, dHeads, dWs, ws_bytes));
         CHECK_HIP(hipDeviceSynchronize());
         CHECK_HIP(hipMemcpy(out, dOut, sizeof(float) * 6, hipMemcpyDeviceToHost));
         ok &= close_enough(out[0], total, 0, "one-call fused step loss");

@@ -655,13 +655,21 @@ def test_fused_step_deterministic_and_sorted():
     assert torch.equal(torch.sort(heads[4 + B // 2 + 1:4 + B // 2 + 1 + nB]).values, torch.nonzero(hd[B:]).flatten())
 
 
-def test_sharded_step_world1_equals_fused():
+@pytest.mark.parametrize('variant', ['via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup'])
+def test_sharded_step_world1_equals_fused(variant, monkeypatch):
     """shard.ShardedBPRStep with libcdrhip ops over a 1-rank RCCL group == fused.FusedBPRStep (same kernels, plus the
-    route / all-to-all / build-grad-rows path).  World 2 is covered on CPU by tests/test_shard_gloo.py."""
+    route / all-to-all / build-grad-rows path).  World 2 is covered on CPU by tests/test_shard_gloo.py.  Variants: the one-rank
+    all-to-alls sent through RCCL (the collective calls of the multi-GPU path exercised on one GPU) or handed on in place (the product's
+    one-rank form); the requester's half on the one-GPU forward-and-update kernel (round 5) or as the round-2 two-pass step; and the
+    exchange without id de-duplication."""
     import socket
     import torch.distributed as dist
+    from recbole_cdr_amd import shard as shard_mod
     from recbole_cdr_amd.fused import FusedBPRStep
     from recbole_cdr_amd.shard import ShardedBPRStep
+    comm, form = variant.split('-')
+    monkeypatch.setattr(shard_mod, 'SELF_VIA_COLLECTIVE', comm == 'via_rccl')
+    kw = {'fused': {}, 'two_pass': {'fuse_singles': False}, 'no_dedup': {'dedup': False}}[form]
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
                             device_id=torch.device(DEV))
@@ -671,7 +679,7 @@ def test_sharded_step_world1_equals_fused():
         U0, I0 = torch.randn(nu, D, device=DEV) * 0.1, torch.randn(ni, D, device=DEV) * 0.1
         Ua, Ia, Ub, Ib = U0.clone(), I0.clone(), U0.clone(), I0.clone()
         fa = FusedBPRStep(Ua, Ia, B, opt='adam', reg_weight=0.02, lr=0.01)
-        fb = ShardedBPRStep(Ub, Ib, nu, ni, B, opt='adam', reg_weight=0.02, lr=0.01)
+        fb = ShardedBPRStep(Ub, Ib, nu, ni, B, opt='adam', reg_weight=0.02, lr=0.01, **kw)
         for step in range(3):
             u = torch.randint(0, nu, (B,), device=DEV); p = torch.randint(0, ni, (B,), device=DEV)
             n = torch.randint(0, ni, (B,), device=DEV)
