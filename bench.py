@@ -201,6 +201,7 @@ def parse():
     ap.add_argument('--no-config-legs', action='store_true', help='c5, N=1: skip the compact C1-C4 legs (BASELINE configs[0..3]) behind the headline')
     ap.add_argument('--no-e2e', action='store_true', help='c5, N=1: skip the end-to-end leg (CrossDomainTrainer.fit over SOURCE / TARGET / OVERLAP epochs + evaluate at the headline table sizes)')
     ap.add_argument('--only-e2e', action='store_true', help='c5, N=1: the end-to-end leg alone')
+    ap.add_argument('--no-map', action='store_true', help='c5: skip the OVERLAP-phase leg (profiling runs of the BPR step alone)')
     ap.add_argument('--no-ingest', action='store_true', help='c5, N=1: skip the ingest leg (overlap id remap of the C5 id space on the device)')
     ap.add_argument('--only-ingest', action='store_true', help='c5, N=1: the ingest leg alone')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)

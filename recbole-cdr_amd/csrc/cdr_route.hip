@@ -63,6 +63,17 @@ __global__ __launch_bounds__(kBlock) void inverse_perm_kernel(const uint32_t* __
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) pos[perm[q]] = q;
 }
 
+// The owner key has <= 10 significant bits (world <= 1024): ONE Onesweep pass of 9- or 10-bit digits whatever the item count.  rocPRIM's
+// default configuration merge-sorts up to 2^20 items however few key bits there are: 0.6 ms for the 1,048,576 triples of a C5 domain step
+// (block sort + ~48 merge launches, profiles/r05_force_shard_row_kernel_stats.csv before this) against one ~35 us pass.
+using route_sort_config = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 10,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    (size_t)1 << 12>;          // merge sort only below 4,096 items
+template <class... A>
+inline hipError_t route_sort(A... a) { return rocprim::radix_sort_pairs<route_sort_config>(a...); }
+
 inline unsigned bits_for(int64_t v) {
     unsigned b = 1;
     while (b < 32 && ((int64_t)1 << b) < v) ++b;
@@ -81,7 +92,7 @@ extern "C" int cdr_route_by_owner(cdr_ctx* ctx, void* stream, const int64_t* ids
     const size_t arr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t starts_bytes = (((size_t)world + 2) * sizeof(int64_t) + 255) & ~(size_t)255;
     size_t tmp_need = 0;
-    CDR_HIP(rocprim::radix_sort_pairs(nullptr, tmp_need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+    CDR_HIP(route_sort(nullptr, tmp_need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                       (uint32_t*)nullptr, (size_t)n, 0u, bits_for(world)));
     CDR_CHECK_ARG(workspace_bytes >= 3 * arr + starts_bytes + tmp_need);
     uint32_t* keys_in = (uint32_t*)workspace;
@@ -92,7 +103,7 @@ extern "C" int cdr_route_by_owner(cdr_ctx* ctx, void* stream, const int64_t* ids
     size_t tmp_bytes = workspace_bytes - 3 * arr - starts_bytes;
     owner_keys_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(ids0, n0, ids1, n1, (int64_t)world, keys_in, vals_in);
     CDR_LAUNCH_CHECK();
-    CDR_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)vals_in, perm, (size_t)n,
+    CDR_HIP(route_sort(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)vals_in, perm, (size_t)n,
                                       0u, bits_for(world), s));
     bucket_bounds_kernel<<<dim3(grid_for(n + 1)), dim3(kBlock), 0, s>>>(keys_out, n, world, starts);
     CDR_LAUNCH_CHECK();
@@ -104,7 +115,7 @@ extern "C" int cdr_route_by_owner(cdr_ctx* ctx, void* stream, const int64_t* ids
 extern "C" int cdr_route_workspace_bytes(int64_t n, int world, size_t* bytes) {
     CDR_CHECK_ARG(bytes && n > 0 && world >= 1 && world <= 1024);
     size_t tmp_need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+    hipError_t e = route_sort(nullptr, tmp_need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                              (uint32_t*)nullptr, (size_t)n, 0u, bits_for(world));
     if (e != hipSuccess) { cdr_set_error("cdr_route_workspace_bytes: %s", hipGetErrorString(e)); return (int)e; }
     const size_t arr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;

@@ -230,6 +230,13 @@ def _a2a(inp, in_splits, out_splits, group, trailing=()):
     return out
 
 
+def _allreduce(t, group):
+    """In-place sum over the ranks; with ONE rank there is nothing to add (and no cross-stream hand-over to RCCL's stream to pay for)."""
+    if dist.get_world_size(group) > 1 or SELF_VIA_COLLECTIVE:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def _gather_counts(counts, extra, group, world):
     """All ranks' bucket counts (+ one extra int per rank) -> list of tensors (no host sync yet)."""
     payload = torch.cat([counts, torch.tensor([extra], device=counts.device, dtype=torch.int64)])
@@ -366,7 +373,7 @@ class ShardedBPRStep:
                 sums = self.out[6:9].clone()
             else:
                 sums = torch.zeros(3, device=uid.device, dtype=torch.float32)
-            dist.all_reduce(sums, group=grp)
+            _allreduce(sums, grp)
             ops.finish_sums(sums, B_global, self.reg_weight, self.out)
 
             # ---- 3. user rows are local; item gradients go home ---------------------------------------------------
@@ -408,7 +415,7 @@ class ShardedBPRStep:
                     norms = ops.batch_norms(self.U, irows, u_loc, ip)
                 else:
                     norms = torch.zeros(3, device=dev, dtype=torch.float32)
-                dist.all_reduce(norms, group=grp)
+                _allreduce(norms, grp)
                 ops.finish_sums(norms, B_global, self.reg_weight, self.out)          # out[4:6] = the coefficients every rank uses
                 if Bl:
                     GP = ops.local_step(self.U, self._moments(self.ustate), irows, u_loc, ip, in_, B_global, self.gamma, self.reg_weight,
@@ -416,7 +423,7 @@ class ShardedBPRStep:
                     loss = self.out[6:7].clone()
                 else:
                     loss = torch.zeros(1, device=dev, dtype=torch.float32)
-                dist.all_reduce(loss, group=grp)
+                _allreduce(loss, grp)
                 norms[0:1] = loss                                                    # {global loss sum, global sum u^2, global sum p^2}
                 ops.finish_sums(norms, B_global, self.reg_weight, self.out)
                 gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq) if Bl else torch.empty(0, self.D, device=dev, dtype=torch.float32)
@@ -430,7 +437,7 @@ class ShardedBPRStep:
                     sums = self.out[6:9].clone()
                 else:
                     sums = torch.zeros(3, device=dev, dtype=torch.float32)
-                dist.all_reduce(sums, group=grp)
+                _allreduce(sums, grp)
                 ops.finish_sums(sums, B_global, self.reg_weight, self.out)
                 if Bl:
                     ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,
