@@ -63,16 +63,16 @@ __global__ __launch_bounds__(kBlock) void inverse_perm_kernel(const uint32_t* __
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) pos[perm[q]] = q;
 }
 
-// The owner key has <= 10 significant bits (world <= 1024): ONE Onesweep pass of 9- or 10-bit digits whatever the item count.  rocPRIM's
+// The owner key has <= 10 significant bits (world <= 1024): one Onesweep pass of 9-bit digits (two past 512 ranks) whatever the item count.  rocPRIM's
 // default configuration merge-sorts up to 2^20 items however few key bits there are: 0.6 ms for the 1,048,576 triples of a C5 domain step
 // (block sort + ~48 merge launches, profiles/r05_force_shard_row_kernel_stats.csv before this) against one ~35 us pass.
 using route_sort_config = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 10,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
                                         rocprim::block_radix_rank_algorithm::match>,
     (size_t)1 << 12>;          // merge sort only below 4,096 items
 template <class... A>
-inline hipError_t route_sort(A... a) { return rocprim::radix_sort_pairs<route_sort_config>(a...); }
+inline hipError_t route_sort(A&&... a) { return rocprim::radix_sort_pairs<route_sort_config>(static_cast<A&&>(a)...); }     // (the size argument is an in/out reference)
 
 inline unsigned bits_for(int64_t v) {
     unsigned b = 1;

@@ -15,11 +15,14 @@ from recbole_cdr_amd.fused import FusedBPRStep  # noqa: E402
 nu, ni, B, D = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (50_000_000, 10_000_000, 1 << 20, 128)
 dev = torch.device('cuda:0')
 res = {'rows_u': nu, 'rows_i': ni, 'B_per_rank': B, 'D': D, 'runs': []}
-for G in (1, 2, 4, 8):
-    Ds = D // G
+# (G, column divisor, batch multiplier): the plain dimension layout at G ranks (every rank: D / G columns, G x B triples per DOMAIN, two
+# domain steps per step) and the domain-groups form at 8 ranks (a rank serves ONE domain: D / 4 columns, 4 x 2B triples, one domain step per step)
+SHAPES = [(1, 1, 1, 'dim'), (2, 2, 2, 'dim'), (4, 4, 4, 'dim'), (8, 8, 8, 'dim'), (8, 4, 8, 'dim-groups (one domain per rank: per STEP, not per domain step)')]
+for G, cdiv, bmul, label in SHAPES:
+    Ds = D // cdiv
     U = torch.randn(nu, Ds, device=dev) * 0.01
     I = torch.randn(ni, Ds, device=dev) * 0.01
-    Bg = G * B
+    Bg = bmul * B
     step = DimShardedBPRStep(U, I, Bg, opt='adam', lr=1e-3, reg_weight=1e-3) if G > 1 else FusedBPRStep(U, I, Bg, opt='adam', lr=1e-3, reg_weight=1e-3)
     batches = [(torch.randint(1, nu, (Bg,), device=dev), torch.randint(1, ni, (Bg,), device=dev), torch.randint(1, ni, (Bg,), device=dev))
                for _ in range(4)]
@@ -40,7 +43,7 @@ for G in (1, 2, 4, 8):
     for name, t in B_.timing_collect(dev):
         per.setdefault(name, []).append(t)
     B_.timing_enable(dev, 0)
-    res['runs'].append({'G': G, 'Ds': Ds, 'global_batch': Bg, 'ms_per_domain_step': round(ms, 3),
+    res['runs'].append({'G': G, 'layout': label, 'Ds': Ds, 'global_batch': Bg, 'ms_per_domain_step': round(ms, 3),
                         'vs_G1': None, 'kernels_ms': {k: round(sum(v) / len(v), 3) for k, v in per.items()}})
     del U, I, step, batches
     torch.cuda.empty_cache()
