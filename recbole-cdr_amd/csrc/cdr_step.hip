@@ -336,7 +336,8 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
 }
 
 // One lane group per piece of a long segment: partial[pi] = signed sum of the piece's gradient rows in occurrence order,
-// pcnt[pi] = its EmbLoss occurrences.  Four row loads in flight per lane; the adds stay in order.
+// pcnt[pi] = its EmbLoss occurrences.  Sixteen row loads in flight per lane (round 5: a 256-occurrence piece was 64 dependent rounds of
+// ~1.5 us with four -- the whole Zipf(1.05) B = 65,536 step waited for them); the adds stay in occurrence order.
 template <int LPR, bool SIGNED>
 __device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __restrict__ perm,
                                                    const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
@@ -345,7 +346,7 @@ __device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __rest
                                                    const seg_piece* __restrict__ pieces, float* __restrict__ partial,
                                                    int* __restrict__ pcnt) {
     constexpr int GPB = kBlock / LPR;
-    constexpr int UN = 4;
+    constexpr int UN = 16;
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
     const int64_t TG = (int64_t)gridDim.x * GPB;
@@ -413,10 +414,18 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
             const float4 w = ld4(wp);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int cnt = 0;
-            for (int64_t k = 0; k < np; ++k) {
-                const float4 g = ld4(partial + (sg.base + k) * D + 4 * ch);
-                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-                cnt += pcnt[sg.base + k];
+            for (int64_t k0 = 0; k0 < np; k0 += 8) {                  // eight piece sums in flight, added in piece order
+                float4 g[8]; int c[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = k0 + j < np;
+                    g[j] = in ? ld4(partial + (sg.base + k0 + j) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    c[j] = in ? pcnt[sg.base + k0 + j] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k0 + j < np) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; cnt += c[j]; }
+                }
             }
             apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
                               w, acc, c * (float)cnt, hp);
@@ -981,14 +990,27 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
                     else { acc.x += g1[j].x; acc.y += g1[j].y; acc.z += g1[j].z; acc.w += g1[j].w; }
                     cnt += ((int64_t)o1[j] < reg_limit) ? 1 : 0;
                 }
-                if (k2[j] == row[j]) {                                     // third and later occurrences: the general walk
-                    for (int64_t e = q[j] + 2; e < n && keys[e] == row[j]; ++e) {
-                        const int64_t o = perm[e];
-                        const bool neg = SIGNED && o >= neg_start;
-                        const float4 g = live ? ld4(G + (neg ? o - neg_start : o) * D + 4 * sub) : z4;
-                        if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
-                        else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
-                        cnt += (o < reg_limit) ? 1 : 0;
+                if (k2[j] == row[j]) {                                     // third and later occurrences (at most kLongSeg - 2 of them)
+                    // the segment's end first (its keys are neighbours in memory), then the gradient rows eight at a time: one at a time
+                    // this walk was a chain of up to 30 dependent ~1.5 us loads per segment, which is what a Zipf batch's step waited for
+                    int64_t end = q[j] + 3;
+                    while (end < n && end <= q[j] + kLongSeg && keys[end] == row[j]) ++end;
+                    for (int64_t e0 = q[j] + 2; e0 < end; e0 += 8) {
+                        int64_t o[8]; float4 g[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) o[u] = e0 + u < end ? (int64_t)perm[e0 + u] : -1;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool neg = SIGNED && o[u] >= neg_start;
+                            g[u] = (o[u] >= 0 && live) ? ld4(G + (neg ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (o[u] < 0) continue;
+                            if (SIGNED && o[u] >= neg_start) { acc.x -= g[u].x; acc.y -= g[u].y; acc.z -= g[u].z; acc.w -= g[u].w; }
+                            else { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+                            cnt += (o[u] < reg_limit) ? 1 : 0;
+                        }
                     }
                 }
                 const float4 wn = upd_math<OPT>(w[j], m[j], v[j], acc, c * (float)cnt, hp);
