@@ -744,7 +744,7 @@ def run_c5(args, world, rank, dev):
                               'design_bytes': dom_k['design_bytes'], 'design_GBps': dom_k['design_GBps'],
                               'design_frac': dom_k['design_GBps'] / HBM_PEAK_GBS,
                               'traffic': pmc_traffic(dom_k['kernel'].split(' ')[0]),
-                              'rocprof': 'profiles/r04_bench_c5_headline_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `python bench.py --headline-only` '
+                              'rocprof': 'profiles/r05_bench_c5_headline_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `python bench.py --headline-only` '
                                          '(single stream, this kernel on the headline batch only; the default command also launches it on the k = 4 and synthetic-grid '
                                          'batches and beside the other domain\'s kernels, so ITS stats file averages over several situations)'}
         result['kernels'] = kernels
@@ -1099,8 +1099,8 @@ def pmc_traffic(kernel):
         v = None
     if v is None:
         return None
-    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_r04.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                                  'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --single-stream --steps 3 --warmup 1`; not measured in this invocation)'}
+    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_r05.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                  'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --no-ingest --single-stream --steps 3 --warmup 1`; not measured in this invocation)'}
 
 
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
@@ -1362,8 +1362,10 @@ def run_model_workload(args, world, rank, dev):
         gather_bw, stream_bw = measured_gather_bandwidth(dev, foot, D)
         roof_bw, roof_rec = cache_roof(foot, 4 * D)
         roof_bw = roof_bw or max(gather_bw, stream_bw)
-        roof = {'bound': 'cache', 'achieved': gbs, 'peak': roof_bw, 'unit': 'GB/s', 'frac': gbs / roof_bw, 'algorithmic_bytes': byts,
-                'peak_what': 'the working set of this configuration (tables, gradients, adjacency: %.0f MB) sits in L2 / Infinity Cache, where the HBM peak '
+        roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
+                'frac_of_measured_cache_gather_rate': gbs / roof_bw, 'measured_cache_gather_rate_GBs': roof_bw,
+                'peak_what': 'peak = the guide\'s HBM figure (MI355X_MICROARCH.md, 8 TB/s): the only roof the guide supports.  INFORMATIONAL beside it '
+                             '(frac_of_measured_cache_gather_rate): the working set of this configuration (tables, gradients, adjacency: %.0f MB) sits in L2 / Infinity Cache, where the HBM peak '
                              'bounds nothing.  peak = the MEASURED rate of uniformly random %d-B row gathers (8 rows in flight per lane group) out of a '
                              'working set of that size: tools/mb_cache_bw.hip, filed as profiles/r04_mb_cache_bw.txt (builder run; 25 TB/s out of L2-resident '
                              '4 MB, 7.5 TB/s out of 77 MB, 5.8 TB/s out of HBM).  The product\'s own gather kernel (cdr_embloss_fwd) measured IN THIS RUN on the '
@@ -1385,8 +1387,9 @@ def run_model_workload(args, world, rank, dev):
         roof_bw, roof_rec = cache_roof(foot, 4 * D)
         roof_bw = roof_bw or max(gather_bw, stream_bw)
         n_launch = 4
-        roof = {'bound': 'launch', 'achieved': gbs, 'peak': roof_bw, 'unit': 'GB/s', 'frac': gbs / roof_bw, 'algorithmic_bytes': byts,
-                'peak_what': 'peak = the MEASURED rate of uniformly random %d-B row gathers out of a %.0f MB working set (L2-resident; tools/mb_cache_bw.hip, '
+        roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes': byts,
+                'frac_of_measured_cache_gather_rate': gbs / roof_bw, 'measured_cache_gather_rate_GBs': roof_bw, 'limited_by': 'launch latency',
+                'peak_what': 'peak = the guide\'s HBM figure (8 TB/s).  INFORMATIONAL (measured_cache_gather_rate_GBs): the MEASURED rate of uniformly random %d-B row gathers out of a %.0f MB working set (L2-resident; tools/mb_cache_bw.hip, '
                              'profiles/r04_mb_cache_bw.txt, builder run).  The step is not bound by it: it is %d dependent launches of ~5-10 us each '
                              '(producer, forward, backward, Adam) -- ms_per_step and launches_per_step are the figures that matter here' % (4 * D, foot / 1e6, n_launch),
                 'cache_roof_record': roof_rec, 'product_gather_kernel_GBs_measured_in_run': gather_bw, 'launches_per_step': n_launch,

@@ -62,6 +62,18 @@ class CoNet(CrossDomainRecommender):
         self.row_opt = DeferredRowAdam(self.table_parameters(), [0, 1, 0, 1], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         return self.row_opt
 
+    def train(self, mode=True):
+        if mode:
+            self.__dict__.pop('_eval_P', None)            # (full_sort_predict's evaluation-mode cache of the item part of layer 1)
+        return super().train(mode)
+
+    def on_train_steps(self):
+        self.__dict__.pop('_eval_P', None)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop('_eval_P', None)
+        return super().load_state_dict(*args, **kwargs)
+
     def sync_tables(self):
         """Every table row up to date (no-op unless a deferred optimizer has postponed work): before anything reads whole tables."""
         if self.row_opt is not None:
@@ -201,7 +213,13 @@ class CoNet(CrossDomainRecommender):
         items = self.target_item_embedding.weight[:self.target_num_items]
         lin1 = self.target_crossunit_linear[0]
         W1 = lin1.weight                                              # [h1, 2D]
-        P = F_.gemm(items, W1[:, D:], trans_b=True)                    # [N, h1]
+        # P depends on the item table and W1 only: in evaluation mode (recbole's evaluate calls full_sort_predict once per user batch --
+        # one user per call at the default eval_batch_size) it is formed once and kept until the model trains again
+        P = None if self.training else self.__dict__.get('_eval_P')
+        if P is None:
+            P = F_.gemm(items, W1[:, D:], trans_b=True)                # [N, h1]
+            if not self.training:
+                self.__dict__['_eval_P'] = P
         Q = F_.gemm(user_e, W1[:, :D], trans_b=True, bias=lin1.bias)    # [U, h1]
         tail = list(self.target_crossunit_linear)[1:]
         if (self.__dict__.get('fullsort_fused', True) and tail

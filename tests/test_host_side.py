@@ -301,7 +301,11 @@ def test_filed_bench_lines_of_this_round_parse():
         txt = open(path).read().strip()
         assert '\n' not in txt and len(txt) <= 4096, path
         d = json.loads(txt)
-        assert isinstance(d['value'], float) and isinstance(d['roofline'], dict) and isinstance(d['cpu_baseline'], dict) and d['detail_file'], path
+        assert isinstance(d['value'], float) and isinstance(d['roofline'], dict) and d['detail_file'], path
+        for k in ('metric', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+            assert k in d, (path, k)
+        if os.path.basename(path) == 'r05_bench_c5_line.json':            # the driver's command: the CPU baseline rides on the same line
+            assert isinstance(d['cpu_baseline'], dict) and d['cpu_baseline']['kind'] == 'port' and d['roofline']['traffic'] > 0
 
 
 @both_sessions
