@@ -14,7 +14,7 @@ region.  With N>1 the tables are row-sharded (row r on rank r % N) and every ran
 (weak scaling in batch; table size fixed); rows/gradients travel by RCCL all-to-all (shard.py).
 
 `--workload c1|c2|c3|c4` run BASELINE configs[0..3] (CMF and EMCDR at ml-1m->ml-100k sizes, CoNet Amazon sizes, BiTGCF Douban sizes)
-through the drop-in class contract (autograd + exact dense Adam), the whole step replayed as one hipGraph.
+through the drop-in class contract (autograd + dense Adam in torch.optim.Adam's semantics), the whole step replayed as one hipGraph.
 """
 import argparse
 import json
@@ -1106,7 +1106,7 @@ def pmc_traffic(kernel):
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
 def run_model_workload(args, world, rank, dev):
     """BASELINE configs[2] (CoNet, Amazon-Books -> Movies sizes, D=128, k=4 pointwise) and configs[3] (BiTGCF, Douban sizes,
-    2 layers, D=64) through the drop-in class contract: calculate_loss -> backward -> exact dense Adam (the reference's
+    2 layers, D=64) through the drop-in class contract: calculate_loss -> backward -> dense Adam (the reference's
     loop, trainer.py:59-73).  Reports rows/s (a row = one (u, i, label) row of a domain's batch) and the oracle on the
     host cores beside it."""
     import numpy as np
@@ -1296,7 +1296,7 @@ def run_model_workload(args, world, rank, dev):
               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
               'higher_is_better': True, 'scaling': 'strong' if rowshard is not None else 'weak', 'vs_baseline': None, 'dtype': 'f32',
               'data': 'synthetic' + ('; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo' if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')) else ''),
-              'config': {'workload': name + (', drop-in autograd + exact dense Adam evaluated lazily per row (bit-identical to the dense sweep)' if deferred else ', drop-in autograd + exact dense Adam') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if sdp is not None else ', eager trainer loop' if args.no_graph else ', batch production + step replayed as one hipGraph per batch'),
+              'config': {'workload': name + (', drop-in autograd + dense Adam (torch.optim.Adam semantics, update term on 1-ulp rcp / sqrt: DESIGN 5) evaluated lazily per row (bit-identical to this library\'s dense sweep)' if deferred else ', drop-in autograd + dense Adam (torch.optim.Adam semantics, update term on 1-ulp rcp / sqrt: DESIGN 5)') + (', tables + Adam state + adjacency rows row-sharded over %d ranks, per-layer all-gather of E (forward) and of g(1+E) (backward), batch replicated' % world if rowshard is not None else ', data parallel with row-sharded optimizer state (reduce-scatter + all-gather per step)' if sdp is not None else ', eager trainer loop' if args.no_graph else ', batch production + step replayed as one hipGraph per batch'),
                          'rows_per_step': rows_per_step, 'via': via,
                          'trainer_steps': None if trainer is None else dict(stats, warmup_steps_run=args.steps, optimizer=type(opt).__name__,
                                                                             timed='one fit() = one shuffled epoch of exactly --steps full batches, sampler + loader + step + loss read-back')},
@@ -1394,7 +1394,7 @@ def run_model_workload(args, world, rank, dev):
                              '(producer, forward, backward, Adam) -- ms_per_step and launches_per_step are the figures that matter here' % (4 * D, foot / 1e6, n_launch),
                 'cache_roof_record': roof_rec, 'product_gather_kernel_GBs_measured_in_run': gather_bw, 'launches_per_step': n_launch,
                 'frac_of_hbm_peak_nominal': gbs / HBM_PEAK_GBS,
-                'what': 'gather (%d B per row) + exact dense Adam over the parameters that received a gradient (7 x 4 B per element)' % per_row, 'traffic': None}
+                'what': 'gather (%d B per row) + dense Adam over the parameters that received a gradient (7 x 4 B per element)' % per_row, 'traffic': None}
     result['roofline'] = roof
     if rowshard is not None:
         p_ = rowshard.part
