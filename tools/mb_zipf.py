@@ -8,7 +8,7 @@ from recbole_cdr_amd import binding as B_
 from recbole_cdr_amd.fused import FusedBPRStep
 
 dev = torch.device('cuda', 0)
-nu, TOI, D, B = int(os.environ.get('NU', 20_000_001)), 10_000_000, 128, 1 << 20
+nu, TOI, D, B = int(os.environ.get("NU", 20_000_001)), 10_000_000, 128, int(os.environ.get("MB_B", 1 << 20))
 ni = 1 + 2 * TOI
 g = torch.Generator(device=dev); g.manual_seed(1)
 U = torch.randn(nu, D, device=dev) * 0.01; I = torch.randn(ni, D, device=dev) * 0.01
