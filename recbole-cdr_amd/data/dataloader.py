@@ -253,19 +253,30 @@ class FullSortEvalLoader:
             pos = torch.searchsorted(users_t, hi_u).clamp_(max=users_t.numel() - 1)
             keep = users_t[pos] == hi_u                                                    # history of evaluated users only
             hi_u, hi_i = hi_u[keep], hi_i[keep]
-        starts = users_t[::self.step].contiguous()                                          # (a strided boundary tensor makes searchsorted warn on stderr)
         self.users = users_t.cpu().numpy()
-        self._ev_ptr = np.append(torch.searchsorted(ev_u, starts, right=False).cpu().numpy(), ev_u.numel())
-        self._hi_ptr = np.append(torch.searchsorted(hi_u, starts, right=False).cpu().numpy(), hi_u.numel())
-        rank = torch.searchsorted(users_t, ev_u)                                           # position of each pair's user among the evaluated users
-        hrank = torch.searchsorted(users_t, hi_u) if hi_u.numel() else hi_u
-        self._ev = (rank % self.step, ev_i.contiguous())
-        self._hi = (hrank % self.step, hi_i.contiguous())
+        self._users_t, self._ev_u, self._hi_u = users_t, ev_u, hi_u
+        self._rank = torch.searchsorted(users_t, ev_u)                                     # position of each pair's user among the evaluated users
+        self._hrank = torch.searchsorted(users_t, hi_u) if hi_u.numel() else hi_u
+        ev_i, hi_i = ev_i.contiguous(), hi_i.contiguous()
         if revoke is not None:
             from .remap import revoke_map
-            self._ev = (self._ev[0], revoke_map(self._ev[1], *revoke))
-            self._hi = (self._hi[0], revoke_map(self._hi[1], *revoke) if self._hi[1].numel() else self._hi[1])
-        self._users_t = users_t
+            ev_i = revoke_map(ev_i, *revoke)
+            hi_i = revoke_map(hi_i, *revoke) if hi_i.numel() else hi_i
+        self._ev_i, self._hi_i = ev_i, hi_i
+        self.rebatch(self.step)
+
+    def rebatch(self, users_per_batch):
+        """Cut the same evaluated users into batches of ``users_per_batch`` (the per-user results do not depend on the cut).  recbole sizes
+        the batch for the [U, N] score matrix; an evaluation that never forms it (``Trainer.evaluate`` on ``full_sort_topk``) asks for a
+        throughput-sized batch here: one user per call is ~100 x slower per user than 1,024."""
+        import numpy as np
+        self.step = max(int(users_per_batch), 1)
+        starts = self._users_t[::self.step].contiguous()                                   # (a strided boundary tensor makes searchsorted warn on stderr)
+        self._ev_ptr = np.append(torch.searchsorted(self._ev_u, starts, right=False).cpu().numpy(), self._ev_u.numel())
+        self._hi_ptr = np.append(torch.searchsorted(self._hi_u, starts, right=False).cpu().numpy(), self._hi_u.numel())
+        self._ev = (self._rank % self.step, self._ev_i)
+        self._hi = (self._hrank % self.step, self._hi_i)
+        return self
 
     def __len__(self):
         return (len(self.users) + self.step - 1) // self.step

@@ -2019,6 +2019,16 @@ def test_end_to_end_emcdr_learns_with_device_sampler():
     ref_t = trainer.evaluate(valid[1])
     for k in res_t:
         assert abs(res_t[k] - ref_t[k]) < 1e-6 and abs(res_s[k] - ref_s[k]) < 1e-6, (k, res_t[k], ref_t[k], res_s[k], ref_s[k])
+    # Trainer.evaluate re-cut both loaders into throughput-sized user batches for the fused path (round 5); recbole's own cut
+    # (eval_batch_size // item_num users per call: config['eval_users_per_batch'] = 0) gives the same metrics
+    assert valid[1].step == 1024
+    trainer.fused_topk = True
+    trainer.config = dict(trainer.config, eval_users_per_batch=0)
+    valid[1].rebatch(max(4096 // ids.target_num_items, 1))
+    small_t = trainer.evaluate(valid[1])
+    assert valid[1].step == max(4096 // ids.target_num_items, 1)
+    for k in res_t:
+        assert abs(res_t[k] - small_t[k]) < 1e-6, (k, res_t[k], small_t[k])
 
 
 @pytest.mark.parametrize('D', [64, 8, 24, 48, 96, 128, 260])
@@ -2793,7 +2803,7 @@ def test_plain_c_consumer_of_the_abi():
     # (RCCL's bootstrap of the one-rank communicator picks a network interface: pin it to loopback -- a fresh box's hostname may not resolve)
     env = dict(os.environ, NCCL_SOCKET_IFNAME='lo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     try:
-        r = subprocess.run([exe], capture_output=True, timeout=150, env=env)
+        r = subprocess.run([exe], capture_output=True, timeout=60, env=env)           # (6 s when nothing stands still)
     except subprocess.TimeoutExpired as e:                         # say WHERE it stood still: the program prints a line per stage
         so_far = (e.stderr or b'').decode()
         if 'stage comm' not in so_far.strip().splitlines()[-1]:

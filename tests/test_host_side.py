@@ -190,6 +190,18 @@ def test_full_sort_eval_loader_batches(users_per_batch):
         assert got_hist == {p for p in hi_set if p[0] in us}
     assert users_seen == sorted({p[0] for p in ev_set})
     assert len(loader) == (len(users_seen) + loader.step - 1) // loader.step
+    # the same users re-cut into other batch sizes (what Trainer.evaluate does for the fused top-k path): every batch still carries
+    # exactly its own users' pairs, rows relative to the batch
+    for step in (1, 5, 64, 10_000):
+        assert loader.rebatch(step).step == step
+        seen = []
+        for inter, (hr, hc), pu, pi in loader:
+            us = inter['uid'].tolist()
+            assert 1 <= len(us) <= step
+            seen += us
+            assert {(us[r], c) for r, c in zip(pu.tolist(), pi.tolist())} == {p for p in ev_set if p[0] in us}
+            assert {(us[r], c) for r, c in zip(hr.tolist(), hc.tolist())} == {p for p in hi_set if p[0] in us}
+        assert seen == users_seen and len(loader) == (len(seen) + step - 1) // step
 
 
 def test_alias_table_matches_reference_construction():
