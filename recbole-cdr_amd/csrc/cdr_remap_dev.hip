@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void rd_compact_kernel(const uint32_t* __re
 }
 
 // key[q] = bytes [8 j, 8 j + 8) of token list[q], big-endian, zero padded (j < 0: the token's length)
-__global__ __launch_bounds__(kBlock) void rd_keys_kernel(tok_src t, const uint32_t* __restrict__ list, int64_t nv, int j,
+__global__ __launch_bounds__(kBlock) void rd_keys_kernel(tok_src t, const uint32_t* __restrict__ list, int64_t nv, int j, int shift,
                                                          uint64_t* __restrict__ keys) {
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < nv; q += (int64_t)gridDim.x * kBlock) {
         const uint8_t* p; int64_t len;
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kBlock) void rd_keys_kernel(tok_src t, const uint32
             const int64_t b0 = 8 * (int64_t)j;
 #pragma unroll
             for (int b = 0; b < 8; ++b) k = (k << 8) | (uint64_t)(b0 + b < len ? p[b0 + b] : (uint8_t)0);
+            k >>= shift;                                     // the chunk's bytes that can be real (the longest token decides), right-aligned
         }
         keys[q] = k;
     }
@@ -256,11 +257,15 @@ extern "C" int cdr_overlap_remap_dev(void* stream, const uint8_t* src_bytes, con
     unsigned len_bits = 1;
     while (len_bits < 64 && (h[1] >> len_bits)) ++len_bits;
     for (int j = -1, left = K + 1; left > 0; --left, j = left - 1) {          // j = -1, K - 1, K - 2, ..., 0
-        rd_keys_kernel<<<dim3(grid_for(nv)), dim3(kBlock), 0, s>>>(t, list[cur], nv, j, keys[0]);
+        const int64_t real = j < 0 ? 0 : ((int64_t)h[1] - 8 * (int64_t)j >= 8 ? 8 : (int64_t)h[1] - 8 * (int64_t)j);
+        rd_keys_kernel<<<dim3(grid_for(nv)), dim3(kBlock), 0, s>>>(t, list[cur], nv, j, (int)(64 - 8 * real), keys[0]);
         CDR_LAUNCH_CHECK();
         tb = L.tmp_bytes;
+        // only the key bits that can differ are sorted on: the length needs len_bits; chunk j holds min(8, longest - 8 j) real bytes
+        // (tokens of up to 9 bytes: 1 + 1 + 8 digit passes of 8 bits instead of 1 + 8 + 8)
+        const unsigned hi = j < 0 ? len_bits : (unsigned)(8 * real);          // (rd_keys_kernel right-aligns the chunk's real bytes: bits [0, hi))
         CDR_HIP(rocprim::radix_sort_pairs(tmp, tb, (const uint64_t*)keys[0], keys[1], (const uint32_t*)list[cur], list[cur ^ 1], (size_t)nv, 0u,
-                                          j < 0 ? len_bits : 64u, s));
+                                          hi, s));
         cur ^= 1;
     }
     if (passes_out) *passes_out = K + 1;
