@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 47
+#define CDR_ABI_VERSION 48
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -579,6 +579,18 @@ int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float* user_tab,
                            float beta2, float eps, float weight_decay, int64_t* step_user_dev, int64_t* step_item_dev, float* hp_dev,
                            float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
                            void* sort_ws, size_t sort_ws_bytes);
+
+/* The pointwise step -- (user, item, label) rows of EMCDR's default MF model (emcdr.py:111-122: MSE on the raw dot) and CMF (cmf.py:75-99:
+ * BCE on sigmoid(dot)) with reg_weight * EmbLoss(U[uid], I[iid]) -- as ONE call on the forward-and-update pass: rows that occur once in the
+ * batch are updated by the kernel that gathers them, duplicate rows through GU / GI and the segmented applies.  Replaces
+ * cdr_point_fwd_grad -> cdr_sort_ids_two_tables -> cdr_rowwise_apply x 2.  loss_kind: CDR_LOSS_MSE | CDR_LOSS_BCE.  Buffers as
+ * cdr_bpr_step_fused's for B rows: keys / perm [2 B], flags [4 B] (4-byte aligned), heads cdr_bpr_step_fused_heads_words(B) words,
+ * GU / GI [B, D], sort workspace cdr_sort_workspace_bytes(2 B, 2 * next power of two of the larger row count). */
+int cdr_point_step_fused(cdr_ctx* ctx, void* stream, int loss_kind, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,
+                         float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D, const int64_t* uid, const int64_t* iid,
+                         const float* label, int64_t B, float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int64_t step_user, int64_t step_item, float* out9, float* GU, float* GI, uint32_t* keys, uint32_t* perm,
+                         uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes);
 
 /* ---- the fused single-occurrence update inside the two multi-GPU layouts (reference math emcdr.py:110-154 on sharded tables:
  * the reference itself is single-device, parity = the one-GPU result).

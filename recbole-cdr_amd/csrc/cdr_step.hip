@@ -820,6 +820,83 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
     }
 }
 
+// The pointwise rows (user, item, label) -- EMCDR's default MF latent factor model (emcdr.py:111-122: MSE on the raw dot) and CMF's BCE
+// (cmf.py:75-99) -- through the same forward-and-update pass (round 5): flags4[t] byte 0 / byte 1 = the row's user / item occurs once in the
+// batch; such a row is updated in place from registers (gradient g v resp. g u plus its EmbLoss term), a duplicate row's gradient row goes
+// to GU[t] / GI[t] for the segmented apply.  Same prefetch discipline as bpr_fwd_apply_kernel (ids, labels and flags of the next iteration
+// requested behind this iteration's row loads and waited for before its stores).
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
+                                                                 const int64_t* __restrict__ iid, const float* __restrict__ label,
+                                                                 const uint32_t* __restrict__ flags4, int64_t B, float invB,
+                                                                 const float* __restrict__ coef, apply_hp hu, apply_hp hi,
+                                                                 float* __restrict__ GU, float* __restrict__ GI, double* __restrict__ partials) {
+    HP_FROM_DEV(hu); HP_FROM_DEV(hi);
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const bool live = sub < (D >> 2);
+    const float cu = coef[0], ci = coef[1];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    double acc[3] = {0.0, 0.0, 0.0};
+    uint32_t iu, ii, fl; float yl;
+    {
+        const int64_t tc = gg < B ? gg : B - 1;
+        iu = (uint32_t)uid[tc]; ii = (uint32_t)iid[tc]; fl = flags4[tc]; yl = label[tc];
+    }
+    asm volatile("" : "+v"(iu), "+v"(ii), "+v"(fl), "+v"(yl));
+    for (int64_t t = gg; t < B; t += TG) {
+        const bool fu = (fl & 0xFFu) != 0, fi = (fl & 0xFF00u) != 0;
+        const int64_t ou = (int64_t)iu * D + 4 * sub, oi = (int64_t)ii * D + 4 * sub;
+        float4 u = live ? ld4(TU.W + ou) : z4, v = live ? ld4(TI.W + oi) : z4;
+        float4 um = z4, uv = z4, im = z4, iv = z4;
+        if (OPT == 1) {
+            if (live && fu) { um = ld4(TU.M + ou); uv = ld4(TU.V + ou); }
+            if (live && fi) { im = ld4(TI.M + oi); iv = ld4(TI.V + oi); }
+        }
+        uint32_t ju, ji, gl; float yn;
+        {
+            const int64_t tn = t + TG, tc = tn < B ? tn : B - 1;
+            ju = (uint32_t)uid[tc]; ji = (uint32_t)iid[tc]; gl = flags4[tc]; yn = label[tc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float dx = group_sum<LPR>(dot4(u, v));
+        const float su = group_sum<LPR>(dot4(u, u));
+        const float si = group_sum<LPR>(dot4(v, v));
+        float l, g;
+        if (loss_kind == CDR_LOSS_MSE) {
+            const float d = dx - yl;
+            l = d * d; g = 2.0f * d * invB;
+        } else {                                               // torch BCELoss on sigmoid(dot): -100 log clamp, 1e-12 backward clamp
+            const float p = sigmoidf_(dx);
+            l = (yl - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - yl * fmaxf(logf(p), -100.0f);
+            const float pq = (1.0f - p) * p;
+            g = (p - yl) / fmaxf(pq, 1e-12f) * invB * pq;
+        }
+        asm volatile("" : "+v"(ju), "+v"(ji), "+v"(gl), "+v"(yn));        // every request of this iteration has returned: stores below wait on nothing older
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 gu = make_float4(g * v.x, g * v.y, g * v.z, g * v.w);
+        const float4 gi = make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
+        if (fu) {
+            const float4 wu = upd_math<OPT>(u, um, uv, gu, cu, hu);
+            if (live) { if (OPT == 1) { st4(TU.M + ou, um); st4(TU.V + ou, uv); } st4(TU.W + ou, wu); }
+        } else if (live) st4(GU + t * D + 4 * sub, gu);
+        if (fi) {
+            const float4 wi = upd_math<OPT>(v, im, iv, gi, ci, hi);
+            if (live) { if (OPT == 1) { st4(TI.M + oi, im); st4(TI.V + oi, iv); } st4(TI.W + oi, wi); }
+        } else if (live) st4(GI + t * D + 4 * sub, gi);
+        if (sub == 0) { acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si; }
+        iu = ju; ii = ji; fl = gl; yl = yn;
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
 // The same idea on recbole's pairwise batch layout (S positives tiled k times, negatives k-major: crossdomain_sampler.py:148-152;
 // csrc/cdr_kstep.hip): one lane group per POSITIVE gathers u and p once and its k negatives; every row among them that occurs once
 // in the step's lists (users [S]; items [pid | nid]) is updated in place from registers -- user: sum_m g_m (p - n_m) + k c_u u,
@@ -1489,6 +1566,68 @@ extern "C" int cdr_bpr_step_fused_dev(cdr_ctx* ctx, void* stream, int opt, float
                                keys, perm, flags, heads, sort_ws, sort_ws_bytes);
 }
 
+
+// ---- round 5: the pointwise step (EMCDR-MF / CMF rows: emcdr.py:111-122, cmf.py:75-99) as ONE call on the forward-and-update pass ---------
+// Same structure as cdr_bpr_step_fused with two rows per batch row: EmbLoss norms of (U[uid], I[iid]) -> coefficients, ONE sort of both
+// id lists + occurrence flags, point_fwd_apply_kernel (rows occurring once updated in place), segmented applies over the duplicate rows.
+// Buffers as cdr_bpr_step_fused's with B = the number of (user, item, label) rows: keys / perm [2 B], flags [4 B], heads
+// cdr_bpr_step_fused_heads_words(B) words, GU / GI [B, D], sort workspace cdr_sort_workspace_bytes(2 B, ...).
+extern "C" int cdr_point_step_fused(cdr_ctx* ctx, void* stream, int loss_kind, int opt, float* user_tab, float* user_m, float* user_v,
+                                    int64_t user_rows, float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D,
+                                    const int64_t* uid, const int64_t* iid, const float* label, int64_t B, float reg_weight, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item,
+                                    float* out9, float* GU, float* GI, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                                    void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && out9 && GU && GI && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG((loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE) && D > 0 && (D & 3) == 0 && D <= 256 && B > 0 && 2 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    if (reg_weight != 0.f) {
+        const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
+        {
+            cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+            DISPATCH_LPR(lpr, batch_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, iid, B, ctx->partials));
+        }
+        CDR_LAUNCH_CHECK();
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, reg_weight, out9, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, (unsigned*)heads);
+    } else {
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, 0.f, out9, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, (unsigned*)heads);
+    }
+    CDR_LAUNCH_CHECK();
+    uint32_t key_base = 0;
+    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, iid, B, nullptr, 0, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    unsigned* cnt = (unsigned*)heads;
+    uint32_t* headsA = heads + 4;
+    uint32_t* headsB = headsA + (B / 2 + 1);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(grid_for(2 * B, kBlock * kFlagIT)), dim3(kBlock), 0, s>>>(keys, perm, B, 2 * B, 4, flags, headsA, headsB, cnt);
+    }
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
+    const int grid = grid_for(B, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_POINT_FWD_GRAD, s);
+#define PA_ARGS loss_kind, TU, TI, D, uid, iid, label, (const uint32_t*)flags, B, 1.0f / (float)B, out9 + 4, hu, hi, GU, GI, ctx->partials
+        if (opt == 0) { DISPATCH_LPR(lpr, point_fwd_apply_kernel<L, 0><<<dim3(grid), dim3(kBlock), 0, s>>>(PA_ARGS)); }
+        else { DISPATCH_LPR(lpr, point_fwd_apply_kernel<L, 1><<<dim3(grid), dim3(kBlock), 0, s>>>(PA_ARGS)); }
+#undef PA_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, B, headsA, cnt, GU, B, B, out9 + 4, hu, 0},
+                               {item_tab, item_m, item_v, keys + B, perm + B, B, headsB, cnt + 1, GI, B, B, out9 + 5, hi, key_base}};
+    dups_plan pl;
+    rc = dups_plan_make(ctx, D, sides, pl);
+    if (rc) return rc;
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, D, pl);
+}
 
 // ---- round 5: the fused single-occurrence update inside the two multi-GPU layouts -----------------------------------
 // DIMENSION shard (cdr_dimshard.hip): the step is cut in two around the all-reduce of the partial scores.

@@ -345,7 +345,7 @@ class NativePointDimOps(NativeDimOps):
         from . import binding as B_
         from .fused import FusedPointStep
         self.B_ = B_
-        self.fs = FusedPointStep(user_cols, item_cols, max_global_batch, **kw)
+        self.fs = FusedPointStep(user_cols, item_cols, max_global_batch, fuse_singles=False, **kw)      # (the two halves around the all-reduce: the two-pass form)
         self.out = self.fs.out6
 
     def partial(self, uid, iid, label, dot):

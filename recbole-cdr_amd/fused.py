@@ -343,7 +343,7 @@ class FusedPointStep:
     on sigmoid(dot), plus ``reg_weight * EmbLoss(u_rows, i_rows)``; both tables updated row-wise on the batch's rows."""
 
     def __init__(self, user_table, item_table, max_batch, loss='mse', opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, reg_weight=0.0, user_state=None, item_state=None):
+                 weight_decay=0.0, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True):
         assert user_table.is_cuda and item_table.is_cuda, 'FusedPointStep needs ROCm device tensors'
         assert user_table.shape[1] == item_table.shape[1]
         self.U, self.I = user_table, item_table
@@ -368,11 +368,28 @@ class FusedPointStep:
                   'cdr_sort_workspace_bytes')
         self.ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
         self._key_base = ctypes.c_uint32(0)
+        # round 5: rows that occur once in the batch are updated by the forward kernel itself (cdr_point_step_fused), as in FusedBPRStep;
+        # fuse_singles=False (or CDR_FUSE_SINGLES=0) keeps the two-pass form (the dimension-sharded step drives its halves)
+        self.fuse_singles = bool(fuse_singles) and self.D % 4 == 0 and self.D <= 256 and os.environ.get('CDR_FUSE_SINGLES', '1') != '0'
+        if self.fuse_singles:
+            words = ctypes.c_int64(0)
+            B_._check(B_.load().cdr_bpr_step_fused_heads_words(Bm, ctypes.byref(words)), 'cdr_bpr_step_fused_heads_words')
+            self.flags = torch.zeros(4 * Bm, device=dev, dtype=torch.uint8)      # {user, item, -, -} per row
+            self.heads = torch.empty(int(words.value), device=dev, dtype=torch.int32)
 
     def step(self, uid, iid, label):
         """uid / iid int64 [B], label fp32 [B].  Returns out6 (view; [0] = total loss)."""
         B = uid.numel()
         assert B <= self.max_batch
+        if self.fuse_singles:
+            us, its = self.ustate, self.istate
+            us.advance(); its.advance()
+            B_.call('cdr_point_step_fused', B_.ctx(self.U.device), B_.stream(), self.kind, self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
+                    B_.f32(us.exp_avg_sq), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq), its.table.shape[0],
+                    self.D, B_.i64(uid), B_.i64(iid), B_.f32(label), B, float(self.reg_weight), float(self.lr), float(self.betas[0]),
+                    float(self.betas[1]), float(self.eps), float(self.wd), us.step, its.step, B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI),
+                    B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws.numel())
+            return self.out6
         B_.call('cdr_point_fwd_grad', B_.ctx(self.U.device), B_.stream(), self.kind, B_.f32(self.U), B_.f32(self.I), self.D, B_.i64(uid),
                 B_.i64(iid), B_.f32(label), B, float(self.reg_weight), B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI))
         return self.sort_apply(uid, iid)

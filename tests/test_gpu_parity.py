@@ -2534,6 +2534,45 @@ def test_fused_point_step_vs_oracle(loss, opt, D):
             si.m.copy_(fs.istate.exp_avg.cpu()); si.v.copy_(fs.istate.exp_avg_sq.cpu())
 
 
+@pytest.mark.parametrize('loss', ['mse', 'bce'])
+@pytest.mark.parametrize('opt,D', [('adam', 128), ('sgd', 64), ('adam', 20)])
+def test_fused_point_step_one_call_equals_two_pass(loss, opt, D):
+    """Round 5: cdr_point_step_fused (rows occurring once updated by the forward kernel, duplicate rows through the segmented applies)
+    against the two-pass form it replaces (cdr_point_fwd_grad -> sort -> cdr_rowwise_apply x 2) over three free-running steps of 30,000
+    rows in recbole's pointwise layout (every user twice: positive + sampled negative), with a hot item (thousands of occurrences: the
+    piece path), a hot user and rows outside the batch untouched; and bit-reproducible on a rerun."""
+    from recbole_cdr_amd.fused import FusedPointStep
+    torch.manual_seed(D + len(loss))
+    nu, ni, S, lr, reg = 40000, 25000, 15000, 0.01, 0.02
+    U, I = torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1
+    def batches():
+        g = torch.Generator().manual_seed(5)
+        for step in range(3):
+            u = torch.randint(1, nu, (S,), generator=g); p = torch.randint(1, ni, (S,), generator=g); n = torch.randint(1, ni, (S,), generator=g)
+            if step == 1:
+                p[:4000] = 11; n[200:900] = 11; u[5000:5100] = 42
+            yield torch.cat([u, u]).to(DEV), torch.cat([p, n]).to(DEV), torch.cat([torch.ones(S), torch.zeros(S)]).to(DEV)
+    runs = []
+    for fuse in (True, False, True):
+        Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+        fs = FusedPointStep(Ud, Id, 2 * S, loss=loss, opt=opt, lr=lr, reg_weight=reg, fuse_singles=fuse)
+        assert fs.fuse_singles == fuse
+        losses = [fs.step(*b)[0].clone() for b in batches()]
+        runs.append((torch.stack(losses), Ud, Id, fs.ustate.exp_avg, fs.istate.exp_avg_sq, fs.ustate.step, fs.istate.step))
+    a, b, c = runs
+    assert a[5] == b[5] == 3 and a[6] == b[6] == 3
+    assert_close(a[0], b[0], rtol=1e-6, what='losses')
+    atol = lr * 1e-2 if opt == 'adam' else 1e-7
+    assert_close(a[1], b[1], rtol=1e-5, atol=atol, what='users'); assert_close(a[2], b[2], rtol=1e-5, atol=atol, what='items')
+    if opt == 'adam':
+        assert_close(a[3], b[3], what='exp_avg users'); assert_close(a[4], b[4], what='exp_avg_sq items')
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]), 'the one-call step must be bit-reproducible'
+    untouched = torch.ones(nu, dtype=torch.bool); 
+    for u, _, _ in batches():
+        untouched[u.cpu()] = False
+    assert torch.equal(a[1].cpu()[untouched], U[untouched]), 'rows outside the batches must not move'
+
+
 def test_trainer_rowwise_mode_mf():
     """optimizer_mode='rowwise' with EMCDR's DEFAULT latent factor model (MF, pointwise labels): two SOURCE epochs and one
     OVERLAP epoch against the oracle's row-wise steps."""
