@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 48
+#define CDR_ABI_VERSION 49
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -591,6 +591,19 @@ int cdr_point_step_fused(cdr_ctx* ctx, void* stream, int loss_kind, int opt, flo
                          const float* label, int64_t B, float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int64_t step_user, int64_t step_item, float* out9, float* GU, float* GI, uint32_t* keys, uint32_t* perm,
                          uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes);
+
+/* The same step per POSITIVE, for recbole's pointwise batch layout (TrainDataLoader._neg_sampling under data/dataloader.py:114-162): uid [S]
+ * (the first S entries of the user column tiled 1 + k times), iid [S + S k] = [positives | k-major negatives], label [S + S k].  In that
+ * layout every user row occurs 1 + k times, so the per-row call above finds no user that occurs once; here the user row of a positive is
+ * gathered once, its gradient over the 1 + k rows summed in registers, and a user that occurs in one positive is updated in place.  Sizes
+ * of flags / heads from cdr_bpr_step_fused_kmajor_sizes(S, k); GU [S, D], GI [S + S k, D]; keys / perm [2 S + S k]; out12: 12 floats
+ * (out12[9] = the user coefficient per list occurrence, scratch). */
+int cdr_point_step_fused_kmajor(cdr_ctx* ctx, void* stream, int loss_kind, int opt, float* user_tab, float* user_m, float* user_v,
+                                int64_t user_rows, float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D,
+                                const int64_t* uid, const int64_t* iid, const float* label, int64_t S, int k, float reg_weight, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int64_t step_user, int64_t step_item, float* out12,
+                                float* GU, float* GI, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws,
+                                size_t sort_ws_bytes);
 
 /* ---- the fused single-occurrence update inside the two multi-GPU layouts (reference math emcdr.py:110-154 on sharded tables:
  * the reference itself is single-device, parity = the one-GPU result).

@@ -994,6 +994,145 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs T
     }
 }
 
+// ---- pointwise rows per POSITIVE (round 5) ---------------------------------------------------------------------------------------------
+// recbole's pointwise batch (TrainDataLoader._neg_sampling, driven by data/dataloader.py:114-162): S positives, the user column tiled 1 + k
+// times, items = [positives | k-major negatives], labels = [1] * S + [0] * S k.  In that layout EVERY user row occurs 1 + k times, so the
+// per-row kernel above never finds a user that occurs once; here one lane group takes a positive with its k negatives: the user row is
+// gathered once, its gradient sum_r g_r i_r accumulated in registers, and a user that occurs in ONE positive is updated in place (EmbLoss
+// count 1 + k); every item row among the 1 + k that occurs once in [pid | nid] is updated in place (g_r u, EmbLoss count 1).  Lists, flags
+// and gradient buffers exactly as bpr_fwd_apply_kmajor_kernel's: users [S] -> GU [S, D]; items [pid | nid] -> GI [S + S k, D].
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void point_norms_kmajor_kernel(const float* __restrict__ U, const float* __restrict__ I, int D,
+                                                                    const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int64_t S,
+                                                                    int k, double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[2 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const bool live = sub < (D >> 2);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    double acc[2] = {0.0, 0.0};
+    for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; j < S; j += (int64_t)gridDim.x * GPB) {
+        const float4 u = live ? ld4(U + uid[j] * D + 4 * sub) : z4;
+        float si = 0.f;
+        for (int r0 = 0; r0 <= k; r0 += 4) {                       // four item rows in flight
+            float4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (live && r0 + c <= k) ? ld4(I + iid[j + (int64_t)(r0 + c) * S] * D + 4 * sub) : z4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) si += dot4(v[c], v[c]);
+        }
+        const float su = group_sum<LPR>(dot4(u, u)), st = group_sum<LPR>(si);
+        if (sub == 0) { acc[0] += (double)(1 + k) * (double)su; acc[1] += (double)st; }
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+// out9[4], out9[5] = reg_weight / (B ||rows||) as coef_finish_kernel; out9[9] = (1 + k) out9[4]: the user coefficient per LIST occurrence
+__global__ __launch_bounds__(kBlock) void point_coef_kmajor_kernel(const double* __restrict__ partials, int nblocks, int64_t B, int k,
+                                                                   float reg_weight, float* __restrict__ out9, unsigned* __restrict__ zero4) {
+    __shared__ double smem[2 * (kBlock / 64)];
+    if (zero4 && threadIdx.x >= 64 && threadIdx.x < 68) zero4[threadIdx.x - 64] = 0u;
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1];
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        const float nu = (float)sqrt(acc[0]), ni = (float)sqrt(acc[1]);
+        out9[4] = (reg_weight != 0.f && nu > 0.f) ? reg_weight / ((float)B * nu) : 0.f;
+        out9[5] = (reg_weight != 0.f && ni > 0.f) ? reg_weight / ((float)B * ni) : 0.f;
+        out9[9] = (float)(1 + k) * out9[4];
+    }
+}
+
+template <int LPR, int OPT, int KC>
+__global__ __launch_bounds__(kBlock) void point_fwd_apply_kmajor_kernel(int loss_kind, tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
+                                                                        const int64_t* __restrict__ iid, const float* __restrict__ label,
+                                                                        const uint8_t* __restrict__ flags, int fstride, int64_t S, int k,
+                                                                        float invB, const float* __restrict__ coef, apply_hp hu, apply_hp hi,
+                                                                        float* __restrict__ GU, float* __restrict__ GI,
+                                                                        double* __restrict__ partials) {
+    HP_FROM_DEV(hu); HP_FROM_DEV(hi);
+    constexpr int GPB = kBlock / LPR;
+    __shared__ double smem[3 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const bool live = sub < (D >> 2);
+    const float cu = coef[5], ci = coef[1];                 // coef = out9 + 4: {c_u, c_i, ..., (1 + k) c_u at out9[9]}
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; j < S; j += (int64_t)gridDim.x * GPB) {
+        const uint8_t* fl = flags + j * fstride;
+        const int64_t iu = uid[j];
+        const bool fu = fl[0] != 0;
+        const int64_t ou = iu * D + 4 * sub;
+        float4 u = z4, um = z4, uv = z4;
+        if (live) {
+            u = ld4(TU.W + ou);
+            if (OPT == 1 && fu) { um = ld4(TU.M + ou); uv = ld4(TU.V + ou); }
+        }
+        float4 gu = z4;
+        float su = 0.f;
+        for (int r0 = 0; r0 <= k; r0 += KC) {                   // item rows r = 0 (the positive), 1 .. k (negatives), KC at a time
+            int64_t oi[KC]; bool fi[KC]; float yl[KC];
+            float4 v[KC], vm[KC], vv[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int r = r0 + c <= k ? r0 + c : k;
+                oi[c] = iid[j + (int64_t)r * S] * D + 4 * sub;
+                fi[c] = fl[1 + r] != 0 && r0 + c <= k;
+                yl[c] = label[j + (int64_t)r * S];
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                v[c] = live ? ld4(TI.W + oi[c]) : z4;
+                vm[c] = vv[c] = z4;
+                if (OPT == 1 && live && fi[c]) { vm[c] = ld4(TI.M + oi[c]); vv[c] = ld4(TI.V + oi[c]); }
+            }
+            if (r0 == 0) su = group_sum<LPR>(dot4(u, u));
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const float dx = group_sum<LPR>(dot4(u, v[c]));
+                const float si = group_sum<LPR>(dot4(v[c], v[c]));
+                if (r0 + c <= k) {
+                    const float y = yl[c];
+                    float l, g;
+                    if (loss_kind == CDR_LOSS_MSE) {
+                        const float d = dx - y;
+                        l = d * d; g = 2.0f * d * invB;
+                    } else {
+                        const float p = sigmoidf_(dx);
+                        l = (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+                        const float pq = (1.0f - p) * p;
+                        g = (p - y) / fmaxf(pq, 1e-12f) * invB * pq;
+                    }
+                    gu.x += g * v[c].x; gu.y += g * v[c].y; gu.z += g * v[c].z; gu.w += g * v[c].w;
+                    if (sub == 0) { acc[0] += (double)l; acc[2] += (double)si; }
+                    const float4 gi = make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
+                    if (fi[c]) {
+                        const float4 wi = upd_math<OPT>(v[c], vm[c], vv[c], gi, ci, hi);
+                        if (live) { if (OPT == 1) { st4(TI.M + oi[c], vm[c]); st4(TI.V + oi[c], vv[c]); } st4(TI.W + oi[c], wi); }
+                    } else if (live) st4(GI + (j + (int64_t)(r0 + c) * S) * D + 4 * sub, gi);
+                }
+            }
+        }
+        if (sub == 0) acc[1] += (double)(1 + k) * (double)su;
+        if (fu) {
+            const float4 wu = upd_math<OPT>(u, um, uv, gu, cu, hu);
+            if (live) { if (OPT == 1) { st4(TU.M + ou, um); st4(TU.V + ou, uv); } st4(TU.W + ou, wu); }
+        } else if (live) st4(GU + j * D + 4 * sub, gu);
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
 // The segmented apply over the DUPLICATE segments only: heads[0 .. *nheads) are the sorted positions of their first occurrences
 // (any order: every segment is summed by one lane group in occurrence order, whoever takes it).  Long segments as in
 // rowwise_apply_kernel.
@@ -1625,6 +1764,66 @@ extern "C" int cdr_point_step_fused(cdr_ctx* ctx, void* stream, int loss_kind, i
     rc = dups_plan_make(ctx, D, sides, pl);
     if (rc) return rc;
     step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, D, pl);
+}
+
+// The pointwise step per POSITIVE: uid [S] (the first S entries of recbole's tiled user column), iid [S + S k] = [positives | k-major
+// negatives], label [S + S k].  Sizes from cdr_bpr_step_fused_kmajor_sizes(S, k); GU [S, D], GI [S + S k, D]; keys / perm [2 S + S k].
+extern "C" int cdr_point_step_fused_kmajor(cdr_ctx* ctx, void* stream, int loss_kind, int opt, float* user_tab, float* user_m, float* user_v,
+                                           int64_t user_rows, float* item_tab, float* item_m, float* item_v, int64_t item_rows, int D,
+                                           const int64_t* uid, const int64_t* iid, const float* label, int64_t S, int k, float reg_weight,
+                                           float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step_user,
+                                           int64_t step_item, float* out12, float* GU, float* GI, uint32_t* keys, uint32_t* perm,
+                                           uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && out12 && GU && GI && keys && perm && flags && heads && sort_ws);
+    CDR_CHECK_ARG((loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE) && D > 0 && (D & 3) == 0 && D <= 256 && S > 0 && k >= 1 && k <= 64);
+    const int64_t nI = S + S * (int64_t)k, B = nI;
+    CDR_CHECK_ARG(S + nI <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const int fstride = (2 + k + 3) & ~3;
+    const int ngrid = reg_weight != 0.f ? grid_for(S, kBlock / lpr) : 0;
+    if (reg_weight != 0.f) {
+        cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+        DISPATCH_LPR(lpr, point_norms_kmajor_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, iid, S, k, ctx->partials));
+        CDR_LAUNCH_CHECK();
+    }
+    point_coef_kmajor_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, B, k, reg_weight, out12, (unsigned*)heads);
+    CDR_LAUNCH_CHECK();
+    uint32_t key_base = 0;
+    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, S, user_rows, iid, S, iid + S, S * (int64_t)k, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    unsigned* cnt = (unsigned*)heads;
+    uint32_t* headsA = heads + 4;
+    uint32_t* headsB = headsA + (S / 2 + 1);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(grid_for(S + nI, kBlock * kFlagIT)), dim3(kBlock), 0, s>>>(keys, perm, S, S + nI, fstride, flags, headsA, headsB, cnt);
+    }
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
+    const int grid = grid_for(S, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_POINT_FWD_GRAD, s);
+#define PK_ARGS loss_kind, TU, TI, D, uid, iid, label, flags, fstride, S, k, 1.0f / (float)B, out12 + 4, hu, hi, GU, GI, ctx->partials
+        if (opt == 0) { DISPATCH_LPR(lpr, point_fwd_apply_kmajor_kernel<L, 0, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(PK_ARGS)); }
+        else if (k <= 1) { DISPATCH_LPR(lpr, point_fwd_apply_kmajor_kernel<L, 1, 2><<<dim3(grid), dim3(kBlock), 0, s>>>(PK_ARGS)); }
+        else { DISPATCH_LPR(lpr, point_fwd_apply_kmajor_kernel<L, 1, 3><<<dim3(grid), dim3(kBlock), 0, s>>>(PK_ARGS)); }
+#undef PK_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    // duplicate rows: users over GU [S, D] with (1 + k) c_u per list occurrence (out12[9]); items over GI [S + S k, D], every occurrence
+    // with c_i (reg_limit = the whole list)
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, S, headsA, cnt, GU, S, S, out12 + 9, hu, 0},
+                               {item_tab, item_m, item_v, keys + S, perm + S, nI, headsB, cnt + 1, GI, nI, nI, out12 + 5, hi, key_base}};
+    dups_plan pl;
+    rc = dups_plan_make(ctx, D, sides, pl);
+    if (rc) return rc;
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out12, pl.side[0].counters, pl.side[1].counters);
     CDR_LAUNCH_CHECK();
     return apply_dups_pair(ctx, s, opt, D, pl);
 }

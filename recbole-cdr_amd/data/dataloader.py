@@ -85,6 +85,7 @@ class DomainTrainLoader:
         lab = torch.zeros(S * self.times, device=users.device, dtype=torch.float32)
         lab[:S] = 1.0
         out[self.label_field] = lab
+        out.point_k = self.neg_k                 # layout hint for the per-positive pointwise step (fused.KMajorPointStep)
         return out
 
 

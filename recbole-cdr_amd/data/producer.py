@@ -53,6 +53,7 @@ class DeviceBatchProducer:
                 lab = torch.zeros(n, device=dev, dtype=torch.float32)
                 lab[:self.S] = 1.0                                    # recbole's pointwise layout: [1] * S + [0] * (S k); never changes
                 self.fields = Interaction({loader.uid_field: self.out_users, loader.iid_field: self.out_items, loader.label_field: lab})
+                self.fields.point_k = self.k
             else:
                 self.out_neg = torch.zeros(n, device=dev, dtype=torch.int64)
                 self.fields = Interaction({loader.uid_field: self.out_users, loader.iid_field: self.out_items,
@@ -71,6 +72,8 @@ class DeviceBatchProducer:
         nf = Interaction({k: (v if (k == getattr(self.loader, 'label_field', None) and self.pointwise) else torch.zeros_like(v)) for k, v in f.items()})
         if getattr(f, 'k_major', None) is not None:
             nf.k_major = f.k_major
+        if getattr(f, 'point_k', None) is not None:
+            nf.point_k = f.point_k
         if self.kind == 'overlap':
             self._slots.append((nf[self.loader.field], None, None, nf))
         else:

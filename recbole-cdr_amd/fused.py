@@ -416,6 +416,59 @@ class FusedPointStep:
         return self.out6
 
 
+class KMajorPointStep:
+    """``FusedPointStep`` cut along recbole's pointwise batch layout: S positives, the user column tiled 1 + k times, items =
+    [positives | k-major negatives], labels [1] * S + [0] * S k (TrainDataLoader._neg_sampling).  One lane group per POSITIVE gathers
+    the user row once and sums its gradient over the 1 + k rows in registers; users that occur in one positive and item rows that occur
+    once are updated by that kernel, the rest by the segmented applies (csrc/cdr_step.hip: point_fwd_apply_kmajor_kernel).  Same loss
+    and per-row gradients as ``FusedPointStep`` on the S (1 + k) rows."""
+
+    def __init__(self, user_table, item_table, max_positives, k=1, loss='mse', opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, reg_weight=0.0, user_state=None, item_state=None):
+        assert user_table.is_cuda and item_table.is_cuda, 'KMajorPointStep needs ROCm device tensors'
+        assert user_table.shape[1] == item_table.shape[1] and user_table.shape[1] % 4 == 0 and user_table.shape[1] <= 256 and 1 <= int(k) <= 64
+        self.U, self.I = user_table, item_table
+        self.D, self.k = user_table.shape[1], int(k)
+        self.kind = B_.CDR_LOSS_MSE if loss == 'mse' else B_.CDR_LOSS_BCE
+        self.opt = OPT_ADAM if opt == 'adam' else OPT_SGD
+        self.lr, self.betas, self.eps, self.wd, self.reg_weight = lr, betas, eps, weight_decay, reg_weight
+        self.ustate = user_state if user_state is not None else RowwiseState(user_table, self.opt)
+        self.istate = item_state if item_state is not None else RowwiseState(item_table, self.opt)
+        dev = user_table.device
+        Sm = int(max_positives)
+        nI = Sm * (1 + self.k)
+        self.max_positives = Sm
+        self.max_batch = nI
+        self.GU = torch.empty(Sm, self.D, device=dev, dtype=torch.float32)
+        self.GI = torch.empty(nI, self.D, device=dev, dtype=torch.float32)
+        fb, hw = ctypes.c_int64(0), ctypes.c_int64(0)
+        B_._check(B_.load().cdr_bpr_step_fused_kmajor_sizes(Sm, self.k, ctypes.byref(fb), ctypes.byref(hw)), 'cdr_bpr_step_fused_kmajor_sizes')
+        self.flags = torch.zeros(int(fb.value), device=dev, dtype=torch.uint8)
+        self.heads = torch.empty(int(hw.value), device=dev, dtype=torch.int32)
+        self.out6 = torch.zeros(12, device=dev, dtype=torch.float32)
+        self.keys = torch.empty(Sm + nI, device=dev, dtype=torch.int32)
+        self.perm = torch.empty(Sm + nI, device=dev, dtype=torch.int32)
+        rows = max(user_table.shape[0], item_table.shape[0])
+        need = ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_sort_workspace_bytes(Sm + nI, 2 << (rows - 1).bit_length(), ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+        self.ws = torch.empty(int(need.value), device=dev, dtype=torch.uint8)
+
+    def step(self, uid, iid, label):
+        """uid int64 [S (1 + k)] tiled (or [S]: the first S entries are read), iid int64 [S (1 + k)], label fp32 [S (1 + k)].
+        Returns out6 (view; [0] = total loss)."""
+        n = iid.numel()
+        S = n // (1 + self.k)
+        assert S * (1 + self.k) == n and S <= self.max_positives and uid.numel() >= S and label.numel() == n
+        us, its = self.ustate, self.istate
+        us.advance(); its.advance()
+        B_.call('cdr_point_step_fused_kmajor', B_.ctx(self.U.device), B_.stream(), self.kind, self.opt, B_.f32(us.table), B_.f32(us.exp_avg),
+                B_.f32(us.exp_avg_sq), us.table.shape[0], B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq), its.table.shape[0],
+                self.D, B_.i64(uid), B_.i64(iid), B_.f32(label), S, self.k, float(self.reg_weight), float(self.lr), float(self.betas[0]),
+                float(self.betas[1]), float(self.eps), float(self.wd), us.step, its.step, B_.f32(self.out6), B_.f32(self.GU), B_.f32(self.GI),
+                B_.raw(self.keys), B_.raw(self.perm), B_.raw(self.flags), B_.raw(self.heads), B_.raw(self.ws), self.ws.numel())
+        return self.out6
+
+
 class FusedMapStep:
     """EMCDR's OVERLAP phase (emcdr.py:133-137 ``calculate_map_loss``: MSE(mapping(source_e[idx]), target_e[idx])) as an
     O(batch) step: the two embedding tables are updated row-wise on the overlapped ids only; the mapping function's own

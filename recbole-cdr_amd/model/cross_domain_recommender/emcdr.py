@@ -159,6 +159,22 @@ class EMCDR(CrossDomainRecommender):
         item = interaction[getattr(self, f'{domain.upper()}_ITEM_ID')].reshape(-1)
         if self.latent_factor_model == 'MF':
             label = interaction[getattr(self, f'{domain.upper()}_LABEL')].reshape(-1).float()
+            # recbole's pointwise batches tile S positives 1 + k times (Interaction.point_k, set by the loader): at large batches the
+            # per-positive step gathers each user row once and updates it in place (in this layout NO user row occurs once per row list)
+            pk = getattr(interaction, 'point_k', None)
+            rows = user.numel()
+            D_ = getattr(self, f'{domain}_user_embedding').weight.shape[1]
+            if pk is not None and 1 <= pk <= 64 and rows % (1 + pk) == 0 and rows > 8192 and D_ % 4 == 0 and D_ <= 256:
+                from ...fused import KMajorPointStep
+                key = ('mfk', domain, pk)
+                step = cache['steps'].get(key)
+                if step is None or step.max_positives < rows // (1 + pk):
+                    step = KMajorPointStep(getattr(self, f'{domain}_user_embedding').weight.data,
+                                           getattr(self, f'{domain}_item_embedding').weight.data, rows // (1 + pk), k=pk, loss='mse',
+                                           reg_weight=self.reg_weight, user_state=state(f'{domain}_user_embedding'),
+                                           item_state=state(f'{domain}_item_embedding'), **hp)
+                    cache['steps'][key] = step
+                return step.step(user, item, label)[0]
             key = ('mf', domain)
             step = cache['steps'].get(key)
             if step is None or step.max_batch < user.numel():

@@ -2573,6 +2573,80 @@ def test_fused_point_step_one_call_equals_two_pass(loss, opt, D):
     assert torch.equal(a[1].cpu()[untouched], U[untouched]), 'rows outside the batches must not move'
 
 
+@pytest.mark.parametrize('loss', ['mse', 'bce'])
+@pytest.mark.parametrize('opt,D,k', [('adam', 128, 1), ('adam', 64, 3), ('sgd', 32, 2), ('adam', 20, 5)])
+def test_kmajor_point_step_equals_per_row_step(loss, opt, D, k):
+    """Round 5: fused.KMajorPointStep (one lane group per positive: the user row gathered once, users that occur in one positive updated
+    in place with EmbLoss count 1 + k) against the per-row two-pass step on the SAME S (1 + k) rows of recbole's pointwise layout, three
+    free-running steps: losses, both tables, moments; with users shared by several positives, a negative equal to its own positive, a hot
+    item (thousands of occurrences) and rows outside the batches untouched; bit-reproducible on a rerun."""
+    from recbole_cdr_amd.fused import FusedPointStep, KMajorPointStep
+    torch.manual_seed(D + k)
+    nu, ni, S, lr, reg = 30000, 20000, 12000, 0.01, 0.02
+    U, I = torch.randn(nu, D) * 0.1, torch.randn(ni, D) * 0.1
+    def batches():
+        g = torch.Generator().manual_seed(9)
+        for step in range(3):
+            u = torch.randint(1, nu, (S,), generator=g); p = torch.randint(1, ni, (S,), generator=g)
+            n = torch.randint(1, ni, (S * k,), generator=g)
+            if step == 1:
+                p[:3000] = 11; n[200:900] = 11; u[5000:5100] = 42; n[7000] = p[7000]
+            y = torch.cat([torch.ones(S), torch.zeros(S * k)])
+            yield u.repeat(1 + k).to(DEV), torch.cat([p, n]).to(DEV), y.to(DEV)
+    runs = []
+    for form in ('kmajor', 'per_row', 'kmajor'):
+        Ud, Id = U.clone().to(DEV), I.clone().to(DEV)
+        if form == 'kmajor':
+            fs = KMajorPointStep(Ud, Id, S, k=k, loss=loss, opt=opt, lr=lr, reg_weight=reg)
+        else:
+            fs = FusedPointStep(Ud, Id, S * (1 + k), loss=loss, opt=opt, lr=lr, reg_weight=reg, fuse_singles=False)
+        losses = [fs.step(*b).clone() for b in batches()]
+        runs.append((torch.stack(losses)[:, :6], Ud, Id, fs.ustate.exp_avg, fs.istate.exp_avg_sq))
+    a, b, c = runs
+    assert_close(a[0], b[0], rtol=2e-6, what='loss, main, norms, coefficients of every step')
+    atol = lr * 1e-2 if opt == 'adam' else 1e-7
+    assert_close(a[1], b[1], rtol=1e-5, atol=atol, what='users'); assert_close(a[2], b[2], rtol=1e-5, atol=atol, what='items')
+    if opt == 'adam':
+        assert_close(a[3], b[3], what='exp_avg users'); assert_close(a[4], b[4], what='exp_avg_sq items')
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]), 'bit-reproducible'
+    untouched = torch.ones(ni, dtype=torch.bool)
+    for _, i_, _ in batches():
+        untouched[i_.cpu()] = False
+    assert torch.equal(a[2].cpu()[untouched], I[untouched]), 'item rows outside the batches must not move'
+
+
+def test_emcdr_mf_rowwise_large_batch_takes_the_per_positive_step():
+    """EMCDR's default MF model through ``fused_train_step`` on a loader-shaped pointwise batch (Interaction.point_k): above 8,192 rows the
+    per-positive step runs (cache key 'mfk') and lands on the per-row step's result."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.data.interaction import Interaction
+    from recbole_cdr_amd.model.cross_domain_recommender.emcdr import EMCDR
+    ids = IdSpace(OU=3000, TOU=2000, SOU=2500, OI=1, TOI=4000, SOI=4500)
+    ds = FakeDataset(ids, np.zeros((1, 2), np.int64), np.zeros((1, 2), np.int64))
+    cfg = base_config(DEV, latent_factor_model='MF', source_embedding_size=32, target_embedding_size=32, reg_weight=0.01,
+                      mapping_function='linear', mlp_hidden_size=[16], learning_rate=0.01)
+    S, k = 6000, 1
+    g = torch.Generator().manual_seed(2)
+    u = torch.randint(1, ids.OU + ids.TOU, (S,), generator=g); p = torch.randint(1, ids.target_num_items, (S,), generator=g)
+    n = torch.randint(1, ids.target_num_items, (S * k,), generator=g)
+    outs = []
+    for hint in (True, False):
+        torch.manual_seed(1)
+        m = EMCDR(cfg, ds).to(DEV)
+        m.set_phase('TARGET')
+        inter = Interaction({'target_user_id': u.repeat(1 + k).to(DEV), 'target_item_id': torch.cat([p, n]).to(DEV),
+                             'target_label': torch.cat([torch.ones(S), torch.zeros(S * k)]).to(DEV)})
+        if hint:
+            inter.point_k = k
+        ls = [float(m.fused_train_step(inter, lr=0.01)) for _ in range(2)]
+        keys = [kk[0] for kk in m.__dict__['_fused']['steps']]
+        assert ('mfk' in keys) == hint and ('mf' in keys) == (not hint), keys
+        outs.append((ls, m.target_user_embedding.weight.detach().clone(), m.target_item_embedding.weight.detach().clone()))
+    (la, Ua, Ia), (lb, Ub, Ib) = outs
+    assert_close(torch.tensor(la), torch.tensor(lb), rtol=2e-6, what='losses')
+    assert_close(Ua, Ub, rtol=1e-5, atol=1e-4, what='users'); assert_close(Ia, Ib, rtol=1e-5, atol=1e-4, what='items')
+
+
 def test_trainer_rowwise_mode_mf():
     """optimizer_mode='rowwise' with EMCDR's DEFAULT latent factor model (MF, pointwise labels): two SOURCE epochs and one
     OVERLAP epoch against the oracle's row-wise steps."""
