@@ -80,6 +80,9 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
         for name, leg in fs.items():
             if isinstance(leg, dict) and isinstance(leg.get('items_per_s'), (int, float)):
                 extra['fullsort_items_per_s_' + name.replace('=', '')] = leg['items_per_s']
+    mfp = result.get('mf_pointwise')
+    if isinstance(mfp, dict) and mfp.get('rows_per_s'):
+        extra['mf_pointwise_rows_per_s'] = mfp['rows_per_s']
     ing = result.get('ingest')
     if isinstance(ing, dict) and ing.get('value'):
         extra['ingest_tokens_per_s'] = ing['value']
@@ -817,6 +820,45 @@ def run_c5(args, world, rank, dev):
                                      'what': 'the SOURCE and the TARGET domain step of every benchmark step enqueued on two HIP streams (same kernels, same batches)'}
     except Exception as e:  # noqa: BLE001
         result.setdefault('leg_errors', {})['two_streams'] = repr(e)[:500]
+    try:
+        # ---- EMCDR's DEFAULT latent factor model (MF: pointwise MSE, emcdr.py:111-122) on recbole's pointwise layout at the headline's
+        # table sizes: S = B / 2 positives + one sampled negative each = B rows per domain step, the per-positive step against the per-row forms
+        if rank == 0 and not sharded and not getattr(args, 'no_extra_legs', False) and args.opt == 'adam' and D % 4 == 0 and D <= 256:
+            from recbole_cdr_amd.fused import KMajorPointStep, FusedPointStep
+            Sp = B // 2
+            st0 = steps['source']
+            mfb = []
+            for _ in range(4):
+                u_ = torch.randint(1, OU, (Sp,), device=dev, generator=gen)
+                it_ = torch.randint(1 + TOI, 1 + 2 * TOI, (2 * Sp,), device=dev, generator=gen)
+                mfb.append((u_.repeat(2), it_, torch.cat([torch.ones(Sp, device=dev), torch.zeros(Sp, device=dev)])))
+            mf = {}
+            for name, mk in (('per_positive', lambda: KMajorPointStep(tabs['su'], tabs['si'], Sp, k=1, loss='mse', opt='adam', reg_weight=0.01,
+                                                                      user_state=st0.ustate, item_state=st0.istate)),
+                             ('per_row_two_pass', lambda: FusedPointStep(tabs['su'], tabs['si'], 2 * Sp, loss='mse', opt='adam', reg_weight=0.01,
+                                                                         user_state=st0.ustate, item_state=st0.istate, fuse_singles=False))):
+                stp = mk()
+                for i in range(3):
+                    stp.step(*mfb[i % 4])
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                n_it = max(args.steps // 2, 5)
+                for i in range(n_it):
+                    stp.step(*mfb[i % 4])
+                torch.cuda.synchronize()
+                mf[name] = (time.perf_counter() - t0) / n_it * 1e3
+                del stp
+            rows_mf = 2 * Sp
+            result['mf_pointwise'] = {
+                'rows_per_domain_step': rows_mf, 'positives': Sp, 'k': 1, 'ms_per_domain_step': mf['per_positive'], 'rows_per_s': rows_mf / (mf['per_positive'] * 1e-3),
+                'per_row_two_pass_ms': mf['per_row_two_pass'], 'speedup_vs_two_pass': mf['per_row_two_pass'] / mf['per_positive'],
+                'frac_of_hbm_peak_at_6_x_4D_per_touched_row': (Sp * 6 * 4 * D + 2 * Sp * 6 * 4 * D) / (mf['per_positive'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'what': 'EMCDR-MF (pointwise MSE + EmbLoss) row-wise Adam step on recbole\'s pointwise batch layout (users tiled 1 + k times, '
+                        'items = [positives | negatives]) at the headline\'s table sizes: fused.KMajorPointStep (cdr_point_step_fused_kmajor) against '
+                        'the round-2 two-pass form; bytes model: 6 x 4D per distinct row touched (S user rows + 2 S item rows)'}
+            del mfb
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        result.setdefault('leg_errors', {})['mf_pointwise'] = repr(e)[:500]
     try:
         # ---- the per-positive (k-major) step at k = 4, and the reference-default 2,048-row batch as one hipGraph -------------
         if rank == 0 and not sharded and not getattr(args, 'no_extra_legs', False):
