@@ -433,14 +433,23 @@ class Trainer:
         FullSortEvalDataLoader; returns {metric@k: value} for recall / mrr / ndcg / hit / precision."""
         self.model.eval()
         kmax = max(self.topk)
-        hits, pos_len = [], []
         fused = self.fused_topk and hasattr(self.model, 'full_sort_topk')
         # recbole cuts the evaluated users so that the [U, N] score matrix fits eval_batch_size entries (ONE user per call over a 10 M-item
         # catalogue at the default 4,096).  The fused mask + top-k path never forms that matrix, so it re-cuts a loader that allows it
         # into throughput-sized batches (config['eval_users_per_batch'], default 1,024; 0 keeps recbole's cut): same users, same metrics
         want = int(self.config['eval_users_per_batch']) if 'eval_users_per_batch' in self.config else 1024
+        restore = None
         if fused and want > 0 and hasattr(eval_data, 'rebatch') and getattr(eval_data, 'step', want) < want:
+            restore = eval_data.step                      # (the caller's cut comes back afterwards: another consumer may need [U, N] to fit)
             eval_data.rebatch(want)
+        try:
+            return self._evaluate_batches(eval_data, fused, kmax)
+        finally:
+            if restore is not None:
+                eval_data.rebatch(restore)
+
+    def _evaluate_batches(self, eval_data, fused, kmax):
+        hits, pos_len = [], []
         for interaction, history_index, positive_u, positive_i in eval_data:
             interaction = interaction.to(self.device)
             n_user = len(interaction)

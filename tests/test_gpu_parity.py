@@ -2021,12 +2021,19 @@ def test_end_to_end_emcdr_learns_with_device_sampler():
         assert abs(res_t[k] - ref_t[k]) < 1e-6 and abs(res_s[k] - ref_s[k]) < 1e-6, (k, res_t[k], ref_t[k], res_s[k], ref_s[k])
     # Trainer.evaluate re-cut both loaders into throughput-sized user batches for the fused path (round 5); recbole's own cut
     # (eval_batch_size // item_num users per call: config['eval_users_per_batch'] = 0) gives the same metrics
-    assert valid[1].step == 1024
+    own_cut = max(4096 // ids.target_num_items, 1)
+    assert valid[1].step == own_cut                              # (the loader's own cut is back after every evaluate)
     trainer.fused_topk = True
+    seen = []
+    orig_rebatch = valid[1].rebatch
+    valid[1].rebatch = lambda n: (seen.append(n), orig_rebatch(n))[1]
+    again_t = trainer.evaluate(valid[1])
+    assert seen == [1024, own_cut], seen
     trainer.config = dict(trainer.config, eval_users_per_batch=0)
-    valid[1].rebatch(max(4096 // ids.target_num_items, 1))
     small_t = trainer.evaluate(valid[1])
-    assert valid[1].step == max(4096 // ids.target_num_items, 1)
+    assert seen == [1024, own_cut] and valid[1].step == own_cut
+    for k in res_t:
+        assert abs(res_t[k] - again_t[k]) < 1e-6, (k, res_t[k], again_t[k])
     for k in res_t:
         assert abs(res_t[k] - small_t[k]) < 1e-6, (k, res_t[k], small_t[k])
 
