@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 49
+#define CDR_ABI_VERSION 50
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -621,6 +621,17 @@ int cdr_bpr_step_from_diff(cdr_ctx* ctx, void* stream, int opt, float* user_tab,
                            float gamma, float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay,
                            int64_t step_user, int64_t step_item, const float* diff, uint32_t key_base, float* out9, float* GU, float* GP,
                            const uint32_t* keys, const uint32_t* perm, const uint8_t* flags, uint32_t* heads);
+/* The pointwise rows (EMCDR-MF / CMF) of the dimension layout, cut the same way around the all-reduce of cdr_point_partial_dot's output:
+ * cdr_point_step_presort (ids only) and cdr_point_step_from_dot (dot [B + 2] = all-reduced {<u, i> ..., sum u^2, sum i^2}); buffers as
+ * cdr_point_step_fused's. */
+int cdr_point_step_presort(cdr_ctx* ctx, void* stream, const int64_t* uid, const int64_t* iid, int64_t B, int64_t user_rows, int64_t item_rows,
+                           uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes,
+                           uint32_t* key_base_out);
+int cdr_point_step_from_dot(cdr_ctx* ctx, void* stream, int loss_kind, int opt, float* user_tab, float* user_m, float* user_v, float* item_tab,
+                            float* item_m, float* item_v, int Ds, const int64_t* uid, const int64_t* iid, const float* label, int64_t B,
+                            float reg_weight, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step_user,
+                            int64_t step_item, const float* dot, uint32_t key_base, float* out9, float* GU, float* GI, const uint32_t* keys,
+                            const uint32_t* perm, const uint8_t* flags, uint32_t* heads);
 /* ROW shard -- a rank's triples after user-aligned routing: local user rows u_loc, the item rows it asked for in `irows` (one row per
  * distinct item, indexed by ip / in).
  *   cdr_batch_norm_sums       sums3 = {0, sum ||U[u]||^2, sum ||irows[ip]||^2}: all-reduce over the ranks, then cdr_loss_finish_sums puts the

@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -125,6 +125,10 @@ _SIGNATURES = {
     'cdr_point_step_fused_kmajor': [_c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr,
                                     _c_ptr, _c_ptr, _c_i64, _c_int, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr,
                                     _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_point_step_presort': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t, _c_ptr],
+    'cdr_point_step_from_dot': [_c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_i64, _c_ptr, ctypes.c_uint32, _c_ptr, _c_ptr, _c_ptr,
+                                _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     'cdr_sort_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_timing_enable': [_c_ptr, _c_int],
     'cdr_timing_collect': [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_f32), _c_int, ctypes.POINTER(_c_int)],

@@ -825,12 +825,14 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
 // batch; such a row is updated in place from registers (gradient g v resp. g u plus its EmbLoss term), a duplicate row's gradient row goes
 // to GU[t] / GI[t] for the segmented apply.  Same prefetch discipline as bpr_fwd_apply_kernel (ids, labels and flags of the next iteration
 // requested behind this iteration's row loads and waited for before its stores).
-template <int LPR, int OPT>
+// XD: the row's dot <u, i> is GIVEN (xdot[t]: the all-reduced sum of every rank's column-slice partials, the dimension-sharded step).
+template <int LPR, int OPT, bool XD = false>
 __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
                                                                  const int64_t* __restrict__ iid, const float* __restrict__ label,
                                                                  const uint32_t* __restrict__ flags4, int64_t B, float invB,
                                                                  const float* __restrict__ coef, apply_hp hu, apply_hp hi,
-                                                                 float* __restrict__ GU, float* __restrict__ GI, double* __restrict__ partials) {
+                                                                 float* __restrict__ GU, float* __restrict__ GI, double* __restrict__ partials,
+                                                                 const float* __restrict__ xdot = nullptr) {
     HP_FROM_DEV(hu); HP_FROM_DEV(hi);
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
@@ -841,12 +843,13 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, 
     const float cu = coef[0], ci = coef[1];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     double acc[3] = {0.0, 0.0, 0.0};
-    uint32_t iu, ii, fl; float yl;
+    uint32_t iu, ii, fl; float yl, xd = 0.f;
     {
         const int64_t tc = gg < B ? gg : B - 1;
         iu = (uint32_t)uid[tc]; ii = (uint32_t)iid[tc]; fl = flags4[tc]; yl = label[tc];
+        if (XD) xd = xdot[tc];
     }
-    asm volatile("" : "+v"(iu), "+v"(ii), "+v"(fl), "+v"(yl));
+    asm volatile("" : "+v"(iu), "+v"(ii), "+v"(fl), "+v"(yl), "+v"(xd));
     for (int64_t t = gg; t < B; t += TG) {
         const bool fu = (fl & 0xFFu) != 0, fi = (fl & 0xFF00u) != 0;
         const int64_t ou = (int64_t)iu * D + 4 * sub, oi = (int64_t)ii * D + 4 * sub;
@@ -856,15 +859,16 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, 
             if (live && fu) { um = ld4(TU.M + ou); uv = ld4(TU.V + ou); }
             if (live && fi) { im = ld4(TI.M + oi); iv = ld4(TI.V + oi); }
         }
-        uint32_t ju, ji, gl; float yn;
+        uint32_t ju, ji, gl; float yn, xn = 0.f;
         {
             const int64_t tn = t + TG, tc = tn < B ? tn : B - 1;
             ju = (uint32_t)uid[tc]; ji = (uint32_t)iid[tc]; gl = flags4[tc]; yn = label[tc];
+            if (XD) xn = xdot[tc];
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float dx = group_sum<LPR>(dot4(u, v));
-        const float su = group_sum<LPR>(dot4(u, u));
-        const float si = group_sum<LPR>(dot4(v, v));
+        const float dx = XD ? xd : group_sum<LPR>(dot4(u, v));
+        const float su = XD ? 0.f : group_sum<LPR>(dot4(u, u));
+        const float si = XD ? 0.f : group_sum<LPR>(dot4(v, v));
         float l, g;
         if (loss_kind == CDR_LOSS_MSE) {
             const float d = dx - yl;
@@ -875,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, 
             const float pq = (1.0f - p) * p;
             g = (p - yl) / fmaxf(pq, 1e-12f) * invB * pq;
         }
-        asm volatile("" : "+v"(ju), "+v"(ji), "+v"(gl), "+v"(yn));        // every request of this iteration has returned: stores below wait on nothing older
+        asm volatile("" : "+v"(ju), "+v"(ji), "+v"(gl), "+v"(yn), "+v"(xn));        // every request of this iteration has returned: stores below wait on nothing older
         __builtin_amdgcn_sched_barrier(0);
         const float4 gu = make_float4(g * v.x, g * v.y, g * v.z, g * v.w);
         const float4 gi = make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, 
             if (live) { if (OPT == 1) { st4(TI.M + oi, im); st4(TI.V + oi, iv); } st4(TI.W + oi, wi); }
         } else if (live) st4(GI + t * D + 4 * sub, gi);
         if (sub == 0) { acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si; }
-        iu = ju; ii = ji; fl = gl; yl = yn;
+        iu = ju; ii = ji; fl = gl; yl = yn; xd = xn;
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -1884,6 +1888,62 @@ extern "C" int cdr_bpr_step_from_diff(cdr_ctx* ctx, void* stream, int opt, float
     int rc = dups_plan_make(ctx, Ds, sides, pl);
     if (rc) return rc;
     step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters, diff + B);
+    CDR_LAUNCH_CHECK();
+    return apply_dups_pair(ctx, s, opt, Ds, pl);
+}
+
+// The pointwise rows of the dimension layout (cdr_point_partial_dot -> all-reduce -> here), same cut as the BPR pair above:
+//   cdr_point_step_presort   ids only (under the all-reduce): two-table sort of uid / iid + occurrence flags + duplicate-segment heads
+//   cdr_point_step_from_dot  dot [B + 2] = all-reduced {<u, i> ..., sum u^2, sum i^2}
+extern "C" int cdr_point_step_presort(cdr_ctx* ctx, void* stream, const int64_t* uid, const int64_t* iid, int64_t B, int64_t user_rows,
+                                      int64_t item_rows, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads, void* sort_ws,
+                                      size_t sort_ws_bytes, uint32_t* key_base_out) {
+    CDR_CHECK_ARG(ctx && uid && iid && keys && perm && flags && heads && sort_ws && key_base_out && B > 0 && 2 * B <= (int64_t)0x7FFFFFFF);
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, iid, B, nullptr, 0, item_rows, keys, perm, key_base_out, sort_ws, sort_ws_bytes);
+    if (rc) return rc;
+    CDR_HIP(cdr_zero_u32(heads, 4, s));
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(grid_for(2 * B, kBlock * kFlagIT)), dim3(kBlock), 0, s>>>(keys, perm, B, 2 * B, 4, flags, heads + 4, heads + 4 + (B / 2 + 1), (unsigned*)heads);
+    }
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_point_step_from_dot(cdr_ctx* ctx, void* stream, int loss_kind, int opt, float* user_tab, float* user_m, float* user_v,
+                                       float* item_tab, float* item_m, float* item_v, int Ds, const int64_t* uid, const int64_t* iid,
+                                       const float* label, int64_t B, float reg_weight, float lr, float beta1, float beta2, float eps,
+                                       float weight_decay, int64_t step_user, int64_t step_item, const float* dot, uint32_t key_base,
+                                       float* out9, float* GU, float* GI, const uint32_t* keys, const uint32_t* perm, const uint8_t* flags,
+                                       uint32_t* heads) {
+    CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && dot && out9 && GU && GI && keys && perm && flags && heads);
+    CDR_CHECK_ARG((loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE) && Ds > 0 && (Ds & 3) == 0 && Ds <= 256 && B > 0);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && item_m && item_v && step_user > 0 && step_item > 0));
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(Ds);
+    coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, 0, B, reg_weight, out9, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, dot + B);
+    CDR_LAUNCH_CHECK();
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{item_tab, item_m, item_v};
+    const int grid = grid_for(B, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_POINT_FWD_GRAD, s);
+#define PA_ARGS loss_kind, TU, TI, Ds, uid, iid, label, (const uint32_t*)flags, B, 1.0f / (float)B, out9 + 4, hu, hi, GU, GI, ctx->partials, dot
+        if (opt == 0) { DISPATCH_LPR(lpr, point_fwd_apply_kernel<L, 0, true><<<dim3(grid), dim3(kBlock), 0, s>>>(PA_ARGS)); }
+        else { DISPATCH_LPR(lpr, point_fwd_apply_kernel<L, 1, true><<<dim3(grid), dim3(kBlock), 0, s>>>(PA_ARGS)); }
+#undef PA_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    unsigned* cnt = (unsigned*)heads;
+    const dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, B, heads + 4, cnt, GU, B, B, out9 + 4, hu, 0},
+                               {item_tab, item_m, item_v, keys + B, perm + B, B, heads + 4 + (B / 2 + 1), cnt + 1, GI, B, B, out9 + 5, hi, key_base}};
+    dups_plan pl;
+    int rc = dups_plan_make(ctx, Ds, sides, pl);
+    if (rc) return rc;
+    step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters, dot + B);
     CDR_LAUNCH_CHECK();
     return apply_dups_pair(ctx, s, opt, Ds, pl);
 }

@@ -345,7 +345,10 @@ class NativePointDimOps(NativeDimOps):
         from . import binding as B_
         from .fused import FusedPointStep
         self.B_ = B_
-        self.fs = FusedPointStep(user_cols, item_cols, max_global_batch, fuse_singles=False, **kw)      # (the two halves around the all-reduce: the two-pass form)
+        # the two halves around the all-reduce; since round 5 the second half is the forward-and-update pass fed with the given dots
+        # (cdr_point_step_from_dot); fuse_singles=False keeps the two-pass form
+        self.fs = FusedPointStep(user_cols, item_cols, max_global_batch, fuse_singles=kw.pop('fuse_singles', True), **kw)
+        self.fused = self.fs.fuse_singles
         self.out = self.fs.out6
 
     def partial(self, uid, iid, label, dot):
@@ -355,11 +358,26 @@ class NativePointDimOps(NativeDimOps):
 
     def grad_apply(self, uid, iid, label, dot):
         B_, fs = self.B_, self.fs
+        if self.fused:
+            us, its = fs.ustate, fs.istate
+            us.advance(); its.advance()
+            B_.call('cdr_point_step_from_dot', B_.ctx(fs.U.device), B_.stream(), fs.kind, fs.opt, B_.f32(us.table), B_.f32(us.exp_avg),
+                    B_.f32(us.exp_avg_sq), B_.f32(its.table), B_.f32(its.exp_avg), B_.f32(its.exp_avg_sq), fs.D, B_.i64(uid), B_.i64(iid),
+                    B_.f32(label), uid.numel(), float(fs.reg_weight), float(fs.lr), float(fs.betas[0]), float(fs.betas[1]), float(fs.eps),
+                    float(fs.wd), us.step, its.step, B_.f32(dot), int(fs._key_base.value), B_.f32(fs.out6), B_.f32(fs.GU), B_.f32(fs.GI),
+                    B_.raw(fs.keys), B_.raw(fs.perm), B_.raw(fs.flags), B_.raw(fs.heads))
+            return fs.out6
         B_.call('cdr_point_grad_from_dot', B_.ctx(fs.U.device), B_.stream(), fs.kind, B_.f32(fs.U), B_.f32(fs.I), fs.D, B_.i64(uid),
                 B_.i64(iid), B_.f32(label), uid.numel(), float(fs.reg_weight), B_.f32(dot), B_.f32(fs.out6), B_.f32(fs.GU), B_.f32(fs.GI))
         return fs.apply_sorted(uid.numel())
 
     def presort(self, uid, iid, label):
+        if self.fused:
+            import ctypes
+            B_, fs = self.B_, self.fs
+            B_.call('cdr_point_step_presort', B_.ctx(fs.U.device), B_.stream(), B_.i64(uid), B_.i64(iid), uid.numel(), fs.U.shape[0], fs.I.shape[0],
+                    B_.raw(fs.keys), B_.raw(fs.perm), B_.raw(fs.flags), B_.raw(fs.heads), B_.raw(fs.ws), fs.ws.numel(), ctypes.byref(fs._key_base))
+            return
         self.fs.sort_ids(uid, iid)
 
 

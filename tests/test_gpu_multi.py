@@ -270,6 +270,33 @@ def test_dim_sharded_step_on_rccl_world1_equals_fused():
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('loss,opt', [('mse', 'adam'), ('bce', 'adam'), ('mse', 'sgd')])
+def test_dim_sharded_point_second_half_one_pass_equals_two_pass(loss, opt):
+    """DimShardedPointStep at world 1: the forward-and-update pass fed with the given dots (cdr_point_step_presort +
+    cdr_point_step_from_dot) against the two-pass form (cdr_point_grad_from_dot -> cdr_rowwise_apply x 2), batches with long
+    duplicate segments on both tables; 1e-6 relative on the loss scalars, tables to the Adam contraction tolerance."""
+    from recbole_cdr_amd.dimshard import DimShardedPointStep, NativePointDimOps
+    torch.manual_seed(5)
+    nu, ni, D, B = 3001, 1501, 48, 6000
+    U, I = torch.randn(nu, D, device=DEV) * 0.1, torch.randn(ni, D, device=DEV) * 0.1
+    tabs = [(U.clone(), I.clone()) for _ in range(2)]
+    hp = dict(loss=loss, opt=opt, lr=0.01, reg_weight=0.02)
+    steps = [DimShardedPointStep(Ut, It, B, ops=NativePointDimOps(Ut, It, B, fuse_singles=f, **hp)) for (Ut, It), f in zip(tabs, (True, False))]
+    assert steps[0].ops.fused and not steps[1].ops.fused
+    for it in range(4):
+        u, i = torch.randint(0, nu, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV)
+        y = (torch.rand(B, device=DEV) < 0.4).float()
+        if it == 1:
+            u[:1000] = 7; i[:70] = 3                       # segments beyond the piece threshold and medium ones
+        if it == 2:
+            u = torch.arange(B, device=DEV) % nu; i = torch.arange(B, device=DEV) % ni
+        outs = [st.step(u, i, y).clone() for st in steps]
+        assert_close(outs[0][:4], outs[1][:4], rtol=1e-6, atol=0, what=f'out it{it}')
+    assert_close(tabs[0][0], tabs[1][0], rtol=2e-5, atol=1e-5, what='U')
+    assert_close(tabs[0][1], tabs[1][1], rtol=2e-5, atol=1e-5, what='I')
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The whole EMCDR schedule over several ranks: SOURCE and TARGET BPR steps in the dimension layout, the phase switch
 # (tables AND Adam moments transposed to row shards, update counts kept), OVERLAP steps in the row layout, sharded top-k.
