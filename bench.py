@@ -94,7 +94,7 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
                                                         'sharding': _clip(v.get('sharding', ''), 60)}) for k, v in lay.items()}
     lf = result.get('layout_fallback')
     if isinstance(lf, dict):
-        extra['layout_fallback'] = {k: lf.get(k) for k in ('used', 'fell_back', 'ranks_seen') if k in lf}
+        extra['layout_fallback'] = {k: lf.get(k) for k in ('used', 'fell_back', 'ranks_seen', 'comm') if k in lf}
     ex = result.get('exchange')
     if isinstance(ex, dict):
         extra['exchange'] = {k: v for k, v in ex.items() if isinstance(v, (int, float))}
@@ -224,6 +224,9 @@ def parse():
                          'the ranks (D/(N/2) columns, twice the batch per rank)')
     ap.add_argument('--replica-dp', action='store_true', help='c4 with N>1: replica data parallelism with sharded Adam (dp.py) instead of the row-sharded graph')
     ap.add_argument('--single-stream', action='store_true', help='c5, N=1: enqueue the TARGET domain step behind the SOURCE domain step on one stream (default: two streams)')
+    ap.add_argument('--comm', default='torch', choices=['torch', 'cabi'],
+                    help='c5 row shard: the data-path exchanges through torch.distributed (RCCL) or through the C ABI\'s own communicator '
+                         '(cdr_comm_init + cdr_a2a_ids / cdr_a2a_rows / cdr_allreduce_sum_f32; falls back to torch if it does not come up)')
     ap.add_argument('--single-layout', action='store_true', help='N>1: time only the --shard layout (default: both, in one record)')
     ap.add_argument('--preflight-seconds', type=float, default=30.0, help='N>1: deadline for a candidate layout to create its groups and run its first two steps on every rank')
     ap.add_argument('--no-layout-fallback', action='store_true', help='N>1: fail instead of trying the next layout / independent replicas')
@@ -352,9 +355,14 @@ def run_c5(args, world, rank, dev):
         first, _ = c5_layouts.resolve(world, args.shard, D, not args.no_domain_groups)
         if args.shard == 'dim' and first == 'row':
             print('bench: --dim %d does not cut into float4 slices over %d ranks; using --shard row' % (D, world), file=sys.stderr)
+        if args.comm == 'cabi':
+            args.shard = 'row'                             # the C ABI's exchanges are the row shard's
+            first = 'row'
         order = ['dim-groups', 'dim', 'row']
         chain = [first] + [m for m in order[order.index(first) + 1:]
                            if m == 'row' or c5_layouts.resolve(world, 'dim', D, m == 'dim-groups')[0] == m]
+        if args.comm == 'cabi':
+            chain = ['row-cabi', 'row']
         if args.single_layout or args.no_layout_fallback:
             chain = chain[:1]
 
@@ -366,9 +374,13 @@ def run_c5(args, world, rank, dev):
         all_groups = {name: c5_layouts.make_groups(world, name) for name in chain}
 
         def build(name):
-            cand = c5_layouts.build(world, rank, 'row' if name == 'row' else 'dim', D, B, n_users, n_items, make_table, dict(opt=args.opt, reg_weight=0.01),
-                                    domain_groups=name == 'dim-groups', pipeline=not args.no_pipeline, dedup=not args.no_dedup, device=dev,
-                                    groups=all_groups[name])
+            row_comm = None
+            if name == 'row-cabi':
+                from recbole_cdr_amd.shard import CabiComm
+                row_comm = lambda g: CabiComm(g, dev)  # noqa: E731
+            cand = c5_layouts.build(world, rank, 'row' if name.startswith('row') else 'dim', D, B, n_users, n_items, make_table,
+                                    dict(opt=args.opt, reg_weight=0.01), domain_groups=name == 'dim-groups', pipeline=not args.no_pipeline,
+                                    dedup=not args.no_dedup, device=dev, groups=all_groups[name], row_comm=row_comm)
             cand.batches = make_batches(cand.mode == 'dim-groups', cand.my_dom)
             return cand
 
@@ -519,6 +531,16 @@ def run_c5(args, world, rank, dev):
         except Exception as e:  # noqa: BLE001
             result['layout_fallback']['ranks_seen_error'] = repr(e)[:200]
 
+    comms = {d: st.comm for d, st in steps.items() if getattr(st, 'comm', None) is not None} if sharded else {}
+    if comms:
+        # the row shard's data path went through the C ABI's communicator: its own rank count (cdr_comm_info) and how many calls it served
+        lf = result.setdefault('layout_fallback', {'used': lay.mode, 'attempts': [], 'fell_back': False})
+        lf['ranks_seen'] = {d: c.info()[1] for d, c in comms.items()}
+        lf['comm'] = 'cabi'
+        result['config']['comm'] = 'C ABI communicator (cdr_comm_init, cdr_a2a_ids / cdr_a2a_rows / cdr_allreduce_sum_f32); bucket counts over torch.distributed'
+        result['cabi_calls_total'] = {k: sum(c.calls[k] for c in comms.values()) for k in ('cdr_a2a_ids', 'cdr_a2a_rows', 'cdr_allreduce_sum_f32')}
+    elif sharded and args.comm == 'cabi':
+        result.setdefault('layout_fallback', {})['comm'] = 'torch (the C ABI communicator did not come up: see attempts)'
     if sharded:
         # what the links carried and how long this rank's two domain streams spent inside all-to-alls (they overlap each other
         # and the other domain's kernels, so this is NOT additive with the kernel times: it says which side bounds the step)

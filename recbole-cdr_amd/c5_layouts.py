@@ -66,11 +66,12 @@ def make_groups(world, mode):
 
 
 def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, domain_groups=True, pipeline=True, dedup=True, device=None,
-          dim_ops=None, row_ops=None, plain_step=None, groups=None):
+          dim_ops=None, row_ops=None, plain_step=None, groups=None, row_comm=None):
     """``make_table(name, rows, cols, total_cols)`` -> this rank's fp32 table [rows, cols] (name in su, si, tu, ti).
     ``step_kw``: optimizer / loss keywords of the step classes (opt, reg_weight, lr ...).
     ``dim_ops(user_cols, item_cols, max_global_batch)`` / ``row_ops()``: compute stand-ins for the CPU tests (None: native kernels).
-    ``plain_step(user_tab, item_tab, max_batch)``: the single-GPU step class for a one-rank domain group (default FusedBPRStep)."""
+    ``plain_step(user_tab, item_tab, max_batch)``: the single-GPU step class for a one-rank domain group (default FusedBPRStep).
+    ``row_comm(group)`` -> shard.CabiComm: the row layout's exchanges through the C ABI's communicator (None: torch.distributed)."""
     from .dimshard import DimShardedBPRStep
     from .shard import ShardedBPRStep, shard_rows
     lay = C5Layout()
@@ -102,5 +103,6 @@ def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, doma
         lay.groups = groups if groups is not None else make_groups(world, 'row')
         for d in ('source', 'target'):
             lay.steps[d] = ShardedBPRStep(lay.tabs[d[0] + 'u'], lay.tabs[d[0] + 'i'], n_users, n_items, B, group=lay.groups[d],
-                                          ops=row_ops() if row_ops is not None else None, stream=mk_stream(), dedup=dedup, **step_kw)
+                                          ops=row_ops() if row_ops is not None else None, stream=mk_stream(), dedup=dedup,
+                                          comm=row_comm(lay.groups[d]) if row_comm is not None else None, **step_kw)
     return lay

@@ -237,6 +237,72 @@ def _allreduce(t, group):
     return t
 
 
+class CabiComm:
+    """The row shard's data-path exchanges through the C ABI's own communicator (cdr_comm_init + cdr_a2a_ids / cdr_a2a_rows /
+    cdr_allreduce_sum_f32, include/cdr_hip.h family (10)) instead of torch.distributed: what a host that is not Python calls.
+    The 128-byte id travels over the existing process group (the "host's own means"); the bucket COUNTS stay on that group too
+    (control plane, a few integers).  One communicator per (domain, stream), as one process group per domain.  With one rank the
+    calls are still issued (self send / receive inside one RCCL group): that is what a one-GPU box can test."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes
+        from . import binding as B_
+        self.B_, self.group = B_, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        idb = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            B_.call('cdr_comm_unique_id', ctypes.cast(idb, ctypes.c_void_p))
+        box = [bytes(idb)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        idb = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        self.comm = ctypes.c_void_p()
+        if device is not None:
+            torch.cuda.set_device(device)
+        B_.call('cdr_comm_init', ctypes.cast(ctypes.pointer(self.comm), ctypes.c_void_p), self.rank, self.world, ctypes.cast(idb, ctypes.c_void_p))
+        self.calls = {'cdr_a2a_ids': 0, 'cdr_a2a_rows': 0, 'cdr_allreduce_sum_f32': 0}
+
+    def info(self):
+        """(rank, world) as the communicator itself reports them (cdr_comm_info)."""
+        import ctypes
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        self.B_.call('cdr_comm_info', self.comm, ctypes.cast(ctypes.pointer(r), ctypes.c_void_p), ctypes.cast(ctypes.pointer(w), ctypes.c_void_p))
+        return r.value, w.value
+
+    def a2a(self, inp, in_splits, out_splits, trailing=()):
+        import ctypes
+        B_ = self.B_
+        unit = 1
+        for t in trailing:
+            unit *= int(t)
+        inp = inp.contiguous()
+        out = torch.empty((sum(out_splits),) + tuple(trailing), device=inp.device, dtype=inp.dtype)
+        if inp.dtype == torch.int64:
+            sc = (ctypes.c_int64 * self.world)(*[int(c) * unit for c in in_splits])
+            rc = (ctypes.c_int64 * self.world)(*[int(c) * unit for c in out_splits])
+            B_.call('cdr_a2a_ids', self.comm, B_.stream(), B_.i64(inp), ctypes.cast(sc, ctypes.c_void_p), B_.i64(out), ctypes.cast(rc, ctypes.c_void_p))
+            self.calls['cdr_a2a_ids'] += 1
+        elif inp.dtype == torch.float32:
+            sc = (ctypes.c_int64 * self.world)(*[int(c) for c in in_splits])
+            rc = (ctypes.c_int64 * self.world)(*[int(c) for c in out_splits])
+            B_.call('cdr_a2a_rows', self.comm, B_.stream(), B_.f32(inp), ctypes.cast(sc, ctypes.c_void_p), B_.f32(out), ctypes.cast(rc, ctypes.c_void_p), unit)
+            self.calls['cdr_a2a_rows'] += 1
+        else:
+            raise TypeError('CabiComm.a2a: int64 ids or fp32 rows, got %s' % inp.dtype)
+        return out
+
+    def allreduce(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self.B_.call('cdr_allreduce_sum_f32', self.comm, self.B_.stream(), self.B_.f32(t), t.numel())
+        self.calls['cdr_allreduce_sum_f32'] += 1
+        return t
+
+    def close(self):
+        if self.comm:
+            self.B_.call('cdr_comm_destroy', self.comm)
+            self.comm = None
+
+
 def _gather_counts(counts, extra, group, world):
     """All ranks' bucket counts (+ one extra int per rank) -> list of tensors (no host sync yet)."""
     payload = torch.cat([counts, torch.tensor([extra], device=counts.device, dtype=torch.int64)])
@@ -251,9 +317,10 @@ class ShardedBPRStep:
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
-                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True):
+                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True, comm=None):
         from .fused import RowwiseState
         self.group = group
+        self.comm = comm                          # optional CabiComm: rows / ids / sums travel through the C ABI's communicator
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         assert user_shard.shape[0] == shard_rows(n_users_total, self.world, self.rank)
@@ -291,15 +358,25 @@ class ShardedBPRStep:
         torch.cuda.synchronize()
         return self._prof['bytes'], sum(a.elapsed_time(b) for a, b in self._prof['events'])
 
+    def _a2a(self, inp, in_splits, out_splits, group, trailing=()):
+        if self.comm is not None and inp.is_cuda:
+            return self.comm.a2a(inp, in_splits, out_splits, trailing)
+        return _a2a(inp, in_splits, out_splits, group, trailing)
+
+    def _sum(self, t, group):
+        if self.comm is not None and t.is_cuda:
+            return self.comm.allreduce(t)
+        return _allreduce(t, group)
+
     def _x(self, inp, in_splits, out_splits, group, trailing=()):
         prof = self.__dict__.get('_prof')
         if not prof or not inp.is_cuda:
-            return _a2a(inp, in_splits, out_splits, group, trailing)
+            return self._a2a(inp, in_splits, out_splits, group, trailing)
         row = inp.element_size() * (inp.numel() // max(inp.shape[0], 1))
         prof['bytes'] += row * (sum(in_splits) - in_splits[self.rank])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        out = _a2a(inp, in_splits, out_splits, group, trailing)
+        out = self._a2a(inp, in_splits, out_splits, group, trailing)
         b.record()
         prof['events'].append((a, b))
         return out
@@ -373,7 +450,7 @@ class ShardedBPRStep:
                 sums = self.out[6:9].clone()
             else:
                 sums = torch.zeros(3, device=uid.device, dtype=torch.float32)
-            _allreduce(sums, grp)
+            self._sum(sums, grp)
             ops.finish_sums(sums, B_global, self.reg_weight, self.out)
 
             # ---- 3. user rows are local; item gradients go home ---------------------------------------------------
@@ -415,7 +492,7 @@ class ShardedBPRStep:
                     norms = ops.batch_norms(self.U, irows, u_loc, ip)
                 else:
                     norms = torch.zeros(3, device=dev, dtype=torch.float32)
-                _allreduce(norms, grp)
+                self._sum(norms, grp)
                 ops.finish_sums(norms, B_global, self.reg_weight, self.out)          # out[4:6] = the coefficients every rank uses
                 if Bl:
                     GP = ops.local_step(self.U, self._moments(self.ustate), irows, u_loc, ip, in_, B_global, self.gamma, self.reg_weight,
@@ -423,7 +500,7 @@ class ShardedBPRStep:
                     loss = self.out[6:7].clone()
                 else:
                     loss = torch.zeros(1, device=dev, dtype=torch.float32)
-                _allreduce(loss, grp)
+                self._sum(loss, grp)
                 norms[0:1] = loss                                                    # {global loss sum, global sum u^2, global sum p^2}
                 ops.finish_sums(norms, B_global, self.reg_weight, self.out)
                 gi = ops.segsum(plan, GP[:Bl], Bl, irows, self.out[5:6], n_uniq) if Bl else torch.empty(0, self.D, device=dev, dtype=torch.float32)
@@ -437,7 +514,7 @@ class ShardedBPRStep:
                     sums = self.out[6:9].clone()
                 else:
                     sums = torch.zeros(3, device=dev, dtype=torch.float32)
-                _allreduce(sums, grp)
+                self._sum(sums, grp)
                 ops.finish_sums(sums, B_global, self.reg_weight, self.out)
                 if Bl:
                     ops.sort_apply(self.U, self._moments(self.ustate), u_loc, GU[:Bl], self.opt, self.hp, self.ustate.step,

@@ -656,6 +656,47 @@ def test_bench_multi_rank_layout_fallback(inject, used, tmp_path):
         assert 'INDEPENDENT REPLICAS' in d['config']['sharding'] and [a['ok'] for a in fb['attempts']] == [False, False]
 
 
+def test_bench_comm_cabi_one_rank(tmp_path):
+    """`bench.py --force-shard --comm cabi`: the row-sharded step's exchanges go through cdr_comm_init + cdr_a2a_ids /
+    cdr_a2a_rows / cdr_allreduce_sum_f32; the line carries the communicator's own rank count.  One rank is what a one-GPU box allows."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--force-shard', '--comm', 'cabi', '--steps', '3', '--warmup', '2', '--users', '400001',
+           '--items-per-domain', '100000', '--batch', '8192', '--no-fullsort', '--no-cpu-baseline', '--no-ingest',
+           '--detail-file', str(tmp_path / 'detail.json')]
+    p = subprocess.run(cmd, cwd=root, env=dict(os.environ, NCCL_SOCKET_IFNAME='lo'), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line, d = _bench_line_and_detail(p, tmp_path)
+    assert line['layout_fallback']['comm'] == 'cabi' and line['layout_fallback']['ranks_seen'] == {'source': 1, 'target': 1}
+    calls = d['cabi_calls_total']
+    assert calls['cdr_a2a_ids'] > 0 and calls['cdr_a2a_rows'] == calls['cdr_a2a_ids'] and calls['cdr_allreduce_sum_f32'] > 0
+    assert 'row' in d['config']['sharding'] and 'C ABI communicator' in d['config']['comm'] and 0 < d['final_loss'] < 10
+
+
+def test_bench_comm_cabi_falls_back_to_torch_when_the_communicator_does_not_come_up(tmp_path):
+    """Two ranks on ONE device: RCCL refuses the C ABI communicator (duplicate GPU), every rank abandons 'row-cabi' under the preflight
+    watchdog and the row layout comes up over torch.distributed (gloo here) -- the line still prints and says so."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CDR_BENCH_SHARED_GPU='1', NCCL_SOCKET_IFNAME='lo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--comm', 'cabi', '--steps', '3', '--warmup', '2', '--users', '400001',
+           '--items-per-domain', '100000', '--batch', '8192', '--preflight-seconds', '30', '--no-fullsort',
+           '--detail-file', str(tmp_path / 'detail.json')]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line, d = _bench_line_and_detail(p, tmp_path)
+    fb = d['layout_fallback']
+    assert fb['attempts'][0]['layout'] == 'row-cabi' and fb['attempts'][0]['ok'] is False and fb['used'] == 'row' and fb['fell_back'] is True
+    assert 'torch' in fb['comm'] and d['value'] > 0
+
+
 @pytest.mark.parametrize('inject,used', [('', 'rowshard'), ('rowshard:raise@1', 'replica-dp'), ('rowshard,replica-dp:raise@0', 'replicas')])
 def test_bench_c4_multi_rank_layout_fallback(inject, used, tmp_path):
     """`bench.py --workload c4 --gpus 2` (BASELINE configs[3]: the row-sharded graph) under the same watchdog: rowshard -> replica data

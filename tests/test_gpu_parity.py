@@ -655,13 +655,14 @@ def test_fused_step_deterministic_and_sorted():
     assert torch.equal(torch.sort(heads[4 + B // 2 + 1:4 + B // 2 + 1 + nB]).values, torch.nonzero(hd[B:]).flatten())
 
 
-@pytest.mark.parametrize('variant', ['via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup'])
+@pytest.mark.parametrize('variant', ['via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup', 'cabi-fused', 'cabi-no_dedup'])
 def test_sharded_step_world1_equals_fused(variant, monkeypatch):
     """shard.ShardedBPRStep with libcdrhip ops over a 1-rank RCCL group == fused.FusedBPRStep (same kernels, plus the
     route / all-to-all / build-grad-rows path).  World 2 is covered on CPU by tests/test_shard_gloo.py.  Variants: the one-rank
     all-to-alls sent through RCCL (the collective calls of the multi-GPU path exercised on one GPU) or handed on in place (the product's
-    one-rank form); the requester's half on the one-GPU forward-and-update kernel (round 5) or as the round-2 two-pass step; and the
-    exchange without id de-duplication."""
+    one-rank form) or through the C ABI's own communicator (shard.CabiComm: cdr_comm_init + cdr_a2a_ids / cdr_a2a_rows /
+    cdr_allreduce_sum_f32, what `bench.py --comm cabi` drives); the requester's half on the one-GPU forward-and-update kernel (round 5) or as
+    the round-2 two-pass step; and the exchange without id de-duplication."""
     import socket
     import torch.distributed as dist
     from recbole_cdr_amd import shard as shard_mod
@@ -679,6 +680,11 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
         U0, I0 = torch.randn(nu, D, device=DEV) * 0.1, torch.randn(ni, D, device=DEV) * 0.1
         Ua, Ia, Ub, Ib = U0.clone(), I0.clone(), U0.clone(), I0.clone()
         fa = FusedBPRStep(Ua, Ia, B, opt='adam', reg_weight=0.02, lr=0.01)
+        cabi = None
+        if comm == 'cabi':
+            cabi = shard_mod.CabiComm(None, torch.device(DEV))
+            assert cabi.info() == (0, 1)
+            kw = dict(kw, comm=cabi)
         fb = ShardedBPRStep(Ub, Ib, nu, ni, B, opt='adam', reg_weight=0.02, lr=0.01, **kw)
         for step in range(3):
             u = torch.randint(0, nu, (B,), device=DEV); p = torch.randint(0, ni, (B,), device=DEV)
@@ -688,6 +694,11 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
             assert_close(lb, la, rtol=1e-6, what=f'loss step {step}')
         assert_close(Ub, Ua, rtol=2e-5, atol=0.01 * 1e-2); assert_close(Ib, Ia, rtol=2e-5, atol=0.01 * 1e-2)
         assert_close(fb.ustate.exp_avg, fa.ustate.exp_avg, rtol=2e-5); assert_close(fb.istate.exp_avg, fa.istate.exp_avg, rtol=2e-5)
+        if cabi is not None:
+            # per step: the triples + the item ids (int64), the item rows + the gradient rows (fp32), the sums
+            want_sums = 6 if form == 'fused' else 3
+            assert cabi.calls == {'cdr_a2a_ids': 6, 'cdr_a2a_rows': 6, 'cdr_allreduce_sum_f32': want_sums}, cabi.calls
+            cabi.close()
     finally:
         dist.destroy_process_group()
 

@@ -28,11 +28,16 @@ if has legs; then
 fi
 if has e2e; then python bench.py --only-e2e > $O/bench_e2e.json 2> $O/bench_e2e.err; echo "e2e rc=$?"; fi
 if has ingest; then python bench.py --only-ingest > $O/bench_ingest.json 2> $O/bench_ingest.err; echo "ingest rc=$?"; fi
+if has shard_cabi; then
+  FS="--force-shard --single-layout --no-fullsort --no-cpu-baseline --no-config-legs --no-e2e --no-ingest --steps 10 --warmup 3"
+  python bench.py $FS --shard row --comm cabi --detail-file $O/force_shard_row_cabi.json 2> $O/force_shard_row_cabi.err | line > $O/force_shard_row_cabi_line.json; echo "force-shard row cabi rc=$?"
+fi
 if has shard; then
   FS="--force-shard --single-layout --no-fullsort --no-cpu-baseline --no-config-legs --no-e2e --no-ingest --steps 10 --warmup 3"
   python bench.py $FS --shard row --detail-file $O/force_shard_row.json 2> $O/force_shard_row.err | line > $O/force_shard_row_line.json; echo "force-shard row rc=$?"
   python bench.py $FS --shard dim --detail-file $O/force_shard_dim.json 2> $O/force_shard_dim.err | line > $O/force_shard_dim_line.json; echo "force-shard dim rc=$?"
   CDR_A2A_SELF_VIA_RCCL=1 python bench.py $FS --shard row --detail-file $O/force_shard_row_via_rccl.json 2> /dev/null | line > $O/force_shard_row_via_rccl_line.json; echo "force-shard row via rccl rc=$?"
+  python bench.py $FS --shard row --comm cabi --detail-file $O/force_shard_row_cabi.json 2> /dev/null | line > $O/force_shard_row_cabi_line.json; echo "force-shard row cabi rc=$?"
   python bench.py $FS --shard row --no-dedup --detail-file $O/force_shard_row_no_dedup.json 2> /dev/null | line > /dev/null; echo "force-shard row no-dedup rc=$?"
   python tools/mb_dimshard.py > $O/mb_dimshard.json 2> $O/mb_dimshard.err; echo "mb_dimshard rc=$?"
 fi
