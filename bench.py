@@ -578,14 +578,26 @@ def run_c5(args, world, rank, dev):
         # N > 1: the exchange adds all-to-alls between the kernels; the kernels themselves are the 1-GPU ones.  Buckets
         # are balanced in expectation (uniform ids), so one fwd_grad launch sees ~B triples: 3 rows read, GU + 2 GI rows
         # written (scatter mode).  Rank 0's own HIP-event durations.
-        ms = mean_ms('bpr_fwd_grad_kernel')
-        byts = B * (3 * 4 * D + 24) + B * 3 * 4 * D
+        if timings.get('bpr_fwd_apply_kernel'):
+            # round 5: the requester's half runs the one-GPU step's forward-and-update pass on the rows it holds (user rows of its own shard,
+            # the item rows it was sent): per triple three rows read; user rows occurring once (most, at uniform ids) read-modify-written
+            # with their Adam moments, the positive-side gradient row written for the segmented sum behind it
+            kname = 'bpr_fwd_apply_kernel'
+            ms = mean_ms(kname)
+            nmom = 3 if args.opt == 'adam' else 1
+            byts = B * (3 * 4 * D + 24) + B * (2 * nmom - 1) * 4 * D + B * 4 * D
+            what = 'bpr_fwd_apply_kernel (rank 0: ~B triples per launch on the rows held after user-aligned routing; user rows updated in place)'
+        else:
+            kname = 'bpr_fwd_grad_kernel'
+            ms = mean_ms(kname)
+            byts = B * (3 * 4 * D + 24) + B * 3 * 4 * D
+            what = 'bpr_fwd_grad_kernel (rank 0, scatter mode, ~B triples per launch)'
         gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        result['roofline'] = {'bound': 'hbm', 'kernel': 'bpr_fwd_grad_kernel (rank 0, scatter mode, ~B triples per launch)',
-                              'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                              'avg_launch_ms': ms, 'traffic': None}
+        result['roofline'] = {'bound': 'hbm', 'kernel': what, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                              'avg_launch_ms': ms, 'algorithmic_bytes': byts, 'traffic': None}
         result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
-                             ('bpr_fwd_grad_kernel', 'rowwise_apply_kernel(users)', 'sort_ids')]
+                             (kname, 'batch_norms_kernel', 'occ_flags_kernel', 'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)', 'sort_ids')
+                             if timings.get(k)]
         if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
             result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
 
@@ -1831,6 +1843,8 @@ def conet_fullsort_leg(args, dev):
             flops = pair_flop * Uu * Nn
             byts = 4.0 * (Nn * layers[0] + Uu * layers[0] + Uu * Nn)                       # P read once, Q, scores written
             case = {'items_per_s': Uu * Nn / (ms * 1e-3), 'ms': ms, 'U': Uu, 'N': Nn,
+                    'path': 'one launch: cdr_conet_fullsort_users (Q formed inside; evaluation-mode call packed once)' if model.__dict__.get('_eval_few') is not None and model.__dict__['_eval_few'].takes(inter[model.TARGET_USER_ID])
+                    else 'gather + Q contraction + cdr_conet_fullsort (P cached in evaluation mode)',
                     'kernel': {'name': 'conet_fullsort_kernel', 'avg_ms': kms, 'algorithmic_flops': flops, 'achieved_TFLOPs': flops / (kms * 1e-3) / 1e12,
                                'frac_fp32_mfma_peak': flops / (kms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                'algorithmic_bytes': byts, 'achieved_GBs': byts / (kms * 1e-3) / 1e9, 'frac_hbm_peak': byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 50
+#define CDR_ABI_VERSION 51
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -396,6 +396,14 @@ int cdr_conet_fullsort_supported(int h1, int n_tail, const int* tail_dims);
 int cdr_conet_fullsort(void* stream, const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t U, int64_t N, int h1,
                        int n_tail, const int* tail_dims, const float* const* W, const float* const* b, const float* wo,
                        const float* bo, float* out, int64_t ldo);
+/* The same scores with Q formed INSIDE the launch, Q[u] = W1u user_table[uid[u]] + b1 (W1u = the first D columns of the first layer's weight,
+ * row stride ldw1): one launch per call instead of gather + contraction + scoring.  For the few-users call of recbole's evaluation loop
+ * (conet.py:222-242 runs once per eval batch -- ONE user at the default eval_batch_size over a large catalogue); correct for any U, but every
+ * workgroup re-forms its users' Q rows, so throughput-sized user batches belong to cdr_conet_fullsort. */
+int cdr_conet_fullsort_users(void* stream, const float* P, int64_t ldp, const float* user_table, int64_t ldu, const int64_t* uid,
+                             const float* W1u, int64_t ldw1, const float* b1, int D, int64_t U, int64_t N, int h1, int n_tail,
+                             const int* tail_dims, const float* const* W, const float* const* b, const float* wo, const float* bo,
+                             float* out, int64_t ldo);
 
 /* ---- SSCDR helpers (sscdr.py:120-187) -------------------------------------------------------------------------- */
 /* embedding_normalize: len = sum x^2, y = x / (len > 1 ? len : 1)  -- the squared-length quirk is kept */

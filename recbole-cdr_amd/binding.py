@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 50
+ABI_VERSION = 51
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -266,6 +266,8 @@ _SIGNATURES = {
                       _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t, _c_int],
     'cdr_conet_fullsort_supported': [_c_int, _c_int, _c_ptr],
     'cdr_conet_fullsort': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64],
+    'cdr_conet_fullsort_users': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr,
+                                 _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64],
     'cdr_overlap_remap': [ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, ctypes.c_char_p, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_revoke_map': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     'cdr_adam_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64],

@@ -38,6 +38,9 @@ struct fs_args {
     const float* wo; const float* bo;            // output unit [d_last], [1]
     float* out; int64_t ldo;                     // [U, N]
     int users_per_block;                         // a multiple of 8
+    // QF (a few users per call -- recbole's evaluation hands over ONE user at the default eval_batch_size): Q is not read but formed while
+    // the chunk is staged, Q[u][f] = b1[f] + <W1u[f, :], UT[uid[u], :]>, so a call is this one launch (no gather, no [U, h1] contraction)
+    const float* UT; int64_t ldu; const int64_t* uid; const float* W1u; int64_t ldw1; const float* b1; int D;
 };
 
 #define FS_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
@@ -54,12 +57,74 @@ __device__ __forceinline__ int fs_feat(int r, int h) { return 8 * (r >> 2) + 4 *
 
 // S1: K steps of the first tail layer (h1 <= 2 S1; half h contracts features h S1 + s).  G2/G3/G4: 8-feature register groups of the
 // tail layers' outputs (G = 0: layer absent); the next layer contracts 4 G steps.
-template <int S1, int G2, int G3, int G4>
-__global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
+// The Q rows of users [u0, u0 + nu) into LDS.  QF: formed here from the table rows -- four lanes per (user, feature) element, each a quarter
+// of the D-long dot with its loads issued together, summed inside the quad (the first form, one lane per element walking D dependent
+// iterations, cost ~40 us per staging: twice the whole scoring launch at one user x 1 M items).
+// (inlined as first written, its float4 temporaries pushed the default tower's kernel from 184 + 32 to 228 + 32 registers -- one resident
+//  wave per SIMD instead of two, 1.5x on the scoring loop; as a call, 249 + 32 and scratch.  The kernel now carries the two-waves bound.)
+template <int S1>
+__device__ __forceinline__ void fs_form_q(const fs_args& a, float* __restrict__ Ql, int64_t u0, int nu) {
+    {
+        const int Dq = ((a.D + 15) >> 4) << 2;                       // a quarter of the row, rounded up to whole float4s
+        const bool vec = !(a.ldu & 3) && !(a.ldw1 & 3) && !((uintptr_t)a.UT & 15) && !((uintptr_t)a.W1u & 15);
+        for (int t = threadIdx.x; t < nu * 2 * S1 * 4; t += kFsBlock) {      // (8 S1 is a multiple of 64: whole waves run the same trips)
+            const int e = t >> 2, part = t & 3;
+            const int uu = e / (2 * S1), f = e - uu * 2 * S1;
+            float q = 0.f;
+            if (f < a.h1) {
+                const float* __restrict__ ur = a.UT + a.uid[u0 + uu] * a.ldu;
+                const float* __restrict__ wr = a.W1u + (int64_t)f * a.ldw1;
+                const int d0 = part * Dq, d1 = d0 + Dq < a.D ? d0 + Dq : a.D;
+                int d = d0;
+                if (vec) {
+                    float q1 = 0.f, q2 = 0.f, q3 = 0.f;
+                    for (; d + 16 <= d1; d += 16) {
+                        const float4 w0 = ld4(wr + d), w1 = ld4(wr + d + 4), w2 = ld4(wr + d + 8), w3 = ld4(wr + d + 12);
+                        const float4 x0 = ld4(ur + d), x1 = ld4(ur + d + 4), x2 = ld4(ur + d + 8), x3 = ld4(ur + d + 12);
+                        q += w0.x * x0.x + w0.y * x0.y + w0.z * x0.z + w0.w * x0.w;
+                        q1 += w1.x * x1.x + w1.y * x1.y + w1.z * x1.z + w1.w * x1.w;
+                        q2 += w2.x * x2.x + w2.y * x2.y + w2.z * x2.z + w2.w * x2.w;
+                        q3 += w3.x * x3.x + w3.y * x3.y + w3.z * x3.z + w3.w * x3.w;
+                    }
+                    for (; d + 4 <= d1; d += 4) {
+                        const float4 w0 = ld4(wr + d), x0 = ld4(ur + d);
+                        q += w0.x * x0.x + w0.y * x0.y + w0.z * x0.z + w0.w * x0.w;
+                    }
+                    q += (q1 + q2) + q3;
+                }
+                for (; d < d1; ++d) q += wr[d] * ur[d];
+            }
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            if (part == 0) Ql[e] = f < a.h1 ? q + a.b1[f] : 0.f;
+        }
+    }
+}
+
+template <int S1, bool QF>
+__device__ __forceinline__ void fs_stage_q(const fs_args& a, float* __restrict__ Ql, int64_t u0, int nu) {
+    if (QF) {
+        fs_form_q<S1>(a, Ql, u0, nu);
+    } else {
+        for (int e = threadIdx.x; e < nu * 2 * S1; e += kFsBlock) {
+            const int uu = e / (2 * S1), f = e - uu * 2 * S1;
+            Ql[e] = f < a.h1 ? a.Q[(u0 + uu) * a.ldq + f] : 0.f;
+        }
+    }
+}
+
+template <int S1, int G2, int G3, int G4, bool QF>
+__global__ __launch_bounds__(kFsBlock, (G3 <= 2 && G4 <= 1) ? 2 : 1) void conet_fullsort_kernel(fs_args a) {
     __shared__ __attribute__((aligned(16))) float Ql[kFsUsers * 2 * S1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const int d2 = a.d[0], d3 = G3 ? a.d[1] : 0, d4 = G4 ? a.d[2] : 0;
     constexpr int R2 = 4 * G2, R3 = 4 * G3, R4 = 4 * G4;
+    const int64_t u_lo = (int64_t)blockIdx.y * a.users_per_block;
+    const int64_t u_hi = u_lo + a.users_per_block < a.U ? u_lo + a.users_per_block : a.U;
+    // a workgroup whose users fit ONE chunk stages them once, not once per tile round -- first thing, so that its loads (QF: id -> table
+    // row, a dependent pair) are in flight under the ~100 weight-fragment loads below
+    const bool one_chunk = u_hi - u_lo <= kFsUsers;
+    if (one_chunk) fs_stage_q<S1, QF>(a, Ql, u_lo, (int)(u_hi - u_lo));
 
     // ---- static per-lane weight fragments, in the K order of the register chain ------------------------------------------------
     // (every address is clamped into its array and the value masked afterwards: straight-line loads -- a bounds BRANCH per element made
@@ -101,12 +166,11 @@ __global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
     const float bo = a.bo[0];
     const bool p_vec = !(a.ldp & 3) && !(a.h1 & 3) && !((uintptr_t)a.P & 15);
 
-    const int64_t u_lo = (int64_t)blockIdx.y * a.users_per_block;
-    const int64_t u_hi = u_lo + a.users_per_block < a.U ? u_lo + a.users_per_block : a.U;
     const int64_t n_tiles = (a.N + 31) >> 5;
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
     // every wave of the workgroup runs the same number of tile rounds (the Q chunk is staged behind workgroup barriers)
     const int64_t rounds = (n_tiles + tile_stride - 1) / tile_stride;
+    if (one_chunk) __syncthreads();                                  // (staged at the top of the kernel)
     for (int64_t rd = 0; rd < rounds; ++rd) {
         const int64_t tile = ((int64_t)rd * gridDim.x + blockIdx.x) * 4 + wave;
         const bool live = tile < n_tiles;
@@ -131,12 +195,11 @@ __global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
         }
         for (int64_t u0 = u_lo; u0 < u_hi; u0 += kFsUsers) {
             const int nu = (int)(u_hi - u0 < kFsUsers ? u_hi - u0 : kFsUsers);
-            __syncthreads();                                       // the previous chunk has been consumed by every wave
-            for (int e = threadIdx.x; e < nu * 2 * S1; e += kFsBlock) {
-                const int uu = e / (2 * S1), f = e - uu * 2 * S1;
-                Ql[e] = f < a.h1 ? a.Q[(u0 + uu) * a.ldq + f] : 0.f;
+            if (!one_chunk) {
+                __syncthreads();                                   // the previous chunk has been consumed by every wave
+                fs_stage_q<S1, QF>(a, Ql, u0, nu);
+                __syncthreads();
             }
-            __syncthreads();
             if (!live) continue;
             for (int uu = 0; uu < nu; ++uu) {
                 const float* q = Ql + uu * 2 * S1 + h * S1;
@@ -178,8 +241,8 @@ __global__ __launch_bounds__(kFsBlock) void conet_fullsort_kernel(fs_args a) {
     }
 }
 
-template <int S1, int G2, int G3, int G4>
-int fs_launch(const fs_args& a, hipStream_t s) {
+template <int S1, int G2, int G3, int G4, bool QF>
+int fs_launch_q(const fs_args& a, hipStream_t s) {
     const int64_t n_tiles = (a.N + 31) >> 5;
     // user chunks per block: enough workgroups to cover the chip's 1,024 SIMDs about twice when the problem allows it
     fs_args b = a;
@@ -194,8 +257,27 @@ int fs_launch(const fs_args& a, hipStream_t s) {
     gy = (groups + per - 1) / per;
     b.users_per_block = (int)(per * 8);
     if (gx > 8 * CDR_NUM_CU) gx = 8 * CDR_NUM_CU;            // waves walk the remaining tiles (their weights stay loaded)
-    conet_fullsort_kernel<S1, G2, G3, G4><<<dim3((unsigned)gx, (unsigned)gy), dim3(kFsBlock), 0, s>>>(b);
+    conet_fullsort_kernel<S1, G2, G3, G4, QF><<<dim3((unsigned)gx, (unsigned)gy), dim3(kFsBlock), 0, s>>>(b);
     return 0;
+}
+
+template <int S1, int G2, int G3, int G4>
+int fs_launch(const fs_args& a, hipStream_t s) {
+    return a.uid ? fs_launch_q<S1, G2, G3, G4, true>(a, s) : fs_launch_q<S1, G2, G3, G4, false>(a, s);
+}
+
+int fs_dispatch(const fs_args& a, hipStream_t s) {
+    const int n_tail = a.n_tail;
+    const int g2 = (a.d[0] + 7) / 8, g3 = n_tail > 1 ? (a.d[1] + 7) / 8 : 0, g4 = n_tail > 2 ? (a.d[2] + 7) / 8 : 0;
+    const bool small1 = a.h1 <= 32;
+    // the reference's default tower [.., 64, 32, 16, 8] (properties/model/CoNet.yaml) gets its exact instantiation; anything else within
+    // range runs zero-padded on the next larger one
+    if (!small1 && n_tail == 3 && g2 <= 4 && g3 <= 2 && g4 <= 1) fs_launch<32, 4, 2, 1>(a, s);
+    else if (n_tail == 3) small1 ? fs_launch<16, 4, 4, 4>(a, s) : fs_launch<32, 4, 4, 4>(a, s);
+    else if (n_tail == 2) small1 ? fs_launch<16, 4, 4, 0>(a, s) : fs_launch<32, 4, 4, 0>(a, s);
+    else small1 ? fs_launch<16, 4, 0, 0>(a, s) : fs_launch<32, 4, 0, 0>(a, s);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
 }
 
 }  // namespace
@@ -222,15 +304,30 @@ extern "C" int cdr_conet_fullsort(void* stream, const float* P, int64_t ldp, con
         CDR_CHECK_ARG(W[t] && b[t]);
         a.d[t] = tail_dims[t]; a.W[t] = W[t]; a.b[t] = b[t];
     }
-    hipStream_t s = (hipStream_t)stream;
-    const int g2 = (a.d[0] + 7) / 8, g3 = n_tail > 1 ? (a.d[1] + 7) / 8 : 0, g4 = n_tail > 2 ? (a.d[2] + 7) / 8 : 0;
-    const bool small1 = h1 <= 32;
-    // the reference's default tower [.., 64, 32, 16, 8] (properties/model/CoNet.yaml) gets its exact instantiation; anything else within
-    // range runs zero-padded on the next larger one
-    if (!small1 && n_tail == 3 && g2 <= 4 && g3 <= 2 && g4 <= 1) fs_launch<32, 4, 2, 1>(a, s);
-    else if (n_tail == 3) small1 ? fs_launch<16, 4, 4, 4>(a, s) : fs_launch<32, 4, 4, 4>(a, s);
-    else if (n_tail == 2) small1 ? fs_launch<16, 4, 4, 0>(a, s) : fs_launch<32, 4, 4, 0>(a, s);
-    else small1 ? fs_launch<16, 4, 0, 0>(a, s) : fs_launch<32, 4, 0, 0>(a, s);
-    CDR_LAUNCH_CHECK();
-    return CDR_OK;
+    return fs_dispatch(a, (hipStream_t)stream);
+}
+
+// The same scores with the user half of the first layer formed inside the launch: uid [U] rows of user_table [*, ldu >= D],
+// W1u = the first D columns of the first layer's weight [h1, ldw1 >= D], b1 [h1].  Meant for the few-users call of recbole's evaluation
+// loop (conet.py:222-242 is entered once per eval batch: one user at the default eval_batch_size over a large catalogue); any U is correct,
+// but every workgroup re-forms its users' Q rows, so large U belongs to cdr_conet_fullsort.
+extern "C" int cdr_conet_fullsort_users(void* stream, const float* P, int64_t ldp, const float* user_table, int64_t ldu, const int64_t* uid,
+                                        const float* W1u, int64_t ldw1, const float* b1, int D, int64_t U, int64_t N, int h1, int n_tail,
+                                        const int* tail_dims, const float* const* W, const float* const* b, const float* wo, const float* bo,
+                                        float* out, int64_t ldo) {
+    CDR_CHECK_ARG(P && user_table && uid && W1u && b1 && out && W && b && wo && bo && tail_dims);
+    CDR_CHECK_ARG(U > 0 && N > 0 && D > 0 && ldp >= h1 && ldu >= D && ldw1 >= D && ldo >= N);
+    if (!cdr_conet_fullsort_supported(h1, n_tail, tail_dims)) {
+        cdr_set_error("cdr_conet_fullsort_users: tower [%d -> %d layers] outside the kernel's range (first width <= 64, 1..3 further layers of width <= 32)",
+                      h1, n_tail);
+        return CDR_EINVAL;
+    }
+    fs_args a{};
+    a.P = P; a.ldp = ldp; a.U = U; a.N = N; a.h1 = h1; a.n_tail = n_tail; a.wo = wo; a.bo = bo; a.out = out; a.ldo = ldo;
+    a.UT = user_table; a.ldu = ldu; a.uid = uid; a.W1u = W1u; a.ldw1 = ldw1; a.b1 = b1; a.D = D;
+    for (int t = 0; t < n_tail; ++t) {
+        CDR_CHECK_ARG(W[t] && b[t]);
+        a.d[t] = tail_dims[t]; a.W[t] = W[t]; a.b[t] = b[t];
+    }
+    return fs_dispatch(a, (hipStream_t)stream);
 }

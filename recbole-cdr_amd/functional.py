@@ -886,6 +886,45 @@ def conet_fullsort(P, Q, weights, biases, wo, bo, out=None):
     return out
 
 
+class ConetFullsortFewUsers:
+    """CoNet.full_sort_predict for a FEW users as one launch (cdr_conet_fullsort_users): everything that does not change between calls --
+    P, the tower, the table and first-layer pointers -- is packed into ctypes arguments ONCE; a call allocates the [U, N] scores and fills in
+    the ids.  Built by the model in evaluation mode and dropped when it trains again (the pointers are those of the tensors held here)."""
+    MAX_USERS = 8
+    MAX_PAIRS = 262144       # beyond ~this many (user, item) pairs the scoring launch outlasts the host's three enqueues: nothing left to save
+
+    @torch.no_grad()
+    def __init__(self, P, user_table, W1, b1, D, weights, biases, wo, bo):
+        _dev_check(P, user_table, W1, b1, wo, bo, *weights, *biases)
+        assert P.stride(1) == 1 and user_table.stride(1) == 1 and W1.stride(1) == 1 and user_table.shape[1] >= D and W1.shape[1] >= D
+        T = len(weights)
+        self.keep = [P, user_table, W1, b1.contiguous(), [w.contiguous() for w in weights], [b.contiguous() for b in biases],
+                     wo.reshape(-1).contiguous(), bo.reshape(-1).contiguous()]
+        _P, _ut, _W1, _b1, ws, bs, wo_, bo_ = self.keep
+        self.N, self.dev, self.table_ptr = P.shape[0], P.device, user_table.data_ptr()
+        self.dims = (ctypes.c_int * T)(*[int(w.shape[0]) for w in ws])
+        self.Wp = (ctypes.c_void_p * T)(*[w.data_ptr() for w in ws])
+        self.bp = (ctypes.c_void_p * T)(*[b.data_ptr() for b in bs])
+        c = B_._c_ptr
+        self.head = (c(P.data_ptr()), P.stride(0), c(user_table.data_ptr()), user_table.stride(0))
+        self.mid = (c(W1.data_ptr()), W1.stride(0), c(_b1.data_ptr()), int(D))
+        self.tail = (self.N, P.shape[1], T, self.dims, self.Wp, self.bp, c(wo_.data_ptr()), c(bo_.data_ptr()))
+        self.fn = getattr(B_.load(), 'cdr_conet_fullsort_users')
+
+    def takes(self, uid):
+        U = uid.shape[0]
+        return U <= self.MAX_USERS and U * self.N <= self.MAX_PAIRS and uid.dtype == torch.int64 and uid.is_contiguous() and uid.device == self.dev
+
+    def __call__(self, uid):
+        """uid: int64 device tensor [U], contiguous."""
+        U = uid.shape[0]
+        out = torch.empty(U, self.N, device=self.dev, dtype=torch.float32)
+        rc = self.fn(B_.stream(), *self.head, B_._c_ptr(uid.data_ptr()), *self.mid, U, *self.tail, B_._c_ptr(out.data_ptr()), self.N)
+        if rc:
+            B_._check(rc, 'cdr_conet_fullsort_users')
+        return out
+
+
 class ConetFusedLoss(Function):
     """CoNet.calculate_loss (conet.py:183-203) as ONE autograd node on the fused tower kernels: forward = gather + every
     cross unit of both towers + output units + BCE x2 + sum ||H_l||_F in one launch (+ a finishing block); backward = data

@@ -64,14 +64,19 @@ class CoNet(CrossDomainRecommender):
 
     def train(self, mode=True):
         if mode:
-            self.__dict__.pop('_eval_P', None)            # (full_sort_predict's evaluation-mode cache of the item part of layer 1)
+            self._drop_eval_cache()
         return super().train(mode)
 
-    def on_train_steps(self):
+    def _drop_eval_cache(self):
+        """full_sort_predict's evaluation-mode caches: the item part of layer 1 and the packed few-users call built on it."""
         self.__dict__.pop('_eval_P', None)
+        self.__dict__.pop('_eval_few', None)
+
+    def on_train_steps(self):
+        self._drop_eval_cache()
 
     def load_state_dict(self, *args, **kwargs):
-        self.__dict__.pop('_eval_P', None)
+        self._drop_eval_cache()
         return super().load_state_dict(*args, **kwargs)
 
     def sync_tables(self):
@@ -209,7 +214,11 @@ class CoNet(CrossDomainRecommender):
         over the N rows -- instead of the reference's Python loop over users with a repeat()ed [N, 2D] input."""
         D = self.latent_dim
         self.sync_tables()
-        user_e = F_.gather_rows(self.target_user_embedding.weight, interaction[self.TARGET_USER_ID])
+        few = None if self.training else self.__dict__.get('_eval_few')
+        uid = interaction[self.TARGET_USER_ID]
+        if few is not None and few.takes(uid) and few.table_ptr == self.target_user_embedding.weight.data_ptr():
+            return few(uid)                                             # a few users, evaluation mode: ONE launch (see below)
+        user_e = F_.gather_rows(self.target_user_embedding.weight, uid)
         items = self.target_item_embedding.weight[:self.target_num_items]
         lin1 = self.target_crossunit_linear[0]
         W1 = lin1.weight                                              # [h1, 2D]
@@ -227,6 +236,11 @@ class CoNet(CrossDomainRecommender):
             # every (user, item) pair through layers 2.. and the output unit in ONE launch, activations in registers
             # (csrc/cdr_conet_fullsort.hip) -- no per-user loop, no [N, h] intermediates
             lo = self.target_outputunit[0]
+            if not self.training and '_eval_few' not in self.__dict__:
+                # recbole's evaluation enters here once per eval batch -- ONE user at the default eval_batch_size over a large catalogue:
+                # from the second call on such a call is one launch with Q formed inside it (cdr_conet_fullsort_users), arguments packed once
+                self.__dict__['_eval_few'] = F_.ConetFullsortFewUsers(P, self.target_user_embedding.weight, W1, lin1.bias, D, [l.weight for l in tail],
+                                                                      [l.bias for l in tail], lo.weight, lo.bias)
             return F_.conet_fullsort(P, Q, [l.weight for l in tail], [l.bias for l in tail], lo.weight, lo.bias)
         rows = []
         for u in range(user_e.shape[0]):

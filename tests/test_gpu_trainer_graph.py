@@ -329,6 +329,68 @@ def test_conet_fullsort_kernel_vs_fp64_tower(D, layers, U, N):
     assert_close(got, want.float(), rtol=1e-5, what='conet fullsort')
 
 
+@pytest.mark.parametrize('D,layers,U,N', [(16, [64, 32, 16, 8], 1, 77), (128, [64, 32, 16, 8], 1, 5000), (8, [12, 8, 4], 3, 41), (32, [48, 24], 8, 100),
+                                          (20, [20, 32, 32, 32], 5, 65), (64, [64, 8], 40, 33)])
+def test_conet_fullsort_users_entry_vs_fp64_tower(D, layers, U, N):
+    """cdr_conet_fullsort_users (the few-users call of recbole's evaluation loop as ONE launch: the user half of the first layer formed
+    inside it from the table row) against the fp64 tower, 1e-5 relative; a padded table (row stride > D), repeated ids, and more users
+    than one LDS chunk."""
+    from recbole_cdr_amd import functional as F_
+    g = torch.Generator().manual_seed(D + N + U)
+    dims = [2 * D] + layers
+    Ws = [torch.randn(b, a, generator=g) * (2.0 / (a + b)) ** 0.5 for a, b in zip(dims[:-1], dims[1:])]
+    bs = [torch.randn(b, generator=g) * 0.1 for b in dims[1:]]
+    wo, bo = torch.randn(1, dims[-1], generator=g) * 0.5, torch.randn(1, generator=g) * 0.1
+    table = torch.randn(50, D + 4, generator=g) * 0.3
+    uid = torch.randint(0, 50, (U,), generator=g)
+    if U > 2:
+        uid[1] = uid[0]
+    users, items = table[uid, :D], torch.randn(N, D, generator=g) * 0.3
+    x = torch.cat([users.double().unsqueeze(1).expand(U, N, D), items.double().unsqueeze(0).expand(U, N, D)], dim=2)
+    for W, b in zip(Ws, bs):
+        x = torch.relu(x @ W.double().t() + b.double())
+    want = torch.sigmoid(x @ wo.double().t() + bo.double()).squeeze(-1)
+    dv = lambda t: t.to(DEV)
+    W1 = dv(Ws[0])
+    P = F_.gemm(dv(items), W1[:, D:], trans_b=True)
+    call = F_.ConetFullsortFewUsers(P, dv(table)[:, :D], W1, dv(bs[0]), D, [dv(w) for w in Ws[1:]], [dv(b) for b in bs[1:]], dv(wo), dv(bo))
+    got = call(dv(uid))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (U, N)
+    assert_close(got, want.float(), rtol=1e-5, what='conet fullsort users')
+
+
+def test_conet_full_sort_predict_few_users_in_eval_mode_is_the_one_launch_call_and_follows_training():
+    """CoNet.full_sort_predict in evaluation mode: the first call builds P and the packed few-users call, later calls with <= 8 users are
+    that one launch -- equal to the general path to 1e-5; a training step in between drops the cache (the scores follow the new weights)."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    ids = IdSpace(OU=50, TOU=30, SOU=20, OI=1, TOI=2999, SOI=500)
+    cfg = base_config(DEV, embedding_size=32, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+    torch.manual_seed(2)
+    model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+    model.eval()
+    one = {'target_user_id': torch.tensor([7], device=DEV)}
+    many = {'target_user_id': torch.arange(1, 41, device=DEV)}
+    with torch.no_grad():
+        ref_many = model.full_sort_predict(many)                      # general path; builds the caches
+        assert '_eval_few' in model.__dict__ and '_eval_P' in model.__dict__
+        got = model.full_sort_predict(one)                            # one launch
+        assert_close(got, ref_many[6:7], rtol=1e-5, what='few users vs general path')
+        five = {'target_user_id': torch.tensor([3, 9, 9, 40, 1], device=DEV)}
+        assert_close(model.full_sort_predict(five), ref_many[[2, 8, 8, 39, 0]], rtol=1e-5, what='five users')
+        model.train()
+        assert '_eval_few' not in model.__dict__ and '_eval_P' not in model.__dict__
+        for p in model.target_crossunit_linear[0].parameters():
+            p.mul_(0.5)
+        model.target_user_embedding.weight[7].mul_(2.0)
+        model.eval()
+        a = model.full_sort_predict(one)                              # general path again (rebuilds), then the one-launch call
+        b = model.full_sort_predict(one)
+        assert_close(b, a, rtol=1e-5, what='after training: few users vs general path')
+        assert float((a - got).abs().max()) > 1e-4                    # (the weights did change)
+
+
 def test_conet_full_sort_predict_fused_equals_layerwise_path():
     """CoNet.full_sort_predict on the one-launch kernel against the same model's per-user contraction path (the round-3 product
     path, still what towers outside the kernel's range take): C3-shaped tower, 40 users x 3,000 items."""
