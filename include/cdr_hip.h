@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 51
+#define CDR_ABI_VERSION 52
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -126,6 +126,12 @@ int cdr_point_fwd_pair(cdr_ctx* ctx, void* stream, int loss_kind, const float* c
                        const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
                        const int64_t* const* iid, const float* const* label, const int64_t* B, const float* reg_weight,
                        float* const* out4, float* const* gcoef, float* const* scores, const float* w, float* total);
+/* ... with reg tables reg_D <= D floats wide (reg_D % 4 == 0; reg tables required when reg_D < D): BiTGCF's whole loss value in one launch,
+ * BCE on rows of the propagated stacks + reg_weight x EmbLoss of the batch's EGO rows (bitgcf.py:222-240). */
+int cdr_point_fwd_pair_ex(cdr_ctx* ctx, void* stream, int loss_kind, const float* const* user_tab, const float* const* item_tab,
+                          const float* const* reg_user_tab, const float* const* reg_item_tab, int D, int reg_D, const int64_t* const* uid,
+                          const int64_t* const* iid, const float* const* label, const int64_t* B, const float* reg_weight,
+                          float* const* out4, float* const* gcoef, float* const* scores, const float* w, float* total);
 int cdr_point_bwd_dense_pair(cdr_ctx* ctx, void* stream, const float* const* user_tab, const float* const* item_tab,
                              const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
                              const int64_t* const* iid, const int64_t* B, const float* const* gcoef, const float* const* out4,
@@ -511,6 +517,12 @@ int cdr_embloss_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, const flo
 int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const float* item_tab, int D, const int64_t* uid,
                           const int64_t* iid, int64_t B, const float* out3, const float* grad_out,
                           float* grad_user_tab, float* grad_item_tab);
+/* Two EmbLoss backward passes in one launch (host arrays of two, as cdr_point_fwd_pair): norms[d] -> {||U_b||_F, ||I_b||_F} on the device
+ * (out3 + 1 of cdr_embloss_fwd, out4 + 2 of cdr_point_fwd_pair_ex), row coefficient scale[d] * grad_out[d][0] / (B ||rows||)
+ * (grad_out NULL or grad_out[d] NULL = 1); gradients are ADDED (fp32 atomics) into the given tables. */
+int cdr_embloss_bwd_dense_pair(void* stream, const float* const* user_tab, const float* const* item_tab, int D, const int64_t* const* uid,
+                               const int64_t* const* iid, const int64_t* B, const float* const* norms, const float* const* grad_out,
+                               const float* scale, float* const* grad_user_tab, float* const* grad_item_tab);
 
 /* ---- integer paths (bit-exact) --------------------------------------------------------------------------------
  * cdr_overlap_remap (HOST function, no GPU): CrossDomainDataset.calculate_user_item_from_both_domain + _remap_fields for

@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 51
+ABI_VERSION = 52
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -230,6 +230,8 @@ _SIGNATURES = {
     'cdr_inc_i64': [_c_ptr, _c_ptr],
     'cdr_point_fwd_pair': [_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 10,
     'cdr_point_bwd_dense_pair': [_c_ptr, _c_ptr] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] * 12,
+    'cdr_point_fwd_pair_ex': [_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 4 + [_c_int, _c_int] + [_c_ptr] * 10,
+    'cdr_embloss_bwd_dense_pair': [_c_ptr, _c_ptr, _c_ptr, _c_int] + [_c_ptr] * 8,
     'cdr_scalar_mix': [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr],

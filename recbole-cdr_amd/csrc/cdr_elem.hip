@@ -356,6 +356,30 @@ __global__ __launch_bounds__(kBlock) void embloss_bwd_kernel(const float* __rest
     }
 }
 
+// both domains' EmbLoss gradients in one launch (blockIdx.y = domain); norms[d] -> {||U_b||_F, ||I_b||_F}, the row coefficient is
+// scale[d] * grad_out[d][0] / (B ||rows||)
+struct embloss_pair { const float* U[2]; const float* I[2]; const int64_t* uid[2]; const int64_t* iid[2]; int64_t B[2];
+                      const float* norms[2]; const float* go[2]; float scale[2]; float* gU[2]; float* gI[2]; };
+__global__ __launch_bounds__(kBlock) void embloss_bwd_pair_kernel(embloss_pair a, int D) {
+    const int d = blockIdx.y;
+    const float* __restrict__ U = a.U[d]; const float* __restrict__ I = a.I[d];
+    const int64_t* __restrict__ uid = a.uid[d]; const int64_t* __restrict__ iid = a.iid[d];
+    float* __restrict__ gU = a.gU[d]; float* __restrict__ gI = a.gI[d];
+    const int64_t B = a.B[d];
+    const float go = (a.go[d] ? a.go[d][0] : 1.0f) * a.scale[d];
+    const float nu = a.norms[d][0], ni = a.norms[d][1];
+    const float cu = nu > 0.f ? go / ((float)B * nu) : 0.f;
+    const float ci = ni > 0.f ? go / ((float)B * ni) : 0.f;
+    const int64_t total = B * D, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t t = e / D;
+        const int c = (int)(e - t * D);
+        const int64_t iu = uid[t], ii = iid[t];
+        atomicAdd(gU + iu * D + c, cu * U[iu * D + c]);
+        atomicAdd(gI + ii * D + c, ci * I[ii * D + c]);
+    }
+}
+
 }  // namespace
 
 #define EL_GRID(total) dim3(grid_cap(((total) + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream
@@ -549,6 +573,24 @@ extern "C" int cdr_embloss_bwd_dense(void* stream, const float* user_tab, const 
                                      float* grad_user_tab, float* grad_item_tab) {
     CDR_CHECK_ARG(user_tab && item_tab && uid && iid && out3 && grad_user_tab && grad_item_tab && B > 0 && D > 0);
     embloss_bwd_kernel<<<EL_GRID(B * D)>>>(user_tab, item_tab, D, uid, iid, B, out3, grad_out, grad_user_tab, grad_item_tab);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_embloss_bwd_dense_pair(void* stream, const float* const* user_tab, const float* const* item_tab, int D,
+                                          const int64_t* const* uid, const int64_t* const* iid, const int64_t* B, const float* const* norms,
+                                          const float* const* grad_out, const float* scale, float* const* grad_user_tab,
+                                          float* const* grad_item_tab) {
+    CDR_CHECK_ARG(user_tab && item_tab && uid && iid && B && norms && scale && grad_user_tab && grad_item_tab && D > 0);
+    embloss_pair a{};
+    int64_t bmax = 0;
+    for (int d = 0; d < 2; ++d) {
+        CDR_CHECK_ARG(user_tab[d] && item_tab[d] && uid[d] && iid[d] && norms[d] && grad_user_tab[d] && grad_item_tab[d] && B[d] > 0);
+        a.U[d] = user_tab[d]; a.I[d] = item_tab[d]; a.uid[d] = uid[d]; a.iid[d] = iid[d]; a.B[d] = B[d]; a.norms[d] = norms[d];
+        a.go[d] = grad_out ? grad_out[d] : nullptr; a.scale[d] = scale[d]; a.gU[d] = grad_user_tab[d]; a.gI[d] = grad_item_tab[d];
+        if (B[d] > bmax) bmax = B[d];
+    }
+    embloss_bwd_pair_kernel<<<dim3(grid_cap((bmax * D + kBlock - 1) / kBlock), 2), dim3(kBlock), 0, (hipStream_t)stream>>>(a, D);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -222,11 +222,12 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_dense_scalar_kernel(const floa
 }
 
 // ------------------------------------------------------------------------------------------------ pointwise forward
-// SAME: the EmbLoss tables are the dot tables (EMCDR-MF, CMF); otherwise (BiTGCF) the reg rows come from other tables.
+// SAME: the EmbLoss tables are the dot tables (EMCDR-MF, CMF); otherwise (BiTGCF) the reg rows come from other tables, DR <= D floats
+// wide (BiTGCF scores rows of the (L + 1) D-wide layer stack and regularises the D-wide ego rows: bitgcf.py:222-240).
 template <int LPR, bool SAME>
 __device__ __forceinline__ void point_fwd_body(int loss_kind, const float* __restrict__ U,
                                                            const float* __restrict__ I, const float* __restrict__ RU,
-                                                           const float* __restrict__ RI, int D,
+                                                           const float* __restrict__ RI, int D, int DR,
                                                            const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
                                                            const float* __restrict__ label, int64_t B,
                                                            float* __restrict__ gcoef, float* __restrict__ scores,
@@ -260,7 +261,7 @@ __device__ __forceinline__ void point_fwd_body(int loss_kind, const float* __res
                 if (t < B && live) {
                     a[r] = ld4(U + iu[r] * D + 4 * sub);
                     b[r] = ld4(I + ii[r] * D + 4 * sub);
-                    if (!SAME) { ra[r] = ld4(RU + iu[r] * D + 4 * sub); rb[r] = ld4(RI + ii[r] * D + 4 * sub); }
+                    if (!SAME && 4 * sub < DR) { ra[r] = ld4(RU + iu[r] * DR + 4 * sub); rb[r] = ld4(RI + ii[r] * DR + 4 * sub); }
                 }
             }
 #pragma unroll
@@ -279,8 +280,8 @@ __device__ __forceinline__ void point_fwd_body(int loss_kind, const float* __res
                         const float4 a = ld4(U + iu[r] * D + 4 * c), b = ld4(I + ii[r] * D + 4 * c);
                         dxs[r] += dot4(a, b);
                         if (SAME) { sus[r] += dot4(a, a); sis[r] += dot4(b, b); }
-                        else {
-                            const float4 ra = ld4(RU + iu[r] * D + 4 * c), rb = ld4(RI + ii[r] * D + 4 * c);
+                        else if (4 * c < DR) {
+                            const float4 ra = ld4(RU + iu[r] * DR + 4 * c), rb = ld4(RI + ii[r] * DR + 4 * c);
                             sus[r] += dot4(ra, ra); sis[r] += dot4(rb, rb);
                         }
                     }
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
                                                            unsigned* __restrict__ ticket, float reg_weight, float* __restrict__ out4,
                                                            uint4* __restrict__ scrub, int64_t scrub_n16) {
     cdr_scrub(scrub, scrub_n16);
-    point_fwd_body<LPR, SAME>(loss_kind, U, I, RU, RI, D, uid, iid, label, B, gcoef, scores, partials);
+    point_fwd_body<LPR, SAME>(loss_kind, U, I, RU, RI, D, D, uid, iid, label, B, gcoef, scores, partials);
     if (ticket && cdr_sign_in_last(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
 }
 
@@ -339,6 +340,7 @@ struct point_pair {
     const int64_t* uid[2]; const int64_t* iid[2]; const float* label[2]; int64_t B[2];
     float* gcoef[2]; float* scores[2]; float* out4[2]; float reg[2];
     const float* go[2]; float* gU[2]; float* gI[2]; float* gRU[2]; float* gRI[2]; float gscale[2];
+    int DR;                                      // row width of RU / RI (= D unless the reg tables are narrower: cdr_point_fwd_pair_ex)
 };
 constexpr size_t kPairPartials = (size_t)(CDR_MAX_PARTIAL_BLOCKS / 2) * CDR_PARTIAL_STRIDE;
 
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, p
                                                                 float* __restrict__ total, uint4* __restrict__ scrub, int64_t scrub_n16) {
     const int d = blockIdx.y;
     cdr_scrub(scrub, scrub_n16);
-    point_fwd_body<LPR, SAME>(loss_kind, a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.uid[d], a.iid[d], a.label[d], a.B[d], a.gcoef[d],
+    point_fwd_body<LPR, SAME>(loss_kind, a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.DR, a.uid[d], a.iid[d], a.label[d], a.B[d], a.gcoef[d],
                               a.scores[d], partials + d * kPairPartials);
     // small grids: the block (of either batch) that signs in last finishes both losses and their weighted total
     if (ticket && cdr_sign_in_last(ticket, gridDim.x * gridDim.y)) {
@@ -584,10 +586,24 @@ extern "C" int cdr_point_fwd_pair(cdr_ctx* ctx, void* stream, int loss_kind, con
                                   const float* const* reg_user_tab, const float* const* reg_item_tab, int D, const int64_t* const* uid,
                                   const int64_t* const* iid, const float* const* label, const int64_t* B, const float* reg_weight,
                                   float* const* out4, float* const* gcoef, float* const* scores, const float* w, float* total) {
+    return cdr_point_fwd_pair_ex(ctx, stream, loss_kind, user_tab, item_tab, reg_user_tab, reg_item_tab, D, D, uid, iid, label, B, reg_weight, out4,
+                                 gcoef, scores, w, total);
+}
+
+// ... with reg tables reg_D <= D floats wide (both % 4 == 0): BiTGCF's loss in ONE launch -- BCE on rows of the propagated (L + 1) D-wide
+// stacks + reg_weight x EmbLoss of the batch's D-wide EGO rows (bitgcf.py:222-240) -- instead of a point loss, two EmbLoss passes with
+// their finishing blocks and two scalar adds.
+extern "C" int cdr_point_fwd_pair_ex(cdr_ctx* ctx, void* stream, int loss_kind, const float* const* user_tab, const float* const* item_tab,
+                                     const float* const* reg_user_tab, const float* const* reg_item_tab, int D, int reg_D,
+                                     const int64_t* const* uid, const int64_t* const* iid, const float* const* label, const int64_t* B,
+                                     const float* reg_weight, float* const* out4, float* const* gcoef, float* const* scores, const float* w,
+                                     float* total) {
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && iid && label && B && reg_weight && out4 && D > 0 && (D & 3) == 0);
+    CDR_CHECK_ARG(reg_D > 0 && reg_D <= D && (reg_D & 3) == 0 && (reg_D == D || (reg_user_tab && reg_item_tab)));
     CDR_CHECK_ARG(loss_kind == CDR_LOSS_MSE || loss_kind == CDR_LOSS_BCE);
     CDR_CHECK_ARG((total == nullptr) || w);
     point_pair a{};
+    a.DR = reg_D;
     bool same = true;
     int64_t bmax = 0;
     for (int d = 0; d < 2; ++d) {

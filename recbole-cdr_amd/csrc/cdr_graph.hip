@@ -196,6 +196,9 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_fwd_kernel(const int64_t* __
     }
 }
 
+// (Tried: the flagged rows' products g (.) (1 + E) formed once per row by a pass over the flag list, one gather per flagged non-zero
+//  instead of two -- 27.3 -> 25.2 and 49.2 -> 45.5 us at C4 for 5.4 + 5.7 us of extra launches: the kernel is bound by its index walk and
+//  flag probes, not by the gathers.  Not kept.)
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_flagged_bwd_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
                                                                   const float* __restrict__ values, int64_t n_rows,
@@ -667,6 +670,141 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(mix_arg a, const float*
     }
 }
 
+// The same two kernels with one lane group of LPR = D / 4 lanes per row (a float4 per lane; D % 4 == 0, D <= 256): at D = 64 a wave
+// moves four rows per request (1 KB) where the one-float-per-lane form above moves one (256 B) -- the C4 step spent 120 us in these
+// elementwise passes at 3.5 TB/s.  Same arithmetic per element, same counter-based dropout draw per element index; the squared norms are
+// summed per lane (x, y, z, w) and then across the group, i.e. in a different order than above (1 ulp).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void mix_fwd_vec_kernel(mix_arg a, const float* __restrict__ newS, const float* __restrict__ newT,
+                                                             float* __restrict__ S2, float* __restrict__ T2, float* __restrict__ catS,
+                                                             float* __restrict__ catT, int64_t ldc, float* __restrict__ nS, float* __restrict__ nT,
+                                                             const uint8_t* __restrict__ flags) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR, D = a.D;
+    const bool live = sub < (D >> 2);
+    const int64_t n = a.nu + a.ni;
+    const bool drop = a.dr.p > 0.f;
+    const uint64_t seed_s = drop ? drop_seed_of(a.dr, a.dr.salt_s) : 0, seed_t = drop ? drop_seed_of(a.dr, a.dr.salt_t) : 0;
+    const float scale = drop ? 1.0f / (1.0f - a.dr.p) : 1.0f;
+    const int64_t g0 = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR, TG = (int64_t)gridDim.x * GPB;
+    const int64_t rounds = (n + TG - 1) / TG;                     // every group runs the same trips (the group sums are wave-wide instructions)
+    for (int64_t it = 0; it < rounds; ++it) {
+        const int64_t r = g0 + it * TG;
+        const bool row = r < n;
+        const bool skip = row && flags && !flags[r];             // a row the loss never reads (last layer): its block of the stack is zero
+        const bool work = row && !skip && live;
+        float so[4] = {0.f, 0.f, 0.f, 0.f}, to[4] = {0.f, 0.f, 0.f, 0.f};
+        if (work) {
+            const bool user = r < a.nu;
+            const int64_t rl = user ? r : r - a.nu;
+            const bool mixrow = rl < (user ? a.OU : a.OI);
+            float da = 0.f, db = 0.f;
+            if (mixrow) { da = (user ? a.deg_su : a.deg_si)[rl]; db = (user ? a.deg_tu : a.deg_ti)[rl]; }
+            const int64_t e0 = r * D + 4 * sub;
+            const float4 sv = ld4(newS + e0), tv = ld4(newT + e0);
+            const float s4[4] = {sv.x, sv.y, sv.z, sv.w}, t4[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s_ = s4[k], t_ = t4[k];
+                if (drop) {
+                    s_ = drop_factor(seed_s, e0 + k, a.dr.p, scale) != 0.f ? s_ * scale : 0.0f;
+                    t_ = drop_factor(seed_t, e0 + k, a.dr.p, scale) != 0.f ? t_ * scale : 0.0f;
+                }
+                if (mixrow) {
+                    const float lap = (da * s_ + db * t_) / ((da + db) + 1e-7f);
+                    const float s_lam = a.lam_s * s_ + (1.0f - a.lam_s) * t_;
+                    const float t_lam = a.lam_t * t_ + (1.0f - a.lam_t) * s_;
+                    so[k] = (s_lam + lap) / 2.0f; to[k] = (t_lam + lap) / 2.0f;
+                } else { so[k] = s_; to[k] = t_; }
+            }
+            st4(S2 + e0, make_float4(so[0], so[1], so[2], so[3]));
+            st4(T2 + e0, make_float4(to[0], to[1], to[2], to[3]));
+        }
+        float ss = (so[0] * so[0] + so[1] * so[1]) + (so[2] * so[2] + so[3] * so[3]);
+        float st = (to[0] * to[0] + to[1] * to[1]) + (to[2] * to[2] + to[3] * to[3]);
+        ss = group_sum<LPR>(ss); st = group_sum<LPR>(st);
+        const float ns_ = sqrtf(ss), nt_ = sqrtf(st);
+        const float ds_ = fmaxf(ns_, 1e-12f), dt_ = fmaxf(nt_, 1e-12f);
+        if (row && live) {
+            st4(catS + r * ldc + 4 * sub, make_float4(so[0] / ds_, so[1] / ds_, so[2] / ds_, so[3] / ds_));       // (skipped rows: so = 0 -> zeros)
+            st4(catT + r * ldc + 4 * sub, make_float4(to[0] / dt_, to[1] / dt_, to[2] / dt_, to[3] / dt_));
+        }
+        if (row && !skip && sub == 0) { nS[r] = ns_; nT[r] = nt_; }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void mix_bwd_vec_kernel(mix_arg a, const float* __restrict__ S2, const float* __restrict__ T2,
+                                                             const float* __restrict__ nS, const float* __restrict__ nT,
+                                                             const float* __restrict__ gcatS, const float* __restrict__ gcatT, int64_t ldg,
+                                                             const float* __restrict__ gS_prev, const float* __restrict__ gT_prev,
+                                                             float* __restrict__ gnS, float* __restrict__ gnT, const uint8_t* __restrict__ flags) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR, D = a.D;
+    const bool live = sub < (D >> 2);
+    const int64_t n = a.nu + a.ni;
+    const bool drop = a.dr.p > 0.f;
+    const uint64_t seed_s = drop ? drop_seed_of(a.dr, a.dr.salt_s) : 0, seed_t = drop ? drop_seed_of(a.dr, a.dr.salt_t) : 0;
+    const float scale = drop ? 1.0f / (1.0f - a.dr.p) : 1.0f;
+    const int64_t g0 = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR, TG = (int64_t)gridDim.x * GPB;
+    const int64_t rounds = (n + TG - 1) / TG;
+    for (int64_t it = 0; it < rounds; ++it) {
+        const int64_t r = g0 + it * TG;
+        const bool row = r < n;
+        const bool skip = row && flags && !flags[r];             // (only with gS_prev == nullptr) no gradient reaches this row: exact zeros
+        const bool work = row && !skip && live;
+        float xs[4] = {0.f, 0.f, 0.f, 0.f}, xt[4] = {0.f, 0.f, 0.f, 0.f}, gys[4] = {0.f, 0.f, 0.f, 0.f}, gyt[4] = {0.f, 0.f, 0.f, 0.f};
+        float ns_ = 0.f, nt_ = 0.f;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+        if (work) {
+            ns_ = nS[r]; nt_ = nT[r];
+            const int64_t e0 = r * D + 4 * sub;
+            const float4 a4 = ld4(S2 + e0), b4 = ld4(T2 + e0), c4 = ld4(gcatS + r * ldg + 4 * sub), d4 = ld4(gcatT + r * ldg + 4 * sub);
+            if (gS_prev) { pa = ld4(gS_prev + e0); pb = ld4(gT_prev + e0); }
+            xs[0] = a4.x; xs[1] = a4.y; xs[2] = a4.z; xs[3] = a4.w; xt[0] = b4.x; xt[1] = b4.y; xt[2] = b4.z; xt[3] = b4.w;
+            gys[0] = c4.x; gys[1] = c4.y; gys[2] = c4.z; gys[3] = c4.w; gyt[0] = d4.x; gyt[1] = d4.y; gyt[2] = d4.z; gyt[3] = d4.w;
+        }
+        const float ds_ = fmaxf(ns_, 1e-12f), dt_ = fmaxf(nt_, 1e-12f);
+        float dS = 0.f, dT = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dS += (xs[k] / ds_) * gys[k]; dT += (xt[k] / dt_) * gyt[k]; }
+        dS = group_sum<LPR>(dS); dT = group_sum<LPR>(dT);
+        if (!(row && live)) continue;                            // (behind the group sums: nothing wave-wide follows)
+        const int64_t e0 = r * D + 4 * sub;
+        if (skip) {
+            st4(gnS + e0, make_float4(0.f, 0.f, 0.f, 0.f)); st4(gnT + e0, make_float4(0.f, 0.f, 0.f, 0.f));
+            continue;
+        }
+        const float pS = ns_ > 1e-12f ? dS : 0.f, pT = nt_ > 1e-12f ? dT : 0.f;
+        const bool user = r < a.nu;
+        const int64_t rl = user ? r : r - a.nu;
+        const bool mixrow = rl < (user ? a.OU : a.OI);
+        float wsv = 0.f, wtv = 0.f;
+        if (mixrow) {
+            const float dsv = (user ? a.deg_su : a.deg_si)[rl], dtv = (user ? a.deg_tu : a.deg_ti)[rl];
+            const float dl = (dsv + dtv) + 1e-7f;
+            wsv = dsv / dl; wtv = dtv / dl;
+        }
+        const float pas[4] = {pa.x, pa.y, pa.z, pa.w}, pbs[4] = {pb.x, pb.y, pb.z, pb.w};
+        float os[4], ot[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float ga = pas[k] + (gys[k] - (xs[k] / ds_) * pS) / ds_;
+            const float gb = pbs[k] + (gyt[k] - (xt[k] / dt_) * pT) / dt_;
+            if (mixrow) {
+                os[k] = 0.5f * (ga * (a.lam_s + wsv) + gb * ((1.0f - a.lam_t) + wsv));
+                ot[k] = 0.5f * (ga * ((1.0f - a.lam_s) + wtv) + gb * (a.lam_t + wtv));
+            } else { os[k] = ga; ot[k] = gb; }
+            if (drop) {
+                os[k] = drop_factor(seed_s, e0 + k, a.dr.p, scale) != 0.f ? os[k] * scale : 0.0f;
+                ot[k] = drop_factor(seed_t, e0 + k, a.dr.p, scale) != 0.f ? ot[k] * scale : 0.0f;
+            }
+        }
+        st4(gnS + e0, make_float4(os[0], os[1], os[2], os[3]));
+        st4(gnT + e0, make_float4(ot[0], ot[1], ot[2], ot[3]));
+    }
+}
+
 // the row-flag work buffer (cdr_row_flags): byte flags [rows], bit map [ceil(rows / 32)] words, the list's length, the list [rows]
 struct row_flag_views { uint8_t* flags; uint32_t* bitmap; int32_t* count; int32_t* list; size_t zero_bytes, bytes; };
 inline row_flag_views flag_views(const uint8_t* work, int64_t rows) {
@@ -829,6 +967,20 @@ extern "C" int cdr_transfer_bwd(void* stream, const float* gS_out, const float* 
     return CDR_OK;
 }
 
+// the float4 form: D a multiple of 4 up to 256, every operand 16-byte aligned with a row stride that keeps it so (NULL operands pass)
+static inline bool mix_vec_ok(int D, int64_t ld, const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
+                              const float* p5) {
+    if (D <= 0 || (D & 3) || D > 256 || (ld & 3)) return false;
+    const uintptr_t m = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)p3 | (uintptr_t)p4 | (uintptr_t)p5;
+    return (m & 15) == 0;
+}
+static inline int64_t mix_vec_grid(int64_t rows, int lpr) {
+    const int gpb = kBlock / lpr;
+    int64_t grid = (rows + gpb - 1) / gpb;
+    if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
+    return grid < 1 ? 1 : grid;
+}
+
 #define MIX_DISPATCH(KERNEL, ...)                                                                                                   \
     switch ((D + 63) / 64) {                                                                                                      \
         case 1: KERNEL<1><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(__VA_ARGS__); break;                    \
@@ -846,6 +998,13 @@ extern "C" int cdr_bitgcf_mix_fwd(void* stream, const float* newS, const float* 
     CDR_CHECK_ARG(newS && newT && deg_su && deg_tu && deg_si && deg_ti && S2 && T2 && catS_block && catT_block && nS && nT);
     CDR_CHECK_ARG(nu > 0 && ni > 0 && D > 0 && D <= 64 * kMixMaxJ && ldc >= D && p >= 0.f && p < 1.f);
     const mix_arg a{deg_su, deg_tu, deg_si, deg_ti, nu, ni, OU, OI, D, lam_s, lam_t, drop_arg{p, seed, seed_dev, salt_s, salt_t, 0}};
+    if (mix_vec_ok(D, ldc, newS, newT, S2, T2, catS_block, catT_block)) {
+        const int lpr = cdr_lpr_for(D);
+        const int64_t grid = mix_vec_grid(nu + ni, lpr);
+        DISPATCH_LPR(lpr, mix_fwd_vec_kernel<L><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(a, newS, newT, S2, T2, catS_block, catT_block, ldc, nS, nT, row_flags));
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
+    }
     int64_t grid = (nu + ni + 3) / 4;
     if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
     MIX_DISPATCH(mix_fwd_kernel, a, newS, newT, S2, T2, catS_block, catT_block, ldc, nS, nT, row_flags);
@@ -862,9 +1021,16 @@ extern "C" int cdr_bitgcf_mix_bwd(void* stream, const float* S2, const float* T2
     CDR_CHECK_ARG(S2 && T2 && nS && nT && gcatS_block && gcatT_block && deg_su && deg_tu && deg_si && deg_ti && gnS && gnT);
     CDR_CHECK_ARG(nu > 0 && ni > 0 && D > 0 && D <= 64 * kMixMaxJ && ldg >= D && p >= 0.f && p < 1.f && ((gS_prev == nullptr) == (gT_prev == nullptr)));
     const mix_arg a{deg_su, deg_tu, deg_si, deg_ti, nu, ni, OU, OI, D, lam_s, lam_t, drop_arg{p, seed, seed_dev, salt_s, salt_t, 0}};
+    CDR_CHECK_ARG(!row_flags || !gS_prev);                    // flags mean "no gradient reaches the other rows": last layer only
+    if (mix_vec_ok(D, ldg, S2, T2, gcatS_block, gcatT_block, gnS, gnT) && mix_vec_ok(D, ldg, gS_prev, gT_prev, gnS, gnT, gnS, gnT)) {
+        const int lpr = cdr_lpr_for(D);
+        const int64_t grid = mix_vec_grid(nu + ni, lpr);
+        DISPATCH_LPR(lpr, mix_bwd_vec_kernel<L><<<dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream>>>(a, S2, T2, nS, nT, gcatS_block, gcatT_block, ldg, gS_prev, gT_prev, gnS, gnT, row_flags));
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
+    }
     int64_t grid = (nu + ni + 3) / 4;
     if (grid > CDR_NUM_CU * 16) grid = CDR_NUM_CU * 16;
-    CDR_CHECK_ARG(!row_flags || !gS_prev);                    // flags mean "no gradient reaches the other rows": last layer only
     MIX_DISPATCH(mix_bwd_kernel, a, S2, T2, nS, nT, gcatS_block, gcatT_block, ldg, gS_prev, gT_prev, gnS, gnT, row_flags);
     CDR_LAUNCH_CHECK();
     return CDR_OK;

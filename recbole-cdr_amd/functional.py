@@ -1295,6 +1295,93 @@ class BiTGCFPropagate(Function):
         return (gS[:nu], gS[nu:], gT[:nu], gT[nu:]) + (None,) * 13
 
 
+class _InnerCtx:
+    """What a Function's forward / backward need of ``ctx`` when another node runs them as a part of itself (BiTGCFLoss)."""
+    needs_input_grad = (True,)
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, _flag):
+        pass
+
+
+class BiTGCFLoss(Function):
+    """BiTGCF.calculate_loss (bitgcf.py:207-240) as ONE autograd node: the propagation (BiTGCFPropagate's forward, last layer on the
+    batch's rows), then both domains' losses -- BCE on the batch's rows of the propagated stacks + reg_weight x EmbLoss of the batch's EGO
+    rows -- in ONE launch (cdr_point_fwd_pair_ex: the EmbLoss rows ride in the same lane groups as the stack rows; the finishing block
+    writes bce + reg_weight (||U_b|| + ||I_b||) / B).  Backward: one scatter launch into the stack gradients (zero-filled on the side by
+    the loss launch), the propagation's backward, one launch for both domains' EmbLoss gradient rows added into the table gradients.
+    Against separate nodes (round 4): no EmbLoss partial / finish launches (4), no scalar adds and their backward scalings (4), one EmbLoss
+    backward launch instead of two, no fill launch: 37 -> 27 launches per step at BASELINE C4.  Returns (loss_source [1], loss_target [1])."""
+
+    @staticmethod
+    def forward(ctx, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p, drop_seed, reg_weight,
+                us, is_, ls, ut, it, lt):
+        dev, D = su.device, su.shape[1]
+        nu = su.shape[0]
+        inner = _InnerCtx()
+        S, T, _, _ = BiTGCFPropagate.forward(inner, su, si, tu, ti, gs, gt, deg, n_layers, lam_s, lam_t, connect_way, OU, OI, drop_p, drop_seed,
+                                             (us, is_, ut, it), False)
+        W = S.shape[1]
+        assert W % 4 == 0 and D % 4 == 0 and S.is_contiguous() and T.is_contiguous()
+        ids = [_ids(us), _ids(is_), _ids(ut), _ids(it)]
+        labels = [ls.reshape(-1).contiguous().to(torch.float32), lt.reshape(-1).contiguous().to(torch.float32)]
+        ego = [su.contiguous(), si.contiguous(), tu.contiguous(), ti.contiguous()]
+        out8 = torch.empty(2, 4, device=dev, dtype=torch.float32)
+        gc = [torch.empty(ids[0].numel(), device=dev, dtype=torch.float32), torch.empty(ids[2].numel(), device=dev, dtype=torch.float32)]
+        gstack = None
+        if any(ctx.needs_input_grad[:4]):
+            gstack = torch.empty(2, S.shape[0], W, device=dev, dtype=torch.float32)          # zero-filled by the loss launch, on the side
+            B_.call('cdr_ctx_scrub_next', B_.ctx(dev), B_.raw(gstack), 4 * gstack.numel())
+        P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+        io = 4 * nu * W                                               # byte offset of the item rows inside a stack
+        B_._alive.extend(ids + labels + ego)
+        B_.call('cdr_point_fwd_pair_ex', B_.ctx(dev), B_.stream(), B_.CDR_LOSS_BCE, P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io),
+                P2(ego[0].data_ptr(), ego[2].data_ptr()), P2(ego[1].data_ptr(), ego[3].data_ptr()), W, D,
+                P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), P2(labels[0].data_ptr(), labels[1].data_ptr()),
+                I2(ids[0].numel(), ids[2].numel()), F2(float(reg_weight), float(reg_weight)), P2(out8.data_ptr(), out8.data_ptr() + 16),
+                P2(gc[0].data_ptr(), gc[1].data_ptr()), None, None, None)
+        ctx.inner, ctx.keep = inner, (S, T, ids, gc, out8, ego, gstack)
+        ctx.nu, ctx.reg_weight = nu, float(reg_weight)
+        ctx.set_materialize_grads(False)
+        return out8[0, :1], out8[1, :1]
+
+    @staticmethod
+    def backward(ctx, g_s, g_t):
+        S, T, ids, gc, out8, ego, gstack = ctx.keep
+        dev, W, D, nu = S.device, S.shape[1], ego[0].shape[1], ctx.nu
+        zero = None
+        gos = []
+        for g in (g_s, g_t):
+            if g is None:
+                zero = torch.zeros(1, device=dev, dtype=torch.float32) if zero is None else zero
+                g = zero
+            gos.append(g.reshape(-1)[:1].contiguous().to(torch.float32))
+        if gstack is None:
+            gstack = torch.zeros(2, S.shape[0], W, device=dev, dtype=torch.float32)
+        ctx.keep = None
+        gS, gT = gstack[0], gstack[1]
+        P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
+        io = 4 * nu * W
+        nB = I2(ids[0].numel(), ids[2].numel())
+        # stack gradients only (reg_weight 0 here: the EmbLoss rows belong to the EGO tables and are added at the end, below)
+        B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io), None, None, W,
+                P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), nB,
+                P2(gc[0].data_ptr(), gc[1].data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(0.0, 0.0),
+                P2(gos[0].data_ptr(), gos[1].data_ptr()), None, P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr() + io, gT.data_ptr() + io), None, None)
+        grads = BiTGCFPropagate.backward(ctx.inner, gS, gT, None, None)
+        gsu, gsi, gtu, gti = grads[:4]                              # views of two [n, D] buffers: users, then items
+        if ctx.reg_weight != 0.0:
+            B_.call('cdr_embloss_bwd_dense_pair', B_.stream(), P2(ego[0].data_ptr(), ego[2].data_ptr()), P2(ego[1].data_ptr(), ego[3].data_ptr()), D,
+                    P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), nB,
+                    P2(out8.data_ptr() + 8, out8.data_ptr() + 24), P2(gos[0].data_ptr(), gos[1].data_ptr()), F2(ctx.reg_weight, ctx.reg_weight),
+                    P2(gsu.data_ptr(), gtu.data_ptr()), P2(gsi.data_ptr(), gti.data_ptr()))
+        del gos
+        ctx.inner = None
+        return (gsu, gsi, gtu, gti) + (None,) * 18
+
+
 class EmbLossRows(Function):
     """recbole EmbLoss of gathered EGO rows: (||U[uid]||_F + ||I[iid]||_F) / B  (bitgcf.py:231-233)."""
 

@@ -17,6 +17,7 @@ import torch
 
 from .binding import capturing
 from .data.interaction import Interaction
+from .utils import total_loss as _total
 
 
 def dev_of(interaction):
@@ -85,7 +86,7 @@ class GraphedTrainStep:
         # their addresses are the same on every replay
         self.optimizer.zero_grad(set_to_none=True)
         losses = self.model.calculate_loss(interaction)
-        loss = sum(losses) if isinstance(losses, tuple) else losses
+        loss = _total(losses)
         if loss.dim():
             loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()   # (a [1]-shaped loss: a view, not a reduction launch)
         loss.backward(self._one if loss.dtype == torch.float32 else None)
@@ -139,7 +140,7 @@ class GraphedTrainStep:
             cur = st[i & 1]
             self.optimizer.zero_grad(set_to_none=True)
             losses = M.calculate_loss(cur)
-            loss = sum(losses) if isinstance(losses, tuple) else losses
+            loss = _total(losses)
             if loss.dim():
                 loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
             side.wait_stream(main)
@@ -166,7 +167,7 @@ class GraphedTrainStep:
         for i in range(k):
             self.optimizer.zero_grad(set_to_none=True)
             losses = self.model.calculate_loss(self.static)
-            loss = sum(losses) if isinstance(losses, tuple) else losses
+            loss = _total(losses)
             if loss.dim():
                 loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
             side.wait_stream(main)

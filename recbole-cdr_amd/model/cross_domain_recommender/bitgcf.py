@@ -57,6 +57,8 @@ class BiTGCF(CrossDomainRecommender):
         self.connect_way = config['connect_way']
         # config['bitgcf_sparse_last_layer'] = False: every row of the last layer is computed in calculate_loss, as the reference does
         self.sparse_last_layer = bool(config['bitgcf_sparse_last_layer']) if 'bitgcf_sparse_last_layer' in config else True
+        # config['bitgcf_fused_loss'] = False: propagation, point loss and EmbLoss as separate autograd nodes (the round-4 form)
+        self.fused_loss = bool(config['bitgcf_fused_loss']) if 'bitgcf_fused_loss' in config else True
 
         self.source_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
         self.target_user_embedding = nn.Embedding(self.total_num_users, self.latent_dim)
@@ -119,6 +121,17 @@ class BiTGCF(CrossDomainRecommender):
         # with the SAME row of the other, so both batches flag both stacks)
         hint = (interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.TARGET_USER_ID],
                 interaction[self.TARGET_ITEM_ID]) if self.sparse_last_layer else None
+        D = self.source_user_embedding.weight.shape[1]
+        if hint is not None and self.fused_loss and D % 4 == 0 and not F_.deterministic():
+            # propagation + both domains' BCE + reg_weight x EmbLoss as ONE autograd node (functional.BiTGCFLoss): 27 launches per step
+            # at BASELINE C4 instead of 37
+            return F_.BiTGCFLoss.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
+                                       self.target_user_embedding.weight, self.target_item_embedding.weight,
+                                       self.source_graph, self.target_graph, self.degrees, int(self.n_layers),
+                                       float(self.domain_lambda_source), float(self.domain_lambda_target), self.connect_way,
+                                       int(self.overlapped_num_users), int(self.overlapped_num_items), *self._dropout_args(), float(self.reg_weight),
+                                       interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.SOURCE_LABEL],
+                                       interaction[self.TARGET_USER_ID], interaction[self.TARGET_ITEM_ID], interaction[self.TARGET_LABEL])
         S, T, reg_s, reg_t = self._propagate(hint, emb_loss=hint is not None)
         nu = self.total_num_users
         su, si, sl = interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.SOURCE_LABEL]

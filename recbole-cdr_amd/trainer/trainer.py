@@ -9,7 +9,7 @@ the dense optimizer is the native exact Adam (csrc/cdr_rows.hip ``cdr_adam_dense
 import numpy as np
 import torch
 
-from ..utils import train_mode2state
+from ..utils import train_mode2state, total_loss as _total
 
 
 class DenseAdam(torch.optim.Optimizer):
@@ -231,7 +231,7 @@ class Trainer:
     def _eager_step(self, interaction):
         self.optimizer.zero_grad(set_to_none=True)
         losses = self.model.calculate_loss(interaction)
-        loss = sum(losses) if isinstance(losses, tuple) else losses
+        loss = _total(losses)
         loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
         loss.backward()
         from ..graph_step import step_and_sum
@@ -317,7 +317,7 @@ class Trainer:
                 continue
             self.optimizer.zero_grad()
             losses = self.model.calculate_loss(interaction)
-            loss = sum(losses) if isinstance(losses, tuple) else losses
+            loss = _total(losses)
             loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()   # (a [1]-shaped loss: a view, not a reduction launch)
             loss.backward()
             if self.clip_grad_norm:

@@ -40,3 +40,15 @@ def get_trainer(model_type, model_name):
     pkg = __name__.rsplit('.', 1)[0]
     trainer_mod = importlib.import_module(f'{pkg}.trainer')
     return getattr(trainer_mod, model_name + 'Trainer', trainer_mod.CrossDomainTrainer)
+
+
+def total_loss(losses):
+    """The scalar a trainer backpropagates: ``losses`` itself, or the sum of a tuple's parts (the reference's ``sum(losses)``,
+    trainer.py:55-63) -- added left to right WITHOUT Python sum()'s leading ``0 +`` (a launch of its own inside a captured step; adding
+    0.0 changes no bit)."""
+    if not isinstance(losses, tuple):
+        return losses
+    out = losses[0]
+    for part in losses[1:]:
+        out = out + part
+    return out

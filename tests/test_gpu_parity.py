@@ -1604,6 +1604,45 @@ def test_bitgcf_training_dropout_value_parity_with_the_same_mask(sparse_last, co
         assert_close(v.grad, P[k].grad, what=f'grad {k} under dropout')
 
 
+@pytest.mark.parametrize('connect_way,L,D,reg', [('concat', 2, 16, 1e-3), ('concat', 3, 32, 0.05), ('mean', 2, 64, 1e-2), ('concat', 1, 8, 0.0)])
+def test_bitgcf_loss_as_one_node_equals_the_separate_nodes(connect_way, L, D, reg):
+    """functional.BiTGCFLoss (propagation + BCE on the stacks + reg_weight x EmbLoss of the ego rows in one autograd node, the loss value in
+    ONE launch through cdr_point_fwd_pair_ex with D-wide reg rows beside (L + 1) D-wide stack rows) against the round-4 form
+    (config bitgcf_fused_loss = False: BiTGCFPropagate + TwoStackPointLoss + two scalar adds): both losses to 1e-6, all four table
+    gradients to 1e-5 (fp32 atomics in both), batches with repeated users and items; the trainer's total_loss adds them in the same order."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.bitgcf import BiTGCF
+    from recbole_cdr_amd.utils import total_loss
+    ids = IdSpace(OU=30, TOU=25, SOU=20, OI=1, TOI=40, SOI=35)
+    rng = np.random.RandomState(5)
+    su_ = np.r_[1:ids.OU, ids.OU + ids.TOU:ids.total_num_users]; si_ = np.r_[ids.OI + ids.TOI:ids.total_num_items]
+    tu_ = np.r_[1:ids.OU + ids.TOU]; ti_ = np.r_[1:ids.OI + ids.TOI]
+    s_pairs = np.unique(np.stack([rng.choice(su_, 400), rng.choice(si_, 400)], 1), axis=0)
+    t_pairs = np.unique(np.stack([rng.choice(tu_, 500), rng.choice(ti_, 500)], 1), axis=0)
+    ds = FakeDataset(ids, s_pairs=s_pairs.astype(np.int64), t_pairs=t_pairs.astype(np.int64))
+    B = 96
+    inter = {'source_user_id': torch.from_numpy(rng.choice(su_, B)), 'source_item_id': torch.from_numpy(rng.choice(si_, B)),
+             'source_label': torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32)),
+             'target_user_id': torch.from_numpy(rng.choice(tu_, B)), 'target_item_id': torch.from_numpy(rng.choice(ti_, B)),
+             'target_label': torch.from_numpy((rng.rand(B) < 0.5).astype(np.float32))}
+    inter['source_user_id'][:10] = inter['source_user_id'][0]; inter['target_item_id'][:7] = inter['target_item_id'][0]
+    got = []
+    for fused in (True, False):
+        cfg = base_config(DEV, embedding_size=D, n_layers=L, reg_weight=reg, lambda_source=0.8, lambda_target=0.7, drop_rate=0.0,
+                          connect_way=connect_way, bitgcf_fused_loss=fused)
+        torch.manual_seed(1)
+        model = BiTGCF(cfg, ds).to(DEV)
+        model.train()
+        assert model.fused_loss is fused
+        losses = model.calculate_loss(to_dev(inter, DEV))
+        assert isinstance(losses, tuple) and len(losses) == 2
+        total_loss(losses).sum().backward()
+        got.append((torch.stack([x.detach().reshape(()) for x in losses]), {k: v.grad.clone() for k, v in model.named_parameters()}))
+    assert_close(got[0][0], got[1][0], rtol=1e-6, what='losses')
+    for k in got[0][1]:
+        assert_close(got[0][1][k], got[1][1][k], rtol=1e-5, what=f'grad {k}')
+
+
 @pytest.mark.parametrize('U,N,D', [(1, 1000, 128), (3, 777, 64), (4, 5000, 128), (33, 4133, 128), (64, 6400, 64), (100, 8229, 128),
                                    (300, 20011, 64), (130, 63, 128), (40, 2000, 32)])
 def test_fullsort_paths_vs_fp64(U, N, D):
