@@ -603,7 +603,9 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         constexpr bool PIPE = !TOPK && (MT == 2 || K == 64);
         // D = 128, two tiles per wave: also the LDS park of the prefetched tile moves into the phase (+8 % at U = 1,024; it lost
         // 5..20 % at D = 64, where the phase is half as long)
-        constexpr bool PARK_IN = PIPE && MT == 2 && K == 128;
+        // (round 5: the top-k form parks there as well -- it has no stores to hide, but its park sat exposed between the phase and the
+        //  threshold compare)
+        constexpr bool PARK_IN = (PIPE || TOPK) && MT == 2 && K == 128;
         f32x16 prev[MT];
         int prev_tile = -1;
         for (; tile < NT; tile += n_stripes) {
