@@ -317,6 +317,9 @@ __device__ __forceinline__ bool topk_masked(const topk_mask& mk, int64_t u, int 
 }
 
 // e / ec: this lane's list entry (lanes >= k carry -inf / -1 and never change).  Returns the new k-th value.
+// DEDUP: a candidate whose column already sits in the list is dropped (the persistent kernel's overflow recovery re-offers a whole tile,
+// part of which may have entered the list through the queues already).
+template <bool DEDUP = false>
 __device__ __forceinline__ float topk_offer(float v, int col, float thr, float& e, int& ec, int k, const topk_mask& mk, int64_t u) {
     const int lane = threadIdx.x & 63;
     bool pass = v > thr;
@@ -331,6 +334,7 @@ __device__ __forceinline__ float topk_offer(float v, int col, float thr, float& 
         const float cv = __shfl(v, l);
         const int cc = __shfl(col, l);
         if (!(cv > thr)) continue;                                             // wave-uniform: the k-th value rose meanwhile
+        if (DEDUP && __ballot(lane < k && ec == cc)) continue;
         const int pos = __popcll(__ballot(lane < k && e >= cv));                // entries that stay in front (ties: first seen)
         const float up = __shfl_up(e, 1);
         const int upc = __shfl_up(ec, 1);
@@ -477,6 +481,9 @@ static int gemv_topk_dispatch(hipStream_t s, const float* users, int U, int D, c
 }
 
 constexpr int kTopkQueue = 256;
+#ifndef TOPK_TEST_FIRST_STEP
+#define TOPK_TEST_FIRST_STEP 0
+#endif
 
 struct topk_out {
     int k;
@@ -488,6 +495,8 @@ struct topk_out {
 
 // Mask test for the queued candidates, one per lane (64 binary searches in flight), then the survivors enter their
 // user's list one at a time (LDS only).  Thresholds may have risen since a candidate was queued: re-tested on insert.
+// (Tried in round 5: row-parallel insertion -- lane l owns row l's list and walks the compacted queue itself: every step of such a
+//  per-lane loop is a dependent LDS round trip, 26.7 -> 32.3 ms at U = 1,024, k = 10.)
 __device__ __forceinline__ void topk_flush(volatile float* qv, volatile int* qc, volatile int* qu, int qn, volatile float* thr_l,
                                            volatile float* lv, volatile int* lc, const topk_out& tk, int64_t u0) {
     const int lane = threadIdx.x & 63;
@@ -510,7 +519,7 @@ __device__ __forceinline__ void topk_flush(volatile float* qv, volatile int* qc,
             if (!(cv > thr)) continue;
             float e = lane < tk.k ? lv[cu * tk.k + lane] : -INFINITY;
             int ec = lane < tk.k ? lc[cu * tk.k + lane] : -1;
-            const float nthr = topk_offer(lane == 0 ? cv : -INFINITY, cc, thr, e, ec, tk.k, none, 0);
+            const float nthr = topk_offer<true>(lane == 0 ? cv : -INFINITY, cc, thr, e, ec, tk.k, none, 0);
             if (lane < tk.k) { lv[cu * tk.k + lane] = e; lc[cu * tk.k + lane] = ec; }
             if (lane == 0) thr_l[cu] = nthr;
         }
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
     volatile float* qv = q0 + wave * QC * 3;
     volatile int* qc = reinterpret_cast<volatile int*>(qv + QC);
     volatile int* qu = qc + QC;
-    int* qcnt = reinterpret_cast<int*>(const_cast<float*>(q0) + 4 * QC * 3);                  // [4] queue fills, [4] = overflow flag
+    int* qcnt = reinterpret_cast<int*>(const_cast<float*>(q0) + 4 * QC * 3);                  // [4] queue fills, [4] = overflow flag, [5] = attention flag (a queue half full / overflowed)
 
     for (int mb = mslot; mb < MB; mb += MBc) {
         const int m0 = mb * BM + wm * 32 * MT;
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         if (TOPK) {
             for (int i = tid; i < BM; i += 256) thr_l[i] = -INFINITY;
             for (int i = tid; i < BM * tk.k; i += 256) { lv[i] = -INFINITY; lc[i] = -1; }
-            if (tid < 5) qcnt[tid] = 0;
+            if (tid < 6) qcnt[tid] = 0;
         }
         // this wave's user rows, whole K, in registers (loaded once per user block)
         float4 a[MT][KS];
@@ -608,6 +617,42 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         constexpr bool PARK_IN = (PIPE || TOPK) && MT == 2 && K == 128;
         f32x16 prev[MT];
         int prev_tile = -1;
+        // the slow path of one tile (accumulators x): through LDS, the owner waves scan their rows; queued candidates first, then the tile's
+        auto slow_scan = [&](const f32x16 (&x)[MT], int tl) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sc[(wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * SCS + wn * 32 + li] = x[t][r];
+            __syncthreads();
+            if (tid == 0) qcnt[4] = 0;
+            int qn = qcnt[wave];               // the owner wave scans its rows: private appends, flushes as it goes
+            if (qn > QC) qn = QC;
+            const int col = tk.col_off + tl * BN + lane;
+            const float tl_ = thr_l[wave * RPW + (lane % RPW)];
+#pragma unroll 1
+            for (int r0 = 0; r0 < RPW; r0 += 8) {                         // eight rows' scores at a time (independent reads)
+                float vr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vr[j] = sc[(wave * RPW + r0 + j) * SCS + lane];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ul = wave * RPW + r0 + j;
+                    const float thr = __shfl(tl_, r0 + j);
+                    const bool pass = vr[j] > thr && (int64_t)mb * BM + ul < M;
+                    const unsigned long long m = __ballot(pass);
+                    if (m == 0) continue;
+                    if (qn + 64 > QC) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+                    if (pass) {
+                        const int at = qn + __popcll(m & ((1ull << lane) - 1));
+                        qv[at] = vr[j]; qc[at] = col; qu[at] = ul;
+                    }
+                    qn += __popcll(m);
+                }
+            }
+            if (qn) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
+            if (lane == 0) qcnt[wave] = 0;
+        };
         for (; tile < NT; tile += n_stripes) {
             const int next = tile + n_stripes;
             const bool has_next = next < NT;
@@ -627,6 +672,67 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             const float* bs = smem + buf * BUF + frag_off;
+            const bool pend = TOPK && prev_tile >= 0;             // a tile's accumulators wait in `prev` for their threshold test
+            // The waiting tile against its users' k-th values, branch-free inside the phase: the thresholds of the wave's 32 MT user rows
+            // come as 4 MT 16-byte LDS reads issued in front of the first MFMA (they only change in the drain phases, which sit between
+            // barriers; rows past M get +inf), each K step then tests four rows with plain compares into a per-lane bit mask -- a few VALU
+            // instructions per MFMA, no waitcnt, no branch (the first shadowed form tested and appended inside the phase: a stalled LDS
+            // read or a branch there keeps the wave from issuing its next MFMA, and the compare cost 6 ms of 28 exactly as it had behind
+            // the phase).  Survivors (bits set) are appended to the owners' queues behind the phase: about half of the tiles have none.
+            // (Register pressure decides here: holding all 4 MT threshold float4 through the phase pushed the kernel's arrays out of the 256
+            //  architectural VGPRs -- 247 AGPRs of moves -- and the test cost 5 ms of 28: thresholds are read one group AHEAD of their test,
+            //  four registers at a time.  Tried: the compares as wave masks OR-ed on the scalar unit with the exact per-lane tests redone
+            //  behind the phase for the tiles that have a candidate -- 24.0 -> 24.7 ms at k = 1, 26.7 -> 29.6 at k = 10.)
+            unsigned passmask = 0u, validmask = 0xFFFFFFFFu;
+            const float* thr_base = const_cast<const float*>(thr_l) + wm * 32 * MT + 4 * lh;
+            constexpr int TG0 = TOPK_TEST_FIRST_STEP;                // first K step that tests a group
+            float4 th_next = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pend && (int64_t)(mb + 1) * BM > M) {               // the last user block: rows past M never survive
+#pragma unroll
+                for (int g = 0; g < MT * 4; ++g)
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl) {
+                        const int ul = wm * 32 * MT + 32 * (g >> 2) + 8 * (g & 3) + 4 * lh + rl;
+                        if ((int64_t)mb * BM + ul >= M) validmask &= ~(1u << (4 * g + rl));
+                    }
+            }
+            auto test_group = [&](int g) {
+                if (g == 0) th_next = *reinterpret_cast<const float4*>(thr_base);
+                const float4 th = th_next;
+                if (g + 1 < MT * 4) th_next = *reinterpret_cast<const float4*>(thr_base + 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3));
+                const int t = g >> 2, r4 = g & 3;
+                passmask |= (prev[t][4 * r4] > th.x ? 1u : 0u) << (4 * g);
+                passmask |= (prev[t][4 * r4 + 1] > th.y ? 1u : 0u) << (4 * g + 1);
+                passmask |= (prev[t][4 * r4 + 2] > th.z ? 1u : 0u) << (4 * g + 2);
+                passmask |= (prev[t][4 * r4 + 3] > th.w ? 1u : 0u) << (4 * g + 3);
+            };
+            // bit 4 g + rl of a lane's mask: accumulator 4 (g & 3) + rl of tile row block g >> 2 survived -> one slot in the queue of the wave
+            // that owns its row
+            auto append_survivors = [&]() {
+                passmask &= validmask;
+                if (__ballot(passmask != 0u) == 0) return;
+#pragma unroll
+                for (int g = 0; g < MT * 4; ++g) {
+                    if (__ballot((passmask >> (4 * g)) & 0xFu) == 0) continue;
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl) {
+                        const int t = g >> 2, r = 4 * (g & 3) + rl;
+                        if (!((passmask >> (4 * g + rl)) & 1u)) continue;
+                        const int ul = wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int owner = ul / RPW;
+                        const int slot = atomicAdd(&qcnt[owner], 1);
+                        if (slot < QC) {
+                            volatile float* ov = q0 + owner * QC * 3;
+                            ov[slot] = prev[t][r];
+                            reinterpret_cast<volatile int*>(ov + QC)[slot] = tk.col_off + prev_tile * BN + wn * 32 + li;
+                            reinterpret_cast<volatile int*>(ov + 2 * QC)[slot] = ul;
+                            if (slot >= QC / 2 - 1) qcnt[5] = 1;          // half full: every wave drains behind the next barrier
+                        } else {
+                            qcnt[4] = 1; qcnt[5] = 1;
+                        }
+                    }
+                }
+            };
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const float4 b = ld4(bs + 8 * s);
@@ -637,6 +743,9 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].z, b.z, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s].w, b.w, acc[t], 0, 0, 0);
                 }
+                // TOPK: the tile that waits in `prev` is compared with its users' k-th values HERE, one group of four user rows per K step,
+                // in the shadow of this tile's MFMAs (round 5: behind the phase the same work cost 2,400 of a tile's 13,900 cycles)
+                if (TOPK && pend && s >= TG0 && s < TG0 + MT * 4) test_group(s - TG0);
                 if (PARK_IN && s == KS / 4) {   // the prefetched tile is parked inside the phase too (its loads landed a while ago)
                     float* dst = smem + (buf ^ 1) * BUF;
 #pragma unroll
@@ -685,101 +794,48 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                 }
                 __syncthreads();
             } else {
-                // Fast path: every accumulator is compared IN REGISTERS with the k-th value of its user row; the rare survivor
-                // (expected k ln(n/k) per user over the whole stream) reserves a slot in the queue of the wave that owns the
-                // row's list (LDS atomic) -- no LDS round trip of the score tile, no extra barrier.  Queues are drained between
-                // two barriers when one is half full.  The first tiles of a user block (thresholds still -inf) and any tile
-                // whose survivors do not fit take the slow path: the whole tile goes through LDS and the owner waves scan it.
-                bool slow = tiles_done < 2;
-                const int qstart = qcnt[wave];
-                // the k-th values of four consecutive user rows come as one 16-byte LDS read (they only change in the drain
-                // phases, which sit between barriers)
-                float4 th4[MT][4];
-                bool any = false;
-                if (!slow) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4) {
-                            th4[t][r4] = *reinterpret_cast<const float4*>(const_cast<const float*>(thr_l) + wm * 32 * MT + 32 * t + 8 * r4 + 4 * lh);
-                            any |= acc[t][4 * r4] > th4[t][r4].x || acc[t][4 * r4 + 1] > th4[t][r4].y ||
-                                   acc[t][4 * r4 + 2] > th4[t][r4].z || acc[t][4 * r4 + 3] > th4[t][r4].w;
-                        }
+                // Fast path: every accumulator is compared IN REGISTERS with the k-th value of its user row (offer_group, in the shadow of
+                // the NEXT tile's MFMA phase); the rare survivor (expected k ln(n/k) per user over the whole stream) reserves a slot in
+                // the queue of the wave that owns the row's list (LDS atomic) -- no LDS round trip of the score tile.  Queues are drained
+                // between two barriers when one is half full.  The first tiles of a user block (thresholds still -inf) and any tile whose
+                // survivors do not fit take the slow path: the whole tile goes through LDS and the owner waves scan it (a candidate that
+                // had entered a list through the queues already is dropped there: topk_offer<DEDUP>).
+                if (pend) {
+                    if constexpr (KS - TG0 < MT * 4) { for (int g = KS - TG0; g < MT * 4; ++g) test_group(g); }
+                    append_survivors();
                 }
-                if (!slow && __ballot(any)) {       // about half of the tiles end here: no survivor in the whole wave
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4) {
-                          const float th[4] = {th4[t][r4].x, th4[t][r4].y, th4[t][r4].z, th4[t][r4].w};
-#pragma unroll
-                          for (int rl = 0; rl < 4; ++rl) {
-                            const int r = 4 * r4 + rl;
-                            const int ul = wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            const bool pass = acc[t][r] > th[rl] && (int64_t)mb * BM + ul < M;
-                            if (__ballot(pass) == 0) continue;
-                            if (pass) {
-                                const int owner = ul / RPW;
-                                const int slot = atomicAdd(&qcnt[owner], 1);
-                                if (slot < QC) {
-                                    volatile float* ov = q0 + owner * QC * 3;
-                                    ov[slot] = acc[t][r];
-                                    reinterpret_cast<volatile int*>(ov + QC)[slot] = tk.col_off + tile * BN + wn * 32 + li;
-                                    reinterpret_cast<volatile int*>(ov + 2 * QC)[slot] = ul;
-                                } else {
-                                    qcnt[4] = 1;
-                                }
-                            }
-                          }
-                        }
-                }
-                __syncthreads();                   // parked tile + queue appends visible
-                if (!slow && qcnt[4]) {            // some queue overflowed: forget this tile's appends, redo it the slow way
-                    slow = true;
-                    if (lane == 0) qcnt[wave] = qstart;
-                }
+                __syncthreads();                   // parked tile + the waiting tile's queue appends visible
+                const int att = qcnt[5];           // ONE LDS read per tile: some queue is half full or overflowed (set by the appender)
                 bool refresh = false;
-                if (slow) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            sc[(wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * SCS + wn * 32 + li] = acc[t][r];
-                    __syncthreads();
-                    if (tid == 0) qcnt[4] = 0;
-                    int qn = qcnt[wave];           // the owner wave scans its rows: private appends, flushes as it goes
-                    const int col = tk.col_off + tile * BN + lane;
-                    const float tl = thr_l[wave * RPW + (lane % RPW)];
-#pragma unroll 1
-                    for (int r0 = 0; r0 < RPW; r0 += 8) {                         // eight rows' scores at a time (independent reads)
-                        float vr[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) vr[j] = sc[(wave * RPW + r0 + j) * SCS + lane];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int ul = wave * RPW + r0 + j;
-                            const float thr = __shfl(tl, r0 + j);
-                            const bool pass = vr[j] > thr && (int64_t)mb * BM + ul < M;
-                            const unsigned long long m = __ballot(pass);
-                            if (m == 0) continue;
-                            if (pass) {
-                                const int at = qn + __popcll(m & ((1ull << lane) - 1));
-                                qv[at] = vr[j]; qc[at] = col; qu[at] = ul;
-                            }
-                            qn += __popcll(m);
-                            if (qn > QC - 64) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
-                        }
-                    }
-                    if (qn) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
-                    if (lane == 0) qcnt[wave] = 0;
-                    refresh = true;
-                } else if (qcnt[0] >= QC / 2 || qcnt[1] >= QC / 2 || qcnt[2] >= QC / 2 || qcnt[3] >= QC / 2) {   // uniform
-                    const int qn = qcnt[wave];
-                    if (qn) topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM);
-                    if (lane == 0) qcnt[wave] = 0;
+                if (att && qcnt[4]) {              // some queue overflowed: the waiting tile goes the slow way
+                    if (lane == 0 && qcnt[wave] > QC) qcnt[wave] = QC;
+                    slow_scan(prev, prev_tile);
                     refresh = true;
                 }
-                if (refresh) __syncthreads();      // lists, k-th values and empty queues visible before anyone appends again
+                const bool slow_now = tiles_done < 2;
+                if (slow_now) {
+                    if (refresh) __syncthreads();
+                    slow_scan(acc, tile);
+                    refresh = true;
+                    prev_tile = -1;
+                } else {
+                    if (att && !refresh && (qcnt[0] >= QC / 2 || qcnt[1] >= QC / 2 || qcnt[2] >= QC / 2 || qcnt[3] >= QC / 2)) {   // uniform
+                        const int qn = qcnt[wave];
+                        if (qn) topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM);
+                        if (lane == 0) qcnt[wave] = 0;
+                        refresh = true;
+                    }
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) prev[t] = acc[t];
+                    prev_tile = tile;
+                }
+                if (refresh) {                     // lists, k-th values and empty queues visible before anyone appends again
+                    __syncthreads();
+                    if (att) {                     // (uniform) everyone has read the flag: clear it between two barriers
+                        if (tid == 0) qcnt[5] = 0;
+                        __syncthreads();
+                    }
+                }
                 ++tiles_done;
             }
             buf ^= 1;
@@ -794,7 +850,39 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                     if (m < M) cpp[(int64_t)m * ldc] = prev[t][r];
                 }
         }
-        if (TOPK) {                            // drain what the fast path left in the queues
+        if (TOPK) {
+            if (prev_tile >= 0) {              // the last tile of this user block still waits for its threshold test
+                const auto tail_group = [&](int t, int r4) {
+                    const float4 th4 = *reinterpret_cast<const float4*>(const_cast<const float*>(thr_l) + wm * 32 * MT + 32 * t + 8 * r4 + 4 * lh);
+                    const float th[4] = {th4.x, th4.y, th4.z, th4.w};
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl) {
+                        const int r = 4 * r4 + rl;
+                        const int ul = wm * 32 * MT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (prev[t][r] > th[rl] && (int64_t)mb * BM + ul < M) {
+                            const int owner = ul / RPW;
+                            const int slot = atomicAdd(&qcnt[owner], 1);
+                            if (slot < QC) {
+                                volatile float* ov = q0 + owner * QC * 3;
+                                ov[slot] = prev[t][r];
+                                reinterpret_cast<volatile int*>(ov + QC)[slot] = tk.col_off + prev_tile * BN + wn * 32 + li;
+                                reinterpret_cast<volatile int*>(ov + 2 * QC)[slot] = ul;
+                            } else {
+                                qcnt[4] = 1;
+                            }
+                        }
+                    }
+                };
+#pragma unroll
+                for (int g = 0; g < MT * 4; ++g) tail_group(g >> 2, g & 3);
+                __syncthreads();
+                if (qcnt[4]) {
+                    if (lane == 0 && qcnt[wave] > QC) qcnt[wave] = QC;
+                    slow_scan(prev, prev_tile);
+                    __syncthreads();
+                }
+            }
+            // drain what the fast path left in the queues
             const int qn = qcnt[wave];
             if (qn) topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM);
         }

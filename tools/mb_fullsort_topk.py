@@ -35,6 +35,12 @@ out = torch.empty(U, N, device=dev)
 ms_plain, _ = timed(lambda: F_.fullsort_scores(ue, W, out=out))
 del out
 torch.cuda.empty_cache()
+for kk in [int(x) for x in os.environ.get('MB_K', '').split(',') if x]:
+    ms_k, _ = timed(lambda: F_.fullsort_topk(ue, W, None, kk, exclude_first_col=True))
+    print(f'  (top-{kk} without a history mask: {ms_k:.2f} ms)')
+if os.environ.get('MB_NOHIST'):
+    ms_nh, _ = timed(lambda: F_.fullsort_topk(ue, W, None, 10, exclude_first_col=True))
+    print(f'  (top-10 without a history mask: {ms_nh:.2f} ms)')
 ms_topk, (tv, ti) = timed(lambda: F_.fullsort_topk(ue, W, None, 10, hist_indptr=indptr, hist_cols=cols, exclude_first_col=True))
 # spot check of the lists against an fp64 product for 4 users
 for u in (0, 1, U // 2, U - 1):
