@@ -228,7 +228,7 @@ def parse():
                     help='c5 row shard: the data-path exchanges through torch.distributed (RCCL) or through the C ABI\'s own communicator '
                          '(cdr_comm_init + cdr_a2a_ids / cdr_a2a_rows / cdr_allreduce_sum_f32; falls back to torch if it does not come up)')
     ap.add_argument('--single-layout', action='store_true', help='N>1: time only the --shard layout (default: both, in one record)')
-    ap.add_argument('--preflight-seconds', type=float, default=30.0, help='N>1: deadline for a candidate layout to create its groups and run its first two steps on every rank')
+    ap.add_argument('--preflight-seconds', type=float, default=45.0, help='N>1: deadline for a candidate layout to create its groups and run its first two steps on every rank')
     ap.add_argument('--no-layout-fallback', action='store_true', help='N>1: fail instead of trying the next layout / independent replicas')
     ap.add_argument('--no-dedup', action='store_true', help='sharded path: exchange one row per occurrence instead of one per distinct item')
     return ap.parse_args()
