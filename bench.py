@@ -563,15 +563,30 @@ def run_c5(args, world, rank, dev):
         pn = st0.ids[Bg:3 * Bg] if gsz > 1 else torch.cat(batches[(args.steps - 1) % pool]['source'][1:])
         uniq_i = int(torch.unique(pn).numel())
         nmom = 6 if args.opt == 'adam' else 2
-        ms = mean_ms('rowwise_apply_kernel(items)')
-        byts = 2 * Bg * (8 + 4 * Ds) + uniq_i * nmom * 4 * Ds
+        if timings.get('bpr_fwd_apply_kernel'):
+            # round 5: the second half of the dimension-sharded step is the one-GPU forward-and-update pass on Ds-column rows (fed with the
+            # all-reduced scores): rows occurring once in the group's global batch are read-modify-written with their moments, the others
+            # get one gradient row per occurrence (the headline's formula at width Ds)
+            uu = st0.ids[:Bg] if gsz > 1 else batches[(args.steps - 1) % pool]['source'][0]
+            cu = torch.unique(uu, return_counts=True)[1]
+            ci = torch.unique(pn, return_counts=True)[1]
+            su_, si_ = int((cu == 1).sum()), int((ci == 1).sum())
+            row_b = 4 * Ds
+            kname = 'bpr_fwd_apply_kernel'
+            ms = mean_ms(kname)
+            byts = (su_ + si_) * nmom * row_b + (3 * Bg - su_ - si_) * row_b
+            what = 'bpr_fwd_apply_kernel (rank 0: the %d triples of its group\'s global batch on %d-column rows; %d user and %d item rows occur once)' % (Bg, Ds, su_, si_)
+        else:
+            kname = 'rowwise_apply_kernel(items)'
+            ms = mean_ms(kname)
+            byts = 2 * Bg * (8 + 4 * Ds) + uniq_i * nmom * 4 * Ds
+            what = 'rowwise_apply_kernel(items) (rank 0: %d occurrences of its group\'s global batch on %d-column rows)' % (2 * Bg, Ds)
         gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        result['roofline'] = {'bound': 'hbm', 'kernel': 'rowwise_apply_kernel(items) (rank 0: %d occurrences of its group\'s global batch on %d-column rows)' % (2 * Bg, Ds),
-                              'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                              'avg_launch_ms': ms, 'traffic': None}
+        result['roofline'] = {'bound': 'hbm', 'kernel': what, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                              'avg_launch_ms': ms, 'algorithmic_bytes': byts, 'traffic': None}
         result['kernels'] = [{'kernel': k, 'avg_ms': mean_ms(k)} for k in
-                             ('bpr_fwd_grad_kernel', 'bpr_partial_diff_kernel', 'bpr_grad_from_diff_kernel', 'sort_ids',
-                              'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)') if timings.get(k)]
+                             ('bpr_fwd_apply_kernel', 'batch_norms_kernel', 'occ_flags_kernel', 'bpr_fwd_grad_kernel', 'bpr_partial_diff_kernel',
+                              'bpr_grad_from_diff_kernel', 'sort_ids', 'rowwise_apply_kernel(users)', 'rowwise_apply_kernel(items)') if timings.get(k)]
         if int(os.environ.get('CDR_BENCH_SHARED_GPU', '0')):
             result['data'] = 'synthetic; FUNCTIONAL CHECK ONLY: all ranks share cuda:0 over gloo'
     if rank == 0 and sharded and not dim_mode:
@@ -585,7 +600,7 @@ def run_c5(args, world, rank, dev):
             kname = 'bpr_fwd_apply_kernel'
             ms = mean_ms(kname)
             nmom = 3 if args.opt == 'adam' else 1
-            byts = B * (3 * 4 * D + 24) + B * (2 * nmom - 1) * 4 * D + B * 4 * D
+            byts = B * (3 * 4 * D + 24) + B * (2 * nmom - 1) * 4 * D + B * 4 * D        # (as if every user row occurred once: an upper bound on the bytes)
             what = 'bpr_fwd_apply_kernel (rank 0: ~B triples per launch on the rows held after user-aligned routing; user rows updated in place)'
         else:
             kname = 'bpr_fwd_grad_kernel'

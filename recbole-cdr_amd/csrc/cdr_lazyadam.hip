@@ -138,7 +138,9 @@ __global__ __launch_bounds__(kBlock) void lz_prepare1_kernel(lz_args a, float2* 
         counters[1] = t;
     }
     // (Tried on the C3 stream, 41.7 us as written: scalar loop control via readfirstlane 46.5 us; eight rows in flight per lane group
-    //  46.9 us; the four tables interleaved over a 1-D grid 58.3 us.  ~20 us of it is the replay's VALU time at full chip occupancy.)
+    //  46.9 us; the four tables interleaved over a 1-D grid 58.3 us.  ~20 us of it is the replay's VALU time at full chip occupancy.
+    //  Round 5: s_setprio 1..3 by the row's lag, so that the most-postponed rows' waves win their SIMD's issue slots: 42.05 -> 42.27 us.
+    //  The launch is the sum of the replays, not the longest of them.)
     // A row wider than 64 elements is spread over several WAVES, which all read last[row] and of which one moves it: every iteration
     // of the (block-uniform) loop therefore has a barrier between the reads and that write.  (Without it a wave that starts its
     // iteration after its sibling has finished finds last[row] already advanced and leaves its part of the row unreplayed -- which is
