@@ -552,6 +552,12 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
     const int mslot = j % MBc, sidx = j / MBc;
     if (sidx >= S) return;
     const int stripe = xcd * S + sidx, n_stripes = 8 * S;
+    // a stripe is a CONTIGUOUS range of item tiles (round 5; it was every n_stripes-th tile): a workgroup's successive tiles then read
+    // adjacent item rows and write adjacent 256-byte pieces of each of its users' score rows -- same sharing of a tile between the user
+    // blocks of a stripe, DRAM pages that stay open
+    const int tiles_per_stripe = (NT + n_stripes - 1) / n_stripes;
+    const int tile_begin = stripe * tiles_per_stripe;
+    const int tile_end = tile_begin + tiles_per_stripe < NT ? tile_begin + tiles_per_stripe : NT;
 
     // per-thread staging geometry (compile-time divisors)
     int st_lds[NQ];
@@ -580,6 +586,7 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
 
     for (int mb = mslot; mb < MB; mb += MBc) {
         const int m0 = mb * BM + wm * 32 * MT;
+        const bool full_rows = (int64_t)(mb + 1) * BM <= M;          // (workgroup-uniform) every user row of this block exists
         int tiles_done = 0;
         if (TOPK) {
             for (int i = tid; i < BM; i += 256) thr_l[i] = -INFINITY;
@@ -598,9 +605,9 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                 if (r >= M) a[t][s] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        int tile = stripe;
+        int tile = tile_begin;
         int buf = 0;
-        if (tile < NT) {
+        if (tile < tile_end) {
             const float* bp = B + (int64_t)tile * BN * K;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) st4(smem + st_lds[q], ld4(bp + st_gl[q]));
@@ -653,9 +660,9 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
             if (qn) { topk_flush(qv, qc, qu, qn, thr_l, lv, lc, tk, (int64_t)mb * BM); qn = 0; }
             if (lane == 0) qcnt[wave] = 0;
         };
-        for (; tile < NT; tile += n_stripes) {
-            const int next = tile + n_stripes;
-            const bool has_next = next < NT;
+        for (; tile < tile_end; ++tile) {
+            const int next = tile + 1;
+            const bool has_next = next < tile_end;
             // issue the next tile's global loads now; they land while the MFMAs below run
             float4 stage[NQ];
             {
@@ -756,13 +763,28 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
                     constexpr int PER = (MT * 16 + KS / 2 - 1) / (KS / 2);
                     if (prev_tile >= 0) {
                         float* cpp = C + (int64_t)prev_tile * BN + wn * 32 + li;
+                        // a user block that lies wholly inside M (all but the last) stores without a per-lane row test: as written
+                        // first, every store sat behind its own exec-mask save / branch (28 of them inside the MFMA phase), each one a
+                        // scheduling fence between two MFMAs
+                        if (full_rows) {
 #pragma unroll
-                        for (int j = 0; j < PER; ++j) {
-                            const int i = (PARK_IN ? s - KS / 2 : s) * PER + j;
-                            if (i < MT * 16) {
-                                const int t = i / 16, r = i % 16;
-                                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                                if (m < M) cpp[(int64_t)m * ldc] = prev[t][r];
+                            for (int j = 0; j < PER; ++j) {
+                                const int i = (PARK_IN ? s - KS / 2 : s) * PER + j;
+                                if (i < MT * 16) {
+                                    const int t = i / 16, r = i % 16;
+                                    const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                    cpp[(int64_t)m * ldc] = prev[t][r];
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < PER; ++j) {
+                                const int i = (PARK_IN ? s - KS / 2 : s) * PER + j;
+                                if (i < MT * 16) {
+                                    const int t = i / 16, r = i % 16;
+                                    const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                    if (m < M) cpp[(int64_t)m * ldc] = prev[t][r];
+                                }
                             }
                         }
                     }
@@ -789,7 +811,7 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            if (m < M) cp[(int64_t)m * ldc] = acc[t][r];
+                            if (full_rows || m < M) cp[(int64_t)m * ldc] = acc[t][r];
                         }
                 }
                 __syncthreads();
