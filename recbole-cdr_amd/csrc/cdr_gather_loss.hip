@@ -612,6 +612,7 @@ extern "C" int cdr_point_fwd_pair_ex(cdr_ctx* ctx, void* stream, int loss_kind, 
         a.RU[d] = (reg_user_tab && reg_user_tab[d]) ? reg_user_tab[d] : user_tab[d];
         a.RI[d] = (reg_item_tab && reg_item_tab[d]) ? reg_item_tab[d] : item_tab[d];
         same = same && a.RU[d] == a.U[d] && a.RI[d] == a.I[d];
+        CDR_CHECK_ARG(reg_D == D || (reg_user_tab[d] && reg_item_tab[d] && reg_user_tab[d] != user_tab[d] && reg_item_tab[d] != item_tab[d]));   // narrower reg rows: tables of their own
         a.uid[d] = uid[d]; a.iid[d] = iid[d]; a.label[d] = label[d]; a.B[d] = B[d];
         a.gcoef[d] = gcoef ? gcoef[d] : nullptr; a.scores[d] = scores ? scores[d] : nullptr; a.out4[d] = out4[d]; a.reg[d] = reg_weight[d];
         if (B[d] > bmax) bmax = B[d];

@@ -902,6 +902,7 @@ class ConetFullsortFewUsers:
                      wo.reshape(-1).contiguous(), bo.reshape(-1).contiguous()]
         _P, _ut, _W1, _b1, ws, bs, wo_, bo_ = self.keep
         self.N, self.dev, self.table_ptr = P.shape[0], P.device, user_table.data_ptr()
+        self.param_ptrs = tuple(t.data_ptr() for t in [W1, b1, wo, bo] + list(weights) + list(biases))      # (fresh(): the model checks them per call)
         self.dims = (ctypes.c_int * T)(*[int(w.shape[0]) for w in ws])
         self.Wp = (ctypes.c_void_p * T)(*[w.data_ptr() for w in ws])
         self.bp = (ctypes.c_void_p * T)(*[b.data_ptr() for b in bs])
@@ -910,6 +911,12 @@ class ConetFullsortFewUsers:
         self.mid = (c(W1.data_ptr()), W1.stride(0), c(_b1.data_ptr()), int(D))
         self.tail = (self.N, P.shape[1], T, self.dims, self.Wp, self.bp, c(wo_.data_ptr()), c(bo_.data_ptr()))
         self.fn = getattr(B_.load(), 'cdr_conet_fullsort_users')
+
+    def fresh(self, user_table, W1, b1, weights, biases, wo, bo):
+        """The pointers packed at construction are still the model's (a parameter re-allocated since -- ``.to()``, ``.data = ...`` -- makes the
+        pack stale; in-place updates keep it valid)."""
+        return (self.table_ptr == user_table.data_ptr()
+                and self.param_ptrs == tuple(t.data_ptr() for t in [W1, b1, wo, bo] + list(weights) + list(biases)))
 
     def takes(self, uid):
         U = uid.shape[0]

@@ -216,7 +216,13 @@ class CoNet(CrossDomainRecommender):
         self.sync_tables()
         few = None if self.training else self.__dict__.get('_eval_few')
         uid = interaction[self.TARGET_USER_ID]
-        if few is not None and few.takes(uid) and few.table_ptr == self.target_user_embedding.weight.data_ptr():
+        if few is not None and few.takes(uid):
+            lin1, lo = self.target_crossunit_linear[0], self.target_outputunit[0]
+            tail = list(self.target_crossunit_linear)[1:]
+            if not few.fresh(self.target_user_embedding.weight, lin1.weight, lin1.bias, [l.weight for l in tail], [l.bias for l in tail], lo.weight, lo.bias):
+                self._drop_eval_cache()                                  # a parameter was re-allocated: rebuild P and the pack below
+                few = None
+        if few is not None and few.takes(uid):
             return few(uid)                                             # a few users, evaluation mode: ONE launch (see below)
         user_e = F_.gather_rows(self.target_user_embedding.weight, uid)
         items = self.target_item_embedding.weight[:self.target_num_items]
