@@ -711,7 +711,7 @@ def test_bench_c4_multi_rank_layout_fallback(inject, used, tmp_path):
     env = dict(os.environ, CDR_BENCH_SHARED_GPU='1', CDR_PREFLIGHT_FAIL=inject)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--workload', 'c4', '--gpus', '2', '--steps', '4', '--warmup', '1',
-           '--preflight-seconds', '60', '--no-cpu-baseline', '--detail-file', str(tmp_path / 'detail.json')]
+           '--preflight-seconds', '25', '--no-cpu-baseline', '--detail-file', str(tmp_path / 'detail.json')]
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line, d = _bench_line_and_detail(p, tmp_path)
