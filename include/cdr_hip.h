@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 52
+#define CDR_ABI_VERSION 53
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -256,6 +256,37 @@ int cdr_scatter_add_rows_ld(void* stream, float* grad_tab, int D, const int64_t*
  * grad_tab receives the sum of its occurrences' rows src[perm[e] * lds ..] in occurrence order -- no float atomics */
 int cdr_scatter_rows_sorted(void* stream, float* grad_tab, int D, const uint32_t* keys_sorted, const uint32_t* perm, int64_t n,
                             const float* src, int64_t lds);
+/* ---- Ordered dense backward: the drop-in losses' DENSE gradients without float atomics and without a sort (round 5) -------------------
+ * replaces the scatter half of torch's embedding backward behind emcdr.py:111-154 (BPR / MF), cmf.py:81-99, bitgcf.py:221-247 and the
+ * plain nn.Embedding gathers of the other models, at the reference's own batch sizes (overall.yaml:19 train_batch_size = 2,048).
+ * A LIST is every occurrence that adds into one gradient buffer, in a fixed order: up to CDR_ORD_MAX_SEGS segments laid end to end
+ * (e.g. the item list of a BPR batch = its positives, then its negatives).  Entry j of a segment contributes
+ *     a_j * (X[xj] - Y[yid[j]]) + c * R[ids[j]]        a_j = sign * go * coef[j]   (coef NULL: a_j = sign, no go)
+ *                                                      xj  = xid ? xid[j] : j      (X NULL: no first term; Y NULL: no subtraction)
+ *                                                      c   = go * reg_weight / (B * norm[0])   (R NULL, reg_weight 0 or norm 0: none)
+ *     go  = (go_ptr ? go_ptr[0] : 1) * go_scale
+ * to row ids[j] of g.  One lane group per entry: the list's ids sit in LDS, the group scans them once in order; an entry with an equal id
+ * EARLIER in the list is not the row's first occurrence and leaves; the first occurrence adds the terms of every later equal entry in
+ * list order to a zero and writes the row with ONE plain store (accumulate: adds the sum to the row's earlier content instead, still
+ * one read-modify-write by one group).  g must be zero where no entry points (the forward launch clears it);
+ * two lists of one call must not point at the same rows.  Result: bit-reproducible from run to run, the occurrence-order sum that
+ * cdr_scatter_rows_sorted gives, in one launch and O(total^2 / lanes) compares -- meant for total <= CDR_ORD_MAX_TOTAL per list
+ * (CDR_EINVAL beyond; callers keep the sorted or the atomic form there).  D % 4 == 0, D <= 256, every row stride in floats. */
+#define CDR_ORD_MAX_SEGS 4
+#define CDR_ORD_MAX_LISTS 4
+#define CDR_ORD_MAX_TOTAL 16384
+typedef struct cdr_ord_seg {
+    const int64_t* ids; int64_t n;
+    const float* coef; float sign;
+    const float* go; float go_scale;
+    const float* X; const int64_t* xid; const float* Y; const int64_t* yid; int64_t x_stride;
+    const float* R; int64_t r_stride; const float* norm; float reg_weight; int64_t B;
+} cdr_ord_seg;
+typedef struct cdr_ord_list {
+    float* g; int64_t g_stride; int32_t nseg; int32_t accumulate;     /* accumulate != 0: row = row + sum (g holds earlier gradients) */
+    cdr_ord_seg seg[CDR_ORD_MAX_SEGS];
+} cdr_ord_list;
+int cdr_ordered_bwd(void* stream, int D, const cdr_ord_list* lists, int nlists);
 int cdr_overlap_mask(void* stream, const int64_t* ids, int64_t n, int64_t n_overlap, float* out);   /* id < n ? 1 : 0 */
 int cdr_rowscale(void* stream, const float* x, const float* scale, int64_t M, int64_t N, float* out);
 int cdr_bcast_add_act(void* stream, const float* P, const float* q, int64_t N, int64_t H, int act, float* out);

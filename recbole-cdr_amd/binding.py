@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 52
+ABI_VERSION = 53
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -142,6 +142,7 @@ _SIGNATURES = {
     'cdr_gather_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
     'cdr_scatter_add_rows_ld': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64],
     'cdr_scatter_rows_sorted': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64],
+    'cdr_ordered_bwd': [_c_ptr, _c_int, _c_ptr, _c_int],
     'cdr_overlap_mask': [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
     'cdr_rowscale': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr],
     'cdr_bcast_add_act': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr],
@@ -283,6 +284,21 @@ class BatchJob(ctypes.Structure):
                 ('keys', _c_ptr), ('prob', _c_ptr), ('alias', _c_ptr), ('n_keys', _c_i64),
                 ('used_indptr', _c_ptr), ('used_indices', _c_ptr), ('seed', ctypes.c_uint64),
                 ('out_users', _c_ptr), ('out_items', _c_ptr), ('out_neg', _c_ptr), ('fail_flag', _c_ptr)]
+
+
+ORD_MAX_SEGS, ORD_MAX_LISTS, ORD_MAX_TOTAL = 4, 4, 16384
+
+
+class OrdSeg(ctypes.Structure):
+    """``cdr_ord_seg`` of include/cdr_hip.h."""
+    _fields_ = [('ids', _c_ptr), ('n', _c_i64), ('coef', _c_ptr), ('sign', _c_f32), ('go', _c_ptr), ('go_scale', _c_f32),
+                ('X', _c_ptr), ('xid', _c_ptr), ('Y', _c_ptr), ('yid', _c_ptr), ('x_stride', _c_i64),
+                ('R', _c_ptr), ('r_stride', _c_i64), ('norm', _c_ptr), ('reg_weight', _c_f32), ('B', _c_i64)]
+
+
+class OrdList(ctypes.Structure):
+    """``cdr_ord_list`` of include/cdr_hip.h."""
+    _fields_ = [('g', _c_ptr), ('g_stride', _c_i64), ('nseg', ctypes.c_int32), ('accumulate', ctypes.c_int32), ('seg', OrdSeg * ORD_MAX_SEGS)]
 
 
 _lib = None

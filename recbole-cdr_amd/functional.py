@@ -28,7 +28,7 @@ def _prezero_for_backward(ctx, *tables):
     launch was ~5 us of a 40 us step at the reference's default batch.  ``_grads_for`` hands them out in the backward."""
     ctx.pre = None
     tabs = [t for t in tables if t is not None]
-    if deterministic() or not tabs or not any(ctx.needs_input_grad) or not all(t.is_contiguous() for t in tabs):
+    if (deterministic() and not ordered_backward()) or not tabs or not any(ctx.needs_input_grad) or not all(t.is_contiguous() for t in tabs):
         return
     offs, n = [], 0
     for t in tabs:
@@ -65,6 +65,74 @@ def set_deterministic(flag):
 
 def deterministic():
     return _DETERMINISTIC[0] or os.environ.get('CDR_DETERMINISTIC', '0') == '1'
+
+
+# ---- ordered dense backward: what ``set_deterministic(True)`` runs at the reference's batch sizes ----------------------------------
+# cdr_ordered_bwd (csrc/cdr_ordered.hip): every list of occurrences that adds into one gradient buffer is walked by ONE launch that
+# finds each row's occurrences by an all-pairs id test out of LDS and sums their terms in list order -- the occurrence-order sum of
+# the sorted form above without the gathers, the per-occurrence rows, the id sort and the segmented scatter: one launch instead of
+# 10-20.  It is quadratic in the list length, so it takes lists of up to ``ordered_max()`` entries (4,096 = the item list of a
+# 2,048-triple BPR batch, overall.yaml:19; config / env CDR_ORDERED_MAX, at most 16,384; 0 or ``set_ordered_backward(False)``
+# switches it off) and longer lists keep the sorted form.  Measured (tools/mb_ordered_bwd.py, profiles/r05_mb_ordered_bwd.txt):
+# forward + backward of a 2,048-triple BPR batch 40 us against 54.5 sorted (25 with atomics), CMF's two domains 56 against 87 (32.5).
+_ORDERED = [True]
+_ORDERED_MAX = [None]
+
+
+def set_ordered_backward(flag, max_entries=None):
+    _ORDERED[0] = bool(flag)
+    _ORDERED_MAX[0] = None if max_entries is None else int(max_entries)
+
+
+def ordered_max():
+    if _ORDERED_MAX[0] is not None:
+        return max(0, min(int(_ORDERED_MAX[0]), B_.ORD_MAX_TOTAL))
+    return max(0, min(int(os.environ.get('CDR_ORDERED_MAX', '4096')), B_.ORD_MAX_TOTAL))
+
+
+def ordered_backward():
+    return _ORDERED[0] and ordered_max() > 0
+
+
+def ordered_fits(D, *totals):
+    """Under ``set_deterministic`` the ordered launch takes these lists: float4 rows of at most 256 floats, every list within the cap."""
+    if not deterministic() or not ordered_backward() or D % 4 != 0 or D > 256:
+        return False
+    cap = ordered_max()
+    return all(0 <= int(t) <= cap for t in totals) and any(int(t) > 0 for t in totals)
+
+
+_ord_fits = ordered_fits
+
+
+def _ptr(t, byte_off=0):
+    return None if t is None else t.data_ptr() + byte_off
+
+
+def _ord_seg(ids, coef=None, sign=1.0, go=None, go_scale=1.0, X=None, xid=None, Y=None, yid=None, x_stride=0,
+             R=None, r_stride=0, norm=None, reg=0.0, B=1):
+    """One segment of a list (cdr_ord_seg); pointer arguments are integers (``tensor.data_ptr()`` + byte offset) or None."""
+    sg = B_.OrdSeg()
+    sg.ids, sg.n = ids.data_ptr(), ids.numel()
+    sg.coef, sg.sign, sg.go, sg.go_scale = coef, float(sign), go, float(go_scale)
+    sg.X, sg.xid, sg.Y, sg.yid, sg.x_stride = X, xid, Y, yid, int(x_stride)
+    sg.R, sg.r_stride, sg.norm, sg.reg_weight, sg.B = R, int(r_stride), norm, float(reg), int(B)
+    return sg
+
+
+def _ordered_bwd(D, lists, keep=(), accumulate=False):
+    """lists: [(g pointer, g row stride, [segments])] -- one launch; ``keep`` holds the operands until it is enqueued.  accumulate: the
+    sums are added to the rows' earlier content (buffers that already hold another node's gradient)."""
+    lists = [l for l in lists if l[2]]
+    if not lists:
+        return
+    arr = (B_.OrdList * len(lists))()
+    for k, (g, gs, segs) in enumerate(lists):
+        arr[k].g, arr[k].g_stride, arr[k].nseg, arr[k].accumulate = g, int(gs), len(segs), int(bool(accumulate))
+        for q, sg in enumerate(segs):
+            arr[k].seg[q] = sg
+    B_.call('cdr_ordered_bwd', B_.stream(), int(D), arr, len(lists))
+    del keep
 
 
 _arange_cache = {}
@@ -148,6 +216,18 @@ class BPRGatherLoss(Function):
     def backward(ctx, grad_out):
         user_w, item_w, uid, pid, nid, g, out4 = ctx.saved_tensors
         go = grad_out.reshape(-1).contiguous().to(torch.float32)
+        n, D = uid.numel(), user_w.shape[1]
+        if _ord_fits(D, n, 2 * n) and user_w.is_contiguous() and item_w.is_contiguous():
+            gU, gI = _grads_for(ctx, user_w, item_w)
+            uw, iw, gp, o4, gop = user_w.data_ptr(), item_w.data_ptr(), g.data_ptr(), out4.data_ptr(), go.data_ptr()
+            _ordered_bwd(D, [
+                (gU.data_ptr(), D, [_ord_seg(uid, coef=gp, go=gop, X=iw, xid=pid.data_ptr(), Y=iw, yid=nid.data_ptr(), x_stride=D,
+                                             R=uw, r_stride=D, norm=o4 + 8, reg=ctx.reg_weight, B=n)]),
+                (gI.data_ptr(), D, [_ord_seg(pid, coef=gp, go=gop, X=uw, xid=uid.data_ptr(), x_stride=D,
+                                             R=iw, r_stride=D, norm=o4 + 12, reg=ctx.reg_weight, B=n),
+                                    _ord_seg(nid, coef=gp, sign=-1.0, go=gop, X=uw, xid=uid.data_ptr(), x_stride=D)])],
+                keep=(go, gU, gI))
+            return gU, gI, None, None, None, None, None
         if deterministic():
             dev, D, n = user_w.device, user_w.shape[1], uid.numel()
             ar = _arange(dev, 2 * n)
@@ -195,6 +275,32 @@ class PointGatherLoss(Function):
         # the same tensor as user AND item operand (BiTGCF scores rows of one stacked [users ; items] table): one gradient buffer,
         # both scatters add into it, and autograd gets it once -- instead of two table-sized buffers plus the add that merges them
         shared = user_w.data_ptr() == item_w.data_ptr() and user_w.shape == item_w.shape and user_w.stride() == item_w.stride()
+        n, D = uid.numel(), user_w.shape[1]
+        if (_ord_fits(D, 2 * n if shared else n) and user_w.is_contiguous() and item_w.is_contiguous()
+                and all(r is None or (r.is_contiguous() and r.shape[1] == D) for r in (reg_user_w, reg_item_w))):
+            go = grad_out.reshape(-1).contiguous().to(torch.float32)
+            uw, iw, gp, o4, gop = user_w.data_ptr(), item_w.data_ptr(), g.data_ptr(), out4.data_ptr(), go.data_ptr()
+            sep_u = reg_user_w is not None and reg_user_w.data_ptr() != uw
+            sep_i = reg_item_w is not None and reg_item_w.data_ptr() != iw
+            if shared:
+                gU = torch.zeros_like(user_w)
+                gI = gU
+            else:
+                gU, gI = _zeros_like2(user_w, item_w)
+            gRU = torch.zeros_like(reg_user_w) if reg_user_w is not None else None
+            gRI = torch.zeros_like(reg_item_w) if reg_item_w is not None else None
+            reg_kw = dict(r_stride=D, reg=ctx.reg_weight, B=n)
+            su = _ord_seg(uid, coef=gp, go=gop, X=iw, xid=iid.data_ptr(), x_stride=D,
+                          **({} if sep_u else dict(R=uw, norm=o4 + 8, **reg_kw)))
+            si = _ord_seg(iid, coef=gp, go=gop, X=uw, xid=uid.data_ptr(), x_stride=D,
+                          **({} if sep_i else dict(R=iw, norm=o4 + 12, **reg_kw)))
+            lists = [(gU.data_ptr(), D, [su, si])] if shared else [(gU.data_ptr(), D, [su]), (gI.data_ptr(), D, [si])]
+            if sep_u and ctx.reg_weight != 0.0:
+                lists.append((gRU.data_ptr(), D, [_ord_seg(uid, go=gop, R=reg_user_w.data_ptr(), norm=o4 + 8, **reg_kw)]))
+            if sep_i and ctx.reg_weight != 0.0:
+                lists.append((gRI.data_ptr(), D, [_ord_seg(iid, go=gop, R=reg_item_w.data_ptr(), norm=o4 + 12, **reg_kw)]))
+            _ordered_bwd(D, lists, keep=(go, gU, gI, gRU, gRI))
+            return None, gU, (None if shared else gI), gRU, gRI, None, None, None, None
         if deterministic():
             go = grad_out.reshape(-1).contiguous().to(torch.float32)
             dU, dI, dRU, dRI = _det_point_rows(user_w, item_w, reg_user_w, reg_item_w, uid, iid, g, B_.f32(out4), ctx.reg_weight, go)
@@ -282,6 +388,17 @@ class TwoDomainPointLoss(Function):
         user_w, item_w, su, si, tu, ti, g_s, g_t, out8, w = ctx.saved_tensors
         dev, D = user_w.device, user_w.shape[1]
         go = grad_out.reshape(-1)[:1].contiguous().to(torch.float32)
+        ns, nt = su.numel(), tu.numel()
+        if _ord_fits(D, ns + nt) and user_w.is_contiguous() and item_w.is_contiguous():
+            gU, gI = _grads_for(ctx, user_w, item_w)
+            uw, iw, o8, gop = user_w.data_ptr(), item_w.data_ptr(), out8.data_ptr(), go.data_ptr()
+            segs_u, segs_i = [], []
+            for d, (u, i, gc, reg, n_, sc) in enumerate(((su, si, g_s, ctx.regs[0], ns, ctx.alpha), (tu, ti, g_t, ctx.regs[1], nt, 1.0 - ctx.alpha))):
+                kw = dict(coef=gc.data_ptr(), go=gop, go_scale=sc, x_stride=D, r_stride=D, reg=reg, B=n_)
+                segs_u.append(_ord_seg(u, X=iw, xid=i.data_ptr(), R=uw, norm=o8 + 16 * d + 8, **kw))
+                segs_i.append(_ord_seg(i, X=uw, xid=u.data_ptr(), R=iw, norm=o8 + 16 * d + 12, **kw))
+            _ordered_bwd(D, [(gU.data_ptr(), D, segs_u), (gI.data_ptr(), D, segs_i)], keep=(go, gU, gI))
+            return None, gU, gI, None, None, None, None, None, None, None, None, None
         if deterministic():
             go2 = torch.empty(2, device=dev, dtype=torch.float32)
             B_.call('cdr_scalar_mix', B_.stream(), 1, 2, None, 0, B_.f32(w), B_.f32(go), B_.f32(go2))
@@ -347,6 +464,16 @@ class TwoStackPointLoss(Function):
                 zero = torch.zeros(1, device=dev, dtype=torch.float32) if zero is None else zero
                 g = zero
             gos.append(g.reshape(-1)[:1].contiguous().to(torch.float32))
+        if _ord_fits(D, us.numel(), ut.numel()):
+            gS, gT = _zeros_like2(S, T)
+            io = 4 * ctx.nu * D
+            lists = []
+            for W, gW, u, i, gc, gop in ((S, gS, us, is_, gc_s, gos[0]), (T, gT, ut, it, gc_t, gos[1])):
+                kw = dict(coef=gc.data_ptr(), go=gop.data_ptr(), x_stride=D)
+                lists.append((gW.data_ptr(), D, [_ord_seg(u, X=W.data_ptr() + io, xid=i.data_ptr(), **kw)]))        # user rows < nu
+                lists.append((gW.data_ptr() + io, D, [_ord_seg(i, X=W.data_ptr(), xid=u.data_ptr(), **kw)]))        # item rows from nu on
+            _ordered_bwd(D, lists, keep=(gos, gS, gT))
+            return None, gS, gT, None, None, None, None, None, None, None
         if deterministic():
             # per-occurrence rows of each stack (users, then items at row nu + i), then one in-order segment sum per stack
             outs = []
@@ -436,6 +563,12 @@ class GatherRows(Function):
     @staticmethod
     def backward(ctx, grad_out):
         (flat,) = ctx.saved_tensors
+        if _ord_fits(ctx.wshape[1], flat.numel()):
+            D = ctx.wshape[1]
+            gW = torch.zeros(ctx.wshape, device=grad_out.device, dtype=torch.float32)
+            go = grad_out.reshape(-1, D).contiguous().to(torch.float32)
+            _ordered_bwd(D, [(gW.data_ptr(), D, [_ord_seg(flat, X=go.data_ptr(), x_stride=D)])], keep=(go, gW))
+            return gW, None
         if deterministic():
             return _scatter_rows_deterministic(ctx.wshape, flat, grad_out.reshape(-1, ctx.wshape[1])), None
         gW = torch.zeros(ctx.wshape, device=grad_out.device, dtype=torch.float32)
@@ -1051,6 +1184,21 @@ class GatherMapRows(Function):
         ss, ts, os_ = ctx.shapes
         n, D = idx.numel(), ss[1]
         dev = idx.device
+        if _ord_fits(D, 2 * n) and ss[1] == ts[1] == os_[1]:
+            ns_, nt_, no_ = ss[0] * D, ts[0] * D, os_[0] * D
+            flat = torch.zeros(ns_ + nt_ + no_, device=dev, dtype=torch.float32)
+            gs, gt, go_ = flat[:ns_].view(ss), flat[ns_:ns_ + nt_].view(ts), flat[ns_ + nt_:].view(os_)
+            gX3 = None if gX3 is None else gX3.contiguous()
+            gT = None if gT is None else gT.contiguous()
+            lists = []
+            if gX3 is not None:
+                x0 = gX3.data_ptr()
+                lists.append((gs.data_ptr(), D, [_ord_seg(idx, X=x0, x_stride=D)]))
+                lists.append((go_.data_ptr(), D, [_ord_seg(pos, X=x0 + 4 * n * D, x_stride=D), _ord_seg(neg, X=x0 + 8 * n * D, x_stride=D)]))
+            if gT is not None:
+                lists.append((gt.data_ptr(), D, [_ord_seg(idx, X=gT.data_ptr(), x_stride=D)]))
+            _ordered_bwd(D, lists, keep=(flat, gX3, gT))
+            return gs, gt, go_, None, None, None, None
         if deterministic():
             zx, zt = (lambda: torch.zeros(3 * n, D, device=dev)), (lambda: torch.zeros(n, D, device=dev))
             gX3 = zx() if gX3 is None else gX3.contiguous()
@@ -1372,14 +1520,30 @@ class BiTGCFLoss(Function):
         P2, I2, F2 = ctypes.c_void_p * 2, ctypes.c_int64 * 2, ctypes.c_float * 2
         io = 4 * nu * W
         nB = I2(ids[0].numel(), ids[2].numel())
+        ordered = _ord_fits(W, ids[0].numel(), ids[1].numel(), ids[2].numel(), ids[3].numel())
         # stack gradients only (reg_weight 0 here: the EmbLoss rows belong to the EGO tables and are added at the end, below)
-        B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io), None, None, W,
+        if ordered:
+            lists = []
+            for X_, gX_, u, i, c, gop in ((S, gS, ids[0], ids[1], gc[0], gos[0]), (T, gT, ids[2], ids[3], gc[1], gos[1])):
+                kw = dict(coef=c.data_ptr(), go=gop.data_ptr(), x_stride=W)
+                lists.append((gX_.data_ptr(), W, [_ord_seg(u, X=X_.data_ptr() + io, xid=i.data_ptr(), **kw)]))       # user rows < nu
+                lists.append((gX_.data_ptr() + io, W, [_ord_seg(i, X=X_.data_ptr(), xid=u.data_ptr(), **kw)]))       # item rows from nu on
+            _ordered_bwd(W, lists)
+        else:
+            B_.call('cdr_point_bwd_dense_pair', B_.ctx(dev), B_.stream(), P2(S.data_ptr(), T.data_ptr()), P2(S.data_ptr() + io, T.data_ptr() + io), None, None, W,
                 P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), nB,
                 P2(gc[0].data_ptr(), gc[1].data_ptr()), P2(out8.data_ptr(), out8.data_ptr() + 16), F2(0.0, 0.0),
-                P2(gos[0].data_ptr(), gos[1].data_ptr()), None, P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr() + io, gT.data_ptr() + io), None, None)
+                    P2(gos[0].data_ptr(), gos[1].data_ptr()), None, P2(gS.data_ptr(), gT.data_ptr()), P2(gS.data_ptr() + io, gT.data_ptr() + io), None, None)
         grads = BiTGCFPropagate.backward(ctx.inner, gS, gT, None, None)
         gsu, gsi, gtu, gti = grads[:4]                              # views of two [n, D] buffers: users, then items
-        if ctx.reg_weight != 0.0:
+        if ctx.reg_weight != 0.0 and ordered and D <= 256 and all(g_.is_contiguous() for g_ in (gsu, gsi, gtu, gti)):
+            lists = []
+            for d, (gu_, gi_) in enumerate(((gsu, gsi), (gtu, gti))):
+                kw = dict(go=gos[d].data_ptr(), r_stride=D, reg=ctx.reg_weight, B=ids[2 * d].numel())
+                lists.append((gu_.data_ptr(), D, [_ord_seg(ids[2 * d], R=ego[2 * d].data_ptr(), norm=out8.data_ptr() + 16 * d + 8, **kw)]))
+                lists.append((gi_.data_ptr(), D, [_ord_seg(ids[2 * d + 1], R=ego[2 * d + 1].data_ptr(), norm=out8.data_ptr() + 16 * d + 12, **kw)]))
+            _ordered_bwd(D, lists, accumulate=True)
+        elif ctx.reg_weight != 0.0:
             B_.call('cdr_embloss_bwd_dense_pair', B_.stream(), P2(ego[0].data_ptr(), ego[2].data_ptr()), P2(ego[1].data_ptr(), ego[3].data_ptr()), D,
                     P2(ids[0].data_ptr(), ids[2].data_ptr()), P2(ids[1].data_ptr(), ids[3].data_ptr()), nB,
                     P2(out8.data_ptr() + 8, out8.data_ptr() + 24), P2(gos[0].data_ptr(), gos[1].data_ptr()), F2(ctx.reg_weight, ctx.reg_weight),
@@ -1405,6 +1569,14 @@ class EmbLossRows(Function):
     @staticmethod
     def backward(ctx, go):
         U, I, uid, iid, out3 = ctx.saved_tensors
+        if _ord_fits(U.shape[1], uid.numel(), iid.numel()) and U.is_contiguous() and I.is_contiguous() and U.shape[1] == I.shape[1]:
+            n, D = uid.numel(), U.shape[1]
+            gU, gI = _zeros_like2(U, I)
+            g1 = go.reshape(-1).contiguous().to(torch.float32)
+            kw = dict(go=g1.data_ptr(), r_stride=D, reg=1.0, B=n)
+            _ordered_bwd(D, [(gU.data_ptr(), D, [_ord_seg(uid, R=U.data_ptr(), norm=out3.data_ptr() + 4, **kw)]),
+                             (gI.data_ptr(), D, [_ord_seg(iid, R=I.data_ptr(), norm=out3.data_ptr() + 8, **kw)])], keep=(g1, gU, gI))
+            return gU, gI, None, None
         if deterministic():
             # the same kernel on the gathered rows with the occurrence index as the id (one add per address), then in-order segment sums
             n, D = uid.numel(), U.shape[1]

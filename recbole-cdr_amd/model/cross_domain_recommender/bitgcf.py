@@ -122,7 +122,10 @@ class BiTGCF(CrossDomainRecommender):
         hint = (interaction[self.SOURCE_USER_ID], interaction[self.SOURCE_ITEM_ID], interaction[self.TARGET_USER_ID],
                 interaction[self.TARGET_ITEM_ID]) if self.sparse_last_layer else None
         D = self.source_user_embedding.weight.shape[1]
-        if hint is not None and self.fused_loss and D % 4 == 0 and not F_.deterministic():
+        # (under set_deterministic the one-node form needs its four scatter lists inside the ordered launch's reach)
+        det_ok = not F_.deterministic() or F_.ordered_fits((int(self.n_layers) + 1) * D, interaction[self.SOURCE_USER_ID].numel(),
+                                                           interaction[self.TARGET_USER_ID].numel())
+        if hint is not None and self.fused_loss and D % 4 == 0 and det_ok:
             # propagation + both domains' BCE + reg_weight x EmbLoss as ONE autograd node (functional.BiTGCFLoss): 27 launches per step
             # at BASELINE C4 instead of 37
             return F_.BiTGCFLoss.apply(self.source_user_embedding.weight, self.source_item_embedding.weight,
