@@ -1,6 +1,6 @@
 // Ordered dense backward (cdr_ordered_bwd): the drop-in losses' dense gradients as occurrence-order sums, one launch, no float
 // atomics, no sort.  See include/cdr_hip.h for the term a list entry contributes.  functional.set_deterministic(True) runs it for lists
-// of up to 4,096 entries (the reference's batch, overall.yaml:19); beyond that the id sort + segmented scatter is the faster route.
+// of up to 8,192 entries (four times the reference's batch, overall.yaml:19); beyond that the id sort + segmented scatter is faster.
 //
 // One WAVE per list entry (1,024-thread workgroups: 16 entries, four waves per SIMD).  The workgroup stages the low words of the
 // list's ids in LDS (the entry's own index operands are requested first and travel meanwhile).  A wave runs over the list in trips of

@@ -71,10 +71,11 @@ def deterministic():
 # cdr_ordered_bwd (csrc/cdr_ordered.hip): every list of occurrences that adds into one gradient buffer is walked by ONE launch that
 # finds each row's occurrences by an all-pairs id test out of LDS and sums their terms in list order -- the occurrence-order sum of
 # the sorted form above without the gathers, the per-occurrence rows, the id sort and the segmented scatter: one launch instead of
-# 10-20.  It is quadratic in the list length, so it takes lists of up to ``ordered_max()`` entries (4,096 = the item list of a
-# 2,048-triple BPR batch, overall.yaml:19; config / env CDR_ORDERED_MAX, at most 16,384; 0 or ``set_ordered_backward(False)``
-# switches it off) and longer lists keep the sorted form.  Measured (tools/mb_ordered_bwd.py, profiles/r05_mb_ordered_bwd.txt):
-# forward + backward of a 2,048-triple BPR batch 40 us against 54.5 sorted (25 with atomics), CMF's two domains 56 against 87 (32.5).
+# 10-20.  It is quadratic in the list length, so it takes lists of up to ``ordered_max()`` entries (8,192: twice the item list of a
+# 2,048-triple BPR batch, overall.yaml:19, and where it still beats the sorted form; env CDR_ORDERED_MAX, at most 16,384; 0 or
+# ``set_ordered_backward(False)`` switches it off) and longer lists keep the sorted form.  Measured (tools/mb_ordered_bwd.py,
+# profiles/r05_mb_ordered_bwd.txt): forward + backward of a 2,048-triple BPR batch 40 us against 54 sorted (25 with atomics), CMF's two
+# domains 56 against 87 (32.5); 4,096 triples 60 against 66; 8,192 triples (lists of 16,384) 123 against 100 -- hence the cap.
 _ORDERED = [True]
 _ORDERED_MAX = [None]
 
@@ -87,7 +88,7 @@ def set_ordered_backward(flag, max_entries=None):
 def ordered_max():
     if _ORDERED_MAX[0] is not None:
         return max(0, min(int(_ORDERED_MAX[0]), B_.ORD_MAX_TOTAL))
-    return max(0, min(int(os.environ.get('CDR_ORDERED_MAX', '4096')), B_.ORD_MAX_TOTAL))
+    return max(0, min(int(os.environ.get('CDR_ORDERED_MAX', '8192')), B_.ORD_MAX_TOTAL))
 
 
 def ordered_backward():

@@ -138,11 +138,11 @@ def test_ordered_backward_is_what_set_deterministic_runs_and_where_it_stops():
         return list(seen)
 
     assert run(2048) == ['cdr_bpr_bwd_dense']                                               # the default: atomics
-    assert F_.ordered_max() == 4096
+    assert F_.ordered_max() == 8192
     try:
         F_.set_deterministic(True)
-        assert run(2048) == ['cdr_ordered_bwd']
-        got = run(4096)                                                                     # item list 8,192 > ordered_max()
+        assert run(2048) == ['cdr_ordered_bwd'] and run(4096) == ['cdr_ordered_bwd']
+        got = run(8192)                                                                     # item list 16,384 > ordered_max()
         assert 'cdr_ordered_bwd' not in got and 'cdr_scatter_rows_sorted' in got
         F_.set_ordered_backward(True, max_entries=16384)
         assert run(8192) == ['cdr_ordered_bwd']                                             # raised: up to the kernel's own limit

@@ -9,7 +9,7 @@ for wl in c1 c2 c4; do
 done
 python - <<'PY' | tee gpurun_out/det/summary.txt
 import json
-print('atomic-free dense backward (CDR_DETERMINISTIC=1) vs the default float-atomic scatter; bench.py --workload cN through CrossDomainTrainer.fit, 200 steps')
+print('atomic-free dense backward (CDR_DETERMINISTIC=1: cdr_ordered_bwd for lists <= 8,192 since round 5, the sorted form beyond) vs the default float-atomic scatter; bench.py --workload cN through CrossDomainTrainer.fit, 200 steps')
 for wl in ("c1", "c2", "c4"):
     r = {}
     for d in (0, 1):
@@ -19,7 +19,6 @@ for wl in ("c1", "c2", "c4"):
             r[d] = {'error': repr(e)}
     for d in (0, 1):
         x = r[d]
-        print('%s deterministic=%d: ms_per_step %s  value %s  flag_in_line %s  graph %s  final_loss %s' % (
-            wl, d, x.get('ms_per_step'), x.get('value'), x.get('deterministic_backward'),
-            ((x.get('config') or {}).get('trainer_steps') or {}), x.get('final_loss')))
+        print('%s deterministic=%d: ms_per_step %s  value %s  flag_in_line %s' % (
+            wl, d, x.get('ms_per_step'), x.get('value'), x.get('deterministic_backward')))
 PY
