@@ -104,3 +104,51 @@ def test_a2a_plan_offsets_for_peers_other_than_self():
     bad = np.array([1, -1], np.int64)
     assert lib.cdr_a2a_plan(2, bad.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), 1, 8, None, None, None, None, None, None) != 0
     assert lib.cdr_a2a_plan(2, bad.ctypes.data_as(ctypes.c_void_p), None, 1, 8, None, None, None, None, None, None) != 0     # NULL counts
+
+
+def test_by_value_structs_of_the_header_match_their_ctypes_mirrors(tmp_path):
+    """cdr_batch_job, cdr_ord_seg and cdr_ord_list cross the boundary BY VALUE: the ctypes mirrors in binding.py must have the size and
+    every field offset a C compiler gives the header's declarations (gcc prints them; no GPU, no library call).  Also: cdr_ordered_bwd
+    refuses a list it cannot take (too long, two EmbLoss-free segments are fine, a row wider than 256 floats) before it touches a device."""
+    import subprocess
+    mirrors = {'cdr_batch_job': binding.BatchJob, 'cdr_ord_seg': binding.OrdSeg, 'cdr_ord_list': binding.OrdList}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdr_hip.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    r = subprocess.run(['gcc', '-std=c11', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = subprocess.run([str(exe)], capture_output=True, check=True).stdout.decode().split('\n')
+    seen = 0
+    for line in out:
+        if not line.strip():
+            continue
+        cname, what, val = line.split()
+        cls = mirrors[cname]
+        want = ctypes.sizeof(cls) if what == 'size' else getattr(cls, what).offset
+        assert int(val) == want, f'{cname}.{what}: header {val}, ctypes {want}'
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in mirrors.values())
+    assert binding.ORD_MAX_SEGS == 4 and binding.ORD_MAX_LISTS == 4 and binding.ORD_MAX_TOTAL == 16384
+    text = open(os.path.join(ROOT, 'include', 'cdr_hip.h')).read()
+    for name, val in (('CDR_ORD_MAX_SEGS', 4), ('CDR_ORD_MAX_LISTS', 4), ('CDR_ORD_MAX_TOTAL', 16384)):
+        assert re.search(rf'#define {name} {val}\b', text), name
+    # argument checks come before any launch: CDR_EINVAL (non-zero) and a message, on a box without a GPU too
+    lib = binding.load()
+    arr = (binding.OrdList * 1)()
+    ids = (ctypes.c_int64 * 4)(1, 2, 3, 4)
+    buf = (ctypes.c_float * 16)()
+    arr[0].g, arr[0].g_stride, arr[0].nseg = ctypes.addressof(buf), 4, 1
+    arr[0].seg[0].ids, arr[0].seg[0].n = ctypes.addressof(ids), binding.ORD_MAX_TOTAL + 1
+    assert lib.cdr_ordered_bwd(None, 4, arr, 1) != 0                       # a list beyond CDR_ORD_MAX_TOTAL
+    arr[0].seg[0].n = 4
+    assert lib.cdr_ordered_bwd(None, 260, arr, 1) != 0                     # rows wider than 256 floats
+    assert lib.cdr_ordered_bwd(None, 6, arr, 1) != 0                       # D % 4 != 0
+    assert lib.cdr_ordered_bwd(None, 4, arr, 5) != 0                       # more than CDR_ORD_MAX_LISTS
+    arr[0].g_stride = 2
+    assert lib.cdr_ordered_bwd(None, 4, arr, 1) != 0                       # row stride narrower than the row
