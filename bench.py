@@ -2045,7 +2045,8 @@ def main():
             import gc
             gc.collect(); torch.cuda.empty_cache()
             legs = {}
-            for wl, extra in (('c1', {}), ('c2', {}), ('c3', {}), ('c4', {'full_last_layer': True}), ('c4', {})):
+            for wl, extra in (('c1', {}), ('c2', {}), ('c3', {}), ('c4', {'full_last_layer': True}), ('c4', {}),
+                              ('c1', {'deterministic_leg': True}), ('c2', {'deterministic_leg': True})):
                 a = copy.copy(args)
                 a.workload, a.steps, a.warmup, a.cpu_seconds = wl, 200, 20, 3.0
                 for k_, v_ in extra.items():
@@ -2053,6 +2054,14 @@ def main():
                 if wl == 'c4' and not extra:
                     a.no_cpu_baseline = True                 # same CPU formulation as the full-last-layer leg: measured once
                 name = wl if not (wl == 'c4' and extra) else 'c4_full_last_layer'
+                det_leg = bool(extra.get('deterministic_leg'))
+                if det_leg:
+                    # the same leg under functional.set_deterministic(True): the drop-in losses' dense gradients without float atomics
+                    # (cdr_ordered_bwd at these batch sizes) -- what run-to-run reproducibility costs, in the driver's own run
+                    from recbole_cdr_amd import functional as F_det
+                    name, a.no_cpu_baseline = wl + '_deterministic', True
+                    was_det = F_det.deterministic()
+                    F_det.set_deterministic(True)
                 try:
                     r = run_model_workload(a, world, rank, dev)
                     legs[name] = {k_: r.get(k_) for k_ in ('value', 'unit', 'ms_per_step', 'steps', 'roofline', 'kernels', 'cpu_baseline', 'final_loss')
@@ -2065,6 +2074,9 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     result.setdefault('leg_errors', {})['config_' + name] = repr(e)[:500]
                     print('bench: config leg %s failed: %r' % (name, e), file=sys.stderr)
+                finally:
+                    if det_leg:
+                        F_det.set_deterministic(was_det)
                 gc.collect(); torch.cuda.empty_cache()
             result['configs'] = legs
     else:
