@@ -2,12 +2,12 @@
 // atomics, no sort.  See include/cdr_hip.h for the term a list entry contributes.  functional.set_deterministic(True) runs it for lists
 // of up to 8,192 entries (four times the reference's batch, overall.yaml:19); beyond that the id sort + segmented scatter is faster.
 //
-// One WAVE per list entry (1,024-thread workgroups: 16 entries, four waves per SIMD).  The workgroup stages the low words of the
+// One WAVE per list entry (512-thread workgroups: 8 entries; three of them on a CU, six waves per SIMD).  The workgroup stages the low words of the
 // list's ids in LDS (the entry's own index operands are requested first and travel meanwhile).  A wave runs over the list in trips of
 // 512 positions: lane l reads the ids at base + 64 m + l, m < 8, so the wave ballot of slice m IS the hit map of 64 consecutive
 // positions in list order; a trip without a hit is 8 LDS reads, 8 compares, their OR and one scalar branch.  Hits arrive in ascending
 // position: a hit below the entry's own position means an earlier occurrence owns the row and the wave leaves before it has added
-// anything; the first occurrence queues the later ones and adds them in list order to a zero, 4 x (64 / lanes-per-row) at a time --
+// anything; the first occurrence queues the later ones and adds them in list order to a zero, 2 x (64 / lanes-per-row) at a time --
 // every lane group of the wave fetches a different occurrence's operands (index loads together, then row loads together), the terms go
 // round by lane shuffles and every lane adds them in the same order -- and writes the row with one plain store.
 //
@@ -15,15 +15,16 @@
 // 18.8 us): descriptor + staging 2.1 us, the scan 5 us on average and 12 us for the slowest wave -- N^2 / 16 lane compares per SIMD
 // cycle is nothing, the instruction stream around them (and, for two thirds of the waves at this density, the walk over a trip's hits)
 // is what the SIMDs issue -- and 2.6 us for the first occurrences' dependent index -> row loads at the end.  A row with c occurrences
-// costs its first occurrence c / 16 rounds of two memory latencies (D <= 64): one item holding 13 % of a 4,096-entry list, 280 us.
+// costs its first occurrence c / 8 rounds of two memory latencies (D <= 64): one item holding 13 % of a 4,096-entry list, 280 us.
 #include "cdr_common.h"
 
 namespace {
 
-constexpr int kBlock = 1024;       // 16 waves: one wave per list entry, 4 waves per SIMD (<= 128 registers)
+constexpr int kBlock = 512;        // 8 waves: one wave per list entry; 80 registers: three workgroups (six waves per SIMD) on a CU
 constexpr int kEPB = kBlock / 64;   // list entries per workgroup
 constexpr int kIT = 512;            // list positions a wave tests per trip
-constexpr int kQMax = 16;           // later occurrences a wave adds per round, at most
+constexpr int kSL = 2;              // occurrences per lane group and round (4: 115 registers, one workgroup per CU less -- slower, r05_ab_ordered_ksl.txt)
+constexpr int kQMax = 4 * kSL;      // later occurrences a wave adds per round, at most
 
 struct ord_args {
     cdr_ord_list l[CDR_ORD_MAX_LISTS];
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void ordered_bwd_kernel(ord_args a, int D) 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and known to be
     const int D4 = D >> 2;
     const int LPRe = D4 <= 16 ? 16 : D4 <= 32 ? 32 : 64;
-    const int G = 64 / LPRe, QC = 4 * G;                          // occurrences added per round: 16 (D <= 64), 8 (D <= 128), 4
+    const int G = 64 / LPRe, QC = kSL * G;                          // occurrences added per round: 8 (D <= 64), 4 (D <= 128), 2
     const int sub = lane % LPRe, h = lane / LPRe;
     const int e = (int)blockIdx.x * kEPB + wv;
     const bool live = sub < D4;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void ordered_bwd_kernel(ord_args a, int D) 
     // A trip with hits walks the bits of its maps: a position below the entry's own ends the wave (an earlier occurrence owns the
     // row), its own position is skipped, later ones are queued.  The queue is added in ONE place, when it holds QC positions or at the
     // extra ``tail`` trip: the entry's own term first (always the first of its row's sum), then the later occurrences in list order --
-    // lane group h fetches occurrences h, G + h, 2 G + h, 3 G + h (index loads together, then row loads together), the terms are handed
+    // lane group h fetches occurrences h and G + h (index loads together, then row loads together), the terms are handed
     // round with lane shuffles and added by every lane in list order.
     const int trips = Npad / kIT;
     for (int it = 0; it <= trips; ++it) {
@@ -219,12 +220,12 @@ __global__ __launch_bounds__(kBlock) void ordered_bwd_kernel(ord_args a, int D) 
                     self_done = true;
                 }
                 if (nq > 0) {
-                    int qs[4], qj[4];
-                    float qcf[4];
-                    int64_t qxi[4], qyi[4];
-                    bool ok[4];
+                    int qs[kSL], qj[kSL];
+                    float qcf[kSL];
+                    int64_t qxi[kSL], qyi[kSL];
+                    bool ok[kSL];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {                 // index loads: this lane group's (up to) four occurrences
+                    for (int i = 0; i < kSL; ++i) {                 // index loads: this lane group's (up to) four occurrences
                         const int z = i * G + h;
                         ok[i] = z < nq;
                         const int p = ok[i] ? qpos[wv][z] : 0;
@@ -238,11 +239,11 @@ __global__ __launch_bounds__(kBlock) void ordered_bwd_kernel(ord_args a, int D) 
                             if (S.X) { qxi[i] = S.xid ? S.xid[qj[i]] : (int64_t)qj[i]; if (S.Y) qyi[i] = S.yid[qj[i]]; }
                         }
                     }
-                    float4 t[4];
+                    float4 t[kSL];
                     {
-                        float4 x[4], y[4], r[4];
+                        float4 x[kSL], y[kSL], r[kSL];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {             // row loads
+                        for (int i = 0; i < kSL; ++i) {             // row loads
                             x[i] = y[i] = r[i] = zero4();
                             if (ok[i] && live) {
                                 const cdr_ord_seg& S = L.seg[qs[i]];
@@ -251,11 +252,11 @@ __global__ __launch_bounds__(kBlock) void ordered_bwd_kernel(ord_args a, int D) 
                             }
                         }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < kSL; ++i)
                             t[i] = ok[i] ? term_of(L.seg[qs[i]], seg_go[qs[i]], seg_c[qs[i]], qcf[i], x[i], y[i], r[i]) : zero4();
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {                 // list order: occurrence i G + g comes from lane group g
+                    for (int i = 0; i < kSL; ++i) {                 // list order: occurrence i G + g comes from lane group g
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             if (g < G && i * G + g < nq) {        // uniform

@@ -74,8 +74,8 @@ def deterministic():
 # 10-20.  It is quadratic in the list length, so it takes lists of up to ``ordered_max()`` entries (8,192: twice the item list of a
 # 2,048-triple BPR batch, overall.yaml:19, and where it still beats the sorted form; env CDR_ORDERED_MAX, at most 16,384; 0 or
 # ``set_ordered_backward(False)`` switches it off) and longer lists keep the sorted form.  Measured (tools/mb_ordered_bwd.py,
-# profiles/r05_mb_ordered_bwd.txt): forward + backward of a 2,048-triple BPR batch 40 us against 54 sorted (25 with atomics), CMF's two
-# domains 56 against 87 (32.5); 4,096 triples 60 against 66; 8,192 triples (lists of 16,384) 123 against 100 -- hence the cap.
+# profiles/r05_mb_ordered_bwd.txt): forward + backward of a 2,048-triple BPR batch 36 us against 55 sorted (25 with atomics), CMF's two
+# domains 50 against 87 (33); 4,096 triples 50 against 67; 8,192 triples (lists of 16,384) 116 against 101 -- hence the cap.
 _ORDERED = [True]
 _ORDERED_MAX = [None]
 
