@@ -466,6 +466,16 @@ __global__ __launch_bounds__(kBlock) void loss_finish_pair_kernel(const double* 
     }
 }
 
+// Rows a lane group walks per trip of its loop (<= unroll): small batches get one workgroup per CU's worth of groups before any group
+// takes a second row -- at the reference's batch (2,048 rows) the unrolled form put 16-32 workgroups on 256 CUs and every group worked
+// through 4-8 rows one after the other; the loop is grid-stride, so a wider grid simply leaves the later unroll slots empty.
+inline int64_t units_for(int64_t B, int unroll, int per_block) {
+    int64_t u = (B + (int64_t)CDR_NUM_CU * per_block - 1) / ((int64_t)CDR_NUM_CU * per_block);
+    if (u < 1) u = 1;
+    if (u > unroll) u = unroll;
+    return (B + u - 1) / u;
+}
+
 inline int grid_for(int64_t units, int per_block) {
     int64_t g = (units + per_block - 1) / per_block;
     const int64_t cap = CDR_NUM_CU * 8;       // 2048 blocks = 8 per CU, grid-stride beyond (guide G11)
@@ -501,7 +511,7 @@ extern "C" int cdr_bpr_fwd(cdr_ctx* ctx, void* stream, const float* user_tab, co
     cdr_time_scope* ts = new cdr_time_scope(ctx, CDR_TAG_BPR_FWD, s);
     if ((D & 3) == 0) {
         const int lpr = cdr_lpr_for(D);
-        grid = grid_for((B + kUnroll - 1) / kUnroll, kBlock / lpr);
+        grid = grid_for(units_for(B, kUnroll, kBlock / lpr), kBlock / lpr);
         fused_finish = grid <= kSignInMaxBlocks;
         DISPATCH_LPR(lpr, bpr_fwd_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D,
                                               uid, pid, nid, B, gamma, gcoef, ctx->partials, fused_finish ? ctx->tickets : nullptr,
@@ -558,7 +568,7 @@ extern "C" int cdr_point_fwd(cdr_ctx* ctx, void* stream, int loss_kind, const fl
     if (zs && (D & 3) != 0) { CDR_HIP(cdr_zero_u32(zs, zn * 4, s)); }
     if ((D & 3) == 0) {
         const int lpr = cdr_lpr_for(D);
-        grid = grid_for((B + kUnrollPoint - 1) / kUnrollPoint, kBlock / lpr);
+        grid = grid_for(units_for(B, kUnrollPoint, kBlock / lpr), kBlock / lpr);
         fused_finish = grid <= kSignInMaxBlocks;
         unsigned* tk = fused_finish ? ctx->tickets : nullptr;
         if (same) {
@@ -619,7 +629,7 @@ extern "C" int cdr_point_fwd_pair_ex(cdr_ctx* ctx, void* stream, int loss_kind, 
     }
     hipStream_t s = (hipStream_t)stream;
     const int lpr = cdr_lpr_for(D);
-    int grid = grid_for((bmax + kUnrollPoint - 1) / kUnrollPoint, kBlock / lpr);
+    int grid = grid_for(units_for(bmax, kUnrollPoint, kBlock / lpr), kBlock / lpr);
     if (grid > CDR_MAX_PARTIAL_BLOCKS / 2) grid = CDR_MAX_PARTIAL_BLOCKS / 2;
     const bool fused_finish = 2 * grid <= kSignInMaxBlocks;
     unsigned* tk = fused_finish ? ctx->tickets : nullptr;
