@@ -344,6 +344,43 @@ struct point_pair {
 };
 constexpr size_t kPairPartials = (size_t)(CDR_MAX_PARTIAL_BLOCKS / 2) * CDR_PARTIAL_STRIDE;
 
+// Both batches' finishing pass as ONE pass: the six partial sums are read together and reduced together (block_sum_d<6> adds each
+// of them in loss_finish_body's order, so every value is the one two passes give) -- the second pass's loads used to wait for the
+// first pass's reduction, a memory latency and two barriers in a launch that is little else at 2 x 2,048 rows.
+template <bool SYS>
+__device__ __forceinline__ void loss_finish_pair_body(const double* __restrict__ partials, int nblocks, const point_pair& a,
+                                                      const float* __restrict__ w, float* __restrict__ total) {
+    __shared__ double smem[6 * (kBlock / 64)];
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o0 = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        const double* o1 = o0 + kPairPartials;
+        if (SYS) {
+            acc[0] += cdr_load_sys(o0); acc[1] += cdr_load_sys(o0 + 1); acc[2] += cdr_load_sys(o0 + 2);
+            acc[3] += cdr_load_sys(o1); acc[4] += cdr_load_sys(o1 + 1); acc[5] += cdr_load_sys(o1 + 2);
+        } else {
+            acc[0] += o0[0]; acc[1] += o0[1]; acc[2] += o0[2]; acc[3] += o1[0]; acc[4] += o1[1]; acc[5] += o1[2];
+        }
+    }
+    block_sum_d<6>(acc, smem);
+    if (threadIdx.x == 0) {
+        float tot[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const float main_loss = (float)(acc[3 * d] / (double)a.B[d]);
+            const float nu = (float)sqrt(acc[3 * d + 1]), ni = (float)sqrt(acc[3 * d + 2]);
+            float* out4 = a.out4[d];
+            out4[1] = main_loss; out4[2] = nu; out4[3] = ni;
+            tot[d] = main_loss + a.reg[d] * ((nu + ni) / (float)a.B[d]);
+            out4[0] = tot[d];
+        }
+        if (total) {
+#pragma clang fp contract(off)
+            total[0] = (0.f + tot[0] * w[0]) + tot[1] * w[1];
+        }
+    }
+}
+
 template <int LPR, bool SAME>
 __global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, point_pair a, int D, double* __restrict__ partials,
                                                                 unsigned* __restrict__ ticket, const float* __restrict__ w,
@@ -353,16 +390,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, p
     point_fwd_body<LPR, SAME>(loss_kind, a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.DR, a.uid[d], a.iid[d], a.label[d], a.B[d], a.gcoef[d],
                               a.scores[d], partials + d * kPairPartials);
     // small grids: the block (of either batch) that signs in last finishes both losses and their weighted total
-    if (ticket && cdr_sign_in_last(ticket, gridDim.x * gridDim.y)) {
-        loss_finish_body<true>(partials, gridDim.x, a.B[0], a.reg[0], a.out4[0]);
-        __syncthreads();
-        loss_finish_body<true>(partials + kPairPartials, gridDim.x, a.B[1], a.reg[1], a.out4[1]);
-        __syncthreads();
-        if (total && threadIdx.x == 0) {
-#pragma clang fp contract(off)
-            total[0] = (0.f + a.out4[0][0] * w[0]) + a.out4[1][0] * w[1];
-        }
-    }
+    if (ticket && cdr_sign_in_last(ticket, gridDim.x * gridDim.y)) loss_finish_pair_body<true>(partials, gridDim.x, a, w, total);
 }
 
 __global__ __launch_bounds__(kBlock) void point_fwd_scalar_kernel(int loss_kind, const float* __restrict__ U,
