@@ -494,11 +494,14 @@ __global__ __launch_bounds__(kBlock) void loss_finish_pair_kernel(const double* 
     }
 }
 
-// Rows a lane group walks per trip of its loop (<= unroll): small batches get one workgroup per CU's worth of groups before any group
-// takes a second row -- at the reference's batch (2,048 rows) the unrolled form put 16-32 workgroups on 256 CUs and every group worked
-// through 4-8 rows one after the other; the loop is grid-stride, so a wider grid simply leaves the later unroll slots empty.
+// Rows a lane group walks per trip of its loop (<= unroll): small batches get kSmallGrid workgroups' worth of lane groups before any
+// group takes a second row -- at the reference's batch (2,048 rows) the unrolled form put 16-32 workgroups on 256 CUs and every group
+// worked through 4-8 rows one after the other; the loop is grid-stride, so a wider grid simply leaves the later unroll slots empty.
+// Not a workgroup per CU: every workgroup signs in on ONE word for the finishing pass, and same-address atomics queue up -- swept on the
+// box at 2,048 rows (C1 through fit): 16-32 workgroups 0.0383 ms, 64: 0.0344, 128: 0.0355, 256 (pair kernel): 0.0357.
+constexpr int kSmallGrid = 64;
 inline int64_t units_for(int64_t B, int unroll, int per_block) {
-    int64_t u = (B + (int64_t)CDR_NUM_CU * per_block - 1) / ((int64_t)CDR_NUM_CU * per_block);
+    int64_t u = (B + (int64_t)kSmallGrid * per_block - 1) / ((int64_t)kSmallGrid * per_block);
     if (u < 1) u = 1;
     if (u > unroll) u = unroll;
     return (B + u - 1) / u;
