@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 53
+#define CDR_ABI_VERSION 54
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -237,7 +237,9 @@ int cdr_adam_multi_dev(void* stream, int count, float* const* params, const floa
                        float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev,
                        float lr, float beta1, float beta2, float eps, float weight_decay, const float* loss, float* loss_sum,
                        unsigned* ticket);
-/* ticket (optional): a zero-initialised device word owned by the caller.  With it, updates of up to 512 fat workgroups run as ONE
+#define CDR_SIGNIN_WORDS 288
+/* ticket (optional): CDR_SIGNIN_WORDS zero-initialised device words owned by the caller (a two-level sign-in: eight group counters a cache
+ * line apart behind one word; one word was enough up to ABI 53).  With it, updates of up to 512 fat workgroups run as ONE
  * launch: the kernel evaluates update number step + 1 itself and its last workgroup to finish stores the counters (and the loss total). */
 
 /* cdr_gemm_f32 with a per-output-row scale and a pre-activation accumulate -- the CoNet cross unit

@@ -34,7 +34,8 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 53
+ABI_VERSION = 54
+SIGNIN_WORDS = 288          # CDR_SIGNIN_WORDS: the sign-in words cdr_adam_multi_dev's ``ticket`` points at
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3

@@ -155,6 +155,28 @@ __device__ __forceinline__ bool cdr_sign_in_last(unsigned* ticket, unsigned nblo
     __syncthreads();
     return cdr_last_flag_ != 0;
 }
+// The same for grids of a hundred workgroups and more: sign-ins on ONE word queue up at the memory side (measured: C1's pair loss kernel
+// 11.6 us at 256 workgroups, and faster at 128 with a quarter of the lane groups idle), so the workgroups sign in on kSignGroups words a
+// cache line apart (workgroup id modulo kSignGroups) and the last of each group signs in on the word in front of them: at most
+// nblocks / kSignGroups + kSignGroups arrivals per address.  ticket: CDR_SIGNIN_WORDS zero-initialised words; every counter wraps to 0.
+// Ordering as above, one hop longer: a group's last arrival happens after every member's stores were acknowledged, the finisher's after
+// every group's.
+constexpr unsigned kSignGroups = 8, kSignStride = 32;
+__device__ __forceinline__ bool cdr_sign_in_last_wide(unsigned* ticket, unsigned nblocks) {
+    __shared__ int cdr_last_flag_w_;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned K = nblocks < kSignGroups ? nblocks : kSignGroups;
+        const unsigned g = bid % K, ng = (nblocks - g + K - 1) / K;
+        int last = 0;
+        if (atomicInc(ticket + kSignStride * (1 + g), ng - 1) == ng - 1) last = atomicInc(ticket, K - 1) == K - 1 ? 1 : 0;
+        cdr_last_flag_w_ = last;
+    }
+    __syncthreads();
+    return cdr_last_flag_w_ != 0;
+}
 // Side job of a forward kernel: zero-fill n16 16-byte words (the dense gradient buffers its backward will scatter into -- a separate fill
 // launch is ~5 us of a 40 us step; spread over a kernel that is waiting on its gathers anyway it is free).
 __device__ __forceinline__ void cdr_scrub(uint4* __restrict__ z, int64_t n16) {

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float* __restrict
         cdr_store_sys(o, acc[0]); cdr_store_sys(o + 1, acc[1]); cdr_store_sys(o + 2, acc[2]);
     }
     // small grids: the block that signs in last is the finishing pass (no second launch)
-    if (ticket && cdr_sign_in_last(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
+    if (ticket && cdr_sign_in_last_wide(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
 }
 
 // generic scalar path (D not a multiple of 4): one wave per interaction
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_kernel(int loss_kind, const 
                                                            uint4* __restrict__ scrub, int64_t scrub_n16) {
     cdr_scrub(scrub, scrub_n16);
     point_fwd_body<LPR, SAME>(loss_kind, U, I, RU, RI, D, D, uid, iid, label, B, gcoef, scores, partials);
-    if (ticket && cdr_sign_in_last(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
+    if (ticket && cdr_sign_in_last_wide(ticket, gridDim.x)) loss_finish_body<true>(partials, gridDim.x, B, reg_weight, out4);
 }
 
 // Two batches in one launch (blockIdx.y = batch; CMF's two domains on shared tables, BiTGCF's two stacks): same arithmetic per batch,
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void point_fwd_pair_kernel(int loss_kind, p
     point_fwd_body<LPR, SAME>(loss_kind, a.U[d], a.I[d], a.RU[d], a.RI[d], D, a.DR, a.uid[d], a.iid[d], a.label[d], a.B[d], a.gcoef[d],
                               a.scores[d], partials + d * kPairPartials);
     // small grids: the block (of either batch) that signs in last finishes both losses and their weighted total
-    if (ticket && cdr_sign_in_last(ticket, gridDim.x * gridDim.y)) loss_finish_pair_body<true>(partials, gridDim.x, a, w, total);
+    if (ticket && cdr_sign_in_last_wide(ticket, gridDim.x * gridDim.y)) loss_finish_pair_body<true>(partials, gridDim.x, a, w, total);
 }
 
 __global__ __launch_bounds__(kBlock) void point_fwd_scalar_kernel(int loss_kind, const float* __restrict__ U,
@@ -497,9 +497,10 @@ __global__ __launch_bounds__(kBlock) void loss_finish_pair_kernel(const double* 
 // Rows a lane group walks per trip of its loop (<= unroll): small batches get kSmallGrid workgroups' worth of lane groups before any
 // group takes a second row -- at the reference's batch (2,048 rows) the unrolled form put 16-32 workgroups on 256 CUs and every group
 // worked through 4-8 rows one after the other; the loop is grid-stride, so a wider grid simply leaves the later unroll slots empty.
-// Not a workgroup per CU: every workgroup signs in on ONE word for the finishing pass, and same-address atomics queue up -- swept on the
-// box at 2,048 rows (C1 through fit): 16-32 workgroups 0.0383 ms, 64: 0.0344, 128: 0.0355, 256 (pair kernel): 0.0357.
-constexpr int kSmallGrid = 64;
+// Swept on the box at 2,048 rows (C1 through fit).  With every workgroup signing in on ONE word for the finishing pass: 16-32
+// workgroups 0.0383 ms, 64: 0.0344, 128: 0.0355, 256: 0.0357 (same-address atomics queue up); with the two-level sign-in
+// (cdr_sign_in_last_wide): 64: 0.0339, 128: 0.0335, 256: 0.0336.
+constexpr int kSmallGrid = 128;
 inline int64_t units_for(int64_t B, int unroll, int per_block) {
     int64_t u = (B + (int64_t)kSmallGrid * per_block - 1) / ((int64_t)kSmallGrid * per_block);
     if (u < 1) u = 1;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     const float step_size = hp[0], bc2_sqrt = hp[1];
     const int64_t stride = (int64_t)nb * kBlock;
     auto sign_out = [&]() {
-        if (TICKET && cdr_sign_in_last(ticket, gridDim.x)) {
+        if (TICKET && cdr_sign_in_last_wide(ticket, gridDim.x)) {
             if ((int)threadIdx.x < a.count) a.step[threadIdx.x][0] += 1;
             if (threadIdx.x == 63 && loss_sum) loss_sum[0] += loss[0];
         }

@@ -48,7 +48,7 @@ class DenseAdam(torch.optim.Optimizer):
             lp, self.loss_pair = self.loss_pair, None
             tk = self.__dict__.get('_ticket')
             if tk is None or tk.device != ps_dev:
-                tk = self._ticket = torch.zeros(1, device=ps_dev, dtype=torch.int32)        # sign-in word of the one-launch form
+                tk = self._ticket = torch.zeros(B_.SIGNIN_WORDS, device=ps_dev, dtype=torch.int32)        # sign-in words of the one-launch form
             B_.call('cdr_adam_multi_dev', B_.stream(), n, arr(ps), arr(gs), arr(ms), arr(vs), (ctypes.c_int64 * n)(*ns), arr(ss),
                     float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
                     float(group['weight_decay']), None if lp is None else B_.f32(lp[0]), None if lp is None else B_.f32(lp[1]), B_.raw(tk))

@@ -136,7 +136,7 @@ def test_by_value_structs_of_the_header_match_their_ctypes_mirrors(tmp_path):
     assert seen == sum(len(c._fields_) + 1 for c in mirrors.values())
     assert binding.ORD_MAX_SEGS == 4 and binding.ORD_MAX_LISTS == 4 and binding.ORD_MAX_TOTAL == 16384
     text = open(os.path.join(ROOT, 'include', 'cdr_hip.h')).read()
-    for name, val in (('CDR_ORD_MAX_SEGS', 4), ('CDR_ORD_MAX_LISTS', 4), ('CDR_ORD_MAX_TOTAL', 16384)):
+    for name, val in (('CDR_ORD_MAX_SEGS', 4), ('CDR_ORD_MAX_LISTS', 4), ('CDR_ORD_MAX_TOTAL', 16384), ('CDR_SIGNIN_WORDS', binding.SIGNIN_WORDS)):
         assert re.search(rf'#define {name} {val}\b', text), name
     # argument checks come before any launch: CDR_EINVAL (non-zero) and a message, on a box without a GPU too
     lib = binding.load()
