@@ -567,7 +567,12 @@ extern "C" int cdr_bpr_bwd_dense(cdr_ctx* ctx, void* stream, const float* user_t
     CDR_CHECK_ARG(ctx && user_tab && item_tab && uid && pid && nid && gcoef && out4 && grad_user_tab && grad_item_tab);
     CDR_CHECK_ARG(D > 0 && B > 0);
     hipStream_t s = (hipStream_t)stream;
-    if ((D & 3) == 0) {
+    // From 64 floats a row the wave-per-triple form is the faster one at every batch size measured: each of its atomic instructions
+    // covers 64 CONSECUTIVE floats of a gradient row (one coalesced request), where a lane group's float4 form issues four per row with
+    // its lanes 16 bytes apart -- forward + backward of a 2,048-triple batch 23.8 -> 19.0 us (D = 64), 36.5 -> 26.7 (D = 128); 8,192
+    // triples 40.8 -> 24.1 and 69.2 -> 35.5 (tools/mb_ordered_bwd.py, atomic column; profiles/r05_ab_bwd_dense_form.txt).  Narrower rows
+    // would leave most of a wave idle and keep the lane groups.
+    if ((D & 3) == 0 && D < 64) {
         const int lpr = cdr_lpr_for(D);
         const int grid = grid_for(B, kBlock / lpr);
         DISPATCH_LPR(lpr, bpr_bwd_dense_kernel<L><<<dim3(grid), dim3(kBlock), 0, s>>>(user_tab, item_tab,
