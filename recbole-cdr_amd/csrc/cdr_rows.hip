@@ -273,6 +273,20 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     // the two bias corrections (two fp64 pow each) once per block, not once per thread: they were a third of this kernel's time on
     // the 43 MB of C4's tables and most of it on the few KB of C3's tower weights.  Same expression, same value.
     __shared__ float hp[2];
+    const int64_t stride = (int64_t)nb * kBlock;
+    const bool vec16 = !(n & 3) && !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15);
+    // the one-launch form's fat workgroups make at most four trips per thread: ask for every trip's operands BEFORE waiting for the two
+    // bias corrections (thread 0's four fp64 pow are a microsecond the loads can travel under, in a launch that is little more)
+    const bool early = TICKET && vec16 && stride * 4 >= (n >> 2);
+    const int64_t e0 = (int64_t)lb * kBlock + threadIdx.x;
+    float4 pv4[4], mv4[4], vv4[4], gv4[4];
+    if (early) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t e = e0 + r * stride;
+            if (e < (n >> 2)) { pv4[r] = ld4(p + 4 * e); mv4[r] = ld4(m + 4 * e); vv4[r] = ld4(v + 4 * e); gv4[r] = ld4(g + 4 * e); }
+        }
+    }
     if (threadIdx.x == 0) {
         float ss, bc;
         cdr_adam_hp((double)(a.step[t][0] + (TICKET ? 1 : 0)), lr, b1, b2, ss, bc);
@@ -280,14 +294,29 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     }
     __syncthreads();
     const float step_size = hp[0], bc2_sqrt = hp[1];
-    const int64_t stride = (int64_t)nb * kBlock;
     auto sign_out = [&]() {
         if (TICKET && cdr_sign_in_last_wide(ticket, gridDim.x)) {
             if ((int)threadIdx.x < a.count) a.step[threadIdx.x][0] += 1;
             if (threadIdx.x == 63 && loss_sum) loss_sum[0] += loss[0];
         }
     };
-    if (!(n & 3) && !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) {           // 16-B requests
+    if (early) {
+        const int64_t n4 = n >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t e = e0 + r * stride;
+            if (e < n4) {
+                pv4[r].x = cdr_adam_elem(pv4[r].x, gv4[r].x, mv4[r].x, vv4[r].x, b1, b2, eps, wd, step_size, bc2_sqrt);
+                pv4[r].y = cdr_adam_elem(pv4[r].y, gv4[r].y, mv4[r].y, vv4[r].y, b1, b2, eps, wd, step_size, bc2_sqrt);
+                pv4[r].z = cdr_adam_elem(pv4[r].z, gv4[r].z, mv4[r].z, vv4[r].z, b1, b2, eps, wd, step_size, bc2_sqrt);
+                pv4[r].w = cdr_adam_elem(pv4[r].w, gv4[r].w, mv4[r].w, vv4[r].w, b1, b2, eps, wd, step_size, bc2_sqrt);
+                st4(p + 4 * e, pv4[r]); st4(m + 4 * e, mv4[r]); st4(v + 4 * e, vv4[r]);
+            }
+        }
+        sign_out();
+        return;
+    }
+    if (vec16) {           // 16-B requests
         const int64_t n4 = n >> 2;
         for (int64_t e = (int64_t)lb * kBlock + threadIdx.x; e < n4; e += stride) {
             float4 pv = ld4(p + 4 * e), mv = ld4(m + 4 * e), vv = ld4(v + 4 * e);
