@@ -45,7 +45,7 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
-#define CDR_ABI_VERSION 54
+#define CDR_ABI_VERSION 55
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -700,6 +700,44 @@ int cdr_bpr_shard_local_step(cdr_ctx* ctx, void* stream, int opt, float* user_ta
                              int64_t B_global, float gamma, float reg_weight, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int64_t step_user, float* out9, float* GU, float* GP, uint32_t* keys, uint32_t* perm,
                              uint8_t* flags, uint32_t* heads, void* sort_ws, size_t sort_ws_bytes);
+/* Round 6 -- the row shard's step on its own passes (north_star's layout; parity = the one-GPU result of emcdr.py:110-154, the reference has no
+ * multi-GPU code).  Per rank and domain step:
+ *   cdr_route_triples      stage 0: triples bucketed by the owner of their USER row (uid % world, stable), written interleaved {uid / world, pid,
+ *                          nid} in owner order into send3 [n, 3]; counts [world] (device).  Workspace: cdr_route_triples_workspace_bytes.
+ *   cdr_bpr_shard_plan     after the all-to-all of the triples (recv3 [Bl, 3]): ONE radix sort of {user rows | item keys (owner << bits) | local
+ *                          row} -> u_loc [Bl]; keys / perm [3 Bl] (section A = users, B = [positives | negatives]); flags [4 Bl] (4-byte aligned;
+ *                          byte 0 / 1 / 2 of triple t = its user / positive / negative is the ONLY occurrence of its row in this rank's lists);
+ *                          heads (cdr_bpr_shard_plan_sizes words: counters[4] | duplicate user segments | duplicate item segments); the request
+ *                          list: uniq_local [<= 2 Bl] (distinct item rows, grouped by owner, ascending local row), uidx [2 Bl] (sorted position ->
+ *                          slot), umap [2 Bl] (occurrence -> slot: ip = umap, in = umap + Bl), counts [world + 1] (slots per owner), n_uniq [1].
+ *   cdr_gather_rows_norms  the owner: out[r] = tab[ids[r]], nrm2[r] = ||tab[ids[r]]||^2 -- the squared norms travel beside the rows (4 B each).
+ *   cdr_shard_norm_sums    sums3 = {0, sum_t ||U[u_loc[t]]||^2, sum_t nrm2[ip[t]]} -> all-reduce -> cdr_loss_finish_sums: the EmbLoss coefficients
+ *                          of the GLOBAL batch in out9[4..5] before any row moves.
+ *   cdr_bpr_shard_step     one forward-and-update pass: user rows occurring once updated in place (GU for the others); an item occurrence that
+ *                          is the only one of its row has its finished gradient row (g u + c_i p | -g u) written straight into its send slot
+ *                          GS[slot] (GS [n_uniq, D]); GP[t] = g_t u_t only where a duplicate needs it; then one launch for the duplicate user
+ *                          rows (segmented apply) and the duplicate item segments (GS[slot] = signed sum in occurrence order + c_i #pos row).
+ *                          out9[4..5] in; out9[6] = this rank's loss sum out (out9[7..8], the all-reduced norm sums, stay).
+ *   cdr_shard_owner_apply  the owner: ids = `runs` ascending duplicate-free runs (one per requesting rank), grads one summed row per id ->
+ *                          row-wise optimizer.  One run is applied as it stands (no sort); several are radix-sorted first (stable: rank order).
+ *                          keys / perm [n]; ws as cdr_sort_workspace_bytes(n, table_rows) (unused for one run). */
+int cdr_route_triples_workspace_bytes(int64_t n, int world, size_t* bytes);
+int cdr_route_triples(cdr_ctx* ctx, void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t n, int world,
+                      int64_t* send3, int64_t* counts, void* workspace, size_t workspace_bytes);
+int cdr_bpr_shard_plan_sizes(int64_t Bl, int64_t user_rows, int64_t item_local_rows, int world, int64_t* heads_words, size_t* ws_bytes);
+int cdr_bpr_shard_plan(cdr_ctx* ctx, void* stream, const int64_t* recv3, int64_t Bl, int64_t user_rows, int64_t item_local_rows, int world,
+                       int64_t* u_loc, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads, uint32_t* uidx, int64_t* uniq_local,
+                       int64_t* umap, int64_t* counts, int64_t* n_uniq, void* ws, size_t ws_bytes);
+int cdr_gather_rows_norms(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out, float* nrm2);
+int cdr_shard_norm_sums(cdr_ctx* ctx, void* stream, const float* user_tab, int D, const int64_t* u_loc, const float* nrm2, const int64_t* ip,
+                        int64_t Bl, float* sums3);
+int cdr_bpr_shard_step(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, const float* irows, int D,
+                       const int64_t* u_loc, const int64_t* umap, int64_t Bl, int64_t B_global, float gamma, float reg_weight, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int64_t step_user, float* out9, float* GU, float* GP, float* GS,
+                       const uint32_t* keys, const uint32_t* perm, const uint8_t* flags, uint32_t* heads, const uint32_t* uidx);
+int cdr_shard_owner_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int64_t table_rows, int D,
+                          const int64_t* ids, int64_t n, int runs, const float* grads, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int64_t step, uint32_t* keys, uint32_t* perm, void* ws, size_t ws_bytes);
 /* ... and on recbole's pairwise batch layout (S positives tiled k times, k-major negatives: crossdomain_sampler.py:148-152): one
  * lane group per positive, u and p gathered once; uid / pid [S], nid [S k]; the loss, the per-row gradients and the update are
  * those of cdr_bpr_step_fused on the B = S k tiled rows.  GU [S, D]; GI [S + S k, D] (gradient rows of the duplicate item

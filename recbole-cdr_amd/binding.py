@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 54
+ABI_VERSION = 55
 SIGNIN_WORDS = 288          # CDR_SIGNIN_WORDS: the sign-in words cdr_adam_multi_dev's ``ticket`` points at
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
@@ -117,6 +117,17 @@ _SIGNATURES = {
     'cdr_bpr_shard_local_step': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                  _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                  _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_route_triples_workspace_bytes': [_c_i64, _c_int, ctypes.POINTER(ctypes.c_size_t)],
+    'cdr_route_triples': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_bpr_shard_plan_sizes': [_c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(_c_i64), ctypes.POINTER(ctypes.c_size_t)],
+    'cdr_bpr_shard_plan': [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                           _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_gather_rows_norms': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr],
+    'cdr_shard_norm_sums': [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
+    'cdr_bpr_shard_step': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_f32, _c_f32,
+                           _c_f32, _c_f32, _c_f32, _c_f32, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_shard_owner_apply': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64, _c_int, _c_ptr, _c_f32, _c_f32, _c_f32,
+                              _c_f32, _c_f32, _c_i64, _c_ptr, _c_ptr, _c_ptr, ctypes.c_size_t],
     'cdr_overlap_remap_dev_workspace_bytes': [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_overlap_remap_dev': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                               ctypes.c_size_t, _c_ptr],

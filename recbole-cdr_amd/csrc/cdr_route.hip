@@ -63,6 +63,21 @@ __global__ __launch_bounds__(kBlock) void inverse_perm_kernel(const uint32_t* __
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) pos[perm[q]] = q;
 }
 
+// send3[q] = {uid / G, pid, nid} of triple perm[q] (perm == nullptr: q itself): the routed triples in owner order, interleaved -- one
+// all-to-all moves them (24 bytes each)
+__global__ __launch_bounds__(kBlock) void pack_triples_kernel(const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
+                                                              const int64_t* __restrict__ nid, const uint32_t* __restrict__ perm,
+                                                              int64_t n, int64_t G, int64_t* __restrict__ send3) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        const int64_t o = perm ? (int64_t)perm[q] : q;
+        send3[3 * q] = uid[o] / G; send3[3 * q + 1] = pid[o]; send3[3 * q + 2] = nid[o];
+    }
+}
+__global__ void set_count_kernel(int64_t* __restrict__ counts, int64_t n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counts[0] = n;
+}
+
 // The owner key has <= 10 significant bits (world <= 1024): one Onesweep pass of 9-bit digits (two past 512 ranks) whatever the item count.  rocPRIM's
 // default configuration merge-sorts up to 2^20 items however few key bits there are: 0.6 ms for the 1,048,576 triples of a C5 domain step
 // (block sort + ~48 merge launches, profiles/r05_force_shard_row_kernel_stats.csv before this) against one ~35 us pass.
@@ -121,6 +136,42 @@ extern "C" int cdr_route_workspace_bytes(int64_t n, int world, size_t* bytes) {
     const size_t arr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t starts_bytes = (((size_t)world + 2) * sizeof(int64_t) + 255) & ~(size_t)255;
     *bytes = 3 * arr + starts_bytes + ((tmp_need + 255) & ~(size_t)255);
+    return CDR_OK;
+}
+
+// Stage 0 of the row-sharded step in one call: bucket the triples by the owner of their USER row (uid % world, stable) and write them
+// interleaved, {uid / world, pid, nid}, in owner order; counts[k] = triples for owner k.  One owner: nothing to bucket, one pass.
+extern "C" int cdr_route_triples_workspace_bytes(int64_t n, int world, size_t* bytes) {
+    CDR_CHECK_ARG(bytes && n > 0 && world >= 1 && world <= 1024);
+    if (world == 1) { *bytes = 256; return CDR_OK; }
+    size_t r = 0;
+    int rc = cdr_route_workspace_bytes(n, world, &r);
+    if (rc) return rc;
+    *bytes = r + (((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255);
+    return CDR_OK;
+}
+
+extern "C" int cdr_route_triples(cdr_ctx* ctx, void* stream, const int64_t* uid, const int64_t* pid, const int64_t* nid, int64_t n, int world,
+                                 int64_t* send3, int64_t* counts, void* workspace, size_t workspace_bytes) {
+    CDR_CHECK_ARG(uid && pid && nid && send3 && counts && workspace && n > 0 && n <= (int64_t)0x7FFFFFFF && world >= 1 && world <= 1024);
+    hipStream_t s = (hipStream_t)stream;
+    if (world == 1) {
+        pack_triples_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(uid, pid, nid, nullptr, n, 1, send3);
+        CDR_LAUNCH_CHECK();
+        set_count_kernel<<<dim3(1), dim3(64), 0, s>>>(counts, n);
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
+    }
+    size_t need = 0;
+    int rc = cdr_route_triples_workspace_bytes(n, world, &need);
+    if (rc) return rc;
+    CDR_CHECK_ARG(workspace_bytes >= need);
+    const size_t parr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t* perm = (uint32_t*)workspace;
+    rc = cdr_route_by_owner(ctx, stream, uid, n, nullptr, 0, world, perm, counts, (char*)workspace + parr, workspace_bytes - parr);
+    if (rc) return rc;
+    pack_triples_kernel<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(uid, pid, nid, perm, n, (int64_t)world, send3);
+    CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
 

@@ -46,6 +46,38 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     }
 }
 
+// gather + squared row norms: out[r,:] = tab[ids[r],:], nrm2[r] = ||tab[ids[r],:]||^2 (the row-sharded step's owner side: the requester
+// needs the EmbLoss norm of the rows it asked for, and the owner has them in registers anyway).  One lane group per row, four rows in flight.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void gather_rows_norms_kernel(const float* __restrict__ tab, int D, const int64_t* __restrict__ ids,
+                                                                   int64_t n, float* __restrict__ out, float* __restrict__ nrm2) {
+    constexpr int GPB = kBlock / LPR, UN = 4;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const bool live = sub < (D >> 2);
+    for (int64_t base = gg; base < n; base += TG * UN) {
+        int64_t id[UN];
+        float4 v[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) { const int64_t r = base + j * TG; id[j] = ids[r < n ? r : n - 1]; }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int64_t r = base + j * TG;
+            v[j] = (r < n && live) ? ld4(tab + id[j] * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int64_t r = base + j * TG;
+            const float s2 = group_sum<LPR>(dot4(v[j], v[j]));
+            if (r < n) {
+                if (live) st4(out + r * D + 4 * sub, v[j]);
+                if (sub == 0) nrm2[r] = s2;
+            }
+        }
+    }
+}
+
 template <bool SELECT>
 __global__ __launch_bounds__(kBlock) void gather_rows_scalar_kernel(const float* __restrict__ tab, const float* __restrict__ mapped,
                                                                     int D, const int64_t* __restrict__ ids, int64_t n,
@@ -427,6 +459,21 @@ extern "C" int cdr_gather_rows(void* stream, const float* tab, int D, const int6
     } else {
         const int64_t total = n * D;
         gather_rows_scalar_kernel<false><<<dim3(grid_cap((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(tab, nullptr, D, ids, n, 0, out);
+    }
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_gather_rows_norms(void* stream, const float* tab, int D, const int64_t* ids, int64_t n, float* out, float* nrm2) {
+    CDR_CHECK_ARG(tab && ids && out && nrm2 && D > 0 && (D & 3) == 0 && D <= 256 && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const int64_t groups = (n + 3) / 4;
+    switch (lpr) {
+#define GRN_CASE(L) case L: gather_rows_norms_kernel<L><<<dim3(grid_cap((groups + (kBlock / L) - 1) / (kBlock / L))), dim3(kBlock), 0, s>>>(tab, D, ids, n, out, nrm2); break;
+        GRN_CASE(1) GRN_CASE(2) GRN_CASE(4) GRN_CASE(8) GRN_CASE(16) GRN_CASE(32)
+        default: gather_rows_norms_kernel<64><<<dim3(grid_cap((groups + 3) / 4)), dim3(kBlock), 0, s>>>(tab, D, ids, n, out, nrm2); break;
+#undef GRN_CASE
     }
     CDR_LAUNCH_CHECK();
     return CDR_OK;

@@ -17,6 +17,9 @@
 #include <cstring>
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
 
@@ -696,13 +699,18 @@ __global__ __launch_bounds__(kBlock) void shard_sums_kernel(const double* __rest
 
 // XD (round 5, the dimension-sharded step): the triple's score x_t = <u,p> - <u,n> is GIVEN (xdiff[t]: the all-reduced sum of every
 // rank's column-slice partials, cdr_dimshard.hip) instead of being formed from the rows held here; the norm partials are not produced.
-template <int LPR, int OPT, int UN, bool XD = false>
+// SH (round 6, the row-sharded step): the item "table" TI.W is the buffer of RECEIVED rows (one per distinct item this rank asked for,
+// read-only) and an item occurrence flagged "only occurrence of its row" is not updated -- its finished gradient row (g u + c_i p for the
+// positive, -g u for the negative) is written straight into the send slot of its row, GS[ip] / GS[in]; GP[t] = g u only when one of the
+// triple's two item rows is a duplicate (the segmented sum over the duplicates reads it).
+template <int LPR, int OPT, int UN, bool XD = false, bool SH = false>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_ptrs TI, int D, const int64_t* __restrict__ uid,
                                                                const int64_t* __restrict__ pid, const int64_t* __restrict__ nid,
                                                                const uint32_t* __restrict__ flags4, int64_t B, float gamma, float invB,
                                                                const float* __restrict__ coef, apply_hp hu, apply_hp hi,
                                                                float* __restrict__ GU, float* __restrict__ GP,
-                                                               double* __restrict__ partials, const float* __restrict__ xdiff = nullptr) {
+                                                               double* __restrict__ partials, const float* __restrict__ xdiff = nullptr,
+                                                               float* __restrict__ GS = nullptr) {
     HP_FROM_DEV(hu); HP_FROM_DEV(hi);
     constexpr int GPB = kBlock / LPR;
     __shared__ double smem[3 * (kBlock / 64)];
@@ -747,8 +755,8 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             um[r] = uv[r] = pm[r] = pv[r] = nm[r] = nv[r] = z4;
             if (OPT == 1) {
                 if (ok && fu[r]) { um[r] = ld4(TU.M + ou[r]); uv[r] = ld4(TU.V + ou[r]); }
-                if (ok && fp[r]) { pm[r] = ld4(TI.M + op[r]); pv[r] = ld4(TI.V + op[r]); }
-                if (ok && fn[r]) { nm[r] = ld4(TI.M + on[r]); nv[r] = ld4(TI.V + on[r]); }
+                if (!SH && ok && fp[r]) { pm[r] = ld4(TI.M + op[r]); pv[r] = ld4(TI.V + op[r]); }
+                if (!SH && ok && fn[r]) { nm[r] = ld4(TI.M + on[r]); nv[r] = ld4(TI.V + on[r]); }
             }
         }
         uint32_t ju[UN], jp[UN], jn[UN], gl[UN];
@@ -795,6 +803,11 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
                 if (live) { if (OPT == 1) { st4(TU.M + ou[r], um[r]); st4(TU.V + ou[r], uv[r]); } st4(TU.W + ou[r], wu); }
             } else if (ok) st4(GU + t * D + 4 * sub, gu);
             // ---- positive item row (EmbLoss occurrence), negative item row (gradient -g u, no EmbLoss)
+            if (SH) {
+                if (fp[r] && live) st4(GS + op[r], make_float4(__builtin_fmaf(ci, p[r].x, gi.x), __builtin_fmaf(ci, p[r].y, gi.y),
+                                                               __builtin_fmaf(ci, p[r].z, gi.z), __builtin_fmaf(ci, p[r].w, gi.w)));
+                if (fn[r] && live) st4(GS + on[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w));
+            } else {
             if (fp[r]) {
                 const float4 wp = upd_math<OPT>(p[r], pm[r], pv[r], gi, ci, hi);
                 if (live) { if (OPT == 1) { st4(TI.M + op[r], pm[r]); st4(TI.V + op[r], pv[r]); } st4(TI.W + op[r], wp); }
@@ -802,6 +815,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             if (fn[r]) {
                 const float4 wn = upd_math<OPT>(n[r], nm[r], nv[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w), 0.f, hi);
                 if (live) { if (OPT == 1) { st4(TI.M + on[r], nm[r]); st4(TI.V + on[r], nv[r]); } st4(TI.W + on[r], wn); }
+            }
             }
             if (ok && !(fp[r] && fn[r])) st4(GP + t * D + 4 * sub, gi);
             if (t < B && sub == 0) {
@@ -1299,6 +1313,7 @@ struct dup_side {
     float* W; float* M; float* V; const uint32_t* keys; const uint32_t* perm; int64_t n; const uint32_t* heads; const unsigned* nheads;
     const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp;
     unsigned* counters; seg_long* longs; seg_piece* pieces; int* pcnt; float* partial;
+    float* out = nullptr; const uint32_t* uidx = nullptr;     // row shard, item side: W = the received rows (read-only), out[uidx[position]] = the segment's sum
 };
 template <int LPR, int OPT>
 __global__ __launch_bounds__(kBlock) void rowwise_apply_dups2_kernel(int D, dup_side a, dup_side b) {
@@ -1317,6 +1332,283 @@ __global__ __launch_bounds__(kBlock) void seg_long_finish2_kernel(int D, dup_sid
     const dup_side& t = blockIdx.y ? b : a;
     if (t.counters == nullptr) return;
     seg_long_finish_body<LPR, OPT>(t.W, t.M, t.V, D, t.keys, t.reg_coef, t.hp, t.counters, t.longs, t.partial, t.pcnt);
+}
+
+// ================================================================================================ round 6: the row-sharded step's own passes
+// Keys of one requester-side sort for BOTH lists of a rank's routed triples (recv3 [Bl, 3] = {local user row, positive item, negative
+// item}, item ids global): section A [0, Bl) = the user rows; section B [Bl, 3 Bl) = key_base + ((owner << lb) | local row) of [p | n],
+// so that the distinct item rows come out grouped by owner, ascending inside an owner -- the order in which they are requested.
+// Also unpacks the user column and clears the two head-list counters (cnt) of occ_flags_kernel.
+__global__ __launch_bounds__(kBlock) void shard_keys_kernel(const int64_t* __restrict__ recv3, int64_t Bl, uint32_t G, unsigned lb,
+                                                            uint32_t key_base, int64_t* __restrict__ u_loc, uint32_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ vals, unsigned* __restrict__ cnt) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) cnt[threadIdx.x] = 0u;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < Bl; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t u = recv3[3 * t];
+        const uint32_t p = (uint32_t)recv3[3 * t + 1], n = (uint32_t)recv3[3 * t + 2];
+        u_loc[t] = u;
+        keys[t] = (uint32_t)u; vals[t] = (uint32_t)t;
+        keys[Bl + t] = key_base + (((p % G) << lb) | (p / G)); vals[Bl + t] = (uint32_t)t;
+        keys[2 * Bl + t] = key_base + (((n % G) << lb) | (n / G)); vals[2 * Bl + t] = (uint32_t)(Bl + t);
+    }
+}
+
+struct head_flag_op {                          // 1 where a sorted position starts a new key (the scan's input, never materialised)
+    const uint32_t* keys;
+    __device__ uint32_t operator()(uint32_t q) const { return (q == 0u || keys[q] != keys[q - 1]) ? 1u : 0u; }
+};
+
+// Section B after the scan of its head flags: uidx[q] = dense index of q's segment (= the distinct item's slot in the request list and in
+// both row buffers), umap[occurrence] = the same per occurrence ([0, Bl) positives, [Bl, 2 Bl) negatives), uniq_local[j] = the local row
+// asked of the owner, starts[k] = first slot of owner k (no atomics), n_uniq.
+__global__ __launch_bounds__(kBlock) void shard_emit_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                                            const uint32_t* __restrict__ excl, int64_t n, int world, unsigned lb,
+                                                            uint32_t key_base, uint32_t* __restrict__ uidx, int64_t* __restrict__ uniq_local,
+                                                            int64_t* __restrict__ umap, int64_t* __restrict__ starts,
+                                                            int64_t* __restrict__ n_uniq) {
+    const uint32_t lmask = (1u << lb) - 1u;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += (int64_t)gridDim.x * kBlock) {
+        const uint32_t key = keys[q] - key_base;
+        const uint32_t prev = q > 0 ? keys[q - 1] - key_base : 0u;
+        const bool head = q == 0 || prev != key;
+        const uint32_t j = excl[q] + (head ? 1u : 0u) - 1u;
+        uidx[q] = j;
+        umap[perm[q]] = (int64_t)j;
+        if (head) {
+            uniq_local[j] = (int64_t)(key & lmask);
+            const int owner = (int)(key >> lb), before = q > 0 ? (int)(prev >> lb) : -1;
+            for (int k = before + 1; k <= owner; ++k) starts[k] = (int64_t)j;
+        }
+        if (q == n - 1) {
+            n_uniq[0] = (int64_t)j + 1;
+            for (int k = (int)(key >> lb) + 1; k <= world; ++k) starts[k] = (int64_t)j + 1;
+        }
+    }
+}
+__global__ void shard_counts_kernel(int64_t* __restrict__ starts_counts, int world) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int k = 0; k < world; ++k) starts_counts[k] = starts_counts[k + 1] - starts_counts[k];
+}
+
+// partials[block] = {sum_t ||U[u_loc[t]]||^2, sum_t nrm2[ip[t]]}: the EmbLoss norms of a rank's routed triples.  The item rows' squared
+// norms were formed by their OWNERS while they gathered the rows (cdr_gather_rows_norms) and travelled beside them: 4 bytes per distinct
+// row instead of a second pass over the received rows.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void shard_norms_kernel(const float* __restrict__ U, int D, const int64_t* __restrict__ uid,
+                                                             const float* __restrict__ nrm2, const int64_t* __restrict__ ip, int64_t B,
+                                                             double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    constexpr int UNR = 8;
+    __shared__ double smem[2 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const bool live = sub < (D >> 2);
+    double acc[2] = {0.0, 0.0};
+    for (int64_t base = gg; base < B; base += TG * UNR) {
+        int64_t iu[UNR], ii[UNR];
+        float4 u[UNR];
+        float pn[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const int64_t tc = t < B ? t : B - 1;
+            iu[r] = uid[tc]; ii[r] = ip[tc];
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            u[r] = (t < B && live) ? ld4(U + iu[r] * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pn[r] = (t < B && sub == 0) ? nrm2[ii[r]] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const float su = group_sum<LPR>(dot4(u[r], u[r]));
+            if (sub == 0) { acc[0] += (double)su; acc[1] += (double)pn[r]; }
+        }
+    }
+    block_sum_d<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+// The duplicate ITEM segments of a rank's routed triples: out[uidx[head]] = signed sum of GP over the segment's occurrences, in
+// occurrence order (+ for positives, - for negatives) + c_i * #positives * (the received row) -- the one gradient row that goes home for
+// that item.  Structure and summation order of rowwise_apply_dups_body (SU segments in flight; third and later occurrences eight at a
+// time; long segments registered for the piece kernels); nothing is updated here.
+template <int LPR>
+__device__ __forceinline__ void segsum_dups_body(int D, const dup_side& t) {
+    constexpr int GPB = kBlock / LPR;
+    constexpr int SU = 4;
+    const uint32_t* __restrict__ keys = t.keys; const uint32_t* __restrict__ perm = t.perm; const uint32_t* __restrict__ heads = t.heads;
+    const float* __restrict__ G = t.G; const float* __restrict__ rows = t.W; float* __restrict__ out = t.out;
+    const uint32_t* __restrict__ uidx = t.uidx;
+    const int64_t n = t.n, neg_start = t.neg_start, reg_limit = t.reg_limit;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float c = t.reg_coef ? t.reg_coef[0] : 0.f;
+    const int64_t nh = (int64_t)t.nheads[0];
+    const bool live = sub < D4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t h0 = gg * SU; h0 < nh; h0 += TG * SU) {
+        int64_t q[SU]; uint32_t row[SU], k2[SU]; bool ok[SU];
+#pragma unroll
+        for (int j = 0; j < SU; ++j) { ok[j] = h0 + j < nh; q[j] = ok[j] ? (int64_t)heads[h0 + j] : 0; }
+        uint32_t far[SU], o0[SU], o1[SU], ju[SU];
+#pragma unroll
+        for (int j = 0; j < SU; ++j) {
+            row[j] = keys[q[j]];
+            k2[j] = q[j] + 2 < n ? keys[q[j] + 2] : ~0u;
+            far[j] = q[j] + kLongSeg < n ? keys[q[j] + kLongSeg] : ~0u;
+            o0[j] = perm[q[j]]; o1[j] = q[j] + 1 < n ? perm[q[j] + 1] : 0u;
+            ju[j] = uidx[q[j]];
+        }
+        float4 w[SU], g0[SU], g1[SU];
+#pragma unroll
+        for (int j = 0; j < SU; ++j) {
+            ok[j] = ok[j] && !(far[j] == row[j] && row[j] != ~0u && q[j] + kLongSeg < n);
+            w[j] = g0[j] = g1[j] = z4;
+            if (ok[j] && live) {
+                if (c != 0.f) w[j] = ld4(rows + (int64_t)ju[j] * D + 4 * sub);
+                const bool n0 = (int64_t)o0[j] >= neg_start, n1 = (int64_t)o1[j] >= neg_start;
+                g0[j] = ld4(G + (n0 ? (int64_t)o0[j] - neg_start : (int64_t)o0[j]) * D + 4 * sub);
+                g1[j] = ld4(G + (n1 ? (int64_t)o1[j] - neg_start : (int64_t)o1[j]) * D + 4 * sub);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SU; ++j) {
+            if (!ok[j]) continue;
+            float4 acc = z4;
+            int cnt = 0;
+            {
+                const bool n0 = (int64_t)o0[j] >= neg_start, n1 = (int64_t)o1[j] >= neg_start;
+                if (n0) { acc.x -= g0[j].x; acc.y -= g0[j].y; acc.z -= g0[j].z; acc.w -= g0[j].w; }
+                else { acc.x += g0[j].x; acc.y += g0[j].y; acc.z += g0[j].z; acc.w += g0[j].w; }
+                cnt += ((int64_t)o0[j] < reg_limit) ? 1 : 0;
+                if (n1) { acc.x -= g1[j].x; acc.y -= g1[j].y; acc.z -= g1[j].z; acc.w -= g1[j].w; }
+                else { acc.x += g1[j].x; acc.y += g1[j].y; acc.z += g1[j].z; acc.w += g1[j].w; }
+                cnt += ((int64_t)o1[j] < reg_limit) ? 1 : 0;
+            }
+            if (k2[j] == row[j]) {
+                int64_t end = q[j] + 3;
+                while (end < n && end <= q[j] + kLongSeg && keys[end] == row[j]) ++end;
+                for (int64_t e0 = q[j] + 2; e0 < end; e0 += 8) {
+                    int64_t o[8]; float4 g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o[u] = e0 + u < end ? (int64_t)perm[e0 + u] : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        g[u] = (o[u] >= 0 && live) ? ld4(G + (o[u] >= neg_start ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (o[u] < 0) continue;
+                        if (o[u] >= neg_start) { acc.x -= g[u].x; acc.y -= g[u].y; acc.z -= g[u].z; acc.w -= g[u].w; }
+                        else { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+                        cnt += (o[u] < reg_limit) ? 1 : 0;
+                    }
+                }
+            }
+            const float rc = c * (float)cnt;
+            if (live) st4(out + (int64_t)ju[j] * D + 4 * sub, make_float4(__builtin_fmaf(rc, w[j].x, acc.x), __builtin_fmaf(rc, w[j].y, acc.y),
+                                                                          __builtin_fmaf(rc, w[j].z, acc.z), __builtin_fmaf(rc, w[j].w, acc.w)));
+        }
+    }
+    if (t.counters == nullptr) return;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q + kLongSeg < n; q += (int64_t)gridDim.x * kBlock) {
+        const uint32_t row = keys[q];
+        const uint32_t before = keys[q > 0 ? q - 1 : 0];
+        const uint32_t far = keys[q + kLongSeg];
+        if ((q > 0 && before == row) || far != row) continue;
+        int64_t lo = q + kLongSeg, hi = n;
+        while (lo + 1 < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] == row) lo = mid; else hi = mid;
+        }
+        const int64_t len = hi - q;
+        const unsigned np = (unsigned)((len + kPiece - 1) / kPiece);
+        const unsigned base = atomicAdd(&t.counters[0], np);
+        const unsigned li = atomicAdd(&t.counters[1], 1u);
+        t.longs[li] = seg_long{q, len, (int64_t)base};
+        for (unsigned k = 0; k < np; ++k) {
+            const int64_t st = q + (int64_t)k * kPiece;
+            t.pieces[base + k] = seg_piece{st, (hi - st) < kPiece ? (hi - st) : (int64_t)kPiece};
+        }
+    }
+}
+template <int LPR>
+__device__ __forceinline__ void segsum_long_finish_body(int D, const dup_side& t) {
+    constexpr int GPB = kBlock / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int D4 = D >> 2;
+    const float c = t.reg_coef ? t.reg_coef[0] : 0.f;
+    const int64_t nl = t.counters[1];
+    for (int64_t li = gg; li < nl; li += TG) {
+        const seg_long sg = t.longs[li];
+        const int64_t j = t.uidx[sg.head];
+        const int64_t np = (sg.len + kPiece - 1) / kPiece;
+        for (int ch = sub; ch < D4; ch += LPR) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cnt = 0;
+            for (int64_t k0 = 0; k0 < np; k0 += 8) {
+                float4 g[8]; int cc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = k0 + u < np;
+                    g[u] = in ? ld4(t.partial + (sg.base + k0 + u) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    cc[u] = in ? t.pcnt[sg.base + k0 + u] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < np) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; cnt += cc[u]; }
+            }
+            const float rc = c * (float)cnt;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c != 0.f) w = ld4(t.W + j * D + 4 * ch);
+            st4(t.out + j * D + 4 * ch, make_float4(__builtin_fmaf(rc, w.x, acc.x), __builtin_fmaf(rc, w.y, acc.y),
+                                                    __builtin_fmaf(rc, w.z, acc.z), __builtin_fmaf(rc, w.w, acc.w)));
+        }
+    }
+}
+// blockIdx.y = 0: the duplicate USER rows (updated in place, as in the one-GPU step); 1: the duplicate ITEM segments (summed for the way home)
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void shard_dups_kernel(int D, dup_side a, dup_side b) {
+    if (blockIdx.y == 0)
+        rowwise_apply_dups_body<LPR, OPT, true>(a.W, a.M, a.V, D, a.keys, a.perm, a.n, a.heads, a.nheads, a.G, a.neg_start, a.reg_limit, a.reg_coef, a.hp,
+                                                a.counters, a.longs, a.pieces);
+    else segsum_dups_body<LPR>(D, b);
+}
+template <int LPR, int OPT>
+__global__ __launch_bounds__(kBlock) void shard_long_finish_kernel(int D, dup_side a, dup_side b) {
+    if (blockIdx.y == 0) {
+        if (a.counters) seg_long_finish_body<LPR, OPT>(a.W, a.M, a.V, D, a.keys, a.reg_coef, a.hp, a.counters, a.longs, a.partial, a.pcnt);
+    } else if (b.counters) segsum_long_finish_body<LPR>(D, b);
+}
+// out9[6] = this rank's loss sum (out9[7..8] keep the all-reduced norm sums the caller put there) + both sides' long-segment counters cleared
+__global__ __launch_bounds__(kBlock) void shard_sums2_kernel(const double* __restrict__ partials, int nblocks, float* __restrict__ out9,
+                                                             unsigned* __restrict__ zero_a, unsigned* __restrict__ zero_b) {
+    __shared__ double smem[3 * (kBlock / 64)];
+    if (zero_a && threadIdx.x >= 64 && threadIdx.x < 68) zero_a[threadIdx.x - 64] = 0u;
+    if (zero_b && threadIdx.x >= 128 && threadIdx.x < 132) zero_b[threadIdx.x - 128] = 0u;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const double* o = partials + (size_t)b * CDR_PARTIAL_STRIDE;
+        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
+    }
+    block_sum_d<3>(acc, smem);
+    if (threadIdx.x == 0) out9[6] = (float)acc[0];
+}
+// keys / perm of a list that is ALREADY one ascending duplicate-free run (what one requester sends an owner): nothing to sort
+__global__ __launch_bounds__(kBlock) void sorted_run_keys_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ perm) {
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += (int64_t)gridDim.x * kBlock) {
+        keys[q] = (uint32_t)ids[q]; perm[q] = (uint32_t)q;
+    }
 }
 
 }  // namespace
@@ -1535,7 +1827,8 @@ namespace {
 // Both tables' duplicate-row applies of a fused step: one scratch request carved for the two sides, three launches with blockIdx.y =
 // side instead of six (+ two counter clears, which the caller folds into step_finish_keep_kernel: dups_plan first, then that launch).
 struct dup_host { float* table; float* m; float* v; const uint32_t* keys; const uint32_t* perm; int64_t n; const uint32_t* heads; const unsigned* nheads;
-                  const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp; uint32_t key_base; };
+                  const float* G; int64_t neg_start, reg_limit; const float* reg_coef; apply_hp hp; uint32_t key_base;
+                  float* out = nullptr; const uint32_t* uidx = nullptr; };
 struct dups_plan { dup_side side[2]; int64_t long_cap[2], piece_cap[2]; };
 
 static int dups_plan_make(cdr_ctx* ctx, int D, const dup_host (&h)[2], dups_plan& pl) {
@@ -1567,6 +1860,7 @@ static int dups_plan_make(cdr_ctx* ctx, int D, const dup_host (&h)[2], dups_plan
         t.keys = h[i].keys; t.perm = h[i].perm; t.n = h[i].n; t.heads = h[i].heads; t.nheads = h[i].nheads; t.G = h[i].G;
         t.neg_start = h[i].neg_start; t.reg_limit = h[i].reg_limit; t.reg_coef = h[i].reg_coef; t.hp = h[i].hp;
         t.counters = nullptr; t.longs = nullptr; t.pieces = nullptr; t.pcnt = nullptr; t.partial = nullptr;
+        t.out = h[i].out; t.uidx = h[i].uidx;
         if (pl.long_cap[i]) {
             t.counters = (unsigned*)(base + off[i][0]); t.longs = (seg_long*)(base + off[i][1]); t.pieces = (seg_piece*)(base + off[i][2]);
             t.pcnt = (int*)(base + off[i][3]); t.partial = (float*)(base + off[i][4]);
@@ -2014,6 +2308,183 @@ extern "C" int cdr_bpr_shard_local_step(cdr_ctx* ctx, void* stream, int opt, flo
     shard_sums_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, out9, pl.side[0].counters);
     CDR_LAUNCH_CHECK();
     return apply_dups_pair(ctx, s, opt, D, pl);
+}
+
+// ---- round 6: the row-sharded step on its own passes --------------------------------------------------------------
+//   cdr_bpr_shard_plan   ONE sort for both lists of a rank's routed triples (user rows | item keys grouped by owner) -> occurrence flags of
+//                        both (user occurs once -> updated in place; item occurs once -> its gradient row goes straight into its send
+//                        slot), the duplicate segments' heads, and the request list: distinct item rows per owner, occurrence -> slot map.
+//   cdr_shard_norm_sums  EmbLoss norm sums from the local user rows and the owners' per-row squared norms.
+//   cdr_bpr_shard_step   the forward-and-update pass (SH): user rows as in the one-GPU step; gradient rows of single item occurrences written
+//                        once, into GS; GP only where a duplicate needs it; then ONE launch for the duplicate user rows (update) and the
+//                        duplicate item segments (sum -> GS).
+namespace {
+struct shard_bits { unsigned lb, hb; uint32_t key_base; };
+static int shard_key_bits(int64_t user_rows, int64_t item_local_rows, int world, shard_bits& kb) {
+    if (user_rows <= 0 || item_local_rows <= 0 || world < 1 || world > 1024) return CDR_EINVAL;
+    kb.lb = bits_for(item_local_rows);
+    const unsigned ob = world > 1 ? bits_for(world) : 0u;
+    const unsigned ub = bits_for(user_rows);
+    kb.hb = ub > kb.lb + ob ? ub : kb.lb + ob;
+    if (kb.hb >= 31) return CDR_EINVAL;
+    kb.key_base = 1u << kb.hb;
+    return CDR_OK;
+}
+}  // namespace
+
+extern "C" int cdr_bpr_shard_plan_sizes(int64_t Bl, int64_t user_rows, int64_t item_local_rows, int world, int64_t* heads_words,
+                                        size_t* ws_bytes) {
+    CDR_CHECK_ARG(heads_words && ws_bytes && Bl > 0 && 3 * Bl <= (int64_t)0x7FFFFFFF);
+    shard_bits kb;
+    CDR_CHECK_ARG(shard_key_bits(user_rows, item_local_rows, world, kb) == CDR_OK);
+    *heads_words = 4 + (Bl / 2 + 1) + (Bl + 1);
+    size_t sort_need = 0;
+    int rc = cdr_sort_workspace_bytes(3 * Bl, (int64_t)kb.key_base * 2, &sort_need);
+    if (rc) return rc;
+    size_t tmp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp, rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), head_flag_op{nullptr}),
+                                           (uint32_t*)nullptr, 0u, (size_t)(2 * Bl), rocprim::plus<uint32_t>());
+    if (e != hipSuccess) { cdr_set_error("cdr_bpr_shard_plan_sizes: %s", hipGetErrorString(e)); return (int)e; }
+    const size_t scan_need = (((size_t)(2 * Bl) * sizeof(uint32_t) + 255) & ~(size_t)255) + ((tmp + 255) & ~(size_t)255);
+    *ws_bytes = sort_need > scan_need ? sort_need : scan_need;
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_shard_plan(cdr_ctx* ctx, void* stream, const int64_t* recv3, int64_t Bl, int64_t user_rows, int64_t item_local_rows,
+                                  int world, int64_t* u_loc, uint32_t* keys, uint32_t* perm, uint8_t* flags, uint32_t* heads,
+                                  uint32_t* uidx, int64_t* uniq_local, int64_t* umap, int64_t* counts, int64_t* n_uniq, void* ws,
+                                  size_t ws_bytes) {
+    CDR_CHECK_ARG(ctx && recv3 && u_loc && keys && perm && flags && heads && uidx && uniq_local && umap && counts && n_uniq && ws);
+    CDR_CHECK_ARG(Bl > 0 && 3 * Bl <= (int64_t)0x7FFFFFFF && ((uintptr_t)flags & 3) == 0);
+    shard_bits kb;
+    CDR_CHECK_ARG(shard_key_bits(user_rows, item_local_rows, world, kb) == CDR_OK);
+    int64_t hw = 0; size_t need = 0;
+    int rc = cdr_bpr_shard_plan_sizes(Bl, user_rows, item_local_rows, world, &hw, &need);
+    if (rc) return rc;
+    CDR_CHECK_ARG(ws_bytes >= need);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = 3 * Bl;
+    const size_t arr = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t* keys_in = (uint32_t*)ws;
+    uint32_t* vals_in = (uint32_t*)((char*)ws + arr);
+    void* tmp = (char*)ws + 2 * arr;
+    size_t tmp_bytes = ws_bytes - 2 * arr;
+    unsigned* cnt = (unsigned*)heads;
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_SORT, s);
+        shard_keys_kernel<<<dim3(grid_for(Bl, kBlock)), dim3(kBlock), 0, s>>>(recv3, Bl, (uint32_t)world, kb.lb, kb.key_base, u_loc, keys_in, vals_in, cnt);
+        CDR_LAUNCH_CHECK();
+        CDR_HIP(sort_pairs(tmp, tmp_bytes, keys_in, keys, vals_in, perm, (size_t)n, kb.hb + 1, s));
+    }
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+        occ_flags_kernel<<<dim3(grid_for(n, kBlock * kFlagIT)), dim3(kBlock), 0, s>>>(keys, perm, Bl, n, 4, flags, heads + 4, heads + 4 + (Bl / 2 + 1), cnt);
+    }
+    CDR_LAUNCH_CHECK();
+    // the request list from section B (the sort's inputs are dead: the scan reuses the workspace)
+    const int64_t nB = 2 * Bl;
+    const uint32_t* keysB = keys + Bl;
+    const size_t arrB = ((size_t)nB * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t* excl = (uint32_t*)ws;
+    void* stmp = (char*)ws + arrB;
+    size_t stmp_bytes = ws_bytes - arrB;
+    CDR_HIP(rocprim::exclusive_scan(stmp, stmp_bytes, rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), head_flag_op{keysB}),
+                                    excl, 0u, (size_t)nB, rocprim::plus<uint32_t>(), s));
+    shard_emit_kernel<<<dim3(grid_for(nB, kBlock)), dim3(kBlock), 0, s>>>(keysB, perm + Bl, excl, nB, world, kb.lb, kb.key_base, uidx, uniq_local, umap,
+                                                                          counts, n_uniq);
+    CDR_LAUNCH_CHECK();
+    shard_counts_kernel<<<dim3(1), dim3(64), 0, s>>>(counts, world);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_shard_norm_sums(cdr_ctx* ctx, void* stream, const float* user_tab, int D, const int64_t* u_loc, const float* nrm2,
+                                   const int64_t* ip, int64_t Bl, float* sums3) {
+    CDR_CHECK_ARG(ctx && user_tab && u_loc && nrm2 && ip && sums3 && D > 0 && (D & 3) == 0 && D <= 256 && Bl > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const int ngrid = grid_for((Bl + 7) / 8, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+        DISPATCH_LPR(lpr, shard_norms_kernel<L><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, D, u_loc, nrm2, ip, Bl, ctx->partials));
+    }
+    CDR_LAUNCH_CHECK();
+    norm_sums_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, ngrid, sums3);
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_bpr_shard_step(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, const float* irows, int D,
+                                  const int64_t* u_loc, const int64_t* umap, int64_t Bl, int64_t B_global, float gamma, float reg_weight,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step_user, float* out9, float* GU,
+                                  float* GP, float* GS, const uint32_t* keys, const uint32_t* perm, const uint8_t* flags, uint32_t* heads,
+                                  const uint32_t* uidx) {
+    CDR_CHECK_ARG(ctx && user_tab && irows && u_loc && umap && out9 && GU && GP && GS && keys && perm && flags && heads && uidx);
+    CDR_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 256 && Bl > 0 && 3 * Bl <= (int64_t)0x7FFFFFFF && B_global >= Bl);
+    CDR_CHECK_ARG(opt == 0 || (opt == 1 && user_m && user_v && step_user > 0));
+    CDR_CHECK_ARG(((uintptr_t)flags & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = cdr_lpr_for(D);
+    const apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
+    const apply_hp hi = make_hp(0, lr, beta1, beta2, eps, weight_decay, 1);                // (no item row is updated on this side)
+    const tab_ptrs TU{user_tab, user_m, user_v}, TI{const_cast<float*>(irows), nullptr, nullptr};
+    const int grid = grid_for(Bl, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_BPR_FWD_APPLY, s);
+#define FA_ARGS TU, TI, D, u_loc, umap, umap + Bl, (const uint32_t*)flags, Bl, gamma, 1.0f / (float)B_global, out9 + 4, hu, hi, GU, GP, ctx->partials, nullptr, GS
+        if (opt == 0) { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 0, 1, false, true><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+        else { DISPATCH_LPR(lpr, bpr_fwd_apply_kernel<L, 1, 1, false, true><<<dim3(grid), dim3(kBlock), 0, s>>>(FA_ARGS)); }
+#undef FA_ARGS
+    }
+    CDR_LAUNCH_CHECK();
+    unsigned* cnt = (unsigned*)heads;
+    dup_host sides[2] = {{user_tab, user_m, user_v, keys, perm, Bl, heads + 4, cnt, GU, Bl, Bl, out9 + 4, hu, 0},
+                         {const_cast<float*>(irows), nullptr, nullptr, keys + Bl, perm + Bl, 2 * Bl, heads + 4 + (Bl / 2 + 1), cnt + 1, GP, Bl, Bl,
+                          out9 + 5, hi, 0}};
+    sides[1].out = GS; sides[1].uidx = uidx;
+    dups_plan pl;
+    int rc = dups_plan_make(ctx, D, sides, pl);
+    if (rc) return rc;
+    shard_sums2_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, out9, pl.side[0].counters, pl.side[1].counters);
+    CDR_LAUNCH_CHECK();
+    const int dgrid = grid_for((2 * Bl) / 16 + 1, kBlock / lpr);
+    {
+        cdr_time_scope ts(ctx, CDR_TAG_APPLY_SIGNED, s);
+        if (opt == 0) { DISPATCH_LPR(lpr, shard_dups_kernel<L, 0><<<dim3(dgrid, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
+        else { DISPATCH_LPR(lpr, shard_dups_kernel<L, 1><<<dim3(dgrid, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
+    }
+    CDR_LAUNCH_CHECK();
+    if (pl.long_cap[0] || pl.long_cap[1]) {
+        const int64_t pc = pl.piece_cap[0] > pl.piece_cap[1] ? pl.piece_cap[0] : pl.piece_cap[1];
+        const int64_t lc = pl.long_cap[0] > pl.long_cap[1] ? pl.long_cap[0] : pl.long_cap[1];
+        const int gp = grid_for(pc < 16384 ? pc : 16384, kBlock / lpr);
+        DISPATCH_LPR(lpr, seg_piece_sum2_kernel<L><<<dim3(gp, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1]));
+        CDR_LAUNCH_CHECK();
+        const int gl = grid_for(lc < 4096 ? lc : 4096, kBlock / lpr);
+        if (opt == 0) { DISPATCH_LPR(lpr, shard_long_finish_kernel<L, 0><<<dim3(gl, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
+        else { DISPATCH_LPR(lpr, shard_long_finish_kernel<L, 1><<<dim3(gl, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1])); }
+        CDR_LAUNCH_CHECK();
+    }
+    return CDR_OK;
+}
+
+// The owner's side: ids = `runs` ascending duplicate-free runs of local rows (one per requesting rank, in rank order), grads one summed
+// gradient row per id (EmbLoss term inside).  One run needs no sort: the list IS the sorted segment list; several runs are radix-sorted
+// as everywhere (stable: rows asked for by several ranks are summed in rank order).
+extern "C" int cdr_shard_owner_apply(cdr_ctx* ctx, void* stream, int opt, float* table, float* exp_avg, float* exp_avg_sq, int64_t table_rows,
+                                     int D, const int64_t* ids, int64_t n, int runs, const float* grads, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, int64_t step, uint32_t* keys, uint32_t* perm, void* ws, size_t ws_bytes) {
+    CDR_CHECK_ARG(ctx && table && ids && grads && keys && perm && n > 0 && runs >= 1 && table_rows > 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (runs == 1) {
+        sorted_run_keys_kernel<<<dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s>>>(ids, n, keys, perm);
+        CDR_LAUNCH_CHECK();
+    } else {
+        int rc = cdr_sort_ids(ctx, stream, ids, n, nullptr, 0, table_rows, keys, perm, ws, ws_bytes);
+        if (rc) return rc;
+    }
+    return cdr_rowwise_apply(ctx, stream, opt, table, exp_avg, exp_avg_sq, D, keys, perm, n, grads, n, 0, nullptr, lr, beta1, beta2, eps,
+                             weight_decay, step, nullptr, 0);
 }
 
 // ---- the per-positive (k-major) form: uid / pid [S] (the first S entries of recbole's tiled [S k] columns), nid [S k] k-major

@@ -214,6 +214,96 @@ class NativeOps:
                 B_.i64(local_ids) if tagged else None, 0)
 
 
+    # ---- round 6: the step on its own passes (cdr_route_triples / cdr_bpr_shard_plan / cdr_gather_rows_norms / cdr_shard_norm_sums /
+    # cdr_bpr_shard_step / cdr_shard_owner_apply) -------------------------------------------------------------------------------------
+    def route_triples(self, uid, pid, nid, world):
+        """-> (send3 int64 [B, 3] = {uid // world, pid, nid} in owner order of uid % world (stable), counts int64 [world])."""
+        B_ = self.B_
+        n, dev = uid.numel(), uid.device
+        send3 = torch.empty(n, 3, device=dev, dtype=torch.int64)
+        counts = torch.zeros(world, device=dev, dtype=torch.int64)
+        if n == 0:
+            return send3, counts
+        need = ctypes.c_size_t(0)
+        B_._check(B_.load().cdr_route_triples_workspace_bytes(n, world, ctypes.byref(need)), 'cdr_route_triples_workspace_bytes')
+        ws = self._workspace(('route3', torch.cuda.current_stream().cuda_stream), need.value, dev)
+        B_.call('cdr_route_triples', B_.ctx(self.device), B_.stream(), B_.i64(uid), B_.i64(pid), B_.i64(nid), n, int(world), B_.i64(send3),
+                B_.i64(counts), B_.raw(ws), ws.numel())
+        return send3, counts
+
+    def plan(self, recv3, world, user_rows, item_local_rows, D):
+        """One sort for both lists of the routed triples -> the flags / duplicate heads of the forward-and-update pass and the request list
+        (``uniq_local`` grouped by owner, ``umap`` occurrence -> slot, ``counts`` per owner).  Buffers persist per (stream, table)."""
+        B_ = self.B_
+        Bl, dev = recv3.shape[0], recv3.device
+        key = ('plan', torch.cuda.current_stream().cuda_stream, int(user_rows), int(item_local_rows))
+        buf = self._ws.get(key)
+        if buf is None or buf['cap'] < Bl:
+            cap = max(int(Bl * 1.25), 1024)
+            words, need = ctypes.c_int64(0), ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_bpr_shard_plan_sizes(cap, int(user_rows), int(item_local_rows), int(world), ctypes.byref(words), ctypes.byref(need)),
+                      'cdr_bpr_shard_plan_sizes')
+            e = lambda n, dt: torch.empty(n, device=dev, dtype=dt)  # noqa: E731
+            buf = self._ws[key] = {
+                'cap': cap, 'u_loc': e(cap, torch.int64), 'keys': e(3 * cap, torch.int32), 'perm': e(3 * cap, torch.int32),
+                'flags': torch.zeros(4 * cap, device=dev, dtype=torch.uint8), 'heads': e(int(words.value), torch.int32),
+                'uidx': e(2 * cap, torch.int32), 'uniq_local': e(2 * cap, torch.int64), 'umap': e(2 * cap, torch.int64),
+                'counts': e(world + 1, torch.int64), 'n_uniq': e(1, torch.int64), 'ws': e(int(need.value), torch.uint8),
+                'GU': torch.empty(cap, D, device=dev, dtype=torch.float32), 'GP': torch.empty(cap, D, device=dev, dtype=torch.float32)}
+        B_.call('cdr_bpr_shard_plan', B_.ctx(self.device), B_.stream(), B_.i64(recv3), Bl, int(user_rows), int(item_local_rows), int(world),
+                B_.i64(buf['u_loc']), B_.raw(buf['keys']), B_.raw(buf['perm']), B_.raw(buf['flags']), B_.raw(buf['heads']), B_.raw(buf['uidx']),
+                B_.i64(buf['uniq_local']), B_.i64(buf['umap']), B_.i64(buf['counts']), B_.i64(buf['n_uniq']), B_.raw(buf['ws']), buf['ws'].numel())
+        return {'Bl': Bl, 'buf': buf, 'u_loc': buf['u_loc'][:Bl], 'uniq_local': buf['uniq_local'], 'umap': buf['umap'][:2 * Bl],
+                'counts': buf['counts'][:world]}
+
+    def gather_rows_norms(self, table, local_ids):
+        """The owner's side: (rows [n, D], their squared norms [n])."""
+        B_ = self.B_
+        n, D = local_ids.numel(), table.shape[1]
+        rows = torch.empty(n, D, device=table.device, dtype=torch.float32)
+        nrm2 = torch.empty(n, device=table.device, dtype=torch.float32)
+        if n:
+            B_.call('cdr_gather_rows_norms', B_.stream(), B_.f32(table), D, B_.i64(local_ids), n, B_.f32(rows), B_.f32(nrm2))
+        return rows, nrm2
+
+    def norm_sums(self, utab, plan, nrm2, sums3):
+        """sums3 <- {0, sum ||U[u]||^2, sum nrm2[ip]} of this rank's routed triples."""
+        B_ = self.B_
+        B_.call('cdr_shard_norm_sums', B_.ctx(self.device), B_.stream(), B_.f32(utab), utab.shape[1], B_.i64(plan['u_loc']), B_.f32(nrm2),
+                B_.i64(plan['umap']), plan['Bl'], B_.f32(sums3))
+
+    def shard_step(self, utab, ustate, irows, plan, n_uniq, B_mean, gamma, reg_weight, opt, hp, step, out):
+        """The requester's half in one call; returns GS [n_uniq, D]: ONE finished gradient row per distinct item (EmbLoss term inside).
+        ``out[4:6]`` = the coefficients (in); ``out[6]`` = this rank's loss sum (out)."""
+        B_ = self.B_
+        buf, Bl, D = plan['buf'], plan['Bl'], utab.shape[1]
+        GS = torch.empty(n_uniq, D, device=utab.device, dtype=torch.float32)
+        m, v = ustate if ustate is not None else (None, None)
+        B_.call('cdr_bpr_shard_step', B_.ctx(self.device), B_.stream(), opt, B_.f32(utab), B_.f32(m), B_.f32(v), B_.f32(irows), D,
+                B_.i64(plan['u_loc']), B_.i64(plan['umap']), Bl, int(B_mean), float(gamma), float(reg_weight), float(hp['lr']), float(hp['b1']),
+                float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step), B_.f32(out), B_.f32(buf['GU']), B_.f32(buf['GP']), B_.f32(GS),
+                B_.raw(buf['keys']), B_.raw(buf['perm']), B_.raw(buf['flags']), B_.raw(buf['heads']), B_.raw(buf['uidx']))
+        return GS
+
+    def owner_apply(self, table, state, ids, runs, grads, opt, hp, step):
+        """``ids``: ``runs`` ascending duplicate-free runs of local rows (one per requesting rank); ``grads`` one summed gradient row per id."""
+        B_ = self.B_
+        n = ids.numel()
+        if n == 0:
+            return
+        dev = table.device
+        need = ctypes.c_size_t(0)
+        if runs > 1:
+            B_._check(B_.load().cdr_sort_workspace_bytes(n, table.shape[0], ctypes.byref(need)), 'cdr_sort_workspace_bytes')
+        ws = self._workspace(('sort', torch.cuda.current_stream().cuda_stream), max(need.value, 256), dev)
+        kp = self._workspace(('owner_kp', torch.cuda.current_stream().cuda_stream), 8 * n, dev)
+        keys, perm = kp[:4 * n], kp[4 * n:8 * n]
+        m, v = (state if state is not None else (None, None))
+        B_.call('cdr_shard_owner_apply', B_.ctx(self.device), B_.stream(), opt, B_.f32(table), B_.f32(m), B_.f32(v), table.shape[0], table.shape[1],
+                B_.i64(ids), n, int(runs), B_.f32(grads), float(hp['lr']), float(hp['b1']), float(hp['b2']), float(hp['eps']), float(hp['wd']),
+                int(step), B_.raw(keys), B_.raw(perm), B_.raw(ws), ws.numel())
+
+
 SELF_VIA_COLLECTIVE = bool(int(__import__('os').environ.get('CDR_A2A_SELF_VIA_RCCL', '0')))   # 1: the round-1..4 behaviour (A/B runs, RCCL bring-up on one GPU)
 
 
@@ -317,7 +407,7 @@ class ShardedBPRStep:
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
-                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True, comm=None):
+                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True, comm=None, direct=True):
         from .fused import RowwiseState
         self.group = group
         self.comm = comm                          # optional CabiComm: rows / ids / sums travel through the C ABI's communicator
@@ -342,6 +432,9 @@ class ShardedBPRStep:
         # (with dedup) the requester's half on the one-GPU step's kernels: user rows occurring once updated by the forward pass itself
         self.fuse_singles = bool(fuse_singles) and self.D % 4 == 0 and self.D <= 256
         self.n_items_total = int(n_items_total)
+        # round 6 (the default): one sort per rank and step, gradient rows of items that occur once written straight into their send slot,
+        # the owners' squared row norms beside the rows, one sorted run applied without a sort
+        self.direct = bool(direct) and self.dedup and self.fuse_singles and hasattr(self.ops, 'plan')
 
     def loss_value(self):
         return self.out[0]
@@ -402,9 +495,12 @@ class ShardedBPRStep:
 
         # ---- 0. triples travel to the owner of their user row ---------------------------------------------------
         with self._on_stream():
-            perm0, counts0 = ops.route(uid, None, G)
-            send3 = torch.stack((ops.permute(uid, None, perm0, G), ops.permute(pid, None, perm0, 1),
-                                 ops.permute(nid, None, perm0, 1)), dim=1).contiguous()
+            if self.direct:
+                send3, counts0 = ops.route_triples(uid, pid, nid, G)
+            else:
+                perm0, counts0 = ops.route(uid, None, G)
+                send3 = torch.stack((ops.permute(uid, None, perm0, G), ops.permute(pid, None, perm0, 1),
+                                     ops.permute(nid, None, perm0, 1)), dim=1).contiguous()
             gathered = _gather_counts(counts0, B, grp, G)
         yield
         with self._on_stream():
@@ -414,8 +510,13 @@ class ShardedBPRStep:
             B_global = sum(int(allc[r][G]) for r in range(G))
             recv3 = self._x(send3, t_send, t_recv, grp, (3,))
             Bl = recv3.shape[0]                                              # triples whose user row is mine
-            u_loc = recv3[:, 0].contiguous()
-            p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
+            if not self.direct:
+                u_loc = recv3[:, 0].contiguous()
+                p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
+
+        if self.direct:
+            yield from self._items_direct(uid.device, B_global, recv3)
+            return
 
         if self.dedup:                              # (outside the stream context: the generator yields in there)
             yield from self._items_dedup(uid.device, Bl, B_global, u_loc, p2, n2)
@@ -462,6 +563,49 @@ class ShardedBPRStep:
             ops.sort_apply(self.I, self._moments(self.istate), i_req, gi_recv, self.opt, self.hp, self.istate.step,
                            reg_coef=self.out[5:6], tagged=True)
 
+
+    def _items_direct(self, dev, B_global, recv3):
+        """Steps 1-3, round 6.  Per rank: ONE sort (user rows | item keys grouped by owner) gives the request list and both flag sets; the
+        owners send the rows with their squared norms (the EmbLoss norm needs no second pass over the received rows); the forward-and-update
+        pass writes the finished gradient row of every item that occurs once straight into its send slot and only duplicate items go through a
+        segmented sum; an owner that was asked by one rank applies the (already ascending, duplicate-free) list as it stands."""
+        G, grp, ops = self.world, self.group, self.ops
+        Bl = recv3.shape[0]
+        with self._on_stream():
+            if Bl:
+                plan = ops.plan(recv3, G, self.U.shape[0], shard_rows(self.n_items_total, G, 0), self.D)
+                counts1 = plan['counts']
+            else:
+                plan, counts1 = None, torch.zeros(G, device=dev, dtype=torch.int64)
+            gathered = _gather_counts(counts1, 0, grp, G)
+        yield
+        with self._on_stream():
+            allc = torch.stack(gathered).tolist()                           # host sync #2
+            i_send = [int(c) for c in allc[self.rank][:G]]
+            i_recv = [int(allc[r][self.rank]) for r in range(G)]
+            n_uniq = sum(i_send)
+            uniq = plan['uniq_local'][:n_uniq] if Bl else torch.empty(0, device=dev, dtype=torch.int64)
+            i_req = self._x(uniq, i_send, i_recv, grp)                          # my item rows other ranks want, each once per rank
+            rows, nrm2 = ops.gather_rows_norms(self.I, i_req)
+            irows = self._x(rows, i_recv, i_send, grp, (self.D,))
+            inrm = self._x(nrm2, i_recv, i_send, grp)
+            sums = self.out[6:9]                                                # {loss sum, sum u^2, sum p^2}: all-reduced in place
+            if Bl:
+                ops.norm_sums(self.U, plan, inrm, sums)
+            else:
+                sums.zero_()
+            self._sum(sums, grp)
+            ops.finish_sums(sums, B_global, self.reg_weight, self.out)          # out[4:6] = the coefficients every rank uses
+            if Bl:
+                gi = ops.shard_step(self.U, self._moments(self.ustate), irows, plan, n_uniq, B_global, self.gamma, self.reg_weight, self.opt,
+                                    self.hp, self.ustate.step, self.out)        # out[6] = this rank's loss sum
+            else:
+                gi = torch.empty(0, self.D, device=dev, dtype=torch.float32)
+                self.out[6:7].zero_()
+            self._sum(self.out[6:7], grp)
+            ops.finish_sums(sums, B_global, self.reg_weight, self.out)
+            gi_recv = self._x(gi, i_send, i_recv, grp, (self.D,))
+            ops.owner_apply(self.I, self._moments(self.istate), i_req, G, gi_recv, self.opt, self.hp, self.istate.step)
 
     def _items_dedup(self, dev, Bl, B_global, u_loc, p2, n2):
         """Steps 1-3 with id de-duplication: every distinct item row crosses xGMI once per step in each direction (the rows

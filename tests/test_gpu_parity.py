@@ -655,7 +655,8 @@ def test_fused_step_deterministic_and_sorted():
     assert torch.equal(torch.sort(heads[4 + B // 2 + 1:4 + B // 2 + 1 + nB]).values, torch.nonzero(hd[B:]).flatten())
 
 
-@pytest.mark.parametrize('variant', ['via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup', 'cabi-fused', 'cabi-no_dedup'])
+@pytest.mark.parametrize('variant', ['via_rccl-direct', 'bypass-direct', 'via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup', 'cabi-direct',
+                                     'cabi-fused', 'cabi-no_dedup'])
 def test_sharded_step_world1_equals_fused(variant, monkeypatch):
     """shard.ShardedBPRStep with libcdrhip ops over a 1-rank RCCL group == fused.FusedBPRStep (same kernels, plus the
     route / all-to-all / build-grad-rows path).  World 2 is covered on CPU by tests/test_shard_gloo.py.  Variants: the one-rank
@@ -670,7 +671,8 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
     from recbole_cdr_amd.shard import ShardedBPRStep
     comm, form = variant.split('-')
     monkeypatch.setattr(shard_mod, 'SELF_VIA_COLLECTIVE', comm == 'via_rccl')
-    kw = {'fused': {}, 'two_pass': {'fuse_singles': False}, 'no_dedup': {'dedup': False}}[form]
+    # direct: round 6 (one sort per rank, single item occurrences written into their send slot by the forward pass); fused: round 5's staged form
+    kw = {'direct': {}, 'fused': {'direct': False}, 'two_pass': {'fuse_singles': False}, 'no_dedup': {'dedup': False}}[form]
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
                             device_id=torch.device(DEV))
@@ -686,6 +688,7 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
             assert cabi.info() == (0, 1)
             kw = dict(kw, comm=cabi)
         fb = ShardedBPRStep(Ub, Ib, nu, ni, B, opt='adam', reg_weight=0.02, lr=0.01, **kw)
+        assert fb.direct == (form == 'direct')
         for step in range(3):
             u = torch.randint(0, nu, (B,), device=DEV); p = torch.randint(0, ni, (B,), device=DEV)
             n = torch.randint(0, ni, (B,), device=DEV)
@@ -696,8 +699,9 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
         assert_close(fb.ustate.exp_avg, fa.ustate.exp_avg, rtol=2e-5); assert_close(fb.istate.exp_avg, fa.istate.exp_avg, rtol=2e-5)
         if cabi is not None:
             # per step: the triples + the item ids (int64), the item rows + the gradient rows (fp32), the sums
-            want_sums = 6 if form == 'fused' else 3
-            assert cabi.calls == {'cdr_a2a_ids': 6, 'cdr_a2a_rows': 6, 'cdr_allreduce_sum_f32': want_sums}, cabi.calls
+            want_sums = 6 if form in ('fused', 'direct') else 3
+            want_rows = 9 if form == 'direct' else 6                     # direct: the owners' squared row norms travel beside the rows
+            assert cabi.calls == {'cdr_a2a_ids': 6, 'cdr_a2a_rows': want_rows, 'cdr_allreduce_sum_f32': want_sums}, cabi.calls
             cabi.close()
     finally:
         dist.destroy_process_group()

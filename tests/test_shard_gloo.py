@@ -103,12 +103,42 @@ class OracleOps:
             st.m, st.v = state
             _apply_rows(table, st, rows, Gs, 'adam', hp['lr'], step, hp['b1'], hp['b2'], hp['eps'])
 
+    # ---- round 6: the coarse ops of the direct form (shard.NativeOps.route_triples / plan / gather_rows_norms / norm_sums / shard_step / owner_apply)
+    def route_triples(self, uid, pid, nid, world):
+        owner = uid % world
+        perm = torch.argsort(owner, stable=True)
+        return torch.stack((uid[perm] // world, pid[perm], nid[perm]), 1).contiguous(), torch.bincount(owner, minlength=world)
+
+    def plan(self, recv3, world, user_rows, item_local_rows, D):
+        d = self.dedup(recv3[:, 1].contiguous(), recv3[:, 2].contiguous(), world, item_local_rows)
+        return {'Bl': recv3.shape[0], 'u_loc': recv3[:, 0].contiguous(), 'uniq_local': d['uniq_local'], 'umap': d['umap'], 'counts': d['counts'], 'n': d['n']}
+
+    def gather_rows_norms(self, table, local_ids):
+        rows = table[local_ids].clone()
+        return rows, (rows * rows).sum(1)
+
+    def norm_sums(self, utab, plan, nrm2, sums3):
+        u = utab[plan['u_loc']]
+        sums3[0], sums3[1], sums3[2] = 0.0, (u * u).sum(), nrm2[plan['umap'][:plan['Bl']]].sum()
+
+    def shard_step(self, utab, ustate, irows, plan, n_uniq, B_mean, gamma, reg_weight, opt, hp, step, out):
+        Bl = plan['Bl']
+        keep = out[4:9].clone()
+        GP = self.local_step(utab, ustate, irows, plan['u_loc'], plan['umap'][:Bl], plan['umap'][Bl:], B_mean, gamma, reg_weight, opt, hp, step, out)
+        loss = out[6].clone()
+        out[4:9] = keep                                          # the all-reduced norm sums (and the coefficients) stay; only out[6] is this call's
+        out[6] = loss
+        return self.segsum(plan, GP, Bl, irows, out[5:6], n_uniq)
+
+    def owner_apply(self, table, state, ids, runs, grads, opt, hp, step):
+        self.sort_apply(table, state, ids, grads, opt, hp, step)
+
 
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, opt, dedup, q):
+def _worker(rank, world, port, opt, dedup, q, direct=True):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -120,7 +150,8 @@ def _worker(rank, world, port, opt, dedup, q):
         U = torch.randn(nu, D) * 0.3
         I = torch.randn(ni, D) * 0.3
         Ul, Il = shard_of(U, world, rank), shard_of(I, world, rank)
-        st = ShardedBPRStep(Ul, Il, nu, ni, B, opt=opt, lr=lr, reg_weight=reg, ops=OracleOps(), dedup=dedup)
+        st = ShardedBPRStep(Ul, Il, nu, ni, B, opt=opt, lr=lr, reg_weight=reg, ops=OracleOps(), dedup=dedup, direct=direct)
+        assert st.direct == (direct and dedup)
         losses = []
         batches = []
         for step in range(3):
@@ -136,15 +167,17 @@ def _worker(rank, world, port, opt, dedup, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('dedup', [False, True])
+@pytest.mark.parametrize('dedup', [False, True, 'staged'])
 @pytest.mark.parametrize('opt', ['sgd', 'adam'])
 def test_sharded_step_matches_single_process(opt, dedup):
+    direct = dedup is True                      # True: the round-6 direct form; 'staged': round 5's (dedup, per-item sums of every row); False: no dedup
+    dedup = bool(dedup)
     from oracle import train_step as ts
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, dedup, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, dedup, q, direct)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
