@@ -213,6 +213,8 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true', default=bool(int(os.environ.get('CDR_NO_PIPELINE', '0'))),
                     help='sharded path: run the two domain steps back to back on one stream')
     ap.add_argument('--force-shard', action='store_true', help='run the sharded exchange path even with 1 rank')
+    ap.add_argument('--no-prefetch', action='store_true', help="row shard: do not run the next batch's id-only stages on a side stream behind this step's kernels (A/B)")
+    ap.add_argument('--no-direct', action='store_true', help="row shard: round 5's staged form (A/B)")
     ap.add_argument('--routed-batch-loss', action='store_true', help='c4 row shard: the routed batch loss even with one rank (--force-shard A/B)')
     ap.add_argument('--replicated-batch-loss', action='store_true', help='c4 row shard: every rank scores the whole batch on the all-gathered stacked tables '
                                                                          '(round-3 form) instead of its B/N slice on routed rows')
@@ -382,6 +384,10 @@ def run_c5(args, world, rank, dev):
                                     dict(opt=args.opt, reg_weight=0.01), domain_groups=name == 'dim-groups', pipeline=not args.no_pipeline,
                                     dedup=not args.no_dedup, device=dev, groups=all_groups[name], row_comm=row_comm)
             cand.batches = make_batches(cand.mode == 'dim-groups', cand.my_dom)
+            cand.prefetch = not args.no_prefetch
+            if args.no_direct and cand.mode == 'row':
+                for st in cand.steps.values():
+                    st.direct = False
             return cand
 
         def first_steps(cand):

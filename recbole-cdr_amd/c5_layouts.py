@@ -20,6 +20,7 @@ class C5Layout:
         self.steps, self.tabs = {}, {}
         self.mode, self.my_dom, self.half, self.Ds = None, None, None, None
         self.pipeline = False
+        self.prefetch = True
 
     # ---- one benchmark step = one batch of every domain this rank works on -------------------------------------------------
     def rank_domains(self):
@@ -34,9 +35,16 @@ class C5Layout:
                 st.step(*b[self.my_dom], next_batch=batches[(i + 1) % len(batches)][self.my_dom])
             else:
                 st.step(*b[self.my_dom])
-        elif self.mode == 'row' and self.pipeline:
-            from .shard import run_pipelined
-            run_pipelined([self.steps[d].step_gen(*b[d]) for d in ('source', 'target')])
+        elif self.mode == 'row':
+            # the following batch's id-only stages run on a side stream behind this step's kernels (ShardedBPRStep.step_gen, direct form)
+            nb = batches[(i + 1) % len(batches)] if self.prefetch else None
+            kw = lambda d: {'next_batch': nb[d]} if (nb is not None and self.steps[d].direct) else {}  # noqa: E731
+            if self.pipeline:
+                from .shard import run_pipelined
+                run_pipelined([self.steps[d].step_gen(*b[d], **kw(d)) for d in ('source', 'target')])
+            else:
+                for d in ('source', 'target'):
+                    self.steps[d].step(*b[d], **kw(d))
         else:
             for d in ('source', 'target'):
                 self.steps[d].step(*b[d])
@@ -62,7 +70,10 @@ def make_groups(world, mode):
     if mode == 'dim-groups':
         half = world // 2
         return {'source': dist.new_group(list(range(half))), 'target': dist.new_group(list(range(half, world)))}
-    return {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+    g = {d: dist.new_group(list(range(world))) for d in ('source', 'target')}
+    if mode == 'row':        # the id-only stages of the row layout run on a side stream: their own communicators (shard.ShardedBPRStep.index_group)
+        g.update({d + '_ix': dist.new_group(list(range(world))) for d in ('source', 'target')})
+    return g
 
 
 def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, domain_groups=True, pipeline=True, dedup=True, device=None,
@@ -104,5 +115,5 @@ def build(world, rank, layout, D, B, n_users, n_items, make_table, step_kw, doma
         for d in ('source', 'target'):
             lay.steps[d] = ShardedBPRStep(lay.tabs[d[0] + 'u'], lay.tabs[d[0] + 'i'], n_users, n_items, B, group=lay.groups[d],
                                           ops=row_ops() if row_ops is not None else None, stream=mk_stream(), dedup=dedup,
-                                          comm=row_comm(lay.groups[d]) if row_comm is not None else None, **step_kw)
+                                          comm=row_comm(lay.groups[d]) if row_comm is not None else None, index_group=lay.groups.get(d + '_ix'), **step_kw)
     return lay

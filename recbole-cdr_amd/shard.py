@@ -231,12 +231,13 @@ class NativeOps:
                 B_.i64(counts), B_.raw(ws), ws.numel())
         return send3, counts
 
-    def plan(self, recv3, world, user_rows, item_local_rows, D):
+    def plan(self, recv3, world, user_rows, item_local_rows, D, slot=0):
         """One sort for both lists of the routed triples -> the flags / duplicate heads of the forward-and-update pass and the request list
-        (``uniq_local`` grouped by owner, ``umap`` occurrence -> slot, ``counts`` per owner).  Buffers persist per (stream, table)."""
+        (``uniq_local`` grouped by owner, ``umap`` occurrence -> slot, ``counts`` per owner).  Buffers persist per (stream, table, ``slot``): a
+        prefetching caller alternates two slots, the next step's plan is built while this step's kernels still read theirs."""
         B_ = self.B_
         Bl, dev = recv3.shape[0], recv3.device
-        key = ('plan', torch.cuda.current_stream().cuda_stream, int(user_rows), int(item_local_rows))
+        key = ('plan', torch.cuda.current_stream().cuda_stream, int(user_rows), int(item_local_rows), int(slot))
         buf = self._ws.get(key)
         if buf is None or buf['cap'] < Bl:
             cap = max(int(Bl * 1.25), 1024)
@@ -248,8 +249,7 @@ class NativeOps:
                 'cap': cap, 'u_loc': e(cap, torch.int64), 'keys': e(3 * cap, torch.int32), 'perm': e(3 * cap, torch.int32),
                 'flags': torch.zeros(4 * cap, device=dev, dtype=torch.uint8), 'heads': e(int(words.value), torch.int32),
                 'uidx': e(2 * cap, torch.int32), 'uniq_local': e(2 * cap, torch.int64), 'umap': e(2 * cap, torch.int64),
-                'counts': e(world + 1, torch.int64), 'n_uniq': e(1, torch.int64), 'ws': e(int(need.value), torch.uint8),
-                'GU': torch.empty(cap, D, device=dev, dtype=torch.float32), 'GP': torch.empty(cap, D, device=dev, dtype=torch.float32)}
+                'counts': e(world + 1, torch.int64), 'n_uniq': e(1, torch.int64), 'ws': e(int(need.value), torch.uint8)}
         B_.call('cdr_bpr_shard_plan', B_.ctx(self.device), B_.stream(), B_.i64(recv3), Bl, int(user_rows), int(item_local_rows), int(world),
                 B_.i64(buf['u_loc']), B_.raw(buf['keys']), B_.raw(buf['perm']), B_.raw(buf['flags']), B_.raw(buf['heads']), B_.raw(buf['uidx']),
                 B_.i64(buf['uniq_local']), B_.i64(buf['umap']), B_.i64(buf['counts']), B_.i64(buf['n_uniq']), B_.raw(buf['ws']), buf['ws'].numel())
@@ -278,10 +278,15 @@ class NativeOps:
         B_ = self.B_
         buf, Bl, D = plan['buf'], plan['Bl'], utab.shape[1]
         GS = torch.empty(n_uniq, D, device=utab.device, dtype=torch.float32)
+        gkey = ('gugp', torch.cuda.current_stream().cuda_stream, utab.data_ptr())
+        gg = self._ws.get(gkey)
+        if gg is None or gg[0].shape[0] < Bl:
+            cap = max(int(Bl * 1.25), 1024)
+            gg = self._ws[gkey] = (torch.empty(cap, D, device=utab.device, dtype=torch.float32), torch.empty(cap, D, device=utab.device, dtype=torch.float32))
         m, v = ustate if ustate is not None else (None, None)
         B_.call('cdr_bpr_shard_step', B_.ctx(self.device), B_.stream(), opt, B_.f32(utab), B_.f32(m), B_.f32(v), B_.f32(irows), D,
                 B_.i64(plan['u_loc']), B_.i64(plan['umap']), Bl, int(B_mean), float(gamma), float(reg_weight), float(hp['lr']), float(hp['b1']),
-                float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step), B_.f32(out), B_.f32(buf['GU']), B_.f32(buf['GP']), B_.f32(GS),
+                float(hp['b2']), float(hp['eps']), float(hp['wd']), int(step), B_.f32(out), B_.f32(gg[0]), B_.f32(gg[1]), B_.f32(GS),
                 B_.raw(buf['keys']), B_.raw(buf['perm']), B_.raw(buf['flags']), B_.raw(buf['heads']), B_.raw(buf['uidx']))
         return GS
 
@@ -396,6 +401,8 @@ class CabiComm:
 def _gather_counts(counts, extra, group, world):
     """All ranks' bucket counts (+ one extra int per rank) -> list of tensors (no host sync yet)."""
     payload = torch.cat([counts, torch.tensor([extra], device=counts.device, dtype=torch.int64)])
+    if world == 1 and not SELF_VIA_COLLECTIVE:
+        return [payload]
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
     return gathered
@@ -407,9 +414,12 @@ class ShardedBPRStep:
 
     def __init__(self, user_shard, item_shard, n_users_total, n_items_total, max_batch, opt='adam', lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, gamma=1e-10, reg_weight=0.0, group=None, ops=None,
-                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True, comm=None, direct=True):
+                 stream=None, user_state=None, item_state=None, dedup=True, fuse_singles=True, comm=None, direct=True, index_group=None):
         from .fused import RowwiseState
         self.group = group
+        # the id-only stages' own process group (= communicator): prefetched on a side stream they must not queue behind the main stage's
+        # row exchanges on one RCCL stream (None: the step's group; fine on one rank and under gloo)
+        self.index_group = index_group if index_group is not None else group
         self.comm = comm                          # optional CabiComm: rows / ids / sums travel through the C ABI's communicator
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -481,26 +491,38 @@ class ShardedBPRStep:
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
-    def step(self, uid, pid, nid):
-        for _ in self.step_gen(uid, pid, nid):
+    def step(self, uid, pid, nid, next_batch=None):
+        for _ in self.step_gen(uid, pid, nid, next_batch=next_batch):
             pass
         return self.out
 
-    def step_gen(self, uid, pid, nid):
-        """Generator form of one step: yields at the two points where the host must wait for bucket counts."""
+    def step_gen(self, uid, pid, nid, next_batch=None):
+        """Generator form of one step: yields at the two points where the host must wait for bucket counts.
+        ``next_batch`` (direct form): the following step's (uid, pid, nid), if known -- its id-only stages (routing, the triples' and the
+        request lists' all-to-alls, the sort, both host waits) are run on a side stream right behind this step's kernels, which then contain
+        no host wait at all; the tensors must stay unmodified until that step is called with them."""
         G, grp, ops = self.world, self.group, self.ops
         B = uid.numel()
         self.ustate.advance()                      # per table, on every rank (also one whose buckets came up empty)
         self.istate.advance()
+        if self.direct:
+            if uid.is_cuda and next_batch is not None:
+                with self._on_stream():
+                    self._step_start = torch.cuda.Event()
+                    self._step_start.record(torch.cuda.current_stream(uid.device))
+            ix = self._take_prefetched(uid, pid, nid)
+            if ix is None:
+                ix = yield from self._index_gen(uid, pid, nid, side=False)
+            self._main(ix)
+            if next_batch is not None:
+                self._prefetched = yield from self._index_gen(*next_batch, side=True)
+            return
 
         # ---- 0. triples travel to the owner of their user row ---------------------------------------------------
         with self._on_stream():
-            if self.direct:
-                send3, counts0 = ops.route_triples(uid, pid, nid, G)
-            else:
-                perm0, counts0 = ops.route(uid, None, G)
-                send3 = torch.stack((ops.permute(uid, None, perm0, G), ops.permute(pid, None, perm0, 1),
-                                     ops.permute(nid, None, perm0, 1)), dim=1).contiguous()
+            perm0, counts0 = ops.route(uid, None, G)
+            send3 = torch.stack((ops.permute(uid, None, perm0, G), ops.permute(pid, None, perm0, 1),
+                                 ops.permute(nid, None, perm0, 1)), dim=1).contiguous()
             gathered = _gather_counts(counts0, B, grp, G)
         yield
         with self._on_stream():
@@ -510,13 +532,8 @@ class ShardedBPRStep:
             B_global = sum(int(allc[r][G]) for r in range(G))
             recv3 = self._x(send3, t_send, t_recv, grp, (3,))
             Bl = recv3.shape[0]                                              # triples whose user row is mine
-            if not self.direct:
-                u_loc = recv3[:, 0].contiguous()
-                p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
-
-        if self.direct:
-            yield from self._items_direct(uid.device, B_global, recv3)
-            return
+            u_loc = recv3[:, 0].contiguous()
+            p2, n2 = recv3[:, 1].contiguous(), recv3[:, 2].contiguous()
 
         if self.dedup:                              # (outside the stream context: the generator yields in there)
             yield from self._items_dedup(uid.device, Bl, B_global, u_loc, p2, n2)
@@ -564,28 +581,84 @@ class ShardedBPRStep:
                            reg_coef=self.out[5:6], tagged=True)
 
 
-    def _items_direct(self, dev, B_global, recv3):
-        """Steps 1-3, round 6.  Per rank: ONE sort (user rows | item keys grouped by owner) gives the request list and both flag sets; the
-        owners send the rows with their squared norms (the EmbLoss norm needs no second pass over the received rows); the forward-and-update
-        pass writes the finished gradient row of every item that occurs once straight into its send slot and only duplicate items go through a
-        segmented sum; an owner that was asked by one rank applies the (already ascending, duplicate-free) list as it stands."""
-        G, grp, ops = self.world, self.group, self.ops
-        Bl = recv3.shape[0]
-        with self._on_stream():
+    # ---- the direct form (round 6): an id-only index stage (prefetchable) + a main stage without host waits -------------------------
+    def _take_prefetched(self, uid, pid, nid):
+        ix = self.__dict__.pop('_prefetched', None)
+        if ix is not None and ix['key'] == (uid.data_ptr(), pid.data_ptr(), nid.data_ptr(), uid.numel()):
+            return ix
+        return None
+
+    def _side_stream(self, dev):
+        if self.__dict__.get('_istream') is None:
+            self._istream = torch.cuda.Stream(device=dev)
+            self._slot_free = [None, None]         # events: the main stage that last read plan slot k has been enqueued up to here
+        return self._istream
+
+    def _index_gen(self, uid, pid, nid, side):
+        """Everything of a step that needs only its ids: triples to the owners of their user rows, ONE sort per rank (user rows | item keys
+        grouped by owner) -> flags, duplicate heads, the request list; the request lists to the item owners.  Yields at the two host waits
+        (bucket counts).  ``side``: on the step's side stream, into the plan slot the running main stage does not read."""
+        G, grp, ops = self.world, self.index_group, self.ops
+        dev, B = uid.device, uid.numel()
+        cuda = uid.is_cuda
+        self._slot = slot = 1 - self.__dict__.get('_slot', 1)
+        # (a C-ABI communicator is one RCCL communicator: its calls must not run on two streams at once -> no side stream with it)
+        side = side and cuda and self.comm is None
+        if side:
+            main = self.stream if self.stream is not None else torch.cuda.current_stream(dev)
+            ist = self._side_stream(dev)
+            # behind whatever the caller enqueued before this step (the producer of the next batch), and behind the main stage that last
+            # read this plan slot -- NOT behind the main stage that has just been enqueued: that is the overlap
+            ist.wait_event(self._step_start)
+            ist.wait_stream(main) if self._slot_free[slot] is None else ist.wait_event(self._slot_free[slot])
+            on = lambda: torch.cuda.stream(ist)  # noqa: E731
+        else:
+            on = self._on_stream
+        with on():
+            send3, counts0 = ops.route_triples(uid, pid, nid, G)
+            gathered = _gather_counts(counts0, B, grp, G)
+        yield
+        with on():
+            allc = torch.stack(gathered).tolist()                           # host wait #1
+            t_send = [int(c) for c in allc[self.rank][:G]]
+            t_recv = [int(allc[r][self.rank]) for r in range(G)]
+            B_global = sum(int(allc[r][G]) for r in range(G))
+            recv3 = self._x(send3, t_send, t_recv, grp, (3,))
+            Bl = recv3.shape[0]                                              # triples whose user row is mine
             if Bl:
-                plan = ops.plan(recv3, G, self.U.shape[0], shard_rows(self.n_items_total, G, 0), self.D)
+                plan = ops.plan(recv3, G, self.U.shape[0], shard_rows(self.n_items_total, G, 0), self.D, slot=slot)
                 counts1 = plan['counts']
             else:
                 plan, counts1 = None, torch.zeros(G, device=dev, dtype=torch.int64)
             gathered = _gather_counts(counts1, 0, grp, G)
         yield
-        with self._on_stream():
-            allc = torch.stack(gathered).tolist()                           # host sync #2
+        with on():
+            allc = torch.stack(gathered).tolist()                           # host wait #2
             i_send = [int(c) for c in allc[self.rank][:G]]
             i_recv = [int(allc[r][self.rank]) for r in range(G)]
             n_uniq = sum(i_send)
             uniq = plan['uniq_local'][:n_uniq] if Bl else torch.empty(0, device=dev, dtype=torch.int64)
             i_req = self._x(uniq, i_send, i_recv, grp)                          # my item rows other ranks want, each once per rank
+            done = None
+            if side:
+                done = torch.cuda.Event()
+                done.record(ist)
+                for t in (recv3, i_req):                                        # allocated on the side stream, read by the main stage
+                    t.record_stream(main)
+        return {'key': (uid.data_ptr(), pid.data_ptr(), nid.data_ptr(), B), 'hold': (uid, pid, nid, recv3), 'Bl': Bl, 'B_global': B_global,
+                'plan': plan, 'i_send': i_send, 'i_recv': i_recv, 'n_uniq': n_uniq, 'i_req': i_req, 'done': done, 'slot': slot}
+
+    def _main(self, ix):
+        """Rows out, rows back, forward-and-update, gradient rows home, owner apply -- no host wait.  The owners send the rows with their
+        squared norms (the EmbLoss norm needs no second pass over the received rows); the forward-and-update pass writes the finished gradient
+        row of every item that occurs once straight into its send slot and only duplicate items go through a segmented sum; an owner that was
+        asked by one rank applies the (already ascending, duplicate-free) list as it stands."""
+        G, grp, ops = self.world, self.group, self.ops
+        Bl, B_global, plan, i_send, i_recv, n_uniq, i_req = (ix[k] for k in ('Bl', 'B_global', 'plan', 'i_send', 'i_recv', 'n_uniq', 'i_req'))
+        dev = i_req.device
+        with self._on_stream():
+            if ix['done'] is not None:
+                torch.cuda.current_stream(dev).wait_event(ix['done'])
             rows, nrm2 = ops.gather_rows_norms(self.I, i_req)
             irows = self._x(rows, i_recv, i_send, grp, (self.D,))
             inrm = self._x(nrm2, i_recv, i_send, grp)
@@ -606,6 +679,10 @@ class ShardedBPRStep:
             ops.finish_sums(sums, B_global, self.reg_weight, self.out)
             gi_recv = self._x(gi, i_send, i_recv, grp, (self.D,))
             ops.owner_apply(self.I, self._moments(self.istate), i_req, G, gi_recv, self.opt, self.hp, self.istate.step)
+            if self.__dict__.get('_istream') is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self._slot_free[ix['slot']] = ev
 
     def _items_dedup(self, dev, Bl, B_global, u_loc, p2, n2):
         """Steps 1-3 with id de-duplication: every distinct item row crosses xGMI once per step in each direction (the rows

@@ -655,7 +655,7 @@ def test_fused_step_deterministic_and_sorted():
     assert torch.equal(torch.sort(heads[4 + B // 2 + 1:4 + B // 2 + 1 + nB]).values, torch.nonzero(hd[B:]).flatten())
 
 
-@pytest.mark.parametrize('variant', ['via_rccl-direct', 'bypass-direct', 'via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup', 'cabi-direct',
+@pytest.mark.parametrize('variant', ['via_rccl-direct', 'bypass-direct', 'bypass-prefetch', 'via_rccl-prefetch', 'via_rccl-fused', 'bypass-fused', 'via_rccl-two_pass', 'via_rccl-no_dedup', 'cabi-direct',
                                      'cabi-fused', 'cabi-no_dedup'])
 def test_sharded_step_world1_equals_fused(variant, monkeypatch):
     """shard.ShardedBPRStep with libcdrhip ops over a 1-rank RCCL group == fused.FusedBPRStep (same kernels, plus the
@@ -672,6 +672,8 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
     comm, form = variant.split('-')
     monkeypatch.setattr(shard_mod, 'SELF_VIA_COLLECTIVE', comm == 'via_rccl')
     # direct: round 6 (one sort per rank, single item occurrences written into their send slot by the forward pass); fused: round 5's staged form
+    prefetch = form == 'prefetch'                # the next batch's id-only stages on a side stream behind this step's kernels
+    form = 'direct' if prefetch else form
     kw = {'direct': {}, 'fused': {'direct': False}, 'two_pass': {'fuse_singles': False}, 'no_dedup': {'dedup': False}}[form]
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
@@ -689,19 +691,26 @@ def test_sharded_step_world1_equals_fused(variant, monkeypatch):
             kw = dict(kw, comm=cabi)
         fb = ShardedBPRStep(Ub, Ib, nu, ni, B, opt='adam', reg_weight=0.02, lr=0.01, **kw)
         assert fb.direct == (form == 'direct')
-        for step in range(3):
-            u = torch.randint(0, nu, (B,), device=DEV); p = torch.randint(0, ni, (B,), device=DEV)
-            n = torch.randint(0, ni, (B,), device=DEV)
+        batches = [(torch.randint(0, nu, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV), torch.randint(0, ni, (B,), device=DEV))
+                   for _ in range(4)]
+        for step in range(4):
+            u, p, n = batches[step]
             la = fa.step(u, p, n)[0].clone()
-            lb = fb.step(u, p, n)[0].clone()
+            if prefetch:
+                # (step 2 hands over a batch that is NOT the one used next: the prefetched plan must be dropped, not used)
+                nb = batches[step + 1] if step < 2 else (batches[0] if step == 2 else None)
+                lb = fb.step(u, p, n, next_batch=nb)[0].clone()
+                assert ('_prefetched' in fb.__dict__) == (nb is not None)
+            else:
+                lb = fb.step(u, p, n)[0].clone()
             assert_close(lb, la, rtol=1e-6, what=f'loss step {step}')
         assert_close(Ub, Ua, rtol=2e-5, atol=0.01 * 1e-2); assert_close(Ib, Ia, rtol=2e-5, atol=0.01 * 1e-2)
         assert_close(fb.ustate.exp_avg, fa.ustate.exp_avg, rtol=2e-5); assert_close(fb.istate.exp_avg, fa.istate.exp_avg, rtol=2e-5)
         if cabi is not None:
             # per step: the triples + the item ids (int64), the item rows + the gradient rows (fp32), the sums
-            want_sums = 6 if form in ('fused', 'direct') else 3
-            want_rows = 9 if form == 'direct' else 6                     # direct: the owners' squared row norms travel beside the rows
-            assert cabi.calls == {'cdr_a2a_ids': 6, 'cdr_a2a_rows': want_rows, 'cdr_allreduce_sum_f32': want_sums}, cabi.calls
+            want_sums = 8 if form in ('fused', 'direct') else 4
+            want_rows = 12 if form == 'direct' else 8                    # direct: the owners' squared row norms travel beside the rows
+            assert cabi.calls == {'cdr_a2a_ids': 8, 'cdr_a2a_rows': want_rows, 'cdr_allreduce_sum_f32': want_sums}, cabi.calls
             cabi.close()
     finally:
         dist.destroy_process_group()
@@ -2190,12 +2199,16 @@ def _shared_gpu_worker(rank, world, port, pipelined, dedup, q):
                     p[: B // 3] = p[0]; n[100:700] = p[0]                # one hot item, also as a negative: long item segments
                 per_dom.append((u, p, n))
             batches.append(per_dom)
+        dev_b = [[tuple(t.to(DEV) for t in dom) for dom in per_dom] for per_dom in batches]
+        for it in range(3):
+            # (dedup = the direct form: the following batch's id-only stages are prefetched on a side stream behind this step's kernels)
+            nxt = (lambda d: {'next_batch': dev_b[it + 1][d]} if (dedup and it + 1 < 3) else {})  # noqa: E731
             if pipelined:
                 torch.cuda.synchronize()
-                run_pipelined([steps[d].step_gen(*(t.to(DEV) for t in per_dom[d])) for d in range(len(tabs))])
+                run_pipelined([steps[d].step_gen(*dev_b[it][d], **nxt(d)) for d in range(len(tabs))])
                 torch.cuda.synchronize()
             else:
-                steps[0].step(*(t.to(DEV) for t in per_dom[0]))
+                steps[0].step(*dev_b[it][0], **nxt(0))
             losses.append([float(s.out[0]) for s in steps])
         q.put((rank, [(a.cpu().numpy(), b.cpu().numpy()) for a, b in shards], losses,
                [[tuple(t.numpy() for t in dom) for dom in it] for it in batches]))

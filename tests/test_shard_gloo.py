@@ -109,7 +109,7 @@ class OracleOps:
         perm = torch.argsort(owner, stable=True)
         return torch.stack((uid[perm] // world, pid[perm], nid[perm]), 1).contiguous(), torch.bincount(owner, minlength=world)
 
-    def plan(self, recv3, world, user_rows, item_local_rows, D):
+    def plan(self, recv3, world, user_rows, item_local_rows, D, slot=0):
         d = self.dedup(recv3[:, 1].contiguous(), recv3[:, 2].contiguous(), world, item_local_rows)
         return {'Bl': recv3.shape[0], 'u_loc': recv3[:, 0].contiguous(), 'uniq_local': d['uniq_local'], 'umap': d['umap'], 'counts': d['counts'], 'n': d['n']}
 
