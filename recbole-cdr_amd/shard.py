@@ -590,7 +590,7 @@ class ShardedBPRStep:
 
     def _side_stream(self, dev):
         if self.__dict__.get('_istream') is None:
-            self._istream = torch.cuda.Stream(device=dev)
+            self._istream = torch.cuda.Stream(device=dev, priority=int(__import__('os').environ.get('CDR_SIDE_PRIO', '0')))
             self._slot_free = [None, None]         # events: the main stage that last read plan slot k has been enqueued up to here
         return self._istream
 
