@@ -218,9 +218,10 @@ def parse():
     ap.add_argument('--routed-batch-loss', action='store_true', help='c4 row shard: the routed batch loss even with one rank (--force-shard A/B)')
     ap.add_argument('--replicated-batch-loss', action='store_true', help='c4 row shard: every rank scores the whole batch on the all-gathered stacked tables '
                                                                          '(round-3 form) instead of its B/N slice on routed rows')
-    ap.add_argument('--shard', default='dim', choices=['dim', 'row'],
-                    help='N>1 layout of the C5 tables: dim = every rank holds D/N columns of every row (ids all-gathered, one partial '
-                         'score per triple all-reduced); row = rows r %% N with the row / gradient-row all-to-all exchange')
+    ap.add_argument('--shard', default='row', choices=['dim', 'row'],
+                    help='N>1 layout of the C5 tables whose numbers the line carries (the other one is timed into `layouts`): row = rows r %% N with the '
+                         'row / gradient-row all-to-all exchange (BASELINE configs[4] / north_star; the default since round 6); dim = every rank '
+                         'holds D/N columns of every row (ids all-gathered, one partial score per triple all-reduced)')
     ap.add_argument('--no-domain-groups', action='store_true',
                     help='--shard dim: shard BOTH domains over all N ranks (D/N columns each) instead of giving each domain one half of '
                          'the ranks (D/(N/2) columns, twice the batch per rank)')
@@ -360,9 +361,13 @@ def run_c5(args, world, rank, dev):
         if args.comm == 'cabi':
             args.shard = 'row'                             # the C ABI's exchanges are the row shard's
             first = 'row'
-        order = ['dim-groups', 'dim', 'row']
-        chain = [first] + [m for m in order[order.index(first) + 1:]
-                           if m == 'row' or c5_layouts.resolve(world, 'dim', D, m == 'dim-groups')[0] == m]
+        # fallback order behind the first candidate: the row shard first (north_star's layout) then the dimension layouts, or -- with
+        # --shard dim -- the dimension layouts then the row shard; a candidate that does not resolve for this world / D is left out
+        dims = [m for m in ('dim-groups', 'dim') if c5_layouts.resolve(world, 'dim', D, m == 'dim-groups')[0] == m]
+        if first == 'row':
+            chain = ['row'] + ([] if args.shard == 'dim' else dims)       # (--shard dim that resolved to row: D does not cut -- nothing behind it)
+        else:
+            chain = dims[dims.index(first):] + ['row']
         if args.comm == 'cabi':
             chain = ['row-cabi', 'row']
         if args.single_layout or args.no_layout_fallback:
@@ -2015,7 +2020,7 @@ def main():
     if args.workload == 'c5' and (world > 1 or args.force_shard) and not args.single_layout:
         # N > 1: BOTH layouts of the C5 tables in one record -- north_star's row shard (rows r % N, row / gradient-row all-to-all)
         # and the dimension shard (D/N columns of every row, ids all-gathered, one partial score per triple all-reduced) -- so
-        # that one hardware run shows them side by side.  The headline fields are those of --shard (default dim).
+        # that one hardware run shows them side by side.  The headline fields are those of --shard (default row: north_star's).
         import copy
         import gc
         try:
@@ -2035,9 +2040,9 @@ def main():
             pick = lambda r: None if r is None else {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'n_gpus', 'exchange', 'kernels',
                                                                           'roofline', 'layout_fallback')} | {'sharding': r['config']['sharding']}
             result['layouts'] = {first: pick(result), second: pick(other)}
-            # BASELINE.json's north_star names the ROW shard (item / user tables row-sharded, all-to-all of rows); the headline fields are the
-            # layout that came up first in the preflight order (dim: 16 B per triple over xGMI instead of ~2 KB) -- both are timed in this
-            # one record so that the first hardware run answers the >= 6x question for the layout north_star names as well
+            # BASELINE.json's north_star names the ROW shard (item / user tables row-sharded, all-to-all of rows): since round 6 it is the
+            # layout of the headline fields (--shard row is the default); the dimension layout (16 B per triple over xGMI instead of ~2 KB)
+            # is timed into `layouts.dim` of the same record
             result['north_star_layout'] = 'row'
     elif args.workload == 'c5':
         try:
