@@ -68,6 +68,12 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
     if isinstance(cb, dict):
         line['cpu_baseline'] = {k: (_clip(v, 260) if isinstance(v, str) else v) for k, v in cb.items()
                                 if k in ('value', 'unit', 'cores', 'kind', 'sample', 'host_cores', 'cpu_model')}
+        rfm = cb.get('reference_formulation')
+        if isinstance(rfm, dict) and rfm.get('value'):
+            # the reference's OWN formulation of the step (dense autograd gradients + torch.optim.Adam over every row), same host, same shape
+            line['cpu_baseline']['reference_formulation'] = {'value': rfm['value'], 'unit': rfm.get('unit'), 'cores': rfm.get('cores')}
+        if cb.get('spread') is not None:
+            line['cpu_baseline']['spread'] = round(cb['spread'], 3)
         if cb.get('value') and result.get('value'):
             line['vs_cpu'] = round(result['value'] / cb['value'], 1)
     # a handful of scalars a reader wants beside the headline without opening the detail file
@@ -1837,6 +1843,7 @@ def conet_fullsort_leg(args, dev):
         torch.manual_seed(2022)
         model = CoNet(cfg, ds).to(dev)
         model.eval()
+        model.freeze_for_eval()                                # what CrossDomainTrainer.evaluate does around its loop of full_sort_predict calls
         for Uu in (1, 64):
             inter = {model.TARGET_USER_ID: torch.arange(1, 1 + Uu, device=dev, dtype=torch.int64)}
             for _ in range(3):
@@ -1911,31 +1918,36 @@ def cpu_baseline(args):
     I = torch.empty(ni, D).normal_(0, 0.01, generator=g)
     us, is_ = ts.RowwiseAdamState(U), ts.RowwiseAdamState(I)
     mk = lambda hi: torch.randint(1, hi, (B,), generator=g)
-    # pick the intra-op thread count that serves this step best on this host (all cores is not always the fastest
-    # for gather/index_add-bound torch ops); the count used is reported as `cores`
-    best = (None, 0.0)
-    for nt in sorted({min(ncores, t) for t in (4, 8, 16, 32, 64, ncores)}):
+    # FIXED thread count = the host's cores (round 6: the round-5 "best of a sweep" figure moved 4.5 x between two boxes of one CPU model --
+    # a single timed step per candidate decided it); `value` = the MEDIAN of >= 5 samples of >= 20 steps each.  The sweep over thread counts
+    # is still taken (short), but only reported (`thread_sweep`, detail file).
+    step_no = [0]
+    def one_step():
+        step_no[0] += 1
+        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), step_no[0], opt=args.opt)
+    def sample(nt, steps):
         torch.set_num_threads(nt)
-        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 1, opt=args.opt)
+        one_step()                                  # (thread pool + first touch at this count outside the sample)
         t0 = time.perf_counter()
-        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 2, opt=args.opt)
-        rate = B / (time.perf_counter() - t0)
-        if rate > best[1]:
-            best = (nt, rate)
-        if time.perf_counter() - t0 > 5.0:
+        for _ in range(steps):
+            one_step()
+        return B * steps / (time.perf_counter() - t0)
+    used = ncores
+    sweep = {}
+    for nt in sorted({min(ncores, t) for t in (1, 4, 8, 16, 32, 64, ncores)}):
+        t0 = time.perf_counter()
+        sweep[str(nt)] = sample(nt, 3)
+        if time.perf_counter() - t0 > 6.0 and nt != ncores:
             break
-    used = best[0]
-    def measure(nt, seconds):
-        torch.set_num_threads(nt)
-        ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), 3, opt=args.opt)
-        t0 = time.perf_counter(); n = 0
-        while (time.perf_counter() - t0 < seconds or n < 5) and n < 200:          # at least 5 steps whatever the time box
-            ts.rowwise_step(U, I, us, is_, mk(nu), mk(ni), mk(ni), n + 4, opt=args.opt)
-            n += 1
-        return B * n / (time.perf_counter() - t0), n
-    rate, steps = measure(used, args.cpu_seconds)
-    rate_all, n_all = measure(ncores, min(args.cpu_seconds, 6.0))          # torch.set_num_threads(os.cpu_count()) ...
-    rate_one, n_one = measure(1, min(args.cpu_seconds, 6.0))               # ... and a 1-thread figure
+    sample(used, 5)                                 # warm at the count that is reported
+    n_samples, per = 5, 20
+    t_one = B / max(sweep.get(str(used)) or sample(used, 3), 1.0)
+    while n_samples * per * t_one > max(args.cpu_seconds, 5.0) * 2.5 and per > 5:      # a slow host: shorter samples, still five of them
+        per -= 5
+    samples = sorted(sample(used, per) for _ in range(n_samples))
+    rate, steps = samples[len(samples) // 2], n_samples * per
+    rate_all, n_all = rate, steps
+    rate_one, n_one = sweep.get('1', 0.0), 3
     # the reference's OWN formulation beside the port's: dense autograd (index_select backward = a dense [rows, D] gradient) and
     # torch.optim.Adam over every row of both tables each step (recbole Trainer + emcdr.py:110-131), same tables, same batch shape; bounded to a
     # few steps -- each one sweeps the 1.5 GB of tables several times
@@ -1968,10 +1980,12 @@ def cpu_baseline(args):
             model = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')][0]
     except Exception:
         pass
-    sample = ('EMCDR-BPR D=%d, oracle row-wise step (fwd+bwd+lazy %s), batches of %d triples on down-scaled tables %d users x %d items '
-              '(host RAM)' % (D, args.opt, B, nu, ni))
+    sample_txt = ('EMCDR-BPR D=%d, oracle row-wise step (fwd+bwd+lazy %s), batches of %d triples on down-scaled tables %d users x %d items '
+                  '(host RAM)' % (D, args.opt, B, nu, ni))
     return {'value': rate, 'unit': 'interactions/s', 'cores': used, 'host_cores': ncores, 'os_cpu_count': os.cpu_count(), 'kind': 'port', 'cpu_model': model,
-            'sample': '%d steps, %s, torch %d threads (best of a sweep)' % (steps, sample, used),
+            'sample': 'median of %d samples of %d steps, %s, torch %d threads (all host cores, fixed)' % (n_samples, per, sample_txt, used),
+            'samples': samples, 'spread': (samples[-1] - samples[0]) / rate if rate else None,
+            'thread_sweep': {'unit': 'interactions/s', 'what': '3 steps per thread count, reported only (value uses all host cores)', 'by_threads': sweep},
             'all_cores': {'value': rate_all, 'unit': 'interactions/s', 'cores': ncores, 'sample': '%d steps, same shape' % n_all},
             'one_thread': {'value': rate_one, 'unit': 'interactions/s', 'cores': 1, 'sample': '%d steps, same shape' % n_one},
             'reference_formulation': ref_form}

@@ -196,22 +196,34 @@ constexpr int kSignInMaxBlocks = 512;        // beyond this the same-address ato
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // Row traffic that is touched once per step (table rows, moments, gradient rows, staged rows of tables far larger than the caches) is
-// marked non-temporal: replicated alternating A/B on one MI355X (profiles/r06_ab_nt.txt) -- the C5 step 3.975 -> 3.878 ms, its
-// forward-and-update kernel 1.480 -> 1.445 ms (0.725 -> 0.743 of the HBM peak), the row-sharded step at one rank 6.32 -> 6.02 ms.
-// -DCDR_NO_STREAM_NT builds the plain-policy library for that A/B.
+// marked non-temporal when a row is at least 512 bytes (LPR >= 32 lanes of one float4): replicated alternating A/B on one MI355X
+// (profiles/r06_ab_nt.txt) -- the C5 step 3.975 -> 3.878 ms, its forward-and-update kernel 1.480 -> 1.445 ms (0.725 -> 0.743 of the HBM
+// peak), the row-sharded step at one rank 6.32 -> 6.02 ms.  NOT for narrower rows: on the dimension layout's 64- and 128-byte column slices
+// the same hint LOSES 7-12 % (tools/mb_dimshard.py, profiles/r06_mb_dimshard_nt_ab.json: a row that is read and written back relies on the
+// line staying in L2 between the two).  -DCDR_NO_STREAM_NT builds the plain-policy library for that A/B.
 #ifndef CDR_NO_STREAM_NT
 typedef float cdr_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld4s(const float* p) {
-    const cdr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const cdr_v4f*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
+template <bool NT>
+__device__ __forceinline__ float4 ld4n(const float* p) {
+    if constexpr (NT) {
+        const cdr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const cdr_v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return ld4(p);
+    }
 }
-__device__ __forceinline__ void st4s(float* p, float4 v) {
-    cdr_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-    __builtin_nontemporal_store(w, reinterpret_cast<cdr_v4f*>(p));
+template <bool NT>
+__device__ __forceinline__ void st4n(float* p, float4 v) {
+    if constexpr (NT) {
+        cdr_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+        __builtin_nontemporal_store(w, reinterpret_cast<cdr_v4f*>(p));
+    } else {
+        st4(p, v);
+    }
 }
 #else
-__device__ __forceinline__ float4 ld4s(const float* p) { return ld4(p); }
-__device__ __forceinline__ void st4s(float* p, float4 v) { st4(p, v); }
+template <bool NT> __device__ __forceinline__ float4 ld4n(const float* p) { return ld4(p); }
+template <bool NT> __device__ __forceinline__ void st4n(float* p, float4 v) { st4(p, v); }
 #endif
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 

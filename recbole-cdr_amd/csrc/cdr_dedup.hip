@@ -100,15 +100,15 @@ __global__ __launch_bounds__(kBlock) void segsum_head_kernel(const uint32_t* __r
             for (int64_t e = q; e < n && keys[e] == key; ++e) {
                 const int64_t o = perm[e];
                 const bool neg = o >= neg_start;
-                add_signed(acc, ld4s(G + (neg ? o - neg_start : o) * D + 4 * ch), neg);
+                add_signed(acc, ld4n<(LPR >= 32)>(G + (neg ? o - neg_start : o) * D + 4 * ch), neg);
                 cnt += neg ? 0 : 1;
             }
             if (c != 0.f && cnt) {
-                const float4 w = ld4s(rows + j * D + 4 * ch);
+                const float4 w = ld4n<(LPR >= 32)>(rows + j * D + 4 * ch);
                 const float rc = c * (float)cnt;
                 acc.x += rc * w.x; acc.y += rc * w.y; acc.z += rc * w.z; acc.w += rc * w.w;
             }
-            st4s(out + j * D + 4 * ch, acc);
+            st4n<(LPR >= 32)>(out + j * D + 4 * ch, acc);
         }
     }
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q + kLongSeg < n; q += (int64_t)gridDim.x * kBlock) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void segsum_piece_kernel(int D, const uint3
                 for (int j = 0; j < UN; ++j) o[j] = (e0 + j < pc.len) ? (int64_t)perm[pc.start + e0 + j] : -1;
 #pragma unroll
                 for (int j = 0; j < UN; ++j)
-                    g[j] = o[j] >= 0 ? ld4s(G + (o[j] >= neg_start ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[j] = o[j] >= 0 ? ld4n<(LPR >= 32)>(G + (o[j] >= neg_start ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int j = 0; j < UN; ++j) {
                     if (o[j] < 0) continue;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void segsum_piece_kernel(int D, const uint3
                     cnt += o[j] >= neg_start ? 0 : 1;
                 }
             }
-            st4s(partial + pi * D + 4 * ch, acc);
+            st4n<(LPR >= 32)>(partial + pi * D + 4 * ch, acc);
             if (ch == 0) pcnt[pi] = cnt;
         }
     }
@@ -189,16 +189,16 @@ __global__ __launch_bounds__(kBlock) void segsum_long_finish_kernel(int D, const
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int cnt = 0;
             for (int64_t k = 0; k < np; ++k) {
-                const float4 g = ld4s(partial + (sg.base + k) * D + 4 * ch);
+                const float4 g = ld4n<(LPR >= 32)>(partial + (sg.base + k) * D + 4 * ch);
                 acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                 cnt += pcnt[sg.base + k];
             }
             if (c != 0.f && cnt) {
-                const float4 w = ld4s(rows + j * D + 4 * ch);
+                const float4 w = ld4n<(LPR >= 32)>(rows + j * D + 4 * ch);
                 const float rc = c * (float)cnt;
                 acc.x += rc * w.x; acc.y += rc * w.y; acc.z += rc * w.z; acc.w += rc * w.w;
             }
-            st4s(out + j * D + 4 * ch, acc);
+            st4n<(LPR >= 32)>(out + j * D + 4 * ch, acc);
         }
     }
 }

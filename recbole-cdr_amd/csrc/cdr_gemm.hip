@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void fullsort_gemv_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + it + r;
-                x[r] = (row < N && live) ? ld4(items + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[r] = (row < N && live) ? ld4n<true>(items + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void fullsort_gemv_topk_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + it + r;
-                x[r] = (row < N && live) ? ld4(items + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[r] = (row < N && live) ? ld4n<true>(items + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -64,14 +64,14 @@ __global__ __launch_bounds__(kBlock) void gather_rows_norms_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const int64_t r = base + j * TG;
-            v[j] = (r < n && live) ? ld4s(tab + id[j] * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[j] = (r < n && live) ? ld4n<(LPR >= 32)>(tab + id[j] * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const int64_t r = base + j * TG;
             const float s2 = group_sum<LPR>(dot4(v[j], v[j]));
             if (r < n) {
-                if (live) st4s(out + r * D + 4 * sub, v[j]);
+                if (live) st4n<(LPR >= 32)>(out + r * D + 4 * sub, v[j]);
                 if (sub == 0) nrm2[r] = s2;
             }
         }

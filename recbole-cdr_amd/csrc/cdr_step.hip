@@ -73,9 +73,9 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
             const int64_t t = base + (int64_t)r * TG;
             u[r] = p[r] = n[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < B && live) {
-                u[r] = ld4s(U + iu[r] * D + 4 * sub);
-                p[r] = ld4s(I + ip[r] * D + 4 * sub);
-                n[r] = ld4s(I + in[r] * D + 4 * sub);
+                u[r] = ld4n<(LPR >= 32)>(U + iu[r] * D + 4 * sub);
+                p[r] = ld4n<(LPR >= 32)>(I + ip[r] * D + 4 * sub);
+                n[r] = ld4n<(LPR >= 32)>(I + in[r] * D + 4 * sub);
             }
         }
 #pragma unroll
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_grad_kernel(const float* __res
                 const float s = sigmoidf_(dp - dn);
                 const float g = -invB * (s * (1.0f - s)) / (gamma + s);
                 if (live) {
-                    st4s(GU + t * D + 4 * sub, make_float4(g * (p[r].x - n[r].x), g * (p[r].y - n[r].y),
+                    st4n<(LPR >= 32)>(GU + t * D + 4 * sub, make_float4(g * (p[r].x - n[r].x), g * (p[r].y - n[r].y),
                                                           g * (p[r].z - n[r].z), g * (p[r].w - n[r].w)));
                     if (SCATTER) {
-                        st4s(GP + ip[r] * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
-                        st4s(GP + in[r] * D + 4 * sub, make_float4(-g * u[r].x, -g * u[r].y, -g * u[r].z, -g * u[r].w));
+                        st4n<(LPR >= 32)>(GP + ip[r] * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                        st4n<(LPR >= 32)>(GP + in[r] * D + 4 * sub, make_float4(-g * u[r].x, -g * u[r].y, -g * u[r].z, -g * u[r].w));
                     } else {
-                        st4s(GP + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                        st4n<(LPR >= 32)>(GP + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
                     }
                 }
                 if (sub == 0) {
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(kBlock) void point_fwd_grad_kernel(int loss_kind, c
             const int64_t t = base + (int64_t)r * TG;
             u[r] = v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < B && live) {
-                u[r] = ld4s(U + iu[r] * D + 4 * sub);
-                v[r] = ld4s(I + ii[r] * D + 4 * sub);
+                u[r] = ld4n<(LPR >= 32)>(U + iu[r] * D + 4 * sub);
+                v[r] = ld4n<(LPR >= 32)>(I + ii[r] * D + 4 * sub);
             }
         }
 #pragma unroll
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void point_fwd_grad_kernel(int loss_kind, c
                     g = (p - y) / fmaxf(pq, 1e-12f) * invB * pq;
                 }
                 if (live) {
-                    st4s(GU + t * D + 4 * sub, make_float4(g * v[r].x, g * v[r].y, g * v[r].z, g * v[r].w));
-                    st4s(GI + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
+                    st4n<(LPR >= 32)>(GU + t * D + 4 * sub, make_float4(g * v[r].x, g * v[r].y, g * v[r].z, g * v[r].w));
+                    st4n<(LPR >= 32)>(GI + t * D + 4 * sub, make_float4(g * u[r].x, g * u[r].y, g * u[r].z, g * u[r].w));
                 }
                 if (sub == 0) { acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si; }
             }
@@ -246,7 +246,7 @@ struct seg_piece { int64_t start; int64_t len; };
 struct apply_hp { float lr, b1, b2, eps, wd, step_size, bc2_sqrt; const float* dev; };
 #define HP_FROM_DEV(h) do { if ((h).dev) { (h).step_size = (h).dev[0]; (h).bc2_sqrt = (h).dev[1]; } } while (0)
 
-template <int OPT>
+template <int LPR, int OPT>
 __device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __restrict__ mp, float* __restrict__ vp, float4 w,
                                              float4 acc, float rc, const apply_hp& h) {
     float4 gr = make_float4(acc.x + rc * w.x, acc.y + rc * w.y, acc.z + rc * w.z, acc.w + rc * w.w);
@@ -255,17 +255,17 @@ __device__ __forceinline__ void apply_update(float* __restrict__ wp, float* __re
         if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
         wn = make_float4(w.x - h.lr * gr.x, w.y - h.lr * gr.y, w.z - h.lr * gr.z, w.w - h.lr * gr.w);
     } else {
-        float4 m = ld4s(mp), v = ld4s(vp);
+        float4 m = ld4n<(LPR >= 32)>(mp), v = ld4n<(LPR >= 32)>(vp);
         if (h.wd != 0.f) { gr.x += h.wd * w.x; gr.y += h.wd * w.y; gr.z += h.wd * w.z; gr.w += h.wd * w.w; }
         m.x += (gr.x - m.x) * (1.0f - h.b1); m.y += (gr.y - m.y) * (1.0f - h.b1);
         m.z += (gr.z - m.z) * (1.0f - h.b1); m.w += (gr.w - m.w) * (1.0f - h.b1);
         v.x = h.b2 * v.x + (1.0f - h.b2) * gr.x * gr.x; v.y = h.b2 * v.y + (1.0f - h.b2) * gr.y * gr.y;
         v.z = h.b2 * v.z + (1.0f - h.b2) * gr.z * gr.z; v.w = h.b2 * v.w + (1.0f - h.b2) * gr.w * gr.w;
-        st4s(mp, m); st4s(vp, v);
+        st4n<(LPR >= 32)>(mp, m); st4n<(LPR >= 32)>(vp, v);
         wn = make_float4(w.x - cdr_adam_term(m.x, v.x, h.step_size, h.bc2_sqrt, h.eps), w.y - cdr_adam_term(m.y, v.y, h.step_size, h.bc2_sqrt, h.eps),
                          w.z - cdr_adam_term(m.z, v.z, h.step_size, h.bc2_sqrt, h.eps), w.w - cdr_adam_term(m.w, v.w, h.step_size, h.bc2_sqrt, h.eps));
     }
-    st4s(wp, wn);
+    st4n<(LPR >= 32)>(wp, wn);
 }
 
 template <int LPR, int OPT, bool SIGNED>
@@ -296,18 +296,18 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
         if (head && !is_long) {
             for (int ch = sub; ch < D4; ch += LPR) {
                 float* wp = W + (int64_t)row * D + 4 * ch;
-                const float4 w = ld4s(wp);
+                const float4 w = ld4n<(LPR >= 32)>(wp);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 int cnt = 0;
                 for (int64_t e = q; e < n && keys[e] == row; ++e) {
                     const int64_t o = perm[e];
                     const bool neg = SIGNED && o >= neg_start;
-                    const float4 g = ld4s(G + (neg ? o - neg_start : o) * D + 4 * ch);
+                    const float4 g = ld4n<(LPR >= 32)>(G + (neg ? o - neg_start : o) * D + 4 * ch);
                     if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
                     else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
                     cnt += occ_ids ? (int)((occ_ids[o] >> 62) & 1) : ((o < reg_limit) ? 1 : 0);
                 }
-                apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
+                apply_update<LPR, OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
                                   w, acc, c * (float)cnt, hp);
             }
         }
@@ -367,7 +367,7 @@ __device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __rest
 #pragma unroll
                 for (int j = 0; j < UN; ++j) {
                     neg[j] = SIGNED && o[j] >= neg_start;
-                    g[j] = o[j] >= 0 ? ld4s(G + (neg[j] ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[j] = o[j] >= 0 ? ld4n<(LPR >= 32)>(G + (neg[j] ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int j = 0; j < UN; ++j) {
@@ -377,7 +377,7 @@ __device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __rest
                     cnt += occ_ids ? (int)((occ_ids[o[j]] >> 62) & 1) : ((o[j] < reg_limit) ? 1 : 0);
                 }
             }
-            st4s(partial + pi * D + 4 * ch, acc);
+            st4n<(LPR >= 32)>(partial + pi * D + 4 * ch, acc);
             if (ch == 0) pcnt[pi] = cnt;
         }
     }
@@ -414,7 +414,7 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
         const int64_t np = (sg.len + kPiece - 1) / kPiece;
         for (int ch = sub; ch < D4; ch += LPR) {
             float* wp = W + (int64_t)row * D + 4 * ch;
-            const float4 w = ld4s(wp);
+            const float4 w = ld4n<(LPR >= 32)>(wp);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int cnt = 0;
             for (int64_t k0 = 0; k0 < np; k0 += 8) {                  // eight piece sums in flight, added in piece order
@@ -422,7 +422,7 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool in = k0 + j < np;
-                    g[j] = in ? ld4s(partial + (sg.base + k0 + j) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[j] = in ? ld4n<(LPR >= 32)>(partial + (sg.base + k0 + j) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
                     c[j] = in ? pcnt[sg.base + k0 + j] : 0;
                 }
 #pragma unroll
@@ -430,7 +430,7 @@ __device__ __forceinline__ void seg_long_finish_body(float* __restrict__ W, floa
                     if (k0 + j < np) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; cnt += c[j]; }
                 }
             }
-            apply_update<OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
+            apply_update<LPR, OPT>(wp, OPT ? Mo + (int64_t)row * D + 4 * ch : nullptr, OPT ? Vo + (int64_t)row * D + 4 * ch : nullptr,
                               w, acc, c * (float)cnt, hp);
         }
     }
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void batch_norms_kernel(const float* __rest
         for (int r = 0; r < UNR; ++r) {
             const int64_t t = base + (int64_t)r * TG;
             u[r] = p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < B && live) { u[r] = ld4s(U + iu[r] * D + 4 * sub); p[r] = ld4s(I + ip[r] * D + 4 * sub); }
+            if (t < B && live) { u[r] = ld4n<(LPR >= 32)>(U + iu[r] * D + 4 * sub); p[r] = ld4n<(LPR >= 32)>(I + ip[r] * D + 4 * sub); }
         }
 #pragma unroll
         for (int r = 0; r < UNR; ++r) {
@@ -749,14 +749,14 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             const bool ok = t < B && live;
             fu[r] = (fl[r] & 0xFFu) != 0 && t < B; fp[r] = (fl[r] & 0xFF00u) != 0 && t < B; fn[r] = (fl[r] & 0xFF0000u) != 0 && t < B;
             ou[r] = (int64_t)iu[r] * D + 4 * sub; op[r] = (int64_t)ip[r] * D + 4 * sub; on[r] = (int64_t)in[r] * D + 4 * sub;
-            u[r] = ok ? ld4s(TU.W + ou[r]) : z4;
-            p[r] = ok ? ld4s(TI.W + op[r]) : z4;
-            n[r] = ok ? ld4s(TI.W + on[r]) : z4;
+            u[r] = ok ? ld4n<(LPR >= 32)>(TU.W + ou[r]) : z4;
+            p[r] = ok ? ld4n<(LPR >= 32)>(TI.W + op[r]) : z4;
+            n[r] = ok ? ld4n<(LPR >= 32)>(TI.W + on[r]) : z4;
             um[r] = uv[r] = pm[r] = pv[r] = nm[r] = nv[r] = z4;
             if (OPT == 1) {
-                if (ok && fu[r]) { um[r] = ld4s(TU.M + ou[r]); uv[r] = ld4s(TU.V + ou[r]); }
-                if (!SH && ok && fp[r]) { pm[r] = ld4s(TI.M + op[r]); pv[r] = ld4s(TI.V + op[r]); }
-                if (!SH && ok && fn[r]) { nm[r] = ld4s(TI.M + on[r]); nv[r] = ld4s(TI.V + on[r]); }
+                if (ok && fu[r]) { um[r] = ld4n<(LPR >= 32)>(TU.M + ou[r]); uv[r] = ld4n<(LPR >= 32)>(TU.V + ou[r]); }
+                if (!SH && ok && fp[r]) { pm[r] = ld4n<(LPR >= 32)>(TI.M + op[r]); pv[r] = ld4n<(LPR >= 32)>(TI.V + op[r]); }
+                if (!SH && ok && fn[r]) { nm[r] = ld4n<(LPR >= 32)>(TI.M + on[r]); nv[r] = ld4n<(LPR >= 32)>(TI.V + on[r]); }
             }
         }
         uint32_t ju[UN], jp[UN], jn[UN], gl[UN];
@@ -800,24 +800,24 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kernel(tab_ptrs TU, tab_
             // ---- user row
             if (fu[r]) {
                 const float4 wu = upd_math<OPT>(u[r], um[r], uv[r], gu, cu, hu);
-                if (live) { if (OPT == 1) { st4s(TU.M + ou[r], um[r]); st4s(TU.V + ou[r], uv[r]); } st4s(TU.W + ou[r], wu); }
-            } else if (ok) st4s(GU + t * D + 4 * sub, gu);
+                if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TU.M + ou[r], um[r]); st4n<(LPR >= 32)>(TU.V + ou[r], uv[r]); } st4n<(LPR >= 32)>(TU.W + ou[r], wu); }
+            } else if (ok) st4n<(LPR >= 32)>(GU + t * D + 4 * sub, gu);
             // ---- positive item row (EmbLoss occurrence), negative item row (gradient -g u, no EmbLoss)
             if (SH) {
-                if (fp[r] && live) st4s(GS + op[r], make_float4(__builtin_fmaf(ci, p[r].x, gi.x), __builtin_fmaf(ci, p[r].y, gi.y),
+                if (fp[r] && live) st4n<(LPR >= 32)>(GS + op[r], make_float4(__builtin_fmaf(ci, p[r].x, gi.x), __builtin_fmaf(ci, p[r].y, gi.y),
                                                                __builtin_fmaf(ci, p[r].z, gi.z), __builtin_fmaf(ci, p[r].w, gi.w)));
-                if (fn[r] && live) st4s(GS + on[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w));
+                if (fn[r] && live) st4n<(LPR >= 32)>(GS + on[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w));
             } else {
             if (fp[r]) {
                 const float4 wp = upd_math<OPT>(p[r], pm[r], pv[r], gi, ci, hi);
-                if (live) { if (OPT == 1) { st4s(TI.M + op[r], pm[r]); st4s(TI.V + op[r], pv[r]); } st4s(TI.W + op[r], wp); }
+                if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TI.M + op[r], pm[r]); st4n<(LPR >= 32)>(TI.V + op[r], pv[r]); } st4n<(LPR >= 32)>(TI.W + op[r], wp); }
             }
             if (fn[r]) {
                 const float4 wn = upd_math<OPT>(n[r], nm[r], nv[r], make_float4(0.f - gi.x, 0.f - gi.y, 0.f - gi.z, 0.f - gi.w), 0.f, hi);
-                if (live) { if (OPT == 1) { st4s(TI.M + on[r], nm[r]); st4s(TI.V + on[r], nv[r]); } st4s(TI.W + on[r], wn); }
+                if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TI.M + on[r], nm[r]); st4n<(LPR >= 32)>(TI.V + on[r], nv[r]); } st4n<(LPR >= 32)>(TI.W + on[r], wn); }
             }
             }
-            if (ok && !(fp[r] && fn[r])) st4s(GP + t * D + 4 * sub, gi);
+            if (ok && !(fp[r] && fn[r])) st4n<(LPR >= 32)>(GP + t * D + 4 * sub, gi);
             if (t < B && sub == 0) {
                 acc[0] += (double)lss[r];
                 acc[1] += (double)sus[r];
@@ -867,11 +867,11 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, 
     for (int64_t t = gg; t < B; t += TG) {
         const bool fu = (fl & 0xFFu) != 0, fi = (fl & 0xFF00u) != 0;
         const int64_t ou = (int64_t)iu * D + 4 * sub, oi = (int64_t)ii * D + 4 * sub;
-        float4 u = live ? ld4s(TU.W + ou) : z4, v = live ? ld4s(TI.W + oi) : z4;
+        float4 u = live ? ld4n<(LPR >= 32)>(TU.W + ou) : z4, v = live ? ld4n<(LPR >= 32)>(TI.W + oi) : z4;
         float4 um = z4, uv = z4, im = z4, iv = z4;
         if (OPT == 1) {
-            if (live && fu) { um = ld4s(TU.M + ou); uv = ld4s(TU.V + ou); }
-            if (live && fi) { im = ld4s(TI.M + oi); iv = ld4s(TI.V + oi); }
+            if (live && fu) { um = ld4n<(LPR >= 32)>(TU.M + ou); uv = ld4n<(LPR >= 32)>(TU.V + ou); }
+            if (live && fi) { im = ld4n<(LPR >= 32)>(TI.M + oi); iv = ld4n<(LPR >= 32)>(TI.V + oi); }
         }
         uint32_t ju, ji, gl; float yn, xn = 0.f;
         {
@@ -899,12 +899,12 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kernel(int loss_kind, 
         const float4 gi = make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
         if (fu) {
             const float4 wu = upd_math<OPT>(u, um, uv, gu, cu, hu);
-            if (live) { if (OPT == 1) { st4s(TU.M + ou, um); st4s(TU.V + ou, uv); } st4s(TU.W + ou, wu); }
-        } else if (live) st4s(GU + t * D + 4 * sub, gu);
+            if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TU.M + ou, um); st4n<(LPR >= 32)>(TU.V + ou, uv); } st4n<(LPR >= 32)>(TU.W + ou, wu); }
+        } else if (live) st4n<(LPR >= 32)>(GU + t * D + 4 * sub, gu);
         if (fi) {
             const float4 wi = upd_math<OPT>(v, im, iv, gi, ci, hi);
-            if (live) { if (OPT == 1) { st4s(TI.M + oi, im); st4s(TI.V + oi, iv); } st4s(TI.W + oi, wi); }
-        } else if (live) st4s(GI + t * D + 4 * sub, gi);
+            if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TI.M + oi, im); st4n<(LPR >= 32)>(TI.V + oi, iv); } st4n<(LPR >= 32)>(TI.W + oi, wi); }
+        } else if (live) st4n<(LPR >= 32)>(GI + t * D + 4 * sub, gi);
         if (sub == 0) { acc[0] += (double)l; acc[1] += (double)su; acc[2] += (double)si; }
         iu = ju; ii = ji; fl = gl; yl = yn; xd = xn;
     }
@@ -949,10 +949,10 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs T
         const int64_t ou = iu * D + 4 * sub, op = ip * D + 4 * sub;
         float4 u = z4, p = z4, um = z4, uv = z4, pm = z4, pv = z4;
         if (live) {
-            u = ld4s(TU.W + ou); p = ld4s(TI.W + op);
+            u = ld4n<(LPR >= 32)>(TU.W + ou); p = ld4n<(LPR >= 32)>(TI.W + op);
             if (OPT == 1) {
-                if (fu) { um = ld4s(TU.M + ou); uv = ld4s(TU.V + ou); }
-                if (fp) { pm = ld4s(TI.M + op); pv = ld4s(TI.V + op); }
+                if (fu) { um = ld4n<(LPR >= 32)>(TU.M + ou); uv = ld4n<(LPR >= 32)>(TU.V + ou); }
+                if (fp) { pm = ld4n<(LPR >= 32)>(TI.M + op); pv = ld4n<(LPR >= 32)>(TI.V + op); }
             }
         }
         float4 gu = z4;
@@ -969,9 +969,9 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs T
             }
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                n[c] = live ? ld4s(TI.W + on[c]) : z4;
+                n[c] = live ? ld4n<(LPR >= 32)>(TI.W + on[c]) : z4;
                 nm[c] = nv[c] = z4;
-                if (OPT == 1 && live && fn[c]) { nm[c] = ld4s(TI.M + on[c]); nv[c] = ld4s(TI.V + on[c]); }
+                if (OPT == 1 && live && fn[c]) { nm[c] = ld4n<(LPR >= 32)>(TI.M + on[c]); nv[c] = ld4n<(LPR >= 32)>(TI.V + on[c]); }
             }
             if (m0 == 0) {
                 dp = group_sum<LPR>(dot4(u, p));
@@ -990,20 +990,20 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_apply_kmajor_kernel(tab_ptrs T
                     const float4 gn = make_float4(0.f - g * u.x, 0.f - g * u.y, 0.f - g * u.z, 0.f - g * u.w);
                     if (fn[c]) {
                         const float4 wn = upd_math<OPT>(n[c], nm[c], nv[c], gn, 0.f, hi);
-                        if (live) { if (OPT == 1) { st4s(TI.M + on[c], nm[c]); st4s(TI.V + on[c], nv[c]); } st4s(TI.W + on[c], wn); }
-                    } else if (live) st4s(GI + (S + j + (int64_t)(m0 + c) * S) * D + 4 * sub, gn);
+                        if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TI.M + on[c], nm[c]); st4n<(LPR >= 32)>(TI.V + on[c], nv[c]); } st4n<(LPR >= 32)>(TI.W + on[c], wn); }
+                    } else if (live) st4n<(LPR >= 32)>(GI + (S + j + (int64_t)(m0 + c) * S) * D + 4 * sub, gn);
                 }
             }
         }
         if (fu) {
             const float4 wu = upd_math<OPT>(u, um, uv, gu, cu, hu);
-            if (live) { if (OPT == 1) { st4s(TU.M + ou, um); st4s(TU.V + ou, uv); } st4s(TU.W + ou, wu); }
-        } else if (live) st4s(GU + j * D + 4 * sub, gu);
+            if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TU.M + ou, um); st4n<(LPR >= 32)>(TU.V + ou, uv); } st4n<(LPR >= 32)>(TU.W + ou, wu); }
+        } else if (live) st4n<(LPR >= 32)>(GU + j * D + 4 * sub, gu);
         const float4 gp = make_float4(gs * u.x, gs * u.y, gs * u.z, gs * u.w);
         if (fp) {
             const float4 wp = upd_math<OPT>(p, pm, pv, gp, ci, hi);
-            if (live) { if (OPT == 1) { st4s(TI.M + op, pm); st4s(TI.V + op, pv); } st4s(TI.W + op, wp); }
-        } else if (live) st4s(GI + j * D + 4 * sub, gp);
+            if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TI.M + op, pm); st4n<(LPR >= 32)>(TI.V + op, pv); } st4n<(LPR >= 32)>(TI.W + op, wp); }
+        } else if (live) st4n<(LPR >= 32)>(GI + j * D + 4 * sub, gp);
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -1030,12 +1030,12 @@ __global__ __launch_bounds__(kBlock) void point_norms_kmajor_kernel(const float*
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     double acc[2] = {0.0, 0.0};
     for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; j < S; j += (int64_t)gridDim.x * GPB) {
-        const float4 u = live ? ld4s(U + uid[j] * D + 4 * sub) : z4;
+        const float4 u = live ? ld4n<(LPR >= 32)>(U + uid[j] * D + 4 * sub) : z4;
         float si = 0.f;
         for (int r0 = 0; r0 <= k; r0 += 4) {                       // four item rows in flight
             float4 v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (live && r0 + c <= k) ? ld4s(I + iid[j + (int64_t)(r0 + c) * S] * D + 4 * sub) : z4;
+            for (int c = 0; c < 4; ++c) v[c] = (live && r0 + c <= k) ? ld4n<(LPR >= 32)>(I + iid[j + (int64_t)(r0 + c) * S] * D + 4 * sub) : z4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) si += dot4(v[c], v[c]);
         }
@@ -1090,8 +1090,8 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kmajor_kernel(int loss
         const int64_t ou = iu * D + 4 * sub;
         float4 u = z4, um = z4, uv = z4;
         if (live) {
-            u = ld4s(TU.W + ou);
-            if (OPT == 1 && fu) { um = ld4s(TU.M + ou); uv = ld4s(TU.V + ou); }
+            u = ld4n<(LPR >= 32)>(TU.W + ou);
+            if (OPT == 1 && fu) { um = ld4n<(LPR >= 32)>(TU.M + ou); uv = ld4n<(LPR >= 32)>(TU.V + ou); }
         }
         float4 gu = z4;
         float su = 0.f;
@@ -1107,9 +1107,9 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kmajor_kernel(int loss
             }
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                v[c] = live ? ld4s(TI.W + oi[c]) : z4;
+                v[c] = live ? ld4n<(LPR >= 32)>(TI.W + oi[c]) : z4;
                 vm[c] = vv[c] = z4;
-                if (OPT == 1 && live && fi[c]) { vm[c] = ld4s(TI.M + oi[c]); vv[c] = ld4s(TI.V + oi[c]); }
+                if (OPT == 1 && live && fi[c]) { vm[c] = ld4n<(LPR >= 32)>(TI.M + oi[c]); vv[c] = ld4n<(LPR >= 32)>(TI.V + oi[c]); }
             }
             if (r0 == 0) su = group_sum<LPR>(dot4(u, u));
 #pragma unroll
@@ -1133,16 +1133,16 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kmajor_kernel(int loss
                     const float4 gi = make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
                     if (fi[c]) {
                         const float4 wi = upd_math<OPT>(v[c], vm[c], vv[c], gi, ci, hi);
-                        if (live) { if (OPT == 1) { st4s(TI.M + oi[c], vm[c]); st4s(TI.V + oi[c], vv[c]); } st4s(TI.W + oi[c], wi); }
-                    } else if (live) st4s(GI + (j + (int64_t)(r0 + c) * S) * D + 4 * sub, gi);
+                        if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TI.M + oi[c], vm[c]); st4n<(LPR >= 32)>(TI.V + oi[c], vv[c]); } st4n<(LPR >= 32)>(TI.W + oi[c], wi); }
+                    } else if (live) st4n<(LPR >= 32)>(GI + (j + (int64_t)(r0 + c) * S) * D + 4 * sub, gi);
                 }
             }
         }
         if (sub == 0) acc[1] += (double)(1 + k) * (double)su;
         if (fu) {
             const float4 wu = upd_math<OPT>(u, um, uv, gu, cu, hu);
-            if (live) { if (OPT == 1) { st4s(TU.M + ou, um); st4s(TU.V + ou, uv); } st4s(TU.W + ou, wu); }
-        } else if (live) st4s(GU + j * D + 4 * sub, gu);
+            if (live) { if (OPT == 1) { st4n<(LPR >= 32)>(TU.M + ou, um); st4n<(LPR >= 32)>(TU.V + ou, uv); } st4n<(LPR >= 32)>(TU.W + ou, wu); }
+        } else if (live) st4n<(LPR >= 32)>(GU + j * D + 4 * sub, gu);
     }
     block_sum_d<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -1203,11 +1203,11 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
                 off[j] = (int64_t)row[j] * D + 4 * sub;
                 w[j] = m[j] = v[j] = g0[j] = g1[j] = z4;
                 if (ok[j] && live) {
-                    w[j] = ld4s(W + off[j]);
-                    if (OPT == 1) { m[j] = ld4s(Mo + off[j]); v[j] = ld4s(Vo + off[j]); }
+                    w[j] = ld4n<(LPR >= 32)>(W + off[j]);
+                    if (OPT == 1) { m[j] = ld4n<(LPR >= 32)>(Mo + off[j]); v[j] = ld4n<(LPR >= 32)>(Vo + off[j]); }
                     const bool n0 = SIGNED && (int64_t)o0[j] >= neg_start, n1 = SIGNED && (int64_t)o1[j] >= neg_start;
-                    g0[j] = ld4s(G + (n0 ? (int64_t)o0[j] - neg_start : (int64_t)o0[j]) * D + 4 * sub);
-                    g1[j] = ld4s(G + (n1 ? (int64_t)o1[j] - neg_start : (int64_t)o1[j]) * D + 4 * sub);
+                    g0[j] = ld4n<(LPR >= 32)>(G + (n0 ? (int64_t)o0[j] - neg_start : (int64_t)o0[j]) * D + 4 * sub);
+                    g1[j] = ld4n<(LPR >= 32)>(G + (n1 ? (int64_t)o1[j] - neg_start : (int64_t)o1[j]) * D + 4 * sub);
                 }
             }
 #pragma unroll
@@ -1236,7 +1236,7 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const bool neg = SIGNED && o[u] >= neg_start;
-                            g[u] = (o[u] >= 0 && live) ? ld4s(G + (neg ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
+                            g[u] = (o[u] >= 0 && live) ? ld4n<(LPR >= 32)>(G + (neg ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -1249,8 +1249,8 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
                 }
                 const float4 wn = upd_math<OPT>(w[j], m[j], v[j], acc, c * (float)cnt, hp);
                 if (live) {
-                    if (OPT == 1) { st4s(Mo + off[j], m[j]); st4s(Vo + off[j], v[j]); }
-                    st4s(W + off[j], wn);
+                    if (OPT == 1) { st4n<(LPR >= 32)>(Mo + off[j], m[j]); st4n<(LPR >= 32)>(Vo + off[j], v[j]); }
+                    st4n<(LPR >= 32)>(W + off[j], wn);
                 }
             }
         }
@@ -1262,22 +1262,22 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
             if (is_long) continue;
             for (int ch = sub; ch < D4; ch += LPR) {
                 const int64_t off = (int64_t)row * D + 4 * ch;
-                const float4 w = ld4s(W + off);
+                const float4 w = ld4n<(LPR >= 32)>(W + off);
                 float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
-                if (OPT == 1) { m = ld4s(Mo + off); v = ld4s(Vo + off); }
+                if (OPT == 1) { m = ld4n<(LPR >= 32)>(Mo + off); v = ld4n<(LPR >= 32)>(Vo + off); }
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 int cnt = 0;
                 for (int64_t e = q; e < n && keys[e] == row; ++e) {
                     const int64_t o = perm[e];
                     const bool neg = SIGNED && o >= neg_start;
-                    const float4 g = ld4s(G + (neg ? o - neg_start : o) * D + 4 * ch);
+                    const float4 g = ld4n<(LPR >= 32)>(G + (neg ? o - neg_start : o) * D + 4 * ch);
                     if (neg) { acc.x -= g.x; acc.y -= g.y; acc.z -= g.z; acc.w -= g.w; }
                     else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
                     cnt += (o < reg_limit) ? 1 : 0;
                 }
                 const float4 wn = upd_math<OPT>(w, m, v, acc, c * (float)cnt, hp);
-                if (OPT == 1) { st4s(Mo + off, m); st4s(Vo + off, v); }
-                st4s(W + off, wn);
+                if (OPT == 1) { st4n<(LPR >= 32)>(Mo + off, m); st4n<(LPR >= 32)>(Vo + off, v); }
+                st4n<(LPR >= 32)>(W + off, wn);
             }
         }
     }
@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(kBlock) void shard_norms_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < UNR; ++r) {
             const int64_t t = base + (int64_t)r * TG;
-            u[r] = (t < B && live) ? ld4s(U + iu[r] * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            u[r] = (t < B && live) ? ld4n<(LPR >= 32)>(U + iu[r] * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
             pn[r] = (t < B && sub == 0) ? nrm2[ii[r]] : 0.f;
         }
 #pragma unroll
@@ -1473,10 +1473,10 @@ __device__ __forceinline__ void segsum_dups_body(int D, const dup_side& t) {
             ok[j] = ok[j] && !(far[j] == row[j] && row[j] != ~0u && q[j] + kLongSeg < n);
             w[j] = g0[j] = g1[j] = z4;
             if (ok[j] && live) {
-                if (c != 0.f) w[j] = ld4s(rows + (int64_t)ju[j] * D + 4 * sub);
+                if (c != 0.f) w[j] = ld4n<(LPR >= 32)>(rows + (int64_t)ju[j] * D + 4 * sub);
                 const bool n0 = (int64_t)o0[j] >= neg_start, n1 = (int64_t)o1[j] >= neg_start;
-                g0[j] = ld4s(G + (n0 ? (int64_t)o0[j] - neg_start : (int64_t)o0[j]) * D + 4 * sub);
-                g1[j] = ld4s(G + (n1 ? (int64_t)o1[j] - neg_start : (int64_t)o1[j]) * D + 4 * sub);
+                g0[j] = ld4n<(LPR >= 32)>(G + (n0 ? (int64_t)o0[j] - neg_start : (int64_t)o0[j]) * D + 4 * sub);
+                g1[j] = ld4n<(LPR >= 32)>(G + (n1 ? (int64_t)o1[j] - neg_start : (int64_t)o1[j]) * D + 4 * sub);
             }
         }
 #pragma unroll
@@ -1502,7 +1502,7 @@ __device__ __forceinline__ void segsum_dups_body(int D, const dup_side& t) {
                     for (int u = 0; u < 8; ++u) o[u] = e0 + u < end ? (int64_t)perm[e0 + u] : -1;
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        g[u] = (o[u] >= 0 && live) ? ld4s(G + (o[u] >= neg_start ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
+                        g[u] = (o[u] >= 0 && live) ? ld4n<(LPR >= 32)>(G + (o[u] >= neg_start ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (o[u] < 0) continue;
@@ -1513,7 +1513,7 @@ __device__ __forceinline__ void segsum_dups_body(int D, const dup_side& t) {
                 }
             }
             const float rc = c * (float)cnt;
-            if (live) st4s(out + (int64_t)ju[j] * D + 4 * sub, make_float4(__builtin_fmaf(rc, w[j].x, acc.x), __builtin_fmaf(rc, w[j].y, acc.y),
+            if (live) st4n<(LPR >= 32)>(out + (int64_t)ju[j] * D + 4 * sub, make_float4(__builtin_fmaf(rc, w[j].x, acc.x), __builtin_fmaf(rc, w[j].y, acc.y),
                                                                           __builtin_fmaf(rc, w[j].z, acc.z), __builtin_fmaf(rc, w[j].w, acc.w)));
         }
     }
@@ -1560,7 +1560,7 @@ __device__ __forceinline__ void segsum_long_finish_body(int D, const dup_side& t
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool in = k0 + u < np;
-                    g[u] = in ? ld4s(t.partial + (sg.base + k0 + u) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[u] = in ? ld4n<(LPR >= 32)>(t.partial + (sg.base + k0 + u) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
                     cc[u] = in ? t.pcnt[sg.base + k0 + u] : 0;
                 }
 #pragma unroll
@@ -1569,8 +1569,8 @@ __device__ __forceinline__ void segsum_long_finish_body(int D, const dup_side& t
             }
             const float rc = c * (float)cnt;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c != 0.f) w = ld4s(t.W + j * D + 4 * ch);
-            st4s(t.out + j * D + 4 * ch, make_float4(__builtin_fmaf(rc, w.x, acc.x), __builtin_fmaf(rc, w.y, acc.y),
+            if (c != 0.f) w = ld4n<(LPR >= 32)>(t.W + j * D + 4 * ch);
+            st4n<(LPR >= 32)>(t.out + j * D + 4 * ch, make_float4(__builtin_fmaf(rc, w.x, acc.x), __builtin_fmaf(rc, w.y, acc.y),
                                                     __builtin_fmaf(rc, w.z, acc.z), __builtin_fmaf(rc, w.w, acc.w)));
         }
     }
@@ -1628,8 +1628,8 @@ __global__ __launch_bounds__(kBlock) void apply_run_kernel(float* __restrict__ W
             const int64_t q = base + j * TG;
             w[j] = m[j] = v[j] = g[j] = z4;
             if (ok[j]) {
-                w[j] = ld4s(W + off[j]); g[j] = ld4s(G + q * D + 4 * sub);
-                if (OPT == 1) { m[j] = ld4s(Mo + off[j]); v[j] = ld4s(Vo + off[j]); }
+                w[j] = ld4n<(LPR >= 32)>(W + off[j]); g[j] = ld4n<(LPR >= 32)>(G + q * D + 4 * sub);
+                if (OPT == 1) { m[j] = ld4n<(LPR >= 32)>(Mo + off[j]); v[j] = ld4n<(LPR >= 32)>(Vo + off[j]); }
             }
         }
 #pragma unroll
@@ -1638,8 +1638,8 @@ __global__ __launch_bounds__(kBlock) void apply_run_kernel(float* __restrict__ W
             // (0 + g first: the segmented apply's accumulator starts at zero -- same bits, also for g = -0)
             const float4 acc = make_float4(0.f + g[j].x, 0.f + g[j].y, 0.f + g[j].z, 0.f + g[j].w);
             const float4 wn = upd_math<OPT>(w[j], m[j], v[j], acc, 0.f, hp);
-            if (OPT == 1) { st4s(Mo + off[j], m[j]); st4s(Vo + off[j], v[j]); }
-            st4s(W + off[j], wn);
+            if (OPT == 1) { st4n<(LPR >= 32)>(Mo + off[j], m[j]); st4n<(LPR >= 32)>(Vo + off[j], v[j]); }
+            st4n<(LPR >= 32)>(W + off[j], wn);
         }
     }
 }

@@ -64,6 +64,7 @@ class CoNet(CrossDomainRecommender):
 
     def train(self, mode=True):
         if mode:
+            self.__dict__.pop('_eval_frozen', None)
             self._drop_eval_cache()
         return super().train(mode)
 
@@ -72,10 +73,36 @@ class CoNet(CrossDomainRecommender):
         self.__dict__.pop('_eval_P', None)
         self.__dict__.pop('_eval_few', None)
 
+    # The caches are only ever built and used between ``freeze_for_eval()`` and ``unfreeze_eval()`` -- the caller's promise that no
+    # parameter changes in between (CrossDomainTrainer.evaluate brackets its loop of full_sort_predict calls with the pair).  Outside such
+    # a bracket every call recomputes from the live parameters, as the reference does (conet.py:171-181): an in-place parameter change under
+    # model.eval() -- an optimizer step, p.data.copy_(), an EMA swap, a native update through raw pointers -- is seen by the next call.
+    def freeze_for_eval(self):
+        self._drop_eval_cache()
+        self.__dict__['_eval_frozen'] = True
+        return self
+
+    def unfreeze_eval(self):
+        self.__dict__.pop('_eval_frozen', None)
+        self._drop_eval_cache()
+        return self
+
+    def _eval_caching(self):
+        return (not self.training) and bool(self.__dict__.get('_eval_frozen', False))
+
+    def __getstate__(self):
+        # copy.deepcopy / pickle / torch.save(model): the caches hold ctypes pointers (not picklable) and are cheap to rebuild
+        st = dict(self.__dict__)
+        for k in ('_eval_P', '_eval_few', '_eval_frozen'):
+            st.pop(k, None)
+        return st
+
     def on_train_steps(self):
+        self.__dict__.pop('_eval_frozen', None)
         self._drop_eval_cache()
 
     def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop('_eval_frozen', None)
         self._drop_eval_cache()
         return super().load_state_dict(*args, **kwargs)
 
@@ -214,7 +241,8 @@ class CoNet(CrossDomainRecommender):
         over the N rows -- instead of the reference's Python loop over users with a repeat()ed [N, 2D] input."""
         D = self.latent_dim
         self.sync_tables()
-        few = None if self.training else self.__dict__.get('_eval_few')
+        caching = self._eval_caching()
+        few = self.__dict__.get('_eval_few') if caching else None
         uid = interaction[self.TARGET_USER_ID]
         if few is not None and few.takes(uid):
             lin1, lo = self.target_crossunit_linear[0], self.target_outputunit[0]
@@ -228,12 +256,12 @@ class CoNet(CrossDomainRecommender):
         items = self.target_item_embedding.weight[:self.target_num_items]
         lin1 = self.target_crossunit_linear[0]
         W1 = lin1.weight                                              # [h1, 2D]
-        # P depends on the item table and W1 only: in evaluation mode (recbole's evaluate calls full_sort_predict once per user batch --
-        # one user per call at the default eval_batch_size) it is formed once and kept until the model trains again
-        P = None if self.training else self.__dict__.get('_eval_P')
+        # P depends on the item table and W1 only: inside a freeze_for_eval() bracket (recbole's evaluate calls full_sort_predict once per
+        # user batch -- one user per call at the default eval_batch_size) it is formed once and kept until the bracket closes
+        P = self.__dict__.get('_eval_P') if caching else None
         if P is None:
-            P = F_.gemm(items, W1[:, D:], trans_b=True)                # [N, h1]
-            if not self.training:
+            P = F_.gemm(items, W1[:, D:], trans_b=True)                # [N, h1]  (this method runs under no_grad: no graph is kept with it)
+            if caching:
                 self.__dict__['_eval_P'] = P
         Q = F_.gemm(user_e, W1[:, :D], trans_b=True, bias=lin1.bias)    # [U, h1]
         tail = list(self.target_crossunit_linear)[1:]
@@ -242,7 +270,7 @@ class CoNet(CrossDomainRecommender):
             # every (user, item) pair through layers 2.. and the output unit in ONE launch, activations in registers
             # (csrc/cdr_conet_fullsort.hip) -- no per-user loop, no [N, h] intermediates
             lo = self.target_outputunit[0]
-            if not self.training and '_eval_few' not in self.__dict__:
+            if caching and '_eval_few' not in self.__dict__:
                 # recbole's evaluation enters here once per eval batch -- ONE user at the default eval_batch_size over a large catalogue:
                 # from the second call on such a call is one launch with Q formed inside it (cdr_conet_fullsort_users), arguments packed once
                 self.__dict__['_eval_few'] = F_.ConetFullsortFewUsers(P, self.target_user_embedding.weight, W1, lin1.bias, D, [l.weight for l in tail],

@@ -442,9 +442,16 @@ class Trainer:
         if fused and want > 0 and hasattr(eval_data, 'rebatch') and getattr(eval_data, 'step', want) < want:
             restore = eval_data.step                      # (the caller's cut comes back afterwards: another consumer may need [U, N] to fit)
             eval_data.rebatch(want)
+        # the model's evaluation-mode caches (CoNet: the item half of layer 1, the packed one-user call) live exactly as long as this loop:
+        # nothing trains inside it
+        frozen = hasattr(self.model, 'freeze_for_eval')
+        if frozen:
+            self.model.freeze_for_eval()
         try:
             return self._evaluate_batches(eval_data, fused, kmax)
         finally:
+            if frozen:
+                self.model.unfreeze_eval()
             if restore is not None:
                 eval_data.rebatch(restore)
 

@@ -373,8 +373,23 @@ def test_conet_full_sort_predict_few_users_in_eval_mode_is_the_one_launch_call_a
     one = {'target_user_id': torch.tensor([7], device=DEV)}
     many = {'target_user_id': torch.arange(1, 41, device=DEV)}
     with torch.no_grad():
+        # outside a freeze_for_eval() bracket nothing is cached: an in-place parameter change under eval() is seen by the next call, as in
+        # the reference -- through the tensor, through .data and through a raw-pointer write alike
+        s0 = model.full_sort_predict(one)
+        assert '_eval_few' not in model.__dict__ and '_eval_P' not in model.__dict__
+        model.target_item_embedding.weight.data[5].mul_(3.0)
+        model.target_crossunit_linear[0].weight.data.mul_(1.25)
+        s1 = model.full_sort_predict(one)
+        assert float((s1 - s0).abs().max()) > 0
+        import copy
+        import pickle
+        model.freeze_for_eval()
         ref_many = model.full_sort_predict(many)                      # general path; builds the caches
         assert '_eval_few' in model.__dict__ and '_eval_P' in model.__dict__
+        twin = copy.deepcopy(model)                                   # a best-model copy after validation: the caches (ctypes pointers) stay behind
+        assert '_eval_few' not in twin.__dict__ and '_eval_P' not in twin.__dict__ and not twin._eval_caching()
+        assert_close(twin.full_sort_predict(one), ref_many[6:7], rtol=1e-5, what='deep copy scores')
+        pickle.loads(pickle.dumps(model))
         got = model.full_sort_predict(one)                            # one launch
         assert_close(got, ref_many[6:7], rtol=1e-5, what='few users vs general path')
         five = {'target_user_id': torch.tensor([3, 9, 9, 40, 1], device=DEV)}
@@ -385,6 +400,8 @@ def test_conet_full_sort_predict_few_users_in_eval_mode_is_the_one_launch_call_a
             p.mul_(0.5)
         model.target_user_embedding.weight[7].mul_(2.0)
         model.eval()
+        assert not model._eval_caching()                              # train() closed the bracket
+        model.freeze_for_eval()
         a = model.full_sort_predict(one)                              # general path again (rebuilds), then the one-launch call
         b = model.full_sort_predict(one)
         assert_close(b, a, rtol=1e-5, what='after training: few users vs general path')

@@ -29,7 +29,7 @@ for N in (18564, 1_000_001):
         from recbole_cdr_amd import functional as F_
         F_.ConetFullsortFewUsers.MAX_PAIRS = 1 << 40                 # (time the one-launch call at every size; the product stops at 262,144 pairs)
         for name in ('few_users_one_launch', 'general_three_launches'):
-            model._drop_eval_cache()
+            model.freeze_for_eval()                          # (drops the caches and opens the bracket CrossDomainTrainer.evaluate opens)
             with torch.no_grad():
                 model.full_sort_predict({model.TARGET_USER_ID: torch.arange(1, 20, device=dev)})      # builds P (+ the packed call)
                 if name.startswith('general'):
