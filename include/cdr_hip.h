@@ -45,6 +45,16 @@ const char* cdr_last_error(void);
  * autograd's zeros_like + embedding backward do in the reference (emcdr.py:123-131 under loss.backward()) -- cleared under the
  * forward's gathers instead of by a fill launch of their own.  One pending region per context; consumed by that launch. */
 int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
+/* Ids without a sort (round 6; the medium batches of SURVEY 8d's grid, emcdr.py:110-131 at B = 16,448 ... 131,072 triples): hand the context
+ * one uint32 occurrence counter per row of the two tables the NEXT cdr_bpr_step_fused / _dev calls train (ALL ZERO on entry; every step leaves
+ * them all zero) and a list workspace of cdr_id_count_workspace_bytes(B) bytes.  The step then derives its single-occurrence flags from the
+ * counters and sorts only the duplicate occurrences (a few hundred of 196,608 at uniform ids) -- same flags, same duplicate segments in the
+ * same occurrence order, bit-equal tables; heads[2] / heads[3] of the step's `heads` buffer report the duplicate occurrences and the largest
+ * counter of the batch (the sorted path reports heads[2] only), so that a host can move a heavily skewed stream back to the sorted path
+ * (NULL counters).  Row counts are checked against the step's own; a mismatch, a batch outside the range or a short workspace take the sorted path. */
+int cdr_ctx_set_id_counters(cdr_ctx* ctx, uint32_t* user_counts, int64_t user_rows, uint32_t* item_counts, int64_t item_rows,
+                            void* list_ws, size_t list_ws_bytes);
+int cdr_id_count_workspace_bytes(int64_t B, size_t* bytes);
 #define CDR_ABI_VERSION 55
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 

@@ -69,6 +69,8 @@ _SIGNATURES = {
     'cdr_ctx_destroy': [_c_ptr],
     'cdr_abi_version': [],
     'cdr_ctx_scrub_next': [_c_ptr, _c_ptr, ctypes.c_size_t],
+    'cdr_ctx_set_id_counters': [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, ctypes.c_size_t],
+    'cdr_id_count_workspace_bytes': [_c_i64, ctypes.POINTER(ctypes.c_size_t)],
     'cdr_bpr_fwd': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr, _c_ptr],
     'cdr_bpr_bwd_dense': [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_f32,
                           _c_ptr, _c_ptr, _c_ptr],

@@ -19,6 +19,11 @@ struct cdr_ctx {
     size_t scratch_bytes;
     void* scrub_ptr;                         // cdr_ctx_scrub_next: a region the NEXT forward launch on this context zero-fills on the side
     size_t scrub_bytes;
+    // cdr_ctx_set_id_counters: per-row occurrence counters of the NEXT fused BPR steps' two tables (all zero between steps) and the
+    // duplicate list's workspace -- the count path of the medium-batch step (csrc/cdr_step.hip, "ids without a sort")
+    uint32_t* idc_user; int64_t idc_user_rows;
+    uint32_t* idc_item; int64_t idc_item_rows;
+    void* idc_list; size_t idc_list_bytes;
     // optional HIP-event brackets around the hot kernels, recorded on the launch stream (cdr_timing_*)
     int timing_cap, timing_n;
     hipEvent_t* ev0;

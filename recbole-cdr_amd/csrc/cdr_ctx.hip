@@ -34,6 +34,7 @@ extern "C" int cdr_ctx_create(int device, cdr_ctx** out) {
     c->scratch = nullptr;
     c->scratch_bytes = 0;
     c->scrub_ptr = nullptr; c->scrub_bytes = 0;
+    c->idc_user = c->idc_item = nullptr; c->idc_user_rows = c->idc_item_rows = 0; c->idc_list = nullptr; c->idc_list_bytes = 0;
     c->partials = nullptr;
     c->tickets = nullptr;
     hipError_t e = hipMalloc(&c->partials, sizeof(double) * CDR_MAX_PARTIAL_BLOCKS * CDR_PARTIAL_STRIDE);
@@ -114,5 +115,21 @@ extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
 extern "C" int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes) {
     CDR_CHECK_ARG(ctx && ptr && bytes > 0 && (bytes & 15) == 0 && ((uintptr_t)ptr & 15) == 0);
     ctx->scrub_ptr = ptr; ctx->scrub_bytes = bytes;
+    return CDR_OK;
+}
+
+// The count path of the fused BPR step (cdr_bpr_step_fused / _dev, 16,448 <= B <= 131,072): per-row occurrence counters for the two tables
+// the NEXT steps on this context train (uint32 [rows] each, ALL ZERO on entry and left all zero by every step) and the duplicate list's
+// workspace (cdr_id_count_workspace_bytes).  NULL counters switch back to the sorted path.  The step checks the row counts against its own.
+extern "C" int cdr_ctx_set_id_counters(cdr_ctx* ctx, uint32_t* user_counts, int64_t user_rows, uint32_t* item_counts, int64_t item_rows,
+                                       void* list_ws, size_t list_ws_bytes) {
+    CDR_CHECK_ARG(ctx != nullptr);
+    if (!user_counts || !item_counts || !list_ws) {
+        ctx->idc_user = ctx->idc_item = nullptr; ctx->idc_user_rows = ctx->idc_item_rows = 0; ctx->idc_list = nullptr; ctx->idc_list_bytes = 0;
+        return CDR_OK;
+    }
+    CDR_CHECK_ARG(user_rows > 0 && item_rows > 0 && list_ws_bytes > 0);
+    ctx->idc_user = user_counts; ctx->idc_user_rows = user_rows; ctx->idc_item = item_counts; ctx->idc_item_rows = item_rows;
+    ctx->idc_list = list_ws; ctx->idc_list_bytes = list_ws_bytes;
     return CDR_OK;
 }

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ headsA, uint32_t* __restrict__ headsB,
                                                            unsigned* __restrict__ cnt) {
     constexpr int NW = kBlock / 64;
-    __shared__ unsigned wcnt[2][NW], wbase[2][NW];
+    __shared__ unsigned wcnt[3][NW], wbase[2][NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t base = (int64_t)blockIdx.x * kBlock * kFlagIT; base < n; base += (int64_t)gridDim.x * kBlock * kFlagIT) {
         const int64_t q0 = base + (int64_t)threadIdx.x * kFlagIT;
@@ -565,13 +565,14 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
         }
 #pragma unroll
         for (int j = 0; j < kFlagIT; ++j) o[j] = q0 + j < n ? perm[q0 + j] : 0u;
-        unsigned hA = 0, hB = 0;                           // bit j: position q0 + j heads a duplicate segment
+        unsigned hA = 0, hB = 0, nd = 0;                   // bit j: position q0 + j heads a duplicate segment; nd: positions that are not alone
 #pragma unroll
         for (int j = 0; j < kFlagIT; ++j) {
             const int64_t q = q0 + j;
             if (q < n) {
                 const uint32_t row = k[j + 1];
                 const bool first = q == 0 || k[j] != row, last = q + 1 >= n || k[j + 2] != row;
+                nd += (first && last) ? 0u : 1u;
                 if (q < nA) {
                     flags[(int64_t)fstride * o[j]] = (uint8_t)(first && last);
                     hA |= (unsigned)(first && !last) << j;
@@ -592,8 +593,15 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
             const unsigned a = __shfl_up(pA, d, 64), b = __shfl_up(pB, d, 64);
             if (lane >= d) { pA += a; pB += b; }
         }
-        if (lane == 63) { wcnt[0][wave] = pA; wcnt[1][wave] = pB; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) nd += __shfl_xor(nd, d, 64);
+        if (lane == 63) { wcnt[0][wave] = pA; wcnt[1][wave] = pB; wcnt[2][wave] = nd; }
         __syncthreads();
+        if (threadIdx.x == 2) {                                // cnt[2] += duplicate occurrences: the host binding's statistic (which id path serves this stream)
+            unsigned tot = 0;
+            for (int w = 0; w < NW; ++w) tot += wcnt[2][w];
+            if (tot) atomicAdd(&cnt[2], tot);
+        }
         if (threadIdx.x < 2) {
             const int t = threadIdx.x;
             unsigned tot = 0;
@@ -1286,7 +1294,7 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
         const uint32_t row = keys[q];
         const uint32_t before = keys[q > 0 ? q - 1 : 0];
         const uint32_t far = keys[q + kLongSeg];
-        if ((q > 0 && before == row) || far != row) continue;
+        if ((q > 0 && before == row) || far != row || row == ~0u) continue;       // (~0: the count path's filler behind the duplicate entries)
         int64_t lo = q + kLongSeg, hi = n;
         while (lo + 1 < hi) {
             const int64_t mid = (lo + hi) >> 1;
@@ -1652,6 +1660,173 @@ __global__ __launch_bounds__(kBlock) void sorted_run_keys_kernel(const int64_t* 
     }
 }
 
+// ================================================================================================ round 6: ids without a sort (medium batches)
+// At 65,536 triples the step's id work -- make_keys + nine rocPRIM launches + occurrence flags, 72 us -- was a third of the step, to find
+// the few hundred duplicate occurrences of a uniform batch.  With one uint32 counter per table row (all zero between steps):
+//   batch_norms_count_kernel   the EmbLoss norms pass also counts every occurrence (atomicAdd, integer: order-independent) and fills the
+//                              duplicate arrays with the sentinel key
+//   count_flags_kernel         per triple: a row whose counter reads 1 occurs once (the same flag byte occ_flags_kernel derives from the
+//                              sorted keys); every other occurrence is appended to a list as {key, occurrence}
+//   count_sort_kernel          block 0 sorts that list by (key, occurrence) -- in LDS up to 16,384 entries, in global memory beyond (slow,
+//                              correct: the host binding moves a stream with that many duplicates back to the sorted path) -- and writes
+//                              it out in the sorted path's layout (users at keys[0..), items at keys[B..), heads of every run); the other
+//                              blocks put the counters back to zero.
+// Same flags, same segments in the same occurrence order as the sorted path: the forward-and-update kernel and the segmented applies
+// behind it run unchanged, on identical operands -- bit-equal tables.  (Hashing the ids into a small table instead of one counter per row
+// was measured first, tools/r06/mb_atomics.hip / profiles/r06_mb_atomics.txt: 33.9 us for the insert of 196,608 keys alone.)
+constexpr int64_t kCountMinB = 16448, kCountMaxB = 131072;
+constexpr int kCountLds = 16384;                      // duplicate occurrences block 0 sorts in LDS (128 KB of {key, occurrence} words)
+
+template <int LPR, bool NORMS>
+__global__ __launch_bounds__(kBlock) void batch_norms_count_kernel(const float* __restrict__ U, const float* __restrict__ I, int D,
+                                                                   const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
+                                                                   const int64_t* __restrict__ nid, int64_t B, uint32_t* __restrict__ cu,
+                                                                   uint32_t* __restrict__ ci, uint32_t* __restrict__ keysD,
+                                                                   double* __restrict__ partials) {
+    constexpr int GPB = kBlock / LPR;
+    constexpr int UNR = 8;
+    __shared__ double smem[2 * (kBlock / 64)];
+    const int sub = threadIdx.x % LPR;
+    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const bool live = sub < (D >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < 3 * B; i += (int64_t)gridDim.x * kBlock) keysD[i] = ~0u;
+    double acc[2] = {0.0, 0.0};
+    for (int64_t base = gg; base < B; base += TG * UNR) {
+        int64_t iu[UNR], ip[UNR], in[UNR];
+        float4 u[UNR], p[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            const int64_t tc = t < B ? t : B - 1;
+            iu[r] = uid[tc]; ip[r] = pid[tc]; in[r] = nid[tc];
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int64_t t = base + (int64_t)r * TG;
+            u[r] = p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NORMS && t < B && live) { u[r] = ld4(U + iu[r] * D + 4 * sub); p[r] = ld4(I + ip[r] * D + 4 * sub); }
+            if (t < B && sub == 0) { atomicAdd(cu + iu[r], 1u); atomicAdd(ci + ip[r], 1u); atomicAdd(ci + in[r], 1u); }
+        }
+        if (NORMS) {
+#pragma unroll
+            for (int r = 0; r < UNR; ++r) {
+                const float su = group_sum<LPR>(dot4(u[r], u[r])), sp = group_sum<LPR>(dot4(p[r], p[r]));
+                if (sub == 0) { acc[0] += (double)su; acc[1] += (double)sp; }
+            }
+        }
+    }
+    if (NORMS) {
+        block_sum_d<2>(acc, smem);
+        if (threadIdx.x == 0) {
+            double* o = partials + (size_t)blockIdx.x * CDR_PARTIAL_STRIDE;
+            o[0] = acc[0]; o[1] = acc[1];
+        }
+    }
+}
+
+// cnt[2] += duplicate occurrences (the list's length), cnt[3] = max(the largest counter seen): the host binding's statistics
+__global__ __launch_bounds__(kBlock) void count_flags_kernel(const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
+                                                             const int64_t* __restrict__ nid, int64_t B, const uint32_t* __restrict__ cu,
+                                                             const uint32_t* __restrict__ ci, uint32_t key_base, uint32_t* __restrict__ flags4,
+                                                             uint64_t* __restrict__ list, unsigned* __restrict__ cnt) {
+    constexpr int NW = kBlock / 64;
+    __shared__ unsigned wtot[NW], wbase[NW], wmax[NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t t0 = (int64_t)blockIdx.x * kBlock; t0 < B; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t t = t0 + threadIdx.x;
+        uint32_t u = 0, p = 0, n = 0, c0 = 1, c1 = 1, c2 = 1;
+        if (t < B) {
+            u = (uint32_t)uid[t]; p = (uint32_t)pid[t]; n = (uint32_t)nid[t];
+            c0 = cu[u]; c1 = ci[p]; c2 = ci[n];
+            flags4[t] = (c0 == 1u ? 1u : 0u) | (c1 == 1u ? 0x100u : 0u) | (c2 == 1u ? 0x10000u : 0u);
+        }
+        const unsigned mine = (c0 != 1u) + (c1 != 1u) + (c2 != 1u);
+        unsigned incl = mine, mx = c0 > c1 ? (c0 > c2 ? c0 : c2) : (c1 > c2 ? c1 : c2);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned a = __shfl_up(incl, d, 64), b = __shfl_xor(mx, d, 64);
+            if (lane >= d) incl += a;
+            mx = mx > b ? mx : b;
+        }
+        if (lane == 63) { wtot[wave] = incl; wmax[wave] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0, m = 0;
+            for (int w = 0; w < NW; ++w) { wbase[w] = tot; tot += wtot[w]; m = m > wmax[w] ? m : wmax[w]; }
+            const unsigned b = tot ? atomicAdd(&cnt[2], tot) : 0u;
+            for (int w = 0; w < NW; ++w) wbase[w] += b;
+            if (m > 1u) atomicMax(&cnt[3], m);
+        }
+        __syncthreads();
+        unsigned at = wbase[wave] + incl - mine;
+        if (c0 != 1u) list[at++] = ((uint64_t)u << 32) | (uint32_t)t;
+        if (c1 != 1u) list[at++] = ((uint64_t)(key_base + p) << 32) | (uint32_t)t;
+        if (c2 != 1u) list[at++] = ((uint64_t)(key_base + n) << 32) | (uint32_t)(B + t);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void count_sort_kernel(const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
+                                                          const int64_t* __restrict__ nid, int64_t B, uint32_t* __restrict__ cu,
+                                                          uint32_t* __restrict__ ci, uint32_t key_base, uint64_t* __restrict__ list,
+                                                          uint32_t* __restrict__ keysD, uint32_t* __restrict__ permD,
+                                                          uint32_t* __restrict__ headsA, uint32_t* __restrict__ headsB,
+                                                          unsigned* __restrict__ cnt) {
+    if (blockIdx.x != 0) {                            // every counter this batch touched back to zero (the flags have been taken)
+        const int64_t nth = (int64_t)(gridDim.x - 1) * 1024;
+        for (int64_t t = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; t < B; t += nth) { cu[uid[t]] = 0u; ci[pid[t]] = 0u; ci[nid[t]] = 0u; }
+        return;
+    }
+    extern __shared__ uint64_t srt[];
+    __shared__ unsigned nA_s, hA_s, hB_s;
+    const unsigned nd = cnt[2];
+    if (nd == 0u) return;                             // cnt[0] = cnt[1] = 0 already (coef_finish_kernel)
+    unsigned P = 1024;
+    while (P < nd) P <<= 1;
+    const bool in_lds = nd <= (unsigned)kCountLds;
+    uint64_t* A = in_lds ? srt : list;
+    if (in_lds) { for (unsigned i = threadIdx.x; i < P; i += 1024) srt[i] = i < nd ? list[i] : ~0ull; }
+    else { for (unsigned i = nd + threadIdx.x; i < P; i += 1024) list[i] = ~0ull; }
+    if (threadIdx.x == 0) { hA_s = 0u; hB_s = 0u; }
+    __syncthreads();
+    for (unsigned k = 2; k <= P; k <<= 1) {           // bitonic network, ascending; global-memory passes are fenced by the barrier
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned i = threadIdx.x; i < P; i += 1024) {
+                const unsigned l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = A[i], b = A[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { A[i] = b; A[l] = a; }
+                }
+            }
+            if (!in_lds) __threadfence_block();
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {                           // users sort in front of the items (their keys lack the table bit)
+        unsigned lo = 0, hi = nd;
+        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if ((uint32_t)(A[mid] >> 32) < key_base) lo = mid + 1; else hi = mid; }
+        nA_s = lo;
+    }
+    __syncthreads();
+    const unsigned nA = nA_s;
+    for (unsigned i = threadIdx.x; i < nd; i += 1024) {
+        const uint64_t e = A[i];
+        const uint32_t key = (uint32_t)(e >> 32), occ = (uint32_t)e;
+        const bool head = i == 0u || (uint32_t)(A[i - 1] >> 32) != key;
+        if (i < nA) {
+            keysD[i] = key; permD[i] = occ;
+            if (head) headsA[atomicAdd(&hA_s, 1u)] = i;
+        } else {
+            keysD[B + (i - nA)] = key; permD[B + (i - nA)] = occ;
+            if (head) headsB[atomicAdd(&hB_s, 1u)] = i - nA;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt[0] = hA_s; cnt[1] = hB_s; }
+}
+
 }  // namespace
 
 #define DISPATCH_LPR(lpr, ...)                                  \
@@ -1959,6 +2134,50 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
                                void* sort_ws, size_t sort_ws_bytes) {
     hipStream_t s = (hipStream_t)stream;
     const int lpr = cdr_lpr_for(D);
+    unsigned* cnt = (unsigned*)heads;
+    uint32_t* headsA = heads + 4;
+    uint32_t* headsB = headsA + (B / 2 + 1);           // (cnt[0..3] are cleared by coef_finish_kernel)
+    uint32_t key_base = 0;
+    int rc;
+    // ---- ids without a sort (medium batches, counters handed over by cdr_ctx_set_id_counters): see "round 6: ids without a sort"
+    int64_t P = 1024;
+    while (P < 3 * B) P <<= 1;
+    const bool count_path = ctx->idc_user && ctx->idc_item && ctx->idc_user_rows == user_rows && ctx->idc_item_rows == item_rows &&
+                            B >= kCountMinB && B <= kCountMaxB && ctx->idc_list_bytes >= (size_t)P * sizeof(uint64_t);
+    if (count_path) {
+        const unsigned hb = bits_for(user_rows) > bits_for(item_rows) ? bits_for(user_rows) : bits_for(item_rows);
+        CDR_CHECK_ARG(hb < 31);
+        key_base = 1u << hb;
+        const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
+        {
+            cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
+            if (reg_weight != 0.f) {
+                DISPATCH_LPR(lpr, batch_norms_count_kernel<L, true><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B, ctx->idc_user,
+                                                                                                      ctx->idc_item, keys, ctx->partials));
+            } else {
+                DISPATCH_LPR(lpr, batch_norms_count_kernel<L, false><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B, ctx->idc_user,
+                                                                                                       ctx->idc_item, keys, ctx->partials));
+            }
+        }
+        CDR_LAUNCH_CHECK();
+        coef_finish_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, reg_weight != 0.f ? ngrid : 0, B, reg_weight, out9, 1, step_user_dev, step_item_dev, hp_dev,
+                                                            lr, beta1, beta2, cnt);
+        CDR_LAUNCH_CHECK();
+        {
+            cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
+            count_flags_kernel<<<dim3(grid_for(B, kBlock)), dim3(kBlock), 0, s>>>(uid, pid, nid, B, ctx->idc_user, ctx->idc_item, key_base, (uint32_t*)flags,
+                                                                                 (uint64_t*)ctx->idc_list, cnt);
+            CDR_LAUNCH_CHECK();
+            static const bool lds_ok = [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&count_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kCountLds * (int)sizeof(uint64_t)) == hipSuccess;
+            }();
+            CDR_CHECK_ARG(lds_ok);
+            count_sort_kernel<<<dim3(1 + 128), dim3(1024), kCountLds * sizeof(uint64_t), s>>>(uid, pid, nid, B, ctx->idc_user, ctx->idc_item, key_base,
+                                                                                            (uint64_t*)ctx->idc_list, keys, perm, headsA, headsB, cnt);
+        }
+        CDR_LAUNCH_CHECK();
+    } else {
     // ---- EmbLoss coefficients first (they do not need the sort): out9[4], out9[5]  (+ the device-resident update counts, when given)
     if (reg_weight != 0.f) {
         const int ngrid = grid_for((B + 7) / 8, kBlock / lpr);
@@ -1974,18 +2193,15 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
                                                             (unsigned*)heads);
     }
     CDR_LAUNCH_CHECK();
-    uint32_t key_base = 0;
-    int rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, pid, B, nid, B, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
+    rc = cdr_sort_ids_two_tables(ctx, stream, uid, B, user_rows, pid, B, nid, B, item_rows, keys, perm, &key_base, sort_ws, sort_ws_bytes);
     if (rc) return rc;
-    unsigned* cnt = (unsigned*)heads;
-    uint32_t* headsA = heads + 4;
-    uint32_t* headsB = headsA + (B / 2 + 1);           // (cnt[0..3] were cleared by coef_finish_kernel)
     const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
     {
         cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
         occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, 4, flags, headsA, headsB, cnt);
     }
     CDR_LAUNCH_CHECK();
+    }
     apply_hp hu = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_user);
     apply_hp hi = make_hp(opt, lr, beta1, beta2, eps, weight_decay, step_item);
     if (hp_dev && opt == 1) { hu.dev = hp_dev; hi.dev = hp_dev + 2; }          // the scalars coef_finish_kernel left on the device
@@ -2009,6 +2225,14 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
     step_finish_keep_kernel<<<dim3(1), dim3(kBlock), 0, s>>>(ctx->partials, grid, B, reg_weight, out9, pl.side[0].counters, pl.side[1].counters);
     CDR_LAUNCH_CHECK();
     return apply_dups_pair(ctx, s, opt, D, pl);
+}
+
+extern "C" int cdr_id_count_workspace_bytes(int64_t B, size_t* bytes) {
+    CDR_CHECK_ARG(bytes && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
+    int64_t P = 1024;
+    while (P < 3 * B) P <<= 1;
+    *bytes = (size_t)P * sizeof(uint64_t);
+    return CDR_OK;
 }
 
 extern "C" int cdr_bpr_step_fused(cdr_ctx* ctx, void* stream, int opt, float* user_tab, float* user_m, float* user_v, int64_t user_rows,

@@ -58,7 +58,8 @@ class FusedBPRStep:
     """One object per (user table, item table) pair; buffers are sized for ``max_batch`` triples and reused."""
 
     def __init__(self, user_table, item_table, max_batch, opt='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True, device_counts=True):
+                 weight_decay=0.0, gamma=1e-10, reg_weight=0.0, user_state=None, item_state=None, fuse_singles=True, device_counts=True,
+                 id_path='auto'):
         assert user_table.is_cuda and item_table.is_cuda, 'FusedBPRStep needs ROCm device tensors'
         assert user_table.shape[1] == item_table.shape[1]
         self.U, self.I = user_table, item_table
@@ -96,6 +97,56 @@ class FusedBPRStep:
             B_._check(B_.load().cdr_bpr_step_fused_heads_words(Bm, ctypes.byref(words)), 'cdr_bpr_step_fused_heads_words')
             self.flags = torch.zeros(4 * Bm, device=dev, dtype=torch.uint8)      # {user, positive, negative, -} per triple
             self.heads = torch.empty(int(words.value), device=dev, dtype=torch.int32)
+        # Ids without a sort (round 6, csrc/cdr_step.hip): batches of 16,448 ... 131,072 triples take their single-occurrence flags from one
+        # counter per table row and sort only the duplicate occurrences.  'auto': on, and moved to the sorted path (and back) by the
+        # duplicate statistics the step leaves in heads[2:4] -- read back asynchronously, one step late, never waited for; 'count' / 'sort' pin it.
+        self.id_path = os.environ.get('CDR_ID_PATH', id_path)
+        assert self.id_path in ('auto', 'count', 'sort')
+        self._count = None
+        self._use_count = self.id_path != 'sort'
+        self._stat = None
+
+    COUNT_MIN_B, COUNT_MAX_B = 16448, 131072
+
+    def _count_buffers(self):
+        if self._count is None:
+            dev = self.U.device
+            need = ctypes.c_size_t(0)
+            B_._check(B_.load().cdr_id_count_workspace_bytes(min(self.max_batch, self.COUNT_MAX_B), ctypes.byref(need)), 'cdr_id_count_workspace_bytes')
+            self._count = (torch.zeros(self.U.shape[0], device=dev, dtype=torch.int32), torch.zeros(self.I.shape[0], device=dev, dtype=torch.int32),
+                           torch.empty(int(need.value), device=dev, dtype=torch.uint8))
+        return self._count
+
+    def _select_id_path(self, B):
+        """Hands the counters to (or takes them from) the native context of the current stream before a fused step; folds in the statistics
+        of an EARLIER step if their copy has landed (never waits)."""
+        ctxh = B_.ctx(self.U.device)
+        in_range = self.fuse_singles and self.COUNT_MIN_B <= B <= self.COUNT_MAX_B
+        capturing = torch.cuda.is_current_stream_capturing()
+        if in_range and self.id_path == 'auto' and not capturing:
+            if self._stat is not None and self._stat[1].query():
+                nd, maxc = int(self._stat[0][2]), int(self._stat[0][3])
+                nB = self._stat[2]
+                if self._use_count and (nd > 12288 or maxc > 256):
+                    self._use_count = False                  # a skewed stream: same-address counter updates and a long duplicate list -- the sort serves it better
+                elif not self._use_count and nd <= 4096 and nd * 24 <= 3 * nB:
+                    self._use_count = True
+                self._stat = None
+        on = in_range and self._use_count
+        if on:
+            cu, ci, ws = self._count_buffers()
+            B_.call('cdr_ctx_set_id_counters', ctxh, B_.raw(cu), cu.numel(), B_.raw(ci), ci.numel(), B_.raw(ws), ws.numel())
+        else:
+            B_.call('cdr_ctx_set_id_counters', ctxh, None, 0, None, 0, None, 0)
+        return in_range and self.id_path == 'auto' and not capturing
+
+    def _note_stats(self, B):
+        if self._stat is None:
+            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            host.copy_(self.heads[:4], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stat = (host, ev, B)
 
     def step(self, uid, pid, nid):
         """uid/pid/nid: int64 device tensors [B].  Returns the device tensor out6 (view; [0] = total loss)."""
@@ -112,6 +163,17 @@ class FusedBPRStep:
         """Batch norms and sort first, then ONE pass that also applies the optimizer to every row occurring once in the batch; the
         segmented applies see the duplicate rows only (csrc/cdr_step.hip, "single-occurrence rows in the forward")."""
         us, its = self.ustate, self.istate
+        watch = self._select_id_path(B)
+        try:
+            return self._step_fused_call(uid, pid, nid, B, us, its)
+        finally:
+            # (the context is shared by every step object of this stream: it must not keep pointers into this object's buffers)
+            B_.call('cdr_ctx_set_id_counters', B_.ctx(self.U.device), None, 0, None, 0, None, 0)
+            self._steps_seen = self.__dict__.get('_steps_seen', 0) + 1
+            if watch and (self._steps_seen & 15) == 1:          # every 16th step: one 16-byte copy, read when it has landed
+                self._note_stats(B)
+
+    def _step_fused_call(self, uid, pid, nid, B, us, its):
         if self.opt == OPT_ADAM and self.device_counts:
             # the capturable form: the update counts live on the device and the call advances them itself (the host mirrors follow)
             if self._hp_dev is None:

@@ -580,7 +580,7 @@ def _bench_line_and_detail(p, tmp_path):
     return line, full
 
 
-@pytest.mark.parametrize('world,extra', [(2, []), (4, []), (8, []), (2, ['--shard', 'dim'])])
+@pytest.mark.parametrize('world,extra', [(2, []), pytest.param(4, [], marks=pytest.mark.slow_gpu), pytest.param(8, [], marks=pytest.mark.slow_gpu), (2, ['--shard', 'dim'])])
 def test_bench_multi_rank_line_contract(world, extra, tmp_path):
     """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one rank per process) -- here with every rank on
     cuda:0 over gloo (CDR_BENCH_SHARED_GPU=1, small tables): stdout is exactly ONE JSON line from rank 0 with the contract's
@@ -625,6 +625,7 @@ def test_bench_multi_rank_line_contract(world, extra, tmp_path):
         assert lay['row']['exchange']['bytes_to_other_ranks_per_step_per_rank'] > lay['dim']['exchange']['bytes_to_other_ranks_per_step_per_rank']
 
 
+@pytest.mark.slow_gpu
 @pytest.mark.parametrize('inject,used', [('row:raise@1', 'dim'), ('dim,row:raise@0', 'replicas')])
 def test_bench_multi_rank_layout_fallback(inject, used, tmp_path):
     """The first hardware run of `bench.py --gpus N` must not be losable: a layout that fails to come up on some
@@ -699,7 +700,8 @@ def test_bench_comm_cabi_falls_back_to_torch_when_the_communicator_does_not_come
     assert 'torch' in fb['comm'] and d['value'] > 0
 
 
-@pytest.mark.parametrize('inject,used', [('', 'rowshard'), ('rowshard:raise@1', 'replica-dp'), ('rowshard,replica-dp:raise@0', 'replicas')])
+@pytest.mark.parametrize('inject,used', [('', 'rowshard'), pytest.param('rowshard:raise@1', 'replica-dp', marks=pytest.mark.slow_gpu),
+                                         pytest.param('rowshard,replica-dp:raise@0', 'replicas', marks=pytest.mark.slow_gpu)])
 def test_bench_c4_multi_rank_layout_fallback(inject, used, tmp_path):
     """`bench.py --workload c4 --gpus 2` (BASELINE configs[3]: the row-sharded graph) under the same watchdog: rowshard -> replica data
     parallel -> independent replicas of the product's trainer loop; one JSON line either way.  cuda:0 shared over gloo."""
