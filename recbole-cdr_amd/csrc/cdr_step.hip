@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(kBlock) void sorted_run_keys_kernel(const int64_t* 
 // Same flags, same segments in the same occurrence order as the sorted path: the forward-and-update kernel and the segmented applies
 // behind it run unchanged, on identical operands -- bit-equal tables.  (Hashing the ids into a small table instead of one counter per row
 // was measured first, tools/r06/mb_atomics.hip / profiles/r06_mb_atomics.txt: 33.9 us for the insert of 196,608 keys alone.)
-constexpr int64_t kCountMinB = 16448, kCountMaxB = 131072;
+constexpr int64_t kCountMinB = 16448, kCountMaxB = 131072;    // (profiles/r06_mb_idpath.json: -29 % / -22 % / -9 % of the step at 32,768 / 65,536 / 131,072 uniform triples)
 constexpr int kCountLds = 16384;                      // duplicate occurrences block 0 sorts in LDS (128 KB of {key, occurrence} words)
 
 template <int LPR, bool NORMS>
@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(kBlock) void batch_norms_count_kernel(const float* 
                                                                    const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
                                                                    const int64_t* __restrict__ nid, int64_t B, uint32_t* __restrict__ cu,
                                                                    uint32_t* __restrict__ ci, uint32_t* __restrict__ keysD,
-                                                                   double* __restrict__ partials) {
+                                                                   uint64_t* __restrict__ list_hdr, double* __restrict__ partials) {
     constexpr int GPB = kBlock / LPR;
     constexpr int UNR = 8;
     __shared__ double smem[2 * (kBlock / 64)];
@@ -1691,6 +1691,7 @@ __global__ __launch_bounds__(kBlock) void batch_norms_count_kernel(const float* 
     const int64_t TG = (int64_t)gridDim.x * GPB;
     const bool live = sub < (D >> 2);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < 3 * B; i += (int64_t)gridDim.x * kBlock) keysD[i] = ~0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) list_hdr[0] = 0ull;          // the users' share of the duplicate list (count_flags_kernel)
     double acc[2] = {0.0, 0.0};
     for (int64_t base = gg; base < B; base += TG * UNR) {
         int64_t iu[UNR], ip[UNR], in[UNR];
@@ -1725,13 +1726,16 @@ __global__ __launch_bounds__(kBlock) void batch_norms_count_kernel(const float* 
     }
 }
 
-// cnt[2] += duplicate occurrences (the list's length), cnt[3] = max(the largest counter seen): the host binding's statistics
+// cnt[2] += duplicate occurrences (the list's length), cnt[3] = max(the largest counter seen): the host binding's statistics.
+// list = {header: hdr[0] = the users' share of the list | 7 spare words | entries {key << 32 | occurrence}}
+constexpr int kListHdr = 8;
 __global__ __launch_bounds__(kBlock) void count_flags_kernel(const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
                                                              const int64_t* __restrict__ nid, int64_t B, const uint32_t* __restrict__ cu,
                                                              const uint32_t* __restrict__ ci, uint32_t key_base, uint32_t* __restrict__ flags4,
-                                                             uint64_t* __restrict__ list, unsigned* __restrict__ cnt) {
+                                                             uint64_t* __restrict__ list_hdr, unsigned* __restrict__ cnt) {
     constexpr int NW = kBlock / 64;
-    __shared__ unsigned wtot[NW], wbase[NW], wmax[NW];
+    __shared__ unsigned wtot[NW], wbase[NW], wmax[NW], wusr[NW];
+    uint64_t* __restrict__ list = list_hdr + kListHdr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t t0 = (int64_t)blockIdx.x * kBlock; t0 < B; t0 += (int64_t)gridDim.x * kBlock) {
         const int64_t t = t0 + threadIdx.x;
@@ -1742,21 +1746,23 @@ __global__ __launch_bounds__(kBlock) void count_flags_kernel(const int64_t* __re
             flags4[t] = (c0 == 1u ? 1u : 0u) | (c1 == 1u ? 0x100u : 0u) | (c2 == 1u ? 0x10000u : 0u);
         }
         const unsigned mine = (c0 != 1u) + (c1 != 1u) + (c2 != 1u);
-        unsigned incl = mine, mx = c0 > c1 ? (c0 > c2 ? c0 : c2) : (c1 > c2 ? c1 : c2);
+        unsigned incl = mine, mx = c0 > c1 ? (c0 > c2 ? c0 : c2) : (c1 > c2 ? c1 : c2), usr = c0 != 1u ? 1u : 0u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const unsigned a = __shfl_up(incl, d, 64), b = __shfl_xor(mx, d, 64);
+            const unsigned a = __shfl_up(incl, d, 64), b = __shfl_xor(mx, d, 64), c = __shfl_xor(usr, d, 64);
             if (lane >= d) incl += a;
             mx = mx > b ? mx : b;
+            usr += c;
         }
-        if (lane == 63) { wtot[wave] = incl; wmax[wave] = mx; }
+        if (lane == 63) { wtot[wave] = incl; wmax[wave] = mx; wusr[wave] = usr; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned tot = 0, m = 0;
-            for (int w = 0; w < NW; ++w) { wbase[w] = tot; tot += wtot[w]; m = m > wmax[w] ? m : wmax[w]; }
+            unsigned tot = 0, m = 0, ut = 0;
+            for (int w = 0; w < NW; ++w) { wbase[w] = tot; tot += wtot[w]; m = m > wmax[w] ? m : wmax[w]; ut += wusr[w]; }
             const unsigned b = tot ? atomicAdd(&cnt[2], tot) : 0u;
             for (int w = 0; w < NW; ++w) wbase[w] += b;
             if (m > 1u) atomicMax(&cnt[3], m);
+            if (ut) atomicAdd((unsigned long long*)&list_hdr[0], (unsigned long long)ut);
         }
         __syncthreads();
         unsigned at = wbase[wave] + incl - mine;
@@ -1767,30 +1773,87 @@ __global__ __launch_bounds__(kBlock) void count_flags_kernel(const int64_t* __re
     }
 }
 
+// blocks [0, kRankBlocks): the duplicate list into sorted order.  Up to kCountLds entries by RANK: a block owns 64 entries, one WAVE per
+// sixteenth of the list each, and counts for every entry the entries below it ((key, occurrence) words are distinct) while the whole list
+// passes through LDS in tiles -- the n^2 compares spread over the chip (first cut: 256 entries per block, 1,741 entries on SEVEN CUs, 25 us;
+// a one-workgroup bitonic network before that: 35 us at 2,048 entries, 250 us at 8,192); an entry with no smaller occurrence of its key
+// heads its segment.  Beyond kCountLds entries block 0 alone sorts in global memory (slow, correct).
+// blocks [kRankBlocks, ...): every counter this batch touched back to zero (the flags have been taken).
+constexpr int kRankEPB = 64, kRankParts = 1024 / kRankEPB, kRankBlocks = kCountLds / kRankEPB, kRankTile = 2048;
 __global__ __launch_bounds__(1024) void count_sort_kernel(const int64_t* __restrict__ uid, const int64_t* __restrict__ pid,
                                                           const int64_t* __restrict__ nid, int64_t B, uint32_t* __restrict__ cu,
-                                                          uint32_t* __restrict__ ci, uint32_t key_base, uint64_t* __restrict__ list,
+                                                          uint32_t* __restrict__ ci, uint32_t key_base, uint64_t* __restrict__ list_hdr,
                                                           uint32_t* __restrict__ keysD, uint32_t* __restrict__ permD,
                                                           uint32_t* __restrict__ headsA, uint32_t* __restrict__ headsB,
                                                           unsigned* __restrict__ cnt) {
-    if (blockIdx.x != 0) {                            // every counter this batch touched back to zero (the flags have been taken)
-        const int64_t nth = (int64_t)(gridDim.x - 1) * 1024;
-        for (int64_t t = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; t < B; t += nth) { cu[uid[t]] = 0u; ci[pid[t]] = 0u; ci[nid[t]] = 0u; }
+    if ((int)blockIdx.x >= kRankBlocks) {
+        const int64_t nth = (int64_t)(gridDim.x - kRankBlocks) * 1024;
+        for (int64_t t = (int64_t)(blockIdx.x - kRankBlocks) * 1024 + threadIdx.x; t < B; t += nth) { cu[uid[t]] = 0u; ci[pid[t]] = 0u; ci[nid[t]] = 0u; }
         return;
     }
-    extern __shared__ uint64_t srt[];
+    __shared__ uint64_t tile[kRankTile];
+    __shared__ unsigned part_rank[kRankParts][kRankEPB], part_dup[kRankParts][kRankEPB];
     __shared__ unsigned nA_s, hA_s, hB_s;
+    uint64_t* __restrict__ list = list_hdr + kListHdr;
     const unsigned nd = cnt[2];
     if (nd == 0u) return;                             // cnt[0] = cnt[1] = 0 already (coef_finish_kernel)
+    if (nd <= (unsigned)kCountLds) {
+        const unsigned e0 = blockIdx.x * (unsigned)kRankEPB;
+        if (e0 >= nd) return;
+        const unsigned le = threadIdx.x % kRankEPB, part = threadIdx.x / kRankEPB;
+        const bool have = e0 + le < nd;
+        const uint64_t my = have ? list[e0 + le] : ~0ull;
+        const uint32_t mykey = (uint32_t)(my >> 32);
+        unsigned rank = 0, dup = 0;
+        for (unsigned t0 = 0; t0 < nd; t0 += kRankTile) {
+            for (unsigned i = threadIdx.x; i < (unsigned)kRankTile; i += 1024) tile[i] = t0 + i < nd ? list[t0 + i] : ~0ull;
+            __syncthreads();
+            const unsigned jb = part * (kRankTile / kRankParts);
+#pragma unroll 8
+            for (unsigned j = 0; j < (unsigned)(kRankTile / kRankParts); ++j) {
+                const uint64_t x = tile[jb + j];
+                const bool below = x < my;
+                rank += below ? 1u : 0u;
+                dup |= (below && (uint32_t)(x >> 32) == mykey) ? 1u : 0u;
+            }
+            __syncthreads();
+        }
+        part_rank[part][le] = rank; part_dup[part][le] = dup;
+        if (threadIdx.x == 0) { hA_s = 0u; hB_s = 0u; }
+        __syncthreads();
+        // heads are numbered inside the workgroup first (LDS), one reservation per list and workgroup on the global counters: a returning
+        // atomic per head on ONE word serialises at ~12 ns each (870 heads: 10 us of this launch's first 27)
+        unsigned r = 0, nA = 0, slot = 0;
+        bool head = false, isA = false;
+        if (part == 0 && have) {
+            unsigned dd = 0;
+#pragma unroll
+            for (int q = 0; q < kRankParts; ++q) { r += part_rank[q][le]; dd |= part_dup[q][le]; }
+            head = dd == 0u;
+            nA = (unsigned)list_hdr[0];
+            isA = r < nA;
+            if (isA) { keysD[r] = mykey; permD[r] = (uint32_t)my; }
+            else { keysD[B + (r - nA)] = mykey; permD[B + (r - nA)] = (uint32_t)my; }
+            if (head) slot = atomicAdd(isA ? &hA_s : &hB_s, 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { nA_s = hA_s ? atomicAdd(&cnt[0], hA_s) : 0u; part_rank[0][0] = hB_s ? atomicAdd(&cnt[1], hB_s) : 0u; }
+        __syncthreads();
+        if (head) {
+            if (isA) headsA[nA_s + slot] = r;
+            else headsB[part_rank[0][0] + slot] = r - nA;
+        }
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    // ---- a long list (a skewed stream the host binding has not yet moved to the sorted path): bitonic network in global memory
     unsigned P = 1024;
     while (P < nd) P <<= 1;
-    const bool in_lds = nd <= (unsigned)kCountLds;
-    uint64_t* A = in_lds ? srt : list;
-    if (in_lds) { for (unsigned i = threadIdx.x; i < P; i += 1024) srt[i] = i < nd ? list[i] : ~0ull; }
-    else { for (unsigned i = nd + threadIdx.x; i < P; i += 1024) list[i] = ~0ull; }
+    uint64_t* A = list;
+    for (unsigned i = nd + threadIdx.x; i < P; i += 1024) list[i] = ~0ull;
     if (threadIdx.x == 0) { hA_s = 0u; hB_s = 0u; }
     __syncthreads();
-    for (unsigned k = 2; k <= P; k <<= 1) {           // bitonic network, ascending; global-memory passes are fenced by the barrier
+    for (unsigned k = 2; k <= P; k <<= 1) {
         for (unsigned j = k >> 1; j > 0; j >>= 1) {
             for (unsigned i = threadIdx.x; i < P; i += 1024) {
                 const unsigned l = i ^ j;
@@ -1800,15 +1863,11 @@ __global__ __launch_bounds__(1024) void count_sort_kernel(const int64_t* __restr
                     if ((a > b) == up) { A[i] = b; A[l] = a; }
                 }
             }
-            if (!in_lds) __threadfence_block();
+            __threadfence_block();
             __syncthreads();
         }
     }
-    if (threadIdx.x == 0) {                           // users sort in front of the items (their keys lack the table bit)
-        unsigned lo = 0, hi = nd;
-        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if ((uint32_t)(A[mid] >> 32) < key_base) lo = mid + 1; else hi = mid; }
-        nA_s = lo;
-    }
+    if (threadIdx.x == 0) nA_s = (unsigned)list_hdr[0];
     __syncthreads();
     const unsigned nA = nA_s;
     for (unsigned i = threadIdx.x; i < nd; i += 1024) {
@@ -2143,7 +2202,7 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
     int64_t P = 1024;
     while (P < 3 * B) P <<= 1;
     const bool count_path = ctx->idc_user && ctx->idc_item && ctx->idc_user_rows == user_rows && ctx->idc_item_rows == item_rows &&
-                            B >= kCountMinB && B <= kCountMaxB && ctx->idc_list_bytes >= (size_t)P * sizeof(uint64_t);
+                            B >= kCountMinB && B <= kCountMaxB && ctx->idc_list_bytes >= (size_t)(P + kListHdr) * sizeof(uint64_t);
     if (count_path) {
         const unsigned hb = bits_for(user_rows) > bits_for(item_rows) ? bits_for(user_rows) : bits_for(item_rows);
         CDR_CHECK_ARG(hb < 31);
@@ -2153,10 +2212,10 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
             cdr_time_scope ts(ctx, CDR_TAG_BATCH_NORMS, s);
             if (reg_weight != 0.f) {
                 DISPATCH_LPR(lpr, batch_norms_count_kernel<L, true><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B, ctx->idc_user,
-                                                                                                      ctx->idc_item, keys, ctx->partials));
+                                                                                                      ctx->idc_item, keys, (uint64_t*)ctx->idc_list, ctx->partials));
             } else {
                 DISPATCH_LPR(lpr, batch_norms_count_kernel<L, false><<<dim3(ngrid), dim3(kBlock), 0, s>>>(user_tab, item_tab, D, uid, pid, nid, B, ctx->idc_user,
-                                                                                                       ctx->idc_item, keys, ctx->partials));
+                                                                                                       ctx->idc_item, keys, (uint64_t*)ctx->idc_list, ctx->partials));
             }
         }
         CDR_LAUNCH_CHECK();
@@ -2168,12 +2227,7 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
             count_flags_kernel<<<dim3(grid_for(B, kBlock)), dim3(kBlock), 0, s>>>(uid, pid, nid, B, ctx->idc_user, ctx->idc_item, key_base, (uint32_t*)flags,
                                                                                  (uint64_t*)ctx->idc_list, cnt);
             CDR_LAUNCH_CHECK();
-            static const bool lds_ok = [] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&count_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kCountLds * (int)sizeof(uint64_t)) == hipSuccess;
-            }();
-            CDR_CHECK_ARG(lds_ok);
-            count_sort_kernel<<<dim3(1 + 128), dim3(1024), kCountLds * sizeof(uint64_t), s>>>(uid, pid, nid, B, ctx->idc_user, ctx->idc_item, key_base,
+            count_sort_kernel<<<dim3(kRankBlocks + 128), dim3(1024), 0, s>>>(uid, pid, nid, B, ctx->idc_user, ctx->idc_item, key_base,
                                                                                             (uint64_t*)ctx->idc_list, keys, perm, headsA, headsB, cnt);
         }
         CDR_LAUNCH_CHECK();
@@ -2231,7 +2285,7 @@ extern "C" int cdr_id_count_workspace_bytes(int64_t B, size_t* bytes) {
     CDR_CHECK_ARG(bytes && B > 0 && 3 * B <= (int64_t)0x7FFFFFFF);
     int64_t P = 1024;
     while (P < 3 * B) P <<= 1;
-    *bytes = (size_t)P * sizeof(uint64_t);
+    *bytes = (size_t)(P + 8) * sizeof(uint64_t);             // 8: the list's header words (kListHdr)
     return CDR_OK;
 }
 

@@ -127,9 +127,9 @@ class FusedBPRStep:
             if self._stat is not None and self._stat[1].query():
                 nd, maxc = int(self._stat[0][2]), int(self._stat[0][3])
                 nB = self._stat[2]
-                if self._use_count and (nd > 12288 or maxc > 256):
+                if self._use_count and (nd > 10240 or maxc > 256):
                     self._use_count = False                  # a skewed stream: same-address counter updates and a long duplicate list -- the sort serves it better
-                elif not self._use_count and nd <= 4096 and nd * 24 <= 3 * nB:
+                elif not self._use_count and nd <= 8192:     # (the sorted path reports the duplicate occurrences only: heads[3] stays 0 there)
                     self._use_count = True
                 self._stat = None
         on = in_range and self._use_count

@@ -27,6 +27,8 @@ def _same(a, b):
 @pytest.mark.parametrize('shape', ['uniform', 'dups', 'hot', 'long_list'])
 def test_count_path_is_bit_equal_to_the_sorted_path(shape):
     nu, ni, D, B = 400000, 150000, 128, 40000
+    if shape == 'uniform':
+        nu, ni, D = 6000000, 4000000, 64                        # a few hundred duplicate occurrences: the list is sorted in LDS
     if shape == 'long_list':
         nu, ni = 30000, 20000                                   # ~ 70 % of the occurrences are duplicates: the list is sorted in global memory
     a, b = _pair(nu, ni, D, B)
@@ -67,7 +69,7 @@ def test_count_path_outside_its_range_and_sgd_and_no_reg():
 
 def test_auto_policy_moves_a_skewed_stream_to_the_sorted_path_and_back():
     from recbole_cdr_amd.fused import FusedBPRStep
-    nu, ni, D, B = 400000, 150000, 64, 32768
+    nu, ni, D, B = 6000000, 4000000, 32, 32768
     torch.manual_seed(2)
     st = FusedBPRStep(torch.randn(nu, D, device=DEV) * 0.1, torch.randn(ni, D, device=DEV) * 0.1, B, opt='adam', lr=0.01, reg_weight=0.01)
     assert st.id_path == 'auto' and st._use_count
@@ -87,13 +89,15 @@ def test_count_path_replays_as_a_graph():
     a, b = _pair(nu, ni, D, B)
     u, p, n = (torch.randint(0, hi, (B,), device=DEV) for hi in (nu, ni, ni))
     su, sp, sn = u.clone(), p.clone(), n.clone()
-    b.step(su, sp, sn); a.step(u, p, n)                         # warm (allocates the counters) outside the capture
     from recbole_cdr_amd import binding as B_
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        B_.ctx(DEV)
+        b.step(su, sp, sn)                                      # warm on the capture stream: its context's scratch and the counters are allocated here
+    torch.cuda.synchronize()
+    a.step(u, p, n)
+    with torch.cuda.stream(s):
         with B_.capturing(g, s):
             b.step(su, sp, sn)
     torch.cuda.current_stream().wait_stream(s)

@@ -2,7 +2,10 @@
 the count path (one counter per table row; only duplicate occurrences are sorted) at the C5 table sizes, uniform and Zipf(1.05) positives, eager
 and replayed as a hipGraph.  One MI355X.  python tools/mb_idpath.py [users items D]"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
