@@ -110,7 +110,7 @@ def compact_line(result, detail_file=DETAIL_FILE, limit=LINE_LIMIT):
     if result.get('leg_errors'):
         extra['leg_errors'] = sorted(result['leg_errors'])
     line.update(extra)
-    for k in ('deterministic_backward', 'bench_wall_s'):
+    for k in ('deterministic_backward', 'nondeterministic_legs', 'bench_wall_s'):
         if k in result:
             line[k] = result[k]
     line['detail_file'] = detail_file
@@ -1201,14 +1201,20 @@ def pmc_traffic(kernel):
     counters are collected in separate profiler runs of this same command (tools/profile_bench.sh), NOT in this invocation."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
-        with open(path) as f:
-            v = json.load(f).get(kernel)
+        with open(path, 'rb') as f:
+            raw = f.read()
+        doc = json.loads(raw)
+        v = doc.get(kernel)
     except Exception:
         v = None
     if v is None:
         return None
-    return {'bytes': v, 'source': 'profiles/pmc_traffic.json (builder run of tools/profile_r05.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                                  'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --no-ingest --single-stream --steps 3 --warmup 1`; not measured in this invocation)'}
+    import hashlib
+    blob = hashlib.sha1(b'blob %d\0' % len(raw) + raw).hexdigest()[:12]          # = `git hash-object profiles/pmc_traffic.json`: a stale copy is visible
+    return {'bytes': v, 'collected': doc.get('_collected'), 'git_blob': blob,
+            'source': 'profiles/pmc_traffic.json blob %s collected %s (builder run of tools/profile_r%02d.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                      'passes over `python bench.py --no-cpu-baseline --no-fullsort --no-config-legs --no-e2e --no-ingest --single-stream --steps 3 --warmup 1`; '
+                      'not measured in this invocation)' % (blob, doc.get('_collected', '?'), int(doc.get('_round', 5)))}
 
 
 # ------------------------------------------------------------------------------------------------------ C3 / C4 workloads
@@ -2135,6 +2141,12 @@ def main():
             result['cpu_baseline'] = cpu_baseline(args)
         from recbole_cdr_amd import functional as F_
         result['deterministic_backward'] = bool(F_.deterministic())      # CDR_DETERMINISTIC=1: the drop-in losses' dense gradients without float atomics
+        if not result['deterministic_backward']:
+            # which legs of THIS line are not bit-reproducible run to run: only the drop-in dense backward of the small configurations (fp32
+            # atomics into dense gradients, as torch's own embedding backward); every O(batch) step (the headline, the sharded layouts, the
+            # medium / k-major / pointwise steps, the OVERLAP step), the full-sort legs and the ingest sum in a fixed order
+            result['nondeterministic_legs'] = ['configs.c1', 'configs.c2', 'configs.c4 (BiTGCF scatters)', 'e2e: none', 'headline: none']
+            result['nondeterministic_legs'] = [x for x in result['nondeterministic_legs'] if not x.endswith(': none')]
         result['bench_wall_s'] = round(time.perf_counter() - T_START, 1)  # the whole invocation, imports and every leg included
         emit(result, real_stdout, detail_file=args.detail_file)
     if world > 1 or args.force_shard:
