@@ -551,7 +551,7 @@ constexpr int kFlagIT = 8;
 __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
                                                            int64_t nA, int64_t n, int fstride, uint8_t* __restrict__ flags,
                                                            uint32_t* __restrict__ headsA, uint32_t* __restrict__ headsB,
-                                                           unsigned* __restrict__ cnt) {
+                                                           unsigned* __restrict__ cnt, bool stat = false) {
     constexpr int NW = kBlock / 64;
     __shared__ unsigned wcnt[3][NW], wbase[2][NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -593,11 +593,13 @@ __global__ __launch_bounds__(kBlock) void occ_flags_kernel(const uint32_t* __res
             const unsigned a = __shfl_up(pA, d, 64), b = __shfl_up(pB, d, 64);
             if (lane >= d) { pA += a; pB += b; }
         }
+        if (stat) {                                            // (medium batches only: the statistic that picks their id path)
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) nd += __shfl_xor(nd, d, 64);
+            for (int d = 1; d < 64; d <<= 1) nd += __shfl_xor(nd, d, 64);
+        }
         if (lane == 63) { wcnt[0][wave] = pA; wcnt[1][wave] = pB; wcnt[2][wave] = nd; }
         __syncthreads();
-        if (threadIdx.x == 2) {                                // cnt[2] += duplicate occurrences: the host binding's statistic (which id path serves this stream)
+        if (stat && threadIdx.x == 2) {                        // cnt[2] += duplicate occurrences: the host binding's statistic (which id path serves this stream)
             unsigned tot = 0;
             for (int w = 0; w < NW; ++w) tot += wcnt[2][w];
             if (tot) atomicAdd(&cnt[2], tot);
@@ -2252,7 +2254,7 @@ static int bpr_step_fused_impl(cdr_ctx* ctx, void* stream, int opt, float* user_
     const int fgrid = grid_for(3 * B, kBlock * kFlagIT);
     {
         cdr_time_scope ts(ctx, CDR_TAG_OCC_FLAGS, s);
-        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, 4, flags, headsA, headsB, cnt);
+        occ_flags_kernel<<<dim3(fgrid), dim3(kBlock), 0, s>>>(keys, perm, B, 3 * B, 4, flags, headsA, headsB, cnt, B <= kCountMaxB);
     }
     CDR_LAUNCH_CHECK();
     }
