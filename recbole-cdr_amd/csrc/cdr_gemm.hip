@@ -491,7 +491,15 @@ struct topk_out {
     float* pv;                  // partial lists [producer][M][k]
     int* pc;
     topk_mask mk;
+    const float* seed = nullptr;    // optional: seed[u * seed_stride] = a LOWER BOUND of user u's final k-th value (the k-th value over a sample
+    int64_t seed_stride = 0;        // of the columns): every stripe's threshold starts just below it instead of at -inf (round 6)
 };
+// the threshold a seed stands for: the largest float below it, so that a score EQUAL to the sample's k-th value still enters its list
+__device__ __forceinline__ float topk_seed_thr(const topk_out& tk, int64_t u, int64_t M) {
+    if (!tk.seed || u >= M) return -INFINITY;
+    const float s = tk.seed[u * tk.seed_stride];
+    return s == -INFINITY ? s : nextafterf(s, -INFINITY);
+}
 
 // Mask test for the queued candidates, one per lane (64 binary searches in flight), then the survivors enter their
 // user's list one at a time (LDS only).  Thresholds may have risen since a candidate was queued: re-tested on insert.
@@ -521,7 +529,8 @@ __device__ __forceinline__ void topk_flush(volatile float* qv, volatile int* qc,
             int ec = lane < tk.k ? lc[cu * tk.k + lane] : -1;
             const float nthr = topk_offer<true>(lane == 0 ? cv : -INFINITY, cc, thr, e, ec, tk.k, none, 0);
             if (lane < tk.k) { lv[cu * tk.k + lane] = e; lc[cu * tk.k + lane] = ec; }
-            if (lane == 0) thr_l[cu] = nthr;
+            // (a seeded list is not full for a while: its k-th value is -inf, the seed stays the threshold until the list's own passes it)
+            if (lane == 0) thr_l[cu] = tk.seed ? fmaxf(nthr, topk_seed_thr(tk, u0 + cu, u0 + cu + 1)) : nthr;
         }
     }
 }
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(256, 1) void score_persistent_kernel(const float* _
         const bool full_rows = (int64_t)(mb + 1) * BM <= M;          // (workgroup-uniform) every user row of this block exists
         int tiles_done = 0;
         if (TOPK) {
-            for (int i = tid; i < BM; i += 256) thr_l[i] = -INFINITY;
+            for (int i = tid; i < BM; i += 256) thr_l[i] = topk_seed_thr(tk, (int64_t)mb * BM + i, M);
             for (int i = tid; i < BM * tk.k; i += 256) { lv[i] = -INFINITY; lc[i] = -1; }
             if (tid < 6) qcnt[tid] = 0;
         }
@@ -1097,6 +1106,14 @@ struct topk_plan {
     int64_t producers, score_floats;
 };
 
+// users up to which the fused mask + top-k runs one 32-row tile per wave (BM = 64: twice the row blocks, half the column stripes, so half
+// the insertions -- round 6, U = 128 / 256 / 512 at D = 128: 5.62 -> 4.86, 8.78 -> 8.21, 14.96 -> 14.75 ms; 64 before); the rest of the comment:
+// the lists that have to fill up from -inf); CDR_TOPK_SMALL_U overrides for A/B runs
+static int64_t topk_small_u() {
+    static const int64_t v = [] { const char* e = getenv("CDR_TOPK_SMALL_U"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+    return v;
+}
+
 static size_t fused_lds_bytes(int D, int MT, int k) {
     const int BM = 64 * MT;
     return sizeof(float) * ((size_t)2 * 64 * (D + 4) + (size_t)BM * 65 + BM + (size_t)BM * k * 2 + (size_t)4 * kTopkQueue * 3 + 8);
@@ -1115,7 +1132,7 @@ static topk_plan make_topk_plan(int64_t U, int D, const int64_t n[2], int k, con
     int64_t max_unfused = 0;
     for (int i = 0; i < 2; ++i) {
         if (n[i] <= 0) continue;
-        const int MT = U <= 64 ? 1 : 2;
+        const int MT = U <= topk_small_u() ? 1 : 2;
         p.fused[i] = U > 32 && (D == 64 || D == 128) && n[i] >= 64 && U < ((int64_t)1 << 30) &&
                      (slab[i] == nullptr || ((((uintptr_t)users | (uintptr_t)slab[i]) & 15) == 0)) &&
                      fused_lds_bytes(D, MT, k) <= (size_t)160 * 1024;
@@ -1171,10 +1188,10 @@ extern "C" int cdr_fullsort_topk_workspace_bytes(int64_t U, int D, int64_t n0, i
     return CDR_OK;
 }
 
-extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t U, int D, const float* slab0, int64_t n0,
-                                     const float* slab1, int64_t n1, int k, const int64_t* hist_indptr,
-                                     const int64_t* hist_cols, int exclude_first_col, float* out_vals, int64_t* out_idx,
-                                     void* workspace, size_t workspace_bytes) {
+static int fullsort_topk_impl(void* stream, const float* user_e, int64_t U, int D, const float* slab0, int64_t n0,
+                              const float* slab1, int64_t n1, int k, const int64_t* hist_indptr,
+                              const int64_t* hist_cols, int exclude_first_col, float* out_vals, int64_t* out_idx,
+                              void* workspace, size_t workspace_bytes, const float* seed, int64_t seed_stride) {
     CDR_CHECK_ARG(user_e && out_vals && out_idx && workspace && U > 0 && D > 0 && k >= 1 && k <= 64);
     CDR_CHECK_ARG((slab0 && n0 > 0) || (slab1 && n1 > 0));
     CDR_CHECK_ARG((hist_indptr == nullptr) == (hist_cols == nullptr));
@@ -1213,10 +1230,11 @@ extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t 
             cdr_set_error("cdr_fullsort_topk_f32: operands must be 16-byte aligned");
             return CDR_EINVAL;
         } else if (p.fused[i]) {
-            const topk_out tk{k, (int)col_off, pv + prod * U * k, pc + prod * U * k, mk};
+            topk_out tk{k, (int)col_off, pv + prod * U * k, pc + prod * U * k, mk};
+            tk.seed = seed; tk.seed_stride = seed_stride;
             const int NT = (int)(n[i] / 64);
             const unsigned grid = CDR_NUM_CU;
-            const bool small = U <= 64;
+            const bool small = U <= topk_small_u();
             const size_t lds = fused_lds_bytes(D, small ? 1 : 2, k);
             if (D == 64) {
                 if (small) score_persistent_kernel<1, 64, true><<<dim3(grid), dim3(256), lds, s>>>(user_e, (int)U, slab[i], NT, nullptr, 0, tk);
@@ -1260,6 +1278,35 @@ extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t 
     }
     CDR_LAUNCH_CHECK();
     return CDR_OK;
+}
+
+// Round 6: SEEDED thresholds.  Every column stripe of the fused kernel used to fill its k-entry lists from -inf: k ln(n_stripe / k)
+// insertions per user and stripe (queue, mask test, LDS list update), 128 stripes at U = 256 -- the +31 % of the masked top-10 over plain
+// scoring there.  A first call over a SAMPLE of the columns (the first 65,536 of the first slab, same mask) leaves each user's k-th value
+// over the sample in out_vals[:, k - 1]: a lower bound of the final k-th value (the sample is a subset of the columns), handed to the real
+// call as the starting threshold of every stripe (one float below it, so that ties with it still enter).  Results are unchanged -- every
+// entry of the final top-k is >= its user's seed and passes in its own stripe; a stripe's list may end up shorter than k, which the
+// merges already handle (-inf / -1 fillers never enter).
+constexpr int64_t kTopkSeedCols = 65536;
+extern "C" int cdr_fullsort_topk_f32(void* stream, const float* user_e, int64_t U, int D, const float* slab0, int64_t n0,
+                                     const float* slab1, int64_t n1, int k, const int64_t* hist_indptr,
+                                     const int64_t* hist_cols, int exclude_first_col, float* out_vals, int64_t* out_idx,
+                                     void* workspace, size_t workspace_bytes) {
+    static const bool seeding = [] { const char* e = getenv("CDR_TOPK_SEED"); return !(e && e[0] == '0'); }();
+    const bool first0 = slab0 && n0 > 0;
+    const float* fs = first0 ? slab0 : slab1;
+    const int64_t fn = first0 ? n0 : n1;
+    if (seeding && fs && U > 32 && (D == 64 || D == 128) && fn >= 16 * kTopkSeedCols && k <= kTopkSeedCols / 64 &&
+        ((((uintptr_t)user_e | (uintptr_t)fs) & 15) == 0)) {
+        // the sample call: same users, same mask, the first columns of the first slab (global columns [0, kTopkSeedCols))
+        int rc = fullsort_topk_impl(stream, user_e, U, D, fs, kTopkSeedCols, nullptr, 0, k, hist_indptr, hist_cols, exclude_first_col, out_vals, out_idx,
+                                    workspace, workspace_bytes, nullptr, 0);
+        if (rc) return rc;
+        return fullsort_topk_impl(stream, user_e, U, D, slab0, n0, slab1, n1, k, hist_indptr, hist_cols, exclude_first_col, out_vals, out_idx, workspace,
+                                  workspace_bytes, out_vals + (k - 1), k);
+    }
+    return fullsort_topk_impl(stream, user_e, U, D, slab0, n0, slab1, n1, k, hist_indptr, hist_cols, exclude_first_col, out_vals, out_idx, workspace,
+                              workspace_bytes, nullptr, 0);
 }
 
 extern "C" int cdr_fullsort_neg_sqdist_f32(void* stream, const float* user_e, int64_t U, int D, const float* items,

@@ -2468,6 +2468,40 @@ def test_fullsort_topk_matches_topk_of_masked_scores(U, D, N, k):
     assert torch.equal(got_v2, w2.values) and torch.equal(torch.gather(full, 1, got_i2), w2.values)
 
 
+@pytest.mark.parametrize('U,D,k,two_slabs', [(70, 64, 10, False), (300, 128, 10, True), (40, 128, 20, False), (600, 64, 5, True)])
+def test_fullsort_topk_seeded_thresholds_equal_topk_of_masked_scores(U, D, k, two_slabs):
+    """Round 6: past 16 x 65,536 columns the fused mask + top-k first ranks a SAMPLE (the first 65,536 columns) and starts every column
+    stripe's threshold just below the sample's k-th value.  Same results as torch.topk of the masked matrix -- with exact TIES at the
+    sample's k-th value (duplicated item rows in and outside the sample), with a history that masks each user's best sample columns (the
+    seed must be the k-th value of the MASKED sample), with the first slab alone and with the columns split over two slabs."""
+    from recbole_cdr_amd import functional as F_
+    torch.manual_seed(U + k)
+    N = 16 * 65536 + 4097
+    ue = torch.randn(U, D, device=DEV)
+    tab = torch.randn(N, D, device=DEV)
+    # exact ties: rows of the sample copied to columns far outside it (same score for every user), and inside it
+    src = torch.randint(1, 65536, (3000,), device=DEV)
+    tab[torch.randint(65536, N, (3000,), device=DEV)] = tab[src]
+    tab[torch.randint(1, 65536, (500,), device=DEV)] = tab[src[:500]]
+    n0 = N if not two_slabs else 9 * 65536 + 13
+    slab0, slab1 = tab[:n0].contiguous(), (tab[n0:].contiguous() if two_slabs else None)
+    full = F_.fullsort_scores(ue, slab0, slab1)                                 # (one call: the same contraction kernel family as the fused form)
+    best_sample = torch.topk(full[:, :65536], 12, dim=1).indices                # each user's best SAMPLE columns go into its history ...
+    best_all = torch.topk(full, 5, dim=1).indices                               # ... with its best columns overall
+    cols = [torch.unique(torch.cat([best_sample[u], best_all[u]])) for u in range(U)]
+    indptr = torch.zeros(U + 1, dtype=torch.int64, device=DEV)
+    indptr[1:] = torch.cumsum(torch.tensor([c.numel() for c in cols], device=DEV), 0)
+    hist = torch.cat(cols)
+    masked = full
+    masked[:, 0] = -float('inf')
+    masked[torch.repeat_interleave(torch.arange(U, device=DEV), indptr[1:] - indptr[:-1]), hist] = -float('inf')
+    want_v, want_i = torch.topk(masked, k, dim=1)
+    got_v, got_i = F_.fullsort_topk(ue, slab0, slab1, k=k, hist_indptr=indptr, hist_cols=hist)
+    assert torch.equal(got_v, want_v), (got_v - want_v).abs().max()
+    assert torch.equal(torch.gather(masked, 1, got_i), want_v)                  # columns may differ only between exactly tied scores
+    assert int((got_i.sort(1).values[:, 1:] == got_i.sort(1).values[:, :-1]).sum()) == 0      # ... and never repeat
+
+
 def test_full_c5_size_properties():
     """BASELINE C5 table sizes (one domain: 50,000,001 x 128 users, 20,000,001 x 128 items, B = 1,048,576 triples), through
     properties that do not need an oracle run at that size:
