@@ -832,6 +832,14 @@ typedef struct cdr_batch_job {
 } cdr_batch_job;
 #define CDR_BATCH_MAX_JOBS 4
 int cdr_batch_produce_jobs(void* stream, const cdr_batch_job* jobs, int n_jobs);
+/* cdr_adam_multi_dev(...) and cdr_batch_produce_jobs(jobs) in ONE launch (round 6): the production of the loader's batch i + 1 in
+ * workgroups behind the optimizer's of step i -- the producer overwrites the batch buffers, which the backward of step i was the last
+ * to read; both are latency-bound launches of 6-8 us at the reference's batch (properties/overall.yaml:19), side by side they cost one of
+ * them.  Falls back to the two calls when the update does not fit the one-launch form (no ticket, > 24 tensors, > 512 fat workgroups). */
+int cdr_adam_multi_dev_produce(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, const float* loss, float* loss_sum, unsigned* ticket,
+                               const cdr_batch_job* jobs, int n_jobs);
 int cdr_batch_produce(void* stream, const int64_t* users_all, const int64_t* items_all, int64_t n_rows, int64_t* cursor,
                       int64_t S, int k, int pointwise, int dist, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1,
                       const int64_t* keys, const float* prob, const int64_t* alias, int64_t n_keys,

@@ -250,6 +250,8 @@ _SIGNATURES = {
     'cdr_scalar_mix': [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr],
     'cdr_point_fwd_grad': [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     'cdr_adam_multi_dev': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr],
+    'cdr_adam_multi_dev_produce': [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_ptr,
+                                   _c_ptr, _c_int],
     'cdr_neg_sample_alias': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64, _c_ptr, _c_ptr],
     'cdr_neg_sample_uniform': [_c_ptr, _c_ptr, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, ctypes.c_uint64,
                                _c_ptr, _c_ptr],

@@ -3,6 +3,7 @@
 // wave-instruction, grid capped at 8 blocks per CU with a grid stride.
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
+#include "cdr_produce.h"
 
 namespace {
 
@@ -291,9 +292,9 @@ __global__ void inc_multi_kernel(adam_multi_args a, const float* __restrict__ lo
 // of up to kSignInMaxBlocks workgroups (fatter workgroups: 16 elements per thread); beyond that the same-address sign-ins cost more
 // than the launch they replace (round 3: +6 us at 650 workgroups, +55 us at 10 k).
 template <bool TICKET>
-__global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args a, float lr, float b1, float b2, float eps, float wd,
-                                                                unsigned* __restrict__ ticket, const float* __restrict__ loss,
-                                                                float* __restrict__ loss_sum) {
+__device__ __forceinline__ void adam_multi_body(const adam_multi_args& a, float lr, float b1, float b2, float eps, float wd,
+                                                unsigned* __restrict__ ticket, const float* __restrict__ loss,
+                                                float* __restrict__ loss_sum, unsigned nblocks) {
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.blk_start[t + 1]) ++t;
     const int nb = a.blk_start[t + 1] - a.blk_start[t], lb = (int)blockIdx.x - a.blk_start[t];
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
     __syncthreads();
     const float step_size = hp[0], bc2_sqrt = hp[1];
     auto sign_out = [&]() {
-        if (TICKET && cdr_sign_in_last_wide(ticket, gridDim.x)) {
+        if (TICKET && cdr_sign_in_last_wide(ticket, nblocks)) {
             if ((int)threadIdx.x < a.count) a.step[threadIdx.x][0] += 1;
             if (threadIdx.x == 63 && loss_sum) loss_sum[0] += loss[0];
         }
@@ -368,6 +369,28 @@ __global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args 
         m[e] = mv; v[e] = vv;
     }
     sign_out();
+}
+
+template <bool TICKET>
+__global__ __launch_bounds__(kBlock) void adam_multi_dev_kernel(adam_multi_args a, float lr, float b1, float b2, float eps, float wd,
+                                                                unsigned* __restrict__ ticket, const float* __restrict__ loss,
+                                                                float* __restrict__ loss_sum) {
+    adam_multi_body<TICKET>(a, lr, b1, b2, eps, wd, ticket, loss, loss_sum, gridDim.x);
+}
+
+// The one-launch dense Adam of step i with the loader's batch i + 1 produced in workgroups behind its own (round 6): the two are independent
+// -- the producer overwrites the batch buffers, which the backward of step i (in front of this launch) was the last to read -- and both are
+// latency-bound launches of 6-8 us at the reference's batch (profiles/r06_bench_c1_kernel_stats.csv): side by side they cost one of them.
+struct produce_side { cdr_produce::batch_jobs jobs; int gx[CDR_BATCH_MAX_JOBS]; int n; };
+__global__ __launch_bounds__(kBlock) void adam_multi_produce_kernel(adam_multi_args a, float lr, float b1, float b2, float eps, float wd,
+                                                                    unsigned* __restrict__ ticket, const float* __restrict__ loss,
+                                                                    float* __restrict__ loss_sum, unsigned n_adam, produce_side ps) {
+    if (blockIdx.x < n_adam) { adam_multi_body<true>(a, lr, b1, b2, eps, wd, ticket, loss, loss_sum, n_adam); return; }
+    unsigned b = blockIdx.x - n_adam;
+    for (int j = 0; j < ps.n; ++j) {
+        if (b < (unsigned)ps.gx[j]) { cdr_produce::batch_produce_body(ps.jobs.j[j], b, (unsigned)ps.gx[j]); return; }
+        b -= (unsigned)ps.gx[j];
+    }
 }
 
 // mode 0: out[0] = sum_i x[i * stride] * w[i] in index order (the weighted total of a few loss scalars); mode 1: out[i] = scale[0] * w[i]
@@ -433,6 +456,54 @@ extern "C" int cdr_adam_multi_dev(void* stream, int count, float* const* params,
         adam_multi_dev_kernel<false><<<dim3(blocks), dim3(kBlock), 0, s>>>(a, lr, beta1, beta2, eps, weight_decay, nullptr, nullptr, nullptr);
         CDR_LAUNCH_CHECK();
     }
+    return CDR_OK;
+}
+
+// cdr_adam_multi_dev + cdr_batch_produce_jobs in ONE launch when the update fits the one-launch form (ticket given, <= 24 tensors, <= 512 fat
+// workgroups); otherwise the two calls one after the other.  Same results as the two calls (the jobs' kernels are independent of the update).
+extern "C" int cdr_adam_multi_dev_produce(void* stream, int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                          float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev, float lr, float beta1,
+                                          float beta2, float eps, float weight_decay, const float* loss, float* loss_sum, unsigned* ticket,
+                                          const cdr_batch_job* jobs, int n_jobs) {
+    CDR_CHECK_ARG(count > 0 && params && grads && exp_avg && exp_avg_sq && numel && step_dev);
+    CDR_CHECK_ARG((loss == nullptr) == (loss_sum == nullptr));
+    CDR_CHECK_ARG(jobs && n_jobs >= 1 && n_jobs <= CDR_BATCH_MAX_JOBS);
+    hipStream_t s = (hipStream_t)stream;
+    bool fat = ticket != nullptr && count <= kAdamMulti;
+    int64_t blocks = 0;
+    if (fat) {
+        for (int i = 0; i < count; ++i) blocks += grid_cap((numel[i] + kBlock * 16 - 1) / (kBlock * 16));
+        fat = blocks <= kSignInMaxBlocks;
+    }
+    if (!fat) {
+        int rc = cdr_adam_multi_dev(stream, count, params, grads, exp_avg, exp_avg_sq, numel, step_dev, lr, beta1, beta2, eps, weight_decay, loss,
+                                    loss_sum, ticket);
+        if (rc) return rc;
+        return cdr_batch_produce_jobs(stream, jobs, n_jobs);
+    }
+    adam_multi_args a{};
+    a.count = count;
+    int nb = 0;
+    for (int i = 0; i < count; ++i) {
+        CDR_CHECK_ARG(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && step_dev[i] && numel[i] > 0);
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i]; a.n[i] = numel[i]; a.step[i] = step_dev[i];
+        a.blk_start[i] = nb;
+        nb += grid_cap((numel[i] + kBlock * 16 - 1) / (kBlock * 16));
+    }
+    a.blk_start[count] = nb;
+    produce_side ps{};
+    ps.n = n_jobs;
+    int total = nb;
+    for (int j = 0; j < n_jobs; ++j) {
+        const cdr_batch_job& J = jobs[j];
+        CDR_CHECK_ARG(J.users_all && J.cursor && J.out_users && J.S > 0 && J.k >= 0 && J.n_rows > 0);
+        if (J.k > 0) CDR_CHECK_ARG(J.items_all && J.out_items && (J.pointwise || J.out_neg));
+        ps.jobs.j[j] = J;
+        ps.gx[j] = (int)cdr_produce::job_grid(J);
+        total += ps.gx[j];
+    }
+    adam_multi_produce_kernel<<<dim3((unsigned)total), dim3(kBlock), 0, s>>>(a, lr, beta1, beta2, eps, weight_decay, ticket, loss, loss_sum, (unsigned)nb, ps);
+    CDR_LAUNCH_CHECK();
     return CDR_OK;
 }
 

@@ -118,6 +118,10 @@ class DeviceBatchProducer:
         """Enqueue the production of the NEXT batch on the current stream (capturable)."""
         launch_jobs([self.job(slot)])
 
+    def jobs(self, slot=0):
+        """What ``launch`` would enqueue, for a caller that produces the batch inside another launch (trainer.DenseAdam.produce_jobs)."""
+        return [self.job(slot)]
+
     def full_ahead(self):
         """Does the loader's next batch have all ``step`` rows (what the captured launch produces)?"""
         return self.loader.pr + self.S <= self.loader.pr_end
@@ -161,6 +165,9 @@ class CompositeProducer:
 
     def launch(self, slot=0):
         launch_jobs([p.job(slot) for p in self.parts])         # ONE launch: grid row i produces loader i's batch
+
+    def jobs(self, slot=0):
+        return [p.job(slot) for p in self.parts]
 
     def full_ahead(self):
         return all(p.full_ahead() for p in self.parts)

@@ -22,13 +22,17 @@ def _zeros_like2(a, b):
     return flat[:a.numel()].view(a.shape), flat[a.numel():].view(b.shape)
 
 
-def _prezero_for_backward(ctx, *tables):
+def _prezero_for_backward(ctx, *tables, lists=None):
     """Called in a loss's forward, BEFORE its forward launch: when a backward will follow, allocate the dense gradient buffers of
     ``tables`` now (one flat buffer) and let the forward launch zero-fill them on the side (cdr_ctx_scrub_next) -- the separate fill
     launch was ~5 us of a 40 us step at the reference's default batch.  ``_grads_for`` hands them out in the backward."""
     ctx.pre = None
     tabs = [t for t in tables if t is not None]
     if (deterministic() and not ordered_backward()) or not tabs or not any(ctx.needs_input_grad) or not all(t.is_contiguous() for t in tabs):
+        return
+    # under set_deterministic the buffers are consumed by the ordered launch only; lists past its cap take the sorted route, which brings its
+    # own buffers: do not allocate and scrub table-sized memory for nothing (``lists`` = the occurrence counts per gradient buffer, ADVICE r5)
+    if deterministic() and lists is not None and not ordered_fits(tabs[0].shape[1], *lists):
         return
     offs, n = [], 0
     for t in tabs:
@@ -206,7 +210,7 @@ class BPRGatherLoss(Function):
         n, D = uid.numel(), user_w.shape[1]
         out4 = torch.empty(4, device=user_w.device, dtype=torch.float32)
         g = torch.empty(n, device=user_w.device, dtype=torch.float32)
-        _prezero_for_backward(ctx, user_w, item_w)
+        _prezero_for_backward(ctx, user_w, item_w, lists=(n, 2 * n))
         B_.call('cdr_bpr_fwd', B_.ctx(user_w.device), B_.stream(), B_.f32(user_w), B_.f32(item_w), D,
                 B_.i64(uid), B_.i64(pid), B_.i64(nid), n, float(gamma), float(reg_weight), B_.f32(out4), B_.f32(g))
         ctx.save_for_backward(user_w, item_w, uid, pid, nid, g, out4)

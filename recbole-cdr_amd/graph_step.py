@@ -114,7 +114,19 @@ class GraphedTrainStep:
         buffers after the forward that read them (the backward works on the forward's own copies); the next batch's replay comes
         after this batch's row update on the same stream; the next forward needs both branches."""
         if not self._can_pipeline():
+            # Round 6: with an optimizer that can host the production (trainer.DenseAdam.produce_jobs -> cdr_adam_multi_dev_produce) batch
+            # i + 1 is produced INSIDE step i's optimizer launch -- the two are independent, 6-8 us each at the reference's batch -- so an
+            # unrolled graph holds one stand-alone producer launch instead of k.  Same launches' work on the same operands: bit-identical.
+            fuse = (self.producer is not None and k > 1 and hasattr(self.producer, 'jobs') and hasattr(self.optimizer, 'produce_jobs')
+                    and getattr(self.optimizer, 'row_opt', None) is None and self.pipeline is not False)
             loss = None
+            if fuse:
+                self.producer.launch()
+                for i in range(k):
+                    if i + 1 < k:
+                        self.optimizer.produce_jobs = self.producer.jobs()
+                    loss = self._eager(self.static)
+                return loss
             for _ in range(k):
                 loss = self._whole()
             return loss

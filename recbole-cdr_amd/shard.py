@@ -240,6 +240,8 @@ class NativeOps:
         key = ('plan', torch.cuda.current_stream().cuda_stream, int(user_rows), int(item_local_rows), int(slot))
         buf = self._ws.get(key)
         if buf is None or buf['cap'] < Bl:
+            if buf is not None:
+                self._ws.setdefault('retired', []).append(buf)      # a main stage on another stream may still read the smaller set: never hand it back
             cap = max(int(Bl * 1.25), 1024)
             words, need = ctypes.c_int64(0), ctypes.c_size_t(0)
             B_._check(B_.load().cdr_bpr_shard_plan_sizes(cap, int(user_rows), int(item_local_rows), int(world), ctypes.byref(words), ctypes.byref(need)),

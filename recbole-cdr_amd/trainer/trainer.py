@@ -21,11 +21,27 @@ class DenseAdam(torch.optim.Optimizer):
         # (loss, loss_sum) device scalars handed over by the training loop before ``step()``: the launch that bumps the step counters
         # also adds this step's loss to the epoch's total (no launch of its own).  ``step`` sets it back to None once it has done so.
         self.loss_pair = None
+        # cdr_batch_job's handed over by the training loop before ``step()`` (graph_step: the loader's NEXT batch): produced in workgroups
+        # behind the update's own, in the same launch (cdr_adam_multi_dev_produce).  ``step`` sets it back to None once it has done so.
+        self.produce_jobs = None
 
     @torch.no_grad()
     def step(self, closure=None):
         import ctypes
         from .. import binding as B_
+        jobs, self.produce_jobs = self.produce_jobs, None
+        try:
+            self._step_groups(jobs)
+        finally:
+            jobs = self.__dict__.pop('_jobs_left', jobs)
+            if jobs:                                   # no parameter had a gradient (or several groups): the batch is produced all the same
+                from ..data.producer import launch_jobs
+                launch_jobs(jobs)
+
+    def _step_groups(self, jobs):
+        import ctypes
+        from .. import binding as B_
+        self._jobs_left = jobs
         for group in self.param_groups:
             ps, gs, ms, vs, ns, ss, keep = [], [], [], [], [], [], []
             for p in group['params']:
@@ -49,6 +65,15 @@ class DenseAdam(torch.optim.Optimizer):
             tk = self.__dict__.get('_ticket')
             if tk is None or tk.device != ps_dev:
                 tk = self._ticket = torch.zeros(B_.SIGNIN_WORDS, device=ps_dev, dtype=torch.int32)        # sign-in words of the one-launch form
+            jl = self._jobs_left
+            if jl:
+                self._jobs_left = None
+                jarr = (B_.BatchJob * len(jl))(*jl)
+                B_.call('cdr_adam_multi_dev_produce', B_.stream(), n, arr(ps), arr(gs), arr(ms), arr(vs), (ctypes.c_int64 * n)(*ns), arr(ss),
+                        float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
+                        float(group['weight_decay']), None if lp is None else B_.f32(lp[0]), None if lp is None else B_.f32(lp[1]), B_.raw(tk),
+                        jarr, len(jl))
+                continue
             B_.call('cdr_adam_multi_dev', B_.stream(), n, arr(ps), arr(gs), arr(ms), arr(vs), (ctypes.c_int64 * n)(*ns), arr(ss),
                     float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
                     float(group['weight_decay']), None if lp is None else B_.f32(lp[0]), None if lp is None else B_.f32(lp[1]), B_.raw(tk))
