@@ -338,9 +338,15 @@ __global__ __launch_bounds__(kBlock) void rowwise_apply_kernel(float* __restrict
     }
 }
 
-// One lane group per piece of a long segment: partial[pi] = signed sum of the piece's gradient rows in occurrence order,
-// pcnt[pi] = its EmbLoss occurrences.  Sixteen row loads in flight per lane (round 5: a 256-occurrence piece was 64 dependent rounds of
-// ~1.5 us with four -- the whole Zipf(1.05) B = 65,536 step waited for them); the adds stay in occurrence order.
+// One WORKGROUP per piece of a long segment (round 6; one lane group per piece before): the piece's kPiece = 256 occurrences are cut into
+// eight sub-pieces of kSubPiece = 32; the workgroup's lane groups sum one sub-piece each in occurrence order (sixteen row loads in flight: two
+// rounds), park the eight sub-sums in LDS, and the first lane group adds them in sub-piece order: partial[pi] = ((s0 + s1) + ...) + s7, a fixed
+// association that does not depend on the launch shape.  This is north_star's "LDS staging of the hot rows" where it pays: a hot item's
+// segment (4,068 occurrences at Zipf(1.05), B = 65,536) was 16 pieces of 16 dependent rounds each -- 44.8 us of the step's 300
+// (profiles/r06_zipf65k_kernel_stats_before.csv); the staged sub-sums make it two rounds and one pass through LDS.  pcnt[pi] = the piece's
+// EmbLoss occurrences.  Every long-segment path of this file (two-pass apply, fused duplicate apply, row-shard owner and requester) runs this
+// body, so they keep agreeing bit for bit with each other.
+constexpr int kSubPiece = 32, kSubs = kPiece / kSubPiece;
 template <int LPR, bool SIGNED>
 __device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __restrict__ perm,
                                                    const float* __restrict__ G, int64_t neg_start, int64_t reg_limit,
@@ -350,35 +356,54 @@ __device__ __forceinline__ void seg_piece_sum_body(int D, const uint32_t* __rest
                                                    int* __restrict__ pcnt) {
     constexpr int GPB = kBlock / LPR;
     constexpr int UN = 16;
-    const int sub = threadIdx.x % LPR;
-    const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-    const int64_t TG = (int64_t)gridDim.x * GPB;
+    __shared__ float4 sub_sum[kSubs][64];                     // one row of <= 256 floats per sub-piece (wider rows: chunk by chunk)
+    __shared__ int sub_cnt[kSubs];
+    const int sub = threadIdx.x % LPR, gid = threadIdx.x / LPR;
     const int D4 = D >> 2;
     const int64_t np = counters[0];
-    for (int64_t pi = gg; pi < np; pi += TG) {
+    for (int64_t pi = blockIdx.x; pi < np; pi += gridDim.x) {
         const seg_piece pc = pieces[pi];
-        for (int ch = sub; ch < D4; ch += LPR) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int cnt = 0;
-            for (int64_t e0 = 0; e0 < pc.len; e0 += UN) {
-                int64_t o[UN]; float4 g[UN]; bool neg[UN];
+        for (int ch0 = 0; ch0 < D4; ch0 += 64) {              // 64 float4 chunks of the row at a time (one trip for D <= 256)
+            for (int sp = gid; sp < kSubs; sp += GPB) {
+                const int64_t s0 = (int64_t)sp * kSubPiece, slen = pc.len - s0 < kSubPiece ? pc.len - s0 : (int64_t)kSubPiece;
+                int cnt = 0;
+                for (int ch = ch0 + sub; ch < D4 && ch < ch0 + 64; ch += LPR) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    cnt = 0;
+                    for (int64_t e0 = 0; e0 < slen; e0 += UN) {
+                        int64_t o[UN]; float4 g[UN]; bool neg[UN];
 #pragma unroll
-                for (int j = 0; j < UN; ++j) o[j] = (e0 + j < pc.len) ? (int64_t)perm[pc.start + e0 + j] : -1;
+                        for (int j = 0; j < UN; ++j) o[j] = (e0 + j < slen) ? (int64_t)perm[pc.start + s0 + e0 + j] : -1;
 #pragma unroll
-                for (int j = 0; j < UN; ++j) {
-                    neg[j] = SIGNED && o[j] >= neg_start;
-                    g[j] = o[j] >= 0 ? ld4n<(LPR >= 32)>(G + (neg[j] ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int j = 0; j < UN; ++j) {
+                            neg[j] = SIGNED && o[j] >= neg_start;
+                            g[j] = o[j] >= 0 ? ld4n<(LPR >= 32)>(G + (neg[j] ? o[j] - neg_start : o[j]) * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) {
+                            if (o[j] < 0) continue;
+                            if (neg[j]) { acc.x -= g[j].x; acc.y -= g[j].y; acc.z -= g[j].z; acc.w -= g[j].w; }
+                            else { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; }
+                            cnt += occ_ids ? (int)((occ_ids[o[j]] >> 62) & 1) : ((o[j] < reg_limit) ? 1 : 0);
+                        }
+                    }
+                    sub_sum[sp][ch - ch0] = acc;
                 }
-#pragma unroll
-                for (int j = 0; j < UN; ++j) {
-                    if (o[j] < 0) continue;
-                    if (neg[j]) { acc.x -= g[j].x; acc.y -= g[j].y; acc.z -= g[j].z; acc.w -= g[j].w; }
-                    else { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; }
-                    cnt += occ_ids ? (int)((occ_ids[o[j]] >> 62) & 1) : ((o[j] < reg_limit) ? 1 : 0);
-                }
+                if (sub == 0 && ch0 == 0) sub_cnt[sp] = slen > 0 ? cnt : 0;
             }
-            st4n<(LPR >= 32)>(partial + pi * D + 4 * ch, acc);
-            if (ch == 0) pcnt[pi] = cnt;
+            __syncthreads();
+            const int nsub = (int)((pc.len + kSubPiece - 1) / kSubPiece);
+            for (int c = threadIdx.x; c < 64 && ch0 + c < D4; c += kBlock) {        // sub-piece order: the piece's sum
+                float4 acc = sub_sum[0][c];
+                for (int sp = 1; sp < nsub; ++sp) { const float4 x = sub_sum[sp][c]; acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w; }
+                st4n<(LPR >= 32)>(partial + pi * D + 4 * (ch0 + c), acc);
+            }
+            if (threadIdx.x == 0 && ch0 == 0) {
+                int cn = 0;
+                for (int sp = 0; sp < nsub; ++sp) cn += sub_cnt[sp];
+                pcnt[pi] = cn;
+            }
+            __syncthreads();
         }
     }
 }
@@ -1161,6 +1186,43 @@ __global__ __launch_bounds__(kBlock) void point_fwd_apply_kmajor_kernel(int loss
     }
 }
 
+// End of a MEDIUM segment (3 .. kLongSeg occurrences) headed at sorted position q: the first position past q + 2 whose key differs.
+// One probe per lane and a ballot instead of a walk (round 6): the walk was a chain of up to 30 dependent key loads per segment -- most of
+// the 60 us the duplicate apply took on a Zipf(1.05) batch of 65,536 triples, whose items of rank 100 .. 3,000 have such segments.
+template <int LPR>
+__device__ __forceinline__ int64_t seg_end_probe(const uint32_t* __restrict__ keys, int64_t q, int64_t n, uint32_t row) {
+    if constexpr (LPR >= 32) {
+        const int lane = threadIdx.x & 63, l = lane & 31;
+        const int64_t p = q + 3 + l;
+        const bool same = (LPR == 32 || lane < 32) && p < n && p <= q + kLongSeg && keys[p] == row;
+        const unsigned long long m = __ballot(!same);
+        const uint32_t mg = LPR == 32 ? (uint32_t)(m >> (lane & 32)) : (uint32_t)m;
+        return q + 3 + (mg ? (int64_t)(__ffs((int)mg) - 1) : 32);
+    } else {
+        int64_t end = q + 3;
+        while (end < n && end <= q + kLongSeg && keys[end] == row) ++end;
+        return end;
+    }
+}
+
+// The occurrence numbers of a medium segment's third and later entries, one per lane (lane l of the group: sorted position q + 2 + l),
+// fetched together behind the end probe: the rounds below hand them round with lane shuffles instead of loading perm[] ahead of every
+// round's row loads (one dependent hop per round less).
+template <int LPR>
+__device__ __forceinline__ uint32_t seg_occ_fetch(const uint32_t* __restrict__ perm, int64_t q, int64_t end) {
+    if constexpr (LPR >= 32) {
+        const int l = threadIdx.x & 31;
+        return ((LPR == 32 || (threadIdx.x & 63) < 32) && q + 2 + l < end) ? perm[q + 2 + l] : 0u;
+    } else {
+        return 0u;
+    }
+}
+template <int LPR>
+__device__ __forceinline__ int64_t seg_occ_at(const uint32_t* __restrict__ perm, uint32_t mine, int64_t q, int64_t e) {
+    if constexpr (LPR >= 32) return (int64_t)__shfl(mine, (int)(e - (q + 2)), LPR);      // (LPR = 64: the values sit in the wave's lower half)
+    else return (int64_t)perm[e];
+}
+
 // The segmented apply over the DUPLICATE segments only: heads[0 .. *nheads) are the sorted positions of their first occurrences
 // (any order: every segment is summed by one lane group in occurrence order, whoever takes it).  Long segments as in
 // rowwise_apply_kernel.
@@ -1237,12 +1299,12 @@ __device__ __forceinline__ void rowwise_apply_dups_body(float* __restrict__ W, f
                 if (k2[j] == row[j]) {                                     // third and later occurrences (at most kLongSeg - 2 of them)
                     // the segment's end first (its keys are neighbours in memory), then the gradient rows eight at a time: one at a time
                     // this walk was a chain of up to 30 dependent ~1.5 us loads per segment, which is what a Zipf batch's step waited for
-                    int64_t end = q[j] + 3;
-                    while (end < n && end <= q[j] + kLongSeg && keys[end] == row[j]) ++end;
+                    const int64_t end = seg_end_probe<LPR>(keys, q[j], n, row[j]);
+                    const uint32_t occ_l = seg_occ_fetch<LPR>(perm, q[j], end);
                     for (int64_t e0 = q[j] + 2; e0 < end; e0 += 8) {
                         int64_t o[8]; float4 g[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) o[u] = e0 + u < end ? (int64_t)perm[e0 + u] : -1;
+                        for (int u = 0; u < 8; ++u) { const int64_t ov = seg_occ_at<LPR>(perm, occ_l, q[j], e0 + u < end ? e0 + u : q[j] + 2); o[u] = e0 + u < end ? ov : -1; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const bool neg = SIGNED && o[u] >= neg_start;
@@ -1504,12 +1566,12 @@ __device__ __forceinline__ void segsum_dups_body(int D, const dup_side& t) {
                 cnt += ((int64_t)o1[j] < reg_limit) ? 1 : 0;
             }
             if (k2[j] == row[j]) {
-                int64_t end = q[j] + 3;
-                while (end < n && end <= q[j] + kLongSeg && keys[end] == row[j]) ++end;
+                const int64_t end = seg_end_probe<LPR>(keys, q[j], n, row[j]);
+                const uint32_t occ_l = seg_occ_fetch<LPR>(perm, q[j], end);
                 for (int64_t e0 = q[j] + 2; e0 < end; e0 += 8) {
                     int64_t o[8]; float4 g[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) o[u] = e0 + u < end ? (int64_t)perm[e0 + u] : -1;
+                    for (int u = 0; u < 8; ++u) { const int64_t ov = seg_occ_at<LPR>(perm, occ_l, q[j], e0 + u < end ? e0 + u : q[j] + 2); o[u] = e0 + u < end ? ov : -1; }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         g[u] = (o[u] >= 0 && live) ? ld4n<(LPR >= 32)>(G + (o[u] >= neg_start ? o[u] - neg_start : o[u]) * D + 4 * sub) : z4;
@@ -2086,7 +2148,7 @@ extern "C" int cdr_rowwise_apply(cdr_ctx* ctx, void* stream, int opt, float* tab
     CDR_LAUNCH_CHECK();
     if (may_have_long) {
         // sized for the worst case, but a launch whose counters read 0 retires in a few microseconds
-        const int gp = grid_for(piece_cap < 16384 ? piece_cap : 16384, kBlock / lpr);
+        const int gp = (int)(piece_cap < 2048 ? piece_cap : 2048);          // one workgroup per piece (looping past 2,048)
         if (is_signed) { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, true><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, occ_ids, counters, pieces, partial, pcnt)); }
         else { DISPATCH_LPR(lpr, seg_piece_sum_kernel<L, false><<<dim3(gp), dim3(kBlock), 0, s>>>(D, perm, G, neg_start, reg_limit, occ_ids, counters, pieces, partial, pcnt)); }
         CDR_LAUNCH_CHECK();
@@ -2159,7 +2221,7 @@ static int apply_dups_pair(cdr_ctx* ctx, hipStream_t s, int opt, int D, const du
     if (pl.long_cap[0] || pl.long_cap[1]) {
         const int64_t pc = pl.piece_cap[0] > pl.piece_cap[1] ? pl.piece_cap[0] : pl.piece_cap[1];
         const int64_t lc = pl.long_cap[0] > pl.long_cap[1] ? pl.long_cap[0] : pl.long_cap[1];
-        const int gp = grid_for(pc < 16384 ? pc : 16384, kBlock / lpr);
+        const int gp = (int)(pc < 2048 ? pc : 2048);                        // one workgroup per piece (looping past 2,048)
         DISPATCH_LPR(lpr, seg_piece_sum2_kernel<L><<<dim3(gp, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1]));
         CDR_LAUNCH_CHECK();
         const int gl = grid_for(lc < 4096 ? lc : 4096, kBlock / lpr);
@@ -2778,7 +2840,7 @@ extern "C" int cdr_bpr_shard_step(cdr_ctx* ctx, void* stream, int opt, float* us
     if (pl.long_cap[0] || pl.long_cap[1]) {
         const int64_t pc = pl.piece_cap[0] > pl.piece_cap[1] ? pl.piece_cap[0] : pl.piece_cap[1];
         const int64_t lc = pl.long_cap[0] > pl.long_cap[1] ? pl.long_cap[0] : pl.long_cap[1];
-        const int gp = grid_for(pc < 16384 ? pc : 16384, kBlock / lpr);
+        const int gp = (int)(pc < 2048 ? pc : 2048);                        // one workgroup per piece (looping past 2,048)
         DISPATCH_LPR(lpr, seg_piece_sum2_kernel<L><<<dim3(gp, 2), dim3(kBlock), 0, s>>>(D, pl.side[0], pl.side[1]));
         CDR_LAUNCH_CHECK();
         const int gl = grid_for(lc < 4096 ? lc : 4096, kBlock / lpr);
