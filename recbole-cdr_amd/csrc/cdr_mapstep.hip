@@ -31,6 +31,16 @@
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
 
+// The rows of the two user tables are touched once per step: their LDS-DMA loads and their write-backs are issued non-temporal (rows of
+// 512 bytes; replicated A/B on one MI355X: profiles/r06_ab_map_nt.txt).  -DCDR_NO_MAP_NT builds the plain-policy form.
+#ifndef CDR_NO_MAP_NT
+#define MAP_NT " nt"
+#define MAP_ST4(p, v) st4n<true>((p), (v))
+#else
+#define MAP_NT ""
+#define MAP_ST4(p, v) st4((p), (v))
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -280,8 +290,8 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                     float4 wn;
                     wn.x = upd1(w.x, gg.x, m.x, v.x, opt, ss_s, bc_s); wn.y = upd1(w.y, gg.y, m.y, v.y, opt, ss_s, bc_s);
                     wn.z = upd1(w.z, gg.z, m.z, v.z, opt, ss_s, bc_s); wn.w = upd1(w.w, gg.w, m.w, v.w, opt, ss_s, bc_s);
-                    st4(S + o, wn);
-                    if (opt.opt) { st4(mS + o, m); st4(vS + o, v); }
+                    MAP_ST4(S + o, wn);
+                    if (opt.opt) { MAP_ST4(mS + o, m); MAP_ST4(vS + o, v); }
                 }
                 for (int c = c0; c < (Dt >> 2); c += 8) {
                     const int64_t o = id * Dt + 4 * c;
@@ -291,8 +301,8 @@ __global__ __launch_bounds__(256, 2) void map_step_kernel(map_net net, map_opt o
                     float4 wn;
                     wn.x = upd1(w.x, -gn.x, m.x, v.x, opt, ss_t, bc_t); wn.y = upd1(w.y, -gn.y, m.y, v.y, opt, ss_t, bc_t);
                     wn.z = upd1(w.z, -gn.z, m.z, v.z, opt, ss_t, bc_t); wn.w = upd1(w.w, -gn.w, m.w, v.w, opt, ss_t, bc_t);
-                    st4(T + o, wn);
-                    if (opt.opt) { st4(mT + o, m); st4(vT + o, v); }
+                    MAP_ST4(T + o, wn);
+                    if (opt.opt) { MAP_ST4(mT + o, m); MAP_ST4(vT + o, v); }
                 }
             }
         }
@@ -347,7 +357,7 @@ template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_wai
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 
@@ -422,17 +432,17 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
         const unsigned d0 = __builtin_amdgcn_readfirstlane(dst_bytes + (unsigned)pw * 1024u);   // instruction i = pw + 4 q writes 1 KiB at i * 1 KiB
         unsigned keep;
         if constexpr (NQ == 4)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
                          : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]),
                            "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u), "s"(d0 + 12288u)
                          : "memory");
         else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(base + off[0]), "v"(base + off[1]), "s"(d0), "s"(d0 + 4096u) : "memory");
     };
     auto lds_off = [](const float* p) {
@@ -468,8 +478,8 @@ __global__ __launch_bounds__(512, 1) void map_pipe_kernel(map_net net, map_opt o
             wn.x = updq(w[q].x, sign * g[q].x, m[q].x, v[q].x, opt, ssz, rbc); wn.y = updq(w[q].y, sign * g[q].y, m[q].y, v[q].y, opt, ssz, rbc);
             wn.z = updq(w[q].z, sign * g[q].z, m[q].z, v[q].z, opt, ssz, rbc); wn.w = updq(w[q].w, sign * g[q].w, m[q].w, v[q].w, opt, ssz, rbc);
             if (okf[q] != 0.f) {
-                st4(tab + o[q], wn);
-                if (adam) { st4(mtab + o[q], m[q]); st4(vtab + o[q], v[q]); }
+                MAP_ST4(tab + o[q], wn);
+                if (adam) { MAP_ST4(mtab + o[q], m[q]); MAP_ST4(vtab + o[q], v[q]); }
             }
         }
     };
@@ -773,17 +783,17 @@ __global__ __launch_bounds__(512, 1) void map_pipe2_kernel(map_net net, map_opt 
         const unsigned d0 = __builtin_amdgcn_readfirstlane(dst_bytes + (unsigned)pw * 1024u);   // instruction i = pw + 4 q writes 1 KiB at i * 1 KiB
         unsigned keep;
         if constexpr (NQ == 4)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
                          : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]),
                            "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u), "s"(d0 + 12288u)
                          : "memory");
         else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(base + off[0]), "v"(base + off[1]), "s"(d0), "s"(d0 + 4096u) : "memory");
     };
     auto lds_off = [](const float* p) {
@@ -819,8 +829,8 @@ __global__ __launch_bounds__(512, 1) void map_pipe2_kernel(map_net net, map_opt 
             wn.x = updq(w[q].x, sign * g[q].x, m[q].x, v[q].x, opt, ssz, rbc); wn.y = updq(w[q].y, sign * g[q].y, m[q].y, v[q].y, opt, ssz, rbc);
             wn.z = updq(w[q].z, sign * g[q].z, m[q].z, v[q].z, opt, ssz, rbc); wn.w = updq(w[q].w, sign * g[q].w, m[q].w, v[q].w, opt, ssz, rbc);
             if (okf[q] != 0.f) {
-                st4(tab + o[q], wn);
-                if (adam) { st4(mtab + o[q], m[q]); st4(vtab + o[q], v[q]); }
+                MAP_ST4(tab + o[q], wn);
+                if (adam) { MAP_ST4(mtab + o[q], m[q]); MAP_ST4(vtab + o[q], v[q]); }
             }
         }
     };
@@ -1153,17 +1163,17 @@ __global__ __launch_bounds__(512, 1) void map_pipe3_kernel(map_net net, map_opt 
         const unsigned d0 = __builtin_amdgcn_readfirstlane(dst_bytes + (unsigned)pw * 1024u);   // instruction i = pw + 4 q writes 1 KiB at i * 1 KiB
         unsigned keep;
         if constexpr (NQ == 4)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
                          : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]),
                            "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u), "s"(d0 + 12288u)
                          : "memory");
         else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MAP_NT "\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MAP_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(base + off[0]), "v"(base + off[1]), "s"(d0), "s"(d0 + 4096u) : "memory");
     };
     auto lds_off = [](const float* p) {
@@ -1199,8 +1209,8 @@ __global__ __launch_bounds__(512, 1) void map_pipe3_kernel(map_net net, map_opt 
             wn.x = updq(w[q].x, sign * g[q].x, m[q].x, v[q].x, opt, ssz, rbc); wn.y = updq(w[q].y, sign * g[q].y, m[q].y, v[q].y, opt, ssz, rbc);
             wn.z = updq(w[q].z, sign * g[q].z, m[q].z, v[q].z, opt, ssz, rbc); wn.w = updq(w[q].w, sign * g[q].w, m[q].w, v[q].w, opt, ssz, rbc);
             if (okf[q] != 0.f) {
-                st4(tab + o[q], wn);
-                if (adam) { st4(mtab + o[q], m[q]); st4(vtab + o[q], v[q]); }
+                MAP_ST4(tab + o[q], wn);
+                if (adam) { MAP_ST4(mtab + o[q], m[q]); MAP_ST4(vtab + o[q], v[q]); }
             }
         }
     };

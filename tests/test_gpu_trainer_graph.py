@@ -90,6 +90,52 @@ def test_batch_producer_layout_draws_and_cursor(pointwise, k):
     assert int(smp.fail.item()) == 0
 
 
+@pytest.mark.parametrize('pointwise,k,two', [(False, 1, False), (True, 2, True)])
+def test_adam_launch_that_also_produces_the_next_batch_equals_the_two_launches(pointwise, k, two):
+    """Round 6 (cdr_adam_multi_dev_produce, trainer.DenseAdam.produce_jobs): the dense Adam of a step with the loader's next batch produced
+    in workgroups behind its own -- parameters, moments, update counts, the produced batch (both loaders of a BOTH state), the cursors and
+    the draw counters equal the optimizer launch followed by the producer launch, bit for bit, over several steps."""
+    from recbole_cdr_amd.data.producer import DeviceBatchProducer, CompositeProducer
+    from recbole_cdr_amd.trainer.trainer import DenseAdam
+    from recbole_cdr_amd.utils import InputType
+    ids, ds, s_pairs, t_pairs = _dataset()
+    it = InputType.POINTWISE if pointwise else InputType.PAIRWISE
+    batch = 64 * (1 + k if pointwise else k)
+
+    def setup():
+        dls = _loaders(ids, ds, s_pairs, t_pairs, it, batch, k)
+        parts = [DeviceBatchProducer(dls.source_dataloader)] + ([DeviceBatchProducer(dls.target_dataloader)] if two else [])
+        prod = CompositeProducer(parts) if two else parts[0]
+        torch.manual_seed(4)
+        ps = [torch.nn.Parameter(torch.randn(300, 64, device=DEV)), torch.nn.Parameter(torch.randn(17, device=DEV)), torch.nn.Parameter(torch.randn(40, 33, device=DEV))]
+        return prod, ps, DenseAdam(ps, lr=0.01)
+    pa, psa, oa = setup()
+    pb, psb, ob = setup()
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    for step in range(4):
+        grads = [torch.randn(p.shape, device=DEV, generator=g) for p in psa]
+        for p, q, gr in zip(psa, psb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(); pa.launch()                                   # two launches
+        ob.produce_jobs = pb.jobs(); ob.step()                   # one
+        assert ob.produce_jobs is None
+        torch.cuda.synchronize()
+        for p, q in zip(psa, psb):
+            assert torch.equal(p, q) and torch.equal(oa.state[p]['exp_avg'], ob.state[q]['exp_avg']) and torch.equal(oa.state[p]['exp_avg_sq'], ob.state[q]['exp_avg_sq'])
+            assert int(oa.state[p]['step']) == int(ob.state[q]['step']) == step + 1
+        for k_ in pa.fields:
+            assert torch.equal(pa.fields[k_], pb.fields[k_]), k_
+        for ca, cb in zip(pa.state_tensors(), pb.state_tensors()):
+            assert torch.equal(ca, cb) and int(ca[0]) == (step + 1) * 64 and int(ca[2]) == 0
+    # a step in which no parameter has a gradient still produces its batch
+    for q in psb:
+        q.grad = None
+    ob.produce_jobs = pb.jobs(); ob.step(); pa.launch()
+    torch.cuda.synchronize()
+    for k_ in pa.fields:
+        assert torch.equal(pa.fields[k_], pb.fields[k_]), k_
+
+
 def test_batch_producer_overlap_slices_and_graph_replay():
     """k = 0: OverlapDataloader's [OB, 1] slices; captured once, every replay yields the next slice."""
     from recbole_cdr_amd import binding as B_
