@@ -1,3 +1,5 @@
+# A/B harness of round 6 (run on the GPU box through gpurun).  The variant library is built out of tree from a copy of csrc/ with the macro named
+# in DESIGN.md / csrc (e.g. -DCDR_NO_STREAM_NT, -DCDR_NO_MAP_NT) and LIB=tools/r06/ab/<name>.so; CDR_LIB_PATH selects it per run.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06q
 P=$GRAFT_REPO_ROOT/tools/r06/ab/libcdrhip_nomapnt.so
