@@ -132,7 +132,7 @@ class FusedBPRStep:
                 elif not self._use_count and nd <= 8192:     # (the sorted path reports the duplicate occurrences only: heads[3] stays 0 there)
                     self._use_count = True
                 self._stat = None
-        on = in_range and self._use_count
+        on = in_range and self._use_count and not (capturing and self._count is None)     # (never allocate + zero-fill 4 B per table row inside a capture)
         if on:
             cu, ci, ws = self._count_buffers()
             B_.call('cdr_ctx_set_id_counters', ctxh, B_.raw(cu), cu.numel(), B_.raw(ci), ci.numel(), B_.raw(ws), ws.numel())
