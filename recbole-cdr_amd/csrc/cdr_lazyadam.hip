@@ -21,6 +21,7 @@
 // Memory per step: 3 row reads + 3 row writes per touched row (twice: prepare + apply) instead of 7 x the table.
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -183,6 +184,136 @@ __global__ __launch_bounds__(kBlock) void lz_prepare1_kernel(lz_args a, float2* 
     }
 }
 
+// ---- the same, TWO elements per lane, the ring scalars staged in LDS (round 6) -----------------------------------------------------
+// lz_prepare1_kernel's inner loop is 135 instructions per eight updates of one element, of which 47 fetch the eight ring entries (64-bit
+// index arithmetic per lane and eight global loads) and 16 are the quarter-rate v_sqrt / v_rcp: ~90 SIMD cycles per update of 64 elements.
+// Here (a) a workgroup copies the window of the ring its rows need -- the last max-lag entries, the same for every row up to where each
+// starts -- into LDS once, and a chunk's eight entries are eight ds_read_b64 off ONE address register with immediate offsets; (b) a lane
+// owns two neighbouring elements as a 2-vector, so every add / multiply of the update is one v_pk_*_f32 for both (the sqrt / rcp stay one
+// per element): ~53 cycles per update of 64 elements.  A D = 128 row is one wave again -- no barrier for the row's `last`, no second wave
+// to race with.  Element by element the operations are lz_elem_nograd's, in its order, contraction off: bit-identical rows.
+typedef float lz_f2 __attribute__((ext_vector_type(2)));
+constexpr int kWin = 1024;                                              // ring entries staged per workgroup (8 KB); a longer lag starts from global memory
+
+__device__ __forceinline__ lz_f2 lz_elem2_nograd(lz_f2 pv, lz_f2& m, lz_f2& v, float b1, float b2, float eps, float step_size, float bc2) {
+#pragma clang fp contract(off)
+#ifdef CDR_ADAM_IEEE
+    lz_f2 r;
+    float mx = m.x, my = m.y, vx = v.x, vy = v.y;
+    r.x = lz_elem_nograd(pv.x, mx, vx, b1, b2, eps, step_size, bc2);
+    r.y = lz_elem_nograd(pv.y, my, vy, b1, b2, eps, step_size, bc2);
+    m.x = mx; m.y = my; v.x = vx; v.y = vy;
+    return r;
+#else
+    const lz_f2 mv = m + (-m) * (1.0f - b1);                             // (0 - m) and -m differ for m = +-0 only, and m + (+-0)(1 - b1) is m's +0 either way
+    const lz_f2 vv = b2 * v;
+    m = mv; v = vv;
+    lz_f2 sq, rc;
+    sq.x = __builtin_amdgcn_sqrtf(vv.x); sq.y = __builtin_amdgcn_sqrtf(vv.y);
+    const lz_f2 denom = sq * bc2 + eps;                                  // cdr_adam_term, both elements at once
+    rc.x = __builtin_amdgcn_rcpf(denom.x); rc.y = __builtin_amdgcn_rcpf(denom.y);
+    return pv - step_size * (mv * rc);
+#endif
+}
+
+__global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* __restrict__ hp, int64_t* __restrict__ counters, int lanes_per_row) {
+    // Dependent memory round trips of a workgroup: {keys, the newest kBlock ring entries} -> {last, W, M, V} -> replay -> stores.  (As first
+    // written -- keys -> last -> window of the longest lag -> rows -- a launch over rows that were all less than 48 updates behind still took
+    // 22 us: four trips of latency per workgroup and ~4.6 rounds of workgroups per CU.)  The row is requested together with its `last`,
+    // before it is known whether it has anything to replay (duplicate occurrences excepted: they are known from the keys).
+    __shared__ float2 win[kWin];                                        // win[p] = the scalars of update to - kWin + 1 + p
+    __shared__ int lag_max[2];
+    const lz_table tb = a.t[blockIdx.y];
+    const int rows_per_block = kBlock / lanes_per_row;
+    const int sub = threadIdx.x % lanes_per_row;
+    const int grp = threadIdx.x / lanes_per_row;
+    const int64_t TG = (int64_t)gridDim.x * rows_per_block;
+    const int D = a.D, D2 = D >> 1;
+    const int64_t t = counters[0] + 1;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        float ss, bc;
+        cdr_adam_hp((double)t, a.lr, a.b1, a.b2, ss, bc);
+        hp[t & a.hp_mask] = make_float2(ss, bc);
+        counters[1] = t;
+    }
+    const int64_t to = t - 1;
+    const int64_t w0 = to - kWin + 1;
+    int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    // first trip's keys, then the window's newest entries
+    uint32_t row = 0; bool mine = false;
+    if (grp < rows_per_block && base + grp < tb.n) {
+        const int64_t q = base + grp;
+        row = tb.keys[q];
+        mine = !(q > 0 && tb.keys[q - 1] == row);                       // one lane group per DISTINCT row
+    }
+    {
+        const int p = kWin - kBlock + (int)threadIdx.x;
+        if (w0 + p >= 1) win[p] = hp[(w0 + p) & a.hp_mask];
+    }
+    if (threadIdx.x < 2) lag_max[threadIdx.x] = 0;
+    int staged = kBlock;                                                // ring entries in `win`, counted from the newest (block-uniform)
+    __syncthreads();
+    for (int trip = 0; base < tb.n; base += TG, ++trip) {               // block-uniform: barriers inside
+        int64_t from = to;
+        lz_f2 w = {0.f, 0.f}, m = {0.f, 0.f}, v = {0.f, 0.f};
+        const int64_t o = (int64_t)row * D + 2 * sub;
+        if (mine) {
+            from = tb.last[row];
+            if (sub < D2) { w = *(const lz_f2*)(tb.W + o); m = *(const lz_f2*)(tb.M + o); v = *(const lz_f2*)(tb.V + o); }
+        }
+        if (sub == 0 && from < to) atomicMax(&lag_max[trip & 1], (int)(to - from));
+        if (threadIdx.x == 0) lag_max[(trip + 1) & 1] = 0;              // last read before the barrier that ended the previous trip
+        __syncthreads();                                                 // (also: every wave of a wide row has read `last` before one moves it)
+        int need = lag_max[trip & 1];
+        need = need < kWin ? need : kWin;
+        if (need > staged) {
+            for (int p = kWin - need + (int)threadIdx.x; p < kWin - staged; p += kBlock) win[p] = hp[(w0 + p) & a.hp_mask];
+            staged = need;
+            __syncthreads();
+        }
+        if (from < to) {
+            // (zero moments without weight decay: a fixed point, as in replay(); a pair with one such element replays it to itself)
+            if (sub < D2 && (a.wd != 0.f || m.x != 0.f || m.y != 0.f || v.x != 0.f || v.y != 0.f)) {
+                int64_t tau = from + 1;
+                if (a.wd == 0.f) {
+                    for (; tau < to - kWin + 1; ++tau) {                 // postponed further than the window holds
+                        const float2 h = hp[tau & a.hp_mask];
+                        w = lz_elem2_nograd(w, m, v, a.b1, a.b2, a.eps, h.x, h.y);
+                    }
+                    constexpr int CH = 8;
+                    int p = (int)(tau - w0);
+                    for (; p + CH <= kWin; p += CH) {                    // eight updates, straight line
+                        float2 h[CH];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) h[j] = win[p + j];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) w = lz_elem2_nograd(w, m, v, a.b1, a.b2, a.eps, h[j].x, h[j].y);
+                    }
+                    for (; p < kWin; ++p) { const float2 h = win[p]; w = lz_elem2_nograd(w, m, v, a.b1, a.b2, a.eps, h.x, h.y); }
+                } else {
+                    for (; tau <= to; ++tau) {
+                        const float2 h = hp[tau & a.hp_mask];
+                        float mx = m.x, my = m.y, vx = v.x, vy = v.y;
+                        w.x = cdr_adam_elem(w.x, 0.f, mx, vx, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
+                        w.y = cdr_adam_elem(w.y, 0.f, my, vy, a.b1, a.b2, a.eps, a.wd, h.x, h.y);
+                        m.x = mx; m.y = my; v.x = vx; v.y = vy;
+                    }
+                }
+                *(lz_f2*)(tb.W + o) = w; *(lz_f2*)(tb.M + o) = m; *(lz_f2*)(tb.V + o) = v;
+            }
+            if (sub == 0) tb.last[row] = (int32_t)to;
+        }
+        // next trip's keys
+        row = 0; mine = false;
+        if (grp < rows_per_block && base + TG + grp < tb.n) {
+            const int64_t q = base + TG + grp;
+            row = tb.keys[q];
+            mine = !(q > 0 && tb.keys[q - 1] == row);
+        }
+        __syncthreads();
+    }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void lz_apply_kernel(lz_args a, const float2* __restrict__ hp, int64_t* __restrict__ counters) {
     constexpr int GPB = kBlock / LPR;
@@ -298,6 +429,12 @@ int fill(lz_args& a, int count, int D, float* const* W, float* const* M, float* 
     return 1;
 }
 
+// CDR_LZ_PREPARE=1: the one-element-per-lane kernel of rounds 4-5 (A/B runs)
+inline bool prepare_one_per_lane() {
+    static const bool v = [] { const char* e = getenv("CDR_LZ_PREPARE"); return e && e[0] == '1'; }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* const* W, float* const* M, float* const* V,
@@ -308,6 +445,19 @@ extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* cons
     lz_args a; int64_t nmax;
     if (!fill(a, count, D, W, M, V, last, keys_sorted, nullptr, n, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax, hp_capacity)) {
         cdr_set_error("cdr_lazy_adam_prepare: bad table description"); return CDR_EINVAL;
+    }
+    if (D % 2 == 0 && D <= 2 * kBlock && !prepare_one_per_lane()) {
+        // two elements per lane, ring scalars out of LDS (see lz_prepare2_kernel): a row takes D / 2 lanes, rounded up to a power of two
+        // inside a wave or to whole waves
+        const int D2 = D / 2;
+        int lanes = 1;
+        if (D2 <= 64) { while (lanes < D2) lanes *= 2; } else lanes = (D2 + 63) / 64 * 64;
+        const int rpb = kBlock / lanes;
+        int64_t g = (nmax + rpb - 1) / rpb;
+        if (g > CDR_NUM_CU * 32) g = CDR_NUM_CU * 32;
+        lz_prepare2_kernel<<<dim3((unsigned)g, count), dim3(kBlock), 0, (hipStream_t)stream>>>(a, (float2*)hp_table, counters, lanes);
+        CDR_LAUNCH_CHECK();
+        return CDR_OK;
     }
     if (D <= kBlock) {
         // one element per lane: a row takes D lanes rounded up to whole waves (see lz_prepare1_kernel)
