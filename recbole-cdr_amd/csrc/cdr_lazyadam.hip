@@ -221,6 +221,10 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
     // written -- keys -> last -> window of the longest lag -> rows -- a launch over rows that were all less than 48 updates behind still took
     // 22 us: four trips of latency per workgroup and ~4.6 rounds of workgroups per CU.)  The row is requested together with its `last`,
     // before it is known whether it has anything to replay (duplicate occurrences excepted: they are known from the keys).
+    // C3 in steady state (rocprofv3, 400 steps): lz_prepare1_kernel 47.8 us, this kernel 36.3 us -- against ~18-26 us of VALU issue time
+    // for the step's ~4-6 x 10^5 postponed row-updates (per update of 64 element pairs: 12-13 full-rate instructions and 2 x 2 quarter-rate
+    // v_sqrt / v_rcp = ~114 cycles).  Tried and not kept: a window per WAVE and no workgroup barrier for rows of one wave (a lane group
+    // on a duplicate occurrence leaves at once instead of waiting at the barriers): 37.9 us -- four times the ring requests.
     __shared__ float2 win[kWin];                                        // win[p] = the scalars of update to - kWin + 1 + p
     __shared__ int lag_max[2];
     const lz_table tb = a.t[blockIdx.y];

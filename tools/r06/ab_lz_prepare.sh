@@ -21,10 +21,10 @@ for rep in 1 2; do
 done
 for v in 0 1; do
   rm -rf $O/trace_lz_$v
-  CDR_LZ_PREPARE=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lz_$v -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --no-fullsort --steps 40 --warmup 8 > /dev/null 2>&1
+  CDR_LZ_PREPARE=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lz_$v -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --no-fullsort --steps 400 --warmup 40 > /dev/null 2>&1
   echo "== kernel stats CDR_LZ_PREPARE=$v"
   f=$(find $O/trace_lz_$v -name '*kernel_stats.csv' | head -1)
-  head -12 $f | cut -c1-160
+  grep -E 'lz_|conet_fb|rank_' $f | cut -c1-200
 done
 } > $O/ab_lz_prepare.txt 2>&1
 tail -60 $O/ab_lz_prepare.txt
