@@ -1,8 +1,8 @@
 # A/B of the unrolled CoNet step's launch order (bench.py --workload c3): plain | one batch ahead on the side stream | two batches ahead
 ulimit -c 0
 O=gpurun_out/c3p; mkdir -p $O
-python -m pytest tests/test_gpu_trainer_graph.py -q -x -k "conet or producer" 2>&1 | tail -3
-for v in "1 8" "one_ahead 8" "0 8" "1 16" "1 4"; do
+:
+for v in "1 8" "two_ahead 8" "0 8" "1 16" "two_ahead 16"; do
   set -- $v
   CDR_GRAPH_PIPELINE=$1 CDR_GRAPH_UNROLL=$2 python bench.py --workload c3 --no-cpu-baseline --no-fullsort --steps 400 --warmup 40 > $O/p$1_u$2.json 2> $O/p$1_u$2.err || echo "rc=$? for $v"
   python - <<PY

@@ -6,9 +6,9 @@ import recbole_cdr_amd  # noqa
 from recbole_cdr_amd import binding as B_
 dev = 'cuda:0'
 g = torch.Generator(device=dev).manual_seed(0)
-for sizes in ([(100, 0)], [(2048, 0), (2048, 2048)], [(512, 0), (512, 2048)], [(4096, 0), (4096, 4096)], [(8190, 0), (8190, 0)], [(8192, 0), (8192, 8192)]):
-    a = [torch.randint(0, 50_000_000, (n0,), device=dev, generator=g) for n0, _ in sizes]
-    b = [torch.randint(0, 10_000_000, (n1,), device=dev, generator=g) if n1 else None for _, n1 in sizes]
+for sizes in ([(100, 0)], [(2048, 0), (2048, 2048)], [(512, 0), (512, 2048)], [(4096, 0), (4096, 4096)], [(8190, 0), (8190, 0)], [(4095, 4095), (4095, 4095)], [(8192, 0), (8192, 8192)]):
+    a = [torch.randint(0, int(os.environ.get('IDMAX', 50_000_000)), (n0,), device=dev, generator=g) for n0, _ in sizes]
+    b = [torch.randint(0, int(os.environ.get('IDMAX', 10_000_000)), (n1,), device=dev, generator=g) if n1 else None for _, n1 in sizes]
     offs, tot = [], 0
     for n0, n1 in sizes:
         offs.append(tot); tot += n0 + n1
