@@ -55,7 +55,7 @@ int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
 int cdr_ctx_set_id_counters(cdr_ctx* ctx, uint32_t* user_counts, int64_t user_rows, uint32_t* item_counts, int64_t item_rows,
                             void* list_ws, size_t list_ws_bytes);
 int cdr_id_count_workspace_bytes(int64_t B, size_t* bytes);
-#define CDR_ABI_VERSION 55
+#define CDR_ABI_VERSION 56
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -418,9 +418,16 @@ int cdr_lazy_adam_flush(void* stream, int D, float* W, float* M, float* V, int32
  * No float atomics: partial sums are added in a fixed order.  cdr_conet_plan gives act_width and the workspace size.
  * Training steps: cdr_conet_fwd with gz, gx0 and the workspace given (all three or none) also runs the DATA backward of every row
  * block in the same launch, for a unit upstream gradient, and reports it in *data_gradients_done (0: this shape keeps the two-launch
- * route); cdr_conet_bwd is then called with that flag, skips its data pass and applies grad_out (any value) to the results.       */
+ * route); cdr_conet_bwd is then called with that flag, skips its data pass and applies grad_out (any value) to the results.
+ * cdr_conet_defer_finish(ctx, 1): from now on a TRAINING forward on this context does not add its blocks' loss partials itself -- `out`
+ * is complete only after the cdr_conet_bwd that follows on the same stream (its weight-gradient launch gets one workgroup more instead
+ * of the forward's finishing launch).  For a caller that differentiates every loss at once and reads it afterwards (a captured step:
+ * graph_step.GraphedTrainStep); the drop-in default (0) keeps `out` valid when cdr_conet_fwd's launches retire, as conet.py:186-203's
+ * caller expects (recbole's Trainer checks the loss for NaN before backward()).  A deferred forward that is followed by another forward
+ * instead of its backward is finished first.                                                                                        */
 #define CDR_CONET_MAX_LAYERS 8
 int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width, size_t* workspace_bytes);
+int cdr_conet_defer_finish(cdr_ctx* ctx, int on);
 int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab, const float* ti_tab,
                   int D, const int64_t* user_s /* [n_source] */, const int64_t* user_t /* [R - n_source] */, const int64_t* item_s,
                   const int64_t* item_t, int64_t R, int64_t n_source, int64_t n_overlap, int overlap_users, int L, const int* dims,

@@ -24,6 +24,12 @@ struct cdr_ctx {
     uint32_t* idc_user; int64_t idc_user_rows;
     uint32_t* idc_item; int64_t idc_item_rows;
     void* idc_list; size_t idc_list_bytes;
+    // cdr_conet_defer_finish: a training forward of the CoNet towers leaves the addition of its blocks' loss partials to the backward's
+    // weight-gradient launch (one workgroup more there instead of a launch of its own); `pending` between the two calls
+    int conet_defer, conet_pending, conet_fin_grid;
+    int64_t conet_fin_ns, conet_fin_R;
+    float* conet_fin_out;
+    void* conet_fin_stream;
     // optional HIP-event brackets around the hot kernels, recorded on the launch stream (cdr_timing_*)
     int timing_cap, timing_n;
     hipEvent_t* ev0;

@@ -1502,11 +1502,18 @@ __device__ __forceinline__ void wgrad_job(const wg_src& q, int64_t r_begin, bool
 }
 
 // One WORKGROUP per (job, group of four row chunks); wave w takes chunk 4 g + w.
+// `fin` (cdr_conet_defer_finish): the launch's LAST workgroup adds the forward blocks' loss partials instead of a weight-gradient job
+// (conet_fwd_finish_kernel's work; the reader of `out`, conet_wgrad_finish_kernel, is the next launch)
+struct conet_fin { const double* partials; float* out; int nblocks; int64_t n_source; };
 __global__ __launch_bounds__(256) void conet_wgrad_kernel(conet_net net, conet_tiles jl, int64_t R, int64_t kc,
                                                           const float* __restrict__ x0, const float* __restrict__ acts,
                                                           const float* __restrict__ gz, const float* __restrict__ maskf,
-                                                          float* __restrict__ wpart) {
+                                                          float* __restrict__ wpart, conet_fin fin) {
     extern __shared__ __attribute__((aligned(16))) float red[];          // [4][kJobFloats]
+    if (fin.out && blockIdx.x == gridDim.x - 1) {
+        conet_finish_block(net, fin.partials, fin.nblocks, fin.n_source, R, fin.out, reinterpret_cast<double*>(red));
+        return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int jb = (int)(blockIdx.x % (unsigned)jl.ntiles), g = (int)(blockIdx.x / (unsigned)jl.ntiles);
     const job_id d = decode_job(net, jl, jb);
@@ -1734,6 +1741,12 @@ extern "C" int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width,
     return CDR_OK;
 }
 
+extern "C" int cdr_conet_defer_finish(cdr_ctx* ctx, int on) {
+    CDR_CHECK_ARG(ctx);
+    ctx->conet_defer = on ? 1 : 0;
+    return CDR_OK;
+}
+
 extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, const float* si_tab, const float* tu_tab,
                              const float* ti_tab, int D, const int64_t* user_s, const int64_t* user_t, const int64_t* item_s,
                              const int64_t* item_t, int64_t R, int64_t n_source,
@@ -1753,6 +1766,12 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)rows_grid(R);
+    if (ctx->conet_pending) {                    // a deferred forward whose backward never came: its loss is added now, before its partials go
+        ctx->conet_pending = 0;
+        conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)ctx->conet_fin_stream>>>(net, ctx->partials, ctx->conet_fin_grid, ctx->conet_fin_ns,
+                                                                                              ctx->conet_fin_R, ctx->conet_fin_out);
+        CDR_LAUNCH_CHECK();
+    }
     if (gz && lp.fb_bytes) {                     // training step: forward and data backward of every 32-row block in one launch
         int aw = 0; size_t need = 0;
         rc = cdr_conet_plan(L, dims, R, &aw, &need);
@@ -1783,8 +1802,13 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
                                                                               ou_part);
         }
         CDR_LAUNCH_CHECK();
-        conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(net, ctx->partials, grid, n_source, R, out);
-        CDR_LAUNCH_CHECK();
+        if (ctx->conet_defer) {                  // cdr_conet_bwd's weight-gradient launch adds the partials
+            ctx->conet_pending = 1; ctx->conet_fin_grid = grid; ctx->conet_fin_ns = n_source; ctx->conet_fin_R = R; ctx->conet_fin_out = out;
+            ctx->conet_fin_stream = stream;
+        } else {
+            conet_fwd_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(net, ctx->partials, grid, n_source, R, out);
+            CDR_LAUNCH_CHECK();
+        }
         *data_gradients_done = 1;
         return CDR_OK;
     }
@@ -1841,10 +1865,19 @@ extern "C" int cdr_conet_bwd(cdr_ctx* ctx, void* stream, int64_t R, int64_t n_so
                                                                      lp.strideG1, gz, gx0, ou_part);
     }
     CDR_LAUNCH_CHECK();
+    conet_fin fin{nullptr, nullptr, 0, 0};
+    if (ctx->conet_pending) {
+        if (ctx->conet_fin_out != out || ctx->conet_fin_R != R || ctx->conet_fin_stream != stream) {
+            cdr_set_error("cdr_conet_bwd: a deferred forward (cdr_conet_defer_finish) is pending for another loss / stream");
+            return CDR_EINVAL;
+        }
+        fin = conet_fin{ctx->partials, ctx->conet_fin_out, ctx->conet_fin_grid, ctx->conet_fin_ns};
+        ctx->conet_pending = 0;
+    }
     {
         cdr_time_scope ts(ctx, CDR_TAG_CONET_WGRAD, s);
-        conet_wgrad_kernel<<<dim3((unsigned)(tl.ntiles * ngroup)), dim3(256), 4 * kJobFloats * sizeof(float), s>>>(net, tl, R, kc, x0, acts, gz,
-                                                                                                                    maskf, wpart);
+        conet_wgrad_kernel<<<dim3((unsigned)(tl.ntiles * ngroup + (fin.out ? 1 : 0))), dim3(256), 4 * kJobFloats * sizeof(float), s>>>(
+            net, tl, R, kc, x0, acts, gz, maskf, wpart, fin);
     }
     CDR_LAUNCH_CHECK();
     conet_wgrad_finish_kernel<<<dim3((unsigned)(tl.ntiles * ((kJobFloats + 255) / 256) + 1)), dim3(256), 0, s>>>(

@@ -1102,6 +1102,10 @@ class ConetFusedLoss(Function):
             # (a workspace of its own: its output-unit partials must survive until THIS node's backward, whatever runs in between)
             gz, gx0, ws = f32(R, aw.value), f32(R, 4 * D), torch.empty(int(need.value), device=dev, dtype=torch.uint8)
         done = ctypes.c_int(0)
+        # a captured, pipelined step (graph_step.GraphedTrainStep) differentiates every loss at once and reads it afterwards: the addition of
+        # the forward blocks' loss partials then rides in the backward's weight-gradient launch (cdr_conet_defer_finish; ``out`` -- and the
+        # loss tensor -- are complete only behind that launch).  Everyone else gets the loss when the forward's launches retire.
+        B_.call('cdr_conet_defer_finish', B_.ctx(dev), 1 if (train and row_opt is not None and getattr(row_opt, 'defer_finish', False)) else 0)
         B_.call('cdr_conet_fwd', B_.ctx(dev), B_.stream(), B_.f32(su), B_.f32(si), B_.f32(tu), B_.f32(ti), D, B_.i64(user_s),
                 B_.i64(user_t), B_.i64(item_s), B_.i64(item_t), R, int(n_source), int(n_overlap), 1 if overlap_users else 0, L, dims_c,
                 pp, B_.f32(label_s), B_.f32(label_t), B_.f32(x0), B_.f32(acts), B_.f32(prob), B_.f32(maskf), B_.f32(label),

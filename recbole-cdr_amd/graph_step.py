@@ -13,6 +13,7 @@ Where the batch comes from:
 ``loss_sum`` (a device scalar): every step -- replayed or eager -- adds its loss to it, inside the graph for replays, so an epoch's
 loss total costs no extra launch and no host sync per step (``CrossDomainTrainer`` reads it once per epoch).
 """
+import os
 import torch
 
 from .binding import capturing
@@ -175,6 +176,19 @@ class GraphedTrainStep:
         rows} beside the main stream's weight gradients and dense Adam."""
         self.producer.launch()
         self.model.prepare_batch(self.static)
+        loss = None
+        ro = getattr(self.optimizer, 'row_opt', None)
+        try:
+            # every loss of this sequence is differentiated at once and read only by the optimizer's launch behind the backward: the model's
+            # forward may leave the addition of its loss partials to its backward's launches (CoNet: cdr_conet_defer_finish, one launch less)
+            if ro is not None and os.environ.get('CDR_CONET_DEFER_FINISH', '1') != '0':
+                ro.defer_finish = True
+            return self._one_ahead_steps(k, main, side)
+        finally:
+            if ro is not None:
+                ro.defer_finish = False
+
+    def _one_ahead_steps(self, k, main, side):
         loss = None
         for i in range(k):
             self.optimizer.zero_grad(set_to_none=True)

@@ -46,6 +46,7 @@ class DeferredRowAdam:
         # ``apply_early()`` launches the update then, and the ``step()`` that follows the backward only does the bookkeeping
         self.early = None
         self._applied_early = False
+        self.defer_finish = False        # set around a pipelined captured step: the model's forward may leave its loss total to the backward's launches
         self._prepared = None            # id of the batch ``prepare`` last ran for (``prepare_once``)
 
     # ---- id sort (per list): the small rank sort up to 16,384 ids, the radix sort above --------------------------------------

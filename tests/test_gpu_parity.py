@@ -982,6 +982,65 @@ def test_conet_fused_ragged_shapes_and_determinism(R, n_s, hidden, D):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+def test_conet_loss_total_deferred_to_the_backward_launch():
+    """``cdr_conet_defer_finish`` (what a pipelined captured step switches on through ``row_opt.defer_finish``): the forward leaves the
+    addition of its blocks' loss partials to the backward's weight-gradient launch.  Same loss bits, same loss parts, same layer
+    gradients and same trained rows as the default order; a deferred forward followed by ANOTHER forward instead of its backward is
+    finished first, and a forward that is not deferred is complete when its own launches retire."""
+    from oracle.common import IdSpace
+    from recbole_cdr_amd.model.cross_domain_recommender.conet import CoNet
+    from recbole_cdr_amd.trainer.trainer import RowAwareAdam
+    ids = IdSpace(OU=300, TOU=500, SOU=700, OI=1, TOI=900, SOI=1100)
+    cfg = base_config(DEV, embedding_size=128, reg_weight=0.01, mlp_hidden_size=[64, 32, 16, 8])
+    rs = np.random.RandomState(5)
+    n_s, n_t = 1001, 777
+    inters = []
+    for _ in range(3):
+        inters.append(to_dev({'source_user_id': torch.from_numpy(rs.randint(0, ids.total_num_users, n_s)),
+                              'source_item_id': torch.from_numpy(rs.randint(0, ids.total_num_items, n_s)),
+                              'source_label': torch.from_numpy((rs.rand(n_s) < 0.3).astype(np.float32)),
+                              'target_user_id': torch.from_numpy(rs.randint(0, ids.OU + ids.TOU, n_t)),
+                              'target_item_id': torch.from_numpy(rs.randint(0, ids.OI + ids.TOI, n_t)),
+                              'target_label': torch.from_numpy((rs.rand(n_t) < 0.3).astype(np.float32))}, DEV))
+
+    def train(defer):
+        torch.manual_seed(13)
+        model = CoNet(cfg, FakeDataset(ids)).to(DEV)
+        opt = RowAwareAdam(model, lr=1e-2)
+        ro = opt.row_opt
+        losses, parts, grads = [], [], None
+        for it in inters:
+            opt.zero_grad(set_to_none=True)
+            ro.defer_finish = defer
+            loss = model.calculate_loss(it)
+            ro.defer_finish = False
+            loss.backward()
+            losses.append(loss.detach().clone()); parts.append(model.last_loss_parts.detach().clone())
+            grads = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+            opt.step()
+        model.sync_tables()
+        return losses, parts, grads, {k: v.detach().clone() for k, v in model.named_parameters()}, model, ro
+
+    a = train(False)
+    b = train(True)
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert torch.equal(x, y)
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    model, ro = b[4], b[5]
+    ro.defer_finish = True
+    l1 = model.calculate_loss(inters[0])                     # deferred, and its backward never comes
+    ro.defer_finish = False
+    l2 = model.calculate_loss(inters[1])                     # finishes l1 first; complete itself when its launches retire
+    torch.cuda.synchronize()
+    v1, v2 = float(l1), float(l2)
+    with torch.no_grad():                                    # plain forwards of the same batches
+        r1, r2 = float(model.calculate_loss(inters[0])), float(model.calculate_loss(inters[1]))
+    assert v1 == r1 and v2 == r2, (v1, r1, v2, r2)
+
+
 def test_conet_forward_and_data_backward_in_one_launch(monkeypatch):
     """A differentiated CoNet forward also runs the data backward of every row block in the same launch (conet_fb_kernel), for a
     unit upstream gradient: (a) same loss bits and same gradients as the two-launch route (table and layer gradients bit for bit: same
