@@ -55,7 +55,7 @@ int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
 int cdr_ctx_set_id_counters(cdr_ctx* ctx, uint32_t* user_counts, int64_t user_rows, uint32_t* item_counts, int64_t item_rows,
                             void* list_ws, size_t list_ws_bytes);
 int cdr_id_count_workspace_bytes(int64_t B, size_t* bytes);
-#define CDR_ABI_VERSION 56
+#define CDR_ABI_VERSION 57
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -847,6 +847,13 @@ int cdr_adam_multi_dev_produce(void* stream, int count, float* const* params, co
                                float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev, float lr, float beta1,
                                float beta2, float eps, float weight_decay, const float* loss, float* loss_sum, unsigned* ticket,
                                const cdr_batch_job* jobs, int n_jobs);
+/* cdr_lazy_adam_apply(...) and cdr_batch_produce_jobs(jobs) in ONE launch: the deferred Adam's row update of step i with the loader's batch
+ * i + 1 produced in workgroups behind its own (the update reads the sorted ids and the gradient rows, never the batch buffers).  Same
+ * results as the two calls.                                                                                                            */
+int cdr_lazy_adam_apply_produce(void* stream, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
+                                const uint32_t* const* keys_sorted, const uint32_t* const* perm, const int64_t* n, const float* const* G,
+                                const int64_t* ldg, float lr, float beta1, float beta2, float eps, float weight_decay, const void* hp_table,
+                                int64_t hp_capacity, int64_t* counters, const cdr_batch_job* jobs, int n_jobs);
 int cdr_batch_produce(void* stream, const int64_t* users_all, const int64_t* items_all, int64_t n_rows, int64_t* cursor,
                       int64_t S, int k, int pointwise, int dist, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1,
                       const int64_t* keys, const float* prob, const int64_t* alias, int64_t n_keys,

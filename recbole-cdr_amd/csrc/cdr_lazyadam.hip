@@ -21,6 +21,7 @@
 // Memory per step: 3 row reads + 3 row writes per touched row (twice: prepare + apply) instead of 7 x the table.
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
+#include "cdr_produce.h"
 #include <stdlib.h>
 
 namespace {
@@ -318,13 +319,26 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
     }
 }
 
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void lz_apply_kernel(lz_args a, const float2* __restrict__ hp, int64_t* __restrict__ counters) {
+// PROD (cdr_lazy_adam_apply_produce): the loader's next batch is produced by workgroups behind the update's own in grid row 0 -- the two
+// are independent (the update reads the sorted ids and the gradient rows, never the batch buffers) and the producer alone is a 10 us launch
+struct lz_prod { cdr_produce::batch_jobs jobs; int gx[CDR_BATCH_MAX_JOBS]; int n; unsigned n_apply; };
+template <int LPR, bool PROD>
+__global__ __launch_bounds__(kBlock) void lz_apply_kernel(lz_args a, const float2* __restrict__ hp, int64_t* __restrict__ counters, lz_prod ps) {
     constexpr int GPB = kBlock / LPR;
+    if (PROD && blockIdx.x >= ps.n_apply) {
+        if (blockIdx.y == 0) {
+            unsigned b = blockIdx.x - ps.n_apply;
+            for (int j = 0; j < ps.n; ++j) {
+                if (b < (unsigned)ps.gx[j]) { cdr_produce::batch_produce_body(ps.jobs.j[j], b, (unsigned)ps.gx[j]); return; }
+                b -= (unsigned)ps.gx[j];
+            }
+        }
+        return;
+    }
     const lz_table tb = a.t[blockIdx.y];
     const int sub = threadIdx.x % LPR;
     const int64_t gg = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-    const int64_t TG = (int64_t)gridDim.x * GPB;
+    const int64_t TG = (int64_t)(PROD ? ps.n_apply : gridDim.x) * GPB;
     const int D = a.D, D4 = D >> 2;
     const int64_t t = counters[1];
     const float2 h = hp[t & a.hp_mask];
@@ -491,7 +505,35 @@ extern "C" int cdr_lazy_adam_apply(void* stream, int count, int D, float* const*
     const int lpr = cdr_lpr_for(D);
     const dim3 grid(grid_for(nmax, kBlock / lpr), count);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_LPR(lpr, lz_apply_kernel<L><<<grid, dim3(kBlock), 0, s>>>(a, (const float2*)hp_table, counters));
+    DISPATCH_LPR(lpr, lz_apply_kernel<L, false><<<grid, dim3(kBlock), 0, s>>>(a, (const float2*)hp_table, counters, lz_prod{}));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+extern "C" int cdr_lazy_adam_apply_produce(void* stream, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
+                                           const uint32_t* const* keys_sorted, const uint32_t* const* perm, const int64_t* n, const float* const* G,
+                                           const int64_t* ldg, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                           const void* hp_table, int64_t hp_capacity, int64_t* counters, const cdr_batch_job* jobs, int n_jobs) {
+    CDR_CHECK_ARG(hp_table && counters && jobs && n_jobs >= 1 && n_jobs <= CDR_BATCH_MAX_JOBS);
+    lz_args a; int64_t nmax;
+    if (!fill(a, count, D, W, M, V, last, keys_sorted, perm, n, G, ldg, lr, beta1, beta2, eps, weight_decay, true, &nmax, hp_capacity)) {
+        cdr_set_error("cdr_lazy_adam_apply_produce: bad table description"); return CDR_EINVAL;
+    }
+    lz_prod ps{};
+    ps.n = n_jobs;
+    const int lpr = cdr_lpr_for(D);
+    ps.n_apply = (unsigned)grid_for(nmax, kBlock / lpr);
+    int64_t total = ps.n_apply;
+    for (int j = 0; j < n_jobs; ++j) {
+        const cdr_batch_job& J = jobs[j];
+        CDR_CHECK_ARG(J.users_all && J.cursor && J.out_users && J.S > 0 && J.k >= 0 && J.n_rows > 0);
+        if (J.k > 0) CDR_CHECK_ARG(J.items_all && J.out_items && (J.pointwise || J.out_neg));
+        ps.jobs.j[j] = J;
+        ps.gx[j] = (int)cdr_produce::job_grid(J);
+        total += ps.gx[j];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_LPR(lpr, lz_apply_kernel<L, true><<<dim3((unsigned)total, count), dim3(kBlock), 0, s>>>(a, (const float2*)hp_table, counters, ps));
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

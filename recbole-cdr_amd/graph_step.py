@@ -197,10 +197,20 @@ class GraphedTrainStep:
             if loss.dim():
                 loss = loss.reshape(()) if loss.numel() == 1 else loss.sum()
             side.wait_stream(main)
+            ro = getattr(self.optimizer, 'row_opt', None)
             with torch.cuda.stream(side):
+                # the row update's launch also produces batch i + 1 (lazyadam.DeferredRowAdam.produce_jobs: one launch less on this chain)
+                fused = (ro is not None and i + 1 < k and hasattr(ro, 'produce_jobs') and hasattr(self.producer, 'jobs')
+                         and os.environ.get('CDR_APPLY_PRODUCE', '1') != '0')
+                if fused:
+                    ro.produce_jobs = self.producer.jobs()
                 ahead = bool(self.model.apply_rows_early())
+                produced = fused and ro.produce_jobs is None
+                if ro is not None and hasattr(ro, 'produce_jobs'):
+                    ro.produce_jobs = None
                 if ahead and i + 1 < k:
-                    self.producer.launch()
+                    if not produced:
+                        self.producer.launch()
                     self.model.prepare_batch(self.static)
             loss.backward(self._one)
             loss = loss.detach()

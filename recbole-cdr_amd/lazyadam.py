@@ -46,6 +46,7 @@ class DeferredRowAdam:
         # ``apply_early()`` launches the update then, and the ``step()`` that follows the backward only does the bookkeeping
         self.early = None
         self._applied_early = False
+        self.produce_jobs = None          # set by a pipelined captured step: the next apply launch also produces the loader's next batch (consumed there)
         self.defer_finish = False        # set around a pipelined captured step: the model's forward may leave its loss total to the backward's launches
         self._prepared = None            # id of the batch ``prepare`` last ran for (``prepare_once``)
 
@@ -156,6 +157,15 @@ class DeferredRowAdam:
         nT = len(self.tables)
         keep = [[t.data for t in self.tables], self.exp_avg, self.exp_avg_sq, self.last, [k for k, _, _ in per], [p for _, p, _ in per], G]
         gp = (ctypes.c_void_p * nT)(*[G.data_ptr() + 4 * c for c in cols])
+        jobs, self.produce_jobs = self.produce_jobs, None
+        if jobs:
+            jarr = (B_.BatchJob * len(jobs))(*jobs)
+            B_.call('cdr_lazy_adam_apply_produce', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
+                    self._ptrs(keep[3]), self._ptrs(keep[4]), self._ptrs(keep[5]), (ctypes.c_int64 * nT)(*[n for _, _, n in per]), gp,
+                    (ctypes.c_int64 * nT)(*([int(ld)] * nT)), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp),
+                    self.capacity, B_.i64(self.counters), jarr, len(jobs))
+            del keep
+            return
         B_.call('cdr_lazy_adam_apply', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
                 self._ptrs(keep[3]), self._ptrs(keep[4]), self._ptrs(keep[5]), (ctypes.c_int64 * nT)(*[n for _, _, n in per]), gp,
                 (ctypes.c_int64 * nT)(*([int(ld)] * nT)), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp),
