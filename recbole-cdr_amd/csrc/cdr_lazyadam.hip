@@ -22,6 +22,7 @@
 #include "cdr_common.h"
 #include "cdr_adam_math.h"
 #include "cdr_produce.h"
+#include "cdr_ranksort.h"
 #include <stdlib.h>
 
 namespace {
@@ -217,7 +218,15 @@ __device__ __forceinline__ lz_f2 lz_elem2_nograd(lz_f2 pv, lz_f2& m, lz_f2& v, f
 #endif
 }
 
-__global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* __restrict__ hp, int64_t* __restrict__ counters, int lanes_per_row) {
+// CLAIM (cdr_lazy_adam_prepare_sort_small): the batch's ids come UNSORTED, as the lists the small rank sort takes, and a row is taken by
+// whichever of its occurrences exchanges `to` into last[row] first (the winner gets the row's old update number, the others read `to`
+// and have nothing to do: same rows replayed over the same updates whoever wins) -- so the replay no longer waits for the id sort, and
+// the sort's counting pass runs as further workgroups of THIS launch (ranksort::rank_count_body; its scatter is the next launch, needed
+// by the row update only).  The launch is 1-D then: workgroup b < n_prep is workgroup b % gx of table b / gx.
+struct lz_claim { ranksort::small_sort_args sa; uint32_t* rank; int seg_of[kMaxTab]; unsigned gx, n_prep; };
+template <bool CLAIM>
+__global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* __restrict__ hp, int64_t* __restrict__ counters, int lanes_per_row,
+                                                             lz_claim cl) {
     // Dependent memory round trips of a workgroup: {keys, the newest kBlock ring entries} -> {last, W, M, V} -> replay -> stores.  (As first
     // written -- keys -> last -> window of the longest lag -> rows -- a launch over rows that were all less than 48 updates behind still took
     // 22 us: four trips of latency per workgroup and ~4.6 rounds of workgroups per CU.)  The row is requested together with its `last`,
@@ -226,16 +235,25 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
     // for the step's ~4-6 x 10^5 postponed row-updates (per update of 64 element pairs: 12-13 full-rate instructions and 2 x 2 quarter-rate
     // v_sqrt / v_rcp = ~114 cycles).  Tried and not kept: a window per WAVE and no workgroup barrier for rows of one wave (a lane group
     // on a duplicate occurrence leaves at once instead of waiting at the barriers): 37.9 us -- four times the ring requests.
-    __shared__ float2 win[kWin];                                        // win[p] = the scalars of update to - kWin + 1 + p
+    __shared__ __attribute__((aligned(16))) float2 win[kWin];           // win[p] = the scalars of update to - kWin + 1 + p
     __shared__ int lag_max[2];
-    const lz_table tb = a.t[blockIdx.y];
+    __shared__ int from_sh[CLAIM ? kBlock : 1];
+    if (CLAIM && blockIdx.x >= cl.n_prep) {
+        ranksort::rank_count_body(cl.sa, cl.rank, (int)(blockIdx.x - cl.n_prep), reinterpret_cast<uint32_t*>(win));
+        return;
+    }
+    const unsigned bx = CLAIM ? blockIdx.x % cl.gx : blockIdx.x, by = CLAIM ? blockIdx.x / cl.gx : blockIdx.y, gx = CLAIM ? cl.gx : gridDim.x;
+    lz_table tb = a.t[by];
+    const ranksort::small_seg sg = cl.sa.seg[CLAIM ? cl.seg_of[by] : 0];
+    if (CLAIM) tb.n = sg.n0 + sg.n1;
+    auto id_at = [&](int64_t q) { return (uint32_t)(q < sg.n0 ? sg.ids0[q] : sg.ids1[q - sg.n0]); };
     const int rows_per_block = kBlock / lanes_per_row;
     const int sub = threadIdx.x % lanes_per_row;
     const int grp = threadIdx.x / lanes_per_row;
-    const int64_t TG = (int64_t)gridDim.x * rows_per_block;
+    const int64_t TG = (int64_t)gx * rows_per_block;
     const int D = a.D, D2 = D >> 1;
     const int64_t t = counters[0] + 1;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (bx == 0 && by == 0 && threadIdx.x == 0) {
         float ss, bc;
         cdr_adam_hp((double)t, a.lr, a.b1, a.b2, ss, bc);
         hp[t & a.hp_mask] = make_float2(ss, bc);
@@ -243,13 +261,16 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
     }
     const int64_t to = t - 1;
     const int64_t w0 = to - kWin + 1;
-    int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    int64_t base = (int64_t)bx * rows_per_block;
     // first trip's keys, then the window's newest entries
     uint32_t row = 0; bool mine = false;
     if (grp < rows_per_block && base + grp < tb.n) {
         const int64_t q = base + grp;
-        row = tb.keys[q];
-        mine = !(q > 0 && tb.keys[q - 1] == row);                       // one lane group per DISTINCT row
+        if (CLAIM) { row = id_at(q); mine = true; }                      // (every occurrence tries; one gets the row)
+        else {
+            row = tb.keys[q];
+            mine = !(q > 0 && tb.keys[q - 1] == row);                   // one lane group per DISTINCT row
+        }
     }
     {
         const int p = kWin - kBlock + (int)threadIdx.x;
@@ -262,13 +283,25 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
         int64_t from = to;
         lz_f2 w = {0.f, 0.f}, m = {0.f, 0.f}, v = {0.f, 0.f};
         const int64_t o = (int64_t)row * D + 2 * sub;
-        if (mine) {
-            from = tb.last[row];
-            if (sub < D2) { w = *(const lz_f2*)(tb.W + o); m = *(const lz_f2*)(tb.M + o); v = *(const lz_f2*)(tb.V + o); }
+        if (CLAIM) {
+            if (sub == 0 && grp < rows_per_block) {
+                const int old = mine ? atomicExch(&tb.last[row], (int32_t)to) : (int)to;
+                from_sh[grp] = old;
+                if (old < (int)to) atomicMax(&lag_max[trip & 1], (int)to - old);
+            }
+        } else {
+            if (mine) {
+                from = tb.last[row];
+                if (sub < D2) { w = *(const lz_f2*)(tb.W + o); m = *(const lz_f2*)(tb.M + o); v = *(const lz_f2*)(tb.V + o); }
+            }
+            if (sub == 0 && from < to) atomicMax(&lag_max[trip & 1], (int)(to - from));
         }
-        if (sub == 0 && from < to) atomicMax(&lag_max[trip & 1], (int)(to - from));
         if (threadIdx.x == 0) lag_max[(trip + 1) & 1] = 0;              // last read before the barrier that ended the previous trip
         __syncthreads();                                                 // (also: every wave of a wide row has read `last` before one moves it)
+        if (CLAIM) {
+            from = grp < rows_per_block ? (int64_t)from_sh[grp] : to;
+            if (from < to && sub < D2) { w = *(const lz_f2*)(tb.W + o); m = *(const lz_f2*)(tb.M + o); v = *(const lz_f2*)(tb.V + o); }
+        }
         int need = lag_max[trip & 1];
         need = need < kWin ? need : kWin;
         if (need > staged) {
@@ -306,14 +339,17 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
                 }
                 *(lz_f2*)(tb.W + o) = w; *(lz_f2*)(tb.M + o) = m; *(lz_f2*)(tb.V + o) = v;
             }
-            if (sub == 0) tb.last[row] = (int32_t)to;
+            if (!CLAIM && sub == 0) tb.last[row] = (int32_t)to;
         }
         // next trip's keys
         row = 0; mine = false;
         if (grp < rows_per_block && base + TG + grp < tb.n) {
             const int64_t q = base + TG + grp;
-            row = tb.keys[q];
-            mine = !(q > 0 && tb.keys[q - 1] == row);
+            if (CLAIM) { row = id_at(q); mine = true; }
+            else {
+                row = tb.keys[q];
+                mine = !(q > 0 && tb.keys[q - 1] == row);
+            }
         }
         __syncthreads();
     }
@@ -473,7 +509,7 @@ extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* cons
         const int rpb = kBlock / lanes;
         int64_t g = (nmax + rpb - 1) / rpb;
         if (g > CDR_NUM_CU * 32) g = CDR_NUM_CU * 32;
-        lz_prepare2_kernel<<<dim3((unsigned)g, count), dim3(kBlock), 0, (hipStream_t)stream>>>(a, (float2*)hp_table, counters, lanes);
+        lz_prepare2_kernel<false><<<dim3((unsigned)g, count), dim3(kBlock), 0, (hipStream_t)stream>>>(a, (float2*)hp_table, counters, lanes, lz_claim{});
         CDR_LAUNCH_CHECK();
         return CDR_OK;
     }
@@ -489,6 +525,53 @@ extern "C" int cdr_lazy_adam_prepare(void* stream, int count, int D, float* cons
     const int lpr = cdr_lpr_for(D);
     const dim3 grid(grid_for(nmax, kBlock / lpr), count);
     DISPATCH_LPR(lpr, lz_prepare_kernel<L><<<grid, dim3(kBlock), 0, (hipStream_t)stream>>>(a, (float2*)hp_table, counters));
+    CDR_LAUNCH_CHECK();
+    return CDR_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(ranksort::kTile) void lz_rank_scatter_kernel(ranksort::small_sort_args a, uint32_t* __restrict__ rank,
+                                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ perm_out) {
+    ranksort::rank_scatter_body(a, rank, keys_out, perm_out, blockIdx.x);
+}
+}  // namespace
+
+// cdr_sort_ids_small(lists) + cdr_lazy_adam_prepare(tables) in TWO launches instead of three, with the replay no longer behind the sort:
+// {replay of every table's rows (rows claimed through `last`, see lz_prepare2_kernel<true>) + the sort's counting pass} -> {the sort's scatter}.
+// table_list[i] = the list table i's rows are named by.  Same rows, same sorted keys / positions as the two calls.
+extern "C" int cdr_lazy_adam_prepare_sort_small(void* stream, int count, int D, float* const* W, float* const* M, float* const* V,
+                                                int32_t* const* last, const int* table_list, int nseg, const int64_t* const* ids0,
+                                                const int64_t* n0, const int64_t* const* ids1, const int64_t* n1, const int64_t* out_off,
+                                                uint32_t* keys_out, uint32_t* perm_out, uint32_t* rank_scratch, int64_t max_id, float lr,
+                                                float beta1, float beta2, float eps, float weight_decay, void* hp_table, int64_t hp_capacity,
+                                                int64_t* counters, int64_t step_host) {
+    CDR_CHECK_ARG(hp_table && counters && step_host >= 1 && table_list && keys_out && perm_out && rank_scratch);
+    CDR_CHECK_ARG(D % 2 == 0 && D <= 2 * kBlock);
+    lz_args a; int64_t nmax = 0;
+    if (!fill(a, count, D, W, M, V, last, nullptr, nullptr, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax, hp_capacity)) {
+        cdr_set_error("cdr_lazy_adam_prepare_sort_small: bad table description"); return CDR_EINVAL;
+    }
+    lz_claim cl{};
+    if (!ranksort::plan(cl.sa, nseg, ids0, n0, ids1, n1, out_off, max_id)) { cdr_set_error("cdr_lazy_adam_prepare_sort_small: bad list description"); return CDR_EINVAL; }
+    cl.rank = rank_scratch;
+    for (int i = 0; i < count; ++i) {
+        CDR_CHECK_ARG(table_list[i] >= 0 && table_list[i] < nseg);
+        cl.seg_of[i] = table_list[i];
+        const int64_t n = cl.sa.seg[table_list[i]].n0 + cl.sa.seg[table_list[i]].n1;
+        if (n > nmax) nmax = n;
+    }
+    const int D2 = D / 2;
+    int lanes = 1;
+    if (D2 <= 64) { while (lanes < D2) lanes *= 2; } else lanes = (D2 + 63) / 64 * 64;
+    const int rpb = kBlock / lanes;
+    int64_t g = (nmax + rpb - 1) / rpb;
+    if (g > CDR_NUM_CU * 32) g = CDR_NUM_CU * 32;
+    cl.gx = (unsigned)g;
+    cl.n_prep = (unsigned)(g * count);
+    hipStream_t s = (hipStream_t)stream;
+    lz_prepare2_kernel<true><<<dim3(cl.n_prep + (unsigned)cl.sa.count_blocks), dim3(kBlock), 0, s>>>(a, (float2*)hp_table, counters, lanes, cl);
+    CDR_LAUNCH_CHECK();
+    lz_rank_scatter_kernel<<<dim3(cl.sa.scatter_blocks), dim3(ranksort::kTile), 0, s>>>(cl.sa, rank_scratch, keys_out, perm_out);
     CDR_LAUNCH_CHECK();
     return CDR_OK;
 }

@@ -7,6 +7,7 @@ postpones those updates and replays them, in order, just before the row is read 
 operations in the same order on the same operands -- at O(batch) memory traffic per step.
 """
 import ctypes
+import os
 
 import torch
 
@@ -98,8 +99,49 @@ class DeferredRowAdam:
     @torch.no_grad()
     def prepare(self, id_lists):
         """Before the forward pass: sort the batch's ids and bring their rows up to the update before the coming one."""
+        if self._prepare_sort_small(id_lists):
+            return
         self._sorted = self._sort(id_lists)
         self._launch_prepare()
+
+    def _prepare_sort_small(self, id_lists, slot=0):
+        """Short lists (the small rank sort's range): the replay and the sort's counting pass in ONE launch, the sort's scatter behind it
+        (cdr_lazy_adam_prepare_sort_small: rows claimed through ``last``, so the replay no longer waits for the sort).  Same state and
+        same sorted lists as ``_sort`` + ``_launch_prepare``; CDR_LZ_CLAIM=0 keeps those."""
+        if os.environ.get('CDR_LZ_CLAIM', '1') == '0' or self.D % 2 or self.D > 512:
+            return False
+        dev = self.tables[0].device
+        pairs = [x if isinstance(x, (tuple, list)) else (x, None) for x in id_lists]
+        pairs = [(a.reshape(-1).contiguous().to(torch.int64), None if b is None or b.numel() == 0 else b.reshape(-1).contiguous().to(torch.int64))
+                 for a, b in pairs]
+        ns = [int(a.numel()) + (0 if b is None else int(b.numel())) for a, b in pairs]
+        if not ns or min(ns) <= 0 or max(ns) > 16384 or len(ns) > 4:
+            return False
+        key = tuple(ns) + (('slot', slot),)
+        if key not in self._bufs:
+            tot = sum(ns)
+            self._bufs[key] = (torch.empty(tot, device=dev, dtype=torch.int32), torch.empty(tot, device=dev, dtype=torch.int32),
+                               torch.zeros(tot, device=dev, dtype=torch.int32))
+        keys, perm, rank = self._bufs[key]
+        offs, o = [], 0
+        for n in ns:
+            offs.append(o); o += n
+        rows = max(t.shape[0] for t in self.tables)
+        m, nT = len(ns), len(self.tables)
+        if not torch.cuda.is_current_stream_capturing():
+            self._bound_lag()
+        B_._alive.extend([t for p in pairs for t in p if t is not None])
+        keep = [[t.data for t in self.tables], self.exp_avg, self.exp_avg_sq, self.last]
+        B_.call('cdr_lazy_adam_prepare_sort_small', B_.stream(), nT, self.D, self._ptrs(keep[0]), self._ptrs(keep[1]), self._ptrs(keep[2]),
+                self._ptrs(keep[3]), (ctypes.c_int * nT)(*[int(j) for j in self.table_list]), m,
+                (ctypes.c_void_p * m)(*[a.data_ptr() for a, _ in pairs]), (ctypes.c_int64 * m)(*[a.numel() for a, _ in pairs]),
+                (ctypes.c_void_p * m)(*[None if b is None else b.data_ptr() for _, b in pairs]),
+                (ctypes.c_int64 * m)(*[0 if b is None else b.numel() for _, b in pairs]), (ctypes.c_int64 * m)(*offs), B_.raw(keys),
+                B_.raw(perm), B_.raw(rank), rows, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp), self.capacity,
+                B_.i64(self.counters), self.step_count + 1)
+        del keep
+        self._sorted = [(keys[of:of + n], perm[of:of + n], n) for n, of in zip(ns, offs)]
+        return True
 
     @torch.no_grad()
     def sort_ahead(self, id_lists, slot):
