@@ -1184,6 +1184,49 @@ def test_deferred_adam_ring_of_update_scalars_wraps():
     assert torch.equal(od.state[dense]['exp_avg'], ol.exp_avg[0]) and torch.equal(od.state[dense]['exp_avg_sq'], ol.exp_avg_sq[0])
 
 
+@pytest.mark.parametrize('D,n_big', [(128, 8190), (64, 3000), (192, 1500), (8, 700)])
+def test_deferred_adam_claimed_rows_equal_the_sorted_route(monkeypatch, D, n_big):
+    """``cdr_lazy_adam_prepare_sort_small`` (rows claimed through ``last`` by whichever occurrence comes first, the replay in one launch with
+    the sort's counting pass) against ``cdr_sort_ids_small`` + ``cdr_lazy_adam_prepare`` (``CDR_LZ_CLAIM=0``): lists with heavy duplication
+    (every user five times, as a C3 batch has them), lists given as pairs of tensors, rows of one wave, half a wave, several waves and
+    four lanes, more list positions than one trip of the grid covers.  Rows, moments, ``last`` and the sorted lists: torch.equal."""
+    from recbole_cdr_amd.lazyadam import DeferredRowAdam
+    gen = torch.Generator().manual_seed(D)
+    rows = (5000, 3000)
+    tabs = [torch.randn(rows[i % 2], D, generator=gen) * 0.1 for i in range(4)]
+
+    def run(claim):
+        monkeypatch.setenv('CDR_LZ_CLAIM', '1' if claim else '0')
+        g2 = torch.Generator().manual_seed(7)
+        params = [torch.nn.Parameter(t.clone().to(DEV)) for t in tabs]
+        ol = DeferredRowAdam(params, [0, 1, 0, 1], lr=0.01)
+        sorted_lists = []
+        for step in range(12):
+            nu = n_big // 5
+            users = torch.randint(0, rows[0], (nu,), generator=g2)
+            ulist = users.repeat(5)[torch.randperm(5 * nu, generator=g2)]
+            items = torch.randint(0, rows[1], (5 * nu,), generator=g2)
+            cut = int(torch.randint(1, 5 * nu - 1, (1,), generator=g2))
+            lists = [(ulist[:cut].to(DEV), ulist[cut:].to(DEV)), (items[:cut].to(DEV), items[cut:].to(DEV))]
+            R = 5 * nu
+            G = (torch.randn(R, 4 * D, generator=g2) * 1e-2).to(DEV)
+            ol.prepare(lists)
+            sorted_lists.append([(k.clone(), p_.clone()) for k, p_, _ in ol._sorted])
+            ol.pending = (G, (0, D, 2 * D, 3 * D), 4 * D)
+            ol.step()
+        last = [l.clone() for l in ol.last]
+        ol.flush()
+        return [p.data.clone() for p in params], [m.clone() for m in ol.exp_avg], [v.clone() for v in ol.exp_avg_sq], last, sorted_lists
+
+    a, b = run(False), run(True)
+    for xs, ys in zip(a[:4], b[:4]):
+        for x, y in zip(xs, ys):
+            assert torch.equal(x, y)
+    for sa, sb in zip(a[4], b[4]):
+        for (k0, p0), (k1, p1) in zip(sa, sb):
+            assert torch.equal(k0, k1) and torch.equal(p0, p1)
+
+
 @pytest.mark.parametrize('wd', [0.0, 0.01])
 def test_deferred_adam_is_bit_identical_to_the_dense_sweep(wd):
     """lazyadam.DeferredRowAdam == trainer.DenseAdam (the reference's torch.optim.Adam semantics over whole tables) BIT FOR BIT:
