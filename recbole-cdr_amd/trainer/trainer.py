@@ -202,7 +202,10 @@ class Trainer:
         # step is capturable (model.fused_graph_key)
         self.graph_step_rowwise = bool(config['graph_step'] if 'graph_step' in config else True) and on_gpu and self.optimizer_mode == 'rowwise'
         # steps per graph launch on a device loader (the idle time between two graph launches is ~5-9 us: amortised over this many steps)
-        self.graph_unroll = int(config['graph_unroll']) if 'graph_unroll' in config else 8
+        # config['graph_unroll']; default 8 -- 16 for a step that runs software-pipelined over two streams (below): a two-stream graph's launch
+        # boundary costs ~30-40 us of idle chip, 8 steps per graph leave ~4 us of it in every step (C3: 0.1535 -> 0.149 ms; 32: 0.1475;
+        # the single-stream steps of C1 / C2 / C4 gain <= 1.5 % and keep 8 -- an epoch's tail of < unroll steps runs one step per launch)
+        self.graph_unroll = int(config['graph_unroll']) if 'graph_unroll' in config else None
         # ... and, for models that can run part of the next step ahead (CoNet on the deferred Adam), those steps software-pipelined over two streams
         gp = config['graph_pipeline'] if 'graph_pipeline' in config else True
         self.graph_pipeline = gp if isinstance(gp, str) else bool(gp)          # True (one batch ahead) | 'two_ahead' | False
@@ -241,8 +244,13 @@ class Trainer:
         if gs is None:
             from ..graph_step import GraphedTrainStep
             try:
+                unroll = self.graph_unroll
+                if unroll is None:
+                    pipelined = (producer is not None and bool(self.graph_pipeline) and hasattr(self.model, 'prepare_batch')
+                                 and hasattr(self.model, 'apply_rows_early') and getattr(self.optimizer, 'row_opt', None) is not None)
+                    unroll = 16 if pipelined else 8
                 gs = GraphedTrainStep(self.model, self.optimizer, example, producer=producer, loss_sum=self._loss_sum,
-                                      unroll=self.graph_unroll, pipeline=self.graph_pipeline)
+                                      unroll=unroll, pipeline=self.graph_pipeline)
                 self.graph_stats['captures'] += 1
             except Exception as e:                                      # noqa: BLE001 -- reported, and the eager loop still trains
                 import warnings

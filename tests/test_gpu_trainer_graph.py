@@ -623,7 +623,7 @@ def test_conet_pipelined_unrolled_graph_is_bit_identical_to_the_plain_order():
         trainer._train_epoch = lambda data, e, o=orig, l=log: (l.append(o(data, e)) or l[-1])
         trainer.fit(dl)
         gs = [g for g in trainer._graphs.values() if g][0]
-        assert bool(gs._can_pipeline()) == bool(pipe) and gs.unroll == 8 and trainer.graph_stats['replayed'] >= 3 * 16
+        assert bool(gs._can_pipeline()) == bool(pipe) and gs.unroll == (16 if pipe else 8) and trainer.graph_stats['replayed'] >= 3 * 16
         assert (gs._statics is not None) == (pipe == 'two_ahead')          # (the two-batches-deep order really ran on its second batch slot)
         outs.append((log, {k: v.detach().clone() for k, v in model.state_dict().items()}, trainer.optimizer.state_dict()))
     (ls, ps, os_) = outs[1]                                                  # the plain order
