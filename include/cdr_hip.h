@@ -55,7 +55,7 @@ int cdr_ctx_scrub_next(cdr_ctx* ctx, void* ptr, size_t bytes);
 int cdr_ctx_set_id_counters(cdr_ctx* ctx, uint32_t* user_counts, int64_t user_rows, uint32_t* item_counts, int64_t item_rows,
                             void* list_ws, size_t list_ws_bytes);
 int cdr_id_count_workspace_bytes(int64_t B, size_t* bytes);
-#define CDR_ABI_VERSION 58
+#define CDR_ABI_VERSION 59
 int cdr_abi_version(void);                          /* == CDR_ABI_VERSION of the header the library was built from; bumped on any signature change */
 
 /* Optional measurement aid: HIP-event brackets around the hot kernels, recorded on the stream each kernel is launched
@@ -401,7 +401,11 @@ int cdr_lazy_adam_prepare_sort_small(void* stream, int count, int D, float* cons
                                      const int* table_list, int nseg, const int64_t* const* ids0, const int64_t* n0,
                                      const int64_t* const* ids1, const int64_t* n1, const int64_t* out_off, uint32_t* keys_out,
                                      uint32_t* perm_out, uint32_t* rank_scratch, int64_t max_id, float lr, float beta1, float beta2, float eps,
-                                     float weight_decay, void* hp_table, int64_t hp_capacity, int64_t* counters, int64_t step_host);
+                                     float weight_decay, void* hp_table, int64_t hp_capacity, int64_t* counters, int64_t step_host,
+                                     const int64_t* table_rows /* [count]: rows of every table (sweep_period > 0) */,
+                                     int sweep_period /* 0: off.  P >= 2: every call also brings a window of rows / P rows of each table up
+                                        to date (the window moves on by its length per update), so that no row is ever more than ~P updates
+                                        behind: bounds the replay launch's tail; results unchanged (a postponed update is replayed once) */);
 int cdr_lazy_adam_apply(void* stream, int count, int D, float* const* W, float* const* M, float* const* V, int32_t* const* last,
                         const uint32_t* const* keys_sorted, const uint32_t* const* perm, const int64_t* n, const float* const* G,
                         const int64_t* ldg, float lr, float beta1, float beta2, float eps, float weight_decay, const void* hp_table,

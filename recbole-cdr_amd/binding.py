@@ -34,7 +34,7 @@ def capturing(graph, stream):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('CDR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libcdrhip.so')   # env: A/B builds only
-ABI_VERSION = 58
+ABI_VERSION = 59
 SIGNIN_WORDS = 288          # CDR_SIGNIN_WORDS: the sign-in words cdr_adam_multi_dev's ``ticket`` points at
 
 CDR_LOSS_MSE, CDR_LOSS_BCE = 0, 1
@@ -275,7 +275,7 @@ _SIGNATURES = {
     'cdr_lazy_adam_prepare': [_c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32,
                               _c_ptr, _c_i64, _c_ptr, _c_i64],
     'cdr_lazy_adam_prepare_sort_small': [_c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
-                                         _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_i64, _c_ptr, _c_i64],
+                                         _c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_int],
     'cdr_lazy_adam_apply': [_c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32,
                             _c_f32, _c_f32, _c_f32, _c_ptr, _c_i64, _c_ptr],
     'cdr_lazy_adam_apply_produce': [_c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f32, _c_f32,

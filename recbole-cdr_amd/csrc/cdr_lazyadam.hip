@@ -223,7 +223,15 @@ __device__ __forceinline__ lz_f2 lz_elem2_nograd(lz_f2 pv, lz_f2& m, lz_f2& v, f
 // and have nothing to do: same rows replayed over the same updates whoever wins) -- so the replay no longer waits for the id sort, and
 // the sort's counting pass runs as further workgroups of THIS launch (ranksort::rank_count_body; its scatter is the next launch, needed
 // by the row update only).  The launch is 1-D then: workgroup b < n_prep is workgroup b % gx of table b / gx.
-struct lz_claim { ranksort::small_sort_args sa; uint32_t* rank; int seg_of[kMaxTab]; unsigned gx, n_prep; };
+// SWEEP (inside CLAIM): the launch's FIRST workgroups are not the batch's: every update, a window of rows[y] / sweep_period rows of each
+// table (the window moves by its own length per update and wraps) is claimed like a batch row and brought up to date.  No row is then
+// ever more than ~sweep_period updates behind, which bounds the launch's tail -- a C3 user row comes up every ~95 updates on average,
+// the most-postponed one of a batch was 300-700 behind, and its serial replay (114 cycles per update), started wherever the dispatcher
+// happened to put it, was up to ~19 us of the launch; the window's rows, all ~sweep_period behind, start first.  The arithmetic is
+// conserved (a postponed update is replayed once, by whoever claims the row first); a window row that is also in the batch goes to one of
+// the two claimants as any row of the batch does.
+struct lz_claim { ranksort::small_sort_args sa; uint32_t* rank; int seg_of[kMaxTab]; unsigned gx, n_prep;
+                  unsigned n_sweep, sweep_start[kMaxTab + 1]; int64_t rows[kMaxTab], chunk[kMaxTab]; int period; };
 template <bool CLAIM>
 __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* __restrict__ hp, int64_t* __restrict__ counters, int lanes_per_row,
                                                              lz_claim cl) {
@@ -238,15 +246,28 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
     __shared__ __attribute__((aligned(16))) float2 win[kWin];           // win[p] = the scalars of update to - kWin + 1 + p
     __shared__ int lag_max[2];
     __shared__ int from_sh[CLAIM ? kBlock : 1];
-    if (CLAIM && blockIdx.x >= cl.n_prep) {
-        ranksort::rank_count_body(cl.sa, cl.rank, (int)(blockIdx.x - cl.n_prep), reinterpret_cast<uint32_t*>(win));
+    if (CLAIM && blockIdx.x >= cl.n_sweep + cl.n_prep) {
+        ranksort::rank_count_body(cl.sa, cl.rank, (int)(blockIdx.x - cl.n_sweep - cl.n_prep), reinterpret_cast<uint32_t*>(win));
         return;
     }
-    const unsigned bx = CLAIM ? blockIdx.x % cl.gx : blockIdx.x, by = CLAIM ? blockIdx.x / cl.gx : blockIdx.y, gx = CLAIM ? cl.gx : gridDim.x;
+    const bool sweep = CLAIM && blockIdx.x < cl.n_sweep;
+    unsigned bx = blockIdx.x, by = blockIdx.y, gx = gridDim.x;
+    if (CLAIM) {
+        if (sweep) {
+            by = 0;
+            for (int y = 1; y < a.count; ++y) if (blockIdx.x >= cl.sweep_start[y]) by = y;
+            bx = blockIdx.x - cl.sweep_start[by]; gx = cl.sweep_start[by + 1] - cl.sweep_start[by];
+        } else {
+            const unsigned b = blockIdx.x - cl.n_sweep;
+            bx = b % cl.gx; by = b / cl.gx; gx = cl.gx;
+        }
+    }
     lz_table tb = a.t[by];
     const ranksort::small_seg sg = cl.sa.seg[CLAIM ? cl.seg_of[by] : 0];
-    if (CLAIM) tb.n = sg.n0 + sg.n1;
-    auto id_at = [&](int64_t q) { return (uint32_t)(q < sg.n0 ? sg.ids0[q] : sg.ids1[q - sg.n0]); };
+    if (CLAIM) tb.n = sweep ? cl.chunk[by] : sg.n0 + sg.n1;
+    int64_t sweep_first = 0;
+    auto id_at = [&](int64_t q) { return sweep ? (uint32_t)(sweep_first + q) : (uint32_t)(q < sg.n0 ? sg.ids0[q] : sg.ids1[q - sg.n0]); };
+    auto id_ok = [&](int64_t q) { return !sweep || sweep_first + q < cl.rows[by]; };
     const int rows_per_block = kBlock / lanes_per_row;
     const int sub = threadIdx.x % lanes_per_row;
     const int grp = threadIdx.x / lanes_per_row;
@@ -261,12 +282,13 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
     }
     const int64_t to = t - 1;
     const int64_t w0 = to - kWin + 1;
+    if (sweep) sweep_first = (to % cl.period) * cl.chunk[by];
     int64_t base = (int64_t)bx * rows_per_block;
     // first trip's keys, then the window's newest entries
     uint32_t row = 0; bool mine = false;
     if (grp < rows_per_block && base + grp < tb.n) {
         const int64_t q = base + grp;
-        if (CLAIM) { row = id_at(q); mine = true; }                      // (every occurrence tries; one gets the row)
+        if (CLAIM) { row = id_at(q); mine = id_ok(q); }                  // (every occurrence tries; one gets the row)
         else {
             row = tb.keys[q];
             mine = !(q > 0 && tb.keys[q - 1] == row);                   // one lane group per DISTINCT row
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void lz_prepare2_kernel(lz_args a, float2* 
         row = 0; mine = false;
         if (grp < rows_per_block && base + TG + grp < tb.n) {
             const int64_t q = base + TG + grp;
-            if (CLAIM) { row = id_at(q); mine = true; }
+            if (CLAIM) { row = id_at(q); mine = id_ok(q); }
             else {
                 row = tb.keys[q];
                 mine = !(q > 0 && tb.keys[q - 1] == row);
@@ -544,8 +566,9 @@ extern "C" int cdr_lazy_adam_prepare_sort_small(void* stream, int count, int D, 
                                                 const int64_t* n0, const int64_t* const* ids1, const int64_t* n1, const int64_t* out_off,
                                                 uint32_t* keys_out, uint32_t* perm_out, uint32_t* rank_scratch, int64_t max_id, float lr,
                                                 float beta1, float beta2, float eps, float weight_decay, void* hp_table, int64_t hp_capacity,
-                                                int64_t* counters, int64_t step_host) {
+                                                int64_t* counters, int64_t step_host, const int64_t* table_rows, int sweep_period) {
     CDR_CHECK_ARG(hp_table && counters && step_host >= 1 && table_list && keys_out && perm_out && rank_scratch);
+    CDR_CHECK_ARG(sweep_period == 0 || (table_rows && sweep_period >= 2 && sweep_period < hp_capacity));
     CDR_CHECK_ARG(D % 2 == 0 && D <= 2 * kBlock);
     lz_args a; int64_t nmax = 0;
     if (!fill(a, count, D, W, M, V, last, nullptr, nullptr, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay, false, &nmax, hp_capacity)) {
@@ -568,8 +591,19 @@ extern "C" int cdr_lazy_adam_prepare_sort_small(void* stream, int count, int D, 
     if (g > CDR_NUM_CU * 32) g = CDR_NUM_CU * 32;
     cl.gx = (unsigned)g;
     cl.n_prep = (unsigned)(g * count);
+    cl.period = sweep_period > 0 ? sweep_period : 1;
+    for (int i = 0; i < count; ++i) {
+        cl.sweep_start[i] = cl.n_sweep;
+        if (sweep_period > 0) {
+            CDR_CHECK_ARG(table_rows[i] > 0);
+            cl.rows[i] = table_rows[i];
+            cl.chunk[i] = (table_rows[i] + sweep_period - 1) / sweep_period;
+            cl.n_sweep += (unsigned)((cl.chunk[i] + rpb - 1) / rpb);
+        }
+    }
+    cl.sweep_start[count] = cl.n_sweep;
     hipStream_t s = (hipStream_t)stream;
-    lz_prepare2_kernel<true><<<dim3(cl.n_prep + (unsigned)cl.sa.count_blocks), dim3(kBlock), 0, s>>>(a, (float2*)hp_table, counters, lanes, cl);
+    lz_prepare2_kernel<true><<<dim3(cl.n_sweep + cl.n_prep + (unsigned)cl.sa.count_blocks), dim3(kBlock), 0, s>>>(a, (float2*)hp_table, counters, lanes, cl);
     CDR_LAUNCH_CHECK();
     lz_rank_scatter_kernel<<<dim3(cl.sa.scatter_blocks), dim3(ranksort::kTile), 0, s>>>(cl.sa, rank_scratch, keys_out, perm_out);
     CDR_LAUNCH_CHECK();

@@ -138,10 +138,16 @@ class DeferredRowAdam:
                 (ctypes.c_void_p * m)(*[None if b is None else b.data_ptr() for _, b in pairs]),
                 (ctypes.c_int64 * m)(*[0 if b is None else b.numel() for _, b in pairs]), (ctypes.c_int64 * m)(*offs), B_.raw(keys),
                 B_.raw(perm), B_.raw(rank), rows, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, B_.raw(self.hp), self.capacity,
-                B_.i64(self.counters), self.step_count + 1)
+                B_.i64(self.counters), self.step_count + 1, (ctypes.c_int64 * nT)(*[int(t.shape[0]) for t in self.tables]), self._sweep_period())
         del keep
         self._sorted = [(keys[of:of + n], perm[of:of + n], n) for n, of in zip(ns, offs)]
         return True
+
+    def _sweep_period(self):
+        """Updates after which the replay's moving window has visited every row (cdr_lazy_adam_prepare_sort_small): 256 (128-512 measure alike at C3), less than the ring
+        holds; CDR_LZ_SWEEP=0 switches the window off, any other number sets the period."""
+        p = int(os.environ.get('CDR_LZ_SWEEP', '256'))
+        return 0 if p <= 0 else max(2, min(p, self.capacity // 2))
 
     @torch.no_grad()
     def sort_ahead(self, id_lists, slot):

@@ -1195,8 +1195,9 @@ def test_deferred_adam_claimed_rows_equal_the_sorted_route(monkeypatch, D, n_big
     rows = (5000, 3000)
     tabs = [torch.randn(rows[i % 2], D, generator=gen) * 0.1 for i in range(4)]
 
-    def run(claim):
+    def run(claim, sweep=0):
         monkeypatch.setenv('CDR_LZ_CLAIM', '1' if claim else '0')
+        monkeypatch.setenv('CDR_LZ_SWEEP', str(sweep))
         g2 = torch.Generator().manual_seed(7)
         params = [torch.nn.Parameter(t.clone().to(DEV)) for t in tabs]
         ol = DeferredRowAdam(params, [0, 1, 0, 1], lr=0.01)
@@ -1225,6 +1226,17 @@ def test_deferred_adam_claimed_rows_equal_the_sorted_route(monkeypatch, D, n_big
     for sa, sb in zip(a[4], b[4]):
         for (k0, p0), (k1, p1) in zip(sa, sb):
             assert torch.equal(k0, k1) and torch.equal(p0, p1)
+    # ... and with the moving window that keeps every row within a few updates of the current one (period 5: the window wraps twice in
+    # these 12 updates; 128 in the product): rows outside the batches are replayed EARLIER, to the same bits -- rows and moments after the
+    # final flush and the sorted lists are equal, ``last`` is (much) further on
+    c = run(True, sweep=5)
+    for xs, ys in zip(a[:3], c[:3]):
+        for x, y in zip(xs, ys):
+            assert torch.equal(x, y)
+    for sa, sc in zip(a[4], c[4]):
+        for (k0, p0), (k1, p1) in zip(sa, sc):
+            assert torch.equal(k0, k1) and torch.equal(p0, p1)
+    assert all(int((lc >= la).all()) for la, lc in zip(a[3], c[3])) and sum(int((lc > la).sum()) for la, lc in zip(a[3], c[3])) > 1000
 
 
 @pytest.mark.parametrize('wd', [0.0, 0.01])
