@@ -172,11 +172,11 @@ class GraphedTrainStep:
         return loss
 
     def _whole_many_one_ahead(self, k, main, side):
-        """The default pipelined order: the side stream runs {row update of step i -> produce batch i+1 -> its id sort -> the replay of its
-        rows} beside the main stream's weight gradients and dense Adam."""
+        """The default pipelined order: the side stream runs {row update of step i, which also produces batch i+1 -> the replay of its rows
+        in one launch with its id sort's counting pass -> the sort's scatter} beside the main stream's weight gradients (+ loss total) and
+        dense Adam (round 6: three launches on that chain, six before)."""
         self.producer.launch()
         self.model.prepare_batch(self.static)
-        loss = None
         ro = getattr(self.optimizer, 'row_opt', None)
         try:
             # every loss of this sequence is differentiated at once and read only by the optimizer's launch behind the backward: the model's
