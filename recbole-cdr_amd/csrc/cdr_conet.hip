@@ -44,6 +44,7 @@ struct conet_net {
     int dims[kMaxL + 1];
     int act_off[kMaxL + 1];                     // column of layer l's outputs in acts / gz; act_off[L] = row width
     int wl_off[kMaxL + 1];                      // float offset of layer l's {Ws, Wt, H} block in the LDS weight area (l >= 1)
+    int hsq_chunk[kMaxL];                       // conet_fb_kernel: elements of H_l per workgroup's slice of sum H_l^2 (host: ceil(n / grid) -- a division per layer and use otherwise)
     const float* Ws[kMaxL]; const float* bs[kMaxL]; const float* Wt[kMaxL]; const float* bt[kMaxL]; const float* H[kMaxL];
     const float* wo[2]; const float* bo[2];
 };
@@ -1122,7 +1123,7 @@ __device__ __forceinline__ void stage_weights_dma(const conet_net& net, float* w
 // this block's slice [lo, hi) of H_l (the sum of squares is split over the grid: conet_fwd_kernel)
 __device__ __forceinline__ void hsq_slice(const conet_net& net, int l, int& lo, int& hi) {
     const int n = net.dims[l] * net.dims[l + 1];
-    const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int chunk = net.hsq_chunk[l];
     lo = (int)blockIdx.x * chunk;
     hi = lo + chunk < n ? lo + chunk : n;
 }
@@ -1773,6 +1774,7 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
         CDR_LAUNCH_CHECK();
     }
     if (gz && lp.fb_bytes) {                     // training step: forward and data backward of every 32-row block in one launch
+        for (int l = 0; l < L; ++l) net.hsq_chunk[l] = (dims[l] * dims[l + 1] + grid - 1) / grid;
         int aw = 0; size_t need = 0;
         rc = cdr_conet_plan(L, dims, R, &aw, &need);
         if (rc) return rc;
