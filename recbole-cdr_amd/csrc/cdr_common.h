@@ -26,6 +26,9 @@ struct cdr_ctx {
     void* idc_list; size_t idc_list_bytes;
     // cdr_conet_defer_finish: a training forward of the CoNet towers leaves the addition of its blocks' loss partials to the backward's
     // weight-gradient launch (one workgroup more there instead of a launch of its own); `pending` between the two calls
+    // conet_fb_kernel's weight staging: per 16-byte chunk of the padded LDS weight area, the address it is copied from (built on the host,
+    // re-sent only when a parameter moved; csrc/cdr_conet.hip: conet_dma_table)
+    unsigned long long* conet_tab_dev; unsigned long long* conet_tab_pin; unsigned long long* conet_tab_shadow; int conet_tab_cap, conet_tab_n;
     int conet_defer, conet_pending, conet_fin_grid;
     int64_t conet_fin_ns, conet_fin_R;
     float* conet_fin_out;

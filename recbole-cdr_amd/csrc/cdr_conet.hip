@@ -27,6 +27,7 @@
 #include <string.h>
 #include <type_traits>
 #include "cdr_common.h"
+#include <vector>
 
 namespace {
 
@@ -44,6 +45,7 @@ struct conet_net {
     int dims[kMaxL + 1];
     int act_off[kMaxL + 1];                     // column of layer l's outputs in acts / gz; act_off[L] = row width
     int wl_off[kMaxL + 1];                      // float offset of layer l's {Ws, Wt, H} block in the LDS weight area (l >= 1)
+    const unsigned long long* dma_tab;          // stage_weights_dma: source address per padded chunk of the LDS weight area (null: computed per lane)
     int hsq_chunk[kMaxL];                       // conet_fb_kernel: elements of H_l per workgroup's slice of sum H_l^2 (host: ceil(n / grid) -- a division per layer and use otherwise)
     const float* Ws[kMaxL]; const float* bs[kMaxL]; const float* Wt[kMaxL]; const float* bt[kMaxL]; const float* H[kMaxL];
     const float* wo[2]; const float* bo[2];
@@ -1093,6 +1095,30 @@ __device__ __forceinline__ void stage_weights_dma(const conet_net& net, float* w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)wl;
     const int total = net.wl_off[net.L] >> 2;                       // padded chunks
+    if (net.dma_tab) {
+        // the sources come from a table the host filled (conet_dma_table): the arithmetic below is ~100 dependent instructions per trip of
+        // a wave that runs it once, at ~10 cycles each with two waves on a SIMD -- 4.5 us of every workgroup's 60
+        constexpr int kTrips = 8;                                   // (the host offers the table only when this covers the area)
+        const float* src[kTrips];
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int i0 = 64 * wave + k * (int)blockDim.x;
+            int c = i0 + lane;
+            if (c >= total) c = total - 1;
+            src[k] = i0 < total ? reinterpret_cast<const float*>(net.dma_tab[c]) : nullptr;
+        }
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int i0 = 64 * wave + k * (int)blockDim.x;
+            if (i0 < total) {                                       // wave-uniform
+                const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)i0 * 16u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src[k]), "s"(dst) : "memory");
+            }
+        }
+        return;
+    }
     for (int i0 = 64 * wave; i0 < total; i0 += (int)blockDim.x) {
         int c = i0 + lane;
         if (c >= total) c = total - 1;                              // (the last instruction's tail lanes: a valid source, dropped below)
@@ -1621,6 +1647,8 @@ int fill_net(conet_net& net, lds_plan& lp, int L, const int* dims, const float* 
     if (L < 1 || L > kMaxL || !dims || !params) return 0;
     net.L = L;
     net.vec = 1;
+    net.dma_tab = nullptr;
+    for (int l = 0; l < kMaxL; ++l) net.hsq_chunk[l] = 0;
     int off = 0;
     for (int l = 0; l <= L; ++l) {
         if (dims[l] <= 0 || (dims[l] & 3)) return 0;                 // float4 chunks along every contraction index
@@ -1742,6 +1770,51 @@ extern "C" int cdr_conet_plan(int L, const int* dims, int64_t R, int* act_width,
     return CDR_OK;
 }
 
+// stage_weights_dma's per-chunk source addresses (its own arithmetic, on the host), kept in the context and re-sent only when they change
+// (a parameter was re-allocated).  Returns the device table, or null: the kernel then computes the addresses itself -- the table does not
+// cover the area, allocation failed, or the table would have to change while the stream is capturing.
+static const unsigned long long* conet_dma_table(cdr_ctx* ctx, const conet_net& net, int threads, hipStream_t s) {
+    const int total = net.wl_off[net.L] >> 2;
+    if (!net.wlds || total <= 0 || total > 8 * threads) return nullptr;
+    std::vector<unsigned long long> tab((size_t)total);
+    for (int c = 0; c < total; ++c) {
+        const float* src = net.Ws[1];
+        for (int l = 1; l < net.L; ++l) {
+            const int din = net.dims[l], dout = net.dims[l + 1], q1 = (din >> 2) + 1, n1 = dout * q1;
+            const int r3 = c - (net.wl_off[l] >> 2);
+            if (r3 >= 0 && r3 < 3 * n1) {
+                const int mat = r3 / n1, r = r3 - mat * n1, row = r / q1, col = r - row * q1;
+                src = (mat == 0 ? net.Ws[l] : mat == 1 ? net.Wt[l] : net.H[l]) + (int64_t)row * din + 4 * (col < q1 - 1 ? col : 0);
+            }
+        }
+        tab[c] = (unsigned long long)(uintptr_t)src;
+    }
+    if (ctx->conet_tab_n == total && ctx->conet_tab_shadow && memcmp(ctx->conet_tab_shadow, tab.data(), (size_t)total * 8) == 0)
+        return ctx->conet_tab_dev;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    if (ctx->conet_tab_cap < total) {
+        if (ctx->conet_tab_dev) (void)hipFree(ctx->conet_tab_dev);
+        if (ctx->conet_tab_pin) (void)hipHostFree(ctx->conet_tab_pin);
+        free(ctx->conet_tab_shadow);
+        ctx->conet_tab_dev = ctx->conet_tab_pin = ctx->conet_tab_shadow = nullptr;
+        ctx->conet_tab_cap = ctx->conet_tab_n = 0;
+        const size_t bytes = (size_t)total * 8;
+        if (hipMalloc((void**)&ctx->conet_tab_dev, bytes) != hipSuccess || hipHostMalloc((void**)&ctx->conet_tab_pin, bytes) != hipSuccess ||
+            !(ctx->conet_tab_shadow = (unsigned long long*)malloc(bytes))) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ctx->conet_tab_cap = total;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;         // (an earlier copy out of the pinned buffer; tables change once in a run)
+    memcpy(ctx->conet_tab_pin, tab.data(), (size_t)total * 8);
+    if (hipMemcpyAsync(ctx->conet_tab_dev, ctx->conet_tab_pin, (size_t)total * 8, hipMemcpyHostToDevice, s) != hipSuccess) { ctx->conet_tab_n = 0; return nullptr; }
+    memcpy(ctx->conet_tab_shadow, tab.data(), (size_t)total * 8);
+    ctx->conet_tab_n = total;
+    return ctx->conet_tab_dev;
+}
+
 extern "C" int cdr_conet_defer_finish(cdr_ctx* ctx, int on) {
     CDR_CHECK_ARG(ctx);
     ctx->conet_defer = on ? 1 : 0;
@@ -1788,6 +1861,7 @@ extern "C" int cdr_conet_fwd(cdr_ctx* ctx, void* stream, const float* su_tab, co
         const char* fbw = getenv("CDR_CONET_FB_WAVES");               // "4": the four-wave kernel (A/B runs and the bit-equality test only)
         const bool waves4 = fbw && atoi(fbw) == 4;
         const bool eight = lp.fb8 && !waves4;
+        net.dma_tab = getenv("CDR_CONET_NO_DMA_TABLE") ? nullptr : conet_dma_table(ctx, net, eight ? 512 : 256, s);
         rc = lds_opt_in(eight ? (const void*)conet_fb_kernel<8> : (const void*)conet_fb_kernel<4>, lp.fb_bytes);
         if (rc) return rc;
         {

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "cdr_common.h"
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -106,6 +107,9 @@ extern "C" int cdr_ctx_destroy(cdr_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->tickets) (void)hipFree(ctx->tickets);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->conet_tab_dev) (void)hipFree(ctx->conet_tab_dev);
+    if (ctx->conet_tab_pin) (void)hipHostFree(ctx->conet_tab_pin);
+    free(ctx->conet_tab_shadow);
     delete ctx;
     return CDR_OK;
 }
