@@ -1154,11 +1154,17 @@ __device__ __forceinline__ void hsq_slice(const conet_net& net, int l, int& lo, 
     hi = lo + chunk < n ? lo + chunk : n;
 }
 
-__device__ __forceinline__ void prologue_issue(const conet_net& net, float* wl, fb_prologue& pr) {
-    const int t = threadIdx.x, dL = net.dims[net.L];
+// In two halves, with the first block's gather between them: {the first block's ids} -> weights' DMA -> {its rows} -> the small loads below
+// -> LDS stores, so that the gather's two dependent round trips run under the prologue's instruction issue instead of behind it.  (Tried
+// earlier in round 6, when the DMA loop and this half were 8 us of address arithmetic: no gain -- the prologue was issue-bound whatever the
+// order.  With the DMA table and the host-side slice bounds it is 4.4 us of issue and the gather's latency is what is left.)
+__device__ __forceinline__ void prologue_dma(const conet_net& net, float* wl) {
     STAMP(43);
     if (net.wlds) stage_weights_dma(net, wl);
     STAMP(44);
+}
+__device__ __forceinline__ void prologue_small(const conet_net& net, fb_prologue& pr) {
+    const int t = threadIdx.x, dL = net.dims[net.L];
     pr.wo = 0.f;
     if (t < 2 * (dL + 1)) {
         const int tower = t / (dL + 1), jj = t - tower * (dL + 1);
@@ -1222,8 +1228,17 @@ __global__ __launch_bounds__(64 * NW) void conet_fb_kernel(conet_net net, conet_
     STAMP(40);
     STAMPB(0);
     fb_prologue pr;
-    prologue_issue(net, wl, pr);
     const int64_t nrb = (R + kRows - 1) / kRows;
+    // the first block's ids and label: requested before anything else (see prologue_dma)
+    int64_t uid0 = 0, iid0 = 0;
+    float y0 = 0.f;
+    if ((int64_t)blockIdx.x < nrb) {
+        const int64_t g = (int64_t)blockIdx.x * kRows + t / TPR, gc = g < R ? g : R - 1;
+        const bool src = gc < n_source;
+        uid0 = src ? user_s[gc] : user_t[gc - n_source]; iid0 = src ? item_s[gc] : item_t[gc - n_source];
+        y0 = (t % TPR) == 0 ? (src ? label_s[gc] : label_t[gc - n_source]) : 0.f;
+    }
+    prologue_dma(net, wl);
     auto gather = [&](int64_t rb, auto first) {   // ---- gather [su | si | tu | ti] of 32 rows (8 threads per row, 16 B each): every row request of a 128-column pass is in
             //      flight before anything is parked
             float* bufA = smem + lo.a_off[0];
@@ -1232,8 +1247,13 @@ __global__ __launch_bounds__(64 * NW) void conet_fb_kernel(conet_net net, conet_
             const bool valid = g < R;
             const int64_t gc = valid ? g : R - 1;
             const bool src = gc < n_source;
-            const int64_t uid = src ? user_s[gc] : user_t[gc - n_source], iid = src ? item_s[gc] : item_t[gc - n_source];
-            const float y = c0 == 0 ? (src ? label_s[gc] : label_t[gc - n_source]) : 0.f;
+            int64_t uid, iid;
+            float y;
+            if (decltype(first)::value) { uid = uid0; iid = iid0; y = y0; }
+            else {
+                uid = src ? user_s[gc] : user_t[gc - n_source]; iid = src ? item_s[gc] : item_t[gc - n_source];
+                y = c0 == 0 ? (src ? label_s[gc] : label_t[gc - n_source]) : 0.f;
+            }
             float* xr = bufA + row * (4 * D + 4);
             for (int cb = 0; cb < D4; cb += 32) {
                 float4 a[NI], b[NI], e[NI], f[NI];
@@ -1245,7 +1265,7 @@ __global__ __launch_bounds__(64 * NW) void conet_fb_kernel(conet_net net, conet_
                         e[i] = ld4(tu + uid * D + 4 * c); f[i] = ld4(ti + iid * D + 4 * c);
                     }
                 }
-                if (decltype(first)::value && cb == 0) prologue_commit(net, wo_sh, hq, pr);
+                if (decltype(first)::value && cb == 0) { prologue_small(net, pr); prologue_commit(net, wo_sh, hq, pr); }
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int c = cb + c0 + TPR * i;
@@ -1274,7 +1294,7 @@ __global__ __launch_bounds__(64 * NW) void conet_fb_kernel(conet_net net, conet_
     // prologue's LDS stores inside it (inside the loop, the prologue's registers would stay live through every MFMA phase)
     STAMP(0);
     if ((int64_t)blockIdx.x < nrb) gather((int64_t)blockIdx.x, std::true_type{});
-    else { prologue_commit(net, wo_sh, hq, pr); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else { prologue_small(net, pr); prologue_commit(net, wo_sh, hq, pr); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         lds_barrier();
         STAMP(1);
